@@ -1,0 +1,104 @@
+"""Drop-in for the reference's Cython module `CRISPResso2.CRISPResso2Align`
+(reference CRISPResso2/CRISPResso2Align.pyx): same names, signatures, return types and
+error behaviour; `global_align` runs on the MI355X through the C ABI (no CPU fallback).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native
+
+
+def read_matrix(path):
+    """Read a score matrix in NCBI format (reference pyx:33-61).
+
+    The score for a 'C' changing to an 'A' is stored as mat[ord('C'), ord('A')].
+    Returns int64[max_ord+1, max_ord+1].  Row k of the file is taken to belong to header k,
+    as in the reference.
+    """
+    with open(path) as fh:
+        headers = None
+        while headers is None:
+            line = fh.readline().strip()
+            if line[0] == '#':
+                continue
+            headers = [ord(x) for x in line.split(' ') if x]
+        mat_size = max(headers) + 1
+        a = np.zeros((mat_size, mat_size), dtype=np.int64)
+        ai = 0
+        line = fh.readline()
+        while line:
+            line_vals = [int(x) for x in line[:-1].split(' ')[1:] if x]
+            for ohidx, val in zip(headers, line_vals):
+                a[headers[ai], ohidx] = val
+            ai += 1
+            line = fh.readline()
+    return a
+
+
+def make_matrix(match_score=5, mismatch_score=-4, n_mismatch_score=-2, n_match_score=-1):
+    """Match/mismatch score matrix over A,T,C,G,N (reference pyx:63-99); defaults equal EDNAFULL's values."""
+    nuc_ords = [ord(x) for x in 'ATCG']
+    n = ord('N')
+    a = np.zeros((max(nuc_ords + [n]) + 1,) * 2, dtype=np.int64)
+    for x in nuc_ords:
+        for y in nuc_ords:
+            a[x, y] = match_score if x == y else mismatch_score
+        a[x, n] = n_mismatch_score
+        a[n, x] = n_mismatch_score
+    a[n, n] = n_match_score
+    return a
+
+
+def _as_int64(arr, ndim, name):
+    """The reference's typed buffers reject anything but int64 ndarrays (ValueError: Buffer dtype mismatch)."""
+    if not isinstance(arr, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)" % (name, type(arr).__name__))
+    if arr.dtype != np.int64:
+        raise ValueError("Buffer dtype mismatch, expected 'DTYPE_LONG' but got '%s'" % arr.dtype.name)
+    if arr.ndim != ndim:
+        raise ValueError("Buffer has wrong number of dimensions (expected %d, got %d)" % (ndim, arr.ndim))
+    return np.ascontiguousarray(arr)
+
+
+def global_align(pystr_seqj, pystr_seqi, matrix, gap_incentive, gap_open=-1, gap_extend=-1):
+    """Global alignment (Needleman-Wunsch, affine gaps, per-position gap incentive) of the read
+    `pystr_seqj` against the reference `pystr_seqi` (reference pyx:101-434).
+
+    Returns (aligned_read, aligned_ref, round(100*matches/len, 3)).
+    A gap_incentive of the wrong length prints the reference's message and returns 0 (pyx:124-126).
+    """
+    if not isinstance(pystr_seqj, str):
+        raise TypeError("Argument 'pystr_seqj' has incorrect type (expected str, got %s)" % type(pystr_seqj).__name__)
+    if not isinstance(pystr_seqi, str):
+        raise TypeError("Argument 'pystr_seqi' has incorrect type (expected str, got %s)" % type(pystr_seqi).__name__)
+    m = _as_int64(matrix, 2, 'matrix')
+    g = _as_int64(gap_incentive, 1, 'gap_incentive')
+    bj = pystr_seqj.encode('UTF-8')
+    bi = pystr_seqi.encode('UTF-8')
+    max_i = len(pystr_seqi)
+    if len(g) != max_i + 1:
+        print('\nERROR: Mismatch in gap_incentive length (gap_incentive: ' + str(len(g)) + ' ref: ' + str(max_i + 1) + '\n')
+        return 0
+    ctx = _native.default_context()
+    cap = len(bi) + len(bj) + 1
+    oj = ctypes.create_string_buffer(cap)
+    oi = ctypes.create_string_buffer(cap)
+    n = ctypes.c_int32(0)
+    mt = ctypes.c_int32(0)
+    st = ctypes.c_int32(0)
+    rc = ctx.lib.c2_global_align(ctx.handle, bj, len(bj), bi, len(bi),
+                                 m.ctypes.data_as(ctypes.c_void_p), int(m.shape[0]),
+                                 g.ctypes.data_as(ctypes.c_void_p), int(g.shape[0]),
+                                 int(gap_open), int(gap_extend), oj, oi,
+                                 ctypes.byref(n), ctypes.byref(mt), ctypes.byref(st))
+    ctx.check(rc, "c2_global_align")
+    if st.value != 0:
+        # outside the reference's defined domain (empty sequence, out-of-matrix character, or a traceback
+        # through cells the reference never initialises): the reference raises 'wtf4!', reads garbage or
+        # crashes there; this implementation always raises.
+        raise Exception('global_align: undefined alignment (status %d) for seqj: %s seqi: %s' % (st.value, pystr_seqj, pystr_seqi))
+    align_j = oj.raw[:n.value].decode('UTF-8', 'strict')
+    align_i = oi.raw[:n.value].decode('UTF-8', 'strict')
+    final_score = 100 * mt.value / float(n.value)
+    return align_j, align_i, round(final_score, 3)

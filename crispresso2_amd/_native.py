@@ -1,0 +1,164 @@
+"""ctypes binding of libcrispresso2_amd.so (the C ABI declared in include/crispresso2_amd.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible, the calls
+raise.  Build the library with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C crispresso2_amd/csrc`.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcrispresso2_amd.so")
+
+# every symbol include/crispresso2_amd.h declares
+SYMBOLS = [
+    "c2_device_count", "c2_create", "c2_destroy", "c2_last_error", "c2_abi_version",
+    "c2_set_scoring", "c2_set_refs",
+    "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
+    "c2_timing_enable", "c2_timing_read", "c2_launch_info",
+    "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
+    "c2_count_vectors_device", "c2_selftest",
+]
+
+REC_DTYPE = np.dtype([
+    ("aln_len", "<u2"), ("matches", "<u2"), ("insertion_n", "<u2"), ("deletion_n", "<u2"), ("substitution_n", "<u2"),
+    ("all_insertion_events", "<u2"), ("win_insertion_events", "<u2"), ("all_deletion_events", "<u2"),
+    ("win_deletion_events", "<u2"), ("all_deletion_bases", "<u2"), ("all_substitutions", "<u2"),
+    ("irregular_ends", "u1"), ("status", "u1"), ("strand", "u1"), ("reserved0", "u1"),
+    ("ref_id", "<u2"), ("reserved2", "<u4")])
+assert REC_DTYPE.itemsize == 32
+
+STATUS_EMPTY, STATUS_OOB_CHAR, STATUS_SENTINEL_PATH, STATUS_UNINIT_PTR, STATUS_RC_CHAR, STATUS_TOO_LONG = 1, 2, 4, 8, 16, 32
+E_OVERFLOW = -6
+LIST_COUNT = 15
+
+
+class Batch(ctypes.Structure):
+    """struct c2_batch"""
+    _fields_ = [
+        ("n_reads", ctypes.c_uint64),
+        ("reads", ctypes.c_void_p), ("offsets", ctypes.c_void_p), ("ref_ids", ctypes.c_void_p), ("strands", ctypes.c_void_p),
+        ("all_refs", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("aln_read", ctypes.c_void_p), ("aln_ref", ctypes.c_void_p),
+        ("aln_stride", ctypes.c_uint32), ("reserved2", ctypes.c_uint32),
+        ("records", ctypes.c_void_p),
+    ]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the shared library (no device call).  Raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeError("crispresso2_amd: %s is missing -- build the HIP extension first "
+                                  "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH)
+            lib.c2_last_error.restype = ctypes.c_char_p
+            lib.c2_last_error.argtypes = [ctypes.c_void_p]
+            lib.c2_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+            lib.c2_destroy.argtypes = [ctypes.c_void_p]
+            lib.c2_destroy.restype = None
+            _lib = lib
+    return _lib
+
+
+class Context:
+    """One c2_ctx bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.handle = ctypes.c_void_p()
+        rc = self.lib.c2_create(int(device), ctypes.byref(self.handle))
+        if rc != 0:
+            msg = self.lib.c2_last_error(None)
+            raise NativeError("crispresso2_amd: cannot create a GPU context on device %d: %s (rc=%d); "
+                              "this package has no CPU fallback" % (device, msg.decode() if msg else "?", rc))
+        self.device = int(device)
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.c2_last_error(self.handle)
+            raise NativeError("%s failed: %s (rc=%d)" % (what, msg.decode() if msg else "?", rc))
+
+    def close(self):
+        if self.handle:
+            self.lib.c2_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scoring / refs
+    def set_scoring(self, matrix, gap_open, gap_extend):
+        m = np.ascontiguousarray(matrix, dtype=np.int64)
+        if m.ndim != 2 or m.shape[0] != m.shape[1]:
+            raise ValueError("score matrix must be square")
+        self.check(self.lib.c2_set_scoring(self.handle, m.ctypes.data_as(ctypes.c_void_p), int(m.shape[0]),
+                                           int(gap_open), int(gap_extend)), "c2_set_scoring")
+
+    def set_refs(self, seqs, gap_incentives, include_idxs):
+        n = len(seqs)
+        bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in seqs]
+        arr = (ctypes.c_char_p * n)(*bs)
+        lens = np.array([len(b) for b in bs], dtype=np.int32)
+        g = [np.ascontiguousarray(x, dtype=np.int64) for x in gap_incentives]
+        for k in range(n):
+            if g[k].shape[0] != lens[k] + 1:
+                raise ValueError("gap_incentive of reference %d must have len(ref)+1 entries" % k)
+        gp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in g])
+        inc = [np.ascontiguousarray(np.asarray(list(x), dtype=np.int64).astype(np.int32)) for x in include_idxs]
+        ip = (ctypes.c_void_p * n)(*[x.ctypes.data if x.size else None for x in inc])
+        ninc = np.array([x.size for x in inc], dtype=np.int32)
+        self.check(self.lib.c2_set_refs(self.handle, n, arr, lens.ctypes.data_as(ctypes.c_void_p), gp, ip,
+                                        ninc.ctypes.data_as(ctypes.c_void_p)), "c2_set_refs")
+
+    # ---- batch
+    def align_classify_device(self, batch, stream=None):
+        self.check(self.lib.c2_align_classify_batch_device(self.handle, ctypes.byref(batch),
+                                                           ctypes.c_void_p(stream or 0)), "c2_align_classify_batch_device")
+
+    def align_classify_host(self, batch):
+        self.check(self.lib.c2_align_classify_batch_host(self.handle, ctypes.byref(batch)), "c2_align_classify_batch_host")
+
+    def synchronize(self, stream=None):
+        self.check(self.lib.c2_synchronize(self.handle, ctypes.c_void_p(stream or 0)), "c2_synchronize")
+
+    def timing_enable(self, on=True):
+        self.check(self.lib.c2_timing_enable(self.handle, int(bool(on))), "c2_timing_enable")
+
+    def timing_read(self, reset=True):
+        ms = ctypes.c_double(0)
+        n = ctypes.c_int64(0)
+        self.check(self.lib.c2_timing_read(self.handle, ctypes.byref(ms), ctypes.byref(n), int(bool(reset))), "c2_timing_read")
+        return ms.value, n.value
+
+    def launch_info(self, max_read_len):
+        v = [ctypes.c_int32(0) for _ in range(5)]
+        self.check(self.lib.c2_launch_info(self.handle, int(max_read_len), *[ctypes.byref(x) for x in v]), "c2_launch_info")
+        return dict(zip(("rows_per_lane", "passes", "lds_bytes", "workgroups_per_cu", "compute_units"), [x.value for x in v]))
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on the current device (LOCAL_RANK, else 0) for the per-call API."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

@@ -1,0 +1,59 @@
+// Host-side preparation shared by the C ABI (c2_api.hip) and the test-only wave emulator
+// harness (tests/emu/): plain C++, no HIP.  Marshals the reference's Python-level inputs
+// (int64 score matrix indexed by ord(char), include_idxs list) into the kernel's compact tables.
+#pragma once
+#include <stdint.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "c2_device.h"
+
+struct c2_scoring_tables {
+    uint8_t code_of_char[256];
+    std::vector<int16_t> tbl;     // n_codes x n_codes, [ref code][read code]
+    int n_codes = 0;
+};
+
+// matrix: row-major int64[dim][dim], indexed [ord(ref)][ord(read)] (CRISPResso2Align.pyx:212).
+// Characters with an all-zero row and column share one code; ord >= dim (or >= 128: `char` is
+// signed in the reference) is an out-of-bounds read there and gets C2_INVALID_CODE here.
+inline bool c2_build_scoring(const int64_t* matrix, int dim, c2_scoring_tables& out, std::string& err) {
+    if (!matrix || dim <= 0) { err = "score matrix missing"; return false; }
+    std::fill(out.code_of_char, out.code_of_char + 256, (uint8_t)C2_INVALID_CODE);
+    const int lim = dim < 128 ? dim : 128;
+    std::vector<int> syms;
+    bool any_zero = false;
+    for (int c = 0; c < lim; ++c) {
+        bool nz = false;
+        for (int k = 0; k < dim && !nz; ++k) nz = matrix[(size_t)c * dim + k] != 0 || matrix[(size_t)k * dim + c] != 0;
+        if (nz) syms.push_back(c); else any_zero = true;
+    }
+    const int n = (int)syms.size() + (any_zero ? 1 : 0);
+    if (n > C2_MAX_CODES) { err = "score matrix has more than " + std::to_string(C2_MAX_CODES - 1) + " scoring symbols"; return false; }
+    out.n_codes = n;
+    out.tbl.assign((size_t)n * n, 0);
+    for (size_t a = 0; a < syms.size(); ++a) out.code_of_char[syms[a]] = (uint8_t)a;
+    if (any_zero) for (int c = 0; c < lim; ++c) if (out.code_of_char[c] == C2_INVALID_CODE) out.code_of_char[c] = (uint8_t)syms.size();
+    for (size_t a = 0; a < syms.size(); ++a)
+        for (size_t b = 0; b < syms.size(); ++b) {
+            const int64_t v = matrix[(size_t)syms[a] * dim + syms[b]];
+            if (v < -32768 || v > 32767) { err = "score matrix entry outside int16"; return false; }
+            out.tbl[a * n + b] = (int16_t)v;
+        }
+    return true;
+}
+
+// inc_prefix[x] = number of distinct include idxs < x, x in [0, Li+1]
+inline void c2_build_inc_prefix(const int32_t* inc, int n_inc, int Li, std::vector<uint16_t>& out) {
+    std::vector<uint8_t> bit((size_t)Li + 2, 0);
+    for (int k = 0; k < n_inc; ++k) if (inc[k] >= 0 && inc[k] <= Li) bit[inc[k]] = 1;
+    out.assign((size_t)Li + 2, 0);
+    uint16_t run = 0;
+    for (int x = 0; x < Li + 2; ++x) { out[x] = run; run = (uint16_t)(run + bit[x]); }
+}
+
+// rows per lane for the systolic sweep: smallest R in 1..4 whose single pass covers max_li, else 4
+inline int c2_choose_rows_per_lane(int max_li) {
+    for (int R = 1; R <= 4; ++R) if (max_li <= 64 * R) return R;
+    return 4;
+}

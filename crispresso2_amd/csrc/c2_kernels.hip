@@ -1,0 +1,540 @@
+// c2_kernels.hip -- CDNA4 (gfx950) kernels for CRISPResso2's align + classify hot path.
+//
+// Replaces, bit-identically on the reference's defined domain:
+//   CRISPResso2Align.global_align               (reference CRISPResso2/CRISPResso2Align.pyx:101-434)
+//   CRISPRessoCOREResources.find_indels_substitutions (CRISPResso2/CRISPRessoCOREResources.pyx:68-187)
+//
+// Design (DESIGN.md has the long form):
+//   * one 64-lane wavefront = one workgroup = one (read, reference) alignment at a time;
+//     workgroups are persistent and stride over the task list.
+//   * the Gotoh M/I/J recurrences run as a systolic anti-diagonal sweep: lane l owns R
+//     consecutive reference rows, at step t it computes read column j = t - l of those rows.
+//     Row-to-row hand-off between neighbouring lanes is one DPP wave_shr:1 per value
+//     (no LDS round trip); lane 0 is fed from the row-0 boundary (or, for references longer
+//     than 64*R rows, from the previous pass's bottom row kept in LDS).
+//   * int32 scores exactly as the reference's C ints; the three tie rules are kept as
+//     compare results, 4 pointer bits per cell, 16 bits per lane-step, stored with one
+//     ds_write_b16 per step into an LDS pointer plane -- the 6 x (Li+1) x (Lj+1) int32
+//     matrices of the reference (1.5 MB per 250x250 alignment) never exist.
+//   * traceback is wave-parallel: the 64 lanes probe 64 consecutive cells along the current
+//     direction (diagonal / row / column), a ballot finds the length of the run, and the run's
+//     columns are emitted by the lanes in one shot; a typical amplicon read needs < 10 rounds.
+//   * the indel / substitution / quantification-window classification is computed from the
+//     aligned strings while they are still in LDS (ballot + popcount prefix scans).
+//   * HBM traffic is the algorithmic minimum: the read comes in once (coalesced byte loads),
+//     the two aligned strings and one 32-byte record go out once.
+#include <hip/hip_runtime.h>
+#include "c2_device.h"
+
+#define C2_DPP_WAVE_SHR1 0x138
+
+// lane n receives `src` of lane n-1; lane 0 keeps `old`
+__device__ __forceinline__ int c2_shr1(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, C2_DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int c2_imax(int a, int b) { return a > b ? a : b; }
+
+struct c2_lds_plan {
+    // byte offsets into dynamic LDS (all multiples of 16)
+    uint32_t ptr, bnd, tbl, read, code, ref, incp, tmp_read, tmp_ref, total;
+    uint32_t col_stride;  // halfwords per pointer column
+};
+
+__host__ __device__ inline uint32_t c2_align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+// The same function sizes the LDS on the host and carves it in the kernel.
+__host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_passes, int n_codes) {
+    c2_lds_plan p;
+    const uint32_t max_li = (uint32_t)max_passes * 64u * (uint32_t)R;
+    p.col_stride = C2_LANES + C2_PTR_PAD;
+    uint32_t off = 0;
+    p.ptr = off;      off += c2_align16((uint32_t)max_passes * (uint32_t)max_lj * p.col_stride * 2u);
+    p.bnd = off;      off += (max_passes > 1) ? c2_align16(3u * ((uint32_t)max_lj + 1u) * 4u) : 0u;
+    p.tbl = off;      off += c2_align16((uint32_t)n_codes * (uint32_t)n_codes * 2u);
+    p.read = off;     off += c2_align16((uint32_t)max_lj);
+    p.code = off;     off += c2_align16((uint32_t)max_lj);
+    p.ref = off;      off += c2_align16(max_li);
+    p.incp = off;     off += c2_align16((max_li + 2u) * 2u);
+    p.tmp_read = off; off += c2_align16(max_li + (uint32_t)max_lj);
+    p.tmp_ref = off;  off += c2_align16(max_li + (uint32_t)max_lj);
+    p.total = off;
+    return p;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char c2_smem[];
+
+// h-state (argmax with the reference's tie rule, pyx:216-228) of a cell on row 0 or column 0,
+// from the closed-form boundary values (pyx:153-176).
+__device__ __forceinline__ int c2_boundary_hstate(int i, int j, int min_score, int ge, int g0) {
+    if (i == 0 && j == 0) return C2_ST_M;                 // M[0,0]=0 beats I=J=min_score
+    if (i == 0) return (ge * j + g0 >= min_score) ? C2_ST_I : C2_ST_J;   // M=J=min_score, I=ge*j+g0
+    return (ge * i + g0 <= min_score) ? C2_ST_I : C2_ST_J;              // M=I=min_score, J=ge*i+g0
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
+{
+    const int lane = threadIdx.x;
+    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes);
+    uint16_t* sPtr = (uint16_t*)(c2_smem + P.ptr);
+    int* sBnd = (int*)(c2_smem + P.bnd);
+    int16_t* sTbl = (int16_t*)(c2_smem + P.tbl);
+    unsigned char* sRead = c2_smem + P.read;
+    unsigned char* sCode = c2_smem + P.code;
+    unsigned char* sRef = c2_smem + P.ref;
+    uint16_t* sIncP = (uint16_t*)(c2_smem + P.incp);
+    unsigned char* sTmpRead = c2_smem + P.tmp_read;
+    unsigned char* sTmpRef = c2_smem + P.tmp_ref;
+    const int colStride = (int)P.col_stride;
+    const int ROWS_PER_PASS = 64 * R;
+    const int ge = A.gap_extend, go = A.gap_open;
+
+    // score table -> LDS, once per workgroup
+    for (int k = lane; k < A.n_codes * A.n_codes; k += 64) sTbl[k] = A.score_tbl[k];
+
+    int cur_ref = -1;
+    int Li = 0, g0 = 0;
+
+    for (uint64_t task = blockIdx.x; task < A.n_tasks; task += gridDim.x) {
+        uint64_t read_id;
+        int ref_id;
+        if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
+        else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
+        const int rc = A.strands ? (int)A.strands[task] : 0;
+        const uint64_t off = A.offsets[read_id];
+        const int Lj = (int)(A.offsets[read_id + 1] - off);
+        int status = 0;
+        const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
+
+        __syncthreads();   // previous task's LDS readers are done
+        // ---- reference: chars, window prefix, per-lane row constants (reloaded only when the amplicon changes)
+        if (ref_id != cur_ref) {
+            cur_ref = ref_id;
+            const c2_dev_ref rf = A.refs[ref_id];
+            Li = rf.len;
+            g0 = rf.gap_incentive[0];
+            const int LiLoad = Li < A.max_passes * ROWS_PER_PASS ? Li : A.max_passes * ROWS_PER_PASS;
+            for (int k = lane; k < LiLoad; k += 64) sRef[k] = rf.seq[k];
+            for (int k = lane; k < LiLoad + 2; k += 64) sIncP[k] = rf.inc_prefix[k];
+        }
+        const c2_dev_ref rf = A.refs[ref_id];
+        // ---- read: coalesced byte loads (64 consecutive bytes per instruction), optional reverse complement
+        for (int k = lane; k < LjLoad; k += 64) {
+            unsigned char ch;
+            if (!rc) ch = A.reads[off + (uint64_t)k];
+            else {
+                ch = A.reads[off + (uint64_t)(Lj - 1 - k)];
+                if (ch >= 'a' && ch <= 'z') ch -= 32;                       // seq.upper(), CRISPRessoShared.py:402
+                unsigned char cc = 0;
+                if (ch == 'A') cc = 'T'; else if (ch == 'C') cc = 'G'; else if (ch == 'G') cc = 'C';
+                else if (ch == 'T') cc = 'A'; else if (ch == 'N' || ch == '_' || ch == '-') cc = ch;
+                if (cc == 0) { status |= C2_STATUS_RC_CHAR; cc = 'N'; }
+                ch = cc;
+            }
+            const unsigned char code = A.code_of_char[ch];
+            if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
+            sRead[k] = ch;
+            sCode[k] = code;
+        }
+        {
+            int bad = 0;
+            for (int k = lane; k < Li && k < A.max_passes * ROWS_PER_PASS; k += 64) if (A.code_of_char[sRef[k]] == C2_INVALID_CODE) bad = 1;
+            if (bad) status |= C2_STATUS_OOB_CHAR;
+        }
+        if (Li <= 0 || Lj <= 0) status |= C2_STATUS_EMPTY;
+        const int passes = (Li + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+        if (Lj > A.max_lj || passes > A.max_passes) status |= C2_STATUS_TOO_LONG;
+        status = (__ballot(status & C2_STATUS_EMPTY) ? C2_STATUS_EMPTY : 0) |
+                 (__ballot(status & C2_STATUS_OOB_CHAR) ? C2_STATUS_OOB_CHAR : 0) |
+                 (__ballot(status & C2_STATUS_RC_CHAR) ? C2_STATUS_RC_CHAR : 0) |
+                 (__ballot(status & C2_STATUS_TOO_LONG) ? C2_STATUS_TOO_LONG : 0);
+        __syncthreads();
+
+        c2_aln_record rec;
+        rec.aln_len = 0; rec.matches = 0; rec.insertion_n = 0; rec.deletion_n = 0; rec.substitution_n = 0;
+        rec.all_insertion_events = 0; rec.win_insertion_events = 0; rec.all_deletion_events = 0;
+        rec.win_deletion_events = 0; rec.all_deletion_bases = 0; rec.all_substitutions = 0;
+        rec.irregular_ends = 0; rec.strand = (uint8_t)rc; rec.reserved0 = 0; rec.ref_id = (uint16_t)ref_id;
+        rec.reserved2 = 0;
+
+        if (status == 0) {
+            // pyx:150  int min_score = gap_open * max_j * max_i   (wraps like the reference's C int)
+            const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
+
+            // =========================== DP: systolic sweep, pass by pass ===========================
+            for (int p = 0; p < passes; ++p) {
+                const int row0 = p * ROWS_PER_PASS + lane * R;      // 0-based row above this lane's strip
+                int a[R], b[R], c[R], delta[R], rowoff[R];
+                int Ml[R], Il[R], Hl[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = row0 + r + 1;                      // 1-based reference row
+                    const int ic = i <= Li ? i : Li;                 // padding rows below Li compute garbage nobody reads
+                    const int gi = rf.gap_incentive[ic], gim1 = rf.gap_incentive[ic - 1];
+                    const bool last_row = (i == Li);
+                    // last row: gap_open is replaced by gap_extend (pyx:277-317); last column: same (pyx:234-273), via delta
+                    a[r] = (last_row ? ge : go) + gi;                // I opened from M
+                    b[r] = ge + gi;                                  // I extended (incentive on every extension, pyx:197)
+                    c[r] = (last_row ? ge : go) + gim1;              // J opened from M (incentive only on open, pyx:205-207)
+                    delta[r] = last_row ? 0 : (ge - go);
+                    rowoff[r] = (int)A.code_of_char[sRef[ic - 1]] * A.n_codes;
+                    const int J0 = ge * i + g0;                      // jScore[i,0], pyx:170-171
+                    Ml[r] = min_score; Il[r] = min_score;            // mScore[i,0], iScore[i,0]
+                    Hl[r] = c2_imax(min_score, J0);
+                }
+                int Mb = min_score, Jb = ge * (row0 + R) + g0, Hb = Hl[R - 1];
+                // diagonal input of the strip's first row at its first column: H(row0, 0)
+                int dgsave = (row0 == 0) ? 0 : c2_imax(min_score, ge * row0 + g0);
+                int cj = 0;
+                unsigned bits = 0;
+                const int nrows = (Li - p * ROWS_PER_PASS) < ROWS_PER_PASS ? (Li - p * ROWS_PER_PASS) : ROWS_PER_PASS;
+                const int nl = (nrows + R - 1) / R;
+                const int steps = Lj + nl - 1;
+                const bool feeds_next = (p + 1 < passes);
+                uint16_t* myPtr = sPtr + (size_t)p * (size_t)A.max_lj * colStride + lane;
+
+                for (int t = 1; t <= steps; ++t) {
+                    // boundary row above lane 0 at column t
+                    int bM, bJ, bH, bC;
+                    if (p == 0) { bM = min_score; bJ = min_score; bH = c2_imax(min_score, ge * t + g0); }
+                    else { const int tt = t <= Lj ? t : Lj; bM = sBnd[3 * tt]; bJ = sBnd[3 * tt + 1]; bH = sBnd[3 * tt + 2]; }
+                    bC = sCode[(t <= Lj ? t : Lj) - 1];
+                    // hand-off from the lane above (all lanes, full EXEC)
+                    const int upM0 = c2_shr1(bM, Mb);
+                    const int upJ0 = c2_shr1(bJ, Jb);
+                    const int upH = c2_shr1(bH, Hb);
+                    cj = c2_shr1(bC, cj);
+                    const int j = t - lane;
+                    if (j >= 1 && j <= Lj) {
+                        const bool lastcol = (j == Lj);
+                        int upM = upM0, upJ = upJ0, dg = dgsave;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const int corr = lastcol ? delta[r] : 0;
+                            const int s = (int)sTbl[rowoff[r] + cj];
+                            const int iFromM = Ml[r] + a[r] + corr;
+                            const int iExt = Il[r] + b[r];
+                            const bool ib = iFromM > iExt;                    // pyx:191-196: tie -> extend
+                            const int In = ib ? iFromM : iExt;
+                            const int jFromM = upM + c[r] + corr;
+                            const int jExt = upJ + ge;
+                            const bool jb = jFromM > jExt;                    // pyx:199-211: tie -> extend
+                            const int Jn = jb ? jFromM : jExt;
+                            const int Mn = dg + s;                            // H(i-1,j-1) + matrix[ci,cj], pyx:213-228
+                            const int t2 = c2_imax(Mn, Jn);
+                            const bool hI = In >= t2;                         // I wins all ties
+                            const bool hJ = Jn >= Mn;                         // J beats M on a tie
+                            const int Hn = c2_imax(t2, In);
+                            bits = (bits << 4) | ((unsigned)ib << 3) | ((unsigned)jb << 2) | ((unsigned)hI << 1) | (unsigned)hJ;
+                            dg = Hl[r];
+                            Ml[r] = Mn; Il[r] = In; Hl[r] = Hn;
+                            upM = Mn; upJ = Jn;
+                        }
+                        Mb = upM; Jb = upJ; Hb = Hl[R - 1];
+                        myPtr[(j - 1) * colStride] = (uint16_t)bits;
+                        if (feeds_next && lane == 63) { sBnd[3 * j] = Mb; sBnd[3 * j + 1] = Jb; sBnd[3 * j + 2] = Hb; }
+                    }
+                    dgsave = upH;
+                }
+                __syncthreads();
+            }
+
+            // =========================== traceback: wave-parallel run detection ===========================
+            int i = Li, j = Lj, cnt = 0, matches = 0;
+            int s;
+            {
+                const int pp = (i - 1) / ROWS_PER_PASS, rem = (i - 1) % ROWS_PER_PASS;
+                const unsigned hw = sPtr[((size_t)pp * A.max_lj + (j - 1)) * colStride + rem / R];
+                const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
+                s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // pyx:349-358
+            }
+            while (i > 0 || j > 0) {
+                if (i == 0 || j == 0) {
+                    const int need = (i == 0) ? C2_ST_I : C2_ST_J;           // initialised chains: iPointer[0,1:], jPointer[1:,0]
+                    if (s != need) { status |= (s == C2_ST_M) ? C2_STATUS_SENTINEL_PATH : C2_STATUS_UNINIT_PTR; break; }
+                    const int len = (i == 0) ? j : i;
+                    for (int k = lane; k < len; k += 64) {
+                        sTmpRead[cnt + k] = (i == 0) ? sRead[j - 1 - k] : (unsigned char)'-';
+                        sTmpRef[cnt + k] = (i == 0) ? (unsigned char)'-' : sRef[i - 1 - k];
+                    }
+                    cnt += len; i = 0; j = 0;
+                    break;
+                }
+                const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
+                const int ik = i - lane * di, jk = j - lane * dj;
+                const bool valid = (ik >= 1) && (jk >= 1);
+                int ns = 0;
+                if (valid) {
+                    // cell whose pointer nibble decides the next state
+                    const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
+                    if (pi == 0 || pj == 0) {
+                        ns = c2_boundary_hstate(pi, pj, min_score, ge, g0);   // only reachable for s == M
+                    } else {
+                        const int pp = (pi - 1) / ROWS_PER_PASS, rem = (pi - 1) % ROWS_PER_PASS;
+                        const unsigned hw = sPtr[((size_t)pp * A.max_lj + (pj - 1)) * colStride + rem / R];
+                        const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
+                        if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
+                        else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
+                        else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
+                    }
+                }
+                const unsigned long long vmask = __ballot(valid);
+                const unsigned long long cmask = __ballot(valid && ns == s);
+                const int nv = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
+                const int nc = (~cmask == 0ull) ? 64 : __builtin_ctzll(~cmask);
+                int E, s_next;
+                if (nc < nv) { E = nc + 1; s_next = __builtin_amdgcn_readlane(ns, nc); }
+                else { E = nv; s_next = s; }
+                unsigned char rch = '-', fch = '-';
+                if (lane < E) {
+                    if (s != C2_ST_J) rch = sRead[jk - 1];
+                    if (s != C2_ST_I) fch = sRef[ik - 1];
+                    sTmpRead[cnt + lane] = rch;
+                    sTmpRef[cnt + lane] = fch;
+                }
+                if (s == C2_ST_M) matches += __popcll(__ballot(lane < E && rch == fch));   // pyx:375-376
+                cnt += E; i -= E * di; j -= E * dj; s = s_next;
+            }
+            __syncthreads();
+
+            if (status == 0) {
+                const int T = cnt;
+                // =========================== aligned strings out (reversed copy, pyx:434) ===========================
+                uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
+                uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
+                for (int cidx = lane; cidx < T; cidx += 64) {
+                    outR[cidx] = sTmpRead[T - 1 - cidx];
+                    outF[cidx] = sTmpRef[T - 1 - cidx];
+                }
+                // =========================== classification (COREResources.pyx:68-187) ===========================
+                // column c (forward order) = tmp[T-1-c].  The aligner never emits a double-gap column and never
+                // puts an insertion column next to a deletion column (I and J only hand over to M), so every gap
+                // run is pure and idx advances by one on every non-insertion column.
+                int idx_base = 0, last_rf = -1, last_rd = -1;
+                int n_all_sub = 0, n_win_sub = 0, n_all_ins = 0, n_win_ins = 0, n_all_del = 0, n_win_del = 0;
+                int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;   // per-lane partial sums
+                const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                for (int base = 0; base < T; base += 64) {
+                    const int cidx = base + lane;
+                    const bool in = cidx < T;
+                    const unsigned char rd = in ? sTmpRead[T - 1 - cidx] : 0, rfc = in ? sTmpRef[T - 1 - cidx] : 0;
+                    const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
+                    const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
+                    const int idx = idx_base + __popcll(m_rf & lt);             // ref bases left of this column
+                    const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
+                    const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
+                    const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
+                    // substitution, pyx:113-118
+                    const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
+                    const bool sub_win = sub && (sIncP[idx + 1] != sIncP[idx]);
+                    n_all_sub += __popcll(__ballot(sub));
+                    n_win_sub += __popcll(__ballot(sub_win));
+                    // insertion closes at this column, pyx:119-128; leading insertions (idx==0) are never opened, pyx:136
+                    const bool ins_close = rf_ng && (prev_rf != cidx - 1) && idx > 0;
+                    const bool ins_win = ins_close && (sIncP[idx] != sIncP[idx - 1]) && (sIncP[idx + 1] != sIncP[idx]);
+                    n_all_ins += __popcll(__ballot(ins_close));
+                    n_win_ins += __popcll(__ballot(ins_win));
+                    if (ins_win) acc_ins_n += cidx - 1 - prev_rf;
+                    // deletion closes at this column, pyx:145-153
+                    const bool del_close = rd_ng && (prev_rd != cidx - 1);
+                    const int dlen = cidx - 1 - prev_rd;
+                    const bool del_win = del_close && (sIncP[idx] != sIncP[idx - dlen]);   // include set hits range(start,end)
+                    n_all_del += __popcll(__ballot(del_close));
+                    n_win_del += __popcll(__ballot(del_win));
+                    if (del_close) acc_del_bases += dlen;
+                    if (del_win) acc_del_n += dlen;
+                    idx_base += __popcll(m_rf);
+                    if (m_rf) last_rf = base + 63 - __clzll((long long)m_rf);
+                    if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
+                }
+                // trailing deletion, pyx:155-162
+                int tr_bases = 0, tr_win = 0;
+                if (last_rd != T - 1) {
+                    const int dlen = T - 1 - last_rd;
+                    tr_bases = dlen;
+                    n_all_del += 1;
+                    if (sIncP[idx_base] != sIncP[idx_base - dlen]) { tr_win = dlen; n_win_del += 1; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    acc_ins_n += __shfl_xor(acc_ins_n, m);
+                    acc_del_n += __shfl_xor(acc_del_n, m);
+                    acc_del_bases += __shfl_xor(acc_del_bases, m);
+                }
+                const unsigned char r0 = sTmpRead[T - 1], f0 = sTmpRef[T - 1], rL = sTmpRead[0], fL = sTmpRef[0];
+                rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
+                rec.aln_len = (uint16_t)T;
+                rec.matches = (uint16_t)matches;
+                rec.insertion_n = (uint16_t)acc_ins_n;
+                rec.deletion_n = (uint16_t)(acc_del_n + tr_win);
+                rec.substitution_n = (uint16_t)n_win_sub;
+                rec.all_insertion_events = (uint16_t)n_all_ins;
+                rec.win_insertion_events = (uint16_t)n_win_ins;
+                rec.all_deletion_events = (uint16_t)n_all_del;
+                rec.win_deletion_events = (uint16_t)n_win_del;
+                rec.all_deletion_bases = (uint16_t)(acc_del_bases + tr_bases);
+                rec.all_substitutions = (uint16_t)n_all_sub;
+            }
+        }
+        rec.status = (uint8_t)status;
+        if (lane == 0) A.records[task] = rec;
+    }
+}
+
+// =====================================================================================
+// Per-call classifier with full position lists: find_indels_substitutions
+// (CRISPRessoCOREResources.pyx:68-187) and find_indels_substitutions_legacy (pyx:190-315).
+// Accepts ANY pair of equal-length strings, including shapes the aligner never emits
+// (double-gap columns, insertion next to deletion), so it follows the reference's column
+// walk literally.  This is the drop-in for the reference's per-call API (O(10) calls per
+// run); the throughput path is the fused classifier in c2_align_classify_kernel.
+// One lane walks; launch <<<1, 64>>>.
+// =====================================================================================
+struct c2_list_writer {
+    int32_t* base; int32_t cap; int32_t n;
+    __device__ __forceinline__ void push(int32_t v) { if (n < cap) base[n] = v; n++; }
+};
+
+__device__ inline bool c2_inc_has(const int32_t* inc, int n, int x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (inc[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo < n && inc[lo] == x;
+}
+// include_set.intersection(range(a, b)) non-empty
+__device__ inline bool c2_inc_hits(const int32_t* inc, int n, int a, int b) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (inc[mid] < a) lo = mid + 1; else hi = mid; }
+    return lo < n && inc[lo] < b;
+}
+
+__global__ __launch_bounds__(64) void c2_classify_lists_kernel(c2_classify_args A)
+{
+    if (threadIdx.x != 0) return;
+    c2_list_writer L[C2_LIST_COUNT];
+    for (int k = 0; k < C2_LIST_COUNT; ++k) { L[k].base = A.lists + (size_t)k * A.cap; L[k].cap = A.cap; L[k].n = 0; }
+    const uint8_t* rd = A.read_al; const uint8_t* rf = A.ref_al;
+    const int32_t* inc = A.include_sorted; const int ni = A.n_include; const int n = A.n;
+    int32_t* rp = L[C2_LIST_REF_POSITIONS].base;       // cap >= n is guaranteed by the host
+    int64_t ins_n = 0, del_n = 0;
+    int idx = 0;
+    if (!A.legacy) {
+        int start_deletion = -1, start_insertion = -1, cur_ins = 0;                  // pyx:94,101,109
+        for (int c = 0; c < n; ++c) {                                                 // pyx:110
+            if (rf[c] != '-') {
+                L[C2_LIST_REF_POSITIONS].push(idx);
+                if (rf[c] != rd[c] && rd[c] != '-' && rd[c] != 'N') {                 // pyx:113
+                    L[C2_LIST_ALL_SUBSTITUTION_POSITIONS].push(idx); L[C2_LIST_ALL_SUBSTITUTION_VALUES].push(rd[c]);
+                    if (c2_inc_has(inc, ni, idx)) { L[C2_LIST_SUBSTITUTION_POSITIONS].push(idx); L[C2_LIST_SUBSTITUTION_VALUES].push(rd[c]); }
+                }
+                if (start_insertion != -1) {                                          // pyx:119-128
+                    L[C2_LIST_ALL_INSERTION_LEFT_POSITIONS].push(start_insertion);
+                    L[C2_LIST_ALL_INSERTION_POSITIONS].push(start_insertion); L[C2_LIST_ALL_INSERTION_POSITIONS].push(idx);
+                    if (c2_inc_has(inc, ni, start_insertion) && c2_inc_has(inc, ni, idx)) {
+                        L[C2_LIST_INSERTION_COORDINATES].push(start_insertion); L[C2_LIST_INSERTION_COORDINATES].push(idx);
+                        L[C2_LIST_INSERTION_POSITIONS].push(start_insertion); L[C2_LIST_INSERTION_POSITIONS].push(idx);
+                        L[C2_LIST_INSERTION_SIZES].push(cur_ins); ins_n += cur_ins;
+                    }
+                    start_insertion = -1;
+                }
+                cur_ins = 0; idx++;
+            } else {                                                                  // pyx:131-138
+                L[C2_LIST_REF_POSITIONS].push(idx == 0 ? -1 : -idx);
+                if (idx > 0 && start_insertion == -1) start_insertion = idx - 1;
+                cur_ins++;
+            }
+            if (rd[c] == '-' && start_deletion == -1) {                               // pyx:140-144
+                start_deletion = (c - 1 >= 0) ? rp[c] : 0;
+            } else if (rd[c] != '-' && start_deletion != -1) {                        // pyx:145-153
+                const int end_deletion = rp[c];
+                for (int q = start_deletion; q < end_deletion; ++q) L[C2_LIST_ALL_DELETION_POSITIONS].push(q);
+                L[C2_LIST_ALL_DELETION_COORDINATES].push(start_deletion); L[C2_LIST_ALL_DELETION_COORDINATES].push(end_deletion);
+                if (c2_inc_hits(inc, ni, start_deletion, end_deletion)) {
+                    for (int q = start_deletion; q < end_deletion; ++q) L[C2_LIST_DELETION_POSITIONS].push(q);
+                    L[C2_LIST_DELETION_COORDINATES].push(start_deletion); L[C2_LIST_DELETION_COORDINATES].push(end_deletion);
+                    L[C2_LIST_DELETION_SIZES].push(end_deletion - start_deletion); del_n += end_deletion - start_deletion;
+                }
+                start_deletion = -1;
+            }
+        }
+        if (start_deletion != -1 && n > 0) {                                          // pyx:155-162
+            const int end_deletion = rp[n - 1];
+            for (int q = start_deletion; q < end_deletion + 1; ++q) L[C2_LIST_ALL_DELETION_POSITIONS].push(q);
+            L[C2_LIST_ALL_DELETION_COORDINATES].push(start_deletion); L[C2_LIST_ALL_DELETION_COORDINATES].push(end_deletion + 1);
+            if (c2_inc_hits(inc, ni, start_deletion, end_deletion + 1)) {
+                for (int q = start_deletion; q < end_deletion + 1; ++q) L[C2_LIST_DELETION_POSITIONS].push(q);
+                L[C2_LIST_DELETION_COORDINATES].push(start_deletion); L[C2_LIST_DELETION_COORDINATES].push(end_deletion + 1);
+                L[C2_LIST_DELETION_SIZES].push(end_deletion + 1 - start_deletion); del_n += end_deletion + 1 - start_deletion;
+            }
+        }
+    } else {
+        // legacy, pyx:190-315
+        for (int c = 0; c < n; ++c) {                                                 // pyx:218-233
+            const uint8_t ch = rf[c];
+            if (ch == 'A' || ch == 'T' || ch == 'C' || ch == 'G' || ch == 'N') {
+                L[C2_LIST_REF_POSITIONS].push(idx);
+                if (rf[c] != rd[c] && rd[c] != '-' && rd[c] != 'N') {
+                    L[C2_LIST_ALL_SUBSTITUTION_POSITIONS].push(idx); L[C2_LIST_ALL_SUBSTITUTION_VALUES].push(rd[c]);
+                    if (c2_inc_has(inc, ni, idx)) { L[C2_LIST_SUBSTITUTION_POSITIONS].push(idx); L[C2_LIST_SUBSTITUTION_VALUES].push(rd[c]); }
+                }
+                idx++;
+            } else {
+                L[C2_LIST_REF_POSITIONS].push(idx == 0 ? -1 : -idx);
+            }
+        }
+        // deletions: runs of '-' in the read, pyx:253-267
+        for (int st = 0; st < n;) {
+            if (rd[st] != '-') { ++st; continue; }
+            int en = st; while (en < n && rd[en] == '-') ++en;
+            int ref_st = 0;
+            if (st - 1 > 0) ref_st = rp[st];
+            int ref_en = idx - 1;
+            if (en < n) ref_en = rp[en];
+            for (int q = ref_st; q < ref_en; ++q) L[C2_LIST_ALL_DELETION_POSITIONS].push(q);
+            L[C2_LIST_ALL_DELETION_COORDINATES].push(ref_st); L[C2_LIST_ALL_DELETION_COORDINATES].push(ref_en);
+            if (c2_inc_hits(inc, ni, ref_st, ref_en)) {
+                for (int q = ref_st; q < ref_en; ++q) L[C2_LIST_DELETION_POSITIONS].push(q);
+                L[C2_LIST_DELETION_COORDINATES].push(ref_st); L[C2_LIST_DELETION_COORDINATES].push(ref_en);
+                L[C2_LIST_DELETION_SIZES].push(en - st); del_n += en - st;
+            }
+            st = en;
+        }
+        // insertions: runs of '-' in the reference, pyx:271-288 (either flank in the window counts, pyx:284)
+        for (int st = 0; st < n;) {
+            if (rf[st] != '-') { ++st; continue; }
+            int en = st; while (en < n && rf[en] == '-') ++en;
+            if (st != 0 && en != n) {
+                const int ref_st = rp[st - 1], ref_en = rp[en];
+                L[C2_LIST_ALL_INSERTION_LEFT_POSITIONS].push(ref_st);
+                L[C2_LIST_ALL_INSERTION_POSITIONS].push(ref_st); L[C2_LIST_ALL_INSERTION_POSITIONS].push(ref_en);
+                if (c2_inc_has(inc, ni, ref_st) || c2_inc_has(inc, ni, ref_en)) {
+                    L[C2_LIST_INSERTION_COORDINATES].push(ref_st); L[C2_LIST_INSERTION_COORDINATES].push(ref_en);
+                    L[C2_LIST_INSERTION_POSITIONS].push(ref_st); L[C2_LIST_INSERTION_POSITIONS].push(ref_en);
+                    L[C2_LIST_INSERTION_SIZES].push(en - st); ins_n += en - st;
+                }
+            }
+            st = en;
+        }
+    }
+    for (int k = 0; k < C2_LIST_COUNT; ++k) A.list_len[k] = L[k].n;
+    A.counts[0] = ins_n; A.counts[1] = del_n; A.counts[2] = L[C2_LIST_SUBSTITUTION_POSITIONS].n;
+}
+
+// calculate_homology, COREResources.pyx:318-327 (float32 accumulator; result = score / strlen(a))
+__global__ __launch_bounds__(64) void c2_homology_kernel(const uint8_t* a, const uint8_t* b, int n, float* out)
+{
+    if (threadIdx.x != 0) return;
+    float score = 0.0f;
+    for (int k = 0; k < n; ++k) if (a[k] == b[k]) score += 1;
+    *out = score / (float)n;
+}
+
+// Hardware self-test of the cross-lane primitives the DP relies on (wave_shr:1 with `old` kept in lane 0).
+__global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
+{
+    const int lane = threadIdx.x;
+    out[lane] = c2_shr1(-7, lane * 3 + 1);                      // expect lane0=-7, lane n = 3(n-1)+1
+    out[64 + lane] = __builtin_amdgcn_readlane(lane * 5, 17);   // expect 85 everywhere
+    const unsigned long long m = __ballot(lane % 3 == 0);
+    out[128 + lane] = __popcll(m) + (lane == 0 ? __builtin_ctzll(~m) : 0);
+}

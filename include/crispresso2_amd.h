@@ -1,0 +1,186 @@
+/*
+ * crispresso2_amd.h -- C ABI of libcrispresso2_amd.so
+ *
+ * MI355X (gfx950) implementation of CRISPResso2's per-read align + classify hot path.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository, pinellolab/CRISPResso2 v2.3.4).  Plain pointers and sizes only;
+ * nothing here depends on Python or torch.  INTEGRATION.md shows the ctypes binding the
+ * reference side uses (crispresso2_amd/_native.py is that binding).
+ *
+ * Conventions
+ *   - functions return 0 on success, a negative C2_E_* code on failure; c2_last_error()
+ *     returns a human-readable message for the last failure on that context
+ *     (c2_last_error(NULL) for failures of c2_create itself).
+ *   - "device pointer" = address in the HBM of the context's GPU; "host pointer" = ordinary
+ *     process memory.  All arguments are borrowed for the duration of the call only.
+ *   - every computation runs on the GPU.  There is no CPU fallback: without a usable
+ *     device c2_create fails.
+ */
+#ifndef CRISPRESSO2_AMD_H
+#define CRISPRESSO2_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C2_ABI_VERSION 1
+
+/* error codes */
+#define C2_E_INVALID   -1   /* bad argument */
+#define C2_E_DEVICE    -2   /* HIP runtime error (no device, launch failure, ...) */
+#define C2_E_NOMEM     -3
+#define C2_E_STATE     -4   /* scoring / references not set */
+#define C2_E_TOO_LARGE -5   /* problem does not fit the kernel's LDS plan (see DESIGN.md limits) */
+#define C2_E_OVERFLOW  -6   /* caller's output buffer too small; required sizes are reported */
+
+/* per-alignment status bits, c2_aln_record.status (0 = valid alignment) */
+#define C2_STATUS_EMPTY         1
+#define C2_STATUS_OOB_CHAR      2
+#define C2_STATUS_SENTINEL_PATH 4
+#define C2_STATUS_UNINIT_PTR    8
+#define C2_STATUS_RC_CHAR       16
+#define C2_STATUS_TOO_LONG      32
+
+typedef struct c2_ctx c2_ctx;
+
+/* One record per executed (read, reference) alignment; 32 bytes; layout is ABI. */
+typedef struct c2_aln_record {
+    uint16_t aln_len;              /* columns; length of both aligned strings */
+    uint16_t matches;              /* score = round(100*matches/float(aln_len), 3): CRISPResso2Align.pyx:433-434 */
+    uint16_t insertion_n;          /* CRISPRessoCOREResources.pyx:165 */
+    uint16_t deletion_n;           /* pyx:164 */
+    uint16_t substitution_n;       /* pyx:163 */
+    uint16_t all_insertion_events; /* len(all_insertion_left_positions) */
+    uint16_t win_insertion_events; /* len(insertion_sizes) */
+    uint16_t all_deletion_events;  /* len(all_deletion_coordinates) */
+    uint16_t win_deletion_events;  /* len(deletion_coordinates) */
+    uint16_t all_deletion_bases;   /* len(all_deletion_positions) */
+    uint16_t all_substitutions;    /* len(all_substitution_positions) */
+    uint8_t  irregular_ends;       /* CRISPRessoCORE.py:729-733 */
+    uint8_t  status;               /* C2_STATUS_* */
+    uint8_t  strand;               /* 0 '+', 1 '-' */
+    uint8_t  reserved0;
+    uint16_t ref_id;
+    uint32_t reserved2;
+} c2_aln_record;
+#ifdef __cplusplus
+static_assert(sizeof(c2_aln_record) == 32, "c2_aln_record is ABI: 32 bytes");
+#endif
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+
+/* Number of visible GPUs (0 if none / HIP unusable). */
+int c2_device_count(void);
+
+/* Create a context bound to GPU `device` (one context per process per GPU is the intended
+ * use: CRISPRessoMultiProcessing's process pool becomes one process per GPU). */
+int c2_create(int device, c2_ctx** out);
+void c2_destroy(c2_ctx* ctx);
+const char* c2_last_error(const c2_ctx* ctx);
+int c2_abi_version(void);
+
+/* ---- scoring and references ----------------------------------------------------------- */
+
+/* Score matrix as produced by CRISPResso2Align.read_matrix / make_matrix (pyx:33-99):
+ * row-major int64[mat_dim][mat_dim] indexed [ord(ref char)][ord(read char)] (pyx:212),
+ * plus the two gap parameters of global_align (pyx:104-105). */
+int c2_set_scoring(c2_ctx* ctx, const int64_t* matrix, int32_t mat_dim, int32_t gap_open, int32_t gap_extend);
+
+/* The reference amplicons of a run: what CRISPRessoCORE.py:3236-3268 keeps in refs[name]
+ * ('sequence', 'gap_incentive' int64[len+1], 'include_idxs').  include_idx[r] may be NULL
+ * when n_include[r] == 0. */
+int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int32_t* lens,
+                const int64_t* const* gap_incentives,
+                const int32_t* const* include_idx, const int32_t* n_include);
+
+/* ---- batch path: replaces the per-read loop of CRISPRessoCORE.py:1957-1981 / :1226-1232 - */
+
+typedef struct c2_batch {
+    uint64_t n_reads;
+    const uint8_t*  reads;     /* byte arena holding the read sequences back to back */
+    const uint64_t* offsets;   /* n_reads+1 byte offsets; read k = reads[offsets[k] .. offsets[k+1]) */
+    const uint16_t* ref_ids;   /* per read amplicon id (CRISPRessoPooled semantics) or NULL = reference 0 */
+    const uint8_t*  strands;   /* per task: 1 = align reverse_complement(read) (CRISPRessoCORE.py:672), or NULL */
+    int32_t all_refs;          /* 1: align every read to every reference (CRISPRessoCORE.py:653);
+                                  task t = read t / n_refs against reference t % n_refs; ref_ids ignored */
+    int32_t reserved;
+    /* outputs, n_tasks = n_reads * (all_refs ? n_refs : 1) entries each */
+    uint8_t* aln_read;         /* n_tasks x aln_stride: aligned read  (global_align()[0]) */
+    uint8_t* aln_ref;          /* n_tasks x aln_stride: aligned reference (global_align()[1]) */
+    uint32_t aln_stride;       /* >= longest read + longest reference */
+    uint32_t reserved2;
+    c2_aln_record* records;    /* n_tasks */
+} c2_batch;
+
+/* All pointers in `b` are DEVICE pointers; the launch is enqueued on `hip_stream`
+ * (a hipStream_t, NULL = the context's own stream) and the call returns without waiting. */
+int c2_align_classify_batch_device(c2_ctx* ctx, const c2_batch* b, void* hip_stream);
+
+/* All pointers in `b` are HOST pointers; stages through the context's device buffers
+ * (H2D, launch, D2H) and returns when the results are in host memory. */
+int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b);
+
+/* Block until everything enqueued on the context's stream (or `hip_stream`) is done. */
+int c2_synchronize(c2_ctx* ctx, void* hip_stream);
+
+/* Kernel timing with HIP events on the launch stream: enable, run launches, then read the
+ * accumulated kernel milliseconds and launch count (synchronises the recorded events). */
+int c2_timing_enable(c2_ctx* ctx, int on);
+int c2_timing_read(c2_ctx* ctx, double* total_ms, int64_t* launches, int reset);
+
+/* Launch geometry chosen for the current references / longest read (for DESIGN/bench reporting). */
+int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, int32_t* passes,
+                   int32_t* lds_bytes, int32_t* workgroups_per_cu, int32_t* compute_units);
+
+/* ---- per-call path: same contract as the reference's Cython functions ------------------ */
+
+/* global_align(pystr_seqj, pystr_seqi, matrix, gap_incentive, gap_open, gap_extend), pyx:103-105.
+ * Host pointers.  out_read_aln / out_ref_aln need Lj+Li bytes.  n_gap_incentive != Li+1 is
+ * reported through *out_status = -1 (the reference prints and returns 0, pyx:124-126);
+ * otherwise *out_status holds the C2_STATUS_* bits of the alignment. */
+int c2_global_align(c2_ctx* ctx, const char* read, int32_t Lj, const char* ref, int32_t Li,
+                    const int64_t* matrix, int32_t mat_dim,
+                    const int64_t* gap_incentive, int32_t n_gap_incentive,
+                    int32_t gap_open, int32_t gap_extend,
+                    char* out_read_aln, char* out_ref_aln,
+                    int32_t* out_len, int32_t* out_matches, int32_t* out_status);
+
+/* find_indels_substitutions(read_seq_al, ref_seq_al, _include_indx), COREResources.pyx:71, and
+ * find_indels_substitutions_legacy (pyx:193) when legacy != 0.  Any two equal-length strings are
+ * accepted (including shapes the aligner never emits).  Results come back as flat int32 lists:
+ * `out` is a caller buffer of `out_cap` int32; `out_index[2*k]`/`out_index[2*k+1]` receive offset and
+ * length of list k (C2_LIST_* order).  Returns C2_E_OVERFLOW and the needed size in *out_needed if
+ * out_cap is too small. */
+enum {
+    C2_LIST_REF_POSITIONS = 0,
+    C2_LIST_ALL_INSERTION_POSITIONS,
+    C2_LIST_ALL_INSERTION_LEFT_POSITIONS,
+    C2_LIST_INSERTION_POSITIONS,
+    C2_LIST_INSERTION_COORDINATES,      /* flattened (start, end) pairs */
+    C2_LIST_INSERTION_SIZES,
+    C2_LIST_ALL_DELETION_POSITIONS,
+    C2_LIST_ALL_DELETION_COORDINATES,   /* pairs */
+    C2_LIST_DELETION_POSITIONS,
+    C2_LIST_DELETION_COORDINATES,       /* pairs */
+    C2_LIST_DELETION_SIZES,
+    C2_LIST_ALL_SUBSTITUTION_POSITIONS,
+    C2_LIST_ALL_SUBSTITUTION_VALUES,    /* character codes */
+    C2_LIST_SUBSTITUTION_POSITIONS,
+    C2_LIST_SUBSTITUTION_VALUES,        /* character codes */
+    C2_LIST_COUNT
+};
+int c2_find_indels_substitutions(c2_ctx* ctx, const char* read_aln, const char* ref_aln, int32_t n,
+                                 const int32_t* include_idx, int32_t n_include, int32_t legacy,
+                                 int32_t* out, int32_t out_cap, int32_t* out_index /* 2*C2_LIST_COUNT */,
+                                 int64_t* out_counts /* insertion_n, deletion_n, substitution_n */,
+                                 int32_t* out_needed);
+
+/* calculate_homology(a, b), COREResources.pyx:318-327: matches over strlen(a), float32 accumulator. */
+int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

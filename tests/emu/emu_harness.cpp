@@ -1,0 +1,70 @@
+// Wave-emulator harness -- TEST INFRASTRUCTURE ONLY.
+// Compiles crispresso2_amd/csrc/c2_kernels.hip unchanged with g++ (hip/hip_runtime.h is the shim in
+// this directory) and runs it on 64 cooperative fibers.  tests/test_kernel_emulated.py drives it
+// through ctypes and compares with the oracle.  Not part of the product; never used as a fallback.
+#include "emu_runtime.h"
+#include <vector>
+#include <string>
+#include "../../crispresso2_amd/csrc/c2_host_prep.h"
+
+alignas(16) unsigned char c2_smem[163840];
+#include "../../crispresso2_amd/csrc/c2_kernels.hip"
+
+extern "C" {
+
+int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offsets, const uint16_t* ref_ids,
+                    const uint8_t* strands, int all_refs,
+                    int n_refs, const char* const* seqs, const int32_t* lens, const int64_t* const* gap_inc,
+                    const int32_t* const* include_idx, const int32_t* n_include,
+                    const int64_t* matrix, int dim, int go, int ge,
+                    uint8_t* aln_read, uint8_t* aln_ref, uint32_t aln_stride, c2_aln_record* records,
+                    int force_R, unsigned grid)
+{
+    c2_scoring_tables sc; std::string err;
+    if (!c2_build_scoring(matrix, dim, sc, err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return -1; }
+    std::vector<c2_dev_ref> refs(n_refs);
+    std::vector<std::vector<int32_t>> g32(n_refs);
+    std::vector<std::vector<uint16_t>> incp(n_refs);
+    int max_li = 1;
+    for (int r = 0; r < n_refs; ++r) {
+        g32[r].resize(lens[r] + 1);
+        for (int k = 0; k <= lens[r]; ++k) g32[r][k] = (int32_t)gap_inc[r][k];
+        c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
+        refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = g32[r].data(); refs[r].inc_prefix = incp[r].data();
+        refs[r].len = lens[r]; refs[r].reserved = 0;
+        max_li = std::max(max_li, lens[r]);
+    }
+    int max_lj = 1;
+    for (uint64_t k = 0; k < n_reads; ++k) max_lj = std::max<int>(max_lj, (int)(offsets[k + 1] - offsets[k]));
+    const int R = force_R ? force_R : c2_choose_rows_per_lane(max_li);
+    c2_align_args A;
+    A.reads = reads; A.offsets = offsets; A.ref_ids = ref_ids; A.strands = strands; A.refs = refs.data();
+    A.score_tbl = sc.tbl.data(); A.code_of_char = sc.code_of_char;
+    A.aln_read = aln_read; A.aln_ref = aln_ref; A.records = records;
+    A.n_tasks = n_reads * (uint64_t)(all_refs ? n_refs : 1); A.aln_stride = aln_stride; A.n_refs = n_refs; A.all_refs = all_refs;
+    A.n_codes = sc.n_codes; A.gap_open = go; A.gap_extend = ge; A.max_lj = max_lj;
+    A.max_passes = (max_li + 64 * R - 1) / (64 * R);
+    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes);
+    if (P.total > sizeof(c2_smem)) { fprintf(stderr, "emu: LDS plan %u too large\n", P.total); return -5; }
+    if (grid == 0) grid = (unsigned)std::min<uint64_t>(A.n_tasks, 3);
+    switch (R) {
+        case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1>(A); }); break;
+        case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2>(A); }); break;
+        case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3>(A); }); break;
+        default: emu::launch(grid, [&] { c2_align_classify_kernel<4>(A); }); break;
+    }
+    return 0;
+}
+
+int emu_classify_lists(const uint8_t* read_al, const uint8_t* ref_al, int n, const int32_t* include_sorted, int n_include,
+                       int legacy, int cap, int32_t* lists, int32_t* list_len, int64_t* counts)
+{
+    c2_classify_args A;
+    A.read_al = read_al; A.ref_al = ref_al; A.include_sorted = include_sorted; A.n = n; A.n_include = n_include;
+    A.legacy = legacy; A.cap = cap; A.lists = lists; A.list_len = list_len; A.counts = counts;
+    emu::launch(1, [&] { c2_classify_lists_kernel(A); });
+    return 0;
+}
+
+int emu_selftest(int* out) { emu::launch(1, [&] { c2_selftest_kernel(out); }); return 0; }
+}

@@ -1,0 +1,55 @@
+// Fiber scheduler for the wave emulator (see hip/hip_runtime.h). TEST INFRASTRUCTURE ONLY.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <functional>
+#include <vector>
+
+namespace emu {
+int cur_lane = 0;
+dim3_ block_idx, grid_dim, block_dim;
+ucontext_t lane_ctx[W], sched_ctx;
+bool lane_done[W];
+uint64_t xl_slots[2][W];
+int xl_phase = 0;
+int bar_count = 0;
+unsigned bar_gen = 0;
+static std::function<void()>* cur_body = nullptr;
+static std::vector<char> stacks;
+
+static void lane_entry() {
+    (*cur_body)();
+    lane_done[cur_lane] = true;
+    // hand control to any unfinished lane, else back to the scheduler
+    for (int k = 1; k <= W; ++k) {
+        int c = (cur_lane + k) % W;
+        if (!lane_done[c]) { int me = cur_lane; cur_lane = c; swapcontext(&lane_ctx[me], &lane_ctx[c]); }
+    }
+    setcontext(&sched_ctx);
+}
+
+template <class F>
+void launch(unsigned grid, F body) {
+    std::function<void()> fn = body;
+    cur_body = &fn;
+    const size_t STK = 256 * 1024;
+    stacks.resize(STK * W);
+    grid_dim.x = grid; block_dim.x = W;
+    for (unsigned b = 0; b < grid; ++b) {
+        block_idx.x = b;
+        bar_count = 0;
+        for (int l = 0; l < W; ++l) {
+            lane_done[l] = false;
+            getcontext(&lane_ctx[l]);
+            lane_ctx[l].uc_stack.ss_sp = stacks.data() + STK * l;
+            lane_ctx[l].uc_stack.ss_size = STK;
+            lane_ctx[l].uc_link = &sched_ctx;
+            makecontext(&lane_ctx[l], (void (*)())lane_entry, 0);
+        }
+        cur_lane = 0;
+        volatile bool started = false;
+        getcontext(&sched_ctx);
+        if (!started) { started = true; setcontext(&lane_ctx[0]); }
+        for (int l = 0; l < W; ++l) if (!lane_done[l]) { fprintf(stderr, "emu: lane %d never finished\n", l); abort(); }
+    }
+}
+}  // namespace emu

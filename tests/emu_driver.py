@@ -1,0 +1,98 @@
+"""ctypes driver for the wave emulator (tests/emu/) -- TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU_DIR = os.path.join(HERE, "emu")
+LIB = os.path.join(EMU_DIR, "libc2_emu.so")
+
+REC_DTYPE = np.dtype([
+    ("aln_len", "<u2"), ("matches", "<u2"), ("insertion_n", "<u2"), ("deletion_n", "<u2"), ("substitution_n", "<u2"),
+    ("all_insertion_events", "<u2"), ("win_insertion_events", "<u2"), ("all_deletion_events", "<u2"),
+    ("win_deletion_events", "<u2"), ("all_deletion_bases", "<u2"), ("all_substitutions", "<u2"),
+    ("irregular_ends", "u1"), ("status", "u1"), ("strand", "u1"), ("reserved0", "u1"),
+    ("ref_id", "<u2"), ("reserved2", "<u4")])
+assert REC_DTYPE.itemsize == 32
+
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(EMU_DIR, f) for f in ("emu_harness.cpp", "emu_runtime.h", "hip/hip_runtime.h")]
+    srcs += [os.path.join(ROOT, "crispresso2_amd/csrc", f) for f in ("c2_kernels.hip", "c2_device.h", "c2_host_prep.h")]
+    srcs.append(os.path.join(ROOT, "include/crispresso2_amd.h"))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", EMU_DIR,
+                               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "crispresso2_amd/csrc"),
+                               "-x", "c++", os.path.join(EMU_DIR, "emu_harness.cpp"), "-o", LIB])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB)
+    return _lib
+
+
+def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_extend,
+                ref_ids=None, strands=None, all_refs=False, force_R=0, grid=0):
+    """reads: list[str]; refs: list[str]; returns (list[(s1, s2)], records ndarray)"""
+    n = len(reads)
+    arena = "".join(reads).encode()
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    nrefs = len(refs)
+    seqs = (ctypes.c_char_p * nrefs)(*[r.encode() for r in refs])
+    lens = np.array([len(r) for r in refs], dtype=np.int32)
+    g = [np.ascontiguousarray(x, dtype=np.int64) for x in gap_incentives]
+    gp = (ctypes.c_void_p * nrefs)(*[x.ctypes.data for x in g])
+    inc = [np.ascontiguousarray(np.asarray(list(x), dtype=np.int64).astype(np.int32)) for x in includes]
+    ip = (ctypes.c_void_p * nrefs)(*[x.ctypes.data for x in inc])
+    ninc = np.array([len(x) for x in inc], dtype=np.int32)
+    m = np.ascontiguousarray(matrix, dtype=np.int64)
+    ntasks = n * (nrefs if all_refs else 1)
+    stride = (max(len(r) for r in reads) + int(lens.max()) + 15) // 16 * 16
+    o1 = np.zeros((ntasks, stride), dtype=np.uint8)
+    o2 = np.zeros((ntasks, stride), dtype=np.uint8)
+    rec = np.zeros(ntasks, dtype=REC_DTYPE)
+    rid = None if ref_ids is None else np.ascontiguousarray(ref_ids, dtype=np.uint16)
+    st = None if strands is None else np.ascontiguousarray(strands, dtype=np.uint8)
+    rc = lib().emu_align_batch(
+        ctypes.c_uint64(n), arena, offs.ctypes.data_as(ctypes.c_void_p),
+        None if rid is None else rid.ctypes.data_as(ctypes.c_void_p),
+        None if st is None else st.ctypes.data_as(ctypes.c_void_p), int(all_refs),
+        nrefs, seqs, lens.ctypes.data_as(ctypes.c_void_p), gp, ip, ninc.ctypes.data_as(ctypes.c_void_p),
+        m.ctypes.data_as(ctypes.c_void_p), int(m.shape[0]), int(gap_open), int(gap_extend),
+        o1.ctypes.data_as(ctypes.c_void_p), o2.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(stride),
+        rec.ctypes.data_as(ctypes.c_void_p), int(force_R), ctypes.c_uint(grid))
+    assert rc == 0, rc
+    out = []
+    for k in range(ntasks):
+        L = int(rec["aln_len"][k])
+        out.append((o1[k, :L].tobytes().decode(), o2[k, :L].tobytes().decode()))
+    return out, rec
+
+
+N_LISTS = 15
+
+
+def classify_lists(read_al, ref_al, include, legacy=False):
+    n = len(ref_al)
+    inc = np.ascontiguousarray(sorted(set(int(x) for x in include)), dtype=np.int32)
+    cap = 2 * n + 8
+    while True:
+        lists = np.zeros((N_LISTS, cap), dtype=np.int32)
+        lens = np.zeros(N_LISTS, dtype=np.int32)
+        counts = np.zeros(3, dtype=np.int64)
+        lib().emu_classify_lists(read_al.encode(), ref_al.encode(), n, inc.ctypes.data_as(ctypes.c_void_p), len(inc),
+                                 int(legacy), cap, lists.ctypes.data_as(ctypes.c_void_p),
+                                 lens.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p))
+        if lens.max() <= cap:
+            break
+        cap = int(lens.max()) + 8
+    return [lists[k, :lens[k]].tolist() for k in range(N_LISTS)], counts.tolist()

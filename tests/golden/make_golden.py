@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the REFERENCE itself (run in the dev container only).
+
+Needs /root/reference (for its unit tests and FANC fixture) and oracle/_ref (the reference's own
+Cython hot path compiled by oracle/build_ref.py).  The JSON written here is what travels: nothing
+at test time reads /root/reference.
+
+  ref_unit_kats.json   every global_align / find_indels_substitutions(_legacy) call made by the
+                       reference's own unit tests (tests/unit_tests/test_CRISPResso2Align.py,
+                       test_CRISPRessoCOREResources.py) with the value it returned; recorded while
+                       those tests ran green against oracle/_ref, so the values are exactly the
+                       known answers those tests assert.
+  fuzz_align.json      random + adversarial (read, ref, gap_incentive, gap params) -> reference output
+  fuzz_classify.json   random aligned-string pairs (incl. shapes the aligner never emits) -> payload
+  realistic.json       150/223/250-bp amplicon cases + the first reads of tests/FANC.Cas9.fastq:
+                       alignment and classifier payload
+"""
+import importlib.util
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+import oracle  # noqa: E402
+from oracle import build_ref  # noqa: E402
+
+build_ref.build()
+A, R = oracle.ref()
+EDNA = A.read_matrix(os.path.join(ROOT, "oracle/_ref/EDNAFULL"))
+BLOSUM = A.read_matrix(os.path.join(ROOT, "oracle/_ref/BLOSUM62"))
+
+
+def jsonable(x):
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.floating,)):
+        return float(x)
+    if isinstance(x, tuple):
+        return [jsonable(v) for v in x]
+    if isinstance(x, list):
+        return [jsonable(v) for v in x]
+    if isinstance(x, dict):
+        return {k: jsonable(v) for k, v in x.items()}
+    return x
+
+
+def payload_dict(p):
+    d = p.__dict__ if not isinstance(p, dict) else p
+    return jsonable(dict(d))
+
+
+# ---------------------------------------------------------------- 1. reference unit-test KATs
+def record_unit_kats():
+    calls = []
+
+    def matname(m):
+        if m.shape == EDNA.shape and (m == EDNA).all():
+            return "EDNAFULL"
+        if m.shape == BLOSUM.shape and (m == BLOSUM).all():
+            return "BLOSUM62"
+        raise ValueError("unknown matrix")
+
+    class AlignProxy(types.ModuleType):
+        read_matrix = staticmethod(A.read_matrix)
+        make_matrix = staticmethod(A.make_matrix)
+
+        @staticmethod
+        def global_align(seqj, seqi, matrix, gap_incentive, gap_open=-1, gap_extend=-1):
+            out = A.global_align(seqj, seqi, matrix=matrix, gap_incentive=gap_incentive,
+                                 gap_open=gap_open, gap_extend=gap_extend)
+            calls.append({"fn": "global_align", "seqj": seqj, "seqi": seqi, "matrix": matname(matrix),
+                          "gap_incentive": jsonable(gap_incentive), "gap_open": gap_open,
+                          "gap_extend": gap_extend, "out": jsonable(out)})
+            return out
+
+    class ResProxy(types.ModuleType):
+        ResultsSlotsDict = R.ResultsSlotsDict
+        calculate_homology = staticmethod(R.calculate_homology)
+
+        @staticmethod
+        def find_indels_substitutions(a, b, inc):
+            out = R.find_indels_substitutions(a, b, inc)
+            calls.append({"fn": "find_indels_substitutions", "read_al": a, "ref_al": b,
+                          "include": jsonable(list(inc)), "out": payload_dict(out)})
+            return out
+
+        @staticmethod
+        def find_indels_substitutions_legacy(a, b, inc):
+            out = R.find_indels_substitutions_legacy(a, b, inc)
+            calls.append({"fn": "find_indels_substitutions_legacy", "read_al": a, "ref_al": b,
+                          "include": jsonable(list(inc)), "out": payload_dict(out)})
+            return out
+
+    pkg = types.ModuleType("CRISPResso2")
+    pkg.CRISPResso2Align = AlignProxy("CRISPResso2.CRISPResso2Align")
+    pkg.CRISPRessoCOREResources = ResProxy("CRISPResso2.CRISPRessoCOREResources")
+    saved = {k: sys.modules.get(k) for k in ("CRISPResso2", "CRISPResso2.CRISPResso2Align",
+                                             "CRISPResso2.CRISPRessoCOREResources")}
+    sys.modules["CRISPResso2"] = pkg
+    sys.modules["CRISPResso2.CRISPResso2Align"] = pkg.CRISPResso2Align
+    sys.modules["CRISPResso2.CRISPRessoCOREResources"] = pkg.CRISPRessoCOREResources
+    cwd = os.getcwd()
+    n_tests = 0
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "CRISPResso2"))
+        for f in ("EDNAFULL", "BLOSUM62"):
+            with open(os.path.join(ROOT, "oracle/_ref", f)) as src, open(os.path.join(td, "CRISPResso2", f), "w") as dst:
+                dst.write(src.read())
+        os.chdir(td)
+        try:
+            for tf in ("test_CRISPResso2Align.py", "test_CRISPRessoCOREResources.py"):
+                spec = importlib.util.spec_from_file_location("reftest_" + tf[:-3],
+                                                              os.path.join(REF, "tests/unit_tests", tf))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                for name in sorted(dir(mod)):
+                    if name.startswith("test_") and callable(getattr(mod, name)):
+                        first = len(calls)
+                        getattr(mod, name)()          # raises if the reference's own assertion fails
+                        for c in calls[first:]:
+                            c["ref_test"] = tf + "::" + name
+                        n_tests += 1
+        finally:
+            os.chdir(cwd)
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+    print("reference unit tests run green against oracle/_ref: %d tests, %d recorded calls" % (n_tests, len(calls)))
+    return calls
+
+
+# ---------------------------------------------------------------- 2. fuzz
+def mutate(rng, ref, alphabet):
+    s = list(ref)
+    for _ in range(rng.integers(0, 4)):
+        if not s:
+            break
+        k = rng.integers(0, 4)
+        p = int(rng.integers(0, len(s)))
+        if k == 0:
+            s[p] = str(rng.choice(alphabet))
+        elif k == 1:
+            del s[p:p + int(rng.integers(1, 8))]
+        elif k == 2:
+            ins = "".join(rng.choice(alphabet, int(rng.integers(1, 8))))
+            s[p:p] = list(ins)
+        else:
+            s = list("".join(rng.choice(alphabet, int(rng.integers(0, 6))))) + s
+    if rng.random() < 0.2:
+        s += list("".join(rng.choice(alphabet, int(rng.integers(1, 10)))))
+    if not s:
+        s = [str(rng.choice(alphabet))]
+    return "".join(s)
+
+
+def safe_ref_align(seqj, seqi, mat, g, go, ge):
+    """Run the reference only where it is defined (no uninitialised-pointer reads: SURVEY App. A.6)."""
+    st = oracle.global_align_raw(seqj, seqi, mat, g, go, ge)[0]
+    if st & ~oracle.WARN_SENTINEL_PATH:
+        return None
+    return A.global_align(seqj, seqi, matrix=mat, gap_incentive=g, gap_open=go, gap_extend=ge)
+
+
+def fuzz_align(n_per=220):
+    rng = np.random.default_rng(777)
+    out = []
+    alphabets = [list("ACGT"), list("ACGTN"), list("AC"), list("A"), list("ACGTRYKMSWN")]
+    for (go, ge) in [(-20, -2), (-50, 0), (-5, -3), (-20, 0), (-3, -3), (-1, -1)]:
+        k = 0
+        while k < n_per:
+            alpha = alphabets[int(rng.integers(0, len(alphabets)))]
+            L = int(rng.integers(1, 61))
+            ref = "".join(rng.choice(alpha, L))
+            read = mutate(rng, ref, alpha) if rng.random() < 0.8 else "".join(rng.choice(alpha, int(rng.integers(1, 61))))
+            g = np.zeros(L + 1, dtype=np.int64)
+            for _ in range(int(rng.integers(0, 4))):
+                g[int(rng.integers(0, L + 1))] = int(rng.choice([1, 1, 2, 5, -1]))
+            res = safe_ref_align(read, ref, EDNA, g, go, ge)
+            if res is None:
+                continue
+            out.append({"seqj": read, "seqi": ref, "matrix": "EDNAFULL", "gap_incentive": g.tolist(),
+                        "gap_open": go, "gap_extend": ge, "out": jsonable(res)})
+            k += 1
+    # amino-acid alignments with BLOSUM62 (CRISPRessoShared.py:1602-1607 uses the -1/-1 defaults)
+    aa = list("ARNDCQEGHILKMFPSTWYV*")
+    k = 0
+    while k < 80:
+        L = int(rng.integers(2, 40))
+        ref = "".join(rng.choice(aa, L))
+        read = mutate(rng, ref, aa)
+        g = np.zeros(L + 1, dtype=np.int64)
+        res = safe_ref_align(read, ref, BLOSUM, g, -1, -1)
+        if res is None:
+            continue
+        out.append({"seqj": read, "seqi": ref, "matrix": "BLOSUM62", "gap_incentive": g.tolist(),
+                    "gap_open": -1, "gap_extend": -1, "out": jsonable(res)})
+        k += 1
+    return out
+
+
+def fuzz_classify(n=500):
+    rng = np.random.default_rng(4242)
+    out = []
+    for k in range(n):
+        L = int(rng.integers(1, 70))
+        # columns drawn so that every shape occurs: match, sub, N, ins, del, and (rarely) double gap
+        cols = rng.choice(6, L, p=[0.62, 0.08, 0.03, 0.12, 0.13, 0.02])
+        read, ref = [], []
+        for c in cols:
+            b = str(rng.choice(list("ACGT")))
+            if c == 0:
+                read.append(b); ref.append(b)
+            elif c == 1:
+                read.append(b); ref.append(str(rng.choice([x for x in "ACGT" if x != b])))
+            elif c == 2:
+                read.append("N"); ref.append(b)
+            elif c == 3:
+                read.append(b); ref.append("-")
+            elif c == 4:
+                read.append("-"); ref.append(b)
+            else:
+                read.append("-"); ref.append("-")
+        read, ref = "".join(read), "".join(ref)
+        nref = sum(1 for c in ref if c != "-")
+        if rng.random() < 0.5:
+            inc = sorted(set(int(x) for x in rng.integers(0, max(nref, 1), int(rng.integers(0, 12)))))
+        else:
+            a = int(rng.integers(0, max(nref, 1)))
+            inc = list(range(a, min(nref, a + int(rng.integers(1, 30)))))
+        for fn in ("find_indels_substitutions", "find_indels_substitutions_legacy"):
+            if fn.endswith("legacy") and k % 3:
+                continue
+            try:
+                p = getattr(R, fn)(read, ref, inc)
+            except Exception:      # e.g. OverflowError on the double-gap quirk: not a usable vector
+                continue
+            out.append({"fn": fn, "read_al": read, "ref_al": ref, "include": inc, "out": payload_dict(p)})
+    return out
+
+
+def synth_reads(rng, amplicon, cut, n):
+    """SURVEY §8d read model (small sample)."""
+    L = len(amplicon)
+    reads = []
+    for _ in range(n):
+        s = list(amplicon)
+        for p in range(L):
+            if rng.random() < 0.005:
+                s[p] = str(rng.choice(list("ACGT")))
+        if rng.random() < 0.30:
+            dl = min(60, 1 + int(rng.geometric(0.12)))
+            st = max(0, cut - int(rng.integers(0, dl + 1)))
+            del s[st:st + dl]
+        if rng.random() < 0.10:
+            ins = list(rng.choice(list("ACGT"), int(rng.integers(1, 16))))
+            c = min(cut, len(s))
+            s[c:c] = ins
+        if rng.random() < 0.01:
+            for p in rng.integers(0, len(s), 3):
+                s[int(p)] = "N"
+        s += list(rng.choice(list("ACGT"), L))
+        reads.append("".join(s[:L]))
+    return reads
+
+
+def realistic():
+    rng = np.random.default_rng(99)
+    out = []
+    for L, n in ((150, 40), (250, 40)):
+        amplicon = "".join(np.random.default_rng(20240601).choice(list("ACGT"), L))
+        cut = L // 2
+        g = np.zeros(L + 1, dtype=np.int64)
+        g[cut + 1] = 1
+        inc = [cut, cut + 1]
+        reads = synth_reads(rng, amplicon, cut, n)
+        # a few unrelated reads and overhang reads
+        reads += ["".join(rng.choice(list("ACGT"), L)) for _ in range(3)]
+        reads += [amplicon[7:] + "ACGTACG", "TTTT" + amplicon[:-4]]
+        for rd in reads:
+            s1, s2, sc = A.global_align(rd, amplicon, matrix=EDNA, gap_incentive=g, gap_open=-20, gap_extend=-2)
+            p = R.find_indels_substitutions(s1, s2, inc)
+            out.append({"seqj": rd, "seqi": amplicon, "matrix": "EDNAFULL", "gap_incentive": g.tolist(),
+                        "gap_open": -20, "gap_extend": -2, "include": inc,
+                        "out": [s1, s2, sc], "payload": payload_dict(p)})
+    # FANC: reference tests/Cas9.amplicons.txt + tests/FANC.Cas9.fastq (223-bp amplicon; cut 91 -> gap_incentive[92]=1)
+    with open(os.path.join(REF, "tests/Cas9.amplicons.txt")) as fh:
+        for line in fh:
+            f = line.split()
+            if f and f[0] == "FANC":
+                fanc = f[1].upper()
+    g = np.zeros(len(fanc) + 1, dtype=np.int64)
+    g[92] = 1
+    inc = [91, 92]
+    seqs = []
+    with open(os.path.join(REF, "tests/FANC.Cas9.fastq")) as fh:
+        lines = fh.read().split("\n")
+    for k in range(1, len(lines), 4):
+        if lines[k] and lines[k] not in seqs:
+            seqs.append(lines[k])
+    for rd in seqs[:70]:
+        s1, s2, sc = A.global_align(rd, fanc, matrix=EDNA, gap_incentive=g, gap_open=-20, gap_extend=-2)
+        p = R.find_indels_substitutions(s1, s2, inc)
+        out.append({"seqj": rd, "seqi": fanc, "matrix": "EDNAFULL", "gap_incentive": g.tolist(),
+                    "gap_open": -20, "gap_extend": -2, "include": inc, "src": "FANC.Cas9.fastq",
+                    "out": [s1, s2, sc], "payload": payload_dict(p)})
+    return out
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as fh:
+        json.dump(obj, fh, separators=(",", ":"))
+    print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    dump("ref_unit_kats.json", record_unit_kats())
+    dump("fuzz_align.json", fuzz_align())
+    dump("fuzz_classify.json", fuzz_classify())
+    dump("realistic.json", realistic())

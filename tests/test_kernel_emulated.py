@@ -1,0 +1,156 @@
+"""The HIP kernel SOURCE (crispresso2_amd/csrc/c2_kernels.hip), compiled unchanged for the host by
+the wave emulator in tests/emu/, against the golden vectors and the oracle (CPU only).
+
+This checks the kernel's logic -- systolic schedule, tie rules, pointer packing, wave-parallel
+traceback, fused classification, multi-pass references -- in the GPU-less container.  It is a test
+harness, not a product path; the `-m gpu` tests are the parity tests proper.
+"""
+import numpy as np
+import pytest
+
+import emu_driver as E
+import oracle
+from helpers import load_golden, matrices
+
+
+@pytest.fixture(scope="module")
+def mats():
+    E.build()
+    return matrices()
+
+
+def check_record(rec, payload, s1, s2):
+    """summary record vs the reference's payload + the derived fields of CRISPRessoCORE.py:726-744"""
+    assert rec["insertion_n"] == payload["insertion_n"]
+    assert rec["deletion_n"] == payload["deletion_n"]
+    assert rec["substitution_n"] == payload["substitution_n"]
+    assert rec["all_insertion_events"] == len(payload["all_insertion_left_positions"])
+    assert rec["win_insertion_events"] == len(payload["insertion_sizes"])
+    assert rec["all_deletion_events"] == len(payload["all_deletion_coordinates"])
+    assert rec["win_deletion_events"] == len(payload["deletion_coordinates"])
+    assert rec["all_deletion_bases"] == len(payload["all_deletion_positions"])
+    assert rec["all_substitutions"] == len(payload["all_substitution_positions"])
+    irregular = (s1[0] == "-" or s2[0] == "-" or s1[0] != s2[0]) or (s1[-1] == "-" or s2[-1] == "-" or s1[-1] != s2[-1])
+    assert bool(rec["irregular_ends"]) == irregular
+
+
+def run_vectors(vecs, mats, force_R=0, batch=64):
+    """Group vectors that share (ref, gap_incentive, matrix, params) into one emulated launch each."""
+    groups = {}
+    for v in vecs:
+        key = (v["seqi"], tuple(v["gap_incentive"]), v["matrix"], v["gap_open"], v["gap_extend"], tuple(v.get("include", [])))
+        groups.setdefault(key, []).append(v)
+    n = 0
+    for (seqi, g, mat, go, ge, inc), vs in groups.items():
+        for b in range(0, len(vs), batch):
+            chunk = vs[b:b + batch]
+            res, rec = E.align_batch([v["seqj"] for v in chunk], [seqi], [list(g)], [list(inc)], mats[mat], go, ge,
+                                     force_R=force_R, grid=min(len(chunk), 3))
+            for v, (s1, s2), r in zip(chunk, res, rec):
+                assert r["status"] == 0, (v, r)
+                assert [s1, s2] == v["out"][:2], v
+                assert round(100 * int(r["matches"]) / float(int(r["aln_len"])), 3) == v["out"][2]
+                payload = v.get("payload") or oracle.find_indels_substitutions(s1, s2, list(inc))
+                check_record(r, payload, s1, s2)
+                n += 1
+    return n
+
+
+def test_emulated_kernel_reference_unit_test_answers(mats):
+    kats = [k for k in load_golden("ref_unit_kats.json") if k["fn"] == "global_align"]
+    assert run_vectors(kats, mats) == len(kats)
+
+
+def test_emulated_kernel_fuzz_vectors(mats):
+    vecs = load_golden("fuzz_align.json")
+    assert run_vectors(vecs, mats) == len(vecs)
+
+
+def test_emulated_kernel_realistic_vectors(mats):
+    vecs = load_golden("realistic.json")
+    assert run_vectors(vecs, mats) == len(vecs)
+
+
+@pytest.mark.parametrize("R", [1, 2, 3])
+def test_emulated_kernel_multipass(mats, R):
+    """Force fewer rows per lane so that 150..250-row references need 2..4 passes through the LDS boundary row."""
+    vecs = load_golden("realistic.json")
+    vecs = vecs[:12] + vecs[45:57] + vecs[-12:]
+    assert run_vectors(vecs, mats, force_R=R) == len(vecs)
+    small = load_golden("fuzz_align.json")[::7]
+    assert run_vectors(small, mats, force_R=R) == len(small)
+
+
+def test_emulated_kernel_reverse_complement_and_ref_ids(mats):
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    vecs = load_golden("realistic.json")
+    a, b = vecs[0], vecs[50]           # 150-bp and 250-bp amplicons
+    reads, rids, strands, exp = [], [], [], []
+    for k, v in enumerate(vecs[:10] + vecs[45:55]):
+        rid = 0 if v["seqi"] == a["seqi"] else 1
+        rc = k % 2
+        rd = v["seqj"]
+        reads.append("".join(comp[c] for c in reversed(rd)) if rc else rd)
+        rids.append(rid); strands.append(rc); exp.append(v)
+    res, rec = E.align_batch(reads, [a["seqi"], b["seqi"]], [a["gap_incentive"], b["gap_incentive"]],
+                             [a["include"], b["include"]], mats["EDNAFULL"], -20, -2, ref_ids=rids, strands=strands)
+    for v, (s1, s2), r, rid, rc in zip(exp, res, rec, rids, strands):
+        assert r["status"] == 0 and r["ref_id"] == rid and r["strand"] == rc
+        assert [s1, s2] == v["out"][:2]
+        check_record(r, v["payload"], s1, s2)
+
+
+def test_emulated_kernel_all_refs_mode(mats):
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(5)
+    refs = ["".join(rng.choice(list("ACGT"), L)) for L in (40, 55, 47)]
+    gis = [np.zeros(len(r) + 1, dtype=np.int64) for r in refs]
+    for g in gis:
+        g[len(g) // 2] = 1
+    incs = [[len(r) // 2 - 1, len(r) // 2] for r in refs]
+    reads = [refs[k % 3][:20] + "ACG" + refs[k % 3][22:] for k in range(7)]
+    res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, all_refs=True)
+    assert len(res) == 21
+    for t, ((s1, s2), r) in enumerate(zip(res, rec)):
+        rd, rf = reads[t // 3], t % 3
+        exp = oracle.global_align_raw(rd, refs[rf], m, gis[rf], -20, -2)
+        assert (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:]
+        check_record(r, oracle.find_indels_substitutions(s1, s2, incs[rf]), s1, s2)
+
+
+def test_emulated_kernel_status_bits(mats):
+    m = mats["EDNAFULL"]
+    g = np.zeros(5, dtype=np.int64)
+    res, rec = E.align_batch(["ACGa", "ACGT", "AC-T"], ["ACGT"], [g], [[1, 2]], m, -20, -2, strands=[0, 0, 1])
+    assert rec["status"][0] & 2          # 'a' is outside the 90x90 EDNAFULL matrix
+    assert rec["status"][1] == 0
+    assert rec["status"][2] == 0         # '-' is legal input to reverse_complement
+    res, rec = E.align_batch(["ACRT"], ["ACGT"], [g], [[1, 2]], m, -20, -2, strands=[1])
+    assert rec["status"][0] & 16         # 'R' -> KeyError in CRISPRessoShared.reverse_complement
+    # a path that leaves the reference's defined domain: the oracle flags it, so must the kernel
+    st = oracle.global_align_raw("TT", "G", m, np.array([1, 0], dtype=np.int64), -1, -1)[0]
+    res, rec = E.align_batch(["TT"], ["G"], [np.array([1, 0], dtype=np.int64)], [[0]], m, -1, -1)
+    assert st != 0 and rec["status"][0] & (4 | 8)
+
+
+def test_emulated_classify_lists(mats):
+    from helpers import PAYLOAD_FIELDS
+    order = ["ref_positions", "all_insertion_positions", "all_insertion_left_positions", "insertion_positions",
+             "insertion_coordinates", "insertion_sizes", "all_deletion_positions", "all_deletion_coordinates",
+             "deletion_positions", "deletion_coordinates", "deletion_sizes", "all_substitution_positions",
+             "all_substitution_values", "substitution_positions", "substitution_values"]
+    vecs = load_golden("fuzz_classify.json") + [k for k in load_golden("ref_unit_kats.json") if k["fn"].startswith("find_indels")]
+    n_legacy = 0
+    for v in vecs:
+        legacy = v["fn"].endswith("legacy")
+        lists, counts = E.classify_lists(v["read_al"], v["ref_al"], v["include"], legacy=legacy)
+        got = dict(zip(order, lists))
+        for f in ("insertion_coordinates", "all_deletion_coordinates", "deletion_coordinates"):
+            got[f] = [[got[f][k], got[f][k + 1]] for k in range(0, len(got[f]), 2)]
+        for f in ("all_substitution_values", "substitution_values"):
+            got[f] = [chr(c) for c in got[f]]
+        got["insertion_n"], got["deletion_n"], got["substitution_n"] = counts
+        for f in PAYLOAD_FIELDS:
+            assert got[f] == v["out"][f], (f, v)
+        n_legacy += legacy
+    assert n_legacy >= 100
