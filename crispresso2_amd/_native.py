@@ -20,7 +20,7 @@ SYMBOLS = [
     "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
-    "c2_count_vectors_device", "c2_selftest",
+    "c2_selftest",
 ]
 
 REC_DTYPE = np.dtype([
@@ -41,7 +41,7 @@ class Batch(ctypes.Structure):
     _fields_ = [
         ("n_reads", ctypes.c_uint64),
         ("reads", ctypes.c_void_p), ("offsets", ctypes.c_void_p), ("ref_ids", ctypes.c_void_p), ("strands", ctypes.c_void_p),
-        ("all_refs", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("all_refs", ctypes.c_int32), ("max_read_len", ctypes.c_int32),
         ("aln_read", ctypes.c_void_p), ("aln_ref", ctypes.c_void_p),
         ("aln_stride", ctypes.c_uint32), ("reserved2", ctypes.c_uint32),
         ("records", ctypes.c_void_p),

@@ -1,0 +1,493 @@
+// c2_api.hip -- host side of the C ABI declared in include/crispresso2_amd.h.
+//
+// Marshals the reference's Python-level inputs into the kernel's tables, owns the device
+// buffers of a context, picks the launch geometry (rows per lane, passes, LDS plan, persistent
+// grid) and launches the kernels of c2_kernels.hip.  Nothing here computes an alignment or a
+// classification on the CPU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "crispresso2_amd.h"
+#include "c2_device.h"
+#include "c2_host_prep.h"
+#include "c2_kernels.hip"
+
+namespace {
+
+std::string g_create_error;
+std::mutex g_mutex;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct TimedLaunch { hipEvent_t a, b; };
+
+}  // namespace
+
+struct c2_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string err;
+    // scoring
+    bool have_scoring = false;
+    c2_scoring_tables sc;
+    int gap_open = -1, gap_extend = -1;
+    DevBuf d_tbl, d_code;
+    std::vector<int64_t> matrix_copy;   // to skip re-upload when c2_global_align is called with the same matrix
+    // refs
+    int n_refs = 0;
+    int max_li = 0;
+    std::vector<int> ref_len;
+    DevBuf d_refblob, d_refdesc;
+    // staging for the host batch path and the per-call path
+    DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;
+    // timing
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    // LDS opt-in already requested for these kernels
+    bool lds_attr_set[5] = {false, false, false, false, false};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return C2_E_DEVICE;                                                             \
+        }                                                                                   \
+    } while (0)
+
+int ensure(c2_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = std::max<size_t>(bytes, 256);
+    want = (want + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return C2_E_NOMEM; }
+    b.cap = want;
+    return 0;
+}
+
+void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+struct Geometry {
+    int R, passes, max_lj, blocks_per_cu;
+    uint32_t lds;
+};
+
+int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
+    if (!ctx->have_scoring || ctx->n_refs <= 0) { ctx->err = "scoring and references must be set first"; return C2_E_STATE; }
+    g.R = c2_choose_rows_per_lane(ctx->max_li);
+    g.passes = (ctx->max_li + 64 * g.R - 1) / (64 * g.R);
+    g.max_lj = std::max(max_lj, 1);
+    const c2_lds_plan P = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes);
+    g.lds = P.total;
+    const size_t lds_cu = ctx->prop.maxSharedMemoryPerMultiProcessor ? ctx->prop.maxSharedMemoryPerMultiProcessor : 163840;
+    const size_t lds_wg = std::min<size_t>(lds_cu, 163840);
+    if (g.lds > lds_wg) {
+        ctx->err = "alignment of " + std::to_string(ctx->max_li) + " x " + std::to_string(g.max_lj) +
+                   " needs " + std::to_string(g.lds) + " bytes of LDS pointer plane; limit is " + std::to_string(lds_wg);
+        return C2_E_TOO_LARGE;
+    }
+    g.blocks_per_cu = (int)std::min<size_t>(32, lds_cu / g.lds);   // one wave per workgroup; 32 waves per CU at most
+    if (g.blocks_per_cu < 1) g.blocks_per_cu = 1;
+    return 0;
+}
+
+template <int R>
+int launch_align(c2_ctx* ctx, const c2_align_args& A, const Geometry& g, hipStream_t s) {
+    if (!ctx->lds_attr_set[R] || g.lds > 65536) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_classify_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        ctx->lds_attr_set[R] = true;
+    }
+    const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)g.blocks_per_cu;
+    const unsigned grid = (unsigned)std::min<uint64_t>(A.n_tasks, resident);
+    TimedLaunch tl{};
+    if (ctx->timing) {
+        HIPCHK(ctx, hipEventCreate(&tl.a)); HIPCHK(ctx, hipEventCreate(&tl.b));
+        HIPCHK(ctx, hipEventRecord(tl.a, s));
+    }
+    hipLaunchKernelGGL(c2_align_classify_kernel<R>, dim3(grid), dim3(64), g.lds, s, A);
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(tl.b, s)); ctx->timed.push_back(tl); }
+    return 0;
+}
+
+int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
+    Geometry g;
+    int rc = geometry(ctx, max_lj, g);
+    if (rc) return rc;
+    if (b->n_reads == 0) return 0;
+    const uint64_t n_tasks = b->n_reads * (uint64_t)(b->all_refs ? ctx->n_refs : 1);
+    if (b->aln_stride < (uint32_t)(ctx->max_li + g.max_lj)) { ctx->err = "aln_stride smaller than longest read + longest reference"; return C2_E_INVALID; }
+    c2_align_args A;
+    A.reads = b->reads; A.offsets = b->offsets; A.ref_ids = b->all_refs ? nullptr : b->ref_ids; A.strands = b->strands;
+    A.refs = (const c2_dev_ref*)ctx->d_refdesc.p;
+    A.score_tbl = (const int16_t*)ctx->d_tbl.p; A.code_of_char = (const uint8_t*)ctx->d_code.p;
+    A.aln_read = b->aln_read; A.aln_ref = b->aln_ref; A.records = b->records;
+    A.n_tasks = n_tasks; A.aln_stride = b->aln_stride; A.n_refs = ctx->n_refs; A.all_refs = b->all_refs ? 1 : 0;
+    A.n_codes = ctx->sc.n_codes; A.gap_open = ctx->gap_open; A.gap_extend = ctx->gap_extend;
+    A.max_lj = g.max_lj; A.max_passes = g.passes;
+    switch (g.R) {
+        case 1: return launch_align<1>(ctx, A, g, s);
+        case 2: return launch_align<2>(ctx, A, g, s);
+        case 3: return launch_align<3>(ctx, A, g, s);
+        default: return launch_align<4>(ctx, A, g, s);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int c2_abi_version(void) { return C2_ABI_VERSION; }
+
+int c2_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* c2_last_error(const c2_ctx* ctx) {
+    if (!ctx) return g_create_error.c_str();
+    return ctx->err.c_str();
+}
+
+int c2_create(int device, c2_ctx** out) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!out) { g_create_error = "out is NULL"; return C2_E_INVALID; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count 0"); return C2_E_DEVICE; }
+    if (device < 0 || device >= n) { g_create_error = "device index out of range"; return C2_E_INVALID; }
+    c2_ctx* ctx = new c2_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("device init: ") + hipGetErrorString(e);
+        delete ctx;
+        return C2_E_DEVICE;
+    }
+    *out = ctx;
+    return 0;
+}
+
+void c2_destroy(c2_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc};
+    for (DevBuf* b : all) release(*b);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int c2_set_scoring(c2_ctx* ctx, const int64_t* matrix, int32_t mat_dim, int32_t gap_open, int32_t gap_extend) {
+    if (!ctx) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nel = (size_t)mat_dim * (size_t)mat_dim;
+    const bool same = ctx->have_scoring && ctx->matrix_copy.size() == nel && matrix &&
+                      memcmp(ctx->matrix_copy.data(), matrix, nel * sizeof(int64_t)) == 0;
+    ctx->gap_open = gap_open; ctx->gap_extend = gap_extend;
+    if (same) return 0;
+    c2_scoring_tables sc;
+    if (!c2_build_scoring(matrix, mat_dim, sc, ctx->err)) return C2_E_INVALID;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_tbl, sc.tbl.size() * sizeof(int16_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_code, 256))) return rc;
+    // make sure no launch still reads the old tables
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(ctx->d_tbl.p, sc.tbl.data(), sc.tbl.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_code.p, sc.code_of_char, 256, hipMemcpyHostToDevice));
+    ctx->sc = sc;
+    ctx->matrix_copy.assign(matrix, matrix + nel);
+    ctx->have_scoring = true;
+    return 0;
+}
+
+int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int32_t* lens,
+                const int64_t* const* gap_incentives, const int32_t* const* include_idx, const int32_t* n_include) {
+    if (!ctx || n_refs <= 0 || n_refs > 65535 || !seqs || !lens || !gap_incentives) { if (ctx) ctx->err = "bad reference arguments"; return C2_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // one blob: per ref [seq | pad][gap_incentive int32 x (L+1)][inc_prefix uint16 x (L+2)]
+    std::vector<uint8_t> blob;
+    std::vector<size_t> off_seq(n_refs), off_g(n_refs), off_p(n_refs);
+    int max_li = 0;
+    for (int r = 0; r < n_refs; ++r) {
+        const int L = lens[r];
+        if (L < 0 || L > 60000) { ctx->err = "reference length out of range"; return C2_E_INVALID; }
+        max_li = std::max(max_li, L);
+        auto align = [&](size_t a) { blob.resize((blob.size() + a - 1) / a * a); };
+        align(16); off_seq[r] = blob.size(); blob.insert(blob.end(), (const uint8_t*)seqs[r], (const uint8_t*)seqs[r] + L);
+        align(16); off_g[r] = blob.size(); blob.resize(blob.size() + (size_t)(L + 1) * 4);
+        int32_t* g32 = (int32_t*)(blob.data() + off_g[r]);
+        for (int k = 0; k <= L; ++k) g32[k] = (int32_t)gap_incentives[r][k];   // the reference adds it into C ints
+        std::vector<uint16_t> ip;
+        c2_build_inc_prefix(include_idx ? include_idx[r] : nullptr, (include_idx && n_include) ? n_include[r] : 0, L, ip);
+        align(16); off_p[r] = blob.size();
+        blob.insert(blob.end(), (const uint8_t*)ip.data(), (const uint8_t*)(ip.data() + ip.size()));
+    }
+    int rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = ensure(ctx, ctx->d_refblob, blob.size()))) return rc;
+    if ((rc = ensure(ctx, ctx->d_refdesc, sizeof(c2_dev_ref) * (size_t)n_refs))) return rc;
+    std::vector<c2_dev_ref> desc(n_refs);
+    ctx->ref_len.resize(n_refs);
+    for (int r = 0; r < n_refs; ++r) {
+        uint8_t* base = (uint8_t*)ctx->d_refblob.p;
+        desc[r].seq = base + off_seq[r];
+        desc[r].gap_incentive = (const int32_t*)(base + off_g[r]);
+        desc[r].inc_prefix = (const uint16_t*)(base + off_p[r]);
+        desc[r].len = lens[r]; desc[r].reserved = 0;
+        ctx->ref_len[r] = lens[r];
+    }
+    HIPCHK(ctx, hipMemcpy(ctx->d_refblob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_refdesc.p, desc.data(), sizeof(c2_dev_ref) * (size_t)n_refs, hipMemcpyHostToDevice));
+    ctx->n_refs = n_refs;
+    ctx->max_li = std::max(max_li, 1);
+    return 0;
+}
+
+int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, int32_t* passes, int32_t* lds_bytes,
+                   int32_t* workgroups_per_cu, int32_t* compute_units) {
+    if (!ctx) return C2_E_INVALID;
+    Geometry g;
+    int rc = geometry(ctx, max_read_len, g);
+    if (rc) return rc;
+    if (rows_per_lane) *rows_per_lane = g.R;
+    if (passes) *passes = g.passes;
+    if (lds_bytes) *lds_bytes = (int32_t)g.lds;
+    if (workgroups_per_cu) *workgroups_per_cu = g.blocks_per_cu;
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    return 0;
+}
+
+int c2_timing_enable(c2_ctx* ctx, int on) { if (!ctx) return C2_E_INVALID; ctx->timing = on != 0; return 0; }
+
+int c2_timing_read(c2_ctx* ctx, double* total_ms, int64_t* launches, int reset) {
+    if (!ctx) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double tot = 0;
+    for (auto& t : ctx->timed) {
+        HIPCHK(ctx, hipEventSynchronize(t.b));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, t.a, t.b));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)ctx->timed.size();
+    if (reset) {
+        for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        ctx->timed.clear();
+    }
+    return 0;
+}
+
+int c2_synchronize(c2_ctx* ctx, void* hip_stream) {
+    if (!ctx) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : ctx->stream));
+    return 0;
+}
+
+int c2_align_classify_batch_device(c2_ctx* ctx, const c2_batch* b, void* hip_stream) {
+    if (!ctx || !b) return C2_E_INVALID;
+    if (b->n_reads && (!b->reads || !b->offsets || !b->aln_read || !b->aln_ref || !b->records)) { ctx->err = "NULL batch pointer"; return C2_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // device-resident offsets: the host cannot see the longest read, the caller states it (max_read_len);
+    // reads longer than that are reported per record as C2_STATUS_TOO_LONG, never overrun the LDS plan.
+    const int max_lj = b->max_read_len > 0 ? b->max_read_len : (int)b->aln_stride - ctx->max_li;
+    if (max_lj < 1) { ctx->err = "aln_stride must be at least longest reference + longest read"; return C2_E_INVALID; }
+    return run_align(ctx, b, max_lj, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+}
+
+int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
+    if (!ctx || !b) return C2_E_INVALID;
+    if (b->n_reads == 0) return 0;
+    if (!b->reads || !b->offsets || !b->aln_read || !b->aln_ref || !b->records) { ctx->err = "NULL batch pointer"; return C2_E_INVALID; }
+    if (!ctx->have_scoring || ctx->n_refs <= 0) { ctx->err = "scoring and references must be set first"; return C2_E_STATE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = b->n_reads;
+    const uint64_t n_tasks = n * (uint64_t)(b->all_refs ? ctx->n_refs : 1);
+    int max_lj = 1;
+    for (uint64_t k = 0; k < n; ++k) {
+        if (b->offsets[k + 1] < b->offsets[k]) { ctx->err = "offsets must be non-decreasing"; return C2_E_INVALID; }
+        max_lj = (int)std::max<uint64_t>(max_lj, b->offsets[k + 1] - b->offsets[k]);
+    }
+    if (!b->all_refs && b->ref_ids)
+        for (uint64_t k = 0; k < n; ++k) if (b->ref_ids[k] >= ctx->n_refs) { ctx->err = "ref_id out of range"; return C2_E_INVALID; }
+    const uint32_t need_stride = (uint32_t)(ctx->max_li + max_lj);
+    if (b->aln_stride < need_stride) { ctx->err = "aln_stride smaller than longest read + longest reference"; return C2_E_INVALID; }
+    const uint64_t nbytes = b->offsets[n] - b->offsets[0];
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_reads, nbytes + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->d_offsets, (n + 1) * 8))) return rc;
+    if (b->ref_ids && !b->all_refs) if ((rc = ensure(ctx, ctx->d_refids, n * 2))) return rc;
+    if (b->strands) if ((rc = ensure(ctx, ctx->d_strands, n_tasks))) return rc;
+    if ((rc = ensure(ctx, ctx->d_aln_read, n_tasks * (uint64_t)b->aln_stride))) return rc;
+    if ((rc = ensure(ctx, ctx->d_aln_ref, n_tasks * (uint64_t)b->aln_stride))) return rc;
+    if ((rc = ensure(ctx, ctx->d_records, n_tasks * sizeof(c2_aln_record)))) return rc;
+    hipStream_t s = ctx->stream;
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t k = 0; k <= n; ++k) rel[k] = b->offsets[k] - b->offsets[0];
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_reads.p, b->reads + b->offsets[0], nbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_offsets.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (b->ref_ids && !b->all_refs) HIPCHK(ctx, hipMemcpyAsync(ctx->d_refids.p, b->ref_ids, n * 2, hipMemcpyHostToDevice, s));
+    if (b->strands) HIPCHK(ctx, hipMemcpyAsync(ctx->d_strands.p, b->strands, n_tasks, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));      // `rel` is pageable host memory owned by this call
+    c2_batch d = *b;
+    d.reads = (const uint8_t*)ctx->d_reads.p; d.offsets = (const uint64_t*)ctx->d_offsets.p;
+    d.ref_ids = (b->ref_ids && !b->all_refs) ? (const uint16_t*)ctx->d_refids.p : nullptr;
+    d.strands = b->strands ? (const uint8_t*)ctx->d_strands.p : nullptr;
+    d.aln_read = (uint8_t*)ctx->d_aln_read.p; d.aln_ref = (uint8_t*)ctx->d_aln_ref.p; d.records = (c2_aln_record*)ctx->d_records.p;
+    if ((rc = run_align(ctx, &d, max_lj, s))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(b->aln_read, d.aln_read, n_tasks * (uint64_t)b->aln_stride, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(b->aln_ref, d.aln_ref, n_tasks * (uint64_t)b->aln_stride, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(b->records, d.records, n_tasks * sizeof(c2_aln_record), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return 0;
+}
+
+int c2_global_align(c2_ctx* ctx, const char* read, int32_t Lj, const char* ref, int32_t Li,
+                    const int64_t* matrix, int32_t mat_dim, const int64_t* gap_incentive, int32_t n_gap_incentive,
+                    int32_t gap_open, int32_t gap_extend, char* out_read_aln, char* out_ref_aln,
+                    int32_t* out_len, int32_t* out_matches, int32_t* out_status) {
+    if (!ctx || !read || !ref || !matrix || !gap_incentive || !out_read_aln || !out_ref_aln || !out_len || !out_matches || !out_status) {
+        if (ctx) ctx->err = "NULL argument";
+        return C2_E_INVALID;
+    }
+    *out_len = 0; *out_matches = 0; *out_status = 0;
+    if (n_gap_incentive != Li + 1) { *out_status = -1; return 0; }          // CRISPResso2Align.pyx:124-126
+    if (Li <= 0 || Lj <= 0) { *out_status = C2_STATUS_EMPTY; return 0; }      // undefined in the reference
+    int rc;
+    if ((rc = c2_set_scoring(ctx, matrix, mat_dim, gap_open, gap_extend))) return rc;
+    const char* seqs[1] = {ref};
+    const int32_t lens[1] = {Li};
+    const int64_t* gis[1] = {gap_incentive};
+    const int32_t* incs[1] = {nullptr};
+    const int32_t ninc[1] = {0};
+    if ((rc = c2_set_refs(ctx, 1, seqs, lens, gis, incs, ninc))) return rc;
+    const uint32_t stride = (uint32_t)((Li + Lj + 15) / 16 * 16);
+    std::vector<uint8_t> o1(stride), o2(stride);
+    c2_aln_record rec;
+    memset(&rec, 0, sizeof rec);
+    const uint64_t offs[2] = {0, (uint64_t)Lj};
+    c2_batch b;
+    memset(&b, 0, sizeof b);
+    b.n_reads = 1; b.reads = (const uint8_t*)read; b.offsets = offs;
+    b.aln_read = o1.data(); b.aln_ref = o2.data(); b.aln_stride = stride; b.records = &rec;
+    if ((rc = c2_align_classify_batch_host(ctx, &b))) return rc;
+    *out_status = rec.status;
+    if (rec.status == 0) {
+        memcpy(out_read_aln, o1.data(), rec.aln_len);
+        memcpy(out_ref_aln, o2.data(), rec.aln_len);
+        *out_len = rec.aln_len; *out_matches = rec.matches;
+    }
+    return 0;
+}
+
+int c2_find_indels_substitutions(c2_ctx* ctx, const char* read_aln, const char* ref_aln, int32_t n,
+                                 const int32_t* include_idx, int32_t n_include, int32_t legacy,
+                                 int32_t* out, int32_t out_cap, int32_t* out_index, int64_t* out_counts, int32_t* out_needed) {
+    if (!ctx || !read_aln || !ref_aln || n < 0 || !out || !out_index || !out_counts) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> inc(include_idx, include_idx + (n_include > 0 ? n_include : 0));
+    std::sort(inc.begin(), inc.end());
+    inc.erase(std::unique(inc.begin(), inc.end()), inc.end());
+    hipStream_t s = ctx->stream;
+    int cap = std::max(2 * n + 8, 64);
+    std::vector<int32_t> lens(C2_LIST_COUNT);
+    std::vector<int32_t> lists;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        // d_misc layout: [read n][ref n][pad][include][list_len 15][counts 3 x int64][lists 15 x cap]
+        size_t o_read = 0, o_ref = (size_t)n, o_inc = ((size_t)2 * n + 15) / 16 * 16;
+        size_t o_len = o_inc + ((inc.size() * 4 + 15) / 16 * 16);
+        size_t o_cnt = o_len + 64, o_lists = o_cnt + 32;
+        size_t total = o_lists + (size_t)C2_LIST_COUNT * cap * 4;
+        int rc;
+        if ((rc = ensure(ctx, ctx->d_misc, total))) return rc;
+        uint8_t* base = (uint8_t*)ctx->d_misc.p;
+        if (n) {
+            HIPCHK(ctx, hipMemcpyAsync(base + o_read, read_aln, n, hipMemcpyHostToDevice, s));
+            HIPCHK(ctx, hipMemcpyAsync(base + o_ref, ref_aln, n, hipMemcpyHostToDevice, s));
+        }
+        if (!inc.empty()) HIPCHK(ctx, hipMemcpyAsync(base + o_inc, inc.data(), inc.size() * 4, hipMemcpyHostToDevice, s));
+        c2_classify_args A;
+        A.read_al = base + o_read; A.ref_al = base + o_ref; A.include_sorted = (const int32_t*)(base + o_inc);
+        A.n = n; A.n_include = (int32_t)inc.size(); A.legacy = legacy ? 1 : 0; A.cap = cap;
+        A.lists = (int32_t*)(base + o_lists); A.list_len = (int32_t*)(base + o_len); A.counts = (int64_t*)(base + o_cnt);
+        hipLaunchKernelGGL(c2_classify_lists_kernel, dim3(1), dim3(64), 0, s, A);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(lens.data(), base + o_len, C2_LIST_COUNT * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(out_counts, base + o_cnt, 24, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        const int need = *std::max_element(lens.begin(), lens.end());
+        if (need <= cap) {
+            lists.resize((size_t)C2_LIST_COUNT * cap);
+            HIPCHK(ctx, hipMemcpy(lists.data(), base + o_lists, lists.size() * 4, hipMemcpyDeviceToHost));
+            break;
+        }
+        cap = need + 8;   // only the negative-coordinate quirk of the reference can get here
+        if (attempt == 2) { ctx->err = "classification lists did not converge"; return C2_E_DEVICE; }
+    }
+    int64_t total = 0;
+    for (int k = 0; k < C2_LIST_COUNT; ++k) total += lens[k];
+    if (out_needed) *out_needed = (int32_t)total;
+    if (total > out_cap) { ctx->err = "output buffer too small"; return C2_E_OVERFLOW; }
+    int32_t pos = 0;
+    for (int k = 0; k < C2_LIST_COUNT; ++k) {
+        out_index[2 * k] = pos; out_index[2 * k + 1] = lens[k];
+        if (lens[k]) memcpy(out + pos, lists.data() + (size_t)k * cap, (size_t)lens[k] * 4);
+        pos += lens[k];
+    }
+    return 0;
+}
+
+int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out) {
+    if (!ctx || !a || !b || !out || n < 0) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_misc, (size_t)2 * n + 64))) return rc;
+    uint8_t* base = (uint8_t*)ctx->d_misc.p;
+    const size_t o_out = ((size_t)2 * n + 15) / 16 * 16;
+    if ((rc = ensure(ctx, ctx->d_misc, o_out + 16))) return rc;
+    base = (uint8_t*)ctx->d_misc.p;
+    hipStream_t s = ctx->stream;
+    if (n) {
+        HIPCHK(ctx, hipMemcpyAsync(base, a, n, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + n, b, n, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(c2_homology_kernel, dim3(1), dim3(64), 0, s, base, base + n, n, (float*)(base + o_out));
+    HIPCHK(ctx, hipGetLastError());
+    float f = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&f, base + o_out, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    *out = (double)f;
+    return 0;
+}
+
+int c2_selftest(c2_ctx* ctx, int32_t* out192) {
+    if (!ctx || !out192) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_misc, 192 * 4))) return rc;
+    hipLaunchKernelGGL(c2_selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)ctx->d_misc.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out192, ctx->d_misc.p, 192 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""Deterministic synthetic amplicon-sequencing reads for the BASELINE.json configs.
+
+Amplicon: numpy.random.default_rng(20240601 [+ amplicon id]).choice("ACGT", L); cut site c = L//2, so the reference's
+setup would put gap_incentive[c+1] = 1 and include_idxs = [c, c+1] (defaults -w 1 -wc -3).
+Reads are generated in independent blocks of BLOCK reads (seed sequence [20240602, amplicon id, block index]), so any prefix
+of a data set is reproducible without generating the rest.  Per read, starting from the amplicon:
+  * substitutions at rate 0.005 per base,
+  * with p = 0.30 one deletion of min(60, Geometric(0.12)) bases placed so that it overlaps the cut site,
+  * with p = 0.10 one insertion of U[1,15] random bases at the cut site,
+  * with p = 0.01 three random positions become 'N',
+  * random "downstream" bases are appended and the read is truncated, so EVERY read has exactly L bases
+    (the DP is always L x L), forward strand.
+"""
+import numpy as np
+
+BLOCK = 1 << 16
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _bases(x):
+    """uint8 codes 0..3 -> ASCII 'A','C','G','T' (arithmetic: numpy's take() on uint8 indices is slow)."""
+    o = (x << 1) + np.uint8(65)
+    o += (x == 2).view(np.uint8) << 1
+    o += (x == 3).view(np.uint8) * np.uint8(13)
+    return o
+
+
+def make_amplicon(L, amplicon_id=0):
+    seed = 20240601 if amplicon_id == 0 else [20240601, int(amplicon_id)]
+    return _bases(np.random.default_rng(seed).integers(0, 4, L, dtype=np.uint8)).tobytes().decode()
+
+
+def amplicon_setup(L, amplicon_id=0):
+    """-> (sequence, gap_incentive int64[L+1], include_idxs list) as CRISPRessoCORE.py:3205-3207 would build them."""
+    seq = make_amplicon(L, amplicon_id)
+    cut = L // 2
+    g = np.zeros(L + 1, dtype=np.int64)
+    g[cut + 1] = 1
+    return seq, g, [cut, cut + 1]
+
+
+def _block(amplicon_u8, n, block_index, amplicon_id):
+    L = amplicon_u8.shape[0]
+    cut = L // 2
+    rng = np.random.default_rng([20240602, int(amplicon_id), int(block_index)])
+    # the substituted template of every read (sparse substitutions)
+    n_sub = int(rng.binomial(n * L, 0.005))
+    sub_pos = rng.integers(0, n * L, n_sub)
+    sub_base = _bases(rng.integers(0, 4, n_sub, dtype=np.uint8))
+    has_del = rng.random(n) < 0.30
+    del_len = np.minimum(60, rng.geometric(0.12, n)).astype(np.int16)
+    del_len[~has_del] = 0
+    del_start = np.maximum(0, cut - (rng.random(n) * (del_len + 1)).astype(np.int16)).astype(np.int16)
+    has_ins = rng.random(n) < 0.10
+    ins_len = rng.integers(1, 16, n).astype(np.int16)
+    ins_len[~has_ins] = 0
+    filler = _bases(rng.integers(0, 4, (n, L), dtype=np.uint8))   # inserted bases and downstream bases come from here
+    p = np.arange(L, dtype=np.int16)[None, :]
+    # undo the insertion: position in the post-deletion sequence (or -1 inside the inserted run)
+    q = np.where(p < cut, p, np.where(p < cut + ins_len[:, None], np.int16(-1), p - ins_len[:, None]))
+    # undo the deletion: position in the amplicon
+    src = np.where(q < del_start[:, None], q, q + del_len[:, None])
+    src = np.where(q < 0, np.int16(-1), src)
+    tmpl = np.broadcast_to(amplicon_u8, (n, L)).copy().reshape(-1)
+    tmpl[sub_pos] = sub_base
+    tmpl = tmpl.reshape(n, L)
+    inside = (src >= 0) & (src < L)
+    reads = np.where(inside, np.take_along_axis(tmpl, np.clip(src, 0, L - 1), axis=1), filler)
+    has_n = np.nonzero(rng.random(n) < 0.01)[0]
+    if has_n.size:
+        npos = rng.integers(0, L, (has_n.size, 3))
+        reads[has_n[:, None], npos] = ord('N')
+    return np.ascontiguousarray(reads, dtype=np.uint8)
+
+
+def _block_job(job):
+    amp_bytes, b, amplicon_id = job
+    return _block(np.frombuffer(amp_bytes, dtype=np.uint8), BLOCK, b, amplicon_id)
+
+
+def make_reads(L, n, amplicon_id=0, amplicon=None, first_block=0, workers=1):
+    """-> uint8 [n, L] reads (row k is read k of the data set starting at block `first_block`).
+    workers > 1 generates blocks in a fork()ed process pool: call it before the process touches HIP."""
+    amp_s = amplicon or make_amplicon(L, amplicon_id)
+    amp = np.frombuffer(amp_s.encode(), dtype=np.uint8)
+    out = np.empty((n, L), dtype=np.uint8)
+    nblocks = (n + BLOCK - 1) // BLOCK
+    if workers > 1 and nblocks > 1:
+        import multiprocessing as mp
+        jobs = [(amp_s.encode(), first_block + b, amplicon_id) for b in range(nblocks)]
+        with mp.get_context("fork").Pool(min(workers, nblocks)) as pool:
+            for b, blk in enumerate(pool.imap(_block_job, jobs)):
+                start = b * BLOCK
+                m = min(BLOCK, n - start)
+                out[start:start + m] = blk[:m]
+        return out
+    for b, start in enumerate(range(0, n, BLOCK)):
+        m = min(BLOCK, n - start)
+        out[start:start + m] = _block(amp, BLOCK, first_block + b, amplicon_id)[:m]
+    return out
+
+
+def make_variant(amplicon, kind):
+    """Candidate references of config 4: 'hdr' = 6 substitutions + a 3-bp insertion near the cut; 'pe' = a 12-bp replacement."""
+    L = len(amplicon)
+    cut = L // 2
+    s = list(amplicon)
+    comp = {'A': 'C', 'C': 'G', 'G': 'T', 'T': 'A'}
+    if kind == 'hdr':
+        for d in (-9, -6, -3, 2, 5, 8):
+            s[cut + d] = comp[s[cut + d]]
+        s[cut:cut] = list('GAT')
+    elif kind == 'pe':
+        s[cut - 6:cut + 6] = [comp[c] for c in s[cut - 6:cut + 6]]
+    else:
+        raise ValueError(kind)
+    return ''.join(s)

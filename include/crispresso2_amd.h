@@ -105,7 +105,8 @@ typedef struct c2_batch {
     const uint8_t*  strands;   /* per task: 1 = align reverse_complement(read) (CRISPRessoCORE.py:672), or NULL */
     int32_t all_refs;          /* 1: align every read to every reference (CRISPRessoCORE.py:653);
                                   task t = read t / n_refs against reference t % n_refs; ref_ids ignored */
-    int32_t reserved;
+    int32_t max_read_len;      /* longest read of the batch; sizes the LDS plan.  Device path: required
+                                  (0 = derive the bound aln_stride - longest reference); host path: ignored */
     /* outputs, n_tasks = n_reads * (all_refs ? n_refs : 1) entries each */
     uint8_t* aln_read;         /* n_tasks x aln_stride: aligned read  (global_align()[0]) */
     uint8_t* aln_ref;          /* n_tasks x aln_stride: aligned reference (global_align()[1]) */
@@ -179,6 +180,10 @@ int c2_find_indels_substitutions(c2_ctx* ctx, const char* read_aln, const char* 
 
 /* calculate_homology(a, b), COREResources.pyx:318-327: matches over strlen(a), float32 accumulator. */
 int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out);
+
+/* Hardware self-test of the cross-lane primitives (DPP wave_shr:1, readlane, ballot) the DP depends on;
+ * writes 192 int32 (see c2_selftest_kernel).  Used by the GPU test-suite. */
+int c2_selftest(c2_ctx* ctx, int32_t* out192);
 
 #ifdef __cplusplus
 }
