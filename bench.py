@@ -34,7 +34,8 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--len", type=int, default=250, dest="L", help="read and amplicon length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--workers", type=int, default=0, help="processes generating the synthetic reads (0 = auto; 1 = no fork, for profiler runs)")
     ap.add_argument("--check", type=int, default=300, help="reads compared with the oracle after the timed region")
     args = ap.parse_args()
 
@@ -52,7 +53,7 @@ def main():
 
     # ---------- everything that fork()s happens before this process touches HIP ----------
     ncpu = os.cpu_count() or 1
-    workers = max(1, min(32, ncpu // max(world, 1)))
+    workers = args.workers if args.workers > 0 else max(1, min(32, ncpu // max(world, 1)))
     blocks_per_rank = (n + synth.BLOCK - 1) // synth.BLOCK
     t0 = time.perf_counter()
     reads = synth.make_reads(L, n, first_block=rank * blocks_per_rank, workers=workers)

@@ -40,7 +40,7 @@ struct c2_ctx {
     bool have_scoring = false;
     c2_scoring_tables sc;
     int gap_open = -1, gap_extend = -1;
-    DevBuf d_tbl, d_code;
+    DevBuf d_tbl, d_code, d_pk;
     std::vector<int64_t> matrix_copy;   // to skip re-upload when c2_global_align is called with the same matrix
     // refs
     int n_refs = 0;
@@ -134,6 +134,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.reads = b->reads; A.offsets = b->offsets; A.ref_ids = b->all_refs ? nullptr : b->ref_ids; A.strands = b->strands;
     A.refs = (const c2_dev_ref*)ctx->d_refdesc.p;
     A.score_tbl = (const int16_t*)ctx->d_tbl.p; A.code_of_char = (const uint8_t*)ctx->d_code.p;
+    A.score_pk = ctx->sc.pk.empty() ? nullptr : (const uint32_t*)ctx->d_pk.p;
     A.aln_read = b->aln_read; A.aln_ref = b->aln_ref; A.records = b->records;
     A.n_tasks = n_tasks; A.aln_stride = b->aln_stride; A.n_refs = ctx->n_refs; A.all_refs = b->all_refs ? 1 : 0;
     A.n_codes = ctx->sc.n_codes; A.gap_open = ctx->gap_open; A.gap_extend = ctx->gap_extend;
@@ -187,7 +188,7 @@ void c2_destroy(c2_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
+    DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
                      &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc};
     for (DevBuf* b : all) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -207,10 +208,12 @@ int c2_set_scoring(c2_ctx* ctx, const int64_t* matrix, int32_t mat_dim, int32_t 
     int rc;
     if ((rc = ensure(ctx, ctx->d_tbl, sc.tbl.size() * sizeof(int16_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_code, 256))) return rc;
+    if ((rc = ensure(ctx, ctx->d_pk, C2_MAX_CODES * sizeof(uint32_t)))) return rc;
     // make sure no launch still reads the old tables
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(ctx->d_tbl.p, sc.tbl.data(), sc.tbl.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_code.p, sc.code_of_char, 256, hipMemcpyHostToDevice));
+    if (!sc.pk.empty()) HIPCHK(ctx, hipMemcpy(ctx->d_pk.p, sc.pk.data(), sc.pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     ctx->sc = sc;
     ctx->matrix_copy.assign(matrix, matrix + nel);
     ctx->have_scoring = true;

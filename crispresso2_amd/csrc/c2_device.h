@@ -30,6 +30,7 @@ typedef struct c2_align_args {
     const uint8_t* strands;       // per task: 1 => align the reverse complement, or NULL
     const c2_dev_ref* refs;
     const int16_t* score_tbl;     // n_codes x n_codes, [ref code][read code]
+    const uint32_t* score_pk;     // n_codes words: signed 4-bit scores of read codes 0..7 for each ref code, or NULL
     const uint8_t* code_of_char;  // 256 entries -> code, C2_INVALID_CODE if ord >= matrix dim
     uint8_t* aln_read;            // n_tasks x aln_stride
     uint8_t* aln_ref;             // n_tasks x aln_stride

@@ -11,6 +11,7 @@
 struct c2_scoring_tables {
     uint8_t code_of_char[256];
     std::vector<int16_t> tbl;     // n_codes x n_codes, [ref code][read code]
+    std::vector<uint32_t> pk;     // per ref code: signed 4-bit scores against read codes 0..7 (empty if some score is outside [-8,7])
     int n_codes = 0;
 };
 
@@ -23,11 +24,15 @@ inline bool c2_build_scoring(const int64_t* matrix, int dim, c2_scoring_tables& 
     const int lim = dim < 128 ? dim : 128;
     std::vector<int> syms;
     bool any_zero = false;
+    std::vector<uint8_t> scoring(lim, 0);
     for (int c = 0; c < lim; ++c) {
         bool nz = false;
         for (int k = 0; k < dim && !nz; ++k) nz = matrix[(size_t)c * dim + k] != 0 || matrix[(size_t)k * dim + c] != 0;
-        if (nz) syms.push_back(c); else any_zero = true;
+        scoring[c] = nz; if (!nz) any_zero = true;
     }
+    // the bases that make up real reads get the lowest codes, so that the packed 8-symbol score rows cover them
+    for (const char* q = "ACGTN"; *q; ++q) if (*q < lim && scoring[(int)*q]) { syms.push_back(*q); scoring[(int)*q] = 0; }
+    for (int c = 0; c < lim; ++c) if (scoring[c]) syms.push_back(c);
     const int n = (int)syms.size() + (any_zero ? 1 : 0);
     if (n > C2_MAX_CODES) { err = "score matrix has more than " + std::to_string(C2_MAX_CODES - 1) + " scoring symbols"; return false; }
     out.n_codes = n;
@@ -40,6 +45,14 @@ inline bool c2_build_scoring(const int64_t* matrix, int dim, c2_scoring_tables& 
             if (v < -32768 || v > 32767) { err = "score matrix entry outside int16"; return false; }
             out.tbl[a * n + b] = (int16_t)v;
         }
+    bool nib = true;
+    for (int16_t v : out.tbl) if (v < -8 || v > 7) nib = false;
+    out.pk.clear();
+    if (nib) {
+        out.pk.assign(n, 0);
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < 8 && b < n; ++b) out.pk[a] |= ((uint32_t)out.tbl[(size_t)a * n + b] & 0xFu) << (4 * b);
+    }
     return true;
 }
 

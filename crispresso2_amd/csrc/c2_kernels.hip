@@ -35,6 +35,9 @@ __device__ __forceinline__ int c2_shr1(int old, int src) {
 
 __device__ __forceinline__ int c2_imax(int a, int b) { return a > b ? a : b; }
 
+// sign-extended 4-bit field of x starting at bit `off`
+__device__ __forceinline__ int c2_sbfe4(int x, int off) { return __builtin_amdgcn_sbfe(x, off, 4); }
+
 struct c2_lds_plan {
     // byte offsets into dynamic LDS (all multiples of 16)
     uint32_t ptr, bnd, tbl, read, code, ref, incp, tmp_read, tmp_ref, total;
@@ -72,6 +75,133 @@ __device__ __forceinline__ int c2_boundary_hstate(int i, int j, int min_score, i
     return (ge * i + g0 <= min_score) ? C2_ST_I : C2_ST_J;              // M=I=min_score, J=ge*i+g0
 }
 
+// Per-lane DP state of one systolic pass: R consecutive reference rows.
+template <int R>
+struct c2_strip {
+    int a[R], b[R], c[R], delta[R];   // gap constants of the rows (see c2_dp_pass)
+    int sel[R];                       // PACKED: 8 signed score nibbles of the row's base; else: LDS row offset into the score table
+    int Ml[R], Il[R], Hl[R];          // M, I, H=max(M,I,J) of the rows at the column computed last
+    int Mb, Jb, Hb;                   // bottom row at that column: what the lane below receives
+    int dgsave;                       // H(row above the strip, previous column)
+    int cj;                           // read symbol of the current column (PACKED: 4*code, else code)
+    unsigned bits;                    // pointer nibbles, newest in the low bits
+};
+
+// One column of the strip (the lane is active: 1 <= j <= Lj).  TAIL: the lane may be on the last column, where
+// gap_open is replaced by gap_extend (pyx:234-273) -- delta[] carries ge-go for every row but the last one.
+template <int R, bool PACKED, bool TAIL>
+__device__ __forceinline__ void c2_dp_column(c2_strip<R>& S, const int upM0, const int upJ0, const int ge,
+                                             const bool lastcol, const int16_t* sTbl)
+{
+    int upM = upM0, upJ = upJ0, dg = S.dgsave;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int s;
+        if (PACKED) s = c2_sbfe4(S.sel[r], S.cj);                             // signed nibble number cj/4: one v_bfe_i32
+        else        s = (int)sTbl[S.sel[r] + S.cj];
+        int iFromM = S.Ml[r] + S.a[r];
+        int jFromM = upM + S.c[r];
+        if (TAIL) { const int corr = lastcol ? S.delta[r] : 0; iFromM += corr; jFromM += corr; }
+        const int iExt = S.Il[r] + S.b[r];
+        const bool ib = iFromM > iExt;                    // pyx:191-196: tie -> extend
+        const int In = ib ? iFromM : iExt;
+        const int jExt = upJ + ge;
+        const bool jb = jFromM > jExt;                    // pyx:199-211: tie -> extend
+        const int Jn = jb ? jFromM : jExt;
+        const int Mn = dg + s;                            // H(i-1,j-1) + matrix[ci,cj], pyx:213-228
+        const int t2 = c2_imax(Mn, Jn);
+        const bool hI = In >= t2;                         // I wins all ties
+        const bool hJ = Jn >= Mn;                         // J beats M on a tie
+        const int Hn = c2_imax(t2, In);
+        S.bits = (S.bits << 4) | ((unsigned)ib << 3) | ((unsigned)jb << 2) | ((unsigned)hI << 1) | (unsigned)hJ;
+        dg = S.Hl[r];
+        S.Ml[r] = Mn; S.Il[r] = In; S.Hl[r] = Hn;
+        upM = Mn; upJ = Jn;
+    }
+    S.Mb = upM; S.Jb = upJ; S.Hb = S.Hl[R - 1];
+}
+
+// One step of the systolic sweep: hand-off from the lane above (DPP, full EXEC), then this lane's column j = t - lane.
+template <int R, bool PACKED, bool TAIL>
+__device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const int lane, const int Lj, const int ge, const int g0,
+                                           const int min_score, const bool first, const bool feeds_next,
+                                           int& nC, int& nM, int& nJ, int& nH,
+                                           const unsigned char* sCode, const int16_t* sTbl, int* sBnd,
+                                           uint16_t* myPtr, const int colStride)
+{
+    int bM = min_score, bJ = min_score, bH;
+    if (first) bH = c2_imax(min_score, ge * t + g0);           // H(0,t) = iScore[0,t], pyx:161-162
+    else { bM = nM; bJ = nJ; bH = nH; }
+    const int bC = PACKED ? (nC << 2) : nC;
+    const int tn = (t + 1 <= Lj) ? t + 1 : Lj;
+    nC = sCode[tn - 1];
+    if (!first) { nM = sBnd[3 * tn]; nJ = sBnd[3 * tn + 1]; nH = sBnd[3 * tn + 2]; }
+    const int upM0 = c2_shr1(bM, S.Mb);
+    const int upJ0 = c2_shr1(bJ, S.Jb);
+    const int upH = c2_shr1(bH, S.Hb);
+    S.cj = c2_shr1(bC, S.cj);
+    const int j = t - lane;
+    const bool active = TAIL ? (j >= 1 && j <= Lj) : (j >= 1);
+    if (active) {
+        c2_dp_column<R, PACKED, TAIL>(S, upM0, upJ0, ge, TAIL && (j == Lj), sTbl);
+        myPtr[(j - 1) * colStride] = (uint16_t)S.bits;
+        if (feeds_next && lane == 63) { sBnd[3 * j] = S.Mb; sBnd[3 * j + 1] = S.Jb; sBnd[3 * j + 2] = S.Hb; }
+    }
+    S.dgsave = upH;
+}
+
+// One systolic pass over reference rows p*64R+1 .. p*64R+64R.  SINGLE: the reference fits one pass, so the row above
+// lane 0 is the closed-form row 0 and nothing is handed to a next pass.
+template <int R, bool PACKED, bool SINGLE>
+__device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_ref& rf, const unsigned char* sRef,
+                                           const unsigned char* sCode, const int16_t* sTbl, int* sBnd, uint16_t* myPtr,
+                                           const int colStride, const int lane, const int p, const int passes,
+                                           const int Li, const int Lj, const int g0, const int min_score)
+{
+    const int ROWS_PER_PASS = 64 * R;
+    const int ge = A.gap_extend, go = A.gap_open;
+    const int row0 = p * ROWS_PER_PASS + lane * R;      // 0-based row above this lane's strip
+    c2_strip<R> S;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = row0 + r + 1;                      // 1-based reference row
+        const int ic = i <= Li ? i : Li;                 // padding rows below Li compute garbage nobody reads
+        const int gi = rf.gap_incentive[ic], gim1 = rf.gap_incentive[ic - 1];
+        const bool last_row = (i == Li);
+        // last row: gap_open is replaced by gap_extend (pyx:277-317)
+        S.a[r] = (last_row ? ge : go) + gi;              // I opened from M
+        S.b[r] = ge + gi;                                // I extended (incentive on every extension, pyx:197)
+        S.c[r] = (last_row ? ge : go) + gim1;            // J opened from M (incentive only on open, pyx:205-207)
+        S.delta[r] = last_row ? 0 : (ge - go);
+        const int rcode = (int)A.code_of_char[sRef[ic - 1]];
+        S.sel[r] = PACKED ? (int)A.score_pk[rcode] : rcode * A.n_codes;
+        const int J0 = ge * i + g0;                      // jScore[i,0], pyx:170-171
+        S.Ml[r] = min_score; S.Il[r] = min_score;        // mScore[i,0], iScore[i,0]
+        S.Hl[r] = c2_imax(min_score, J0);
+    }
+    S.Mb = min_score; S.Jb = ge * (row0 + R) + g0; S.Hb = S.Hl[R - 1];
+    // diagonal input of the strip's first row at its first column: H(row0, 0)
+    S.dgsave = (row0 == 0) ? 0 : c2_imax(min_score, ge * row0 + g0);
+    S.cj = 0;
+    S.bits = 0;
+    const int nrows = (Li - p * ROWS_PER_PASS) < ROWS_PER_PASS ? (Li - p * ROWS_PER_PASS) : ROWS_PER_PASS;
+    const int nl = (nrows + R - 1) / R;
+    const int steps = Lj + nl - 1;
+    const bool first = SINGLE || (p == 0);
+    const bool feeds_next = !SINGLE && (p + 1 < passes);
+
+    // values entering lane 0 at step t (column t of the row above the pass), fetched one step ahead
+    int nC = sCode[0];
+    int nM = min_score, nJ = min_score, nH = 0;
+    if (!first) { nM = sBnd[3]; nJ = sBnd[4]; nH = sBnd[5]; }
+    // steps 1 .. Lj-1: no lane can be on the last column or beyond it; steps Lj .. : the general column
+    const int t_split = Lj < steps + 1 ? Lj : steps + 1;
+    for (int t = 1; t < t_split; ++t)
+        c2_dp_step<R, PACKED, false>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, nC, nM, nJ, nH, sCode, sTbl, sBnd, myPtr, colStride);
+    for (int t = t_split; t <= steps; ++t)
+        c2_dp_step<R, PACKED, true>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, nC, nM, nJ, nH, sCode, sTbl, sBnd, myPtr, colStride);
+}
+
 template <int R>
 __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
 {
@@ -105,6 +235,7 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
         const uint64_t off = A.offsets[read_id];
         const int Lj = (int)(A.offsets[read_id + 1] - off);
         int status = 0;
+        int read_code_max = 0;
         const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
 
         __syncthreads();   // previous task's LDS readers are done
@@ -136,6 +267,7 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
             if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
             sRead[k] = ch;
             sCode[k] = code;
+            read_code_max = read_code_max > (int)code ? read_code_max : (int)code;
         }
         {
             int bad = 0;
@@ -163,79 +295,18 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
             const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
 
             // =========================== DP: systolic sweep, pass by pass ===========================
+            // packed = every read symbol has a code < 8 and every score fits a signed nibble: the score row of a
+            // reference base is then one register and a lookup is one v_bfe_i32 (no LDS in the inner loop).
+            const bool packed = (A.score_pk != nullptr) && (__ballot(read_code_max >= 8) == 0ull);
             for (int p = 0; p < passes; ++p) {
-                const int row0 = p * ROWS_PER_PASS + lane * R;      // 0-based row above this lane's strip
-                int a[R], b[R], c[R], delta[R], rowoff[R];
-                int Ml[R], Il[R], Hl[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int i = row0 + r + 1;                      // 1-based reference row
-                    const int ic = i <= Li ? i : Li;                 // padding rows below Li compute garbage nobody reads
-                    const int gi = rf.gap_incentive[ic], gim1 = rf.gap_incentive[ic - 1];
-                    const bool last_row = (i == Li);
-                    // last row: gap_open is replaced by gap_extend (pyx:277-317); last column: same (pyx:234-273), via delta
-                    a[r] = (last_row ? ge : go) + gi;                // I opened from M
-                    b[r] = ge + gi;                                  // I extended (incentive on every extension, pyx:197)
-                    c[r] = (last_row ? ge : go) + gim1;              // J opened from M (incentive only on open, pyx:205-207)
-                    delta[r] = last_row ? 0 : (ge - go);
-                    rowoff[r] = (int)A.code_of_char[sRef[ic - 1]] * A.n_codes;
-                    const int J0 = ge * i + g0;                      // jScore[i,0], pyx:170-171
-                    Ml[r] = min_score; Il[r] = min_score;            // mScore[i,0], iScore[i,0]
-                    Hl[r] = c2_imax(min_score, J0);
-                }
-                int Mb = min_score, Jb = ge * (row0 + R) + g0, Hb = Hl[R - 1];
-                // diagonal input of the strip's first row at its first column: H(row0, 0)
-                int dgsave = (row0 == 0) ? 0 : c2_imax(min_score, ge * row0 + g0);
-                int cj = 0;
-                unsigned bits = 0;
-                const int nrows = (Li - p * ROWS_PER_PASS) < ROWS_PER_PASS ? (Li - p * ROWS_PER_PASS) : ROWS_PER_PASS;
-                const int nl = (nrows + R - 1) / R;
-                const int steps = Lj + nl - 1;
-                const bool feeds_next = (p + 1 < passes);
+                const bool single = (passes == 1);
                 uint16_t* myPtr = sPtr + (size_t)p * (size_t)A.max_lj * colStride + lane;
-
-                for (int t = 1; t <= steps; ++t) {
-                    // boundary row above lane 0 at column t
-                    int bM, bJ, bH, bC;
-                    if (p == 0) { bM = min_score; bJ = min_score; bH = c2_imax(min_score, ge * t + g0); }
-                    else { const int tt = t <= Lj ? t : Lj; bM = sBnd[3 * tt]; bJ = sBnd[3 * tt + 1]; bH = sBnd[3 * tt + 2]; }
-                    bC = sCode[(t <= Lj ? t : Lj) - 1];
-                    // hand-off from the lane above (all lanes, full EXEC)
-                    const int upM0 = c2_shr1(bM, Mb);
-                    const int upJ0 = c2_shr1(bJ, Jb);
-                    const int upH = c2_shr1(bH, Hb);
-                    cj = c2_shr1(bC, cj);
-                    const int j = t - lane;
-                    if (j >= 1 && j <= Lj) {
-                        const bool lastcol = (j == Lj);
-                        int upM = upM0, upJ = upJ0, dg = dgsave;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const int corr = lastcol ? delta[r] : 0;
-                            const int s = (int)sTbl[rowoff[r] + cj];
-                            const int iFromM = Ml[r] + a[r] + corr;
-                            const int iExt = Il[r] + b[r];
-                            const bool ib = iFromM > iExt;                    // pyx:191-196: tie -> extend
-                            const int In = ib ? iFromM : iExt;
-                            const int jFromM = upM + c[r] + corr;
-                            const int jExt = upJ + ge;
-                            const bool jb = jFromM > jExt;                    // pyx:199-211: tie -> extend
-                            const int Jn = jb ? jFromM : jExt;
-                            const int Mn = dg + s;                            // H(i-1,j-1) + matrix[ci,cj], pyx:213-228
-                            const int t2 = c2_imax(Mn, Jn);
-                            const bool hI = In >= t2;                         // I wins all ties
-                            const bool hJ = Jn >= Mn;                         // J beats M on a tie
-                            const int Hn = c2_imax(t2, In);
-                            bits = (bits << 4) | ((unsigned)ib << 3) | ((unsigned)jb << 2) | ((unsigned)hI << 1) | (unsigned)hJ;
-                            dg = Hl[r];
-                            Ml[r] = Mn; Il[r] = In; Hl[r] = Hn;
-                            upM = Mn; upJ = Jn;
-                        }
-                        Mb = upM; Jb = upJ; Hb = Hl[R - 1];
-                        myPtr[(j - 1) * colStride] = (uint16_t)bits;
-                        if (feeds_next && lane == 63) { sBnd[3 * j] = Mb; sBnd[3 * j + 1] = Jb; sBnd[3 * j + 2] = Hb; }
-                    }
-                    dgsave = upH;
+                if (packed) {
+                    if (single) c2_dp_pass<R, true, true>(A, rf, sRef, sCode, sTbl, sBnd, myPtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    else        c2_dp_pass<R, true, false>(A, rf, sRef, sCode, sTbl, sBnd, myPtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                } else {
+                    if (single) c2_dp_pass<R, false, true>(A, rf, sRef, sCode, sTbl, sBnd, myPtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    else        c2_dp_pass<R, false, false>(A, rf, sRef, sCode, sTbl, sBnd, myPtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
                 }
                 __syncthreads();
             }

@@ -18,7 +18,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
                     const int32_t* const* include_idx, const int32_t* n_include,
                     const int64_t* matrix, int dim, int go, int ge,
                     uint8_t* aln_read, uint8_t* aln_ref, uint32_t aln_stride, c2_aln_record* records,
-                    int force_R, unsigned grid)
+                    int force_R, unsigned grid, int no_packed)
 {
     c2_scoring_tables sc; std::string err;
     if (!c2_build_scoring(matrix, dim, sc, err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return -1; }
@@ -40,6 +40,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     c2_align_args A;
     A.reads = reads; A.offsets = offsets; A.ref_ids = ref_ids; A.strands = strands; A.refs = refs.data();
     A.score_tbl = sc.tbl.data(); A.code_of_char = sc.code_of_char;
+    A.score_pk = (sc.pk.empty() || no_packed) ? nullptr : sc.pk.data();
     A.aln_read = aln_read; A.aln_ref = aln_ref; A.records = records;
     A.n_tasks = n_reads * (uint64_t)(all_refs ? n_refs : 1); A.aln_stride = aln_stride; A.n_refs = n_refs; A.all_refs = all_refs;
     A.n_codes = sc.n_codes; A.gap_open = go; A.gap_extend = ge; A.max_lj = max_lj;

@@ -40,7 +40,7 @@ def lib():
 
 
 def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_extend,
-                ref_ids=None, strands=None, all_refs=False, force_R=0, grid=0):
+                ref_ids=None, strands=None, all_refs=False, force_R=0, grid=0, no_packed=False):
     """reads: list[str]; refs: list[str]; returns (list[(s1, s2)], records ndarray)"""
     n = len(reads)
     arena = "".join(reads).encode()
@@ -69,7 +69,7 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
         nrefs, seqs, lens.ctypes.data_as(ctypes.c_void_p), gp, ip, ninc.ctypes.data_as(ctypes.c_void_p),
         m.ctypes.data_as(ctypes.c_void_p), int(m.shape[0]), int(gap_open), int(gap_extend),
         o1.ctypes.data_as(ctypes.c_void_p), o2.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(stride),
-        rec.ctypes.data_as(ctypes.c_void_p), int(force_R), ctypes.c_uint(grid))
+        rec.ctypes.data_as(ctypes.c_void_p), int(force_R), ctypes.c_uint(grid), int(no_packed))
     assert rc == 0, rc
     out = []
     for k in range(ntasks):

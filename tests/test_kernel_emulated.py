@@ -34,7 +34,7 @@ def check_record(rec, payload, s1, s2):
     assert bool(rec["irregular_ends"]) == irregular
 
 
-def run_vectors(vecs, mats, force_R=0, batch=64):
+def run_vectors(vecs, mats, force_R=0, batch=64, no_packed=False):
     """Group vectors that share (ref, gap_incentive, matrix, params) into one emulated launch each."""
     groups = {}
     for v in vecs:
@@ -45,7 +45,7 @@ def run_vectors(vecs, mats, force_R=0, batch=64):
         for b in range(0, len(vs), batch):
             chunk = vs[b:b + batch]
             res, rec = E.align_batch([v["seqj"] for v in chunk], [seqi], [list(g)], [list(inc)], mats[mat], go, ge,
-                                     force_R=force_R, grid=min(len(chunk), 3))
+                                     force_R=force_R, grid=min(len(chunk), 3), no_packed=no_packed)
             for v, (s1, s2), r in zip(chunk, res, rec):
                 assert r["status"] == 0, (v, r)
                 assert [s1, s2] == v["out"][:2], v
@@ -69,6 +69,13 @@ def test_emulated_kernel_fuzz_vectors(mats):
 def test_emulated_kernel_realistic_vectors(mats):
     vecs = load_golden("realistic.json")
     assert run_vectors(vecs, mats) == len(vecs)
+
+
+def test_emulated_kernel_lds_score_table_path(mats):
+    """EDNAFULL normally takes the packed-nibble score rows; force the general LDS score-table path too."""
+    vecs = load_golden("realistic.json")[::4]
+    assert run_vectors(vecs, mats, no_packed=True) == len(vecs)
+    assert run_vectors(vecs[:10], mats, no_packed=True, force_R=2) == 10
 
 
 @pytest.mark.parametrize("R", [1, 2, 3])
