@@ -75,6 +75,29 @@ __device__ __forceinline__ int c2_boundary_hstate(int i, int j, int min_score, i
     return (ge * i + g0 <= min_score) ? C2_ST_I : C2_ST_J;              // M=I=min_score, J=ge*i+g0
 }
 
+// Append the four pointer bits of one cell to `bits` (newest in the low bits):
+//   bit3 = a0 > b0 (I opened), bit2 = a1 > b1 (J opened), bit1 = a2 == b2 (H is I), bit0 = a3 >= b3 (J beats M).
+// On the device: four v_cmp into SGPR pairs, then four v_addc_co_u32 (bits = 2*bits + carry) -- 8 VALU issues, and each
+// compare result is read 3+ issues after it was written (gfx950 needs 2 wait states there, which hipcc cannot see in asm).
+__device__ __forceinline__ void c2_push4(unsigned& bits, int a0, int b0, int a1, int b1, int a2, int b2, int a3, int b3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long m1, m2, m3;
+    asm("v_cmp_gt_i32 %1, %4, %5\n\t"
+        "v_cmp_gt_i32 %2, %6, %7\n\t"
+        "v_cmp_eq_u32 %3, %8, %9\n\t"
+        "v_cmp_ge_i32 vcc, %10, %11\n\t"
+        "v_addc_co_u32 %0, %1, %0, %0, %1\n\t"
+        "v_addc_co_u32 %0, %2, %0, %0, %2\n\t"
+        "v_addc_co_u32 %0, %3, %0, %0, %3\n\t"
+        "v_addc_co_u32 %0, vcc, %0, %0, vcc"
+        : "+v"(bits), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
+        : "vcc");
+#else
+    bits = (bits << 4) | ((unsigned)(a0 > b0) << 3) | ((unsigned)(a1 > b1) << 2) | ((unsigned)(a2 == b2) << 1) | (unsigned)(a3 >= b3);
+#endif
+}
+
 // Per-lane DP state of one systolic pass: R consecutive reference rows.
 template <int R>
 struct c2_strip {
@@ -103,17 +126,13 @@ __device__ __forceinline__ void c2_dp_column(c2_strip<R>& S, const int upM0, con
         int jFromM = upM + S.c[r];
         if (TAIL) { const int corr = lastcol ? S.delta[r] : 0; iFromM += corr; jFromM += corr; }
         const int iExt = S.Il[r] + S.b[r];
-        const bool ib = iFromM > iExt;                    // pyx:191-196: tie -> extend
-        const int In = ib ? iFromM : iExt;
+        const int In = c2_imax(iFromM, iExt);             // pyx:191-196: tie -> extend (pointer bit: iFromM > iExt)
         const int jExt = upJ + ge;
-        const bool jb = jFromM > jExt;                    // pyx:199-211: tie -> extend
-        const int Jn = jb ? jFromM : jExt;
+        const int Jn = c2_imax(jFromM, jExt);             // pyx:199-211: tie -> extend (pointer bit: jFromM > jExt)
         const int Mn = dg + s;                            // H(i-1,j-1) + matrix[ci,cj], pyx:213-228
-        const int t2 = c2_imax(Mn, Jn);
-        const bool hI = In >= t2;                         // I wins all ties
-        const bool hJ = Jn >= Mn;                         // J beats M on a tie
-        const int Hn = c2_imax(t2, In);
-        S.bits = (S.bits << 4) | ((unsigned)ib << 3) | ((unsigned)jb << 2) | ((unsigned)hI << 1) | (unsigned)hJ;
+        const int Hn = c2_imax(c2_imax(Mn, Jn), In);      // v_max3_i32
+        // H is I iff In >= max(Mn, Jn) iff In == Hn (I wins all ties); else J iff Jn >= Mn (J beats M on a tie)
+        c2_push4(S.bits, iFromM, iExt, jFromM, jExt, In, Hn, Jn, Mn);
         dg = S.Hl[r];
         S.Ml[r] = Mn; S.Il[r] = In; S.Hl[r] = Hn;
         upM = Mn; upJ = Jn;
@@ -121,21 +140,37 @@ __device__ __forceinline__ void c2_dp_column(c2_strip<R>& S, const int upM0, con
     S.Mb = upM; S.Jb = upJ; S.Hb = S.Hl[R - 1];
 }
 
+// Symbols of read positions base+l, base+l+64, base+l+128, base+l+192 packed into one register per lane l
+// (PACKED: 4*code, the bit offset of the score nibble).
+template <bool PACKED>
+__device__ __forceinline__ int c2_load_rsym(const unsigned char* sCode, const int base, const int Lj, const int lane) {
+    int w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int q = base + 64 * b + lane;
+        const int c = q < Lj ? (int)sCode[q] : 0;
+        w |= (PACKED ? (c << 2) : c) << (8 * b);
+    }
+    return w;
+}
+
 // One step of the systolic sweep: hand-off from the lane above (DPP, full EXEC), then this lane's column j = t - lane.
 template <int R, bool PACKED, bool TAIL>
 __device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const int lane, const int Lj, const int ge, const int g0,
                                            const int min_score, const bool first, const bool feeds_next,
-                                           int& nC, int& nM, int& nJ, int& nH,
+                                           int& rsym, int& nM, int& nJ, int& nH,
                                            const unsigned char* sCode, const int16_t* sTbl, int* sBnd,
                                            uint16_t* myPtr, const int colStride)
 {
     int bM = min_score, bJ = min_score, bH;
     if (first) bH = c2_imax(min_score, ge * t + g0);           // H(0,t) = iScore[0,t], pyx:161-162
     else { bM = nM; bJ = nJ; bH = nH; }
-    const int bC = PACKED ? (nC << 2) : nC;
-    const int tn = (t + 1 <= Lj) ? t + 1 : Lj;
-    nC = sCode[tn - 1];
-    if (!first) { nM = sBnd[3 * tn]; nJ = sBnd[3 * tn + 1]; nH = sBnd[3 * tn + 2]; }
+    // read symbol of column t: lane (t-1)&63 of rsym holds the symbols of read positions l, l+64, l+128, l+192 of the
+    // current 256-column chunk (v_readlane + scalar byte extract: no LDS access, nothing to wait for)
+    const int pos = t - 1;
+    if ((pos & 255) == 0) rsym = c2_load_rsym<PACKED>(sCode, pos, Lj, lane);
+    const int bC = (__builtin_amdgcn_readlane(rsym, pos & 63) >> ((pos >> 3) & 24)) & 0xff;
+    if (!first) { const int tn = (t + 1 <= Lj) ? t + 1 : Lj; nM = sBnd[3 * tn]; nJ = sBnd[3 * tn + 1]; nH = sBnd[3 * tn + 2]; }
     const int upM0 = c2_shr1(bM, S.Mb);
     const int upJ0 = c2_shr1(bJ, S.Jb);
     const int upH = c2_shr1(bH, S.Hb);
@@ -191,15 +226,15 @@ __device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_
     const bool feeds_next = !SINGLE && (p + 1 < passes);
 
     // values entering lane 0 at step t (column t of the row above the pass), fetched one step ahead
-    int nC = sCode[0];
+    int rsym = 0;
     int nM = min_score, nJ = min_score, nH = 0;
     if (!first) { nM = sBnd[3]; nJ = sBnd[4]; nH = sBnd[5]; }
     // steps 1 .. Lj-1: no lane can be on the last column or beyond it; steps Lj .. : the general column
     const int t_split = Lj < steps + 1 ? Lj : steps + 1;
     for (int t = 1; t < t_split; ++t)
-        c2_dp_step<R, PACKED, false>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, nC, nM, nJ, nH, sCode, sTbl, sBnd, myPtr, colStride);
+        c2_dp_step<R, PACKED, false>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, myPtr, colStride);
     for (int t = t_split; t <= steps; ++t)
-        c2_dp_step<R, PACKED, true>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, nC, nM, nJ, nH, sCode, sTbl, sBnd, myPtr, colStride);
+        c2_dp_step<R, PACKED, true>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, myPtr, colStride);
 }
 
 template <int R>
