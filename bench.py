@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--workers", type=int, default=0, help="processes generating the synthetic reads (0 = auto; 1 = no fork, for profiler runs)")
+    ap.add_argument("--band", type=int, default=-1, help="pointer-plane band: -1 auto, 0 off, n lanes each side")
+    ap.add_argument("--band-wgs", type=int, default=0, help="target workgroups per CU for the automatic band")
     ap.add_argument("--check", type=int, default=300, help="reads compared with the oracle after the timed region")
     args = ap.parse_args()
 
@@ -74,6 +76,7 @@ def main():
     from crispresso2_amd.batch import BatchAligner
     m = A.read_matrix(matrix_path)
     ctx = _native.Context(local_rank)
+    ctx.set_band(args.band, args.band_wgs)
     al = BatchAligner([amp], [gap_inc], [include], m, -20, -2, ctx=ctx)
     stride = al.stride_for(L)
 
@@ -135,6 +138,7 @@ def main():
                 parity = False
                 break
     info = ctx.launch_info(L)
+    band = ctx.band_info(L)
 
     if rank == 0:
         total_reads = world * n * args.steps
@@ -156,7 +160,8 @@ def main():
                                    % ("{:,}".format(n), L, L),
                        "reads_per_gpu_per_step": n, "read_len": L, "amplicon_len": L, "unique_read_fraction": None,
                        "rows_per_lane": info["rows_per_lane"], "lds_bytes_per_workgroup": info["lds_bytes"],
-                       "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"]},
+                       "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
+                       "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "c2_align_classify_kernel", "avg_launch_ms": 1e3 * avg_launch_s, "launches": launches,

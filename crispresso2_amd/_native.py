@@ -20,7 +20,7 @@ SYMBOLS = [
     "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
-    "c2_selftest",
+    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info",
 ]
 
 REC_DTYPE = np.dtype([
@@ -146,6 +146,20 @@ class Context:
         n = ctypes.c_int64(0)
         self.check(self.lib.c2_timing_read(self.handle, ctypes.byref(ms), ctypes.byref(n), int(bool(reset))), "c2_timing_read")
         return ms.value, n.value
+
+    def set_band(self, band_lanes=-1, target_workgroups_per_cu=0):
+        self.check(self.lib.c2_set_band(self.handle, int(band_lanes), int(target_workgroups_per_cu)), "c2_set_band")
+
+    def band_info(self, max_read_len):
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        self.check(self.lib.c2_band_info(self.handle, int(max_read_len), ctypes.byref(a), ctypes.byref(b)), "c2_band_info")
+        return {"band_lanes": a.value, "fallback_tasks_last_launch": b.value}
+
+    def phase_profile(self, enable):
+        """-> the four per-phase cycle counters accumulated so far (then cleared); sets the mode."""
+        out = (ctypes.c_uint64 * 4)()
+        self.check(self.lib.c2_phase_profile(self.handle, int(bool(enable)), out), "c2_phase_profile")
+        return [int(x) for x in out]
 
     def launch_info(self, max_read_len):
         v = [ctypes.c_int32(0) for _ in range(5)]

@@ -53,7 +53,13 @@ struct c2_ctx {
     bool timing = false;
     std::vector<TimedLaunch> timed;
     // LDS opt-in already requested for these kernels
-    bool lds_attr_set[5] = {false, false, false, false, false};
+    // optional per-phase cycle accounting (c2_phase_profile)
+    bool phase_prof = false;
+    DevBuf d_phase;
+    // banded first launch: -1 auto, 0 off, >0 lanes each side; fallback list buffer
+    int band_setting = -1;
+    int band_target_wgs = 12;
+    DevBuf d_fb;
 };
 
 namespace {
@@ -81,44 +87,98 @@ int ensure(c2_ctx* ctx, DevBuf& b, size_t bytes) {
 void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 struct Geometry {
-    int R, passes, max_lj, blocks_per_cu;
-    uint32_t lds;
+    int R, passes, max_lj;
+    uint32_t lds_full; int blocks_full;          // full pointer plane
+    int band_lanes; uint32_t lds_band; int blocks_band;   // banded first launch (band_lanes == 0: not used)
 };
+
+template <int R, bool BAND>
+int occupancy(c2_ctx* ctx, uint32_t lds, int& blocks) {
+    int nb = 0;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_classify_kernel<R, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_classify_kernel<R, BAND>, 64, lds));
+    blocks = nb < 1 ? 1 : nb;
+    return 0;
+}
+
+template <bool BAND>
+int occupancy_r(c2_ctx* ctx, int R, uint32_t lds, int& blocks) {
+    switch (R) {
+        case 1: return occupancy<1, BAND>(ctx, lds, blocks);
+        case 2: return occupancy<2, BAND>(ctx, lds, blocks);
+        case 3: return occupancy<3, BAND>(ctx, lds, blocks);
+        default: return occupancy<4, BAND>(ctx, lds, blocks);
+    }
+}
 
 int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     if (!ctx->have_scoring || ctx->n_refs <= 0) { ctx->err = "scoring and references must be set first"; return C2_E_STATE; }
     g.R = c2_choose_rows_per_lane(ctx->max_li);
     g.passes = (ctx->max_li + 64 * g.R - 1) / (64 * g.R);
     g.max_lj = std::max(max_lj, 1);
-    const c2_lds_plan P = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes);
-    g.lds = P.total;
-    const size_t lds_cu = ctx->prop.maxSharedMemoryPerMultiProcessor ? ctx->prop.maxSharedMemoryPerMultiProcessor : 163840;
-    const size_t lds_wg = std::min<size_t>(lds_cu, 163840);
-    if (g.lds > lds_wg) {
+    const size_t lds_cu = 163840;
+    g.lds_full = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes, C2_LANES).total;
+    if (g.lds_full > lds_cu) {
         ctx->err = "alignment of " + std::to_string(ctx->max_li) + " x " + std::to_string(g.max_lj) +
-                   " needs " + std::to_string(g.lds) + " bytes of LDS pointer plane; limit is " + std::to_string(lds_wg);
+                   " needs " + std::to_string(g.lds_full) + " bytes of LDS pointer plane; limit is " + std::to_string(lds_cu);
         return C2_E_TOO_LARGE;
     }
-    g.blocks_per_cu = (int)std::min<size_t>(32, lds_cu / g.lds);   // one wave per workgroup; 32 waves per CU at most
-    if (g.blocks_per_cu < 1) g.blocks_per_cu = 1;
+    int rc;
+    if ((rc = occupancy_r<false>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
+    // Banded first launch: keep only the pointer words of the lanes near the main diagonal so that more workgroups fit
+    // a CU (the DP is latency-bound at one wave per SIMD).  band: -1 auto, 0 off, >0 lanes on each side.
+    g.band_lanes = 0; g.lds_band = 0; g.blocks_band = 0;
+    int want = ctx->band_setting;
+    if (g.passes == 1 && want != 0) {
+        if (want < 0) {
+            // auto: the widest band that still lets `band_target_wgs` workgroups share a CU's LDS
+            const uint32_t other = c2_make_plan(g.R, g.max_lj, 1, ctx->sc.n_codes, 1).total - (uint32_t)c2_align16((uint32_t)g.max_lj * (1 + C2_PTR_PAD) * 2u);
+            const int64_t budget = (int64_t)(lds_cu / (size_t)ctx->band_target_wgs) - (int64_t)other - 32;
+            const int nslots = (int)(budget / (2 * (int64_t)g.max_lj)) - C2_PTR_PAD;
+            want = (nslots - 1) / 2;
+        }
+        if (want >= 2 && 2 * want + 1 < C2_LANES - 8) {
+            g.band_lanes = want;
+            g.lds_band = c2_make_plan(g.R, g.max_lj, 1, ctx->sc.n_codes, 2 * want + 1).total;
+            if ((rc = occupancy_r<true>(ctx, g.R, g.lds_band, g.blocks_band))) return rc;
+            if (g.blocks_band <= g.blocks_full) g.band_lanes = 0;      // no occupancy to gain
+        }
+    }
+    return 0;
+}
+
+template <int R, bool BAND>
+int launch_one(c2_ctx* ctx, const c2_align_args& A, uint32_t lds, int blocks_per_cu, uint64_t work_items, hipStream_t s) {
+    const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)blocks_per_cu;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(work_items, resident));
+    hipLaunchKernelGGL((c2_align_classify_kernel<R, BAND>), dim3(grid), dim3(64), lds, s, A);
+    HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 
 template <int R>
-int launch_align(c2_ctx* ctx, const c2_align_args& A, const Geometry& g, hipStream_t s) {
-    if (!ctx->lds_attr_set[R] || g.lds > 65536) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_classify_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        ctx->lds_attr_set[R] = true;
-    }
-    const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)g.blocks_per_cu;
-    const unsigned grid = (unsigned)std::min<uint64_t>(A.n_tasks, resident);
+int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s) {
     TimedLaunch tl{};
     if (ctx->timing) {
         HIPCHK(ctx, hipEventCreate(&tl.a)); HIPCHK(ctx, hipEventCreate(&tl.b));
         HIPCHK(ctx, hipEventRecord(tl.a, s));
     }
-    hipLaunchKernelGGL(c2_align_classify_kernel<R>, dim3(grid), dim3(64), g.lds, s, A);
-    HIPCHK(ctx, hipGetLastError());
+    int rc;
+    A.band_lanes = 0; A.reserved = 0; A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
+    if (g.band_lanes > 0) {
+        if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
+        if ((rc = ensure(ctx, ctx->d_fb, 16 + A.n_tasks * sizeof(uint32_t)))) return rc;
+        uint32_t* fb_count = (uint32_t*)ctx->d_fb.p;
+        uint32_t* fb_list = fb_count + 4;
+        HIPCHK(ctx, hipMemsetAsync(fb_count, 0, 16, s));
+        A.band_lanes = g.band_lanes; A.fb_count = fb_count; A.fb_list = fb_list;
+        if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
+        // the tasks whose traceback left the band, redone with the full pointer plane (usually a handful; an empty list costs one tiny launch)
+        A.band_lanes = 0; A.task_list = fb_list; A.task_count = fb_count;
+        if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;
+    } else {
+        if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;
+    }
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(tl.b, s)); ctx->timed.push_back(tl); }
     return 0;
 }
@@ -139,6 +199,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.n_tasks = n_tasks; A.aln_stride = b->aln_stride; A.n_refs = ctx->n_refs; A.all_refs = b->all_refs ? 1 : 0;
     A.n_codes = ctx->sc.n_codes; A.gap_open = ctx->gap_open; A.gap_extend = ctx->gap_extend;
     A.max_lj = g.max_lj; A.max_passes = g.passes;
+    A.phase_cycles = ctx->phase_prof ? (unsigned long long*)ctx->d_phase.p : nullptr;
     switch (g.R) {
         case 1: return launch_align<1>(ctx, A, g, s);
         case 2: return launch_align<2>(ctx, A, g, s);
@@ -189,7 +250,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb};
     for (DevBuf* b : all) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -266,14 +327,41 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
 int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, int32_t* passes, int32_t* lds_bytes,
                    int32_t* workgroups_per_cu, int32_t* compute_units) {
     if (!ctx) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     Geometry g;
     int rc = geometry(ctx, max_read_len, g);
     if (rc) return rc;
     if (rows_per_lane) *rows_per_lane = g.R;
     if (passes) *passes = g.passes;
-    if (lds_bytes) *lds_bytes = (int32_t)g.lds;
-    if (workgroups_per_cu) *workgroups_per_cu = g.blocks_per_cu;
+    if (lds_bytes) *lds_bytes = (int32_t)(g.band_lanes ? g.lds_band : g.lds_full);
+    if (workgroups_per_cu) *workgroups_per_cu = g.band_lanes ? g.blocks_band : g.blocks_full;
     if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    return 0;
+}
+
+int c2_set_band(c2_ctx* ctx, int32_t band_lanes, int32_t target_workgroups_per_cu) {
+    if (!ctx) return C2_E_INVALID;
+    ctx->band_setting = band_lanes;
+    if (target_workgroups_per_cu > 0) ctx->band_target_wgs = target_workgroups_per_cu;
+    return 0;
+}
+
+int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t* fallback_tasks_last_launch) {
+    if (!ctx) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Geometry g;
+    int rc = geometry(ctx, max_read_len, g);
+    if (rc) return rc;
+    if (band_lanes) *band_lanes = g.band_lanes;
+    if (fallback_tasks_last_launch) {
+        *fallback_tasks_last_launch = 0;
+        if (ctx->d_fb.p) {
+            HIPCHK(ctx, hipDeviceSynchronize());
+            uint32_t c = 0;
+            HIPCHK(ctx, hipMemcpy(&c, ctx->d_fb.p, 4, hipMemcpyDeviceToHost));
+            *fallback_tasks_last_launch = (int32_t)c;
+        }
+    }
     return 0;
 }
 
@@ -478,6 +566,18 @@ int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, 
     HIPCHK(ctx, hipMemcpyAsync(&f, base + o_out, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     *out = (double)f;
+    return 0;
+}
+
+int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4) {
+    if (!ctx) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_phase, 4 * sizeof(uint64_t)))) return rc;
+    HIPCHK(ctx, hipDeviceSynchronize());
+    if (out4) HIPCHK(ctx, hipMemcpy(out4, ctx->d_phase.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemset(ctx->d_phase.p, 0, 4 * sizeof(uint64_t)));
+    ctx->phase_prof = enable != 0;
     return 0;
 }
 

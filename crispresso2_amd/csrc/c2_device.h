@@ -12,6 +12,7 @@
 #define C2_INVALID_CODE 255
 #define C2_PTR_PAD 2               // halfword padding of one pointer column (breaks the 128-B bank stride)
 #define C2_LANES 64
+#define C2_STATUS_NEED_FULL 64     // internal: banded launch could not finish the traceback; the full-plane launch overwrites the record
 
 // Device-resident description of one reference amplicon.
 typedef struct c2_dev_ref {
@@ -43,6 +44,13 @@ typedef struct c2_align_args {
     int32_t gap_open, gap_extend;
     int32_t max_lj;               // LDS plan: longest read of this launch
     int32_t max_passes;           // LDS plan: ceil(max Li / (64*R))
+    int32_t band_lanes;           // banded kernel: lanes kept on each side of the main-diagonal lane
+    int32_t reserved;
+    uint32_t* fb_count;           // banded kernel: number of tasks whose traceback left the band ...
+    uint32_t* fb_list;            // ... and their task indices (capacity n_tasks)
+    const uint32_t* task_list;    // full kernel, second launch: run only these tasks (NULL = tasks 0..n_tasks-1)
+    const uint32_t* task_count;   // device-resident length of task_list
+    unsigned long long* phase_cycles; // optional: 4 counters of per-phase shader cycles (profiling), else NULL
 } c2_align_args;
 
 // Kernel arguments for the per-call classifier (find_indels_substitutions / _legacy with full lists).

@@ -47,10 +47,10 @@ struct c2_lds_plan {
 __host__ __device__ inline uint32_t c2_align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 // The same function sizes the LDS on the host and carves it in the kernel.
-__host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_passes, int n_codes) {
+__host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_passes, int n_codes, int nslots) {
     c2_lds_plan p;
     const uint32_t max_li = (uint32_t)max_passes * 64u * (uint32_t)R;
-    p.col_stride = C2_LANES + C2_PTR_PAD;
+    p.col_stride = (uint32_t)nslots + C2_PTR_PAD;      // nslots = 64 (every lane) or 2*band_lanes+1 (banded pointer plane)
     uint32_t off = 0;
     p.ptr = off;      off += c2_align16((uint32_t)max_passes * (uint32_t)max_lj * p.col_stride * 2u);
     p.bnd = off;      off += (max_passes > 1) ? c2_align16(3u * ((uint32_t)max_lj + 1u) * 4u) : 0u;
@@ -96,6 +96,35 @@ __device__ __forceinline__ void c2_push4(unsigned& bits, int a0, int b0, int a1,
 #else
     bits = (bits << 4) | ((unsigned)(a0 > b0) << 3) | ((unsigned)(a1 > b1) << 2) | ((unsigned)(a2 == b2) << 1) | (unsigned)(a3 >= b3);
 #endif
+}
+
+// Optional per-phase cycle accounting (c2_align_args.phase_cycles != NULL): lane 0 adds the s_memtime delta of each
+// phase of each task to a global counter.  Used by tools/phase_profile.py; costs one uniform branch when disabled.
+__device__ __forceinline__ void c2_phase_mark(unsigned long long* acc, int phase, unsigned long long& t_last, int lane) {
+    if (acc) {
+        const unsigned long long now = (unsigned long long)clock64();
+        if (lane == 0) atomicAdd(acc + phase, now - t_last);
+        t_last = (unsigned long long)clock64();
+    }
+}
+
+// floor(x / R) for the rows-per-lane values in use (x < 32768)
+template <int R>
+__device__ __forceinline__ int c2_div_rows(int x) {
+    if (R == 1) return x;
+    if (R == 2) return x >> 1;
+    if (R == 4) return x >> 2;
+    return (x * 21846) >> 16;                           // R == 3
+}
+
+// Halfword index of the pointer word of (row-lane `rl`, column j = jm1+1) inside one pass's pointer plane.
+// BAND: only the lanes within band_lanes of the main-diagonal lane (j-1)/R are stored; *inband tells whether this one is.
+template <int R, bool BAND>
+__device__ __forceinline__ int c2_ptr_index(const int rl, const int jm1, const int colStride, const int band_lanes, bool& inband) {
+    if (!BAND) { inband = true; return jm1 * colStride + rl; }
+    const int slot = rl + band_lanes - c2_div_rows<R>(jm1);
+    inband = (unsigned)slot <= (unsigned)(2 * band_lanes);
+    return jm1 * colStride + slot;
 }
 
 // Per-lane DP state of one systolic pass: R consecutive reference rows.
@@ -155,12 +184,12 @@ __device__ __forceinline__ int c2_load_rsym(const unsigned char* sCode, const in
 }
 
 // One step of the systolic sweep: hand-off from the lane above (DPP, full EXEC), then this lane's column j = t - lane.
-template <int R, bool PACKED, bool TAIL>
+template <int R, bool PACKED, bool TAIL, bool BAND>
 __device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const int lane, const int Lj, const int ge, const int g0,
                                            const int min_score, const bool first, const bool feeds_next,
                                            int& rsym, int& nM, int& nJ, int& nH,
                                            const unsigned char* sCode, const int16_t* sTbl, int* sBnd,
-                                           uint16_t* myPtr, const int colStride)
+                                           uint16_t* planePtr, const int colStride, const int band_lanes)
 {
     int bM = min_score, bJ = min_score, bH;
     if (first) bH = c2_imax(min_score, ge * t + g0);           // H(0,t) = iScore[0,t], pyx:161-162
@@ -179,7 +208,9 @@ __device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const in
     const bool active = TAIL ? (j >= 1 && j <= Lj) : (j >= 1);
     if (active) {
         c2_dp_column<R, PACKED, TAIL>(S, upM0, upJ0, ge, TAIL && (j == Lj), sTbl);
-        myPtr[(j - 1) * colStride] = (uint16_t)S.bits;
+        bool inband;
+        const int pidx = c2_ptr_index<R, BAND>(lane, j - 1, colStride, band_lanes, inband);
+        if (inband) planePtr[pidx] = (uint16_t)S.bits;
         if (feeds_next && lane == 63) { sBnd[3 * j] = S.Mb; sBnd[3 * j + 1] = S.Jb; sBnd[3 * j + 2] = S.Hb; }
     }
     S.dgsave = upH;
@@ -187,9 +218,9 @@ __device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const in
 
 // One systolic pass over reference rows p*64R+1 .. p*64R+64R.  SINGLE: the reference fits one pass, so the row above
 // lane 0 is the closed-form row 0 and nothing is handed to a next pass.
-template <int R, bool PACKED, bool SINGLE>
+template <int R, bool PACKED, bool SINGLE, bool BAND>
 __device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_ref& rf, const unsigned char* sRef,
-                                           const unsigned char* sCode, const int16_t* sTbl, int* sBnd, uint16_t* myPtr,
+                                           const unsigned char* sCode, const int16_t* sTbl, int* sBnd, uint16_t* planePtr,
                                            const int colStride, const int lane, const int p, const int passes,
                                            const int Li, const int Lj, const int g0, const int min_score)
 {
@@ -232,16 +263,20 @@ __device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_
     // steps 1 .. Lj-1: no lane can be on the last column or beyond it; steps Lj .. : the general column
     const int t_split = Lj < steps + 1 ? Lj : steps + 1;
     for (int t = 1; t < t_split; ++t)
-        c2_dp_step<R, PACKED, false>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, myPtr, colStride);
+        c2_dp_step<R, PACKED, false, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
     for (int t = t_split; t <= steps; ++t)
-        c2_dp_step<R, PACKED, true>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, myPtr, colStride);
+        c2_dp_step<R, PACKED, true, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
 }
 
-template <int R>
+// BAND = false: full pointer plane (any path).  BAND = true: only the lanes within A.band_lanes of the main diagonal
+// keep their pointer words (single-pass references only); a traceback that needs a word outside the band appends the
+// task to A.fb_list, and the host re-runs exactly those tasks with the full-plane kernel (A.task_list mode).  The band
+// limits what is STORED, never what is computed, so results do not depend on it.
+template <int R, bool BAND>
 __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
 {
     const int lane = threadIdx.x;
-    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes);
+    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, BAND ? 2 * A.band_lanes + 1 : C2_LANES);
     uint16_t* sPtr = (uint16_t*)(c2_smem + P.ptr);
     int* sBnd = (int*)(c2_smem + P.bnd);
     int16_t* sTbl = (int16_t*)(c2_smem + P.tbl);
@@ -261,7 +296,9 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
     int cur_ref = -1;
     int Li = 0, g0 = 0;
 
-    for (uint64_t task = blockIdx.x; task < A.n_tasks; task += gridDim.x) {
+    const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : A.n_tasks;
+    for (uint64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const uint64_t task = A.task_list ? (uint64_t)A.task_list[it] : it;
         uint64_t read_id;
         int ref_id;
         if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
@@ -274,6 +311,7 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
         const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
 
         __syncthreads();   // previous task's LDS readers are done
+        unsigned long long t_phase = A.phase_cycles ? (unsigned long long)clock64() : 0ull;
         // ---- reference: chars, window prefix, per-lane row constants (reloaded only when the amplicon changes)
         if (ref_id != cur_ref) {
             cur_ref = ref_id;
@@ -311,7 +349,7 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
         }
         if (Li <= 0 || Lj <= 0) status |= C2_STATUS_EMPTY;
         const int passes = (Li + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-        if (Lj > A.max_lj || passes > A.max_passes) status |= C2_STATUS_TOO_LONG;
+        if (Lj > A.max_lj || passes > A.max_passes || (BAND && passes != 1)) status |= C2_STATUS_TOO_LONG;
         status = (__ballot(status & C2_STATUS_EMPTY) ? C2_STATUS_EMPTY : 0) |
                  (__ballot(status & C2_STATUS_OOB_CHAR) ? C2_STATUS_OOB_CHAR : 0) |
                  (__ballot(status & C2_STATUS_RC_CHAR) ? C2_STATUS_RC_CHAR : 0) |
@@ -329,33 +367,40 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
             // pyx:150  int min_score = gap_open * max_j * max_i   (wraps like the reference's C int)
             const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
 
+            c2_phase_mark(A.phase_cycles, 0, t_phase, lane);   // phase 0: task fetch (offsets, read, reference rows)
             // =========================== DP: systolic sweep, pass by pass ===========================
             // packed = every read symbol has a code < 8 and every score fits a signed nibble: the score row of a
             // reference base is then one register and a lookup is one v_bfe_i32 (no LDS in the inner loop).
             const bool packed = (A.score_pk != nullptr) && (__ballot(read_code_max >= 8) == 0ull);
             for (int p = 0; p < passes; ++p) {
                 const bool single = (passes == 1);
-                uint16_t* myPtr = sPtr + (size_t)p * (size_t)A.max_lj * colStride + lane;
+                uint16_t* planePtr = sPtr + (size_t)p * (size_t)A.max_lj * colStride;
                 if (packed) {
-                    if (single) c2_dp_pass<R, true, true>(A, rf, sRef, sCode, sTbl, sBnd, myPtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                    else        c2_dp_pass<R, true, false>(A, rf, sRef, sCode, sTbl, sBnd, myPtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    if (single) c2_dp_pass<R, true, true, BAND>(A, rf, sRef, sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    else        c2_dp_pass<R, true, false, false>(A, rf, sRef, sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
                 } else {
-                    if (single) c2_dp_pass<R, false, true>(A, rf, sRef, sCode, sTbl, sBnd, myPtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                    else        c2_dp_pass<R, false, false>(A, rf, sRef, sCode, sTbl, sBnd, myPtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    if (single) c2_dp_pass<R, false, true, BAND>(A, rf, sRef, sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    else        c2_dp_pass<R, false, false, false>(A, rf, sRef, sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
                 }
                 __syncthreads();
             }
 
+            c2_phase_mark(A.phase_cycles, 1, t_phase, lane);   // phase 1: DP fill
             // =========================== traceback: wave-parallel run detection ===========================
             int i = Li, j = Lj, cnt = 0, matches = 0;
-            int s;
+            int s = C2_ST_M;
+            bool need_full = false;                      // BAND: the path left the stored band
             {
                 const int pp = (i - 1) / ROWS_PER_PASS, rem = (i - 1) % ROWS_PER_PASS;
-                const unsigned hw = sPtr[((size_t)pp * A.max_lj + (j - 1)) * colStride + rem / R];
-                const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
-                s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // pyx:349-358
+                bool inb;
+                const int pidx = c2_ptr_index<R, BAND>(rem / R, j - 1, colStride, A.band_lanes, inb);
+                if (inb) {
+                    const unsigned hw = sPtr[(size_t)pp * A.max_lj * colStride + pidx];
+                    const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
+                    s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // pyx:349-358
+                } else need_full = true;
             }
-            while (i > 0 || j > 0) {
+            while (!need_full && (i > 0 || j > 0)) {
                 if (i == 0 || j == 0) {
                     const int need = (i == 0) ? C2_ST_I : C2_ST_J;           // initialised chains: iPointer[0,1:], jPointer[1:,0]
                     if (s != need) { status |= (s == C2_ST_M) ? C2_STATUS_SENTINEL_PATH : C2_STATUS_UNINIT_PTR; break; }
@@ -371,6 +416,7 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
                 const int ik = i - lane * di, jk = j - lane * dj;
                 const bool valid = (ik >= 1) && (jk >= 1);
                 int ns = 0;
+                bool oob = false;
                 if (valid) {
                     // cell whose pointer nibble decides the next state
                     const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
@@ -378,11 +424,15 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
                         ns = c2_boundary_hstate(pi, pj, min_score, ge, g0);   // only reachable for s == M
                     } else {
                         const int pp = (pi - 1) / ROWS_PER_PASS, rem = (pi - 1) % ROWS_PER_PASS;
-                        const unsigned hw = sPtr[((size_t)pp * A.max_lj + (pj - 1)) * colStride + rem / R];
-                        const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
-                        if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
-                        else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
-                        else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
+                        bool inb;
+                        const int pidx = c2_ptr_index<R, BAND>(rem / R, pj - 1, colStride, A.band_lanes, inb);
+                        if (inb) {
+                            const unsigned hw = sPtr[(size_t)pp * A.max_lj * colStride + pidx];
+                            const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
+                            if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
+                            else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
+                            else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
+                        } else oob = true;                                    // not stored: ns stays 0 (never == s)
                     }
                 }
                 const unsigned long long vmask = __ballot(valid);
@@ -390,8 +440,11 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
                 const int nv = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
                 const int nc = (~cmask == 0ull) ? 64 : __builtin_ctzll(~cmask);
                 int E, s_next;
-                if (nc < nv) { E = nc + 1; s_next = __builtin_amdgcn_readlane(ns, nc); }
-                else { E = nv; s_next = s; }
+                if (nc < nv) {
+                    // lane nc decides the next state; if its pointer word is outside the stored band the full kernel must redo this task
+                    if (BAND && ((__ballot(oob) >> nc) & 1ull)) { need_full = true; break; }
+                    E = nc + 1; s_next = __builtin_amdgcn_readlane(ns, nc);
+                } else { E = nv; s_next = s; }
                 unsigned char rch = '-', fch = '-';
                 if (lane < E) {
                     if (s != C2_ST_J) rch = sRead[jk - 1];
@@ -403,6 +456,11 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
                 cnt += E; i -= E * di; j -= E * dj; s = s_next;
             }
             __syncthreads();
+            c2_phase_mark(A.phase_cycles, 2, t_phase, lane);   // phase 2: traceback
+            if (BAND && need_full) {
+                status |= C2_STATUS_NEED_FULL;
+                if (lane == 0) { const unsigned k = atomicAdd(A.fb_count, 1u); A.fb_list[k] = (uint32_t)task; }
+            }
 
             if (status == 0) {
                 const int T = cnt;
@@ -485,6 +543,7 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
         }
         rec.status = (uint8_t)status;
         if (lane == 0) A.records[task] = rec;
+        c2_phase_mark(A.phase_cycles, 3, t_phase, lane);       // phase 3: strings out, classification, record
     }
 }
 

@@ -135,6 +135,14 @@ int c2_timing_read(c2_ctx* ctx, double* total_ms, int64_t* launches, int reset);
 int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, int32_t* passes,
                    int32_t* lds_bytes, int32_t* workgroups_per_cu, int32_t* compute_units);
 
+/* Pointer-plane banding of the batch kernel (a pure performance knob; results never depend on it).
+ * band_lanes: -1 automatic (default), 0 off, n > 0 keep the pointer words of n lanes on each side of the main diagonal.
+ * Alignments whose traceback leaves the band are redone in the same call by the full-plane kernel.
+ * target_workgroups_per_cu (> 0) steers the automatic choice. */
+int c2_set_band(c2_ctx* ctx, int32_t band_lanes, int32_t target_workgroups_per_cu);
+/* Band in use for reads up to max_read_len, and how many tasks of the most recent launch needed the full-plane pass. */
+int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t* fallback_tasks_last_launch);
+
 /* ---- per-call path: same contract as the reference's Cython functions ------------------ */
 
 /* global_align(pystr_seqj, pystr_seqi, matrix, gap_incentive, gap_open, gap_extend), pyx:103-105.
@@ -180,6 +188,11 @@ int c2_find_indels_substitutions(c2_ctx* ctx, const char* read_aln, const char* 
 
 /* calculate_homology(a, b), COREResources.pyx:318-327: matches over strlen(a), float32 accumulator. */
 int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out);
+
+/* Profiling aid: while enabled, every launch adds the shader cycles each workgroup spends in the four phases of a task
+ * (0 fetch, 1 DP fill, 2 traceback, 3 output+classification) to four device counters.  The call first copies the
+ * counters to out4 (may be NULL) and clears them, then sets the mode. */
+int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4);
 
 /* Hardware self-test of the cross-lane primitives (DPP wave_shr:1, readlane, ballot) the DP depends on;
  * writes 192 int32 (see c2_selftest_kernel).  Used by the GPU test-suite. */

@@ -18,7 +18,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
                     const int32_t* const* include_idx, const int32_t* n_include,
                     const int64_t* matrix, int dim, int go, int ge,
                     uint8_t* aln_read, uint8_t* aln_ref, uint32_t aln_stride, c2_aln_record* records,
-                    int force_R, unsigned grid, int no_packed)
+                    int force_R, unsigned grid, int no_packed, int band_lanes, int* n_fallback)
 {
     c2_scoring_tables sc; std::string err;
     if (!c2_build_scoring(matrix, dim, sc, err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return -1; }
@@ -45,14 +45,36 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     A.n_tasks = n_reads * (uint64_t)(all_refs ? n_refs : 1); A.aln_stride = aln_stride; A.n_refs = n_refs; A.all_refs = all_refs;
     A.n_codes = sc.n_codes; A.gap_open = go; A.gap_extend = ge; A.max_lj = max_lj;
     A.max_passes = (max_li + 64 * R - 1) / (64 * R);
-    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes);
-    if (P.total > sizeof(c2_smem)) { fprintf(stderr, "emu: LDS plan %u too large\n", P.total); return -5; }
+    A.phase_cycles = nullptr;
+    // banded first launch (if asked for and the reference fits one pass), then the full-plane launch over the fallback list
+    std::vector<uint32_t> fb_list(A.n_tasks ? A.n_tasks : 1);
+    uint32_t fb_count = 0;
+    A.band_lanes = 0; A.reserved = 0; A.fb_count = &fb_count; A.fb_list = fb_list.data(); A.task_list = nullptr; A.task_count = nullptr;
     if (grid == 0) grid = (unsigned)std::min<uint64_t>(A.n_tasks, 3);
-    switch (R) {
-        case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1>(A); }); break;
-        case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2>(A); }); break;
-        case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3>(A); }); break;
-        default: emu::launch(grid, [&] { c2_align_classify_kernel<4>(A); }); break;
+    const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
+    if (band) {
+        A.band_lanes = band_lanes;
+        const c2_lds_plan PB = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, 2 * band_lanes + 1);
+        if (PB.total > sizeof(c2_smem)) return -5;
+        switch (R) {
+            case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, true>(A); }); break;
+            case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2, true>(A); }); break;
+            case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3, true>(A); }); break;
+            default: emu::launch(grid, [&] { c2_align_classify_kernel<4, true>(A); }); break;
+        }
+        A.task_list = fb_list.data(); A.task_count = &fb_count;
+        if (n_fallback) *n_fallback = (int)fb_count;
+    } else if (n_fallback) *n_fallback = -1;
+    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, C2_LANES);
+    if (P.total > sizeof(c2_smem)) { fprintf(stderr, "emu: LDS plan %u too large\n", P.total); return -5; }
+    A.band_lanes = 0;
+    if (!band || fb_count > 0) {
+        switch (R) {
+            case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, false>(A); }); break;
+            case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2, false>(A); }); break;
+            case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3, false>(A); }); break;
+            default: emu::launch(grid, [&] { c2_align_classify_kernel<4, false>(A); }); break;
+        }
     }
     return 0;
 }

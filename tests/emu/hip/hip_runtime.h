@@ -96,6 +96,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
     if (!ok) return bound_ctrl ? 0 : old;
     return (int)(uint32_t)v;
 }
+inline long long clock64() { return 0; }
 inline int __builtin_amdgcn_sbfe(int x, int off, int width) { return (int)((unsigned)x << (32 - off - width)) >> (32 - width); }
 inline unsigned long long __ballot(int pred) {
     int ph = emu::xl_phase; (void)ph;

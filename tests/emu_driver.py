@@ -40,7 +40,7 @@ def lib():
 
 
 def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_extend,
-                ref_ids=None, strands=None, all_refs=False, force_R=0, grid=0, no_packed=False):
+                ref_ids=None, strands=None, all_refs=False, force_R=0, grid=0, no_packed=False, band_lanes=0, stats=None):
     """reads: list[str]; refs: list[str]; returns (list[(s1, s2)], records ndarray)"""
     n = len(reads)
     arena = "".join(reads).encode()
@@ -62,6 +62,7 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
     rec = np.zeros(ntasks, dtype=REC_DTYPE)
     rid = None if ref_ids is None else np.ascontiguousarray(ref_ids, dtype=np.uint16)
     st = None if strands is None else np.ascontiguousarray(strands, dtype=np.uint8)
+    nfb = ctypes.c_int(0)
     rc = lib().emu_align_batch(
         ctypes.c_uint64(n), arena, offs.ctypes.data_as(ctypes.c_void_p),
         None if rid is None else rid.ctypes.data_as(ctypes.c_void_p),
@@ -69,7 +70,10 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
         nrefs, seqs, lens.ctypes.data_as(ctypes.c_void_p), gp, ip, ninc.ctypes.data_as(ctypes.c_void_p),
         m.ctypes.data_as(ctypes.c_void_p), int(m.shape[0]), int(gap_open), int(gap_extend),
         o1.ctypes.data_as(ctypes.c_void_p), o2.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(stride),
-        rec.ctypes.data_as(ctypes.c_void_p), int(force_R), ctypes.c_uint(grid), int(no_packed))
+        rec.ctypes.data_as(ctypes.c_void_p), int(force_R), ctypes.c_uint(grid), int(no_packed), int(band_lanes), ctypes.byref(nfb))
+    if stats is not None:
+        stats['fallback'] = stats.get('fallback', 0) + max(nfb.value, 0)
+        stats['tasks'] = stats.get('tasks', 0) + ntasks
     assert rc == 0, rc
     out = []
     for k in range(ntasks):

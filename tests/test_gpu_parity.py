@@ -212,6 +212,39 @@ def test_multi_reference_strands_and_pooled_ids_vs_oracle(mats, ctx):
         assert res.records["strand"][k] == strands[k] and res.records["ref_id"][k] == rids[k]
 
 
+def test_banded_pointer_plane_equals_full_plane(mats, ctx):
+    """The banded first launch + full-plane fallback must give byte-identical outputs to the full-plane kernel alone,
+    for a narrow band (many fallbacks), the automatic band, and with the band off."""
+    from crispresso2_amd import synth
+    from crispresso2_amd.batch import BatchAligner
+    m = mats["EDNAFULL"]
+    L, n = 250, 30_000
+    amp, g, inc = synth.amplicon_setup(L)
+    reads = synth.make_reads(L, n)
+    rng = np.random.default_rng(7)
+    reads[::97] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, reads[::97].shape)]   # unrelated reads wander off-diagonal
+    offsets = np.arange(n + 1, dtype=np.uint64) * L
+    al = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
+    outs = {}
+    try:
+        for band in (0, 2, 6, -1):
+            ctx.set_band(band)
+            res = al.align((reads.reshape(-1), offsets))
+            info = ctx.band_info(L)
+            outs[band] = (res, info)
+            assert (res.records["status"] == 0).all()
+    finally:
+        ctx.set_band(-1)
+    base = outs[0][0]
+    assert outs[0][1]["band_lanes"] == 0
+    for band in (2, 6, -1):
+        res, info = outs[band]
+        assert info["band_lanes"] > 0
+        assert np.array_equal(res.records, base.records)
+        assert np.array_equal(res.aln_read, base.aln_read) and np.array_equal(res.aln_ref, base.aln_ref)
+    assert outs[2][1]["fallback_tasks_last_launch"] > outs[6][1]["fallback_tasks_last_launch"] > 0
+
+
 def test_status_bits(mats, ctx):
     from crispresso2_amd.batch import BatchAligner
     import oracle

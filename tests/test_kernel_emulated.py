@@ -34,7 +34,7 @@ def check_record(rec, payload, s1, s2):
     assert bool(rec["irregular_ends"]) == irregular
 
 
-def run_vectors(vecs, mats, force_R=0, batch=64, no_packed=False):
+def run_vectors(vecs, mats, force_R=0, batch=64, no_packed=False, band_lanes=0, stats=None):
     """Group vectors that share (ref, gap_incentive, matrix, params) into one emulated launch each."""
     groups = {}
     for v in vecs:
@@ -45,7 +45,8 @@ def run_vectors(vecs, mats, force_R=0, batch=64, no_packed=False):
         for b in range(0, len(vs), batch):
             chunk = vs[b:b + batch]
             res, rec = E.align_batch([v["seqj"] for v in chunk], [seqi], [list(g)], [list(inc)], mats[mat], go, ge,
-                                     force_R=force_R, grid=min(len(chunk), 3), no_packed=no_packed)
+                                     force_R=force_R, grid=min(len(chunk), 3), no_packed=no_packed,
+                                     band_lanes=band_lanes, stats=stats)
             for v, (s1, s2), r in zip(chunk, res, rec):
                 assert r["status"] == 0, (v, r)
                 assert [s1, s2] == v["out"][:2], v
@@ -76,6 +77,18 @@ def test_emulated_kernel_lds_score_table_path(mats):
     vecs = load_golden("realistic.json")[::4]
     assert run_vectors(vecs, mats, no_packed=True) == len(vecs)
     assert run_vectors(vecs[:10], mats, no_packed=True, force_R=2) == 10
+
+
+@pytest.mark.parametrize("band_lanes", [1, 3, 8])
+def test_emulated_kernel_banded_pointer_plane_with_fallback(mats, band_lanes):
+    """Banded launch (only lanes near the main diagonal keep their pointer words) + full-plane launch over the tasks
+    whose traceback left the band: the union must be identical to the full kernel, and both launches must be used."""
+    st = {}
+    vecs = load_golden("realistic.json")
+    assert run_vectors(vecs, mats, band_lanes=band_lanes, stats=st) == len(vecs)
+    small = load_golden("fuzz_align.json")[::5]
+    assert run_vectors(small, mats, band_lanes=band_lanes, stats=st) == len(small)
+    assert 0 < st["fallback"] < st["tasks"], st
 
 
 @pytest.mark.parametrize("R", [1, 2, 3])
