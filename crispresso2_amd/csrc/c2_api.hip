@@ -58,7 +58,7 @@ struct c2_ctx {
     DevBuf d_phase;
     // banded first launch: -1 auto, 0 off, >0 lanes each side; fallback list buffer
     int band_setting = -1;
-    int band_target_wgs = 12;
+    int band_target_wgs = 14;
     DevBuf d_fb;
 };
 
@@ -167,16 +167,21 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
     A.band_lanes = 0; A.reserved = 0; A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
     if (g.band_lanes > 0) {
         if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
-        if ((rc = ensure(ctx, ctx->d_fb, 16 + A.n_tasks * sizeof(uint32_t)))) return rc;
-        uint32_t* fb_count = (uint32_t*)ctx->d_fb.p;
-        uint32_t* fb_list = fb_count + 4;
-        HIPCHK(ctx, hipMemsetAsync(fb_count, 0, 16, s));
+        if ((rc = ensure(ctx, ctx->d_fb, 32 + A.n_tasks * sizeof(uint32_t)))) return rc;
+        uint32_t* fb_count = (uint32_t*)ctx->d_fb.p;             // [0] fallback count, [2..3] work counter (banded), [4..5] work counter (full)
+        uint32_t* fb_list = fb_count + 8;
+        HIPCHK(ctx, hipMemsetAsync(fb_count, 0, 32, s));
+        A.work_counter = (unsigned long long*)(fb_count + 2);
         A.band_lanes = g.band_lanes; A.fb_count = fb_count; A.fb_list = fb_list;
         if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
         // the tasks whose traceback left the band, redone with the full pointer plane (usually a handful; an empty list costs one tiny launch)
         A.band_lanes = 0; A.task_list = fb_list; A.task_count = fb_count;
+        A.work_counter = (unsigned long long*)(fb_count + 4);
         if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;
     } else {
+        if ((rc = ensure(ctx, ctx->d_fb, 32))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_fb.p, 0, 32, s));
+        A.work_counter = (unsigned long long*)((uint32_t*)ctx->d_fb.p + 2);
         if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;
     }
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(tl.b, s)); ctx->timed.push_back(tl); }

@@ -12,6 +12,7 @@
 #define C2_INVALID_CODE 255
 #define C2_PTR_PAD 2               // halfword padding of one pointer column (breaks the 128-B bank stride)
 #define C2_LANES 64
+#define C2_TASK_CHUNK 4              // tasks a workgroup takes per atomic
 #define C2_STATUS_NEED_FULL 64     // internal: banded launch could not finish the traceback; the full-plane launch overwrites the record
 
 // Device-resident description of one reference amplicon.
@@ -50,6 +51,7 @@ typedef struct c2_align_args {
     uint32_t* fb_list;            // ... and their task indices (capacity n_tasks)
     const uint32_t* task_list;    // full kernel, second launch: run only these tasks (NULL = tasks 0..n_tasks-1)
     const uint32_t* task_count;   // device-resident length of task_list
+    unsigned long long* work_counter; // device counter the workgroups pull task chunks from; zero before every launch
     unsigned long long* phase_cycles; // optional: 4 counters of per-phase shader cycles (profiling), else NULL
 } c2_align_args;
 

@@ -296,8 +296,23 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
     int cur_ref = -1;
     int Li = 0, g0 = 0;
 
+    // Work distribution: workgroups pull chunks of C2_TASK_CHUNK consecutive tasks from a device counter (one returning
+    // atomic per chunk), so a launch never waits for the slowest statically assigned share and does not depend on how
+    // many workgroups are actually resident.
     const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : A.n_tasks;
-    for (uint64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    uint64_t chunk_base = 0;
+    int chunk_left = 0;
+    for (;;) {
+        if (chunk_left == 0) {
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(A.work_counter, (unsigned long long)C2_TASK_CHUNK);
+            chunk_base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+            chunk_left = C2_TASK_CHUNK;
+        }
+        const uint64_t it = chunk_base;
+        if (it >= n_iter) break;
+        ++chunk_base; --chunk_left;
         const uint64_t task = A.task_list ? (uint64_t)A.task_list[it] : it;
         uint64_t read_id;
         int ref_id;

@@ -49,6 +49,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     // banded first launch (if asked for and the reference fits one pass), then the full-plane launch over the fallback list
     std::vector<uint32_t> fb_list(A.n_tasks ? A.n_tasks : 1);
     uint32_t fb_count = 0;
+    unsigned long long work_counter = 0;
+    A.work_counter = &work_counter;
     A.band_lanes = 0; A.reserved = 0; A.fb_count = &fb_count; A.fb_list = fb_list.data(); A.task_list = nullptr; A.task_count = nullptr;
     if (grid == 0) grid = (unsigned)std::min<uint64_t>(A.n_tasks, 3);
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
@@ -63,6 +65,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             default: emu::launch(grid, [&] { c2_align_classify_kernel<4, true>(A); }); break;
         }
         A.task_list = fb_list.data(); A.task_count = &fb_count;
+        work_counter = 0;
         if (n_fallback) *n_fallback = (int)fb_count;
     } else if (n_fallback) *n_fallback = -1;
     const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, C2_LANES);
