@@ -86,10 +86,19 @@ def main():
     d_aln_ref = torch.empty((n, stride), dtype=torch.uint8, device=dev)
     d_records = torch.empty((n, 32), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    # per-amplicon count tensor (CRISPRessoCORE.py:3865-4115 on the device) -- the only thing the GPUs exchange
+    from crispresso2_amd import counts as C
+    layout = C.CountLayout(1, L, L)
+    d_counts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
+    min_matches = C.min_matches_table([60.0], 2 * L)          # --default_min_aln_score 60
 
     def step():
         al.align_device(n, d_reads.data_ptr(), d_offsets.data_ptr(), d_aln_read.data_ptr(), d_aln_ref.data_ptr(),
                         d_records.data_ptr(), stride, L, stream=stream)
+        d_counts.zero_()
+        C.accumulate_device(ctx, layout, n, d_aln_read.data_ptr(), d_aln_ref.data_ptr(), stride, d_records.data_ptr(),
+                            d_counts.data_ptr(), min_matches=min_matches, stream=stream)
+        C.all_reduce(d_counts)
 
     def fence():
         torch.cuda.synchronize()
@@ -139,6 +148,7 @@ def main():
                 break
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
+    tallies = layout.unpack(d_counts.cpu().numpy(), 0, L)
 
     if rank == 0:
         total_reads = world * n * args.steps
@@ -173,6 +183,9 @@ def main():
                      "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS},
             "cpu_baseline": cpu_baseline,
             "checks": {"all_status_ok": ok_status, "oracle_sample_identical": parity, "oracle_sample": args.check},
+            "counts": {"reads_aligned_all_gpus": tallies["counts_total"], "modified": tallies["counts_modified"],
+                       "unmodified": tallies["counts_unmodified"], "with_insertion": tallies["counts_insertion"],
+                       "with_deletion": tallies["counts_deletion"], "with_substitution": tallies["counts_substitution"]},
             "host": {"cpus": ncpu, "data_generation_s": t_gen},
         }
         if cpu_baseline:

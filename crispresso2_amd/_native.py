@@ -20,7 +20,7 @@ SYMBOLS = [
     "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
-    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info",
+    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_count_vectors_device",
 ]
 
 REC_DTYPE = np.dtype([

@@ -1,0 +1,99 @@
+"""Per-amplicon count tensor: layout, device accumulation and multi-GPU reduction.
+
+The tensor holds, per reference amplicon, what the reference's "Quantifying indels/substitutions" loop builds in Python
+dicts of numpy vectors (CRISPRessoCORE.py:3865-3901 initialised, :3964-4115 filled) plus process_fastq's aln_stats
+(:1974-1979).  c2_count_vectors_kernel fills it on the GPU from the aligned strings that are already in HBM; across GPUs it
+is summed with ONE all-reduce (RCCL over xGMI) -- the only exchange step of the sharded path (reads are independent).
+"""
+import ctypes
+
+import numpy as np
+
+N_VECTORS, N_SCALARS, N_HISTS = 20, 24, 4
+VECTORS = ["all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
+           "all_substitution_count_vectors", "insertion_count_vectors", "deletion_count_vectors",
+           "substitution_count_vectors",
+           "all_substitution_base_vectors_A", "all_substitution_base_vectors_C", "all_substitution_base_vectors_G",
+           "all_substitution_base_vectors_T", "all_substitution_base_vectors_N",
+           "all_base_count_vectors_A", "all_base_count_vectors_C", "all_base_count_vectors_G", "all_base_count_vectors_T",
+           "all_base_count_vectors_N", "all_base_count_vectors_-",
+           "insertion_length_vectors", "deletion_length_vectors"]
+SCALARS = ["counts_total", "counts_modified", "counts_unmodified", "counts_discarded", "counts_insertion", "counts_deletion",
+           "counts_substitution", "counts_only_insertion", "counts_only_deletion", "counts_only_substitution",
+           "counts_insertion_and_deletion", "counts_insertion_and_substitution", "counts_deletion_and_substitution",
+           "counts_insertion_and_deletion_and_substitution",
+           "N_GLOBAL_SUBS", "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS",
+           "alignments_counted"]
+HISTS = ["inserted_n", "deleted_n", "substituted_n", "effective_len"]
+FLAG_IGNORE_SUBSTITUTIONS, FLAG_IGNORE_INSERTIONS, FLAG_IGNORE_DELETIONS, FLAG_DISCARD_INDEL_READS = 1, 2, 4, 8
+assert len(VECTORS) == N_VECTORS and len(HISTS) == N_HISTS
+
+
+class CountLayout:
+    def __init__(self, n_refs, lmax, max_read_len):
+        self.n_refs, self.lmax = int(n_refs), int(lmax)
+        self.hl = self.lmax + int(max_read_len) + 2
+        self.vl = self.lmax + 1
+        self.per_ref = N_VECTORS * self.vl + N_SCALARS + N_HISTS * self.hl
+
+    def shape(self):
+        return (self.n_refs, self.per_ref)
+
+    def unpack(self, counts, ref, ref_len=None):
+        """counts: int64 array [n_refs, per_ref] (numpy).  -> dict name -> vector (length ref_len) / int / histogram dict"""
+        row = np.asarray(counts)[ref]
+        L = self.lmax if ref_len is None else int(ref_len)
+        out = {}
+        for k, name in enumerate(VECTORS):
+            out[name] = row[k * self.vl:k * self.vl + L].copy()
+        base = N_VECTORS * self.vl
+        for k, name in enumerate(SCALARS):
+            out[name] = int(row[base + k])
+        base += N_SCALARS
+        for k, name in enumerate(HISTS):
+            h = row[base + k * self.hl:base + (k + 1) * self.hl]
+            out[name] = {int(i): int(h[i]) for i in np.nonzero(h)[0]}
+        return out
+
+
+def min_matches_table(min_aln_scores, max_t):
+    """uint16 [n_refs, max_t+1]: for every alignment length T, the smallest `matches` with
+    round(100*matches/float(T), 3) > min_aln_score -- the reference's own expression (CRISPResso2Align.pyx:433-434,
+    CRISPRessoCORE.py:697), evaluated here so the device only compares integers."""
+    tab = np.zeros((len(min_aln_scores), max_t + 1), dtype=np.uint16)
+    for r, thr in enumerate(min_aln_scores):
+        for T in range(1, max_t + 1):
+            lo, hi = 0, T + 1                      # the score is monotone in matches
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if round(100 * mid / float(T), 3) > thr:
+                    hi = mid
+                else:
+                    lo = mid + 1
+            tab[r, T] = min(lo, 65535)
+        tab[r, 0] = 65535
+    return tab
+
+
+def accumulate_device(ctx, layout, n_tasks, d_aln_read, d_aln_ref, aln_stride, d_records, d_counts, d_weights=None,
+                      min_matches=None, flags=0, stream=None):
+    """Enqueue c2_count_vectors_kernel.  d_* are device addresses; min_matches is a host uint16 table or None."""
+    mm = None
+    max_t = 0
+    if min_matches is not None:
+        mm = np.ascontiguousarray(min_matches, dtype=np.uint16)
+        max_t = mm.shape[1] - 1
+    rc = ctx.lib.c2_count_vectors_device(
+        ctx.handle, ctypes.c_uint64(n_tasks), ctypes.c_void_p(d_aln_read), ctypes.c_void_p(d_aln_ref),
+        ctypes.c_uint32(aln_stride), ctypes.c_void_p(d_records), ctypes.c_void_p(d_weights or 0),
+        mm.ctypes.data_as(ctypes.c_void_p) if mm is not None else None, int(max_t), int(flags), int(layout.hl),
+        ctypes.c_void_p(d_counts), ctypes.c_void_p(stream or 0))
+    ctx.check(rc, "c2_count_vectors_device")
+
+
+def all_reduce(counts_tensor):
+    """Sum the per-GPU count tensors over all ranks (RCCL all-reduce; a no-op for a single process)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(counts_tensor, op=dist.ReduceOp.SUM)
+    return counts_tensor

@@ -60,6 +60,7 @@ struct c2_ctx {
     int band_setting = -1;
     int band_target_wgs = 14;
     DevBuf d_fb;
+    DevBuf d_cnt;          // count kernel: work counter + min_matches table
 };
 
 namespace {
@@ -255,7 +256,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt};
     for (DevBuf* b : all) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -453,6 +454,48 @@ int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
     HIPCHK(ctx, hipMemcpyAsync(b->aln_ref, d.aln_ref, n_tasks * (uint64_t)b->aln_stride, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(b->records, d.records, n_tasks * sizeof(c2_aln_record), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
+    return 0;
+}
+
+int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_read, const uint8_t* d_aln_ref,
+                            uint32_t aln_stride, const c2_aln_record* d_records, const uint32_t* d_weights,
+                            const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
+                            int64_t* d_counts, void* hip_stream) {
+    if (!ctx || !d_aln_read || !d_aln_ref || !d_records || !d_counts) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
+    if (ctx->n_refs <= 0) { ctx->err = "references must be set first"; return C2_E_STATE; }
+    static_assert(C2_CNT_VECTORS == C2_COUNT_VECTORS && C2_CNT_SCALARS == C2_COUNT_SCALARS && C2_CNT_HISTS == C2_COUNT_HISTS, "count layout");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    if (n_tasks == 0) return 0;
+    const int lmax = ctx->max_li;
+    if (hl < lmax + 2) { ctx->err = "hl too small"; return C2_E_INVALID; }
+    const size_t per_ref = (size_t)C2_CNT_VECTORS * (lmax + 1) + C2_CNT_SCALARS + (size_t)C2_CNT_HISTS * hl;
+    const size_t lds = per_ref * sizeof(int);
+    if (lds > 163840) { ctx->err = "count block does not fit LDS"; return C2_E_TOO_LARGE; }
+    int rc;
+    c2_count_args A;
+    A.min_matches = nullptr;
+    size_t o_tbl = 64;
+    const size_t tbl_bytes = h_min_matches ? (size_t)ctx->n_refs * (size_t)(max_t + 1) * sizeof(uint16_t) : 0;
+    if ((rc = ensure(ctx, ctx->d_cnt, o_tbl + tbl_bytes))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt.p, 0, 64, s));
+    if (h_min_matches) {
+        HIPCHK(ctx, hipMemcpyAsync((uint8_t*)ctx->d_cnt.p + o_tbl, h_min_matches, tbl_bytes, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));      // the table is caller-owned pageable memory
+        A.min_matches = (const uint16_t*)((uint8_t*)ctx->d_cnt.p + o_tbl);
+    }
+    A.aln_read = d_aln_read; A.aln_ref = d_aln_ref; A.records = d_records; A.weights = d_weights;
+    A.refs = (const c2_dev_ref*)ctx->d_refdesc.p; A.counts = (long long*)d_counts;
+    A.work_counter = (unsigned long long*)ctx->d_cnt.p;
+    A.n_tasks = n_tasks; A.aln_stride = aln_stride; A.n_refs = ctx->n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_count_vectors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    int nb = 1;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_count_vectors_kernel, 64, lds));
+    if (nb < 1) nb = 1;
+    const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)nb;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_tasks + 31) / 32, resident));
+    hipLaunchKernelGGL(c2_count_vectors_kernel, dim3(grid), dim3(64), lds, s, A);
+    HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 

@@ -68,3 +68,47 @@ typedef struct c2_classify_args {
     int32_t* list_len;            // C2_LIST_COUNT true lengths (may exceed cap: caller retries)
     int64_t* counts;              // insertion_n, deletion_n, substitution_n
 } c2_classify_args;
+
+// ---- per-amplicon count tensor (what CRISPRessoCORE.py:3865-3901 keeps per reference and :4016-4115 fills) ----
+// One int64 block per reference: C2_CNT_VECTORS vectors of (lmax + 1) entries, then C2_CNT_SCALARS scalars,
+// then C2_CNT_HISTS histograms of hl entries.  crispresso2_amd/counts.py names the slices.
+enum {
+    C2_V_ALL_INSERTION = 0, C2_V_ALL_INSERTION_LEFT, C2_V_ALL_DELETION, C2_V_ALL_SUBSTITUTION,
+    C2_V_INSERTION, C2_V_DELETION, C2_V_SUBSTITUTION,
+    C2_V_ALL_SUB_BASE_A, C2_V_ALL_SUB_BASE_C, C2_V_ALL_SUB_BASE_G, C2_V_ALL_SUB_BASE_T, C2_V_ALL_SUB_BASE_N,
+    C2_V_BASE_A, C2_V_BASE_C, C2_V_BASE_G, C2_V_BASE_T, C2_V_BASE_N, C2_V_BASE_GAP,
+    C2_V_INSERTION_LENGTH, C2_V_DELETION_LENGTH,
+    C2_CNT_VECTORS
+};
+enum {
+    C2_S_TOTAL = 0, C2_S_MODIFIED, C2_S_UNMODIFIED, C2_S_DISCARDED, C2_S_INSERTION, C2_S_DELETION, C2_S_SUBSTITUTION,
+    C2_S_ONLY_INSERTION, C2_S_ONLY_DELETION, C2_S_ONLY_SUBSTITUTION, C2_S_INSERTION_AND_DELETION,
+    C2_S_INSERTION_AND_SUBSTITUTION, C2_S_DELETION_AND_SUBSTITUTION, C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION,
+    C2_S_N_GLOBAL_SUBS, C2_S_N_SUBS_OUTSIDE_WINDOW, C2_S_N_MODS_IN_WINDOW, C2_S_N_MODS_OUTSIDE_WINDOW,
+    C2_S_N_READS_IRREGULAR_ENDS, C2_S_ALIGNMENTS_COUNTED, C2_S_RESERVED0, C2_S_RESERVED1, C2_S_RESERVED2, C2_S_RESERVED3,
+    C2_CNT_SCALARS
+};
+enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_LEN, C2_CNT_HISTS };
+
+#define C2_CNT_FLAG_IGNORE_SUBSTITUTIONS 1
+#define C2_CNT_FLAG_IGNORE_INSERTIONS 2
+#define C2_CNT_FLAG_IGNORE_DELETIONS 4
+#define C2_CNT_FLAG_DISCARD_INDEL_READS 8
+
+typedef struct c2_count_args {
+    const uint8_t* aln_read;      // n_tasks x aln_stride (outputs of the align kernel)
+    const uint8_t* aln_ref;
+    const c2_aln_record* records;
+    const uint32_t* weights;      // per task read multiplicity; 0 = not counted; NULL = 1
+    const uint16_t* min_matches;  // n_refs x (max_t + 1): smallest `matches` whose score exceeds refs[name]['min_aln_score'], or NULL
+    const c2_dev_ref* refs;
+    long long* counts;            // n_refs x per_ref int64, accumulated into (caller zeroes)
+    unsigned long long* work_counter;
+    uint64_t n_tasks;
+    uint32_t aln_stride;
+    int32_t n_refs;
+    int32_t lmax;                 // longest reference
+    int32_t hl;                   // histogram length (>= longest reference + longest read + 1)
+    int32_t max_t;                // longest alignment the min_matches table covers
+    int32_t flags;                // C2_CNT_FLAG_*
+} c2_count_args;

@@ -718,3 +718,208 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
     const unsigned long long m = __ballot(lane % 3 == 0);
     out[128 + lane] = __popcll(m) + (lane == 0 ? __builtin_ctzll(~m) : 0);
 }
+
+// =====================================================================================
+// Per-amplicon count vectors: the device side of the reference's "Quantifying indels/substitutions"
+// loop (CRISPRessoCORE.py:3964-4115, non-coding case) and of process_fastq's aln_stats (:1974-1979).
+// Input: the aligned strings and records the align kernel left in HBM, plus per-task weights
+// (read multiplicity; 0 = read not assigned to this reference).  One wavefront per alignment;
+// every workgroup accumulates into a private int32 copy of one reference's block in LDS (ds_add),
+// and flushes it to the int64 tensor in HBM with one atomic per non-zero entry.  The tensor is what
+// the multi-GPU path reduces with one RCCL all-reduce.
+// =====================================================================================
+__device__ __forceinline__ int c2_wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void c2_count_vectors_kernel(c2_count_args A)
+{
+    const int lane = threadIdx.x;
+    int* acc = (int*)c2_smem;
+    const int VL = A.lmax + 1;                                  // vector length incl. the end slot of the difference arrays
+    const int o_sc = C2_CNT_VECTORS * VL, o_h = o_sc + C2_CNT_SCALARS;
+    const int per_ref = o_h + C2_CNT_HISTS * A.hl;
+    for (int k = lane; k < per_ref; k += 64) acc[k] = 0;
+    __syncthreads();
+    const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
+    const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int cur_ref = -1;
+    long long wsum = 0;                                         // weight accumulated since the last flush (int32 safety)
+    const uint16_t* incp = nullptr;
+    int Li = 0;
+
+    // flush the LDS block of cur_ref into the int64 tensor
+    auto flush = [&]() {
+        if (cur_ref < 0) return;
+        __syncthreads();
+        // deletion vectors were accumulated as difference arrays (start += x, end -= x): integrate them first
+        for (int v = 0; v < 2; ++v) {
+            int* d = acc + (v == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
+            int carry = 0;
+            for (int base = 0; base < VL; base += 64) {
+                const int k = base + lane;
+                const int x = (k < VL) ? d[k] : 0;
+                const int s = c2_wave_incl_scan(x, lane) + carry;
+                if (k < VL) d[k] = s;
+                carry = __shfl(s, 63);
+            }
+        }
+        __syncthreads();
+        long long* out = A.counts + (size_t)cur_ref * per_ref;
+        for (int k = lane; k < per_ref; k += 64) {
+            const int x = acc[k];
+            if (x != 0) { atomicAdd((unsigned long long*)(out + k), (unsigned long long)(long long)x); acc[k] = 0; }
+        }
+        wsum = 0;
+        __syncthreads();
+    };
+
+    uint64_t chunk_base = 0;
+    int chunk_left = 0;
+    for (;;) {
+        if (chunk_left == 0) {
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(A.work_counter, (unsigned long long)(8 * C2_TASK_CHUNK));
+            chunk_base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+            chunk_left = 8 * C2_TASK_CHUNK;
+        }
+        const uint64_t task = chunk_base;
+        if (task >= A.n_tasks) break;
+        ++chunk_base; --chunk_left;
+
+        const c2_aln_record rec = A.records[task];
+        const int w = A.weights ? (int)A.weights[task] : 1;
+        const int T = rec.aln_len, ref = rec.ref_id;
+        bool sel = (rec.status == 0) && (w > 0) && (T > 0);
+        if (sel && A.min_matches) sel = (T <= A.max_t) && (rec.matches >= A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
+        if (!sel) continue;
+        if (ref != cur_ref || wsum + w > (1ll << 21)) {
+            flush();
+            cur_ref = ref; Li = A.refs[ref].len; incp = A.refs[ref].inc_prefix;
+        }
+        wsum += w;
+        // aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979)
+        const int all_ins = rec.all_insertion_events, all_sub = rec.all_substitutions;
+        const int total_mods = all_ins + rec.all_deletion_bases + all_sub;                       // :741
+        const int in_win = rec.substitution_n + rec.deletion_n + rec.insertion_n;              // :742
+        int* scal = acc + o_sc;                                  // scalar counters: lane 0 adds (LDS, any index)
+        const bool l0 = (lane == 0);
+        if (l0) {
+            atomicAdd(scal + C2_S_N_GLOBAL_SUBS, all_sub * w);
+            atomicAdd(scal + C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - rec.substitution_n) * w);
+            atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
+            atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
+            if (rec.irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
+            atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);
+        }
+        if (discard && (rec.deletion_n > 0 || rec.insertion_n > 0)) { if (l0) atomicAdd(scal + C2_S_DISCARDED, w); continue; }   // :3996-4000
+        const bool modified = (!ign_del && rec.deletion_n > 0) || (!ign_ins && rec.insertion_n > 0) || (!ign_sub && rec.substitution_n > 0);
+        const bool has_ins = !ign_ins && rec.insertion_n > 0, has_del = !ign_del && rec.deletion_n > 0, has_sub = !ign_sub && rec.substitution_n > 0;
+        if (l0) {
+            atomicAdd(scal + C2_S_TOTAL, w);
+            atomicAdd(scal + (modified ? C2_S_MODIFIED : C2_S_UNMODIFIED), w);                  // :746-760, :4003-4006
+            if (has_ins) atomicAdd(scal + C2_S_INSERTION, w);
+            if (has_del) atomicAdd(scal + C2_S_DELETION, w);
+            if (has_sub) atomicAdd(scal + C2_S_SUBSTITUTION, w);
+            int combo = -1;                                                                     // :4058-4072
+            if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
+                                         : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
+            else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
+            else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
+            if (combo >= 0) atomicAdd(scal + combo, w);
+        }
+        const bool len_block = has_ins || has_del || has_sub;                                  // :4085 (no coding sequence)
+        if (lane == 0) {
+            if (!ign_ins) atomicAdd(acc + o_h + C2_H_INSERTED_N * A.hl + rec.insertion_n, w);   // :4020
+            if (!ign_del) atomicAdd(acc + o_h + C2_H_DELETED_N * A.hl + rec.deletion_n, w);     // :4030
+            if (!ign_sub) atomicAdd(acc + o_h + C2_H_SUBSTITUTED_N * A.hl + rec.substitution_n, w);   // :4043
+            const int eff = Li + (ign_ins ? 0 : rec.insertion_n) - (ign_del ? 0 : rec.deletion_n);   // :4010-4037
+            atomicAdd(acc + o_h + C2_H_EFFECTIVE_LEN * A.hl + eff, w);
+        }
+        // ---- column walk (same scan as the fused classifier), ds_add into the vectors
+        const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride;
+        const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride;
+        int idx_base = 0, last_rf = -1, last_rd = -1;
+        bool last_rf_close = false, last_rf_wclose = false;
+        for (int base = 0; base < T; base += 64) {
+            const int c = base + lane;
+            const bool in = c < T;
+            const unsigned char rd = in ? R_[c] : 0, rfc = in ? F_[c] : 0;
+            const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
+            const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
+            const int idx = idx_base + __popcll(m_rf & lt);
+            const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
+            const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
+            const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
+            if (rf_ng) {
+                int bv = -1;                                                                    // all_base_count, :4075-4081
+                if (rd == 'A') bv = C2_V_BASE_A; else if (rd == 'C') bv = C2_V_BASE_C; else if (rd == 'G') bv = C2_V_BASE_G;
+                else if (rd == 'T') bv = C2_V_BASE_T; else if (rd == 'N') bv = C2_V_BASE_N; else if (rd == '-') bv = C2_V_BASE_GAP;
+                if (bv >= 0) atomicAdd(acc + bv * VL + idx, w);
+                if (!rd_ng) atomicAdd(acc + C2_V_ALL_DELETION * VL + idx, w);                   // :4028
+            }
+            const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
+            if (sub) {
+                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + idx, w);                           // :4040
+                if (!ign_sub) {
+                    if (incp[idx + 1] != incp[idx]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + idx, w);   // :4044
+                    int sv = -1;                                                                // :4049-4054
+                    if (rd == 'A') sv = C2_V_ALL_SUB_BASE_A; else if (rd == 'C') sv = C2_V_ALL_SUB_BASE_C;
+                    else if (rd == 'G') sv = C2_V_ALL_SUB_BASE_G; else if (rd == 'T') sv = C2_V_ALL_SUB_BASE_T;
+                    if (sv >= 0) atomicAdd(acc + sv * VL + idx, w);
+                }
+            }
+            // insertions: positions [idx-1, idx] of every event; numpy's fancy += counts a repeated position once (:4016, :4021)
+            const bool ins_close = rf_ng && (prev_rf != c - 1) && idx > 0;
+            const bool ins_win = ins_close && (incp[idx] != incp[idx - 1]) && (incp[idx + 1] != incp[idx]);
+            const unsigned long long m_ic = __ballot(ins_close), m_iw = __ballot(ins_win);
+            if (ins_close) {
+                const bool prev_close = (prev_rf >= base) ? ((m_ic >> (prev_rf - base)) & 1ull) : last_rf_close;
+                const bool prev_wclose = (prev_rf >= base) ? ((m_iw >> (prev_rf - base)) & 1ull) : last_rf_wclose;
+                atomicAdd(acc + C2_V_ALL_INSERTION_LEFT * VL + idx - 1, w);                     // :4017
+                atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx, w);
+                if (!prev_close) atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx - 1, w);
+                if (ins_win) {
+                    if (!ign_ins) {
+                        atomicAdd(acc + C2_V_INSERTION * VL + idx, w);
+                        if (!prev_wclose) atomicAdd(acc + C2_V_INSERTION * VL + idx - 1, w);
+                    }
+                    if (len_block) {                                                            // :4104-4106 (scalar index: repeats add twice)
+                        const int sz = (c - 1 - prev_rf) * w;
+                        atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx - 1, sz);
+                        atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx, sz);
+                    }
+                }
+            }
+            // deletions that touch the window: range(start, end) as a difference array (integrated in flush)
+            const bool del_close = rd_ng && (prev_rd != c - 1);
+            if (del_close) {
+                const int dlen = c - 1 - prev_rd;
+                if (incp[idx] != incp[idx - dlen]) {
+                    if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + idx - dlen, w); atomicAdd(acc + C2_V_DELETION * VL + idx, -w); }   // :4031
+                    if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx - dlen, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx, -dlen * w); }   // :4114
+                }
+            }
+            idx_base += __popcll(m_rf);
+            if (m_rf) {
+                const int hi = 63 - __clzll((long long)m_rf);
+                last_rf = base + hi;
+                last_rf_close = (m_ic >> hi) & 1ull;
+                last_rf_wclose = (m_iw >> hi) & 1ull;
+            }
+            if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
+        }
+        if (last_rd != T - 1 && lane == 0) {                                                    // trailing deletion, pyx:155-162
+            const int dlen = T - 1 - last_rd;
+            if (incp[idx_base] != incp[idx_base - dlen]) {
+                if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + idx_base - dlen, w); atomicAdd(acc + C2_V_DELETION * VL + idx_base, -w); }
+                if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx_base - dlen, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx_base, -dlen * w); }
+            }
+        }
+    }
+    flush();
+}

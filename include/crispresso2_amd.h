@@ -135,6 +135,28 @@ int c2_timing_read(c2_ctx* ctx, double* total_ms, int64_t* launches, int reset);
 int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, int32_t* passes,
                    int32_t* lds_bytes, int32_t* workgroups_per_cu, int32_t* compute_units);
 
+/* ---- per-amplicon count tensor: the device side of CRISPRessoCORE.py:3964-4115 (+ aln_stats :1974-1979) ------------
+ * One int64 block per reference: C2_COUNT_VECTORS vectors of (lmax+1) entries [lmax = longest reference], then
+ * C2_COUNT_SCALARS scalars, then C2_COUNT_HISTS histograms of `hl` entries (hl >= longest reference + longest read + 1).
+ * crispresso2_amd/counts.py names every slice.  The tensor is ACCUMULATED into (zero it first), so batches and streams
+ * add up, and it is what the multi-GPU path sums with one RCCL all-reduce. */
+#define C2_COUNT_VECTORS 20
+#define C2_COUNT_SCALARS 24
+#define C2_COUNT_HISTS 4
+#define C2_COUNT_IGNORE_SUBSTITUTIONS 1   /* --ignore_substitutions */
+#define C2_COUNT_IGNORE_INSERTIONS    2   /* --ignore_insertions */
+#define C2_COUNT_IGNORE_DELETIONS     4   /* --ignore_deletions */
+#define C2_COUNT_DISCARD_INDEL_READS  8   /* --discard_indel_reads */
+
+/* All d_* are device pointers (outputs of c2_align_classify_batch_device); d_weights: per task read multiplicity, 0 = do not
+ * count this alignment, NULL = 1.  h_min_matches: HOST table n_refs x (max_t+1) of the smallest `matches` whose score
+ * round(100*matches/len,3) exceeds refs[name]['min_aln_score'] for each alignment length (CRISPRessoCORE.py:697), or NULL
+ * to count every alignment with weight > 0.  d_counts: n_refs x per_ref int64.  Enqueued on hip_stream. */
+int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_read, const uint8_t* d_aln_ref,
+                            uint32_t aln_stride, const c2_aln_record* d_records, const uint32_t* d_weights,
+                            const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
+                            int64_t* d_counts, void* hip_stream);
+
 /* Pointer-plane banding of the batch kernel (a pure performance knob; results never depend on it).
  * band_lanes: -1 automatic (default), 0 off, n > 0 keep the pointer words of n lanes on each side of the main diagonal.
  * Alignments whose traceback leaves the band are redone in the same call by the full-plane kernel.

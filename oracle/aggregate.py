@@ -1,0 +1,102 @@
+"""CPU restatement of the reference's per-amplicon aggregation -- TEST INFRASTRUCTURE ONLY.
+
+Follows CRISPRessoCORE.py:3964-4115 (the "Quantifying indels/substitutions" loop, non-coding case: no exons) and
+process_fastq's aln_stats (:1974-1979), taking per-read classifier payloads (the reference's / the oracle's
+find_indels_substitutions output) and read multiplicities.  Returns plain numpy vectors keyed by the reference's names."""
+from collections import Counter
+
+import numpy as np
+
+
+def aggregate(items, ref_len, ignore_substitutions=False, ignore_insertions=False, ignore_deletions=False,
+              discard_indel_reads=False):
+    """items: iterable of (payload dict incl. 'aln_seq', count)."""
+    L = ref_len
+    v = {k: np.zeros(L) for k in (
+        "all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
+        "all_substitution_count_vectors", "insertion_count_vectors", "deletion_count_vectors", "substitution_count_vectors",
+        "insertion_length_vectors", "deletion_length_vectors")}
+    for n in "ACGTN":
+        v["all_substitution_base_vectors_" + n] = np.zeros(L)
+    for n in "ACGTN-":
+        v["all_base_count_vectors_" + n] = np.zeros(L)
+    s = Counter()
+    h = {k: Counter() for k in ("inserted_n", "deleted_n", "substituted_n", "effective_len")}
+    for p, count in items:
+        # aln_stats, CRISPRessoCORE.py:1974-1979 (payload fields of :734-744)
+        all_ins = len(p["all_insertion_positions"]) // 2
+        subs_out = len(p["all_substitution_positions"]) - len(p["substitution_positions"])
+        total_mods = all_ins + len(p["all_deletion_positions"]) + len(p["all_substitution_positions"])
+        in_win = p["substitution_n"] + p["deletion_n"] + p["insertion_n"]
+        s["N_GLOBAL_SUBS"] += (p["substitution_n"] + subs_out) * count
+        s["N_SUBS_OUTSIDE_WINDOW"] += subs_out * count
+        s["N_MODS_IN_WINDOW"] += in_win * count
+        s["N_MODS_OUTSIDE_WINDOW"] += (total_mods - in_win) * count
+        s1, s2 = p["aln_seq"], p["aln_ref"]
+        if (s1[0] == "-" or s2[0] == "-" or s1[0] != s2[0]) or (s1[-1] == "-" or s2[-1] == "-" or s1[-1] != s2[-1]):
+            s["N_READS_IRREGULAR_ENDS"] += count
+        s["alignments_counted"] += 1
+        if discard_indel_reads and (p["deletion_n"] > 0 or p["insertion_n"] > 0):      # :3996-4000
+            s["counts_discarded"] += count
+            continue
+        s["counts_total"] += count
+        modified = ((not ignore_deletions and p["deletion_n"] > 0) or (not ignore_insertions and p["insertion_n"] > 0)
+                    or (not ignore_substitutions and p["substitution_n"] > 0))          # :746-760
+        s["counts_modified" if modified else "counts_unmodified"] += count
+        eff = L
+        has_ins = has_del = has_sub = False
+        v["all_insertion_count_vectors"][p["all_insertion_positions"]] += count          # :4016 (fancy +=: repeats count once)
+        v["all_insertion_left_count_vectors"][p["all_insertion_left_positions"]] += count
+        if not ignore_insertions:
+            h["inserted_n"][p["insertion_n"]] += count
+            v["insertion_count_vectors"][p["insertion_positions"]] += count
+            eff += p["insertion_n"]
+            if p["insertion_n"] > 0:
+                s["counts_insertion"] += count
+                has_ins = True
+        v["all_deletion_count_vectors"][p["all_deletion_positions"]] += count
+        if not ignore_deletions:
+            h["deleted_n"][p["deletion_n"]] += count
+            v["deletion_count_vectors"][p["deletion_positions"]] += count
+            eff -= p["deletion_n"]
+            if p["deletion_n"] > 0:
+                s["counts_deletion"] += count
+                has_del = True
+        h["effective_len"][eff] += count
+        v["all_substitution_count_vectors"][p["all_substitution_positions"]] += count
+        if not ignore_substitutions:
+            h["substituted_n"][p["substitution_n"]] += count
+            v["substitution_count_vectors"][p["substitution_positions"]] += count
+            if p["substitution_n"] > 0:
+                s["counts_substitution"] += count
+                has_sub = True
+            for nuc in "ATCGN":                                                          # :4048-4054
+                locs = [q for q, b in zip(p["all_substitution_positions"], p["all_substitution_values"]) if b == nuc]
+                if locs:
+                    v["all_substitution_base_vectors_" + nuc][locs] += count
+        if has_del:                                                                      # :4058-4072
+            s["counts_insertion_and_deletion_and_substitution" if (has_ins and has_sub) else
+              "counts_insertion_and_deletion" if has_ins else
+              "counts_deletion_and_substitution" if has_sub else "counts_only_deletion"] += count
+        elif has_ins:
+            s["counts_insertion_and_substitution" if has_sub else "counts_only_insertion"] += count
+        elif has_sub:
+            s["counts_only_substitution"] += count
+        for c, rp in zip(s1, p["ref_positions"]):                                        # :4075-4081
+            if rp >= 0:
+                v["all_base_count_vectors_" + c][rp] += count
+        if has_ins or has_del or has_sub:                                                # :4085, :4104-4115
+            for (a, b), sz in zip(p["insertion_coordinates"], p["insertion_sizes"]):
+                v["insertion_length_vectors"][a] += sz * count
+                v["insertion_length_vectors"][b] += sz * count
+            for (a, b), sz in zip(p["deletion_coordinates"], p["deletion_sizes"]):
+                v["deletion_length_vectors"][list(range(a, b))] += sz * count
+    out = {k: x.astype(np.int64) for k, x in v.items()}
+    out.update({k: int(s[k]) for k in (
+        "counts_total", "counts_modified", "counts_unmodified", "counts_discarded", "counts_insertion", "counts_deletion",
+        "counts_substitution", "counts_only_insertion", "counts_only_deletion", "counts_only_substitution",
+        "counts_insertion_and_deletion", "counts_insertion_and_substitution", "counts_deletion_and_substitution",
+        "counts_insertion_and_deletion_and_substitution", "N_GLOBAL_SUBS", "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW",
+        "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS", "alignments_counted")})
+    out.update({k: {int(a): int(b) for a, b in c.items() if b} for k, c in h.items()})
+    return out

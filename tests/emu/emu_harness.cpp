@@ -92,5 +92,27 @@ int emu_classify_lists(const uint8_t* read_al, const uint8_t* ref_al, int n, con
     return 0;
 }
 
+int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t aln_stride,
+                      const c2_aln_record* records, const uint32_t* weights, const uint16_t* min_matches, int max_t,
+                      int n_refs, const int32_t* lens, const int32_t* const* include_idx, const int32_t* n_include,
+                      int flags, int hl, long long* counts, unsigned grid)
+{
+    std::vector<c2_dev_ref> refs(n_refs);
+    std::vector<std::vector<uint16_t>> incp(n_refs);
+    int lmax = 1;
+    for (int r = 0; r < n_refs; ++r) {
+        c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
+        refs[r].seq = nullptr; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].len = lens[r]; refs[r].reserved = 0;
+        lmax = std::max(lmax, lens[r]);
+    }
+    unsigned long long wc = 0;
+    c2_count_args A;
+    A.aln_read = aln_read; A.aln_ref = aln_ref; A.records = records; A.weights = weights; A.min_matches = min_matches;
+    A.refs = refs.data(); A.counts = counts; A.work_counter = &wc; A.n_tasks = n_tasks; A.aln_stride = aln_stride;
+    A.n_refs = n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
+    emu::launch(grid ? grid : 2, [&] { c2_count_vectors_kernel(A); });
+    return 0;
+}
+
 int emu_selftest(int* out) { emu::launch(1, [&] { c2_selftest_kernel(out); }); return 0; }
 }

@@ -112,10 +112,11 @@ inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)emu::xl
 inline int __shfl(int v, int lane, int width = 64) { (void)width; return (int)(uint32_t)emu::xl_get((uint32_t)v, lane & 63, nullptr); }
 inline int __shfl_xor(int v, int mask, int width = 64) { (void)width; return (int)(uint32_t)emu::xl_get((uint32_t)v, emu::cur_lane ^ mask, nullptr); }
 inline int __shfl_down(int v, unsigned d, int width = 64) { (void)width; int s = emu::cur_lane + (int)d; bool ok; uint64_t r = emu::xl_get((uint32_t)v, s, &ok); return ok ? (int)(uint32_t)r : v; }
+inline int __shfl_up(int v, unsigned d, int width = 64) { (void)width; int s = emu::cur_lane - (int)d; bool ok; uint64_t r = emu::xl_get((uint32_t)v, s, &ok); return ok ? (int)(uint32_t)r : v; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
-template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T, class U> inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
 template <class T> inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 

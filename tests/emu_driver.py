@@ -79,6 +79,8 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
     for k in range(ntasks):
         L = int(rec["aln_len"][k])
         out.append((o1[k, :L].tobytes().decode(), o2[k, :L].tobytes().decode()))
+    if stats is not None:
+        stats["raw"] = (o1, o2)
     return out, rec
 
 
@@ -100,3 +102,29 @@ def classify_lists(read_al, ref_al, include, legacy=False):
             break
         cap = int(lens.max()) + 8
     return [lists[k, :lens[k]].tolist() for k in range(N_LISTS)], counts.tolist()
+
+
+def count_vectors(aln_read, aln_ref, records, ref_lens, includes, max_read_len, weights=None, min_matches=None, flags=0, grid=2):
+    """aln_read/aln_ref: uint8 [n, stride]; records: REC_DTYPE [n].  -> (counts int64 [n_refs, per_ref], layout)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from crispresso2_amd.counts import CountLayout
+    n = len(records)
+    nrefs = len(ref_lens)
+    lay = CountLayout(nrefs, max(ref_lens), max_read_len)
+    counts = np.zeros(lay.shape(), dtype=np.int64)
+    lens = np.array(ref_lens, dtype=np.int32)
+    inc = [np.ascontiguousarray(np.asarray(list(x), dtype=np.int64).astype(np.int32)) for x in includes]
+    ip = (ctypes.c_void_p * nrefs)(*[x.ctypes.data for x in inc])
+    ninc = np.array([len(x) for x in inc], dtype=np.int32)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
+    mm = None if min_matches is None else np.ascontiguousarray(min_matches, dtype=np.uint16)
+    a1 = np.ascontiguousarray(aln_read); a2 = np.ascontiguousarray(aln_ref); rec = np.ascontiguousarray(records)
+    rc = lib().emu_count_vectors(ctypes.c_uint64(n), a1.ctypes.data_as(ctypes.c_void_p), a2.ctypes.data_as(ctypes.c_void_p),
+                                 ctypes.c_uint32(a1.shape[1]), rec.ctypes.data_as(ctypes.c_void_p),
+                                 None if w is None else w.ctypes.data_as(ctypes.c_void_p),
+                                 None if mm is None else mm.ctypes.data_as(ctypes.c_void_p), 0 if mm is None else mm.shape[1] - 1,
+                                 nrefs, lens.ctypes.data_as(ctypes.c_void_p), ip, ninc.ctypes.data_as(ctypes.c_void_p),
+                                 int(flags), int(lay.hl), counts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(grid))
+    assert rc == 0
+    return counts, lay

@@ -1,0 +1,81 @@
+"""c2_count_vectors_kernel (compiled for the host by the wave emulator) against oracle/aggregate.py, the CPU restatement of
+the reference's aggregation loop (CRISPRessoCORE.py:3964-4115) -- CPU only."""
+import numpy as np
+import pytest
+
+import emu_driver as E
+import oracle
+from oracle import aggregate
+from helpers import load_golden, matrices
+from crispresso2_amd import counts as C
+
+
+@pytest.fixture(scope="module")
+def aligned():
+    """realistic.json's 250-bp amplicon reads (incl. adjacent insertions added here), aligned by the emulated kernel."""
+    E.build()
+    mats = matrices()
+    vecs = [v for v in load_golden("realistic.json") if len(v["seqi"]) == 250]
+    amp, g, inc = vecs[0]["seqi"], vecs[0]["gap_incentive"], list(range(100, 150))
+    reads = [v["seqj"] for v in vecs]
+    # two insertions one reference base apart (numpy's fancy += counts the shared position once), a window-edge deletion
+    reads.append(amp[:120] + "TT" + amp[120:121] + "GGG" + amp[121:])
+    reads.append(amp[:95] + amp[103:])
+    reads.append(amp[:-30])
+    st = {}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], mats["EDNAFULL"], -20, -2, stats=st)
+    return amp, inc, reads, res, rec, st["raw"]
+
+
+def payloads(res, inc):
+    out = []
+    for s1, s2 in res:
+        p = oracle.find_indels_substitutions(s1, s2, inc)
+        p["aln_seq"], p["aln_ref"] = s1, s2
+        out.append(p)
+    return out
+
+
+def compare(got, exp, L):
+    for k, v in exp.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(got[k][:L], v), k
+        else:
+            assert got[k] == v, (k, got[k], v)
+
+
+@pytest.mark.parametrize("flags", [0, C.FLAG_IGNORE_SUBSTITUTIONS, C.FLAG_IGNORE_INSERTIONS | C.FLAG_IGNORE_DELETIONS,
+                                   C.FLAG_DISCARD_INDEL_READS])
+def test_count_vectors_match_reference_aggregation(aligned, flags):
+    amp, inc, reads, res, rec, (o1, o2) = aligned
+    rng = np.random.default_rng(1)
+    w = rng.integers(1, 50, len(reads)).astype(np.uint32)
+    w[::11] = 0                                           # reads not assigned to this reference
+    counts, lay = E.count_vectors(o1, o2, rec, [len(amp)], [inc], max(len(r) for r in reads), weights=w, flags=flags)
+    got = lay.unpack(counts, 0, len(amp))
+    items = [(p, int(c)) for p, c in zip(payloads(res, inc), w) if c > 0]
+    exp = aggregate.aggregate(items, len(amp), ignore_substitutions=bool(flags & 1), ignore_insertions=bool(flags & 2),
+                              ignore_deletions=bool(flags & 4), discard_indel_reads=bool(flags & 8))
+    compare(got, exp, len(amp))
+    assert got["counts_total"] + got["counts_discarded"] == int(w.sum())
+
+
+def test_count_vectors_min_alignment_score_gate(aligned):
+    amp, inc, reads, res, rec, (o1, o2) = aligned
+    thr = 97.5
+    mm = C.min_matches_table([thr], int(rec["aln_len"].max()))
+    counts, lay = E.count_vectors(o1, o2, rec, [len(amp)], [inc], max(len(r) for r in reads), min_matches=mm)
+    got = lay.unpack(counts, 0, len(amp))
+    keep = [round(100 * int(r["matches"]) / float(int(r["aln_len"])), 3) > thr for r in rec]
+    assert 0 < sum(keep) < len(keep)
+    exp = aggregate.aggregate([(p, 1) for p, k in zip(payloads(res, inc), keep) if k], len(amp))
+    compare(got, exp, len(amp))
+
+
+def test_min_matches_table_is_the_reference_expression():
+    mm = C.min_matches_table([60.0, 0.0], 300)
+    for T in (1, 7, 64, 255, 300):
+        for thr, row in ((60.0, mm[0]), (0.0, mm[1])):
+            m = int(row[T])
+            assert m > T or round(100 * m / float(T), 3) > thr
+            assert m == 0 or not (round(100 * (m - 1) / float(T), 3) > thr)

@@ -1,0 +1,71 @@
+"""The N > 1 path on CPU: two gloo ranks each count their shard of the alignments (kernel run by the wave emulator, a test
+harness), all-reduce the count tensors, and must end up with the single-process tensor."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import emu_driver as E
+    from helpers import load_golden, matrices
+    from crispresso2_amd import distributed as D
+    D.init("gloo")
+    vecs = [v for v in load_golden("realistic.json") if len(v["seqi"]) == 250]
+    amp, g, inc = vecs[0]["seqi"], vecs[0]["gap_incentive"], vecs[0]["include"]
+    reads = [v["seqj"] for v in vecs]
+    lo, hi = D.my_shard(len(reads))
+    st = {}
+    res, rec = E.align_batch(reads[lo:hi], [amp], [g], [inc], matrices()["EDNAFULL"], -20, -2, stats=st)
+    o1, o2 = st["raw"]
+    counts, lay = E.count_vectors(o1, o2, rec, [len(amp)], [inc], 250)
+    t = torch.from_numpy(counts)
+    D.reduce_counts(t)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "reduced.npy"), t.numpy())
+        res_all, rec_all = E.align_batch(reads, [amp], [g], [inc], matrices()["EDNAFULL"], -20, -2, stats=st)
+        o1, o2 = st["raw"]
+        full, _ = E.count_vectors(o1, o2, rec_all, [len(amp)], [inc], 250)
+        np.save(os.path.join(out_dir, "single.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_count_reduce_equals_single_process(tmp_path):
+    sys.path.insert(0, HERE)
+    import emu_driver as E
+    E.build()                                  # compile once, before the ranks start
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "reduced.npy")
+    b = np.load(tmp_path / "single.npy")
+    assert a.sum() > 0 and np.array_equal(a, b)
+
+
+def test_shard_boundaries_match_reference_semantics():
+    from crispresso2_amd.distributed import shard_boundaries
+    # reference tests/unit_tests/test_CRISPRessoCORE.py:866-980 cases for get_variant_cache_equal_boundaries
+    assert shard_boundaries(100, 4) == [0, 25, 50, 75, 100]
+    assert shard_boundaries(101, 4) == [0, 25, 50, 75, 101]
+    assert shard_boundaries(3, 3) == [0, 1, 2, 3]
+    with pytest.raises(Exception):
+        shard_boundaries(2, 3)

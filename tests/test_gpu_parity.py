@@ -245,6 +245,63 @@ def test_banded_pointer_plane_equals_full_plane(mats, ctx):
     assert outs[2][1]["fallback_tasks_last_launch"] > outs[6][1]["fallback_tasks_last_launch"] > 0
 
 
+def test_count_vectors_device_vs_reference_aggregation(mats, ctx):
+    """c2_count_vectors_kernel on the GPU (fed by the align kernel's outputs in HBM) against oracle/aggregate.py, the CPU
+    restatement of CRISPRessoCORE.py:3964-4115; weights, the min_aln_score gate and the ignore_* / discard flags."""
+    import torch
+    from crispresso2_amd import synth, counts as C
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    from oracle import aggregate
+    m = mats["EDNAFULL"]
+    L, n = 250, 3000
+    amp, g, _ = synth.amplicon_setup(L)
+    inc = list(range(L // 2 - 10, L // 2 + 10))
+    reads = synth.make_reads(L, n)
+    rng = np.random.default_rng(3)
+    reads[::50] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, reads[::50].shape)]     # unrelated: fail the score gate
+    al = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    stride = al.stride_for(L)
+    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    o1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    o2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    rec = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, L, stream=s)
+    torch.cuda.synchronize()
+    from crispresso2_amd import _native
+    records = rec.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+    a1, a2 = o1.cpu().numpy(), o2.cpu().numpy()
+    w = rng.integers(0, 40, n).astype(np.uint32)
+    d_w = torch.from_numpy(w.astype(np.int32)).to(dev)
+    mm = C.min_matches_table([60.0], 2 * L)
+    scores = [round(100 * int(r["matches"]) / float(int(r["aln_len"])), 3) for r in records]
+    assert min(scores) <= 60 < max(scores)
+    payloads = []
+    for k in range(n):
+        T = int(records["aln_len"][k])
+        s1, s2 = a1[k, :T].tobytes().decode(), a2[k, :T].tobytes().decode()
+        p = oracle.find_indels_substitutions(s1, s2, inc)
+        p["aln_seq"], p["aln_ref"] = s1, s2
+        payloads.append(p)
+    lay = C.CountLayout(1, L, L)
+    for flags in (0, C.FLAG_IGNORE_SUBSTITUTIONS, C.FLAG_DISCARD_INDEL_READS):
+        d_counts = torch.zeros(lay.shape(), dtype=torch.int64, device=dev)
+        C.accumulate_device(ctx, lay, n, o1.data_ptr(), o2.data_ptr(), stride, rec.data_ptr(), d_counts.data_ptr(),
+                            d_weights=d_w.data_ptr(), min_matches=mm, flags=flags, stream=s)
+        torch.cuda.synchronize()
+        got = lay.unpack(d_counts.cpu().numpy(), 0, L)
+        items = [(p, int(c)) for p, c, sc in zip(payloads, w, scores) if c > 0 and sc > 60.0]
+        exp = aggregate.aggregate(items, L, ignore_substitutions=bool(flags & 1), discard_indel_reads=bool(flags & 8))
+        for k, v in exp.items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(got[k], v), k
+            else:
+                assert got[k] == v, (k, got[k], v)
+
+
 def test_status_bits(mats, ctx):
     from crispresso2_amd.batch import BatchAligner
     import oracle
