@@ -395,7 +395,8 @@ int c2_timing_read(c2_ctx* ctx, double* total_ms, int64_t* launches, int reset) 
 int c2_synchronize(c2_ctx* ctx, void* hip_stream) {
     if (!ctx) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -407,7 +408,7 @@ int c2_align_classify_batch_device(c2_ctx* ctx, const c2_batch* b, void* hip_str
     // reads longer than that are reported per record as C2_STATUS_TOO_LONG, never overrun the LDS plan.
     const int max_lj = b->max_read_len > 0 ? b->max_read_len : (int)b->aln_stride - ctx->max_li;
     if (max_lj < 1) { ctx->err = "aln_stride must be at least longest reference + longest read"; return C2_E_INVALID; }
-    return run_align(ctx, b, max_lj, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+    return run_align(ctx, b, max_lj, (hipStream_t)hip_stream);
 }
 
 int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
@@ -465,7 +466,7 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     if (ctx->n_refs <= 0) { ctx->err = "references must be set first"; return C2_E_STATE; }
     static_assert(C2_CNT_VECTORS == C2_COUNT_VECTORS && C2_CNT_SCALARS == C2_COUNT_SCALARS && C2_CNT_HISTS == C2_COUNT_HISTS, "count layout");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t s = (hipStream_t)hip_stream;
     if (n_tasks == 0) return 0;
     const int lmax = ctx->max_li;
     if (hl < lmax + 2) { ctx->err = "hl too small"; return C2_E_INVALID; }

@@ -115,15 +115,15 @@ typedef struct c2_batch {
     c2_aln_record* records;    /* n_tasks */
 } c2_batch;
 
-/* All pointers in `b` are DEVICE pointers; the launch is enqueued on `hip_stream`
- * (a hipStream_t, NULL = the context's own stream) and the call returns without waiting. */
+/* All pointers in `b` are DEVICE pointers; the launch is enqueued on `hip_stream` (a hipStream_t; NULL is HIP's
+ * default stream, exactly as in hipLaunchKernelGGL) and the call returns without waiting. */
 int c2_align_classify_batch_device(c2_ctx* ctx, const c2_batch* b, void* hip_stream);
 
 /* All pointers in `b` are HOST pointers; stages through the context's device buffers
  * (H2D, launch, D2H) and returns when the results are in host memory. */
 int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b);
 
-/* Block until everything enqueued on the context's stream (or `hip_stream`) is done. */
+/* Block until everything enqueued on `hip_stream` and on the context's own stream (host-path staging) is done. */
 int c2_synchronize(c2_ctx* ctx, void* hip_stream);
 
 /* Kernel timing with HIP events on the launch stream: enable, run launches, then read the

@@ -325,8 +325,88 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--variants" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
     dump("realistic.json", realistic())
+
+
+# ---------------------------------------------------------------- 5. get_new_variant_object (the caller, CRISPRessoCORE.py:627-798)
+def load_reference_core():
+    """Import the reference's CRISPRessoCORE with its two Cython modules taken from oracle/_ref and seaborn stubbed
+    (CRISPResso2/__init__.py imports the plotting stack, which is not installed here)."""
+    import importlib
+    import importlib.metadata as md
+    pkg = types.ModuleType("CRISPResso2")
+    pkg.__path__ = [os.path.join(REF, "CRISPResso2")]
+    sys.modules["CRISPResso2"] = pkg
+    sys.modules["CRISPResso2.CRISPResso2Align"] = A
+    pkg.CRISPResso2Align = A
+    sys.modules["CRISPResso2.CRISPRessoCOREResources"] = R
+    pkg.CRISPRessoCOREResources = R
+    sb = types.ModuleType("seaborn")
+    sb.set_context = sb.set = sb.set_style = sb.set_theme = lambda *a, **k: None
+    sb.matrix = types.SimpleNamespace(_HeatMapper=object)
+    sb.utils = types.SimpleNamespace()
+    sys.modules["seaborn"] = sb
+    orig = md.version
+    md.version = lambda name: "2.3.4" if name.lower().startswith("crispresso") else orig(name)
+    return importlib.import_module("CRISPResso2.CRISPRessoCORE")
+
+
+def variant_goldens():
+    from crispresso2_amd import refs as RF
+    core = load_reference_core()
+    with open(os.path.join(REF, "tests/Cas9.amplicons.txt")) as fh:
+        for line in fh:
+            f = line.split()
+            if f and f[0] == "FANC":
+                fanc = f[1].upper()
+    seqs = []
+    with open(os.path.join(REF, "tests/FANC.Cas9.fastq")) as fh:
+        lines = fh.read().split("\n")
+    for k in range(1, len(lines), 4):
+        if lines[k] and lines[k] not in seqs:
+            seqs.append(lines[k])
+    # every 3rd read reverse-complemented (ACGTN reads only), a few unrelated reads
+    rng = np.random.default_rng(11)
+    reads = []
+    for k, s in enumerate(seqs):
+        reads.append(RF.reverse_complement(s) if k % 3 == 1 else s)
+    reads += ["".join(rng.choice(list("ACGT"), 200)) for _ in range(4)]
+    cases = []
+    hdr = fanc[:88] + "GATTACA" + fanc[95:]                 # a second, similar reference (HDR-style)
+    for label, ref_specs, flags in (
+            ("FANC", [("FANC", fanc)], {}),
+            ("FANC+HDR", [("FANC", fanc), ("HDR", hdr)], {}),
+            ("FANC+HDR first-ref", [("FANC", fanc), ("HDR", hdr)], {"assign_ambiguous_alignments_to_first_reference": True}),
+            ("FANC+HDR expand", [("FANC", fanc), ("HDR", hdr)], {"expand_ambiguous_alignments": True}),
+            ("FANC legacy/ignore", [("FANC", fanc)], {"use_legacy_insertion_quantification": True, "ignore_substitutions": True})):
+        args = types.SimpleNamespace(aln_seed_count=5, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                                     use_legacy_insertion_quantification=False, ignore_deletions=False, ignore_insertions=False,
+                                     ignore_substitutions=False, assign_ambiguous_alignments_to_first_reference=False,
+                                     expand_ambiguous_alignments=False, prime_editing_pegRNA_scaffold_seq="")
+        for k, v in flags.items():
+            setattr(args, k, v)
+        refs, names = {}, []
+        for nm, sq in ref_specs:
+            refs[nm] = RF.make_ref(nm, sq, [91], [91, 92], min_aln_score=60)
+            names.append(nm)
+        sample = reads if label == "FANC" else reads[::3]
+        outs = []
+        for rd in sample:
+            v = core.get_new_variant_object(args, rd, refs, names, EDNA, None)
+            outs.append(jsonable({k: (payload_dict(x) if k.startswith("variant_") else x) for k, x in v.items()}))
+        cases.append({"label": label, "args": vars(args),
+                      "refs": [{"name": nm, "sequence": refs[nm]["sequence"], "cut_points": [91], "include_idxs": [91, 92],
+                                "min_aln_score": 60, "fw_seeds": refs[nm]["fw_seeds"], "rc_seeds": refs[nm]["rc_seeds"]} for nm in names],
+                      "reads": sample, "variants": outs})
+    return cases
+
+
+if __name__ == "__main__" and "--variants" in sys.argv:
+    import gzip
+    with gzip.open(os.path.join(HERE, "variants.json.gz"), "wt") as fh:
+        json.dump(variant_goldens(), fh, separators=(",", ":"))
+    print("variants.json.gz written")

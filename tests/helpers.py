@@ -15,7 +15,12 @@ PAYLOAD_FIELDS = [
 
 
 def load_golden(name):
-    with open(os.path.join(GOLDEN, name)) as fh:
+    path = os.path.join(GOLDEN, name)
+    if name.endswith(".gz"):
+        import gzip
+        with gzip.open(path, "rt") as fh:
+            return json.load(fh)
+    with open(path) as fh:
         return json.load(fh)
 
 

@@ -356,3 +356,67 @@ def test_full_length_batches_properties_and_sampled_oracle(mats, ctx, L, n):
         st, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, -20, -2)
         assert st == 0 and res.strings(k) == (s1, s2) and int(res.records["matches"][k]) == mt
         check_record(res.records[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+
+
+def _variant_equal(got, exp):
+    """got: dict from crispresso2_amd.variants; exp: JSON form of the reference's dict."""
+    from helpers import norm, PAYLOAD_FIELDS
+    assert set(got.keys()) == set(exp.keys()), (sorted(got.keys()), sorted(exp.keys()))
+    for k, e in exp.items():
+        g = got[k]
+        if k.startswith("variant_"):
+            gd = g.__dict__ if not isinstance(g, dict) else g
+            assert set(gd.keys()) == set(e.keys()), (k, sorted(gd.keys()), sorted(e.keys()))
+            for f, ev in e.items():
+                assert norm(gd[f]) == ev, (k, f, norm(gd[f]), ev)
+        else:
+            assert norm(g) == e, (k, norm(g), e)
+
+
+def test_get_new_variant_objects_vs_reference_function(mats, ctx):
+    """crispresso2_amd.variants.get_new_variant_objects against the reference's own get_new_variant_object
+    (CRISPRessoCORE.py:627-798) on the reads of tests/FANC.Cas9.fastq: strand choice by seeds, reverse complements,
+    two references with ambiguous reads, unaligned reads, legacy quantification and ignore flags."""
+    import types
+    from crispresso2_amd import refs as RF, variants as V
+    cases = load_golden("variants.json.gz")
+    n_amb = n_unal = n_rc = 0
+    for case in cases:
+        args = types.SimpleNamespace(**case["args"])
+        refs, names = {}, []
+        for r in case["refs"]:
+            refs[r["name"]] = RF.make_ref(r["name"], r["sequence"], r["cut_points"], r["include_idxs"], r["min_aln_score"])
+            assert refs[r["name"]]["fw_seeds"] == r["fw_seeds"] and refs[r["name"]]["rc_seeds"] == r["rc_seeds"]
+            names.append(r["name"])
+        got = V.get_new_variant_objects(args, case["reads"], refs, names, mats["EDNAFULL"], None, ctx=ctx)
+        assert len(got) == len(case["variants"])
+        for g, e in zip(got, case["variants"]):
+            _variant_equal(g, e)
+            n_unal += e["best_match_score"] <= 0
+            n_amb += len(e.get("aln_ref_names", [])) > 1
+            n_rc += any(e.get("variant_" + nm, {}).get("aln_strand") == "-" for nm in names)
+    assert n_amb > 0 and n_unal > 0 and n_rc > 0
+
+
+def test_process_fastq_equivalent(mats, ctx, tmp_path):
+    """FASTQ -> unique-read dict -> one batch -> variantCache + aln_stats, against the same bookkeeping done per read."""
+    import types
+    from crispresso2_amd import refs as RF, variants as V
+    case = load_golden("variants.json.gz")[0]
+    args = types.SimpleNamespace(**case["args"])
+    r = case["refs"][0]
+    refs = {r["name"]: RF.make_ref(r["name"], r["sequence"], r["cut_points"], r["include_idxs"], r["min_aln_score"])}
+    reads = case["reads"][:60]
+    fq = tmp_path / "x.fastq"
+    with open(fq, "w") as fh:
+        for k, s in enumerate(reads + reads[:20] + reads[:5]):
+            fh.write("@r%d\n%s\n+\n%s\n" % (k, s, "I" * len(s)))
+    cache, not_aligned, st = V.process_fastq(str(fq), args, refs, [r["name"]], mats["EDNAFULL"], ctx=ctx)
+    assert st["N_TOT_READS"] == 85
+    assert st["N_COMPUTED_ALN"] + st["N_COMPUTED_NOTALN"] == len(set(reads))
+    assert st["N_CACHED_ALN"] + st["N_CACHED_NOTALN"] == 85 - len(set(reads))
+    exp = {s: v for s, v in zip(case["reads"], case["variants"])}
+    for s, v in cache.items():
+        assert v["count"] == (reads + reads[:20] + reads[:5]).count(s)
+        e = dict(exp[s]); e["count"] = v["count"]
+        _variant_equal(v, e)
