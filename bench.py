@@ -60,6 +60,8 @@ def main():
     t0 = time.perf_counter()
     reads = synth.make_reads(L, n, first_block=rank * blocks_per_rank, workers=workers)
     t_gen = time.perf_counter() - t0
+    n_u = min(n, 1_000_000)
+    unique_fraction = float(len(np.unique(reads[:n_u].view([("r", "V%d" % L)]))) / n_u)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline as cb
@@ -168,7 +170,7 @@ def main():
             "config": {"workload": "%s synthetic %d bp reads vs one %d bp amplicon per GPU (BASELINE.json configs[2] shape), "
                                    "every read aligned (dedup off), EDNAFULL, gap_open -20, gap_extend -2, gap_incentive 1 at the cut"
                                    % ("{:,}".format(n), L, L),
-                       "reads_per_gpu_per_step": n, "read_len": L, "amplicon_len": L, "unique_read_fraction": None,
+                       "reads_per_gpu_per_step": n, "read_len": L, "amplicon_len": L, "unique_read_fraction": unique_fraction, "unique_read_fraction_sample": n_u,
                        "rows_per_lane": info["rows_per_lane"], "lds_bytes_per_workgroup": info["lds_bytes"],
                        "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},

@@ -61,6 +61,7 @@ struct c2_ctx {
     int band_target_wgs = 14;
     DevBuf d_fb;
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
+    std::vector<uint16_t> cnt_table;   // host copy of the table that is on the device (skip re-upload when unchanged)
 };
 
 namespace {
@@ -118,7 +119,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     g.passes = (ctx->max_li + 64 * g.R - 1) / (64 * g.R);
     g.max_lj = std::max(max_lj, 1);
     const size_t lds_cu = 163840;
-    g.lds_full = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes, C2_LANES).total;
+    g.lds_full = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes, 0).total;
     if (g.lds_full > lds_cu) {
         ctx->err = "alignment of " + std::to_string(ctx->max_li) + " x " + std::to_string(g.max_lj) +
                    " needs " + std::to_string(g.lds_full) + " bytes of LDS pointer plane; limit is " + std::to_string(lds_cu);
@@ -132,15 +133,14 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     int want = ctx->band_setting;
     if (g.passes == 1 && want != 0) {
         if (want < 0) {
-            // auto: the widest band that still lets `band_target_wgs` workgroups share a CU's LDS
-            const uint32_t other = c2_make_plan(g.R, g.max_lj, 1, ctx->sc.n_codes, 1).total - (uint32_t)c2_align16((uint32_t)g.max_lj * (1 + C2_PTR_PAD) * 2u);
-            const int64_t budget = (int64_t)(lds_cu / (size_t)ctx->band_target_wgs) - (int64_t)other - 32;
-            const int nslots = (int)(budget / (2 * (int64_t)g.max_lj)) - C2_PTR_PAD;
-            want = (nslots - 1) / 2;
+            // auto: the widest band whose plan still lets `band_target_wgs` workgroups share a CU's LDS
+            want = 0;
+            for (int w = 1; w < 24; ++w)
+                if (c2_make_plan(g.R, g.max_lj, 1, ctx->sc.n_codes, w).total <= lds_cu / (size_t)ctx->band_target_wgs) want = w;
         }
-        if (want >= 2 && 2 * want + 1 < C2_LANES - 8) {
+        if (want >= 2 && c2_band_slots(g.R, want) < C2_LANES - 8) {
             g.band_lanes = want;
-            g.lds_band = c2_make_plan(g.R, g.max_lj, 1, ctx->sc.n_codes, 2 * want + 1).total;
+            g.lds_band = c2_make_plan(g.R, g.max_lj, 1, ctx->sc.n_codes, want).total;
             if ((rc = occupancy_r<true>(ctx, g.R, g.lds_band, g.blocks_band))) return rc;
             if (g.blocks_band <= g.blocks_full) g.band_lanes = 0;      // no occupancy to gain
         }
@@ -478,11 +478,16 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     A.min_matches = nullptr;
     size_t o_tbl = 64;
     const size_t tbl_bytes = h_min_matches ? (size_t)ctx->n_refs * (size_t)(max_t + 1) * sizeof(uint16_t) : 0;
+    if (o_tbl + tbl_bytes > ctx->d_cnt.cap) ctx->cnt_table.clear();
     if ((rc = ensure(ctx, ctx->d_cnt, o_tbl + tbl_bytes))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt.p, 0, 64, s));
     if (h_min_matches) {
-        HIPCHK(ctx, hipMemcpyAsync((uint8_t*)ctx->d_cnt.p + o_tbl, h_min_matches, tbl_bytes, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));      // the table is caller-owned pageable memory
+        const size_t nel = tbl_bytes / sizeof(uint16_t);
+        if (ctx->cnt_table.size() != nel || memcmp(ctx->cnt_table.data(), h_min_matches, tbl_bytes) != 0) {
+            HIPCHK(ctx, hipStreamSynchronize(s));      // no earlier launch may still read the old table
+            HIPCHK(ctx, hipMemcpy((uint8_t*)ctx->d_cnt.p + o_tbl, h_min_matches, tbl_bytes, hipMemcpyHostToDevice));
+            ctx->cnt_table.assign(h_min_matches, h_min_matches + nel);
+        }
         A.min_matches = (const uint16_t*)((uint8_t*)ctx->d_cnt.p + o_tbl);
     }
     A.aln_read = d_aln_read; A.aln_ref = d_aln_ref; A.records = d_records; A.weights = d_weights;

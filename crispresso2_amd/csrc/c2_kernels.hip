@@ -47,12 +47,22 @@ struct c2_lds_plan {
 __host__ __device__ inline uint32_t c2_align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 // The same function sizes the LDS on the host and carves it in the kernel.
-__host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_passes, int n_codes, int nslots) {
+// Banded pointer plane: at step t only the lanes lo(t) .. lo(t)+nslots-1 keep their pointer word, where
+// lo(t) = floor((t - 1 - R*W) / (R+1)): lane l is at column j = t - l, the main-diagonal lane of that column is (j-1)/R,
+// and |l - (j-1)/R| <= W  <=>  (R+1)*l within R*W of t-1.  The window is wave-uniform, so the in-band test and the
+// LDS address of a step cost one subtract, one compare and one shift-add per lane.
+__host__ __device__ inline int c2_band_slots(int R, int W) { return (2 * R * W) / (R + 1) + 2; }
+__host__ __device__ inline int c2_band_lo(int R, int W, int t) { return (t - 1 - R * W + 64 * (R + 1)) / (R + 1) - 64; }
+
+// band_lanes = 0: full plane (one row of 64 lanes per read column); > 0: banded plane (one row of nslots per step)
+__host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_passes, int n_codes, int band_lanes) {
+    const int nslots = band_lanes > 0 ? c2_band_slots(R, band_lanes) : C2_LANES;
+    const uint32_t plane_rows = band_lanes > 0 ? (uint32_t)max_lj + 64u : (uint32_t)max_lj;
     c2_lds_plan p;
     const uint32_t max_li = (uint32_t)max_passes * 64u * (uint32_t)R;
-    p.col_stride = (uint32_t)nslots + C2_PTR_PAD;      // nslots = 64 (every lane) or 2*band_lanes+1 (banded pointer plane)
+    p.col_stride = (uint32_t)nslots + C2_PTR_PAD;
     uint32_t off = 0;
-    p.ptr = off;      off += c2_align16((uint32_t)max_passes * (uint32_t)max_lj * p.col_stride * 2u);
+    p.ptr = off;      off += c2_align16((uint32_t)max_passes * plane_rows * p.col_stride * 2u);
     p.bnd = off;      off += (max_passes > 1) ? c2_align16(3u * ((uint32_t)max_lj + 1u) * 4u) : 0u;
     p.tbl = off;      off += c2_align16((uint32_t)n_codes * (uint32_t)n_codes * 2u);
     p.read = off;     off += c2_align16((uint32_t)max_lj);
@@ -117,14 +127,16 @@ __device__ __forceinline__ int c2_div_rows(int x) {
     return (x * 21846) >> 16;                           // R == 3
 }
 
-// Halfword index of the pointer word of (row-lane `rl`, column j = jm1+1) inside one pass's pointer plane.
-// BAND: only the lanes within band_lanes of the main-diagonal lane (j-1)/R are stored; *inband tells whether this one is.
+// Halfword index of the pointer word of (row-lane `rl`, column j) inside one pass's pointer plane.
+// Full plane: row j-1, slot rl.  BAND: row t-1 (t = j + rl is the step at which that lane computed the column), slot
+// rl - lo(t); *inband tells whether the word was stored.
 template <int R, bool BAND>
-__device__ __forceinline__ int c2_ptr_index(const int rl, const int jm1, const int colStride, const int band_lanes, bool& inband) {
-    if (!BAND) { inband = true; return jm1 * colStride + rl; }
-    const int slot = rl + band_lanes - c2_div_rows<R>(jm1);
-    inband = (unsigned)slot <= (unsigned)(2 * band_lanes);
-    return jm1 * colStride + slot;
+__device__ __forceinline__ int c2_ptr_index(const int rl, const int j, const int colStride, const int band_lanes, bool& inband) {
+    if (!BAND) { inband = true; return (j - 1) * colStride + rl; }
+    const int t = j + rl;
+    const int slot = rl - c2_band_lo(R, band_lanes, t);
+    inband = (unsigned)slot < (unsigned)c2_band_slots(R, band_lanes);
+    return (t - 1) * colStride + slot;
 }
 
 // Per-lane DP state of one systolic pass: R consecutive reference rows.
@@ -134,6 +146,7 @@ struct c2_strip {
     int sel[R];                       // PACKED: 8 signed score nibbles of the row's base; else: LDS row offset into the score table
     int Ml[R], Il[R], Hl[R];          // M, I, H=max(M,I,J) of the rows at the column computed last
     int Mb, Jb, Hb;                   // bottom row at that column: what the lane below receives
+    int upM, upJ, upH;                // hand-off registers: lanes 1..63 receive the lane above (DPP), lane 0 keeps the boundary row
     int dgsave;                       // H(row above the strip, previous column)
     int cj;                           // read symbol of the current column (PACKED: 4*code, else code)
     unsigned bits;                    // pointer nibbles, newest in the low bits
@@ -184,36 +197,48 @@ __device__ __forceinline__ int c2_load_rsym(const unsigned char* sCode, const in
 }
 
 // One step of the systolic sweep: hand-off from the lane above (DPP, full EXEC), then this lane's column j = t - lane.
-template <int R, bool PACKED, bool TAIL, bool BAND>
+// PHASE 0: ramp-up (t < 64: lanes with j < 1 wait), 1: steady state (every lane is inside 1..Lj-1: no mask at all),
+// 2: tail (lanes may be on the last column, or past it).
+template <int R, bool PACKED, int PHASE, bool BAND>
 __device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const int lane, const int Lj, const int ge, const int g0,
                                            const int min_score, const bool first, const bool feeds_next,
-                                           int& rsym, int& nM, int& nJ, int& nH,
+                                           const int rsym, int& nM, int& nJ, int& nH,
                                            const unsigned char* sCode, const int16_t* sTbl, int* sBnd,
                                            uint16_t* planePtr, const int colStride, const int band_lanes)
 {
-    int bM = min_score, bJ = min_score, bH;
-    if (first) bH = c2_imax(min_score, ge * t + g0);           // H(0,t) = iScore[0,t], pyx:161-162
-    else { bM = nM; bJ = nJ; bH = nH; }
+    // lane 0's inputs: the row above the pass at column t.  First pass: closed-form row 0 (pyx:153-176): M = J = min_score
+    // (they sit in lane 0 of S.upM / S.upJ since the pass started; the DPP never writes lane 0), H(0,t) = iScore[0,t].
+    if (first) {
+        const int bH = c2_imax(min_score, ge * t + g0);
+        if (lane == 0) S.upH = bH;
+    } else {
+        if (lane == 0) { S.upM = nM; S.upJ = nJ; S.upH = nH; }
+        const int tn = (t + 1 <= Lj) ? t + 1 : Lj;
+        nM = sBnd[3 * tn]; nJ = sBnd[3 * tn + 1]; nH = sBnd[3 * tn + 2];
+    }
     // read symbol of column t: lane (t-1)&63 of rsym holds the symbols of read positions l, l+64, l+128, l+192 of the
     // current 256-column chunk (v_readlane + scalar byte extract: no LDS access, nothing to wait for)
     const int pos = t - 1;
-    if ((pos & 255) == 0) rsym = c2_load_rsym<PACKED>(sCode, pos, Lj, lane);
     const int bC = (__builtin_amdgcn_readlane(rsym, pos & 63) >> ((pos >> 3) & 24)) & 0xff;
-    if (!first) { const int tn = (t + 1 <= Lj) ? t + 1 : Lj; nM = sBnd[3 * tn]; nJ = sBnd[3 * tn + 1]; nH = sBnd[3 * tn + 2]; }
-    const int upM0 = c2_shr1(bM, S.Mb);
-    const int upJ0 = c2_shr1(bJ, S.Jb);
-    const int upH = c2_shr1(bH, S.Hb);
+    S.upM = c2_shr1(S.upM, S.Mb);
+    S.upJ = c2_shr1(S.upJ, S.Jb);
+    S.upH = c2_shr1(S.upH, S.Hb);
     S.cj = c2_shr1(bC, S.cj);
     const int j = t - lane;
-    const bool active = TAIL ? (j >= 1 && j <= Lj) : (j >= 1);
+    bool active = true;
+    if (PHASE == 0) active = (j >= 1);
+    if (PHASE == 2) active = (j >= 1 && j <= Lj);
     if (active) {
-        c2_dp_column<R, PACKED, TAIL>(S, upM0, upJ0, ge, TAIL && (j == Lj), sTbl);
-        bool inband;
-        const int pidx = c2_ptr_index<R, BAND>(lane, j - 1, colStride, band_lanes, inband);
-        if (inband) planePtr[pidx] = (uint16_t)S.bits;
+        c2_dp_column<R, PACKED, PHASE == 2>(S, S.upM, S.upJ, ge, PHASE == 2 && (j == Lj), sTbl);
+        if (BAND) {
+            const int slot = lane - c2_band_lo(R, band_lanes, t);
+            if ((unsigned)slot < (unsigned)c2_band_slots(R, band_lanes)) planePtr[(t - 1) * colStride + slot] = (uint16_t)S.bits;
+        } else {
+            planePtr[(j - 1) * colStride + lane] = (uint16_t)S.bits;
+        }
         if (feeds_next && lane == 63) { sBnd[3 * j] = S.Mb; sBnd[3 * j + 1] = S.Jb; sBnd[3 * j + 2] = S.Hb; }
     }
-    S.dgsave = upH;
+    S.dgsave = S.upH;
 }
 
 // One systolic pass over reference rows p*64R+1 .. p*64R+64R.  SINGLE: the reference fits one pass, so the row above
@@ -250,6 +275,7 @@ __device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_
     S.dgsave = (row0 == 0) ? 0 : c2_imax(min_score, ge * row0 + g0);
     S.cj = 0;
     S.bits = 0;
+    S.upM = min_score; S.upJ = min_score; S.upH = 0;
     const int nrows = (Li - p * ROWS_PER_PASS) < ROWS_PER_PASS ? (Li - p * ROWS_PER_PASS) : ROWS_PER_PASS;
     const int nl = (nrows + R - 1) / R;
     const int steps = Lj + nl - 1;
@@ -260,23 +286,29 @@ __device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_
     int rsym = 0;
     int nM = min_score, nJ = min_score, nH = 0;
     if (!first) { nM = sBnd[3]; nJ = sBnd[4]; nH = sBnd[5]; }
-    // steps 1 .. Lj-1: no lane can be on the last column or beyond it; steps Lj .. : the general column
-    const int t_split = Lj < steps + 1 ? Lj : steps + 1;
-    for (int t = 1; t < t_split; ++t)
-        c2_dp_step<R, PACKED, false, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
-    for (int t = t_split; t <= steps; ++t)
-        c2_dp_step<R, PACKED, true, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
+    // ramp-up: steps 1 .. min(64, Lj)-1;  steady state: 64 .. Lj-1 (all 64 lanes inside the matrix, not on its last column);
+    // tail: Lj .. steps
+    const int t1 = Lj < 64 ? Lj : 64;
+    const int t2 = Lj < steps + 1 ? Lj : steps + 1;
+    int t = 1;
+    while (t <= steps) {
+        // one 256-column chunk of read symbols per register (c2_load_rsym), then the steps that consume it
+        const int seg_end = (((t - 1) | 255) + 1) < steps ? (((t - 1) | 255) + 1) : steps;
+        rsym = c2_load_rsym<PACKED>(sCode, (t - 1) & ~255, Lj, lane);
+        for (; t <= seg_end && t < t1; ++t)
+            c2_dp_step<R, PACKED, 0, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
+        for (; t <= seg_end && t < t2; ++t)
+            c2_dp_step<R, PACKED, 1, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
+        for (; t <= seg_end; ++t)
+            c2_dp_step<R, PACKED, 2, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
+    }
 }
 
-// BAND = false: full pointer plane (any path).  BAND = true: only the lanes within A.band_lanes of the main diagonal
-// keep their pointer words (single-pass references only); a traceback that needs a word outside the band appends the
-// task to A.fb_list, and the host re-runs exactly those tasks with the full-plane kernel (A.task_list mode).  The band
-// limits what is STORED, never what is computed, so results do not depend on it.
 template <int R, bool BAND>
-__global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
+__global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args A)
 {
     const int lane = threadIdx.x;
-    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, BAND ? 2 * A.band_lanes + 1 : C2_LANES);
+    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, BAND ? A.band_lanes : 0);
     uint16_t* sPtr = (uint16_t*)(c2_smem + P.ptr);
     int* sBnd = (int*)(c2_smem + P.bnd);
     int16_t* sTbl = (int16_t*)(c2_smem + P.tbl);
@@ -408,7 +440,7 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
             {
                 const int pp = (i - 1) / ROWS_PER_PASS, rem = (i - 1) % ROWS_PER_PASS;
                 bool inb;
-                const int pidx = c2_ptr_index<R, BAND>(rem / R, j - 1, colStride, A.band_lanes, inb);
+                const int pidx = c2_ptr_index<R, BAND>(rem / R, j, colStride, A.band_lanes, inb);
                 if (inb) {
                     const unsigned hw = sPtr[(size_t)pp * A.max_lj * colStride + pidx];
                     const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
@@ -440,7 +472,7 @@ __global__ __launch_bounds__(64) void c2_align_classify_kernel(c2_align_args A)
                     } else {
                         const int pp = (pi - 1) / ROWS_PER_PASS, rem = (pi - 1) % ROWS_PER_PASS;
                         bool inb;
-                        const int pidx = c2_ptr_index<R, BAND>(rem / R, pj - 1, colStride, A.band_lanes, inb);
+                        const int pidx = c2_ptr_index<R, BAND>(rem / R, pj, colStride, A.band_lanes, inb);
                         if (inb) {
                             const unsigned hw = sPtr[(size_t)pp * A.max_lj * colStride + pidx];
                             const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
@@ -845,10 +877,20 @@ __global__ __launch_bounds__(64) void c2_count_vectors_kernel(c2_count_args A)
         const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride;
         int idx_base = 0, last_rf = -1, last_rd = -1;
         bool last_rf_close = false, last_rf_wclose = false;
+        // all loads of up to 256 columns are issued before the first one is used (one HBM round trip, not four)
+        unsigned char pre_rd[4], pre_rf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 64 * q + lane;
+            pre_rd[q] = (c < T) ? R_[c] : 0;
+            pre_rf[q] = (c < T) ? F_[c] : 0;
+        }
         for (int base = 0; base < T; base += 64) {
             const int c = base + lane;
             const bool in = c < T;
-            const unsigned char rd = in ? R_[c] : 0, rfc = in ? F_[c] : 0;
+            unsigned char rd, rfc;
+            if (base < 256) { rd = pre_rd[(base >> 6) & 3]; rfc = pre_rf[(base >> 6) & 3]; }
+            else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
             const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
             const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
             const int idx = idx_base + __popcll(m_rf & lt);

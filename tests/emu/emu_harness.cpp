@@ -56,7 +56,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
     if (band) {
         A.band_lanes = band_lanes;
-        const c2_lds_plan PB = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, 2 * band_lanes + 1);
+        const c2_lds_plan PB = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, band_lanes);
         if (PB.total > sizeof(c2_smem)) return -5;
         switch (R) {
             case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, true>(A); }); break;
@@ -68,7 +68,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         work_counter = 0;
         if (n_fallback) *n_fallback = (int)fb_count;
     } else if (n_fallback) *n_fallback = -1;
-    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, C2_LANES);
+    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, 0);
     if (P.total > sizeof(c2_smem)) { fprintf(stderr, "emu: LDS plan %u too large\n", P.total); return -5; }
     A.band_lanes = 0;
     if (!band || fb_count > 0) {

@@ -108,6 +108,7 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)emu::xl_get((uint32_t)v, lane, nullptr); }
+inline int __builtin_amdgcn_writelane(int v, int lane, int old) { return emu::cur_lane == lane ? v : old; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)emu::xl_get((uint32_t)v, 0, nullptr); }
 inline int __shfl(int v, int lane, int width = 64) { (void)width; return (int)(uint32_t)emu::xl_get((uint32_t)v, lane & 63, nullptr); }
 inline int __shfl_xor(int v, int mask, int width = 64) { (void)width; return (int)(uint32_t)emu::xl_get((uint32_t)v, emu::cur_lane ^ mask, nullptr); }
