@@ -150,6 +150,17 @@ def main():
                 break
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
+    # HBM bytes per alignment from the committed PMC passes (separate rocprofv3 --pmc runs of this same script; FETCH_SIZE
+    # doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming reads); null when the profile file is absent
+    traffic = traffic_src = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01", "pmc_summary_2M_reads.json")
+    if os.path.exists(pmc_path) and L == 250:
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
+        fetch = sum(v["FETCH_SIZE"] for k, v in pmc["pmc_FETCH_SIZE"].items() if "c2_align" in k)
+        write = sum(v["WRITE_SIZE"] for k, v in pmc["pmc_WRITE_SIZE"].items() if "c2_align" in k)
+        traffic = (2.0 * fetch + write) * 1024.0 / 2.0e6 * n          # bytes per launch of n alignments
+        traffic_src = "profiles/r01/pmc_summary_2M_reads.json (2*FETCH_SIZE + WRITE_SIZE of the align kernels, per alignment, x reads per launch)"
     tallies = layout.unpack(d_counts.cpu().numpy(), 0, L)
 
     if rank == 0:
@@ -175,7 +186,7 @@ def main():
                        "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "c2_align_classify_kernel", "avg_launch_ms": 1e3 * avg_launch_s, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_per_read": alg_bytes / n,

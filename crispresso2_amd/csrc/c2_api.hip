@@ -60,6 +60,8 @@ struct c2_ctx {
     int band_setting = -1;
     int band_target_wgs = 14;
     DevBuf d_fb;
+    int occ_lds[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
+    int occ_blocks[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
     std::vector<uint16_t> cnt_table;   // host copy of the table that is on the device (skip re-upload when unchanged)
 };
@@ -96,10 +98,17 @@ struct Geometry {
 
 template <int R, bool BAND>
 int occupancy(c2_ctx* ctx, uint32_t lds, int& blocks) {
-    int nb = 0;
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_classify_kernel<R, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_classify_kernel<R, BAND>, 64, lds));
-    blocks = nb < 1 ? 1 : nb;
+    // cached per (kernel instance, LDS size): the per-call API path comes through here for every alignment
+    int& cached_lds = ctx->occ_lds[R][BAND ? 1 : 0];
+    int& cached_blocks = ctx->occ_blocks[R][BAND ? 1 : 0];
+    if (cached_lds != (int)lds) {
+        int nb = 0;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_classify_kernel<R, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_classify_kernel<R, BAND>, 64, lds));
+        cached_blocks = nb < 1 ? 1 : nb;
+        cached_lds = (int)lds;
+    }
+    blocks = cached_blocks;
     return 0;
 }
 

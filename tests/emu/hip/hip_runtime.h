@@ -51,14 +51,6 @@ inline void barrier() {
     if (++bar_count == W) { bar_count = 0; bar_gen++; return; }
     while (bar_gen == gen) yield_next();
 }
-// every lane publishes a 64-bit value, returns pointer to the full table (valid until the next exchange+1)
-inline const uint64_t* exchange(uint64_t v) {
-    int ph = xl_phase;            // all lanes see the same phase before the barrier flips it
-    xl_slots[ph][cur_lane] = v;
-    barrier();
-    if (cur_lane == 0 || true) { /* phase flip must happen once: do it by the last arriver */ }
-    return xl_slots[ph];
-}
 struct tid_t { unsigned x, y, z; };
 inline tid_t tid() { return tid_t{(unsigned)cur_lane, 0, 0}; }
 }  // namespace emu
@@ -73,7 +65,6 @@ inline void __syncthreads() { emu::barrier(); }
 // exchange helper with phase alternation handled per call site (two tables, flipped by lane 0 after barrier 2)
 namespace emu {
 inline uint64_t xl_get(uint64_t mine, int src_lane, bool* valid) {
-    static thread_local int dummy; (void)dummy;
     int ph = xl_phase;
     xl_slots[ph][cur_lane] = mine;
     barrier();
@@ -99,7 +90,6 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
 inline long long clock64() { return 0; }
 inline int __builtin_amdgcn_sbfe(int x, int off, int width) { return (int)((unsigned)x << (32 - off - width)) >> (32 - width); }
 inline unsigned long long __ballot(int pred) {
-    int ph = emu::xl_phase; (void)ph;
     emu::xl_slots[0][emu::cur_lane] = pred ? 1 : 0;
     emu::barrier();
     unsigned long long m = 0;

@@ -420,3 +420,94 @@ def test_process_fastq_equivalent(mats, ctx, tmp_path):
         assert v["count"] == (reads + reads[:20] + reads[:5]).count(s)
         e = dict(exp[s]); e["count"] = v["count"]
         _variant_equal(v, e)
+
+
+def test_pooled_96_amplicons_counts_per_amplicon(mats, ctx):
+    """BASELINE config 5 shape at test size: 96 amplicons, every read tagged with its amplicon id (CRISPRessoPooled
+    semantics: each read is aligned to ITS amplicon only), per-amplicon count tensor vs the reference aggregation."""
+    import torch
+    from crispresso2_amd import synth, counts as C, _native
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    from oracle import aggregate
+    m = mats["EDNAFULL"]
+    L, n_amp, per = 250, 96, 40
+    setups = [synth.amplicon_setup(L, 1000 + a) for a in range(n_amp)]
+    reads = np.concatenate([synth.make_reads(L, per, amplicon_id=1000 + a, amplicon=setups[a][0]) for a in range(n_amp)])
+    rids = np.repeat(np.arange(n_amp, dtype=np.uint16), per)
+    perm = np.random.default_rng(0).permutation(len(reads))            # interleave amplicons: ids travel with the reads
+    reads, rids = reads[perm], rids[perm]
+    n = len(reads)
+    al = BatchAligner([s[0] for s in setups], [s[1] for s in setups], [s[2] for s in setups], m, -20, -2, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    stride = al.stride_for(L)
+    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    d_rid = torch.from_numpy(rids.astype(np.int16)).to(dev)
+    o1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    o2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    rec = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, L,
+                    d_ref_ids=d_rid.data_ptr(), stream=s)
+    lay = C.CountLayout(n_amp, L, L)
+    d_counts = torch.zeros(lay.shape(), dtype=torch.int64, device=dev)
+    C.accumulate_device(ctx, lay, n, o1.data_ptr(), o2.data_ptr(), stride, rec.data_ptr(), d_counts.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    records = rec.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+    assert (records["status"] == 0).all() and np.array_equal(records["ref_id"], rids)
+    a1, a2, cnt = o1.cpu().numpy(), o2.cpu().numpy(), d_counts.cpu().numpy()
+    for a in (0, 17, 95):
+        amp, g, inc = setups[a]
+        items = []
+        for k in np.nonzero(rids == a)[0]:
+            st, s1, s2, mt, ln = oracle.global_align_raw(reads[k].tobytes().decode(), amp, m, g, -20, -2)
+            T = int(records["aln_len"][k])
+            assert (a1[k, :T].tobytes().decode(), a2[k, :T].tobytes().decode()) == (s1, s2)
+            p = oracle.find_indels_substitutions(s1, s2, inc)
+            p["aln_seq"], p["aln_ref"] = s1, s2
+            items.append((p, 1))
+        exp = aggregate.aggregate(items, L)
+        got = lay.unpack(cnt, a, L)
+        for k, v in exp.items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(got[k], v), (a, k)
+            else:
+                assert got[k] == v, (a, k, got[k], v)
+    assert sum(lay.unpack(cnt, a, L)["counts_total"] for a in range(n_amp)) == n
+
+
+def test_three_candidate_references_best_reference_selection(mats, ctx):
+    """BASELINE config 4 shape at test size: every read against 3 candidate amplicons (wild type, HDR, prime edit);
+    best reference by the reference's rules (strictly higher score above min_aln_score; ties are ambiguous)."""
+    from crispresso2_amd import synth
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    m = mats["EDNAFULL"]
+    L, n = 250, 300
+    amp, g, inc = synth.amplicon_setup(L)
+    refs = [amp, synth.make_variant(amp, "hdr"), synth.make_variant(amp, "pe")]
+    gis = []
+    for r in refs:
+        x = np.zeros(len(r) + 1, dtype=np.int64)
+        x[L // 2 + 1] = 1
+        gis.append(x)
+    reads = np.concatenate([synth.make_reads(L, n // 3, amplicon=r)[:, :L] if len(r) >= L else synth.make_reads(L, n // 3, amplicon=r)
+                            for r in (refs[0], refs[1][:L], refs[2])])
+    rd = [x.tobytes().decode() for x in reads]
+    al = BatchAligner(refs, gis, [inc] * 3, m, -20, -2, ctx=ctx)
+    res = al.align(rd, all_refs=True)
+    sc = res.scores.reshape(len(rd), 3)
+    best_gpu = []
+    for k in range(len(rd)):
+        exp = [oracle.global_align(rd[k], refs[r], m, gis[r], -20, -2) for r in range(3)]
+        for r in range(3):
+            assert res.strings(3 * k + r) == (exp[r][0], exp[r][1]) and sc[k, r] == exp[r][2]
+        best, names = -1, []
+        for r in range(3):                       # CRISPRessoCORE.py:697-707
+            if exp[r][2] > best and exp[r][2] > 60:
+                best, names = exp[r][2], [r]
+            elif exp[r][2] == best:
+                names.append(r)
+        best_gpu.append(names)
+    assert any(len(x) == 1 and x[0] == 1 for x in best_gpu) and any(len(x) == 1 and x[0] == 2 for x in best_gpu)
