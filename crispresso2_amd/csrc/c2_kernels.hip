@@ -304,6 +304,276 @@ __device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pieces shared by the row-strip kernel (c2_align_classify_kernel) and the diagonal-band kernel (c2_align_diag_kernel)
+// ---------------------------------------------------------------------------------------------------------------
+struct c2_wg {                       // one workgroup's LDS views
+    unsigned char* sRead;            // read characters (reverse-complemented if the task asks for it)
+    unsigned char* sCode;            // their score-table codes
+    unsigned char* sRef;             // reference characters
+    uint16_t* sIncP;                 // window prefix counts of the reference
+    unsigned char* sTmpRead;         // aligned strings, reversed (as the traceback emits them)
+    unsigned char* sTmpRef;
+};
+
+// Pull the next task index from the device counter (chunks of C2_TASK_CHUNK per atomic), so a launch never waits for the
+// slowest statically assigned share and does not depend on how many workgroups are resident.  Returns false when done.
+__device__ __forceinline__ bool c2_next_task(const c2_align_args& A, const int lane, uint64_t& chunk_base, int& chunk_left, uint64_t& task) {
+    const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : A.n_tasks;
+    if (chunk_left == 0) {
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(A.work_counter, (unsigned long long)C2_TASK_CHUNK);
+        chunk_base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                     (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+        chunk_left = C2_TASK_CHUNK;
+    }
+    const uint64_t it = chunk_base;
+    if (it >= n_iter) return false;
+    ++chunk_base; --chunk_left;
+    task = A.task_list ? (uint64_t)A.task_list[it] : it;
+    return true;
+}
+
+// Stage one task in LDS: reference (only when the amplicon changes), read (coalesced byte loads, optional reverse
+// complement), codes.  Returns the wave-uniform status bits.  max_li / A.max_lj bound what may be written.
+__device__ __forceinline__ int c2_fetch_task(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int lane,
+                                             const int max_li, int& cur_ref, int& Li, int& g0, int& Lj, int& ref_id, int& rc,
+                                             bool& ref_changed, bool& packed)
+{
+    uint64_t read_id;
+    if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
+    else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
+    rc = A.strands ? (int)A.strands[task] : 0;
+    const uint64_t off = A.offsets[read_id];
+    Lj = (int)(A.offsets[read_id + 1] - off);
+    int status = 0;
+    int read_code_max = 0;
+    const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
+    ref_changed = (ref_id != cur_ref);
+    if (ref_changed) {
+        cur_ref = ref_id;
+        const c2_dev_ref rf = A.refs[ref_id];
+        Li = rf.len;
+        g0 = rf.gap_incentive[0];
+        const int LiLoad = Li < max_li ? Li : max_li;
+        for (int k = lane; k < LiLoad; k += 64) W.sRef[k] = rf.seq[k];
+        for (int k = lane; k < LiLoad + 2; k += 64) W.sIncP[k] = rf.inc_prefix[k];
+    }
+    for (int k = lane; k < LjLoad; k += 64) {
+        unsigned char ch;
+        if (!rc) ch = A.reads[off + (uint64_t)k];
+        else {
+            ch = A.reads[off + (uint64_t)(Lj - 1 - k)];
+            if (ch >= 'a' && ch <= 'z') ch -= 32;                       // seq.upper(), CRISPRessoShared.py:402
+            unsigned char cc = 0;
+            if (ch == 'A') cc = 'T'; else if (ch == 'C') cc = 'G'; else if (ch == 'G') cc = 'C';
+            else if (ch == 'T') cc = 'A'; else if (ch == 'N' || ch == '_' || ch == '-') cc = ch;
+            if (cc == 0) { status |= C2_STATUS_RC_CHAR; cc = 'N'; }
+            ch = cc;
+        }
+        const unsigned char code = A.code_of_char[ch];
+        if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
+        W.sRead[k] = ch;
+        W.sCode[k] = code;
+        read_code_max = read_code_max > (int)code ? read_code_max : (int)code;
+    }
+    {
+        int bad = 0;
+        for (int k = lane; k < Li && k < max_li; k += 64) if (A.code_of_char[W.sRef[k]] == C2_INVALID_CODE) bad = 1;
+        if (bad) status |= C2_STATUS_OOB_CHAR;
+    }
+    if (Li <= 0 || Lj <= 0) status |= C2_STATUS_EMPTY;
+    if (Lj > A.max_lj || Li > max_li) status |= C2_STATUS_TOO_LONG;
+    status = (__ballot(status & C2_STATUS_EMPTY) ? C2_STATUS_EMPTY : 0) |
+             (__ballot(status & C2_STATUS_OOB_CHAR) ? C2_STATUS_OOB_CHAR : 0) |
+             (__ballot(status & C2_STATUS_RC_CHAR) ? C2_STATUS_RC_CHAR : 0) |
+             (__ballot(status & C2_STATUS_TOO_LONG) ? C2_STATUS_TOO_LONG : 0);
+    // packed = every read symbol has a code < 8 and every score fits a signed nibble: the score row of a reference
+    // base is then one register and a lookup is one v_bfe_i32 (no LDS in the inner loop).
+    packed = (A.score_pk != nullptr) && (__ballot(read_code_max >= 8) == 0ull);
+    return status;
+}
+
+__device__ __forceinline__ void c2_clear_record(c2_aln_record& rec, const int rc, const int ref_id) {
+    rec.aln_len = 0; rec.matches = 0; rec.insertion_n = 0; rec.deletion_n = 0; rec.substitution_n = 0;
+    rec.all_insertion_events = 0; rec.win_insertion_events = 0; rec.all_deletion_events = 0;
+    rec.win_deletion_events = 0; rec.all_deletion_bases = 0; rec.all_substitutions = 0;
+    rec.irregular_ends = 0; rec.status = 0; rec.strand = (uint8_t)rc; rec.reserved0 = 0; rec.ref_id = (uint16_t)ref_id;
+    rec.reserved2 = 0;
+}
+
+// Pointer plane of the row-strip kernel: nibble of cell (pi, pj), pi, pj >= 1.
+template <int R, bool BAND>
+struct c2_row_plane {
+    const uint16_t* sPtr; int max_lj, colStride, band_lanes;
+    __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
+        const int pp = (pi - 1) / (64 * R), rem = (pi - 1) % (64 * R);
+        bool inb;
+        const int pidx = c2_ptr_index<R, BAND>(rem / R, pj, colStride, band_lanes, inb);
+        if (!inb) return false;
+        const unsigned hw = sPtr[(size_t)pp * max_lj * colStride + pidx];
+        nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
+        return true;
+    }
+};
+
+// Traceback (pyx:338-421), wave-parallel: the wave-uniform state (i, j, s) advances one RUN at a time -- lane k probes the
+// k-th cell ahead along the current direction (diagonal for M, row for I, column for J), a ballot gives the length of the
+// run that stays in s, its columns are emitted by the lanes in one shot.  Emits the aligned strings reversed into
+// W.sTmpRead / W.sTmpRef.  need_full: a pointer word that decides the path is not stored in this plane.
+template <class PLANE>
+__device__ __forceinline__ void c2_traceback(const PLANE& P, const c2_wg& W, const int Li, const int Lj, const int min_score,
+                                             const int ge, const int g0, const int lane,
+                                             int& cnt, int& matches, int& status, bool& need_full)
+{
+    int i = Li, j = Lj;
+    int s = C2_ST_M;
+    cnt = 0; matches = 0; need_full = false;
+    {
+        unsigned nib = 0;
+        if (P.fetch(i, j, nib)) s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // start state, pyx:349-358
+        else need_full = true;
+    }
+    while (!need_full && (i > 0 || j > 0)) {
+        if (i == 0 || j == 0) {
+            const int need = (i == 0) ? C2_ST_I : C2_ST_J;           // initialised chains: iPointer[0,1:], jPointer[1:,0]
+            if (s != need) { status |= (s == C2_ST_M) ? C2_STATUS_SENTINEL_PATH : C2_STATUS_UNINIT_PTR; break; }
+            const int len = (i == 0) ? j : i;
+            for (int k = lane; k < len; k += 64) {
+                W.sTmpRead[cnt + k] = (i == 0) ? W.sRead[j - 1 - k] : (unsigned char)'-';
+                W.sTmpRef[cnt + k] = (i == 0) ? (unsigned char)'-' : W.sRef[i - 1 - k];
+            }
+            cnt += len; i = 0; j = 0;
+            break;
+        }
+        const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
+        const int ik = i - lane * di, jk = j - lane * dj;
+        const bool valid = (ik >= 1) && (jk >= 1);
+        int ns = 0;
+        bool oob = false;
+        if (valid) {
+            // cell whose pointer nibble decides the next state
+            const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
+            if (pi == 0 || pj == 0) {
+                ns = c2_boundary_hstate(pi, pj, min_score, ge, g0);   // only reachable for s == M
+            } else {
+                unsigned nib = 0;
+                if (P.fetch(pi, pj, nib)) {
+                    if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
+                    else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
+                    else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
+                } else oob = true;                                    // not stored: ns stays 0 (never == s)
+            }
+        }
+        const unsigned long long vmask = __ballot(valid);
+        const unsigned long long cmask = __ballot(valid && ns == s);
+        const unsigned long long omask = __ballot(oob);
+        const int nv = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
+        const int nc = (~cmask == 0ull) ? 64 : __builtin_ctzll(~cmask);
+        int E, s_next;
+        if (nc < nv) {
+            // lane nc decides the next state; if its pointer word is not stored, another kernel must redo this task
+            if ((omask >> nc) & 1ull) { need_full = true; break; }
+            E = nc + 1; s_next = __builtin_amdgcn_readlane(ns, nc);
+        } else { E = nv; s_next = s; }
+        unsigned char rch = '-', fch = '-';
+        if (lane < E) {
+            if (s != C2_ST_J) rch = W.sRead[jk - 1];
+            if (s != C2_ST_I) fch = W.sRef[ik - 1];
+            W.sTmpRead[cnt + lane] = rch;
+            W.sTmpRef[cnt + lane] = fch;
+        }
+        if (s == C2_ST_M) matches += __popcll(__ballot(lane < E && rch == fch));   // pyx:375-376
+        cnt += E; i -= E * di; j -= E * dj; s = s_next;
+    }
+}
+
+// Aligned strings out (reversed copy, pyx:434) + fused classification (COREResources.pyx:68-187 and the derived counters
+// of CRISPRessoCORE.py:726-760) from the strings still in LDS.  Column c (forward order) = tmp[T-1-c].  The aligner never
+// emits a double-gap column and never puts an insertion column next to a deletion column (I and J only hand over to M),
+// so every gap run is pure and idx advances by one on every non-insertion column.
+__device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int T,
+                                                     const int matches, const int lane, c2_aln_record& rec)
+{
+    const unsigned char* sTmpRead = W.sTmpRead; const unsigned char* sTmpRef = W.sTmpRef; const uint16_t* sIncP = W.sIncP;
+    uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
+    uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
+    for (int cidx = lane; cidx < T; cidx += 64) {
+        outR[cidx] = sTmpRead[T - 1 - cidx];
+        outF[cidx] = sTmpRef[T - 1 - cidx];
+    }
+    int idx_base = 0, last_rf = -1, last_rd = -1;
+    int n_all_sub = 0, n_win_sub = 0, n_all_ins = 0, n_win_ins = 0, n_all_del = 0, n_win_del = 0;
+    int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;   // per-lane partial sums
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = 0; base < T; base += 64) {
+        const int cidx = base + lane;
+        const bool in = cidx < T;
+        const unsigned char rd = in ? sTmpRead[T - 1 - cidx] : 0, rfc = in ? sTmpRef[T - 1 - cidx] : 0;
+        const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
+        const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
+        const int idx = idx_base + __popcll(m_rf & lt);             // ref bases left of this column
+        const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
+        const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
+        const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
+        // substitution, pyx:113-118
+        const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
+        const bool sub_win = sub && (sIncP[idx + 1] != sIncP[idx]);
+        n_all_sub += __popcll(__ballot(sub));
+        n_win_sub += __popcll(__ballot(sub_win));
+        // insertion closes at this column, pyx:119-128; leading insertions (idx==0) are never opened, pyx:136
+        const bool ins_close = rf_ng && (prev_rf != cidx - 1) && idx > 0;
+        const bool ins_win = ins_close && (sIncP[idx] != sIncP[idx - 1]) && (sIncP[idx + 1] != sIncP[idx]);
+        n_all_ins += __popcll(__ballot(ins_close));
+        n_win_ins += __popcll(__ballot(ins_win));
+        if (ins_win) acc_ins_n += cidx - 1 - prev_rf;
+        // deletion closes at this column, pyx:145-153
+        const bool del_close = rd_ng && (prev_rd != cidx - 1);
+        const int dlen = cidx - 1 - prev_rd;
+        const bool del_win = del_close && (sIncP[idx] != sIncP[idx - dlen]);   // include set hits range(start,end)
+        n_all_del += __popcll(__ballot(del_close));
+        n_win_del += __popcll(__ballot(del_win));
+        if (del_close) acc_del_bases += dlen;
+        if (del_win) acc_del_n += dlen;
+        idx_base += __popcll(m_rf);
+        if (m_rf) last_rf = base + 63 - __clzll((long long)m_rf);
+        if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
+    }
+    // trailing deletion, pyx:155-162
+    int tr_bases = 0, tr_win = 0;
+    if (last_rd != T - 1) {
+        const int dlen = T - 1 - last_rd;
+        tr_bases = dlen;
+        n_all_del += 1;
+        if (sIncP[idx_base] != sIncP[idx_base - dlen]) { tr_win = dlen; n_win_del += 1; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        acc_ins_n += __shfl_xor(acc_ins_n, m);
+        acc_del_n += __shfl_xor(acc_del_n, m);
+        acc_del_bases += __shfl_xor(acc_del_bases, m);
+    }
+    const unsigned char r0 = sTmpRead[T - 1], f0 = sTmpRef[T - 1], rL = sTmpRead[0], fL = sTmpRef[0];
+    rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
+    rec.aln_len = (uint16_t)T;
+    rec.matches = (uint16_t)matches;
+    rec.insertion_n = (uint16_t)acc_ins_n;
+    rec.deletion_n = (uint16_t)(acc_del_n + tr_win);
+    rec.substitution_n = (uint16_t)n_win_sub;
+    rec.all_insertion_events = (uint16_t)n_all_ins;
+    rec.win_insertion_events = (uint16_t)n_win_ins;
+    rec.all_deletion_events = (uint16_t)n_all_del;
+    rec.win_deletion_events = (uint16_t)n_win_del;
+    rec.all_deletion_bases = (uint16_t)(acc_del_bases + tr_bases);
+    rec.all_substitutions = (uint16_t)n_all_sub;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-strip kernel.  BAND = false: full pointer plane (any path).  BAND = true: only the lanes within A.band_lanes of the
+// main diagonal keep their pointer words (single-pass references only); a traceback that needs a word outside the band
+// appends the task to A.fb_list, and the host re-runs exactly those tasks with the full-plane kernel (A.task_list mode).
+// The band limits what is STORED, never what is computed, so results do not depend on it.
+// ---------------------------------------------------------------------------------------------------------------
 template <int R, bool BAND>
 __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args A)
 {
@@ -312,12 +582,9 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
     uint16_t* sPtr = (uint16_t*)(c2_smem + P.ptr);
     int* sBnd = (int*)(c2_smem + P.bnd);
     int16_t* sTbl = (int16_t*)(c2_smem + P.tbl);
-    unsigned char* sRead = c2_smem + P.read;
-    unsigned char* sCode = c2_smem + P.code;
-    unsigned char* sRef = c2_smem + P.ref;
-    uint16_t* sIncP = (uint16_t*)(c2_smem + P.incp);
-    unsigned char* sTmpRead = c2_smem + P.tmp_read;
-    unsigned char* sTmpRef = c2_smem + P.tmp_ref;
+    c2_wg W;
+    W.sRead = c2_smem + P.read; W.sCode = c2_smem + P.code; W.sRef = c2_smem + P.ref;
+    W.sIncP = (uint16_t*)(c2_smem + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
     const int colStride = (int)P.col_stride;
     const int ROWS_PER_PASS = 64 * R;
     const int ge = A.gap_extend, go = A.gap_open;
@@ -327,266 +594,52 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
 
     int cur_ref = -1;
     int Li = 0, g0 = 0;
-
-    // Work distribution: workgroups pull chunks of C2_TASK_CHUNK consecutive tasks from a device counter (one returning
-    // atomic per chunk), so a launch never waits for the slowest statically assigned share and does not depend on how
-    // many workgroups are actually resident.
-    const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : A.n_tasks;
-    uint64_t chunk_base = 0;
+    uint64_t chunk_base = 0, task = 0;
     int chunk_left = 0;
-    for (;;) {
-        if (chunk_left == 0) {
-            unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(A.work_counter, (unsigned long long)C2_TASK_CHUNK);
-            chunk_base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
-                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
-            chunk_left = C2_TASK_CHUNK;
-        }
-        const uint64_t it = chunk_base;
-        if (it >= n_iter) break;
-        ++chunk_base; --chunk_left;
-        const uint64_t task = A.task_list ? (uint64_t)A.task_list[it] : it;
-        uint64_t read_id;
-        int ref_id;
-        if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
-        else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
-        const int rc = A.strands ? (int)A.strands[task] : 0;
-        const uint64_t off = A.offsets[read_id];
-        const int Lj = (int)(A.offsets[read_id + 1] - off);
-        int status = 0;
-        int read_code_max = 0;
-        const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
-
+    while (c2_next_task(A, lane, chunk_base, chunk_left, task)) {
         __syncthreads();   // previous task's LDS readers are done
         unsigned long long t_phase = A.phase_cycles ? (unsigned long long)clock64() : 0ull;
-        // ---- reference: chars, window prefix, per-lane row constants (reloaded only when the amplicon changes)
-        if (ref_id != cur_ref) {
-            cur_ref = ref_id;
-            const c2_dev_ref rf = A.refs[ref_id];
-            Li = rf.len;
-            g0 = rf.gap_incentive[0];
-            const int LiLoad = Li < A.max_passes * ROWS_PER_PASS ? Li : A.max_passes * ROWS_PER_PASS;
-            for (int k = lane; k < LiLoad; k += 64) sRef[k] = rf.seq[k];
-            for (int k = lane; k < LiLoad + 2; k += 64) sIncP[k] = rf.inc_prefix[k];
-        }
+        int Lj, ref_id, rc;
+        bool ref_changed, packed;
+        int status = c2_fetch_task(A, W, task, lane, A.max_passes * ROWS_PER_PASS, cur_ref, Li, g0, Lj, ref_id, rc, ref_changed, packed);
         const c2_dev_ref rf = A.refs[ref_id];
-        // ---- read: coalesced byte loads (64 consecutive bytes per instruction), optional reverse complement
-        for (int k = lane; k < LjLoad; k += 64) {
-            unsigned char ch;
-            if (!rc) ch = A.reads[off + (uint64_t)k];
-            else {
-                ch = A.reads[off + (uint64_t)(Lj - 1 - k)];
-                if (ch >= 'a' && ch <= 'z') ch -= 32;                       // seq.upper(), CRISPRessoShared.py:402
-                unsigned char cc = 0;
-                if (ch == 'A') cc = 'T'; else if (ch == 'C') cc = 'G'; else if (ch == 'G') cc = 'C';
-                else if (ch == 'T') cc = 'A'; else if (ch == 'N' || ch == '_' || ch == '-') cc = ch;
-                if (cc == 0) { status |= C2_STATUS_RC_CHAR; cc = 'N'; }
-                ch = cc;
-            }
-            const unsigned char code = A.code_of_char[ch];
-            if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
-            sRead[k] = ch;
-            sCode[k] = code;
-            read_code_max = read_code_max > (int)code ? read_code_max : (int)code;
-        }
-        {
-            int bad = 0;
-            for (int k = lane; k < Li && k < A.max_passes * ROWS_PER_PASS; k += 64) if (A.code_of_char[sRef[k]] == C2_INVALID_CODE) bad = 1;
-            if (bad) status |= C2_STATUS_OOB_CHAR;
-        }
-        if (Li <= 0 || Lj <= 0) status |= C2_STATUS_EMPTY;
         const int passes = (Li + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-        if (Lj > A.max_lj || passes > A.max_passes || (BAND && passes != 1)) status |= C2_STATUS_TOO_LONG;
-        status = (__ballot(status & C2_STATUS_EMPTY) ? C2_STATUS_EMPTY : 0) |
-                 (__ballot(status & C2_STATUS_OOB_CHAR) ? C2_STATUS_OOB_CHAR : 0) |
-                 (__ballot(status & C2_STATUS_RC_CHAR) ? C2_STATUS_RC_CHAR : 0) |
-                 (__ballot(status & C2_STATUS_TOO_LONG) ? C2_STATUS_TOO_LONG : 0);
+        if (BAND && passes != 1) status |= C2_STATUS_TOO_LONG;
         __syncthreads();
 
         c2_aln_record rec;
-        rec.aln_len = 0; rec.matches = 0; rec.insertion_n = 0; rec.deletion_n = 0; rec.substitution_n = 0;
-        rec.all_insertion_events = 0; rec.win_insertion_events = 0; rec.all_deletion_events = 0;
-        rec.win_deletion_events = 0; rec.all_deletion_bases = 0; rec.all_substitutions = 0;
-        rec.irregular_ends = 0; rec.strand = (uint8_t)rc; rec.reserved0 = 0; rec.ref_id = (uint16_t)ref_id;
-        rec.reserved2 = 0;
-
+        c2_clear_record(rec, rc, ref_id);
         if (status == 0) {
             // pyx:150  int min_score = gap_open * max_j * max_i   (wraps like the reference's C int)
             const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
-
             c2_phase_mark(A.phase_cycles, 0, t_phase, lane);   // phase 0: task fetch (offsets, read, reference rows)
             // =========================== DP: systolic sweep, pass by pass ===========================
-            // packed = every read symbol has a code < 8 and every score fits a signed nibble: the score row of a
-            // reference base is then one register and a lookup is one v_bfe_i32 (no LDS in the inner loop).
-            const bool packed = (A.score_pk != nullptr) && (__ballot(read_code_max >= 8) == 0ull);
             for (int p = 0; p < passes; ++p) {
                 const bool single = (passes == 1);
                 uint16_t* planePtr = sPtr + (size_t)p * (size_t)A.max_lj * colStride;
                 if (packed) {
-                    if (single) c2_dp_pass<R, true, true, BAND>(A, rf, sRef, sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                    else        c2_dp_pass<R, true, false, false>(A, rf, sRef, sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    if (single) c2_dp_pass<R, true, true, BAND>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    else        c2_dp_pass<R, true, false, false>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
                 } else {
-                    if (single) c2_dp_pass<R, false, true, BAND>(A, rf, sRef, sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                    else        c2_dp_pass<R, false, false, false>(A, rf, sRef, sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    if (single) c2_dp_pass<R, false, true, BAND>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    else        c2_dp_pass<R, false, false, false>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
                 }
                 __syncthreads();
             }
-
             c2_phase_mark(A.phase_cycles, 1, t_phase, lane);   // phase 1: DP fill
-            // =========================== traceback: wave-parallel run detection ===========================
-            int i = Li, j = Lj, cnt = 0, matches = 0;
-            int s = C2_ST_M;
-            bool need_full = false;                      // BAND: the path left the stored band
-            {
-                const int pp = (i - 1) / ROWS_PER_PASS, rem = (i - 1) % ROWS_PER_PASS;
-                bool inb;
-                const int pidx = c2_ptr_index<R, BAND>(rem / R, j, colStride, A.band_lanes, inb);
-                if (inb) {
-                    const unsigned hw = sPtr[(size_t)pp * A.max_lj * colStride + pidx];
-                    const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
-                    s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // pyx:349-358
-                } else need_full = true;
-            }
-            while (!need_full && (i > 0 || j > 0)) {
-                if (i == 0 || j == 0) {
-                    const int need = (i == 0) ? C2_ST_I : C2_ST_J;           // initialised chains: iPointer[0,1:], jPointer[1:,0]
-                    if (s != need) { status |= (s == C2_ST_M) ? C2_STATUS_SENTINEL_PATH : C2_STATUS_UNINIT_PTR; break; }
-                    const int len = (i == 0) ? j : i;
-                    for (int k = lane; k < len; k += 64) {
-                        sTmpRead[cnt + k] = (i == 0) ? sRead[j - 1 - k] : (unsigned char)'-';
-                        sTmpRef[cnt + k] = (i == 0) ? (unsigned char)'-' : sRef[i - 1 - k];
-                    }
-                    cnt += len; i = 0; j = 0;
-                    break;
-                }
-                const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
-                const int ik = i - lane * di, jk = j - lane * dj;
-                const bool valid = (ik >= 1) && (jk >= 1);
-                int ns = 0;
-                bool oob = false;
-                if (valid) {
-                    // cell whose pointer nibble decides the next state
-                    const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
-                    if (pi == 0 || pj == 0) {
-                        ns = c2_boundary_hstate(pi, pj, min_score, ge, g0);   // only reachable for s == M
-                    } else {
-                        const int pp = (pi - 1) / ROWS_PER_PASS, rem = (pi - 1) % ROWS_PER_PASS;
-                        bool inb;
-                        const int pidx = c2_ptr_index<R, BAND>(rem / R, pj, colStride, A.band_lanes, inb);
-                        if (inb) {
-                            const unsigned hw = sPtr[(size_t)pp * A.max_lj * colStride + pidx];
-                            const unsigned nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
-                            if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
-                            else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
-                            else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
-                        } else oob = true;                                    // not stored: ns stays 0 (never == s)
-                    }
-                }
-                const unsigned long long vmask = __ballot(valid);
-                const unsigned long long cmask = __ballot(valid && ns == s);
-                const int nv = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
-                const int nc = (~cmask == 0ull) ? 64 : __builtin_ctzll(~cmask);
-                int E, s_next;
-                if (nc < nv) {
-                    // lane nc decides the next state; if its pointer word is outside the stored band the full kernel must redo this task
-                    if (BAND && ((__ballot(oob) >> nc) & 1ull)) { need_full = true; break; }
-                    E = nc + 1; s_next = __builtin_amdgcn_readlane(ns, nc);
-                } else { E = nv; s_next = s; }
-                unsigned char rch = '-', fch = '-';
-                if (lane < E) {
-                    if (s != C2_ST_J) rch = sRead[jk - 1];
-                    if (s != C2_ST_I) fch = sRef[ik - 1];
-                    sTmpRead[cnt + lane] = rch;
-                    sTmpRef[cnt + lane] = fch;
-                }
-                if (s == C2_ST_M) matches += __popcll(__ballot(lane < E && rch == fch));   // pyx:375-376
-                cnt += E; i -= E * di; j -= E * dj; s = s_next;
-            }
+            // =========================== traceback ===========================
+            c2_row_plane<R, BAND> plane;
+            plane.sPtr = sPtr; plane.max_lj = A.max_lj; plane.colStride = colStride; plane.band_lanes = A.band_lanes;
+            int cnt, matches;
+            bool need_full;
+            c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, need_full);
             __syncthreads();
             c2_phase_mark(A.phase_cycles, 2, t_phase, lane);   // phase 2: traceback
-            if (BAND && need_full) {
+            if (need_full) {                                   // only possible with BAND
                 status |= C2_STATUS_NEED_FULL;
                 if (lane == 0) { const unsigned k = atomicAdd(A.fb_count, 1u); A.fb_list[k] = (uint32_t)task; }
             }
-
-            if (status == 0) {
-                const int T = cnt;
-                // =========================== aligned strings out (reversed copy, pyx:434) ===========================
-                uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
-                uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
-                for (int cidx = lane; cidx < T; cidx += 64) {
-                    outR[cidx] = sTmpRead[T - 1 - cidx];
-                    outF[cidx] = sTmpRef[T - 1 - cidx];
-                }
-                // =========================== classification (COREResources.pyx:68-187) ===========================
-                // column c (forward order) = tmp[T-1-c].  The aligner never emits a double-gap column and never
-                // puts an insertion column next to a deletion column (I and J only hand over to M), so every gap
-                // run is pure and idx advances by one on every non-insertion column.
-                int idx_base = 0, last_rf = -1, last_rd = -1;
-                int n_all_sub = 0, n_win_sub = 0, n_all_ins = 0, n_win_ins = 0, n_all_del = 0, n_win_del = 0;
-                int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;   // per-lane partial sums
-                const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                for (int base = 0; base < T; base += 64) {
-                    const int cidx = base + lane;
-                    const bool in = cidx < T;
-                    const unsigned char rd = in ? sTmpRead[T - 1 - cidx] : 0, rfc = in ? sTmpRef[T - 1 - cidx] : 0;
-                    const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
-                    const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
-                    const int idx = idx_base + __popcll(m_rf & lt);             // ref bases left of this column
-                    const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
-                    const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
-                    const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
-                    // substitution, pyx:113-118
-                    const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
-                    const bool sub_win = sub && (sIncP[idx + 1] != sIncP[idx]);
-                    n_all_sub += __popcll(__ballot(sub));
-                    n_win_sub += __popcll(__ballot(sub_win));
-                    // insertion closes at this column, pyx:119-128; leading insertions (idx==0) are never opened, pyx:136
-                    const bool ins_close = rf_ng && (prev_rf != cidx - 1) && idx > 0;
-                    const bool ins_win = ins_close && (sIncP[idx] != sIncP[idx - 1]) && (sIncP[idx + 1] != sIncP[idx]);
-                    n_all_ins += __popcll(__ballot(ins_close));
-                    n_win_ins += __popcll(__ballot(ins_win));
-                    if (ins_win) acc_ins_n += cidx - 1 - prev_rf;
-                    // deletion closes at this column, pyx:145-153
-                    const bool del_close = rd_ng && (prev_rd != cidx - 1);
-                    const int dlen = cidx - 1 - prev_rd;
-                    const bool del_win = del_close && (sIncP[idx] != sIncP[idx - dlen]);   // include set hits range(start,end)
-                    n_all_del += __popcll(__ballot(del_close));
-                    n_win_del += __popcll(__ballot(del_win));
-                    if (del_close) acc_del_bases += dlen;
-                    if (del_win) acc_del_n += dlen;
-                    idx_base += __popcll(m_rf);
-                    if (m_rf) last_rf = base + 63 - __clzll((long long)m_rf);
-                    if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
-                }
-                // trailing deletion, pyx:155-162
-                int tr_bases = 0, tr_win = 0;
-                if (last_rd != T - 1) {
-                    const int dlen = T - 1 - last_rd;
-                    tr_bases = dlen;
-                    n_all_del += 1;
-                    if (sIncP[idx_base] != sIncP[idx_base - dlen]) { tr_win = dlen; n_win_del += 1; }
-                }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    acc_ins_n += __shfl_xor(acc_ins_n, m);
-                    acc_del_n += __shfl_xor(acc_del_n, m);
-                    acc_del_bases += __shfl_xor(acc_del_bases, m);
-                }
-                const unsigned char r0 = sTmpRead[T - 1], f0 = sTmpRef[T - 1], rL = sTmpRead[0], fL = sTmpRef[0];
-                rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
-                rec.aln_len = (uint16_t)T;
-                rec.matches = (uint16_t)matches;
-                rec.insertion_n = (uint16_t)acc_ins_n;
-                rec.deletion_n = (uint16_t)(acc_del_n + tr_win);
-                rec.substitution_n = (uint16_t)n_win_sub;
-                rec.all_insertion_events = (uint16_t)n_all_ins;
-                rec.win_insertion_events = (uint16_t)n_win_ins;
-                rec.all_deletion_events = (uint16_t)n_all_del;
-                rec.win_deletion_events = (uint16_t)n_win_del;
-                rec.all_deletion_bases = (uint16_t)(acc_del_bases + tr_bases);
-                rec.all_substitutions = (uint16_t)n_all_sub;
-            }
+            if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec);
         }
         rec.status = (uint8_t)status;
         if (lane == 0) A.records[task] = rec;
