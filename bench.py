@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="processes generating the synthetic reads (0 = auto; 1 = no fork, for profiler runs)")
     ap.add_argument("--band", type=int, default=-1, help="pointer-plane band: -1 auto, 0 off, n lanes each side")
     ap.add_argument("--band-wgs", type=int, default=0, help="target workgroups per CU for the automatic band")
+    ap.add_argument("--kernel", choices=["auto", "band", "full"], default="auto", help="first-launch kernel (auto = diagonal-band with certificate)")
     ap.add_argument("--check", type=int, default=300, help="reads compared with the oracle after the timed region")
     args = ap.parse_args()
 
@@ -79,6 +80,7 @@ def main():
     m = A.read_matrix(matrix_path)
     ctx = _native.Context(local_rank)
     ctx.set_band(args.band, args.band_wgs)
+    ctx.set_kernel_mode(args.kernel)
     al = BatchAligner([amp], [gap_inc], [include], m, -20, -2, ctx=ctx)
     stride = al.stride_for(L)
 
@@ -184,6 +186,7 @@ def main():
                        "reads_per_gpu_per_step": n, "read_len": L, "amplicon_len": L, "unique_read_fraction": unique_fraction, "unique_read_fraction_sample": n_u,
                        "rows_per_lane": info["rows_per_lane"], "lds_bytes_per_workgroup": info["lds_bytes"],
                        "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
+                       "first_launch_kernel": ("c2_align_diag_kernel" if band["band_lanes"] < 0 else "c2_align_classify_kernel (banded)" if band["band_lanes"] > 0 else "c2_align_classify_kernel (full plane)"),
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -20,7 +20,7 @@ SYMBOLS = [
     "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
-    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_count_vectors_device",
+    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_count_vectors_device",
 ]
 
 REC_DTYPE = np.dtype([
@@ -149,6 +149,11 @@ class Context:
 
     def set_band(self, band_lanes=-1, target_workgroups_per_cu=0):
         self.check(self.lib.c2_set_band(self.handle, int(band_lanes), int(target_workgroups_per_cu)), "c2_set_band")
+
+    def set_kernel_mode(self, mode):
+        """'auto' (diagonal-band kernel when applicable), 'band' (banded row-strip), 'full' (full-plane row-strip)"""
+        code = {'auto': 0, 'band': 1, 'full': 2}.get(mode, mode)
+        self.check(self.lib.c2_set_kernel_mode(self.handle, int(code)), "c2_set_kernel_mode")
 
     def band_info(self, max_read_len):
         a, b = ctypes.c_int32(0), ctypes.c_int32(0)

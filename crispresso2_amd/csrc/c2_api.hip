@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <mutex>
 #include <string>
@@ -59,7 +60,10 @@ struct c2_ctx {
     // banded first launch: -1 auto, 0 off, >0 lanes each side; fallback list buffer
     int band_setting = -1;
     int band_target_wgs = 14;
+    int kernel_mode = 0;   // 0 auto (diagonal-band kernel when applicable), 1 banded row-strip, 2 full row-strip
+    int gmax = 0;          // largest gap incentive over the references
     DevBuf d_fb;
+    int occ_diag_lds = -1, occ_diag_blocks = 0;
     int occ_lds[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
     int occ_blocks[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
@@ -94,6 +98,7 @@ struct Geometry {
     int R, passes, max_lj;
     uint32_t lds_full; int blocks_full;          // full pointer plane
     int band_lanes; uint32_t lds_band; int blocks_band;   // banded first launch (band_lanes == 0: not used)
+    bool diag; uint32_t lds_diag; int blocks_diag;         // diagonal-band first launch
 };
 
 template <int R, bool BAND>
@@ -136,11 +141,26 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     }
     int rc;
     if ((rc = occupancy_r<false>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
+    // Diagonal-band first launch (c2_align_diag_kernel): needs the packed score rows and a negative per-gap-base bound
+    g.diag = false; g.lds_diag = 0; g.blocks_diag = 0;
+    if (ctx->kernel_mode == 0 && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
+        g.lds_diag = c2_make_diag_plan(ctx->max_li, g.max_lj).total;
+        if (g.lds_diag <= lds_cu) {
+            if (ctx->occ_diag_lds != (int)g.lds_diag) {
+                int nb = 0;
+                HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_diag_kernel, 64, g.lds_diag));
+                ctx->occ_diag_blocks = nb < 1 ? 1 : nb; ctx->occ_diag_lds = (int)g.lds_diag;
+            }
+            g.blocks_diag = ctx->occ_diag_blocks;
+            g.diag = true;
+        }
+    }
     // Banded first launch: keep only the pointer words of the lanes near the main diagonal so that more workgroups fit
     // a CU (the DP is latency-bound at one wave per SIMD).  band: -1 auto, 0 off, >0 lanes on each side.
     g.band_lanes = 0; g.lds_band = 0; g.blocks_band = 0;
-    int want = ctx->band_setting;
-    if (g.passes == 1 && want != 0) {
+    int want = ctx->kernel_mode == 2 ? 0 : ctx->band_setting;
+    if (!g.diag && g.passes == 1 && want != 0) {
         if (want < 0) {
             // auto: the widest band whose plan still lets `band_target_wgs` workgroups share a CU's LDS
             want = 0;
@@ -174,8 +194,8 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
         HIPCHK(ctx, hipEventRecord(tl.a, s));
     }
     int rc;
-    A.band_lanes = 0; A.reserved = 0; A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
-    if (g.band_lanes > 0) {
+    A.band_lanes = 0; A.reserved = getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0; A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
+    if (g.diag || g.band_lanes > 0) {
         if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
         if ((rc = ensure(ctx, ctx->d_fb, 32 + A.n_tasks * sizeof(uint32_t)))) return rc;
         uint32_t* fb_count = (uint32_t*)ctx->d_fb.p;             // [0] fallback count, [2..3] work counter (banded), [4..5] work counter (full)
@@ -183,7 +203,12 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
         HIPCHK(ctx, hipMemsetAsync(fb_count, 0, 32, s));
         A.work_counter = (unsigned long long*)(fb_count + 2);
         A.band_lanes = g.band_lanes; A.fb_count = fb_count; A.fb_list = fb_list;
-        if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
+        if (g.diag) {
+            const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)g.blocks_diag;
+            const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(A.n_tasks, resident));
+            hipLaunchKernelGGL(c2_align_diag_kernel, dim3(grid), dim3(64), g.lds_diag, s, A);
+            HIPCHK(ctx, hipGetLastError());
+        } else if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
         // the tasks whose traceback left the band, redone with the full pointer plane (usually a handful; an empty list costs one tiny launch)
         A.band_lanes = 0; A.task_list = fb_list; A.task_count = fb_count;
         A.work_counter = (unsigned long long*)(fb_count + 4);
@@ -214,6 +239,12 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.n_tasks = n_tasks; A.aln_stride = b->aln_stride; A.n_refs = ctx->n_refs; A.all_refs = b->all_refs ? 1 : 0;
     A.n_codes = ctx->sc.n_codes; A.gap_open = ctx->gap_open; A.gap_extend = ctx->gap_extend;
     A.max_lj = g.max_lj; A.max_passes = g.passes;
+    A.max_li = ctx->max_li;
+    {
+        int mx = 0;
+        for (int16_t v : ctx->sc.tbl) mx = std::max(mx, (int)v);
+        A.max_score = mx;
+    }
     A.phase_cycles = ctx->phase_prof ? (unsigned long long*)ctx->d_phase.p : nullptr;
     switch (g.R) {
         case 1: return launch_align<1>(ctx, A, g, s);
@@ -324,12 +355,17 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
     if ((rc = ensure(ctx, ctx->d_refdesc, sizeof(c2_dev_ref) * (size_t)n_refs))) return rc;
     std::vector<c2_dev_ref> desc(n_refs);
     ctx->ref_len.resize(n_refs);
+    ctx->gmax = 0;
     for (int r = 0; r < n_refs; ++r) {
         uint8_t* base = (uint8_t*)ctx->d_refblob.p;
         desc[r].seq = base + off_seq[r];
         desc[r].gap_incentive = (const int32_t*)(base + off_g[r]);
         desc[r].inc_prefix = (const uint16_t*)(base + off_p[r]);
-        desc[r].len = lens[r]; desc[r].reserved = 0;
+        desc[r].len = lens[r];
+        int64_t gm = 0;
+        for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, gap_incentives[r][k]);
+        desc[r].gap_incentive_max = (int32_t)std::min<int64_t>(gm, 1 << 20);
+        ctx->gmax = std::max(ctx->gmax, desc[r].gap_incentive_max);
         ctx->ref_len[r] = lens[r];
     }
     HIPCHK(ctx, hipMemcpy(ctx->d_refblob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -348,8 +384,8 @@ int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, in
     if (rc) return rc;
     if (rows_per_lane) *rows_per_lane = g.R;
     if (passes) *passes = g.passes;
-    if (lds_bytes) *lds_bytes = (int32_t)(g.band_lanes ? g.lds_band : g.lds_full);
-    if (workgroups_per_cu) *workgroups_per_cu = g.band_lanes ? g.blocks_band : g.blocks_full;
+    if (lds_bytes) *lds_bytes = (int32_t)(g.diag ? g.lds_diag : g.band_lanes ? g.lds_band : g.lds_full);
+    if (workgroups_per_cu) *workgroups_per_cu = g.diag ? g.blocks_diag : g.band_lanes ? g.blocks_band : g.blocks_full;
     if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
     return 0;
 }
@@ -361,13 +397,19 @@ int c2_set_band(c2_ctx* ctx, int32_t band_lanes, int32_t target_workgroups_per_c
     return 0;
 }
 
+int c2_set_kernel_mode(c2_ctx* ctx, int32_t mode) {
+    if (!ctx || mode < 0 || mode > 2) return C2_E_INVALID;
+    ctx->kernel_mode = mode;
+    return 0;
+}
+
 int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t* fallback_tasks_last_launch) {
     if (!ctx) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Geometry g;
     int rc = geometry(ctx, max_read_len, g);
     if (rc) return rc;
-    if (band_lanes) *band_lanes = g.band_lanes;
+    if (band_lanes) *band_lanes = g.diag ? -1 : g.band_lanes;
     if (fallback_tasks_last_launch) {
         *fallback_tasks_last_launch = 0;
         if (ctx->d_fb.p) {

@@ -12,6 +12,7 @@
 #define C2_INVALID_CODE 255
 #define C2_PTR_PAD 2               // halfword padding of one pointer column (breaks the 128-B bank stride)
 #define C2_LANES 64
+#define C2_DIAG_NEG (-(1 << 30))   // diagonal-band kernel: value of everything outside the band
 #define C2_TASK_CHUNK 4              // tasks a workgroup takes per atomic
 #define C2_STATUS_NEED_FULL 64     // internal: banded launch could not finish the traceback; the full-plane launch overwrites the record
 
@@ -21,7 +22,7 @@ typedef struct c2_dev_ref {
     const int32_t* gap_incentive; // Li+1 (int64 input truncated to int32 exactly as the reference's int arithmetic does)
     const uint16_t* inc_prefix;   // Li+2: inc_prefix[x] = number of include idxs < x  (window membership and range hits)
     int32_t len;                  // Li
-    int32_t reserved;
+    int32_t gap_incentive_max;    // max(0, max_i gap_incentive[i]); max(gap_open, gap_extend) + this bounds what one gap base adds to a score
 } c2_dev_ref;
 
 // Kernel arguments for the fused align + traceback + classify kernel.
@@ -45,7 +46,9 @@ typedef struct c2_align_args {
     int32_t gap_open, gap_extend;
     int32_t max_lj;               // LDS plan: longest read of this launch
     int32_t max_passes;           // LDS plan: ceil(max Li / (64*R))
-    int32_t band_lanes;           // banded kernel: lanes kept on each side of the main-diagonal lane
+    int32_t band_lanes;           // banded row-strip kernel: lanes kept on each side of the main-diagonal lane
+    int32_t max_score;            // diagonal-band kernel: largest entry of the score table (>= 0)
+    int32_t max_li;               // diagonal-band kernel: LDS plan, longest reference
     int32_t reserved;
     uint32_t* fb_count;           // banded kernel: number of tasks whose traceback left the band ...
     uint32_t* fb_list;            // ... and their task indices (capacity n_tasks)

@@ -34,13 +34,14 @@ __device__ __forceinline__ int c2_shr1(int old, int src) {
 }
 
 __device__ __forceinline__ int c2_imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int c2_clamp(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }   // v_med3_i32
 
 // sign-extended 4-bit field of x starting at bit `off`
 __device__ __forceinline__ int c2_sbfe4(int x, int off) { return __builtin_amdgcn_sbfe(x, off, 4); }
 
 struct c2_lds_plan {
     // byte offsets into dynamic LDS (all multiples of 16)
-    uint32_t ptr, bnd, tbl, read, code, ref, incp, tmp_read, tmp_ref, total;
+    uint32_t ptr, bnd, tbl, codeof, read, code, ref, incp, tmp_read, tmp_ref, total;
     uint32_t col_stride;  // halfwords per pointer column
 };
 
@@ -65,6 +66,7 @@ __host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_p
     p.ptr = off;      off += c2_align16((uint32_t)max_passes * plane_rows * p.col_stride * 2u);
     p.bnd = off;      off += (max_passes > 1) ? c2_align16(3u * ((uint32_t)max_lj + 1u) * 4u) : 0u;
     p.tbl = off;      off += c2_align16((uint32_t)n_codes * (uint32_t)n_codes * 2u);
+    p.codeof = off;   off += 256u;
     p.read = off;     off += c2_align16((uint32_t)max_lj);
     p.code = off;     off += c2_align16((uint32_t)max_lj);
     p.ref = off;      off += c2_align16(max_li);
@@ -108,14 +110,21 @@ __device__ __forceinline__ void c2_push4(unsigned& bits, int a0, int b0, int a1,
 #endif
 }
 
-// Optional per-phase cycle accounting (c2_align_args.phase_cycles != NULL): lane 0 adds the s_memtime delta of each
-// phase of each task to a global counter.  Used by tools/phase_profile.py; costs one uniform branch when disabled.
-__device__ __forceinline__ void c2_phase_mark(unsigned long long* acc, int phase, unsigned long long& t_last, int lane) {
+// Optional per-phase cycle accounting (c2_align_args.phase_cycles != NULL): every workgroup sums the s_memtime delta of
+// each phase of each of its tasks in registers and adds the four sums to the global counters once, when it runs out of
+// work.  Used by tools/phase_profile.py; costs one uniform branch per phase when disabled.
+struct c2_phase_acc { unsigned long long t_last, sum[4]; };
+__device__ __forceinline__ void c2_phase_begin(const unsigned long long* acc, c2_phase_acc& P) { if (acc) P.t_last = (unsigned long long)clock64(); }
+template <int PHASE>
+__device__ __forceinline__ void c2_phase_mark(const unsigned long long* acc, c2_phase_acc& P) {
     if (acc) {
         const unsigned long long now = (unsigned long long)clock64();
-        if (lane == 0) atomicAdd(acc + phase, now - t_last);
-        t_last = (unsigned long long)clock64();
+        P.sum[PHASE] += now - P.t_last;
+        P.t_last = now;
     }
+}
+__device__ __forceinline__ void c2_phase_flush(unsigned long long* acc, const c2_phase_acc& P, const int lane) {
+    if (acc && lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(acc + k, P.sum[k]); }
 }
 
 // floor(x / R) for the rows-per-lane values in use (x < 32768)
@@ -334,25 +343,48 @@ __device__ __forceinline__ bool c2_next_task(const c2_align_args& A, const int l
     return true;
 }
 
-// Stage one task in LDS: reference (only when the amplicon changes), read (coalesced byte loads, optional reverse
-// complement), codes.  Returns the wave-uniform status bits.  max_li / A.max_lj bound what may be written.
-__device__ __forceinline__ int c2_fetch_task(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int lane,
-                                             const int max_li, int& cur_ref, int& Li, int& g0, int& Lj, int& ref_id, int& rc,
-                                             bool& ref_changed, bool& packed)
+// The next task's descriptor and the first 256 bytes of its read, requested from HBM while the current task is still in
+// its DP (nothing waits for these loads until c2_commit_task uses them): one task of software pipelining per workgroup.
+struct c2_prefetch {
+    uint64_t task, off;
+    int valid, Lj, ref_id, rc;
+    unsigned b4;                     // read bytes lane, lane+64, lane+128, lane+192 in bytes 0..3 (already reversed for rc tasks)
+};
+
+__device__ __forceinline__ void c2_prefetch_issue(const c2_align_args& A, const int lane, uint64_t& chunk_base, int& chunk_left,
+                                                  c2_prefetch& pf)
 {
+    pf.valid = c2_next_task(A, lane, chunk_base, chunk_left, pf.task) ? 1 : 0;
+    if (!pf.valid) return;
     uint64_t read_id;
-    if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
-    else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
-    rc = A.strands ? (int)A.strands[task] : 0;
-    const uint64_t off = A.offsets[read_id];
-    Lj = (int)(A.offsets[read_id + 1] - off);
+    if (A.all_refs) { read_id = pf.task / (uint64_t)A.n_refs; pf.ref_id = (int)(pf.task % (uint64_t)A.n_refs); }
+    else            { read_id = pf.task; pf.ref_id = A.ref_ids ? (int)A.ref_ids[pf.task] : 0; }
+    pf.rc = A.strands ? (int)A.strands[pf.task] : 0;
+    pf.off = A.offsets[read_id];
+    pf.Lj = (int)(A.offsets[read_id + 1] - pf.off);
+    unsigned b4 = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = 64 * q + lane;
+        const unsigned byte = (k < pf.Lj) ? (unsigned)A.reads[pf.off + (uint64_t)(pf.rc ? pf.Lj - 1 - k : k)] : 0u;
+        b4 |= byte << (8 * q);
+    }
+    pf.b4 = b4;
+}
+
+// Stage the prefetched task in LDS: reference (only when the amplicon changes), read characters (reverse complement on
+// request, CRISPRessoShared.py:399-403) and their codes.  Returns the wave-uniform status bits.  max_li / A.max_lj bound
+// what may be written.  sCodeOf: the 256-entry character -> code table, in LDS.
+__device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_wg& W, const unsigned char* sCodeOf, const c2_prefetch& pf,
+                                              const int lane, const int max_li, int& cur_ref, int& Li, int& g0, bool& packed)
+{
+    const int Lj = pf.Lj, rc = pf.rc;
     int status = 0;
     int read_code_max = 0;
     const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
-    ref_changed = (ref_id != cur_ref);
-    if (ref_changed) {
-        cur_ref = ref_id;
-        const c2_dev_ref rf = A.refs[ref_id];
+    if (pf.ref_id != cur_ref) {
+        cur_ref = pf.ref_id;
+        const c2_dev_ref rf = A.refs[pf.ref_id];
         Li = rf.len;
         g0 = rf.gap_incentive[0];
         const int LiLoad = Li < max_li ? Li : max_li;
@@ -361,17 +393,17 @@ __device__ __forceinline__ int c2_fetch_task(const c2_align_args& A, const c2_wg
     }
     for (int k = lane; k < LjLoad; k += 64) {
         unsigned char ch;
-        if (!rc) ch = A.reads[off + (uint64_t)k];
-        else {
-            ch = A.reads[off + (uint64_t)(Lj - 1 - k)];
-            if (ch >= 'a' && ch <= 'z') ch -= 32;                       // seq.upper(), CRISPRessoShared.py:402
+        if (k < 256) ch = (unsigned char)((pf.b4 >> ((k >> 6) * 8)) & 0xffu);
+        else ch = A.reads[pf.off + (uint64_t)(rc ? Lj - 1 - k : k)];
+        if (rc) {
+            if (ch >= 'a' && ch <= 'z') ch -= 32;                       // seq.upper()
             unsigned char cc = 0;
             if (ch == 'A') cc = 'T'; else if (ch == 'C') cc = 'G'; else if (ch == 'G') cc = 'C';
             else if (ch == 'T') cc = 'A'; else if (ch == 'N' || ch == '_' || ch == '-') cc = ch;
             if (cc == 0) { status |= C2_STATUS_RC_CHAR; cc = 'N'; }
             ch = cc;
         }
-        const unsigned char code = A.code_of_char[ch];
+        const unsigned char code = sCodeOf[ch];
         if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
         W.sRead[k] = ch;
         W.sCode[k] = code;
@@ -379,7 +411,7 @@ __device__ __forceinline__ int c2_fetch_task(const c2_align_args& A, const c2_wg
     }
     {
         int bad = 0;
-        for (int k = lane; k < Li && k < max_li; k += 64) if (A.code_of_char[W.sRef[k]] == C2_INVALID_CODE) bad = 1;
+        for (int k = lane; k < Li && k < max_li; k += 64) if (sCodeOf[W.sRef[k]] == C2_INVALID_CODE) bad = 1;
         if (bad) status |= C2_STATUS_OOB_CHAR;
     }
     if (Li <= 0 || Lj <= 0) status |= C2_STATUS_EMPTY;
@@ -498,9 +530,11 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
     const unsigned char* sTmpRead = W.sTmpRead; const unsigned char* sTmpRef = W.sTmpRef; const uint16_t* sIncP = W.sIncP;
     uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
     uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
-    for (int cidx = lane; cidx < T; cidx += 64) {
-        outR[cidx] = sTmpRead[T - 1 - cidx];
-        outF[cidx] = sTmpRef[T - 1 - cidx];
+    if (!(A.reserved & 1)) {                                   // (debug knob: C2_DEBUG_SKIP_STRINGS measures the cost of these stores)
+        for (int cidx = lane; cidx < T; cidx += 64) {
+            outR[cidx] = sTmpRead[T - 1 - cidx];
+            outF[cidx] = sTmpRef[T - 1 - cidx];
+        }
     }
     int idx_base = 0, last_rf = -1, last_rd = -1;
     int n_all_sub = 0, n_win_sub = 0, n_all_ins = 0, n_win_ins = 0, n_all_del = 0, n_win_del = 0;
@@ -585,6 +619,7 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
     c2_wg W;
     W.sRead = c2_smem + P.read; W.sCode = c2_smem + P.code; W.sRef = c2_smem + P.ref;
     W.sIncP = (uint16_t*)(c2_smem + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
+    unsigned char* sCodeOf = c2_smem + P.codeof;
     const int colStride = (int)P.col_stride;
     const int ROWS_PER_PASS = 64 * R;
     const int ge = A.gap_extend, go = A.gap_open;
@@ -592,16 +627,22 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
     // score table -> LDS, once per workgroup
     for (int k = lane; k < A.n_codes * A.n_codes; k += 64) sTbl[k] = A.score_tbl[k];
 
+    for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
     int cur_ref = -1;
     int Li = 0, g0 = 0;
-    uint64_t chunk_base = 0, task = 0;
+    uint64_t chunk_base = 0;
     int chunk_left = 0;
-    while (c2_next_task(A, lane, chunk_base, chunk_left, task)) {
+    c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
+    c2_prefetch pf;
+    c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);
+    while (pf.valid) {
         __syncthreads();   // previous task's LDS readers are done
-        unsigned long long t_phase = A.phase_cycles ? (unsigned long long)clock64() : 0ull;
-        int Lj, ref_id, rc;
-        bool ref_changed, packed;
-        int status = c2_fetch_task(A, W, task, lane, A.max_passes * ROWS_PER_PASS, cur_ref, Li, g0, Lj, ref_id, rc, ref_changed, packed);
+        c2_phase_begin(A.phase_cycles, PH);
+        const uint64_t task = pf.task;
+        const int Lj = pf.Lj, ref_id = pf.ref_id, rc = pf.rc;
+        bool packed;
+        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_passes * ROWS_PER_PASS, cur_ref, Li, g0, packed);
+        c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);   // next task's loads fly during this task's DP
         const c2_dev_ref rf = A.refs[ref_id];
         const int passes = (Li + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
         if (BAND && passes != 1) status |= C2_STATUS_TOO_LONG;
@@ -612,7 +653,7 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
         if (status == 0) {
             // pyx:150  int min_score = gap_open * max_j * max_i   (wraps like the reference's C int)
             const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
-            c2_phase_mark(A.phase_cycles, 0, t_phase, lane);   // phase 0: task fetch (offsets, read, reference rows)
+            c2_phase_mark<0>(A.phase_cycles, PH);   // phase 0: task fetch (offsets, read, reference rows)
             // =========================== DP: systolic sweep, pass by pass ===========================
             for (int p = 0; p < passes; ++p) {
                 const bool single = (passes == 1);
@@ -626,7 +667,7 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
                 }
                 __syncthreads();
             }
-            c2_phase_mark(A.phase_cycles, 1, t_phase, lane);   // phase 1: DP fill
+            c2_phase_mark<1>(A.phase_cycles, PH);   // phase 1: DP fill
             // =========================== traceback ===========================
             c2_row_plane<R, BAND> plane;
             plane.sPtr = sPtr; plane.max_lj = A.max_lj; plane.colStride = colStride; plane.band_lanes = A.band_lanes;
@@ -634,7 +675,7 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
             bool need_full;
             c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, need_full);
             __syncthreads();
-            c2_phase_mark(A.phase_cycles, 2, t_phase, lane);   // phase 2: traceback
+            c2_phase_mark<2>(A.phase_cycles, PH);   // phase 2: traceback
             if (need_full) {                                   // only possible with BAND
                 status |= C2_STATUS_NEED_FULL;
                 if (lane == 0) { const unsigned k = atomicAdd(A.fb_count, 1u); A.fb_list[k] = (uint32_t)task; }
@@ -643,8 +684,277 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
         }
         rec.status = (uint8_t)status;
         if (lane == 0) A.records[task] = rec;
-        c2_phase_mark(A.phase_cycles, 3, t_phase, lane);       // phase 3: strings out, classification, record
+        c2_phase_mark<3>(A.phase_cycles, PH);       // phase 3: strings out, classification, record
     }
+    c2_phase_flush(A.phase_cycles, PH, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Diagonal-band kernel.  Lanes own DIAGONALS instead of rows: lane l owns d = d0 + 2l ("E") and d0 + 2l + 1 ("O"), 128
+// diagonals around the one that joins (0,0) and (Li,Lj); the sweep runs over anti-diagonals a = i + j, one cell per lane
+// per step (E cells at even a, O cells at odd a), 499 steps x 1 cell instead of 313 steps x 4 cells for 250 x 250.
+// Cells outside the band are never computed (they read as C2_DIAG_NEG), which is exact iff no optimal path leaves the
+// band.  That is PROVEN per alignment after the fill: a path that touches diagonal d outside [0, D] (D = Li - Lj) takes
+// at least |d| + |d - D| gap steps and at most min(Li, Lj) - (steps off the [0,D] corridor) match steps, so it scores at
+// most U = maxS * (len - off) + cb * (gap steps), cb = max(go, ge) + max(0, max g) < 0 the most a gap base can add.  If the
+// banded score H(Li,Lj) > U for both band edges, every optimal path -- and every path that ties with one at any cell the
+// reference's traceback visits -- lies inside the band, where banded and full DP values coincide, so the pointers the
+// traceback reads are the full DP's.  Otherwise (and for reads the packed score rows cannot encode) the task goes to the
+// fallback list and the row-strip kernel redoes it.  Neighbour traffic: two DPP moves per step (wave_shr at even steps,
+// wave_shl at odd steps); row constants {a_i, b_i, c_i, score row} and the column symbol come from LDS tables, fetched
+// one step pair ahead.
+// ---------------------------------------------------------------------------------------------------------------
+#define C2_DPP_WAVE_SHL1 0x130
+// lane n receives `src` of lane n+1; lane 63 keeps `old`
+__device__ __forceinline__ int c2_shl1(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, C2_DPP_WAVE_SHL1, 0xf, 0xf, false);
+}
+
+struct c2_diag_plan { uint32_t plane, rows, codes, codeof, read, code, ref, incp, tmp_read, tmp_ref, total; uint32_t n_words; };
+
+__host__ __device__ inline c2_diag_plan c2_make_diag_plan(int max_li, int max_lj) {
+    c2_diag_plan p;
+    p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // one 32-bit word per lane per 8 anti-diagonals
+    uint32_t off = 0;
+    p.plane = off;    off += p.n_words * 64u * 4u;
+    p.rows = off;     off += c2_align16(((uint32_t)max_li + 2u) * 16u);   // rows 0 .. Li+1 (both ends zero); indices are clamped
+    p.codes = off;    off += c2_align16((uint32_t)max_lj + 2u);            // columns 0 .. Lj+1 (both ends zero)
+    p.codeof = off;   off += 256u;
+    p.read = off;     off += c2_align16((uint32_t)max_lj);
+    p.code = off;     off += c2_align16((uint32_t)max_lj);
+    p.ref = off;      off += c2_align16((uint32_t)max_li);
+    p.incp = off;     off += c2_align16(((uint32_t)max_li + 2u) * 2u);
+    p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
+    p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
+    p.total = off;
+    return p;
+}
+
+struct c2_diag_row { int a, b, c; unsigned prof; };       // 16 bytes: one ds_read_b128
+
+struct c2_diag_plane {
+    const unsigned* words; int d0;
+    __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
+        const int dd = pi - pj - d0;
+        if ((unsigned)dd >= 128u) return false;
+        const int a = pi + pj;
+        nib = (words[(a >> 3) * 64 + (dd >> 1)] >> (4 * (7 - (a & 7)))) & 0xF;
+        return true;
+    }
+};
+
+struct c2_diag_state {
+    int ME, IE, JE, HE;              // latest cell of the even diagonal
+    int MO, IO, JO, HO;              // latest cell of the odd diagonal
+    int upM, upJ;                    // hand-off registers for wave_shr (lane 0 stays C2_DIAG_NEG: outside the band)
+    int lfM, lfI;                    // hand-off registers for wave_shl (lane 63 stays C2_DIAG_NEG)
+    unsigned bits;
+};
+
+// One pair of steps: the E cell on anti-diagonal a = 2k, then the O cell on a + 1.  rowE: constants of the E cell's row,
+// rowO: of the O cell's row (= E row + 1); cj4: 4 * code of their common column.
+// MASK: lanes whose diagonal has not reached its first interior cell yet keep their boundary-cell values.
+// LASTCOL: the column may be the last one, where gap_open is replaced by gap_extend (pyx:234-273): a_i -> b_i, c_i += b_i - a_i.
+template <bool MASK, bool LASTCOL>
+__device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, const c2_diag_row rowE, const c2_diag_row rowO,
+                                             const int cj4, const int ge, const int startE, const int startO, const bool lastcol)
+{
+    // ---- even step: E cell.  left (i, j-1) is this lane's O cell, up (i-1, j) is the O cell of the lane below (wave_shr)
+    S.upM = c2_shr1(S.upM, S.MO);
+    S.upJ = c2_shr1(S.upJ, S.JO);
+    if (!MASK || a >= startE) {
+        const int corr = (LASTCOL && lastcol) ? rowE.b - rowE.a : 0;
+        const int s = c2_sbfe4((int)rowE.prof, cj4);
+        const int iFromM = S.MO + rowE.a + corr;
+        const int iExt = S.IO + rowE.b;
+        const int jFromM = S.upM + rowE.c + corr;
+        const int jExt = S.upJ + ge;
+        const int In = c2_imax(iFromM, iExt);
+        const int Jn = c2_imax(jFromM, jExt);
+        const int Mn = S.HE + s;                             // H(i-1, j-1): this diagonal, two steps ago
+        const int Hn = c2_imax(c2_imax(Mn, Jn), In);
+        c2_push4(S.bits, iFromM, iExt, jFromM, jExt, In, Hn, Jn, Mn);
+        S.ME = Mn; S.IE = In; S.JE = Jn; S.HE = Hn;
+    } else {
+        S.bits <<= 4;
+    }
+    // ---- odd step: O cell.  left (i, j-1) is the E cell of the lane above (wave_shl), up (i-1, j) is this lane's E cell
+    S.lfM = c2_shl1(S.lfM, S.ME);
+    S.lfI = c2_shl1(S.lfI, S.IE);
+    if (!MASK || a + 1 >= startO) {
+        const int corr = (LASTCOL && lastcol) ? rowO.b - rowO.a : 0;
+        const int s = c2_sbfe4((int)rowO.prof, cj4);
+        const int iFromM = S.lfM + rowO.a + corr;
+        const int iExt = S.lfI + rowO.b;
+        const int jFromM = S.ME + rowO.c + corr;
+        const int jExt = S.JE + ge;
+        const int In = c2_imax(iFromM, iExt);
+        const int Jn = c2_imax(jFromM, jExt);
+        const int Mn = S.HO + s;
+        const int Hn = c2_imax(c2_imax(Mn, Jn), In);
+        c2_push4(S.bits, iFromM, iExt, jFromM, jExt, In, Hn, Jn, Mn);
+        S.MO = Mn; S.IO = In; S.JO = Jn; S.HO = Hn;
+    } else {
+        S.bits <<= 4;
+    }
+}
+
+template <bool MASK, bool LASTCOL>
+__device__ __forceinline__ void c2_diag_run(c2_diag_state& S, int& k, const int k_stop, const int lane, const int hE, const int Li, const int Lj,
+                                            const int ge, const int startE, const int startO,
+                                            c2_diag_row& rowE, c2_diag_row& rowO, int& cj4,
+                                            const c2_diag_row* sRows, const unsigned char* sCodes, unsigned* myWords)
+{
+    for (; k <= k_stop; ++k) {
+        // tables of the NEXT pair, fetched now: its column j+1 and the row of its O cell
+        const int cj4n = (int)sCodes[c2_clamp(k + 1 - hE, 0, Lj + 1)];
+        const c2_diag_row rowN = sRows[c2_clamp(k + 2 + hE, 0, Li + 1)];
+        c2_diag_pair<MASK, LASTCOL>(S, 2 * k, rowE, rowO, cj4, ge, startE, startO, LASTCOL && (k - hE == Lj));
+        if ((k & 3) == 3) myWords[(k >> 2) * 64] = S.bits;          // anti-diagonals 8*(k>>2) .. 8*(k>>2)+7 are complete
+        rowE = rowO; rowO = rowN; cj4 = cj4n;
+    }
+}
+
+__global__ __launch_bounds__(64, 4) void c2_align_diag_kernel(c2_align_args A)
+{
+    const int lane = threadIdx.x;
+    const c2_diag_plan P = c2_make_diag_plan(A.max_li, A.max_lj);
+    unsigned* sWords = (unsigned*)(c2_smem + P.plane);
+    c2_diag_row* sRows = (c2_diag_row*)(c2_smem + P.rows);
+    unsigned char* sCodes = c2_smem + P.codes;
+    c2_wg W;
+    W.sRead = c2_smem + P.read; W.sCode = c2_smem + P.code; W.sRef = c2_smem + P.ref;
+    W.sIncP = (uint16_t*)(c2_smem + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
+    const int ge = A.gap_extend, go = A.gap_open;
+    unsigned char* sCodeOf = c2_smem + P.codeof;
+    for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
+
+    int cur_ref = -1, rows_ref = -1;
+    int Li = 0, g0 = 0;
+    uint64_t chunk_base = 0;
+    int chunk_left = 0;
+    c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
+    c2_prefetch pf;
+    c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);
+    while (pf.valid) {
+        __syncthreads();
+        c2_phase_begin(A.phase_cycles, PH);
+        const uint64_t task = pf.task;
+        const int Lj = pf.Lj, ref_id = pf.ref_id, rc = pf.rc;
+        bool packed;
+        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_li, cur_ref, Li, g0, packed);
+        c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);   // next task's loads fly during this task's DP
+        const c2_dev_ref rf = A.refs[ref_id];
+        __syncthreads();
+        c2_aln_record rec;
+        c2_clear_record(rec, rc, ref_id);
+        bool need_full = false;
+        const int D = Li - Lj;
+        const int d0 = ((D >> 1) - 64) & ~1;                  // even; band = d0 .. d0+127 around the corner-to-corner diagonal
+        int cb = 0;
+        if (status == 0) {
+            cb = (go > ge ? go : ge) + rf.gap_incentive_max;      // the most one gap base can add to a score
+            if (!packed || cb >= 0 || d0 > 0 || d0 + 127 < 0 || D < d0 || D > d0 + 127) need_full = true;
+        }
+        if (status == 0 && !need_full) {
+            // ---- tables: row constants (per reference) and 4*code per column (per read), both padded so that the lanes that
+            //      are still before / already past the matrix read zeros instead of running off the arrays
+            if (rows_ref != ref_id) {
+                rows_ref = ref_id;
+                for (int i = lane; i < Li + 2; i += 64) {
+                    c2_diag_row r; r.a = 0; r.b = 0; r.c = 0; r.prof = 0;
+                    if (i >= 1 && i <= Li) {
+                        const int gi = rf.gap_incentive[i], gim1 = rf.gap_incentive[i - 1];
+                        const int open = (i == Li) ? ge : go;               // last row: gap_open -> gap_extend (pyx:277-317)
+                        r.a = open + gi; r.b = ge + gi; r.c = open + gim1;
+                        r.prof = A.score_pk[sCodeOf[W.sRef[i - 1]]];
+                    }
+                    sRows[i] = r;
+                }
+            }
+            for (int j = lane; j < Lj + 2; j += 64)
+                sCodes[j] = (j >= 1 && j <= Lj) ? (unsigned char)(W.sCode[j - 1] << 2) : (unsigned char)0;
+            __syncthreads();
+            const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
+            c2_phase_mark<0>(A.phase_cycles, PH);
+
+            // ---- per-lane diagonals and their boundary cells (pyx:153-176)
+            const int hE = (d0 >> 1) + lane;                  // dE = 2*hE, dO = 2*hE + 1
+            const int dE = 2 * hE, dO = dE + 1;
+            c2_diag_state S;
+            S.bits = 0;
+            S.upM = C2_DIAG_NEG; S.upJ = C2_DIAG_NEG; S.lfM = C2_DIAG_NEG; S.lfI = C2_DIAG_NEG;
+            // diagonal d >= 1 starts at cell (d, 0): M = I = min_score, J = ge*d + g0;  d <= -1 at (0, -d): M = J = min_score,
+            // I = ge*(-d) + g0;  d == 0 at (0, 0): M = 0, I = J = min_score.  H = max of the three.
+            {
+                const int bE = (dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + g0;
+                S.ME = (dE == 0) ? 0 : min_score;
+                S.IE = (dE < 0) ? bE : min_score;
+                S.JE = (dE > 0) ? bE : min_score;
+                S.HE = c2_imax(c2_imax(S.ME, S.IE), S.JE);
+                const int bO = ge * (dO > 0 ? dO : -dO) + g0;   // dO is odd, never 0
+                S.MO = min_score;
+                S.IO = (dO < 0) ? bO : min_score;
+                S.JO = (dO > 0) ? bO : min_score;
+                S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
+            }
+            const int startE = (dE > 0 ? dE : -dE) + 2, startO = (dO > 0 ? dO : -dO) + 2;   // first interior anti-diagonal
+            const int a_end = Li + Lj;
+            const int k_end = a_end >> 1;                      // last pair (its odd step is past the matrix when a_end is even)
+            const int max_start = (d0 + 127 > -d0 ? d0 + 127 : -d0) + 2;
+            const int kA = (max_start + 1) >> 1;               // pairs 1..kA contain lanes that have not started
+            const int kC = (2 * Lj + d0) >> 1;                 // first pair in which some lane is on the last column
+            unsigned* myWords = sWords + lane;
+            int k = 1;
+            c2_diag_row rowE = sRows[c2_clamp(k + hE, 0, Li + 1)], rowO = sRows[c2_clamp(k + 1 + hE, 0, Li + 1)];
+            int cj4 = (int)sCodes[c2_clamp(k - hE, 0, Lj + 1)];
+            const int kA_stop = kA < k_end ? kA : k_end;
+            if (kC <= kA_stop) {
+                c2_diag_run<true, true>(S, k, kA_stop, lane, hE, Li, Lj, ge, startE, startO, rowE, rowO, cj4, sRows, sCodes, myWords);
+            } else {
+                c2_diag_run<true, false>(S, k, kA_stop, lane, hE, Li, Lj, ge, startE, startO, rowE, rowO, cj4, sRows, sCodes, myWords);
+                c2_diag_run<false, false>(S, k, (kC - 1 < k_end ? kC - 1 : k_end), lane, hE, Li, Lj, ge, startE, startO, rowE, rowO, cj4, sRows, sCodes, myWords);
+            }
+            c2_diag_run<false, true>(S, k, k_end, lane, hE, Li, Lj, ge, startE, startO, rowE, rowO, cj4, sRows, sCodes, myWords);
+            // last, partially filled word: left-align it (anti-diagonal a sits at nibble 7 - (a & 7))
+            {
+                const int a_last = 2 * k_end + 1;
+                if ((a_last & 7) != 7) myWords[(a_last >> 3) * 64] = S.bits << (4 * (7 - (a_last & 7)));
+            }
+            __syncthreads();
+            c2_phase_mark<1>(A.phase_cycles, PH);
+
+            // ---- optimality certificate
+            const int lane_end = (D - d0) >> 1;
+            const int Hend = __builtin_amdgcn_readlane((a_end & 1) ? S.HO : S.HE, lane_end);
+            const int maxS = A.max_score;
+            const int dhi1 = d0 + 128, dlo1 = d0 - 1;         // first diagonals outside the band
+            int U = C2_DIAG_NEG;
+            if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + cb * (2 * dhi1 - D));
+            if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + cb * (D - 2 * dlo1));
+            if (!(Hend > U)) need_full = true;
+
+            if (!need_full) {
+                c2_diag_plane plane;
+                plane.words = sWords; plane.d0 = d0;
+                int cnt, matches;
+                bool nf2;
+                c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, nf2);
+                __syncthreads();
+                c2_phase_mark<2>(A.phase_cycles, PH);
+                if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
+                else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec);
+            }
+        }
+        if (need_full) {
+            status |= C2_STATUS_NEED_FULL;
+            if (lane == 0) { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
+        }
+        rec.status = (uint8_t)status;
+        if (lane == 0) A.records[task] = rec;
+        c2_phase_mark<3>(A.phase_cycles, PH);
+    }
+    c2_phase_flush(A.phase_cycles, PH, lane);
 }
 
 // =====================================================================================

@@ -162,7 +162,10 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
  * Alignments whose traceback leaves the band are redone in the same call by the full-plane kernel.
  * target_workgroups_per_cu (> 0) steers the automatic choice. */
 int c2_set_band(c2_ctx* ctx, int32_t band_lanes, int32_t target_workgroups_per_cu);
-/* Band in use for reads up to max_read_len, and how many tasks of the most recent launch needed the full-plane pass. */
+/* First-launch kernel: 0 automatic (diagonal-band kernel with optimality certificate when the scoring allows it, else the
+ * banded row-strip kernel), 1 banded row-strip kernel, 2 full-plane row-strip kernel only.  Results never depend on it. */
+int c2_set_kernel_mode(c2_ctx* ctx, int32_t mode);
+/* Band in use for reads up to max_read_len (-1: the diagonal-band kernel is the first launch), and how many tasks of the most recent launch needed the full-plane pass. */
 int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t* fallback_tasks_last_launch);
 
 /* ---- per-call path: same contract as the reference's Cython functions ------------------ */

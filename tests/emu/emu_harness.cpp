@@ -31,7 +31,10 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         for (int k = 0; k <= lens[r]; ++k) g32[r][k] = (int32_t)gap_inc[r][k];
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
         refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = g32[r].data(); refs[r].inc_prefix = incp[r].data();
-        refs[r].len = lens[r]; refs[r].reserved = 0;
+        refs[r].len = lens[r];
+        int64_t gm = 0;
+        for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, gap_inc[r][k]);
+        refs[r].gap_incentive_max = (int32_t)gm;
         max_li = std::max(max_li, lens[r]);
     }
     int max_lj = 1;
@@ -53,8 +56,22 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     A.work_counter = &work_counter;
     A.band_lanes = 0; A.reserved = 0; A.fb_count = &fb_count; A.fb_list = fb_list.data(); A.task_list = nullptr; A.task_count = nullptr;
     if (grid == 0) grid = (unsigned)std::min<uint64_t>(A.n_tasks, 3);
+    A.max_li = max_li; A.reserved = 0;
+    {
+        int mx = 0;
+        for (int16_t v : sc.tbl) mx = std::max(mx, (int)v);
+        A.max_score = mx;
+    }
+    const bool diag = band_lanes == -1;          // -1: diagonal-band kernel first, full-plane kernel for its fallback list
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
-    if (band) {
+    if (diag) {
+        const c2_diag_plan PD = c2_make_diag_plan(A.max_li, A.max_lj);
+        if (PD.total > sizeof(c2_smem)) return -5;
+        emu::launch(grid, [&] { c2_align_diag_kernel(A); });
+        A.task_list = fb_list.data(); A.task_count = &fb_count;
+        work_counter = 0;
+        if (n_fallback) *n_fallback = (int)fb_count;
+    } else if (band) {
         A.band_lanes = band_lanes;
         const c2_lds_plan PB = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, band_lanes);
         if (PB.total > sizeof(c2_smem)) return -5;
@@ -71,7 +88,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, 0);
     if (P.total > sizeof(c2_smem)) { fprintf(stderr, "emu: LDS plan %u too large\n", P.total); return -5; }
     A.band_lanes = 0;
-    if (!band || fb_count > 0) {
+    if (!(band || diag) || fb_count > 0) {
         switch (R) {
             case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, false>(A); }); break;
             case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2, false>(A); }); break;
@@ -102,7 +119,7 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     int lmax = 1;
     for (int r = 0; r < n_refs; ++r) {
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
-        refs[r].seq = nullptr; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].len = lens[r]; refs[r].reserved = 0;
+        refs[r].seq = nullptr; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].len = lens[r]; refs[r].gap_incentive_max = 0;
         lmax = std::max(lmax, lens[r]);
     }
     unsigned long long wc = 0;

@@ -227,22 +227,30 @@ def test_banded_pointer_plane_equals_full_plane(mats, ctx):
     al = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
     outs = {}
     try:
+        ctx.set_kernel_mode("band")
         for band in (0, 2, 6, -1):
             ctx.set_band(band)
             res = al.align((reads.reshape(-1), offsets))
             info = ctx.band_info(L)
             outs[band] = (res, info)
             assert (res.records["status"] == 0).all()
+        ctx.set_kernel_mode("auto")                 # diagonal-band kernel + certificate, full-plane kernel for the rest
+        ctx.set_band(-1)
+        res = al.align((reads.reshape(-1), offsets))
+        outs["diag"] = (res, ctx.band_info(L))
+        assert (res.records["status"] == 0).all()
     finally:
         ctx.set_band(-1)
+        ctx.set_kernel_mode("auto")
     base = outs[0][0]
     assert outs[0][1]["band_lanes"] == 0
-    for band in (2, 6, -1):
+    for band in (2, 6, -1, "diag"):
         res, info = outs[band]
-        assert info["band_lanes"] > 0
+        assert info["band_lanes"] == -1 if band == "diag" else info["band_lanes"] > 0
         assert np.array_equal(res.records, base.records)
         assert np.array_equal(res.aln_read, base.aln_read) and np.array_equal(res.aln_ref, base.aln_ref)
     assert outs[2][1]["fallback_tasks_last_launch"] > outs[6][1]["fallback_tasks_last_launch"] > 0
+    assert 0 < outs["diag"][1]["fallback_tasks_last_launch"] < n // 20
 
 
 def test_count_vectors_device_vs_reference_aggregation(mats, ctx):

@@ -91,6 +91,55 @@ def test_emulated_kernel_banded_pointer_plane_with_fallback(mats, band_lanes):
     assert 0 < st["fallback"] < st["tasks"], st
 
 
+def test_emulated_diagonal_band_kernel_with_certificate_and_fallback(mats):
+    """c2_align_diag_kernel (lanes = diagonals, 128-diagonal band, proof of optimality after the fill) + the full-plane
+    kernel for the tasks whose certificate fails: identical to the reference on every vector; both paths must be used."""
+    st = {}
+    vecs = load_golden("realistic.json")
+    assert run_vectors(vecs, mats, band_lanes=-1, stats=st) == len(vecs)
+    certified_realistic = st["tasks"] - st["fallback"]
+    assert certified_realistic > len(vecs) // 2, st          # most amplicon reads are certified inside the band
+    vecs = load_golden("fuzz_align.json")
+    assert run_vectors(vecs, mats, band_lanes=-1, stats=st) == len(vecs)
+    kats = [k for k in load_golden("ref_unit_kats.json") if k["fn"] == "global_align"]
+    assert run_vectors(kats, mats, band_lanes=-1, stats=st) == len(kats)
+    assert 0 < st["fallback"] < st["tasks"], st
+
+
+def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats):
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(77)
+    refs = ["".join(rng.choice(list("ACGT"), L)) for L in (180, 223, 140)]
+    gis = [np.zeros(len(r) + 1, dtype=np.int64) for r in refs]
+    for g in gis:
+        g[len(g) // 2] = 1
+    incs = [list(range(len(r) // 2 - 5, len(r) // 2 + 5)) for r in refs]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    reads, rids, strands, truth = [], [], [], []
+    for k in range(36):
+        r = k % 3
+        s = list(refs[r])
+        p = int(rng.integers(10, len(s) - 40))
+        if k % 4 == 0:
+            del s[p:p + int(rng.integers(1, 30))]
+        elif k % 4 == 1:
+            s[p:p] = list(rng.choice(list("ACGT"), int(rng.integers(1, 12))))
+        elif k % 4 == 2:
+            s = s[int(rng.integers(0, 25)):] + list(rng.choice(list("ACGT"), int(rng.integers(0, 30))))
+        s[int(rng.integers(0, len(s)))] = "N"
+        fw = "".join(s)
+        rc = k % 2
+        reads.append("".join(comp[c] for c in reversed(fw)) if rc else fw)
+        rids.append(r); strands.append(rc); truth.append(fw)
+    st = {}
+    res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=rids, strands=strands, band_lanes=-1, stats=st)
+    for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+        exp = oracle.global_align_raw(truth[k], refs[rids[k]], m, gis[rids[k]], -20, -2)
+        assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k
+        check_record(r, oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
+    assert st["fallback"] < st["tasks"]
+
+
 @pytest.mark.parametrize("R", [1, 2, 3])
 def test_emulated_kernel_multipass(mats, R):
     """Force fewer rows per lane so that 150..250-row references need 2..4 passes through the LDS boundary row."""

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--len", type=int, default=250, dest="L")
     ap.add_argument("--band", type=int, default=-1)
     ap.add_argument("--band-wgs", type=int, default=0)
+    ap.add_argument("--kernel", default="auto")
     a = ap.parse_args()
     from crispresso2_amd import synth, _native, CRISPResso2Align as A
     from crispresso2_amd.batch import BatchAligner
@@ -26,6 +27,7 @@ def main():
     reads = synth.make_reads(a.L, a.reads)
     ctx = _native.Context(0)
     ctx.set_band(a.band, a.band_wgs)
+    ctx.set_kernel_mode(a.kernel)
     al = BatchAligner([amp], [g], [inc], A.read_matrix(os.path.join(ROOT, "crispresso2_amd", "EDNAFULL")), -20, -2, ctx=ctx)
     dev = torch.device("cuda", 0)
     n, L = a.reads, a.L
