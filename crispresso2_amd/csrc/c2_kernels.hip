@@ -34,7 +34,16 @@ __device__ __forceinline__ int c2_shr1(int old, int src) {
 }
 
 __device__ __forceinline__ int c2_imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int c2_clamp(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }   // v_med3_i32
+// clamp x to [0, hi] (hi wave-uniform, >= 0): one v_med3_i32
+__device__ __forceinline__ int c2_clamp0(int x, int hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+#else
+    return x < 0 ? 0 : (x > hi ? hi : x);
+#endif
+}
 
 // sign-extended 4-bit field of x starting at bit `off`
 __device__ __forceinline__ int c2_sbfe4(int x, int off) { return __builtin_amdgcn_sbfe(x, off, 4); }
@@ -799,23 +808,40 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
     }
 }
 
+// Four pairs = eight anti-diagonals = one pointer word per lane.  Group g covers pairs k = 4g .. 4g+3.  The five row
+// records and four column symbols of a group are fetched while the previous group computes (R[] / C[] hold the current
+// group's, RN[] / CN[] receive the next group's); indices are clamped into the zero-padded tables, so lanes that are not
+// inside the matrix yet (or any more) read zeros.  k_cap: pair after which H(Li,Lj) is final -- it is copied to Hcap there.
 template <bool MASK, bool LASTCOL>
-__device__ __forceinline__ void c2_diag_run(c2_diag_state& S, int& k, const int k_stop, const int lane, const int hE, const int Li, const int Lj,
-                                            const int ge, const int startE, const int startO,
-                                            c2_diag_row& rowE, c2_diag_row& rowO, int& cj4,
-                                            const c2_diag_row* sRows, const unsigned char* sCodes, unsigned* myWords)
+__device__ __forceinline__ void c2_diag_groups(c2_diag_state& S, int& g, const int g_stop, const int hE, const int Li, const int Lj,
+                                               const int ge, const int startE, const int startO, const int k_cap, const bool cap_odd,
+                                               int& Hcap, c2_diag_row (&R)[5], int (&C)[4],
+                                               const c2_diag_row* sRows, const unsigned char* sCodes, unsigned* myWords)
 {
-    for (; k <= k_stop; ++k) {
-        // tables of the NEXT pair, fetched now: its column j+1 and the row of its O cell
-        const int cj4n = (int)sCodes[c2_clamp(k + 1 - hE, 0, Lj + 1)];
-        const c2_diag_row rowN = sRows[c2_clamp(k + 2 + hE, 0, Li + 1)];
-        c2_diag_pair<MASK, LASTCOL>(S, 2 * k, rowE, rowO, cj4, ge, startE, startO, LASTCOL && (k - hE == Lj));
-        if ((k & 3) == 3) myWords[(k >> 2) * 64] = S.bits;          // anti-diagonals 8*(k>>2) .. 8*(k>>2)+7 are complete
-        rowE = rowO; rowO = rowN; cj4 = cj4n;
+    for (; g <= g_stop; ++g) {
+        const int k0 = 4 * g;
+        c2_diag_row RN[5];
+        int CN[4];
+        RN[0] = R[4];
+#pragma unroll
+        for (int q = 1; q < 5; ++q) RN[q] = sRows[c2_clamp0(k0 + 4 + q + hE, Li + 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) CN[q] = (int)sCodes[c2_clamp0(k0 + 4 + q - hE, Lj + 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + q;
+            c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, startE, startO, LASTCOL && (k - hE == Lj));
+            if (LASTCOL && k == k_cap) Hcap = cap_odd ? S.HO : S.HE;
+        }
+        myWords[g * 64] = S.bits;                                   // anti-diagonals 8g .. 8g+7
+#pragma unroll
+        for (int q = 0; q < 5; ++q) R[q] = RN[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[q] = CN[q];
     }
 }
 
-__global__ __launch_bounds__(64, 4) void c2_align_diag_kernel(c2_align_args A)
+__global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
 {
     const int lane = threadIdx.x;
     const c2_diag_plan P = c2_make_diag_plan(A.max_li, A.max_lj);
@@ -900,33 +926,36 @@ __global__ __launch_bounds__(64, 4) void c2_align_diag_kernel(c2_align_args A)
             }
             const int startE = (dE > 0 ? dE : -dE) + 2, startO = (dO > 0 ? dO : -dO) + 2;   // first interior anti-diagonal
             const int a_end = Li + Lj;
-            const int k_end = a_end >> 1;                      // last pair (its odd step is past the matrix when a_end is even)
+            const int k_end = a_end >> 1;                      // pair that holds the cell (Li, Lj)
             const int max_start = (d0 + 127 > -d0 ? d0 + 127 : -d0) + 2;
-            const int kA = (max_start + 1) >> 1;               // pairs 1..kA contain lanes that have not started
-            const int kC = (2 * Lj + d0) >> 1;                 // first pair in which some lane is on the last column
+            const int gA = ((max_start + 1) >> 1) >> 2;        // groups 0..gA contain lanes that have not started
+            const int gC = ((2 * Lj + d0) >> 1) >> 2;          // first group in which some lane is on the last column
+            const int g_end = k_end >> 2;
             unsigned* myWords = sWords + lane;
-            int k = 1;
-            c2_diag_row rowE = sRows[c2_clamp(k + hE, 0, Li + 1)], rowO = sRows[c2_clamp(k + 1 + hE, 0, Li + 1)];
-            int cj4 = (int)sCodes[c2_clamp(k - hE, 0, Lj + 1)];
-            const int kA_stop = kA < k_end ? kA : k_end;
-            if (kC <= kA_stop) {
-                c2_diag_run<true, true>(S, k, kA_stop, lane, hE, Li, Lj, ge, startE, startO, rowE, rowO, cj4, sRows, sCodes, myWords);
+            // tables of group 0: rows i = k + hE (E cell of pair k) .. and one more for the last O cell; columns j = k - hE
+            c2_diag_row Rw[5];
+            int Cw[4];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Rw[q] = sRows[c2_clamp0(q + hE, Li + 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Cw[q] = (int)sCodes[c2_clamp0(q - hE, Lj + 1)];
+            int Hcap = C2_DIAG_NEG;
+            const bool cap_odd = (a_end & 1) != 0;
+            int g = 0;
+            const int gA_stop = gA < g_end ? gA : g_end;
+            if (gC <= gA_stop) {
+                c2_diag_groups<true, true>(S, g, gA_stop, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords);
             } else {
-                c2_diag_run<true, false>(S, k, kA_stop, lane, hE, Li, Lj, ge, startE, startO, rowE, rowO, cj4, sRows, sCodes, myWords);
-                c2_diag_run<false, false>(S, k, (kC - 1 < k_end ? kC - 1 : k_end), lane, hE, Li, Lj, ge, startE, startO, rowE, rowO, cj4, sRows, sCodes, myWords);
+                c2_diag_groups<true, false>(S, g, gA_stop, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords);
+                c2_diag_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords);
             }
-            c2_diag_run<false, true>(S, k, k_end, lane, hE, Li, Lj, ge, startE, startO, rowE, rowO, cj4, sRows, sCodes, myWords);
-            // last, partially filled word: left-align it (anti-diagonal a sits at nibble 7 - (a & 7))
-            {
-                const int a_last = 2 * k_end + 1;
-                if ((a_last & 7) != 7) myWords[(a_last >> 3) * 64] = S.bits << (4 * (7 - (a_last & 7)));
-            }
+            c2_diag_groups<false, true>(S, g, g_end, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords);
             __syncthreads();
             c2_phase_mark<1>(A.phase_cycles, PH);
 
             // ---- optimality certificate
             const int lane_end = (D - d0) >> 1;
-            const int Hend = __builtin_amdgcn_readlane((a_end & 1) ? S.HO : S.HE, lane_end);
+            const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
             const int maxS = A.max_score;
             const int dhi1 = d0 + 128, dlo1 = d0 - 1;         // first diagonals outside the band
             int U = C2_DIAG_NEG;
