@@ -48,6 +48,12 @@ struct c2_ctx {
     int max_li = 0;
     std::vector<int> ref_len;
     DevBuf d_refblob, d_refdesc;
+    // host copies needed to (re)build the diagonal-band kernel's row tables when refs or scoring change
+    std::vector<std::string> ref_seq;
+    std::vector<std::vector<int32_t>> ref_g32;
+    std::vector<c2_dev_ref> ref_desc;
+    DevBuf d_diagrows;
+    bool diag_rows_dirty = true;
     // staging for the host batch path and the per-call path
     DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;
     // timing
@@ -223,11 +229,36 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
     return 0;
 }
 
+// (Re)build the per-reference row tables of the diagonal-band kernel after the references or the scoring changed.
+int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
+    if (!ctx->diag_rows_dirty) return 0;
+    std::vector<c2_diag_row> all, one;
+    std::vector<size_t> off(ctx->n_refs, 0);
+    for (int r = 0; r < ctx->n_refs; ++r) {
+        c2_build_diag_rows(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, one);
+        off[r] = all.size();
+        all.insert(all.end(), one.begin(), one.end());
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if (!all.empty()) {
+        if ((rc = ensure(ctx, ctx->d_diagrows, all.size() * sizeof(c2_diag_row)))) return rc;
+        HIPCHK(ctx, hipMemcpy(ctx->d_diagrows.p, all.data(), all.size() * sizeof(c2_diag_row), hipMemcpyHostToDevice));
+    }
+    for (int r = 0; r < ctx->n_refs; ++r)
+        ctx->ref_desc[r].diag_rows = all.empty() ? nullptr : (const c2_diag_row*)ctx->d_diagrows.p + off[r];
+    HIPCHK(ctx, hipMemcpy(ctx->d_refdesc.p, ctx->ref_desc.data(), sizeof(c2_dev_ref) * (size_t)ctx->n_refs, hipMemcpyHostToDevice));
+    ctx->diag_rows_dirty = false;
+    return 0;
+}
+
 int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     Geometry g;
     int rc = geometry(ctx, max_lj, g);
     if (rc) return rc;
     if (b->n_reads == 0) return 0;
+    if ((rc = refresh_diag_rows(ctx, s))) return rc;
     const uint64_t n_tasks = b->n_reads * (uint64_t)(b->all_refs ? ctx->n_refs : 1);
     if (b->aln_stride < (uint32_t)(ctx->max_li + g.max_lj)) { ctx->err = "aln_stride smaller than longest read + longest reference"; return C2_E_INVALID; }
     c2_align_args A;
@@ -296,7 +327,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows};
     for (DevBuf* b : all) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -308,6 +339,7 @@ int c2_set_scoring(c2_ctx* ctx, const int64_t* matrix, int32_t mat_dim, int32_t 
     const size_t nel = (size_t)mat_dim * (size_t)mat_dim;
     const bool same = ctx->have_scoring && ctx->matrix_copy.size() == nel && matrix &&
                       memcmp(ctx->matrix_copy.data(), matrix, nel * sizeof(int64_t)) == 0;
+    if (ctx->gap_open != gap_open || ctx->gap_extend != gap_extend) ctx->diag_rows_dirty = true;
     ctx->gap_open = gap_open; ctx->gap_extend = gap_extend;
     if (same) return 0;
     c2_scoring_tables sc;
@@ -324,6 +356,7 @@ int c2_set_scoring(c2_ctx* ctx, const int64_t* matrix, int32_t mat_dim, int32_t 
     ctx->sc = sc;
     ctx->matrix_copy.assign(matrix, matrix + nel);
     ctx->have_scoring = true;
+    ctx->diag_rows_dirty = true;
     return 0;
 }
 
@@ -362,6 +395,7 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         desc[r].gap_incentive = (const int32_t*)(base + off_g[r]);
         desc[r].inc_prefix = (const uint16_t*)(base + off_p[r]);
         desc[r].len = lens[r];
+        desc[r].diag_rows = nullptr;
         int64_t gm = 0;
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, gap_incentives[r][k]);
         desc[r].gap_incentive_max = (int32_t)std::min<int64_t>(gm, 1 << 20);
@@ -372,6 +406,15 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
     HIPCHK(ctx, hipMemcpy(ctx->d_refdesc.p, desc.data(), sizeof(c2_dev_ref) * (size_t)n_refs, hipMemcpyHostToDevice));
     ctx->n_refs = n_refs;
     ctx->max_li = std::max(max_li, 1);
+    ctx->ref_seq.assign(n_refs, std::string());
+    ctx->ref_g32.assign(n_refs, std::vector<int32_t>());
+    for (int r = 0; r < n_refs; ++r) {
+        ctx->ref_seq[r].assign(seqs[r], seqs[r] + lens[r]);
+        ctx->ref_g32[r].resize(lens[r] + 1);
+        for (int k = 0; k <= lens[r]; ++k) ctx->ref_g32[r][k] = (int32_t)gap_incentives[r][k];
+    }
+    ctx->ref_desc = desc;
+    ctx->diag_rows_dirty = true;
     return 0;
 }
 

@@ -12,15 +12,22 @@
 #define C2_INVALID_CODE 255
 #define C2_PTR_PAD 2               // halfword padding of one pointer column (breaks the 128-B bank stride)
 #define C2_LANES 64
-#define C2_DIAG_NEG (-(1 << 30))   // diagonal-band kernel: value of everything outside the band
+#define C2_DIAG_NEG (-(1 << 30))
+#define C2_DIAG_STORE_LO 16          // diagonal-band kernel: lanes STORE_LO .. STORE_LO+STORE_N-1 (the inner 64 of the 128
+#define C2_DIAG_STORE_N 32           //   diagonals) keep their pointer words; a traceback that leaves them is redone by the row-strip kernel   // diagonal-band kernel: value of everything outside the band
 #define C2_TASK_CHUNK 4              // tasks a workgroup takes per atomic
 #define C2_STATUS_NEED_FULL 64     // internal: banded launch could not finish the traceback; the full-plane launch overwrites the record
+
+// Row constants of the diagonal-band kernel: I opened from M (a), I extended (b), J opened from M (c) -- gap_open, gap_extend
+// and the gap incentives of the row folded in, last-row rule included -- and the packed score row of the reference base.
+typedef struct c2_diag_row { int32_t a, b, c; uint32_t prof; } c2_diag_row;   // 16 bytes: one dwordx4 load
 
 // Device-resident description of one reference amplicon.
 typedef struct c2_dev_ref {
     const uint8_t* seq;           // Li bytes
     const int32_t* gap_incentive; // Li+1 (int64 input truncated to int32 exactly as the reference's int arithmetic does)
     const uint16_t* inc_prefix;   // Li+2: inc_prefix[x] = number of include idxs < x  (window membership and range hits)
+    const c2_diag_row* diag_rows; // Li+2 records (rows 0 and Li+1 are zero), or NULL when the scoring has no packed form
     int32_t len;                  // Li
     int32_t gap_incentive_max;    // max(0, max_i gap_incentive[i]); max(gap_open, gap_extend) + this bounds what one gap base adds to a score
 } c2_dev_ref;

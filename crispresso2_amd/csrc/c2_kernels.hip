@@ -719,14 +719,13 @@ __device__ __forceinline__ int c2_shl1(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, C2_DPP_WAVE_SHL1, 0xf, 0xf, false);
 }
 
-struct c2_diag_plan { uint32_t plane, rows, codes, codeof, read, code, ref, incp, tmp_read, tmp_ref, total; uint32_t n_words; };
+struct c2_diag_plan { uint32_t plane, codes, codeof, read, code, ref, incp, tmp_read, tmp_ref, total; uint32_t n_words; };
 
 __host__ __device__ inline c2_diag_plan c2_make_diag_plan(int max_li, int max_lj) {
     c2_diag_plan p;
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // one 32-bit word per lane per 8 anti-diagonals
     uint32_t off = 0;
-    p.plane = off;    off += p.n_words * 64u * 4u;
-    p.rows = off;     off += c2_align16(((uint32_t)max_li + 2u) * 16u);   // rows 0 .. Li+1 (both ends zero); indices are clamped
+    p.plane = off;    off += p.n_words * (uint32_t)C2_DIAG_STORE_N * 4u;
     p.codes = off;    off += c2_align16((uint32_t)max_lj + 2u);            // columns 0 .. Lj+1 (both ends zero)
     p.codeof = off;   off += 256u;
     p.read = off;     off += c2_align16((uint32_t)max_lj);
@@ -739,15 +738,13 @@ __host__ __device__ inline c2_diag_plan c2_make_diag_plan(int max_li, int max_lj
     return p;
 }
 
-struct c2_diag_row { int a, b, c; unsigned prof; };       // 16 bytes: one ds_read_b128
-
 struct c2_diag_plane {
     const unsigned* words; int d0;
     __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
-        const int dd = pi - pj - d0;
-        if ((unsigned)dd >= 128u) return false;
+        const int sl = ((pi - pj - d0) >> 1) - C2_DIAG_STORE_LO;         // stored lane slot of the cell's diagonal
+        if ((unsigned)sl >= (unsigned)C2_DIAG_STORE_N) return false;
         const int a = pi + pj;
-        nib = (words[(a >> 3) * 64 + (dd >> 1)] >> (4 * (7 - (a & 7)))) & 0xF;
+        nib = (words[(a >> 3) * C2_DIAG_STORE_N + sl] >> (4 * (7 - (a & 7)))) & 0xF;
         return true;
     }
 };
@@ -816,7 +813,7 @@ template <bool MASK, bool LASTCOL>
 __device__ __forceinline__ void c2_diag_groups(c2_diag_state& S, int& g, const int g_stop, const int hE, const int Li, const int Lj,
                                                const int ge, const int startE, const int startO, const int k_cap, const bool cap_odd,
                                                int& Hcap, c2_diag_row (&R)[5], int (&C)[4],
-                                               const c2_diag_row* sRows, const unsigned char* sCodes, unsigned* myWords)
+                                               const c2_diag_row* sRows, const unsigned char* sCodes, unsigned* myWords, const bool stores)
 {
     for (; g <= g_stop; ++g) {
         const int k0 = 4 * g;
@@ -833,7 +830,7 @@ __device__ __forceinline__ void c2_diag_groups(c2_diag_state& S, int& g, const i
             c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, startE, startO, LASTCOL && (k - hE == Lj));
             if (LASTCOL && k == k_cap) Hcap = cap_odd ? S.HO : S.HE;
         }
-        myWords[g * 64] = S.bits;                                   // anti-diagonals 8g .. 8g+7
+        if (stores) myWords[g * C2_DIAG_STORE_N] = S.bits;           // anti-diagonals 8g .. 8g+7 (inner lanes only)
 #pragma unroll
         for (int q = 0; q < 5; ++q) R[q] = RN[q];
 #pragma unroll
@@ -846,7 +843,6 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
     const int lane = threadIdx.x;
     const c2_diag_plan P = c2_make_diag_plan(A.max_li, A.max_lj);
     unsigned* sWords = (unsigned*)(c2_smem + P.plane);
-    c2_diag_row* sRows = (c2_diag_row*)(c2_smem + P.rows);
     unsigned char* sCodes = c2_smem + P.codes;
     c2_wg W;
     W.sRead = c2_smem + P.read; W.sCode = c2_smem + P.code; W.sRef = c2_smem + P.ref;
@@ -855,7 +851,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
     unsigned char* sCodeOf = c2_smem + P.codeof;
     for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
 
-    int cur_ref = -1, rows_ref = -1;
+    int cur_ref = -1;
     int Li = 0, g0 = 0;
     uint64_t chunk_base = 0;
     int chunk_left = 0;
@@ -880,24 +876,12 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
         int cb = 0;
         if (status == 0) {
             cb = (go > ge ? go : ge) + rf.gap_incentive_max;      // the most one gap base can add to a score
-            if (!packed || cb >= 0 || d0 > 0 || d0 + 127 < 0 || D < d0 || D > d0 + 127) need_full = true;
+            if (!packed || rf.diag_rows == nullptr || cb >= 0 || d0 > 0 || d0 + 127 < 0 || D < d0 || D > d0 + 127) need_full = true;
         }
         if (status == 0 && !need_full) {
             // ---- tables: row constants (per reference) and 4*code per column (per read), both padded so that the lanes that
             //      are still before / already past the matrix read zeros instead of running off the arrays
-            if (rows_ref != ref_id) {
-                rows_ref = ref_id;
-                for (int i = lane; i < Li + 2; i += 64) {
-                    c2_diag_row r; r.a = 0; r.b = 0; r.c = 0; r.prof = 0;
-                    if (i >= 1 && i <= Li) {
-                        const int gi = rf.gap_incentive[i], gim1 = rf.gap_incentive[i - 1];
-                        const int open = (i == Li) ? ge : go;               // last row: gap_open -> gap_extend (pyx:277-317)
-                        r.a = open + gi; r.b = ge + gi; r.c = open + gim1;
-                        r.prof = A.score_pk[sCodeOf[W.sRef[i - 1]]];
-                    }
-                    sRows[i] = r;
-                }
-            }
+            const c2_diag_row* sRows = rf.diag_rows;           // row constants: 4 KB per amplicon, L1/L2 resident, fetched a group ahead
             for (int j = lane; j < Lj + 2; j += 64)
                 sCodes[j] = (j >= 1 && j <= Lj) ? (unsigned char)(W.sCode[j - 1] << 2) : (unsigned char)0;
             __syncthreads();
@@ -931,7 +915,8 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
             const int gA = ((max_start + 1) >> 1) >> 2;        // groups 0..gA contain lanes that have not started
             const int gC = ((2 * Lj + d0) >> 1) >> 2;          // first group in which some lane is on the last column
             const int g_end = k_end >> 2;
-            unsigned* myWords = sWords + lane;
+            unsigned* myWords = sWords + (lane - C2_DIAG_STORE_LO);
+            const bool stores = (unsigned)(lane - C2_DIAG_STORE_LO) < (unsigned)C2_DIAG_STORE_N;
             // tables of group 0: rows i = k + hE (E cell of pair k) .. and one more for the last O cell; columns j = k - hE
             c2_diag_row Rw[5];
             int Cw[4];
@@ -944,12 +929,12 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
             int g = 0;
             const int gA_stop = gA < g_end ? gA : g_end;
             if (gC <= gA_stop) {
-                c2_diag_groups<true, true>(S, g, gA_stop, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords);
+                c2_diag_groups<true, true>(S, g, gA_stop, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords, stores);
             } else {
-                c2_diag_groups<true, false>(S, g, gA_stop, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords);
-                c2_diag_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords);
+                c2_diag_groups<true, false>(S, g, gA_stop, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords, stores);
+                c2_diag_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords, stores);
             }
-            c2_diag_groups<false, true>(S, g, g_end, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords);
+            c2_diag_groups<false, true>(S, g, g_end, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords, stores);
             __syncthreads();
             c2_phase_mark<1>(A.phase_cycles, PH);
 

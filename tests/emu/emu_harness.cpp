@@ -25,12 +25,15 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     std::vector<c2_dev_ref> refs(n_refs);
     std::vector<std::vector<int32_t>> g32(n_refs);
     std::vector<std::vector<uint16_t>> incp(n_refs);
+    std::vector<std::vector<c2_diag_row>> drows(n_refs);
     int max_li = 1;
     for (int r = 0; r < n_refs; ++r) {
         g32[r].resize(lens[r] + 1);
         for (int k = 0; k <= lens[r]; ++k) g32[r][k] = (int32_t)gap_inc[r][k];
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
         refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = g32[r].data(); refs[r].inc_prefix = incp[r].data();
+        c2_build_diag_rows(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows[r]);
+        refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data();
         refs[r].len = lens[r];
         int64_t gm = 0;
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, gap_inc[r][k]);
@@ -119,7 +122,7 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     int lmax = 1;
     for (int r = 0; r < n_refs; ++r) {
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
-        refs[r].seq = nullptr; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].len = lens[r]; refs[r].gap_incentive_max = 0;
+        refs[r].seq = nullptr; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].diag_rows = nullptr; refs[r].len = lens[r]; refs[r].gap_incentive_max = 0;
         lmax = std::max(lmax, lens[r]);
     }
     unsigned long long wc = 0;
