@@ -565,7 +565,7 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     const int lmax = ctx->max_li;
     if (hl < lmax + 2) { ctx->err = "hl too small"; return C2_E_INVALID; }
     const size_t per_ref = (size_t)C2_CNT_VECTORS * (lmax + 1) + C2_CNT_SCALARS + (size_t)C2_CNT_HISTS * hl;
-    const size_t lds = per_ref * sizeof(int);
+    const size_t lds = c2_count_lds_bytes(per_ref, lmax);
     if (lds > 163840) { ctx->err = "count block does not fit LDS"; return C2_E_TOO_LARGE; }
     int rc;
     c2_count_args A;
@@ -590,11 +590,11 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     A.n_tasks = n_tasks; A.aln_stride = aln_stride; A.n_refs = ctx->n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_count_vectors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     int nb = 1;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_count_vectors_kernel, 64, lds));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_count_vectors_kernel, 64 * C2_CNT_WAVES, lds));
     if (nb < 1) nb = 1;
     const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)nb;
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_tasks + 31) / 32, resident));
-    hipLaunchKernelGGL(c2_count_vectors_kernel, dim3(grid), dim3(64), lds, s, A);
+    hipLaunchKernelGGL(c2_count_vectors_kernel, dim3(grid), dim3(64 * C2_CNT_WAVES), lds, s, A);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }

@@ -1,6 +1,7 @@
 // Plain-data structures shared by the host side (c2_api.hip) and the kernels (c2_kernels.hip).
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 #include "crispresso2_amd.h"   // c2_aln_record, C2_STATUS_* (public ABI)
 
 // traceback / DP states (same numbering as the reference: CRISPResso2Align.pyx:23)
@@ -99,6 +100,15 @@ enum {
     C2_CNT_SCALARS
 };
 enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_LEN, C2_CNT_HISTS };
+
+// count kernel geometry: C2_CNT_WAVES wavefronts share one LDS accumulator block; after the block come
+// C2_CNT_CTL_INTS control words and the current reference's inc_prefix (lmax + 2 uint16)
+#define C2_CNT_WAVES 4
+#define C2_CNT_TASKS_PER_WAVE 8
+#define C2_CNT_CTL_INTS 32
+static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {
+    return (per_ref + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
+}
 
 #define C2_CNT_FLAG_IGNORE_SUBSTITUTIONS 1
 #define C2_CNT_FLAG_IGNORE_INSERTIONS 2

@@ -1143,30 +1143,35 @@ __device__ __forceinline__ int c2_wave_incl_scan(int v, int lane) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void c2_count_vectors_kernel(c2_count_args A)
+__global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_count_args A)
 {
-    const int lane = threadIdx.x;
+    // C2_CNT_WAVES wavefronts share one LDS block (the block is what limits residency, so sharing it multiplies the
+    // waves per CU); each wavefront walks one alignment at a time.  The workgroup takes C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE
+    // consecutive tasks per atomic; lane k of wave v holds the record of task base + k * C2_CNT_WAVES + v.
+    constexpr int NT = 64 * C2_CNT_WAVES, K = C2_CNT_TASKS_PER_WAVE, CHUNK = C2_CNT_WAVES * K, NONE = 0x7fffffff;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* acc = (int*)c2_smem;
     const int VL = A.lmax + 1;                                  // vector length incl. the end slot of the difference arrays
     const int o_sc = C2_CNT_VECTORS * VL, o_h = o_sc + C2_CNT_SCALARS;
     const int per_ref = o_h + C2_CNT_HISTS * A.hl;
-    for (int k = lane; k < per_ref; k += 64) acc[k] = 0;
+    int* ctl = acc + per_ref;                                   // [0..1] chunk base, [2..5] chunk weight per wave, [8..23] two sets of (ref, task) per wave
+    uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
+    for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
     __syncthreads();
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
     const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    int cur_ref = -1;
-    long long wsum = 0;                                         // weight accumulated since the last flush (int32 safety)
-    const uint16_t* incp = nullptr;
-    int Li = 0;
+    int cur_ref = -1;                                           // workgroup-uniform, like everything that guards a barrier
+    int wsum = 0;                                               // weight accumulated since the last flush (int32 safety)
+    int Li = 0, par = 0;
 
-    // flush the LDS block of cur_ref into the int64 tensor
+    // flush the LDS block of cur_ref into the int64 tensor (workgroup-wide)
     auto flush = [&]() {
         if (cur_ref < 0) return;
         __syncthreads();
         // deletion vectors were accumulated as difference arrays (start += x, end -= x): integrate them first
-        for (int v = 0; v < 2; ++v) {
-            int* d = acc + (v == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
+        if (wave < 2) {
+            int* d = acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
             int carry = 0;
             for (int base = 0; base < VL; base += 64) {
                 const int k = base + lane;
@@ -1178,7 +1183,7 @@ __global__ __launch_bounds__(64) void c2_count_vectors_kernel(c2_count_args A)
         }
         __syncthreads();
         long long* out = A.counts + (size_t)cur_ref * per_ref;
-        for (int k = lane; k < per_ref; k += 64) {
+        for (int k = tid; k < per_ref; k += NT) {
             const int x = acc[k];
             if (x != 0) { atomicAdd((unsigned long long*)(out + k), (unsigned long long)(long long)x); acc[k] = 0; }
         }
@@ -1186,159 +1191,207 @@ __global__ __launch_bounds__(64) void c2_count_vectors_kernel(c2_count_args A)
         __syncthreads();
     };
 
-    uint64_t chunk_base = 0;
-    int chunk_left = 0;
     for (;;) {
-        if (chunk_left == 0) {
-            unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(A.work_counter, (unsigned long long)(8 * C2_TASK_CHUNK));
-            chunk_base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
-                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
-            chunk_left = 8 * C2_TASK_CHUNK;
+        if (tid == 0) {
+            const unsigned long long b = atomicAdd(A.work_counter, (unsigned long long)CHUNK);
+            ctl[0] = (int)(unsigned)(b & 0xffffffffu); ctl[1] = (int)(unsigned)(b >> 32);
         }
-        const uint64_t task = chunk_base;
-        if (task >= A.n_tasks) break;
-        ++chunk_base; --chunk_left;
-
-        const c2_aln_record rec = A.records[task];
-        const int w = A.weights ? (int)A.weights[task] : 1;
-        const int T = rec.aln_len, ref = rec.ref_id;
-        bool sel = (rec.status == 0) && (w > 0) && (T > 0);
-        if (sel && A.min_matches) sel = (T <= A.max_t) && (rec.matches >= A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
-        if (!sel) continue;
-        if (ref != cur_ref || wsum + w > (1ll << 21)) {
-            flush();
-            cur_ref = ref; Li = A.refs[ref].len; incp = A.refs[ref].inc_prefix;
+        __syncthreads();
+        const uint64_t chunk_base = (uint64_t)(unsigned)ctl[0] | ((uint64_t)(unsigned)ctl[1] << 32);
+        if (chunk_base >= A.n_tasks) break;
+        // ---- the records of this wave's K tasks, one per lane; selection test of CRISPRessoCORE.py:697 per lane
+        const uint64_t my_task = chunk_base + (uint64_t)((lane & (K - 1)) * C2_CNT_WAVES + wave);
+        unsigned d0 = 0, d1 = 0, d2 = 0, d4 = 0, d5 = 0, d6 = 0; int v_w = 0;
+        bool sel = false;
+        if (lane < K && my_task < A.n_tasks) {
+            const unsigned* rp = (const unsigned*)(A.records + my_task);
+            d0 = rp[0]; d1 = rp[1]; d2 = rp[2]; d4 = rp[4]; d5 = rp[5]; d6 = rp[6];
+            const unsigned wq = A.weights ? A.weights[my_task] : 1u;
+            v_w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
+            const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16), ref = (int)(d6 >> 16);
+            sel = ((d5 >> 24) == 0) && (v_w > 0) && (T > 0);
+            if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
         }
-        wsum += w;
-        // aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979)
-        const int all_ins = rec.all_insertion_events, all_sub = rec.all_substitutions;
-        const int total_mods = all_ins + rec.all_deletion_bases + all_sub;                       // :741
-        const int in_win = rec.substitution_n + rec.deletion_n + rec.insertion_n;              // :742
-        int* scal = acc + o_sc;                                  // scalar counters: lane 0 adds (LDS, any index)
-        const bool l0 = (lane == 0);
-        if (l0) {
-            atomicAdd(scal + C2_S_N_GLOBAL_SUBS, all_sub * w);
-            atomicAdd(scal + C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - rec.substitution_n) * w);
-            atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
-            atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
-            if (rec.irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
-            atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);
-        }
-        if (discard && (rec.deletion_n > 0 || rec.insertion_n > 0)) { if (l0) atomicAdd(scal + C2_S_DISCARDED, w); continue; }   // :3996-4000
-        const bool modified = (!ign_del && rec.deletion_n > 0) || (!ign_ins && rec.insertion_n > 0) || (!ign_sub && rec.substitution_n > 0);
-        const bool has_ins = !ign_ins && rec.insertion_n > 0, has_del = !ign_del && rec.deletion_n > 0, has_sub = !ign_sub && rec.substitution_n > 0;
-        if (l0) {
-            atomicAdd(scal + C2_S_TOTAL, w);
-            atomicAdd(scal + (modified ? C2_S_MODIFIED : C2_S_UNMODIFIED), w);                  // :746-760, :4003-4006
-            if (has_ins) atomicAdd(scal + C2_S_INSERTION, w);
-            if (has_del) atomicAdd(scal + C2_S_DELETION, w);
-            if (has_sub) atomicAdd(scal + C2_S_SUBSTITUTION, w);
-            int combo = -1;                                                                     // :4058-4072
-            if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
-                                         : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
-            else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
-            else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
-            if (combo >= 0) atomicAdd(scal + combo, w);
-        }
-        const bool len_block = has_ins || has_del || has_sub;                                  // :4085 (no coding sequence)
-        if (lane == 0) {
-            if (!ign_ins) atomicAdd(acc + o_h + C2_H_INSERTED_N * A.hl + rec.insertion_n, w);   // :4020
-            if (!ign_del) atomicAdd(acc + o_h + C2_H_DELETED_N * A.hl + rec.deletion_n, w);     // :4030
-            if (!ign_sub) atomicAdd(acc + o_h + C2_H_SUBSTITUTED_N * A.hl + rec.substitution_n, w);   // :4043
-            const int eff = Li + (ign_ins ? 0 : rec.insertion_n) - (ign_del ? 0 : rec.deletion_n);   // :4010-4037
-            atomicAdd(acc + o_h + C2_H_EFFECTIVE_LEN * A.hl + eff, w);
-        }
-        // ---- column walk (same scan as the fused classifier), ds_add into the vectors
-        const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride;
-        const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride;
-        int idx_base = 0, last_rf = -1, last_rd = -1;
-        bool last_rf_close = false, last_rf_wclose = false;
-        // all loads of up to 256 columns are issued before the first one is used (one HBM round trip, not four)
-        unsigned char pre_rd[4], pre_rf[4];
+        unsigned pending = (unsigned)__ballot(sel);
+        {   // chunk weight (clamped per task so the sum cannot wrap): decides flushes before anything is added
+            int wv = sel ? (v_w > (1 << 22) ? (1 << 22) : v_w) : 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = 64 * q + lane;
-            pre_rd[q] = (c < T) ? R_[c] : 0;
-            pre_rf[q] = (c < T) ? F_[c] : 0;
+            for (int d = 1; d < K; d <<= 1) wv += __shfl_xor(wv, d);
+            if (lane == 0) ctl[2 + wave] = wv;
         }
-        for (int base = 0; base < T; base += 64) {
-            const int c = base + lane;
-            const bool in = c < T;
-            unsigned char rd, rfc;
-            if (base < 256) { rd = pre_rd[(base >> 6) & 3]; rfc = pre_rf[(base >> 6) & 3]; }
-            else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
-            const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
-            const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
-            const int idx = idx_base + __popcll(m_rf & lt);
-            const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
-            const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
-            const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
-            if (rf_ng) {
-                int bv = -1;                                                                    // all_base_count, :4075-4081
-                if (rd == 'A') bv = C2_V_BASE_A; else if (rd == 'C') bv = C2_V_BASE_C; else if (rd == 'G') bv = C2_V_BASE_G;
-                else if (rd == 'T') bv = C2_V_BASE_T; else if (rd == 'N') bv = C2_V_BASE_N; else if (rd == '-') bv = C2_V_BASE_GAP;
-                if (bv >= 0) atomicAdd(acc + bv * VL + idx, w);
-                if (!rd_ng) atomicAdd(acc + C2_V_ALL_DELETION * VL + idx, w);                   // :4028
+        __syncthreads();
+        int chunk_w = 0;
+#pragma unroll
+        for (int v = 0; v < C2_CNT_WAVES; ++v) chunk_w += ctl[2 + v];
+        // a chunk heavier than the int32 budget is processed one task at a time with a flush after each
+        const bool heavy = chunk_w > (1 << 21);
+        if (!heavy && wsum + chunk_w > (1 << 21)) flush();
+        wsum += heavy ? 0 : chunk_w;
+        for (;;) {
+            // lowest pending task of the workgroup -> the reference whose tasks are processed in this round
+            const int first = pending ? __builtin_ctz(pending) : -1;
+            int fref = NONE, ftask = NONE;
+            if (first >= 0) { fref = (int)((unsigned)__builtin_amdgcn_readlane((int)d6, first) >> 16); ftask = first * C2_CNT_WAVES + wave; }
+            if (lane == 0) { ctl[8 + par * 8 + wave * 2] = fref; ctl[8 + par * 8 + wave * 2 + 1] = ftask; }
+            __syncthreads();
+            int tref = NONE, ttask = NONE;
+#pragma unroll
+            for (int v = 0; v < C2_CNT_WAVES; ++v) {
+                const int t = ctl[8 + par * 8 + v * 2 + 1];
+                if (t < ttask) { ttask = t; tref = ctl[8 + par * 8 + v * 2]; }
             }
-            const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
-            if (sub) {
-                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + idx, w);                           // :4040
-                if (!ign_sub) {
-                    if (incp[idx + 1] != incp[idx]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + idx, w);   // :4044
-                    int sv = -1;                                                                // :4049-4054
-                    if (rd == 'A') sv = C2_V_ALL_SUB_BASE_A; else if (rd == 'C') sv = C2_V_ALL_SUB_BASE_C;
-                    else if (rd == 'G') sv = C2_V_ALL_SUB_BASE_G; else if (rd == 'T') sv = C2_V_ALL_SUB_BASE_T;
-                    if (sv >= 0) atomicAdd(acc + sv * VL + idx, w);
+            par ^= 1;
+            if (ttask == NONE) break;
+            if (tref != cur_ref) {
+                flush();
+                cur_ref = tref; Li = A.refs[tref].len;
+                const uint16_t* g = A.refs[tref].inc_prefix;
+                for (int k = tid; k < Li + 2; k += NT) incp[k] = g[k];
+                __syncthreads();
+            }
+            unsigned todo = heavy ? ((first >= 0 && ftask == ttask) ? (1u << first) : 0u) : pending;
+            while (todo) {
+                const int kk = __builtin_ctz(todo);
+                todo &= todo - 1;
+                const unsigned r6 = (unsigned)__builtin_amdgcn_readlane((int)d6, kk);
+                if ((int)(r6 >> 16) != tref) continue;
+                pending &= ~(1u << kk);
+                const uint64_t task = chunk_base + (uint64_t)(kk * C2_CNT_WAVES + wave);
+                const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)d0, kk), r1 = (unsigned)__builtin_amdgcn_readlane((int)d1, kk);
+                const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)d2, kk), r4 = (unsigned)__builtin_amdgcn_readlane((int)d4, kk);
+                const unsigned r5 = (unsigned)__builtin_amdgcn_readlane((int)d5, kk);
+                const int w = __builtin_amdgcn_readlane(v_w, kk);
+                const int T = (int)(r0 & 0xffffu);
+                const int insertion_n = (int)(r1 & 0xffffu), deletion_n = (int)(r1 >> 16), substitution_n = (int)(r2 & 0xffffu);
+                const int all_ins = (int)(r2 >> 16), all_del_bases = (int)(r4 >> 16), all_sub = (int)(r5 & 0xffffu);
+                const bool irregular_ends = (r5 >> 16) & 0xffu;
+                // first 256 columns of both strings: requested now, consumed by the column walk below
+                const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride;
+                const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride;
+                unsigned rd4 = 0, rf4 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 64 * q + lane;
+                    if (c < T) { rd4 |= (unsigned)R_[c] << (8 * q); rf4 |= (unsigned)F_[c] << (8 * q); }
                 }
-            }
-            // insertions: positions [idx-1, idx] of every event; numpy's fancy += counts a repeated position once (:4016, :4021)
-            const bool ins_close = rf_ng && (prev_rf != c - 1) && idx > 0;
-            const bool ins_win = ins_close && (incp[idx] != incp[idx - 1]) && (incp[idx + 1] != incp[idx]);
-            const unsigned long long m_ic = __ballot(ins_close), m_iw = __ballot(ins_win);
-            if (ins_close) {
-                const bool prev_close = (prev_rf >= base) ? ((m_ic >> (prev_rf - base)) & 1ull) : last_rf_close;
-                const bool prev_wclose = (prev_rf >= base) ? ((m_iw >> (prev_rf - base)) & 1ull) : last_rf_wclose;
-                atomicAdd(acc + C2_V_ALL_INSERTION_LEFT * VL + idx - 1, w);                     // :4017
-                atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx, w);
-                if (!prev_close) atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx - 1, w);
-                if (ins_win) {
-                    if (!ign_ins) {
-                        atomicAdd(acc + C2_V_INSERTION * VL + idx, w);
-                        if (!prev_wclose) atomicAdd(acc + C2_V_INSERTION * VL + idx - 1, w);
+                // aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979)
+                const int total_mods = all_ins + all_del_bases + all_sub;                               // :741
+                const int in_win = substitution_n + deletion_n + insertion_n;                           // :742
+                int* scal = acc + o_sc;                          // scalar counters: lane 0 adds (LDS, any index)
+                const bool l0 = (lane == 0);
+                if (l0) {
+                    atomicAdd(scal + C2_S_N_GLOBAL_SUBS, all_sub * w);
+                    atomicAdd(scal + C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - substitution_n) * w);
+                    atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
+                    atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
+                    if (irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
+                    atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);
+                }
+                if (discard && (deletion_n > 0 || insertion_n > 0)) { if (l0) atomicAdd(scal + C2_S_DISCARDED, w); continue; }   // :3996-4000
+                const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
+                const bool modified = has_del || has_ins || has_sub;
+                if (l0) {
+                    atomicAdd(scal + C2_S_TOTAL, w);
+                    atomicAdd(scal + (modified ? C2_S_MODIFIED : C2_S_UNMODIFIED), w);          // :746-760, :4003-4006
+                    if (has_ins) atomicAdd(scal + C2_S_INSERTION, w);
+                    if (has_del) atomicAdd(scal + C2_S_DELETION, w);
+                    if (has_sub) atomicAdd(scal + C2_S_SUBSTITUTION, w);
+                    int combo = -1;                                                             // :4058-4072
+                    if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
+                                                 : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
+                    else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
+                    else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
+                    if (combo >= 0) atomicAdd(scal + combo, w);
+                    if (!ign_ins) atomicAdd(acc + o_h + C2_H_INSERTED_N * A.hl + insertion_n, w);   // :4020
+                    if (!ign_del) atomicAdd(acc + o_h + C2_H_DELETED_N * A.hl + deletion_n, w);     // :4030
+                    if (!ign_sub) atomicAdd(acc + o_h + C2_H_SUBSTITUTED_N * A.hl + substitution_n, w);   // :4043
+                    const int eff = Li + (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n);   // :4010-4037
+                    atomicAdd(acc + o_h + C2_H_EFFECTIVE_LEN * A.hl + eff, w);
+                }
+                const bool len_block = modified;                                                // :4085 (no coding sequence)
+                // ---- column walk (same scan as the fused classifier), ds_add into the vectors
+                int idx_base = 0, last_rf = -1, last_rd = -1;
+                bool last_rf_close = false, last_rf_wclose = false;
+                for (int base = 0; base < T; base += 64) {
+                    const int c = base + lane;
+                    const bool in = c < T;
+                    unsigned char rd, rfc;
+                    if (base < 256) { rd = in ? (unsigned char)((rd4 >> ((base >> 6) * 8)) & 0xffu) : 0; rfc = in ? (unsigned char)((rf4 >> ((base >> 6) * 8)) & 0xffu) : 0; }
+                    else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
+                    const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
+                    const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
+                    const int idx = idx_base + __popcll(m_rf & lt);
+                    const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
+                    const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
+                    const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
+                    if (rf_ng) {
+                        int bv = -1;                                                                    // all_base_count, :4075-4081
+                        if (rd == 'A') bv = C2_V_BASE_A; else if (rd == 'C') bv = C2_V_BASE_C; else if (rd == 'G') bv = C2_V_BASE_G;
+                        else if (rd == 'T') bv = C2_V_BASE_T; else if (rd == 'N') bv = C2_V_BASE_N; else if (rd == '-') bv = C2_V_BASE_GAP;
+                        if (bv >= 0) atomicAdd(acc + bv * VL + idx, w);
+                        if (!rd_ng) atomicAdd(acc + C2_V_ALL_DELETION * VL + idx, w);                   // :4028
                     }
-                    if (len_block) {                                                            // :4104-4106 (scalar index: repeats add twice)
-                        const int sz = (c - 1 - prev_rf) * w;
-                        atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx - 1, sz);
-                        atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx, sz);
+                    const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
+                    if (sub) {
+                        atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + idx, w);                           // :4040
+                        if (!ign_sub) {
+                            if (incp[idx + 1] != incp[idx]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + idx, w);   // :4044
+                            int sv = -1;                                                                // :4049-4054
+                            if (rd == 'A') sv = C2_V_ALL_SUB_BASE_A; else if (rd == 'C') sv = C2_V_ALL_SUB_BASE_C;
+                            else if (rd == 'G') sv = C2_V_ALL_SUB_BASE_G; else if (rd == 'T') sv = C2_V_ALL_SUB_BASE_T;
+                            if (sv >= 0) atomicAdd(acc + sv * VL + idx, w);
+                        }
+                    }
+                    // insertions: positions [idx-1, idx] of every event; numpy's fancy += counts a repeated position once (:4016, :4021)
+                    const bool ins_close = rf_ng && (prev_rf != c - 1) && idx > 0;
+                    const bool ins_win = ins_close && (incp[idx] != incp[idx - 1]) && (incp[idx + 1] != incp[idx]);
+                    const unsigned long long m_ic = __ballot(ins_close), m_iw = __ballot(ins_win);
+                    if (ins_close) {
+                        const bool prev_close = (prev_rf >= base) ? ((m_ic >> (prev_rf - base)) & 1ull) : last_rf_close;
+                        const bool prev_wclose = (prev_rf >= base) ? ((m_iw >> (prev_rf - base)) & 1ull) : last_rf_wclose;
+                        atomicAdd(acc + C2_V_ALL_INSERTION_LEFT * VL + idx - 1, w);                     // :4017
+                        atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx, w);
+                        if (!prev_close) atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx - 1, w);
+                        if (ins_win) {
+                            if (!ign_ins) {
+                                atomicAdd(acc + C2_V_INSERTION * VL + idx, w);
+                                if (!prev_wclose) atomicAdd(acc + C2_V_INSERTION * VL + idx - 1, w);
+                            }
+                            if (len_block) {                                                            // :4104-4106 (scalar index: repeats add twice)
+                                const int sz = (c - 1 - prev_rf) * w;
+                                atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx - 1, sz);
+                                atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx, sz);
+                            }
+                        }
+                    }
+                    // deletions that touch the window: range(start, end) as a difference array (integrated in flush)
+                    const bool del_close = rd_ng && (prev_rd != c - 1);
+                    if (del_close) {
+                        const int dlen = c - 1 - prev_rd;
+                        if (incp[idx] != incp[idx - dlen]) {
+                            if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + idx - dlen, w); atomicAdd(acc + C2_V_DELETION * VL + idx, -w); }   // :4031
+                            if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx - dlen, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx, -dlen * w); }   // :4114
+                        }
+                    }
+                    idx_base += __popcll(m_rf);
+                    if (m_rf) {
+                        const int hi = 63 - __clzll((long long)m_rf);
+                        last_rf = base + hi;
+                        last_rf_close = (m_ic >> hi) & 1ull;
+                        last_rf_wclose = (m_iw >> hi) & 1ull;
+                    }
+                    if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
+                }
+                if (last_rd != T - 1 && lane == 0) {                                                    // trailing deletion, pyx:155-162
+                    const int dlen = T - 1 - last_rd;
+                    if (incp[idx_base] != incp[idx_base - dlen]) {
+                        if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + idx_base - dlen, w); atomicAdd(acc + C2_V_DELETION * VL + idx_base, -w); }
+                        if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx_base - dlen, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx_base, -dlen * w); }
                     }
                 }
-            }
-            // deletions that touch the window: range(start, end) as a difference array (integrated in flush)
-            const bool del_close = rd_ng && (prev_rd != c - 1);
-            if (del_close) {
-                const int dlen = c - 1 - prev_rd;
-                if (incp[idx] != incp[idx - dlen]) {
-                    if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + idx - dlen, w); atomicAdd(acc + C2_V_DELETION * VL + idx, -w); }   // :4031
-                    if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx - dlen, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx, -dlen * w); }   // :4114
-                }
-            }
-            idx_base += __popcll(m_rf);
-            if (m_rf) {
-                const int hi = 63 - __clzll((long long)m_rf);
-                last_rf = base + hi;
-                last_rf_close = (m_ic >> hi) & 1ull;
-                last_rf_wclose = (m_iw >> hi) & 1ull;
-            }
-            if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
-        }
-        if (last_rd != T - 1 && lane == 0) {                                                    // trailing deletion, pyx:155-162
-            const int dlen = T - 1 - last_rd;
-            if (incp[idx_base] != incp[idx_base - dlen]) {
-                if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + idx_base - dlen, w); atomicAdd(acc + C2_V_DELETION * VL + idx_base, -w); }
-                if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx_base - dlen, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx_base, -dlen * w); }
-            }
-        }
-    }
+            }   // tasks of this round
+            if (heavy) flush();
+        }       // rounds of this chunk
+    }           // chunks
     flush();
 }

@@ -130,7 +130,7 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     A.aln_read = aln_read; A.aln_ref = aln_ref; A.records = records; A.weights = weights; A.min_matches = min_matches;
     A.refs = refs.data(); A.counts = counts; A.work_counter = &wc; A.n_tasks = n_tasks; A.aln_stride = aln_stride;
     A.n_refs = n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
-    emu::launch(grid ? grid : 2, [&] { c2_count_vectors_kernel(A); });
+    emu::launch(grid ? grid : 2, [&] { c2_count_vectors_kernel(A); }, 64 * C2_CNT_WAVES);
     return 0;
 }
 

@@ -5,14 +5,13 @@
 #include <vector>
 
 namespace emu {
-int cur_lane = 0;
+int cur_lane = 0, n_threads = W;
 dim3_ block_idx, grid_dim, block_dim;
-ucontext_t lane_ctx[W], sched_ctx;
-bool lane_done[W];
-uint64_t xl_slots[2][W];
-int xl_phase = 0;
-int bar_count = 0;
-unsigned bar_gen = 0;
+ucontext_t lane_ctx[MAXT], sched_ctx;
+bool lane_done[MAXT];
+uint64_t xl_slots[2][MAXT];
+int bar_count = 0, wbar_count[MAXW];
+unsigned bar_gen = 0, wbar_gen[MAXW];
 static std::function<void()>* cur_body = nullptr;
 static std::vector<char> stacks;
 
@@ -20,24 +19,27 @@ static void lane_entry() {
     (*cur_body)();
     lane_done[cur_lane] = true;
     // hand control to any unfinished lane, else back to the scheduler
-    for (int k = 1; k <= W; ++k) {
-        int c = (cur_lane + k) % W;
+    for (int k = 1; k <= n_threads; ++k) {
+        int c = (cur_lane + k) % n_threads;
         if (!lane_done[c]) { int me = cur_lane; cur_lane = c; swapcontext(&lane_ctx[me], &lane_ctx[c]); }
     }
     setcontext(&sched_ctx);
 }
 
 template <class F>
-void launch(unsigned grid, F body) {
+void launch(unsigned grid, F body, unsigned block) {
     std::function<void()> fn = body;
     cur_body = &fn;
     const size_t STK = 256 * 1024;
-    stacks.resize(STK * W);
-    grid_dim.x = grid; block_dim.x = W;
+    if (block == 0 || block % W || block > (unsigned)MAXT) { fprintf(stderr, "emu: unsupported block size %u\n", block); abort(); }
+    n_threads = (int)block;
+    stacks.resize(STK * n_threads);
+    grid_dim.x = grid; block_dim.x = block;
     for (unsigned b = 0; b < grid; ++b) {
         block_idx.x = b;
         bar_count = 0;
-        for (int l = 0; l < W; ++l) {
+        for (int w = 0; w < MAXW; ++w) wbar_count[w] = 0;
+        for (int l = 0; l < n_threads; ++l) {
             lane_done[l] = false;
             getcontext(&lane_ctx[l]);
             lane_ctx[l].uc_stack.ss_sp = stacks.data() + STK * l;
@@ -49,7 +51,7 @@ void launch(unsigned grid, F body) {
         volatile bool started = false;
         getcontext(&sched_ctx);
         if (!started) { started = true; setcontext(&lane_ctx[0]); }
-        for (int l = 0; l < W; ++l) if (!lane_done[l]) { fprintf(stderr, "emu: lane %d never finished\n", l); abort(); }
+        for (int l = 0; l < n_threads; ++l) if (!lane_done[l]) { fprintf(stderr, "emu: lane %d never finished\n", l); abort(); }
     }
 }
 }  // namespace emu

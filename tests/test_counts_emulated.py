@@ -72,6 +72,25 @@ def test_count_vectors_min_alignment_score_gate(aligned):
     compare(got, exp, len(amp))
 
 
+def test_count_vectors_interleaved_references_and_heavy_weights(aligned):
+    """Tasks of two references interleaved inside one workgroup chunk (rounds per reference, flush on change) and read
+    multiplicities beyond the int32 budget of the LDS accumulators (one-task-at-a-time path)."""
+    amp, inc, reads, res, rec, (o1, o2) = aligned
+    rng = np.random.default_rng(5)
+    rec2 = rec.copy()
+    rec2["ref_id"] = rng.integers(0, 2, len(rec2)).astype(np.uint16)
+    w = rng.integers(1, 9, len(reads)).astype(np.uint32)
+    w[3] = 3_000_000
+    w[40] = 2_500_000
+    w[41] = 2_200_000
+    counts, lay = E.count_vectors(o1, o2, rec2, [len(amp), len(amp)], [inc, inc], max(len(r) for r in reads), weights=w, grid=3)
+    P = payloads(res, inc)
+    for r in range(2):
+        got = lay.unpack(counts, r, len(amp))
+        items = [(p, int(c)) for p, c, rid in zip(P, w, rec2["ref_id"]) if rid == r]
+        compare(got, aggregate.aggregate(items, len(amp)), len(amp))
+
+
 def test_min_matches_table_is_the_reference_expression():
     mm = C.min_matches_table([60.0, 0.0], 300)
     for T in (1, 7, 64, 255, 300):
