@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="processes generating the synthetic reads (0 = auto; 1 = no fork, for profiler runs)")
     ap.add_argument("--band", type=int, default=-1, help="pointer-plane band: -1 auto, 0 off, n lanes each side")
     ap.add_argument("--band-wgs", type=int, default=0, help="target workgroups per CU for the automatic band")
-    ap.add_argument("--kernel", choices=["auto", "band", "full"], default="auto", help="first-launch kernel (auto = diagonal-band with certificate)")
+    ap.add_argument("--kernel", choices=["auto", "band", "full", "diag1", "diag2"], default="auto",
+                    help="kernel chain (auto = diagonal-band kernels with certificate, 4 -> 2 -> 1 alignments per wavefront)")
     ap.add_argument("--check", type=int, default=300, help="reads compared with the oracle after the timed region")
     args = ap.parse_args()
 
@@ -152,6 +153,9 @@ def main():
                 break
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
+    tiers = ctx.tier_info()
+    chain_names = {"auto": ["c2_align_diagx_kernel<4>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
+                   "diag2": ["c2_align_diagx_kernel<2>", "c2_align_diag_kernel"], "diag1": ["c2_align_diag_kernel"]}
     # HBM bytes per alignment from the committed PMC passes (separate rocprofv3 --pmc runs of this same script; FETCH_SIZE
     # doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming reads); null when the profile file is absent
     traffic = traffic_src = None
@@ -186,7 +190,9 @@ def main():
                        "reads_per_gpu_per_step": n, "read_len": L, "amplicon_len": L, "unique_read_fraction": unique_fraction, "unique_read_fraction_sample": n_u,
                        "rows_per_lane": info["rows_per_lane"], "lds_bytes_per_workgroup": info["lds_bytes"],
                        "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
-                       "first_launch_kernel": ("c2_align_diag_kernel" if band["band_lanes"] < 0 else "c2_align_classify_kernel (banded)" if band["band_lanes"] > 0 else "c2_align_classify_kernel (full plane)"),
+                       "kernel_chain": ((chain_names.get(args.kernel, ["c2_align_diag_kernel"])[-len(tiers):] if band["band_lanes"] < 0 else
+                                         ["c2_align_classify_kernel (banded)"] if band["band_lanes"] > 0 else []) + ["c2_align_classify_kernel (full plane)"]),
+                       "tasks_left_after_each_banded_launch": tiers,
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -20,7 +20,7 @@ SYMBOLS = [
     "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
-    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_count_vectors_device",
+    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_count_vectors_device",
 ]
 
 REC_DTYPE = np.dtype([
@@ -151,14 +151,22 @@ class Context:
         self.check(self.lib.c2_set_band(self.handle, int(band_lanes), int(target_workgroups_per_cu)), "c2_set_band")
 
     def set_kernel_mode(self, mode):
-        """'auto' (diagonal-band kernel when applicable), 'band' (banded row-strip), 'full' (full-plane row-strip)"""
-        code = {'auto': 0, 'band': 1, 'full': 2}.get(mode, mode)
+        """'auto' (diagonal-band tiers 4 -> 2 -> 1 alignments per wavefront when applicable), 'band' (banded row-strip),
+        'full' (full-plane row-strip), 'diag1' (single-alignment diagonal-band kernel), 'diag2' (tiers 2 -> 1)"""
+        code = {'auto': 0, 'band': 1, 'full': 2, 'diag1': 3, 'diag2': 4}.get(mode, mode)
         self.check(self.lib.c2_set_kernel_mode(self.handle, int(code)), "c2_set_kernel_mode")
 
     def band_info(self, max_read_len):
         a, b = ctypes.c_int32(0), ctypes.c_int32(0)
         self.check(self.lib.c2_band_info(self.handle, int(max_read_len), ctypes.byref(a), ctypes.byref(b)), "c2_band_info")
         return {"band_lanes": a.value, "fallback_tasks_last_launch": b.value}
+
+    def tier_info(self):
+        """Banded launches of the most recent batch and the number of tasks each left for the next one."""
+        n = ctypes.c_int32(0)
+        left = (ctypes.c_int32 * 4)()
+        self.check(self.lib.c2_tier_info(self.handle, ctypes.byref(n), left), "c2_tier_info")
+        return [int(left[k]) for k in range(n.value)]
 
     def phase_profile(self, enable):
         """-> the four per-phase cycle counters accumulated so far (then cleared); sets the mode."""

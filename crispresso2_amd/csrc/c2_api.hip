@@ -66,10 +66,15 @@ struct c2_ctx {
     // banded first launch: -1 auto, 0 off, >0 lanes each side; fallback list buffer
     int band_setting = -1;
     int band_target_wgs = 14;
-    int kernel_mode = 0;   // 0 auto (diagonal-band kernel when applicable), 1 banded row-strip, 2 full row-strip
+    // 0 auto (diagonal-band tiers 4 -> 2 -> 1 alignments per wavefront when applicable), 1 banded row-strip, 2 full row-strip,
+    // 3 single-alignment diagonal-band kernel only, 4 tiers 2 -> 1
+    int kernel_mode = 0;
     int gmax = 0;          // largest gap incentive over the references
     DevBuf d_fb;
     int occ_diag_lds = -1, occ_diag_blocks = 0;
+    int occ_x_lds[2] = {-1, -1}, occ_x_blocks[2] = {0, 0};   // [0] 4 alignments per wavefront, [1] 2
+    DevBuf d_plane;        // pointer-word scratch of the multi-alignment diagonal kernels
+    int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
     int occ_lds[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
     int occ_blocks[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
@@ -104,7 +109,8 @@ struct Geometry {
     int R, passes, max_lj;
     uint32_t lds_full; int blocks_full;          // full pointer plane
     int band_lanes; uint32_t lds_band; int blocks_band;   // banded first launch (band_lanes == 0: not used)
-    bool diag; uint32_t lds_diag; int blocks_diag;         // diagonal-band first launch
+    bool diag; uint32_t lds_diag; int blocks_diag;         // diagonal-band launches
+    bool x4, x2; uint32_t lds_x[2]; int blocks_x[2]; uint32_t plane_words;   // multi-alignment tiers in front of it
 };
 
 template <int R, bool BAND>
@@ -149,8 +155,11 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     if ((rc = occupancy_r<false>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
     // Diagonal-band first launch (c2_align_diag_kernel): needs the packed score rows and a negative per-gap-base bound
     g.diag = false; g.lds_diag = 0; g.blocks_diag = 0;
-    if (ctx->kernel_mode == 0 && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
+    g.x4 = g.x2 = false; g.lds_x[0] = g.lds_x[1] = 0; g.blocks_x[0] = g.blocks_x[1] = 0; g.plane_words = 0;
+    const int km = ctx->kernel_mode;
+    if ((km == 0 || km == 3 || km == 4) && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
         g.lds_diag = c2_make_diag_plan(ctx->max_li, g.max_lj).total;
+        if (const char* pad = getenv("C2_DEBUG_DIAG_LDS_PAD")) g.lds_diag += (uint32_t)atoi(pad);   // occupancy experiments
         if (g.lds_diag <= lds_cu) {
             if (ctx->occ_diag_lds != (int)g.lds_diag) {
                 int nb = 0;
@@ -160,6 +169,21 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
             }
             g.blocks_diag = ctx->occ_diag_blocks;
             g.diag = true;
+        }
+        for (int t = 0; t < 2 && g.diag && km != 3; ++t) {
+            if (t == 0 && km != 0) continue;
+            const int na = t == 0 ? 4 : 2;
+            const c2_diagx_plan PX = c2_make_diagx_plan(na, ctx->max_li, g.max_lj);
+            if (PX.total > lds_cu) continue;
+            const void* fn = t == 0 ? (const void*)c2_align_diagx_kernel<4> : (const void*)c2_align_diagx_kernel<2>;
+            if (ctx->occ_x_lds[t] != (int)PX.total) {
+                int nb = 0;
+                HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, PX.total));
+                ctx->occ_x_blocks[t] = nb < 1 ? 1 : nb; ctx->occ_x_lds[t] = (int)PX.total;
+            }
+            g.lds_x[t] = PX.total; g.blocks_x[t] = ctx->occ_x_blocks[t]; g.plane_words = PX.n_words * 64u;                      // [slot][group of 8 anti-diagonals][lane of the slot]
+            (t == 0 ? g.x4 : g.x2) = true;
         }
     }
     // Banded first launch: keep only the pointer words of the lanes near the main diagonal so that more workgroups fit
@@ -203,23 +227,56 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
     A.band_lanes = 0; A.reserved = getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0; A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
     if (g.diag || g.band_lanes > 0) {
         if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
-        if ((rc = ensure(ctx, ctx->d_fb, 32 + A.n_tasks * sizeof(uint32_t)))) return rc;
-        uint32_t* fb_count = (uint32_t*)ctx->d_fb.p;             // [0] fallback count, [2..3] work counter (banded), [4..5] work counter (full)
-        uint32_t* fb_list = fb_count + 8;
-        HIPCHK(ctx, hipMemsetAsync(fb_count, 0, 32, s));
-        A.work_counter = (unsigned long long*)(fb_count + 2);
-        A.band_lanes = g.band_lanes; A.fb_count = fb_count; A.fb_list = fb_list;
+        // d_fb: 16 header words -- [0..3] length of the fallback list each tier leaves, [4 + 2t ..] work counter of launch t --
+        // then two task lists (a tier reads one and fills the other)
+        const size_t list_words = (size_t)A.n_tasks;
+        if ((rc = ensure(ctx, ctx->d_fb, 64 + 2 * list_words * sizeof(uint32_t)))) return rc;
+        uint32_t* hdr = (uint32_t*)ctx->d_fb.p;
+        uint32_t* lists[2] = {hdr + 16, hdr + 16 + list_words};
+        HIPCHK(ctx, hipMemsetAsync(hdr, 0, 64, s));
+        const uint64_t cus = (uint64_t)ctx->prop.multiProcessorCount;
+        int tier = 0;                                            // launches so far; the next one reads lists[(tier - 1) & 1]
+        auto chain = [&](c2_align_args& T) {                     // wire launch `tier` into the chain
+            T.task_list = tier ? lists[(tier - 1) & 1] : nullptr; T.task_count = tier ? hdr + (tier - 1) : nullptr;
+            T.fb_list = lists[tier & 1]; T.fb_count = hdr + tier;
+            T.work_counter = (unsigned long long*)(hdr + 4 + 2 * tier);
+        };
         if (g.diag) {
-            const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)g.blocks_diag;
+            for (int t = 0; t < 2; ++t) {
+                if (!(t == 0 ? g.x4 : g.x2)) continue;
+                const int na = t == 0 ? 4 : 2;
+                const uint64_t resident = cus * (uint64_t)g.blocks_x[t];
+                const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + na - 1) / na, resident));
+                if ((rc = ensure(ctx, ctx->d_plane, (size_t)resident * g.plane_words * sizeof(uint32_t)))) return rc;
+                c2_align_args T = A;
+                chain(T);
+                T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = g.plane_words;
+                if (t == 0) hipLaunchKernelGGL(c2_align_diagx_kernel<4>, dim3(grid), dim3(64), g.lds_x[t], s, T);
+                else        hipLaunchKernelGGL(c2_align_diagx_kernel<2>, dim3(grid), dim3(64), g.lds_x[t], s, T);
+                HIPCHK(ctx, hipGetLastError());
+                ++tier;
+            }
+            const uint64_t resident = cus * (uint64_t)g.blocks_diag;
             const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(A.n_tasks, resident));
-            hipLaunchKernelGGL(c2_align_diag_kernel, dim3(grid), dim3(64), g.lds_diag, s, A);
+            c2_align_args T = A;
+            chain(T);
+            hipLaunchKernelGGL(c2_align_diag_kernel, dim3(grid), dim3(64), g.lds_diag, s, T);
             HIPCHK(ctx, hipGetLastError());
-        } else if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
-        // the tasks whose traceback left the band, redone with the full pointer plane (usually a handful; an empty list costs one tiny launch)
-        A.band_lanes = 0; A.task_list = fb_list; A.task_count = fb_count;
-        A.work_counter = (unsigned long long*)(fb_count + 4);
+            ++tier;
+        } else {
+            A.band_lanes = g.band_lanes;
+            chain(A);
+            if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
+            ++tier;
+        }
+        // the tasks no banded tier could finish, redone with the full pointer plane (usually a handful; an empty list costs one tiny launch)
+        A.band_lanes = 0;
+        chain(A);
+        A.fb_list = nullptr; A.fb_count = nullptr;
+        ctx->last_tiers = tier;
         if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;
     } else {
+        ctx->last_tiers = 0;
         if ((rc = ensure(ctx, ctx->d_fb, 32))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_fb.p, 0, 32, s));
         A.work_counter = (unsigned long long*)((uint32_t*)ctx->d_fb.p + 2);
@@ -271,6 +328,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.n_codes = ctx->sc.n_codes; A.gap_open = ctx->gap_open; A.gap_extend = ctx->gap_extend;
     A.max_lj = g.max_lj; A.max_passes = g.passes;
     A.max_li = ctx->max_li;
+    A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
     {
         int mx = 0;
         for (int16_t v : ctx->sc.tbl) mx = std::max(mx, (int)v);
@@ -327,7 +385,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane};
     for (DevBuf* b : all) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -441,7 +499,7 @@ int c2_set_band(c2_ctx* ctx, int32_t band_lanes, int32_t target_workgroups_per_c
 }
 
 int c2_set_kernel_mode(c2_ctx* ctx, int32_t mode) {
-    if (!ctx || mode < 0 || mode > 2) return C2_E_INVALID;
+    if (!ctx || mode < 0 || mode > 4) return C2_E_INVALID;
     ctx->kernel_mode = mode;
     return 0;
 }
@@ -455,12 +513,26 @@ int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t
     if (band_lanes) *band_lanes = g.diag ? -1 : g.band_lanes;
     if (fallback_tasks_last_launch) {
         *fallback_tasks_last_launch = 0;
-        if (ctx->d_fb.p) {
+        if (ctx->d_fb.p && ctx->last_tiers > 0) {
             HIPCHK(ctx, hipDeviceSynchronize());
             uint32_t c = 0;
-            HIPCHK(ctx, hipMemcpy(&c, ctx->d_fb.p, 4, hipMemcpyDeviceToHost));
+            HIPCHK(ctx, hipMemcpy(&c, (uint32_t*)ctx->d_fb.p + (ctx->last_tiers - 1), 4, hipMemcpyDeviceToHost));
             *fallback_tasks_last_launch = (int32_t)c;
         }
+    }
+    return 0;
+}
+
+int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4) {
+    if (!ctx || !n_tiers || !left_over4) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *n_tiers = ctx->last_tiers;
+    for (int k = 0; k < 4; ++k) left_over4[k] = 0;
+    if (ctx->d_fb.p && ctx->last_tiers > 0) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        uint32_t c[4] = {0, 0, 0, 0};
+        HIPCHK(ctx, hipMemcpy(c, ctx->d_fb.p, 16, hipMemcpyDeviceToHost));
+        for (int k = 0; k < ctx->last_tiers && k < 4; ++k) left_over4[k] = (int32_t)c[k];
     }
     return 0;
 }
@@ -729,14 +801,14 @@ int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4) {
     return 0;
 }
 
-int c2_selftest(c2_ctx* ctx, int32_t* out192) {
-    if (!ctx || !out192) return C2_E_INVALID;
+int c2_selftest(c2_ctx* ctx, int32_t* out320) {
+    if (!ctx || !out320) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->d_misc, 192 * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_misc, 320 * 4))) return rc;
     hipLaunchKernelGGL(c2_selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)ctx->d_misc.p);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(out192, ctx->d_misc.p, 192 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out320, ctx->d_misc.p, 320 * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

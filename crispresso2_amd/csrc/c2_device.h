@@ -13,9 +13,9 @@
 #define C2_INVALID_CODE 255
 #define C2_PTR_PAD 2               // halfword padding of one pointer column (breaks the 128-B bank stride)
 #define C2_LANES 64
-#define C2_DIAG_NEG (-(1 << 30))
+#define C2_DIAG_NEG (-(1 << 30))     // diagonal-band kernels: value of everything outside the band
 #define C2_DIAG_STORE_LO 16          // diagonal-band kernel: lanes STORE_LO .. STORE_LO+STORE_N-1 (the inner 64 of the 128
-#define C2_DIAG_STORE_N 32           //   diagonals) keep their pointer words; a traceback that leaves them is redone by the row-strip kernel   // diagonal-band kernel: value of everything outside the band
+#define C2_DIAG_STORE_N 32           //   diagonals) keep their pointer words; a traceback that leaves them is redone by the row-strip kernel
 #define C2_TASK_CHUNK 4              // tasks a workgroup takes per atomic
 #define C2_STATUS_NEED_FULL 64     // internal: banded launch could not finish the traceback; the full-plane launch overwrites the record
 
@@ -64,6 +64,10 @@ typedef struct c2_align_args {
     const uint32_t* task_count;   // device-resident length of task_list
     unsigned long long* work_counter; // device counter the workgroups pull task chunks from; zero before every launch
     unsigned long long* phase_cycles; // optional: 4 counters of per-phase shader cycles (profiling), else NULL
+    uint32_t* plane;              // multi-alignment diagonal kernel: pointer words in HBM/L2, plane_words_per_wg per workgroup
+    uint32_t plane_words_per_wg;
+    uint32_t reserved3;
+    const struct c2_diag_row* diag_base;   // start of the buffer every reference's diag_rows points into
 } c2_align_args;
 
 // Kernel arguments for the per-call classifier (find_indels_substitutions / _legacy with full lists).

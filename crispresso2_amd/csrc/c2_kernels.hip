@@ -88,6 +88,13 @@ __host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_p
 
 extern __shared__ __attribute__((aligned(16))) unsigned char c2_smem[];
 
+// Region executed with some lanes switched off in EXEC for its whole length (one s_and_saveexec; no per-instruction
+// cost).  The wave emulator (tests/emu) supplies its own definition, which parks the inactive fibers.
+#ifndef C2_LANES_ACTIVE_BEGIN
+#define C2_LANES_ACTIVE_BEGIN(cond) if (cond) {
+#define C2_LANES_ACTIVE_END() }
+#endif
+
 // h-state (argmax with the reference's tie rule, pyx:216-228) of a cell on row 0 or column 0,
 // from the closed-form boundary values (pyx:153-176).
 __device__ __forceinline__ int c2_boundary_hstate(int i, int j, int min_score, int ge, int g0) {
@@ -363,22 +370,26 @@ struct c2_prefetch {
 __device__ __forceinline__ void c2_prefetch_issue(const c2_align_args& A, const int lane, uint64_t& chunk_base, int& chunk_left,
                                                   c2_prefetch& pf)
 {
-    pf.valid = c2_next_task(A, lane, chunk_base, chunk_left, pf.task) ? 1 : 0;
-    if (!pf.valid) return;
-    uint64_t read_id;
-    if (A.all_refs) { read_id = pf.task / (uint64_t)A.n_refs; pf.ref_id = (int)(pf.task % (uint64_t)A.n_refs); }
-    else            { read_id = pf.task; pf.ref_id = A.ref_ids ? (int)A.ref_ids[pf.task] : 0; }
-    pf.rc = A.strands ? (int)A.strands[pf.task] : 0;
-    pf.off = A.offsets[read_id];
-    pf.Lj = (int)(A.offsets[read_id + 1] - pf.off);
+    // (locals, one unconditional struct assignment at the end: keeps the struct in registers)
+    uint64_t task = 0, off = 0;
+    int Lj = 0, ref_id = 0, rc = 0;
     unsigned b4 = 0;
+    const bool valid = c2_next_task(A, lane, chunk_base, chunk_left, task);
+    if (valid) {
+        uint64_t read_id;
+        if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
+        else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
+        rc = A.strands ? (int)A.strands[task] : 0;
+        off = A.offsets[read_id];
+        Lj = (int)(A.offsets[read_id + 1] - off);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = 64 * q + lane;
-        const unsigned byte = (k < pf.Lj) ? (unsigned)A.reads[pf.off + (uint64_t)(pf.rc ? pf.Lj - 1 - k : k)] : 0u;
-        b4 |= byte << (8 * q);
+        for (int q = 0; q < 4; ++q) {
+            const int k = 64 * q + lane;
+            const unsigned byte = (k < Lj) ? (unsigned)A.reads[off + (uint64_t)(rc ? Lj - 1 - k : k)] : 0u;
+            b4 |= byte << (8 * q);
+        }
     }
-    pf.b4 = b4;
+    pf.task = task; pf.off = off; pf.valid = valid ? 1 : 0; pf.Lj = Lj; pf.ref_id = ref_id; pf.rc = rc; pf.b4 = b4;
 }
 
 // Stage the prefetched task in LDS: reference (only when the amplicon changes), read characters (reverse complement on
@@ -971,6 +982,328 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
     c2_phase_flush(A.phase_cycles, PH, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-alignment diagonal-band kernel: NA (2 or 4) alignments share one wavefront.  One anti-diagonal step costs the
+// same ~19 VALU issues whether 64, 31 or 15 of the lanes hold diagonals that matter, and an amplicon read rarely needs
+// more than a few diagonals either side of the corner-to-corner one -- so the wavefront is cut into NA lane groups of
+// LPA = 64 / NA lanes, each sweeping its own alignment with a band of 2 * (LPA - 1) diagonals, all with the same
+// instruction stream (per-lane table bases and clamps instead of wave-uniform ones).  The last lane of every group is
+// switched off in EXEC for the whole fill: a DPP move whose source lane is disabled leaves its destination alone, so the
+// first lane of the next group (wave_shr) and the last live lane of this group (wave_shl) keep C2_DIAG_NEG, exactly
+// what the lanes at the two ends of the wavefront see.  Isolation costs no instruction.
+// A band this narrow fails the optimality certificate more often; those tasks go to the fallback list and the host
+// chains the launches NA = 4 -> NA = 2 -> c2_align_diag_kernel (128 diagonals) -> row-strip kernel (any path), each over
+// the previous list.  The pointer words go to a per-workgroup scratch plane in HBM/L2 instead of LDS (16 KB per group of
+// alignments would halve the resident waves; the words are written once, coalesced, and the traceback reads a handful
+// of them), read back with agent-scope loads that bypass the CU's L1.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int c2_med3(int x, int lo, int hi) {          // clamp x to [lo, hi], lo <= hi
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+#else
+    return x < lo ? lo : (x > hi ? hi : x);
+#endif
+}
+
+struct c2_diagx_plan {
+    uint32_t codeof, table, tmp_read, tmp_ref, stage, slot0, slot_bytes, total, n_words;
+    uint32_t codes, read, code, ref, incp;                          // offsets inside one alignment's slot
+};
+
+__host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, int max_lj) {
+    c2_diagx_plan p;
+    p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
+    uint32_t off = 0;
+    p.codeof = off;   off += 256u;                                  // character -> code
+    p.table = off;    off += 4u * 20u * 4u;                         // 4 slots x C2X_INTS
+    p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
+    p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
+    p.stage = off;    off += p.n_words * (64u / (uint32_t)na) * 4u; // pointer words of the alignment being traced
+    p.slot0 = off;
+    uint32_t so = 0;
+    p.codes = so;    so += c2_align16((uint32_t)max_lj + 2u);
+    p.read = so;     so += c2_align16((uint32_t)max_lj);
+    p.code = so;     so += c2_align16((uint32_t)max_lj);
+    p.ref = so;      so += c2_align16((uint32_t)max_li);
+    p.incp = so;     so += c2_align16(((uint32_t)max_li + 2u) * 2u);
+    p.slot_bytes = so;
+    p.total = p.slot0 + (uint32_t)na * so;
+    return p;
+}
+
+// pointer words of ONE alignment, staged in LDS: [group of 8 anti-diagonals][lane of the alignment's lane group]
+struct c2_diagx_plane {
+    const unsigned* words; int d0, lpa;
+    __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
+        const int sl = (pi - pj - d0) >> 1;                              // lane of the cell's diagonal inside its group
+        if ((unsigned)sl >= (unsigned)(lpa - 1)) return false;
+        const int a = pi + pj;
+        nib = (words[(a >> 3) * lpa + sl] >> (4 * (7 - (a & 7)))) & 0xF;
+        return true;
+    }
+};
+
+// per-lane view of the tables and of the matrix edges
+struct c2_diagx_lane {
+    int hRow, rowLo, rowHi;          // row record of pair k's E cell: rows[clamp(k + hRow, rowLo, rowHi)]
+    int hCol, colLo, colHi;          // column symbol of pair k: LDS byte clamp(k + hCol, colLo, colHi)
+    int kLast;                       // pair whose cells are on the last column
+    int kCap; bool capOdd;           // pair (and cell of it) that holds H(Li, Lj), if this lane owns that diagonal
+    int startE, startO;              // first interior anti-diagonal of the two diagonals
+};
+
+template <bool MASK, bool LASTCOL>
+__device__ __forceinline__ void c2_diagx_groups(c2_diag_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const int ge,
+                                                int& Hcap, c2_diag_row (&R)[5], int (&C)[4],
+                                                const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride)
+{
+    for (; g <= g_stop; ++g) {
+        const int k0 = 4 * g;
+        c2_diag_row RN[5];
+        int CN[4];
+        RN[0] = R[4];
+#pragma unroll
+        for (int q = 1; q < 5; ++q) RN[q] = rows[c2_med3(k0 + 4 + q + L.hRow, L.rowLo, L.rowHi)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) CN[q] = (int)lds[c2_med3(k0 + 4 + q + L.hCol, L.colLo, L.colHi)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + q;
+            c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, L.startE, L.startO, LASTCOL && (k == L.kLast));
+            if (LASTCOL && k == L.kCap) Hcap = L.capOdd ? S.HO : S.HE;
+        }
+        myWords[g * wordStride] = S.bits;                            // anti-diagonals 8g .. 8g+7
+#pragma unroll
+        for (int q = 0; q < 5; ++q) R[q] = RN[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[q] = CN[q];
+    }
+}
+
+// per-alignment ("slot") table in LDS: wave-uniform values written by lane 0 and read back through readfirstlane, so the
+// staging / traceback / output code exists once (a loop over the slots) instead of once per slot
+enum { C2X_VALID = 0, C2X_TASK_LO, C2X_TASK_HI, C2X_LJ, C2X_REF, C2X_RC, C2X_STATUS, C2X_PACKED, C2X_CURREF, C2X_LI, C2X_G0,
+       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_INTS = 20 };
+__device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
+
+template <int NA>
+__global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
+{
+    constexpr int LPA = 64 / NA, NL = LPA - 1, BANDW = 2 * NL;       // lanes per alignment, live lanes, diagonals per band
+    const int lane = threadIdx.x, slot = lane / LPA, sl = lane - slot * LPA;
+    const c2_diagx_plan P = c2_make_diagx_plan(NA, A.max_li, A.max_lj);
+    unsigned char* sCodeOf = c2_smem + P.codeof;
+    int* sTab = (int*)(c2_smem + P.table);
+    auto wg_of = [&](const int s) {
+        unsigned char* base = c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes;
+        c2_wg W;
+        W.sRead = base + P.read; W.sCode = base + P.code; W.sRef = base + P.ref;
+        W.sIncP = (uint16_t*)(base + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
+        return W;
+    };
+    unsigned* sStage = (unsigned*)(c2_smem + P.stage);
+    unsigned* gWords = A.plane + (size_t)blockIdx.x * A.plane_words_per_wg;   // [slot][group][lane of the slot]
+    const int slotWords = (int)P.n_words * LPA;
+    const int ge = A.gap_extend, go = A.gap_open;
+    for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
+    if (lane < NA) { sTab[lane * C2X_INTS + C2X_CURREF] = -1; sTab[lane * C2X_INTS + C2X_LI] = 0; sTab[lane * C2X_INTS + C2X_G0] = 0; }
+
+    uint64_t chunk_base = 0;
+    int chunk_left = 0;
+    c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
+    c2_prefetch pf[NA];
+#pragma unroll
+    for (int s = 0; s < NA; ++s) c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf[s]);
+    while (pf[0].valid) {
+        __syncthreads();
+        c2_phase_begin(A.phase_cycles, PH);
+        // ---- stage the NA prefetched tasks in their LDS slots (unrolled: pf[] must stay in registers -- a scratch access
+        //      here would queue behind the previous group's output stores in vmcnt)
+#pragma unroll
+        for (int s = 0; s < NA; ++s) {
+            int* T = sTab + s * C2X_INTS;
+            int cref = c2_uni(T + C2X_CURREF), li = c2_uni(T + C2X_LI), g0 = c2_uni(T + C2X_G0);
+            int st = 0;
+            bool packed = false;
+            if (pf[s].valid) st = c2_commit_task(A, wg_of(s), sCodeOf, pf[s], lane, A.max_li, cref, li, g0, packed);
+            if (lane == 0) {
+                T[C2X_VALID] = pf[s].valid; T[C2X_TASK_LO] = (int)(unsigned)(pf[s].task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(pf[s].task >> 32);
+                T[C2X_LJ] = pf[s].Lj; T[C2X_REF] = pf[s].ref_id; T[C2X_RC] = pf[s].rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
+                T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NA; ++s) c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf[s]);   // next group's loads fly during this DP
+        __syncthreads();
+
+        // ---- band of every alignment; the tables its lanes read; the wave-uniform loop limits
+        bool any_ok = false;
+        int gA = 0, gC = 0x7fffffff, g_end = 0;
+#pragma nounroll
+        for (int s = 0; s < NA; ++s) {
+            int* T = sTab + s * C2X_INTS;
+            const int Li = c2_uni(T + C2X_LI), Lj = c2_uni(T + C2X_LJ);
+            bool ok = false;
+            int D = 0, d0 = 0, cb = 0, minsc = 0, rowBase = 0;
+            if (c2_uni(T + C2X_VALID) && c2_uni(T + C2X_STATUS) == 0) {
+                const c2_dev_ref rf = A.refs[c2_uni(T + C2X_REF)];
+                D = Li - Lj;
+                d0 = ((D >> 1) - NL) & ~1;                     // even; band = d0 .. d0 + BANDW - 1 around the corner-to-corner diagonal
+                cb = (go > ge ? go : ge) + rf.gap_incentive_max;          // the most one gap base can add to a score
+                ok = c2_uni(T + C2X_PACKED) && rf.diag_rows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
+                     D >= d0 && D <= d0 + BANDW - 1;
+                if (ok) {
+                    any_ok = true;
+                    const c2_wg W = wg_of(s);
+                    unsigned char* sCodes = c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes;
+                    for (int j = lane; j < Lj + 2; j += 64)
+                        sCodes[j] = (j >= 1 && j <= Lj) ? (unsigned char)(W.sCode[j - 1] << 2) : (unsigned char)0;
+                    minsc = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
+                    rowBase = (int)(rf.diag_rows - A.diag_base);
+                    const int max_start = (d0 + BANDW - 1 > -d0 ? d0 + BANDW - 1 : -d0) + 2;
+                    const int gA_s = ((max_start + 1) >> 1) >> 2;          // groups 0..gA contain lanes that have not started
+                    const int gC_s = ((2 * Lj + d0) >> 1) >> 2;            // first group in which some lane is on the last column
+                    const int ge_s = ((Li + Lj) >> 1) >> 2;                // group of the cell (Li, Lj)
+                    gA = gA > gA_s ? gA : gA_s; gC = gC < gC_s ? gC : gC_s; g_end = g_end > ge_s ? g_end : ge_s;
+                }
+            }
+            if (lane == 0) {
+                T[C2X_OK] = ok ? 1 : 0; T[C2X_D] = D; T[C2X_D0] = d0; T[C2X_CB] = cb; T[C2X_MINSC] = minsc; T[C2X_ROWBASE] = rowBase;
+                T[C2X_BAND_LI] = ok ? Li : 0; T[C2X_BAND_LJ] = ok ? Lj : 0;
+            }
+        }
+        __syncthreads();
+        c2_phase_mark<0>(A.phase_cycles, PH);
+
+        int Hcap = C2_DIAG_NEG;
+        if (any_ok) {
+            const int* T = sTab + slot * C2X_INTS;                 // this lane's alignment
+            const int vLi = T[C2X_BAND_LI], vLj = T[C2X_BAND_LJ], vd0 = T[C2X_D0], vg0 = T[C2X_G0], vmin = T[C2X_MINSC];
+            const int vrow = T[C2X_ROWBASE], vcode = (int)(P.slot0 + (uint32_t)slot * P.slot_bytes + P.codes);
+            C2_LANES_ACTIVE_BEGIN(sl != NL)
+            // ---- per-lane diagonals and their boundary cells (pyx:153-176), as in c2_align_diag_kernel
+            const int hE = (vd0 >> 1) + sl;                    // dE = 2*hE, dO = 2*hE + 1
+            const int dE = 2 * hE, dO = dE + 1;
+            c2_diag_state S;
+            S.bits = 0;
+            S.upM = C2_DIAG_NEG; S.upJ = C2_DIAG_NEG; S.lfM = C2_DIAG_NEG; S.lfI = C2_DIAG_NEG;
+            {
+                const int bE = (dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + vg0;
+                S.ME = (dE == 0) ? 0 : vmin;
+                S.IE = (dE < 0) ? bE : vmin;
+                S.JE = (dE > 0) ? bE : vmin;
+                S.HE = c2_imax(c2_imax(S.ME, S.IE), S.JE);
+                const int bO = ge * (dO > 0 ? dO : -dO) + vg0;   // dO is odd, never 0
+                S.MO = vmin;
+                S.IO = (dO < 0) ? bO : vmin;
+                S.JO = (dO > 0) ? bO : vmin;
+                S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
+            }
+            c2_diagx_lane L;
+            L.hRow = hE + vrow; L.rowLo = vrow; L.rowHi = vrow + vLi + 1;
+            L.hCol = vcode - hE; L.colLo = vcode; L.colHi = vcode + vLj + 1;
+            L.kLast = vLj + hE;
+            L.kCap = (vLi + vLj) >> 1; L.capOdd = ((vLi + vLj) & 1) != 0;
+            L.startE = (dE > 0 ? dE : -dE) + 2; L.startO = (dO > 0 ? dO : -dO) + 2;
+            const c2_diag_row* rows = A.diag_base;
+            c2_diag_row Rw[5];
+            int Cw[4];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Rw[q] = rows[c2_med3(q + L.hRow, L.rowLo, L.rowHi)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Cw[q] = (int)c2_smem[c2_med3(q + L.hCol, L.colLo, L.colHi)];
+            unsigned* myWords = gWords + slot * slotWords + sl;
+            int g = 0;
+            const int gA_stop = gA < g_end ? gA : g_end;
+            if (gC <= gA_stop) {
+                c2_diagx_groups<true, true>(S, g, gA_stop, L, ge, Hcap, Rw, Cw, rows, c2_smem, myWords, LPA);
+            } else {
+                c2_diagx_groups<true, false>(S, g, gA_stop, L, ge, Hcap, Rw, Cw, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge, Hcap, Rw, Cw, rows, c2_smem, myWords, LPA);
+            }
+            c2_diagx_groups<false, true>(S, g, g_end, L, ge, Hcap, Rw, Cw, rows, c2_smem, myWords, LPA);
+            C2_LANES_ACTIVE_END()
+        }
+        __syncthreads();                                           // (waits for the plane stores)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // drop this CU's stale L1 lines of the plane before reading it back
+        c2_phase_mark<1>(A.phase_cycles, PH);
+
+        // ---- per alignment: optimality certificate (see c2_align_diag_kernel), traceback, output.  The pointer words of
+        //      alignment s + 1 are requested before alignment s is traced and written out: a load issued after those stores
+        //      would wait for them (one vmcnt for loads and stores), a load issued before them does not.
+        constexpr int STG = 16 / NA;                               // 16-byte words per lane in flight: 64 * STG * 16 B covers 500 anti-diagonals
+        uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
+        q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = uint4{0u, 0u, 0u, 0u};
+#define C2_STG_LOAD(n) if (STG > n) { const int k = 64 * n + lane; q##n = src[k < n16 ? k : 0]; }
+#define C2_STG_STORE(n) if (STG > n) { const int k = 64 * n + lane; if (k < n16) dst[k] = q##n; }
+        auto request_words = [&](const int s2) {
+            const uint4* src = (const uint4*)(gWords + s2 * slotWords);
+            const int n16 = (g_end + 1) * (LPA / 4);
+            C2_STG_LOAD(0) C2_STG_LOAD(1) C2_STG_LOAD(2) C2_STG_LOAD(3) C2_STG_LOAD(4) C2_STG_LOAD(5) C2_STG_LOAD(6) C2_STG_LOAD(7)
+        };
+        request_words(0);
+#pragma nounroll
+        for (int s = 0; s < NA; ++s) {
+            const int* T = sTab + s * C2X_INTS;
+            if (!c2_uni(T + C2X_VALID)) continue;
+            const uint64_t task = (uint64_t)(unsigned)c2_uni(T + C2X_TASK_LO) | ((uint64_t)(unsigned)c2_uni(T + C2X_TASK_HI) << 32);
+            const int Li = c2_uni(T + C2X_LI), Lj = c2_uni(T + C2X_LJ), g0 = c2_uni(T + C2X_G0);
+            int status = c2_uni(T + C2X_STATUS);
+            const bool ok = c2_uni(T + C2X_OK) != 0;
+            c2_aln_record rec;
+            c2_clear_record(rec, c2_uni(T + C2X_RC), c2_uni(T + C2X_REF));
+            bool need_full = (status == 0) && !ok;
+            bool requested = false;
+            if (ok) {
+                const int D = c2_uni(T + C2X_D), d0 = c2_uni(T + C2X_D0), cb = c2_uni(T + C2X_CB), minsc = c2_uni(T + C2X_MINSC);
+                const int lane_end = s * LPA + ((D - d0) >> 1);
+                const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
+                const int maxS = A.max_score;
+                const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
+                int U = C2_DIAG_NEG;
+                if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + cb * (2 * dhi1 - D));
+                if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + cb * (D - 2 * dlo1));
+                if (!(Hend > U)) need_full = true;
+                if (!need_full) {
+                    const c2_wg W = wg_of(s);
+                    // the alignment's pointer words: registers (requested from HBM/L2 before the previous alignment's
+                    // output stores were issued) -> LDS; words beyond the first batch (long sequences) are fetched here
+                    {
+                        const uint4* src = (const uint4*)(gWords + s * slotWords);
+                        uint4* dst = (uint4*)sStage;
+                        const int n16 = ((((Li + Lj) >> 1) >> 2) + 1) * (LPA / 4);
+                        C2_STG_STORE(0) C2_STG_STORE(1) C2_STG_STORE(2) C2_STG_STORE(3) C2_STG_STORE(4) C2_STG_STORE(5) C2_STG_STORE(6) C2_STG_STORE(7)
+                        for (int k = 64 * STG + lane; k < n16; k += 64) dst[k] = src[k];
+                    }
+                    __syncthreads();
+                    if (s + 1 < NA) { request_words(s + 1); requested = true; }
+                    c2_diagx_plane plane;
+                    plane.words = sStage; plane.d0 = d0; plane.lpa = LPA;
+                    int cnt, matches;
+                    bool nf2;
+                    c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
+                    __syncthreads();
+                    c2_phase_mark<2>(A.phase_cycles, PH);
+                    if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
+                    else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec);
+                }
+            }
+            if (!requested && s + 1 < NA) request_words(s + 1);
+            if (need_full) {
+                status |= C2_STATUS_NEED_FULL;
+                if (lane == 0) { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
+            }
+            rec.status = (uint8_t)status;
+            if (lane == 0) A.records[task] = rec;
+            c2_phase_mark<3>(A.phase_cycles, PH);
+        }
+    }
+    c2_phase_flush(A.phase_cycles, PH, lane);
+}
+
 // =====================================================================================
 // Per-call classifier with full position lists: find_indels_substitutions
 // (CRISPRessoCOREResources.pyx:68-187) and find_indels_substitutions_legacy (pyx:190-315).
@@ -1126,6 +1459,15 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
     out[64 + lane] = __builtin_amdgcn_readlane(lane * 5, 17);   // expect 85 everywhere
     const unsigned long long m = __ballot(lane % 3 == 0);
     out[128 + lane] = __popcll(m) + (lane == 0 ? __builtin_ctzll(~m) : 0);
+    // a lane that is switched off in EXEC is an invalid DPP source: its neighbour keeps `old` (what isolates the lane
+    // groups of c2_align_diagx_kernel from each other).  expect: lanes 31 -> -99, 32 (shr) / 30 (shl) -> -7
+    int r = -99, l = -99;
+    C2_LANES_ACTIVE_BEGIN(lane != 31)
+        r = c2_shr1(-7, lane * 3 + 1);
+        l = c2_shl1(-7, lane * 3 + 1);
+    C2_LANES_ACTIVE_END()
+    out[192 + lane] = r;
+    out[256 + lane] = l;
 }
 
 // =====================================================================================

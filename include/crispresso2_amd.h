@@ -162,11 +162,15 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
  * Alignments whose traceback leaves the band are redone in the same call by the full-plane kernel.
  * target_workgroups_per_cu (> 0) steers the automatic choice. */
 int c2_set_band(c2_ctx* ctx, int32_t band_lanes, int32_t target_workgroups_per_cu);
-/* First-launch kernel: 0 automatic (diagonal-band kernel with optimality certificate when the scoring allows it, else the
- * banded row-strip kernel), 1 banded row-strip kernel, 2 full-plane row-strip kernel only.  Results never depend on it. */
+/* Kernel chain: 0 automatic (when the scoring allows it: diagonal-band kernels with optimality certificate, 4 then 2 then 1
+ * alignments per wavefront, each over the tasks the previous one could not certify; else the banded row-strip kernel),
+ * 1 banded row-strip kernel, 2 full-plane row-strip kernel only, 3 single-alignment diagonal-band kernel only, 4 diagonal
+ * tiers 2 -> 1.  Every chain ends with the full-plane kernel over what is left.  Results never depend on the mode. */
 int c2_set_kernel_mode(c2_ctx* ctx, int32_t mode);
-/* Band in use for reads up to max_read_len (-1: the diagonal-band kernel is the first launch), and how many tasks of the most recent launch needed the full-plane pass. */
+/* Band in use for reads up to max_read_len (-1: diagonal-band kernels come first), and how many tasks of the most recent launch needed the full-plane pass. */
 int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t* fallback_tasks_last_launch);
+/* Most recent batch: number of banded launches in front of the full-plane launch, and how many tasks each of them left over. */
+int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4);
 
 /* ---- per-call path: same contract as the reference's Cython functions ------------------ */
 
@@ -219,9 +223,9 @@ int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, 
  * counters to out4 (may be NULL) and clears them, then sets the mode. */
 int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4);
 
-/* Hardware self-test of the cross-lane primitives (DPP wave_shr:1, readlane, ballot) the DP depends on;
- * writes 192 int32 (see c2_selftest_kernel).  Used by the GPU test-suite. */
-int c2_selftest(c2_ctx* ctx, int32_t* out192);
+/* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1, also with a lane switched off in EXEC,
+ * readlane, ballot) the DP depends on; writes 320 int32 (see c2_selftest_kernel).  Used by the GPU test-suite. */
+int c2_selftest(c2_ctx* ctx, int32_t* out320);
 
 #ifdef __cplusplus
 }

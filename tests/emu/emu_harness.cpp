@@ -65,15 +65,57 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         for (int16_t v : sc.tbl) mx = std::max(mx, (int)v);
         A.max_score = mx;
     }
-    const bool diag = band_lanes == -1;          // -1: diagonal-band kernel first, full-plane kernel for its fallback list
+    // band_lanes: -1 single-alignment diagonal-band kernel, -2 / -4 the 2- / 4-alignments-per-wavefront kernel, -7 the whole
+    // chain 4 -> 2 -> 1; every chain ends with the full-plane kernel over what is left (the host library's launch order)
+    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -7;
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
+    std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1);
+    uint32_t fb_counts[4] = {0, 0, 0, 0};
+    std::vector<uint32_t> plane;
+    A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0;
+    A.diag_base = nullptr;
+    if (!no_packed && n_refs > 0 && !drows[0].empty()) {
+        // the references' row tables must sit in one buffer (the kernels index it relative to diag_base)
+        static std::vector<c2_diag_row> all_rows;
+        all_rows.clear();
+        std::vector<size_t> off(n_refs);
+        for (int r = 0; r < n_refs; ++r) { off[r] = all_rows.size(); all_rows.insert(all_rows.end(), drows[r].begin(), drows[r].end()); }
+        for (int r = 0; r < n_refs; ++r) refs[r].diag_rows = all_rows.data() + off[r];
+        A.diag_base = all_rows.data();
+    }
     if (diag) {
-        const c2_diag_plan PD = c2_make_diag_plan(A.max_li, A.max_lj);
-        if (PD.total > sizeof(c2_smem)) return -5;
-        emu::launch(grid, [&] { c2_align_diag_kernel(A); });
-        A.task_list = fb_list.data(); A.task_count = &fb_count;
+        uint32_t* lists[2] = {fb_list.data(), fb_list2.data()};
+        int tier = 0;
+        auto chain = [&](c2_align_args& T) {
+            T.task_list = tier ? lists[(tier - 1) & 1] : nullptr; T.task_count = tier ? &fb_counts[tier - 1] : nullptr;
+            T.fb_list = lists[tier & 1]; T.fb_count = &fb_counts[tier];
+            work_counter = 0;
+        };
+        for (int na = 4; na >= 2; na >>= 1) {
+            if (!(band_lanes == -7 || band_lanes == -na)) continue;
+            const c2_diagx_plan PX = c2_make_diagx_plan(na, A.max_li, A.max_lj);
+            if (PX.total > sizeof(c2_smem)) return -5;
+            plane.assign((size_t)grid * PX.n_words * 64u, 0xdeadbeefu);
+            c2_align_args T = A;
+            chain(T);
+            T.plane = plane.data(); T.plane_words_per_wg = PX.n_words * 64u;
+            if (na == 4) emu::launch(grid, [&] { c2_align_diagx_kernel<4>(T); });
+            else         emu::launch(grid, [&] { c2_align_diagx_kernel<2>(T); });
+            ++tier;
+        }
+        if (band_lanes == -7 || band_lanes == -1) {
+            const c2_diag_plan PD = c2_make_diag_plan(A.max_li, A.max_lj);
+            if (PD.total > sizeof(c2_smem)) return -5;
+            c2_align_args T = A;
+            chain(T);
+            emu::launch(grid, [&] { c2_align_diag_kernel(T); });
+            ++tier;
+        }
+        A.task_list = lists[(tier - 1) & 1]; A.task_count = &fb_counts[tier - 1];
+        A.fb_list = nullptr; A.fb_count = nullptr;
         work_counter = 0;
-        if (n_fallback) *n_fallback = (int)fb_count;
+        fb_count = fb_counts[tier - 1];
+        if (n_fallback) *n_fallback = (int)fb_counts[0];
     } else if (band) {
         A.band_lanes = band_lanes;
         const c2_lds_plan PB = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, band_lanes);

@@ -12,6 +12,9 @@ bool lane_done[MAXT];
 uint64_t xl_slots[2][MAXT];
 int bar_count = 0, wbar_count[MAXW];
 unsigned bar_gen = 0, wbar_gen[MAXW];
+int active_count[MAXW], rconv_count[MAXW];
+unsigned rconv_gen[MAXW];
+bool lane_inactive[MAXT];
 static std::function<void()>* cur_body = nullptr;
 static std::vector<char> stacks;
 
@@ -38,7 +41,8 @@ void launch(unsigned grid, F body, unsigned block) {
     for (unsigned b = 0; b < grid; ++b) {
         block_idx.x = b;
         bar_count = 0;
-        for (int w = 0; w < MAXW; ++w) wbar_count[w] = 0;
+        for (int w = 0; w < MAXW; ++w) { wbar_count[w] = 0; active_count[w] = W; rconv_count[w] = 0; }
+        for (int l = 0; l < MAXT; ++l) lane_inactive[l] = false;
         for (int l = 0; l < n_threads; ++l) {
             lane_done[l] = false;
             getcontext(&lane_ctx[l]);

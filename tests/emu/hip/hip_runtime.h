@@ -36,6 +36,9 @@ extern bool lane_done[MAXT];
 extern uint64_t xl_slots[2][MAXT];
 extern int bar_count, wbar_count[MAXW];
 extern unsigned bar_gen, wbar_gen[MAXW];
+extern int active_count[MAXW], rconv_count[MAXW];   // lanes of a wave inside a C2_LANES_ACTIVE region / arrived at its end
+extern unsigned rconv_gen[MAXW];
+extern bool lane_inactive[MAXT];
 
 inline void yield_next() {
     int me = cur_lane;
@@ -56,14 +59,46 @@ inline void barrier() {                       // workgroup barrier (s_barrier)
 inline void wave_barrier() {                  // rendezvous of the 64 lanes of one wavefront (lock-step execution)
     const int w = cur_lane / W;
     unsigned gen = wbar_gen[w];
-    if (++wbar_count[w] == W) { wbar_count[w] = 0; wbar_gen[w]++; return; }
+    if (++wbar_count[w] >= active_count[w]) { wbar_count[w] = 0; wbar_gen[w]++; return; }
     while (wbar_gen[w] == gen) yield_next();
 }
+// EXEC-masked region (C2_LANES_ACTIVE_BEGIN / _END in the kernels): lanes whose condition is false skip the region and
+// wait at its end; inside, cross-lane operations rendezvous among the active lanes only, and a DPP move whose source lane
+// is inactive leaves the destination untouched (gfx9 DPP semantics with bound_ctrl = 0).  Not nestable.
+struct exec_scope {
+    bool active;
+    explicit exec_scope(bool a) : active(a) {
+        if (a) return;
+        const int w = cur_lane / W;
+        lane_inactive[cur_lane] = true;
+        xl_slots[1][cur_lane] = 0;
+        --active_count[w];
+        if (wbar_count[w] > 0 && wbar_count[w] >= active_count[w]) { wbar_count[w] = 0; wbar_gen[w]++; }
+    }
+    ~exec_scope() {
+        const int w = cur_lane / W;
+        const unsigned gen = rconv_gen[w];
+        if (++rconv_count[w] == W) {
+            rconv_count[w] = 0; active_count[w] = W;
+            for (int l = 0; l < W; ++l) lane_inactive[w * W + l] = false;
+            rconv_gen[w]++;
+            return;
+        }
+        while (rconv_gen[w] == gen) yield_next();
+    }
+};
 inline int lane_id() { return cur_lane % W; }
 inline int wave_base() { return cur_lane - cur_lane % W; }
 struct tid_t { unsigned x, y, z; };
 inline tid_t tid() { return tid_t{(unsigned)cur_lane, 0, 0}; }
 }  // namespace emu
+
+#define C2_LANES_ACTIVE_BEGIN(cond) { emu::exec_scope c2_exec_scope_(cond); if (c2_exec_scope_.active) {
+#define C2_LANES_ACTIVE_END() } }
+struct uint4 { unsigned x, y, z, w; };
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
 
 #define threadIdx (emu::tid())
 #define blockIdx (emu::block_idx)
@@ -77,7 +112,7 @@ namespace emu {
 inline uint64_t xl_get(uint64_t mine, int src_lane, bool* valid) {     // src_lane: lane inside this thread's wavefront
     xl_slots[0][cur_lane] = mine;
     wave_barrier();
-    uint64_t r = 0; bool ok = src_lane >= 0 && src_lane < W;
+    uint64_t r = 0; bool ok = src_lane >= 0 && src_lane < W && !lane_inactive[wave_base() + src_lane];
     if (ok) r = xl_slots[0][wave_base() + src_lane];
     if (valid) *valid = ok;
     wave_barrier();                 // everyone has read before anyone may overwrite

@@ -36,14 +36,25 @@ def check_record(rec, payload, s1, s2):
     assert bool(rec["irregular_ends"]) == irregular
 
 
-def test_cross_lane_primitives(ctx):
-    """DPP wave_shr:1 keeps `old` in lane 0 and shifts lane n-1 -> n; readlane; 64-bit ballot."""
-    out = np.zeros(192, dtype=np.int32)
-    ctx.check(ctx.lib.c2_selftest(ctx.handle, out.ctypes.data_as(ctypes.c_void_p)), "c2_selftest")
+def check_selftest(out):
     assert out[0] == -7
     assert (out[1:64] == 3 * np.arange(0, 63) + 1).all()
     assert (out[64:128] == 85).all()
     assert out[128] == 22 + 1 and (out[129:192] == 22).all()
+    # lane 31 switched off in EXEC: it keeps its value, and the lanes that would read it keep `old`
+    shr = 3 * np.arange(-1, 63) + 1
+    shr[0] = -7; shr[31] = -99; shr[32] = -7
+    assert (out[192:256] == shr).all(), out[192:256]
+    shl = 3 * np.arange(1, 65) + 1
+    shl[63] = -7; shl[31] = -99; shl[30] = -7
+    assert (out[256:320] == shl).all(), out[256:320]
+
+
+def test_cross_lane_primitives(ctx):
+    """DPP wave_shr:1 keeps `old` in lane 0 and shifts lane n-1 -> n; readlane; 64-bit ballot."""
+    out = np.zeros(320, dtype=np.int32)
+    ctx.check(ctx.lib.c2_selftest(ctx.handle, out.ctypes.data_as(ctypes.c_void_p)), "c2_selftest")
+    check_selftest(out)
 
 
 def run_batch_vectors(vecs, mats, ctx):
@@ -234,23 +245,31 @@ def test_banded_pointer_plane_equals_full_plane(mats, ctx):
             info = ctx.band_info(L)
             outs[band] = (res, info)
             assert (res.records["status"] == 0).all()
-        ctx.set_kernel_mode("auto")                 # diagonal-band kernel + certificate, full-plane kernel for the rest
         ctx.set_band(-1)
-        res = al.align((reads.reshape(-1), offsets))
-        outs["diag"] = (res, ctx.band_info(L))
-        assert (res.records["status"] == 0).all()
+        # diagonal-band kernels + certificate: 1 alignment per wavefront; tiers 2 -> 1; tiers 4 -> 2 -> 1 (the default)
+        tiers = {}
+        for mode in ("diag1", "diag2", "auto"):
+            ctx.set_kernel_mode(mode)
+            res = al.align((reads.reshape(-1), offsets))
+            outs[mode] = (res, ctx.band_info(L))
+            tiers[mode] = ctx.tier_info()
+            assert (res.records["status"] == 0).all()
     finally:
         ctx.set_band(-1)
         ctx.set_kernel_mode("auto")
     base = outs[0][0]
     assert outs[0][1]["band_lanes"] == 0
-    for band in (2, 6, -1, "diag"):
+    for band in (2, 6, -1, "diag1", "diag2", "auto"):
         res, info = outs[band]
-        assert info["band_lanes"] == -1 if band == "diag" else info["band_lanes"] > 0
+        assert info["band_lanes"] == -1 if isinstance(band, str) else info["band_lanes"] > 0
         assert np.array_equal(res.records, base.records)
         assert np.array_equal(res.aln_read, base.aln_read) and np.array_equal(res.aln_ref, base.aln_ref)
     assert outs[2][1]["fallback_tasks_last_launch"] > outs[6][1]["fallback_tasks_last_launch"] > 0
-    assert 0 < outs["diag"][1]["fallback_tasks_last_launch"] < n // 20
+    assert 0 < outs["diag1"][1]["fallback_tasks_last_launch"] < n // 20
+    # every tier certifies most of what it gets and hands the rest down; the last banded tier is the same in all chains
+    assert len(tiers["diag1"]) == 1 and len(tiers["diag2"]) == 2 and len(tiers["auto"]) == 3
+    assert n // 2 > tiers["auto"][0] > tiers["auto"][1] >= tiers["auto"][2] > 0
+    assert tiers["auto"][1] == tiers["diag2"][0] and tiers["auto"][2] == tiers["diag2"][1] == tiers["diag1"][0]
 
 
 def test_count_vectors_device_vs_reference_aggregation(mats, ctx):

@@ -106,7 +106,24 @@ def test_emulated_diagonal_band_kernel_with_certificate_and_fallback(mats):
     assert 0 < st["fallback"] < st["tasks"], st
 
 
-def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats):
+@pytest.mark.parametrize("mode", [-2, -4, -7])
+def test_emulated_multi_alignment_diagonal_kernels(mats, mode):
+    """c2_align_diagx_kernel: 2 (-2) or 4 (-4) alignments per wavefront, lane groups isolated by an EXEC-disabled lane,
+    pointer words in a global scratch plane; -7 is the host library's whole chain 4 -> 2 -> 1 -> full-plane kernel.
+    Identical to the reference on every vector; the narrow bands must certify a good share of the amplicon reads."""
+    st = {}
+    vecs = load_golden("realistic.json")
+    assert run_vectors(vecs, mats, band_lanes=mode, stats=st) == len(vecs)
+    assert st["tasks"] - st["fallback"] > len(vecs) // 4, st
+    vecs = load_golden("fuzz_align.json")[::3]
+    assert run_vectors(vecs, mats, band_lanes=mode, stats=st) == len(vecs)
+    kats = [k for k in load_golden("ref_unit_kats.json") if k["fn"] == "global_align"]
+    assert run_vectors(kats, mats, band_lanes=mode, stats=st) == len(kats)
+    assert 0 < st["fallback"] < st["tasks"], st
+
+
+@pytest.mark.parametrize("mode", [-1, -2, -4, -7])
+def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats, mode):
     m = mats["EDNAFULL"]
     rng = np.random.default_rng(77)
     refs = ["".join(rng.choice(list("ACGT"), L)) for L in (180, 223, 140)]
@@ -132,7 +149,7 @@ def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats):
         reads.append("".join(comp[c] for c in reversed(fw)) if rc else fw)
         rids.append(r); strands.append(rc); truth.append(fw)
     st = {}
-    res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=rids, strands=strands, band_lanes=-1, stats=st)
+    res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=rids, strands=strands, band_lanes=mode, stats=st)
     for k, ((s1, s2), r) in enumerate(zip(res, rec)):
         exp = oracle.global_align_raw(truth[k], refs[rids[k]], m, gis[rids[k]], -20, -2)
         assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k

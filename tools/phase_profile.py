@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--len", type=int, default=250, dest="L")
     ap.add_argument("--band", type=int, default=-1)
     ap.add_argument("--band-wgs", type=int, default=0)
-    ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--kernel", default="auto", help="auto | diag2 | diag1 | band | full")
     a = ap.parse_args()
     from crispresso2_amd import synth, _native, CRISPResso2Align as A
     from crispresso2_amd.batch import BatchAligner
