@@ -304,7 +304,7 @@ int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
         HIPCHK(ctx, hipMemcpy(ctx->d_diagrows.p, all.data(), all.size() * sizeof(c2_diag_row), hipMemcpyHostToDevice));
     }
     for (int r = 0; r < ctx->n_refs; ++r)
-        ctx->ref_desc[r].diag_rows = all.empty() ? nullptr : (const c2_diag_row*)ctx->d_diagrows.p + off[r];
+        ctx->ref_desc[r].diag_rows = all.empty() ? nullptr : (const c2_diag_row*)ctx->d_diagrows.p + off[r] + C2_DIAG_ROW_PAD;
     HIPCHK(ctx, hipMemcpy(ctx->d_refdesc.p, ctx->ref_desc.data(), sizeof(c2_dev_ref) * (size_t)ctx->n_refs, hipMemcpyHostToDevice));
     ctx->diag_rows_dirty = false;
     return 0;

@@ -16,6 +16,8 @@
 #define C2_DIAG_NEG (-(1 << 30))     // diagonal-band kernels: value of everything outside the band
 #define C2_DIAG_STORE_LO 16          // diagonal-band kernel: lanes STORE_LO .. STORE_LO+STORE_N-1 (the inner 64 of the 128
 #define C2_DIAG_STORE_N 32           //   diagonals) keep their pointer words; a traceback that leaves them is redone by the row-strip kernel
+#define C2_DIAG_ROW_PAD 128          // zero row records in front of row 0 and behind row Li+1 of every reference's table
+#define C2_DIAG_CODE_PAD 32          // zero column symbols in front of column 0 (multi-alignment kernel's LDS tables)
 #define C2_TASK_CHUNK 4              // tasks a workgroup takes per atomic
 #define C2_STATUS_NEED_FULL 64     // internal: banded launch could not finish the traceback; the full-plane launch overwrites the record
 
@@ -28,7 +30,7 @@ typedef struct c2_dev_ref {
     const uint8_t* seq;           // Li bytes
     const int32_t* gap_incentive; // Li+1 (int64 input truncated to int32 exactly as the reference's int arithmetic does)
     const uint16_t* inc_prefix;   // Li+2: inc_prefix[x] = number of include idxs < x  (window membership and range hits)
-    const c2_diag_row* diag_rows; // Li+2 records (rows 0 and Li+1 are zero), or NULL when the scoring has no packed form
+    const c2_diag_row* diag_rows; // row 0 of Li+2 records (rows 0 and Li+1 are zero) with C2_DIAG_ROW_PAD zero records on either side; NULL when the scoring has no packed form
     int32_t len;                  // Li
     int32_t gap_incentive_max;    // max(0, max_i gap_incentive[i]); max(gap_open, gap_extend) + this bounds what one gap base adds to a score
 } c2_dev_ref;

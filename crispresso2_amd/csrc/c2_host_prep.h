@@ -65,20 +65,22 @@ inline void c2_build_inc_prefix(const int32_t* inc, int n_inc, int Li, std::vect
     for (int x = 0; x < Li + 2; ++x) { out[x] = run; run = (uint16_t)(run + bit[x]); }
 }
 
-// Row records of the diagonal-band kernel for one reference (c2_diag_row[Li+2], rows 0 and Li+1 zero); empty if the
+// Row records of the diagonal-band kernels for one reference (rows 0 .. Li+1, rows 0 and Li+1 zero, plus padding); empty if the
 // scoring has no packed form.  g32: the gap incentives already truncated to int32.
 inline void c2_build_diag_rows(const char* seq, int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend,
                                std::vector<c2_diag_row>& out) {
     out.clear();
     if (sc.pk.empty()) return;
-    out.assign((size_t)Li + 2, c2_diag_row{0, 0, 0, 0u});
+    // C2_DIAG_ROW_PAD zero records on either side: lanes whose diagonal has not entered the matrix yet (or has left it) index
+    // past the ends; row i is out[C2_DIAG_ROW_PAD + i]
+    out.assign((size_t)Li + 2 + 2 * C2_DIAG_ROW_PAD, c2_diag_row{0, 0, 0, 0u});
     for (int i = 1; i <= Li; ++i) {
         const int open = (i == Li) ? gap_extend : gap_open;        // last row: gap_open -> gap_extend (CRISPResso2Align.pyx:277-317)
         c2_diag_row r;
         r.a = open + g32[i]; r.b = gap_extend + g32[i]; r.c = open + g32[i - 1];
         const uint8_t code = sc.code_of_char[(unsigned char)seq[i - 1]];
         r.prof = code == C2_INVALID_CODE ? 0u : sc.pk[code];
-        out[i] = r;
+        out[C2_DIAG_ROW_PAD + i] = r;
     }
 }
 

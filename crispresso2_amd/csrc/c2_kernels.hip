@@ -1024,7 +1024,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     p.stage = off;    off += p.n_words * (64u / (uint32_t)na) * 4u; // pointer words of the alignment being traced
     p.slot0 = off;
     uint32_t so = 0;
-    p.codes = so;    so += c2_align16((uint32_t)max_lj + 2u);
+    p.codes = so;    so += c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 8u);   // zeros | columns 0 .. Lj+1 | zeros
     p.read = so;     so += c2_align16((uint32_t)max_lj);
     p.code = so;     so += c2_align16((uint32_t)max_lj);
     p.ref = so;      so += c2_align16((uint32_t)max_li);
@@ -1046,40 +1046,63 @@ struct c2_diagx_plane {
     }
 };
 
-// per-lane view of the tables and of the matrix edges
+// per-lane view of the tables and of the matrix edges.  The row table (global memory) and the column-symbol table (LDS) are
+// padded with zeros, so a lane that is before / past the matrix needs no clamp at the low end and one v_min at the high end
+// per group; the records of a group are consecutive, so one address serves all of its loads (immediate offsets).
 struct c2_diagx_lane {
-    int hRow, rowLo, rowHi;          // row record of pair k's E cell: rows[clamp(k + hRow, rowLo, rowHi)]
-    int hCol, colLo, colHi;          // column symbol of pair k: LDS byte clamp(k + hCol, colLo, colHi)
+    unsigned rowOff, rowMax;         // byte offset from A.diag_base of row (hE + 0) of pair 0's E cell; largest offset a group may start at
+    unsigned colOff, colMax;         // LDS byte address of column (0 - hE); largest address a group may start at
     int kLast;                       // pair whose cells are on the last column
     int kCap; bool capOdd;           // pair (and cell of it) that holds H(Li, Lj), if this lane owns that diagonal
     int startE, startO;              // first interior anti-diagonal of the two diagonals
 };
 
+// rows and column symbols of group g (pairs 4g .. 4g+3): five row records (the O cell of the last pair needs row + 1) and four symbols
+__device__ __forceinline__ void c2_diagx_fetch(const int g, const c2_diagx_lane& L, const c2_diag_row* rows, const unsigned char* lds,
+                                               c2_diag_row (&R)[5], int (&C)[4])
+{
+    const unsigned ro = min(L.rowOff + (unsigned)(g * 4 * (int)sizeof(c2_diag_row)), L.rowMax);
+    const c2_diag_row* rp = (const c2_diag_row*)((const unsigned char*)rows + ro);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) R[q] = rp[q];
+    const unsigned co = min(L.colOff + (unsigned)(g * 4), L.colMax);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) C[q] = (int)lds[co + q];
+}
+
+// One group = four pairs = eight anti-diagonals = one pointer word per lane; the next group's tables are requested first.
+template <bool MASK, bool LASTCOL>
+__device__ __forceinline__ void c2_diagx_group(c2_diag_state& S, const int g, const c2_diagx_lane& L, const int ge, int& Hcap,
+                                               const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
+                                               const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride)
+{
+    c2_diagx_fetch(g + 1, L, rows, lds, RN, CN);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = 4 * g + q;
+        c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, L.startE, L.startO, LASTCOL && (k == L.kLast));
+        if (LASTCOL && k == L.kCap) Hcap = L.capOdd ? S.HO : S.HE;
+    }
+    myWords[g * wordStride] = S.bits;                                // anti-diagonals 8g .. 8g+7
+}
+
+// Groups g .. g_stop; the tables alternate between two register sets (no copies).  `cur` tells which set holds group g's.
 template <bool MASK, bool LASTCOL>
 __device__ __forceinline__ void c2_diagx_groups(c2_diag_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const int ge,
-                                                int& Hcap, c2_diag_row (&R)[5], int (&C)[4],
+                                                int& Hcap, c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
                                                 const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride)
 {
-    for (; g <= g_stop; ++g) {
-        const int k0 = 4 * g;
-        c2_diag_row RN[5];
-        int CN[4];
-        RN[0] = R[4];
+    for (; g + 1 <= g_stop; g += 2) {
+        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, RA, CA, RB, CB, rows, lds, myWords, wordStride);
+        c2_diagx_group<MASK, LASTCOL>(S, g + 1, L, ge, Hcap, RB, CB, RA, CA, rows, lds, myWords, wordStride);
+    }
+    if (g <= g_stop) {                                               // odd count: one more group, then move its successor's tables to set A
+        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, RA, CA, RB, CB, rows, lds, myWords, wordStride);
+        ++g;
 #pragma unroll
-        for (int q = 1; q < 5; ++q) RN[q] = rows[c2_med3(k0 + 4 + q + L.hRow, L.rowLo, L.rowHi)];
+        for (int q = 0; q < 5; ++q) RA[q] = RB[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) CN[q] = (int)lds[c2_med3(k0 + 4 + q + L.hCol, L.colLo, L.colHi)];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + q;
-            c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, L.startE, L.startO, LASTCOL && (k == L.kLast));
-            if (LASTCOL && k == L.kCap) Hcap = L.capOdd ? S.HO : S.HE;
-        }
-        myWords[g * wordStride] = S.bits;                            // anti-diagonals 8g .. 8g+7
-#pragma unroll
-        for (int q = 0; q < 5; ++q) R[q] = RN[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) C[q] = CN[q];
+        for (int q = 0; q < 4; ++q) CA[q] = CB[q];
     }
 }
 
@@ -1111,33 +1134,93 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
     for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
     if (lane < NA) { sTab[lane * C2X_INTS + C2X_CURREF] = -1; sTab[lane * C2X_INTS + C2X_LI] = 0; sTab[lane * C2X_INTS + C2X_G0] = 0; }
 
-    uint64_t chunk_base = 0;
-    int chunk_left = 0;
     c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
+    // Task fetch as a four-stage software pipeline, one stage per group of NA alignments, so that no stage ever waits for
+    // the memory access it depends on (in list mode every one of them misses the caches):
+    //   A0  atomic on the work counter for the group four iterations ahead
+    //   A   lane s < NA: task index of slot s (from the task list, if any)              -- three ahead
+    //   B   lane s < NA: read offsets, reference id and strand of that task             -- two ahead
+    //   C   the first 256 read bytes of every slot, lanes = bytes (c2_prefetch)         -- one ahead
+    //   D   c2_commit_task into LDS, then the fill                                      -- this iteration
+    // Each stage consumes what the previous iteration's earlier stage requested; the barrier at the top of the loop has
+    // waited for all of it.  Task indices fit 32 bits in these launches (the host checks).
+    const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : A.n_tasks;
+    unsigned long long pend = 0;
+    bool pend_valid = false, exhausted = false;
+    unsigned mA_task = 0; int mA_valid = 0;
+    unsigned mB_task = 0; int mB_valid = 0, mB_ref = 0, mB_rc = 0;
+    unsigned long long mB_off = 0, mB_off1 = 0;
     c2_prefetch pf[NA];
 #pragma unroll
-    for (int s = 0; s < NA; ++s) c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf[s]);
-    while (pf[0].valid) {
+    for (int s = 0; s < NA; ++s) { pf[s].task = 0; pf[s].off = 0; pf[s].valid = 0; pf[s].Lj = 0; pf[s].ref_id = 0; pf[s].rc = 0; pf[s].b4 = 0; }
+    for (int iter = 0;; ++iter) {
         __syncthreads();
+        const bool have_group = pf[0].valid != 0;
+        if (iter >= 4 && !have_group) break;
         c2_phase_begin(A.phase_cycles, PH);
-        // ---- stage the NA prefetched tasks in their LDS slots (unrolled: pf[] must stay in registers -- a scratch access
+        // ---- D: stage the NA prefetched tasks in their LDS slots (unrolled: pf[] must stay in registers -- a scratch access
         //      here would queue behind the previous group's output stores in vmcnt)
+        if (have_group) {
 #pragma unroll
-        for (int s = 0; s < NA; ++s) {
-            int* T = sTab + s * C2X_INTS;
-            int cref = c2_uni(T + C2X_CURREF), li = c2_uni(T + C2X_LI), g0 = c2_uni(T + C2X_G0);
-            int st = 0;
-            bool packed = false;
-            if (pf[s].valid) st = c2_commit_task(A, wg_of(s), sCodeOf, pf[s], lane, A.max_li, cref, li, g0, packed);
-            if (lane == 0) {
-                T[C2X_VALID] = pf[s].valid; T[C2X_TASK_LO] = (int)(unsigned)(pf[s].task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(pf[s].task >> 32);
-                T[C2X_LJ] = pf[s].Lj; T[C2X_REF] = pf[s].ref_id; T[C2X_RC] = pf[s].rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
-                T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0;
+            for (int s = 0; s < NA; ++s) {
+                int* T = sTab + s * C2X_INTS;
+                int cref = c2_uni(T + C2X_CURREF), li = c2_uni(T + C2X_LI), g0 = c2_uni(T + C2X_G0);
+                int st = 0;
+                bool packed = false;
+                if (pf[s].valid) st = c2_commit_task(A, wg_of(s), sCodeOf, pf[s], lane, A.max_li, cref, li, g0, packed);
+                if (lane == 0) {
+                    T[C2X_VALID] = pf[s].valid; T[C2X_TASK_LO] = (int)(unsigned)(pf[s].task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(pf[s].task >> 32);
+                    T[C2X_LJ] = pf[s].Lj; T[C2X_REF] = pf[s].ref_id; T[C2X_RC] = pf[s].rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
+                    T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0;
+                }
             }
         }
+        // ---- C: read bytes of the next group
 #pragma unroll
-        for (int s = 0; s < NA; ++s) c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf[s]);   // next group's loads fly during this DP
+        for (int s = 0; s < NA; ++s) {
+            const int v = __builtin_amdgcn_readlane(mB_valid, s);
+            const uint64_t off = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mB_off & 0xffffffffull), s) |
+                                 ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mB_off >> 32), s) << 32);
+            const uint64_t off1 = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mB_off1 & 0xffffffffull), s) |
+                                  ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mB_off1 >> 32), s) << 32);
+            const int Lj = (int)(off1 - off), rc = __builtin_amdgcn_readlane(mB_rc, s);
+            unsigned b4 = 0;
+            if (v) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = 64 * q + lane;
+                    const unsigned byte = (k < Lj) ? (unsigned)A.reads[off + (uint64_t)(rc ? Lj - 1 - k : k)] : 0u;
+                    b4 |= byte << (8 * q);
+                }
+            }
+            pf[s].valid = v; pf[s].task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mB_task, s); pf[s].off = off;
+            pf[s].Lj = v ? Lj : 0; pf[s].ref_id = __builtin_amdgcn_readlane(mB_ref, s); pf[s].rc = rc; pf[s].b4 = b4;
+        }
+        // ---- B: descriptors of the group after that
+        mB_valid = mA_valid; mB_task = mA_task; mB_off = 0; mB_off1 = 0; mB_ref = 0; mB_rc = 0;
+        if (lane < NA && mA_valid) {
+            unsigned read_id;
+            if (A.all_refs) { read_id = mA_task / (unsigned)A.n_refs; mB_ref = (int)(mA_task % (unsigned)A.n_refs); }
+            else            { read_id = mA_task; mB_ref = A.ref_ids ? (int)A.ref_ids[mA_task] : 0; }
+            mB_rc = A.strands ? (int)A.strands[mA_task] : 0;
+            mB_off = A.offsets[read_id]; mB_off1 = A.offsets[read_id + 1];
+        }
+        // ---- A: task indices of the group after that;  A0: the work counter for the one after
+        mA_valid = 0; mA_task = 0;
+        if (pend_valid) {
+            const uint64_t base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pend >> 32)) << 32) |
+                                  (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pend & 0xffffffffull));
+            const uint64_t it = base + (uint64_t)lane;
+            if (base >= n_iter) exhausted = true;
+            if (lane < NA && it < n_iter) { mA_valid = 1; mA_task = A.task_list ? A.task_list[it] : (unsigned)it; }
+        }
+        pend = 0; pend_valid = false;
+        if (!exhausted) {
+            if (lane == 0) pend = atomicAdd(A.work_counter, (unsigned long long)NA);
+            pend_valid = true;
+        }
         __syncthreads();
+        if (!have_group) continue;
 
         // ---- band of every alignment; the tables its lanes read; the wave-uniform loop limits
         bool any_ok = false;
@@ -1147,7 +1230,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             int* T = sTab + s * C2X_INTS;
             const int Li = c2_uni(T + C2X_LI), Lj = c2_uni(T + C2X_LJ);
             bool ok = false;
-            int D = 0, d0 = 0, cb = 0, minsc = 0, rowBase = 0;
+            int D = 0, d0 = 0, cb = 0, minsc = 0, rowBase = C2_DIAG_ROW_PAD;   // (idle slot: row 0 of the buffer's first table)
             if (c2_uni(T + C2X_VALID) && c2_uni(T + C2X_STATUS) == 0) {
                 const c2_dev_ref rf = A.refs[c2_uni(T + C2X_REF)];
                 D = Li - Lj;
@@ -1158,9 +1241,12 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 if (ok) {
                     any_ok = true;
                     const c2_wg W = wg_of(s);
+                    // 4 * code of columns 1 .. Lj between zeros: C2_DIAG_CODE_PAD + 1 in front (columns < 1), 9 behind (columns > Lj)
                     unsigned char* sCodes = c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes;
-                    for (int j = lane; j < Lj + 2; j += 64)
-                        sCodes[j] = (j >= 1 && j <= Lj) ? (unsigned char)(W.sCode[j - 1] << 2) : (unsigned char)0;
+                    for (int j = lane; j < C2_DIAG_CODE_PAD + Lj + 2 + 8; j += 64) {
+                        const int col = j - C2_DIAG_CODE_PAD;
+                        sCodes[j] = (col >= 1 && col <= Lj) ? (unsigned char)(W.sCode[col - 1] << 2) : (unsigned char)0;
+                    }
                     minsc = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
                     rowBase = (int)(rf.diag_rows - A.diag_base);
                     const int max_start = (d0 + BANDW - 1 > -d0 ? d0 + BANDW - 1 : -d0) + 2;
@@ -1182,7 +1268,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
         if (any_ok) {
             const int* T = sTab + slot * C2X_INTS;                 // this lane's alignment
             const int vLi = T[C2X_BAND_LI], vLj = T[C2X_BAND_LJ], vd0 = T[C2X_D0], vg0 = T[C2X_G0], vmin = T[C2X_MINSC];
-            const int vrow = T[C2X_ROWBASE], vcode = (int)(P.slot0 + (uint32_t)slot * P.slot_bytes + P.codes);
+            const int vrow = T[C2X_ROWBASE], vcode = (int)(P.slot0 + (uint32_t)slot * P.slot_bytes + P.codes) + C2_DIAG_CODE_PAD;
             C2_LANES_ACTIVE_BEGIN(sl != NL)
             // ---- per-lane diagonals and their boundary cells (pyx:153-176), as in c2_align_diag_kernel
             const int hE = (vd0 >> 1) + sl;                    // dE = 2*hE, dO = 2*hE + 1
@@ -1203,28 +1289,27 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
             }
             c2_diagx_lane L;
-            L.hRow = hE + vrow; L.rowLo = vrow; L.rowHi = vrow + vLi + 1;
-            L.hCol = vcode - hE; L.colLo = vcode; L.colHi = vcode + vLj + 1;
+            L.rowOff = (unsigned)((vrow + hE) * (int)sizeof(c2_diag_row));
+            L.rowMax = (unsigned)((vrow + vLi + 1 + C2_DIAG_ROW_PAD - 5) * (int)sizeof(c2_diag_row));
+            L.colOff = (unsigned)(vcode - hE);
+            L.colMax = (unsigned)(vcode + vLj + 2);
             L.kLast = vLj + hE;
             L.kCap = (vLi + vLj) >> 1; L.capOdd = ((vLi + vLj) & 1) != 0;
             L.startE = (dE > 0 ? dE : -dE) + 2; L.startO = (dO > 0 ? dO : -dO) + 2;
             const c2_diag_row* rows = A.diag_base;
-            c2_diag_row Rw[5];
-            int Cw[4];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) Rw[q] = rows[c2_med3(q + L.hRow, L.rowLo, L.rowHi)];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Cw[q] = (int)c2_smem[c2_med3(q + L.hCol, L.colLo, L.colHi)];
+            c2_diag_row RA[5], RB[5];
+            int CA[4], CB[4];
+            c2_diagx_fetch(0, L, rows, c2_smem, RA, CA);
             unsigned* myWords = gWords + slot * slotWords + sl;
             int g = 0;
             const int gA_stop = gA < g_end ? gA : g_end;
             if (gC <= gA_stop) {
-                c2_diagx_groups<true, true>(S, g, gA_stop, L, ge, Hcap, Rw, Cw, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<true, true>(S, g, gA_stop, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             } else {
-                c2_diagx_groups<true, false>(S, g, gA_stop, L, ge, Hcap, Rw, Cw, rows, c2_smem, myWords, LPA);
-                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge, Hcap, Rw, Cw, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<true, false>(S, g, gA_stop, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             }
-            c2_diagx_groups<false, true>(S, g, g_end, L, ge, Hcap, Rw, Cw, rows, c2_smem, myWords, LPA);
+            c2_diagx_groups<false, true>(S, g, g_end, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             C2_LANES_ACTIVE_END()
         }
         __syncthreads();                                           // (waits for the plane stores)

@@ -33,7 +33,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
         refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = g32[r].data(); refs[r].inc_prefix = incp[r].data();
         c2_build_diag_rows(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows[r]);
-        refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data();
+        refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
         refs[r].len = lens[r];
         int64_t gm = 0;
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, gap_inc[r][k]);
@@ -80,7 +80,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         all_rows.clear();
         std::vector<size_t> off(n_refs);
         for (int r = 0; r < n_refs; ++r) { off[r] = all_rows.size(); all_rows.insert(all_rows.end(), drows[r].begin(), drows[r].end()); }
-        for (int r = 0; r < n_refs; ++r) refs[r].diag_rows = all_rows.data() + off[r];
+        for (int r = 0; r < n_refs; ++r) refs[r].diag_rows = all_rows.data() + off[r] + C2_DIAG_ROW_PAD;
         A.diag_base = all_rows.data();
     }
     if (diag) {
