@@ -120,7 +120,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    kernel_ms, launches = ctx.timing_read()
+    kernel_ms, first_ms, launches = ctx.timing_read_split()
     ctx.timing_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -134,8 +134,8 @@ def main():
     bytes_in = n * L + (n + 1) * 8
     bytes_out = 2 * aln_cols + 32 * n
     alg_bytes = bytes_in + bytes_out
-    avg_launch_s = (kernel_ms / max(launches, 1)) / 1e3
-    achieved_gbs = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    avg_launch_s = (kernel_ms / max(launches, 1)) / 1e3          # the whole launch chain of one batch
+    avg_first_s = (first_ms / max(launches, 1)) / 1e3            # its first kernel: the one that sees every task
     cells = n * (L + 1) * (L + 1)
     parity = None
     if rank == 0 and args.check > 0:
@@ -158,15 +158,23 @@ def main():
                    "diag2": ["c2_align_diagx_kernel<2>", "c2_align_diag_kernel"], "diag1": ["c2_align_diag_kernel"]}
     # HBM bytes per alignment from the committed PMC passes (separate rocprofv3 --pmc runs of this same script; FETCH_SIZE
     # doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming reads); null when the profile file is absent
+    chain = ((chain_names.get(args.kernel, ["c2_align_diag_kernel"])[-len(tiers):] if band["band_lanes"] < 0 else
+              ["c2_align_classify_kernel<%d, true>" % info["rows_per_lane"]] if band["band_lanes"] > 0 else [])
+             + ["c2_align_classify_kernel<%d, false>" % info["rows_per_lane"]])
+    dominant = chain[0]
+    # algorithmic bytes of the dominant kernel's launch: every read and offset in; strings + record out for the tasks it finishes
+    done_first = n - (tiers[0] if tiers else 0)
+    alg_first = bytes_in + int(bytes_out * (done_first / float(n)))
+    achieved_gbs = alg_first / avg_first_s / 1e9 if avg_first_s > 0 else 0.0
     traffic = traffic_src = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01", "pmc_summary_2M_reads.json")
-    if os.path.exists(pmc_path) and L == 250:
+    pmc_path = os.path.join(ROOT, "profiles", "r01", "pmc_summary_default.json")
+    if os.path.exists(pmc_path) and L == 250 and args.kernel == "auto":
         with open(pmc_path) as fh:
-            pmc = json.load(fh)
-        fetch = sum(v["FETCH_SIZE"] for k, v in pmc["pmc_FETCH_SIZE"].items() if "c2_align" in k)
-        write = sum(v["WRITE_SIZE"] for k, v in pmc["pmc_WRITE_SIZE"].items() if "c2_align" in k)
-        traffic = (2.0 * fetch + write) * 1024.0 / 2.0e6 * n          # bytes per launch of n alignments
-        traffic_src = "profiles/r01/pmc_summary_2M_reads.json (2*FETCH_SIZE + WRITE_SIZE of the align kernels, per alignment, x reads per launch)"
+            pmc = json.load(fh)["kernels"].get(dominant)
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / 2.0e6 * n      # bytes per launch of n alignments
+            traffic_src = ("profiles/r01/pmc_summary_default.json: (2*FETCH_SIZE + WRITE_SIZE) KB of %s over 2,000,000 reads, scaled to "
+                           "the reads of one launch; includes the kernel's pointer-word scratch plane (written once, read back once)" % dominant)
     tallies = layout.unpack(d_counts.cpu().numpy(), 0, L)
 
     if rank == 0:
@@ -190,18 +198,19 @@ def main():
                        "reads_per_gpu_per_step": n, "read_len": L, "amplicon_len": L, "unique_read_fraction": unique_fraction, "unique_read_fraction_sample": n_u,
                        "rows_per_lane": info["rows_per_lane"], "lds_bytes_per_workgroup": info["lds_bytes"],
                        "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
-                       "kernel_chain": ((chain_names.get(args.kernel, ["c2_align_diag_kernel"])[-len(tiers):] if band["band_lanes"] < 0 else
-                                         ["c2_align_classify_kernel (banded)"] if band["band_lanes"] > 0 else []) + ["c2_align_classify_kernel (full plane)"]),
+                       "kernel_chain": chain,
                        "tasks_left_after_each_banded_launch": tiers,
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "c2_align_classify_kernel", "avg_launch_ms": 1e3 * avg_launch_s, "launches": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_bytes_per_read": alg_bytes / n,
-                         "note": "integer DP: VALU-bound by construction, HBM fraction is small (SURVEY 8d); see valu"},
+                         "kernel": dominant, "avg_launch_ms": 1e3 * avg_first_s, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_first,
+                         "algorithmic_bytes_per_read": alg_first / n,
+                         "chain_avg_ms": 1e3 * avg_launch_s, "chain_algorithmic_bytes": alg_bytes,
+                         "note": "integer DP: VALU-issue-bound by construction, HBM fraction is small (SURVEY 8d); see valu and profiles/r01/README.md"},
             "valu": {"cells_per_s": cells / avg_launch_s if avg_launch_s > 0 else 0.0,
                      "gcups": cells / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0,
+                     "note": "full-matrix cell updates the reference would perform per second of launch-chain time (the banded kernels compute fewer)",
                      "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS},
             "cpu_baseline": cpu_baseline,
             "checks": {"all_status_ok": ok_status, "oracle_sample_identical": parity, "oracle_sample": args.check},

@@ -20,7 +20,7 @@ SYMBOLS = [
     "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
-    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_count_vectors_device",
+    "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_timing_read_split", "c2_count_vectors_device",
 ]
 
 REC_DTYPE = np.dtype([
@@ -146,6 +146,14 @@ class Context:
         n = ctypes.c_int64(0)
         self.check(self.lib.c2_timing_read(self.handle, ctypes.byref(ms), ctypes.byref(n), int(bool(reset))), "c2_timing_read")
         return ms.value, n.value
+
+    def timing_read_split(self, reset=True):
+        """-> (ms of the whole launch chains, ms of their first kernels, batches)"""
+        ms, first = ctypes.c_double(0), ctypes.c_double(0)
+        n = ctypes.c_int64(0)
+        self.check(self.lib.c2_timing_read_split(self.handle, ctypes.byref(ms), ctypes.byref(first), ctypes.byref(n), int(bool(reset))),
+                   "c2_timing_read_split")
+        return ms.value, first.value, n.value
 
     def set_band(self, band_lanes=-1, target_workgroups_per_cu=0):
         self.check(self.lib.c2_set_band(self.handle, int(band_lanes), int(target_workgroups_per_cu)), "c2_set_band")

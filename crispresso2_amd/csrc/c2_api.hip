@@ -28,7 +28,7 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-struct TimedLaunch { hipEvent_t a, b; };
+struct TimedLaunch { hipEvent_t a, m, b; };   // before the chain, after its first kernel, after its last
 
 }  // namespace
 
@@ -220,9 +220,11 @@ template <int R>
 int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s) {
     TimedLaunch tl{};
     if (ctx->timing) {
-        HIPCHK(ctx, hipEventCreate(&tl.a)); HIPCHK(ctx, hipEventCreate(&tl.b));
+        HIPCHK(ctx, hipEventCreate(&tl.a)); HIPCHK(ctx, hipEventCreate(&tl.m)); HIPCHK(ctx, hipEventCreate(&tl.b));
         HIPCHK(ctx, hipEventRecord(tl.a, s));
     }
+    bool first_marked = false;
+    auto mark_first = [&]() { if (ctx->timing && !first_marked) { (void)hipEventRecord(tl.m, s); first_marked = true; } };
     int rc;
     A.band_lanes = 0; A.reserved = getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0; A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
     if (g.diag || g.band_lanes > 0) {
@@ -254,6 +256,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
                 if (t == 0) hipLaunchKernelGGL(c2_align_diagx_kernel<4>, dim3(grid), dim3(64), g.lds_x[t], s, T);
                 else        hipLaunchKernelGGL(c2_align_diagx_kernel<2>, dim3(grid), dim3(64), g.lds_x[t], s, T);
                 HIPCHK(ctx, hipGetLastError());
+                mark_first();
                 ++tier;
             }
             const uint64_t resident = cus * (uint64_t)g.blocks_diag;
@@ -262,11 +265,13 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
             chain(T);
             hipLaunchKernelGGL(c2_align_diag_kernel, dim3(grid), dim3(64), g.lds_diag, s, T);
             HIPCHK(ctx, hipGetLastError());
+            mark_first();
             ++tier;
         } else {
             A.band_lanes = g.band_lanes;
             chain(A);
             if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
+            mark_first();
             ++tier;
         }
         // the tasks no banded tier could finish, redone with the full pointer plane (usually a handful; an empty list costs one tiny launch)
@@ -282,6 +287,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
         A.work_counter = (unsigned long long*)((uint32_t*)ctx->d_fb.p + 2);
         if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;
     }
+    mark_first();
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(tl.b, s)); ctx->timed.push_back(tl); }
     return 0;
 }
@@ -539,23 +545,30 @@ int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4) {
 
 int c2_timing_enable(c2_ctx* ctx, int on) { if (!ctx) return C2_E_INVALID; ctx->timing = on != 0; return 0; }
 
-int c2_timing_read(c2_ctx* ctx, double* total_ms, int64_t* launches, int reset) {
+int c2_timing_read_split(c2_ctx* ctx, double* total_ms, double* first_kernel_ms, int64_t* launches, int reset) {
     if (!ctx) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    double tot = 0;
+    double tot = 0, first = 0;
     for (auto& t : ctx->timed) {
         HIPCHK(ctx, hipEventSynchronize(t.b));
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, t.a, t.b));
         tot += ms;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, t.a, t.m));
+        first += ms;
     }
     if (total_ms) *total_ms = tot;
+    if (first_kernel_ms) *first_kernel_ms = first;
     if (launches) *launches = (int64_t)ctx->timed.size();
     if (reset) {
-        for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.m); (void)hipEventDestroy(t.b); }
         ctx->timed.clear();
     }
     return 0;
+}
+
+int c2_timing_read(c2_ctx* ctx, double* total_ms, int64_t* launches, int reset) {
+    return c2_timing_read_split(ctx, total_ms, nullptr, launches, reset);
 }
 
 int c2_synchronize(c2_ctx* ctx, void* hip_stream) {

@@ -130,6 +130,8 @@ int c2_synchronize(c2_ctx* ctx, void* hip_stream);
  * accumulated kernel milliseconds and launch count (synchronises the recorded events). */
 int c2_timing_enable(c2_ctx* ctx, int on);
 int c2_timing_read(c2_ctx* ctx, double* total_ms, int64_t* launches, int reset);
+/* Same, and also the summed time of the FIRST kernel of every batch's launch chain (the kernel that sees every task). */
+int c2_timing_read_split(c2_ctx* ctx, double* total_ms, double* first_kernel_ms, int64_t* launches, int reset);
 
 /* Launch geometry chosen for the current references / longest read (for DESIGN/bench reporting). */
 int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, int32_t* passes,
