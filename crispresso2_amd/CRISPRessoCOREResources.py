@@ -108,9 +108,7 @@ def _classify(read_seq_al, ref_seq_al, _include_indx, legacy):
     return res, counts
 
 
-def find_indels_substitutions(read_seq_al, ref_seq_al, _include_indx):
-    """Reference pyx:68-187.  Returns a ResultsSlotsDict with the 18 classifier fields."""
-    res, counts = _classify(read_seq_al, ref_seq_al, _include_indx, 0)
+def _payload(res, counts):
     return ResultsSlotsDict(
         all_insertion_positions=res['all_insertion_positions'],
         all_insertion_left_positions=res['all_insertion_left_positions'],
@@ -136,10 +134,20 @@ def find_indels_substitutions(read_seq_al, ref_seq_al, _include_indx):
     )
 
 
+def find_indels_substitutions(read_seq_al, ref_seq_al, _include_indx):
+    """Reference pyx:68-187.  Returns a ResultsSlotsDict with the 18 classifier fields."""
+    res, counts = _classify(read_seq_al, ref_seq_al, _include_indx, 0)
+    return _payload(res, counts)
+
+
 def find_indels_substitutions_legacy(read_seq_al, ref_seq_al, _include_indx):
     """Reference pyx:190-315 (--use_legacy_insertion_quantification): plain dict; deletion_n / insertion_n are
     numpy sums of the size lists, as in the reference (np.sum([]) is the float 0.0)."""
     res, counts = _classify(read_seq_al, ref_seq_al, _include_indx, 1)
+    return _payload_legacy(res, counts)
+
+
+def _payload_legacy(res, counts):
     return {
         'all_insertion_positions': res['all_insertion_positions'],
         'all_insertion_left_positions': res['all_insertion_left_positions'],
@@ -163,6 +171,44 @@ def find_indels_substitutions_legacy(read_seq_al, ref_seq_al, _include_indx):
 
         'ref_positions': res['ref_positions'],
     }
+
+
+def find_indels_substitutions_batch(pairs, include_sets, set_ids=None, legacy=False, ctx=None):
+    """The classifier calls of a whole batch of alignments in a few launches (c2_classify_lists_batch): `pairs` is a sequence
+    of (read_seq_al, ref_seq_al), `include_sets` a list of include-index collections and set_ids[k] says which of them
+    pair k uses (default: set 0).  Returns what find_indels_substitutions (or _legacy) returns for every pair, in order."""
+    n = len(pairs)
+    if n == 0:
+        return []
+    ctx = ctx or _native.default_context()
+    enc = []
+    for a, b in pairs:
+        br = a.encode('utf-8') if isinstance(a, str) else bytes(a)
+        bf = b.encode('utf-8') if isinstance(b, str) else bytes(b)
+        if len(br) < len(bf):
+            raise IndexError('string index out of range')
+        enc.append((br, bf))
+    lens = np.array([len(bf) for _, bf in enc], dtype=np.int32)
+    stride = max(16, (int(lens.max()) + 15) // 16 * 16)
+    a1 = np.zeros((n, stride), dtype=np.uint8)
+    a2 = np.zeros((n, stride), dtype=np.uint8)
+    for k, (br, bf) in enumerate(enc):
+        a1[k, :len(bf)] = np.frombuffer(br, dtype=np.uint8)[:len(bf)]
+        a2[k, :len(bf)] = np.frombuffer(bf, dtype=np.uint8)
+    index, values, counts = ctx.classify_lists_batch(a1, a2, lens, set_ids, include_sets, legacy=legacy)
+    out = []
+    for t in range(n):
+        res = {}
+        base = t * _native.LIST_COUNT
+        for k, name in enumerate(_LISTS):
+            v = values[index[base + k]:index[base + k + 1]].tolist()
+            if name in _PAIRS:
+                v = [(v[i], v[i + 1]) for i in range(0, len(v), 2)]
+            elif name in _CHARS:
+                v = np.array([chr(c) for c in v])
+            res[name] = v
+        out.append(_payload_legacy(res, counts[t]) if legacy else _payload(res, counts[t]))
+    return out
 
 
 def calculate_homology(a, b):

@@ -21,6 +21,7 @@ SYMBOLS = [
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
     "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_timing_read_split", "c2_count_vectors_device",
+    "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
 ]
 
 REC_DTYPE = np.dtype([
@@ -70,6 +71,13 @@ def load():
             lib.c2_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
             lib.c2_destroy.argtypes = [ctypes.c_void_p]
             lib.c2_destroy.restype = None
+            lib.c2_lists_total.restype = ctypes.c_uint64
+            lib.c2_lists_total.argtypes = [ctypes.c_void_p]
+            for fn in (lib.c2_lists_index, lib.c2_lists_values, lib.c2_lists_counts):
+                fn.restype = ctypes.c_void_p
+                fn.argtypes = [ctypes.c_void_p]
+            lib.c2_lists_free.restype = None
+            lib.c2_lists_free.argtypes = [ctypes.c_void_p]
             _lib = lib
     return _lib
 
@@ -168,6 +176,35 @@ class Context:
         a, b = ctypes.c_int32(0), ctypes.c_int32(0)
         self.check(self.lib.c2_band_info(self.handle, int(max_read_len), ctypes.byref(a), ctypes.byref(b)), "c2_band_info")
         return {"band_lanes": a.value, "fallback_tasks_last_launch": b.value}
+
+    def classify_lists_batch(self, aln_read, aln_ref, lens, set_ids, include_sets, legacy=False):
+        """c2_classify_lists_batch: aln_read / aln_ref uint8 [n, stride] (host), lens int32 [n], set_ids uint16 [n] or None,
+        include_sets: list of integer sequences.  -> (index int64 [n*15+1], values int32, counts int64 [n, 3])"""
+        a1 = np.ascontiguousarray(aln_read, dtype=np.uint8)
+        a2 = np.ascontiguousarray(aln_ref, dtype=np.uint8)
+        n, stride = a1.shape
+        ln = np.ascontiguousarray(lens, dtype=np.int32)
+        ids = None if set_ids is None else np.ascontiguousarray(set_ids, dtype=np.uint16)
+        sets = [np.asarray(list(x), dtype=np.int64).astype(np.int32) for x in include_sets]
+        off = np.zeros(len(sets) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([x.size for x in sets])
+        flat = np.ascontiguousarray(np.concatenate(sets) if sets and off[-1] else np.zeros(1, dtype=np.int32), dtype=np.int32)
+        h = ctypes.c_void_p()
+        self.check(self.lib.c2_classify_lists_batch(
+            self.handle, ctypes.c_uint64(n), a1.ctypes.data_as(ctypes.c_void_p), a2.ctypes.data_as(ctypes.c_void_p),
+            ctypes.c_uint32(stride), ln.ctypes.data_as(ctypes.c_void_p),
+            None if ids is None else ids.ctypes.data_as(ctypes.c_void_p), flat.ctypes.data_as(ctypes.c_void_p),
+            off.ctypes.data_as(ctypes.c_void_p), len(sets), int(bool(legacy)), ctypes.byref(h)), "c2_classify_lists_batch")
+        try:
+            tot = int(self.lib.c2_lists_total(h))
+            index = np.ctypeslib.as_array(ctypes.cast(self.lib.c2_lists_index(h), ctypes.POINTER(ctypes.c_int64)), (n * LIST_COUNT + 1,)).copy()
+            values = (np.ctypeslib.as_array(ctypes.cast(self.lib.c2_lists_values(h), ctypes.POINTER(ctypes.c_int32)), (tot,)).copy()
+                      if tot else np.zeros(0, dtype=np.int32))
+            counts = (np.ctypeslib.as_array(ctypes.cast(self.lib.c2_lists_counts(h), ctypes.POINTER(ctypes.c_int64)), (n, 3)).copy()
+                      if n else np.zeros((0, 3), dtype=np.int64))
+        finally:
+            self.lib.c2_lists_free(h)
+        return index, values, counts
 
     def tier_info(self):
         """Banded launches of the most recent batch and the number of tasks each left for the next one."""

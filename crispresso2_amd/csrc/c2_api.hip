@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <memory>
 
 #include "crispresso2_amd.h"
 #include "c2_device.h"
@@ -74,6 +75,7 @@ struct c2_ctx {
     int occ_diag_lds = -1, occ_diag_blocks = 0;
     int occ_x_lds[2] = {-1, -1}, occ_x_blocks[2] = {0, 0};   // [0] 4 alignments per wavefront, [1] 2
     DevBuf d_plane;        // pointer-word scratch of the multi-alignment diagonal kernels
+    DevBuf d_lists, d_lists_out;   // batched classifier: staging and flat output
     int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
     int occ_lds[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
     int occ_blocks[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -391,7 +393,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -778,6 +780,105 @@ int c2_find_indels_substitutions(c2_ctx* ctx, const char* read_aln, const char* 
     }
     return 0;
 }
+
+struct c2_lists {
+    std::vector<int64_t> index;    // n * C2_LIST_COUNT + 1 offsets into values
+    std::vector<int32_t> values;
+    std::vector<int64_t> counts;   // n x 3
+};
+
+int c2_classify_lists_batch(c2_ctx* ctx, uint64_t n, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t stride,
+                            const int32_t* lens, const uint16_t* set_ids, const int32_t* include_idx, const int64_t* include_off,
+                            int32_t n_sets, int32_t legacy, c2_lists** out) {
+    if (!ctx || !out || (n && (!aln_read || !aln_ref || !lens)) || n_sets < 1 || !include_off || stride == 0) {
+        if (ctx) ctx->err = "bad argument"; return C2_E_INVALID;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the include sets, each sorted and unique (Python's `in` / set.intersection semantics; any integers)
+    std::vector<int32_t> inc;
+    std::vector<int64_t> inc_off(1, 0);
+    for (int k = 0; k < n_sets; ++k) {
+        std::vector<int32_t> one(include_idx + include_off[k], include_idx + include_off[k + 1]);
+        std::sort(one.begin(), one.end());
+        one.erase(std::unique(one.begin(), one.end()), one.end());
+        inc.insert(inc.end(), one.begin(), one.end());
+        inc_off.push_back((int64_t)inc.size());
+    }
+    for (uint64_t t = 0; t < n; ++t) {
+        if (lens[t] < 0 || (uint32_t)lens[t] > stride) { ctx->err = "alignment longer than stride"; return C2_E_INVALID; }
+        if (set_ids && set_ids[t] >= n_sets) { ctx->err = "include set id out of range"; return C2_E_INVALID; }
+    }
+    std::unique_ptr<c2_lists> R(new c2_lists);
+    R->index.assign((size_t)n * C2_LIST_COUNT + 1, 0);
+    R->counts.assign((size_t)n * 3, 0);
+    hipStream_t s = ctx->stream;
+    const uint64_t CH = 32768;
+    std::vector<int32_t> llen;
+    std::vector<int64_t> loff;
+    int rc;
+    for (uint64_t c0 = 0; c0 < n; c0 += CH) {
+        const uint64_t m = std::min<uint64_t>(CH, n - c0);
+        // d_lists layout: [read m*stride][ref m*stride][lens m][set ids m][include][include_off][scratch m*stride*4][len m*15][off m*15*8][counts m*3*8]
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        size_t o = 0;
+        const size_t o_rd = o; o += al(m * stride);
+        const size_t o_rf = o; o += al(m * stride);
+        const size_t o_ln = o; o += al(m * 4);
+        const size_t o_id = o; o += al(m * 2);
+        const size_t o_inc = o; o += al(inc.size() * 4 + 4);
+        const size_t o_ioff = o; o += al(inc_off.size() * 8);
+        const size_t o_rp = o; o += al(m * (size_t)stride * 4);
+        const size_t o_len = o; o += al(m * C2_LIST_COUNT * 4);
+        const size_t o_off = o; o += al(m * C2_LIST_COUNT * 8);
+        const size_t o_cnt = o; o += al(m * 3 * 8);
+        if ((rc = ensure(ctx, ctx->d_lists, o))) return rc;
+        uint8_t* base = (uint8_t*)ctx->d_lists.p;
+        HIPCHK(ctx, hipMemcpyAsync(base + o_rd, aln_read + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_rf, aln_ref + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_ln, lens + c0, m * 4, hipMemcpyHostToDevice, s));
+        if (set_ids) HIPCHK(ctx, hipMemcpyAsync(base + o_id, set_ids + c0, m * 2, hipMemcpyHostToDevice, s));
+        if (!inc.empty()) HIPCHK(ctx, hipMemcpyAsync(base + o_inc, inc.data(), inc.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_ioff, inc_off.data(), inc_off.size() * 8, hipMemcpyHostToDevice, s));
+        c2_classify_batch_args A;
+        A.aln_read = base + o_rd; A.aln_ref = base + o_rf; A.lens = (const int32_t*)(base + o_ln);
+        A.set_ids = set_ids ? (const uint16_t*)(base + o_id) : nullptr;
+        A.include_sorted = (const int32_t*)(base + o_inc); A.include_off = (const int64_t*)(base + o_ioff);
+        A.n = m; A.stride = stride; A.legacy = legacy ? 1 : 0; A.pass = 0; A.reserved = 0;
+        A.scratch_rp = (int32_t*)(base + o_rp); A.list_len = (int32_t*)(base + o_len); A.list_off = (const int64_t*)(base + o_off);
+        A.values = nullptr; A.counts = (int64_t*)(base + o_cnt);
+        const unsigned grid = (unsigned)((m + 63) / 64);
+        hipLaunchKernelGGL(c2_classify_lists_batch_kernel, dim3(grid), dim3(64), 0, s, A);
+        HIPCHK(ctx, hipGetLastError());
+        llen.resize(m * C2_LIST_COUNT);
+        HIPCHK(ctx, hipMemcpyAsync(llen.data(), base + o_len, llen.size() * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(R->counts.data() + c0 * 3, base + o_cnt, m * 3 * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        loff.resize(llen.size());
+        int64_t tot = 0;
+        for (size_t k = 0; k < llen.size(); ++k) { loff[k] = tot; tot += llen[k]; }
+        const int64_t g0 = (int64_t)R->values.size();
+        for (size_t k = 0; k < llen.size(); ++k) R->index[c0 * C2_LIST_COUNT + k] = g0 + loff[k];
+        R->values.resize((size_t)(g0 + tot));
+        R->index[(c0 + m) * C2_LIST_COUNT] = g0 + tot;
+        if (tot > 0) {
+            if ((rc = ensure(ctx, ctx->d_lists_out, (size_t)tot * 4))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(base + o_off, loff.data(), loff.size() * 8, hipMemcpyHostToDevice, s));
+            A.pass = 1; A.values = (int32_t*)ctx->d_lists_out.p;
+            hipLaunchKernelGGL(c2_classify_lists_batch_kernel, dim3(grid), dim3(64), 0, s, A);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(R->values.data() + g0, ctx->d_lists_out.p, (size_t)tot * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipStreamSynchronize(s));
+        }
+    }
+    *out = R.release();
+    return 0;
+}
+
+uint64_t c2_lists_total(const c2_lists* r) { return r ? (uint64_t)r->values.size() : 0; }
+const int64_t* c2_lists_index(const c2_lists* r) { return r ? r->index.data() : nullptr; }
+const int32_t* c2_lists_values(const c2_lists* r) { return r ? r->values.data() : nullptr; }
+const int64_t* c2_lists_counts(const c2_lists* r) { return r ? r->counts.data() : nullptr; }
+void c2_lists_free(c2_lists* r) { delete r; }
 
 int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out) {
     if (!ctx || !a || !b || !out || n < 0) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }

@@ -86,6 +86,26 @@ typedef struct c2_classify_args {
     int64_t* counts;              // insertion_n, deletion_n, substitution_n
 } c2_classify_args;
 
+// Batched classifier (c2_classify_lists_batch_kernel): one lane per alignment, two passes.
+typedef struct c2_classify_batch_args {
+    const uint8_t* aln_read;      // n x stride
+    const uint8_t* aln_ref;
+    const int32_t* lens;          // n: columns of each alignment (<= stride)
+    const uint16_t* set_ids;      // n: which include set, or NULL (set 0)
+    const int32_t* include_sorted;// the include sets, each sorted and unique, back to back
+    const int64_t* include_off;   // n_sets + 1 offsets into include_sorted
+    uint64_t n;
+    uint32_t stride;
+    int32_t legacy;
+    int32_t pass;                 // 0: count list lengths, 1: write the lists
+    int32_t reserved;
+    int32_t* scratch_rp;          // pass 0: n x stride reference positions (the walk reads them back)
+    int32_t* list_len;            // n x C2_LIST_COUNT: written by pass 0, read by pass 1
+    const int64_t* list_off;      // n x C2_LIST_COUNT offsets into values (pass 1)
+    int32_t* values;              // pass 1 output
+    int64_t* counts;              // n x 3: insertion_n, deletion_n, substitution_n (pass 0)
+} c2_classify_batch_args;
+
 // ---- per-amplicon count tensor (what CRISPRessoCORE.py:3865-3901 keeps per reference and :4016-4115 fills) ----
 // One int64 block per reference: C2_CNT_VECTORS vectors of (lmax + 1) entries, then C2_CNT_SCALARS scalars,
 // then C2_CNT_HISTS histograms of hl entries.  crispresso2_amd/counts.py names the slices.

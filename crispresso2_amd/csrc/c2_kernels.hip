@@ -1415,17 +1415,15 @@ __device__ inline bool c2_inc_hits(const int32_t* inc, int n, int a, int b) {
     return lo < n && inc[lo] < b;
 }
 
-__global__ __launch_bounds__(64) void c2_classify_lists_kernel(c2_classify_args A)
+// The column walk of one alignment by one lane; the caller owns the list writers (L[C2_LIST_REF_POSITIONS] must have
+// room for all n entries: the walk reads them back).
+__device__ __forceinline__ void c2_classify_walk(const uint8_t* rd, const uint8_t* rf, const int n, const int32_t* inc, const int ni,
+                                                 const int legacy, c2_list_writer (&L)[C2_LIST_COUNT], int64_t& ins_n, int64_t& del_n)
 {
-    if (threadIdx.x != 0) return;
-    c2_list_writer L[C2_LIST_COUNT];
-    for (int k = 0; k < C2_LIST_COUNT; ++k) { L[k].base = A.lists + (size_t)k * A.cap; L[k].cap = A.cap; L[k].n = 0; }
-    const uint8_t* rd = A.read_al; const uint8_t* rf = A.ref_al;
-    const int32_t* inc = A.include_sorted; const int ni = A.n_include; const int n = A.n;
-    int32_t* rp = L[C2_LIST_REF_POSITIONS].base;       // cap >= n is guaranteed by the host
-    int64_t ins_n = 0, del_n = 0;
+    int32_t* rp = L[C2_LIST_REF_POSITIONS].base;
+    ins_n = 0; del_n = 0;
     int idx = 0;
-    if (!A.legacy) {
+    if (!legacy) {
         int start_deletion = -1, start_insertion = -1, cur_ins = 0;                  // pyx:94,101,109
         for (int c = 0; c < n; ++c) {                                                 // pyx:110
             if (rf[c] != '-') {
@@ -1523,8 +1521,46 @@ __global__ __launch_bounds__(64) void c2_classify_lists_kernel(c2_classify_args 
             st = en;
         }
     }
+}
+
+__global__ __launch_bounds__(64) void c2_classify_lists_kernel(c2_classify_args A)
+{
+    if (threadIdx.x != 0) return;
+    c2_list_writer L[C2_LIST_COUNT];
+    for (int k = 0; k < C2_LIST_COUNT; ++k) { L[k].base = A.lists + (size_t)k * A.cap; L[k].cap = A.cap; L[k].n = 0; }
+    int64_t ins_n, del_n;
+    c2_classify_walk(A.read_al, A.ref_al, A.n, A.include_sorted, A.n_include, A.legacy, L, ins_n, del_n);   // cap >= n is guaranteed by the host
     for (int k = 0; k < C2_LIST_COUNT; ++k) A.list_len[k] = L[k].n;
     A.counts[0] = ins_n; A.counts[1] = del_n; A.counts[2] = L[C2_LIST_SUBSTITUTION_POSITIONS].n;
+}
+
+// Batched form: one LANE per alignment (the walk is serial in the column index; alignments are independent), two passes
+// over the same walk -- pass 0 counts the 15 list lengths (reference positions go to a scratch row), the host turns the
+// lengths into offsets, pass 1 writes every list at its place in one flat int32 array.  Used by
+// crispresso2_amd.variants.get_new_variant_objects (one launch pair per 32 k alignments instead of one launch each).
+__global__ __launch_bounds__(64) void c2_classify_lists_batch_kernel(c2_classify_batch_args A)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (t >= A.n) return;
+    const int set = A.set_ids ? (int)A.set_ids[t] : 0;
+    const int32_t* inc = A.include_sorted + A.include_off[set];
+    const int ni = (int)(A.include_off[set + 1] - A.include_off[set]);
+    const int n = A.lens[t];
+    c2_list_writer L[C2_LIST_COUNT];
+#pragma unroll
+    for (int k = 0; k < C2_LIST_COUNT; ++k) {
+        if (A.pass == 0) { L[k].base = nullptr; L[k].cap = 0; }
+        else { L[k].base = A.values + A.list_off[t * C2_LIST_COUNT + k]; L[k].cap = A.list_len[t * C2_LIST_COUNT + k]; }
+        L[k].n = 0;
+    }
+    if (A.pass == 0) { L[C2_LIST_REF_POSITIONS].base = A.scratch_rp + t * (uint64_t)A.stride; L[C2_LIST_REF_POSITIONS].cap = (int32_t)A.stride; }
+    int64_t ins_n, del_n;
+    c2_classify_walk(A.aln_read + t * (uint64_t)A.stride, A.aln_ref + t * (uint64_t)A.stride, n, inc, ni, A.legacy, L, ins_n, del_n);
+    if (A.pass == 0) {
+#pragma unroll
+        for (int k = 0; k < C2_LIST_COUNT; ++k) A.list_len[t * C2_LIST_COUNT + k] = L[k].n;
+        A.counts[t * 3] = ins_n; A.counts[t * 3 + 1] = del_n; A.counts[t * 3 + 2] = L[C2_LIST_SUBSTITUTION_POSITIONS].n;
+    }
 }
 
 // calculate_homology, COREResources.pyx:318-327 (float32 accumulator; result = score / strlen(a))

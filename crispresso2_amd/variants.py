@@ -79,9 +79,14 @@ def align_all(args, fastq_seqs, refs, ref_names, aln_matrix, ctx=None):
 
 
 def get_new_variant_objects(args, fastq_seqs, refs, ref_names, aln_matrix, pe_scaffold_dna_info=None, ctx=None):
-    """One result dict per read, equal to get_new_variant_object(args, seq, refs, ref_names, aln_matrix, pe_info)."""
+    """One result dict per read, equal to get_new_variant_object(args, seq, refs, ref_names, aln_matrix, pe_info).
+    Alignments: one batch per reference (align_all); classifier payloads of all best alignments: one batched call
+    (c2_classify_lists_batch) instead of one find_indels_substitutions launch per read."""
+    ctx = ctx or _native.default_context()
     per_read = align_all(args, fastq_seqs, refs, ref_names, aln_matrix, ctx=ctx)
-    variants = []
+    ref_index = {name: r for r, name in enumerate(ref_names)}
+    chosen = []                                                    # per read: scores, details and the best matches (:689-707)
+    jobs, job_sets = [], []                                        # (s1, s2) of every best match, and its reference
     for k in range(len(fastq_seqs)):
         aln_scores = []
         best_match_score = -1
@@ -101,6 +106,19 @@ def get_new_variant_objects(args, fastq_seqs, refs, ref_names, aln_matrix, pe_sc
                 best_match_s2s.append(s2)
                 best_match_names.append(ref_name)
                 best_match_strands.append(strand)
+        first_job = len(jobs)
+        if best_match_score > 0:
+            for idx, name in enumerate(best_match_names):
+                jobs.append((best_match_s1s[idx], best_match_s2s[idx]))
+                job_sets.append(ref_index[name])
+        chosen.append((aln_scores, ref_aln_details, best_match_score, best_match_s1s, best_match_s2s, best_match_names,
+                       best_match_strands, first_job))
+    payloads = CRISPRessoCOREResources.find_indels_substitutions_batch(
+        jobs, [refs[name]['include_idxs'] for name in ref_names], set_ids=np.array(job_sets, dtype=np.uint16),
+        legacy=bool(args.use_legacy_insertion_quantification), ctx=ctx)
+    variants = []
+    for k in range(len(fastq_seqs)):
+        aln_scores, ref_aln_details, best_match_score, best_match_s1s, best_match_s2s, best_match_names, best_match_strands, first_job = chosen[k]
         new_variant = {'count': 1}
         if best_match_score <= 0:                                  # not aligned: scores only (:767-773)
             new_variant['aln_scores'] = aln_scores
@@ -115,10 +133,7 @@ def get_new_variant_objects(args, fastq_seqs, refs, ref_names, aln_matrix, pe_sc
         class_names = []
         for idx, best_match_name in enumerate(best_match_names):
             s1, s2 = best_match_s1s[idx], best_match_s2s[idx]
-            if args.use_legacy_insertion_quantification:
-                payload = CRISPRessoCOREResources.find_indels_substitutions_legacy(s1, s2, refs[best_match_name]['include_idxs'])
-            else:
-                payload = CRISPRessoCOREResources.find_indels_substitutions(s1, s2, refs[best_match_name]['include_idxs'])
+            payload = payloads[first_job + idx]                    # find_indels_substitutions[_legacy](s1, s2, include_idxs), :721-724
             payload['ref_name'] = best_match_name
             payload['aln_scores'] = aln_scores
             payload['irregular_ends'] = bool(s1[0] == '-' or s2[0] == '-' or s1[0] != s2[0]

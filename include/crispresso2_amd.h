@@ -220,6 +220,22 @@ int c2_find_indels_substitutions(c2_ctx* ctx, const char* read_aln, const char* 
 /* calculate_homology(a, b), COREResources.pyx:318-327: matches over strlen(a), float32 accumulator. */
 int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out);
 
+/* Batched find_indels_substitutions[_legacy] (CRISPRessoCOREResources.pyx:68-187 / :190-315): the per-read classifier calls of
+ * get_new_variant_object (CRISPRessoCORE.py:721-724) for n alignments in a few launches.  Host pointers.  aln_read / aln_ref:
+ * n rows of `stride` bytes, lens[t] columns valid in row t; set_ids[t] (NULL = 0) picks one of n_sets include sets,
+ * include_idx[include_off[k] .. include_off[k+1]) (any integers, any order).  The result owns three arrays:
+ * index[n * C2_LIST_COUNT + 1] (list k of alignment t is values[index[t*C2_LIST_COUNT+k] .. index[t*C2_LIST_COUNT+k+1]), C2_LIST_* order),
+ * values, counts[n][3] = insertion_n, deletion_n, substitution_n. */
+typedef struct c2_lists c2_lists;
+int c2_classify_lists_batch(c2_ctx* ctx, uint64_t n, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t stride,
+                            const int32_t* lens, const uint16_t* set_ids, const int32_t* include_idx, const int64_t* include_off,
+                            int32_t n_sets, int32_t legacy, c2_lists** out);
+uint64_t c2_lists_total(const c2_lists* r);
+const int64_t* c2_lists_index(const c2_lists* r);
+const int32_t* c2_lists_values(const c2_lists* r);
+const int64_t* c2_lists_counts(const c2_lists* r);
+void c2_lists_free(c2_lists* r);
+
 /* Profiling aid: while enabled, every launch adds the shader cycles each workgroup spends in the four phases of a task
  * (0 fetch, 1 DP fill, 2 traceback, 3 output+classification) to four device counters.  The call first copies the
  * counters to out4 (may be NULL) and clears them, then sets the mode. */

@@ -154,6 +154,28 @@ int emu_classify_lists(const uint8_t* read_al, const uint8_t* ref_al, int n, con
     return 0;
 }
 
+// batched classifier: pass 0 (lengths), host prefix sum, pass 1 (values) -- the host library's sequence
+int emu_classify_lists_batch(uint64_t n, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t stride, const int32_t* lens,
+                             const uint16_t* set_ids, const int32_t* include_sorted, const int64_t* include_off, int legacy,
+                             int64_t* index /* n*15+1 */, int32_t* values, int64_t values_cap, int64_t* counts /* n*3 */)
+{
+    std::vector<int32_t> scratch((size_t)n * stride), llen((size_t)n * C2_LIST_COUNT);
+    std::vector<int64_t> loff((size_t)n * C2_LIST_COUNT);
+    c2_classify_batch_args A;
+    A.aln_read = aln_read; A.aln_ref = aln_ref; A.lens = lens; A.set_ids = set_ids; A.include_sorted = include_sorted;
+    A.include_off = include_off; A.n = n; A.stride = stride; A.legacy = legacy; A.pass = 0; A.reserved = 0;
+    A.scratch_rp = scratch.data(); A.list_len = llen.data(); A.list_off = loff.data(); A.values = nullptr; A.counts = counts;
+    const unsigned grid = (unsigned)((n + 63) / 64);
+    emu::launch(grid, [&] { c2_classify_lists_batch_kernel(A); });
+    int64_t tot = 0;
+    for (size_t k = 0; k < llen.size(); ++k) { loff[k] = tot; index[k] = tot; tot += llen[k]; }
+    index[llen.size()] = tot;
+    if (tot > values_cap) return -6;
+    A.pass = 1; A.values = values;
+    emu::launch(grid, [&] { c2_classify_lists_batch_kernel(A); });
+    return 0;
+}
+
 int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t aln_stride,
                       const c2_aln_record* records, const uint32_t* weights, const uint16_t* min_matches, int max_t,
                       int n_refs, const int32_t* lens, const int32_t* const* include_idx, const int32_t* n_include,

@@ -104,6 +104,32 @@ def classify_lists(read_al, ref_al, include, legacy=False):
     return [lists[k, :lens[k]].tolist() for k in range(N_LISTS)], counts.tolist()
 
 
+def classify_lists_batch(pairs, includes, legacy=False):
+    """pairs: [(read_al, ref_al)], includes: one include collection per pair -> per pair ([15 lists], [3 counts])"""
+    n = len(pairs)
+    lens = np.array([len(b) for _, b in pairs], dtype=np.int32)
+    stride = int(lens.max()) + 3
+    a1 = np.zeros((n, stride), dtype=np.uint8); a2 = np.zeros((n, stride), dtype=np.uint8)
+    for k, (a, b) in enumerate(pairs):
+        a1[k, :len(b)] = np.frombuffer(a.encode(), dtype=np.uint8)[:len(b)]
+        a2[k, :len(b)] = np.frombuffer(b.encode(), dtype=np.uint8)
+    sets = [np.array(sorted(set(int(x) for x in inc)), dtype=np.int32) for inc in includes]
+    off = np.zeros(n + 1, dtype=np.int64); off[1:] = np.cumsum([x.size for x in sets])
+    flat = np.ascontiguousarray(np.concatenate(sets + [np.zeros(1, dtype=np.int32)]), dtype=np.int32)
+    ids = np.arange(n, dtype=np.uint16)
+    index = np.zeros(n * N_LISTS + 1, dtype=np.int64)
+    cap = int(lens.sum()) * 12 + 1024
+    values = np.zeros(cap, dtype=np.int32)
+    counts = np.zeros((n, 3), dtype=np.int64)
+    rc = lib().emu_classify_lists_batch(ctypes.c_uint64(n), a1.ctypes.data_as(ctypes.c_void_p), a2.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_uint32(stride), lens.ctypes.data_as(ctypes.c_void_p), ids.ctypes.data_as(ctypes.c_void_p),
+                                        flat.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p), int(legacy),
+                                        index.ctypes.data_as(ctypes.c_void_p), values.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(cap),
+                                        counts.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, rc
+    return [([values[index[t * N_LISTS + k]:index[t * N_LISTS + k + 1]].tolist() for k in range(N_LISTS)], counts[t].tolist()) for t in range(n)]
+
+
 def count_vectors(aln_read, aln_ref, records, ref_lens, includes, max_read_len, weights=None, min_matches=None, flags=0, grid=2):
     """aln_read/aln_ref: uint8 [n, stride]; records: REC_DTYPE [n].  -> (counts int64 [n_refs, per_ref], layout)"""
     import sys

@@ -149,6 +149,22 @@ def test_classify_lists_fuzz_vectors(ctx):
     assert n_legacy >= 100
 
 
+def test_classify_lists_batch_equals_per_call_answers(ctx):
+    """c2_classify_lists_batch (one lane per alignment, count pass + write pass) on all the reference-generated classifier
+    vectors at once -- every vector with its own include set, negative-coordinate quirk cases included."""
+    from crispresso2_amd import CRISPRessoCOREResources as R
+    vecs = load_golden("fuzz_classify.json")
+    for legacy in (False, True):
+        vs = [v for v in vecs if v["fn"].endswith("legacy") == legacy]
+        assert len(vs) >= 100
+        out = R.find_indels_substitutions_batch([(v["read_al"], v["ref_al"]) for v in vs], [v["include"] for v in vs],
+                                                set_ids=np.arange(len(vs), dtype=np.uint16), legacy=legacy)
+        assert len(out) == len(vs)
+        for p, v in zip(out, vs):
+            assert payload_diff(p, v["out"]) == [], v
+    assert R.find_indels_substitutions_batch([], [[1]]) == []
+
+
 def test_calculate_homology(ctx):
     from crispresso2_amd import CRISPRessoCOREResources as R
     import oracle

@@ -227,9 +227,19 @@ def test_emulated_classify_lists(mats):
              "all_substitution_values", "substitution_positions", "substitution_values"]
     vecs = load_golden("fuzz_classify.json") + [k for k in load_golden("ref_unit_kats.json") if k["fn"].startswith("find_indels")]
     n_legacy = 0
-    for v in vecs:
+    # the batched kernel (one lane per alignment, count pass + write pass) must give the per-call kernel's lists
+    batched = {}
+    for legacy in (False, True):
+        vs = [(k, v) for k, v in enumerate(vecs) if v["fn"].endswith("legacy") == legacy][:150]
+        outs = E.classify_lists_batch([(v["read_al"], v["ref_al"]) for _, v in vs], [v["include"] for _, v in vs], legacy=legacy)
+        for (k, _), o in zip(vs, outs):
+            batched[k] = o
+    assert len(batched) >= 200
+    for kv, v in enumerate(vecs):
         legacy = v["fn"].endswith("legacy")
         lists, counts = E.classify_lists(v["read_al"], v["ref_al"], v["include"], legacy=legacy)
+        if kv in batched:
+            assert batched[kv] == (lists, counts), v
         got = dict(zip(order, lists))
         for f in ("insertion_coordinates", "all_deletion_coordinates", "deletion_coordinates"):
             got[f] = [[got[f][k], got[f][k + 1]] for k in range(0, len(got[f]), 2)]
