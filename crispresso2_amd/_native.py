@@ -22,6 +22,8 @@ SYMBOLS = [
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
     "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_timing_read_split", "c2_count_vectors_device",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
+    "c2_fastq_unique", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
+    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error",
 ]
 
 REC_DTYPE = np.dtype([
@@ -78,6 +80,16 @@ def load():
                 fn.argtypes = [ctypes.c_void_p]
             lib.c2_lists_free.restype = None
             lib.c2_lists_free.argtypes = [ctypes.c_void_p]
+            for fn in (lib.c2_fastq_n_unique, lib.c2_fastq_n_reads, lib.c2_fastq_arena_bytes):
+                fn.restype = ctypes.c_uint64
+                fn.argtypes = [ctypes.c_void_p]
+            for fn in (lib.c2_fastq_arena, lib.c2_fastq_offsets, lib.c2_fastq_counts):
+                fn.restype = ctypes.c_void_p
+                fn.argtypes = [ctypes.c_void_p]
+            lib.c2_fastq_free.restype = None
+            lib.c2_fastq_free.argtypes = [ctypes.c_void_p]
+            lib.c2_fastq_last_error.restype = ctypes.c_char_p
+            lib.c2_fastq_unique.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
             _lib = lib
     return _lib
 
@@ -223,6 +235,28 @@ class Context:
         v = [ctypes.c_int32(0) for _ in range(5)]
         self.check(self.lib.c2_launch_info(self.handle, int(max_read_len), *[ctypes.byref(x) for x in v]), "c2_launch_info")
         return dict(zip(("rows_per_lane", "passes", "lds_bytes", "workgroups_per_cu", "compute_units"), [x.value for x in v]))
+
+
+def fastq_unique(path):
+    """c2_fastq_unique (host code, needs no GPU): -> (arena uint8, offsets uint64 [n_unique+1], counts uint32 [n_unique], n_reads)
+    -- the unique sequences of the FASTQ in first-seen order, packed as the align kernels take them."""
+    lib = load()
+    h = ctypes.c_void_p()
+    rc = lib.c2_fastq_unique(os.fsencode(path), ctypes.byref(h))
+    if rc != 0:
+        raise NativeError("c2_fastq_unique: %s" % lib.c2_fastq_last_error().decode())
+    try:
+        n = int(lib.c2_fastq_n_unique(h))
+        nb = int(lib.c2_fastq_arena_bytes(h))
+        arena = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_arena(h), ctypes.POINTER(ctypes.c_uint8)), (nb,)).copy()
+                 if nb else np.zeros(0, dtype=np.uint8))
+        offsets = np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_offsets(h), ctypes.POINTER(ctypes.c_uint64)), (n + 1,)).copy()
+        counts = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_counts(h), ctypes.POINTER(ctypes.c_uint32)), (n,)).copy()
+                  if n else np.zeros(0, dtype=np.uint32))
+        total = int(lib.c2_fastq_n_reads(h))
+    finally:
+        lib.c2_fastq_free(h)
+    return arena, offsets, counts, total
 
 
 _default_ctx = None

@@ -1,0 +1,338 @@
+// c2_fastq.cpp -- FASTQ ingest + exact de-duplication on the host.
+//
+// Replaces the first pass of process_fastq (reference CRISPResso2/CRISPRessoCORE.py:1820-1849): a Python readline loop
+// over the (optionally gzip'ed) FASTQ that builds `variantCache[sequence] = number of copies`.  Same semantics:
+//   * text mode with universal newlines: a line ends at "\n", "\r\n" or a lone "\r" (open(..., 'rt') / gzip.open(x, 'rt'));
+//   * records are taken four lines at a time starting from any non-empty first line; nothing is validated;
+//   * the sequence is line 2 with str.strip() applied (ASCII whitespace incl. \x0b \x0c \x1c-\x1f); no upper-casing;
+//   * a record cut short by the end of the file still counts (its sequence may be empty);
+//   * unique sequences keep first-seen order (Python dict order), counts are exact.
+// Output: the unique sequences packed back to back (the byte arena + offsets the align kernels take) and their counts.
+// No GPU involved; zlib inflates .gz input (concatenated members too, like Python's gzip module).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <thread>
+#include <memory>
+
+#include "crispresso2_amd.h"
+
+struct c2_fastq {
+    std::vector<uint8_t> arena;
+    std::vector<uint64_t> offsets;     // n_unique + 1
+    std::vector<uint32_t> counts;      // n_unique
+    uint64_t n_reads = 0;
+};
+
+namespace {
+
+thread_local std::string g_fastq_error;
+
+inline bool py_space(uint8_t c) { return (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x20); }
+
+// 64-bit hash of a byte string (multiply-fold over 8-byte words); quality only matters for table occupancy
+inline uint64_t hash_bytes(const uint8_t* p, size_t n) {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n * 0xff51afd7ed558ccdull;
+    while (n >= 8) {
+        uint64_t w; memcpy(&w, p, 8);
+        h = (h ^ w) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+        p += 8; n -= 8;
+    }
+    uint64_t w = 0;
+    if (n) memcpy(&w, p, n);
+    h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32;
+    return h;
+}
+
+struct Dedup {
+    c2_fastq* R;
+    std::vector<uint32_t> table;       // open addressing, 0 = empty, else index + 1
+    std::vector<uint64_t> hashes;      // per unique sequence
+    uint64_t mask = 0;
+    explicit Dedup(c2_fastq* r) : R(r) { table.assign(1u << 16, 0); mask = table.size() - 1; R->offsets.push_back(0); }
+    void grow() {
+        std::vector<uint32_t> t(table.size() * 2, 0);
+        const uint64_t m = t.size() - 1;
+        for (uint32_t k = 0; k < (uint32_t)hashes.size(); ++k) {
+            uint64_t pos = hashes[k] & m;
+            while (t[pos]) pos = (pos + 1) & m;
+            t[pos] = k + 1;
+        }
+        table.swap(t); mask = m;
+    }
+    bool add(const uint8_t* s, size_t n, uint32_t copies = 1) {
+        const uint64_t h = hash_bytes(s, n);
+        uint64_t pos = h & mask;
+        while (table[pos]) {
+            const uint32_t k = table[pos] - 1;
+            if (hashes[k] == h) {
+                const uint64_t o = R->offsets[k];
+                if (R->offsets[k + 1] - o == n && (n == 0 || memcmp(R->arena.data() + o, s, n) == 0)) { R->counts[k] += copies; return true; }
+            }
+            pos = (pos + 1) & mask;
+        }
+        if (hashes.size() >= 0xfffffffeull) return false;
+        table[pos] = (uint32_t)hashes.size() + 1;
+        hashes.push_back(h);
+        R->arena.insert(R->arena.end(), s, s + n);
+        R->offsets.push_back((uint64_t)R->arena.size());
+        R->counts.push_back(copies);
+        if (hashes.size() * 2 > table.size()) grow();
+        return true;
+    }
+};
+
+// Line splitter with Python's universal-newline rule, fed block by block.
+struct Lines {
+    Dedup& D;
+    std::string cur;                   // the line being assembled (without its terminator)
+    bool pending_cr = false;           // last block ended in '\r': a following '\n' belongs to the same terminator
+    int line_in_record = 0;            // 0 id, 1 sequence, 2 plus, 3 quality
+    bool in_record = false;
+    bool ok = true;
+    explicit Lines(Dedup& d) : D(d) {}
+    // a complete line (terminated, or the unterminated tail of the file when `at_eof`)
+    void line(const char* p, size_t n, bool terminated) {
+        // readline() returns '' only at EOF: an unterminated empty tail is "no line"
+        if (!terminated && n == 0) return;
+        if (!in_record) { in_record = true; line_in_record = 0; }     // any non-empty readline() result starts a record
+        if (line_in_record == 1) {
+            const uint8_t* s = (const uint8_t*)p; size_t len = n;
+            while (len && py_space(s[0])) { ++s; --len; }
+            while (len && py_space(s[len - 1])) --len;
+            if (!D.add(s, len)) ok = false;
+            ++D.R->n_reads;
+        }
+        if (++line_in_record == 4) in_record = false;
+    }
+    void feed(const char* buf, size_t n) {
+        size_t i = 0;
+        if (pending_cr) { pending_cr = false; if (n && buf[0] == '\n') i = 1; }
+        if (memchr(buf + i, '\r', n - i) == nullptr) {
+            // fast path (no carriage return in this block): lines end at '\n', found with memchr; the three lines of a
+            // record that are not the sequence are skipped without looking at their bytes
+            size_t start = i;
+            while (start < n) {
+                const char* nl = (const char*)memchr(buf + start, '\n', n - start);
+                if (!nl) break;
+                const size_t end = (size_t)(nl - buf);
+                if (cur.empty()) line(buf + start, end - start, true);
+                else { cur.append(buf + start, end - start); line(cur.data(), cur.size(), true); cur.clear(); }
+                start = end + 1;
+            }
+            if (start < n) {
+                // keep only what a later line() call needs: the bytes of a sequence line, one marker byte otherwise
+                if (in_record && line_in_record == 1) cur.append(buf + start, n - start);
+                else if (cur.empty()) cur.push_back('x');
+            }
+            return;
+        }
+        size_t start = i;
+        for (; i < n; ++i) {
+            const char c = buf[i];
+            if (c != '\n' && c != '\r') continue;
+            if (cur.empty()) line(buf + start, i - start, true);
+            else { cur.append(buf + start, i - start); line(cur.data(), cur.size(), true); cur.clear(); }
+            if (c == '\r') { if (i + 1 < n) { if (buf[i + 1] == '\n') ++i; } else pending_cr = true; }
+            start = i + 1;
+        }
+        if (start < n) cur.append(buf + start, n - start);
+    }
+    void finish() {
+        if (!cur.empty()) { line(cur.data(), cur.size(), false); cur.clear(); }
+        // a record whose sequence line never came: the reference's readline() returned '' and ''.strip() was counted
+        if (in_record && line_in_record == 1) { if (!D.add((const uint8_t*)"", 0)) ok = false; ++D.R->n_reads; }
+    }
+};
+
+
+// ---- plain (not gzip'ed) files: the mapped file is cut into byte ranges parsed by one thread each.  The reference frames
+// records by LINE NUMBER (four readline() calls per record from the top of the file, whatever the lines contain), so
+// the ranges first count their line terminators; a prefix sum gives every range the number of the first line that starts
+// inside it, and line numbers 1 mod 4 are sequence lines.  Per-range tables are merged in file order, which reproduces
+// the global first-seen order.
+inline bool term_end(const char* b, size_t n, size_t p) {      // does a line terminator END at byte p?
+    return b[p] == '\n' || (b[p] == '\r' && (p + 1 >= n || b[p + 1] != '\n'));
+}
+
+uint64_t count_terminators(const char* b, size_t n, size_t lo, size_t hi) {
+    uint64_t c = 0;
+    if (memchr(b + lo, '\r', hi - lo) == nullptr) {
+        for (size_t i = lo; i < hi; ++i) c += (b[i] == '\n');
+        return c;
+    }
+    for (size_t i = lo; i < hi; ++i) c += term_end(b, n, i) ? 1 : 0;
+    return c;
+}
+
+struct RangeResult { c2_fastq R; Dedup D; uint64_t n_seq = 0; bool ok = true; RangeResult() : D(&R) {} };
+
+// lines that START in [lo, hi); `line_no` = number of the first of them
+void parse_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t line_no, RangeResult* out) {
+    Dedup& D = out->D;
+    size_t pos = lo;
+    if (lo > 0 && !term_end(b, n, lo - 1)) {                    // lo is inside a line that started earlier: skip to its end
+        while (pos < n && !term_end(b, n, pos)) ++pos;
+        ++pos;
+    }
+    const bool has_cr = memchr(b + lo, '\r', (hi < n ? hi : n) - lo) != nullptr;
+    while (pos < hi && pos < n) {
+        size_t end;                                              // first byte of the terminator, or n
+        if (!has_cr) {
+            const char* nl = (const char*)memchr(b + pos, '\n', n - pos);
+            end = nl ? (size_t)(nl - b) : n;
+            // a '\r' may still sit beyond hi, inside a line that starts here
+            if (end > hi) { const char* cr = (const char*)memchr(b + pos, '\r', end - pos); if (cr) end = (size_t)(cr - b); }
+        } else {
+            end = pos;
+            while (end < n && b[end] != '\n' && b[end] != '\r') ++end;
+        }
+        if ((line_no & 3) == 1) {
+            const uint8_t* s = (const uint8_t*)b + pos; size_t len = end - pos;
+            while (len && py_space(s[0])) { ++s; --len; }
+            while (len && py_space(s[len - 1])) --len;
+            if (!D.add(s, len)) { out->ok = false; return; }
+            ++out->n_seq;
+        }
+        ++line_no;
+        if (end >= n) break;
+        pos = end + ((b[end] == '\r' && end + 1 < n && b[end + 1] == '\n') ? 2 : 1);
+    }
+}
+
+int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads) {
+    std::vector<size_t> cut(threads + 1);
+    for (unsigned t = 0; t <= threads; ++t) cut[t] = (size_t)((unsigned __int128)n * t / threads);
+    std::vector<uint64_t> terms(threads, 0);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] { terms[t] = count_terminators(b, n, cut[t], cut[t + 1]); });
+        for (auto& th : pool) th.join();
+    }
+    // number of the first line that starts at or after cut[t]: lines started before = 1 + terminators ending before cut[t] - 1
+    std::vector<uint64_t> first(threads, 0);
+    uint64_t before = 0;                                         // terminators ending at positions < cut[t]
+    for (unsigned t = 0; t < threads; ++t) {
+        if (t == 0) first[t] = 0;
+        else first[t] = before + (term_end(b, n, cut[t] - 1) ? 0 : 1);    // a line that starts exactly at cut[t] has number `before`
+        before += terms[t];
+    }
+    const uint64_t total_terms = before;
+    std::vector<std::unique_ptr<RangeResult>> res(threads);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) {
+            res[t].reset(new RangeResult);
+            pool.emplace_back([&, t] { parse_range(b, n, cut[t], cut[t + 1], first[t], res[t].get()); });
+        }
+        for (auto& th : pool) th.join();
+    }
+    // merge in file order; the first range's table becomes the global one (no copy of its sequences)
+    if (!res[0]->ok) return C2_E_TOO_LARGE;
+    Dedup& G = res[0]->D;
+    uint64_t n_reads = res[0]->n_seq;
+    for (unsigned t = 1; t < threads; ++t) {
+        if (!res[t]->ok) return C2_E_TOO_LARGE;
+        const c2_fastq& P = res[t]->R;
+        for (size_t k = 0; k < P.counts.size(); ++k)
+            if (!G.add(P.arena.data() + P.offsets[k], (size_t)(P.offsets[k + 1] - P.offsets[k]), P.counts[k])) return C2_E_TOO_LARGE;
+        n_reads += res[t]->n_seq;
+        res[t].reset();
+    }
+    // lines in the file = terminators + (1 if the file does not end with one and is not empty); a record whose sequence
+    // line never came still counts, with the empty sequence (readline() returned '')
+    const uint64_t lines = total_terms + ((n > 0 && !term_end(b, n, n - 1)) ? 1 : 0);
+    if ((lines & 3) == 1) { if (!G.add((const uint8_t*)"", 0)) return C2_E_TOO_LARGE; ++n_reads; }
+    R->arena.swap(res[0]->R.arena); R->offsets.swap(res[0]->R.offsets); R->counts.swap(res[0]->R.counts);
+    R->n_reads = n_reads;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* c2_fastq_last_error(void) { return g_fastq_error.c_str(); }
+
+int c2_fastq_unique(const char* path, c2_fastq** out) {
+    if (!path || !out) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    *out = nullptr;
+    // gzip'ed input (magic 1f 8b) goes through zlib; anything else is read directly
+    bool gz = false;
+    {
+        FILE* probe = fopen(path, "rb");
+        if (!probe) { g_fastq_error = std::string("cannot open ") + path; return C2_E_INVALID; }
+        unsigned char magic[2] = {0, 0};
+        gz = fread(magic, 1, 2, probe) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        fclose(probe);
+    }
+    c2_fastq* R = new c2_fastq;
+    if (!gz) {
+        const int fd = open(path, O_RDONLY);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); g_fastq_error = std::string("cannot open ") + path; delete R; return C2_E_INVALID; }
+        const size_t n = (size_t)st.st_size;
+        int rc = 0;
+        if (n > 0) {
+            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); g_fastq_error = std::string("cannot map ") + path; delete R; return C2_E_INVALID; }
+            madvise(m, n, MADV_SEQUENTIAL);
+            unsigned threads = std::thread::hardware_concurrency();
+            const unsigned by_size = (unsigned)(n / (8u << 20)) + 1;          // at least 8 MiB per thread
+            if (threads > by_size) threads = by_size;
+            if (const char* e = getenv("C2_FASTQ_THREADS")) threads = (unsigned)atoi(e);   // tests: any count on any size
+            if (threads > 64) threads = 64;
+            if (threads < 1) threads = 1;
+            if ((size_t)threads > n) threads = (unsigned)n;
+            delete R; R = new c2_fastq;                       // (parse_plain_parallel builds its own tables)
+            rc = parse_plain_parallel((const char*)m, n, R, threads);
+            munmap(m, n);
+        } else {
+            R->offsets.push_back(0);
+        }
+        close(fd);
+        if (rc) { g_fastq_error = "more than 2^32 - 2 unique sequences"; delete R; return rc; }
+        *out = R;
+        return 0;
+    }
+    Dedup D(R);
+    Lines L(D);
+    std::vector<char> buf(4u << 20);
+    gzFile f = gzopen(path, "rb");
+    if (!f) { g_fastq_error = std::string("cannot open ") + path; delete R; return C2_E_INVALID; }
+    gzbuffer(f, 1u << 20);
+    for (;;) {
+        const int got = gzread(f, buf.data(), (unsigned)buf.size());
+        if (got < 0) {
+            int errnum = 0;
+            g_fastq_error = std::string("read error in ") + path + ": " + gzerror(f, &errnum);
+            gzclose(f); delete R; return C2_E_INVALID;
+        }
+        if (got == 0) break;
+        L.feed(buf.data(), (size_t)got);
+        if (!L.ok) break;
+    }
+    gzclose(f);
+    L.finish();
+    if (!L.ok) { g_fastq_error = "more than 2^32 - 2 unique sequences"; delete R; return C2_E_TOO_LARGE; }
+    *out = R;
+    return 0;
+}
+
+uint64_t c2_fastq_n_unique(const c2_fastq* r) { return r ? (uint64_t)r->counts.size() : 0; }
+uint64_t c2_fastq_n_reads(const c2_fastq* r) { return r ? r->n_reads : 0; }
+uint64_t c2_fastq_arena_bytes(const c2_fastq* r) { return r ? (uint64_t)r->arena.size() : 0; }
+const uint8_t* c2_fastq_arena(const c2_fastq* r) { return r ? r->arena.data() : nullptr; }
+const uint64_t* c2_fastq_offsets(const c2_fastq* r) { return r ? r->offsets.data() : nullptr; }
+const uint32_t* c2_fastq_counts(const c2_fastq* r) { return r ? r->counts.data() : nullptr; }
+void c2_fastq_free(c2_fastq* r) { delete r; }
+
+}  // extern "C"

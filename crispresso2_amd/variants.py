@@ -179,19 +179,16 @@ def get_new_variant_objects(args, fastq_seqs, refs, ref_names, aln_matrix, pe_sc
 
 def read_fastq_unique(path):
     """First pass of process_fastq (CRISPRessoCORE.py:1825-1849): sequence line of every 4-line record -> dict seq -> count
-    (insertion-ordered, like the reference's variantCache before alignment).  Plain or gzip."""
-    import gzip
-    opener = gzip.open if str(path).endswith('.gz') else open
+    (insertion-ordered, like the reference's variantCache before alignment).  Plain or gzip.  Parsing and de-duplication
+    run in the native library (c2_fastq_unique); an empty sequence (blank line / truncated record: the reference would
+    hand '' to global_align, which is undefined there) is dropped."""
+    arena, offsets, counts, _ = _native.fastq_unique(path)
+    buf = arena.tobytes()
     cache = {}
-    with opener(path, 'rt') as fh:
-        while True:
-            if not fh.readline():
-                break
-            seq = fh.readline().strip()
-            fh.readline()
-            fh.readline()
-            if seq:
-                cache[seq] = cache.get(seq, 0) + 1
+    for k in range(len(counts)):
+        a, b = int(offsets[k]), int(offsets[k + 1])
+        if b > a:
+            cache[buf[a:b].decode('utf-8')] = int(counts[k])
     return cache
 
 

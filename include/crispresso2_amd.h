@@ -241,6 +241,21 @@ void c2_lists_free(c2_lists* r);
  * counters to out4 (may be NULL) and clears them, then sets the mode. */
 int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4);
 
+/* ---- FASTQ ingest + exact de-duplication (host code, no GPU): the first pass of process_fastq,
+ * CRISPRessoCORE.py:1820-1849 -- every 4-line record's sequence line, str.strip()'ed, counted per distinct sequence in
+ * first-seen order; plain or gzip'ed input, universal newlines.  The result owns: the unique sequences back to back
+ * (arena + n_unique+1 offsets: what c2_align_classify_batch_* take) and counts[n_unique].  Errors: c2_fastq_last_error(). */
+typedef struct c2_fastq c2_fastq;
+int c2_fastq_unique(const char* path, c2_fastq** out);
+uint64_t c2_fastq_n_unique(const c2_fastq* r);
+uint64_t c2_fastq_n_reads(const c2_fastq* r);
+uint64_t c2_fastq_arena_bytes(const c2_fastq* r);
+const uint8_t* c2_fastq_arena(const c2_fastq* r);
+const uint64_t* c2_fastq_offsets(const c2_fastq* r);
+const uint32_t* c2_fastq_counts(const c2_fastq* r);
+void c2_fastq_free(c2_fastq* r);
+const char* c2_fastq_last_error(void);
+
 /* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1, also with a lane switched off in EXEC,
  * readlane, ballot) the DP depends on; writes 320 int32 (see c2_selftest_kernel).  Used by the GPU test-suite. */
 int c2_selftest(c2_ctx* ctx, int32_t* out320);

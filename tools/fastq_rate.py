@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Rate of the FASTQ ingest + de-duplication step in front of the kernels: the native parser (c2_fastq_unique) against the
+reference's way of doing it, a Python readline loop (CRISPRessoCORE.py:1820-1849, restated inline below so that this
+tool imports nothing from oracle/).  Host-only; no GPU needed.
+    python tools/fastq_rate.py [--reads N] [--len L] [--dir DIR]"""
+import argparse
+import gzip
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def python_loop(path):
+    opener = (lambda x: gzip.open(x, 'rt')) if path.endswith('.gz') else open
+    cache = {}
+    with opener(path) as fh:
+        fastq_id = fh.readline()
+        while fastq_id:
+            seq = fh.readline().strip()
+            fh.readline().strip()
+            fh.readline()
+            if seq in cache:
+                cache[seq] += 1
+            else:
+                cache[seq] = 1
+            fastq_id = fh.readline()
+    return cache
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--len", type=int, default=250, dest="L")
+    ap.add_argument("--dir", default=None)
+    a = ap.parse_args()
+    from crispresso2_amd import synth, _native
+    reads = synth.make_reads(a.L, a.reads, workers=1)
+    qual = b"I" * a.L
+    d = a.dir or tempfile.mkdtemp(prefix="c2fq_")
+    plain, gz = os.path.join(d, "r.fastq"), os.path.join(d, "r.fastq.gz")
+    with open(plain, "wb") as fh:
+        for k in range(a.reads):
+            fh.write(b"@read%d\n%s\n+\n%s\n" % (k, reads[k].tobytes(), qual))
+    with open(plain, "rb") as src, gzip.open(gz, "wb", compresslevel=4) as dst:
+        while True:
+            b = src.read(1 << 24)
+            if not b:
+                break
+            dst.write(b)
+    out = {"reads": a.reads, "read_len": a.L, "plain_bytes": os.path.getsize(plain), "gz_bytes": os.path.getsize(gz)}
+    for name, path in (("plain", plain), ("gz", gz)):
+        t0 = time.perf_counter()
+        arena, offsets, counts, total = _native.fastq_unique(path)
+        t1 = time.perf_counter()
+        ref = python_loop(path)
+        t2 = time.perf_counter()
+        assert total == a.reads and len(ref) == len(counts) and sum(ref.values()) == int(counts.sum())
+        out[name] = {"native_s": t1 - t0, "native_reads_per_s": a.reads / (t1 - t0), "python_loop_s": t2 - t1,
+                     "python_loop_reads_per_s": a.reads / (t2 - t1), "speedup": (t2 - t1) / (t1 - t0), "unique": int(len(counts))}
+    for p in (plain, gz):
+        os.remove(p)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
