@@ -1617,7 +1617,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
     const int VL = A.lmax + 1;                                  // vector length incl. the end slot of the difference arrays
     const int o_sc = C2_CNT_VECTORS * VL, o_h = o_sc + C2_CNT_SCALARS;
     const int per_ref = o_h + C2_CNT_HISTS * A.hl;
-    int* ctl = acc + per_ref;                                   // [0..1] chunk base, [2..5] chunk weight per wave, [8..23] two sets of (ref, task) per wave
+    int* ctl = acc + per_ref;                                   // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
     uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
     for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
     __syncthreads();
@@ -1695,13 +1695,13 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
             const int first = pending ? __builtin_ctz(pending) : -1;
             int fref = NONE, ftask = NONE;
             if (first >= 0) { fref = (int)((unsigned)__builtin_amdgcn_readlane((int)d6, first) >> 16); ftask = first * C2_CNT_WAVES + wave; }
-            if (lane == 0) { ctl[8 + par * 8 + wave * 2] = fref; ctl[8 + par * 8 + wave * 2 + 1] = ftask; }
+            if (lane == 0) { ctl[16 + par * 2 * C2_CNT_WAVES + wave * 2] = fref; ctl[16 + par * 2 * C2_CNT_WAVES + wave * 2 + 1] = ftask; }
             __syncthreads();
             int tref = NONE, ttask = NONE;
 #pragma unroll
             for (int v = 0; v < C2_CNT_WAVES; ++v) {
-                const int t = ctl[8 + par * 8 + v * 2 + 1];
-                if (t < ttask) { ttask = t; tref = ctl[8 + par * 8 + v * 2]; }
+                const int t = ctl[16 + par * 2 * C2_CNT_WAVES + v * 2 + 1];
+                if (t < ttask) { ttask = t; tref = ctl[16 + par * 2 * C2_CNT_WAVES + v * 2]; }
             }
             par ^= 1;
             if (ttask == NONE) break;

@@ -1,0 +1,236 @@
+"""FASTQ -> per-amplicon count tensors, end to end on the MI355X: the count outputs of a CRISPResso run
+(`process_fastq` CRISPRessoCORE.py:1735-2000 + the "Quantifying indels/substitutions" loop :3964-4115) without building a
+Python object per read.
+
+    ingest + exact de-duplication      c2_fastq_unique (host, native)                         :1820-1849
+    strand plan per (read, reference)  the seed test of get_new_variant_object                  :656-687
+    alignments                         one all-references batch on the device (+ one small batch for the pairs whose
+                                       seeds are inconclusive: those are aligned on both strands, :675-687)
+    best reference / ambiguity         the reference's float comparisons on scores formed from (matches, length)  :689-707, :779-785
+    reverse-complement merge           :3970-3975
+    count vectors                      c2_count_vectors_kernel with the read multiplicities as weights  :3996-4115
+    aln_stats                          :1974-1979 from the 32-byte records
+
+Only 32 bytes per alignment come back to the host; the aligned strings stay in HBM for the count kernel.  The per-read
+dict path (variants.get_new_variant_objects) remains for callers that need the reference's per-read payloads.
+"""
+import numpy as np
+
+from . import _native
+from . import counts as C
+from .batch import BatchAligner, score_from_counts
+
+_RC_TABLE = bytes.maketrans(b"ACGTN_-", b"TGCAN_-")
+
+
+def strand_plans(seqs, refs, ref_names, args):
+    """uint8 [n, k]: 0 forward only, 1 reverse complement only, 2 both (the seed test of CRISPRessoCORE.py:656-687).
+    seqs: list of bytes."""
+    n, k = len(seqs), len(ref_names)
+    plan = np.full((n, k), 2, dtype=np.uint8)
+    for r, name in enumerate(ref_names):
+        m = min(args.aln_seed_count, len(refs[name]['fw_seeds']))
+        fw = [s.encode() for s in refs[name]['fw_seeds'][:m]]
+        rc = [s.encode() for s in refs[name]['rc_seeds'][:m]]
+        seed_min = args.aln_seed_min
+        for i, s in enumerate(seqs):
+            found_fw = found_rc = 0
+            for q in range(m):
+                if fw[q] in s:
+                    found_fw += 1
+                if rc[q] in s:
+                    found_rc += 1
+            if found_fw > seed_min and found_rc == 0:
+                plan[i, r] = 0
+            elif found_fw == 0 and found_rc > seed_min:
+                plan[i, r] = 1
+    return plan
+
+
+def _merge_reverse_complements(seqs, aligned, cnt):
+    """In place on cnt (int64): the reference's merge of a read with its reverse complement when both are in variantCache
+    (CRISPRessoCORE.py:3970-3975), in variantCache order.  A read that is its own reverse complement is counted twice by
+    that code; so it is here.  Reads with characters reverse_complement() cannot map (a KeyError in the reference) are
+    left alone."""
+    index = {s: i for i, s in enumerate(seqs) if aligned[i]}
+    for i, s in enumerate(seqs):
+        if not aligned[i] or cnt[i] == 0:
+            continue
+        up = s.upper()
+        if up.translate(None, b"ACGTN_-"):
+            continue
+        j = index.get(up[::-1].translate(_RC_TABLE))
+        if j is not None and cnt[j] > 0:
+            c = cnt[i] + cnt[j]
+            cnt[j] = 0
+            cnt[i] = c
+
+
+class QuantResult:
+    """per_ref[name]: the dict of counts.CountLayout.unpack (vectors named after the reference's variables);
+    stats: N_TOT_READS, N_CACHED_ALN, ... (process_fastq's aln_stats) plus N_TOTAL and N_AMBIGUOUS of the aggregation loop."""
+    def __init__(self, per_ref, stats, layout, tensor):
+        self.per_ref, self.stats, self.layout, self.tensor = per_ref, stats, layout, tensor
+
+
+def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False):
+    """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities."""
+    import torch
+    ctx = ctx or _native.default_context()
+    n, k = len(read_counts), len(ref_names)
+    L = [len(refs[name]['sequence']) for name in ref_names]
+    dev = torch.device("cuda", device)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+    max_lj = int(lens.max()) if n else 1
+    aligner = BatchAligner([refs[name]['sequence'] for name in ref_names], [refs[name]['gap_incentive'] for name in ref_names],
+                           [refs[name]['include_idxs'] for name in ref_names], aln_matrix,
+                           args.needleman_wunsch_gap_open, args.needleman_wunsch_gap_extend, ctx=ctx)
+    layout = C.CountLayout(k, max(L), max_lj)
+    d_counts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
+    flags = ((C.FLAG_IGNORE_SUBSTITUTIONS if args.ignore_substitutions else 0) | (C.FLAG_IGNORE_INSERTIONS if args.ignore_insertions else 0) |
+             (C.FLAG_IGNORE_DELETIONS if args.ignore_deletions else 0) | (C.FLAG_DISCARD_INDEL_READS if getattr(args, 'discard_indel_reads', False) else 0))
+    stats = dict(N_TOT_READS=int(np.asarray(read_counts, dtype=np.int64).sum()), N_CACHED_ALN=0, N_CACHED_NOTALN=0, N_COMPUTED_ALN=0,
+                 N_COMPUTED_NOTALN=0, N_GLOBAL_SUBS=0, N_SUBS_OUTSIDE_WINDOW=0, N_MODS_IN_WINDOW=0, N_MODS_OUTSIDE_WINDOW=0,
+                 N_READS_IRREGULAR_ENDS=0, N_TOTAL=0, N_AMBIGUOUS=0)
+    if n == 0:
+        return QuantResult({name: layout.unpack(d_counts.cpu().numpy(), r, L[r]) for r, name in enumerate(ref_names)}, stats, layout, d_counts)
+    buf = np.ascontiguousarray(arena, dtype=np.uint8).tobytes()
+    seqs = [buf[int(offsets[i]):int(offsets[i + 1])] for i in range(n)]
+    plan = strand_plans(seqs, refs, ref_names, args)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    stride = aligner.stride_for(max_lj)
+
+    # ---- batch 1: every read against every reference, on the strand the seeds ask for (forward when they ask for both)
+    d_reads = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8).copy() if buf else np.zeros(1, dtype=np.uint8)).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_str1 = torch.from_numpy((plan == 1).astype(np.uint8).reshape(-1)).to(dev)
+    n1 = n * k
+    a1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
+    f1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
+    r1 = torch.empty((n1, 32), dtype=torch.uint8, device=dev)
+    aligner.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), a1.data_ptr(), f1.data_ptr(), r1.data_ptr(), stride, max_lj,
+                         d_strands=d_str1.data_ptr(), all_refs=True, stream=stream)
+    rec1 = r1.cpu().numpy().view(_native.REC_DTYPE).reshape(n, k)
+
+    # ---- batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments
+    bi, br = np.nonzero(plan == 2)
+    n2 = len(bi)
+    rec2 = None
+    if n2:
+        off2 = np.zeros(n2 + 1, dtype=np.uint64)
+        off2[1:] = np.cumsum(lens[bi])
+        arena2 = np.frombuffer(b"".join(seqs[i] for i in bi), dtype=np.uint8)
+        max_lj2 = int(lens[bi].max())
+        stride2 = aligner.stride_for(max_lj2)
+        d_reads2 = torch.from_numpy(arena2.copy() if arena2.size else np.zeros(1, dtype=np.uint8)).to(dev)
+        d_off2 = torch.from_numpy(off2.astype(np.int64)).to(dev)
+        d_rid2 = torch.from_numpy(br.astype(np.int16)).to(dev)
+        d_str2 = torch.ones(n2, dtype=torch.uint8, device=dev)
+        a2 = torch.empty((n2, stride2), dtype=torch.uint8, device=dev)
+        f2 = torch.empty((n2, stride2), dtype=torch.uint8, device=dev)
+        r2 = torch.empty((n2, 32), dtype=torch.uint8, device=dev)
+        aligner.align_device(n2, d_reads2.data_ptr(), d_off2.data_ptr(), a2.data_ptr(), f2.data_ptr(), r2.data_ptr(), stride2, max_lj2,
+                             d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=stream)
+        rec2 = r2.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+    for rec in (rec1.reshape(-1), rec2 if rec2 is not None else rec1.reshape(-1)[:0]):
+        bad = rec["status"] != 0
+        if bad.any():
+            st = int(rec["status"][np.nonzero(bad)[0][0]])
+            if st & _native.STATUS_RC_CHAR:
+                raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
+            raise Exception('global_align: undefined alignment (status %d)' % st)
+
+    # ---- strand and reference choice, with the reference's float comparisons (:683, :697-707)
+    score = score_from_counts(rec1["matches"].reshape(-1), rec1["aln_len"].reshape(-1)).reshape(n, k)
+    use2 = np.zeros((n, k), dtype=bool)
+    slot2 = np.full((n, k), -1, dtype=np.int64)
+    if n2:
+        s2 = score_from_counts(rec2["matches"], rec2["aln_len"])
+        better = s2 > score[bi, br]                              # strict: ties keep the forward alignment
+        use2[bi[better], br[better]] = True
+        slot2[bi, br] = np.arange(n2)
+        score[bi[better], br[better]] = s2[better]
+    best = np.full(n, -1.0)
+    member = np.zeros((n, k), dtype=bool)
+    for r, name in enumerate(ref_names):
+        s_r = score[:, r]
+        c1 = (s_r > best) & (s_r > refs[name]['min_aln_score'])
+        best = np.where(c1, s_r, best)
+        member[c1, :] = False
+        member[c1, r] = True
+        member[~c1 & (s_r == best), r] = True
+    aligned = best > 0
+    n_best = member.sum(axis=1)
+    raw = np.asarray(read_counts, dtype=np.int64)
+    stats['N_COMPUTED_ALN'] = int(aligned.sum())
+    stats['N_COMPUTED_NOTALN'] = int(n - aligned.sum())
+    stats['N_CACHED_ALN'] = int((raw[aligned] - 1).sum())
+    stats['N_CACHED_NOTALN'] = int((raw[~aligned] - 1).sum())
+    # aln_stats use the payload of the LAST best match (new_variant['best_match_name'], :764) and the raw multiplicity
+    last_best = np.where(aligned, k - 1 - np.argmax(member[:, ::-1], axis=1), 0)
+    ii = np.nonzero(aligned)[0]
+
+    def field(name):
+        v1 = rec1[name][ii, last_best[ii]].astype(np.int64)
+        if n2:
+            u = use2[ii, last_best[ii]]
+            v1[u] = rec2[name][slot2[ii[u], last_best[ii[u]]]].astype(np.int64)
+        return v1
+    c_raw = raw[ii]
+    sub_all, sub_win = field("all_substitutions"), field("substitution_n")
+    total_mods = field("all_insertion_events") + field("all_deletion_bases") + sub_all
+    in_win = sub_win + field("deletion_n") + field("insertion_n")
+    stats['N_GLOBAL_SUBS'] = int((sub_all * c_raw).sum())
+    stats['N_SUBS_OUTSIDE_WINDOW'] = int(((sub_all - sub_win) * c_raw).sum())
+    stats['N_MODS_IN_WINDOW'] = int((in_win * c_raw).sum())
+    stats['N_MODS_OUTSIDE_WINDOW'] = int(((total_mods - in_win) * c_raw).sum())
+    stats['N_READS_IRREGULAR_ENDS'] = int((field("irregular_ends") * c_raw).sum())
+
+    # ---- aggregation weights (:3964-4000): rc merge, ambiguous reads, which references a read counts for
+    cnt = raw.copy()
+    _merge_reverse_complements(seqs, aligned, cnt)
+    stats['N_TOTAL'] = int(cnt[aligned].sum())
+    counted = member.copy()
+    ambiguous = aligned & (n_best > 1)
+    if args.assign_ambiguous_alignments_to_first_reference:
+        first = np.argmax(member, axis=1)
+        counted[ambiguous, :] = False
+        counted[ambiguous, first[ambiguous]] = True
+    elif not args.expand_ambiguous_alignments:
+        counted[ambiguous, :] = False
+        stats['N_AMBIGUOUS'] = int(cnt[ambiguous].sum())
+    counted[~aligned, :] = False
+    if cnt.max() > 0xFFFFFFFF:
+        raise OverflowError("a read multiplicity exceeds 2^32 - 1")
+    w1 = np.where(counted & ~use2, cnt[:, None], 0).astype(np.uint32).reshape(-1)
+    d_w1 = torch.from_numpy(w1.view(np.int32)).to(dev)
+    C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_counts.data_ptr(),
+                        d_weights=d_w1.data_ptr(), flags=flags, stream=stream)
+    if n2:
+        w2 = np.where(counted[bi, br] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
+        d_w2 = torch.from_numpy(w2.view(np.int32)).to(dev)
+        C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_counts.data_ptr(),
+                            d_weights=d_w2.data_ptr(), flags=flags, stream=stream)
+    if reduce_across_ranks:
+        C.all_reduce(d_counts)
+    torch.cuda.synchronize(dev)
+    host = d_counts.cpu().numpy()
+    per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
+    return QuantResult(per_ref, stats, layout, d_counts)
+
+
+def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0):
+    """FASTQ file -> QuantResult.  Empty sequences (blank line / truncated record) are dropped, as in
+    variants.read_fastq_unique; N_TOT_READS counts every record of the file."""
+    arena, offsets, counts, n_reads = _native.fastq_unique(path)
+    lens = offsets[1:] - offsets[:-1]
+    if len(counts) and (lens == 0).any():
+        keep = np.nonzero(lens > 0)[0]                          # at most one empty key
+        new_off = np.zeros(len(keep) + 1, dtype=np.uint64)
+        new_off[1:] = np.cumsum(lens[keep])
+        arena = np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in keep]) if len(keep) else np.zeros(0, dtype=np.uint8)
+        offsets, counts = new_off, counts[keep]
+    res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device)
+    res.stats['N_READS_INPUT'] = int(n_reads)
+    return res

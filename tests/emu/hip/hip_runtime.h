@@ -25,7 +25,7 @@
 
 namespace emu {
 constexpr int W = 64;            // wavefront width
-constexpr int MAXT = 256;        // threads per workgroup the emulator supports
+constexpr int MAXT = 512;        // threads per workgroup the emulator supports
 constexpr int MAXW = MAXT / W;
 struct dim3_ { unsigned x = 1, y = 1, z = 1; };
 extern int cur_lane;             // thread index inside the workgroup (wave = cur_lane / 64, lane = cur_lane % 64)

@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -403,6 +403,40 @@ def variant_goldens():
                                 "min_aln_score": 60, "fw_seeds": refs[nm]["fw_seeds"], "rc_seeds": refs[nm]["rc_seeds"]} for nm in names],
                       "reads": sample, "variants": outs})
     return cases
+
+
+# ---------------------------------------------------------------- 6. a whole run: tests/FANC.Cas9.fastq and its expected result tables
+def fanc_run():
+    """The reference's own end-to-end test (tests/Makefile: CRISPResso -r1 FANC.Cas9.fastq -a <amplicon> -g <guide>) and the
+    result tables its repository keeps for it (tests/expectedResults/CRISPResso_on_FANC.Cas9/)."""
+    amplicon = guide = None
+    with open(os.path.join(REF, "tests/Makefile")) as fh:
+        for line in fh:
+            if "CRISPResso -r1 FANC.Cas9.fastq -a" in line and " -e " not in line:
+                f = line.split()
+                amplicon, guide = f[f.index("-a") + 1], f[f.index("-g") + 1]
+    with open(os.path.join(REF, "tests/FANC.Cas9.fastq")) as fh:
+        fastq = fh.read()
+    exp = os.path.join(REF, "tests/expectedResults/CRISPResso_on_FANC.Cas9")
+    with open(os.path.join(exp, "CRISPResso_quantification_of_editing_frequency.txt")) as fh:
+        head = fh.readline().rstrip("\n").split("\t")
+        row = fh.readline().rstrip("\n").split("\t")
+    quant = dict(zip(head, row))
+    nuc = {}
+    with open(os.path.join(exp, "Nucleotide_frequency_table.txt")) as fh:
+        ref_row = fh.readline().rstrip("\n").split("\t")[1:]
+        for line in fh:
+            f = line.rstrip("\n").split("\t")
+            nuc[f[0]] = [float(x) for x in f[1:]]
+    return {"amplicon": amplicon, "guide": guide, "cut_point": amplicon.index(guide) + len(guide) - 3 - 1, "fastq": fastq,
+            "quantification": quant, "nucleotide_frequency_reference_row": ref_row, "nucleotide_frequency": nuc}
+
+
+if __name__ == "__main__" and "--fanc" in sys.argv:
+    import gzip
+    with gzip.open(os.path.join(HERE, "fanc_run.json.gz"), "wt") as fh:
+        json.dump(fanc_run(), fh, separators=(",", ":"))
+    print("fanc_run.json.gz written")
 
 
 if __name__ == "__main__" and "--variants" in sys.argv:

@@ -2,6 +2,7 @@
 CPU oracle on the same seeded inputs.  Integer / byte work: the bar is bit-exact.  Run on an MI355X
 with `pytest -m gpu`."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -554,3 +555,107 @@ def test_three_candidate_references_best_reference_selection(mats, ctx):
                 names.append(r)
         best_gpu.append(names)
     assert any(len(x) == 1 and x[0] == 1 for x in best_gpu) and any(len(x) == 1 and x[0] == 2 for x in best_gpu)
+
+
+def _default_args(**over):
+    from types import SimpleNamespace
+    a = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                        use_legacy_insertion_quantification=False, ignore_deletions=False, ignore_insertions=False,
+                        ignore_substitutions=False, assign_ambiguous_alignments_to_first_reference=False,
+                        expand_ambiguous_alignments=False, prime_editing_pegRNA_scaffold_seq="", discard_indel_reads=False)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_whole_run_fanc_fastq_equals_the_reference_result_tables(mats, ctx, tmp_path):
+    """The reference's own end-to-end test (tests/Makefile: CRISPResso -r1 FANC.Cas9.fastq -a ... -g ...): FASTQ file ->
+    native ingest -> device alignments -> best-reference / strand rules -> count kernel, against the result tables the
+    reference repository keeps for that run (quantification of editing frequency + nucleotide frequency table)."""
+    import gzip
+    import json
+    from crispresso2_amd import pipeline, refs as RF
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fanc_run.json.gz"), "rt") as fh:
+        g = json.load(fh)
+    fq = tmp_path / "FANC.Cas9.fastq"
+    fq.write_text(g["fastq"])
+    cut = g["cut_point"]
+    ref = RF.make_ref("Reference", g["amplicon"], [cut], [cut, cut + 1], min_aln_score=60)
+    res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], mats["EDNAFULL"], _default_args(), ctx=ctx)
+    q, c = g["quantification"], res.per_ref["Reference"]
+    assert res.stats["N_READS_INPUT"] == int(q["Reads_in_input"]) == res.stats["N_TOT_READS"]
+    assert res.stats["N_TOTAL"] == int(q["Reads_aligned_all_amplicons"])
+    got = {"Reads_aligned": c["counts_total"], "Unmodified": c["counts_unmodified"], "Modified": c["counts_modified"],
+           "Discarded": c["counts_discarded"], "Insertions": c["counts_insertion"], "Deletions": c["counts_deletion"],
+           "Substitutions": c["counts_substitution"], "Only Insertions": c["counts_only_insertion"],
+           "Only Deletions": c["counts_only_deletion"], "Only Substitutions": c["counts_only_substitution"],
+           "Insertions and Deletions": c["counts_insertion_and_deletion"],
+           "Insertions and Substitutions": c["counts_insertion_and_substitution"],
+           "Deletions and Substitutions": c["counts_deletion_and_substitution"],
+           "Insertions Deletions and Substitutions": c["counts_insertion_and_deletion_and_substitution"]}
+    assert got == {k_: int(q[k_]) for k_ in got}
+    assert round(100.0 * c["counts_unmodified"] / c["counts_total"], 8) == float(q["Unmodified%"])
+    assert list(g["amplicon"]) == g["nucleotide_frequency_reference_row"]
+    for base in "ACGTN-":
+        assert [float(x) for x in c["all_base_count_vectors_" + base]] == g["nucleotide_frequency"][base], base
+
+
+def test_pipeline_equals_per_read_path_plus_reference_aggregation(mats, ctx):
+    """pipeline.quantify_unique (device-resident; 32 bytes per alignment come back) against the per-read dict path
+    (variants.get_new_variant_objects, itself pinned to the reference's function) fed through oracle/aggregate.py, with
+    two similar references (ambiguous reads), reverse-complemented reads and their forward twins (rc merge), the
+    ambiguity flags and ignore_substitutions."""
+    import gzip
+    import json
+    from crispresso2_amd import pipeline, variants, refs as RF
+    from oracle import aggregate
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "variants.json.gz"), "rt") as fh:
+        cases = json.load(fh)
+    base = [c for c in cases if c["label"] == "FANC+HDR"][0]
+    reads = list(dict.fromkeys(base["reads"]))
+    reads += [RF.reverse_complement(r) for r in reads[:25] if RF.reverse_complement(r) not in reads]      # rc twins of counted reads
+    fanc = base["refs"][0]["sequence"]
+    reads += [fanc[:80] + fanc[100:], fanc[:78] + fanc[101:]]          # the two references differ only inside 88..95: equal scores
+    rng = np.random.default_rng(9)
+    mult = rng.integers(1, 40, len(reads)).astype(np.uint32)
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    for over in ({}, {"assign_ambiguous_alignments_to_first_reference": True}, {"expand_ambiguous_alignments": True},
+                 {"ignore_substitutions": True}, {"discard_indel_reads": True}):
+        args = _default_args(**over)
+        refs = {r["name"]: RF.make_ref(r["name"], r["sequence"], r["cut_points"], r["include_idxs"], min_aln_score=r["min_aln_score"])
+                for r in base["refs"]}
+        names = [r["name"] for r in base["refs"]]
+        res = pipeline.quantify_unique(arena, offsets, mult, refs, names, mats["EDNAFULL"], args, ctx=ctx)
+        vs = variants.get_new_variant_objects(args, reads, refs, names, mats["EDNAFULL"], ctx=ctx)
+        # the aggregation loop's bookkeeping (CRISPRessoCORE.py:3964-4000) on the per-read dicts
+        cache = {r: dict(v, count=int(c)) for r, v, c in zip(reads, vs, mult) if v["best_match_score"] > 0}
+        items = {nm: [] for nm in names}
+        n_total = 0
+        for r in list(cache):
+            v = cache[r]
+            if v["count"] == 0:
+                continue
+            rc = RF.reverse_complement(r)
+            if rc in cache and cache[rc]["count"] > 0:
+                v["count"] += cache[rc]["count"]
+                cache[rc]["count"] = 0
+            n_total += v["count"]
+            if v["class_name"] == "AMBIGUOUS":
+                continue
+            for nm in v["aln_ref_names"]:
+                items[nm].append((v["variant_" + nm], v["count"]))
+        assert res.stats["N_TOTAL"] == n_total
+        if not over:
+            assert sum(v.get("class_name") == "AMBIGUOUS" for v in vs) >= 2 and res.stats["N_AMBIGUOUS"] > 0
+        for nm, ref in zip(names, base["refs"]):
+            exp = aggregate.aggregate(items[nm], len(ref["sequence"]), ignore_substitutions=args.ignore_substitutions,
+                                      ignore_insertions=args.ignore_insertions, ignore_deletions=args.ignore_deletions,
+                                      discard_indel_reads=args.discard_indel_reads)
+            got = res.per_ref[nm]
+            for k_, v_ in exp.items():
+                if isinstance(v_, np.ndarray):
+                    assert np.array_equal(got[k_][:len(ref["sequence"])], v_), (over, nm, k_)
+                else:
+                    assert got[k_] == v_, (over, nm, k_, got[k_], v_)
