@@ -23,7 +23,7 @@ SYMBOLS = [
     "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_timing_read_split", "c2_count_vectors_device",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
-    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error",
+    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error", "c2_strand_plan", "c2_merge_reverse_complements",
 ]
 
 REC_DTYPE = np.dtype([
@@ -67,6 +67,14 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise NativeError("crispresso2_amd: %s is missing -- build the HIP extension first "
                                   "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+            # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and can no longer see the GPU once another
+            # copy (the /opt/rocm one this library would pull in by itself) has initialised the device.  Importing torch
+            # first makes the dynamic loader hand torch's copy to this library as well.  Without torch installed the
+            # library simply uses /opt/rocm's.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             lib = ctypes.CDLL(LIB_PATH)
             lib.c2_last_error.restype = ctypes.c_char_p
             lib.c2_last_error.argtypes = [ctypes.c_void_p]
@@ -257,6 +265,38 @@ def fastq_unique(path):
     finally:
         lib.c2_fastq_free(h)
     return arena, offsets, counts, total
+
+
+def strand_plan(arena, offsets, fw_seeds, rc_seeds, seed_min):
+    """c2_strand_plan for one reference -> uint8 [n] (0 forward, 1 reverse complement, 2 both)."""
+    lib = load()
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    out = np.zeros(n, dtype=np.uint8)
+    m = len(fw_seeds)
+    fw = (ctypes.c_char_p * max(m, 1))(*[s.encode() for s in fw_seeds])
+    rc = (ctypes.c_char_p * max(m, 1))(*[s.encode() for s in rc_seeds])
+    rcode = lib.c2_strand_plan(arena.ctypes.data_as(ctypes.c_void_p) if arena.size else None, offsets.ctypes.data_as(ctypes.c_void_p),
+                               ctypes.c_uint64(n), fw, rc, int(m), int(seed_min), out.ctypes.data_as(ctypes.c_void_p))
+    if rcode != 0:
+        raise NativeError("c2_strand_plan: %s" % lib.c2_fastq_last_error().decode())
+    return out
+
+
+def merge_reverse_complements(arena, offsets, aligned, counts):
+    """c2_merge_reverse_complements, in place on counts (int64 [n])."""
+    lib = load()
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    al = np.ascontiguousarray(aligned, dtype=np.uint8)
+    assert counts.dtype == np.int64 and counts.flags["C_CONTIGUOUS"]
+    rcode = lib.c2_merge_reverse_complements(arena.ctypes.data_as(ctypes.c_void_p) if arena.size else None,
+                                             offsets.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(offsets) - 1),
+                                             al.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p))
+    if rcode != 0:
+        raise NativeError("c2_merge_reverse_complements: %s" % lib.c2_fastq_last_error().decode())
+    return counts
 
 
 _default_ctx = None

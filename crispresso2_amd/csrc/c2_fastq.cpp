@@ -327,6 +327,108 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
     return 0;
 }
 
+// ---- host-side helpers of the read -> reference bookkeeping that sits between ingest and the kernels ----------------
+
+// Strand plan of get_new_variant_object (CRISPRessoCORE.py:656-687) for every read against one reference:
+// found_fw / found_rc = how many of the first n_seeds forward / reverse-complement seeds occur in the read (Python `in`);
+// 0 = forward only (found_fw > seed_min and found_rc == 0), 1 = reverse complement only (found_fw == 0 and found_rc >
+// seed_min), 2 = both.
+int c2_strand_plan(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const char* const* fw_seeds, const char* const* rc_seeds,
+                   int32_t n_seeds, int32_t seed_min, uint8_t* out_plan) {
+    if (!offsets || !out_plan || n_seeds < 0 || (n_seeds && (!fw_seeds || !rc_seeds))) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
+    std::vector<std::string> fw, rc;
+    for (int q = 0; q < n_seeds; ++q) { fw.emplace_back(fw_seeds[q]); rc.emplace_back(rc_seeds[q]); }
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads > 64) threads = 64;
+    if (threads < 1 || n < 4096) threads = 1;
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i) {
+            const void* s = arena + offsets[i];
+            const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+            int found_fw = 0, found_rc = 0;
+            for (int q = 0; q < n_seeds; ++q) {
+                if (fw[q].empty() || (len >= fw[q].size() && memmem(s, len, fw[q].data(), fw[q].size()))) ++found_fw;
+                if (rc[q].empty() || (len >= rc[q].size() && memmem(s, len, rc[q].data(), rc[q].size()))) ++found_rc;
+            }
+            out_plan[i] = (found_fw > seed_min && found_rc == 0) ? 0 : (found_fw == 0 && found_rc > seed_min) ? 1 : 2;
+        }
+    };
+    if (threads == 1) { work(0, n); return 0; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+    for (auto& th : pool) th.join();
+    return 0;
+}
+
+// The reverse-complement merge of the aggregation loop (CRISPRessoCORE.py:3970-3975), in variantCache order: for every
+// aligned read with a non-zero count, if reverse_complement(read) (upper-cased, ACGTN_- only; anything else is a KeyError
+// in the reference and is skipped here) is an aligned read with a non-zero count, that count is added to this read and
+// zeroed there -- a read equal to its own reverse complement therefore doubles, as it does in the reference.
+int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const uint8_t* aligned, int64_t* counts) {
+    if (!offsets || !aligned || !counts) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
+    // 1. hashes of the aligned reads (threads), 2. table hash -> index (serial inserts, cheap), 3. for every read the index of
+    // the read that equals its reverse complement, or -1 (threads; the table is read-only by then), 4. the reference's
+    // sequential count transfer over that partner array.
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads > 64) threads = 64;
+    if (threads < 1 || n < 8192) threads = 1;
+    auto run = [&](auto&& fn) {
+        if (threads == 1) { fn((uint64_t)0, n); return; }
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(fn, n * t / threads, n * (t + 1) / threads);
+        for (auto& th : pool) th.join();
+    };
+    std::vector<uint64_t> hs(n, 0);
+    run([&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i)
+            if (aligned[i]) hs[i] = hash_bytes(arena + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
+    });
+    uint64_t cap = 1024;
+    while (cap < 2 * n + 2) cap <<= 1;
+    std::vector<uint64_t> table(cap, 0);                         // index + 1
+    const uint64_t mask = cap - 1;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!aligned[i]) continue;
+        uint64_t pos = hs[i] & mask;
+        while (table[pos]) pos = (pos + 1) & mask;
+        table[pos] = i + 1;
+    }
+    std::vector<int64_t> partner(n, -1);
+    run([&](uint64_t lo, uint64_t hi) {
+        std::vector<uint8_t> rc;
+        for (uint64_t i = lo; i < hi; ++i) {
+            if (!aligned[i]) continue;
+            const uint8_t* s = arena + offsets[i];
+            const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+            rc.resize(len);
+            bool ok = true;
+            for (size_t k = 0; k < len && ok; ++k) {
+                uint8_t c = s[len - 1 - k];
+                if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+                switch (c) {
+                    case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'T': c = 'A'; break;
+                    case 'N': case '_': case '-': break;
+                    default: ok = false;
+                }
+                rc[k] = c;
+            }
+            if (!ok) continue;
+            uint64_t pos = hash_bytes(rc.data(), len) & mask;
+            while (table[pos]) {
+                const uint64_t j = table[pos] - 1;
+                if ((size_t)(offsets[j + 1] - offsets[j]) == len && (len == 0 || memcmp(arena + offsets[j], rc.data(), len) == 0)) { partner[i] = (int64_t)j; break; }
+                pos = (pos + 1) & mask;
+            }
+        }
+    });
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!aligned[i] || counts[i] == 0 || partner[i] < 0) continue;
+        const int64_t j = partner[i];
+        if (counts[j] > 0) { const int64_t c = counts[i] + counts[j]; counts[j] = 0; counts[i] = c; }
+    }
+    return 0;
+}
+
 uint64_t c2_fastq_n_unique(const c2_fastq* r) { return r ? (uint64_t)r->counts.size() : 0; }
 uint64_t c2_fastq_n_reads(const c2_fastq* r) { return r ? r->n_reads : 0; }
 uint64_t c2_fastq_arena_bytes(const c2_fastq* r) { return r ? (uint64_t)r->arena.size() : 0; }

@@ -20,50 +20,15 @@ from . import _native
 from . import counts as C
 from .batch import BatchAligner, score_from_counts
 
-_RC_TABLE = bytes.maketrans(b"ACGTN_-", b"TGCAN_-")
-
-
-def strand_plans(seqs, refs, ref_names, args):
-    """uint8 [n, k]: 0 forward only, 1 reverse complement only, 2 both (the seed test of CRISPRessoCORE.py:656-687).
-    seqs: list of bytes."""
-    n, k = len(seqs), len(ref_names)
-    plan = np.full((n, k), 2, dtype=np.uint8)
+def strand_plans(arena, offsets, refs, ref_names, args):
+    """uint8 [n, k]: 0 forward only, 1 reverse complement only, 2 both (the seed test of CRISPRessoCORE.py:656-687), by the
+    native threaded c2_strand_plan."""
+    n = len(offsets) - 1
+    plan = np.empty((n, len(ref_names)), dtype=np.uint8)
     for r, name in enumerate(ref_names):
         m = min(args.aln_seed_count, len(refs[name]['fw_seeds']))
-        fw = [s.encode() for s in refs[name]['fw_seeds'][:m]]
-        rc = [s.encode() for s in refs[name]['rc_seeds'][:m]]
-        seed_min = args.aln_seed_min
-        for i, s in enumerate(seqs):
-            found_fw = found_rc = 0
-            for q in range(m):
-                if fw[q] in s:
-                    found_fw += 1
-                if rc[q] in s:
-                    found_rc += 1
-            if found_fw > seed_min and found_rc == 0:
-                plan[i, r] = 0
-            elif found_fw == 0 and found_rc > seed_min:
-                plan[i, r] = 1
+        plan[:, r] = _native.strand_plan(arena, offsets, refs[name]['fw_seeds'][:m], refs[name]['rc_seeds'][:m], args.aln_seed_min)
     return plan
-
-
-def _merge_reverse_complements(seqs, aligned, cnt):
-    """In place on cnt (int64): the reference's merge of a read with its reverse complement when both are in variantCache
-    (CRISPRessoCORE.py:3970-3975), in variantCache order.  A read that is its own reverse complement is counted twice by
-    that code; so it is here.  Reads with characters reverse_complement() cannot map (a KeyError in the reference) are
-    left alone."""
-    index = {s: i for i, s in enumerate(seqs) if aligned[i]}
-    for i, s in enumerate(seqs):
-        if not aligned[i] or cnt[i] == 0:
-            continue
-        up = s.upper()
-        if up.translate(None, b"ACGTN_-"):
-            continue
-        j = index.get(up[::-1].translate(_RC_TABLE))
-        if j is not None and cnt[j] > 0:
-            c = cnt[i] + cnt[j]
-            cnt[j] = 0
-            cnt[i] = c
 
 
 class QuantResult:
@@ -73,9 +38,20 @@ class QuantResult:
         self.per_ref, self.stats, self.layout, self.tensor = per_ref, stats, layout, tensor
 
 
-def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False):
-    """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities."""
+def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
+                    timings=None):
+    """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
+    timings: optional dict that receives the wall seconds of every stage."""
+    import time
     import torch
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + now - t_last[0]
+            t_last[0] = now
     ctx = ctx or _native.default_context()
     n, k = len(read_counts), len(ref_names)
     L = [len(refs[name]['sequence']) for name in ref_names]
@@ -95,14 +71,14 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
                  N_READS_IRREGULAR_ENDS=0, N_TOTAL=0, N_AMBIGUOUS=0)
     if n == 0:
         return QuantResult({name: layout.unpack(d_counts.cpu().numpy(), r, L[r]) for r, name in enumerate(ref_names)}, stats, layout, d_counts)
-    buf = np.ascontiguousarray(arena, dtype=np.uint8).tobytes()
-    seqs = [buf[int(offsets[i]):int(offsets[i + 1])] for i in range(n)]
-    plan = strand_plans(seqs, refs, ref_names, args)
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    plan = strand_plans(arena, offsets, refs, ref_names, args)
+    lap("strand_plan")
     stream = torch.cuda.current_stream(dev).cuda_stream
     stride = aligner.stride_for(max_lj)
 
     # ---- batch 1: every read against every reference, on the strand the seeds ask for (forward when they ask for both)
-    d_reads = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8).copy() if buf else np.zeros(1, dtype=np.uint8)).to(dev)
+    d_reads = torch.from_numpy(arena if arena.size else np.zeros(1, dtype=np.uint8)).to(dev)
     d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
     d_str1 = torch.from_numpy((plan == 1).astype(np.uint8).reshape(-1)).to(dev)
     n1 = n * k
@@ -112,6 +88,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     aligner.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), a1.data_ptr(), f1.data_ptr(), r1.data_ptr(), stride, max_lj,
                          d_strands=d_str1.data_ptr(), all_refs=True, stream=stream)
     rec1 = r1.cpu().numpy().view(_native.REC_DTYPE).reshape(n, k)
+    lap("h2d_align_records_d2h")
 
     # ---- batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments
     bi, br = np.nonzero(plan == 2)
@@ -120,7 +97,9 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     if n2:
         off2 = np.zeros(n2 + 1, dtype=np.uint64)
         off2[1:] = np.cumsum(lens[bi])
-        arena2 = np.frombuffer(b"".join(seqs[i] for i in bi), dtype=np.uint8)
+        # gather the bytes of those reads (a read that is undecided for several references is repeated)
+        src = np.repeat(offsets[bi].astype(np.int64) - off2[:-1].astype(np.int64), lens[bi]) + np.arange(int(off2[-1]), dtype=np.int64)
+        arena2 = arena[src]
         max_lj2 = int(lens[bi].max())
         stride2 = aligner.stride_for(max_lj2)
         d_reads2 = torch.from_numpy(arena2.copy() if arena2.size else np.zeros(1, dtype=np.uint8)).to(dev)
@@ -133,6 +112,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         aligner.align_device(n2, d_reads2.data_ptr(), d_off2.data_ptr(), a2.data_ptr(), f2.data_ptr(), r2.data_ptr(), stride2, max_lj2,
                              d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=stream)
         rec2 = r2.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+    lap("both_strand_pairs")
     for rec in (rec1.reshape(-1), rec2 if rec2 is not None else rec1.reshape(-1)[:0]):
         bad = rec["status"] != 0
         if bad.any():
@@ -187,9 +167,10 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     stats['N_MODS_OUTSIDE_WINDOW'] = int(((total_mods - in_win) * c_raw).sum())
     stats['N_READS_IRREGULAR_ENDS'] = int((field("irregular_ends") * c_raw).sum())
 
+    lap("selection_and_stats")
     # ---- aggregation weights (:3964-4000): rc merge, ambiguous reads, which references a read counts for
-    cnt = raw.copy()
-    _merge_reverse_complements(seqs, aligned, cnt)
+    cnt = np.ascontiguousarray(raw.copy())
+    _native.merge_reverse_complements(arena, offsets, aligned, cnt)
     stats['N_TOTAL'] = int(cnt[aligned].sum())
     counted = member.copy()
     ambiguous = aligned & (n_best > 1)
@@ -203,6 +184,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     counted[~aligned, :] = False
     if cnt.max() > 0xFFFFFFFF:
         raise OverflowError("a read multiplicity exceeds 2^32 - 1")
+    lap("rc_merge_weights")
     w1 = np.where(counted & ~use2, cnt[:, None], 0).astype(np.uint32).reshape(-1)
     d_w1 = torch.from_numpy(w1.view(np.int32)).to(dev)
     C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_counts.data_ptr(),
@@ -216,14 +198,19 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         C.all_reduce(d_counts)
     torch.cuda.synchronize(dev)
     host = d_counts.cpu().numpy()
+    lap("count_kernels")
     per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
     return QuantResult(per_ref, stats, layout, d_counts)
 
 
-def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0):
+def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None):
     """FASTQ file -> QuantResult.  Empty sequences (blank line / truncated record) are dropped, as in
     variants.read_fastq_unique; N_TOT_READS counts every record of the file."""
+    import time
+    t0 = time.perf_counter()
     arena, offsets, counts, n_reads = _native.fastq_unique(path)
+    if timings is not None:
+        timings["ingest_dedup"] = time.perf_counter() - t0
     lens = offsets[1:] - offsets[:-1]
     if len(counts) and (lens == 0).any():
         keep = np.nonzero(lens > 0)[0]                          # at most one empty key
@@ -231,6 +218,6 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0):
         new_off[1:] = np.cumsum(lens[keep])
         arena = np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in keep]) if len(keep) else np.zeros(0, dtype=np.uint8)
         offsets, counts = new_off, counts[keep]
-    res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device)
+    res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings)
     res.stats['N_READS_INPUT'] = int(n_reads)
     return res

@@ -255,6 +255,12 @@ const uint64_t* c2_fastq_offsets(const c2_fastq* r);
 const uint32_t* c2_fastq_counts(const c2_fastq* r);
 void c2_fastq_free(c2_fastq* r);
 const char* c2_fastq_last_error(void);
+/* Host-side bookkeeping between ingest and kernels, over the same arena/offsets layout (errors: c2_fastq_last_error()):
+ * the seed test that picks the strand(s) a read is aligned on (CRISPRessoCORE.py:656-687) -> out_plan[n] in {0 forward,
+ * 1 reverse complement, 2 both}, and the reverse-complement merge of read counts (CRISPRessoCORE.py:3970-3975), in place. */
+int c2_strand_plan(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const char* const* fw_seeds, const char* const* rc_seeds,
+                   int32_t n_seeds, int32_t seed_min, uint8_t* out_plan);
+int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const uint8_t* aligned, int64_t* counts);
 
 /* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1, also with a lane switched off in EXEC,
  * readlane, ballot) the DP depends on; writes 320 int32 (see c2_selftest_kernel).  Used by the GPU test-suite. */

@@ -138,3 +138,76 @@ def test_variants_read_fastq_unique_drops_only_the_empty_key(tmp_path):
     got = variants.read_fastq_unique(str(p))
     exp.pop("")
     assert got == exp and list(got) == list(exp)
+
+
+def test_native_strand_plan_equals_the_seed_test(tmp_path):
+    """c2_strand_plan against the seed test of get_new_variant_object (CRISPRessoCORE.py:656-687) as restated in
+    crispresso2_amd.variants._strand_plan (which the variant goldens pin to the reference's function)."""
+    from types import SimpleNamespace
+    from crispresso2_amd import _native, variants, refs as RF
+    rng = np.random.default_rng(21)
+    amp = "".join(rng.choice(list("ACGT"), 230))
+    ref = RF.make_ref("R", amp, [110], [110, 111])
+    reads = []
+    for k in range(6000):
+        s = list(amp)
+        for _ in range(int(rng.integers(0, 12))):
+            s[int(rng.integers(0, len(s)))] = "ACGTN"[int(rng.integers(0, 5))]
+        s = "".join(s[int(rng.integers(0, 60)):len(s) - int(rng.integers(0, 60))])
+        mode = k % 5
+        if mode == 1:
+            s = RF.reverse_complement(s)
+        elif mode == 2:
+            s = s[:len(s) // 2] + RF.reverse_complement(s[len(s) // 2:])        # seeds of both strands
+        elif mode == 3:
+            s = "".join(rng.choice(list("ACGT"), int(rng.integers(1, 40))))      # nothing found
+        reads.append(s)
+    reads += ["", "A", ref["fw_seeds"][0], ref["rc_seeds"][0]]
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    for seed_count, seed_min in ((5, 2), (3, 0), (50, 1), (0, 2)):
+        args = SimpleNamespace(aln_seed_count=seed_count, aln_seed_min=seed_min)
+        m = min(seed_count, len(ref["fw_seeds"]))
+        got = _native.strand_plan(arena, off, ref["fw_seeds"][:m], ref["rc_seeds"][:m], seed_min)
+        exp = np.array([variants._strand_plan(args, s, ref) for s in reads], dtype=np.uint8)
+        assert np.array_equal(got, exp)
+        if seed_count == 5:
+            assert set(np.unique(exp)) == {0, 1, 2}
+
+
+@pytest.mark.parametrize("n_base", [400, 12000])
+def test_native_reverse_complement_merge_equals_the_aggregation_loop(n_base):
+    """c2_merge_reverse_complements against the statements of CRISPRessoCORE.py:3970-3975 on a dict, in cache order;
+    palindromes (counted twice by the reference), lower case, reads with characters reverse_complement() cannot map.
+    The larger case runs the partner search on several threads."""
+    from crispresso2_amd import _native, refs as RF
+    rng = np.random.default_rng(22)
+    base = ["".join(rng.choice(list("ACGTN"), int(rng.integers(4, 30)))) for _ in range(n_base)]
+    reads = list(dict.fromkeys(base + [RF.reverse_complement(b) for b in base[::2]] + ["ACGT", "AATT", "acgt", "AC-GT_N", "ACXGT", "GGCC"]))
+    rng.shuffle(reads)
+    counts = rng.integers(1, 50, len(reads)).astype(np.int64)
+    counts[::13] = 0
+    aligned = rng.random(len(reads)) < 0.8
+    # the reference's loop (variantCache holds the aligned reads only)
+    cache = {r: int(c) for r, c, a in zip(reads, counts, aligned) if a}
+    for variant in cache:
+        variant_count = cache[variant]
+        if variant_count == 0:
+            continue
+        try:
+            rc_variant = RF.reverse_complement(variant)
+        except KeyError:
+            continue
+        if rc_variant in cache and cache[rc_variant] > 0:
+            variant_count += cache[rc_variant]
+            cache[rc_variant] = 0
+            cache[variant] = variant_count
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    got = counts.copy()
+    _native.merge_reverse_complements(arena, off, aligned, got)
+    for k, r in enumerate(reads):
+        assert got[k] == (cache[r] if aligned[k] else counts[k]), r
+    assert got[reads.index("ACGT")] in (0, 2 * counts[reads.index("ACGT")]) or not aligned[reads.index("ACGT")]
