@@ -76,6 +76,7 @@ struct c2_ctx {
     int occ_x_lds[2] = {-1, -1}, occ_x_blocks[2] = {0, 0};   // [0] 4 alignments per wavefront, [1] 2
     DevBuf d_plane;        // pointer-word scratch of the multi-alignment diagonal kernels
     DevBuf d_lists, d_lists_out;   // batched classifier: staging and flat output
+    DevBuf d_order;        // count kernel: histogram + tasks grouped by reference
     int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
     int occ_lds[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
     int occ_blocks[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -393,7 +394,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order};
     for (DevBuf* b : all) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -675,6 +676,21 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     A.refs = (const c2_dev_ref*)ctx->d_refdesc.p; A.counts = (long long*)d_counts;
     A.work_counter = (unsigned long long*)ctx->d_cnt.p;
     A.n_tasks = n_tasks; A.aln_stride = aln_stride; A.n_refs = ctx->n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
+    A.order = nullptr;
+    if (ctx->n_refs > 1 && n_tasks < 0xFFFFFFFFull) {
+        // group the tasks by reference on the device (see c2_ref_histogram_kernel)
+        const size_t hist_bytes = ((size_t)ctx->n_refs * 4 + 255) / 256 * 256;
+        if ((rc = ensure(ctx, ctx->d_order, hist_bytes + n_tasks * sizeof(uint32_t)))) return rc;
+        uint32_t* hist = (uint32_t*)ctx->d_order.p;
+        uint32_t* order = (uint32_t*)((uint8_t*)ctx->d_order.p + hist_bytes);
+        HIPCHK(ctx, hipMemsetAsync(hist, 0, hist_bytes, s));
+        const unsigned gb = (unsigned)((n_tasks + 255) / 256);
+        hipLaunchKernelGGL(c2_ref_histogram_kernel, dim3(gb), dim3(256), 0, s, d_records, n_tasks, hist);
+        hipLaunchKernelGGL(c2_ref_scan_kernel, dim3(1), dim3(64), 0, s, hist, ctx->n_refs);
+        hipLaunchKernelGGL(c2_ref_scatter_kernel, dim3(gb), dim3(256), 0, s, d_records, n_tasks, hist, order);
+        HIPCHK(ctx, hipGetLastError());
+        A.order = order;
+    }
     HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_count_vectors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     int nb = 1;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_count_vectors_kernel, 64 * C2_CNT_WAVES, lds));

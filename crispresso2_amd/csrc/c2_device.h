@@ -157,4 +157,5 @@ typedef struct c2_count_args {
     int32_t hl;                   // histogram length (>= longest reference + longest read + 1)
     int32_t max_t;                // longest alignment the min_matches table covers
     int32_t flags;                // C2_CNT_FLAG_*
+    const uint32_t* order;        // optional: tasks grouped by reference (position -> task), else NULL = task order
 } c2_count_args;

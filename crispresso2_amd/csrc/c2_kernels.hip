@@ -1606,6 +1606,60 @@ __device__ __forceinline__ int c2_wave_incl_scan(int v, int lane) {
     return v;
 }
 
+// Tasks grouped by reference for the count kernel (a chunk of consecutive positions then holds one or two references
+// instead of dozens: with 96 interleaved amplicons the LDS block would be flushed for almost every task).  Counting sort
+// in three tiny launches: histogram of ref_id, exclusive scan (one wavefront), scatter.  The order inside a reference is
+// whatever the atomics give -- the sums do not depend on it.
+// One atomic per distinct reference per wavefront (wave-aggregated): lanes with the same ref_id are found with ballots,
+// their leader adds the group's size, every lane gets base + its rank inside the group.  Returns the lane's slot (or -1).
+__device__ __forceinline__ long long c2_grouped_add(uint32_t* counters, const bool active, const unsigned key, const int lane) {
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long todo = __ballot(active);
+    long long slot = -1;
+    for (int round = 0; round < 4 && todo; ++round) {       // the big groups; what is left after four rounds is scattered
+        const int leader = __builtin_ctzll(todo);
+        const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long grp = __ballot(active && key == k0) & todo;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(counters + k0, (unsigned)__popcll(grp));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+        if ((grp >> lane) & 1ull) slot = (long long)base + __popcll(grp & lt);
+        todo &= ~grp;
+    }
+    if ((todo >> lane) & 1ull) slot = (long long)atomicAdd(counters + key, 1u);
+    return slot;
+}
+
+__global__ __launch_bounds__(256) void c2_ref_histogram_kernel(const c2_aln_record* records, uint64_t n, uint32_t* hist)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool active = t < n;
+    const unsigned key = active ? (unsigned)records[t].ref_id : 0u;
+    (void)c2_grouped_add(hist, active, key, (int)(threadIdx.x & 63));
+}
+
+__global__ __launch_bounds__(64) void c2_ref_scan_kernel(uint32_t* hist, int n_refs)     // hist -> exclusive prefix, in place
+{
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < n_refs; base += 64) {
+        const int k = base + lane;
+        const int x = (k < n_refs) ? (int)hist[k] : 0;
+        const int s = c2_wave_incl_scan(x, lane) + carry;
+        if (k < n_refs) hist[k] = (uint32_t)(s - x);
+        carry = __shfl(s, 63);
+    }
+}
+
+__global__ __launch_bounds__(256) void c2_ref_scatter_kernel(const c2_aln_record* records, uint64_t n, uint32_t* cursor, uint32_t* order)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool active = t < n;
+    const unsigned key = active ? (unsigned)records[t].ref_id : 0u;
+    const long long slot = c2_grouped_add(cursor, active, key, (int)(threadIdx.x & 63));
+    if (active) order[slot] = (uint32_t)t;
+}
+
 __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_count_args A)
 {
     // C2_CNT_WAVES wavefronts share one LDS block (the block is what limits residency, so sharing it multiplies the
@@ -1663,10 +1717,12 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
         const uint64_t chunk_base = (uint64_t)(unsigned)ctl[0] | ((uint64_t)(unsigned)ctl[1] << 32);
         if (chunk_base >= A.n_tasks) break;
         // ---- the records of this wave's K tasks, one per lane; selection test of CRISPRessoCORE.py:697 per lane
-        const uint64_t my_task = chunk_base + (uint64_t)((lane & (K - 1)) * C2_CNT_WAVES + wave);
+        const uint64_t my_pos = chunk_base + (uint64_t)((lane & (K - 1)) * C2_CNT_WAVES + wave);
+        uint64_t my_task = my_pos;
         unsigned d0 = 0, d1 = 0, d2 = 0, d4 = 0, d5 = 0, d6 = 0; int v_w = 0;
         bool sel = false;
-        if (lane < K && my_task < A.n_tasks) {
+        if (lane < K && my_pos < A.n_tasks) {
+            if (A.order) my_task = (uint64_t)A.order[my_pos];            // tasks grouped by reference: few flushes per chunk
             const unsigned* rp = (const unsigned*)(A.records + my_task);
             d0 = rp[0]; d1 = rp[1]; d2 = rp[2]; d4 = rp[4]; d5 = rp[5]; d6 = rp[6];
             const unsigned wq = A.weights ? A.weights[my_task] : 1u;
@@ -1719,7 +1775,8 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 const unsigned r6 = (unsigned)__builtin_amdgcn_readlane((int)d6, kk);
                 if ((int)(r6 >> 16) != tref) continue;
                 pending &= ~(1u << kk);
-                const uint64_t task = chunk_base + (uint64_t)(kk * C2_CNT_WAVES + wave);
+                const uint64_t task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task & 0xffffffffull), kk) |
+                                      ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task >> 32), kk) << 32);
                 const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)d0, kk), r1 = (unsigned)__builtin_amdgcn_readlane((int)d1, kk);
                 const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)d2, kk), r4 = (unsigned)__builtin_amdgcn_readlane((int)d4, kk);
                 const unsigned r5 = (unsigned)__builtin_amdgcn_readlane((int)d5, kk);

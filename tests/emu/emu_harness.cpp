@@ -194,6 +194,15 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     A.aln_read = aln_read; A.aln_ref = aln_ref; A.records = records; A.weights = weights; A.min_matches = min_matches;
     A.refs = refs.data(); A.counts = counts; A.work_counter = &wc; A.n_tasks = n_tasks; A.aln_stride = aln_stride;
     A.n_refs = n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
+    // tasks grouped by reference, as the host library does for more than one reference
+    std::vector<uint32_t> hist(n_refs + 1, 0), order(n_tasks ? n_tasks : 1);
+    A.order = nullptr;
+    if (n_refs > 1) {
+        emu::launch((unsigned)((n_tasks + 255) / 256), [&] { c2_ref_histogram_kernel(records, n_tasks, hist.data()); }, 256);
+        emu::launch(1, [&] { c2_ref_scan_kernel(hist.data(), n_refs); });
+        emu::launch((unsigned)((n_tasks + 255) / 256), [&] { c2_ref_scatter_kernel(records, n_tasks, hist.data(), order.data()); }, 256);
+        A.order = order.data();
+    }
     emu::launch(grid ? grid : 2, [&] { c2_count_vectors_kernel(A); }, 64 * C2_CNT_WAVES);
     return 0;
 }
