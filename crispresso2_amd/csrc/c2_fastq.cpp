@@ -21,7 +21,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
+#include <chrono>
 #include <memory>
+#include <algorithm>
 
 #include "crispresso2_amd.h"
 
@@ -208,7 +210,11 @@ void parse_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t line_no
     }
 }
 
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads) {
+    const bool trace = getenv("C2_FASTQ_TRACE") != nullptr;       // phase times on stderr
+    const double T0 = now_s();
     std::vector<size_t> cut(threads + 1);
     for (unsigned t = 0; t <= threads; ++t) cut[t] = (size_t)((unsigned __int128)n * t / threads);
     std::vector<uint64_t> terms(threads, 0);
@@ -217,6 +223,7 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
         for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] { terms[t] = count_terminators(b, n, cut[t], cut[t + 1]); });
         for (auto& th : pool) th.join();
     }
+    const double T1 = now_s();
     // number of the first line that starts at or after cut[t]: lines started before = 1 + terminators ending before cut[t] - 1
     std::vector<uint64_t> first(threads, 0);
     uint64_t before = 0;                                         // terminators ending at positions < cut[t]
@@ -235,23 +242,109 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
         }
         for (auto& th : pool) th.join();
     }
-    // merge in file order; the first range's table becomes the global one (no copy of its sequences)
-    if (!res[0]->ok) return C2_E_TOO_LARGE;
-    Dedup& G = res[0]->D;
-    uint64_t n_reads = res[0]->n_seq;
-    for (unsigned t = 1; t < threads; ++t) {
-        if (!res[t]->ok) return C2_E_TOO_LARGE;
-        const c2_fastq& P = res[t]->R;
-        for (size_t k = 0; k < P.counts.size(); ++k)
-            if (!G.add(P.arena.data() + P.offsets[k], (size_t)(P.offsets[k + 1] - P.offsets[k]), P.counts[k])) return C2_E_TOO_LARGE;
-        n_reads += res[t]->n_seq;
-        res[t].reset();
+    const double T2 = now_s();
+    // Merge.  Every distinct sequence must end up once, at the position of its first occurrence in the file, with the sum
+    // of its counts.  Partition the hash space over the threads: thread p walks all ranges in file order and keeps, for the
+    // sequences whose hash falls in its partition, the first (range, local index) and the total count -- no two threads
+    // ever touch the same sequence.  The survivors, sorted by that first occurrence, are the global order.
+    for (unsigned t = 0; t < threads; ++t) if (!res[t]->ok) return C2_E_TOO_LARGE;
+    struct First { uint32_t range, local; uint64_t count; };
+    std::vector<std::vector<First>> part(threads);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned p = 0; p < threads; ++p) pool.emplace_back([&, p] {
+            std::vector<First>& mine = part[p];
+            std::vector<uint32_t> table(1u << 12, 0);            // index into `mine` + 1
+            uint64_t mask = table.size() - 1;
+            std::vector<uint64_t> hs;                            // hash of mine[k]
+            for (unsigned t = 0; t < threads; ++t) {
+                const c2_fastq& P = res[t]->R;
+                const std::vector<uint64_t>& H = res[t]->D.hashes;
+                for (size_t k = 0; k < H.size(); ++k) {
+                    const uint64_t h = H[k];
+                    if ((unsigned)((h >> 40) % threads) != p) continue;
+                    const uint8_t* s = P.arena.data() + P.offsets[k];
+                    const size_t len = (size_t)(P.offsets[k + 1] - P.offsets[k]);
+                    uint64_t pos = h & mask;
+                    bool found = false;
+                    while (table[pos]) {
+                        const uint32_t q = table[pos] - 1;
+                        if (hs[q] == h) {
+                            const c2_fastq& Q = res[mine[q].range]->R;
+                            const uint64_t o = Q.offsets[mine[q].local];
+                            if ((size_t)(Q.offsets[mine[q].local + 1] - o) == len && (len == 0 || memcmp(Q.arena.data() + o, s, len) == 0)) {
+                                mine[q].count += P.counts[k]; found = true; break;
+                            }
+                        }
+                        pos = (pos + 1) & mask;
+                    }
+                    if (found) continue;
+                    table[pos] = (uint32_t)mine.size() + 1;
+                    mine.push_back(First{t, (uint32_t)k, P.counts[k]});
+                    hs.push_back(h);
+                    if (mine.size() * 2 > table.size()) {
+                        std::vector<uint32_t> nt(table.size() * 2, 0);
+                        const uint64_t nm = nt.size() - 1;
+                        for (uint32_t q = 0; q < (uint32_t)mine.size(); ++q) { uint64_t pp = hs[q] & nm; while (nt[pp]) pp = (pp + 1) & nm; nt[pp] = q + 1; }
+                        table.swap(nt); mask = nm;
+                    }
+                }
+            }
+        });
+        for (auto& th : pool) th.join();
     }
+    // global order = ascending (range, local index) of the first occurrences: per range, a bitmap-free gather
+    std::vector<std::vector<First>> by_range(threads);
+    for (unsigned p = 0; p < threads; ++p) for (const First& f : part[p]) by_range[f.range].push_back(f);
+    uint64_t n_unique = 0, n_reads = 0;
+    std::vector<uint64_t> first_index(threads + 1, 0);
+    for (unsigned t = 0; t < threads; ++t) { first_index[t] = n_unique; n_unique += by_range[t].size(); n_reads += res[t]->n_seq; }
+    if (n_unique >= 0xfffffffeull) return C2_E_TOO_LARGE;
+    R->offsets.assign(n_unique + 1, 0);
+    R->counts.assign(n_unique, 0);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] {
+            std::vector<First>& v = by_range[t];
+            std::sort(v.begin(), v.end(), [](const First& a, const First& b) { return a.local < b.local; });
+            const c2_fastq& P = res[t]->R;
+            uint64_t g = first_index[t];
+            for (const First& f : v) {
+                R->offsets[g + 1] = P.offsets[f.local + 1] - P.offsets[f.local];      // lengths now, prefix sum below
+                if (f.count > 0xffffffffull) { res[t]->ok = false; return; }
+                R->counts[g] = (uint32_t)f.count;
+                ++g;
+            }
+        });
+        for (auto& th : pool) th.join();
+    }
+    for (unsigned t = 0; t < threads; ++t) if (!res[t]->ok) return C2_E_TOO_LARGE;
+    for (uint64_t g = 0; g < n_unique; ++g) R->offsets[g + 1] += R->offsets[g];
+    R->arena.resize((size_t)R->offsets[n_unique]);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] {
+            const c2_fastq& P = res[t]->R;
+            uint64_t g = first_index[t];
+            for (const First& f : by_range[t]) {
+                memcpy(R->arena.data() + R->offsets[g], P.arena.data() + P.offsets[f.local], (size_t)(P.offsets[f.local + 1] - P.offsets[f.local]));
+                ++g;
+            }
+        });
+        for (auto& th : pool) th.join();
+    }
+    // the empty sequence of a record cut short after its id line: counted like any other sequence, last
+    auto add_empty = [&]() {
+        for (uint64_t g = 0; g < n_unique; ++g)
+            if (R->offsets[g + 1] == R->offsets[g]) { ++R->counts[g]; return; }
+        R->offsets.push_back(R->offsets.back());
+        R->counts.push_back(1);
+    };
+    if (trace) fprintf(stderr, "c2_fastq: %u threads, count %.3f s, parse %.3f s, merge %.3f s\n", threads, T1 - T0, T2 - T1, now_s() - T2);
     // lines in the file = terminators + (1 if the file does not end with one and is not empty); a record whose sequence
     // line never came still counts, with the empty sequence (readline() returned '')
     const uint64_t lines = total_terms + ((n > 0 && !term_end(b, n, n - 1)) ? 1 : 0);
-    if ((lines & 3) == 1) { if (!G.add((const uint8_t*)"", 0)) return C2_E_TOO_LARGE; ++n_reads; }
-    R->arena.swap(res[0]->R.arena); R->offsets.swap(res[0]->R.offsets); R->counts.swap(res[0]->R.counts);
+    if ((lines & 3) == 1) { add_empty(); ++n_reads; }
     R->n_reads = n_reads;
     return 0;
 }
@@ -282,7 +375,7 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
         const size_t n = (size_t)st.st_size;
         int rc = 0;
         if (n > 0) {
-            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m == MAP_FAILED) { close(fd); g_fastq_error = std::string("cannot map ") + path; delete R; return C2_E_INVALID; }
             madvise(m, n, MADV_SEQUENTIAL);
             unsigned threads = std::thread::hardware_concurrency();
