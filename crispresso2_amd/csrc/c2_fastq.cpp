@@ -21,6 +21,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <chrono>
 #include <memory>
 #include <algorithm>
@@ -396,22 +398,40 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
         *out = R;
         return 0;
     }
+    // gzip: zlib inflates on one thread while this thread splits lines and de-duplicates the previous block (two buffers)
     Dedup D(R);
     Lines L(D);
-    std::vector<char> buf(4u << 20);
     gzFile f = gzopen(path, "rb");
     if (!f) { g_fastq_error = std::string("cannot open ") + path; delete R; return C2_E_INVALID; }
     gzbuffer(f, 1u << 20);
-    for (;;) {
-        const int got = gzread(f, buf.data(), (unsigned)buf.size());
-        if (got < 0) {
-            int errnum = 0;
-            g_fastq_error = std::string("read error in ") + path + ": " + gzerror(f, &errnum);
-            gzclose(f); delete R; return C2_E_INVALID;
+    std::vector<char> bufs[2] = {std::vector<char>(8u << 20), std::vector<char>(8u << 20)};
+    int got[2] = {0, 0};
+    std::mutex mu;
+    std::condition_variable cv;
+    int filled[2] = {0, 0};                                   // 0 free, 1 holds data (got[] valid; got <= 0 ends the stream)
+    std::thread producer([&] {
+        for (int k = 0;; k ^= 1) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[k] == 0; }); }
+            const int g = gzread(f, bufs[k].data(), (unsigned)bufs[k].size());
+            { std::lock_guard<std::mutex> lk(mu); got[k] = g; filled[k] = 1; }
+            cv.notify_all();
+            if (g <= 0) return;
         }
-        if (got == 0) break;
-        L.feed(buf.data(), (size_t)got);
-        if (!L.ok) break;
+    });
+    int last = 0;
+    for (int k = 0;; k ^= 1) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[k] == 1; }); }
+        last = got[k];
+        if (last <= 0) break;
+        if (L.ok) L.feed(bufs[k].data(), (size_t)last);
+        { std::lock_guard<std::mutex> lk(mu); filled[k] = 0; }
+        cv.notify_all();
+    }
+    producer.join();
+    if (last < 0) {
+        int errnum = 0;
+        g_fastq_error = std::string("read error in ") + path + ": " + gzerror(f, &errnum);
+        gzclose(f); delete R; return C2_E_INVALID;
     }
     gzclose(f);
     L.finish();
