@@ -428,8 +428,13 @@ def fanc_run():
         for line in fh:
             f = line.rstrip("\n").split("\t")
             nuc[f[0]] = [float(x) for x in f[1:]]
+    raw = {}
+    for name in ("CRISPResso_quantification_of_editing_frequency.txt", "Nucleotide_frequency_table.txt"):
+        with open(os.path.join(exp, name)) as fh:
+            raw[name] = fh.read()
     return {"amplicon": amplicon, "guide": guide, "cut_point": amplicon.index(guide) + len(guide) - 3 - 1, "fastq": fastq,
-            "quantification": quant, "nucleotide_frequency_reference_row": ref_row, "nucleotide_frequency": nuc}
+            "quantification": quant, "nucleotide_frequency_reference_row": ref_row, "nucleotide_frequency": nuc,
+            "expected_files": raw}
 
 
 if __name__ == "__main__" and "--fanc" in sys.argv:

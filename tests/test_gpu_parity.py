@@ -598,6 +598,15 @@ def test_whole_run_fanc_fastq_equals_the_reference_result_tables(mats, ctx, tmp_
     assert list(g["amplicon"]) == g["nucleotide_frequency_reference_row"]
     for base in "ACGTN-":
         assert [float(x) for x in c["all_base_count_vectors_" + base]] == g["nucleotide_frequency"][base], base
+    # the files themselves: byte for byte what the reference repository keeps for this run
+    from crispresso2_amd import tables
+    out = tmp_path / "CRISPResso_on_FANC.Cas9"
+    names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
+    for fn, text in g["expected_files"].items():
+        assert fn in names
+        assert (out / fn).read_text() == text, fn
+    mod = (out / "Modification_count_vectors.txt").read_text().split("\n")
+    assert mod[0].split("\t")[1:] == list(g["amplicon"]) and mod[6].split("\t")[:3] == ["Total", "235", "235"]
 
 
 def test_pipeline_equals_per_read_path_plus_reference_aggregation(mats, ctx):
