@@ -5,24 +5,22 @@
 //   CRISPRessoCOREResources.find_indels_substitutions (CRISPResso2/CRISPRessoCOREResources.pyx:68-187)
 //
 // Design (DESIGN.md has the long form):
-//   * one 64-lane wavefront = one workgroup = one (read, reference) alignment at a time;
-//     workgroups are persistent and stride over the task list.
-//   * the Gotoh M/I/J recurrences run as a systolic anti-diagonal sweep: lane l owns R
-//     consecutive reference rows, at step t it computes read column j = t - l of those rows.
-//     Row-to-row hand-off between neighbouring lanes is one DPP wave_shr:1 per value
-//     (no LDS round trip); lane 0 is fed from the row-0 boundary (or, for references longer
-//     than 64*R rows, from the previous pass's bottom row kept in LDS).
-//   * int32 scores exactly as the reference's C ints; the three tie rules are kept as
-//     compare results, 4 pointer bits per cell, 16 bits per lane-step, stored with one
-//     ds_write_b16 per step into an LDS pointer plane -- the 6 x (Li+1) x (Lj+1) int32
-//     matrices of the reference (1.5 MB per 250x250 alignment) never exist.
-//   * traceback is wave-parallel: the 64 lanes probe 64 consecutive cells along the current
-//     direction (diagonal / row / column), a ballot finds the length of the run, and the run's
-//     columns are emitted by the lanes in one shot; a typical amplicon read needs < 10 rounds.
-//   * the indel / substitution / quantification-window classification is computed from the
-//     aligned strings while they are still in LDS (ballot + popcount prefix scans).
-//   * HBM traffic is the algorithmic minimum: the read comes in once (coalesced byte loads),
-//     the two aligned strings and one 32-byte record go out once.
+//   * every batch runs through a chain of launches; each kernel proves its own results and hands the tasks it cannot prove
+//     to the next one (device-side task lists):
+//       c2_align_diagx_kernel<4>, <2>  lanes own DIAGONALS, the sweep runs over anti-diagonals; 4 or 2 alignments share a
+//                                      wavefront in lane groups isolated by an EXEC-disabled lane; optimality certificate
+//       c2_align_diag_kernel           the same fill with 128 diagonals for one alignment
+//       c2_align_classify_kernel<R,B>  lanes own R reference ROWS (systolic sweep over the whole matrix): any path
+//   * cross-lane traffic is DPP only (wave_shr:1 / wave_shl:1); scores are int32 exactly as the reference's C ints; the
+//     three tie rules are kept as compare results, 4 pointer bits per cell -- the 6 x (Li+1) x (Lj+1) int32 matrices of
+//     the reference (1.5 MB per 250x250 alignment) never exist.
+//   * traceback is wave-parallel: the 64 lanes probe 64 consecutive cells along the current direction (diagonal / row /
+//     column), a ballot finds the length of the run, and the run's columns are emitted by the lanes in one shot.
+//   * the indel / substitution / quantification-window classification is computed from the aligned strings while they are
+//     still in LDS (ballot + popcount prefix scans); c2_count_vectors_kernel turns strings + records into the per-amplicon
+//     count tensor; c2_classify_lists[_batch]_kernel produce the reference's full position lists.
+//   * HBM traffic: the read comes in once (coalesced byte loads), the two aligned strings and one 32-byte record go out
+//     once; the multi-alignment kernels additionally park their pointer words in a scratch plane (written once, read once).
 #include <hip/hip_runtime.h>
 #include "c2_device.h"
 
@@ -998,16 +996,6 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
 // alignments would halve the resident waves; the words are written once, coalesced, and the traceback reads a handful
 // of them), read back with agent-scope loads that bypass the CU's L1.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int c2_med3(int x, int lo, int hi) {          // clamp x to [lo, hi], lo <= hi
-#if defined(__HIP_DEVICE_COMPILE__)
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
-    return r;
-#else
-    return x < lo ? lo : (x > hi ? hi : x);
-#endif
-}
-
 struct c2_diagx_plan {
     uint32_t codeof, table, tmp_read, tmp_ref, stage, slot0, slot_bytes, total, n_words;
     uint32_t codes, read, code, ref, incp;                          // offsets inside one alignment's slot
