@@ -543,7 +543,7 @@ __device__ __forceinline__ void c2_traceback(const PLANE& P, const c2_wg& W, con
 // emits a double-gap column and never puts an insertion column next to a deletion column (I and J only hand over to M),
 // so every gap run is pure and idx advances by one on every non-insertion column.
 __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int T,
-                                                     const int matches, const int lane, c2_aln_record& rec)
+                                                     const int matches, const int lane, c2_aln_record& rec, const int Li, const int Lj)
 {
     const unsigned char* sTmpRead = W.sTmpRead; const unsigned char* sTmpRef = W.sTmpRef; const uint16_t* sIncP = W.sIncP;
     uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
@@ -558,6 +558,20 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
     int n_all_sub = 0, n_win_sub = 0, n_all_ins = 0, n_win_ins = 0, n_all_del = 0, n_win_del = 0;
     int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;   // per-lane partial sums
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (T == Li && T == Lj) {
+        // no gap column in either string (T = Li + insertion columns = Lj + deletion columns): the reference index of a
+        // column is the column, and only substitutions can occur -- most reads of an amplicon run take this path
+        for (int base = 0; base < T; base += 64) {
+            const int cidx = base + lane;
+            const bool in = cidx < T;
+            const unsigned char rd = in ? sTmpRead[T - 1 - cidx] : 0, rfc = in ? sTmpRef[T - 1 - cidx] : 0;
+            const bool sub = in && rd != rfc && rd != 'N';                                  // pyx:113-118
+            const bool sub_win = sub && (sIncP[cidx + 1] != sIncP[cidx]);
+            n_all_sub += __popcll(__ballot(sub));
+            n_win_sub += __popcll(__ballot(sub_win));
+        }
+        last_rd = T - 1;
+    } else
     for (int base = 0; base < T; base += 64) {
         const int cidx = base + lane;
         const bool in = cidx < T;
@@ -698,7 +712,7 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
                 status |= C2_STATUS_NEED_FULL;
                 if (lane == 0) { const unsigned k = atomicAdd(A.fb_count, 1u); A.fb_list[k] = (uint32_t)task; }
             }
-            if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec);
+            if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
         }
         rec.status = (uint8_t)status;
         if (lane == 0) A.records[task] = rec;
@@ -966,7 +980,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
                 __syncthreads();
                 c2_phase_mark<2>(A.phase_cycles, PH);
                 if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec);
+                else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
             }
         }
         if (need_full) {
@@ -1361,7 +1375,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                     __syncthreads();
                     c2_phase_mark<2>(A.phase_cycles, PH);
                     if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                    else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec);
+                    else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
                 }
             }
             if (!requested && s + 1 < NA) request_words(s + 1);
