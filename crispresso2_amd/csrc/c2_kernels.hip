@@ -634,6 +634,45 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
     rec.all_substitutions = (uint16_t)n_all_sub;
 }
 
+// Shortcut for the commonest alignment of an amplicon run: equal lengths and no gap at all.  The reference's traceback stays
+// in state M from (L, L) to (0, 0) iff the H-state of every cell (i, i) is M, i.e. the two low pointer bits of all L main-
+// diagonal cells are clear (start-state rule pyx:349-358 for (L, L); Mptr(i+1, i+1) = H-state of (i, i) for the rest; the
+// boundary cell (0, 0) is M).  64 lanes read those nibbles in ceil(L/64) probes and one ballot decides; the aligned
+// strings are then the read and the reference themselves, and only substitutions can occur.  Returns false (nothing
+// written) if the path leaves the diagonal or a nibble is not stored in this plane.
+template <class PLANE>
+__device__ __forceinline__ bool c2_try_gapless(const PLANE& P, const c2_align_args& A, const c2_wg& W, const uint64_t task, const int L,
+                                               const int lane, c2_aln_record& rec)
+{
+    bool off = false;
+    for (int base = 0; base < L; base += 64) {
+        const int i = base + lane + 1;
+        if (i <= L) { unsigned nib = 0; if (!P.fetch(i, i, nib) || (nib & 3u)) off = true; }
+    }
+    if (__ballot(off)) return false;
+    uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
+    uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
+    const bool strings = !(A.reserved & 1);
+    int matches = 0, n_all_sub = 0, n_win_sub = 0;
+    for (int base = 0; base < L; base += 64) {
+        const int c = base + lane;
+        const bool in = c < L;
+        const unsigned char rd = in ? W.sRead[c] : 0, rf = in ? W.sRef[c] : 0;
+        if (in && strings) { outR[c] = rd; outF[c] = rf; }
+        matches += __popcll(__ballot(in && rd == rf));                                   // pyx:375-376
+        const bool sub = in && rd != rf && rd != 'N';                                    // COREResources.pyx:113-118 (no '-' here)
+        n_all_sub += __popcll(__ballot(sub));
+        n_win_sub += __popcll(__ballot(sub && (W.sIncP[c + 1] != W.sIncP[c])));
+    }
+    const unsigned char r0 = W.sRead[0], f0 = W.sRef[0], rL = W.sRead[L - 1], fL = W.sRef[L - 1];
+    rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
+    rec.aln_len = (uint16_t)L;
+    rec.matches = (uint16_t)matches;
+    rec.substitution_n = (uint16_t)n_win_sub;
+    rec.all_substitutions = (uint16_t)n_all_sub;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Row-strip kernel.  BAND = false: full pointer plane (any path).  BAND = true: only the lanes within A.band_lanes of the
 // main diagonal keep their pointer words (single-pass references only); a traceback that needs a word outside the band
@@ -703,16 +742,18 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
             // =========================== traceback ===========================
             c2_row_plane<R, BAND> plane;
             plane.sPtr = sPtr; plane.max_lj = A.max_lj; plane.colStride = colStride; plane.band_lanes = A.band_lanes;
-            int cnt, matches;
-            bool need_full;
-            c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, need_full);
-            __syncthreads();
-            c2_phase_mark<2>(A.phase_cycles, PH);   // phase 2: traceback
-            if (need_full) {                                   // only possible with BAND
-                status |= C2_STATUS_NEED_FULL;
-                if (lane == 0) { const unsigned k = atomicAdd(A.fb_count, 1u); A.fb_list[k] = (uint32_t)task; }
+            if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
+                int cnt, matches;
+                bool need_full;
+                c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, need_full);
+                __syncthreads();
+                c2_phase_mark<2>(A.phase_cycles, PH);   // phase 2: traceback
+                if (need_full) {                                   // only possible with BAND
+                    status |= C2_STATUS_NEED_FULL;
+                    if (lane == 0) { const unsigned k = atomicAdd(A.fb_count, 1u); A.fb_list[k] = (uint32_t)task; }
+                }
+                if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
             }
-            if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
         }
         rec.status = (uint8_t)status;
         if (lane == 0) A.records[task] = rec;
@@ -974,13 +1015,15 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
             if (!need_full) {
                 c2_diag_plane plane;
                 plane.words = sWords; plane.d0 = d0;
-                int cnt, matches;
-                bool nf2;
-                c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, nf2);
-                __syncthreads();
-                c2_phase_mark<2>(A.phase_cycles, PH);
-                if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
+                if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
+                    int cnt, matches;
+                    bool nf2;
+                    c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, nf2);
+                    __syncthreads();
+                    c2_phase_mark<2>(A.phase_cycles, PH);
+                    if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
+                    else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
+                }
             }
         }
         if (need_full) {
@@ -1369,13 +1412,15 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                     if (s + 1 < NA) { request_words(s + 1); requested = true; }
                     c2_diagx_plane plane;
                     plane.words = sStage; plane.d0 = d0; plane.lpa = LPA;
-                    int cnt, matches;
-                    bool nf2;
-                    c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
-                    __syncthreads();
-                    c2_phase_mark<2>(A.phase_cycles, PH);
-                    if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                    else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
+                    if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
+                        int cnt, matches;
+                        bool nf2;
+                        c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
+                        __syncthreads();
+                        c2_phase_mark<2>(A.phase_cycles, PH);
+                        if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
+                        else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
+                    }
                 }
             }
             if (!requested && s + 1 < NA) request_words(s + 1);
