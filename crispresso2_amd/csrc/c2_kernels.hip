@@ -394,8 +394,11 @@ __device__ __forceinline__ void c2_prefetch_issue(const c2_align_args& A, const 
 // request, CRISPRessoShared.py:399-403) and their codes.  Returns the wave-uniform status bits.  max_li / A.max_lj bound
 // what may be written.  sCodeOf: the 256-entry character -> code table, in LDS.
 __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_wg& W, const unsigned char* sCodeOf, const c2_prefetch& pf,
-                                              const int lane, const int max_li, int& cur_ref, int& Li, int& g0, bool& packed)
+                                              const int lane, const int max_li, int& cur_ref, int& Li, int& g0, bool& packed,
+                                              unsigned char* sCodes4 = nullptr)
 {
+    // sCodes4 (multi-alignment kernel): the zero-padded table of 4 * code per column, written in the same pass -- columns
+    // 1 .. Lj at sCodes4[C2_DIAG_CODE_PAD + 1 ..]; the zeros in front are written once per kernel, the nine behind per task
     const int Lj = pf.Lj, rc = pf.rc;
     int status = 0;
     int read_code_max = 0;
@@ -425,8 +428,10 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
         if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
         W.sRead[k] = ch;
         W.sCode[k] = code;
+        if (sCodes4) sCodes4[C2_DIAG_CODE_PAD + 1 + k] = (unsigned char)(code << 2);
         read_code_max = read_code_max > (int)code ? read_code_max : (int)code;
     }
+    if (sCodes4 && lane < 9) sCodes4[C2_DIAG_CODE_PAD + 1 + LjLoad + lane] = 0;
     {
         int bad = 0;
         for (int k = lane; k < Li && k < max_li; k += 64) if (sCodeOf[W.sRef[k]] == C2_INVALID_CODE) bad = 1;
@@ -1178,6 +1183,8 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
     const int ge = A.gap_extend, go = A.gap_open;
     for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
     if (lane < NA) { sTab[lane * C2X_INTS + C2X_CURREF] = -1; sTab[lane * C2X_INTS + C2X_LI] = 0; sTab[lane * C2X_INTS + C2X_G0] = 0; }
+    for (int s = 0; s < NA; ++s)                                   // zeros in front of column 1 of every slot's symbol table (written once)
+        if (lane <= C2_DIAG_CODE_PAD) c2_smem[P.slot0 + (uint32_t)s * P.slot_bytes + P.codes + lane] = 0;
 
     c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
     // Task fetch as a four-stage software pipeline, one stage per group of NA alignments, so that no stage ever waits for
@@ -1212,7 +1219,8 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 int cref = c2_uni(T + C2X_CURREF), li = c2_uni(T + C2X_LI), g0 = c2_uni(T + C2X_G0);
                 int st = 0;
                 bool packed = false;
-                if (pf[s].valid) st = c2_commit_task(A, wg_of(s), sCodeOf, pf[s], lane, A.max_li, cref, li, g0, packed);
+                if (pf[s].valid) st = c2_commit_task(A, wg_of(s), sCodeOf, pf[s], lane, A.max_li, cref, li, g0, packed,
+                                                      c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes);
                 if (lane == 0) {
                     T[C2X_VALID] = pf[s].valid; T[C2X_TASK_LO] = (int)(unsigned)(pf[s].task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(pf[s].task >> 32);
                     T[C2X_LJ] = pf[s].Lj; T[C2X_REF] = pf[s].ref_id; T[C2X_RC] = pf[s].rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
@@ -1285,13 +1293,6 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                      D >= d0 && D <= d0 + BANDW - 1;
                 if (ok) {
                     any_ok = true;
-                    const c2_wg W = wg_of(s);
-                    // 4 * code of columns 1 .. Lj between zeros: C2_DIAG_CODE_PAD + 1 in front (columns < 1), 9 behind (columns > Lj)
-                    unsigned char* sCodes = c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes;
-                    for (int j = lane; j < C2_DIAG_CODE_PAD + Lj + 2 + 8; j += 64) {
-                        const int col = j - C2_DIAG_CODE_PAD;
-                        sCodes[j] = (col >= 1 && col <= Lj) ? (unsigned char)(W.sCode[col - 1] << 2) : (unsigned char)0;
-                    }
                     minsc = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
                     rowBase = (int)(rf.diag_rows - A.diag_base);
                     const int max_start = (d0 + BANDW - 1 > -d0 ? d0 + BANDW - 1 : -d0) + 2;
