@@ -896,6 +896,67 @@ const int32_t* c2_lists_values(const c2_lists* r) { return r ? r->values.data() 
 const int64_t* c2_lists_counts(const c2_lists* r) { return r ? r->counts.data() : nullptr; }
 void c2_lists_free(c2_lists* r) { delete r; }
 
+int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const uint8_t* f1, const uint8_t* s2, const uint8_t* f2,
+                             uint32_t stride, const int32_t* n1, const int32_t* n2, const uint8_t* q1, const uint8_t* q2,
+                             uint32_t qstride, const int32_t* lq1, const int32_t* lq2, const uint8_t* best1,
+                             uint8_t* out_aln, uint8_t* out_ref, uint8_t* out_qual, uint32_t ostride, int32_t* out_info) {
+    if (!ctx || (n && (!s1 || !f1 || !s2 || !f2 || !n1 || !n2 || !q1 || !q2 || !lq1 || !lq2 || !best1 || !out_aln || !out_ref || !out_qual || !out_info))) {
+        if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID;
+    }
+    if (n == 0) return 0;
+    if (stride == 0 || qstride == 0 || ostride < 2 * stride) { ctx->err = "ostride must be at least 2 * stride"; return C2_E_INVALID; }
+    for (uint64_t t = 0; t < n; ++t)
+        if (n1[t] < 0 || n2[t] < 0 || (uint32_t)n1[t] > stride || (uint32_t)n2[t] > stride || lq1[t] < 0 || lq2[t] < 0 ||
+            (uint32_t)lq1[t] > qstride || (uint32_t)lq2[t] > qstride) { ctx->err = "length exceeds stride"; return C2_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t CH = 65536;
+    int rc;
+    for (uint64_t c0 = 0; c0 < n; c0 += CH) {
+        const uint64_t m = std::min<uint64_t>(CH, n - c0);
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        size_t o = 0;
+        const size_t o_s1 = o; o += al(m * stride);
+        const size_t o_f1 = o; o += al(m * stride);
+        const size_t o_s2 = o; o += al(m * stride);
+        const size_t o_f2 = o; o += al(m * stride);
+        const size_t o_q1 = o; o += al(m * qstride);
+        const size_t o_q2 = o; o += al(m * qstride);
+        const size_t o_n = o; o += al(m * 4 * 4);                 // n1, n2, lq1, lq2
+        const size_t o_b = o; o += al(m);
+        const size_t o_oa = o; o += al(m * ostride);
+        const size_t o_or = o; o += al(m * ostride);
+        const size_t o_oq = o; o += al(m * ostride);
+        const size_t o_info = o; o += al(m * 16);
+        if ((rc = ensure(ctx, ctx->d_lists, o))) return rc;
+        uint8_t* base = (uint8_t*)ctx->d_lists.p;
+        HIPCHK(ctx, hipMemcpyAsync(base + o_s1, s1 + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_f1, f1 + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_s2, s2 + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_f2, f2 + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_q1, q1 + c0 * qstride, m * qstride, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_q2, q2 + c0 * qstride, m * qstride, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_n, n1 + c0, m * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_n + m * 4, n2 + c0, m * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_n + m * 8, lq1 + c0, m * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_n + m * 12, lq2 + c0, m * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(base + o_b, best1 + c0, m, hipMemcpyHostToDevice, s));
+        c2_consensus_args A;
+        A.s1 = base + o_s1; A.f1 = base + o_f1; A.s2 = base + o_s2; A.f2 = base + o_f2; A.q1 = base + o_q1; A.q2 = base + o_q2;
+        A.n1 = (const int32_t*)(base + o_n); A.n2 = A.n1 + m; A.lq1 = A.n1 + 2 * m; A.lq2 = A.n1 + 3 * m;
+        A.best1 = base + o_b; A.n = m; A.stride = stride; A.qstride = qstride; A.ostride = ostride; A.reserved = 0;
+        A.o_aln = base + o_oa; A.o_ref = base + o_or; A.o_qual = base + o_oq; A.o_info = (int32_t*)(base + o_info);
+        hipLaunchKernelGGL(c2_consensus_pairs_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, A);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(out_aln + c0 * ostride, base + o_oa, m * ostride, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(out_ref + c0 * ostride, base + o_or, m * ostride, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(out_qual + c0 * ostride, base + o_oq, m * ostride, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(out_info + c0 * 4, base + o_info, m * 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
 int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out) {
     if (!ctx || !a || !b || !out || n < 0) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -106,6 +106,20 @@ typedef struct c2_classify_batch_args {
     int64_t* counts;              // n x 3: insertion_n, deletion_n, substitution_n (pass 0)
 } c2_classify_batch_args;
 
+// Paired-read consensus (c2_consensus_pairs_kernel): one lane per read pair.
+typedef struct c2_consensus_args {
+    const uint8_t* s1; const uint8_t* f1;   // aligned read 1 / its aligned reference: n x stride
+    const uint8_t* s2; const uint8_t* f2;   // aligned read 2 / its aligned reference
+    const uint8_t* q1; const uint8_t* q2;   // quality strings (one character per non-gap read base): n x qstride
+    const int32_t* n1; const int32_t* n2;   // alignment lengths
+    const int32_t* lq1; const int32_t* lq2; // quality lengths
+    const uint8_t* best1;                   // score_r1 >= score_r2
+    uint64_t n;
+    uint32_t stride, qstride, ostride, reserved;
+    uint8_t* o_aln; uint8_t* o_ref; uint8_t* o_qual;   // n x ostride (ostride >= 2 * stride)
+    int32_t* o_info;                        // n x 4: consensus length, quality length, matching columns, flags (1 caching_is_ok, 2 IndexError in the reference)
+} c2_consensus_args;
+
 // ---- per-amplicon count tensor (what CRISPRessoCORE.py:3865-3901 keeps per reference and :4016-4115 fills) ----
 // One int64 block per reference: C2_CNT_VECTORS vectors of (lmax + 1) entries, then C2_CNT_SCALARS scalars,
 // then C2_CNT_HISTS histograms of hl entries.  crispresso2_amd/counts.py names the slices.

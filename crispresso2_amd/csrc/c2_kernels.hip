@@ -1611,6 +1611,91 @@ __global__ __launch_bounds__(64) void c2_classify_lists_batch_kernel(c2_classify
     }
 }
 
+// get_consensus_alignment_from_pairs (CRISPRessoCORE.py:829-984) with get_greater_qual_nuc (:800-826): the two-pointer walk
+// over the alignments of read 1 and read 2 against the same reference, statement for statement -- including that the
+// double-gap column adds no quality character, that a read alone past the other's end copies its gaps, and that the
+// strings are trimmed where the consensus reference starts or ends with '-'.  A quality index past the end of its string
+// is an IndexError in the reference: flag 2, and the host raises.  One lane per pair.
+__global__ __launch_bounds__(64) void c2_consensus_pairs_kernel(c2_consensus_args A)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (t >= A.n) return;
+    const uint8_t* s1 = A.s1 + t * A.stride; const uint8_t* f1 = A.f1 + t * A.stride;
+    const uint8_t* s2 = A.s2 + t * A.stride; const uint8_t* f2 = A.f2 + t * A.stride;
+    const uint8_t* q1 = A.q1 + t * A.qstride; const uint8_t* q2 = A.q2 + t * A.qstride;
+    const int n1 = A.n1[t], n2 = A.n2[t], lq1 = A.lq1[t], lq2 = A.lq2[t];
+    const bool best1 = A.best1[t] != 0;
+    uint8_t* oa = A.o_aln + t * A.ostride; uint8_t* orf = A.o_ref + t * A.ostride; uint8_t* oq = A.o_qual + t * A.ostride;
+    int start1 = 0; while (start1 < n1 && s1[start1] == '-') ++start1;            // len(s) - len(s.lstrip('-'))
+    int start2 = 0; while (start2 < n2 && s2[start2] == '-') ++start2;
+    int stop1 = n1 - 1; while (stop1 >= 0 && s1[stop1] == '-') --stop1;            // len(s.rstrip('-')) - 1
+    int stop2 = n2 - 1; while (stop2 >= 0 && s2[stop2] == '-') --stop2;
+    int i1 = 0, i2 = 0, qi1 = 0, qi2 = 0, na = 0, nq = 0;
+    bool caching = true, index_error = false;
+    auto Q1 = [&]() -> uint8_t { if (qi1 >= lq1) { index_error = true; return (uint8_t)'!'; } return q1[qi1]; };
+    auto Q2 = [&]() -> uint8_t { if (qi2 >= lq2) { index_error = true; return (uint8_t)'!'; } return q2[qi2]; };
+    auto greater = [&](uint8_t c1, uint8_t a, uint8_t c2, uint8_t b, uint8_t& nuc, uint8_t& q) {     // :800-826
+        if (c1 == c2) { nuc = c1; q = a >= b ? a : b; return; }
+        caching = false;
+        if (a == b) { nuc = best1 ? c1 : c2; q = b; }
+        else if (a > b) { nuc = c1; q = a; }
+        else { nuc = c2; q = b; }
+    };
+    while ((i1 < n1 || i2 < n2) && !index_error) {
+        const bool in1 = i1 < n1, in2 = i2 < n2;
+        if (in1 && f1[i1] == '-' && in2 && f2[i2] == '-') {
+            uint8_t nuc, q; const uint8_t a = Q1(), b = Q2();
+            greater(s1[i1], a, s2[i2], b, nuc, q);
+            oa[na] = nuc; orf[na] = '-'; ++na; oq[nq++] = q;
+            ++qi1; ++qi2; ++i1; ++i2;
+            continue;
+        } else if (in1 && f1[i1] == '-') {
+            oa[na] = s1[i1]; orf[na] = '-'; ++na; oq[nq++] = Q1();
+            ++qi1; ++i1;
+            continue;
+        } else if (in2 && f2[i2] == '-') {
+            oa[na] = s2[i2]; orf[na] = '-'; ++na; oq[nq++] = Q2();
+            ++qi2; ++i2;
+            continue;
+        }
+        if (in1 && s1[i1] == '-' && in2 && s2[i2] == '-') {
+            oa[na] = ((start1 <= i1 && i1 <= stop1) || (start2 <= i2 && i2 <= stop2)) ? '-' : 'N';
+            orf[na] = f1[i1]; ++na;
+        } else if (in1 && s1[i1] == '-' && in2 && s2[i2] != '-') {
+            oa[na] = s2[i2]; orf[na] = f2[i2]; ++na; oq[nq++] = Q2(); ++qi2;
+        } else if (in1 && s1[i1] != '-' && in2 && s2[i2] == '-') {
+            oa[na] = s1[i1]; orf[na] = f1[i1]; ++na; oq[nq++] = Q1(); ++qi1;
+        } else if (in1 && in2) {
+            uint8_t nuc, q; const uint8_t a = Q1(), b = Q2();
+            greater(s1[i1], a, s2[i2], b, nuc, q);
+            oa[na] = nuc; orf[na] = f1[i1]; ++na; oq[nq++] = q; ++qi1; ++qi2;
+        } else if (in1) {
+            oa[na] = (s1[i1] == '-' && start1 <= i1 && i1 <= stop1) ? (uint8_t)'N' : s1[i1];
+            oq[nq++] = Q1(); orf[na] = f1[i1]; ++na; ++qi1;
+        } else if (in2) {
+            oa[na] = (s2[i2] == '-' && start2 <= i2 && i2 <= stop2) ? (uint8_t)'N' : s2[i2];
+            oq[nq++] = Q2(); orf[na] = f2[i2]; ++na; ++qi2;
+        }
+        ++i1; ++i2;
+    }
+    // trim where the consensus reference starts / ends with '-' (quality string sliced by the same counts, :968-975)
+    int lead = 0; while (lead < na && orf[lead] == '-') ++lead;
+    int trail = 0; while (trail < na - lead && orf[na - 1 - trail] == '-') ++trail;
+    if (lead >= na) index_error = true;                                            // final_ref[0] on an empty string
+    const int len = index_error ? 0 : na - lead - trail;
+    int qlen = nq - (lead < nq ? lead : nq);
+    qlen -= (trail < qlen ? trail : qlen);
+    int hom = 0;
+    for (int k = 0; k < len; ++k) {
+        const uint8_t a = oa[lead + k], r = orf[lead + k];
+        oa[k] = a; orf[k] = r;
+        hom += (a == r);
+    }
+    for (int k = 0; k < qlen; ++k) oq[k] = oq[(lead < nq ? lead : nq) + k];
+    int32_t* info = A.o_info + t * 4;
+    info[0] = len; info[1] = qlen; info[2] = hom; info[3] = (caching ? 1 : 0) | (index_error ? 2 : 0);
+}
+
 // calculate_homology, COREResources.pyx:318-327 (float32 accumulator; result = score / strlen(a))
 __global__ __launch_bounds__(64) void c2_homology_kernel(const uint8_t* a, const uint8_t* b, int n, float* out)
 {

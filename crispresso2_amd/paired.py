@@ -1,0 +1,219 @@
+"""Paired reads: batched equivalents of the reference's `get_consensus_alignment_from_pairs` (CRISPRessoCORE.py:829-984) and
+`get_new_variant_object_from_paired` (:987-1169).
+
+Both reads of a pair are aligned to every reference on the device (one batch; forward and/or reverse-complement as the
+seed test over BOTH reads decides, :1024-1064), the two alignments are merged column by column by
+c2_consensus_pairs_kernel (one lane per pair: the reference's two-pointer walk with its quality rule, :800-826), and the
+consensus alignments of the best references are classified by the batched classifier.  The per-pair dicts equal the
+reference's, including what it leaves out for pairs (no 'aln_strand', no 'best_match_name', float
+'insertions_outside_window' / 'total_mods') and `caching_is_ok` of the LAST consensus call of the pair.
+"""
+import ctypes
+
+import numpy as np
+
+from . import CRISPRessoCOREResources, _native
+from .batch import BatchAligner
+
+
+def _rows(strings, stride):
+    a = np.zeros((len(strings), stride), dtype=np.uint8)
+    for k, s in enumerate(strings):
+        b = s.encode() if isinstance(s, str) else bytes(s)
+        a[k, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+    return a
+
+
+def consensus_batch(items, ctx=None):
+    """items: sequence of (aln_seq_r1, aln_ref_r1, score_r1, qual_r1, aln_seq_r2, aln_ref_r2, score_r2, qual_r2).
+    -> list of (final_aln, final_qual, final_ref, score, caching_is_ok) as the reference returns them; an item on which the
+    reference raises IndexError (a quality index past the end of its string) raises IndexError here."""
+    n = len(items)
+    if n == 0:
+        return []
+    ctx = ctx or _native.default_context()
+    n1 = np.array([len(it[1]) for it in items], dtype=np.int32)
+    n2 = np.array([len(it[5]) for it in items], dtype=np.int32)
+    for it in items:
+        if len(it[0]) < len(it[1]) or len(it[4]) < len(it[5]):
+            raise IndexError('string index out of range')
+    lq1 = np.array([len(it[3]) for it in items], dtype=np.int32)
+    lq2 = np.array([len(it[7]) for it in items], dtype=np.int32)
+    stride = max(16, (int(max(n1.max(), n2.max())) + 15) // 16 * 16)
+    qstride = max(16, (int(max(lq1.max(), lq2.max())) + 15) // 16 * 16)
+    ostride = 2 * stride
+    s1, f1 = _rows([it[0][:len(it[1])] for it in items], stride), _rows([it[1] for it in items], stride)
+    s2, f2 = _rows([it[4][:len(it[5])] for it in items], stride), _rows([it[5] for it in items], stride)
+    q1, q2 = _rows([it[3] for it in items], qstride), _rows([it[7] for it in items], qstride)
+    best1 = np.array([1 if it[2] >= it[6] else 0 for it in items], dtype=np.uint8)        # is_best_aln_r1, :876
+    oa = np.zeros((n, ostride), dtype=np.uint8)
+    orf = np.zeros((n, ostride), dtype=np.uint8)
+    oq = np.zeros((n, ostride), dtype=np.uint8)
+    info = np.zeros((n, 4), dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ctx.check(ctx.lib.c2_consensus_pairs_batch(ctx.handle, ctypes.c_uint64(n), p(s1), p(f1), p(s2), p(f2), ctypes.c_uint32(stride),
+                                               p(n1), p(n2), p(q1), p(q2), ctypes.c_uint32(qstride), p(lq1), p(lq2), p(best1),
+                                               p(oa), p(orf), p(oq), ctypes.c_uint32(ostride), p(info)), "c2_consensus_pairs_batch")
+    out = []
+    for k in range(n):
+        ln, lq, hom, fl = (int(x) for x in info[k])
+        if fl & 2:
+            raise IndexError('string index out of range')
+        out.append((oa[k, :ln].tobytes().decode(), oq[k, :lq].tobytes().decode(), orf[k, :ln].tobytes().decode(),
+                    round(float(100 * hom / float(ln)), 3), bool(fl & 1)))
+    return out
+
+
+def get_consensus_alignment_from_pairs(aln_seq_r1, aln_ref_r1, score_r1, qual_r1, aln_seq_r2, aln_ref_r2, score_r2, qual_r2):
+    """Same signature and return value as the reference function (CRISPRessoCORE.py:829)."""
+    return consensus_batch([(aln_seq_r1, aln_ref_r1, score_r1, qual_r1, aln_seq_r2, aln_ref_r2, score_r2, qual_r2)])[0]
+
+
+def _pair_plan(args, s1, s2, ref):
+    """0 forward, 1 reverse complement, 2 both: the seed test over both reads of the pair (:1024-1036)."""
+    found_fw = found_rc = 0
+    for k in range(min(args.aln_seed_count, len(ref['fw_seeds']))):
+        if ref['fw_seeds'][k] in s1 or ref['fw_seeds'][k] in s2:
+            found_fw += 1
+        if ref['rc_seeds'][k] in s1 or ref['rc_seeds'][k] in s2:
+            found_rc += 1
+    if found_fw > args.aln_seed_min and found_rc == 0:
+        return 0
+    if found_fw == 0 and found_rc > args.aln_seed_min:
+        return 1
+    return 2
+
+
+def get_new_variant_objects_from_paired(args, pairs, refs, ref_names, aln_matrix, pe_scaffold_dna_info=None, ctx=None):
+    """pairs: sequence of (fastq1_seq, fastq2_seq, fastq1_qual, fastq2_qual).  One dict per pair, equal to
+    get_new_variant_object_from_paired(args, *pair, refs, ref_names, aln_matrix, pe_scaffold_dna_info)."""
+    from copy import deepcopy
+    ctx = ctx or _native.default_context()
+    aligner = BatchAligner([refs[n]['sequence'] for n in ref_names], [refs[n]['gap_incentive'] for n in ref_names],
+                           [refs[n]['include_idxs'] for n in ref_names], aln_matrix,
+                           args.needleman_wunsch_gap_open, args.needleman_wunsch_gap_extend, ctx=ctx)
+    npairs, k = len(pairs), len(ref_names)
+    # ---- every alignment the pairs need: (pair, reference, strand) x (read 1, read 2)
+    plans = [[_pair_plan(args, p[0], p[1], refs[name]) for name in ref_names] for p in pairs]
+    reads, rids, strands, slot = [], [], [], {}
+    for i, p in enumerate(pairs):
+        for r in range(k):
+            for st in ((0,) if plans[i][r] == 0 else (1,) if plans[i][r] == 1 else (0, 1)):
+                slot[(i, r, st)] = len(reads)
+                reads += [p[0], p[1]]
+                rids += [r, r]
+                strands += [st, st]
+    res = aligner.align(reads, ref_ids=np.array(rids, dtype=np.uint16), strands=np.array(strands, dtype=np.uint8)) if reads else None
+    if res is not None:
+        bad = res.records['status'] != 0
+        if bad.any():
+            st = int(res.records['status'][np.nonzero(bad)[0][0]])
+            if st & _native.STATUS_RC_CHAR:
+                raise KeyError("reverse_complement: character outside ACGTN_-")
+            raise Exception('global_align: undefined alignment (status %d)' % st)
+        scores = res.scores
+    # ---- consensus of every (pair, reference, strand)
+    items, item_of = [], {}
+    for key, t in slot.items():
+        i = key[0]
+        a1, a2 = res.strings(t), res.strings(t + 1)
+        item_of[key] = len(items)
+        items.append((a1[0], a1[1], float(scores[t]), pairs[i][2], a2[0], a2[1], float(scores[t + 1]), pairs[i][3]))
+    cons = consensus_batch(items, ctx=ctx)
+    # ---- per pair: reference choice (:1066-1081) -> classifier jobs
+    chosen, jobs, job_sets = [], [], []
+    for i in range(npairs):
+        aln_scores, ref_aln_details = [], []
+        best_match_score = -1
+        best_s1s, best_s2s, best_names = [], [], []
+        caching_is_ok = True
+        for r, ref_name in enumerate(ref_names):
+            pl = plans[i][r]
+            if pl == 0 or pl == 1:
+                s1, qual, s2, score, caching_is_ok = cons[item_of[(i, r, pl)]]
+            else:
+                fws1, fwqual, fws2, fwscore, _ = cons[item_of[(i, r, 0)]]
+                rvs1, rvqual, rvs2, rvscore, caching_is_ok = cons[item_of[(i, r, 1)]]      # caching flag of the LAST call, :1049
+                s1, qual, s2, score = fws1, fwqual, fws2, fwscore
+                if rvscore > fwscore:
+                    s1, qual, s2, score = rvs1, rvqual, rvs2, rvscore
+            aln_scores.append(score)
+            ref_aln_details.append((ref_name, s1, s2, score, qual))
+            if score > best_match_score and score > refs[ref_name]['min_aln_score']:
+                best_match_score = score
+                best_s1s, best_s2s, best_names = [s1], [s2], [ref_name]
+            elif score == best_match_score:
+                best_s1s.append(s1)
+                best_s2s.append(s2)
+                best_names.append(ref_name)
+        first_job = len(jobs)
+        if best_match_score > 0:
+            for idx, name in enumerate(best_names):
+                jobs.append((best_s1s[idx], best_s2s[idx]))
+                job_sets.append(ref_names.index(name))
+        chosen.append((aln_scores, ref_aln_details, best_match_score, best_s1s, best_s2s, best_names, caching_is_ok, first_job))
+    payloads = CRISPRessoCOREResources.find_indels_substitutions_batch(
+        jobs, [refs[name]['include_idxs'] for name in ref_names], set_ids=np.array(job_sets, dtype=np.uint16),
+        legacy=bool(args.use_legacy_insertion_quantification), ctx=ctx)
+    variants = []
+    for i in range(npairs):
+        aln_scores, ref_aln_details, best_match_score, best_s1s, best_s2s, best_names, caching_is_ok, first_job = chosen[i]
+        new_variant = {'count': 1}
+        if best_match_score <= 0:                                  # :1145-1152
+            new_variant['aln_scores'] = aln_scores
+            new_variant['ref_aln_details'] = ref_aln_details
+            new_variant['best_match_score'] = best_match_score
+            new_variant['caching_is_ok'] = caching_is_ok
+            variants.append(new_variant)
+            continue
+        new_variant['aln_ref_names'] = best_names
+        new_variant['aln_scores'] = aln_scores
+        new_variant['ref_aln_details'] = ref_aln_details
+        new_variant['best_match_score'] = best_match_score
+        new_variant['caching_is_ok'] = caching_is_ok
+        class_names = []
+        for idx, best_match_name in enumerate(best_names):
+            s1, s2 = best_s1s[idx], best_s2s[idx]
+            payload = payloads[first_job + idx]
+            payload['ref_name'] = best_match_name
+            payload['aln_scores'] = aln_scores
+            is_modified = False
+            if not args.ignore_deletions and payload['deletion_n'] > 0:
+                is_modified = True
+            elif not args.ignore_insertions and payload['insertion_n'] > 0:
+                is_modified = True
+            elif not args.ignore_substitutions and payload['substitution_n'] > 0:
+                is_modified = True
+            payload['irregular_ends'] = False                      # :1106-1110
+            if s1[0] == '-' or s2[0] == '-' or s1[0] != s2[0]:
+                payload['irregular_ends'] = True
+            elif s1[-1] == '-' or s2[-1] == '-' or s1[-1] != s2[-1]:
+                payload['irregular_ends'] = True
+            payload['insertions_outside_window'] = (len(payload['all_insertion_positions']) / 2) - (len(payload['insertion_positions']) / 2)
+            payload['deletions_outside_window'] = len(payload['all_deletion_coordinates']) - len(payload['deletion_coordinates'])
+            payload['substitutions_outside_window'] = len(payload['all_substitution_positions']) - len(payload['substitution_positions'])
+            payload['total_mods'] = (len(payload['all_insertion_positions']) / 2) + len(payload['all_deletion_positions']) + len(payload['all_substitution_positions'])
+            payload['mods_in_window'] = payload['substitution_n'] + payload['deletion_n'] + payload['insertion_n']
+            payload['mods_outside_window'] = payload['total_mods'] - payload['mods_in_window']
+            class_names.append(best_match_name + ("_MODIFIED" if is_modified else "_UNMODIFIED"))
+            payload['classification'] = 'MODIFIED' if is_modified else 'UNMODIFIED'
+            payload['aln_seq'] = s1
+            payload['aln_ref'] = s2
+            new_variant['variant_' + best_match_name] = payload
+        new_variant['class_name'] = "&".join(class_names)
+        if len(best_names) > 1:                                    # :1155-1160
+            if args.assign_ambiguous_alignments_to_first_reference:
+                new_variant['class_name'] = class_names[0]
+                new_variant['aln_ref_names'] = [best_names[0]]
+            elif not args.expand_ambiguous_alignments:
+                new_variant['class_name'] = 'AMBIGUOUS'
+        if getattr(args, 'prime_editing_pegRNA_scaffold_seq', '') and 'Prime-edited' in best_names:          # :1164-1172
+            loc = new_variant['variant_Prime-edited']['ref_positions'].index(pe_scaffold_dna_info[0] - 1) + 1
+            if new_variant['variant_Prime-edited']['aln_seq'][loc:(loc + len(pe_scaffold_dna_info[1]))] == pe_scaffold_dna_info[1]:
+                new_variant['aln_ref_names'] = ["Scaffold-incorporated"]
+                new_variant['class_name'] = "Scaffold-incorporated"
+                old_payload = deepcopy(new_variant['variant_Prime-edited'])
+                old_payload['ref_name'] = "Scaffold-incorporated"
+                new_variant['variant_' + "Scaffold-incorporated"] = old_payload
+        variants.append(new_variant)
+    return variants

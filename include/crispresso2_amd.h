@@ -241,6 +241,17 @@ void c2_lists_free(c2_lists* r);
  * counters to out4 (may be NULL) and clears them, then sets the mode. */
 int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4);
 
+/* Paired reads: get_consensus_alignment_from_pairs (CRISPRessoCORE.py:829-984) for n pairs at once.  Host pointers.
+ * s1/f1, s2/f2: aligned read / aligned reference of read 1 and read 2 (n rows of `stride` bytes, n1[t] / n2[t] columns);
+ * q1/q2: the reads' quality strings (n rows of `qstride`, lq1[t] / lq2[t] characters); best1[t] = (score_r1 >= score_r2).
+ * Outputs: n rows of `ostride` >= 2*stride bytes each for the consensus aligned sequence, reference and quality, and
+ * out_info[t] = {length of sequence and reference, length of the quality string, columns where they are equal, flags:
+ * 1 = caching_is_ok, 2 = the reference raises IndexError on these inputs}. */
+int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const uint8_t* f1, const uint8_t* s2, const uint8_t* f2,
+                             uint32_t stride, const int32_t* n1, const int32_t* n2, const uint8_t* q1, const uint8_t* q2,
+                             uint32_t qstride, const int32_t* lq1, const int32_t* lq2, const uint8_t* best1,
+                             uint8_t* out_aln, uint8_t* out_ref, uint8_t* out_qual, uint32_t ostride, int32_t* out_info);
+
 /* ---- FASTQ ingest + exact de-duplication (host code, no GPU): the first pass of process_fastq,
  * CRISPRessoCORE.py:1820-1849 -- every 4-line record's sequence line, str.strip()'ed, counted per distinct sequence in
  * first-seen order; plain or gzip'ed input, universal newlines.  The result owns: the unique sequences back to back

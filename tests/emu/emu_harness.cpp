@@ -176,6 +176,19 @@ int emu_classify_lists_batch(uint64_t n, const uint8_t* aln_read, const uint8_t*
     return 0;
 }
 
+int emu_consensus_pairs(uint64_t n, const uint8_t* s1, const uint8_t* f1, const uint8_t* s2, const uint8_t* f2, uint32_t stride,
+                        const int32_t* n1, const int32_t* n2, const uint8_t* q1, const uint8_t* q2, uint32_t qstride,
+                        const int32_t* lq1, const int32_t* lq2, const uint8_t* best1,
+                        uint8_t* o_aln, uint8_t* o_ref, uint8_t* o_qual, uint32_t ostride, int32_t* o_info)
+{
+    c2_consensus_args A;
+    A.s1 = s1; A.f1 = f1; A.s2 = s2; A.f2 = f2; A.q1 = q1; A.q2 = q2; A.n1 = n1; A.n2 = n2; A.lq1 = lq1; A.lq2 = lq2; A.best1 = best1;
+    A.n = n; A.stride = stride; A.qstride = qstride; A.ostride = ostride; A.reserved = 0;
+    A.o_aln = o_aln; A.o_ref = o_ref; A.o_qual = o_qual; A.o_info = o_info;
+    emu::launch((unsigned)((n + 63) / 64), [&] { c2_consensus_pairs_kernel(A); });
+    return 0;
+}
+
 int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t aln_stride,
                       const c2_aln_record* records, const uint32_t* weights, const uint16_t* min_matches, int max_t,
                       int n_refs, const int32_t* lens, const int32_t* const* include_idx, const int32_t* n_include,

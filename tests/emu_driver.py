@@ -130,6 +130,33 @@ def classify_lists_batch(pairs, includes, legacy=False):
     return [([values[index[t * N_LISTS + k]:index[t * N_LISTS + k + 1]].tolist() for k in range(N_LISTS)], counts[t].tolist()) for t in range(n)]
 
 
+def consensus_pairs(items):
+    """items: (aln_seq_r1, aln_ref_r1, score_r1, qual_r1, aln_seq_r2, aln_ref_r2, score_r2, qual_r2) -> per item
+    (final_aln, final_qual, final_ref, matching columns, caching_is_ok, index_error)"""
+    n = len(items)
+
+    def rows(strs, stride):
+        a = np.zeros((n, stride), dtype=np.uint8)
+        for k, x in enumerate(strs):
+            a[k, :len(x)] = np.frombuffer(x.encode(), dtype=np.uint8)
+        return a
+    n1 = np.array([len(it[1]) for it in items], dtype=np.int32); n2 = np.array([len(it[5]) for it in items], dtype=np.int32)
+    lq1 = np.array([len(it[3]) for it in items], dtype=np.int32); lq2 = np.array([len(it[7]) for it in items], dtype=np.int32)
+    stride = int(max(n1.max(), n2.max())) + 1; qstride = int(max(lq1.max(), lq2.max())) + 1; ostride = 2 * stride
+    s1, f1 = rows([it[0] for it in items], stride), rows([it[1] for it in items], stride)
+    s2, f2 = rows([it[4] for it in items], stride), rows([it[5] for it in items], stride)
+    q1, q2 = rows([it[3] for it in items], qstride), rows([it[7] for it in items], qstride)
+    best1 = np.array([1 if it[2] >= it[6] else 0 for it in items], dtype=np.uint8)
+    oa = np.zeros((n, ostride), dtype=np.uint8); orf = np.zeros((n, ostride), dtype=np.uint8); oq = np.zeros((n, ostride), dtype=np.uint8)
+    info = np.zeros((n, 4), dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib().emu_consensus_pairs(ctypes.c_uint64(n), p(s1), p(f1), p(s2), p(f2), ctypes.c_uint32(stride), p(n1), p(n2), p(q1), p(q2),
+                                   ctypes.c_uint32(qstride), p(lq1), p(lq2), p(best1), p(oa), p(orf), p(oq), ctypes.c_uint32(ostride), p(info))
+    assert rc == 0
+    return [(oa[k, :info[k, 0]].tobytes().decode(), oq[k, :info[k, 1]].tobytes().decode(), orf[k, :info[k, 0]].tobytes().decode(),
+             int(info[k, 2]), bool(info[k, 3] & 1), bool(info[k, 3] & 2)) for k in range(n)]
+
+
 def count_vectors(aln_read, aln_ref, records, ref_lens, includes, max_read_len, weights=None, min_matches=None, flags=0, grid=2):
     """aln_read/aln_ref: uint8 [n, stride]; records: REC_DTYPE [n].  -> (counts int64 [n_refs, per_ref], layout)"""
     import sys

@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -442,6 +442,133 @@ if __name__ == "__main__" and "--fanc" in sys.argv:
     with gzip.open(os.path.join(HERE, "fanc_run.json.gz"), "wt") as fh:
         json.dump(fanc_run(), fh, separators=(",", ":"))
     print("fanc_run.json.gz written")
+
+
+# ---------------------------------------------------------------- 7. paired reads (CRISPRessoCORE.py:800-1169)
+def paired_goldens():
+    """(a) every call the reference's own unit test makes to get_consensus_alignment_from_pairs
+    (tests/unit_tests/test_CRISPRessoCORE.py:27-460), recorded through a proxy; (b) the same function on read pairs cut
+    from the FANC reads (R1 = head, R2 = tail, overlapping or not, substitutions in the overlap, random qualities),
+    aligned by the reference's global_align; (c) get_new_variant_object_from_paired on such pairs."""
+    import contextlib
+    import importlib.util
+    from crispresso2_amd import refs as RF
+    core = load_reference_core()
+    out = {"unit": [], "fuzz": [], "variants": []}
+
+    def record(bucket):
+        orig = core.get_consensus_alignment_from_pairs
+
+        def proxy(*a):
+            try:
+                res = orig(*a)
+                bucket.append({"args": jsonable(list(a)), "out": jsonable(list(res))})
+                return res
+            except Exception as e:                                  # the reference's undefined corner (IndexError on qualities)
+                bucket.append({"args": jsonable(list(a)), "raises": type(e).__name__})
+                raise
+        return orig, proxy
+
+    # (a)
+    class _Check(contextlib.nullcontext):                            # stand-in for pytest_check.check: the asserts of the
+        def __getattr__(self, name):                                 # reference's test are not what is recorded here
+            return lambda *a, **k: None
+    pc = types.ModuleType("pytest_check")
+    pc.check = _Check()
+    sys.modules["pytest_check"] = pc
+    isn = types.ModuleType("inline_snapshot")
+    isn.snapshot = lambda x=None: x
+    sys.modules["inline_snapshot"] = isn
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        spec = importlib.util.spec_from_file_location("ref_test_core", os.path.join(REF, "tests/unit_tests/test_CRISPRessoCORE.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        orig, proxy = record(out["unit"])
+        core.get_consensus_alignment_from_pairs = proxy
+        try:
+            mod.test_get_consensus_alignment_from_pairs()
+        finally:
+            core.get_consensus_alignment_from_pairs = orig
+    finally:
+        os.chdir(cwd)
+
+    # (b) + (c)
+    with open(os.path.join(REF, "tests/Cas9.amplicons.txt")) as fh:
+        for line in fh:
+            f = line.split()
+            if f and f[0] == "FANC":
+                fanc = f[1].upper()
+    seqs = []
+    with open(os.path.join(REF, "tests/FANC.Cas9.fastq")) as fh:
+        lines = fh.read().split("\n")
+    for k in range(1, len(lines), 4):
+        if lines[k] and lines[k] not in seqs and set(lines[k]) <= set("ACGTN"):
+            seqs.append(lines[k])
+    rng = np.random.default_rng(31)
+    g = np.zeros(len(fanc) + 1, dtype=np.int64)
+    g[92] = 1
+
+    def make_pair(s):
+        n = len(s)
+        a = int(rng.integers(n // 3, n - 10))                        # R1 = s[:a]
+        b = int(rng.integers(5, min(n - 5, a + 40)))                 # R2 = s[b:]  (b < a: overlap; b > a: a hole between the reads)
+        r1, r2 = list(s[:a]), list(s[b:])
+        for _ in range(int(rng.integers(0, 4))):
+            r2[int(rng.integers(0, len(r2)))] = "ACGT"[int(rng.integers(0, 4))]
+        q = lambda m: "".join(chr(int(x)) for x in rng.integers(35, 75, m))
+        return "".join(r1), "".join(r2), q(len(r1)), q(len(r2))
+
+    pairs = [make_pair(seqs[k % len(seqs)]) for k in range(260)]
+    orig, proxy = record(out["fuzz"])
+    for r1, r2, q1, q2 in pairs:
+        a1 = A.global_align(r1, fanc, matrix=EDNA, gap_incentive=g, gap_open=-20, gap_extend=-2)
+        a2 = A.global_align(r2, fanc, matrix=EDNA, gap_incentive=g, gap_open=-20, gap_extend=-2)
+        try:
+            proxy(a1[0], a1[1], a1[2], q1, a2[0], a2[1], a2[2], q2)
+        except Exception:
+            pass
+    hdr = fanc[:88] + "GATTACA" + fanc[95:]
+    for label, ref_specs, flags in (("FANC", [("FANC", fanc)], {}),
+                                    ("FANC+HDR", [("FANC", fanc), ("HDR", hdr)], {}),
+                                    ("FANC+HDR expand legacy", [("FANC", fanc), ("HDR", hdr)], {"expand_ambiguous_alignments": True, "use_legacy_insertion_quantification": True})):
+        args = types.SimpleNamespace(aln_seed_count=5, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                                     use_legacy_insertion_quantification=False, ignore_deletions=False, ignore_insertions=False,
+                                     ignore_substitutions=False, assign_ambiguous_alignments_to_first_reference=False,
+                                     expand_ambiguous_alignments=False, prime_editing_pegRNA_scaffold_seq="")
+        for k, v in flags.items():
+            setattr(args, k, v)
+        refs, names = {}, []
+        for nm, sq in ref_specs:
+            refs[nm] = RF.make_ref(nm, sq, [91], [91, 92], min_aln_score=60)
+            names.append(nm)
+        sample, outs = [], []
+        for k, (r1, r2, q1, q2) in enumerate(pairs[:90 if label == "FANC" else 45]):
+            if k % 4 == 1:                                           # both reads from the other strand
+                r1, r2 = RF.reverse_complement(r1), RF.reverse_complement(r2)
+            elif k % 11 == 2:                                        # unrelated pair
+                r1 = "".join(rng.choice(list("ACGT"), 120)); q1 = "I" * 120
+            try:
+                v = core.get_new_variant_object_from_paired(args, r1, r2, q1, q2, refs, names, EDNA, None)
+            except Exception as e:
+                sample.append([r1, r2, q1, q2]); outs.append({"raises": type(e).__name__})
+                continue
+            sample.append([r1, r2, q1, q2])
+            outs.append(jsonable({k2: (payload_dict(x) if k2.startswith("variant_") else x) for k2, x in v.items()}))
+        out["variants"].append({"label": label, "args": vars(args),
+                                "refs": [{"name": nm, "sequence": refs[nm]["sequence"], "cut_points": [91], "include_idxs": [91, 92],
+                                          "min_aln_score": 60} for nm in names],
+                                "pairs": sample, "variants": outs})
+    return out
+
+
+if __name__ == "__main__" and "--paired" in sys.argv:
+    import gzip
+    d = paired_goldens()
+    with gzip.open(os.path.join(HERE, "paired.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("paired.json.gz written:", {k: len(v) for k, v in d.items()}, sum("raises" in c for c in d["fuzz"]), "fuzz calls raise")
 
 
 if __name__ == "__main__" and "--variants" in sys.argv:

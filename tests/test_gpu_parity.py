@@ -668,3 +668,39 @@ def test_pipeline_equals_per_read_path_plus_reference_aggregation(mats, ctx):
                     assert np.array_equal(got[k_][:len(ref["sequence"])], v_), (over, nm, k_)
                 else:
                     assert got[k_] == v_, (over, nm, k_, got[k_], v_)
+
+
+def test_paired_consensus_and_variants_vs_reference_functions(mats, ctx):
+    """crispresso2_amd.paired against the reference's get_consensus_alignment_from_pairs (every call its own unit test makes
+    + pairs cut from the FANC reads) and get_new_variant_object_from_paired (one / two references, both strands, unrelated
+    reads, ambiguity flags, legacy quantification) -- goldens recorded from the reference (make_golden.py --paired)."""
+    import types
+    from crispresso2_amd import paired, refs as RF
+    g = load_golden("paired.json.gz")
+    calls = g["unit"] + g["fuzz"]
+    assert len(g["unit"]) >= 15 and len(g["fuzz"]) >= 200
+    ok = [c for c in calls if "raises" not in c]
+    got = paired.consensus_batch([tuple(c["args"]) for c in ok], ctx=ctx)
+    for c, o in zip(ok, got):
+        assert list(o) == c["out"], (c, o)
+    assert any(not c["out"][4] for c in ok) and any(c["out"][4] for c in ok)         # caching_is_ok both ways
+    for c in calls:
+        if "raises" in c:
+            with pytest.raises(IndexError):
+                paired.get_consensus_alignment_from_pairs(*c["args"])
+    one = ok[0]
+    assert list(paired.get_consensus_alignment_from_pairs(*one["args"])) == one["out"]
+    n_amb = n_unal = 0
+    for case in g["variants"]:
+        args = types.SimpleNamespace(**case["args"])
+        refs, names = {}, []
+        for r in case["refs"]:
+            refs[r["name"]] = RF.make_ref(r["name"], r["sequence"], r["cut_points"], r["include_idxs"], r["min_aln_score"])
+            names.append(r["name"])
+        vs = paired.get_new_variant_objects_from_paired(args, [tuple(p) for p in case["pairs"]], refs, names, mats["EDNAFULL"], None, ctx=ctx)
+        assert len(vs) == len(case["variants"])
+        for v, e in zip(vs, case["variants"]):
+            _variant_equal(v, e)
+            n_amb += len(e.get("aln_ref_names", [])) > 1 or e.get("class_name") == "AMBIGUOUS"
+            n_unal += e["best_match_score"] <= 0
+    assert n_amb >= 3 and n_unal >= 3

@@ -250,3 +250,18 @@ def test_emulated_classify_lists(mats):
             assert got[f] == v["out"][f], (f, v)
         n_legacy += legacy
     assert n_legacy >= 100
+
+
+def test_emulated_paired_consensus_kernel():
+    """c2_consensus_pairs_kernel against the reference's get_consensus_alignment_from_pairs: every call of the reference's own
+    unit test and 260 pairs cut from the FANC reads (goldens recorded from the reference, make_golden.py --paired)."""
+    g = load_golden("paired.json.gz")
+    calls = [c for c in g["unit"] + g["fuzz"] if "raises" not in c]
+    assert len(calls) >= 250
+    outs = E.consensus_pairs([tuple(c["args"]) for c in calls])
+    for c, (aln, qual, ref, hom, caching, err) in zip(calls, outs):
+        assert not err
+        assert [aln, qual, ref, round(float(100 * hom / float(len(ref))), 3), caching] == c["out"], c
+    # a quality string that is too short is an IndexError in the reference: flagged, not read out of bounds
+    bad = E.consensus_pairs([("ACGT", "ACGT", 100.0, "II", "ACGT", "ACGT", 100.0, "IIII")])[0]
+    assert bad[5]
