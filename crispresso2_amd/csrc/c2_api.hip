@@ -113,7 +113,7 @@ struct Geometry {
     uint32_t lds_full; int blocks_full;          // full pointer plane
     int band_lanes; uint32_t lds_band; int blocks_band;   // banded first launch (band_lanes == 0: not used)
     bool diag; uint32_t lds_diag; int blocks_diag;         // diagonal-band launches
-    bool x4, x2; uint32_t lds_x[2]; int blocks_x[2]; uint32_t plane_words;   // multi-alignment tiers in front of it
+    bool x[2]; uint32_t lds_x[2]; int blocks_x[2]; uint32_t plane_words;   // multi-alignment tiers in front of it: 4, 2 per wavefront
 };
 
 template <int R, bool BAND>
@@ -158,7 +158,8 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     if ((rc = occupancy_r<false>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
     // Diagonal-band first launch (c2_align_diag_kernel): needs the packed score rows and a negative per-gap-base bound
     g.diag = false; g.lds_diag = 0; g.blocks_diag = 0;
-    g.x4 = g.x2 = false; g.lds_x[0] = g.lds_x[1] = 0; g.blocks_x[0] = g.blocks_x[1] = 0; g.plane_words = 0;
+    for (int t = 0; t < 2; ++t) { g.x[t] = false; g.lds_x[t] = 0; g.blocks_x[t] = 0; }
+    g.plane_words = 0;
     const int km = ctx->kernel_mode;
     if ((km == 0 || km == 3 || km == 4) && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
         g.lds_diag = c2_make_diag_plan(ctx->max_li, g.max_lj).total;
@@ -174,11 +175,11 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
             g.diag = true;
         }
         for (int t = 0; t < 2 && g.diag && km != 3; ++t) {
-            if (t == 0 && km != 0) continue;
-            const int na = t == 0 ? 4 : 2;
+            const int na = 4 >> t;
+            if (na == 4 && km == 4) continue;                                  // mode 4: 2 -> 1
             const c2_diagx_plan PX = c2_make_diagx_plan(na, ctx->max_li, g.max_lj);
             if (PX.total > lds_cu) continue;
-            const void* fn = t == 0 ? (const void*)c2_align_diagx_kernel<4> : (const void*)c2_align_diagx_kernel<2>;
+            const void* fn = na == 4 ? (const void*)c2_align_diagx_kernel<4> : (const void*)c2_align_diagx_kernel<2>;
             if (ctx->occ_x_lds[t] != (int)PX.total) {
                 int nb = 0;
                 HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -186,7 +187,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
                 ctx->occ_x_blocks[t] = nb < 1 ? 1 : nb; ctx->occ_x_lds[t] = (int)PX.total;
             }
             g.lds_x[t] = PX.total; g.blocks_x[t] = ctx->occ_x_blocks[t]; g.plane_words = PX.n_words * 64u;                      // [slot][group of 8 anti-diagonals][lane of the slot]
-            (t == 0 ? g.x4 : g.x2) = true;
+            g.x[t] = true;
         }
     }
     // Banded first launch: keep only the pointer words of the lanes near the main diagonal so that more workgroups fit
@@ -247,17 +248,21 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
             T.work_counter = (unsigned long long*)(hdr + 4 + 2 * tier);
         };
         if (g.diag) {
+            {   // one scratch plane, sized for the tier with the most resident workgroups (no reallocation between launches)
+                uint64_t most = 0;
+                for (int t = 0; t < 2; ++t) if (g.x[t]) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_x[t]);
+                if (most && (rc = ensure(ctx, ctx->d_plane, (size_t)most * g.plane_words * sizeof(uint32_t)))) return rc;
+            }
             for (int t = 0; t < 2; ++t) {
-                if (!(t == 0 ? g.x4 : g.x2)) continue;
-                const int na = t == 0 ? 4 : 2;
+                if (!g.x[t]) continue;
+                const int na = 4 >> t;
                 const uint64_t resident = cus * (uint64_t)g.blocks_x[t];
                 const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + na - 1) / na, resident));
-                if ((rc = ensure(ctx, ctx->d_plane, (size_t)resident * g.plane_words * sizeof(uint32_t)))) return rc;
                 c2_align_args T = A;
                 chain(T);
                 T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = g.plane_words;
-                if (t == 0) hipLaunchKernelGGL(c2_align_diagx_kernel<4>, dim3(grid), dim3(64), g.lds_x[t], s, T);
-                else        hipLaunchKernelGGL(c2_align_diagx_kernel<2>, dim3(grid), dim3(64), g.lds_x[t], s, T);
+                if (na == 4) hipLaunchKernelGGL(c2_align_diagx_kernel<4>, dim3(grid), dim3(64), g.lds_x[t], s, T);
+                else         hipLaunchKernelGGL(c2_align_diagx_kernel<2>, dim3(grid), dim3(64), g.lds_x[t], s, T);
                 HIPCHK(ctx, hipGetLastError());
                 mark_first();
                 ++tier;

@@ -1068,7 +1068,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
     uint32_t off = 0;
     p.codeof = off;   off += 256u;                                  // character -> code
-    p.table = off;    off += 4u * 20u * 4u;                         // 4 slots x C2X_INTS
+    p.table = off;    off += 8u * 20u * 4u;                         // up to 8 slots x C2X_INTS
     p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
     p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
     p.stage = off;    off += p.n_words * (64u / (uint32_t)na) * 4u; // pointer words of the alignment being traced
@@ -1202,16 +1202,23 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
     unsigned mA_task = 0; int mA_valid = 0;
     unsigned mB_task = 0; int mB_valid = 0, mB_ref = 0, mB_rc = 0;
     unsigned long long mB_off = 0, mB_off1 = 0;
-    c2_prefetch pf[NA];
+    // stage C keeps its per-slot descriptors in lane s of a few VGPRs too (mC_*: no SGPR is live across the fill); only the
+    // read bytes need a register per slot
+    unsigned mC_task = 0; int mC_valid = 0, mC_lj = 0, mC_ref = 0, mC_rc = 0;
+    unsigned long long mC_off = 0;
+    unsigned b4s[NA];
 #pragma unroll
-    for (int s = 0; s < NA; ++s) { pf[s].task = 0; pf[s].off = 0; pf[s].valid = 0; pf[s].Lj = 0; pf[s].ref_id = 0; pf[s].rc = 0; pf[s].b4 = 0; }
+    for (int s = 0; s < NA; ++s) b4s[s] = 0;
+    auto lane64 = [&](const unsigned long long v, const int s) {
+        return (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), s) |
+               ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), s) << 32);
+    };
     for (int iter = 0;; ++iter) {
         __syncthreads();
-        const bool have_group = pf[0].valid != 0;
+        const bool have_group = __builtin_amdgcn_readlane(mC_valid, 0) != 0;
         if (iter >= 4 && !have_group) break;
         c2_phase_begin(A.phase_cycles, PH);
-        // ---- D: stage the NA prefetched tasks in their LDS slots (unrolled: pf[] must stay in registers -- a scratch access
-        //      here would queue behind the previous group's output stores in vmcnt)
+        // ---- D: stage the NA prefetched tasks in their LDS slots
         if (have_group) {
 #pragma unroll
             for (int s = 0; s < NA; ++s) {
@@ -1219,26 +1226,31 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 int cref = c2_uni(T + C2X_CURREF), li = c2_uni(T + C2X_LI), g0 = c2_uni(T + C2X_G0);
                 int st = 0;
                 bool packed = false;
-                if (pf[s].valid) st = c2_commit_task(A, wg_of(s), sCodeOf, pf[s], lane, A.max_li, cref, li, g0, packed,
-                                                      c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes);
+                c2_prefetch cur;
+                cur.valid = __builtin_amdgcn_readlane(mC_valid, s);
+                cur.task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mC_task, s);
+                cur.off = lane64(mC_off, s);
+                cur.Lj = __builtin_amdgcn_readlane(mC_lj, s); cur.ref_id = __builtin_amdgcn_readlane(mC_ref, s);
+                cur.rc = __builtin_amdgcn_readlane(mC_rc, s); cur.b4 = b4s[s];
+                if (cur.valid) st = c2_commit_task(A, wg_of(s), sCodeOf, cur, lane, A.max_li, cref, li, g0, packed,
+                                                   c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes);
                 if (lane == 0) {
-                    T[C2X_VALID] = pf[s].valid; T[C2X_TASK_LO] = (int)(unsigned)(pf[s].task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(pf[s].task >> 32);
-                    T[C2X_LJ] = pf[s].Lj; T[C2X_REF] = pf[s].ref_id; T[C2X_RC] = pf[s].rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
+                    T[C2X_VALID] = cur.valid; T[C2X_TASK_LO] = (int)(unsigned)(cur.task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(cur.task >> 32);
+                    T[C2X_LJ] = cur.Lj; T[C2X_REF] = cur.ref_id; T[C2X_RC] = cur.rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
                     T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0;
                 }
             }
         }
         // ---- C: read bytes of the next group
+        mC_valid = mB_valid; mC_task = mB_task; mC_off = mB_off; mC_ref = mB_ref; mC_rc = mB_rc;
+        mC_lj = mB_valid ? (int)(mB_off1 - mB_off) : 0;
 #pragma unroll
         for (int s = 0; s < NA; ++s) {
-            const int v = __builtin_amdgcn_readlane(mB_valid, s);
-            const uint64_t off = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mB_off & 0xffffffffull), s) |
-                                 ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mB_off >> 32), s) << 32);
-            const uint64_t off1 = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mB_off1 & 0xffffffffull), s) |
-                                  ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mB_off1 >> 32), s) << 32);
-            const int Lj = (int)(off1 - off), rc = __builtin_amdgcn_readlane(mB_rc, s);
+            const int v = __builtin_amdgcn_readlane(mC_valid, s);
             unsigned b4 = 0;
             if (v) {
+                const uint64_t off = lane64(mC_off, s);
+                const int Lj = __builtin_amdgcn_readlane(mC_lj, s), rc = __builtin_amdgcn_readlane(mC_rc, s);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int k = 64 * q + lane;
@@ -1246,8 +1258,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                     b4 |= byte << (8 * q);
                 }
             }
-            pf[s].valid = v; pf[s].task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mB_task, s); pf[s].off = off;
-            pf[s].Lj = v ? Lj : 0; pf[s].ref_id = __builtin_amdgcn_readlane(mB_ref, s); pf[s].rc = rc; pf[s].b4 = b4;
+            b4s[s] = b4;
         }
         // ---- B: descriptors of the group after that
         mB_valid = mA_valid; mB_task = mA_task; mB_off = 0; mB_off1 = 0; mB_ref = 0; mB_rc = 0;
@@ -1365,7 +1376,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
         // ---- per alignment: optimality certificate (see c2_align_diag_kernel), traceback, output.  The pointer words of
         //      alignment s + 1 are requested before alignment s is traced and written out: a load issued after those stores
         //      would wait for them (one vmcnt for loads and stores), a load issued before them does not.
-        constexpr int STG = 16 / NA;                               // 16-byte words per lane in flight: 64 * STG * 16 B covers 500 anti-diagonals
+        constexpr int STG = 16 / NA;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
         uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
         q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = uint4{0u, 0u, 0u, 0u};
 #define C2_STG_LOAD(n) if (STG > n) { const int k = 64 * n + lane; q##n = src[k < n16 ? k : 0]; }

@@ -70,7 +70,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -7;
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1);
-    uint32_t fb_counts[4] = {0, 0, 0, 0};
+    uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
     std::vector<uint32_t> plane;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0;
     A.diag_base = nullptr;
