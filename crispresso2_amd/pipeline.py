@@ -33,9 +33,75 @@ def strand_plans(arena, offsets, refs, ref_names, args):
 
 class QuantResult:
     """per_ref[name]: the dict of counts.CountLayout.unpack (vectors named after the reference's variables);
-    stats: N_TOT_READS, N_CACHED_ALN, ... (process_fastq's aln_stats) plus N_TOTAL and N_AMBIGUOUS of the aggregation loop."""
-    def __init__(self, per_ref, stats, layout, tensor):
+    stats: N_TOT_READS, N_CACHED_ALN, ... (process_fastq's aln_stats) plus N_TOTAL and N_AMBIGUOUS of the aggregation loop;
+    alleles(): the rows of the allele frequency table."""
+    def __init__(self, per_ref, stats, layout, tensor, state=None):
         self.per_ref, self.stats, self.layout, self.tensor = per_ref, stats, layout, tensor
+        self._state = state
+
+    def alleles(self):
+        """Rows (Aligned_Sequence, Reference_Sequence, Reference_Name, Read_Status, n_deleted, n_inserted, n_mutated, #Reads,
+        %Reads) of Alleles_frequency_table.txt: one per (read, reference it counts for), 'AMBIGUOUS_<first reference>' rows
+        for ambiguous reads, 'DISCARDED_<first reference>' rows under --discard_indel_reads (CRISPRessoCORE.py:3926-4010,
+        :4298-4303), sorted as the reference sorts them (#Reads descending, then the two sequences ascending).  Brings the
+        aligned strings of the aligned unique reads to the host."""
+        import torch
+        S = self._state
+        if S is None:
+            return []
+        args, ref_names = S["args"], S["ref_names"]
+        member, aligned, cnt, use2, slot2 = S["member"], S["aligned"], S["cnt"], S["use2"], S["slot2"]
+        k = len(ref_names)
+        discard = bool(getattr(args, 'discard_indel_reads', False))
+        jobs = []                                                   # (read, reference, row label)
+        for i in np.nonzero(aligned & (cnt > 0))[0]:
+            best = np.nonzero(member[i])[0]
+            names = best
+            if len(best) > 1:
+                if args.assign_ambiguous_alignments_to_first_reference:
+                    names = best[:1]
+                elif not args.expand_ambiguous_alignments:
+                    jobs.append((i, best[0], 'AMBIGUOUS_' + ref_names[best[0]], False))
+                    continue
+            for r in names:
+                jobs.append((i, r, ref_names[r], True))
+        if not jobs:
+            return []
+        ji = np.array([j[0] for j in jobs], dtype=np.int64)
+        jr = np.array([j[1] for j in jobs], dtype=np.int64)
+        in2 = use2[ji, jr]
+        rows1 = torch.from_numpy(ji[~in2] * k + jr[~in2]).to(S["a1"].device)
+        rec = np.empty(len(jobs), dtype=_native.REC_DTYPE)
+        seqs = [None] * len(jobs)
+        refs_ = [None] * len(jobs)
+
+        def pull(a, f, rows, where, records):
+            ah, fh = a.index_select(0, rows).cpu().numpy(), f.index_select(0, rows).cpu().numpy()
+            for q, j in enumerate(where):
+                T = int(records[q]["aln_len"])
+                seqs[j], refs_[j] = ah[q, :T].tobytes().decode(), fh[q, :T].tobytes().decode()
+                rec[j] = records[q]
+        w1 = np.nonzero(~in2)[0]
+        if len(w1):
+            pull(S["a1"], S["f1"], rows1, w1, S["rec1"].reshape(-1)[(ji[~in2] * k + jr[~in2])])
+        w2 = np.nonzero(in2)[0]
+        if len(w2):
+            sl = slot2[ji[in2], jr[in2]]
+            pull(S["a2"], S["f2"], torch.from_numpy(sl).to(S["a1"].device), w2, S["rec2"][sl])
+        n_total = self.stats["N_TOTAL"]
+        out = []
+        for j, (i, r, label, counted) in enumerate(jobs):
+            dn, inn, sn = int(rec[j]["deletion_n"]), int(rec[j]["insertion_n"]), int(rec[j]["substitution_n"])
+            modified = ((not args.ignore_deletions and dn > 0) or (not args.ignore_insertions and inn > 0) or
+                        (not args.ignore_substitutions and sn > 0))
+            if counted and discard and (dn > 0 or inn > 0):
+                first = np.nonzero(member[i])[0]
+                first = first[:1] if args.assign_ambiguous_alignments_to_first_reference else first
+                label = 'DISCARDED_' + ref_names[first[0]]
+            reads = int(cnt[i])
+            out.append((seqs[j], refs_[j], label, 'MODIFIED' if modified else 'UNMODIFIED', dn, inn, sn, reads, reads / n_total * 100))
+        out.sort(key=lambda t: (-t[7], t[0], t[1]))
+        return out
 
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
@@ -72,6 +138,8 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     if n == 0:
         return QuantResult({name: layout.unpack(d_counts.cpu().numpy(), r, L[r]) for r, name in enumerate(ref_names)}, stats, layout, d_counts)
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    if not arena.flags.writeable:
+        arena = arena.copy()                                      # torch.from_numpy wants a writable array
     plan = strand_plans(arena, offsets, refs, ref_names, args)
     lap("strand_plan")
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -200,7 +268,9 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     host = d_counts.cpu().numpy()
     lap("count_kernels")
     per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
-    return QuantResult(per_ref, stats, layout, d_counts)
+    state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=slot2,
+                 a1=a1, f1=f1, rec1=rec1, a2=a2 if n2 else None, f2=f2 if n2 else None, rec2=rec2)
+    return QuantResult(per_ref, stats, layout, d_counts, state)
 
 
 def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None):

@@ -4,6 +4,7 @@
     <ref>Nucleotide_frequency_table.txt, <ref>Nucleotide_percentage_table.txt,
     <ref>Quantification_window_nucleotide_{frequency,percentage}_table.txt      plots/data_prep.py:3509-3570 (pandas to_csv of float vectors)
     <ref>Modification_count_vectors.txt, <ref>Quantification_window_modification_count_vectors.txt   CRISPRessoCORE.py:4604-4609, :4668-4687
+    Alleles_frequency_table.txt (unzipped)                                                           CRISPRessoCORE.py:3926-4010, :4298-4303, :4498-4509
 
 `res` is a pipeline.QuantResult.  File names carry the reference's prefix rule: no prefix for a single amplicon named
 'Reference', else '<name>.' (CRISPRessoCORE.py:4618-4640).  The reference accumulates these vectors in float64 numpy
@@ -58,11 +59,20 @@ def _write_count_vectors(path, ref_seq, vectors, names):
             fh.write(nm + "\t" + "\t".join(vec) + "\n")
 
 
+def write_alleles_frequency_table(res, path):
+    """Alleles_frequency_table.txt (the reference zips it): CRISPRessoCORE.py:4498-4509, the non-detailed columns."""
+    with open(path, "w") as fh:
+        fh.write("Aligned_Sequence\tReference_Sequence\tReference_Name\tRead_Status\tn_deleted\tn_inserted\tn_mutated\t#Reads\t%Reads\n")
+        for a, r, name, status, dn, inn, sn, reads, pct in res.alleles():
+            fh.write("%s\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%s\n" % (a, r, name, status, dn, inn, sn, reads, _f(pct)))
+
+
 def write_tables(res, refs, ref_names, out_dir):
     """Writes the tables listed in the module docstring into out_dir; returns the list of file names."""
     os.makedirs(out_dir, exist_ok=True)
-    written = ["CRISPResso_quantification_of_editing_frequency.txt"]
+    written = ["CRISPResso_quantification_of_editing_frequency.txt", "Alleles_frequency_table.txt"]
     write_quantification_of_editing_frequency(res, ref_names, os.path.join(out_dir, written[0]))
+    write_alleles_frequency_table(res, os.path.join(out_dir, written[1]))
     nucs = ["A", "C", "G", "T", "N", "-"]
     for name in ref_names:
         c = res.per_ref[name]

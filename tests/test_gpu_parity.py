@@ -656,6 +656,27 @@ def test_pipeline_equals_per_read_path_plus_reference_aggregation(mats, ctx):
             for nm in v["aln_ref_names"]:
                 items[nm].append((v["variant_" + nm], v["count"]))
         assert res.stats["N_TOTAL"] == n_total
+        # the allele table rows (get_allele_row, :3926-3959; AMBIGUOUS_ / DISCARDED_ labels :3987-4000; sort and %Reads :4298-4303)
+        exp_rows = []
+        for r in cache:
+            v = cache[r]
+            if v["count"] == 0:
+                continue
+
+            def row(label, p):
+                return (p["aln_seq"], p["aln_ref"], label, p["classification"], int(p["deletion_n"]), int(p["insertion_n"]),
+                        int(p["substitution_n"]), v["count"], v["count"] / n_total * 100)
+            if v["class_name"] == "AMBIGUOUS":
+                exp_rows.append(row("AMBIGUOUS_" + v["aln_ref_names"][0], v["variant_" + v["aln_ref_names"][0]]))
+                continue
+            for nm in v["aln_ref_names"]:
+                p = v["variant_" + nm]
+                if args.discard_indel_reads and (p["deletion_n"] > 0 or p["insertion_n"] > 0):
+                    exp_rows.append(row("DISCARDED_" + v["aln_ref_names"][0], p))
+                else:
+                    exp_rows.append(row(nm, p))
+        exp_rows.sort(key=lambda t: (-t[7], t[0], t[1]))
+        assert res.alleles() == exp_rows
         if not over:
             assert sum(v.get("class_name") == "AMBIGUOUS" for v in vs) >= 2 and res.stats["N_AMBIGUOUS"] > 0
         for nm, ref in zip(names, base["refs"]):
