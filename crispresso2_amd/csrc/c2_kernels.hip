@@ -1750,6 +1750,12 @@ __device__ __forceinline__ int c2_wave_incl_scan(int v, int lane) {
     return v;
 }
 
+// all_base_count vector of a read / reference character (CRISPRessoCORE.py:4075-4081), or -1
+__device__ __forceinline__ int c2_base_vector(const unsigned char ch) {
+    return ch == 'A' ? C2_V_BASE_A : ch == 'C' ? C2_V_BASE_C : ch == 'G' ? C2_V_BASE_G : ch == 'T' ? C2_V_BASE_T :
+           ch == 'N' ? C2_V_BASE_N : ch == '-' ? C2_V_BASE_GAP : -1;
+}
+
 // Tasks grouped by reference for the count kernel (a chunk of consecutive positions then holds one or two references
 // instead of dozens: with 96 interleaved amplicons the LDS block would be flushed for almost every task).  Counting sort
 // in three tiny launches: histogram of ref_id, exclusive scan (one wavefront), scatter.  The order inside a reference is
@@ -1840,6 +1846,20 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 const int s = c2_wave_incl_scan(x, lane) + carry;
                 if (k < VL) d[k] = s;
                 carry = __shfl(s, 63);
+            }
+        }
+        __syncthreads();
+        {   // gap-free reads added only their deviations from the reference (see the column walk): every reference position
+            // gets their total weight on the vector of its own base
+            const int g = acc[o_sc + C2_S_RESERVED0];
+            __syncthreads();
+            if (g != 0) {
+                const uint8_t* rs = A.refs[cur_ref].seq;
+                for (int c = tid; c < Li; c += NT) {
+                    const int bv = c2_base_vector(rs[c]);
+                    if (bv >= 0) acc[bv * VL + c] += g;
+                }
+                if (tid == 0) acc[o_sc + C2_S_RESERVED0] = 0;
             }
         }
         __syncthreads();
@@ -1976,6 +1996,36 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 // ---- column walk (same scan as the fused classifier), ds_add into the vectors
                 int idx_base = 0, last_rf = -1, last_rd = -1;
                 bool last_rf_close = false, last_rf_wclose = false;
+                if (T == Li && all_del_bases == 0) {
+                    // No gap column in either string: the reference index of a column is the column, only substitutions can
+                    // occur, and the read's base counts differ from "the reference's own base, once per read" only where the
+                    // read differs from the reference.  So the walk adds the DEVIATIONS (+w on the read's base, -w on the
+                    // reference's) and the read's weight goes to one scalar that flush() spreads over the reference's bases.
+                    for (int base = 0; base < T; base += 64) {
+                        const int c = base + lane;
+                        const bool in = c < T;
+                        unsigned char rd, rfc;
+                        if (base < 256) { rd = in ? (unsigned char)((rd4 >> ((base >> 6) * 8)) & 0xffu) : 0; rfc = in ? (unsigned char)((rf4 >> ((base >> 6) * 8)) & 0xffu) : 0; }
+                        else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
+                        if (in && rd != rfc) {
+                            const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
+                            if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
+                            if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
+                            if (rd != 'N') {
+                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
+                                if (!ign_sub) {
+                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
+                                    int sv = -1;                                                // :4049-4054
+                                    if (rd == 'A') sv = C2_V_ALL_SUB_BASE_A; else if (rd == 'C') sv = C2_V_ALL_SUB_BASE_C;
+                                    else if (rd == 'G') sv = C2_V_ALL_SUB_BASE_G; else if (rd == 'T') sv = C2_V_ALL_SUB_BASE_T;
+                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
+                                }
+                            }
+                        }
+                    }
+                    if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
+                    continue;
+                }
                 for (int base = 0; base < T; base += 64) {
                     const int c = base + lane;
                     const bool in = c < T;

@@ -192,14 +192,14 @@ int emu_consensus_pairs(uint64_t n, const uint8_t* s1, const uint8_t* f1, const 
 int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t aln_stride,
                       const c2_aln_record* records, const uint32_t* weights, const uint16_t* min_matches, int max_t,
                       int n_refs, const int32_t* lens, const int32_t* const* include_idx, const int32_t* n_include,
-                      int flags, int hl, long long* counts, unsigned grid)
+                      int flags, int hl, long long* counts, unsigned grid, const char* const* seqs)
 {
     std::vector<c2_dev_ref> refs(n_refs);
     std::vector<std::vector<uint16_t>> incp(n_refs);
     int lmax = 1;
     for (int r = 0; r < n_refs; ++r) {
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
-        refs[r].seq = nullptr; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].diag_rows = nullptr; refs[r].len = lens[r]; refs[r].gap_incentive_max = 0;
+        refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].diag_rows = nullptr; refs[r].len = lens[r]; refs[r].gap_incentive_max = 0;
         lmax = std::max(lmax, lens[r]);
     }
     unsigned long long wc = 0;

@@ -157,8 +157,11 @@ def consensus_pairs(items):
              int(info[k, 2]), bool(info[k, 3] & 1), bool(info[k, 3] & 2)) for k in range(n)]
 
 
-def count_vectors(aln_read, aln_ref, records, ref_lens, includes, max_read_len, weights=None, min_matches=None, flags=0, grid=2):
-    """aln_read/aln_ref: uint8 [n, stride]; records: REC_DTYPE [n].  -> (counts int64 [n_refs, per_ref], layout)"""
+def count_vectors(aln_read, aln_ref, records, ref_seqs, includes, max_read_len, weights=None, min_matches=None, flags=0, grid=2):
+    """aln_read/aln_ref: uint8 [n, stride]; records: REC_DTYPE [n]; ref_seqs: the reference strings.
+    -> (counts int64 [n_refs, per_ref], layout)"""
+    ref_lens = [len(x) for x in ref_seqs]
+    seq_ptrs = (ctypes.c_char_p * len(ref_seqs))(*[x.encode() for x in ref_seqs])
     import sys
     sys.path.insert(0, ROOT)
     from crispresso2_amd.counts import CountLayout
@@ -178,6 +181,6 @@ def count_vectors(aln_read, aln_ref, records, ref_lens, includes, max_read_len, 
                                  None if w is None else w.ctypes.data_as(ctypes.c_void_p),
                                  None if mm is None else mm.ctypes.data_as(ctypes.c_void_p), 0 if mm is None else mm.shape[1] - 1,
                                  nrefs, lens.ctypes.data_as(ctypes.c_void_p), ip, ninc.ctypes.data_as(ctypes.c_void_p),
-                                 int(flags), int(lay.hl), counts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(grid))
+                                 int(flags), int(lay.hl), counts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(grid), seq_ptrs)
     assert rc == 0
     return counts, lay

@@ -51,7 +51,7 @@ def test_count_vectors_match_reference_aggregation(aligned, flags):
     rng = np.random.default_rng(1)
     w = rng.integers(1, 50, len(reads)).astype(np.uint32)
     w[::11] = 0                                           # reads not assigned to this reference
-    counts, lay = E.count_vectors(o1, o2, rec, [len(amp)], [inc], max(len(r) for r in reads), weights=w, flags=flags)
+    counts, lay = E.count_vectors(o1, o2, rec, [amp], [inc], max(len(r) for r in reads), weights=w, flags=flags)
     got = lay.unpack(counts, 0, len(amp))
     items = [(p, int(c)) for p, c in zip(payloads(res, inc), w) if c > 0]
     exp = aggregate.aggregate(items, len(amp), ignore_substitutions=bool(flags & 1), ignore_insertions=bool(flags & 2),
@@ -64,7 +64,7 @@ def test_count_vectors_min_alignment_score_gate(aligned):
     amp, inc, reads, res, rec, (o1, o2) = aligned
     thr = 97.5
     mm = C.min_matches_table([thr], int(rec["aln_len"].max()))
-    counts, lay = E.count_vectors(o1, o2, rec, [len(amp)], [inc], max(len(r) for r in reads), min_matches=mm)
+    counts, lay = E.count_vectors(o1, o2, rec, [amp], [inc], max(len(r) for r in reads), min_matches=mm)
     got = lay.unpack(counts, 0, len(amp))
     keep = [round(100 * int(r["matches"]) / float(int(r["aln_len"])), 3) > thr for r in rec]
     assert 0 < sum(keep) < len(keep)
@@ -83,7 +83,7 @@ def test_count_vectors_interleaved_references_and_heavy_weights(aligned):
     w[3] = 3_000_000
     w[40] = 2_500_000
     w[41] = 2_200_000
-    counts, lay = E.count_vectors(o1, o2, rec2, [len(amp), len(amp)], [inc, inc], max(len(r) for r in reads), weights=w, grid=3)
+    counts, lay = E.count_vectors(o1, o2, rec2, [amp, amp], [inc, inc], max(len(r) for r in reads), weights=w, grid=3)
     P = payloads(res, inc)
     for r in range(2):
         got = lay.unpack(counts, r, len(amp))

@@ -37,14 +37,14 @@ def _worker(rank, world, port, out_dir):
     st = {}
     res, rec = E.align_batch(reads[lo:hi], [amp], [g], [inc], matrices()["EDNAFULL"], -20, -2, stats=st)
     o1, o2 = st["raw"]
-    counts, lay = E.count_vectors(o1, o2, rec, [len(amp)], [inc], 250)
+    counts, lay = E.count_vectors(o1, o2, rec, [amp], [inc], 250)
     t = torch.from_numpy(counts)
     D.reduce_counts(t)
     if rank == 0:
         np.save(os.path.join(out_dir, "reduced.npy"), t.numpy())
         res_all, rec_all = E.align_batch(reads, [amp], [g], [inc], matrices()["EDNAFULL"], -20, -2, stats=st)
         o1, o2 = st["raw"]
-        full, _ = E.count_vectors(o1, o2, rec_all, [len(amp)], [inc], 250)
+        full, _ = E.count_vectors(o1, o2, rec_all, [amp], [inc], 250)
         np.save(os.path.join(out_dir, "single.npy"), full)
     dist.barrier()
     dist.destroy_process_group()
