@@ -151,6 +151,36 @@ def main():
             if st != 0 or T != ln or a_r[j, :T].tobytes().decode() != s1 or a_f[j, :T].tobytes().decode() != s2 or int(rec["matches"][k]) != mt:
                 parity = False
                 break
+    # size-independent properties on EVERY alignment of the full-size batch (device-side, in slices): no double-gap column;
+    # removing the gaps gives back the read and the amplicon (every base exactly once, in order); `matches` and
+    # `all_deletion_bases` of the record agree with the strings
+    props = None
+    if args.check > 0:
+        props = True
+        d_amp = torch.from_numpy(np.frombuffer(amp.encode(), dtype=np.uint8).copy()).to(dev)
+        d_reads2 = d_reads.view(n, L)
+        recs_t = d_records.view(torch.int16)                      # aln_len, matches are the first two uint16 (< 32768 here)
+        cols = torch.arange(stride, device=dev)[None, :]
+        dash = ord("-")
+        SL = 500_000
+        for a0 in range(0, n, SL):
+            a1 = min(n, a0 + SL)
+            T_ = recs_t[a0:a1, 0].to(torch.int64)
+            mt_ = recs_t[a0:a1, 1].to(torch.int64)
+            delb_ = recs_t[a0:a1, 9].to(torch.int64)
+            R_, F_ = d_aln_read[a0:a1], d_aln_ref[a0:a1]
+            valid = cols < T_[:, None]
+            rgap = (R_ == dash) & valid
+            fgap = (F_ == dash) & valid
+            ok = not bool((rgap & fgap).any())
+            keep_r, keep_f = valid & ~rgap, valid & ~fgap
+            ok = ok and bool((keep_r.sum(1) == L).all()) and bool((keep_f.sum(1) == L).all())
+            if ok:
+                ok = bool(torch.equal(R_[keep_r].view(a1 - a0, L), d_reads2[a0:a1]))
+                ok = ok and bool(torch.equal(F_[keep_f].view(a1 - a0, L), d_amp[None, :].expand(a1 - a0, L)))
+                ok = ok and bool(torch.equal(((R_ == F_) & keep_r & keep_f).sum(1), mt_)) and bool(torch.equal(rgap.sum(1), delb_))
+            props = props and ok
+            del valid, rgap, fgap, keep_r, keep_f
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
     tiers = ctx.tier_info()
@@ -213,7 +243,8 @@ def main():
                      "note": "full-matrix cell updates the reference would perform per second of launch-chain time (the banded kernels compute fewer)",
                      "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS},
             "cpu_baseline": cpu_baseline,
-            "checks": {"all_status_ok": ok_status, "oracle_sample_identical": parity, "oracle_sample": args.check},
+            "checks": {"all_status_ok": ok_status, "oracle_sample_identical": parity, "oracle_sample": args.check,
+                       "full_batch_properties_hold": props},
             "counts": {"reads_aligned_all_gpus": tallies["counts_total"], "modified": tallies["counts_modified"],
                        "unmodified": tallies["counts_unmodified"], "with_insertion": tallies["counts_insertion"],
                        "with_deletion": tallies["counts_deletion"], "with_substitution": tallies["counts_substitution"]},
