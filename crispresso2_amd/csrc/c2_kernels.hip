@@ -32,17 +32,6 @@ __device__ __forceinline__ int c2_shr1(int old, int src) {
 }
 
 __device__ __forceinline__ int c2_imax(int a, int b) { return a > b ? a : b; }
-// clamp x to [0, hi] (hi wave-uniform, >= 0): one v_med3_i32
-__device__ __forceinline__ int c2_clamp0(int x, int hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    int r;
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
-    return r;
-#else
-    return x < 0 ? 0 : (x > hi ? hi : x);
-#endif
-}
-
 // sign-extended 4-bit field of x starting at bit `off`
 __device__ __forceinline__ int c2_sbfe4(int x, int off) { return __builtin_amdgcn_sbfe(x, off, 4); }
 
@@ -795,7 +784,7 @@ __host__ __device__ inline c2_diag_plan c2_make_diag_plan(int max_li, int max_lj
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // one 32-bit word per lane per 8 anti-diagonals
     uint32_t off = 0;
     p.plane = off;    off += p.n_words * (uint32_t)C2_DIAG_STORE_N * 4u;
-    p.codes = off;    off += c2_align16((uint32_t)max_lj + 2u);            // columns 0 .. Lj+1 (both ends zero)
+    p.codes = off;    off += c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 8u);   // zeros | columns 0 .. Lj+1 | zeros
     p.codeof = off;   off += 256u;
     p.read = off;     off += c2_align16((uint32_t)max_lj);
     p.code = off;     off += c2_align16((uint32_t)max_lj);
@@ -873,175 +862,6 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
         S.bits <<= 4;
     }
 }
-
-// Four pairs = eight anti-diagonals = one pointer word per lane.  Group g covers pairs k = 4g .. 4g+3.  The five row
-// records and four column symbols of a group are fetched while the previous group computes (R[] / C[] hold the current
-// group's, RN[] / CN[] receive the next group's); indices are clamped into the zero-padded tables, so lanes that are not
-// inside the matrix yet (or any more) read zeros.  k_cap: pair after which H(Li,Lj) is final -- it is copied to Hcap there.
-template <bool MASK, bool LASTCOL>
-__device__ __forceinline__ void c2_diag_groups(c2_diag_state& S, int& g, const int g_stop, const int hE, const int Li, const int Lj,
-                                               const int ge, const int startE, const int startO, const int k_cap, const bool cap_odd,
-                                               int& Hcap, c2_diag_row (&R)[5], int (&C)[4],
-                                               const c2_diag_row* sRows, const unsigned char* sCodes, unsigned* myWords, const bool stores)
-{
-    for (; g <= g_stop; ++g) {
-        const int k0 = 4 * g;
-        c2_diag_row RN[5];
-        int CN[4];
-        RN[0] = R[4];
-#pragma unroll
-        for (int q = 1; q < 5; ++q) RN[q] = sRows[c2_clamp0(k0 + 4 + q + hE, Li + 1)];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) CN[q] = (int)sCodes[c2_clamp0(k0 + 4 + q - hE, Lj + 1)];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + q;
-            c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, startE, startO, LASTCOL && (k - hE == Lj));
-            if (LASTCOL && k == k_cap) Hcap = cap_odd ? S.HO : S.HE;
-        }
-        if (stores) myWords[g * C2_DIAG_STORE_N] = S.bits;           // anti-diagonals 8g .. 8g+7 (inner lanes only)
-#pragma unroll
-        for (int q = 0; q < 5; ++q) R[q] = RN[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) C[q] = CN[q];
-    }
-}
-
-__global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
-{
-    const int lane = threadIdx.x;
-    const c2_diag_plan P = c2_make_diag_plan(A.max_li, A.max_lj);
-    unsigned* sWords = (unsigned*)(c2_smem + P.plane);
-    unsigned char* sCodes = c2_smem + P.codes;
-    c2_wg W;
-    W.sRead = c2_smem + P.read; W.sCode = c2_smem + P.code; W.sRef = c2_smem + P.ref;
-    W.sIncP = (uint16_t*)(c2_smem + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
-    const int ge = A.gap_extend, go = A.gap_open;
-    unsigned char* sCodeOf = c2_smem + P.codeof;
-    for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
-
-    int cur_ref = -1;
-    int Li = 0, g0 = 0;
-    uint64_t chunk_base = 0;
-    int chunk_left = 0;
-    c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
-    c2_prefetch pf;
-    c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);
-    while (pf.valid) {
-        __syncthreads();
-        c2_phase_begin(A.phase_cycles, PH);
-        const uint64_t task = pf.task;
-        const int Lj = pf.Lj, ref_id = pf.ref_id, rc = pf.rc;
-        bool packed;
-        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_li, cur_ref, Li, g0, packed);
-        c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);   // next task's loads fly during this task's DP
-        const c2_dev_ref rf = A.refs[ref_id];
-        __syncthreads();
-        c2_aln_record rec;
-        c2_clear_record(rec, rc, ref_id);
-        bool need_full = false;
-        const int D = Li - Lj;
-        const int d0 = ((D >> 1) - 64) & ~1;                  // even; band = d0 .. d0+127 around the corner-to-corner diagonal
-        int cb = 0;
-        if (status == 0) {
-            cb = (go > ge ? go : ge) + rf.gap_incentive_max;      // the most one gap base can add to a score
-            if (!packed || rf.diag_rows == nullptr || cb >= 0 || d0 > 0 || d0 + 127 < 0 || D < d0 || D > d0 + 127) need_full = true;
-        }
-        if (status == 0 && !need_full) {
-            // ---- tables: row constants (per reference) and 4*code per column (per read), both padded so that the lanes that
-            //      are still before / already past the matrix read zeros instead of running off the arrays
-            const c2_diag_row* sRows = rf.diag_rows;           // row constants: 4 KB per amplicon, L1/L2 resident, fetched a group ahead
-            for (int j = lane; j < Lj + 2; j += 64)
-                sCodes[j] = (j >= 1 && j <= Lj) ? (unsigned char)(W.sCode[j - 1] << 2) : (unsigned char)0;
-            __syncthreads();
-            const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
-            c2_phase_mark<0>(A.phase_cycles, PH);
-
-            // ---- per-lane diagonals and their boundary cells (pyx:153-176)
-            const int hE = (d0 >> 1) + lane;                  // dE = 2*hE, dO = 2*hE + 1
-            const int dE = 2 * hE, dO = dE + 1;
-            c2_diag_state S;
-            S.bits = 0;
-            S.upM = C2_DIAG_NEG; S.upJ = C2_DIAG_NEG; S.lfM = C2_DIAG_NEG; S.lfI = C2_DIAG_NEG;
-            // diagonal d >= 1 starts at cell (d, 0): M = I = min_score, J = ge*d + g0;  d <= -1 at (0, -d): M = J = min_score,
-            // I = ge*(-d) + g0;  d == 0 at (0, 0): M = 0, I = J = min_score.  H = max of the three.
-            {
-                const int bE = (dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + g0;
-                S.ME = (dE == 0) ? 0 : min_score;
-                S.IE = (dE < 0) ? bE : min_score;
-                S.JE = (dE > 0) ? bE : min_score;
-                S.HE = c2_imax(c2_imax(S.ME, S.IE), S.JE);
-                const int bO = ge * (dO > 0 ? dO : -dO) + g0;   // dO is odd, never 0
-                S.MO = min_score;
-                S.IO = (dO < 0) ? bO : min_score;
-                S.JO = (dO > 0) ? bO : min_score;
-                S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
-            }
-            const int startE = (dE > 0 ? dE : -dE) + 2, startO = (dO > 0 ? dO : -dO) + 2;   // first interior anti-diagonal
-            const int a_end = Li + Lj;
-            const int k_end = a_end >> 1;                      // pair that holds the cell (Li, Lj)
-            const int max_start = (d0 + 127 > -d0 ? d0 + 127 : -d0) + 2;
-            const int gA = ((max_start + 1) >> 1) >> 2;        // groups 0..gA contain lanes that have not started
-            const int gC = ((2 * Lj + d0) >> 1) >> 2;          // first group in which some lane is on the last column
-            const int g_end = k_end >> 2;
-            unsigned* myWords = sWords + (lane - C2_DIAG_STORE_LO);
-            const bool stores = (unsigned)(lane - C2_DIAG_STORE_LO) < (unsigned)C2_DIAG_STORE_N;
-            // tables of group 0: rows i = k + hE (E cell of pair k) .. and one more for the last O cell; columns j = k - hE
-            c2_diag_row Rw[5];
-            int Cw[4];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) Rw[q] = sRows[c2_clamp0(q + hE, Li + 1)];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Cw[q] = (int)sCodes[c2_clamp0(q - hE, Lj + 1)];
-            int Hcap = C2_DIAG_NEG;
-            const bool cap_odd = (a_end & 1) != 0;
-            int g = 0;
-            const int gA_stop = gA < g_end ? gA : g_end;
-            if (gC <= gA_stop) {
-                c2_diag_groups<true, true>(S, g, gA_stop, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords, stores);
-            } else {
-                c2_diag_groups<true, false>(S, g, gA_stop, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords, stores);
-                c2_diag_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords, stores);
-            }
-            c2_diag_groups<false, true>(S, g, g_end, hE, Li, Lj, ge, startE, startO, k_end, cap_odd, Hcap, Rw, Cw, sRows, sCodes, myWords, stores);
-            __syncthreads();
-            c2_phase_mark<1>(A.phase_cycles, PH);
-
-            // ---- optimality certificate
-            const int lane_end = (D - d0) >> 1;
-            const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
-            const int maxS = A.max_score;
-            const int dhi1 = d0 + 128, dlo1 = d0 - 1;         // first diagonals outside the band
-            int U = C2_DIAG_NEG;
-            if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + cb * (2 * dhi1 - D));
-            if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + cb * (D - 2 * dlo1));
-            if (!(Hend > U)) need_full = true;
-
-            if (!need_full) {
-                c2_diag_plane plane;
-                plane.words = sWords; plane.d0 = d0;
-                if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
-                    int cnt, matches;
-                    bool nf2;
-                    c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, nf2);
-                    __syncthreads();
-                    c2_phase_mark<2>(A.phase_cycles, PH);
-                    if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                    else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
-                }
-            }
-        }
-        if (need_full) {
-            status |= C2_STATUS_NEED_FULL;
-            if (lane == 0) { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
-        }
-        rec.status = (uint8_t)status;
-        if (lane == 0) A.records[task] = rec;
-        c2_phase_mark<3>(A.phase_cycles, PH);
-    }
-    c2_phase_flush(A.phase_cycles, PH, lane);
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Multi-alignment diagonal-band kernel: NA (2 or 4) alignments share one wavefront.  One anti-diagonal step costs the
@@ -1124,7 +944,8 @@ __device__ __forceinline__ void c2_diagx_fetch(const int g, const c2_diagx_lane&
 template <bool MASK, bool LASTCOL>
 __device__ __forceinline__ void c2_diagx_group(c2_diag_state& S, const int g, const c2_diagx_lane& L, const int ge, int& Hcap,
                                                const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
-                                               const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride)
+                                               const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride,
+                                               const bool stores = true)
 {
     c2_diagx_fetch(g + 1, L, rows, lds, RN, CN);
 #pragma unroll
@@ -1133,21 +954,22 @@ __device__ __forceinline__ void c2_diagx_group(c2_diag_state& S, const int g, co
         c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, L.startE, L.startO, LASTCOL && (k == L.kLast));
         if (LASTCOL && k == L.kCap) Hcap = L.capOdd ? S.HO : S.HE;
     }
-    myWords[g * wordStride] = S.bits;                                // anti-diagonals 8g .. 8g+7
+    if (stores) myWords[g * wordStride] = S.bits;                    // anti-diagonals 8g .. 8g+7
 }
 
 // Groups g .. g_stop; the tables alternate between two register sets (no copies).  `cur` tells which set holds group g's.
 template <bool MASK, bool LASTCOL>
 __device__ __forceinline__ void c2_diagx_groups(c2_diag_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const int ge,
                                                 int& Hcap, c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
-                                                const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride)
+                                                const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride,
+                                                const bool stores = true)
 {
     for (; g + 1 <= g_stop; g += 2) {
-        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, RA, CA, RB, CB, rows, lds, myWords, wordStride);
-        c2_diagx_group<MASK, LASTCOL>(S, g + 1, L, ge, Hcap, RB, CB, RA, CA, rows, lds, myWords, wordStride);
+        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, RA, CA, RB, CB, rows, lds, myWords, wordStride, stores);
+        c2_diagx_group<MASK, LASTCOL>(S, g + 1, L, ge, Hcap, RB, CB, RA, CA, rows, lds, myWords, wordStride, stores);
     }
     if (g <= g_stop) {                                               // odd count: one more group, then move its successor's tables to set A
-        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, RA, CA, RB, CB, rows, lds, myWords, wordStride);
+        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, RA, CA, RB, CB, rows, lds, myWords, wordStride, stores);
         ++g;
 #pragma unroll
         for (int q = 0; q < 5; ++q) RA[q] = RB[q];
@@ -1155,6 +977,149 @@ __device__ __forceinline__ void c2_diagx_groups(c2_diag_state& S, int& g, const 
         for (int q = 0; q < 4; ++q) CA[q] = CB[q];
     }
 }
+
+__global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
+{
+    const int lane = threadIdx.x;
+    const c2_diag_plan P = c2_make_diag_plan(A.max_li, A.max_lj);
+    unsigned* sWords = (unsigned*)(c2_smem + P.plane);
+    unsigned char* sCodes = c2_smem + P.codes;
+    c2_wg W;
+    W.sRead = c2_smem + P.read; W.sCode = c2_smem + P.code; W.sRef = c2_smem + P.ref;
+    W.sIncP = (uint16_t*)(c2_smem + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
+    const int ge = A.gap_extend, go = A.gap_open;
+    unsigned char* sCodeOf = c2_smem + P.codeof;
+    for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
+
+    int cur_ref = -1;
+    int Li = 0, g0 = 0;
+    uint64_t chunk_base = 0;
+    int chunk_left = 0;
+    c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
+    c2_prefetch pf;
+    c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);
+    while (pf.valid) {
+        __syncthreads();
+        c2_phase_begin(A.phase_cycles, PH);
+        const uint64_t task = pf.task;
+        const int Lj = pf.Lj, ref_id = pf.ref_id, rc = pf.rc;
+        bool packed;
+        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_li, cur_ref, Li, g0, packed);
+        c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);   // next task's loads fly during this task's DP
+        const c2_dev_ref rf = A.refs[ref_id];
+        __syncthreads();
+        c2_aln_record rec;
+        c2_clear_record(rec, rc, ref_id);
+        bool need_full = false;
+        const int D = Li - Lj;
+        const int d0 = ((D >> 1) - 64) & ~1;                  // even; band = d0 .. d0+127 around the corner-to-corner diagonal
+        int cb = 0;
+        if (status == 0) {
+            cb = (go > ge ? go : ge) + rf.gap_incentive_max;      // the most one gap base can add to a score
+            if (!packed || rf.diag_rows == nullptr || cb >= 0 || d0 > 0 || d0 + 127 < 0 || D < d0 || D > d0 + 127) need_full = true;
+        }
+        if (status == 0 && !need_full) {
+            // ---- tables: row constants (per reference) and 4*code per column (per read), both padded so that the lanes that
+            //      are still before / already past the matrix read zeros instead of running off the arrays
+            // (same zero-padded tables and alternating register sets as the multi-alignment kernel)
+            for (int j = lane; j < C2_DIAG_CODE_PAD + Lj + 2 + 8; j += 64) {
+                const int col = j - C2_DIAG_CODE_PAD;
+                sCodes[j] = (col >= 1 && col <= Lj) ? (unsigned char)(W.sCode[col - 1] << 2) : (unsigned char)0;
+            }
+            __syncthreads();
+            const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
+            c2_phase_mark<0>(A.phase_cycles, PH);
+
+            // ---- per-lane diagonals and their boundary cells (pyx:153-176)
+            const int hE = (d0 >> 1) + lane;                  // dE = 2*hE, dO = 2*hE + 1
+            const int dE = 2 * hE, dO = dE + 1;
+            c2_diag_state S;
+            S.bits = 0;
+            S.upM = C2_DIAG_NEG; S.upJ = C2_DIAG_NEG; S.lfM = C2_DIAG_NEG; S.lfI = C2_DIAG_NEG;
+            // diagonal d >= 1 starts at cell (d, 0): M = I = min_score, J = ge*d + g0;  d <= -1 at (0, -d): M = J = min_score,
+            // I = ge*(-d) + g0;  d == 0 at (0, 0): M = 0, I = J = min_score.  H = max of the three.
+            {
+                const int bE = (dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + g0;
+                S.ME = (dE == 0) ? 0 : min_score;
+                S.IE = (dE < 0) ? bE : min_score;
+                S.JE = (dE > 0) ? bE : min_score;
+                S.HE = c2_imax(c2_imax(S.ME, S.IE), S.JE);
+                const int bO = ge * (dO > 0 ? dO : -dO) + g0;   // dO is odd, never 0
+                S.MO = min_score;
+                S.IO = (dO < 0) ? bO : min_score;
+                S.JO = (dO > 0) ? bO : min_score;
+                S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
+            }
+            const int startE = (dE > 0 ? dE : -dE) + 2, startO = (dO > 0 ? dO : -dO) + 2;   // first interior anti-diagonal
+            const int a_end = Li + Lj;
+            const int k_end = a_end >> 1;                      // pair that holds the cell (Li, Lj)
+            const int max_start = (d0 + 127 > -d0 ? d0 + 127 : -d0) + 2;
+            const int gA = ((max_start + 1) >> 1) >> 2;        // groups 0..gA contain lanes that have not started
+            const int gC = ((2 * Lj + d0) >> 1) >> 2;          // first group in which some lane is on the last column
+            const int g_end = k_end >> 2;
+            unsigned* myWords = sWords + (lane - C2_DIAG_STORE_LO);
+            const bool stores = (unsigned)(lane - C2_DIAG_STORE_LO) < (unsigned)C2_DIAG_STORE_N;
+            c2_diagx_lane L;
+            const int vrow = (int)(rf.diag_rows - A.diag_base), vcode = (int)P.codes + C2_DIAG_CODE_PAD;
+            L.rowOff = (unsigned)((vrow + hE) * (int)sizeof(c2_diag_row));
+            L.rowMax = (unsigned)((vrow + Li + 1 + C2_DIAG_ROW_PAD - 5) * (int)sizeof(c2_diag_row));
+            L.colOff = (unsigned)(vcode - hE);
+            L.colMax = (unsigned)(vcode + Lj + 2);
+            L.kLast = Lj + hE;
+            L.kCap = k_end; L.capOdd = (a_end & 1) != 0;
+            L.startE = startE; L.startO = startO;
+            const c2_diag_row* rows = A.diag_base;
+            c2_diag_row RA[5], RB[5];
+            int CA[4], CB[4];
+            c2_diagx_fetch(0, L, rows, c2_smem, RA, CA);
+            int Hcap = C2_DIAG_NEG;
+            int g = 0;
+            const int gA_stop = gA < g_end ? gA : g_end;
+            if (gC <= gA_stop) {
+                c2_diagx_groups<true, true>(S, g, gA_stop, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+            } else {
+                c2_diagx_groups<true, false>(S, g, gA_stop, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+            }
+            c2_diagx_groups<false, true>(S, g, g_end, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+            __syncthreads();
+            c2_phase_mark<1>(A.phase_cycles, PH);
+
+            // ---- optimality certificate
+            const int lane_end = (D - d0) >> 1;
+            const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
+            const int maxS = A.max_score;
+            const int dhi1 = d0 + 128, dlo1 = d0 - 1;         // first diagonals outside the band
+            int U = C2_DIAG_NEG;
+            if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + cb * (2 * dhi1 - D));
+            if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + cb * (D - 2 * dlo1));
+            if (!(Hend > U)) need_full = true;
+
+            if (!need_full) {
+                c2_diag_plane plane;
+                plane.words = sWords; plane.d0 = d0;
+                if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
+                    int cnt, matches;
+                    bool nf2;
+                    c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, nf2);
+                    __syncthreads();
+                    c2_phase_mark<2>(A.phase_cycles, PH);
+                    if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
+                    else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
+                }
+            }
+        }
+        if (need_full) {
+            status |= C2_STATUS_NEED_FULL;
+            if (lane == 0) { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
+        }
+        rec.status = (uint8_t)status;
+        if (lane == 0) A.records[task] = rec;
+        c2_phase_mark<3>(A.phase_cycles, PH);
+    }
+    c2_phase_flush(A.phase_cycles, PH, lane);
+}
+
 
 // per-alignment ("slot") table in LDS: wave-uniform values written by lane 0 and read back through readfirstlane, so the
 // staging / traceback / output code exists once (a loop over the slots) instead of once per slot
