@@ -143,9 +143,9 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 
 // count kernel geometry: C2_CNT_WAVES wavefronts share one LDS accumulator block; after the block come
 // C2_CNT_CTL_INTS control words and the current reference's inc_prefix (lmax + 2 uint16)
-#define C2_CNT_WAVES 8
+#define C2_CNT_WAVES 4
 #define C2_CNT_TASKS_PER_WAVE 32
-#define C2_CNT_CTL_INTS 64          // >= 16 + 4 * C2_CNT_WAVES
+#define C2_CNT_CTL_INTS 96          // >= 16 + 4 * C2_CNT_WAVES
 static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {
     return (per_ref + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
 }
