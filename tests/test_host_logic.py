@@ -117,3 +117,46 @@ def test_count_layout_roundtrip():
     u = lay.unpack(x, 1, 223)
     assert u["all_substitution_count_vectors"][7] == 5 and len(u["all_substitution_count_vectors"]) == 223
     assert u["counts_modified"] == 9 and u["substituted_n"] == {4: 3}
+
+
+def test_tables_write_the_reference_formats_from_a_count_tensor(tmp_path):
+    """tables.write_tables on a QuantResult built from oracle/aggregate.py output (no GPU): the FANC.Cas9 result files of the
+    reference repository must come out byte for byte when the counts are right, and the other tables must be well formed."""
+    import gzip
+    import json
+    import os
+    import numpy as np
+    import oracle
+    from oracle import aggregate
+    from crispresso2_amd import tables, counts as C, refs as RF
+    from crispresso2_amd.pipeline import QuantResult
+    from helpers import matrices
+    here = os.path.dirname(os.path.abspath(__file__))
+    with gzip.open(os.path.join(here, "golden", "fanc_run.json.gz"), "rt") as fh:
+        g = json.load(fh)
+    amp, cut = g["amplicon"], g["cut_point"]
+    ref = RF.make_ref("Reference", amp, [cut], [cut, cut + 1], min_aln_score=60)
+    m = matrices()["EDNAFULL"]
+    lines = g["fastq"].split("\n")
+    reads = [lines[k] for k in range(1, len(lines), 4) if lines[k]]
+    # the reference's single-amplicon flow with the CPU oracle: forward strand only (the FANC reads are), min_aln_score 60
+    items, n_total = [], 0
+    for rd in reads:
+        s1, s2, score = oracle.global_align(rd, amp, m, ref["gap_incentive"], -20, -2)
+        if score > 60:
+            p = oracle.find_indels_substitutions(s1, s2, ref["include_idxs"])
+            p["aln_seq"], p["aln_ref"] = s1, s2
+            items.append((p, 1))
+            n_total += 1
+    agg = aggregate.aggregate(items, len(amp))
+    lay = C.CountLayout(1, len(amp), max(len(r) for r in reads))
+    per_ref = {"Reference": agg}
+    res = QuantResult(per_ref, {"N_TOT_READS": len(reads), "N_READS_INPUT": len(reads), "N_TOTAL": n_total}, lay, None)
+    names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(tmp_path))
+    for fn, text in g["expected_files"].items():
+        assert fn in names and (tmp_path / fn).read_text() == text, fn
+    win = (tmp_path / "Quantification_window_nucleotide_frequency_table.txt").read_text().split("\n")
+    assert win[0] == "\t" + "\t".join(amp[cut:cut + 2]) and len(win) == 8
+    pct = (tmp_path / "Nucleotide_percentage_table.txt").read_text().split("\n")[1].split("\t")
+    assert pct[0] == "A" and abs(float(pct[4]) - 1.0) < 1e-12          # position 4 of the amplicon is an A in every aligned read
+    assert tables.ref_plot_name(["Reference"], "Reference") == "" and tables.ref_plot_name(["A", "B"], "A") == "A."
