@@ -767,9 +767,10 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
 // banded score H(Li,Lj) > U for both band edges, every optimal path -- and every path that ties with one at any cell the
 // reference's traceback visits -- lies inside the band, where banded and full DP values coincide, so the pointers the
 // traceback reads are the full DP's.  Otherwise (and for reads the packed score rows cannot encode) the task goes to the
-// fallback list and the row-strip kernel redoes it.  Neighbour traffic: two DPP moves per step (wave_shr at even steps,
-// wave_shl at odd steps); row constants {a_i, b_i, c_i, score row} and the column symbol come from LDS tables, fetched
-// one step pair ahead.
+// fallback list and the next launch of the chain redoes it.  Neighbour traffic: two DPP moves per step (wave_shr at even
+// steps, wave_shl at odd steps); row constants {a_i, b_i, c_i, score row} come from a zero-padded per-reference table in
+// global memory (L2-resident), the column symbols from a zero-padded LDS table, both fetched one group of eight
+// anti-diagonals ahead (c2_diagx_fetch).
 // ---------------------------------------------------------------------------------------------------------------
 #define C2_DPP_WAVE_SHL1 0x130
 // lane n receives `src` of lane n+1; lane 63 keeps `old`
