@@ -223,3 +223,49 @@ def process_fastq(path, args, refs, ref_names, aln_matrix, pe_scaffold_dna_info=
         if p['irregular_ends']:
             st['N_READS_IRREGULAR_ENDS'] += c
     return variantCache, not_aligned, st
+
+
+def process_fastq_write_out(fastq_input, fastq_output, args, refs, ref_names, aln_matrix, pe_scaffold_dna_info=None, ctx=None):
+    """process_fastq_write_out equivalent (CRISPRessoCORE.py:2283-2350): process_fastq, then the input FASTQ written again
+    (gzip) with every read's alignment summary on its '+' line.  -> (variantCache, not_aligned_variants, aln_stats)"""
+    from . import variant_io
+    cache, not_aligned, st = process_fastq(fastq_input, args, refs, ref_names, aln_matrix, pe_scaffold_dna_info, ctx=ctx)
+    variant_io.write_annotated_fastq(fastq_input, fastq_output, cache, not_aligned)
+    return cache, not_aligned, st
+
+
+def process_fastq_sharded(path, args, refs, ref_names, aln_matrix, variants_dir, pe_scaffold_dna_info=None, ctx=None,
+                          rank=None, world=None, get_variants=None):
+    """The reference's n_processes > 1 route (CRISPRessoCORE.py:1870-1985) with one GPU rank in place of each worker
+    process: every rank de-duplicates the FASTQ (host work, identical on all ranks), computes the variants of ITS slice of
+    the unique reads (get_variant_cache_equal_boundaries) on its GPU, writes them as variants_<rank>.tsv in the reference's
+    format; after a barrier rank 0 merges the files with the parent's bookkeeping.  Like the reference, fewer unique
+    reads than ranks falls back to the one-process route (on rank 0).
+    -> (variantCache, not_aligned_variants, aln_stats) on rank 0, None elsewhere."""
+    import os
+    from . import variant_io
+    from .distributed import shard_boundaries
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    get_variants = get_variants or get_new_variant_objects
+    counts = read_fastq_unique(path)
+    seqs = list(counts.keys())
+    if world <= 1 or len(seqs) <= world:
+        if rank != 0:
+            return None
+        if get_variants is get_new_variant_objects:
+            return process_fastq(path, args, refs, ref_names, aln_matrix, pe_scaffold_dna_info, ctx=ctx)
+        world = 1
+    b = shard_boundaries(len(seqs), world)
+    mine = seqs[b[rank]:b[rank + 1]]
+    variants = get_variants(args, mine, refs, ref_names, aln_matrix, pe_scaffold_dna_info, ctx=ctx)
+    variant_io.write_variant_file(variants_dir, rank, mine, variants)
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+    if rank != 0:
+        return None
+    paths = [os.path.join(variants_dir, "variants_%d.tsv" % k) for k in range(world)]
+    st, not_aligned = variant_io.merge_variant_files(paths, counts, args)
+    return counts, not_aligned, st

@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -576,3 +576,88 @@ if __name__ == "__main__" and "--variants" in sys.argv:
     with gzip.open(os.path.join(HERE, "variants.json.gz"), "wt") as fh:
         json.dump(variant_goldens(), fh, separators=(",", ":"))
     print("variants.json.gz written")
+
+
+# ---------------------------------------------------------------- 8. variant files and --fastq_output (CRISPRessoCORE.py:1198-1242, :1900-1985, :2283-2350)
+def variant_io_goldens():
+    """The reference's process_fastq / process_fastq_write_out on tests/FANC.Cas9.fastq (every 5th read duplicated, a few
+    reads reverse-complemented, two unrelated reads): the variants_<k>.tsv files its worker processes write (-p 2), the
+    statistics and not-aligned reads of both routes, and the annotated --fastq_output text."""
+    import gzip
+    from crispresso2_amd import refs as RF
+    core = load_reference_core()
+    fanc = None
+    with open(os.path.join(REF, "tests/Cas9.amplicons.txt")) as fh:
+        for line in fh:
+            f = line.split()
+            if f and f[0] == "FANC":
+                fanc = f[1].upper()
+    hdr = fanc[:88] + "GATTACA" + fanc[95:]
+    with open(os.path.join(REF, "tests/FANC.Cas9.fastq")) as fh:
+        lines = fh.read().split("\n")
+    rng = np.random.default_rng(12)
+    recs = []
+    for k in range(0, len(lines) - 3, 4):
+        rid, seq, plus, qual = lines[k:k + 4]
+        if k // 4 % 7 == 3 and set(seq) <= set("ACGTN"):
+            seq, qual = RF.reverse_complement(seq), qual[::-1]
+        recs.append((rid, seq, plus, qual))
+        if k // 4 % 5 == 0:
+            recs.append((rid + "/dup", seq, plus, qual))
+    for k in range(2):
+        s = "".join(rng.choice(list("ACGT"), 180))
+        recs.append(("@unrelated%d" % k, s, "+", "I" * 180))
+    fastq = "".join("%s\n%s\n%s\n%s\n" % r for r in recs)
+    out = {"fastq": fastq, "cases": []}
+    for label, ref_specs, flags in (
+            ("FANC", [("FANC", fanc)], {}),
+            ("FANC+HDR", [("FANC", fanc), ("HDR", hdr)], {}),
+            ("FANC+HDR expand", [("FANC", fanc), ("HDR", hdr)], {"expand_ambiguous_alignments": True})):
+        base = dict(aln_seed_count=5, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                    use_legacy_insertion_quantification=False, ignore_deletions=False, ignore_insertions=False,
+                    ignore_substitutions=False, assign_ambiguous_alignments_to_first_reference=False,
+                    expand_ambiguous_alignments=False, prime_editing_pegRNA_scaffold_seq="", prime_editing_pegRNA_extension_seq="",
+                    needleman_wunsch_aln_matrix_loc="EDNAFULL", debug=False, fastq_output=True, crispresso_merge=False)
+        base.update(flags)
+        refs, names = {}, []
+        for nm, sq in ref_specs:
+            refs[nm] = RF.make_ref(nm, sq, [91], [91, 92], min_aln_score=60)
+            names.append(nm)
+        case = {"label": label, "args": dict(base),
+                "refs": [{"name": nm, "sequence": refs[nm]["sequence"], "cut_points": [91], "include_idxs": [91, 92],
+                          "min_aln_score": 60} for nm in names]}
+        with tempfile.TemporaryDirectory() as tmp:
+            fq = os.path.join(tmp, "in.fastq")
+            with open(fq, "w") as fh:
+                fh.write(fastq)
+            # route 1: one process, annotated output
+            args = types.SimpleNamespace(n_processes="1", **base)
+            cache = {}
+            fq_out = os.path.join(tmp, "out.fastq.gz")
+            st, not_aln = core.process_fastq_write_out(fq, fq_out, cache, names, refs, args, [], tmp)
+            with gzip.open(fq_out, "rt") as fh:
+                case["annotated"] = fh.read()
+            case["single"] = {"aln_stats": jsonable(st), "not_aligned": list(not_aln.keys()), "aligned": list(cache.keys()),
+                              "counts": [cache[k]["count"] for k in cache]}
+            # route 2: two worker processes -> variants_0.tsv, variants_1.tsv, merged by the parent
+            args = types.SimpleNamespace(n_processes="2", **base)
+            cache = {}
+            to_remove = []
+            st, not_aln = core.process_fastq(fq, cache, names, refs, args, to_remove, tmp)
+            tsv = []
+            for p in to_remove:
+                with open(p) as fh:
+                    tsv.append(fh.read())
+            case["tsv"] = tsv
+            case["multi"] = {"aln_stats": jsonable(st), "not_aligned": list(not_aln.keys()), "aligned": list(cache.keys()),
+                             "counts": [cache[k]["count"] for k in cache]}
+        out["cases"].append(case)
+    return out
+
+
+if __name__ == "__main__" and "--variant-io" in sys.argv:
+    import gzip
+    d = variant_io_goldens()
+    with gzip.open(os.path.join(HERE, "variant_io.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("variant_io.json.gz written:", [(c["label"], len(c["tsv"]), c["single"]["aln_stats"]["N_TOT_READS"]) for c in d["cases"]])

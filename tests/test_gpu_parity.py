@@ -725,3 +725,36 @@ def test_paired_consensus_and_variants_vs_reference_functions(mats, ctx):
             n_amb += len(e.get("aln_ref_names", [])) > 1 or e.get("class_name") == "AMBIGUOUS"
             n_unal += e["best_match_score"] <= 0
     assert n_amb >= 3 and n_unal >= 3
+
+
+def test_variant_files_and_annotated_fastq_equal_the_reference_text(mats, ctx, tmp_path):
+    """SURVEY 8(f)-4 end to end on the device: FASTQ -> unique reads -> device alignments + classifier -> the variants_<k>.tsv
+    files of the reference's two-worker run and its --fastq_output file, byte for byte; both routes' statistics."""
+    import gzip
+    import types
+    from crispresso2_amd import refs as RF, variants as V
+    gold = load_golden("variant_io.json.gz")
+    fq = tmp_path / "in.fastq"
+    fq.write_text(gold["fastq"])
+    for case in gold["cases"]:
+        args = types.SimpleNamespace(**case["args"])
+        refs, names = {}, []
+        for r in case["refs"]:
+            refs[r["name"]] = RF.make_ref(r["name"], r["sequence"], r["cut_points"], r["include_idxs"], r["min_aln_score"])
+            names.append(r["name"])
+        out = tmp_path / "out.fastq.gz"
+        cache, not_aligned, st = V.process_fastq_write_out(str(fq), str(out), args, refs, names, mats["EDNAFULL"], ctx=ctx)
+        with gzip.open(out, "rt") as fh:
+            assert fh.read() == case["annotated"]
+        assert st == case["single"]["aln_stats"]
+        assert list(not_aligned) == case["single"]["not_aligned"] and list(cache) == case["single"]["aligned"]
+        assert [cache[k]["count"] for k in cache] == case["single"]["counts"]
+        # the sharded route, both "ranks" run here one after the other (no process group: the barrier is skipped)
+        d = tmp_path / case["label"].replace(" ", "_").replace("+", "_")
+        d.mkdir()
+        assert V.process_fastq_sharded(str(fq), args, refs, names, mats["EDNAFULL"], str(d), ctx=ctx, rank=1, world=2) is None
+        cache, not_aligned, st = V.process_fastq_sharded(str(fq), args, refs, names, mats["EDNAFULL"], str(d), ctx=ctx, rank=0, world=2)
+        for k in range(2):
+            assert (d / ("variants_%d.tsv" % k)).read_text() == case["tsv"][k]
+        assert st == case["multi"]["aln_stats"]
+        assert list(not_aligned) == case["multi"]["not_aligned"] and list(cache) == case["multi"]["aligned"]
