@@ -25,6 +25,7 @@ SYMBOLS = [
     "c2_fastq_unique", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error", "c2_strand_plan", "c2_merge_reverse_complements",
     "c2_consensus_pairs_batch",
+    "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets",
 ]
 
 REC_DTYPE = np.dtype([
@@ -89,10 +90,13 @@ def load():
                 fn.argtypes = [ctypes.c_void_p]
             lib.c2_lists_free.restype = None
             lib.c2_lists_free.argtypes = [ctypes.c_void_p]
-            for fn in (lib.c2_fastq_n_unique, lib.c2_fastq_n_reads, lib.c2_fastq_arena_bytes):
+            for fn in (lib.c2_fastq_n_unique, lib.c2_fastq_n_reads, lib.c2_fastq_arena_bytes, lib.c2_fastq_aux_bytes):
                 fn.restype = ctypes.c_uint64
                 fn.argtypes = [ctypes.c_void_p]
-            for fn in (lib.c2_fastq_arena, lib.c2_fastq_offsets, lib.c2_fastq_counts):
+            lib.c2_fastq_unique_paired.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+            lib.c2_fastq_paired_occurrences.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                        ctypes.POINTER(ctypes.c_void_p)]
+            for fn in (lib.c2_fastq_arena, lib.c2_fastq_offsets, lib.c2_fastq_counts, lib.c2_fastq_aux, lib.c2_fastq_aux_offsets):
                 fn.restype = ctypes.c_void_p
                 fn.argtypes = [ctypes.c_void_p]
             lib.c2_fastq_free.restype = None
@@ -266,6 +270,69 @@ def fastq_unique(path):
     finally:
         lib.c2_fastq_free(h)
     return arena, offsets, counts, total
+
+
+def _fastq_strings(lib, h, n, data_fn, bytes_fn, offsets_fn):
+    nb = int(bytes_fn(h))
+    if n == 0:
+        return []
+    buf = ctypes.string_at(data_fn(h), nb) if nb else b""
+    off = np.ctypeslib.as_array(ctypes.cast(offsets_fn(h), ctypes.POINTER(ctypes.c_uint64)), (n + 1,))
+    return [buf[int(off[k]):int(off[k + 1])].decode('utf-8') for k in range(n)]
+
+
+class PairedFastq:
+    """c2_fastq_unique_paired (host code, needs no GPU): the unique read pairs of two FASTQ files read in lockstep.
+    keys[k] = seq1 + '+' + reverse_complement(seq2), counts[k] copies, quals[k] = qual1 + ' ' + qual2[::-1] of the first
+    occurrence, all in first-seen order; n_pairs = records read.  occurrences(selected) re-reads the files."""
+
+    def __init__(self, path1, path2):
+        lib = load()
+        self._lib, self._paths = lib, (os.fsencode(path1), os.fsencode(path2))
+        self._h = ctypes.c_void_p()
+        rc = lib.c2_fastq_unique_paired(self._paths[0], self._paths[1], ctypes.byref(self._h))
+        if rc != 0:
+            msg = lib.c2_fastq_last_error().decode()
+            if msg.startswith("KeyError"):
+                raise KeyError(msg)
+            raise NativeError("c2_fastq_unique_paired: %s" % msg)
+        h = self._h
+        n = int(lib.c2_fastq_n_unique(h))
+        self.keys = _fastq_strings(lib, h, n, lib.c2_fastq_arena, lib.c2_fastq_arena_bytes, lib.c2_fastq_offsets)
+        self.quals = _fastq_strings(lib, h, n, lib.c2_fastq_aux, lib.c2_fastq_aux_bytes, lib.c2_fastq_aux_offsets)
+        self.counts = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_counts(h), ctypes.POINTER(ctypes.c_uint32)), (n,)).copy()
+                       if n else np.zeros(0, dtype=np.uint32))
+        self.n_pairs = int(lib.c2_fastq_n_reads(h))
+
+    def occurrences(self, selected):
+        """selected: bool per key -> (key index per occurrence, quality pair per occurrence), in file order."""
+        lib = self._lib
+        sel = np.ascontiguousarray(selected, dtype=np.uint8)
+        if sel.shape != (len(self.keys),):
+            raise ValueError("one flag per key")
+        out = ctypes.c_void_p()
+        rc = lib.c2_fastq_paired_occurrences(self._paths[0], self._paths[1], self._h, sel.ctypes.data_as(ctypes.c_void_p), ctypes.byref(out))
+        if rc != 0:
+            raise NativeError("c2_fastq_paired_occurrences: %s" % lib.c2_fastq_last_error().decode())
+        try:
+            m = int(lib.c2_fastq_n_unique(out))
+            idx = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_counts(out), ctypes.POINTER(ctypes.c_uint32)), (m,)).copy()
+                   if m else np.zeros(0, dtype=np.uint32))
+            quals = _fastq_strings(lib, out, m, lib.c2_fastq_aux, lib.c2_fastq_aux_bytes, lib.c2_fastq_aux_offsets)
+        finally:
+            lib.c2_fastq_free(out)
+        return idx, quals
+
+    def close(self):
+        if self._h:
+            self._lib.c2_fastq_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def strand_plan(arena, offsets, fw_seeds, rc_seeds, seed_min):

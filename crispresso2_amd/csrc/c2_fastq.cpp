@@ -34,6 +34,8 @@ struct c2_fastq {
     std::vector<uint64_t> offsets;     // n_unique + 1
     std::vector<uint32_t> counts;      // n_unique
     uint64_t n_reads = 0;
+    std::vector<uint8_t> aux;          // paired input: the quality pair "q1 q2[::-1]" of every entry, back to back
+    std::vector<uint64_t> aux_offsets; // n_unique + 1 (empty for single-file input)
 };
 
 namespace {
@@ -72,9 +74,24 @@ struct Dedup {
         }
         table.swap(t); mask = m;
     }
-    bool add(const uint8_t* s, size_t n, uint32_t copies = 1) {
+    // index of a sequence already in the table, or -1
+    int64_t find(const uint8_t* s, size_t n) const {
         const uint64_t h = hash_bytes(s, n);
         uint64_t pos = h & mask;
+        while (table[pos]) {
+            const uint32_t k = table[pos] - 1;
+            if (hashes[k] == h) {
+                const uint64_t o = R->offsets[k];
+                if (R->offsets[k + 1] - o == n && (n == 0 || memcmp(R->arena.data() + o, s, n) == 0)) return (int64_t)k;
+            }
+            pos = (pos + 1) & mask;
+        }
+        return -1;
+    }
+    bool add(const uint8_t* s, size_t n, uint32_t copies = 1, bool* fresh = nullptr) {
+        const uint64_t h = hash_bytes(s, n);
+        uint64_t pos = h & mask;
+        if (fresh) *fresh = false;
         while (table[pos]) {
             const uint32_t k = table[pos] - 1;
             if (hashes[k] == h) {
@@ -84,6 +101,7 @@ struct Dedup {
             pos = (pos + 1) & mask;
         }
         if (hashes.size() >= 0xfffffffeull) return false;
+        if (fresh) *fresh = true;
         table[pos] = (uint32_t)hashes.size() + 1;
         hashes.push_back(h);
         R->arena.insert(R->arena.end(), s, s + n);
@@ -351,6 +369,106 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
     return 0;
 }
 
+
+// ---- paired input (process_paired_fastq, CRISPRessoCORE.py:1296-1334): two files read in lockstep ---------------------
+// readline() of a text-mode file object with universal newlines, over zlib (gzread passes plain files through)
+struct TextReader {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+    bool eof = false, err = false;
+    ~TextReader() { if (f) gzclose(f); }
+    bool open(const char* path) {
+        f = gzopen(path, "rb");
+        if (!f) return false;
+        gzbuffer(f, 1u << 20);
+        buf.resize(1u << 20);
+        return true;
+    }
+    bool fill() {
+        if (eof) return false;
+        const int g = gzread(f, buf.data(), (unsigned)buf.size());
+        if (g <= 0) { eof = true; err = g < 0; pos = end = 0; return false; }
+        pos = 0; end = (size_t)g;
+        return true;
+    }
+    // false = readline() returned '' (end of file); otherwise `line` holds the line without its terminator
+    bool readline(std::string& line) {
+        line.clear();
+        bool any = false;
+        for (;;) {
+            if (pos == end && !fill()) return any;
+            size_t i = pos;
+            while (i < end && buf[i] != '\n' && buf[i] != '\r') ++i;
+            if (i > pos) { line.append(buf.data() + pos, i - pos); any = true; }
+            if (i == end) { pos = end; continue; }
+            const char c = buf[i];
+            pos = i + 1;
+            if (c == '\r') {
+                if (pos == end) fill();
+                if (pos < end && buf[pos] == '\n') ++pos;
+            }
+            return true;
+        }
+    }
+};
+
+inline void py_strip(std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && py_space((uint8_t)s[a])) ++a;
+    while (b > a && py_space((uint8_t)s[b - 1])) --b;
+    if (a || b != s.size()) s = s.substr(a, b - a);
+}
+
+// CRISPRessoShared.reverse_complement (CRISPRessoShared.py:399-403): upper-case, then A<->T C<->G, N _ - unchanged; any
+// other character is a KeyError there -> false here
+inline bool reverse_complement_into(const std::string& s, std::string& out) {
+    out.resize(s.size());
+    for (size_t k = 0; k < s.size(); ++k) {
+        char c = s[s.size() - 1 - k];
+        if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+        switch (c) {
+            case 'A': c = 'T'; break; case 'T': c = 'A'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break;
+            case 'N': case '_': case '-': break;
+            default: return false;
+        }
+        out[k] = c;
+    }
+    return true;
+}
+
+// One pass over the two files with the reference's statements: record = 4 readline() calls per file, the loop ends when
+// either file's id line is ''.  visit(key = seq1 + '+' + rc(seq2), quals = qual1 + ' ' + qual2[::-1]) -> false stops.
+template <class Visit>
+int for_each_pair(const char* path1, const char* path2, uint64_t* n_pairs, Visit visit) {
+    TextReader r1, r2;
+    if (!r1.open(path1)) { g_fastq_error = std::string("cannot open ") + path1; return C2_E_INVALID; }
+    if (!r2.open(path2)) { g_fastq_error = std::string("cannot open ") + path2; return C2_E_INVALID; }
+    std::string id1, id2, s1, s2, skip, q1, q2, rc2, key, quals;
+    uint64_t n = 0;
+    bool h1 = r1.readline(id1), h2 = r2.readline(id2);
+    while (h1 && h2) {
+        r1.readline(s1); py_strip(s1);
+        r1.readline(skip);
+        r1.readline(q1); py_strip(q1);
+        r2.readline(s2); py_strip(s2);
+        if (!reverse_complement_into(s2, rc2)) {
+            g_fastq_error = "KeyError: reverse_complement of a read with a character outside ACGTN_- (pair " + std::to_string(n) + ")";
+            return C2_E_INVALID;
+        }
+        r2.readline(skip);
+        r2.readline(q2); py_strip(q2);
+        key.assign(s1); key.push_back('+'); key.append(rc2);
+        quals.assign(q1); quals.push_back(' '); quals.append(q2.rbegin(), q2.rend());
+        ++n;
+        if (!visit(key, quals)) return C2_E_TOO_LARGE;
+        h1 = r1.readline(id1); h2 = r2.readline(id2);
+    }
+    if (r1.err || r2.err) { g_fastq_error = "read error in the paired FASTQ input"; return C2_E_INVALID; }
+    *n_pairs = n;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -541,6 +659,67 @@ int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, 
     }
     return 0;
 }
+
+// ---- paired input -----------------------------------------------------------------------------------------------------
+// First pass of process_paired_fastq's n_processes > 1 route (CRISPRessoCORE.py:1296-1334): variantCache[seq1 + '+' +
+// reverse_complement(seq2)] = [copies, qual1 + ' ' + qual2[::-1] of the FIRST occurrence], keys in first-seen order.
+int c2_fastq_unique_paired(const char* path1, const char* path2, c2_fastq** out) {
+    if (!path1 || !path2 || !out) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<c2_fastq> R(new c2_fastq);
+    Dedup D(R.get());
+    R->aux_offsets.push_back(0);
+    uint64_t n = 0;
+    const int rc = for_each_pair(path1, path2, &n, [&](const std::string& key, const std::string& quals) {
+        bool fresh = false;
+        if (!D.add((const uint8_t*)key.data(), key.size(), 1, &fresh)) return false;
+        if (fresh) {
+            R->aux.insert(R->aux.end(), quals.begin(), quals.end());
+            R->aux_offsets.push_back((uint64_t)R->aux.size());
+        }
+        return true;
+    });
+    if (rc == C2_E_TOO_LARGE) g_fastq_error = "more than 2^32 - 2 unique read pairs";
+    if (rc) return rc;
+    R->n_reads = n;
+    *out = R.release();
+    return 0;
+}
+
+// Second pass (CRISPRessoCORE.py:1452-1513): every occurrence, in file order, of the pairs whose key is selected
+// (selected[k] != 0 for key k of `uniq`): out->counts[j] = k, entry j of out's aux arena = that occurrence's own quality pair.
+// (out's sequence arena stays empty; the keys are in `uniq`.)
+int c2_fastq_paired_occurrences(const char* path1, const char* path2, const c2_fastq* uniq, const uint8_t* selected, c2_fastq** out) {
+    if (!path1 || !path2 || !uniq || !selected || !out) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    *out = nullptr;
+    c2_fastq T;                                               // a table over the keys of `uniq`
+    Dedup D(&T);
+    const uint64_t nu = (uint64_t)uniq->counts.size();
+    for (uint64_t k = 0; k < nu; ++k)
+        if (!D.add(uniq->arena.data() + uniq->offsets[k], (size_t)(uniq->offsets[k + 1] - uniq->offsets[k]))) { g_fastq_error = "too many keys"; return C2_E_TOO_LARGE; }
+    std::unique_ptr<c2_fastq> R(new c2_fastq);
+    R->offsets.push_back(0);
+    R->aux_offsets.push_back(0);
+    uint64_t n = 0;
+    const int rc = for_each_pair(path1, path2, &n, [&](const std::string& key, const std::string& quals) {
+        const int64_t k = D.find((const uint8_t*)key.data(), key.size());
+        if (k >= 0 && selected[k]) {
+            R->counts.push_back((uint32_t)k);
+            R->offsets.push_back(0);
+            R->aux.insert(R->aux.end(), quals.begin(), quals.end());
+            R->aux_offsets.push_back((uint64_t)R->aux.size());
+        }
+        return true;
+    });
+    if (rc) return rc;
+    R->n_reads = n;
+    *out = R.release();
+    return 0;
+}
+
+uint64_t c2_fastq_aux_bytes(const c2_fastq* r) { return r ? (uint64_t)r->aux.size() : 0; }
+const uint8_t* c2_fastq_aux(const c2_fastq* r) { return r ? r->aux.data() : nullptr; }
+const uint64_t* c2_fastq_aux_offsets(const c2_fastq* r) { return (r && !r->aux_offsets.empty()) ? r->aux_offsets.data() : nullptr; }
 
 uint64_t c2_fastq_n_unique(const c2_fastq* r) { return r ? (uint64_t)r->counts.size() : 0; }
 uint64_t c2_fastq_n_reads(const c2_fastq* r) { return r ? r->n_reads : 0; }

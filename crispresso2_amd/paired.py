@@ -217,3 +217,109 @@ def get_new_variant_objects_from_paired(args, pairs, refs, ref_names, aln_matrix
                 new_variant['variant_' + "Scaffold-incorporated"] = old_payload
         variants.append(new_variant)
     return variants
+
+
+def read_paired_fastq_unique(fastq1_filename, fastq2_filename):
+    """First pass of process_paired_fastq (CRISPRessoCORE.py:1296-1334) in the native library (c2_fastq_unique_paired):
+    -> (variantCache {seq1 + '+' + reverse_complement(seq2): [copies, qual1 + ' ' + qual2[::-1] of the first occurrence]},
+    the PairedFastq handle for the second pass)."""
+    pf = _native.PairedFastq(fastq1_filename, fastq2_filename)
+    return {k: [int(c), q] for k, c, q in zip(pf.keys, pf.counts, pf.quals)}, pf
+
+
+def _split_pair(key, quals):
+    fastq1_seq, fastq2_seq = key.split('+')                         # :1225-1226 (a '+' inside a read is a ValueError there too)
+    fastq1_qual, fastq2_qual = quals.split(' ')
+    return fastq1_seq, fastq2_seq, fastq1_qual, fastq2_qual
+
+
+def process_paired_fastq(fastq1_filename, fastq2_filename, args, refs, ref_names, aln_matrix, pe_scaffold_dna_info=None, ctx=None,
+                         variants_dir=None, rank=None, world=None, get_variants=None):
+    """process_paired_fastq, the n_processes > 1 route (CRISPRessoCORE.py:1296-1516), with GPU ranks as the workers:
+    unique pairs (native ingest) -> every rank computes the variants of its slice of the keys with the qualities of each
+    key's first occurrence (device alignments, consensus kernel, batched classifier) -> with `variants_dir`, the slices
+    travel as variants_<rank>.tsv in the reference's format and rank 0 merges them; keys seen more than once whose
+    consensus had to choose a base by quality (`caching_is_ok` false) are computed again for every occurrence with that
+    occurrence's own qualities; pair keys are replaced by the consensus read.
+    -> (variantCache, not_aligned_variants, aln_stats) on rank 0, None elsewhere."""
+    import os
+    from . import variant_io
+    from .distributed import shard_boundaries
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    get_variants = get_variants or get_new_variant_objects_from_paired
+    cache, pf = read_paired_fastq_unique(fastq1_filename, fastq2_filename)
+    keys = list(cache.keys())
+    if world > 1 and variants_dir is None:
+        raise ValueError("variants_dir is needed to exchange the variants of %d ranks" % world)
+    if len(keys) < world:
+        raise Exception("The number of unique sequences is less than the number of processes. Please reduce the number of processes.")
+    b = shard_boundaries(len(keys), world) if keys else [0] * (world + 1)
+    mine = keys[b[rank]:b[rank + 1]]
+    variants = get_variants(args, [_split_pair(k, cache[k][1]) for k in mine], refs, ref_names, aln_matrix, pe_scaffold_dna_info, ctx=ctx)
+    if variants_dir is not None:
+        variant_io.write_variant_file(variants_dir, rank, mine, variants)
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+        if rank != 0:
+            return None
+        computed = (kv for k in range(world) for kv in variant_io.read_variant_file(os.path.join(variants_dir, "variants_%d.tsv" % k)))
+    else:
+        computed = zip(mine, variants)
+    # ---- the parent's merge (:1382-1437)
+    st = variant_io.new_aln_stats()
+    expand = args.expand_ambiguous_alignments
+    re_aln, not_aln = {}, {}
+    for seq, variant in computed:
+        if cache[seq][0] > 1 and not variant["caching_is_ok"]:
+            re_aln[seq] = variant
+            del cache[seq]
+            continue
+        count = cache[seq][0]
+        st['N_TOT_READS'] += count
+        variant['count'] = count
+        if variant['best_match_score'] <= 0:
+            st['N_COMPUTED_NOTALN'] += 1
+            st['N_CACHED_NOTALN'] += count - 1
+            not_aln[seq] = variant
+        else:
+            cache[seq] = variant
+            st['N_COMPUTED_ALN'] += 1
+            st['N_CACHED_ALN'] += count - 1
+            if len(variant['aln_ref_names']) == 1 or expand:
+                variant_io.account_variant(st, variant, count, variant['aln_ref_names'])
+    for seq in not_aln:
+        del cache[seq]
+    for key in list(cache.keys()):                                  # pair key -> consensus read (:1439-1448)
+        if '+' in key:
+            variant = cache.pop(key)
+            new_key = variant["variant_" + variant['aln_ref_names'][0]]['aln_seq']
+            if new_key in cache:
+                cache[new_key]['count'] += variant['count']
+            else:
+                cache[new_key] = variant
+    if re_aln:                                                      # second pass over the files (:1450-1513)
+        index_of = {k: i for i, k in enumerate(keys)}
+        selected = np.zeros(len(keys), dtype=np.uint8)
+        for k in re_aln:
+            selected[index_of[k]] = 1
+        idx, quals = pf.occurrences(selected)
+        again = get_variants(args, [_split_pair(keys[int(i)], q) for i, q in zip(idx, quals)], refs, ref_names, aln_matrix,
+                             pe_scaffold_dna_info, ctx=ctx)
+        for variant in again:
+            st['N_TOT_READS'] += 1
+            if variant['best_match_score'] <= 0:
+                st['N_COMPUTED_NOTALN'] += 1
+                continue
+            st['N_COMPUTED_ALN'] += 1
+            aln_seq = variant["variant_" + variant['aln_ref_names'][0]]['aln_seq']
+            if aln_seq in cache:
+                cache[aln_seq]['count'] += 1
+            else:
+                cache[aln_seq] = variant
+            if len(variant['aln_ref_names']) == 1 or expand:
+                variant_io.account_variant(st, variant, 1, variant['aln_ref_names'])
+    pf.close()
+    return cache, not_aln, st

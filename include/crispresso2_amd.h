@@ -266,6 +266,17 @@ const uint64_t* c2_fastq_offsets(const c2_fastq* r);
 const uint32_t* c2_fastq_counts(const c2_fastq* r);
 void c2_fastq_free(c2_fastq* r);
 const char* c2_fastq_last_error(void);
+/* Paired input: the first pass of process_paired_fastq's n_processes > 1 route, CRISPRessoCORE.py:1296-1334 -- the two
+ * files read in lockstep, key = seq1 + '+' + reverse_complement(seq2) (both str.strip()'ed; CRISPRessoShared.py:399-403's
+ * reverse complement: a character outside ACGTN_- fails like its KeyError), counted per distinct key in first-seen order;
+ * the aux arena holds, per key, the quality pair qual1 + ' ' + qual2[::-1] of its FIRST occurrence.
+ * c2_fastq_paired_occurrences is the second pass of that route (:1452-1513): every occurrence, in file order, of the keys
+ * with selected[k] != 0 -- out's counts[j] = k and aux entry j = the occurrence's own quality pair. */
+int c2_fastq_unique_paired(const char* path1, const char* path2, c2_fastq** out);
+int c2_fastq_paired_occurrences(const char* path1, const char* path2, const c2_fastq* uniq, const uint8_t* selected, c2_fastq** out);
+uint64_t c2_fastq_aux_bytes(const c2_fastq* r);
+const uint8_t* c2_fastq_aux(const c2_fastq* r);
+const uint64_t* c2_fastq_aux_offsets(const c2_fastq* r);
 /* Host-side bookkeeping between ingest and kernels, over the same arena/offsets layout (errors: c2_fastq_last_error()):
  * the seed test that picks the strand(s) a read is aligned on (CRISPRessoCORE.py:656-687) -> out_plan[n] in {0 forward,
  * 1 reverse complement, 2 both}, and the reverse-complement merge of read counts (CRISPRessoCORE.py:3970-3975), in place. */

@@ -661,3 +661,114 @@ if __name__ == "__main__" and "--variant-io" in sys.argv:
     with gzip.open(os.path.join(HERE, "variant_io.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("variant_io.json.gz written:", [(c["label"], len(c["tsv"]), c["single"]["aln_stats"]["N_TOT_READS"]) for c in d["cases"]])
+
+
+# ---------------------------------------------------------------- 9. paired FASTQ files through process_paired_fastq (-p 2), CRISPRessoCORE.py:1245-1733
+def paired_fastq_goldens():
+    """Two FASTQ files of read pairs cut from the FANC reads (exact duplicates, duplicates with other qualities -- the case
+    the reference re-aligns per occurrence --, pairs from the other strand, unrelated pairs) through the reference's
+    process_paired_fastq with two worker processes: its variants_<k>.tsv files, the calls its parent makes to
+    get_new_variant_object_from_paired in the second pass, and the final variantCache / statistics."""
+    from crispresso2_amd import refs as RF
+    core = load_reference_core()
+    Shared = sys.modules["CRISPResso2.CRISPRessoShared"]
+    with open(os.path.join(REF, "tests/Cas9.amplicons.txt")) as fh:
+        for line in fh:
+            f = line.split()
+            if f and f[0] == "FANC":
+                fanc = f[1].upper()
+    hdr = fanc[:88] + "GATTACA" + fanc[95:]
+    seqs = []
+    with open(os.path.join(REF, "tests/FANC.Cas9.fastq")) as fh:
+        lines = fh.read().split("\n")
+    for k in range(1, len(lines), 4):
+        if lines[k] and lines[k] not in seqs and set(lines[k]) <= set("ACGTN"):
+            seqs.append(lines[k])
+    rng = np.random.default_rng(41)
+    q = lambda m: "".join(chr(int(x)) for x in rng.integers(35, 75, m))
+
+    def make_pair(s):
+        n = len(s)
+        a = int(rng.integers(n // 2, n - 10))
+        b = int(rng.integers(5, max(6, a - 20)))                      # always an overlap
+        r1, r2 = list(s[:a]), list(s[b:])
+        for _ in range(int(rng.integers(0, 3))):                      # disagreements inside the overlap: chosen by quality
+            p = int(rng.integers(0, max(1, a - b)))
+            r2[p] = "ACGT"[int(rng.integers(0, 4))]
+        return "".join(r1), "".join(r2), q(len(r1)), q(len(r2))
+
+    recs = []
+    for k in range(120):
+        r1, r2, q1, q2 = make_pair(seqs[k % len(seqs)])
+        if k % 5 == 1:
+            r1, r2 = RF.reverse_complement(r1), RF.reverse_complement(r2)
+        if k % 17 == 3:
+            r1, q1 = "".join(rng.choice(list("ACGT"), 110)), "I" * 110
+            r2, q2 = "".join(rng.choice(list("ACGT"), 90)), "I" * 90
+        recs.append((r1, r2, q1, q2))
+        if k % 3 == 0:
+            recs.append((r1, r2, q1, q2))                             # exact copy
+        if k % 4 == 0:
+            recs.append((r1, r2, q(len(r1)), q(len(r2))))             # same reads, other qualities
+        if k % 8 == 0:
+            recs.append((r1, r2, q(len(r1)), q(len(r2))))
+    order = rng.permutation(len(recs))
+    recs = [recs[int(i)] for i in order]
+    # file 2 holds read 2 as sequenced: the reverse complement of its amplicon-orientation form, qualities reversed
+    fq1 = "".join("@p%d/1\n%s\n+\n%s\n" % (k, r[0], r[2]) for k, r in enumerate(recs))
+    fq2 = "".join("@p%d/2\n%s\n+\n%s\n" % (k, RF.reverse_complement(r[1]), r[3][::-1]) for k, r in enumerate(recs))
+    out = {"fastq1": fq1, "fastq2": fq2, "cases": []}
+    for label, ref_specs, flags in (("FANC", [("FANC", fanc)], {}),
+                                    ("FANC+HDR expand", [("FANC", fanc), ("HDR", hdr)], {"expand_ambiguous_alignments": True})):
+        base = dict(aln_seed_count=5, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                    use_legacy_insertion_quantification=False, ignore_deletions=False, ignore_insertions=False,
+                    ignore_substitutions=False, assign_ambiguous_alignments_to_first_reference=False,
+                    expand_ambiguous_alignments=False, prime_editing_pegRNA_scaffold_seq="", prime_editing_pegRNA_extension_seq="",
+                    needleman_wunsch_aln_matrix_loc="EDNAFULL", debug=False, fastq_output=False, crispresso_merge=True)
+        base.update(flags)
+        refs, names = {}, []
+        for nm, sq in ref_specs:
+            refs[nm] = RF.make_ref(nm, sq, [91], [91, 92], min_aln_score=60)
+            names.append(nm)
+        case = {"label": label, "args": dict(base),
+                "refs": [{"name": nm, "sequence": refs[nm]["sequence"], "cut_points": [91], "include_idxs": [91, 92],
+                          "min_aln_score": 60} for nm in names]}
+        with tempfile.TemporaryDirectory() as tmp:
+            p1, p2 = os.path.join(tmp, "r1.fastq"), os.path.join(tmp, "r2.fastq")
+            with open(p1, "w") as fh:
+                fh.write(fq1)
+            with open(p2, "w") as fh:
+                fh.write(fq2)
+            args = types.SimpleNamespace(n_processes="2", **base)
+            second_pass = []
+            orig = core.get_new_variant_object_from_paired
+
+            def proxy(a, s1, s2, q1, q2, *rest):
+                v = orig(a, s1, s2, q1, q2, *rest)
+                second_pass.append([s1, s2, q1, q2, json.dumps(v, cls=Shared.CRISPRessoJSONEncoder)])
+                return v
+            core.get_new_variant_object_from_paired = proxy
+            try:
+                cache, to_remove = {}, []
+                st, not_aln = core.process_paired_fastq(p1, p2, cache, names, refs, args, to_remove, tmp)
+            finally:
+                core.get_new_variant_object_from_paired = orig
+            tsv = []
+            for p in to_remove:
+                with open(p) as fh:
+                    tsv.append(fh.read())
+            case["tsv"] = tsv
+            case["second_pass"] = second_pass
+            case["result"] = {"aln_stats": jsonable(st), "not_aligned": list(not_aln.keys()), "aligned": list(cache.keys()),
+                              "counts": [cache[k]["count"] for k in cache],
+                              "variants": [json.dumps(cache[k], cls=Shared.CRISPRessoJSONEncoder) for k in cache]}
+        out["cases"].append(case)
+    return out
+
+
+if __name__ == "__main__" and "--paired-fastq" in sys.argv:
+    import gzip
+    d = paired_fastq_goldens()
+    with gzip.open(os.path.join(HERE, "paired_fastq.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("paired_fastq.json.gz written:", [(c["label"], len(c["tsv"]), len(c["second_pass"]), c["result"]["aln_stats"]) for c in d["cases"]])

@@ -211,3 +211,95 @@ def test_native_reverse_complement_merge_equals_the_aggregation_loop(n_base):
     for k, r in enumerate(reads):
         assert got[k] == (cache[r] if aligned[k] else counts[k]), r
     assert got[reads.index("ACGT")] in (0, 2 * counts[reads.index("ACGT")]) or not aligned[reads.index("ACGT")]
+
+
+# ---- paired input: c2_fastq_unique_paired / c2_fastq_paired_occurrences vs the reference's lockstep loop -------------
+
+def check_paired(p1, p2):
+    from crispresso2_amd import _native
+    exp, n = ofq.read_paired_fastq_unique(str(p1), str(p2))
+    pf = _native.PairedFastq(str(p1), str(p2))
+    assert pf.n_pairs == n
+    assert pf.keys == list(exp.keys())
+    assert [int(c) for c in pf.counts] == [v[0] for v in exp.values()]
+    assert pf.quals == [v[1] for v in exp.values()]
+    # second pass: every occurrence of the keys seen more than once
+    sel = pf.counts > 1
+    idx, quals = pf.occurrences(sel)
+    wanted = {k for k, v in exp.items() if v[0] > 1}
+    occ = ofq.paired_occurrences(str(p1), str(p2), wanted)
+    assert [pf.keys[int(i)] for i in idx] == [o[0] for o in occ]
+    assert quals == [o[1] + ' ' + o[2] for o in occ]
+    pf.close()
+    return pf
+
+
+def paired_records(pairs, nl="\n"):
+    r1 = "".join("@p%d/1%s%s%s+%s%s%s" % (k, nl, p[0], nl, nl, p[2], nl) for k, p in enumerate(pairs))
+    r2 = "".join("@p%d/2%s%s%s+%s%s%s" % (k, nl, p[1], nl, nl, p[3], nl) for k, p in enumerate(pairs))
+    return r1, r2
+
+
+def random_pairs(n, rng, pool=60):
+    base = []
+    for _ in range(pool):
+        a, b = int(rng.integers(30, 150)), int(rng.integers(30, 150))
+        base.append(("".join(rng.choice(list("ACGTN"), a)), "".join(rng.choice(list("ACGTNacgt"), b))))
+    out = []
+    for _ in range(n):
+        s1, s2 = base[int(rng.integers(0, pool))]
+        q = lambda m: "".join(chr(int(x)) for x in rng.integers(33, 74, m))
+        out.append((s1, s2, q(len(s1)), q(len(s2))))
+    return out
+
+
+def test_paired_plain_gzip_crlf(tmp_path):
+    rng = np.random.default_rng(21)
+    pairs = random_pairs(3000, rng)
+    for tag, nl in (("lf", "\n"), ("crlf", "\r\n"), ("cr", "\r")):
+        t1, t2 = paired_records(pairs, nl)
+        p1, p2 = tmp_path / (tag + "_1.fastq"), tmp_path / (tag + "_2.fastq")
+        p1.write_bytes(t1.encode())
+        p2.write_bytes(t2.encode())
+        pf = check_paired(p1, p2)
+        assert len(pf.keys) <= 60 and pf.n_pairs == 3000
+    t1, t2 = paired_records(pairs)
+    g1, g2 = tmp_path / "a_1.fastq.gz", tmp_path / "a_2.fastq.gz"
+    with gzip.open(g1, "wt") as fh:
+        fh.write(t1)
+    with gzip.open(g2, "wt") as fh:
+        fh.write(t2)
+    check_paired(g1, g2)
+    check_paired(g1, tmp_path / "lf_2.fastq")                       # one gzip'ed, one plain
+
+
+def test_paired_unequal_lengths_whitespace_and_truncation(tmp_path):
+    rng = np.random.default_rng(22)
+    pairs = random_pairs(200, rng, pool=15)
+    t1, t2 = paired_records(pairs)
+    p1, p2 = tmp_path / "x_1.fastq", tmp_path / "x_2.fastq"
+    # file 2 shorter: the loop stops with the shorter file
+    p1.write_text(t1)
+    p2.write_text("".join(t2.splitlines(keepends=True)[:4 * 150]))
+    assert check_paired(p1, p2).n_pairs == 150
+    # file 2 cut in the middle of a record (no quality line, no terminator): '' qualities, the record still counts
+    p2.write_text("".join(t2.splitlines(keepends=True)[:4 * 150 + 2]).rstrip("\n"))
+    assert check_paired(p1, p2).n_pairs == 151
+    # whitespace around sequences / qualities, blank id lines ('\n' is a true value), empty files
+    p1.write_text("@a\n  ACGT \t\n+\n IIII \n\n\x0bGGCC\x0c\n+\nJJJJ\n")
+    p2.write_text("@a\n\tTTGA\n+\nABCD  \n\ncctt \n+\n EFGH\n")
+    pf = check_paired(p1, p2)
+    assert pf.keys == ["ACGT+TCAA", "GGCC+AAGG"] and pf.quals == ["IIII DCBA", "JJJJ HGFE"]
+    p1.write_text("")
+    assert check_paired(p1, p2).n_pairs == 0
+
+
+def test_paired_bad_base_is_a_key_error(tmp_path):
+    from crispresso2_amd import _native
+    p1, p2 = tmp_path / "k_1.fastq", tmp_path / "k_2.fastq"
+    p1.write_text("@a\nACGT\n+\nIIII\n")
+    p2.write_text("@a\nACRT\n+\nIIII\n")                             # R: not in the reference's complement table
+    with pytest.raises(KeyError):
+        ofq.read_paired_fastq_unique(str(p1), str(p2))
+    with pytest.raises(KeyError):
+        _native.PairedFastq(str(p1), str(p2))

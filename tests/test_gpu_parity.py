@@ -758,3 +758,37 @@ def test_variant_files_and_annotated_fastq_equal_the_reference_text(mats, ctx, t
             assert (d / ("variants_%d.tsv" % k)).read_text() == case["tsv"][k]
         assert st == case["multi"]["aln_stats"]
         assert list(not_aligned) == case["multi"]["not_aligned"] and list(cache) == case["multi"]["aligned"]
+
+
+def test_paired_fastq_files_equal_the_reference_run(mats, ctx, tmp_path):
+    """process_paired_fastq on the device: two FASTQ files -> native paired ingest -> alignments, consensus kernel and
+    classifier on the GPU -> the reference's variants_<k>.tsv files byte for byte, its per-occurrence second pass, final
+    variantCache (keys, order, counts, every dict as JSON text) and statistics (make_golden.py --paired-fastq)."""
+    import json
+    import types
+    from crispresso2_amd import refs as RF, paired as P, variant_io as IO
+    gold = load_golden("paired_fastq.json.gz")
+    p1, p2 = tmp_path / "r1.fastq", tmp_path / "r2.fastq"
+    p1.write_text(gold["fastq1"])
+    p2.write_text(gold["fastq2"])
+    for case in gold["cases"]:
+        args = types.SimpleNamespace(**case["args"])
+        refs, names = {}, []
+        for r in case["refs"]:
+            refs[r["name"]] = RF.make_ref(r["name"], r["sequence"], r["cut_points"], r["include_idxs"], r["min_aln_score"])
+            names.append(r["name"])
+        d = tmp_path / ("v_" + case["label"].replace(" ", "_").replace("+", "_"))
+        d.mkdir()
+        assert P.process_paired_fastq(str(p1), str(p2), args, refs, names, mats["EDNAFULL"], ctx=ctx, variants_dir=str(d), rank=1, world=2) is None
+        cache, not_aln, st = P.process_paired_fastq(str(p1), str(p2), args, refs, names, mats["EDNAFULL"], ctx=ctx, variants_dir=str(d),
+                                                    rank=0, world=2)
+        for k in range(2):
+            assert (d / ("variants_%d.tsv" % k)).read_text() == case["tsv"][k]
+        exp = case["result"]
+        assert st == exp["aln_stats"]
+        assert list(not_aln) == exp["not_aligned"] and list(cache) == exp["aligned"]
+        assert [cache[k]["count"] for k in cache] == exp["counts"]
+        assert [json.dumps(cache[k], cls=IO.CRISPRessoJSONEncoder) for k in cache] == exp["variants"]
+        # one process, nothing on disk: same result
+        cache1, not_aln1, st1 = P.process_paired_fastq(str(p1), str(p2), args, refs, names, mats["EDNAFULL"], ctx=ctx)
+        assert st1 == st and list(cache1) == list(cache) and [cache1[k]["count"] for k in cache1] == exp["counts"]
