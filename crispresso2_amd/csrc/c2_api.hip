@@ -997,14 +997,14 @@ int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4) {
     return 0;
 }
 
-int c2_selftest(c2_ctx* ctx, int32_t* out320) {
-    if (!ctx || !out320) return C2_E_INVALID;
+int c2_selftest(c2_ctx* ctx, int32_t* out448) {
+    if (!ctx || !out448) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->d_misc, 320 * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_misc, 448 * 4))) return rc;
     hipLaunchKernelGGL(c2_selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)ctx->d_misc.p);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(out320, ctx->d_misc.p, 320 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out448, ctx->d_misc.p, 448 * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

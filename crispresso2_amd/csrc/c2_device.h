@@ -13,7 +13,8 @@
 #define C2_INVALID_CODE 255
 #define C2_PTR_PAD 2               // halfword padding of one pointer column (breaks the 128-B bank stride)
 #define C2_LANES 64
-#define C2_DIAG_NEG (-(1 << 30))     // diagonal-band kernels: value of everything outside the band
+#define C2_DIAG_NEG (-(1 << 30))     // diagonal-band kernels: "no score yet" of the certificate's H(Li, Lj)
+#define C2_DIAG_BIAS (1 << 30)       // diagonal-band kernels: added to every DP value, so that a cell outside the band reads as 0
 #define C2_DIAG_STORE_LO 16          // diagonal-band kernel: lanes STORE_LO .. STORE_LO+STORE_N-1 (the inner 64 of the 128
 #define C2_DIAG_STORE_N 32           //   diagonals) keep their pointer words; a traceback that leaves them is redone by the row-strip kernel
 #define C2_DIAG_ROW_PAD 128          // zero row records in front of row 0 and behind row Li+1 of every reference's table

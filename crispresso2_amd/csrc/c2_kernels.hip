@@ -760,7 +760,7 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
 // Diagonal-band kernel.  Lanes own DIAGONALS instead of rows: lane l owns d = d0 + 2l ("E") and d0 + 2l + 1 ("O"), 128
 // diagonals around the one that joins (0,0) and (Li,Lj); the sweep runs over anti-diagonals a = i + j, one cell per lane
 // per step (E cells at even a, O cells at odd a), 499 steps x 1 cell instead of 313 steps x 4 cells for 250 x 250.
-// Cells outside the band are never computed (they read as C2_DIAG_NEG), which is exact iff no optimal path leaves the
+// Cells outside the band are never computed (they read as -2^30: the number 0 under C2_DIAG_BIAS), which is exact iff no optimal path leaves the
 // band.  That is PROVEN per alignment after the fill: a path that touches diagonal d outside [0, D] (D = Li - Lj) takes
 // at least |d| + |d - D| gap steps and at most min(Li, Lj) - (steps off the [0,D] corridor) match steps, so it scores at
 // most U = maxS * (len - off) + cb * (gap steps), cb = max(go, ge) + max(0, max g) < 0 the most a gap base can add.  If the
@@ -777,6 +777,18 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
 __device__ __forceinline__ int c2_shl1(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, C2_DPP_WAVE_SHL1, 0xf, 0xf, false);
 }
+// The diagonal kernels keep every DP value with C2_DIAG_BIAS added, so that "outside the band" is the number 0 -- which is
+// what a DPP read with bound_ctrl set returns for a lane without a source (wavefront end, or a source lane switched off in
+// EXEC).  A bound_ctrl move with old = 0 folds into the VALU instruction that consumes it (v_add_u32_dpp): the hand-off
+// between neighbouring diagonals then costs no instruction of its own.  All recurrences add constants to DP values and
+// compare sums of that form, so the bias changes no comparison (values stay within [-2^20, 2^30 + 2^20]).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C2_KEEP_IN_VGPR(x) asm volatile("" : "+v"(x))
+#else
+#define C2_KEEP_IN_VGPR(x) (void)(x)
+#endif
+__device__ __forceinline__ int c2_shr1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_WAVE_SHR1, 0xf, 0xf, true); }
+__device__ __forceinline__ int c2_shl1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_WAVE_SHL1, 0xf, 0xf, true); }
 
 struct c2_diag_plan { uint32_t plane, codes, codeof, read, code, ref, incp, tmp_read, tmp_ref, total; uint32_t n_words; };
 
@@ -811,10 +823,8 @@ struct c2_diag_plane {
 struct c2_diag_state {
     int ME, IE, JE, HE;              // latest cell of the even diagonal
     int MO, IO, JO, HO;              // latest cell of the odd diagonal
-    int upM, upJ;                    // hand-off registers for wave_shr (lane 0 stays C2_DIAG_NEG: outside the band)
-    int lfM, lfI;                    // hand-off registers for wave_shl (lane 63 stays C2_DIAG_NEG)
     unsigned bits;
-};
+};                                   // (all values carry C2_DIAG_BIAS; a neighbour outside the band reads as 0)
 
 // One pair of steps: the E cell on anti-diagonal a = 2k, then the O cell on a + 1.  rowE: constants of the E cell's row,
 // rowO: of the O cell's row (= E row + 1); cj4: 4 * code of their common column.
@@ -824,16 +834,17 @@ template <bool MASK, bool LASTCOL>
 __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, const c2_diag_row rowE, const c2_diag_row rowO,
                                              const int cj4, const int ge, const int startE, const int startO, const bool lastcol)
 {
-    // ---- even step: E cell.  left (i, j-1) is this lane's O cell, up (i-1, j) is the O cell of the lane below (wave_shr)
-    S.upM = c2_shr1(S.upM, S.MO);
-    S.upJ = c2_shr1(S.upJ, S.JO);
+    // ---- even step: E cell.  left (i, j-1) is this lane's O cell, up (i-1, j) is the O cell of the lane below (wave_shr).
+    //      `ge` is a VGPR here: a DPP instruction cannot take an SGPR as its second source.
+    const int upM = c2_shr1z(S.MO);
+    const int upJ = c2_shr1z(S.JO);
     if (!MASK || a >= startE) {
         const int corr = (LASTCOL && lastcol) ? rowE.b - rowE.a : 0;
         const int s = c2_sbfe4((int)rowE.prof, cj4);
         const int iFromM = S.MO + rowE.a + corr;
         const int iExt = S.IO + rowE.b;
-        const int jFromM = S.upM + rowE.c + corr;
-        const int jExt = S.upJ + ge;
+        const int jFromM = upM + rowE.c + corr;
+        const int jExt = upJ + ge;
         const int In = c2_imax(iFromM, iExt);
         const int Jn = c2_imax(jFromM, jExt);
         const int Mn = S.HE + s;                             // H(i-1, j-1): this diagonal, two steps ago
@@ -844,13 +855,13 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
         S.bits <<= 4;
     }
     // ---- odd step: O cell.  left (i, j-1) is the E cell of the lane above (wave_shl), up (i-1, j) is this lane's E cell
-    S.lfM = c2_shl1(S.lfM, S.ME);
-    S.lfI = c2_shl1(S.lfI, S.IE);
+    const int lfM = c2_shl1z(S.ME);
+    const int lfI = c2_shl1z(S.IE);
     if (!MASK || a + 1 >= startO) {
         const int corr = (LASTCOL && lastcol) ? rowO.b - rowO.a : 0;
         const int s = c2_sbfe4((int)rowO.prof, cj4);
-        const int iFromM = S.lfM + rowO.a + corr;
-        const int iExt = S.lfI + rowO.b;
+        const int iFromM = lfM + rowO.a + corr;
+        const int iExt = lfI + rowO.b;
         const int jFromM = S.ME + rowO.c + corr;
         const int jExt = S.JE + ge;
         const int In = c2_imax(iFromM, iExt);
@@ -870,8 +881,8 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
 // more than a few diagonals either side of the corner-to-corner one -- so the wavefront is cut into NA lane groups of
 // LPA = 64 / NA lanes, each sweeping its own alignment with a band of 2 * (LPA - 1) diagonals, all with the same
 // instruction stream (per-lane table bases and clamps instead of wave-uniform ones).  The last lane of every group is
-// switched off in EXEC for the whole fill: a DPP move whose source lane is disabled leaves its destination alone, so the
-// first lane of the next group (wave_shr) and the last live lane of this group (wave_shl) keep C2_DIAG_NEG, exactly
+// switched off in EXEC for the whole fill: a DPP read (bound_ctrl set) whose source lane is disabled returns 0, so the
+// first lane of the next group (wave_shr) and the last live lane of this group (wave_shl) see "outside the band", exactly
 // what the lanes at the two ends of the wavefront see.  Isolation costs no instruction.
 // A band this narrow fails the optimality certificate more often; those tasks go to the fallback list and the host
 // chains the launches NA = 4 -> NA = 2 -> c2_align_diag_kernel (128 diagonals) -> row-strip kernel (any path), each over
@@ -928,14 +939,17 @@ struct c2_diagx_lane {
     int startE, startO;              // first interior anti-diagonal of the two diagonals
 };
 
-// rows and column symbols of group g (pairs 4g .. 4g+3): five row records (the O cell of the last pair needs row + 1) and four symbols
+// rows and column symbols of group g (pairs 4g .. 4g+3): five row records (the O cell of the last pair needs row + 1) and four symbols.
+// FIRST = false: record 0 is the caller's business -- it is record 4 of group g - 1 (also when the v_min below clamps either
+// group's address: every record from the clamp on is zero padding), so a group costs four 16-byte loads, not five.
+template <bool FIRST>
 __device__ __forceinline__ void c2_diagx_fetch(const int g, const c2_diagx_lane& L, const c2_diag_row* rows, const unsigned char* lds,
                                                c2_diag_row (&R)[5], int (&C)[4])
 {
     const unsigned ro = min(L.rowOff + (unsigned)(g * 4 * (int)sizeof(c2_diag_row)), L.rowMax);
     const c2_diag_row* rp = (const c2_diag_row*)((const unsigned char*)rows + ro);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) R[q] = rp[q];
+    for (int q = FIRST ? 0 : 1; q < 5; ++q) R[q] = rp[q];
     const unsigned co = min(L.colOff + (unsigned)(g * 4), L.colMax);
 #pragma unroll
     for (int q = 0; q < 4; ++q) C[q] = (int)lds[co + q];
@@ -948,12 +962,13 @@ __device__ __forceinline__ void c2_diagx_group(c2_diag_state& S, const int g, co
                                                const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride,
                                                const bool stores = true)
 {
-    c2_diagx_fetch(g + 1, L, rows, lds, RN, CN);
+    RN[0] = R[4];
+    c2_diagx_fetch<false>(g + 1, L, rows, lds, RN, CN);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int k = 4 * g + q;
         c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, L.startE, L.startO, LASTCOL && (k == L.kLast));
-        if (LASTCOL && k == L.kCap) Hcap = L.capOdd ? S.HO : S.HE;
+        if (LASTCOL && k == L.kCap) Hcap = (L.capOdd ? S.HO : S.HE) - C2_DIAG_BIAS;
     }
     if (stores) myWords[g * wordStride] = S.bits;                    // anti-diagonals 8g .. 8g+7
 }
@@ -1036,19 +1051,19 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
             const int dE = 2 * hE, dO = dE + 1;
             c2_diag_state S;
             S.bits = 0;
-            S.upM = C2_DIAG_NEG; S.upJ = C2_DIAG_NEG; S.lfM = C2_DIAG_NEG; S.lfI = C2_DIAG_NEG;
             // diagonal d >= 1 starts at cell (d, 0): M = I = min_score, J = ge*d + g0;  d <= -1 at (0, -d): M = J = min_score,
-            // I = ge*(-d) + g0;  d == 0 at (0, 0): M = 0, I = J = min_score.  H = max of the three.
+            // I = ge*(-d) + g0;  d == 0 at (0, 0): M = 0, I = J = min_score.  H = max of the three.  (+ C2_DIAG_BIAS)
             {
-                const int bE = (dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + g0;
-                S.ME = (dE == 0) ? 0 : min_score;
-                S.IE = (dE < 0) ? bE : min_score;
-                S.JE = (dE > 0) ? bE : min_score;
+                const int ms = min_score + C2_DIAG_BIAS;
+                const int bE = ((dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + g0) + C2_DIAG_BIAS;
+                S.ME = (dE == 0) ? C2_DIAG_BIAS : ms;
+                S.IE = (dE < 0) ? bE : ms;
+                S.JE = (dE > 0) ? bE : ms;
                 S.HE = c2_imax(c2_imax(S.ME, S.IE), S.JE);
-                const int bO = ge * (dO > 0 ? dO : -dO) + g0;   // dO is odd, never 0
-                S.MO = min_score;
-                S.IO = (dO < 0) ? bO : min_score;
-                S.JO = (dO > 0) ? bO : min_score;
+                const int bO = ge * (dO > 0 ? dO : -dO) + g0 + C2_DIAG_BIAS;   // dO is odd, never 0
+                S.MO = ms;
+                S.IO = (dO < 0) ? bO : ms;
+                S.JO = (dO > 0) ? bO : ms;
                 S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
             }
             const int startE = (dE > 0 ? dE : -dE) + 2, startO = (dO > 0 ? dO : -dO) + 2;   // first interior anti-diagonal
@@ -1072,17 +1087,19 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
             const c2_diag_row* rows = A.diag_base;
             c2_diag_row RA[5], RB[5];
             int CA[4], CB[4];
-            c2_diagx_fetch(0, L, rows, c2_smem, RA, CA);
+            c2_diagx_fetch<true>(0, L, rows, c2_smem, RA, CA);
             int Hcap = C2_DIAG_NEG;
             int g = 0;
             const int gA_stop = gA < g_end ? gA : g_end;
+            int geV = ge;                                          // gap_extend in a VGPR (second source of a DPP add)
+            C2_KEEP_IN_VGPR(geV);
             if (gC <= gA_stop) {
-                c2_diagx_groups<true, true>(S, g, gA_stop, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
             } else {
-                c2_diagx_groups<true, false>(S, g, gA_stop, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
-                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
             }
-            c2_diagx_groups<false, true>(S, g, g_end, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
             __syncthreads();
             c2_phase_mark<1>(A.phase_cycles, PH);
 
@@ -1298,17 +1315,17 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             const int dE = 2 * hE, dO = dE + 1;
             c2_diag_state S;
             S.bits = 0;
-            S.upM = C2_DIAG_NEG; S.upJ = C2_DIAG_NEG; S.lfM = C2_DIAG_NEG; S.lfI = C2_DIAG_NEG;
             {
-                const int bE = (dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + vg0;
-                S.ME = (dE == 0) ? 0 : vmin;
-                S.IE = (dE < 0) ? bE : vmin;
-                S.JE = (dE > 0) ? bE : vmin;
+                const int ms = vmin + C2_DIAG_BIAS;
+                const int bE = ((dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + vg0) + C2_DIAG_BIAS;
+                S.ME = (dE == 0) ? C2_DIAG_BIAS : ms;
+                S.IE = (dE < 0) ? bE : ms;
+                S.JE = (dE > 0) ? bE : ms;
                 S.HE = c2_imax(c2_imax(S.ME, S.IE), S.JE);
-                const int bO = ge * (dO > 0 ? dO : -dO) + vg0;   // dO is odd, never 0
-                S.MO = vmin;
-                S.IO = (dO < 0) ? bO : vmin;
-                S.JO = (dO > 0) ? bO : vmin;
+                const int bO = ge * (dO > 0 ? dO : -dO) + vg0 + C2_DIAG_BIAS;   // dO is odd, never 0
+                S.MO = ms;
+                S.IO = (dO < 0) ? bO : ms;
+                S.JO = (dO > 0) ? bO : ms;
                 S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
             }
             c2_diagx_lane L;
@@ -1322,17 +1339,19 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             const c2_diag_row* rows = A.diag_base;
             c2_diag_row RA[5], RB[5];
             int CA[4], CB[4];
-            c2_diagx_fetch(0, L, rows, c2_smem, RA, CA);
+            c2_diagx_fetch<true>(0, L, rows, c2_smem, RA, CA);
             unsigned* myWords = gWords + slot * slotWords + sl;
             int g = 0;
             const int gA_stop = gA < g_end ? gA : g_end;
+            int geV = ge;                                          // gap_extend in a VGPR (second source of a DPP add)
+            C2_KEEP_IN_VGPR(geV);
             if (gC <= gA_stop) {
-                c2_diagx_groups<true, true>(S, g, gA_stop, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             } else {
-                c2_diagx_groups<true, false>(S, g, gA_stop, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
-                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             }
-            c2_diagx_groups<false, true>(S, g, g_end, L, ge, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             C2_LANES_ACTIVE_END()
         }
         __syncthreads();                                           // (waits for the plane stores)
@@ -1699,6 +1718,17 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
     C2_LANES_ACTIVE_END()
     out[192 + lane] = r;
     out[256 + lane] = l;
+    // the form the diagonal kernels use: bound_ctrl set, folded into an add (v_add_u32_dpp) -- a lane without a source
+    // (wavefront end, or source switched off in EXEC) must read 0.  expect 1000 in lanes 0 and 32 (shr) / 63 and 30 (shl)
+    int rz = -99, lz = -99;
+    int k1000 = 1000;
+    C2_KEEP_IN_VGPR(k1000);
+    C2_LANES_ACTIVE_BEGIN(lane != 31)
+        rz = c2_shr1z(lane * 3 + 1) + k1000;
+        lz = c2_shl1z(lane * 3 + 1) + k1000;
+    C2_LANES_ACTIVE_END()
+    out[320 + lane] = rz;
+    out[384 + lane] = lz;
 }
 
 // =====================================================================================

@@ -284,9 +284,10 @@ int c2_strand_plan(const uint8_t* arena, const uint64_t* offsets, uint64_t n, co
                    int32_t n_seeds, int32_t seed_min, uint8_t* out_plan);
 int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const uint8_t* aligned, int64_t* counts);
 
-/* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1, also with a lane switched off in EXEC,
- * readlane, ballot) the DP depends on; writes 320 int32 (see c2_selftest_kernel).  Used by the GPU test-suite. */
-int c2_selftest(c2_ctx* ctx, int32_t* out320);
+/* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1 with and without bound_ctrl, also with a
+ * lane switched off in EXEC, readlane, ballot) the DP depends on; writes 448 int32 (see c2_selftest_kernel).  Used by the
+ * GPU test-suite. */
+int c2_selftest(c2_ctx* ctx, int32_t* out448);
 
 #ifdef __cplusplus
 }

@@ -49,11 +49,18 @@ def check_selftest(out):
     shl = 3 * np.arange(1, 65) + 1
     shl[63] = -7; shl[31] = -99; shl[30] = -7
     assert (out[256:320] == shl).all(), out[256:320]
+    # bound_ctrl set + folded into an add: a lane without a source reads 0
+    shrz = 3 * np.arange(-1, 63) + 1 + 1000
+    shrz[0] = 1000; shrz[31] = -99; shrz[32] = 1000
+    assert (out[320:384] == shrz).all(), out[320:384]
+    shlz = 3 * np.arange(1, 65) + 1 + 1000
+    shlz[63] = 1000; shlz[31] = -99; shlz[30] = 1000
+    assert (out[384:448] == shlz).all(), out[384:448]
 
 
 def test_cross_lane_primitives(ctx):
     """DPP wave_shr:1 keeps `old` in lane 0 and shifts lane n-1 -> n; readlane; 64-bit ballot."""
-    out = np.zeros(320, dtype=np.int32)
+    out = np.zeros(448, dtype=np.int32)
     ctx.check(ctx.lib.c2_selftest(ctx.handle, out.ctypes.data_as(ctypes.c_void_p)), "c2_selftest")
     check_selftest(out)
 
