@@ -15,8 +15,8 @@
 #define C2_LANES 64
 #define C2_DIAG_NEG (-(1 << 30))     // diagonal-band kernels: "no score yet" of the certificate's H(Li, Lj)
 #define C2_DIAG_BIAS (1 << 30)       // diagonal-band kernels: added to every DP value, so that a cell outside the band reads as 0
-#define C2_DIAG_STORE_LO 16          // diagonal-band kernel: lanes STORE_LO .. STORE_LO+STORE_N-1 (the inner 64 of the 128
-#define C2_DIAG_STORE_N 32           //   diagonals) keep their pointer words; a traceback that leaves them is redone by the row-strip kernel
+#define C2_DIAG_STORE_LO 0           // diagonal-band kernel: lanes STORE_LO .. STORE_LO+STORE_N-1 keep their pointer words in LDS (all 64:
+#define C2_DIAG_STORE_N 64           //   16 KB for 500 anti-diagonals; its 175 VGPRs allow 8 workgroups per CU, which 19 KB of LDS each still fit)
 #define C2_DIAG_ROW_PAD 128          // zero row records in front of row 0 and behind row Li+1 of every reference's table
 #define C2_DIAG_CODE_PAD 32          // zero column symbols in front of column 0 (multi-alignment kernel's LDS tables)
 #define C2_TASK_CHUNK 4              // tasks a workgroup takes per atomic

@@ -809,6 +809,27 @@ __host__ __device__ inline c2_diag_plan c2_make_diag_plan(int max_li, int max_lj
     return p;
 }
 
+// Upper bound of the score of any path from (0,0) to (Li,Lj) that touches a diagonal outside the band [dlo1 + 1, dhi1 - 1]
+// (D = Li - Lj lies inside it).  Such a path takes nv >= dhi1 steps down (or nh >= -dlo1 steps right), nh = nv - D, and at
+// most Li - nv diagonal steps of at most maxS each.  A step right costs at most cb = max(go, ge) + max(0, max g): an insertion
+// in the incentive's row pays ge + g per base.  A step DOWN never collects the incentive when it extends (jExt = ge + J,
+// pyx:201), and opening costs go + g[i-1] -- or ge + g[i-1] where the reference waives the open: the run down column 0 from
+// (0,0) (pyx:170), a step that lands on the last row, the run in the last column (pyx:234-317): at most three such places on
+// a path.  So if go + max g <= ge, the nv steps down cost at most ge * nv + 3 * max g; otherwise cb each, like the steps right.
+// Every term falls as nv grows, so the bound is taken at the smallest nv.  -> C2_DIAG_NEG if no such path exists.
+__device__ __forceinline__ int c2_outside_band_bound(const int maxS, const int Li, const int Lj, const int D, const int dhi1, const int dlo1,
+                                                     const int cb, const int go, const int ge)
+{
+    if (maxS < 0) return 0x7fffffff;                            // (the bound grows with nv then: no certificate)
+    const int gm = cb - (go > ge ? go : ge);                    // max(0, max gap incentive)
+    const bool waived = go + gm <= ge;
+    const int down = waived ? ge : cb, extra = waived ? 3 * gm : 0;
+    int U = C2_DIAG_NEG;
+    if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + down * dhi1 + extra + cb * (dhi1 - D));
+    if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + down * (D - dlo1) + extra + cb * (-dlo1));
+    return U;
+}
+
 struct c2_diag_plane {
     const unsigned* words; int d0;
     __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
@@ -1108,9 +1129,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
             const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
             const int maxS = A.max_score;
             const int dhi1 = d0 + 128, dlo1 = d0 - 1;         // first diagonals outside the band
-            int U = C2_DIAG_NEG;
-            if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + cb * (2 * dhi1 - D));
-            if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + cb * (D - 2 * dlo1));
+            const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge);
             if (!(Hend > U)) need_full = true;
 
             if (!need_full) {
@@ -1390,9 +1409,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
                 const int maxS = A.max_score;
                 const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
-                int U = C2_DIAG_NEG;
-                if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + cb * (2 * dhi1 - D));
-                if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + cb * (D - 2 * dlo1));
+                const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge);
                 if (!(Hend > U)) need_full = true;
                 if (!need_full) {
                     const c2_wg W = wg_of(s);
