@@ -468,9 +468,11 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         desc[r].inc_prefix = (const uint16_t*)(base + off_p[r]);
         desc[r].len = lens[r];
         desc[r].diag_rows = nullptr;
-        int64_t gm = 0;
-        for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, gap_incentives[r][k]);
+        int64_t gm = 0;                                          // over the values the kernels add: the reference's C ints
+        for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)(int32_t)gap_incentives[r][k]);
         desc[r].gap_incentive_max = (int32_t)std::min<int64_t>(gm, 1 << 20);
+        desc[r].gap_incentive_last_pos = (int32_t)gap_incentives[r][lens[r]] > 0 ? 1 : 0;
+        desc[r].reserved = 0;
         ctx->gmax = std::max(ctx->gmax, desc[r].gap_incentive_max);
         ctx->ref_len[r] = lens[r];
     }

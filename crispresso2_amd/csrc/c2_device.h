@@ -34,6 +34,8 @@ typedef struct c2_dev_ref {
     const c2_diag_row* diag_rows; // row 0 of Li+2 records (rows 0 and Li+1 are zero) with C2_DIAG_ROW_PAD zero records on either side; NULL when the scoring has no packed form
     int32_t len;                  // Li
     int32_t gap_incentive_max;    // max(0, max_i gap_incentive[i]); max(gap_open, gap_extend) + this bounds what one gap base adds to a score
+    int32_t gap_incentive_last_pos; // gap_incentive[Li] > 0: insertions along the last row collect an incentive without paying an open
+    int32_t reserved;
 } c2_dev_ref;
 
 // Kernel arguments for the fused align + traceback + classify kernel.

@@ -810,23 +810,30 @@ __host__ __device__ inline c2_diag_plan c2_make_diag_plan(int max_li, int max_lj
 }
 
 // Upper bound of the score of any path from (0,0) to (Li,Lj) that touches a diagonal outside the band [dlo1 + 1, dhi1 - 1]
-// (D = Li - Lj lies inside it).  Such a path takes nv >= dhi1 steps down (or nh >= -dlo1 steps right), nh = nv - D, and at
-// most Li - nv diagonal steps of at most maxS each.  A step right costs at most cb = max(go, ge) + max(0, max g): an insertion
-// in the incentive's row pays ge + g per base.  A step DOWN never collects the incentive when it extends (jExt = ge + J,
-// pyx:201), and opening costs go + g[i-1] -- or ge + g[i-1] where the reference waives the open: the run down column 0 from
-// (0,0) (pyx:170), a step that lands on the last row, the run in the last column (pyx:234-317): at most three such places on
-// a path.  So if go + max g <= ge, the nv steps down cost at most ge * nv + 3 * max g; otherwise cb each, like the steps right.
+// (D = Li - Lj lies inside it).  Such a path takes nv >= dhi1 steps down (or nh >= -dlo1 steps right), nh = nv - D, and
+// exactly Li - nv diagonal steps of at most maxS each.  With gm = max(0, max g) and cb = max(go, ge) + gm:
+//  * a step DOWN never collects the incentive when it extends (jExt = ge + J, pyx:201); opening costs go + g[i-1] -- or
+//    ge + g[i-1] where the reference waives the open: the run down column 0 from (0,0) (pyx:170), a step that lands on the
+//    last row, the run in the last column (pyx:234-317), at most three such places on a path.  If go + gm <= ge, the nv
+//    steps down therefore cost at most ge * nv + 3 gm; otherwise cb each.
+//  * a step RIGHT in row i costs ge + g[i] (extension) or go + g[i] (open; ge + g[i] on the last row or when it lands on the
+//    last column -- one step, once per path); the run along row 0 costs ge per step + g[0] once (pyx:160).  In a row without
+//    incentive every step costs at most ge (go <= ge); a run inside an interior incentive row pays its open, n (ge + gm) +
+//    (go - ge) for n steps.  So nh steps right cost at most max(ge * nh, cb * nh + (go - ge)) + 2 gm -- unless the LAST row
+//    carries an incentive (`last_pos`) or go > ge: then cb each.
 // Every term falls as nv grows, so the bound is taken at the smallest nv.  -> C2_DIAG_NEG if no such path exists.
 __device__ __forceinline__ int c2_outside_band_bound(const int maxS, const int Li, const int Lj, const int D, const int dhi1, const int dlo1,
-                                                     const int cb, const int go, const int ge)
+                                                     const int cb, const int go, const int ge, const int last_pos)
 {
     if (maxS < 0) return 0x7fffffff;                            // (the bound grows with nv then: no certificate)
     const int gm = cb - (go > ge ? go : ge);                    // max(0, max gap incentive)
     const bool waived = go + gm <= ge;
     const int down = waived ? ge : cb, extra = waived ? 3 * gm : 0;
+    const bool runs = go <= ge && !last_pos;
+    auto right = [&](const int nh) { return runs ? c2_imax(ge * nh, cb * nh + (go - ge)) + 2 * gm : cb * nh; };
     int U = C2_DIAG_NEG;
-    if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + down * dhi1 + extra + cb * (dhi1 - D));
-    if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + down * (D - dlo1) + extra + cb * (-dlo1));
+    if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + down * dhi1 + extra + right(dhi1 - D));
+    if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + down * (D - dlo1) + extra + right(-dlo1));
     return U;
 }
 
@@ -1129,7 +1136,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
             const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
             const int maxS = A.max_score;
             const int dhi1 = d0 + 128, dlo1 = d0 - 1;         // first diagonals outside the band
-            const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge);
+            const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge, rf.gap_incentive_last_pos);
             if (!(Hend > U)) need_full = true;
 
             if (!need_full) {
@@ -1161,7 +1168,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
 // per-alignment ("slot") table in LDS: wave-uniform values written by lane 0 and read back through readfirstlane, so the
 // staging / traceback / output code exists once (a loop over the slots) instead of once per slot
 enum { C2X_VALID = 0, C2X_TASK_LO, C2X_TASK_HI, C2X_LJ, C2X_REF, C2X_RC, C2X_STATUS, C2X_PACKED, C2X_CURREF, C2X_LI, C2X_G0,
-       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_INTS = 20 };
+       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_INTS = 20 };
 __device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
 
 template <int NA>
@@ -1296,12 +1303,14 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             int* T = sTab + s * C2X_INTS;
             const int Li = c2_uni(T + C2X_LI), Lj = c2_uni(T + C2X_LJ);
             bool ok = false;
-            int D = 0, d0 = 0, cb = 0, minsc = 0, rowBase = C2_DIAG_ROW_PAD;   // (idle slot: row 0 of the buffer's first table)
+            int D = 0, d0 = 0, cb = 0, minsc = 0, lastpos = 0, rowBase = C2_DIAG_ROW_PAD;   // (idle slot: row 0 of the buffer's first table)
             if (c2_uni(T + C2X_VALID) && c2_uni(T + C2X_STATUS) == 0) {
                 const c2_dev_ref rf = A.refs[c2_uni(T + C2X_REF)];
                 D = Li - Lj;
-                d0 = ((D >> 1) - NL) & ~1;                     // even; band = d0 .. d0 + BANDW - 1 around the corner-to-corner diagonal
+                d0 = ((D - BANDW + 3) >> 1) & ~1;              // even; band = d0 .. d0 + BANDW - 1, the first diagonals outside it (d0 - 1, d0 + BANDW) as
+                                                               // symmetric about D / 2 as an even d0 allows: the two sides of c2_outside_band_bound are then equal
                 cb = (go > ge ? go : ge) + rf.gap_incentive_max;          // the most one gap base can add to a score
+                lastpos = rf.gap_incentive_last_pos;
                 ok = c2_uni(T + C2X_PACKED) && rf.diag_rows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
                      D >= d0 && D <= d0 + BANDW - 1;
                 if (ok) {
@@ -1316,7 +1325,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 }
             }
             if (lane == 0) {
-                T[C2X_OK] = ok ? 1 : 0; T[C2X_D] = D; T[C2X_D0] = d0; T[C2X_CB] = cb; T[C2X_MINSC] = minsc; T[C2X_ROWBASE] = rowBase;
+                T[C2X_OK] = ok ? 1 : 0; T[C2X_D] = D; T[C2X_D0] = d0; T[C2X_CB] = cb; T[C2X_MINSC] = minsc; T[C2X_ROWBASE] = rowBase; T[C2X_LASTPOS] = lastpos;
                 T[C2X_BAND_LI] = ok ? Li : 0; T[C2X_BAND_LJ] = ok ? Lj : 0;
             }
         }
@@ -1409,7 +1418,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
                 const int maxS = A.max_score;
                 const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
-                const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge);
+                const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge, c2_uni(T + C2X_LASTPOS));
                 if (!(Hend > U)) need_full = true;
                 if (!need_full) {
                     const c2_wg W = wg_of(s);

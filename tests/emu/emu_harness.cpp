@@ -36,8 +36,9 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
         refs[r].len = lens[r];
         int64_t gm = 0;
-        for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, gap_inc[r][k]);
+        for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)g32[r][k]);
         refs[r].gap_incentive_max = (int32_t)gm;
+        refs[r].gap_incentive_last_pos = g32[r][lens[r]] > 0 ? 1 : 0; refs[r].reserved = 0;
         max_li = std::max(max_li, lens[r]);
     }
     int max_lj = 1;
@@ -199,7 +200,7 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     int lmax = 1;
     for (int r = 0; r < n_refs; ++r) {
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
-        refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].diag_rows = nullptr; refs[r].len = lens[r]; refs[r].gap_incentive_max = 0;
+        refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].diag_rows = nullptr; refs[r].len = lens[r]; refs[r].gap_incentive_max = 0; refs[r].gap_incentive_last_pos = 0; refs[r].reserved = 0;
         lmax = std::max(lmax, lens[r]);
     }
     unsigned long long wc = 0;

@@ -52,3 +52,50 @@ def matrices():
     d = os.path.dirname(A.__file__)
     return {"EDNAFULL": A.read_matrix(os.path.join(d, "EDNAFULL")),
             "BLOSUM62": A.read_matrix(os.path.join(d, "BLOSUM62"))}
+
+
+def adversarial_case(rng, n, L=120):
+    """References whose gap incentives sit where the out-of-band bound has to be careful -- last row, row 0, a block of rows,
+    one large value -- and reads built so that the cheap gapped paths are the good ones: long insertions exactly in the
+    incentive rows, insertions after the last reference base, leading deletions/insertions, long deletions next to them."""
+    import numpy as np
+    refs = ["".join(rng.choice(list("ACGT"), L + 7 * k)) for k in range(4)]
+    gis = []
+    for k, r in enumerate(refs):
+        g = np.zeros(len(r) + 1, dtype=np.int64)
+        if k == 0:
+            g[len(r)] = 1; g[len(r) // 2] = 1                     # the LAST row carries an incentive
+        elif k == 1:
+            g[0] = 1; g[1] = 1                                    # row 0 and row 1
+        elif k == 2:
+            g[40:46] = 1                                          # a block of incentive rows
+        else:
+            g[len(r) // 3] = 1; g[2 * len(r) // 3] = 1
+        gis.append(g)
+    incs = [list(range(len(r) // 2 - 3, len(r) // 2 + 3)) for r in refs]
+    reads, rids = [], []
+    for t in range(n):
+        k = int(rng.integers(0, 4))
+        s = list(refs[k])
+        rows = np.nonzero(gis[k])[0]
+        kind = t % 8
+        ins = lambda m: list(rng.choice(list("ACGT"), m))
+        if kind == 0:                                             # long insertion right in an incentive row (after ref base row)
+            p = int(rows[int(rng.integers(0, len(rows)))]); s[p:p] = ins(int(rng.integers(8, 45)))
+        elif kind == 1:                                           # bases appended after the last reference base / in front of the first
+            s = s + ins(int(rng.integers(5, 40))) if t % 16 == 1 else ins(int(rng.integers(5, 40))) + s
+        elif kind == 2:                                           # leading / trailing deletion
+            d = int(rng.integers(5, 40)); s = s[d:] if t % 16 == 2 else s[:len(s) - d]
+        elif kind == 3:                                           # long deletion + the same number of bases appended (equal lengths)
+            d = int(rng.integers(8, 45)); p = int(rng.integers(5, len(s) - d - 5)); del s[p:p + d]; s += ins(d)
+        elif kind == 4:                                           # insertion in an incentive row, the tail cut off (equal lengths)
+            p = int(rows[int(rng.integers(0, len(rows)))]); m = int(rng.integers(5, 30)); s[p:p] = ins(m); s = s[:len(refs[k])]
+        elif kind == 5:                                           # deletion ending at an incentive row
+            p = int(rows[int(rng.integers(0, len(rows)))]); d = int(rng.integers(3, 30)); del s[max(0, p - d):p]
+        elif kind == 6:                                           # two events
+            p = int(rng.integers(5, len(s) // 2)); del s[p:p + int(rng.integers(1, 15))]
+            p = int(rng.integers(len(s) // 2, len(s) - 2)); s[p:p] = ins(int(rng.integers(1, 20)))
+        for q in np.nonzero(rng.random(len(s)) < 0.01)[0]:
+            s[q] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(s) if s else "A"); rids.append(k)
+    return refs, gis, incs, reads, rids

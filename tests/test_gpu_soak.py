@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import matrices
+from helpers import adversarial_case, matrices
 from test_gpu_parity import check_record
 
 pytestmark = pytest.mark.gpu
@@ -80,3 +80,28 @@ def test_soak_every_alignment_vs_oracle(ctx, go, ge, seed):
     tiers = ctx.tier_info()
     if (go, ge) == (-20, -2):
         assert len(tiers) == 3 and tiers[0] > tiers[2] > 0          # all four kernels did part of the batch
+
+
+@pytest.mark.parametrize("go,ge,scale", [(-20, -2, 1), (-20, -4, 3), (-6, -2, 1), (-20, -7, 6), (-2, -3, 1)])
+def test_soak_adversarial_gap_incentives(ctx, go, ge, scale):
+    """Gap incentives where the diagonal kernels' out-of-band bound has exceptions (last row, row 0, blocks of rows, large
+    values; gap_open > gap_extend) with reads that make the cheap gapped paths optimal: every alignment vs the oracle."""
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    m = matrices()["EDNAFULL"]
+    rng = np.random.default_rng(500 + scale - go)
+    n = int(os.environ.get("C2_SOAK_N", 4000))
+    refs, gis, incs, reads, rids = adversarial_case(rng, n, L=int(rng.integers(100, 230)))
+    gis = [g * scale for g in gis]
+    al = BatchAligner(refs, gis, incs, m, go, ge, ctx=ctx)
+    res = al.align(reads, ref_ids=np.array(rids, dtype=np.uint16))
+    bad = 0
+    for k in range(n):
+        st, s1, s2, mt, ln = oracle.global_align_raw(reads[k], refs[rids[k]], m, gis[rids[k]], go, ge)
+        r = res.records[k]
+        if st != 0:
+            assert r["status"] != 0, k
+            bad += 1
+            continue
+        assert r["status"] == 0 and res.strings(k) == (s1, s2) and int(r["matches"]) == mt and int(r["aln_len"]) == ln, (k, rids[k])
+    assert bad < n // 10

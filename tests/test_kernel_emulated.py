@@ -10,7 +10,7 @@ import pytest
 
 import emu_driver as E
 import oracle
-from helpers import load_golden, matrices
+from helpers import adversarial_case, load_golden, matrices
 
 
 @pytest.fixture(scope="module")
@@ -155,6 +155,23 @@ def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats, mo
         assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k
         check_record(r, oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
     assert st["fallback"] < st["tasks"]
+
+
+@pytest.mark.parametrize("go,ge,scale", [(-20, -2, 1), (-20, -4, 3), (-6, -2, 1)])
+def test_emulated_chain_adversarial_gap_incentives(mats, go, ge, scale):
+    """The out-of-band bound of the diagonal kernels (c2_outside_band_bound) prices steps down at gap_extend and steps right
+    by runs; these references put the incentives where that reasoning has exceptions (last row, row 0, blocks of rows, values
+    up to 3) and the reads make the cheap gapped paths optimal.  Whole chain 4 -> 2 -> 1 -> full plane vs the oracle."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(1000 + scale - go)
+    refs, gis, incs, reads, rids = adversarial_case(rng, 96)
+    gis = [g * scale for g in gis]
+    st = {}
+    res, rec = E.align_batch(reads, refs, gis, incs, m, go, ge, ref_ids=rids, band_lanes=-7, grid=3, stats=st)
+    for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+        exp = oracle.global_align_raw(reads[k], refs[rids[k]], m, gis[rids[k]], go, ge)
+        assert exp[0] == 0 and r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], (k, rids[k])
+    assert 0 < st["fallback"] < st["tasks"], st
 
 
 @pytest.mark.parametrize("R", [1, 2, 3])
