@@ -1955,6 +1955,45 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 __syncthreads();
             }
             unsigned todo = heavy ? ((first >= 0 && ftask == ttask) ? (1u << first) : 0u) : pending;
+            // ---- scalar counters and histograms of ALL tasks of this round at once: lane k holds the record of its own task, so
+            //      every lane adds its task's contributions (LDS atomics; ~20 instructions per round instead of per task).
+            //      aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979), then the tallies of :3996-4072.
+            if (lane < K && ((todo >> lane) & 1u) && (int)(d6 >> 16) == tref) {
+                const int w = v_w;
+                const int insertion_n = (int)(d1 & 0xffffu), deletion_n = (int)(d1 >> 16), substitution_n = (int)(d2 & 0xffffu);
+                const int all_ins = (int)(d2 >> 16), all_del_bases = (int)(d4 >> 16), all_sub = (int)(d5 & 0xffffu);
+                const bool irregular_ends = (d5 >> 16) & 0xffu;
+                const int total_mods = all_ins + all_del_bases + all_sub;                               // :741
+                const int in_win = substitution_n + deletion_n + insertion_n;                           // :742
+                int* scal = acc + o_sc;
+                atomicAdd(scal + C2_S_N_GLOBAL_SUBS, all_sub * w);
+                atomicAdd(scal + C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - substitution_n) * w);
+                atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
+                atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
+                if (irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
+                atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);
+                if (discard && (deletion_n > 0 || insertion_n > 0)) atomicAdd(scal + C2_S_DISCARDED, w);                     // :3996-4000
+                else {
+                    const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
+                    const bool modified = has_del || has_ins || has_sub;
+                    atomicAdd(scal + C2_S_TOTAL, w);
+                    atomicAdd(scal + (modified ? C2_S_MODIFIED : C2_S_UNMODIFIED), w);          // :746-760, :4003-4006
+                    if (has_ins) atomicAdd(scal + C2_S_INSERTION, w);
+                    if (has_del) atomicAdd(scal + C2_S_DELETION, w);
+                    if (has_sub) atomicAdd(scal + C2_S_SUBSTITUTION, w);
+                    int combo = -1;                                                             // :4058-4072
+                    if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
+                                                 : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
+                    else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
+                    else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
+                    if (combo >= 0) atomicAdd(scal + combo, w);
+                    if (!ign_ins) atomicAdd(acc + o_h + C2_H_INSERTED_N * A.hl + insertion_n, w);   // :4020
+                    if (!ign_del) atomicAdd(acc + o_h + C2_H_DELETED_N * A.hl + deletion_n, w);     // :4030
+                    if (!ign_sub) atomicAdd(acc + o_h + C2_H_SUBSTITUTED_N * A.hl + substitution_n, w);   // :4043
+                    const int eff = Li + (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n);   // :4010-4037
+                    atomicAdd(acc + o_h + C2_H_EFFECTIVE_LEN * A.hl + eff, w);
+                }
+            }
             while (todo) {
                 const int kk = __builtin_ctz(todo);
                 todo &= todo - 1;
@@ -1980,40 +2019,9 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                     const int c = 64 * q + lane;
                     if (c < T) { rd4 |= (unsigned)R_[c] << (8 * q); rf4 |= (unsigned)F_[c] << (8 * q); }
                 }
-                // aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979)
-                const int total_mods = all_ins + all_del_bases + all_sub;                               // :741
-                const int in_win = substitution_n + deletion_n + insertion_n;                           // :742
-                int* scal = acc + o_sc;                          // scalar counters: lane 0 adds (LDS, any index)
-                const bool l0 = (lane == 0);
-                if (l0) {
-                    atomicAdd(scal + C2_S_N_GLOBAL_SUBS, all_sub * w);
-                    atomicAdd(scal + C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - substitution_n) * w);
-                    atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
-                    atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
-                    if (irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
-                    atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);
-                }
-                if (discard && (deletion_n > 0 || insertion_n > 0)) { if (l0) atomicAdd(scal + C2_S_DISCARDED, w); continue; }   // :3996-4000
+                if (discard && (deletion_n > 0 || insertion_n > 0)) continue;                      // counted above; no vectors (:3996-4000)
                 const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
                 const bool modified = has_del || has_ins || has_sub;
-                if (l0) {
-                    atomicAdd(scal + C2_S_TOTAL, w);
-                    atomicAdd(scal + (modified ? C2_S_MODIFIED : C2_S_UNMODIFIED), w);          // :746-760, :4003-4006
-                    if (has_ins) atomicAdd(scal + C2_S_INSERTION, w);
-                    if (has_del) atomicAdd(scal + C2_S_DELETION, w);
-                    if (has_sub) atomicAdd(scal + C2_S_SUBSTITUTION, w);
-                    int combo = -1;                                                             // :4058-4072
-                    if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
-                                                 : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
-                    else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
-                    else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
-                    if (combo >= 0) atomicAdd(scal + combo, w);
-                    if (!ign_ins) atomicAdd(acc + o_h + C2_H_INSERTED_N * A.hl + insertion_n, w);   // :4020
-                    if (!ign_del) atomicAdd(acc + o_h + C2_H_DELETED_N * A.hl + deletion_n, w);     // :4030
-                    if (!ign_sub) atomicAdd(acc + o_h + C2_H_SUBSTITUTED_N * A.hl + substitution_n, w);   // :4043
-                    const int eff = Li + (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n);   // :4010-4037
-                    atomicAdd(acc + o_h + C2_H_EFFECTIVE_LEN * A.hl + eff, w);
-                }
                 const bool len_block = modified;                                                // :4085 (no coding sequence)
                 // ---- column walk (same scan as the fused classifier), ds_add into the vectors
                 int idx_base = 0, last_rf = -1, last_rd = -1;
