@@ -1958,7 +1958,16 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
             // ---- scalar counters and histograms of ALL tasks of this round at once: lane k holds the record of its own task, so
             //      every lane adds its task's contributions (LDS atomics; ~20 instructions per round instead of per task).
             //      aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979), then the tallies of :3996-4072.
-            if (lane < K && ((todo >> lane) & 1u) && (int)(d6 >> 16) == tref) {
+            const bool mine = lane < K && ((todo >> lane) & 1u) && (int)(d6 >> 16) == tref;
+            {   // an alignment whose two strings are the reference itself (no gap column, every column a match) adds nothing but
+                // its weight to the "spread over the reference's bases" scalar: done here, its strings are never read
+                const int T_ = (int)(d0 & 0xffffu), matches_ = (int)(d0 >> 16);
+                const bool perfect = mine && T_ == Li && matches_ == T_ && (d4 >> 16) == 0u && d1 == 0u;
+                if (perfect) atomicAdd(acc + o_sc + C2_S_RESERVED0, v_w);
+                const unsigned pm = (unsigned)__ballot(perfect);
+                todo &= ~pm; pending &= ~pm;
+            }
+            if (mine) {
                 const int w = v_w;
                 const int insertion_n = (int)(d1 & 0xffffu), deletion_n = (int)(d1 >> 16), substitution_n = (int)(d2 & 0xffffu);
                 const int all_ins = (int)(d2 >> 16), all_del_bases = (int)(d4 >> 16), all_sub = (int)(d5 & 0xffffu);
