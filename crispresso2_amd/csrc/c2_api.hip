@@ -175,11 +175,11 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
             g.diag = true;
         }
         for (int t = 0; t < 2 && g.diag && km != 3; ++t) {
-            const int na = 4 >> t;
-            if (na == 4 && km == 4) continue;                                  // mode 4: 2 -> 1
+            const int na = t == 0 ? C2_TIER0_NA : 2;
+            if (t == 0 && km == 4) continue;                                   // mode 4: 2 -> 1
             const c2_diagx_plan PX = c2_make_diagx_plan(na, ctx->max_li, g.max_lj);
             if (PX.total > lds_cu) continue;
-            const void* fn = na == 4 ? (const void*)c2_align_diagx_kernel<4> : (const void*)c2_align_diagx_kernel<2>;
+            const void* fn = t == 0 ? (const void*)c2_align_diagx_kernel<C2_TIER0_NA> : (const void*)c2_align_diagx_kernel<2>;
             if (ctx->occ_x_lds[t] != (int)PX.total) {
                 int nb = 0;
                 HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -255,13 +255,13 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
             }
             for (int t = 0; t < 2; ++t) {
                 if (!g.x[t]) continue;
-                const int na = 4 >> t;
+                const int na = t == 0 ? C2_TIER0_NA : 2;
                 const uint64_t resident = cus * (uint64_t)g.blocks_x[t];
                 const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + na - 1) / na, resident));
                 c2_align_args T = A;
                 chain(T);
                 T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = g.plane_words;
-                if (na == 4) hipLaunchKernelGGL(c2_align_diagx_kernel<4>, dim3(grid), dim3(64), g.lds_x[t], s, T);
+                if (t == 0) hipLaunchKernelGGL(c2_align_diagx_kernel<C2_TIER0_NA>, dim3(grid), dim3(64), g.lds_x[t], s, T);
                 else         hipLaunchKernelGGL(c2_align_diagx_kernel<2>, dim3(grid), dim3(64), g.lds_x[t], s, T);
                 HIPCHK(ctx, hipGetLastError());
                 mark_first();

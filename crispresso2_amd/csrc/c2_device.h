@@ -19,6 +19,9 @@
 #define C2_DIAG_STORE_N 64           //   16 KB for 500 anti-diagonals; its 175 VGPRs allow 8 workgroups per CU, which 19 KB of LDS each still fit)
 #define C2_DIAG_ROW_PAD 128          // zero row records in front of row 0 and behind row Li+1 of every reference's table
 #define C2_DIAG_CODE_PAD 32          // zero column symbols in front of column 0 (multi-alignment kernel's LDS tables)
+#ifndef C2_TIER0_NA
+#define C2_TIER0_NA 4               // alignments per wavefront in the first launch of the chain (4, or 5: lane groups of 12)
+#endif
 #define C2_TASK_CHUNK 4              // tasks a workgroup takes per atomic
 #define C2_STATUS_NEED_FULL 64     // internal: banded launch could not finish the traceback; the full-plane launch overwrites the record
 

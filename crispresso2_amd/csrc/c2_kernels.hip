@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             const int* T = sTab + slot * C2X_INTS;                 // this lane's alignment
             const int vLi = T[C2X_BAND_LI], vLj = T[C2X_BAND_LJ], vd0 = T[C2X_D0], vg0 = T[C2X_G0], vmin = T[C2X_MINSC];
             const int vrow = T[C2X_ROWBASE], vcode = (int)(P.slot0 + (uint32_t)slot * P.slot_bytes + P.codes) + C2_DIAG_CODE_PAD;
-            C2_LANES_ACTIVE_BEGIN(sl != NL)
+            C2_LANES_ACTIVE_BEGIN(sl != NL && slot < NA)           // (slot >= NA: the lanes 64 / NA does not use up, e.g. 60..63 of five groups of 12)
             // ---- per-lane diagonals and their boundary cells (pyx:153-176), as in c2_align_diag_kernel
             const int hE = (vd0 >> 1) + sl;                    // dE = 2*hE, dO = 2*hE + 1
             const int dE = 2 * hE, dO = dE + 1;

@@ -68,7 +68,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     }
     // band_lanes: -1 single-alignment diagonal-band kernel, -2 / -4 the 2- / 4-alignments-per-wavefront kernel, -7 the whole
     // chain 4 -> 2 -> 1; every chain ends with the full-plane kernel over what is left (the host library's launch order)
-    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -7;
+    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75;
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1);
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
@@ -92,19 +92,23 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             T.fb_list = lists[tier & 1]; T.fb_count = &fb_counts[tier];
             work_counter = 0;
         };
-        for (int na = 4; na >= 2; na >>= 1) {
-            if (!(band_lanes == -7 || band_lanes == -na)) continue;
+        // -5: five alignments per wavefront (lane groups of 12, lanes 60..63 idle); -75: the chain 5 -> 2 -> 1 -> full plane
+        const int nas[3] = {(band_lanes == -5 || band_lanes == -75) ? 5 : 4, 2, 0};
+        for (int q = 0; nas[q]; ++q) {
+            const int na = nas[q];
+            if (!(band_lanes == -7 || band_lanes == -75 || band_lanes == -na)) continue;
             const c2_diagx_plan PX = c2_make_diagx_plan(na, A.max_li, A.max_lj);
             if (PX.total > sizeof(c2_smem)) return -5;
             plane.assign((size_t)grid * PX.n_words * 64u, 0xdeadbeefu);
             c2_align_args T = A;
             chain(T);
             T.plane = plane.data(); T.plane_words_per_wg = PX.n_words * 64u;
-            if (na == 4) emu::launch(grid, [&] { c2_align_diagx_kernel<4>(T); });
+            if (na == 5) emu::launch(grid, [&] { c2_align_diagx_kernel<5>(T); });
+            else if (na == 4) emu::launch(grid, [&] { c2_align_diagx_kernel<4>(T); });
             else         emu::launch(grid, [&] { c2_align_diagx_kernel<2>(T); });
             ++tier;
         }
-        if (band_lanes == -7 || band_lanes == -1) {
+        if (band_lanes == -7 || band_lanes == -75 || band_lanes == -1) {
             const c2_diag_plan PD = c2_make_diag_plan(A.max_li, A.max_lj);
             if (PD.total > sizeof(c2_smem)) return -5;
             c2_align_args T = A;
