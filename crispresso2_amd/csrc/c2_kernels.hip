@@ -761,14 +761,13 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
 // diagonals around the one that joins (0,0) and (Li,Lj); the sweep runs over anti-diagonals a = i + j, one cell per lane
 // per step (E cells at even a, O cells at odd a), 499 steps x 1 cell instead of 313 steps x 4 cells for 250 x 250.
 // Cells outside the band are never computed (they read as -2^30: the number 0 under C2_DIAG_BIAS), which is exact iff no optimal path leaves the
-// band.  That is PROVEN per alignment after the fill: a path that touches diagonal d outside [0, D] (D = Li - Lj) takes
-// at least |d| + |d - D| gap steps and at most min(Li, Lj) - (steps off the [0,D] corridor) match steps, so it scores at
-// most U = maxS * (len - off) + cb * (gap steps), cb = max(go, ge) + max(0, max g) < 0 the most a gap base can add.  If the
-// banded score H(Li,Lj) > U for both band edges, every optimal path -- and every path that ties with one at any cell the
+// band.  That is PROVEN per alignment after the fill: c2_outside_band_bound gives the most any path that touches a diagonal
+// beyond either band edge can score (its steps down, steps right and diagonal steps priced by the reference's own cost
+// rules).  If the banded score H(Li,Lj) exceeds it, every optimal path -- and every path that ties with one at any cell the
 // reference's traceback visits -- lies inside the band, where banded and full DP values coincide, so the pointers the
 // traceback reads are the full DP's.  Otherwise (and for reads the packed score rows cannot encode) the task goes to the
-// fallback list and the next launch of the chain redoes it.  Neighbour traffic: two DPP moves per step (wave_shr at even
-// steps, wave_shl at odd steps); row constants {a_i, b_i, c_i, score row} come from a zero-padded per-reference table in
+// fallback list and the next launch of the chain redoes it.  Neighbour traffic: two DPP reads per step (wave_shr at even
+// steps, wave_shl at odd steps), folded into the adds that consume them; row constants {a_i, b_i, c_i, score row} come from a zero-padded per-reference table in
 // global memory (L2-resident), the column symbols from a zero-padded LDS table, both fetched one group of eight
 // anti-diagonals ahead (c2_diagx_fetch).
 // ---------------------------------------------------------------------------------------------------------------
@@ -967,7 +966,7 @@ struct c2_diagx_lane {
     int startE, startO;              // first interior anti-diagonal of the two diagonals
 };
 
-// rows and column symbols of group g (pairs 4g .. 4g+3): five row records (the O cell of the last pair needs row + 1) and four symbols.
+// rows and column symbols of group g (pairs 4g .. 4g+3): row records 0..4 (the O cell of the last pair needs row + 1) and four symbols.
 // FIRST = false: record 0 is the caller's business -- it is record 4 of group g - 1 (also when the v_min below clamps either
 // group's address: every record from the clamp on is zero padding), so a group costs four 16-byte loads, not five.
 template <bool FIRST>
