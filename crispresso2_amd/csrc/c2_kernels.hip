@@ -383,7 +383,7 @@ __device__ __forceinline__ void c2_prefetch_issue(const c2_align_args& A, const 
 // request, CRISPRessoShared.py:399-403) and their codes.  Returns the wave-uniform status bits.  max_li / A.max_lj bound
 // what may be written.  sCodeOf: the 256-entry character -> code table, in LDS.
 __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_wg& W, const unsigned char* sCodeOf, const c2_prefetch& pf,
-                                              const int lane, const int max_li, int& cur_ref, int& Li, int& g0, bool& packed,
+                                              const int lane, const int max_li, int& cur_ref, int& Li, int& g0, int& ref_bad, bool& packed,
                                               unsigned char* sCodes4 = nullptr)
 {
     // sCodes4 (multi-alignment kernel): the zero-padded table of 4 * code per column, written in the same pass -- columns
@@ -398,7 +398,13 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
         Li = rf.len;
         g0 = rf.gap_incentive[0];
         const int LiLoad = Li < max_li ? Li : max_li;
-        for (int k = lane; k < LiLoad; k += 64) W.sRef[k] = rf.seq[k];
+        int bad = 0;                                            // a reference character outside the score matrix: checked when the
+        for (int k = lane; k < LiLoad; k += 64) {               // reference is staged, remembered with it (ref_bad)
+            const unsigned char ch = rf.seq[k];
+            W.sRef[k] = ch;
+            if (sCodeOf[ch] == C2_INVALID_CODE) bad = 1;
+        }
+        ref_bad = __ballot(bad) ? 1 : 0;
         for (int k = lane; k < LiLoad + 2; k += 64) W.sIncP[k] = rf.inc_prefix[k];
     }
     for (int k = lane; k < LjLoad; k += 64) {
@@ -416,22 +422,19 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
         const unsigned char code = sCodeOf[ch];
         if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
         W.sRead[k] = ch;
-        W.sCode[k] = code;
-        if (sCodes4) sCodes4[C2_DIAG_CODE_PAD + 1 + k] = (unsigned char)(code << 2);
+        if (sCodes4) sCodes4[C2_DIAG_CODE_PAD + 1 + k] = (unsigned char)(code << 2);   // (the multi-alignment kernel reads only this table)
+        else W.sCode[k] = code;
         read_code_max = read_code_max > (int)code ? read_code_max : (int)code;
     }
     if (sCodes4 && lane < 9) sCodes4[C2_DIAG_CODE_PAD + 1 + LjLoad + lane] = 0;
-    {
-        int bad = 0;
-        for (int k = lane; k < Li && k < max_li; k += 64) if (sCodeOf[W.sRef[k]] == C2_INVALID_CODE) bad = 1;
-        if (bad) status |= C2_STATUS_OOB_CHAR;
-    }
+    if (ref_bad) status |= C2_STATUS_OOB_CHAR;
     if (Li <= 0 || Lj <= 0) status |= C2_STATUS_EMPTY;
     if (Lj > A.max_lj || Li > max_li) status |= C2_STATUS_TOO_LONG;
-    status = (__ballot(status & C2_STATUS_EMPTY) ? C2_STATUS_EMPTY : 0) |
-             (__ballot(status & C2_STATUS_OOB_CHAR) ? C2_STATUS_OOB_CHAR : 0) |
-             (__ballot(status & C2_STATUS_RC_CHAR) ? C2_STATUS_RC_CHAR : 0) |
-             (__ballot(status & C2_STATUS_TOO_LONG) ? C2_STATUS_TOO_LONG : 0);
+    if (__ballot(status != 0))                                  // (rare: one ballot decides for the usual task)
+        status = (__ballot(status & C2_STATUS_EMPTY) ? C2_STATUS_EMPTY : 0) |
+                 (__ballot(status & C2_STATUS_OOB_CHAR) ? C2_STATUS_OOB_CHAR : 0) |
+                 (__ballot(status & C2_STATUS_RC_CHAR) ? C2_STATUS_RC_CHAR : 0) |
+                 (__ballot(status & C2_STATUS_TOO_LONG) ? C2_STATUS_TOO_LONG : 0);
     // packed = every read symbol has a code < 8 and every score fits a signed nibble: the score row of a reference
     // base is then one register and a lookup is one v_bfe_i32 (no LDS in the inner loop).
     packed = (A.score_pk != nullptr) && (__ballot(read_code_max >= 8) == 0ull);
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
 
     for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
     int cur_ref = -1;
-    int Li = 0, g0 = 0;
+    int Li = 0, g0 = 0, ref_bad = 0;
     uint64_t chunk_base = 0;
     int chunk_left = 0;
     c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
         const uint64_t task = pf.task;
         const int Lj = pf.Lj, ref_id = pf.ref_id, rc = pf.rc;
         bool packed;
-        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_passes * ROWS_PER_PASS, cur_ref, Li, g0, packed);
+        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_passes * ROWS_PER_PASS, cur_ref, Li, g0, ref_bad, packed);
         c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);   // next task's loads fly during this task's DP
         const c2_dev_ref rf = A.refs[ref_id];
         const int passes = (Li + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
@@ -927,7 +930,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
     uint32_t off = 0;
     p.codeof = off;   off += 256u;                                  // character -> code
-    p.table = off;    off += 8u * 20u * 4u;                         // up to 8 slots x C2X_INTS
+    p.table = off;    off += 8u * 24u * 4u;                         // up to 8 slots x C2X_INTS
     p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
     p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
     p.stage = off;    off += p.n_words * (64u / (uint32_t)na) * 4u; // pointer words of the alignment being traced
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
     for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
 
     int cur_ref = -1;
-    int Li = 0, g0 = 0;
+    int Li = 0, g0 = 0, ref_bad = 0;
     uint64_t chunk_base = 0;
     int chunk_left = 0;
     c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
         const uint64_t task = pf.task;
         const int Lj = pf.Lj, ref_id = pf.ref_id, rc = pf.rc;
         bool packed;
-        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_li, cur_ref, Li, g0, packed);
+        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_li, cur_ref, Li, g0, ref_bad, packed);
         c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);   // next task's loads fly during this task's DP
         const c2_dev_ref rf = A.refs[ref_id];
         __syncthreads();
@@ -1167,7 +1170,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
 // per-alignment ("slot") table in LDS: wave-uniform values written by lane 0 and read back through readfirstlane, so the
 // staging / traceback / output code exists once (a loop over the slots) instead of once per slot
 enum { C2X_VALID = 0, C2X_TASK_LO, C2X_TASK_HI, C2X_LJ, C2X_REF, C2X_RC, C2X_STATUS, C2X_PACKED, C2X_CURREF, C2X_LI, C2X_G0,
-       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_INTS = 20 };
+       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_INTS = 24 };
 __device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
 
 template <int NA>
@@ -1190,7 +1193,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
     const int slotWords = (int)P.n_words * LPA;
     const int ge = A.gap_extend, go = A.gap_open;
     for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
-    if (lane < NA) { sTab[lane * C2X_INTS + C2X_CURREF] = -1; sTab[lane * C2X_INTS + C2X_LI] = 0; sTab[lane * C2X_INTS + C2X_G0] = 0; }
+    if (lane < NA) { sTab[lane * C2X_INTS + C2X_CURREF] = -1; sTab[lane * C2X_INTS + C2X_LI] = 0; sTab[lane * C2X_INTS + C2X_G0] = 0; sTab[lane * C2X_INTS + C2X_REFBAD] = 0; }
     for (int s = 0; s < NA; ++s)                                   // zeros in front of column 1 of every slot's symbol table (written once)
         if (lane <= C2_DIAG_CODE_PAD) c2_smem[P.slot0 + (uint32_t)s * P.slot_bytes + P.codes + lane] = 0;
 
@@ -1231,7 +1234,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
 #pragma unroll
             for (int s = 0; s < NA; ++s) {
                 int* T = sTab + s * C2X_INTS;
-                int cref = c2_uni(T + C2X_CURREF), li = c2_uni(T + C2X_LI), g0 = c2_uni(T + C2X_G0);
+                int cref = c2_uni(T + C2X_CURREF), li = c2_uni(T + C2X_LI), g0 = c2_uni(T + C2X_G0), rbad = c2_uni(T + C2X_REFBAD);
                 int st = 0;
                 bool packed = false;
                 c2_prefetch cur;
@@ -1240,12 +1243,12 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 cur.off = lane64(mC_off, s);
                 cur.Lj = __builtin_amdgcn_readlane(mC_lj, s); cur.ref_id = __builtin_amdgcn_readlane(mC_ref, s);
                 cur.rc = __builtin_amdgcn_readlane(mC_rc, s); cur.b4 = b4s[s];
-                if (cur.valid) st = c2_commit_task(A, wg_of(s), sCodeOf, cur, lane, A.max_li, cref, li, g0, packed,
+                if (cur.valid) st = c2_commit_task(A, wg_of(s), sCodeOf, cur, lane, A.max_li, cref, li, g0, rbad, packed,
                                                    c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes);
                 if (lane == 0) {
                     T[C2X_VALID] = cur.valid; T[C2X_TASK_LO] = (int)(unsigned)(cur.task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(cur.task >> 32);
                     T[C2X_LJ] = cur.Lj; T[C2X_REF] = cur.ref_id; T[C2X_RC] = cur.rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
-                    T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0;
+                    T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0; T[C2X_REFBAD] = rbad;
                 }
             }
         }
