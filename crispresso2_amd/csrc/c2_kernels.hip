@@ -1172,6 +1172,10 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
 enum { C2X_VALID = 0, C2X_TASK_LO, C2X_TASK_HI, C2X_LJ, C2X_REF, C2X_RC, C2X_STATUS, C2X_PACKED, C2X_CURREF, C2X_LI, C2X_G0,
        C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_INTS = 24 };
 __device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
+// the whole table of one slot with ONE LDS read (lane k gets entry k); C2_TF picks an entry: a v_readlane instead of an
+// LDS round trip per entry
+__device__ __forceinline__ int c2_tab_load(const int* T, const int lane) { return T[lane < C2X_INTS ? lane : 0]; }
+#define C2_TF(v, k) __builtin_amdgcn_readlane((v), (k))
 
 template <int NA>
 __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
@@ -1234,7 +1238,8 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
 #pragma unroll
             for (int s = 0; s < NA; ++s) {
                 int* T = sTab + s * C2X_INTS;
-                int cref = c2_uni(T + C2X_CURREF), li = c2_uni(T + C2X_LI), g0 = c2_uni(T + C2X_G0), rbad = c2_uni(T + C2X_REFBAD);
+                const int tvd = c2_tab_load(T, lane);
+                int cref = C2_TF(tvd, C2X_CURREF), li = C2_TF(tvd, C2X_LI), g0 = C2_TF(tvd, C2X_G0), rbad = C2_TF(tvd, C2X_REFBAD);
                 int st = 0;
                 bool packed = false;
                 c2_prefetch cur;
@@ -1303,17 +1308,18 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
 #pragma nounroll
         for (int s = 0; s < NA; ++s) {
             int* T = sTab + s * C2X_INTS;
-            const int Li = c2_uni(T + C2X_LI), Lj = c2_uni(T + C2X_LJ);
+            const int tvb = c2_tab_load(T, lane);
+            const int Li = C2_TF(tvb, C2X_LI), Lj = C2_TF(tvb, C2X_LJ);
             bool ok = false;
             int D = 0, d0 = 0, cb = 0, minsc = 0, lastpos = 0, rowBase = C2_DIAG_ROW_PAD;   // (idle slot: row 0 of the buffer's first table)
-            if (c2_uni(T + C2X_VALID) && c2_uni(T + C2X_STATUS) == 0) {
-                const c2_dev_ref rf = A.refs[c2_uni(T + C2X_REF)];
+            if (C2_TF(tvb, C2X_VALID) && C2_TF(tvb, C2X_STATUS) == 0) {
+                const c2_dev_ref rf = A.refs[C2_TF(tvb, C2X_REF)];
                 D = Li - Lj;
                 d0 = ((D - BANDW + 3) >> 1) & ~1;              // even; band = d0 .. d0 + BANDW - 1, the first diagonals outside it (d0 - 1, d0 + BANDW) as
                                                                // symmetric about D / 2 as an even d0 allows: the two sides of c2_outside_band_bound are then equal
                 cb = (go > ge ? go : ge) + rf.gap_incentive_max;          // the most one gap base can add to a score
                 lastpos = rf.gap_incentive_last_pos;
-                ok = c2_uni(T + C2X_PACKED) && rf.diag_rows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
+                ok = C2_TF(tvb, C2X_PACKED) && rf.diag_rows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
                      D >= d0 && D <= d0 + BANDW - 1;
                 if (ok) {
                     any_ok = true;
@@ -1405,22 +1411,23 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
 #pragma nounroll
         for (int s = 0; s < NA; ++s) {
             const int* T = sTab + s * C2X_INTS;
-            if (!c2_uni(T + C2X_VALID)) continue;
-            const uint64_t task = (uint64_t)(unsigned)c2_uni(T + C2X_TASK_LO) | ((uint64_t)(unsigned)c2_uni(T + C2X_TASK_HI) << 32);
-            const int Li = c2_uni(T + C2X_LI), Lj = c2_uni(T + C2X_LJ), g0 = c2_uni(T + C2X_G0);
-            int status = c2_uni(T + C2X_STATUS);
-            const bool ok = c2_uni(T + C2X_OK) != 0;
+            const int tv = c2_tab_load(T, lane);
+            if (!C2_TF(tv, C2X_VALID)) continue;
+            const uint64_t task = (uint64_t)(unsigned)C2_TF(tv, C2X_TASK_LO) | ((uint64_t)(unsigned)C2_TF(tv, C2X_TASK_HI) << 32);
+            const int Li = C2_TF(tv, C2X_LI), Lj = C2_TF(tv, C2X_LJ), g0 = C2_TF(tv, C2X_G0);
+            int status = C2_TF(tv, C2X_STATUS);
+            const bool ok = C2_TF(tv, C2X_OK) != 0;
             c2_aln_record rec;
-            c2_clear_record(rec, c2_uni(T + C2X_RC), c2_uni(T + C2X_REF));
+            c2_clear_record(rec, C2_TF(tv, C2X_RC), C2_TF(tv, C2X_REF));
             bool need_full = (status == 0) && !ok;
             bool requested = false;
             if (ok) {
-                const int D = c2_uni(T + C2X_D), d0 = c2_uni(T + C2X_D0), cb = c2_uni(T + C2X_CB), minsc = c2_uni(T + C2X_MINSC);
+                const int D = C2_TF(tv, C2X_D), d0 = C2_TF(tv, C2X_D0), cb = C2_TF(tv, C2X_CB), minsc = C2_TF(tv, C2X_MINSC);
                 const int lane_end = s * LPA + ((D - d0) >> 1);
                 const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
                 const int maxS = A.max_score;
                 const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
-                const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge, c2_uni(T + C2X_LASTPOS));
+                const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge, C2_TF(tv, C2X_LASTPOS));
                 if (!(Hend > U)) need_full = true;
                 if (!need_full) {
                     const c2_wg W = wg_of(s);
