@@ -8,7 +8,8 @@
 //   * a record cut short by the end of the file still counts (its sequence may be empty);
 //   * unique sequences keep first-seen order (Python dict order), counts are exact.
 // Output: the unique sequences packed back to back (the byte arena + offsets the align kernels take) and their counts.
-// No GPU involved; zlib inflates .gz input (concatenated members too, like Python's gzip module).
+// No GPU involved; .gz input (concatenated members too, like Python's gzip module) is inflated by zlib, or -- when the text
+// fits in memory -- into one buffer by all threads (BGZF) / libdeflate, and then parsed like a plain file.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,6 +27,8 @@
 #include <chrono>
 #include <memory>
 #include <algorithm>
+#include <atomic>
+#include <dlfcn.h>
 
 #include "crispresso2_amd.h"
 
@@ -388,7 +391,14 @@ struct TextReader {
     bool fill() {
         if (eof) return false;
         const int g = gzread(f, buf.data(), (unsigned)buf.size());
-        if (g <= 0) { eof = true; err = g < 0; pos = end = 0; return false; }
+        if (g <= 0) {
+            // a gzip stream that stops before its end-of-stream marker is gzread's Z_BUF_ERROR with a return of 0: Python's
+            // gzip module raises EOFError when the reader gets there
+            int errnum = Z_OK;
+            gzerror(f, &errnum);
+            eof = true; err = g < 0 || errnum == Z_BUF_ERROR; pos = end = 0;
+            return false;
+        }
         pos = 0; end = (size_t)g;
         return true;
     }
@@ -471,6 +481,221 @@ int for_each_pair(const char* path1, const char* path2, uint64_t* n_pairs, Visit
 
 }  // namespace
 
+// ---- gzip'ed files, whole-buffer route ------------------------------------------------------------------------------
+// zlib's streaming inflate (~0.7 GB/s of text) is what bounds a .gz run end to end, so when the inflated text fits in
+// memory the file is inflated into ONE buffer and handed to the parallel parser of the plain route:
+//   * BGZF input (bgzip / htslib: every member names its own compressed size in a 'BC' extra subfield, <= 64 KiB of text
+//     each) -- the members are located from the headers alone and inflated by all threads at once;
+//   * any other clean sequence of gzip members -- libdeflate's whole-buffer inflate, member after member (the image ships
+//     libdeflate.so.0 without headers, so it is bound at run time; absent -> the streaming route below).
+// Anything unusual (zero padding, trailing bytes that are no gzip member, a damaged or truncated member, not enough
+// memory) returns false and the streaming zlib route handles the file from the start, so the accepted inputs and the
+// errors are the streaming route's.  C2_FASTQ_GZ = stream | zlib | auto (tests: force a route).
+namespace {
+
+struct Deflate {
+    void* lib = nullptr;
+    void* (*alloc)() = nullptr;
+    void (*release)(void*) = nullptr;
+    int (*gunzip)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;   // libdeflate_gzip_decompress_ex
+    Deflate() {
+        lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return;
+        alloc = (void* (*)())dlsym(lib, "libdeflate_alloc_decompressor");
+        release = (void (*)(void*))dlsym(lib, "libdeflate_free_decompressor");
+        gunzip = (int (*)(void*, const void*, size_t, void*, size_t, size_t*, size_t*))dlsym(lib, "libdeflate_gzip_decompress_ex");
+    }
+    bool ok() const { return alloc && release && gunzip; }
+};
+const Deflate& deflate_lib() { static Deflate d; return d; }
+
+inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+size_t inflate_budget() {                                      // bytes of inflated text the whole-buffer route may hold
+    if (const char* e = getenv("C2_FASTQ_INFLATE_MAX")) return (size_t)strtoull(e, nullptr, 10);
+    const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+    return (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz / 2 : (size_t)4 << 30;
+}
+
+// one complete gzip member -> exactly n_out bytes (zlib checks the CRC and the length)
+bool zlib_gunzip_member(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_out) {
+    z_stream s;
+    memset(&s, 0, sizeof s);
+    if (inflateInit2(&s, 15 + 16) != Z_OK) return false;
+    uint8_t dummy = 0;
+    s.next_in = const_cast<Bytef*>(in); s.avail_in = (uInt)n_in;
+    s.next_out = n_out ? out : &dummy; s.avail_out = (uInt)n_out;
+    const int rc = inflate(&s, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && s.avail_in == 0 && s.total_out == n_out;
+    inflateEnd(&s);
+    return ok;
+}
+
+struct BgzfBlock { size_t at, len, out_at; uint32_t out_len; };
+
+bool bgzf_blocks(const uint8_t* b, size_t n, std::vector<BgzfBlock>& blocks, size_t& total) {
+    size_t p = 0;
+    total = 0;
+    while (p < n) {
+        if (n - p < 26 || b[p] != 0x1f || b[p + 1] != 0x8b || b[p + 2] != 8 || b[p + 3] != 4) return false;   // FLG = FEXTRA only
+        const size_t xlen = (size_t)b[p + 10] | ((size_t)b[p + 11] << 8);
+        if (12 + xlen + 8 > n - p) return false;
+        long bsize = -1;
+        for (size_t q = p + 12, qe = p + 12 + xlen; q + 4 <= qe;) {
+            const size_t slen = (size_t)b[q + 2] | ((size_t)b[q + 3] << 8);
+            if (b[q] == 'B' && b[q + 1] == 'C' && slen == 2 && q + 6 <= qe) bsize = (long)b[q + 4] | ((long)b[q + 5] << 8);
+            q += 4 + slen;
+        }
+        if (bsize < 0) return false;
+        const size_t len = (size_t)bsize + 1;
+        if (len < 12 + xlen + 8 || len > n - p) return false;
+        const uint32_t isize = le32(b + p + len - 4);
+        if (isize > (1u << 16)) return false;                 // a BGZF block holds at most 64 KiB
+        blocks.push_back(BgzfBlock{p, len, total, isize});
+        total += isize;
+        p += len;
+    }
+    return !blocks.empty();
+}
+
+// the inflated text: anonymous pages (transparent huge pages asked for -- first-touch faults of 4 KiB pages cost as much
+// as the inflate itself), grown in place by mremap
+struct TextBuf {
+    char* p = nullptr;
+    size_t cap = 0;
+    TextBuf() {}
+    TextBuf(const TextBuf&) = delete;
+    TextBuf& operator=(const TextBuf&) = delete;
+    ~TextBuf() { if (p) munmap(p, cap); }
+    char* get() const { return p; }
+    bool reserve(size_t n) {
+        n = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (n <= cap) return true;
+        void* q = p ? mremap(p, cap, n, MREMAP_MAYMOVE) : mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) return false;
+        p = (char*)q; cap = n;
+        madvise(p, cap, MADV_HUGEPAGE);
+        return true;
+    }
+};
+
+bool inflate_bgzf(const uint8_t* b, size_t n, bool use_libdeflate, TextBuf& text, size_t& n_text, unsigned threads) {
+    std::vector<BgzfBlock> blocks;
+    size_t total = 0;
+    if (!bgzf_blocks(b, n, blocks, total) || total > inflate_budget()) return false;
+    if (!text.reserve(total ? total : 1)) return false;
+    const Deflate& L = deflate_lib();
+    const bool fast = use_libdeflate && L.ok();
+    std::atomic<size_t> next(0);
+    std::atomic<bool> good(true);
+    const size_t CHUNK = 64;                                   // blocks per grab (<= 4 MiB of text)
+    auto work = [&] {
+        void* d = fast ? L.alloc() : nullptr;
+        if (fast && !d) { good = false; return; }
+        for (;;) {
+            const size_t k0 = next.fetch_add(CHUNK);
+            if (k0 >= blocks.size() || !good.load(std::memory_order_relaxed)) break;
+            const size_t k1 = std::min(blocks.size(), k0 + CHUNK);
+            for (size_t k = k0; k < k1; ++k) {
+                const BgzfBlock& B = blocks[k];
+                uint8_t* o = (uint8_t*)text.get() + B.out_at;
+                bool ok;
+                if (fast) {
+                    size_t ui = 0, uo = 0;
+                    uint8_t dummy = 0;
+                    ok = L.gunzip(d, b + B.at, B.len, B.out_len ? o : &dummy, B.out_len, &ui, &uo) == 0 && ui == B.len && uo == B.out_len;
+                } else {
+                    ok = zlib_gunzip_member(b + B.at, B.len, o, B.out_len);
+                }
+                if (!ok) { good = false; break; }
+            }
+        }
+        if (d) L.release(d);
+    };
+    if (threads > blocks.size() / CHUNK + 1) threads = (unsigned)(blocks.size() / CHUNK + 1);
+    if (threads <= 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work);
+        for (auto& th : pool) th.join();
+    }
+    n_text = total;
+    return good;
+}
+
+bool inflate_members(const uint8_t* b, size_t n, TextBuf& text, size_t& n_text) {
+    const Deflate& L = deflate_lib();
+    if (!L.ok() || n < 18) return false;
+    const size_t budget = inflate_budget();
+    size_t cap = std::max<size_t>((size_t)le32(b + n - 4), 4 * n) + 4096;     // ISIZE of the last member: exact for a one-member file < 4 GiB
+    if (cap > budget) return false;
+    void* d = text.reserve(cap) ? L.alloc() : nullptr;
+    if (!d) return false;
+    cap = text.cap;
+    size_t p = 0, o = 0;
+    bool ok = true;
+    while (p < n) {
+        if (n - p < 18 || b[p] != 0x1f || b[p + 1] != 0x8b) { ok = false; break; }
+        size_t ui = 0, uo = 0;
+        const int rc = L.gunzip(d, b + p, n - p, text.get() + o, cap - o, &ui, &uo);
+        if (rc == 3) {                                         // LIBDEFLATE_INSUFFICIENT_SPACE: grow, inflate this member again
+            if (cap > budget / 2) { ok = false; break; }
+            if (!text.reserve(cap * 2)) { ok = false; break; }
+            cap = text.cap;
+            continue;
+        }
+        if (rc != 0 || ui == 0) { ok = false; break; }
+        p += ui; o += uo;
+    }
+    L.release(d);
+    n_text = o;
+    return ok;
+}
+
+unsigned plain_threads(size_t n) {
+    unsigned threads = std::thread::hardware_concurrency();
+    const unsigned by_size = (unsigned)(n / (8u << 20)) + 1;              // at least 8 MiB per thread
+    if (threads > by_size) threads = by_size;
+    if (const char* e = getenv("C2_FASTQ_THREADS")) threads = (unsigned)atoi(e);   // tests: any count on any size
+    if (threads > 64) threads = 64;
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = (unsigned)n;
+    return threads;
+}
+
+// 1 = parsed into R through the whole-buffer route, 0 = not applicable (use the streaming route), < 0 = error code
+int fastq_unique_gz_whole(const char* path, c2_fastq* R) {
+    const char* route = getenv("C2_FASTQ_GZ");
+    if (route && !strcmp(route, "stream")) return 0;
+    const bool use_libdeflate = !(route && !strcmp(route, "zlib"));
+    const bool trace = getenv("C2_FASTQ_TRACE") != nullptr;
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || st.st_size < 18) { if (fd >= 0) close(fd); return 0; }
+    const size_t n = (size_t)st.st_size;
+    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return 0;
+    const double T0 = now_s();
+    TextBuf text;
+    size_t n_text = 0;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    if (hw > 64) hw = 64;
+    const char* how = "bgzf";
+    bool ok = inflate_bgzf((const uint8_t*)m, n, use_libdeflate, text, n_text, hw);
+    if (!ok && use_libdeflate) { how = "libdeflate"; ok = inflate_members((const uint8_t*)m, n, text, n_text); }
+    munmap(m, n);
+    if (!ok) return 0;
+    if (trace) fprintf(stderr, "c2_fastq: gz whole-buffer route (%s), %zu -> %zu bytes in %.3f s\n", how, n, n_text, now_s() - T0);
+    if (n_text == 0) { R->offsets.push_back(0); return 1; }
+    const int rc = parse_plain_parallel(text.get(), n_text, R, plain_threads(n_text));
+    return rc ? rc : 1;
+}
+
+}  // namespace
+
+
 extern "C" {
 
 const char* c2_fastq_last_error(void) { return g_fastq_error.c_str(); }
@@ -498,15 +723,7 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
             void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m == MAP_FAILED) { close(fd); g_fastq_error = std::string("cannot map ") + path; delete R; return C2_E_INVALID; }
             madvise(m, n, MADV_SEQUENTIAL);
-            unsigned threads = std::thread::hardware_concurrency();
-            const unsigned by_size = (unsigned)(n / (8u << 20)) + 1;          // at least 8 MiB per thread
-            if (threads > by_size) threads = by_size;
-            if (const char* e = getenv("C2_FASTQ_THREADS")) threads = (unsigned)atoi(e);   // tests: any count on any size
-            if (threads > 64) threads = 64;
-            if (threads < 1) threads = 1;
-            if ((size_t)threads > n) threads = (unsigned)n;
-            delete R; R = new c2_fastq;                       // (parse_plain_parallel builds its own tables)
-            rc = parse_plain_parallel((const char*)m, n, R, threads);
+            rc = parse_plain_parallel((const char*)m, n, R, plain_threads(n));
             munmap(m, n);
         } else {
             R->offsets.push_back(0);
@@ -516,7 +733,14 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
         *out = R;
         return 0;
     }
-    // gzip: zlib inflates on one thread while this thread splits lines and de-duplicates the previous block (two buffers)
+    // gzip: whole-buffer route when it applies (BGZF on all threads, or libdeflate) ...
+    {
+        const int w = fastq_unique_gz_whole(path, R);
+        if (w < 0) { g_fastq_error = "more than 2^32 - 2 unique sequences"; delete R; return w; }
+        if (w == 1) { *out = R; return 0; }
+        delete R; R = new c2_fastq;
+    }
+    // ... else zlib inflates on one thread while this thread splits lines and de-duplicates the previous block (two buffers)
     Dedup D(R);
     Lines L(D);
     gzFile f = gzopen(path, "rb");
@@ -546,10 +770,15 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
         cv.notify_all();
     }
     producer.join();
-    if (last < 0) {
-        int errnum = 0;
-        g_fastq_error = std::string("read error in ") + path + ": " + gzerror(f, &errnum);
-        gzclose(f); delete R; return C2_E_INVALID;
+    {
+        // gzread reports a stream that stops before its end-of-stream marker as Z_BUF_ERROR with a return of 0, not -1;
+        // the reference's gzip.open(...) loop dies with EOFError there, so it is an error here too
+        int errnum = Z_OK;
+        const char* what = gzerror(f, &errnum);
+        if (last < 0 || errnum == Z_BUF_ERROR) {
+            g_fastq_error = std::string("read error in ") + path + ": " + (what ? what : "");
+            gzclose(f); delete R; return C2_E_INVALID;
+        }
     }
     gzclose(f);
     L.finish();

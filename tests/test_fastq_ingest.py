@@ -123,6 +123,107 @@ def test_long_lines_across_read_blocks(tmp_path):
     check(p)
 
 
+def bgzf_bytes(data, block=0xff00, level=6, eof=True):
+    """BGZF as bgzip writes it: gzip members with a 'BC' extra subfield holding (member size - 1), <= 64 KiB of text each,
+    and the empty end-of-file member."""
+    import struct
+    import zlib
+    out = []
+    chunks = [data[k:k + block] for k in range(0, len(data), block)] + ([b""] if eof else [])
+    for c in chunks:
+        z = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = z.compress(c) + z.flush()
+        size = 12 + 6 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, size - 1)
+                   + body + struct.pack("<II", zlib.crc32(c), len(c)))
+    return b"".join(out)
+
+
+GZ_ROUTES = ["auto", "zlib", "stream"]
+
+
+@pytest.mark.parametrize("route", GZ_ROUTES)
+def test_gzip_routes_bgzf_members_and_single_stream(tmp_path, monkeypatch, route):
+    """.gz input takes one of three routes (whole-buffer BGZF on all threads, whole-buffer libdeflate, streaming zlib);
+    every route must give the reference's dict for every kind of file, and files a route does not accept fall through."""
+    monkeypatch.setenv("C2_FASTQ_GZ", route)
+    rng = np.random.default_rng(11)
+    text = records(random_seqs(6000, rng)).encode()
+    crlf = records(random_seqs(900, rng), nl="\r\n").encode()
+    files = {
+        "bgzf.fastq.gz": bgzf_bytes(text),
+        "bgzf_small_blocks.fastq.gz": bgzf_bytes(text, block=997),          # block edges inside ids, sequences, terminators
+        "bgzf_no_eof.fastq.gz": bgzf_bytes(text, eof=False),
+        "bgzf_crlf.fastq.gz": bgzf_bytes(crlf, block=1234),
+        "bgzf_then_plain_member.fastq.gz": bgzf_bytes(text[:100000], eof=False) + gzip.compress(text[100000:]),
+        "one_member.fastq.gz": gzip.compress(text, compresslevel=1),
+        "three_members.fastq.gz": gzip.compress(text[:70001]) + gzip.compress(text[70001:70002]) + gzip.compress(text[70002:]),
+        "empty_member_inside.fastq.gz": gzip.compress(text[:5000]) + gzip.compress(b"") + gzip.compress(text[5000:]),
+        "empty_text.fastq.gz": gzip.compress(b""),
+        "empty_bgzf.fastq.gz": bgzf_bytes(b""),
+        "truncated_record.fastq.gz": gzip.compress(b"@a\nACGT\n+\nIIII\n@b\nGGCC"),
+        "stored_blocks.fastq.gz": gzip.compress(text[:200000], compresslevel=0),
+        "with_name_and_comment.fastq.gz": None,
+    }
+    import io
+    bio = io.BytesIO()
+    with gzip.GzipFile(filename="reads_with_a_name.fastq", mode="wb", fileobj=bio, mtime=12345) as fh:
+        fh.write(text[:50000])
+    files["with_name_and_comment.fastq.gz"] = bio.getvalue()
+    for name, blob in files.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        check(p)
+
+
+def test_gzip_whole_buffer_growth_and_memory_budget(tmp_path, monkeypatch):
+    """A highly compressible member outgrows the first buffer estimate (4 x the file) and is inflated again into a larger
+    one; with a budget smaller than the text the file goes through the streaming route.  Same result either way."""
+    seq = "ACGT" * 60
+    text = records([seq] * 20000 + ["TTTT" * 50] * 3).encode()
+    two = gzip.compress(text, compresslevel=9) + gzip.compress(text[:len(records([seq] * 100))], compresslevel=9)
+    assert 4 * len(two) < len(text)                            # the ISIZE hint (last member) and 4 x file are both too small
+    p = tmp_path / "grow.fastq.gz"
+    p.write_bytes(two)
+    check(p)
+    monkeypatch.setenv("C2_FASTQ_INFLATE_MAX", "100000")
+    check(p)
+    q = tmp_path / "bgzf_budget.fastq.gz"
+    q.write_bytes(bgzf_bytes(text))
+    check(q)
+
+
+@pytest.mark.parametrize("route", GZ_ROUTES)
+def test_gzip_damaged_or_padded_files_behave_like_the_streaming_route(tmp_path, monkeypatch, route):
+    """Whatever the whole-buffer routes cannot take as a clean run of members is left to zlib's gzread from the start, so
+    all routes agree: trailing bytes that are no gzip member and zero padding are ignored, a member cut short or with a
+    wrong checksum is a read error."""
+    from crispresso2_amd import _native
+    monkeypatch.setenv("C2_FASTQ_GZ", route)
+    rng = np.random.default_rng(12)
+    text = records(random_seqs(3000, rng)).encode()
+    exp, n = ofq.read_fastq_unique_from_text(text.decode()) if hasattr(ofq, "read_fastq_unique_from_text") else (None, None)
+    good = gzip.compress(text)
+    plain = tmp_path / "same.fastq"
+    plain.write_bytes(text)
+    want = native(plain)
+    for name, blob in {"zero_padded.fastq.gz": good + b"\x00" * 700, "trailing_garbage.fastq.gz": good + b"not a gzip member",
+                       "bgzf_zero_padded.fastq.gz": bgzf_bytes(text) + b"\x00" * 512}.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        assert native(p) == want, name
+    bad_crc = bytearray(good)
+    bad_crc[-6] ^= 0x55
+    bgzf = bytearray(bgzf_bytes(text))
+    bgzf[len(bgzf) // 2] ^= 0xff                                 # damage inside a block's deflate data
+    for name, blob in {"cut_short.fastq.gz": good[:len(good) // 2], "bad_crc.fastq.gz": bytes(bad_crc), "bgzf_damaged.fastq.gz": bytes(bgzf),
+                       "bgzf_cut_short.fastq.gz": bgzf_bytes(text)[:-40 - 28]}.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        with pytest.raises(_native.NativeError):
+            _native.fastq_unique(str(p))
+
+
 def test_missing_file_raises(tmp_path):
     from crispresso2_amd import _native
     with pytest.raises(_native.NativeError):
@@ -303,3 +404,21 @@ def test_paired_bad_base_is_a_key_error(tmp_path):
         ofq.read_paired_fastq_unique(str(p1), str(p2))
     with pytest.raises(KeyError):
         _native.PairedFastq(str(p1), str(p2))
+
+
+def test_paired_gzip_cut_short_is_an_error_like_pythons_eoferror(tmp_path):
+    """gzip.open(...) raises EOFError when a stream stops before its end-of-stream marker; zlib's gzread only sets
+    Z_BUF_ERROR and returns what it has -- the native reader turns that into an error for either file."""
+    from crispresso2_amd import _native
+    rng = np.random.default_rng(21)
+    pairs = random_pairs(400, rng)
+    t1, t2 = paired_records(pairs)
+    g1, g2 = gzip.compress(t1.encode()), gzip.compress(t2.encode())
+    for k, (b1, b2) in enumerate([(g1[:len(g1) // 2], g2), (g1, g2[:len(g2) // 2])]):
+        p1, p2 = tmp_path / ("t%d_1.fastq.gz" % k), tmp_path / ("t%d_2.fastq.gz" % k)
+        p1.write_bytes(b1)
+        p2.write_bytes(b2)
+        with pytest.raises(EOFError):
+            ofq.read_paired_fastq_unique(str(p1), str(p2))
+        with pytest.raises(_native.NativeError):
+            _native.PairedFastq(str(p1), str(p2))

@@ -33,6 +33,21 @@ def python_loop(path):
     return cache
 
 
+def write_bgzf(src, dst, block=0xff00, level=4):
+    """bgzip's format: gzip members of <= 64 KiB of text, each with its compressed size in a 'BC' extra subfield."""
+    import struct
+    import zlib
+    with open(src, "rb") as fin, open(dst, "wb") as fout:
+        while True:
+            c = fin.read(block)
+            z = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = z.compress(c) + z.flush()
+            fout.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+                       + body + struct.pack("<II", zlib.crc32(c), len(c)))
+            if not c:
+                break
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=1_000_000)
@@ -71,7 +86,27 @@ def main():
         assert total == a.reads and len(ref) == len(counts) and sum(ref.values()) == int(counts.sum())
         out[name] = {"native_s": t1 - t0, "native_reads_per_s": a.reads / (t1 - t0), "python_loop_s": t2 - t1,
                      "python_loop_reads_per_s": a.reads / (t2 - t1), "speedup": (t2 - t1) / (t1 - t0), "unique": int(len(counts))}
-    for p in (plain, gz):
+    # the routes a .gz file can take (c2_fastq.cpp): whole-buffer libdeflate (default for a plain gzip stream), BGZF members
+    # inflated by all threads (default for bgzip output), zlib streaming (the fallback)
+    bgzf = os.path.join(d, "r.bgzf.fastq.gz")
+    write_bgzf(plain, bgzf)
+    out["bgzf_bytes"] = os.path.getsize(bgzf)
+    routes = {}
+    for name, path, route in (("gz_stream_zlib", gz, "stream"), ("gz_whole_libdeflate", gz, "auto"),
+                              ("bgzf_threads_libdeflate", bgzf, "auto"), ("bgzf_threads_zlib", bgzf, "zlib"), ("bgzf_stream_zlib", bgzf, "stream")):
+        os.environ["C2_FASTQ_GZ"] = route
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            arena, offsets, counts, total = _native.fastq_unique(path)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        assert total == a.reads and len(counts) == out["plain"]["unique"]
+        routes[name] = {"native_s": best, "native_reads_per_s": a.reads / best}
+    os.environ.pop("C2_FASTQ_GZ", None)
+    out["gz_routes"] = routes
+    out["host_threads"] = os.cpu_count()
+    for p in (plain, gz, bgzf):
         os.remove(p)
     print(json.dumps(out))
 
