@@ -230,3 +230,82 @@ def write_annotated_fastq(fastq_input, fastq_output, variantCache, not_aligned_v
                 notes[seq] = note
             out.write(fastq_id + seq + "\n" + plus + note + "\n" + qual)
             fastq_id = src.readline()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --bam_output: the SAM text (process_single_fastq_write_bam_out, CRISPRessoCORE.py:2351-2515)
+
+# CRISPRessoShared.CIGAR_LOOKUP (CRISPRessoShared.py:426-434): (read column, reference column) -> operation; any other pair
+# of characters is a KeyError there and here
+_CIGAR_OP = {}
+for _a in "ACGTN":
+    for _b in "ACGTN":
+        _CIGAR_OP[(_a, _b)] = 'M'
+    _CIGAR_OP[(_a, '-')] = 'I'
+    _CIGAR_OP[('-', _a)] = 'D'
+del _a, _b
+
+
+def cigar_elements(aln_seq, aln_ref):
+    """`unexplode_cigar(''.join(CIGAR_LOOKUP[x] for x in zip(aln_seq, aln_ref)))` (CRISPRessoShared.py:561-582): run-length
+    elements such as ['93M', '3D', '127M']."""
+    els, prev, run = [], None, 0
+    for pair in zip(aln_seq, aln_ref):
+        op = _CIGAR_OP[pair]
+        if op == prev:
+            run += 1
+        else:
+            if prev is not None:
+                els.append(str(run) + prev)
+            prev, run = op, 1
+    if prev is not None:
+        els.append(str(run) + prev)
+    return els
+
+
+_COMPLEMENT = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A', 'N': 'N', '_': '_', '-': '-'}
+
+
+def sam_entry(fastq_id, seq, qual, variant, refs):
+    """The eleven SAM columns + the `c2:Z:` field of one read (:2398-2496) as a list of strings.  A read that did not align
+    is unmapped (flag 4); an aligned read sits on its first assigned reference's contig (`refs[name]['aln_chr']`,
+    `['aln_start']`), flag 16 when read and contig strands differ; on a '-' strand contig the CIGAR elements, the read and
+    the qualities are reversed (:2464-2472).  The optional field is the --fastq_output annotation behind `c2:Z:`."""
+    note = "c2:Z:" + crispresso2_annotation(variant)[1:]
+    if variant['best_match_score'] <= 0:
+        return [fastq_id, '4', '*', '0', '0', '*', '*', '0', '0', seq, qual, note]
+    first = variant['aln_ref_names'][0]
+    p = variant['variant_' + first]
+    els = cigar_elements(p['aln_seq'], p['aln_ref'])
+    flag = '16' if p['aln_strand'] == '-' else '0'
+    cigar = ''.join(els)
+    if refs[first]['aln_strand'] == '-':
+        flag = '0' if flag == '16' else '16'
+        cigar = ''.join(els[::-1])
+        seq = ''.join(_COMPLEMENT[c] for c in reversed(seq.upper()))       # CRISPRessoShared.reverse_complement (:399-403)
+        qual = qual[::-1]
+    return [fastq_id, flag, refs[first]['aln_chr'], str(refs[first]['aln_start']), str(int(variant['best_match_score'])), cigar,
+            '*', '0', '0', seq, qual, note]
+
+
+def write_annotated_sam(fastq_input, sam_output, bam_header, variantCache, not_aligned_variants, refs):
+    """Second half of process_single_fastq_write_bam_out (:2385-2500): `bam_header`, then one SAM line per input record, in
+    input order.  Like the reference: the id is the stripped first line without its first character and an empty id ends the
+    loop; a read in neither dict writes nothing; every aligned read's dict gets its columns under 'sam_entry'.  What the
+    reference does next -- `samtools sort` + `samtools index` into the .bam -- is the caller's business (samtools is an
+    external program there too)."""
+    with open(sam_output, 'wt') as out, _open_text(fastq_input) as src:
+        out.write(bam_header)
+        fastq_id = src.readline().strip()[1:]
+        while fastq_id:
+            seq = src.readline().strip()
+            src.readline()
+            qual = src.readline().strip()
+            if seq in not_aligned_variants:
+                out.write("\t".join(sam_entry(fastq_id, seq, qual, not_aligned_variants[seq], refs)) + "\n")
+            if seq in variantCache:
+                variant = variantCache[seq]
+                entry = sam_entry(fastq_id, seq, qual, variant, refs)
+                variant['sam_entry'] = entry
+                out.write("\t".join(entry) + "\n")
+            fastq_id = src.readline().strip()[1:]

@@ -234,6 +234,17 @@ def process_fastq_write_out(fastq_input, fastq_output, args, refs, ref_names, al
     return cache, not_aligned, st
 
 
+def process_single_fastq_write_bam_out(fastq_input, bam_output, bam_header, args, refs, ref_names, aln_matrix, pe_scaffold_dna_info=None, ctx=None):
+    """process_single_fastq_write_bam_out equivalent (CRISPRessoCORE.py:2351-2515) up to the SAM text: process_fastq, then
+    `bam_output + ".sam"` with the header and one line per input read (`refs[name]` must carry aln_chr / aln_start /
+    aln_strand, as the reference requires).  Sorting and indexing that file into `bam_output` is `samtools`' job in the
+    reference (:2503) and is left to the caller here.  -> (variantCache, not_aligned_variants, aln_stats)"""
+    from . import variant_io
+    cache, not_aligned, st = process_fastq(fastq_input, args, refs, ref_names, aln_matrix, pe_scaffold_dna_info, ctx=ctx)
+    variant_io.write_annotated_sam(fastq_input, bam_output + ".sam", bam_header, cache, not_aligned, refs)
+    return cache, not_aligned, st
+
+
 def process_fastq_sharded(path, args, refs, ref_names, aln_matrix, variants_dir, pe_scaffold_dna_info=None, ctx=None,
                           rank=None, world=None, get_variants=None):
     """The reference's n_processes > 1 route (CRISPRessoCORE.py:1870-1985) with one GPU rank in place of each worker

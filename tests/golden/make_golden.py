@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -661,6 +661,72 @@ if __name__ == "__main__" and "--variant-io" in sys.argv:
     with gzip.open(os.path.join(HERE, "variant_io.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("variant_io.json.gz written:", [(c["label"], len(c["tsv"]), c["single"]["aln_stats"]["N_TOT_READS"]) for c in d["cases"]])
+
+
+# ---------------------------------------------------------------- 8b. --bam_output: the SAM text of process_single_fastq_write_bam_out, CRISPRessoCORE.py:2351-2515
+def sam_output_goldens():
+    """The reference's process_single_fastq_write_bam_out on the FASTQ of variant_io.json.gz: the .sam text it writes before it
+    hands over to `samtools sort` (not installed here: the call fails AFTER the file is complete, and debug=True keeps the
+    file).  Amplicons as their own contigs (:3473-3486) on the '+' strand, and once on the '-' strand at an offset (what the
+    bowtie2 route records in refs[...]['aln_*']).  The variant dicts the reference computed are recorded as its own
+    variants TSV lines, so the writer can be checked on the CPU from them."""
+    import gzip
+    from crispresso2_amd import refs as RF
+    core = load_reference_core()
+    with gzip.open(os.path.join(HERE, "variant_io.json.gz"), "rt") as fh:
+        vio = json.load(fh)
+    out = {"cases": []}
+    for case, strand, start in [(vio["cases"][0], "+", 1), (vio["cases"][1], "+", 1), (vio["cases"][2], "-", 1001), (vio["cases"][1], "-", 77)]:
+        base = dict(case["args"])
+        base.update(debug=True, fastq_output=False, bam_output=True)
+        refs, names = {}, []
+        header = '@HD\tVN:1.0\tSO:unknown\n'
+        for r in case["refs"]:
+            nm = r["name"]
+            refs[nm] = RF.make_ref(nm, r["sequence"], r["cut_points"], r["include_idxs"], r["min_aln_score"])
+            refs[nm].update(aln_genome='None', aln_chr=nm if strand == "+" else "chr_" + nm, aln_start=start,
+                            aln_end=start + len(r["sequence"]) - 1, aln_strand=strand)
+            header += '@SQ\tSN:%s\tLN:%s\n' % (refs[nm]["aln_chr"], len(r["sequence"]))
+            names.append(nm)
+        header += '@PG\tID:crispresso2\tPN:crispresso2\tVN:2.3.4\tCL:"CRISPResso -r1 in.fastq --bam_output"\n'
+        with tempfile.TemporaryDirectory() as tmp:
+            fq = os.path.join(tmp, "in.fastq")
+            with open(fq, "w") as fh:
+                fh.write(vio["fastq"])
+            args = types.SimpleNamespace(n_processes="1", **base)
+            cache = {}
+            bam = os.path.join(tmp, "out.bam")
+            try:
+                core.process_single_fastq_write_bam_out(fq, bam, header, cache, names, refs, args, [], tmp)
+                raise SystemExit("samtools is installed?  the golden expects the sort step to fail after the .sam is written")
+            except core.CRISPRessoShared.BadParameterException:
+                pass
+            with open(bam + ".sam") as fh:
+                sam = fh.read()
+            # the dicts as the reference serialises them (sam_entry is added by the writer itself: leave it out)
+            enc = core.CRISPRessoShared.CRISPRessoJSONEncoder
+            lines = []
+            for k, v in cache.items():
+                v = dict(v)
+                v.pop("sam_entry", None)
+                lines.append(k + "\t" + json.dumps(v, cls=enc))
+            # the not-aligned reads are only returned by process_fastq: run it again for them
+            cache2 = {}
+            st, not_aln = core.process_fastq(fq, cache2, names, refs, types.SimpleNamespace(n_processes="1", **base), [], tmp)
+            na_lines = [k + "\t" + json.dumps(v, cls=enc) for k, v in not_aln.items()]
+        out["cases"].append({"label": case["label"] + " strand" + strand + " start%d" % start, "args": base, "refs": case["refs"],
+                             "aln": {nm: {k: refs[nm][k] for k in ("aln_genome", "aln_chr", "aln_start", "aln_end", "aln_strand")} for nm in names},
+                             "header": header, "sam": sam, "variant_lines": lines, "not_aligned_lines": na_lines})
+    out["fastq"] = vio["fastq"]
+    return out
+
+
+if __name__ == "__main__" and "--sam" in sys.argv:
+    import gzip
+    d = sam_output_goldens()
+    with gzip.open(os.path.join(HERE, "sam_output.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("sam_output.json.gz written:", [(c["label"], c["sam"].count("\n"), len(c["variant_lines"]), len(c["not_aligned_lines"])) for c in d["cases"]])
 
 
 # ---------------------------------------------------------------- 9. paired FASTQ files through process_paired_fastq (-p 2), CRISPRessoCORE.py:1245-1733

@@ -158,3 +158,66 @@ def test_two_rank_variant_files_merge_to_the_reference_result(gold, tmp_path):
         got = json.load(fh)
     assert got["st"] == case["multi"]["aln_stats"] and got["not_aligned"] == case["multi"]["not_aligned"]
     assert got["aligned"] == case["multi"]["aligned"] and got["counts"] == case["multi"]["counts"]
+
+
+def test_sam_text_of_bam_output_equals_the_reference_file():
+    """--bam_output (CRISPRessoCORE.py:2351-2515): the .sam text the reference writes before `samtools sort`, from the variant
+    dicts IT computed (recorded as its own JSON lines by make_golden.py --sam): contigs on both strands, start offsets,
+    unmapped reads, two assigned references per read (expand_ambiguous_alignments); every dict gets its 'sam_entry'."""
+    from crispresso2_amd import variant_io as IO
+    import tempfile
+    gold = load_golden("sam_output.json.gz")
+    n_lines = n_rev = n_unmapped = 0
+    for case in gold["cases"]:
+        cache, not_aln = {}, {}
+        for bucket, lines in ((cache, case["variant_lines"]), (not_aln, case["not_aligned_lines"])):
+            for line in lines:
+                seq, js = line.split("\t")
+                bucket[seq] = json.loads(js, cls=IO.CRISPRessoJSONDecoder)
+        with tempfile.TemporaryDirectory() as tmp:
+            fq = _write(os.path.join(tmp, "in.fastq"), gold["fastq"])
+            sam = os.path.join(tmp, "out.bam.sam")
+            IO.write_annotated_sam(fq, sam, case["header"], cache, not_aln, case["aln"])
+            with open(sam) as fh:
+                text = fh.read()
+        assert text == case["sam"], case["label"]
+        body = [l.split("\t") for l in text.splitlines() if not l.startswith("@")]
+        n_lines += len(body)
+        n_rev += sum(f[1] == "16" for f in body)
+        n_unmapped += sum(f[1] == "4" for f in body)
+        assert all(len(f) == 12 for f in body)
+        assert all(v["sam_entry"][9] in (k, IO.sam_entry("x", k, "", v, case["aln"])[9]) for k, v in cache.items())
+    assert n_lines == 4 * 302 and n_rev > 100 and n_unmapped == 4 * 20
+
+
+def test_cigar_elements_and_unknown_symbols():
+    from crispresso2_amd import variant_io as IO
+    assert IO.cigar_elements("AC--GTNA", "ACGGGT-A") == ["2M", "2D", "2M", "1I", "1M"]
+    assert IO.cigar_elements("", "") == []
+    with pytest.raises(KeyError):                                   # the reference's table has no lower case / IUPAC / double gap
+        IO.cigar_elements("AcG", "ACG")
+    with pytest.raises(KeyError):
+        IO.cigar_elements("A-G", "A-G")
+
+
+@pytest.mark.gpu
+def test_bam_output_sam_text_from_the_device_route(tmp_path):
+    """process_single_fastq_write_bam_out with the variant dicts computed on the GPU (device alignments + device classifier):
+    the reference's .sam text byte for byte, for every recorded case."""
+    from helpers import matrices
+    from crispresso2_amd import _native, refs as RF, variants as V
+    ctx = _native.default_context()
+    gold = load_golden("sam_output.json.gz")
+    fq = _write(tmp_path / "in.fastq", gold["fastq"])
+    for k, case in enumerate(gold["cases"]):
+        args = types.SimpleNamespace(**case["args"])
+        refs, names = {}, []
+        for r in case["refs"]:
+            refs[r["name"]] = RF.make_ref(r["name"], r["sequence"], r["cut_points"], r["include_idxs"], r["min_aln_score"])
+            refs[r["name"]].update(case["aln"][r["name"]])
+            names.append(r["name"])
+        bam = str(tmp_path / ("out%d.bam" % k))
+        cache, not_aligned, st = V.process_single_fastq_write_bam_out(fq, bam, case["header"], args, refs, names, matrices()["EDNAFULL"], ctx=ctx)
+        with open(bam + ".sam") as fh:
+            assert fh.read() == case["sam"], case["label"]
+        assert st["N_TOT_READS"] == 302 and len(not_aligned) == len(case["not_aligned_lines"])
