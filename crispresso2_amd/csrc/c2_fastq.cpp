@@ -664,18 +664,12 @@ unsigned plain_threads(size_t n) {
 }
 
 // 1 = parsed into R through the whole-buffer route, 0 = not applicable (use the streaming route), < 0 = error code
-int fastq_unique_gz_whole(const char* path, c2_fastq* R) {
+int fastq_unique_gz_whole(const uint8_t* m, size_t n, c2_fastq* R) {
     const char* route = getenv("C2_FASTQ_GZ");
     if (route && !strcmp(route, "stream")) return 0;
     const bool use_libdeflate = !(route && !strcmp(route, "zlib"));
     const bool trace = getenv("C2_FASTQ_TRACE") != nullptr;
-    const int fd = open(path, O_RDONLY);
-    struct stat st;
-    if (fd < 0 || fstat(fd, &st) != 0 || st.st_size < 18) { if (fd >= 0) close(fd); return 0; }
-    const size_t n = (size_t)st.st_size;
-    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return 0;
+    if (n < 18) return 0;
     const double T0 = now_s();
     TextBuf text;
     size_t n_text = 0;
@@ -683,15 +677,63 @@ int fastq_unique_gz_whole(const char* path, c2_fastq* R) {
     if (hw < 1) hw = 1;
     if (hw > 64) hw = 64;
     const char* how = "bgzf";
-    bool ok = inflate_bgzf((const uint8_t*)m, n, use_libdeflate, text, n_text, hw);
-    if (!ok && use_libdeflate) { how = "libdeflate"; ok = inflate_members((const uint8_t*)m, n, text, n_text); }
-    munmap(m, n);
+    bool ok = inflate_bgzf(m, n, use_libdeflate, text, n_text, hw);
+    if (!ok && use_libdeflate) { how = "libdeflate"; ok = inflate_members(m, n, text, n_text); }
     if (!ok) return 0;
     if (trace) fprintf(stderr, "c2_fastq: gz whole-buffer route (%s), %zu -> %zu bytes in %.3f s\n", how, n, n_text, now_s() - T0);
     if (n_text == 0) { R->offsets.push_back(0); return 1; }
     const int rc = parse_plain_parallel(text.get(), n_text, R, plain_threads(n_text));
     return rc ? rc : 1;
 }
+
+// The streaming route: Python's gzip reader (gzip.py, _GzipReader) over the mapped file with zlib's inflate -- members back
+// to back; zero bytes after a member are skipped; anything else where a member should start is BadGzipFile("Not a gzipped
+// file") there; input that ends inside a member is EOFError there; a wrong CRC / length is BadGzipFile.  All errors here.
+// (zlib's own gzread ignores trailing bytes and reports a truncated stream as end of file.)
+struct GzMembers {
+    const uint8_t* b = nullptr;
+    size_t n = 0, pos = 0;
+    z_stream zs;
+    bool open = false, done = false;
+    std::string err;
+    ~GzMembers() { if (open) inflateEnd(&zs); }
+    bool init(const uint8_t* b_, size_t n_) {
+        b = b_; n = n_;
+        memset(&zs, 0, sizeof zs);
+        open = inflateInit2(&zs, 15 + 16) == Z_OK;
+        if (!open) err = "zlib: inflateInit2 failed";
+        return open;
+    }
+    // up to cap bytes of text into out; 0 = end of the data, -1 = error (err says which)
+    long read(char* out, size_t cap) {
+        size_t got = 0;
+        while (got < cap && !done) {
+            if (zs.avail_in == 0) {
+                const size_t take = std::min<size_t>(n - pos, (size_t)1 << 30);
+                if (take == 0) { err = "Compressed file ended before the end-of-stream marker was reached"; return -1; }
+                zs.next_in = const_cast<Bytef*>(b + pos); zs.avail_in = (uInt)take; pos += take;
+            }
+            const size_t room = std::min<size_t>(cap - got, (size_t)1 << 30);
+            zs.next_out = (Bytef*)out + got; zs.avail_out = (uInt)room;
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            got += room - zs.avail_out;
+            if (rc == Z_STREAM_END) {
+                size_t p = pos - zs.avail_in;                  // first byte after this member
+                while (p < n && b[p] == 0) ++p;
+                if (p == n) { done = true; break; }
+                if (n - p < 2 || b[p] != 0x1f || b[p + 1] != 0x8b) { err = "Not a gzipped file (bytes after the last member)"; return -1; }
+                inflateReset(&zs);
+                pos = p; zs.avail_in = 0;
+            } else if (rc == Z_BUF_ERROR) {
+                if (zs.avail_in != 0 && zs.avail_out != 0) { err = "zlib: no progress"; return -1; }
+            } else if (rc != Z_OK) {
+                err = zs.msg ? zs.msg : "invalid gzip data";
+                return -1;
+            }
+        }
+        return (long)got;
+    }
+};
 
 }  // namespace
 
@@ -733,9 +775,18 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
         *out = R;
         return 0;
     }
-    // gzip: whole-buffer route when it applies (BGZF on all threads, or libdeflate) ...
+    // gzip: the file is mapped; whole-buffer route when it applies (BGZF on all threads, or libdeflate) ...
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); g_fastq_error = std::string("cannot open ") + path; delete R; return C2_E_INVALID; }
+    const size_t n = (size_t)st.st_size;
+    void* mapped = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (mapped == MAP_FAILED) { g_fastq_error = std::string("cannot map ") + path; delete R; return C2_E_INVALID; }
+    struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{mapped, n};
+    const uint8_t* m = (const uint8_t*)mapped;
     {
-        const int w = fastq_unique_gz_whole(path, R);
+        const int w = fastq_unique_gz_whole(m, n, R);
         if (w < 0) { g_fastq_error = "more than 2^32 - 2 unique sequences"; delete R; return w; }
         if (w == 1) { *out = R; return 0; }
         delete R; R = new c2_fastq;
@@ -743,24 +794,23 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
     // ... else zlib inflates on one thread while this thread splits lines and de-duplicates the previous block (two buffers)
     Dedup D(R);
     Lines L(D);
-    gzFile f = gzopen(path, "rb");
-    if (!f) { g_fastq_error = std::string("cannot open ") + path; delete R; return C2_E_INVALID; }
-    gzbuffer(f, 1u << 20);
+    GzMembers gm;
+    if (!gm.init(m, n)) { g_fastq_error = gm.err; delete R; return C2_E_INVALID; }
     std::vector<char> bufs[2] = {std::vector<char>(8u << 20), std::vector<char>(8u << 20)};
-    int got[2] = {0, 0};
+    long got[2] = {0, 0};
     std::mutex mu;
     std::condition_variable cv;
     int filled[2] = {0, 0};                                   // 0 free, 1 holds data (got[] valid; got <= 0 ends the stream)
     std::thread producer([&] {
         for (int k = 0;; k ^= 1) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[k] == 0; }); }
-            const int g = gzread(f, bufs[k].data(), (unsigned)bufs[k].size());
+            const long g = gm.read(bufs[k].data(), bufs[k].size());
             { std::lock_guard<std::mutex> lk(mu); got[k] = g; filled[k] = 1; }
             cv.notify_all();
             if (g <= 0) return;
         }
     });
-    int last = 0;
+    long last = 0;
     for (int k = 0;; k ^= 1) {
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[k] == 1; }); }
         last = got[k];
@@ -770,17 +820,7 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
         cv.notify_all();
     }
     producer.join();
-    {
-        // gzread reports a stream that stops before its end-of-stream marker as Z_BUF_ERROR with a return of 0, not -1;
-        // the reference's gzip.open(...) loop dies with EOFError there, so it is an error here too
-        int errnum = Z_OK;
-        const char* what = gzerror(f, &errnum);
-        if (last < 0 || errnum == Z_BUF_ERROR) {
-            g_fastq_error = std::string("read error in ") + path + ": " + (what ? what : "");
-            gzclose(f); delete R; return C2_E_INVALID;
-        }
-    }
-    gzclose(f);
+    if (last < 0) { g_fastq_error = std::string("read error in ") + path + ": " + gm.err; delete R; return C2_E_INVALID; }
     L.finish();
     if (!L.ok) { g_fastq_error = "more than 2^32 - 2 unique sequences"; delete R; return C2_E_TOO_LARGE; }
     *out = R;
