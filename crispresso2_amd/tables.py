@@ -5,6 +5,11 @@
     <ref>Quantification_window_nucleotide_{frequency,percentage}_table.txt      plots/data_prep.py:3509-3570 (pandas to_csv of float vectors)
     <ref>Modification_count_vectors.txt, <ref>Quantification_window_modification_count_vectors.txt   CRISPRessoCORE.py:4604-4609, :4668-4687
     Alleles_frequency_table.txt (unzipped)                                                           CRISPRessoCORE.py:3926-4010, :4298-4303, :4498-4509
+    CRISPResso_mapping_statistics.txt                                                                CRISPRessoCORE.py:4591-4594
+    <ref>Effect_vector_{insertion,deletion,substitution,combined}.txt  (np.savetxt '%d', '%.18e')    CRISPRessoCORE.py:4380-4390, :4600-4602, :4650-4665
+    <ref>Indel_histogram.txt, <ref>Insertion_histogram.txt, <ref>Deletion_histogram.txt, <ref>Substitution_histogram.txt
+                                                                                                     CRISPRessoCORE.py:4349-4377, :4750-4775
+(the reference writes the effect vectors and histograms only when it also draws its plots; here they are always written)
 
 `res` is a pipeline.QuantResult.  File names carry the reference's prefix rule: no prefix for a single amplicon named
 'Reference', else '<name>.' (CRISPRessoCORE.py:4618-4640).  The reference accumulates these vectors in float64 numpy
@@ -67,12 +72,49 @@ def write_alleles_frequency_table(res, path):
             fh.write("%s\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%s\n" % (a, r, name, status, dn, inn, sn, reads, _f(pct)))
 
 
+def write_mapping_statistics(res, path):
+    """CRISPResso_mapping_statistics.txt (:4591-4594).  Without a preprocessing step (no trimming / merging: out of scope
+    here) the reads after preprocessing are the reads in the input."""
+    st = res.stats
+    n_in = st.get("N_READS_INPUT", st["N_TOT_READS"])
+    vals = [n_in, st.get("N_READS_AFTER_PREPROCESSING", n_in), st["N_TOTAL"], st["N_COMPUTED_ALN"], st["N_CACHED_ALN"],
+            st["N_COMPUTED_NOTALN"], st["N_CACHED_NOTALN"]]
+    with open(path, "w") as fh:
+        fh.write("READS IN INPUTS\tREADS AFTER PREPROCESSING\tREADS ALIGNED\tN_COMPUTED_ALN\tN_CACHED_ALN\tN_COMPUTED_NOTALN\tN_CACHED_NOTALN\n")
+        fh.write("\t".join(str(x) for x in vals) + "\n")
+
+
+def _write_effect_vector(path, vector):
+    """save_vector_to_file (:4600-4602): np.savetxt of (position, value) rows, fmt '%d' / '%.18e', '# '-commented header."""
+    with open(path, "w") as fh:
+        fh.write("# amplicon position\teffect\n")
+        for k, x in enumerate(vector):
+            fh.write("%d\t%.18e\n" % (k + 1, x))
+
+
+def _histogram_bins(hist, floor):
+    """x = 0 .. max(floor, largest key), y = the counts (:4349-4358; missing keys count 0)."""
+    top = max(floor, max(hist.keys() or [0]))
+    return list(range(top + 1)), [int(hist.get(x, 0)) for x in range(top + 1)]
+
+
+def _write_histogram(path, columns, xs, ys):
+    with open(path, "w") as fh:
+        fh.write("%s\t%s\n" % columns)
+        for x, y in zip(xs, ys):
+            fh.write("%d\t%d\n" % (x, y))
+
+
 def write_tables(res, refs, ref_names, out_dir):
     """Writes the tables listed in the module docstring into out_dir; returns the list of file names."""
+    import numpy as np
     os.makedirs(out_dir, exist_ok=True)
     written = ["CRISPResso_quantification_of_editing_frequency.txt", "Alleles_frequency_table.txt"]
     write_quantification_of_editing_frequency(res, ref_names, os.path.join(out_dir, written[0]))
     write_alleles_frequency_table(res, os.path.join(out_dir, written[1]))
+    if all(k in res.stats for k in ("N_TOTAL", "N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN")):
+        written.append("CRISPResso_mapping_statistics.txt")
+        write_mapping_statistics(res, os.path.join(out_dir, written[-1]))
     nucs = ["A", "C", "G", "T", "N", "-"]
     for name in ref_names:
         c = res.per_ref[name]
@@ -92,6 +134,27 @@ def write_tables(res, refs, ref_names, out_dir):
         fn = prefix + "Modification_count_vectors.txt"
         _write_count_vectors(os.path.join(out_dir, fn), seq, [fl(a_ins), fl(a_insl), fl(a_del), fl(a_sub), fl(a_ins + a_del + a_sub), tot_row],
                              ["Insertions", "Insertions_Left", "Deletions", "Substitutions", "All_modifications", "Total"])
+        written.append(fn)
+        # effect vectors: 100 * window count vector / reads of this amplicon, zeros without reads (:4380-4415)
+        win = {"insertion": ins[:L], "deletion": dele[:L], "substitution": sub[:L], "combined": (ins + dele + sub)[:L]}
+        for kind, vec in win.items():
+            fn = prefix + "Effect_vector_%s.txt" % kind
+            v = 100 * np.asarray(vec, dtype=np.float64) / total if total > 0 else np.zeros(L)
+            _write_effect_vector(os.path.join(out_dir, fn), v)
+            written.append(fn)
+        # histograms of the per-read counts in the quantification window and of the effective length (:4349-4377, :4750-4775)
+        for fn, cols, hist, sign in ((prefix + "Insertion_histogram.txt", ("ins_size", "fq"), c["inserted_n"], 1),
+                                     (prefix + "Deletion_histogram.txt", ("del_size", "fq"), c["deleted_n"], -1),
+                                     (prefix + "Substitution_histogram.txt", ("sub_count", "fq"), c["substituted_n"], 1)):
+            xs, ys = _histogram_bins(hist, 15)
+            _write_histogram(os.path.join(out_dir, fn), cols, [sign * x for x in xs], ys)
+            written.append(fn)
+        eff = c["effective_len"]
+        lo = min(L - 15, min(eff.keys() or [0]))                   # (with no reads the reference's range starts at 0)
+        hi = max(L + 15, max(eff.keys() or [0]))
+        fn = prefix + "Indel_histogram.txt"
+        _write_histogram(os.path.join(out_dir, fn), ("indel_size", "fq"), [x - L for x in range(lo, hi + 1)],
+                         [int(eff.get(x, 0)) for x in range(lo, hi + 1)])
         written.append(fn)
         if total < 1:                                              # plots/data_prep.py:3510
             continue

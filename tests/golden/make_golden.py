@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -442,6 +442,53 @@ if __name__ == "__main__" and "--fanc" in sys.argv:
     with gzip.open(os.path.join(HERE, "fanc_run.json.gz"), "wt") as fh:
         json.dump(fanc_run(), fh, separators=(",", ":"))
     print("fanc_run.json.gz written")
+
+
+# ---------------------------------------------------------------- 6b. every text file of the reference's FANC.Cas9 run
+def fanc_full_run():
+    """The reference's main() on its own end-to-end test (CRISPResso -r1 FANC.Cas9.fastq -a ... -g ...) run HERE, with the
+    plot functions replaced by no-ops (matplotlib/seaborn are not what is recorded) but WITHOUT --suppress_plots, so that
+    the files it only writes next to its plots (effect vectors, histograms) exist: every .txt file of the output folder and
+    the unzipped allele table.  The two files the reference repository keeps for this test are among them, identical."""
+    import importlib
+    import zipfile
+    core = load_reference_core()
+    P = importlib.import_module("CRISPResso2.plots.CRISPRessoPlot")
+    for k in dir(P):
+        if k.startswith("plot_") and callable(getattr(P, k)):
+            setattr(P, k, (lambda *a, **kw: None))
+    g = fanc_run()
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fq = os.path.join(tmp, "FANC.Cas9.fastq")
+        with open(fq, "w") as fh:
+            fh.write(g["fastq"])
+        argv = sys.argv
+        sys.argv = ["CRISPResso", "-r1", fq, "-a", g["amplicon"], "-g", g["guide"], "--suppress_report", "-o", tmp]
+        try:
+            core.main()
+        except SystemExit as e:
+            assert e.code in (0, None), e.code
+        finally:
+            sys.argv = argv
+        out = os.path.join(tmp, "CRISPResso_on_FANC.Cas9")
+        for fn in sorted(os.listdir(out)):
+            if fn.endswith(".txt") and fn != "CRISPResso_RUNNING_LOG.txt":
+                with open(os.path.join(out, fn)) as fh:
+                    files[fn] = fh.read()
+        with zipfile.ZipFile(os.path.join(out, "Alleles_frequency_table.zip")) as z:
+            files["Alleles_frequency_table.txt"] = z.read("Alleles_frequency_table.txt").decode()
+    for fn, text in g["expected_files"].items():
+        assert files[fn] == text, fn
+    return {"amplicon": g["amplicon"], "guide": g["guide"], "cut_point": g["cut_point"], "files": files}
+
+
+if __name__ == "__main__" and "--fanc-full" in sys.argv:
+    import gzip
+    d = fanc_full_run()
+    with gzip.open(os.path.join(HERE, "fanc_full_run.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("fanc_full_run.json.gz written:", {k: len(v) for k, v in d["files"].items()})
 
 
 # ---------------------------------------------------------------- 7. paired reads (CRISPRessoCORE.py:800-1169)
