@@ -9,6 +9,8 @@
     <ref>Effect_vector_{insertion,deletion,substitution,combined}.txt  (np.savetxt '%d', '%.18e')    CRISPRessoCORE.py:4380-4390, :4600-4602, :4650-4665
     <ref>Indel_histogram.txt, <ref>Insertion_histogram.txt, <ref>Deletion_histogram.txt, <ref>Substitution_histogram.txt
                                                                                                      CRISPRessoCORE.py:4349-4377, :4750-4775
+    <ref>Alleles_frequency_table_around_<guide>.txt  (when refs[name] carries 'sgRNA_orig_sequences')   CRISPRessoShared.py:1513-1531,
+                                                                                                     plots/data_prep.py:285-301, CRISPRessoCORE.py:5250-5273
 (the reference writes the effect vectors and histograms only when it also draws its plots; here they are always written)
 
 `res` is a pipeline.QuantResult.  File names carry the reference's prefix rule: no prefix for a single amplicon named
@@ -105,9 +107,65 @@ def _write_histogram(path, columns, xs, ys):
             fh.write("%d\t%d\n" % (x, y))
 
 
-def write_tables(res, refs, ref_names, out_dir):
+def alleles_around_cut(rows, ref_name, cut_point, ref_len, plot_window_size=20):
+    """Rows of <ref>Alleles_frequency_table_around_<sgRNA>.txt from the allele table rows of `QuantResult.alleles()`:
+    CRISPRessoShared.get_dataframe_around_cut_asymmetrical (CRISPRessoShared.py:1513-1531) with the window of
+    plots/data_prep.py:285-301 (`plot_window_size` bases either side of the cut, clipped at the amplicon's ends).  Every allele
+    of THIS reference is cut down to the alignment columns around the column that holds reference base `cut_point`
+    (`ref_positions.index(cut_point)`: gap columns carry negative positions and never match), alleles that coincide there
+    (same two strings, same Unedited flag and edit counts) are merged -- #Reads added, %Reads added the way pandas' groupby
+    adds floats (Kahan-compensated, in table order) -- and sorted by #Reads descending, then the two strings.
+    -> list of (Aligned_Sequence, Reference_Sequence, Unedited, n_deleted, n_inserted, n_mutated, #Reads, %Reads)"""
+    left = plot_window_size if cut_point - plot_window_size + 1 >= 0 else cut_point + 1
+    right = plot_window_size if cut_point + plot_window_size < ref_len else ref_len - cut_point - 1
+    groups = {}
+    for a, r, name, status, dn, inn, sn, reads, pct in rows:
+        if name != ref_name:
+            continue
+        seen, cut_idx = -1, -1
+        for col, ch in enumerate(r):
+            if ch != '-':
+                seen += 1
+                if seen == cut_point:
+                    cut_idx = col
+                    break
+        if cut_idx < 0:
+            raise ValueError("%d is not in list" % cut_point)          # ref_positions.index(cut_point)
+        key = (a[cut_idx - left + 1:cut_idx + right + 1], r[cut_idx - left + 1:cut_idx + right + 1],
+               status == 'UNMODIFIED', int(dn), int(inn), int(sn))
+        g = groups.get(key)
+        if g is None:
+            g = groups[key] = [0, 0.0, 0.0]                              # #Reads, %Reads, its compensation term
+        g[0] += int(reads)
+        y = float(pct) - g[2]
+        t = g[1] + y
+        g[2] = t - g[1] - y
+        g[1] = t
+    out = [k + (g[0], g[1]) for k, g in sorted(groups.items())]         # groupby(sort=True) order, then a stable sort
+    out.sort(key=lambda t: (-t[6], t[0], t[1]))
+    return out
+
+
+def slugify(value):
+    """CRISPRessoShared.slugify (CRISPRessoShared.py:418-423): file-name form of a guide label."""
+    import re
+    import unicodedata
+    value = unicodedata.normalize('NFKD', value).encode('ascii', 'ignore')
+    value = re.sub(rb'[\s\'*"/\\\[\]:;|,<>?]', b'_', value).strip()
+    return re.sub(rb'_{2,}', b'_', value).decode('utf-8')
+
+
+def write_alleles_around_cut(rows, path):
+    with open(path, "w") as fh:
+        fh.write("Aligned_Sequence\tReference_Sequence\tUnedited\tn_deleted\tn_inserted\tn_mutated\t#Reads\t%Reads\n")
+        for a, r, unedited, dn, inn, sn, reads, pct in rows:
+            fh.write("%s\t%s\t%s\t%d\t%d\t%d\t%d\t%s\n" % (a, r, "True" if unedited else "False", dn, inn, sn, reads, _f(pct)))
+
+
+def write_tables(res, refs, ref_names, out_dir, plot_window_size=20):
     """Writes the tables listed in the module docstring into out_dir; returns the list of file names."""
     import numpy as np
+    allele_rows = None
     os.makedirs(out_dir, exist_ok=True)
     written = ["CRISPResso_quantification_of_editing_frequency.txt", "Alleles_frequency_table.txt"]
     write_quantification_of_editing_frequency(res, ref_names, os.path.join(out_dir, written[0]))
@@ -168,4 +226,14 @@ def write_tables(res, refs, ref_names, out_dir):
                                (prefix + "Nucleotide_percentage_table.txt", list(seq), [[x / total for x in r] for r in rows_all])):
             _write_frame(os.path.join(out_dir, fn), cols, rows, nucs)
             written.append(fn)
+        # alleles around each guide's cut (CRISPRessoCORE.py:5250-5273); needs the guides' sequences for the file names
+        guides = refs[name].get("sgRNA_orig_sequences") or []
+        if guides:
+            if allele_rows is None:
+                allele_rows = res.alleles()
+            labels = refs[name].get("sgRNA_names") or [""] * len(guides)
+            for cut_point, guide, label in zip(refs[name]["sgRNA_cut_points"], guides, labels):
+                fn = prefix + "Alleles_frequency_table_around_" + slugify(label if label != "" else "sgRNA_" + guide) + ".txt"
+                write_alleles_around_cut(alleles_around_cut(allele_rows, name, cut_point, L, plot_window_size), os.path.join(out_dir, fn))
+                written.append(fn)
     return written

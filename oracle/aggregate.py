@@ -100,3 +100,38 @@ def aggregate(items, ref_len, ignore_substitutions=False, ignore_insertions=Fals
         "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS", "alignments_counted")})
     out.update({k: {int(a): int(b) for a, b in c.items() if b} for k, c in h.items()})
     return out
+
+
+def alleles_around_cut(rows, ref_name, cut_point, ref_len, plot_window_size=20):
+    """Restatement with pandas of CRISPRessoShared.get_dataframe_around_cut_asymmetrical (CRISPRessoShared.py:1513-1531) and
+    the window of plots/data_prep.py:285-301, on allele table rows (Aligned_Sequence, Reference_Sequence, Reference_Name,
+    Read_Status, n_deleted, n_inserted, n_mutated, #Reads, %Reads).  -> the text pandas' to_csv writes (CRISPRessoCORE.py:5272)."""
+    import io
+    import pandas as pd
+    left = plot_window_size if cut_point - plot_window_size + 1 >= 0 else cut_point + 1
+    right = plot_window_size if cut_point + plot_window_size < ref_len else ref_len - cut_point - 1
+    df = pd.DataFrame([r for r in rows if r[2] == ref_name], columns=['Aligned_Sequence', 'Reference_Sequence', 'Reference_Name', 'Read_Status',
+                                                                     'n_deleted', 'n_inserted', 'n_mutated', '#Reads', '%Reads'])
+
+    def positions(ref_al):                                            # CRISPRessoCOREResources.pyx:105-133
+        out, idx = [], 0
+        for c in ref_al:
+            if c != '-':
+                out.append(idx)
+                idx += 1
+            else:
+                out.append(-1 if idx == 0 else -idx)
+        return out
+
+    def cut_row(row):
+        k = positions(row['Reference_Sequence']).index(cut_point)
+        return (row['Aligned_Sequence'][k - left + 1:k + right + 1], row['Reference_Sequence'][k - left + 1:k + right + 1],
+                row['Read_Status'] == 'UNMODIFIED', row['n_deleted'], row['n_inserted'], row['n_mutated'], row['#Reads'], row['%Reads'])
+    d = pd.DataFrame(list(df.apply(cut_row, axis=1).values),
+                     columns=['Aligned_Sequence', 'Reference_Sequence', 'Unedited', 'n_deleted', 'n_inserted', 'n_mutated', '#Reads', '%Reads'])
+    d = d.groupby(['Aligned_Sequence', 'Reference_Sequence', 'Unedited', 'n_deleted', 'n_inserted', 'n_mutated']).sum().reset_index().set_index('Aligned_Sequence')
+    d.sort_values(by=['#Reads', 'Aligned_Sequence', 'Reference_Sequence'], inplace=True, ascending=[False, True, True])
+    d['Unedited'] = d['Unedited'] > 0
+    buf = io.StringIO()
+    d.to_csv(buf, sep='\t', header=True, index=True, index_label=d.index.name)
+    return buf.getvalue()

@@ -4,9 +4,8 @@ tests/golden/fanc_full_run.json.gz holds every .txt file the REFERENCE wrote for
 (make_golden.py --fanc-full: its main(), plot functions replaced by no-ops) plus the unzipped allele table.  tables.write_tables
 must reproduce, from the count tensor: quantification of editing frequency, mapping statistics, nucleotide frequency /
 percentage tables (amplicon and quantification window), modification count vectors (both), the four effect vectors, the
-four histograms and the allele frequency table.  CPU: counts built by the oracle (oracle/aggregate.py); GPU: the
-device-resident pipeline.  Not reproduced (plot data preparation, out of scope): Alleles_frequency_table_around_sgRNA_*.txt,
-Alleles_homology_scores.txt."""
+four histograms, the allele frequency table and the alleles around the guide's cut.  CPU: counts built by the oracle
+(oracle/aggregate.py); GPU: the device-resident pipeline.  Not reproduced: Alleles_homology_scores.txt (data of a plot)."""
 import gzip
 import json
 import os
@@ -30,7 +29,7 @@ def _golden():
 def _compare(g, names, out_dir, skip=()):
     n = 0
     for fn, text in g["files"].items():
-        if fn in NOT_REPRODUCED or fn.startswith("Alleles_frequency_table_around_") or fn in skip:
+        if fn in NOT_REPRODUCED or fn in skip:
             continue
         assert fn in names, fn
         with open(os.path.join(out_dir, fn)) as fh:
@@ -47,6 +46,7 @@ def test_tables_from_oracle_counts_equal_every_file_of_the_reference_run(tmp_pat
     g = _golden()
     amp, cut = g["amplicon"], g["cut_point"]
     ref = RF.make_ref("Reference", amp, [cut], [cut, cut + 1], min_aln_score=60)
+    ref["sgRNA_orig_sequences"] = [g["guide"]]
     m = matrices()["EDNAFULL"]
     lines = g["fastq"].split("\n")
     reads = [lines[k] for k in range(1, len(lines), 4) if lines[k]]
@@ -82,7 +82,7 @@ def test_tables_from_oracle_counts_equal_every_file_of_the_reference_run(tmp_pat
             return sorted(rows, key=lambda t: (-t[7], t[0], t[1]))
     res = WithAlleles({"Reference": agg}, stats, lay, None)
     names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(tmp_path))
-    assert _compare(g, names, str(tmp_path)) == 17
+    assert _compare(g, names, str(tmp_path)) == 18
     # an amplicon without reads: zero effect vectors, the reference's histogram ranges
     empty = aggregate.aggregate([], len(amp))
     res0 = QuantResult({"Reference": empty}, dict(stats, N_TOTAL=0), lay, None)
@@ -104,6 +104,7 @@ def test_tables_from_the_device_pipeline_equal_every_file_of_the_reference_run(t
     fq.write_text(g["fastq"])
     cut = g["cut_point"]
     ref = RF.make_ref("Reference", g["amplicon"], [cut], [cut, cut + 1], min_aln_score=60)
+    ref["sgRNA_orig_sequences"] = [g["guide"]]
     args = argparse.Namespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
                               use_legacy_insertion_quantification=False, ignore_deletions=False, ignore_insertions=False,
                               ignore_substitutions=False, assign_ambiguous_alignments_to_first_reference=False,
@@ -111,4 +112,55 @@ def test_tables_from_the_device_pipeline_equal_every_file_of_the_reference_run(t
     res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], args, ctx=_native.default_context())
     out = tmp_path / "CRISPResso_on_FANC.Cas9"
     names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
-    assert _compare(g, names, str(out)) == 17
+    assert _compare(g, names, str(out)) == 18
+
+
+def test_alleles_around_cut_random_tables_windows_at_the_amplicon_ends_and_merging(tmp_path):
+    """tables.alleles_around_cut against the pandas restatement of the reference's function (oracle/aggregate.py): random
+    allele tables with indels, cuts next to either end of the amplicon (clipped windows), several references, rows that
+    coincide inside the window (merged: #Reads added, %Reads added with pandas' compensated float sum)."""
+    import numpy as np
+    from oracle import aggregate
+    from crispresso2_amd import tables
+    rng = np.random.default_rng(77)
+    for trial in range(40):
+        L = int(rng.integers(30, 90))
+        ref = "".join(rng.choice(list("ACGT"), L))
+        rows, total = [], 0
+        for k in range(int(rng.integers(1, 60))):
+            a, r = list(ref), list(ref)
+            for _ in range(int(rng.integers(0, 4))):                         # substitutions, deletions, insertions as the aligner writes them
+                kind, at = int(rng.integers(0, 3)), int(rng.integers(0, len(r)))
+                if kind == 0 and a[at] != '-' and r[at] != '-':
+                    a[at] = "ACGT"[int(rng.integers(0, 4))]
+                elif kind == 1:
+                    n = int(rng.integers(1, 6))
+                    for q in range(at, min(len(r), at + n)):
+                        if r[q] != '-' and a[q] != '-':
+                            a[q] = '-'
+                else:
+                    ins = list(rng.choice(list("ACGT"), int(rng.integers(1, 5))))
+                    if at > 0 and a[at - 1] != '-' and (at >= len(a) or a[at] != '-'):
+                        a[at:at] = ins
+                        r[at:at] = ['-'] * len(ins)
+            a, r = "".join(a), "".join(r)
+            dn, inn = a.count('-'), r.count('-')
+            sn = sum(x != y and x != '-' and y != '-' for x, y in zip(a, r))
+            reads = int(rng.integers(1, 50))
+            total += reads
+            rows.append([a, r, ["R1", "R2", "AMBIGUOUS_R1"][int(rng.integers(0, 3))], "MODIFIED" if dn + inn + sn else "UNMODIFIED", dn, inn, sn, reads])
+        seen, uniq = set(), []
+        for row in rows:                                                      # the allele table has one row per (strings, reference)
+            if (row[0], row[1], row[2]) not in seen:
+                seen.add((row[0], row[1], row[2]))
+                uniq.append(tuple(row) + (row[7] / total * 100,))
+        uniq.sort(key=lambda t: (-t[7], t[0], t[1]))
+        for cut in (0, 1, int(rng.integers(0, L)), L - 2, L - 1):
+            for name in ("R1", "R2"):
+                if not any(u[2] == name for u in uniq):
+                    continue
+                w = int(rng.integers(1, 25)) if trial % 2 else 20
+                got = tables.alleles_around_cut(uniq, name, cut, L, plot_window_size=w)
+                p = tmp_path / "t.txt"
+                tables.write_alleles_around_cut(got, str(p))
+                assert p.read_text() == aggregate.alleles_around_cut(uniq, name, cut, L, w), (trial, cut, name, w)
