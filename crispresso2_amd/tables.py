@@ -66,12 +66,23 @@ def _write_count_vectors(path, ref_seq, vectors, names):
             fh.write(nm + "\t" + "\t".join(vec) + "\n")
 
 
-def write_alleles_frequency_table(res, path):
-    """Alleles_frequency_table.txt (the reference zips it): CRISPRessoCORE.py:4498-4509, the non-detailed columns."""
+def write_alleles_frequency_table(res, path, dsODN=""):
+    """Alleles_frequency_table.txt (the reference zips it): CRISPRessoCORE.py:4498-4527, the non-detailed columns.  With
+    --dsODN two more columns say whether the aligned read contains the oligo, or the oligo without its first and last three
+    bases, on either strand -- `str.find(...) > 0`, so a match at the very start of the read does not count (:4512-4524)."""
+    from .refs import reverse_complement
+    head = "Aligned_Sequence\tReference_Sequence\tReference_Name\tRead_Status\tn_deleted\tn_inserted\tn_mutated\t#Reads\t%Reads"
+    probes = []
+    if dsODN != "":
+        if len(dsODN) <= 6:
+            raise KeyError("contains dsODN fragment")                  # the reference selects a column it never made (:4519-4524)
+        head += "\tcontains dsODN\tcontains dsODN fragment"
+        probes = [(dsODN, reverse_complement(dsODN)), (dsODN[3:-3], reverse_complement(dsODN[3:-3]))]
     with open(path, "w") as fh:
-        fh.write("Aligned_Sequence\tReference_Sequence\tReference_Name\tRead_Status\tn_deleted\tn_inserted\tn_mutated\t#Reads\t%Reads\n")
+        fh.write(head + "\n")
         for a, r, name, status, dn, inn, sn, reads, pct in res.alleles():
-            fh.write("%s\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%s\n" % (a, r, name, status, dn, inn, sn, reads, _f(pct)))
+            extra = "".join("\t" + ("True" if (a.find(fw) > 0 or a.find(rv) > 0) else "False") for fw, rv in probes)
+            fh.write("%s\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%s%s\n" % (a, r, name, status, dn, inn, sn, reads, _f(pct), extra))
 
 
 def write_mapping_statistics(res, path):
@@ -162,14 +173,14 @@ def write_alleles_around_cut(rows, path):
             fh.write("%s\t%s\t%s\t%d\t%d\t%d\t%d\t%s\n" % (a, r, "True" if unedited else "False", dn, inn, sn, reads, _f(pct)))
 
 
-def write_tables(res, refs, ref_names, out_dir, plot_window_size=20):
+def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN=""):
     """Writes the tables listed in the module docstring into out_dir; returns the list of file names."""
     import numpy as np
     allele_rows = None
     os.makedirs(out_dir, exist_ok=True)
     written = ["CRISPResso_quantification_of_editing_frequency.txt", "Alleles_frequency_table.txt"]
     write_quantification_of_editing_frequency(res, ref_names, os.path.join(out_dir, written[0]))
-    write_alleles_frequency_table(res, os.path.join(out_dir, written[1]))
+    write_alleles_frequency_table(res, os.path.join(out_dir, written[1]), dsODN=dsODN)
     if all(k in res.stats for k in ("N_TOTAL", "N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN")):
         written.append("CRISPResso_mapping_statistics.txt")
         write_mapping_statistics(res, os.path.join(out_dir, written[-1]))

@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -489,6 +489,82 @@ if __name__ == "__main__" and "--fanc-full" in sys.argv:
     with gzip.open(os.path.join(HERE, "fanc_full_run.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("fanc_full_run.json.gz written:", {k: len(v) for k, v in d["files"].items()})
+
+
+# ---------------------------------------------------------------- 6c. the reference's second end-to-end test: two amplicons, many parameters
+PARAMS_TABLES = ("CRISPResso_quantification_of_editing_frequency.txt", "CRISPResso_mapping_statistics.txt", "Alleles_frequency_table.txt",
+                 "Nucleotide_frequency_table.txt", "Nucleotide_percentage_table.txt", "Quantification_window_nucleotide_frequency_table.txt",
+                 "Quantification_window_nucleotide_percentage_table.txt", "Modification_count_vectors.txt",
+                 "Quantification_window_modification_count_vectors.txt", "Effect_vector_insertion.txt", "Effect_vector_deletion.txt",
+                 "Effect_vector_substitution.txt", "Effect_vector_combined.txt", "Indel_histogram.txt", "Insertion_histogram.txt",
+                 "Deletion_histogram.txt", "Substitution_histogram.txt", "Alleles_frequency_table_around_")
+
+
+def params_run():
+    """tests/Makefile's CRISPResso_on_params (FANC amplicon + expected HDR amplicon, -qwc quantification window coordinates,
+    -q 30, --default_min_aln_score 80, named and flexible guides, a coding sequence ...) run HERE through the reference's
+    main().  Recorded: the reads that survive its quality filter (preprocessing is out of scope: they are the input of the
+    hot path), the per-amplicon records it derived (sequence, include_idxs, cut points, gap incentives, seeds, guides --
+    CRISPResso2_info.json), and the result tables that come from the count tensor and the allele rows."""
+    import gzip
+    import importlib
+    import zipfile
+    core = load_reference_core()
+    P = importlib.import_module("CRISPResso2.plots.CRISPRessoPlot")
+    for k in dir(P):
+        if k.startswith("plot_") and callable(getattr(P, k)):
+            setattr(P, k, (lambda *a, **kw: None))
+    with open(os.path.join(REF, "tests/Makefile")) as fh:
+        line = [l for l in fh if "CRISPResso -r1 FANC.Cas9.fastq" in l and " -e " in l][0].split()
+    argv = line[line.index("CRISPResso"):]
+    argv[argv.index("-r1") + 1] = os.path.join(REF, "tests/FANC.Cas9.fastq")
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        old = sys.argv
+        sys.argv = argv + ["--suppress_report", "-o", tmp, "--keep_intermediate"]
+        try:
+            core.main()
+        except SystemExit as e:
+            assert e.code in (0, None), e.code
+        finally:
+            sys.argv = old
+        out = os.path.join(tmp, "CRISPResso_on_params")
+        with open(os.path.join(out, "CRISPResso2_info.json")) as fh:
+            info = json.load(fh)
+        with gzip.open(os.path.join(out, "FANC.Cas9_filtered.fastq.gz"), "rt") as fh:
+            fastq = fh.read()
+        for fn in sorted(os.listdir(out)):
+            base = fn.split(".", 1)[1] if fn.split(".", 1)[0] in info["results"]["refs"] else fn
+            if fn.endswith(".txt") and any(base == t or (t.endswith("_") and base.startswith(t)) for t in PARAMS_TABLES):
+                with open(os.path.join(out, fn)) as fh:
+                    files[fn] = fh.read()
+        with zipfile.ZipFile(os.path.join(out, "Alleles_frequency_table.zip")) as z:
+            files["Alleles_frequency_table.txt"] = z.read("Alleles_frequency_table.txt").decode()
+    exp = os.path.join(REF, "tests/expectedResults/CRISPResso_on_params")
+    for fn in os.listdir(exp):                                       # what the reference repository keeps for this run
+        with open(os.path.join(exp, fn)) as fh:
+            assert files[fn] == fh.read(), fn
+    refs = []
+    for nm, r in info["results"]["refs"].items():
+        refs.append({"name": nm, "sequence": r["sequence"], "min_aln_score": r["min_aln_score"], "gap_incentive": r["gap_incentive"]["value"],
+                     "include_idxs": [int(x) for x in r["include_idxs"]], "sgRNA_cut_points": r["sgRNA_cut_points"],
+                     "sgRNA_orig_sequences": r["sgRNA_orig_sequences"], "sgRNA_names": r["sgRNA_names"],
+                     "fw_seeds": r["fw_seeds"], "rc_seeds": r["rc_seeds"]})
+    a = info["running_info"]["args"]["value"] if "value" in info["running_info"]["args"] else info["running_info"]["args"]
+    keep = ("aln_seed_count", "aln_seed_len", "aln_seed_min", "needleman_wunsch_gap_open", "needleman_wunsch_gap_extend",
+            "use_legacy_insertion_quantification", "ignore_deletions", "ignore_insertions", "ignore_substitutions",
+            "assign_ambiguous_alignments_to_first_reference", "expand_ambiguous_alignments", "prime_editing_pegRNA_scaffold_seq",
+            "discard_indel_reads", "plot_window_size", "dsODN")
+    return {"command": " ".join(argv), "fastq_after_quality_filter": fastq, "refs": refs, "args": {k: a[k] for k in keep},
+            "alignment_stats": info["running_info"]["alignment_stats"], "files": files}
+
+
+if __name__ == "__main__" and "--params" in sys.argv:
+    import gzip
+    d = params_run()
+    with gzip.open(os.path.join(HERE, "params_run.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("params_run.json.gz written:", sorted(d["files"]), d["args"], d["alignment_stats"])
 
 
 # ---------------------------------------------------------------- 7. paired reads (CRISPRessoCORE.py:800-1169)

@@ -164,3 +164,106 @@ def test_alleles_around_cut_random_tables_windows_at_the_amplicon_ends_and_mergi
                 p = tmp_path / "t.txt"
                 tables.write_alleles_around_cut(got, str(p))
                 assert p.read_text() == aggregate.alleles_around_cut(uniq, name, cut, L, w), (trial, cut, name, w)
+
+
+# ---- the reference's second end-to-end test: CRISPResso_on_params (tests/Makefile) -------------------------------------------
+def _params_golden():
+    import numpy as np
+    with gzip.open(os.path.join(HERE, "golden", "params_run.json.gz"), "rt") as fh:
+        g = json.load(fh)
+    refs, names = {}, []
+    for r in g["refs"]:
+        d = dict(r)
+        d["gap_incentive"] = np.array(r["gap_incentive"], dtype=int)
+        d["include_idxs"] = np.array(r["include_idxs"])
+        d["sequence_length"] = len(r["sequence"])
+        refs[r["name"]] = d
+        names.append(r["name"])
+    return g, refs, names
+
+
+def _compare_params(g, written, out_dir):
+    for fn, text in g["files"].items():
+        assert fn in written, fn
+        with open(os.path.join(out_dir, fn)) as fh:
+            assert fh.read() == text, fn
+    return len(g["files"])
+
+
+def test_params_run_tables_from_oracle_counts(tmp_path):
+    """Two amplicons (FANC + the expected HDR allele), quantification window from coordinates, min_aln_score 80, three guides
+    (named, flexible), --dsODN: the reads that survive the reference's quality filter + the per-amplicon records it derived
+    (make_golden.py --params) -> oracle alignments, the reference's best-amplicon rule (CRISPRessoCORE.py:697-707), oracle
+    aggregation -> 37 result files of the reference's run byte for byte (two of them are kept in its repository)."""
+    import oracle
+    from oracle import aggregate
+    from crispresso2_amd import tables, counts as C
+    from crispresso2_amd.pipeline import QuantResult
+    g, refs, names = _params_golden()
+    m = matrices()["EDNAFULL"]
+    lines = g["fastq_after_quality_filter"].split("\n")
+    reads = [lines[k] for k in range(1, len(lines) - 1, 4)]
+    unique = {}
+    for rd in reads:
+        unique[rd] = unique.get(rd, 0) + 1
+    go, ge = g["args"]["needleman_wunsch_gap_open"], g["args"]["needleman_wunsch_gap_extend"]
+    stats = dict(N_TOT_READS=len(reads), N_READS_INPUT=g["alignment_stats"]["N_READS_INPUT"], N_READS_AFTER_PREPROCESSING=len(reads),
+                 N_TOTAL=0, N_COMPUTED_ALN=0, N_CACHED_ALN=0, N_COMPUTED_NOTALN=0, N_CACHED_NOTALN=0)
+    items, rows = {nm: [] for nm in names}, []
+    for rd, c in unique.items():
+        best, best_names, al = 0, [], {}
+        for nm in names:                                            # forward strand: the reads of this file are
+            s1, s2, score = oracle.global_align(rd, refs[nm]["sequence"], m, refs[nm]["gap_incentive"], go, ge)
+            al[nm] = (s1, s2)
+            if score > best and score > refs[nm]["min_aln_score"]:
+                best, best_names = score, [nm]
+            elif score == best:
+                best_names.append(nm)
+        if best <= 0:
+            stats["N_COMPUTED_NOTALN"] += 1
+            stats["N_CACHED_NOTALN"] += c - 1
+            continue
+        stats["N_COMPUTED_ALN"] += 1
+        stats["N_CACHED_ALN"] += c - 1
+        stats["N_TOTAL"] += c
+        assert len(best_names) == 1                                 # no ambiguous read in this run
+        nm = best_names[0]
+        p = oracle.find_indels_substitutions(al[nm][0], al[nm][1], refs[nm]["include_idxs"])
+        p["aln_seq"], p["aln_ref"] = al[nm]
+        items[nm].append((p, c))
+        mod = p["insertion_n"] + p["deletion_n"] + p["substitution_n"] > 0
+        rows.append((al[nm][0], al[nm][1], nm, "MODIFIED" if mod else "UNMODIFIED", p["deletion_n"], p["insertion_n"], p["substitution_n"], c))
+    for k in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS"):
+        assert stats[k] == g["alignment_stats"][k], k
+    per_ref = {nm: aggregate.aggregate(items[nm], len(refs[nm]["sequence"])) for nm in names}
+    lay = C.CountLayout(2, max(len(refs[nm]["sequence"]) for nm in names), max(len(r) for r in reads))
+
+    class WithAlleles(QuantResult):
+        def alleles(self):
+            return sorted([r + (r[7] / stats["N_TOTAL"] * 100,) for r in rows], key=lambda t: (-t[7], t[0], t[1]))
+    res = WithAlleles(per_ref, stats, lay, None)
+    written = tables.write_tables(res, refs, names, str(tmp_path), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(tmp_path)) == 37
+    with pytest.raises(KeyError):                                   # the reference's own failure for an oligo of <= 6 bases
+        tables.write_alleles_frequency_table(res, str(tmp_path / "x.txt"), dsODN="ACGTAC")
+
+
+@pytest.mark.gpu
+def test_params_run_tables_from_the_device_pipeline(tmp_path):
+    """The same run through pipeline.quantify_fastq: native ingest, seeds, both amplicons aligned on the GPU, best-amplicon
+    selection, count kernel -> the same 37 files."""
+    import argparse
+    from crispresso2_amd import _native, pipeline, tables
+    g, refs, names = _params_golden()
+    fq = tmp_path / "FANC.Cas9_filtered.fastq"
+    fq.write_text(g["fastq_after_quality_filter"])
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], argparse.Namespace(**a), ctx=_native.default_context())
+    for k in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS", "N_GLOBAL_SUBS",
+              "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS"):
+        assert res.stats[k] == g["alignment_stats"][k], k
+    res.stats["N_READS_INPUT"] = g["alignment_stats"]["N_READS_INPUT"]                 # reads before the quality filter (preprocessing: not here)
+    res.stats["N_READS_AFTER_PREPROCESSING"] = g["alignment_stats"]["N_READS_AFTER_PREPROCESSING"]
+    out = tmp_path / "CRISPResso_on_params"
+    written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(out)) == 37
