@@ -282,3 +282,26 @@ def test_emulated_paired_consensus_kernel():
     # a quality string that is too short is an IndexError in the reference: flagged, not read out of bounds
     bad = E.consensus_pairs([("ACGT", "ACGT", 100.0, "II", "ACGT", "ACGT", 100.0, "IIII")])[0]
     assert bad[5]
+
+
+def test_emulated_chain_on_the_reads_of_the_reference_params_run(mats):
+    """The reads of the reference's CRISPResso_on_params test (real FANC amplicon reads, 250 bp against 223 / 2xx bp
+    amplicons whose gap incentive is set at three cut points, quantification window of 17 scattered positions) against BOTH
+    amplicons through the default launch chain (4 -> 2 -> 1 alignments per wavefront, full plane last): every string, score
+    and classifier count equals the oracle's."""
+    g = load_golden("params_run.json.gz")
+    m = mats["EDNAFULL"]
+    refs = [r["sequence"] for r in g["refs"]]
+    gis = [np.array(r["gap_incentive"], dtype=np.int64) for r in g["refs"]]
+    incs = [r["include_idxs"] for r in g["refs"]]
+    lines = g["fastq_after_quality_filter"].split("\n")
+    reads = list(dict.fromkeys(lines[k] for k in range(1, len(lines) - 1, 4)))
+    st = {}
+    res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, all_refs=True, band_lanes=-7, stats=st)
+    assert len(res) == 2 * len(reads)
+    for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+        rd, ri = reads[k // 2], k % 2
+        exp = oracle.global_align_raw(rd, refs[ri], m, gis[ri], -20, -2)
+        assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k
+        check_record(r, oracle.find_indels_substitutions(s1, s2, incs[ri]), s1, s2)
+    assert st["fallback"] < st["tasks"]
