@@ -267,3 +267,66 @@ def test_params_run_tables_from_the_device_pipeline(tmp_path):
     out = tmp_path / "CRISPResso_on_params"
     written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
     assert _compare_params(g, written, str(out)) == 37
+
+
+def test_params_run_tables_from_the_emulated_kernels(tmp_path):
+    """The same run with the HIP kernels compiled for the host by the wave emulator (tests/emu): every read against both
+    amplicons through the default launch chain, best amplicon from the 32-byte records with the reference's score expression,
+    c2_count_vectors_kernel with the read multiplicities as weights -> the count tensor -> the 37 files.  (CPU stand-in for
+    test_params_run_tables_from_the_device_pipeline: same kernels, same tables; only the host-side selection of pipeline.py is not exercised here.)"""
+    import numpy as np
+    import emu_driver as E
+    from crispresso2_amd import tables
+    from crispresso2_amd.pipeline import QuantResult
+    g, refs, names = _params_golden()
+    m = matrices()["EDNAFULL"]
+    lines = g["fastq_after_quality_filter"].split("\n")
+    reads = [lines[k] for k in range(1, len(lines) - 1, 4)]
+    unique = {}
+    for rd in reads:
+        unique[rd] = unique.get(rd, 0) + 1
+    ureads = list(unique)
+    seqs = [refs[nm]["sequence"] for nm in names]
+    st = {}
+    res, rec = E.align_batch(ureads, seqs, [refs[nm]["gap_incentive"] for nm in names], [list(refs[nm]["include_idxs"]) for nm in names],
+                             m, g["args"]["needleman_wunsch_gap_open"], g["args"]["needleman_wunsch_gap_extend"], all_refs=True, band_lanes=-7, stats=st)
+    o1, o2 = st["raw"]
+    k = len(names)
+    weights = np.zeros(len(rec), dtype=np.uint32)
+    stats = dict(N_TOT_READS=len(reads), N_READS_INPUT=g["alignment_stats"]["N_READS_INPUT"], N_READS_AFTER_PREPROCESSING=len(reads),
+                 N_TOTAL=0, N_COMPUTED_ALN=0, N_CACHED_ALN=0, N_COMPUTED_NOTALN=0, N_CACHED_NOTALN=0)
+    rows = []
+    for i, rd in enumerate(ureads):
+        best, best_refs = 0, []
+        for r, nm in enumerate(names):
+            t = rec[i * k + r]
+            assert t["status"] == 0 and t["ref_id"] == r
+            score = round(100 * int(t["matches"]) / float(int(t["aln_len"])), 3)
+            if score > best and score > refs[nm]["min_aln_score"]:
+                best, best_refs = score, [r]
+            elif score == best:
+                best_refs.append(r)
+        c = unique[rd]
+        if best <= 0:
+            stats["N_COMPUTED_NOTALN"] += 1
+            stats["N_CACHED_NOTALN"] += c - 1
+            continue
+        assert len(best_refs) == 1
+        stats["N_COMPUTED_ALN"] += 1
+        stats["N_CACHED_ALN"] += c - 1
+        stats["N_TOTAL"] += c
+        t = i * k + best_refs[0]
+        weights[t] = c
+        s1, s2 = res[t]
+        mod = int(rec[t]["insertion_n"]) + int(rec[t]["deletion_n"]) + int(rec[t]["substitution_n"]) > 0
+        rows.append((s1, s2, names[best_refs[0]], "MODIFIED" if mod else "UNMODIFIED", int(rec[t]["deletion_n"]), int(rec[t]["insertion_n"]),
+                     int(rec[t]["substitution_n"]), c))
+    counts, lay = E.count_vectors(o1, o2, rec, seqs, [list(refs[nm]["include_idxs"]) for nm in names], max(len(r) for r in ureads), weights=weights)
+    per_ref = {nm: lay.unpack(counts, r, len(seqs[r])) for r, nm in enumerate(names)}
+
+    class WithAlleles(QuantResult):
+        def alleles(self):
+            return sorted([r + (r[7] / stats["N_TOTAL"] * 100,) for r in rows], key=lambda t: (-t[7], t[0], t[1]))
+    written = tables.write_tables(WithAlleles(per_ref, stats, lay, None), refs, names, str(tmp_path),
+                                  plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(tmp_path)) == 37
