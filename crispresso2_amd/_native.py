@@ -22,7 +22,7 @@ SYMBOLS = [
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
     "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_timing_read_split", "c2_count_vectors_device",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
-    "c2_fastq_unique", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
+    "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error", "c2_strand_plan", "c2_merge_reverse_complements",
     "c2_consensus_pairs_batch",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets",
@@ -103,6 +103,8 @@ def load():
             lib.c2_fastq_free.argtypes = [ctypes.c_void_p]
             lib.c2_fastq_last_error.restype = ctypes.c_char_p
             lib.c2_fastq_unique.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+            lib.c2_fastq_unique_filtered.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
             _lib = lib
     return _lib
 
@@ -250,12 +252,21 @@ class Context:
         return dict(zip(("rows_per_lane", "passes", "lds_bytes", "workgroups_per_cu", "compute_units"), [x.value for x in v]))
 
 
-def fastq_unique(path):
+def fastq_unique(path, min_single_bp_quality=0, min_average_read_quality=0, min_bp_quality_or_N=0, stats=None):
     """c2_fastq_unique (host code, needs no GPU): -> (arena uint8, offsets uint64 [n_unique+1], counts uint32 [n_unique], n_reads)
-    -- the unique sequences of the FASTQ in first-seen order, packed as the align kernels take them."""
+    -- the unique sequences of the FASTQ in first-seen order, packed as the align kernels take them.  With any of the three
+    quality options (> 0) the reference's read filter (filterFastqs.py) runs fused in front, n_reads is the number of reads
+    that passed, and `stats` (a dict) receives N_READS_INPUT as the reference counts it."""
     lib = load()
     h = ctypes.c_void_p()
-    rc = lib.c2_fastq_unique(os.fsencode(path), ctypes.byref(h))
+    if min_single_bp_quality > 0 or min_average_read_quality > 0 or min_bp_quality_or_N > 0:
+        lines = ctypes.c_uint64(0)
+        rc = lib.c2_fastq_unique_filtered(os.fsencode(path), int(min_single_bp_quality), int(min_average_read_quality),
+                                          int(min_bp_quality_or_N), ctypes.byref(h), ctypes.byref(lines))
+        if rc == 0 and stats is not None:
+            stats["N_READS_INPUT"] = int(float(lines.value) / 4.0)          # get_n_reads_fastq, CRISPRessoShared.py:746-747
+    else:
+        rc = lib.c2_fastq_unique(os.fsencode(path), ctypes.byref(h))
     if rc != 0:
         raise NativeError("c2_fastq_unique: %s" % lib.c2_fastq_last_error().decode())
     try:

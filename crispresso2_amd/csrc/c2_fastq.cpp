@@ -735,6 +735,131 @@ struct GzMembers {
     }
 };
 
+// ---- read filter fused into the ingest (filterFastqs.py, called from CRISPRessoCORE.py:3696-3717) ----------------------
+// The reference rewrites the FASTQ before it reads it: records are four '\n'-terminated lines in BINARY mode, each with
+// bytes.rstrip() applied (space \t \n \r \x0b \x0c), the loop stops at the first empty id line; a read is kept if the mean
+// and / or the minimum of its qualities (uint8 arithmetic: byte - 33 wraps) reach the thresholds, and bases whose quality is
+// below min_bp_qual_or_N become 'N'.  Here the surviving records are written into a memory buffer with exactly the bytes
+// of that intermediate file and the buffer goes to the parallel parser -- no file in between.  The order of the tests and
+// the failures are the reference's, per combination of options (filterFastqs.py:128-226): minimum of an empty quality
+// line (numpy: zero-size array), sequence and quality lines of different length when bases are masked (numpy: boolean
+// index mismatch), and the read-only buffer of run_mBP_mBPN (min_single_bp_quality + min_bp_quality_or_N without
+// min_average_read_quality raises for the first read that passes).
+inline bool bytes_space(uint8_t c) { return c == ' ' || (c >= 0x09 && c <= 0x0d); }
+
+struct TextSource {                                             // the whole text of a FASTQ in memory: mapped plain file or inflated .gz
+    void* mapped = nullptr; size_t mapped_n = 0;
+    TextBuf inflated;
+    const char* p = nullptr; size_t n = 0;
+    ~TextSource() { if (mapped) munmap(mapped, mapped_n); }
+    bool open_path(const char* path, std::string& err) {
+        const int fd = open(path, O_RDONLY);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); err = std::string("cannot open ") + path; return false; }
+        mapped_n = (size_t)st.st_size;
+        if (mapped_n == 0) { close(fd); p = ""; n = 0; return true; }
+        mapped = mmap(nullptr, mapped_n, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (mapped == MAP_FAILED) { mapped = nullptr; err = std::string("cannot map ") + path; return false; }
+        const uint8_t* b = (const uint8_t*)mapped;
+        if (!(mapped_n >= 2 && b[0] == 0x1f && b[1] == 0x8b)) { p = (const char*)mapped; n = mapped_n; return true; }
+        const char* route = getenv("C2_FASTQ_GZ");
+        const bool stream_only = route && !strcmp(route, "stream");
+        const bool use_libdeflate = !(route && !strcmp(route, "zlib"));
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        if (hw > 64) hw = 64;
+        size_t got = 0;
+        bool ok = !stream_only && mapped_n >= 18 && inflate_bgzf(b, mapped_n, use_libdeflate, inflated, got, hw);
+        if (!ok && !stream_only && use_libdeflate && mapped_n >= 18) ok = inflate_members(b, mapped_n, inflated, got);
+        if (!ok) {
+            GzMembers gm;
+            if (!gm.init(b, mapped_n)) { err = gm.err; return false; }
+            got = 0;
+            for (;;) {
+                if (!inflated.reserve(got + ((size_t)8 << 20))) { err = "out of memory inflating the FASTQ"; return false; }
+                const long g = gm.read(inflated.get() + got, inflated.cap - got);
+                if (g < 0) { err = std::string("read error in ") + path + ": " + gm.err; return false; }
+                if (g == 0) break;
+                got += (size_t)g;
+            }
+        }
+        p = inflated.get() ? inflated.get() : ""; n = got;
+        return true;
+    }
+};
+
+// -> 0 ok; C2_E_INVALID with err set for the reference's failures
+int filter_fastq_text(const char* b, size_t n, int min_bp, int min_av, int min_bpn, TextBuf& out, size_t& n_out, uint64_t& nonempty_lines, std::string& err) {
+    nonempty_lines = 0;
+    for (size_t pos = 0; pos < n;) {                            // `grep -c .` of get_n_reads_fastq (CRISPRessoShared.py:743-748)
+        const char* e = (const char*)memchr(b + pos, '\n', n - pos);
+        const size_t end = e ? (size_t)(e - b) : n;
+        nonempty_lines += end > pos;
+        pos = end + 1;
+    }
+    n_out = 0;
+    if (!out.reserve(n + 4096)) { err = "out of memory"; return C2_E_INVALID; }
+    char* o = out.get();
+    size_t pos = 0;
+    struct Line { size_t a, z; };
+    auto next = [&](Line& L) {                                   // readline().rstrip()
+        if (pos >= n) { L.a = L.z = n; return; }
+        const char* e = (const char*)memchr(b + pos, '\n', n - pos);
+        size_t end = e ? (size_t)(e - b) : n;
+        L.a = pos;
+        pos = e ? end + 1 : n;
+        while (end > L.a && bytes_space((uint8_t)b[end - 1])) --end;
+        L.z = end;
+    };
+    uint64_t rec = 0;
+    for (;; ++rec) {
+        Line id, sq, pl, ql;
+        next(id);
+        if (id.z == id.a) break;
+        next(sq); next(pl); next(ql);
+        const size_t nq = ql.z - ql.a, ns = sq.z - sq.a;
+        const uint8_t* q = (const uint8_t*)b + ql.a;
+        auto fail = [&](const char* what) {
+            err = "filterFastqs, record " + std::to_string(rec) + ": " + what;
+            return C2_E_INVALID;
+        };
+        auto min_ok = [&](bool& keep) -> int {
+            if (nq == 0) return fail("ValueError: zero-size array to reduction operation minimum which has no identity (empty quality line)");
+            unsigned mn = 255;
+            for (size_t k = 0; k < nq; ++k) { const unsigned v = (uint8_t)(q[k] - 33); if (v < mn) mn = v; }
+            keep = (int)mn >= min_bp;
+            return 0;
+        };
+        auto mean_ok = [&]() {
+            if (nq == 0) return false;                           // numpy: mean of an empty slice is nan, nan >= x is False
+            uint64_t sum = 0;
+            for (size_t k = 0; k < nq; ++k) sum += (uint8_t)(q[k] - 33);
+            return (double)sum / (double)nq >= (double)min_av;
+        };
+        bool keep = true;
+        if (min_bp > 0 && min_av > 0 && min_bpn <= 0) {          // run_mBP_mRQ: mean first
+            keep = mean_ok();
+            if (keep) { const int rc = min_ok(keep); if (rc) return rc; }
+        } else {
+            if (min_bp > 0) { const int rc = min_ok(keep); if (rc) return rc; }
+            if (keep && min_av > 0) keep = mean_ok();
+        }
+        if (!keep) continue;
+        if (min_bpn > 0) {
+            if (min_bp > 0 && min_av <= 0) return fail("ValueError: assignment destination is read-only (run_mBP_mBPN masks a numpy.frombuffer view)");
+            if (ns != nq) return fail("IndexError: boolean index did not match indexed array (sequence and quality lines differ in length)");
+        }
+        memcpy(o + n_out, b + id.a, id.z - id.a); n_out += id.z - id.a; o[n_out++] = '\n';
+        memcpy(o + n_out, b + sq.a, ns);
+        if (min_bpn > 0) for (size_t k = 0; k < ns; ++k) if ((int)(uint8_t)(q[k] - 33) < min_bpn) o[n_out + k] = 'N';
+        n_out += ns; o[n_out++] = '\n';
+        memcpy(o + n_out, b + pl.a, pl.z - pl.a); n_out += pl.z - pl.a; o[n_out++] = '\n';
+        memcpy(o + n_out, b + ql.a, nq); n_out += nq; o[n_out++] = '\n';
+    }
+    return 0;
+}
+
 }  // namespace
 
 
@@ -823,6 +948,31 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
     if (last < 0) { g_fastq_error = std::string("read error in ") + path + ": " + gm.err; delete R; return C2_E_INVALID; }
     L.finish();
     if (!L.ok) { g_fastq_error = "more than 2^32 - 2 unique sequences"; delete R; return C2_E_TOO_LARGE; }
+    *out = R;
+    return 0;
+}
+
+int c2_fastq_unique_filtered(const char* path, int32_t min_bp_qual_in_read, int32_t min_av_read_qual, int32_t min_bp_qual_or_N,
+                             c2_fastq** out, uint64_t* nonempty_lines_in_input) {
+    if (!path || !out) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    *out = nullptr;
+    if (min_bp_qual_in_read <= 0 && min_av_read_qual <= 0 && min_bp_qual_or_N <= 0) {
+        g_fastq_error = "no filter requested (the reference exits with 'Finished -- No modifications requested')";
+        return C2_E_INVALID;
+    }
+    TextSource src;
+    std::string err;
+    if (!src.open_path(path, err)) { g_fastq_error = err; return C2_E_INVALID; }
+    TextBuf filtered;
+    size_t n_f = 0;
+    uint64_t lines = 0;
+    const int rc = filter_fastq_text(src.p, src.n, min_bp_qual_in_read, min_av_read_qual, min_bp_qual_or_N, filtered, n_f, lines, err);
+    if (rc) { g_fastq_error = err; return rc; }
+    if (nonempty_lines_in_input) *nonempty_lines_in_input = lines;
+    c2_fastq* R = new c2_fastq;
+    if (n_f == 0) { R->offsets.push_back(0); *out = R; return 0; }
+    const int prc = parse_plain_parallel(filtered.get(), n_f, R, plain_threads(n_f));
+    if (prc) { g_fastq_error = "more than 2^32 - 2 unique sequences"; delete R; return prc; }
     *out = R;
     return 0;
 }

@@ -278,7 +278,11 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
     variants.read_fastq_unique; N_TOT_READS counts every record of the file."""
     import time
     t0 = time.perf_counter()
-    arena, offsets, counts, n_reads = _native.fastq_unique(path)
+    # --min_single_bp_quality / --min_average_read_quality / --min_bp_quality_or_N: the reference filters the file first
+    # (CRISPRessoCORE.py:3696-3717); here the filter runs inside the ingest
+    flt = [int(getattr(args, k_, 0) or 0) for k_ in ('min_single_bp_quality', 'min_average_read_quality', 'min_bp_quality_or_N')]
+    ingest_stats = {}
+    arena, offsets, counts, n_reads = _native.fastq_unique(path, *flt, stats=ingest_stats)
     if timings is not None:
         timings["ingest_dedup"] = time.perf_counter() - t0
     lens = offsets[1:] - offsets[:-1]
@@ -289,5 +293,6 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
         arena = np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in keep]) if len(keep) else np.zeros(0, dtype=np.uint8)
         offsets, counts = new_off, counts[keep]
     res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings)
-    res.stats['N_READS_INPUT'] = int(n_reads)
+    res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
+    res.stats['N_READS_AFTER_PREPROCESSING'] = int(n_reads)
     return res

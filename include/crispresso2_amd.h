@@ -258,6 +258,15 @@ int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const u
  * (arena + n_unique+1 offsets: what c2_align_classify_batch_* take) and counts[n_unique].  Errors: c2_fastq_last_error(). */
 typedef struct c2_fastq c2_fastq;
 int c2_fastq_unique(const char* path, c2_fastq** out);
+/* c2_fastq_unique with the reference's read filter fused in front (CRISPResso2/filterFastqs.py:128-226, called from
+ * CRISPRessoCORE.py:3696-3717 for --min_single_bp_quality / --min_average_read_quality / --min_bp_quality_or_N; <= 0 = not
+ * set): the records that pass, with low-quality bases masked to 'N', are what gets de-duplicated -- the same bytes the
+ * reference writes to its *_filtered.fastq.gz, without the file.  c2_fastq_n_reads = reads after the filter;
+ * *nonempty_lines_in_input = what `grep -c .` counts in the input (the reference's N_READS_INPUT is int(that / 4.0),
+ * CRISPRessoShared.py:743-748).  The reference's own failures (empty quality line under a minimum, sequence / quality
+ * length mismatch under masking, the read-only buffer of its single-bp + mask combination) return C2_E_INVALID. */
+int c2_fastq_unique_filtered(const char* path, int32_t min_bp_qual_in_read, int32_t min_av_read_qual, int32_t min_bp_qual_or_N,
+                             c2_fastq** out, uint64_t* nonempty_lines_in_input);
 uint64_t c2_fastq_n_unique(const c2_fastq* r);
 uint64_t c2_fastq_n_reads(const c2_fastq* r);
 uint64_t c2_fastq_arena_bytes(const c2_fastq* r);

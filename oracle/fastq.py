@@ -78,3 +78,51 @@ def paired_occurrences(path1, path2, wanted):
     f1.close()
     f2.close()
     return out
+
+
+def filter_fastq(path_in, path_out, min_bp_qual_in_read=None, min_av_read_qual=None, min_bp_qual_or_N=None):
+    """Single-file route of filterFastqs.filterFastqs (reference CRISPResso2/filterFastqs.py:29-126 dispatch, :128-226 the
+    seven loops), restated as ONE loop with the statements of each loop in its own order: binary readline + rstrip, uint8
+    qualities minus 33, numpy mean / min, N-masking through a boolean index -- including run_mBP_mBPN's missing .copy()
+    (assignment into a read-only frombuffer view raises).  Pinned: FANC.Cas9.fastq with -q 30 gives byte for byte the
+    *_filtered.fastq.gz content of the reference's CRISPResso_on_params run (tests/golden/params_run.json.gz).
+    -> int(`grep -c .` / 4.0) of the input, the reference's N_READS_INPUT (CRISPRessoShared.py:743-748)."""
+    import io
+    import numpy
+    mBP, mRQ, mBPN = bool(min_bp_qual_in_read), bool(min_av_read_qual), bool(min_bp_qual_or_N)
+    if not (mBP or mRQ or mBPN):
+        raise SystemExit('Finished -- No modifications requested')                      # :105
+    f1_in = io.BufferedReader(gzip.open(path_in, 'rb')) if str(path_in).endswith('.gz') else open(path_in, 'rb')     # :48-57
+    f1_out = gzip.open(path_out, 'wt') if str(path_out).endswith('.gz') else open(path_out, 'w')                     # :60-63
+    try:
+        idLine = f1_in.readline().rstrip().decode('utf-8')
+        while idLine:
+            seqLine = f1_in.readline().rstrip()
+            plusLine = f1_in.readline().rstrip()
+            qualLine = f1_in.readline().rstrip()
+            npQualLine = numpy.frombuffer(qualLine, dtype=numpy.uint8) - 33
+            keep = True
+            if mBP and mRQ and not mBPN:                                                  # run_mBP_mRQ :167-179: mean, then min
+                keep = bool(numpy.mean(npQualLine) >= min_av_read_qual)
+                if keep:
+                    keep = bool(numpy.min(npQualLine) >= min_bp_qual_in_read)
+            else:                                                                         # every other loop: min (if asked), then mean (if asked)
+                if mBP:
+                    keep = bool(numpy.min(npQualLine) >= min_bp_qual_in_read)
+                if keep and mRQ:
+                    keep = bool(numpy.mean(npQualLine) >= min_av_read_qual)
+            if keep:
+                if mBPN:
+                    npSeqLine = numpy.frombuffer(seqLine, 'c') if (mBP and not mRQ) else numpy.frombuffer(seqLine, 'c').copy()   # :191 vs :136, :206, :223
+                    npSeqLine[npQualLine < min_bp_qual_or_N] = 'N'
+                    seq_text = npSeqLine.tobytes().decode('utf-8')
+                else:
+                    seq_text = seqLine.decode('utf-8')
+                f1_out.write("%s\n%s\n%s\n%s\n" % (idLine, seq_text, plusLine.decode('utf-8'), qualLine.decode('utf-8')))
+            idLine = f1_in.readline().rstrip().decode('utf-8')
+    finally:
+        f1_in.close()
+        f1_out.close()
+    opener = gzip.open if str(path_in).endswith('.gz') else open
+    with opener(path_in, 'rb') as fh:
+        return int(float(sum(1 for line in fh.read().split(b'\n') if line)) / 4.0)

@@ -428,3 +428,101 @@ def test_paired_gzip_cut_short_is_an_error_like_pythons_eoferror(tmp_path):
             ofq.read_paired_fastq_unique(str(p1), str(p2))
         with pytest.raises(_native.NativeError):
             _native.PairedFastq(str(p1), str(p2))
+
+
+# ---- the read filter of filterFastqs.py, fused into the native ingest ------------------------------------------------------
+def native_filtered(path, mbp, mrq, mbpn):
+    from crispresso2_amd import _native
+    st = {}
+    arena, offsets, counts, total = _native.fastq_unique(str(path), min_single_bp_quality=mbp, min_average_read_quality=mrq,
+                                                         min_bp_quality_or_N=mbpn, stats=st)
+    buf = arena.tobytes()
+    seqs = [buf[int(offsets[k]):int(offsets[k + 1])].decode() for k in range(len(counts))]
+    return dict(zip(seqs, (int(c) for c in counts))), seqs, total, st["N_READS_INPUT"]
+
+
+def check_filtered(path, tmp_path, mbp, mrq, mbpn):
+    """the oracle writes the reference's intermediate file and reads it back with the reference's loop; the native route
+    must give the same dict, order and counts from the ORIGINAL file in one pass"""
+    mid = tmp_path / "oracle_filtered.fastq"
+    n_in = ofq.filter_fastq(str(path), str(mid), mbp or None, mrq or None, mbpn or None)
+    exp, n = ofq.read_fastq_unique(str(mid))
+    got, order, total, n_input = native_filtered(path, mbp, mrq, mbpn)
+    assert (total, n_input) == (n, n_in)
+    assert got == exp and order == list(exp.keys())
+    return n
+
+
+def test_read_filter_reproduces_the_filtered_file_of_the_reference_params_run(tmp_path):
+    """FANC.Cas9.fastq with -q 30 (CRISPResso_on_params): the oracle's filtered text is the content of the reference's own
+    FANC.Cas9_filtered.fastq.gz (pins the restatement), and the fused native route sees exactly those reads."""
+    from helpers import load_golden
+    raw = tmp_path / "FANC.Cas9.fastq"
+    raw.write_text(load_golden("fanc_run.json.gz")["fastq"])
+    want = load_golden("params_run.json.gz")
+    mid = tmp_path / "f.fastq"
+    assert ofq.filter_fastq(str(raw), str(mid), None, 30, None) == want["alignment_stats"]["N_READS_INPUT"] == 250
+    assert mid.read_text() == want["fastq_after_quality_filter"]
+    assert check_filtered(raw, tmp_path, 0, 30, 0) == want["alignment_stats"]["N_READS_AFTER_PREPROCESSING"] == 231
+    g = tmp_path / "FANC.Cas9.fastq.gz"
+    with gzip.open(g, "wb") as fh:
+        fh.write(raw.read_bytes())
+    assert check_filtered(g, tmp_path, 0, 30, 0) == 231
+
+
+@pytest.mark.parametrize("opts", [(0, 25, 0), (12, 0, 0), (0, 0, 15), (10, 22, 0), (0, 24, 14), (8, 20, 12)])
+@pytest.mark.parametrize("route", ["auto", "stream"])
+def test_read_filter_option_combinations_random_files(tmp_path, monkeypatch, opts, route):
+    monkeypatch.setenv("C2_FASTQ_GZ", route)
+    rng = np.random.default_rng(sum(opts))
+    seqs = random_seqs(1500, rng, lo=15, hi=120, pool=40)
+    recs = []
+    for k, s in enumerate(seqs):
+        q = rng.integers(33 + int(rng.integers(0, 30)), 75, len(s))
+        if k % 17 == 0:
+            q[int(rng.integers(0, len(s)))] = 33 + int(rng.integers(0, 10))        # one bad base
+        pad = ["", " ", "\t ", "\r"][k % 4]                                        # rstrip() takes these off every line
+        recs.append("@r%d%s\n%s%s\n+%s\n%s%s\n" % (k, pad, s, pad, pad, "".join(chr(int(x)) for x in q), pad))
+    text = "".join(recs)
+    p = tmp_path / "q.fastq"
+    p.write_bytes(text.encode())
+    n = check_filtered(p, tmp_path, *opts)
+    assert 0 < n < len(seqs) or opts == (0, 0, 15)
+    g = tmp_path / "q.fastq.gz"
+    g.write_bytes(bgzf_bytes(text.encode(), block=5000) if sum(opts) % 2 else gzip.compress(text.encode()))
+    assert check_filtered(g, tmp_path, *opts) == n
+
+
+def test_read_filter_framing_wraparound_and_the_reference_failures(tmp_path):
+    from crispresso2_amd import _native
+    cases = {
+        "blank_id_line_ends_the_file": ("@a\nACGT\n+\nIIII\n\n@b\nGGCC\n+\nIIII\n", (0, 20, 0)),
+        "truncated_last_record": ("@a\nACGT\n+\nIIII\n@b\nGGCC\n", (0, 20, 0)),             # empty quality line: mean is nan -> dropped
+        "no_final_newline": ("@a\nACGT\n+\nIIII\n@b\nGGCC\n+\nIII5", (0, 20, 15)),
+        "qualities_below_33_wrap": ("@a\nACGT\n+\n I!I\n@b\nGGCC\n+\nIIII\n", (0, 60, 0)),       # ' ' - 33 = 255 in uint8
+        "wrap_passes_the_minimum": ("@a\nACGT\n+\n  \x1f \n", (200, 0, 0)),
+        "crlf": ("@a\r\nACGT\r\n+\r\nII#I\r\n@b\r\nGGCC\r\n+\r\nIIII\r\n", (0, 0, 20)),
+        "cr_only_is_one_line": ("@a\rACGT\r+\rIIII\r", (0, 10, 0)),
+        "nothing_passes": ("@a\nACGT\n+\n####\n", (0, 30, 0)),
+        "lowercase_masked": ("@a\nacgt\n+\nI#I#\n", (0, 0, 10)),
+    }
+    for name, (text, opts) in cases.items():
+        p = tmp_path / (name + ".fastq")
+        p.write_bytes(text.encode("latin-1"))
+        check_filtered(p, tmp_path, *opts)
+    failing = {
+        "empty_quality_under_minimum": ("@a\nACGT\n+\n\n", (5, 0, 0), ValueError),
+        "length_mismatch_under_masking": ("@a\nACGT\n+\nIII\n", (0, 0, 10), IndexError),
+        "read_only_view_of_run_mBP_mBPN": ("@a\nACGT\n+\nIIII\n", (5, 0, 10), ValueError),
+    }
+    for name, (text, opts, exc) in failing.items():
+        p = tmp_path / (name + ".fastq")
+        p.write_bytes(text.encode())
+        with pytest.raises(exc):
+            ofq.filter_fastq(str(p), str(tmp_path / "o.fastq"), opts[0] or None, opts[1] or None, opts[2] or None)
+        with pytest.raises(_native.NativeError):
+            native_filtered(p, *opts)
+    # the read-only failure needs a read that reaches the masking step: none does here, and neither side fails
+    p = tmp_path / "mBP_mBPN_nothing_passes.fastq"
+    p.write_bytes(b"@a\nACGT\n+\n#III\n")
+    check_filtered(p, tmp_path, 5, 0, 10)

@@ -330,3 +330,21 @@ def test_params_run_tables_from_the_emulated_kernels(tmp_path):
     written = tables.write_tables(WithAlleles(per_ref, stats, lay, None), refs, names, str(tmp_path),
                                   plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
     assert _compare_params(g, written, str(tmp_path)) == 37
+
+
+@pytest.mark.gpu
+def test_params_run_from_the_unfiltered_fastq_with_the_fused_read_filter(tmp_path):
+    """CRISPResso_on_params from its real input: FANC.Cas9.fastq with -q 30 fused into the ingest (no intermediate file) ->
+    the same 37 files, READS IN INPUTS 250 / READS AFTER PREPROCESSING 231 from the library itself."""
+    import argparse
+    from crispresso2_amd import _native, pipeline, tables
+    g, refs, names = _params_golden()
+    fq = tmp_path / "FANC.Cas9.fastq"
+    fq.write_text(_golden()["fastq"])
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    a["min_average_read_quality"] = 30
+    res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], argparse.Namespace(**a), ctx=_native.default_context())
+    assert (res.stats["N_READS_INPUT"], res.stats["N_READS_AFTER_PREPROCESSING"]) == (250, 231)
+    out = tmp_path / "CRISPResso_on_params"
+    written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(out)) == 37
