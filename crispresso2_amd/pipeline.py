@@ -35,9 +35,12 @@ class QuantResult:
     """per_ref[name]: the dict of counts.CountLayout.unpack (vectors named after the reference's variables);
     stats: N_TOT_READS, N_CACHED_ALN, ... (process_fastq's aln_stats) plus N_TOTAL and N_AMBIGUOUS of the aggregation loop;
     alleles(): the rows of the allele frequency table."""
-    def __init__(self, per_ref, stats, layout, tensor, state=None):
+    def __init__(self, per_ref, stats, layout, tensor, state=None, first_ref_view=None):
         self.per_ref, self.stats, self.layout, self.tensor = per_ref, stats, layout, tensor
         self._state = state
+        # {name: all_* count vectors of the reads counted for that amplicon, in the coordinates of the FIRST amplicon}
+        # (CRISPRessoCORE.py:4195-4270; built for runs with an expected HDR amplicon / prime-editing extension), else None
+        self.first_ref_view = first_ref_view
 
     def alleles(self):
         """Rows (Aligned_Sequence, Reference_Sequence, Reference_Name, Read_Status, n_deleted, n_inserted, n_mutated, #Reads,
@@ -262,15 +265,51 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         d_w2 = torch.from_numpy(w2.view(np.int32)).to(dev)
         C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_counts.data_ptr(),
                             d_weights=d_w2.data_ptr(), flags=flags, stream=stream)
+    # ---- every amplicon's reads in the coordinates of the FIRST amplicon (:4195-4270; runs with an expected HDR amplicon or a
+    # prime-editing extension).  The alignment of every read against the first amplicon is already on the device
+    # (ref_aln_details[0]); the reference classifies it again and adds its all_* positions and bases into arrays of the
+    # amplicon the read is counted for.  Here: one more count launch per other amplicon r over those alignments, weighted
+    # with the multiplicities of the reads counted for r; row 0 of that launch's tensor is amplicon r's view.  No ignore_* /
+    # discard flags: the reference's loop has none.
+    d_view = None
+    if k > 1 and (getattr(args, 'expected_hdr_amplicon_seq', '') or getattr(args, 'prime_editing_pegRNA_extension_seq', '')):
+        d_view = torch.zeros((k,) + tuple(layout.shape()), dtype=torch.int64, device=dev)
+        for r in range(1, k):
+            wv = np.zeros((n, k), dtype=np.uint32)
+            wv[:, 0] = np.where(counted[:, r] & ~use2[:, 0], cnt, 0)
+            d_wv = torch.from_numpy(wv.reshape(-1).view(np.int32)).to(dev)
+            C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_view[r].data_ptr(),
+                                d_weights=d_wv.data_ptr(), flags=0, stream=stream)
+            if n2:
+                wv2 = np.where((br == 0) & counted[bi, r] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
+                if wv2.any():
+                    d_wv2 = torch.from_numpy(wv2.view(np.int32)).to(dev)
+                    C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_view[r].data_ptr(),
+                                        d_weights=d_wv2.data_ptr(), flags=0, stream=stream)
+            torch.cuda.synchronize(dev)                              # the weight tensors of this round are done with
     if reduce_across_ranks:
         C.all_reduce(d_counts)
+        if d_view is not None:
+            C.all_reduce(d_view)
     torch.cuda.synchronize(dev)
     host = d_counts.cpu().numpy()
     lap("count_kernels")
     per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
+    first_ref_view = None
+    if d_view is not None:
+        view_keys = (["all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
+                      "all_substitution_count_vectors"] + ["all_base_count_vectors_" + x for x in "ACGTN-"])
+        host_view = d_view.cpu().numpy()
+        first_ref_view = {ref_names[0]: {kk: per_ref[ref_names[0]][kk] for kk in view_keys}}
+        for r in range(1, k):
+            u = layout.unpack(host_view[r], 0, L[0])
+            first_ref_view[ref_names[r]] = {kk: u[kk] for kk in view_keys}
+        for v in first_ref_view.values():
+            v["all_indelsub_count_vectors"] = (v["all_insertion_count_vectors"] + v["all_deletion_count_vectors"]
+                                               + v["all_substitution_count_vectors"])
     state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=slot2,
                  a1=a1, f1=f1, rec1=rec1, a2=a2 if n2 else None, f2=f2 if n2 else None, rec2=rec2)
-    return QuantResult(per_ref, stats, layout, d_counts, state)
+    return QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
 
 
 def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None):

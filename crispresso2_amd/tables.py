@@ -173,6 +173,49 @@ def write_alleles_around_cut(rows, path):
             fh.write("%s\t%s\t%s\t%d\t%d\t%d\t%d\t%s\n" % (a, r, "True" if unedited else "False", dn, inn, sn, reads, _f(pct)))
 
 
+def write_reads_from_all_amplicons_tables(res, refs, ref_names, out_dir):
+    """<first ref>Reads_from_all_amplicons_{modification,nucleotide}_percent_table.txt (CRISPRessoCORE.py:5104-5114 from
+    plots/data_prep.py:247-282, :943-982): for every amplicon with reads, the insertion / deletion / substitution counts and
+    the base counts of ITS reads in the coordinates of the FIRST amplicon (`res.first_ref_view`, the arrays of
+    CRISPRessoCORE.py:4195-4270), divided by that amplicon's read count.  The reference passes these fractions through text
+    (numpy concatenates them with the row labels into a string array) and through pandas' to_numeric before printing, which
+    changes the last digits of some values; the same two steps are taken here so that the files agree byte for byte."""
+    import numpy as np
+    import pandas as pd
+    view = res.first_ref_view
+    with_reads = [nm for nm in ref_names if res.per_ref[nm]["counts_total"] > 0]
+    first = with_reads[0]
+    seq = refs[first]["sequence"]
+    L = len(seq)
+
+    def as_printed(label_cells, values):
+        cells = np.concatenate((label_cells, values))[len(label_cells):]
+        return [repr(float(x)) for x in pd.to_numeric(pd.Series(list(cells)), errors='coerce')]
+    prefix = ref_plot_name(ref_names, first)
+    written = []
+    fn = prefix + "Reads_from_all_amplicons_modification_percent_table.txt"
+    with open(os.path.join(out_dir, fn), "w") as fh:
+        fh.write("Amplicon\tModification\t" + "\t".join(seq) + "\n")
+        for nm in with_reads:
+            tot = float(res.per_ref[nm]["counts_total"])
+            v = view[nm]
+            for label, key in (("Insertions", "all_insertion_count_vectors"), ("Insertions_Left", "all_insertion_left_count_vectors"),
+                               ("Deletions", "all_deletion_count_vectors"), ("Substitutions", "all_substitution_count_vectors"),
+                               ("All_modifications", "all_indelsub_count_vectors")):
+                fh.write("\t".join([nm, label] + as_printed([nm, label], np.array(v[key][:L]).astype(float) / tot)) + "\n")
+            fh.write("\t".join([nm, "Total"] + as_printed([nm, "Total"], [res.per_ref[nm]["counts_total"]] * L)) + "\n")
+    written.append(fn)
+    fn = prefix + "Reads_from_all_amplicons_nucleotide_percent_table.txt"
+    with open(os.path.join(out_dir, fn), "w") as fh:
+        fh.write("Amplicon\tNucleotide\t" + "\t".join(seq) + "\n")
+        for nm in with_reads:
+            tot = float(res.per_ref[nm]["counts_total"])
+            for nuc in "ACGTN-":
+                fh.write("\t".join([nm, nuc] + as_printed([nm, nuc], np.array(view[nm]["all_base_count_vectors_" + nuc][:L]).astype(float) / tot)) + "\n")
+    written.append(fn)
+    return written
+
+
 def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN=""):
     """Writes the tables listed in the module docstring into out_dir; returns the list of file names."""
     import numpy as np
@@ -247,4 +290,6 @@ def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN=""):
                 fn = prefix + "Alleles_frequency_table_around_" + slugify(label if label != "" else "sgRNA_" + guide) + ".txt"
                 write_alleles_around_cut(alleles_around_cut(allele_rows, name, cut_point, L, plot_window_size), os.path.join(out_dir, fn))
                 written.append(fn)
+    if getattr(res, "first_ref_view", None) and any(res.per_ref[nm]["counts_total"] > 0 for nm in ref_names):
+        written += write_reads_from_all_amplicons_tables(res, refs, ref_names, out_dir)
     return written

@@ -135,3 +135,39 @@ def alleles_around_cut(rows, ref_name, cut_point, ref_len, plot_window_size=20):
     buf = io.StringIO()
     d.to_csv(buf, sep='\t', header=True, index=True, index_label=d.index.name)
     return buf.getvalue()
+
+
+def remap_to_first_reference(first_ref_vectors, items_by_ref, ref1_len, ref1_include_idxs):
+    """Restatement of the 'all reads with respect to ref1' arrays (CRISPRessoCORE.py:4195-4264), built when an expected HDR
+    amplicon or a prime-editing extension is given.  first_ref_vectors: the aggregate() result of the first reference (its
+    all_* vectors are copied, :4217-4224); items_by_ref: {name of another reference: [(s1, s2, count)]} with the alignment of
+    every read counted for that reference AGAINST THE FIRST reference (variant['ref_aln_details'][0]).
+    -> {name: {vector name: numpy vector of length ref1_len}} for the first reference (key None) and the others."""
+    import oracle
+    names = ("all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
+             "all_substitution_count_vectors")
+    out = {None: {k: first_ref_vectors[k].copy() for k in names}}
+    out[None]["all_indelsub_count_vectors"] = (first_ref_vectors["all_insertion_count_vectors"] + first_ref_vectors["all_deletion_count_vectors"]
+                                               + first_ref_vectors["all_substitution_count_vectors"])
+    for n in "ACGTN-":
+        out[None]["all_base_count_vectors_" + n] = first_ref_vectors["all_base_count_vectors_" + n].copy()
+    for name, items in items_by_ref.items():
+        v = {k: np.zeros(ref1_len) for k in names + ("all_indelsub_count_vectors",)}
+        for n in "ACGTN-":
+            v["all_base_count_vectors_" + n] = np.zeros(ref1_len)
+        for s1, s2, count in items:
+            payload = oracle.find_indels_substitutions(s1, s2, ref1_include_idxs)                      # :4247
+            v["all_insertion_count_vectors"][payload['all_insertion_positions']] += count               # :4256-4264
+            v["all_insertion_left_count_vectors"][payload['all_insertion_left_positions']] += count
+            v["all_indelsub_count_vectors"][payload['all_insertion_positions']] += count
+            v["all_deletion_count_vectors"][payload['all_deletion_positions']] += count
+            v["all_indelsub_count_vectors"][payload['all_deletion_positions']] += count
+            v["all_substitution_count_vectors"][payload['all_substitution_positions']] += count
+            v["all_indelsub_count_vectors"][payload['all_substitution_positions']] += count
+            ref_pos = payload['ref_positions']
+            for i in range(len(s1)):                                                                    # :4266-4270
+                if ref_pos[i] < 0:
+                    continue
+                v["all_base_count_vectors_" + s1[i]][ref_pos[i]] += count
+        out[name] = v
+    return out

@@ -497,7 +497,8 @@ PARAMS_TABLES = ("CRISPResso_quantification_of_editing_frequency.txt", "CRISPRes
                  "Quantification_window_nucleotide_percentage_table.txt", "Modification_count_vectors.txt",
                  "Quantification_window_modification_count_vectors.txt", "Effect_vector_insertion.txt", "Effect_vector_deletion.txt",
                  "Effect_vector_substitution.txt", "Effect_vector_combined.txt", "Indel_histogram.txt", "Insertion_histogram.txt",
-                 "Deletion_histogram.txt", "Substitution_histogram.txt", "Alleles_frequency_table_around_")
+                 "Deletion_histogram.txt", "Substitution_histogram.txt", "Alleles_frequency_table_around_",
+                 "Reads_from_all_amplicons_modification_percent_table.txt", "Reads_from_all_amplicons_nucleotide_percent_table.txt")
 
 
 def params_run():
@@ -554,7 +555,7 @@ def params_run():
     keep = ("aln_seed_count", "aln_seed_len", "aln_seed_min", "needleman_wunsch_gap_open", "needleman_wunsch_gap_extend",
             "use_legacy_insertion_quantification", "ignore_deletions", "ignore_insertions", "ignore_substitutions",
             "assign_ambiguous_alignments_to_first_reference", "expand_ambiguous_alignments", "prime_editing_pegRNA_scaffold_seq",
-            "discard_indel_reads", "plot_window_size", "dsODN")
+            "discard_indel_reads", "plot_window_size", "dsODN", "expected_hdr_amplicon_seq", "prime_editing_pegRNA_extension_seq")
     return {"command": " ".join(argv), "fastq_after_quality_filter": fastq, "refs": refs, "args": {k: a[k] for k in keep},
             "alignment_stats": info["running_info"]["alignment_stats"], "files": files}
 

@@ -194,7 +194,7 @@ def test_params_run_tables_from_oracle_counts(tmp_path):
     """Two amplicons (FANC + the expected HDR allele), quantification window from coordinates, min_aln_score 80, three guides
     (named, flexible), --dsODN: the reads that survive the reference's quality filter + the per-amplicon records it derived
     (make_golden.py --params) -> oracle alignments, the reference's best-amplicon rule (CRISPRessoCORE.py:697-707), oracle
-    aggregation -> 37 result files of the reference's run byte for byte (two of them are kept in its repository)."""
+    aggregation -> 39 result files of the reference's run byte for byte (two of them are kept in its repository)."""
     import oracle
     from oracle import aggregate
     from crispresso2_amd import tables, counts as C
@@ -210,6 +210,7 @@ def test_params_run_tables_from_oracle_counts(tmp_path):
     stats = dict(N_TOT_READS=len(reads), N_READS_INPUT=g["alignment_stats"]["N_READS_INPUT"], N_READS_AFTER_PREPROCESSING=len(reads),
                  N_TOTAL=0, N_COMPUTED_ALN=0, N_CACHED_ALN=0, N_COMPUTED_NOTALN=0, N_CACHED_NOTALN=0)
     items, rows = {nm: [] for nm in names}, []
+    to_first = {nm: [] for nm in names[1:]}
     for rd, c in unique.items():
         best, best_names, al = 0, [], {}
         for nm in names:                                            # forward strand: the reads of this file are
@@ -231,6 +232,8 @@ def test_params_run_tables_from_oracle_counts(tmp_path):
         p = oracle.find_indels_substitutions(al[nm][0], al[nm][1], refs[nm]["include_idxs"])
         p["aln_seq"], p["aln_ref"] = al[nm]
         items[nm].append((p, c))
+        if nm != names[0]:
+            to_first[nm].append((al[names[0]][0], al[names[0]][1], c))        # ref_aln_details[0]: its alignment against the first amplicon
         mod = p["insertion_n"] + p["deletion_n"] + p["substitution_n"] > 0
         rows.append((al[nm][0], al[nm][1], nm, "MODIFIED" if mod else "UNMODIFIED", p["deletion_n"], p["insertion_n"], p["substitution_n"], c))
     for k in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS"):
@@ -242,8 +245,12 @@ def test_params_run_tables_from_oracle_counts(tmp_path):
         def alleles(self):
             return sorted([r + (r[7] / stats["N_TOTAL"] * 100,) for r in rows], key=lambda t: (-t[7], t[0], t[1]))
     res = WithAlleles(per_ref, stats, lay, None)
+    # the run has an expected HDR amplicon: every amplicon's reads in the coordinates of the first one (:4195-4270)
+    view = aggregate.remap_to_first_reference(per_ref[names[0]], to_first, len(refs[names[0]]["sequence"]), refs[names[0]]["include_idxs"])
+    view[names[0]] = view.pop(None)
+    res.first_ref_view = view
     written = tables.write_tables(res, refs, names, str(tmp_path), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
-    assert _compare_params(g, written, str(tmp_path)) == 37
+    assert _compare_params(g, written, str(tmp_path)) == 39
     with pytest.raises(KeyError):                                   # the reference's own failure for an oligo of <= 6 bases
         tables.write_alleles_frequency_table(res, str(tmp_path / "x.txt"), dsODN="ACGTAC")
 
@@ -251,7 +258,7 @@ def test_params_run_tables_from_oracle_counts(tmp_path):
 @pytest.mark.gpu
 def test_params_run_tables_from_the_device_pipeline(tmp_path):
     """The same run through pipeline.quantify_fastq: native ingest, seeds, both amplicons aligned on the GPU, best-amplicon
-    selection, count kernel -> the same 37 files."""
+    selection, count kernel -> the same 39 files."""
     import argparse
     from crispresso2_amd import _native, pipeline, tables
     g, refs, names = _params_golden()
@@ -266,13 +273,13 @@ def test_params_run_tables_from_the_device_pipeline(tmp_path):
     res.stats["N_READS_AFTER_PREPROCESSING"] = g["alignment_stats"]["N_READS_AFTER_PREPROCESSING"]
     out = tmp_path / "CRISPResso_on_params"
     written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
-    assert _compare_params(g, written, str(out)) == 37
+    assert _compare_params(g, written, str(out)) == 39
 
 
 def test_params_run_tables_from_the_emulated_kernels(tmp_path):
     """The same run with the HIP kernels compiled for the host by the wave emulator (tests/emu): every read against both
     amplicons through the default launch chain, best amplicon from the 32-byte records with the reference's score expression,
-    c2_count_vectors_kernel with the read multiplicities as weights -> the count tensor -> the 37 files.  (CPU stand-in for
+    c2_count_vectors_kernel with the read multiplicities as weights -> the count tensor -> the 39 files.  (CPU stand-in for
     test_params_run_tables_from_the_device_pipeline: same kernels, same tables; only the host-side selection of pipeline.py is not exercised here.)"""
     import numpy as np
     import emu_driver as E
@@ -327,15 +334,30 @@ def test_params_run_tables_from_the_emulated_kernels(tmp_path):
     class WithAlleles(QuantResult):
         def alleles(self):
             return sorted([r + (r[7] / stats["N_TOTAL"] * 100,) for r in rows], key=lambda t: (-t[7], t[0], t[1]))
-    written = tables.write_tables(WithAlleles(per_ref, stats, lay, None), refs, names, str(tmp_path),
-                                  plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
-    assert _compare_params(g, written, str(tmp_path)) == 37
+    res_ = WithAlleles(per_ref, stats, lay, None)
+    # the first-amplicon view, the way pipeline.py builds it: one more count launch per other amplicon over the alignments against
+    # the FIRST amplicon, weighted with the multiplicities of the reads counted for that amplicon; row 0 of the result is the view
+    view_keys = ["all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
+                 "all_substitution_count_vectors"] + ["all_base_count_vectors_" + x for x in "ACGTN-"]
+    view = {names[0]: {kk: per_ref[names[0]][kk] for kk in view_keys}}
+    for r in range(1, k):
+        w_r = np.zeros(len(rec), dtype=np.uint32)
+        w_r[0::k] = weights[r::k]                                    # weight of task (i, r) moved onto task (i, 0)
+        c_r, _ = E.count_vectors(o1, o2, rec, seqs, [list(refs[nm]["include_idxs"]) for nm in names], max(len(r_) for r_ in ureads), weights=w_r)
+        u = lay.unpack(c_r, 0, len(seqs[0]))
+        view[names[r]] = {kk: u[kk] for kk in view_keys}
+    for nm in names:
+        view[nm]["all_indelsub_count_vectors"] = (view[nm]["all_insertion_count_vectors"] + view[nm]["all_deletion_count_vectors"]
+                                                  + view[nm]["all_substitution_count_vectors"])
+    res_.first_ref_view = view
+    written = tables.write_tables(res_, refs, names, str(tmp_path), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(tmp_path)) == 39
 
 
 @pytest.mark.gpu
 def test_params_run_from_the_unfiltered_fastq_with_the_fused_read_filter(tmp_path):
     """CRISPResso_on_params from its real input: FANC.Cas9.fastq with -q 30 fused into the ingest (no intermediate file) ->
-    the same 37 files, READS IN INPUTS 250 / READS AFTER PREPROCESSING 231 from the library itself."""
+    the same 39 files, READS IN INPUTS 250 / READS AFTER PREPROCESSING 231 from the library itself."""
     import argparse
     from crispresso2_amd import _native, pipeline, tables
     g, refs, names = _params_golden()
@@ -347,4 +369,56 @@ def test_params_run_from_the_unfiltered_fastq_with_the_fused_read_filter(tmp_pat
     assert (res.stats["N_READS_INPUT"], res.stats["N_READS_AFTER_PREPROCESSING"]) == (250, 231)
     out = tmp_path / "CRISPResso_on_params"
     written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
-    assert _compare_params(g, written, str(out)) == 37
+    assert _compare_params(g, written, str(out)) == 39
+
+
+# ---- pipeline.py itself on the CPU: its device calls redirected to the wave emulator (tests/pipeline_on_emulator.py) --------
+def _pipeline_args(extra=None):
+    import argparse
+    a = dict(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+             use_legacy_insertion_quantification=False, ignore_deletions=False, ignore_insertions=False,
+             ignore_substitutions=False, assign_ambiguous_alignments_to_first_reference=False,
+             expand_ambiguous_alignments=False, prime_editing_pegRNA_scaffold_seq="", discard_indel_reads=False)
+    a.update(extra or {})
+    return argparse.Namespace(**a)
+
+
+def test_pipeline_host_logic_on_the_emulator_fanc_run(tmp_path):
+    """pipeline.quantify_fastq end to end without a GPU: native ingest, seeds, emulated launch chain, selection, reverse-
+    complement merge, emulated count kernel, allele rows from the string buffers -> the 18 files of the reference's FANC run."""
+    from pipeline_on_emulator import emulated_device
+    from crispresso2_amd import pipeline, tables, refs as RF
+    g = _golden()
+    fq = tmp_path / "FANC.Cas9.fastq"
+    fq.write_text(g["fastq"])
+    cut = g["cut_point"]
+    ref = RF.make_ref("Reference", g["amplicon"], [cut], [cut, cut + 1], min_aln_score=60)
+    ref["sgRNA_orig_sequences"] = [g["guide"]]
+    with emulated_device():
+        res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args())
+        out = tmp_path / "out"
+        names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
+    assert res.first_ref_view is None
+    assert _compare(g, names, str(out)) == 18
+
+
+def test_pipeline_host_logic_on_the_emulator_params_run_with_fused_filter_and_hdr_view(tmp_path):
+    """The two-amplicon run from its raw FASTQ: read filter fused into the ingest, both amplicons per read, best-amplicon
+    selection, count launches, the first-amplicon view launches (expected HDR amplicon) -> the 39 files."""
+    from pipeline_on_emulator import emulated_device
+    from crispresso2_amd import pipeline, tables
+    g, refs, names = _params_golden()
+    fq = tmp_path / "FANC.Cas9.fastq"
+    fq.write_text(_golden()["fastq"])
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    a["min_average_read_quality"] = 30
+    with emulated_device():
+        res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
+        out = tmp_path / "out"
+        written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert (res.stats["N_READS_INPUT"], res.stats["N_READS_AFTER_PREPROCESSING"]) == (250, 231)
+    for k in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS", "N_GLOBAL_SUBS",
+              "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS"):
+        assert res.stats[k] == g["alignment_stats"][k], k
+    assert set(res.first_ref_view) == set(names)
+    assert _compare_params(g, written, str(out)) == 39
