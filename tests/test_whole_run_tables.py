@@ -422,3 +422,32 @@ def test_pipeline_host_logic_on_the_emulator_params_run_with_fused_filter_and_hd
         assert res.stats[k] == g["alignment_stats"][k], k
     assert set(res.first_ref_view) == set(names)
     assert _compare_params(g, written, str(out)) == 39
+
+
+def test_pipeline_on_the_emulator_both_strand_batch_feeds_counts_view_and_alleles(tmp_path):
+    """Same run with every third unique read reverse-complemented and the seed test made inconclusive (aln_seed_min beyond the
+    number of seeds), so that every (read, amplicon) pair is also aligned as its reverse complement in the second batch and the
+    reverse-complemented reads take their alignments -- counts, first-amplicon view and allele rows -- from THAT batch.  No
+    read coexists with its reverse complement, so by symmetry the reference's result files are the same 39."""
+    from pipeline_on_emulator import emulated_device
+    from crispresso2_amd import pipeline, tables, refs as RF
+    g, refs, names = _params_golden()
+    lines = g["fastq_after_quality_filter"].split("\n")
+    recs, order = [], {}
+    for k in range(0, len(lines) - 1, 4):
+        rid, seq, plus, qual = lines[k:k + 4]
+        if order.setdefault(seq, len(order)) % 3 == 1:               # all copies of a read together: no read meets its reverse complement
+            seq, qual = RF.reverse_complement(seq), qual[::-1]
+        recs.append("%s\n%s\n%s\n%s\n" % (rid, seq, plus, qual))
+    fq = tmp_path / "mixed_strands.fastq"
+    fq.write_text("".join(recs))
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    a["aln_seed_min"] = 1000
+    with emulated_device():
+        res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
+        S = res._state
+        assert S["rec2"] is not None and S["use2"][:, 0].sum() > 30 and (~S["use2"][:, 0]).sum() > 60
+        res.stats["N_READS_INPUT"] = 250                              # the file fed here is the already filtered one
+        out = tmp_path / "out"
+        written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(out)) == 39
