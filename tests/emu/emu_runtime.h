@@ -9,6 +9,8 @@ int cur_lane = 0, n_threads = W;
 dim3_ block_idx, grid_dim, block_dim;
 ucontext_t lane_ctx[MAXT], sched_ctx;
 bool lane_done[MAXT];
+jmp_buf lane_jb[MAXT];
+bool lane_has_jb[MAXT];
 uint64_t xl_slots[2][MAXT];
 int bar_count = 0, wbar_count[MAXW];
 unsigned bar_gen = 0, wbar_gen[MAXW];
@@ -24,7 +26,7 @@ static void lane_entry() {
     // hand control to any unfinished lane, else back to the scheduler
     for (int k = 1; k <= n_threads; ++k) {
         int c = (cur_lane + k) % n_threads;
-        if (!lane_done[c]) { int me = cur_lane; cur_lane = c; swapcontext(&lane_ctx[me], &lane_ctx[c]); }
+        if (!lane_done[c]) { cur_lane = c; switch_to(c); }          // this fiber is finished: nothing to save
     }
     setcontext(&sched_ctx);
 }
@@ -45,6 +47,7 @@ void launch(unsigned grid, F body, unsigned block) {
         for (int l = 0; l < MAXT; ++l) lane_inactive[l] = false;
         for (int l = 0; l < n_threads; ++l) {
             lane_done[l] = false;
+            lane_has_jb[l] = false;
             getcontext(&lane_ctx[l]);
             lane_ctx[l].uc_stack.ss_sp = stacks.data() + STK * l;
             lane_ctx[l].uc_stack.ss_size = STK;

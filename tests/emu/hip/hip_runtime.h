@@ -9,6 +9,7 @@
 // behaviour; the -m gpu tests are the parity tests proper.
 #pragma once
 #include <ucontext.h>
+#include <setjmp.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,15 @@ extern int n_threads;
 extern dim3_ block_idx, grid_dim, block_dim;
 extern ucontext_t lane_ctx[MAXT], sched_ctx;
 extern bool lane_done[MAXT];
+// A fiber that has run is suspended / resumed with _setjmp / _longjmp (no signal-mask system call per switch, unlike
+// swapcontext: a third of the emulator's run time); ucontext only starts fibers.  Built with _FORTIFY_SOURCE off (the
+// fortified longjmp refuses to jump between stacks).
+extern jmp_buf lane_jb[MAXT];
+extern bool lane_has_jb[MAXT];
+inline void switch_to(int nxt) {              // resume (or start) fiber nxt; does not return
+    if (lane_has_jb[nxt]) _longjmp(lane_jb[nxt], 1);
+    setcontext(&lane_ctx[nxt]);
+}
 extern uint64_t xl_slots[2][MAXT];
 extern int bar_count, wbar_count[MAXW];
 extern unsigned bar_gen, wbar_gen[MAXW];
@@ -49,7 +59,8 @@ inline void yield_next() {
     }
     if (nxt == me) { fprintf(stderr, "emu: deadlock (non-uniform cross-lane op?)\n"); abort(); }
     cur_lane = nxt;
-    swapcontext(&lane_ctx[me], &lane_ctx[nxt]);
+    lane_has_jb[me] = true;
+    if (_setjmp(lane_jb[me]) == 0) switch_to(nxt);
 }
 inline void barrier() {                       // workgroup barrier (s_barrier)
     unsigned gen = bar_gen;

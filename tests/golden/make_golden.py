@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -548,7 +548,7 @@ def params_run():
     refs = []
     for nm, r in info["results"]["refs"].items():
         refs.append({"name": nm, "sequence": r["sequence"], "min_aln_score": r["min_aln_score"], "gap_incentive": r["gap_incentive"]["value"],
-                     "include_idxs": [int(x) for x in r["include_idxs"]], "sgRNA_cut_points": r["sgRNA_cut_points"],
+                     "include_idxs": [int(x) for x in (r["include_idxs"]["value"] if isinstance(r["include_idxs"], dict) else r["include_idxs"])], "sgRNA_cut_points": r["sgRNA_cut_points"],
                      "sgRNA_orig_sequences": r["sgRNA_orig_sequences"], "sgRNA_names": r["sgRNA_names"],
                      "fw_seeds": r["fw_seeds"], "rc_seeds": r["rc_seeds"]})
     a = info["running_info"]["args"]["value"] if "value" in info["running_info"]["args"] else info["running_info"]["args"]
@@ -566,6 +566,75 @@ if __name__ == "__main__" and "--params" in sys.argv:
     with gzip.open(os.path.join(HERE, "params_run.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("params_run.json.gz written:", sorted(d["files"]), d["args"], d["alignment_stats"])
+
+
+# ---------------------------------------------------------------- 6d. two different amplicons in one run (the pooled test data through CORE)
+def both_run():
+    """tests/Both.Cas9.fastq (reads of the FANC and of the HEK3 amplicon, the reference's CRISPRessoPooled test input) through ONE
+    CRISPResso run with both amplicons and their guides (-a A,B -an FANC,HEK3 -g gA,gB): every read aligned against both,
+    assigned to the better one -- the per-read shape of BASELINE.json's pooled configuration.  Recorded like params_run()."""
+    import importlib
+    import zipfile
+    core = load_reference_core()
+    P = importlib.import_module("CRISPResso2.plots.CRISPRessoPlot")
+    for k in dir(P):
+        if k.startswith("plot_") and callable(getattr(P, k)):
+            setattr(P, k, (lambda *a, **kw: None))
+    amps = {}
+    with open(os.path.join(REF, "tests/Cas9.amplicons.txt")) as fh:
+        for line in fh:
+            f = line.split()
+            if len(f) >= 3:
+                amps[f[0]] = (f[1], f[2])
+    names = ["FANC", "HEK3"]
+    with open(os.path.join(REF, "tests/Both.Cas9.fastq")) as fh:
+        fastq = fh.read()
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fq = os.path.join(tmp, "Both.Cas9.fastq")
+        with open(fq, "w") as fh:
+            fh.write(fastq)
+        argv = ["CRISPResso", "-r1", fq, "-a", ",".join(amps[n][0] for n in names), "-an", ",".join(names),
+                "-g", ",".join(amps[n][1] for n in names), "--suppress_report", "-o", tmp]
+        old = sys.argv
+        sys.argv = argv
+        try:
+            core.main()
+        except SystemExit as e:
+            assert e.code in (0, None), e.code
+        finally:
+            sys.argv = old
+        out = os.path.join(tmp, "CRISPResso_on_Both.Cas9")
+        with open(os.path.join(out, "CRISPResso2_info.json")) as fh:
+            info = json.load(fh)
+        for fn in sorted(os.listdir(out)):
+            base = fn.split(".", 1)[1] if fn.split(".", 1)[0] in info["results"]["refs"] else fn
+            if fn.endswith(".txt") and any(base == t or (t.endswith("_") and base.startswith(t)) for t in PARAMS_TABLES):
+                with open(os.path.join(out, fn)) as fh:
+                    files[fn] = fh.read()
+        with zipfile.ZipFile(os.path.join(out, "Alleles_frequency_table.zip")) as z:
+            files["Alleles_frequency_table.txt"] = z.read("Alleles_frequency_table.txt").decode()
+    refs = []
+    for nm, r in info["results"]["refs"].items():
+        refs.append({"name": nm, "sequence": r["sequence"], "min_aln_score": r["min_aln_score"], "gap_incentive": r["gap_incentive"]["value"],
+                     "include_idxs": [int(x) for x in (r["include_idxs"]["value"] if isinstance(r["include_idxs"], dict) else r["include_idxs"])], "sgRNA_cut_points": r["sgRNA_cut_points"],
+                     "sgRNA_orig_sequences": r["sgRNA_orig_sequences"], "sgRNA_names": r["sgRNA_names"],
+                     "fw_seeds": r["fw_seeds"], "rc_seeds": r["rc_seeds"]})
+    a = info["running_info"]["args"]["value"] if "value" in info["running_info"]["args"] else info["running_info"]["args"]
+    keep = ("aln_seed_count", "aln_seed_len", "aln_seed_min", "needleman_wunsch_gap_open", "needleman_wunsch_gap_extend",
+            "use_legacy_insertion_quantification", "ignore_deletions", "ignore_insertions", "ignore_substitutions",
+            "assign_ambiguous_alignments_to_first_reference", "expand_ambiguous_alignments", "prime_editing_pegRNA_scaffold_seq",
+            "discard_indel_reads", "plot_window_size", "dsODN", "expected_hdr_amplicon_seq", "prime_editing_pegRNA_extension_seq")
+    return {"command": " ".join(argv[:1] + ["-r1", "Both.Cas9.fastq"] + argv[3:-2]), "fastq": fastq, "refs": refs, "args": {k: a[k] for k in keep},
+            "alignment_stats": info["running_info"]["alignment_stats"], "files": files}
+
+
+if __name__ == "__main__" and "--both" in sys.argv:
+    import gzip
+    d = both_run()
+    with gzip.open(os.path.join(HERE, "both_run.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("both_run.json.gz written:", len(d["files"]), "files", d["alignment_stats"])
 
 
 # ---------------------------------------------------------------- 7. paired reads (CRISPRessoCORE.py:800-1169)

@@ -167,9 +167,9 @@ def test_alleles_around_cut_random_tables_windows_at_the_amplicon_ends_and_mergi
 
 
 # ---- the reference's second end-to-end test: CRISPResso_on_params (tests/Makefile) -------------------------------------------
-def _params_golden():
+def _params_golden(name="params_run.json.gz"):
     import numpy as np
-    with gzip.open(os.path.join(HERE, "golden", "params_run.json.gz"), "rt") as fh:
+    with gzip.open(os.path.join(HERE, "golden", name), "rt") as fh:
         g = json.load(fh)
     refs, names = {}, []
     for r in g["refs"]:
@@ -451,3 +451,36 @@ def test_pipeline_on_the_emulator_both_strand_batch_feeds_counts_view_and_allele
         out = tmp_path / "out"
         written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
     assert _compare_params(g, written, str(out)) == 39
+
+
+# ---- two different amplicons in one run: the reference's pooled test reads (FANC + HEK3) through CRISPResso core -----------------
+def _both_run(tmp_path, ctx=None):
+    from crispresso2_amd import pipeline, tables
+    g, refs, names = _params_golden("both_run.json.gz")
+    fq = tmp_path / "Both.Cas9.fastq"
+    fq.write_text(g["fastq"])
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a), ctx=ctx)
+    for k in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS", "N_GLOBAL_SUBS",
+              "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS", "N_READS_INPUT"):
+        assert res.stats[k] == g["alignment_stats"][k], k
+    assert res.first_ref_view is None                                # no HDR amplicon, no prime-editing extension
+    out = tmp_path / "CRISPResso_on_Both.Cas9"
+    written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(out)) == 33
+    assert res.per_ref["FANC"]["counts_total"] > 200 and res.per_ref["HEK3"]["counts_total"] > 200
+
+
+def test_pipeline_on_the_emulator_two_amplicon_run_of_the_pooled_test_reads(tmp_path):
+    """500 reads of two unrelated amplicons (223 and 2xx bp), each read against both on the emulated launch chain (the reads of
+    the other amplicon are the 'unrelated read' case of the band certificate), assigned to the better one -> the 33 result
+    files of the reference's run with `-a A,B -an FANC,HEK3 -g gA,gB` (make_golden.py --both)."""
+    from pipeline_on_emulator import emulated_device
+    with emulated_device():
+        _both_run(tmp_path)
+
+
+@pytest.mark.gpu
+def test_two_amplicon_run_of_the_pooled_test_reads_on_the_device(tmp_path):
+    from crispresso2_amd import _native
+    _both_run(tmp_path, ctx=_native.default_context())
