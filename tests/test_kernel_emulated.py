@@ -305,3 +305,44 @@ def test_emulated_chain_on_the_reads_of_the_reference_params_run(mats):
         assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k
         check_record(r, oracle.find_indels_substitutions(s1, s2, incs[ri]), s1, s2)
     assert st["fallback"] < st["tasks"]
+
+
+@pytest.mark.parametrize("go,ge,seed", [(-20, -2, 11), (-10, -3, 12), (-5, -1, 13)])
+def test_emulated_chain_soak_mixed_batches(mats, go, ge, seed):
+    """The GPU soak's generator (tests/test_gpu_soak.py: three references of different lengths, both strands, long indels,
+    truncated / unrelated reads, N and IUPAC symbols, one or two cut sites) through the emulated default chain: EVERY
+    alignment and record against the oracle, on the CPU."""
+    from test_gpu_soak import COMP, mutate
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(seed)
+    refs = ["".join(rng.choice(list("ACGT"), L)) for L in (int(rng.integers(60, 120)), int(rng.integers(180, 260)), int(rng.integers(120, 200)))]
+    gis, incs = [], []
+    for r in refs:
+        g = np.zeros(len(r) + 1, dtype=np.int64)
+        g[len(r) // 2 + 1] = 1
+        if seed % 2 == 0:
+            g[len(r) // 3] = 1
+        gis.append(g)
+        incs.append(list(range(len(r) // 2 - 3, len(r) // 2 + 3)))
+    n = 700
+    rids = rng.integers(0, 3, n).astype(np.uint16)
+    truth = [mutate(rng, refs[r]) for r in rids]
+    strands = np.array([1 if (rng.random() < 0.3 and set(t) <= set("ACGTN")) else 0 for t in truth], dtype=np.uint8)
+    reads = [("".join(COMP[c] for c in reversed(t)) if st else t) for t, st in zip(truth, strands)]
+    st = {}
+    res, rec = E.align_batch(reads, refs, gis, incs, m, go, ge, ref_ids=rids, strands=strands, band_lanes=-7, stats=st)
+    n_undefined = 0
+    for k in range(n):
+        status, s1, s2, mt, ln = oracle.global_align_raw(truth[k], refs[rids[k]], m, gis[rids[k]], go, ge)
+        r = rec[k]
+        if status != 0:
+            assert r["status"] != 0, k
+            n_undefined += 1
+            continue
+        assert r["status"] == 0 and res[k] == (s1, s2) and int(r["matches"]) == mt and int(r["aln_len"]) == ln, k
+        check_record(r, oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
+    assert n_undefined < n // 10
+    if (go, ge) == (-5, -1):
+        assert st["fallback"] == st["tasks"]                        # max(go, ge) + incentive = 0: the diagonal kernels do not apply
+    else:
+        assert 0 < st["fallback"] < st["tasks"]
