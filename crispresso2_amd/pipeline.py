@@ -121,6 +121,11 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
             now = time.perf_counter()
             timings[name] = timings.get(name, 0.0) + now - t_last[0]
             t_last[0] = now
+    if getattr(args, 'prime_editing_pegRNA_scaffold_seq', '') and 'Prime-edited' in ref_names:
+        # the scaffold rule (CRISPRessoCORE.py:786-796) re-labels reads by a substring test on their aligned string; the count
+        # route does not bring strings to the host -- use variants.get_new_variant_objects (it implements the rule)
+        raise NotImplementedError("prime_editing_pegRNA_scaffold_seq: the device-resident count route has no scaffold rule; "
+                                  "use variants.process_fastq for this run")
     ctx = ctx or _native.default_context()
     n, k = len(read_counts), len(ref_names)
     L = [len(refs[name]['sequence']) for name in ref_names]

@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -635,6 +635,84 @@ if __name__ == "__main__" and "--both" in sys.argv:
     with gzip.open(os.path.join(HERE, "both_run.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("both_run.json.gz written:", len(d["files"]), "files", d["alignment_stats"])
+
+
+# ---------------------------------------------------------------- 6e. a prime-editing run (Reference + Prime-edited amplicon, ambiguous reads)
+def pe_run():
+    """A prime-editing run of the reference's main(): FANC amplicon, its guide as pegRNA spacer, an extension that writes one
+    substitution two bases after the nick (no scaffold sequence).  The reference derives the 'Prime-edited' amplicon itself.
+    Input: the first 120 FANC.Cas9 reads, every third carrying the edit -- reads that do not reach the edited base align
+    equally well to both amplicons (AMBIGUOUS rows, N_AMBIGUOUS), and the first-amplicon view is built (:4195-4270)."""
+    import importlib
+    import zipfile
+    from crispresso2_amd import refs as RF
+    core = load_reference_core()
+    P = importlib.import_module("CRISPResso2.plots.CRISPRessoPlot")
+    for k in dir(P):
+        if k.startswith("plot_") and callable(getattr(P, k)):
+            setattr(P, k, (lambda *a, **kw: None))
+    g = fanc_run()
+    amp, guide = g["amplicon"], g["guide"]
+    nick = amp.index(guide) + len(guide) - 3
+    edited = amp[:nick + 1] + ("T" if amp[nick + 1] != "T" else "G") + amp[nick + 2:]
+    ext = RF.reverse_complement(amp[nick - 13:nick] + edited[nick:nick + 12])
+    lines = g["fastq"].split("\n")
+    recs = []
+    for k in range(0, 4 * 120, 4):
+        rid, seq, plus, qual = lines[k:k + 4]
+        if (k // 4) % 3 == 0:
+            p = seq.find(amp[nick - 10:nick + 2])
+            if p >= 0:
+                seq = seq[:p + 11] + edited[nick + 1] + seq[p + 12:]
+        recs.append("%s\n%s\n%s\n%s\n" % (rid, seq, plus, qual))
+    fastq = "".join(recs)
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fq = os.path.join(tmp, "pe.fastq")
+        with open(fq, "w") as fh:
+            fh.write(fastq)
+        argv = ["CRISPResso", "-r1", fq, "-a", amp, "--prime_editing_pegRNA_spacer_seq", guide, "--prime_editing_pegRNA_extension_seq", ext,
+                "--suppress_report", "-o", tmp]
+        old = sys.argv
+        sys.argv = argv
+        try:
+            core.main()
+        except SystemExit as e:
+            assert e.code in (0, None), e.code
+        finally:
+            sys.argv = old
+        out = os.path.join(tmp, "CRISPResso_on_pe")
+        with open(os.path.join(out, "CRISPResso2_info.json")) as fh:
+            info = json.load(fh)
+        for fn in sorted(os.listdir(out)):
+            base = fn.split(".", 1)[1] if fn.split(".", 1)[0] in info["results"]["refs"] else fn
+            if fn.endswith(".txt") and any(base == t or (t.endswith("_") and base.startswith(t)) for t in PARAMS_TABLES):
+                with open(os.path.join(out, fn)) as fh:
+                    files[fn] = fh.read()
+        with zipfile.ZipFile(os.path.join(out, "Alleles_frequency_table.zip")) as z:
+            files["Alleles_frequency_table.txt"] = z.read("Alleles_frequency_table.txt").decode()
+    refs = []
+    for nm, r in info["results"]["refs"].items():
+        inc = r["include_idxs"]["value"] if isinstance(r["include_idxs"], dict) else r["include_idxs"]
+        refs.append({"name": nm, "sequence": r["sequence"], "min_aln_score": r["min_aln_score"], "gap_incentive": r["gap_incentive"]["value"],
+                     "include_idxs": [int(x) for x in inc], "sgRNA_cut_points": r["sgRNA_cut_points"],
+                     "sgRNA_orig_sequences": r["sgRNA_orig_sequences"], "sgRNA_names": r["sgRNA_names"],
+                     "fw_seeds": r["fw_seeds"], "rc_seeds": r["rc_seeds"]})
+    a = info["running_info"]["args"]["value"] if "value" in info["running_info"]["args"] else info["running_info"]["args"]
+    keep = ("aln_seed_count", "aln_seed_len", "aln_seed_min", "needleman_wunsch_gap_open", "needleman_wunsch_gap_extend",
+            "use_legacy_insertion_quantification", "ignore_deletions", "ignore_insertions", "ignore_substitutions",
+            "assign_ambiguous_alignments_to_first_reference", "expand_ambiguous_alignments", "prime_editing_pegRNA_scaffold_seq",
+            "discard_indel_reads", "plot_window_size", "dsODN", "expected_hdr_amplicon_seq", "prime_editing_pegRNA_extension_seq")
+    return {"command": "CRISPResso -r1 pe.fastq " + " ".join(argv[3:-2]), "fastq": fastq, "refs": refs, "args": {k: a[k] for k in keep},
+            "alignment_stats": info["running_info"]["alignment_stats"], "files": files}
+
+
+if __name__ == "__main__" and "--pe" in sys.argv:
+    import gzip
+    d = pe_run()
+    with gzip.open(os.path.join(HERE, "pe_run.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("pe_run.json.gz written:", len(d["files"]), "files", [r["name"] for r in d["refs"]], d["alignment_stats"])
 
 
 # ---------------------------------------------------------------- 7. paired reads (CRISPRessoCORE.py:800-1169)

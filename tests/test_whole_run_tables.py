@@ -484,3 +484,43 @@ def test_pipeline_on_the_emulator_two_amplicon_run_of_the_pooled_test_reads(tmp_
 def test_two_amplicon_run_of_the_pooled_test_reads_on_the_device(tmp_path):
     from crispresso2_amd import _native
     _both_run(tmp_path, ctx=_native.default_context())
+
+
+# ---- a prime-editing run: Reference + Prime-edited amplicon, ambiguous reads, first-amplicon view -----------------------------
+def _pe_run(tmp_path, ctx=None):
+    from crispresso2_amd import pipeline, tables
+    g, refs, names = _params_golden("pe_run.json.gz")
+    assert names == ["Reference", "Prime-edited"] and g["args"]["prime_editing_pegRNA_extension_seq"]
+    fq = tmp_path / "pe.fastq"
+    fq.write_text(g["fastq"])
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a), ctx=ctx)
+    for k in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS", "N_GLOBAL_SUBS",
+              "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS", "N_READS_INPUT"):
+        assert res.stats[k] == g["alignment_stats"][k], k
+    assert res.stats["N_AMBIGUOUS"] > 0 and set(res.first_ref_view) == set(names)
+    out = tmp_path / "CRISPResso_on_pe"
+    written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(out)) == 35
+    amb = [l for l in (out / "Alleles_frequency_table.txt").read_text().split("\n") if "\tAMBIGUOUS_Reference\t" in l]
+    assert len(amb) >= 5
+
+
+def test_pipeline_on_the_emulator_prime_editing_run(tmp_path):
+    """Reference's main() with a pegRNA spacer + extension (make_golden.py --pe): it derives the 'Prime-edited' amplicon; reads
+    that do not reach the edited base tie between the two amplicons (AMBIGUOUS_ rows of the allele table, not counted for
+    either), and the reads counted for 'Prime-edited' are also viewed in the first amplicon's coordinates -> its 35 files."""
+    from pipeline_on_emulator import emulated_device
+    with emulated_device():
+        _pe_run(tmp_path)
+    from crispresso2_amd import pipeline
+    g, refs, names = _params_golden("pe_run.json.gz")
+    a = dict(g["args"], prime_editing_pegRNA_scaffold_seq="GGCACCGAGTCGGTGC")
+    with pytest.raises(NotImplementedError):                       # the scaffold rule lives in variants.get_new_variant_objects only
+        pipeline.quantify_unique(None, None, [1], refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
+
+
+@pytest.mark.gpu
+def test_prime_editing_run_on_the_device(tmp_path):
+    from crispresso2_amd import _native
+    _pe_run(tmp_path, ctx=_native.default_context())
