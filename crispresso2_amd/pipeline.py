@@ -57,7 +57,11 @@ class QuantResult:
         k = len(ref_names)
         discard = bool(getattr(args, 'discard_indel_reads', False))
         jobs = []                                                   # (read, reference, row label)
+        hit = S.get("scaffold_hit")
         for i in np.nonzero(aligned & (cnt > 0))[0]:
+            if hit is not None and hit[i]:                          # aln_ref_names = ['Scaffold-incorporated'], its Prime-edited alignment
+                jobs.append((i, S["scaffold_ref"], 'Scaffold-incorporated', True))
+                continue
             best = np.nonzero(member[i])[0]
             names = best
             if len(best) > 1:
@@ -98,9 +102,12 @@ class QuantResult:
             modified = ((not args.ignore_deletions and dn > 0) or (not args.ignore_insertions and inn > 0) or
                         (not args.ignore_substitutions and sn > 0))
             if counted and discard and (dn > 0 or inn > 0):
-                first = np.nonzero(member[i])[0]
-                first = first[:1] if args.assign_ambiguous_alignments_to_first_reference else first
-                label = 'DISCARDED_' + ref_names[first[0]]
+                if label == 'Scaffold-incorporated':
+                    label = 'DISCARDED_Scaffold-incorporated'
+                else:
+                    first = np.nonzero(member[i])[0]
+                    first = first[:1] if args.assign_ambiguous_alignments_to_first_reference else first
+                    label = 'DISCARDED_' + ref_names[first[0]]
             reads = int(cnt[i])
             out.append((seqs[j], refs_[j], label, 'MODIFIED' if modified else 'UNMODIFIED', dn, inn, sn, reads, reads / n_total * 100))
         out.sort(key=lambda t: (-t[7], t[0], t[1]))
@@ -108,9 +115,13 @@ class QuantResult:
 
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
-                    timings=None):
+                    timings=None, pe_scaffold_dna_info=None):
     """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
-    timings: optional dict that receives the wall seconds of every stage."""
+    timings: optional dict that receives the wall seconds of every stage.
+    pe_scaffold_dna_info: (index, dna) of get_pe_scaffold_search for runs with --prime_editing_pegRNA_scaffold_seq: reads whose
+    alignment against 'Prime-edited' carries `dna` right after reference base index-1 are counted for 'Scaffold-incorporated'
+    (a copy of the Prime-edited amplicon that nothing is aligned to, CRISPRessoCORE.py:786-796, :3759-3764) -- the result then
+    has that extra amplicon."""
     import time
     import torch
     t_last = [time.perf_counter()]
@@ -121,11 +132,9 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
             now = time.perf_counter()
             timings[name] = timings.get(name, 0.0) + now - t_last[0]
             t_last[0] = now
-    if getattr(args, 'prime_editing_pegRNA_scaffold_seq', '') and 'Prime-edited' in ref_names:
-        # the scaffold rule (CRISPRessoCORE.py:786-796) re-labels reads by a substring test on their aligned string; the count
-        # route does not bring strings to the host -- use variants.get_new_variant_objects (it implements the rule)
-        raise NotImplementedError("prime_editing_pegRNA_scaffold_seq: the device-resident count route has no scaffold rule; "
-                                  "use variants.process_fastq for this run")
+    scaffold_rule = bool(getattr(args, 'prime_editing_pegRNA_scaffold_seq', '')) and 'Prime-edited' in ref_names
+    if scaffold_rule and (pe_scaffold_dna_info is None or pe_scaffold_dna_info[1] is None):
+        raise ValueError("prime_editing_pegRNA_scaffold_seq needs pe_scaffold_dna_info = (index, dna) of get_pe_scaffold_search")
     ctx = ctx or _native.default_context()
     n, k = len(read_counts), len(ref_names)
     L = [len(refs[name]['sequence']) for name in ref_names]
@@ -258,6 +267,45 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         counted[ambiguous, :] = False
         stats['N_AMBIGUOUS'] = int(cnt[ambiguous].sum())
     counted[~aligned, :] = False
+    # ---- prime-editing scaffold rule (:786-796): a read whose best amplicons include 'Prime-edited' and whose alignment against it
+    # shows the scaffold's first bases right after the extension is counted for 'Scaffold-incorporated' ONLY (ambiguous or not),
+    # with that alignment.  The aligned strings of the candidate reads come to the host for the substring test.
+    scaffold_hit = np.zeros(n, dtype=bool)
+    pe = ref_names.index('Prime-edited') if scaffold_rule else -1
+    if scaffold_rule:
+        cand = np.nonzero(aligned & member[:, pe])[0]
+        if len(cand):
+            idx0, dna = int(pe_scaffold_dna_info[0]) - 1, pe_scaffold_dna_info[1]
+            in2 = use2[cand, pe]
+            pairs = [None] * len(cand)
+
+            def pull(a, f, rows, where, lens_):
+                ah, fh = a.index_select(0, rows).cpu().numpy(), f.index_select(0, rows).cpu().numpy()
+                for q, j in enumerate(where):
+                    pairs[j] = (ah[q, :int(lens_[q])].tobytes().decode(), fh[q, :int(lens_[q])].tobytes().decode())
+            w_1 = np.nonzero(~in2)[0]
+            if len(w_1):
+                t_ = cand[w_1] * k + pe
+                pull(a1, f1, torch.from_numpy(t_).to(dev), w_1, rec1.reshape(-1)["aln_len"][t_])
+            w_2 = np.nonzero(in2)[0]
+            if len(w_2):
+                sl = slot2[cand[w_2], pe]
+                pull(a2, f2, torch.from_numpy(sl).to(dev), w_2, rec2["aln_len"][sl])
+            for j, (s_read, s_ref) in enumerate(pairs):
+                seen, col = -1, -1
+                for c_, ch in enumerate(s_ref):                    # ref_positions.index(idx0): the column of reference base idx0
+                    if ch != '-':
+                        seen += 1
+                        if seen == idx0:
+                            col = c_
+                            break
+                if col < 0:
+                    raise ValueError("%d is not in list" % idx0)
+                if s_read[col + 1:col + 1 + len(dna)] == dna:
+                    scaffold_hit[cand[j]] = True
+        counted[scaffold_hit, :] = False
+        if not args.assign_ambiguous_alignments_to_first_reference and not args.expand_ambiguous_alignments:
+            stats['N_AMBIGUOUS'] = int(cnt[ambiguous & ~scaffold_hit].sum())
     if cnt.max() > 0xFFFFFFFF:
         raise OverflowError("a read multiplicity exceeds 2^32 - 1")
     lap("rc_merge_weights")
@@ -270,6 +318,20 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         d_w2 = torch.from_numpy(w2.view(np.int32)).to(dev)
         C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_counts.data_ptr(),
                             d_weights=d_w2.data_ptr(), flags=flags, stream=stream)
+    d_scaffold = None
+    if scaffold_rule:
+        d_scaffold = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)       # row `pe` = the 'Scaffold-incorporated' amplicon
+        ws = np.zeros((n, k), dtype=np.uint32)
+        ws[:, pe] = np.where(scaffold_hit & ~use2[:, pe], cnt, 0)
+        d_ws = torch.from_numpy(ws.reshape(-1).view(np.int32)).to(dev)
+        C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_scaffold.data_ptr(),
+                            d_weights=d_ws.data_ptr(), flags=flags, stream=stream)
+        if n2:
+            ws2 = np.where((br == pe) & scaffold_hit[bi] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
+            d_ws2 = torch.from_numpy(ws2.view(np.int32)).to(dev)
+            C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_scaffold.data_ptr(),
+                                d_weights=d_ws2.data_ptr(), flags=flags, stream=stream)
+        torch.cuda.synchronize(dev)
     # ---- every amplicon's reads in the coordinates of the FIRST amplicon (:4195-4270; runs with an expected HDR amplicon or a
     # prime-editing extension).  The alignment of every read against the first amplicon is already on the device
     # (ref_aln_details[0]); the reference classifies it again and adds its all_* positions and bases into arrays of the
@@ -278,15 +340,16 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     # discard flags: the reference's loop has none.
     d_view = None
     if k > 1 and (getattr(args, 'expected_hdr_amplicon_seq', '') or getattr(args, 'prime_editing_pegRNA_extension_seq', '')):
-        d_view = torch.zeros((k,) + tuple(layout.shape()), dtype=torch.int64, device=dev)
-        for r in range(1, k):
+        d_view = torch.zeros((k + (1 if scaffold_rule else 0),) + tuple(layout.shape()), dtype=torch.int64, device=dev)
+        for r in range(1, k + (1 if scaffold_rule else 0)):
+            for_r = counted[:, r] if r < k else scaffold_hit          # row k: the reads counted for 'Scaffold-incorporated'
             wv = np.zeros((n, k), dtype=np.uint32)
-            wv[:, 0] = np.where(counted[:, r] & ~use2[:, 0], cnt, 0)
+            wv[:, 0] = np.where(for_r & ~use2[:, 0], cnt, 0)
             d_wv = torch.from_numpy(wv.reshape(-1).view(np.int32)).to(dev)
             C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_view[r].data_ptr(),
                                 d_weights=d_wv.data_ptr(), flags=0, stream=stream)
             if n2:
-                wv2 = np.where((br == 0) & counted[bi, r] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
+                wv2 = np.where((br == 0) & for_r[bi] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
                 if wv2.any():
                     d_wv2 = torch.from_numpy(wv2.view(np.int32)).to(dev)
                     C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_view[r].data_ptr(),
@@ -296,28 +359,35 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         C.all_reduce(d_counts)
         if d_view is not None:
             C.all_reduce(d_view)
+        if d_scaffold is not None:
+            C.all_reduce(d_scaffold)
     torch.cuda.synchronize(dev)
     host = d_counts.cpu().numpy()
     lap("count_kernels")
     per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
+    out_names = list(ref_names)
+    if scaffold_rule:
+        per_ref['Scaffold-incorporated'] = layout.unpack(d_scaffold.cpu().numpy(), pe, L[pe])
+        out_names.append('Scaffold-incorporated')
     first_ref_view = None
     if d_view is not None:
         view_keys = (["all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
                       "all_substitution_count_vectors"] + ["all_base_count_vectors_" + x for x in "ACGTN-"])
         host_view = d_view.cpu().numpy()
         first_ref_view = {ref_names[0]: {kk: per_ref[ref_names[0]][kk] for kk in view_keys}}
-        for r in range(1, k):
+        for r in range(1, len(out_names)):
             u = layout.unpack(host_view[r], 0, L[0])
-            first_ref_view[ref_names[r]] = {kk: u[kk] for kk in view_keys}
+            first_ref_view[out_names[r]] = {kk: u[kk] for kk in view_keys}
         for v in first_ref_view.values():
             v["all_indelsub_count_vectors"] = (v["all_insertion_count_vectors"] + v["all_deletion_count_vectors"]
                                                + v["all_substitution_count_vectors"])
     state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=slot2,
+                 scaffold_hit=scaffold_hit, scaffold_ref=pe,
                  a1=a1, f1=f1, rec1=rec1, a2=a2 if n2 else None, f2=f2 if n2 else None, rec2=rec2)
     return QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
 
 
-def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None):
+def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None, pe_scaffold_dna_info=None):
     """FASTQ file -> QuantResult.  Empty sequences (blank line / truncated record) are dropped, as in
     variants.read_fastq_unique; N_TOT_READS counts every record of the file."""
     import time
@@ -336,7 +406,8 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
         new_off[1:] = np.cumsum(lens[keep])
         arena = np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in keep]) if len(keep) else np.zeros(0, dtype=np.uint8)
         offsets, counts = new_off, counts[keep]
-    res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings)
+    res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
+                          pe_scaffold_dna_info=pe_scaffold_dna_info)
     res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
     res.stats['N_READS_AFTER_PREPROCESSING'] = int(n_reads)
     return res

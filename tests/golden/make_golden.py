@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -713,6 +713,92 @@ if __name__ == "__main__" and "--pe" in sys.argv:
     with gzip.open(os.path.join(HERE, "pe_run.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("pe_run.json.gz written:", len(d["files"]), "files", [r["name"] for r in d["refs"]], d["alignment_stats"])
+
+
+# ---------------------------------------------------------------- 6f. prime editing with a scaffold sequence ('Scaffold-incorporated')
+def pe_scaffold_run():
+    """pe_run()'s input plus reads in which reverse transcription ran on into the pegRNA scaffold (the Prime-edited amplicon
+    with the first 6-9 bases of the scaffold's DNA right after the extension), and --prime_editing_pegRNA_scaffold_seq: the
+    reference re-labels those reads 'Scaffold-incorporated' (CRISPRessoCORE.py:786-796) and counts them, with their alignment
+    against 'Prime-edited', for a third amplicon that nothing is aligned to (:3759-3764).  pe_scaffold_dna_info is recorded from
+    the reference's get_pe_scaffold_search."""
+    import gzip
+    import importlib
+    import zipfile
+    from crispresso2_amd import refs as RF
+    core = load_reference_core()
+    P = importlib.import_module("CRISPResso2.plots.CRISPRessoPlot")
+    for k in dir(P):
+        if k.startswith("plot_") and callable(getattr(P, k)):
+            setattr(P, k, (lambda *a, **kw: None))
+    with gzip.open(os.path.join(HERE, "pe_run.json.gz"), "rt") as fh:
+        pe = json.load(fh)
+    argv0 = pe["command"].split()
+    amp = argv0[argv0.index("-a") + 1]
+    guide = argv0[argv0.index("--prime_editing_pegRNA_spacer_seq") + 1]
+    ext = argv0[argv0.index("--prime_editing_pegRNA_extension_seq") + 1]
+    scaffold = "GTTTTAGAGCTAGAAATAGCAAGTTAAAATAAGGCTAGTCCGTTATCAACTTGAAAAAGTGGCACCGAGTCGGTGC"
+    pe_seq = [r for r in pe["refs"] if r["name"] == "Prime-edited"][0]["sequence"]
+    info_tuple = core.CRISPRessoPlotData.get_pe_scaffold_search(pe_seq, ext, scaffold, 1)
+    loc, scaffold_dna = info_tuple[0], RF.reverse_complement(scaffold)
+    rng = np.random.default_rng(9)
+    recs = [pe["fastq"]]
+    for k in range(14):
+        s = pe_seq[:loc] + scaffold_dna[:6 + k % 4] + pe_seq[loc:]
+        if k % 5 == 4:                                              # one with a substitution far from the cut as well
+            s = s[:30] + ("A" if s[30] != "A" else "C") + s[31:]
+        if k % 7 == 6:
+            s = RF.reverse_complement(s)
+        recs.append("@scaffold%d\n%s\n+\n%s\n" % (k, s, "I" * len(s)))
+    fastq = "".join(recs)
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fq = os.path.join(tmp, "pes.fastq")
+        with open(fq, "w") as fh:
+            fh.write(fastq)
+        argv = ["CRISPResso", "-r1", fq, "-a", amp, "--prime_editing_pegRNA_spacer_seq", guide, "--prime_editing_pegRNA_extension_seq", ext,
+                "--prime_editing_pegRNA_scaffold_seq", scaffold, "--suppress_report", "-o", tmp]
+        old = sys.argv
+        sys.argv = argv
+        try:
+            core.main()
+        except SystemExit as e:
+            assert e.code in (0, None), e.code
+        finally:
+            sys.argv = old
+        out = os.path.join(tmp, "CRISPResso_on_pes")
+        with open(os.path.join(out, "CRISPResso2_info.json")) as fh:
+            info = json.load(fh)
+        for fn in sorted(os.listdir(out)):
+            base = fn.split(".", 1)[1] if fn.split(".", 1)[0] in info["results"]["refs"] else fn
+            if fn.endswith(".txt") and any(base == t or (t.endswith("_") and base.startswith(t)) for t in PARAMS_TABLES):
+                with open(os.path.join(out, fn)) as fh:
+                    files[fn] = fh.read()
+        with zipfile.ZipFile(os.path.join(out, "Alleles_frequency_table.zip")) as z:
+            files["Alleles_frequency_table.txt"] = z.read("Alleles_frequency_table.txt").decode()
+    refs = []
+    for nm, r in info["results"]["refs"].items():
+        inc = r["include_idxs"]["value"] if isinstance(r["include_idxs"], dict) else r["include_idxs"]
+        refs.append({"name": nm, "sequence": r["sequence"], "min_aln_score": r["min_aln_score"], "gap_incentive": r["gap_incentive"]["value"],
+                     "include_idxs": [int(x) for x in inc], "sgRNA_cut_points": r["sgRNA_cut_points"],
+                     "sgRNA_orig_sequences": r["sgRNA_orig_sequences"], "sgRNA_names": r["sgRNA_names"],
+                     "fw_seeds": r["fw_seeds"], "rc_seeds": r["rc_seeds"]})
+    a = info["running_info"]["args"]["value"] if "value" in info["running_info"]["args"] else info["running_info"]["args"]
+    keep = ("aln_seed_count", "aln_seed_len", "aln_seed_min", "needleman_wunsch_gap_open", "needleman_wunsch_gap_extend",
+            "use_legacy_insertion_quantification", "ignore_deletions", "ignore_insertions", "ignore_substitutions",
+            "assign_ambiguous_alignments_to_first_reference", "expand_ambiguous_alignments", "prime_editing_pegRNA_scaffold_seq",
+            "discard_indel_reads", "plot_window_size", "dsODN", "expected_hdr_amplicon_seq", "prime_editing_pegRNA_extension_seq")
+    return {"command": "CRISPResso -r1 pes.fastq " + " ".join(argv[3:-2]), "fastq": fastq, "refs": refs, "args": {k: a[k] for k in keep},
+            "pe_scaffold_dna_info": [int(info_tuple[0]), info_tuple[1]],
+            "alignment_stats": info["running_info"]["alignment_stats"], "files": files}
+
+
+if __name__ == "__main__" and "--pe-scaffold" in sys.argv:
+    import gzip
+    d = pe_scaffold_run()
+    with gzip.open(os.path.join(HERE, "pe_scaffold_run.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("pe_scaffold_run.json.gz written:", len(d["files"]), "files", [r["name"] for r in d["refs"]], d["pe_scaffold_dna_info"], d["alignment_stats"])
 
 
 # ---------------------------------------------------------------- 7. paired reads (CRISPRessoCORE.py:800-1169)

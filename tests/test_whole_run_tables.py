@@ -516,7 +516,7 @@ def test_pipeline_on_the_emulator_prime_editing_run(tmp_path):
     from crispresso2_amd import pipeline
     g, refs, names = _params_golden("pe_run.json.gz")
     a = dict(g["args"], prime_editing_pegRNA_scaffold_seq="GGCACCGAGTCGGTGC")
-    with pytest.raises(NotImplementedError):                       # the scaffold rule lives in variants.get_new_variant_objects only
+    with pytest.raises(ValueError):                                 # a scaffold sequence without the (index, dna) of get_pe_scaffold_search
         pipeline.quantify_unique(None, None, [1], refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
 
 
@@ -524,3 +524,39 @@ def test_pipeline_on_the_emulator_prime_editing_run(tmp_path):
 def test_prime_editing_run_on_the_device(tmp_path):
     from crispresso2_amd import _native
     _pe_run(tmp_path, ctx=_native.default_context())
+
+
+# ---- prime editing with a scaffold sequence: the 'Scaffold-incorporated' amplicon nothing is aligned to -----------------------------
+def _pe_scaffold_run(tmp_path, ctx=None):
+    from crispresso2_amd import pipeline, tables
+    g, refs, names = _params_golden("pe_scaffold_run.json.gz")
+    assert names == ["Reference", "Prime-edited", "Scaffold-incorporated"]
+    assert refs["Scaffold-incorporated"]["sequence"] == refs["Prime-edited"]["sequence"]          # the reference's deepcopy (:3759-3764)
+    fq = tmp_path / "pes.fastq"
+    fq.write_text(g["fastq"])
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    res = pipeline.quantify_fastq(str(fq), refs, names[:2], matrices()["EDNAFULL"], _pipeline_args(a), ctx=ctx,
+                                  pe_scaffold_dna_info=tuple(g["pe_scaffold_dna_info"]))
+    for k in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS", "N_GLOBAL_SUBS",
+              "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS", "N_READS_INPUT"):
+        assert res.stats[k] == g["alignment_stats"][k], k
+    assert res.per_ref["Scaffold-incorporated"]["counts_total"] >= 10 and set(res.first_ref_view) == set(names)
+    out = tmp_path / "CRISPResso_on_pes"
+    written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(out)) == 51
+
+
+def test_pipeline_on_the_emulator_prime_editing_scaffold_run(tmp_path):
+    """make_golden.py --pe-scaffold: the reference's run with --prime_editing_pegRNA_scaffold_seq over reads in which reverse
+    transcription ran on into the scaffold.  The count route pulls the aligned strings of the reads whose best amplicons
+    include 'Prime-edited', applies the substring rule (:786-796), counts the hits for 'Scaffold-incorporated' in a launch of
+    their own and labels their allele rows -> the reference's 51 result files (three amplicons)."""
+    from pipeline_on_emulator import emulated_device
+    with emulated_device():
+        _pe_scaffold_run(tmp_path)
+
+
+@pytest.mark.gpu
+def test_prime_editing_scaffold_run_on_the_device(tmp_path):
+    from crispresso2_amd import _native
+    _pe_scaffold_run(tmp_path, ctx=_native.default_context())
