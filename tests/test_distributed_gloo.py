@@ -69,3 +69,62 @@ def test_shard_boundaries_match_reference_semantics():
     assert shard_boundaries(3, 3) == [0, 1, 2, 3]
     with pytest.raises(Exception):
         shard_boundaries(2, 3)
+
+
+def _pipeline_worker(rank, world, port, out_dir):
+    """pipeline.quantify_unique on this rank's contiguous shard of the unique reads with reduce_across_ranks=True (device calls on
+    the wave emulator): count tensor, first-amplicon view and the Scaffold-incorporated tensor are all-reduced over gloo."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pickle
+    from helpers import matrices
+    from pipeline_on_emulator import emulated_device
+    from test_whole_run_tables import _params_golden, _pipeline_args
+    from crispresso2_amd import distributed as D, pipeline, _native
+    D.init("gloo")
+    g, refs, names = _params_golden("pe_scaffold_run.json.gz")
+    fq = os.path.join(out_dir, "in%d.fastq" % rank)
+    with open(fq, "w") as fh:
+        fh.write(g["fastq"])
+    arena, offsets, counts, n_reads = _native.fastq_unique(fq)
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    lo, hi = D.my_shard(len(counts)) if world > 1 else (0, len(counts))
+    sub_off = (offsets[lo:hi + 1] - offsets[lo]).astype(np.uint64)
+    sub_arena = arena[int(offsets[lo]):int(offsets[hi])]
+    with emulated_device():
+        res = pipeline.quantify_unique(sub_arena, sub_off, counts[lo:hi], refs, names[:2], matrices()["EDNAFULL"], _pipeline_args(a),
+                                       reduce_across_ranks=world > 1, pe_scaffold_dna_info=tuple(g["pe_scaffold_dna_info"]))
+    if rank == 0:
+        with open(os.path.join(out_dir, "world%d.pkl" % world), "wb") as fh:
+            pickle.dump({"per_ref": res.per_ref, "view": res.first_ref_view}, fh)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_pipeline_reduce_of_counts_view_and_scaffold_tensors(tmp_path):
+    """Every tensor the count route exchanges (per-amplicon counts, first-amplicon view, Scaffold-incorporated) summed over two
+    gloo ranks equals the single-process result, for the prime-editing scaffold run."""
+    import pickle
+    sys.path.insert(0, HERE)
+    import emu_driver as E
+    E.build()
+    _pipeline_worker(0, 1, 0, str(tmp_path))
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = pickle.load(open(tmp_path / "world1.pkl", "rb"))
+    two = pickle.load(open(tmp_path / "world2.pkl", "rb"))
+
+    def same(a, b):
+        assert set(a) == set(b)
+        for k, v in a.items():
+            if isinstance(v, dict) and v and isinstance(next(iter(v.values())), np.ndarray):
+                same(v, b[k])
+            elif isinstance(v, np.ndarray):
+                assert np.array_equal(v, b[k]), k
+            else:
+                assert v == b[k], k
+    for nm in ("Reference", "Prime-edited", "Scaffold-incorporated"):
+        same(one["per_ref"][nm], two["per_ref"][nm])
+        same(one["view"][nm], two["view"][nm])
+    assert one["per_ref"]["Scaffold-incorporated"]["counts_total"] >= 10
