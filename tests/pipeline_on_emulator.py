@@ -5,8 +5,10 @@ device entry points to the wave emulator (tests/emu: the same HIP kernel source 
     BatchAligner.align_device   -> emu_driver.align_batch over the bytes behind those addresses (default launch chain)
     counts.accumulate_device    -> emu_driver.count_vectors, added into the tensor behind d_counts
 
+    BatchAligner.align / Context.classify_lists_batch (the per-read route of variants.py) -> the same emulator entry points
+
 Everything else -- native ingest, strand plans, strand / best-amplicon selection, reverse-complement merge, weights, the
-first-amplicon view, statistics, allele rows -- is the product's own code.  Used by tests only; the product never imports this."""
+first-amplicon view, statistics, allele rows, the per-read dicts and their files -- is the product's own code.  Used by tests only; the product never imports this."""
 import contextlib
 import ctypes
 
@@ -50,6 +52,50 @@ class EmulatedAligner:
         _view(d_records, 32 * ntasks)[:] = rec.view(np.uint8).reshape(-1)
 
 
+    # the host-memory API of the per-read route (variants.py, paired.py): BatchAligner.align -> BatchResult
+    def align(self, reads, ref_ids=None, strands=None, all_refs=False):
+        from crispresso2_amd.batch import BatchResult
+        if isinstance(reads, tuple):
+            arena, off = reads
+            buf = np.asarray(arena, dtype=np.uint8).tobytes()
+            reads = [buf[int(off[i]):int(off[i + 1])].decode() for i in range(len(off) - 1)]
+        st = {}
+        _, rec = E.align_batch(list(reads), self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=ref_ids, strands=strands,
+                               all_refs=all_refs, band_lanes=-7, stats=st)
+        o1, o2 = st["raw"]
+        return BatchResult(o1, o2, rec.view(_native_rec_dtype()), len(reads), len(self.seqs), all_refs)
+
+
+def _native_rec_dtype():
+    from crispresso2_amd import _native
+    return _native.REC_DTYPE
+
+
+class EmulatedContext:
+    """stands in for _native.Context where the per-read route asks it for the batched classifier (c2_classify_lists_batch)"""
+    def classify_lists_batch(self, aln_read, aln_ref, lens, set_ids, include_sets, legacy=False):
+        a1 = np.ascontiguousarray(aln_read, dtype=np.uint8)
+        a2 = np.ascontiguousarray(aln_ref, dtype=np.uint8)
+        n, stride = a1.shape
+        ln = np.ascontiguousarray(lens, dtype=np.int32)
+        ids = np.zeros(n, dtype=np.uint16) if set_ids is None else np.ascontiguousarray(set_ids, dtype=np.uint16)
+        sets = [np.array(sorted(set(int(x) for x in inc)), dtype=np.int32) for inc in include_sets]
+        off = np.zeros(len(sets) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([x.size for x in sets])
+        flat = np.ascontiguousarray(np.concatenate(sets + [np.zeros(1, dtype=np.int32)]), dtype=np.int32)
+        index = np.zeros(n * E.N_LISTS + 1, dtype=np.int64)
+        cap = int(ln.sum()) * 12 + 1024
+        values = np.zeros(cap, dtype=np.int32)
+        counts = np.zeros((n, 3), dtype=np.int64)
+        rc = E.lib().emu_classify_lists_batch(ctypes.c_uint64(n), a1.ctypes.data_as(ctypes.c_void_p), a2.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_uint32(stride), ln.ctypes.data_as(ctypes.c_void_p), ids.ctypes.data_as(ctypes.c_void_p),
+                                              flat.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p), int(bool(legacy)),
+                                              index.ctypes.data_as(ctypes.c_void_p), values.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(cap),
+                                              counts.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, rc
+        return index, values[:int(index[-1])].copy(), counts
+
+
 def _accumulate(aligners):
     def accumulate_device(ctx, layout, n_tasks, d_aln_read, d_aln_ref, aln_stride, d_records, d_counts, d_weights=None,
                           min_matches=None, flags=0, stream=None):
@@ -70,7 +116,7 @@ def _accumulate(aligners):
 def emulated_device():
     """Inside the block pipeline.quantify_* run on the emulator; restored afterwards."""
     import torch
-    from crispresso2_amd import pipeline, counts as C, _native
+    from crispresso2_amd import pipeline, variants, counts as C, _native
     made = []
 
     def make_aligner(*a, **kw):
@@ -80,14 +126,17 @@ def emulated_device():
     class _Stream:
         cuda_stream = 0
     saved = (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context)
+    saved_variants_aligner = variants.BatchAligner
+    variants.BatchAligner = make_aligner
     real_device = torch.device
     torch.device = lambda *a, **k: real_device("cpu")
     torch.cuda.current_stream = lambda *a, **k: _Stream()
     torch.cuda.synchronize = lambda *a, **k: None
     pipeline.BatchAligner = make_aligner
     C.accumulate_device = _accumulate(made)
-    _native.default_context = lambda *a, **k: object()
+    _native.default_context = lambda *a, **k: EmulatedContext()
     try:
         yield
     finally:
         torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context = saved
+        variants.BatchAligner = saved_variants_aligner

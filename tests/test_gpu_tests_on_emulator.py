@@ -1,0 +1,48 @@
+"""The GPU parity tests of the per-read route and of the count pipeline, run on the CPU: the test FUNCTIONS of tests/test_gpu_parity.py /
+test_variant_io.py are called as they are, with the product's device entry points redirected to the wave emulator
+(tests/pipeline_on_emulator.py).  What runs on the MI355X at round end therefore already ran here against the same goldens --
+same product code above the three device calls, same kernel source below them."""
+import pytest
+
+from helpers import matrices
+from pipeline_on_emulator import EmulatedContext, emulated_device
+
+
+@pytest.fixture(scope="module")
+def mats():
+    return matrices()
+
+
+def test_get_new_variant_objects_and_process_fastq_on_the_emulator(mats, tmp_path):
+    import test_gpu_parity as G
+    with emulated_device():
+        G.test_get_new_variant_objects_vs_reference_function(mats, EmulatedContext())
+        G.test_process_fastq_equivalent(mats, EmulatedContext(), tmp_path)
+
+
+def test_variant_files_annotated_fastq_and_sam_on_the_emulator(mats, tmp_path, monkeypatch):
+    import test_gpu_parity as G
+    import test_variant_io as VIO
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    with emulated_device():
+        G.test_variant_files_and_annotated_fastq_equal_the_reference_text(mats, EmulatedContext(), tmp_path / "a")
+        VIO.test_bam_output_sam_text_from_the_device_route(tmp_path / "b")
+
+
+def test_count_pipeline_gpu_tests_on_the_emulator(mats, tmp_path):
+    import test_gpu_parity as G
+    with emulated_device():
+        G.test_whole_run_fanc_fastq_equals_the_reference_result_tables(mats, EmulatedContext(), tmp_path)
+        G.test_pipeline_equals_per_read_path_plus_reference_aggregation(mats, EmulatedContext())
+
+
+def test_whole_run_gpu_tests_on_the_emulator(tmp_path):
+    import test_whole_run_tables as W
+    for k, fn in enumerate((W.test_tables_from_the_device_pipeline_equal_every_file_of_the_reference_run,
+                            W.test_params_run_tables_from_the_device_pipeline,
+                            W.test_params_run_from_the_unfiltered_fastq_with_the_fused_read_filter)):
+        d = tmp_path / str(k)
+        d.mkdir()
+        with emulated_device():
+            fn(d)
