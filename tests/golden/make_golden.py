@@ -325,7 +325,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv and "--variant-scaffold" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -799,6 +799,43 @@ if __name__ == "__main__" and "--pe-scaffold" in sys.argv:
     with gzip.open(os.path.join(HERE, "pe_scaffold_run.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("pe_scaffold_run.json.gz written:", len(d["files"]), "files", [r["name"] for r in d["refs"]], d["pe_scaffold_dna_info"], d["alignment_stats"])
+
+
+# ---------------------------------------------------------------- 6g. get_new_variant_object with the scaffold rule (:786-796)
+def variant_scaffold_goldens():
+    """The reference's get_new_variant_object for every unique read of pe_scaffold_run.json.gz, with the run's amplicon records,
+    --prime_editing_pegRNA_scaffold_seq and pe_scaffold_dna_info: the per-read dicts incl. the 'Scaffold-incorporated' re-labelling."""
+    import gzip
+    core = load_reference_core()
+    with gzip.open(os.path.join(HERE, "pe_scaffold_run.json.gz"), "rt") as fh:
+        g = json.load(fh)
+    refs, names = {}, []
+    for r in g["refs"][:2]:
+        d = dict(r)
+        d["gap_incentive"] = np.array(r["gap_incentive"], dtype=int)
+        d["include_idxs"] = np.array(r["include_idxs"])
+        d["sequence_length"] = len(r["sequence"])
+        refs[r["name"]] = d
+        names.append(r["name"])
+    lines = g["fastq"].split("\n")
+    reads = list(dict.fromkeys(lines[k] for k in range(1, len(lines) - 1, 4)))
+    a = dict(g["args"])
+    a.update(needleman_wunsch_aln_matrix_loc="EDNAFULL")
+    args = types.SimpleNamespace(**a)
+    info = tuple(g["pe_scaffold_dna_info"])
+    outs = []
+    for rd in reads:
+        v = core.get_new_variant_object(args, rd, refs, names, EDNA, info)
+        outs.append(jsonable({k: (payload_dict(x) if k.startswith("variant_") else x) for k, x in v.items()}))
+    return {"reads": reads, "variants": outs, "n_scaffold": sum(v.get("class_name") == "Scaffold-incorporated" for v in outs)}
+
+
+if __name__ == "__main__" and "--variant-scaffold" in sys.argv:
+    import gzip
+    d = variant_scaffold_goldens()
+    with gzip.open(os.path.join(HERE, "variants_scaffold.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("variants_scaffold.json.gz written:", len(d["reads"]), "reads,", d["n_scaffold"], "scaffold-incorporated")
 
 
 # ---------------------------------------------------------------- 7. paired reads (CRISPRessoCORE.py:800-1169)

@@ -560,3 +560,32 @@ def test_pipeline_on_the_emulator_prime_editing_scaffold_run(tmp_path):
 def test_prime_editing_scaffold_run_on_the_device(tmp_path):
     from crispresso2_amd import _native
     _pe_scaffold_run(tmp_path, ctx=_native.default_context())
+
+
+def _variant_scaffold_check(ctx):
+    """variants.get_new_variant_objects with the scaffold rule against the reference's get_new_variant_object (make_golden.py
+    --variant-scaffold): every dict of the 121 unique reads of the scaffold run, eight of them re-labelled 'Scaffold-incorporated'."""
+    import types
+    from helpers import load_golden
+    from test_gpu_parity import _variant_equal
+    from crispresso2_amd import variants as V
+    g, refs, names = _params_golden("pe_scaffold_run.json.gz")
+    gold = load_golden("variants_scaffold.json.gz")
+    args = types.SimpleNamespace(**g["args"])
+    got = V.get_new_variant_objects(args, gold["reads"], refs, names[:2], matrices()["EDNAFULL"], tuple(g["pe_scaffold_dna_info"]), ctx=ctx)
+    assert len(got) == len(gold["variants"])
+    for a, e in zip(got, gold["variants"]):
+        _variant_equal(a, e)
+    assert sum(v.get("class_name") == "Scaffold-incorporated" for v in got) == gold["n_scaffold"] == 8
+
+
+def test_per_read_scaffold_rule_on_the_emulator():
+    from pipeline_on_emulator import EmulatedContext, emulated_device
+    with emulated_device():
+        _variant_scaffold_check(EmulatedContext())
+
+
+@pytest.mark.gpu
+def test_per_read_scaffold_rule_on_the_device():
+    from crispresso2_amd import _native
+    _variant_scaffold_check(_native.default_context())
