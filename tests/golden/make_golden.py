@@ -14,6 +14,13 @@ at test time reads /root/reference.
   fuzz_classify.json   random aligned-string pairs (incl. shapes the aligner never emits) -> payload
   realistic.json       150/223/250-bp amplicon cases + the first reads of tests/FANC.Cas9.fastq:
                        alignment and classifier payload
+  (flags)              --variants variants.json.gz, --fanc fanc_run.json.gz, --paired paired.json.gz, --variant-io
+                       variant_io.json.gz, --paired-fastq paired_fastq.json.gz, --sam sam_output.json.gz (the .sam text of
+                       --bam_output), and whole runs of the reference's main() with its plot functions stubbed out:
+                       --fanc-full (every .txt of its FANC.Cas9 test), --params (its CRISPResso_on_params test: reads after
+                       its quality filter, derived amplicon records, result tables), --both (its pooled test reads as a
+                       two-amplicon core run), --pe / --pe-scaffold (prime-editing runs), --variant-scaffold (per-read dicts
+                       under the scaffold rule)
 """
 import importlib.util
 import json
