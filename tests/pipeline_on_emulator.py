@@ -71,8 +71,22 @@ def _native_rec_dtype():
     return _native.REC_DTYPE
 
 
+class _EmulatedLib:
+    @staticmethod
+    def c2_consensus_pairs_batch(handle, *args):                    # same arguments as the emulator's entry point, minus the context
+        return E.lib().emu_consensus_pairs(*args)
+
+
 class EmulatedContext:
-    """stands in for _native.Context where the per-read route asks it for the batched classifier (c2_classify_lists_batch)"""
+    """stands in for _native.Context where the per-read routes ask it for the batched classifier (c2_classify_lists_batch) and the
+    paired-read consensus kernel (c2_consensus_pairs_batch)"""
+    lib = _EmulatedLib()
+    handle = None
+
+    @staticmethod
+    def check(rc, what):
+        assert rc == 0, (what, rc)
+
     def classify_lists_batch(self, aln_read, aln_ref, lens, set_ids, include_sets, legacy=False):
         a1 = np.ascontiguousarray(aln_read, dtype=np.uint8)
         a2 = np.ascontiguousarray(aln_ref, dtype=np.uint8)
@@ -116,7 +130,7 @@ def _accumulate(aligners):
 def emulated_device():
     """Inside the block pipeline.quantify_* run on the emulator; restored afterwards."""
     import torch
-    from crispresso2_amd import pipeline, variants, counts as C, _native
+    from crispresso2_amd import pipeline, variants, paired, counts as C, _native
     made = []
 
     def make_aligner(*a, **kw):
@@ -126,8 +140,8 @@ def emulated_device():
     class _Stream:
         cuda_stream = 0
     saved = (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context)
-    saved_variants_aligner = variants.BatchAligner
-    variants.BatchAligner = make_aligner
+    saved_variants_aligner, saved_paired_aligner = variants.BatchAligner, paired.BatchAligner
+    variants.BatchAligner = paired.BatchAligner = make_aligner
     real_device = torch.device
     torch.device = lambda *a, **k: real_device("cpu")
     torch.cuda.current_stream = lambda *a, **k: _Stream()
@@ -139,4 +153,4 @@ def emulated_device():
         yield
     finally:
         torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context = saved
-        variants.BatchAligner = saved_variants_aligner
+        variants.BatchAligner, paired.BatchAligner = saved_variants_aligner, saved_paired_aligner

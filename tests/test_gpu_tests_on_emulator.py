@@ -46,3 +46,12 @@ def test_whole_run_gpu_tests_on_the_emulator(tmp_path):
         d.mkdir()
         with emulated_device():
             fn(d)
+
+
+def test_paired_read_gpu_tests_on_the_emulator(mats, tmp_path):
+    """consensus kernel + paired per-pair dicts (reference unit-test calls, FANC pairs, recorded dicts) and the paired FASTQ route
+    (TSV files, second pass, final cache) -- tests/test_gpu_parity.py's functions on the emulator."""
+    import test_gpu_parity as G
+    with emulated_device():
+        G.test_paired_consensus_and_variants_vs_reference_functions(mats, EmulatedContext())
+        G.test_paired_fastq_files_equal_the_reference_run(mats, EmulatedContext(), tmp_path)
