@@ -777,7 +777,10 @@ struct TextSource {                                             // the whole tex
             if (!gm.init(b, mapped_n)) { err = gm.err; return false; }
             got = 0;
             for (;;) {
-                if (!inflated.reserve(got + ((size_t)8 << 20))) { err = "out of memory inflating the FASTQ"; return false; }
+                if (got + ((size_t)8 << 20) > inflate_budget() || !inflated.reserve(got + ((size_t)8 << 20))) {
+                    err = std::string("the text of ") + path + " does not fit the in-memory budget of the fused read filter (C2_FASTQ_INFLATE_MAX)";
+                    return false;
+                }
                 const long g = gm.read(inflated.get() + got, inflated.cap - got);
                 if (g < 0) { err = std::string("read error in ") + path + ": " + gm.err; return false; }
                 if (g == 0) break;
