@@ -132,6 +132,10 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
             now = time.perf_counter()
             timings[name] = timings.get(name, 0.0) + now - t_last[0]
             t_last[0] = now
+    if getattr(args, 'use_legacy_insertion_quantification', False):
+        # find_indels_substitutions_legacy (an insertion counts when EITHER flank is in the window, COREResources.pyx:284) is not
+        # what the kernels' fused classification computes; the per-read route has it (c2_classify_lists_kernel, legacy=1)
+        raise NotImplementedError("use_legacy_insertion_quantification: use variants.process_fastq (per-read route) for this run")
     scaffold_rule = bool(getattr(args, 'prime_editing_pegRNA_scaffold_seq', '')) and 'Prime-edited' in ref_names
     if scaffold_rule and (pe_scaffold_dna_info is None or pe_scaffold_dna_info[1] is None):
         raise ValueError("prime_editing_pegRNA_scaffold_seq needs pe_scaffold_dna_info = (index, dna) of get_pe_scaffold_search")

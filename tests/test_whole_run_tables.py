@@ -518,6 +518,8 @@ def test_pipeline_on_the_emulator_prime_editing_run(tmp_path):
     a = dict(g["args"], prime_editing_pegRNA_scaffold_seq="GGCACCGAGTCGGTGC")
     with pytest.raises(ValueError):                                 # a scaffold sequence without the (index, dna) of get_pe_scaffold_search
         pipeline.quantify_unique(None, None, [1], refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
+    with pytest.raises(NotImplementedError):                        # the count route has no legacy insertion rule and says so
+        pipeline.quantify_unique(None, None, [1], refs, names, matrices()["EDNAFULL"], _pipeline_args(dict(g["args"], use_legacy_insertion_quantification=True)))
 
 
 @pytest.mark.gpu
