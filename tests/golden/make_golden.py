@@ -20,7 +20,7 @@ at test time reads /root/reference.
                        --fanc-full (every .txt of its FANC.Cas9 test), --params (its CRISPResso_on_params test: reads after
                        its quality filter, derived amplicon records, result tables), --both (its pooled test reads as a
                        two-amplicon core run), --pe / --pe-scaffold (prime-editing runs), --variant-scaffold (per-read dicts
-                       under the scaffold rule)
+                       under the scaffold rule), --single-runs (its HEK3 and untreated-FANC test FASTQs)
 """
 import importlib.util
 import json
@@ -332,7 +332,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv and "--variant-scaffold" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv and "--variant-scaffold" not in sys.argv and "--single-runs" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -843,6 +843,65 @@ if __name__ == "__main__" and "--variant-scaffold" in sys.argv:
     with gzip.open(os.path.join(HERE, "variants_scaffold.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("variants_scaffold.json.gz written:", len(d["reads"]), "reads,", d["n_scaffold"], "scaffold-incorporated")
+
+
+# ---------------------------------------------------------------- 6h. the reference's other test FASTQs as single-amplicon runs
+def single_amplicon_runs():
+    """tests/HEK3.Cas9.fastq against the HEK3 amplicon and tests/FANC.Untreated.fastq against the FANC amplicon (amplicons and
+    guides from tests/Cas9.amplicons.txt) through the reference's main(), recorded like fanc_full_run()."""
+    import importlib
+    import zipfile
+    core = load_reference_core()
+    P = importlib.import_module("CRISPResso2.plots.CRISPRessoPlot")
+    for k in dir(P):
+        if k.startswith("plot_") and callable(getattr(P, k)):
+            setattr(P, k, (lambda *a, **kw: None))
+    amps = {}
+    with open(os.path.join(REF, "tests/Cas9.amplicons.txt")) as fh:
+        for line in fh:
+            f = line.split()
+            if len(f) >= 3:
+                amps[f[0]] = (f[1].upper(), f[2].upper())
+    cases = []
+    for fastq_name, amp_name in (("HEK3.Cas9.fastq", "HEK3"), ("FANC.Untreated.fastq", "FANC")):
+        amplicon, guide = amps[amp_name]
+        with open(os.path.join(REF, "tests", fastq_name)) as fh:
+            fastq = fh.read()
+        files = {}
+        with tempfile.TemporaryDirectory() as tmp:
+            fq = os.path.join(tmp, fastq_name)
+            with open(fq, "w") as fh:
+                fh.write(fastq)
+            old = sys.argv
+            sys.argv = ["CRISPResso", "-r1", fq, "-a", amplicon, "-g", guide, "--suppress_report", "-o", tmp]
+            try:
+                core.main()
+            except SystemExit as e:
+                assert e.code in (0, None), e.code
+            finally:
+                sys.argv = old
+            out = os.path.join(tmp, "CRISPResso_on_" + fastq_name.replace(".fastq", ""))
+            with open(os.path.join(out, "CRISPResso2_info.json")) as fh:
+                info = json.load(fh)
+            for fn in sorted(os.listdir(out)):
+                if fn.endswith(".txt") and any(fn == t or (t.endswith("_") and fn.startswith(t)) for t in PARAMS_TABLES):
+                    with open(os.path.join(out, fn)) as fh:
+                        files[fn] = fh.read()
+            with zipfile.ZipFile(os.path.join(out, "Alleles_frequency_table.zip")) as z:
+                files["Alleles_frequency_table.txt"] = z.read("Alleles_frequency_table.txt").decode()
+        r = info["results"]["refs"]["Reference"]
+        inc = r["include_idxs"]["value"] if isinstance(r["include_idxs"], dict) else r["include_idxs"]
+        cases.append({"fastq_name": fastq_name, "fastq": fastq, "amplicon": amplicon, "guide": guide, "cut_points": r["sgRNA_cut_points"],
+                      "include_idxs": [int(x) for x in inc], "alignment_stats": info["running_info"]["alignment_stats"], "files": files})
+    return cases
+
+
+if __name__ == "__main__" and "--single-runs" in sys.argv:
+    import gzip
+    d = single_amplicon_runs()
+    with gzip.open(os.path.join(HERE, "single_runs.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("single_runs.json.gz written:", [(c["fastq_name"], len(c["files"]), c["alignment_stats"]["N_TOT_READS"], c["alignment_stats"]["N_COMPUTED_ALN"]) for c in d])
 
 
 # ---------------------------------------------------------------- 7. paired reads (CRISPRessoCORE.py:800-1169)

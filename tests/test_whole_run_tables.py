@@ -591,3 +591,35 @@ def test_per_read_scaffold_rule_on_the_emulator():
 def test_per_read_scaffold_rule_on_the_device():
     from crispresso2_amd import _native
     _variant_scaffold_check(_native.default_context())
+
+
+# ---- the reference's other test FASTQs (HEK3 amplicon; untreated FANC sample) as single-amplicon runs --------------------------------
+def _single_runs(tmp_path, ctx=None):
+    from helpers import load_golden
+    from crispresso2_amd import pipeline, tables, refs as RF
+    for k, c in enumerate(load_golden("single_runs.json.gz")):
+        ref = RF.make_ref("Reference", c["amplicon"], c["cut_points"], c["include_idxs"], min_aln_score=60)
+        ref["sgRNA_orig_sequences"] = [c["guide"]]
+        fq = tmp_path / c["fastq_name"]
+        fq.write_text(c["fastq"])
+        res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(), ctx=ctx)
+        for key in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS", "N_GLOBAL_SUBS",
+                    "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS", "N_READS_INPUT"):
+            assert res.stats[key] == c["alignment_stats"][key], (c["fastq_name"], key)
+        out = tmp_path / ("out%d" % k)
+        written = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
+        assert _compare_params(c, written, str(out)) == 18, c["fastq_name"]
+
+
+def test_pipeline_on_the_emulator_hek3_and_untreated_runs(tmp_path):
+    """make_golden.py --single-runs: tests/HEK3.Cas9.fastq (another amplicon, other read shapes) and tests/FANC.Untreated.fastq
+    through the reference's main(); 18 result files each from pipeline.py on the emulated kernels."""
+    from pipeline_on_emulator import emulated_device
+    with emulated_device():
+        _single_runs(tmp_path)
+
+
+@pytest.mark.gpu
+def test_hek3_and_untreated_runs_on_the_device(tmp_path):
+    from crispresso2_amd import _native
+    _single_runs(tmp_path, ctx=_native.default_context())
