@@ -792,73 +792,148 @@ struct TextSource {                                             // the whole tex
     }
 };
 
-// -> 0 ok; C2_E_INVALID with err set for the reference's failures
-int filter_fastq_text(const char* b, size_t n, int min_bp, int min_av, int min_bpn, TextBuf& out, size_t& n_out, uint64_t& nonempty_lines, std::string& err) {
-    nonempty_lines = 0;
-    for (size_t pos = 0; pos < n;) {                            // `grep -c .` of get_n_reads_fastq (CRISPRessoShared.py:743-748)
-        const char* e = (const char*)memchr(b + pos, '\n', n - pos);
-        const size_t end = e ? (size_t)(e - b) : n;
-        nonempty_lines += end > pos;
-        pos = end + 1;
+// One '\n'-terminated line range of the text: the records whose id line STARTS in [lo, hi) (line numbers 0 mod 4 from the
+// top of the file; a record's other lines may lie beyond hi).  Stops at its first empty id line (`stop_rec`) or failure
+// (`err_rec`, `err`); the caller orders these events over the ranges as the serial loop would meet them.
+struct FilterRange {
+    std::vector<char> out;
+    uint64_t nonempty_lines = 0, stop_rec = UINT64_MAX, err_rec = UINT64_MAX;
+    std::string err;
+};
+
+void filter_fastq_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t first_line, int min_bp, int min_av, int min_bpn, FilterRange& R) {
+    // first line start at or after lo
+    size_t pos = lo;
+    if (lo > 0 && b[lo - 1] != '\n') {
+        const char* e = (const char*)memchr(b + lo, '\n', n - lo);
+        if (!e) return;                                          // no line starts in this range
+        pos = (size_t)(e - b) + 1;
     }
-    n_out = 0;
-    if (!out.reserve(n + 4096)) { err = "out of memory"; return C2_E_INVALID; }
-    char* o = out.get();
-    size_t pos = 0;
-    struct Line { size_t a, z; };
-    auto next = [&](Line& L) {                                   // readline().rstrip()
-        if (pos >= n) { L.a = L.z = n; return; }
-        const char* e = (const char*)memchr(b + pos, '\n', n - pos);
+    if (pos >= hi) return;
+    uint64_t line = first_line;
+    R.out.reserve((hi - lo) + 64);
+    struct Line { size_t a, z, next; };
+    auto read_line = [&](size_t at, Line& L) {                   // readline().rstrip() at byte `at`
+        if (at >= n) { L.a = L.z = L.next = n; return; }
+        const char* e = (const char*)memchr(b + at, '\n', n - at);
         size_t end = e ? (size_t)(e - b) : n;
-        L.a = pos;
-        pos = e ? end + 1 : n;
+        L.a = at;
+        L.next = e ? end + 1 : n;
         while (end > L.a && bytes_space((uint8_t)b[end - 1])) --end;
         L.z = end;
     };
-    uint64_t rec = 0;
-    for (;; ++rec) {
-        Line id, sq, pl, ql;
-        next(id);
-        if (id.z == id.a) break;
-        next(sq); next(pl); next(ql);
-        const size_t nq = ql.z - ql.a, ns = sq.z - sq.a;
-        const uint8_t* q = (const uint8_t*)b + ql.a;
-        auto fail = [&](const char* what) {
-            err = "filterFastqs, record " + std::to_string(rec) + ": " + what;
-            return C2_E_INVALID;
-        };
-        auto min_ok = [&](bool& keep) -> int {
-            if (nq == 0) return fail("ValueError: zero-size array to reduction operation minimum which has no identity (empty quality line)");
-            unsigned mn = 255;
-            for (size_t k = 0; k < nq; ++k) { const unsigned v = (uint8_t)(q[k] - 33); if (v < mn) mn = v; }
-            keep = (int)mn >= min_bp;
-            return 0;
-        };
-        auto mean_ok = [&]() {
-            if (nq == 0) return false;                           // numpy: mean of an empty slice is nan, nan >= x is False
-            uint64_t sum = 0;
-            for (size_t k = 0; k < nq; ++k) sum += (uint8_t)(q[k] - 33);
-            return (double)sum / (double)nq >= (double)min_av;
-        };
-        bool keep = true;
-        if (min_bp > 0 && min_av > 0 && min_bpn <= 0) {          // run_mBP_mRQ: mean first
-            keep = mean_ok();
-            if (keep) { const int rc = min_ok(keep); if (rc) return rc; }
-        } else {
-            if (min_bp > 0) { const int rc = min_ok(keep); if (rc) return rc; }
-            if (keep && min_av > 0) keep = mean_ok();
+    bool active = true;                                          // false once this range hit its stop / failure: only lines are counted then
+    while (pos < n && pos < hi) {
+        const char* e = (const char*)memchr(b + pos, '\n', n - pos);
+        const size_t end = e ? (size_t)(e - b) : n;
+        R.nonempty_lines += end > pos;                           // `grep -c .` of get_n_reads_fastq (CRISPRessoShared.py:743-748)
+        if (active && (line & 3) == 0) {
+            const uint64_t rec = line >> 2;
+            Line id, sq, pl, ql;
+            read_line(pos, id);
+            if (id.z == id.a) { R.stop_rec = rec; active = false; }
+            else {
+                read_line(id.next, sq); read_line(sq.next, pl); read_line(pl.next, ql);
+                const size_t nq = ql.z - ql.a, ns = sq.z - sq.a;
+                const uint8_t* q = (const uint8_t*)b + ql.a;
+                const char* failure = nullptr;
+                bool keep = true;
+                auto min_ok = [&]() {
+                    if (nq == 0) { failure = "ValueError: zero-size array to reduction operation minimum which has no identity (empty quality line)"; return false; }
+                    unsigned mn = 255;
+                    for (size_t k = 0; k < nq; ++k) { const unsigned v = (uint8_t)(q[k] - 33); if (v < mn) mn = v; }
+                    return (int)mn >= min_bp;
+                };
+                auto mean_ok = [&]() {
+                    if (nq == 0) return false;                   // numpy: mean of an empty slice is nan, nan >= x is False
+                    uint64_t sum = 0;
+                    for (size_t k = 0; k < nq; ++k) sum += (uint8_t)(q[k] - 33);
+                    return (double)sum / (double)nq >= (double)min_av;
+                };
+                if (min_bp > 0 && min_av > 0 && min_bpn <= 0) {  // run_mBP_mRQ: mean first
+                    keep = mean_ok();
+                    if (keep) keep = min_ok();
+                } else {
+                    if (min_bp > 0) keep = min_ok();
+                    if (keep && !failure && min_av > 0) keep = mean_ok();
+                }
+                if (!failure && keep && min_bpn > 0) {
+                    if (min_bp > 0 && min_av <= 0) failure = "ValueError: assignment destination is read-only (run_mBP_mBPN masks a numpy.frombuffer view)";
+                    else if (ns != nq) failure = "IndexError: boolean index did not match indexed array (sequence and quality lines differ in length)";
+                }
+                if (failure) {
+                    R.err_rec = rec;
+                    R.err = "filterFastqs, record " + std::to_string(rec) + ": " + failure;
+                    active = false;
+                } else if (keep) {
+                    const size_t at = R.out.size();
+                    R.out.resize(at + (id.z - id.a) + ns + (pl.z - pl.a) + nq + 4);
+                    char* o = R.out.data() + at;
+                    memcpy(o, b + id.a, id.z - id.a); o += id.z - id.a; *o++ = '\n';
+                    memcpy(o, b + sq.a, ns);
+                    if (min_bpn > 0) for (size_t k = 0; k < ns; ++k) if ((int)(uint8_t)(q[k] - 33) < min_bpn) o[k] = 'N';
+                    o += ns; *o++ = '\n';
+                    memcpy(o, b + pl.a, pl.z - pl.a); o += pl.z - pl.a; *o++ = '\n';
+                    memcpy(o, b + ql.a, nq); o += nq; *o++ = '\n';
+                }
+            }
         }
-        if (!keep) continue;
-        if (min_bpn > 0) {
-            if (min_bp > 0 && min_av <= 0) return fail("ValueError: assignment destination is read-only (run_mBP_mBPN masks a numpy.frombuffer view)");
-            if (ns != nq) return fail("IndexError: boolean index did not match indexed array (sequence and quality lines differ in length)");
+        ++line;
+        pos = end + 1;
+    }
+}
+
+// -> 0 ok; C2_E_INVALID with err set for the reference's failures.  The text is cut into byte ranges filtered by one thread each
+// (line numbers from a parallel count of '\n', as in the plain parser); the ranges' outputs are concatenated up to the first
+// empty id line, and a failure counts only if the serial loop would have reached it.
+int filter_fastq_text(const char* b, size_t n, int min_bp, int min_av, int min_bpn, TextBuf& out, size_t& n_out, uint64_t& nonempty_lines, std::string& err) {
+    nonempty_lines = 0;
+    n_out = 0;
+    unsigned threads = n ? plain_threads(n) : 1;
+    if (threads < 1) threads = 1;
+    std::vector<size_t> cut(threads + 1);
+    for (unsigned t = 0; t <= threads; ++t) cut[t] = (size_t)((unsigned __int128)n * t / threads);
+    std::vector<uint64_t> newlines(threads, 0);
+    auto run = [&](auto fn) {
+        if (threads == 1) { fn(0u); return; }
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(fn, t);
+        for (auto& th : pool) th.join();
+    };
+    run([&](unsigned t) {
+        uint64_t c = 0;
+        for (const char* p = b + cut[t], *e = b + cut[t + 1]; p < e;) {
+            const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
+            if (!q) break;
+            ++c; p = q + 1;
         }
-        memcpy(o + n_out, b + id.a, id.z - id.a); n_out += id.z - id.a; o[n_out++] = '\n';
-        memcpy(o + n_out, b + sq.a, ns);
-        if (min_bpn > 0) for (size_t k = 0; k < ns; ++k) if ((int)(uint8_t)(q[k] - 33) < min_bpn) o[n_out + k] = 'N';
-        n_out += ns; o[n_out++] = '\n';
-        memcpy(o + n_out, b + pl.a, pl.z - pl.a); n_out += pl.z - pl.a; o[n_out++] = '\n';
-        memcpy(o + n_out, b + ql.a, nq); n_out += nq; o[n_out++] = '\n';
+        newlines[t] = c;
+    });
+    std::vector<FilterRange> R(threads);
+    std::vector<uint64_t> first_line(threads, 0);                // number of the first line that STARTS at or after cut[t]
+    {
+        uint64_t before = 0;                                     // '\n' bytes in [0, cut[t])
+        for (unsigned t = 0; t < threads; ++t) {
+            // the line containing byte cut[t] has number `before`; if it started earlier the first line starting here is the next one
+            first_line[t] = (cut[t] == 0 || b[cut[t] - 1] == '\n') ? before : before + 1;
+            before += newlines[t];
+        }
+    }
+    run([&](unsigned t) { filter_fastq_range(b, n, cut[t], cut[t + 1], first_line[t], min_bp, min_av, min_bpn, R[t]); });
+    size_t total = 0;
+    unsigned last = threads;                                     // ranges [0, last) contribute their output
+    for (unsigned t = 0; t < threads; ++t) {
+        nonempty_lines += R[t].nonempty_lines;
+    }
+    for (unsigned t = 0; t < threads; ++t) {
+        if (R[t].err_rec != UINT64_MAX && R[t].err_rec < R[t].stop_rec) { err = R[t].err; return C2_E_INVALID; }
+        total += R[t].out.size();
+        if (R[t].stop_rec != UINT64_MAX) { last = t + 1; break; }
+    }
+    if (!out.reserve(total + 4096)) { err = "out of memory"; return C2_E_INVALID; }
+    for (unsigned t = 0; t < last && t < threads; ++t) {
+        if (!R[t].out.empty()) memcpy(out.get() + n_out, R[t].out.data(), R[t].out.size());
+        n_out += R[t].out.size();
     }
     return 0;
 }

@@ -526,3 +526,41 @@ def test_read_filter_framing_wraparound_and_the_reference_failures(tmp_path):
     p = tmp_path / "mBP_mBPN_nothing_passes.fastq"
     p.write_bytes(b"@a\nACGT\n+\n#III\n")
     check_filtered(p, tmp_path, 5, 0, 10)
+
+
+@pytest.mark.parametrize("threads", [2, 3, 7, 16, 61])
+def test_read_filter_on_line_ranges(tmp_path, monkeypatch, threads):
+    """The filter cuts the text into byte ranges (one thread each; record framing from a count of '\\n'); force many ranges onto
+    small files: range edges inside any of the four lines, a blank id line (everything after it is dropped, also what later
+    ranges produced), failures before and after such a stop (only the former count), CRLF, no final newline."""
+    from crispresso2_amd import _native
+    monkeypatch.setenv("C2_FASTQ_THREADS", str(threads))
+    rng = np.random.default_rng(300 + threads)
+    for trial in range(12):
+        seqs = random_seqs(int(rng.integers(1, 90)), rng, lo=5, hi=60, pool=15)
+        recs = []
+        for k, s in enumerate(seqs):
+            q = "".join(chr(int(x)) for x in rng.integers(33, 75, len(s)))
+            nl = "\r\n" if trial % 3 == 2 else "\n"
+            recs.append("@r%d%s%s%s+%s%s%s" % (k, nl, s, nl, nl, q, nl))
+        if trial % 4 == 1 and len(recs) > 3:
+            recs.insert(int(rng.integers(1, len(recs))), "\n")             # a blank id line: the reference's loop ends there
+        text = "".join(recs)
+        if trial % 5 == 3:
+            text = text.rstrip("\r\n")
+        p = tmp_path / ("t%d.fastq" % trial)
+        p.write_bytes(text.encode())
+        for opts in ((0, 30, 0), (5, 0, 0), (0, 20, 12), (4, 18, 9)):
+            check_filtered(p, tmp_path, *opts)
+    # a failure AFTER the blank id line is never reached; one BEFORE it is
+    good = "@a\nACGT\n+\nIIII\n" * 9
+    bad = "@b\nACGT\n+\nIII\n"                                        # sequence / quality length mismatch under masking
+    p = tmp_path / "after_stop.fastq"
+    p.write_bytes((good + "\n" + bad + good).encode())
+    check_filtered(p, tmp_path, 0, 0, 10)
+    p = tmp_path / "before_stop.fastq"
+    p.write_bytes((good + bad + good + "\n" + good).encode())
+    with pytest.raises(IndexError):
+        ofq.filter_fastq(str(p), str(tmp_path / "o.fastq"), None, None, 10)
+    with pytest.raises(_native.NativeError):
+        native_filtered(p, 0, 0, 10)
