@@ -796,7 +796,8 @@ struct TextSource {                                             // the whole tex
 // top of the file; a record's other lines may lie beyond hi).  Stops at its first empty id line (`stop_rec`) or failure
 // (`err_rec`, `err`); the caller orders these events over the ranges as the serial loop would meet them.
 struct FilterRange {
-    std::vector<char> out;
+    TextBuf out;                                                 // (anonymous huge pages; no zero-fill pass as a growing std::vector would add)
+    size_t len = 0;
     uint64_t nonempty_lines = 0, stop_rec = UINT64_MAX, err_rec = UINT64_MAX;
     std::string err;
 };
@@ -811,7 +812,7 @@ void filter_fastq_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t 
     }
     if (pos >= hi) return;
     uint64_t line = first_line;
-    R.out.reserve((hi - lo) + 64);
+    if (!R.out.reserve((hi - lo) + 4096)) { R.err_rec = 0; R.err = "out of memory"; return; }
     struct Line { size_t a, z, next; };
     auto read_line = [&](size_t at, Line& L) {                   // readline().rstrip() at byte `at`
         if (at >= n) { L.a = L.z = L.next = n; return; }
@@ -866,9 +867,12 @@ void filter_fastq_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t 
                     R.err = "filterFastqs, record " + std::to_string(rec) + ": " + failure;
                     active = false;
                 } else if (keep) {
-                    const size_t at = R.out.size();
-                    R.out.resize(at + (id.z - id.a) + ns + (pl.z - pl.a) + nq + 4);
-                    char* o = R.out.data() + at;
+                    const size_t need = (id.z - id.a) + ns + (pl.z - pl.a) + nq + 4;
+                    if (R.len + need > R.out.cap && !R.out.reserve(R.len + need + ((size_t)1 << 20))) {
+                        R.err_rec = rec; R.err = "out of memory"; active = false; ++line; pos = end + 1; continue;
+                    }
+                    char* o = R.out.get() + R.len;
+                    R.len += need;
                     memcpy(o, b + id.a, id.z - id.a); o += id.z - id.a; *o++ = '\n';
                     memcpy(o, b + sq.a, ns);
                     if (min_bpn > 0) for (size_t k = 0; k < ns; ++k) if ((int)(uint8_t)(q[k] - 33) < min_bpn) o[k] = 'N';
@@ -927,13 +931,13 @@ int filter_fastq_text(const char* b, size_t n, int min_bp, int min_av, int min_b
     }
     for (unsigned t = 0; t < threads; ++t) {
         if (R[t].err_rec != UINT64_MAX && R[t].err_rec < R[t].stop_rec) { err = R[t].err; return C2_E_INVALID; }
-        total += R[t].out.size();
+        total += R[t].len;
         if (R[t].stop_rec != UINT64_MAX) { last = t + 1; break; }
     }
     if (!out.reserve(total + 4096)) { err = "out of memory"; return C2_E_INVALID; }
     for (unsigned t = 0; t < last && t < threads; ++t) {
-        if (!R[t].out.empty()) memcpy(out.get() + n_out, R[t].out.data(), R[t].out.size());
-        n_out += R[t].out.size();
+        if (R[t].len) memcpy(out.get() + n_out, R[t].out.get(), R[t].len);
+        n_out += R[t].len;
     }
     return 0;
 }
