@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- aligned+classified reads/sec of the align + classify hot path on MI355X.
 
-A "step" is one pass of the hot path (c2_align_classify_kernel: NW fill + traceback + fused
-classification) over one batch of synthetic reads that is already resident in HBM.
-N = 1 workload: BASELINE.json configs[2], "10M synthetic 250 bp reads vs one 250 bp amplicon"
-(the configuration the metric is quoted on).  N > 1: every rank runs the same amount of work on its own
-shard of the read stream (weak scaling, no data-path collective; the per-amplicon count reduction is the
-only exchange and is included in the step when it is enabled).
+A "step" is one pass of the hot path over one batch of synthetic reads that is already resident in HBM: the launch chain
+of the align kernels (c2_align_diagx_kernel<4> -> <2> -> c2_align_diag_kernel -> c2_align_classify_kernel: NW fill with
+optimality certificate, traceback, fused classification), for several candidate amplicons the strand / best-amplicon choice
+(c2_select_best_kernel), the per-amplicon count tensor (c2_count_vectors_kernel) and its all-reduce over the ranks.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run
-with one rank per GPU.  Rank 0 prints ONE JSON line.
+  --config 3 (default)  BASELINE.json configs[2]: 10 M synthetic 250 bp reads vs one 250 bp amplicon -- the configuration
+                        the metric is quoted on
+  --config 2            configs[1]: 1 M x 150 bp reads vs one 150 bp amplicon
+  --config 4            configs[3]: 10 M x 250 bp reads, every read against 3 candidate amplicons (wild type, HDR, prime edit;
+                        60 / 20 / 20 % of the reads derive from them), best-amplicon choice inside the step
+  --config 5            configs[4]: CRISPRessoPooled-style, 96 amplicons, reads tagged with their amplicon: this rank's
+                        shard of the 100 M-read stream (12.5 M reads per GPU)
+N > 1: every rank runs the same amount of work on its own shard of the read stream (weak scaling, no data-path collective;
+the all-reduce of the per-amplicon count tensor is the only exchange and is inside the step).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run with one rank
+per GPU.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -22,8 +30,76 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz int32 lane-ops/s
+HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4
+CLOCK_HZ = 2.4e9
+# MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+VALU_SIMD32_WAVE_INSTR_PER_S = N_SIMD * CLOCK_HZ / 2.0
+# measured on this chip (tools/valu_microbench*.hip, profiles/r01/valu_microbench*.txt): every opcode of the DP cell
+# (v_max_i32, v_max3_i32, v_cmp + v_addc, v_bfe_i32, DPP forms, VOP3) costs ~4.2 cycles of SIMD time at >= 3 waves per SIMD
+VALU_MEASURED_CYCLES_PER_INSTR = 4.2
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+
+CONFIG_DEFAULTS = {2: (150, 1_000_000), 3: (250, 10_000_000), 4: (250, 10_000_000), 5: (250, 12_500_000)}
+
+
+def build_workload(config, L, n, rank, workers):
+    """-> dict(refs=[(seq, gap_incentive, include)], reads uint8 [n, L], ref_ids uint16 [n] or None, all_refs, text)"""
+    from crispresso2_amd import synth
+    blocks = (n + synth.BLOCK - 1) // synth.BLOCK
+    if config in (2, 3):
+        amp, g, inc = synth.amplicon_setup(L)
+        reads = synth.make_reads(L, n, first_block=rank * blocks, workers=workers)
+        return dict(refs=[(amp, g, inc)], reads=reads, ref_ids=None, all_refs=False,
+                    text="%s synthetic %d bp reads vs one %d bp amplicon per GPU (BASELINE.json configs[%d] shape), every read aligned "
+                         "(dedup off)" % ("{:,}".format(n), L, L, config - 1))
+    if config == 4:
+        amp, g, inc = synth.amplicon_setup(L)
+        variants = [amp, synth.make_variant(amp, "hdr"), synth.make_variant(amp, "pe")]
+        refs = []
+        for r in variants:
+            x = np.zeros(len(r) + 1, dtype=np.int64)
+            x[L // 2 + 1] = 1
+            refs.append((r, x, inc))
+        # 60 % of the reads derive from the amplicon, 20 % from each variant (its first L bases), in a fixed pattern of
+        # BLOCK-read blocks [wt wt wt hdr pe]; the same error / indel model on all of them (SURVEY.md 8d)
+        reads = np.empty((n, L), dtype=np.uint8)
+        pattern = [0, 0, 0, 1, 2]
+        n_blocks_of = [sum(1 for b in range(blocks) if pattern[b % 5] == src) for src in range(3)]
+        pools = [synth.make_reads(L, n_blocks_of[src] * synth.BLOCK, amplicon_id=100 + src, amplicon=variants[src][:L],
+                                  first_block=rank * blocks, workers=workers) if n_blocks_of[src] else None for src in range(3)]
+        per_src = [0, 0, 0]
+        for b in range(blocks):
+            src = pattern[b % 5]
+            a0, m = b * synth.BLOCK, min(synth.BLOCK, n - b * synth.BLOCK)
+            reads[a0:a0 + m] = pools[src][per_src[src] * synth.BLOCK:per_src[src] * synth.BLOCK + m]
+            per_src[src] += 1
+        del pools
+        return dict(refs=refs, reads=reads, ref_ids=None, all_refs=True,
+                    text="%s synthetic %d bp reads per GPU, each against 3 candidate amplicons (wild type %d bp, HDR %d bp, prime edit %d bp; "
+                         "60/20/20 %% of the reads derive from them; BASELINE.json configs[3] shape), best-amplicon choice in the step, "
+                         "every read aligned (dedup off)" % ("{:,}".format(n), L, len(variants[0]), len(variants[1]), len(variants[2])))
+    if config == 5:
+        n_amp = 96
+        setups = [synth.amplicon_setup(L, 1000 + k) for k in range(n_amp)]
+        per = (n + n_amp - 1) // n_amp
+        pb = (per + synth.BLOCK - 1) // synth.BLOCK
+        reads = np.empty((n, L), dtype=np.uint8)
+        rids = np.empty(n, dtype=np.uint16)
+        pos = 0
+        for k in range(n_amp):
+            m = min(per, n - pos)
+            if m <= 0:
+                break
+            reads[pos:pos + m] = synth.make_reads(L, m, amplicon_id=1000 + k, amplicon=setups[k][0], first_block=rank * pb,
+                                                  workers=workers)
+            rids[pos:pos + m] = k
+            pos += m
+        return dict(refs=setups, reads=reads, ref_ids=rids, all_refs=False,
+                    text="%s synthetic %d bp reads per GPU = this rank's shard of the pooled stream, 96 amplicons of %d bp, every read "
+                         "tagged with its amplicon and grouped by amplicon in the input (BASELINE.json configs[4] shape), every read "
+                         "aligned (dedup off)" % ("{:,}".format(n), L, L))
+    raise SystemExit("--config must be 2, 3, 4 or 5")
 
 
 def main():
@@ -31,16 +107,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
-    ap.add_argument("--len", type=int, default=250, dest="L", help="read and amplicon length")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5], help="BASELINE.json workload shape (3 = the headline)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = the configuration's size)")
+    ap.add_argument("--len", type=int, default=0, dest="L", help="read and amplicon length (0 = the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--workers", type=int, default=0, help="processes generating the synthetic reads (0 = auto; 1 = no fork, for profiler runs)")
     ap.add_argument("--band", type=int, default=-1, help="pointer-plane band: -1 auto, 0 off, n lanes each side")
     ap.add_argument("--band-wgs", type=int, default=0, help="target workgroups per CU for the automatic band")
     ap.add_argument("--kernel", choices=["auto", "band", "full", "diag1", "diag2"], default="auto",
                     help="kernel chain (auto = diagonal-band kernels with certificate, 4 -> 2 -> 1 alignments per wavefront)")
-    ap.add_argument("--check", type=int, default=300, help="reads compared with the oracle after the timed region")
+    ap.add_argument("--check", type=int, default=300, help="reads compared with the C oracle after the timed region (0 = no checks at all)")
+    ap.add_argument("--no-full-plane-check", action="store_true", help="skip the chain-vs-full-plane comparison of every alignment")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -49,25 +127,27 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    L, n = args.L, args.reads
-
-    from crispresso2_amd import synth
-    amp, gap_inc, include = synth.amplicon_setup(L)
+    L = args.L or CONFIG_DEFAULTS[args.config][0]
+    n = args.reads or CONFIG_DEFAULTS[args.config][1]
+    GO, GE, MIN_ALN_SCORE = -20, -2, 60.0
     matrix_path = os.path.join(ROOT, "crispresso2_amd", "EDNAFULL")
 
     # ---------- everything that fork()s happens before this process touches HIP ----------
     ncpu = os.cpu_count() or 1
     workers = args.workers if args.workers > 0 else max(1, min(32, ncpu // max(world, 1)))
-    blocks_per_rank = (n + synth.BLOCK - 1) // synth.BLOCK
     t0 = time.perf_counter()
-    reads = synth.make_reads(L, n, first_block=rank * blocks_per_rank, workers=workers)
+    wl = build_workload(args.config, L, n, rank, workers)
     t_gen = time.perf_counter() - t0
+    reads, refs, all_refs = wl["reads"], wl["refs"], wl["all_refs"]
+    k = len(refs)
+    n_tasks = n * (k if all_refs else 1)
     n_u = min(n, 1_000_000)
     unique_fraction = float(len(np.unique(reads[:n_u].view([("r", "V%d" % L)]))) / n_u)
-    cpu_baseline = None
+    cpu_baseline, cpu_legs = None, []
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline as cb
-        cpu_baseline = cb.run(reads, amp, gap_inc, include, matrix_path, -20, -2, cores=ncpu, target_seconds=args.cpu_seconds)
+        cpu_baseline, cpu_legs = cb.run(reads, refs, matrix_path, GO, GE, ref_ids=wl["ref_ids"], all_refs=all_refs, cores=ncpu,
+                                        target_seconds=args.cpu_seconds)
 
     import torch
     import torch.distributed as dist
@@ -77,33 +157,54 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from crispresso2_amd import CRISPResso2Align as A, _native
+    from crispresso2_amd import counts as C
     from crispresso2_amd.batch import BatchAligner
     m = A.read_matrix(matrix_path)
     ctx = _native.Context(local_rank)
     ctx.set_band(args.band, args.band_wgs)
     ctx.set_kernel_mode(args.kernel)
-    al = BatchAligner([amp], [gap_inc], [include], m, -20, -2, ctx=ctx)
+    al = BatchAligner([r[0] for r in refs], [r[1] for r in refs], [r[2] for r in refs], m, GO, GE, ctx=ctx)
     stride = al.stride_for(L)
+    Lmax = al.max_ref_len
 
     d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
     d_offsets = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
-    d_aln_read = torch.empty((n, stride), dtype=torch.uint8, device=dev)
-    d_aln_ref = torch.empty((n, stride), dtype=torch.uint8, device=dev)
-    d_records = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    d_rids = None if wl["ref_ids"] is None else torch.from_numpy(wl["ref_ids"].astype(np.int16)).to(dev)
+    d_aln_read = torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev)
+    d_aln_ref = torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev)
+    d_records = torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     # per-amplicon count tensor (CRISPRessoCORE.py:3865-4115 on the device) -- the only thing the GPUs exchange
-    from crispresso2_amd import counts as C
-    layout = C.CountLayout(1, L, L)
+    layout = C.CountLayout(k, Lmax, L)
     d_counts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
-    min_matches = C.min_matches_table([60.0], 2 * L)          # --default_min_aln_score 60
+    min_matches = C.min_matches_table([MIN_ALN_SCORE] * k, Lmax + L)          # --default_min_aln_score 60
+    d_weights = d_selstats = None
+    if all_refs:
+        d_weights = torch.zeros(n_tasks, dtype=torch.int32, device=dev)
+        d_selstats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
+        min_mscore = C.min_mscore_table([MIN_ALN_SCORE] * k)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
-    def step():
-        al.align_device(n, d_reads.data_ptr(), d_offsets.data_ptr(), d_aln_read.data_ptr(), d_aln_ref.data_ptr(),
-                        d_records.data_ptr(), stride, L, stream=stream)
+    def align_into(a_read, a_ref, recs):
+        al.align_device(n, d_reads.data_ptr(), d_offsets.data_ptr(), a_read.data_ptr(), a_ref.data_ptr(), recs.data_ptr(), stride, L,
+                        d_ref_ids=None if d_rids is None else d_rids.data_ptr(), all_refs=all_refs, stream=stream)
+
+    def step(e=None):
+        if e: e[0].record()
+        align_into(d_aln_read, d_aln_ref, d_records)
+        if e: e[1].record()
+        if all_refs:
+            # strand / best-amplicon choice on the device (CRISPRessoCORE.py:697-707) -> the weight of every alignment in the count pass
+            d_selstats.zero_()
+            C.select_best_device(ctx, n, k, d_records.data_ptr(), min_mscore, C.SELECT_DROP_AMBIGUOUS, Lmax + L,
+                                 d_weights=d_weights.data_ptr(), d_stats=d_selstats.data_ptr(), stream=stream)
+        if e: e[2].record()
         d_counts.zero_()
-        C.accumulate_device(ctx, layout, n, d_aln_read.data_ptr(), d_aln_ref.data_ptr(), stride, d_records.data_ptr(),
-                            d_counts.data_ptr(), min_matches=min_matches, stream=stream)
+        C.accumulate_device(ctx, layout, n_tasks, d_aln_read.data_ptr(), d_aln_ref.data_ptr(), stride, d_records.data_ptr(),
+                            d_counts.data_ptr(), d_weights=d_weights.data_ptr() if all_refs else None,
+                            min_matches=None if all_refs else min_matches, stream=stream)
         C.all_reduce(d_counts)
+        if e: e[3].record()
 
     def fence():
         torch.cuda.synchronize()
@@ -116,8 +217,8 @@ def main():
     fence()
     ctx.timing_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for s_ in range(args.steps):
+        step(ev[s_])
     fence()
     dt = time.perf_counter() - t0
     kernel_ms, first_ms, launches = ctx.timing_read_split()
@@ -126,45 +227,101 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    align_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / max(args.steps, 1)
+    select_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / max(args.steps, 1)
+    count_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / max(args.steps, 1)
 
-    # ---------- after the timed region: algorithmic bytes of one launch, parity spot check ----------
+    # ---------- after the timed region: algorithmic bytes of one launch, parity checks ----------
     rec = d_records.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
     ok_status = bool((rec["status"] == 0).all())
     aln_cols = int(rec["aln_len"].astype(np.int64).sum())
-    bytes_in = n * L + (n + 1) * 8
-    bytes_out = 2 * aln_cols + 32 * n
+    bytes_in = n_tasks * (L + 8) + (0 if d_rids is None else 2 * n)
+    bytes_out = 2 * aln_cols + 32 * n_tasks
     alg_bytes = bytes_in + bytes_out
     avg_launch_s = (kernel_ms / max(launches, 1)) / 1e3          # the whole launch chain of one batch
     avg_first_s = (first_ms / max(launches, 1)) / 1e3            # its first kernel: the one that sees every task
-    cells = n * (L + 1) * (L + 1)
-    parity = None
+    ref_cells = np.array([(len(r[0]) + 1) * (L + 1) for r in refs], dtype=np.int64)      # cells of the reference's full matrix
+    if all_refs:
+        cells = int(n * ref_cells.sum())
+    elif wl["ref_ids"] is not None:
+        cells = int(ref_cells[wl["ref_ids"].astype(np.int64)].sum())
+    else:
+        cells = int(n * ref_cells[0])
+    tiers = ctx.tier_info()
+
+    def task_ref(t):
+        return (t % k) if all_refs else (int(wl["ref_ids"][t]) if wl["ref_ids"] is not None else 0)
+
+    checks = {"all_status_ok": ok_status}
     if rank == 0 and args.check > 0:
         import oracle
+        from oracle import cpu_baseline as cb
+        # (1) a random sample against the C restatement
         rng = np.random.default_rng(12345)
-        idx = rng.integers(0, n, args.check)
-        a_r = d_aln_read[torch.from_numpy(idx).to(dev)].cpu().numpy()
-        a_f = d_aln_ref[torch.from_numpy(idx).to(dev)].cpu().numpy()
+        idx = rng.integers(0, n_tasks, args.check)
+        t_idx = torch.from_numpy(idx).to(dev)
+        a_r = d_aln_read[t_idx].cpu().numpy()
+        a_f = d_aln_ref[t_idx].cpu().numpy()
         parity = True
-        for j, k in enumerate(idx):
-            st, s1, s2, mt, ln = oracle.global_align_raw(reads[k].tobytes().decode(), amp, m, gap_inc, -20, -2)
-            T = int(rec["aln_len"][k])
-            if st != 0 or T != ln or a_r[j, :T].tobytes().decode() != s1 or a_f[j, :T].tobytes().decode() != s2 or int(rec["matches"][k]) != mt:
+        for j, t in enumerate(idx):
+            r = task_ref(int(t))
+            rd = reads[int(t) // k if all_refs else int(t)].tobytes().decode()
+            st, s1, s2, mt, ln = oracle.global_align_raw(rd, refs[r][0], m, refs[r][1], GO, GE)
+            T = int(rec["aln_len"][t])
+            if st != 0 or T != ln or a_r[j, :T].tobytes().decode() != s1 or a_f[j, :T].tobytes().decode() != s2 or int(rec["matches"][t]) != mt:
                 parity = False
                 break
-    # size-independent properties on EVERY alignment of the full-size batch (device-side, in slices): no double-gap column;
+        checks["oracle_sample_identical"] = parity
+        checks["oracle_sample"] = args.check
+        # (2) EVERY alignment the CPU-baseline legs computed with the reference itself (strings by digest, the three window counts)
+        if cpu_legs:
+            compared = identical = 0
+            CH = 65536
+            for leg in cpu_legs:
+                a0, cnt_r = leg["first_read"], leg["n_reads"]
+                t0_, nt = a0 * (k if all_refs else 1), cnt_r * (k if all_refs else 1)
+                dig = np.zeros(nt, dtype=np.uint64)
+                for c0 in range(0, nt, CH):
+                    c1 = min(nt, c0 + CH)
+                    ar = d_aln_read[t0_ + c0:t0_ + c1].cpu().numpy()
+                    af = d_aln_ref[t0_ + c0:t0_ + c1].cpu().numpy()
+                    Ts = rec["aln_len"][t0_ + c0:t0_ + c1]
+                    for q in range(c1 - c0):
+                        T = int(Ts[q])
+                        dig[c0 + q] = cb.digest(ar[q, :T].tobytes(), af[q, :T].tobytes())
+                same = dig == leg["digests"]
+                rr = np.arange(cnt_r)
+                tb = t0_ + (rr * k + leg["best_ref"].astype(np.int64) if all_refs else rr)
+                same_cnt = ((rec["insertion_n"][tb] == leg["counts"][:, 0]) & (rec["deletion_n"][tb] == leg["counts"][:, 1]) &
+                            (rec["substitution_n"][tb] == leg["counts"][:, 2]))
+                if all_refs:
+                    same = same.reshape(cnt_r, k).all(axis=1)
+                compared += cnt_r
+                identical += int((same & same_cnt).sum())
+            checks["reference_compared_n"] = compared
+            checks["reference_identical_n"] = identical
+            checks["reference_identical"] = bool(compared == identical)
+    # (3) size-independent properties on EVERY alignment of the full-size batch (device-side, in slices): no double-gap column;
     # removing the gaps gives back the read and the amplicon (every base exactly once, in order); `matches` and
     # `all_deletion_bases` of the record agree with the strings
-    props = None
     if args.check > 0:
         props = True
-        d_amp = torch.from_numpy(np.frombuffer(amp.encode(), dtype=np.uint8).copy()).to(dev)
+        Li_t = torch.tensor([len(r[0]) for r in refs], dtype=torch.int64, device=dev)
+        d_amps = torch.zeros((k, Lmax), dtype=torch.uint8, device=dev)
+        for r in range(k):
+            d_amps[r, :len(refs[r][0])] = torch.from_numpy(np.frombuffer(refs[r][0].encode(), dtype=np.uint8).copy()).to(dev)
         d_reads2 = d_reads.view(n, L)
         recs_t = d_records.view(torch.int16)                      # aln_len, matches are the first two uint16 (< 32768 here)
         cols = torch.arange(stride, device=dev)[None, :]
+        colsL = torch.arange(Lmax, device=dev)[None, :]
         dash = ord("-")
         SL = 500_000
-        for a0 in range(0, n, SL):
-            a1 = min(n, a0 + SL)
+        for a0 in range(0, n_tasks, SL):
+            a1 = min(n_tasks, a0 + SL)
+            tt = torch.arange(a0, a1, device=dev)
+            rid_ = (tt % k) if all_refs else (d_rids[a0:a1].to(torch.int64) if d_rids is not None else torch.zeros(a1 - a0, dtype=torch.int64, device=dev))
+            rd_ = (tt // k) if all_refs else tt
+            Li_ = Li_t[rid_]
             T_ = recs_t[a0:a1, 0].to(torch.int64)
             mt_ = recs_t[a0:a1, 1].to(torch.int64)
             delb_ = recs_t[a0:a1, 9].to(torch.int64)
@@ -174,38 +331,93 @@ def main():
             fgap = (F_ == dash) & valid
             ok = not bool((rgap & fgap).any())
             keep_r, keep_f = valid & ~rgap, valid & ~fgap
-            ok = ok and bool((keep_r.sum(1) == L).all()) and bool((keep_f.sum(1) == L).all())
+            ok = ok and bool((keep_r.sum(1) == L).all()) and bool((keep_f.sum(1) == Li_).all())
             if ok:
-                ok = bool(torch.equal(R_[keep_r].view(a1 - a0, L), d_reads2[a0:a1]))
-                ok = ok and bool(torch.equal(F_[keep_f].view(a1 - a0, L), d_amp[None, :].expand(a1 - a0, L)))
+                ok = bool(torch.equal(R_[keep_r].view(a1 - a0, L), d_reads2[rd_]))
+                # the reference's bases in order: rank of every kept column -> compare with the amplicon at that rank
+                rank_f = torch.cumsum(keep_f.to(torch.int32), 1) - 1
+                want = d_amps[rid_][:, :].gather(1, rank_f.clamp(min=0, max=Lmax - 1).to(torch.int64))
+                ok = ok and bool(((F_ == want) | ~keep_f).all())
                 ok = ok and bool(torch.equal(((R_ == F_) & keep_r & keep_f).sum(1), mt_)) and bool(torch.equal(rgap.sum(1), delb_))
+                del rank_f, want
             props = props and ok
             del valid, rgap, fgap, keep_r, keep_f
+        checks["full_batch_properties_hold"] = props
+        del colsL
+    # (4) the launch chain's certificates, exhaustively: the SAME batch through the full-plane row-strip kernel (every cell
+    # of every matrix computed, any path followed) into second buffers; every aligned string and every record must be equal
+    if rank == 0 and args.check > 0 and not args.no_full_plane_check and args.kernel == "auto":
+        b_read = torch.zeros((n_tasks, stride), dtype=torch.uint8, device=dev)
+        b_ref = torch.zeros((n_tasks, stride), dtype=torch.uint8, device=dev)
+        b_rec = torch.zeros((n_tasks, 32), dtype=torch.uint8, device=dev)
+        ctx.set_kernel_mode("full")
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        align_into(b_read, b_ref, b_rec)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf
+        ctx.set_kernel_mode(args.kernel)
+        equal_n = 0
+        cols = torch.arange(stride, device=dev)[None, :]
+        recs_t = d_records.view(torch.int16)
+        for a0 in range(0, n_tasks, 1_000_000):
+            a1 = min(n_tasks, a0 + 1_000_000)
+            valid = cols < recs_t[a0:a1, 0].to(torch.int64)[:, None]
+            same = (((d_aln_read[a0:a1] == b_read[a0:a1]) & (d_aln_ref[a0:a1] == b_ref[a0:a1])) | ~valid).all(1)
+            same &= (d_records[a0:a1] == b_rec[a0:a1]).all(1)
+            equal_n += int(same.sum().item())
+        checks["chain_equals_full_plane_n"] = equal_n
+        checks["chain_equals_full_plane"] = bool(equal_n == n_tasks)
+        checks["full_plane_pass_s"] = tf
+        del b_read, b_ref, b_rec
+
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
-    tiers = ctx.tier_info()
     chain_names = {"auto": ["c2_align_diagx_kernel<4>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
                    "diag2": ["c2_align_diagx_kernel<2>", "c2_align_diag_kernel"], "diag1": ["c2_align_diag_kernel"]}
-    # HBM bytes per alignment from the committed PMC passes (separate rocprofv3 --pmc runs of this same script; FETCH_SIZE
-    # doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming reads); null when the profile file is absent
     chain = ((chain_names.get(args.kernel, ["c2_align_diag_kernel"])[-len(tiers):] if band["band_lanes"] < 0 else
               ["c2_align_classify_kernel<%d, true>" % info["rows_per_lane"]] if band["band_lanes"] > 0 else [])
              + ["c2_align_classify_kernel<%d, false>" % info["rows_per_lane"]])
     dominant = chain[0]
     # algorithmic bytes of the dominant kernel's launch: every read and offset in; strings + record out for the tasks it finishes
-    done_first = n - (tiers[0] if tiers else 0)
-    alg_first = bytes_in + int(bytes_out * (done_first / float(n)))
+    done_first = n_tasks - (tiers[0] if tiers else 0)
+    alg_first = bytes_in + int(bytes_out * (done_first / float(n_tasks)))
     achieved_gbs = alg_first / avg_first_s / 1e9 if avg_first_s > 0 else 0.0
+    # HBM bytes and instruction counts per alignment from the committed PMC passes of THIS round's build (separate rocprofv3
+    # --pmc runs of this same script over 2 M reads; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming
+    # reads); null when the profile file is absent or the run is not the default one
     traffic = traffic_src = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01", "pmc_summary_default.json")
-    if os.path.exists(pmc_path) and L == 250 and args.kernel == "auto":
+    valu_per_aln = salu_per_aln = None
+    pmc_path = os.path.join(PROFILE_DIR, "pmc_summary_default.json")
+    if os.path.exists(pmc_path) and args.config == 3 and L == 250 and args.kernel == "auto":
         with open(pmc_path) as fh:
-            pmc = json.load(fh)["kernels"].get(dominant)
+            pj = json.load(fh)
+        pmc = pj["kernels"].get(dominant)
+        pmc_reads = float(pj.get("reads", 2.0e6))
         if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / 2.0e6 * n      # bytes per launch of n alignments
-            traffic_src = ("profiles/r01/pmc_summary_default.json: (2*FETCH_SIZE + WRITE_SIZE) KB of %s over 2,000,000 reads, scaled to "
-                           "the reads of one launch; includes the kernel's pointer-word scratch plane (written once, read back once)" % dominant)
-    tallies = layout.unpack(d_counts.cpu().numpy(), 0, L)
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / pmc_reads * n      # bytes per launch of n alignments
+            traffic_src = ("profiles/r02/pmc_summary_default.json: (2*FETCH_SIZE + WRITE_SIZE) KB of %s over %d reads, scaled to "
+                           "the reads of one launch; includes the kernel's pointer-word scratch plane" % (dominant, int(pmc_reads)))
+        if pmc and "SQ_INSTS_VALU" in pmc:
+            valu_per_aln = pmc["SQ_INSTS_VALU"] / pmc_reads
+            salu_per_aln = pmc.get("SQ_INSTS_SALU", 0.0) / pmc_reads
+    tallies = [layout.unpack(d_counts.cpu().numpy(), r, len(refs[r][0])) for r in range(k)]
+    valu = {"cells_per_s": cells / avg_launch_s if avg_launch_s > 0 else 0.0,
+            "gcups": cells / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0,
+            "note": "gcups = full-matrix cell updates the reference would perform per second of launch-chain time (the banded kernels "
+                    "compute fewer); the fractions are of the dominant kernel: wave-instructions it issues per second against (a) what a "
+                    "SIMD was measured to issue for this opcode mix and (b) the SIMD-32 two-cycle rate of MI355X_MICROARCH.md",
+            "kernel": dominant,
+            "wave_instr_per_alignment": valu_per_aln, "salu_instr_per_alignment": salu_per_aln,
+            "cycles_per_instr_measured": VALU_MEASURED_CYCLES_PER_INSTR,
+            "cycles_per_instr_source": "profiles/r01/valu_microbench.txt, valu_microbench2.txt (tools/valu_microbench*.hip)",
+            "peak_wave_instr_per_s_simd32": VALU_SIMD32_WAVE_INSTR_PER_S,
+            "peak_lane_ops_per_s": VALU_SIMD32_WAVE_INSTR_PER_S * 64}
+    if valu_per_aln and avg_first_s > 0:
+        rate = valu_per_aln * n_tasks / avg_first_s
+        valu["wave_instr_per_s"] = rate
+        valu["frac_of_measured_issue"] = rate / (N_SIMD * CLOCK_HZ / VALU_MEASURED_CYCLES_PER_INSTR)
+        valu["frac_of_simd32_peak"] = rate / VALU_SIMD32_WAVE_INSTR_PER_S
 
     if rank == 0:
         total_reads = world * n * args.steps
@@ -222,34 +434,35 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "%s synthetic %d bp reads vs one %d bp amplicon per GPU (BASELINE.json configs[2] shape), "
-                                   "every read aligned (dedup off), EDNAFULL, gap_open -20, gap_extend -2, gap_incentive 1 at the cut"
-                                   % ("{:,}".format(n), L, L),
-                       "reads_per_gpu_per_step": n, "read_len": L, "amplicon_len": L, "unique_read_fraction": unique_fraction, "unique_read_fraction_sample": n_u,
+            "config": {"workload": wl["text"] + ", EDNAFULL, gap_open -20, gap_extend -2, gap_incentive 1 at the cut",
+                       "baseline_config": args.config,
+                       "reads_per_gpu_per_step": n, "alignments_per_gpu_per_step": n_tasks, "read_len": L, "amplicon_len": Lmax, "n_amplicons": k,
+                       "unique_read_fraction": unique_fraction, "unique_read_fraction_sample": n_u,
                        "rows_per_lane": info["rows_per_lane"], "lds_bytes_per_workgroup": info["lds_bytes"],
                        "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
                        "kernel_chain": chain,
                        "tasks_left_after_each_banded_launch": tiers,
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
+            "alignments_per_s": world * n_tasks * args.steps / dt,
+            "step_breakdown_ms": {"align_chain": align_ms, "select_best": select_ms, "count_vectors_and_all_reduce": count_ms,
+                                  "note": "rank 0, events on the launch stream, mean over the timed steps"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dominant, "avg_launch_ms": 1e3 * avg_first_s, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_first,
-                         "algorithmic_bytes_per_read": alg_first / n,
+                         "algorithmic_bytes_per_read": alg_first / n_tasks,
                          "chain_avg_ms": 1e3 * avg_launch_s, "chain_algorithmic_bytes": alg_bytes,
-                         "note": "integer DP: VALU-issue-bound by construction, HBM fraction is small (SURVEY 8d); see valu and profiles/r01/README.md"},
-            "valu": {"cells_per_s": cells / avg_launch_s if avg_launch_s > 0 else 0.0,
-                     "gcups": cells / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0,
-                     "note": "full-matrix cell updates the reference would perform per second of launch-chain time (the banded kernels compute fewer)",
-                     "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS},
+                         "note": "integer DP: VALU-issue-bound by construction, HBM fraction is small (SURVEY 8d); see valu and profiles/r02/README.md"},
+            "valu": valu,
             "cpu_baseline": cpu_baseline,
-            "checks": {"all_status_ok": ok_status, "oracle_sample_identical": parity, "oracle_sample": args.check,
-                       "full_batch_properties_hold": props},
-            "counts": {"reads_aligned_all_gpus": tallies["counts_total"], "modified": tallies["counts_modified"],
-                       "unmodified": tallies["counts_unmodified"], "with_insertion": tallies["counts_insertion"],
-                       "with_deletion": tallies["counts_deletion"], "with_substitution": tallies["counts_substitution"]},
+            "checks": checks,
+            "counts": [{"amplicon": r, "reads_aligned_all_gpus": tl["counts_total"], "modified": tl["counts_modified"],
+                        "unmodified": tl["counts_unmodified"], "with_insertion": tl["counts_insertion"],
+                        "with_deletion": tl["counts_deletion"], "with_substitution": tl["counts_substitution"]} for r, tl in list(enumerate(tallies))[:4]],
             "host": {"cpus": ncpu, "data_generation_s": t_gen},
         }
+        if all_refs:
+            out["selection"] = dict(zip(C.SELECT_STATS, d_selstats.cpu().numpy().tolist()))
         if cpu_baseline:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_baseline["value"]
         print(json.dumps(out))

@@ -97,3 +97,50 @@ def all_reduce(counts_tensor):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(counts_tensor, op=dist.ReduceOp.SUM)
     return counts_tensor
+
+
+# ---- best-reference selection on the device (c2_select_best_device) ----
+SELECT_STATS = ["N_COMPUTED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_ALN", "N_CACHED_NOTALN", "N_GLOBAL_SUBS", "N_SUBS_OUTSIDE_WINDOW",
+                "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS", "n_bad_status", "a_bad_status"]
+SELECT_DROP_AMBIGUOUS, SELECT_FIRST, SELECT_EXPAND = 0, 1, 2
+SELECT_MAX_ALN_LEN = 7999
+
+
+def min_mscore_table(min_aln_scores):
+    """uint32 [n_refs]: the smallest integer k with k / 1000.0 > refs[name]['min_aln_score'].  The reference compares the
+    Python float round(100*matches/float(len), 3) with min_aln_score (CRISPRessoCORE.py:697); that float is the double nearest
+    to k/1000 for an integer k, so the comparison is one of integers once this threshold is known."""
+    out = np.zeros(len(min_aln_scores), dtype=np.uint32)
+    for r, thr in enumerate(min_aln_scores):
+        lo, hi = 0, 100001                       # scores lie in [0, 100]
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if mid / 1000.0 > thr:
+                hi = mid
+            else:
+                lo = mid + 1
+        out[r] = lo
+    return out
+
+
+def select_mode(args):
+    if getattr(args, 'assign_ambiguous_alignments_to_first_reference', False):
+        return SELECT_FIRST
+    if getattr(args, 'expand_ambiguous_alignments', False):
+        return SELECT_EXPAND
+    return SELECT_DROP_AMBIGUOUS
+
+
+def select_best_device(ctx, n_reads, n_refs, d_records, min_mscore, mode, max_aln_len, d_records2=None, d_slot2=None,
+                       d_raw_counts=None, d_counts=None, d_member=None, d_use2=None, d_flags=None, d_weights=None,
+                       d_weights2=None, d_stats=None, stream=None):
+    """Enqueue c2_select_best_kernel.  d_* are device addresses (ints) or None; min_mscore: host uint32 [n_refs]."""
+    mm = np.ascontiguousarray(min_mscore, dtype=np.uint32)
+    if mm.shape != (n_refs,):
+        raise ValueError("one threshold per reference")
+    P = lambda x: ctypes.c_void_p(x or 0)
+    rc = ctx.lib.c2_select_best_device(
+        ctx.handle, ctypes.c_uint64(n_reads), int(n_refs), P(d_records), P(d_records2), P(d_slot2),
+        mm.ctypes.data_as(ctypes.c_void_p), P(d_raw_counts), P(d_counts), int(mode), int(max_aln_len),
+        P(d_member), P(d_use2), P(d_flags), P(d_weights), P(d_weights2), P(d_stats), P(stream))
+    ctx.check(rc, "c2_select_best_device")

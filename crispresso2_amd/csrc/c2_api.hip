@@ -81,6 +81,8 @@ struct c2_ctx {
     int occ_lds[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
     int occ_blocks[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
+    DevBuf d_sel;          // selection kernel: per-reference score thresholds
+    std::vector<uint32_t> sel_table;
     std::vector<uint16_t> cnt_table;   // host copy of the table that is on the device (skip re-upload when unchanged)
 };
 
@@ -399,7 +401,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel};
     for (DevBuf* b : all) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -705,6 +707,38 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)nb;
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_tasks + 31) / 32, resident));
     hipLaunchKernelGGL(c2_count_vectors_kernel, dim3(grid), dim3(64 * C2_CNT_WAVES), lds, s, A);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int c2_select_best_device(c2_ctx* ctx, uint64_t n_reads, int32_t n_refs, const c2_aln_record* d_records,
+                          const c2_aln_record* d_records2, const int32_t* d_slot2, const uint32_t* h_min_mscore,
+                          const uint32_t* d_raw_counts, const uint32_t* d_counts, int32_t mode, int32_t max_aln_len,
+                          uint64_t* d_member, uint64_t* d_use2, uint8_t* d_flags, uint32_t* d_weights, uint32_t* d_weights2,
+                          uint64_t* d_stats, void* hip_stream) {
+    if (!ctx || !d_records || !h_min_mscore || n_refs <= 0 || n_refs > 64 || mode < 0 || mode > 2) { if (ctx) ctx->err = "bad selection arguments"; return C2_E_INVALID; }
+    if ((d_records2 != nullptr) != (d_slot2 != nullptr)) { ctx->err = "d_records2 and d_slot2 go together"; return C2_E_INVALID; }
+    static_assert(C2_SEL_STATS == C2_SELECT_STATS, "selection statistics");
+    // the integer form of round(100*matches/len, 3) is exact below 8000 columns (c2_mscore)
+    if (max_aln_len >= 8000) { ctx->err = "c2_select_best_device: alignments of 8000 columns or more"; return C2_E_TOO_LARGE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_reads == 0) return 0;
+    hipStream_t s = (hipStream_t)hip_stream;
+    int rc;
+    // thresholds: a small device table, re-uploaded when it changes
+    if ((rc = ensure(ctx, ctx->d_sel, 64 * sizeof(uint32_t)))) return rc;
+    if (ctx->sel_table.size() != (size_t)n_refs || memcmp(ctx->sel_table.data(), h_min_mscore, (size_t)n_refs * 4) != 0) {
+        HIPCHK(ctx, hipStreamSynchronize(s));          // no earlier launch may still read the old table
+        HIPCHK(ctx, hipMemcpy(ctx->d_sel.p, h_min_mscore, (size_t)n_refs * 4, hipMemcpyHostToDevice));
+        ctx->sel_table.assign(h_min_mscore, h_min_mscore + n_refs);
+    }
+    c2_select_args A;
+    A.records = d_records; A.records2 = d_records2; A.slot2 = d_slot2; A.min_mscore = (const uint32_t*)ctx->d_sel.p;
+    A.raw_counts = d_raw_counts; A.counts = d_counts;
+    A.member = (unsigned long long*)d_member; A.use2 = (unsigned long long*)d_use2; A.flags = d_flags;
+    A.weights = d_weights; A.weights2 = d_weights2; A.stats = (unsigned long long*)d_stats;
+    A.n_reads = n_reads; A.n_refs = n_refs; A.mode = mode;
+    hipLaunchKernelGGL(c2_select_best_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, A);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }

@@ -179,3 +179,31 @@ typedef struct c2_count_args {
     int32_t flags;                // C2_CNT_FLAG_*
     const uint32_t* order;        // optional: tasks grouped by reference (position -> task), else NULL = task order
 } c2_count_args;
+
+// ---- best-reference selection on the device (CRISPRessoCORE.py:683, :697-707, :779-785) ----
+// One lane per read over the k alignments of that read (all-references layout: task = read * n_refs + ref).
+#define C2_SEL_MODE_DROP_AMBIGUOUS 0      // default: a read that ties between amplicons counts for none (class AMBIGUOUS)
+#define C2_SEL_MODE_FIRST 1               // --assign_ambiguous_alignments_to_first_reference
+#define C2_SEL_MODE_EXPAND 2              // --expand_ambiguous_alignments
+#define C2_SEL_FLAG_ALIGNED 1
+#define C2_SEL_FLAG_AMBIGUOUS 2
+enum { C2_SEL_N_COMPUTED_ALN = 0, C2_SEL_N_COMPUTED_NOTALN, C2_SEL_N_CACHED_ALN, C2_SEL_N_CACHED_NOTALN, C2_SEL_N_GLOBAL_SUBS,
+       C2_SEL_N_SUBS_OUTSIDE_WINDOW, C2_SEL_N_MODS_IN_WINDOW, C2_SEL_N_MODS_OUTSIDE_WINDOW, C2_SEL_N_READS_IRREGULAR_ENDS,
+       C2_SEL_N_BAD_STATUS, C2_SEL_FIRST_BAD_STATUS, C2_SEL_STATS };
+typedef struct c2_select_args {
+    const c2_aln_record* records;   // n_reads x n_refs: the alignments on the strand the seeds asked for
+    const c2_aln_record* records2;  // reverse-complement alignments of the (read, reference) pairs aligned on both strands, or NULL
+    const int32_t* slot2;           // n_reads x n_refs: index into records2, -1 = none; NULL when records2 is NULL
+    const uint32_t* min_mscore;     // n_refs: smallest milli-score (1000 * score) that exceeds refs[name]['min_aln_score']
+    const uint32_t* raw_counts;     // per read multiplicity before the reverse-complement merge (aln_stats), NULL = 1
+    const uint32_t* counts;         // per read multiplicity the weights are formed from, NULL = 1
+    unsigned long long* member;     // out, per read: bit r = reference r is a best match (may be NULL)
+    unsigned long long* use2;       // out, per read: bit r = the reverse-complement alignment won against reference r (may be NULL)
+    uint8_t* flags;                 // out, per read: C2_SEL_FLAG_* (may be NULL)
+    uint32_t* weights;              // out, n_reads x n_refs: multiplicity with which task (read, r) enters the count pass (may be NULL)
+    uint32_t* weights2;             // out, one per records2 entry (may be NULL)
+    unsigned long long* stats;      // out, C2_SEL_STATS sums (aln_stats of process_fastq, CRISPRessoCORE.py:1974-1979), may be NULL
+    uint64_t n_reads;
+    int32_t n_refs;
+    int32_t mode;                   // C2_SEL_MODE_*
+} c2_select_args;

@@ -1767,6 +1767,110 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
 }
 
 // =====================================================================================
+// Strand and best-reference choice of get_new_variant_object on the device (CRISPRessoCORE.py:683 strand: strict '>';
+// :697-707 best reference: first strictly better score that also exceeds refs[name]['min_aln_score'], later equal scores
+// join; :710 aligned iff the best score is > 0; :779-785 ambiguous reads), one lane per read over its k records.
+// The reference compares Python floats round(100*matches/float(len), 3); here the same order on integers: c2_mscore is
+// 1000 x that rounded value.  100000*m/T is a multiple of 1/T, so unless it is an exact tie it lies >= 1/(2T) from the
+// rounding boundary -- far more than the double's error -- and an exact tie has the form odd/2000 = x with T a multiple
+// of 64 * 5^j (T < 8000): x is then a dyadic rational, the double is exact and Python rounds half to even.  The host
+// refuses alignments of 8000 columns and more (c2_select_best_device).
+// =====================================================================================
+__host__ __device__ inline uint32_t c2_mscore(const uint32_t matches, const uint32_t T) {
+    if (T == 0) return 0;
+    const uint64_t num = 100000ull * matches;
+    uint64_t q = num / T;
+    const uint64_t r = num - q * T;
+    if (2 * r > T) ++q; else if (2 * r == T) q += (q & 1ull);
+    return (uint32_t)q;
+}
+
+__global__ __launch_bounds__(256) void c2_select_best_kernel(c2_select_args A)
+{
+    const uint64_t read = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    unsigned long long st[C2_SEL_STATS];
+#pragma unroll
+    for (int q = 0; q < C2_SEL_STATS; ++q) st[q] = 0;
+    if (read < A.n_reads) {
+        const int k = A.n_refs;
+        long long best = -1;
+        unsigned long long member = 0, use2 = 0;
+        int last = -1; bool last2 = false;
+        for (int r = 0; r < k; ++r) {
+            const uint64_t t = read * (uint64_t)k + (uint64_t)r;
+            const c2_aln_record* rec = A.records + t;
+            if (rec->status != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rec->status; }
+            long long ms = (long long)c2_mscore(rec->matches, rec->aln_len);
+            bool second = false;
+            if (A.records2 && A.slot2) {
+                const int sl = A.slot2[t];
+                if (sl >= 0) {
+                    const c2_aln_record* rec2 = A.records2 + sl;
+                    if (rec2->status != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rec2->status; }
+                    const long long ms2 = (long long)c2_mscore(rec2->matches, rec2->aln_len);
+                    if (ms2 > ms) { ms = ms2; second = true; }              // :683  if (rvscore > fwscore)
+                }
+            }
+            if (second) use2 |= 1ull << r;
+            if (ms > best && ms >= (long long)A.min_mscore[r]) { best = ms; member = 1ull << r; last = r; last2 = second; }   // :697
+            else if (ms == best) { member |= 1ull << r; last = r; last2 = second; }                                           // :703
+        }
+        const bool aligned = best > 0;                                       // :710
+        if (!aligned) member = 0;
+        const int nb = __popcll(member);
+        unsigned long long counted = member;
+        bool ambiguous = false;
+        if (nb > 1) {
+            if (A.mode == C2_SEL_MODE_FIRST) counted = member & (~member + 1ull);
+            else if (A.mode != C2_SEL_MODE_EXPAND) { counted = 0; ambiguous = true; }
+        }
+        if (A.member) A.member[read] = member;
+        if (A.use2) A.use2[read] = use2;
+        if (A.flags) A.flags[read] = (uint8_t)((aligned ? C2_SEL_FLAG_ALIGNED : 0) | (ambiguous ? C2_SEL_FLAG_AMBIGUOUS : 0));
+        const uint32_t w = A.counts ? A.counts[read] : 1u;
+        if (A.weights) {
+            for (int r = 0; r < k; ++r) {
+                const uint64_t t = read * (uint64_t)k + (uint64_t)r;
+                const bool c = (counted >> r) & 1ull, u = (use2 >> r) & 1ull;
+                A.weights[t] = (c && !u) ? w : 0u;
+                if (A.weights2 && A.slot2 && A.slot2[t] >= 0) A.weights2[A.slot2[t]] = (c && u) ? w : 0u;
+            }
+        }
+        // aln_stats of process_fastq (:1974-1979): payload of the LAST best match, raw multiplicity
+        const unsigned long long raw = A.raw_counts ? (unsigned long long)A.raw_counts[read] : 1ull;
+        if (aligned) {
+            st[C2_SEL_N_COMPUTED_ALN] = 1; st[C2_SEL_N_CACHED_ALN] = raw - 1ull;
+            const c2_aln_record* rec = (last2 ? A.records2 + A.slot2[read * (uint64_t)k + (uint64_t)last] : A.records + read * (uint64_t)k + (uint64_t)last);
+            const unsigned long long sub_all = rec->all_substitutions, sub_win = rec->substitution_n;
+            const unsigned long long total = (unsigned long long)rec->all_insertion_events + rec->all_deletion_bases + sub_all;
+            const unsigned long long in_win = sub_win + rec->deletion_n + rec->insertion_n;
+            st[C2_SEL_N_GLOBAL_SUBS] = sub_all * raw;
+            st[C2_SEL_N_SUBS_OUTSIDE_WINDOW] = (sub_all - sub_win) * raw;
+            st[C2_SEL_N_MODS_IN_WINDOW] = in_win * raw;
+            st[C2_SEL_N_MODS_OUTSIDE_WINDOW] = (total - in_win) * raw;       // (two's complement like the host's int64 sum)
+            st[C2_SEL_N_READS_IRREGULAR_ENDS] = (unsigned long long)rec->irregular_ends * raw;
+        } else {
+            st[C2_SEL_N_COMPUTED_NOTALN] = 1; st[C2_SEL_N_CACHED_NOTALN] = raw - 1ull;
+        }
+    }
+    if (A.stats) {
+        // wavefront sums, one atomic per statistic per wavefront (FIRST_BAD_STATUS: any non-zero value will do)
+#pragma unroll
+        for (int q = 0; q < C2_SEL_STATS; ++q) {
+            unsigned long long v = st[q];
+            if (q == C2_SEL_FIRST_BAD_STATUS) { if (v != 0) A.stats[q] = v; continue; }   // (plain store: any one of them will do)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xffffffffull), m);
+                const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m);
+                v += ((unsigned long long)hi << 32) | lo;
+            }
+            if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(A.stats + q, v);
+        }
+    }
+}
+
+// =====================================================================================
 // Per-amplicon count vectors: the device side of the reference's "Quantifying indels/substitutions"
 // loop (CRISPRessoCORE.py:3964-4115, non-coding case) and of process_fastq's aln_stats (:1974-1979).
 // Input: the aligned strings and records the align kernel left in HBM, plus per-task weights

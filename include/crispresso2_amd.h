@@ -159,6 +159,27 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
                             const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
                             int64_t* d_counts, void* hip_stream);
 
+/* Strand and best-reference choice of get_new_variant_object (CRISPRessoCORE.py:683, :697-707, :710, :779-785) over the
+ * records of an all-references batch: d_records is n_reads x n_refs (task = read * n_refs + reference).  Optional second
+ * batch: d_records2 holds the reverse-complement alignments of the (read, reference) pairs whose seeds were inconclusive,
+ * d_slot2 (n_reads x n_refs, -1 = none) says where.  h_min_mscore: HOST table of n_refs thresholds -- the smallest integer
+ * k with k/1000.0 > refs[name]['min_aln_score'] (scores are round(100*matches/len, 3), compared as 1000 x score).
+ * mode: 0 ambiguous reads count for no reference, 1 --assign_ambiguous_alignments_to_first_reference,
+ * 2 --expand_ambiguous_alignments.  Outputs (device pointers, any may be NULL): d_member / d_use2 one 64-bit mask per read
+ * (bit r: reference r is a best match / its reverse-complement alignment won), d_flags one byte per read (1 aligned,
+ * 2 ambiguous), d_weights (n_reads x n_refs) and d_weights2 (one per d_records2 entry): the multiplicity with which each
+ * alignment enters c2_count_vectors_device, formed from d_counts (NULL = 1); d_stats: 11 uint64 sums, the caller zeroes
+ * them -- N_COMPUTED_ALN, N_COMPUTED_NOTALN, N_CACHED_ALN, N_CACHED_NOTALN, N_GLOBAL_SUBS, N_SUBS_OUTSIDE_WINDOW,
+ * N_MODS_IN_WINDOW, N_MODS_OUTSIDE_WINDOW, N_READS_IRREGULAR_ENDS (CRISPRessoCORE.py:1974-1979, weighted with d_raw_counts),
+ * records with a non-zero status, one such status.  n_refs <= 64; alignments of 8000 columns or more are refused
+ * (C2_E_TOO_LARGE: max_aln_len states the bound the caller guarantees).  Enqueued on hip_stream. */
+#define C2_SELECT_STATS 11
+int c2_select_best_device(c2_ctx* ctx, uint64_t n_reads, int32_t n_refs, const c2_aln_record* d_records,
+                          const c2_aln_record* d_records2, const int32_t* d_slot2, const uint32_t* h_min_mscore,
+                          const uint32_t* d_raw_counts, const uint32_t* d_counts, int32_t mode, int32_t max_aln_len,
+                          uint64_t* d_member, uint64_t* d_use2, uint8_t* d_flags, uint32_t* d_weights, uint32_t* d_weights2,
+                          uint64_t* d_stats, void* hip_stream);
+
 /* Pointer-plane banding of the batch kernel (a pure performance knob; results never depend on it).
  * band_lanes: -1 automatic (default), 0 off, n > 0 keep the pointer words of n lanes on each side of the main diagonal.
  * Alignments whose traceback leaves the band are redone in the same call by the full-plane kernel.

@@ -171,3 +171,34 @@ def remap_to_first_reference(first_ref_vectors, items_by_ref, ref1_len, ref1_inc
                 v["all_base_count_vectors_" + s1[i]][ref_pos[i]] += count
         out[name] = v
     return out
+
+
+def select_best(scores, scores_rc, min_aln_scores, assign_first=False, expand=False):
+    """Strand and best-reference choice of get_new_variant_object, per read, as the reference's loop does it
+    (CRISPRessoCORE.py:683 strand, :697-707 best match, :710 aligned, :779-785 ambiguous reads).
+    scores: [k] floats of the alignments on the seeds' strand; scores_rc: [k] floats or None per reference (the
+    reverse-complement alignment of a pair aligned on both strands).  -> (best_match_names as indices, use_rc flags [k],
+    aligned, counted-for indices, ambiguous)"""
+    best_match_score = -1
+    best = []
+    use_rc = [False] * len(scores)
+    for idx in range(len(scores)):
+        score = scores[idx]
+        if scores_rc is not None and scores_rc[idx] is not None and scores_rc[idx] > score:      # :683
+            score = scores_rc[idx]
+            use_rc[idx] = True
+        if score > best_match_score and score > min_aln_scores[idx]:                              # :697
+            best_match_score = score
+            best = [idx]
+        elif score == best_match_score:                                                           # :703
+            best.append(idx)
+    aligned = best_match_score > 0                                                                # :710
+    if not aligned:
+        return [], use_rc, False, [], False
+    counted, ambiguous = list(best), False
+    if len(best) > 1:                                                                             # :779-785
+        if assign_first:
+            counted = best[:1]
+        elif not expand:
+            counted, ambiguous = [], True
+    return best, use_rc, True, counted, ambiguous

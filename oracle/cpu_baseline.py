@@ -1,80 +1,162 @@
 """CPU baseline leg of bench.py -- TEST/MEASUREMENT INFRASTRUCTURE ONLY.
 
-Times the reference's own Cython hot path (oracle/_ref, kind "reference") -- or, if that is not
-built, the C restatement (kind "port") -- on this host's cores: a process pool over chunks of reads,
-each worker calling global_align + find_indels_substitutions per read, nothing else in the loop
-(BASELINE.md plan (A), the figure most favourable to the reference)."""
+Times the reference's own Cython hot path (oracle/_ref, kind "reference") -- or, if that is not built, the C restatement
+(kind "port") -- on this host's cores: process pools over chunks of reads, each worker calling global_align per (read,
+candidate amplicon) and find_indels_substitutions on the best alignment, nothing else in the loop (BASELINE.md plan (A),
+the figure most favourable to the reference).  Measured: ONE process, then a sweep over pool sizes
+(32, 64, 128, 256, ... up to the host's CPUs); the best rate is the baseline and the curve is reported with it.
+
+Every alignment the legs compute is also kept as a 64-bit digest of its two aligned strings (blake2b; ~1 us next to the
+~0.8-5 ms the alignment takes in the pool) together with the classifier's three counts, so bench.py can compare ALL of them
+with what the device produced for the same reads (checks.reference_identical_n) instead of throwing them away."""
+import hashlib
 import os
 import sys
 import time
+
+import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _state = {}
 
 
-def _init(amplicon, gap_incentive, include, matrix_path, go, ge):
+def digest(s1, s2):
+    """64-bit digest of one alignment's two strings (bytes); bench.py applies the same function to the device's output."""
+    return int.from_bytes(hashlib.blake2b(s1 + b"|" + s2, digest_size=8).digest(), "little")
+
+
+def _init(refs, matrix_path, go, ge):
+    """refs: list of (sequence, gap_incentive list, include list)"""
     if _ROOT not in sys.path:
         sys.path.insert(0, _ROOT)
-    import numpy as np
     import oracle
     ref = oracle.ref()
     if ref is not None:
         A, R = ref
         m = A.read_matrix(matrix_path)
         _state["kind"] = "reference"
-        _state["align"] = lambda rd: A.global_align(rd, amplicon, matrix=m, gap_incentive=g, gap_open=go, gap_extend=ge)
-        _state["classify"] = lambda s1, s2: R.find_indels_substitutions(s1, s2, inc)
+        _state["align"] = lambda rd, r: A.global_align(rd, seqs[r], matrix=m, gap_incentive=gs[r], gap_open=go, gap_extend=ge)
+        _state["classify"] = lambda s1, s2, r: R.find_indels_substitutions(s1, s2, incs[r])
     else:
         from crispresso2_amd import CRISPResso2Align as PA      # read_matrix only (file parsing)
         m = PA.read_matrix(matrix_path)
         _state["kind"] = "port"
-        _state["align"] = lambda rd: oracle.global_align(rd, amplicon, m, g, go, ge)
-        _state["classify"] = lambda s1, s2: oracle.find_indels_substitutions(s1, s2, inc)
-    g = np.asarray(gap_incentive, dtype=np.int64)
-    inc = np.asarray(include)
+        _state["align"] = lambda rd, r: oracle.global_align(rd, seqs[r], m, gs[r], go, ge)
+        _state["classify"] = lambda s1, s2, r: oracle.find_indels_substitutions(s1, s2, incs[r])
+    seqs = [x[0] for x in refs]
+    gs = [np.asarray(x[1], dtype=np.int64) for x in refs]
+    incs = [np.asarray(x[2]) for x in refs]
+    _state["n_refs"] = len(refs)
 
 
 def _work(chunk):
-    """chunk: (bytes of concatenated fixed-length reads, read length) -> (reads done, modified reads)"""
-    blob, L = chunk
+    """chunk: (bytes of concatenated fixed-length reads, read length, ref ids bytes (uint16) or None, all_refs)
+    -> (reads done, modified reads, digests uint64 [tasks], counts int32 [reads, 3], best ref per read uint16)"""
+    blob, L, rid_bytes, all_refs = chunk
     n = len(blob) // L
-    mod = 0
+    k = _state["n_refs"] if all_refs else 1
+    rids = np.frombuffer(rid_bytes, dtype=np.uint16) if rid_bytes is not None else None
     align, classify = _state["align"], _state["classify"]
-    for k in range(n):
-        s1, s2, _ = align(blob[k * L:(k + 1) * L].decode())
-        p = classify(s1, s2)
+    dig = np.zeros(n * k, dtype=np.uint64)
+    cnt = np.zeros((n, 3), dtype=np.int32)
+    best_ref = np.zeros(n, dtype=np.uint16)
+    mod = 0
+    for i in range(n):
+        rd = blob[i * L:(i + 1) * L].decode()
+        if all_refs:
+            # get_new_variant_object's loop over the candidate amplicons (CRISPRessoCORE.py:653-707), forward strand
+            best, bs = None, -1.0
+            for r in range(k):
+                s1, s2, sc = align(rd, r)
+                dig[i * k + r] = digest(s1.encode(), s2.encode())
+                if sc > bs:
+                    bs, best = sc, (s1, s2, r)
+            s1, s2, r = best
+        else:
+            r = int(rids[i]) if rids is not None else 0
+            s1, s2, _ = align(rd, r)
+            dig[i] = digest(s1.encode(), s2.encode())
+        p = classify(s1, s2, r)
+        cnt[i] = (p["insertion_n"], p["deletion_n"], p["substitution_n"])
+        best_ref[i] = r
         if p["insertion_n"] or p["deletion_n"] or p["substitution_n"]:
             mod += 1
-    return n, mod
+    return n, mod, dig, cnt, best_ref
 
 
 def _kind(_):
     return _state["kind"]
 
 
-def run(reads_u8, amplicon, gap_incentive, include, matrix_path, go, ge, cores=None, target_seconds=15.0):
-    """reads_u8: uint8 [n, L].  Uses a bounded prefix sized for ~target_seconds of work.  -> dict"""
-    import multiprocessing as mp
-    cores = cores or os.cpu_count() or 1
+def _leg(ctx, procs, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, seconds, max_reads):
+    """One pool size on reads [start, start + sample) -> (dict, reads consumed, kind)"""
     n, L = reads_u8.shape
-    ctx = mp.get_context("fork")      # bench.py calls this BEFORE it touches HIP, so fork is safe
-    with ctx.Pool(cores, initializer=_init, initargs=(amplicon, list(map(int, gap_incentive)), list(map(int, include)),
-                                                      matrix_path, go, ge)) as pool:
-        kind = pool.map(_kind, range(cores))[0]
-        # calibrate on a few reads per worker
-        cal = min(n, 64 * cores)
+    n = min(n, start + max_reads)
+    with ctx.Pool(procs, initializer=_init, initargs=(refs, matrix_path, go, ge)) as pool:
+        kind = pool.map(_kind, range(procs))[0]
+
+        def chunk_of(a, b):
+            return (reads_u8[a:b].tobytes(), L, None if ref_ids is None else np.ascontiguousarray(ref_ids[a:b], dtype=np.uint16).tobytes(), all_refs)
+        # calibrate on a few reads per worker (kept: they are compared with the device too)
+        per = 8 if procs > 1 else 32
+        cal = min(n - start, per * procs)
         t0 = time.perf_counter()
-        pool.map(_work, [(reads_u8[k:k + 64].tobytes(), L) for k in range(0, cal, 64)])
-        per_read = (time.perf_counter() - t0) * cores / max(cal, 1)
-        sample = int(min(n, max(cores * 256, target_seconds * cores / max(per_read, 1e-6))))
-        chunk = max(64, sample // (cores * 8))
-        chunks = [(reads_u8[k:min(k + chunk, sample)].tobytes(), L) for k in range(0, sample, chunk)]
+        done0 = pool.map(_work, [chunk_of(start + a, min(start + a + per, start + cal)) for a in range(0, cal, per)])
+        per_read = (time.perf_counter() - t0) * procs / max(cal, 1)
+        a0 = start + cal
+        sample = int(min(n - a0, max(procs * 16, seconds * procs / max(per_read, 1e-6))))
+        chunk = max(8, sample // (procs * 8))
+        bounds = [(a0 + a, min(a0 + a + chunk, a0 + sample)) for a in range(0, sample, chunk)]
         t0 = time.perf_counter()
-        done = pool.map(_work, chunks)
+        done = pool.map(_work, [chunk_of(a, b) for a, b in bounds])
         dt = time.perf_counter() - t0
     nd = sum(d[0] for d in done)
-    return {"value": nd / dt, "unit": "reads/s", "cores": cores, "kind": kind,
-            "sample": "first %d of the benchmark's reads (%d bp vs %d bp amplicon), %.1f s wall on %d processes, "
-                      "global_align + find_indels_substitutions per read" % (nd, L, len(amplicon), dt, cores),
-            "modified_in_sample": sum(d[1] for d in done)}
+    allc = done0 + done
+    out = {"procs": procs, "reads": nd, "seconds": dt, "reads_per_s": nd / dt if dt > 0 else 0.0,
+           "modified_in_sample": int(sum(d[1] for d in done))}
+    res = {"first_read": start, "n_reads": cal + nd,
+           "digests": np.concatenate([d[2] for d in allc]) if allc else np.zeros(0, dtype=np.uint64),
+           "counts": np.concatenate([d[3] for d in allc]) if allc else np.zeros((0, 3), dtype=np.int32),
+           "best_ref": np.concatenate([d[4] for d in allc]) if allc else np.zeros(0, dtype=np.uint16)}
+    return out, res, kind
+
+
+def run(reads_u8, refs, matrix_path, go, ge, ref_ids=None, all_refs=False, cores=None, target_seconds=20.0, sweep=None):
+    """reads_u8: uint8 [n, L]; refs: list of (sequence, gap_incentive, include_idxs); ref_ids: uint16 [n] or None;
+    all_refs: every read against every reference.  Every leg works on its own consecutive slice of the reads, sized for its
+    share of ~target_seconds.  -> (dict for the bench line, list of per-leg results with the digests)"""
+    import multiprocessing as mp
+    cores = cores or os.cpu_count() or 1
+    refs = [(s, list(map(int, g)), list(map(int, inc))) for s, g, inc in refs]
+    if sweep is None:
+        sweep = [p for p in (32, 64, 128, 256, 512) if p <= cores]
+        if cores not in sweep and (not sweep or cores > sweep[-1] * 1.2 or cores < 32):
+            sweep.append(cores)
+    legs = [1] + [p for p in sweep if p > 1]
+    ctx = mp.get_context("fork")      # bench.py calls this BEFORE it touches HIP, so fork is safe
+    share = target_seconds / (len(legs) + 0.5)
+    curve, results, start, kind = [], [], 0, None
+    n, L = reads_u8.shape
+    for q, p in enumerate(legs):
+        if start >= n:
+            break
+        leg, res, kind = _leg(ctx, p, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, share * (0.5 if p == 1 else 1.0),
+                              max(1, (n - start) // (len(legs) - q)))
+        curve.append(leg)
+        results.append(res)
+        start += res["n_reads"]
+    multi = [c for c in curve if c["procs"] > 1] or curve
+    best = max(multi, key=lambda c: c["reads_per_s"])
+    one = next((c for c in curve if c["procs"] == 1), None)
+    k = len(refs) if all_refs else 1
+    out = {"value": best["reads_per_s"], "unit": "reads/s", "cores": best["procs"], "kind": kind,
+           "best_procs": best["procs"], "host_cpus": cores,
+           "one_proc_reads_per_s": one["reads_per_s"] if one else None,
+           "curve": [{"procs": c["procs"], "reads_per_s": c["reads_per_s"], "reads": c["reads"], "seconds": c["seconds"]} for c in curve],
+           "alignments_per_read": k,
+           "sample": "reads %d..%d of the benchmark's reads (%d bp, %d candidate amplicon%s per read), one consecutive slice per "
+                     "pool size; global_align per (read, amplicon) + find_indels_substitutions on the best alignment; best pool "
+                     "size %d: %d reads in %.1f s wall" % (0, start, L, k, "" if k == 1 else "s", best["procs"], best["reads"], best["seconds"]),
+           "modified_in_sample": best["modified_in_sample"]}
+    return out, results

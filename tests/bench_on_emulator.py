@@ -1,0 +1,110 @@
+"""TEST INFRASTRUCTURE ONLY -- runs bench.py's own main() on a machine without a GPU: torch's "cuda" device becomes the CPU, and
+the four device entry points bench.py uses (BatchAligner.align_device, counts.accumulate_device, counts.select_best_device,
+the Context's bookkeeping calls) are redirected to the wave emulator (tests/emu: the same HIP kernel source compiled for the
+host).  Used to check the script's plumbing -- workload builders, the CPU-baseline legs and the exhaustive comparison of
+their digests with the "device" output, the chain-vs-full-plane check, the JSON line -- before GPU minutes are spent on it."""
+import contextlib
+import ctypes
+import io
+import json
+import sys
+
+import numpy as np
+
+import emu_driver as E
+from pipeline_on_emulator import EmulatedAligner, _view, _accumulate
+
+
+class _Ctx:
+    """stands in for _native.Context"""
+    def __init__(self, device=0):
+        self.mode = "auto"
+        self.tiers = []
+
+    def set_band(self, *a): pass
+    def set_kernel_mode(self, mode): self.mode = mode
+    def timing_enable(self, on): pass
+    def timing_read_split(self): return 3.0, 2.0, 1
+    def tier_info(self): return [7, 3, 1]
+    def launch_info(self, L): return dict(rows_per_lane=4, passes=1, lds_bytes=0, workgroups_per_cu=1, compute_units=1)
+    def band_info(self, L): return dict(band_lanes=-1, fallback_tasks_last_launch=0)
+
+
+class _Aligner(EmulatedAligner):
+    """the launch chain the context's kernel mode asks for: 'auto' = 4 -> 2 -> 1 -> full plane, 'full' = full plane only"""
+    def __init__(self, *a, ctx=None, **kw):
+        super().__init__(*a, **kw)
+        self.ctx = ctx
+
+    def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None):
+        n, k = int(n_reads), len(self.seqs)
+        off = _view(d_offsets, 8 * (n + 1)).view(np.int64)
+        arena = _view(d_reads, max(int(off[-1]), 1)).tobytes()
+        reads = [arena[int(off[i]):int(off[i + 1])].decode() for i in range(n)]
+        ntasks = n * k if all_refs else n
+        rids = None if d_ref_ids is None else _view(d_ref_ids, 2 * n).view(np.int16).astype(np.uint16)
+        st = {}
+        _, rec = E.align_batch(reads, self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=rids, all_refs=all_refs,
+                               band_lanes=-7 if self.ctx.mode == "auto" else 0, stats=st)
+        o1, o2 = st["raw"]
+        w = min(o1.shape[1], aln_stride)
+        a = _view(d_aln_read, ntasks * aln_stride).reshape(ntasks, aln_stride)
+        f = _view(d_aln_ref, ntasks * aln_stride).reshape(ntasks, aln_stride)
+        a[:, :w] = o1[:, :w]
+        f[:, :w] = o2[:, :w]
+        _view(d_records, 32 * ntasks)[:] = rec.view(np.uint8).reshape(-1)
+
+
+def _select(ctx, n_reads, n_refs, d_records, min_mscore, mode, max_aln_len, d_records2=None, d_slot2=None, d_raw_counts=None,
+            d_counts=None, d_member=None, d_use2=None, d_flags=None, d_weights=None, d_weights2=None, d_stats=None, stream=None):
+    mm = np.ascontiguousarray(min_mscore, dtype=np.uint32)
+    P = lambda x: ctypes.c_void_p(x or 0)
+    rc = E.lib().emu_select_best(ctypes.c_uint64(n_reads), int(n_refs), P(d_records), P(d_records2), P(d_slot2),
+                                 mm.ctypes.data_as(ctypes.c_void_p), P(d_raw_counts), P(d_counts), int(mode), P(d_member), P(d_use2),
+                                 P(d_flags), P(d_weights), P(d_weights2), P(d_stats))
+    assert rc == 0
+
+
+class _Event:
+    def __init__(self, enable_timing=False): pass
+    def record(self): pass
+    def elapsed_time(self, other): return 1.0
+
+
+def run_bench(argv):
+    """bench.main() with `argv` on the emulator -> the parsed JSON line"""
+    import torch
+    import bench
+    from crispresso2_amd import _native, batch, counts as C
+    made = []
+
+    def make_aligner(*a, **kw):
+        made.append(_Aligner(*a, **kw))
+        return made[-1]
+
+    class _Stream:
+        cuda_stream = 0
+    real_device = torch.device
+    saved = (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, torch.cuda.set_device, torch.cuda.Event,
+             batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout)
+    torch.device = lambda *a, **k: real_device("cpu")
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.Event = _Event
+    batch.BatchAligner = make_aligner
+    C.accumulate_device = _accumulate(made)
+    C.select_best_device = _select
+    _native.Context = _Ctx
+    sys.argv = ["bench.py"] + list(argv)
+    buf = io.StringIO()
+    sys.stdout = buf
+    try:
+        bench.main()
+    finally:
+        (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, torch.cuda.set_device, torch.cuda.Event,
+         batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout) = saved
+    lines = [x for x in buf.getvalue().splitlines() if x.startswith("{")]
+    assert len(lines) == 1, buf.getvalue()
+    return json.loads(lines[0])

@@ -225,5 +225,20 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     return 0;
 }
 
+int emu_select_best(uint64_t n_reads, int n_refs, const c2_aln_record* records, const c2_aln_record* records2, const int32_t* slot2,
+                    const uint32_t* min_mscore, const uint32_t* raw_counts, const uint32_t* counts, int mode,
+                    unsigned long long* member, unsigned long long* use2, uint8_t* flags, uint32_t* weights, uint32_t* weights2,
+                    unsigned long long* stats)
+{
+    c2_select_args A;
+    A.records = records; A.records2 = records2; A.slot2 = slot2; A.min_mscore = min_mscore; A.raw_counts = raw_counts; A.counts = counts;
+    A.member = member; A.use2 = use2; A.flags = flags; A.weights = weights; A.weights2 = weights2; A.stats = stats;
+    A.n_reads = n_reads; A.n_refs = n_refs; A.mode = mode;
+    emu::launch((unsigned)((n_reads + 255) / 256), [&] { c2_select_best_kernel(A); }, 256);
+    return 0;
+}
+
+uint32_t emu_mscore(uint32_t matches, uint32_t T) { return c2_mscore(matches, T); }
+
 int emu_selftest(int* out) { emu::launch(1, [&] { c2_selftest_kernel(out); }); return 0; }
 }
