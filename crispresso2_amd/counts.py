@@ -91,6 +91,17 @@ def accumulate_device(ctx, layout, n_tasks, d_aln_read, d_aln_ref, aln_stride, d
     ctx.check(rc, "c2_count_vectors_device")
 
 
+def all_reduce_max(value, device):
+    """max of an integer over all ranks (the ranks agree on the tensor layout with it); the value itself for one process"""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+    return int(value)
+
+
 def all_reduce(counts_tensor):
     """Sum the per-GPU count tensors over all ranks (RCCL all-reduce; a no-op for a single process)."""
     import torch.distributed as dist

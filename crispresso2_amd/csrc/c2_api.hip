@@ -312,8 +312,7 @@ int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
         off[r] = all.size();
         all.insert(all.end(), one.begin(), one.end());
     }
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipDeviceSynchronize());      // (any stream may still run kernels that read the old row tables)
     int rc;
     if (!all.empty()) {
         if ((rc = ensure(ctx, ctx->d_diagrows, all.size() * sizeof(c2_diag_row)))) return rc;
@@ -345,6 +344,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.max_lj = g.max_lj; A.max_passes = g.passes;
     A.max_li = ctx->max_li;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
+    A.mat_dim = ctx->sc.mat_dim; A.first_ext_code = ctx->sc.first_ext_code;
     {
         int mx = 0;
         for (int16_t v : ctx->sc.tbl) mx = std::max(mx, (int)v);
@@ -422,8 +422,8 @@ int c2_set_scoring(c2_ctx* ctx, const int64_t* matrix, int32_t mat_dim, int32_t 
     if ((rc = ensure(ctx, ctx->d_tbl, sc.tbl.size() * sizeof(int16_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_code, 256))) return rc;
     if ((rc = ensure(ctx, ctx->d_pk, C2_MAX_CODES * sizeof(uint32_t)))) return rc;
-    // make sure no launch still reads the old tables
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // make sure no launch still reads the old tables -- launches may be on any stream of the caller's, so wait for the device
+    HIPCHK(ctx, hipDeviceSynchronize());
     HIPCHK(ctx, hipMemcpy(ctx->d_tbl.p, sc.tbl.data(), sc.tbl.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_code.p, sc.code_of_char, 256, hipMemcpyHostToDevice));
     if (!sc.pk.empty()) HIPCHK(ctx, hipMemcpy(ctx->d_pk.p, sc.pk.data(), sc.pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -457,7 +457,7 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         blob.insert(blob.end(), (const uint8_t*)ip.data(), (const uint8_t*)(ip.data() + ip.size()));
     }
     int rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipDeviceSynchronize());      // earlier launches (on whatever stream the caller used) may still read the old tables
     if ((rc = ensure(ctx, ctx->d_refblob, blob.size()))) return rc;
     if ((rc = ensure(ctx, ctx->d_refdesc, sizeof(c2_dev_ref) * (size_t)n_refs))) return rc;
     std::vector<c2_dev_ref> desc(n_refs);
@@ -474,7 +474,7 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)(int32_t)gap_incentives[r][k]);
         desc[r].gap_incentive_max = (int32_t)std::min<int64_t>(gm, 1 << 20);
         desc[r].gap_incentive_last_pos = (int32_t)gap_incentives[r][lens[r]] > 0 ? 1 : 0;
-        desc[r].reserved = 0;
+        { int mc = 0; for (int k = 0; k < lens[r]; ++k) mc = std::max(mc, (int)(unsigned char)seqs[r][k]); desc[r].max_char = mc; }
         ctx->gmax = std::max(ctx->gmax, desc[r].gap_incentive_max);
         ctx->ref_len[r] = lens[r];
     }

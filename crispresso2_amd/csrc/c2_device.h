@@ -38,7 +38,7 @@ typedef struct c2_dev_ref {
     int32_t len;                  // Li
     int32_t gap_incentive_max;    // max(0, max_i gap_incentive[i]); max(gap_open, gap_extend) + this bounds what one gap base adds to a score
     int32_t gap_incentive_last_pos; // gap_incentive[Li] > 0: insertions along the last row collect an incentive without paying an open
-    int32_t reserved;
+    int32_t max_char;             // largest byte of seq (a read character >= the matrix dimension is defined iff max_char * dim + it < dim * dim)
 } c2_dev_ref;
 
 // Kernel arguments for the fused align + traceback + classify kernel.
@@ -75,6 +75,8 @@ typedef struct c2_align_args {
     uint32_t* plane;              // multi-alignment diagonal kernel: pointer words in HBM/L2, plane_words_per_wg per workgroup
     uint32_t plane_words_per_wg;
     uint32_t reserved3;
+    int32_t mat_dim;              // dimension of the reference's score matrix (CRISPResso2Align.pyx:212 reads the flat element ci * dim + cj)
+    int32_t first_ext_code;       // codes >= this belong to read characters with ord >= mat_dim (c2_build_scoring); never valid in a reference
     const struct c2_diag_row* diag_base;   // start of the buffer every reference's diag_rows points into
 } c2_align_args;
 

@@ -13,38 +13,74 @@ struct c2_scoring_tables {
     std::vector<int16_t> tbl;     // n_codes x n_codes, [ref code][read code]
     std::vector<uint32_t> pk;     // per ref code: signed 4-bit scores against read codes 0..7 (empty if some score is outside [-8,7])
     int n_codes = 0;
+    int first_ext_code = 0;       // codes >= this: READ characters with dim <= ord < 128 (see c2_build_scoring); invalid in a reference
+    int mat_dim = 0;
 };
 
 // matrix: row-major int64[dim][dim], indexed [ord(ref)][ord(read)] (CRISPResso2Align.pyx:212).
-// Characters with an all-zero row and column share one code; ord >= dim (or >= 128: `char` is
-// signed in the reference) is an out-of-bounds read there and gets C2_INVALID_CODE here.
+// Characters with an all-zero row and column share one code.  The reference indexes the matrix with bounds checking off, so
+// a READ character with dim <= ord < 128 reads the flat element ci * dim + cj -- a later row of the same buffer (its own
+// main() does that on every default run: the flexiguide sequence defaults to the string "None", CRISPRessoCORE.py:3095-3105;
+// lower-case reads do it too).  Such characters get codes of their own, >= first_ext_code, whose table COLUMN holds those
+// elements: one shared code when they are all zero (EDNAFULL, BLOSUM62, make_matrix: always), else one code each.  Whether
+// the element exists at all depends on the largest reference character (c2_dev_ref.max_char): the kernels check
+// max_char * dim + cj < dim * dim per alignment.  A reference character >= dim, and any byte >= 128 (`char` is signed in
+// the reference), is an out-of-bounds read there and gets C2_INVALID_CODE / C2_STATUS_OOB_CHAR here.
 inline bool c2_build_scoring(const int64_t* matrix, int dim, c2_scoring_tables& out, std::string& err) {
     if (!matrix || dim <= 0) { err = "score matrix missing"; return false; }
     std::fill(out.code_of_char, out.code_of_char + 256, (uint8_t)C2_INVALID_CODE);
     const int lim = dim < 128 ? dim : 128;
     std::vector<int> syms;
     bool any_zero = false;
-    std::vector<uint8_t> scoring(lim, 0);
+    std::vector<uint8_t> scoring(lim, 0), is_sym(lim, 0);
     for (int c = 0; c < lim; ++c) {
         bool nz = false;
         for (int k = 0; k < dim && !nz; ++k) nz = matrix[(size_t)c * dim + k] != 0 || matrix[(size_t)k * dim + c] != 0;
-        scoring[c] = nz; if (!nz) any_zero = true;
+        scoring[c] = nz; is_sym[c] = nz; if (!nz) any_zero = true;
     }
     // the bases that make up real reads get the lowest codes, so that the packed 8-symbol score rows cover them
     for (const char* q = "ACGTN"; *q; ++q) if (*q < lim && scoring[(int)*q]) { syms.push_back(*q); scoring[(int)*q] = 0; }
     for (int c = 0; c < lim; ++c) if (scoring[c]) syms.push_back(c);
-    const int n = (int)syms.size() + (any_zero ? 1 : 0);
+    // read characters beyond the matrix: the flat elements ci * dim + c, for every reference character ci that leaves them inside the buffer
+    std::vector<int> ext_nz;
+    bool ext_zero = false;
+    std::vector<int> ext_kind(128, 0);                     // 0 invalid, 1 all zero, 2 own column
+    for (int c = dim; c < 128; ++c) {
+        bool nz_sym = false, nz_other = false;
+        for (int ci = 0; ci < lim; ++ci) {
+            const size_t e = (size_t)ci * dim + c;
+            if (e >= (size_t)dim * dim) break;
+            if (matrix[e] != 0) { if (is_sym[ci]) nz_sym = true; else nz_other = true; }
+        }
+        if (nz_other) continue;                            // (a non-zero score against a symbol of the shared zero code: not representable, stays invalid)
+        ext_kind[c] = nz_sym ? 2 : 1;
+        if (nz_sym) ext_nz.push_back(c); else ext_zero = true;
+    }
+    const int zero_code = (int)syms.size();
+    const int first_ext = zero_code + (any_zero ? 1 : 0);
+    const int n = first_ext + (ext_zero ? 1 : 0) + (int)ext_nz.size();
     if (n > C2_MAX_CODES) { err = "score matrix has more than " + std::to_string(C2_MAX_CODES - 1) + " scoring symbols"; return false; }
     out.n_codes = n;
+    out.first_ext_code = first_ext;
+    out.mat_dim = dim;
     out.tbl.assign((size_t)n * n, 0);
     for (size_t a = 0; a < syms.size(); ++a) out.code_of_char[syms[a]] = (uint8_t)a;
-    if (any_zero) for (int c = 0; c < lim; ++c) if (out.code_of_char[c] == C2_INVALID_CODE) out.code_of_char[c] = (uint8_t)syms.size();
-    for (size_t a = 0; a < syms.size(); ++a)
+    if (any_zero) for (int c = 0; c < lim; ++c) if (out.code_of_char[c] == C2_INVALID_CODE) out.code_of_char[c] = (uint8_t)zero_code;
+    for (int c = dim; c < 128; ++c) if (ext_kind[c] == 1) out.code_of_char[c] = (uint8_t)first_ext;
+    for (size_t x = 0; x < ext_nz.size(); ++x) out.code_of_char[ext_nz[x]] = (uint8_t)(first_ext + (ext_zero ? 1 : 0) + (int)x);
+    for (size_t a = 0; a < syms.size(); ++a) {
         for (size_t b = 0; b < syms.size(); ++b) {
             const int64_t v = matrix[(size_t)syms[a] * dim + syms[b]];
             if (v < -32768 || v > 32767) { err = "score matrix entry outside int16"; return false; }
             out.tbl[a * n + b] = (int16_t)v;
         }
+        for (size_t x = 0; x < ext_nz.size(); ++x) {
+            const size_t e = (size_t)syms[a] * dim + ext_nz[x];
+            const int64_t v = e < (size_t)dim * dim ? matrix[e] : 0;
+            if (v < -32768 || v > 32767) { err = "score matrix entry outside int16"; return false; }
+            out.tbl[a * n + (size_t)(first_ext + (ext_zero ? 1 : 0)) + x] = (int16_t)v;
+        }
+    }
     bool nib = true;
     for (int16_t v : out.tbl) if (v < -8 || v > 7) nib = false;
     out.pk.clear();

@@ -402,7 +402,7 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
         for (int k = lane; k < LiLoad; k += 64) {               // reference is staged, remembered with it (ref_bad)
             const unsigned char ch = rf.seq[k];
             W.sRef[k] = ch;
-            if (sCodeOf[ch] == C2_INVALID_CODE) bad = 1;
+            if ((int)sCodeOf[ch] >= A.first_ext_code) bad = 1;      // ord >= matrix dimension (codes >= first_ext_code are read-only symbols)
         }
         ref_bad = __ballot(bad) ? 1 : 0;
         for (int k = lane; k < LiLoad + 2; k += 64) W.sIncP[k] = rf.inc_prefix[k];
@@ -438,6 +438,14 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
     // packed = every read symbol has a code < 8 and every score fits a signed nibble: the score row of a reference
     // base is then one register and a lookup is one v_bfe_i32 (no LDS in the inner loop).
     packed = (A.score_pk != nullptr) && (__ballot(read_code_max >= 8) == 0ull);
+    if (__ballot(read_code_max >= A.first_ext_code && read_code_max != (int)C2_INVALID_CODE)) {
+        // a read character beyond the matrix dimension: the reference reads the flat element ci * dim + cj (pyx:212, bounds
+        // checking off), which exists iff the LARGEST reference character keeps it inside the buffer (rare path: one more pass)
+        const int lim = A.mat_dim * A.mat_dim - A.refs[pf.ref_id].max_char * A.mat_dim;
+        bool oob = false;
+        for (int k = lane; k < LjLoad; k += 64) if ((int)W.sRead[k] >= lim) oob = true;
+        if (__ballot(oob)) status |= C2_STATUS_OOB_CHAR;
+    }
     return status;
 }
 

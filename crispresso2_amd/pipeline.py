@@ -6,12 +6,14 @@ Python object per read.
     strand plan per (read, reference)  the seed test of get_new_variant_object                  :656-687
     alignments                         one all-references batch on the device (+ one small batch for the pairs whose
                                        seeds are inconclusive: those are aligned on both strands, :675-687)
-    best reference / ambiguity         the reference's float comparisons on scores formed from (matches, length)  :689-707, :779-785
+    best reference / ambiguity         c2_select_best_kernel on the device: the reference's score comparisons as integers (1000 x the
+                                       rounded score), strand choice, ambiguity, aln_stats                        :683, :689-707, :779-785
     reverse-complement merge           :3970-3975
     count vectors                      c2_count_vectors_kernel with the read multiplicities as weights  :3996-4115
     aln_stats                          :1974-1979 from the 32-byte records
 
-Only 32 bytes per alignment come back to the host; the aligned strings stay in HBM for the count kernel.  The per-read
+Per read 17 bytes come back to the host (two 64-bit masks and a flag byte); records and aligned strings stay in HBM for the
+count kernel (QuantResult.alleles() fetches the rows it prints).  The per-read
 dict path (variants.get_new_variant_objects) remains for callers that need the reference's per-read payloads.
 """
 import numpy as np
@@ -79,6 +81,9 @@ class QuantResult:
         in2 = use2[ji, jr]
         rows1 = torch.from_numpy(ji[~in2] * k + jr[~in2]).to(S["a1"].device)
         rec = np.empty(len(jobs), dtype=_native.REC_DTYPE)
+
+        def records_of(r_dev, rows):
+            return r_dev.index_select(0, rows).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
         seqs = [None] * len(jobs)
         refs_ = [None] * len(jobs)
 
@@ -90,11 +95,12 @@ class QuantResult:
                 rec[j] = records[q]
         w1 = np.nonzero(~in2)[0]
         if len(w1):
-            pull(S["a1"], S["f1"], rows1, w1, S["rec1"].reshape(-1)[(ji[~in2] * k + jr[~in2])])
+            pull(S["a1"], S["f1"], rows1, w1, records_of(S["r1"], rows1))
         w2 = np.nonzero(in2)[0]
         if len(w2):
             sl = slot2[ji[in2], jr[in2]]
-            pull(S["a2"], S["f2"], torch.from_numpy(sl).to(S["a1"].device), w2, S["rec2"][sl])
+            rows2 = torch.from_numpy(sl).to(S["a1"].device)
+            pull(S["a2"], S["f2"], rows2, w2, records_of(S["r2"], rows2))
         n_total = self.stats["N_TOTAL"]
         out = []
         for j, (i, r, label, counted) in enumerate(jobs):
@@ -112,6 +118,66 @@ class QuantResult:
             out.append((seqs[j], refs_[j], label, 'MODIFIED' if modified else 'UNMODIFIED', dn, inn, sn, reads, reads / n_total * 100))
         out.sort(key=lambda t: (-t[7], t[0], t[1]))
         return out
+
+
+FORCE_HOST_SELECTION = False     # tests: run the host restatement of the selection instead of c2_select_best_kernel
+
+
+def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
+    """Strand / best-reference choice and aln_stats from the records on the host, with the reference's float comparisons on
+    scores formed by its own expression -- the route for more than 64 amplicons in one all-references batch or alignments
+    of 8000 columns and more (what c2_select_best_kernel's masks / integer scores do not cover).  -> member, use2, aligned"""
+    rec1 = r1.cpu().numpy().view(_native.REC_DTYPE).reshape(n, k)
+    rec2 = r2.cpu().numpy().view(_native.REC_DTYPE).reshape(-1) if n2 else None
+    for rec in (rec1.reshape(-1), rec2 if rec2 is not None else rec1.reshape(-1)[:0]):
+        bad = rec["status"] != 0
+        if bad.any():
+            st = int(rec["status"][np.nonzero(bad)[0][0]])
+            if st & _native.STATUS_RC_CHAR:
+                raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
+            raise Exception('global_align: undefined alignment (status %d)' % st)
+    score = score_from_counts(rec1["matches"].reshape(-1), rec1["aln_len"].reshape(-1)).reshape(n, k)
+    use2 = np.zeros((n, k), dtype=bool)
+    if n2:
+        s2 = score_from_counts(rec2["matches"], rec2["aln_len"])
+        better = s2 > score[bi, br]                              # strict: ties keep the forward alignment
+        use2[bi[better], br[better]] = True
+        score[bi[better], br[better]] = s2[better]
+    best = np.full(n, -1.0)
+    member = np.zeros((n, k), dtype=bool)
+    for r in range(k):
+        s_r = score[:, r]
+        c1 = (s_r > best) & (s_r > min_scores[r])
+        best = np.where(c1, s_r, best)
+        member[c1, :] = False
+        member[c1, r] = True
+        member[~c1 & (s_r == best), r] = True
+    aligned = best > 0
+    member[~aligned, :] = False
+    stats['N_COMPUTED_ALN'] = int(aligned.sum())
+    stats['N_COMPUTED_NOTALN'] = int(n - aligned.sum())
+    stats['N_CACHED_ALN'] = int((raw[aligned] - 1).sum())
+    stats['N_CACHED_NOTALN'] = int((raw[~aligned] - 1).sum())
+    # aln_stats use the payload of the LAST best match (new_variant['best_match_name'], :764) and the raw multiplicity
+    last_best = np.where(aligned, k - 1 - np.argmax(member[:, ::-1], axis=1), 0)
+    ii = np.nonzero(aligned)[0]
+
+    def field(name):
+        v1 = rec1[name][ii, last_best[ii]].astype(np.int64)
+        if n2:
+            u = use2[ii, last_best[ii]]
+            v1[u] = rec2[name][slot2[ii[u], last_best[ii[u]]]].astype(np.int64)
+        return v1
+    c_raw = raw[ii]
+    sub_all, sub_win = field("all_substitutions"), field("substitution_n")
+    total_mods = field("all_insertion_events") + field("all_deletion_bases") + sub_all
+    in_win = sub_win + field("deletion_n") + field("insertion_n")
+    stats['N_GLOBAL_SUBS'] = int((sub_all * c_raw).sum())
+    stats['N_SUBS_OUTSIDE_WINDOW'] = int(((sub_all - sub_win) * c_raw).sum())
+    stats['N_MODS_IN_WINDOW'] = int((in_win * c_raw).sum())
+    stats['N_MODS_OUTSIDE_WINDOW'] = int(((total_mods - in_win) * c_raw).sum())
+    stats['N_READS_IRREGULAR_ENDS'] = int((field("irregular_ends") * c_raw).sum())
+    return member, use2, aligned
 
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
@@ -149,6 +215,9 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     aligner = BatchAligner([refs[name]['sequence'] for name in ref_names], [refs[name]['gap_incentive'] for name in ref_names],
                            [refs[name]['include_idxs'] for name in ref_names], aln_matrix,
                            args.needleman_wunsch_gap_open, args.needleman_wunsch_gap_extend, ctx=ctx)
+    if reduce_across_ranks:
+        # every rank must build the SAME tensor (the histogram length depends on the longest read): agree on it first
+        max_lj = C.all_reduce_max(max_lj, dev)
     layout = C.CountLayout(k, max(L), max_lj)
     d_counts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
     flags = ((C.FLAG_IGNORE_SUBSTITUTIONS if args.ignore_substitutions else 0) | (C.FLAG_IGNORE_INSERTIONS if args.ignore_insertions else 0) |
@@ -156,7 +225,24 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     stats = dict(N_TOT_READS=int(np.asarray(read_counts, dtype=np.int64).sum()), N_CACHED_ALN=0, N_CACHED_NOTALN=0, N_COMPUTED_ALN=0,
                  N_COMPUTED_NOTALN=0, N_GLOBAL_SUBS=0, N_SUBS_OUTSIDE_WINDOW=0, N_MODS_IN_WINDOW=0, N_MODS_OUTSIDE_WINDOW=0,
                  N_READS_IRREGULAR_ENDS=0, N_TOTAL=0, N_AMBIGUOUS=0)
+    want_view = k > 1 and bool(getattr(args, 'expected_hdr_amplicon_seq', '') or getattr(args, 'prime_editing_pegRNA_extension_seq', ''))
+    STAT_KEYS = sorted(stats)
+
+    def reduce_stats():
+        """the integer statistics summed over the ranks (each rank counted its own shard)"""
+        if reduce_across_ranks:
+            v = C.all_reduce(torch.tensor([stats[q] for q in STAT_KEYS], dtype=torch.int64, device=dev)).cpu().numpy()
+            for q, x in zip(STAT_KEYS, v):
+                stats[q] = int(x)
     if n == 0:
+        # an empty shard still takes part in every collective of the other ranks (same tensors, zeros)
+        if reduce_across_ranks:
+            C.all_reduce(d_counts)
+            if want_view:
+                C.all_reduce(torch.zeros((k + (1 if scaffold_rule else 0),) + tuple(layout.shape()), dtype=torch.int64, device=dev))
+            if scaffold_rule:
+                C.all_reduce(torch.zeros(layout.shape(), dtype=torch.int64, device=dev))
+            reduce_stats()
         return QuantResult({name: layout.unpack(d_counts.cpu().numpy(), r, L[r]) for r, name in enumerate(ref_names)}, stats, layout, d_counts)
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
     if not arena.flags.writeable:
@@ -176,13 +262,13 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     r1 = torch.empty((n1, 32), dtype=torch.uint8, device=dev)
     aligner.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), a1.data_ptr(), f1.data_ptr(), r1.data_ptr(), stride, max_lj,
                          d_strands=d_str1.data_ptr(), all_refs=True, stream=stream)
-    rec1 = r1.cpu().numpy().view(_native.REC_DTYPE).reshape(n, k)
-    lap("h2d_align_records_d2h")
+    lap("h2d_align")
 
     # ---- batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments
     bi, br = np.nonzero(plan == 2)
     n2 = len(bi)
-    rec2 = None
+    r2 = a2 = f2 = None
+    stride2 = stride
     if n2:
         off2 = np.zeros(n2 + 1, dtype=np.uint64)
         off2[1:] = np.cumsum(lens[bi])
@@ -200,62 +286,45 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         r2 = torch.empty((n2, 32), dtype=torch.uint8, device=dev)
         aligner.align_device(n2, d_reads2.data_ptr(), d_off2.data_ptr(), a2.data_ptr(), f2.data_ptr(), r2.data_ptr(), stride2, max_lj2,
                              d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=stream)
-        rec2 = r2.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
     lap("both_strand_pairs")
-    for rec in (rec1.reshape(-1), rec2 if rec2 is not None else rec1.reshape(-1)[:0]):
-        bad = rec["status"] != 0
-        if bad.any():
-            st = int(rec["status"][np.nonzero(bad)[0][0]])
-            if st & _native.STATUS_RC_CHAR:
-                raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
-            raise Exception('global_align: undefined alignment (status %d)' % st)
-
-    # ---- strand and reference choice, with the reference's float comparisons (:683, :697-707)
-    score = score_from_counts(rec1["matches"].reshape(-1), rec1["aln_len"].reshape(-1)).reshape(n, k)
-    use2 = np.zeros((n, k), dtype=bool)
+    # ---- strand and reference choice (:683, :697-707), ambiguity, aln_stats: on the device.  Host selection (the same
+    # comparisons on Python floats) remains for what the kernel's 64-bit masks / exact integer scores do not cover.
+    raw = np.asarray(read_counts, dtype=np.int64)
+    if raw.size and raw.max() > 0x7FFFFFFF:
+        raise OverflowError("a read multiplicity exceeds 2^31 - 1")
+    min_scores = [refs[name]['min_aln_score'] for name in ref_names]
     slot2 = np.full((n, k), -1, dtype=np.int64)
     if n2:
-        s2 = score_from_counts(rec2["matches"], rec2["aln_len"])
-        better = s2 > score[bi, br]                              # strict: ties keep the forward alignment
-        use2[bi[better], br[better]] = True
         slot2[bi, br] = np.arange(n2)
-        score[bi[better], br[better]] = s2[better]
-    best = np.full(n, -1.0)
-    member = np.zeros((n, k), dtype=bool)
-    for r, name in enumerate(ref_names):
-        s_r = score[:, r]
-        c1 = (s_r > best) & (s_r > refs[name]['min_aln_score'])
-        best = np.where(c1, s_r, best)
-        member[c1, :] = False
-        member[c1, r] = True
-        member[~c1 & (s_r == best), r] = True
-    aligned = best > 0
+    mode = C.select_mode(args)
+    on_device = k <= 64 and max(stride, stride2) <= C.SELECT_MAX_ALN_LEN and not FORCE_HOST_SELECTION
+    d_slot2 = torch.from_numpy(slot2.astype(np.int32).reshape(-1)).to(dev) if n2 else None
+    if on_device:
+        d_member = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_use2 = torch.zeros(n, dtype=torch.int64, device=dev)
+        d_flags = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_stats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
+        d_raw = torch.from_numpy(raw.astype(np.uint32).view(np.int32)).to(dev)
+        min_mscore = C.min_mscore_table(min_scores)
+        C.select_best_device(ctx, n, k, r1.data_ptr(), min_mscore, mode, max(stride, stride2),
+                             d_records2=r2.data_ptr() if n2 else None, d_slot2=d_slot2.data_ptr() if n2 else None,
+                             d_raw_counts=d_raw.data_ptr(), d_member=d_member.data_ptr(), d_use2=d_use2.data_ptr(),
+                             d_flags=d_flags.data_ptr(), d_stats=d_stats.data_ptr(), stream=stream)
+        st = dict(zip(C.SELECT_STATS, d_stats.cpu().numpy().tolist()))
+        if st["n_bad_status"]:
+            if int(st["a_bad_status"]) & _native.STATUS_RC_CHAR:
+                raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
+            raise Exception('global_align: undefined alignment (status %d)' % int(st["a_bad_status"]))
+        bits = np.arange(k, dtype=np.uint64)[None, :]
+        member = ((d_member.cpu().numpy().view(np.uint64)[:, None] >> bits) & np.uint64(1)).astype(bool)
+        use2 = ((d_use2.cpu().numpy().view(np.uint64)[:, None] >> bits) & np.uint64(1)).astype(bool)
+        aligned = (d_flags.cpu().numpy() & 1) != 0
+        for q in ('N_COMPUTED_ALN', 'N_COMPUTED_NOTALN', 'N_CACHED_ALN', 'N_CACHED_NOTALN', 'N_GLOBAL_SUBS', 'N_SUBS_OUTSIDE_WINDOW',
+                  'N_MODS_IN_WINDOW', 'N_MODS_OUTSIDE_WINDOW', 'N_READS_IRREGULAR_ENDS'):
+            stats[q] = int(st[q])
+    else:
+        member, use2, aligned = _select_on_host(r1, r2, n, k, n2, bi if n2 else None, br if n2 else None, slot2, min_scores, raw, stats)
     n_best = member.sum(axis=1)
-    raw = np.asarray(read_counts, dtype=np.int64)
-    stats['N_COMPUTED_ALN'] = int(aligned.sum())
-    stats['N_COMPUTED_NOTALN'] = int(n - aligned.sum())
-    stats['N_CACHED_ALN'] = int((raw[aligned] - 1).sum())
-    stats['N_CACHED_NOTALN'] = int((raw[~aligned] - 1).sum())
-    # aln_stats use the payload of the LAST best match (new_variant['best_match_name'], :764) and the raw multiplicity
-    last_best = np.where(aligned, k - 1 - np.argmax(member[:, ::-1], axis=1), 0)
-    ii = np.nonzero(aligned)[0]
-
-    def field(name):
-        v1 = rec1[name][ii, last_best[ii]].astype(np.int64)
-        if n2:
-            u = use2[ii, last_best[ii]]
-            v1[u] = rec2[name][slot2[ii[u], last_best[ii[u]]]].astype(np.int64)
-        return v1
-    c_raw = raw[ii]
-    sub_all, sub_win = field("all_substitutions"), field("substitution_n")
-    total_mods = field("all_insertion_events") + field("all_deletion_bases") + sub_all
-    in_win = sub_win + field("deletion_n") + field("insertion_n")
-    stats['N_GLOBAL_SUBS'] = int((sub_all * c_raw).sum())
-    stats['N_SUBS_OUTSIDE_WINDOW'] = int(((sub_all - sub_win) * c_raw).sum())
-    stats['N_MODS_IN_WINDOW'] = int((in_win * c_raw).sum())
-    stats['N_MODS_OUTSIDE_WINDOW'] = int(((total_mods - in_win) * c_raw).sum())
-    stats['N_READS_IRREGULAR_ENDS'] = int((field("irregular_ends") * c_raw).sum())
-
     lap("selection_and_stats")
     # ---- aggregation weights (:3964-4000): rc merge, ambiguous reads, which references a read counts for
     cnt = np.ascontiguousarray(raw.copy())
@@ -289,12 +358,12 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
                     pairs[j] = (ah[q, :int(lens_[q])].tobytes().decode(), fh[q, :int(lens_[q])].tobytes().decode())
             w_1 = np.nonzero(~in2)[0]
             if len(w_1):
-                t_ = cand[w_1] * k + pe
-                pull(a1, f1, torch.from_numpy(t_).to(dev), w_1, rec1.reshape(-1)["aln_len"][t_])
+                t_ = torch.from_numpy(cand[w_1] * k + pe).to(dev)
+                pull(a1, f1, t_, w_1, r1.index_select(0, t_).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)["aln_len"])
             w_2 = np.nonzero(in2)[0]
             if len(w_2):
-                sl = slot2[cand[w_2], pe]
-                pull(a2, f2, torch.from_numpy(sl).to(dev), w_2, rec2["aln_len"][sl])
+                sl = torch.from_numpy(slot2[cand[w_2], pe]).to(dev)
+                pull(a2, f2, sl, w_2, r2.index_select(0, sl).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)["aln_len"])
             for j, (s_read, s_ref) in enumerate(pairs):
                 seen, col = -1, -1
                 for c_, ch in enumerate(s_ref):                    # ref_positions.index(idx0): the column of reference base idx0
@@ -310,16 +379,29 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         counted[scaffold_hit, :] = False
         if not args.assign_ambiguous_alignments_to_first_reference and not args.expand_ambiguous_alignments:
             stats['N_AMBIGUOUS'] = int(cnt[ambiguous & ~scaffold_hit].sum())
-    if cnt.max() > 0xFFFFFFFF:
-        raise OverflowError("a read multiplicity exceeds 2^32 - 1")
+    if cnt.max() > 0x7FFFFFFF:
+        raise OverflowError("a read multiplicity exceeds 2^31 - 1")          # (the count kernel's weights are int32)
     lap("rc_merge_weights")
-    w1 = np.where(counted & ~use2, cnt[:, None], 0).astype(np.uint32).reshape(-1)
-    d_w1 = torch.from_numpy(w1.view(np.int32)).to(dev)
+    d_w2 = None
+    if on_device:
+        # the weight of every alignment in the count pass: the kernel again, now with the merged multiplicities (a read the
+        # scaffold rule took away counts for no amplicon here)
+        d_cnt = torch.from_numpy(np.where(scaffold_hit, 0, cnt).astype(np.uint32).view(np.int32)).to(dev)
+        d_w1 = torch.zeros(n1, dtype=torch.int32, device=dev)
+        if n2:
+            d_w2 = torch.zeros(n2, dtype=torch.int32, device=dev)
+        C.select_best_device(ctx, n, k, r1.data_ptr(), min_mscore, mode, max(stride, stride2),
+                             d_records2=r2.data_ptr() if n2 else None, d_slot2=d_slot2.data_ptr() if n2 else None,
+                             d_counts=d_cnt.data_ptr(), d_weights=d_w1.data_ptr(), d_weights2=d_w2.data_ptr() if n2 else None, stream=stream)
+    else:
+        w1 = np.where(counted & ~use2, cnt[:, None], 0).astype(np.uint32).reshape(-1)
+        d_w1 = torch.from_numpy(w1.view(np.int32)).to(dev)
+        if n2:
+            w2 = np.where(counted[bi, br] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
+            d_w2 = torch.from_numpy(w2.view(np.int32)).to(dev)
     C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_counts.data_ptr(),
                         d_weights=d_w1.data_ptr(), flags=flags, stream=stream)
     if n2:
-        w2 = np.where(counted[bi, br] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
-        d_w2 = torch.from_numpy(w2.view(np.int32)).to(dev)
         C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_counts.data_ptr(),
                             d_weights=d_w2.data_ptr(), flags=flags, stream=stream)
     d_scaffold = None
@@ -343,7 +425,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     # with the multiplicities of the reads counted for r; row 0 of that launch's tensor is amplicon r's view.  No ignore_* /
     # discard flags: the reference's loop has none.
     d_view = None
-    if k > 1 and (getattr(args, 'expected_hdr_amplicon_seq', '') or getattr(args, 'prime_editing_pegRNA_extension_seq', '')):
+    if want_view:
         d_view = torch.zeros((k + (1 if scaffold_rule else 0),) + tuple(layout.shape()), dtype=torch.int64, device=dev)
         for r in range(1, k + (1 if scaffold_rule else 0)):
             for_r = counted[:, r] if r < k else scaffold_hit          # row k: the reads counted for 'Scaffold-incorporated'
@@ -365,6 +447,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
             C.all_reduce(d_view)
         if d_scaffold is not None:
             C.all_reduce(d_scaffold)
+        reduce_stats()
     torch.cuda.synchronize(dev)
     host = d_counts.cpu().numpy()
     lap("count_kernels")
@@ -387,7 +470,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
                                                + v["all_substitution_count_vectors"])
     state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=slot2,
                  scaffold_hit=scaffold_hit, scaffold_ref=pe,
-                 a1=a1, f1=f1, rec1=rec1, a2=a2 if n2 else None, f2=f2 if n2 else None, rec2=rec2)
+                 a1=a1, f1=f1, r1=r1, a2=a2, f2=f2, r2=r2)
     return QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
 
 

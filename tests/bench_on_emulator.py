@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 import emu_driver as E
-from pipeline_on_emulator import EmulatedAligner, _view, _accumulate
+from pipeline_on_emulator import EmulatedAligner, _view, _accumulate, _select
 
 
 class _Ctx:
@@ -54,16 +54,6 @@ class _Aligner(EmulatedAligner):
         a[:, :w] = o1[:, :w]
         f[:, :w] = o2[:, :w]
         _view(d_records, 32 * ntasks)[:] = rec.view(np.uint8).reshape(-1)
-
-
-def _select(ctx, n_reads, n_refs, d_records, min_mscore, mode, max_aln_len, d_records2=None, d_slot2=None, d_raw_counts=None,
-            d_counts=None, d_member=None, d_use2=None, d_flags=None, d_weights=None, d_weights2=None, d_stats=None, stream=None):
-    mm = np.ascontiguousarray(min_mscore, dtype=np.uint32)
-    P = lambda x: ctypes.c_void_p(x or 0)
-    rc = E.lib().emu_select_best(ctypes.c_uint64(n_reads), int(n_refs), P(d_records), P(d_records2), P(d_slot2),
-                                 mm.ctypes.data_as(ctypes.c_void_p), P(d_raw_counts), P(d_counts), int(mode), P(d_member), P(d_use2),
-                                 P(d_flags), P(d_weights), P(d_weights2), P(d_stats))
-    assert rc == 0
 
 
 class _Event:

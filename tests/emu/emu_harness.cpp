@@ -5,6 +5,8 @@
 #include "emu_runtime.h"
 #include <vector>
 #include <string>
+#include <algorithm>
+#include <string.h>
 #include "../../crispresso2_amd/csrc/c2_host_prep.h"
 
 alignas(16) unsigned char c2_smem[163840];
@@ -38,7 +40,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         int64_t gm = 0;
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)g32[r][k]);
         refs[r].gap_incentive_max = (int32_t)gm;
-        refs[r].gap_incentive_last_pos = g32[r][lens[r]] > 0 ? 1 : 0; refs[r].reserved = 0;
+        refs[r].gap_incentive_last_pos = g32[r][lens[r]] > 0 ? 1 : 0;
+        { int mc = 0; for (int k = 0; k < lens[r]; ++k) mc = std::max(mc, (int)(unsigned char)seqs[r][k]); refs[r].max_char = mc; }
         max_li = std::max(max_li, lens[r]);
     }
     int max_lj = 1;
@@ -74,6 +77,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
     std::vector<uint32_t> plane;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0;
+    A.mat_dim = sc.mat_dim; A.first_ext_code = sc.first_ext_code;
     A.diag_base = nullptr;
     if (!no_packed && n_refs > 0 && !drows[0].empty()) {
         // the references' row tables must sit in one buffer (the kernels index it relative to diag_base)
@@ -204,7 +208,7 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     int lmax = 1;
     for (int r = 0; r < n_refs; ++r) {
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
-        refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].diag_rows = nullptr; refs[r].len = lens[r]; refs[r].gap_incentive_max = 0; refs[r].gap_incentive_last_pos = 0; refs[r].reserved = 0;
+        refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = nullptr; refs[r].inc_prefix = incp[r].data(); refs[r].diag_rows = nullptr; refs[r].len = lens[r]; refs[r].gap_incentive_max = 0; refs[r].gap_incentive_last_pos = 0; refs[r].max_char = 0;
         lmax = std::max(lmax, lens[r]);
     }
     unsigned long long wc = 0;
@@ -222,6 +226,78 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
         A.order = order.data();
     }
     emu::launch(grid ? grid : 2, [&] { c2_count_vectors_kernel(A); }, 64 * C2_CNT_WAVES);
+    return 0;
+}
+
+// The per-call C ABI on the emulator, argument for argument (the context handle is ignored): what
+// crispresso2_amd.CRISPResso2Align.global_align / CRISPRessoCOREResources.find_indels_substitutions[_legacy] call.
+// Host-side marshalling follows c2_api.hip (c2_global_align, c2_find_indels_substitutions).
+int emu_c2_global_align(void*, const char* read, int32_t Lj, const char* ref, int32_t Li, const int64_t* matrix, int32_t mat_dim,
+                        const int64_t* gap_incentive, int32_t n_gap_incentive, int32_t gap_open, int32_t gap_extend,
+                        char* out_read_aln, char* out_ref_aln, int32_t* out_len, int32_t* out_matches, int32_t* out_status)
+{
+    *out_len = 0; *out_matches = 0; *out_status = 0;
+    if (n_gap_incentive != Li + 1) { *out_status = -1; return 0; }
+    if (Li <= 0 || Lj <= 0) { *out_status = C2_STATUS_EMPTY; return 0; }
+    const uint64_t offs[2] = {0, (uint64_t)Lj};
+    const char* seqs[1] = {ref};
+    const int32_t lens[1] = {Li};
+    const int64_t* gis[1] = {gap_incentive};
+    const int32_t* incs[1] = {nullptr};
+    const int32_t ninc[1] = {0};
+    const uint32_t stride = (uint32_t)((Li + Lj + 15) / 16 * 16);
+    std::vector<uint8_t> o1(stride), o2(stride);
+    c2_aln_record rec;
+    memset(&rec, 0, sizeof rec);
+    int nfb = 0;
+    const int rc = emu_align_batch(1, (const uint8_t*)read, offs, nullptr, nullptr, 0, 1, seqs, lens, gis, incs, ninc, matrix, mat_dim,
+                                   gap_open, gap_extend, o1.data(), o2.data(), stride, &rec, 0, 1, 0, -7, &nfb);
+    if (rc == -5) return C2_E_TOO_LARGE;
+    if (rc) return C2_E_INVALID;
+    *out_status = rec.status;
+    if (rec.status == 0) {
+        memcpy(out_read_aln, o1.data(), rec.aln_len);
+        memcpy(out_ref_aln, o2.data(), rec.aln_len);
+        *out_len = rec.aln_len; *out_matches = rec.matches;
+    }
+    return 0;
+}
+
+int emu_c2_find_indels_substitutions(void*, const char* read_aln, const char* ref_aln, int32_t n, const int32_t* include_idx,
+                                     int32_t n_include, int32_t legacy, int32_t* out, int32_t out_cap, int32_t* out_index,
+                                     int64_t* out_counts, int32_t* out_needed)
+{
+    std::vector<int32_t> inc(include_idx, include_idx + (n_include > 0 ? n_include : 0));
+    std::sort(inc.begin(), inc.end());
+    inc.erase(std::unique(inc.begin(), inc.end()), inc.end());
+    int cap = std::max(2 * n + 8, 64);
+    std::vector<int32_t> lens(C2_LIST_COUNT), lists;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        lists.assign((size_t)C2_LIST_COUNT * cap, 0);
+        emu_classify_lists((const uint8_t*)read_aln, (const uint8_t*)ref_aln, n, inc.data(), (int)inc.size(), legacy, cap, lists.data(), lens.data(), out_counts);
+        const int need = *std::max_element(lens.begin(), lens.end());
+        if (need <= cap) break;
+        cap = need + 8;
+        if (attempt == 2) return C2_E_DEVICE;
+    }
+    int64_t total = 0;
+    for (int k = 0; k < C2_LIST_COUNT; ++k) total += lens[k];
+    if (out_needed) *out_needed = (int32_t)total;
+    if (total > out_cap) return C2_E_OVERFLOW;
+    int32_t pos = 0;
+    for (int k = 0; k < C2_LIST_COUNT; ++k) {
+        out_index[2 * k] = pos; out_index[2 * k + 1] = lens[k];
+        if (lens[k]) memcpy(out + pos, lists.data() + (size_t)k * cap, (size_t)lens[k] * 4);
+        pos += lens[k];
+    }
+    return 0;
+}
+
+int emu_c2_calculate_homology(void*, const char* a, const char* b, int32_t n, double* out)
+{
+    float f = 0;
+    emu::launch(1, [&] { c2_homology_kernel((const uint8_t*)a, (const uint8_t*)b, n, &f); });
+    *out = (double)f;
     return 0;
 }
 

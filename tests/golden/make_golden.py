@@ -332,7 +332,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv and "--variant-scaffold" not in sys.argv and "--single-runs" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv and "--variant-scaffold" not in sys.argv and "--single-runs" not in sys.argv and "--core-calls" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -1298,3 +1298,84 @@ if __name__ == "__main__" and "--paired-fastq" in sys.argv:
     with gzip.open(os.path.join(HERE, "paired_fastq.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("paired_fastq.json.gz written:", [(c["label"], len(c["tsv"]), len(c["second_pass"]), c["result"]["aln_stats"]) for c in d["cases"]])
+
+
+# ---------------------------------------------------------------- 12. every call the reference's main() makes into its two Cython modules
+def core_calls():
+    """The reference's main() on its two end-to-end tests (tests/Makefile:20, :23; --suppress_plots --suppress_report) with its OWN
+    Cython modules (oracle/_ref), every call into them recorded with its arguments and the value it returned -- the per-call
+    contract of the drop-in, as the reference exercises it: window computation and flexiguide calls (the default flexiguide
+    sequence is the string "None": a read with characters beyond the score matrix), the hot loop of process_fastq, the HDR
+    remap.  Identical calls are kept once.  tests/test_gpu_parity.py replays them through the shim on the GPU (the reference
+    itself cannot travel to the GPU box); tests/test_dropin_reference_core.py runs the same two commands over the shim here."""
+    core = load_reference_core()
+    seen, calls = set(), []
+
+    def rec_align(fn):
+        def wrapped(seqj, seqi, matrix=None, gap_incentive=None, gap_open=-1, gap_extend=-1):
+            out = fn(seqj, seqi, matrix=matrix, gap_incentive=gap_incentive, gap_open=gap_open, gap_extend=gap_extend)
+            mname = ("EDNAFULL" if matrix.shape == EDNA.shape and (matrix == EDNA).all() else
+                     "BLOSUM62" if matrix.shape == BLOSUM.shape and (matrix == BLOSUM).all() else None)
+            assert mname, "a matrix other than EDNAFULL / BLOSUM62"
+            key = ("a", mname, seqj, seqi, tuple(int(x) for x in np.nonzero(gap_incentive)[0]), tuple(int(x) for x in gap_incentive[np.nonzero(gap_incentive)[0]]),
+                   int(gap_open), int(gap_extend))
+            if key not in seen:
+                seen.add(key)
+                calls.append({"fn": "global_align", "seqj": seqj, "seqi": seqi, "matrix": mname,
+                              "gi_nonzero": [[int(i), int(gap_incentive[i])] for i in np.nonzero(gap_incentive)[0]], "gi_len": int(len(gap_incentive)),
+                              "gap_open": int(gap_open), "gap_extend": int(gap_extend), "out": jsonable(list(out))})
+            return out
+        return wrapped
+
+    def rec_classify(fn, name):
+        def wrapped(read_al, ref_al, include):
+            out = fn(read_al, ref_al, include)
+            inc = [int(x) for x in include]
+            key = (name, read_al, ref_al, tuple(inc))
+            if key not in seen:
+                seen.add(key)
+                calls.append({"fn": name, "read_al": read_al, "ref_al": ref_al, "include": inc, "out": payload_dict(out)})
+            return out
+        return wrapped
+    orig = (A.global_align, R.find_indels_substitutions, R.find_indels_substitutions_legacy)
+    A.global_align = rec_align(orig[0])
+    R.find_indels_substitutions = rec_classify(orig[1], "find_indels_substitutions")
+    R.find_indels_substitutions_legacy = rec_classify(orig[2], "find_indels_substitutions_legacy")
+    runs = {}
+    try:
+        with open(os.path.join(REF, "tests/Makefile")) as fh:
+            lines = [ln for ln in fh if "time CRISPResso -r1 FANC.Cas9.fastq" in ln]
+        for ln in lines:
+            argv = ln.split()[2:]
+            argv = [a for a in argv if a != "--debug"]
+            name = "CRISPResso_on_" + (argv[argv.index("-n") + 1] if "-n" in argv else "FANC.Cas9")
+            n0 = len(calls)
+            with tempfile.TemporaryDirectory() as tmp:
+                argv[argv.index("-r1") + 1] = os.path.join(REF, "tests", "FANC.Cas9.fastq")
+                saved = sys.argv
+                sys.argv = ["CRISPResso"] + argv + ["-o", tmp, "--suppress_plots", "--suppress_report"]
+                try:
+                    core.main()
+                except SystemExit as e:
+                    assert e.code in (0, None), e.code
+                finally:
+                    sys.argv = saved
+                exp = os.path.join(REF, "tests/expectedResults", name)
+                for fn in os.listdir(exp):
+                    with open(os.path.join(exp, fn)) as a, open(os.path.join(tmp, name, fn)) as b:
+                        assert a.read() == b.read(), (name, fn)
+            runs[name] = [n0, len(calls)]
+    finally:
+        A.global_align, R.find_indels_substitutions, R.find_indels_substitutions_legacy = orig
+    return {"runs": runs, "calls": calls}
+
+
+if __name__ == "__main__" and "--core-calls" in sys.argv:
+    import gzip
+    d = core_calls()
+    with gzip.open(os.path.join(HERE, "core_calls.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    kinds = {}
+    for c in d["calls"]:
+        kinds[c["fn"]] = kinds.get(c["fn"], 0) + 1
+    print("core_calls.json.gz written:", d["runs"], kinds)

@@ -126,6 +126,18 @@ def _accumulate(aligners):
     return accumulate_device
 
 
+def _select(ctx, n_reads, n_refs, d_records, min_mscore, mode, max_aln_len, d_records2=None, d_slot2=None, d_raw_counts=None,
+            d_counts=None, d_member=None, d_use2=None, d_flags=None, d_weights=None, d_weights2=None, d_stats=None, stream=None):
+    """counts.select_best_device -> c2_select_best_kernel on the emulator (same arguments)"""
+    assert n_refs <= 64 and max_aln_len < 8000
+    mm = np.ascontiguousarray(min_mscore, dtype=np.uint32)
+    P = lambda x: ctypes.c_void_p(x or 0)
+    rc = E.lib().emu_select_best(ctypes.c_uint64(n_reads), int(n_refs), P(d_records), P(d_records2), P(d_slot2),
+                                 mm.ctypes.data_as(ctypes.c_void_p), P(d_raw_counts), P(d_counts), int(mode), P(d_member), P(d_use2),
+                                 P(d_flags), P(d_weights), P(d_weights2), P(d_stats))
+    assert rc == 0
+
+
 @contextlib.contextmanager
 def emulated_device():
     """Inside the block pipeline.quantify_* run on the emulator; restored afterwards."""
@@ -140,6 +152,8 @@ def emulated_device():
     class _Stream:
         cuda_stream = 0
     saved = (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context)
+    saved_select = C.select_best_device
+    C.select_best_device = _select
     saved_variants_aligner, saved_paired_aligner = variants.BatchAligner, paired.BatchAligner
     variants.BatchAligner = paired.BatchAligner = make_aligner
     real_device = torch.device
@@ -154,3 +168,4 @@ def emulated_device():
     finally:
         torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context = saved
         variants.BatchAligner, paired.BatchAligner = saved_variants_aligner, saved_paired_aligner
+        C.select_best_device = saved_select

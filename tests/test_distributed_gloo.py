@@ -128,3 +128,59 @@ def test_two_rank_pipeline_reduce_of_counts_view_and_scaffold_tensors(tmp_path):
         same(one["per_ref"][nm], two["per_ref"][nm])
         same(one["view"][nm], two["view"][nm])
     assert one["per_ref"]["Scaffold-incorporated"]["counts_total"] >= 10
+
+
+def _ragged_worker(rank, world, port, out_dir):
+    """Shards with DIFFERENT longest reads (the unique reads sorted by length, cut unevenly) and one EMPTY shard: every rank
+    must still build the same tensors and take part in every collective, and the integer statistics come back summed."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pickle
+    from helpers import matrices
+    from pipeline_on_emulator import emulated_device
+    from test_whole_run_tables import _params_golden, _pipeline_args
+    from crispresso2_amd import distributed as D, pipeline, _native
+    D.init("gloo")
+    g, refs, names = _params_golden("pe_scaffold_run.json.gz")
+    fq = os.path.join(out_dir, "in%d.fastq" % rank)
+    with open(fq, "w") as fh:
+        fh.write(g["fastq"])
+    arena, offsets, counts, n_reads = _native.fastq_unique(fq)
+    lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+    order = np.argsort(lens, kind="stable")
+    n = len(order)
+    assert lens[order[0]] < lens[order[-1]]
+    cuts = [0, n] if world == 1 else [0, n // 3, n, n]            # rank 0: the short reads, rank 1: the rest, rank 2: nothing
+    mine = order[cuts[rank]:cuts[rank + 1]]
+    sub_off = np.zeros(len(mine) + 1, dtype=np.uint64)
+    sub_off[1:] = np.cumsum(lens[mine])
+    sub_arena = (np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in mine]) if len(mine) else np.zeros(0, dtype=np.uint8))
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    with emulated_device():
+        res = pipeline.quantify_unique(sub_arena, sub_off, counts[mine], refs, names[:2], matrices()["EDNAFULL"], _pipeline_args(a),
+                                       reduce_across_ranks=world > 1, pe_scaffold_dna_info=tuple(g["pe_scaffold_dna_info"]))
+    with open(os.path.join(out_dir, "ragged_world%d_rank%d.pkl" % (world, rank)), "wb") as fh:
+        pickle.dump({"per_ref": res.per_ref, "stats": res.stats, "shape": tuple(res.layout.shape())}, fh)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_ragged_and_empty_shards_reduce_to_the_single_process_result(tmp_path):
+    import pickle
+    sys.path.insert(0, HERE)
+    import emu_driver as E
+    E.build()
+    _ragged_worker(0, 1, 0, str(tmp_path))
+    mp.spawn(_ragged_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    one = pickle.load(open(tmp_path / "ragged_world1_rank0.pkl", "rb"))
+    for rank in range(3):
+        got = pickle.load(open(tmp_path / ("ragged_world3_rank%d.pkl" % rank), "rb"))
+        assert got["shape"] == one["shape"]                        # the layout was agreed on, whatever the shard held
+        assert got["stats"] == one["stats"], rank                  # ... and the statistics are the run's, not the shard's
+        if rank < 2:                                               # (the empty rank returns before the scaffold amplicon is added)
+            for nm in one["per_ref"]:
+                for key, v in one["per_ref"][nm].items():
+                    w = got["per_ref"][nm][key]
+                    assert np.array_equal(v, w) if isinstance(v, np.ndarray) else v == w, (rank, nm, key)

@@ -142,8 +142,14 @@ def test_per_call_error_behaviour(mats, ctx, capsys):
         CRISPResso2Align.global_align(b"ACGT", "ACGT", matrix=m, gap_incentive=np.zeros(5, dtype=int))
     with pytest.raises(ValueError):
         CRISPResso2Align.global_align("ACGT", "ACGT", matrix=m, gap_incentive=np.zeros(5, dtype=np.int32))
-    with pytest.raises(Exception):       # a character outside the matrix: undefined in the reference, refused here
-        CRISPResso2Align.global_align("ACGa", "ACGT", matrix=m, gap_incentive=np.zeros(5, dtype=int))
+    with pytest.raises(Exception):       # a reference character outside the matrix: out of bounds in the reference, refused here
+        CRISPResso2Align.global_align("ACGT", "ACGa", matrix=m, gap_incentive=np.zeros(5, dtype=int))
+    with pytest.raises(Exception):       # 'a' against 'Y' (the matrix's last row): past the end of the flat buffer
+        CRISPResso2Align.global_align("ACGa", "ACGY", matrix=m, gap_incentive=np.zeros(5, dtype=int))
+    # 'a' against A/C/G/T is an element of the buffer (pyx:212, bounds checking off): the reference's answer
+    import oracle
+    assert CRISPResso2Align.global_align("ACGa", "ACGT", matrix=m, gap_incentive=np.zeros(5, dtype=int)) == \
+        tuple(oracle.global_align("ACGa", "ACGT", m, np.zeros(5, dtype=np.int64)))
 
 
 def test_classify_lists_fuzz_vectors(ctx):

@@ -224,10 +224,18 @@ def test_emulated_kernel_all_refs_mode(mats):
 def test_emulated_kernel_status_bits(mats):
     m = mats["EDNAFULL"]
     g = np.zeros(5, dtype=np.int64)
-    res, rec = E.align_batch(["ACGa", "ACGT", "AC-T"], ["ACGT"], [g], [[1, 2]], m, -20, -2, strands=[0, 0, 1])
-    assert rec["status"][0] & 2          # 'a' is outside the 90x90 EDNAFULL matrix
+    res, rec = E.align_batch(["ACG\u00e9"[:3] + "T", "ACGT", "AC-T"], ["ACGT"], [g], [[1, 2]], m, -20, -2, strands=[0, 0, 1])
+    assert rec["status"][0] == 0
     assert rec["status"][1] == 0
     assert rec["status"][2] == 0         # '-' is legal input to reverse_complement
+    # a read character beyond the 90 x 90 matrix reads the flat element ci * 90 + cj in the reference (bounds checking off):
+    # defined while the largest reference character keeps it inside the buffer ('T': 84 * 90 + 97 < 8100), refused otherwise
+    # ('Y' = 89, the last row); a REFERENCE character beyond the matrix is always out of bounds
+    res, rec = E.align_batch(["ACGa", "ACGa", "ACGT"], ["ACGT", "ACGY", "ACGa"], [g, g, g], [[1, 2]] * 3, m, -20, -2, ref_ids=[0, 1, 2])
+    assert rec["status"][0] == 0 and res[0] == oracle.global_align("ACGa", "ACGT", m, g, -20, -2)[:2]
+    assert rec["status"][1] & 2 and rec["status"][2] & 2
+    assert oracle.global_align_raw("ACGa", "ACGY", m, g, -20, -2)[0] & oracle.ERR_OOB_CHAR
+    assert oracle.global_align_raw("ACGT", "ACGa", m, g, -20, -2)[0] & oracle.ERR_OOB_CHAR
     res, rec = E.align_batch(["ACRT"], ["ACGT"], [g], [[1, 2]], m, -20, -2, strands=[1])
     assert rec["status"][0] & 16         # 'R' -> KeyError in CRISPRessoShared.reverse_complement
     # a path that leaves the reference's defined domain: the oracle flags it, so must the kernel

@@ -446,7 +446,7 @@ def test_pipeline_on_the_emulator_both_strand_batch_feeds_counts_view_and_allele
     with emulated_device():
         res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
         S = res._state
-        assert S["rec2"] is not None and S["use2"][:, 0].sum() > 30 and (~S["use2"][:, 0]).sum() > 60
+        assert S["r2"] is not None and S["use2"][:, 0].sum() > 30 and (~S["use2"][:, 0]).sum() > 60
         res.stats["N_READS_INPUT"] = 250                              # the file fed here is the already filtered one
         out = tmp_path / "out"
         written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
