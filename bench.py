@@ -202,7 +202,7 @@ def main():
         d_counts.zero_()
         C.accumulate_device(ctx, layout, n_tasks, d_aln_read.data_ptr(), d_aln_ref.data_ptr(), stride, d_records.data_ptr(),
                             d_counts.data_ptr(), d_weights=d_weights.data_ptr() if all_refs else None,
-                            min_matches=None if all_refs else min_matches, stream=stream)
+                            min_matches=None if all_refs else min_matches, flags=C.FLAG_ALL_REFS_LAYOUT if all_refs else 0, stream=stream)
         C.all_reduce(d_counts)
         if e: e[3].record()
 

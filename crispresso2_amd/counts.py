@@ -26,6 +26,7 @@ SCALARS = ["counts_total", "counts_modified", "counts_unmodified", "counts_disca
            "alignments_counted"]
 HISTS = ["inserted_n", "deleted_n", "substituted_n", "effective_len"]
 FLAG_IGNORE_SUBSTITUTIONS, FLAG_IGNORE_INSERTIONS, FLAG_IGNORE_DELETIONS, FLAG_DISCARD_INDEL_READS = 1, 2, 4, 8
+FLAG_ALL_REFS_LAYOUT = 16        # the tasks are one all-references batch (task = read * n_refs + reference)
 assert len(VECTORS) == N_VECTORS and len(HISTS) == N_HISTS
 
 

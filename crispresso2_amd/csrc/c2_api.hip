@@ -232,7 +232,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
     bool first_marked = false;
     auto mark_first = [&]() { if (ctx->timing && !first_marked) { (void)hipEventRecord(tl.m, s); first_marked = true; } };
     int rc;
-    A.band_lanes = 0; A.reserved = getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0; A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
+    A.band_lanes = 0; A.reserved = (getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0) | (getenv("C2_DEBUG_SKIP_EPILOGUE") ? 2 : 0) | (getenv("C2_DEBUG_HALF_FILL") ? 4 : 0);   // (measurement knobs) A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
     if (g.diag || g.band_lanes > 0) {
         if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
         // d_fb: 16 header words -- [0..3] length of the fallback list each tier leaves, [4 + 2t ..] work counter of launch t --
@@ -686,7 +686,8 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     A.work_counter = (unsigned long long*)ctx->d_cnt.p;
     A.n_tasks = n_tasks; A.aln_stride = aln_stride; A.n_refs = ctx->n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
     A.order = nullptr;
-    if (ctx->n_refs > 1 && n_tasks < 0xFFFFFFFFull) {
+    if ((flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) && (ctx->n_refs <= 1 || n_tasks % (uint64_t)ctx->n_refs != 0)) A.flags = flags & ~C2_CNT_FLAG_ALL_REFS_LAYOUT;
+    if (ctx->n_refs > 1 && n_tasks < 0xFFFFFFFFull && !(A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT)) {
         // group the tasks by reference on the device (see c2_ref_histogram_kernel)
         const size_t hist_bytes = ((size_t)ctx->n_refs * 4 + 255) / 256 * 256;
         if ((rc = ensure(ctx, ctx->d_order, hist_bytes + n_tasks * sizeof(uint32_t)))) return rc;

@@ -162,6 +162,7 @@ static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {
 #define C2_CNT_FLAG_IGNORE_INSERTIONS 2
 #define C2_CNT_FLAG_IGNORE_DELETIONS 4
 #define C2_CNT_FLAG_DISCARD_INDEL_READS 8
+#define C2_CNT_FLAG_ALL_REFS_LAYOUT 16     // the tasks are an all-references batch: task = read * n_refs + reference
 
 typedef struct c2_count_args {
     const uint8_t* aln_read;      // n_tasks x aln_stride (outputs of the align kernel)

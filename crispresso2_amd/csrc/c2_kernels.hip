@@ -645,6 +645,8 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
 // boundary cell (0, 0) is M).  64 lanes read those nibbles in ceil(L/64) probes and one ballot decides; the aligned
 // strings are then the read and the reference themselves, and only substitutions can occur.  Returns false (nothing
 // written) if the path leaves the diagonal or a nibble is not stored in this plane.
+__device__ __forceinline__ void c2_emit_gapless(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int L, const int lane,
+                                                c2_aln_record& rec);
 template <class PLANE>
 __device__ __forceinline__ bool c2_try_gapless(const PLANE& P, const c2_align_args& A, const c2_wg& W, const uint64_t task, const int L,
                                                const int lane, c2_aln_record& rec)
@@ -655,6 +657,15 @@ __device__ __forceinline__ bool c2_try_gapless(const PLANE& P, const c2_align_ar
         if (i <= L) { unsigned nib = 0; if (!P.fetch(i, i, nib) || (nib & 3u)) off = true; }
     }
     if (__ballot(off)) return false;
+    c2_emit_gapless(A, W, task, L, lane, rec);
+    return true;
+}
+
+// A gap-free alignment of two sequences of equal length: the aligned strings are the read and the reference themselves, and
+// only substitutions can occur.  Strings out, counts into `rec`.
+__device__ __forceinline__ void c2_emit_gapless(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int L, const int lane,
+                                                c2_aln_record& rec)
+{
     uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
     uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
     const bool strings = !(A.reserved & 1);
@@ -675,7 +686,6 @@ __device__ __forceinline__ bool c2_try_gapless(const PLANE& P, const c2_align_ar
     rec.matches = (uint16_t)matches;
     rec.substitution_n = (uint16_t)n_win_sub;
     rec.all_substitutions = (uint16_t)n_all_sub;
-    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -994,19 +1004,32 @@ __device__ __forceinline__ void c2_diagx_fetch(const int g, const c2_diagx_lane&
 }
 
 // One group = four pairs = eight anti-diagonals = one pointer word per lane; the next group's tables are requested first.
+// c2_gapfree: the "is the alignment gap-free" predicate of c2_try_gapless, kept in registers while the pointer bits are made.
+// acc collects the two low pointer bits ("H is I", "J beats M") of every E cell a lane has finished -- for the lane that owns
+// diagonal 0 of a square alignment those are the main-diagonal cells (i, i) -- one v_and_or per group of eight anti-
+// diagonals; cap is acc at the moment the lane passes the cell (Li, Lj) (the cells a lane computes beyond that are zero-
+// padding garbage, like H).  cap == 0 in that lane <=> the traceback never leaves state M: no pointer word has to be read back.
+struct c2_gapfree { unsigned acc, cap; };
+#define C2_GAPFREE_E_LOW2 0x30303030u      // E cells sit in the odd nibbles of a word (anti-diagonals 8g, 8g+2, ...): their bits 1..0
+
 template <bool MASK, bool LASTCOL>
-__device__ __forceinline__ void c2_diagx_group(c2_diag_state& S, const int g, const c2_diagx_lane& L, const int ge, int& Hcap,
+__device__ __forceinline__ void c2_diagx_group(c2_diag_state& S, const int g, const c2_diagx_lane& L, const int ge, int& Hcap, c2_gapfree& GF,
                                                const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
                                                const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride,
                                                const bool stores = true)
 {
     RN[0] = R[4];
     c2_diagx_fetch<false>(g + 1, L, rows, lds, RN, CN);
+    GF.acc |= S.bits & C2_GAPFREE_E_LOW2;                            // the previous group's word (0 before the first group)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int k = 4 * g + q;
         c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, L.startE, L.startO, LASTCOL && (k == L.kLast));
-        if (LASTCOL && k == L.kCap) Hcap = (L.capOdd ? S.HO : S.HE) - C2_DIAG_BIAS;
+        if (LASTCOL && k == L.kCap) {
+            Hcap = (L.capOdd ? S.HO : S.HE) - C2_DIAG_BIAS;
+            // nibbles of this group so far: the low 8 (q + 1) bits of the word in the making (the O cell of this pair lies beyond the matrix)
+            GF.cap = GF.acc | (S.bits & (C2_GAPFREE_E_LOW2 & (q == 3 ? 0xffffffffu : ((1u << (8 * (q + 1))) - 1u))));
+        }
     }
     if (stores) myWords[g * wordStride] = S.bits;                    // anti-diagonals 8g .. 8g+7
 }
@@ -1014,16 +1037,16 @@ __device__ __forceinline__ void c2_diagx_group(c2_diag_state& S, const int g, co
 // Groups g .. g_stop; the tables alternate between two register sets (no copies).  `cur` tells which set holds group g's.
 template <bool MASK, bool LASTCOL>
 __device__ __forceinline__ void c2_diagx_groups(c2_diag_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const int ge,
-                                                int& Hcap, c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
+                                                int& Hcap, c2_gapfree& GF, c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
                                                 const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride,
                                                 const bool stores = true)
 {
     for (; g + 1 <= g_stop; g += 2) {
-        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, RA, CA, RB, CB, rows, lds, myWords, wordStride, stores);
-        c2_diagx_group<MASK, LASTCOL>(S, g + 1, L, ge, Hcap, RB, CB, RA, CA, rows, lds, myWords, wordStride, stores);
+        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, GF, RA, CA, RB, CB, rows, lds, myWords, wordStride, stores);
+        c2_diagx_group<MASK, LASTCOL>(S, g + 1, L, ge, Hcap, GF, RB, CB, RA, CA, rows, lds, myWords, wordStride, stores);
     }
     if (g <= g_stop) {                                               // odd count: one more group, then move its successor's tables to set A
-        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, RA, CA, RB, CB, rows, lds, myWords, wordStride, stores);
+        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, GF, RA, CA, RB, CB, rows, lds, myWords, wordStride, stores);
         ++g;
 #pragma unroll
         for (int q = 0; q < 5; ++q) RA[q] = RB[q];
@@ -1127,17 +1150,18 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
             int CA[4], CB[4];
             c2_diagx_fetch<true>(0, L, rows, c2_smem, RA, CA);
             int Hcap = C2_DIAG_NEG;
+            c2_gapfree GF; GF.acc = 0; GF.cap = 0xffffffffu;       // (this kernel reads its LDS plane instead: c2_try_gapless)
             int g = 0;
             const int gA_stop = gA < g_end ? gA : g_end;
             int geV = ge;                                          // gap_extend in a VGPR (second source of a DPP add)
             C2_KEEP_IN_VGPR(geV);
             if (gC <= gA_stop) {
-                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
             } else {
-                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
-                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
             }
-            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
+            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
             __syncthreads();
             c2_phase_mark<1>(A.phase_cycles, PH);
 
@@ -1349,6 +1373,8 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
         c2_phase_mark<0>(A.phase_cycles, PH);
 
         int Hcap = C2_DIAG_NEG;
+        c2_gapfree GF; GF.acc = 0; GF.cap = 0xffffffffu;
+        if (A.reserved & 4) g_end >>= 1;                           // (debug knob C2_DEBUG_HALF_FILL: what half of the fill costs; nothing is certified then)
         if (any_ok) {
             const int* T = sTab + slot * C2X_INTS;                 // this lane's alignment
             const int vLi = T[C2X_BAND_LI], vLj = T[C2X_BAND_LJ], vd0 = T[C2X_D0], vg0 = T[C2X_G0], vmin = T[C2X_MINSC];
@@ -1390,21 +1416,46 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             int geV = ge;                                          // gap_extend in a VGPR (second source of a DPP add)
             C2_KEEP_IN_VGPR(geV);
             if (gC <= gA_stop) {
-                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             } else {
-                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
-                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             }
-            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             C2_LANES_ACTIVE_END()
         }
         __syncthreads();                                           // (waits for the plane stores)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // drop this CU's stale L1 lines of the plane before reading it back
         c2_phase_mark<1>(A.phase_cycles, PH);
 
-        // ---- per alignment: optimality certificate (see c2_align_diag_kernel), traceback, output.  The pointer words of
-        //      alignment s + 1 are requested before alignment s is traced and written out: a load issued after those stores
-        //      would wait for them (one vmcnt for loads and stores), a load issued before them does not.
+        // ---- per alignment: optimality certificate (see c2_align_diag_kernel), then one of three ends:
+        //        gap-free   the main-diagonal lane's c2_gapfree word is 0: the strings are the read and the reference, no pointer
+        //                   word is ever read back (most reads of an amplicon run)
+        //        traced     the alignment's pointer words come back from the scratch plane into LDS, traceback, output
+        //        handed on  no certificate: the task goes to the next launch's list
+        //      First pass: the decision of every slot (wave-uniform bit masks) -- the words of the NEXT traced slot have to be
+        //      requested before the current one is written out (a load issued after those stores would wait for them: one
+        //      vmcnt for loads and stores), so the traced slots must be known before the first one is handled.
+        unsigned m_valid = 0, m_full = 0, m_gapfree = 0, m_trace = 0;
+#pragma nounroll
+        for (int s = 0; s < NA; ++s) {
+            const int tv = c2_tab_load(sTab + s * C2X_INTS, lane);
+            if (!C2_TF(tv, C2X_VALID)) continue;
+            m_valid |= 1u << s;
+            const int status = C2_TF(tv, C2X_STATUS);
+            if (status != 0) continue;
+            if (!C2_TF(tv, C2X_OK)) { m_full |= 1u << s; continue; }
+            const int Li = C2_TF(tv, C2X_LI), Lj = C2_TF(tv, C2X_LJ);
+            const int D = C2_TF(tv, C2X_D), d0 = C2_TF(tv, C2X_D0), cb = C2_TF(tv, C2X_CB);
+            const int lane_end = s * LPA + ((D - d0) >> 1);
+            const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
+            const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
+            const int U = c2_outside_band_bound(A.max_score, Li, Lj, D, dhi1, dlo1, cb, go, ge, C2_TF(tv, C2X_LASTPOS));
+            if (!(Hend > U)) { m_full |= 1u << s; continue; }
+            if (A.reserved & 2) continue;                              // (debug knob C2_DEBUG_SKIP_EPILOGUE: certified, nothing written)
+            if (Li == Lj && __builtin_amdgcn_readlane((int)GF.cap, lane_end) == 0) m_gapfree |= 1u << s;
+            else m_trace |= 1u << s;
+        }
         constexpr int STG = 16 / NA;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
         uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
         q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = uint4{0u, 0u, 0u, 0u};
@@ -1415,55 +1466,45 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             const int n16 = (g_end + 1) * (LPA / 4);
             C2_STG_LOAD(0) C2_STG_LOAD(1) C2_STG_LOAD(2) C2_STG_LOAD(3) C2_STG_LOAD(4) C2_STG_LOAD(5) C2_STG_LOAD(6) C2_STG_LOAD(7)
         };
-        request_words(0);
+        if (m_trace) request_words(__builtin_ctz(m_trace));
 #pragma nounroll
         for (int s = 0; s < NA; ++s) {
+            if (!((m_valid >> s) & 1u)) continue;
             const int* T = sTab + s * C2X_INTS;
             const int tv = c2_tab_load(T, lane);
-            if (!C2_TF(tv, C2X_VALID)) continue;
             const uint64_t task = (uint64_t)(unsigned)C2_TF(tv, C2X_TASK_LO) | ((uint64_t)(unsigned)C2_TF(tv, C2X_TASK_HI) << 32);
             const int Li = C2_TF(tv, C2X_LI), Lj = C2_TF(tv, C2X_LJ), g0 = C2_TF(tv, C2X_G0);
             int status = C2_TF(tv, C2X_STATUS);
-            const bool ok = C2_TF(tv, C2X_OK) != 0;
             c2_aln_record rec;
             c2_clear_record(rec, C2_TF(tv, C2X_RC), C2_TF(tv, C2X_REF));
-            bool need_full = (status == 0) && !ok;
-            bool requested = false;
-            if (ok) {
-                const int D = C2_TF(tv, C2X_D), d0 = C2_TF(tv, C2X_D0), cb = C2_TF(tv, C2X_CB), minsc = C2_TF(tv, C2X_MINSC);
-                const int lane_end = s * LPA + ((D - d0) >> 1);
-                const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
-                const int maxS = A.max_score;
-                const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
-                const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge, C2_TF(tv, C2X_LASTPOS));
-                if (!(Hend > U)) need_full = true;
-                if (!need_full) {
-                    const c2_wg W = wg_of(s);
-                    // the alignment's pointer words: registers (requested from HBM/L2 before the previous alignment's
-                    // output stores were issued) -> LDS; words beyond the first batch (long sequences) are fetched here
-                    {
-                        const uint4* src = (const uint4*)(gWords + s * slotWords);
-                        uint4* dst = (uint4*)sStage;
-                        const int n16 = ((((Li + Lj) >> 1) >> 2) + 1) * (LPA / 4);
-                        C2_STG_STORE(0) C2_STG_STORE(1) C2_STG_STORE(2) C2_STG_STORE(3) C2_STG_STORE(4) C2_STG_STORE(5) C2_STG_STORE(6) C2_STG_STORE(7)
-                        for (int k = 64 * STG + lane; k < n16; k += 64) dst[k] = src[k];
-                    }
-                    __syncthreads();
-                    if (s + 1 < NA) { request_words(s + 1); requested = true; }
-                    c2_diagx_plane plane;
-                    plane.words = sStage; plane.d0 = d0; plane.lpa = LPA;
-                    if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
-                        int cnt, matches;
-                        bool nf2;
-                        c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
-                        __syncthreads();
-                        c2_phase_mark<2>(A.phase_cycles, PH);
-                        if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                        else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
-                    }
+            bool need_full = (m_full >> s) & 1u;
+            if ((m_gapfree >> s) & 1u) {
+                c2_emit_gapless(A, wg_of(s), task, Li, lane, rec);
+            } else if ((m_trace >> s) & 1u) {
+                const int d0 = C2_TF(tv, C2X_D0), minsc = C2_TF(tv, C2X_MINSC);
+                const c2_wg W = wg_of(s);
+                // the alignment's pointer words: registers (requested from HBM/L2 before the previous alignment's
+                // output stores were issued) -> LDS; words beyond the first batch (long sequences) are fetched here
+                {
+                    const uint4* src = (const uint4*)(gWords + s * slotWords);
+                    uint4* dst = (uint4*)sStage;
+                    const int n16 = ((((Li + Lj) >> 1) >> 2) + 1) * (LPA / 4);
+                    C2_STG_STORE(0) C2_STG_STORE(1) C2_STG_STORE(2) C2_STG_STORE(3) C2_STG_STORE(4) C2_STG_STORE(5) C2_STG_STORE(6) C2_STG_STORE(7)
+                    for (int k = 64 * STG + lane; k < n16; k += 64) dst[k] = src[k];
                 }
+                __syncthreads();
+                const unsigned later = m_trace & ~((2u << s) - 1u);     // traced slots after this one
+                if (later) request_words(__builtin_ctz(later));
+                c2_diagx_plane plane;
+                plane.words = sStage; plane.d0 = d0; plane.lpa = LPA;
+                int cnt, matches;
+                bool nf2;
+                c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
+                __syncthreads();
+                c2_phase_mark<2>(A.phase_cycles, PH);
+                if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
+                else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
             }
-            if (!requested && s + 1 < NA) request_words(s + 1);
             if (need_full) {
                 status |= C2_STATUS_NEED_FULL;
                 if (lane == 0) { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
@@ -1786,10 +1827,12 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
 // =====================================================================================
 __host__ __device__ inline uint32_t c2_mscore(const uint32_t matches, const uint32_t T) {
     if (T == 0) return 0;
-    const uint64_t num = 100000ull * matches;
-    uint64_t q = num / T;
-    const uint64_t r = num - q * T;
-    if (2 * r > T) ++q; else if (2 * r == T) q += (q & 1ull);
+    const uint64_t num = 100000ull * matches;                        // < 2^33
+    // floor(num / T) through one double division (exact operands; the quotient may be off by one): corrected with integers
+    int64_t q = (int64_t)((double)num / (double)T);
+    int64_t r = (int64_t)num - q * (int64_t)T;
+    if (r < 0) { --q; r += T; } else if (r >= (int64_t)T) { ++q; r -= T; }
+    if (2 * r > (int64_t)T) ++q; else if (2 * r == (int64_t)T) q += (q & 1);
     return (uint32_t)q;
 }
 
@@ -2030,13 +2073,20 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
         bool sel = false;
         if (lane < K && my_pos < A.n_tasks) {
             if (A.order) my_task = (uint64_t)A.order[my_pos];            // tasks grouped by reference: few flushes per chunk
-            const unsigned* rp = (const unsigned*)(A.records + my_task);
-            d0 = rp[0]; d1 = rp[1]; d2 = rp[2]; d4 = rp[4]; d5 = rp[5]; d6 = rp[6];
+            else if (A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) {            // all-references batch (task = read * n_refs + reference): the same grouping by arithmetic
+                const uint64_t nr = A.n_tasks / (uint64_t)A.n_refs;
+                const uint64_t r = my_pos / nr;
+                my_task = (my_pos - r * nr) * (uint64_t)A.n_refs + r;
+            }
             const unsigned wq = A.weights ? A.weights[my_task] : 1u;
             v_w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
-            const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16), ref = (int)(d6 >> 16);
-            sel = ((d5 >> 24) == 0) && (v_w > 0) && (T > 0);
-            if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
+            if (v_w > 0) {                                               // (an alignment that is not counted is not even read: most of an all-references batch)
+                const unsigned* rp = (const unsigned*)(A.records + my_task);
+                d0 = rp[0]; d1 = rp[1]; d2 = rp[2]; d4 = rp[4]; d5 = rp[5]; d6 = rp[6];
+                const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16), ref = (int)(d6 >> 16);
+                sel = ((d5 >> 24) == 0) && (T > 0);
+                if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
+            }
         }
         unsigned pending = (unsigned)__ballot(sel);
         {   // chunk weight (clamped per task so the sum cannot wrap): decides flushes before anything is added

@@ -400,7 +400,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
             w2 = np.where(counted[bi, br] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
             d_w2 = torch.from_numpy(w2.view(np.int32)).to(dev)
     C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_counts.data_ptr(),
-                        d_weights=d_w1.data_ptr(), flags=flags, stream=stream)
+                        d_weights=d_w1.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=stream)
     if n2:
         C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_counts.data_ptr(),
                             d_weights=d_w2.data_ptr(), flags=flags, stream=stream)
@@ -411,7 +411,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         ws[:, pe] = np.where(scaffold_hit & ~use2[:, pe], cnt, 0)
         d_ws = torch.from_numpy(ws.reshape(-1).view(np.int32)).to(dev)
         C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_scaffold.data_ptr(),
-                            d_weights=d_ws.data_ptr(), flags=flags, stream=stream)
+                            d_weights=d_ws.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=stream)
         if n2:
             ws2 = np.where((br == pe) & scaffold_hit[bi] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
             d_ws2 = torch.from_numpy(ws2.view(np.int32)).to(dev)
@@ -433,7 +433,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
             wv[:, 0] = np.where(for_r & ~use2[:, 0], cnt, 0)
             d_wv = torch.from_numpy(wv.reshape(-1).view(np.int32)).to(dev)
             C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_view[r].data_ptr(),
-                                d_weights=d_wv.data_ptr(), flags=0, stream=stream)
+                                d_weights=d_wv.data_ptr(), flags=C.FLAG_ALL_REFS_LAYOUT, stream=stream)
             if n2:
                 wv2 = np.where((br == 0) & for_r[bi] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
                 if wv2.any():

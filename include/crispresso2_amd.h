@@ -149,6 +149,7 @@ int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, in
 #define C2_COUNT_IGNORE_INSERTIONS    2   /* --ignore_insertions */
 #define C2_COUNT_IGNORE_DELETIONS     4   /* --ignore_deletions */
 #define C2_COUNT_DISCARD_INDEL_READS  8   /* --discard_indel_reads */
+#define C2_COUNT_ALL_REFS_LAYOUT      16  /* the tasks are one all_refs batch (task = read * n_refs + reference; n_tasks a multiple of n_refs) */
 
 /* All d_* are device pointers (outputs of c2_align_classify_batch_device); d_weights: per task read multiplicity, 0 = do not
  * count this alignment, NULL = 1.  h_min_matches: HOST table n_refs x (max_t+1) of the smallest `matches` whose score

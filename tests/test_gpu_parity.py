@@ -364,11 +364,21 @@ def test_status_bits(mats, ctx):
     import oracle
     m = mats["EDNAFULL"]
     al = BatchAligner(["ACGT"], [np.zeros(5, dtype=np.int64)], [[1, 2]], m, -20, -2, ctx=ctx)
-    res = al.align(["ACGa", "ACGT", "", "ACRT"], strands=[0, 0, 0, 1])
-    assert res.records["status"][0] & 2
+    # reads b"ACG\x85", "ACGT", "" and "ACRT" (the last one reverse-complemented) as a packed arena
+    res = al.align((np.frombuffer(b"ACG\x85ACGTACRT", dtype=np.uint8).copy(), np.array([0, 4, 8, 8, 12], dtype=np.uint64)), strands=[0, 0, 0, 1])
+    assert res.records["status"][0] & 2          # a byte >= 128 indexes the matrix backwards in the reference (signed char): refused
     assert res.records["status"][1] == 0
     assert res.records["status"][2] & 1
     assert res.records["status"][3] & 16
+    # a read character beyond the 90 x 90 matrix reads the flat element ci * 90 + cj in the reference (pyx:212, bounds checking off):
+    # defined while the largest reference character keeps it inside the buffer, refused otherwise; a reference character beyond
+    # the matrix is always out of bounds
+    g = np.zeros(5, dtype=np.int64)
+    al = BatchAligner(["ACGT", "ACGY", "ACGa"], [g, g, g], [[1, 2]] * 3, m, -20, -2, ctx=ctx)
+    res = al.align(["ACGa", "ACGa", "ACGT", "None"], ref_ids=[0, 1, 2, 0])
+    assert res.records["status"][0] == 0 and res.strings(0) == tuple(oracle.global_align("ACGa", "ACGT", m, g, -20, -2)[:2])
+    assert res.records["status"][1] & 2 and res.records["status"][2] & 2
+    assert res.records["status"][3] == 0 and res.strings(3) == tuple(oracle.global_align("None", "ACGT", m, g, -20, -2)[:2])
     al = BatchAligner(["G"], [np.array([1, 0], dtype=np.int64)], [[0]], m, -1, -1, ctx=ctx)
     res = al.align(["TT"])
     assert oracle.global_align_raw("TT", "G", m, np.array([1, 0], dtype=np.int64), -1, -1)[0] != 0

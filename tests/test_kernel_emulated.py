@@ -354,3 +354,40 @@ def test_emulated_chain_soak_mixed_batches(mats, go, ge, seed):
         assert st["fallback"] == st["tasks"]                        # max(go, ge) + incentive = 0: the diagonal kernels do not apply
     else:
         assert 0 < st["fallback"] < st["tasks"]
+
+
+def test_gap_free_predicate_kept_in_registers_every_length_residue(mats):
+    """c2_align_diagx_kernel decides "gap-free" from the two low pointer bits of the main-diagonal cells, collected in the
+    lane's registers during the fill and captured at the cell (L, L) (c2_gapfree) -- no pointer word is read back for such
+    reads.  Square alignments of every length residue mod 8 (the capture masks the word in the making by the position of the
+    last cell inside its group), without gaps (must take the shortcut and give the reference's strings), with a gap or a
+    terminal overhang close to either end (must NOT), against the oracle."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(424242)
+    for na in (-4, -2):
+        reads, refs, gis, incs, rids = [], [], [], [], []
+        for L in range(33, 58):
+            ref = "".join(rng.choice(list("ACGT"), L))
+            g = np.zeros(L + 1, dtype=np.int64)
+            g[L // 2 + 1] = 1
+            variants = [ref]                                                        # identical
+            r = list(ref); r[int(rng.integers(0, L))] = "N"; variants.append("".join(r))
+            r = list(ref); r[L - 1] = {"A": "C", "C": "G", "G": "T", "T": "A"}[r[L - 1]]; variants.append("".join(r))   # last cell a mismatch
+            r = list(ref); r[0] = {"A": "C", "C": "G", "G": "T", "T": "A"}[r[0]]; variants.append("".join(r))
+            variants.append(ref[:L - 2] + ref[L - 1] + "A")                         # one base deleted near the end, padded: same length, gapped
+            variants.append("T" + ref[:L - 1])                                      # shifted by one: gaps at both ends
+            variants.append(ref[1:] + "G")
+            variants.append(ref[:3] + ref[5:] + "CA")                               # deletion near the start
+            for v in variants:
+                assert len(v) == L
+                reads.append(v); rids.append(len(refs))
+            refs.append(ref); gis.append(g); incs.append([L // 2, L // 2 + 1])
+        res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=rids, band_lanes=na, grid=3)
+        n_gapfree = 0
+        for k, rd in enumerate(reads):
+            st, s1, s2, mt, ln = oracle.global_align_raw(rd, refs[rids[k]], m, gis[rids[k]], -20, -2)
+            assert st == 0 and rec["status"][k] == 0 and res[k] == (s1, s2) and int(rec["matches"][k]) == mt and int(rec["aln_len"][k]) == ln, (na, k, rd)
+            p = oracle.find_indels_substitutions(s1, s2, incs[rids[k]])
+            assert (rec["insertion_n"][k], rec["deletion_n"][k], rec["substitution_n"][k]) == (p["insertion_n"], p["deletion_n"], p["substitution_n"])
+            n_gapfree += "-" not in s1 and "-" not in s2
+        assert n_gapfree >= 4 * 25
