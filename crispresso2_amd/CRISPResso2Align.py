@@ -10,30 +10,27 @@ from . import _native
 
 
 def read_matrix(path):
-    """Read a score matrix in NCBI format (reference pyx:33-61).
-
-    The score for a 'C' changing to an 'A' is stored as mat[ord('C'), ord('A')].
-    Returns int64[max_ord+1, max_ord+1].  Row k of the file is taken to belong to header k,
-    as in the reference.
-    """
+    """Score matrix file in NCBI format -> int64[max_ord+1, max_ord+1] with mat[ord(a), ord(b)] = score of a against b
+    (reference pyx:33-61).  Same reading rules as the reference, quirks included: '#' lines before the column header are
+    skipped (a blank line there is an IndexError, as in the reference); columns are the header's symbols in order; the k-th
+    row of numbers belongs to the k-th header symbol whatever its own label says; the LAST character of every row line is
+    dropped before it is split (the newline -- or a digit, if the file does not end with one)."""
     with open(path) as fh:
-        headers = None
-        while headers is None:
-            line = fh.readline().strip()
-            if line[0] == '#':
-                continue
-            headers = [ord(x) for x in line.split(' ') if x]
-        mat_size = max(headers) + 1
-        a = np.zeros((mat_size, mat_size), dtype=np.int64)
-        ai = 0
-        line = fh.readline()
-        while line:
-            line_vals = [int(x) for x in line[:-1].split(' ')[1:] if x]
-            for ohidx, val in zip(headers, line_vals):
-                a[headers[ai], ohidx] = val
-            ai += 1
-            line = fh.readline()
-    return a
+        rows = fh.readlines()
+    cursor = 0
+    while True:
+        head = rows[cursor].strip() if cursor < len(rows) else ''
+        cursor += 1
+        if head[0] != '#':                                  # ('' -> IndexError: string index out of range)
+            break
+    columns = [ord(tok) for tok in head.split(' ') if tok]
+    size = max(columns) + 1
+    mat = np.zeros((size, size), dtype=np.int64)
+    for row_no, text in enumerate(rows[cursor:]):
+        scores = [int(tok) for tok in text[:-1].split(' ')[1:] if tok]
+        for col, score in zip(columns, scores):
+            mat[columns[row_no], col] = score               # (looked up per value: a blank line past the last row is harmless, as in the reference)
+    return mat
 
 
 def make_matrix(match_score=5, mismatch_score=-4, n_mismatch_score=-2, n_match_score=-1):

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcrispresso2_amd.so")
+LIB_PATH = os.environ.get("C2_AMD_LIB") or os.path.join(_HERE, "lib", "libcrispresso2_amd.so")   # (C2_AMD_LIB: another build of the same library, for A/B runs)
 
 # every symbol include/crispresso2_amd.h declares
 SYMBOLS = [
@@ -21,6 +21,7 @@ SYMBOLS = [
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
     "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_timing_read_split", "c2_count_vectors_device", "c2_select_best_device",
+    "c2_comm_unique_id", "c2_comm_init", "c2_reduce_counts", "c2_comm_destroy",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error", "c2_strand_plan", "c2_merge_reverse_complements",
@@ -233,6 +234,27 @@ class Context:
             self.lib.c2_lists_free(h)
         return index, values, counts
 
+    # ---- multi-GPU exchange through the C ABI (RCCL); torch.distributed is only used to hand the communicator id around
+    def comm_init(self, rank=None, world=None):
+        """Collective: every rank calls it.  The 128-byte id comes from rank 0 (c2_comm_unique_id) and travels through
+        torch.distributed's object broadcast when a process group exists (world > 1)."""
+        rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        buf = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            self.check(self.lib.c2_comm_unique_id(buf), "c2_comm_unique_id")
+        if world > 1:
+            import torch.distributed as dist
+            box = [bytes(buf)]
+            dist.broadcast_object_list(box, src=0)
+            buf = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        self.check(self.lib.c2_comm_init(self.handle, rank, world, buf), "c2_comm_init")
+
+    def reduce_counts(self, d_counts, n_elements, stream=None):
+        """in-place sum over the ranks of n_elements int64 at the device address d_counts (c2_reduce_counts)"""
+        self.check(self.lib.c2_reduce_counts(self.handle, ctypes.c_void_p(d_counts), ctypes.c_uint64(n_elements), ctypes.c_void_p(stream or 0)),
+                   "c2_reduce_counts")
+
     def tier_info(self):
         """Banded launches of the most recent batch and the number of tasks each left for the next one."""
         n = ctypes.c_int32(0)
@@ -281,6 +303,53 @@ def fastq_unique(path, min_single_bp_quality=0, min_average_read_quality=0, min_
     finally:
         lib.c2_fastq_free(h)
     return arena, offsets, counts, total
+
+
+class FastqUnique:
+    """c2_fastq_unique without the copies: arena / offsets / counts are VIEWS of the native handle's memory (211 MB for 845 k
+    unique 250-bp reads), valid until close().  Same arguments and statistics as fastq_unique()."""
+
+    def __init__(self, path, min_single_bp_quality=0, min_average_read_quality=0, min_bp_quality_or_N=0, stats=None):
+        lib = load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        if min_single_bp_quality > 0 or min_average_read_quality > 0 or min_bp_quality_or_N > 0:
+            lines = ctypes.c_uint64(0)
+            rc = lib.c2_fastq_unique_filtered(os.fsencode(path), int(min_single_bp_quality), int(min_average_read_quality),
+                                              int(min_bp_quality_or_N), ctypes.byref(self._h), ctypes.byref(lines))
+            if rc == 0 and stats is not None:
+                stats["N_READS_INPUT"] = int(float(lines.value) / 4.0)          # get_n_reads_fastq, CRISPRessoShared.py:746-747
+        else:
+            rc = lib.c2_fastq_unique(os.fsencode(path), ctypes.byref(self._h))
+        if rc != 0:
+            raise NativeError("c2_fastq_unique: %s" % lib.c2_fastq_last_error().decode())
+        h = self._h
+        n = int(lib.c2_fastq_n_unique(h))
+        nb = int(lib.c2_fastq_arena_bytes(h))
+        self.arena = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_arena(h), ctypes.POINTER(ctypes.c_uint8)), (nb,))
+                      if nb else np.zeros(0, dtype=np.uint8))
+        self.offsets = np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_offsets(h), ctypes.POINTER(ctypes.c_uint64)), (n + 1,))
+        self.counts = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_counts(h), ctypes.POINTER(ctypes.c_uint32)), (n,))
+                       if n else np.zeros(0, dtype=np.uint32))
+        self.n_reads = int(lib.c2_fastq_n_reads(h))
+
+    def close(self):
+        if self._h:
+            self.arena = self.offsets = self.counts = None
+            self._lib.c2_fastq_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _fastq_strings(lib, h, n, data_fn, bytes_fn, offsets_fn):

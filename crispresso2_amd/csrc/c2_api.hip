@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 #include <memory>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is bound with dlopen (the copy PyTorch-ROCm already loaded, if any)
 
 #include "crispresso2_amd.h"
 #include "c2_device.h"
@@ -82,6 +84,8 @@ struct c2_ctx {
     int occ_blocks[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
     DevBuf d_sel;          // selection kernel: per-reference score thresholds
+    ncclComm_t comm = nullptr; // RCCL communicator of c2_comm_init (one rank per GPU)
+    int comm_world = 0;
     std::vector<uint32_t> sel_table;
     std::vector<uint16_t> cnt_table;   // host copy of the table that is on the device (skip re-upload when unchanged)
 };
@@ -232,7 +236,8 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
     bool first_marked = false;
     auto mark_first = [&]() { if (ctx->timing && !first_marked) { (void)hipEventRecord(tl.m, s); first_marked = true; } };
     int rc;
-    A.band_lanes = 0; A.reserved = (getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0) | (getenv("C2_DEBUG_SKIP_EPILOGUE") ? 2 : 0) | (getenv("C2_DEBUG_HALF_FILL") ? 4 : 0);   // (measurement knobs) A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
+    A.band_lanes = 0; A.reserved = (getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0) | (getenv("C2_DEBUG_SKIP_EPILOGUE") ? 2 : 0) | (getenv("C2_DEBUG_HALF_FILL") ? 4 : 0);   // (measurement knobs)
+    A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
     if (g.diag || g.band_lanes > 0) {
         if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
         // d_fb: 16 header words -- [0..3] length of the fallback list each tier leaves, [4 + 2t ..] work counter of launch t --
@@ -345,6 +350,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.max_li = ctx->max_li;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
     A.mat_dim = ctx->sc.mat_dim; A.first_ext_code = ctx->sc.first_ext_code;
+    c2_build_base_luts(ctx->sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
     {
         int mx = 0;
         for (int16_t v : ctx->sc.tbl) mx = std::max(mx, (int)v);
@@ -403,6 +409,7 @@ void c2_destroy(c2_ctx* ctx) {
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
                      &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel};
     for (DevBuf* b : all) release(*b);
+    (void)c2_comm_destroy(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -712,6 +719,84 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     return 0;
 }
 
+// ---- multi-GPU: the only exchange step of the sharded path, SURVEY 8(e): all-reduce of the per-amplicon count tensor over RCCL ----
+namespace {
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy that is already in the process (torch.distributed's), else the ROCm installation's
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names) if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* n : names) if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.h) { api.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+        api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.err = "librccl.so lacks an expected symbol";
+    });
+    return &api;
+}
+#define RCCLCHK(ctx, api, call)                                                                             \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess) {                                                                            \
+            (ctx)->err = std::string(#call) + ": " + ((api)->GetErrorString ? (api)->GetErrorString(r_) : "rccl error"); \
+            return C2_E_DEVICE;                                                                             \
+        }                                                                                                   \
+    } while (0)
+}  // namespace
+
+int c2_comm_unique_id(uint8_t* out_id) {
+    RcclApi* R = rccl();
+    if (!out_id || !R->err.empty()) { g_create_error = R->err.empty() ? "out_id is NULL" : R->err; return C2_E_DEVICE; }
+    static_assert(sizeof(ncclUniqueId) == C2_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return C2_E_DEVICE; }
+    memcpy(out_id, &id, sizeof id);
+    return 0;
+}
+
+int c2_comm_init(c2_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) { if (ctx) ctx->err = "bad communicator arguments"; return C2_E_INVALID; }
+    RcclApi* R = rccl();
+    if (!R->err.empty()) { ctx->err = R->err; return C2_E_DEVICE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm) { (void)R->CommDestroy(ctx->comm); ctx->comm = nullptr; }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    RCCLCHK(ctx, R, R->CommInitRank(&ctx->comm, world, uid, rank));
+    ctx->comm_world = world;
+    return 0;
+}
+
+int c2_reduce_counts(c2_ctx* ctx, int64_t* d_counts, uint64_t n_elements, void* hip_stream) {
+    if (!ctx || (!d_counts && n_elements)) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
+    if (!ctx->comm) { ctx->err = "c2_comm_init has not been called"; return C2_E_STATE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_elements == 0) return 0;
+    RcclApi* R = rccl();
+    RCCLCHK(ctx, R, R->AllReduce(d_counts, d_counts, (size_t)n_elements, ncclInt64, ncclSum, ctx->comm, (hipStream_t)hip_stream));
+    return 0;
+}
+
+int c2_comm_destroy(c2_ctx* ctx) {
+    if (!ctx) return C2_E_INVALID;
+    if (ctx->comm) { RcclApi* R = rccl(); if (R->CommDestroy) (void)R->CommDestroy(ctx->comm); ctx->comm = nullptr; ctx->comm_world = 0; }
+    return 0;
+}
+
 int c2_select_best_device(c2_ctx* ctx, uint64_t n_reads, int32_t n_refs, const c2_aln_record* d_records,
                           const c2_aln_record* d_records2, const int32_t* d_slot2, const uint32_t* h_min_mscore,
                           const uint32_t* d_raw_counts, const uint32_t* d_counts, int32_t mode, int32_t max_aln_len,
@@ -739,7 +824,7 @@ int c2_select_best_device(c2_ctx* ctx, uint64_t n_reads, int32_t n_refs, const c
     A.member = (unsigned long long*)d_member; A.use2 = (unsigned long long*)d_use2; A.flags = d_flags;
     A.weights = d_weights; A.weights2 = d_weights2; A.stats = (unsigned long long*)d_stats;
     A.n_reads = n_reads; A.n_refs = n_refs; A.mode = mode;
-    hipLaunchKernelGGL(c2_select_best_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(c2_select_best_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), C2_SEL_STATS * sizeof(unsigned long long), s, A);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }

@@ -18,7 +18,7 @@
 #define C2_DIAG_STORE_LO 0           // diagonal-band kernel: lanes STORE_LO .. STORE_LO+STORE_N-1 keep their pointer words in LDS (all 64:
 #define C2_DIAG_STORE_N 64           //   16 KB for 500 anti-diagonals; its 175 VGPRs allow 8 workgroups per CU, which 19 KB of LDS each still fit)
 #define C2_DIAG_ROW_PAD 128          // zero row records in front of row 0 and behind row Li+1 of every reference's table
-#define C2_DIAG_CODE_PAD 32          // zero column symbols in front of column 0 (multi-alignment kernel's LDS tables)
+#define C2_DIAG_CODE_PAD 35          // zero column symbols in front of column 0 (multi-alignment kernel's LDS tables); PAD + 1 is a multiple of 4: column 1 is dword-aligned
 #ifndef C2_TIER0_NA
 #define C2_TIER0_NA 4               // alignments per wavefront in the first launch of the chain (4, or 5: lane groups of 12)
 #endif
@@ -77,6 +77,8 @@ typedef struct c2_align_args {
     uint32_t reserved3;
     int32_t mat_dim;              // dimension of the reference's score matrix (CRISPResso2Align.pyx:212 reads the flat element ci * dim + cj)
     int32_t first_ext_code;       // codes >= this belong to read characters with ord >= mat_dim (c2_build_scoring); never valid in a reference
+    uint32_t lut_code_lo, lut_code_hi;  // 8-entry byte tables indexed by (ch >> 1) & 7 (A 0, C 1, T 2, G 3, N 7): the score-table code of that base ...
+    uint32_t lut_chr_lo, lut_chr_hi;    // ... and the base itself (0xFF where the entry is no base or its code is not a packed one): v_perm_b32 look-ups
     const struct c2_diag_row* diag_base;   // start of the buffer every reference's diag_rows points into
 } c2_align_args;
 

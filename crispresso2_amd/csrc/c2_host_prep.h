@@ -92,6 +92,24 @@ inline bool c2_build_scoring(const int64_t* matrix, int dim, c2_scoring_tables& 
     return true;
 }
 
+// The two 8-entry byte tables the multi-alignment kernels' read staging looks bases up in with v_perm_b32, indexed by
+// (ch >> 1) & 7 -- a perfect hash of A (0), C (1), T (2), G (3), N (7): the score-table code of the base, and the base itself
+// (to verify that the byte really was that base).  An entry whose base has no packed code (>= 8, or not a scoring symbol of
+// this matrix) holds 0xFF in the letter table, so such reads never pass the check and take the general staging path.
+inline void c2_build_base_luts(const c2_scoring_tables& sc, uint32_t& code_lo, uint32_t& code_hi, uint32_t& chr_lo, uint32_t& chr_hi) {
+    unsigned char code[8], chr[8];
+    for (int k = 0; k < 8; ++k) { code[k] = 0xFF; chr[k] = 0xFF; }
+    for (const char* q = "ACTGN"; *q; ++q) {
+        const int k = (*q >> 1) & 7;
+        const unsigned char c = sc.code_of_char[(unsigned char)*q];
+        if (c < 8 && !sc.pk.empty()) { code[k] = c; chr[k] = (unsigned char)*q; }
+    }
+    code_lo = code[0] | (code[1] << 8) | (code[2] << 16) | ((uint32_t)code[3] << 24);
+    code_hi = code[4] | (code[5] << 8) | (code[6] << 16) | ((uint32_t)code[7] << 24);
+    chr_lo = chr[0] | (chr[1] << 8) | (chr[2] << 16) | ((uint32_t)chr[3] << 24);
+    chr_hi = chr[4] | (chr[5] << 8) | (chr[6] << 16) | ((uint32_t)chr[7] << 24);
+}
+
 // inc_prefix[x] = number of distinct include idxs < x, x in [0, Li+1]
 inline void c2_build_inc_prefix(const int32_t* inc, int n_inc, int Li, std::vector<uint16_t>& out) {
     std::vector<uint8_t> bit((size_t)Li + 2, 0);

@@ -382,9 +382,41 @@ __device__ __forceinline__ void c2_prefetch_issue(const c2_align_args& A, const 
 // Stage the prefetched task in LDS: reference (only when the amplicon changes), read characters (reverse complement on
 // request, CRISPRessoShared.py:399-403) and their codes.  Returns the wave-uniform status bits.  max_li / A.max_lj bound
 // what may be written.  sCodeOf: the 256-entry character -> code table, in LDS.
+// Stage a reference in its LDS slot (characters, window prefix counts; `bad`: a character outside the score matrix) -- done
+// only when the amplicon of a slot changes.  sWin (optional): per dword of four reference positions, bit 7 of byte b set iff
+// position 4k + b lies in the quantification window (what c2_emit_gapless4 tests substitutions against).
+__device__ __forceinline__ void c2_stage_ref(const c2_align_args& A, const c2_wg& W, const unsigned char* sCodeOf, const int ref_id, const int lane,
+                                             const int max_li, int& Li, int& g0, int& ref_bad, uint32_t* sWin = nullptr)
+{
+    const c2_dev_ref rf = A.refs[ref_id];
+    Li = rf.len;
+    g0 = rf.gap_incentive[0];
+    const int LiLoad = Li < max_li ? Li : max_li;
+    int bad = 0;                                            // a reference character outside the score matrix: checked when the
+    for (int k = lane; k < LiLoad; k += 64) {               // reference is staged, remembered with it (ref_bad)
+        const unsigned char ch = rf.seq[k];
+        W.sRef[k] = ch;
+        if ((int)sCodeOf[ch] >= A.first_ext_code) bad = 1;      // ord >= matrix dimension (codes >= first_ext_code are read-only symbols)
+    }
+    ref_bad = __ballot(bad) ? 1 : 0;
+    for (int k = lane; k < LiLoad + 2; k += 64) W.sIncP[k] = rf.inc_prefix[k];
+    if (sWin) {
+        for (int k = lane; 4 * k < LiLoad; k += 64) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c = 4 * k + b;
+                if (c < LiLoad && rf.inc_prefix[c + 1] != rf.inc_prefix[c]) m |= 0x80u << (8 * b);
+            }
+            sWin[k] = m;
+        }
+    }
+}
+
+template <bool HAVE_B4 = true>
 __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_wg& W, const unsigned char* sCodeOf, const c2_prefetch& pf,
                                               const int lane, const int max_li, int& cur_ref, int& Li, int& g0, int& ref_bad, bool& packed,
-                                              unsigned char* sCodes4 = nullptr)
+                                              unsigned char* sCodes4 = nullptr, uint32_t* sWin = nullptr)
 {
     // sCodes4 (multi-alignment kernel): the zero-padded table of 4 * code per column, written in the same pass -- columns
     // 1 .. Lj at sCodes4[C2_DIAG_CODE_PAD + 1 ..]; the zeros in front are written once per kernel, the nine behind per task
@@ -394,22 +426,11 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
     const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
     if (pf.ref_id != cur_ref) {
         cur_ref = pf.ref_id;
-        const c2_dev_ref rf = A.refs[pf.ref_id];
-        Li = rf.len;
-        g0 = rf.gap_incentive[0];
-        const int LiLoad = Li < max_li ? Li : max_li;
-        int bad = 0;                                            // a reference character outside the score matrix: checked when the
-        for (int k = lane; k < LiLoad; k += 64) {               // reference is staged, remembered with it (ref_bad)
-            const unsigned char ch = rf.seq[k];
-            W.sRef[k] = ch;
-            if ((int)sCodeOf[ch] >= A.first_ext_code) bad = 1;      // ord >= matrix dimension (codes >= first_ext_code are read-only symbols)
-        }
-        ref_bad = __ballot(bad) ? 1 : 0;
-        for (int k = lane; k < LiLoad + 2; k += 64) W.sIncP[k] = rf.inc_prefix[k];
+        c2_stage_ref(A, W, sCodeOf, pf.ref_id, lane, max_li, Li, g0, ref_bad, sWin);
     }
     for (int k = lane; k < LjLoad; k += 64) {
         unsigned char ch;
-        if (k < 256) ch = (unsigned char)((pf.b4 >> ((k >> 6) * 8)) & 0xffu);
+        if (HAVE_B4 && k < 256) ch = (unsigned char)((pf.b4 >> ((k >> 6) * 8)) & 0xffu);
         else ch = A.reads[pf.off + (uint64_t)(rc ? Lj - 1 - k : k)];
         if (rc) {
             if (ch >= 'a' && ch <= 'z') ch -= 32;                       // seq.upper()
@@ -659,6 +680,45 @@ __device__ __forceinline__ bool c2_try_gapless(const PLANE& P, const c2_align_ar
     if (__ballot(off)) return false;
     c2_emit_gapless(A, W, task, L, lane, rec);
     return true;
+}
+
+// c2_emit_gapless for the multi-alignment kernels, four columns per lane: the read and the reference leave LDS as dwords and
+// go out as dwords (rows are 16-byte aligned: the caller checks the base pointers); mismatching bytes are found with the
+// "has a zero byte" bit trick on read ^ reference, the few lanes that hold one are visited with scalar code.
+// sWin: c2_stage_ref's window masks.  L <= 256 (the caller checks).
+__device__ __forceinline__ void c2_emit_gapless4(const c2_align_args& A, const c2_wg& W, const uint32_t* sWin, const uint64_t task, const int L,
+                                                 const int lane, c2_aln_record& rec)
+{
+    const int p = 4 * lane;
+    const int nb = L - p;                                             // valid bytes of this lane's dword
+    const uint32_t valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
+    const uint32_t rd = ((const uint32_t*)W.sRead)[lane] & valid, rf = ((const uint32_t*)W.sRef)[lane] & valid;
+    if (!(A.reserved & 1) && nb > 0) {
+        ((uint32_t*)(A.aln_read + task * (uint64_t)A.aln_stride))[lane] = rd;      // (a partial last dword is padded with zeros: the row has room, aln_stride is a multiple of 16)
+        ((uint32_t*)(A.aln_ref + task * (uint64_t)A.aln_stride))[lane] = rf;
+    }
+    const uint32_t x = rd ^ rf;
+    const uint32_t mm = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;      // bit 7 of every byte in which read and reference differ
+    int mism = 0, n_all_sub = 0, n_win_sub = 0;
+    unsigned long long todo = __ballot(mm != 0);
+    if (todo) {
+        const uint32_t y = rd ^ 0x4e4e4e4eu;                                         // COREResources.pyx:113-118: a read 'N' is no substitution
+        const uint32_t sub = mm & ((((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u);
+        const uint32_t win = sub & sWin[lane];
+        while (todo) {                                                               // (a read of an amplicon run differs in a lane or two)
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            mism += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)mm, l));
+            n_all_sub += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)sub, l));
+            n_win_sub += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)win, l));
+        }
+    }
+    const unsigned char r0 = W.sRead[0], f0 = W.sRef[0], rL = W.sRead[L - 1], fL = W.sRef[L - 1];
+    rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
+    rec.aln_len = (uint16_t)L;
+    rec.matches = (uint16_t)(L - mism);                                              // pyx:375-376
+    rec.substitution_n = (uint16_t)n_win_sub;
+    rec.all_substitutions = (uint16_t)n_all_sub;
 }
 
 // A gap-free alignment of two sequences of equal length: the aligned strings are the read and the reference themselves, and
@@ -940,7 +1000,7 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
 // ---------------------------------------------------------------------------------------------------------------
 struct c2_diagx_plan {
     uint32_t codeof, table, tmp_read, tmp_ref, stage, slot0, slot_bytes, total, n_words;
-    uint32_t codes, read, code, ref, incp;                          // offsets inside one alignment's slot
+    uint32_t codes, read, code, ref, incp, win;                     // offsets inside one alignment's slot
 };
 
 __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, int max_lj) {
@@ -954,11 +1014,12 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     p.stage = off;    off += p.n_words * (64u / (uint32_t)na) * 4u; // pointer words of the alignment being traced
     p.slot0 = off;
     uint32_t so = 0;
-    p.codes = so;    so += c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 8u);   // zeros | columns 0 .. Lj+1 | zeros
+    p.codes = so;    so += c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 16u);  // zeros | columns 0 .. Lj+1 | zeros (the staging writes them as dwords: up to 15 behind column Lj)
     p.read = so;     so += c2_align16((uint32_t)max_lj);
     p.code = so;     so += c2_align16((uint32_t)max_lj);
     p.ref = so;      so += c2_align16((uint32_t)max_li);
     p.incp = so;     so += c2_align16(((uint32_t)max_li + 2u) * 2u);
+    p.win = so;      so += c2_align16((uint32_t)max_li + 4u);            // one byte per reference position, read as dwords: 0x80 = inside the quantification window
     p.slot_bytes = so;
     p.total = p.slot0 + (uint32_t)na * so;
     return p;
@@ -1224,6 +1285,9 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
         W.sIncP = (uint16_t*)(base + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
         return W;
     };
+    auto win_of = [&](const int s) { return (uint32_t*)(c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.win); };
+    // rows of the output arrays can be written as dwords (c2_emit_gapless4) when their addresses are multiples of 4
+    const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);
     unsigned* sStage = (unsigned*)(c2_smem + P.stage);
     unsigned* gWords = A.plane + (size_t)blockIdx.x * A.plane_words_per_wg;   // [slot][group][lane of the slot]
     const int slotWords = (int)P.n_words * LPA;
@@ -1267,7 +1331,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
         c2_phase_begin(A.phase_cycles, PH);
         // ---- D: stage the NA prefetched tasks in their LDS slots
         if (have_group) {
-#pragma unroll
+#pragma nounroll                                                     // (one copy of the staging code: the read dwords are picked by a uniform select)
             for (int s = 0; s < NA; ++s) {
                 int* T = sTab + s * C2X_INTS;
                 const int tvd = c2_tab_load(T, lane);
@@ -1279,9 +1343,36 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 cur.task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mC_task, s);
                 cur.off = lane64(mC_off, s);
                 cur.Lj = __builtin_amdgcn_readlane(mC_lj, s); cur.ref_id = __builtin_amdgcn_readlane(mC_ref, s);
-                cur.rc = __builtin_amdgcn_readlane(mC_rc, s); cur.b4 = b4s[s];
-                if (cur.valid) st = c2_commit_task(A, wg_of(s), sCodeOf, cur, lane, A.max_li, cref, li, g0, rbad, packed,
-                                                   c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes);
+                cur.rc = __builtin_amdgcn_readlane(mC_rc, s); cur.b4 = 0;
+                if (cur.valid) {
+                    unsigned char* sCodes4 = c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes;
+                    bool done = false;
+                    if (!cur.rc && cur.Lj >= 4 && cur.Lj <= 256 && cur.Lj <= A.max_lj) {
+                        // the usual read: forward strand, at most 256 bases, nothing but A C G T N.  Four bases per lane: codes through two
+                        // byte permutes ((ch >> 1) & 7 is a perfect hash of the five letters), checked by permuting the letters back.
+                        const c2_wg W = wg_of(s);
+                        if (cur.ref_id != cref) { cref = cur.ref_id; c2_stage_ref(A, W, sCodeOf, cur.ref_id, lane, A.max_li, li, g0, rbad, win_of(s)); }
+                        uint32_t w = b4s[0];
+#pragma unroll
+                        for (int q = 1; q < NA; ++q) if (s == q) w = b4s[q];
+                        const uint32_t idx = (w >> 1) & 0x07070707u;
+                        const uint32_t codes = __builtin_amdgcn_perm(A.lut_code_hi, A.lut_code_lo, idx);
+                        const uint32_t chk = __builtin_amdgcn_perm(A.lut_chr_hi, A.lut_chr_lo, idx);
+                        const int nb = cur.Lj - 4 * lane;
+                        const uint32_t valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
+                        if (__ballot(((chk ^ w) & valid) != 0) == 0ull) {
+                            if (nb > 0) {
+                                ((uint32_t*)W.sRead)[lane] = w;
+                                ((uint32_t*)(sCodes4 + C2_DIAG_CODE_PAD + 1))[lane] = (codes & valid) << 2;    // 4 * code per column, zeros behind the last one
+                            }
+                            if (lane < 3) ((uint32_t*)(sCodes4 + C2_DIAG_CODE_PAD + 1))[((cur.Lj + 3) >> 2) + lane] = 0u;   // ... nine zeros at least
+                            st = (rbad ? C2_STATUS_OOB_CHAR : 0) | (li <= 0 ? C2_STATUS_EMPTY : 0) | (li > A.max_li ? C2_STATUS_TOO_LONG : 0);
+                            packed = true;
+                            done = true;
+                        }
+                    }
+                    if (!done) st = c2_commit_task<false>(A, wg_of(s), sCodeOf, cur, lane, A.max_li, cref, li, g0, rbad, packed, sCodes4, win_of(s));
+                }
                 if (lane == 0) {
                     T[C2X_VALID] = cur.valid; T[C2X_TASK_LO] = (int)(unsigned)(cur.task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(cur.task >> 32);
                     T[C2X_LJ] = cur.Lj; T[C2X_REF] = cur.ref_id; T[C2X_RC] = cur.rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
@@ -1294,16 +1385,20 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
         mC_lj = mB_valid ? (int)(mB_off1 - mB_off) : 0;
 #pragma unroll
         for (int s = 0; s < NA; ++s) {
+            // one dword per lane: bytes 4l .. 4l+3 of the read (what the fast staging above takes); the dword that holds the read's
+            // last bytes is loaded so that it ENDS at the last byte and shifted down -- nothing behind the read is touched.  Reads
+            // of fewer than 4 or more than 256 bases and reverse-complemented ones are staged by c2_commit_task from memory.
             const int v = __builtin_amdgcn_readlane(mC_valid, s);
             unsigned b4 = 0;
             if (v) {
                 const uint64_t off = lane64(mC_off, s);
-                const int Lj = __builtin_amdgcn_readlane(mC_lj, s), rc = __builtin_amdgcn_readlane(mC_rc, s);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = 64 * q + lane;
-                    const unsigned byte = (k < Lj) ? (unsigned)A.reads[off + (uint64_t)(rc ? Lj - 1 - k : k)] : 0u;
-                    b4 |= byte << (8 * q);
+                const int Lj = __builtin_amdgcn_readlane(mC_lj, s);
+                const int p = 4 * lane;
+                if (Lj >= 4 && p < Lj) {
+                    const int q = p < Lj - 4 ? p : Lj - 4;
+                    uint32_t w;
+                    __builtin_memcpy(&w, A.reads + off + (uint64_t)q, 4);
+                    b4 = w >> (8 * (p - q));
                 }
             }
             b4s[s] = b4;
@@ -1479,7 +1574,8 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             c2_clear_record(rec, C2_TF(tv, C2X_RC), C2_TF(tv, C2X_REF));
             bool need_full = (m_full >> s) & 1u;
             if ((m_gapfree >> s) & 1u) {
-                c2_emit_gapless(A, wg_of(s), task, Li, lane, rec);
+                if (rows_aligned && Li <= 256) c2_emit_gapless4(A, wg_of(s), win_of(s), task, Li, lane, rec);
+                else c2_emit_gapless(A, wg_of(s), task, Li, lane, rec);
             } else if ((m_trace >> s) & 1u) {
                 const int d0 = C2_TF(tv, C2X_D0), minsc = C2_TF(tv, C2X_MINSC);
                 const c2_wg W = wg_of(s);
@@ -1850,8 +1946,11 @@ __global__ __launch_bounds__(256) void c2_select_best_kernel(c2_select_args A)
         for (int r = 0; r < k; ++r) {
             const uint64_t t = read * (uint64_t)k + (uint64_t)r;
             const c2_aln_record* rec = A.records + t;
-            if (rec->status != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rec->status; }
-            long long ms = (long long)c2_mscore(rec->matches, rec->aln_len);
+            // (what the choice needs of a record -- length, matches, status -- with two loads instead of one per field)
+            const unsigned w0 = ((const unsigned*)rec)[0], w5 = ((const unsigned*)rec)[5];
+            const unsigned rstatus = w5 >> 24;
+            if (rstatus != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rstatus; }
+            long long ms = (long long)c2_mscore(w0 >> 16, w0 & 0xffffu);
             bool second = false;
             if (A.records2 && A.slot2) {
                 const int sl = A.slot2[t];
@@ -1905,19 +2004,18 @@ __global__ __launch_bounds__(256) void c2_select_best_kernel(c2_select_args A)
         }
     }
     if (A.stats) {
-        // wavefront sums, one atomic per statistic per wavefront (FIRST_BAD_STATUS: any non-zero value will do)
+        // block sums in LDS (a thread adds only what is non-zero: a handful of LDS atomics), then one global atomic per statistic
+        // per block; FIRST_BAD_STATUS: any non-zero value will do (plain store)
+        unsigned long long* blk = (unsigned long long*)c2_smem;       // (launched with C2_SEL_STATS * 8 bytes of dynamic LDS)
+        if (threadIdx.x < C2_SEL_STATS) blk[threadIdx.x] = 0ull;
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < C2_SEL_STATS; ++q) {
-            unsigned long long v = st[q];
-            if (q == C2_SEL_FIRST_BAD_STATUS) { if (v != 0) A.stats[q] = v; continue; }   // (plain store: any one of them will do)
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xffffffffull), m);
-                const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m);
-                v += ((unsigned long long)hi << 32) | lo;
-            }
-            if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(A.stats + q, v);
+            if (q == C2_SEL_FIRST_BAD_STATUS) { if (st[q] != 0) A.stats[q] = st[q]; continue; }
+            if (st[q] != 0) atomicAdd(&blk[q], st[q]);
         }
+        __syncthreads();
+        if (threadIdx.x < C2_SEL_STATS && threadIdx.x != C2_SEL_FIRST_BAD_STATUS && blk[threadIdx.x] != 0) atomicAdd(A.stats + threadIdx.x, blk[threadIdx.x]);
     }
 }
 

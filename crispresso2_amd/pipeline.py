@@ -483,18 +483,19 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
     # (CRISPRessoCORE.py:3696-3717); here the filter runs inside the ingest
     flt = [int(getattr(args, k_, 0) or 0) for k_ in ('min_single_bp_quality', 'min_average_read_quality', 'min_bp_quality_or_N')]
     ingest_stats = {}
-    arena, offsets, counts, n_reads = _native.fastq_unique(path, *flt, stats=ingest_stats)
-    if timings is not None:
-        timings["ingest_dedup"] = time.perf_counter() - t0
-    lens = offsets[1:] - offsets[:-1]
-    if len(counts) and (lens == 0).any():
-        keep = np.nonzero(lens > 0)[0]                          # at most one empty key
-        new_off = np.zeros(len(keep) + 1, dtype=np.uint64)
-        new_off[1:] = np.cumsum(lens[keep])
-        arena = np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in keep]) if len(keep) else np.zeros(0, dtype=np.uint8)
-        offsets, counts = new_off, counts[keep]
-    res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
-                          pe_scaffold_dna_info=pe_scaffold_dna_info)
+    with _native.FastqUnique(path, *flt, stats=ingest_stats) as fq:      # views of the native arena: nothing is copied on the host
+        arena, offsets, counts, n_reads = fq.arena, fq.offsets, fq.counts, fq.n_reads
+        if timings is not None:
+            timings["ingest_dedup"] = time.perf_counter() - t0
+        lens = offsets[1:] - offsets[:-1]
+        if len(counts) and (lens == 0).any():
+            keep = np.nonzero(lens > 0)[0]                          # at most one empty key
+            new_off = np.zeros(len(keep) + 1, dtype=np.uint64)
+            new_off[1:] = np.cumsum(lens[keep])
+            arena = np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in keep]) if len(keep) else np.zeros(0, dtype=np.uint8)
+            offsets, counts = new_off, counts[keep]
+        res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
+                              pe_scaffold_dna_info=pe_scaffold_dna_info)
     res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
     res.stats['N_READS_AFTER_PREPROCESSING'] = int(n_reads)
     return res

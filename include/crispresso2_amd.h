@@ -160,6 +160,19 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
                             const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
                             int64_t* d_counts, void* hip_stream);
 
+/* ---- multi-GPU: replaces CRISPRessoMultiProcessing's process pool + the variants_<k>.tsv exchange (CRISPRessoCORE.py:1870-1985) ----
+ * One process per GPU, reads sharded by contiguous ranges, no data-path collective; the per-amplicon count tensor of
+ * c2_count_vectors_device is the only thing exchanged: one RCCL all-reduce (sum, int64) over xGMI.
+ * c2_comm_unique_id: rank 0 obtains the 128-byte communicator id and hands it to the other ranks by any means (a file, MPI,
+ * torch.distributed's store); c2_comm_init: collective over all `world` ranks, binds the communicator to the context's GPU
+ * (librccl.so is bound at run time: the copy already loaded in the process, else the ROCm installation's);
+ * c2_reduce_counts: in-place all-reduce of n_elements int64 at the device pointer d_counts, enqueued on hip_stream. */
+#define C2_COMM_ID_BYTES 128
+int c2_comm_unique_id(uint8_t* out_id);
+int c2_comm_init(c2_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id);
+int c2_reduce_counts(c2_ctx* ctx, int64_t* d_counts, uint64_t n_elements, void* hip_stream);
+int c2_comm_destroy(c2_ctx* ctx);
+
 /* Strand and best-reference choice of get_new_variant_object (CRISPRessoCORE.py:683, :697-707, :710, :779-785) over the
  * records of an all-references batch: d_records is n_reads x n_refs (task = read * n_refs + reference).  Optional second
  * batch: d_records2 holds the reverse-complement alignments of the (read, reference) pairs whose seeds were inconclusive,

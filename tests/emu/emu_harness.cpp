@@ -78,6 +78,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     std::vector<uint32_t> plane;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0;
     A.mat_dim = sc.mat_dim; A.first_ext_code = sc.first_ext_code;
+    c2_build_base_luts(sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
+    if (no_packed) A.lut_chr_lo = A.lut_chr_hi = 0xffffffffu;
     A.diag_base = nullptr;
     if (!no_packed && n_refs > 0 && !drows[0].empty()) {
         // the references' row tables must sit in one buffer (the kernels index it relative to diag_base)

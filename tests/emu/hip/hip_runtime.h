@@ -143,6 +143,18 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
     return (int)(uint32_t)v;
 }
 inline long long clock64() { return 0; }
+inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned shift) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (shift & 31)); }
+// v_perm_b32 for selectors 0..7: byte i of the result = byte sel[i] of the 64-bit {hi, lo}
+inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned k = (sel >> (8 * i)) & 0xffu;
+        if (k > 7) { fprintf(stderr, "emu: unsupported v_perm selector %u\n", k); abort(); }
+        r |= (uint32_t)((v >> (8 * k)) & 0xffu) << (8 * i);
+    }
+    return r;
+}
 inline int __builtin_amdgcn_sbfe(int x, int off, int width) { return (int)((unsigned)x << (32 - off - width)) >> (32 - width); }
 inline unsigned long long __ballot(int pred) {
     emu::xl_slots[1][emu::cur_lane] = pred ? 1 : 0;

@@ -26,7 +26,7 @@ def build(force=False):
     srcs += [os.path.join(ROOT, "crispresso2_amd/csrc", f) for f in ("c2_kernels.hip", "c2_device.h", "c2_host_prep.h")]
     srcs.append(os.path.join(ROOT, "include/crispresso2_amd.h"))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-U_FORTIFY_SOURCE", "-D_FORTIFY_SOURCE=0", "-std=c++17", "-shared", "-fPIC", "-I", EMU_DIR,
+        subprocess.check_call(["g++", "-O1", "-U_FORTIFY_SOURCE", "-D_FORTIFY_SOURCE=0", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("C2_EMU_CFLAGS", "").split() + ["-I", EMU_DIR,
                                "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "crispresso2_amd/csrc"),
                                "-x", "c++", os.path.join(EMU_DIR, "emu_harness.cpp"), "-o", LIB])
 

@@ -815,3 +815,16 @@ def test_paired_fastq_files_equal_the_reference_run(mats, ctx, tmp_path):
         # one process, nothing on disk: same result
         cache1, not_aln1, st1 = P.process_paired_fastq(str(p1), str(p2), args, refs, names, mats["EDNAFULL"], ctx=ctx)
         assert st1 == st and list(cache1) == list(cache) and [cache1[k]["count"] for k in cache1] == exp["counts"]
+
+
+def test_count_reduce_through_the_c_abi_rccl(ctx):
+    """c2_comm_unique_id / c2_comm_init / c2_reduce_counts on the one GPU of this box: a communicator of one rank, the all-reduce
+    leaves the tensor as it is (the N-rank sum is covered by the gloo tests and by bench.py --gpus N through torch.distributed)."""
+    import torch
+    t = torch.arange(5000, dtype=torch.int64, device="cuda") * 3 - 7
+    want = t.clone()
+    ctx.comm_init(rank=0, world=1)
+    ctx.reduce_counts(t.data_ptr(), t.numel(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(t, want)
+    ctx.check(ctx.lib.c2_comm_destroy(ctx.handle), "c2_comm_destroy")
