@@ -115,8 +115,9 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="processes generating the synthetic reads (0 = auto; 1 = no fork, for profiler runs)")
     ap.add_argument("--band", type=int, default=-1, help="pointer-plane band: -1 auto, 0 off, n lanes each side")
     ap.add_argument("--band-wgs", type=int, default=0, help="target workgroups per CU for the automatic band")
-    ap.add_argument("--kernel", choices=["auto", "band", "full", "diag1", "diag2"], default="auto",
-                    help="kernel chain (auto = diagonal-band kernels with certificate, 4 -> 2 -> 1 alignments per wavefront)")
+    ap.add_argument("--kernel", choices=["auto", "band", "full", "diag1", "diag2", "diag4"], default="auto",
+                    help="kernel chain (auto = diagonal-band kernels with certificate: 8 alignments per wavefront in int16 pairs -> 2 -> 1; "
+                         "diag4 = the 32-bit chain 4 -> 2 -> 1)")
     ap.add_argument("--check", type=int, default=300, help="reads compared with the C oracle after the timed region (0 = no checks at all)")
     ap.add_argument("--no-full-plane-check", action="store_true", help="skip the chain-vs-full-plane comparison of every alignment")
     args = ap.parse_args()
@@ -373,8 +374,11 @@ def main():
 
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
-    chain_names = {"auto": ["c2_align_diagx_kernel<4>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
+    chain_names = {"auto": ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
+                   "diag4": ["c2_align_diagx_kernel<4>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
                    "diag2": ["c2_align_diagx_kernel<2>", "c2_align_diag_kernel"], "diag1": ["c2_align_diag_kernel"]}
+    if os.environ.get("C2_NO_PACKED_FILL"):
+        chain_names["auto"] = chain_names["diag4"]
     chain = ((chain_names.get(args.kernel, ["c2_align_diag_kernel"])[-len(tiers):] if band["band_lanes"] < 0 else
               ["c2_align_classify_kernel<%d, true>" % info["rows_per_lane"]] if band["band_lanes"] > 0 else [])
              + ["c2_align_classify_kernel<%d, false>" % info["rows_per_lane"]])

@@ -195,9 +195,10 @@ class Context:
         self.check(self.lib.c2_set_band(self.handle, int(band_lanes), int(target_workgroups_per_cu)), "c2_set_band")
 
     def set_kernel_mode(self, mode):
-        """'auto' (diagonal-band tiers 4 -> 2 -> 1 alignments per wavefront when applicable), 'band' (banded row-strip),
-        'full' (full-plane row-strip), 'diag1' (single-alignment diagonal-band kernel), 'diag2' (tiers 2 -> 1)"""
-        code = {'auto': 0, 'band': 1, 'full': 2, 'diag1': 3, 'diag2': 4}.get(mode, mode)
+        """'auto' (diagonal-band tiers: 8 alignments per wavefront in int16 pairs where the reference admits it, else 4; then 2; then
+        1), 'diag4' (tiers 4 -> 2 -> 1, 32-bit cells only), 'diag2' (2 -> 1), 'diag1' (single-alignment diagonal-band kernel),
+        'band' (banded row-strip), 'full' (full-plane row-strip)"""
+        code = {'auto': 0, 'band': 1, 'full': 2, 'diag1': 3, 'diag2': 4, 'diag4': 5}.get(mode, mode)
         self.check(self.lib.c2_set_kernel_mode(self.handle, int(code)), "c2_set_kernel_mode")
 
     def band_info(self, max_read_len):

@@ -55,8 +55,12 @@ struct c2_ctx {
     std::vector<std::string> ref_seq;
     std::vector<std::vector<int32_t>> ref_g32;
     std::vector<c2_dev_ref> ref_desc;
-    DevBuf d_diagrows;
+    DevBuf d_diagrows, d_diagrows_pk;   // row tables of the diagonal kernels: 32-bit records, and the packed (int16 pair) ones at the same indices
     bool diag_rows_dirty = true;
+    std::vector<uint8_t> ref_pk_ok;     // per reference: admitted to the packed fill (c2_pk_eligible)
+    bool any_pk_ok = false;
+    bool pk_dirty = true;
+    int occ_pk_lds = -1, occ_pk_blocks = 0;
     // staging for the host batch path and the per-call path
     DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;
     // timing
@@ -120,6 +124,7 @@ struct Geometry {
     int band_lanes; uint32_t lds_band; int blocks_band;   // banded first launch (band_lanes == 0: not used)
     bool diag; uint32_t lds_diag; int blocks_diag;         // diagonal-band launches
     bool x[2]; uint32_t lds_x[2]; int blocks_x[2]; uint32_t plane_words;   // multi-alignment tiers in front of it: 4, 2 per wavefront
+    bool pk; uint32_t lds_pk; int blocks_pk; uint32_t plane_words_pk;      // packed first tier (8 per wavefront, int16) in place of the 4-per-wavefront one
 };
 
 template <int R, bool BAND>
@@ -148,6 +153,19 @@ int occupancy_r(c2_ctx* ctx, int R, uint32_t lds, int& blocks) {
     }
 }
 
+// which references the packed (int16) fill may take: host-side arithmetic on the copies kept for the row tables
+void update_pk_eligibility(c2_ctx* ctx) {
+    if (!ctx->pk_dirty) return;
+    ctx->ref_pk_ok.assign((size_t)ctx->n_refs, 0);
+    ctx->any_pk_ok = false;
+    if (ctx->have_scoring && !getenv("C2_NO_PACKED_FILL"))
+        for (int r = 0; r < ctx->n_refs; ++r) {
+            ctx->ref_pk_ok[r] = c2_pk_eligible(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, 62) ? 1 : 0;
+            if (ctx->ref_pk_ok[r]) ctx->any_pk_ok = true;
+        }
+    ctx->pk_dirty = false;
+}
+
 int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     if (!ctx->have_scoring || ctx->n_refs <= 0) { ctx->err = "scoring and references must be set first"; return C2_E_STATE; }
     g.R = c2_choose_rows_per_lane(ctx->max_li);
@@ -166,8 +184,10 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     g.diag = false; g.lds_diag = 0; g.blocks_diag = 0;
     for (int t = 0; t < 2; ++t) { g.x[t] = false; g.lds_x[t] = 0; g.blocks_x[t] = 0; }
     g.plane_words = 0;
+    g.pk = false; g.lds_pk = 0; g.blocks_pk = 0; g.plane_words_pk = 0;
     const int km = ctx->kernel_mode;
-    if ((km == 0 || km == 3 || km == 4) && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
+    update_pk_eligibility(ctx);
+    if ((km == 0 || km == 3 || km == 4 || km == 5) && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
         g.lds_diag = c2_make_diag_plan(ctx->max_li, g.max_lj).total;
         if (const char* pad = getenv("C2_DEBUG_DIAG_LDS_PAD")) g.lds_diag += (uint32_t)atoi(pad);   // occupancy experiments
         if (g.lds_diag <= lds_cu) {
@@ -180,10 +200,24 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
             g.blocks_diag = ctx->occ_diag_blocks;
             g.diag = true;
         }
+        if (g.diag && km == 0 && ctx->any_pk_ok) {
+            // first tier: eight alignments per wavefront, two per lane group in int16 (c2_align_diagp_kernel)
+            const c2_diagx_plan PP = c2_make_diagx_plan(8, ctx->max_li, g.max_lj, true);
+            if (PP.total <= lds_cu) {
+                if (ctx->occ_pk_lds != (int)PP.total) {
+                    int nb = 0;
+                    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_diagp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_diagp_kernel<8>, 64, PP.total));
+                    ctx->occ_pk_blocks = nb < 1 ? 1 : nb; ctx->occ_pk_lds = (int)PP.total;
+                }
+                g.pk = true; g.lds_pk = PP.total; g.blocks_pk = ctx->occ_pk_blocks; g.plane_words_pk = PP.n_words * 128u;   // 8 slots x 16 lanes
+            }
+        }
         for (int t = 0; t < 2 && g.diag && km != 3; ++t) {
             const int na = t == 0 ? C2_TIER0_NA : 2;
-            if (t == 0 && km == 4) continue;                                   // mode 4: 2 -> 1
-            const c2_diagx_plan PX = c2_make_diagx_plan(na, ctx->max_li, g.max_lj);
+            if (t == 0 && (km == 4 || g.pk)) continue;                         // mode 4: 2 -> 1; the packed tier stands in for the 4-per-wavefront one
+            c2_diagx_plan PX = c2_make_diagx_plan(na, ctx->max_li, g.max_lj);
+            if (const char* pad = getenv("C2_DEBUG_X_LDS_PAD")) PX.total += (uint32_t)atoi(pad);   // occupancy experiments
             if (PX.total > lds_cu) continue;
             const void* fn = t == 0 ? (const void*)c2_align_diagx_kernel<C2_TIER0_NA> : (const void*)c2_align_diagx_kernel<2>;
             if (ctx->occ_x_lds[t] != (int)PX.total) {
@@ -255,10 +289,22 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
             T.work_counter = (unsigned long long*)(hdr + 4 + 2 * tier);
         };
         if (g.diag) {
-            {   // one scratch plane, sized for the tier with the most resident workgroups (no reallocation between launches)
+            {   // one scratch plane, sized for the tier that needs the most (no reallocation between launches)
                 uint64_t most = 0;
-                for (int t = 0; t < 2; ++t) if (g.x[t]) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_x[t]);
-                if (most && (rc = ensure(ctx, ctx->d_plane, (size_t)most * g.plane_words * sizeof(uint32_t)))) return rc;
+                for (int t = 0; t < 2; ++t) if (g.x[t]) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_x[t] * g.plane_words);
+                if (g.pk) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk * g.plane_words_pk);
+                if (most && (rc = ensure(ctx, ctx->d_plane, (size_t)most * sizeof(uint32_t)))) return rc;
+            }
+            if (g.pk) {
+                const uint64_t resident = cus * (uint64_t)g.blocks_pk;
+                const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + 7) / 8, resident));
+                c2_align_args T = A;
+                chain(T);
+                T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = g.plane_words_pk;
+                hipLaunchKernelGGL(c2_align_diagp_kernel<8>, dim3(grid), dim3(64), g.lds_pk, s, T);
+                HIPCHK(ctx, hipGetLastError());
+                mark_first();
+                ++tier;
             }
             for (int t = 0; t < 2; ++t) {
                 if (!g.x[t]) continue;
@@ -310,12 +356,19 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
 // (Re)build the per-reference row tables of the diagonal-band kernel after the references or the scoring changed.
 int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
     if (!ctx->diag_rows_dirty) return 0;
-    std::vector<c2_diag_row> all, one;
+    std::vector<c2_diag_row> all, one, allpk;
     std::vector<size_t> off(ctx->n_refs, 0);
+    update_pk_eligibility(ctx);
     for (int r = 0; r < ctx->n_refs; ++r) {
         c2_build_diag_rows(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, one);
         off[r] = all.size();
         all.insert(all.end(), one.begin(), one.end());
+        if (ctx->any_pk_ok) {                                      // the packed tables mirror the indexing; a reference that is not admitted gets padding
+            const size_t want = one.size();
+            if (ctx->ref_pk_ok[r]) c2_build_diag_rows_pk(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, one);
+            else one.assign(want, c2_diag_row{0, 0, 0, 5u * 256u});
+            allpk.insert(allpk.end(), one.begin(), one.end());
+        }
     }
     HIPCHK(ctx, hipDeviceSynchronize());      // (any stream may still run kernels that read the old row tables)
     int rc;
@@ -323,8 +376,14 @@ int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
         if ((rc = ensure(ctx, ctx->d_diagrows, all.size() * sizeof(c2_diag_row)))) return rc;
         HIPCHK(ctx, hipMemcpy(ctx->d_diagrows.p, all.data(), all.size() * sizeof(c2_diag_row), hipMemcpyHostToDevice));
     }
-    for (int r = 0; r < ctx->n_refs; ++r)
+    if (!allpk.empty()) {
+        if ((rc = ensure(ctx, ctx->d_diagrows_pk, allpk.size() * sizeof(c2_diag_row)))) return rc;
+        HIPCHK(ctx, hipMemcpy(ctx->d_diagrows_pk.p, allpk.data(), allpk.size() * sizeof(c2_diag_row), hipMemcpyHostToDevice));
+    }
+    for (int r = 0; r < ctx->n_refs; ++r) {
         ctx->ref_desc[r].diag_rows = all.empty() ? nullptr : (const c2_diag_row*)ctx->d_diagrows.p + off[r] + C2_DIAG_ROW_PAD;
+        ctx->ref_desc[r].pk_ok = (!allpk.empty() && ctx->ref_pk_ok[r]) ? 1 : 0;
+    }
     HIPCHK(ctx, hipMemcpy(ctx->d_refdesc.p, ctx->ref_desc.data(), sizeof(c2_dev_ref) * (size_t)ctx->n_refs, hipMemcpyHostToDevice));
     ctx->diag_rows_dirty = false;
     return 0;
@@ -349,6 +408,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.max_lj = g.max_lj; A.max_passes = g.passes;
     A.max_li = ctx->max_li;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
+    A.diagpk_base = ctx->any_pk_ok ? (const c2_diag_row*)ctx->d_diagrows_pk.p : nullptr;
     A.mat_dim = ctx->sc.mat_dim; A.first_ext_code = ctx->sc.first_ext_code;
     c2_build_base_luts(ctx->sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
     {
@@ -407,7 +467,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_diagrows_pk, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel};
     for (DevBuf* b : all) release(*b);
     (void)c2_comm_destroy(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -420,7 +480,7 @@ int c2_set_scoring(c2_ctx* ctx, const int64_t* matrix, int32_t mat_dim, int32_t 
     const size_t nel = (size_t)mat_dim * (size_t)mat_dim;
     const bool same = ctx->have_scoring && ctx->matrix_copy.size() == nel && matrix &&
                       memcmp(ctx->matrix_copy.data(), matrix, nel * sizeof(int64_t)) == 0;
-    if (ctx->gap_open != gap_open || ctx->gap_extend != gap_extend) ctx->diag_rows_dirty = true;
+    if (ctx->gap_open != gap_open || ctx->gap_extend != gap_extend) { ctx->diag_rows_dirty = true; ctx->pk_dirty = true; }
     ctx->gap_open = gap_open; ctx->gap_extend = gap_extend;
     if (same) return 0;
     c2_scoring_tables sc;
@@ -437,7 +497,7 @@ int c2_set_scoring(c2_ctx* ctx, const int64_t* matrix, int32_t mat_dim, int32_t 
     ctx->sc = sc;
     ctx->matrix_copy.assign(matrix, matrix + nel);
     ctx->have_scoring = true;
-    ctx->diag_rows_dirty = true;
+    ctx->diag_rows_dirty = true; ctx->pk_dirty = true;
     return 0;
 }
 
@@ -476,7 +536,7 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         desc[r].gap_incentive = (const int32_t*)(base + off_g[r]);
         desc[r].inc_prefix = (const uint16_t*)(base + off_p[r]);
         desc[r].len = lens[r];
-        desc[r].diag_rows = nullptr;
+        desc[r].diag_rows = nullptr; desc[r].pk_ok = 0; desc[r].reserved1 = 0;
         int64_t gm = 0;                                          // over the values the kernels add: the reference's C ints
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)(int32_t)gap_incentives[r][k]);
         desc[r].gap_incentive_max = (int32_t)std::min<int64_t>(gm, 1 << 20);
@@ -497,7 +557,7 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         for (int k = 0; k <= lens[r]; ++k) ctx->ref_g32[r][k] = (int32_t)gap_incentives[r][k];
     }
     ctx->ref_desc = desc;
-    ctx->diag_rows_dirty = true;
+    ctx->diag_rows_dirty = true; ctx->pk_dirty = true;
     return 0;
 }
 
@@ -524,7 +584,7 @@ int c2_set_band(c2_ctx* ctx, int32_t band_lanes, int32_t target_workgroups_per_c
 }
 
 int c2_set_kernel_mode(c2_ctx* ctx, int32_t mode) {
-    if (!ctx || mode < 0 || mode > 4) return C2_E_INVALID;
+    if (!ctx || mode < 0 || mode > 5) return C2_E_INVALID;
     ctx->kernel_mode = mode;
     return 0;
 }

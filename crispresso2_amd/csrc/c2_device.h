@@ -39,6 +39,8 @@ typedef struct c2_dev_ref {
     int32_t gap_incentive_max;    // max(0, max_i gap_incentive[i]); max(gap_open, gap_extend) + this bounds what one gap base adds to a score
     int32_t gap_incentive_last_pos; // gap_incentive[Li] > 0: insertions along the last row collect an incentive without paying an open
     int32_t max_char;             // largest byte of seq (a read character >= the matrix dimension is defined iff max_char * dim + it < dim * dim)
+    int32_t pk_ok;                // admitted to the int16 fill of c2_align_diagp_kernel (c2_pk_eligible); its packed row table sits at the same index in diagpk_base
+    int32_t reserved1;
 } c2_dev_ref;
 
 // Kernel arguments for the fused align + traceback + classify kernel.
@@ -80,6 +82,7 @@ typedef struct c2_align_args {
     uint32_t lut_code_lo, lut_code_hi;  // 8-entry byte tables indexed by (ch >> 1) & 7 (A 0, C 1, T 2, G 3, N 7): the score-table code of that base ...
     uint32_t lut_chr_lo, lut_chr_hi;    // ... and the base itself (0xFF where the entry is no base or its code is not a packed one): v_perm_b32 look-ups
     const struct c2_diag_row* diag_base;   // start of the buffer every reference's diag_rows points into
+    const struct c2_diag_row* diagpk_base; // the packed kernels' row tables, same indexing: {a, b, c} as int16 pairs, prof = LDS offset of the symbol's pair-score table
 } c2_align_args;
 
 // Kernel arguments for the per-call classifier (find_indels_substitutions / _legacy with full lists).

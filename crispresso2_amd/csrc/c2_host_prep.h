@@ -138,6 +138,46 @@ inline void c2_build_diag_rows(const char* seq, int Li, const int32_t* g32, cons
     }
 }
 
+// ---- the packed (int16, two alignments per lane) fill of c2_align_diagp_kernel -------------------------------------------
+// A reference is admitted if every DP value the banded fill can hold provably fits an int16 around the kernel's bias
+// (C2_PK_BIAS = 16384) with room for the pointer-bit differences, and if the reference's finite sentinel
+// min_score = gap_open * Li * Lj lies below every real value anyway (so that replacing it by -bias changes no comparison):
+//   hi  = most a real cell value can be: max(0, max score) per diagonal step
+//   lo  = how far below zero a real cell value can lie: every in-band cell is reached by a near-diagonal in-band path
+//         (diagonal steps at the worst score, one gap run of at most band + 4 bases, a few opens)
+// over alignments whose read is within `band` bases of the reference's length (wider differences never enter this kernel).
+inline bool c2_pk_eligible(const char* seq, int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend, int band) {
+    if (sc.pk.empty() || Li <= 0) return false;
+    for (int i = 0; i < Li; ++i) if (sc.code_of_char[(unsigned char)seq[i]] >= 5) return false;      // pair-score tables exist for codes 0..4 (A C G T N)
+    int64_t smax = 0, smin = 0, gabs = 0;
+    for (int16_t v : sc.tbl) { smax = std::max<int64_t>(smax, v); smin = std::min<int64_t>(smin, v); }
+    for (int i = 0; i <= Li; ++i) gabs = std::max<int64_t>(gabs, g32[i] < 0 ? -(int64_t)g32[i] : (int64_t)g32[i]);
+    const int64_t go = gap_open < 0 ? -(int64_t)gap_open : gap_open, ge = gap_extend < 0 ? -(int64_t)gap_extend : gap_extend;
+    if (go + gabs > 2000 || ge + gabs > 2000) return false;
+    const int64_t L = (int64_t)Li + band;
+    const int64_t hi = smax * L, lo = L * (-smin) + 4 * go + (band + 4) * (ge + gabs);
+    if (hi + lo > 14000) return false;
+    if (gap_open >= 0 || (int64_t)(-gap_open) * Li * std::max<int64_t>(1, Li - band) <= hi + lo + 64) return false;   // the sentinel must be out of reach
+    return true;
+}
+
+// Row records of the packed kernel for one reference, same indexing as c2_build_diag_rows: {a, b, c} duplicated into both
+// int16 halves, prof = byte offset of the reference symbol's pair-score table (code * 256; table 5 = zeros for rows 0, Li+1
+// and the padding, so that cells outside the matrix add nothing -- as with the 32-bit records' empty score row).
+inline void c2_build_diag_rows_pk(const char* seq, int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend,
+                                  std::vector<c2_diag_row>& out) {
+    out.assign((size_t)Li + 2 + 2 * C2_DIAG_ROW_PAD, c2_diag_row{0, 0, 0, 5u * 256u});
+    auto dup = [](int x) { return (int32_t)(((uint32_t)x & 0xffffu) | ((uint32_t)x << 16)); };
+    for (int i = 1; i <= Li; ++i) {
+        const int open = (i == Li) ? gap_extend : gap_open;
+        c2_diag_row r;
+        r.a = dup(open + g32[i]); r.b = dup(gap_extend + g32[i]); r.c = dup(open + g32[i - 1]);
+        const uint8_t code = sc.code_of_char[(unsigned char)seq[i - 1]];
+        r.prof = (code < 5 ? (uint32_t)code : 5u) * 256u;
+        out[C2_DIAG_ROW_PAD + i] = r;
+    }
+}
+
 // rows per lane for the systolic sweep: smallest R in 1..4 whose single pass covers max_li, else 4
 inline int c2_choose_rows_per_lane(int max_li) {
     for (int R = 1; R <= 4; ++R) if (max_li <= 64 * R) return R;

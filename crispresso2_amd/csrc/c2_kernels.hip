@@ -413,10 +413,13 @@ __device__ __forceinline__ void c2_stage_ref(const c2_align_args& A, const c2_wg
     }
 }
 
+// code_shift / code_or (packed kernel): the column table holds pair symbols, code A << 5 | code B << 2 -- the first alignment of
+// a lane group writes its codes shifted by 5 (and the zeros around them), the second ORs its codes in shifted by 2.
 template <bool HAVE_B4 = true>
 __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_wg& W, const unsigned char* sCodeOf, const c2_prefetch& pf,
                                               const int lane, const int max_li, int& cur_ref, int& Li, int& g0, int& ref_bad, bool& packed,
-                                              unsigned char* sCodes4 = nullptr, uint32_t* sWin = nullptr)
+                                              unsigned char* sCodes4 = nullptr, uint32_t* sWin = nullptr, const int code_shift = 2, const bool code_or = false,
+                                              const bool stage_ref = true)
 {
     // sCodes4 (multi-alignment kernel): the zero-padded table of 4 * code per column, written in the same pass -- columns
     // 1 .. Lj at sCodes4[C2_DIAG_CODE_PAD + 1 ..]; the zeros in front are written once per kernel, the nine behind per task
@@ -424,7 +427,7 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
     int status = 0;
     int read_code_max = 0;
     const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
-    if (pf.ref_id != cur_ref) {
+    if (stage_ref && pf.ref_id != cur_ref) {
         cur_ref = pf.ref_id;
         c2_stage_ref(A, W, sCodeOf, pf.ref_id, lane, max_li, Li, g0, ref_bad, sWin);
     }
@@ -443,11 +446,14 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
         const unsigned char code = sCodeOf[ch];
         if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
         W.sRead[k] = ch;
-        if (sCodes4) sCodes4[C2_DIAG_CODE_PAD + 1 + k] = (unsigned char)(code << 2);   // (the multi-alignment kernel reads only this table)
+        if (sCodes4) {                                                               // (the multi-alignment kernels read only this table)
+            const unsigned char cv = (unsigned char)((code & 7u) << code_shift);
+            if (code_or) sCodes4[C2_DIAG_CODE_PAD + 1 + k] |= cv; else sCodes4[C2_DIAG_CODE_PAD + 1 + k] = cv;
+        }
         else W.sCode[k] = code;
         read_code_max = read_code_max > (int)code ? read_code_max : (int)code;
     }
-    if (sCodes4 && lane < 9) sCodes4[C2_DIAG_CODE_PAD + 1 + LjLoad + lane] = 0;
+    if (sCodes4 && !code_or && lane < 16) sCodes4[C2_DIAG_CODE_PAD + 1 + LjLoad + lane] = 0;   // (16: the packed kernel's OR pass touches whole dwords)
     if (ref_bad) status |= C2_STATUS_OOB_CHAR;
     if (Li <= 0 || Lj <= 0) status |= C2_STATUS_EMPTY;
     if (Lj > A.max_lj || Li > max_li) status |= C2_STATUS_TOO_LONG;
@@ -704,13 +710,19 @@ __device__ __forceinline__ void c2_emit_gapless4(const c2_align_args& A, const c
     if (todo) {
         const uint32_t y = rd ^ 0x4e4e4e4eu;                                         // COREResources.pyx:113-118: a read 'N' is no substitution
         const uint32_t sub = mm & ((((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u);
-        const uint32_t win = sub & sWin[lane];
+        const uint32_t win = sWin ? (sub & sWin[lane]) : 0u;
         while (todo) {                                                               // (a read of an amplicon run differs in a lane or two)
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1ull;
             mism += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)mm, l));
-            n_all_sub += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)sub, l));
-            n_win_sub += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)win, l));
+            const unsigned subl = (unsigned)__builtin_amdgcn_readlane((int)sub, l);
+            n_all_sub += __builtin_popcount(subl);
+            if (sWin) n_win_sub += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)win, l));
+            else if (subl) {                                                         // no mask table (packed kernel): the window prefix counts of the lane's four positions
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if ((subl >> (8 * b + 7)) & 1u) n_win_sub += (W.sIncP[4 * l + b + 1] != W.sIncP[4 * l + b]) ? 1 : 0;
+            }
         }
     }
     const unsigned char r0 = W.sRead[0], f0 = W.sRef[0], rL = W.sRead[L - 1], fL = W.sRef[L - 1];
@@ -984,6 +996,97 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Packed fill (c2_align_diagp_kernel): TWO alignments per lane, 16 bits each.  A lane group sweeps two reads of the same
+// length against the same reference; every DP value is an int16 with C2_PK_BIAS added (0 = "outside the band" = what a DPP read
+// with bound_ctrl returns, in both halves), every recurrence one v_pk_*_i16 instruction for both.  The host admits a
+// reference to this kernel only if its DP values provably stay inside int16 around the bias (c2_pk_eligible): the reference's
+// finite sentinel min_score = gap_open * Li * Lj is replaced by -C2_PK_BIAS (the number 0), which changes no comparison a
+// traceback can see: sentinel-derived values keep their order among themselves (same offsets) and stay below every real value.
+// Pointer bits: the sign of four packed differences per cell, shifted into a 16-bit shift register per alignment
+// (v_pk_lshrrev_b16 + v_and_or_b32) -- 24 VALU instructions per anti-diagonal step for the two alignments, against 2 x 18.9.
+// ---------------------------------------------------------------------------------------------------------------
+#define C2_PK_BIAS 16384
+#define C2_PK_LUT_CODES 6                     // reference symbols with codes 0..4 (A C G T N), plus an all-zero table (index 5) for the padding rows
+#define C2_PK_PAD_TABLE 5
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef short c2_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short c2_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned c2_pk_add(const unsigned a, const unsigned b) { return __builtin_bit_cast(unsigned, (c2_s16x2)(__builtin_bit_cast(c2_s16x2, a) + __builtin_bit_cast(c2_s16x2, b))); }
+__device__ __forceinline__ unsigned c2_pk_sub(const unsigned a, const unsigned b) { return __builtin_bit_cast(unsigned, (c2_s16x2)(__builtin_bit_cast(c2_s16x2, a) - __builtin_bit_cast(c2_s16x2, b))); }
+__device__ __forceinline__ unsigned c2_pk_max(const unsigned a, const unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(c2_s16x2, a), __builtin_bit_cast(c2_s16x2, b))); }
+__device__ __forceinline__ unsigned c2_pk_lshr(const unsigned a, const int n) { return __builtin_bit_cast(unsigned, (c2_u16x2)(__builtin_bit_cast(c2_u16x2, a) >> (c2_u16x2)(unsigned short)n)); }
+#else
+__device__ __forceinline__ unsigned c2_pk_add(const unsigned a, const unsigned b) { return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16); }
+__device__ __forceinline__ unsigned c2_pk_sub(const unsigned a, const unsigned b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
+__device__ __forceinline__ unsigned c2_pk_max(const unsigned a, const unsigned b) {
+    const int al = (int16_t)(a & 0xffffu), bl = (int16_t)(b & 0xffffu), ah = (int16_t)(a >> 16), bh = (int16_t)(b >> 16);
+    return ((unsigned)(al > bl ? al : bl) & 0xffffu) | ((unsigned)(ah > bh ? ah : bh) << 16);
+}
+__device__ __forceinline__ unsigned c2_pk_lshr(const unsigned a, const int n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
+#endif
+__host__ __device__ inline unsigned c2_pk_dup(const int x) { return ((unsigned)x & 0xffffu) | ((unsigned)x << 16); }   // the same int16 in both halves
+
+struct c2_pk_state {
+    unsigned ME, IE, JE, HE;         // latest cell of the even diagonal, two alignments packed
+    unsigned MO, IO, JO, HO;         // latest cell of the odd diagonal
+    unsigned acc;                    // pointer bits of the word in the making: a 16-bit shift register per alignment, newest bit on top
+    unsigned gf;                     // AND of the finished words (gap-free predicate: bits 2, 3 of the E cells' nibbles all set)
+};
+
+// one pointer bit per alignment: the sign of `d` (bits 15 and 31) enters the two shift registers
+__device__ __forceinline__ void c2_pk_push(unsigned& acc, const unsigned d) { acc = c2_pk_lshr(acc, 1) | (d & 0x80008000u); }
+// a cell that is not computed: nibble 0011 in push order = "nothing opened, H is not I, M beats J" (neutral for the gap-free predicate)
+__device__ __forceinline__ void c2_pk_push_none(unsigned& acc) { acc = c2_pk_lshr(acc, 4) | 0xC000C000u; }
+
+// One pair of steps (E cell on anti-diagonal a = 2k, O cell on a + 1) for both alignments of the lane.  rowE / rowO: packed row
+// constants {a, b, c} (both halves equal: the two reads share the reference); sE / sO: the score pairs of the two cells.
+template <bool MASK, bool LASTCOL>
+__device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2_diag_row rowE, const c2_diag_row rowO, const unsigned sE, const unsigned sO,
+                                           const unsigned ge2, const int startE, const int startO, const bool lastcol)
+{
+    const unsigned upM = (unsigned)c2_shr1z((int)S.MO);
+    const unsigned upJ = (unsigned)c2_shr1z((int)S.JO);
+    if (!MASK || a >= startE) {
+        const unsigned corr = (LASTCOL && lastcol) ? c2_pk_sub((unsigned)rowE.b, (unsigned)rowE.a) : 0u;
+        const unsigned iFromM = c2_pk_add(c2_pk_add(S.MO, (unsigned)rowE.a), corr);
+        const unsigned iExt = c2_pk_add(S.IO, (unsigned)rowE.b);
+        const unsigned jFromM = c2_pk_add(c2_pk_add(upM, (unsigned)rowE.c), corr);
+        const unsigned jExt = c2_pk_add(upJ, ge2);
+        const unsigned In = c2_pk_max(iFromM, iExt);
+        const unsigned Jn = c2_pk_max(jFromM, jExt);
+        const unsigned Mn = c2_pk_add(S.HE, sE);
+        const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
+        c2_pk_push(S.acc, c2_pk_sub(iExt, iFromM));           // I opened   (iFromM > iExt)
+        c2_pk_push(S.acc, c2_pk_sub(jExt, jFromM));           // J opened   (jFromM > jExt)
+        c2_pk_push(S.acc, c2_pk_sub(In, Hn));                 // NOT H is I (In < Hn; In <= Hn always)
+        c2_pk_push(S.acc, c2_pk_sub(Jn, Mn));                 // NOT J beats M (Jn < Mn)
+        S.ME = Mn; S.IE = In; S.JE = Jn; S.HE = Hn;
+    } else {
+        c2_pk_push_none(S.acc);
+    }
+    const unsigned lfM = (unsigned)c2_shl1z((int)S.ME);
+    const unsigned lfI = (unsigned)c2_shl1z((int)S.IE);
+    if (!MASK || a + 1 >= startO) {
+        const unsigned corr = (LASTCOL && lastcol) ? c2_pk_sub((unsigned)rowO.b, (unsigned)rowO.a) : 0u;
+        const unsigned iFromM = c2_pk_add(c2_pk_add(lfM, (unsigned)rowO.a), corr);
+        const unsigned iExt = c2_pk_add(lfI, (unsigned)rowO.b);
+        const unsigned jFromM = c2_pk_add(c2_pk_add(S.ME, (unsigned)rowO.c), corr);
+        const unsigned jExt = c2_pk_add(S.JE, ge2);
+        const unsigned In = c2_pk_max(iFromM, iExt);
+        const unsigned Jn = c2_pk_max(jFromM, jExt);
+        const unsigned Mn = c2_pk_add(S.HO, sO);
+        const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
+        c2_pk_push(S.acc, c2_pk_sub(iExt, iFromM));
+        c2_pk_push(S.acc, c2_pk_sub(jExt, jFromM));
+        c2_pk_push(S.acc, c2_pk_sub(In, Hn));
+        c2_pk_push(S.acc, c2_pk_sub(Jn, Mn));
+        S.MO = Mn; S.IO = In; S.JO = Jn; S.HO = Hn;
+    } else {
+        c2_pk_push_none(S.acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Multi-alignment diagonal-band kernel: NA (2 or 4) alignments share one wavefront.  One anti-diagonal step costs the
 // same ~19 VALU issues whether 64, 31 or 15 of the lanes hold diagonals that matter, and an amplicon read rarely needs
 // more than a few diagonals either side of the corner-to-corner one -- so the wavefront is cut into NA lane groups of
@@ -1000,18 +1103,43 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
 // ---------------------------------------------------------------------------------------------------------------
 struct c2_diagx_plan {
     uint32_t codeof, table, tmp_read, tmp_ref, stage, slot0, slot_bytes, total, n_words;
+    uint32_t pairlut, pcodes0, pcodes_bytes, group0, group_bytes, gref, gincp;   // packed kernels only
     uint32_t codes, read, code, ref, incp, win;                     // offsets inside one alignment's slot
 };
 
-__host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, int max_lj) {
+__host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, int max_lj, bool pk = false) {
     c2_diagx_plan p;
+    const uint32_t lpa = 64u / (uint32_t)(pk ? na / 2 : na);        // lanes of one lane group (pk: two alignments share a group, 16 bits each)
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
     uint32_t off = 0;
     p.codeof = off;   off += 256u;                                  // character -> code
     p.table = off;    off += 8u * 24u * 4u;                         // up to 8 slots x C2X_INTS
     p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
     p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
-    p.stage = off;    off += p.n_words * (64u / (uint32_t)na) * 4u; // pointer words of the alignment being traced
+    p.stage = off;    off += p.n_words * lpa * 4u;                  // pointer words of the alignment being traced
+    p.pairlut = off;  p.pcodes0 = off; p.pcodes_bytes = 0; p.group0 = off; p.group_bytes = 0; p.gref = 0; p.gincp = 0;
+    if (pk) {
+        // LDS is what limits the resident waves of this kernel (8 alignments per wavefront), so its layout is lean: the lane
+        // groups' column tables share the bytes of the two traceback strings (the fill is over when a traceback starts; the
+        // staging rewrites the tables, zeros in front included, every time); reference + window prefix once per lane group (its
+        // two alignments share the reference); per alignment only the read
+        p.pcodes_bytes = c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 16u);   // per lane group: (code A << 5 | code B << 2) per column
+        p.pcodes0 = p.tmp_read;
+        const uint32_t need = (uint32_t)(na / 2) * p.pcodes_bytes, have = 2u * c2_align16((uint32_t)max_li + (uint32_t)max_lj);
+        if (need > have) { off += need - have; }                    // (tmp_read, tmp_ref, stage are consecutive: the tables may run into `stage`, which is rewritten before use too)
+        p.stage = p.tmp_ref + c2_align16((uint32_t)max_li + (uint32_t)max_lj) + (need > have ? need - have : 0u);
+        off = p.stage + p.n_words * lpa * 4u;
+        p.pairlut = off;  off += (uint32_t)C2_PK_LUT_CODES * 256u;  // per reference symbol: the score pair of every (symbol of read A, symbol of read B)
+        p.group0 = off;
+        p.gref = 0; p.gincp = c2_align16((uint32_t)max_li);
+        p.group_bytes = p.gincp + c2_align16(((uint32_t)max_li + 2u) * 2u);
+        off += (uint32_t)(na / 2) * p.group_bytes;
+        p.slot0 = off;
+        p.codes = 0; p.read = 0; p.code = 0; p.ref = 0; p.incp = 0; p.win = 0;
+        p.slot_bytes = c2_align16((uint32_t)max_lj);
+        p.total = p.slot0 + (uint32_t)na * p.slot_bytes;
+        return p;
+    }
     p.slot0 = off;
     uint32_t so = 0;
     p.codes = so;    so += c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 16u);  // zeros | columns 0 .. Lj+1 | zeros (the staging writes them as dwords: up to 15 behind column Lj)
@@ -1027,12 +1155,17 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
 
 // pointer words of ONE alignment, staged in LDS: [group of 8 anti-diagonals][lane of the alignment's lane group]
 struct c2_diagx_plane {
-    const unsigned* words; int d0, lpa;
+    const unsigned* words; int d0, lpa; bool pk;
     __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
         const int sl = (pi - pj - d0) >> 1;                              // lane of the cell's diagonal inside its group
         if ((unsigned)sl >= (unsigned)(lpa - 1)) return false;
         const int a = pi + pj;
-        nib = (words[(a >> 3) * lpa + sl] >> (4 * (7 - (a & 7)))) & 0xF;
+        const unsigned w = words[(a >> 3) * lpa + sl];
+        if (!pk) { nib = (w >> (4 * (7 - (a & 7)))) & 0xF; return true; }
+        // packed kernels (c2_pk_push): anti-diagonal 8g + c in bits 4c .. 4c+3, oldest push lowest: I opened, J opened, NOT "H is I",
+        // NOT "J beats M"
+        const unsigned n = (w >> (4 * (a & 7))) & 0xF;
+        nib = ((n & 1u) << 3) | ((n & 2u) << 1) | ((~n >> 1) & 2u) | ((~n >> 3) & 1u);
         return true;
     }
 };
@@ -1270,22 +1403,92 @@ __device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_re
 __device__ __forceinline__ int c2_tab_load(const int* T, const int lane) { return T[lane < C2X_INTS ? lane : 0]; }
 #define C2_TF(v, k) __builtin_amdgcn_readlane((v), (k))
 
-template <int NA>
-__global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
+// ---- packed fill: one group = four pairs = eight anti-diagonals = one pointer word per lane AND PER ALIGNMENT.
+// Rows come from the packed row table (A.diagpk_base: {a, b, c} duplicated into both halves, and the LDS offset of the reference
+// symbol's pair-score table), columns from the lane group's pair-symbol table; the eight score pairs of the group are LDS
+// look-ups (row table offset + pair symbol), requested at the top of the group.
+struct c2_pk_cap { unsigned H, gf; };                              // the two alignments' H(Li, Lj) and gap-free words, captured at the cell (Li, Lj)
+
+template <bool MASK, bool LASTCOL>
+__device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
+                                            const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
+                                            const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
+                                            unsigned* wordsA, unsigned* wordsB, const int wordStride)
 {
-    constexpr int LPA = 64 / NA, NL = LPA - 1, BANDW = 2 * NL;       // lanes per alignment, live lanes, diagonals per band
-    const int lane = threadIdx.x, slot = lane / LPA, sl = lane - slot * LPA;
-    const c2_diagx_plan P = c2_make_diagx_plan(NA, A.max_li, A.max_lj);
+    RN[0] = R[4];
+    c2_diagx_fetch<false>(g + 1, L, rows, lds, RN, CN);
+    unsigned sc[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[2 * q] = *(const unsigned*)(lds + lutBase + R[q].prof + (unsigned)C[q]);
+        sc[2 * q + 1] = *(const unsigned*)(lds + lutBase + R[q + 1].prof + (unsigned)C[q]);
+    }
+    unsigned w0 = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = 4 * g + q;
+        c2_pk_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], sc[2 * q], sc[2 * q + 1], ge2, L.startE, L.startO, LASTCOL && (k == L.kLast));
+        if (q == 1) { w0 = S.acc; S.gf &= w0; }                    // anti-diagonals 8g .. 8g+3 of both alignments
+        if (q == 3) S.gf &= S.acc;                                  // ... 8g+4 .. 8g+7
+        if (LASTCOL && k == L.kCap) {
+            CAP.H = L.capOdd ? S.HO : S.HE;
+            // q even: the word in the making holds two cells so far, the E cell in bits 8..11 of each half
+            CAP.gf = (q & 1) ? S.gf : (S.gf & (S.acc | 0xF3FFF3FFu));
+        }
+    }
+    // alignment A's word: the low halves, alignment B's: the high halves (anti-diagonal 8g + c in bits 4c .. 4c+3)
+    wordsA[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x05040100u);
+    wordsB[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x07060302u);
+}
+
+template <bool MASK, bool LASTCOL>
+__device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
+                                             c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
+                                             const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
+                                             unsigned* wordsA, unsigned* wordsB, const int wordStride)
+{
+    for (; g + 1 <= g_stop; g += 2) {
+        c2_pk_group<MASK, LASTCOL>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL>(S, g + 1, L, ge2, CAP, RB, CB, RA, CA, rows, lds, lutBase, wordsA, wordsB, wordStride);
+    }
+    if (g <= g_stop) {
+        c2_pk_group<MASK, LASTCOL>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        ++g;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) RA[q] = RB[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) CA[q] = CB[q];
+    }
+}
+
+template <int NA, bool PK>
+__device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
+{
+    // PK (c2_align_diagp_kernel): NA alignments in NA / 2 lane groups, two per group (slots 2g and 2g+1 in the two halves of the lanes' registers)
+    constexpr int NG = PK ? NA / 2 : NA;                             // lane groups
+    constexpr int LPA = 64 / NG, NL = LPA - 1, BANDW = 2 * NL;       // lanes per group, live lanes, diagonals per band
+    const int lane = threadIdx.x, grp = lane / LPA, sl = lane - grp * LPA;
+    const int slot = PK ? 2 * grp : grp;                             // (PK: the group's first slot)
+    const c2_diagx_plan P = c2_make_diagx_plan(NA, A.max_li, A.max_lj, PK);
     unsigned char* sCodeOf = c2_smem + P.codeof;
     int* sTab = (int*)(c2_smem + P.table);
     auto wg_of = [&](const int s) {
         unsigned char* base = c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes;
         c2_wg W;
-        W.sRead = base + P.read; W.sCode = base + P.code; W.sRef = base + P.ref;
-        W.sIncP = (uint16_t*)(base + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
+        if (PK) {                                                  // the read per alignment, reference and window prefix per lane group
+            unsigned char* gb = c2_smem + P.group0 + (uint32_t)(s >> 1) * P.group_bytes;
+            W.sRead = base; W.sCode = nullptr; W.sRef = gb + P.gref; W.sIncP = (uint16_t*)(gb + P.gincp);
+        } else {
+            W.sRead = base + P.read; W.sCode = base + P.code; W.sRef = base + P.ref; W.sIncP = (uint16_t*)(base + P.incp);
+        }
+        W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
         return W;
     };
-    auto win_of = [&](const int s) { return (uint32_t*)(c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.win); };
+    auto win_of = [&](const int s) { return PK ? (uint32_t*)nullptr : (uint32_t*)(c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.win); };
+    // the column table the fill reads: per alignment (4 * code), or per lane group (PK: the pair symbols)
+    auto coltab_of = [&](const int s) {
+        return PK ? c2_smem + P.pcodes0 + (uint32_t)(s >> 1) * P.pcodes_bytes : c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes;
+    };
     // rows of the output arrays can be written as dwords (c2_emit_gapless4) when their addresses are multiples of 4
     const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);
     unsigned* sStage = (unsigned*)(c2_smem + P.stage);
@@ -1294,9 +1497,21 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
     const int ge = A.gap_extend, go = A.gap_open;
     for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
     if (lane < NA) { sTab[lane * C2X_INTS + C2X_CURREF] = -1; sTab[lane * C2X_INTS + C2X_LI] = 0; sTab[lane * C2X_INTS + C2X_G0] = 0; sTab[lane * C2X_INTS + C2X_REFBAD] = 0; }
-    for (int s = 0; s < NA; ++s)                                   // zeros in front of column 1 of every slot's symbol table (written once)
-        if (lane <= C2_DIAG_CODE_PAD) c2_smem[P.slot0 + (uint32_t)s * P.slot_bytes + P.codes + lane] = 0;
+    if (!PK)
+        for (int s = 0; s < NA; ++s)                               // zeros in front of column 1 of every slot's symbol table (written once)
+            if (lane <= C2_DIAG_CODE_PAD) c2_smem[P.slot0 + (uint32_t)s * P.slot_bytes + P.codes + lane] = 0;
 
+    if (PK) {
+        // pair-score tables: for reference symbol rc (codes 0..4; table 5 = zeros, for the padding rows) and read symbols (cA, cB) the two
+        // int16 scores side by side, at byte offset rc * 256 + (cA << 5 | cB << 2) -- the column table holds that pair symbol
+        unsigned* lut = (unsigned*)(c2_smem + P.pairlut);
+        for (int e = lane; e < C2_PK_LUT_CODES * 64; e += 64) {
+            const int rc = e >> 6, cA = (e >> 3) & 7, cB = e & 7;
+            unsigned v = 0;
+            if (rc < C2_PK_PAD_TABLE && rc < A.n_codes) v = ((unsigned)c2_sbfe4((int)A.score_pk[rc], 4 * cA) & 0xffffu) | ((unsigned)c2_sbfe4((int)A.score_pk[rc], 4 * cB) << 16);
+            lut[e] = v;
+        }
+    }
     c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
     // Task fetch as a four-stage software pipeline, one stage per group of NA alignments, so that no stage ever waits for
     // the memory access it depends on (in list mode every one of them misses the caches):
@@ -1345,13 +1560,24 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 cur.Lj = __builtin_amdgcn_readlane(mC_lj, s); cur.ref_id = __builtin_amdgcn_readlane(mC_ref, s);
                 cur.rc = __builtin_amdgcn_readlane(mC_rc, s); cur.b4 = 0;
                 if (cur.valid) {
-                    unsigned char* sCodes4 = c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes;
+                    unsigned char* sCodes4 = coltab_of(s);
                     bool done = false;
-                    if (!cur.rc && cur.Lj >= 4 && cur.Lj <= 256 && cur.Lj <= A.max_lj) {
+                    // PK: the second alignment of a lane group (odd slot) shares the group's reference and column table with the first: it
+                    // joins only if the first one is staged and runs (valid, no status, packed), against the same reference, with a read
+                    // of the same length -- otherwise it is handed to the next launch (packed = false, no status)
+                    bool joins = true;
+                    const bool second = PK && (s & 1);
+                    if (second) {
+                        const int tva = c2_tab_load(T - C2X_INTS, lane);
+                        joins = C2_TF(tva, C2X_VALID) && C2_TF(tva, C2X_STATUS) == 0 && C2_TF(tva, C2X_PACKED) &&
+                                C2_TF(tva, C2X_REF) == cur.ref_id && C2_TF(tva, C2X_LJ) == cur.Lj;
+                        cref = C2_TF(tva, C2X_CURREF); li = C2_TF(tva, C2X_LI); g0 = C2_TF(tva, C2X_G0); rbad = C2_TF(tva, C2X_REFBAD);   // the group's reference
+                    }
+                    if (joins && !cur.rc && cur.Lj >= 4 && cur.Lj <= 256 && cur.Lj <= A.max_lj) {
                         // the usual read: forward strand, at most 256 bases, nothing but A C G T N.  Four bases per lane: codes through two
                         // byte permutes ((ch >> 1) & 7 is a perfect hash of the five letters), checked by permuting the letters back.
                         const c2_wg W = wg_of(s);
-                        if (cur.ref_id != cref) { cref = cur.ref_id; c2_stage_ref(A, W, sCodeOf, cur.ref_id, lane, A.max_li, li, g0, rbad, win_of(s)); }
+                        if (!second && cur.ref_id != cref) { cref = cur.ref_id; c2_stage_ref(A, W, sCodeOf, cur.ref_id, lane, A.max_li, li, g0, rbad, win_of(s)); }
                         uint32_t w = b4s[0];
 #pragma unroll
                         for (int q = 1; q < NA; ++q) if (s == q) w = b4s[q];
@@ -1361,17 +1587,26 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                         const int nb = cur.Lj - 4 * lane;
                         const uint32_t valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
                         if (__ballot(((chk ^ w) & valid) != 0) == 0ull) {
+                            uint32_t* col = (uint32_t*)(sCodes4 + C2_DIAG_CODE_PAD + 1);
                             if (nb > 0) {
                                 ((uint32_t*)W.sRead)[lane] = w;
-                                ((uint32_t*)(sCodes4 + C2_DIAG_CODE_PAD + 1))[lane] = (codes & valid) << 2;    // 4 * code per column, zeros behind the last one
+                                if (!PK) col[lane] = (codes & valid) << 2;                    // 4 * code per column, zeros behind the last one
+                                else if (!second) col[lane] = (codes & valid) << 5;          // pair symbol: code A << 5 ...
+                                else col[lane] |= (codes & valid) << 2;                      // ... | code B << 2
                             }
-                            if (lane < 3) ((uint32_t*)(sCodes4 + C2_DIAG_CODE_PAD + 1))[((cur.Lj + 3) >> 2) + lane] = 0u;   // ... nine zeros at least
+                            if (!second && lane < 3) col[((cur.Lj + 3) >> 2) + lane] = 0u;    // ... nine zeros at least
+                            if (PK && !second && lane < (C2_DIAG_CODE_PAD + 1) / 4) ((uint32_t*)sCodes4)[lane] = 0u;   // (the table shares its bytes with the traceback strings: zeros in front every time)
                             st = (rbad ? C2_STATUS_OOB_CHAR : 0) | (li <= 0 ? C2_STATUS_EMPTY : 0) | (li > A.max_li ? C2_STATUS_TOO_LONG : 0);
                             packed = true;
                             done = true;
                         }
                     }
-                    if (!done) st = c2_commit_task<false>(A, wg_of(s), sCodeOf, cur, lane, A.max_li, cref, li, g0, rbad, packed, sCodes4, win_of(s));
+                    if (!done && joins) {
+                        if (PK && !second && lane < (C2_DIAG_CODE_PAD + 1) / 4) ((uint32_t*)sCodes4)[lane] = 0u;
+                        st = c2_commit_task<false>(A, wg_of(s), sCodeOf, cur, lane, A.max_li, cref, li, g0, rbad, packed, sCodes4, win_of(s),
+                                                   PK && !second ? 5 : 2, second, !second);
+                    }
+                    if (!joins) { st = 0; packed = false; }
                 }
                 if (lane == 0) {
                     T[C2X_VALID] = cur.valid; T[C2X_TASK_LO] = (int)(unsigned)(cur.task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(cur.task >> 32);
@@ -1448,6 +1683,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 lastpos = rf.gap_incentive_last_pos;
                 ok = C2_TF(tvb, C2X_PACKED) && rf.diag_rows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
                      D >= d0 && D <= d0 + BANDW - 1;
+                if (PK && ok) ok = rf.pk_ok != 0;               // the reference must be admitted to the int16 fill (c2_pk_eligible); pairs were formed by the staging
                 if (ok) {
                     any_ok = true;
                     minsc = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
@@ -1469,12 +1705,58 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
 
         int Hcap = C2_DIAG_NEG;
         c2_gapfree GF; GF.acc = 0; GF.cap = 0xffffffffu;
+        c2_pk_cap CAP; CAP.H = 0u; CAP.gf = 0u;                    // (H = 0 in both halves: below every bound; gf = 0: not gap-free)
         if (A.reserved & 4) g_end >>= 1;                           // (debug knob C2_DEBUG_HALF_FILL: what half of the fill costs; nothing is certified then)
-        if (any_ok) {
+        if (PK && any_ok) {
+            const int* T = sTab + slot * C2X_INTS;                 // the lane group's first alignment (the second one, if any, has the same geometry)
+            const int vLi = T[C2X_BAND_LI], vLj = T[C2X_BAND_LJ], vd0 = T[C2X_D0], vg0 = T[C2X_G0];
+            const int vrow = T[C2X_ROWBASE], vcode = (int)(P.pcodes0 + (uint32_t)grp * P.pcodes_bytes) + C2_DIAG_CODE_PAD;
+            C2_LANES_ACTIVE_BEGIN(sl != NL && grp < NG)
+            const int hE = (vd0 >> 1) + sl;
+            const int dE = 2 * hE, dO = dE + 1;
+            c2_pk_state S;
+            S.acc = 0u; S.gf = 0xffffffffu;
+            {
+                // boundary cells (pyx:153-176) with the bias; the sentinel min_score is the number 0 here
+                const int bE = ((dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + vg0) + C2_PK_BIAS;
+                const int mE = (dE == 0) ? C2_PK_BIAS : 0, iE = (dE < 0) ? bE : 0, jE = (dE > 0) ? bE : 0;
+                S.ME = c2_pk_dup(mE); S.IE = c2_pk_dup(iE); S.JE = c2_pk_dup(jE); S.HE = c2_pk_dup(c2_imax(c2_imax(mE, iE), jE));
+                const int bO = ge * (dO > 0 ? dO : -dO) + vg0 + C2_PK_BIAS;
+                const int iO = (dO < 0) ? bO : 0, jO = (dO > 0) ? bO : 0;
+                S.MO = 0u; S.IO = c2_pk_dup(iO); S.JO = c2_pk_dup(jO); S.HO = c2_pk_dup(c2_imax(iO, jO));
+            }
+            c2_diagx_lane L;
+            L.rowOff = (unsigned)((vrow + hE) * (int)sizeof(c2_diag_row));
+            L.rowMax = (unsigned)((vrow + vLi + 1 + C2_DIAG_ROW_PAD - 5) * (int)sizeof(c2_diag_row));
+            L.colOff = (unsigned)(vcode - hE);
+            L.colMax = (unsigned)(vcode + vLj + 2);
+            L.kLast = vLj + hE;
+            L.kCap = (vLi + vLj) >> 1; L.capOdd = ((vLi + vLj) & 1) != 0;
+            L.startE = (dE > 0 ? dE : -dE) + 2; L.startO = (dO > 0 ? dO : -dO) + 2;
+            const c2_diag_row* rows = A.diagpk_base;
+            c2_diag_row RA[5], RB[5];
+            int CA[4], CB[4];
+            c2_diagx_fetch<true>(0, L, rows, c2_smem, RA, CA);
+            unsigned* wordsA = gWords + slot * slotWords + sl;
+            unsigned* wordsB = wordsA + slotWords;
+            int g = 0;
+            const int gA_stop = gA < g_end ? gA : g_end;
+            unsigned ge2 = c2_pk_dup(ge);
+            const unsigned lutBase = P.pairlut;
+            if (gC <= gA_stop) {
+                c2_pk_groups<true, true>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+            } else {
+                c2_pk_groups<true, false>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+            }
+            c2_pk_groups<false, true>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+            C2_LANES_ACTIVE_END()
+        }
+        if (!PK && any_ok) {
             const int* T = sTab + slot * C2X_INTS;                 // this lane's alignment
             const int vLi = T[C2X_BAND_LI], vLj = T[C2X_BAND_LJ], vd0 = T[C2X_D0], vg0 = T[C2X_G0], vmin = T[C2X_MINSC];
             const int vrow = T[C2X_ROWBASE], vcode = (int)(P.slot0 + (uint32_t)slot * P.slot_bytes + P.codes) + C2_DIAG_CODE_PAD;
-            C2_LANES_ACTIVE_BEGIN(sl != NL && slot < NA)           // (slot >= NA: the lanes 64 / NA does not use up, e.g. 60..63 of five groups of 12)
+            C2_LANES_ACTIVE_BEGIN(sl != NL && grp < NG)            // (grp >= NG: the lanes 64 / NG does not use up, e.g. 60..63 of five groups of 12)
             // ---- per-lane diagonals and their boundary cells (pyx:153-176), as in c2_align_diag_kernel
             const int hE = (vd0 >> 1) + sl;                    // dE = 2*hE, dO = 2*hE + 1
             const int dE = 2 * hE, dO = dE + 1;
@@ -1542,16 +1824,25 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
             if (!C2_TF(tv, C2X_OK)) { m_full |= 1u << s; continue; }
             const int Li = C2_TF(tv, C2X_LI), Lj = C2_TF(tv, C2X_LJ);
             const int D = C2_TF(tv, C2X_D), d0 = C2_TF(tv, C2X_D0), cb = C2_TF(tv, C2X_CB);
-            const int lane_end = s * LPA + ((D - d0) >> 1);
-            const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
+            const int lane_end = (PK ? (s >> 1) : s) * LPA + ((D - d0) >> 1);
+            int Hend;
+            bool gapfree;
+            if (PK) {
+                const int half = 16 * (s & 1);
+                Hend = (int)(int16_t)(((unsigned)__builtin_amdgcn_readlane((int)CAP.H, lane_end) >> half) & 0xffffu) - C2_PK_BIAS;
+                gapfree = (((unsigned)__builtin_amdgcn_readlane((int)CAP.gf, lane_end) >> half) & 0x0C0Cu) == 0x0C0Cu;
+            } else {
+                Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
+                gapfree = __builtin_amdgcn_readlane((int)GF.cap, lane_end) == 0;
+            }
             const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
             const int U = c2_outside_band_bound(A.max_score, Li, Lj, D, dhi1, dlo1, cb, go, ge, C2_TF(tv, C2X_LASTPOS));
             if (!(Hend > U)) { m_full |= 1u << s; continue; }
             if (A.reserved & 2) continue;                              // (debug knob C2_DEBUG_SKIP_EPILOGUE: certified, nothing written)
-            if (Li == Lj && __builtin_amdgcn_readlane((int)GF.cap, lane_end) == 0) m_gapfree |= 1u << s;
+            if (Li == Lj && gapfree) m_gapfree |= 1u << s;
             else m_trace |= 1u << s;
         }
-        constexpr int STG = 16 / NA;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
+        constexpr int STG = 16 / NG;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
         uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
         q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = uint4{0u, 0u, 0u, 0u};
 #define C2_STG_LOAD(n) if (STG > n) { const int k = 64 * n + lane; q##n = src[k < n16 ? k : 0]; }
@@ -1592,7 +1883,7 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
                 const unsigned later = m_trace & ~((2u << s) - 1u);     // traced slots after this one
                 if (later) request_words(__builtin_ctz(later));
                 c2_diagx_plane plane;
-                plane.words = sStage; plane.d0 = d0; plane.lpa = LPA;
+                plane.words = sStage; plane.d0 = d0; plane.lpa = LPA; plane.pk = PK;
                 int cnt, matches;
                 bool nf2;
                 c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
@@ -1612,6 +1903,13 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A)
     }
     c2_phase_flush(A.phase_cycles, PH, lane);
 }
+
+template <int NA>
+__global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A) { c2_diagx_body<NA, false>(A); }
+
+// NA alignments per wavefront, two per lane group, int16 DP values (see "Packed fill")
+template <int NA>
+__global__ __launch_bounds__(64, 3) void c2_align_diagp_kernel(c2_align_args A) { c2_diagx_body<NA, true>(A); }
 
 // =====================================================================================
 // Per-call classifier with full position lists: find_indels_substitutions

@@ -46,7 +46,7 @@ class _Aligner(EmulatedAligner):
         rids = None if d_ref_ids is None else _view(d_ref_ids, 2 * n).view(np.int16).astype(np.uint16)
         st = {}
         _, rec = E.align_batch(reads, self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=rids, all_refs=all_refs,
-                               band_lanes=-7 if self.ctx.mode == "auto" else 0, stats=st)
+                               band_lanes=-87 if self.ctx.mode == "auto" else 0, stats=st)
         o1, o2 = st["raw"]
         w = min(o1.shape[1], aln_stride)
         a = _view(d_aln_read, ntasks * aln_stride).reshape(ntasks, aln_stride)

@@ -27,7 +27,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     std::vector<c2_dev_ref> refs(n_refs);
     std::vector<std::vector<int32_t>> g32(n_refs);
     std::vector<std::vector<uint16_t>> incp(n_refs);
-    std::vector<std::vector<c2_diag_row>> drows(n_refs);
+    std::vector<std::vector<c2_diag_row>> drows(n_refs), drows_pk(n_refs);
+    bool any_pk = false;
     int max_li = 1;
     for (int r = 0; r < n_refs; ++r) {
         g32[r].resize(lens[r] + 1);
@@ -36,6 +37,9 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = g32[r].data(); refs[r].inc_prefix = incp[r].data();
         c2_build_diag_rows(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows[r]);
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
+        refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 62)) ? 1 : 0; refs[r].reserved1 = 0;
+        if (refs[r].pk_ok) { c2_build_diag_rows_pk(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows_pk[r]); any_pk = true; }
+        else drows_pk[r].assign(drows[r].size(), c2_diag_row{0, 0, 0, 5u * 256u});
         refs[r].len = lens[r];
         int64_t gm = 0;
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)g32[r][k]);
@@ -71,7 +75,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     }
     // band_lanes: -1 single-alignment diagonal-band kernel, -2 / -4 the 2- / 4-alignments-per-wavefront kernel, -7 the whole
     // chain 4 -> 2 -> 1; every chain ends with the full-plane kernel over what is left (the host library's launch order)
-    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75;
+    // -8: the packed kernel (8 per wavefront, int16 pairs) alone; -87: the library's default chain 8 (packed) -> 2 -> 1
+    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75 || band_lanes == -8 || band_lanes == -87;
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1);
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
@@ -80,15 +85,20 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     A.mat_dim = sc.mat_dim; A.first_ext_code = sc.first_ext_code;
     c2_build_base_luts(sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
     if (no_packed) A.lut_chr_lo = A.lut_chr_hi = 0xffffffffu;
-    A.diag_base = nullptr;
+    A.diag_base = nullptr; A.diagpk_base = nullptr;
     if (!no_packed && n_refs > 0 && !drows[0].empty()) {
         // the references' row tables must sit in one buffer (the kernels index it relative to diag_base)
-        static std::vector<c2_diag_row> all_rows;
-        all_rows.clear();
+        static std::vector<c2_diag_row> all_rows, all_rows_pk;
+        all_rows.clear(); all_rows_pk.clear();
         std::vector<size_t> off(n_refs);
-        for (int r = 0; r < n_refs; ++r) { off[r] = all_rows.size(); all_rows.insert(all_rows.end(), drows[r].begin(), drows[r].end()); }
+        for (int r = 0; r < n_refs; ++r) {
+            off[r] = all_rows.size();
+            all_rows.insert(all_rows.end(), drows[r].begin(), drows[r].end());
+            all_rows_pk.insert(all_rows_pk.end(), drows_pk[r].begin(), drows_pk[r].end());
+        }
         for (int r = 0; r < n_refs; ++r) refs[r].diag_rows = all_rows.data() + off[r] + C2_DIAG_ROW_PAD;
         A.diag_base = all_rows.data();
+        A.diagpk_base = all_rows_pk.data();
     }
     if (diag) {
         uint32_t* lists[2] = {fb_list.data(), fb_list2.data()};
@@ -99,10 +109,20 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             work_counter = 0;
         };
         // -5: five alignments per wavefront (lane groups of 12, lanes 60..63 idle); -75: the chain 5 -> 2 -> 1 -> full plane
+        if ((band_lanes == -8 || band_lanes == -87) && any_pk) {
+            const c2_diagx_plan PP = c2_make_diagx_plan(8, A.max_li, A.max_lj, true);
+            if (PP.total > sizeof(c2_smem)) return -5;
+            plane.assign((size_t)grid * PP.n_words * 128u, 0xdeadbeefu);
+            c2_align_args T = A;
+            chain(T);
+            T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 128u;
+            emu::launch(grid, [&] { c2_align_diagp_kernel<8>(T); });
+            ++tier;
+        }
         const int nas[3] = {(band_lanes == -5 || band_lanes == -75) ? 5 : 4, 2, 0};
         for (int q = 0; nas[q]; ++q) {
             const int na = nas[q];
-            if (!(band_lanes == -7 || band_lanes == -75 || band_lanes == -na)) continue;
+            if (!(band_lanes == -7 || band_lanes == -75 || band_lanes == -na || (band_lanes == -87 && na == 2))) continue;
             const c2_diagx_plan PX = c2_make_diagx_plan(na, A.max_li, A.max_lj);
             if (PX.total > sizeof(c2_smem)) return -5;
             plane.assign((size_t)grid * PX.n_words * 64u, 0xdeadbeefu);
@@ -114,7 +134,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             else         emu::launch(grid, [&] { c2_align_diagx_kernel<2>(T); });
             ++tier;
         }
-        if (band_lanes == -7 || band_lanes == -75 || band_lanes == -1) {
+        if (band_lanes == -7 || band_lanes == -75 || band_lanes == -1 || band_lanes == -87) {
             const c2_diag_plan PD = c2_make_diag_plan(A.max_li, A.max_lj);
             if (PD.total > sizeof(c2_smem)) return -5;
             c2_align_args T = A;
@@ -122,11 +142,15 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             emu::launch(grid, [&] { c2_align_diag_kernel(T); });
             ++tier;
         }
-        A.task_list = lists[(tier - 1) & 1]; A.task_count = &fb_counts[tier - 1];
+        if (tier == 0) {                                           // (no banded tier ran, e.g. -8 without an admitted reference: everything to the full plane)
+            A.task_list = nullptr; A.task_count = nullptr; fb_count = 1;
+        } else {
+            A.task_list = lists[(tier - 1) & 1]; A.task_count = &fb_counts[tier - 1];
+            fb_count = fb_counts[tier - 1];
+        }
         A.fb_list = nullptr; A.fb_count = nullptr;
         work_counter = 0;
-        fb_count = fb_counts[tier - 1];
-        if (n_fallback) *n_fallback = (int)fb_counts[0];
+        if (n_fallback) *n_fallback = tier ? (int)fb_counts[0] : -1;
     } else if (band) {
         A.band_lanes = band_lanes;
         const c2_lds_plan PB = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, band_lanes);

@@ -41,7 +41,7 @@ class EmulatedAligner:
         rids = None if d_ref_ids is None else _view(d_ref_ids, 2 * n).view(np.int16).astype(np.uint16)
         st = {}
         _, rec = E.align_batch(reads, self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=rids, strands=strands,
-                               all_refs=all_refs, band_lanes=-7, stats=st)
+                               all_refs=all_refs, band_lanes=-87, stats=st)
         o1, o2 = st["raw"]
         w = min(o1.shape[1], aln_stride)
         assert int(rec["aln_len"].max()) <= w
@@ -61,7 +61,7 @@ class EmulatedAligner:
             reads = [buf[int(off[i]):int(off[i + 1])].decode() for i in range(len(off) - 1)]
         st = {}
         _, rec = E.align_batch(list(reads), self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=ref_ids, strands=strands,
-                               all_refs=all_refs, band_lanes=-7, stats=st)
+                               all_refs=all_refs, band_lanes=-87, stats=st)
         o1, o2 = st["raw"]
         return BatchResult(o1, o2, rec.view(_native_rec_dtype()), len(reads), len(self.seqs), all_refs)
 

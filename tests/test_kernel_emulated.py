@@ -106,7 +106,7 @@ def test_emulated_diagonal_band_kernel_with_certificate_and_fallback(mats):
     assert 0 < st["fallback"] < st["tasks"], st
 
 
-@pytest.mark.parametrize("mode", [-2, -4, -5, -7, -75])
+@pytest.mark.parametrize("mode", [-2, -4, -5, -7, -75, -8, -87])
 def test_emulated_multi_alignment_diagonal_kernels(mats, mode):
     """c2_align_diagx_kernel: 2 (-2) or 4 (-4) alignments per wavefront, lane groups isolated by an EXEC-disabled lane,
     pointer words in a global scratch plane; -7 is the host library's whole chain 4 -> 2 -> 1 -> full-plane kernel.
@@ -122,7 +122,7 @@ def test_emulated_multi_alignment_diagonal_kernels(mats, mode):
     assert 0 < st["fallback"] < st["tasks"], st
 
 
-@pytest.mark.parametrize("mode", [-1, -2, -4, -5, -7, -75])
+@pytest.mark.parametrize("mode", [-1, -2, -4, -5, -7, -75, -8, -87])
 def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats, mode):
     m = mats["EDNAFULL"]
     rng = np.random.default_rng(77)
@@ -157,8 +157,9 @@ def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats, mo
     assert st["fallback"] < st["tasks"]
 
 
+@pytest.mark.parametrize("chain", [-7, -87])
 @pytest.mark.parametrize("go,ge,scale", [(-20, -2, 1), (-20, -4, 3), (-6, -2, 1)])
-def test_emulated_chain_adversarial_gap_incentives(mats, go, ge, scale):
+def test_emulated_chain_adversarial_gap_incentives(mats, go, ge, scale, chain):
     """The out-of-band bound of the diagonal kernels (c2_outside_band_bound) prices steps down at gap_extend and steps right
     by runs; these references put the incentives where that reasoning has exceptions (last row, row 0, blocks of rows, values
     up to 3) and the reads make the cheap gapped paths optimal.  Whole chain 4 -> 2 -> 1 -> full plane vs the oracle."""
@@ -167,7 +168,7 @@ def test_emulated_chain_adversarial_gap_incentives(mats, go, ge, scale):
     refs, gis, incs, reads, rids = adversarial_case(rng, 96)
     gis = [g * scale for g in gis]
     st = {}
-    res, rec = E.align_batch(reads, refs, gis, incs, m, go, ge, ref_ids=rids, band_lanes=-7, grid=3, stats=st)
+    res, rec = E.align_batch(reads, refs, gis, incs, m, go, ge, ref_ids=rids, band_lanes=chain, grid=3, stats=st)
     for k, ((s1, s2), r) in enumerate(zip(res, rec)):
         exp = oracle.global_align_raw(reads[k], refs[rids[k]], m, gis[rids[k]], go, ge)
         assert exp[0] == 0 and r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], (k, rids[k])
@@ -315,8 +316,9 @@ def test_emulated_chain_on_the_reads_of_the_reference_params_run(mats):
     assert st["fallback"] < st["tasks"]
 
 
+@pytest.mark.parametrize("chain", [-7, -87])
 @pytest.mark.parametrize("go,ge,seed", [(-20, -2, 11), (-10, -3, 12), (-5, -1, 13)])
-def test_emulated_chain_soak_mixed_batches(mats, go, ge, seed):
+def test_emulated_chain_soak_mixed_batches(mats, go, ge, seed, chain):
     """The GPU soak's generator (tests/test_gpu_soak.py: three references of different lengths, both strands, long indels,
     truncated / unrelated reads, N and IUPAC symbols, one or two cut sites) through the emulated default chain: EVERY
     alignment and record against the oracle, on the CPU."""
@@ -338,7 +340,7 @@ def test_emulated_chain_soak_mixed_batches(mats, go, ge, seed):
     strands = np.array([1 if (rng.random() < 0.3 and set(t) <= set("ACGTN")) else 0 for t in truth], dtype=np.uint8)
     reads = [("".join(COMP[c] for c in reversed(t)) if st else t) for t, st in zip(truth, strands)]
     st = {}
-    res, rec = E.align_batch(reads, refs, gis, incs, m, go, ge, ref_ids=rids, strands=strands, band_lanes=-7, stats=st)
+    res, rec = E.align_batch(reads, refs, gis, incs, m, go, ge, ref_ids=rids, strands=strands, band_lanes=chain, stats=st)
     n_undefined = 0
     for k in range(n):
         status, s1, s2, mt, ln = oracle.global_align_raw(truth[k], refs[rids[k]], m, gis[rids[k]], go, ge)
@@ -391,3 +393,49 @@ def test_gap_free_predicate_kept_in_registers_every_length_residue(mats):
             assert (rec["insertion_n"][k], rec["deletion_n"][k], rec["substitution_n"][k]) == (p["insertion_n"], p["deletion_n"], p["substitution_n"])
             n_gapfree += "-" not in s1 and "-" not in s2
         assert n_gapfree >= 4 * 25
+
+
+def test_packed_kernel_pairs_singles_and_mismatched_neighbours(mats):
+    """c2_align_diagp_kernel: two alignments per lane group in int16 halves.  Lane groups whose two tasks share reference and
+    read length run as a pair; a second task of another length or another reference is handed to the next launch; a group
+    with one task runs it in both halves; references the int16 range does not admit (here: one too short for the sentinel
+    argument, one with an IUPAC symbol) never enter the packed fill.  Every alignment and record against the oracle, through
+    the packed kernel alone (-8: what it leaves goes to the full-plane kernel) and through the default chain (-87)."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(8088)
+    refs = ["".join(rng.choice(list("ACGT"), L)) for L in (200, 231, 90)]
+    refs.append(refs[0][:100] + "R" + refs[0][101:])                       # IUPAC symbol: code >= 8
+    gis, incs = [], []
+    for r in refs:
+        g = np.zeros(len(r) + 1, dtype=np.int64)
+        g[len(r) // 2 + 1] = 1
+        gis.append(g)
+        incs.append([len(r) // 2, len(r) // 2 + 1])
+    reads, rids = [], []
+    for k in range(333):                                                    # (odd: the last lane group holds one task)
+        r = int(rng.choice([0, 0, 0, 1, 1, 2, 3]))
+        t = list(refs[r].replace("R", "A"))
+        for _ in range(int(rng.integers(0, 4))):
+            t[int(rng.integers(0, len(t)))] = str(rng.choice(list("ACGTN")))
+        t = "".join(t)
+        kind = rng.random()
+        if kind < 0.25:
+            d = int(rng.integers(1, 14)); p0 = int(rng.integers(5, len(t) - 20)); t = t[:p0] + t[p0 + d:] + "".join(rng.choice(list("ACGT"), d))   # deletion, length kept
+        elif kind < 0.4:
+            d = int(rng.integers(1, 10)); p0 = int(rng.integers(5, len(t) - 20)); t = (t[:p0] + "".join(rng.choice(list("ACGT"), d)) + t[p0:])[:len(t)]   # insertion, length kept
+        elif kind < 0.6:
+            t = t[:len(t) - int(rng.integers(1, 9))]                         # shorter read: another length in the neighbouring half
+        reads.append(t); rids.append(r)
+    for chain in (-8, -87):
+        st = {}
+        res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=rids, band_lanes=chain, grid=3, stats=st)
+        for k, rd in enumerate(reads):
+            status, s1, s2, mt, ln = oracle.global_align_raw(rd, refs[rids[k]], m, gis[rids[k]], -20, -2)
+            assert status == 0 and rec["status"][k] == 0 and res[k] == (s1, s2) and int(rec["matches"][k]) == mt and int(rec["aln_len"][k]) == ln, (chain, k)
+            check_record(rec[k], oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
+        assert 0 < st["fallback"] < st["tasks"], st
+    # the same reads in pairs of equal (reference, length): hardly anything is handed on
+    order = sorted(range(len(reads)), key=lambda k: (rids[k], len(reads[k])))
+    st2 = {}
+    E.align_batch([reads[k] for k in order], refs, gis, incs, m, -20, -2, ref_ids=[rids[k] for k in order], band_lanes=-8, grid=3, stats=st2)
+    assert st2["fallback"] < st["fallback"]

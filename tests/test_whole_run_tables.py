@@ -296,7 +296,7 @@ def test_params_run_tables_from_the_emulated_kernels(tmp_path):
     seqs = [refs[nm]["sequence"] for nm in names]
     st = {}
     res, rec = E.align_batch(ureads, seqs, [refs[nm]["gap_incentive"] for nm in names], [list(refs[nm]["include_idxs"]) for nm in names],
-                             m, g["args"]["needleman_wunsch_gap_open"], g["args"]["needleman_wunsch_gap_extend"], all_refs=True, band_lanes=-7, stats=st)
+                             m, g["args"]["needleman_wunsch_gap_open"], g["args"]["needleman_wunsch_gap_extend"], all_refs=True, band_lanes=-87, stats=st)
     o1, o2 = st["raw"]
     k = len(names)
     weights = np.zeros(len(rec), dtype=np.uint32)

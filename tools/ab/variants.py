@@ -32,7 +32,8 @@ def main():
                 k, _, val = kv.partition("=")
                 env[k] = val or "1"
             p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(a.config), "--reads", str(a.reads), "--steps", str(a.steps),
-                                "--warmup", "1", "--no-cpu-baseline", "--check", "0", "--workers", "8"], capture_output=True, text=True, env=env, cwd=ROOT)
+                                "--warmup", "1", "--no-cpu-baseline", "--check", env.get("C2_AB_CHECK", "0"), "--no-full-plane-check", "--workers", "8"],
+                               capture_output=True, text=True, env=env, cwd=ROOT)
             line = [x for x in p.stdout.splitlines() if x.startswith("{")]
             if not line:
                 print(label, "FAILED", p.stderr[-400:])
@@ -41,8 +42,8 @@ def main():
             r = d["roofline"]
             row = (r["avg_launch_ms"], r["chain_avg_ms"], d["ms_per_step"], d["step_breakdown_ms"]["count_vectors_and_all_reduce"])
             res.setdefault(label, []).append(row)
-            print("%-28s first kernel %8.3f ms  chain %8.3f ms  step %8.3f ms  count %7.3f ms  left %s" %
-                  ((label,) + row + (d["config"]["tasks_left_after_each_banded_launch"],)), flush=True)
+            print("%-28s first kernel %8.3f ms  chain %8.3f ms  step %8.3f ms  count %7.3f ms  left %s  %s" %
+                  ((label,) + row + (d["config"]["tasks_left_after_each_banded_launch"], d.get("checks", ""))), flush=True)
     print(json.dumps({k: [sum(x[i] for x in v) / len(v) for i in range(4)] for k, v in res.items()}))
 
 
