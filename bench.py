@@ -374,7 +374,7 @@ def main():
 
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
-    chain_names = {"auto": ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
+    chain_names = {"auto": ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<2>" if os.environ.get("C2_NO_PACKED_TIER2") else "c2_align_diagp_kernel<4>", "c2_align_diag_kernel"],
                    "diag4": ["c2_align_diagx_kernel<4>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
                    "diag2": ["c2_align_diagx_kernel<2>", "c2_align_diag_kernel"], "diag1": ["c2_align_diag_kernel"]}
     if os.environ.get("C2_NO_PACKED_FILL"):

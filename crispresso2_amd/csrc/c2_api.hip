@@ -60,7 +60,7 @@ struct c2_ctx {
     std::vector<uint8_t> ref_pk_ok;     // per reference: admitted to the packed fill (c2_pk_eligible)
     bool any_pk_ok = false;
     bool pk_dirty = true;
-    int occ_pk_lds = -1, occ_pk_blocks = 0;
+    int occ_pk_lds = -1, occ_pk_blocks = 0, occ_pk2_lds = -1, occ_pk2_blocks = 0;
     // staging for the host batch path and the per-call path
     DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;
     // timing
@@ -125,6 +125,7 @@ struct Geometry {
     bool diag; uint32_t lds_diag; int blocks_diag;         // diagonal-band launches
     bool x[2]; uint32_t lds_x[2]; int blocks_x[2]; uint32_t plane_words;   // multi-alignment tiers in front of it: 4, 2 per wavefront
     bool pk; uint32_t lds_pk; int blocks_pk; uint32_t plane_words_pk;      // packed first tier (8 per wavefront, int16) in place of the 4-per-wavefront one
+    bool pk2; uint32_t lds_pk2; int blocks_pk2; uint32_t plane_words_pk2;  // packed second tier (4 per wavefront, 62 diagonals) in place of the 2-per-wavefront one
 };
 
 template <int R, bool BAND>
@@ -185,6 +186,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     for (int t = 0; t < 2; ++t) { g.x[t] = false; g.lds_x[t] = 0; g.blocks_x[t] = 0; }
     g.plane_words = 0;
     g.pk = false; g.lds_pk = 0; g.blocks_pk = 0; g.plane_words_pk = 0;
+    g.pk2 = false; g.lds_pk2 = 0; g.blocks_pk2 = 0; g.plane_words_pk2 = 0;
     const int km = ctx->kernel_mode;
     update_pk_eligibility(ctx);
     if ((km == 0 || km == 3 || km == 4 || km == 5) && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
@@ -212,10 +214,21 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
                 }
                 g.pk = true; g.lds_pk = PP.total; g.blocks_pk = ctx->occ_pk_blocks; g.plane_words_pk = PP.n_words * 128u;   // 8 slots x 16 lanes
             }
+            // second tier: four per wavefront, two lane groups of 32 lanes (62 diagonals) in int16
+            const c2_diagx_plan P2 = c2_make_diagx_plan(4, ctx->max_li, g.max_lj, true);
+            if (g.pk && P2.total <= lds_cu && !getenv("C2_NO_PACKED_TIER2")) {
+                if (ctx->occ_pk2_lds != (int)P2.total) {
+                    int nb = 0;
+                    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_diagp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_diagp_kernel<4>, 64, P2.total));
+                    ctx->occ_pk2_blocks = nb < 1 ? 1 : nb; ctx->occ_pk2_lds = (int)P2.total;
+                }
+                g.pk2 = true; g.lds_pk2 = P2.total; g.blocks_pk2 = ctx->occ_pk2_blocks; g.plane_words_pk2 = P2.n_words * 128u;   // 4 slots x 32 lanes
+            }
         }
         for (int t = 0; t < 2 && g.diag && km != 3; ++t) {
             const int na = t == 0 ? C2_TIER0_NA : 2;
-            if (t == 0 && (km == 4 || g.pk)) continue;                         // mode 4: 2 -> 1; the packed tier stands in for the 4-per-wavefront one
+            if (t == 0 && km == 4) continue;                                   // mode 4: 2 -> 1  (with a packed kernel in the tier, the 32-bit kernel runs what it could not pair)
             c2_diagx_plan PX = c2_make_diagx_plan(na, ctx->max_li, g.max_lj);
             if (const char* pad = getenv("C2_DEBUG_X_LDS_PAD")) PX.total += (uint32_t)atoi(pad);   // occupancy experiments
             if (PX.total > lds_cu) continue;
@@ -272,72 +285,89 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
     int rc;
     A.band_lanes = 0; A.reserved = (getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0) | (getenv("C2_DEBUG_SKIP_EPILOGUE") ? 2 : 0) | (getenv("C2_DEBUG_HALF_FILL") ? 4 : 0);   // (measurement knobs)
     A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
+    A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0; A.reserved4 = 0;
     if (g.diag || g.band_lanes > 0) {
         if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
-        // d_fb: 16 header words -- [0..3] length of the fallback list each tier leaves, [4 + 2t ..] work counter of launch t --
-        // then two task lists (a tier reads one and fills the other)
+        // d_fb: 64 header words -- [0..7] length of the list each BAND tier leaves for the next one, [8..15] length of the list of
+        // tasks a packed kernel could not pair (run by the 32-bit kernel of the same band), [16 + 2l ..] work counter of launch l --
+        // then three task lists: two that alternate between band tiers and one for the unpaired tasks
         const size_t list_words = (size_t)A.n_tasks;
-        if ((rc = ensure(ctx, ctx->d_fb, 64 + 2 * list_words * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, ctx->d_fb, 256 + 3 * list_words * sizeof(uint32_t)))) return rc;
         uint32_t* hdr = (uint32_t*)ctx->d_fb.p;
-        uint32_t* lists[2] = {hdr + 16, hdr + 16 + list_words};
-        HIPCHK(ctx, hipMemsetAsync(hdr, 0, 64, s));
+        uint32_t* lists[2] = {hdr + 64, hdr + 64 + list_words};
+        uint32_t* ulist = hdr + 64 + 2 * list_words;
+        HIPCHK(ctx, hipMemsetAsync(hdr, 0, 256, s));
         const uint64_t cus = (uint64_t)ctx->prop.multiProcessorCount;
-        int tier = 0;                                            // launches so far; the next one reads lists[(tier - 1) & 1]
-        auto chain = [&](c2_align_args& T) {                     // wire launch `tier` into the chain
-            T.task_list = tier ? lists[(tier - 1) & 1] : nullptr; T.task_count = tier ? hdr + (tier - 1) : nullptr;
+        int tier = 0;                                            // band tiers so far; the next one reads lists[(tier - 1) & 1]
+        int launch = 0;                                          // launches so far (each has its own work counter)
+        // wire a launch into the chain.  from_unpaired: it runs the tasks the packed kernel of this band tier could not pair and
+        // appends what IT cannot finish to the same list as that kernel
+        auto chain = [&](c2_align_args& T, const bool from_unpaired, const bool packed_kernel) {
+            if (from_unpaired) { T.task_list = ulist; T.task_count = hdr + 8 + tier; }
+            else { T.task_list = tier ? lists[(tier - 1) & 1] : nullptr; T.task_count = tier ? hdr + (tier - 1) : nullptr; }
             T.fb_list = lists[tier & 1]; T.fb_count = hdr + tier;
-            T.work_counter = (unsigned long long*)(hdr + 4 + 2 * tier);
+            T.un_list = packed_kernel ? ulist : nullptr; T.un_count = packed_kernel ? hdr + 8 + tier : nullptr;
+            T.pair_order = packed_kernel && !from_unpaired && tier == 0 && T.all_refs && T.n_refs > 1;
+            T.work_counter = (unsigned long long*)(hdr + 16 + 2 * launch);
+            ++launch;
         };
         if (g.diag) {
             {   // one scratch plane, sized for the tier that needs the most (no reallocation between launches)
                 uint64_t most = 0;
                 for (int t = 0; t < 2; ++t) if (g.x[t]) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_x[t] * g.plane_words);
                 if (g.pk) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk * g.plane_words_pk);
+                if (g.pk2) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk2 * g.plane_words_pk2);
                 if (most && (rc = ensure(ctx, ctx->d_plane, (size_t)most * sizeof(uint32_t)))) return rc;
             }
-            if (g.pk) {
-                const uint64_t resident = cus * (uint64_t)g.blocks_pk;
-                const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + 7) / 8, resident));
-                c2_align_args T = A;
-                chain(T);
-                T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = g.plane_words_pk;
-                hipLaunchKernelGGL(c2_align_diagp_kernel<8>, dim3(grid), dim3(64), g.lds_pk, s, T);
-                HIPCHK(ctx, hipGetLastError());
-                mark_first();
-                ++tier;
-            }
+            // band tier t (0: 30 diagonals, 1: 62): the packed kernel if the tier has one, then the 32-bit kernel of the same band --
+            // over everything if there is no packed kernel, else over the tasks the packed kernel could not pair
             for (int t = 0; t < 2; ++t) {
-                if (!g.x[t]) continue;
-                const int na = t == 0 ? C2_TIER0_NA : 2;
-                const uint64_t resident = cus * (uint64_t)g.blocks_x[t];
-                const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + na - 1) / na, resident));
-                c2_align_args T = A;
-                chain(T);
-                T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = g.plane_words;
-                if (t == 0) hipLaunchKernelGGL(c2_align_diagx_kernel<C2_TIER0_NA>, dim3(grid), dim3(64), g.lds_x[t], s, T);
-                else         hipLaunchKernelGGL(c2_align_diagx_kernel<2>, dim3(grid), dim3(64), g.lds_x[t], s, T);
-                HIPCHK(ctx, hipGetLastError());
-                mark_first();
+                const bool packed = t == 0 ? g.pk : g.pk2;
+                if (!packed && !g.x[t]) continue;
+                if (packed) {
+                    const int na = t == 0 ? 8 : 4;
+                    const uint64_t resident = cus * (uint64_t)(t == 0 ? g.blocks_pk : g.blocks_pk2);
+                    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + na - 1) / na, resident));
+                    c2_align_args T = A;
+                    chain(T, false, true);
+                    T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = t == 0 ? g.plane_words_pk : g.plane_words_pk2;
+                    if (t == 0) hipLaunchKernelGGL(c2_align_diagp_kernel<8>, dim3(grid), dim3(64), g.lds_pk, s, T);
+                    else         hipLaunchKernelGGL(c2_align_diagp_kernel<4>, dim3(grid), dim3(64), g.lds_pk2, s, T);
+                    HIPCHK(ctx, hipGetLastError());
+                    mark_first();
+                }
+                if (g.x[t]) {
+                    const int na = t == 0 ? C2_TIER0_NA : 2;
+                    const uint64_t resident = cus * (uint64_t)g.blocks_x[t];
+                    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + na - 1) / na, resident));
+                    c2_align_args T = A;
+                    chain(T, packed, false);
+                    T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = g.plane_words;
+                    if (t == 0) hipLaunchKernelGGL(c2_align_diagx_kernel<C2_TIER0_NA>, dim3(grid), dim3(64), g.lds_x[t], s, T);
+                    else         hipLaunchKernelGGL(c2_align_diagx_kernel<2>, dim3(grid), dim3(64), g.lds_x[t], s, T);
+                    HIPCHK(ctx, hipGetLastError());
+                    mark_first();
+                }
                 ++tier;
             }
             const uint64_t resident = cus * (uint64_t)g.blocks_diag;
             const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(A.n_tasks, resident));
             c2_align_args T = A;
-            chain(T);
+            chain(T, false, false);
             hipLaunchKernelGGL(c2_align_diag_kernel, dim3(grid), dim3(64), g.lds_diag, s, T);
             HIPCHK(ctx, hipGetLastError());
             mark_first();
             ++tier;
         } else {
             A.band_lanes = g.band_lanes;
-            chain(A);
+            chain(A, false, false);
             if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
             mark_first();
             ++tier;
         }
         // the tasks no banded tier could finish, redone with the full pointer plane (usually a handful; an empty list costs one tiny launch)
         A.band_lanes = 0;
-        chain(A);
+        chain(A, false, false);
         A.fb_list = nullptr; A.fb_count = nullptr;
         ctx->last_tiers = tier;
         if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;

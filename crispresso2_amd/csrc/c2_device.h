@@ -68,8 +68,13 @@ typedef struct c2_align_args {
     int32_t max_score;            // diagonal-band kernel: largest entry of the score table (>= 0)
     int32_t max_li;               // diagonal-band kernel: LDS plan, longest reference
     int32_t reserved;
+    int32_t pair_order;           // packed kernels, all-references batches without a task list: positions are mapped to tasks so that the two slots of a
+                                  // lane group hold two consecutive reads against the SAME reference (position 2k*q + i -> read 2q + (i & 1), reference i >> 1)
+    int32_t reserved4;
     uint32_t* fb_count;           // banded kernel: number of tasks whose traceback left the band ...
     uint32_t* fb_list;            // ... and their task indices (capacity n_tasks)
+    uint32_t* un_count;           // packed kernels: tasks that found no partner for their lane group (another reference or read length next to them) ...
+    uint32_t* un_list;            // ... go to this list, which a 32-bit kernel of the SAME band runs next (NULL: they go to fb_list)
     const uint32_t* task_list;    // full kernel, second launch: run only these tasks (NULL = tasks 0..n_tasks-1)
     const uint32_t* task_count;   // device-resident length of task_list
     unsigned long long* work_counter; // device counter the workgroups pull task chunks from; zero before every launch

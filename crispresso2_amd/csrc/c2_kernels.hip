@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
 // per-alignment ("slot") table in LDS: wave-uniform values written by lane 0 and read back through readfirstlane, so the
 // staging / traceback / output code exists once (a loop over the slots) instead of once per slot
 enum { C2X_VALID = 0, C2X_TASK_LO, C2X_TASK_HI, C2X_LJ, C2X_REF, C2X_RC, C2X_STATUS, C2X_PACKED, C2X_CURREF, C2X_LI, C2X_G0,
-       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_INTS = 24 };
+       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_UNPAIRED, C2X_INTS = 24 };
 __device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
 // the whole table of one slot with ONE LDS read (lane k gets entry k); C2_TF picks an entry: a v_readlane instead of an
 // LDS round trip per entry
@@ -1522,7 +1522,9 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
     //   D   c2_commit_task into LDS, then the fill                                      -- this iteration
     // Each stage consumes what the previous iteration's earlier stage requested; the barrier at the top of the loop has
     // waited for all of it.  Task indices fit 32 bits in these launches (the host checks).
-    const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : A.n_tasks;
+    const bool pair_order = PK && A.pair_order && !A.task_list && A.all_refs;
+    const uint64_t n_reads_po = pair_order ? A.n_tasks / (uint64_t)A.n_refs : 0;
+    const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : (pair_order ? ((n_reads_po + 1) >> 1) * 2u * (uint64_t)A.n_refs : A.n_tasks);
     unsigned long long pend = 0;
     bool pend_valid = false, exhausted = false;
     unsigned mA_task = 0; int mA_valid = 0;
@@ -1552,7 +1554,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                 const int tvd = c2_tab_load(T, lane);
                 int cref = C2_TF(tvd, C2X_CURREF), li = C2_TF(tvd, C2X_LI), g0 = C2_TF(tvd, C2X_G0), rbad = C2_TF(tvd, C2X_REFBAD);
                 int st = 0;
-                bool packed = false;
+                bool packed = false, unpaired = false;
                 c2_prefetch cur;
                 cur.valid = __builtin_amdgcn_readlane(mC_valid, s);
                 cur.task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mC_task, s);
@@ -1607,11 +1609,12 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                                                    PK && !second ? 5 : 2, second, !second);
                     }
                     if (!joins) { st = 0; packed = false; }
+                    unpaired = !joins;
                 }
                 if (lane == 0) {
                     T[C2X_VALID] = cur.valid; T[C2X_TASK_LO] = (int)(unsigned)(cur.task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(cur.task >> 32);
                     T[C2X_LJ] = cur.Lj; T[C2X_REF] = cur.ref_id; T[C2X_RC] = cur.rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
-                    T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0; T[C2X_REFBAD] = rbad;
+                    T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0; T[C2X_REFBAD] = rbad; T[C2X_UNPAIRED] = unpaired ? 1 : 0;
                 }
             }
         }
@@ -1654,7 +1657,14 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                                   (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pend & 0xffffffffull));
             const uint64_t it = base + (uint64_t)lane;
             if (base >= n_iter) exhausted = true;
-            if (lane < NA && it < n_iter) { mA_valid = 1; mA_task = A.task_list ? A.task_list[it] : (unsigned)it; }
+            if (lane < NA && it < n_iter) {
+                if (pair_order) {
+                    // consecutive positions 2m, 2m+1 (the two slots of a lane group): reads 2q, 2q+1 against the same reference
+                    const uint64_t blk = it / (2u * (uint64_t)A.n_refs), i = it - blk * 2u * (uint64_t)A.n_refs;
+                    const uint64_t rd = 2u * blk + (i & 1u);
+                    if (rd < n_reads_po) { mA_valid = 1; mA_task = (unsigned)(rd * (uint64_t)A.n_refs + (i >> 1)); }
+                } else { mA_valid = 1; mA_task = A.task_list ? A.task_list[it] : (unsigned)it; }
+            }
         }
         pend = 0; pend_valid = false;
         if (!exhausted) {
@@ -1894,7 +1904,11 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             }
             if (need_full) {
                 status |= C2_STATUS_NEED_FULL;
-                if (lane == 0) { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
+                const bool to_unpaired = PK && A.un_list && C2_TF(tv, C2X_UNPAIRED);
+                if (lane == 0) {
+                    if (to_unpaired) { const unsigned q = atomicAdd(A.un_count, 1u); A.un_list[q] = (uint32_t)task; }   // same band, 32-bit kernel
+                    else { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
+                }
             }
             rec.status = (uint8_t)status;
             if (lane == 0) A.records[task] = rec;

@@ -12,7 +12,11 @@
 alignas(16) unsigned char c2_smem[163840];
 #include "../../crispresso2_amd/csrc/c2_kernels.hip"
 
+static unsigned g_last_unpaired = 0;     // tasks the first packed tier of the last emu_align_batch could not pair
+
 extern "C" {
+
+unsigned emu_last_unpaired() { return g_last_unpaired; }
 
 int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offsets, const uint16_t* ref_ids,
                     const uint8_t* strands, int all_refs,
@@ -75,13 +79,15 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     }
     // band_lanes: -1 single-alignment diagonal-band kernel, -2 / -4 the 2- / 4-alignments-per-wavefront kernel, -7 the whole
     // chain 4 -> 2 -> 1; every chain ends with the full-plane kernel over what is left (the host library's launch order)
-    // -8: the packed kernel (8 per wavefront, int16 pairs) alone; -87: the library's default chain 8 (packed) -> 2 -> 1
-    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75 || band_lanes == -8 || band_lanes == -87;
+    // -8 / -84: the packed kernels (8 / 4 per wavefront, int16 pairs) alone; -87: the library's default chain 8 (packed) -> 4 (packed) -> 1
+    // (references the packed fill does not admit: 2 per wavefront in 32 bits instead)
+    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75 || band_lanes == -8 || band_lanes == -84 || band_lanes == -87;
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1);
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
     std::vector<uint32_t> plane;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0;
+    A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0; A.reserved4 = 0;
     A.mat_dim = sc.mat_dim; A.first_ext_code = sc.first_ext_code;
     c2_build_base_luts(sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
     if (no_packed) A.lut_chr_lo = A.lut_chr_hi = 0xffffffffu;
@@ -102,46 +108,59 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     }
     if (diag) {
         uint32_t* lists[2] = {fb_list.data(), fb_list2.data()};
+        std::vector<uint32_t> un_list(A.n_tasks ? A.n_tasks : 1);
+        uint32_t un_counts[5] = {0, 0, 0, 0, 0};
         int tier = 0;
-        auto chain = [&](c2_align_args& T) {
-            T.task_list = tier ? lists[(tier - 1) & 1] : nullptr; T.task_count = tier ? &fb_counts[tier - 1] : nullptr;
+        // the host library's wiring (c2_api.hip, launch_align): a band tier = the packed kernel (if any), then the 32-bit kernel of the
+        // same band -- over everything, or over the tasks the packed kernel could not pair
+        auto chain = [&](c2_align_args& T, const bool from_unpaired, const bool packed_kernel) {
+            if (from_unpaired) { T.task_list = un_list.data(); T.task_count = &un_counts[tier]; }
+            else { T.task_list = tier ? lists[(tier - 1) & 1] : nullptr; T.task_count = tier ? &fb_counts[tier - 1] : nullptr; }
             T.fb_list = lists[tier & 1]; T.fb_count = &fb_counts[tier];
+            T.un_list = packed_kernel ? un_list.data() : nullptr; T.un_count = packed_kernel ? &un_counts[tier] : nullptr;
+            T.pair_order = packed_kernel && !from_unpaired && tier == 0 && T.all_refs && T.n_refs > 1;
             work_counter = 0;
         };
         // -5: five alignments per wavefront (lane groups of 12, lanes 60..63 idle); -75: the chain 5 -> 2 -> 1 -> full plane
-        if ((band_lanes == -8 || band_lanes == -87) && any_pk) {
-            const c2_diagx_plan PP = c2_make_diagx_plan(8, A.max_li, A.max_lj, true);
-            if (PP.total > sizeof(c2_smem)) return -5;
-            plane.assign((size_t)grid * PP.n_words * 128u, 0xdeadbeefu);
-            c2_align_args T = A;
-            chain(T);
-            T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 128u;
-            emu::launch(grid, [&] { c2_align_diagp_kernel<8>(T); });
-            ++tier;
-        }
-        const int nas[3] = {(band_lanes == -5 || band_lanes == -75) ? 5 : 4, 2, 0};
-        for (int q = 0; nas[q]; ++q) {
-            const int na = nas[q];
-            if (!(band_lanes == -7 || band_lanes == -75 || band_lanes == -na || (band_lanes == -87 && na == 2))) continue;
-            const c2_diagx_plan PX = c2_make_diagx_plan(na, A.max_li, A.max_lj);
-            if (PX.total > sizeof(c2_smem)) return -5;
-            plane.assign((size_t)grid * PX.n_words * 64u, 0xdeadbeefu);
-            c2_align_args T = A;
-            chain(T);
-            T.plane = plane.data(); T.plane_words_per_wg = PX.n_words * 64u;
-            if (na == 5) emu::launch(grid, [&] { c2_align_diagx_kernel<5>(T); });
-            else if (na == 4) emu::launch(grid, [&] { c2_align_diagx_kernel<4>(T); });
-            else         emu::launch(grid, [&] { c2_align_diagx_kernel<2>(T); });
+        for (int t = 0; t < 2; ++t) {
+            const int pna = t == 0 ? 8 : 4, xna = t == 0 ? ((band_lanes == -5 || band_lanes == -75) ? 5 : 4) : 2;
+            const bool packed = any_pk && (band_lanes == -87 || band_lanes == -(80 + (t == 0 ? 0 : 4)) || (band_lanes == -8 && t == 0));
+            const bool xk = band_lanes == -7 || band_lanes == -75 || band_lanes == -xna || band_lanes == -87 || (packed && (band_lanes == -8 || band_lanes == -84));
+            if (!packed && !xk) continue;
+            if (packed) {
+                const c2_diagx_plan PP = c2_make_diagx_plan(pna, A.max_li, A.max_lj, true);
+                if (PP.total > sizeof(c2_smem)) return -5;
+                plane.assign((size_t)grid * PP.n_words * 128u, 0xdeadbeefu);
+                c2_align_args T = A;
+                chain(T, false, true);
+                T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 128u;
+                if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed %d tier %d\n", pna, tier);
+                if (pna == 8) emu::launch(grid, [&] { c2_align_diagp_kernel<8>(T); });
+                else          emu::launch(grid, [&] { c2_align_diagp_kernel<4>(T); });
+            }
+            if (xk) {
+                const c2_diagx_plan PX = c2_make_diagx_plan(xna, A.max_li, A.max_lj);
+                if (PX.total > sizeof(c2_smem)) return -5;
+                plane.assign((size_t)grid * PX.n_words * 64u, 0xdeadbeefu);
+                c2_align_args T = A;
+                chain(T, packed, false);
+                T.plane = plane.data(); T.plane_words_per_wg = PX.n_words * 64u;
+                if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch x %d tier %d from_unpaired %d count %u\n", xna, tier, (int)packed, packed ? un_counts[tier] : 0u);
+                if (xna == 5) emu::launch(grid, [&] { c2_align_diagx_kernel<5>(T); });
+                else if (xna == 4) emu::launch(grid, [&] { c2_align_diagx_kernel<4>(T); });
+                else          emu::launch(grid, [&] { c2_align_diagx_kernel<2>(T); });
+            }
             ++tier;
         }
         if (band_lanes == -7 || band_lanes == -75 || band_lanes == -1 || band_lanes == -87) {
             const c2_diag_plan PD = c2_make_diag_plan(A.max_li, A.max_lj);
             if (PD.total > sizeof(c2_smem)) return -5;
             c2_align_args T = A;
-            chain(T);
+            chain(T, false, false);
             emu::launch(grid, [&] { c2_align_diag_kernel(T); });
             ++tier;
         }
+        g_last_unpaired = un_counts[0];
         if (tier == 0) {                                           // (no banded tier ran, e.g. -8 without an admitted reference: everything to the full plane)
             A.task_list = nullptr; A.task_count = nullptr; fb_count = 1;
         } else {

@@ -72,6 +72,7 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
         o1.ctypes.data_as(ctypes.c_void_p), o2.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(stride),
         rec.ctypes.data_as(ctypes.c_void_p), int(force_R), ctypes.c_uint(grid), int(no_packed), int(band_lanes), ctypes.byref(nfb))
     if stats is not None:
+        stats['unpaired'] = stats.get('unpaired', 0) + int(lib().emu_last_unpaired())
         stats['fallback'] = stats.get('fallback', 0) + max(nfb.value, 0)
         stats['tasks'] = stats.get('tasks', 0) + ntasks
     assert rc == 0, rc

@@ -106,7 +106,7 @@ def test_emulated_diagonal_band_kernel_with_certificate_and_fallback(mats):
     assert 0 < st["fallback"] < st["tasks"], st
 
 
-@pytest.mark.parametrize("mode", [-2, -4, -5, -7, -75, -8, -87])
+@pytest.mark.parametrize("mode", [-2, -4, -5, -7, -75, -8, -84, -87])
 def test_emulated_multi_alignment_diagonal_kernels(mats, mode):
     """c2_align_diagx_kernel: 2 (-2) or 4 (-4) alignments per wavefront, lane groups isolated by an EXEC-disabled lane,
     pointer words in a global scratch plane; -7 is the host library's whole chain 4 -> 2 -> 1 -> full-plane kernel.
@@ -122,7 +122,7 @@ def test_emulated_multi_alignment_diagonal_kernels(mats, mode):
     assert 0 < st["fallback"] < st["tasks"], st
 
 
-@pytest.mark.parametrize("mode", [-1, -2, -4, -5, -7, -75, -8, -87])
+@pytest.mark.parametrize("mode", [-1, -2, -4, -5, -7, -75, -8, -84, -87])
 def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats, mode):
     m = mats["EDNAFULL"]
     rng = np.random.default_rng(77)
@@ -426,7 +426,7 @@ def test_packed_kernel_pairs_singles_and_mismatched_neighbours(mats):
         elif kind < 0.6:
             t = t[:len(t) - int(rng.integers(1, 9))]                         # shorter read: another length in the neighbouring half
         reads.append(t); rids.append(r)
-    for chain in (-8, -87):
+    for chain in (-8, -84, -87):
         st = {}
         res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=rids, band_lanes=chain, grid=3, stats=st)
         for k, rd in enumerate(reads):
@@ -434,8 +434,10 @@ def test_packed_kernel_pairs_singles_and_mismatched_neighbours(mats):
             assert status == 0 and rec["status"][k] == 0 and res[k] == (s1, s2) and int(rec["matches"][k]) == mt and int(rec["aln_len"][k]) == ln, (chain, k)
             check_record(rec[k], oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
         assert 0 < st["fallback"] < st["tasks"], st
-    # the same reads in pairs of equal (reference, length): hardly anything is handed on
+        if chain == -8:
+            assert st["unpaired"] > 40, st                                  # neighbours of another reference / length went to the 32-bit kernel of the band
+    # the same reads in pairs of equal (reference, length): hardly anything is left unpaired
     order = sorted(range(len(reads)), key=lambda k: (rids[k], len(reads[k])))
     st2 = {}
     E.align_batch([reads[k] for k in order], refs, gis, incs, m, -20, -2, ref_ids=[rids[k] for k in order], band_lanes=-8, grid=3, stats=st2)
-    assert st2["fallback"] < st["fallback"]
+    assert st2["unpaired"] < 40 and st2["unpaired"] < st["unpaired"] // 3, (st2, st)
