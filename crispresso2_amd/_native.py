@@ -49,7 +49,7 @@ class Batch(ctypes.Structure):
         ("reads", ctypes.c_void_p), ("offsets", ctypes.c_void_p), ("ref_ids", ctypes.c_void_p), ("strands", ctypes.c_void_p),
         ("all_refs", ctypes.c_int32), ("max_read_len", ctypes.c_int32),
         ("aln_read", ctypes.c_void_p), ("aln_ref", ctypes.c_void_p),
-        ("aln_stride", ctypes.c_uint32), ("reserved2", ctypes.c_uint32),
+        ("aln_stride", ctypes.c_uint32), ("flags", ctypes.c_uint32),
         ("records", ctypes.c_void_p),
     ]
 

@@ -108,8 +108,9 @@ class BatchAligner:
     def stride_for(self, max_read_len):
         return (self.max_ref_len + int(max_read_len) + 15) // 16 * 16
 
-    def align(self, reads, ref_ids=None, strands=None, all_refs=False):
-        """reads: list of str, or (arena uint8, offsets uint64).  Returns a BatchResult (host memory)."""
+    def align(self, reads, ref_ids=None, strands=None, all_refs=False, legacy=False):
+        """reads: list of str, or (arena uint8, offsets uint64).  Returns a BatchResult (host memory).
+        legacy: the records' window counts follow find_indels_substitutions_legacy (--use_legacy_insertion_quantification)."""
         arena, offsets = reads if isinstance(reads, tuple) else pack_reads(reads)
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -144,11 +145,12 @@ class BatchAligner:
         b.aln_ref = aln_ref.ctypes.data
         b.aln_stride = stride
         b.records = records.ctypes.data
+        b.flags = 1 if legacy else 0
         self.ctx.align_classify_host(b)
         return BatchResult(aln_read, aln_ref, records, n, self.n_refs, all_refs)
 
     def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
-                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None):
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False):
         """All d_* are device addresses (ints).  Enqueues one launch on `stream` and returns immediately."""
         b = _native.Batch()
         b.n_reads = int(n_reads)
@@ -162,4 +164,5 @@ class BatchAligner:
         b.aln_ref = d_aln_ref
         b.aln_stride = int(aln_stride)
         b.records = d_records
+        b.flags = 1 if legacy else 0
         self.ctx.align_classify_device(b, stream)

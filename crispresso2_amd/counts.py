@@ -27,6 +27,7 @@ SCALARS = ["counts_total", "counts_modified", "counts_unmodified", "counts_disca
 HISTS = ["inserted_n", "deleted_n", "substituted_n", "effective_len"]
 FLAG_IGNORE_SUBSTITUTIONS, FLAG_IGNORE_INSERTIONS, FLAG_IGNORE_DELETIONS, FLAG_DISCARD_INDEL_READS = 1, 2, 4, 8
 FLAG_ALL_REFS_LAYOUT = 16        # the tasks are one all-references batch (task = read * n_refs + reference)
+FLAG_LEGACY_CLASSIFIER = 32      # --use_legacy_insertion_quantification: positions of find_indels_substitutions_legacy
 assert len(VECTORS) == N_VECTORS and len(HISTS) == N_HISTS
 
 

@@ -285,7 +285,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
     int rc;
     A.band_lanes = 0; A.reserved = (getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0) | (getenv("C2_DEBUG_SKIP_EPILOGUE") ? 2 : 0) | (getenv("C2_DEBUG_HALF_FILL") ? 4 : 0);   // (measurement knobs)
     A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
-    A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0; A.reserved4 = 0;
+    A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0;
     if (g.diag || g.band_lanes > 0) {
         if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
         // d_fb: 64 header words -- [0..7] length of the list each BAND tier leaves for the next one, [8..15] length of the list of
@@ -437,6 +437,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.n_codes = ctx->sc.n_codes; A.gap_open = ctx->gap_open; A.gap_extend = ctx->gap_extend;
     A.max_lj = g.max_lj; A.max_passes = g.passes;
     A.max_li = ctx->max_li;
+    A.legacy = (b->flags & C2_BATCH_LEGACY_CLASSIFIER) ? 1 : 0;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
     A.diagpk_base = ctx->any_pk_ok ? (const c2_diag_row*)ctx->d_diagrows_pk.p : nullptr;
     A.mat_dim = ctx->sc.mat_dim; A.first_ext_code = ctx->sc.first_ext_code;

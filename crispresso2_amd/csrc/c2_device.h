@@ -70,7 +70,7 @@ typedef struct c2_align_args {
     int32_t reserved;
     int32_t pair_order;           // packed kernels, all-references batches without a task list: positions are mapped to tasks so that the two slots of a
                                   // lane group hold two consecutive reads against the SAME reference (position 2k*q + i -> read 2q + (i & 1), reference i >> 1)
-    int32_t reserved4;
+    int32_t legacy;               // fused classification follows find_indels_substitutions_legacy (COREResources.pyx:190-315)
     uint32_t* fb_count;           // banded kernel: number of tasks whose traceback left the band ...
     uint32_t* fb_list;            // ... and their task indices (capacity n_tasks)
     uint32_t* un_count;           // packed kernels: tasks that found no partner for their lane group (another reference or read length next to them) ...
@@ -173,6 +173,7 @@ static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {
 #define C2_CNT_FLAG_IGNORE_DELETIONS 4
 #define C2_CNT_FLAG_DISCARD_INDEL_READS 8
 #define C2_CNT_FLAG_ALL_REFS_LAYOUT 16     // the tasks are an all-references batch: task = read * n_refs + reference
+#define C2_CNT_FLAG_LEGACY 32              // find_indels_substitutions_legacy's positions
 
 typedef struct c2_count_args {
     const uint8_t* aln_read;      // n_tasks x aln_stride (outputs of the align kernel)

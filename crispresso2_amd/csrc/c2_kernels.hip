@@ -621,17 +621,21 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
         n_win_sub += __popcll(__ballot(sub_win));
         // insertion closes at this column, pyx:119-128; leading insertions (idx==0) are never opened, pyx:136
         const bool ins_close = rf_ng && (prev_rf != cidx - 1) && idx > 0;
-        const bool ins_win = ins_close && (sIncP[idx] != sIncP[idx - 1]) && (sIncP[idx + 1] != sIncP[idx]);
+        // in the window: both flanks (pyx:121) -- the legacy classifier: either flank (pyx:284)
+        const bool fl = ins_close && (sIncP[idx] != sIncP[idx - 1]), fr = ins_close && (sIncP[idx + 1] != sIncP[idx]);
+        const bool ins_win = A.legacy ? (fl || fr) : (fl && fr);
         n_all_ins += __popcll(__ballot(ins_close));
         n_win_ins += __popcll(__ballot(ins_win));
         if (ins_win) acc_ins_n += cidx - 1 - prev_rf;
         // deletion closes at this column, pyx:145-153
         const bool del_close = rd_ng && (prev_rd != cidx - 1);
         const int dlen = cidx - 1 - prev_rd;
-        const bool del_win = del_close && (sIncP[idx] != sIncP[idx - dlen]);   // include set hits range(start,end)
+        // legacy (pyx:253-258): a run that starts in column 0 or 1 is given reference start 0 (`if st-1 > 0`)
+        const int dstart = (A.legacy && prev_rd <= 0) ? 0 : idx - dlen;
+        const bool del_win = del_close && (sIncP[idx] != sIncP[dstart]);       // include set hits range(start,end)
         n_all_del += __popcll(__ballot(del_close));
         n_win_del += __popcll(__ballot(del_win));
-        if (del_close) acc_del_bases += dlen;
+        if (del_close) acc_del_bases += idx - dstart;
         if (del_win) acc_del_n += dlen;
         idx_base += __popcll(m_rf);
         if (m_rf) last_rf = base + 63 - __clzll((long long)m_rf);
@@ -641,9 +645,17 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
     int tr_bases = 0, tr_win = 0;
     if (last_rd != T - 1) {
         const int dlen = T - 1 - last_rd;
-        tr_bases = dlen;
         n_all_del += 1;
-        if (sIncP[idx_base] != sIncP[idx_base - dlen]) { tr_win = dlen; n_win_del += 1; }
+        if (!A.legacy) {
+            tr_bases = dlen;
+            if (sIncP[idx_base] != sIncP[idx_base - dlen]) { tr_win = dlen; n_win_del += 1; }
+        } else {
+            // legacy (pyx:259-261): a run that reaches the end of the alignment ends at reference index idx - 1 (exclusive), and
+            // starts at 0 if it begins in column 0 or 1
+            const int dstart = last_rd <= 0 ? 0 : idx_base - dlen, dend = idx_base - 1;
+            tr_bases = dend > dstart ? dend - dstart : 0;
+            if (dend > dstart && sIncP[dend] != sIncP[dstart]) { tr_win = dlen; n_win_del += 1; }
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -2423,6 +2435,8 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
     __syncthreads();
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
     const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
+    const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);   // string rows readable as dwords
+    const bool legacy = A.flags & C2_CNT_FLAG_LEGACY;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int cur_ref = -1;                                           // workgroup-uniform, like everything that guards a barrier
     int wsum = 0;                                               // weight accumulated since the last flush (int32 safety)
@@ -2493,6 +2507,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
             if (v_w > 0) {                                               // (an alignment that is not counted is not even read: most of an all-references batch)
                 const unsigned* rp = (const unsigned*)(A.records + my_task);
                 d0 = rp[0]; d1 = rp[1]; d2 = rp[2]; d4 = rp[4]; d5 = rp[5]; d6 = rp[6];
+                if (legacy && (rp[3] >> 16) != 0u) d4 |= 0x80000000u;         // legacy: a deletion event can have NO positions (all_deletion_bases 0): mark "has a deletion column" in the top bit
                 const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16), ref = (int)(d6 >> 16);
                 sel = ((d5 >> 24) == 0) && (T > 0);
                 if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
@@ -2551,7 +2566,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
             if (mine) {
                 const int w = v_w;
                 const int insertion_n = (int)(d1 & 0xffffu), deletion_n = (int)(d1 >> 16), substitution_n = (int)(d2 & 0xffffu);
-                const int all_ins = (int)(d2 >> 16), all_del_bases = (int)(d4 >> 16), all_sub = (int)(d5 & 0xffffu);
+                const int all_ins = (int)(d2 >> 16), all_del_bases = (int)((d4 >> 16) & 0x7fffu), all_sub = (int)(d5 & 0xffffu);
                 const bool irregular_ends = (d5 >> 16) & 0xffu;
                 const int total_mods = all_ins + all_del_bases + all_sub;                               // :741
                 const int in_win = substitution_n + deletion_n + insertion_n;                           // :742
@@ -2598,25 +2613,60 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 const int w = __builtin_amdgcn_readlane(v_w, kk);
                 const int T = (int)(r0 & 0xffffu);
                 const int insertion_n = (int)(r1 & 0xffffu), deletion_n = (int)(r1 >> 16), substitution_n = (int)(r2 & 0xffffu);
-                const int all_ins = (int)(r2 >> 16), all_del_bases = (int)(r4 >> 16), all_sub = (int)(r5 & 0xffffu);
+                const int all_ins = (int)(r2 >> 16), all_del_bases = (int)((r4 >> 16) & 0x7fffu), all_sub = (int)(r5 & 0xffffu);
+                const bool any_del_column = (r4 >> 16) != 0u;                                      // (positions, or the legacy marker)
                 const bool irregular_ends = (r5 >> 16) & 0xffu;
-                // first 256 columns of both strings: requested now, consumed by the column walk below
                 const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride;
                 const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride;
+                if (discard && (deletion_n > 0 || insertion_n > 0)) continue;                      // counted above; no vectors (:3996-4000)
+                if (rows_aligned && T == Li && !any_del_column) {
+                    // No gap column in either string (the usual read).  Four columns per lane: read and reference as dwords, the bytes
+                    // in which they differ by the "has a zero byte" trick on their XOR; only those add anything (the DEVIATIONS from
+                    // "the reference's own base, once per read": see the byte-wise walk below)
+                    for (int base = 0; base < T; base += 256) {
+                        const int p = base + 4 * lane, nb = T - p;
+                        unsigned rdw = 0, rfw = 0;
+                        if (nb > 0) { rdw = ((const unsigned*)R_)[p >> 2]; rfw = ((const unsigned*)F_)[p >> 2]; }
+                        const unsigned valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
+                        const unsigned x = (rdw ^ rfw) & valid;
+                        unsigned mm = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+                        while (mm) {
+                            const int b = __builtin_ctz(mm) >> 3;
+                            mm &= mm - 1u;
+                            const int c = p + b;
+                            const unsigned char rd = (unsigned char)(rdw >> (8 * b)), rfc = (unsigned char)(rfw >> (8 * b));
+                            const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
+                            if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
+                            if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
+                            if (rd != 'N') {
+                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
+                                if (!ign_sub) {
+                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
+                                    int sv = -1;                                                // :4049-4054
+                                    if (rd == 'A') sv = C2_V_ALL_SUB_BASE_A; else if (rd == 'C') sv = C2_V_ALL_SUB_BASE_C;
+                                    else if (rd == 'G') sv = C2_V_ALL_SUB_BASE_G; else if (rd == 'T') sv = C2_V_ALL_SUB_BASE_T;
+                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
+                                }
+                            }
+                        }
+                    }
+                    if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
+                    continue;
+                }
+                // first 256 columns of both strings: requested now, consumed by the column walk below
                 unsigned rd4 = 0, rf4 = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = 64 * q + lane;
                     if (c < T) { rd4 |= (unsigned)R_[c] << (8 * q); rf4 |= (unsigned)F_[c] << (8 * q); }
                 }
-                if (discard && (deletion_n > 0 || insertion_n > 0)) continue;                      // counted above; no vectors (:3996-4000)
                 const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
                 const bool modified = has_del || has_ins || has_sub;
                 const bool len_block = modified;                                                // :4085 (no coding sequence)
                 // ---- column walk (same scan as the fused classifier), ds_add into the vectors
                 int idx_base = 0, last_rf = -1, last_rd = -1;
                 bool last_rf_close = false, last_rf_wclose = false;
-                if (T == Li && all_del_bases == 0) {
+                if (T == Li && !any_del_column) {
                     // No gap column in either string: the reference index of a column is the column, only substitutions can
                     // occur, and the read's base counts differ from "the reference's own base, once per read" only where the
                     // read differs from the reference.  So the walk adds the DEVIATIONS (+w on the read's base, -w on the
@@ -2678,7 +2728,8 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                     }
                     // insertions: positions [idx-1, idx] of every event; numpy's fancy += counts a repeated position once (:4016, :4021)
                     const bool ins_close = rf_ng && (prev_rf != c - 1) && idx > 0;
-                    const bool ins_win = ins_close && (incp[idx] != incp[idx - 1]) && (incp[idx + 1] != incp[idx]);
+                    const bool fl = ins_close && (incp[idx] != incp[idx - 1]), fr = ins_close && (incp[idx + 1] != incp[idx]);
+                    const bool ins_win = legacy ? (fl || fr) : (fl && fr);                              // pyx:121 / legacy pyx:284
                     const unsigned long long m_ic = __ballot(ins_close), m_iw = __ballot(ins_win);
                     if (ins_close) {
                         const bool prev_close = (prev_rf >= base) ? ((m_ic >> (prev_rf - base)) & 1ull) : last_rf_close;
@@ -2702,9 +2753,13 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                     const bool del_close = rd_ng && (prev_rd != c - 1);
                     if (del_close) {
                         const int dlen = c - 1 - prev_rd;
-                        if (incp[idx] != incp[idx - dlen]) {
-                            if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + idx - dlen, w); atomicAdd(acc + C2_V_DELETION * VL + idx, -w); }   // :4031
-                            if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx - dlen, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx, -dlen * w); }   // :4114
+                        // legacy (pyx:253-258): a run that starts in column 0 or 1 gets reference start 0 -- position 0 joins its
+                        // positions although the read has a base there
+                        const int dstart = (legacy && prev_rd <= 0) ? 0 : idx - dlen;
+                        if (legacy && prev_rd == 0) atomicAdd(acc + C2_V_ALL_DELETION * VL + 0, w);
+                        if (incp[idx] != incp[dstart]) {
+                            if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + dstart, w); atomicAdd(acc + C2_V_DELETION * VL + idx, -w); }   // :4031
+                            if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx, -dlen * w); }   // :4114
                         }
                     }
                     idx_base += __popcll(m_rf);
@@ -2718,9 +2773,15 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 }
                 if (last_rd != T - 1 && lane == 0) {                                                    // trailing deletion, pyx:155-162
                     const int dlen = T - 1 - last_rd;
-                    if (incp[idx_base] != incp[idx_base - dlen]) {
-                        if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + idx_base - dlen, w); atomicAdd(acc + C2_V_DELETION * VL + idx_base, -w); }
-                        if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx_base - dlen, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx_base, -dlen * w); }
+                    // legacy (pyx:259-261): the run ends at reference index idx - 1, exclusive -- the last base is not among its positions
+                    const int dstart = (legacy && last_rd <= 0) ? 0 : idx_base - dlen, dend = legacy ? idx_base - 1 : idx_base;
+                    if (legacy) {
+                        atomicAdd(acc + C2_V_ALL_DELETION * VL + idx_base - 1, -w);
+                        if (last_rd == 0) atomicAdd(acc + C2_V_ALL_DELETION * VL + 0, w);
+                    }
+                    if (dend > dstart && incp[dend] != incp[dstart]) {
+                        if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + dstart, w); atomicAdd(acc + C2_V_DELETION * VL + dend, -w); }
+                        if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dend, -dlen * w); }
                     }
                 }
             }   // tasks of this round

@@ -198,10 +198,15 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
             now = time.perf_counter()
             timings[name] = timings.get(name, 0.0) + now - t_last[0]
             t_last[0] = now
-    if getattr(args, 'use_legacy_insertion_quantification', False):
-        # find_indels_substitutions_legacy (an insertion counts when EITHER flank is in the window, COREResources.pyx:284) is not
-        # what the kernels' fused classification computes; the per-read route has it (c2_classify_lists_kernel, legacy=1)
-        raise NotImplementedError("use_legacy_insertion_quantification: use variants.process_fastq (per-read route) for this run")
+    legacy = bool(getattr(args, 'use_legacy_insertion_quantification', False))
+    if legacy:
+        # find_indels_substitutions_legacy (COREResources.pyx:190-315) on the count route: the fused classifier and the count kernel
+        # follow its rules (an insertion counts when EITHER flank is in the window; its reference coordinates of a deletion that starts
+        # in column 0 / 1 or reaches the end).  Its `nucSet` treats any other reference character as a gap, which the kernels do not.
+        for name in ref_names:
+            if set(refs[name]['sequence']) - set('ACGTN'):
+                raise NotImplementedError("use_legacy_insertion_quantification with a reference character outside ACGTN: "
+                                          "use variants.process_fastq (per-read route) for this run")
     scaffold_rule = bool(getattr(args, 'prime_editing_pegRNA_scaffold_seq', '')) and 'Prime-edited' in ref_names
     if scaffold_rule and (pe_scaffold_dna_info is None or pe_scaffold_dna_info[1] is None):
         raise ValueError("prime_editing_pegRNA_scaffold_seq needs pe_scaffold_dna_info = (index, dna) of get_pe_scaffold_search")
@@ -221,7 +226,8 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     layout = C.CountLayout(k, max(L), max_lj)
     d_counts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
     flags = ((C.FLAG_IGNORE_SUBSTITUTIONS if args.ignore_substitutions else 0) | (C.FLAG_IGNORE_INSERTIONS if args.ignore_insertions else 0) |
-             (C.FLAG_IGNORE_DELETIONS if args.ignore_deletions else 0) | (C.FLAG_DISCARD_INDEL_READS if getattr(args, 'discard_indel_reads', False) else 0))
+             (C.FLAG_IGNORE_DELETIONS if args.ignore_deletions else 0) | (C.FLAG_DISCARD_INDEL_READS if getattr(args, 'discard_indel_reads', False) else 0) |
+             (C.FLAG_LEGACY_CLASSIFIER if legacy else 0))
     stats = dict(N_TOT_READS=int(np.asarray(read_counts, dtype=np.int64).sum()), N_CACHED_ALN=0, N_CACHED_NOTALN=0, N_COMPUTED_ALN=0,
                  N_COMPUTED_NOTALN=0, N_GLOBAL_SUBS=0, N_SUBS_OUTSIDE_WINDOW=0, N_MODS_IN_WINDOW=0, N_MODS_OUTSIDE_WINDOW=0,
                  N_READS_IRREGULAR_ENDS=0, N_TOTAL=0, N_AMBIGUOUS=0)
@@ -261,7 +267,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     f1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
     r1 = torch.empty((n1, 32), dtype=torch.uint8, device=dev)
     aligner.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), a1.data_ptr(), f1.data_ptr(), r1.data_ptr(), stride, max_lj,
-                         d_strands=d_str1.data_ptr(), all_refs=True, stream=stream)
+                         d_strands=d_str1.data_ptr(), all_refs=True, stream=stream, legacy=legacy)
     lap("h2d_align")
 
     # ---- batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments
@@ -285,7 +291,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
         f2 = torch.empty((n2, stride2), dtype=torch.uint8, device=dev)
         r2 = torch.empty((n2, 32), dtype=torch.uint8, device=dev)
         aligner.align_device(n2, d_reads2.data_ptr(), d_off2.data_ptr(), a2.data_ptr(), f2.data_ptr(), r2.data_ptr(), stride2, max_lj2,
-                             d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=stream)
+                             d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=stream, legacy=legacy)
     lap("both_strand_pairs")
     # ---- strand and reference choice (:683, :697-707), ambiguity, aln_stats: on the device.  Host selection (the same
     # comparisons on Python floats) remains for what the kernel's 64-bit masks / exact integer scores do not cover.
@@ -433,13 +439,13 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
             wv[:, 0] = np.where(for_r & ~use2[:, 0], cnt, 0)
             d_wv = torch.from_numpy(wv.reshape(-1).view(np.int32)).to(dev)
             C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_view[r].data_ptr(),
-                                d_weights=d_wv.data_ptr(), flags=C.FLAG_ALL_REFS_LAYOUT, stream=stream)
+                                d_weights=d_wv.data_ptr(), flags=C.FLAG_ALL_REFS_LAYOUT | (C.FLAG_LEGACY_CLASSIFIER if legacy else 0), stream=stream)
             if n2:
                 wv2 = np.where((br == 0) & for_r[bi] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
                 if wv2.any():
                     d_wv2 = torch.from_numpy(wv2.view(np.int32)).to(dev)
                     C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_view[r].data_ptr(),
-                                        d_weights=d_wv2.data_ptr(), flags=0, stream=stream)
+                                        d_weights=d_wv2.data_ptr(), flags=C.FLAG_LEGACY_CLASSIFIER if legacy else 0, stream=stream)
             torch.cuda.synchronize(dev)                              # the weight tensors of this round are done with
     if reduce_across_ranks:
         C.all_reduce(d_counts)

@@ -111,9 +111,11 @@ typedef struct c2_batch {
     uint8_t* aln_read;         /* n_tasks x aln_stride: aligned read  (global_align()[0]) */
     uint8_t* aln_ref;          /* n_tasks x aln_stride: aligned reference (global_align()[1]) */
     uint32_t aln_stride;       /* >= longest read + longest reference */
-    uint32_t reserved2;
+    uint32_t flags;            /* C2_BATCH_*: bit 0 = the record's window counts follow find_indels_substitutions_legacy
+                                  (--use_legacy_insertion_quantification, CRISPRessoCORE.py:721-722) */
     c2_aln_record* records;    /* n_tasks */
 } c2_batch;
+#define C2_BATCH_LEGACY_CLASSIFIER 1u
 
 /* All pointers in `b` are DEVICE pointers; the launch is enqueued on `hip_stream` (a hipStream_t; NULL is HIP's
  * default stream, exactly as in hipLaunchKernelGGL) and the call returns without waiting. */
@@ -150,6 +152,8 @@ int c2_launch_info(c2_ctx* ctx, int32_t max_read_len, int32_t* rows_per_lane, in
 #define C2_COUNT_IGNORE_DELETIONS     4   /* --ignore_deletions */
 #define C2_COUNT_DISCARD_INDEL_READS  8   /* --discard_indel_reads */
 #define C2_COUNT_ALL_REFS_LAYOUT      16  /* the tasks are one all_refs batch (task = read * n_refs + reference; n_tasks a multiple of n_refs) */
+#define C2_COUNT_LEGACY_CLASSIFIER    32  /* positions as find_indels_substitutions_legacy gives them (COREResources.pyx:190-315); the records must come
+                                             from a batch aligned with C2_BATCH_LEGACY_CLASSIFIER */
 
 /* All d_* are device pointers (outputs of c2_align_classify_batch_device); d_weights: per task read multiplicity, 0 = do not
  * count this alignment, NULL = 1.  h_min_matches: HOST table n_refs x (max_t+1) of the smallest `matches` whose score

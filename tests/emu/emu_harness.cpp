@@ -87,7 +87,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
     std::vector<uint32_t> plane;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0;
-    A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0; A.reserved4 = 0;
+    A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0; A.legacy = getenv("C2_EMU_LEGACY") ? 1 : 0;
     A.mat_dim = sc.mat_dim; A.first_ext_code = sc.first_ext_code;
     c2_build_base_luts(sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
     if (no_packed) A.lut_chr_lo = A.lut_chr_hi = 0xffffffffu;

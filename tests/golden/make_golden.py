@@ -332,7 +332,7 @@ def dump(name, obj):
     print("%-22s %6d vectors %8.1f KB" % (name, len(obj), os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv and "--variant-scaffold" not in sys.argv and "--single-runs" not in sys.argv and "--core-calls" not in sys.argv:
+if __name__ == "__main__" and "--variants" not in sys.argv and "--fanc" not in sys.argv and "--paired" not in sys.argv and "--variant-io" not in sys.argv and "--paired-fastq" not in sys.argv and "--sam" not in sys.argv and "--fanc-full" not in sys.argv and "--params" not in sys.argv and "--both" not in sys.argv and "--pe" not in sys.argv and "--pe-scaffold" not in sys.argv and "--legacy" not in sys.argv and "--variant-scaffold" not in sys.argv and "--single-runs" not in sys.argv and "--core-calls" not in sys.argv:
     dump("ref_unit_kats.json", record_unit_kats())
     dump("fuzz_align.json", fuzz_align())
     dump("fuzz_classify.json", fuzz_classify())
@@ -642,6 +642,89 @@ if __name__ == "__main__" and "--both" in sys.argv:
     with gzip.open(os.path.join(HERE, "both_run.json.gz"), "wt") as fh:
         json.dump(d, fh, separators=(",", ":"))
     print("both_run.json.gz written:", len(d["files"]), "files", d["alignment_stats"])
+
+
+# ---------------------------------------------------------------- 6d'. a run with --use_legacy_insertion_quantification
+def legacy_run():
+    """The reference's main() with --use_legacy_insertion_quantification (find_indels_substitutions_legacy, COREResources.pyx:190-315)
+    and a 2-bp window (-w 2, so the either-flank rule of the legacy insertion test changes what is counted): the first 150 FANC.Cas9
+    reads plus reads built for the legacy corner cases -- an insertion whose left / right flank alone is in the window, reads that
+    stop short of the amplicon's end (trailing deletion: its last base is not a deleted position), reads that start one / two bases
+    late (a deletion run in column 0 / 1 starts at reference position 0)."""
+    import importlib
+    import zipfile
+    core = load_reference_core()
+    P = importlib.import_module("CRISPResso2.plots.CRISPRessoPlot")
+    for k in dir(P):
+        if k.startswith("plot_") and callable(getattr(P, k)):
+            setattr(P, k, (lambda *a, **kw: None))
+    g = fanc_run()
+    amp, guide = g["amplicon"], g["guide"]
+    cut = g["cut_point"]
+    lines = g["fastq"].split("\n")
+    recs = ["%s\n%s\n%s\n%s\n" % tuple(lines[k:k + 4]) for k in range(0, 4 * 150, 4)]
+    built = []
+    for off in (-3, -2, -1, 0, 1, 2, 3, 4):                                        # insertions walking across the window
+        for ins in ("G", "TT", "ACG"):
+            built.append(amp[:cut + off] + ins + amp[cut + off:])
+    for short in (1, 2, 3, 5):
+        built.append(amp[:-short])                                                  # trailing deletion
+        built.append(amp[short:])                                                   # leading deletion
+        built.append(amp[:1] + amp[1 + short:])                                     # deletion run from column 1
+        built.append(amp[:cut - 1] + amp[cut - 1 + short:])                         # deletion at the cut
+    built.append(amp[:-1] + ("A" if amp[-1] != "A" else "C"))                       # substitution in the last base
+    built.append(amp[:cut] + "GG" + amp[cut + 4:-2])                                # insertion + deletion + short end
+    for n, seq in enumerate(built):
+        for rep in range(1 + n % 3):
+            recs.append("@built_%d_%d\n%s\n+\n%s\n" % (n, rep, seq, "I" * len(seq)))
+    fastq = "".join(recs)
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fq = os.path.join(tmp, "legacy.fastq")
+        with open(fq, "w") as fh:
+            fh.write(fastq)
+        argv = ["CRISPResso", "-r1", fq, "-a", amp, "-g", guide, "-w", "2", "--use_legacy_insertion_quantification", "--suppress_report", "-o", tmp]
+        old = sys.argv
+        sys.argv = argv
+        try:
+            core.main()
+        except SystemExit as e:
+            assert e.code in (0, None), e.code
+        finally:
+            sys.argv = old
+        out = os.path.join(tmp, "CRISPResso_on_legacy")
+        with open(os.path.join(out, "CRISPResso2_info.json")) as fh:
+            info = json.load(fh)
+        for fn in sorted(os.listdir(out)):
+            base = fn.split(".", 1)[1] if fn.split(".", 1)[0] in info["results"]["refs"] else fn
+            if fn.endswith(".txt") and any(base == t or (t.endswith("_") and base.startswith(t)) for t in PARAMS_TABLES):
+                with open(os.path.join(out, fn)) as fh:
+                    files[fn] = fh.read()
+        with zipfile.ZipFile(os.path.join(out, "Alleles_frequency_table.zip")) as z:
+            files["Alleles_frequency_table.txt"] = z.read("Alleles_frequency_table.txt").decode()
+    refs = []
+    for nm, r in info["results"]["refs"].items():
+        inc = r["include_idxs"]["value"] if isinstance(r["include_idxs"], dict) else r["include_idxs"]
+        refs.append({"name": nm, "sequence": r["sequence"], "min_aln_score": r["min_aln_score"], "gap_incentive": r["gap_incentive"]["value"],
+                     "include_idxs": [int(x) for x in inc], "sgRNA_cut_points": r["sgRNA_cut_points"],
+                     "sgRNA_orig_sequences": r["sgRNA_orig_sequences"], "sgRNA_names": r["sgRNA_names"],
+                     "fw_seeds": r["fw_seeds"], "rc_seeds": r["rc_seeds"]})
+    a = info["running_info"]["args"]["value"] if "value" in info["running_info"]["args"] else info["running_info"]["args"]
+    keep = ("aln_seed_count", "aln_seed_len", "aln_seed_min", "needleman_wunsch_gap_open", "needleman_wunsch_gap_extend",
+            "use_legacy_insertion_quantification", "ignore_deletions", "ignore_insertions", "ignore_substitutions",
+            "assign_ambiguous_alignments_to_first_reference", "expand_ambiguous_alignments", "prime_editing_pegRNA_scaffold_seq",
+            "discard_indel_reads", "plot_window_size", "dsODN", "expected_hdr_amplicon_seq", "prime_editing_pegRNA_extension_seq")
+    return {"command": "CRISPResso -r1 legacy.fastq " + " ".join(argv[3:-2]), "fastq": fastq, "refs": refs, "args": {k: a[k] for k in keep},
+            "alignment_stats": info["running_info"]["alignment_stats"], "files": files}
+
+
+if __name__ == "__main__" and "--legacy" in sys.argv:
+    import gzip
+    d = legacy_run()
+    assert d["args"]["use_legacy_insertion_quantification"] is True
+    with gzip.open(os.path.join(HERE, "legacy_run.json.gz"), "wt") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    print("legacy_run.json.gz written:", len(d["files"]), "files", d["alignment_stats"])
 
 
 # ---------------------------------------------------------------- 6e. a prime-editing run (Reference + Prime-edited amplicon, ambiguous reads)

@@ -31,7 +31,12 @@ class EmulatedAligner:
         return (self.max_ref_len + int(max_read_len) + 15) // 16 * 16
 
     def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
-                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None):
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False):
+        import os
+        if legacy:
+            os.environ["C2_EMU_LEGACY"] = "1"
+        else:
+            os.environ.pop("C2_EMU_LEGACY", None)
         n, k = int(n_reads), len(self.seqs)
         off = _view(d_offsets, 8 * (n + 1)).view(np.int64)
         arena = _view(d_reads, max(int(off[-1]), 1)).tobytes()

@@ -98,3 +98,77 @@ def test_min_matches_table_is_the_reference_expression():
             m = int(row[T])
             assert m > T or round(100 * m / float(T), 3) > thr
             assert m == 0 or not (round(100 * (m - 1) / float(T), 3) > thr)
+
+
+# ---- --use_legacy_insertion_quantification on the count route -----------------------------------------------------------
+_LIST_NAMES = ("ref_positions", "all_insertion_positions", "all_insertion_left_positions", "insertion_positions", "insertion_coordinates",
+               "insertion_sizes", "all_deletion_positions", "all_deletion_coordinates", "deletion_positions", "deletion_coordinates",
+               "deletion_sizes", "all_substitution_positions", "all_substitution_values", "substitution_positions", "substitution_values")
+
+
+def legacy_payload(s1, s2, inc):
+    """find_indels_substitutions_legacy's payload: from the reference's own module when oracle/_ref is built, else from the emulated
+    c2_classify_lists_kernel with legacy = 1 (itself pinned against reference-generated vectors, test_kernel_emulated.py)."""
+    ref = oracle.ref()
+    if ref is not None:
+        p = dict(ref[1].find_indels_substitutions_legacy(s1, s2, inc))
+        p["insertion_n"], p["deletion_n"] = int(p["insertion_n"]), int(p["deletion_n"])
+    else:
+        lists, cnt = E.classify_lists(s1, s2, inc, legacy=True)
+        p = dict(zip(_LIST_NAMES, lists))
+        for k in ("insertion_coordinates", "all_deletion_coordinates", "deletion_coordinates"):
+            p[k] = [(p[k][i], p[k][i + 1]) for i in range(0, len(p[k]), 2)]
+        p["insertion_n"], p["deletion_n"], p["substitution_n"] = cnt
+    p["aln_seq"], p["aln_ref"] = s1, s2
+    return p
+
+
+def test_legacy_classifier_on_the_count_route(monkeypatch):
+    """Fused classifier + count kernel with the legacy rules (COREResources.pyx:190-315): an insertion counts when EITHER flank is in
+    the window; a deletion that starts in column 0 or 1 gets reference start 0; one that reaches the end of the alignment stops
+    one base short.  Reads built to hit exactly those cases, window edges next to the events; records and every count vector
+    against the reference's legacy classifier + the restated aggregation loop."""
+    E.build()
+    m = matrices()["EDNAFULL"]
+    rng = np.random.default_rng(2024)
+    amp = "".join(rng.choice(list("ACGT"), 120))
+    g = np.zeros(121, dtype=np.int64); g[61] = 1
+    reads = []
+    for _ in range(60):
+        t = list(amp)
+        for _ in range(int(rng.integers(0, 3))):
+            t[int(rng.integers(0, 120))] = str(rng.choice(list("ACGTN")))
+        t = "".join(t)
+        k = rng.random()
+        if k < 0.2:   t = t[0] + t[int(rng.integers(2, 9)):]                           # deletion that starts in column 1
+        elif k < 0.35: t = t[int(rng.integers(1, 7)):]                                  # leading deletion
+        elif k < 0.55: t = t[:120 - int(rng.integers(1, 8))]                            # trailing deletion
+        elif k < 0.75:
+            p0 = int(rng.integers(40, 80)); t = t[:p0] + "".join(rng.choice(list("ACGT"), int(rng.integers(1, 6)))) + t[p0:]   # insertion
+        elif k < 0.9:
+            p0 = int(rng.integers(40, 80)); t = t[:p0] + t[p0 + int(rng.integers(1, 12)):]
+        reads.append(t)
+    reads += [amp[0] + amp[3:118], amp[:119], amp[1:]]                                  # column-1 start AND trailing; one-base trailing; one-base leading
+    for inc in ([59, 60], list(range(55, 66)), [0, 1, 2], [117, 118, 119], list(range(0, 120))):
+        monkeypatch.setenv("C2_EMU_LEGACY", "1")
+        st = {}
+        res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+        o1, o2 = st["raw"]
+        P = [legacy_payload(s1, s2, inc) for s1, s2 in res]
+        for k, p in enumerate(P):
+            r = rec[k]
+            assert r["status"] == 0
+            assert (int(r["insertion_n"]), int(r["deletion_n"]), int(r["substitution_n"])) == (p["insertion_n"], p["deletion_n"], p["substitution_n"]), (inc[:3], k, res[k])
+            assert int(r["all_deletion_bases"]) == len(p["all_deletion_positions"]), (k, res[k])
+            assert int(r["win_insertion_events"]) == len(p["insertion_sizes"]) and int(r["all_insertion_events"]) == len(p["all_insertion_left_positions"])
+            assert int(r["win_deletion_events"]) == len(p["deletion_sizes"]) and int(r["all_deletion_events"]) == len(p["all_deletion_coordinates"])
+        w = rng.integers(1, 9, len(reads)).astype(np.uint32)
+        counts, lay = E.count_vectors(o1, o2, rec, [amp], [inc], max(len(r) for r in reads), weights=w, flags=C.FLAG_LEGACY_CLASSIFIER)
+        got = lay.unpack(counts, 0, len(amp))
+        exp = aggregate.aggregate([(p, int(c)) for p, c in zip(P, w)], len(amp))
+        compare(got, exp, len(amp))
+    # and the default classifier disagrees on these reads (the test would not notice a flag that does nothing)
+    monkeypatch.delenv("C2_EMU_LEGACY")
+    res2, rec2 = E.align_batch(reads, [amp], [g], [list(range(55, 66))], m, -20, -2, band_lanes=-87)
+    assert res2 == res
+    assert (rec2["all_deletion_bases"] != [len(legacy_payload(s1, s2, [0])["all_deletion_positions"]) for s1, s2 in res]).any()

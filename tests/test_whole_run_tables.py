@@ -518,14 +518,50 @@ def test_pipeline_on_the_emulator_prime_editing_run(tmp_path):
     a = dict(g["args"], prime_editing_pegRNA_scaffold_seq="GGCACCGAGTCGGTGC")
     with pytest.raises(ValueError):                                 # a scaffold sequence without the (index, dna) of get_pe_scaffold_search
         pipeline.quantify_unique(None, None, [1], refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
-    with pytest.raises(NotImplementedError):                        # the count route has no legacy insertion rule and says so
-        pipeline.quantify_unique(None, None, [1], refs, names, matrices()["EDNAFULL"], _pipeline_args(dict(g["args"], use_legacy_insertion_quantification=True)))
+    odd = {n: dict(refs[n], sequence=refs[n]["sequence"][:5] + "R" + refs[n]["sequence"][6:]) for n in names}
+    with pytest.raises(NotImplementedError):                        # the legacy classifier's nucSet rule for a non-ACGTN reference base is not on the count route
+        pipeline.quantify_unique(None, None, [1], odd, names, matrices()["EDNAFULL"], _pipeline_args(dict(g["args"], use_legacy_insertion_quantification=True)))
 
 
 @pytest.mark.gpu
 def test_prime_editing_run_on_the_device(tmp_path):
     from crispresso2_amd import _native
     _pe_run(tmp_path, ctx=_native.default_context())
+
+
+# ---- --use_legacy_insertion_quantification: find_indels_substitutions_legacy on the count route ------------------------------------
+def _legacy_run(tmp_path, ctx=None):
+    from crispresso2_amd import pipeline, tables
+    g, refs, names = _params_golden("legacy_run.json.gz")
+    assert g["args"]["use_legacy_insertion_quantification"] is True
+    fq = tmp_path / "legacy.fastq"
+    fq.write_text(g["fastq"])
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a), ctx=ctx)
+    for k in ("N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN", "N_TOT_READS", "N_GLOBAL_SUBS",
+              "N_SUBS_OUTSIDE_WINDOW", "N_MODS_IN_WINDOW", "N_MODS_OUTSIDE_WINDOW", "N_READS_IRREGULAR_ENDS", "N_READS_INPUT"):
+        assert res.stats[k] == g["alignment_stats"][k], k
+    out = tmp_path / "CRISPResso_on_legacy"
+    written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+    assert _compare_params(g, written, str(out)) == len(g["files"])
+    # the same reads under the default classifier give different tables (the golden pins the legacy rules, not the common part)
+    res2 = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(dict(a, use_legacy_insertion_quantification=False)), ctx=ctx)
+    assert res2.stats["N_MODS_IN_WINDOW"] != res.stats["N_MODS_IN_WINDOW"] or res2.stats["N_MODS_OUTSIDE_WINDOW"] != res.stats["N_MODS_OUTSIDE_WINDOW"]
+
+
+def test_pipeline_on_the_emulator_legacy_insertion_quantification_run(tmp_path):
+    """make_golden.py --legacy: the reference's main() with --use_legacy_insertion_quantification -w 2 over FANC reads plus reads
+    built for the legacy corner cases (one-flank insertions, trailing / leading / column-1 deletions) -> its 18 result files,
+    from the fused classifier's legacy rules and the count kernel's legacy coordinates."""
+    from pipeline_on_emulator import emulated_device
+    with emulated_device():
+        _legacy_run(tmp_path)
+
+
+@pytest.mark.gpu
+def test_legacy_insertion_quantification_run_on_the_device(tmp_path):
+    from crispresso2_amd import _native
+    _legacy_run(tmp_path, ctx=_native.default_context())
 
 
 # ---- prime editing with a scaffold sequence: the 'Scaffold-incorporated' amplicon nothing is aligned to -----------------------------
