@@ -84,8 +84,8 @@ struct c2_ctx {
     DevBuf d_lists, d_lists_out;   // batched classifier: staging and flat output
     DevBuf d_order;        // count kernel: histogram + tasks grouped by reference
     int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
-    int occ_lds[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
-    int occ_blocks[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int occ_lds[5][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
+    int occ_blocks[5][3] = {};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
     DevBuf d_sel;          // selection kernel: per-reference score thresholds
     ncclComm_t comm = nullptr; // RCCL communicator of c2_comm_init (one rank per GPU)
@@ -121,6 +121,7 @@ void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0;
 struct Geometry {
     int R, passes, max_lj;
     uint32_t lds_full; int blocks_full;          // full pointer plane
+    bool full_hbm; uint64_t full_plane_words;    // ... in per-workgroup HBM scratch (it does not fit LDS): 32-bit words per workgroup
     int band_lanes; uint32_t lds_band; int blocks_band;   // banded first launch (band_lanes == 0: not used)
     bool diag; uint32_t lds_diag; int blocks_diag;         // diagonal-band launches
     bool x[2]; uint32_t lds_x[2]; int blocks_x[2]; uint32_t plane_words;   // multi-alignment tiers in front of it: 4, 2 per wavefront
@@ -128,11 +129,11 @@ struct Geometry {
     bool pk2; uint32_t lds_pk2; int blocks_pk2; uint32_t plane_words_pk2;  // packed second tier (4 per wavefront, 62 diagonals) in place of the 2-per-wavefront one
 };
 
-template <int R, bool BAND>
+template <int R, int BAND>          // (the kernel's MODE: 0 full plane in LDS, 1 banded, 2 full plane in HBM)
 int occupancy(c2_ctx* ctx, uint32_t lds, int& blocks) {
     // cached per (kernel instance, LDS size): the per-call API path comes through here for every alignment
-    int& cached_lds = ctx->occ_lds[R][BAND ? 1 : 0];
-    int& cached_blocks = ctx->occ_blocks[R][BAND ? 1 : 0];
+    int& cached_lds = ctx->occ_lds[R][BAND];
+    int& cached_blocks = ctx->occ_blocks[R][BAND];
     if (cached_lds != (int)lds) {
         int nb = 0;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_classify_kernel<R, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -144,7 +145,7 @@ int occupancy(c2_ctx* ctx, uint32_t lds, int& blocks) {
     return 0;
 }
 
-template <bool BAND>
+template <int BAND>
 int occupancy_r(c2_ctx* ctx, int R, uint32_t lds, int& blocks) {
     switch (R) {
         case 1: return occupancy<1, BAND>(ctx, lds, blocks);
@@ -174,13 +175,20 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     g.max_lj = std::max(max_lj, 1);
     const size_t lds_cu = 163840;
     g.lds_full = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes, 0).total;
-    if (g.lds_full > lds_cu) {
-        ctx->err = "alignment of " + std::to_string(ctx->max_li) + " x " + std::to_string(g.max_lj) +
-                   " needs " + std::to_string(g.lds_full) + " bytes of LDS pointer plane; limit is " + std::to_string(lds_cu);
-        return C2_E_TOO_LARGE;
-    }
+    g.full_hbm = false; g.full_plane_words = 0;
     int rc;
-    if ((rc = occupancy_r<false>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
+    if (g.lds_full > lds_cu || getenv("C2_FORCE_HBM_PLANE")) {
+        // the full pointer plane does not fit LDS: it goes to per-workgroup scratch in HBM, LDS keeps the O(Li + Lj) parts
+        g.full_hbm = true;
+        g.lds_full = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes, 0, true).total;
+        g.full_plane_words = (c2_hbm_plane_halfwords(g.max_lj, g.passes) + 1) / 2;
+        if (g.lds_full > lds_cu || g.full_plane_words > 0xFFFFFFFFull) {
+            ctx->err = "alignment of " + std::to_string(ctx->max_li) + " x " + std::to_string(g.max_lj) +
+                       " needs " + std::to_string(g.lds_full) + " bytes of LDS for its strings and boundary rows; limit is " + std::to_string(lds_cu);
+            return C2_E_TOO_LARGE;
+        }
+        if ((rc = occupancy_r<2>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
+    } else if ((rc = occupancy_r<0>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
     // Diagonal-band first launch (c2_align_diag_kernel): needs the packed score rows and a negative per-gap-base bound
     g.diag = false; g.lds_diag = 0; g.blocks_diag = 0;
     for (int t = 0; t < 2; ++t) { g.x[t] = false; g.lds_x[t] = 0; g.blocks_x[t] = 0; }
@@ -247,7 +255,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     // a CU (the DP is latency-bound at one wave per SIMD).  band: -1 auto, 0 off, >0 lanes on each side.
     g.band_lanes = 0; g.lds_band = 0; g.blocks_band = 0;
     int want = ctx->kernel_mode == 2 ? 0 : ctx->band_setting;
-    if (!g.diag && g.passes == 1 && want != 0) {
+    if (!g.diag && g.passes == 1 && want != 0 && !g.full_hbm) {
         if (want < 0) {
             // auto: the widest band whose plan still lets `band_target_wgs` workgroups share a CU's LDS
             want = 0;
@@ -257,18 +265,39 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
         if (want >= 2 && c2_band_slots(g.R, want) < C2_LANES - 8) {
             g.band_lanes = want;
             g.lds_band = c2_make_plan(g.R, g.max_lj, 1, ctx->sc.n_codes, want).total;
-            if ((rc = occupancy_r<true>(ctx, g.R, g.lds_band, g.blocks_band))) return rc;
+            if ((rc = occupancy_r<1>(ctx, g.R, g.lds_band, g.blocks_band))) return rc;
             if (g.blocks_band <= g.blocks_full) g.band_lanes = 0;      // no occupancy to gain
         }
     }
     return 0;
 }
 
-template <int R, bool BAND>
+template <int R, int BAND>
 int launch_one(c2_ctx* ctx, const c2_align_args& A, uint32_t lds, int blocks_per_cu, uint64_t work_items, hipStream_t s) {
     const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)blocks_per_cu;
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(work_items, resident));
     hipLaunchKernelGGL((c2_align_classify_kernel<R, BAND>), dim3(grid), dim3(64), lds, s, A);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// workgroups of the HBM-plane launch: what is resident, but no more than fit C2_HBM_PLANE_BUDGET bytes of scratch
+constexpr uint64_t C2_HBM_PLANE_BUDGET = 8ull << 30;
+uint64_t hbm_plane_wgs(const c2_ctx* ctx, const Geometry& g, uint64_t work_items) {
+    const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)g.blocks_full;
+    const uint64_t by_budget = std::max<uint64_t>(1, C2_HBM_PLANE_BUDGET / (g.full_plane_words * 4));
+    return std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(work_items, resident), by_budget));
+}
+
+// the last launch of every chain: full pointer plane, in LDS or (if it does not fit) in HBM scratch
+template <int R>
+int launch_full(c2_ctx* ctx, c2_align_args& A, const Geometry& g, hipStream_t s) {
+    if (!g.full_hbm) return launch_one<R, 0>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s);
+    const uint64_t wgs = hbm_plane_wgs(ctx, g, A.n_tasks);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_plane, (size_t)(wgs * g.full_plane_words * sizeof(uint32_t))))) return rc;
+    A.plane = (uint32_t*)ctx->d_plane.p; A.plane_words_per_wg = (uint32_t)g.full_plane_words;
+    hipLaunchKernelGGL((c2_align_classify_kernel<R, 2>), dim3((unsigned)wgs), dim3(64), g.lds_full, s, A);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -317,6 +346,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
                 for (int t = 0; t < 2; ++t) if (g.x[t]) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_x[t] * g.plane_words);
                 if (g.pk) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk * g.plane_words_pk);
                 if (g.pk2) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk2 * g.plane_words_pk2);
+                if (g.full_hbm) most = std::max<uint64_t>(most, hbm_plane_wgs(ctx, g, A.n_tasks) * g.full_plane_words);
                 if (most && (rc = ensure(ctx, ctx->d_plane, (size_t)most * sizeof(uint32_t)))) return rc;
             }
             // band tier t (0: 30 diagonals, 1: 62): the packed kernel if the tier has one, then the 32-bit kernel of the same band --
@@ -361,7 +391,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
         } else {
             A.band_lanes = g.band_lanes;
             chain(A, false, false);
-            if ((rc = launch_one<R, true>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
+            if ((rc = launch_one<R, 1>(ctx, A, g.lds_band, g.blocks_band, A.n_tasks, s))) return rc;
             mark_first();
             ++tier;
         }
@@ -370,13 +400,13 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
         chain(A, false, false);
         A.fb_list = nullptr; A.fb_count = nullptr;
         ctx->last_tiers = tier;
-        if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;
+        if ((rc = launch_full<R>(ctx, A, g, s))) return rc;
     } else {
         ctx->last_tiers = 0;
         if ((rc = ensure(ctx, ctx->d_fb, 32))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_fb.p, 0, 32, s));
         A.work_counter = (unsigned long long*)((uint32_t*)ctx->d_fb.p + 2);
-        if ((rc = launch_one<R, false>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s))) return rc;
+        if ((rc = launch_full<R>(ctx, A, g, s))) return rc;
     }
     mark_first();
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(tl.b, s)); ctx->timed.push_back(tl); }

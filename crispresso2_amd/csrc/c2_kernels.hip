@@ -52,14 +52,17 @@ __host__ __device__ inline int c2_band_slots(int R, int W) { return (2 * R * W) 
 __host__ __device__ inline int c2_band_lo(int R, int W, int t) { return (t - 1 - R * W + 64 * (R + 1)) / (R + 1) - 64; }
 
 // band_lanes = 0: full plane (one row of 64 lanes per read column); > 0: banded plane (one row of nslots per step)
-__host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_passes, int n_codes, int band_lanes) {
+// plane_in_hbm: the pointer plane lives in a per-workgroup scratch area of HBM instead (c2_hbm_plane_halfwords: one row of
+// 64 halfwords per STEP of the sweep, so that a step's 64 stores are one 128-byte line); LDS then only holds the O(Li + Lj) parts.
+__host__ __device__ inline uint64_t c2_hbm_plane_halfwords(int max_lj, int max_passes) { return (uint64_t)max_passes * ((uint64_t)max_lj + 64u) * 64u; }
+__host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_passes, int n_codes, int band_lanes, bool plane_in_hbm = false) {
     const int nslots = band_lanes > 0 ? c2_band_slots(R, band_lanes) : C2_LANES;
     const uint32_t plane_rows = band_lanes > 0 ? (uint32_t)max_lj + 64u : (uint32_t)max_lj;
     c2_lds_plan p;
     const uint32_t max_li = (uint32_t)max_passes * 64u * (uint32_t)R;
-    p.col_stride = (uint32_t)nslots + C2_PTR_PAD;
+    p.col_stride = plane_in_hbm ? 64u : (uint32_t)nslots + C2_PTR_PAD;
     uint32_t off = 0;
-    p.ptr = off;      off += c2_align16((uint32_t)max_passes * plane_rows * p.col_stride * 2u);
+    p.ptr = off;      off += plane_in_hbm ? 0u : c2_align16((uint32_t)max_passes * plane_rows * p.col_stride * 2u);
     p.bnd = off;      off += (max_passes > 1) ? c2_align16(3u * ((uint32_t)max_lj + 1u) * 4u) : 0u;
     p.tbl = off;      off += c2_align16((uint32_t)n_codes * (uint32_t)n_codes * 2u);
     p.codeof = off;   off += 256u;
@@ -142,9 +145,11 @@ __device__ __forceinline__ int c2_div_rows(int x) {
 // Halfword index of the pointer word of (row-lane `rl`, column j) inside one pass's pointer plane.
 // Full plane: row j-1, slot rl.  BAND: row t-1 (t = j + rl is the step at which that lane computed the column), slot
 // rl - lo(t); *inband tells whether the word was stored.
-template <int R, bool BAND>
+// MODE 0: full plane in LDS, 1: banded plane in LDS (BAND), 2: full plane in HBM scratch, row t-1, slot rl.
+template <int R, int MODE>
 __device__ __forceinline__ int c2_ptr_index(const int rl, const int j, const int colStride, const int band_lanes, bool& inband) {
-    if (!BAND) { inband = true; return (j - 1) * colStride + rl; }
+    if (MODE == 2) { inband = true; return (j + rl - 1) * 64 + rl; }
+    if (MODE == 0) { inband = true; return (j - 1) * colStride + rl; }
     const int t = j + rl;
     const int slot = rl - c2_band_lo(R, band_lanes, t);
     inband = (unsigned)slot < (unsigned)c2_band_slots(R, band_lanes);
@@ -211,7 +216,7 @@ __device__ __forceinline__ int c2_load_rsym(const unsigned char* sCode, const in
 // One step of the systolic sweep: hand-off from the lane above (DPP, full EXEC), then this lane's column j = t - lane.
 // PHASE 0: ramp-up (t < 64: lanes with j < 1 wait), 1: steady state (every lane is inside 1..Lj-1: no mask at all),
 // 2: tail (lanes may be on the last column, or past it).
-template <int R, bool PACKED, int PHASE, bool BAND>
+template <int R, bool PACKED, int PHASE, int MODE>
 __device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const int lane, const int Lj, const int ge, const int g0,
                                            const int min_score, const bool first, const bool feeds_next,
                                            const int rsym, int& nM, int& nJ, int& nH,
@@ -242,9 +247,11 @@ __device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const in
     if (PHASE == 2) active = (j >= 1 && j <= Lj);
     if (active) {
         c2_dp_column<R, PACKED, PHASE == 2>(S, S.upM, S.upJ, ge, PHASE == 2 && (j == Lj), sTbl);
-        if (BAND) {
+        if (MODE == 1) {
             const int slot = lane - c2_band_lo(R, band_lanes, t);
             if ((unsigned)slot < (unsigned)c2_band_slots(R, band_lanes)) planePtr[(t - 1) * colStride + slot] = (uint16_t)S.bits;
+        } else if (MODE == 2) {
+            planePtr[(t - 1) * 64 + lane] = (uint16_t)S.bits;             // (HBM: one 128-byte line per step)
         } else {
             planePtr[(j - 1) * colStride + lane] = (uint16_t)S.bits;
         }
@@ -255,7 +262,7 @@ __device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const in
 
 // One systolic pass over reference rows p*64R+1 .. p*64R+64R.  SINGLE: the reference fits one pass, so the row above
 // lane 0 is the closed-form row 0 and nothing is handed to a next pass.
-template <int R, bool PACKED, bool SINGLE, bool BAND>
+template <int R, bool PACKED, bool SINGLE, int MODE>
 __device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_ref& rf, const unsigned char* sRef,
                                            const unsigned char* sCode, const int16_t* sTbl, int* sBnd, uint16_t* planePtr,
                                            const int colStride, const int lane, const int p, const int passes,
@@ -308,11 +315,11 @@ __device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_
         const int seg_end = (((t - 1) | 255) + 1) < steps ? (((t - 1) | 255) + 1) : steps;
         rsym = c2_load_rsym<PACKED>(sCode, (t - 1) & ~255, Lj, lane);
         for (; t <= seg_end && t < t1; ++t)
-            c2_dp_step<R, PACKED, 0, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
+            c2_dp_step<R, PACKED, 0, MODE>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
         for (; t <= seg_end && t < t2; ++t)
-            c2_dp_step<R, PACKED, 1, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
+            c2_dp_step<R, PACKED, 1, MODE>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
         for (; t <= seg_end; ++t)
-            c2_dp_step<R, PACKED, 2, BAND>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
+            c2_dp_step<R, PACKED, 2, MODE>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
     }
 }
 
@@ -485,15 +492,15 @@ __device__ __forceinline__ void c2_clear_record(c2_aln_record& rec, const int rc
 }
 
 // Pointer plane of the row-strip kernel: nibble of cell (pi, pj), pi, pj >= 1.
-template <int R, bool BAND>
+template <int R, int MODE>
 struct c2_row_plane {
-    const uint16_t* sPtr; int max_lj, colStride, band_lanes;
+    const uint16_t* sPtr; int pass_halfwords, colStride, band_lanes;
     __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
         const int pp = (pi - 1) / (64 * R), rem = (pi - 1) % (64 * R);
         bool inb;
-        const int pidx = c2_ptr_index<R, BAND>(rem / R, pj, colStride, band_lanes, inb);
+        const int pidx = c2_ptr_index<R, MODE>(rem / R, pj, colStride, band_lanes, inb);
         if (!inb) return false;
-        const unsigned hw = sPtr[(size_t)pp * max_lj * colStride + pidx];
+        const unsigned hw = sPtr[(size_t)pp * (size_t)pass_halfwords + pidx];
         nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
         return true;
     }
@@ -778,12 +785,15 @@ __device__ __forceinline__ void c2_emit_gapless(const c2_align_args& A, const c2
 // appends the task to A.fb_list, and the host re-runs exactly those tasks with the full-plane kernel (A.task_list mode).
 // The band limits what is STORED, never what is computed, so results do not depend on it.
 // ---------------------------------------------------------------------------------------------------------------
-template <int R, bool BAND>
+template <int R, int MODE>
 __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args A)
 {
+    constexpr bool BAND = MODE == 1;
+    constexpr int MULTI = MODE == 2 ? 2 : 0;                     // plane mode of the multi-pass sweeps (never banded)
     const int lane = threadIdx.x;
-    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, BAND ? A.band_lanes : 0);
-    uint16_t* sPtr = (uint16_t*)(c2_smem + P.ptr);
+    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, BAND ? A.band_lanes : 0, MODE == 2);
+    const int pass_halfwords = MODE == 2 ? (A.max_lj + 64) * 64 : A.max_lj * (int)P.col_stride;
+    uint16_t* sPtr = MODE == 2 ? (uint16_t*)(A.plane + (size_t)blockIdx.x * A.plane_words_per_wg) : (uint16_t*)(c2_smem + P.ptr);
     int* sBnd = (int*)(c2_smem + P.bnd);
     int16_t* sTbl = (int16_t*)(c2_smem + P.tbl);
     c2_wg W;
@@ -827,20 +837,21 @@ __global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args 
             // =========================== DP: systolic sweep, pass by pass ===========================
             for (int p = 0; p < passes; ++p) {
                 const bool single = (passes == 1);
-                uint16_t* planePtr = sPtr + (size_t)p * (size_t)A.max_lj * colStride;
+                uint16_t* planePtr = sPtr + (size_t)p * (size_t)pass_halfwords;
                 if (packed) {
-                    if (single) c2_dp_pass<R, true, true, BAND>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                    else        c2_dp_pass<R, true, false, false>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    if (single) c2_dp_pass<R, true, true, MODE>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    else        c2_dp_pass<R, true, false, MULTI>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
                 } else {
-                    if (single) c2_dp_pass<R, false, true, BAND>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                    else        c2_dp_pass<R, false, false, false>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    if (single) c2_dp_pass<R, false, true, MODE>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
+                    else        c2_dp_pass<R, false, false, MULTI>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
                 }
                 __syncthreads();
             }
+            if (MODE == 2) __threadfence_block();                 // the traceback reads other lanes' pointer words back from HBM
             c2_phase_mark<1>(A.phase_cycles, PH);   // phase 1: DP fill
             // =========================== traceback ===========================
-            c2_row_plane<R, BAND> plane;
-            plane.sPtr = sPtr; plane.max_lj = A.max_lj; plane.colStride = colStride; plane.band_lanes = A.band_lanes;
+            c2_row_plane<R, MODE> plane;
+            plane.sPtr = sPtr; plane.pass_halfwords = pass_halfwords; plane.colStride = colStride; plane.band_lanes = A.band_lanes;
             if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
                 int cnt, matches;
                 bool need_full;

@@ -175,24 +175,40 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         const c2_lds_plan PB = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, band_lanes);
         if (PB.total > sizeof(c2_smem)) return -5;
         switch (R) {
-            case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, true>(A); }); break;
-            case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2, true>(A); }); break;
-            case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3, true>(A); }); break;
-            default: emu::launch(grid, [&] { c2_align_classify_kernel<4, true>(A); }); break;
+            case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, 1>(A); }); break;
+            case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2, 1>(A); }); break;
+            case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3, 1>(A); }); break;
+            default: emu::launch(grid, [&] { c2_align_classify_kernel<4, 1>(A); }); break;
         }
         A.task_list = fb_list.data(); A.task_count = &fb_count;
         work_counter = 0;
         if (n_fallback) *n_fallback = (int)fb_count;
     } else if (n_fallback) *n_fallback = -1;
     const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, 0);
-    if (P.total > sizeof(c2_smem)) { fprintf(stderr, "emu: LDS plan %u too large\n", P.total); return -5; }
     A.band_lanes = 0;
+    if (P.total > sizeof(c2_smem) || getenv("C2_EMU_HBM_PLANE")) {
+        // the host library's rule: a pointer plane that does not fit LDS lives in per-workgroup HBM scratch
+        const c2_lds_plan PH = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, 0, true);
+        if (PH.total > sizeof(c2_smem)) { fprintf(stderr, "emu: LDS plan %u too large\n", PH.total); return -5; }
+        const uint64_t words = (c2_hbm_plane_halfwords(A.max_lj, A.max_passes) + 1) / 2;
+        std::vector<uint32_t> scratch((size_t)words * (size_t)grid, 0xdeadbeefu);
+        A.plane = scratch.data(); A.plane_words_per_wg = (uint32_t)words;
+        if (!(band || diag) || fb_count > 0) {
+            switch (R) {
+                case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, 2>(A); }); break;
+                case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2, 2>(A); }); break;
+                case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3, 2>(A); }); break;
+                default: emu::launch(grid, [&] { c2_align_classify_kernel<4, 2>(A); }); break;
+            }
+        }
+        return 0;
+    }
     if (!(band || diag) || fb_count > 0) {
         switch (R) {
-            case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, false>(A); }); break;
-            case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2, false>(A); }); break;
-            case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3, false>(A); }); break;
-            default: emu::launch(grid, [&] { c2_align_classify_kernel<4, false>(A); }); break;
+            case 1: emu::launch(grid, [&] { c2_align_classify_kernel<1, 0>(A); }); break;
+            case 2: emu::launch(grid, [&] { c2_align_classify_kernel<2, 0>(A); }); break;
+            case 3: emu::launch(grid, [&] { c2_align_classify_kernel<3, 0>(A); }); break;
+            default: emu::launch(grid, [&] { c2_align_classify_kernel<4, 0>(A); }); break;
         }
     }
     return 0;

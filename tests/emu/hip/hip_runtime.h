@@ -117,6 +117,7 @@ struct uint4 { unsigned x, y, z, w; };
 #define blockDim (emu::block_dim)
 
 inline void __syncthreads() { emu::barrier(); }
+inline void __threadfence_block() {}
 
 // exchange helper with phase alternation handled per call site (two tables, flipped by lane 0 after barrier 2)
 namespace emu {

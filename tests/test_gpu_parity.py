@@ -219,6 +219,65 @@ def test_long_references_multipass_vs_oracle(mats, ctx):
             check_record(res.records[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
 
 
+@pytest.mark.parametrize("li,lj", [(600, 600), (1000, 300), (300, 1000), (40, 2500), (2000, 2000)])
+def test_alignments_larger_than_the_lds_pointer_plane_vs_oracle(mats, ctx, li, lj):
+    """600 x 600 / 1000 x 300 and beyond: the full pointer plane exceeds the 160 KB of LDS, so the chain's last launch keeps it in
+    per-workgroup HBM scratch (r01 answered C2_E_TOO_LARGE here).  Bit-exact against the oracle, whole chain and full-plane only."""
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    rng = np.random.default_rng(li * 7 + lj)
+    m = mats["EDNAFULL"]
+    ref = "".join(rng.choice(list("ACGT"), li))
+    g = np.zeros(li + 1, dtype=np.int64)
+    g[li // 2] = 1
+    inc = list(range(li // 2 - 10, li // 2 + 10))
+    reads = []
+    for _ in range(40):
+        base = (ref * (lj // li + 1))[:lj] if lj >= li else ref[int(rng.integers(0, li - lj)):][:lj]
+        s = list(base)
+        for _e in range(int(rng.integers(0, 5))):
+            p = int(rng.integers(5, len(s) - 5))
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                s[p] = "ACGT"[int(rng.integers(0, 4))]
+            elif k == 1:
+                del s[p:p + int(rng.integers(1, 150))]
+            else:
+                s[p:p] = list(rng.choice(list("ACGT"), int(rng.integers(1, 30))))
+        reads.append("".join(s)[:max(lj, 20)])
+    reads.append("".join(rng.choice(list("ACGT"), lj)))
+    al = BatchAligner([ref], [g], [inc], m, -20, -2, ctx=ctx)
+    for mode in ("auto", "full"):
+        ctx.set_kernel_mode(mode)
+        try:
+            res = al.align(reads)
+        finally:
+            ctx.set_kernel_mode("auto")
+        for k, rd in enumerate(reads):
+            st, s1, s2, mt, ln = oracle.global_align_raw(rd, ref, m, g, -20, -2)
+            assert st == 0 and res.records["status"][k] == 0, (mode, k)
+            assert res.strings(k) == (s1, s2), (mode, k)
+            assert (int(res.records["matches"][k]), int(res.records["aln_len"][k])) == (mt, ln)
+            check_record(res.records[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+
+
+def test_hbm_pointer_plane_forced_on_amplicon_sized_batches(mats, ctx):
+    """C2_FORCE_HBM_PLANE routes the full-plane launch of ordinary batches through the HBM-plane instance: same bytes out."""
+    os.environ["C2_FORCE_HBM_PLANE"] = "1"
+    try:
+        ctx.set_kernel_mode("full")
+        try:
+            for name in ("realistic.json", "fuzz_align.json"):
+                vecs = load_golden(name)
+                assert run_batch_vectors(vecs, mats, ctx) == len(vecs)
+        finally:
+            ctx.set_kernel_mode("auto")
+        vecs = load_golden("realistic.json")
+        assert run_batch_vectors(vecs, mats, ctx) == len(vecs)
+    finally:
+        del os.environ["C2_FORCE_HBM_PLANE"]
+
+
 def test_multi_reference_strands_and_pooled_ids_vs_oracle(mats, ctx):
     """all_refs (every read x every reference, CRISPRessoCORE.py:653), per-read amplicon ids (Pooled), reverse complement."""
     from crispresso2_amd import synth

@@ -441,3 +441,65 @@ def test_packed_kernel_pairs_singles_and_mismatched_neighbours(mats):
     st2 = {}
     E.align_batch([reads[k] for k in order], refs, gis, incs, m, -20, -2, ref_ids=[rids[k] for k in order], band_lanes=-8, grid=3, stats=st2)
     assert st2["unpaired"] < 40 and st2["unpaired"] < st["unpaired"] // 3, (st2, st)
+
+
+# ---- pointer plane in HBM: alignments whose full plane does not fit a CU's LDS --------------------------------------------------
+def _edited(rng, ref, n_events):
+    s = list(ref)
+    for _ in range(n_events):
+        p = int(rng.integers(5, len(s) - 5))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            s[p] = "ACGT"[int(rng.integers(0, 4))]
+        elif kind == 1:
+            del s[p:p + int(rng.integers(1, 12))]
+        else:
+            s[p:p] = list("".join(rng.choice(list("ACGT"), int(rng.integers(1, 12)))))
+    return "".join(s)
+
+
+@pytest.mark.parametrize("R", [0, 1, 2])
+def test_emulated_kernel_pointer_plane_in_hbm_small_cases(mats, R, monkeypatch):
+    """The HBM-plane instance of the row-strip kernel (plane row = step of the sweep) forced on sizes that would fit LDS:
+    single- and multi-pass references, packed and LDS score tables, identical to the reference on every vector."""
+    monkeypatch.setenv("C2_EMU_HBM_PLANE", "1")
+    vecs = load_golden("realistic.json")
+    vecs = vecs[:10] + vecs[45:55] + vecs[-10:]
+    assert run_vectors(vecs, mats, force_R=R) == len(vecs)
+    small = load_golden("fuzz_align.json")[::5]
+    assert run_vectors(small, mats, force_R=R, no_packed=(R == 2)) == len(small)
+    kats = [k for k in load_golden("ref_unit_kats.json") if k["fn"] == "global_align"]
+    assert run_vectors(kats, mats, force_R=R, band_lanes=-87 if R == 0 else 0) == len(kats)
+
+
+@pytest.mark.parametrize("li,lj", [(600, 600), (1000, 300), (300, 1000), (40, 2500)])
+def test_emulated_kernel_alignments_larger_than_the_lds_plane(mats, li, lj):
+    """600 x 600 needs 237 KB of pointer words, 1000 x 300 196 KB: more than the 160 KB of LDS.  The chain's last launch keeps
+    them in HBM scratch instead (r01: C2_E_TOO_LARGE); the diagonal tiers in front of it are unaffected.  Edited copies (the band
+    certifies them), unrelated reads and reads with a long deletion (the full-plane launch has to finish them)."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(li * 7 + lj)
+    ref = "".join(rng.choice(list("ACGT"), li))
+    g = np.zeros(li + 1, dtype=np.int64)
+    g[li // 2] = 1
+    inc = list(range(li // 2 - 10, li // 2 + 10))
+    reads = []
+    if lj == li:
+        reads += [_edited(rng, ref, 3) for _ in range(3)]
+        reads.append(ref[:200] + ref[420:])                                  # a 220-base deletion: outside every band
+        reads.append("".join(rng.choice(list("ACGT"), lj)))                  # unrelated
+    else:
+        lo = int(rng.integers(0, max(1, li - lj))) if li > lj else 0
+        reads.append((ref[lo:lo + lj] if li > lj else ref + "".join(rng.choice(list("ACGT"), lj - li)))[:lj])
+        reads.append("".join(rng.choice(list("ACGT"), lj)))
+        reads.append(_edited(rng, (ref * (lj // li + 1))[:lj], 4))
+    for chain in (0, -87):
+        st = {}
+        res, rec = E.align_batch(reads, [ref], [g], [inc], m, -20, -2, band_lanes=chain, grid=3, stats=st)
+        for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+            exp = oracle.global_align_raw(reads[k], ref, m, g, -20, -2)
+            assert exp[0] == 0 and r["status"] == 0, (k, r)
+            assert (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], (chain, k)
+            check_record(r, oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+        if chain and lj == li:
+            assert 0 < st["fallback"] < st["tasks"], st
