@@ -24,7 +24,7 @@ SYMBOLS = [
     "c2_comm_unique_id", "c2_comm_init", "c2_reduce_counts", "c2_comm_destroy",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
-    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error", "c2_strand_plan", "c2_merge_reverse_complements",
+    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error", "c2_strand_plan", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners",
     "c2_consensus_pairs_batch",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets",
 ]
@@ -335,10 +335,17 @@ class FastqUnique:
         self.n_reads = int(lib.c2_fastq_n_reads(h))
 
     def close(self):
+        """Releases the native memory.  Large arenas are handed to a helper thread (unmapping a few hundred megabytes takes tens
+        of milliseconds of kernel time that nobody has to wait for; ctypes drops the GIL for the call)."""
         if self._h:
+            big = self.arena is not None and self.arena.size > (32 << 20)
             self.arena = self.offsets = self.counts = None
-            self._lib.c2_fastq_free(self._h)
-            self._h = ctypes.c_void_p()
+            h, self._h = self._h, ctypes.c_void_p()
+            if big and not os.environ.get("C2_SYNC_FREE"):
+                import threading
+                threading.Thread(target=self._lib.c2_fastq_free, args=(h,), name="c2-fastq-free", daemon=False).start()
+            else:
+                self._lib.c2_fastq_free(h)
 
     def __enter__(self):
         return self
@@ -445,6 +452,34 @@ def merge_reverse_complements(arena, offsets, aligned, counts):
                                              al.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p))
     if rcode != 0:
         raise NativeError("c2_merge_reverse_complements: %s" % lib.c2_fastq_last_error().decode())
+    return counts
+
+
+def rc_partners(arena, offsets):
+    """c2_rc_partners -> int64 [n]: index of the read equal to reverse_complement(read i), or -1.  (ctypes releases the GIL for the
+    call: pipeline.quantify_unique runs it on a thread while the device aligns.)"""
+    lib = load()
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    out = np.empty(n, dtype=np.int64)
+    rcode = lib.c2_rc_partners(arena.ctypes.data_as(ctypes.c_void_p) if arena.size else None, offsets.ctypes.data_as(ctypes.c_void_p),
+                               ctypes.c_uint64(n), out.ctypes.data_as(ctypes.c_void_p))
+    if rcode != 0:
+        raise NativeError("c2_rc_partners: %s" % lib.c2_fastq_last_error().decode())
+    return out
+
+
+def merge_counts_with_partners(aligned, partner, counts):
+    """c2_merge_counts_with_partners, in place on counts (int64 [n])."""
+    lib = load()
+    al = np.ascontiguousarray(aligned, dtype=np.uint8)
+    pt = np.ascontiguousarray(partner, dtype=np.int64)
+    assert counts.dtype == np.int64 and counts.flags["C_CONTIGUOUS"] and len(pt) == len(counts) == len(al)
+    rcode = lib.c2_merge_counts_with_partners(ctypes.c_uint64(len(counts)), al.ctypes.data_as(ctypes.c_void_p),
+                                              pt.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p))
+    if rcode != 0:
+        raise NativeError("c2_merge_counts_with_partners: %s" % lib.c2_fastq_last_error().decode())
     return counts
 
 

@@ -212,7 +212,8 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
         }
         if (g.diag && km == 0 && ctx->any_pk_ok) {
             // first tier: eight alignments per wavefront, two per lane group in int16 (c2_align_diagp_kernel)
-            const c2_diagx_plan PP = c2_make_diagx_plan(8, ctx->max_li, g.max_lj, true);
+            c2_diagx_plan PP = c2_make_diagx_plan(8, ctx->max_li, g.max_lj, true);
+            if (const char* pad = getenv("C2_DEBUG_PK_LDS_PAD")) PP.total += (uint32_t)atoi(pad);   // occupancy experiments
             if (PP.total <= lds_cu) {
                 if (ctx->occ_pk_lds != (int)PP.total) {
                     int nb = 0;
@@ -1153,6 +1154,7 @@ int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const u
     }
     if (n == 0) return 0;
     if (stride == 0 || qstride == 0 || ostride < 2 * stride) { ctx->err = "ostride must be at least 2 * stride"; return C2_E_INVALID; }
+    if ((stride & 3u) || (qstride & 3u)) { ctx->err = "stride and qstride must be multiples of 4"; return C2_E_INVALID; }
     for (uint64_t t = 0; t < n; ++t)
         if (n1[t] < 0 || n2[t] < 0 || (uint32_t)n1[t] > stride || (uint32_t)n2[t] > stride || lq1[t] < 0 || lq2[t] < 0 ||
             (uint32_t)lq1[t] > qstride || (uint32_t)lq2[t] > qstride) { ctx->err = "length exceeds stride"; return C2_E_INVALID; }

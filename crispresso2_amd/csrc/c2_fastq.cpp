@@ -32,8 +32,32 @@
 
 #include "crispresso2_amd.h"
 
+// Byte arena that never value-initialises what it hands out (a std::vector<uint8_t>::resize to the size of all unique reads is a
+// serial zero-fill of hundreds of megabytes -- and of their page faults -- right before the threads overwrite every byte).
+struct ByteBuf {
+    uint8_t* p = nullptr; size_t n = 0, cap = 0;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf&) = delete;
+    ByteBuf& operator=(const ByteBuf&) = delete;
+    ~ByteBuf() { free(p); }
+    uint8_t* data() { return p; }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        size_t c = cap ? cap : 4096;
+        while (c < want) c += c / 2 + 4096;
+        uint8_t* q = (uint8_t*)realloc(p, c);
+        if (!q) throw std::bad_alloc();
+        p = q; cap = c;
+    }
+    void resize(size_t want) { reserve(want); n = want; }              // new bytes are NOT initialised
+    void append(const uint8_t* a, size_t len) { if (len) { reserve(n + len); memcpy(p + n, a, len); n += len; } }
+};
+
 struct c2_fastq {
-    std::vector<uint8_t> arena;
+    ByteBuf arena;
     std::vector<uint64_t> offsets;     // n_unique + 1
     std::vector<uint32_t> counts;      // n_unique
     uint64_t n_reads = 0;
@@ -107,7 +131,7 @@ struct Dedup {
         if (fresh) *fresh = true;
         table[pos] = (uint32_t)hashes.size() + 1;
         hashes.push_back(h);
-        R->arena.insert(R->arena.end(), s, s + n);
+        R->arena.append(s, n);
         R->offsets.push_back((uint64_t)R->arena.size());
         R->counts.push_back(copies);
         if (hashes.size() * 2 > table.size()) grow();
@@ -316,9 +340,18 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
         });
         for (auto& th : pool) th.join();
     }
+    const double T3 = now_s();
     // global order = ascending (range, local index) of the first occurrences: per range, a bitmap-free gather
     std::vector<std::vector<First>> by_range(threads);
-    for (unsigned p = 0; p < threads; ++p) for (const First& f : part[p]) by_range[f.range].push_back(f);
+    {   // every range collects (and sorts) its own survivors from all partitions
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] {
+            std::vector<First>& v = by_range[t];
+            for (unsigned p = 0; p < threads; ++p) for (const First& f : part[p]) if (f.range == t) v.push_back(f);
+            std::sort(v.begin(), v.end(), [](const First& a, const First& b) { return a.local < b.local; });
+        });
+        for (auto& th : pool) th.join();
+    }
     uint64_t n_unique = 0, n_reads = 0;
     std::vector<uint64_t> first_index(threads + 1, 0);
     for (unsigned t = 0; t < threads; ++t) { first_index[t] = n_unique; n_unique += by_range[t].size(); n_reads += res[t]->n_seq; }
@@ -329,7 +362,6 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] {
             std::vector<First>& v = by_range[t];
-            std::sort(v.begin(), v.end(), [](const First& a, const First& b) { return a.local < b.local; });
             const c2_fastq& P = res[t]->R;
             uint64_t g = first_index[t];
             for (const First& f : v) {
@@ -342,8 +374,10 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
         for (auto& th : pool) th.join();
     }
     for (unsigned t = 0; t < threads; ++t) if (!res[t]->ok) return C2_E_TOO_LARGE;
+    const double T4 = now_s();
     for (uint64_t g = 0; g < n_unique; ++g) R->offsets[g + 1] += R->offsets[g];
     R->arena.resize((size_t)R->offsets[n_unique]);
+    const double T5 = now_s();
     {
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] {
@@ -363,7 +397,8 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
         R->offsets.push_back(R->offsets.back());
         R->counts.push_back(1);
     };
-    if (trace) fprintf(stderr, "c2_fastq: %u threads, count %.3f s, parse %.3f s, merge %.3f s\n", threads, T1 - T0, T2 - T1, now_s() - T2);
+    if (trace) fprintf(stderr, "c2_fastq: %u threads, count %.3f s, parse %.3f s, merge %.3f s (partition %.3f, order %.3f, prefix %.3f, copy %.3f)\n",
+                       threads, T1 - T0, T2 - T1, now_s() - T2, T3 - T2, T4 - T3, T5 - T4, now_s() - T5);
     // lines in the file = terminators + (1 if the file does not end with one and is not empty); a record whose sequence
     // line never came still counts, with the empty sequence (readline() returned '')
     const uint64_t lines = total_terms + ((n > 0 && !term_end(b, n, n - 1)) ? 1 : 0);
@@ -1157,6 +1192,88 @@ int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, 
         if (!aligned[i] || counts[i] == 0 || partner[i] < 0) continue;
         const int64_t j = partner[i];
         if (counts[j] > 0) { const int64_t c = counts[i] + counts[j]; counts[j] = 0; counts[i] = c; }
+    }
+    return 0;
+}
+
+// The same merge in two steps, so that the expensive one -- which read equals the reverse complement of which -- does not wait for
+// the alignments (a host thread runs it while the device aligns): c2_rc_partners looks the partner up among ALL reads, and
+// c2_merge_counts_with_partners applies the reference's sequential transfer, skipping partners that are not aligned (the
+// reference's cache holds the aligned reads only).  Same result as c2_merge_reverse_complements.
+int c2_rc_partners(const uint8_t* arena, const uint64_t* offsets, uint64_t n, int64_t* partner) {
+    if (!offsets || !partner) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char* e = getenv("C2_HOST_THREADS")) threads = (unsigned)atoi(e);
+    if (threads > 64) threads = 64;
+    if (threads < 1 || n < 8192) threads = 1;
+    auto run = [&](auto&& fn) {
+        if (threads == 1) { fn((uint64_t)0, n); return; }
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(fn, n * t / threads, n * (t + 1) / threads);
+        for (auto& th : pool) th.join();
+    };
+    std::vector<uint64_t> hs(n, 0);
+    run([&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i) hs[i] = hash_bytes(arena + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
+    });
+    uint64_t cap = 1024;
+    while (cap < 2 * n + 2) cap <<= 1;
+    const uint64_t mask = cap - 1;
+    // lock-free parallel inserts: a slot is claimed with a compare-and-swap (the reads are distinct, so nothing is ever updated)
+    std::unique_ptr<std::atomic<uint64_t>[]> table(new std::atomic<uint64_t>[cap]);
+    run([&](uint64_t lo, uint64_t hi) {
+        const uint64_t a = cap * lo / (n ? n : 1), b = (hi == n) ? cap : cap * hi / (n ? n : 1);
+        for (uint64_t q = a; q < b; ++q) table[q].store(0, std::memory_order_relaxed);
+    });
+    run([&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i) {
+            uint64_t pos = hs[i] & mask;
+            for (;;) {
+                uint64_t seen = table[pos].load(std::memory_order_relaxed);
+                if (seen == 0 && table[pos].compare_exchange_strong(seen, i + 1, std::memory_order_relaxed)) break;
+                pos = (pos + 1) & mask;
+            }
+        }
+    });
+    run([&](uint64_t lo, uint64_t hi) {
+        std::vector<uint8_t> rc;
+        for (uint64_t i = lo; i < hi; ++i) {
+            partner[i] = -1;
+            const uint8_t* s = arena + offsets[i];
+            const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+            rc.resize(len);
+            bool ok = true;
+            for (size_t k = 0; k < len && ok; ++k) {
+                uint8_t c = s[len - 1 - k];
+                if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+                switch (c) {
+                    case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'T': c = 'A'; break;
+                    case 'N': case '_': case '-': break;
+                    default: ok = false;
+                }
+                rc[k] = c;
+            }
+            if (!ok) continue;
+            uint64_t pos = hash_bytes(rc.data(), len) & mask;
+            for (;;) {
+                const uint64_t e = table[pos].load(std::memory_order_relaxed);
+                if (!e) break;
+                const uint64_t j = e - 1;
+                if ((size_t)(offsets[j + 1] - offsets[j]) == len && (len == 0 || memcmp(arena + offsets[j], rc.data(), len) == 0)) { partner[i] = (int64_t)j; break; }
+                pos = (pos + 1) & mask;
+            }
+        }
+    });
+    return 0;
+}
+
+int c2_merge_counts_with_partners(uint64_t n, const uint8_t* aligned, const int64_t* partner, int64_t* counts) {
+    if (!aligned || !partner || !counts) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!aligned[i] || counts[i] == 0 || partner[i] < 0) continue;
+        const int64_t j = partner[i];
+        if ((uint64_t)j >= n) { g_fastq_error = "partner index out of range"; return C2_E_INVALID; }
+        if (aligned[j] && counts[j] > 0) { const int64_t c = counts[i] + counts[j]; counts[j] = 0; counts[i] = c; }
     }
     return 0;
 }

@@ -2126,14 +2126,26 @@ __global__ __launch_bounds__(64) void c2_classify_lists_batch_kernel(c2_classify
 // over the alignments of read 1 and read 2 against the same reference, statement for statement -- including that the
 // double-gap column adds no quality character, that a read alone past the other's end copies its gaps, and that the
 // strings are trimmed where the consensus reference starts or ends with '-'.  A quality index past the end of its string
-// is an IndexError in the reference: flag 2, and the host raises.  One lane per pair.
+// is an IndexError in the reference: flag 2, and the host raises.  One lane per pair; every lane walks its own rows, so the
+// six input strings are read a dword at a time (c2_row_bytes: the walk's indices only ever step by one, a dword serves four
+// of them) instead of one byte per load instruction.
+struct c2_row_bytes {
+    const uint32_t* w; uint32_t cur; int at;
+    __device__ __forceinline__ c2_row_bytes(const uint8_t* row) : w((const uint32_t*)row), cur(0), at(-1) {}
+    __device__ __forceinline__ uint8_t operator[](const int i) {
+        const int q = i >> 2;
+        if (q != at) { cur = w[q]; at = q; }
+        return (uint8_t)(cur >> ((i & 3) * 8));
+    }
+};
+
 __global__ __launch_bounds__(64) void c2_consensus_pairs_kernel(c2_consensus_args A)
 {
     const uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x;
     if (t >= A.n) return;
-    const uint8_t* s1 = A.s1 + t * A.stride; const uint8_t* f1 = A.f1 + t * A.stride;
-    const uint8_t* s2 = A.s2 + t * A.stride; const uint8_t* f2 = A.f2 + t * A.stride;
-    const uint8_t* q1 = A.q1 + t * A.qstride; const uint8_t* q2 = A.q2 + t * A.qstride;
+    // (rows start at multiples of 4: the host checks the strides and allocates the arrays)
+    c2_row_bytes s1(A.s1 + t * A.stride), f1(A.f1 + t * A.stride), s2(A.s2 + t * A.stride), f2(A.f2 + t * A.stride);
+    c2_row_bytes q1(A.q1 + t * A.qstride), q2(A.q2 + t * A.qstride);
     const int n1 = A.n1[t], n2 = A.n2[t], lq1 = A.lq1[t], lq2 = A.lq2[t];
     const bool best1 = A.best1[t] != 0;
     uint8_t* oa = A.o_aln + t * A.ostride; uint8_t* orf = A.o_ref + t * A.ostride; uint8_t* oq = A.o_qual + t * A.ostride;

@@ -182,6 +182,19 @@ def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
                     timings=None, pe_scaffold_dna_info=None):
+    """See _quantify_unique.  (This wrapper only makes sure that the host thread the run starts -- it reads `arena`, which may be a
+    view of native memory the caller frees -- has ended before control returns, also when the run raises.)"""
+    threads = []
+    try:
+        return _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
+                                timings, pe_scaffold_dna_info, threads)
+    finally:
+        for t in threads:
+            t.join()
+
+
+def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
+                     timings, pe_scaffold_dna_info, _threads):
     """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
     timings: optional dict that receives the wall seconds of every stage.
     pe_scaffold_dna_info: (index, dna) of get_pe_scaffold_search for runs with --prime_editing_pegRNA_scaffold_seq: reads whose
@@ -253,6 +266,20 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
     if not arena.flags.writeable:
         arena = arena.copy()                                      # torch.from_numpy wants a writable array
+    lap("setup")
+    # which read is the reverse complement of which (for the count merge of :3970-3975) does not depend on the alignments: a host
+    # thread looks that up while the device aligns
+    import threading
+    partners = {}
+
+    def _find_partners():
+        try:
+            partners['index'] = _native.rc_partners(arena, offsets)
+        except BaseException as e:                                   # re-raised by the main thread at the join
+            partners['error'] = e
+    partner_thread = threading.Thread(target=_find_partners, name="c2-rc-partners")
+    _threads.append(partner_thread)
+    partner_thread.start()
     plan = strand_plans(arena, offsets, refs, ref_names, args)
     lap("strand_plan")
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -334,7 +361,10 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     lap("selection_and_stats")
     # ---- aggregation weights (:3964-4000): rc merge, ambiguous reads, which references a read counts for
     cnt = np.ascontiguousarray(raw.copy())
-    _native.merge_reverse_complements(arena, offsets, aligned, cnt)
+    partner_thread.join()
+    if 'error' in partners:
+        raise partners['error']
+    _native.merge_counts_with_partners(aligned, partners['index'], cnt)
     stats['N_TOTAL'] = int(cnt[aligned].sum())
     counted = member.copy()
     ambiguous = aligned & (n_best > 1)
@@ -477,6 +507,7 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
     state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=slot2,
                  scaffold_hit=scaffold_hit, scaffold_ref=pe,
                  a1=a1, f1=f1, r1=r1, a2=a2, f2=f2, r2=r2)
+    lap("unpack")
     return QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
 
 
@@ -500,8 +531,13 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
             new_off[1:] = np.cumsum(lens[keep])
             arena = np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in keep]) if len(keep) else np.zeros(0, dtype=np.uint8)
             offsets, counts = new_off, counts[keep]
+        if timings is not None:
+            timings["drop_empty_key"] = time.perf_counter() - t0 - timings["ingest_dedup"]
         res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
                               pe_scaffold_dna_info=pe_scaffold_dna_info)
+        t_free = time.perf_counter()
+    if timings is not None:
+        timings["free_ingest"] = time.perf_counter() - t_free
     res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
     res.stats['N_READS_AFTER_PREPROCESSING'] = int(n_reads)
     return res

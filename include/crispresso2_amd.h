@@ -283,6 +283,7 @@ int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4);
 /* Paired reads: get_consensus_alignment_from_pairs (CRISPRessoCORE.py:829-984) for n pairs at once.  Host pointers.
  * s1/f1, s2/f2: aligned read / aligned reference of read 1 and read 2 (n rows of `stride` bytes, n1[t] / n2[t] columns);
  * q1/q2: the reads' quality strings (n rows of `qstride`, lq1[t] / lq2[t] characters); best1[t] = (score_r1 >= score_r2).
+ * stride and qstride are multiples of 4 (the kernel reads the rows as dwords).
  * Outputs: n rows of `ostride` >= 2*stride bytes each for the consensus aligned sequence, reference and quality, and
  * out_info[t] = {length of sequence and reference, length of the quality string, columns where they are equal, flags:
  * 1 = caching_is_ok, 2 = the reference raises IndexError on these inputs}. */
@@ -331,6 +332,10 @@ const uint64_t* c2_fastq_aux_offsets(const c2_fastq* r);
 int c2_strand_plan(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const char* const* fw_seeds, const char* const* rc_seeds,
                    int32_t n_seeds, int32_t seed_min, uint8_t* out_plan);
 int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const uint8_t* aligned, int64_t* counts);
+/* The same merge in two steps: c2_rc_partners (independent of the alignments: partner[i] = index of the read that equals
+ * reverse_complement(read i), or -1; a host thread can run it while the device aligns) and the sequential count transfer over it. */
+int c2_rc_partners(const uint8_t* arena, const uint64_t* offsets, uint64_t n, int64_t* partner);
+int c2_merge_counts_with_partners(uint64_t n, const uint8_t* aligned, const int64_t* partner, int64_t* counts);
 
 /* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1 with and without bound_ctrl, also with a
  * lane switched off in EXEC, readlane, ballot) the DP depends on; writes 448 int32 (see c2_selftest_kernel).  Used by the

@@ -564,3 +564,34 @@ def test_read_filter_on_line_ranges(tmp_path, monkeypatch, threads):
         ofq.filter_fastq(str(p), str(tmp_path / "o.fastq"), None, None, 10)
     with pytest.raises(_native.NativeError):
         native_filtered(p, 0, 0, 10)
+
+
+@pytest.mark.parametrize("n_base,threads", [(400, None), (12000, "5"), (12000, "1")])
+def test_native_partner_search_plus_count_transfer_equals_the_one_step_merge(n_base, threads, monkeypatch):
+    """c2_rc_partners (parallel inserts into one table, lookup among ALL reads) + c2_merge_counts_with_partners (skips partners that
+    are not aligned) = c2_merge_reverse_complements -- the pipeline runs the first on a thread while the device aligns."""
+    from crispresso2_amd import _native, refs as RF
+    if threads:
+        monkeypatch.setenv("C2_HOST_THREADS", threads)
+    rng = np.random.default_rng(23 + n_base)
+    base = ["".join(rng.choice(list("ACGTN"), int(rng.integers(4, 30)))) for _ in range(n_base)]
+    reads = list(dict.fromkeys(base + [RF.reverse_complement(b) for b in base[::2]] + ["ACGT", "AATT", "acgt", "AC-GT_N", "ACXGT", "GGCC", ""]))
+    rng.shuffle(reads)
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    partner = _native.rc_partners(arena, off)
+    index = {r: k for k, r in enumerate(reads)}
+    for k, r in enumerate(reads):
+        try:
+            exp = index.get(RF.reverse_complement(r), -1)
+        except KeyError:
+            exp = -1
+        assert partner[k] == exp, r
+    for seed in range(3):
+        r2 = np.random.default_rng(seed)
+        counts = r2.integers(0, 50, len(reads)).astype(np.int64)
+        aligned = r2.random(len(reads)) < 0.7
+        one = _native.merge_reverse_complements(arena, off, aligned, counts.copy())
+        two = _native.merge_counts_with_partners(aligned, partner, counts.copy())
+        assert np.array_equal(one, two)
