@@ -120,6 +120,9 @@ def main():
                          "diag4 = the 32-bit chain 4 -> 2 -> 1)")
     ap.add_argument("--check", type=int, default=300, help="reads compared with the C oracle after the timed region (0 = no checks at all)")
     ap.add_argument("--no-full-plane-check", action="store_true", help="skip the chain-vs-full-plane comparison of every alignment")
+    ap.add_argument("--serial", action="store_true",
+                    help="one stream, one set of output buffers: the count pass of a batch ends before the next batch's launch chain starts "
+                         "(default: it runs on a second stream while the next batch is aligned into the other buffer set)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,10 +174,17 @@ def main():
     d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
     d_offsets = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
     d_rids = None if wl["ref_ids"] is None else torch.from_numpy(wl["ref_ids"].astype(np.int16)).to(dev)
-    d_aln_read = torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev)
-    d_aln_ref = torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev)
-    d_records = torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # output buffers: two sets, so that batch k+1 is aligned while batch k is still being counted (one set with --serial)
+    n_sets = 1 if args.serial else 2
+    out_sets = [(torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev), torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev),
+                 torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)) for _ in range(n_sets)]
+    d_aln_read, d_aln_ref, d_records = out_sets[0]
+    t_align = torch.cuda.current_stream()
+    t_count = t_align if args.serial else torch.cuda.Stream(device=dev)
+    stream = t_align.cuda_stream
+    count_stream = t_count.cuda_stream
+    aligned_ev = [torch.cuda.Event() for _ in range(n_sets)]
+    counted_ev = [None] * n_sets
     # per-amplicon count tensor (CRISPRessoCORE.py:3865-4115 on the device) -- the only thing the GPUs exchange
     layout = C.CountLayout(k, Lmax, L)
     d_counts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
@@ -184,28 +194,43 @@ def main():
         d_weights = torch.zeros(n_tasks, dtype=torch.int32, device=dev)
         d_selstats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
         min_mscore = C.min_mscore_table([MIN_ALN_SCORE] * k)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
 
     def align_into(a_read, a_ref, recs):
         al.align_device(n, d_reads.data_ptr(), d_offsets.data_ptr(), a_read.data_ptr(), a_ref.data_ptr(), recs.data_ptr(), stride, L,
                         d_ref_ids=None if d_rids is None else d_rids.data_ptr(), all_refs=all_refs, stream=stream)
 
+    step_no = [0]
+
     def step(e=None):
-        if e: e[0].record()
-        align_into(d_aln_read, d_aln_ref, d_records)
-        if e: e[1].record()
-        if all_refs:
-            # strand / best-amplicon choice on the device (CRISPRessoCORE.py:697-707) -> the weight of every alignment in the count pass
-            d_selstats.zero_()
-            C.select_best_device(ctx, n, k, d_records.data_ptr(), min_mscore, C.SELECT_DROP_AMBIGUOUS, Lmax + L,
-                                 d_weights=d_weights.data_ptr(), d_stats=d_selstats.data_ptr(), stream=stream)
-        if e: e[2].record()
-        d_counts.zero_()
-        C.accumulate_device(ctx, layout, n_tasks, d_aln_read.data_ptr(), d_aln_ref.data_ptr(), stride, d_records.data_ptr(),
-                            d_counts.data_ptr(), d_weights=d_weights.data_ptr() if all_refs else None,
-                            min_matches=None if all_refs else min_matches, flags=C.FLAG_ALL_REFS_LAYOUT if all_refs else 0, stream=stream)
-        C.all_reduce(d_counts)
-        if e: e[3].record()
+        """One batch: launch chain on the align stream into buffer set i; reference choice, count pass and all-reduce on the count
+        stream (the same stream with --serial).  Set i is aligned into again only after its previous batch has been counted."""
+        i = step_no[0] % n_sets
+        step_no[0] += 1
+        a_read, a_ref, recs = out_sets[i]
+        if counted_ev[i] is not None:
+            t_align.wait_event(counted_ev[i])
+        if e: e[0].record(t_align)
+        align_into(a_read, a_ref, recs)
+        if e: e[1].record(t_align)
+        aligned_ev[i].record(t_align)
+        t_count.wait_event(aligned_ev[i])
+        with torch.cuda.stream(t_count):
+            if e: e[4].record(t_count)
+            if all_refs:
+                # strand / best-amplicon choice on the device (CRISPRessoCORE.py:697-707) -> the weight of every alignment in the count pass
+                d_selstats.zero_()
+                C.select_best_device(ctx, n, k, recs.data_ptr(), min_mscore, C.SELECT_DROP_AMBIGUOUS, Lmax + L,
+                                     d_weights=d_weights.data_ptr(), d_stats=d_selstats.data_ptr(), stream=count_stream)
+            if e: e[2].record(t_count)
+            d_counts.zero_()
+            C.accumulate_device(ctx, layout, n_tasks, a_read.data_ptr(), a_ref.data_ptr(), stride, recs.data_ptr(),
+                                d_counts.data_ptr(), d_weights=d_weights.data_ptr() if all_refs else None,
+                                min_matches=None if all_refs else min_matches, flags=C.FLAG_ALL_REFS_LAYOUT if all_refs else 0, stream=count_stream)
+            C.all_reduce(d_counts)
+            if e: e[3].record(t_count)
+            counted_ev[i] = torch.cuda.Event()
+            counted_ev[i].record(t_count)
 
     def fence():
         torch.cuda.synchronize()
@@ -229,10 +254,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     align_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / max(args.steps, 1)
-    select_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / max(args.steps, 1)
+    select_ms = sum(e[4].elapsed_time(e[2]) for e in ev) / max(args.steps, 1)
     count_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / max(args.steps, 1)
 
     # ---------- after the timed region: algorithmic bytes of one launch, parity checks ----------
+    while len(out_sets) > 1:                                      # (every set holds the same bytes: the checks read set 0)
+        out_sets.pop()
+    torch.cuda.empty_cache()
     rec = d_records.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
     ok_status = bool((rec["status"] == 0).all())
     aln_cols = int(rec["aln_len"].astype(np.int64).sum())
@@ -449,7 +477,9 @@ def main():
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
             "alignments_per_s": world * n_tasks * args.steps / dt,
             "step_breakdown_ms": {"align_chain": align_ms, "select_best": select_ms, "count_vectors_and_all_reduce": count_ms,
-                                  "note": "rank 0, events on the launch stream, mean over the timed steps"},
+                                  "note": "rank 0, HIP events on the stream of each phase, mean over the timed steps" +
+                                          ("" if args.serial else "; the count pass of batch k runs on a second stream while batch k+1 is aligned "
+                                           "(two output buffer sets), so the phases overlap and do not add up to ms_per_step")},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dominant, "avg_launch_ms": 1e3 * avg_first_s, "launches": launches,

@@ -58,7 +58,7 @@ class _Aligner(EmulatedAligner):
 
 class _Event:
     def __init__(self, enable_timing=False): pass
-    def record(self): pass
+    def record(self, stream=None): pass
     def elapsed_time(self, other): return 1.0
 
 
@@ -75,9 +75,17 @@ def run_bench(argv):
 
     class _Stream:
         cuda_stream = 0
+        def __init__(self, *a, **k): pass
+        def wait_event(self, e): pass
+        def __enter__(self): return self
+        def __exit__(self, *exc): return False
     real_device = torch.device
     saved = (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, torch.cuda.set_device, torch.cuda.Event,
-             batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout)
+             batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout,
+             torch.cuda.Stream, torch.cuda.stream, torch.cuda.empty_cache)
+    torch.cuda.Stream = _Stream
+    torch.cuda.stream = lambda st: st
+    torch.cuda.empty_cache = lambda: None
     torch.device = lambda *a, **k: real_device("cpu")
     torch.cuda.current_stream = lambda *a, **k: _Stream()
     torch.cuda.synchronize = lambda *a, **k: None
@@ -94,7 +102,8 @@ def run_bench(argv):
         bench.main()
     finally:
         (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, torch.cuda.set_device, torch.cuda.Event,
-         batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout) = saved
+         batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout,
+         torch.cuda.Stream, torch.cuda.stream, torch.cuda.empty_cache) = saved
     lines = [x for x in buf.getvalue().splitlines() if x.startswith("{")]
     assert len(lines) == 1, buf.getvalue()
     return json.loads(lines[0])

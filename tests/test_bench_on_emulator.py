@@ -6,10 +6,10 @@ import pytest
 import bench_on_emulator as BE
 
 
-@pytest.mark.parametrize("config,reads", [(3, 260), (2, 200), (4, 150), (5, 192)])
-def test_bench_line_on_the_emulator(config, reads):
-    out = BE.run_bench(["--config", str(config), "--reads", str(reads), "--steps", "1", "--warmup", "0", "--workers", "1",
-                        "--cpu-seconds", "1.5", "--check", "40"])
+@pytest.mark.parametrize("config,reads,steps,extra", [(3, 260, 1, []), (2, 200, 3, []), (4, 150, 2, ["--serial"]), (5, 192, 1, [])])
+def test_bench_line_on_the_emulator(config, reads, steps, extra):
+    out = BE.run_bench(["--config", str(config), "--reads", str(reads), "--steps", str(steps), "--warmup", "0", "--workers", "1",
+                        "--cpu-seconds", "1.5", "--check", "40"] + extra)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "checks", "valu"):
         assert key in out, key
