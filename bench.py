@@ -120,9 +120,10 @@ def main():
                          "diag4 = the 32-bit chain 4 -> 2 -> 1)")
     ap.add_argument("--check", type=int, default=300, help="reads compared with the C oracle after the timed region (0 = no checks at all)")
     ap.add_argument("--no-full-plane-check", action="store_true", help="skip the chain-vs-full-plane comparison of every alignment")
-    ap.add_argument("--serial", action="store_true",
-                    help="one stream, one set of output buffers: the count pass of a batch ends before the next batch's launch chain starts "
-                         "(default: it runs on a second stream while the next batch is aligned into the other buffer set)")
+    ap.add_argument("--overlap-count", action="store_true",
+                    help="run the count pass of batch k on a second stream while batch k+1 is aligned into a second set of output buffers "
+                         "(measured on MI355X, profiles/r02/README.md: no gain -- the persistent workgroups of the launch chain leave the "
+                         "count kernel nothing to run on, and it slows them; the default keeps one stream)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,13 +175,13 @@ def main():
     d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
     d_offsets = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
     d_rids = None if wl["ref_ids"] is None else torch.from_numpy(wl["ref_ids"].astype(np.int16)).to(dev)
-    # output buffers: two sets, so that batch k+1 is aligned while batch k is still being counted (one set with --serial)
-    n_sets = 1 if args.serial else 2
+    # output buffers: one set; two with --overlap-count, so that batch k+1 is aligned while batch k is still being counted
+    n_sets = 2 if args.overlap_count else 1
     out_sets = [(torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev), torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev),
                  torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)) for _ in range(n_sets)]
     d_aln_read, d_aln_ref, d_records = out_sets[0]
     t_align = torch.cuda.current_stream()
-    t_count = t_align if args.serial else torch.cuda.Stream(device=dev)
+    t_count = torch.cuda.Stream(device=dev) if args.overlap_count else t_align
     stream = t_align.cuda_stream
     count_stream = t_count.cuda_stream
     aligned_ev = [torch.cuda.Event() for _ in range(n_sets)]
@@ -204,7 +205,7 @@ def main():
 
     def step(e=None):
         """One batch: launch chain on the align stream into buffer set i; reference choice, count pass and all-reduce on the count
-        stream (the same stream with --serial).  Set i is aligned into again only after its previous batch has been counted."""
+        stream (the same stream unless --overlap-count).  Set i is aligned into again only after its previous batch has been counted."""
         i = step_no[0] % n_sets
         step_no[0] += 1
         a_read, a_ref, recs = out_sets[i]
@@ -478,7 +479,7 @@ def main():
             "alignments_per_s": world * n_tasks * args.steps / dt,
             "step_breakdown_ms": {"align_chain": align_ms, "select_best": select_ms, "count_vectors_and_all_reduce": count_ms,
                                   "note": "rank 0, HIP events on the stream of each phase, mean over the timed steps" +
-                                          ("" if args.serial else "; the count pass of batch k runs on a second stream while batch k+1 is aligned "
+                                          ("" if not args.overlap_count else "; the count pass of batch k runs on a second stream while batch k+1 is aligned "
                                            "(two output buffer sets), so the phases overlap and do not add up to ms_per_step")},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -23,7 +23,7 @@ SYMBOLS = [
     "c2_selftest", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_timing_read_split", "c2_count_vectors_device", "c2_select_best_device",
     "c2_comm_unique_id", "c2_comm_init", "c2_reduce_counts", "c2_comm_destroy",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
-    "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
+    "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error", "c2_strand_plan", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners",
     "c2_consensus_pairs_batch",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets",
@@ -91,7 +91,7 @@ def load():
                 fn.argtypes = [ctypes.c_void_p]
             lib.c2_lists_free.restype = None
             lib.c2_lists_free.argtypes = [ctypes.c_void_p]
-            for fn in (lib.c2_fastq_n_unique, lib.c2_fastq_n_reads, lib.c2_fastq_arena_bytes, lib.c2_fastq_aux_bytes):
+            for fn in (lib.c2_fastq_n_unique, lib.c2_fastq_n_reads, lib.c2_fastq_nonempty_lines, lib.c2_fastq_arena_bytes, lib.c2_fastq_aux_bytes):
                 fn.restype = ctypes.c_uint64
                 fn.argtypes = [ctypes.c_void_p]
             lib.c2_fastq_unique_paired.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
@@ -301,9 +301,19 @@ def fastq_unique(path, min_single_bp_quality=0, min_average_read_quality=0, min_
         counts = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_counts(h), ctypes.POINTER(ctypes.c_uint32)), (n,)).copy()
                   if n else np.zeros(0, dtype=np.uint32))
         total = int(lib.c2_fastq_n_reads(h))
+        if stats is not None:
+            _line_stats(stats, int(lib.c2_fastq_nonempty_lines(h)))
     finally:
         lib.c2_fastq_free(h)
     return arena, offsets, counts, total
+
+
+def _line_stats(stats, parsed_nonempty_lines):
+    """N_READS_AFTER_PREPROCESSING = get_n_reads_fastq of the text that was parsed (CRISPRessoCORE.py:3723-3727: the filtered file,
+    or the input itself -- then N_READS_INPUT is the same number, :3539)."""
+    n = int(float(parsed_nonempty_lines) / 4.0)
+    stats["N_READS_AFTER_PREPROCESSING"] = n
+    stats.setdefault("N_READS_INPUT", n)
 
 
 class FastqUnique:
@@ -333,6 +343,8 @@ class FastqUnique:
         self.counts = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_counts(h), ctypes.POINTER(ctypes.c_uint32)), (n,))
                        if n else np.zeros(0, dtype=np.uint32))
         self.n_reads = int(lib.c2_fastq_n_reads(h))
+        if stats is not None:
+            _line_stats(stats, int(lib.c2_fastq_nonempty_lines(h)))
 
     def close(self):
         """Releases the native memory.  Large arenas are handed to a helper thread (unmapping a few hundred megabytes takes tens

@@ -28,6 +28,7 @@
 #include <memory>
 #include <algorithm>
 #include <atomic>
+#include <tuple>
 #include <dlfcn.h>
 
 #include "crispresso2_amd.h"
@@ -35,11 +36,13 @@
 // Byte arena that never value-initialises what it hands out (a std::vector<uint8_t>::resize to the size of all unique reads is a
 // serial zero-fill of hundreds of megabytes -- and of their page faults -- right before the threads overwrite every byte).
 struct ByteBuf {
-    uint8_t* p = nullptr; size_t n = 0, cap = 0;
+    uint8_t* p = nullptr; size_t n = 0, cap = 0; bool mapped = false;   // mapped: an anonymous mapping with huge pages asked for
+    static constexpr size_t MAP_FROM = (size_t)8 << 20;                 // (the page faults of a few hundred megabytes of 4 KiB pages cost more than copying the bytes)
     ByteBuf() = default;
     ByteBuf(const ByteBuf&) = delete;
     ByteBuf& operator=(const ByteBuf&) = delete;
-    ~ByteBuf() { free(p); }
+    ~ByteBuf() { release(); }
+    void release() { if (p) { if (mapped) munmap(p, cap); else free(p); } p = nullptr; n = cap = 0; mapped = false; }
     uint8_t* data() { return p; }
     const uint8_t* data() const { return p; }
     size_t size() const { return n; }
@@ -48,6 +51,15 @@ struct ByteBuf {
         if (want <= cap) return;
         size_t c = cap ? cap : 4096;
         while (c < want) c += c / 2 + 4096;
+        if (c >= MAP_FROM) {
+            c = (c + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            void* q = mapped ? mremap(p, cap, c, MREMAP_MAYMOVE) : mmap(nullptr, c, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) throw std::bad_alloc();
+            madvise(q, c, MADV_HUGEPAGE);
+            if (!mapped) { if (n) memcpy(q, p, n); free(p); }
+            p = (uint8_t*)q; cap = c; mapped = true;
+            return;
+        }
         uint8_t* q = (uint8_t*)realloc(p, c);
         if (!q) throw std::bad_alloc();
         p = q; cap = c;
@@ -61,6 +73,7 @@ struct c2_fastq {
     std::vector<uint64_t> offsets;     // n_unique + 1
     std::vector<uint32_t> counts;      // n_unique
     uint64_t n_reads = 0;
+    uint64_t nonempty_lines = 0;       // what `grep -c .` counts in the parsed text: '\n'-terminated lines with at least one byte (get_n_reads_fastq)
     std::vector<uint8_t> aux;          // paired input: the quality pair "q1 q2[::-1]" of every entry, back to back
     std::vector<uint64_t> aux_offsets; // n_unique + 1 (empty for single-file input)
 };
@@ -162,7 +175,13 @@ struct Lines {
         }
         if (++line_in_record == 4) in_record = false;
     }
+    char last_byte = '\n';             // for the `grep -c .` count: a non-newline byte right after a '\n' (or at the start) opens a counted line
     void feed(const char* buf, size_t n) {
+        {
+            uint64_t ne = 0; char prev = last_byte;
+            for (size_t q = 0; q < n; ++q) { const char x = buf[q]; ne += (x != '\n') & (prev == '\n'); prev = x; }
+            D.R->nonempty_lines += ne; last_byte = prev;
+        }
         size_t i = 0;
         if (pending_cr) { pending_cr = false; if (n && buf[0] == '\n') i = 1; }
         if (memchr(buf + i, '\r', n - i) == nullptr) {
@@ -212,13 +231,17 @@ inline bool term_end(const char* b, size_t n, size_t p) {      // does a line te
     return b[p] == '\n' || (b[p] == '\r' && (p + 1 >= n || b[p + 1] != '\n'));
 }
 
-uint64_t count_terminators(const char* b, size_t n, size_t lo, size_t hi) {
-    uint64_t c = 0;
+// -> line terminators that end in [lo, hi); *nonempty += lines of `grep -c .` that START there ('\n' is its only terminator)
+uint64_t count_terminators(const char* b, size_t n, size_t lo, size_t hi, uint64_t* nonempty) {
+    uint64_t c = 0, ne = 0;
+    char prev = lo ? b[lo - 1] : '\n';
     if (memchr(b + lo, '\r', hi - lo) == nullptr) {
-        for (size_t i = lo; i < hi; ++i) c += (b[i] == '\n');
+        for (size_t i = lo; i < hi; ++i) { const char x = b[i]; c += (x == '\n'); ne += (x != '\n') & (prev == '\n'); prev = x; }
+        *nonempty += ne;
         return c;
     }
-    for (size_t i = lo; i < hi; ++i) c += term_end(b, n, i) ? 1 : 0;
+    for (size_t i = lo; i < hi; ++i) { const char x = b[i]; c += term_end(b, n, i) ? 1 : 0; ne += (x != '\n') & (prev == '\n'); prev = x; }
+    *nonempty += ne;
     return c;
 }
 
@@ -264,12 +287,13 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
     const double T0 = now_s();
     std::vector<size_t> cut(threads + 1);
     for (unsigned t = 0; t <= threads; ++t) cut[t] = (size_t)((unsigned __int128)n * t / threads);
-    std::vector<uint64_t> terms(threads, 0);
+    std::vector<uint64_t> terms(threads, 0), starts(threads, 0);
     {
         std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] { terms[t] = count_terminators(b, n, cut[t], cut[t + 1]); });
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] { terms[t] = count_terminators(b, n, cut[t], cut[t + 1], &starts[t]); });
         for (auto& th : pool) th.join();
     }
+    for (unsigned t = 0; t < threads; ++t) R->nonempty_lines += starts[t];
     const double T1 = now_s();
     // number of the first line that starts at or after cut[t]: lines started before = 1 + terminators ending before cut[t] - 1
     std::vector<uint64_t> first(threads, 0);
@@ -404,6 +428,13 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
     const uint64_t lines = total_terms + ((n > 0 && !term_end(b, n, n - 1)) ? 1 : 0);
     if ((lines & 3) == 1) { add_empty(); ++n_reads; }
     R->n_reads = n_reads;
+    // the per-range tables and arenas (as many bytes again as the result) are released off the caller's path: unmapping them
+    // is tens of milliseconds of kernel time for a gigabyte of input
+    if (n >= ((size_t)64 << 20) && !getenv("C2_SYNC_FREE")) {
+        auto* junk = new std::tuple<decltype(res), decltype(part), decltype(by_range)>(std::move(res), std::move(part), std::move(by_range));
+        std::thread([junk] { delete junk; }).detach();
+    }
+    if (trace) fprintf(stderr, "c2_fastq: released the range tables after %.3f s\n", now_s() - T0);
     return 0;
 }
 
@@ -895,7 +926,9 @@ void filter_fastq_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t 
                 }
                 if (!failure && keep && min_bpn > 0) {
                     if (min_bp > 0 && min_av <= 0) failure = "ValueError: assignment destination is read-only (run_mBP_mBPN masks a numpy.frombuffer view)";
-                    else if (ns != nq) failure = "IndexError: boolean index did not match indexed array (sequence and quality lines differ in length)";
+                    // (numpy accepts a boolean index of size 0 for any array: a record with an EMPTY quality line -- a file cut short
+                    // inside a record -- is written unmasked by run_mBPN and the run goes on)
+                    else if (nq != 0 && ns != nq) failure = "IndexError: boolean index did not match indexed array (sequence and quality lines differ in length)";
                 }
                 if (failure) {
                     R.err_rec = rec;
@@ -910,7 +943,7 @@ void filter_fastq_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t 
                     R.len += need;
                     memcpy(o, b + id.a, id.z - id.a); o += id.z - id.a; *o++ = '\n';
                     memcpy(o, b + sq.a, ns);
-                    if (min_bpn > 0) for (size_t k = 0; k < ns; ++k) if ((int)(uint8_t)(q[k] - 33) < min_bpn) o[k] = 'N';
+                    if (min_bpn > 0) for (size_t k = 0; k < ns && k < nq; ++k) if ((int)(uint8_t)(q[k] - 33) < min_bpn) o[k] = 'N';
                     o += ns; *o++ = '\n';
                     memcpy(o, b + pl.a, pl.z - pl.a); o += pl.z - pl.a; *o++ = '\n';
                     memcpy(o, b + ql.a, nq); o += nq; *o++ = '\n';
@@ -1341,6 +1374,7 @@ const uint64_t* c2_fastq_aux_offsets(const c2_fastq* r) { return (r && !r->aux_o
 
 uint64_t c2_fastq_n_unique(const c2_fastq* r) { return r ? (uint64_t)r->counts.size() : 0; }
 uint64_t c2_fastq_n_reads(const c2_fastq* r) { return r ? r->n_reads : 0; }
+uint64_t c2_fastq_nonempty_lines(const c2_fastq* r) { return r ? r->nonempty_lines : 0; }
 uint64_t c2_fastq_arena_bytes(const c2_fastq* r) { return r ? (uint64_t)r->arena.size() : 0; }
 const uint8_t* c2_fastq_arena(const c2_fastq* r) { return r ? r->arena.data() : nullptr; }
 const uint64_t* c2_fastq_offsets(const c2_fastq* r) { return r ? r->offsets.data() : nullptr; }

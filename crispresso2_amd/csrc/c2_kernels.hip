@@ -2462,7 +2462,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
     const bool legacy = A.flags & C2_CNT_FLAG_LEGACY;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int cur_ref = -1;                                           // workgroup-uniform, like everything that guards a barrier
-    int wsum = 0;                                               // weight accumulated since the last flush (int32 safety)
+    unsigned wsum = 0;                                          // load accumulated since the last flush (int32 safety, see C2_CNT_LOAD_BUDGET)
     int Li = 0, par = 0;
 
     // flush the LDS block of cur_ref into the int64 tensor (workgroup-wide)
@@ -2537,20 +2537,26 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
             }
         }
         unsigned pending = (unsigned)__ballot(sel);
-        {   // chunk weight (clamped per task so the sum cannot wrap): decides flushes before anything is added
-            int wv = sel ? (v_w > (1 << 22) ? (1 << 22) : v_w) : 0;
+        // Everything an alignment adds to an int32 entry of the block is its weight times a count of its own columns -- at most
+        // w * aln_len, its LOAD.  The loads since the last flush stay within C2_CNT_LOAD_BUDGET (2^30), so no entry can wrap;
+        // saturating sums decide the flushes before anything is added.
+        const int my_T = (int)(d0 & 0xffffu);
+        int w_left = sel ? v_w : 0;                                  // (heavy chunks: what of the task's weight is still to be added)
+        {
+            const unsigned long long ld = sel ? (unsigned long long)(unsigned)v_w * (unsigned long long)(my_T > 0 ? my_T : 1) : 0ull;
+            unsigned wv = ld > C2_CNT_LOAD_BUDGET ? C2_CNT_LOAD_BUDGET + 1u : (unsigned)ld;
 #pragma unroll
-            for (int d = 1; d < K; d <<= 1) wv += __shfl_xor(wv, d);
-            if (lane == 0) ctl[2 + wave] = wv;
+            for (int d = 1; d < K; d <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)wv, d); wv = (wv + o > C2_CNT_LOAD_BUDGET) ? C2_CNT_LOAD_BUDGET + 1u : wv + o; }
+            if (lane == 0) ctl[2 + wave] = (int)wv;
         }
         __syncthreads();
-        int chunk_w = 0;
+        unsigned chunk_w = 0;
 #pragma unroll
-        for (int v = 0; v < C2_CNT_WAVES; ++v) chunk_w += ctl[2 + v];
-        // a chunk heavier than the int32 budget is processed one task at a time with a flush after each
-        const bool heavy = chunk_w > (1 << 21);
-        if (!heavy && wsum + chunk_w > (1 << 21)) flush();
-        wsum += heavy ? 0 : chunk_w;
+        for (int v = 0; v < C2_CNT_WAVES; ++v) { const unsigned o = (unsigned)ctl[2 + v]; chunk_w = (chunk_w + o > C2_CNT_LOAD_BUDGET) ? C2_CNT_LOAD_BUDGET + 1u : chunk_w + o; }
+        // a chunk heavier than the budget is processed one task at a time, its weight in pieces whose load fits, with a flush after each
+        const bool heavy = chunk_w > C2_CNT_LOAD_BUDGET;
+        if (!heavy && wsum + chunk_w > C2_CNT_LOAD_BUDGET) flush();
+        wsum += heavy ? 0u : chunk_w;
         for (;;) {
             // lowest pending task of the workgroup -> the reference whose tasks are processed in this round
             const int first = pending ? __builtin_ctz(pending) : -1;
@@ -2578,16 +2584,19 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
             //      every lane adds its task's contributions (LDS atomics; ~20 instructions per round instead of per task).
             //      aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979), then the tallies of :3996-4072.
             const bool mine = lane < K && ((todo >> lane) & 1u) && (int)(d6 >> 16) == tref;
+            // the weight this round adds for the lane's task: all of it, or (heavy) a piece whose load fits the budget
+            const int piece = (int)(C2_CNT_LOAD_BUDGET / (unsigned)(my_T > 0 ? my_T : 1));
+            const int w_round = (heavy && w_left > piece) ? piece : w_left;
             {   // an alignment whose two strings are the reference itself (no gap column, every column a match) adds nothing but
                 // its weight to the "spread over the reference's bases" scalar: done here, its strings are never read
                 const int T_ = (int)(d0 & 0xffffu), matches_ = (int)(d0 >> 16);
                 const bool perfect = mine && T_ == Li && matches_ == T_ && (d4 >> 16) == 0u && d1 == 0u;
-                if (perfect) atomicAdd(acc + o_sc + C2_S_RESERVED0, v_w);
+                if (perfect) atomicAdd(acc + o_sc + C2_S_RESERVED0, w_round);
                 const unsigned pm = (unsigned)__ballot(perfect);
                 todo &= ~pm; pending &= ~pm;
             }
             if (mine) {
-                const int w = v_w;
+                const int w = w_round;
                 const int insertion_n = (int)(d1 & 0xffffu), deletion_n = (int)(d1 >> 16), substitution_n = (int)(d2 & 0xffffu);
                 const int all_ins = (int)(d2 >> 16), all_del_bases = (int)((d4 >> 16) & 0x7fffu), all_sub = (int)(d5 & 0xffffu);
                 const bool irregular_ends = (d5 >> 16) & 0xffu;
@@ -2599,7 +2608,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
                 atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
                 if (irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
-                atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);
+                if (w_left == v_w) atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);                       // (once per alignment, not per piece of a heavy weight)
                 if (discard && (deletion_n > 0 || insertion_n > 0)) atomicAdd(scal + C2_S_DISCARDED, w);                     // :3996-4000
                 else {
                     const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
@@ -2633,7 +2642,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)d0, kk), r1 = (unsigned)__builtin_amdgcn_readlane((int)d1, kk);
                 const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)d2, kk), r4 = (unsigned)__builtin_amdgcn_readlane((int)d4, kk);
                 const unsigned r5 = (unsigned)__builtin_amdgcn_readlane((int)d5, kk);
-                const int w = __builtin_amdgcn_readlane(v_w, kk);
+                const int w = __builtin_amdgcn_readlane(w_round, kk);
                 const int T = (int)(r0 & 0xffffu);
                 const int insertion_n = (int)(r1 & 0xffffu), deletion_n = (int)(r1 >> 16), substitution_n = (int)(r2 & 0xffffu);
                 const int all_ins = (int)(r2 >> 16), all_del_bases = (int)((r4 >> 16) & 0x7fffu), all_sub = (int)(r5 & 0xffffu);
@@ -2808,7 +2817,12 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                     }
                 }
             }   // tasks of this round
-            if (heavy) flush();
+            if (heavy) {
+                // a task whose weight was added only in part stays pending for another round
+                if (mine) w_left -= w_round;
+                pending |= (unsigned)__ballot(mine && w_left > 0);
+                flush();
+            }
         }       // rounds of this chunk
     }           // chunks
     flush();

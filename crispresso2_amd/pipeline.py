@@ -266,6 +266,9 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
     if not arena.flags.writeable:
         arena = arena.copy()                                      # torch.from_numpy wants a writable array
+    # the reads go to the device now: the copy is in flight while the host tests the seeds
+    d_reads = torch.from_numpy(arena if arena.size else np.zeros(1, dtype=np.uint8)).to(dev, non_blocking=True)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev, non_blocking=True)
     lap("setup")
     # which read is the reverse complement of which (for the count merge of :3970-3975) does not depend on the alignments: a host
     # thread looks that up while the device aligns
@@ -286,8 +289,6 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     stride = aligner.stride_for(max_lj)
 
     # ---- batch 1: every read against every reference, on the strand the seeds ask for (forward when they ask for both)
-    d_reads = torch.from_numpy(arena if arena.size else np.zeros(1, dtype=np.uint8)).to(dev)
-    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
     d_str1 = torch.from_numpy((plan == 1).astype(np.uint8).reshape(-1)).to(dev)
     n1 = n * k
     a1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
@@ -512,8 +513,8 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
 
 
 def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None, pe_scaffold_dna_info=None):
-    """FASTQ file -> QuantResult.  Empty sequences (blank line / truncated record) are dropped, as in
-    variants.read_fastq_unique; N_TOT_READS counts every record of the file."""
+    """FASTQ file -> QuantResult.  Empty sequences (blank line / truncated record) are dropped, as in variants.read_fastq_unique
+    (the reference's aligner indexes seq[-1] of an empty string: undefined there), and N_TOT_READS counts the records that are left."""
     import time
     t0 = time.perf_counter()
     # --min_single_bp_quality / --min_average_read_quality / --min_bp_quality_or_N: the reference filters the file first
@@ -538,6 +539,8 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
         t_free = time.perf_counter()
     if timings is not None:
         timings["free_ingest"] = time.perf_counter() - t_free
+    # as the reference counts them: non-empty lines / 4 of the input and of the text that was parsed (get_n_reads_fastq) -- these
+    # differ from the number of records only for files with blank lines or a truncated tail
     res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
-    res.stats['N_READS_AFTER_PREPROCESSING'] = int(n_reads)
+    res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats.get('N_READS_AFTER_PREPROCESSING', int(n_reads))
     return res

@@ -309,6 +309,10 @@ int c2_fastq_unique_filtered(const char* path, int32_t min_bp_qual_in_read, int3
                              c2_fastq** out, uint64_t* nonempty_lines_in_input);
 uint64_t c2_fastq_n_unique(const c2_fastq* r);
 uint64_t c2_fastq_n_reads(const c2_fastq* r);
+/* Lines with at least one byte in the text that was parsed ('\n'-terminated, as `grep -c .` counts them): the reference's
+ * get_n_reads_fastq (CRISPRessoShared.py:743-748) is int(that / 4.0) -- N_READS_INPUT of an unfiltered file, and
+ * N_READS_AFTER_PREPROCESSING of the filtered text when the read filter ran in front (c2_fastq_unique_filtered). */
+uint64_t c2_fastq_nonempty_lines(const c2_fastq* r);
 uint64_t c2_fastq_arena_bytes(const c2_fastq* r);
 const uint8_t* c2_fastq_arena(const c2_fastq* r);
 const uint64_t* c2_fastq_offsets(const c2_fastq* r);

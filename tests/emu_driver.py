@@ -25,10 +25,19 @@ def build(force=False):
     srcs = [os.path.join(EMU_DIR, f) for f in ("emu_harness.cpp", "emu_runtime.h", "hip/hip_runtime.h")]
     srcs += [os.path.join(ROOT, "crispresso2_amd/csrc", f) for f in ("c2_kernels.hip", "c2_device.h", "c2_host_prep.h")]
     srcs.append(os.path.join(ROOT, "include/crispresso2_amd.h"))
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-U_FORTIFY_SOURCE", "-D_FORTIFY_SOURCE=0", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("C2_EMU_CFLAGS", "").split() + ["-I", EMU_DIR,
-                               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "crispresso2_amd/csrc"),
-                               "-x", "c++", os.path.join(EMU_DIR, "emu_harness.cpp"), "-o", LIB])
+    def stale():
+        return not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs)
+    if force or stale():
+        # one builder at a time (pytest-xdist workers all get here after a source change), and the library appears atomically
+        import fcntl
+        with open(LIB + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                tmp = LIB + ".tmp.%d" % os.getpid()
+                subprocess.check_call(["g++", "-O1", "-U_FORTIFY_SOURCE", "-D_FORTIFY_SOURCE=0", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("C2_EMU_CFLAGS", "").split() + ["-I", EMU_DIR,
+                                       "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "crispresso2_amd/csrc"),
+                                       "-x", "c++", os.path.join(EMU_DIR, "emu_harness.cpp"), "-o", tmp])
+                os.replace(tmp, LIB)
 
 
 def lib():

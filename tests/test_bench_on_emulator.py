@@ -6,7 +6,7 @@ import pytest
 import bench_on_emulator as BE
 
 
-@pytest.mark.parametrize("config,reads,steps,extra", [(3, 260, 1, []), (2, 200, 3, []), (4, 150, 2, ["--serial"]), (5, 192, 1, [])])
+@pytest.mark.parametrize("config,reads,steps,extra", [(3, 260, 1, []), (2, 200, 3, []), (4, 150, 2, ["--overlap-count"]), (5, 192, 1, [])])
 def test_bench_line_on_the_emulator(config, reads, steps, extra):
     out = BE.run_bench(["--config", str(config), "--reads", str(reads), "--steps", str(steps), "--warmup", "0", "--workers", "1",
                         "--cpu-seconds", "1.5", "--check", "40"] + extra)

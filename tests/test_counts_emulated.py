@@ -80,9 +80,11 @@ def test_count_vectors_interleaved_references_and_heavy_weights(aligned):
     rec2 = rec.copy()
     rec2["ref_id"] = rng.integers(0, 2, len(rec2)).astype(np.uint16)
     w = rng.integers(1, 9, len(reads)).astype(np.uint32)
-    w[3] = 3_000_000
-    w[40] = 2_500_000
-    w[41] = 2_200_000
+    w[3] = 30_000_000                  # beyond the load budget (weight x alignment length <= 2^30 per flush): added in pieces
+    w[40] = 2_000_000_000              # close to the int32 limit of a weight: ~270 pieces
+    w[41] = 25_000_000
+    w[len(reads) - 3] = 1_900_000_000  # the read with two insertions (length sums are weight x size)
+    w[len(reads) - 1] = 1_700_000_000  # a 30-base trailing deletion (difference arrays, deletion length sums)
     counts, lay = E.count_vectors(o1, o2, rec2, [amp, amp], [inc, inc], max(len(r) for r in reads), weights=w, grid=3)
     P = payloads(res, inc)
     for r in range(2):

@@ -4,7 +4,8 @@ unchanged" -- executed.  The reference's UNMODIFIED CRISPRessoCORE.main() runs i
 reference's module names (tests/dropin_inject.py = INTEGRATION.md section 1), and the files the reference repository keeps as
 expected results must come out byte for byte; then the reference's own unit-test files for the two modules (and for
 CRISPRessoCORE's consensus / variant functions, which call them) are collected unchanged and run against the shim.
-Device calls go to the wave emulator here; tools/dropin_on_gpu.py replays the recorded calls of the same run on the GPU.
+Device calls go to the wave emulator here; tests/test_core_calls.py replays every call those two runs make (recorded with the
+reference's own modules) through the product's modules on the GPU (-m gpu) and on the emulator.
 Skipped when /root/reference is absent (the GPU box)."""
 import os
 import subprocess

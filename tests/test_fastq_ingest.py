@@ -505,6 +505,9 @@ def test_read_filter_framing_wraparound_and_the_reference_failures(tmp_path):
         "cr_only_is_one_line": ("@a\rACGT\r+\rIIII\r", (0, 10, 0)),
         "nothing_passes": ("@a\nACGT\n+\n####\n", (0, 30, 0)),
         "lowercase_masked": ("@a\nacgt\n+\nI#I#\n", (0, 0, 10)),
+        # numpy takes a boolean index of size 0 for any array: an EMPTY quality line under masking alone is written unmasked
+        "empty_quality_under_masking_alone": ("@a\nACGT\n+\nI#II\n@b\nGGCC\n+\n\n@c\nTTAA\n+\n#III\n", (0, 0, 10)),
+        "record_cut_after_the_plus_line_under_masking": ("@a\nACGT\n+\nI#II\n@b\nGGCC\n+\n", (0, 0, 10)),
     }
     for name, (text, opts) in cases.items():
         p = tmp_path / (name + ".fastq")
@@ -595,3 +598,37 @@ def test_native_partner_search_plus_count_transfer_equals_the_one_step_merge(n_b
         one = _native.merge_reverse_complements(arena, off, aligned, counts.copy())
         two = _native.merge_counts_with_partners(aligned, partner, counts.copy())
         assert np.array_equal(one, two)
+
+
+def test_nonempty_line_count_is_what_get_n_reads_fastq_counts(tmp_path, monkeypatch):
+    """c2_fastq_nonempty_lines = `grep -c .` of the parsed text (CRISPRessoShared.py:743-748) on every ingest route; the read counts
+    the reference reports are int(that / 4.0) -- different from the number of records for blank lines and truncated tails."""
+    import subprocess
+    from crispresso2_amd import _native
+    texts = {
+        "plain": "@a\nACGT\n+\nIIII\n@b\nGGCC\n+\nIIII\n",
+        "blank_lines": "@a\nACGT\n+\nIIII\n\n\n@b\nGGCC\n+\nIIII\n\n",
+        "truncated": "@a\nACGT\n+\nIIII\n@b\nGG",
+        "crlf": "@a\r\nACGT\r\n+\r\nIIII\r\n\r\n@b\r\nGGCC\r\n+\r\nIIII\r\n",       # a line holding only '\r' is not empty for grep
+        "cr_only": "@a\rACGT\r+\rIIII\r",
+        "empty_sequence": "@a\n\n+\n\n@b\nGGCC\n+\nIIII\n",
+    }
+    rng = np.random.default_rng(3)
+    big = "".join("@r%d\n%s\n+\n%s\n%s" % (k, "".join(rng.choice(list("ACGT"), 30)), "I" * 30, "\n" if k % 97 == 0 else "") for k in range(4000))
+    texts["big_with_blank_lines"] = big
+    for name, text in texts.items():
+        p = tmp_path / (name + ".fastq")
+        p.write_bytes(text.encode())
+        want = int(subprocess.run("cat < %s | grep -c ." % p, shell=True, capture_output=True, text=True).stdout or 0)
+        gz = tmp_path / (name + ".fastq.gz")
+        with gzip.open(gz, "wb") as fh:
+            fh.write(text.encode())
+        for path, envs in ((p, [{}, {"C2_FASTQ_THREADS": "5"}]), (gz, [{"C2_FASTQ_GZ": "stream"}, {"C2_FASTQ_GZ": "auto"}])):
+            for env in envs:
+                for k_, v_ in env.items():
+                    monkeypatch.setenv(k_, v_)
+                st = {}
+                _native.fastq_unique(str(path), stats=st)
+                for k_ in env:
+                    monkeypatch.delenv(k_)
+                assert st["N_READS_AFTER_PREPROCESSING"] == st["N_READS_INPUT"] == int(float(want) / 4.0), (name, path, env, st, want)
