@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include <memory>
@@ -92,6 +93,11 @@ struct c2_ctx {
     int comm_world = 0;
     std::vector<uint32_t> sel_table;
     std::vector<uint16_t> cnt_table;   // host copy of the table that is on the device (skip re-upload when unchanged)
+    // host batch path, pipelined: pinned staging (two sets), copy streams and their events
+    void* pin_in[2] = {nullptr, nullptr}; size_t pin_in_cap[2] = {0, 0};
+    void* pin_out[2] = {nullptr, nullptr}; size_t pin_out_cap[2] = {0, 0};
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -532,6 +538,15 @@ void c2_destroy(c2_ctx* ctx) {
                      &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_diagrows_pk, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel};
     for (DevBuf* b : all) release(*b);
     (void)c2_comm_destroy(ctx);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->pin_in[k]) (void)hipHostFree(ctx->pin_in[k]);
+        if (ctx->pin_out[k]) (void)hipHostFree(ctx->pin_out[k]);
+        if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
+        if (ctx->ev_done[k]) (void)hipEventDestroy(ctx->ev_done[k]);
+        if (ctx->ev_out[k]) (void)hipEventDestroy(ctx->ev_out[k]);
+    }
+    if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
+    if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -731,6 +746,135 @@ int c2_align_classify_batch_device(c2_ctx* ctx, const c2_batch* b, void* hip_str
     return run_align(ctx, b, max_lj, (hipStream_t)hip_stream);
 }
 
+namespace {
+
+int ensure_pinned(c2_ctx* ctx, void*& p, size_t& cap, size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->err = std::string("hipHostMalloc: ") + hipGetErrorString(e); p = nullptr; return C2_E_NOMEM; }
+    cap = want;
+    return 0;
+}
+
+// memcpy on a few threads (pinned staging <-> the caller's pageable arrays: one thread moves ~10 GB/s, the link more)
+void copy_parallel(void* dst, const void* src, size_t n, unsigned threads) {
+    if (threads < 2 || n < ((size_t)4 << 20)) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) {
+        const size_t a = n * t / threads, z = n * (t + 1) / threads;
+        pool.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, z - a); });
+    }
+    for (auto& th : pool) th.join();
+}
+
+// Host batch, pipelined.  The batch is cut into chunks of reads; for chunk c, concurrently:
+//   host threads   reads of chunk c+1 -> pinned input set;   pinned output set of chunk c-1 -> the caller's arrays
+//   stream s_in    pinned input of chunk c+1 -> device
+//   ctx->stream    launch chain of chunk c (after its input arrived)
+//   stream s_out   outputs of chunk c-1 -> pinned output set
+// Offsets / reference ids / strands are small and go up front.  Two pinned sets each way; events order their reuse.
+int align_host_pipelined(c2_ctx* ctx, const c2_batch* b, int max_lj, uint64_t chunk_reads) {
+    const uint64_t n = b->n_reads;
+    const uint64_t tpr = (uint64_t)(b->all_refs ? ctx->n_refs : 1);          // tasks per read
+    const uint64_t n_tasks = n * tpr;
+    const uint64_t stride = b->aln_stride;
+    const uint64_t base0 = b->offsets[0];
+    const uint64_t nbytes = b->offsets[n] - base0;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_reads, nbytes + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->d_offsets, (n + 1) * 8))) return rc;
+    if (b->ref_ids && !b->all_refs) if ((rc = ensure(ctx, ctx->d_refids, n * 2))) return rc;
+    if (b->strands) if ((rc = ensure(ctx, ctx->d_strands, n_tasks))) return rc;
+    if ((rc = ensure(ctx, ctx->d_aln_read, n_tasks * stride))) return rc;
+    if ((rc = ensure(ctx, ctx->d_aln_ref, n_tasks * stride))) return rc;
+    if ((rc = ensure(ctx, ctx->d_records, n_tasks * sizeof(c2_aln_record)))) return rc;
+    if (!ctx->s_in) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_out[k], hipEventDisableTiming));
+        }
+    }
+    hipStream_t s = ctx->stream;
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char* e = getenv("C2_HOST_THREADS")) threads = (unsigned)atoi(e);
+    threads = std::max(1u, std::min(threads, 16u));
+    // chunk boundaries and the largest chunk, in input bytes and in tasks
+    const uint64_t n_chunks = (n + chunk_reads - 1) / chunk_reads;
+    auto c_lo = [&](uint64_t c) { return std::min<uint64_t>(n, c * chunk_reads); };
+    uint64_t max_in = 0;
+    for (uint64_t c = 0; c < n_chunks; ++c) max_in = std::max<uint64_t>(max_in, b->offsets[c_lo(c + 1)] - b->offsets[c_lo(c)]);
+    const uint64_t max_tasks = std::min<uint64_t>(n, chunk_reads) * tpr;
+    const size_t out_bytes = (size_t)(max_tasks * (2 * stride + sizeof(c2_aln_record)));
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = ensure_pinned(ctx, ctx->pin_in[k], ctx->pin_in_cap[k], (size_t)max_in + 16))) return rc;
+        if ((rc = ensure_pinned(ctx, ctx->pin_out[k], ctx->pin_out_cap[k], out_bytes))) return rc;
+    }
+    // small arrays up front (pageable copies on the compute stream; `rel` must outlive them)
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t k = 0; k <= n; ++k) rel[k] = b->offsets[k] - base0;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_offsets.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (b->ref_ids && !b->all_refs) HIPCHK(ctx, hipMemcpyAsync(ctx->d_refids.p, b->ref_ids, n * 2, hipMemcpyHostToDevice, s));
+    if (b->strands) HIPCHK(ctx, hipMemcpyAsync(ctx->d_strands.p, b->strands, n_tasks, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+
+    auto stage_in = [&](uint64_t c) -> int {                      // host: reads of chunk c -> pinned set; s_in: -> device
+        const int k = (int)(c & 1);
+        const uint64_t a = rel[c_lo(c)], z = rel[c_lo(c + 1)];
+        if (c >= 2) HIPCHK(ctx, hipEventSynchronize(ctx->ev_in[k]));          // the set's previous copy (chunk c-2) has left it
+        copy_parallel(ctx->pin_in[k], b->reads + base0 + a, (size_t)(z - a), threads);
+        if (z > a) HIPCHK(ctx, hipMemcpyAsync((uint8_t*)ctx->d_reads.p + a, ctx->pin_in[k], (size_t)(z - a), hipMemcpyHostToDevice, ctx->s_in));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_in[k], ctx->s_in));
+        return 0;
+    };
+    auto drain_out = [&](uint64_t c) -> int {                      // host: pinned outputs of chunk c -> the caller's arrays
+        const int k = (int)(c & 1);
+        const uint64_t t0 = c_lo(c) * tpr, nt = (c_lo(c + 1) - c_lo(c)) * tpr;
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev_out[k]));
+        const uint8_t* po = (const uint8_t*)ctx->pin_out[k];
+        copy_parallel(b->aln_read + t0 * stride, po, (size_t)(nt * stride), threads);
+        copy_parallel(b->aln_ref + t0 * stride, po + max_tasks * stride, (size_t)(nt * stride), threads);
+        memcpy(b->records + t0, po + 2 * max_tasks * stride, (size_t)(nt * sizeof(c2_aln_record)));
+        return 0;
+    };
+    if ((rc = stage_in(0))) return rc;
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        const int k = (int)(c & 1);
+        const uint64_t r0 = c_lo(c), nr = c_lo(c + 1) - r0, t0 = r0 * tpr, nt = nr * tpr;
+        // launch chain of chunk c, after its reads arrived
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_in[k], 0));
+        c2_batch d = *b;
+        d.n_reads = nr;
+        d.reads = (const uint8_t*)ctx->d_reads.p; d.offsets = (const uint64_t*)ctx->d_offsets.p + r0;
+        d.ref_ids = (b->ref_ids && !b->all_refs) ? (const uint16_t*)ctx->d_refids.p + r0 : nullptr;
+        d.strands = b->strands ? (const uint8_t*)ctx->d_strands.p + t0 : nullptr;
+        d.aln_read = (uint8_t*)ctx->d_aln_read.p + t0 * stride; d.aln_ref = (uint8_t*)ctx->d_aln_ref.p + t0 * stride;
+        d.records = (c2_aln_record*)ctx->d_records.p + t0;
+        if ((rc = run_align(ctx, &d, max_lj, s))) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_done[k], s));
+        // the next chunk's reads travel while this one computes
+        if (c + 1 < n_chunks && (rc = stage_in(c + 1))) return rc;
+        // outputs of chunk c -> pinned set k (free once chunk c-2 was drained, which happened below in iteration c-1)
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->s_out, ctx->ev_done[k], 0));
+        uint8_t* po = (uint8_t*)ctx->pin_out[k];
+        HIPCHK(ctx, hipMemcpyAsync(po, d.aln_read, (size_t)(nt * stride), hipMemcpyDeviceToHost, ctx->s_out));
+        HIPCHK(ctx, hipMemcpyAsync(po + max_tasks * stride, d.aln_ref, (size_t)(nt * stride), hipMemcpyDeviceToHost, ctx->s_out));
+        HIPCHK(ctx, hipMemcpyAsync(po + 2 * max_tasks * stride, d.records, (size_t)(nt * sizeof(c2_aln_record)), hipMemcpyDeviceToHost, ctx->s_out));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_out[k], ctx->s_out));
+        // meanwhile: the previous chunk's outputs go to the caller
+        if (c >= 1 && (rc = drain_out(c - 1))) return rc;
+    }
+    if ((rc = drain_out(n_chunks - 1))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // namespace
+
 int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
     if (!ctx || !b) return C2_E_INVALID;
     if (b->n_reads == 0) return 0;
@@ -750,6 +894,13 @@ int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
     if (b->aln_stride < need_stride) { ctx->err = "aln_stride smaller than longest read + longest reference"; return C2_E_INVALID; }
     const uint64_t nbytes = b->offsets[n] - b->offsets[0];
     int rc;
+    {   // large batches: chunks through pinned staging, copies both ways overlapped with the launch chains
+        uint64_t pipe_min = 131072, chunk_tasks = 65536;
+        if (const char* e = getenv("C2_HOST_PIPE_MIN_TASKS")) pipe_min = strtoull(e, nullptr, 10);
+        if (const char* e = getenv("C2_HOST_PIPE_CHUNK_TASKS")) chunk_tasks = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        const uint64_t tpr = (uint64_t)(b->all_refs ? ctx->n_refs : 1);
+        if (n_tasks >= pipe_min && n >= 2) return align_host_pipelined(ctx, b, max_lj, std::max<uint64_t>(1, chunk_tasks / tpr));
+    }
     if ((rc = ensure(ctx, ctx->d_reads, nbytes + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_offsets, (n + 1) * 8))) return rc;
     if (b->ref_ids && !b->all_refs) if ((rc = ensure(ctx, ctx->d_refids, n * 2))) return rc;

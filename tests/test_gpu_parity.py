@@ -312,6 +312,64 @@ def test_multi_reference_strands_and_pooled_ids_vs_oracle(mats, ctx):
         assert res.records["strand"][k] == strands[k] and res.records["ref_id"][k] == rids[k]
 
 
+def test_host_batch_pipelined_through_pinned_staging_equals_the_one_shot_path(mats, ctx):
+    """c2_align_classify_batch_host cuts large batches into chunks (pinned staging both ways, copies overlapped with the launch
+    chains).  Forced here on small ragged batches with odd chunk sizes -- single reference, per-read amplicon ids + strands, and
+    an all-references batch: the same bytes as the one-shot path, and a 300 k-read batch at the default sizes against it."""
+    from crispresso2_amd import synth
+    from crispresso2_amd.batch import BatchAligner
+    m = mats["EDNAFULL"]
+    amp, g, inc = synth.amplicon_setup(250)
+    hdr, pe = synth.make_variant(amp, "hdr"), synth.make_variant(amp, "pe")
+    refs = [amp, hdr, pe[:-17]]
+    gis = [np.zeros(len(r) + 1, dtype=np.int64) for r in refs]
+    for x in gis:
+        x[126] = 1
+    incs = [[125, 126]] * 3
+    rng = np.random.default_rng(99)
+    reads_u8 = synth.make_reads(250, 700)
+    reads = [r.tobytes().decode()[:int(rng.integers(180, 251))] for r in reads_u8]          # ragged
+    rids = rng.integers(0, 3, len(reads))
+    strands = rng.integers(0, 2, len(reads))
+    al = BatchAligner(refs, gis, incs, m, -20, -2, ctx=ctx)
+
+    def run(**kw):
+        r = al.align(reads, **kw)
+        return r.aln_read.copy(), r.aln_ref.copy(), r.records.copy()
+
+    def same(a, b):
+        T = a[2]["aln_len"].astype(np.int64)
+        cols = np.arange(a[0].shape[1])[None, :] < T[:, None]
+        return ((a[0] == b[0]) | ~cols).all() and ((a[1] == b[1]) | ~cols).all() and (a[2].tobytes() == b[2].tobytes())
+
+    os.environ["C2_HOST_PIPE_MIN_TASKS"] = str(1 << 40)
+    try:
+        base = [run(), run(ref_ids=rids, strands=strands), run(all_refs=True)]
+    finally:
+        del os.environ["C2_HOST_PIPE_MIN_TASKS"]
+    for chunk in (37, 256, 699, 5000):
+        os.environ["C2_HOST_PIPE_MIN_TASKS"] = "1"
+        os.environ["C2_HOST_PIPE_CHUNK_TASKS"] = str(chunk)
+        try:
+            got = [run(), run(ref_ids=rids, strands=strands), run(all_refs=True)]
+        finally:
+            del os.environ["C2_HOST_PIPE_MIN_TASKS"], os.environ["C2_HOST_PIPE_CHUNK_TASKS"]
+        for a, b_ in zip(got, base):
+            assert (a[2]["status"] == 0).all() and same(a, b_), chunk
+    # default sizes
+    n = 300_000
+    big = synth.make_reads(250, n)
+    offsets = np.arange(n + 1, dtype=np.uint64) * 250
+    al1 = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
+    r1 = al1.align((big.reshape(-1), offsets))
+    os.environ["C2_HOST_PIPE_MIN_TASKS"] = str(1 << 40)
+    try:
+        r0 = al1.align((big.reshape(-1), offsets))
+    finally:
+        del os.environ["C2_HOST_PIPE_MIN_TASKS"]
+    assert same((r1.aln_read, r1.aln_ref, r1.records), (r0.aln_read, r0.aln_ref, r0.records))
+
+
 def test_banded_pointer_plane_equals_full_plane(mats, ctx):
     """The banded first launch + full-plane fallback must give byte-identical outputs to the full-plane kernel alone,
     for a narrow band (many fallbacks), the automatic band, and with the band off."""
