@@ -163,7 +163,8 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 // C2_CNT_CTL_INTS control words and the current reference's inc_prefix (lmax + 2 uint16)
 #define C2_CNT_WAVES 4
 #define C2_CNT_TASKS_PER_WAVE 32
-#define C2_CNT_CTL_INTS 96          // >= 16 + 4 * C2_CNT_WAVES
+#define C2_CNT_CTL_BASE_INTS 96     // >= 16 + 4 * C2_CNT_WAVES
+#define C2_CNT_CTL_INTS (C2_CNT_CTL_BASE_INTS + C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE)   // + per task of a chunk: the part of a heavy weight that is still to be added
 #define C2_CNT_LOAD_BUDGET (1u << 30) // sum of weight x alignment length an LDS block may take between two flushes (its entries are int32)
 static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {
     return (per_ref + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;

@@ -2441,7 +2441,7 @@ __global__ __launch_bounds__(256) void c2_ref_scatter_kernel(const c2_aln_record
     if (active) order[slot] = (uint32_t)t;
 }
 
-__global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_count_args A)
+__global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(c2_count_args A)
 {
     // C2_CNT_WAVES wavefronts share one LDS block (the block is what limits residency, so sharing it multiplies the
     // waves per CU); each wavefront walks one alignment at a time.  The workgroup takes C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE
@@ -2540,19 +2540,23 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
         // Everything an alignment adds to an int32 entry of the block is its weight times a count of its own columns -- at most
         // w * aln_len, its LOAD.  The loads since the last flush stay within C2_CNT_LOAD_BUDGET (2^30), so no entry can wrap;
         // saturating sums decide the flushes before anything is added.
-        const int my_T = (int)(d0 & 0xffffu);
-        int w_left = sel ? v_w : 0;                                  // (heavy chunks: what of the task's weight is still to be added)
-        {
-            const unsigned long long ld = sel ? (unsigned long long)(unsigned)v_w * (unsigned long long)(my_T > 0 ? my_T : 1) : 0ull;
-            unsigned wv = ld > C2_CNT_LOAD_BUDGET ? C2_CNT_LOAD_BUDGET + 1u : (unsigned)ld;
+        // (heavy chunks: v_w is what of the task's weight is still to be added; `counted`: lanes whose alignment has been counted once)
+        unsigned counted = 0;
+        {   // (a task above 2^26 makes the chunk heavy by itself; the others add up in 32 bits: 32 x 2^26 = 2^31)
+            const unsigned my_T = d0 & 0xffffu;
+            const unsigned long long ld = sel ? (unsigned long long)(unsigned)v_w * (unsigned long long)(my_T > 0 ? my_T : 1u) : 0ull;
+            const bool big = ld > (1ull << 26);
+            unsigned wv = big ? 0u : (unsigned)ld;
 #pragma unroll
-            for (int d = 1; d < K; d <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)wv, d); wv = (wv + o > C2_CNT_LOAD_BUDGET) ? C2_CNT_LOAD_BUDGET + 1u : wv + o; }
+            for (int d = 1; d < K; d <<= 1) wv += (unsigned)__shfl_xor((int)wv, d);
+            if (__ballot(big) != 0ull || wv > C2_CNT_LOAD_BUDGET) wv = C2_CNT_LOAD_BUDGET + 1u;
             if (lane == 0) ctl[2 + wave] = (int)wv;
         }
         __syncthreads();
-        unsigned chunk_w = 0;
+        unsigned long long chunk_sum = 0;
 #pragma unroll
-        for (int v = 0; v < C2_CNT_WAVES; ++v) { const unsigned o = (unsigned)ctl[2 + v]; chunk_w = (chunk_w + o > C2_CNT_LOAD_BUDGET) ? C2_CNT_LOAD_BUDGET + 1u : chunk_w + o; }
+        for (int v = 0; v < C2_CNT_WAVES; ++v) chunk_sum += (unsigned)ctl[2 + v];
+        const unsigned chunk_w = chunk_sum > C2_CNT_LOAD_BUDGET ? C2_CNT_LOAD_BUDGET + 1u : (unsigned)chunk_sum;
         // a chunk heavier than the budget is processed one task at a time, its weight in pieces whose load fits, with a flush after each
         const bool heavy = chunk_w > C2_CNT_LOAD_BUDGET;
         if (!heavy && wsum + chunk_w > C2_CNT_LOAD_BUDGET) flush();
@@ -2585,18 +2589,26 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
             //      aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979), then the tallies of :3996-4072.
             const bool mine = lane < K && ((todo >> lane) & 1u) && (int)(d6 >> 16) == tref;
             // the weight this round adds for the lane's task: all of it, or (heavy) a piece whose load fits the budget
-            const int piece = (int)(C2_CNT_LOAD_BUDGET / (unsigned)(my_T > 0 ? my_T : 1));
-            const int w_round = (heavy && w_left > piece) ? piece : w_left;
+            // heavy chunks: v_w becomes the piece of the weight this round adds, the remainder waits in LDS (no register of the
+            // common path is spent on it: the kernel sits at 96 VGPRs = 5 waves per SIMD)
+            int* rest_slot = ctl + C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1));
+            if (heavy && mine) {
+                const unsigned my_T = d0 & 0xffffu;
+                const int piece = (int)(C2_CNT_LOAD_BUDGET / (my_T > 0 ? my_T : 1u));
+                const int rest = v_w > piece ? v_w - piece : 0;
+                *rest_slot = rest;
+                v_w -= rest;
+            }
             {   // an alignment whose two strings are the reference itself (no gap column, every column a match) adds nothing but
                 // its weight to the "spread over the reference's bases" scalar: done here, its strings are never read
                 const int T_ = (int)(d0 & 0xffffu), matches_ = (int)(d0 >> 16);
                 const bool perfect = mine && T_ == Li && matches_ == T_ && (d4 >> 16) == 0u && d1 == 0u;
-                if (perfect) atomicAdd(acc + o_sc + C2_S_RESERVED0, w_round);
+                if (perfect) atomicAdd(acc + o_sc + C2_S_RESERVED0, v_w);
                 const unsigned pm = (unsigned)__ballot(perfect);
                 todo &= ~pm; pending &= ~pm;
             }
             if (mine) {
-                const int w = w_round;
+                const int w = v_w;
                 const int insertion_n = (int)(d1 & 0xffffu), deletion_n = (int)(d1 >> 16), substitution_n = (int)(d2 & 0xffffu);
                 const int all_ins = (int)(d2 >> 16), all_del_bases = (int)((d4 >> 16) & 0x7fffu), all_sub = (int)(d5 & 0xffffu);
                 const bool irregular_ends = (d5 >> 16) & 0xffu;
@@ -2608,7 +2620,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
                 atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
                 if (irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
-                if (w_left == v_w) atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);                       // (once per alignment, not per piece of a heavy weight)
+                if (!((counted >> lane) & 1u)) atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);           // (once per alignment, not per piece of a heavy weight)
                 if (discard && (deletion_n > 0 || insertion_n > 0)) atomicAdd(scal + C2_S_DISCARDED, w);                     // :3996-4000
                 else {
                     const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
@@ -2642,7 +2654,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
                 const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)d0, kk), r1 = (unsigned)__builtin_amdgcn_readlane((int)d1, kk);
                 const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)d2, kk), r4 = (unsigned)__builtin_amdgcn_readlane((int)d4, kk);
                 const unsigned r5 = (unsigned)__builtin_amdgcn_readlane((int)d5, kk);
-                const int w = __builtin_amdgcn_readlane(w_round, kk);
+                const int w = __builtin_amdgcn_readlane(v_w, kk);
                 const int T = (int)(r0 & 0xffffu);
                 const int insertion_n = (int)(r1 & 0xffffu), deletion_n = (int)(r1 >> 16), substitution_n = (int)(r2 & 0xffffu);
                 const int all_ins = (int)(r2 >> 16), all_del_bases = (int)((r4 >> 16) & 0x7fffu), all_sub = (int)(r5 & 0xffffu);
@@ -2819,8 +2831,9 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES) void c2_count_vectors_kernel(c2_
             }   // tasks of this round
             if (heavy) {
                 // a task whose weight was added only in part stays pending for another round
-                if (mine) w_left -= w_round;
-                pending |= (unsigned)__ballot(mine && w_left > 0);
+                counted |= (unsigned)__ballot(mine);
+                if (mine) v_w = *rest_slot;
+                pending |= (unsigned)__ballot(mine && v_w > 0);
                 flush();
             }
         }       // rounds of this chunk
