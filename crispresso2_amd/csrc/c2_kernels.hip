@@ -1025,8 +1025,8 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
 // reference to this kernel only if its DP values provably stay inside int16 around the bias (c2_pk_eligible): the reference's
 // finite sentinel min_score = gap_open * Li * Lj is replaced by -C2_PK_BIAS (the number 0), which changes no comparison a
 // traceback can see: sentinel-derived values keep their order among themselves (same offsets) and stay below every real value.
-// Pointer bits: the sign of four packed differences per cell, shifted into a 16-bit shift register per alignment
-// (v_pk_lshrrev_b16 + v_and_or_b32) -- 24 VALU instructions per anti-diagonal step for the two alignments, against 2 x 18.9.
+// Pointer bits: the signs of four packed differences per cell, gathered by two v_perm_b32 and pushed into four byte-wide shift
+// registers (c2_pk_push4) -- ~24.7 VALU instructions per cell for the two alignments together, against 2 x 17.2 in the 32-bit kernels.
 // ---------------------------------------------------------------------------------------------------------------
 #define C2_PK_BIAS 16384
 #define C2_PK_LUT_CODES 6                     // reference symbols with codes 0..4 (A C G T N), plus an all-zero table (index 5) for the padding rows
@@ -1052,14 +1052,25 @@ __host__ __device__ inline unsigned c2_pk_dup(const int x) { return ((unsigned)x
 struct c2_pk_state {
     unsigned ME, IE, JE, HE;         // latest cell of the even diagonal, two alignments packed
     unsigned MO, IO, JO, HO;         // latest cell of the odd diagonal
-    unsigned acc;                    // pointer bits of the word in the making: a 16-bit shift register per alignment, newest bit on top
-    unsigned gf;                     // AND of the finished words (gap-free predicate: bits 2, 3 of the E cells' nibbles all set)
+    unsigned acc;                    // pointer bits of the word in the making: four byte-wide shift registers (see c2_pk_push4), newest cell on top
+    unsigned gf;                     // AND of the finished words (gap-free predicate: "H is not I" and "M beats J" of the E cells all set)
 };
 
-// one pointer bit per alignment: the sign of `d` (bits 15 and 31) enters the two shift registers
-__device__ __forceinline__ void c2_pk_push(unsigned& acc, const unsigned d) { acc = c2_pk_lshr(acc, 1) | (d & 0x80008000u); }
-// a cell that is not computed: nibble 0011 in push order = "nothing opened, H is not I, M beats J" (neutral for the gap-free predicate)
-__device__ __forceinline__ void c2_pk_push_none(unsigned& acc) { acc = c2_pk_lshr(acc, 4) | 0xC000C000u; }
+// The four pointer bits of one cell, for both alignments, from the SIGNS of four packed differences (bits 15 and 31 of each).
+// Two v_perm_b32 gather the eight sign-carrying bytes, one shift + one bit-select interleave them, one shift + one bit-select
+// push them into `acc` -- 6 instructions per cell instead of 8 (a 16-bit shift + and-or per bit).  `acc` is four byte-wide
+// shift registers, two bits per cell, newest cell in bits 7..6, four cells per byte:
+//     byte 0: alignment A  { I opened (iFromM > iExt), NOT "H is I" (In < Hn) }      byte 1: A  { J opened, NOT "J beats M" (Jn < Mn) }
+//     byte 2: alignment B  { I opened, NOT "H is I" }                                 byte 3: B  { J opened, NOT "J beats M" }
+#define C2_PK_HI_BYTES 0x03070105u            // v_perm selector: [hi byte of x.lo16, hi byte of y.lo16, hi byte of x.hi16, hi byte of y.hi16] of (x, y)
+__device__ __forceinline__ void c2_pk_push4(unsigned& acc, const unsigned dI, const unsigned dJ, const unsigned dH, const unsigned dM) {
+    const unsigned p_open = __builtin_amdgcn_perm(dI, dJ, C2_PK_HI_BYTES);             // sign of dI / dJ in bit 7 of bytes 0,2 / 1,3
+    const unsigned p_state = __builtin_amdgcn_perm(dH, dM, C2_PK_HI_BYTES);            // sign of dH / dM likewise
+    const unsigned r = (p_open & 0x80808080u) | ((p_state >> 1) & 0x7f7f7f7fu);         // bits 7 and 6 of every byte are the cell's; the rest is noise
+    acc = (r & 0xC0C0C0C0u) | ((acc >> 2) & 0x3F3F3F3Fu);                                // (v_bfi_b32 through inline asm was measured: not faster than what hipcc makes of this)
+}
+// a cell that is not computed: "nothing opened, H is not I, M beats J" (neutral for the gap-free predicate)
+__device__ __forceinline__ void c2_pk_push_none(unsigned& acc) { acc = 0x40404040u | ((acc >> 2) & 0x3F3F3F3Fu); }
 
 // One pair of steps (E cell on anti-diagonal a = 2k, O cell on a + 1) for both alignments of the lane.  rowE / rowO: packed row
 // constants {a, b, c} (both halves equal: the two reads share the reference); sE / sO: the score pairs of the two cells.
@@ -1079,10 +1090,8 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
         const unsigned Jn = c2_pk_max(jFromM, jExt);
         const unsigned Mn = c2_pk_add(S.HE, sE);
         const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
-        c2_pk_push(S.acc, c2_pk_sub(iExt, iFromM));           // I opened   (iFromM > iExt)
-        c2_pk_push(S.acc, c2_pk_sub(jExt, jFromM));           // J opened   (jFromM > jExt)
-        c2_pk_push(S.acc, c2_pk_sub(In, Hn));                 // NOT H is I (In < Hn; In <= Hn always)
-        c2_pk_push(S.acc, c2_pk_sub(Jn, Mn));                 // NOT J beats M (Jn < Mn)
+        // I opened (iFromM > iExt), J opened (jFromM > jExt), NOT H is I (In < Hn; In <= Hn always), NOT J beats M (Jn < Mn)
+        c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
         S.ME = Mn; S.IE = In; S.JE = Jn; S.HE = Hn;
     } else {
         c2_pk_push_none(S.acc);
@@ -1099,10 +1108,7 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
         const unsigned Jn = c2_pk_max(jFromM, jExt);
         const unsigned Mn = c2_pk_add(S.HO, sO);
         const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
-        c2_pk_push(S.acc, c2_pk_sub(iExt, iFromM));
-        c2_pk_push(S.acc, c2_pk_sub(jExt, jFromM));
-        c2_pk_push(S.acc, c2_pk_sub(In, Hn));
-        c2_pk_push(S.acc, c2_pk_sub(Jn, Mn));
+        c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
         S.MO = Mn; S.IO = In; S.JO = Jn; S.HO = Hn;
     } else {
         c2_pk_push_none(S.acc);
@@ -1185,10 +1191,12 @@ struct c2_diagx_plane {
         const int a = pi + pj;
         const unsigned w = words[(a >> 3) * lpa + sl];
         if (!pk) { nib = (w >> (4 * (7 - (a & 7)))) & 0xF; return true; }
-        // packed kernels (c2_pk_push): anti-diagonal 8g + c in bits 4c .. 4c+3, oldest push lowest: I opened, J opened, NOT "H is I",
-        // NOT "J beats M"
-        const unsigned n = (w >> (4 * (a & 7))) & 0xF;
-        nib = ((n & 1u) << 3) | ((n & 2u) << 1) | ((~n >> 1) & 2u) | ((~n >> 3) & 1u);
+        // packed kernels (c2_pk_push4): the word's low half holds anti-diagonals 8g .. 8g+3, its high half 8g+4 .. 8g+7; in a half,
+        // byte 0 = { I opened, NOT "H is I" } and byte 1 = { J opened, NOT "J beats M" }, cell c in bits 2c+1 .. 2c of both
+        const int c = a & 7;
+        const unsigned h = w >> (16 * (c >> 2));
+        const unsigned ih = (h >> (2 * (c & 3))) & 3u, jm = (h >> (8 + 2 * (c & 3))) & 3u;
+        nib = ((ih >> 1) << 3) | ((jm >> 1) << 2) | (((ih & 1u) ^ 1u) << 1) | ((jm & 1u) ^ 1u);
         return true;
     }
 };
@@ -1455,11 +1463,11 @@ __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c
         if (q == 3) S.gf &= S.acc;                                  // ... 8g+4 .. 8g+7
         if (LASTCOL && k == L.kCap) {
             CAP.H = L.capOdd ? S.HO : S.HE;
-            // q even: the word in the making holds two cells so far, the E cell in bits 8..11 of each half
-            CAP.gf = (q & 1) ? S.gf : (S.gf & (S.acc | 0xF3FFF3FFu));
+            // q even: the word in the making holds two cells so far, the E cell in bits 5..4 of every byte ("H is not I" / "M beats J" = bit 4)
+            CAP.gf = (q & 1) ? S.gf : (S.gf & (S.acc | 0xEFEFEFEFu));
         }
     }
-    // alignment A's word: the low halves, alignment B's: the high halves (anti-diagonal 8g + c in bits 4c .. 4c+3)
+    // alignment A's word: bytes 0, 1 of the two accumulators, alignment B's: bytes 2, 3 (layout: c2_diagx_plane::fetch)
     wordsA[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x05040100u);
     wordsB[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x07060302u);
 }
@@ -1863,7 +1871,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             if (PK) {
                 const int half = 16 * (s & 1);
                 Hend = (int)(int16_t)(((unsigned)__builtin_amdgcn_readlane((int)CAP.H, lane_end) >> half) & 0xffffu) - C2_PK_BIAS;
-                gapfree = (((unsigned)__builtin_amdgcn_readlane((int)CAP.gf, lane_end) >> half) & 0x0C0Cu) == 0x0C0Cu;
+                gapfree = (((unsigned)__builtin_amdgcn_readlane((int)CAP.gf, lane_end) >> half) & 0x1111u) == 0x1111u;   // the E cells (cells 0 and 2 of a word): bits 0 and 4 of both bytes
             } else {
                 Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
                 gapfree = __builtin_amdgcn_readlane((int)GF.cap, lane_end) == 0;
