@@ -1031,6 +1031,7 @@ __device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, cons
 #define C2_PK_BIAS 16384
 #define C2_PK_LUT_CODES 6                     // reference symbols with codes 0..4 (A C G T N), plus an all-zero table (index 5) for the padding rows
 #define C2_PK_PAD_TABLE 5
+#define C2_PK_LUT_LDS_OFFSET 1024u            // = character codes (256) + per-slot table (8 x 24 ints) in c2_make_diagx_plan
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef short c2_s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short c2_u16x2 __attribute__((ext_vector_type(2)));
@@ -1143,6 +1144,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     uint32_t off = 0;
     p.codeof = off;   off += 256u;                                  // character -> code
     p.table = off;    off += 8u * 24u * 4u;                         // up to 8 slots x C2X_INTS
+    if (pk) off += (uint32_t)C2_PK_LUT_CODES * 256u;                // pair-score tables at the FIXED offset C2_PK_LUT_LDS_OFFSET: it folds into the look-ups' immediate offset
     p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
     p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
     p.stage = off;    off += p.n_words * lpa * 4u;                  // pointer words of the alignment being traced
@@ -1158,7 +1160,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
         if (need > have) { off += need - have; }                    // (tmp_read, tmp_ref, stage are consecutive: the tables may run into `stage`, which is rewritten before use too)
         p.stage = p.tmp_ref + c2_align16((uint32_t)max_li + (uint32_t)max_lj) + (need > have ? need - have : 0u);
         off = p.stage + p.n_words * lpa * 4u;
-        p.pairlut = off;  off += (uint32_t)C2_PK_LUT_CODES * 256u;  // per reference symbol: the score pair of every (symbol of read A, symbol of read B)
+        p.pairlut = C2_PK_LUT_LDS_OFFSET;                           // per reference symbol: the score pair of every (symbol of read A, symbol of read B)
         p.group0 = off;
         p.gref = 0; p.gincp = c2_align16((uint32_t)max_li);
         p.group_bytes = p.gincp + c2_align16(((uint32_t)max_li + 2u) * 2u);
@@ -1451,8 +1453,8 @@ __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c
     unsigned sc[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        sc[2 * q] = *(const unsigned*)(lds + lutBase + R[q].prof + (unsigned)C[q]);
-        sc[2 * q + 1] = *(const unsigned*)(lds + lutBase + R[q + 1].prof + (unsigned)C[q]);
+        sc[2 * q] = *(const unsigned*)(lds + C2_PK_LUT_LDS_OFFSET + R[q].prof + (unsigned)C[q]);
+        sc[2 * q + 1] = *(const unsigned*)(lds + C2_PK_LUT_LDS_OFFSET + R[q + 1].prof + (unsigned)C[q]);
     }
     unsigned w0 = 0;
 #pragma unroll
