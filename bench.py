@@ -2,9 +2,13 @@
 """bench.py -- aligned+classified reads/sec of the align + classify hot path on MI355X.
 
 A "step" is one pass of the hot path over one batch of synthetic reads that is already resident in HBM: the launch chain
-of the align kernels (c2_align_diagx_kernel<4> -> <2> -> c2_align_diag_kernel -> c2_align_classify_kernel: NW fill with
-optimality certificate, traceback, fused classification), for several candidate amplicons the strand / best-amplicon choice
+of the align kernels (c2_align_diagp_kernel<8> -> c2_align_diagp_kernel<4> -> c2_align_diag_kernel -> c2_align_classify_kernel,
+each packed kernel followed by the 32-bit kernel of its band over the tasks it could not pair: NW fill with optimality
+certificate, traceback, fused classification), for several candidate amplicons the strand / best-amplicon choice
 (c2_select_best_kernel), the per-amplicon count tensor (c2_count_vectors_kernel) and its all-reduce over the ranks.
+After the timed region: the checks (`checks` in the JSON line) -- an oracle sample, size-independent properties of every
+alignment, the whole batch once more through the full-plane kernel alone compared byte for byte with what the chain wrote,
+and every alignment of the cpu_baseline legs (the reference's own compiled code) against the device's.
 
   --config 3 (default)  BASELINE.json configs[2]: 10 M synthetic 250 bp reads vs one 250 bp amplicon -- the configuration
                         the metric is quoted on
