@@ -1311,7 +1311,7 @@ int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const u
             (uint32_t)lq1[t] > qstride || (uint32_t)lq2[t] > qstride) { ctx->err = "length exceeds stride"; return C2_E_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const uint64_t CH = 65536;
+    const uint64_t CH = 65536;                                    // (measured: 262144 pairs per launch is SLOWER, 25.7 vs 19 ns per pair -- every lane streams its own rows, more lanes in flight thrash L2)
     int rc;
     for (uint64_t c0 = 0; c0 < n; c0 += CH) {
         const uint64_t m = std::min<uint64_t>(CH, n - c0);

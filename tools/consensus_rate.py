@@ -23,7 +23,7 @@ def main():
     from crispresso2_amd.batch import BatchAligner
     L, n = 250, a.pairs
     amp, g, inc = synth.amplicon_setup(L)
-    r1 = synth.make_reads(L, n, workers=8)
+    r1 = synth.make_reads(L, n, workers=1)            # (no fork: forked children hang in rocprofv3's exit handler)
     rng = np.random.default_rng(7)
     r2 = r1.copy()                                             # read 2: the same fragment with its own sequencing errors
     err = rng.random(r2.shape) < 0.004
