@@ -469,7 +469,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            # the arithmetic type of the dominant kernel's DP cells: int16 pairs in the packed kernels (proven range, c2_pk_eligible), int32 otherwise
+            "dtype": "int16" if dominant.startswith("c2_align_diagp") else "int32",
             "data": "synthetic",
             "config": {"workload": wl["text"] + ", EDNAFULL, gap_open -20, gap_extend -2, gap_incentive 1 at the cut",
                        "baseline_config": args.config,
