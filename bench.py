@@ -471,6 +471,9 @@ def main():
             "vs_baseline": None,
             # the arithmetic type of the dominant kernel's DP cells: int16 pairs in the packed kernels (proven range, c2_pk_eligible), int32 otherwise
             "dtype": "int16" if dominant.startswith("c2_align_diagp") else "int32",
+            "dtype_note": "exact integer DP, not a precision trade: the packed kernels hold two alignments per 32-bit lane as int16 pairs only for "
+                          "references whose DP values the host proves to fit (c2_pk_eligible); everything else runs the int32 kernels; the "
+                          "results are bit-identical either way (checks.chain_equals_full_plane_n covers every alignment of the batch)",
             "data": "synthetic",
             "config": {"workload": wl["text"] + ", EDNAFULL, gap_open -20, gap_extend -2, gap_incentive 1 at the cut",
                        "baseline_config": args.config,
