@@ -2451,6 +2451,9 @@ __global__ __launch_bounds__(256) void c2_ref_scatter_kernel(const c2_aln_record
     if (active) order[slot] = (uint32_t)t;
 }
 
+// (launch bounds: 5 workgroups per CU = 5 waves per SIMD = 96 VGPRs.  Left alone the compiler takes 101 -- 99 + 2 that hold 103 spilled
+// SGPRs -- and the kernel runs at 4 waves per SIMD, 8 % slower; with the bound it is 8 % slower than a 96-VGPR build WITHOUT the bound
+// would be (measured with round 1's source, which fits by itself: the occupancy target changes the schedule), but that is not on offer.)
 __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(c2_count_args A)
 {
     // C2_CNT_WAVES wavefronts share one LDS block (the block is what limits residency, so sharing it multiplies the
@@ -2552,11 +2555,11 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
         // saturating sums decide the flushes before anything is added.
         // (heavy chunks: v_w is what of the task's weight is still to be added; `counted`: lanes whose alignment has been counted once)
         unsigned counted = 0;
-        {   // (a task above 2^26 makes the chunk heavy by itself; the others add up in 32 bits: 32 x 2^26 = 2^31)
-            const unsigned my_T = d0 & 0xffffu;
-            const unsigned long long ld = sel ? (unsigned long long)(unsigned)v_w * (unsigned long long)(my_T > 0 ? my_T : 1u) : 0ull;
-            const bool big = ld > (1ull << 26);
-            unsigned wv = big ? 0u : (unsigned)ld;
+        {   // (a task above ~2^26 makes the chunk heavy by itself; the others add up in 32 bits: 32 x 2^26 = 2^31.  The size test is
+            // done in float -- 6.0e7 is safely below 2^26 for its rounding -- so that no 64-bit product has to be formed)
+            const unsigned my_T = (d0 & 0xffffu) ? (d0 & 0xffffu) : 1u;
+            const bool big = sel && (float)v_w * (float)my_T > 6.0e7f;
+            unsigned wv = (sel && !big) ? (unsigned)v_w * my_T : 0u;
 #pragma unroll
             for (int d = 1; d < K; d <<= 1) wv += (unsigned)__shfl_xor((int)wv, d);
             if (__ballot(big) != 0ull || wv > C2_CNT_LOAD_BUDGET) wv = C2_CNT_LOAD_BUDGET + 1u;
@@ -2601,12 +2604,11 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
             // the weight this round adds for the lane's task: all of it, or (heavy) a piece whose load fits the budget
             // heavy chunks: v_w becomes the piece of the weight this round adds, the remainder waits in LDS (no register of the
             // common path is spent on it: the kernel sits at 96 VGPRs = 5 waves per SIMD)
-            int* rest_slot = ctl + C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1));
             if (heavy && mine) {
                 const unsigned my_T = d0 & 0xffffu;
                 const int piece = (int)(C2_CNT_LOAD_BUDGET / (my_T > 0 ? my_T : 1u));
                 const int rest = v_w > piece ? v_w - piece : 0;
-                *rest_slot = rest;
+                ctl[C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1))] = rest;
                 v_w -= rest;
             }
             {   // an alignment whose two strings are the reference itself (no gap column, every column a match) adds nothing but
@@ -2842,7 +2844,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
             if (heavy) {
                 // a task whose weight was added only in part stays pending for another round
                 counted |= (unsigned)__ballot(mine);
-                if (mine) v_w = *rest_slot;
+                if (mine) v_w = ctl[C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1))];
                 pending |= (unsigned)__ballot(mine && v_w > 0);
                 flush();
             }
