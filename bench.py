@@ -163,7 +163,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("C2_BENCH_BACKEND", "nccl")           # ("gloo": the CPU test of the multi-rank plumbing, tests/test_bench_on_emulator.py)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from crispresso2_amd import CRISPResso2Align as A, _native
     from crispresso2_amd import counts as C

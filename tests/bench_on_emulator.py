@@ -6,6 +6,7 @@ their digests with the "device" output, the chain-vs-full-plane check, the JSON 
 import contextlib
 import ctypes
 import io
+import os
 import json
 import sys
 
@@ -105,5 +106,8 @@ def run_bench(argv):
          batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout,
          torch.cuda.Stream, torch.cuda.stream, torch.cuda.empty_cache) = saved
     lines = [x for x in buf.getvalue().splitlines() if x.startswith("{")]
+    if int(os.environ.get("RANK", "0")) != 0:                        # only rank 0 prints
+        assert not lines, buf.getvalue()
+        return None
     assert len(lines) == 1, buf.getvalue()
     return json.loads(lines[0])

@@ -22,3 +22,39 @@ def test_bench_line_on_the_emulator(config, reads, steps, extra):
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["one_proc_reads_per_s"] > 0 and len(cb["curve"]) >= 2
     assert sum(c["reads_aligned_all_gpus"] for c in out["counts"]) > 0
+
+
+def test_bench_two_ranks_over_gloo_on_the_emulator(tmp_path):
+    """bench.py's N > 1 plumbing without GPUs: two processes (RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them),
+    gloo in place of RCCL, the device calls on the emulator.  Every rank aligns its own shard of the read stream, the count tensor
+    is all-reduced inside the step, the time is the maximum over the ranks, and rank 0 alone prints the line -- whose value is the
+    whole job's and whose counts are the sum over both shards."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, json; sys.path.insert(0, %r); import bench_on_emulator as BE; "
+            "out = BE.run_bench(['--gpus', '2', '--config', '3', '--reads', '160', '--steps', '2', '--warmup', '1', '--workers', '1', "
+            "'--no-cpu-baseline', '--check', '20']); print('RESULT ' + json.dumps(out))" % here)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   C2_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-3000:]
+    res = [json.loads([x for x in so.splitlines() if x.startswith("RESULT ")][-1][7:]) for so, _ in outs]
+    assert res[1] is None
+    out = res[0]
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["reads_per_gpu_per_step"] == 160
+    assert out["value"] == pytest.approx(2 * 160 * 2 / (out["ms_per_step"] * 2 / 1e3), rel=1e-6)      # whole job: both ranks' reads
+    single = BE.run_bench(["--config", "3", "--reads", "160", "--steps", "1", "--warmup", "0", "--workers", "1", "--no-cpu-baseline", "--check", "0"])
+    # rank 0's shard alone aligns fewer reads than the all-reduced tensor holds (the second shard is a different block of the stream)
+    assert out["counts"][0]["reads_aligned_all_gpus"] > single["counts"][0]["reads_aligned_all_gpus"] >= 100
+    assert out["counts"][0]["reads_aligned_all_gpus"] <= 320
