@@ -1405,4 +1405,16 @@ int c2_selftest(c2_ctx* ctx, int32_t* out448) {
     return 0;
 }
 
+int c2_selftest_rows(c2_ctx* ctx, int32_t* out128) {
+    if (!ctx || !out128) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_misc, 128 * 4))) return rc;
+    hipLaunchKernelGGL(c2_selftest_rows_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)ctx->d_misc.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out128, ctx->d_misc.p, 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 }  // extern "C"

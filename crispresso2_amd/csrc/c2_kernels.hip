@@ -904,6 +904,13 @@ __device__ __forceinline__ int c2_shl1(int old, int src) {
 #endif
 __device__ __forceinline__ int c2_shr1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_WAVE_SHR1, 0xf, 0xf, true); }
 __device__ __forceinline__ int c2_shl1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_WAVE_SHL1, 0xf, 0xf, true); }
+// The same hand-off inside a ROW of 16 lanes (row_shr:1 / row_shl:1): the first / last lane of a row has no source and reads 0.
+// A lane group of 16 lanes (eight alignments per wavefront, packed) is exactly a row, so its two ends see "outside the band"
+// without a lane being switched off: all 16 lanes hold diagonals (32 per band instead of 30).
+#define C2_DPP_ROW_SHR1 0x111
+#define C2_DPP_ROW_SHL1 0x101
+__device__ __forceinline__ int c2_rshr1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_ROW_SHR1, 0xf, 0xf, true); }
+__device__ __forceinline__ int c2_rshl1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_ROW_SHL1, 0xf, 0xf, true); }
 
 struct c2_diag_plan { uint32_t plane, codes, codeof, read, code, ref, incp, tmp_read, tmp_ref, total; uint32_t n_words; };
 
@@ -1075,12 +1082,13 @@ __device__ __forceinline__ void c2_pk_push_none(unsigned& acc) { acc = 0x4040404
 
 // One pair of steps (E cell on anti-diagonal a = 2k, O cell on a + 1) for both alignments of the lane.  rowE / rowO: packed row
 // constants {a, b, c} (both halves equal: the two reads share the reference); sE / sO: the score pairs of the two cells.
-template <bool MASK, bool LASTCOL>
+// ROW: the lane group is a DPP row of 16 lanes (row_shr / row_shl hand-off, no lane switched off).
+template <bool MASK, bool LASTCOL, bool ROW>
 __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2_diag_row rowE, const c2_diag_row rowO, const unsigned sE, const unsigned sO,
                                            const unsigned ge2, const int startE, const int startO, const bool lastcol)
 {
-    const unsigned upM = (unsigned)c2_shr1z((int)S.MO);
-    const unsigned upJ = (unsigned)c2_shr1z((int)S.JO);
+    const unsigned upM = (unsigned)(ROW ? c2_rshr1z((int)S.MO) : c2_shr1z((int)S.MO));
+    const unsigned upJ = (unsigned)(ROW ? c2_rshr1z((int)S.JO) : c2_shr1z((int)S.JO));
     if (!MASK || a >= startE) {
         const unsigned corr = (LASTCOL && lastcol) ? c2_pk_sub((unsigned)rowE.b, (unsigned)rowE.a) : 0u;
         const unsigned iFromM = c2_pk_add(c2_pk_add(S.MO, (unsigned)rowE.a), corr);
@@ -1097,8 +1105,8 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
     } else {
         c2_pk_push_none(S.acc);
     }
-    const unsigned lfM = (unsigned)c2_shl1z((int)S.ME);
-    const unsigned lfI = (unsigned)c2_shl1z((int)S.IE);
+    const unsigned lfM = (unsigned)(ROW ? c2_rshl1z((int)S.ME) : c2_shl1z((int)S.ME));
+    const unsigned lfI = (unsigned)(ROW ? c2_rshl1z((int)S.IE) : c2_shl1z((int)S.IE));
     if (!MASK || a + 1 >= startO) {
         const unsigned corr = (LASTCOL && lastcol) ? c2_pk_sub((unsigned)rowO.b, (unsigned)rowO.a) : 0u;
         const unsigned iFromM = c2_pk_add(c2_pk_add(lfM, (unsigned)rowO.a), corr);
@@ -1186,10 +1194,10 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
 
 // pointer words of ONE alignment, staged in LDS: [group of 8 anti-diagonals][lane of the alignment's lane group]
 struct c2_diagx_plane {
-    const unsigned* words; int d0, lpa; bool pk;
+    const unsigned* words; int d0, lpa, nl; bool pk;               // nl: lanes of a group that hold diagonals (lpa - 1, or lpa for a row-DPP group)
     __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
         const int sl = (pi - pj - d0) >> 1;                              // lane of the cell's diagonal inside its group
-        if ((unsigned)sl >= (unsigned)(lpa - 1)) return false;
+        if ((unsigned)sl >= (unsigned)nl) return false;
         const int a = pi + pj;
         const unsigned w = words[(a >> 3) * lpa + sl];
         if (!pk) { nib = (w >> (4 * (7 - (a & 7)))) & 0xF; return true; }
@@ -1442,7 +1450,7 @@ __device__ __forceinline__ int c2_tab_load(const int* T, const int lane) { retur
 // look-ups (row table offset + pair symbol), requested at the top of the group.
 struct c2_pk_cap { unsigned H, gf; };                              // the two alignments' H(Li, Lj) and gap-free words, captured at the cell (Li, Lj)
 
-template <bool MASK, bool LASTCOL>
+template <bool MASK, bool LASTCOL, bool ROW>
 __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
                                             const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
                                             const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
@@ -1460,7 +1468,7 @@ __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int k = 4 * g + q;
-        c2_pk_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], sc[2 * q], sc[2 * q + 1], ge2, L.startE, L.startO, LASTCOL && (k == L.kLast));
+        c2_pk_pair<MASK, LASTCOL, ROW>(S, 2 * k, R[q], R[q + 1], sc[2 * q], sc[2 * q + 1], ge2, L.startE, L.startO, LASTCOL && (k == L.kLast));
         if (q == 1) { w0 = S.acc; S.gf &= w0; }                    // anti-diagonals 8g .. 8g+3 of both alignments
         if (q == 3) S.gf &= S.acc;                                  // ... 8g+4 .. 8g+7
         if (LASTCOL && k == L.kCap) {
@@ -1474,18 +1482,18 @@ __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c
     wordsB[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x07060302u);
 }
 
-template <bool MASK, bool LASTCOL>
+template <bool MASK, bool LASTCOL, bool ROW>
 __device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
                                              c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
                                              const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
                                              unsigned* wordsA, unsigned* wordsB, const int wordStride)
 {
     for (; g + 1 <= g_stop; g += 2) {
-        c2_pk_group<MASK, LASTCOL>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
-        c2_pk_group<MASK, LASTCOL>(S, g + 1, L, ge2, CAP, RB, CB, RA, CA, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW>(S, g + 1, L, ge2, CAP, RB, CB, RA, CA, rows, lds, lutBase, wordsA, wordsB, wordStride);
     }
     if (g <= g_stop) {
-        c2_pk_group<MASK, LASTCOL>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
         ++g;
 #pragma unroll
         for (int q = 0; q < 5; ++q) RA[q] = RB[q];
@@ -1499,7 +1507,11 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
 {
     // PK (c2_align_diagp_kernel): NA alignments in NA / 2 lane groups, two per group (slots 2g and 2g+1 in the two halves of the lanes' registers)
     constexpr int NG = PK ? NA / 2 : NA;                             // lane groups
-    constexpr int LPA = 64 / NG, NL = LPA - 1, BANDW = 2 * NL;       // lanes per group, live lanes, diagonals per band
+    // lanes per group, live lanes, diagonals per band.  A packed group of 16 lanes is a DPP row: its hand-off is row_shr / row_shl,
+    // which already reads 0 at the row's ends, so no lane is switched off and all 16 hold diagonals (c2_rshr1z)
+    constexpr int LPA = 64 / NG;
+    constexpr bool ROWDPP = PK && LPA == 16;
+    constexpr int NL = ROWDPP ? LPA : LPA - 1, BANDW = 2 * NL;
     const int lane = threadIdx.x, grp = lane / LPA, sl = lane - grp * LPA;
     const int slot = PK ? 2 * grp : grp;                             // (PK: the group's first slot)
     const c2_diagx_plan P = c2_make_diagx_plan(NA, A.max_li, A.max_lj, PK);
@@ -1787,12 +1799,12 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             unsigned ge2 = c2_pk_dup(ge);
             const unsigned lutBase = P.pairlut;
             if (gC <= gA_stop) {
-                c2_pk_groups<true, true>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<true, true, ROWDPP>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             } else {
-                c2_pk_groups<true, false>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
-                c2_pk_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<true, false, ROWDPP>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<false, false, ROWDPP>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             }
-            c2_pk_groups<false, true>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+            c2_pk_groups<false, true, ROWDPP>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             C2_LANES_ACTIVE_END()
         }
         if (!PK && any_ok) {
@@ -1926,7 +1938,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                 const unsigned later = m_trace & ~((2u << s) - 1u);     // traced slots after this one
                 if (later) request_words(__builtin_ctz(later));
                 c2_diagx_plane plane;
-                plane.words = sStage; plane.d0 = d0; plane.lpa = LPA; plane.pk = PK;
+                plane.words = sStage; plane.d0 = d0; plane.lpa = LPA; plane.nl = NL; plane.pk = PK;
                 int cnt, matches;
                 bool nf2;
                 c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
@@ -2266,6 +2278,18 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
     C2_LANES_ACTIVE_END()
     out[320 + lane] = rz;
     out[384 + lane] = lz;
+}
+
+// ... and of the row forms (c2_rshr1z / c2_rshl1z: the hand-off of the 16-lane groups of c2_align_diagp_kernel<8>), folded into an
+// add like the kernels use them: out[lane] = value of lane - 1 (0 at the start of a row of 16) + 1000, out[64 + lane] = value of
+// lane + 1 (0 at the end of a row) + 1000.
+__global__ __launch_bounds__(64) void c2_selftest_rows_kernel(int* out)
+{
+    const int lane = threadIdx.x;
+    int k1000 = 1000;
+    C2_KEEP_IN_VGPR(k1000);
+    out[lane] = c2_rshr1z(lane * 3 + 1) + k1000;
+    out[64 + lane] = c2_rshl1z(lane * 3 + 1) + k1000;
 }
 
 // =====================================================================================

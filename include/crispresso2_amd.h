@@ -345,6 +345,10 @@ int c2_merge_counts_with_partners(uint64_t n, const uint8_t* aligned, const int6
  * lane switched off in EXEC, readlane, ballot) the DP depends on; writes 448 int32 (see c2_selftest_kernel).  Used by the
  * GPU test-suite. */
 int c2_selftest(c2_ctx* ctx, int32_t* out448);
+/* ... and of the row forms (DPP row_shr:1 / row_shl:1 with bound_ctrl: the hand-off inside the 16-lane groups of the packed
+ * kernel): out[lane] = 1000 + value of lane - 1 (0 at the start of a row of 16 lanes), out[64 + lane] = 1000 + value of lane + 1
+ * (0 at the end of a row), values 3 * lane + 1. */
+int c2_selftest_rows(c2_ctx* ctx, int32_t* out128);
 
 #ifdef __cplusplus
 }

@@ -136,11 +136,14 @@ inline uint64_t xl_get(uint64_t mine, int src_lane, bool* valid) {     // src_la
 inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     (void)row_mask; (void)bank_mask;
     int from;
+    bool in_row = true;
     if (dpp_ctrl == 0x138) from = emu::lane_id() - 1;        // wave_shr:1
     else if (dpp_ctrl == 0x130) from = emu::lane_id() + 1;   // wave_shl:1
+    else if (dpp_ctrl == 0x111) { from = emu::lane_id() - 1; in_row = (emu::lane_id() & 15) != 0; }    // row_shr:1 (rows of 16 lanes)
+    else if (dpp_ctrl == 0x101) { from = emu::lane_id() + 1; in_row = (emu::lane_id() & 15) != 15; }   // row_shl:1
     else { fprintf(stderr, "emu: unsupported dpp_ctrl %x\n", dpp_ctrl); abort(); }
-    bool ok; uint64_t v = emu::xl_get((uint32_t)src, from, &ok);
-    if (!ok) return bound_ctrl ? 0 : old;
+    bool ok; uint64_t v = emu::xl_get((uint32_t)src, in_row ? from : -1, &ok);
+    if (!ok || !in_row) return bound_ctrl ? 0 : old;
     return (int)(uint32_t)v;
 }
 inline long long clock64() { return 0; }

@@ -63,6 +63,12 @@ def test_cross_lane_primitives(ctx):
     out = np.zeros(448, dtype=np.int32)
     ctx.check(ctx.lib.c2_selftest(ctx.handle, out.ctypes.data_as(ctypes.c_void_p)), "c2_selftest")
     check_selftest(out)
+    # row forms (hand-off inside the 16-lane groups of c2_align_diagp_kernel<8>): a row's first / last lane reads 0
+    rows = np.zeros(128, dtype=np.int32)
+    ctx.check(ctx.lib.c2_selftest_rows(ctx.handle, rows.ctypes.data_as(ctypes.c_void_p)), "c2_selftest_rows")
+    lane = np.arange(64)
+    assert (rows[:64] == np.where(lane % 16 == 0, 1000, 3 * (lane - 1) + 1 + 1000)).all(), rows[:64]
+    assert (rows[64:] == np.where(lane % 16 == 15, 1000, 3 * (lane + 1) + 1 + 1000)).all(), rows[64:]
 
 
 def run_batch_vectors(vecs, mats, ctx):
