@@ -2,7 +2,7 @@
 """bench.py -- aligned+classified reads/sec of the align + classify hot path on MI355X.
 
 A "step" is one pass of the hot path over one batch of synthetic reads that is already resident in HBM: the launch chain
-of the align kernels (c2_align_diagp_kernel<8> -> c2_align_diagp_kernel<4> -> c2_align_diag_kernel -> c2_align_classify_kernel,
+of the align kernels (c2_align_diagp_kernel<8> -> c2_align_diagp_kernel<4> -> c2_align_diagp_kernel<2> -> c2_align_classify_kernel,
 each packed kernel followed by the 32-bit kernel of its band over the tasks it could not pair: NW fill with optimality
 certificate, traceback, fused classification), for several candidate amplicons the strand / best-amplicon choice
 (c2_select_best_kernel), the per-amplicon count tensor (c2_count_vectors_kernel) and its all-reduce over the ranks.
@@ -408,7 +408,8 @@ def main():
 
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
-    chain_names = {"auto": ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<2>" if os.environ.get("C2_NO_PACKED_TIER2") else "c2_align_diagp_kernel<4>", "c2_align_diag_kernel"],
+    chain_names = {"auto": ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<2>" if os.environ.get("C2_NO_PACKED_TIER2") else "c2_align_diagp_kernel<4>",
+                            "c2_align_diag_kernel" if (os.environ.get("C2_NO_PACKED_TIER2") or os.environ.get("C2_NO_PACKED_TIER3")) else "c2_align_diagp_kernel<2>"],
                    "diag4": ["c2_align_diagx_kernel<4>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
                    "diag2": ["c2_align_diagx_kernel<2>", "c2_align_diag_kernel"], "diag1": ["c2_align_diag_kernel"]}
     if os.environ.get("C2_NO_PACKED_FILL"):

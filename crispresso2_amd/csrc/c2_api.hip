@@ -61,7 +61,7 @@ struct c2_ctx {
     std::vector<uint8_t> ref_pk_ok;     // per reference: admitted to the packed fill (c2_pk_eligible)
     bool any_pk_ok = false;
     bool pk_dirty = true;
-    int occ_pk_lds = -1, occ_pk_blocks = 0, occ_pk2_lds = -1, occ_pk2_blocks = 0;
+    int occ_pk_lds = -1, occ_pk_blocks = 0, occ_pk2_lds = -1, occ_pk2_blocks = 0, occ_pk3_lds = -1, occ_pk3_blocks = 0;
     // staging for the host batch path and the per-call path
     DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;
     // timing
@@ -133,6 +133,7 @@ struct Geometry {
     bool x[2]; uint32_t lds_x[2]; int blocks_x[2]; uint32_t plane_words;   // multi-alignment tiers in front of it: 4, 2 per wavefront
     bool pk; uint32_t lds_pk; int blocks_pk; uint32_t plane_words_pk;      // packed first tier (8 per wavefront, int16) in place of the 4-per-wavefront one
     bool pk2; uint32_t lds_pk2; int blocks_pk2; uint32_t plane_words_pk2;  // packed second tier (4 per wavefront, 62 diagonals) in place of the 2-per-wavefront one
+    bool pk3; uint32_t lds_pk3; int blocks_pk3; uint32_t plane_words_pk3;  // packed third tier (2 per wavefront, 128 diagonals) in front of c2_align_diag_kernel
 };
 
 template <int R, int BAND>          // (the kernel's MODE: 0 full plane in LDS, 1 banded, 2 full plane in HBM)
@@ -168,7 +169,7 @@ void update_pk_eligibility(c2_ctx* ctx) {
     ctx->any_pk_ok = false;
     if (ctx->have_scoring && !getenv("C2_NO_PACKED_FILL"))
         for (int r = 0; r < ctx->n_refs; ++r) {
-            ctx->ref_pk_ok[r] = c2_pk_eligible(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, 62) ? 1 : 0;
+            ctx->ref_pk_ok[r] = c2_pk_eligible(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, 126) ? 1 : 0;   // (the widest band a packed kernel sweeps)
             if (ctx->ref_pk_ok[r]) ctx->any_pk_ok = true;
         }
     ctx->pk_dirty = false;
@@ -201,6 +202,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
     g.plane_words = 0;
     g.pk = false; g.lds_pk = 0; g.blocks_pk = 0; g.plane_words_pk = 0;
     g.pk2 = false; g.lds_pk2 = 0; g.blocks_pk2 = 0; g.plane_words_pk2 = 0;
+    g.pk3 = false; g.lds_pk3 = 0; g.blocks_pk3 = 0; g.plane_words_pk3 = 0;
     const int km = ctx->kernel_mode;
     update_pk_eligibility(ctx);
     if ((km == 0 || km == 3 || km == 4 || km == 5) && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
@@ -239,6 +241,17 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
                     ctx->occ_pk2_blocks = nb < 1 ? 1 : nb; ctx->occ_pk2_lds = (int)P2.total;
                 }
                 g.pk2 = true; g.lds_pk2 = P2.total; g.blocks_pk2 = ctx->occ_pk2_blocks; g.plane_words_pk2 = P2.n_words * 128u;   // 4 slots x 32 lanes
+            }
+            // third tier: two per wavefront, one lane group of 64 lanes (126 diagonals) in int16
+            const c2_diagx_plan P3 = c2_make_diagx_plan(2, ctx->max_li, g.max_lj, true);
+            if (g.pk2 && P3.total <= lds_cu && !getenv("C2_NO_PACKED_TIER3")) {
+                if (ctx->occ_pk3_lds != (int)P3.total) {
+                    int nb = 0;
+                    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_diagp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_diagp_kernel<2>, 64, P3.total));
+                    ctx->occ_pk3_blocks = nb < 1 ? 1 : nb; ctx->occ_pk3_lds = (int)P3.total;
+                }
+                g.pk3 = true; g.lds_pk3 = P3.total; g.blocks_pk3 = ctx->occ_pk3_blocks; g.plane_words_pk3 = P3.n_words * 128u;   // 2 slots x 64 lanes
             }
         }
         for (int t = 0; t < 2 && g.diag && km != 3; ++t) {
@@ -353,6 +366,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
                 for (int t = 0; t < 2; ++t) if (g.x[t]) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_x[t] * g.plane_words);
                 if (g.pk) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk * g.plane_words_pk);
                 if (g.pk2) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk2 * g.plane_words_pk2);
+                if (g.pk3) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk3 * g.plane_words_pk3);
                 if (g.full_hbm) most = std::max<uint64_t>(most, hbm_plane_wgs(ctx, g, A.n_tasks) * g.full_plane_words);
                 if (most && (rc = ensure(ctx, ctx->d_plane, (size_t)most * sizeof(uint32_t)))) return rc;
             }
@@ -387,10 +401,20 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
                 }
                 ++tier;
             }
+            if (g.pk3) {                                               // third band tier, packed: two alignments per wavefront
+                const uint64_t resident3 = cus * (uint64_t)g.blocks_pk3;
+                const unsigned grid3 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + 1) / 2, resident3));
+                c2_align_args T3 = A;
+                chain(T3, false, true);
+                T3.plane = (uint32_t*)ctx->d_plane.p; T3.plane_words_per_wg = g.plane_words_pk3;
+                hipLaunchKernelGGL(c2_align_diagp_kernel<2>, dim3(grid3), dim3(64), g.lds_pk3, s, T3);
+                HIPCHK(ctx, hipGetLastError());
+                mark_first();
+            }
             const uint64_t resident = cus * (uint64_t)g.blocks_diag;
             const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(A.n_tasks, resident));
             c2_align_args T = A;
-            chain(T, false, false);
+            chain(T, g.pk3, false);                                     // (after a packed kernel: the tasks it could not pair)
             hipLaunchKernelGGL(c2_align_diag_kernel, dim3(grid), dim3(64), g.lds_diag, s, T);
             HIPCHK(ctx, hipGetLastError());
             mark_first();

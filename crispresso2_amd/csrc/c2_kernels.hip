@@ -1511,7 +1511,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
     // which already reads 0 at the row's ends, so no lane is switched off and all 16 hold diagonals (c2_rshr1z)
     constexpr int LPA = 64 / NG;
     constexpr bool ROWDPP = PK && LPA == 16;
-    constexpr int NL = ROWDPP ? LPA : LPA - 1, BANDW = 2 * NL;
+    constexpr int NL = (ROWDPP || NG == 1) ? LPA : LPA - 1, BANDW = 2 * NL;   // (one group = the whole wavefront: its ends read 0 anyway)
     const int lane = threadIdx.x, grp = lane / LPA, sl = lane - grp * LPA;
     const int slot = PK ? 2 * grp : grp;                             // (PK: the group's first slot)
     const c2_diagx_plan P = c2_make_diagx_plan(NA, A.max_li, A.max_lj, PK);
@@ -1897,7 +1897,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             if (Li == Lj && gapfree) m_gapfree |= 1u << s;
             else m_trace |= 1u << s;
         }
-        constexpr int STG = 16 / NG;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
+        constexpr int STG = 16 / NG > 8 ? 8 : 16 / NG;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
         uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
         q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = uint4{0u, 0u, 0u, 0u};
 #define C2_STG_LOAD(n) if (STG > n) { const int k = 64 * n + lane; q##n = src[k < n16 ? k : 0]; }

@@ -41,7 +41,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = g32[r].data(); refs[r].inc_prefix = incp[r].data();
         c2_build_diag_rows(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows[r]);
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
-        refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 62)) ? 1 : 0; refs[r].reserved1 = 0;
+        refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 126)) ? 1 : 0; refs[r].reserved1 = 0;
         if (refs[r].pk_ok) { c2_build_diag_rows_pk(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows_pk[r]); any_pk = true; }
         else drows_pk[r].assign(drows[r].size(), c2_diag_row{0, 0, 0, 5u * 256u});
         refs[r].len = lens[r];
@@ -81,7 +81,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     // chain 4 -> 2 -> 1; every chain ends with the full-plane kernel over what is left (the host library's launch order)
     // -8 / -84: the packed kernels (8 / 4 per wavefront, int16 pairs) alone; -87: the library's default chain 8 (packed) -> 4 (packed) -> 1
     // (references the packed fill does not admit: 2 per wavefront in 32 bits instead)
-    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75 || band_lanes == -8 || band_lanes == -84 || band_lanes == -87;
+    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75 || band_lanes == -8 || band_lanes == -84 || band_lanes == -87 || band_lanes == -82;
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1);
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
@@ -152,11 +152,24 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             }
             ++tier;
         }
-        if (band_lanes == -7 || band_lanes == -75 || band_lanes == -1 || band_lanes == -87) {
+        if (band_lanes == -7 || band_lanes == -75 || band_lanes == -1 || band_lanes == -87 || band_lanes == -82) {
+            // third band tier (128 diagonals): two alignments per wavefront in int16 halves (c2_align_diagp_kernel<2>, one lane group of
+            // 64 lanes) where the references admit it, then the single-alignment kernel -- over everything, or over what could not be paired
+            const bool packed = any_pk && (band_lanes == -87 || band_lanes == -82);
+            if (packed) {
+                const c2_diagx_plan PP = c2_make_diagx_plan(2, A.max_li, A.max_lj, true);
+                if (PP.total > sizeof(c2_smem)) return -5;
+                plane.assign((size_t)grid * PP.n_words * 128u, 0xdeadbeefu);
+                c2_align_args T = A;
+                chain(T, false, true);
+                T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 128u;
+                if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed 2 tier %d\n", tier);
+                emu::launch(grid, [&] { c2_align_diagp_kernel<2>(T); });
+            }
             const c2_diag_plan PD = c2_make_diag_plan(A.max_li, A.max_lj);
             if (PD.total > sizeof(c2_smem)) return -5;
             c2_align_args T = A;
-            chain(T, false, false);
+            chain(T, packed, false);
             emu::launch(grid, [&] { c2_align_diag_kernel(T); });
             ++tier;
         }

@@ -106,7 +106,7 @@ def test_emulated_diagonal_band_kernel_with_certificate_and_fallback(mats):
     assert 0 < st["fallback"] < st["tasks"], st
 
 
-@pytest.mark.parametrize("mode", [-2, -4, -5, -7, -75, -8, -84, -87])
+@pytest.mark.parametrize("mode", [-2, -4, -5, -7, -75, -8, -84, -87, -82])
 def test_emulated_multi_alignment_diagonal_kernels(mats, mode):
     """c2_align_diagx_kernel: 2 (-2) or 4 (-4) alignments per wavefront, lane groups isolated by an EXEC-disabled lane,
     pointer words in a global scratch plane; -7 is the host library's whole chain 4 -> 2 -> 1 -> full-plane kernel.
@@ -122,7 +122,7 @@ def test_emulated_multi_alignment_diagonal_kernels(mats, mode):
     assert 0 < st["fallback"] < st["tasks"], st
 
 
-@pytest.mark.parametrize("mode", [-1, -2, -4, -5, -7, -75, -8, -84, -87])
+@pytest.mark.parametrize("mode", [-1, -2, -4, -5, -7, -75, -8, -84, -87, -82])
 def test_emulated_diagonal_band_kernel_unequal_lengths_rc_and_multi_ref(mats, mode):
     m = mats["EDNAFULL"]
     rng = np.random.default_rng(77)
