@@ -157,3 +157,32 @@ def select_best_device(ctx, n_reads, n_refs, d_records, min_mscore, mode, max_al
         mm.ctypes.data_as(ctypes.c_void_p), P(d_raw_counts), P(d_counts), int(mode), int(max_aln_len),
         P(d_member), P(d_use2), P(d_flags), P(d_weights), P(d_weights2), P(d_stats), P(stream))
     ctx.check(rc, "c2_select_best_device")
+
+
+def seed_tables(refs, ref_names, seed_count):
+    """The seeds of c2_strand_plan_device: (blob uint8, off int32 [k, 2, S], len int32 [k, 2, S], n_seeds int32 [k], S) from
+    refs[name]['fw_seeds'] / ['rc_seeds'] (the first min(seed_count, len) of each reference take part, CRISPRessoCORE.py:656-661)."""
+    k = len(ref_names)
+    ns = np.array([min(int(seed_count), len(refs[name]['fw_seeds'])) for name in ref_names], dtype=np.int32)
+    S = max(1, int(ns.max()) if k else 1)
+    off = np.zeros((k, 2, S), dtype=np.int32)
+    ln = np.zeros((k, 2, S), dtype=np.int32)
+    parts, pos = [], 0
+    for r, name in enumerate(ref_names):
+        for st, key in enumerate(('fw_seeds', 'rc_seeds')):
+            for q in range(int(ns[r])):
+                b = refs[name][key][q].encode()
+                off[r, st, q], ln[r, st, q] = pos, len(b)
+                parts.append(b)
+                pos += len(b)
+    blob = np.frombuffer(b"".join(parts), dtype=np.uint8).copy() if pos else np.zeros(0, dtype=np.uint8)
+    return blob, off, ln, ns, S
+
+
+def strand_plan_device(ctx, n_reads, d_reads, d_offsets, max_read_len, refs, ref_names, seed_count, seed_min, d_plan, stream=None):
+    """c2_strand_plan_device: the seed test of get_new_variant_object for reads that are on the device -> d_plan uint8 [n, k]."""
+    blob, off, ln, ns, S = seed_tables(refs, ref_names, seed_count)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else None
+    ctx.check(ctx.lib.c2_strand_plan_device(ctx.handle, ctypes.c_uint64(int(n_reads)), ctypes.c_void_p(d_reads), ctypes.c_void_p(d_offsets),
+                                            int(max_read_len), len(ref_names), int(S), P(ns), P(blob), int(blob.size), P(off), P(ln),
+                                            int(seed_min), ctypes.c_void_p(d_plan), ctypes.c_void_p(stream)), "c2_strand_plan_device")

@@ -89,6 +89,7 @@ struct c2_ctx {
     int occ_blocks[5][3] = {};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
     DevBuf d_sel;          // selection kernel: per-reference score thresholds
+    DevBuf d_seeds;        // strand-plan kernel: seed bytes and tables
     ncclComm_t comm = nullptr; // RCCL communicator of c2_comm_init (one rank per GPU)
     int comm_world = 0;
     std::vector<uint32_t> sel_table;
@@ -559,7 +560,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_diagrows_pk, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_diagrows_pk, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel, &ctx->d_seeds};
     for (DevBuf* b : all) release(*b);
     (void)c2_comm_destroy(ctx);
     for (int k = 0; k < 2; ++k) {
@@ -1414,6 +1415,42 @@ int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4) {
     if (out4) HIPCHK(ctx, hipMemcpy(out4, ctx->d_phase.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemset(ctx->d_phase.p, 0, 4 * sizeof(uint64_t)));
     ctx->phase_prof = enable != 0;
+    return 0;
+}
+
+int c2_strand_plan_device(c2_ctx* ctx, uint64_t n_reads, const uint8_t* d_reads, const uint64_t* d_offsets, int32_t max_read_len,
+                          int32_t n_refs, int32_t max_seeds, const int32_t* h_n_seeds, const uint8_t* h_seed_blob, int32_t blob_bytes,
+                          const int32_t* h_seed_off, const int32_t* h_seed_len, int32_t seed_min, uint8_t* d_plan, void* hip_stream) {
+    if (!ctx || !d_reads || !d_offsets || !d_plan || n_refs <= 0 || max_seeds < 0 || blob_bytes < 0 || max_read_len < 0 ||
+        (max_seeds && (!h_n_seeds || !h_seed_off || !h_seed_len)) || (blob_bytes && !h_seed_blob)) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
+    if (n_reads == 0) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    const size_t tbl = (size_t)n_refs * 2 * (size_t)std::max(max_seeds, 1);
+    for (int r = 0; r < n_refs; ++r) if (h_n_seeds && (h_n_seeds[r] < 0 || h_n_seeds[r] > max_seeds)) { ctx->err = "n_seeds out of range"; return C2_E_INVALID; }
+    for (size_t q = 0; q < (max_seeds ? tbl : 0); ++q)
+        if (h_seed_len[q] < 0 || h_seed_off[q] < 0 || (int64_t)h_seed_off[q] + h_seed_len[q] > blob_bytes) { ctx->err = "seed outside the blob"; return C2_E_INVALID; }
+    const uint32_t lds = 4u * (uint32_t)((max_read_len + 15) & ~15);
+    if (lds > 163840u) { ctx->err = "read longer than the strand-plan kernel's LDS row"; return C2_E_TOO_LARGE; }
+    // one staging block: blob | seed_off | seed_len | n_seeds  (host copy first: a single small upload)
+    const size_t o_off = ((size_t)blob_bytes + 15) & ~(size_t)15, o_len = o_off + tbl * 4, o_n = o_len + tbl * 4, total = o_n + (size_t)n_refs * 4;
+    std::vector<uint8_t> host(total, 0);
+    if (blob_bytes) memcpy(host.data(), h_seed_blob, (size_t)blob_bytes);
+    if (max_seeds) { memcpy(host.data() + o_off, h_seed_off, tbl * 4); memcpy(host.data() + o_len, h_seed_len, tbl * 4); memcpy(host.data() + o_n, h_n_seeds, (size_t)n_refs * 4); }
+    int rc;
+    if (total > ctx->d_seeds.cap) HIPCHK(ctx, hipDeviceSynchronize());          // (an earlier launch may still read the old block)
+    if ((rc = ensure(ctx, ctx->d_seeds, total))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_seeds.p, host.data(), total, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));                                         // `host` is pageable memory owned by this call
+    c2_strand_args A;
+    const uint8_t* base = (const uint8_t*)ctx->d_seeds.p;
+    A.reads = d_reads; A.offsets = d_offsets; A.n_reads = n_reads; A.seed_blob = base;
+    A.seed_off = (const int32_t*)(base + o_off); A.seed_len = (const int32_t*)(base + o_len); A.n_seeds = (const int32_t*)(base + o_n);
+    A.n_refs = n_refs; A.max_seeds = std::max(max_seeds, 1); A.seed_min = seed_min; A.max_read_len = max_read_len; A.plan = d_plan;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_strand_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    const uint64_t wgs = std::min<uint64_t>((n_reads + 3) / 4, (uint64_t)ctx->prop.multiProcessorCount * 8u);
+    hipLaunchKernelGGL(c2_strand_plan_kernel, dim3((unsigned)std::max<uint64_t>(1, wgs)), dim3(256), lds, s, A);
+    HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 

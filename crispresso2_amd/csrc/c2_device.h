@@ -138,6 +138,17 @@ typedef struct c2_consensus_args {
     int32_t* o_info;                        // n x 4: consensus length, quality length, matching columns, flags (1 caching_is_ok, 2 IndexError in the reference)
 } c2_consensus_args;
 
+// ---- seed test that picks the strand(s) of an alignment (CRISPRessoCORE.py:656-687) on the device ----
+struct c2_strand_args {
+    const uint8_t* reads; const uint64_t* offsets; uint64_t n_reads;
+    const uint8_t* seed_blob;         // all seeds back to back
+    const int32_t* seed_off;          // [n_refs][2 (forward, reverse complement)][max_seeds]: byte offset into seed_blob
+    const int32_t* seed_len;          // same shape: length (0 = the empty seed: Python's '' in s is True)
+    const int32_t* n_seeds;           // [n_refs]: seeds that take part (min(aln_seed_count, seeds of the reference))
+    int32_t n_refs, max_seeds, seed_min, max_read_len;
+    uint8_t* plan;                    // [n_reads][n_refs]: 0 forward only, 1 reverse complement only, 2 both
+};
+
 // ---- per-amplicon count tensor (what CRISPRessoCORE.py:3865-3901 keeps per reference and :4016-4115 fills) ----
 // One int64 block per reference: C2_CNT_VECTORS vectors of (lmax + 1) entries, then C2_CNT_SCALARS scalars,
 // then C2_CNT_HISTS histograms of hl entries.  crispresso2_amd/counts.py names the slices.

@@ -2293,6 +2293,50 @@ __global__ __launch_bounds__(64) void c2_selftest_rows_kernel(int* out)
 }
 
 // =====================================================================================
+// The seed test of get_new_variant_object (CRISPRessoCORE.py:656-687) for a batch of reads that are already on the device:
+// found_fw / found_rc = how many of the reference's first n seeds (forward / reverse complement) occur in the read (Python `in`:
+// the empty seed always does, a seed longer than the read never); plan = 0 forward only (found_fw > seed_min and found_rc == 0),
+// 1 reverse complement only (found_fw == 0 and found_rc > seed_min), else 2 (both strands are aligned).  One wavefront per read:
+// the read goes to LDS, lane p tests the window that starts at p (+64, +128, ...), a ballot says whether any window matched.
+// Same answers as the host's c2_strand_plan (tests/test_select_emulated.py, test_gpu_parity.py).
+// =====================================================================================
+__global__ __launch_bounds__(256) void c2_strand_plan_kernel(c2_strand_args A)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t row = (uint32_t)((A.max_read_len + 15) & ~15);
+    unsigned char* sRead = c2_smem + (uint32_t)wave * row;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4u + (uint64_t)wave; i < A.n_reads; i += (uint64_t)gridDim.x * 4u) {
+        const uint64_t o = A.offsets[i];
+        const int Lj = (int)(A.offsets[i + 1] - o);
+        for (int k = lane; k < Lj; k += 64) sRead[k] = A.reads[o + (uint64_t)k];
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < A.n_refs; ++r) {
+            int found[2] = {0, 0};
+            const int ns = A.n_seeds[r];
+            for (int st = 0; st < 2; ++st)
+                for (int q = 0; q < ns; ++q) {
+                    const int idx = (r * 2 + st) * A.max_seeds + q;
+                    const int len = A.seed_len[idx];
+                    if (len == 0) { ++found[st]; continue; }
+                    if (len > Lj) continue;
+                    const uint8_t* seed = A.seed_blob + A.seed_off[idx];
+                    bool any = false;
+                    for (int base = 0; base + len <= Lj && !any; base += 64) {
+                        const int p = base + lane;
+                        bool ok = p + len <= Lj;
+                        for (int k = 0; k < len && __ballot(ok) != 0ull; ++k) ok = ok && sRead[ok ? p + k : 0] == seed[k];
+                        any = __ballot(ok) != 0ull;
+                    }
+                    if (any) ++found[st];
+                }
+            if (lane == 0)
+                A.plan[i * (uint64_t)A.n_refs + (uint64_t)r] = (found[0] > A.seed_min && found[1] == 0) ? 0 : (found[0] == 0 && found[1] > A.seed_min) ? 1 : 2;
+        }
+        __builtin_amdgcn_wave_barrier();                            // (the next read overwrites the row)
+    }
+}
+
+// =====================================================================================
 // Strand and best-reference choice of get_new_variant_object on the device (CRISPRessoCORE.py:683 strand: strict '>';
 // :697-707 best reference: first strictly better score that also exceeds refs[name]['min_aln_score'], later equal scores
 // join; :710 aligned iff the best score is > 0; :779-785 ambiguous reads), one lane per read over its k records.

@@ -120,7 +120,8 @@ class QuantResult:
         return out
 
 
-FORCE_HOST_SELECTION = False     # tests: run the host restatement of the selection instead of c2_select_best_kernel
+FORCE_HOST_SELECTION = False
+FORCE_HOST_STRAND_PLAN = False      # tests: the host's c2_strand_plan instead of c2_strand_plan_device     # tests: run the host restatement of the selection instead of c2_select_best_kernel
 
 
 def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
@@ -283,9 +284,17 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     partner_thread = threading.Thread(target=_find_partners, name="c2-rc-partners")
     _threads.append(partner_thread)
     partner_thread.start()
-    plan = strand_plans(arena, offsets, refs, ref_names, args)
-    lap("strand_plan")
     stream = torch.cuda.current_stream(dev).cuda_stream
+    # the seed test that picks the strand(s) of every (read, reference) alignment (:656-687): on the device, over the reads that
+    # were just sent there (FORCE_HOST_STRAND_PLAN: the host's threaded c2_strand_plan instead -- the tests compare the two)
+    if FORCE_HOST_STRAND_PLAN:
+        plan = strand_plans(arena, offsets, refs, ref_names, args)
+    else:
+        d_plan = torch.empty(n * k, dtype=torch.uint8, device=dev)
+        C.strand_plan_device(ctx, n, d_reads.data_ptr(), d_off.data_ptr(), max_lj, refs, ref_names, args.aln_seed_count, args.aln_seed_min,
+                             d_plan.data_ptr(), stream=stream)
+        plan = d_plan.cpu().numpy().reshape(n, k)
+    lap("strand_plan")
     stride = aligner.stride_for(max_lj)
 
     # ---- batch 1: every read against every reference, on the strand the seeds ask for (forward when they ask for both)

@@ -336,6 +336,13 @@ const uint64_t* c2_fastq_aux_offsets(const c2_fastq* r);
 int c2_strand_plan(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const char* const* fw_seeds, const char* const* rc_seeds,
                    int32_t n_seeds, int32_t seed_min, uint8_t* out_plan);
 int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, uint64_t n, const uint8_t* aligned, int64_t* counts);
+/* c2_strand_plan for reads that are already on the device, all references at once (one wavefront per read).  d_reads / d_offsets:
+ * the arena and its offsets in device memory; the seeds come from the host: seed_blob holds their bytes, seed_off / seed_len
+ * [n_refs][2 (forward, reverse complement)][max_seeds] locate them, n_seeds[r] <= max_seeds is how many of reference r take part
+ * (min(aln_seed_count, seeds the reference has)).  d_plan: uint8 [n_reads][n_refs], as c2_strand_plan's.  Enqueued on hip_stream. */
+int c2_strand_plan_device(c2_ctx* ctx, uint64_t n_reads, const uint8_t* d_reads, const uint64_t* d_offsets, int32_t max_read_len,
+                          int32_t n_refs, int32_t max_seeds, const int32_t* n_seeds, const uint8_t* seed_blob, int32_t blob_bytes,
+                          const int32_t* seed_off, const int32_t* seed_len, int32_t seed_min, uint8_t* d_plan, void* hip_stream);
 /* The same merge in two steps: c2_rc_partners (independent of the alignments: partner[i] = index of the read that equals
  * reverse_complement(read i), or -1; a host thread can run it while the device aligns) and the sequential count transfer over it. */
 int c2_rc_partners(const uint8_t* arena, const uint64_t* offsets, uint64_t n, int64_t* partner);

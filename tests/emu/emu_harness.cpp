@@ -303,6 +303,20 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     return 0;
 }
 
+// c2_strand_plan_device on the emulator: same arguments, minus the context and the stream
+int emu_strand_plan(uint64_t n_reads, const uint8_t* reads, const uint64_t* offsets, int32_t max_read_len, int32_t n_refs, int32_t max_seeds,
+                    const int32_t* n_seeds, const uint8_t* seed_blob, int32_t blob_bytes, const int32_t* seed_off, const int32_t* seed_len,
+                    int32_t seed_min, uint8_t* plan)
+{
+    (void)blob_bytes;
+    c2_strand_args A;
+    A.reads = reads; A.offsets = offsets; A.n_reads = n_reads; A.seed_blob = seed_blob; A.seed_off = seed_off; A.seed_len = seed_len;
+    A.n_seeds = n_seeds; A.n_refs = n_refs; A.max_seeds = max_seeds; A.seed_min = seed_min; A.max_read_len = max_read_len; A.plan = plan;
+    if ((size_t)4 * (size_t)((max_read_len + 15) & ~15) > sizeof(c2_smem)) return -5;
+    emu::launch(3, [&] { c2_strand_plan_kernel(A); }, 256);
+    return 0;
+}
+
 // The per-call C ABI on the emulator, argument for argument (the context handle is ignored): what
 // crispresso2_amd.CRISPResso2Align.global_align / CRISPRessoCOREResources.find_indels_substitutions[_legacy] call.
 // Host-side marshalling follows c2_api.hip (c2_global_align, c2_find_indels_substitutions).

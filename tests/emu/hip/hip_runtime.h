@@ -118,6 +118,7 @@ struct uint4 { unsigned x, y, z, w; };
 
 inline void __syncthreads() { emu::barrier(); }
 inline void __threadfence_block() {}
+inline void __builtin_amdgcn_wave_barrier() { emu::wave_barrier(); }
 
 // exchange helper with phase alternation handled per call site (two tables, flipped by lane 0 after barrier 2)
 namespace emu {

@@ -143,6 +143,16 @@ def _select(ctx, n_reads, n_refs, d_records, min_mscore, mode, max_aln_len, d_re
     assert rc == 0
 
 
+def _strand_plan(ctx, n_reads, d_reads, d_offsets, max_read_len, refs, ref_names, seed_count, seed_min, d_plan, stream=None):
+    """counts.strand_plan_device -> c2_strand_plan_kernel on the emulator (same arguments)"""
+    from crispresso2_amd import counts as C
+    blob, off, ln, ns, S = C.seed_tables(refs, ref_names, seed_count)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else None
+    rc = E.lib().emu_strand_plan(ctypes.c_uint64(int(n_reads)), ctypes.c_void_p(d_reads), ctypes.c_void_p(d_offsets), int(max_read_len),
+                                 len(ref_names), int(S), P(ns), P(blob), int(blob.size), P(off), P(ln), int(seed_min), ctypes.c_void_p(d_plan))
+    assert rc == 0
+
+
 @contextlib.contextmanager
 def emulated_device():
     """Inside the block pipeline.quantify_* run on the emulator; restored afterwards."""
@@ -159,6 +169,8 @@ def emulated_device():
     saved = (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context)
     saved_select = C.select_best_device
     C.select_best_device = _select
+    saved_strand = C.strand_plan_device
+    C.strand_plan_device = _strand_plan
     saved_variants_aligner, saved_paired_aligner = variants.BatchAligner, paired.BatchAligner
     variants.BatchAligner = paired.BatchAligner = make_aligner
     real_device = torch.device
@@ -174,3 +186,4 @@ def emulated_device():
         torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context = saved
         variants.BatchAligner, paired.BatchAligner = saved_variants_aligner, saved_paired_aligner
         C.select_best_device = saved_select
+        C.strand_plan_device = saved_strand

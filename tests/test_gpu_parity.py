@@ -940,6 +940,51 @@ def test_paired_fastq_files_equal_the_reference_run(mats, ctx, tmp_path):
         assert st1 == st and list(cache1) == list(cache) and [cache1[k]["count"] for k in cache1] == exp["counts"]
 
 
+def test_strand_plan_kernel_equals_the_host_seed_test(ctx):
+    """c2_strand_plan_device (reads on the device, all references, one wavefront per read) = the host's c2_strand_plan on reads of both
+    strands, chimeras, unrelated and very short reads, for several seed counts / lengths / thresholds."""
+    import torch
+    from types import SimpleNamespace
+    from crispresso2_amd import _native, counts as C, refs as RF, synth
+    amp, _g, inc = synth.amplicon_setup(250)
+    amp2 = synth.make_variant(amp, "pe")[:-31]
+    rng = np.random.default_rng(4)
+    reads = []
+    for r in synth.make_reads(250, 3000):
+        s = r.tobytes().decode()
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            s = RF.reverse_complement(s)
+        elif kind == 1:
+            s = s[:int(rng.integers(1, 40))]
+        elif kind == 2:
+            s = "".join(rng.choice(list("ACGT"), int(rng.integers(5, 300))))
+        elif kind == 3:
+            s = s[:100] + RF.reverse_complement(s[100:])
+        reads.append(s)
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8).copy()
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    dev = torch.device("cuda", 0)
+    d_reads = torch.from_numpy(arena).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    for seed_count, seed_len, seed_min in ((5, 10, 2), (1, 10, 0), (9, 7, 4), (3, 40, 1), (0, 10, 0)):
+        made = max(seed_count, 2)
+        refs = {"A": RF.make_ref("A", amp, [125], inc, aln_seed_count=made, aln_seed_len=seed_len),
+                "B": RF.make_ref("B", amp2, [110], [109, 110], aln_seed_count=made, aln_seed_len=seed_len)}
+        names = ["A", "B"]
+        d_plan = torch.full((len(reads) * 2,), 9, dtype=torch.uint8, device=dev)
+        C.strand_plan_device(ctx, len(reads), d_reads.data_ptr(), d_off.data_ptr(), max(len(r) for r in reads), refs, names, seed_count, seed_min,
+                             d_plan.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+        plan = d_plan.cpu().numpy().reshape(-1, 2)
+        for r, name in enumerate(names):
+            m = min(seed_count, len(refs[name]["fw_seeds"]))
+            host = _native.strand_plan(arena, off, refs[name]["fw_seeds"][:m], refs[name]["rc_seeds"][:m], seed_min)
+            assert np.array_equal(plan[:, r], host), (seed_count, seed_len, seed_min, name)
+        if seed_count == 5:
+            assert set(np.unique(plan)) == {0, 1, 2}
+
+
 def test_count_reduce_through_the_c_abi_rccl(ctx):
     """c2_comm_unique_id / c2_comm_init / c2_reduce_counts on the one GPU of this box: a communicator of one rank, the all-reduce
     leaves the tensor as it is (the N-rank sum is covered by the gloo tests and by bench.py --gpus N through torch.distributed)."""

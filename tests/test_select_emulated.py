@@ -115,3 +115,55 @@ def test_select_kernel_reports_records_with_a_status():
     rec1["status"][3, 1] = 16
     *_, stats = _run_kernel(rec1, np.zeros(0, dtype=E.REC_DTYPE), np.zeros((5, 2), dtype=np.int32), [60.0, 60.0], None, None, 0)
     assert int(stats[C.SELECT_STATS.index("n_bad_status")]) == 1 and int(stats[C.SELECT_STATS.index("a_bad_status")]) == 16
+
+
+def _seed_case(seed_count, seed_len, seed_min):
+    """reads of mixed strands / lengths (shorter than a seed too), references with seed lists as the reference's setup builds them"""
+    from crispresso2_amd import refs as RF, synth
+    from types import SimpleNamespace
+    amp, _g, inc = synth.amplicon_setup(250)
+    amp2 = synth.make_variant(amp, "pe")[:-31]
+    args = SimpleNamespace(aln_seed_count=seed_count, aln_seed_len=seed_len, aln_seed_min=seed_min)
+    made = max(seed_count, 2)                                        # (the seeds a reference has; args.aln_seed_count says how many take part)
+    refs = {"A": RF.make_ref("A", amp, [125], inc, min_aln_score=60, aln_seed_count=made, aln_seed_len=seed_len),
+            "B": RF.make_ref("B", amp2, [110], [109, 110], min_aln_score=60, aln_seed_count=made, aln_seed_len=seed_len)}
+    rng = np.random.default_rng(seed_count * 100 + seed_len)
+    reads = []
+    for r in synth.make_reads(250, 150):
+        s = r.tobytes().decode()
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            s = RF.reverse_complement(s)
+        elif kind == 1:
+            s = s[:int(rng.integers(1, 40))]                        # shorter than most seeds' positions, some shorter than a seed
+        elif kind == 2:
+            s = "".join(rng.choice(list("ACGT"), int(rng.integers(5, 260))))
+        elif kind == 3:
+            s = s[:100] + RF.reverse_complement(s[100:])             # seeds of both strands
+        reads.append(s)
+    return args, refs, ["A", "B"], reads
+
+
+@pytest.mark.parametrize("seed_count,seed_len,seed_min", [(5, 10, 2), (1, 10, 0), (9, 7, 4), (3, 40, 1), (0, 10, 0)])
+def test_strand_plan_kernel_equals_the_host_seed_test(seed_count, seed_len, seed_min):
+    """c2_strand_plan_kernel (one wavefront per read, all references) on the emulator = the host's threaded c2_strand_plan = the
+    statements of get_new_variant_object (CRISPRessoCORE.py:656-687) in variants._strand_plan."""
+    from crispresso2_amd import _native, counts as C, variants
+    args, refs, names, reads = _seed_case(seed_count, seed_len, seed_min)
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8).copy()
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    blob, soff, slen, ns, S = C.seed_tables(refs, names, args.aln_seed_count)
+    plan = np.full((len(reads), len(names)), 9, dtype=np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else None
+    rc = E.lib().emu_strand_plan(ctypes.c_uint64(len(reads)), P(arena), P(off), int(max(len(r) for r in reads)), len(names), int(S), P(ns), P(blob),
+                                 int(blob.size), P(soff), P(slen), int(seed_min), P(plan))
+    assert rc == 0
+    for r, name in enumerate(names):
+        m = min(args.aln_seed_count, len(refs[name]["fw_seeds"]))
+        host = _native.strand_plan(arena, off, refs[name]["fw_seeds"][:m], refs[name]["rc_seeds"][:m], args.aln_seed_min)
+        assert np.array_equal(plan[:, r], host), name
+        exp = np.array([variants._strand_plan(args, s, refs[name]) for s in reads], dtype=np.uint8)
+        assert np.array_equal(plan[:, r], exp), name
+    if seed_count == 5:
+        assert set(np.unique(plan)) == {0, 1, 2}

@@ -10,6 +10,7 @@ import gzip
 import json
 import os
 
+import numpy as np
 import pytest
 
 from helpers import matrices
@@ -447,6 +448,15 @@ def test_pipeline_on_the_emulator_both_strand_batch_feeds_counts_view_and_allele
         res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
         S = res._state
         assert S["r2"] is not None and S["use2"][:, 0].sum() > 30 and (~S["use2"][:, 0]).sum() > 60
+        # the seed test ran in c2_strand_plan_kernel; the host's c2_strand_plan gives the same run
+        pipeline.FORCE_HOST_STRAND_PLAN = True
+        try:
+            res_h = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
+        finally:
+            pipeline.FORCE_HOST_STRAND_PLAN = False
+        assert res_h.stats == res.stats and np.array_equal(res_h._state["use2"], S["use2"])
+        assert all(np.array_equal(res_h.per_ref[nm][kk], vv) if isinstance(vv, np.ndarray) else res_h.per_ref[nm][kk] == vv
+                   for nm in names for kk, vv in res.per_ref[nm].items())
         res.stats["N_READS_INPUT"] = 250                              # the file fed here is the already filtered one
         out = tmp_path / "out"
         written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
