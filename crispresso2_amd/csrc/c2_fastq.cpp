@@ -1040,8 +1040,14 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
             void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m == MAP_FAILED) { close(fd); g_fastq_error = std::string("cannot map ") + path; delete R; return C2_E_INVALID; }
             madvise(m, n, MADV_SEQUENTIAL);
+            const bool trace = getenv("C2_FASTQ_TRACE") != nullptr;
+            const double T0 = now_s();
             rc = parse_plain_parallel((const char*)m, n, R, plain_threads(n));
+            const double T1 = now_s();
+            // (unmapping a gigabyte of page-cache pages is ~20 ms of kernel time.  Doing it on a helper thread was measured and is
+            // WORSE: munmap holds the address space's lock, and the caller's next page faults -- numpy and torch allocating -- wait for it)
             munmap(m, n);
+            if (trace) fprintf(stderr, "c2_fastq: parse call %.3f s, unmap %.3f s\n", T1 - T0, now_s() - T1);
         } else {
             R->offsets.push_back(0);
         }
