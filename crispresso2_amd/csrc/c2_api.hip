@@ -458,7 +458,7 @@ int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
         if (ctx->any_pk_ok) {                                      // the packed tables mirror the indexing; a reference that is not admitted gets padding
             const size_t want = one.size();
             if (ctx->ref_pk_ok[r]) c2_build_diag_rows_pk(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, one);
-            else one.assign(want, c2_diag_row{0, 0, 0, 5u * 256u});
+            else one.assign(want, c2_diag_row{0, 0, 0, 5u * C2_PK_LUT_STRIDE});
             allpk.insert(allpk.end(), one.begin(), one.end());
         }
     }

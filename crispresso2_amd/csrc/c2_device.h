@@ -181,6 +181,10 @@ static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {
     return (per_ref + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
 }
 
+// packed (int16) fill: byte stride between the pair-score tables of two reference symbols in LDS.  65 dwords, not 64: lanes that hold the
+// same pair of read symbols against DIFFERENT reference symbols -- the usual case, the reads resemble each other -- then hit different banks
+#define C2_PK_LUT_STRIDE 260u
+
 #define C2_CNT_FLAG_IGNORE_SUBSTITUTIONS 1
 #define C2_CNT_FLAG_IGNORE_INSERTIONS 2
 #define C2_CNT_FLAG_IGNORE_DELETIONS 4

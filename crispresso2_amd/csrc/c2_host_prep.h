@@ -162,18 +162,18 @@ inline bool c2_pk_eligible(const char* seq, int Li, const int32_t* g32, const c2
 }
 
 // Row records of the packed kernel for one reference, same indexing as c2_build_diag_rows: {a, b, c} duplicated into both
-// int16 halves, prof = byte offset of the reference symbol's pair-score table (code * 256; table 5 = zeros for rows 0, Li+1
+// int16 halves, prof = byte offset of the reference symbol's pair-score table (code * C2_PK_LUT_STRIDE; table 5 = zeros for rows 0, Li+1
 // and the padding, so that cells outside the matrix add nothing -- as with the 32-bit records' empty score row).
 inline void c2_build_diag_rows_pk(const char* seq, int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend,
                                   std::vector<c2_diag_row>& out) {
-    out.assign((size_t)Li + 2 + 2 * C2_DIAG_ROW_PAD, c2_diag_row{0, 0, 0, 5u * 256u});
+    out.assign((size_t)Li + 2 + 2 * C2_DIAG_ROW_PAD, c2_diag_row{0, 0, 0, 5u * C2_PK_LUT_STRIDE});
     auto dup = [](int x) { return (int32_t)(((uint32_t)x & 0xffffu) | ((uint32_t)x << 16)); };
     for (int i = 1; i <= Li; ++i) {
         const int open = (i == Li) ? gap_extend : gap_open;
         c2_diag_row r;
         r.a = dup(open + g32[i]); r.b = dup(gap_extend + g32[i]); r.c = dup(open + g32[i - 1]);
         const uint8_t code = sc.code_of_char[(unsigned char)seq[i - 1]];
-        r.prof = (code < 5 ? (uint32_t)code : 5u) * 256u;
+        r.prof = (code < 5 ? (uint32_t)code : 5u) * C2_PK_LUT_STRIDE;
         out[C2_DIAG_ROW_PAD + i] = r;
     }
 }

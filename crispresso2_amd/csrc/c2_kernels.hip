@@ -1152,7 +1152,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     uint32_t off = 0;
     p.codeof = off;   off += 256u;                                  // character -> code
     p.table = off;    off += 8u * 24u * 4u;                         // up to 8 slots x C2X_INTS
-    if (pk) off += (uint32_t)C2_PK_LUT_CODES * 256u;                // pair-score tables at the FIXED offset C2_PK_LUT_LDS_OFFSET: it folds into the look-ups' immediate offset
+    if (pk) off += c2_align16((uint32_t)C2_PK_LUT_CODES * C2_PK_LUT_STRIDE);                // pair-score tables at the FIXED offset C2_PK_LUT_LDS_OFFSET: it folds into the look-ups' immediate offset
     p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
     p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
     p.stage = off;    off += p.n_words * lpa * 4u;                  // pointer words of the alignment being traced
@@ -1548,13 +1548,13 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
 
     if (PK) {
         // pair-score tables: for reference symbol rc (codes 0..4; table 5 = zeros, for the padding rows) and read symbols (cA, cB) the two
-        // int16 scores side by side, at byte offset rc * 256 + (cA << 5 | cB << 2) -- the column table holds that pair symbol
+        // int16 scores side by side, at byte offset rc * C2_PK_LUT_STRIDE + (cA << 5 | cB << 2) -- the column table holds that pair symbol
         unsigned* lut = (unsigned*)(c2_smem + P.pairlut);
         for (int e = lane; e < C2_PK_LUT_CODES * 64; e += 64) {
             const int rc = e >> 6, cA = (e >> 3) & 7, cB = e & 7;
             unsigned v = 0;
             if (rc < C2_PK_PAD_TABLE && rc < A.n_codes) v = ((unsigned)c2_sbfe4((int)A.score_pk[rc], 4 * cA) & 0xffffu) | ((unsigned)c2_sbfe4((int)A.score_pk[rc], 4 * cB) << 16);
-            lut[e] = v;
+            lut[rc * (int)(C2_PK_LUT_STRIDE / 4u) + (e & 63)] = v;
         }
     }
     c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;

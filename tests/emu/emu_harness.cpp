@@ -43,7 +43,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
         refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 126)) ? 1 : 0; refs[r].reserved1 = 0;
         if (refs[r].pk_ok) { c2_build_diag_rows_pk(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows_pk[r]); any_pk = true; }
-        else drows_pk[r].assign(drows[r].size(), c2_diag_row{0, 0, 0, 5u * 256u});
+        else drows_pk[r].assign(drows[r].size(), c2_diag_row{0, 0, 0, 5u * C2_PK_LUT_STRIDE});
         refs[r].len = lens[r];
         int64_t gm = 0;
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)g32[r][k]);
