@@ -124,6 +124,7 @@ def main():
                          "diag4 = the 32-bit chain 4 -> 2 -> 1)")
     ap.add_argument("--check", type=int, default=300, help="reads compared with the C oracle after the timed region (0 = no checks at all)")
     ap.add_argument("--no-full-plane-check", action="store_true", help="skip the chain-vs-full-plane comparison of every alignment")
+    ap.add_argument("--no-dedup-leg", action="store_true", help="skip the dedup-on measurement after the timed region (single-amplicon configurations)")
     ap.add_argument("--overlap-count", action="store_true",
                     help="run the count pass of batch k on a second stream while batch k+1 is aligned into a second set of output buffers "
                          "(measured on MI355X, profiles/r02/README.md: no gain -- the persistent workgroups of the launch chain leave the "
@@ -263,7 +264,64 @@ def main():
     select_ms = sum(e[4].elapsed_time(e[2]) for e in ev) / max(args.steps, 1)
     count_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / max(args.steps, 1)
 
-    # ---------- after the timed region: algorithmic bytes of one launch, parity checks ----------
+    # ---------- after the timed region: the same batch the way the reference feeds its aligner -- "dedup on": only the UNIQUE reads are
+    # aligned, their multiplicities are the weights of the count pass (SURVEY 8d asks for both; the headline above is dedup off).
+    # The de-duplication itself (host, outside the timed region here; tools/e2e_rate.py times it inside a FASTQ -> tensors run) is
+    # a 64-bit hash + an exact byte comparison of every read with its group's first member.
+    dedup_on = None
+    if rank == 0 and world == 1 and not all_refs and wl["ref_ids"] is None and not args.no_dedup_leg:
+        t_d = time.perf_counter()
+        W = (L + 7) // 8
+        padded = np.zeros((n, W * 8), dtype=np.uint8)
+        padded[:, :L] = reads
+        rng_h = np.random.default_rng(99)
+        m1 = (rng_h.integers(1, 1 << 62, W, dtype=np.uint64) << np.uint64(1)) | np.uint64(1)
+        m2 = (rng_h.integers(1, 1 << 62, W, dtype=np.uint64) << np.uint64(1)) | np.uint64(1)
+        with np.errstate(over="ignore"):
+            x = padded.view(np.uint64) * m1[None, :]                  # (a plain multiply-sum loses the high bytes of a word: two
+            x ^= x >> np.uint64(32)                                   #  differences there cancel with probability 1/256 -- fold them down first)
+            x *= m2[None, :]
+            h = x.sum(axis=1, dtype=np.uint64)
+        del padded, x
+        _, first, inverse, mult_counts = np.unique(h, return_index=True, return_inverse=True, return_counts=True)
+        exact = True
+        for c0 in range(0, n, 1 << 20):                               # every read equals the first read of its hash group
+            c1 = min(n, c0 + (1 << 20))
+            exact = exact and bool((reads[c0:c1] == reads[first[inverse[c0:c1]]]).all())
+        if exact:
+            nu = len(first)
+            d_ureads = torch.from_numpy(np.ascontiguousarray(reads[first]).reshape(-1)).to(dev)
+            d_uoff = torch.arange(nu + 1, dtype=torch.int64, device=dev) * L
+            d_uw = torch.from_numpy(mult_counts.astype(np.uint32).view(np.int32)).to(dev)
+            host_dedup_s = time.perf_counter() - t_d
+            ua = torch.empty((nu, stride), dtype=torch.uint8, device=dev)    # (own buffers: the checks below read the timed batch's outputs)
+            uf = torch.empty((nu, stride), dtype=torch.uint8, device=dev)
+            ur = torch.empty((nu, 32), dtype=torch.uint8, device=dev)
+            d_ucounts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
+
+            def dedup_step():
+                al.align_device(nu, d_ureads.data_ptr(), d_uoff.data_ptr(), ua.data_ptr(), uf.data_ptr(), ur.data_ptr(), stride, L, stream=stream)
+                d_ucounts.zero_()
+                C.accumulate_device(ctx, layout, nu, ua.data_ptr(), uf.data_ptr(), stride, ur.data_ptr(), d_ucounts.data_ptr(),
+                                    d_weights=d_uw.data_ptr(), min_matches=min_matches, stream=stream)
+            dedup_step()
+            torch.cuda.synchronize()
+            t_u = time.perf_counter()
+            for _ in range(args.steps):
+                dedup_step()
+            torch.cuda.synchronize()
+            dt_u = time.perf_counter() - t_u
+            # the weighted tensor of the unique reads = the tensor of all reads (but for the scalar that counts ALIGNMENTS, not reads)
+            tu, ta = d_ucounts.clone(), d_counts.clone()
+            for t_ in (tu, ta):
+                t_.view(k, -1)[:, layout.scalar_offset("alignments_counted")] = 0
+            same_tensor = bool(torch.equal(tu, ta))
+            dedup_on = {"unique_reads": int(nu), "reads_per_s": n * args.steps / dt_u, "ms_per_step": 1e3 * dt_u / args.steps,
+                        "count_tensor_equals_dedup_off": same_tensor, "host_dedup_seconds_not_timed": host_dedup_s,
+                        "note": "the batch's unique reads aligned once, multiplicities as weights of the count pass; reads/s counts every read of the batch"}
+            del d_ureads, d_uoff, d_uw, ua, uf, ur
+            torch.cuda.empty_cache()
+    # ---------- algorithmic bytes of one launch, parity checks ----------
     while len(out_sets) > 1:                                      # (every set holds the same bytes: the checks read set 0)
         out_sets.pop()
     torch.cuda.empty_cache()
@@ -499,6 +557,7 @@ def main():
                          "chain_avg_ms": 1e3 * avg_launch_s, "chain_algorithmic_bytes": alg_bytes,
                          "note": "integer DP: VALU-issue-bound by construction, HBM fraction is small (SURVEY 8d); see valu and profiles/r02/README.md"},
             "valu": valu,
+            "dedup_on": dedup_on,
             "cpu_baseline": cpu_baseline,
             "checks": checks,
             "counts": [{"amplicon": r, "reads_aligned_all_gpus": tl["counts_total"], "modified": tl["counts_modified"],

@@ -41,6 +41,10 @@ class CountLayout:
     def shape(self):
         return (self.n_refs, self.per_ref)
 
+    def scalar_offset(self, name):
+        """index of a scalar counter inside one reference's row of the tensor"""
+        return N_VECTORS * self.vl + SCALARS.index(name)
+
     def unpack(self, counts, ref, ref_len=None):
         """counts: int64 array [n_refs, per_ref] (numpy).  -> dict name -> vector (length ref_len) / int / histogram dict"""
         row = np.asarray(counts)[ref]

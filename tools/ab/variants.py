@@ -32,7 +32,7 @@ def main():
                 k, _, val = kv.partition("=")
                 env[k] = val or "1"
             p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(a.config), "--reads", str(a.reads), "--steps", str(a.steps),
-                                "--warmup", "1", "--no-cpu-baseline", "--check", env.get("C2_AB_CHECK", "0"), "--no-full-plane-check", "--workers", "8"],
+                                "--warmup", "1", "--no-cpu-baseline", "--check", env.get("C2_AB_CHECK", "0"), "--no-full-plane-check", "--no-dedup-leg", "--workers", "8"],
                                capture_output=True, text=True, env=env, cwd=ROOT)
             line = [x for x in p.stdout.splitlines() if x.startswith("{")]
             if not line:
