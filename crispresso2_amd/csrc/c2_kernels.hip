@@ -617,6 +617,19 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
         const unsigned char rd = in ? sTmpRead[T - 1 - cidx] : 0, rfc = in ? sTmpRef[T - 1 - cidx] : 0;
         const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
         const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
+        {   // 64 columns without a gap, and no gap run open in front of them (most chunks of a traced alignment: its indels sit in one
+            // or two places): only substitutions can occur here, and the reference index of a column is idx_base + lane
+            const unsigned long long m_in = __ballot(in);
+            if (m_rf == m_in && m_rd == m_in && last_rf == base - 1 && last_rd == base - 1) {
+                const int idx0 = idx_base + lane;
+                const bool sub0 = in && rd != rfc && rd != 'N';
+                n_all_sub += __popcll(__ballot(sub0));
+                n_win_sub += __popcll(__ballot(sub0 && (sIncP[idx0 + 1] != sIncP[idx0])));
+                const int cols = __popcll(m_in);
+                idx_base += cols; last_rf = base + cols - 1; last_rd = last_rf;
+                continue;
+            }
+        }
         const int idx = idx_base + __popcll(m_rf & lt);             // ref bases left of this column
         const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
         const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
