@@ -177,8 +177,8 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 #define C2_CNT_CTL_BASE_INTS 96     // >= 16 + 4 * C2_CNT_WAVES
 #define C2_CNT_CTL_INTS (C2_CNT_CTL_BASE_INTS + C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE)   // + per task of a chunk: the part of a heavy weight that is still to be added
 #define C2_CNT_LOAD_BUDGET (1u << 30) // sum of weight x alignment length an LDS block may take between two flushes (its entries are int32)
-static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {
-    return (per_ref + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
+static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {      // block + the LDS-only `cov` vector (lmax + 1) + control words + inc_prefix
+    return (per_ref + ((size_t)lmax + 1) + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
 }
 
 // packed (int16) fill: byte stride between the pair-score tables of two reference symbols in LDS.  65 dwords, not 64: lanes that hold the

@@ -2546,9 +2546,13 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
     const int VL = A.lmax + 1;                                  // vector length incl. the end slot of the difference arrays
     const int o_sc = C2_CNT_VECTORS * VL, o_h = o_sc + C2_CNT_SCALARS;
     const int per_ref = o_h + C2_CNT_HISTS * A.hl;
-    int* ctl = acc + per_ref;                                   // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
+    // cov: difference array over the reference positions of "weight of the alignments whose read base EQUALS the reference's here" --
+    // runs of matching columns add +w at their first position and -w behind their last; flush() integrates it and adds every
+    // position's total to the count vector of the reference's own base there (an LDS-only vector, not part of the tensor)
+    int* cov = acc + per_ref;
+    int* ctl = cov + VL;                                        // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
     uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
-    for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
+    for (int k = tid; k < per_ref + VL; k += NT) acc[k] = 0;
     __syncthreads();
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
     const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
@@ -2564,8 +2568,8 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
         if (cur_ref < 0) return;
         __syncthreads();
         // deletion vectors were accumulated as difference arrays (start += x, end -= x): integrate them first
-        if (wave < 2) {
-            int* d = acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
+        if (wave < 3) {
+            int* d = wave == 2 ? cov : acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
             int carry = 0;
             for (int base = 0; base < VL; base += 64) {
                 const int k = base + lane;
@@ -2580,11 +2584,15 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
             // gets their total weight on the vector of its own base
             const int g = acc[o_sc + C2_S_RESERVED0];
             __syncthreads();
-            if (g != 0) {
+            {   // ... plus, per position, the weight of the alignments with gaps whose read matches the reference there (cov, integrated above)
                 const uint8_t* rs = A.refs[cur_ref].seq;
-                for (int c = tid; c < Li; c += NT) {
-                    const int bv = c2_base_vector(rs[c]);
-                    if (bv >= 0) acc[bv * VL + c] += g;
+                for (int c = tid; c < VL; c += NT) {
+                    const int x = g + cov[c];
+                    cov[c] = 0;
+                    if (c < Li && x != 0) {
+                        const int bv = c2_base_vector(rs[c]);
+                        if (bv >= 0) acc[bv * VL + c] += x;
+                    }
                 }
                 if (tid == 0) acc[o_sc + C2_S_RESERVED0] = 0;
             }
@@ -2845,8 +2853,18 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
                     const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
                     const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
                     const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
-                    if (rf_ng) {
-                        int bv = -1;                                                                    // all_base_count, :4075-4081
+                    // all_base_count, :4075-4081.  Columns where the read's base IS the reference's (nearly all of them) are not added one
+                    // by one: a run of them adds its weight to the difference array `cov` at its two ends (see flush)
+                    const bool same = rf_ng && rd == rfc;
+                    {
+                        const unsigned long long m_same = __ballot(same);
+                        if (same) {
+                            if (lane == 0 || !((m_same >> (lane - 1)) & 1ull)) atomicAdd(cov + idx, w);
+                            if (lane == 63 || !((m_same >> (lane + 1)) & 1ull)) atomicAdd(cov + idx + 1, -w);
+                        }
+                    }
+                    if (rf_ng && !same) {
+                        int bv = -1;
                         if (rd == 'A') bv = C2_V_BASE_A; else if (rd == 'C') bv = C2_V_BASE_C; else if (rd == 'G') bv = C2_V_BASE_G;
                         else if (rd == 'T') bv = C2_V_BASE_T; else if (rd == 'N') bv = C2_V_BASE_N; else if (rd == '-') bv = C2_V_BASE_GAP;
                         if (bv >= 0) atomicAdd(acc + bv * VL + idx, w);
