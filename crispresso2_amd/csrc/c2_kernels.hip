@@ -2881,6 +2881,16 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
                             if (sv >= 0) atomicAdd(acc + sv * VL + idx, w);
                         }
                     }
+                    {   // 64 columns without a gap and no gap run open in front of them (most chunks of an alignment with gaps): no insertion
+                        // or deletion can close here -- the rest of the body would find nothing
+                        const unsigned long long m_in = __ballot(in);
+                        if (m_rf == m_in && m_rd == m_in && last_rf == base - 1 && last_rd == base - 1) {
+                            const int cols = __popcll(m_in);
+                            idx_base += cols; last_rf = base + cols - 1; last_rd = last_rf;
+                            last_rf_close = false; last_rf_wclose = false;
+                            continue;
+                        }
+                    }
                     // insertions: positions [idx-1, idx] of every event; numpy's fancy += counts a repeated position once (:4016, :4021)
                     const bool ins_close = rf_ng && (prev_rf != c - 1) && idx > 0;
                     const bool fl = ins_close && (incp[idx] != incp[idx - 1]), fr = ins_close && (incp[idx + 1] != incp[idx]);
