@@ -271,6 +271,12 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
             g.lds_x[t] = PX.total; g.blocks_x[t] = ctx->occ_x_blocks[t]; g.plane_words = PX.n_words * 64u;                      // [slot][group of 8 anti-diagonals][lane of the slot]
             g.x[t] = true;
         }
+        // A packed kernel hands the tasks it could not pair to the 32-bit kernel of the SAME band (un_list).  That kernel's LDS plan is
+        // the larger one (references of ~3.3-4 kb fit the packed plan only): without it nothing would ever run those tasks, so such a
+        // tier gets no packed kernel either and its tasks fall through to the next tier.  (The third packed tier's unpaired list is
+        // run by c2_align_diag_kernel, which every diagonal chain has.)
+        if (g.pk && !g.x[0]) g.pk = false;
+        if (g.pk2 && !g.x[1]) g.pk2 = false;
     }
     // Banded first launch: keep only the pointer words of the lanes near the main diagonal so that more workgroups fit
     // a CU (the DP is latency-bound at one wave per SIMD).  band: -1 auto, 0 off, >0 lanes on each side.

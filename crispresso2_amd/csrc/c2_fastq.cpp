@@ -82,6 +82,24 @@ namespace {
 
 thread_local std::string g_fastq_error;
 
+// Helper threads that release large scratch tables off the caller's path.  They are never detached: a process that exits (or
+// unloads the library) right after an ingest would otherwise run static destructors while such a thread is still inside
+// free() / munmap().  At most one is outstanding -- starting the next one joins the previous -- and the registry's destructor
+// (library unload / exit) joins the last.
+struct HelperThreads {
+    std::mutex m;
+    std::vector<std::thread> t;
+    template <class F> void run(F&& f) {
+        std::lock_guard<std::mutex> lk(m);
+        for (auto& x : t) if (x.joinable()) x.join();
+        t.clear();
+        t.emplace_back(std::forward<F>(f));
+    }
+    ~HelperThreads() { for (auto& x : t) if (x.joinable()) x.join(); }
+};
+static HelperThreads g_helpers;
+
+
 inline bool py_space(uint8_t c) { return (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x20); }
 
 // 64-bit hash of a byte string (multiply-fold over 8-byte words); quality only matters for table occupancy
@@ -432,7 +450,7 @@ int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads)
     // is tens of milliseconds of kernel time for a gigabyte of input
     if (n >= ((size_t)64 << 20) && !getenv("C2_SYNC_FREE")) {
         auto* junk = new std::tuple<decltype(res), decltype(part), decltype(by_range)>(std::move(res), std::move(part), std::move(by_range));
-        std::thread([junk] { delete junk; }).detach();
+        g_helpers.run([junk] { delete junk; });
     }
     if (trace) fprintf(stderr, "c2_fastq: released the range tables after %.3f s\n", now_s() - T0);
     return 0;

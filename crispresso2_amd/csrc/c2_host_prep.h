@@ -154,6 +154,14 @@ inline bool c2_pk_eligible(const char* seq, int Li, const int32_t* g32, const c2
     for (int i = 0; i <= Li; ++i) gabs = std::max<int64_t>(gabs, g32[i] < 0 ? -(int64_t)g32[i] : (int64_t)g32[i]);
     const int64_t go = gap_open < 0 ? -(int64_t)gap_open : gap_open, ge = gap_extend < 0 ? -(int64_t)gap_extend : gap_extend;
     if (go + gabs > 2000 || ge + gabs > 2000) return false;
+    // `hi` below counts diagonal steps only: no gap step may ADD score (an incentive larger than |gap_extend| or |gap_open| would let
+    // runs at several cut sites stack positive excursions on top of hi).  The diagonal chain asks for the same (geometry()); stated
+    // here too so that the range proof stands on its own.
+    {
+        int64_t gpos = 0;
+        for (int i = 0; i <= Li; ++i) gpos = std::max<int64_t>(gpos, g32[i]);
+        if (std::max<int64_t>(gap_open, gap_extend) + gpos >= 0) return false;
+    }
     const int64_t L = (int64_t)Li + band;
     const int64_t hi = smax * L, lo = L * (-smin) + 4 * go + (band + 4) * (ge + gabs);
     if (hi + lo > 14000) return false;

@@ -44,12 +44,23 @@ class QuantResult:
         # (CRISPRessoCORE.py:4195-4270; built for runs with an expected HDR amplicon / prime-editing extension), else None
         self.first_ref_view = first_ref_view
 
-    def alleles(self):
+    def alleles(self, gather=False):
         """Rows (Aligned_Sequence, Reference_Sequence, Reference_Name, Read_Status, n_deleted, n_inserted, n_mutated, #Reads,
         %Reads) of Alleles_frequency_table.txt: one per (read, reference it counts for), 'AMBIGUOUS_<first reference>' rows
         for ambiguous reads, 'DISCARDED_<first reference>' rows under --discard_indel_reads (CRISPRessoCORE.py:3926-4010,
         :4298-4303), sorted as the reference sorts them (#Reads descending, then the two sequences ascending).  Brings the
-        aligned strings of the aligned unique reads to the host."""
+        aligned strings of the aligned unique reads to the host.
+        gather (sharded run, a collective: every rank calls it): the rows of all ranks' shards, on every rank."""
+        if gather:
+            import torch.distributed as dist
+            mine = self.alleles()
+            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+                return mine
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, mine)
+            rows = [r for part in parts for r in part]
+            rows.sort(key=lambda t: (-t[7], t[0], t[1]))
+            return rows
         import torch
         S = self._state
         if S is None:
@@ -120,8 +131,8 @@ class QuantResult:
         return out
 
 
-FORCE_HOST_SELECTION = False
-FORCE_HOST_STRAND_PLAN = False      # tests: the host's c2_strand_plan instead of c2_strand_plan_device     # tests: run the host restatement of the selection instead of c2_select_best_kernel
+FORCE_HOST_SELECTION = False        # tests: run the host restatement of the selection (_select_on_host) instead of c2_select_best_kernel
+FORCE_HOST_STRAND_PLAN = False      # tests: the host's c2_strand_plan instead of c2_strand_plan_device
 
 
 def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
@@ -182,21 +193,29 @@ def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
 
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
-                    timings=None, pe_scaffold_dna_info=None):
+                    timings=None, pe_scaffold_dna_info=None, shard=None):
     """See _quantify_unique.  (This wrapper only makes sure that the host thread the run starts -- it reads `arena`, which may be a
     view of native memory the caller frees -- has ended before control returns, also when the run raises.)"""
     threads = []
     try:
         return _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
-                                timings, pe_scaffold_dna_info, threads)
+                                timings, pe_scaffold_dna_info, threads, shard)
     finally:
         for t in threads:
             t.join()
 
 
 def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
-                     timings, pe_scaffold_dna_info, _threads):
+                     timings, pe_scaffold_dna_info, _threads, shard=None):
     """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
+    shard: None -- this process aligns every read it was given.  Otherwise arena / offsets / read_counts are the WHOLE run's unique
+    reads (every rank holds the same list, as every worker of the reference sees the parent's variantCache keys) and `shard` names
+    the part this rank aligns: (lo, hi) for a contiguous range (distributed.my_shard = get_variant_cache_equal_boundaries) or an
+    index array.  The reverse-complement merge (:3970-3975) then runs over the whole list exactly as in one process: partners are
+    looked up among ALL unique reads, the ranks exchange which of their reads aligned (one byte per unique read, all-reduced),
+    and every rank applies the reference's sequential count transfer to the global counts before it weighs its own reads -- so the
+    all-reduced tensors equal the single-process ones also when a read and its reverse complement land in different shards.
+    Implies reduce_across_ranks.
     timings: optional dict that receives the wall seconds of every stage.
     pe_scaffold_dna_info: (index, dna) of get_pe_scaffold_search for runs with --prime_editing_pegRNA_scaffold_seq: reads whose
     alignment against 'Prime-edited' carries `dna` right after reference base index-1 are counted for 'Scaffold-incorporated'
@@ -225,10 +244,30 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if scaffold_rule and (pe_scaffold_dna_info is None or pe_scaffold_dna_info[1] is None):
         raise ValueError("prime_editing_pegRNA_scaffold_seq needs pe_scaffold_dna_info = (index, dna) of get_pe_scaffold_search")
     ctx = ctx or _native.default_context()
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    # the whole run's unique reads (what the reverse-complement partner search looks at) and the part this process aligns
+    g_arena, g_offsets, g_raw = arena, offsets, np.asarray(read_counts, dtype=np.int64)
+    n_global = len(g_raw)
+    shard_idx = None
+    if shard is not None:
+        reduce_across_ranks = True
+        if isinstance(shard, tuple):
+            lo, hi = int(shard[0]), int(shard[1])
+            shard_idx = slice(lo, hi)
+            arena = np.asarray(arena)[int(offsets[lo]):int(offsets[hi])]
+            offsets = (offsets[lo:hi + 1] - offsets[lo]).astype(np.uint64)
+        else:
+            shard_idx = np.asarray(shard, dtype=np.int64)
+            ln_ = (offsets[1:] - offsets[:-1]).astype(np.int64)[shard_idx]
+            new_off = np.zeros(len(shard_idx) + 1, dtype=np.uint64)
+            new_off[1:] = np.cumsum(ln_)
+            src = np.repeat(offsets[:-1].astype(np.int64)[shard_idx] - new_off[:-1].astype(np.int64), ln_) + np.arange(int(new_off[-1]), dtype=np.int64)
+            arena = np.asarray(arena)[src] if len(src) else np.zeros(0, dtype=np.uint8)
+            offsets = new_off
+        read_counts = g_raw[shard_idx]
     n, k = len(read_counts), len(ref_names)
     L = [len(refs[name]['sequence']) for name in ref_names]
     dev = torch.device("cuda", device)
-    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
     max_lj = int(lens.max()) if n else 1
     aligner = BatchAligner([refs[name]['sequence'] for name in ref_names], [refs[name]['gap_incentive'] for name in ref_names],
@@ -254,16 +293,60 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             v = C.all_reduce(torch.tensor([stats[q] for q in STAT_KEYS], dtype=torch.int64, device=dev)).cpu().numpy()
             for q, x in zip(STAT_KEYS, v):
                 stats[q] = int(x)
+    pe = ref_names.index('Prime-edited') if scaffold_rule else -1
+
+    def finish(d_view, d_scaffold, state):
+        """the tensors (already all-reduced when sharded) -> QuantResult; the same for a rank whose shard is empty"""
+        host = d_counts.cpu().numpy()
+        lap("count_kernels")
+        per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
+        out_names = list(ref_names)
+        if scaffold_rule:
+            per_ref['Scaffold-incorporated'] = layout.unpack(d_scaffold.cpu().numpy(), pe, L[pe])
+            out_names.append('Scaffold-incorporated')
+        first_ref_view = None
+        if d_view is not None:
+            view_keys = (["all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
+                          "all_substitution_count_vectors"] + ["all_base_count_vectors_" + x for x in "ACGTN-"])
+            host_view = d_view.cpu().numpy()
+            first_ref_view = {ref_names[0]: {kk: per_ref[ref_names[0]][kk] for kk in view_keys}}
+            for r in range(1, len(out_names)):
+                u = layout.unpack(host_view[r], 0, L[0])
+                first_ref_view[out_names[r]] = {kk: u[kk] for kk in view_keys}
+            for v in first_ref_view.values():
+                v["all_indelsub_count_vectors"] = (v["all_insertion_count_vectors"] + v["all_deletion_count_vectors"]
+                                                   + v["all_substitution_count_vectors"])
+        lap("unpack")
+        return QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
+
+    def exchange_aligned(aligned_local):
+        """sharded run: which unique reads of the WHOLE list aligned -- every rank contributes its part (one byte per read)"""
+        t = torch.zeros(max(n_global, 1), dtype=torch.uint8, device=dev)
+        if n:
+            idx_t = (torch.arange(shard_idx.start, shard_idx.stop, device=dev) if isinstance(shard_idx, slice)
+                     else torch.from_numpy(shard_idx).to(dev))
+            t[idx_t] = torch.from_numpy(np.ascontiguousarray(aligned_local, dtype=np.uint8)).to(dev)
+        C.all_reduce(t)
+        return t.cpu().numpy()[:n_global] != 0
     if n == 0:
-        # an empty shard still takes part in every collective of the other ranks (same tensors, zeros)
+        # an empty shard still takes part in every collective of the other ranks (same tensors, zeros, same order) and gets the
+        # same result as they do
+        d_view = d_scaffold = None
         if reduce_across_ranks:
+            if shard is not None:
+                exchange_aligned(None)
             C.all_reduce(d_counts)
             if want_view:
-                C.all_reduce(torch.zeros((k + (1 if scaffold_rule else 0),) + tuple(layout.shape()), dtype=torch.int64, device=dev))
+                d_view = C.all_reduce(torch.zeros((k + (1 if scaffold_rule else 0),) + tuple(layout.shape()), dtype=torch.int64, device=dev))
             if scaffold_rule:
-                C.all_reduce(torch.zeros(layout.shape(), dtype=torch.int64, device=dev))
+                d_scaffold = C.all_reduce(torch.zeros(layout.shape(), dtype=torch.int64, device=dev))
             reduce_stats()
-        return QuantResult({name: layout.unpack(d_counts.cpu().numpy(), r, L[r]) for r, name in enumerate(ref_names)}, stats, layout, d_counts)
+        elif scaffold_rule:
+            d_scaffold = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
+            d_view = torch.zeros((k + 1,) + tuple(layout.shape()), dtype=torch.int64, device=dev) if want_view else None
+        elif want_view:
+            d_view = torch.zeros((k,) + tuple(layout.shape()), dtype=torch.int64, device=dev)
+        return finish(d_view, d_scaffold, None)
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
     if not arena.flags.writeable:
         arena = arena.copy()                                      # torch.from_numpy wants a writable array
@@ -278,7 +361,8 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
 
     def _find_partners():
         try:
-            partners['index'] = _native.rc_partners(arena, offsets)
+            partners['index'] = (_native.rc_partners(arena, offsets) if shard is None else
+                                 _native.rc_partners(np.ascontiguousarray(g_arena, dtype=np.uint8), g_offsets))
         except BaseException as e:                                   # re-raised by the main thread at the join
             partners['error'] = e
     partner_thread = threading.Thread(target=_find_partners, name="c2-rc-partners")
@@ -374,7 +458,14 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     partner_thread.join()
     if 'error' in partners:
         raise partners['error']
-    _native.merge_counts_with_partners(aligned, partners['index'], cnt)
+    if shard is None:
+        _native.merge_counts_with_partners(aligned, partners['index'], cnt)
+    else:
+        # the reference's sequential transfer over the WHOLE variantCache order, with every rank's `aligned` flags: a read whose
+        # reverse complement was aligned by another rank gives its copies to (or takes them from) that read exactly as in one process
+        g_cnt = np.ascontiguousarray(g_raw.copy())
+        _native.merge_counts_with_partners(exchange_aligned(aligned), partners['index'], g_cnt)
+        cnt = np.ascontiguousarray(g_cnt[shard_idx])
     stats['N_TOTAL'] = int(cnt[aligned].sum())
     counted = member.copy()
     ambiguous = aligned & (n_best > 1)
@@ -390,7 +481,6 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     # shows the scaffold's first bases right after the extension is counted for 'Scaffold-incorporated' ONLY (ambiguous or not),
     # with that alignment.  The aligned strings of the candidate reads come to the host for the substring test.
     scaffold_hit = np.zeros(n, dtype=bool)
-    pe = ref_names.index('Prime-edited') if scaffold_rule else -1
     if scaffold_rule:
         cand = np.nonzero(aligned & member[:, pe])[0]
         if len(cand):
@@ -495,35 +585,20 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             C.all_reduce(d_scaffold)
         reduce_stats()
     torch.cuda.synchronize(dev)
-    host = d_counts.cpu().numpy()
-    lap("count_kernels")
-    per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
-    out_names = list(ref_names)
-    if scaffold_rule:
-        per_ref['Scaffold-incorporated'] = layout.unpack(d_scaffold.cpu().numpy(), pe, L[pe])
-        out_names.append('Scaffold-incorporated')
-    first_ref_view = None
-    if d_view is not None:
-        view_keys = (["all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
-                      "all_substitution_count_vectors"] + ["all_base_count_vectors_" + x for x in "ACGTN-"])
-        host_view = d_view.cpu().numpy()
-        first_ref_view = {ref_names[0]: {kk: per_ref[ref_names[0]][kk] for kk in view_keys}}
-        for r in range(1, len(out_names)):
-            u = layout.unpack(host_view[r], 0, L[0])
-            first_ref_view[out_names[r]] = {kk: u[kk] for kk in view_keys}
-        for v in first_ref_view.values():
-            v["all_indelsub_count_vectors"] = (v["all_insertion_count_vectors"] + v["all_deletion_count_vectors"]
-                                               + v["all_substitution_count_vectors"])
     state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=slot2,
                  scaffold_hit=scaffold_hit, scaffold_ref=pe,
                  a1=a1, f1=f1, r1=r1, a2=a2, f2=f2, r2=r2)
-    lap("unpack")
-    return QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
+    return finish(d_view, d_scaffold, state)
 
 
-def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None, pe_scaffold_dna_info=None):
+def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None, pe_scaffold_dna_info=None,
+                   shard_across_ranks=False):
     """FASTQ file -> QuantResult.  Empty sequences (blank line / truncated record) are dropped, as in variants.read_fastq_unique
-    (the reference's aligner indexes seq[-1] of an empty string: undefined there), and N_TOT_READS counts the records that are left."""
+    (the reference's aligner indexes seq[-1] of an empty string: undefined there), and N_TOT_READS counts the records that are left.
+    shard_across_ranks (torch.distributed initialised, one process per GPU): every rank de-duplicates the file -- the parent's
+    variantCache of the reference, which all its workers see -- aligns ITS contiguous range of the unique reads
+    (get_variant_cache_equal_boundaries, CRISPRessoCORE.py:1172-1195) and the count tensors are all-reduced; the result is the
+    single-process one on every rank (quantify_unique, `shard`)."""
     import time
     t0 = time.perf_counter()
     # --min_single_bp_quality / --min_average_read_quality / --min_bp_quality_or_N: the reference filters the file first
@@ -543,8 +618,14 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
             offsets, counts = new_off, counts[keep]
         if timings is not None:
             timings["drop_empty_key"] = time.perf_counter() - t0 - timings["ingest_dedup"]
+        shard = None
+        if shard_across_ranks:
+            import torch.distributed as dist
+            from . import distributed as D
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                shard = D.my_shard(len(counts), dist.get_rank(), dist.get_world_size())
         res = quantify_unique(arena, offsets, counts, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
-                              pe_scaffold_dna_info=pe_scaffold_dna_info)
+                              pe_scaffold_dna_info=pe_scaffold_dna_info, shard=shard)
         t_free = time.perf_counter()
     if timings is not None:
         timings["free_ingest"] = time.perf_counter() - t_free

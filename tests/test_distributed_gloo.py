@@ -89,12 +89,10 @@ def _pipeline_worker(rank, world, port, out_dir):
         fh.write(g["fastq"])
     arena, offsets, counts, n_reads = _native.fastq_unique(fq)
     a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
-    lo, hi = D.my_shard(len(counts)) if world > 1 else (0, len(counts))
-    sub_off = (offsets[lo:hi + 1] - offsets[lo]).astype(np.uint64)
-    sub_arena = arena[int(offsets[lo]):int(offsets[hi])]
     with emulated_device():
-        res = pipeline.quantify_unique(sub_arena, sub_off, counts[lo:hi], refs, names[:2], matrices()["EDNAFULL"], _pipeline_args(a),
-                                       reduce_across_ranks=world > 1, pe_scaffold_dna_info=tuple(g["pe_scaffold_dna_info"]))
+        res = pipeline.quantify_unique(arena, offsets, counts, refs, names[:2], matrices()["EDNAFULL"], _pipeline_args(a),
+                                       shard=D.my_shard(len(counts)) if world > 1 else None,
+                                       pe_scaffold_dna_info=tuple(g["pe_scaffold_dna_info"]))
     if rank == 0:
         with open(os.path.join(out_dir, "world%d.pkl" % world), "wb") as fh:
             pickle.dump({"per_ref": res.per_ref, "view": res.first_ref_view}, fh)
@@ -153,15 +151,12 @@ def _ragged_worker(rank, world, port, out_dir):
     assert lens[order[0]] < lens[order[-1]]
     cuts = [0, n] if world == 1 else [0, n // 3, n, n]            # rank 0: the short reads, rank 1: the rest, rank 2: nothing
     mine = order[cuts[rank]:cuts[rank + 1]]
-    sub_off = np.zeros(len(mine) + 1, dtype=np.uint64)
-    sub_off[1:] = np.cumsum(lens[mine])
-    sub_arena = (np.concatenate([arena[int(offsets[i]):int(offsets[i + 1])] for i in mine]) if len(mine) else np.zeros(0, dtype=np.uint8))
     a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
     with emulated_device():
-        res = pipeline.quantify_unique(sub_arena, sub_off, counts[mine], refs, names[:2], matrices()["EDNAFULL"], _pipeline_args(a),
-                                       reduce_across_ranks=world > 1, pe_scaffold_dna_info=tuple(g["pe_scaffold_dna_info"]))
+        res = pipeline.quantify_unique(arena, offsets, counts, refs, names[:2], matrices()["EDNAFULL"], _pipeline_args(a),
+                                       shard=mine if world > 1 else None, pe_scaffold_dna_info=tuple(g["pe_scaffold_dna_info"]))
     with open(os.path.join(out_dir, "ragged_world%d_rank%d.pkl" % (world, rank)), "wb") as fh:
-        pickle.dump({"per_ref": res.per_ref, "stats": res.stats, "shape": tuple(res.layout.shape())}, fh)
+        pickle.dump({"per_ref": res.per_ref, "view": res.first_ref_view, "stats": res.stats, "shape": tuple(res.layout.shape())}, fh)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -179,8 +174,94 @@ def test_ragged_and_empty_shards_reduce_to_the_single_process_result(tmp_path):
         got = pickle.load(open(tmp_path / ("ragged_world3_rank%d.pkl" % rank), "rb"))
         assert got["shape"] == one["shape"]                        # the layout was agreed on, whatever the shard held
         assert got["stats"] == one["stats"], rank                  # ... and the statistics are the run's, not the shard's
-        if rank < 2:                                               # (the empty rank returns before the scaffold amplicon is added)
+        assert set(got["per_ref"]) == set(one["per_ref"]) and set(got["view"]) == set(one["view"])
+        for nm in one["per_ref"]:                                  # every rank -- the one with the empty shard too -- holds the run's result
+            for key, v in one["per_ref"][nm].items():
+                w = got["per_ref"][nm][key]
+                assert np.array_equal(v, w) if isinstance(v, np.ndarray) else v == w, (rank, nm, key)
+            for key, v in one["view"][nm].items():
+                assert np.array_equal(v, got["view"][nm][key]), (rank, nm, key)
+
+
+# ---- a read and its reverse complement in DIFFERENT shards: the merge of CRISPRessoCORE.py:3970-3975 must still be the whole run's ----
+def _split_partner_fastq():
+    """The params run's reads plus reverse-complemented copies placed so that partners are far apart in first-seen order: the
+    reverse complements of early unique reads at the END of the file (the partner that keeps the copies is in the first shard,
+    the one that gives them away in the last), those of late unique reads at the START (the other way round), with different
+    multiplicities."""
+    from crispresso2_amd import refs as RF
+    from test_whole_run_tables import _params_golden
+    g, refs, names = _params_golden()
+    lines = g["fastq_after_quality_filter"].split("\n")
+    recs = [lines[k:k + 4] for k in range(0, len(lines) - 1, 4)]
+    uniq = list(dict.fromkeys(r[1] for r in recs))
+    rc = lambda r, tag: ["@%s_%s" % (r[0][1:].split()[0], tag), RF.reverse_complement(r[1]), "+", r[3][::-1]]
+    first_of = {}
+    for r in recs:
+        first_of.setdefault(r[1], r)
+    head = [rc(first_of[u], "h%d" % q) for q, u in enumerate(uniq[-30:]) for _ in range(q % 3 + 1)]
+    tail = [rc(first_of[u], "t%d" % q) for q, u in enumerate(uniq[:40]) for _ in range(q % 2 + 1)]
+    text = "".join("%s\n%s\n%s\n%s\n" % tuple(r) for r in head + recs + tail)
+    return g, refs, names, text
+
+
+def _split_partner_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pickle
+    from helpers import matrices
+    from pipeline_on_emulator import emulated_device
+    from test_whole_run_tables import _pipeline_args
+    from crispresso2_amd import distributed as D, pipeline
+    D.init("gloo")
+    g, refs, names, text = _split_partner_fastq()
+    fq = os.path.join(out_dir, "split_w%d_r%d.fastq" % (world, rank))
+    with open(fq, "w") as fh:
+        fh.write(text)
+    a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+    with emulated_device():
+        res = pipeline.quantify_fastq(fq, refs, names, matrices()["EDNAFULL"], _pipeline_args(a), shard_across_ranks=True)
+        rows = res.alleles(gather=True)
+    with open(os.path.join(out_dir, "split_world%d_rank%d.pkl" % (world, rank)), "wb") as fh:
+        pickle.dump({"per_ref": res.per_ref, "view": res.first_ref_view, "stats": res.stats, "alleles": rows}, fh)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_reverse_complement_partners_in_different_shards_merge_as_in_one_process(tmp_path):
+    """VERDICT r02 item 1b.  2 and 3 gloo ranks, pipeline.quantify_fastq(shard_across_ranks=True): count tensors, first-amplicon
+    view, statistics and the gathered allele rows equal the single-process run on a file whose reverse-complement partners sit
+    in different shards (a rank-local merge leaves both partners' rows in the allele table)."""
+    import pickle
+    sys.path.insert(0, HERE)
+    import emu_driver as E
+    from crispresso2_amd import _native, distributed as D
+    E.build()
+    g, refs, names, text = _split_partner_fastq()
+    fq = tmp_path / "probe.fastq"
+    fq.write_text(text)
+    arena, offsets, counts, n_reads = _native.fastq_unique(str(fq))
+    partner = _native.rc_partners(np.ascontiguousarray(arena), offsets)
+    for world in (2, 3):
+        b = np.array(D.shard_boundaries(len(counts), world))
+        shard_of = np.searchsorted(b, np.arange(len(counts)), side="right") - 1
+        has = partner >= 0
+        straddle = int((shard_of[has] != shard_of[partner[has]]).sum())
+        assert straddle >= 60, (world, straddle)                    # the file does what it was built for
+    _split_partner_worker(0, 1, 0, str(tmp_path))
+    one = pickle.load(open(tmp_path / "split_world1_rank0.pkl", "rb"))
+    assert len(one["alleles"]) > 50
+    for world in (2, 3):
+        mp.spawn(_split_partner_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+        for rank in range(world):
+            got = pickle.load(open(tmp_path / ("split_world%d_rank%d.pkl" % (world, rank)), "rb"))
+            assert got["stats"] == one["stats"], (world, rank)
+            assert got["alleles"] == one["alleles"], (world, rank)
             for nm in one["per_ref"]:
                 for key, v in one["per_ref"][nm].items():
                     w = got["per_ref"][nm][key]
-                    assert np.array_equal(v, w) if isinstance(v, np.ndarray) else v == w, (rank, nm, key)
+                    assert np.array_equal(v, w) if isinstance(v, np.ndarray) else v == w, (world, rank, nm, key)
+                for key, v in one["view"][nm].items():
+                    assert np.array_equal(v, got["view"][nm][key]), (world, rank, nm, key)
