@@ -20,13 +20,28 @@ and every alignment of the cpu_baseline legs (the reference's own compiled code)
 N > 1: every rank runs the same amount of work on its own shard of the read stream (weak scaling, no data-path collective;
 the all-reduce of the per-amplicon count tensor is the only exchange and is inside the step).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run with one rank
-per GPU.  Rank 0 prints ONE JSON line.
+After the headline's timed region and checks, the default run (no --config / --reads / --len / --kernel / --no-extras) adds, in
+the same JSON line:
+  int32_chain    the same batch through the 32-bit launch chain (c2_align_diagx_kernel<4> -> <2> -> c2_align_diag_kernel -> full plane:
+                 the reference's C-int arithmetic, CRISPResso2Align.pyx:142-147), timed the same way -- the number that stands next to
+                 the headline's packed-int16 first tier
+  other_configs  BASELINE.json configs[1], [3], [4] (--config 2, 4, 5) at full size: 3 timed steps each and the chain = full-plane
+                 comparison of every alignment
+  e2e            FASTQ -> count tensors (pipeline.quantify_fastq: native ingest + de-duplication, seed test, alignments, selection,
+                 reverse-complement merge, count kernel) on the headline's reads written to /dev/shm, plain and BGZF
+
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 it runs one rank per GPU over RCCL: under
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) it is one of the ranks; started bare it
+spawns its own N ranks on this node (the reference's fan-out needs no launcher either, CRISPRessoCORE.py:1870-1898) and rank 0's
+line is the output.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -42,7 +57,9 @@ VALU_SIMD32_WAVE_INSTR_PER_S = N_SIMD * CLOCK_HZ / 2.0
 # measured on this chip (tools/valu_microbench*.hip, profiles/r01/valu_microbench*.txt): every opcode of the DP cell
 # (v_max_i32, v_max3_i32, v_cmp + v_addc, v_bfe_i32, DPP forms, VOP3) costs ~4.2 cycles of SIMD time at >= 3 waves per SIMD
 VALU_MEASURED_CYCLES_PER_INSTR = 4.2
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+VALU_MEASURED_SOURCE = "profiles/r01/valu_microbench.txt, valu_microbench2.txt (tools/valu_microbench*.hip)"
+PROFILE_ROUNDS = ["r03", "r02"]                 # the PMC summary of the newest round that has one
+GO, GE, MIN_ALN_SCORE = -20, -2, 60.0
 
 CONFIG_DEFAULTS = {2: (150, 1_000_000), 3: (250, 10_000_000), 4: (250, 10_000_000), 5: (250, 12_500_000)}
 
@@ -106,6 +123,381 @@ def build_workload(config, L, n, rank, workers):
     raise SystemExit("--config must be 2, 3, 4 or 5")
 
 
+SPAWN_CMD = [sys.executable, os.path.abspath(__file__)]     # what a rank is (tests/bench_emulated_main.py puts its own script here)
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` started bare: this process becomes the launcher of N ranks of itself on this node (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them; rank k uses GPU k).  The ranks inherit stdout, so
+    rank 0's JSON line is this command's output.  A rank that fails takes the others down with it."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), C2_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # the host driver only supports dmabuf IPC (RCCL needs it)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+        procs.append(subprocess.Popen(SPAWN_CMD + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:                                      # our own children, by handle
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+class Job:
+    """One workload resident in HBM: its reads, output buffers, count tensor, the step (launch chain -> best-amplicon choice ->
+    count pass -> all-reduce), the timed run and the exhaustive chain-vs-full-plane comparison."""
+
+    def __init__(self, ctx, wl, L, matrix, dev, world, kernel="auto", overlap_count=False):
+        import torch
+        from crispresso2_amd import counts as C
+        from crispresso2_amd.batch import BatchAligner
+        self.torch, self.C, self.ctx, self.wl, self.L, self.dev, self.world, self.kernel = torch, C, ctx, wl, L, dev, world, kernel
+        refs, reads = wl["refs"], wl["reads"]
+        self.all_refs = all_refs = wl["all_refs"]
+        self.n = n = reads.shape[0]
+        self.k = k = len(refs)
+        self.n_tasks = n_tasks = n * (k if all_refs else 1)
+        ctx.set_kernel_mode(kernel)
+        self.al = BatchAligner([r[0] for r in refs], [r[1] for r in refs], [r[2] for r in refs], matrix, GO, GE, ctx=ctx)
+        self.stride = stride = self.al.stride_for(L)
+        self.Lmax = self.al.max_ref_len
+        self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+        self.d_offsets = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
+        self.d_rids = None if wl["ref_ids"] is None else torch.from_numpy(wl["ref_ids"].astype(np.int16)).to(dev)
+        # output buffers: one set; two with --overlap-count, so that batch k+1 is aligned while batch k is still being counted
+        self.n_sets = 2 if overlap_count else 1
+        self.out_sets = [(torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev), torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev),
+                          torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)) for _ in range(self.n_sets)]
+        self.t_align = torch.cuda.current_stream()
+        self.t_count = torch.cuda.Stream(device=dev) if overlap_count else self.t_align
+        self.stream = self.t_align.cuda_stream
+        self.count_stream = self.t_count.cuda_stream
+        self.aligned_ev = [torch.cuda.Event() for _ in range(self.n_sets)]
+        self.counted_ev = [None] * self.n_sets
+        # per-amplicon count tensor (CRISPRessoCORE.py:3865-4115 on the device) -- the only thing the GPUs exchange
+        self.layout = C.CountLayout(k, self.Lmax, L)
+        self.d_counts = torch.zeros(self.layout.shape(), dtype=torch.int64, device=dev)
+        self.min_matches = C.min_matches_table([MIN_ALN_SCORE] * k, self.Lmax + L)          # --default_min_aln_score 60
+        self.d_weights = self.d_selstats = None
+        if all_refs:
+            self.d_weights = torch.zeros(n_tasks, dtype=torch.int32, device=dev)
+            self.d_selstats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
+            self.min_mscore = C.min_mscore_table([MIN_ALN_SCORE] * k)
+        self.step_no = 0
+
+    @property
+    def outputs(self):
+        return self.out_sets[0]
+
+    def align_into(self, a_read, a_ref, recs):
+        self.al.align_device(self.n, self.d_reads.data_ptr(), self.d_offsets.data_ptr(), a_read.data_ptr(), a_ref.data_ptr(), recs.data_ptr(),
+                             self.stride, self.L, d_ref_ids=None if self.d_rids is None else self.d_rids.data_ptr(), all_refs=self.all_refs,
+                             stream=self.stream)
+
+    def step(self, e=None):
+        """One batch: launch chain on the align stream into buffer set i; reference choice, count pass and all-reduce on the count
+        stream (the same stream unless --overlap-count).  Set i is aligned into again only after its previous batch has been counted."""
+        torch, C = self.torch, self.C
+        i = self.step_no % self.n_sets
+        self.step_no += 1
+        a_read, a_ref, recs = self.out_sets[i]
+        if self.counted_ev[i] is not None:
+            self.t_align.wait_event(self.counted_ev[i])
+        if e: e[0].record(self.t_align)
+        self.align_into(a_read, a_ref, recs)
+        if e: e[1].record(self.t_align)
+        self.aligned_ev[i].record(self.t_align)
+        self.t_count.wait_event(self.aligned_ev[i])
+        with torch.cuda.stream(self.t_count):
+            if e: e[4].record(self.t_count)
+            if self.all_refs:
+                # strand / best-amplicon choice on the device (CRISPRessoCORE.py:697-707) -> the weight of every alignment in the count pass
+                self.d_selstats.zero_()
+                C.select_best_device(self.ctx, self.n, self.k, recs.data_ptr(), self.min_mscore, C.SELECT_DROP_AMBIGUOUS, self.Lmax + self.L,
+                                     d_weights=self.d_weights.data_ptr(), d_stats=self.d_selstats.data_ptr(), stream=self.count_stream)
+            if e: e[2].record(self.t_count)
+            self.d_counts.zero_()
+            C.accumulate_device(self.ctx, self.layout, self.n_tasks, a_read.data_ptr(), a_ref.data_ptr(), self.stride, recs.data_ptr(),
+                                self.d_counts.data_ptr(), d_weights=self.d_weights.data_ptr() if self.all_refs else None,
+                                min_matches=None if self.all_refs else self.min_matches,
+                                flags=C.FLAG_ALL_REFS_LAYOUT if self.all_refs else 0, stream=self.count_stream)
+            C.all_reduce(self.d_counts)
+            if e: e[3].record(self.t_count)
+            self.counted_ev[i] = torch.cuda.Event()
+            self.counted_ev[i].record(self.t_count)
+
+    def fence(self):
+        import torch.distributed as dist
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, warmup, steps):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; the time is the maximum over the ranks."""
+        import torch.distributed as dist
+        torch = self.torch
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        self.ctx.timing_enable(True)
+        t0 = time.perf_counter()
+        for s_ in range(steps):
+            self.step(ev[s_])
+        self.fence()
+        dt = time.perf_counter() - t0
+        kernel_ms, first_ms, launches = self.ctx.timing_read_split()
+        self.ctx.timing_enable(False)
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        ns = max(steps, 1)
+        return dict(dt=dt, steps=steps, kernel_ms=kernel_ms, first_ms=first_ms, launches=launches,
+                    align_ms=sum(e[0].elapsed_time(e[1]) for e in ev) / ns, select_ms=sum(e[4].elapsed_time(e[2]) for e in ev) / ns,
+                    count_ms=sum(e[2].elapsed_time(e[3]) for e in ev) / ns,
+                    reads_per_s=self.world * self.n * steps / dt, alignments_per_s=self.world * self.n_tasks * steps / dt)
+
+    def chain_equals_full_plane(self):
+        """The launch chain's certificates, exhaustively: the SAME batch through the full-plane row-strip kernel (every cell of every
+        matrix computed, any path followed) into second buffers; every aligned string and every record must be equal.
+        -> (tasks that are equal, seconds of the full-plane pass)"""
+        torch = self.torch
+        d_aln_read, d_aln_ref, d_records = self.outputs
+        n_tasks, stride, dev = self.n_tasks, self.stride, self.dev
+        b_read = torch.zeros((n_tasks, stride), dtype=torch.uint8, device=dev)
+        b_ref = torch.zeros((n_tasks, stride), dtype=torch.uint8, device=dev)
+        b_rec = torch.zeros((n_tasks, 32), dtype=torch.uint8, device=dev)
+        self.ctx.set_kernel_mode("full")
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        self.align_into(b_read, b_ref, b_rec)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf
+        self.ctx.set_kernel_mode(self.kernel)
+        equal_n = 0
+        cols = torch.arange(stride, device=dev)[None, :]
+        recs_t = d_records.view(torch.int16)
+        for a0 in range(0, n_tasks, 1_000_000):
+            a1 = min(n_tasks, a0 + 1_000_000)
+            valid = cols < recs_t[a0:a1, 0].to(torch.int64)[:, None]
+            same = (((d_aln_read[a0:a1] == b_read[a0:a1]) & (d_aln_ref[a0:a1] == b_ref[a0:a1])) | ~valid).all(1)
+            same &= (d_records[a0:a1] == b_rec[a0:a1]).all(1)
+            equal_n += int(same.sum().item())
+        del b_read, b_ref, b_rec
+        torch.cuda.empty_cache()
+        return equal_n, tf
+
+    def properties_hold(self):
+        """Size-independent properties on EVERY alignment of the batch (device-side, in slices): no double-gap column; removing the gaps
+        gives back the read and the amplicon (every base exactly once, in order); `matches` and `all_deletion_bases` of the record agree
+        with the strings."""
+        torch = self.torch
+        d_aln_read, d_aln_ref, d_records = self.outputs
+        refs, k, n, L, Lmax, stride, dev, n_tasks = self.wl["refs"], self.k, self.n, self.L, self.Lmax, self.stride, self.dev, self.n_tasks
+        props = True
+        Li_t = torch.tensor([len(r[0]) for r in refs], dtype=torch.int64, device=dev)
+        d_amps = torch.zeros((k, Lmax), dtype=torch.uint8, device=dev)
+        for r in range(k):
+            d_amps[r, :len(refs[r][0])] = torch.from_numpy(np.frombuffer(refs[r][0].encode(), dtype=np.uint8).copy()).to(dev)
+        d_reads2 = self.d_reads.view(n, L)
+        recs_t = d_records.view(torch.int16)                      # aln_len, matches are the first two uint16 (< 32768 here)
+        cols = torch.arange(stride, device=dev)[None, :]
+        dash = ord("-")
+        SL = 500_000
+        for a0 in range(0, n_tasks, SL):
+            a1 = min(n_tasks, a0 + SL)
+            tt = torch.arange(a0, a1, device=dev)
+            rid_ = ((tt % k) if self.all_refs else
+                    (self.d_rids[a0:a1].to(torch.int64) if self.d_rids is not None else torch.zeros(a1 - a0, dtype=torch.int64, device=dev)))
+            rd_ = (tt // k) if self.all_refs else tt
+            Li_ = Li_t[rid_]
+            T_ = recs_t[a0:a1, 0].to(torch.int64)
+            mt_ = recs_t[a0:a1, 1].to(torch.int64)
+            delb_ = recs_t[a0:a1, 9].to(torch.int64)
+            R_, F_ = d_aln_read[a0:a1], d_aln_ref[a0:a1]
+            valid = cols < T_[:, None]
+            rgap = (R_ == dash) & valid
+            fgap = (F_ == dash) & valid
+            ok = not bool((rgap & fgap).any())
+            keep_r, keep_f = valid & ~rgap, valid & ~fgap
+            ok = ok and bool((keep_r.sum(1) == L).all()) and bool((keep_f.sum(1) == Li_).all())
+            if ok:
+                ok = bool(torch.equal(R_[keep_r].view(a1 - a0, L), d_reads2[rd_]))
+                # the reference's bases in order: rank of every kept column -> compare with the amplicon at that rank
+                rank_f = torch.cumsum(keep_f.to(torch.int32), 1) - 1
+                want = d_amps[rid_][:, :].gather(1, rank_f.clamp(min=0, max=Lmax - 1).to(torch.int64))
+                ok = ok and bool(((F_ == want) | ~keep_f).all())
+                ok = ok and bool(torch.equal(((R_ == F_) & keep_r & keep_f).sum(1), mt_)) and bool(torch.equal(rgap.sum(1), delb_))
+                del rank_f, want
+            props = props and ok
+            del valid, rgap, fgap, keep_r, keep_f
+        return props
+
+    def tallies(self):
+        host = self.d_counts.cpu().numpy()
+        return [self.layout.unpack(host, r, len(self.wl["refs"][r][0])) for r in range(self.k)]
+
+    def free(self):
+        self.out_sets = []
+        self.d_reads = self.d_offsets = self.d_rids = self.d_weights = self.d_counts = None
+        self.torch.cuda.empty_cache()
+
+
+def _dedup_on_leg(job, reads, steps):
+    """The same batch the way the reference feeds its aligner -- "dedup on": only the UNIQUE reads are aligned, their multiplicities are the
+    weights of the count pass (SURVEY 8d asks for both; the headline is dedup off).  The de-duplication itself (host, outside the timed
+    region here; the e2e leg times it inside a FASTQ -> tensors run) is a 64-bit hash + an exact byte comparison of every read with its
+    group's first member."""
+    torch, C, ctx, dev, L, n, k, layout = job.torch, job.C, job.ctx, job.dev, job.L, job.n, job.k, job.layout
+    stride, stream = job.stride, job.stream
+    t_d = time.perf_counter()
+    W = (L + 7) // 8
+    padded = np.zeros((n, W * 8), dtype=np.uint8)
+    padded[:, :L] = reads
+    rng_h = np.random.default_rng(99)
+    m1 = (rng_h.integers(1, 1 << 62, W, dtype=np.uint64) << np.uint64(1)) | np.uint64(1)
+    m2 = (rng_h.integers(1, 1 << 62, W, dtype=np.uint64) << np.uint64(1)) | np.uint64(1)
+    with np.errstate(over="ignore"):
+        x = padded.view(np.uint64) * m1[None, :]                  # (a plain multiply-sum loses the high bytes of a word: two
+        x ^= x >> np.uint64(32)                                   #  differences there cancel with probability 1/256 -- fold them down first)
+        x *= m2[None, :]
+        h = x.sum(axis=1, dtype=np.uint64)
+    del padded, x
+    _, first, inverse, mult_counts = np.unique(h, return_index=True, return_inverse=True, return_counts=True)
+    for c0 in range(0, n, 1 << 20):                               # every read equals the first read of its hash group
+        c1 = min(n, c0 + (1 << 20))
+        if not bool((reads[c0:c1] == reads[first[inverse[c0:c1]]]).all()):
+            return None
+    nu = len(first)
+    d_ureads = torch.from_numpy(np.ascontiguousarray(reads[first]).reshape(-1)).to(dev)
+    d_uoff = torch.arange(nu + 1, dtype=torch.int64, device=dev) * L
+    d_uw = torch.from_numpy(mult_counts.astype(np.uint32).view(np.int32)).to(dev)
+    host_dedup_s = time.perf_counter() - t_d
+    ua = torch.empty((nu, stride), dtype=torch.uint8, device=dev)    # (own buffers: the checks read the timed batch's outputs)
+    uf = torch.empty((nu, stride), dtype=torch.uint8, device=dev)
+    ur = torch.empty((nu, 32), dtype=torch.uint8, device=dev)
+    d_ucounts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
+
+    def dedup_step():
+        job.al.align_device(nu, d_ureads.data_ptr(), d_uoff.data_ptr(), ua.data_ptr(), uf.data_ptr(), ur.data_ptr(), stride, L, stream=stream)
+        d_ucounts.zero_()
+        C.accumulate_device(ctx, layout, nu, ua.data_ptr(), uf.data_ptr(), stride, ur.data_ptr(), d_ucounts.data_ptr(),
+                            d_weights=d_uw.data_ptr(), min_matches=job.min_matches, stream=stream)
+    dedup_step()
+    torch.cuda.synchronize()
+    t_u = time.perf_counter()
+    for _ in range(steps):
+        dedup_step()
+    torch.cuda.synchronize()
+    dt_u = time.perf_counter() - t_u
+    # the weighted tensor of the unique reads = the tensor of all reads (but for the scalar that counts ALIGNMENTS, not reads)
+    tu, ta = d_ucounts.clone(), job.d_counts.clone()
+    for t_ in (tu, ta):
+        t_.view(k, -1)[:, layout.scalar_offset("alignments_counted")] = 0
+    same_tensor = bool(torch.equal(tu, ta))
+    out = {"unique_reads": int(nu), "reads_per_s": n * steps / dt_u, "ms_per_step": 1e3 * dt_u / steps,
+           "count_tensor_equals_dedup_off": same_tensor, "host_dedup_seconds_not_timed": host_dedup_s,
+           "note": "the batch's unique reads aligned once, multiplicities as weights of the count pass; reads/s counts every read of the batch"}
+    del d_ureads, d_uoff, d_uw, ua, uf, ur
+    torch.cuda.empty_cache()
+    return out
+
+
+def _e2e_prepare(reads, workers):
+    """(host, before HIP) the headline's reads as a FASTQ file in /dev/shm -- plain, and BGZF-compressed by a process pool -- sized down if
+    the file system is too small.  -> dict(dir, plain, bgzf, reads, bytes_plain, bytes_bgzf, write_s) or {"skipped": reason}"""
+    from crispresso2_amd import synth
+    n, L = reads.shape
+    per = 2 * L + 16
+    want = os.environ.get("C2_BENCH_E2E_DIR")
+    cands = [want] if want else ["/dev/shm", tempfile.gettempdir()]
+    for base in cands:
+        try:
+            free = shutil.disk_usage(base).free
+        except OSError:
+            continue
+        m = n
+        if free < 1.4 * per * n:
+            m = int(free / (1.4 * per))
+            m -= m % 1000
+        if m < min(n, 100_000):
+            continue
+        d = None
+        try:
+            d = tempfile.mkdtemp(prefix="c2bench_", dir=base)
+            t0 = time.perf_counter()
+            plain, bgzf = os.path.join(d, "reads.fastq"), os.path.join(d, "reads.bgzf.fastq.gz")
+            b1 = synth.write_fastq(reads[:m], plain)
+            t1 = time.perf_counter()
+            b2 = synth.write_bgzf(plain, bgzf, workers=workers)
+            return dict(dir=d, plain=plain, bgzf=bgzf, reads=m, bytes_plain=b1, bytes_bgzf=b2, write_plain_s=t1 - t0, write_bgzf_s=time.perf_counter() - t1)
+        except OSError:
+            if d:
+                shutil.rmtree(d, ignore_errors=True)
+            continue
+    return {"skipped": "no file system with room for the FASTQ file (%s)" % ", ".join(cands)}
+
+
+def _e2e_leg(files, ctx, L, matrix, repeat=2):
+    """FASTQ -> count tensors with the wall time of every stage (pipeline.quantify_fastq), the plain file and the BGZF file."""
+    from types import SimpleNamespace
+    from crispresso2_amd import pipeline, refs as RF, synth
+    amp, g, inc = synth.amplicon_setup(L)
+    args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=GO, needleman_wunsch_gap_extend=GE,
+                           ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
+                           assign_ambiguous_alignments_to_first_reference=False, expand_ambiguous_alignments=False, discard_indel_reads=False)
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=MIN_ALN_SCORE)
+    out = {"reads": files["reads"], "file_bytes": files["bytes_plain"], "file_bytes_bgzf": files["bytes_bgzf"],
+           "file_system": os.path.dirname(files["dir"]), "write_seconds_not_timed": {"plain": files["write_plain_s"], "bgzf": files["write_bgzf_s"]}}
+    tallies = {}
+    for kind, path in (("plain", files["plain"]), ("bgzf", files["bgzf"])):
+        runs = []
+        for rep in range(repeat + 1):                                # the first run is the warm-up (context, allocations, page cache)
+            tm = {}
+            t0 = time.perf_counter()
+            res = pipeline.quantify_fastq(path, {"Reference": ref}, ["Reference"], matrix, args, ctx=ctx, timings=tm)
+            runs.append((time.perf_counter() - t0, tm))
+            c = res.per_ref["Reference"]
+            tallies[kind] = (res.stats["N_TOT_READS"], res.stats["N_TOTAL"], c["counts_total"], c["counts_modified"], c["counts_insertion"],
+                             c["counts_deletion"], c["counts_substitution"])
+            uniq = res.stats["N_COMPUTED_ALN"] + res.stats["N_COMPUTED_NOTALN"]
+            del res
+            time.sleep(0.3)                                          # (the run's buffers are unmapped by helper threads: let them finish)
+        dt, tm = min(runs[1:], key=lambda x: x[0])
+        out[kind] = {"seconds": dt, "reads_per_s": files["reads"] / dt, "seconds_all_runs": [r[0] for r in runs], "stage_seconds": tm,
+                     "unique_reads": uniq}
+    out["reads_per_s"] = out["plain"]["reads_per_s"]
+    out["stage_seconds"] = out["plain"]["stage_seconds"]
+    out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"]
+    out["tallies"] = dict(zip(("N_TOT_READS", "N_TOTAL", "counts_total", "modified", "with_insertion", "with_deletion", "with_substitution"),
+                              tallies["plain"]))
+    out["note"] = ("pipeline.quantify_fastq on the headline's reads as a FASTQ file (qualities 'I'), page cache warm: native ingest + exact "
+                   "de-duplication, seed test, alignments of the unique reads, selection, reverse-complement merge, count kernel; best of %d "
+                   "runs after a warm-up; reads/s counts every read of the file" % repeat)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,22 +517,30 @@ def main():
     ap.add_argument("--check", type=int, default=300, help="reads compared with the C oracle after the timed region (0 = no checks at all)")
     ap.add_argument("--no-full-plane-check", action="store_true", help="skip the chain-vs-full-plane comparison of every alignment")
     ap.add_argument("--no-dedup-leg", action="store_true", help="skip the dedup-on measurement after the timed region (single-amplicon configurations)")
+    ap.add_argument("--extras", choices=["auto", "on", "off"], default="auto",
+                    help="the legs after the headline: int32 chain, the other BASELINE configurations, FASTQ -> tensors (auto: on for the "
+                         "plain default run -- no --config / --reads / --len / --kernel)")
+    ap.add_argument("--no-extras", dest="extras", action="store_const", const="off")
+    ap.add_argument("--extra-reads", type=int, default=0, help="reads per GPU of the other configurations and of the FASTQ leg (0 = full size)")
+    ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--overlap-count", action="store_true",
                     help="run the count pass of batch k on a second stream while batch k+1 is aligned into a second set of output buffers "
                          "(measured on MI355X, profiles/r02/README.md: no gain -- the persistent workgroups of the launch chain leave the "
                          "count kernel nothing to run on, and it slows them; the default keeps one stream)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     L = args.L or CONFIG_DEFAULTS[args.config][0]
     n = args.reads or CONFIG_DEFAULTS[args.config][1]
-    GO, GE, MIN_ALN_SCORE = -20, -2, 60.0
     matrix_path = os.path.join(ROOT, "crispresso2_amd", "EDNAFULL")
+    extras = args.extras == "on" or (args.extras == "auto" and args.config == 3 and not args.reads and not args.L and args.kernel == "auto"
+                                     and not args.overlap_count)
 
     # ---------- everything that fork()s happens before this process touches HIP ----------
     ncpu = os.cpu_count() or 1
@@ -158,173 +558,58 @@ def main():
         from oracle import cpu_baseline as cb
         cpu_baseline, cpu_legs = cb.run(reads, refs, matrix_path, GO, GE, ref_ids=wl["ref_ids"], all_refs=all_refs, cores=ncpu,
                                         target_seconds=args.cpu_seconds)
+    other_wl, e2e_files = {}, None
+    if extras:
+        t0 = time.perf_counter()
+        for cfg in (2, 4, 5):
+            if cfg != args.config:
+                Lc, nc = CONFIG_DEFAULTS[cfg]
+                other_wl[cfg] = (Lc, build_workload(cfg, Lc, min(nc, args.extra_reads) if args.extra_reads else nc, rank, workers))
+        t_gen_other = time.perf_counter() - t0
+        if rank == 0 and world == 1 and not all_refs and wl["ref_ids"] is None:
+            try:
+                e2e_files = _e2e_prepare(reads[:args.extra_reads] if args.extra_reads else reads, min(64, max(workers, ncpu // 4)))
+            except Exception as e:                                   # the headline must not die of a side leg
+                e2e_files = {"skipped": "writing the FASTQ files failed: %r" % (e,)}
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("C2_BENCH_BACKEND", "nccl")               # ("gloo": the CPU test of the multi-rank plumbing, tests/test_bench_on_emulator.py)
+    dev_index = local_rank
+    if world > 1 and backend != "nccl" and torch.cuda.is_available() and torch.cuda.device_count() <= local_rank:
+        dev_index = local_rank % torch.cuda.device_count()              # (plumbing runs only: several gloo ranks sharing the box's GPUs)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    ranks_seen, rccl_version = 1, None
     if world > 1:
-        backend = os.environ.get("C2_BENCH_BACKEND", "nccl")           # ("gloo": the CPU test of the multi-rank plumbing, tests/test_bench_on_emulator.py)
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        ranks_seen = dist.get_world_size()
+    try:
+        v = torch.cuda.nccl.version()
+        rccl_version = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        pass
 
     from crispresso2_amd import CRISPResso2Align as A, _native
     from crispresso2_amd import counts as C
-    from crispresso2_amd.batch import BatchAligner
     m = A.read_matrix(matrix_path)
-    ctx = _native.Context(local_rank)
+    ctx = _native.Context(dev_index)
     ctx.set_band(args.band, args.band_wgs)
-    ctx.set_kernel_mode(args.kernel)
-    al = BatchAligner([r[0] for r in refs], [r[1] for r in refs], [r[2] for r in refs], m, GO, GE, ctx=ctx)
-    stride = al.stride_for(L)
-    Lmax = al.max_ref_len
+    job = Job(ctx, wl, L, m, dev, world, kernel=args.kernel, overlap_count=args.overlap_count)
+    stride, Lmax, layout = job.stride, job.Lmax, job.layout
+    tm = job.timed(args.warmup, args.steps)
+    dt, kernel_ms, first_ms, launches = tm["dt"], tm["kernel_ms"], tm["first_ms"], tm["launches"]
+    tiers = ctx.tier_info()
 
-    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
-    d_offsets = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
-    d_rids = None if wl["ref_ids"] is None else torch.from_numpy(wl["ref_ids"].astype(np.int16)).to(dev)
-    # output buffers: one set; two with --overlap-count, so that batch k+1 is aligned while batch k is still being counted
-    n_sets = 2 if args.overlap_count else 1
-    out_sets = [(torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev), torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev),
-                 torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)) for _ in range(n_sets)]
-    d_aln_read, d_aln_ref, d_records = out_sets[0]
-    t_align = torch.cuda.current_stream()
-    t_count = torch.cuda.Stream(device=dev) if args.overlap_count else t_align
-    stream = t_align.cuda_stream
-    count_stream = t_count.cuda_stream
-    aligned_ev = [torch.cuda.Event() for _ in range(n_sets)]
-    counted_ev = [None] * n_sets
-    # per-amplicon count tensor (CRISPRessoCORE.py:3865-4115 on the device) -- the only thing the GPUs exchange
-    layout = C.CountLayout(k, Lmax, L)
-    d_counts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
-    min_matches = C.min_matches_table([MIN_ALN_SCORE] * k, Lmax + L)          # --default_min_aln_score 60
-    d_weights = d_selstats = None
-    if all_refs:
-        d_weights = torch.zeros(n_tasks, dtype=torch.int32, device=dev)
-        d_selstats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
-        min_mscore = C.min_mscore_table([MIN_ALN_SCORE] * k)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
-
-    def align_into(a_read, a_ref, recs):
-        al.align_device(n, d_reads.data_ptr(), d_offsets.data_ptr(), a_read.data_ptr(), a_ref.data_ptr(), recs.data_ptr(), stride, L,
-                        d_ref_ids=None if d_rids is None else d_rids.data_ptr(), all_refs=all_refs, stream=stream)
-
-    step_no = [0]
-
-    def step(e=None):
-        """One batch: launch chain on the align stream into buffer set i; reference choice, count pass and all-reduce on the count
-        stream (the same stream unless --overlap-count).  Set i is aligned into again only after its previous batch has been counted."""
-        i = step_no[0] % n_sets
-        step_no[0] += 1
-        a_read, a_ref, recs = out_sets[i]
-        if counted_ev[i] is not None:
-            t_align.wait_event(counted_ev[i])
-        if e: e[0].record(t_align)
-        align_into(a_read, a_ref, recs)
-        if e: e[1].record(t_align)
-        aligned_ev[i].record(t_align)
-        t_count.wait_event(aligned_ev[i])
-        with torch.cuda.stream(t_count):
-            if e: e[4].record(t_count)
-            if all_refs:
-                # strand / best-amplicon choice on the device (CRISPRessoCORE.py:697-707) -> the weight of every alignment in the count pass
-                d_selstats.zero_()
-                C.select_best_device(ctx, n, k, recs.data_ptr(), min_mscore, C.SELECT_DROP_AMBIGUOUS, Lmax + L,
-                                     d_weights=d_weights.data_ptr(), d_stats=d_selstats.data_ptr(), stream=count_stream)
-            if e: e[2].record(t_count)
-            d_counts.zero_()
-            C.accumulate_device(ctx, layout, n_tasks, a_read.data_ptr(), a_ref.data_ptr(), stride, recs.data_ptr(),
-                                d_counts.data_ptr(), d_weights=d_weights.data_ptr() if all_refs else None,
-                                min_matches=None if all_refs else min_matches, flags=C.FLAG_ALL_REFS_LAYOUT if all_refs else 0, stream=count_stream)
-            C.all_reduce(d_counts)
-            if e: e[3].record(t_count)
-            counted_ev[i] = torch.cuda.Event()
-            counted_ev[i].record(t_count)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.timing_enable(True)
-    t0 = time.perf_counter()
-    for s_ in range(args.steps):
-        step(ev[s_])
-    fence()
-    dt = time.perf_counter() - t0
-    kernel_ms, first_ms, launches = ctx.timing_read_split()
-    ctx.timing_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    align_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / max(args.steps, 1)
-    select_ms = sum(e[4].elapsed_time(e[2]) for e in ev) / max(args.steps, 1)
-    count_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / max(args.steps, 1)
-
-    # ---------- after the timed region: the same batch the way the reference feeds its aligner -- "dedup on": only the UNIQUE reads are
-    # aligned, their multiplicities are the weights of the count pass (SURVEY 8d asks for both; the headline above is dedup off).
-    # The de-duplication itself (host, outside the timed region here; tools/e2e_rate.py times it inside a FASTQ -> tensors run) is
-    # a 64-bit hash + an exact byte comparison of every read with its group's first member.
     dedup_on = None
     if rank == 0 and world == 1 and not all_refs and wl["ref_ids"] is None and not args.no_dedup_leg:
-        t_d = time.perf_counter()
-        W = (L + 7) // 8
-        padded = np.zeros((n, W * 8), dtype=np.uint8)
-        padded[:, :L] = reads
-        rng_h = np.random.default_rng(99)
-        m1 = (rng_h.integers(1, 1 << 62, W, dtype=np.uint64) << np.uint64(1)) | np.uint64(1)
-        m2 = (rng_h.integers(1, 1 << 62, W, dtype=np.uint64) << np.uint64(1)) | np.uint64(1)
-        with np.errstate(over="ignore"):
-            x = padded.view(np.uint64) * m1[None, :]                  # (a plain multiply-sum loses the high bytes of a word: two
-            x ^= x >> np.uint64(32)                                   #  differences there cancel with probability 1/256 -- fold them down first)
-            x *= m2[None, :]
-            h = x.sum(axis=1, dtype=np.uint64)
-        del padded, x
-        _, first, inverse, mult_counts = np.unique(h, return_index=True, return_inverse=True, return_counts=True)
-        exact = True
-        for c0 in range(0, n, 1 << 20):                               # every read equals the first read of its hash group
-            c1 = min(n, c0 + (1 << 20))
-            exact = exact and bool((reads[c0:c1] == reads[first[inverse[c0:c1]]]).all())
-        if exact:
-            nu = len(first)
-            d_ureads = torch.from_numpy(np.ascontiguousarray(reads[first]).reshape(-1)).to(dev)
-            d_uoff = torch.arange(nu + 1, dtype=torch.int64, device=dev) * L
-            d_uw = torch.from_numpy(mult_counts.astype(np.uint32).view(np.int32)).to(dev)
-            host_dedup_s = time.perf_counter() - t_d
-            ua = torch.empty((nu, stride), dtype=torch.uint8, device=dev)    # (own buffers: the checks below read the timed batch's outputs)
-            uf = torch.empty((nu, stride), dtype=torch.uint8, device=dev)
-            ur = torch.empty((nu, 32), dtype=torch.uint8, device=dev)
-            d_ucounts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
-
-            def dedup_step():
-                al.align_device(nu, d_ureads.data_ptr(), d_uoff.data_ptr(), ua.data_ptr(), uf.data_ptr(), ur.data_ptr(), stride, L, stream=stream)
-                d_ucounts.zero_()
-                C.accumulate_device(ctx, layout, nu, ua.data_ptr(), uf.data_ptr(), stride, ur.data_ptr(), d_ucounts.data_ptr(),
-                                    d_weights=d_uw.data_ptr(), min_matches=min_matches, stream=stream)
-            dedup_step()
-            torch.cuda.synchronize()
-            t_u = time.perf_counter()
-            for _ in range(args.steps):
-                dedup_step()
-            torch.cuda.synchronize()
-            dt_u = time.perf_counter() - t_u
-            # the weighted tensor of the unique reads = the tensor of all reads (but for the scalar that counts ALIGNMENTS, not reads)
-            tu, ta = d_ucounts.clone(), d_counts.clone()
-            for t_ in (tu, ta):
-                t_.view(k, -1)[:, layout.scalar_offset("alignments_counted")] = 0
-            same_tensor = bool(torch.equal(tu, ta))
-            dedup_on = {"unique_reads": int(nu), "reads_per_s": n * args.steps / dt_u, "ms_per_step": 1e3 * dt_u / args.steps,
-                        "count_tensor_equals_dedup_off": same_tensor, "host_dedup_seconds_not_timed": host_dedup_s,
-                        "note": "the batch's unique reads aligned once, multiplicities as weights of the count pass; reads/s counts every read of the batch"}
-            del d_ureads, d_uoff, d_uw, ua, uf, ur
-            torch.cuda.empty_cache()
+        dedup_on = _dedup_on_leg(job, reads, args.steps)
     # ---------- algorithmic bytes of one launch, parity checks ----------
-    while len(out_sets) > 1:                                      # (every set holds the same bytes: the checks read set 0)
-        out_sets.pop()
+    while len(job.out_sets) > 1:                                  # (every set holds the same bytes: the checks read set 0)
+        job.out_sets.pop()
     torch.cuda.empty_cache()
+    d_aln_read, d_aln_ref, d_records = job.outputs
+    d_rids = job.d_rids
     rec = d_records.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
     ok_status = bool((rec["status"] == 0).all())
     aln_cols = int(rec["aln_len"].astype(np.int64).sum())
@@ -340,7 +625,6 @@ def main():
         cells = int(ref_cells[wl["ref_ids"].astype(np.int64)].sum())
     else:
         cells = int(n * ref_cells[0])
-    tiers = ctx.tier_info()
 
     def task_ref(t):
         return (t % k) if all_refs else (int(wl["ref_ids"][t]) if wl["ref_ids"] is not None else 0)
@@ -394,75 +678,15 @@ def main():
             checks["reference_compared_n"] = compared
             checks["reference_identical_n"] = identical
             checks["reference_identical"] = bool(compared == identical)
-    # (3) size-independent properties on EVERY alignment of the full-size batch (device-side, in slices): no double-gap column;
-    # removing the gaps gives back the read and the amplicon (every base exactly once, in order); `matches` and
-    # `all_deletion_bases` of the record agree with the strings
+    # (3) size-independent properties on EVERY alignment of the full-size batch
     if args.check > 0:
-        props = True
-        Li_t = torch.tensor([len(r[0]) for r in refs], dtype=torch.int64, device=dev)
-        d_amps = torch.zeros((k, Lmax), dtype=torch.uint8, device=dev)
-        for r in range(k):
-            d_amps[r, :len(refs[r][0])] = torch.from_numpy(np.frombuffer(refs[r][0].encode(), dtype=np.uint8).copy()).to(dev)
-        d_reads2 = d_reads.view(n, L)
-        recs_t = d_records.view(torch.int16)                      # aln_len, matches are the first two uint16 (< 32768 here)
-        cols = torch.arange(stride, device=dev)[None, :]
-        colsL = torch.arange(Lmax, device=dev)[None, :]
-        dash = ord("-")
-        SL = 500_000
-        for a0 in range(0, n_tasks, SL):
-            a1 = min(n_tasks, a0 + SL)
-            tt = torch.arange(a0, a1, device=dev)
-            rid_ = (tt % k) if all_refs else (d_rids[a0:a1].to(torch.int64) if d_rids is not None else torch.zeros(a1 - a0, dtype=torch.int64, device=dev))
-            rd_ = (tt // k) if all_refs else tt
-            Li_ = Li_t[rid_]
-            T_ = recs_t[a0:a1, 0].to(torch.int64)
-            mt_ = recs_t[a0:a1, 1].to(torch.int64)
-            delb_ = recs_t[a0:a1, 9].to(torch.int64)
-            R_, F_ = d_aln_read[a0:a1], d_aln_ref[a0:a1]
-            valid = cols < T_[:, None]
-            rgap = (R_ == dash) & valid
-            fgap = (F_ == dash) & valid
-            ok = not bool((rgap & fgap).any())
-            keep_r, keep_f = valid & ~rgap, valid & ~fgap
-            ok = ok and bool((keep_r.sum(1) == L).all()) and bool((keep_f.sum(1) == Li_).all())
-            if ok:
-                ok = bool(torch.equal(R_[keep_r].view(a1 - a0, L), d_reads2[rd_]))
-                # the reference's bases in order: rank of every kept column -> compare with the amplicon at that rank
-                rank_f = torch.cumsum(keep_f.to(torch.int32), 1) - 1
-                want = d_amps[rid_][:, :].gather(1, rank_f.clamp(min=0, max=Lmax - 1).to(torch.int64))
-                ok = ok and bool(((F_ == want) | ~keep_f).all())
-                ok = ok and bool(torch.equal(((R_ == F_) & keep_r & keep_f).sum(1), mt_)) and bool(torch.equal(rgap.sum(1), delb_))
-                del rank_f, want
-            props = props and ok
-            del valid, rgap, fgap, keep_r, keep_f
-        checks["full_batch_properties_hold"] = props
-        del colsL
-    # (4) the launch chain's certificates, exhaustively: the SAME batch through the full-plane row-strip kernel (every cell
-    # of every matrix computed, any path followed) into second buffers; every aligned string and every record must be equal
+        checks["full_batch_properties_hold"] = job.properties_hold()
+    # (4) the launch chain's certificates, exhaustively: the same batch through the full-plane kernel alone
     if rank == 0 and args.check > 0 and not args.no_full_plane_check and args.kernel == "auto":
-        b_read = torch.zeros((n_tasks, stride), dtype=torch.uint8, device=dev)
-        b_ref = torch.zeros((n_tasks, stride), dtype=torch.uint8, device=dev)
-        b_rec = torch.zeros((n_tasks, 32), dtype=torch.uint8, device=dev)
-        ctx.set_kernel_mode("full")
-        torch.cuda.synchronize()
-        tf = time.perf_counter()
-        align_into(b_read, b_ref, b_rec)
-        torch.cuda.synchronize()
-        tf = time.perf_counter() - tf
-        ctx.set_kernel_mode(args.kernel)
-        equal_n = 0
-        cols = torch.arange(stride, device=dev)[None, :]
-        recs_t = d_records.view(torch.int16)
-        for a0 in range(0, n_tasks, 1_000_000):
-            a1 = min(n_tasks, a0 + 1_000_000)
-            valid = cols < recs_t[a0:a1, 0].to(torch.int64)[:, None]
-            same = (((d_aln_read[a0:a1] == b_read[a0:a1]) & (d_aln_ref[a0:a1] == b_ref[a0:a1])) | ~valid).all(1)
-            same &= (d_records[a0:a1] == b_rec[a0:a1]).all(1)
-            equal_n += int(same.sum().item())
+        equal_n, tf = job.chain_equals_full_plane()
         checks["chain_equals_full_plane_n"] = equal_n
         checks["chain_equals_full_plane"] = bool(equal_n == n_tasks)
         checks["full_plane_pass_s"] = tf
-        del b_read, b_ref, b_rec
 
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
@@ -480,25 +704,27 @@ def main():
     done_first = n_tasks - (tiers[0] if tiers else 0)
     alg_first = bytes_in + int(bytes_out * (done_first / float(n_tasks)))
     achieved_gbs = alg_first / avg_first_s / 1e9 if avg_first_s > 0 else 0.0
-    # HBM bytes and instruction counts per alignment from the committed PMC passes of THIS round's build (separate rocprofv3
+    # HBM bytes and instruction counts per alignment from the committed PMC passes of the newest round's build (separate rocprofv3
     # --pmc runs of this same script over 2 M reads; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming
     # reads); null when the profile file is absent or the run is not the default one
     traffic = traffic_src = None
     valu_per_aln = salu_per_aln = None
-    pmc_path = os.path.join(PROFILE_DIR, "pmc_summary_default.json")
-    if os.path.exists(pmc_path) and args.config == 3 and L == 250 and args.kernel == "auto":
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", r_, "pmc_summary_default.json") for r_ in PROFILE_ROUNDS) if os.path.exists(q)), None)
+    if pmc_path and args.config == 3 and L == 250 and args.kernel == "auto":
         with open(pmc_path) as fh:
             pj = json.load(fh)
         pmc = pj["kernels"].get(dominant)
         pmc_reads = float(pj.get("reads", 2.0e6))
+        pmc_rel = os.path.relpath(pmc_path, ROOT)
         if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / pmc_reads * n      # bytes per launch of n alignments
-            traffic_src = ("profiles/r02/pmc_summary_default.json: (2*FETCH_SIZE + WRITE_SIZE) KB of %s over %d reads, scaled to "
-                           "the reads of one launch; includes the kernel's pointer-word scratch plane" % (dominant, int(pmc_reads)))
+            traffic_src = ("%s: (2*FETCH_SIZE + WRITE_SIZE) KB of %s over %d reads, scaled to the reads of one launch; includes the "
+                           "kernel's pointer-word scratch plane" % (pmc_rel, dominant, int(pmc_reads)))
         if pmc and "SQ_INSTS_VALU" in pmc:
             valu_per_aln = pmc["SQ_INSTS_VALU"] / pmc_reads
             salu_per_aln = pmc.get("SQ_INSTS_SALU", 0.0) / pmc_reads
-    tallies = [layout.unpack(d_counts.cpu().numpy(), r, len(refs[r][0])) for r in range(k)]
+    tallies = job.tallies()
+    selection = dict(zip(C.SELECT_STATS, job.d_selstats.cpu().numpy().tolist())) if all_refs else None
     valu = {"cells_per_s": cells / avg_launch_s if avg_launch_s > 0 else 0.0,
             "gcups": cells / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0,
             "note": "gcups = full-matrix cell updates the reference would perform per second of launch-chain time (the banded kernels "
@@ -507,7 +733,7 @@ def main():
             "kernel": dominant,
             "wave_instr_per_alignment": valu_per_aln, "salu_instr_per_alignment": salu_per_aln,
             "cycles_per_instr_measured": VALU_MEASURED_CYCLES_PER_INSTR,
-            "cycles_per_instr_source": "profiles/r01/valu_microbench.txt, valu_microbench2.txt (tools/valu_microbench*.hip)",
+            "cycles_per_instr_source": VALU_MEASURED_SOURCE,
             "peak_wave_instr_per_s_simd32": VALU_SIMD32_WAVE_INSTR_PER_S,
             "peak_lane_ops_per_s": VALU_SIMD32_WAVE_INSTR_PER_S * 64}
     if valu_per_aln and avg_first_s > 0:
@@ -516,6 +742,66 @@ def main():
         valu["frac_of_measured_issue"] = rate / (N_SIMD * CLOCK_HZ / VALU_MEASURED_CYCLES_PER_INSTR)
         valu["frac_of_simd32_peak"] = rate / VALU_SIMD32_WAVE_INSTR_PER_S
 
+    # ---------- after the headline: the int32 chain on the same batch, the other BASELINE shapes, FASTQ -> tensors ----------
+    int32_chain = other_configs = e2e = None
+    if extras:
+        # the same reads, buffers and step with the 32-bit kernels only (the reference's DP is C int, pyx:142-147): all ranks take part
+        ctx.set_kernel_mode("diag4")
+        job.kernel = "diag4"
+        t32 = job.timed(1, args.extra_steps)
+        rec32_same = bool(torch.equal(job.outputs[2].cpu(), torch.from_numpy(rec.view(np.uint8).reshape(-1, 32))))
+        int32_chain = {"reads_per_s": t32["reads_per_s"], "ms_per_step": 1e3 * t32["dt"] / args.extra_steps, "steps": args.extra_steps,
+                       "kernel_chain": chain_names["diag4"] + [chain[-1]], "dtype": "int32",
+                       "tasks_left_after_each_banded_launch": ctx.tier_info(), "align_chain_ms": t32["align_ms"],
+                       "records_equal_the_packed_chain": rec32_same,
+                       "note": "c2_set_kernel_mode(diag4): the same batch, buffers and step as the headline with every DP cell in int32"}
+        ctx.set_kernel_mode(args.kernel)
+        job.kernel = args.kernel
+    job.free()
+    del job, d_aln_read, d_aln_ref, d_records
+    torch.cuda.empty_cache()
+    if extras:
+        other_configs = {"data_generation_s": t_gen_other}
+        for cfg, (Lc, wlc) in sorted(other_wl.items()):
+            try:
+                jc = Job(ctx, wlc, Lc, m, dev, world, kernel="auto")
+                tc = jc.timed(1, args.extra_steps)
+                tiers_c = ctx.tier_info()
+                rec_c = jc.outputs[2].cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+                entry = {"workload": wlc["text"], "reads_per_gpu_per_step": jc.n, "alignments_per_gpu_per_step": jc.n_tasks, "n_amplicons": jc.k,
+                         "steps": args.extra_steps, "ms_per_step": 1e3 * tc["dt"] / args.extra_steps, "reads_per_s": tc["reads_per_s"],
+                         "alignments_per_s": tc["alignments_per_s"],
+                         "step_breakdown_ms": {"align_chain": tc["align_ms"], "select_best": tc["select_ms"], "count_vectors_and_all_reduce": tc["count_ms"]},
+                         "tasks_left_after_each_banded_launch": tiers_c, "all_status_ok": bool((rec_c["status"] == 0).all())}
+                del rec_c
+                if rank == 0 and args.check > 0 and not args.no_full_plane_check:
+                    eq, tf = jc.chain_equals_full_plane()
+                    entry["chain_equals_full_plane_n"] = eq
+                    entry["chain_equals_full_plane"] = bool(eq == jc.n_tasks)
+                tl = jc.tallies()
+                entry["reads_aligned_all_gpus"] = int(sum(t_["counts_total"] for t_ in tl))
+                entry["modified"] = int(sum(t_["counts_modified"] for t_ in tl))
+                if jc.all_refs:
+                    entry["selection"] = dict(zip(C.SELECT_STATS, jc.d_selstats.cpu().numpy().tolist()))
+                jc.free()
+                del jc
+            except Exception as e:                                   # (a side leg reports its failure; collectives inside it would hang the
+                entry = {"error": repr(e)}                           #  other ranks only if one rank alone failed -- then the launcher ends the job)
+                if world > 1:
+                    raise
+            other_configs["config%d" % cfg] = entry
+        del other_wl
+        if e2e_files is not None:
+            if "skipped" in e2e_files:
+                e2e = e2e_files
+            else:
+                try:
+                    e2e = _e2e_leg(e2e_files, ctx, L, m)
+                except Exception as e:
+                    e2e = {"error": repr(e)}
+                finally:
+                    shutil.rmtree(e2e_files["dir"], ignore_errors=True)
+
     if rank == 0:
         total_reads = world * n * args.steps
         out = {
@@ -523,6 +809,8 @@ def main():
             "value": total_reads / dt,
             "unit": "reads/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "collective_backend": (backend if world > 1 else None), "rccl_version": rccl_version,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
@@ -533,7 +821,8 @@ def main():
             "dtype": "int16" if dominant.startswith("c2_align_diagp") else "int32",
             "dtype_note": "exact integer DP, not a precision trade: the packed kernels hold two alignments per 32-bit lane as int16 pairs only for "
                           "references whose DP values the host proves to fit (c2_pk_eligible); everything else runs the int32 kernels; the "
-                          "results are bit-identical either way (checks.chain_equals_full_plane_n covers every alignment of the batch)",
+                          "results are bit-identical either way (checks.chain_equals_full_plane_n covers every alignment of the batch); "
+                          "int32_chain is the same step with the 32-bit kernels only",
             "data": "synthetic",
             "config": {"workload": wl["text"] + ", EDNAFULL, gap_open -20, gap_extend -2, gap_incentive 1 at the cut",
                        "baseline_config": args.config,
@@ -545,7 +834,7 @@ def main():
                        "tasks_left_after_each_banded_launch": tiers,
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
             "alignments_per_s": world * n_tasks * args.steps / dt,
-            "step_breakdown_ms": {"align_chain": align_ms, "select_best": select_ms, "count_vectors_and_all_reduce": count_ms,
+            "step_breakdown_ms": {"align_chain": tm["align_ms"], "select_best": tm["select_ms"], "count_vectors_and_all_reduce": tm["count_ms"],
                                   "note": "rank 0, HIP events on the stream of each phase, mean over the timed steps" +
                                           ("" if not args.overlap_count else "; the count pass of batch k runs on a second stream while batch k+1 is aligned "
                                            "(two output buffer sets), so the phases overlap and do not add up to ms_per_step")},
@@ -555,8 +844,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_first,
                          "algorithmic_bytes_per_read": alg_first / n_tasks,
                          "chain_avg_ms": 1e3 * avg_launch_s, "chain_algorithmic_bytes": alg_bytes,
-                         "note": "integer DP: VALU-issue-bound by construction, HBM fraction is small (SURVEY 8d); see valu and profiles/r02/README.md"},
+                         "note": "integer DP: VALU-issue-bound by construction, HBM fraction is small (SURVEY 8d); see valu and profiles/*/README.md"},
             "valu": valu,
+            "int32_chain": int32_chain,
+            "other_configs": other_configs,
+            "e2e": e2e,
             "dedup_on": dedup_on,
             "cpu_baseline": cpu_baseline,
             "checks": checks,
@@ -565,11 +857,12 @@ def main():
                         "with_deletion": tl["counts_deletion"], "with_substitution": tl["counts_substitution"]} for r, tl in list(enumerate(tallies))[:4]],
             "host": {"cpus": ncpu, "data_generation_s": t_gen},
         }
-        if all_refs:
-            out["selection"] = dict(zip(C.SELECT_STATS, d_selstats.cpu().numpy().tolist()))
+        if selection is not None:
+            out["selection"] = selection
         if cpu_baseline:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_baseline["value"]
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

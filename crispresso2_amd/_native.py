@@ -20,7 +20,7 @@ SYMBOLS = [
     "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
-    "c2_selftest", "c2_selftest_rows", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_timing_read_split", "c2_count_vectors_device", "c2_select_best_device",
+    "c2_selftest", "c2_selftest_rows", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_tier_info_ex", "c2_chain_info", "c2_timing_read_split", "c2_count_vectors_device", "c2_select_best_device",
     "c2_comm_unique_id", "c2_comm_init", "c2_reduce_counts", "c2_comm_destroy",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
@@ -262,6 +262,23 @@ class Context:
         left = (ctypes.c_int32 * 4)()
         self.check(self.lib.c2_tier_info(self.handle, ctypes.byref(n), left), "c2_tier_info")
         return [int(left[k]) for k in range(n.value)]
+
+    CHAIN_KERNELS = ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<4>", "c2_align_diagp_kernel<4>", "c2_align_diagx_kernel<2>",
+                     "c2_align_diagp_kernel<2>", "c2_align_diag_kernel", "banded row-strip", "full plane in HBM scratch"]
+
+    def chain_info(self, max_read_len, n_refs):
+        """-> (names of the kernels in the launch chain for reads up to max_read_len, [packed fill admits reference r])"""
+        kern = ctypes.c_uint32(0)
+        ok = (ctypes.c_uint8 * max(n_refs, 1))()
+        self.check(self.lib.c2_chain_info(self.handle, int(max_read_len), ctypes.byref(kern), ok), "c2_chain_info")
+        return [nm for b, nm in enumerate(self.CHAIN_KERNELS) if kern.value >> b & 1], [bool(ok[r]) for r in range(n_refs)]
+
+    def tier_info_ex(self):
+        """-> (left_over, unpaired) per band tier of the most recent batch (c2_tier_info_ex)."""
+        n = ctypes.c_int32(0)
+        left, un = (ctypes.c_int32 * 8)(), (ctypes.c_int32 * 8)()
+        self.check(self.lib.c2_tier_info_ex(self.handle, ctypes.byref(n), left, un), "c2_tier_info_ex")
+        return [int(left[k]) for k in range(n.value)], [int(un[k]) for k in range(n.value)]
 
     def phase_profile(self, enable):
         """-> the four per-phase cycle counters accumulated so far (then cleared); sets the mode."""

@@ -730,6 +730,35 @@ int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4) {
     return 0;
 }
 
+// Which kernels the launch chain of a batch with reads up to max_read_len consists of, and which references the packed fill admits.
+int c2_chain_info(c2_ctx* ctx, int32_t max_read_len, uint32_t* kernels, uint8_t* ref_packed_ok) {
+    if (!ctx || !kernels) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Geometry g;
+    int rc = geometry(ctx, max_read_len, g);
+    if (rc) return rc;
+    *kernels = (g.pk ? 1u : 0u) | (g.x[0] ? 2u : 0u) | (g.pk2 ? 4u : 0u) | (g.x[1] ? 8u : 0u) | (g.pk3 ? 16u : 0u) | (g.diag ? 32u : 0u) |
+               (g.band_lanes > 0 ? 64u : 0u) | (g.full_hbm ? 128u : 0u);
+    if (ref_packed_ok) for (int r = 0; r < ctx->n_refs; ++r) ref_packed_ok[r] = ctx->ref_pk_ok[r];
+    return 0;
+}
+
+// c2_tier_info plus, per band tier, the tasks its packed kernel could not pair (handed to the 32-bit kernel of the same band).  A tier
+// with a packed kernel therefore finished at least  tasks_in - unpaired - left_over  of its tasks in int16 arithmetic.
+int c2_tier_info_ex(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over8, int32_t* unpaired8) {
+    if (!ctx || !n_tiers || !left_over8 || !unpaired8) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *n_tiers = ctx->last_tiers;
+    for (int k = 0; k < 8; ++k) left_over8[k] = unpaired8[k] = 0;
+    if (ctx->d_fb.p && ctx->last_tiers > 0) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        uint32_t c[16];
+        HIPCHK(ctx, hipMemcpy(c, ctx->d_fb.p, 64, hipMemcpyDeviceToHost));
+        for (int k = 0; k < ctx->last_tiers && k < 8; ++k) { left_over8[k] = (int32_t)c[k]; unpaired8[k] = (int32_t)c[8 + k]; }
+    }
+    return 0;
+}
+
 int c2_timing_enable(c2_ctx* ctx, int on) { if (!ctx) return C2_E_INVALID; ctx->timing = on != 0; return 0; }
 
 int c2_timing_read_split(c2_ctx* ctx, double* total_ms, double* first_kernel_ms, int64_t* launches, int reset) {

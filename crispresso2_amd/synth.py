@@ -115,3 +115,71 @@ def make_variant(amplicon, kind):
     else:
         raise ValueError(kind)
     return ''.join(s)
+
+
+# ---- the same reads as FASTQ files (bench.py's FASTQ -> count tensors leg, tools/e2e_rate.py) ----------------------------------
+def write_fastq(reads, path, chunk=1 << 20):
+    """reads uint8 [n, L] -> a 4-line FASTQ file: '@r<9-digit index>', the read, '+', qualities 'I' * L.  -> bytes written"""
+    n, L = reads.shape
+    W = 12 + (L + 1) + 2 + (L + 1)
+    with open(path, "wb") as fh:
+        for a in range(0, n, chunk):
+            m = min(chunk, n - a)
+            rec = np.empty((m, W), dtype=np.uint8)
+            rec[:, 0], rec[:, 1] = ord('@'), ord('r')
+            idx = np.arange(a, a + m, dtype=np.int64)
+            for d in range(9):
+                rec[:, 10 - d] = (idx % 10 + 48).astype(np.uint8)
+                idx //= 10
+            rec[:, 11] = 10
+            rec[:, 12:12 + L] = reads[a:a + m]
+            rec[:, 12 + L] = 10
+            rec[:, 13 + L], rec[:, 14 + L] = ord('+'), 10
+            rec[:, 15 + L:15 + 2 * L] = ord('I')
+            rec[:, 15 + 2 * L] = 10
+            rec.tofile(fh)
+    return n * W
+
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _bgzf_slice(job):
+    """one byte range of the plain file -> its BGZF members (blocks of <= 65280 input bytes, each a gzip member whose 'BC' extra
+    subfield holds the member's size - 1: the SAM specification's block format, what bgzip / htslib write)"""
+    import struct
+    import zlib
+    path, a, b, level = job
+    with open(path, "rb") as fh:
+        fh.seek(a)
+        data = fh.read(b - a)
+    out = []
+    for p in range(0, len(data), 65280):
+        blk = data[p:p + 65280]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cd = c.compress(blk) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cd) + 25) + cd +
+                   struct.pack("<II", zlib.crc32(blk) & 0xffffffff, len(blk)))
+    return b"".join(out)
+
+
+def write_bgzf(src_path, dst_path, workers=1, level=1, slice_bytes=65280 * 256):
+    """plain file -> BGZF file (fork()ed pool when workers > 1: call it before the process touches HIP).  -> bytes written"""
+    import os
+    size = os.path.getsize(src_path)
+    jobs = [(src_path, a, min(size, a + slice_bytes), level) for a in range(0, size, slice_bytes)]
+    total = 0
+    with open(dst_path, "wb") as fh:
+        if workers > 1 and len(jobs) > 1:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+                for part in pool.imap(_bgzf_slice, jobs):
+                    fh.write(part)
+                    total += len(part)
+        else:
+            for j in jobs:
+                part = _bgzf_slice(j)
+                fh.write(part)
+                total += len(part)
+        fh.write(_BGZF_EOF)
+    return total + len(_BGZF_EOF)

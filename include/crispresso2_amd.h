@@ -212,6 +212,14 @@ int c2_set_kernel_mode(c2_ctx* ctx, int32_t mode);
 int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t* fallback_tasks_last_launch);
 /* Most recent batch: number of banded launches in front of the full-plane launch, and how many tasks each of them left over. */
 int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4);
+/* The launch chain a batch with reads up to max_read_len would get: *kernels bit 0 c2_align_diagp_kernel<8>, 1 c2_align_diagx_kernel<4>,
+ * 2 diagp<4>, 3 diagx<2>, 4 diagp<2>, 5 c2_align_diag_kernel, 6 banded row-strip first launch, 7 the last launch keeps its pointer plane
+ * in HBM scratch; ref_packed_ok (n_refs bytes, may be NULL): 1 where the packed int16 fill admits the reference (its DP values provably
+ * fit, c2_pk_eligible) -- the int32 kernels run everything else (the reference's C ints, CRISPResso2Align.pyx:142-147). */
+int c2_chain_info(c2_ctx* ctx, int32_t max_read_len, uint32_t* kernels, uint8_t* ref_packed_ok);
+/* The same for up to 8 tiers, plus per tier the number of tasks its packed (int16) kernel could not pair and handed to the 32-bit
+ * kernel of the same band: a tier with a packed kernel finished at least tasks_in - unpaired - left_over tasks in int16 arithmetic. */
+int c2_tier_info_ex(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over8, int32_t* unpaired8);
 
 /* ---- per-call path: same contract as the reference's Cython functions ------------------ */
 

@@ -84,23 +84,29 @@ def run_bench(argv):
     saved = (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, torch.cuda.set_device, torch.cuda.Event,
              batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout,
              torch.cuda.Stream, torch.cuda.stream, torch.cuda.empty_cache)
-    torch.cuda.Stream = _Stream
-    torch.cuda.stream = lambda st: st
-    torch.cuda.empty_cache = lambda: None
-    torch.device = lambda *a, **k: real_device("cpu")
-    torch.cuda.current_stream = lambda *a, **k: _Stream()
-    torch.cuda.synchronize = lambda *a, **k: None
-    torch.cuda.set_device = lambda *a, **k: None
-    torch.cuda.Event = _Event
-    batch.BatchAligner = make_aligner
-    C.accumulate_device = _accumulate(made)
-    C.select_best_device = _select
-    _native.Context = _Ctx
+    def apply():
+        torch.cuda.Stream = _Stream
+        torch.cuda.stream = lambda st: st
+        torch.cuda.empty_cache = lambda: None
+        torch.device = lambda *a, **k: real_device("cpu")
+        torch.cuda.current_stream = lambda *a, **k: _Stream()
+        torch.cuda.synchronize = lambda *a, **k: None
+        torch.cuda.set_device = lambda *a, **k: None
+        torch.cuda.Event = _Event
+        batch.BatchAligner = make_aligner
+        C.accumulate_device = _accumulate(made)
+        C.select_best_device = _select
+        _native.Context = _Ctx
     sys.argv = ["bench.py"] + list(argv)
     buf = io.StringIO()
     sys.stdout = buf
+    from pipeline_on_emulator import emulated_device
     try:
-        bench.main()
+        # (the FASTQ -> tensors leg runs pipeline.quantify_fastq: its device calls go to the emulator too; ONE list of aligners, so
+        # that the count pass of either route sees the aligner of the batch it counts)
+        with emulated_device(made):
+            apply()
+            bench.main()
     finally:
         (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, torch.cuda.set_device, torch.cuda.Event,
          batch.BatchAligner, C.accumulate_device, C.select_best_device, _native.Context, sys.argv, sys.stdout,

@@ -154,11 +154,12 @@ def _strand_plan(ctx, n_reads, d_reads, d_offsets, max_read_len, refs, ref_names
 
 
 @contextlib.contextmanager
-def emulated_device():
-    """Inside the block pipeline.quantify_* run on the emulator; restored afterwards."""
+def emulated_device(made=None):
+    """Inside the block pipeline.quantify_* run on the emulator; restored afterwards.  made: the caller's list of emulated aligners
+    (bench_on_emulator shares its own, so that the count pass always sees the aligner of the batch it counts)."""
     import torch
     from crispresso2_amd import pipeline, variants, paired, counts as C, _native
-    made = []
+    made = [] if made is None else made
 
     def make_aligner(*a, **kw):
         made.append(EmulatedAligner(*a, **kw))

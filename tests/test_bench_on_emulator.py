@@ -63,3 +63,44 @@ def test_bench_two_ranks_over_gloo_on_the_emulator(tmp_path):
     # rank 0's shard alone aligns fewer reads than the all-reduced tensor holds (the second shard is a different block of the stream)
     assert out["counts"][0]["reads_aligned_all_gpus"] > single["counts"][0]["reads_aligned_all_gpus"] >= 100
     assert out["counts"][0]["reads_aligned_all_gpus"] <= 320
+
+
+def test_bench_started_bare_with_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 --steps K --warmup W` with NOTHING prepared in the environment (no RANK /
+    WORLD_SIZE / MASTER_*: the driver's command form) must start its two ranks itself and print rank 0's single line.  Here through
+    tests/bench_emulated_main.py (the same main() and launcher, device calls on the emulator, gloo in place of RCCL)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["C2_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(here, "bench_emulated_main.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "130",
+                        "--workers", "1", "--no-cpu-baseline", "--check", "10", "--extras", "on", "--extra-reads", "70", "--extra-steps", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = [json.loads(x[7:]) for x in p.stdout.splitlines() if x.startswith("RESULT ")]
+    assert len(res) == 2 and sum(r is not None for r in res) == 1, p.stdout[-2000:]
+    out = next(r for r in res if r is not None)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["collective_backend"] == "gloo" and out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"]["reads_per_gpu_per_step"] == 130 and 130 < out["counts"][0]["reads_aligned_all_gpus"] <= 260
+    # the legs behind the headline ran on both ranks too (their steps hold collectives): the int32 chain and BASELINE's 8-GPU shape
+    assert out["int32_chain"]["records_equal_the_packed_chain"] and out["int32_chain"]["reads_per_s"] > 0
+    c5 = out["other_configs"]["config5"]
+    assert c5["n_amplicons"] == 96 and c5["reads_per_gpu_per_step"] == 70 and 70 < c5["reads_aligned_all_gpus"] <= 140
+    assert out["e2e"] is None                                          # (the FASTQ leg is a one-process measurement)
+
+
+def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fastq_leg():
+    """the default run's line alone must show the int32 chain's rate, configs 2 / 4 / 5 with their
+    chain = full-plane check, and FASTQ -> tensors (plain and BGZF)."""
+    out = BE.run_bench(["--steps", "1", "--warmup", "0", "--reads", "150", "--workers", "1", "--cpu-seconds", "1.0", "--check", "10",
+                        "--extras", "on", "--extra-reads", "90", "--extra-steps", "1"])
+    assert out["dtype"] == "int16" and out["int32_chain"]["dtype"] == "int32" and out["int32_chain"]["records_equal_the_packed_chain"]
+    for cfg, k_ in ((2, 1), (4, 3), (5, 1)):
+        e = out["other_configs"]["config%d" % cfg]
+        assert e["chain_equals_full_plane"] and e["chain_equals_full_plane_n"] == 90 * k_ and e["all_status_ok"] and e["reads_per_s"] > 0
+    e2e = out["e2e"]
+    assert e2e["reads"] == 90 and e2e["plain_equals_bgzf"] and e2e["plain"]["reads_per_s"] > 0 and e2e["bgzf"]["reads_per_s"] > 0
+    assert e2e["tallies"]["N_TOT_READS"] == 90 and set(e2e["stage_seconds"]) >= {"ingest_dedup", "h2d_align", "count_kernels"}

@@ -105,3 +105,156 @@ def test_soak_adversarial_gap_incentives(ctx, go, ge, scale):
             continue
         assert r["status"] == 0 and res.strings(k) == (s1, s2) and int(r["matches"]) == mt and int(r["aln_len"]) == ln, (k, rids[k])
     assert bad < n // 10
+
+
+# ---- the packed int16 fill (c2_align_diagp_kernel) attacked where its range proof (c2_pk_eligible) is tight -------------------------
+def _equal_length_reads(rng, ref, n):
+    """Reads of EXACTLY len(ref) -- neighbouring slots pair only with the same reference and read length -- that reach the
+    extremes of the DP value range: the reference itself (every cell on the best path at +max score), every base mismatched
+    (the worst score per diagonal step), all N, long runs of N, and the usual edits with the length restored."""
+    L = len(ref)
+    other = {"A": "C", "C": "A", "G": "T", "T": "G"}
+    ins = lambda m: list(rng.choice(list("ACGT"), m))
+    out = []
+    for t in range(n):
+        s = list(ref)
+        kind = t % 10
+        if kind == 0:
+            pass                                                           # all match: H(Li, Lj) = max score * L
+        elif kind == 1:
+            s = [other[c] for c in s]                                      # all mismatch: H = min score * L (or a gapped path)
+        elif kind == 2:
+            s = ["N"] * L if t % 20 == 2 else s[:L // 3] + ["N"] * (L - 2 * (L // 3)) + s[L - L // 3:]
+        elif kind == 3:                                                    # deletion, tail refilled
+            d = int(rng.integers(1, 60)); p = int(rng.integers(5, L - d - 5)); del s[p:p + d]; s += ins(d)
+        elif kind == 4:                                                    # insertion, tail cut
+            m = int(rng.integers(1, 40)); p = int(rng.integers(5, L - 5)); s[p:p] = ins(m); s = s[:L]
+        elif kind == 5:                                                    # shifted: leading bases dropped / prepended
+            d = int(rng.integers(1, 25)); s = (s[d:] + ins(d)) if t % 20 == 5 else (ins(d) + s)[:L]
+        elif kind == 6:                                                    # first half mismatched, second half matched
+            h = int(rng.integers(L // 4, 3 * L // 4)); s = [other[c] for c in s[:h]] + s[h:]
+        elif kind == 7:                                                    # unrelated
+            s = ins(L)
+        for q in np.nonzero(rng.random(L) < (0.01 if kind != 9 else 0.08))[0]:
+            s[q] = "ACGTN"[int(rng.integers(0, 5))]
+        out.append("".join(s))
+    return out
+
+
+def _packed_limit_len(ctx, m, go, ge, g_at, gval, lo, hi):
+    """largest Li in [lo, hi] whose random reference the packed fill still admits (bisection on c2_chain_info), or None"""
+    from crispresso2_amd.batch import BatchAligner
+
+    def admitted(L):
+        ref = "ACGT" * (L // 4) + "ACGT"[:L % 4]
+        g = np.zeros(L + 1, dtype=np.int64)
+        for pos in g_at(L):
+            g[pos] = gval
+        BatchAligner([ref], [g], [[L // 2]], m, go, ge, ctx=ctx)
+        return ctx.chain_info(L, 1)[1][0]
+    if not admitted(lo):
+        return None
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        lo, hi = (mid, hi) if admitted(mid) else (lo, mid - 1)
+    return lo
+
+
+PACKED_CASES = [
+    # (go, ge, incentive value, rows that carry it, reference lengths: numbers, or "limit" = the longest admitted one and limit+1)
+    (-20, -2, 1, lambda L: [L // 2 + 1], [250, 600, 1000, 1300, "limit"]),
+    (-5, -3, 2, lambda L: [0, L // 3, L], [250, "limit"]),                 # incentives on row 0 and on the last row
+    (-200, -20, 19, lambda L: [0, L // 2, L // 2 + 1, L], [250, 600, "limit"]),   # the largest incentive the diagonal chain takes (|ge| - 1)
+    (-1990, -3, 2, lambda L: [L // 2], [100]),                             # gap_open at the cap of c2_pk_eligible (|go| + |g| <= 2000)
+    (-50, 0, 1, lambda L: [L // 2 + 1], [250]),                            # gap_extend 0: no diagonal chain at all -> int32 row-strip kernels
+]
+
+
+@pytest.mark.parametrize("case", range(len(PACKED_CASES)))
+def test_soak_packed_int16_fill_at_the_limits_of_its_range_proof(ctx, case):
+    """VERDICT r02, Weak 2.  Batches built to PAIR (one reference, all reads of its length) at the reference lengths / gap
+    parameters / incentives where c2_pk_eligible's bound hi + lo <= 14000 is tight, with reads that reach the extremes of the value
+    range; every alignment against the oracle, the packed kernel's own share of the work from c2_tier_info_ex, and the first
+    length beyond the limit must be refused (it then runs the int32 kernels, with the same results)."""
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    go, ge, gval, g_at, lens = PACKED_CASES[case]
+    m = matrices()["EDNAFULL"]
+    rng = np.random.default_rng(9000 + case)
+    plan = []
+    for L in lens:
+        if L == "limit":
+            lim = _packed_limit_len(ctx, m, go, ge, g_at, gval, 300, 1600)
+            assert lim is not None and 900 < lim < 1500, lim
+            plan += [(lim, True), (lim + 1, False)]
+        else:
+            plan.append((L, None))
+    for L, want_packed in plan:
+        ref = "".join(rng.choice(list("ACGT"), L))
+        g = np.zeros(L + 1, dtype=np.int64)
+        for pos in g_at(L):
+            g[pos] = gval
+        inc = list(range(L // 2 - 3, L // 2 + 3))
+        n = int(os.environ.get("C2_SOAK_N", 240 if L > 900 else 600))
+        reads = _equal_length_reads(rng, ref, n)
+        al = BatchAligner([ref], [g], [inc], m, go, ge, ctx=ctx)
+        kernels, ok = ctx.chain_info(L, 1)
+        packed = "c2_align_diagp_kernel<8>" in kernels
+        if want_packed is not None:
+            assert ok[0] == want_packed and packed == want_packed, (L, kernels, ok)
+        if (go, ge) == (-50, 0):
+            assert not packed and "c2_align_diag_kernel" not in kernels
+        res = al.align(reads)
+        left, unpaired = ctx.tier_info_ex()
+        bad = 0
+        for k in range(n):
+            st, s1, s2, mt, ln = oracle.global_align_raw(reads[k], ref, m, g, go, ge)
+            r = res.records[k]
+            if st != 0:
+                assert r["status"] != 0, (L, k)
+                bad += 1
+                continue
+            assert r["status"] == 0 and res.strings(k) == (s1, s2) and int(r["matches"]) == mt and int(r["aln_len"]) == ln, (case, L, k)
+            check_record(r, oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+        assert bad == 0
+        if packed:
+            # everything paired (same reference, same length); what the int16 kernels THEMSELVES finished (a tier's 32-bit twin only
+            # ever sees the unpaired tasks): at least 15 % in the first tier, 40 % over the three packed tiers -- the extreme reads
+            # (all mismatched, unrelated, long indels) go down the chain through all of them to the full-plane kernel
+            assert len(left) == 3 and max(unpaired) <= 1, (L, left, unpaired)
+            tier_in = [n, left[0], left[1]]
+            by_packed = [tier_in[t] - unpaired[t] - left[t] for t in range(3)]
+            assert by_packed[0] >= 0.15 * n and sum(by_packed) >= 0.4 * n and left[2] > 0, (case, L, left, unpaired)
+
+
+def test_packed_tier_whose_32bit_twin_does_not_fit_lds_drops_no_task(ctx):
+    """a ~3.5 kb reference admitted by c2_pk_eligible (match 1 / mismatch -1) fits the packed kernels' LDS plan
+    but not the 32-bit kernels' of the same band; reads of different lengths cannot pair, and used to be left on a list nobody ran."""
+    from crispresso2_amd import CRISPResso2Align as A
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    m = A.make_matrix(match_score=1, mismatch_score=-1, n_mismatch_score=-1, n_match_score=-1)
+    rng = np.random.default_rng(77)
+    L = 3500
+    ref = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64)
+    g[L // 2 + 1] = 1
+    inc = [L // 2, L // 2 + 1]
+    reads = []
+    for t in range(24):
+        s = list(ref)
+        d = int(rng.integers(0, 40))
+        p = int(rng.integers(10, L - 100))
+        del s[p:p + d]
+        for q in np.nonzero(rng.random(len(s)) < 0.01)[0]:
+            s[q] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(s) + ("" if t % 3 else "ACGT" * (t % 5)))
+    reads += [reads[0], reads[0]]                                          # one pair that CAN pair
+    al = BatchAligner([ref], [g], [inc], m, -4, -2, ctx=ctx)
+    kernels, ok = ctx.chain_info(max(len(r) for r in reads), 1)
+    assert ok[0], "the case needs a reference the packed fill admits"
+    res = al.align(reads)
+    for k, rd in enumerate(reads):
+        st, s1, s2, mt, ln = oracle.global_align_raw(rd, ref, m, g, -4, -2)
+        r = res.records[k]
+        assert st == 0 and r["status"] == 0 and res.strings(k) == (s1, s2) and int(r["matches"]) == mt, (k, kernels)
