@@ -7,6 +7,7 @@ import ctypes
 import numpy as np
 
 from . import _native
+from . import prime as _prime
 
 
 def read_matrix(path):
@@ -77,6 +78,11 @@ def global_align(pystr_seqj, pystr_seqi, matrix, gap_incentive, gap_open=-1, gap
     if len(g) != max_i + 1:
         print('\nERROR: Mismatch in gap_incentive length (gap_incentive: ' + str(len(g)) + ' ref: ' + str(max_i + 1) + '\n')
         return 0
+    # a run whose reads were registered with crispresso2_amd.prime answers from one device batch (same kernels, same results)
+    hit = _prime.lookup_alignment(pystr_seqj, pystr_seqi, m, g, gap_open, gap_extend)
+    if hit is not None:
+        return hit
+    _prime.stats["per_call_align"] += 1
     ctx = _native.default_context()
     cap = len(bi) + len(bj) + 1
     oj = ctypes.create_string_buffer(cap)

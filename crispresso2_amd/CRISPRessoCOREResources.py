@@ -9,6 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _native
+from . import prime as _prime
 
 
 class ResultsSlotsDict():
@@ -136,6 +137,10 @@ def _payload(res, counts):
 
 def find_indels_substitutions(read_seq_al, ref_seq_al, _include_indx):
     """Reference pyx:68-187.  Returns a ResultsSlotsDict with the 18 classifier fields."""
+    hit = _prime.lookup_payload(read_seq_al, ref_seq_al, _include_indx, 0, _payload)
+    if hit is not None:
+        return hit
+    _prime.stats["per_call_classify"] += 1
     res, counts = _classify(read_seq_al, ref_seq_al, _include_indx, 0)
     return _payload(res, counts)
 
@@ -143,6 +148,10 @@ def find_indels_substitutions(read_seq_al, ref_seq_al, _include_indx):
 def find_indels_substitutions_legacy(read_seq_al, ref_seq_al, _include_indx):
     """Reference pyx:190-315 (--use_legacy_insertion_quantification): plain dict; deletion_n / insertion_n are
     numpy sums of the size lists, as in the reference (np.sum([]) is the float 0.0)."""
+    hit = _prime.lookup_payload(read_seq_al, ref_seq_al, _include_indx, 1, _payload_legacy)
+    if hit is not None:
+        return hit
+    _prime.stats["per_call_classify"] += 1
     res, counts = _classify(read_seq_al, ref_seq_al, _include_indx, 1)
     return _payload_legacy(res, counts)
 

@@ -37,11 +37,16 @@ class _EmuLib:
 
 
 class _EmuContext:
-    """stands in for _native.Context for the per-call API: same attributes the shim modules use"""
+    """stands in for _native.Context for the per-call API: same attributes the shim modules use (plus the batched classifier that
+    crispresso2_amd.prime asks for)"""
     handle = None
 
     def __init__(self):
         self.lib = _EmuLib()
+
+    def classify_lists_batch(self, *a, **k):
+        from pipeline_on_emulator import EmulatedContext
+        return EmulatedContext().classify_lists_batch(*a, **k)
 
     @staticmethod
     def check(rc, what):
@@ -73,6 +78,9 @@ def inject():
     if use_emulator():
         ctx = _EmuContext()
         _native.default_context = lambda *a, **k: ctx
+        from crispresso2_amd import batch
+        from pipeline_on_emulator import EmulatedAligner
+        batch.BatchAligner = EmulatedAligner                         # (crispresso2_amd.prime's one-batch-per-amplicon route)
     pkg = types.ModuleType("CRISPResso2")
     pkg.__path__ = [os.path.join(REF, "CRISPResso2")]
     sys.modules["CRISPResso2"] = pkg

@@ -54,3 +54,46 @@ def test_reference_main_calls_replayed_on_the_emulator():
 def test_reference_main_calls_replayed_on_the_gpu():
     from crispresso2_amd import CRISPResso2Align as A, CRISPRessoCOREResources as R
     replay(A, R, matrices())
+
+
+def _fanc_fastq(tmp_path):
+    fq = tmp_path / "FANC.Cas9.fastq"
+    fq.write_text(load_golden("fanc_run.json.gz")["fastq"])
+    return str(fq)
+
+
+def _primed_replay(A, R, tmp_path):
+    """the same replay with the run's FASTQ registered (crispresso2_amd.prime): identical answers, most of them from batches"""
+    from crispresso2_amd import prime
+    prime.register_reads(_fanc_fastq(tmp_path))
+    try:
+        replay(A, R, matrices())
+        st = dict(prime.stats)
+    finally:
+        prime.clear()
+    # two runs x (one or two amplicons) x (forward, sometimes reverse-complement) batches; the hot loops' calls were look-ups
+    assert 2 <= st["batches"] <= 8 and 1 <= st["classify_batches"] <= 6, st
+    assert st["align_hits"] > 350 and st["classify_hits"] > 250, st
+    assert st["per_call_align"] == 671 - st["align_hits"] and st["per_call_classify"] == 385 - st["classify_hits"], st
+    return st
+
+
+def test_reference_main_calls_replayed_from_primed_batches_on_the_emulator(tmp_path):
+    sys.path.insert(0, HERE)
+    import dropin_inject as D
+    from pipeline_on_emulator import EmulatedAligner
+    from crispresso2_amd import CRISPResso2Align as A, CRISPRessoCOREResources as R, _native, batch
+    saved = (_native.default_context, batch.BatchAligner)
+    ctx = D._EmuContext()
+    _native.default_context = lambda *a, **k: ctx
+    batch.BatchAligner = EmulatedAligner
+    try:
+        _primed_replay(A, R, tmp_path)
+    finally:
+        _native.default_context, batch.BatchAligner = saved
+
+
+@pytest.mark.gpu
+def test_reference_main_calls_replayed_from_primed_batches_on_the_gpu(tmp_path):
+    from crispresso2_amd import CRISPResso2Align as A, CRISPRessoCOREResources as R
+    _primed_replay(A, R, tmp_path)

@@ -56,6 +56,8 @@ def fi_(*a, **k):
 A.global_align, R.find_indels_substitutions = ga_, fi_
 D.run_core_main(["CRISPResso", "-r1", %(fastq)r, "-o", %(out)r, "--suppress_plots", "--suppress_report"] + %(extra)r)
 print("DROPIN_CALLS", calls["align"], calls["classify"])
+from crispresso2_amd import prime
+print("DROPIN_PRIME", " ".join("%%s=%%d" %% kv for kv in sorted(prime.stats.items())))
 '''
 
 
@@ -86,3 +88,36 @@ def test_reference_unit_tests_collected_unchanged_pass_against_the_shim(test_fil
     tail = p.stdout[-2500:] + p.stderr[-1500:]
     assert p.returncode == 0, tail
     assert " passed" in p.stdout and " failed" not in p.stdout, tail
+
+
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_reference_main_unchanged_gets_its_alignments_from_one_batch_when_primed(name, tmp_path):
+    """the same unmodified main(), with C2_PRIME_FROM_ARGV=1 in the environment (crispresso2_amd.prime reads the
+    -r1 of the reference's own command line): after the first misses of the hot loop ALL unique reads of the FASTQ are aligned in one
+    device batch per amplicon (and classified in one), the rest of the run's >200 calls are look-ups -- the files are the same and
+    only a handful of per-call launches remain."""
+    extra, expected = RUNS[name]
+    code = RUNNER % dict(tests=HERE, fastq=os.path.join(REF, "tests", "FANC.Cas9.fastq"), out=str(tmp_path), extra=extra)
+    env = dict(os.environ, C2_DROPIN_DEVICE="emulator", C2_PRIME_FROM_ARGV="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=3000)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = [x for x in p.stdout.splitlines() if x.startswith("DROPIN_CALLS")][-1].split()
+    n_align, n_classify = int(line[1]), int(line[2])
+    assert n_align > 200 and n_classify > 150, line
+    st = dict(kv.split("=") for kv in [x for x in p.stdout.splitlines() if x.startswith("DROPIN_PRIME")][-1].split()[1:])
+    st = {k: int(v) for k, v in st.items()}
+    n_amplicons = 2 if "params" in name else 1
+    assert 1 <= st["batches"] <= 2 * n_amplicons and 1 <= st["classify_batches"] <= 2 * n_amplicons, st
+    assert st["align_hits"] > (350 if "params" in name else 150) and st["classify_hits"] > 100, st
+    # what is left per call: the run's set-up alignments (guides, amplicons against each other) and -- with a coding sequence (-c, the
+    # params run) -- the exon analysis of the aggregation loop, which aligns SLICES of aligned reads against the exon with gap
+    # penalties -1 / -1 (CRISPRessoCORE.py:4100-4171: strings no FASTQ holds).  Every hot-loop call was a look-up.
+    assert st["per_call_align"] == n_align - st["align_hits"] and st["per_call_classify"] == n_classify - st["classify_hits"], st
+    assert st["per_call_align"] < (200 if "params" in name else 40) and st["per_call_classify"] < 8, st
+    outdir = os.path.join(str(tmp_path), name)
+    for made, kept in expected.items():
+        with open(os.path.join(outdir, made)) as fh:
+            got = fh.read()
+        with open(os.path.join(REF, "tests", "expectedResults", name, kept)) as fh:
+            want = fh.read()
+        assert got == want, made

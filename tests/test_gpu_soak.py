@@ -185,7 +185,7 @@ def test_soak_packed_int16_fill_at_the_limits_of_its_range_proof(ctx, case):
     for L in lens:
         if L == "limit":
             lim = _packed_limit_len(ctx, m, go, ge, g_at, gval, 300, 1600)
-            assert lim is not None and 900 < lim < 1500, lim
+            assert lim is not None and 500 < lim < 1500, lim
             plan += [(lim, True), (lim + 1, False)]
         else:
             plan.append((L, None))
