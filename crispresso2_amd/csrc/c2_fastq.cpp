@@ -30,6 +30,7 @@
 #include <atomic>
 #include <tuple>
 #include <dlfcn.h>
+#include <functional>
 
 #include "crispresso2_amd.h"
 
@@ -65,6 +66,7 @@ struct ByteBuf {
         p = q; cap = c;
     }
     void resize(size_t want) { reserve(want); n = want; }              // new bytes are NOT initialised
+    void swap(ByteBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(mapped, o.mapped); }
     void append(const uint8_t* a, size_t len) { if (len) { reserve(n + len); memcpy(p + n, a, len); n += len; } }
 };
 
@@ -300,160 +302,35 @@ void parse_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t line_no
 
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads) {
-    const bool trace = getenv("C2_FASTQ_TRACE") != nullptr;       // phase times on stderr
-    const double T0 = now_s();
-    std::vector<size_t> cut(threads + 1);
-    for (unsigned t = 0; t <= threads; ++t) cut[t] = (size_t)((unsigned __int128)n * t / threads);
-    std::vector<uint64_t> terms(threads, 0), starts(threads, 0);
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] { terms[t] = count_terminators(b, n, cut[t], cut[t + 1], &starts[t]); });
-        for (auto& th : pool) th.join();
-    }
-    for (unsigned t = 0; t < threads; ++t) R->nonempty_lines += starts[t];
-    const double T1 = now_s();
-    // number of the first line that starts at or after cut[t]: lines started before = 1 + terminators ending before cut[t] - 1
-    std::vector<uint64_t> first(threads, 0);
-    uint64_t before = 0;                                         // terminators ending at positions < cut[t]
-    for (unsigned t = 0; t < threads; ++t) {
-        if (t == 0) first[t] = 0;
-        else first[t] = before + (term_end(b, n, cut[t] - 1) ? 0 : 1);    // a line that starts exactly at cut[t] has number `before`
-        before += terms[t];
-    }
-    const uint64_t total_terms = before;
-    std::vector<std::unique_ptr<RangeResult>> res(threads);
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t) {
-            res[t].reset(new RangeResult);
-            pool.emplace_back([&, t] { parse_range(b, n, cut[t], cut[t + 1], first[t], res[t].get()); });
-        }
-        for (auto& th : pool) th.join();
-    }
-    const double T2 = now_s();
-    // Merge.  Every distinct sequence must end up once, at the position of its first occurrence in the file, with the sum
-    // of its counts.  Partition the hash space over the threads: thread p walks all ranges in file order and keeps, for the
-    // sequences whose hash falls in its partition, the first (range, local index) and the total count -- no two threads
-    // ever touch the same sequence.  The survivors, sorted by that first occurrence, are the global order.
-    for (unsigned t = 0; t < threads; ++t) if (!res[t]->ok) return C2_E_TOO_LARGE;
-    struct First { uint32_t range, local; uint64_t count; };
-    std::vector<std::vector<First>> part(threads);
-    {
-        std::vector<std::thread> pool;
-        for (unsigned p = 0; p < threads; ++p) pool.emplace_back([&, p] {
-            std::vector<First>& mine = part[p];
-            std::vector<uint32_t> table(1u << 12, 0);            // index into `mine` + 1
-            uint64_t mask = table.size() - 1;
-            std::vector<uint64_t> hs;                            // hash of mine[k]
-            for (unsigned t = 0; t < threads; ++t) {
-                const c2_fastq& P = res[t]->R;
-                const std::vector<uint64_t>& H = res[t]->D.hashes;
-                for (size_t k = 0; k < H.size(); ++k) {
-                    const uint64_t h = H[k];
-                    if ((unsigned)((h >> 40) % threads) != p) continue;
-                    const uint8_t* s = P.arena.data() + P.offsets[k];
-                    const size_t len = (size_t)(P.offsets[k + 1] - P.offsets[k]);
-                    uint64_t pos = h & mask;
-                    bool found = false;
-                    while (table[pos]) {
-                        const uint32_t q = table[pos] - 1;
-                        if (hs[q] == h) {
-                            const c2_fastq& Q = res[mine[q].range]->R;
-                            const uint64_t o = Q.offsets[mine[q].local];
-                            if ((size_t)(Q.offsets[mine[q].local + 1] - o) == len && (len == 0 || memcmp(Q.arena.data() + o, s, len) == 0)) {
-                                mine[q].count += P.counts[k]; found = true; break;
-                            }
-                        }
-                        pos = (pos + 1) & mask;
-                    }
-                    if (found) continue;
-                    table[pos] = (uint32_t)mine.size() + 1;
-                    mine.push_back(First{t, (uint32_t)k, P.counts[k]});
-                    hs.push_back(h);
-                    if (mine.size() * 2 > table.size()) {
-                        std::vector<uint32_t> nt(table.size() * 2, 0);
-                        const uint64_t nm = nt.size() - 1;
-                        for (uint32_t q = 0; q < (uint32_t)mine.size(); ++q) { uint64_t pp = hs[q] & nm; while (nt[pp]) pp = (pp + 1) & nm; nt[pp] = q + 1; }
-                        table.swap(nt); mask = nm;
-                    }
-                }
-            }
-        });
-        for (auto& th : pool) th.join();
-    }
-    const double T3 = now_s();
-    // global order = ascending (range, local index) of the first occurrences: per range, a bitmap-free gather
-    std::vector<std::vector<First>> by_range(threads);
-    {   // every range collects (and sorts) its own survivors from all partitions
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] {
-            std::vector<First>& v = by_range[t];
-            for (unsigned p = 0; p < threads; ++p) for (const First& f : part[p]) if (f.range == t) v.push_back(f);
-            std::sort(v.begin(), v.end(), [](const First& a, const First& b) { return a.local < b.local; });
-        });
-        for (auto& th : pool) th.join();
-    }
-    uint64_t n_unique = 0, n_reads = 0;
-    std::vector<uint64_t> first_index(threads + 1, 0);
-    for (unsigned t = 0; t < threads; ++t) { first_index[t] = n_unique; n_unique += by_range[t].size(); n_reads += res[t]->n_seq; }
-    if (n_unique >= 0xfffffffeull) return C2_E_TOO_LARGE;
-    R->offsets.assign(n_unique + 1, 0);
-    R->counts.assign(n_unique, 0);
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] {
-            std::vector<First>& v = by_range[t];
-            const c2_fastq& P = res[t]->R;
-            uint64_t g = first_index[t];
-            for (const First& f : v) {
-                R->offsets[g + 1] = P.offsets[f.local + 1] - P.offsets[f.local];      // lengths now, prefix sum below
-                if (f.count > 0xffffffffull) { res[t]->ok = false; return; }
-                R->counts[g] = (uint32_t)f.count;
-                ++g;
-            }
-        });
-        for (auto& th : pool) th.join();
-    }
-    for (unsigned t = 0; t < threads; ++t) if (!res[t]->ok) return C2_E_TOO_LARGE;
-    const double T4 = now_s();
-    for (uint64_t g = 0; g < n_unique; ++g) R->offsets[g + 1] += R->offsets[g];
-    R->arena.resize((size_t)R->offsets[n_unique]);
-    const double T5 = now_s();
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] {
-            const c2_fastq& P = res[t]->R;
-            uint64_t g = first_index[t];
-            for (const First& f : by_range[t]) {
-                memcpy(R->arena.data() + R->offsets[g], P.arena.data() + P.offsets[f.local], (size_t)(P.offsets[f.local + 1] - P.offsets[f.local]));
-                ++g;
-            }
-        });
-        for (auto& th : pool) th.join();
-    }
-    // the empty sequence of a record cut short after its id line: counted like any other sequence, last
-    auto add_empty = [&]() {
-        for (uint64_t g = 0; g < n_unique; ++g)
-            if (R->offsets[g + 1] == R->offsets[g]) { ++R->counts[g]; return; }
-        R->offsets.push_back(R->offsets.back());
-        R->counts.push_back(1);
-    };
-    if (trace) fprintf(stderr, "c2_fastq: %u threads, count %.3f s, parse %.3f s, merge %.3f s (partition %.3f, order %.3f, prefix %.3f, copy %.3f)\n",
-                       threads, T1 - T0, T2 - T1, now_s() - T2, T3 - T2, T4 - T3, T5 - T4, now_s() - T5);
-    // lines in the file = terminators + (1 if the file does not end with one and is not empty); a record whose sequence
-    // line never came still counts, with the empty sequence (readline() returned '')
-    const uint64_t lines = total_terms + ((n > 0 && !term_end(b, n, n - 1)) ? 1 : 0);
-    if ((lines & 3) == 1) { add_empty(); ++n_reads; }
-    R->n_reads = n_reads;
-    // the per-range tables and arenas (as many bytes again as the result) are released off the caller's path: unmapping them
-    // is tens of milliseconds of kernel time for a gigabyte of input
-    if (n >= ((size_t)64 << 20) && !getenv("C2_SYNC_FREE")) {
-        auto* junk = new std::tuple<decltype(res), decltype(part), decltype(by_range)>(std::move(res), std::move(part), std::move(by_range));
-        g_helpers.run([junk] { delete junk; });
-    }
-    if (trace) fprintf(stderr, "c2_fastq: released the range tables after %.3f s\n", now_s() - T0);
+#include "c2_fastq_stream.h"
+
+size_t stream_range_bytes() {
+    if (const char* e = getenv("C2_FASTQ_RANGE_BYTES")) { const long long v = atoll(e); if (v > 0) return (size_t)v; }
+    return (size_t)4 << 20;
+}
+
+// the finished stream's result -> R (arena moved, not copied)
+int stream_into(FastqStream& S, c2_fastq* R) {
+    R->counts.assign(S.offsets.size() - 1, 0);
+    if (!S.counts_into(R->counts.data())) return C2_E_TOO_LARGE;
+    R->arena.swap(S.arena);
+    R->offsets.swap(S.offsets);
+    R->n_reads = S.n_reads;
+    R->nonempty_lines += S.nonempty_lines;
     return 0;
+}
+
+// text in memory (inflated .gz, filtered records) -> R, on `threads` threads
+int parse_plain_parallel(const char* b, size_t n, c2_fastq* R, unsigned threads) {
+    const bool trace = getenv("C2_FASTQ_TRACE") != nullptr;
+    const double T0 = now_s();
+    FastqStream S;
+    S.mem = b; S.n = n;
+    if (!S.init(threads, stream_range_bytes())) { g_fastq_error = S.err; return C2_E_INVALID; }
+    while (!S.done) if (!S.next()) { g_fastq_error = S.err; return S.overflow ? C2_E_TOO_LARGE : C2_E_INVALID; }
+    const int rc = stream_into(S, R);
+    if (trace) fprintf(stderr, "c2_fastq: %u threads, %zu bytes in memory, %.3f s\n", threads, n, now_s() - T0);
+    return rc;
 }
 
 
@@ -738,10 +615,11 @@ bool inflate_members(const uint8_t* b, size_t n, TextBuf& text, size_t& n_text) 
 
 unsigned plain_threads(size_t n) {
     unsigned threads = std::thread::hardware_concurrency();
-    const unsigned by_size = (unsigned)(n / (8u << 20)) + 1;              // at least 8 MiB per thread
+    const unsigned by_size = (unsigned)(n / (4u << 20)) + 1;              // at least 4 MiB per thread
     if (threads > by_size) threads = by_size;
-    if (const char* e = getenv("C2_FASTQ_THREADS")) threads = (unsigned)atoi(e);   // tests: any count on any size
-    if (threads > 64) threads = 64;
+    unsigned cap = 128;                                                    // (memory-bound work: SMT siblings add little)
+    if (const char* e = getenv("C2_FASTQ_THREADS")) { threads = (unsigned)atoi(e); cap = 256; }   // tests / measurements: any count on any size
+    if (threads > cap) threads = cap;
     if (threads < 1) threads = 1;
     if ((size_t)threads > n) threads = (unsigned)n;
     return threads;
@@ -1049,28 +927,25 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
     }
     c2_fastq* R = new c2_fastq;
     if (!gz) {
-        const int fd = open(path, O_RDONLY);
+        // plain text: pread() by the stream engine's threads, chunk after chunk (c2_fastq_stream.h)
+        FastqStream S;
+        S.fd = open(path, O_RDONLY);
         struct stat st;
-        if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); g_fastq_error = std::string("cannot open ") + path; delete R; return C2_E_INVALID; }
-        const size_t n = (size_t)st.st_size;
+        if (S.fd < 0 || fstat(S.fd, &st) != 0) { g_fastq_error = std::string("cannot open ") + path; delete R; return C2_E_INVALID; }
+        S.n = (size_t)st.st_size;
         int rc = 0;
-        if (n > 0) {
-            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) { close(fd); g_fastq_error = std::string("cannot map ") + path; delete R; return C2_E_INVALID; }
-            madvise(m, n, MADV_SEQUENTIAL);
+        if (S.n > 0) {
             const bool trace = getenv("C2_FASTQ_TRACE") != nullptr;
             const double T0 = now_s();
-            rc = parse_plain_parallel((const char*)m, n, R, plain_threads(n));
-            const double T1 = now_s();
-            // (unmapping a gigabyte of page-cache pages is ~20 ms of kernel time.  Doing it on a helper thread was measured and is
-            // WORSE: munmap holds the address space's lock, and the caller's next page faults -- numpy and torch allocating -- wait for it)
-            munmap(m, n);
-            if (trace) fprintf(stderr, "c2_fastq: parse call %.3f s, unmap %.3f s\n", T1 - T0, now_s() - T1);
+            const unsigned threads = plain_threads(S.n);
+            if (!S.init(threads, stream_range_bytes())) { g_fastq_error = S.err; delete R; return C2_E_INVALID; }
+            while (!S.done) if (!S.next()) { g_fastq_error = S.err; delete R; return S.overflow ? C2_E_TOO_LARGE : C2_E_INVALID; }
+            rc = stream_into(S, R);
+            if (trace) fprintf(stderr, "c2_fastq: %u threads, %zu bytes, %u chunks, %.3f s\n", threads, S.n, S.chunk_no / 2, now_s() - T0);
         } else {
             R->offsets.push_back(0);
         }
-        close(fd);
-        if (rc) { g_fastq_error = "more than 2^32 - 2 unique sequences"; delete R; return rc; }
+        if (rc) { g_fastq_error = "more than 2^32 - 2 copies of one sequence"; delete R; return rc; }
         *out = R;
         return 0;
     }

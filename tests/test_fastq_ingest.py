@@ -83,11 +83,15 @@ def test_whitespace_blank_lines_truncation_and_lowercase(tmp_path):
         check(p)
 
 
-@pytest.mark.parametrize("threads", [1, 2, 3, 7, 16, 64])
-def test_parallel_ranges_edge_cases_and_random_files(tmp_path, monkeypatch, threads):
+@pytest.mark.parametrize("threads,range_bytes", [(1, 0), (2, 0), (3, 0), (7, 0), (16, 0), (64, 0), (1, 7), (2, 5), (3, 1), (5, 23), (16, 2), (4, 64)])
+def test_parallel_ranges_edge_cases_and_random_files(tmp_path, monkeypatch, threads, range_bytes):
     """Plain files are parsed by byte ranges on several threads (line numbers from a terminator count); force many ranges
-    onto small files so that range edges fall inside ids, sequences, terminators ("\\r|\\n"), blank lines and the tail."""
+    onto small files so that range edges fall inside ids, sequences, terminators ("\\r|\\n"), blank lines and the tail.
+    range_bytes > 0: the text is also cut into many CHUNKS of threads x range_bytes (the streaming engine: a chunk's ranges are
+    counted, parsed and merged before the next chunk is read; line numbers, the per-thread tables and the global table carry over)."""
     monkeypatch.setenv("C2_FASTQ_THREADS", str(threads))
+    if range_bytes:
+        monkeypatch.setenv("C2_FASTQ_RANGE_BYTES", str(range_bytes))
     rng = np.random.default_rng(100 + threads)
     fixed = ["@a\nACGT\n+\nIIII\n@b\nGGCC\n+\nIIII", "@a\r\nACGT\r\n+\r\nIIII\r\n@b\r\nGG\r\n+\r\nII\r\n", "\n\n\n\n\n", "@a\n",
              "@a\nAC\n+\nII\n\n", "x", "\r", "\r\n", "@a\rACGT\r+\rIIII\r@b\rTTTT\r+\rIIII\r", "@a\n  AC GT \t\n+\nIIII\n@b\n\n+\n\n"]
@@ -107,7 +111,7 @@ def test_parallel_ranges_edge_cases_and_random_files(tmp_path, monkeypatch, thre
         p = tmp_path / ("r%d.fastq" % k)
         p.write_bytes(text.encode())
         check(p)
-    big = records(random_seqs(3000, rng))
+    big = records(random_seqs(3000 if not range_bytes or range_bytes >= 16 else 60, rng))      # (tiny chunks: a short file is enough)
     p = tmp_path / "big.fastq"
     p.write_text(big)
     check(p)
@@ -632,3 +636,28 @@ def test_nonempty_line_count_is_what_get_n_reads_fastq_counts(tmp_path, monkeypa
                 for k_ in env:
                     monkeypatch.delenv(k_)
                 assert st["N_READS_AFTER_PREPROCESSING"] == st["N_READS_INPUT"] == int(float(want) / 4.0), (name, path, env, st, want)
+
+
+@pytest.mark.parametrize("threads,range_bytes", [(1, 300), (3, 170), (8, 64), (8, 4096), (32, 100)])
+def test_streamed_chunks_keep_first_seen_order_and_counts_across_chunks(tmp_path, monkeypatch, threads, range_bytes):
+    """Many chunks over one file with heavy duplication ACROSS chunks (a few hot sequences everywhere, sequences that come back
+    after thousands of records, a read that only ever appears as the last record): unique reads in global first-seen order,
+    exact multiplicities, arena bytes -- the plain file through pread() and the same text through the in-memory route (.gz)."""
+    monkeypatch.setenv("C2_FASTQ_THREADS", str(threads))
+    monkeypatch.setenv("C2_FASTQ_RANGE_BYTES", str(range_bytes))
+    rng = np.random.default_rng(threads * 1000 + range_bytes)
+    pool = ["".join(rng.choice(list("ACGTN"), int(rng.integers(1, 70)))) for _ in range(400)]
+    hot = pool[:5]
+    seqs = []
+    for k in range(6000):
+        r = rng.random()
+        seqs.append(hot[int(rng.integers(0, 5))] if r < 0.4 else pool[int(rng.integers(0, 400))] if r < 0.9 else
+                    "".join(rng.choice(list("ACGT"), int(rng.integers(1, 90)))))
+    seqs.append("TTTTGGGGCCCCAAAA" * 3)
+    p = tmp_path / "many_chunks.fastq"
+    p.write_text(records(seqs))
+    check(p)
+    gz = tmp_path / "many_chunks.fastq.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(records(seqs).encode())
+    check(gz)
