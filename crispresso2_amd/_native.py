@@ -24,7 +24,7 @@ SYMBOLS = [
     "c2_comm_unique_id", "c2_comm_init", "c2_reduce_counts", "c2_comm_destroy",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
-    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners",
+    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners",
     "c2_consensus_pairs_batch",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets",
 ]
@@ -102,6 +102,18 @@ def load():
                 fn.argtypes = [ctypes.c_void_p]
             lib.c2_fastq_free.restype = None
             lib.c2_fastq_free.argtypes = [ctypes.c_void_p]
+            for fn in (lib.c2_fastq_stream_arena, lib.c2_fastq_stream_offsets):
+                fn.restype = ctypes.c_void_p
+                fn.argtypes = [ctypes.c_void_p]
+            for fn in (lib.c2_fastq_stream_text_bytes, lib.c2_fastq_stream_n_reads, lib.c2_fastq_stream_nonempty_lines,
+                       lib.c2_fastq_stream_nonempty_lines_input):
+                fn.restype = ctypes.c_uint64
+                fn.argtypes = [ctypes.c_void_p]
+            lib.c2_fastq_stream_close.restype = None
+            lib.c2_fastq_stream_close.argtypes = [ctypes.c_void_p]
+            lib.c2_fastq_stream_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+            lib.c2_fastq_stream_next.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int32)]
+            lib.c2_fastq_stream_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
             lib.c2_fastq_last_error.restype = ctypes.c_char_p
             lib.c2_fastq_unique.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
             lib.c2_fastq_unique_filtered.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -331,6 +343,80 @@ def _line_stats(stats, parsed_nonempty_lines):
     n = int(float(parsed_nonempty_lines) / 4.0)
     stats["N_READS_AFTER_PREPROCESSING"] = n
     stats.setdefault("N_READS_INPUT", n)
+
+
+class FastqStream:
+    """c2_fastq_stream_*: the ingest of FastqUnique chunk by chunk.  next() parses one more chunk (all host threads; ctypes drops
+    the GIL) and returns (unique reads so far, done); everything below that mark is final -- `arena` (one view over the whole
+    reservation: the pointer never moves), offsets_slice(a, b) (copied out: the native array may move at the next call), first-seen
+    order.  counts() are the multiplicities so far (final once done).  Same statistics as FastqUnique when done."""
+
+    def __init__(self, path, min_single_bp_quality=0, min_average_read_quality=0, min_bp_quality_or_N=0):
+        lib = load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        rc = lib.c2_fastq_stream_open(os.fsencode(path), int(min_single_bp_quality), int(min_average_read_quality), int(min_bp_quality_or_N),
+                                      ctypes.byref(self._h))
+        if rc != 0:
+            raise NativeError("c2_fastq_stream_open: %s" % lib.c2_fastq_last_error().decode())
+        self.filtered = min_single_bp_quality > 0 or min_average_read_quality > 0 or min_bp_quality_or_N > 0
+        self.text_bytes = int(lib.c2_fastq_stream_text_bytes(self._h))
+        ptr = lib.c2_fastq_stream_arena(self._h)
+        self.arena = (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), (self.text_bytes + 1,))
+                      if ptr else np.zeros(1, dtype=np.uint8))
+        self.n_unique, self.arena_bytes, self.done = 0, 0, self.text_bytes == 0
+
+    def next(self):
+        nu, ab, dn = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_int32(0)
+        rc = self._lib.c2_fastq_stream_next(self._h, ctypes.byref(nu), ctypes.byref(ab), ctypes.byref(dn))
+        if rc != 0:
+            raise NativeError("c2_fastq_stream_next: %s" % self._lib.c2_fastq_last_error().decode())
+        self.n_unique, self.arena_bytes, self.done = int(nu.value), int(ab.value), bool(dn.value)
+        return self.n_unique, self.done
+
+    def offsets_slice(self, a, b):
+        """offsets[a : b + 1] of the unique reads a .. b - 1 (a copy)"""
+        ptr = self._lib.c2_fastq_stream_offsets(self._h)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint64)), (self.n_unique + 1,))[a:b + 1].copy()
+
+    def counts(self):
+        out = np.zeros(self.n_unique, dtype=np.uint32)
+        rc = self._lib.c2_fastq_stream_counts(self._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(self.n_unique))
+        if rc != 0:
+            raise NativeError("c2_fastq_stream_counts: %s" % self._lib.c2_fastq_last_error().decode())
+        return out
+
+    @property
+    def n_reads(self):
+        return int(self._lib.c2_fastq_stream_n_reads(self._h))
+
+    def line_stats(self, stats):
+        if self.filtered:
+            stats["N_READS_INPUT"] = int(float(self._lib.c2_fastq_stream_nonempty_lines_input(self._h)) / 4.0)
+        _line_stats(stats, int(self._lib.c2_fastq_stream_nonempty_lines(self._h)))
+
+    def close(self):
+        if self._h:
+            big = self.arena_bytes > (32 << 20)
+            self.arena = None
+            h, self._h = self._h, ctypes.c_void_p()
+            if big and not os.environ.get("C2_SYNC_FREE"):
+                import threading
+                threading.Thread(target=self._lib.c2_fastq_stream_close, args=(h,), name="c2-fastq-free", daemon=False).start()
+            else:
+                self._lib.c2_fastq_stream_close(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FastqUnique:

@@ -1026,6 +1026,78 @@ int c2_fastq_unique_filtered(const char* path, int32_t min_bp_qual_in_read, int3
     return 0;
 }
 
+// ---- the same ingest, chunk by chunk: after every c2_fastq_stream_next the unique reads seen so far (arena bytes, offsets, in
+// first-seen order) are final, so the caller can hand the new ones to the GPU while the next chunk is parsed
+// (pipeline.quantify_fastq).  The arena pointer never moves; the offsets pointer is valid until the next call.
+}  // extern "C"
+struct c2_fastq_stream {
+    FastqStream S;
+    TextSource src;                // .gz input / input of the read filter: the whole text in memory
+    TextBuf filtered;              // output of the read filter
+    uint64_t lines_input = 0;      // non-empty lines of the text in front of the filter
+};
+extern "C" {
+
+int c2_fastq_stream_open(const char* path, int32_t min_bp_qual_in_read, int32_t min_av_read_qual, int32_t min_bp_qual_or_N, c2_fastq_stream** out) {
+    if (!path || !out) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<c2_fastq_stream> H(new c2_fastq_stream);
+    const bool filter = min_bp_qual_in_read > 0 || min_av_read_qual > 0 || min_bp_qual_or_N > 0;
+    bool gz = false;
+    {
+        FILE* probe = fopen(path, "rb");
+        if (!probe) { g_fastq_error = std::string("cannot open ") + path; return C2_E_INVALID; }
+        unsigned char magic[2] = {0, 0};
+        gz = fread(magic, 1, 2, probe) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        fclose(probe);
+    }
+    if (!gz && !filter) {
+        H->S.fd = open(path, O_RDONLY);
+        struct stat st;
+        if (H->S.fd < 0 || fstat(H->S.fd, &st) != 0) { g_fastq_error = std::string("cannot open ") + path; return C2_E_INVALID; }
+        H->S.n = (size_t)st.st_size;
+    } else {
+        std::string err;
+        if (!H->src.open_path(path, err)) { g_fastq_error = err; return C2_E_INVALID; }
+        H->S.mem = H->src.p; H->S.n = H->src.n;
+        if (filter) {
+            size_t n_f = 0;
+            const int rc = filter_fastq_text(H->src.p, H->src.n, min_bp_qual_in_read, min_av_read_qual, min_bp_qual_or_N, H->filtered, n_f, H->lines_input, err);
+            if (rc) { g_fastq_error = err; return rc; }
+            H->S.mem = n_f ? H->filtered.get() : ""; H->S.n = n_f;
+        }
+    }
+    if (!H->S.init(H->S.n ? plain_threads(H->S.n) : 1, stream_range_bytes())) { g_fastq_error = H->S.err; return C2_E_INVALID; }
+    if (H->S.n == 0) H->S.done = true;
+    *out = H.release();
+    return 0;
+}
+
+int c2_fastq_stream_next(c2_fastq_stream* h, uint64_t* n_unique, uint64_t* arena_bytes, int32_t* done) {
+    if (!h) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    if (!h->S.done && !h->S.next()) { g_fastq_error = h->S.err; return h->S.overflow ? C2_E_TOO_LARGE : C2_E_INVALID; }
+    if (n_unique) *n_unique = (uint64_t)h->S.offsets.size() - 1;
+    if (arena_bytes) *arena_bytes = h->S.offsets.back();
+    if (done) *done = h->S.done ? 1 : 0;
+    return 0;
+}
+
+const uint8_t* c2_fastq_stream_arena(const c2_fastq_stream* h) { return h ? h->S.arena.data() : nullptr; }
+const uint64_t* c2_fastq_stream_offsets(const c2_fastq_stream* h) { return h ? h->S.offsets.data() : nullptr; }
+uint64_t c2_fastq_stream_text_bytes(const c2_fastq_stream* h) { return h ? (uint64_t)h->S.n : 0; }
+uint64_t c2_fastq_stream_n_reads(const c2_fastq_stream* h) { return h ? h->S.n_reads : 0; }
+uint64_t c2_fastq_stream_nonempty_lines(const c2_fastq_stream* h) { return h ? h->S.nonempty_lines : 0; }
+uint64_t c2_fastq_stream_nonempty_lines_input(const c2_fastq_stream* h) { return h ? h->lines_input : 0; }
+
+int c2_fastq_stream_counts(c2_fastq_stream* h, uint32_t* out, uint64_t n) {
+    if (!h || (!out && n)) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    if (n != (uint64_t)h->S.offsets.size() - 1) { g_fastq_error = "counts: n differs from the number of unique reads"; return C2_E_INVALID; }
+    if (!h->S.counts_into(out)) { g_fastq_error = "more than 2^32 - 1 copies of one sequence"; return C2_E_TOO_LARGE; }
+    return 0;
+}
+
+void c2_fastq_stream_close(c2_fastq_stream* h) { delete h; }
+
 // ---- host-side helpers of the read -> reference bookkeeping that sits between ingest and the kernels ----------------
 
 // Strand plan of get_new_variant_object (CRISPRessoCORE.py:656-687) for every read against one reference:

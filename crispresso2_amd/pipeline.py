@@ -192,21 +192,154 @@ def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
     return member, use2, aligned
 
 
+STREAM_MIN_BATCH = 200_000          # unique reads: smaller arrivals wait for the next chunk (a launch chain per chunk is not free)
+
+
+def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings):
+    """Ingest and device overlapped (replaces "parse the whole file, then align", CRISPRessoCORE.py:1825-1849 + :1957-1981).
+    A host thread drives the native chunked parser (_native.FastqStream.next: all cores, GIL released); whenever it has brought
+    STREAM_MIN_BATCH new unique reads, this thread copies them through pinned staging to the device on a copy stream and enqueues
+    the seed test (c2_strand_plan_kernel) and the all-references alignment batch for exactly those reads on the compute stream.
+    Nothing waits for the device until the file is exhausted.  -> the unique reads (arena, offsets, final multiplicities), the
+    strand plan and the concatenated outputs of batch 1 (task = read * n_refs + reference, as in the one-batch flow)."""
+    import queue
+    import threading
+    import time
+    import torch
+    t_start = time.perf_counter()
+    k = len(ref_names)
+    on_gpu = dev.type == "cuda"
+    compute = torch.cuda.current_stream(dev)
+    copy_stream = torch.cuda.Stream(device=dev) if on_gpu else compute
+    q = queue.Queue()
+
+    def producer():
+        try:
+            done = fq.done
+            seen = 0
+            while not done:
+                nu, done = fq.next()
+                if nu - seen >= STREAM_MIN_BATCH or (done and nu > seen):
+                    q.put((seen, nu, fq.offsets_slice(seen, nu)))
+                    seen = nu
+            q.put(None)
+        except BaseException as e:
+            q.put(e)
+    th = threading.Thread(target=producer, name="c2-fastq-stream")
+    th.start()
+    staging = [None, None]                # pinned (arena bytes, offsets) buffers, alternating; an event says when the copy out of one is done
+    staged_ev = [None, None]
+    parts, off_parts, dropped = [], [], []
+    turn = 0
+    t_ingest_done = None
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            n0, n1, off = item
+            empty = np.nonzero(off[1:] == off[:-1])[0]
+            if len(empty):
+                # the empty sequence (blank line / truncated record; at most one unique read): dropped, as in quantify_fastq's one-batch
+                # flow (the reference's aligner indexes seq[-1] of an empty string: undefined there)
+                dropped.extend((n0 + empty).tolist())
+                off = np.delete(off, empty + 1)
+            m = len(off) - 1
+            if m == 0:
+                continue
+            base = int(off[0])
+            nbytes = int(off[-1]) - base
+            lens = (off[1:] - off[:-1]).astype(np.int64)
+            max_lj = max(int(lens.max()), 1)
+            rel = (off - off[0]).astype(np.int64)
+            i = turn & 1
+            turn += 1
+            if staged_ev[i] is not None:
+                staged_ev[i].synchronize()
+            if on_gpu:
+                if staging[i] is None or staging[i][0].numel() < nbytes or staging[i][1].numel() < m + 1:
+                    staging[i] = (torch.empty(max(nbytes, 1) * 5 // 4, dtype=torch.uint8, pin_memory=True),
+                                  torch.empty((m + 1) * 5 // 4, dtype=torch.int64, pin_memory=True))
+                hb, ho = staging[i][0][:max(nbytes, 1)], staging[i][1][:m + 1]
+                hb.numpy()[:nbytes] = fq.arena[base:base + nbytes]
+                ho.numpy()[:] = rel
+                with torch.cuda.stream(copy_stream):
+                    d_reads = hb.to(dev, non_blocking=True)
+                    d_off = ho.to(dev, non_blocking=True)
+                    staged_ev[i] = torch.cuda.Event()
+                    staged_ev[i].record(copy_stream)
+                compute.wait_event(staged_ev[i])
+                d_reads.record_stream(compute)
+                d_off.record_stream(compute)
+            else:                                                     # (tests: the "device" is host memory)
+                d_reads = torch.from_numpy(np.ascontiguousarray(fq.arena[base:base + max(nbytes, 1)]).copy())
+                d_off = torch.from_numpy(rel.copy())
+            stream = compute.cuda_stream
+            d_plan = torch.empty(m * k, dtype=torch.uint8, device=dev)
+            C.strand_plan_device(ctx, m, d_reads.data_ptr(), d_off.data_ptr(), max_lj, refs, ref_names, args.aln_seed_count, args.aln_seed_min,
+                                 d_plan.data_ptr(), stream=stream)
+            d_str = (d_plan == 1).to(torch.uint8)
+            stride = aligner.stride_for(max_lj)
+            a = torch.empty((m * k, stride), dtype=torch.uint8, device=dev)
+            f = torch.empty((m * k, stride), dtype=torch.uint8, device=dev)
+            r = torch.empty((m * k, 32), dtype=torch.uint8, device=dev)
+            aligner.align_device(m, d_reads.data_ptr(), d_off.data_ptr(), a.data_ptr(), f.data_ptr(), r.data_ptr(), stride, max_lj,
+                                 d_strands=d_str.data_ptr(), all_refs=True, stream=stream, legacy=legacy)
+            parts.append((a, f, r, d_plan, stride, d_reads, d_off, d_str))
+            off_parts.append(off)
+    finally:
+        th.join()
+    t_ingest_done = time.perf_counter()
+    n = fq.n_unique - len(dropped)
+    if off_parts:
+        offsets = np.concatenate([off_parts[0]] + [o[1:] for o in off_parts[1:]]).astype(np.uint64)
+    else:
+        offsets = np.zeros(1, dtype=np.uint64)
+    counts = fq.counts()
+    if dropped:
+        counts = np.delete(counts, dropped)
+    arena = fq.arena[:int(offsets[-1])]
+    stride = max([p_[4] for p_ in parts], default=aligner.stride_for(1))
+
+    def widen(x, st):
+        return x if st == stride else torch.nn.functional.pad(x, (0, stride - st))
+    if len(parts) == 1:
+        a1, f1, r1, d_plan = parts[0][0], parts[0][1], parts[0][2], parts[0][3]
+    elif parts:
+        a1 = torch.cat([widen(p_[0], p_[4]) for p_ in parts])
+        f1 = torch.cat([widen(p_[1], p_[4]) for p_ in parts])
+        r1 = torch.cat([p_[2] for p_ in parts])
+        d_plan = torch.cat([p_[3] for p_ in parts])
+    else:
+        a1 = f1 = torch.empty((0, stride), dtype=torch.uint8, device=dev)
+        r1 = torch.empty((0, 32), dtype=torch.uint8, device=dev)
+        d_plan = torch.empty(0, dtype=torch.uint8, device=dev)
+    plan = d_plan.cpu().numpy().reshape(n, k)                          # (waits for the last batch)
+    del parts
+    if timings is not None:
+        timings["ingest_dedup_streamed"] = t_ingest_done - t_start
+        timings["stream_tail_device"] = time.perf_counter() - t_ingest_done
+        timings["stream_batches"] = turn
+    return dict(arena=arena, offsets=offsets, counts=counts, plan=plan, stride=stride, a1=a1, f1=f1, r1=r1)
+
+
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
-                    timings=None, pe_scaffold_dna_info=None, shard=None):
+                    timings=None, pe_scaffold_dna_info=None, shard=None, fastq_stream=None):
     """See _quantify_unique.  (This wrapper only makes sure that the host thread the run starts -- it reads `arena`, which may be a
     view of native memory the caller frees -- has ended before control returns, also when the run raises.)"""
     threads = []
     try:
         return _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
-                                timings, pe_scaffold_dna_info, threads, shard)
+                                timings, pe_scaffold_dna_info, threads, shard, fastq_stream)
     finally:
         for t in threads:
             t.join()
 
 
 def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
-                     timings, pe_scaffold_dna_info, _threads, shard=None):
+                     timings, pe_scaffold_dna_info, _threads, shard=None, fastq_stream=None):
     """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
     shard: None -- this process aligns every read it was given.  Otherwise arena / offsets / read_counts are the WHOLE run's unique
     reads (every rank holds the same list, as every worker of the reference sees the parent's variantCache keys) and `shard` names
@@ -216,6 +349,8 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     and every rank applies the reference's sequential count transfer to the global counts before it weighs its own reads -- so the
     all-reduced tensors equal the single-process ones also when a read and its reverse complement land in different shards.
     Implies reduce_across_ranks.
+    fastq_stream: a _native.FastqStream instead of arena / offsets / read_counts -- the file is parsed chunk by chunk on a host thread
+    while the device already runs the seed test and the alignments of the unique reads the previous chunks brought (_stream_front).
     timings: optional dict that receives the wall seconds of every stage.
     pe_scaffold_dna_info: (index, dna) of get_pe_scaffold_search for runs with --prime_editing_pegRNA_scaffold_seq: reads whose
     alignment against 'Prime-edited' carries `dna` right after reference base index-1 are counted for 'Scaffold-incorporated'
@@ -244,6 +379,17 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if scaffold_rule and (pe_scaffold_dna_info is None or pe_scaffold_dna_info[1] is None):
         raise ValueError("prime_editing_pegRNA_scaffold_seq needs pe_scaffold_dna_info = (index, dna) of get_pe_scaffold_search")
     ctx = ctx or _native.default_context()
+    dev = torch.device("cuda", device)
+    aligner = BatchAligner([refs[name]['sequence'] for name in ref_names], [refs[name]['gap_incentive'] for name in ref_names],
+                           [refs[name]['include_idxs'] for name in ref_names], aln_matrix,
+                           args.needleman_wunsch_gap_open, args.needleman_wunsch_gap_extend, ctx=ctx)
+    front = None
+    if fastq_stream is not None:
+        if shard is not None:
+            raise ValueError("a sharded run cuts the list of ALL unique reads: it cannot start before the file is parsed")
+        front = _stream_front(fastq_stream, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
+        arena, offsets, read_counts = front["arena"], front["offsets"], front["counts"]
+        t_last[0] = time.perf_counter()
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     # the whole run's unique reads (what the reverse-complement partner search looks at) and the part this process aligns
     g_arena, g_offsets, g_raw = arena, offsets, np.asarray(read_counts, dtype=np.int64)
@@ -267,12 +413,8 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         read_counts = g_raw[shard_idx]
     n, k = len(read_counts), len(ref_names)
     L = [len(refs[name]['sequence']) for name in ref_names]
-    dev = torch.device("cuda", device)
     lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
     max_lj = int(lens.max()) if n else 1
-    aligner = BatchAligner([refs[name]['sequence'] for name in ref_names], [refs[name]['gap_incentive'] for name in ref_names],
-                           [refs[name]['include_idxs'] for name in ref_names], aln_matrix,
-                           args.needleman_wunsch_gap_open, args.needleman_wunsch_gap_extend, ctx=ctx)
     if reduce_across_ranks:
         # every rank must build the SAME tensor (the histogram length depends on the longest read): agree on it first
         max_lj = C.all_reduce_max(max_lj, dev)
@@ -348,11 +490,12 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             d_view = torch.zeros((k,) + tuple(layout.shape()), dtype=torch.int64, device=dev)
         return finish(d_view, d_scaffold, None)
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
-    if not arena.flags.writeable:
-        arena = arena.copy()                                      # torch.from_numpy wants a writable array
-    # the reads go to the device now: the copy is in flight while the host tests the seeds
-    d_reads = torch.from_numpy(arena if arena.size else np.zeros(1, dtype=np.uint8)).to(dev, non_blocking=True)
-    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev, non_blocking=True)
+    if front is None:
+        if not arena.flags.writeable:
+            arena = arena.copy()                                      # torch.from_numpy wants a writable array
+        # the reads go to the device now: the copy is in flight while the host tests the seeds
+        d_reads = torch.from_numpy(arena if arena.size else np.zeros(1, dtype=np.uint8)).to(dev, non_blocking=True)
+        d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev, non_blocking=True)
     lap("setup")
     # which read is the reverse complement of which (for the count merge of :3970-3975) does not depend on the alignments: a host
     # thread looks that up while the device aligns
@@ -369,26 +512,30 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     _threads.append(partner_thread)
     partner_thread.start()
     stream = torch.cuda.current_stream(dev).cuda_stream
-    # the seed test that picks the strand(s) of every (read, reference) alignment (:656-687): on the device, over the reads that
-    # were just sent there (FORCE_HOST_STRAND_PLAN: the host's threaded c2_strand_plan instead -- the tests compare the two)
-    if FORCE_HOST_STRAND_PLAN:
-        plan = strand_plans(arena, offsets, refs, ref_names, args)
-    else:
-        d_plan = torch.empty(n * k, dtype=torch.uint8, device=dev)
-        C.strand_plan_device(ctx, n, d_reads.data_ptr(), d_off.data_ptr(), max_lj, refs, ref_names, args.aln_seed_count, args.aln_seed_min,
-                             d_plan.data_ptr(), stream=stream)
-        plan = d_plan.cpu().numpy().reshape(n, k)
-    lap("strand_plan")
-    stride = aligner.stride_for(max_lj)
-
-    # ---- batch 1: every read against every reference, on the strand the seeds ask for (forward when they ask for both)
-    d_str1 = torch.from_numpy((plan == 1).astype(np.uint8).reshape(-1)).to(dev)
     n1 = n * k
-    a1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
-    f1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
-    r1 = torch.empty((n1, 32), dtype=torch.uint8, device=dev)
-    aligner.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), a1.data_ptr(), f1.data_ptr(), r1.data_ptr(), stride, max_lj,
-                         d_strands=d_str1.data_ptr(), all_refs=True, stream=stream, legacy=legacy)
+    if front is not None:
+        # seed test and batch 1 ran chunk by chunk while the file was parsed
+        plan, stride, a1, f1, r1 = front["plan"], front["stride"], front["a1"], front["f1"], front["r1"]
+    else:
+        # the seed test that picks the strand(s) of every (read, reference) alignment (:656-687): on the device, over the reads that
+        # were just sent there (FORCE_HOST_STRAND_PLAN: the host's threaded c2_strand_plan instead -- the tests compare the two)
+        if FORCE_HOST_STRAND_PLAN:
+            plan = strand_plans(arena, offsets, refs, ref_names, args)
+        else:
+            d_plan = torch.empty(n * k, dtype=torch.uint8, device=dev)
+            C.strand_plan_device(ctx, n, d_reads.data_ptr(), d_off.data_ptr(), max_lj, refs, ref_names, args.aln_seed_count, args.aln_seed_min,
+                                 d_plan.data_ptr(), stream=stream)
+            plan = d_plan.cpu().numpy().reshape(n, k)
+        lap("strand_plan")
+        stride = aligner.stride_for(max_lj)
+
+        # ---- batch 1: every read against every reference, on the strand the seeds ask for (forward when they ask for both)
+        d_str1 = torch.from_numpy((plan == 1).astype(np.uint8).reshape(-1)).to(dev)
+        a1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
+        f1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
+        r1 = torch.empty((n1, 32), dtype=torch.uint8, device=dev)
+        aligner.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), a1.data_ptr(), f1.data_ptr(), r1.data_ptr(), stride, max_lj,
+                             d_strands=d_str1.data_ptr(), all_refs=True, stream=stream, legacy=legacy)
     lap("h2d_align")
 
     # ---- batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments
@@ -592,19 +739,44 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
 
 
 def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None, pe_scaffold_dna_info=None,
-                   shard_across_ranks=False):
+                   shard_across_ranks=False, stream=True):
     """FASTQ file -> QuantResult.  Empty sequences (blank line / truncated record) are dropped, as in variants.read_fastq_unique
     (the reference's aligner indexes seq[-1] of an empty string: undefined there), and N_TOT_READS counts the records that are left.
     shard_across_ranks (torch.distributed initialised, one process per GPU): every rank de-duplicates the file -- the parent's
     variantCache of the reference, which all its workers see -- aligns ITS contiguous range of the unique reads
     (get_variant_cache_equal_boundaries, CRISPRessoCORE.py:1172-1195) and the count tensors are all-reduced; the result is the
-    single-process one on every rank (quantify_unique, `shard`)."""
+    single-process one on every rank (quantify_unique, `shard`).
+    stream (default; one process): the file is parsed in chunks on a host thread while the device already aligns the unique reads of
+    the chunks before (_stream_front) -- same result as the one-batch flow (stream=False), which sharded runs keep."""
     import time
     t0 = time.perf_counter()
     # --min_single_bp_quality / --min_average_read_quality / --min_bp_quality_or_N: the reference filters the file first
     # (CRISPRessoCORE.py:3696-3717); here the filter runs inside the ingest
     flt = [int(getattr(args, k_, 0) or 0) for k_ in ('min_single_bp_quality', 'min_average_read_quality', 'min_bp_quality_or_N')]
     ingest_stats = {}
+    sharded = False
+    if shard_across_ranks:
+        import torch.distributed as dist
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if stream and not sharded and not FORCE_HOST_STRAND_PLAN:
+        fq = None
+        try:
+            fq = _native.FastqStream(path, *flt)
+        except _native.NativeError as e:
+            if "in-memory budget" not in str(e):                     # (a .gz whose text does not fit in memory streams through zlib below)
+                raise
+        if fq is not None:
+            with fq:
+                res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
+                                      pe_scaffold_dna_info=pe_scaffold_dna_info, fastq_stream=fq)
+                fq.line_stats(ingest_stats)
+                n_reads = fq.n_reads
+                t_free = time.perf_counter()
+            if timings is not None:
+                timings["free_ingest"] = time.perf_counter() - t_free
+            res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
+            res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats.get('N_READS_AFTER_PREPROCESSING', int(n_reads))
+            return res
     with _native.FastqUnique(path, *flt, stats=ingest_stats) as fq:      # views of the native arena: nothing is copied on the host
         arena, offsets, counts, n_reads = fq.arena, fq.offsets, fq.counts, fq.n_reads
         if timings is not None:

@@ -327,6 +327,23 @@ const uint64_t* c2_fastq_offsets(const c2_fastq* r);
 const uint32_t* c2_fastq_counts(const c2_fastq* r);
 void c2_fastq_free(c2_fastq* r);
 const char* c2_fastq_last_error(void);
+/* The same ingest chunk by chunk (replaces the reference's one readline loop over the whole file, CRISPRessoCORE.py:1820-1849, when
+ * the caller wants to overlap it with the device): _open takes the path and the three read-filter thresholds (all 0: no filter;
+ * plain text is then pread() chunk by chunk, .gz / filtered input is held in memory); every _next parses one more chunk and
+ * reports the number of unique reads and arena bytes so far and whether the text is exhausted.  Everything below those marks is
+ * final: arena bytes (the pointer never moves), offsets (the pointer is valid until the next _next), first-seen order.
+ * Multiplicities keep growing until done; _counts copies them out (n = the current number of unique reads). */
+typedef struct c2_fastq_stream c2_fastq_stream;
+int c2_fastq_stream_open(const char* path, int32_t min_bp_qual_in_read, int32_t min_av_read_qual, int32_t min_bp_qual_or_N, c2_fastq_stream** out);
+int c2_fastq_stream_next(c2_fastq_stream* s, uint64_t* n_unique, uint64_t* arena_bytes, int32_t* done);
+const uint8_t* c2_fastq_stream_arena(const c2_fastq_stream* s);
+const uint64_t* c2_fastq_stream_offsets(const c2_fastq_stream* s);
+uint64_t c2_fastq_stream_text_bytes(const c2_fastq_stream* s);
+uint64_t c2_fastq_stream_n_reads(const c2_fastq_stream* s);
+uint64_t c2_fastq_stream_nonempty_lines(const c2_fastq_stream* s);          /* of the parsed text (after the filter) */
+uint64_t c2_fastq_stream_nonempty_lines_input(const c2_fastq_stream* s);    /* of the text in front of the filter (0 without one) */
+int c2_fastq_stream_counts(c2_fastq_stream* s, uint32_t* out, uint64_t n);
+void c2_fastq_stream_close(c2_fastq_stream* s);
 /* Paired input: the first pass of process_paired_fastq's n_processes > 1 route, CRISPRessoCORE.py:1296-1334 -- the two
  * files read in lockstep, key = seq1 + '+' + reverse_complement(seq2) (both str.strip()'ed; CRISPRessoShared.py:399-403's
  * reverse complement: a character outside ACGTN_- fails like its KeyError), counted per distinct key in first-seen order;

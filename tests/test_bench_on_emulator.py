@@ -103,4 +103,4 @@ def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fa
         assert e["chain_equals_full_plane"] and e["chain_equals_full_plane_n"] == 90 * k_ and e["all_status_ok"] and e["reads_per_s"] > 0
     e2e = out["e2e"]
     assert e2e["reads"] == 90 and e2e["plain_equals_bgzf"] and e2e["plain"]["reads_per_s"] > 0 and e2e["bgzf"]["reads_per_s"] > 0
-    assert e2e["tallies"]["N_TOT_READS"] == 90 and set(e2e["stage_seconds"]) >= {"ingest_dedup", "h2d_align", "count_kernels"}
+    assert e2e["tallies"]["N_TOT_READS"] == 90 and set(e2e["stage_seconds"]) >= {"ingest_dedup_streamed", "stream_tail_device", "count_kernels"}

@@ -669,3 +669,52 @@ def test_pipeline_on_the_emulator_hek3_and_untreated_runs(tmp_path):
 def test_hek3_and_untreated_runs_on_the_device(tmp_path):
     from crispresso2_amd import _native
     _single_runs(tmp_path, ctx=_native.default_context())
+
+
+@pytest.mark.parametrize("run", ["fanc", "params", "one_batch"])
+def test_streamed_ingest_in_many_small_batches_gives_the_same_files(tmp_path, monkeypatch, run):
+    """pipeline.quantify_fastq's streamed flow forced into MANY batches (chunks of 3 x 2 KiB of text, a device batch for every 15 new
+    unique reads: different longest reads per batch, so the batches' output strides differ and are widened when joined) -- the same
+    18 / 39 files of the reference's runs; `one_batch` is the same file through stream=False, and both flows must agree on every
+    statistic and tensor."""
+    from pipeline_on_emulator import emulated_device
+    from crispresso2_amd import pipeline, tables, refs as RF
+    monkeypatch.setenv("C2_FASTQ_THREADS", "3")
+    monkeypatch.setenv("C2_FASTQ_RANGE_BYTES", "2048")
+    monkeypatch.setattr(pipeline, "STREAM_MIN_BATCH", 15)
+    if run == "params":
+        g, refs, names = _params_golden()
+        fq = tmp_path / "FANC.Cas9.fastq"
+        fq.write_text(_golden()["fastq"])
+        a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+        a["min_average_read_quality"] = 30
+        with emulated_device():
+            res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
+            out = tmp_path / "out"
+            written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+        assert (res.stats["N_READS_INPUT"], res.stats["N_READS_AFTER_PREPROCESSING"]) == (250, 231)
+        assert _compare_params(g, written, str(out)) == 39
+        return
+    g = _golden()
+    fq = tmp_path / "FANC.Cas9.fastq"
+    fq.write_text(g["fastq"] + "@trailing_id_only\n")                 # + a record cut short after its id: the empty sequence, dropped
+    cut = g["cut_point"]
+    ref = RF.make_ref("Reference", g["amplicon"], [cut], [cut, cut + 1], min_aln_score=60)
+    ref["sgRNA_orig_sequences"] = [g["guide"]]
+    with emulated_device():
+        tm = {}
+        res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(), timings=tm,
+                                      stream=(run != "one_batch"))
+        assert ("ingest_dedup_streamed" in tm) == (run != "one_batch")
+        assert run == "one_batch" or tm["stream_batches"] >= 8
+        other = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(),
+                                        stream=(run == "one_batch"))
+        assert other.stats == res.stats
+        for kk, vv in res.per_ref["Reference"].items():
+            ww = other.per_ref["Reference"][kk]
+            assert np.array_equal(vv, ww) if isinstance(vv, np.ndarray) else vv == ww, kk
+        assert res.alleles() == other.alleles()
+        res.stats["N_READS_INPUT"] = res.stats["N_READS_AFTER_PREPROCESSING"] = 250       # (the extra id line is not part of the reference's run)
+        out = tmp_path / "out"
+        names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
+    assert _compare(g, names, str(out)) == 18
