@@ -21,6 +21,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <sched.h>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -256,9 +257,15 @@ uint64_t count_terminators(const char* b, size_t n, size_t lo, size_t hi, uint64
     uint64_t c = 0, ne = 0;
     char prev = lo ? b[lo - 1] : '\n';
     if (memchr(b + lo, '\r', hi - lo) == nullptr) {
-        for (size_t i = lo; i < hi; ++i) { const char x = b[i]; c += (x == '\n'); ne += (x != '\n') & (prev == '\n'); prev = x; }
-        *nonempty += ne;
-        return c;
+        // no carriage return in the range: terminators are the '\n' bytes.  Both counts from the bytes themselves (b[i - 1] read from
+        // memory, no loop-carried state), so the compiler turns the loop into wide compares + horizontal adds
+        size_t i = lo;
+        if (i < hi) { const char x = b[i]; c += (x == '\n'); ne += (x != '\n') & (prev == '\n'); ++i; }
+        const char* q = b;
+        uint64_t c2 = 0, ne2 = 0;
+        for (; i < hi; ++i) { c2 += (uint64_t)(q[i] == '\n'); ne2 += (uint64_t)((q[i] != '\n') & (q[i - 1] == '\n')); }
+        *nonempty += ne + ne2;
+        return c + c2;
     }
     for (size_t i = lo; i < hi; ++i) { const char x = b[i]; c += term_end(b, n, i) ? 1 : 0; ne += (x != '\n') & (prev == '\n'); prev = x; }
     *nonempty += ne;
@@ -303,6 +310,15 @@ void parse_range(const char* b, size_t n, size_t lo, size_t hi, uint64_t line_no
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #include "c2_fastq_stream.h"
+
+// plain files: the ranges read the page cache through a mapping (fault-around maps 16 pages per fault) or through pread() into the
+// threads' buffers (no page-table work, but the kernel copies every page).  C2_FASTQ_SOURCE=mmap|pread; measured per round.
+bool plain_source_is_mapped() {
+    const char* e = getenv("C2_FASTQ_SOURCE");
+    if (e && !strcmp(e, "pread")) return false;
+    if (e && !strcmp(e, "mmap")) return true;
+    return true;
+}
 
 size_t stream_range_bytes() {
     if (const char* e = getenv("C2_FASTQ_RANGE_BYTES")) { const long long v = atoll(e); if (v > 0) return (size_t)v; }
@@ -613,8 +629,43 @@ bool inflate_members(const uint8_t* b, size_t n, TextBuf& text, size_t& n_text) 
     return ok;
 }
 
+// CPUs this process may actually use: the hardware threads, cut to the cgroup's CPU bandwidth quota (cpu.max "<quota> <period>", or
+// cgroup v1's cfs files) and to the affinity mask.  Running more threads than the quota does not add throughput -- the group is
+// throttled for the rest of every period once the quota is spent -- it only adds stalls of up to a period (100 ms).
+unsigned usable_cpus() {
+    static unsigned cached = 0;
+    if (cached) return cached;
+    unsigned n = std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (unsigned)c < n) n = (unsigned)c; }
+    auto read_two = [](const char* path, long long& a, long long& b) {
+        FILE* f = fopen(path, "r");
+        if (!f) return false;
+        char x[64] = {0}, y[64] = {0};
+        const int got = fscanf(f, "%63s %63s", x, y);
+        fclose(f);
+        if (got < 1 || !strcmp(x, "max")) return false;
+        a = atoll(x); b = got >= 2 ? atoll(y) : 0;
+        return a > 0;
+    };
+    long long quota = 0, period = 0;
+    if (read_two("/sys/fs/cgroup/cpu.max", quota, period) && period > 0) {
+        const unsigned q = (unsigned)((quota + period - 1) / period);
+        if (q >= 1 && q < n) n = q;
+    } else {
+        long long q1 = 0, p1 = 0, dummy = 0;
+        if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q1, dummy) && read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p1, dummy) && p1 > 0) {
+            const unsigned q = (unsigned)((q1 + p1 - 1) / p1);
+            if (q >= 1 && q < n) n = q;
+        }
+    }
+    cached = n;
+    return n;
+}
+
 unsigned plain_threads(size_t n) {
-    unsigned threads = std::thread::hardware_concurrency();
+    unsigned threads = usable_cpus();
     const unsigned by_size = (unsigned)(n / (4u << 20)) + 1;              // at least 4 MiB per thread
     if (threads > by_size) threads = by_size;
     unsigned cap = 128;                                                    // (memory-bound work: SMT siblings add little)
@@ -635,7 +686,7 @@ int fastq_unique_gz_whole(const uint8_t* m, size_t n, c2_fastq* R) {
     const double T0 = now_s();
     TextBuf text;
     size_t n_text = 0;
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = usable_cpus();
     if (hw < 1) hw = 1;
     if (hw > 64) hw = 64;
     const char* how = "bgzf";
@@ -728,7 +779,7 @@ struct TextSource {                                             // the whole tex
         const char* route = getenv("C2_FASTQ_GZ");
         const bool stream_only = route && !strcmp(route, "stream");
         const bool use_libdeflate = !(route && !strcmp(route, "zlib"));
-        unsigned hw = std::thread::hardware_concurrency();
+        unsigned hw = usable_cpus();
         if (hw < 1) hw = 1;
         if (hw > 64) hw = 64;
         size_t got = 0;
@@ -934,6 +985,11 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
         if (S.fd < 0 || fstat(S.fd, &st) != 0) { g_fastq_error = std::string("cannot open ") + path; delete R; return C2_E_INVALID; }
         S.n = (size_t)st.st_size;
         int rc = 0;
+        struct Unmap { void* p = nullptr; size_t n = 0; ~Unmap() { if (p) munmap(p, n); } } mapped;
+        if (S.n > 0 && plain_source_is_mapped()) {
+            void* m = mmap(nullptr, S.n, PROT_READ, MAP_PRIVATE, S.fd, 0);
+            if (m != MAP_FAILED) { mapped.p = m; mapped.n = S.n; S.mem = (const char*)m; }
+        }
         if (S.n > 0) {
             const bool trace = getenv("C2_FASTQ_TRACE") != nullptr;
             const double T0 = now_s();
@@ -941,7 +997,9 @@ int c2_fastq_unique(const char* path, c2_fastq** out) {
             if (!S.init(threads, stream_range_bytes())) { g_fastq_error = S.err; delete R; return C2_E_INVALID; }
             while (!S.done) if (!S.next()) { g_fastq_error = S.err; delete R; return S.overflow ? C2_E_TOO_LARGE : C2_E_INVALID; }
             rc = stream_into(S, R);
-            if (trace) fprintf(stderr, "c2_fastq: %u threads, %zu bytes, %u chunks, %.3f s\n", threads, S.n, S.chunk_no / 2, now_s() - T0);
+            if (trace) fprintf(stderr, "c2_fastq: %u threads, %zu bytes, %u chunks, %.3f s (load+count %.3f, parse %.3f, grow %.3f, insert %.3f, survivors %.3f, "
+                               "copy %.3f, re-point %.3f, serial %.3f)\n", threads, S.n, S.chunk_no / 2, now_s() - T0, S.phase_s[0], S.phase_s[1], S.phase_s[2],
+                               S.phase_s[3], S.phase_s[4], S.phase_s[5], S.phase_s[6], S.phase_s[7]);
         } else {
             R->offsets.push_back(0);
         }
@@ -1035,6 +1093,8 @@ struct c2_fastq_stream {
     TextSource src;                // .gz input / input of the read filter: the whole text in memory
     TextBuf filtered;              // output of the read filter
     uint64_t lines_input = 0;      // non-empty lines of the text in front of the filter
+    void* plain_map = nullptr; size_t plain_map_n = 0;       // a plain file read through a mapping
+    ~c2_fastq_stream() { if (plain_map) munmap(plain_map, plain_map_n); }
 };
 extern "C" {
 
@@ -1056,6 +1116,10 @@ int c2_fastq_stream_open(const char* path, int32_t min_bp_qual_in_read, int32_t 
         struct stat st;
         if (H->S.fd < 0 || fstat(H->S.fd, &st) != 0) { g_fastq_error = std::string("cannot open ") + path; return C2_E_INVALID; }
         H->S.n = (size_t)st.st_size;
+        if (H->S.n > 0 && plain_source_is_mapped()) {
+            void* m = mmap(nullptr, H->S.n, PROT_READ, MAP_PRIVATE, H->S.fd, 0);
+            if (m != MAP_FAILED) { H->plain_map = m; H->plain_map_n = H->S.n; H->S.mem = (const char*)m; }
+        }
     } else {
         std::string err;
         if (!H->src.open_path(path, err)) { g_fastq_error = err; return C2_E_INVALID; }
@@ -1109,7 +1173,7 @@ int c2_strand_plan(const uint8_t* arena, const uint64_t* offsets, uint64_t n, co
     if (!offsets || !out_plan || n_seeds < 0 || (n_seeds && (!fw_seeds || !rc_seeds))) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
     std::vector<std::string> fw, rc;
     for (int q = 0; q < n_seeds; ++q) { fw.emplace_back(fw_seeds[q]); rc.emplace_back(rc_seeds[q]); }
-    unsigned threads = std::thread::hardware_concurrency();
+    unsigned threads = usable_cpus();
     if (threads > 64) threads = 64;
     if (threads < 1 || n < 4096) threads = 1;
     auto work = [&](uint64_t lo, uint64_t hi) {
@@ -1140,7 +1204,7 @@ int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, 
     // 1. hashes of the aligned reads (threads), 2. table hash -> index (serial inserts, cheap), 3. for every read the index of
     // the read that equals its reverse complement, or -1 (threads; the table is read-only by then), 4. the reference's
     // sequential count transfer over that partner array.
-    unsigned threads = std::thread::hardware_concurrency();
+    unsigned threads = usable_cpus();
     if (threads > 64) threads = 64;
     if (threads < 1 || n < 8192) threads = 1;
     auto run = [&](auto&& fn) {
@@ -1206,7 +1270,7 @@ int c2_merge_reverse_complements(const uint8_t* arena, const uint64_t* offsets, 
 // reference's cache holds the aligned reads only).  Same result as c2_merge_reverse_complements.
 int c2_rc_partners(const uint8_t* arena, const uint64_t* offsets, uint64_t n, int64_t* partner) {
     if (!offsets || !partner) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
-    unsigned threads = std::thread::hardware_concurrency();
+    unsigned threads = usable_cpus();
     if (const char* e = getenv("C2_HOST_THREADS")) threads = (unsigned)atoi(e);
     if (threads > 64) threads = 64;
     if (threads < 1 || n < 8192) threads = 1;

@@ -74,7 +74,7 @@ struct StreamEntry {                      // one unique sequence of the run
 struct LocalSeq { uint64_t h; const uint8_t* p; uint32_t len; uint32_t entry; uint64_t pending; };
 constexpr uint32_t C2_NO_ENTRY = 0xffffffffu;
 
-struct LocalSet {                         // a thread's own table: persists over the chunks
+struct alignas(128) LocalSet {             // a thread's own table: persists over the chunks (own cache lines: its vectors' end pointers move with every new sequence)
     std::vector<uint32_t> slots = std::vector<uint32_t>(1u << 12, 0);
     uint64_t mask = (1u << 12) - 1;
     std::vector<LocalSeq> u;
@@ -126,6 +126,7 @@ struct FastqStream {
     uint64_t n_reads = 0, nonempty_lines = 0;
     bool done = false, overflow = false;
     std::string err;
+    double phase_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // A load + count, B parse, (grow), C global insert, D survivors, E arena copy, F re-point, serial parts
 
     ~FastqStream() { if (slots) munmap((void*)slots, slots_cap * sizeof(std::atomic<uint32_t>)); if (fd >= 0) close(fd); }
 
@@ -198,6 +199,8 @@ struct FastqStream {
         std::vector<uint64_t> terms(T, 0), starts(T, 0), first(T, 0), n_seq(T, 0);
         std::vector<const char*> base(T, nullptr);
         std::vector<size_t> have(T, 0);                              // base[t][x] is valid for x in [max(cut[t], 1) - 1, have[t])
+        double tp = now_s();
+        auto lapse = [&](int k) { const double t = now_s(); phase_s[k] += t - tp; tp = t; };
         // A: load + count.  The view of a range reaches back one byte (is cut[t] a line start?) and forward to the end of the last
         // line that starts inside it (+ one byte, to tell "\r\n" from "\r")
         pool->run([&](unsigned t) {
@@ -216,6 +219,7 @@ struct FastqStream {
             base[t] = B; have[t] = b;
             terms[t] = count_terminators(B, n, lo, hi, &starts[t]);
         });
+        lapse(0);
         uint64_t before = terms_before;
         for (unsigned t = 0; t < T; ++t) {
             const size_t lo = cut[t];
@@ -266,19 +270,22 @@ struct FastqStream {
             n_seq[t] = seqs;
         });
         if (overflow) { err = "a sequence line of 4 GiB"; return false; }
+        lapse(1);
         // room in the global table for everything this chunk can add
         size_t incoming = 0;
         for (unsigned t = 0; t < T; ++t) { incoming += local[t].u.size() - local[t].first_new; n_reads += n_seq[t]; }
-        const size_t need_entries = (size_t)n_entries.load() + incoming + T;
+        const size_t need_entries = (size_t)n_entries.load() + incoming + (size_t)T * 257;
         if (need_entries >= 0xfffffff0ull) { err = "more than 2^32 - 2 unique sequences"; overflow = true; return false; }
         while (seg.size() << SEG_BITS < need_entries) seg.emplace_back(new StreamEntry[(size_t)1 << SEG_BITS]);
         if (need_entries * 2 > slots_cap && !grow_slots(need_entries * 3)) return false;
         const uint64_t gmask = slots_cap - 1;
+        lapse(2);
         // C: what is new to a thread goes to the global table (created there, or found: another thread / an earlier chunk had it);
         // the counts every thread collected in this chunk are added to the entries
         pool->run([&](unsigned t) {
             LocalSet& L = local[t];
             uint32_t spare = C2_NO_ENTRY;
+            uint32_t id_next = 0, id_end = 0;                           // entry ids are taken from the shared counter 256 at a time
             for (size_t i = 0; i < L.u.size(); ++i) {
                 LocalSeq& q = L.u[i];
                 if (!q.pending) continue;
@@ -288,7 +295,10 @@ struct FastqStream {
                     for (;;) {
                         uint32_t s = slots[p].load(std::memory_order_acquire);
                         if (s == 0) {
-                            if (spare == C2_NO_ENTRY) spare = n_entries.fetch_add(1);
+                            if (spare == C2_NO_ENTRY) {
+                                if (id_next == id_end) { id_next = n_entries.fetch_add(256); id_end = id_next + 256; }
+                                spare = id_next++;
+                            }
                             StreamEntry& E = entry(spare);
                             E.h = q.h; E.len = q.len; E.src = q.p; E.chunk = cur; E.arena_off = 0; E.gidx = 0;
                             E.first.store(key, std::memory_order_relaxed); E.count.store(0, std::memory_order_relaxed);
@@ -312,7 +322,9 @@ struct FastqStream {
                 q.pending = 0;
             }
             if (spare != C2_NO_ENTRY) entry(spare).gidx = C2_NO_ENTRY;      // reserved, never published
+            for (; id_next < id_end; ++id_next) entry(id_next).gidx = C2_NO_ENTRY;
         });
+        lapse(3);
         // D: the unique reads this chunk adds, per range in file order: the thread's new sequences whose entry was created in
         // this chunk with THIS occurrence as its first
         std::vector<uint64_t> n_new(T + 1, 0), new_bytes(T + 1, 0);
@@ -325,6 +337,7 @@ struct FastqStream {
             }
             n_new[t] = c; new_bytes[t] = by;
         });
+        lapse(4);
         const uint64_t g0 = offsets.size() - 1, a0 = offsets.back();
         uint64_t gs = g0, as = a0;
         for (unsigned t = 0; t < T; ++t) { const uint64_t c = n_new[t], by = new_bytes[t]; n_new[t] = gs; new_bytes[t] = as; gs += c; as += by; }
@@ -332,6 +345,7 @@ struct FastqStream {
         offsets.resize(gs + 1);
         entry_of.resize(gs);
         arena.resize((size_t)as);
+        lapse(7);
         // E: copy them into the arena
         pool->run([&](unsigned t) {
             LocalSet& L = local[t];
@@ -346,11 +360,13 @@ struct FastqStream {
                 offsets[g] = a;
             }
         });
+        lapse(5);
         // F: the threads' tables point into the arena from now on (their buffers are refilled by the next chunk)
         pool->run([&](unsigned t) {
             LocalSet& L = local[t];
             for (size_t i = L.first_new; i < L.u.size(); ++i) L.u[i].p = arena.data() + entry(L.u[i].entry).arena_off;
         });
+        lapse(6);
         // (the chunk is closed: entries created in it now answer from the arena)
         terms_before = before;
         pos = hi0;
