@@ -276,7 +276,7 @@ class Context:
         return [int(left[k]) for k in range(n.value)]
 
     CHAIN_KERNELS = ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<4>", "c2_align_diagp_kernel<4>", "c2_align_diagx_kernel<2>",
-                     "c2_align_diagp_kernel<2>", "c2_align_diag_kernel", "banded row-strip", "full plane in HBM scratch"]
+                     "c2_align_diagp_kernel<2>", "c2_align_diag_kernel", "banded row-strip", "full plane in HBM scratch", "packed fill with 32-bit adds"]
 
     def chain_info(self, max_read_len, n_refs):
         """-> (names of the kernels in the launch chain for reads up to max_read_len, [packed fill admits reference r])"""

@@ -60,6 +60,8 @@ struct c2_ctx {
     bool diag_rows_dirty = true;
     std::vector<uint8_t> ref_pk_ok;     // per reference: admitted to the packed fill (c2_pk_eligible)
     bool any_pk_ok = false;
+    int pk_bias = 0;                    // ... and this value bias (c2_pk_add32_bias_needed)
+    int pk_beta = 0;                    // > 0: the admitted references run the packed kernels' 32-bit-add variant with this bias (c2_pk_add32_ok)
     bool pk_dirty = true;
     int occ_pk_lds = -1, occ_pk_blocks = 0, occ_pk2_lds = -1, occ_pk2_blocks = 0, occ_pk3_lds = -1, occ_pk3_blocks = 0;
     // staging for the host batch path and the per-call path
@@ -173,7 +175,31 @@ void update_pk_eligibility(c2_ctx* ctx) {
             ctx->ref_pk_ok[r] = c2_pk_eligible(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, 126) ? 1 : 0;   // (the widest band a packed kernel sweeps)
             if (ctx->ref_pk_ok[r]) ctx->any_pk_ok = true;
         }
+    // the 32-bit-add variant of the packed fill: one bias for the whole context (the score-pair tables in LDS carry it), admitted only
+    // if every reference the packed fill admits stays in range with it
+    ctx->pk_beta = 0;
+    if (ctx->any_pk_ok && !getenv("C2_NO_PK_ADD32")) {
+        int beta = 0;
+        for (int r = 0; r < ctx->n_refs; ++r)
+            if (ctx->ref_pk_ok[r]) beta = std::max(beta, c2_pk_beta_needed(ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend));
+        int bias = 0;
+        for (int r = 0; r < ctx->n_refs; ++r)
+            if (ctx->ref_pk_ok[r]) bias = std::max(bias, c2_pk_add32_bias_needed(ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, 126));
+        bool ok = beta > 0;
+        for (int r = 0; r < ctx->n_refs && ok; ++r)
+            if (ctx->ref_pk_ok[r]) ok = c2_pk_add32_ok(ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, 126, beta, bias);
+        if (ok) { ctx->pk_beta = beta; ctx->pk_bias = bias; }
+    }
     ctx->pk_dirty = false;
+}
+
+// the packed kernel of a tier: NA alignments per wavefront, with packed (v_pk_add_i16) or plain 32-bit adds
+const void* pk_kernel(int na, bool add32) {
+    switch (na) {
+        case 8: return add32 ? (const void*)c2_align_diagp_kernel<8, true> : (const void*)c2_align_diagp_kernel<8, false>;
+        case 4: return add32 ? (const void*)c2_align_diagp_kernel<4, true> : (const void*)c2_align_diagp_kernel<4, false>;
+        default: return add32 ? (const void*)c2_align_diagp_kernel<2, true> : (const void*)c2_align_diagp_kernel<2, false>;
+    }
 }
 
 int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
@@ -224,33 +250,33 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
             c2_diagx_plan PP = c2_make_diagx_plan(8, ctx->max_li, g.max_lj, true);
             if (const char* pad = getenv("C2_DEBUG_PK_LDS_PAD")) PP.total += (uint32_t)atoi(pad);   // occupancy experiments
             if (PP.total <= lds_cu) {
-                if (ctx->occ_pk_lds != (int)PP.total) {
+                if (ctx->occ_pk_lds != (int)PP.total * (ctx->pk_beta > 0 ? -1 : 1)) {
                     int nb = 0;
-                    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_diagp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_diagp_kernel<8>, 64, PP.total));
-                    ctx->occ_pk_blocks = nb < 1 ? 1 : nb; ctx->occ_pk_lds = (int)PP.total;
+                    HIPCHK(ctx, hipFuncSetAttribute(pk_kernel(8, ctx->pk_beta > 0), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pk_kernel(8, ctx->pk_beta > 0), 64, PP.total));
+                    ctx->occ_pk_blocks = nb < 1 ? 1 : nb; ctx->occ_pk_lds = (int)PP.total * (ctx->pk_beta > 0 ? -1 : 1);
                 }
                 g.pk = true; g.lds_pk = PP.total; g.blocks_pk = ctx->occ_pk_blocks; g.plane_words_pk = PP.n_words * 128u;   // 8 slots x 16 lanes
             }
             // second tier: four per wavefront, two lane groups of 32 lanes (62 diagonals) in int16
             const c2_diagx_plan P2 = c2_make_diagx_plan(4, ctx->max_li, g.max_lj, true);
             if (g.pk && P2.total <= lds_cu && !getenv("C2_NO_PACKED_TIER2")) {
-                if (ctx->occ_pk2_lds != (int)P2.total) {
+                if (ctx->occ_pk2_lds != (int)P2.total * (ctx->pk_beta > 0 ? -1 : 1)) {
                     int nb = 0;
-                    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_diagp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_diagp_kernel<4>, 64, P2.total));
-                    ctx->occ_pk2_blocks = nb < 1 ? 1 : nb; ctx->occ_pk2_lds = (int)P2.total;
+                    HIPCHK(ctx, hipFuncSetAttribute(pk_kernel(4, ctx->pk_beta > 0), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pk_kernel(4, ctx->pk_beta > 0), 64, P2.total));
+                    ctx->occ_pk2_blocks = nb < 1 ? 1 : nb; ctx->occ_pk2_lds = (int)P2.total * (ctx->pk_beta > 0 ? -1 : 1);
                 }
                 g.pk2 = true; g.lds_pk2 = P2.total; g.blocks_pk2 = ctx->occ_pk2_blocks; g.plane_words_pk2 = P2.n_words * 128u;   // 4 slots x 32 lanes
             }
             // third tier: two per wavefront, one lane group of 64 lanes (126 diagonals) in int16
             const c2_diagx_plan P3 = c2_make_diagx_plan(2, ctx->max_li, g.max_lj, true);
             if (g.pk2 && P3.total <= lds_cu && !getenv("C2_NO_PACKED_TIER3")) {
-                if (ctx->occ_pk3_lds != (int)P3.total) {
+                if (ctx->occ_pk3_lds != (int)P3.total * (ctx->pk_beta > 0 ? -1 : 1)) {
                     int nb = 0;
-                    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_align_diagp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_align_diagp_kernel<2>, 64, P3.total));
-                    ctx->occ_pk3_blocks = nb < 1 ? 1 : nb; ctx->occ_pk3_lds = (int)P3.total;
+                    HIPCHK(ctx, hipFuncSetAttribute(pk_kernel(2, ctx->pk_beta > 0), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pk_kernel(2, ctx->pk_beta > 0), 64, P3.total));
+                    ctx->occ_pk3_blocks = nb < 1 ? 1 : nb; ctx->occ_pk3_lds = (int)P3.total * (ctx->pk_beta > 0 ? -1 : 1);
                 }
                 g.pk3 = true; g.lds_pk3 = P3.total; g.blocks_pk3 = ctx->occ_pk3_blocks; g.plane_words_pk3 = P3.n_words * 128u;   // 2 slots x 64 lanes
             }
@@ -389,8 +415,11 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
                     c2_align_args T = A;
                     chain(T, false, true);
                     T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = t == 0 ? g.plane_words_pk : g.plane_words_pk2;
-                    if (t == 0) hipLaunchKernelGGL(c2_align_diagp_kernel<8>, dim3(grid), dim3(64), g.lds_pk, s, T);
-                    else         hipLaunchKernelGGL(c2_align_diagp_kernel<4>, dim3(grid), dim3(64), g.lds_pk2, s, T);
+                    const bool a32 = ctx->pk_beta > 0;
+                    if (t == 0) { if (a32) hipLaunchKernelGGL((c2_align_diagp_kernel<8, true>), dim3(grid), dim3(64), g.lds_pk, s, T);
+                                  else     hipLaunchKernelGGL((c2_align_diagp_kernel<8, false>), dim3(grid), dim3(64), g.lds_pk, s, T); }
+                    else        { if (a32) hipLaunchKernelGGL((c2_align_diagp_kernel<4, true>), dim3(grid), dim3(64), g.lds_pk2, s, T);
+                                  else     hipLaunchKernelGGL((c2_align_diagp_kernel<4, false>), dim3(grid), dim3(64), g.lds_pk2, s, T); }
                     HIPCHK(ctx, hipGetLastError());
                     mark_first();
                 }
@@ -414,7 +443,8 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
                 c2_align_args T3 = A;
                 chain(T3, false, true);
                 T3.plane = (uint32_t*)ctx->d_plane.p; T3.plane_words_per_wg = g.plane_words_pk3;
-                hipLaunchKernelGGL(c2_align_diagp_kernel<2>, dim3(grid3), dim3(64), g.lds_pk3, s, T3);
+                if (ctx->pk_beta > 0) hipLaunchKernelGGL((c2_align_diagp_kernel<2, true>), dim3(grid3), dim3(64), g.lds_pk3, s, T3);
+                else                  hipLaunchKernelGGL((c2_align_diagp_kernel<2, false>), dim3(grid3), dim3(64), g.lds_pk3, s, T3);
                 HIPCHK(ctx, hipGetLastError());
                 mark_first();
             }
@@ -463,7 +493,7 @@ int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
         all.insert(all.end(), one.begin(), one.end());
         if (ctx->any_pk_ok) {                                      // the packed tables mirror the indexing; a reference that is not admitted gets padding
             const size_t want = one.size();
-            if (ctx->ref_pk_ok[r]) c2_build_diag_rows_pk(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, one);
+            if (ctx->ref_pk_ok[r]) c2_build_diag_rows_pk(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend, one, ctx->pk_beta);
             else one.assign(want, c2_diag_row{0, 0, 0, 5u * C2_PK_LUT_STRIDE});
             allpk.insert(allpk.end(), one.begin(), one.end());
         }
@@ -506,7 +536,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.max_lj = g.max_lj; A.max_passes = g.passes;
     A.max_li = ctx->max_li;
     A.legacy = (b->flags & C2_BATCH_LEGACY_CLASSIFIER) ? 1 : 0;
-    A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
+    A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)ctx->pk_beta; A.pk_bias = (uint32_t)ctx->pk_bias; A.reserved4 = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
     A.diagpk_base = ctx->any_pk_ok ? (const c2_diag_row*)ctx->d_diagrows_pk.p : nullptr;
     A.mat_dim = ctx->sc.mat_dim; A.first_ext_code = ctx->sc.first_ext_code;
     c2_build_base_luts(ctx->sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
@@ -738,7 +768,7 @@ int c2_chain_info(c2_ctx* ctx, int32_t max_read_len, uint32_t* kernels, uint8_t*
     int rc = geometry(ctx, max_read_len, g);
     if (rc) return rc;
     *kernels = (g.pk ? 1u : 0u) | (g.x[0] ? 2u : 0u) | (g.pk2 ? 4u : 0u) | (g.x[1] ? 8u : 0u) | (g.pk3 ? 16u : 0u) | (g.diag ? 32u : 0u) |
-               (g.band_lanes > 0 ? 64u : 0u) | (g.full_hbm ? 128u : 0u);
+               (g.band_lanes > 0 ? 64u : 0u) | (g.full_hbm ? 128u : 0u) | ((g.pk && ctx->pk_beta > 0) ? 256u : 0u);
     if (ref_packed_ok) for (int r = 0; r < ctx->n_refs; ++r) ref_packed_ok[r] = ctx->ref_pk_ok[r];
     return 0;
 }

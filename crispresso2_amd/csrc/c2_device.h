@@ -81,13 +81,16 @@ typedef struct c2_align_args {
     unsigned long long* phase_cycles; // optional: 4 counters of per-phase shader cycles (profiling), else NULL
     uint32_t* plane;              // multi-alignment diagonal kernel: pointer words in HBM/L2, plane_words_per_wg per workgroup
     uint32_t plane_words_per_wg;
-    uint32_t reserved3;
+    uint32_t pk_beta;             // packed kernels: 0, or the per-anti-diagonal bias of the 32-bit-add variant (c2_pk_add32_ok): its row tables, score pairs
+                                  // and boundary values carry it, H(Li, Lj) comes back minus pk_beta * (Li + Lj)
     int32_t mat_dim;              // dimension of the reference's score matrix (CRISPResso2Align.pyx:212 reads the flat element ci * dim + cj)
     int32_t first_ext_code;       // codes >= this belong to read characters with ord >= mat_dim (c2_build_scoring); never valid in a reference
     uint32_t lut_code_lo, lut_code_hi;  // 8-entry byte tables indexed by (ch >> 1) & 7 (A 0, C 1, T 2, G 3, N 7): the score-table code of that base ...
     uint32_t lut_chr_lo, lut_chr_hi;    // ... and the base itself (0xFF where the entry is no base or its code is not a packed one): v_perm_b32 look-ups
     const struct c2_diag_row* diag_base;   // start of the buffer every reference's diag_rows points into
     const struct c2_diag_row* diagpk_base; // the packed kernels' row tables, same indexing: {a, b, c} as int16 pairs, prof = LDS offset of the symbol's pair-score table
+    uint32_t pk_bias;             // the 32-bit-add variant's value bias (c2_pk_add32_bias_needed); the packed-add variant uses the constant C2_PK_BIAS
+    uint32_t reserved4;
 } c2_align_args;
 
 // Kernel arguments for the per-call classifier (find_indels_substitutions / _legacy with full lists).

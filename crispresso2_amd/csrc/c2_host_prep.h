@@ -169,17 +169,73 @@ inline bool c2_pk_eligible(const char* seq, int Li, const int32_t* g32, const c2
     return true;
 }
 
+// ---- the packed fill with plain 32-bit adds (c2_align_diagp_kernel<NA, true>) --------------------------------------------------
+// On gfx950 v_pk_add_i16 issues at half the rate of v_add_u32 (profiles/r03/valu_microbench4.txt: 4.15 against 2.3 cycles per
+// wave64 instruction), and ten of a cell pair's ~25 instructions are such adds.  A 32-bit add of two int16 pairs is the packed add
+// as long as no carry leaves the low half -- true when both halves of both operands are non-negative and stay below 2^15.  The
+// values are (bias 16384 + score >= 0, or the exact 0 of "outside the band"); the constants become non-negative by a bias of
+// beta per ANTI-DIAGONAL: a gap step (one anti-diagonal) adds its constant + beta, a diagonal step (two) its score + 2 beta.  Every
+// value that enters one cell's comparisons lies on the same anti-diagonal, so all of them carry the same beta * (i + j): no
+// comparison changes, H(Li, Lj) is read back minus beta * (Li + Lj).  beta = the largest magnitude among the gap constants of
+// the admitted references (20 for the default gap_open -20).
+// Admitted when, on top of c2_pk_eligible: gap_open <= gap_extend (the last-column correction b - a is then non-negative too) and
+// the biased values stay inside int16: bias + hi + beta * (anti-diagonals of the largest admitted alignment) <= 32000, with the
+// bias as small as c2_pk_eligible's margin allows (lo + hi + 2384 instead of the fixed 16384: 6,272 for a 250-bp amplicon with the
+// default scoring, which admits amplicons up to ~410 bp at gap_open -20).
+// Sentinel-derived values (chains that start from the 0 of a cell outside the band) grow by at most beta + maxS / 2 per anti-diagonal
+// while every real value carries beta per anti-diagonal on top of 16384 - lo, so they stay below the real ones exactly as without
+// the bias (c2_pk_eligible's margin); differences of two values of one cell are bounded by the largest value, < 2^15.
+inline int c2_pk_beta_needed(int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend) {
+    int64_t need = gap_extend < 0 ? -(int64_t)gap_extend : 0;
+    for (int i = 1; i <= Li; ++i) {
+        const int64_t open = (i == Li) ? gap_extend : gap_open;
+        need = std::max<int64_t>(need, -(open + g32[i]));
+        need = std::max<int64_t>(need, -((int64_t)gap_extend + g32[i]));
+        need = std::max<int64_t>(need, -(open + g32[i - 1]));
+    }
+    int64_t smin = 0;
+    for (int16_t v : sc.tbl) smin = std::min<int64_t>(smin, v);
+    need = std::max<int64_t>(need, (-smin + 1) / 2);
+    return need > 30000 ? 30000 : (int)need;
+}
+// hi / lo of c2_pk_eligible for one reference (the most a real cell value can be above, and lie below, the bias)
+inline void c2_pk_range(int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend, int band, int64_t& hi, int64_t& lo) {
+    int64_t smax = 0, smin = 0, gabs = 0;
+    for (int16_t v : sc.tbl) { smax = std::max<int64_t>(smax, v); smin = std::min<int64_t>(smin, v); }
+    for (int i = 0; i <= Li; ++i) gabs = std::max<int64_t>(gabs, g32[i] < 0 ? -(int64_t)g32[i] : (int64_t)g32[i]);
+    const int64_t go = gap_open < 0 ? -(int64_t)gap_open : gap_open, ge = gap_extend < 0 ? -(int64_t)gap_extend : gap_extend;
+    const int64_t L = (int64_t)Li + band;
+    hi = smax * L; lo = L * (-smin) + 4 * go + (band + 4) * (ge + gabs);
+}
+// The bias the 32-bit-add variant needs for this reference: real values must stay above every sentinel-derived one by the margin
+// c2_pk_eligible keeps (bias - lo >= hi + 2384); and whether, with the context's `bias` and `beta`, its largest biased value
+// bias + hi + beta * (anti-diagonals of its longest admitted read, Lj <= Li + band) still fits an int16 with room (<= 32000).
+inline int c2_pk_add32_bias_needed(int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend, int band) {
+    int64_t hi, lo;
+    c2_pk_range(Li, g32, sc, gap_open, gap_extend, band, hi, lo);
+    const int64_t b = lo + hi + 2384;
+    return b > 32000 ? 32000 : (int)((b + 63) & ~(int64_t)63);
+}
+inline bool c2_pk_add32_ok(int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend, int band, int beta, int bias) {
+    if (beta <= 0 || gap_open > gap_extend) return false;
+    int64_t hi, lo;
+    c2_pk_range(Li, g32, sc, gap_open, gap_extend, band, hi, lo);
+    const int64_t L = (int64_t)Li + band;
+    return bias >= lo + hi + 2384 && (int64_t)bias + hi + (int64_t)beta * (2 * L + 8) <= 32000;
+}
+
 // Row records of the packed kernel for one reference, same indexing as c2_build_diag_rows: {a, b, c} duplicated into both
 // int16 halves, prof = byte offset of the reference symbol's pair-score table (code * C2_PK_LUT_STRIDE; table 5 = zeros for rows 0, Li+1
 // and the padding, so that cells outside the matrix add nothing -- as with the 32-bit records' empty score row).
 inline void c2_build_diag_rows_pk(const char* seq, int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend,
-                                  std::vector<c2_diag_row>& out) {
+                                  std::vector<c2_diag_row>& out, int beta = 0) {
+    // beta > 0: the constants of the 32-bit-add variant (see c2_pk_add32_ok): every gap constant + beta, all non-negative
     out.assign((size_t)Li + 2 + 2 * C2_DIAG_ROW_PAD, c2_diag_row{0, 0, 0, 5u * C2_PK_LUT_STRIDE});
     auto dup = [](int x) { return (int32_t)(((uint32_t)x & 0xffffu) | ((uint32_t)x << 16)); };
     for (int i = 1; i <= Li; ++i) {
         const int open = (i == Li) ? gap_extend : gap_open;
         c2_diag_row r;
-        r.a = dup(open + g32[i]); r.b = dup(gap_extend + g32[i]); r.c = dup(open + g32[i - 1]);
+        r.a = dup(open + g32[i] + beta); r.b = dup(gap_extend + g32[i] + beta); r.c = dup(open + g32[i - 1] + beta);
         const uint8_t code = sc.code_of_char[(unsigned char)seq[i - 1]];
         r.prof = (code < 5 ? (uint32_t)code : 5u) * C2_PK_LUT_STRIDE;
         out[C2_DIAG_ROW_PAD + i] = r;

@@ -1096,7 +1096,12 @@ __device__ __forceinline__ void c2_pk_push_none(unsigned& acc) { acc = 0x4040404
 // One pair of steps (E cell on anti-diagonal a = 2k, O cell on a + 1) for both alignments of the lane.  rowE / rowO: packed row
 // constants {a, b, c} (both halves equal: the two reads share the reference); sE / sO: the score pairs of the two cells.
 // ROW: the lane group is a DPP row of 16 lanes (row_shr / row_shl hand-off, no lane switched off).
-template <bool MASK, bool LASTCOL, bool ROW>
+// ADD32: the sums are plain 32-bit adds (v_add_u32, full rate) instead of v_pk_add_i16 (half rate): every operand half is
+// non-negative and the sums stay below 2^15 (c2_pk_add32_ok), so no carry crosses the halves.  The differences and maxima stay packed.
+template <bool ADD32>
+__device__ __forceinline__ unsigned c2_pk_sum(const unsigned a, const unsigned b) { return ADD32 ? a + b : c2_pk_add(a, b); }
+
+template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
 __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2_diag_row rowE, const c2_diag_row rowO, const unsigned sE, const unsigned sO,
                                            const unsigned ge2, const int startE, const int startO, const bool lastcol)
 {
@@ -1104,13 +1109,13 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
     const unsigned upJ = (unsigned)(ROW ? c2_rshr1z((int)S.JO) : c2_shr1z((int)S.JO));
     if (!MASK || a >= startE) {
         const unsigned corr = (LASTCOL && lastcol) ? c2_pk_sub((unsigned)rowE.b, (unsigned)rowE.a) : 0u;
-        const unsigned iFromM = c2_pk_add(c2_pk_add(S.MO, (unsigned)rowE.a), corr);
-        const unsigned iExt = c2_pk_add(S.IO, (unsigned)rowE.b);
-        const unsigned jFromM = c2_pk_add(c2_pk_add(upM, (unsigned)rowE.c), corr);
-        const unsigned jExt = c2_pk_add(upJ, ge2);
+        const unsigned iFromM = c2_pk_sum<ADD32>(c2_pk_sum<ADD32>(S.MO, (unsigned)rowE.a), corr);
+        const unsigned iExt = c2_pk_sum<ADD32>(S.IO, (unsigned)rowE.b);
+        const unsigned jFromM = c2_pk_sum<ADD32>(c2_pk_sum<ADD32>(upM, (unsigned)rowE.c), corr);
+        const unsigned jExt = c2_pk_sum<ADD32>(upJ, ge2);
         const unsigned In = c2_pk_max(iFromM, iExt);
         const unsigned Jn = c2_pk_max(jFromM, jExt);
-        const unsigned Mn = c2_pk_add(S.HE, sE);
+        const unsigned Mn = c2_pk_sum<ADD32>(S.HE, sE);
         const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
         // I opened (iFromM > iExt), J opened (jFromM > jExt), NOT H is I (In < Hn; In <= Hn always), NOT J beats M (Jn < Mn)
         c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
@@ -1122,13 +1127,13 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
     const unsigned lfI = (unsigned)(ROW ? c2_rshl1z((int)S.IE) : c2_shl1z((int)S.IE));
     if (!MASK || a + 1 >= startO) {
         const unsigned corr = (LASTCOL && lastcol) ? c2_pk_sub((unsigned)rowO.b, (unsigned)rowO.a) : 0u;
-        const unsigned iFromM = c2_pk_add(c2_pk_add(lfM, (unsigned)rowO.a), corr);
-        const unsigned iExt = c2_pk_add(lfI, (unsigned)rowO.b);
-        const unsigned jFromM = c2_pk_add(c2_pk_add(S.ME, (unsigned)rowO.c), corr);
-        const unsigned jExt = c2_pk_add(S.JE, ge2);
+        const unsigned iFromM = c2_pk_sum<ADD32>(c2_pk_sum<ADD32>(lfM, (unsigned)rowO.a), corr);
+        const unsigned iExt = c2_pk_sum<ADD32>(lfI, (unsigned)rowO.b);
+        const unsigned jFromM = c2_pk_sum<ADD32>(c2_pk_sum<ADD32>(S.ME, (unsigned)rowO.c), corr);
+        const unsigned jExt = c2_pk_sum<ADD32>(S.JE, ge2);
         const unsigned In = c2_pk_max(iFromM, iExt);
         const unsigned Jn = c2_pk_max(jFromM, jExt);
-        const unsigned Mn = c2_pk_add(S.HO, sO);
+        const unsigned Mn = c2_pk_sum<ADD32>(S.HO, sO);
         const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
         c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
         S.MO = Mn; S.IO = In; S.JO = Jn; S.HO = Hn;
@@ -1463,7 +1468,7 @@ __device__ __forceinline__ int c2_tab_load(const int* T, const int lane) { retur
 // look-ups (row table offset + pair symbol), requested at the top of the group.
 struct c2_pk_cap { unsigned H, gf; };                              // the two alignments' H(Li, Lj) and gap-free words, captured at the cell (Li, Lj)
 
-template <bool MASK, bool LASTCOL, bool ROW>
+template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
 __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
                                             const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
                                             const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
@@ -1481,7 +1486,7 @@ __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int k = 4 * g + q;
-        c2_pk_pair<MASK, LASTCOL, ROW>(S, 2 * k, R[q], R[q + 1], sc[2 * q], sc[2 * q + 1], ge2, L.startE, L.startO, LASTCOL && (k == L.kLast));
+        c2_pk_pair<MASK, LASTCOL, ROW, ADD32>(S, 2 * k, R[q], R[q + 1], sc[2 * q], sc[2 * q + 1], ge2, L.startE, L.startO, LASTCOL && (k == L.kLast));
         if (q == 1) { w0 = S.acc; S.gf &= w0; }                    // anti-diagonals 8g .. 8g+3 of both alignments
         if (q == 3) S.gf &= S.acc;                                  // ... 8g+4 .. 8g+7
         if (LASTCOL && k == L.kCap) {
@@ -1495,18 +1500,18 @@ __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c
     wordsB[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x07060302u);
 }
 
-template <bool MASK, bool LASTCOL, bool ROW>
+template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
 __device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
                                              c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
                                              const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
                                              unsigned* wordsA, unsigned* wordsB, const int wordStride)
 {
     for (; g + 1 <= g_stop; g += 2) {
-        c2_pk_group<MASK, LASTCOL, ROW>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
-        c2_pk_group<MASK, LASTCOL, ROW>(S, g + 1, L, ge2, CAP, RB, CB, RA, CA, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g + 1, L, ge2, CAP, RB, CB, RA, CA, rows, lds, lutBase, wordsA, wordsB, wordStride);
     }
     if (g <= g_stop) {
-        c2_pk_group<MASK, LASTCOL, ROW>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
         ++g;
 #pragma unroll
         for (int q = 0; q < 5; ++q) RA[q] = RB[q];
@@ -1515,9 +1520,11 @@ __device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g
     }
 }
 
-template <int NA, bool PK>
+template <int NA, bool PK, bool ADD32 = false>
 __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
 {
+    const int beta = (PK && ADD32) ? (int)A.pk_beta : 0;               // per-anti-diagonal bias of the 32-bit-add variant (else 0)
+    const int PKB = (PK && ADD32) ? (int)A.pk_bias : C2_PK_BIAS;        // the value bias: the smallest one that keeps c2_pk_eligible's margin there
     // PK (c2_align_diagp_kernel): NA alignments in NA / 2 lane groups, two per group (slots 2g and 2g+1 in the two halves of the lanes' registers)
     constexpr int NG = PK ? NA / 2 : NA;                             // lane groups
     // lanes per group, live lanes, diagonals per band.  A packed group of 16 lanes is a DPP row: its hand-off is row_shr / row_shl,
@@ -1566,7 +1573,8 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
         for (int e = lane; e < C2_PK_LUT_CODES * 64; e += 64) {
             const int rc = e >> 6, cA = (e >> 3) & 7, cB = e & 7;
             unsigned v = 0;
-            if (rc < C2_PK_PAD_TABLE && rc < A.n_codes) v = ((unsigned)c2_sbfe4((int)A.score_pk[rc], 4 * cA) & 0xffffu) | ((unsigned)c2_sbfe4((int)A.score_pk[rc], 4 * cB) << 16);
+            if (rc < C2_PK_PAD_TABLE && rc < A.n_codes)
+                v = ((unsigned)(c2_sbfe4((int)A.score_pk[rc], 4 * cA) + 2 * beta) & 0xffffu) | ((unsigned)(c2_sbfe4((int)A.score_pk[rc], 4 * cB) + 2 * beta) << 16);
             lut[rc * (int)(C2_PK_LUT_STRIDE / 4u) + (e & 63)] = v;
         }
     }
@@ -1786,10 +1794,11 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             S.acc = 0u; S.gf = 0xffffffffu;
             {
                 // boundary cells (pyx:153-176) with the bias; the sentinel min_score is the number 0 here
-                const int bE = ((dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + vg0) + C2_PK_BIAS;
-                const int mE = (dE == 0) ? C2_PK_BIAS : 0, iE = (dE < 0) ? bE : 0, jE = (dE > 0) ? bE : 0;
+                // (beta: the boundary cell of diagonal d lies on anti-diagonal |d|)
+                const int bE = ((dE == 0) ? 0 : (ge + beta) * (dE > 0 ? dE : -dE) + vg0) + PKB;
+                const int mE = (dE == 0) ? PKB : 0, iE = (dE < 0) ? bE : 0, jE = (dE > 0) ? bE : 0;
                 S.ME = c2_pk_dup(mE); S.IE = c2_pk_dup(iE); S.JE = c2_pk_dup(jE); S.HE = c2_pk_dup(c2_imax(c2_imax(mE, iE), jE));
-                const int bO = ge * (dO > 0 ? dO : -dO) + vg0 + C2_PK_BIAS;
+                const int bO = (ge + beta) * (dO > 0 ? dO : -dO) + vg0 + PKB;
                 const int iO = (dO < 0) ? bO : 0, jO = (dO > 0) ? bO : 0;
                 S.MO = 0u; S.IO = c2_pk_dup(iO); S.JO = c2_pk_dup(jO); S.HO = c2_pk_dup(c2_imax(iO, jO));
             }
@@ -1809,15 +1818,15 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             unsigned* wordsB = wordsA + slotWords;
             int g = 0;
             const int gA_stop = gA < g_end ? gA : g_end;
-            unsigned ge2 = c2_pk_dup(ge);
+            unsigned ge2 = c2_pk_dup(ge + beta);
             const unsigned lutBase = P.pairlut;
             if (gC <= gA_stop) {
-                c2_pk_groups<true, true, ROWDPP>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<true, true, ROWDPP, ADD32>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             } else {
-                c2_pk_groups<true, false, ROWDPP>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
-                c2_pk_groups<false, false, ROWDPP>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<true, false, ROWDPP, ADD32>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<false, false, ROWDPP, ADD32>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             }
-            c2_pk_groups<false, true, ROWDPP>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+            c2_pk_groups<false, true, ROWDPP, ADD32>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             C2_LANES_ACTIVE_END()
         }
         if (!PK && any_ok) {
@@ -1897,7 +1906,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             bool gapfree;
             if (PK) {
                 const int half = 16 * (s & 1);
-                Hend = (int)(int16_t)(((unsigned)__builtin_amdgcn_readlane((int)CAP.H, lane_end) >> half) & 0xffffu) - C2_PK_BIAS;
+                Hend = (int)(int16_t)(((unsigned)__builtin_amdgcn_readlane((int)CAP.H, lane_end) >> half) & 0xffffu) - PKB - beta * (Li + Lj);
                 gapfree = (((unsigned)__builtin_amdgcn_readlane((int)CAP.gf, lane_end) >> half) & 0x1111u) == 0x1111u;   // the E cells (cells 0 and 2 of a word): bits 0 and 4 of both bytes
             } else {
                 Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
@@ -1980,8 +1989,8 @@ template <int NA>
 __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A) { c2_diagx_body<NA, false>(A); }
 
 // NA alignments per wavefront, two per lane group, int16 DP values (see "Packed fill")
-template <int NA>
-__global__ __launch_bounds__(64, 3) void c2_align_diagp_kernel(c2_align_args A) { c2_diagx_body<NA, true>(A); }
+template <int NA, bool ADD32 = false>
+__global__ __launch_bounds__(64, 3) void c2_align_diagp_kernel(c2_align_args A) { c2_diagx_body<NA, true, ADD32>(A); }
 
 // =====================================================================================
 // Per-call classifier with full position lists: find_indels_substitutions

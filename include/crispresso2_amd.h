@@ -214,7 +214,7 @@ int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t
 int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4);
 /* The launch chain a batch with reads up to max_read_len would get: *kernels bit 0 c2_align_diagp_kernel<8>, 1 c2_align_diagx_kernel<4>,
  * 2 diagp<4>, 3 diagx<2>, 4 diagp<2>, 5 c2_align_diag_kernel, 6 banded row-strip first launch, 7 the last launch keeps its pointer plane
- * in HBM scratch; ref_packed_ok (n_refs bytes, may be NULL): 1 where the packed int16 fill admits the reference (its DP values provably
+ * in HBM scratch, 8 the packed kernels run their 32-bit-add variant (c2_pk_add32_ok: sums as v_add_u32 under a per-anti-diagonal bias); ref_packed_ok (n_refs bytes, may be NULL): 1 where the packed int16 fill admits the reference (its DP values provably
  * fit, c2_pk_eligible) -- the int32 kernels run everything else (the reference's C ints, CRISPResso2Align.pyx:142-147). */
 int c2_chain_info(c2_ctx* ctx, int32_t max_read_len, uint32_t* kernels, uint8_t* ref_packed_ok);
 /* The same for up to 8 tiers, plus per tier the number of tasks its packed (int16) kernel could not pair and handed to the 32-bit

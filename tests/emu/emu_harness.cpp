@@ -12,11 +12,14 @@
 alignas(16) unsigned char c2_smem[163840];
 #include "../../crispresso2_amd/csrc/c2_kernels.hip"
 
+static int g_last_pk_beta = 0, g_last_pk_bias = 0;   // the last emu_align_batch's 32-bit-add parameters (0: packed adds)
 static unsigned g_last_unpaired = 0;     // tasks the first packed tier of the last emu_align_batch could not pair
 
 extern "C" {
 
 unsigned emu_last_unpaired() { return g_last_unpaired; }
+int emu_last_pk_beta() { return g_last_pk_beta; }
+int emu_last_pk_bias() { return g_last_pk_bias; }
 
 int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offsets, const uint16_t* ref_ids,
                     const uint8_t* strands, int all_refs,
@@ -42,8 +45,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         c2_build_diag_rows(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows[r]);
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
         refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 126)) ? 1 : 0; refs[r].reserved1 = 0;
-        if (refs[r].pk_ok) { c2_build_diag_rows_pk(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows_pk[r]); any_pk = true; }
-        else drows_pk[r].assign(drows[r].size(), c2_diag_row{0, 0, 0, 5u * C2_PK_LUT_STRIDE});
+        if (refs[r].pk_ok) any_pk = true;
         refs[r].len = lens[r];
         int64_t gm = 0;
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)g32[r][k]);
@@ -51,6 +53,23 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         refs[r].gap_incentive_last_pos = g32[r][lens[r]] > 0 ? 1 : 0;
         { int mc = 0; for (int k = 0; k < lens[r]; ++k) mc = std::max(mc, (int)(unsigned char)seqs[r][k]); refs[r].max_char = mc; }
         max_li = std::max(max_li, lens[r]);
+    }
+    // the library's choice (c2_api.hip, update_pk_eligibility): one bias for the batch, the 32-bit-add variant only if every admitted
+    // reference stays in range with it (C2_EMU_NO_ADD32: the packed-add variant, as for references beyond that range)
+    int pk_beta = 0, pk_bias = 0;
+    if (any_pk && !getenv("C2_EMU_NO_ADD32")) {
+        int beta = 0;
+        for (int r = 0; r < n_refs; ++r) if (refs[r].pk_ok) beta = std::max(beta, c2_pk_beta_needed(lens[r], g32[r].data(), sc, go, ge));
+        int bias = 0;
+        for (int r = 0; r < n_refs; ++r) if (refs[r].pk_ok) bias = std::max(bias, c2_pk_add32_bias_needed(lens[r], g32[r].data(), sc, go, ge, 126));
+        bool ok = beta > 0;
+        for (int r = 0; r < n_refs && ok; ++r) if (refs[r].pk_ok) ok = c2_pk_add32_ok(lens[r], g32[r].data(), sc, go, ge, 126, beta, bias);
+        if (ok) { pk_beta = beta; pk_bias = bias; }
+    }
+    g_last_pk_beta = pk_beta; g_last_pk_bias = pk_bias;
+    for (int r = 0; r < n_refs; ++r) {
+        if (refs[r].pk_ok) c2_build_diag_rows_pk(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows_pk[r], pk_beta);
+        else drows_pk[r].assign(drows[r].size(), c2_diag_row{0, 0, 0, 5u * C2_PK_LUT_STRIDE});
     }
     int max_lj = 1;
     for (uint64_t k = 0; k < n_reads; ++k) max_lj = std::max<int>(max_lj, (int)(offsets[k + 1] - offsets[k]));
@@ -86,7 +105,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1);
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
     std::vector<uint32_t> plane;
-    A.plane = nullptr; A.plane_words_per_wg = 0; A.reserved3 = 0;
+    A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)pk_beta; A.pk_bias = (uint32_t)pk_bias; A.reserved4 = 0;
     A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0; A.legacy = getenv("C2_EMU_LEGACY") ? 1 : 0;
     A.mat_dim = sc.mat_dim; A.first_ext_code = sc.first_ext_code;
     c2_build_base_luts(sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
@@ -135,8 +154,10 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
                 chain(T, false, true);
                 T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 128u;
                 if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed %d tier %d\n", pna, tier);
-                if (pna == 8) emu::launch(grid, [&] { c2_align_diagp_kernel<8>(T); });
-                else          emu::launch(grid, [&] { c2_align_diagp_kernel<4>(T); });
+                if (pk_beta > 0) { if (pna == 8) emu::launch(grid, [&] { c2_align_diagp_kernel<8, true>(T); });
+                                   else          emu::launch(grid, [&] { c2_align_diagp_kernel<4, true>(T); }); }
+                else             { if (pna == 8) emu::launch(grid, [&] { c2_align_diagp_kernel<8, false>(T); });
+                                   else          emu::launch(grid, [&] { c2_align_diagp_kernel<4, false>(T); }); }
             }
             if (xk) {
                 const c2_diagx_plan PX = c2_make_diagx_plan(xna, A.max_li, A.max_lj);
@@ -164,7 +185,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
                 chain(T, false, true);
                 T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 128u;
                 if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed 2 tier %d\n", tier);
-                emu::launch(grid, [&] { c2_align_diagp_kernel<2>(T); });
+                if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diagp_kernel<2, true>(T); });
+                else             emu::launch(grid, [&] { c2_align_diagp_kernel<2, false>(T); });
             }
             const c2_diag_plan PD = c2_make_diag_plan(A.max_li, A.max_lj);
             if (PD.total > sizeof(c2_smem)) return -5;

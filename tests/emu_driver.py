@@ -82,6 +82,7 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
         rec.ctypes.data_as(ctypes.c_void_p), int(force_R), ctypes.c_uint(grid), int(no_packed), int(band_lanes), ctypes.byref(nfb))
     if stats is not None:
         stats['unpaired'] = stats.get('unpaired', 0) + int(lib().emu_last_unpaired())
+        stats['pk_beta'], stats['pk_bias'] = int(lib().emu_last_pk_beta()), int(lib().emu_last_pk_bias())
         stats['fallback'] = stats.get('fallback', 0) + max(nfb.value, 0)
         stats['tasks'] = stats.get('tasks', 0) + ntasks
     assert rc == 0, rc

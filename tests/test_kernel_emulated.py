@@ -503,3 +503,59 @@ def test_emulated_kernel_alignments_larger_than_the_lds_plane(mats, li, lj):
             check_record(r, oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
         if chain and lj == li:
             assert 0 < st["fallback"] < st["tasks"], st
+
+
+# ---- the two variants of the packed fill: sums as v_pk_add_i16, or as plain 32-bit adds under a per-anti-diagonal bias ----------------
+@pytest.mark.parametrize("mode", [-8, -84, -87, -82])
+def test_packed_fill_with_packed_adds_is_still_exact(mats, mode, monkeypatch):
+    """The default for the usual amplicons is now the 32-bit-add variant (c2_pk_add32_ok); references beyond its range keep the
+    packed adds (C2_EMU_NO_ADD32 forces them here): the same vectors through that variant."""
+    monkeypatch.setenv("C2_EMU_NO_ADD32", "1")
+    st = {}
+    vecs = load_golden("realistic.json")
+    assert run_vectors(vecs, mats, band_lanes=mode, stats=st) == len(vecs)
+    assert st["pk_beta"] == 0 and st["tasks"] - st["fallback"] > len(vecs) // 4, st
+    kats = [k for k in load_golden("ref_unit_kats.json") if k["fn"] == "global_align"]
+    assert run_vectors(kats, mats, band_lanes=mode, stats=st) == len(kats)
+
+
+def _extreme_equal_length_reads(rng, ref, n):
+    from test_gpu_soak import _equal_length_reads
+    return _equal_length_reads(rng, ref, n)
+
+
+@pytest.mark.parametrize("go,ge,gval", [(-20, -2, 1), (-8, -3, 2), (-30, -30, 5)])
+def test_packed_fill_32bit_adds_at_the_limit_of_their_range(mats, go, ge, gval):
+    """c2_pk_add32_ok admits a reference while bias + hi + beta * (anti-diagonals) <= 32000.  At the longest admitted length -- reads of
+    that length, so that they pair: the reference itself (the largest values), every base mismatched (the smallest), all N, long
+    indels -- every alignment against the oracle; one base longer must fall back to the packed adds (same results)."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(4242 - go)
+
+    def probe(L):
+        ref = "ACGT" * (L // 4) + "ACGT"[:L % 4]
+        g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = gval
+        st = {}
+        E.align_batch([ref, ref], [ref], [g], [[L // 2]], m, go, ge, band_lanes=-8, stats=st)
+        return st["pk_beta"]
+    lo, hi = 200, 900                                                   # (below ~150 bp the reference's finite sentinel is in reach: no packed fill at all)
+    assert probe(lo) > 0
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        lo, hi = (mid, hi) if probe(mid) > 0 else (lo, mid - 1)
+    limit = lo
+    assert 150 < limit < 900, limit
+    for L, want in ((limit, True), (limit + 1, False)):
+        ref = "".join(rng.choice(list("ACGT"), L))
+        g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = gval; g[0] = gval; g[L] = gval if gval < -ge else 0
+        inc = list(range(L // 2 - 3, L // 2 + 3))
+        reads = _extreme_equal_length_reads(rng, ref, 40)
+        st = {}
+        res, rec = E.align_batch(reads, [ref], [g], [inc], m, go, ge, band_lanes=-87, stats=st)
+        assert (st["pk_beta"] > 0) == want, (L, st)
+        if want:
+            assert st["pk_beta"] >= -go and st["pk_bias"] < 16384
+        for k, rd in enumerate(reads):
+            status, s1, s2, mt, ln = oracle.global_align_raw(rd, ref, m, g, go, ge)
+            assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k)
+            check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
