@@ -1386,6 +1386,39 @@ const int32_t* c2_lists_values(const c2_lists* r) { return r ? r->values.data() 
 const int64_t* c2_lists_counts(const c2_lists* r) { return r ? r->counts.data() : nullptr; }
 void c2_lists_free(c2_lists* r) { delete r; }
 
+// Launch only: every pointer is a device address.  The paired route keeps both reads' alignments on the device (BatchAligner.align_device)
+// and hands their rows straight to this; only the qualities come from the host.  65,536 pairs per launch: every lane streams its own
+// rows, and more lanes in flight thrash L2 (25.7 against 19 ns per pair at 262,144).
+int c2_consensus_pairs_device(c2_ctx* ctx, uint64_t n, const uint8_t* d_s1, const uint8_t* d_f1, const uint8_t* d_s2, const uint8_t* d_f2,
+                              uint32_t stride, const int32_t* d_n1, const int32_t* d_n2, const uint8_t* d_q1, const uint8_t* d_q2,
+                              uint32_t qstride, const int32_t* d_lq1, const int32_t* d_lq2, const uint8_t* d_best1,
+                              uint8_t* d_out_aln, uint8_t* d_out_ref, uint8_t* d_out_qual, uint32_t ostride, int32_t* d_out_info, void* hip_stream) {
+    if (!ctx || (n && (!d_s1 || !d_f1 || !d_s2 || !d_f2 || !d_n1 || !d_n2 || !d_q1 || !d_q2 || !d_lq1 || !d_lq2 || !d_best1 || !d_out_aln || !d_out_ref ||
+                       !d_out_qual || !d_out_info))) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
+    if (n == 0) return 0;
+    if (stride == 0 || qstride == 0 || ostride < 2 * stride) { ctx->err = "ostride must be at least 2 * stride"; return C2_E_INVALID; }
+    if ((stride & 3u) || (qstride & 3u)) { ctx->err = "stride and qstride must be multiples of 4"; return C2_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    const uint64_t CH = 65536;
+    for (uint64_t c0 = 0; c0 < n; c0 += CH) {
+        const uint64_t m = std::min<uint64_t>(CH, n - c0);
+        c2_consensus_args A;
+        A.s1 = d_s1 + c0 * stride; A.f1 = d_f1 + c0 * stride; A.s2 = d_s2 + c0 * stride; A.f2 = d_f2 + c0 * stride;
+        A.q1 = d_q1 + c0 * qstride; A.q2 = d_q2 + c0 * qstride;
+        A.n1 = d_n1 + c0; A.n2 = d_n2 + c0; A.lq1 = d_lq1 + c0; A.lq2 = d_lq2 + c0; A.best1 = d_best1 + c0;
+        A.n = m; A.stride = stride; A.qstride = qstride; A.ostride = ostride; A.reserved = 0;
+        A.o_aln = d_out_aln + c0 * ostride; A.o_ref = d_out_ref + c0 * ostride; A.o_qual = d_out_qual + c0 * ostride; A.o_info = d_out_info + c0 * 4;
+        hipLaunchKernelGGL(c2_consensus_pairs_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, A);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
+// Host arrays.  Chunks of 65,536 pairs through pinned staging, three streams: while chunk c runs, chunk c + 1's six input streams are
+// packed into a pinned block by a few host threads and copied in, and chunk c - 1's results come back -- only the bytes that were
+// written: the lengths first (16 bytes per pair), then the three output arrays as 2-D copies of the widest row (rows are 2 * stride
+// wide; a consensus is about as long as the longer of the two alignments).
 int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const uint8_t* f1, const uint8_t* s2, const uint8_t* f2,
                              uint32_t stride, const int32_t* n1, const int32_t* n2, const uint8_t* q1, const uint8_t* q2,
                              uint32_t qstride, const int32_t* lq1, const int32_t* lq2, const uint8_t* best1,
@@ -1400,51 +1433,98 @@ int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const u
         if (n1[t] < 0 || n2[t] < 0 || (uint32_t)n1[t] > stride || (uint32_t)n2[t] > stride || lq1[t] < 0 || lq2[t] < 0 ||
             (uint32_t)lq1[t] > qstride || (uint32_t)lq2[t] > qstride) { ctx->err = "length exceeds stride"; return C2_E_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const uint64_t CH = 65536;                                    // (measured: 262144 pairs per launch is SLOWER, 25.7 vs 19 ns per pair -- every lane streams its own rows, more lanes in flight thrash L2)
-    int rc;
-    for (uint64_t c0 = 0; c0 < n; c0 += CH) {
-        const uint64_t m = std::min<uint64_t>(CH, n - c0);
-        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-        size_t o = 0;
-        const size_t o_s1 = o; o += al(m * stride);
-        const size_t o_f1 = o; o += al(m * stride);
-        const size_t o_s2 = o; o += al(m * stride);
-        const size_t o_f2 = o; o += al(m * stride);
-        const size_t o_q1 = o; o += al(m * qstride);
-        const size_t o_q2 = o; o += al(m * qstride);
-        const size_t o_n = o; o += al(m * 4 * 4);                 // n1, n2, lq1, lq2
-        const size_t o_b = o; o += al(m);
-        const size_t o_oa = o; o += al(m * ostride);
-        const size_t o_or = o; o += al(m * ostride);
-        const size_t o_oq = o; o += al(m * ostride);
-        const size_t o_info = o; o += al(m * 16);
-        if ((rc = ensure(ctx, ctx->d_lists, o))) return rc;
-        uint8_t* base = (uint8_t*)ctx->d_lists.p;
-        HIPCHK(ctx, hipMemcpyAsync(base + o_s1, s1 + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_f1, f1 + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_s2, s2 + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_f2, f2 + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_q1, q1 + c0 * qstride, m * qstride, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_q2, q2 + c0 * qstride, m * qstride, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_n, n1 + c0, m * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_n + m * 4, n2 + c0, m * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_n + m * 8, lq1 + c0, m * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_n + m * 12, lq2 + c0, m * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_b, best1 + c0, m, hipMemcpyHostToDevice, s));
-        c2_consensus_args A;
-        A.s1 = base + o_s1; A.f1 = base + o_f1; A.s2 = base + o_s2; A.f2 = base + o_f2; A.q1 = base + o_q1; A.q2 = base + o_q2;
-        A.n1 = (const int32_t*)(base + o_n); A.n2 = A.n1 + m; A.lq1 = A.n1 + 2 * m; A.lq2 = A.n1 + 3 * m;
-        A.best1 = base + o_b; A.n = m; A.stride = stride; A.qstride = qstride; A.ostride = ostride; A.reserved = 0;
-        A.o_aln = base + o_oa; A.o_ref = base + o_or; A.o_qual = base + o_oq; A.o_info = (int32_t*)(base + o_info);
-        hipLaunchKernelGGL(c2_consensus_pairs_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, A);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(out_aln + c0 * ostride, base + o_oa, m * ostride, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipMemcpyAsync(out_ref + c0 * ostride, base + o_or, m * ostride, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipMemcpyAsync(out_qual + c0 * ostride, base + o_oq, m * ostride, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipMemcpyAsync(out_info + c0 * 4, base + o_info, m * 16, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
+    if (!ctx->s_in) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_out[k], hipEventDisableTiming));
+        }
     }
+    hipStream_t s = ctx->stream;
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char* e = getenv("C2_HOST_THREADS")) threads = (unsigned)atoi(e);
+    threads = std::max(1u, std::min(threads, 16u));
+    const uint64_t CH = 65536;
+    const uint64_t n_chunks = (n + CH - 1) / CH, mmax = std::min<uint64_t>(CH, n);
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    // one chunk's input block (the same layout in pinned and device memory) and output arrays
+    const size_t o_s1 = 0, o_f1 = o_s1 + al(mmax * stride), o_s2 = o_f1 + al(mmax * stride), o_f2 = o_s2 + al(mmax * stride);
+    const size_t o_q1 = o_f2 + al(mmax * stride), o_q2 = o_q1 + al(mmax * qstride), o_n = o_q2 + al(mmax * qstride);
+    const size_t o_b = o_n + al(mmax * 16), in_bytes = o_b + al(mmax);
+    const size_t o_oa = 0, o_or = al(mmax * ostride), o_oq = 2 * al(mmax * ostride), o_info = 3 * al(mmax * ostride), out_bytes = o_info + al(mmax * 16);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_lists, 2 * in_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->d_lists_out, 2 * out_bytes))) return rc;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = ensure_pinned(ctx, ctx->pin_in[k], ctx->pin_in_cap[k], in_bytes))) return rc;
+        if ((rc = ensure_pinned(ctx, ctx->pin_out[k], ctx->pin_out_cap[k], out_bytes))) return rc;
+    }
+    auto m_of = [&](uint64_t c) { return std::min<uint64_t>(CH, n - c * CH); };
+    auto stage_in = [&](uint64_t c) -> int {
+        const int k = (int)(c & 1);
+        const uint64_t c0 = c * CH, m = m_of(c);
+        if (c >= 2) HIPCHK(ctx, hipEventSynchronize(ctx->ev_in[k]));
+        uint8_t* pi = (uint8_t*)ctx->pin_in[k];
+        copy_parallel(pi + o_s1, s1 + c0 * stride, m * stride, threads);
+        copy_parallel(pi + o_f1, f1 + c0 * stride, m * stride, threads);
+        copy_parallel(pi + o_s2, s2 + c0 * stride, m * stride, threads);
+        copy_parallel(pi + o_f2, f2 + c0 * stride, m * stride, threads);
+        copy_parallel(pi + o_q1, q1 + c0 * qstride, m * qstride, threads);
+        copy_parallel(pi + o_q2, q2 + c0 * qstride, m * qstride, threads);
+        memcpy(pi + o_n, n1 + c0, m * 4); memcpy(pi + o_n + mmax * 4, n2 + c0, m * 4);
+        memcpy(pi + o_n + mmax * 8, lq1 + c0, m * 4); memcpy(pi + o_n + mmax * 12, lq2 + c0, m * 4);
+        memcpy(pi + o_b, best1 + c0, m);
+        HIPCHK(ctx, hipMemcpyAsync((uint8_t*)ctx->d_lists.p + k * in_bytes, pi, in_bytes, hipMemcpyHostToDevice, ctx->s_in));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_in[k], ctx->s_in));
+        return 0;
+    };
+    // results of chunk c: lengths, then the written part of the rows, then to the caller's arrays
+    auto fetch_out = [&](uint64_t c) -> int {
+        const int k = (int)(c & 1);
+        const uint64_t c0 = c * CH, m = m_of(c);
+        uint8_t* dout = (uint8_t*)ctx->d_lists_out.p + k * out_bytes;
+        uint8_t* po = (uint8_t*)ctx->pin_out[k];
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->s_out, ctx->ev_done[k], 0));
+        HIPCHK(ctx, hipMemcpyAsync(po + o_info, dout + o_info, m * 16, hipMemcpyDeviceToHost, ctx->s_out));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->s_out));
+        const int32_t* info = (const int32_t*)(po + o_info);
+        uint32_t w = 4;
+        for (uint64_t t = 0; t < m; ++t) w = std::max<uint32_t>(w, (uint32_t)std::max(info[4 * t], info[4 * t + 1]));
+        w = std::min<uint32_t>((w + 15u) & ~15u, ostride);
+        HIPCHK(ctx, hipMemcpy2DAsync(po + o_oa, w, dout + o_oa, ostride, w, m, hipMemcpyDeviceToHost, ctx->s_out));
+        HIPCHK(ctx, hipMemcpy2DAsync(po + o_or, w, dout + o_or, ostride, w, m, hipMemcpyDeviceToHost, ctx->s_out));
+        HIPCHK(ctx, hipMemcpy2DAsync(po + o_oq, w, dout + o_oq, ostride, w, m, hipMemcpyDeviceToHost, ctx->s_out));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->s_out));
+        memcpy(out_info + c0 * 4, info, m * 16);
+        auto rows = [&](uint8_t* dst, const uint8_t* src) {
+            auto part = [=](uint64_t a, uint64_t z) { for (uint64_t t = a; t < z; ++t) memcpy(dst + (c0 + t) * ostride, src + t * w, w); };
+            if (threads < 2 || m < 4096) { part(0, m); return; }
+            std::vector<std::thread> pool;
+            for (unsigned q = 0; q < threads; ++q) pool.emplace_back(part, m * q / threads, m * (q + 1) / threads);
+            for (auto& th : pool) th.join();
+        };
+        rows(out_aln, po + o_oa); rows(out_ref, po + o_or); rows(out_qual, po + o_oq);
+        return 0;
+    };
+    if ((rc = stage_in(0))) return rc;
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        const int k = (int)(c & 1);
+        const uint64_t m = m_of(c);
+        uint8_t* din = (uint8_t*)ctx->d_lists.p + k * in_bytes;
+        uint8_t* dout = (uint8_t*)ctx->d_lists_out.p + k * out_bytes;
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_in[k], 0));
+        const int32_t* dn = (const int32_t*)(din + o_n);
+        if ((rc = c2_consensus_pairs_device(ctx, m, din + o_s1, din + o_f1, din + o_s2, din + o_f2, stride, dn, dn + mmax, din + o_q1, din + o_q2, qstride,
+                                            dn + 2 * mmax, dn + 3 * mmax, din + o_b, dout + o_oa, dout + o_or, dout + o_oq, ostride,
+                                            (int32_t*)(dout + o_info), (void*)s))) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_done[k], s));
+        if (c + 1 < n_chunks && (rc = stage_in(c + 1))) return rc;          // the next chunk travels while this one runs
+        if (c >= 1 && (rc = fetch_out(c - 1))) return rc;                   // ... and the previous one's results come back
+    }
+    if ((rc = fetch_out(n_chunks - 1))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(s));
     return 0;
 }
 

@@ -299,6 +299,12 @@ int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const u
                              uint32_t stride, const int32_t* n1, const int32_t* n2, const uint8_t* q1, const uint8_t* q2,
                              uint32_t qstride, const int32_t* lq1, const int32_t* lq2, const uint8_t* best1,
                              uint8_t* out_aln, uint8_t* out_ref, uint8_t* out_qual, uint32_t ostride, int32_t* out_info);
+/* The same with every pointer a DEVICE address (launch only, on hip_stream): the paired route keeps both reads' alignments on the
+ * device -- the rows c2_align_classify_batch_device wrote -- and only the qualities travel from the host. */
+int c2_consensus_pairs_device(c2_ctx* ctx, uint64_t n, const uint8_t* d_s1, const uint8_t* d_f1, const uint8_t* d_s2, const uint8_t* d_f2,
+                              uint32_t stride, const int32_t* d_n1, const int32_t* d_n2, const uint8_t* d_q1, const uint8_t* d_q2,
+                              uint32_t qstride, const int32_t* d_lq1, const int32_t* d_lq2, const uint8_t* d_best1,
+                              uint8_t* d_out_aln, uint8_t* d_out_ref, uint8_t* d_out_qual, uint32_t ostride, int32_t* d_out_info, void* hip_stream);
 
 /* ---- FASTQ ingest + exact de-duplication (host code, no GPU): the first pass of process_fastq,
  * CRISPRessoCORE.py:1820-1849 -- every 4-line record's sequence line, str.strip()'ed, counted per distinct sequence in

@@ -996,3 +996,51 @@ def test_count_reduce_through_the_c_abi_rccl(ctx):
     torch.cuda.synchronize()
     assert torch.equal(t, want)
     ctx.check(ctx.lib.c2_comm_destroy(ctx.handle), "c2_comm_destroy")
+
+
+def test_consensus_host_call_in_several_pipelined_chunks_and_the_device_entry(mats, ctx):
+    """c2_consensus_pairs_batch over more than two chunks of 65,536 pairs (pinned staging on three streams, results fetched as
+    lengths + the written part of the rows): every pair's result equals what the same pair gives in a small call; and
+    c2_consensus_pairs_device (every array already in HBM) writes the same rows and lengths."""
+    import ctypes
+    import torch
+    from crispresso2_amd import paired
+    g = load_golden("paired.json.gz")
+    ok = [tuple(c["args"]) for c in g["unit"] + g["fuzz"] if "raises" not in c]
+    want = paired.consensus_batch(ok, ctx=ctx)
+    reps = 150_000 // len(ok) + 1
+    rng = np.random.default_rng(5)
+    order = rng.permutation(len(ok) * reps) % len(ok)
+    got = paired.consensus_batch([ok[k] for k in order], ctx=ctx)
+    assert len(got) == len(order) > 2 * 65536
+    for k, o in zip(order[::97], got[::97]):
+        assert o == want[k]
+    assert all(o == want[k] for k, o in zip(order[-300:], got[-300:])) and all(o == want[k] for k, o in zip(order[65530:65545], got[65530:65545]))
+    # device entry on the first 3000 pairs of that order
+    items = [ok[k] for k in order[:3000]]
+    n = len(items)
+    n1 = np.array([len(it[1]) for it in items], dtype=np.int32); n2 = np.array([len(it[5]) for it in items], dtype=np.int32)
+    lq1 = np.array([len(it[3]) for it in items], dtype=np.int32); lq2 = np.array([len(it[7]) for it in items], dtype=np.int32)
+    stride = max(16, (int(max(n1.max(), n2.max())) + 15) // 16 * 16)
+    qstride = max(16, (int(max(lq1.max(), lq2.max())) + 15) // 16 * 16)
+    ostride = 2 * stride
+    rows = paired._rows
+    host = [rows([it[0][:len(it[1])] for it in items], stride), rows([it[1] for it in items], stride), rows([it[4][:len(it[5])] for it in items], stride),
+            rows([it[5] for it in items], stride), n1, n2, rows([it[3] for it in items], qstride), rows([it[7] for it in items], qstride), lq1, lq2,
+            np.array([1 if it[2] >= it[6] else 0 for it in items], dtype=np.uint8)]
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in host]
+    d_oa = torch.zeros((n, ostride), dtype=torch.uint8, device=dev); d_or = torch.zeros_like(d_oa); d_oq = torch.zeros_like(d_oa)
+    d_info = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    ctx.check(ctx.lib.c2_consensus_pairs_device(ctx.handle, ctypes.c_uint64(n), P(d[0]), P(d[1]), P(d[2]), P(d[3]), ctypes.c_uint32(stride), P(d[4]), P(d[5]),
+                                                P(d[6]), P(d[7]), ctypes.c_uint32(qstride), P(d[8]), P(d[9]), P(d[10]), P(d_oa), P(d_or), P(d_oq),
+                                                ctypes.c_uint32(ostride), P(d_info), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "c2_consensus_pairs_device")
+    torch.cuda.synchronize()
+    info, oa, orf, oq = d_info.cpu().numpy(), d_oa.cpu().numpy(), d_or.cpu().numpy(), d_oq.cpu().numpy()
+    for k in range(n):
+        ln, lq, hom, fl = (int(x) for x in info[k])
+        assert not fl & 2
+        assert (oa[k, :ln].tobytes().decode(), oq[k, :lq].tobytes().decode(), orf[k, :ln].tobytes().decode(),
+                round(float(100 * hom / float(ln)), 3), bool(fl & 1)) == want[order[k]], k
