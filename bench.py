@@ -54,10 +54,13 @@ N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9
 # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 VALU_SIMD32_WAVE_INSTR_PER_S = N_SIMD * CLOCK_HZ / 2.0
-# measured on this chip (tools/valu_microbench*.hip, profiles/r01/valu_microbench*.txt): every opcode of the DP cell
-# (v_max_i32, v_max3_i32, v_cmp + v_addc, v_bfe_i32, DPP forms, VOP3) costs ~4.2 cycles of SIMD time at >= 3 waves per SIMD
-VALU_MEASURED_CYCLES_PER_INSTR = 4.2
-VALU_MEASURED_SOURCE = "profiles/r01/valu_microbench.txt, valu_microbench2.txt (tools/valu_microbench*.hip)"
+# measured on this chip with counted cycles (tools/valu_microbench4.hip under rocprofv3 --pmc GRBM_GUI_ACTIVE, profiles/r03/valu_microbench4.txt;
+# the clock during those kernels is 2.40 GHz): two issue classes.  Half rate, ~4.15 cycles of SIMD time per wave64 instruction: v_max/min,
+# every VOP3 three-operand form, v_perm_b32, v_pk_*, DPP forms, carry / compare forms, v_lshlrev.  Full rate, ~2.3 cycles: v_add/sub_u32,
+# v_and/or/xor, right shifts, v_mov, v_fma_f32 (the guide's reference point).  The DP cell is mostly half-rate opcodes.
+VALU_MEASURED_CYCLES_PER_INSTR = 4.15
+VALU_FULL_RATE_CYCLES_PER_INSTR = 2.3
+VALU_MEASURED_SOURCE = "profiles/r03/valu_microbench4.txt (tools/valu_microbench4.hip, cycles from GRBM_GUI_ACTIVE; clock 2.40 GHz)"
 PROFILE_ROUNDS = ["r03", "r02"]                 # the PMC summary of the newest round that has one
 GO, GE, MIN_ALN_SCORE = -20, -2, 60.0
 
@@ -690,8 +693,13 @@ def main():
 
     info = ctx.launch_info(L)
     band = ctx.band_info(L)
-    chain_names = {"auto": ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<2>" if os.environ.get("C2_NO_PACKED_TIER2") else "c2_align_diagp_kernel<4>",
-                            "c2_align_diag_kernel" if (os.environ.get("C2_NO_PACKED_TIER2") or os.environ.get("C2_NO_PACKED_TIER3")) else "c2_align_diagp_kernel<2>"],
+    # (kernel names as rocprofv3 prints them: the packed kernels' second template argument says whether their sums are 32-bit adds)
+    add32 = False
+    if hasattr(ctx, "chain_info"):
+        add32 = "packed fill with 32-bit adds" in ctx.chain_info(L, k)[0]
+    pkv = ", true>" if add32 else ", false>"
+    chain_names = {"auto": ["c2_align_diagp_kernel<8" + pkv, "c2_align_diagx_kernel<2>" if os.environ.get("C2_NO_PACKED_TIER2") else "c2_align_diagp_kernel<4" + pkv,
+                            "c2_align_diag_kernel" if (os.environ.get("C2_NO_PACKED_TIER2") or os.environ.get("C2_NO_PACKED_TIER3")) else "c2_align_diagp_kernel<2" + pkv],
                    "diag4": ["c2_align_diagx_kernel<4>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
                    "diag2": ["c2_align_diagx_kernel<2>", "c2_align_diag_kernel"], "diag1": ["c2_align_diag_kernel"]}
     if os.environ.get("C2_NO_PACKED_FILL"):
@@ -732,7 +740,7 @@ def main():
                     "SIMD was measured to issue for this opcode mix and (b) the SIMD-32 two-cycle rate of MI355X_MICROARCH.md",
             "kernel": dominant,
             "wave_instr_per_alignment": valu_per_aln, "salu_instr_per_alignment": salu_per_aln,
-            "cycles_per_instr_measured": VALU_MEASURED_CYCLES_PER_INSTR,
+            "cycles_per_instr_measured": VALU_MEASURED_CYCLES_PER_INSTR, "cycles_per_instr_full_rate_class": VALU_FULL_RATE_CYCLES_PER_INSTR,
             "cycles_per_instr_source": VALU_MEASURED_SOURCE,
             "peak_wave_instr_per_s_simd32": VALU_SIMD32_WAVE_INSTR_PER_S,
             "peak_lane_ops_per_s": VALU_SIMD32_WAVE_INSTR_PER_S * 64}
@@ -819,6 +827,7 @@ def main():
             "vs_baseline": None,
             # the arithmetic type of the dominant kernel's DP cells: int16 pairs in the packed kernels (proven range, c2_pk_eligible), int32 otherwise
             "dtype": "int16" if dominant.startswith("c2_align_diagp") else "int32",
+            "packed_fill_sums": ("v_add_u32 under a per-anti-diagonal bias (c2_pk_add32_ok)" if add32 else "v_pk_add_i16") if dominant.startswith("c2_align_diagp") else None,
             "dtype_note": "exact integer DP, not a precision trade: the packed kernels hold two alignments per 32-bit lane as int16 pairs only for "
                           "references whose DP values the host proves to fit (c2_pk_eligible); everything else runs the int32 kernels; the "
                           "results are bit-identical either way (checks.chain_equals_full_plane_n covers every alignment of the batch); "

@@ -11,7 +11,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --check 0 --no-dedup-leg --workers 1"
+COMMON="--no-cpu-baseline --check 0 --no-dedup-leg --workers 1 --no-extras"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- \
     python "$ROOT/bench.py" --steps 3 --warmup 1 $COMMON "$@" > "$OUT/trace_bench.log" 2>&1
 i=0
