@@ -84,6 +84,7 @@ struct c2_ctx {
     int occ_diag_lds = -1, occ_diag_blocks = 0;
     int occ_x_lds[2] = {-1, -1}, occ_x_blocks[2] = {0, 0};   // [0] 4 alignments per wavefront, [1] 2
     DevBuf d_plane;        // pointer-word scratch of the multi-alignment diagonal kernels
+    DevBuf d_cnt_block;            // count route: the workgroups' accumulator blocks when they do not fit LDS
     DevBuf d_lists, d_lists_out;   // batched classifier: staging and flat output
     DevBuf d_order;        // count kernel: histogram + tasks grouped by reference
     int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
@@ -596,7 +597,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_diagrows_pk, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel, &ctx->d_seeds};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_diagrows_pk, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel, &ctx->d_seeds, &ctx->d_cnt_block};
     for (DevBuf* b : all) release(*b);
     (void)c2_comm_destroy(ctx);
     for (int k = 0; k < 2; ++k) {
@@ -1032,8 +1033,14 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     const int lmax = ctx->max_li;
     if (hl < lmax + 2) { ctx->err = "hl too small"; return C2_E_INVALID; }
     const size_t per_ref = (size_t)C2_CNT_VECTORS * (lmax + 1) + C2_CNT_SCALARS + (size_t)C2_CNT_HISTS * hl;
-    const size_t lds = c2_count_lds_bytes(per_ref, lmax);
-    if (lds > 163840) { ctx->err = "count block does not fit LDS"; return C2_E_TOO_LARGE; }
+    size_t lds = c2_count_lds_bytes(per_ref, lmax);
+    // the int32 accumulator block of a workgroup normally lives in LDS; amplicons beyond ~1,650 bp (with 250-bp reads) take the variant
+    // that keeps it in HBM scratch (LDS then only holds the O(lmax) parts)
+    const bool hbm_block = lds > 163840 || getenv("C2_COUNT_HBM_BLOCK");
+    if (hbm_block) {
+        lds = c2_count_lds_bytes_hbm(lmax);
+        if (lds > 163840) { ctx->err = "count route: reference of " + std::to_string(lmax) + " bp needs " + std::to_string(lds) + " bytes of LDS"; return C2_E_TOO_LARGE; }
+    }
     int rc;
     c2_count_args A;
     A.min_matches = nullptr;
@@ -1071,13 +1078,22 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
         HIPCHK(ctx, hipGetLastError());
         A.order = order;
     }
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_count_vectors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    const void* fn = hbm_block ? (const void*)c2_count_vectors_hbm_kernel : (const void*)c2_count_vectors_kernel;
+    HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     int nb = 1;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)c2_count_vectors_kernel, 64 * C2_CNT_WAVES, lds));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * C2_CNT_WAVES, lds));
     if (nb < 1) nb = 1;
-    const uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)nb;
+    uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)nb;
+    A.block_scratch = nullptr; A.block_ints = 0;
+    if (hbm_block) {
+        A.block_ints = (per_ref + 63) / 64 * 64;
+        resident = std::max<uint64_t>(1, std::min<uint64_t>(resident, ((uint64_t)2 << 30) / (A.block_ints * sizeof(int))));     // at most 2 GiB of blocks
+        if ((rc = ensure(ctx, ctx->d_cnt_block, (size_t)(resident * A.block_ints * sizeof(int))))) return rc;
+        A.block_scratch = (int32_t*)ctx->d_cnt_block.p;
+    }
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_tasks + 31) / 32, resident));
-    hipLaunchKernelGGL(c2_count_vectors_kernel, dim3(grid), dim3(64 * C2_CNT_WAVES), lds, s, A);
+    if (hbm_block) hipLaunchKernelGGL(c2_count_vectors_hbm_kernel, dim3(grid), dim3(64 * C2_CNT_WAVES), lds, s, A);
+    else           hipLaunchKernelGGL(c2_count_vectors_kernel, dim3(grid), dim3(64 * C2_CNT_WAVES), lds, s, A);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }

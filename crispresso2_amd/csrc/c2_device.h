@@ -180,6 +180,10 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 #define C2_CNT_CTL_BASE_INTS 96     // >= 16 + 4 * C2_CNT_WAVES
 #define C2_CNT_CTL_INTS (C2_CNT_CTL_BASE_INTS + C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE)   // + per task of a chunk: the part of a heavy weight that is still to be added
 #define C2_CNT_LOAD_BUDGET (1u << 30) // sum of weight x alignment length an LDS block may take between two flushes (its entries are int32)
+// LDS of the variant whose accumulator block lives in HBM: the difference array, the control words, the window prefix
+static inline size_t c2_count_lds_bytes_hbm(int lmax) {
+    return (((size_t)lmax + 1) + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
+}
 static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {      // block + the LDS-only `cov` vector (lmax + 1) + control words + inc_prefix
     return (per_ref + ((size_t)lmax + 1) + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
 }
@@ -212,6 +216,8 @@ typedef struct c2_count_args {
     int32_t max_t;                // longest alignment the min_matches table covers
     int32_t flags;                // C2_CNT_FLAG_*
     const uint32_t* order;        // optional: tasks grouped by reference (position -> task), else NULL = task order
+    int32_t* block_scratch;       // c2_count_vectors_hbm_kernel: one int32 accumulator block per workgroup in HBM (amplicons whose block does not fit LDS)
+    uint64_t block_ints;          // ... its size in ints
 } c2_count_args;
 
 // ---- best-reference selection on the device (CRISPRessoCORE.py:683, :697-707, :779-785) ----

@@ -2544,25 +2544,34 @@ __global__ __launch_bounds__(256) void c2_ref_scatter_kernel(const c2_aln_record
 // (launch bounds: 5 workgroups per CU = 5 waves per SIMD = 96 VGPRs.  Left alone the compiler takes 101 -- 99 + 2 that hold 103 spilled
 // SGPRs -- and the kernel runs at 4 waves per SIMD, 8 % slower; with the bound it is 8 % slower than a 96-VGPR build WITHOUT the bound
 // would be (measured with round 1's source, which fits by itself: the occupancy target changes the schedule), but that is not on offer.)
-__global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(c2_count_args A)
+// HBM: the int32 accumulator block of the workgroup lives in global memory (A.block_scratch) instead of LDS -- amplicons beyond
+// ~1,650 bp, whose block does not fit 160 KB.  Its updates are the same atomics (they execute in L2); what reads the block with plain
+// loads -- the flush -- first drops the CU's L1 lines (agent-scope fence), and the flush takes every entry with an exchange.
+template <bool HBM>
+__device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
 {
     // C2_CNT_WAVES wavefronts share one LDS block (the block is what limits residency, so sharing it multiplies the
     // waves per CU); each wavefront walks one alignment at a time.  The workgroup takes C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE
     // consecutive tasks per atomic; lane k of wave v holds the record of task base + k * C2_CNT_WAVES + v.
     constexpr int NT = 64 * C2_CNT_WAVES, K = C2_CNT_TASKS_PER_WAVE, CHUNK = C2_CNT_WAVES * K, NONE = 0x7fffffff;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int* acc = (int*)c2_smem;
+    int* acc = HBM ? A.block_scratch + (size_t)blockIdx.x * (size_t)A.block_ints : (int*)c2_smem;
     const int VL = A.lmax + 1;                                  // vector length incl. the end slot of the difference arrays
     const int o_sc = C2_CNT_VECTORS * VL, o_h = o_sc + C2_CNT_SCALARS;
     const int per_ref = o_h + C2_CNT_HISTS * A.hl;
+    auto block_barrier = [&]() {                                // a barrier after which plain loads see the block's latest values
+        __syncthreads();
+        if (HBM) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    };
     // cov: difference array over the reference positions of "weight of the alignments whose read base EQUALS the reference's here" --
     // runs of matching columns add +w at their first position and -w behind their last; flush() integrates it and adds every
     // position's total to the count vector of the reference's own base there (an LDS-only vector, not part of the tensor)
-    int* cov = acc + per_ref;
+    int* cov = HBM ? (int*)c2_smem : acc + per_ref;
     int* ctl = cov + VL;                                        // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
     uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
-    for (int k = tid; k < per_ref + VL; k += NT) acc[k] = 0;
-    __syncthreads();
+    for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
+    for (int k = tid; k < VL; k += NT) cov[k] = 0;
+    block_barrier();
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
     const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
     const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);   // string rows readable as dwords
@@ -2575,7 +2584,7 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
     // flush the LDS block of cur_ref into the int64 tensor (workgroup-wide)
     auto flush = [&]() {
         if (cur_ref < 0) return;
-        __syncthreads();
+        block_barrier();
         // deletion vectors were accumulated as difference arrays (start += x, end -= x): integrate them first
         if (wave < 3) {
             int* d = wave == 2 ? cov : acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
@@ -2588,11 +2597,11 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
                 carry = __shfl(s, 63);
             }
         }
-        __syncthreads();
+        block_barrier();
         {   // gap-free reads added only their deviations from the reference (see the column walk): every reference position
             // gets their total weight on the vector of its own base
             const int g = acc[o_sc + C2_S_RESERVED0];
-            __syncthreads();
+            block_barrier();
             {   // ... plus, per position, the weight of the alignments with gaps whose read matches the reference there (cov, integrated above)
                 const uint8_t* rs = A.refs[cur_ref].seq;
                 for (int c = tid; c < VL; c += NT) {
@@ -2606,14 +2615,14 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
                 if (tid == 0) acc[o_sc + C2_S_RESERVED0] = 0;
             }
         }
-        __syncthreads();
+        block_barrier();
         long long* out = A.counts + (size_t)cur_ref * per_ref;
         for (int k = tid; k < per_ref; k += NT) {
-            const int x = acc[k];
-            if (x != 0) { atomicAdd((unsigned long long*)(out + k), (unsigned long long)(long long)x); acc[k] = 0; }
+            const int x = HBM ? atomicExch(acc + k, 0) : acc[k];
+            if (x != 0) { atomicAdd((unsigned long long*)(out + k), (unsigned long long)(long long)x); if (!HBM) acc[k] = 0; }
         }
         wsum = 0;
-        __syncthreads();
+        block_barrier();
     };
 
     for (;;) {
@@ -2970,3 +2979,6 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(
     }           // chunks
     flush();
 }
+
+__global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(c2_count_args A) { c2_count_vectors_body<false>(A); }
+__global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_hbm_kernel(c2_count_args A) { c2_count_vectors_body<true>(A); }

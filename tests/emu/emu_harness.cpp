@@ -321,6 +321,16 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
         emu::launch((unsigned)((n_tasks + 255) / 256), [&] { c2_ref_scatter_kernel(records, n_tasks, hist.data(), order.data()); }, 256);
         A.order = order.data();
     }
+    A.block_scratch = nullptr; A.block_ints = 0;
+    if (getenv("C2_EMU_COUNT_HBM")) {
+        // the variant whose accumulator blocks live in "HBM" (one per workgroup), as the library takes for amplicons beyond the LDS block
+        const size_t per_ref = (size_t)C2_CNT_VECTORS * (lmax + 1) + C2_CNT_SCALARS + (size_t)C2_CNT_HISTS * hl;
+        A.block_ints = (per_ref + 63) / 64 * 64;
+        std::vector<int32_t> blocks((size_t)(grid ? grid : 2) * A.block_ints, 0x5a5a5a5a);       // (garbage: the kernel must zero its block)
+        A.block_scratch = blocks.data();
+        emu::launch(grid ? grid : 2, [&] { c2_count_vectors_hbm_kernel(A); }, 64 * C2_CNT_WAVES);
+        return 0;
+    }
     emu::launch(grid ? grid : 2, [&] { c2_count_vectors_kernel(A); }, 64 * C2_CNT_WAVES);
     return 0;
 }

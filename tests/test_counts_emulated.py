@@ -174,3 +174,31 @@ def test_legacy_classifier_on_the_count_route(monkeypatch):
     res2, rec2 = E.align_batch(reads, [amp], [g], [list(range(55, 66))], m, -20, -2, band_lanes=-87)
     assert res2 == res
     assert (rec2["all_deletion_bases"] != [len(legacy_payload(s1, s2, [0])["all_deletion_positions"]) for s1, s2 in res]).any()
+
+
+@pytest.mark.parametrize("flags", [0, C.FLAG_IGNORE_INSERTIONS | C.FLAG_IGNORE_DELETIONS, C.FLAG_DISCARD_INDEL_READS])
+def test_count_vectors_with_the_accumulator_block_in_hbm(aligned, flags, monkeypatch):
+    """c2_count_vectors_hbm_kernel: the workgroup's int32 block in global memory instead of LDS (amplicons beyond ~1,650 bp take it;
+    forced here): same tensors, incl. the interleaved-references / heavy-weight rounds (flush per reference, weights in pieces)."""
+    monkeypatch.setenv("C2_EMU_COUNT_HBM", "1")
+    amp, inc, reads, res, rec, (o1, o2) = aligned
+    rng = np.random.default_rng(1)
+    w = rng.integers(1, 50, len(reads)).astype(np.uint32)
+    w[::11] = 0
+    counts, lay = E.count_vectors(o1, o2, rec, [amp], [inc], max(len(r) for r in reads), weights=w, flags=flags)
+    got = lay.unpack(counts, 0, len(amp))
+    items = [(p, int(c)) for p, c in zip(payloads(res, inc), w) if c > 0]
+    exp = aggregate.aggregate(items, len(amp), ignore_substitutions=bool(flags & 1), ignore_insertions=bool(flags & 2),
+                              ignore_deletions=bool(flags & 4), discard_indel_reads=bool(flags & 8))
+    compare(got, exp, len(amp))
+    if flags == 0:
+        rec2 = rec.copy()
+        rec2["ref_id"] = rng.integers(0, 2, len(rec2)).astype(np.uint16)
+        w2 = rng.integers(1, 9, len(reads)).astype(np.uint32)
+        w2[3] = 30_000_000
+        w2[40] = 2_000_000_000
+        counts, lay = E.count_vectors(o1, o2, rec2, [amp, amp], [inc, inc], max(len(r) for r in reads), weights=w2, grid=3)
+        P = payloads(res, inc)
+        for r in range(2):
+            items = [(p, int(c)) for p, c, rid in zip(P, w2, rec2["ref_id"]) if rid == r]
+            compare(lay.unpack(counts, r, len(amp)), aggregate.aggregate(items, len(amp)), len(amp))
