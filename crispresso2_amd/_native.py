@@ -24,7 +24,7 @@ SYMBOLS = [
     "c2_comm_unique_id", "c2_comm_init", "c2_reduce_counts", "c2_comm_destroy",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
-    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners",
+    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners",
     "c2_consensus_pairs_batch", "c2_consensus_pairs_device",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets",
 ]
@@ -114,6 +114,7 @@ def load():
             lib.c2_fastq_stream_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
             lib.c2_fastq_stream_next.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int32)]
             lib.c2_fastq_stream_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+            lib.c2_fastq_stream_rc_partners.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
             lib.c2_fastq_last_error.restype = ctypes.c_char_p
             lib.c2_fastq_unique.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
             lib.c2_fastq_unique_filtered.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -384,6 +385,15 @@ class FastqStream:
         rc = self._lib.c2_fastq_stream_counts(self._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(self.n_unique))
         if rc != 0:
             raise NativeError("c2_fastq_stream_counts: %s" % self._lib.c2_fastq_last_error().decode())
+        return out
+
+    def rc_partners(self):
+        """-> int64 [n_unique]: index of the unique read equal to reverse_complement(read i), or -1 (rc_partners(), from the ingest's own
+        table; the stream must be done).  ctypes drops the GIL: a host thread can run it while the device works."""
+        out = np.empty(self.n_unique, dtype=np.int64)
+        rc = self._lib.c2_fastq_stream_rc_partners(self._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(self.n_unique))
+        if rc != 0:
+            raise NativeError("c2_fastq_stream_rc_partners: %s" % self._lib.c2_fastq_last_error().decode())
         return out
 
     @property

@@ -31,6 +31,7 @@
 #include <atomic>
 #include <tuple>
 #include <dlfcn.h>
+#include <immintrin.h>
 #include <functional>
 
 #include "crispresso2_amd.h"
@@ -105,17 +106,30 @@ static HelperThreads g_helpers;
 
 inline bool py_space(uint8_t c) { return (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x20); }
 
-// 64-bit hash of a byte string (multiply-fold over 8-byte words); quality only matters for table occupancy
+// 64-bit hash of a byte string; quality only matters for table occupancy (equality is always decided by the bytes).  Four
+// independent multiply-fold lanes over 32-byte blocks -- one lane is a chain of dependent multiplies, ~5 cycles per 8 bytes; four
+// of them keep the multiplier busy (a 250-base read: ~12 ns instead of ~40) -- then the tail word by word.
 inline uint64_t hash_bytes(const uint8_t* p, size_t n) {
-    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n * 0xff51afd7ed558ccdull;
+    const uint64_t K0 = 0xc4ceb9fe1a85ec53ull, K1 = 0xff51afd7ed558ccdull, K2 = 0x9e3779b97f4a7c15ull, K3 = 0xd6e8feb86659fd93ull;
+    uint64_t h0 = K2 ^ (uint64_t)n * K1, h1 = K0, h2 = K1, h3 = K3;
+    while (n >= 32) {
+        uint64_t w0, w1, w2, w3;
+        memcpy(&w0, p, 8); memcpy(&w1, p + 8, 8); memcpy(&w2, p + 16, 8); memcpy(&w3, p + 24, 8);
+        h0 = (h0 ^ w0) * K0; h0 ^= h0 >> 29;
+        h1 = (h1 ^ w1) * K1; h1 ^= h1 >> 31;
+        h2 = (h2 ^ w2) * K3; h2 ^= h2 >> 30;
+        h3 = (h3 ^ w3) * K2; h3 ^= h3 >> 28;
+        p += 32; n -= 32;
+    }
+    uint64_t h = h0 ^ (h1 * K3) ^ ((h2 << 21) | (h2 >> 43)) ^ (h3 * K0);
     while (n >= 8) {
         uint64_t w; memcpy(&w, p, 8);
-        h = (h ^ w) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+        h = (h ^ w) * K0; h ^= h >> 29;
         p += 8; n -= 8;
     }
     uint64_t w = 0;
     if (n) memcpy(&w, p, n);
-    h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32;
+    h = (h ^ w) * K1; h ^= h >> 32;
     return h;
 }
 
@@ -252,10 +266,37 @@ inline bool term_end(const char* b, size_t n, size_t p) {      // does a line te
     return b[p] == '\n' || (b[p] == '\r' && (p + 1 >= n || b[p + 1] != '\n'));
 }
 
+// The no-carriage-return case of count_terminators, 32 bytes per step (AVX2): newline mask m; a `grep -c .` line starts where a byte
+// is not '\n' and its predecessor is.  -> false if a '\r' turned up (the caller then takes the general loop).
+__attribute__((target("avx2,popcnt")))
+static bool count_newlines_avx2(const char* b, size_t lo, size_t hi, char prev, uint64_t& c_out, uint64_t& ne_out) {
+    const __m256i NL = _mm256_set1_epi8('\n'), CR = _mm256_set1_epi8('\r');
+    uint64_t c = 0, ne = 0;
+    unsigned carry = prev == '\n' ? 1u : 0u, any_cr = 0;
+    size_t i = lo;
+    for (; i + 32 <= hi; i += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i*)(b + i));
+        const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, NL));
+        any_cr |= (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, CR));
+        c += (uint64_t)__builtin_popcount(m);
+        ne += (uint64_t)__builtin_popcount(~m & ((m << 1) | carry));
+        carry = m >> 31;
+    }
+    char pv = carry ? '\n' : 'x';
+    for (; i < hi; ++i) { const char x = b[i]; any_cr |= (x == '\r'); c += (x == '\n'); ne += (x != '\n') & (pv == '\n'); pv = x; }
+    c_out = c; ne_out = ne;
+    return any_cr == 0;
+}
+
 // -> line terminators that end in [lo, hi); *nonempty += lines of `grep -c .` that START there ('\n' is its only terminator)
 uint64_t count_terminators(const char* b, size_t n, size_t lo, size_t hi, uint64_t* nonempty) {
     uint64_t c = 0, ne = 0;
     char prev = lo ? b[lo - 1] : '\n';
+    static const bool have_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
+    if (have_avx2 && hi > lo) {
+        uint64_t c1 = 0, ne1 = 0;
+        if (count_newlines_avx2(b, lo, hi, prev, c1, ne1)) { *nonempty += ne1; return c1; }
+    }
     if (memchr(b + lo, '\r', hi - lo) == nullptr) {
         // no carriage return in the range: terminators are the '\n' bytes.  Both counts from the bytes themselves (b[i - 1] read from
         // memory, no loop-carried state), so the compiler turns the loop into wide compares + horizontal adds
@@ -1157,6 +1198,14 @@ int c2_fastq_stream_counts(c2_fastq_stream* h, uint32_t* out, uint64_t n) {
     if (!h || (!out && n)) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
     if (n != (uint64_t)h->S.offsets.size() - 1) { g_fastq_error = "counts: n differs from the number of unique reads"; return C2_E_INVALID; }
     if (!h->S.counts_into(out)) { g_fastq_error = "more than 2^32 - 1 copies of one sequence"; return C2_E_TOO_LARGE; }
+    return 0;
+}
+
+int c2_fastq_stream_rc_partners(c2_fastq_stream* h, int64_t* partner, uint64_t n) {
+    if (!h || (!partner && n)) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    if (!h->S.done) { g_fastq_error = "rc_partners: the stream is not exhausted yet"; return C2_E_STATE; }
+    if (n != (uint64_t)h->S.offsets.size() - 1) { g_fastq_error = "rc_partners: n differs from the number of unique reads"; return C2_E_INVALID; }
+    h->S.rc_partners_into(partner);
     return 0;
 }
 

@@ -85,8 +85,18 @@ struct alignas(128) LocalSet {             // a thread's own table: persists ove
         for (uint32_t k = 0; k < (uint32_t)u.size(); ++k) { uint64_t pos = u[k].h & m; while (t[pos]) pos = (pos + 1) & m; t[pos] = k + 1; }
         slots.swap(t); mask = m;
     }
-    void add(const uint8_t* s, uint32_t len) {
-        const uint64_t h = hash_bytes(s, len);
+    void add(const uint8_t* s, uint32_t len) { add_hashed(s, len, hash_bytes(s, len)); }
+    // the look-up of one sequence touches three lines nobody has in cache (slot -> u[k] -> the representative's bytes): the parser
+    // keeps a few sequences in flight and asks for those lines ahead of time (stage 1, 2, 3), see FastqStream::next, phase B
+    void prefetch_slot(uint64_t h) const { __builtin_prefetch(&slots[h & mask]); }
+    void prefetch_entry(uint64_t h) const { const uint32_t k = slots[h & mask]; if (k) __builtin_prefetch(&u[k - 1]); }
+    void prefetch_bytes(uint64_t h) const {
+        const uint32_t k = slots[h & mask];
+        if (!k) return;
+        const LocalSeq& q = u[k - 1];
+        for (uint32_t o = 0; o < q.len; o += 64) __builtin_prefetch(q.p + o);
+    }
+    void add_hashed(const uint8_t* s, uint32_t len, const uint64_t h) {
         uint64_t pos = h & mask;
         while (slots[pos]) {
             LocalSeq& q = u[slots[pos] - 1];
@@ -246,6 +256,10 @@ struct FastqStream {
             uint64_t line_no = first[t];
             const bool has_cr = memchr(b + lo, '\r', e - lo) != nullptr;
             uint64_t seqs = 0;
+            constexpr unsigned RING = 12;
+            struct Pending { const uint8_t* s; uint32_t len; uint64_t h; };
+            Pending ring[RING];
+            uint64_t rn = 0;
             while (p < hi && p < n) {
                 size_t end;                                          // first byte of the terminator, or n
                 if (!has_cr) {
@@ -260,13 +274,22 @@ struct FastqStream {
                     while (len && py_space(s[0])) { ++s; --len; }
                     while (len && py_space(s[len - 1])) --len;
                     if (len > 0xfffffff0ull) { overflow = true; return; }
-                    L.add(s, (uint32_t)len);
+                    // a ring of RING sequences in flight: hashed now (slot line requested), entry line requested RING/3 sequences
+                    // later, the representative's bytes after 2 RING/3, added to the table when the ring comes round
+                    Pending& slot_ = ring[rn % RING];
+                    if (rn >= RING) L.add_hashed(slot_.s, slot_.len, slot_.h);
+                    slot_.s = s; slot_.len = (uint32_t)len; slot_.h = hash_bytes(s, len);
+                    L.prefetch_slot(slot_.h);
+                    if (rn >= RING / 3) L.prefetch_entry(ring[(rn - RING / 3) % RING].h);
+                    if (rn >= 2 * RING / 3) L.prefetch_bytes(ring[(rn - 2 * RING / 3) % RING].h);
+                    ++rn;
                     ++seqs;
                 }
                 ++line_no;
                 if (end >= n) break;
                 p = end + ((b[end] == '\r' && end + 1 < n && b[end + 1] == '\n') ? 2 : 1);
             }
+            for (uint64_t q = rn > RING ? rn - RING : 0; q < rn; ++q) { const Pending& P_ = ring[q % RING]; L.add_hashed(P_.s, P_.len, P_.h); }   // drain, in order
             n_seq[t] = seqs;
         });
         if (overflow) { err = "a sequence line of 4 GiB"; return false; }
@@ -286,7 +309,15 @@ struct FastqStream {
             LocalSet& L = local[t];
             uint32_t spare = C2_NO_ENTRY;
             uint32_t id_next = 0, id_end = 0;                           // entry ids are taken from the shared counter 256 at a time
-            for (size_t i = 0; i < L.u.size(); ++i) {
+            const size_t nu_ = L.u.size();
+            for (size_t i = 0; i < nu_; ++i) {
+                // (the global slot of a sequence that is new to this thread, and the entry behind it, are lines nobody has in cache: ask
+                // for them a few sequences ahead)
+                if (i + 8 < nu_ && L.u[i + 8].entry == C2_NO_ENTRY) __builtin_prefetch(&slots[L.u[i + 8].h & gmask]);
+                if (i + 4 < nu_ && L.u[i + 4].entry == C2_NO_ENTRY) {
+                    const uint32_t s4 = slots[L.u[i + 4].h & gmask].load(std::memory_order_relaxed);
+                    if (s4) __builtin_prefetch(&entry(s4 - 1));
+                } else if (i + 4 < nu_ && L.u[i + 4].pending) __builtin_prefetch(&entry(L.u[i + 4].entry));
                 LocalSeq& q = L.u[i];
                 if (!q.pending) continue;
                 if (q.entry == C2_NO_ENTRY) {
@@ -400,6 +431,44 @@ struct FastqStream {
             offsets.push_back(offsets.back());
             entry_of.push_back(id);
         }
+    }
+
+    // partner[g] = index of the unique read that equals reverse_complement(read g) (CRISPRessoShared.py:399-403: upper-cased, ACGTN_-
+    // only; anything else is a KeyError there and gets -1 here), or -1 -- what c2_rc_partners computes, looked up in the table the
+    // ingest already built (no second table, no second hash of every read), on the stream's own threads.
+    void rc_partners_into(int64_t* partner) {
+        const uint64_t nu = offsets.size() - 1;
+        const uint64_t gmask = slots_cap - 1;
+        pool->run([&](unsigned t) {
+            std::vector<uint8_t> rc;
+            for (uint64_t g = nu * t / T, end = nu * (t + 1) / T; g < end; ++g) {
+                partner[g] = -1;
+                const uint8_t* s = arena.data() + offsets[g];
+                const size_t len = (size_t)(offsets[g + 1] - offsets[g]);
+                rc.resize(len);
+                bool ok = true;
+                for (size_t k = 0; k < len && ok; ++k) {
+                    uint8_t c = s[len - 1 - k];
+                    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+                    switch (c) {
+                        case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'T': c = 'A'; break;
+                        case 'N': case '_': case '-': break;
+                        default: ok = false;
+                    }
+                    rc[k] = c;
+                }
+                if (!ok) continue;
+                const uint64_t h = hash_bytes(rc.data(), len);
+                for (uint64_t p = h & gmask;; p = (p + 1) & gmask) {
+                    const uint32_t e = slots[p].load(std::memory_order_relaxed);
+                    if (!e) break;
+                    const StreamEntry& E = entry(e - 1);
+                    if (E.h == h && E.len == len && E.gidx != C2_NO_ENTRY && (len == 0 || memcmp(arena.data() + E.arena_off, rc.data(), len) == 0)) {
+                        partner[g] = (int64_t)E.gidx; break;
+                    }
+                }
+            }
+        });
     }
 
     // multiplicities of the unique reads seen so far -> out[n_unique]; false if one exceeds 32 bits

@@ -322,7 +322,8 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
         timings["ingest_dedup_streamed"] = t_ingest_done - t_start
         timings["stream_tail_device"] = time.perf_counter() - t_ingest_done
         timings["stream_batches"] = turn
-    return dict(arena=arena, offsets=offsets, counts=counts, plan=plan, stride=stride, a1=a1, f1=f1, r1=r1)
+    return dict(arena=arena, offsets=offsets, counts=counts, plan=plan, stride=stride, a1=a1, f1=f1, r1=r1,
+                rc_partners=None if dropped else fq.rc_partners)
 
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
@@ -504,8 +505,11 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
 
     def _find_partners():
         try:
-            partners['index'] = (_native.rc_partners(arena, offsets) if shard is None else
-                                 _native.rc_partners(np.ascontiguousarray(g_arena, dtype=np.uint8), g_offsets))
+            if front is not None and front.get("rc_partners") is not None:
+                partners['index'] = front["rc_partners"]()            # (from the table the streamed ingest built: no second hash of every read)
+            else:
+                partners['index'] = (_native.rc_partners(arena, offsets) if shard is None else
+                                     _native.rc_partners(np.ascontiguousarray(g_arena, dtype=np.uint8), g_offsets))
         except BaseException as e:                                   # re-raised by the main thread at the join
             partners['error'] = e
     partner_thread = threading.Thread(target=_find_partners, name="c2-rc-partners")

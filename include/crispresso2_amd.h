@@ -349,6 +349,8 @@ uint64_t c2_fastq_stream_n_reads(const c2_fastq_stream* s);
 uint64_t c2_fastq_stream_nonempty_lines(const c2_fastq_stream* s);          /* of the parsed text (after the filter) */
 uint64_t c2_fastq_stream_nonempty_lines_input(const c2_fastq_stream* s);    /* of the text in front of the filter (0 without one) */
 int c2_fastq_stream_counts(c2_fastq_stream* s, uint32_t* out, uint64_t n);
+/* c2_rc_partners (below) for the stream's unique reads, answered from the table the ingest built (after done; n = number of unique reads) */
+int c2_fastq_stream_rc_partners(c2_fastq_stream* s, int64_t* partner, uint64_t n);
 void c2_fastq_stream_close(c2_fastq_stream* s);
 /* Paired input: the first pass of process_paired_fastq's n_processes > 1 route, CRISPRessoCORE.py:1296-1334 -- the two
  * files read in lockstep, key = seq1 + '+' + reverse_complement(seq2) (both str.strip()'ed; CRISPRessoShared.py:399-403's

@@ -661,3 +661,40 @@ def test_streamed_chunks_keep_first_seen_order_and_counts_across_chunks(tmp_path
     with gzip.open(gz, "wb") as fh:
         fh.write(records(seqs).encode())
     check(gz)
+
+
+@pytest.mark.parametrize("threads,range_bytes", [(1, 0), (4, 512), (16, 0)])
+def test_stream_rc_partners_equal_the_standalone_search(tmp_path, monkeypatch, threads, range_bytes):
+    """c2_fastq_stream_rc_partners answers "which unique read is reverse_complement(read i)" from the table the ingest built; it must
+    equal c2_rc_partners (its own table over the same reads): pairs in both orders, a read that is its own reverse complement,
+    lower-case reads (upper-cased before complementing), characters outside ACGTN_- (no partner), reads without a partner."""
+    from crispresso2_amd import _native
+    monkeypatch.setenv("C2_FASTQ_THREADS", str(threads))
+    if range_bytes:
+        monkeypatch.setenv("C2_FASTQ_RANGE_BYTES", str(range_bytes))
+    rng = np.random.default_rng(77 + threads)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "_": "_", "-": "-"}
+    rc = lambda s_: "".join(comp[c] for c in reversed(s_.upper()))
+    base = ["".join(rng.choice(list("ACGTN"), int(rng.integers(4, 80)))) for _ in range(300)]
+    seqs = []
+    for k, b in enumerate(base):
+        seqs.append(b)
+        if k % 3 == 0:
+            seqs.append(rc(b))
+        if k % 7 == 0:
+            seqs.append(b.lower())
+        if k % 11 == 0:
+            seqs.append(b[:5] + "R" + b[5:])
+    seqs += ["ACGT", "AATT", "GGCC_-", "acgt"]                          # palindromes: their own partners
+    order = rng.permutation(len(seqs))
+    p = tmp_path / "rc.fastq"
+    p.write_text(records([seqs[k] for k in order] * 2))
+    with _native.FastqStream(str(p)) as fq:
+        while not fq.done:
+            fq.next()
+        got = fq.rc_partners()
+        off = fq.offsets_slice(0, fq.n_unique)
+        arena = fq.arena[:fq.arena_bytes].copy()
+    want = _native.rc_partners(arena, off)
+    assert np.array_equal(got, want)
+    assert (got >= 0).sum() > 150 and (got == np.arange(len(got))).sum() >= 3 and (got < 0).sum() > 50

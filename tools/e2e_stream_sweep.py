@@ -19,7 +19,10 @@ del reads
 
 
 def ingest(threads, rb):
-    os.environ["C2_FASTQ_THREADS"] = str(threads)
+    if threads:
+        os.environ["C2_FASTQ_THREADS"] = str(threads)
+    else:
+        os.environ.pop("C2_FASTQ_THREADS", None)
     os.environ["C2_FASTQ_RANGE_BYTES"] = str(rb)
     best = 1e9
     for _ in range(3):
@@ -31,7 +34,7 @@ def ingest(threads, rb):
         time.sleep(0.3)
     return best, nu
 
-combos = [(64, 4 << 20), (128, 4 << 20)] if a.quick else [(t, rb) for t in (32, 64, 96, 128, 192, 256) for rb in (1 << 20, 4 << 20, 16 << 20)]
+combos = [(0, 4 << 20), (0, 16 << 20)] if a.quick else [(t, rb) for t in (32, 64, 96, 128, 192, 256) for rb in (1 << 20, 4 << 20, 16 << 20)]
 for t, rb in combos:
     dt, nu = ingest(t, rb)
     print(json.dumps({"ingest_only": {"threads": t, "range_bytes": rb, "seconds": round(dt, 4), "reads_per_s": round(a.reads / dt), "unique": nu}}), flush=True)
@@ -43,10 +46,13 @@ args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needle
 ref = R.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
 m = A.read_matrix(os.path.join(ROOT, "crispresso2_amd", "EDNAFULL"))
 best_ingest = (128, 4 << 20)
-for threads, rb, stream, minb in ([(128, 4 << 20, True, 200_000), (128, 4 << 20, False, 0)] if a.quick else
+for threads, rb, stream, minb in ([(0, 4 << 20, True, 200_000), (0, 4 << 20, True, 500_000), (0, 16 << 20, True, 500_000), (0, 4 << 20, False, 0)] if a.quick else
                                   [(128, 4 << 20, False, 0), (64, 4 << 20, True, 200_000), (128, 4 << 20, True, 200_000), (128, 4 << 20, True, 500_000),
                                    (128, 4 << 20, True, 1_000_000), (128, 1 << 20, True, 200_000), (192, 4 << 20, True, 500_000), (128, 16 << 20, True, 500_000)]):
-    os.environ["C2_FASTQ_THREADS"] = str(threads)
+    if threads:
+        os.environ["C2_FASTQ_THREADS"] = str(threads)
+    else:
+        os.environ.pop("C2_FASTQ_THREADS", None)
     os.environ["C2_FASTQ_RANGE_BYTES"] = str(rb)
     pipeline.STREAM_MIN_BATCH = minb or 200_000
     runs = []
