@@ -697,4 +697,4 @@ def test_stream_rc_partners_equal_the_standalone_search(tmp_path, monkeypatch, t
         arena = fq.arena[:fq.arena_bytes].copy()
     want = _native.rc_partners(arena, off)
     assert np.array_equal(got, want)
-    assert (got >= 0).sum() > 150 and (got == np.arange(len(got))).sum() >= 3 and (got < 0).sum() > 50
+    assert (got >= 0).sum() > 150 and (got == np.arange(len(got))).sum() >= 2 and (got < 0).sum() > 50
