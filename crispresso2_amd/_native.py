@@ -24,7 +24,7 @@ SYMBOLS = [
     "c2_comm_unique_id", "c2_comm_init", "c2_reduce_counts", "c2_comm_destroy",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
-    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners",
+    "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners", "c2_gather_reads",
     "c2_consensus_pairs_batch", "c2_consensus_pairs_device",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets",
 ]
@@ -593,6 +593,23 @@ def rc_partners(arena, offsets):
     if rcode != 0:
         raise NativeError("c2_rc_partners: %s" % lib.c2_fastq_last_error().decode())
     return out
+
+
+def gather_reads(arena, offsets, idx):
+    """c2_gather_reads -> (uint8 arena of the reads idx[...] back to back, uint64 offsets [len(idx) + 1])"""
+    lib = load()
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    m = len(idx)
+    off = np.zeros(m + 1, dtype=np.uint64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    if lib.c2_gather_reads(P(arena) if arena.size else None, P(offsets), P(idx), ctypes.c_uint64(m), None, P(off)) != 0:
+        raise NativeError("c2_gather_reads: %s" % lib.c2_fastq_last_error().decode())
+    out = np.empty(max(int(off[-1]), 1), dtype=np.uint8)
+    if lib.c2_gather_reads(P(arena) if arena.size else None, P(offsets), P(idx), ctypes.c_uint64(m), P(out), P(off)) != 0:
+        raise NativeError("c2_gather_reads: %s" % lib.c2_fastq_last_error().decode())
+    return out[:int(off[-1])], off
 
 
 def merge_counts_with_partners(aligned, partner, counts):

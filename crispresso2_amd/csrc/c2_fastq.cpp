@@ -1384,6 +1384,30 @@ int c2_rc_partners(const uint8_t* arena, const uint64_t* offsets, uint64_t n, in
     return 0;
 }
 
+// The reads idx[0..m) of an arena, packed back to back (a read may repeat): out_offsets[m + 1], out_arena sized by the caller from
+// the lengths.  The count route uses it for the (read, reference) pairs that are aligned on both strands (CRISPRessoCORE.py:675-687);
+// numpy's fancy indexing needs an 8-byte index per BYTE for the same thing.
+int c2_gather_reads(const uint8_t* arena, const uint64_t* offsets, const int64_t* idx, uint64_t m, uint8_t* out_arena, uint64_t* out_offsets) {
+    if (!offsets || !idx || !out_offsets || (m && !out_arena && false)) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
+    out_offsets[0] = 0;
+    for (uint64_t k = 0; k < m; ++k) out_offsets[k + 1] = out_offsets[k] + (offsets[idx[k] + 1] - offsets[idx[k]]);
+    if (!out_arena) return 0;                                        // (first call: sizes only)
+    unsigned threads = usable_cpus();
+    if (threads > 32) threads = 32;
+    if (threads < 1 || m < 8192) threads = 1;
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t k = lo; k < hi; ++k) {
+            const uint64_t a = offsets[idx[k]], len = offsets[idx[k] + 1] - a;
+            if (len) memcpy(out_arena + out_offsets[k], arena + a, (size_t)len);
+        }
+    };
+    if (threads == 1) { work(0, m); return 0; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work, m * t / threads, m * (t + 1) / threads);
+    for (auto& th : pool) th.join();
+    return 0;
+}
+
 int c2_merge_counts_with_partners(uint64_t n, const uint8_t* aligned, const int64_t* partner, int64_t* counts) {
     if (!aligned || !partner || !counts) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
     for (uint64_t i = 0; i < n; ++i) {

@@ -548,14 +548,11 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     r2 = a2 = f2 = None
     stride2 = stride
     if n2:
-        off2 = np.zeros(n2 + 1, dtype=np.uint64)
-        off2[1:] = np.cumsum(lens[bi])
         # gather the bytes of those reads (a read that is undecided for several references is repeated)
-        src = np.repeat(offsets[bi].astype(np.int64) - off2[:-1].astype(np.int64), lens[bi]) + np.arange(int(off2[-1]), dtype=np.int64)
-        arena2 = arena[src]
+        arena2, off2 = _native.gather_reads(arena, offsets, bi)
         max_lj2 = int(lens[bi].max())
         stride2 = aligner.stride_for(max_lj2)
-        d_reads2 = torch.from_numpy(arena2.copy() if arena2.size else np.zeros(1, dtype=np.uint8)).to(dev)
+        d_reads2 = torch.from_numpy(arena2 if arena2.size else np.zeros(1, dtype=np.uint8)).to(dev)
         d_off2 = torch.from_numpy(off2.astype(np.int64)).to(dev)
         d_rid2 = torch.from_numpy(br.astype(np.int16)).to(dev)
         d_str2 = torch.ones(n2, dtype=torch.uint8, device=dev)

@@ -380,6 +380,9 @@ int c2_strand_plan_device(c2_ctx* ctx, uint64_t n_reads, const uint8_t* d_reads,
  * reverse_complement(read i), or -1; a host thread can run it while the device aligns) and the sequential count transfer over it. */
 int c2_rc_partners(const uint8_t* arena, const uint64_t* offsets, uint64_t n, int64_t* partner);
 int c2_merge_counts_with_partners(uint64_t n, const uint8_t* aligned, const int64_t* partner, int64_t* counts);
+/* The reads idx[0..m) of an arena packed back to back (repeats allowed) -> out_offsets[m + 1] and, unless out_arena is NULL (sizes
+ * only), their bytes: the second batch of the count route (reads aligned on both strands, CRISPRessoCORE.py:675-687). */
+int c2_gather_reads(const uint8_t* arena, const uint64_t* offsets, const int64_t* idx, uint64_t m, uint8_t* out_arena, uint64_t* out_offsets);
 
 /* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1 with and without bound_ctrl, also with a
  * lane switched off in EXEC, readlane, ballot) the DP depends on; writes 448 int32 (see c2_selftest_kernel).  Used by the

@@ -554,6 +554,15 @@ def _legacy_run(tmp_path, ctx=None):
     out = tmp_path / "CRISPResso_on_legacy"
     written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
     assert _compare_params(g, written, str(out)) == len(g["files"])
+    # the statistics come from c2_select_best_kernel's uint64 accumulators (stored as int64); the host restatement of the
+    # selection must give the same numbers under the legacy classifier too (whose window counts can exceed the all_* counts:
+    # N_MODS_OUTSIDE_WINDOW is then a difference of wrapped terms on both routes)
+    pipeline.FORCE_HOST_SELECTION = True
+    try:
+        res_h = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a), ctx=ctx)
+    finally:
+        pipeline.FORCE_HOST_SELECTION = False
+    assert res_h.stats == res.stats
     # the same reads under the default classifier give different tables (the golden pins the legacy rules, not the common part)
     res2 = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(dict(a, use_legacy_insertion_quantification=False)), ctx=ctx)
     assert res2.stats["N_MODS_IN_WINDOW"] != res.stats["N_MODS_IN_WINDOW"] or res2.stats["N_MODS_OUTSIDE_WINDOW"] != res.stats["N_MODS_OUTSIDE_WINDOW"]
