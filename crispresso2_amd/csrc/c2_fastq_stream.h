@@ -439,35 +439,56 @@ struct FastqStream {
     void rc_partners_into(int64_t* partner) {
         const uint64_t nu = offsets.size() - 1;
         const uint64_t gmask = slots_cap - 1;
+        // complement of an upper-cased base, 0 = not in ACGTN_- (lower-case letters map like their capitals: the reference upper-cases first)
+        uint8_t comp[256];
+        memset(comp, 0, sizeof comp);
+        comp['A'] = 'T'; comp['C'] = 'G'; comp['G'] = 'C'; comp['T'] = 'A'; comp['N'] = 'N'; comp['_'] = '_'; comp['-'] = '-';
+        comp['a'] = 'T'; comp['c'] = 'G'; comp['g'] = 'C'; comp['t'] = 'A'; comp['n'] = 'N';
         pool->run([&](unsigned t) {
-            std::vector<uint8_t> rc;
-            for (uint64_t g = nu * t / T, end = nu * (t + 1) / T; g < end; ++g) {
-                partner[g] = -1;
-                const uint8_t* s = arena.data() + offsets[g];
-                const size_t len = (size_t)(offsets[g + 1] - offsets[g]);
-                rc.resize(len);
-                bool ok = true;
-                for (size_t k = 0; k < len && ok; ++k) {
-                    uint8_t c = s[len - 1 - k];
-                    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
-                    switch (c) {
-                        case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'T': c = 'A'; break;
-                        case 'N': case '_': case '-': break;
-                        default: ok = false;
-                    }
-                    rc[k] = c;
-                }
-                if (!ok) continue;
-                const uint64_t h = hash_bytes(rc.data(), len);
-                for (uint64_t p = h & gmask;; p = (p + 1) & gmask) {
+            // the look-up of one read misses the cache three times (slot, entry, the candidate's bytes): RING reads are in flight, each
+            // stage asks for the next line of a read a few positions behind
+            constexpr unsigned RING = 12;
+            struct Pend { std::vector<uint8_t> rc; uint64_t h; uint64_t g; bool ok; };
+            Pend ring[RING];
+            const uint64_t g0 = nu * t / T, g1 = nu * (t + 1) / T;
+            auto finish_one = [&](const Pend& P) {
+                partner[P.g] = -1;
+                if (!P.ok) return;
+                const size_t len = P.rc.size();
+                for (uint64_t p = P.h & gmask;; p = (p + 1) & gmask) {
                     const uint32_t e = slots[p].load(std::memory_order_relaxed);
                     if (!e) break;
                     const StreamEntry& E = entry(e - 1);
-                    if (E.h == h && E.len == len && E.gidx != C2_NO_ENTRY && (len == 0 || memcmp(arena.data() + E.arena_off, rc.data(), len) == 0)) {
-                        partner[g] = (int64_t)E.gidx; break;
+                    if (E.h == P.h && E.len == len && E.gidx != C2_NO_ENTRY && (len == 0 || memcmp(arena.data() + E.arena_off, P.rc.data(), len) == 0)) {
+                        partner[P.g] = (int64_t)E.gidx; break;
+                    }
+                }
+            };
+            uint64_t rn = 0;
+            for (uint64_t g = g0; g < g1; ++g, ++rn) {
+                Pend& P = ring[rn % RING];
+                if (rn >= RING) finish_one(P);
+                const uint8_t* s = arena.data() + offsets[g];
+                const size_t len = (size_t)(offsets[g + 1] - offsets[g]);
+                P.rc.resize(len);
+                uint8_t bad = 0xff;
+                for (size_t k = 0; k < len; ++k) { const uint8_t c = comp[s[len - 1 - k]]; P.rc[k] = c; bad &= (uint8_t)(c ? 0xff : 0); }
+                P.ok = bad != 0 || len == 0; P.g = g;
+                P.h = P.ok ? hash_bytes(P.rc.data(), len) : 0;
+                if (P.ok) __builtin_prefetch(&slots[P.h & gmask]);
+                if (rn >= RING / 3) {
+                    const Pend& Q = ring[(rn - RING / 3) % RING];
+                    if (Q.ok) { const uint32_t e = slots[Q.h & gmask].load(std::memory_order_relaxed); if (e) __builtin_prefetch(&entry(e - 1)); }
+                }
+                if (rn >= 2 * RING / 3) {
+                    const Pend& Q = ring[(rn - 2 * RING / 3) % RING];
+                    if (Q.ok) {
+                        const uint32_t e = slots[Q.h & gmask].load(std::memory_order_relaxed);
+                        if (e) { const StreamEntry& E = entry(e - 1); if (E.h == Q.h) for (uint32_t o = 0; o < E.len; o += 64) __builtin_prefetch(arena.data() + E.arena_off + o); }
                     }
                 }
             }
+            for (uint64_t q = rn > RING ? rn - RING : 0; q < rn; ++q) finish_one(ring[q % RING]);
         });
     }
 

@@ -192,6 +192,55 @@ def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
     return member, use2, aligned
 
 
+RC_PARTNERS_ON_DEVICE_MIN = 200_000   # unique reads (all of one length) from which the reverse-complement partner search runs on the device
+
+
+def rc_partners_device(d_reads2d):
+    """The partner search of the count merge (CRISPRessoCORE.py:3970-3975: which unique read equals reverse_complement(read i);
+    CRISPRessoShared.py:399-403: upper-cased first, ACGTN_- only) for reads of ONE length that are already in HBM as a [n, L] byte
+    matrix: a 64-bit weighted-sum hash of every read and of every reverse complement, one sort + binary search to pair equal hashes,
+    then the candidate's BYTES compared with the reverse complement -- the hash only proposes, equality decides.  -> int64 [n] on the
+    host (-1: no partner), or None if a proposed pair failed the byte comparison (two different reads with one hash: the caller takes
+    the host search).  A few device passes over n x L bytes (milliseconds for millions of reads) instead of ~0.5 us per read and core."""
+    import torch
+    n, L = d_reads2d.shape
+    dev = d_reads2d.device
+    R = d_reads2d
+    comp = torch.zeros_like(R)
+    for src, dst in (("A", "T"), ("C", "G"), ("G", "C"), ("T", "A"), ("N", "N"), ("_", "_"), ("-", "-"), ("a", "T"), ("c", "G"), ("g", "C"), ("t", "A"), ("n", "N")):
+        comp = torch.where(R == ord(src), torch.full_like(R, ord(dst)), comp)
+    valid = (comp != 0).all(dim=1)
+    rcb = comp.flip(1).contiguous()
+    g = torch.Generator(device="cpu")
+    g.manual_seed(0x5eed)
+    w = (torch.randint(1, 1 << 62, (L,), generator=g, dtype=torch.int64) * 2 + 1).to(dev)
+    h = torch.empty(n, dtype=torch.int64, device=dev)
+    hr = torch.empty(n, dtype=torch.int64, device=dev)
+    CH = 1 << 18
+    MIX = -7046029254386353131                                         # 0x9E3779B97F4A7C15 as a signed 64-bit number
+    for a0 in range(0, n, CH):
+        a1 = min(n, a0 + CH)
+        x = R[a0:a1].to(torch.int64)
+        h[a0:a1] = ((x * MIX + (x << 17)) * w).sum(dim=1)                      # (byte value mixed before weighting: int64 wrap-around is the modulus)
+        y = rcb[a0:a1].to(torch.int64)
+        hr[a0:a1] = ((y * MIX + (y << 17)) * w).sum(dim=1)
+    hs, order = torch.sort(h)
+    pos = torch.searchsorted(hs, hr).clamp(max=n - 1)
+    hit = (hs[pos] == hr) & valid
+    rows = torch.nonzero(hit).reshape(-1)
+    partner = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    if rows.numel():
+        cand = order[pos[rows]]
+        same = torch.empty(rows.numel(), dtype=torch.bool, device=dev)
+        for a0 in range(0, rows.numel(), CH):
+            a1 = min(rows.numel(), a0 + CH)
+            same[a0:a1] = (R[cand[a0:a1]] == rcb[rows[a0:a1]]).all(dim=1)
+        if not bool(same.all()):
+            return None
+        partner[rows] = cand
+    return partner.cpu().numpy()
+
+
 STREAM_MIN_BATCH = 200_000          # unique reads: smaller arrivals wait for the next chunk (a launch chain per chunk is not free)
 
 
@@ -317,13 +366,16 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
         r1 = torch.empty((0, 32), dtype=torch.uint8, device=dev)
         d_plan = torch.empty(0, dtype=torch.uint8, device=dev)
     plan = d_plan.cpu().numpy().reshape(n, k)                          # (waits for the last batch)
+    d_reads_all = None
+    if parts and n >= RC_PARTNERS_ON_DEVICE_MIN:                       # (kept for the partner search on the device)
+        d_reads_all = parts[0][5] if len(parts) == 1 else torch.cat([p_[5][:int(o[-1] - o[0])] for p_, o in zip(parts, off_parts)])
     del parts
     if timings is not None:
         timings["ingest_dedup_streamed"] = t_ingest_done - t_start
         timings["stream_tail_device"] = time.perf_counter() - t_ingest_done
         timings["stream_batches"] = turn
     return dict(arena=arena, offsets=offsets, counts=counts, plan=plan, stride=stride, a1=a1, f1=f1, r1=r1,
-                rc_partners=None if dropped else fq.rc_partners)
+                rc_partners=None if dropped else fq.rc_partners, d_reads_all=d_reads_all)
 
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
@@ -505,13 +557,20 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
 
     def _find_partners():
         try:
-            if front is not None and front.get("rc_partners") is not None:
+            if partners.get('index') is not None:
+                pass                                                  # (found on the device, below)
+            elif front is not None and front.get("rc_partners") is not None:
                 partners['index'] = front["rc_partners"]()            # (from the table the streamed ingest built: no second hash of every read)
             else:
                 partners['index'] = (_native.rc_partners(arena, offsets) if shard is None else
                                      _native.rc_partners(np.ascontiguousarray(g_arena, dtype=np.uint8), g_offsets))
         except BaseException as e:                                   # re-raised by the main thread at the join
             partners['error'] = e
+    # reads of one length that are already in HBM: the search runs there (milliseconds); anything else on the host thread
+    if shard is None and n >= RC_PARTNERS_ON_DEVICE_MIN and int(lens.min()) == max_lj:
+        d_all = front["d_reads_all"] if front is not None else d_reads
+        if d_all is not None and d_all.numel() >= n * max_lj:
+            partners['index'] = rc_partners_device(d_all[:n * max_lj].view(n, max_lj))
     partner_thread = threading.Thread(target=_find_partners, name="c2-rc-partners")
     _threads.append(partner_thread)
     partner_thread.start()

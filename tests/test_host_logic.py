@@ -160,3 +160,38 @@ def test_tables_write_the_reference_formats_from_a_count_tensor(tmp_path):
     pct = (tmp_path / "Nucleotide_percentage_table.txt").read_text().split("\n")[1].split("\t")
     assert pct[0] == "A" and abs(float(pct[4]) - 1.0) < 1e-12          # position 4 of the amplicon is an A in every aligned read
     assert tables.ref_plot_name(["Reference"], "Reference") == "" and tables.ref_plot_name(["A", "B"], "A") == "A."
+
+
+def test_rc_partner_search_with_torch_ops_equals_the_native_search():
+    """pipeline.rc_partners_device (reads of one length as a byte matrix; runs on the GPU in production, on CPU tensors here) against
+    c2_rc_partners: pairs in both orders, palindromes, lower-case reads, characters outside ACGTN_-, reads without a partner."""
+    import numpy as np
+    import torch
+    from crispresso2_amd import _native, pipeline
+    rng = np.random.default_rng(11)
+    L = 37
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "_": "_", "-": "-"}
+    rc = lambda s_: "".join(comp[c] for c in reversed(s_.upper()))
+    base = ["".join(rng.choice(list("ACGTN"), L)) for _ in range(400)]
+    seqs = []
+    for k, b in enumerate(base):
+        seqs.append(b)
+        if k % 3 == 0:
+            seqs.append(rc(b))
+        if k % 7 == 0:
+            seqs.append(b.lower())
+        if k % 11 == 0:
+            seqs.append(b[:5] + "R" + b[6:])
+        if k % 13 == 0:
+            seqs.append(b[:9] + "-_" + b[11:])
+    half = "".join(rng.choice(list("ACGT"), L // 2))
+    seqs.append(half + "N" + rc(half))                                 # its own reverse complement
+    seqs = list(dict.fromkeys(seqs))
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[k] for k in order]
+    arena = np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy()
+    off = (np.arange(len(seqs) + 1, dtype=np.uint64) * L)
+    want = _native.rc_partners(arena, off)
+    got = pipeline.rc_partners_device(torch.from_numpy(arena).view(len(seqs), L))
+    assert got is not None and np.array_equal(got, want)
+    assert (want >= 0).sum() > 200 and (want == np.arange(len(seqs))).sum() >= 1 and (want < 0).sum() > 100

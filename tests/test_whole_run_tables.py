@@ -727,3 +727,39 @@ def test_streamed_ingest_in_many_small_batches_gives_the_same_files(tmp_path, mo
         out = tmp_path / "out"
         names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
     assert _compare(g, names, str(out)) == 18
+
+
+def test_partner_search_on_the_device_gives_the_same_run(tmp_path, monkeypatch):
+    """Reads of one length with reverse-complement partners among them: pipeline.quantify_fastq with the partner search on the
+    "device" (torch ops over the read matrix; RC_PARTNERS_ON_DEVICE_MIN lowered) -- streamed in several batches and in one batch --
+    against the host search: same statistics, tensors and allele rows (the merged reads' copies go to the first of each pair)."""
+    from pipeline_on_emulator import emulated_device
+    from crispresso2_amd import pipeline, synth, refs as RF
+    L = 150
+    amp, g_, inc = synth.amplicon_setup(L)
+    reads = synth.make_reads(L, 90)
+    seqs = [r.tobytes().decode() for r in reads]
+    seqs = seqs + [RF.reverse_complement(s_) for s_ in seqs[:25]] + seqs[:10]
+    fq = tmp_path / "rc.fastq"
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (k, s_, "I" * L) for k, s_ in enumerate(seqs)))
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
+    monkeypatch.setenv("C2_FASTQ_THREADS", "2")
+    monkeypatch.setenv("C2_FASTQ_RANGE_BYTES", "4096")
+    monkeypatch.setattr(pipeline, "STREAM_MIN_BATCH", 20)
+    results = []
+    with emulated_device():
+        for dev_min, stream in ((10**9, True), (1, True), (1, False)):
+            monkeypatch.setattr(pipeline, "RC_PARTNERS_ON_DEVICE_MIN", dev_min)
+            called = []
+            orig = pipeline.rc_partners_device
+            monkeypatch.setattr(pipeline, "rc_partners_device", lambda m_: (called.append(m_.shape), orig(m_))[1])
+            res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(), stream=stream)
+            monkeypatch.setattr(pipeline, "rc_partners_device", orig)
+            assert bool(called) == (dev_min == 1)
+            results.append((res.stats, res.per_ref["Reference"], res.alleles()))
+    st0, pr0, al0 = results[0]
+    assert st0["N_TOTAL"] > 100 and len(al0) < len(set(seqs))           # merged pairs: fewer rows than unique reads
+    for st, pr, al in results[1:]:
+        assert st == st0 and al == al0
+        for kk, vv in pr0.items():
+            assert np.array_equal(vv, pr[kk]) if isinstance(vv, np.ndarray) else vv == pr[kk], kk
