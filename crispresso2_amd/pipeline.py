@@ -195,50 +195,58 @@ def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
 RC_PARTNERS_ON_DEVICE_MIN = 200_000   # unique reads (all of one length) from which the reverse-complement partner search runs on the device
 
 
+class _DevicePartners:
+    """what rc_partners_device enqueued: result() waits for it -> int64 [n] on the host, or None (a proposed pair failed the byte
+    comparison: two different reads with one hash -- the caller takes the host search)"""
+    def __init__(self, partner, bad):
+        self._partner, self._bad = partner, bad
+
+    def result(self):
+        if bool(self._bad.item()):
+            return None
+        return self._partner.cpu().numpy()
+
+
 def rc_partners_device(d_reads2d):
     """The partner search of the count merge (CRISPRessoCORE.py:3970-3975: which unique read equals reverse_complement(read i);
     CRISPRessoShared.py:399-403: upper-cased first, ACGTN_- only) for reads of ONE length that are already in HBM as a [n, L] byte
-    matrix: a 64-bit weighted-sum hash of every read and of every reverse complement, one sort + binary search to pair equal hashes,
-    then the candidate's BYTES compared with the reverse complement -- the hash only proposes, equality decides.  -> int64 [n] on the
-    host (-1: no partner), or None if a proposed pair failed the byte comparison (two different reads with one hash: the caller takes
-    the host search).  A few device passes over n x L bytes (milliseconds for millions of reads) instead of ~0.5 us per read and core."""
+    matrix: a 64-bit hash of every read and of every reverse complement (weighted sum of their 8-byte words), one sort + binary
+    search to pair equal hashes, then the candidate's BYTES compared with the reverse complement -- the hash only proposes, equality
+    decides.  Everything is enqueued on the current stream and nothing waits: -> _DevicePartners, whose result() is asked for when
+    the merge needs it (a few device passes over n x L bytes, ~20 ms for 3.5 M reads, while the host prepares the next launches;
+    the host search costs ~0.5 us per read and core)."""
     import torch
     n, L = d_reads2d.shape
     dev = d_reads2d.device
     R = d_reads2d
     comp = torch.zeros_like(R)
     for src, dst in (("A", "T"), ("C", "G"), ("G", "C"), ("T", "A"), ("N", "N"), ("_", "_"), ("-", "-"), ("a", "T"), ("c", "G"), ("g", "C"), ("t", "A"), ("n", "N")):
-        comp = torch.where(R == ord(src), torch.full_like(R, ord(dst)), comp)
+        comp.masked_fill_(R == ord(src), ord(dst))
     valid = (comp != 0).all(dim=1)
     rcb = comp.flip(1).contiguous()
+    del comp
+    W = (L + 7) // 8
     g = torch.Generator(device="cpu")
     g.manual_seed(0x5eed)
-    w = (torch.randint(1, 1 << 62, (L,), generator=g, dtype=torch.int64) * 2 + 1).to(dev)
-    h = torch.empty(n, dtype=torch.int64, device=dev)
-    hr = torch.empty(n, dtype=torch.int64, device=dev)
-    CH = 1 << 18
-    MIX = -7046029254386353131                                         # 0x9E3779B97F4A7C15 as a signed 64-bit number
-    for a0 in range(0, n, CH):
-        a1 = min(n, a0 + CH)
-        x = R[a0:a1].to(torch.int64)
-        h[a0:a1] = ((x * MIX + (x << 17)) * w).sum(dim=1)                      # (byte value mixed before weighting: int64 wrap-around is the modulus)
-        y = rcb[a0:a1].to(torch.int64)
-        hr[a0:a1] = ((y * MIX + (y << 17)) * w).sum(dim=1)
+    w = (torch.randint(1, 1 << 62, (W,), generator=g, dtype=torch.int64) * 2 + 1).to(dev)
+
+    def hash_rows(M):                                                  # [n, L] bytes -> int64 [n]: the rows' 8-byte words, mixed, weighted, summed (wrap-around)
+        P = M if L == 8 * W else torch.nn.functional.pad(M, (0, 8 * W - L))
+        x = P.contiguous().view(torch.int64).view(n, W)
+        x = x ^ (x >> 29)
+        return (x * w).sum(dim=1)
+    h, hr = hash_rows(R), hash_rows(rcb)
     hs, order = torch.sort(h)
     pos = torch.searchsorted(hs, hr).clamp(max=n - 1)
     hit = (hs[pos] == hr) & valid
-    rows = torch.nonzero(hit).reshape(-1)
-    partner = torch.full((n,), -1, dtype=torch.int64, device=dev)
-    if rows.numel():
-        cand = order[pos[rows]]
-        same = torch.empty(rows.numel(), dtype=torch.bool, device=dev)
-        for a0 in range(0, rows.numel(), CH):
-            a1 = min(rows.numel(), a0 + CH)
-            same[a0:a1] = (R[cand[a0:a1]] == rcb[rows[a0:a1]]).all(dim=1)
-        if not bool(same.all()):
-            return None
-        partner[rows] = cand
-    return partner.cpu().numpy()
+    cand = order[pos]
+    same = torch.empty(n, dtype=torch.bool, device=dev)
+    CH = 1 << 20
+    for a0 in range(0, n, CH):
+        a1 = min(n, a0 + CH)
+        same[a0:a1] = (R[cand[a0:a1]] == rcb[a0:a1]).all(dim=1)
+    partner = torch.where(hit & same, cand, torch.full_like(cand, -1))
+    return _DevicePartners(partner, (hit & ~same).any())
 
 
 STREAM_MIN_BATCH = 200_000          # unique reads: smaller arrivals wait for the next chunk (a launch chain per chunk is not free)
@@ -557,9 +565,9 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
 
     def _find_partners():
         try:
-            if partners.get('index') is not None:
-                pass                                                  # (found on the device, below)
-            elif front is not None and front.get("rc_partners") is not None:
+            if partners.get('device') is not None:
+                return                                                # (enqueued on the device, below; fetched at the merge)
+            if front is not None and front.get("rc_partners") is not None:
                 partners['index'] = front["rc_partners"]()            # (from the table the streamed ingest built: no second hash of every read)
             else:
                 partners['index'] = (_native.rc_partners(arena, offsets) if shard is None else
@@ -570,7 +578,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if shard is None and n >= RC_PARTNERS_ON_DEVICE_MIN and int(lens.min()) == max_lj:
         d_all = front["d_reads_all"] if front is not None else d_reads
         if d_all is not None and d_all.numel() >= n * max_lj:
-            partners['index'] = rc_partners_device(d_all[:n * max_lj].view(n, max_lj))
+            partners['device'] = rc_partners_device(d_all[:n * max_lj].view(n, max_lj))
     partner_thread = threading.Thread(target=_find_partners, name="c2-rc-partners")
     _threads.append(partner_thread)
     partner_thread.start()
@@ -665,6 +673,10 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     partner_thread.join()
     if 'error' in partners:
         raise partners['error']
+    if partners.get('device') is not None:
+        partners['index'] = partners['device'].result()
+        if partners['index'] is None:                                # (a hash collision among the reads: the host search decides)
+            partners['index'] = _native.rc_partners(arena, offsets)
     if shard is None:
         _native.merge_counts_with_partners(aligned, partners['index'], cnt)
     else:

@@ -192,6 +192,6 @@ def test_rc_partner_search_with_torch_ops_equals_the_native_search():
     arena = np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy()
     off = (np.arange(len(seqs) + 1, dtype=np.uint64) * L)
     want = _native.rc_partners(arena, off)
-    got = pipeline.rc_partners_device(torch.from_numpy(arena).view(len(seqs), L))
+    got = pipeline.rc_partners_device(torch.from_numpy(arena).view(len(seqs), L)).result()
     assert got is not None and np.array_equal(got, want)
     assert (want >= 0).sum() > 200 and (want == np.arange(len(seqs))).sum() >= 1 and (want < 0).sum() > 100

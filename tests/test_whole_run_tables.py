@@ -752,7 +752,7 @@ def test_partner_search_on_the_device_gives_the_same_run(tmp_path, monkeypatch):
             monkeypatch.setattr(pipeline, "RC_PARTNERS_ON_DEVICE_MIN", dev_min)
             called = []
             orig = pipeline.rc_partners_device
-            monkeypatch.setattr(pipeline, "rc_partners_device", lambda m_: (called.append(m_.shape), orig(m_))[1])
+            monkeypatch.setattr(pipeline, "rc_partners_device", lambda m_: (called.append(m_.shape), orig(m_))[1])     # (-> _DevicePartners)
             res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(), stream=stream)
             monkeypatch.setattr(pipeline, "rc_partners_device", orig)
             assert bool(called) == (dev_min == 1)
