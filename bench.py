@@ -474,7 +474,10 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
     out = {"reads": files["reads"], "file_bytes": files["bytes_plain"], "file_bytes_bgzf": files["bytes_bgzf"],
            "file_system": os.path.dirname(files["dir"]), "write_seconds_not_timed": {"plain": files["write_plain_s"], "bgzf": files["write_bgzf_s"]}}
     tallies = {}
-    for kind, path in (("plain", files["plain"]), ("bgzf", files["bgzf"])):
+    for kind, path in (("plain", files["plain"]), ("plain_host_parser", files["plain"]), ("bgzf", files["bgzf"])):
+        # plain: the text is uploaded as it is and framed + de-duplicated by the c2_fq_* kernels (fastq_device); plain_host_parser: the
+        # same file through the native host parser (what compressed or filtered input uses), for comparison
+        os.environ["C2_FQ_INGEST"] = "host" if kind == "plain_host_parser" else "auto"
         runs = []
         for rep in range(repeat + 2):                                # the first run is the warm-up (context, allocations, page cache); the last one
             tm = {} if rep == repeat + 1 else None                    # collects the stage times (a device synchronisation per stage: not a timed run)
@@ -485,20 +488,22 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
             tallies[kind] = (res.stats["N_TOT_READS"], res.stats["N_TOTAL"], c["counts_total"], c["counts_modified"], c["counts_insertion"],
                              c["counts_deletion"], c["counts_substitution"])
             uniq = res.stats["N_COMPUTED_ALN"] + res.stats["N_COMPUTED_NOTALN"]
+            route = getattr(res, "ingest_route", "host")
             del res
             time.sleep(0.3)                                          # (the run's buffers are unmapped by helper threads: let them finish)
         dt = min(r[0] for r in runs[1:repeat + 1])
         tm = runs[-1][1]
         out[kind] = {"seconds": dt, "reads_per_s": files["reads"] / dt, "seconds_all_runs": [r[0] for r in runs], "stage_seconds": tm,
                      "stage_seconds_note": "from one more run with a device synchronisation after every stage (the last of seconds_all_runs); the "
-                                           "timed runs have none", "unique_reads": uniq}
+                                           "timed runs have none", "unique_reads": uniq, "ingest_route": route}
+    os.environ.pop("C2_FQ_INGEST", None)
     out["reads_per_s"] = out["plain"]["reads_per_s"]
     out["stage_seconds"] = out["plain"]["stage_seconds"]
-    out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"]
+    out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"] == tallies["plain_host_parser"]
     out["tallies"] = dict(zip(("N_TOT_READS", "N_TOTAL", "counts_total", "modified", "with_insertion", "with_deletion", "with_substitution"),
                               tallies["plain"]))
-    out["note"] = ("pipeline.quantify_fastq on the headline's reads as a FASTQ file (qualities 'I'), page cache warm: native ingest + exact "
-                   "de-duplication, seed test, alignments of the unique reads, selection, reverse-complement merge, count kernel; best of %d "
+    out["note"] = ("pipeline.quantify_fastq on the headline's reads as a FASTQ file (qualities 'I'), page cache warm: ingest + exact "
+                   "de-duplication (plain: on the device; plain_host_parser / bgzf: the native host parser), seed test, alignments of the unique reads, selection, reverse-complement merge, count kernel; best of %d "
                    "runs after a warm-up; reads/s counts every read of the file" % repeat)
     return out
 

@@ -152,6 +152,49 @@ struct c2_strand_args {
     uint8_t* plan;                    // [n_reads][n_refs]: 0 forward only, 1 reverse complement only, 2 both
 };
 
+// ---- FASTQ framing + exact de-duplication on the device (the readline loop of process_fastq, CRISPRessoCORE.py:1820-1849) ----
+// The text (no '\r' in it: the host falls back to its own parser otherwise) lies in HBM; lines end at '\n'; line k is ended by
+// newline k (0-based); record r = lines 4r .. 4r + 3; its sequence is line 4r + 1: it starts behind newline 4r and ends at newline 4r + 1.
+#define C2_FQ_LDS_BYTES 1024u          // dynamic LDS of the two framing kernels
+#define C2_FQ_TILE 16384u              // bytes of text per workgroup of the two framing kernels (256 threads x 64 bytes)
+struct c2_fq_frame_args {
+    const uint8_t* text;              // the whole text; bytes [0, hi) are resident
+    uint64_t lo, hi;                  // this launch frames [lo, hi); lo is a multiple of C2_FQ_TILE
+    uint32_t* tile_newlines;          // per tile of [lo, hi): '\n' bytes               (count kernel out, lines kernel in as EXCLUSIVE prefix, 64-bit)
+    uint32_t* tile_empty;             // per tile: '\n' bytes preceded by '\n' (or at text position 0): the empty lines `grep -c .` does not count
+    const uint64_t* tile_base;        // lines kernel: number of newlines in front of every tile (from the start of the TEXT)
+    uint32_t* flags;                  // bit 0: a '\r' was seen
+    uint64_t* seq_start;              // per record: first byte of its sequence line
+    uint64_t* seq_end;                // per record: the newline that ends it
+    uint64_t n_records_cap;           // entries of the two arrays
+};
+// one wavefront per record (grid-stride): strip() the sequence line, look it up in / add it to the table
+struct c2_fq_dedup_args {
+    const uint8_t* text;
+    const uint64_t* seq_start; const uint64_t* seq_end;
+    const uint64_t* range;            // device memory: records [range[0], range[1]) -- written by the stream that counted the newlines, so
+                                      // that no host round trip sits between the framing of a chunk and its de-duplication
+    uint64_t n_records_cap;           // entries of the per-record arrays (a range beyond it sets flag bit 2)
+    unsigned long long* slots;        // open addressing: 0 = empty, else (stripped start << 24 | length) of the key's representative
+    uint64_t mask;                    // slots - 1
+    uint32_t* count;                  // per slot: occurrences
+    uint32_t* first;                  // per slot: smallest record number (first-seen order); initialised to 0xffffffff
+    uint32_t* slot_of;                // per record: its slot
+    unsigned long long* rinfo;        // per record: (stripped start << 24 | length)
+    uint32_t* flags;                  // bit 1: a sequence line of 2^24 bytes or more, or a text position beyond 2^40; bit 2: more records than
+                                      // the arrays hold; bit 3: the table is more than half full (the host falls back on any of them)
+    uint32_t* n_unique;               // += keys created by this launch
+};
+// out[out_offsets[i] ..] = the bytes info[records ? records[i] : i] names (start << 24 | length)
+struct c2_fq_gather_args {
+    const uint8_t* text;
+    const unsigned long long* info;
+    const int64_t* records;           // may be null
+    const int64_t* out_offsets;       // n + 1 byte offsets into out
+    uint8_t* out;
+    uint64_t n;
+};
+
 // ---- per-amplicon count tensor (what CRISPRessoCORE.py:3865-3901 keeps per reference and :4016-4115 fills) ----
 // One int64 block per reference: C2_CNT_VECTORS vectors of (lmax + 1) entries, then C2_CNT_SCALARS scalars,
 // then C2_CNT_HISTS histograms of hl entries.  crispresso2_amd/counts.py names the slices.

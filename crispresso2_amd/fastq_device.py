@@ -1,0 +1,289 @@
+"""FASTQ text -> the run's unique reads, framed and de-duplicated ON THE DEVICE (the readline loop of process_fastq,
+reference CRISPResso2/CRISPRessoCORE.py:1825-1849: `variantCache[fastq_seq] += 1` per record).
+
+Why: on the GPU box the host may use 16 CPUs; the native chunked parser (c2_fastq_stream) then needs 0.26-0.39 s for a 10 M-read file
+whose 5.16 GB of text cross the link in 0.10 s.  Here the text is uploaded as it lies in the file (host threads only copy it into
+pinned staging) and four kernels do what the parser does:
+
+  c2_fq_count_kernel   per 16 KB tile: newlines, newlines that end an empty line (`grep -c .`), "a carriage return was seen"
+  c2_fq_lines_kernel   with the prefix sum of those counts: where every record's sequence line starts and ends
+  c2_fq_dedup_kernel   one wavefront per record: str.strip(), hash, look-up / insert in an open-addressing table in HBM whose keys ARE
+                       the bytes of the first occurrence in the text (equality = byte comparison); occurrences and first record per key
+  c2_fq_gather_kernel  the unique reads, in first-seen order, back to back: the arena the align kernels read
+
+Nothing between the chunks waits for the device: the number of complete records is kept in device memory and the de-duplication
+kernel reads its range from there.  The result is exactly c2_fastq_stream's (same reads, same order, same multiplicities, same
+line statistics) for text without carriage returns, without quality filters, uncompressed; anything else -- and any of the kernels'
+"I cannot" flags (a line of 16 MB, more records / keys than estimated) -- is DeviceIngestUnavailable, and the caller uses the host
+parser.  The product has no CPU fallback for COMPUTE; this module is an ingest route, and the host parser is the other one."""
+import os
+
+import numpy as np
+
+from . import _native
+
+TILE = 16384
+CHUNK_BYTES = int(os.environ.get("C2_FQ_DEVICE_CHUNK", 64 << 20))
+MIN_TEXT_BYTES = int(os.environ.get("C2_FQ_DEVICE_MIN", 64 << 20))      # below this the host parser is as fast and needs no table
+MAX_TEXT_BYTES = 1 << 36                                                 # 64 GiB of text resident; beyond: the host parser
+_pinned = {}
+
+
+class DeviceIngestUnavailable(Exception):
+    """this file goes through the host parser (the reason is the message)"""
+
+
+def usable_cpus():
+    """the CPUs this process may use: cgroup quota (cpu.max), affinity"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# ---- the four launches (tests replace these with the wave emulator's entries) ----
+def fq_count(ctx, d_text, lo, hi, d_tile_nl, d_tile_empty, d_flags, stream):
+    import ctypes
+    ctx.check(ctx.lib.c2_fq_count_device(ctx.handle, ctypes.c_void_p(d_text), ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_void_p(d_tile_nl),
+                                         ctypes.c_void_p(d_tile_empty), ctypes.c_void_p(d_flags), ctypes.c_void_p(stream)), "c2_fq_count_device")
+
+
+def fq_lines(ctx, d_text, lo, hi, d_tile_base, d_seq_start, d_seq_end, cap, stream):
+    import ctypes
+    ctx.check(ctx.lib.c2_fq_lines_device(ctx.handle, ctypes.c_void_p(d_text), ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_void_p(d_tile_base),
+                                         ctypes.c_void_p(d_seq_start), ctypes.c_void_p(d_seq_end), ctypes.c_uint64(cap), ctypes.c_void_p(stream)),
+              "c2_fq_lines_device")
+
+
+def fq_dedup(ctx, d_text, d_seq_start, d_seq_end, d_range, cap, d_slots, n_slots, d_count, d_first, d_slot_of, d_rinfo, d_flags, d_n_unique, stream):
+    import ctypes
+    V = ctypes.c_void_p
+    ctx.check(ctx.lib.c2_fq_dedup_device(ctx.handle, V(d_text), V(d_seq_start), V(d_seq_end), V(d_range), ctypes.c_uint64(cap), V(d_slots),
+                                         ctypes.c_uint64(n_slots), V(d_count), V(d_first), V(d_slot_of), V(d_rinfo), V(d_flags), V(d_n_unique),
+                                         V(stream)), "c2_fq_dedup_device")
+
+
+def fq_gather(ctx, d_text, d_info, d_records, d_out_offsets, d_out, n, stream):
+    import ctypes
+    V = ctypes.c_void_p
+    ctx.check(ctx.lib.c2_fq_gather_device(ctx.handle, V(d_text), V(d_info), V(d_records or 0), V(d_out_offsets), V(d_out), ctypes.c_uint64(n),
+                                          V(stream)), "c2_fq_gather_device")
+
+
+def gather_reads_device(ctx, d_reads, d_off, idx, dev, stream):
+    """the reads idx[...] of a device arena (d_off: int64 [n + 1]) back to back -> (uint8 tensor, int64 offsets tensor, longest read);
+    _native.gather_reads for reads that never were on the host"""
+    import torch
+    d_idx = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(dev)
+    lens = d_off[d_idx + 1] - d_off[d_idx]
+    if int(lens.max().item()) >= (1 << 24):
+        raise _native.NativeError("gather_reads_device: a read of 2^24 bytes or more")
+    info = (d_off[d_idx] << 24) | lens
+    out_off = torch.zeros(len(idx) + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=out_off[1:])
+    out = torch.empty(max(int(out_off[-1].item()), 1), dtype=torch.uint8, device=dev)
+    fq_gather(ctx, d_reads.data_ptr(), info.data_ptr(), None, out_off.data_ptr(), out.data_ptr(), len(idx), stream)
+    return out, out_off, int(lens.max().item())
+
+
+def applicable(path, filters=(0, 0, 0)):
+    """-> None if the device route can take this file, else why not"""
+    if os.environ.get("C2_FQ_INGEST", "auto") == "host":
+        return "C2_FQ_INGEST=host"
+    if any(filters):
+        return "quality filters run in the host parser"
+    try:
+        size = os.path.getsize(path)
+        with open(path, "rb") as fh:
+            magic = fh.read(2)
+    except OSError as e:
+        return str(e)
+    if magic == b"\x1f\x8b" or str(path).endswith(".gz"):
+        return "compressed text is inflated by the host parser"
+    if size < MIN_TEXT_BYTES and os.environ.get("C2_FQ_INGEST", "auto") != "device":
+        return "small file"
+    if size > MAX_TEXT_BYTES or size == 0:
+        return "text of %d bytes" % size
+    return None
+
+
+class DeviceIngest:
+    """feed(lo, hi) after bytes [lo, hi) of the text are in d_text (in order, lo a multiple of TILE except that the last chunk may end
+    anywhere); finish() -> the unique reads.  All work is enqueued on torch's current stream of `dev`."""
+
+    def __init__(self, ctx, dev, text_bytes, est_records, d_text=None):
+        import torch
+        self.ctx, self.dev, self.T = ctx, dev, int(text_bytes)
+        self.cap = int(est_records)
+        if self.cap >= (1 << 31) - 2:
+            raise DeviceIngestUnavailable("more than 2^31 records expected")
+        n_slots = 1 << 12
+        while n_slots < 2 * self.cap:
+            n_slots <<= 1
+        if n_slots > (1 << 30):
+            raise DeviceIngestUnavailable("table of more than 2^30 slots")
+        self.n_slots = n_slots
+        i64, i32 = torch.int64, torch.int32
+        self.d_text = d_text if d_text is not None else torch.empty(max(self.T, 1), dtype=torch.uint8, device=dev)
+        self.seq_start = torch.full((self.cap,), self.T, dtype=i64, device=dev)     # (a record whose newline never comes: its line
+        self.seq_end = torch.full((self.cap,), self.T, dtype=i64, device=dev)       #  starts / ends where the text ends)
+        self.slot_of = torch.empty(self.cap, dtype=i32, device=dev)
+        self.rinfo = torch.empty(self.cap, dtype=i64, device=dev)
+        self.slots = torch.zeros(n_slots, dtype=i64, device=dev)
+        self.count = torch.zeros(n_slots, dtype=i32, device=dev)
+        self.first = torch.full((n_slots,), -1, dtype=i32, device=dev)              # 0xffffffff
+        self.flags = torch.zeros(1, dtype=i32, device=dev)
+        self.n_unique = torch.zeros(1, dtype=i32, device=dev)
+        self.newlines = torch.zeros(1, dtype=i64, device=dev)                       # in the text so far
+        self.empty_lines = torch.zeros(1, dtype=i64, device=dev)
+        self.range = torch.zeros(2, dtype=i64, device=dev)                          # records de-duplicated so far: [., range[1])
+        self.fed = 0
+
+    def _stream(self):
+        import torch
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _dedup_to(self, r1):
+        import torch
+        self.range = torch.cat([self.range[1:2], r1.reshape(1)])                    # (a new tensor: the launch before may still read the old one)
+        fq_dedup(self.ctx, self.d_text.data_ptr(), self.seq_start.data_ptr(), self.seq_end.data_ptr(), self.range.data_ptr(), self.cap,
+                 self.slots.data_ptr(), self.n_slots, self.count.data_ptr(), self.first.data_ptr(), self.slot_of.data_ptr(), self.rinfo.data_ptr(),
+                 self.flags.data_ptr(), self.n_unique.data_ptr(), self._stream())
+
+    def feed(self, lo, hi):
+        import torch
+        if lo != self.fed or lo % TILE or hi > self.T or hi <= lo:
+            raise ValueError("chunks come in order, from a multiple of %d" % TILE)
+        self.fed = hi
+        tiles = (hi - lo + TILE - 1) // TILE
+        tile_nl = torch.empty(tiles, dtype=torch.int32, device=self.dev)
+        tile_em = torch.empty(tiles, dtype=torch.int32, device=self.dev)
+        s = self._stream()
+        fq_count(self.ctx, self.d_text.data_ptr(), lo, hi, tile_nl.data_ptr(), tile_em.data_ptr(), self.flags.data_ptr(), s)
+        nl = tile_nl.to(torch.int64)
+        upto = torch.cumsum(nl, 0)
+        base = (upto - nl) + self.newlines
+        fq_lines(self.ctx, self.d_text.data_ptr(), lo, hi, base.data_ptr(), self.seq_start.data_ptr(), self.seq_end.data_ptr(), self.cap, s)
+        self.newlines = self.newlines + upto[-1:]
+        self.empty_lines = self.empty_lines + tile_em.sum(dtype=torch.int64).reshape(1)
+        # a record is complete once the newline behind its sequence line (number 4 r + 1) was seen
+        self._dedup_to((self.newlines + 2) // 4)
+        self._keep = (tile_nl, tile_em, base)                                       # (alive until the next launch is enqueued behind them)
+
+    def finish(self, unterminated):
+        """unterminated: the text does not end with a newline (its last line still counts).  -> dict(d_reads, d_off, offsets, counts,
+        n_reads, nonempty_lines, n_unique); waits for the device."""
+        import torch
+        if self.fed != self.T:
+            raise ValueError("%d of %d bytes were fed" % (self.fed, self.T))
+        dev = self.dev
+        lines = self.newlines + (1 if unterminated else 0)
+        self._dedup_to((lines + 3) // 4)                                            # readline() loop: every started group of four lines is a record
+        n_records = int(self.range[1].item())
+        flags = int(self.flags.item())
+        if flags & 1:
+            raise DeviceIngestUnavailable("carriage returns in the text")
+        if flags & ~1:
+            raise DeviceIngestUnavailable("device ingest gave up (flags %d: 2 = line too long, 4 = more records than estimated, 8 = table too full)" % flags)
+        nonempty = int(lines.item()) - int(self.empty_lines.item())
+        slot_of = self.slot_of[:n_records].to(torch.int64)
+        is_first = self.first[slot_of].to(torch.int64) == torch.arange(n_records, dtype=torch.int64, device=dev)
+        rec = torch.nonzero(is_first).reshape(-1)                                   # first occurrences, in file order = first-seen order
+        info = self.rinfo[rec]
+        lens = info & 0xffffff
+        keep = lens > 0                                                             # (the empty key, if any, is not a read: quantify_fastq drops it)
+        n_empty = 0
+        if not bool(keep.all().item()):
+            drop = rec[~keep]
+            n_empty = int(self.count[self.slot_of[drop].to(torch.int64)].sum().item())
+            rec, lens = rec[keep], lens[keep]
+        n = int(rec.numel())
+        d_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens, 0, out=d_off[1:])
+        total = int(d_off[-1].item())
+        d_reads = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+        fq_gather(self.ctx, self.d_text.data_ptr(), self.rinfo.data_ptr(), rec.data_ptr(), d_off.data_ptr(), d_reads.data_ptr(), n, self._stream())
+        counts = self.count[self.slot_of[rec].to(torch.int64)].to(torch.int64)
+        out = dict(d_reads=d_reads, d_off=d_off, offsets=d_off.cpu().numpy().astype(np.uint64), counts=counts.cpu().numpy(),
+                   n_reads=n_records, n_empty_records=n_empty, nonempty_lines=nonempty, n_unique=n, max_len=int(lens.max().item()) if n else 0,
+                   min_len=int(lens.min().item()) if n else 0)
+        return out
+
+
+def estimate_records(path, size):
+    """records the file is expected to hold, from the line density of its first MB, with a quarter of slack"""
+    with open(path, "rb") as fh:
+        head = fh.read(1 << 20)
+    nl = head.count(b"\n")
+    per_byte = (nl + 1) / max(len(head), 1)
+    return int(size * per_byte / 4.0 * 1.25) + 4096
+
+
+def ingest_file(path, ctx, dev, timings=None):
+    """the whole file -> DeviceIngest.finish()'s dict.  Host threads copy the text into two pinned buffers in turn; every chunk is framed
+    and de-duplicated on the compute stream while the next one is copied and uploaded."""
+    import time
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    size = os.path.getsize(path)
+    on_gpu = dev.type == "cuda"
+    ing = DeviceIngest(ctx, dev, size, estimate_records(path, size))
+    chunk = max(TILE, CHUNK_BYTES // TILE * TILE)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        last = os.pread(fd, 1, size - 1)
+        if not on_gpu:                                                # (tests: the "device" is host memory)
+            view = ing.d_text.numpy()
+            for lo in range(0, size, chunk):
+                hi = min(size, lo + chunk)
+                got = os.preadv(fd, [memoryview(view[lo:hi])], lo)
+                if got != hi - lo:
+                    raise OSError("short read")
+                ing.feed(lo, hi)
+            return ing.finish(last != b"\n")
+        threads = min(16, usable_cpus())
+        key = (chunk, dev.index)
+        if key not in _pinned:
+            _pinned[key] = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        pins = _pinned[key]
+        compute = torch.cuda.current_stream(dev)
+        copy_stream = torch.cuda.Stream(device=dev)
+        evs = [None, None]
+
+        def read_into(args):
+            buf, off, n = args
+            while n:
+                got = os.preadv(fd, [buf[:n]], off)
+                if got <= 0:
+                    raise OSError("short read")
+                buf, off, n = buf[got:], off + got, n - got
+        with ThreadPoolExecutor(threads) as pool:
+            for c, lo in enumerate(range(0, size, chunk)):
+                hi = min(size, lo + chunk)
+                k = c & 1
+                if evs[k] is not None:
+                    evs[k].synchronize()                              # the upload out of this buffer is done
+                mv = memoryview(pins[k].numpy())
+                step = -(-(hi - lo) // threads)
+                step = (step + 4095) // 4096 * 4096
+                list(pool.map(read_into, [(mv[q:min(hi - lo, q + step)], lo + q, min(hi - lo, q + step) - q) for q in range(0, hi - lo, step)]))
+                with torch.cuda.stream(copy_stream):
+                    ing.d_text[lo:hi].copy_(pins[k][:hi - lo], non_blocking=True)
+                    evs[k] = torch.cuda.Event()
+                    evs[k].record(copy_stream)
+                compute.wait_event(evs[k])
+                ing.feed(lo, hi)
+        if timings is not None:
+            timings["upload_text"] = time.perf_counter() - t0
+        out = ing.finish(last != b"\n")
+        if timings is not None:
+            timings["device_dedup_tail"] = time.perf_counter() - t0 - timings["upload_text"]
+        return out
+    finally:
+        os.close(fd)

@@ -387,20 +387,20 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
 
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
-                    timings=None, pe_scaffold_dna_info=None, shard=None, fastq_stream=None):
+                    timings=None, pe_scaffold_dna_info=None, shard=None, fastq_stream=None, device_reads=None):
     """See _quantify_unique.  (This wrapper only makes sure that the host thread the run starts -- it reads `arena`, which may be a
     view of native memory the caller frees -- has ended before control returns, also when the run raises.)"""
     threads = []
     try:
         return _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
-                                timings, pe_scaffold_dna_info, threads, shard, fastq_stream)
+                                timings, pe_scaffold_dna_info, threads, shard, fastq_stream, device_reads)
     finally:
         for t in threads:
             t.join()
 
 
 def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
-                     timings, pe_scaffold_dna_info, _threads, shard=None, fastq_stream=None):
+                     timings, pe_scaffold_dna_info, _threads, shard=None, fastq_stream=None, device_reads=None):
     """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
     shard: None -- this process aligns every read it was given.  Otherwise arena / offsets / read_counts are the WHOLE run's unique
     reads (every rank holds the same list, as every worker of the reference sees the parent's variantCache keys) and `shard` names
@@ -412,6 +412,8 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     Implies reduce_across_ranks.
     fastq_stream: a _native.FastqStream instead of arena / offsets / read_counts -- the file is parsed chunk by chunk on a host thread
     while the device already runs the seed test and the alignments of the unique reads the previous chunks brought (_stream_front).
+    device_reads: fastq_device.ingest_file's result instead of arena / offsets / read_counts -- the unique reads were framed and
+    de-duplicated on the device and never were on the host (`arena` stays None; the rare host-side uses download them).
     timings: optional dict that receives the wall seconds of every stage.
     pe_scaffold_dna_info: (index, dna) of get_pe_scaffold_search for runs with --prime_editing_pegRNA_scaffold_seq: reads whose
     alignment against 'Prime-edited' carries `dna` right after reference base index-1 are counted for 'Scaffold-incorporated'
@@ -451,6 +453,10 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         front = _stream_front(fastq_stream, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
         arena, offsets, read_counts = front["arena"], front["offsets"], front["counts"]
         t_last[0] = time.perf_counter()
+    if device_reads is not None:
+        if shard is not None or fastq_stream is not None:
+            raise ValueError("device_reads is the single-process route")
+        arena, offsets, read_counts = None, device_reads["offsets"], device_reads["counts"]
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     # the whole run's unique reads (what the reverse-complement partner search looks at) and the part this process aligns
     g_arena, g_offsets, g_raw = arena, offsets, np.asarray(read_counts, dtype=np.int64)
@@ -550,8 +556,14 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         elif want_view:
             d_view = torch.zeros((k,) + tuple(layout.shape()), dtype=torch.int64, device=dev)
         return finish(d_view, d_scaffold, None)
-    arena = np.ascontiguousarray(arena, dtype=np.uint8)
-    if front is None:
+    def host_arena():
+        """the reads' bytes on the host (device_reads: downloaded when a host-side step needs them after all)"""
+        return arena if arena is not None else device_reads["d_reads"][:int(offsets[-1])].cpu().numpy()
+    if device_reads is not None:
+        d_reads, d_off = device_reads["d_reads"], device_reads["d_off"]
+    else:
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    if front is None and device_reads is None:
         if not arena.flags.writeable:
             arena = arena.copy()                                      # torch.from_numpy wants a writable array
         # the reads go to the device now: the copy is in flight while the host tests the seeds
@@ -570,7 +582,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             if front is not None and front.get("rc_partners") is not None:
                 partners['index'] = front["rc_partners"]()            # (from the table the streamed ingest built: no second hash of every read)
             else:
-                partners['index'] = (_native.rc_partners(arena, offsets) if shard is None else
+                partners['index'] = (_native.rc_partners(host_arena(), offsets) if shard is None else
                                      _native.rc_partners(np.ascontiguousarray(g_arena, dtype=np.uint8), g_offsets))
         except BaseException as e:                                   # re-raised by the main thread at the join
             partners['error'] = e
@@ -616,11 +628,15 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     stride2 = stride
     if n2:
         # gather the bytes of those reads (a read that is undecided for several references is repeated)
-        arena2, off2 = _native.gather_reads(arena, offsets, bi)
         max_lj2 = int(lens[bi].max())
         stride2 = aligner.stride_for(max_lj2)
-        d_reads2 = torch.from_numpy(arena2 if arena2.size else np.zeros(1, dtype=np.uint8)).to(dev)
-        d_off2 = torch.from_numpy(off2.astype(np.int64)).to(dev)
+        if device_reads is not None:
+            from . import fastq_device
+            d_reads2, d_off2, _ = fastq_device.gather_reads_device(ctx, d_reads, d_off, bi, dev, stream)
+        else:
+            arena2, off2 = _native.gather_reads(arena, offsets, bi)
+            d_reads2 = torch.from_numpy(arena2 if arena2.size else np.zeros(1, dtype=np.uint8)).to(dev)
+            d_off2 = torch.from_numpy(off2.astype(np.int64)).to(dev)
         d_rid2 = torch.from_numpy(br.astype(np.int16)).to(dev)
         d_str2 = torch.ones(n2, dtype=torch.uint8, device=dev)
         a2 = torch.empty((n2, stride2), dtype=torch.uint8, device=dev)
@@ -676,7 +692,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if partners.get('device') is not None:
         partners['index'] = partners['device'].result()
         if partners['index'] is None:                                # (a hash collision among the reads: the host search decides)
-            partners['index'] = _native.rc_partners(arena, offsets)
+            partners['index'] = _native.rc_partners(host_arena(), offsets)
     if shard is None:
         _native.merge_counts_with_partners(aligned, partners['index'], cnt)
     else:
@@ -831,6 +847,25 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
         import torch.distributed as dist
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if stream and not sharded and not FORCE_HOST_STRAND_PLAN:
+        # plain text without filters: framed and de-duplicated on the device (fastq_device); anything it cannot take: the host parser
+        from . import fastq_device
+        why_not = fastq_device.applicable(path, flt)
+        if why_not is None:
+            import torch
+            try:
+                ing = fastq_device.ingest_file(path, ctx or _native.default_context(), torch.device("cuda", device), timings=timings)
+            except fastq_device.DeviceIngestUnavailable as e:
+                why_not = str(e)
+            else:
+                res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
+                                      pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=ing)
+                _native._line_stats(ingest_stats, ing["nonempty_lines"])
+                res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT']
+                res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats['N_READS_AFTER_PREPROCESSING']
+                res.ingest_route = "device"
+                return res
+        if timings is not None:
+            timings["host_parser_because"] = why_not
         fq = None
         try:
             fq = _native.FastqStream(path, *flt)

@@ -384,6 +384,34 @@ int c2_merge_counts_with_partners(uint64_t n, const uint8_t* aligned, const int6
  * only), their bytes: the second batch of the count route (reads aligned on both strands, CRISPRessoCORE.py:675-687). */
 int c2_gather_reads(const uint8_t* arena, const uint64_t* offsets, const int64_t* idx, uint64_t m, uint8_t* out_arena, uint64_t* out_offsets);
 
+/* ---- FASTQ framing and exact de-duplication ON THE DEVICE (the readline loop of process_fastq, CRISPRessoCORE.py:1825-1849, for text
+ * that is uploaded as it lies in the file; the host parser above is a quarter as fast on a 16-CPU host as the link delivers the text).
+ * Semantics = c2_fastq_stream's for text WITHOUT carriage returns (Python's text mode would translate them: flag bit 0 tells the host
+ * to use its own parser): records are four consecutive '\n'-terminated lines from the top, the second one str.strip()ped.
+ * All buffers are device memory owned by the caller; every call only enqueues on hip_stream.  The host-side driver is
+ * crispresso2_amd/fastq_device.py.
+ *   c2_fq_count_device  text [lo, hi) (lo a multiple of C2_FQ_TILE_BYTES = 16384; bytes [0, hi) resident) -> per tile of 16384 bytes: the
+ *                       number of '\n' and the number of '\n' that end an EMPTY line; flags |= 1 if a '\r' was seen.
+ *   c2_fq_lines_device  the same range again, with tile_base[t] = number of '\n' in the text in front of tile t (the caller's
+ *                       prefix sum): seq_start[r] = first byte of record r's sequence line (behind newline 4r), seq_end[r] = the
+ *                       newline that ends it (newline 4r + 1); entries for records >= n_records_cap are not written.
+ *   c2_fq_dedup_device  records [range[0], range[1]) (two uint64 in DEVICE memory): stripped sequence -> rinfo[r] = start << 24 |
+ *                       length; looked up in / inserted into the open-addressing table `slots` (n_slots a power of two, zeroed by the
+ *                       caller; `first` filled with 0xff): count[slot] += 1, first[slot] = min(first[slot], r), slot_of[r] = slot,
+ *                       *n_unique += new keys.  Equal means equal bytes (compared, not hashed).  flags |= 2: a line of 2^24 bytes or
+ *                       more / text beyond 2^40; |= 4: range beyond n_records_cap; |= 8: table more than half full.
+ *   c2_fq_gather_device out[out_offsets[i] ..) = the bytes info[records ? records[i] : i] names (start << 24 | length) in `text`. */
+#define C2_FQ_TILE_BYTES 16384
+int c2_fq_count_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, uint32_t* d_tile_newlines, uint32_t* d_tile_empty,
+                       uint32_t* d_flags, void* hip_stream);
+int c2_fq_lines_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, const uint64_t* d_tile_base, uint64_t* d_seq_start,
+                       uint64_t* d_seq_end, uint64_t n_records_cap, void* hip_stream);
+int c2_fq_dedup_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_seq_start, const uint64_t* d_seq_end, const uint64_t* d_range,
+                       uint64_t n_records_cap, uint64_t* d_slots, uint64_t n_slots, uint32_t* d_count, uint32_t* d_first,
+                       uint32_t* d_slot_of, uint64_t* d_rinfo, uint32_t* d_flags, uint32_t* d_n_unique, void* hip_stream);
+int c2_fq_gather_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_info, const int64_t* d_records, const int64_t* d_out_offsets,
+                        uint8_t* d_out, uint64_t n, void* hip_stream);
+
 /* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1 with and without bound_ctrl, also with a
  * lane switched off in EXEC, readlane, ballot) the DP depends on; writes 448 int32 (see c2_selftest_kernel).  Used by the
  * GPU test-suite. */

@@ -349,6 +349,41 @@ int emu_strand_plan(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     return 0;
 }
 
+// c2_fq_*_device on the emulator: same arguments, minus the context and the stream; `grid` of the grid-stride kernels is small
+int emu_fq_count(const uint8_t* text, uint64_t lo, uint64_t hi, uint32_t* tile_newlines, uint32_t* tile_empty, uint32_t* flags)
+{
+    if (hi <= lo) return 0;
+    c2_fq_frame_args A{};
+    A.text = text; A.lo = lo; A.hi = hi; A.tile_newlines = tile_newlines; A.tile_empty = tile_empty; A.flags = flags;
+    emu::launch((unsigned)((hi - lo + C2_FQ_TILE - 1) / C2_FQ_TILE), [&] { c2_fq_count_kernel(A); }, 256);
+    return 0;
+}
+int emu_fq_lines(const uint8_t* text, uint64_t lo, uint64_t hi, const uint64_t* tile_base, uint64_t* seq_start, uint64_t* seq_end, uint64_t cap)
+{
+    if (hi <= lo) return 0;
+    c2_fq_frame_args A{};
+    A.text = text; A.lo = lo; A.hi = hi; A.tile_base = tile_base; A.seq_start = seq_start; A.seq_end = seq_end; A.n_records_cap = cap;
+    emu::launch((unsigned)((hi - lo + C2_FQ_TILE - 1) / C2_FQ_TILE), [&] { c2_fq_lines_kernel(A); }, 256);
+    return 0;
+}
+int emu_fq_dedup(const uint8_t* text, const uint64_t* seq_start, const uint64_t* seq_end, const uint64_t* range, uint64_t cap, uint64_t* slots,
+                 uint64_t n_slots, uint32_t* count, uint32_t* first, uint32_t* slot_of, uint64_t* rinfo, uint32_t* flags, uint32_t* n_unique)
+{
+    c2_fq_dedup_args A{};
+    A.text = text; A.seq_start = seq_start; A.seq_end = seq_end; A.range = range; A.n_records_cap = cap; A.slots = (unsigned long long*)slots;
+    A.mask = n_slots - 1; A.count = count; A.first = first; A.slot_of = slot_of; A.rinfo = (unsigned long long*)rinfo; A.flags = flags; A.n_unique = n_unique;
+    emu::launch(3, [&] { c2_fq_dedup_kernel(A); }, 256);
+    return 0;
+}
+int emu_fq_gather(const uint8_t* text, const uint64_t* info, const int64_t* records, const int64_t* out_offsets, uint8_t* out, uint64_t n)
+{
+    if (!n) return 0;
+    c2_fq_gather_args A{};
+    A.text = text; A.info = (const unsigned long long*)info; A.records = records; A.out_offsets = out_offsets; A.out = out; A.n = n;
+    emu::launch(3, [&] { c2_fq_gather_kernel(A); }, 256);
+    return 0;
+}
+
 // The per-call C ABI on the emulator, argument for argument (the context handle is ignored): what
 // crispresso2_amd.CRISPResso2Align.global_align / CRISPRessoCOREResources.find_indels_substitutions[_legacy] call.
 // Host-side marshalling follows c2_api.hip (c2_global_align, c2_find_indels_substitutions).

@@ -1,0 +1,137 @@
+"""The device ingest (crispresso2_amd/fastq_device.py: c2_fq_count / lines / dedup / gather kernels) on the wave emulator, against the
+oracle's restatement of the reference's readline loop (oracle/fastq.py, CRISPRessoCORE.py:1825-1849) and against the host parser's line
+statistics: same unique reads, same first-seen order, same multiplicities, for well-formed text, blank lines, whitespace around the
+sequence, truncated tails, text without a final newline, text cut into several chunks and tiles."""
+import ctypes
+import contextlib
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import emu_driver as E
+from oracle import fastq as O
+from crispresso2_amd import fastq_device as FD, _native
+
+
+@contextlib.contextmanager
+def emulated_fq_kernels(chunk=FD.TILE):
+    V, U = ctypes.c_void_p, ctypes.c_uint64
+    lib = E.lib()
+
+    def count(ctx, d_text, lo, hi, nl, em, flags, stream):
+        assert lib.emu_fq_count(V(d_text), U(lo), U(hi), V(nl), V(em), V(flags)) == 0
+
+    def lines(ctx, d_text, lo, hi, base, s, e, cap, stream):
+        assert lib.emu_fq_lines(V(d_text), U(lo), U(hi), V(base), V(s), V(e), U(cap)) == 0
+
+    def dedup(ctx, d_text, s, e, rng, cap, slots, n_slots, cnt, first, slot_of, rinfo, flags, n_unique, stream):
+        assert lib.emu_fq_dedup(V(d_text), V(s), V(e), V(rng), U(cap), V(slots), U(n_slots), V(cnt), V(first), V(slot_of), V(rinfo), V(flags),
+                                V(n_unique)) == 0
+
+    def gather(ctx, d_text, info, records, out_off, out, n, stream):
+        assert lib.emu_fq_gather(V(d_text), V(info), V(records or 0), V(out_off), V(out), U(n)) == 0
+    saved = (FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES, torch.cuda.current_stream)
+
+    class _S:
+        cuda_stream = 0
+    FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES = count, lines, dedup, gather, chunk
+    torch.cuda.current_stream = lambda *a, **k: _S()
+    try:
+        yield
+    finally:
+        FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES, torch.cuda.current_stream = saved
+
+
+def device_unique(path, chunk=FD.TILE):
+    with emulated_fq_kernels(chunk):
+        out = FD.ingest_file(str(path), None, torch.device("cpu"))
+    arena, off = out["d_reads"].numpy(), out["offsets"]
+    reads = [arena[int(off[i]):int(off[i + 1])].tobytes().decode("latin-1") for i in range(out["n_unique"])]
+    return reads, out["counts"].tolist(), out
+
+
+def check(path, chunk=FD.TILE):
+    want, n_reads = O.read_fastq_unique(str(path))
+    reads, counts, out = device_unique(path, chunk)
+    n_empty = want.pop("", 0)
+    assert reads == list(want.keys())
+    assert counts == list(want.values())
+    assert out["n_reads"] == n_reads and out["n_empty_records"] == n_empty
+    st = {}
+    with _native.FastqStream(str(path)) as fq:
+        while not fq.done:
+            fq.next()
+        fq.line_stats(st)
+    assert int(float(out["nonempty_lines"]) / 4.0) == st["N_READS_AFTER_PREPROCESSING"]
+    return out
+
+
+def records(rng, n, length=40, pool=None):
+    pool = pool or ["".join(rng.choice("ACGTN") for _ in range(rng.randint(1, length))) for _ in range(max(2, n // 3))]
+    return "".join("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(rng.choice(pool) for _ in range(n)))
+
+
+def test_well_formed_text_over_several_tiles_and_chunks(tmp_path):
+    rng = random.Random(5)
+    p = tmp_path / "a.fastq"
+    p.write_text(records(rng, 1500))
+    assert os.path.getsize(p) > 4 * FD.TILE
+    out = check(p)
+    assert out["n_reads"] == 1500
+    check(p, chunk=2 * FD.TILE)
+    check(p, chunk=1 << 30)
+
+
+@pytest.mark.parametrize("tail", ["", "@x", "@x\n", "@x\nACGT", "@x\nACGT\n", "@x\nACGT\n+", "@x\nACGT\n+\n", "@x\nACGT\n+\nIIII", "\n", "\n\n",
+                                  "@x\n  ACGT \t\n+\nIIII\n", "@x\n\x0bAC GT\x1c\n+\nIIII\n\n\n@y\n\n"])
+def test_tails_and_blank_lines(tmp_path, tail):
+    rng = random.Random(9)
+    p = tmp_path / "b.fastq"
+    p.write_text(records(rng, 40, pool=["ACGT", "ACGTT", "GGGG"]) + tail)
+    check(p)
+
+
+def test_blank_lines_shift_the_records_as_in_the_reference(tmp_path):
+    # a blank line in the middle: every later "record" is four lines from there on, whatever they hold
+    p = tmp_path / "c.fastq"
+    p.write_text("@a\nAAAA\n+\nIIII\n\n@b\nCCCC\n+\nIIII\n@c\nGGGG\n+\nIIII\n" * 30)
+    check(p)
+
+
+def test_long_and_short_sequences_and_a_tile_boundary_inside_a_line(tmp_path):
+    rng = random.Random(2)
+    big = "".join(rng.choice("ACGT") for _ in range(3 * FD.TILE + 77))
+    p = tmp_path / "d.fastq"
+    p.write_text("@l\n%s\n+\n%s\n" % (big, "I" * len(big)) + records(rng, 30, length=5) + "@l2\n%s\n+\nI\n" % big + "@l3\n%sA\n+\nI\n" % big[:-1])
+    out = check(p)
+    assert out["max_len"] == len(big)
+
+
+def test_carriage_returns_go_to_the_host_parser(tmp_path):
+    p = tmp_path / "e.fastq"
+    p.write_text("@a\r\nAAAA\r\n+\r\nIIII\r\n" * 3)
+    with emulated_fq_kernels():
+        with pytest.raises(FD.DeviceIngestUnavailable):
+            FD.ingest_file(str(p), None, torch.device("cpu"))
+
+
+def test_more_records_than_estimated_goes_to_the_host_parser(tmp_path):
+    # the first MB has long lines, the rest short ones: the estimate of the table is too small, the kernels say so
+    p = tmp_path / "f.fastq"
+    p.write_text("@a\n%s\n+\n%s\n" % ("A" * 400000, "I" * 400000) * 2 + "@b\nC\n+\nI\n" * 60000)
+    with emulated_fq_kernels(1 << 30):
+        with pytest.raises(FD.DeviceIngestUnavailable):
+            FD.ingest_file(str(p), None, torch.device("cpu"))
+
+
+def test_applicable():
+    assert FD.applicable("/nonexistent.fastq") is not None
+    assert FD.applicable(__file__, (30, 0, 0)) == "quality filters run in the host parser"
+    assert FD.applicable(__file__) == "small file"

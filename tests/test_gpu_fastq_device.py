@@ -1,0 +1,90 @@
+"""The device ingest on the MI355X (c2_fq_count / lines / dedup / gather kernels through the C-ABI, driven by crispresso2_amd/fastq_device.py)
+against the host parser (c2_fastq_stream, itself checked against the oracle's readline loop in the CPU suite): same unique reads in the
+same order with the same multiplicities and line statistics -- many chunks, many workgroups racing for the same table slots -- and the
+same run (statistics, count tensors, allele rows) from pipeline.quantify_fastq whichever route framed the file."""
+import os
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_unique(path):
+    from crispresso2_amd import _native
+    st = {}
+    with _native.FastqStream(str(path)) as fq:
+        while not fq.done:
+            fq.next()
+        n = fq.n_unique
+        off = fq.offsets_slice(0, n).astype(np.int64)
+        arena = np.array(fq.arena[:int(off[-1])], copy=True)
+        counts = fq.counts().astype(np.int64)
+        fq.line_stats(st)
+        n_reads = fq.n_reads
+    return arena, off, counts, st, n_reads
+
+
+def _write(path, n, L, rng, n_pool, tail=""):
+    pool = ["".join(rng.choice("ACGT") for _ in range(rng.randint(L // 2, L))) for _ in range(n_pool)]
+    pool[7] = "  " + pool[7] + "\t"                                   # (whitespace the reference strips; equals no other read)
+    pool[9] = pool[8]
+    with open(path, "w") as fh:
+        for i in range(n):
+            s = pool[min(int(rng.expovariate(1.0 / (n_pool / 6.0))), n_pool - 1)]
+            fh.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+        fh.write(tail)
+
+
+@pytest.mark.parametrize("tail", ["", "@cut\nACGTACGT", "@id_only\n", "\n\n@x\nAC\n+\n"])
+def test_device_ingest_equals_the_host_parser(tmp_path, monkeypatch, tail):
+    import torch
+    from crispresso2_amd import fastq_device as FD, _native
+    rng = random.Random(len(tail) + 3)
+    p = tmp_path / "t.fastq"
+    _write(p, 300_000, 120, rng, 40_000, tail)
+    monkeypatch.setattr(FD, "CHUNK_BYTES", 1 << 20)                    # ~80 chunks
+    ctx = _native.default_context()
+    out = FD.ingest_file(str(p), ctx, torch.device("cuda", 0))
+    arena, off, counts, st, n_reads = _host_unique(p)
+    lens = off[1:] - off[:-1]
+    keep = lens > 0
+    assert out["n_reads"] == n_reads
+    assert int(float(out["nonempty_lines"]) / 4.0) == st["N_READS_AFTER_PREPROCESSING"]
+    assert out["n_empty_records"] == int(counts[~keep].sum())
+    assert out["n_unique"] == int(keep.sum())
+    assert np.array_equal(out["counts"], counts[keep])
+    assert np.array_equal(np.diff(out["offsets"].astype(np.int64)), lens[keep])
+    want = np.concatenate([arena[off[i]:off[i + 1]] for i in np.nonzero(keep)[0]]) if keep.any() else np.zeros(0, np.uint8)
+    assert np.array_equal(out["d_reads"][:int(out["offsets"][-1])].cpu().numpy(), want)
+    assert int(counts.sum()) == n_reads
+
+
+def test_whole_run_is_the_same_on_either_route(tmp_path, monkeypatch):
+    from crispresso2_amd import pipeline, synth, refs as RF, fastq_device as FD
+    from helpers import matrices
+    L = 150
+    amp, g_, inc = synth.amplicon_setup(L)
+    reads = synth.make_reads(L, 60_000)
+    seqs = [r.tobytes().decode() for r in reads]
+    seqs = seqs + [RF.reverse_complement(s_) for s_ in seqs[:5000]] + seqs[:20_000] + ["ACGT" * 30, "TTTTGGGGCCCC" * 9] * 3
+    fq = tmp_path / "run.fastq"
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (k, s_, "I" * len(s_)) for k, s_ in enumerate(seqs)) + "@id_only\n")
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
+    args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                           ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
+                           assign_ambiguous_alignments_to_first_reference=False, expand_ambiguous_alignments=False, discard_indel_reads=False)
+    monkeypatch.setattr(FD, "CHUNK_BYTES", 4 << 20)
+    results = []
+    for route in ("host", "device"):
+        monkeypatch.setenv("C2_FQ_INGEST", route)
+        res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], args)
+        assert (getattr(res, "ingest_route", None) == "device") == (route == "device")
+        results.append((res.stats, res.per_ref["Reference"], res.alleles()))
+    (st0, pr0, al0), (st1, pr1, al1) = results
+    assert st0 == st1 and al0 == al1
+    assert st0["N_TOT_READS"] == len(seqs)
+    for kk, vv in pr0.items():
+        assert np.array_equal(vv, pr1[kk]) if isinstance(vv, np.ndarray) else vv == pr1[kk], kk

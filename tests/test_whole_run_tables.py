@@ -763,3 +763,66 @@ def test_partner_search_on_the_device_gives_the_same_run(tmp_path, monkeypatch):
         assert st == st0 and al == al0
         for kk, vv in pr0.items():
             assert np.array_equal(vv, pr[kk]) if isinstance(vv, np.ndarray) else vv == pr[kk], kk
+
+
+def test_device_ingest_gives_the_same_files(tmp_path, monkeypatch):
+    """pipeline.quantify_fastq with the text framed and de-duplicated by the c2_fq_* kernels (fastq_device; chunks of one tile) instead
+    of the host parser: the 18 files of the reference's FANC.Cas9 run, and every statistic, tensor and allele row of the host-parser
+    flow.  The file carries a record cut short after its id line (the empty sequence: dropped by both)."""
+    from pipeline_on_emulator import emulated_device
+    from test_fastq_device_emulated import emulated_fq_kernels
+    from crispresso2_amd import pipeline, tables, refs as RF
+    g = _golden()
+    fq = tmp_path / "FANC.Cas9.fastq"
+    fq.write_text(g["fastq"] + "@trailing_id_only\n")
+    cut = g["cut_point"]
+    ref = RF.make_ref("Reference", g["amplicon"], [cut], [cut, cut + 1], min_aln_score=60)
+    ref["sgRNA_orig_sequences"] = [g["guide"]]
+    with emulated_device(), emulated_fq_kernels():
+        monkeypatch.setenv("C2_FQ_INGEST", "device")
+        tm = {}
+        res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(), timings=tm)
+        assert getattr(res, "ingest_route", None) == "device" and "host_parser_because" not in tm
+        monkeypatch.setenv("C2_FQ_INGEST", "host")
+        tm = {}
+        other = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(), timings=tm)
+        assert tm["host_parser_because"] == "C2_FQ_INGEST=host" and "ingest_dedup_streamed" in tm
+        assert other.stats == res.stats
+        for kk, vv in res.per_ref["Reference"].items():
+            ww = other.per_ref["Reference"][kk]
+            assert np.array_equal(vv, ww) if isinstance(vv, np.ndarray) else vv == ww, kk
+        assert res.alleles() == other.alleles()
+        res.stats["N_READS_INPUT"] = res.stats["N_READS_AFTER_PREPROCESSING"] = 250       # (the extra id line is not part of the reference's run)
+        out = tmp_path / "out"
+        names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
+    assert _compare(g, names, str(out)) == 18
+
+
+def test_device_ingest_with_both_strand_reads_and_partners(tmp_path, monkeypatch):
+    """reads whose seeds leave the strand open (aligned on both: the second batch is gathered ON the device from the device arena)
+    and reverse-complement partners (device search): device ingest = host parser"""
+    from pipeline_on_emulator import emulated_device
+    from test_fastq_device_emulated import emulated_fq_kernels
+    from crispresso2_amd import pipeline, synth, refs as RF
+    L = 150
+    amp, g_, inc = synth.amplicon_setup(L)
+    reads = synth.make_reads(L, 60)
+    seqs = [r.tobytes().decode() for r in reads]
+    seqs = seqs + [RF.reverse_complement(s_) for s_ in seqs[:15]] + seqs[:10] + ["ACGT" * 30, "TTTTGGGGCCCC" * 9]      # (the last two: no seed hits)
+    fq = tmp_path / "rc.fastq"
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (k, s_, "I" * len(s_)) for k, s_ in enumerate(seqs)))
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
+    results = []
+    with emulated_device(), emulated_fq_kernels():
+        for route, dev_min in (("host", 10**9), ("device", 10**9), ("device", 1)):
+            monkeypatch.setenv("C2_FQ_INGEST", route)
+            monkeypatch.setattr(pipeline, "RC_PARTNERS_ON_DEVICE_MIN", dev_min)
+            res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args())
+            assert (getattr(res, "ingest_route", None) == "device") == (route == "device")
+            results.append((res.stats, res.per_ref["Reference"], res.alleles(), res._state["slot2"]))
+    st0, pr0, al0, slot2 = results[0]
+    assert (slot2 >= 0).sum() >= 2                                   # (the second batch ran)
+    for st, pr, al, _ in results[1:]:
+        assert st == st0 and al == al0
+        for kk, vv in pr0.items():
+            assert np.array_equal(vv, pr[kk]) if isinstance(vv, np.ndarray) else vv == pr[kk], kk

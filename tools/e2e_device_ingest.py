@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Round 3 measurement: FASTQ -> count tensors with the file framed and de-duplicated on the device (crispresso2_amd/fastq_device.py)
+against the host parser, on a 10 M-read synthetic file in /dev/shm; chunk sizes of the upload; the stages of the device route.
+python tools/e2e_device_ingest.py [--reads N] [--chunks 16,64,256]"""
+import argparse, json, os, sys, tempfile, time
+from types import SimpleNamespace
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=10_000_000)
+ap.add_argument("--chunks", default="16,64,256")
+a = ap.parse_args()
+import torch
+from crispresso2_amd import synth, _native, pipeline, refs as R, CRISPResso2Align as A, fastq_device as FD
+L = 250
+reads = synth.make_reads(L, a.reads, workers=32)
+d = tempfile.mkdtemp(prefix="c2di_", dir="/dev/shm")
+p = os.path.join(d, "r.fastq")
+synth.write_fastq(reads, p)
+del reads
+amp, g, inc = synth.amplicon_setup(L)
+args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                       ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
+                       assign_ambiguous_alignments_to_first_reference=False, expand_ambiguous_alignments=False, discard_indel_reads=False)
+ref = R.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
+m = A.read_matrix(os.path.join(ROOT, "crispresso2_amd", "EDNAFULL"))
+ctx = _native.default_context()
+dev = torch.device("cuda", 0)
+tallies = {}
+try:
+    for chunk_mb in [int(x) for x in a.chunks.split(",")]:
+        FD.CHUNK_BYTES = chunk_mb << 20
+        # the ingest alone
+        best = None
+        for rep in range(4):
+            torch.cuda.synchronize()
+            tm = {}
+            t0 = time.perf_counter()
+            out = FD.ingest_file(p, ctx, dev, timings=tm)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if rep and (best is None or dt < best[0]):
+                best = (dt, dict(tm), out["n_unique"], out["n_reads"])
+            del out
+        print(json.dumps({"device_ingest_only": {"chunk_mb": chunk_mb, "seconds": round(best[0], 4), "reads_per_s": round(a.reads / best[0]),
+                                                  "stages": {k: round(v, 4) for k, v in best[1].items()}, "unique": best[2], "records": best[3]}}), flush=True)
+    for route, chunk_mb in [("device", 64), ("device", 16), ("device", 256), ("host", 0)]:
+        os.environ["C2_FQ_INGEST"] = route
+        if chunk_mb:
+            FD.CHUNK_BYTES = chunk_mb << 20
+        runs = []
+        for rep in range(4):
+            tm = {} if rep == 3 else None
+            t0 = time.perf_counter()
+            res = pipeline.quantify_fastq(p, {"Reference": ref}, ["Reference"], m, args, ctx=ctx, timings=tm)
+            runs.append((time.perf_counter() - t0, tm))
+            c = res.per_ref["Reference"]
+            tallies[(route, chunk_mb)] = (res.stats["N_TOT_READS"], res.stats["N_TOTAL"], c["counts_total"], c["counts_modified"], c["counts_insertion"],
+                                          c["counts_deletion"], c["counts_substitution"], res.stats["N_READS_INPUT"])
+            assert getattr(res, "ingest_route", "host") == route
+            del res
+            time.sleep(0.3)
+        dt = min(r[0] for r in runs[1:3])
+        print(json.dumps({"e2e": {"route": route, "chunk_mb": chunk_mb, "seconds": round(dt, 4), "reads_per_s": round(a.reads / dt),
+                                  "all_runs": [round(r[0], 4) for r in runs],
+                                  "stages_of_an_instrumented_run": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in runs[-1][1].items()}}}), flush=True)
+    print(json.dumps({"same_tallies_on_every_route": len(set(tallies.values())) == 1, "tallies": list(tallies.values())[0]}))
+finally:
+    os.remove(p)
+    os.rmdir(d)
