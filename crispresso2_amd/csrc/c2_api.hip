@@ -93,6 +93,7 @@ struct c2_ctx {
     DevBuf d_cnt;          // count kernel: work counter + min_matches table
     DevBuf d_sel;          // selection kernel: per-reference score thresholds
     DevBuf d_seeds;        // strand-plan kernel: seed bytes and tables
+    std::vector<uint8_t> seeds_host;   // ... and what they hold (the staging block of the last c2_strand_plan_device call)
     ncclComm_t comm = nullptr; // RCCL communicator of c2_comm_init (one rank per GPU)
     int comm_world = 0;
     std::vector<uint32_t> sel_table;
@@ -1599,10 +1600,15 @@ int c2_strand_plan_device(c2_ctx* ctx, uint64_t n_reads, const uint8_t* d_reads,
     if (blob_bytes) memcpy(host.data(), h_seed_blob, (size_t)blob_bytes);
     if (max_seeds) { memcpy(host.data() + o_off, h_seed_off, tbl * 4); memcpy(host.data() + o_len, h_seed_len, tbl * 4); memcpy(host.data() + o_n, h_n_seeds, (size_t)n_refs * 4); }
     int rc;
-    if (total > ctx->d_seeds.cap) HIPCHK(ctx, hipDeviceSynchronize());          // (an earlier launch may still read the old block)
-    if ((rc = ensure(ctx, ctx->d_seeds, total))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_seeds.p, host.data(), total, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));                                         // `host` is pageable memory owned by this call
+    if (!(ctx->seeds_host.size() == total && memcmp(ctx->seeds_host.data(), host.data(), total) == 0)) {
+        // (the same seeds as last time -- every batch of a streamed run -- are on the device already: no upload, and no wait on the stream)
+        HIPCHK(ctx, hipDeviceSynchronize());                                      // an earlier launch may still read the old block
+        ctx->seeds_host.clear();
+        if ((rc = ensure(ctx, ctx->d_seeds, total))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_seeds.p, host.data(), total, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));                                     // `host` is pageable memory owned by this call
+        ctx->seeds_host = host;
+    }
     c2_strand_args A;
     const uint8_t* base = (const uint8_t*)ctx->d_seeds.p;
     A.reads = d_reads; A.offsets = d_offsets; A.n_reads = n_reads; A.seed_blob = base;
@@ -1647,14 +1653,14 @@ int c2_fq_lines_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t
 
 int c2_fq_dedup_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_seq_start, const uint64_t* d_seq_end, const uint64_t* d_range,
                        uint64_t n_records_cap, uint64_t* d_slots, uint64_t n_slots, uint32_t* d_count, uint32_t* d_first,
-                       uint32_t* d_slot_of, uint64_t* d_rinfo, uint32_t* d_flags, uint32_t* d_n_unique, void* hip_stream) {
+                       uint32_t* d_slot_of, uint64_t* d_rinfo, uint32_t* d_flags, uint32_t* d_stats, void* hip_stream) {
     if (!ctx || !d_text || !d_seq_start || !d_seq_end || !d_range || !d_slots || !d_count || !d_first || !d_slot_of || !d_rinfo || !d_flags ||
-        !d_n_unique || n_slots < 2 || (n_slots & (n_slots - 1)) || n_slots > 0xffffffffull) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
+        !d_stats || n_slots < 2 || (n_slots & (n_slots - 1)) || n_slots > 0xffffffffull) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     c2_fq_dedup_args A{};
     A.text = d_text; A.seq_start = d_seq_start; A.seq_end = d_seq_end; A.range = d_range; A.n_records_cap = n_records_cap;
     A.slots = (unsigned long long*)d_slots; A.mask = n_slots - 1; A.count = d_count; A.first = d_first; A.slot_of = d_slot_of;
-    A.rinfo = (unsigned long long*)d_rinfo; A.flags = d_flags; A.n_unique = d_n_unique;
+    A.rinfo = (unsigned long long*)d_rinfo; A.flags = d_flags; A.stats = d_stats;
     // grid-stride over the records (how many is only known on the device): enough wavefronts to cover the latency of the table probes
     hipLaunchKernelGGL(c2_fq_dedup_kernel, dim3((unsigned)ctx->prop.multiProcessorCount * 16u), dim3(256), 0, (hipStream_t)hip_stream, A);
     HIPCHK(ctx, hipGetLastError());

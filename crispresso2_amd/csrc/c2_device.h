@@ -183,7 +183,7 @@ struct c2_fq_dedup_args {
     unsigned long long* rinfo;        // per record: (stripped start << 24 | length)
     uint32_t* flags;                  // bit 1: a sequence line of 2^24 bytes or more, or a text position beyond 2^40; bit 2: more records than
                                       // the arrays hold; bit 3: the table is more than half full (the host falls back on any of them)
-    uint32_t* n_unique;               // += keys created by this launch
+    uint32_t* stats;                  // [0] += keys created by this launch, [1] = max(., their lengths), [2] += 1 for the empty key
 };
 // out[out_offsets[i] ..] = the bytes info[records ? records[i] : i] names (start << 24 | length)
 struct c2_fq_gather_args {

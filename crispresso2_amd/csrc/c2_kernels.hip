@@ -3137,7 +3137,12 @@ __global__ __launch_bounds__(256) void c2_fq_dedup_kernel(c2_fq_dedup_args A)
                     atomicAdd(A.count + p, 1u);
                     atomicMin(A.first + p, (unsigned)r);
                     A.slot_of[r] = (uint32_t)p;
-                    if (created) { const unsigned u = atomicAdd(A.n_unique, 1u); if (2ull * (u + 1ull) > A.mask + 1ull) atomicOr(A.flags, 8u); }
+                    if (created) {
+                        const unsigned u = atomicAdd(A.stats, 1u);
+                        if (2ull * (u + 1ull) > A.mask + 1ull) atomicOr(A.flags, 8u);
+                        atomicMax(A.stats + 1, (unsigned)len);
+                        if (len == 0) atomicAdd(A.stats + 2, 1u);
+                    }
                 }
                 break;
             }

@@ -113,10 +113,15 @@ def applicable(path, filters=(0, 0, 0)):
 
 
 class DeviceIngest:
-    """feed(lo, hi) after bytes [lo, hi) of the text are in d_text (in order, lo a multiple of TILE except that the last chunk may end
-    anywhere); finish() -> the unique reads.  All work is enqueued on torch's current stream of `dev`."""
+    """feed(lo, hi) after bytes [lo, hi) of the text are in d_text (in order, lo a multiple of TILE; the last chunk may end anywhere);
+    finish() once everything was fed.  All work is enqueued on torch's current stream of `dev`; nothing waits for the device before
+    finish() except poll(), which only waits for chunks fed `lag` chunks ago.
+    Batches: take_batch(r1, m, max_len) hands out the m unique non-empty reads whose FIRST occurrence is a record in
+    [records handed out so far, r1) -- final as soon as those records are de-duplicated, because later records have larger numbers --
+    so the caller can align them while later chunks are still being uploaded."""
 
     def __init__(self, ctx, dev, text_bytes, est_records, d_text=None):
+        import collections
         import torch
         self.ctx, self.dev, self.T = ctx, dev, int(text_bytes)
         self.cap = int(est_records)
@@ -138,11 +143,17 @@ class DeviceIngest:
         self.count = torch.zeros(n_slots, dtype=i32, device=dev)
         self.first = torch.full((n_slots,), -1, dtype=i32, device=dev)              # 0xffffffff
         self.flags = torch.zeros(1, dtype=i32, device=dev)
-        self.n_unique = torch.zeros(1, dtype=i32, device=dev)
+        self.stats = torch.zeros(4, dtype=i32, device=dev)                          # keys, longest key, empty keys (c2_fq_dedup_args.stats)
         self.newlines = torch.zeros(1, dtype=i64, device=dev)                       # in the text so far
         self.empty_lines = torch.zeros(1, dtype=i64, device=dev)
         self.range = torch.zeros(2, dtype=i64, device=dev)                          # records de-duplicated so far: [., range[1])
         self.fed = 0
+        self.batch_r0 = 0                                                           # records below this were handed out in batches
+        self.batch_u0 = 0                                                           # ... and so many unique non-empty reads
+        self.batches = []                                                           # (rec, d_off) of every batch handed out
+        self._snaps = collections.deque()
+        self._ring = None
+        self._ring_at = 0
 
     def _stream(self):
         import torch
@@ -150,10 +161,10 @@ class DeviceIngest:
 
     def _dedup_to(self, r1):
         import torch
-        self.range = torch.cat([self.range[1:2], r1.reshape(1)])                    # (a new tensor: the launch before may still read the old one)
+        self.range = torch.cat([self.range[1:2], r1.reshape(1)])
         fq_dedup(self.ctx, self.d_text.data_ptr(), self.seq_start.data_ptr(), self.seq_end.data_ptr(), self.range.data_ptr(), self.cap,
                  self.slots.data_ptr(), self.n_slots, self.count.data_ptr(), self.first.data_ptr(), self.slot_of.data_ptr(), self.rinfo.data_ptr(),
-                 self.flags.data_ptr(), self.n_unique.data_ptr(), self._stream())
+                 self.flags.data_ptr(), self.stats.data_ptr(), self._stream())
 
     def feed(self, lo, hi):
         import torch
@@ -173,45 +184,106 @@ class DeviceIngest:
         self.empty_lines = self.empty_lines + tile_em.sum(dtype=torch.int64).reshape(1)
         # a record is complete once the newline behind its sequence line (number 4 r + 1) was seen
         self._dedup_to((self.newlines + 2) // 4)
-        self._keep = (tile_nl, tile_em, base)                                       # (alive until the next launch is enqueued behind them)
 
-    def finish(self, unterminated):
-        """unterminated: the text does not end with a newline (its last line still counts).  -> dict(d_reads, d_off, offsets, counts,
-        n_reads, nonempty_lines, n_unique); waits for the device."""
+    # ---- what the host may know without waiting ----
+    def mark(self):
+        """after feed(): (records de-duplicated, keys, longest key, empty keys, flags) as of this chunk start their way to the host"""
         import torch
-        if self.fed != self.T:
-            raise ValueError("%d of %d bytes were fed" % (self.fed, self.T))
-        dev = self.dev
-        lines = self.newlines + (1 if unterminated else 0)
-        self._dedup_to((lines + 3) // 4)                                            # readline() loop: every started group of four lines is a record
-        n_records = int(self.range[1].item())
-        flags = int(self.flags.item())
+        vals = torch.cat([self.range[1:2], self.stats[:3].to(torch.int64), self.flags.to(torch.int64)])
+        if self.dev.type != "cuda":
+            self._snaps.append((None, vals.clone()))
+            return
+        if self._ring is None:
+            self._ring = torch.empty((64, 5), dtype=torch.int64, pin_memory=True)
+        if len(self._snaps) >= 60:
+            self._snaps.popleft()[0].synchronize()
+        row = self._ring[self._ring_at % 64]
+        self._ring_at += 1
+        row.copy_(vals, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._snaps.append((ev, row))
+
+    def poll(self, lag=2):
+        """-> the newest (records, unique non-empty reads, longest) that reached the host, or None; waits only for marks older than `lag`"""
+        got = None
+        while self._snaps and (len(self._snaps) > lag or self._snaps[0][0] is None or self._snaps[0][0].query()):
+            ev, row = self._snaps.popleft()
+            if ev is not None:
+                ev.synchronize()
+            got = [int(x) for x in row.tolist()]
+        if got is None:
+            return None
+        r1, keys, longest, empty_keys, flags = got
+        self._check(flags, r1)
+        return r1, keys - empty_keys, longest
+
+    def _check(self, flags, r1):
         if flags & 1:
             raise DeviceIngestUnavailable("carriage returns in the text")
         if flags & ~1:
             raise DeviceIngestUnavailable("device ingest gave up (flags %d: 2 = line too long, 4 = more records than estimated, 8 = table too full)" % flags)
-        nonempty = int(lines.item()) - int(self.empty_lines.item())
-        slot_of = self.slot_of[:n_records].to(torch.int64)
-        is_first = self.first[slot_of].to(torch.int64) == torch.arange(n_records, dtype=torch.int64, device=dev)
-        rec = torch.nonzero(is_first).reshape(-1)                                   # first occurrences, in file order = first-seen order
-        info = self.rinfo[rec]
-        lens = info & 0xffffff
-        keep = lens > 0                                                             # (the empty key, if any, is not a read: quantify_fastq drops it)
-        n_empty = 0
-        if not bool(keep.all().item()):
-            drop = rec[~keep]
-            n_empty = int(self.count[self.slot_of[drop].to(torch.int64)].sum().item())
-            rec, lens = rec[keep], lens[keep]
-        n = int(rec.numel())
-        d_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        if r1 > self.cap:
+            raise DeviceIngestUnavailable("more records than estimated")
+
+    def take_batch(self, r1, m, max_len):
+        """-> (d_reads uint8 [m * max_len reserved], d_off int64 [m + 1]) of the m unique non-empty reads first seen in records [batch_r0, r1)"""
+        import torch
+        dev, ra = self.dev, self.batch_r0
+        idx = torch.arange(ra, r1, dtype=torch.int64, device=dev)
+        slot = self.slot_of[ra:r1].to(torch.int64)
+        info = self.rinfo[ra:r1]
+        mask = (self.first[slot].to(torch.int64) == idx) & ((info & 0xffffff) > 0)
+        dest = torch.where(mask, torch.cumsum(mask, 0) - 1, m).clamp_(max=m)
+        rec = torch.empty(m + 1, dtype=torch.int64, device=dev).scatter_(0, dest, idx)[:m]     # first occurrences, in file order
+        lens = self.rinfo[rec] & 0xffffff
+        d_off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
         torch.cumsum(lens, 0, out=d_off[1:])
-        total = int(d_off[-1].item())
-        d_reads = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
-        fq_gather(self.ctx, self.d_text.data_ptr(), self.rinfo.data_ptr(), rec.data_ptr(), d_off.data_ptr(), d_reads.data_ptr(), n, self._stream())
-        counts = self.count[self.slot_of[rec].to(torch.int64)].to(torch.int64)
-        out = dict(d_reads=d_reads, d_off=d_off, offsets=d_off.cpu().numpy().astype(np.uint64), counts=counts.cpu().numpy(),
-                   n_reads=n_records, n_empty_records=n_empty, nonempty_lines=nonempty, n_unique=n, max_len=int(lens.max().item()) if n else 0,
-                   min_len=int(lens.min().item()) if n else 0)
+        d_reads = torch.empty(max(m * max_len, 1), dtype=torch.uint8, device=dev)
+        fq_gather(self.ctx, self.d_text.data_ptr(), self.rinfo.data_ptr(), rec.data_ptr(), d_off.data_ptr(), d_reads.data_ptr(), m, self._stream())
+        self.batch_r0, self.batch_u0 = r1, self.batch_u0 + m
+        self.batches.append((rec, d_off))
+        return d_reads, d_off
+
+    def finish(self, unterminated, on_batch=None):
+        """unterminated: the text does not end with a newline (its last line still counts).  Hands out the last batch (everything, if
+        none was taken before) and -> dict(offsets, counts, n_reads, nonempty_lines, n_unique, max_len, min_len, ...); waits for the device.
+        on_batch(m, d_reads, d_off, max_len): called for the last batch, as the caller did for the earlier ones."""
+        import torch
+        if self.fed != self.T:
+            raise ValueError("%d of %d bytes were fed" % (self.fed, self.T))
+        lines = self.newlines + (1 if unterminated else 0)
+        self._dedup_to((lines + 3) // 4)                                            # readline() loop: every started group of four lines is a record
+        self._snaps.clear()
+        n_records, keys, longest, empty_keys, flags = [int(x) for x in torch.cat([self.range[1:2], self.stats[:3].to(torch.int64),
+                                                                               self.flags.to(torch.int64)]).tolist()]
+        self._check(flags, n_records)
+        nonempty = int(lines.item()) - int(self.empty_lines.item())
+        m = keys - empty_keys - self.batch_u0
+        last = None
+        if m > 0:
+            last = self.take_batch(n_records, m, longest)
+            if on_batch is not None:
+                on_batch(m, last[0], last[1], longest)
+        n = self.batch_u0
+        n_empty = 0
+        if empty_keys:
+            first_empty = torch.nonzero((self.rinfo[:n_records] & 0xffffff) == 0)[:1].reshape(-1)
+            n_empty = int(self.count[self.slot_of[first_empty].to(torch.int64)].sum().item())
+        if self.batches:
+            rec = torch.cat([b[0] for b in self.batches])
+            lens = torch.cat([b[1][1:] - b[1][:-1] for b in self.batches])
+            counts = self.count[self.slot_of[rec].to(torch.int64)].to(torch.int64).cpu().numpy()
+            lens_h = lens.cpu().numpy()
+        else:
+            counts, lens_h = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(lens_h, out=offsets[1:])
+        out = dict(offsets=offsets, counts=counts, n_reads=n_records, n_empty_records=n_empty, nonempty_lines=nonempty, n_unique=n,
+                   max_len=int(lens_h.max()) if n else 0, min_len=int(lens_h.min()) if n else 0,
+                   batch_bytes=[int(b[1][-1].item()) for b in self.batches])
+        if last is not None and len(self.batches) == 1:
+            out["d_reads"], out["d_off"] = last
         return out
 
 
@@ -224,9 +296,12 @@ def estimate_records(path, size):
     return int(size * per_byte / 4.0 * 1.25) + 4096
 
 
-def ingest_file(path, ctx, dev, timings=None):
+def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
     """the whole file -> DeviceIngest.finish()'s dict.  Host threads copy the text into two pinned buffers in turn; every chunk is framed
-    and de-duplicated on the compute stream while the next one is copied and uploaded."""
+    and de-duplicated on the compute stream while the next one is copied and uploaded.
+    on_batch(m, d_reads, d_off, max_len): called (on this thread, with the compute stream current) whenever min_batch new unique reads
+    are final, and for the rest at the end -- the caller enqueues their alignments behind the de-duplication, under the upload.
+    Without it the result carries one batch: d_reads / d_off of all unique reads."""
     import time
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -235,6 +310,18 @@ def ingest_file(path, ctx, dev, timings=None):
     on_gpu = dev.type == "cuda"
     ing = DeviceIngest(ctx, dev, size, estimate_records(path, size))
     chunk = max(TILE, CHUNK_BYTES // TILE * TILE)
+
+    def after_feed():
+        if on_batch is None:
+            return
+        ing.mark()
+        snap = ing.poll()
+        if snap is not None:
+            r1, uniq, longest = snap
+            if uniq - ing.batch_u0 >= min_batch and r1 > ing.batch_r0:
+                m = uniq - ing.batch_u0
+                d_reads, d_off = ing.take_batch(r1, m, longest)
+                on_batch(m, d_reads, d_off, longest)
     fd = os.open(path, os.O_RDONLY)
     try:
         last = os.pread(fd, 1, size - 1)
@@ -246,7 +333,8 @@ def ingest_file(path, ctx, dev, timings=None):
                 if got != hi - lo:
                     raise OSError("short read")
                 ing.feed(lo, hi)
-            return ing.finish(last != b"\n")
+                after_feed()
+            return ing.finish(last != b"\n", on_batch)
         threads = min(16, usable_cpus())
         key = (chunk, dev.index)
         if key not in _pinned:
@@ -279,9 +367,10 @@ def ingest_file(path, ctx, dev, timings=None):
                     evs[k].record(copy_stream)
                 compute.wait_event(evs[k])
                 ing.feed(lo, hi)
+                after_feed()
         if timings is not None:
             timings["upload_text"] = time.perf_counter() - t0
-        out = ing.finish(last != b"\n")
+        out = ing.finish(last != b"\n", on_batch)
         if timings is not None:
             timings["device_dedup_tail"] = time.perf_counter() - t0 - timings["upload_text"]
         return out

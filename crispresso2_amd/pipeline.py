@@ -16,6 +16,8 @@ Per read 17 bytes come back to the host (two 64-bit masks and a flag byte); reco
 count kernel (QuantResult.alleles() fetches the rows it prints).  The per-read
 dict path (variants.get_new_variant_objects) remains for callers that need the reference's per-read payloads.
 """
+import os
+
 import numpy as np
 
 from . import _native
@@ -252,6 +254,75 @@ def rc_partners_device(d_reads2d):
 STREAM_MIN_BATCH = 200_000          # unique reads: smaller arrivals wait for the next chunk (a launch chain per chunk is not free)
 
 
+def _enqueue_first_batch(aligner, ctx, dev, refs, ref_names, args, legacy, m, d_reads, d_off, max_lj, stream):
+    """m reads that are on the device (arena + int64 offsets): the seed test (c2_strand_plan_kernel) and their alignments against every
+    reference on the strand it asks for, enqueued on `stream` -> (aligned reads, aligned refs, records, plan, stride, reads, offsets, strands)"""
+    import torch
+    k = len(ref_names)
+    d_plan = torch.empty(m * k, dtype=torch.uint8, device=dev)
+    C.strand_plan_device(ctx, m, d_reads.data_ptr(), d_off.data_ptr(), max_lj, refs, ref_names, args.aln_seed_count, args.aln_seed_min,
+                         d_plan.data_ptr(), stream=stream)
+    d_str = (d_plan == 1).to(torch.uint8)
+    stride = aligner.stride_for(max_lj)
+    a = torch.empty((m * k, stride), dtype=torch.uint8, device=dev)
+    f = torch.empty((m * k, stride), dtype=torch.uint8, device=dev)
+    r = torch.empty((m * k, 32), dtype=torch.uint8, device=dev)
+    aligner.align_device(m, d_reads.data_ptr(), d_off.data_ptr(), a.data_ptr(), f.data_ptr(), r.data_ptr(), stride, max_lj,
+                         d_strands=d_str.data_ptr(), all_refs=True, stream=stream, legacy=legacy)
+    return (a, f, r, d_plan, stride, d_reads, d_off, d_str)
+
+
+def _join_first_batches(parts, aligner, dev):
+    """the batches' outputs as one (rows of narrower batches padded to the widest stride) -> a1, f1, r1, d_plan, stride"""
+    import torch
+    stride = max([p_[4] for p_ in parts], default=aligner.stride_for(1))
+
+    def widen(x, st):
+        return x if st == stride else torch.nn.functional.pad(x, (0, stride - st))
+    if len(parts) == 1:
+        return parts[0][0], parts[0][1], parts[0][2], parts[0][3], stride
+    if parts:
+        return (torch.cat([widen(p_[0], p_[4]) for p_ in parts]), torch.cat([widen(p_[1], p_[4]) for p_ in parts]),
+                torch.cat([p_[2] for p_ in parts]), torch.cat([p_[3] for p_ in parts]), stride)
+    return (torch.empty((0, stride), dtype=torch.uint8, device=dev), torch.empty((0, stride), dtype=torch.uint8, device=dev),
+            torch.empty((0, 32), dtype=torch.uint8, device=dev), torch.empty(0, dtype=torch.uint8, device=dev), stride)
+
+
+def _device_front(path, aligner, ctx, dev, refs, ref_names, args, legacy, timings):
+    """_stream_front for text that is framed and de-duplicated ON the device (fastq_device.ingest_file): whenever STREAM_MIN_BATCH new
+    unique reads are final, their seed test and alignments are enqueued behind the de-duplication kernels -- the device works on them
+    while the host copies the next chunks of the text into pinned memory and the link carries them.  The reads never are on the host
+    (`arena` is None; "device_reads" carries them for the steps that need their bytes).  Raises DeviceIngestUnavailable."""
+    import time
+    import torch
+    from . import fastq_device
+    t0 = time.perf_counter()
+    k = len(ref_names)
+    parts = []
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def on_batch(m, d_reads, d_off, max_len):
+        parts.append(_enqueue_first_batch(aligner, ctx, dev, refs, ref_names, args, legacy, m, d_reads, d_off, max(max_len, 1), stream))
+    ing = fastq_device.ingest_file(path, ctx, dev, timings=timings, on_batch=on_batch, min_batch=STREAM_MIN_BATCH)
+    n = ing["n_unique"]
+    a1, f1, r1, d_plan, stride = _join_first_batches(parts, aligner, dev)
+    plan = d_plan.cpu().numpy().reshape(n, k)
+    if len(parts) == 1:
+        d_reads_all, d_off_all = parts[0][5], parts[0][6]
+    elif parts:
+        d_reads_all = torch.cat([p_[5][:b] for p_, b in zip(parts, ing["batch_bytes"])])
+        d_off_all = torch.from_numpy(ing["offsets"].astype(np.int64)).to(dev)
+    else:
+        d_reads_all, d_off_all = torch.zeros(1, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    del parts
+    if timings is not None:
+        timings["stream_batches"] = len(ing["batch_bytes"])
+        timings["device_front"] = time.perf_counter() - t0
+    ing["d_reads"], ing["d_off"] = d_reads_all, d_off_all
+    return dict(arena=None, offsets=ing["offsets"], counts=ing["counts"], plan=plan, stride=stride, a1=a1, f1=f1, r1=r1, rc_partners=None,
+                d_reads_all=d_reads_all if n >= RC_PARTNERS_ON_DEVICE_MIN else None, device_reads=ing)
+
+
 def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings):
     """Ingest and device overlapped (replaces "parse the whole file, then align", CRISPRessoCORE.py:1825-1849 + :1957-1981).
     A host thread drives the native chunked parser (_native.FastqStream.next: all cores, GIL released); whenever it has brought
@@ -333,18 +404,7 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
             else:                                                     # (tests: the "device" is host memory)
                 d_reads = torch.from_numpy(np.ascontiguousarray(fq.arena[base:base + max(nbytes, 1)]).copy())
                 d_off = torch.from_numpy(rel.copy())
-            stream = compute.cuda_stream
-            d_plan = torch.empty(m * k, dtype=torch.uint8, device=dev)
-            C.strand_plan_device(ctx, m, d_reads.data_ptr(), d_off.data_ptr(), max_lj, refs, ref_names, args.aln_seed_count, args.aln_seed_min,
-                                 d_plan.data_ptr(), stream=stream)
-            d_str = (d_plan == 1).to(torch.uint8)
-            stride = aligner.stride_for(max_lj)
-            a = torch.empty((m * k, stride), dtype=torch.uint8, device=dev)
-            f = torch.empty((m * k, stride), dtype=torch.uint8, device=dev)
-            r = torch.empty((m * k, 32), dtype=torch.uint8, device=dev)
-            aligner.align_device(m, d_reads.data_ptr(), d_off.data_ptr(), a.data_ptr(), f.data_ptr(), r.data_ptr(), stride, max_lj,
-                                 d_strands=d_str.data_ptr(), all_refs=True, stream=stream, legacy=legacy)
-            parts.append((a, f, r, d_plan, stride, d_reads, d_off, d_str))
+            parts.append(_enqueue_first_batch(aligner, ctx, dev, refs, ref_names, args, legacy, m, d_reads, d_off, max_lj, compute.cuda_stream))
             off_parts.append(off)
     finally:
         th.join()
@@ -358,21 +418,7 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
     if dropped:
         counts = np.delete(counts, dropped)
     arena = fq.arena[:int(offsets[-1])]
-    stride = max([p_[4] for p_ in parts], default=aligner.stride_for(1))
-
-    def widen(x, st):
-        return x if st == stride else torch.nn.functional.pad(x, (0, stride - st))
-    if len(parts) == 1:
-        a1, f1, r1, d_plan = parts[0][0], parts[0][1], parts[0][2], parts[0][3]
-    elif parts:
-        a1 = torch.cat([widen(p_[0], p_[4]) for p_ in parts])
-        f1 = torch.cat([widen(p_[1], p_[4]) for p_ in parts])
-        r1 = torch.cat([p_[2] for p_ in parts])
-        d_plan = torch.cat([p_[3] for p_ in parts])
-    else:
-        a1 = f1 = torch.empty((0, stride), dtype=torch.uint8, device=dev)
-        r1 = torch.empty((0, 32), dtype=torch.uint8, device=dev)
-        d_plan = torch.empty(0, dtype=torch.uint8, device=dev)
+    a1, f1, r1, d_plan, stride = _join_first_batches(parts, aligner, dev)
     plan = d_plan.cpu().numpy().reshape(n, k)                          # (waits for the last batch)
     d_reads_all = None
     if parts and n >= RC_PARTNERS_ON_DEVICE_MIN:                       # (kept for the partner search on the device)
@@ -412,8 +458,9 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     Implies reduce_across_ranks.
     fastq_stream: a _native.FastqStream instead of arena / offsets / read_counts -- the file is parsed chunk by chunk on a host thread
     while the device already runs the seed test and the alignments of the unique reads the previous chunks brought (_stream_front).
-    device_reads: fastq_device.ingest_file's result instead of arena / offsets / read_counts -- the unique reads were framed and
-    de-duplicated on the device and never were on the host (`arena` stays None; the rare host-side uses download them).
+    device_reads: instead of arena / offsets / read_counts -- the path of a FASTQ file that is framed and de-duplicated on the device
+    with batch 1 running under its upload (_device_front; raises fastq_device.DeviceIngestUnavailable), or fastq_device.ingest_file's
+    result (one batch).  The unique reads never are on the host (`arena` stays None; the rare host-side uses download them).
     timings: optional dict that receives the wall seconds of every stage.
     pe_scaffold_dna_info: (index, dna) of get_pe_scaffold_search for runs with --prime_editing_pegRNA_scaffold_seq: reads whose
     alignment against 'Prime-edited' carries `dna` right after reference base index-1 are counted for 'Scaffold-incorporated'
@@ -456,6 +503,11 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if device_reads is not None:
         if shard is not None or fastq_stream is not None:
             raise ValueError("device_reads is the single-process route")
+        if isinstance(device_reads, (str, os.PathLike)):
+            # a FASTQ file: framed, de-duplicated AND aligned (batch 1) chunk by chunk under its upload (_device_front)
+            front = _device_front(os.fspath(device_reads), aligner, ctx, dev, refs, ref_names, args, legacy, timings)
+            device_reads = front["device_reads"]
+            t_last[0] = time.perf_counter()
         arena, offsets, read_counts = None, device_reads["offsets"], device_reads["counts"]
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     # the whole run's unique reads (what the reverse-complement partner search looks at) and the part this process aligns
@@ -526,7 +578,10 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
                 v["all_indelsub_count_vectors"] = (v["all_insertion_count_vectors"] + v["all_deletion_count_vectors"]
                                                    + v["all_substitution_count_vectors"])
         lap("unpack")
-        return QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
+        res = QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
+        if device_reads is not None:
+            res.device_ingest = {q: device_reads[q] for q in ("n_reads", "nonempty_lines", "n_unique", "n_empty_records") if q in device_reads}
+        return res
 
     def exchange_aligned(aligned_local):
         """sharded run: which unique reads of the WHOLE list aligned -- every rank contributes its part (one byte per read)"""
@@ -851,15 +906,13 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
         from . import fastq_device
         why_not = fastq_device.applicable(path, flt)
         if why_not is None:
-            import torch
             try:
-                ing = fastq_device.ingest_file(path, ctx or _native.default_context(), torch.device("cuda", device), timings=timings)
+                res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
+                                      pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=path)
             except fastq_device.DeviceIngestUnavailable as e:
                 why_not = str(e)
             else:
-                res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
-                                      pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=ing)
-                _native._line_stats(ingest_stats, ing["nonempty_lines"])
+                _native._line_stats(ingest_stats, res.device_ingest["nonempty_lines"])
                 res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT']
                 res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats['N_READS_AFTER_PREPROCESSING']
                 res.ingest_route = "device"

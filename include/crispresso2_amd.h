@@ -398,7 +398,8 @@ int c2_gather_reads(const uint8_t* arena, const uint64_t* offsets, const int64_t
  *   c2_fq_dedup_device  records [range[0], range[1]) (two uint64 in DEVICE memory): stripped sequence -> rinfo[r] = start << 24 |
  *                       length; looked up in / inserted into the open-addressing table `slots` (n_slots a power of two, zeroed by the
  *                       caller; `first` filled with 0xff): count[slot] += 1, first[slot] = min(first[slot], r), slot_of[r] = slot,
- *                       *n_unique += new keys.  Equal means equal bytes (compared, not hashed).  flags |= 2: a line of 2^24 bytes or
+ *                       stats[0] += new keys, stats[1] = max(stats[1], their lengths), stats[2] += 1 if the empty sequence became a
+ *                       key (three uint32).  Equal means equal bytes (compared, not hashed).  flags |= 2: a line of 2^24 bytes or
  *                       more / text beyond 2^40; |= 4: range beyond n_records_cap; |= 8: table more than half full.
  *   c2_fq_gather_device out[out_offsets[i] ..) = the bytes info[records ? records[i] : i] names (start << 24 | length) in `text`. */
 #define C2_FQ_TILE_BYTES 16384
@@ -408,7 +409,7 @@ int c2_fq_lines_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t
                        uint64_t* d_seq_end, uint64_t n_records_cap, void* hip_stream);
 int c2_fq_dedup_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_seq_start, const uint64_t* d_seq_end, const uint64_t* d_range,
                        uint64_t n_records_cap, uint64_t* d_slots, uint64_t n_slots, uint32_t* d_count, uint32_t* d_first,
-                       uint32_t* d_slot_of, uint64_t* d_rinfo, uint32_t* d_flags, uint32_t* d_n_unique, void* hip_stream);
+                       uint32_t* d_slot_of, uint64_t* d_rinfo, uint32_t* d_flags, uint32_t* d_stats, void* hip_stream);
 int c2_fq_gather_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_info, const int64_t* d_records, const int64_t* d_out_offsets,
                         uint8_t* d_out, uint64_t n, void* hip_stream);
 

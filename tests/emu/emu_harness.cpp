@@ -367,11 +367,11 @@ int emu_fq_lines(const uint8_t* text, uint64_t lo, uint64_t hi, const uint64_t* 
     return 0;
 }
 int emu_fq_dedup(const uint8_t* text, const uint64_t* seq_start, const uint64_t* seq_end, const uint64_t* range, uint64_t cap, uint64_t* slots,
-                 uint64_t n_slots, uint32_t* count, uint32_t* first, uint32_t* slot_of, uint64_t* rinfo, uint32_t* flags, uint32_t* n_unique)
+                 uint64_t n_slots, uint32_t* count, uint32_t* first, uint32_t* slot_of, uint64_t* rinfo, uint32_t* flags, uint32_t* stats)
 {
     c2_fq_dedup_args A{};
     A.text = text; A.seq_start = seq_start; A.seq_end = seq_end; A.range = range; A.n_records_cap = cap; A.slots = (unsigned long long*)slots;
-    A.mask = n_slots - 1; A.count = count; A.first = first; A.slot_of = slot_of; A.rinfo = (unsigned long long*)rinfo; A.flags = flags; A.n_unique = n_unique;
+    A.mask = n_slots - 1; A.count = count; A.first = first; A.slot_of = slot_of; A.rinfo = (unsigned long long*)rinfo; A.flags = flags; A.stats = stats;
     emu::launch(3, [&] { c2_fq_dedup_kernel(A); }, 256);
     return 0;
 }

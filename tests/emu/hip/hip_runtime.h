@@ -183,6 +183,7 @@ template <class T, class U> inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o
 template <class T, class U> inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
 template <class T, class U> inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
 template <class T, class U> inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <class T, class U> inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
 template <class T, class U, class V> inline T atomicCAS(T* p, U cmp, V v) { T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
 template <class T> inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> inline T max(T a, T b) { return a > b ? a : b; }

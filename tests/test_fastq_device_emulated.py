@@ -31,9 +31,9 @@ def emulated_fq_kernels(chunk=FD.TILE):
     def lines(ctx, d_text, lo, hi, base, s, e, cap, stream):
         assert lib.emu_fq_lines(V(d_text), U(lo), U(hi), V(base), V(s), V(e), U(cap)) == 0
 
-    def dedup(ctx, d_text, s, e, rng, cap, slots, n_slots, cnt, first, slot_of, rinfo, flags, n_unique, stream):
+    def dedup(ctx, d_text, s, e, rng, cap, slots, n_slots, cnt, first, slot_of, rinfo, flags, stats, stream):
         assert lib.emu_fq_dedup(V(d_text), V(s), V(e), V(rng), U(cap), V(slots), U(n_slots), V(cnt), V(first), V(slot_of), V(rinfo), V(flags),
-                                V(n_unique)) == 0
+                                V(stats)) == 0
 
     def gather(ctx, d_text, info, records, out_off, out, n, stream):
         assert lib.emu_fq_gather(V(d_text), V(info), V(records or 0), V(out_off), V(out), U(n)) == 0

@@ -778,11 +778,13 @@ def test_device_ingest_gives_the_same_files(tmp_path, monkeypatch):
     cut = g["cut_point"]
     ref = RF.make_ref("Reference", g["amplicon"], [cut], [cut, cut + 1], min_aln_score=60)
     ref["sgRNA_orig_sequences"] = [g["guide"]]
+    monkeypatch.setattr(pipeline, "STREAM_MIN_BATCH", 15)             # (a batch of alignments whenever 15 new unique reads are final)
     with emulated_device(), emulated_fq_kernels():
         monkeypatch.setenv("C2_FQ_INGEST", "device")
         tm = {}
         res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(), timings=tm)
         assert getattr(res, "ingest_route", None) == "device" and "host_parser_because" not in tm
+        assert tm["stream_batches"] >= 4, tm
         monkeypatch.setenv("C2_FQ_INGEST", "host")
         tm = {}
         other = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args(), timings=tm)
