@@ -231,11 +231,11 @@ class DeviceIngest:
         import torch
         dev, ra = self.dev, self.batch_r0
         idx = torch.arange(ra, r1, dtype=torch.int64, device=dev)
-        slot = self.slot_of[ra:r1].to(torch.int64)
+        slot = self.slot_of[ra:r1].to(torch.int64).clamp_(min=0)
         info = self.rinfo[ra:r1]
         mask = (self.first[slot].to(torch.int64) == idx) & ((info & 0xffffff) > 0)
-        dest = torch.where(mask, torch.cumsum(mask, 0) - 1, m).clamp_(max=m)
-        rec = torch.empty(m + 1, dtype=torch.int64, device=dev).scatter_(0, dest, idx)[:m]     # first occurrences, in file order
+        # first occurrences, in file order; their number is known (m), so nothing waits for the device here
+        rec = torch.nonzero_static(mask, size=m, fill_value=0).reshape(-1) + ra
         lens = self.rinfo[rec] & 0xffffff
         d_off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
         torch.cumsum(lens, 0, out=d_off[1:])
@@ -335,14 +335,16 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
                 ing.feed(lo, hi)
                 after_feed()
             return ing.finish(last != b"\n", on_batch)
+        import queue
+        import threading
         threads = min(16, usable_cpus())
         key = (chunk, dev.index)
         if key not in _pinned:
-            _pinned[key] = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            _pinned[key] = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
         pins = _pinned[key]
         compute = torch.cuda.current_stream(dev)
         copy_stream = torch.cuda.Stream(device=dev)
-        evs = [None, None]
+        q = queue.Queue()
 
         def read_into(args):
             buf, off, n = args
@@ -351,23 +353,45 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
                 if got <= 0:
                     raise OSError("short read")
                 buf, off, n = buf[got:], off + got, n - got
-        with ThreadPoolExecutor(threads) as pool:
-            for c, lo in enumerate(range(0, size, chunk)):
-                hi = min(size, lo + chunk)
-                k = c & 1
-                if evs[k] is not None:
-                    evs[k].synchronize()                              # the upload out of this buffer is done
-                mv = memoryview(pins[k].numpy())
-                step = -(-(hi - lo) // threads)
-                step = (step + 4095) // 4096 * 4096
-                list(pool.map(read_into, [(mv[q:min(hi - lo, q + step)], lo + q, min(hi - lo, q + step) - q) for q in range(0, hi - lo, step)]))
-                with torch.cuda.stream(copy_stream):
-                    ing.d_text[lo:hi].copy_(pins[k][:hi - lo], non_blocking=True)
-                    evs[k] = torch.cuda.Event()
-                    evs[k].record(copy_stream)
-                compute.wait_event(evs[k])
+
+        def producer():
+            """file -> pinned buffers (all host threads) -> device, chunk after chunk; this thread only waits and enqueues copies, so
+            the thread that enqueues kernels is never in its way"""
+            evs = [None] * len(pins)
+            try:
+                with ThreadPoolExecutor(threads) as pool:
+                    for c, lo in enumerate(range(0, size, chunk)):
+                        hi = min(size, lo + chunk)
+                        k = c % len(pins)
+                        if evs[k] is not None:
+                            evs[k].synchronize()                      # the upload out of this buffer is done
+                        mv = memoryview(pins[k].numpy())
+                        step = -(-(hi - lo) // threads)
+                        step = (step + 4095) // 4096 * 4096
+                        list(pool.map(read_into, [(mv[a_:min(hi - lo, a_ + step)], lo + a_, min(hi - lo, a_ + step) - a_) for a_ in range(0, hi - lo, step)]))
+                        with torch.cuda.stream(copy_stream):
+                            ing.d_text[lo:hi].copy_(pins[k][:hi - lo], non_blocking=True)
+                            evs[k] = torch.cuda.Event()
+                            evs[k].record(copy_stream)
+                        q.put((lo, hi, evs[k]))
+                q.put(None)
+            except BaseException as e:
+                q.put(e)
+        th = threading.Thread(target=producer, name="c2-fastq-upload")
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                lo, hi, ev = item
+                compute.wait_event(ev)
                 ing.feed(lo, hi)
                 after_feed()
+        finally:
+            th.join()
         if timings is not None:
             timings["upload_text"] = time.perf_counter() - t0
         out = ing.finish(last != b"\n", on_batch)
