@@ -27,6 +27,25 @@ m = A.read_matrix(os.path.join(ROOT, "crispresso2_amd", "EDNAFULL"))
 ctx = _native.default_context()
 dev = torch.device("cuda", 0)
 tallies = {}
+
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+mask = torch.rand(a.reads, device=dev) < 0.355
+k_true = int(mask.sum().item())
+big = torch.empty(3_549_140, dtype=torch.int64, device=dev)
+print(json.dumps({"torch_ops_ms": {"nonzero": round(timed(lambda: torch.nonzero(mask)), 3),
+                                   "nonzero_static": round(timed(lambda: torch.nonzero_static(mask, size=k_true)), 3),
+                                   "cumsum_10M_int64": round(timed(lambda: torch.cumsum(mask, 0)), 3),
+                                   "d2h_28MB_pageable": round(timed(lambda: big.cpu()), 3)}}), flush=True)
+del mask, big
 try:
     for chunk_mb in [int(x) for x in a.chunks.split(",")]:
         FD.CHUNK_BYTES = chunk_mb << 20
