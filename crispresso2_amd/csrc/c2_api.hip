@@ -1662,7 +1662,7 @@ int c2_fq_dedup_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_seq
     A.slots = (unsigned long long*)d_slots; A.mask = n_slots - 1; A.count = d_count; A.first = d_first; A.slot_of = d_slot_of;
     A.rinfo = (unsigned long long*)d_rinfo; A.flags = d_flags; A.stats = d_stats;
     // grid-stride over the records (how many is only known on the device): enough wavefronts to cover the latency of the table probes
-    hipLaunchKernelGGL(c2_fq_dedup_kernel, dim3((unsigned)ctx->prop.multiProcessorCount * 16u), dim3(256), 0, (hipStream_t)hip_stream, A);
+    hipLaunchKernelGGL(c2_fq_dedup_kernel, dim3((unsigned)ctx->prop.multiProcessorCount * 8u), dim3(256), C2_FQ_DEDUP_LDS_BYTES, (hipStream_t)hip_stream, A);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }

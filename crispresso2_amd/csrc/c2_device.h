@@ -156,6 +156,7 @@ struct c2_strand_args {
 // The text (no '\r' in it: the host falls back to its own parser otherwise) lies in HBM; lines end at '\n'; line k is ended by
 // newline k (0-based); record r = lines 4r .. 4r + 3; its sequence is line 4r + 1: it starts behind newline 4r and ends at newline 4r + 1.
 #define C2_FQ_LDS_BYTES 1024u          // dynamic LDS of the two framing kernels
+#define C2_FQ_DEDUP_LDS_BYTES 2064u    // ... of the de-duplication kernel (its per-workgroup count table, c2_kernels.hip)
 #define C2_FQ_TILE 16384u              // bytes of text per workgroup of the two framing kernels (256 threads x 64 bytes)
 struct c2_fq_frame_args {
     const uint8_t* text;              // the whole text; bytes [0, hi) are resident
@@ -182,7 +183,7 @@ struct c2_fq_dedup_args {
     uint32_t* slot_of;                // per record: its slot
     unsigned long long* rinfo;        // per record: (stripped start << 24 | length)
     uint32_t* flags;                  // bit 1: a sequence line of 2^24 bytes or more, or a text position beyond 2^40; bit 2: more records than
-                                      // the arrays hold; bit 3: the table is more than half full (the host falls back on any of them)
+                                      // the arrays hold (the host falls back on any of them, and when stats[0] exceeds half the table)
     uint32_t* stats;                  // [0] += keys created by this launch, [1] = max(., their lengths), [2] += 1 for the empty key
 };
 // out[out_offsets[i] ..] = the bytes info[records ? records[i] : i] names (start << 24 | length)

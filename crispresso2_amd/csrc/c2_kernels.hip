@@ -3088,11 +3088,20 @@ __device__ __forceinline__ unsigned long long c2_fq_weight(unsigned long long k)
     return (k ^ (k >> 31)) | 1ull;
 }
 
+// Same-address atomics serialise in L2 (measured: 80 k of them per launch cost 1 ms -- in real data more than half of the reads are
+// one sequence): the table slot is READ before it is CAS-ed, `first` is read before it is lowered, and the occurrences are added up
+// in a small LDS table per workgroup (C2_FQ_AGG entries: slot -> count; a collision goes to HBM directly) that is flushed at the end.
+#define C2_FQ_AGG 256
 __global__ __launch_bounds__(256) void c2_fq_dedup_kernel(c2_fq_dedup_args A)
 {
+    unsigned* const agg_key = (unsigned*)c2_smem;                   // [C2_FQ_AGG] slot + 1, 0 = free       (dynamic LDS: C2_FQ_DEDUP_LDS_BYTES)
+    unsigned* const agg_cnt = agg_key + C2_FQ_AGG;                  // [C2_FQ_AGG]
+    unsigned* const agg_stats = agg_cnt + C2_FQ_AGG;                // [3] keys created, longest, empty keys
     const int lane = threadIdx.x & 63;
     const uint64_t r0 = A.range[0], r1 = A.range[1];
     if (r1 > A.n_records_cap || r1 >= 0xffffffffull) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(A.flags, 4u); return; }
+    for (unsigned e = threadIdx.x; e < 2u * C2_FQ_AGG + 3u; e += blockDim.x) agg_key[e] = 0u;
+    __syncthreads();
     for (uint64_t r = r0 + (uint64_t)blockIdx.x * 4u + (uint64_t)(threadIdx.x >> 6); r < r1; r += (uint64_t)gridDim.x * 4u) {
         uint64_t s = A.seq_start[r], e = A.seq_end[r];
         if (e < s) e = s;
@@ -3119,7 +3128,10 @@ __global__ __launch_bounds__(256) void c2_fq_dedup_kernel(c2_fq_dedup_args A)
         uint64_t p = h & A.mask;
         for (;;) {
             unsigned long long cur = 0;
-            if (lane == 0) cur = atomicCAS(A.slots + p, 0ull, me);    // empty: this record's own bytes become the key's representative
+            if (lane == 0) {
+                cur = __hip_atomic_load(A.slots + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == 0ull) cur = atomicCAS(A.slots + p, 0ull, me);          // empty: this record's own bytes become the key's representative
+            }
             cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur >> 32)) << 32) |
                   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur & 0xffffffffull));
             const bool created = cur == 0ull;
@@ -3134,20 +3146,29 @@ __global__ __launch_bounds__(256) void c2_fq_dedup_kernel(c2_fq_dedup_args A)
             }
             if (created || same) {
                 if (lane == 0) {
-                    atomicAdd(A.count + p, 1u);
-                    atomicMin(A.first + p, (unsigned)r);
                     A.slot_of[r] = (uint32_t)p;
+                    if (__hip_atomic_load(A.first + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)r) atomicMin(A.first + p, (unsigned)r);
+                    const unsigned a = ((unsigned)p * 0x9e3779b1u) >> 24;         // (C2_FQ_AGG = 2^8)
+                    const unsigned was = atomicCAS(agg_key + a, 0u, (unsigned)p + 1u);
+                    if (was == 0u || was == (unsigned)p + 1u) atomicAdd(agg_cnt + a, 1u);
+                    else atomicAdd(A.count + p, 1u);
                     if (created) {
-                        const unsigned u = atomicAdd(A.stats, 1u);
-                        if (2ull * (u + 1ull) > A.mask + 1ull) atomicOr(A.flags, 8u);
-                        atomicMax(A.stats + 1, (unsigned)len);
-                        if (len == 0) atomicAdd(A.stats + 2, 1u);
+                        atomicAdd(agg_stats, 1u);
+                        atomicMax(agg_stats + 1, (unsigned)len);
+                        if (len == 0) atomicAdd(agg_stats + 2, 1u);
                     }
                 }
                 break;
             }
             p = (p + 1) & A.mask;
         }
+    }
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < C2_FQ_AGG; e += blockDim.x) if (agg_key[e]) atomicAdd(A.count + (agg_key[e] - 1u), agg_cnt[e]);
+    if (threadIdx.x == 0 && agg_stats[0]) {
+        atomicAdd(A.stats, agg_stats[0]);
+        atomicMax(A.stats + 1, agg_stats[1]);
+        if (agg_stats[2]) atomicAdd(A.stats + 2, agg_stats[2]);
     }
 }
 

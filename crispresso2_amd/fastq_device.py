@@ -215,15 +215,15 @@ class DeviceIngest:
         if got is None:
             return None
         r1, keys, longest, empty_keys, flags = got
-        self._check(flags, r1)
+        self._check(flags, r1, keys)
         return r1, keys - empty_keys, longest
 
-    def _check(self, flags, r1):
+    def _check(self, flags, r1, keys):
         if flags & 1:
             raise DeviceIngestUnavailable("carriage returns in the text")
         if flags & ~1:
-            raise DeviceIngestUnavailable("device ingest gave up (flags %d: 2 = line too long, 4 = more records than estimated, 8 = table too full)" % flags)
-        if r1 > self.cap:
+            raise DeviceIngestUnavailable("device ingest gave up (flags %d: 2 = line too long, 4 = more records than estimated)" % flags)
+        if r1 > self.cap or 2 * keys > self.n_slots:
             raise DeviceIngestUnavailable("more records than estimated")
 
     def take_batch(self, r1, m, max_len, may_wait=False):
@@ -260,7 +260,7 @@ class DeviceIngest:
         self._snaps.clear()
         n_records, keys, longest, empty_keys, flags = [int(x) for x in torch.cat([self.range[1:2], self.stats[:3].to(torch.int64),
                                                                                self.flags.to(torch.int64)]).tolist()]
-        self._check(flags, n_records)
+        self._check(flags, n_records, keys)
         nonempty = int(lines.item()) - int(self.empty_lines.item())
         m = keys - empty_keys - self.batch_u0
         last = None

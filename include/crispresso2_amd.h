@@ -400,7 +400,7 @@ int c2_gather_reads(const uint8_t* arena, const uint64_t* offsets, const int64_t
  *                       caller; `first` filled with 0xff): count[slot] += 1, first[slot] = min(first[slot], r), slot_of[r] = slot,
  *                       stats[0] += new keys, stats[1] = max(stats[1], their lengths), stats[2] += 1 if the empty sequence became a
  *                       key (three uint32).  Equal means equal bytes (compared, not hashed).  flags |= 2: a line of 2^24 bytes or
- *                       more / text beyond 2^40; |= 4: range beyond n_records_cap; |= 8: table more than half full.
+ *                       more / text beyond 2^40; |= 4: range beyond n_records_cap.  The caller keeps stats[0] below n_slots / 2.
  *   c2_fq_gather_device out[out_offsets[i] ..) = the bytes info[records ? records[i] : i] names (start << 24 | length) in `text`. */
 #define C2_FQ_TILE_BYTES 16384
 int c2_fq_count_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, uint32_t* d_tile_newlines, uint32_t* d_tile_empty,
