@@ -1680,6 +1680,23 @@ int c2_fq_gather_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_in
     return 0;
 }
 
+int c2_fq_rc_partner_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_info, const int64_t* d_records, uint64_t n,
+                            const uint64_t* d_slots, uint64_t n_slots, int32_t* d_partner_slot, void* hip_stream) {
+    if (!ctx || !d_text || !d_info || !d_records || !d_slots || !d_partner_slot || n_slots < 2 || (n_slots & (n_slots - 1)) || n_slots > 0x7fffffffull) {
+        if (ctx) ctx->err = "bad argument";
+        return C2_E_INVALID;
+    }
+    if (n == 0) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    c2_fq_rc_args A{};
+    A.text = d_text; A.info = (const unsigned long long*)d_info; A.records = d_records; A.n = n; A.slots = (const unsigned long long*)d_slots;
+    A.mask = n_slots - 1; A.partner_slot = d_partner_slot;
+    const uint64_t wgs = std::min<uint64_t>((n + 3) / 4, (uint64_t)ctx->prop.multiProcessorCount * 16u);
+    hipLaunchKernelGGL(c2_fq_rc_partner_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)hip_stream, A);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 int c2_selftest(c2_ctx* ctx, int32_t* out448) {
     if (!ctx || !out448) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));

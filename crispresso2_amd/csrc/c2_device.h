@@ -196,6 +196,17 @@ struct c2_fq_gather_args {
     uint64_t n;
 };
 
+// which unique read equals reverse_complement(unique read i) (the count merge of CRISPRessoCORE.py:3970-3975; CRISPRessoShared.py:399-403:
+// upper-cased first, ACGTN_- only): looked up in the table the de-duplication built -- one wavefront per unique read
+struct c2_fq_rc_args {
+    const uint8_t* text;
+    const unsigned long long* info;   // per record: start << 24 | length
+    const int64_t* records;           // the unique reads: record numbers
+    uint64_t n;
+    const unsigned long long* slots; uint64_t mask;
+    int32_t* partner_slot;            // per unique read: the slot of the key that equals its reverse complement, -1: none (or a character outside the alphabet)
+};
+
 // ---- per-amplicon count tensor (what CRISPRessoCORE.py:3865-3901 keeps per reference and :4016-4115 fills) ----
 // One int64 block per reference: C2_CNT_VECTORS vectors of (lmax + 1) entries, then C2_CNT_SCALARS scalars,
 // then C2_CNT_HISTS histograms of hl entries.  crispresso2_amd/counts.py names the slices.

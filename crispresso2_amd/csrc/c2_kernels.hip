@@ -3182,3 +3182,57 @@ __global__ __launch_bounds__(256) void c2_fq_gather_kernel(c2_fq_gather_args A)
         for (uint64_t k = (uint64_t)lane; k < len; k += 64) o[k] = A.text[s + k];
     }
 }
+
+// complement of an upper-cased read character, 0 outside ACGTN_- (CRISPRessoShared.reverse_complement's dictionary)
+__device__ __forceinline__ unsigned c2_fq_complement(const unsigned c) {
+    switch (c) {
+        case 'A': case 'a': return 'T';
+        case 'C': case 'c': return 'G';
+        case 'G': case 'g': return 'C';
+        case 'T': case 't': return 'A';
+        case 'N': case 'n': return 'N';
+        case '_': return '_';
+        case '-': return '-';
+        default: return 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void c2_fq_rc_partner_kernel(c2_fq_rc_args A)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4u + (uint64_t)(threadIdx.x >> 6); i < A.n; i += (uint64_t)gridDim.x * 4u) {
+        const unsigned long long info = A.info[A.records[i]];
+        const uint64_t s = info >> 24, len = info & 0xffffffull;
+        // the hash the de-duplication kernel would give the reverse complement: its byte k is the complement of this read's byte len - 1 - k
+        unsigned long long h = 0;
+        bool bad = false;
+        for (uint64_t k = (uint64_t)lane; k < len; k += 64) {
+            const unsigned c = c2_fq_complement(A.text[s + len - 1 - k]);
+            bad = bad || c == 0u;
+            h += ((unsigned long long)c + 1ull) * c2_fq_weight(k);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(h & 0xffffffffull), d), hi = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), d);
+            h += ((unsigned long long)hi << 32) | (unsigned long long)lo;
+        }
+        h ^= len * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+        int found = -1;
+        if (__ballot(bad) == 0ull) {
+            uint64_t p = h & A.mask;
+            for (;;) {
+                const unsigned long long cur = A.slots[p];             // (wave-uniform address)
+                if (cur == 0ull) break;
+                const uint64_t os = cur >> 24, ol = cur & 0xffffffull;
+                if (ol == len) {
+                    bool eq = true;
+                    for (uint64_t k = (uint64_t)lane; k < len; k += 64) eq = eq && (unsigned)A.text[os + k] == c2_fq_complement(A.text[s + len - 1 - k]);
+                    if (__ballot(!eq) == 0ull) { found = (int)p; break; }
+                }
+                p = (p + 1) & A.mask;
+            }
+        }
+        if (lane == 0) A.partner_slot[i] = found;
+    }
+}

@@ -75,6 +75,13 @@ def fq_gather(ctx, d_text, d_info, d_records, d_out_offsets, d_out, n, stream):
                                           V(stream)), "c2_fq_gather_device")
 
 
+def fq_rc_partner(ctx, d_text, d_info, d_records, n, d_slots, n_slots, d_partner_slot, stream):
+    import ctypes
+    V = ctypes.c_void_p
+    ctx.check(ctx.lib.c2_fq_rc_partner_device(ctx.handle, V(d_text), V(d_info), V(d_records), ctypes.c_uint64(n), V(d_slots), ctypes.c_uint64(n_slots),
+                                              V(d_partner_slot), V(stream)), "c2_fq_rc_partner_device")
+
+
 def gather_reads_device(ctx, d_reads, d_off, idx, dev, stream):
     """the reads idx[...] of a device arena (d_off: int64 [n + 1]) back to back -> (uint8 tensor, int64 offsets tensor, longest read);
     _native.gather_reads for reads that never were on the host"""
@@ -252,15 +259,25 @@ class DeviceIngest:
         """unterminated: the text does not end with a newline (its last line still counts).  Hands out the last batch (everything, if
         none was taken before) and -> dict(offsets, counts, n_reads, nonempty_lines, n_unique, max_len, min_len, ...); waits for the device.
         on_batch(m, d_reads, d_off, max_len): called for the last batch, as the caller did for the earlier ones."""
+        import time
         import torch
         if self.fed != self.T:
             raise ValueError("%d of %d bytes were fed" % (self.fed, self.T))
+        trace = [] if os.environ.get("C2_FQ_TRACE") else None
+
+        def lap(what):
+            if trace is not None:
+                if self.dev.type == "cuda":
+                    torch.cuda.synchronize(self.dev)
+                trace.append((what, time.perf_counter()))
+        lap("queue drained")
         lines = self.newlines + (1 if unterminated else 0)
         self._dedup_to((lines + 3) // 4)                                            # readline() loop: every started group of four lines is a record
         self._snaps.clear()
         n_records, keys, longest, empty_keys, flags = [int(x) for x in torch.cat([self.range[1:2], self.stats[:3].to(torch.int64),
                                                                                self.flags.to(torch.int64)]).tolist()]
         self._check(flags, n_records, keys)
+        lap("last records de-duplicated")
         nonempty = int(lines.item()) - int(self.empty_lines.item())
         m = keys - empty_keys - self.batch_u0
         last = None
@@ -268,6 +285,7 @@ class DeviceIngest:
             last = self.take_batch(n_records, m, longest, may_wait=True)
             if on_batch is not None:
                 on_batch(m, last[0], last[1], longest)
+        lap("last batch handed out")
         n = self.batch_u0
         n_empty = 0
         if empty_keys:
@@ -280,13 +298,28 @@ class DeviceIngest:
             lens_h = lens.cpu().numpy()
         else:
             counts, lens_h = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
-        offsets = np.zeros(n + 1, dtype=np.uint64)
-        np.cumsum(lens_h, out=offsets[1:])
+        # which unique read is the reverse complement of which (the count merge asks): looked up in the table, which is still here
+        rc_partner = np.zeros(0, dtype=np.int64)
+        if self.batches:
+            slot_u = self.slot_of[rec].to(torch.int64)
+            pslot = torch.empty(n, dtype=torch.int32, device=self.dev)
+            fq_rc_partner(self.ctx, self.d_text.data_ptr(), self.rinfo.data_ptr(), rec.data_ptr(), n, self.slots.data_ptr(), self.n_slots,
+                          pslot.data_ptr(), self._stream())
+            unique_of_slot = torch.full((self.n_slots,), -1, dtype=torch.int64, device=self.dev)
+            unique_of_slot[slot_u] = torch.arange(n, dtype=torch.int64, device=self.dev)
+            rc_partner = torch.where(pslot >= 0, unique_of_slot[pslot.to(torch.int64).clamp_(min=0)], -1).cpu().numpy()
+        lap("multiplicities and lengths on the host")
+        off64 = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens_h, out=off64[1:])
+        offsets = off64.view(np.uint64)
         out = dict(offsets=offsets, counts=counts, n_reads=n_records, n_empty_records=n_empty, nonempty_lines=nonempty, n_unique=n,
                    max_len=int(lens_h.max()) if n else 0, min_len=int(lens_h.min()) if n else 0,
-                   batch_bytes=[int(b[1][-1].item()) for b in self.batches])
+                   batch_bytes=[int(b[1][-1].item()) for b in self.batches], rc_partner=rc_partner)
         if last is not None and len(self.batches) == 1:
             out["d_reads"], out["d_off"] = last
+        lap("offsets")
+        if trace is not None:
+            out["finish_trace_ms"] = {w: round((t - trace[i][1]) * 1e3, 3) for i, (w, t) in enumerate(trace[1:])}
         return out
 
 

@@ -311,7 +311,7 @@ def _device_front(path, aligner, ctx, dev, refs, ref_names, args, legacy, timing
         d_reads_all, d_off_all = parts[0][5], parts[0][6]
     elif parts:
         d_reads_all = torch.cat([p_[5][:b] for p_, b in zip(parts, ing["batch_bytes"])])
-        d_off_all = torch.from_numpy(ing["offsets"].astype(np.int64)).to(dev)
+        d_off_all = torch.from_numpy(ing["offsets"].view(np.int64)).to(dev)
     else:
         d_reads_all, d_off_all = torch.zeros(1, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
     del parts
@@ -319,8 +319,9 @@ def _device_front(path, aligner, ctx, dev, refs, ref_names, args, legacy, timing
         timings["stream_batches"] = len(ing["batch_bytes"])
         timings["device_front"] = time.perf_counter() - t0
     ing["d_reads"], ing["d_off"] = d_reads_all, d_off_all
-    return dict(arena=None, offsets=ing["offsets"], counts=ing["counts"], plan=plan, stride=stride, a1=a1, f1=f1, r1=r1, rc_partners=None,
-                d_reads_all=d_reads_all if n >= RC_PARTNERS_ON_DEVICE_MIN else None, device_reads=ing)
+    # (the reverse-complement partners come with the ingest: looked up in its table -- no second search)
+    return dict(arena=None, offsets=ing["offsets"], counts=ing["counts"], plan=plan, stride=stride, a1=a1, f1=f1, r1=r1,
+                rc_partners=lambda: ing["rc_partner"], d_reads_all=None, device_reads=ing)
 
 
 def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings):

@@ -401,7 +401,10 @@ int c2_gather_reads(const uint8_t* arena, const uint64_t* offsets, const int64_t
  *                       stats[0] += new keys, stats[1] = max(stats[1], their lengths), stats[2] += 1 if the empty sequence became a
  *                       key (three uint32).  Equal means equal bytes (compared, not hashed).  flags |= 2: a line of 2^24 bytes or
  *                       more / text beyond 2^40; |= 4: range beyond n_records_cap.  The caller keeps stats[0] below n_slots / 2.
- *   c2_fq_gather_device out[out_offsets[i] ..) = the bytes info[records ? records[i] : i] names (start << 24 | length) in `text`. */
+ *   c2_fq_gather_device out[out_offsets[i] ..) = the bytes info[records ? records[i] : i] names (start << 24 | length) in `text`.
+ *   c2_fq_rc_partner_device  for the n unique reads records[0..n): partner_slot[i] = the table slot whose key equals
+ *                       reverse_complement(read i) (CRISPRessoShared.py:399-403: upper-cased, ACGTN_- only), -1 if there is none or the
+ *                       read has another character -- c2_rc_partners through the table the de-duplication built. */
 #define C2_FQ_TILE_BYTES 16384
 int c2_fq_count_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, uint32_t* d_tile_newlines, uint32_t* d_tile_empty,
                        uint32_t* d_flags, void* hip_stream);
@@ -412,6 +415,8 @@ int c2_fq_dedup_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_seq
                        uint32_t* d_slot_of, uint64_t* d_rinfo, uint32_t* d_flags, uint32_t* d_stats, void* hip_stream);
 int c2_fq_gather_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_info, const int64_t* d_records, const int64_t* d_out_offsets,
                         uint8_t* d_out, uint64_t n, void* hip_stream);
+int c2_fq_rc_partner_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_info, const int64_t* d_records, uint64_t n,
+                            const uint64_t* d_slots, uint64_t n_slots, int32_t* d_partner_slot, void* hip_stream);
 
 /* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1 with and without bound_ctrl, also with a
  * lane switched off in EXEC, readlane, ballot) the DP depends on; writes 448 int32 (see c2_selftest_kernel).  Used by the

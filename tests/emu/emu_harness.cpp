@@ -384,6 +384,16 @@ int emu_fq_gather(const uint8_t* text, const uint64_t* info, const int64_t* reco
     return 0;
 }
 
+int emu_fq_rc_partner(const uint8_t* text, const uint64_t* info, const int64_t* records, uint64_t n, const uint64_t* slots, uint64_t n_slots, int32_t* partner_slot)
+{
+    if (!n) return 0;
+    c2_fq_rc_args A{};
+    A.text = text; A.info = (const unsigned long long*)info; A.records = records; A.n = n; A.slots = (const unsigned long long*)slots; A.mask = n_slots - 1;
+    A.partner_slot = partner_slot;
+    emu::launch(3, [&] { c2_fq_rc_partner_kernel(A); }, 256);
+    return 0;
+}
+
 // The per-call C ABI on the emulator, argument for argument (the context handle is ignored): what
 // crispresso2_amd.CRISPResso2Align.global_align / CRISPRessoCOREResources.find_indels_substitutions[_legacy] call.
 // Host-side marshalling follows c2_api.hip (c2_global_align, c2_find_indels_substitutions).

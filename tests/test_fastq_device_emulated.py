@@ -37,7 +37,10 @@ def emulated_fq_kernels(chunk=FD.TILE):
 
     def gather(ctx, d_text, info, records, out_off, out, n, stream):
         assert lib.emu_fq_gather(V(d_text), V(info), V(records or 0), V(out_off), V(out), U(n)) == 0
-    saved = (FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES, torch.cuda.current_stream)
+    def rc_partner(ctx, d_text, info, records, n, slots, n_slots, pslot, stream):
+        assert lib.emu_fq_rc_partner(V(d_text), V(info), V(records), U(n), V(slots), U(n_slots), V(pslot)) == 0
+    saved = (FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES, torch.cuda.current_stream, FD.fq_rc_partner)
+    FD.fq_rc_partner = rc_partner
 
     class _S:
         cuda_stream = 0
@@ -46,7 +49,7 @@ def emulated_fq_kernels(chunk=FD.TILE):
     try:
         yield
     finally:
-        FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES, torch.cuda.current_stream = saved
+        FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES, torch.cuda.current_stream, FD.fq_rc_partner = saved
 
 
 def device_unique(path, chunk=FD.TILE):
@@ -135,3 +138,22 @@ def test_applicable():
     assert FD.applicable("/nonexistent.fastq") is not None
     assert FD.applicable(__file__, (30, 0, 0)) == "quality filters run in the host parser"
     assert FD.applicable(__file__) == "small file"
+
+
+def test_reverse_complement_partners_from_the_table(tmp_path):
+    """partner[i] = the unique read that equals reverse_complement(read i): the device's look-up in its own table against the host search
+    (c2_rc_partners) -- pairs, palindromes (their own partner), lower case (upper-cased before complementing: the partner is the
+    upper-case reverse complement, not the other way round), characters outside the alphabet (no partner), reads without a partner"""
+    from crispresso2_amd import refs as RF
+    rng = random.Random(11)
+    base = ["".join(rng.choice("ACGT") for _ in range(rng.randint(20, 90))) for _ in range(200)]
+    seqs = base + [RF.reverse_complement(s) for s in base[:80]] + ["ACGT", "AATT", "acgt", "ACGTNN", "NNACGT", "AC-GT_", "_AC-GT", "ACXGT", "ACYGT",
+                                                                  "ggatcc", "GGATCC", base[5].lower(), "A" * 70, "T" * 70, "A" * 69]
+    rng.shuffle(seqs)
+    p = tmp_path / "rc.fastq"
+    p.write_text("".join("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(seqs + seqs[:50])))
+    reads, counts, out = device_unique(p, chunk=FD.TILE)
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    want = _native.rc_partners(arena, out["offsets"])
+    assert np.array_equal(out["rc_partner"], want)
+    assert (want >= 0).sum() >= 160 and (want == np.arange(len(want))).sum() >= 3

@@ -60,6 +60,25 @@ def test_device_ingest_equals_the_host_parser(tmp_path, monkeypatch, tail):
     want = np.concatenate([arena[off[i]:off[i + 1]] for i in np.nonzero(keep)[0]]) if keep.any() else np.zeros(0, np.uint8)
     assert np.array_equal(out["d_reads"][:int(out["offsets"][-1])].cpu().numpy(), want)
     assert int(counts.sum()) == n_reads
+    assert np.array_equal(out["rc_partner"], _native.rc_partners(want, out["offsets"]))
+
+
+def test_reverse_complement_partners_from_the_table(tmp_path, monkeypatch):
+    import torch
+    from crispresso2_amd import fastq_device as FD, _native, refs as RF
+    rng = random.Random(4)
+    base = ["".join(rng.choice("ACGT") for _ in range(rng.randint(60, 150))) for _ in range(30_000)]
+    seqs = base + [RF.reverse_complement(s) for s in base[:12_000]] + ["ACGT", "AATT", "acgt", "ACGTNN", "NNACGT", "AC-GT_", "_AC-GT", "ACXGT", "ggatcc",
+                                                                      "GGATCC", base[5].lower()]
+    rng.shuffle(seqs)
+    p = tmp_path / "rc.fastq"
+    p.write_text("".join("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(seqs + seqs[:9000])))
+    monkeypatch.setattr(FD, "CHUNK_BYTES", 1 << 20)
+    out = FD.ingest_file(str(p), _native.default_context(), torch.device("cuda", 0))
+    arena = out["d_reads"][:int(out["offsets"][-1])].cpu().numpy()
+    want = _native.rc_partners(arena, out["offsets"])
+    assert np.array_equal(out["rc_partner"], want)
+    assert (want >= 0).sum() >= 24_000
 
 
 def test_whole_run_is_the_same_on_either_route(tmp_path, monkeypatch):

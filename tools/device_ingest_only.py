@@ -21,7 +21,7 @@ try:
         t0 = time.perf_counter()
         out = FD.ingest_file(p, ctx, dev, timings=tm)
         torch.cuda.synchronize()
-        print(json.dumps({"seconds": round(time.perf_counter() - t0, 4), "stages": {k: round(v, 4) for k, v in tm.items()}, "unique": out["n_unique"]}), flush=True)
+        print(json.dumps({"seconds": round(time.perf_counter() - t0, 4), "stages": {k: round(v, 4) for k, v in tm.items()}, "unique": out["n_unique"], "finish_trace_ms": out.get("finish_trace_ms")}), flush=True)
         del out
 finally:
     os.remove(p)
