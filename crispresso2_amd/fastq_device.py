@@ -46,6 +46,14 @@ def usable_cpus():
     return max(1, n)
 
 
+def copy_threads():
+    """host threads that copy the text into pinned memory.  Not all the CPUs the container may use: under a CFS quota a process that
+    exceeds it is stopped for the rest of the 100 ms period -- every thread of it, also the one that enqueues the kernels"""
+    if os.environ.get("C2_FQ_COPY_THREADS"):
+        return max(1, int(os.environ["C2_FQ_COPY_THREADS"]))
+    return max(2, min(16, usable_cpus() // 2))
+
+
 # ---- the four launches (tests replace these with the wave emulator's entries) ----
 def fq_count(ctx, d_text, lo, hi, d_tile_nl, d_tile_empty, d_flags, stream):
     import ctypes
@@ -310,11 +318,17 @@ class DeviceIngest:
             rc_partner = torch.where(pslot >= 0, unique_of_slot[pslot.to(torch.int64).clamp_(min=0)], -1).cpu().numpy()
         lap("multiplicities and lengths on the host")
         off64 = np.zeros(n + 1, dtype=np.int64)
+        lap("zeros")
         np.cumsum(lens_h, out=off64[1:])
+        lap("cumsum")
         offsets = off64.view(np.uint64)
+        mx, mn = (int(lens_h.max()), int(lens_h.min())) if n else (0, 0)
+        lap("max min")
+        ends = np.cumsum([int(b[0].numel()) for b in self.batches], dtype=np.int64)
+        bb = [int(x) for x in np.diff(off64[np.concatenate([[0], ends])])] if self.batches else []      # bytes of every batch
+        lap("batch bytes")
         out = dict(offsets=offsets, counts=counts, n_reads=n_records, n_empty_records=n_empty, nonempty_lines=nonempty, n_unique=n,
-                   max_len=int(lens_h.max()) if n else 0, min_len=int(lens_h.min()) if n else 0,
-                   batch_bytes=[int(b[1][-1].item()) for b in self.batches], rc_partner=rc_partner)
+                   max_len=mx, min_len=mn, batch_bytes=bb, rc_partner=rc_partner)
         if last is not None and len(self.batches) == 1:
             out["d_reads"], out["d_off"] = last
         lap("offsets")
@@ -373,7 +387,7 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
             return ing.finish(last != b"\n", on_batch)
         import queue
         import threading
-        threads = min(16, usable_cpus())
+        threads = copy_threads()
         key = (chunk, dev.index)
         if key not in _pinned:
             _pinned[key] = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
