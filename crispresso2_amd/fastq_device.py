@@ -21,6 +21,7 @@ import os
 import numpy as np
 
 from . import _native
+from .hostcopy import to_host
 
 TILE = 16384
 CHUNK_BYTES = int(os.environ.get("C2_FQ_DEVICE_CHUNK", 64 << 20))
@@ -302,8 +303,8 @@ class DeviceIngest:
         if self.batches:
             rec = torch.cat([b[0] for b in self.batches])
             lens = torch.cat([b[1][1:] - b[1][:-1] for b in self.batches])
-            counts = self.count[self.slot_of[rec].to(torch.int64)].to(torch.int64).cpu().numpy()
-            lens_h = lens.cpu().numpy()
+            counts = to_host(self.count[self.slot_of[rec].to(torch.int64)], np.int64)     # (32-bit over the link, widened on the host)
+            lens_h = to_host(lens.to(torch.int32), np.int64)
         else:
             counts, lens_h = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
         # which unique read is the reverse complement of which (the count merge asks): looked up in the table, which is still here
@@ -315,7 +316,7 @@ class DeviceIngest:
                           pslot.data_ptr(), self._stream())
             unique_of_slot = torch.full((self.n_slots,), -1, dtype=torch.int64, device=self.dev)
             unique_of_slot[slot_u] = torch.arange(n, dtype=torch.int64, device=self.dev)
-            rc_partner = torch.where(pslot >= 0, unique_of_slot[pslot.to(torch.int64).clamp_(min=0)], -1).cpu().numpy()
+            rc_partner = to_host(torch.where(pslot >= 0, unique_of_slot[pslot.to(torch.int64).clamp_(min=0)], -1).to(torch.int32), np.int64)
         lap("multiplicities and lengths on the host")
         off64 = np.zeros(n + 1, dtype=np.int64)
         lap("zeros")

@@ -1,0 +1,32 @@
+"""Device tensor -> numpy array through pinned staging memory this module keeps.
+
+Why not tensor.cpu(): a device-to-host copy into PAGEABLE memory makes the HIP runtime lock the destination pages for the transfer;
+measured on the MI355X box (profiles/r03/README.md, "Ingest"): after three 28 MB copies of that kind the next small copy -- an .item() --
+took 20-35 ms, every time.  Through a pinned buffer the same three arrays cost their transfer (0.5 ms each at the link's rate) plus one
+host memcpy each, and nothing later pays for them."""
+import numpy as np
+
+_staging = {}
+
+
+def to_host(t, dtype=None):
+    """-> a numpy array that owns its memory (dtype: converted on the host while copying out of the staging buffer).  Waits for the
+    current stream of the tensor's device."""
+    import torch
+    if t.device.type != "cuda":
+        a = t.numpy()
+        return a.astype(dtype) if dtype is not None else a.copy()
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0:
+        return np.zeros(tuple(t.shape), dtype=dtype or t.numpy(force=True).dtype)
+    key = t.device.index
+    buf = _staging.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, pin_memory=True)
+        _staging[key] = buf
+    view = buf[:nbytes].view(t.dtype).view(t.shape)
+    view.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    a = view.numpy()
+    return a.astype(dtype) if dtype is not None else a.copy()

@@ -22,6 +22,7 @@ import numpy as np
 
 from . import _native
 from . import counts as C
+from .hostcopy import to_host
 from .batch import BatchAligner, score_from_counts
 
 def strand_plans(arena, offsets, refs, ref_names, args):
@@ -206,7 +207,7 @@ class _DevicePartners:
     def result(self):
         if bool(self._bad.item()):
             return None
-        return self._partner.cpu().numpy()
+        return to_host(self._partner)
 
 
 def rc_partners_device(d_reads2d):
@@ -306,7 +307,7 @@ def _device_front(path, aligner, ctx, dev, refs, ref_names, args, legacy, timing
     ing = fastq_device.ingest_file(path, ctx, dev, timings=timings, on_batch=on_batch, min_batch=STREAM_MIN_BATCH)
     n = ing["n_unique"]
     a1, f1, r1, d_plan, stride = _join_first_batches(parts, aligner, dev)
-    plan = d_plan.cpu().numpy().reshape(n, k)
+    plan = to_host(d_plan).reshape(n, k)
     if len(parts) == 1:
         d_reads_all, d_off_all = parts[0][5], parts[0][6]
     elif parts:
@@ -420,7 +421,7 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
         counts = np.delete(counts, dropped)
     arena = fq.arena[:int(offsets[-1])]
     a1, f1, r1, d_plan, stride = _join_first_batches(parts, aligner, dev)
-    plan = d_plan.cpu().numpy().reshape(n, k)                          # (waits for the last batch)
+    plan = to_host(d_plan).reshape(n, k)                               # (waits for the last batch)
     d_reads_all = None
     if parts and n >= RC_PARTNERS_ON_DEVICE_MIN:                       # (kept for the partner search on the device)
         d_reads_all = parts[0][5] if len(parts) == 1 else torch.cat([p_[5][:int(o[-1] - o[0])] for p_, o in zip(parts, off_parts)])
@@ -664,7 +665,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             d_plan = torch.empty(n * k, dtype=torch.uint8, device=dev)
             C.strand_plan_device(ctx, n, d_reads.data_ptr(), d_off.data_ptr(), max_lj, refs, ref_names, args.aln_seed_count, args.aln_seed_min,
                                  d_plan.data_ptr(), stream=stream)
-            plan = d_plan.cpu().numpy().reshape(n, k)
+            plan = to_host(d_plan).reshape(n, k)
         lap("strand_plan")
         stride = aligner.stride_for(max_lj)
 
@@ -730,9 +731,9 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
                 raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
             raise Exception('global_align: undefined alignment (status %d)' % int(st["a_bad_status"]))
         bits = np.arange(k, dtype=np.uint64)[None, :]
-        member = ((d_member.cpu().numpy().view(np.uint64)[:, None] >> bits) & np.uint64(1)).astype(bool)
-        use2 = ((d_use2.cpu().numpy().view(np.uint64)[:, None] >> bits) & np.uint64(1)).astype(bool)
-        aligned = (d_flags.cpu().numpy() & 1) != 0
+        member = ((to_host(d_member).view(np.uint64)[:, None] >> bits) & np.uint64(1)).astype(bool)
+        use2 = ((to_host(d_use2).view(np.uint64)[:, None] >> bits) & np.uint64(1)).astype(bool)
+        aligned = (to_host(d_flags) & 1) != 0
         for q in ('N_COMPUTED_ALN', 'N_COMPUTED_NOTALN', 'N_CACHED_ALN', 'N_CACHED_NOTALN', 'N_GLOBAL_SUBS', 'N_SUBS_OUTSIDE_WINDOW',
                   'N_MODS_IN_WINDOW', 'N_MODS_OUTSIDE_WINDOW', 'N_READS_IRREGULAR_ENDS'):
             stats[q] = int(st[q])
