@@ -1,4 +1,4 @@
-"""Device tensor -> numpy array through pinned staging memory this module keeps.
+"""Device tensor <-> numpy array through pinned staging memory this module keeps.
 
 Why not tensor.cpu(): a device-to-host copy into PAGEABLE memory makes the HIP runtime lock the destination pages for the transfer;
 measured on the MI355X box (profiles/r03/README.md, "Ingest"): after three 28 MB copies of that kind the next small copy -- an .item() --
@@ -30,3 +30,23 @@ def to_host(t, dtype=None):
     torch.cuda.current_stream(t.device).synchronize()
     a = view.numpy()
     return a.astype(dtype) if dtype is not None else a.copy()
+
+
+def to_device(a, dev):
+    """numpy array -> tensor on `dev` (same dtype and shape), staged through the pinned buffer: the array's own (pageable, freshly mapped)
+    pages are never registered with the driver.  Small arrays and non-GPU devices: torch's own copy."""
+    import torch
+    a = np.ascontiguousarray(a)
+    if dev.type != "cuda" or a.nbytes < (1 << 20):
+        return torch.from_numpy(a if a.flags.writeable else a.copy()).to(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    buf = _staging.get(key)
+    if buf is None or buf.numel() < a.nbytes:
+        buf = torch.empty(max(a.nbytes, 64 << 20), dtype=torch.uint8, pin_memory=True)
+        _staging[key] = buf
+    flat = a.reshape(-1).view(np.uint8)
+    buf.numpy()[:a.nbytes] = flat
+    out = torch.empty(a.nbytes, dtype=torch.uint8, device=dev)
+    out.copy_(buf[:a.nbytes], non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()                      # (the staging buffer is free again)
+    return out.view(torch.from_numpy(np.zeros(1, dtype=a.dtype)).dtype).view(a.shape)

@@ -22,7 +22,7 @@ import numpy as np
 
 from . import _native
 from . import counts as C
-from .hostcopy import to_host
+from .hostcopy import to_host, to_device
 from .batch import BatchAligner, score_from_counts
 
 def strand_plans(arena, offsets, refs, ref_names, args):
@@ -670,7 +670,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         stride = aligner.stride_for(max_lj)
 
         # ---- batch 1: every read against every reference, on the strand the seeds ask for (forward when they ask for both)
-        d_str1 = torch.from_numpy((plan == 1).astype(np.uint8).reshape(-1)).to(dev)
+        d_str1 = to_device((plan == 1).astype(np.uint8).reshape(-1), dev)
         a1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
         f1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
         r1 = torch.empty((n1, 32), dtype=torch.uint8, device=dev)
@@ -713,19 +713,21 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         slot2[bi, br] = np.arange(n2)
     mode = C.select_mode(args)
     on_device = k <= 64 and max(stride, stride2) <= C.SELECT_MAX_ALN_LEN and not FORCE_HOST_SELECTION
-    d_slot2 = torch.from_numpy(slot2.astype(np.int32).reshape(-1)).to(dev) if n2 else None
+    d_slot2 = to_device(slot2.astype(np.int32).reshape(-1), dev) if n2 else None
     if on_device:
         d_member = torch.zeros(n, dtype=torch.int64, device=dev)
         d_use2 = torch.zeros(n, dtype=torch.int64, device=dev)
         d_flags = torch.zeros(n, dtype=torch.uint8, device=dev)
         d_stats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
-        d_raw = torch.from_numpy(raw.astype(np.uint32).view(np.int32)).to(dev)
+        d_raw = to_device(raw.astype(np.uint32).view(np.int32), dev)
         min_mscore = C.min_mscore_table(min_scores)
+        lap("selection_inputs")
         C.select_best_device(ctx, n, k, r1.data_ptr(), min_mscore, mode, max(stride, stride2),
                              d_records2=r2.data_ptr() if n2 else None, d_slot2=d_slot2.data_ptr() if n2 else None,
                              d_raw_counts=d_raw.data_ptr(), d_member=d_member.data_ptr(), d_use2=d_use2.data_ptr(),
                              d_flags=d_flags.data_ptr(), d_stats=d_stats.data_ptr(), stream=stream)
         st = dict(zip(C.SELECT_STATS, d_stats.cpu().numpy().tolist()))
+        lap("selection_kernel")
         if st["n_bad_status"]:
             if int(st["a_bad_status"]) & _native.STATUS_RC_CHAR:
                 raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
@@ -814,7 +816,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if on_device:
         # the weight of every alignment in the count pass: the kernel again, now with the merged multiplicities (a read the
         # scaffold rule took away counts for no amplicon here)
-        d_cnt = torch.from_numpy(np.where(scaffold_hit, 0, cnt).astype(np.uint32).view(np.int32)).to(dev)
+        d_cnt = to_device(np.where(scaffold_hit, 0, cnt).astype(np.uint32).view(np.int32), dev)
         d_w1 = torch.zeros(n1, dtype=torch.int32, device=dev)
         if n2:
             d_w2 = torch.zeros(n2, dtype=torch.int32, device=dev)
