@@ -681,6 +681,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     # ---- batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments
     bi, br = np.nonzero(plan == 2)
     n2 = len(bi)
+    lap("both_strand_list")
     r2 = a2 = f2 = None
     stride2 = stride
     if n2:
@@ -732,10 +733,11 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             if int(st["a_bad_status"]) & _native.STATUS_RC_CHAR:
                 raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
             raise Exception('global_align: undefined alignment (status %d)' % int(st["a_bad_status"]))
-        bits = np.arange(k, dtype=np.uint64)[None, :]
-        member = ((to_host(d_member).view(np.uint64)[:, None] >> bits) & np.uint64(1)).astype(bool)
-        use2 = ((to_host(d_use2).view(np.uint64)[:, None] >> bits) & np.uint64(1)).astype(bool)
-        aligned = (to_host(d_flags) & 1) != 0
+        # the kernel's 64-bit masks (bit r: reference r) are taken apart on the device: n x k bytes cross the link, not 16 n
+        bits = torch.arange(k, dtype=torch.int64, device=dev)[None, :]
+        member = to_host(((d_member[:, None] >> bits) & 1).to(torch.uint8)).view(bool)
+        use2 = to_host(((d_use2[:, None] >> bits) & 1).to(torch.uint8)).view(bool)
+        aligned = to_host(d_flags & 1).view(bool)
         for q in ('N_COMPUTED_ALN', 'N_COMPUTED_NOTALN', 'N_CACHED_ALN', 'N_CACHED_NOTALN', 'N_GLOBAL_SUBS', 'N_SUBS_OUTSIDE_WINDOW',
                   'N_MODS_IN_WINDOW', 'N_MODS_OUTSIDE_WINDOW', 'N_READS_IRREGULAR_ENDS'):
             stats[q] = int(st[q])
