@@ -24,7 +24,7 @@ from . import _native
 from .hostcopy import to_host
 
 TILE = 16384
-CHUNK_BYTES = int(os.environ.get("C2_FQ_DEVICE_CHUNK", 64 << 20))
+CHUNK_BYTES = int(os.environ.get("C2_FQ_DEVICE_CHUNK", 128 << 20))
 MIN_TEXT_BYTES = int(os.environ.get("C2_FQ_DEVICE_MIN", 64 << 20))      # below this the host parser is as fast and needs no table
 MAX_TEXT_BYTES = 1 << 36                                                 # 64 GiB of text resident; beyond: the host parser
 _pinned = {}
