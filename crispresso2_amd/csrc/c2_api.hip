@@ -1182,7 +1182,7 @@ int c2_select_best_device(c2_ctx* ctx, uint64_t n_reads, int32_t n_refs, const c
                           const uint32_t* d_raw_counts, const uint32_t* d_counts, int32_t mode, int32_t max_aln_len,
                           uint64_t* d_member, uint64_t* d_use2, uint8_t* d_flags, uint32_t* d_weights, uint32_t* d_weights2,
                           uint64_t* d_stats, void* hip_stream) {
-    if (!ctx || !d_records || !h_min_mscore || n_refs <= 0 || n_refs > 64 || mode < 0 || mode > 2) { if (ctx) ctx->err = "bad selection arguments"; return C2_E_INVALID; }
+    if (!ctx || !d_records || !h_min_mscore || n_refs <= 0 || n_refs > 32767 || mode < 0 || mode > 2) { if (ctx) ctx->err = "bad selection arguments"; return C2_E_INVALID; }
     if ((d_records2 != nullptr) != (d_slot2 != nullptr)) { ctx->err = "d_records2 and d_slot2 go together"; return C2_E_INVALID; }
     static_assert(C2_SEL_STATS == C2_SELECT_STATS, "selection statistics");
     // the integer form of round(100*matches/len, 3) is exact below 8000 columns (c2_mscore)
@@ -1192,7 +1192,8 @@ int c2_select_best_device(c2_ctx* ctx, uint64_t n_reads, int32_t n_refs, const c
     hipStream_t s = (hipStream_t)hip_stream;
     int rc;
     // thresholds: a small device table, re-uploaded when it changes
-    if ((rc = ensure(ctx, ctx->d_sel, 64 * sizeof(uint32_t)))) return rc;
+    if ((size_t)n_refs * sizeof(uint32_t) > ctx->d_sel.cap) { HIPCHK(ctx, hipDeviceSynchronize()); ctx->sel_table.clear(); }      // (the table moves: nothing may still read the old one)
+    if ((rc = ensure(ctx, ctx->d_sel, (size_t)std::max(n_refs, 64) * sizeof(uint32_t)))) return rc;
     if (ctx->sel_table.size() != (size_t)n_refs || memcmp(ctx->sel_table.data(), h_min_mscore, (size_t)n_refs * 4) != 0) {
         HIPCHK(ctx, hipStreamSynchronize(s));          // no earlier launch may still read the old table
         HIPCHK(ctx, hipMemcpy(ctx->d_sel.p, h_min_mscore, (size_t)n_refs * 4, hipMemcpyHostToDevice));

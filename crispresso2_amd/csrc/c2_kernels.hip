@@ -2387,50 +2387,66 @@ __global__ __launch_bounds__(256) void c2_select_best_kernel(c2_select_args A)
     for (int q = 0; q < C2_SEL_STATS; ++q) st[q] = 0;
     if (read < A.n_reads) {
         const int k = A.n_refs;
-        long long best = -1;
-        unsigned long long member = 0, use2 = 0;
-        int last = -1; bool last2 = false;
-        for (int r = 0; r < k; ++r) {
+        const int W = (k + 63) >> 6;                                         // 64-bit words of a read's masks (bit r of word r / 64: reference r)
+        // the score the choice compares for (read, reference r), and whether it is the reverse-complement batch's (:683)
+        auto score_of = [&](const int r, bool& second, const bool tally) -> long long {
             const uint64_t t = read * (uint64_t)k + (uint64_t)r;
             const c2_aln_record* rec = A.records + t;
             // (what the choice needs of a record -- length, matches, status -- with two loads instead of one per field)
             const unsigned w0 = ((const unsigned*)rec)[0], w5 = ((const unsigned*)rec)[5];
             const unsigned rstatus = w5 >> 24;
-            if (rstatus != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rstatus; }
+            if (tally && rstatus != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rstatus; }
             long long ms = (long long)c2_mscore(w0 >> 16, w0 & 0xffffu);
-            bool second = false;
+            second = false;
             if (A.records2 && A.slot2) {
                 const int sl = A.slot2[t];
                 if (sl >= 0) {
                     const c2_aln_record* rec2 = A.records2 + sl;
-                    if (rec2->status != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rec2->status; }
+                    if (tally && rec2->status != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rec2->status; }
                     const long long ms2 = (long long)c2_mscore(rec2->matches, rec2->aln_len);
                     if (ms2 > ms) { ms = ms2; second = true; }              // :683  if (rvscore > fwscore)
                 }
             }
-            if (second) use2 |= 1ull << r;
-            if (ms > best && ms >= (long long)A.min_mscore[r]) { best = ms; member = 1ull << r; last = r; last2 = second; }   // :697
-            else if (ms == best) { member |= 1ull << r; last = r; last2 = second; }                                           // :703
+            return ms;
+        };
+        // pass 1: the best score, where it was set, how many references share it, the last of them.  The reference's loop
+        // (:697 `if score > best_match_score and score > min_aln_score: best_match_names = [name]`, :703 `elif score == best_match_score:
+        // append`) makes reference r a best match iff its score equals the final best AND r is not in front of the reference that set
+        // it (one in front with that score did not pass its threshold, or it would have set the best itself).
+        long long best = -1;
+        int first = -1, last = -1, nb = 0; bool last2 = false;
+        for (int r = 0; r < k; ++r) {
+            bool second;
+            const long long ms = score_of(r, second, true);
+            if (ms > best && ms >= (long long)A.min_mscore[r]) { best = ms; first = r; nb = 1; last = r; last2 = second; }   // :697
+            else if (ms == best) { ++nb; last = r; last2 = second; }                                                           // :703
         }
         const bool aligned = best > 0;                                       // :710
-        if (!aligned) member = 0;
-        const int nb = __popcll(member);
-        unsigned long long counted = member;
-        bool ambiguous = false;
-        if (nb > 1) {
-            if (A.mode == C2_SEL_MODE_FIRST) counted = member & (~member + 1ull);
-            else if (A.mode != C2_SEL_MODE_EXPAND) { counted = 0; ambiguous = true; }
-        }
-        if (A.member) A.member[read] = member;
-        if (A.use2) A.use2[read] = use2;
+        const bool ambiguous = aligned && nb > 1 && A.mode != C2_SEL_MODE_FIRST && A.mode != C2_SEL_MODE_EXPAND;
         if (A.flags) A.flags[read] = (uint8_t)((aligned ? C2_SEL_FLAG_ALIGNED : 0) | (ambiguous ? C2_SEL_FLAG_AMBIGUOUS : 0));
-        const uint32_t w = A.counts ? A.counts[read] : 1u;
-        if (A.weights) {
+        // pass 2: the masks, a word at a time, and the weight of every alignment in the count pass
+        if (A.member || A.use2 || A.weights) {
+            const uint32_t w = A.counts ? A.counts[read] : 1u;
+            unsigned long long member = 0, use2 = 0;
             for (int r = 0; r < k; ++r) {
-                const uint64_t t = read * (uint64_t)k + (uint64_t)r;
-                const bool c = (counted >> r) & 1ull, u = (use2 >> r) & 1ull;
-                A.weights[t] = (c && !u) ? w : 0u;
-                if (A.weights2 && A.slot2 && A.slot2[t] >= 0) A.weights2[A.slot2[t]] = (c && u) ? w : 0u;
+                bool second;
+                const long long ms = score_of(r, second, false);
+                const bool m = aligned && r >= first && ms == best;
+                // counted: every best match (one of them, or --expand_ambiguous_alignments), the first one
+                // (--assign_ambiguous_alignments_to_first_reference), none when the read is ambiguous
+                const bool c = m && (nb == 1 || A.mode == C2_SEL_MODE_EXPAND || (A.mode == C2_SEL_MODE_FIRST && r == first));
+                if (m) member |= 1ull << (r & 63);
+                if (second) use2 |= 1ull << (r & 63);
+                if (A.weights) {
+                    const uint64_t t = read * (uint64_t)k + (uint64_t)r;
+                    A.weights[t] = (c && !second) ? w : 0u;
+                    if (A.weights2 && A.slot2 && A.slot2[t] >= 0) A.weights2[A.slot2[t]] = (c && second) ? w : 0u;
+                }
+                if ((r & 63) == 63 || r == k - 1) {
+                    if (A.member) A.member[read * (uint64_t)W + (uint64_t)(r >> 6)] = member;
+                    if (A.use2) A.use2[read * (uint64_t)W + (uint64_t)(r >> 6)] = use2;
+                    member = 0; use2 = 0;
+                }
             }
         }
         // aln_stats of process_fastq (:1974-1979): payload of the LAST best match, raw multiplicity

@@ -140,8 +140,8 @@ FORCE_HOST_STRAND_PLAN = False      # tests: the host's c2_strand_plan instead o
 
 def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
     """Strand / best-reference choice and aln_stats from the records on the host, with the reference's float comparisons on
-    scores formed by its own expression -- the route for more than 64 amplicons in one all-references batch or alignments
-    of 8000 columns and more (what c2_select_best_kernel's masks / integer scores do not cover).  -> member, use2, aligned"""
+    scores formed by its own expression -- the route for alignments of 8000 columns and more (what c2_select_best_kernel's
+    integer scores do not cover), and the restatement the tests compare the kernel with (FORCE_HOST_SELECTION).  -> member, use2, aligned"""
     rec1 = r1.cpu().numpy().view(_native.REC_DTYPE).reshape(n, k)
     rec2 = r2.cpu().numpy().view(_native.REC_DTYPE).reshape(-1) if n2 else None
     for rec in (rec1.reshape(-1), rec2 if rec2 is not None else rec1.reshape(-1)[:0]):
@@ -713,11 +713,12 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if n2:
         slot2[bi, br] = np.arange(n2)
     mode = C.select_mode(args)
-    on_device = k <= 64 and max(stride, stride2) <= C.SELECT_MAX_ALN_LEN and not FORCE_HOST_SELECTION
+    on_device = max(stride, stride2) <= C.SELECT_MAX_ALN_LEN and not FORCE_HOST_SELECTION
     d_slot2 = to_device(slot2.astype(np.int32).reshape(-1), dev) if n2 else None
     if on_device:
-        d_member = torch.zeros(n, dtype=torch.int64, device=dev)
-        d_use2 = torch.zeros(n, dtype=torch.int64, device=dev)
+        words = (k + 63) // 64                                        # 64-bit words of a read's masks (bit r % 64 of word r / 64: reference r)
+        d_member = torch.zeros((n, words), dtype=torch.int64, device=dev)
+        d_use2 = torch.zeros((n, words), dtype=torch.int64, device=dev)
         d_flags = torch.zeros(n, dtype=torch.uint8, device=dev)
         d_stats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
         d_raw = to_device(raw.astype(np.uint32).view(np.int32), dev)
@@ -734,9 +735,10 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
                 raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
             raise Exception('global_align: undefined alignment (status %d)' % int(st["a_bad_status"]))
         # the kernel's 64-bit masks (bit r: reference r) are taken apart on the device: n x k bytes cross the link, not 16 n
-        bits = torch.arange(k, dtype=torch.int64, device=dev)[None, :]
-        member = to_host(((d_member[:, None] >> bits) & 1).to(torch.uint8)).view(bool)
-        use2 = to_host(((d_use2[:, None] >> bits) & 1).to(torch.uint8)).view(bool)
+        ref_ix = torch.arange(k, dtype=torch.int64, device=dev)
+        word_of, bit_of = ref_ix >> 6, (ref_ix & 63)[None, :]
+        member = to_host(((d_member[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool)
+        use2 = to_host(((d_use2[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool)
         aligned = to_host(d_flags & 1).view(bool)
         for q in ('N_COMPUTED_ALN', 'N_COMPUTED_NOTALN', 'N_CACHED_ALN', 'N_CACHED_NOTALN', 'N_GLOBAL_SUBS', 'N_SUBS_OUTSIDE_WINDOW',
                   'N_MODS_IN_WINDOW', 'N_MODS_OUTSIDE_WINDOW', 'N_READS_IRREGULAR_ENDS'):

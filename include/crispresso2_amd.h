@@ -183,13 +183,13 @@ int c2_comm_destroy(c2_ctx* ctx);
  * d_slot2 (n_reads x n_refs, -1 = none) says where.  h_min_mscore: HOST table of n_refs thresholds -- the smallest integer
  * k with k/1000.0 > refs[name]['min_aln_score'] (scores are round(100*matches/len, 3), compared as 1000 x score).
  * mode: 0 ambiguous reads count for no reference, 1 --assign_ambiguous_alignments_to_first_reference,
- * 2 --expand_ambiguous_alignments.  Outputs (device pointers, any may be NULL): d_member / d_use2 one 64-bit mask per read
- * (bit r: reference r is a best match / its reverse-complement alignment won), d_flags one byte per read (1 aligned,
+ * 2 --expand_ambiguous_alignments.  Outputs (device pointers, any may be NULL): d_member / d_use2 ceil(n_refs / 64) 64-bit words per read
+ * (bit r % 64 of word r / 64: reference r is a best match / its reverse-complement alignment won), d_flags one byte per read (1 aligned,
  * 2 ambiguous), d_weights (n_reads x n_refs) and d_weights2 (one per d_records2 entry): the multiplicity with which each
  * alignment enters c2_count_vectors_device, formed from d_counts (NULL = 1); d_stats: 11 uint64 sums, the caller zeroes
  * them -- N_COMPUTED_ALN, N_COMPUTED_NOTALN, N_CACHED_ALN, N_CACHED_NOTALN, N_GLOBAL_SUBS, N_SUBS_OUTSIDE_WINDOW,
  * N_MODS_IN_WINDOW, N_MODS_OUTSIDE_WINDOW, N_READS_IRREGULAR_ENDS (CRISPRessoCORE.py:1974-1979, weighted with d_raw_counts),
- * records with a non-zero status, one such status.  n_refs <= 64; alignments of 8000 columns or more are refused
+ * records with a non-zero status, one such status.  Alignments of 8000 columns or more are refused
  * (C2_E_TOO_LARGE: max_aln_len states the bound the caller guarantees).  Enqueued on hip_stream. */
 #define C2_SELECT_STATS 11
 int c2_select_best_device(c2_ctx* ctx, uint64_t n_reads, int32_t n_refs, const c2_aln_record* d_records,

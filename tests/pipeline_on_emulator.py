@@ -134,7 +134,7 @@ def _accumulate(aligners):
 def _select(ctx, n_reads, n_refs, d_records, min_mscore, mode, max_aln_len, d_records2=None, d_slot2=None, d_raw_counts=None,
             d_counts=None, d_member=None, d_use2=None, d_flags=None, d_weights=None, d_weights2=None, d_stats=None, stream=None):
     """counts.select_best_device -> c2_select_best_kernel on the emulator (same arguments)"""
-    assert n_refs <= 64 and max_aln_len < 8000
+    assert max_aln_len < 8000
     mm = np.ascontiguousarray(min_mscore, dtype=np.uint32)
     P = lambda x: ctypes.c_void_p(x or 0)
     rc = E.lib().emu_select_best(ctypes.c_uint64(n_reads), int(n_refs), P(d_records), P(d_records2), P(d_slot2),

@@ -35,7 +35,8 @@ def test_min_mscore_table_matches_the_float_comparison():
 def _run_kernel(rec1, rec2, slot2, thr, raw, cnt, mode):
     n, k = rec1.shape
     lib = E.lib()
-    member = np.zeros(n, dtype=np.uint64); use2 = np.zeros(n, dtype=np.uint64); flags = np.zeros(n, dtype=np.uint8)
+    words = (k + 63) // 64                                    # per read: bit r % 64 of word r / 64 = reference r
+    member = np.zeros((n, words), dtype=np.uint64); use2 = np.zeros((n, words), dtype=np.uint64); flags = np.zeros(n, dtype=np.uint8)
     w1 = np.full(n * k, 77, dtype=np.uint32)
     w2 = np.full(max(len(rec2), 1), 77, dtype=np.uint32)
     stats = np.zeros(len(C.SELECT_STATS), dtype=np.uint64)
@@ -49,10 +50,10 @@ def _run_kernel(rec1, rec2, slot2, thr, raw, cnt, mode):
 
 
 @pytest.mark.parametrize("mode", [C.SELECT_DROP_AMBIGUOUS, C.SELECT_FIRST, C.SELECT_EXPAND])
-@pytest.mark.parametrize("k", [1, 3, 7])
+@pytest.mark.parametrize("k", [1, 3, 7, 64, 70, 130])
 def test_select_kernel_equals_the_reference_loop(mode, k):
     rng = np.random.default_rng(100 * k + mode)
-    n = 700                                                   # three workgroups of 256, the last one ragged
+    n = 700 if k < 64 else 300                                # three workgroups of 256, the last one ragged (k >= 64: masks of 1-3 words)
     rec1 = np.zeros((n, k), dtype=E.REC_DTYPE)
     T = rng.integers(200, 520, (n, k))
     # few distinct scores, so that ties between references and between strands are common
@@ -74,7 +75,7 @@ def test_select_kernel_equals_the_reference_loop(mode, k):
         rec2[f] = rec1[f][bi, br] + 1
     slot2 = np.full((n, k), -1, dtype=np.int32)
     slot2[bi, br] = np.arange(len(bi))
-    thr = [60.0, 59.0, 0.0, 61.5, 60.0, 99.0, 60.0][:k]
+    thr = ([60.0, 59.0, 0.0, 61.5, 60.0, 99.0, 60.0] * 19)[:k]
     raw = rng.integers(1, 50, n).astype(np.uint32)
     cnt = (raw + rng.integers(0, 5, n)).astype(np.uint32)
     member, use2, flags, w1, w2, stats = _run_kernel(rec1, rec2, slot2, thr, raw, cnt, mode)
@@ -85,8 +86,8 @@ def test_select_kernel_equals_the_reference_loop(mode, k):
         s_fw = [sc(rec1[i, r]) for r in range(k)]
         s_rc = [sc(rec2[slot2[i, r]]) if slot2[i, r] >= 0 else None for r in range(k)]
         best, use_rc, aligned, counted, ambiguous = AG.select_best(s_fw, s_rc, thr, assign_first=mode == C.SELECT_FIRST, expand=mode == C.SELECT_EXPAND)
-        assert int(member[i]) == sum(1 << r for r in best), i
-        assert int(use2[i]) == sum(1 << r for r in range(k) if use_rc[r]), i
+        assert sum(int(x) << (64 * q) for q, x in enumerate(member[i])) == sum(1 << r for r in best), i
+        assert sum(int(x) << (64 * q) for q, x in enumerate(use2[i])) == sum(1 << r for r in range(k) if use_rc[r]), i
         assert int(flags[i]) == (1 if aligned else 0) | (2 if ambiguous else 0), i
         for r in range(k):
             assert int(w1[i, r]) == (int(cnt[i]) if (r in counted and not use_rc[r]) else 0), (i, r)

@@ -828,3 +828,57 @@ def test_device_ingest_with_both_strand_reads_and_partners(tmp_path, monkeypatch
         assert st == st0 and al == al0
         for kk, vv in pr0.items():
             assert np.array_equal(vv, pr[kk]) if isinstance(vv, np.ndarray) else vv == pr[kk], kk
+
+
+def _many_references_run(tmp_path, ctx=None, n_refs=70):
+    """more references than one 64-bit mask holds: the device selection (two words per read) against the host restatement of the
+    reference's loop (pipeline._select_on_host) -- statistics, tensors, allele rows; some references are identical (ties: ambiguous reads)"""
+    from crispresso2_amd import pipeline, refs as RF
+    rng = np.random.default_rng(70)
+    L = 64
+    seqs = ["".join(rng.choice(list("ACGT"), L)) for _ in range(n_refs)]
+    seqs[66] = seqs[2]                                              # a tie across the word boundary
+    seqs[69] = seqs[65]                                             # ... and inside the second word
+    names = ["amp%d" % i for i in range(n_refs)]
+    refs = {nm: RF.make_ref(nm, sq, [L // 2], [L // 2 - 1, L // 2], min_aln_score=60) for nm, sq in zip(names, seqs)}
+    reads = []
+    for i in (0, 2, 2, 63, 64, 65, 65, 66, 69, 33, 68):
+        s_ = list(seqs[i])
+        if i % 3 == 0:
+            s_[10] = "A" if s_[10] != "A" else "C"
+        reads.append("".join(s_))
+    reads.append(seqs[40][:30] + seqs[40][34:])                     # a deletion
+    reads.append("".join(rng.choice(list("ACGT"), L)))              # aligns to nothing
+    fq = tmp_path / "many.fastq"
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (k, s_, "I" * len(s_)) for k, s_ in enumerate(reads)))
+    out = []
+    for host, mode in ((False, {}), (True, {}), (False, {"expand_ambiguous_alignments": True}), (True, {"expand_ambiguous_alignments": True}),
+                       (False, {"assign_ambiguous_alignments_to_first_reference": True}), (True, {"assign_ambiguous_alignments_to_first_reference": True})):
+        pipeline.FORCE_HOST_SELECTION = host
+        try:
+            res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(mode), ctx=ctx)
+        finally:
+            pipeline.FORCE_HOST_SELECTION = False
+        out.append(res)
+    for dev_res, host_res in zip(out[0::2], out[1::2]):
+        assert dev_res.stats == host_res.stats
+        assert dev_res.alleles() == host_res.alleles()
+        for nm in names:
+            for kk, vv in dev_res.per_ref[nm].items():
+                ww = host_res.per_ref[nm][kk]
+                assert np.array_equal(vv, ww) if isinstance(vv, np.ndarray) else vv == ww, (nm, kk)
+    assert out[0].stats["N_AMBIGUOUS"] >= 5                          # the reads of the identical amplicons
+    assert out[2].per_ref["amp66"]["counts_total"] == out[2].per_ref["amp2"]["counts_total"] >= 2       # expanded: counted for both
+    assert out[4].per_ref["amp66"]["counts_total"] == 0 and out[4].per_ref["amp2"]["counts_total"] >= 2   # first reference only
+
+
+def test_more_than_64_references_select_on_the_device_emulator(tmp_path):
+    from pipeline_on_emulator import emulated_device
+    with emulated_device():
+        _many_references_run(tmp_path)
+
+
+@pytest.mark.gpu
+def test_more_than_64_references_select_on_the_device(tmp_path):
+    from crispresso2_amd import _native
+    _many_references_run(tmp_path, ctx=_native.default_context())
