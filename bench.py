@@ -474,10 +474,11 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
     out = {"reads": files["reads"], "file_bytes": files["bytes_plain"], "file_bytes_bgzf": files["bytes_bgzf"],
            "file_system": os.path.dirname(files["dir"]), "write_seconds_not_timed": {"plain": files["write_plain_s"], "bgzf": files["write_bgzf_s"]}}
     tallies = {}
-    for kind, path in (("plain", files["plain"]), ("plain_host_parser", files["plain"]), ("bgzf", files["bgzf"])):
-        # plain: the text is uploaded as it is and framed + de-duplicated by the c2_fq_* kernels (fastq_device); plain_host_parser: the
-        # same file through the native host parser (what compressed or filtered input uses), for comparison
-        os.environ["C2_FQ_INGEST"] = "host" if kind == "plain_host_parser" else "auto"
+    for kind, path in (("plain", files["plain"]), ("plain_host_parser", files["plain"]), ("bgzf", files["bgzf"]), ("bgzf_host_parser", files["bgzf"])):
+        # plain: the text is uploaded as it is and framed + de-duplicated by the c2_fq_* kernels (fastq_device); bgzf: the host inflates
+        # (all usable threads) and the same kernels frame the text it then holds; *_host_parser: the same files through the native host
+        # parser (what text with carriage returns uses), for comparison
+        os.environ["C2_FQ_INGEST"] = "host" if kind.endswith("_host_parser") else "auto"
         runs = []
         for rep in range(repeat + 2):                                # the first run is the warm-up (context, allocations, page cache); the last one
             tm = {} if rep == repeat + 1 else None                    # collects the stage times (a device synchronisation per stage: not a timed run)
@@ -499,11 +500,11 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
     os.environ.pop("C2_FQ_INGEST", None)
     out["reads_per_s"] = out["plain"]["reads_per_s"]
     out["stage_seconds"] = out["plain"]["stage_seconds"]
-    out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"] == tallies["plain_host_parser"]
+    out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"] == tallies["plain_host_parser"] == tallies["bgzf_host_parser"]
     out["tallies"] = dict(zip(("N_TOT_READS", "N_TOTAL", "counts_total", "modified", "with_insertion", "with_deletion", "with_substitution"),
                               tallies["plain"]))
     out["note"] = ("pipeline.quantify_fastq on the headline's reads as a FASTQ file (qualities 'I'), page cache warm: ingest + exact "
-                   "de-duplication (plain: on the device; plain_host_parser / bgzf: the native host parser), seed test, alignments of the unique reads, selection, reverse-complement merge, count kernel; best of %d "
+                   "de-duplication (plain / bgzf: on the device, bgzf after the host inflated it; *_host_parser: the native host parser), seed test, alignments of the unique reads, selection, reverse-complement merge, count kernel; best of %d "
                    "runs after a warm-up; reads/s counts every read of the file" % repeat)
     return out
 

@@ -103,7 +103,7 @@ def load():
                 fn.argtypes = [ctypes.c_void_p]
             lib.c2_fastq_free.restype = None
             lib.c2_fastq_free.argtypes = [ctypes.c_void_p]
-            for fn in (lib.c2_fastq_stream_arena, lib.c2_fastq_stream_offsets):
+            for fn in (lib.c2_fastq_stream_arena, lib.c2_fastq_stream_offsets, lib.c2_fastq_stream_text):
                 fn.restype = ctypes.c_void_p
                 fn.argtypes = [ctypes.c_void_p]
             for fn in (lib.c2_fastq_stream_text_bytes, lib.c2_fastq_stream_n_reads, lib.c2_fastq_stream_nonempty_lines,
@@ -367,6 +367,20 @@ class FastqStream:
         self.arena = (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), (self.text_bytes + 1,))
                       if ptr else np.zeros(1, dtype=np.uint8))
         self.n_unique, self.arena_bytes, self.done = 0, 0, self.text_bytes == 0
+
+    def text(self):
+        """the text next() would parse, as a read-only view of native memory (inflated / filtered / mapped input), or None (a plain file
+        that is read chunk by chunk); valid until close()"""
+        ptr = self._lib.c2_fastq_stream_text(self._h)
+        if not ptr or not self.text_bytes:
+            return None
+        a = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), (self.text_bytes,))
+        a.flags.writeable = False
+        return a
+
+    def lines_input(self):
+        """non-empty lines of the text in front of the read filter (filtered streams)"""
+        return int(self._lib.c2_fastq_stream_nonempty_lines_input(self._h))
 
     def next(self):
         nu, ab, dn = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_int32(0)

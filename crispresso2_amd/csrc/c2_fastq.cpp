@@ -1190,6 +1190,7 @@ int c2_fastq_stream_next(c2_fastq_stream* h, uint64_t* n_unique, uint64_t* arena
 const uint8_t* c2_fastq_stream_arena(const c2_fastq_stream* h) { return h ? h->S.arena.data() : nullptr; }
 const uint64_t* c2_fastq_stream_offsets(const c2_fastq_stream* h) { return h ? h->S.offsets.data() : nullptr; }
 uint64_t c2_fastq_stream_text_bytes(const c2_fastq_stream* h) { return h ? (uint64_t)h->S.n : 0; }
+const uint8_t* c2_fastq_stream_text(const c2_fastq_stream* h) { return h ? (const uint8_t*)h->S.mem : nullptr; }
 uint64_t c2_fastq_stream_n_reads(const c2_fastq_stream* h) { return h ? h->S.n_reads : 0; }
 uint64_t c2_fastq_stream_nonempty_lines(const c2_fastq_stream* h) { return h ? h->S.nonempty_lines : 0; }
 uint64_t c2_fastq_stream_nonempty_lines_input(const c2_fastq_stream* h) { return h ? h->lines_input : 0; }

@@ -108,21 +108,36 @@ def gather_reads_device(ctx, d_reads, d_off, idx, dev, stream):
 
 
 def applicable(path, filters=(0, 0, 0)):
-    """-> None if the device route can take this file, else why not"""
+    """-> None if the device route can take this FILE as it lies on disk, else why not (a reason that starts with "in memory:" means
+    the host has to inflate / filter first and the device can frame the text it then holds: text_applicable)"""
     if os.environ.get("C2_FQ_INGEST", "auto") == "host":
         return "C2_FQ_INGEST=host"
-    if any(filters):
-        return "quality filters run in the host parser"
     try:
         size = os.path.getsize(path)
         with open(path, "rb") as fh:
             magic = fh.read(2)
     except OSError as e:
         return str(e)
+    if any(filters):
+        return "in memory: the quality filters run on the host"
     if magic == b"\x1f\x8b" or str(path).endswith(".gz"):
-        return "compressed text is inflated by the host parser"
+        return "in memory: compressed text is inflated on the host"
     if size < MIN_TEXT_BYTES and os.environ.get("C2_FQ_INGEST", "auto") != "device":
         return "small file"
+    if size > MAX_TEXT_BYTES or size == 0:
+        return "text of %d bytes" % size
+    return None
+
+
+def text_applicable(text):
+    """-> None if the device route can take this text (a uint8 array in host memory), else why not"""
+    if os.environ.get("C2_FQ_INGEST", "auto") == "host":
+        return "C2_FQ_INGEST=host"
+    if text is None:
+        return "the text is not in memory"
+    size = int(text.size)
+    if size < MIN_TEXT_BYTES and os.environ.get("C2_FQ_INGEST", "auto") != "device":
+        return "small text"
     if size > MAX_TEXT_BYTES or size == 0:
         return "text of %d bytes" % size
     return None
@@ -346,17 +361,21 @@ def chunk_bytes(size):
     return max(TILE, want // TILE * TILE)
 
 
-def estimate_records(path, size):
-    """records the file is expected to hold, from the line density of its first MB, with a quarter of slack"""
-    with open(path, "rb") as fh:
-        head = fh.read(1 << 20)
+def estimate_records(source, size):
+    """records the text is expected to hold, from the line density of its first MB, with a quarter of slack"""
+    if isinstance(source, np.ndarray):
+        head = source[:1 << 20].tobytes()
+    else:
+        with open(source, "rb") as fh:
+            head = fh.read(1 << 20)
     nl = head.count(b"\n")
     per_byte = (nl + 1) / max(len(head), 1)
     return int(size * per_byte / 4.0 * 1.25) + 4096
 
 
 def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
-    """the whole file -> DeviceIngest.finish()'s dict.  Host threads copy the text into two pinned buffers in turn; every chunk is framed
+    """path: a plain FASTQ file, or the text itself as a uint8 array in host memory (what the host inflated / filtered).
+    The whole text -> DeviceIngest.finish()'s dict.  Host threads copy the text into three pinned buffers in turn; every chunk is framed
     and de-duplicated on the compute stream while the next one is copied and uploaded.
     on_batch(m, d_reads, d_off, max_len): called (on this thread, with the compute stream current) whenever min_batch new unique reads
     are final, and for the rest at the end -- the caller enqueues their alignments behind the de-duplication, under the upload.
@@ -365,7 +384,8 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
     import torch
     from concurrent.futures import ThreadPoolExecutor
     t0 = time.perf_counter()
-    size = os.path.getsize(path)
+    text = path if isinstance(path, np.ndarray) else None
+    size = int(text.size) if text is not None else os.path.getsize(path)
     on_gpu = dev.type == "cuda"
     ing = DeviceIngest(ctx, dev, size, estimate_records(path, size))
     chunk = chunk_bytes(size)
@@ -381,15 +401,16 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
                 m = uniq - ing.batch_u0
                 d_reads, d_off = ing.take_batch(r1, m, longest)
                 on_batch(m, d_reads, d_off, longest)
-    fd = os.open(path, os.O_RDONLY)
+    fd = os.open(path, os.O_RDONLY) if text is None else -1
     try:
-        last = os.pread(fd, 1, size - 1)
+        last = os.pread(fd, 1, size - 1) if text is None else text[size - 1:].tobytes()
         if not on_gpu:                                                # (tests: the "device" is host memory)
             view = ing.d_text.numpy()
             for lo in range(0, size, chunk):
                 hi = min(size, lo + chunk)
-                got = os.preadv(fd, [memoryview(view[lo:hi])], lo)
-                if got != hi - lo:
+                if text is not None:
+                    view[lo:hi] = text[lo:hi]
+                elif os.preadv(fd, [memoryview(view[lo:hi])], lo) != hi - lo:
                     raise OSError("short read")
                 ing.feed(lo, hi)
                 after_feed()
@@ -408,6 +429,9 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
 
         def read_into(args):
             buf, off, n = args
+            if text is not None:
+                np.copyto(np.frombuffer(buf, dtype=np.uint8, count=n), text[off:off + n])
+                return
             while n:
                 got = os.preadv(fd, [buf[:n]], off)
                 if got <= 0:
@@ -459,4 +483,5 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
             timings["device_dedup_tail"] = time.perf_counter() - t0 - timings["upload_text"]
         return out
     finally:
-        os.close(fd)
+        if fd >= 0:
+            os.close(fd)

@@ -505,9 +505,10 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if device_reads is not None:
         if shard is not None or fastq_stream is not None:
             raise ValueError("device_reads is the single-process route")
-        if isinstance(device_reads, (str, os.PathLike)):
-            # a FASTQ file: framed, de-duplicated AND aligned (batch 1) chunk by chunk under its upload (_device_front)
-            front = _device_front(os.fspath(device_reads), aligner, ctx, dev, refs, ref_names, args, legacy, timings)
+        if isinstance(device_reads, (str, os.PathLike, np.ndarray)):
+            # a FASTQ file, or FASTQ text in host memory: framed, de-duplicated AND aligned (batch 1) chunk by chunk under its upload (_device_front)
+            front = _device_front(device_reads if isinstance(device_reads, np.ndarray) else os.fspath(device_reads), aligner, ctx, dev, refs,
+                                  ref_names, args, legacy, timings)
             device_reads = front["device_reads"]
             t_last[0] = time.perf_counter()
         arena, offsets, read_counts = None, device_reads["offsets"], device_reads["counts"]
@@ -910,31 +911,48 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
         import torch.distributed as dist
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if stream and not sharded and not FORCE_HOST_STRAND_PLAN:
-        # plain text without filters: framed and de-duplicated on the device (fastq_device); anything it cannot take: the host parser
+        # the text framed and de-duplicated on the device (fastq_device): a plain file as it lies on disk; compressed or quality-filtered
+        # input after the host has inflated / filtered it into memory (the native stream holds that text: it is uploaded from there and
+        # the host parser never runs).  Anything the kernels cannot take (carriage returns, ...): the host parser.
         from . import fastq_device
+
+        def on_device(source):
+            res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
+                                  pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=source)
+            _native._line_stats(ingest_stats, res.device_ingest["nonempty_lines"])
+            res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT']
+            res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats['N_READS_AFTER_PREPROCESSING']
+            res.ingest_route = "device"
+            return res
         why_not = fastq_device.applicable(path, flt)
         if why_not is None:
             try:
-                res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
-                                      pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=path)
+                return on_device(path)
             except fastq_device.DeviceIngestUnavailable as e:
                 why_not = str(e)
-            else:
-                _native._line_stats(ingest_stats, res.device_ingest["nonempty_lines"])
-                res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT']
-                res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats['N_READS_AFTER_PREPROCESSING']
-                res.ingest_route = "device"
-                return res
-        if timings is not None:
-            timings["host_parser_because"] = why_not
         fq = None
         try:
-            fq = _native.FastqStream(path, *flt)
+            fq = _native.FastqStream(path, *flt)                     # (inflates / filters a compressed or filtered input: its text is in memory now)
         except _native.NativeError as e:
             if "in-memory budget" not in str(e):                     # (a .gz whose text does not fit in memory streams through zlib below)
                 raise
         if fq is not None:
             with fq:
+                if why_not.startswith("in memory:"):
+                    text = fq.text()
+                    why_not = fastq_device.text_applicable(text)
+                    if why_not is None:
+                        if fq.filtered:
+                            ingest_stats["N_READS_INPUT"] = int(float(fq.lines_input()) / 4.0)
+                        try:
+                            res = on_device(text)
+                            res.ingest_route = "device, text from host memory"
+                            return res
+                        except fastq_device.DeviceIngestUnavailable as e:
+                            why_not = str(e)
+                            ingest_stats.pop("N_READS_INPUT", None)
+                if timings is not None:
+                    timings["host_parser_because"] = why_not
                 res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
                                       pe_scaffold_dna_info=pe_scaffold_dna_info, fastq_stream=fq)
                 fq.line_stats(ingest_stats)
@@ -945,6 +963,8 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
             res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
             res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats.get('N_READS_AFTER_PREPROCESSING', int(n_reads))
             return res
+        if timings is not None:
+            timings["host_parser_because"] = why_not
     with _native.FastqUnique(path, *flt, stats=ingest_stats) as fq:      # views of the native arena: nothing is copied on the host
         arena, offsets, counts, n_reads = fq.arena, fq.offsets, fq.counts, fq.n_reads
         if timings is not None:

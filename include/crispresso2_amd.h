@@ -345,6 +345,10 @@ int c2_fastq_stream_next(c2_fastq_stream* s, uint64_t* n_unique, uint64_t* arena
 const uint8_t* c2_fastq_stream_arena(const c2_fastq_stream* s);
 const uint64_t* c2_fastq_stream_offsets(const c2_fastq_stream* s);
 uint64_t c2_fastq_stream_text_bytes(const c2_fastq_stream* s);
+/* the text that _next parses, when it is in memory (inflated .gz / BGZF input, the read filter's output, a mapped plain file; NULL for a
+ * plain file that is pread() in chunks): a caller that frames it on the device (c2_fq_*_device below) uploads it from here and never
+ * calls _next -- the host then has inflated / filtered, the device parses */
+const uint8_t* c2_fastq_stream_text(const c2_fastq_stream* s);
 uint64_t c2_fastq_stream_n_reads(const c2_fastq_stream* s);
 uint64_t c2_fastq_stream_nonempty_lines(const c2_fastq_stream* s);          /* of the parsed text (after the filter) */
 uint64_t c2_fastq_stream_nonempty_lines_input(const c2_fastq_stream* s);    /* of the text in front of the filter (0 without one) */

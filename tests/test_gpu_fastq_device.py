@@ -95,15 +95,51 @@ def test_whole_run_is_the_same_on_either_route(tmp_path, monkeypatch):
     args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
                            ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
                            assign_ambiguous_alignments_to_first_reference=False, expand_ambiguous_alignments=False, discard_indel_reads=False)
-    monkeypatch.setattr(FD, "CHUNK_BYTES", 4 << 20)
+    import gzip
+    gz = tmp_path / "run.fastq.gz"
+    with gzip.open(gz, "wb", compresslevel=1) as fh:
+        fh.write(fq.read_bytes())
+    monkeypatch.setattr(FD, "CHUNK_BYTES", 2 << 20)
+    monkeypatch.setattr(pipeline, "STREAM_MIN_BATCH", 5000)           # (batches of alignments under the upload)
     results = []
+    for route, path, want in (("host", fq, None), ("device", fq, "device"), ("device", gz, "device, text from host memory"), ("host", gz, None)):
+        monkeypatch.setenv("C2_FQ_INGEST", route)
+        tm = {}
+        res = pipeline.quantify_fastq(str(path), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], args, timings=tm)
+        assert getattr(res, "ingest_route", None) == want
+        assert tm["stream_batches"] >= 3, tm
+        results.append((res.stats, res.per_ref["Reference"], res.alleles()))
+    st0, pr0, al0 = results[0]
+    assert st0["N_TOT_READS"] == len(seqs)
+    for st1, pr1, al1 in results[1:]:
+        assert st0 == st1 and al0 == al1
+        for kk, vv in pr0.items():
+            assert np.array_equal(vv, pr1[kk]) if isinstance(vv, np.ndarray) else vv == pr1[kk], kk
+
+
+def test_filtered_input_on_either_route(tmp_path, monkeypatch):
+    """--min_average_read_quality: the host filters into memory, the device frames the filtered text; = the host parser on the same text"""
+    from crispresso2_amd import pipeline, synth, refs as RF, fastq_device as FD
+    from helpers import matrices
+    L = 150
+    amp, g_, inc = synth.amplicon_setup(L)
+    reads = synth.make_reads(L, 40_000)
+    rng = random.Random(8)
+    fq = tmp_path / "q.fastq"
+    with open(fq, "w") as fh:
+        for k, r in enumerate(reads):
+            s_ = r.tobytes().decode()
+            fh.write("@r%d\n%s\n+\n%s\n" % (k, s_, ("I" if rng.random() < 0.8 else "#") * len(s_)))
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
+    args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                           ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False, min_average_read_quality=30,
+                           assign_ambiguous_alignments_to_first_reference=False, expand_ambiguous_alignments=False, discard_indel_reads=False)
+    monkeypatch.setattr(FD, "CHUNK_BYTES", 2 << 20)
+    out = []
     for route in ("host", "device"):
         monkeypatch.setenv("C2_FQ_INGEST", route)
         res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], args)
-        assert (getattr(res, "ingest_route", None) == "device") == (route == "device")
-        results.append((res.stats, res.per_ref["Reference"], res.alleles()))
-    (st0, pr0, al0), (st1, pr1, al1) = results
-    assert st0 == st1 and al0 == al1
-    assert st0["N_TOT_READS"] == len(seqs)
-    for kk, vv in pr0.items():
-        assert np.array_equal(vv, pr1[kk]) if isinstance(vv, np.ndarray) else vv == pr1[kk], kk
+        assert (getattr(res, "ingest_route", None) == "device, text from host memory") == (route == "device")
+        out.append(res)
+    assert out[0].stats == out[1].stats and out[0].stats["N_READS_INPUT"] == 40_000 and 25_000 < out[0].stats["N_READS_AFTER_PREPROCESSING"] < 38_000
+    assert out[0].alleles() == out[1].alleles()

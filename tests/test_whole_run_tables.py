@@ -882,3 +882,49 @@ def test_more_than_64_references_select_on_the_device_emulator(tmp_path):
 def test_more_than_64_references_select_on_the_device(tmp_path):
     from crispresso2_amd import _native
     _many_references_run(tmp_path, ctx=_native.default_context())
+
+
+@pytest.mark.parametrize("kind", ["filtered", "gz", "bgzf"])
+def test_device_ingest_of_text_the_host_inflated_or_filtered(tmp_path, monkeypatch, kind):
+    """compressed / quality-filtered input: the host inflates / filters into memory (c2_fastq_stream_open), the text is framed and
+    de-duplicated by the c2_fq_* kernels from there (the host parser never runs) -- the reference's 39 files of its params run
+    (-q 30: N_READS_INPUT 250, 231 after the filter) and the FANC run's 18 files from a gzip / BGZF file"""
+    import gzip
+    from pipeline_on_emulator import emulated_device
+    from test_fastq_device_emulated import emulated_fq_kernels
+    from crispresso2_amd import pipeline, tables, refs as RF, synth
+    monkeypatch.setenv("C2_FQ_INGEST", "device")
+    monkeypatch.setattr(pipeline, "STREAM_MIN_BATCH", 25)
+    if kind == "filtered":
+        g, refs, names = _params_golden()
+        fq = tmp_path / "FANC.Cas9.fastq"
+        fq.write_text(_golden()["fastq"])
+        a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
+        a["min_average_read_quality"] = 30
+        with emulated_device(), emulated_fq_kernels():
+            tm = {}
+            res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a), timings=tm)
+            out = tmp_path / "out"
+            written = tables.write_tables(res, refs, names, str(out), plot_window_size=g["args"]["plot_window_size"], dsODN=g["args"]["dsODN"])
+        assert res.ingest_route == "device, text from host memory" and "host_parser_because" not in tm and tm["stream_batches"] >= 2
+        assert (res.stats["N_READS_INPUT"], res.stats["N_READS_AFTER_PREPROCESSING"]) == (250, 231)
+        assert _compare_params(g, written, str(out)) == 39
+        return
+    g = _golden()
+    plain = tmp_path / "FANC.Cas9.fastq"
+    plain.write_text(g["fastq"])
+    fq = tmp_path / "FANC.Cas9.fastq.gz"
+    if kind == "gz":
+        with gzip.open(fq, "wt") as fh:
+            fh.write(g["fastq"])
+    else:
+        synth.write_bgzf(str(plain), str(fq), workers=2, level=1)
+    cut = g["cut_point"]
+    ref = RF.make_ref("Reference", g["amplicon"], [cut], [cut, cut + 1], min_aln_score=60)
+    ref["sgRNA_orig_sequences"] = [g["guide"]]
+    with emulated_device(), emulated_fq_kernels():
+        res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args())
+        assert res.ingest_route == "device, text from host memory"
+        out = tmp_path / "out"
+        names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
+    assert _compare(g, names, str(out)) == 18
