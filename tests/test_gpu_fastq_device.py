@@ -107,7 +107,7 @@ def test_whole_run_is_the_same_on_either_route(tmp_path, monkeypatch):
         tm = {}
         res = pipeline.quantify_fastq(str(path), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], args, timings=tm)
         assert getattr(res, "ingest_route", None) == want
-        assert tm["stream_batches"] >= 3, tm
+        assert want is None or tm["stream_batches"] >= 3, tm
         results.append((res.stats, res.per_ref["Reference"], res.alleles()))
     st0, pr0, al0 = results[0]
     assert st0["N_TOT_READS"] == len(seqs)
