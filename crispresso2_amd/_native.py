@@ -25,6 +25,7 @@ SYMBOLS = [
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners", "c2_gather_reads",
+    "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close",
     "c2_consensus_pairs_batch", "c2_consensus_pairs_device",
     "c2_fq_count_device", "c2_fq_lines_device", "c2_fq_dedup_device", "c2_fq_gather_device", "c2_fq_rc_partner_device",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets",
@@ -110,6 +111,14 @@ def load():
                        lib.c2_fastq_stream_nonempty_lines_input):
                 fn.restype = ctypes.c_uint64
                 fn.argtypes = [ctypes.c_void_p]
+            lib.c2_bgzf_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+            lib.c2_bgzf_n_blocks.restype = ctypes.c_uint64
+            lib.c2_bgzf_n_blocks.argtypes = [ctypes.c_void_p]
+            lib.c2_bgzf_text_offsets.restype = ctypes.c_void_p
+            lib.c2_bgzf_text_offsets.argtypes = [ctypes.c_void_p]
+            lib.c2_bgzf_inflate.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32]
+            lib.c2_bgzf_close.restype = None
+            lib.c2_bgzf_close.argtypes = [ctypes.c_void_p]
             lib.c2_fastq_stream_close.restype = None
             lib.c2_fastq_stream_close.argtypes = [ctypes.c_void_p]
             lib.c2_fastq_stream_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
@@ -345,6 +354,39 @@ def _line_stats(stats, parsed_nonempty_lines):
     n = int(float(parsed_nonempty_lines) / 4.0)
     stats["N_READS_AFTER_PREPROCESSING"] = n
     stats.setdefault("N_READS_INPUT", n)
+
+
+class BgzfFile:
+    """c2_bgzf_*: a BGZF file whose members are inflated range by range into memory the caller names (fastq_device uploads the text
+    while it is inflated).  NativeError "not a BGZF file" for anything else."""
+
+    def __init__(self, path):
+        lib = load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        if lib.c2_bgzf_open(os.fsencode(path), ctypes.byref(self._h)) != 0:
+            raise NativeError("c2_bgzf_open: %s" % lib.c2_fastq_last_error().decode())
+        self.n_blocks = int(lib.c2_bgzf_n_blocks(self._h))
+        ptr = lib.c2_bgzf_text_offsets(self._h)
+        self.text_offsets = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint64)), (self.n_blocks + 1,)).copy()
+        self.text_bytes = int(self.text_offsets[-1])
+
+    def inflate(self, b0, b1, dst_address, cap, threads=0):
+        """members [b0, b1) -> memory at dst_address (ctypes drops the GIL; `threads` native threads)"""
+        if self._lib.c2_bgzf_inflate(self._h, ctypes.c_uint64(b0), ctypes.c_uint64(b1), ctypes.c_void_p(dst_address), ctypes.c_uint64(cap),
+                                     int(threads)) != 0:
+            raise NativeError("c2_bgzf_inflate: %s" % self._lib.c2_fastq_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._lib.c2_bgzf_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class FastqStream:

@@ -1626,7 +1626,7 @@ int c2_strand_plan_device(c2_ctx* ctx, uint64_t n_reads, const uint8_t* d_reads,
 static_assert(C2_FQ_TILE == C2_FQ_TILE_BYTES, "header and kernels disagree on the framing tile");
 int c2_fq_count_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, uint32_t* d_tile_newlines, uint32_t* d_tile_empty,
                        uint32_t* d_flags, void* hip_stream) {
-    if (!ctx || !d_text || !d_tile_newlines || !d_tile_empty || !d_flags || hi < lo || (lo % C2_FQ_TILE)) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
+    if (!ctx || !d_text || !d_tile_newlines || !d_tile_empty || !d_flags || hi < lo || (lo % 16u)) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
     if (hi == lo) return 0;
     const uint64_t tiles = (hi - lo + C2_FQ_TILE - 1) / C2_FQ_TILE;
     if (tiles > 0x7fffffffull) { ctx->err = "range too large for one launch"; return C2_E_TOO_LARGE; }
@@ -1640,7 +1640,7 @@ int c2_fq_count_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t
 
 int c2_fq_lines_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, const uint64_t* d_tile_base, uint64_t* d_seq_start,
                        uint64_t* d_seq_end, uint64_t n_records_cap, void* hip_stream) {
-    if (!ctx || !d_text || !d_tile_base || !d_seq_start || !d_seq_end || hi < lo || (lo % C2_FQ_TILE)) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
+    if (!ctx || !d_text || !d_tile_base || !d_seq_start || !d_seq_end || hi < lo || (lo % 16u)) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
     if (hi == lo) return 0;
     const uint64_t tiles = (hi - lo + C2_FQ_TILE - 1) / C2_FQ_TILE;
     if (tiles > 0x7fffffffull) { ctx->err = "range too large for one launch"; return C2_E_TOO_LARGE; }

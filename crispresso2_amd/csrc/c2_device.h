@@ -160,7 +160,7 @@ struct c2_strand_args {
 #define C2_FQ_TILE 16384u              // bytes of text per workgroup of the two framing kernels (256 threads x 64 bytes)
 struct c2_fq_frame_args {
     const uint8_t* text;              // the whole text; bytes [0, hi) are resident
-    uint64_t lo, hi;                  // this launch frames [lo, hi); lo is a multiple of C2_FQ_TILE
+    uint64_t lo, hi;                  // this launch frames [lo, hi) in tiles of C2_FQ_TILE bytes from lo on; lo is a multiple of 16
     uint32_t* tile_newlines;          // per tile of [lo, hi): '\n' bytes               (count kernel out, lines kernel in as EXCLUSIVE prefix, 64-bit)
     uint32_t* tile_empty;             // per tile: '\n' bytes preceded by '\n' (or at text position 0): the empty lines `grep -c .` does not count
     const uint64_t* tile_base;        // lines kernel: number of newlines in front of every tile (from the start of the TEXT)

@@ -1212,6 +1212,89 @@ int c2_fastq_stream_rc_partners(c2_fastq_stream* h, int64_t* partner, uint64_t n
 
 void c2_fastq_stream_close(c2_fastq_stream* h) { delete h; }
 
+// ---- BGZF input, member range by member range (for a caller that uploads the text as it is inflated: fastq_device.py) ----
+}  // extern "C"
+struct c2_bgzf {
+    void* mapped = nullptr; size_t mapped_n = 0;
+    std::vector<BgzfBlock> blocks;
+    std::vector<uint64_t> text_at;                                   // text offset of every block, + the total
+    size_t total = 0;
+    ~c2_bgzf() { if (mapped) munmap(mapped, mapped_n); }
+};
+extern "C" {
+
+int c2_bgzf_open(const char* path, c2_bgzf** out) {
+    if (!path || !out) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<c2_bgzf> H(new c2_bgzf);
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); g_fastq_error = std::string("cannot open ") + path; return C2_E_INVALID; }
+    H->mapped_n = (size_t)st.st_size;
+    if (H->mapped_n < 18) { close(fd); g_fastq_error = "not a BGZF file"; return C2_E_INVALID; }
+    H->mapped = mmap(nullptr, H->mapped_n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (H->mapped == MAP_FAILED) { H->mapped = nullptr; g_fastq_error = std::string("cannot map ") + path; return C2_E_INVALID; }
+    if (!bgzf_blocks((const uint8_t*)H->mapped, H->mapped_n, H->blocks, H->total)) { g_fastq_error = "not a BGZF file"; return C2_E_INVALID; }
+    H->text_at.reserve(H->blocks.size() + 1);
+    for (const BgzfBlock& B : H->blocks) H->text_at.push_back((uint64_t)B.out_at);
+    H->text_at.push_back((uint64_t)H->total);
+    *out = H.release();
+    return 0;
+}
+uint64_t c2_bgzf_n_blocks(const c2_bgzf* h) { return h ? (uint64_t)h->blocks.size() : 0; }
+const uint64_t* c2_bgzf_text_offsets(const c2_bgzf* h) { return h ? h->text_at.data() : nullptr; }
+
+// blocks [b0, b1) inflated into dst (their text back to back; cap >= text_offsets[b1] - text_offsets[b0]) on up to `threads` threads;
+// every member's CRC and length are checked
+int c2_bgzf_inflate(c2_bgzf* h, uint64_t b0, uint64_t b1, uint8_t* dst, uint64_t cap, int32_t threads) {
+    if (!h || !dst || b0 > b1 || b1 > h->blocks.size()) { g_fastq_error = "bad argument"; return C2_E_INVALID; }
+    if (b0 == b1) return 0;
+    const uint64_t base = h->text_at[b0];
+    if (h->text_at[b1] - base > cap) { g_fastq_error = "c2_bgzf_inflate: destination too small"; return C2_E_INVALID; }
+    const uint8_t* b = (const uint8_t*)h->mapped;
+    const Deflate& L = deflate_lib();
+    const char* route = getenv("C2_FASTQ_GZ");
+    const bool fast = L.ok() && !(route && !strcmp(route, "zlib"));
+    std::atomic<size_t> next((size_t)b0);
+    std::atomic<bool> good(true);
+    const size_t CHUNK = 16;
+    auto work = [&] {
+        void* d = fast ? L.alloc() : nullptr;
+        if (fast && !d) { good = false; return; }
+        for (;;) {
+            const size_t k0 = next.fetch_add(CHUNK);
+            if (k0 >= b1 || !good.load(std::memory_order_relaxed)) break;
+            const size_t k1 = std::min((size_t)b1, k0 + CHUNK);
+            for (size_t k = k0; k < k1; ++k) {
+                const BgzfBlock& B = h->blocks[k];
+                uint8_t* o = dst + (B.out_at - base);
+                bool ok;
+                if (fast) {
+                    size_t ui = 0, uo = 0;
+                    uint8_t dummy = 0;
+                    ok = L.gunzip(d, b + B.at, B.len, B.out_len ? o : &dummy, B.out_len, &ui, &uo) == 0 && ui == B.len && uo == B.out_len;
+                } else {
+                    ok = zlib_gunzip_member(b + B.at, B.len, o, B.out_len);
+                }
+                if (!ok) { good = false; break; }
+            }
+        }
+        if (d) L.release(d);
+    };
+    unsigned T = threads > 0 ? (unsigned)threads : usable_cpus();
+    if (T > (b1 - b0) / CHUNK + 1) T = (unsigned)((b1 - b0) / CHUNK + 1);
+    if (T <= 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; ++t) pool.emplace_back(work);
+        for (auto& th : pool) th.join();
+    }
+    if (!good) { g_fastq_error = "c2_bgzf_inflate: a damaged member"; return C2_E_INVALID; }
+    return 0;
+}
+void c2_bgzf_close(c2_bgzf* h) { delete h; }
+
 // ---- host-side helpers of the read -> reference bookkeeping that sits between ingest and the kernels ----------------
 
 // Strand plan of get_new_variant_object (CRISPRessoCORE.py:656-687) for every read against one reference:

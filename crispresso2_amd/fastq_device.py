@@ -129,13 +129,10 @@ def applicable(path, filters=(0, 0, 0)):
     return None
 
 
-def text_applicable(text):
-    """-> None if the device route can take this text (a uint8 array in host memory), else why not"""
+def size_applicable(size):
+    """-> None if the device route takes a text of `size` bytes, else why not"""
     if os.environ.get("C2_FQ_INGEST", "auto") == "host":
         return "C2_FQ_INGEST=host"
-    if text is None:
-        return "the text is not in memory"
-    size = int(text.size)
     if size < MIN_TEXT_BYTES and os.environ.get("C2_FQ_INGEST", "auto") != "device":
         return "small text"
     if size > MAX_TEXT_BYTES or size == 0:
@@ -143,8 +140,15 @@ def text_applicable(text):
     return None
 
 
+def text_applicable(text):
+    """-> None if the device route can take this text (a uint8 array in host memory), else why not"""
+    if text is None:
+        return "the text is not in memory"
+    return size_applicable(int(text.size))
+
+
 class DeviceIngest:
-    """feed(lo, hi) after bytes [lo, hi) of the text are in d_text (in order, lo a multiple of TILE; the last chunk may end anywhere);
+    """feed(lo, hi) after bytes [lo, hi) of the text are in d_text (in order, lo a multiple of 16; the last chunk may end anywhere);
     finish() once everything was fed.  All work is enqueued on torch's current stream of `dev`; nothing waits for the device before
     finish() except poll(), which only waits for chunks fed `lag` chunks ago.
     Batches: take_batch(r1, m, max_len) hands out the m unique non-empty reads whose FIRST occurrence is a record in
@@ -199,8 +203,8 @@ class DeviceIngest:
 
     def feed(self, lo, hi):
         import torch
-        if lo != self.fed or lo % TILE or hi > self.T or hi <= lo:
-            raise ValueError("chunks come in order, from a multiple of %d" % TILE)
+        if lo != self.fed or lo % 16 or hi > self.T or hi <= lo:
+            raise ValueError("chunks come in order, from a multiple of 16")
         self.fed = hi
         tiles = (hi - lo + TILE - 1) // TILE
         tile_nl = torch.empty(tiles, dtype=torch.int32, device=self.dev)
@@ -374,7 +378,8 @@ def estimate_records(source, size):
 
 
 def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
-    """path: a plain FASTQ file, or the text itself as a uint8 array in host memory (what the host inflated / filtered).
+    """path: a plain FASTQ file, the text itself as a uint8 array in host memory (what the host inflated / filtered), or a
+    _native.BgzfFile (its members are inflated chunk by chunk straight into the pinned upload buffers).
     The whole text -> DeviceIngest.finish()'s dict.  Host threads copy the text into three pinned buffers in turn; every chunk is framed
     and de-duplicated on the compute stream while the next one is copied and uploaded.
     on_batch(m, d_reads, d_off, max_len): called (on this thread, with the compute stream current) whenever min_batch new unique reads
@@ -385,10 +390,27 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
     from concurrent.futures import ThreadPoolExecutor
     t0 = time.perf_counter()
     text = path if isinstance(path, np.ndarray) else None
-    size = int(text.size) if text is not None else os.path.getsize(path)
+    bgzf = path if isinstance(path, _native.BgzfFile) else None
+    size = int(text.size) if text is not None else bgzf.text_bytes if bgzf is not None else os.path.getsize(path)
     on_gpu = dev.type == "cuda"
-    ing = DeviceIngest(ctx, dev, size, estimate_records(path, size))
     chunk = chunk_bytes(size)
+    if bgzf is not None:
+        # chunks are whole members: [cuts[c], cuts[c + 1]) in blocks, ~chunk bytes of text each (a member holds at most 64 KiB)
+        offs = bgzf.text_offsets.astype(np.int64)
+        cuts = [0]
+        while cuts[-1] < bgzf.n_blocks:
+            cuts.append(max(cuts[-1] + 1, int(np.searchsorted(offs, offs[cuts[-1]] + chunk - 65536, side="right")) - 1))
+        cuts[-1] = min(cuts[-1], bgzf.n_blocks)
+        chunk = int(max(offs[b] - offs[a] for a, b in zip(cuts[:-1], cuts[1:]))) if size else chunk
+        head = np.empty(min(size, 1 << 20), dtype=np.uint8)
+        n_head = int(np.searchsorted(offs, head.size, side="left"))             # the members that cover the first MB (for the table's size)
+        if size:
+            big = np.empty(int(offs[n_head]), dtype=np.uint8)
+            bgzf.inflate(0, n_head, big.ctypes.data, big.size, 1)
+            head = big[:head.size]
+        ing = DeviceIngest(ctx, dev, size, estimate_records(head, size))
+    else:
+        ing = DeviceIngest(ctx, dev, size, estimate_records(path, size))
 
     def after_feed():
         if on_batch is None:
@@ -401,19 +423,33 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
                 m = uniq - ing.batch_u0
                 d_reads, d_off = ing.take_batch(r1, m, longest)
                 on_batch(m, d_reads, d_off, longest)
-    fd = os.open(path, os.O_RDONLY) if text is None else -1
+    fd = os.open(path, os.O_RDONLY) if (text is None and bgzf is None) else -1
     try:
-        last = os.pread(fd, 1, size - 1) if text is None else text[size - 1:].tobytes()
+        if bgzf is not None:
+            spans = [(int(bgzf.text_offsets[a]), int(bgzf.text_offsets[b]), a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+            last = None                                               # (known once the last member is inflated)
+        else:
+            spans = [(lo, min(size, lo + chunk), 0, 0) for lo in range(0, size, chunk)]
+            last = os.pread(fd, 1, size - 1) if text is None else text[size - 1:].tobytes()
+
+        def feed_upto(up_hi):
+            """the text is resident up to up_hi: frame what is new of it, up to a multiple of 16 (all of it at the end)"""
+            hi = up_hi if up_hi == size else up_hi & ~15
+            if hi > ing.fed:
+                ing.feed(ing.fed, hi)
+                after_feed()
         if not on_gpu:                                                # (tests: the "device" is host memory)
             view = ing.d_text.numpy()
-            for lo in range(0, size, chunk):
-                hi = min(size, lo + chunk)
-                if text is not None:
+            for lo, hi, b0, b1 in spans:
+                if bgzf is not None:
+                    bgzf.inflate(b0, b1, view[lo:hi].ctypes.data, hi - lo, 2)
+                elif text is not None:
                     view[lo:hi] = text[lo:hi]
                 elif os.preadv(fd, [memoryview(view[lo:hi])], lo) != hi - lo:
                     raise OSError("short read")
-                ing.feed(lo, hi)
-                after_feed()
+                feed_upto(hi)
+            if bgzf is not None:
+                last = view[size - 1:size].tobytes()
             return ing.finish(last != b"\n", on_batch)
         import queue
         import threading
@@ -426,6 +462,7 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
         compute = torch.cuda.current_stream(dev)
         copy_stream = torch.cuda.Stream(device=dev)
         q = queue.Queue()
+        tail_byte = []
 
         def read_into(args):
             buf, off, n = args
@@ -444,15 +481,19 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
             evs = [None] * len(pins)
             try:
                 with ThreadPoolExecutor(threads) as pool:
-                    for c, lo in enumerate(range(0, size, chunk)):
-                        hi = min(size, lo + chunk)
+                    for c, (lo, hi, b0, b1) in enumerate(spans):
                         k = c % len(pins)
                         if evs[k] is not None:
                             evs[k].synchronize()                      # the upload out of this buffer is done
-                        mv = memoryview(pins[k].numpy())
-                        step = -(-(hi - lo) // threads)
-                        step = (step + 4095) // 4096 * 4096
-                        list(pool.map(read_into, [(mv[a_:min(hi - lo, a_ + step)], lo + a_, min(hi - lo, a_ + step) - a_) for a_ in range(0, hi - lo, step)]))
+                        if bgzf is not None:                          # members b0 .. b1 - 1 inflated straight into the pinned buffer (native threads)
+                            bgzf.inflate(b0, b1, pins[k].data_ptr(), hi - lo, max(2, usable_cpus() - 2))
+                            if hi == size:
+                                tail_byte.append(bytes(pins[k][hi - lo - 1:hi - lo].numpy()))
+                        else:
+                            mv = memoryview(pins[k].numpy())
+                            step = -(-(hi - lo) // threads)
+                            step = (step + 4095) // 4096 * 4096
+                            list(pool.map(read_into, [(mv[a_:min(hi - lo, a_ + step)], lo + a_, min(hi - lo, a_ + step) - a_) for a_ in range(0, hi - lo, step)]))
                         with torch.cuda.stream(copy_stream):
                             ing.d_text[lo:hi].copy_(pins[k][:hi - lo], non_blocking=True)
                             evs[k] = torch.cuda.Event()
@@ -472,12 +513,13 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
                     raise item
                 lo, hi, ev = item
                 compute.wait_event(ev)
-                ing.feed(lo, hi)
-                after_feed()
+                feed_upto(hi)
         finally:
             th.join()
         if timings is not None:
             timings["upload_text"] = time.perf_counter() - t0
+        if bgzf is not None:
+            last = tail_byte[0]
         out = ing.finish(last != b"\n", on_batch)
         if timings is not None:
             timings["device_dedup_tail"] = time.perf_counter() - t0 - timings["upload_text"]

@@ -505,9 +505,9 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if device_reads is not None:
         if shard is not None or fastq_stream is not None:
             raise ValueError("device_reads is the single-process route")
-        if isinstance(device_reads, (str, os.PathLike, np.ndarray)):
+        if isinstance(device_reads, (str, os.PathLike, np.ndarray, _native.BgzfFile)):
             # a FASTQ file, or FASTQ text in host memory: framed, de-duplicated AND aligned (batch 1) chunk by chunk under its upload (_device_front)
-            front = _device_front(device_reads if isinstance(device_reads, np.ndarray) else os.fspath(device_reads), aligner, ctx, dev, refs,
+            front = _device_front(device_reads if isinstance(device_reads, (np.ndarray, _native.BgzfFile)) else os.fspath(device_reads), aligner, ctx, dev, refs,
                                   ref_names, args, legacy, timings)
             device_reads = front["device_reads"]
             t_last[0] = time.perf_counter()
@@ -930,6 +930,23 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
                 return on_device(path)
             except fastq_device.DeviceIngestUnavailable as e:
                 why_not = str(e)
+        if why_not.startswith("in memory: compressed"):
+            # BGZF: the members are inflated range by range straight into the pinned upload buffers -- inflate, upload and the device's
+            # framing overlap, and the host never holds the text
+            bg = None
+            try:
+                bg = _native.BgzfFile(path)
+            except _native.NativeError:
+                pass                                                  # (some other gzip file: inflated as a whole below)
+            if bg is not None:
+                with bg:
+                    if fastq_device.size_applicable(bg.text_bytes) is None:
+                        try:
+                            res = on_device(bg)
+                            res.ingest_route = "device, members inflated into the upload buffers"
+                            return res
+                        except fastq_device.DeviceIngestUnavailable as e:
+                            why_not = str(e)                          # (e.g. carriage returns: the host parser takes the file)
         fq = None
         try:
             fq = _native.FastqStream(path, *flt)                     # (inflates / filters a compressed or filtered input: its text is in memory now)

@@ -367,6 +367,17 @@ int c2_fastq_paired_occurrences(const char* path1, const char* path2, const c2_f
 uint64_t c2_fastq_aux_bytes(const c2_fastq* r);
 const uint8_t* c2_fastq_aux(const c2_fastq* r);
 const uint64_t* c2_fastq_aux_offsets(const c2_fastq* r);
+/* BGZF input (bgzip / htslib: gzip members of <= 64 KiB of text that name their own size) member range by member range, for a caller
+ * that uploads the text while it is inflated (crispresso2_amd/fastq_device.py): _open maps the file and indexes the members from their
+ * headers (C2_E_INVALID "not a BGZF file" for anything else: padding, foreign members, truncation -- the whole-file routes above decide
+ * about those); _text_offsets: n_blocks + 1 offsets of the members' text; _inflate: members [b0, b1) into dst on `threads` threads
+ * (0: the CPUs the process may use), CRC and length of every member checked. */
+typedef struct c2_bgzf c2_bgzf;
+int c2_bgzf_open(const char* path, c2_bgzf** out);
+uint64_t c2_bgzf_n_blocks(const c2_bgzf* h);
+const uint64_t* c2_bgzf_text_offsets(const c2_bgzf* h);
+int c2_bgzf_inflate(c2_bgzf* h, uint64_t b0, uint64_t b1, uint8_t* dst, uint64_t cap, int32_t threads);
+void c2_bgzf_close(c2_bgzf* h);
 /* Host-side bookkeeping between ingest and kernels, over the same arena/offsets layout (errors: c2_fastq_last_error()):
  * the seed test that picks the strand(s) a read is aligned on (CRISPRessoCORE.py:656-687) -> out_plan[n] in {0 forward,
  * 1 reverse complement, 2 both}, and the reverse-complement merge of read counts (CRISPRessoCORE.py:3970-3975), in place. */
@@ -394,7 +405,7 @@ int c2_gather_reads(const uint8_t* arena, const uint64_t* offsets, const int64_t
  * to use its own parser): records are four consecutive '\n'-terminated lines from the top, the second one str.strip()ped.
  * All buffers are device memory owned by the caller; every call only enqueues on hip_stream.  The host-side driver is
  * crispresso2_amd/fastq_device.py.
- *   c2_fq_count_device  text [lo, hi) (lo a multiple of C2_FQ_TILE_BYTES = 16384; bytes [0, hi) resident) -> per tile of 16384 bytes: the
+ *   c2_fq_count_device  text [lo, hi) (lo a multiple of 16; bytes [0, hi) resident) -> per tile of C2_FQ_TILE_BYTES = 16384 bytes from lo on: the
  *                       number of '\n' and the number of '\n' that end an EMPTY line; flags |= 1 if a '\r' was seen.
  *   c2_fq_lines_device  the same range again, with tile_base[t] = number of '\n' in the text in front of tile t (the caller's
  *                       prefix sum): seq_start[r] = first byte of record r's sequence line (behind newline 4r), seq_end[r] = the

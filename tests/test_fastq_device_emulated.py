@@ -136,8 +136,30 @@ def test_more_records_than_estimated_goes_to_the_host_parser(tmp_path):
 
 def test_applicable():
     assert FD.applicable("/nonexistent.fastq") is not None
-    assert FD.applicable(__file__, (30, 0, 0)) == "quality filters run in the host parser"
+    assert FD.applicable(__file__, (30, 0, 0)).startswith("in memory:")      # (the host filters, the device can frame the filtered text)
     assert FD.applicable(__file__) == "small file"
+    assert FD.size_applicable(0) is not None and FD.size_applicable(FD.MIN_TEXT_BYTES) is None and FD.text_applicable(None) is not None
+
+
+def test_bgzf_members_inflated_chunk_by_chunk(tmp_path):
+    """a BGZF file as the source: members inflated range by range into the text buffer (c2_bgzf_*), framed as they arrive; chunk
+    boundaries are member boundaries, so the framing launches start at multiples of 16 and carry the bytes in between"""
+    from crispresso2_amd import synth
+    rng = random.Random(21)
+    plain = tmp_path / "b.fastq"
+    plain.write_text(records(rng, 2500) + "@cut\nACGTAC")
+    bz = tmp_path / "b.fastq.gz"
+    synth.write_bgzf(str(plain), str(bz), workers=2, level=1)
+    want, n_reads = O.read_fastq_unique(str(plain))
+    for chunk in (FD.TILE, 100_000, 1 << 30):
+        with _native.BgzfFile(str(bz)) as bg, emulated_fq_kernels(chunk):
+            assert bg.text_bytes == os.path.getsize(plain) and bg.n_blocks >= 3
+            out = FD.ingest_file(bg, None, torch.device("cpu"))
+        arena, off = out["d_reads"].numpy(), out["offsets"]
+        reads = [arena[int(off[i]):int(off[i + 1])].tobytes().decode() for i in range(out["n_unique"])]
+        assert reads == list(want.keys()) and out["counts"].tolist() == list(want.values()) and out["n_reads"] == n_reads
+    with pytest.raises(_native.NativeError):
+        _native.BgzfFile(str(plain))
 
 
 def test_reverse_complement_partners_from_the_table(tmp_path):

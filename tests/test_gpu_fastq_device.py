@@ -99,10 +99,13 @@ def test_whole_run_is_the_same_on_either_route(tmp_path, monkeypatch):
     gz = tmp_path / "run.fastq.gz"
     with gzip.open(gz, "wb", compresslevel=1) as fh:
         fh.write(fq.read_bytes())
+    bz = tmp_path / "run.bgzf.fastq.gz"
+    synth.write_bgzf(str(fq), str(bz), workers=4, level=1)
     monkeypatch.setattr(FD, "CHUNK_BYTES", 2 << 20)
     monkeypatch.setattr(pipeline, "STREAM_MIN_BATCH", 5000)           # (batches of alignments under the upload)
     results = []
-    for route, path, want in (("host", fq, None), ("device", fq, "device"), ("device", gz, "device, text from host memory"), ("host", gz, None)):
+    for route, path, want in (("host", fq, None), ("device", fq, "device"), ("device", gz, "device, text from host memory"), ("host", gz, None),
+                              ("device", bz, "device, members inflated into the upload buffers"), ("host", bz, None)):
         monkeypatch.setenv("C2_FQ_INGEST", route)
         tm = {}
         res = pipeline.quantify_fastq(str(path), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], args, timings=tm)
