@@ -322,10 +322,11 @@ class DeviceIngest:
         if self.batches:
             rec = torch.cat([b[0] for b in self.batches])
             lens = torch.cat([b[1][1:] - b[1][:-1] for b in self.batches])
-            counts = to_host(self.count[self.slot_of[rec].to(torch.int64)], np.int64)     # (32-bit over the link, widened on the host)
+            d_counts = self.count[self.slot_of[rec].to(torch.int64)].contiguous()          # (stays on the device for the selection kernel)
+            counts = to_host(d_counts, np.int64)                                          # (32-bit over the link, widened on the host)
             lens_h = to_host(lens.to(torch.int32), np.int64)
         else:
-            counts, lens_h = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+            counts, lens_h, d_counts = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), None
         # which unique read is the reverse complement of which (the count merge asks): looked up in the table, which is still here
         rc_partner = np.zeros(0, dtype=np.int64)
         if self.batches:
@@ -348,7 +349,7 @@ class DeviceIngest:
         bb = [int(x) for x in np.diff(off64[np.concatenate([[0], ends])])] if self.batches else []      # bytes of every batch
         lap("batch bytes")
         out = dict(offsets=offsets, counts=counts, n_reads=n_records, n_empty_records=n_empty, nonempty_lines=nonempty, n_unique=n,
-                   max_len=mx, min_len=mn, batch_bytes=bb, rc_partner=rc_partner)
+                   max_len=mx, min_len=mn, batch_bytes=bb, rc_partner=rc_partner, d_counts=d_counts)
         if last is not None and len(self.batches) == 1:
             out["d_reads"], out["d_off"] = last
         lap("offsets")

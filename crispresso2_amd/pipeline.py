@@ -308,6 +308,7 @@ def _device_front(path, aligner, ctx, dev, refs, ref_names, args, legacy, timing
     n = ing["n_unique"]
     a1, f1, r1, d_plan, stride = _join_first_batches(parts, aligner, dev)
     plan = to_host(d_plan).reshape(n, k)
+    both = to_host(torch.nonzero(d_plan.view(n, k) == 2)) if n else np.zeros((0, 2), dtype=np.int64)   # (the few pairs aligned on both strands)
     if len(parts) == 1:
         d_reads_all, d_off_all = parts[0][5], parts[0][6]
     elif parts:
@@ -322,7 +323,7 @@ def _device_front(path, aligner, ctx, dev, refs, ref_names, args, legacy, timing
     ing["d_reads"], ing["d_off"] = d_reads_all, d_off_all
     # (the reverse-complement partners come with the ingest: looked up in its table -- no second search)
     return dict(arena=None, offsets=ing["offsets"], counts=ing["counts"], plan=plan, stride=stride, a1=a1, f1=f1, r1=r1,
-                rc_partners=lambda: ing["rc_partner"], d_reads_all=None, device_reads=ing)
+                rc_partners=lambda: ing["rc_partner"], d_reads_all=None, device_reads=ing, both=both)
 
 
 def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings):
@@ -680,7 +681,10 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     lap("h2d_align")
 
     # ---- batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments
-    bi, br = np.nonzero(plan == 2)
+    if front is not None and front.get("both") is not None:
+        bi, br = front["both"][:, 0].copy(), front["both"][:, 1].copy()      # (found on the device, row-major like np.nonzero)
+    else:
+        bi, br = np.nonzero(plan == 2)
     n2 = len(bi)
     lap("both_strand_list")
     r2 = a2 = f2 = None
@@ -722,7 +726,8 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         d_use2 = torch.zeros((n, words), dtype=torch.int64, device=dev)
         d_flags = torch.zeros(n, dtype=torch.uint8, device=dev)
         d_stats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
-        d_raw = to_device(raw.astype(np.uint32).view(np.int32), dev)
+        d_raw = (device_reads["d_counts"] if device_reads is not None and device_reads.get("d_counts") is not None
+                 else to_device(raw.astype(np.uint32).view(np.int32), dev))
         min_mscore = C.min_mscore_table(min_scores)
         lap("selection_inputs")
         C.select_best_device(ctx, n, k, r1.data_ptr(), min_mscore, mode, max(stride, stride2),
