@@ -179,3 +179,29 @@ def test_reverse_complement_partners_from_the_table(tmp_path):
     want = _native.rc_partners(arena, out["offsets"])
     assert np.array_equal(out["rc_partner"], want)
     assert (want >= 0).sum() >= 160 and (want == np.arange(len(want))).sum() >= 3
+
+
+def fuzz_text(rng, n_lines, alphabet="ACGTN acgt\t\x0b\x0c\x1c+@I#", max_len=60, blank=0.15):
+    """lines of random bytes (white space of every kind str.strip() knows, empty lines, no FASTQ structure at all), random tail"""
+    out = []
+    for _ in range(n_lines):
+        if rng.random() < blank:
+            out.append("")
+        else:
+            out.append("".join(rng.choice(alphabet) for _ in range(rng.randint(1, max_len))))
+    text = "\n".join(out)
+    return text + rng.choice(["", "\n", "\n\n", " ", "\nAC", "\n \n"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzzed_text_without_any_structure(tmp_path, seed):
+    """the framing is "four lines are a record, whatever they hold": random lines, blank lines, white-space-only lines, every tail --
+    the kernels = the reference's readline loop (oracle) on all of it"""
+    rng = random.Random(1000 + seed)
+    p = tmp_path / "fz.fastq"
+    p.write_text(fuzz_text(rng, rng.randint(50, 2500)))
+    want, n_reads = O.read_fastq_unique(str(p))
+    reads, counts, out = device_unique(p, chunk=rng.choice([FD.TILE, 3 * FD.TILE, 1 << 30]))
+    n_empty = want.pop("", 0)
+    assert reads == list(want.keys()) and counts == list(want.values())
+    assert out["n_reads"] == n_reads and out["n_empty_records"] == n_empty

@@ -146,3 +146,27 @@ def test_filtered_input_on_either_route(tmp_path, monkeypatch):
         out.append(res)
     assert out[0].stats == out[1].stats and out[0].stats["N_READS_INPUT"] == 40_000 and 25_000 < out[0].stats["N_READS_AFTER_PREPROCESSING"] < 38_000
     assert out[0].alleles() == out[1].alleles()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzzed_text_against_the_host_parser(tmp_path, monkeypatch, seed):
+    """text without any FASTQ structure (random lines, blank lines, white space of every kind, every tail), ~2 MB in 64 KB chunks:
+    the kernels = the host parser (= the reference's readline loop, CPU suite) in reads, order, multiplicities, record and line counts"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_fastq_device_emulated import fuzz_text
+    from crispresso2_amd import fastq_device as FD, _native
+    rng = random.Random(500 + seed)
+    p = tmp_path / "fz.fastq"
+    p.write_text(fuzz_text(rng, 60_000, max_len=rng.choice([12, 60, 200]), blank=rng.choice([0.0, 0.1, 0.5])))
+    monkeypatch.setattr(FD, "CHUNK_BYTES", 1 << 16)
+    out = FD.ingest_file(str(p), _native.default_context(), torch.device("cuda", 0))
+    arena, off, counts, st, n_reads = _host_unique(p)
+    lens = off[1:] - off[:-1]
+    keep = lens > 0
+    assert out["n_reads"] == n_reads and out["n_unique"] == int(keep.sum())
+    assert int(float(out["nonempty_lines"]) / 4.0) == st["N_READS_AFTER_PREPROCESSING"]
+    assert np.array_equal(out["counts"], counts[keep]) and np.array_equal(np.diff(out["offsets"].astype(np.int64)), lens[keep])
+    want = np.concatenate([arena[off[i]:off[i + 1]] for i in np.nonzero(keep)[0]]) if keep.any() else np.zeros(0, np.uint8)
+    assert np.array_equal(out["d_reads"][:int(out["offsets"][-1])].cpu().numpy(), want)
