@@ -451,7 +451,8 @@ def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, ar
 def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
                      timings, pe_scaffold_dna_info, _threads, shard=None, fastq_stream=None, device_reads=None):
     """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
-    shard: None -- this process aligns every read it was given.  Otherwise arena / offsets / read_counts are the WHOLE run's unique
+    shard: None -- this process aligns every read it was given.  "mine" (with device_reads): this rank's contiguous range
+    (distributed.my_shard) of the unique reads the device ingest finds.  Otherwise arena / offsets / read_counts are the WHOLE run's unique
     reads (every rank holds the same list, as every worker of the reference sees the parent's variantCache keys) and `shard` names
     the part this rank aligns: (lo, hi) for a contiguous range (distributed.my_shard = get_variant_cache_equal_boundaries) or an
     index array.  The reverse-complement merge (:3970-3975) then runs over the whole list exactly as in one process: partners are
@@ -503,16 +504,27 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         front = _stream_front(fastq_stream, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
         arena, offsets, read_counts = front["arena"], front["offsets"], front["counts"]
         t_last[0] = time.perf_counter()
+    shard_of_all = isinstance(shard, str) and shard == "mine"          # (the rank's range of a list whose length is not known yet)
     if device_reads is not None:
-        if shard is not None or fastq_stream is not None:
-            raise ValueError("device_reads is the single-process route")
+        if fastq_stream is not None or (shard is not None and not shard_of_all and not isinstance(shard, tuple)):
+            raise ValueError("device_reads takes no fastq_stream and only contiguous shards")
         if isinstance(device_reads, (str, os.PathLike, np.ndarray, _native.BgzfFile)):
-            # a FASTQ file, or FASTQ text in host memory: framed, de-duplicated AND aligned (batch 1) chunk by chunk under its upload (_device_front)
-            front = _device_front(device_reads if isinstance(device_reads, (np.ndarray, _native.BgzfFile)) else os.fspath(device_reads), aligner, ctx, dev, refs,
-                                  ref_names, args, legacy, timings)
-            device_reads = front["device_reads"]
+            source = device_reads if isinstance(device_reads, (np.ndarray, _native.BgzfFile)) else os.fspath(device_reads)
+            if shard is None:
+                # a FASTQ file, or FASTQ text in host memory: framed, de-duplicated AND aligned (batch 1) chunk by chunk under its upload (_device_front)
+                front = _device_front(source, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
+                device_reads = front["device_reads"]
+            else:
+                # sharded: every rank frames and de-duplicates the whole text on ITS device (the parent's variantCache of the reference,
+                # which all workers see) and aligns its range of the unique reads
+                from . import fastq_device
+                device_reads = fastq_device.ingest_file(source, ctx, dev, timings=timings)
             t_last[0] = time.perf_counter()
         arena, offsets, read_counts = None, device_reads["offsets"], device_reads["counts"]
+    if shard_of_all:                                                  # (this rank's contiguous range of however many unique reads there are)
+        import torch.distributed as dist
+        from . import distributed as D
+        shard = D.my_shard(len(read_counts), dist.get_rank(), dist.get_world_size())
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     # the whole run's unique reads (what the reverse-complement partner search looks at) and the part this process aligns
     g_arena, g_offsets, g_raw = arena, offsets, np.asarray(read_counts, dtype=np.int64)
@@ -523,7 +535,12 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         if isinstance(shard, tuple):
             lo, hi = int(shard[0]), int(shard[1])
             shard_idx = slice(lo, hi)
-            arena = np.asarray(arena)[int(offsets[lo]):int(offsets[hi])]
+            if device_reads is not None:                              # (the reads are on the device: the shard is a view of them)
+                device_reads = dict(device_reads, d_reads=device_reads["d_reads"][int(offsets[lo]):max(int(offsets[hi]), int(offsets[lo]) + 1)],
+                                    d_off=device_reads["d_off"][lo:hi + 1] - device_reads["d_off"][lo],
+                                    d_counts=None if device_reads.get("d_counts") is None else device_reads["d_counts"][lo:hi].contiguous())
+            else:
+                arena = np.asarray(arena)[int(offsets[lo]):int(offsets[hi])]
             offsets = (offsets[lo:hi + 1] - offsets[lo]).astype(np.uint64)
         else:
             shard_idx = np.asarray(shard, dtype=np.int64)
@@ -638,7 +655,9 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         try:
             if partners.get('device') is not None:
                 return                                                # (enqueued on the device, below; fetched at the merge)
-            if front is not None and front.get("rc_partners") is not None:
+            if device_reads is not None and device_reads.get("rc_partner") is not None:
+                partners['index'] = device_reads["rc_partner"]         # (looked up in the device ingest's table, over ALL unique reads)
+            elif front is not None and front.get("rc_partners") is not None:
                 partners['index'] = front["rc_partners"]()            # (from the table the streamed ingest built: no second hash of every read)
             else:
                 partners['index'] = (_native.rc_partners(host_arena(), offsets) if shard is None else
@@ -646,7 +665,8 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         except BaseException as e:                                   # re-raised by the main thread at the join
             partners['error'] = e
     # reads of one length that are already in HBM: the search runs there (milliseconds); anything else on the host thread
-    if shard is None and n >= RC_PARTNERS_ON_DEVICE_MIN and int(lens.min()) == max_lj:
+    if (shard is None and n >= RC_PARTNERS_ON_DEVICE_MIN and int(lens.min()) == max_lj
+            and not (device_reads is not None and device_reads.get("rc_partner") is not None)):
         d_all = front["d_reads_all"] if front is not None else d_reads
         if d_all is not None and d_all.numel() >= n * max_lj:
             partners['device'] = rc_partners_device(d_all[:n * max_lj].view(n, max_lj))
@@ -987,6 +1007,52 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
             return res
         if timings is not None:
             timings["host_parser_because"] = why_not
+    if sharded and not FORCE_HOST_STRAND_PLAN:
+        # sharded run: every rank frames and de-duplicates the text on ITS device (plain file, BGZF, or what the host inflated / filtered)
+        # and aligns its range of the unique reads; anything the kernels cannot take: the host parser below, on every rank alike --
+        # the ranks agree on the route first (one of them may have found a carriage return the others' estimate missed)
+        import torch
+        from . import fastq_device
+        ctx_ = ctx or _native.default_context()
+        dev_ = torch.device("cuda", device)
+        why_not = fastq_device.applicable(path, flt)
+        ing, holder = None, None
+        try:
+            if why_not is None:
+                ing = fastq_device.ingest_file(path, ctx_, dev_, timings=timings)
+            elif why_not.startswith("in memory:"):
+                bg = None
+                if why_not.startswith("in memory: compressed"):
+                    try:
+                        bg = _native.BgzfFile(path)
+                    except _native.NativeError:
+                        bg = None
+                if bg is not None:
+                    with bg:
+                        if fastq_device.size_applicable(bg.text_bytes) is None:
+                            ing = fastq_device.ingest_file(bg, ctx_, dev_, timings=timings)
+                else:
+                    holder = _native.FastqStream(path, *flt)
+                    text = holder.text()
+                    if fastq_device.text_applicable(text) is None:
+                        if holder.filtered:
+                            ingest_stats["N_READS_INPUT"] = int(float(holder.lines_input()) / 4.0)
+                        ing = fastq_device.ingest_file(text, ctx_, dev_, timings=timings)
+        except (fastq_device.DeviceIngestUnavailable, _native.NativeError):
+            ing = None
+        finally:
+            if holder is not None:
+                holder.close()
+        if C.all_reduce_max(1 if ing is None else 0, dev_) == 0:        # (no rank gave up)
+            res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
+                                  pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=ing, shard="mine")
+            _native._line_stats(ingest_stats, ing["nonempty_lines"])
+            res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT']
+            res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats['N_READS_AFTER_PREPROCESSING']
+            res.ingest_route = "device, sharded"
+            return res
+        ingest_stats.pop("N_READS_INPUT", None)
+        del ing
     with _native.FastqUnique(path, *flt, stats=ingest_stats) as fq:      # views of the native arena: nothing is copied on the host
         arena, offsets, counts, n_reads = fq.arena, fq.offsets, fq.counts, fq.n_reads
         if timings is not None:

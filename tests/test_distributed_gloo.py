@@ -220,9 +220,15 @@ def _split_partner_worker(rank, world, port, out_dir):
     with open(fq, "w") as fh:
         fh.write(text)
     a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
-    with emulated_device():
+    import contextlib
+    device_ingest = bool(os.environ.get("C2_TEST_DEVICE_INGEST"))
+    if device_ingest:
+        from test_fastq_device_emulated import emulated_fq_kernels
+        os.environ["C2_FQ_INGEST"] = "device"
+    with emulated_device(), (emulated_fq_kernels() if device_ingest else contextlib.nullcontext()):
         res = pipeline.quantify_fastq(fq, refs, names, matrices()["EDNAFULL"], _pipeline_args(a), shard_across_ranks=True)
         rows = res.alleles(gather=True)
+    assert (getattr(res, "ingest_route", None) == "device, sharded") == (device_ingest and world > 1)
     with open(os.path.join(out_dir, "split_world%d_rank%d.pkl" % (world, rank)), "wb") as fh:
         pickle.dump({"per_ref": res.per_ref, "view": res.first_ref_view, "stats": res.stats, "alleles": rows}, fh)
     if world > 1:
@@ -253,6 +259,31 @@ def test_reverse_complement_partners_in_different_shards_merge_as_in_one_process
     _split_partner_worker(0, 1, 0, str(tmp_path))
     one = pickle.load(open(tmp_path / "split_world1_rank0.pkl", "rb"))
     assert len(one["alleles"]) > 50
+    for world in (2, 3):
+        mp.spawn(_split_partner_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+        for rank in range(world):
+            got = pickle.load(open(tmp_path / ("split_world%d_rank%d.pkl" % (world, rank)), "rb"))
+            assert got["stats"] == one["stats"], (world, rank)
+            assert got["alleles"] == one["alleles"], (world, rank)
+            for nm in one["per_ref"]:
+                for key, v in one["per_ref"][nm].items():
+                    w = got["per_ref"][nm][key]
+                    assert np.array_equal(v, w) if isinstance(v, np.ndarray) else v == w, (world, rank, nm, key)
+                for key, v in one["view"][nm].items():
+                    assert np.array_equal(v, got["view"][nm][key]), (world, rank, nm, key)
+
+
+def test_sharded_run_with_the_text_framed_on_every_ranks_device(tmp_path, monkeypatch):
+    """the same file and the same comparison with the device ingest: every rank frames and de-duplicates the whole text with the c2_fq_*
+    kernels (emulated), takes its range of the unique reads as a view of the device arena, finds the partners of ALL reads in the
+    ingest's table -- tensors, view, statistics and gathered allele rows equal the single process (host parser)"""
+    import pickle
+    sys.path.insert(0, HERE)
+    import emu_driver as E
+    E.build()
+    _split_partner_worker(0, 1, 0, str(tmp_path))
+    one = pickle.load(open(tmp_path / "split_world1_rank0.pkl", "rb"))
+    monkeypatch.setenv("C2_TEST_DEVICE_INGEST", "1")
     for world in (2, 3):
         mp.spawn(_split_partner_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
         for rank in range(world):

@@ -170,3 +170,56 @@ def test_fuzzed_text_against_the_host_parser(tmp_path, monkeypatch, seed):
     assert np.array_equal(out["counts"], counts[keep]) and np.array_equal(np.diff(out["offsets"].astype(np.int64)), lens[keep])
     want = np.concatenate([arena[off[i]:off[i + 1]] for i in np.nonzero(keep)[0]]) if keep.any() else np.zeros(0, np.uint8)
     assert np.array_equal(out["d_reads"][:int(out["offsets"][-1])].cpu().numpy(), want)
+
+
+def _sharded_worker(rank, world, port, path, out_dir, route):
+    import pickle
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), C2_FQ_INGEST=route)
+    import torch.distributed as dist
+    from helpers import matrices
+    from crispresso2_amd import distributed as D, pipeline, synth, refs as RF
+    if world > 1:
+        D.init("gloo")                                             # (both ranks share the box's one GPU: RCCL needs a GPU per rank)
+    L = 150
+    amp, g_, inc = synth.amplicon_setup(L)
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
+    args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2,
+                           ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
+                           assign_ambiguous_alignments_to_first_reference=False, expand_ambiguous_alignments=False, discard_indel_reads=False)
+    res = pipeline.quantify_fastq(path, {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], args, shard_across_ranks=world > 1)
+    with open(os.path.join(out_dir, "w%d_r%d_%s.pkl" % (world, rank, route)), "wb") as fh:
+        pickle.dump({"per_ref": res.per_ref, "stats": res.stats, "route": getattr(res, "ingest_route", None)}, fh)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_each_frame_the_text_on_the_device(tmp_path):
+    """pipeline.quantify_fastq(shard_across_ranks=True) with two gloo ranks on the box's one GPU: each rank frames and de-duplicates the
+    whole file with the c2_fq_* kernels, aligns its half of the unique reads, the tensors are all-reduced -- = one process, either route
+    (reads with reverse-complement partners in the other rank's half included)"""
+    import pickle
+    import socket
+    import torch.multiprocessing as mp
+    from crispresso2_amd import synth, refs as RF
+    L = 150
+    reads = synth.make_reads(L, 50_000)
+    seqs = [r.tobytes().decode() for r in reads]
+    seqs = [RF.reverse_complement(s_) for s_ in seqs[-4000:]] + seqs + seqs[:15_000]
+    fq = tmp_path / "sh.fastq"
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (k, s_, "I" * len(s_)) for k, s_ in enumerate(seqs)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_sharded_worker, args=(1, 0, str(fq), str(tmp_path), "host"), nprocs=1, join=True)
+    one = pickle.load(open(tmp_path / "w1_r0_host.pkl", "rb"))
+    mp.spawn(_sharded_worker, args=(2, port, str(fq), str(tmp_path), "device"), nprocs=2, join=True)
+    for rank in range(2):
+        got = pickle.load(open(tmp_path / ("w2_r%d_device.pkl" % rank), "rb"))
+        assert got["route"] == "device, sharded"
+        assert got["stats"] == one["stats"], rank
+        for key, v in one["per_ref"]["Reference"].items():
+            w = got["per_ref"]["Reference"][key]
+            assert np.array_equal(v, w) if isinstance(v, np.ndarray) else v == w, (rank, key)
