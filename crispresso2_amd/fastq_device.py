@@ -28,6 +28,7 @@ CHUNK_BYTES = int(os.environ.get("C2_FQ_DEVICE_CHUNK", 256 << 20))     # upper l
 MIN_TEXT_BYTES = int(os.environ.get("C2_FQ_DEVICE_MIN", 64 << 20))      # below this the host parser is as fast and needs no table
 MAX_TEXT_BYTES = 1 << 36                                                 # 64 GiB of text resident; beyond: the host parser
 _pinned = {}
+_upload_lock = None                     # (the pinned upload buffers are per device, not per call: one upload at a time)
 
 
 class DeviceIngestUnavailable(Exception):
@@ -425,6 +426,7 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
                 d_reads, d_off = ing.take_batch(r1, m, longest)
                 on_batch(m, d_reads, d_off, longest)
     fd = os.open(path, os.O_RDONLY) if (text is None and bgzf is None) else -1
+    held = []
     try:
         if bgzf is not None:
             spans = [(int(bgzf.text_offsets[a]), int(bgzf.text_offsets[b]), a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
@@ -454,6 +456,11 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
             return ing.finish(last != b"\n", on_batch)
         import queue
         import threading
+        global _upload_lock
+        if _upload_lock is None:
+            _upload_lock = threading.Lock()
+        _upload_lock.acquire()
+        held.append(True)
         threads = copy_threads()
         key = dev.index
         if key not in _pinned or _pinned[key][0].numel() < chunk:
@@ -526,5 +533,7 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
             timings["device_dedup_tail"] = time.perf_counter() - t0 - timings["upload_text"]
         return out
     finally:
+        if held:
+            _upload_lock.release()
         if fd >= 0:
             os.close(fd)

@@ -4,9 +4,12 @@ Why not tensor.cpu(): a device-to-host copy into PAGEABLE memory makes the HIP r
 measured on the MI355X box (profiles/r03/README.md, "Ingest"): after three 28 MB copies of that kind the next small copy -- an .item() --
 took 20-35 ms, every time.  Through a pinned buffer the same three arrays cost their transfer (0.5 ms each at the link's rate) plus one
 host memcpy each, and nothing later pays for them."""
+import threading
+
 import numpy as np
 
 _staging = {}
+_lock = threading.Lock()                # one staging buffer per device: a copy at a time
 
 
 def to_host(t, dtype=None):
@@ -21,15 +24,16 @@ def to_host(t, dtype=None):
     if nbytes == 0:
         return np.zeros(tuple(t.shape), dtype=dtype or t.numpy(force=True).dtype)
     key = t.device.index
-    buf = _staging.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, pin_memory=True)
-        _staging[key] = buf
-    view = buf[:nbytes].view(t.dtype).view(t.shape)
-    view.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
-    a = view.numpy()
-    return a.astype(dtype) if dtype is not None else a.copy()
+    with _lock:
+        buf = _staging.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, pin_memory=True)
+            _staging[key] = buf
+        view = buf[:nbytes].view(t.dtype).view(t.shape)
+        view.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        a = view.numpy()
+        return a.astype(dtype) if dtype is not None else a.copy()
 
 
 def to_device(a, dev):
@@ -40,13 +44,14 @@ def to_device(a, dev):
     if dev.type != "cuda" or a.nbytes < (1 << 20):
         return torch.from_numpy(a if a.flags.writeable else a.copy()).to(dev)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    buf = _staging.get(key)
-    if buf is None or buf.numel() < a.nbytes:
-        buf = torch.empty(max(a.nbytes, 64 << 20), dtype=torch.uint8, pin_memory=True)
-        _staging[key] = buf
-    flat = a.reshape(-1).view(np.uint8)
-    buf.numpy()[:a.nbytes] = flat
-    out = torch.empty(a.nbytes, dtype=torch.uint8, device=dev)
-    out.copy_(buf[:a.nbytes], non_blocking=True)
-    torch.cuda.current_stream(dev).synchronize()                      # (the staging buffer is free again)
+    with _lock:
+        buf = _staging.get(key)
+        if buf is None or buf.numel() < a.nbytes:
+            buf = torch.empty(max(a.nbytes, 64 << 20), dtype=torch.uint8, pin_memory=True)
+            _staging[key] = buf
+        flat = a.reshape(-1).view(np.uint8)
+        buf.numpy()[:a.nbytes] = flat
+        out = torch.empty(a.nbytes, dtype=torch.uint8, device=dev)
+        out.copy_(buf[:a.nbytes], non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()                  # (the staging buffer is free again)
     return out.view(torch.from_numpy(np.zeros(1, dtype=a.dtype)).dtype).view(a.shape)
