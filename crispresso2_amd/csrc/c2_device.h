@@ -230,7 +230,14 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 
 // count kernel geometry: C2_CNT_WAVES wavefronts share one LDS accumulator block; after the block come
 // C2_CNT_CTL_INTS control words and the current reference's inc_prefix (lmax + 2 uint16)
-#define C2_CNT_WAVES 4
+#ifndef C2_CNT_WAVES
+#define C2_CNT_WAVES 8                 // wavefronts that share one LDS block
+#endif
+#ifndef C2_CNT_OCC
+#define C2_CNT_OCC 8                   // waves per SIMD the count kernels are compiled for (C2_CNT_WAVES x resident workgroups / 4): the kernel waits for
+                                       // memory round trips, one alignment per wave at a time -- 8 waves at 64 VGPRs (some spilled) beat 5 at 96 by 15 %
+                                       // (profiles/r03/ab_count_occupancy.txt)
+#endif
 #define C2_CNT_TASKS_PER_WAVE 32
 #define C2_CNT_CTL_BASE_INTS 96     // >= 16 + 4 * C2_CNT_WAVES
 #define C2_CNT_CTL_INTS (C2_CNT_CTL_BASE_INTS + C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE)   // + per task of a chunk: the part of a heavy weight that is still to be added

@@ -2883,31 +2883,25 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                     else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
                     const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
                     const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
-                    {   // 64 columns in which the read IS the reference, no gap run open in front of them (most chunks of an alignment with
-                        // gaps): nothing closes here and nothing deviates -- only the column counters move
-                        const unsigned long long m_in = __ballot(in);
-                        if (m_rf == m_in && m_rd == m_in && last_rf == base - 1 && last_rd == base - 1 && __ballot(in && rd != rfc) == 0ull) {
-                            const int cols = __popcll(m_in);
-                            idx_base += cols; last_rf = base + cols - 1; last_rd = last_rf;
-                            last_rf_close = false; last_rf_wclose = false;
-                            continue;
-                        }
-                    }
                     const int idx = idx_base + __popcll(m_rf & lt);
                     const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
                     const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
                     const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
-                    // all_base_count, :4075-4081.  A global alignment visits every reference position exactly once, so -- as for the reads
-                    // without gaps -- the alignment's weight goes to ONE scalar that flush() spreads over the reference's own bases, and
-                    // the walk adds only the DEVIATIONS: where the read has another base or a gap, +w there and -w on the reference's base
+                    // all_base_count, :4075-4081.  Columns where the read's base IS the reference's (nearly all of them) are not added one
+                    // by one: a run of them adds its weight to the difference array `cov` at its two ends (see flush)
                     const bool same = rf_ng && rd == rfc;
+                    {
+                        const unsigned long long m_same = __ballot(same);
+                        if (same) {
+                            if (lane == 0 || !((m_same >> (lane - 1)) & 1ull)) atomicAdd(cov + idx, w);
+                            if (lane == 63 || !((m_same >> (lane + 1)) & 1ull)) atomicAdd(cov + idx + 1, -w);
+                        }
+                    }
                     if (rf_ng && !same) {
                         int bv = -1;
                         if (rd == 'A') bv = C2_V_BASE_A; else if (rd == 'C') bv = C2_V_BASE_C; else if (rd == 'G') bv = C2_V_BASE_G;
                         else if (rd == 'T') bv = C2_V_BASE_T; else if (rd == 'N') bv = C2_V_BASE_N; else if (rd == '-') bv = C2_V_BASE_GAP;
                         if (bv >= 0) atomicAdd(acc + bv * VL + idx, w);
-                        const int bvf = c2_base_vector(rfc);
-                        if (bvf >= 0) atomicAdd(acc + bvf * VL + idx, -w);
                         if (!rd_ng) atomicAdd(acc + C2_V_ALL_DELETION * VL + idx, w);                   // :4028
                     }
                     const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
@@ -2976,7 +2970,6 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                     }
                     if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
                 }
-                if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);                               // (the baseline of this alignment, see the walk)
                 if (last_rd != T - 1 && lane == 0) {                                                    // trailing deletion, pyx:155-162
                     const int dlen = T - 1 - last_rd;
                     // legacy (pyx:259-261): the run ends at reference index idx - 1, exclusive -- the last base is not among its positions
@@ -3003,8 +2996,8 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
     flush();
 }
 
-__global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_kernel(c2_count_args A) { c2_count_vectors_body<false>(A); }
-__global__ __launch_bounds__(64 * C2_CNT_WAVES, 5) void c2_count_vectors_hbm_kernel(c2_count_args A) { c2_count_vectors_body<true>(A); }
+__global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vectors_kernel(c2_count_args A) { c2_count_vectors_body<false>(A); }
+__global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vectors_hbm_kernel(c2_count_args A) { c2_count_vectors_body<true>(A); }
 
 
 // =====================================================================================
