@@ -27,8 +27,9 @@ the same JSON line:
                  the headline's packed-int16 first tier
   other_configs  BASELINE.json configs[1], [3], [4] (--config 2, 4, 5) at full size: 3 timed steps each and the chain = full-plane
                  comparison of every alignment
-  e2e            FASTQ -> count tensors (pipeline.quantify_fastq: native ingest + de-duplication, seed test, alignments, selection,
-                 reverse-complement merge, count kernel) on the headline's reads written to /dev/shm, plain and BGZF
+  e2e            FASTQ -> count tensors (pipeline.quantify_fastq: ingest + exact de-duplication, seed test, alignments, selection,
+                 reverse-complement merge, count kernel) on the headline's reads written to /dev/shm: plain text and BGZF, each framed and
+                 de-duplicated on the device under its upload (fastq_device) and, for comparison, through the native host parser
 
 Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 it runs one rank per GPU over RCCL: under
 torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) it is one of the ranks; started bare it
