@@ -830,7 +830,7 @@ def test_device_ingest_with_both_strand_reads_and_partners(tmp_path, monkeypatch
             assert np.array_equal(vv, pr[kk]) if isinstance(vv, np.ndarray) else vv == pr[kk], kk
 
 
-def _many_references_run(tmp_path, ctx=None, n_refs=70):
+def _many_references_run(tmp_path, ctx=None, n_refs=70, expand=True):
     """more references than one 64-bit mask holds: the device selection (two words per read) against the host restatement of the
     reference's loop (pipeline._select_on_host) -- statistics, tensors, allele rows; some references are identical (ties: ambiguous reads)"""
     from crispresso2_amd import pipeline, refs as RF
@@ -852,8 +852,10 @@ def _many_references_run(tmp_path, ctx=None, n_refs=70):
     fq = tmp_path / "many.fastq"
     fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (k, s_, "I" * len(s_)) for k, s_ in enumerate(reads)))
     out = []
-    for host, mode in ((False, {}), (True, {}), (False, {"expand_ambiguous_alignments": True}), (True, {"expand_ambiguous_alignments": True}),
-                       (False, {"assign_ambiguous_alignments_to_first_reference": True}), (True, {"assign_ambiguous_alignments_to_first_reference": True})):
+    runs = [(False, {}), (True, {}), (False, {"assign_ambiguous_alignments_to_first_reference": True}), (True, {"assign_ambiguous_alignments_to_first_reference": True})]
+    if expand:                                                      # (the emulator run leaves this pair to the GPU test: a third of its time)
+        runs += [(False, {"expand_ambiguous_alignments": True}), (True, {"expand_ambiguous_alignments": True})]
+    for host, mode in runs:
         pipeline.FORCE_HOST_SELECTION = host
         try:
             res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(mode), ctx=ctx)
@@ -868,14 +870,15 @@ def _many_references_run(tmp_path, ctx=None, n_refs=70):
                 ww = host_res.per_ref[nm][kk]
                 assert np.array_equal(vv, ww) if isinstance(vv, np.ndarray) else vv == ww, (nm, kk)
     assert out[0].stats["N_AMBIGUOUS"] >= 5                          # the reads of the identical amplicons
-    assert out[2].per_ref["amp66"]["counts_total"] == out[2].per_ref["amp2"]["counts_total"] >= 2       # expanded: counted for both
-    assert out[4].per_ref["amp66"]["counts_total"] == 0 and out[4].per_ref["amp2"]["counts_total"] >= 2   # first reference only
+    assert out[2].per_ref["amp66"]["counts_total"] == 0 and out[2].per_ref["amp2"]["counts_total"] >= 2   # first reference only
+    if expand:
+        assert out[4].per_ref["amp66"]["counts_total"] == out[4].per_ref["amp2"]["counts_total"] >= 2   # expanded: counted for both
 
 
 def test_more_than_64_references_select_on_the_device_emulator(tmp_path):
     from pipeline_on_emulator import emulated_device
     with emulated_device():
-        _many_references_run(tmp_path)
+        _many_references_run(tmp_path, expand=False)
 
 
 @pytest.mark.gpu
