@@ -2497,10 +2497,24 @@ __device__ __forceinline__ int c2_wave_incl_scan(int v, int lane) {
     return v;
 }
 
-// all_base_count vector of a read / reference character (CRISPRessoCORE.py:4075-4081), or -1
+// all_base_count vector of a read / reference character (CRISPRessoCORE.py:4075-4081), or -1.  Without a branch: the compiler turned
+// the chain of comparisons this used to be into a tree of DIVERGENT branches -- ~50 scalar instructions of exec-mask bookkeeping per call,
+// two calls per mismatching column -- and the count kernels are bound by the CU's one scalar unit (244 SALU per alignment,
+// profiles/r03/README.md).  (ch >> 1) & 7 is a perfect hash of A C T G - N (0 1 2 3 6 7); the byte tables are 64-bit constants.
+#define C2_BYTE_TABLE(a0, a1, a2, a3, a6, a7) ((unsigned long long)(a0) | ((unsigned long long)(a1) << 8) | ((unsigned long long)(a2) << 16) | \
+                                               ((unsigned long long)(a3) << 24) | ((unsigned long long)(a6) << 48) | ((unsigned long long)(a7) << 56))
 __device__ __forceinline__ int c2_base_vector(const unsigned char ch) {
-    return ch == 'A' ? C2_V_BASE_A : ch == 'C' ? C2_V_BASE_C : ch == 'G' ? C2_V_BASE_G : ch == 'T' ? C2_V_BASE_T :
-           ch == 'N' ? C2_V_BASE_N : ch == '-' ? C2_V_BASE_GAP : -1;
+    const unsigned sh = (((unsigned)ch >> 1) & 7u) * 8u;
+    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', '-', 'N') >> sh) & 0xffu;
+    const unsigned v = (unsigned)(C2_BYTE_TABLE(C2_V_BASE_A, C2_V_BASE_C, C2_V_BASE_T, C2_V_BASE_G, C2_V_BASE_GAP, C2_V_BASE_N) >> sh) & 0xffu;
+    return is == (unsigned)ch ? (int)v : -1;
+}
+// substitution_count_vectors of a read base (:4049-4054): A C G T only, else -1
+__device__ __forceinline__ int c2_sub_base_vector(const unsigned char ch) {
+    const unsigned sh = (((unsigned)ch >> 1) & 7u) * 8u;
+    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', 0, 0) >> sh) & 0xffu;
+    const unsigned v = (unsigned)(C2_BYTE_TABLE(C2_V_ALL_SUB_BASE_A, C2_V_ALL_SUB_BASE_C, C2_V_ALL_SUB_BASE_T, C2_V_ALL_SUB_BASE_G, 0, 0) >> sh) & 0xffu;
+    return (ch != 0 && is == (unsigned)ch) ? (int)v : -1;
 }
 
 // Tasks grouped by reference for the count kernel (a chunk of consecutive positions then holds one or two references
@@ -2821,9 +2835,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                                 atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
                                 if (!ign_sub) {
                                     if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
-                                    int sv = -1;                                                // :4049-4054
-                                    if (rd == 'A') sv = C2_V_ALL_SUB_BASE_A; else if (rd == 'C') sv = C2_V_ALL_SUB_BASE_C;
-                                    else if (rd == 'G') sv = C2_V_ALL_SUB_BASE_G; else if (rd == 'T') sv = C2_V_ALL_SUB_BASE_T;
+                                    const int sv = c2_sub_base_vector(rd);                      // :4049-4054
                                     if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
                                 }
                             }
@@ -2864,9 +2876,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                                 atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
                                 if (!ign_sub) {
                                     if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
-                                    int sv = -1;                                                // :4049-4054
-                                    if (rd == 'A') sv = C2_V_ALL_SUB_BASE_A; else if (rd == 'C') sv = C2_V_ALL_SUB_BASE_C;
-                                    else if (rd == 'G') sv = C2_V_ALL_SUB_BASE_G; else if (rd == 'T') sv = C2_V_ALL_SUB_BASE_T;
+                                    const int sv = c2_sub_base_vector(rd);                      // :4049-4054
                                     if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
                                 }
                             }
@@ -2898,9 +2908,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                         }
                     }
                     if (rf_ng && !same) {
-                        int bv = -1;
-                        if (rd == 'A') bv = C2_V_BASE_A; else if (rd == 'C') bv = C2_V_BASE_C; else if (rd == 'G') bv = C2_V_BASE_G;
-                        else if (rd == 'T') bv = C2_V_BASE_T; else if (rd == 'N') bv = C2_V_BASE_N; else if (rd == '-') bv = C2_V_BASE_GAP;
+                        const int bv = c2_base_vector(rd);
                         if (bv >= 0) atomicAdd(acc + bv * VL + idx, w);
                         if (!rd_ng) atomicAdd(acc + C2_V_ALL_DELETION * VL + idx, w);                   // :4028
                     }
@@ -2909,9 +2917,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                         atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + idx, w);                           // :4040
                         if (!ign_sub) {
                             if (incp[idx + 1] != incp[idx]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + idx, w);   // :4044
-                            int sv = -1;                                                                // :4049-4054
-                            if (rd == 'A') sv = C2_V_ALL_SUB_BASE_A; else if (rd == 'C') sv = C2_V_ALL_SUB_BASE_C;
-                            else if (rd == 'G') sv = C2_V_ALL_SUB_BASE_G; else if (rd == 'T') sv = C2_V_ALL_SUB_BASE_T;
+                            const int sv = c2_sub_base_vector(rd);                                      // :4049-4054
                             if (sv >= 0) atomicAdd(acc + sv * VL + idx, w);
                         }
                     }
