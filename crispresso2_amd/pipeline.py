@@ -790,17 +790,21 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         g_cnt = np.ascontiguousarray(g_raw.copy())
         _native.merge_counts_with_partners(exchange_aligned(aligned), partners['index'], g_cnt)
         cnt = np.ascontiguousarray(g_cnt[shard_idx])
-    stats['N_TOTAL'] = int(cnt[aligned].sum())
+    # (whole-array arithmetic instead of boolean fancy indexing: these are passes over millions of unique reads)
+    stats['N_TOTAL'] = int(np.dot(cnt, aligned.astype(np.int64)))
     counted = member.copy()
     ambiguous = aligned & (n_best > 1)
+    any_ambiguous = bool(ambiguous.any())
     if args.assign_ambiguous_alignments_to_first_reference:
-        first = np.argmax(member, axis=1)
-        counted[ambiguous, :] = False
-        counted[ambiguous, first[ambiguous]] = True
+        if any_ambiguous:
+            first = np.argmax(member, axis=1)
+            counted[ambiguous, :] = False
+            counted[ambiguous, first[ambiguous]] = True
     elif not args.expand_ambiguous_alignments:
-        counted[ambiguous, :] = False
-        stats['N_AMBIGUOUS'] = int(cnt[ambiguous].sum())
-    counted[~aligned, :] = False
+        if any_ambiguous:
+            counted &= ~ambiguous[:, None]
+        stats['N_AMBIGUOUS'] = int(np.dot(cnt, ambiguous.astype(np.int64))) if any_ambiguous else 0
+    counted &= aligned[:, None]
     # ---- prime-editing scaffold rule (:786-796): a read whose best amplicons include 'Prime-edited' and whose alignment against it
     # shows the scaffold's first bases right after the extension is counted for 'Scaffold-incorporated' ONLY (ambiguous or not),
     # with that alignment.  The aligned strings of the candidate reads come to the host for the substring test.
@@ -846,7 +850,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if on_device:
         # the weight of every alignment in the count pass: the kernel again, now with the merged multiplicities (a read the
         # scaffold rule took away counts for no amplicon here)
-        d_cnt = to_device(np.where(scaffold_hit, 0, cnt).astype(np.uint32).view(np.int32), dev)
+        d_cnt = to_device((np.where(scaffold_hit, 0, cnt) if scaffold_rule else cnt).astype(np.uint32).view(np.int32), dev)
         d_w1 = torch.zeros(n1, dtype=torch.int32, device=dev)
         if n2:
             d_w2 = torch.zeros(n2, dtype=torch.int32, device=dev)
