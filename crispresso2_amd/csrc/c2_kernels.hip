@@ -3205,18 +3205,15 @@ __global__ __launch_bounds__(256) void c2_fq_gather_kernel(c2_fq_gather_args A)
     }
 }
 
-// complement of an upper-cased read character, 0 outside ACGTN_- (CRISPRessoShared.reverse_complement's dictionary)
+// complement of an upper-cased read character, 0 outside ACGTN_- (CRISPRessoShared.reverse_complement's dictionary).  A table look-up,
+// not a switch: the compiler lowers a switch on a per-lane value to a tree of divergent branches (see c2_base_vector).  (c >> 1) & 7
+// sends A/a C/c T/t G/g - N/n to 0 1 2 3 6 7; '_' shares N's slot and is tested by itself.
 __device__ __forceinline__ unsigned c2_fq_complement(const unsigned c) {
-    switch (c) {
-        case 'A': case 'a': return 'T';
-        case 'C': case 'c': return 'G';
-        case 'G': case 'g': return 'C';
-        case 'T': case 't': return 'A';
-        case 'N': case 'n': return 'N';
-        case '_': return '_';
-        case '-': return '-';
-        default: return 0u;
-    }
+    const unsigned h = (c >> 1) & 7u, sh = h * 8u;
+    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', '-', 'N') >> sh) & 0xffu;
+    const unsigned to = (unsigned)(C2_BYTE_TABLE('T', 'G', 'A', 'C', '-', 'N') >> sh) & 0xffu;
+    const bool letter = h != 6u && is != 0u && (c | 0x20u) == (is | 0x20u);
+    return c == '_' ? (unsigned)'_' : (letter || c == '-') ? to : 0u;
 }
 
 __global__ __launch_bounds__(256) void c2_fq_rc_partner_kernel(c2_fq_rc_args A)
