@@ -78,6 +78,21 @@ __host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_p
 
 extern __shared__ __attribute__((aligned(16))) unsigned char c2_smem[];
 
+// (ch >> 1) & 7 is a perfect hash of A C T G - N (0 1 2 3 6 7; lower case lands on the same slots): byte tables as 64-bit constants
+#define C2_BYTE_TABLE(a0, a1, a2, a3, a6, a7) ((unsigned long long)(a0) | ((unsigned long long)(a1) << 8) | ((unsigned long long)(a2) << 16) | \
+                                               ((unsigned long long)(a3) << 24) | ((unsigned long long)(a6) << 48) | ((unsigned long long)(a7) << 56))
+// complement of an upper-cased read character, 0 outside ACGTN_- (CRISPRessoShared.reverse_complement's dictionary).  A table look-up,
+// not a switch: the compiler lowers a switch on a per-lane value to a tree of divergent branches (see c2_base_vector).  (c >> 1) & 7
+// sends A/a C/c T/t G/g - N/n to 0 1 2 3 6 7; '_' shares N's slot and is tested by itself.
+__device__ __forceinline__ unsigned c2_fq_complement(const unsigned c) {
+    const unsigned h = (c >> 1) & 7u, sh = h * 8u;
+    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', '-', 'N') >> sh) & 0xffu;
+    const unsigned to = (unsigned)(C2_BYTE_TABLE('T', 'G', 'A', 'C', '-', 'N') >> sh) & 0xffu;
+    const bool letter = h != 6u && is != 0u && (c | 0x20u) == (is | 0x20u);
+    return c == '_' ? (unsigned)'_' : (letter || c == '-') ? to : 0u;
+}
+
+
 // Region executed with some lanes switched off in EXEC for its whole length (one s_and_saveexec; no per-instruction
 // cost).  The wave emulator (tests/emu) supplies its own definition, which parks the inactive fibers.
 #ifndef C2_LANES_ACTIVE_BEGIN
@@ -443,10 +458,7 @@ __device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_w
         if (HAVE_B4 && k < 256) ch = (unsigned char)((pf.b4 >> ((k >> 6) * 8)) & 0xffu);
         else ch = A.reads[pf.off + (uint64_t)(rc ? Lj - 1 - k : k)];
         if (rc) {
-            if (ch >= 'a' && ch <= 'z') ch -= 32;                       // seq.upper()
-            unsigned char cc = 0;
-            if (ch == 'A') cc = 'T'; else if (ch == 'C') cc = 'G'; else if (ch == 'G') cc = 'C';
-            else if (ch == 'T') cc = 'A'; else if (ch == 'N' || ch == '_' || ch == '-') cc = ch;
+            unsigned char cc = (unsigned char)c2_fq_complement(ch);     // seq.upper(), then the dictionary; 0: a character outside it
             if (cc == 0) { status |= C2_STATUS_RC_CHAR; cc = 'N'; }
             ch = cc;
         }
@@ -2501,8 +2513,6 @@ __device__ __forceinline__ int c2_wave_incl_scan(int v, int lane) {
 // the chain of comparisons this used to be into a tree of DIVERGENT branches -- ~50 scalar instructions of exec-mask bookkeeping per call,
 // two calls per mismatching column -- and the count kernels are bound by the CU's one scalar unit (244 SALU per alignment,
 // profiles/r03/README.md).  (ch >> 1) & 7 is a perfect hash of A C T G - N (0 1 2 3 6 7); the byte tables are 64-bit constants.
-#define C2_BYTE_TABLE(a0, a1, a2, a3, a6, a7) ((unsigned long long)(a0) | ((unsigned long long)(a1) << 8) | ((unsigned long long)(a2) << 16) | \
-                                               ((unsigned long long)(a3) << 24) | ((unsigned long long)(a6) << 48) | ((unsigned long long)(a7) << 56))
 __device__ __forceinline__ int c2_base_vector(const unsigned char ch) {
     const unsigned sh = (((unsigned)ch >> 1) & 7u) * 8u;
     const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', '-', 'N') >> sh) & 0xffu;
@@ -3203,17 +3213,6 @@ __global__ __launch_bounds__(256) void c2_fq_gather_kernel(c2_fq_gather_args A)
         uint8_t* o = A.out + A.out_offsets[i];
         for (uint64_t k = (uint64_t)lane; k < len; k += 64) o[k] = A.text[s + k];
     }
-}
-
-// complement of an upper-cased read character, 0 outside ACGTN_- (CRISPRessoShared.reverse_complement's dictionary).  A table look-up,
-// not a switch: the compiler lowers a switch on a per-lane value to a tree of divergent branches (see c2_base_vector).  (c >> 1) & 7
-// sends A/a C/c T/t G/g - N/n to 0 1 2 3 6 7; '_' shares N's slot and is tested by itself.
-__device__ __forceinline__ unsigned c2_fq_complement(const unsigned c) {
-    const unsigned h = (c >> 1) & 7u, sh = h * 8u;
-    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', '-', 'N') >> sh) & 0xffu;
-    const unsigned to = (unsigned)(C2_BYTE_TABLE('T', 'G', 'A', 'C', '-', 'N') >> sh) & 0xffu;
-    const bool letter = h != 6u && is != 0u && (c | 0x20u) == (is | 0x20u);
-    return c == '_' ? (unsigned)'_' : (letter || c == '-') ? to : 0u;
 }
 
 __global__ __launch_bounds__(256) void c2_fq_rc_partner_kernel(c2_fq_rc_args A)
