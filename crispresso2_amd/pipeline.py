@@ -505,6 +505,8 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         arena, offsets, read_counts = front["arena"], front["offsets"], front["counts"]
         t_last[0] = time.perf_counter()
     shard_of_all = isinstance(shard, str) and shard == "mine"          # (the rank's range of a list whose length is not known yet)
+    if isinstance(shard, str) and not (shard_of_all and device_reads is not None):
+        raise ValueError('shard is None, (lo, hi), an index array, or "mine" together with device_reads')
     if device_reads is not None:
         if fastq_stream is not None or (shard is not None and not shard_of_all and not isinstance(shard, tuple)):
             raise ValueError("device_reads takes no fastq_stream and only contiguous shards")
