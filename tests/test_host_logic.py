@@ -195,3 +195,18 @@ def test_rc_partner_search_with_torch_ops_equals_the_native_search():
     got = pipeline.rc_partners_device(torch.from_numpy(arena).view(len(seqs), L)).result()
     assert got is not None and np.array_equal(got, want)
     assert (want >= 0).sum() > 200 and (want == np.arange(len(seqs))).sum() >= 1 and (want < 0).sum() > 100
+
+
+def test_hostcopy_round_trip_on_the_cpu_device():
+    """hostcopy.to_device / to_host on a non-GPU device: plain copies with the dtype conversions the pipeline asks for"""
+    import torch
+    from crispresso2_amd.hostcopy import to_device, to_host
+    a = np.arange(2_000_000, dtype=np.int32)
+    t = to_device(a, torch.device("cpu"))
+    assert t.dtype == torch.int32 and t.shape == (2_000_000,)
+    b = to_host(t, np.int64)
+    assert b.dtype == np.int64 and np.array_equal(b, a)
+    a[0] = 7                                                          # (copies, not views)
+    assert int(t[0]) in (0, 7) and b[0] == 0
+    e = to_host(torch.zeros((0, 3), dtype=torch.uint8))
+    assert e.shape == (0, 3)
