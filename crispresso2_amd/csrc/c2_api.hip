@@ -1593,8 +1593,14 @@ int c2_strand_plan_device(c2_ctx* ctx, uint64_t n_reads, const uint8_t* d_reads,
     for (int r = 0; r < n_refs; ++r) if (h_n_seeds && (h_n_seeds[r] < 0 || h_n_seeds[r] > max_seeds)) { ctx->err = "n_seeds out of range"; return C2_E_INVALID; }
     for (size_t q = 0; q < (max_seeds ? tbl : 0); ++q)
         if (h_seed_len[q] < 0 || h_seed_off[q] < 0 || (int64_t)h_seed_off[q] + h_seed_len[q] > blob_bytes) { ctx->err = "seed outside the blob"; return C2_E_INVALID; }
-    const uint32_t lds = 4u * (uint32_t)((max_read_len + 15) & ~15);
+    uint32_t lds = 4u * c2_strand_row_bytes(max_read_len);
     if (lds > 163840u) { ctx->err = "read longer than the strand-plan kernel's LDS row"; return C2_E_TOO_LARGE; }
+    // seeds of at most C2_SEED_SLOT bytes whose table fits behind the read rows are compared from LDS, four bytes at a time
+    bool seed_table = max_seeds > 0;
+    for (size_t q = 0; q < (max_seeds ? tbl : 0) && seed_table; ++q) if ((uint32_t)h_seed_len[q] > C2_SEED_SLOT) seed_table = false;
+    if (seed_table && (uint64_t)lds + (uint64_t)tbl * C2_SEED_SLOT > 65536u) seed_table = false;
+    if (getenv("C2_STRAND_PLAN_BYTEWISE")) seed_table = false;
+    if (seed_table) lds += (uint32_t)tbl * C2_SEED_SLOT;
     // one staging block: blob | seed_off | seed_len | n_seeds  (host copy first: a single small upload)
     const size_t o_off = ((size_t)blob_bytes + 15) & ~(size_t)15, o_len = o_off + tbl * 4, o_n = o_len + tbl * 4, total = o_n + (size_t)n_refs * 4;
     std::vector<uint8_t> host(total, 0);
@@ -1615,6 +1621,7 @@ int c2_strand_plan_device(c2_ctx* ctx, uint64_t n_reads, const uint8_t* d_reads,
     A.reads = d_reads; A.offsets = d_offsets; A.n_reads = n_reads; A.seed_blob = base;
     A.seed_off = (const int32_t*)(base + o_off); A.seed_len = (const int32_t*)(base + o_len); A.n_seeds = (const int32_t*)(base + o_n);
     A.n_refs = n_refs; A.max_seeds = std::max(max_seeds, 1); A.seed_min = seed_min; A.max_read_len = max_read_len; A.plan = d_plan;
+    A.seed_table = seed_table ? 1 : 0; A.reserved = 0;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_strand_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     const uint64_t wgs = std::min<uint64_t>((n_reads + 3) / 4, (uint64_t)ctx->prop.multiProcessorCount * 8u);
     hipLaunchKernelGGL(c2_strand_plan_kernel, dim3((unsigned)std::max<uint64_t>(1, wgs)), dim3(256), lds, s, A);

@@ -150,7 +150,13 @@ struct c2_strand_args {
     const int32_t* n_seeds;           // [n_refs]: seeds that take part (min(aln_seed_count, seeds of the reference))
     int32_t n_refs, max_seeds, seed_min, max_read_len;
     uint8_t* plan;                    // [n_reads][n_refs]: 0 forward only, 1 reverse complement only, 2 both
+    int32_t seed_table;               // 1: every seed is at most C2_SEED_SLOT bytes and the table of all of them fits LDS behind the read rows --
+                                      // the kernel copies them there once and compares four bytes at a time; 0: byte by byte from global memory
+    int32_t reserved;
 };
+#define C2_SEED_SLOT 32u               // bytes of one seed in the LDS table (zero padded)
+// LDS of c2_strand_plan_kernel: one row per wavefront (the read, + 16 bytes that the window reads may touch), then the seed table
+#define c2_strand_row_bytes(max_read_len) ((uint32_t)(((max_read_len) + 15) & ~15) + 16u)
 
 // ---- FASTQ framing + exact de-duplication on the device (the readline loop of process_fastq, CRISPRessoCORE.py:1820-1849) ----
 // The text (no '\r' in it: the host falls back to its own parser otherwise) lies in HBM; lines end at '\n'; line k is ended by

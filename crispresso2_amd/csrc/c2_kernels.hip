@@ -2337,8 +2337,19 @@ __global__ __launch_bounds__(64) void c2_selftest_rows_kernel(int* out)
 __global__ __launch_bounds__(256) void c2_strand_plan_kernel(c2_strand_args A)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t row = (uint32_t)((A.max_read_len + 15) & ~15);
+    const uint32_t row = c2_strand_row_bytes(A.max_read_len);
     unsigned char* sRead = c2_smem + (uint32_t)wave * row;
+    unsigned char* sSeeds = c2_smem + 4u * row;                      // [n_refs][2][max_seeds][C2_SEED_SLOT], zero padded (seed_table)
+    if (A.seed_table) {
+        const int n_slots = A.n_refs * 2 * A.max_seeds;
+        for (int e = threadIdx.x; e < n_slots * (int)(C2_SEED_SLOT / 4u); e += blockDim.x) ((uint32_t*)sSeeds)[e] = 0u;
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_slots * (int)C2_SEED_SLOT; e += blockDim.x) {
+            const int slot = e / (int)C2_SEED_SLOT, k = e % (int)C2_SEED_SLOT;
+            if (k < A.seed_len[slot]) sSeeds[e] = A.seed_blob[A.seed_off[slot] + k];
+        }
+        __syncthreads();
+    }
     for (uint64_t i = (uint64_t)blockIdx.x * 4u + (uint64_t)wave; i < A.n_reads; i += (uint64_t)gridDim.x * 4u) {
         const uint64_t o = A.offsets[i];
         const int Lj = (int)(A.offsets[i + 1] - o);
@@ -2353,13 +2364,35 @@ __global__ __launch_bounds__(256) void c2_strand_plan_kernel(c2_strand_args A)
                     const int len = A.seed_len[idx];
                     if (len == 0) { ++found[st]; continue; }
                     if (len > Lj) continue;
-                    const uint8_t* seed = A.seed_blob + A.seed_off[idx];
                     bool any = false;
-                    for (int base = 0; base + len <= Lj && !any; base += 64) {
-                        const int p = base + lane;
-                        bool ok = p + len <= Lj;
-                        for (int k = 0; k < len && __ballot(ok) != 0ull; ++k) ok = ok && sRead[ok ? p + k : 0] == seed[k];
-                        any = __ballot(ok) != 0ull;
+                    if (A.seed_table) {
+                        // four bytes of the seed against four bytes of the window at a time: the window dword at byte p + 4 j comes out of the two
+                        // aligned LDS dwords around it (v_alignbyte); the seed's dwords are read once (same address in every lane: a broadcast)
+                        const uint32_t* sd = (const uint32_t*)(sSeeds + (uint32_t)idx * C2_SEED_SLOT);
+                        const int nd = (len + 3) >> 2;
+                        const uint32_t last_mask = (len & 3) ? ((1u << (8 * (len & 3))) - 1u) : 0xffffffffu;
+                        const uint32_t* sRead32 = (const uint32_t*)sRead;
+                        for (int base = 0; base + len <= Lj && !any; base += 64) {
+                            const int p = base + lane;
+                            const bool in = p + len <= Lj;
+                            const int pc = in ? p : 0;                 // (a lane without a window reads the first one: inside the row)
+                            uint32_t diff = 0;
+                            for (int j = 0; j < nd; ++j) {
+                                const int b = pc + 4 * j;
+                                const uint32_t lo = sRead32[b >> 2], hi = sRead32[(b >> 2) + 1];
+                                const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(b & 3));
+                                diff |= (w ^ sd[j]) & (j == nd - 1 ? last_mask : 0xffffffffu);
+                            }
+                            any = __ballot(in && diff == 0u) != 0ull;
+                        }
+                    } else {
+                        const uint8_t* seed = A.seed_blob + A.seed_off[idx];
+                        for (int base = 0; base + len <= Lj && !any; base += 64) {
+                            const int p = base + lane;
+                            bool ok = p + len <= Lj;
+                            for (int k = 0; k < len && __ballot(ok) != 0ull; ++k) ok = ok && sRead[ok ? p + k : 0] == seed[k];
+                            any = __ballot(ok) != 0ull;
+                        }
                     }
                     if (any) ++found[st];
                 }

@@ -344,7 +344,15 @@ int emu_strand_plan(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     c2_strand_args A;
     A.reads = reads; A.offsets = offsets; A.n_reads = n_reads; A.seed_blob = seed_blob; A.seed_off = seed_off; A.seed_len = seed_len;
     A.n_seeds = n_seeds; A.n_refs = n_refs; A.max_seeds = max_seeds; A.seed_min = seed_min; A.max_read_len = max_read_len; A.plan = plan;
-    if ((size_t)4 * (size_t)((max_read_len + 15) & ~15) > sizeof(c2_smem)) return -5;
+    // the seed table in LDS, as c2_strand_plan_device decides it (C2_EMU_STRAND_BYTEWISE: the byte-by-byte path instead)
+    const size_t tbl = (size_t)n_refs * 2 * (size_t)max_seeds;
+    bool table = tbl > 0 && !getenv("C2_EMU_STRAND_BYTEWISE");
+    for (size_t q = 0; q < tbl && table; ++q) if ((uint32_t)seed_len[q] > C2_SEED_SLOT) table = false;
+    size_t lds = (size_t)4 * c2_strand_row_bytes(max_read_len);
+    if (table && lds + tbl * C2_SEED_SLOT > 65536) table = false;
+    if (table) lds += tbl * C2_SEED_SLOT;
+    A.seed_table = table ? 1 : 0; A.reserved = 0;
+    if (lds > sizeof(c2_smem)) return -5;
     emu::launch(3, [&] { c2_strand_plan_kernel(A); }, 256);
     return 0;
 }

@@ -148,6 +148,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
     return (int)(uint32_t)v;
 }
 inline long long clock64() { return 0; }
+inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned shift) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (shift & 3))); }
 inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned shift) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (shift & 31)); }
 // v_perm_b32 for selectors 0..7: byte i of the result = byte sel[i] of the 64-bit {hi, lo}
 inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t sel) {

@@ -145,10 +145,15 @@ def _seed_case(seed_count, seed_len, seed_min):
     return args, refs, ["A", "B"], reads
 
 
-@pytest.mark.parametrize("seed_count,seed_len,seed_min", [(5, 10, 2), (1, 10, 0), (9, 7, 4), (3, 40, 1), (0, 10, 0)])
-def test_strand_plan_kernel_equals_the_host_seed_test(seed_count, seed_len, seed_min):
+@pytest.mark.parametrize("bytewise", [False, True])
+@pytest.mark.parametrize("seed_count,seed_len,seed_min", [(5, 10, 2), (1, 10, 0), (9, 7, 4), (3, 40, 1), (0, 10, 0), (4, 32, 1), (4, 5, 0)])
+def test_strand_plan_kernel_equals_the_host_seed_test(seed_count, seed_len, seed_min, bytewise, monkeypatch):
     """c2_strand_plan_kernel (one wavefront per read, all references) on the emulator = the host's threaded c2_strand_plan = the
     statements of get_new_variant_object (CRISPRessoCORE.py:656-687) in variants._strand_plan."""
+    # (bytewise: the kernel's byte-by-byte path, which seeds of more than 32 bytes take anyway; else the LDS seed table with four-byte
+    #  window compares -- seed lengths 5, 7, 10, 32 are 2, 2, 3, 8 dwords with and without a partial last one)
+    if bytewise:
+        monkeypatch.setenv("C2_EMU_STRAND_BYTEWISE", "1")
     from crispresso2_amd import _native, counts as C, variants
     args, refs, names, reads = _seed_case(seed_count, seed_len, seed_min)
     arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8).copy()
