@@ -330,6 +330,7 @@ class DeviceIngest:
             counts, lens_h, d_counts = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), None
         # which unique read is the reverse complement of which (the count merge asks): looked up in the table, which is still here
         rc_partner = np.zeros(0, dtype=np.int64)
+        d_rc_partner = None
         if self.batches:
             slot_u = self.slot_of[rec].to(torch.int64)
             pslot = torch.empty(n, dtype=torch.int32, device=self.dev)
@@ -337,7 +338,8 @@ class DeviceIngest:
                           pslot.data_ptr(), self._stream())
             unique_of_slot = torch.full((self.n_slots,), -1, dtype=torch.int64, device=self.dev)
             unique_of_slot[slot_u] = torch.arange(n, dtype=torch.int64, device=self.dev)
-            rc_partner = to_host(torch.where(pslot >= 0, unique_of_slot[pslot.to(torch.int64).clamp_(min=0)], -1).to(torch.int32), np.int64)
+            d_rc_partner = torch.where(pslot >= 0, unique_of_slot[pslot.to(torch.int64).clamp_(min=0)], -1)     # (stays on the device for the count transfer)
+            rc_partner = to_host(d_rc_partner.to(torch.int32), np.int64)
         lap("multiplicities and lengths on the host")
         off64 = np.zeros(n + 1, dtype=np.int64)
         lap("zeros")
@@ -350,7 +352,7 @@ class DeviceIngest:
         bb = [int(x) for x in np.diff(off64[np.concatenate([[0], ends])])] if self.batches else []      # bytes of every batch
         lap("batch bytes")
         out = dict(offsets=offsets, counts=counts, n_reads=n_records, n_empty_records=n_empty, nonempty_lines=nonempty, n_unique=n,
-                   max_len=mx, min_len=mn, batch_bytes=bb, rc_partner=rc_partner, d_counts=d_counts)
+                   max_len=mx, min_len=mn, batch_bytes=bb, rc_partner=rc_partner, d_counts=d_counts, d_rc_partner=d_rc_partner)
         if last is not None and len(self.batches) == 1:
             out["d_reads"], out["d_off"] = last
         lap("offsets")

@@ -42,10 +42,16 @@ class QuantResult:
     alleles(): the rows of the allele frequency table."""
     def __init__(self, per_ref, stats, layout, tensor, state=None, first_ref_view=None):
         self.per_ref, self.stats, self.layout, self.tensor = per_ref, stats, layout, tensor
-        self._state = state
+        self._state_src = state                                       # the dict alleles() reads, or a function that brings it to the host when asked
         # {name: all_* count vectors of the reads counted for that amplicon, in the coordinates of the FIRST amplicon}
         # (CRISPRessoCORE.py:4195-4270; built for runs with an expected HDR amplicon / prime-editing extension), else None
         self.first_ref_view = first_ref_view
+
+    @property
+    def _state(self):
+        if callable(self._state_src):
+            self._state_src = self._state_src()
+        return self._state_src
 
     def alleles(self, gather=False):
         """Rows (Aligned_Sequence, Reference_Sequence, Reference_Name, Read_Status, n_deleted, n_inserted, n_mutated, #Reads,
@@ -136,6 +142,7 @@ class QuantResult:
 
 FORCE_HOST_SELECTION = False        # tests: run the host restatement of the selection (_select_on_host) instead of c2_select_best_kernel
 FORCE_HOST_STRAND_PLAN = False      # tests: the host's c2_strand_plan instead of c2_strand_plan_device
+FORCE_HOST_MERGE = False            # tests: the reverse-complement count transfer and the weights on the host (the reference's sequential loop) instead of the device pass
 
 
 def _select_on_host(r1, r2, n, k, n2, bi, br, slot2, min_scores, raw, stats):
@@ -208,6 +215,10 @@ class _DevicePartners:
         if bool(self._bad.item()):
             return None
         return to_host(self._partner)
+
+    def partner_tensor(self):
+        """the same on the device (int64 [n]), or None"""
+        return None if bool(self._bad.item()) else self._partner
 
 
 def rc_partners_device(d_reads2d):
@@ -762,15 +773,74 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             if int(st["a_bad_status"]) & _native.STATUS_RC_CHAR:
                 raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
             raise Exception('global_align: undefined alignment (status %d)' % int(st["a_bad_status"]))
-        # the kernel's 64-bit masks (bit r: reference r) are taken apart on the device: n x k bytes cross the link, not 16 n
-        ref_ix = torch.arange(k, dtype=torch.int64, device=dev)
-        word_of, bit_of = ref_ix >> 6, (ref_ix & 63)[None, :]
-        member = to_host(((d_member[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool)
-        use2 = to_host(((d_use2[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool)
-        aligned = to_host(d_flags & 1).view(bool)
         for q in ('N_COMPUTED_ALN', 'N_COMPUTED_NOTALN', 'N_CACHED_ALN', 'N_CACHED_NOTALN', 'N_GLOBAL_SUBS', 'N_SUBS_OUTSIDE_WINDOW',
                   'N_MODS_IN_WINDOW', 'N_MODS_OUTSIDE_WINDOW', 'N_READS_IRREGULAR_ENDS'):
             stats[q] = int(st[q])
+        # the kernel's 64-bit masks (bit r: reference r) are taken apart on the device: n x k bytes cross the link, not 16 n
+        ref_ix = torch.arange(k, dtype=torch.int64, device=dev)
+        word_of, bit_of = ref_ix >> 6, (ref_ix & 63)[None, :]
+
+        def masks_to_host():
+            return (to_host(((d_member[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool),
+                    to_host(((d_use2[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool), to_host(d_flags & 1).view(bool))
+        if shard is None and not scaffold_rule and not want_view and not FORCE_HOST_MERGE:
+            # ---- the rest of the run without the host in it: the reverse-complement count transfer (:3970-3975), N_TOTAL / N_AMBIGUOUS, the
+            # weights and the count pass on the device; what alleles() reads comes to the host when it is asked for.  The transfer is
+            # sequential in the reference; over partner PAIRS (i <-> j, or i its own partner) it is independent work: when both reads
+            # aligned and have copies the earlier one takes the later one's (a palindrome doubles).  That needs the partner relation to
+            # be symmetric -- lower-case reads break it (their reverse complement is upper case): then the host applies the loop.
+            partner_thread.join()
+            if 'error' in partners:
+                raise partners['error']
+            if partners.get('device') is not None:
+                d_partner = partners['device'].partner_tensor()
+            elif device_reads is not None and device_reads.get("d_rc_partner") is not None:
+                d_partner = device_reads["d_rc_partner"]
+            else:
+                d_partner = to_device(np.ascontiguousarray(partners['index'], dtype=np.int64), dev)
+            if d_partner is not None:
+                ix = torch.arange(n, dtype=torch.int64, device=dev)
+                has = d_partner >= 0
+                pc = d_partner.clamp(min=0)
+                asym = (has & (d_partner[pc] != ix)).sum()
+                c0 = d_raw.to(torch.int64) & 0xffffffff
+                d_al = (d_flags & 1) != 0
+                ok = d_al & (c0 > 0)
+                takes = has & (d_partner > ix) & ok & ok[pc]                  # the earlier read of an aligned pair with copies
+                gives = has & (d_partner < ix) & takes[pc]                    # ... and its partner
+                own = has & (d_partner == ix) & ok
+                c1 = torch.where(gives, torch.zeros_like(c0), c0 + torch.where(takes, c0[pc], torch.zeros_like(c0)) + torch.where(own, c0, torch.zeros_like(c0)))
+                d_amb = (d_flags & 2) != 0
+                sums = to_host(torch.stack([asym, (c1 * d_al).sum(), (c1 * d_amb).sum(), c1.max() if n else asym * 0]))
+                if int(sums[0]) == 0:
+                    if int(sums[3]) > 0x7FFFFFFF:
+                        raise OverflowError("a read multiplicity exceeds 2^31 - 1")
+                    stats['N_TOTAL'] = int(sums[1])
+                    if not args.assign_ambiguous_alignments_to_first_reference and not args.expand_ambiguous_alignments:
+                        stats['N_AMBIGUOUS'] = int(sums[2])
+                    lap("rc_merge_weights")
+                    d_cnt = c1.to(torch.int32)
+                    d_w1 = torch.zeros(n1, dtype=torch.int32, device=dev)
+                    d_w2 = torch.zeros(n2, dtype=torch.int32, device=dev) if n2 else None
+                    C.select_best_device(ctx, n, k, r1.data_ptr(), min_mscore, mode, max(stride, stride2),
+                                         d_records2=r2.data_ptr() if n2 else None, d_slot2=d_slot2.data_ptr() if n2 else None,
+                                         d_counts=d_cnt.data_ptr(), d_weights=d_w1.data_ptr(), d_weights2=d_w2.data_ptr() if n2 else None, stream=stream)
+                    C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_counts.data_ptr(),
+                                        d_weights=d_w1.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=stream)
+                    if n2:
+                        C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_counts.data_ptr(),
+                                            d_weights=d_w2.data_ptr(), flags=flags, stream=stream)
+                    if reduce_across_ranks:
+                        C.all_reduce(d_counts)
+                        reduce_stats()
+                    torch.cuda.synchronize(dev)
+
+                    def state_on_host():
+                        member_, use2_, aligned_ = masks_to_host()
+                        return dict(args=args, ref_names=list(ref_names), member=member_, aligned=aligned_, cnt=to_host(c1), use2=use2_, slot2=slot2,
+                                    scaffold_hit=np.zeros(n, dtype=bool), scaffold_ref=pe, a1=a1, f1=f1, r1=r1, a2=a2, f2=f2, r2=r2)
+                    return finish(None, None, state_on_host)
+        member, use2, aligned = masks_to_host()
     else:
         member, use2, aligned = _select_on_host(r1, r2, n, k, n2, bi if n2 else None, br if n2 else None, slot2, min_scores, raw, stats)
     n_best = member.sum(axis=1)

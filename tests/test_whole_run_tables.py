@@ -931,3 +931,43 @@ def test_device_ingest_of_text_the_host_inflated_or_filtered(tmp_path, monkeypat
         out = tmp_path / "out"
         names = tables.write_tables(res, {"Reference": ref}, ["Reference"], str(out))
     assert _compare(g, names, str(out)) == 18
+
+
+@pytest.mark.parametrize("lower_case", [False, True])
+def test_count_transfer_on_the_device_equals_the_sequential_loop(tmp_path, monkeypatch, lower_case):
+    """the reverse-complement count transfer (CRISPRessoCORE.py:3970-3975), N_TOTAL / N_AMBIGUOUS and the weights of the count pass
+    computed on the device over partner pairs (pipeline's default for unsharded runs) against the reference's sequential loop on the
+    host (FORCE_HOST_MERGE): pairs both of which aligned, pairs one of which did not, a read that is its own reverse complement,
+    reads with several copies.  lower_case: a lower-case read's reverse complement is upper case -- the partner relation is not
+    symmetric then, and the device pass must leave the run to the host loop (same result either way)."""
+    from pipeline_on_emulator import emulated_device
+    from crispresso2_amd import pipeline, synth, refs as RF
+    L = 120
+    amp, g_, inc = synth.amplicon_setup(L)
+    half = amp[:L // 2]
+    pal = half + RF.reverse_complement(half)                          # its own reverse complement
+    reads = [r.tobytes().decode() for r in synth.make_reads(L, 40)]
+    seqs = reads + [RF.reverse_complement(s_) for s_ in reads[:12]] * 2 + reads[:8] * 3 + [pal] * 3
+    seqs += ["ACGT" * 30, RF.reverse_complement("ACGT" * 30)]          # a pair neither of which aligns
+    if lower_case:
+        seqs += [reads[3].lower(), reads[4].lower()] * 2
+    fq = tmp_path / "merge.fastq"
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (k_, s_, "I" * len(s_)) for k_, s_ in enumerate(seqs)))
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
+    ref2 = RF.make_ref("Palindrome", pal, [L // 2], inc, min_aln_score=60)
+    out = []
+    with emulated_device():
+        for host in (False, True):
+            monkeypatch.setattr(pipeline, "FORCE_HOST_MERGE", host)
+            tm = {}
+            res = pipeline.quantify_fastq(str(fq), {"Reference": ref, "Palindrome": ref2}, ["Reference", "Palindrome"], matrices()["EDNAFULL"],
+                                          _pipeline_args(), timings=tm)
+            out.append((res.stats, res.per_ref, res.alleles(), res._state["cnt"].tolist()))
+    assert out[0][0] == out[1][0] and out[0][2] == out[1][2] and out[0][3] == out[1][3]
+    for nm in ("Reference", "Palindrome"):
+        for kk, vv in out[0][1][nm].items():
+            ww = out[1][1][nm][kk]
+            assert np.array_equal(vv, ww) if isinstance(vv, np.ndarray) else vv == ww, (nm, kk)
+    if not lower_case:
+        assert out[0][1]["Palindrome"]["counts_total"] == 6          # the palindrome's three copies, doubled (the reference's own arithmetic)
+    assert sum(1 for c_ in out[0][3] if c_ == 0) >= 8                 # the partners that gave their copies away
