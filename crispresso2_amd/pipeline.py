@@ -747,12 +747,24 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     if raw.size and raw.max() > 0x7FFFFFFF:
         raise OverflowError("a read multiplicity exceeds 2^31 - 1")
     min_scores = [refs[name]['min_aln_score'] for name in ref_names]
-    slot2 = np.full((n, k), -1, dtype=np.int64)
-    if n2:
-        slot2[bi, br] = np.arange(n2)
+    class _Slot2:
+        """[n, k] -> index of the (read, reference) pair in the both-strand batch, -1: none.  Built on the host only when something there
+        reads it (the host selection, the scaffold rule, alleles()): the kernels take the device copy"""
+        value = None
+
+        def __call__(self):
+            if self.value is None:
+                self.value = np.full((n, k), -1, dtype=np.int64)
+                if n2:
+                    self.value[bi, br] = np.arange(n2)
+            return self.value
+    host_slot2 = _Slot2()
     mode = C.select_mode(args)
     on_device = max(stride, stride2) <= C.SELECT_MAX_ALN_LEN and not FORCE_HOST_SELECTION
-    d_slot2 = to_device(slot2.astype(np.int32).reshape(-1), dev) if n2 else None
+    d_slot2 = None
+    if n2:
+        d_slot2 = torch.full((n * k,), -1, dtype=torch.int32, device=dev)
+        d_slot2[to_device(np.asarray(bi, dtype=np.int64) * k + np.asarray(br, dtype=np.int64), dev)] = torch.arange(n2, dtype=torch.int32, device=dev)
     if on_device:
         words = (k + 63) // 64                                        # 64-bit words of a read's masks (bit r % 64 of word r / 64: reference r)
         d_member = torch.zeros((n, words), dtype=torch.int64, device=dev)
@@ -837,12 +849,12 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
 
                     def state_on_host():
                         member_, use2_, aligned_ = masks_to_host()
-                        return dict(args=args, ref_names=list(ref_names), member=member_, aligned=aligned_, cnt=to_host(c1), use2=use2_, slot2=slot2,
+                        return dict(args=args, ref_names=list(ref_names), member=member_, aligned=aligned_, cnt=to_host(c1), use2=use2_, slot2=host_slot2(),
                                     scaffold_hit=np.zeros(n, dtype=bool), scaffold_ref=pe, a1=a1, f1=f1, r1=r1, a2=a2, f2=f2, r2=r2)
                     return finish(None, None, state_on_host)
         member, use2, aligned = masks_to_host()
     else:
-        member, use2, aligned = _select_on_host(r1, r2, n, k, n2, bi if n2 else None, br if n2 else None, slot2, min_scores, raw, stats)
+        member, use2, aligned = _select_on_host(r1, r2, n, k, n2, bi if n2 else None, br if n2 else None, host_slot2(), min_scores, raw, stats)
     n_best = member.sum(axis=1)
     lap("selection_and_stats")
     # ---- aggregation weights (:3964-4000): rc merge, ambiguous reads, which references a read counts for
@@ -898,7 +910,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
                 pull(a1, f1, t_, w_1, r1.index_select(0, t_).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)["aln_len"])
             w_2 = np.nonzero(in2)[0]
             if len(w_2):
-                sl = torch.from_numpy(slot2[cand[w_2], pe]).to(dev)
+                sl = torch.from_numpy(host_slot2()[cand[w_2], pe]).to(dev)
                 pull(a2, f2, sl, w_2, r2.index_select(0, sl).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)["aln_len"])
             for j, (s_read, s_ref) in enumerate(pairs):
                 seen, col = -1, -1
@@ -985,7 +997,7 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             C.all_reduce(d_scaffold)
         reduce_stats()
     torch.cuda.synchronize(dev)
-    state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=slot2,
+    state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=host_slot2(),
                  scaffold_hit=scaffold_hit, scaffold_ref=pe,
                  a1=a1, f1=f1, r1=r1, a2=a2, f2=f2, r2=r2)
     return finish(d_view, d_scaffold, state)
