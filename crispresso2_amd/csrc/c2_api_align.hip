@@ -1,133 +1,13 @@
-// c2_api.hip -- host side of the C ABI declared in include/crispresso2_amd.h.
-//
-// Marshals the reference's Python-level inputs into the kernel's tables, owns the device
-// buffers of a context, picks the launch geometry (rows per lane, passes, LDS plan, persistent
-// grid) and launches the kernels of c2_kernels.hip.  Nothing here computes an alignment or a
-// classification on the CPU.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <string.h>
-#include <stdlib.h>
-#include <algorithm>
-#include <mutex>
-#include <thread>
-#include <string>
-#include <vector>
-#include <memory>
-#include <dlfcn.h>
-#include <rccl/rccl.h>   // types only: the library is bound with dlopen (the copy PyTorch-ROCm already loaded, if any)
-
-#include "crispresso2_amd.h"
-#include "c2_device.h"
-#include "c2_host_prep.h"
-#include "c2_kernels.hip"
-
-namespace {
+// c2_api_align.hip -- host side of the C ABI declared in include/crispresso2_amd.h: contexts, scoring, references, the align + classify launch chain (device and host batches), the per-call global_align, self-tests.
+// Marshals the caller's inputs into the kernels' tables, owns the device buffers of a context, picks launch geometry and
+// launches.  Nothing here computes an alignment or a classification on the CPU.
+#include "c2_ctx.h"
+#include "c2_k_align.hip"
 
 std::string g_create_error;
 std::mutex g_mutex;
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-};
-
-struct TimedLaunch { hipEvent_t a, m, b; };   // before the chain, after its first kernel, after its last
-
-}  // namespace
-
-struct c2_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipDeviceProp_t prop;
-    std::string err;
-    // scoring
-    bool have_scoring = false;
-    c2_scoring_tables sc;
-    int gap_open = -1, gap_extend = -1;
-    DevBuf d_tbl, d_code, d_pk;
-    std::vector<int64_t> matrix_copy;   // to skip re-upload when c2_global_align is called with the same matrix
-    // refs
-    int n_refs = 0;
-    int max_li = 0;
-    std::vector<int> ref_len;
-    DevBuf d_refblob, d_refdesc;
-    // host copies needed to (re)build the diagonal-band kernel's row tables when refs or scoring change
-    std::vector<std::string> ref_seq;
-    std::vector<std::vector<int32_t>> ref_g32;
-    std::vector<c2_dev_ref> ref_desc;
-    DevBuf d_diagrows, d_diagrows_pk;   // row tables of the diagonal kernels: 32-bit records, and the packed (int16 pair) ones at the same indices
-    bool diag_rows_dirty = true;
-    std::vector<uint8_t> ref_pk_ok;     // per reference: admitted to the packed fill (c2_pk_eligible)
-    bool any_pk_ok = false;
-    int pk_bias = 0;                    // ... and this value bias (c2_pk_add32_bias_needed)
-    int pk_beta = 0;                    // > 0: the admitted references run the packed kernels' 32-bit-add variant with this bias (c2_pk_add32_ok)
-    bool pk_dirty = true;
-    int occ_pk_lds = -1, occ_pk_blocks = 0, occ_pk2_lds = -1, occ_pk2_blocks = 0, occ_pk3_lds = -1, occ_pk3_blocks = 0;
-    // staging for the host batch path and the per-call path
-    DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;
-    // timing
-    bool timing = false;
-    std::vector<TimedLaunch> timed;
-    // LDS opt-in already requested for these kernels
-    // optional per-phase cycle accounting (c2_phase_profile)
-    bool phase_prof = false;
-    DevBuf d_phase;
-    // banded first launch: -1 auto, 0 off, >0 lanes each side; fallback list buffer
-    int band_setting = -1;
-    int band_target_wgs = 14;
-    // 0 auto (diagonal-band tiers 4 -> 2 -> 1 alignments per wavefront when applicable), 1 banded row-strip, 2 full row-strip,
-    // 3 single-alignment diagonal-band kernel only, 4 tiers 2 -> 1
-    int kernel_mode = 0;
-    int gmax = 0;          // largest gap incentive over the references
-    DevBuf d_fb;
-    int occ_diag_lds = -1, occ_diag_blocks = 0;
-    int occ_x_lds[2] = {-1, -1}, occ_x_blocks[2] = {0, 0};   // [0] 4 alignments per wavefront, [1] 2
-    DevBuf d_plane;        // pointer-word scratch of the multi-alignment diagonal kernels
-    DevBuf d_cnt_block;            // count route: the workgroups' accumulator blocks when they do not fit LDS
-    DevBuf d_lists, d_lists_out;   // batched classifier: staging and flat output
-    DevBuf d_order;        // count kernel: histogram + tasks grouped by reference
-    int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
-    int occ_lds[5][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
-    int occ_blocks[5][3] = {};
-    DevBuf d_cnt;          // count kernel: work counter + min_matches table
-    DevBuf d_sel;          // selection kernel: per-reference score thresholds
-    DevBuf d_seeds;        // strand-plan kernel: seed bytes and tables
-    std::vector<uint8_t> seeds_host;   // ... and what they hold (the staging block of the last c2_strand_plan_device call)
-    ncclComm_t comm = nullptr; // RCCL communicator of c2_comm_init (one rank per GPU)
-    int comm_world = 0;
-    std::vector<uint32_t> sel_table;
-    std::vector<uint16_t> cnt_table;   // host copy of the table that is on the device (skip re-upload when unchanged)
-    // host batch path, pipelined: pinned staging (two sets), copy streams and their events
-    void* pin_in[2] = {nullptr, nullptr}; size_t pin_in_cap[2] = {0, 0};
-    void* pin_out[2] = {nullptr, nullptr}; size_t pin_out_cap[2] = {0, 0};
-    hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-};
-
 namespace {
-
-#define HIPCHK(ctx, call)                                                                   \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess) {                                                             \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
-            return C2_E_DEVICE;                                                             \
-        }                                                                                   \
-    } while (0)
-
-int ensure(c2_ctx* ctx, DevBuf& b, size_t bytes) {
-    if (bytes <= b.cap) return 0;
-    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
-    size_t want = std::max<size_t>(bytes, 256);
-    want = (want + 255) & ~(size_t)255;
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return C2_E_NOMEM; }
-    b.cap = want;
-    return 0;
-}
-
-void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 struct Geometry {
     int R, passes, max_lj;
@@ -840,27 +720,6 @@ int c2_align_classify_batch_device(c2_ctx* ctx, const c2_batch* b, void* hip_str
 
 namespace {
 
-int ensure_pinned(c2_ctx* ctx, void*& p, size_t& cap, size_t bytes) {
-    if (bytes <= cap) return 0;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-    const size_t want = (bytes + 4095) & ~(size_t)4095;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e != hipSuccess) { ctx->err = std::string("hipHostMalloc: ") + hipGetErrorString(e); p = nullptr; return C2_E_NOMEM; }
-    cap = want;
-    return 0;
-}
-
-// memcpy on a few threads (pinned staging <-> the caller's pageable arrays: one thread moves ~10 GB/s, the link more)
-void copy_parallel(void* dst, const void* src, size_t n, unsigned threads) {
-    if (threads < 2 || n < ((size_t)4 << 20)) { memcpy(dst, src, n); return; }
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t) {
-        const size_t a = n * t / threads, z = n * (t + 1) / threads;
-        pool.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, z - a); });
-    }
-    for (auto& th : pool) th.join();
-}
-
 // Host batch, pipelined.  The batch is cut into chunks of reads; for chunk c, concurrently:
 //   host threads   reads of chunk c+1 -> pinned input set;   pinned output set of chunk c-1 -> the caller's arrays
 //   stream s_in    pinned input of chunk c+1 -> device
@@ -1021,195 +880,6 @@ int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
     return 0;
 }
 
-int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_read, const uint8_t* d_aln_ref,
-                            uint32_t aln_stride, const c2_aln_record* d_records, const uint32_t* d_weights,
-                            const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
-                            int64_t* d_counts, void* hip_stream) {
-    if (!ctx || !d_aln_read || !d_aln_ref || !d_records || !d_counts) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
-    if (ctx->n_refs <= 0) { ctx->err = "references must be set first"; return C2_E_STATE; }
-    static_assert(C2_CNT_VECTORS == C2_COUNT_VECTORS && C2_CNT_SCALARS == C2_COUNT_SCALARS && C2_CNT_HISTS == C2_COUNT_HISTS, "count layout");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = (hipStream_t)hip_stream;
-    if (n_tasks == 0) return 0;
-    const int lmax = ctx->max_li;
-    if (hl < lmax + 2) { ctx->err = "hl too small"; return C2_E_INVALID; }
-    const size_t per_ref = (size_t)C2_CNT_VECTORS * (lmax + 1) + C2_CNT_SCALARS + (size_t)C2_CNT_HISTS * hl;
-    size_t lds = c2_count_lds_bytes(per_ref, lmax);
-    // the int32 accumulator block of a workgroup normally lives in LDS; amplicons beyond ~1,650 bp (with 250-bp reads) take the variant
-    // that keeps it in HBM scratch (LDS then only holds the O(lmax) parts)
-    const bool hbm_block = lds > 163840 || getenv("C2_COUNT_HBM_BLOCK");
-    if (hbm_block) {
-        lds = c2_count_lds_bytes_hbm(lmax);
-        if (lds > 163840) { ctx->err = "count route: reference of " + std::to_string(lmax) + " bp needs " + std::to_string(lds) + " bytes of LDS"; return C2_E_TOO_LARGE; }
-    }
-    int rc;
-    c2_count_args A;
-    A.min_matches = nullptr;
-    size_t o_tbl = 64;
-    const size_t tbl_bytes = h_min_matches ? (size_t)ctx->n_refs * (size_t)(max_t + 1) * sizeof(uint16_t) : 0;
-    if (o_tbl + tbl_bytes > ctx->d_cnt.cap) ctx->cnt_table.clear();
-    if ((rc = ensure(ctx, ctx->d_cnt, o_tbl + tbl_bytes))) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt.p, 0, 64, s));
-    if (h_min_matches) {
-        const size_t nel = tbl_bytes / sizeof(uint16_t);
-        if (ctx->cnt_table.size() != nel || memcmp(ctx->cnt_table.data(), h_min_matches, tbl_bytes) != 0) {
-            HIPCHK(ctx, hipStreamSynchronize(s));      // no earlier launch may still read the old table
-            HIPCHK(ctx, hipMemcpy((uint8_t*)ctx->d_cnt.p + o_tbl, h_min_matches, tbl_bytes, hipMemcpyHostToDevice));
-            ctx->cnt_table.assign(h_min_matches, h_min_matches + nel);
-        }
-        A.min_matches = (const uint16_t*)((uint8_t*)ctx->d_cnt.p + o_tbl);
-    }
-    A.aln_read = d_aln_read; A.aln_ref = d_aln_ref; A.records = d_records; A.weights = d_weights;
-    A.refs = (const c2_dev_ref*)ctx->d_refdesc.p; A.counts = (long long*)d_counts;
-    A.work_counter = (unsigned long long*)ctx->d_cnt.p;
-    A.n_tasks = n_tasks; A.aln_stride = aln_stride; A.n_refs = ctx->n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
-    A.order = nullptr;
-    if ((flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) && (ctx->n_refs <= 1 || n_tasks % (uint64_t)ctx->n_refs != 0)) A.flags = flags & ~C2_CNT_FLAG_ALL_REFS_LAYOUT;
-    if (ctx->n_refs > 1 && n_tasks < 0xFFFFFFFFull && !(A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT)) {
-        // group the tasks by reference on the device (see c2_ref_histogram_kernel)
-        const size_t hist_bytes = ((size_t)ctx->n_refs * 4 + 255) / 256 * 256;
-        if ((rc = ensure(ctx, ctx->d_order, hist_bytes + n_tasks * sizeof(uint32_t)))) return rc;
-        uint32_t* hist = (uint32_t*)ctx->d_order.p;
-        uint32_t* order = (uint32_t*)((uint8_t*)ctx->d_order.p + hist_bytes);
-        HIPCHK(ctx, hipMemsetAsync(hist, 0, hist_bytes, s));
-        const unsigned gb = (unsigned)((n_tasks + 255) / 256);
-        hipLaunchKernelGGL(c2_ref_histogram_kernel, dim3(gb), dim3(256), 0, s, d_records, n_tasks, hist);
-        hipLaunchKernelGGL(c2_ref_scan_kernel, dim3(1), dim3(64), 0, s, hist, ctx->n_refs);
-        hipLaunchKernelGGL(c2_ref_scatter_kernel, dim3(gb), dim3(256), 0, s, d_records, n_tasks, hist, order);
-        HIPCHK(ctx, hipGetLastError());
-        A.order = order;
-    }
-    const void* fn = hbm_block ? (const void*)c2_count_vectors_hbm_kernel : (const void*)c2_count_vectors_kernel;
-    HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    int nb = 1;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * C2_CNT_WAVES, lds));
-    if (nb < 1) nb = 1;
-    uint64_t resident = (uint64_t)ctx->prop.multiProcessorCount * (uint64_t)nb;
-    A.block_scratch = nullptr; A.block_ints = 0;
-    if (hbm_block) {
-        A.block_ints = (per_ref + 63) / 64 * 64;
-        resident = std::max<uint64_t>(1, std::min<uint64_t>(resident, ((uint64_t)2 << 30) / (A.block_ints * sizeof(int))));     // at most 2 GiB of blocks
-        if ((rc = ensure(ctx, ctx->d_cnt_block, (size_t)(resident * A.block_ints * sizeof(int))))) return rc;
-        A.block_scratch = (int32_t*)ctx->d_cnt_block.p;
-    }
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_tasks + 31) / 32, resident));
-    if (hbm_block) hipLaunchKernelGGL(c2_count_vectors_hbm_kernel, dim3(grid), dim3(64 * C2_CNT_WAVES), lds, s, A);
-    else           hipLaunchKernelGGL(c2_count_vectors_kernel, dim3(grid), dim3(64 * C2_CNT_WAVES), lds, s, A);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-// ---- multi-GPU: the only exchange step of the sharded path, SURVEY 8(e): all-reduce of the per-amplicon count tensor over RCCL ----
-namespace {
-struct RcclApi {
-    void* h = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string err;
-};
-RcclApi* rccl() {
-    static RcclApi api;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        // the copy that is already in the process (torch.distributed's), else the ROCm installation's
-        const char* names[] = {"librccl.so", "librccl.so.1"};
-        for (const char* n : names) if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        for (const char* n : names) if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (!api.h) { api.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
-        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
-        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
-        api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
-        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
-        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
-        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.err = "librccl.so lacks an expected symbol";
-    });
-    return &api;
-}
-#define RCCLCHK(ctx, api, call)                                                                             \
-    do {                                                                                                    \
-        ncclResult_t r_ = (call);                                                                           \
-        if (r_ != ncclSuccess) {                                                                            \
-            (ctx)->err = std::string(#call) + ": " + ((api)->GetErrorString ? (api)->GetErrorString(r_) : "rccl error"); \
-            return C2_E_DEVICE;                                                                             \
-        }                                                                                                   \
-    } while (0)
-}  // namespace
-
-int c2_comm_unique_id(uint8_t* out_id) {
-    RcclApi* R = rccl();
-    if (!out_id || !R->err.empty()) { g_create_error = R->err.empty() ? "out_id is NULL" : R->err; return C2_E_DEVICE; }
-    static_assert(sizeof(ncclUniqueId) == C2_COMM_ID_BYTES, "unique id size");
-    ncclUniqueId id;
-    if (R->GetUniqueId(&id) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return C2_E_DEVICE; }
-    memcpy(out_id, &id, sizeof id);
-    return 0;
-}
-
-int c2_comm_init(c2_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id) {
-    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) { if (ctx) ctx->err = "bad communicator arguments"; return C2_E_INVALID; }
-    RcclApi* R = rccl();
-    if (!R->err.empty()) { ctx->err = R->err; return C2_E_DEVICE; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->comm) { (void)R->CommDestroy(ctx->comm); ctx->comm = nullptr; }
-    ncclUniqueId uid;
-    memcpy(&uid, id, sizeof uid);
-    RCCLCHK(ctx, R, R->CommInitRank(&ctx->comm, world, uid, rank));
-    ctx->comm_world = world;
-    return 0;
-}
-
-int c2_reduce_counts(c2_ctx* ctx, int64_t* d_counts, uint64_t n_elements, void* hip_stream) {
-    if (!ctx || (!d_counts && n_elements)) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
-    if (!ctx->comm) { ctx->err = "c2_comm_init has not been called"; return C2_E_STATE; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (n_elements == 0) return 0;
-    RcclApi* R = rccl();
-    RCCLCHK(ctx, R, R->AllReduce(d_counts, d_counts, (size_t)n_elements, ncclInt64, ncclSum, ctx->comm, (hipStream_t)hip_stream));
-    return 0;
-}
-
-int c2_comm_destroy(c2_ctx* ctx) {
-    if (!ctx) return C2_E_INVALID;
-    if (ctx->comm) { RcclApi* R = rccl(); if (R->CommDestroy) (void)R->CommDestroy(ctx->comm); ctx->comm = nullptr; ctx->comm_world = 0; }
-    return 0;
-}
-
-int c2_select_best_device(c2_ctx* ctx, uint64_t n_reads, int32_t n_refs, const c2_aln_record* d_records,
-                          const c2_aln_record* d_records2, const int32_t* d_slot2, const uint32_t* h_min_mscore,
-                          const uint32_t* d_raw_counts, const uint32_t* d_counts, int32_t mode, int32_t max_aln_len,
-                          uint64_t* d_member, uint64_t* d_use2, uint8_t* d_flags, uint32_t* d_weights, uint32_t* d_weights2,
-                          uint64_t* d_stats, void* hip_stream) {
-    if (!ctx || !d_records || !h_min_mscore || n_refs <= 0 || n_refs > 32767 || mode < 0 || mode > 2) { if (ctx) ctx->err = "bad selection arguments"; return C2_E_INVALID; }
-    if ((d_records2 != nullptr) != (d_slot2 != nullptr)) { ctx->err = "d_records2 and d_slot2 go together"; return C2_E_INVALID; }
-    static_assert(C2_SEL_STATS == C2_SELECT_STATS, "selection statistics");
-    // the integer form of round(100*matches/len, 3) is exact below 8000 columns (c2_mscore)
-    if (max_aln_len >= 8000) { ctx->err = "c2_select_best_device: alignments of 8000 columns or more"; return C2_E_TOO_LARGE; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (n_reads == 0) return 0;
-    hipStream_t s = (hipStream_t)hip_stream;
-    int rc;
-    // thresholds: a small device table, re-uploaded when it changes
-    if ((size_t)n_refs * sizeof(uint32_t) > ctx->d_sel.cap) { HIPCHK(ctx, hipDeviceSynchronize()); ctx->sel_table.clear(); }      // (the table moves: nothing may still read the old one)
-    if ((rc = ensure(ctx, ctx->d_sel, (size_t)std::max(n_refs, 64) * sizeof(uint32_t)))) return rc;
-    if (ctx->sel_table.size() != (size_t)n_refs || memcmp(ctx->sel_table.data(), h_min_mscore, (size_t)n_refs * 4) != 0) {
-        HIPCHK(ctx, hipStreamSynchronize(s));          // no earlier launch may still read the old table
-        HIPCHK(ctx, hipMemcpy(ctx->d_sel.p, h_min_mscore, (size_t)n_refs * 4, hipMemcpyHostToDevice));
-        ctx->sel_table.assign(h_min_mscore, h_min_mscore + n_refs);
-    }
-    c2_select_args A;
-    A.records = d_records; A.records2 = d_records2; A.slot2 = d_slot2; A.min_mscore = (const uint32_t*)ctx->d_sel.p;
-    A.raw_counts = d_raw_counts; A.counts = d_counts;
-    A.member = (unsigned long long*)d_member; A.use2 = (unsigned long long*)d_use2; A.flags = d_flags;
-    A.weights = d_weights; A.weights2 = d_weights2; A.stats = (unsigned long long*)d_stats;
-    A.n_reads = n_reads; A.n_refs = n_refs; A.mode = mode;
-    hipLaunchKernelGGL(c2_select_best_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), C2_SEL_STATS * sizeof(unsigned long long), s, A);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
 int c2_global_align(c2_ctx* ctx, const char* read, int32_t Lj, const char* ref, int32_t Li,
                     const int64_t* matrix, int32_t mat_dim, const int64_t* gap_incentive, int32_t n_gap_incentive,
                     int32_t gap_open, int32_t gap_extend, char* out_read_aln, char* out_ref_aln,
@@ -1248,327 +918,6 @@ int c2_global_align(c2_ctx* ctx, const char* read, int32_t Lj, const char* ref, 
     return 0;
 }
 
-int c2_find_indels_substitutions(c2_ctx* ctx, const char* read_aln, const char* ref_aln, int32_t n,
-                                 const int32_t* include_idx, int32_t n_include, int32_t legacy,
-                                 int32_t* out, int32_t out_cap, int32_t* out_index, int64_t* out_counts, int32_t* out_needed) {
-    if (!ctx || !read_aln || !ref_aln || n < 0 || !out || !out_index || !out_counts) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<int32_t> inc(include_idx, include_idx + (n_include > 0 ? n_include : 0));
-    std::sort(inc.begin(), inc.end());
-    inc.erase(std::unique(inc.begin(), inc.end()), inc.end());
-    hipStream_t s = ctx->stream;
-    int cap = std::max(2 * n + 8, 64);
-    std::vector<int32_t> lens(C2_LIST_COUNT);
-    std::vector<int32_t> lists;
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        // d_misc layout: [read n][ref n][pad][include][list_len 15][counts 3 x int64][lists 15 x cap]
-        size_t o_read = 0, o_ref = (size_t)n, o_inc = ((size_t)2 * n + 15) / 16 * 16;
-        size_t o_len = o_inc + ((inc.size() * 4 + 15) / 16 * 16);
-        size_t o_cnt = o_len + 64, o_lists = o_cnt + 32;
-        size_t total = o_lists + (size_t)C2_LIST_COUNT * cap * 4;
-        int rc;
-        if ((rc = ensure(ctx, ctx->d_misc, total))) return rc;
-        uint8_t* base = (uint8_t*)ctx->d_misc.p;
-        if (n) {
-            HIPCHK(ctx, hipMemcpyAsync(base + o_read, read_aln, n, hipMemcpyHostToDevice, s));
-            HIPCHK(ctx, hipMemcpyAsync(base + o_ref, ref_aln, n, hipMemcpyHostToDevice, s));
-        }
-        if (!inc.empty()) HIPCHK(ctx, hipMemcpyAsync(base + o_inc, inc.data(), inc.size() * 4, hipMemcpyHostToDevice, s));
-        c2_classify_args A;
-        A.read_al = base + o_read; A.ref_al = base + o_ref; A.include_sorted = (const int32_t*)(base + o_inc);
-        A.n = n; A.n_include = (int32_t)inc.size(); A.legacy = legacy ? 1 : 0; A.cap = cap;
-        A.lists = (int32_t*)(base + o_lists); A.list_len = (int32_t*)(base + o_len); A.counts = (int64_t*)(base + o_cnt);
-        hipLaunchKernelGGL(c2_classify_lists_kernel, dim3(1), dim3(64), 0, s, A);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(lens.data(), base + o_len, C2_LIST_COUNT * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipMemcpyAsync(out_counts, base + o_cnt, 24, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        const int need = *std::max_element(lens.begin(), lens.end());
-        if (need <= cap) {
-            lists.resize((size_t)C2_LIST_COUNT * cap);
-            HIPCHK(ctx, hipMemcpy(lists.data(), base + o_lists, lists.size() * 4, hipMemcpyDeviceToHost));
-            break;
-        }
-        cap = need + 8;   // only the negative-coordinate quirk of the reference can get here
-        if (attempt == 2) { ctx->err = "classification lists did not converge"; return C2_E_DEVICE; }
-    }
-    int64_t total = 0;
-    for (int k = 0; k < C2_LIST_COUNT; ++k) total += lens[k];
-    if (out_needed) *out_needed = (int32_t)total;
-    if (total > out_cap) { ctx->err = "output buffer too small"; return C2_E_OVERFLOW; }
-    int32_t pos = 0;
-    for (int k = 0; k < C2_LIST_COUNT; ++k) {
-        out_index[2 * k] = pos; out_index[2 * k + 1] = lens[k];
-        if (lens[k]) memcpy(out + pos, lists.data() + (size_t)k * cap, (size_t)lens[k] * 4);
-        pos += lens[k];
-    }
-    return 0;
-}
-
-struct c2_lists {
-    std::vector<int64_t> index;    // n * C2_LIST_COUNT + 1 offsets into values
-    std::vector<int32_t> values;
-    std::vector<int64_t> counts;   // n x 3
-};
-
-int c2_classify_lists_batch(c2_ctx* ctx, uint64_t n, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t stride,
-                            const int32_t* lens, const uint16_t* set_ids, const int32_t* include_idx, const int64_t* include_off,
-                            int32_t n_sets, int32_t legacy, c2_lists** out) {
-    if (!ctx || !out || (n && (!aln_read || !aln_ref || !lens)) || n_sets < 1 || !include_off || stride == 0) {
-        if (ctx) ctx->err = "bad argument"; return C2_E_INVALID;
-    }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    // the include sets, each sorted and unique (Python's `in` / set.intersection semantics; any integers)
-    std::vector<int32_t> inc;
-    std::vector<int64_t> inc_off(1, 0);
-    for (int k = 0; k < n_sets; ++k) {
-        std::vector<int32_t> one(include_idx + include_off[k], include_idx + include_off[k + 1]);
-        std::sort(one.begin(), one.end());
-        one.erase(std::unique(one.begin(), one.end()), one.end());
-        inc.insert(inc.end(), one.begin(), one.end());
-        inc_off.push_back((int64_t)inc.size());
-    }
-    for (uint64_t t = 0; t < n; ++t) {
-        if (lens[t] < 0 || (uint32_t)lens[t] > stride) { ctx->err = "alignment longer than stride"; return C2_E_INVALID; }
-        if (set_ids && set_ids[t] >= n_sets) { ctx->err = "include set id out of range"; return C2_E_INVALID; }
-    }
-    std::unique_ptr<c2_lists> R(new c2_lists);
-    R->index.assign((size_t)n * C2_LIST_COUNT + 1, 0);
-    R->counts.assign((size_t)n * 3, 0);
-    hipStream_t s = ctx->stream;
-    const uint64_t CH = 32768;
-    std::vector<int32_t> llen;
-    std::vector<int64_t> loff;
-    int rc;
-    for (uint64_t c0 = 0; c0 < n; c0 += CH) {
-        const uint64_t m = std::min<uint64_t>(CH, n - c0);
-        // d_lists layout: [read m*stride][ref m*stride][lens m][set ids m][include][include_off][scratch m*stride*4][len m*15][off m*15*8][counts m*3*8]
-        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-        size_t o = 0;
-        const size_t o_rd = o; o += al(m * stride);
-        const size_t o_rf = o; o += al(m * stride);
-        const size_t o_ln = o; o += al(m * 4);
-        const size_t o_id = o; o += al(m * 2);
-        const size_t o_inc = o; o += al(inc.size() * 4 + 4);
-        const size_t o_ioff = o; o += al(inc_off.size() * 8);
-        const size_t o_rp = o; o += al(m * (size_t)stride * 4);
-        const size_t o_len = o; o += al(m * C2_LIST_COUNT * 4);
-        const size_t o_off = o; o += al(m * C2_LIST_COUNT * 8);
-        const size_t o_cnt = o; o += al(m * 3 * 8);
-        if ((rc = ensure(ctx, ctx->d_lists, o))) return rc;
-        uint8_t* base = (uint8_t*)ctx->d_lists.p;
-        HIPCHK(ctx, hipMemcpyAsync(base + o_rd, aln_read + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_rf, aln_ref + c0 * stride, m * stride, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_ln, lens + c0, m * 4, hipMemcpyHostToDevice, s));
-        if (set_ids) HIPCHK(ctx, hipMemcpyAsync(base + o_id, set_ids + c0, m * 2, hipMemcpyHostToDevice, s));
-        if (!inc.empty()) HIPCHK(ctx, hipMemcpyAsync(base + o_inc, inc.data(), inc.size() * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + o_ioff, inc_off.data(), inc_off.size() * 8, hipMemcpyHostToDevice, s));
-        c2_classify_batch_args A;
-        A.aln_read = base + o_rd; A.aln_ref = base + o_rf; A.lens = (const int32_t*)(base + o_ln);
-        A.set_ids = set_ids ? (const uint16_t*)(base + o_id) : nullptr;
-        A.include_sorted = (const int32_t*)(base + o_inc); A.include_off = (const int64_t*)(base + o_ioff);
-        A.n = m; A.stride = stride; A.legacy = legacy ? 1 : 0; A.pass = 0; A.reserved = 0;
-        A.scratch_rp = (int32_t*)(base + o_rp); A.list_len = (int32_t*)(base + o_len); A.list_off = (const int64_t*)(base + o_off);
-        A.values = nullptr; A.counts = (int64_t*)(base + o_cnt);
-        const unsigned grid = (unsigned)((m + 63) / 64);
-        hipLaunchKernelGGL(c2_classify_lists_batch_kernel, dim3(grid), dim3(64), 0, s, A);
-        HIPCHK(ctx, hipGetLastError());
-        llen.resize(m * C2_LIST_COUNT);
-        HIPCHK(ctx, hipMemcpyAsync(llen.data(), base + o_len, llen.size() * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipMemcpyAsync(R->counts.data() + c0 * 3, base + o_cnt, m * 3 * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        loff.resize(llen.size());
-        int64_t tot = 0;
-        for (size_t k = 0; k < llen.size(); ++k) { loff[k] = tot; tot += llen[k]; }
-        const int64_t g0 = (int64_t)R->values.size();
-        for (size_t k = 0; k < llen.size(); ++k) R->index[c0 * C2_LIST_COUNT + k] = g0 + loff[k];
-        R->values.resize((size_t)(g0 + tot));
-        R->index[(c0 + m) * C2_LIST_COUNT] = g0 + tot;
-        if (tot > 0) {
-            if ((rc = ensure(ctx, ctx->d_lists_out, (size_t)tot * 4))) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(base + o_off, loff.data(), loff.size() * 8, hipMemcpyHostToDevice, s));
-            A.pass = 1; A.values = (int32_t*)ctx->d_lists_out.p;
-            hipLaunchKernelGGL(c2_classify_lists_batch_kernel, dim3(grid), dim3(64), 0, s, A);
-            HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemcpyAsync(R->values.data() + g0, ctx->d_lists_out.p, (size_t)tot * 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(ctx, hipStreamSynchronize(s));
-        }
-    }
-    *out = R.release();
-    return 0;
-}
-
-uint64_t c2_lists_total(const c2_lists* r) { return r ? (uint64_t)r->values.size() : 0; }
-const int64_t* c2_lists_index(const c2_lists* r) { return r ? r->index.data() : nullptr; }
-const int32_t* c2_lists_values(const c2_lists* r) { return r ? r->values.data() : nullptr; }
-const int64_t* c2_lists_counts(const c2_lists* r) { return r ? r->counts.data() : nullptr; }
-void c2_lists_free(c2_lists* r) { delete r; }
-
-// Launch only: every pointer is a device address.  The paired route keeps both reads' alignments on the device (BatchAligner.align_device)
-// and hands their rows straight to this; only the qualities come from the host.  65,536 pairs per launch: every lane streams its own
-// rows, and more lanes in flight thrash L2 (25.7 against 19 ns per pair at 262,144).
-int c2_consensus_pairs_device(c2_ctx* ctx, uint64_t n, const uint8_t* d_s1, const uint8_t* d_f1, const uint8_t* d_s2, const uint8_t* d_f2,
-                              uint32_t stride, const int32_t* d_n1, const int32_t* d_n2, const uint8_t* d_q1, const uint8_t* d_q2,
-                              uint32_t qstride, const int32_t* d_lq1, const int32_t* d_lq2, const uint8_t* d_best1,
-                              uint8_t* d_out_aln, uint8_t* d_out_ref, uint8_t* d_out_qual, uint32_t ostride, int32_t* d_out_info, void* hip_stream) {
-    if (!ctx || (n && (!d_s1 || !d_f1 || !d_s2 || !d_f2 || !d_n1 || !d_n2 || !d_q1 || !d_q2 || !d_lq1 || !d_lq2 || !d_best1 || !d_out_aln || !d_out_ref ||
-                       !d_out_qual || !d_out_info))) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
-    if (n == 0) return 0;
-    if (stride == 0 || qstride == 0 || ostride < 2 * stride) { ctx->err = "ostride must be at least 2 * stride"; return C2_E_INVALID; }
-    if ((stride & 3u) || (qstride & 3u)) { ctx->err = "stride and qstride must be multiples of 4"; return C2_E_INVALID; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = (hipStream_t)hip_stream;
-    const uint64_t CH = 65536;
-    for (uint64_t c0 = 0; c0 < n; c0 += CH) {
-        const uint64_t m = std::min<uint64_t>(CH, n - c0);
-        c2_consensus_args A;
-        A.s1 = d_s1 + c0 * stride; A.f1 = d_f1 + c0 * stride; A.s2 = d_s2 + c0 * stride; A.f2 = d_f2 + c0 * stride;
-        A.q1 = d_q1 + c0 * qstride; A.q2 = d_q2 + c0 * qstride;
-        A.n1 = d_n1 + c0; A.n2 = d_n2 + c0; A.lq1 = d_lq1 + c0; A.lq2 = d_lq2 + c0; A.best1 = d_best1 + c0;
-        A.n = m; A.stride = stride; A.qstride = qstride; A.ostride = ostride; A.reserved = 0;
-        A.o_aln = d_out_aln + c0 * ostride; A.o_ref = d_out_ref + c0 * ostride; A.o_qual = d_out_qual + c0 * ostride; A.o_info = d_out_info + c0 * 4;
-        hipLaunchKernelGGL(c2_consensus_pairs_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, A);
-        HIPCHK(ctx, hipGetLastError());
-    }
-    return 0;
-}
-
-// Host arrays.  Chunks of 65,536 pairs through pinned staging, three streams: while chunk c runs, chunk c + 1's six input streams are
-// packed into a pinned block by a few host threads and copied in, and chunk c - 1's results come back -- only the bytes that were
-// written: the lengths first (16 bytes per pair), then the three output arrays as 2-D copies of the widest row (rows are 2 * stride
-// wide; a consensus is about as long as the longer of the two alignments).
-int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const uint8_t* f1, const uint8_t* s2, const uint8_t* f2,
-                             uint32_t stride, const int32_t* n1, const int32_t* n2, const uint8_t* q1, const uint8_t* q2,
-                             uint32_t qstride, const int32_t* lq1, const int32_t* lq2, const uint8_t* best1,
-                             uint8_t* out_aln, uint8_t* out_ref, uint8_t* out_qual, uint32_t ostride, int32_t* out_info) {
-    if (!ctx || (n && (!s1 || !f1 || !s2 || !f2 || !n1 || !n2 || !q1 || !q2 || !lq1 || !lq2 || !best1 || !out_aln || !out_ref || !out_qual || !out_info))) {
-        if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID;
-    }
-    if (n == 0) return 0;
-    if (stride == 0 || qstride == 0 || ostride < 2 * stride) { ctx->err = "ostride must be at least 2 * stride"; return C2_E_INVALID; }
-    if ((stride & 3u) || (qstride & 3u)) { ctx->err = "stride and qstride must be multiples of 4"; return C2_E_INVALID; }
-    for (uint64_t t = 0; t < n; ++t)
-        if (n1[t] < 0 || n2[t] < 0 || (uint32_t)n1[t] > stride || (uint32_t)n2[t] > stride || lq1[t] < 0 || lq2[t] < 0 ||
-            (uint32_t)lq1[t] > qstride || (uint32_t)lq2[t] > qstride) { ctx->err = "length exceeds stride"; return C2_E_INVALID; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!ctx->s_in) {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_out[k], hipEventDisableTiming));
-        }
-    }
-    hipStream_t s = ctx->stream;
-    unsigned threads = std::thread::hardware_concurrency();
-    if (const char* e = getenv("C2_HOST_THREADS")) threads = (unsigned)atoi(e);
-    threads = std::max(1u, std::min(threads, 16u));
-    const uint64_t CH = 65536;
-    const uint64_t n_chunks = (n + CH - 1) / CH, mmax = std::min<uint64_t>(CH, n);
-    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    // one chunk's input block (the same layout in pinned and device memory) and output arrays
-    const size_t o_s1 = 0, o_f1 = o_s1 + al(mmax * stride), o_s2 = o_f1 + al(mmax * stride), o_f2 = o_s2 + al(mmax * stride);
-    const size_t o_q1 = o_f2 + al(mmax * stride), o_q2 = o_q1 + al(mmax * qstride), o_n = o_q2 + al(mmax * qstride);
-    const size_t o_b = o_n + al(mmax * 16), in_bytes = o_b + al(mmax);
-    const size_t o_oa = 0, o_or = al(mmax * ostride), o_oq = 2 * al(mmax * ostride), o_info = 3 * al(mmax * ostride), out_bytes = o_info + al(mmax * 16);
-    int rc;
-    if ((rc = ensure(ctx, ctx->d_lists, 2 * in_bytes))) return rc;
-    if ((rc = ensure(ctx, ctx->d_lists_out, 2 * out_bytes))) return rc;
-    for (int k = 0; k < 2; ++k) {
-        if ((rc = ensure_pinned(ctx, ctx->pin_in[k], ctx->pin_in_cap[k], in_bytes))) return rc;
-        if ((rc = ensure_pinned(ctx, ctx->pin_out[k], ctx->pin_out_cap[k], out_bytes))) return rc;
-    }
-    auto m_of = [&](uint64_t c) { return std::min<uint64_t>(CH, n - c * CH); };
-    auto stage_in = [&](uint64_t c) -> int {
-        const int k = (int)(c & 1);
-        const uint64_t c0 = c * CH, m = m_of(c);
-        if (c >= 2) HIPCHK(ctx, hipEventSynchronize(ctx->ev_in[k]));
-        uint8_t* pi = (uint8_t*)ctx->pin_in[k];
-        copy_parallel(pi + o_s1, s1 + c0 * stride, m * stride, threads);
-        copy_parallel(pi + o_f1, f1 + c0 * stride, m * stride, threads);
-        copy_parallel(pi + o_s2, s2 + c0 * stride, m * stride, threads);
-        copy_parallel(pi + o_f2, f2 + c0 * stride, m * stride, threads);
-        copy_parallel(pi + o_q1, q1 + c0 * qstride, m * qstride, threads);
-        copy_parallel(pi + o_q2, q2 + c0 * qstride, m * qstride, threads);
-        memcpy(pi + o_n, n1 + c0, m * 4); memcpy(pi + o_n + mmax * 4, n2 + c0, m * 4);
-        memcpy(pi + o_n + mmax * 8, lq1 + c0, m * 4); memcpy(pi + o_n + mmax * 12, lq2 + c0, m * 4);
-        memcpy(pi + o_b, best1 + c0, m);
-        HIPCHK(ctx, hipMemcpyAsync((uint8_t*)ctx->d_lists.p + k * in_bytes, pi, in_bytes, hipMemcpyHostToDevice, ctx->s_in));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_in[k], ctx->s_in));
-        return 0;
-    };
-    // results of chunk c: lengths, then the written part of the rows, then to the caller's arrays
-    auto fetch_out = [&](uint64_t c) -> int {
-        const int k = (int)(c & 1);
-        const uint64_t c0 = c * CH, m = m_of(c);
-        uint8_t* dout = (uint8_t*)ctx->d_lists_out.p + k * out_bytes;
-        uint8_t* po = (uint8_t*)ctx->pin_out[k];
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->s_out, ctx->ev_done[k], 0));
-        HIPCHK(ctx, hipMemcpyAsync(po + o_info, dout + o_info, m * 16, hipMemcpyDeviceToHost, ctx->s_out));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->s_out));
-        const int32_t* info = (const int32_t*)(po + o_info);
-        uint32_t w = 4;
-        for (uint64_t t = 0; t < m; ++t) w = std::max<uint32_t>(w, (uint32_t)std::max(info[4 * t], info[4 * t + 1]));
-        w = std::min<uint32_t>((w + 15u) & ~15u, ostride);
-        HIPCHK(ctx, hipMemcpy2DAsync(po + o_oa, w, dout + o_oa, ostride, w, m, hipMemcpyDeviceToHost, ctx->s_out));
-        HIPCHK(ctx, hipMemcpy2DAsync(po + o_or, w, dout + o_or, ostride, w, m, hipMemcpyDeviceToHost, ctx->s_out));
-        HIPCHK(ctx, hipMemcpy2DAsync(po + o_oq, w, dout + o_oq, ostride, w, m, hipMemcpyDeviceToHost, ctx->s_out));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->s_out));
-        memcpy(out_info + c0 * 4, info, m * 16);
-        auto rows = [&](uint8_t* dst, const uint8_t* src) {
-            auto part = [=](uint64_t a, uint64_t z) { for (uint64_t t = a; t < z; ++t) memcpy(dst + (c0 + t) * ostride, src + t * w, w); };
-            if (threads < 2 || m < 4096) { part(0, m); return; }
-            std::vector<std::thread> pool;
-            for (unsigned q = 0; q < threads; ++q) pool.emplace_back(part, m * q / threads, m * (q + 1) / threads);
-            for (auto& th : pool) th.join();
-        };
-        rows(out_aln, po + o_oa); rows(out_ref, po + o_or); rows(out_qual, po + o_oq);
-        return 0;
-    };
-    if ((rc = stage_in(0))) return rc;
-    for (uint64_t c = 0; c < n_chunks; ++c) {
-        const int k = (int)(c & 1);
-        const uint64_t m = m_of(c);
-        uint8_t* din = (uint8_t*)ctx->d_lists.p + k * in_bytes;
-        uint8_t* dout = (uint8_t*)ctx->d_lists_out.p + k * out_bytes;
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_in[k], 0));
-        const int32_t* dn = (const int32_t*)(din + o_n);
-        if ((rc = c2_consensus_pairs_device(ctx, m, din + o_s1, din + o_f1, din + o_s2, din + o_f2, stride, dn, dn + mmax, din + o_q1, din + o_q2, qstride,
-                                            dn + 2 * mmax, dn + 3 * mmax, din + o_b, dout + o_oa, dout + o_or, dout + o_oq, ostride,
-                                            (int32_t*)(dout + o_info), (void*)s))) return rc;
-        HIPCHK(ctx, hipEventRecord(ctx->ev_done[k], s));
-        if (c + 1 < n_chunks && (rc = stage_in(c + 1))) return rc;          // the next chunk travels while this one runs
-        if (c >= 1 && (rc = fetch_out(c - 1))) return rc;                   // ... and the previous one's results come back
-    }
-    if ((rc = fetch_out(n_chunks - 1))) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    return 0;
-}
-
-int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out) {
-    if (!ctx || !a || !b || !out || n < 0) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc;
-    if ((rc = ensure(ctx, ctx->d_misc, (size_t)2 * n + 64))) return rc;
-    uint8_t* base = (uint8_t*)ctx->d_misc.p;
-    const size_t o_out = ((size_t)2 * n + 15) / 16 * 16;
-    if ((rc = ensure(ctx, ctx->d_misc, o_out + 16))) return rc;
-    base = (uint8_t*)ctx->d_misc.p;
-    hipStream_t s = ctx->stream;
-    if (n) {
-        HIPCHK(ctx, hipMemcpyAsync(base, a, n, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(base + n, b, n, hipMemcpyHostToDevice, s));
-    }
-    hipLaunchKernelGGL(c2_homology_kernel, dim3(1), dim3(64), 0, s, base, base + n, n, (float*)(base + o_out));
-    HIPCHK(ctx, hipGetLastError());
-    float f = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&f, base + o_out, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    *out = (double)f;
-    return 0;
-}
-
 int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4) {
     if (!ctx) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1578,130 +927,6 @@ int c2_phase_profile(c2_ctx* ctx, int enable, uint64_t* out4) {
     if (out4) HIPCHK(ctx, hipMemcpy(out4, ctx->d_phase.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemset(ctx->d_phase.p, 0, 4 * sizeof(uint64_t)));
     ctx->phase_prof = enable != 0;
-    return 0;
-}
-
-int c2_strand_plan_device(c2_ctx* ctx, uint64_t n_reads, const uint8_t* d_reads, const uint64_t* d_offsets, int32_t max_read_len,
-                          int32_t n_refs, int32_t max_seeds, const int32_t* h_n_seeds, const uint8_t* h_seed_blob, int32_t blob_bytes,
-                          const int32_t* h_seed_off, const int32_t* h_seed_len, int32_t seed_min, uint8_t* d_plan, void* hip_stream) {
-    if (!ctx || !d_reads || !d_offsets || !d_plan || n_refs <= 0 || max_seeds < 0 || blob_bytes < 0 || max_read_len < 0 ||
-        (max_seeds && (!h_n_seeds || !h_seed_off || !h_seed_len)) || (blob_bytes && !h_seed_blob)) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
-    if (n_reads == 0) return 0;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = (hipStream_t)hip_stream;
-    const size_t tbl = (size_t)n_refs * 2 * (size_t)std::max(max_seeds, 1);
-    for (int r = 0; r < n_refs; ++r) if (h_n_seeds && (h_n_seeds[r] < 0 || h_n_seeds[r] > max_seeds)) { ctx->err = "n_seeds out of range"; return C2_E_INVALID; }
-    for (size_t q = 0; q < (max_seeds ? tbl : 0); ++q)
-        if (h_seed_len[q] < 0 || h_seed_off[q] < 0 || (int64_t)h_seed_off[q] + h_seed_len[q] > blob_bytes) { ctx->err = "seed outside the blob"; return C2_E_INVALID; }
-    uint32_t lds = 4u * c2_strand_row_bytes(max_read_len);
-    if (lds > 163840u) { ctx->err = "read longer than the strand-plan kernel's LDS row"; return C2_E_TOO_LARGE; }
-    // seeds of at most C2_SEED_SLOT bytes whose table fits behind the read rows are compared from LDS, four bytes at a time
-    bool seed_table = max_seeds > 0;
-    for (size_t q = 0; q < (max_seeds ? tbl : 0) && seed_table; ++q) if ((uint32_t)h_seed_len[q] > C2_SEED_SLOT) seed_table = false;
-    if (seed_table && (uint64_t)lds + (uint64_t)tbl * C2_SEED_SLOT > 65536u) seed_table = false;
-    if (getenv("C2_STRAND_PLAN_BYTEWISE")) seed_table = false;
-    if (seed_table) lds += (uint32_t)tbl * C2_SEED_SLOT;
-    // one staging block: blob | seed_off | seed_len | n_seeds  (host copy first: a single small upload)
-    const size_t o_off = ((size_t)blob_bytes + 15) & ~(size_t)15, o_len = o_off + tbl * 4, o_n = o_len + tbl * 4, total = o_n + (size_t)n_refs * 4;
-    std::vector<uint8_t> host(total, 0);
-    if (blob_bytes) memcpy(host.data(), h_seed_blob, (size_t)blob_bytes);
-    if (max_seeds) { memcpy(host.data() + o_off, h_seed_off, tbl * 4); memcpy(host.data() + o_len, h_seed_len, tbl * 4); memcpy(host.data() + o_n, h_n_seeds, (size_t)n_refs * 4); }
-    int rc;
-    if (!(ctx->seeds_host.size() == total && memcmp(ctx->seeds_host.data(), host.data(), total) == 0)) {
-        // (the same seeds as last time -- every batch of a streamed run -- are on the device already: no upload, and no wait on the stream)
-        HIPCHK(ctx, hipDeviceSynchronize());                                      // an earlier launch may still read the old block
-        ctx->seeds_host.clear();
-        if ((rc = ensure(ctx, ctx->d_seeds, total))) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_seeds.p, host.data(), total, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));                                     // `host` is pageable memory owned by this call
-        ctx->seeds_host = host;
-    }
-    c2_strand_args A;
-    const uint8_t* base = (const uint8_t*)ctx->d_seeds.p;
-    A.reads = d_reads; A.offsets = d_offsets; A.n_reads = n_reads; A.seed_blob = base;
-    A.seed_off = (const int32_t*)(base + o_off); A.seed_len = (const int32_t*)(base + o_len); A.n_seeds = (const int32_t*)(base + o_n);
-    A.n_refs = n_refs; A.max_seeds = std::max(max_seeds, 1); A.seed_min = seed_min; A.max_read_len = max_read_len; A.plan = d_plan;
-    A.seed_table = seed_table ? 1 : 0; A.reserved = 0;
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)c2_strand_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    const uint64_t wgs = std::min<uint64_t>((n_reads + 3) / 4, (uint64_t)ctx->prop.multiProcessorCount * 8u);
-    hipLaunchKernelGGL(c2_strand_plan_kernel, dim3((unsigned)std::max<uint64_t>(1, wgs)), dim3(256), lds, s, A);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-// ---- FASTQ framing + de-duplication on the device (launch-only; crispresso2_amd/fastq_device.py drives them) ----
-static_assert(C2_FQ_TILE == C2_FQ_TILE_BYTES, "header and kernels disagree on the framing tile");
-int c2_fq_count_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, uint32_t* d_tile_newlines, uint32_t* d_tile_empty,
-                       uint32_t* d_flags, void* hip_stream) {
-    if (!ctx || !d_text || !d_tile_newlines || !d_tile_empty || !d_flags || hi < lo || (lo % 16u)) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
-    if (hi == lo) return 0;
-    const uint64_t tiles = (hi - lo + C2_FQ_TILE - 1) / C2_FQ_TILE;
-    if (tiles > 0x7fffffffull) { ctx->err = "range too large for one launch"; return C2_E_TOO_LARGE; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    c2_fq_frame_args A{};
-    A.text = d_text; A.lo = lo; A.hi = hi; A.tile_newlines = d_tile_newlines; A.tile_empty = d_tile_empty; A.flags = d_flags;
-    hipLaunchKernelGGL(c2_fq_count_kernel, dim3((unsigned)tiles), dim3(256), C2_FQ_LDS_BYTES, (hipStream_t)hip_stream, A);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-int c2_fq_lines_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, const uint64_t* d_tile_base, uint64_t* d_seq_start,
-                       uint64_t* d_seq_end, uint64_t n_records_cap, void* hip_stream) {
-    if (!ctx || !d_text || !d_tile_base || !d_seq_start || !d_seq_end || hi < lo || (lo % 16u)) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
-    if (hi == lo) return 0;
-    const uint64_t tiles = (hi - lo + C2_FQ_TILE - 1) / C2_FQ_TILE;
-    if (tiles > 0x7fffffffull) { ctx->err = "range too large for one launch"; return C2_E_TOO_LARGE; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    c2_fq_frame_args A{};
-    A.text = d_text; A.lo = lo; A.hi = hi; A.tile_base = d_tile_base; A.seq_start = d_seq_start; A.seq_end = d_seq_end; A.n_records_cap = n_records_cap;
-    hipLaunchKernelGGL(c2_fq_lines_kernel, dim3((unsigned)tiles), dim3(256), C2_FQ_LDS_BYTES, (hipStream_t)hip_stream, A);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-int c2_fq_dedup_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_seq_start, const uint64_t* d_seq_end, const uint64_t* d_range,
-                       uint64_t n_records_cap, uint64_t* d_slots, uint64_t n_slots, uint32_t* d_count, uint32_t* d_first,
-                       uint32_t* d_slot_of, uint64_t* d_rinfo, uint32_t* d_flags, uint32_t* d_stats, void* hip_stream) {
-    if (!ctx || !d_text || !d_seq_start || !d_seq_end || !d_range || !d_slots || !d_count || !d_first || !d_slot_of || !d_rinfo || !d_flags ||
-        !d_stats || n_slots < 2 || (n_slots & (n_slots - 1)) || n_slots > 0xffffffffull) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    c2_fq_dedup_args A{};
-    A.text = d_text; A.seq_start = d_seq_start; A.seq_end = d_seq_end; A.range = d_range; A.n_records_cap = n_records_cap;
-    A.slots = (unsigned long long*)d_slots; A.mask = n_slots - 1; A.count = d_count; A.first = d_first; A.slot_of = d_slot_of;
-    A.rinfo = (unsigned long long*)d_rinfo; A.flags = d_flags; A.stats = d_stats;
-    // grid-stride over the records (how many is only known on the device): enough wavefronts to cover the latency of the table probes
-    hipLaunchKernelGGL(c2_fq_dedup_kernel, dim3((unsigned)ctx->prop.multiProcessorCount * 8u), dim3(256), C2_FQ_DEDUP_LDS_BYTES, (hipStream_t)hip_stream, A);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-int c2_fq_gather_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_info, const int64_t* d_records, const int64_t* d_out_offsets,
-                        uint8_t* d_out, uint64_t n, void* hip_stream) {
-    if (!ctx || !d_text || !d_info || !d_out_offsets || !d_out) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
-    if (n == 0) return 0;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    c2_fq_gather_args A{};
-    A.text = d_text; A.info = (const unsigned long long*)d_info; A.records = d_records; A.out_offsets = d_out_offsets; A.out = d_out; A.n = n;
-    const uint64_t wgs = std::min<uint64_t>((n + 3) / 4, (uint64_t)ctx->prop.multiProcessorCount * 16u);
-    hipLaunchKernelGGL(c2_fq_gather_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)hip_stream, A);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-int c2_fq_rc_partner_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_info, const int64_t* d_records, uint64_t n,
-                            const uint64_t* d_slots, uint64_t n_slots, int32_t* d_partner_slot, void* hip_stream) {
-    if (!ctx || !d_text || !d_info || !d_records || !d_slots || !d_partner_slot || n_slots < 2 || (n_slots & (n_slots - 1)) || n_slots > 0x7fffffffull) {
-        if (ctx) ctx->err = "bad argument";
-        return C2_E_INVALID;
-    }
-    if (n == 0) return 0;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    c2_fq_rc_args A{};
-    A.text = d_text; A.info = (const unsigned long long*)d_info; A.records = d_records; A.n = n; A.slots = (const unsigned long long*)d_slots;
-    A.mask = n_slots - 1; A.partner_slot = d_partner_slot;
-    const uint64_t wgs = std::min<uint64_t>((n + 3) / 4, (uint64_t)ctx->prop.multiProcessorCount * 16u);
-    hipLaunchKernelGGL(c2_fq_rc_partner_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)hip_stream, A);
-    HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 

@@ -1,4 +1,4 @@
-// Plain-data structures shared by the host side (c2_api.hip) and the kernels (c2_kernels.hip).
+// Plain-data structures shared by the host side (c2_api_*.hip) and the kernels (c2_k_*.hip).
 #pragma once
 #include <stdint.h>
 #include <stddef.h>

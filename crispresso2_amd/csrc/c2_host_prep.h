@@ -1,4 +1,4 @@
-// Host-side preparation shared by the C ABI (c2_api.hip) and the test-only wave emulator
+// Host-side preparation shared by the C ABI (c2_api_*.hip) and the test-only wave emulator
 // harness (tests/emu/): plain C++, no HIP.  Marshals the reference's Python-level inputs
 // (int64 score matrix indexed by ord(char), include_idxs list) into the kernel's compact tables.
 #pragma once

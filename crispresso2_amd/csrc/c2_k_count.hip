@@ -1,0 +1,524 @@
+// c2_k_count.hip -- aligned strings + records -> the per-amplicon count tensor.
+#pragma once
+#include "c2_k_common.h"
+
+// =====================================================================================
+// Per-amplicon count vectors: the device side of the reference's "Quantifying indels/substitutions"
+// loop (CRISPRessoCORE.py:3964-4115, non-coding case) and of process_fastq's aln_stats (:1974-1979).
+// Input: the aligned strings and records the align kernel left in HBM, plus per-task weights
+// (read multiplicity; 0 = read not assigned to this reference).  One wavefront per alignment;
+// every workgroup accumulates into a private int32 copy of one reference's block in LDS (ds_add),
+// and flushes it to the int64 tensor in HBM with one atomic per non-zero entry.  The tensor is what
+// the multi-GPU path reduces with one RCCL all-reduce.
+// =====================================================================================
+__device__ __forceinline__ int c2_wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
+    return v;
+}
+
+// all_base_count vector of a read / reference character (CRISPRessoCORE.py:4075-4081), or -1.  Without a branch: the compiler turned
+// the chain of comparisons this used to be into a tree of DIVERGENT branches -- ~50 scalar instructions of exec-mask bookkeeping per call,
+// two calls per mismatching column -- and the count kernels are bound by the CU's one scalar unit (244 SALU per alignment,
+// profiles/r03/README.md).  (ch >> 1) & 7 is a perfect hash of A C T G - N (0 1 2 3 6 7); the byte tables are 64-bit constants.
+__device__ __forceinline__ int c2_base_vector(const unsigned char ch) {
+    const unsigned sh = (((unsigned)ch >> 1) & 7u) * 8u;
+    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', '-', 'N') >> sh) & 0xffu;
+    const unsigned v = (unsigned)(C2_BYTE_TABLE(C2_V_BASE_A, C2_V_BASE_C, C2_V_BASE_T, C2_V_BASE_G, C2_V_BASE_GAP, C2_V_BASE_N) >> sh) & 0xffu;
+    return is == (unsigned)ch ? (int)v : -1;
+}
+// substitution_count_vectors of a read base (:4049-4054): A C G T only, else -1
+__device__ __forceinline__ int c2_sub_base_vector(const unsigned char ch) {
+    const unsigned sh = (((unsigned)ch >> 1) & 7u) * 8u;
+    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', 0, 0) >> sh) & 0xffu;
+    const unsigned v = (unsigned)(C2_BYTE_TABLE(C2_V_ALL_SUB_BASE_A, C2_V_ALL_SUB_BASE_C, C2_V_ALL_SUB_BASE_T, C2_V_ALL_SUB_BASE_G, 0, 0) >> sh) & 0xffu;
+    return (ch != 0 && is == (unsigned)ch) ? (int)v : -1;
+}
+
+// Tasks grouped by reference for the count kernel (a chunk of consecutive positions then holds one or two references
+// instead of dozens: with 96 interleaved amplicons the LDS block would be flushed for almost every task).  Counting sort
+// in three tiny launches: histogram of ref_id, exclusive scan (one wavefront), scatter.  The order inside a reference is
+// whatever the atomics give -- the sums do not depend on it.
+// One atomic per distinct reference per wavefront (wave-aggregated): lanes with the same ref_id are found with ballots,
+// their leader adds the group's size, every lane gets base + its rank inside the group.  Returns the lane's slot (or -1).
+__device__ __forceinline__ long long c2_grouped_add(uint32_t* counters, const bool active, const unsigned key, const int lane) {
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long todo = __ballot(active);
+    long long slot = -1;
+    for (int round = 0; round < 4 && todo; ++round) {       // the big groups; what is left after four rounds is scattered
+        const int leader = __builtin_ctzll(todo);
+        const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long grp = __ballot(active && key == k0) & todo;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(counters + k0, (unsigned)__popcll(grp));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+        if ((grp >> lane) & 1ull) slot = (long long)base + __popcll(grp & lt);
+        todo &= ~grp;
+    }
+    if ((todo >> lane) & 1ull) slot = (long long)atomicAdd(counters + key, 1u);
+    return slot;
+}
+
+__global__ __launch_bounds__(256) void c2_ref_histogram_kernel(const c2_aln_record* records, uint64_t n, uint32_t* hist)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool active = t < n;
+    const unsigned key = active ? (unsigned)records[t].ref_id : 0u;
+    (void)c2_grouped_add(hist, active, key, (int)(threadIdx.x & 63));
+}
+
+__global__ __launch_bounds__(64) void c2_ref_scan_kernel(uint32_t* hist, int n_refs)     // hist -> exclusive prefix, in place
+{
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < n_refs; base += 64) {
+        const int k = base + lane;
+        const int x = (k < n_refs) ? (int)hist[k] : 0;
+        const int s = c2_wave_incl_scan(x, lane) + carry;
+        if (k < n_refs) hist[k] = (uint32_t)(s - x);
+        carry = __shfl(s, 63);
+    }
+}
+
+__global__ __launch_bounds__(256) void c2_ref_scatter_kernel(const c2_aln_record* records, uint64_t n, uint32_t* cursor, uint32_t* order)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool active = t < n;
+    const unsigned key = active ? (unsigned)records[t].ref_id : 0u;
+    const long long slot = c2_grouped_add(cursor, active, key, (int)(threadIdx.x & 63));
+    if (active) order[slot] = (uint32_t)t;
+}
+
+// (launch bounds: 5 workgroups per CU = 5 waves per SIMD = 96 VGPRs.  Left alone the compiler takes 101 -- 99 + 2 that hold 103 spilled
+// SGPRs -- and the kernel runs at 4 waves per SIMD, 8 % slower; with the bound it is 8 % slower than a 96-VGPR build WITHOUT the bound
+// would be (measured with round 1's source, which fits by itself: the occupancy target changes the schedule), but that is not on offer.)
+// HBM: the int32 accumulator block of the workgroup lives in global memory (A.block_scratch) instead of LDS -- amplicons beyond
+// ~1,650 bp, whose block does not fit 160 KB.  Its updates are the same atomics (they execute in L2); what reads the block with plain
+// loads -- the flush -- first drops the CU's L1 lines (agent-scope fence), and the flush takes every entry with an exchange.
+template <bool HBM>
+__device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
+{
+    // C2_CNT_WAVES wavefronts share one LDS block (the block is what limits residency, so sharing it multiplies the
+    // waves per CU); each wavefront walks one alignment at a time.  The workgroup takes C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE
+    // consecutive tasks per atomic; lane k of wave v holds the record of task base + k * C2_CNT_WAVES + v.
+    constexpr int NT = 64 * C2_CNT_WAVES, K = C2_CNT_TASKS_PER_WAVE, CHUNK = C2_CNT_WAVES * K, NONE = 0x7fffffff;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* acc = HBM ? A.block_scratch + (size_t)blockIdx.x * (size_t)A.block_ints : (int*)c2_smem;
+    const int VL = A.lmax + 1;                                  // vector length incl. the end slot of the difference arrays
+    const int o_sc = C2_CNT_VECTORS * VL, o_h = o_sc + C2_CNT_SCALARS;
+    const int per_ref = o_h + C2_CNT_HISTS * A.hl;
+    auto block_barrier = [&]() {                                // a barrier after which plain loads see the block's latest values
+        __syncthreads();
+        if (HBM) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    };
+    // cov: difference array over the reference positions of "weight of the alignments whose read base EQUALS the reference's here" --
+    // runs of matching columns add +w at their first position and -w behind their last; flush() integrates it and adds every
+    // position's total to the count vector of the reference's own base there (an LDS-only vector, not part of the tensor)
+    int* cov = HBM ? (int*)c2_smem : acc + per_ref;
+    int* ctl = cov + VL;                                        // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
+    uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
+    for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
+    for (int k = tid; k < VL; k += NT) cov[k] = 0;
+    block_barrier();
+    const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
+    const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
+    const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);   // string rows readable as dwords
+    const bool legacy = A.flags & C2_CNT_FLAG_LEGACY;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int cur_ref = -1;                                           // workgroup-uniform, like everything that guards a barrier
+    unsigned wsum = 0;                                          // load accumulated since the last flush (int32 safety, see C2_CNT_LOAD_BUDGET)
+    int Li = 0, par = 0;
+
+    // flush the LDS block of cur_ref into the int64 tensor (workgroup-wide)
+    auto flush = [&]() {
+        if (cur_ref < 0) return;
+        block_barrier();
+        // deletion vectors were accumulated as difference arrays (start += x, end -= x): integrate them first
+        if (wave < 3) {
+            int* d = wave == 2 ? cov : acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
+            int carry = 0;
+            for (int base = 0; base < VL; base += 64) {
+                const int k = base + lane;
+                const int x = (k < VL) ? d[k] : 0;
+                const int s = c2_wave_incl_scan(x, lane) + carry;
+                if (k < VL) d[k] = s;
+                carry = __shfl(s, 63);
+            }
+        }
+        block_barrier();
+        {   // gap-free reads added only their deviations from the reference (see the column walk): every reference position
+            // gets their total weight on the vector of its own base
+            const int g = acc[o_sc + C2_S_RESERVED0];
+            block_barrier();
+            {   // ... plus, per position, the weight of the alignments with gaps whose read matches the reference there (cov, integrated above)
+                const uint8_t* rs = A.refs[cur_ref].seq;
+                for (int c = tid; c < VL; c += NT) {
+                    const int x = g + cov[c];
+                    cov[c] = 0;
+                    if (c < Li && x != 0) {
+                        const int bv = c2_base_vector(rs[c]);
+                        if (bv >= 0) acc[bv * VL + c] += x;
+                    }
+                }
+                if (tid == 0) acc[o_sc + C2_S_RESERVED0] = 0;
+            }
+        }
+        block_barrier();
+        long long* out = A.counts + (size_t)cur_ref * per_ref;
+        for (int k = tid; k < per_ref; k += NT) {
+            const int x = HBM ? atomicExch(acc + k, 0) : acc[k];
+            if (x != 0) { atomicAdd((unsigned long long*)(out + k), (unsigned long long)(long long)x); if (!HBM) acc[k] = 0; }
+        }
+        wsum = 0;
+        block_barrier();
+    };
+
+    for (;;) {
+        if (tid == 0) {
+            const unsigned long long b = atomicAdd(A.work_counter, (unsigned long long)CHUNK);
+            ctl[0] = (int)(unsigned)(b & 0xffffffffu); ctl[1] = (int)(unsigned)(b >> 32);
+        }
+        __syncthreads();
+        const uint64_t chunk_base = (uint64_t)(unsigned)ctl[0] | ((uint64_t)(unsigned)ctl[1] << 32);
+        if (chunk_base >= A.n_tasks) break;
+        // ---- the records of this wave's K tasks, one per lane; selection test of CRISPRessoCORE.py:697 per lane
+        const uint64_t my_pos = chunk_base + (uint64_t)((lane & (K - 1)) * C2_CNT_WAVES + wave);
+        uint64_t my_task = my_pos;
+        unsigned d0 = 0, d1 = 0, d2 = 0, d4 = 0, d5 = 0, d6 = 0; int v_w = 0;
+        bool sel = false;
+        if (lane < K && my_pos < A.n_tasks) {
+            if (A.order) my_task = (uint64_t)A.order[my_pos];            // tasks grouped by reference: few flushes per chunk
+            else if (A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) {            // all-references batch (task = read * n_refs + reference): the same grouping by arithmetic
+                const uint64_t nr = A.n_tasks / (uint64_t)A.n_refs;
+                const uint64_t r = my_pos / nr;
+                my_task = (my_pos - r * nr) * (uint64_t)A.n_refs + r;
+            }
+            const unsigned wq = A.weights ? A.weights[my_task] : 1u;
+            v_w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
+            if (v_w > 0) {                                               // (an alignment that is not counted is not even read: most of an all-references batch)
+                const unsigned* rp = (const unsigned*)(A.records + my_task);
+                d0 = rp[0]; d1 = rp[1]; d2 = rp[2]; d4 = rp[4]; d5 = rp[5]; d6 = rp[6];
+                if (legacy && (rp[3] >> 16) != 0u) d4 |= 0x80000000u;         // legacy: a deletion event can have NO positions (all_deletion_bases 0): mark "has a deletion column" in the top bit
+                const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16), ref = (int)(d6 >> 16);
+                sel = ((d5 >> 24) == 0) && (T > 0);
+                if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
+            }
+        }
+        unsigned pending = (unsigned)__ballot(sel);
+        // Everything an alignment adds to an int32 entry of the block is its weight times a count of its own columns -- at most
+        // w * aln_len, its LOAD.  The loads since the last flush stay within C2_CNT_LOAD_BUDGET (2^30), so no entry can wrap;
+        // saturating sums decide the flushes before anything is added.
+        // (heavy chunks: v_w is what of the task's weight is still to be added; `counted`: lanes whose alignment has been counted once)
+        unsigned counted = 0;
+        {   // (a task above ~2^26 makes the chunk heavy by itself; the others add up in 32 bits: 32 x 2^26 = 2^31.  The size test is
+            // done in float -- 6.0e7 is safely below 2^26 for its rounding -- so that no 64-bit product has to be formed)
+            const unsigned my_T = (d0 & 0xffffu) ? (d0 & 0xffffu) : 1u;
+            const bool big = sel && (float)v_w * (float)my_T > 6.0e7f;
+            unsigned wv = (sel && !big) ? (unsigned)v_w * my_T : 0u;
+#pragma unroll
+            for (int d = 1; d < K; d <<= 1) wv += (unsigned)__shfl_xor((int)wv, d);
+            if (__ballot(big) != 0ull || wv > C2_CNT_LOAD_BUDGET) wv = C2_CNT_LOAD_BUDGET + 1u;
+            if (lane == 0) ctl[2 + wave] = (int)wv;
+        }
+        __syncthreads();
+        unsigned long long chunk_sum = 0;
+#pragma unroll
+        for (int v = 0; v < C2_CNT_WAVES; ++v) chunk_sum += (unsigned)ctl[2 + v];
+        const unsigned chunk_w = chunk_sum > C2_CNT_LOAD_BUDGET ? C2_CNT_LOAD_BUDGET + 1u : (unsigned)chunk_sum;
+        // a chunk heavier than the budget is processed one task at a time, its weight in pieces whose load fits, with a flush after each
+        const bool heavy = chunk_w > C2_CNT_LOAD_BUDGET;
+        if (!heavy && wsum + chunk_w > C2_CNT_LOAD_BUDGET) flush();
+        wsum += heavy ? 0u : chunk_w;
+        for (;;) {
+            // lowest pending task of the workgroup -> the reference whose tasks are processed in this round
+            const int first = pending ? __builtin_ctz(pending) : -1;
+            int fref = NONE, ftask = NONE;
+            if (first >= 0) { fref = (int)((unsigned)__builtin_amdgcn_readlane((int)d6, first) >> 16); ftask = first * C2_CNT_WAVES + wave; }
+            if (lane == 0) { ctl[16 + par * 2 * C2_CNT_WAVES + wave * 2] = fref; ctl[16 + par * 2 * C2_CNT_WAVES + wave * 2 + 1] = ftask; }
+            __syncthreads();
+            int tref = NONE, ttask = NONE;
+#pragma unroll
+            for (int v = 0; v < C2_CNT_WAVES; ++v) {
+                const int t = ctl[16 + par * 2 * C2_CNT_WAVES + v * 2 + 1];
+                if (t < ttask) { ttask = t; tref = ctl[16 + par * 2 * C2_CNT_WAVES + v * 2]; }
+            }
+            par ^= 1;
+            if (ttask == NONE) break;
+            if (tref != cur_ref) {
+                flush();
+                cur_ref = tref; Li = A.refs[tref].len;
+                const uint16_t* g = A.refs[tref].inc_prefix;
+                for (int k = tid; k < Li + 2; k += NT) incp[k] = g[k];
+                __syncthreads();
+            }
+            unsigned todo = heavy ? ((first >= 0 && ftask == ttask) ? (1u << first) : 0u) : pending;
+            // ---- scalar counters and histograms of ALL tasks of this round at once: lane k holds the record of its own task, so
+            //      every lane adds its task's contributions (LDS atomics; ~20 instructions per round instead of per task).
+            //      aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979), then the tallies of :3996-4072.
+            const bool mine = lane < K && ((todo >> lane) & 1u) && (int)(d6 >> 16) == tref;
+            // the weight this round adds for the lane's task: all of it, or (heavy) a piece whose load fits the budget
+            // heavy chunks: v_w becomes the piece of the weight this round adds, the remainder waits in LDS (no register of the
+            // common path is spent on it: the kernel sits at 96 VGPRs = 5 waves per SIMD)
+            if (heavy && mine) {
+                const unsigned my_T = d0 & 0xffffu;
+                const int piece = (int)(C2_CNT_LOAD_BUDGET / (my_T > 0 ? my_T : 1u));
+                const int rest = v_w > piece ? v_w - piece : 0;
+                ctl[C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1))] = rest;
+                v_w -= rest;
+            }
+            {   // an alignment whose two strings are the reference itself (no gap column, every column a match) adds nothing but
+                // its weight to the "spread over the reference's bases" scalar: done here, its strings are never read
+                const int T_ = (int)(d0 & 0xffffu), matches_ = (int)(d0 >> 16);
+                const bool perfect = mine && T_ == Li && matches_ == T_ && (d4 >> 16) == 0u && d1 == 0u;
+                if (perfect) atomicAdd(acc + o_sc + C2_S_RESERVED0, v_w);
+                const unsigned pm = (unsigned)__ballot(perfect);
+                todo &= ~pm; pending &= ~pm;
+            }
+            if (mine) {
+                const int w = v_w;
+                const int insertion_n = (int)(d1 & 0xffffu), deletion_n = (int)(d1 >> 16), substitution_n = (int)(d2 & 0xffffu);
+                const int all_ins = (int)(d2 >> 16), all_del_bases = (int)((d4 >> 16) & 0x7fffu), all_sub = (int)(d5 & 0xffffu);
+                const bool irregular_ends = (d5 >> 16) & 0xffu;
+                const int total_mods = all_ins + all_del_bases + all_sub;                               // :741
+                const int in_win = substitution_n + deletion_n + insertion_n;                           // :742
+                int* scal = acc + o_sc;
+                atomicAdd(scal + C2_S_N_GLOBAL_SUBS, all_sub * w);
+                atomicAdd(scal + C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - substitution_n) * w);
+                atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
+                atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
+                if (irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
+                if (!((counted >> lane) & 1u)) atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);           // (once per alignment, not per piece of a heavy weight)
+                if (discard && (deletion_n > 0 || insertion_n > 0)) atomicAdd(scal + C2_S_DISCARDED, w);                     // :3996-4000
+                else {
+                    const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
+                    const bool modified = has_del || has_ins || has_sub;
+                    atomicAdd(scal + C2_S_TOTAL, w);
+                    atomicAdd(scal + (modified ? C2_S_MODIFIED : C2_S_UNMODIFIED), w);          // :746-760, :4003-4006
+                    if (has_ins) atomicAdd(scal + C2_S_INSERTION, w);
+                    if (has_del) atomicAdd(scal + C2_S_DELETION, w);
+                    if (has_sub) atomicAdd(scal + C2_S_SUBSTITUTION, w);
+                    int combo = -1;                                                             // :4058-4072
+                    if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
+                                                 : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
+                    else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
+                    else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
+                    if (combo >= 0) atomicAdd(scal + combo, w);
+                    if (!ign_ins) atomicAdd(acc + o_h + C2_H_INSERTED_N * A.hl + insertion_n, w);   // :4020
+                    if (!ign_del) atomicAdd(acc + o_h + C2_H_DELETED_N * A.hl + deletion_n, w);     // :4030
+                    if (!ign_sub) atomicAdd(acc + o_h + C2_H_SUBSTITUTED_N * A.hl + substitution_n, w);   // :4043
+                    const int eff = Li + (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n);   // :4010-4037
+                    atomicAdd(acc + o_h + C2_H_EFFECTIVE_LEN * A.hl + eff, w);
+                }
+            }
+            while (todo) {
+                const int kk = __builtin_ctz(todo);
+                todo &= todo - 1;
+                const unsigned r6 = (unsigned)__builtin_amdgcn_readlane((int)d6, kk);
+                if ((int)(r6 >> 16) != tref) continue;
+                pending &= ~(1u << kk);
+                const uint64_t task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task & 0xffffffffull), kk) |
+                                      ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task >> 32), kk) << 32);
+                const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)d0, kk), r1 = (unsigned)__builtin_amdgcn_readlane((int)d1, kk);
+                const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)d2, kk), r4 = (unsigned)__builtin_amdgcn_readlane((int)d4, kk);
+                const unsigned r5 = (unsigned)__builtin_amdgcn_readlane((int)d5, kk);
+                const int w = __builtin_amdgcn_readlane(v_w, kk);
+                const int T = (int)(r0 & 0xffffu);
+                const int insertion_n = (int)(r1 & 0xffffu), deletion_n = (int)(r1 >> 16), substitution_n = (int)(r2 & 0xffffu);
+                const int all_ins = (int)(r2 >> 16), all_del_bases = (int)((r4 >> 16) & 0x7fffu), all_sub = (int)(r5 & 0xffffu);
+                const bool any_del_column = (r4 >> 16) != 0u;                                      // (positions, or the legacy marker)
+                const bool irregular_ends = (r5 >> 16) & 0xffu;
+                const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride;
+                const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride;
+                if (discard && (deletion_n > 0 || insertion_n > 0)) continue;                      // counted above; no vectors (:3996-4000)
+                if (rows_aligned && T == Li && !any_del_column) {
+                    // No gap column in either string (the usual read).  Four columns per lane: read and reference as dwords, the bytes
+                    // in which they differ by the "has a zero byte" trick on their XOR; only those add anything (the DEVIATIONS from
+                    // "the reference's own base, once per read": see the byte-wise walk below)
+                    for (int base = 0; base < T; base += 256) {
+                        const int p = base + 4 * lane, nb = T - p;
+                        unsigned rdw = 0, rfw = 0;
+                        if (nb > 0) { rdw = ((const unsigned*)R_)[p >> 2]; rfw = ((const unsigned*)F_)[p >> 2]; }
+                        const unsigned valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
+                        const unsigned x = (rdw ^ rfw) & valid;
+                        unsigned mm = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+                        while (mm) {
+                            const int b = __builtin_ctz(mm) >> 3;
+                            mm &= mm - 1u;
+                            const int c = p + b;
+                            const unsigned char rd = (unsigned char)(rdw >> (8 * b)), rfc = (unsigned char)(rfw >> (8 * b));
+                            const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
+                            if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
+                            if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
+                            if (rd != 'N') {
+                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
+                                if (!ign_sub) {
+                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
+                                    const int sv = c2_sub_base_vector(rd);                      // :4049-4054
+                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
+                                }
+                            }
+                        }
+                    }
+                    if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
+                    continue;
+                }
+                // first 256 columns of both strings: requested now, consumed by the column walk below
+                unsigned rd4 = 0, rf4 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 64 * q + lane;
+                    if (c < T) { rd4 |= (unsigned)R_[c] << (8 * q); rf4 |= (unsigned)F_[c] << (8 * q); }
+                }
+                const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
+                const bool modified = has_del || has_ins || has_sub;
+                const bool len_block = modified;                                                // :4085 (no coding sequence)
+                // ---- column walk (same scan as the fused classifier), ds_add into the vectors
+                int idx_base = 0, last_rf = -1, last_rd = -1;
+                bool last_rf_close = false, last_rf_wclose = false;
+                if (T == Li && !any_del_column) {
+                    // No gap column in either string: the reference index of a column is the column, only substitutions can
+                    // occur, and the read's base counts differ from "the reference's own base, once per read" only where the
+                    // read differs from the reference.  So the walk adds the DEVIATIONS (+w on the read's base, -w on the
+                    // reference's) and the read's weight goes to one scalar that flush() spreads over the reference's bases.
+                    for (int base = 0; base < T; base += 64) {
+                        const int c = base + lane;
+                        const bool in = c < T;
+                        unsigned char rd, rfc;
+                        if (base < 256) { rd = in ? (unsigned char)((rd4 >> ((base >> 6) * 8)) & 0xffu) : 0; rfc = in ? (unsigned char)((rf4 >> ((base >> 6) * 8)) & 0xffu) : 0; }
+                        else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
+                        if (in && rd != rfc) {
+                            const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
+                            if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
+                            if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
+                            if (rd != 'N') {
+                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
+                                if (!ign_sub) {
+                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
+                                    const int sv = c2_sub_base_vector(rd);                      // :4049-4054
+                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
+                                }
+                            }
+                        }
+                    }
+                    if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
+                    continue;
+                }
+                for (int base = 0; base < T; base += 64) {
+                    const int c = base + lane;
+                    const bool in = c < T;
+                    unsigned char rd, rfc;
+                    if (base < 256) { rd = in ? (unsigned char)((rd4 >> ((base >> 6) * 8)) & 0xffu) : 0; rfc = in ? (unsigned char)((rf4 >> ((base >> 6) * 8)) & 0xffu) : 0; }
+                    else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
+                    const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
+                    const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
+                    const int idx = idx_base + __popcll(m_rf & lt);
+                    const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
+                    const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
+                    const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
+                    // all_base_count, :4075-4081.  Columns where the read's base IS the reference's (nearly all of them) are not added one
+                    // by one: a run of them adds its weight to the difference array `cov` at its two ends (see flush)
+                    const bool same = rf_ng && rd == rfc;
+                    {
+                        const unsigned long long m_same = __ballot(same);
+                        if (same) {
+                            if (lane == 0 || !((m_same >> (lane - 1)) & 1ull)) atomicAdd(cov + idx, w);
+                            if (lane == 63 || !((m_same >> (lane + 1)) & 1ull)) atomicAdd(cov + idx + 1, -w);
+                        }
+                    }
+                    if (rf_ng && !same) {
+                        const int bv = c2_base_vector(rd);
+                        if (bv >= 0) atomicAdd(acc + bv * VL + idx, w);
+                        if (!rd_ng) atomicAdd(acc + C2_V_ALL_DELETION * VL + idx, w);                   // :4028
+                    }
+                    const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
+                    if (sub) {
+                        atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + idx, w);                           // :4040
+                        if (!ign_sub) {
+                            if (incp[idx + 1] != incp[idx]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + idx, w);   // :4044
+                            const int sv = c2_sub_base_vector(rd);                                      // :4049-4054
+                            if (sv >= 0) atomicAdd(acc + sv * VL + idx, w);
+                        }
+                    }
+                    {   // 64 columns without a gap and no gap run open in front of them (most chunks of an alignment with gaps): no insertion
+                        // or deletion can close here -- the rest of the body would find nothing
+                        const unsigned long long m_in = __ballot(in);
+                        if (m_rf == m_in && m_rd == m_in && last_rf == base - 1 && last_rd == base - 1) {
+                            const int cols = __popcll(m_in);
+                            idx_base += cols; last_rf = base + cols - 1; last_rd = last_rf;
+                            last_rf_close = false; last_rf_wclose = false;
+                            continue;
+                        }
+                    }
+                    // insertions: positions [idx-1, idx] of every event; numpy's fancy += counts a repeated position once (:4016, :4021)
+                    const bool ins_close = rf_ng && (prev_rf != c - 1) && idx > 0;
+                    const bool fl = ins_close && (incp[idx] != incp[idx - 1]), fr = ins_close && (incp[idx + 1] != incp[idx]);
+                    const bool ins_win = legacy ? (fl || fr) : (fl && fr);                              // pyx:121 / legacy pyx:284
+                    const unsigned long long m_ic = __ballot(ins_close), m_iw = __ballot(ins_win);
+                    if (ins_close) {
+                        const bool prev_close = (prev_rf >= base) ? ((m_ic >> (prev_rf - base)) & 1ull) : last_rf_close;
+                        const bool prev_wclose = (prev_rf >= base) ? ((m_iw >> (prev_rf - base)) & 1ull) : last_rf_wclose;
+                        atomicAdd(acc + C2_V_ALL_INSERTION_LEFT * VL + idx - 1, w);                     // :4017
+                        atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx, w);
+                        if (!prev_close) atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx - 1, w);
+                        if (ins_win) {
+                            if (!ign_ins) {
+                                atomicAdd(acc + C2_V_INSERTION * VL + idx, w);
+                                if (!prev_wclose) atomicAdd(acc + C2_V_INSERTION * VL + idx - 1, w);
+                            }
+                            if (len_block) {                                                            // :4104-4106 (scalar index: repeats add twice)
+                                const int sz = (c - 1 - prev_rf) * w;
+                                atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx - 1, sz);
+                                atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx, sz);
+                            }
+                        }
+                    }
+                    // deletions that touch the window: range(start, end) as a difference array (integrated in flush)
+                    const bool del_close = rd_ng && (prev_rd != c - 1);
+                    if (del_close) {
+                        const int dlen = c - 1 - prev_rd;
+                        // legacy (pyx:253-258): a run that starts in column 0 or 1 gets reference start 0 -- position 0 joins its
+                        // positions although the read has a base there
+                        const int dstart = (legacy && prev_rd <= 0) ? 0 : idx - dlen;
+                        if (legacy && prev_rd == 0) atomicAdd(acc + C2_V_ALL_DELETION * VL + 0, w);
+                        if (incp[idx] != incp[dstart]) {
+                            if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + dstart, w); atomicAdd(acc + C2_V_DELETION * VL + idx, -w); }   // :4031
+                            if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx, -dlen * w); }   // :4114
+                        }
+                    }
+                    idx_base += __popcll(m_rf);
+                    if (m_rf) {
+                        const int hi = 63 - __clzll((long long)m_rf);
+                        last_rf = base + hi;
+                        last_rf_close = (m_ic >> hi) & 1ull;
+                        last_rf_wclose = (m_iw >> hi) & 1ull;
+                    }
+                    if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
+                }
+                if (last_rd != T - 1 && lane == 0) {                                                    // trailing deletion, pyx:155-162
+                    const int dlen = T - 1 - last_rd;
+                    // legacy (pyx:259-261): the run ends at reference index idx - 1, exclusive -- the last base is not among its positions
+                    const int dstart = (legacy && last_rd <= 0) ? 0 : idx_base - dlen, dend = legacy ? idx_base - 1 : idx_base;
+                    if (legacy) {
+                        atomicAdd(acc + C2_V_ALL_DELETION * VL + idx_base - 1, -w);
+                        if (last_rd == 0) atomicAdd(acc + C2_V_ALL_DELETION * VL + 0, w);
+                    }
+                    if (dend > dstart && incp[dend] != incp[dstart]) {
+                        if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + dstart, w); atomicAdd(acc + C2_V_DELETION * VL + dend, -w); }
+                        if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dend, -dlen * w); }
+                    }
+                }
+            }   // tasks of this round
+            if (heavy) {
+                // a task whose weight was added only in part stays pending for another round
+                counted |= (unsigned)__ballot(mine);
+                if (mine) v_w = ctl[C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1))];
+                pending |= (unsigned)__ballot(mine && v_w > 0);
+                flush();
+            }
+        }       // rounds of this chunk
+    }           // chunks
+    flush();
+}
+
+__global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vectors_kernel(c2_count_args A) { c2_count_vectors_body<false>(A); }
+__global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vectors_hbm_kernel(c2_count_args A) { c2_count_vectors_body<true>(A); }

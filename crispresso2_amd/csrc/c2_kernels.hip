@@ -21,3269 +21,12 @@
 //     count tensor; c2_classify_lists[_batch]_kernel produce the reference's full position lists.
 //   * HBM traffic: the read comes in once (coalesced byte loads), the two aligned strings and one 32-byte record go out
 //     once; the multi-alignment kernels additionally park their pointer words in a scratch plane (written once, read once).
-#include <hip/hip_runtime.h>
-#include "c2_device.h"
-
-#define C2_DPP_WAVE_SHR1 0x138
-
-// lane n receives `src` of lane n-1; lane 0 keeps `old`
-__device__ __forceinline__ int c2_shr1(int old, int src) {
-    return __builtin_amdgcn_update_dpp(old, src, C2_DPP_WAVE_SHR1, 0xf, 0xf, false);
-}
-
-__device__ __forceinline__ int c2_imax(int a, int b) { return a > b ? a : b; }
-// sign-extended 4-bit field of x starting at bit `off`
-__device__ __forceinline__ int c2_sbfe4(int x, int off) { return __builtin_amdgcn_sbfe(x, off, 4); }
-
-struct c2_lds_plan {
-    // byte offsets into dynamic LDS (all multiples of 16)
-    uint32_t ptr, bnd, tbl, codeof, read, code, ref, incp, tmp_read, tmp_ref, total;
-    uint32_t col_stride;  // halfwords per pointer column
-};
-
-__host__ __device__ inline uint32_t c2_align16(uint32_t x) { return (x + 15u) & ~15u; }
-
-// The same function sizes the LDS on the host and carves it in the kernel.
-// Banded pointer plane: at step t only the lanes lo(t) .. lo(t)+nslots-1 keep their pointer word, where
-// lo(t) = floor((t - 1 - R*W) / (R+1)): lane l is at column j = t - l, the main-diagonal lane of that column is (j-1)/R,
-// and |l - (j-1)/R| <= W  <=>  (R+1)*l within R*W of t-1.  The window is wave-uniform, so the in-band test and the
-// LDS address of a step cost one subtract, one compare and one shift-add per lane.
-__host__ __device__ inline int c2_band_slots(int R, int W) { return (2 * R * W) / (R + 1) + 2; }
-__host__ __device__ inline int c2_band_lo(int R, int W, int t) { return (t - 1 - R * W + 64 * (R + 1)) / (R + 1) - 64; }
-
-// band_lanes = 0: full plane (one row of 64 lanes per read column); > 0: banded plane (one row of nslots per step)
-// plane_in_hbm: the pointer plane lives in a per-workgroup scratch area of HBM instead (c2_hbm_plane_halfwords: one row of
-// 64 halfwords per STEP of the sweep, so that a step's 64 stores are one 128-byte line); LDS then only holds the O(Li + Lj) parts.
-__host__ __device__ inline uint64_t c2_hbm_plane_halfwords(int max_lj, int max_passes) { return (uint64_t)max_passes * ((uint64_t)max_lj + 64u) * 64u; }
-__host__ __device__ inline c2_lds_plan c2_make_plan(int R, int max_lj, int max_passes, int n_codes, int band_lanes, bool plane_in_hbm = false) {
-    const int nslots = band_lanes > 0 ? c2_band_slots(R, band_lanes) : C2_LANES;
-    const uint32_t plane_rows = band_lanes > 0 ? (uint32_t)max_lj + 64u : (uint32_t)max_lj;
-    c2_lds_plan p;
-    const uint32_t max_li = (uint32_t)max_passes * 64u * (uint32_t)R;
-    p.col_stride = plane_in_hbm ? 64u : (uint32_t)nslots + C2_PTR_PAD;
-    uint32_t off = 0;
-    p.ptr = off;      off += plane_in_hbm ? 0u : c2_align16((uint32_t)max_passes * plane_rows * p.col_stride * 2u);
-    p.bnd = off;      off += (max_passes > 1) ? c2_align16(3u * ((uint32_t)max_lj + 1u) * 4u) : 0u;
-    p.tbl = off;      off += c2_align16((uint32_t)n_codes * (uint32_t)n_codes * 2u);
-    p.codeof = off;   off += 256u;
-    p.read = off;     off += c2_align16((uint32_t)max_lj);
-    p.code = off;     off += c2_align16((uint32_t)max_lj);
-    p.ref = off;      off += c2_align16(max_li);
-    p.incp = off;     off += c2_align16((max_li + 2u) * 2u);
-    p.tmp_read = off; off += c2_align16(max_li + (uint32_t)max_lj);
-    p.tmp_ref = off;  off += c2_align16(max_li + (uint32_t)max_lj);
-    p.total = off;
-    return p;
-}
-
-extern __shared__ __attribute__((aligned(16))) unsigned char c2_smem[];
-
-// (ch >> 1) & 7 is a perfect hash of A C T G - N (0 1 2 3 6 7; lower case lands on the same slots): byte tables as 64-bit constants
-#define C2_BYTE_TABLE(a0, a1, a2, a3, a6, a7) ((unsigned long long)(a0) | ((unsigned long long)(a1) << 8) | ((unsigned long long)(a2) << 16) | \
-                                               ((unsigned long long)(a3) << 24) | ((unsigned long long)(a6) << 48) | ((unsigned long long)(a7) << 56))
-// complement of an upper-cased read character, 0 outside ACGTN_- (CRISPRessoShared.reverse_complement's dictionary).  A table look-up,
-// not a switch: the compiler lowers a switch on a per-lane value to a tree of divergent branches (see c2_base_vector).  (c >> 1) & 7
-// sends A/a C/c T/t G/g - N/n to 0 1 2 3 6 7; '_' shares N's slot and is tested by itself.
-__device__ __forceinline__ unsigned c2_fq_complement(const unsigned c) {
-    const unsigned h = (c >> 1) & 7u, sh = h * 8u;
-    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', '-', 'N') >> sh) & 0xffu;
-    const unsigned to = (unsigned)(C2_BYTE_TABLE('T', 'G', 'A', 'C', '-', 'N') >> sh) & 0xffu;
-    const bool letter = h != 6u && is != 0u && (c | 0x20u) == (is | 0x20u);
-    return c == '_' ? (unsigned)'_' : (letter || c == '-') ? to : 0u;
-}
-
-
-// Region executed with some lanes switched off in EXEC for its whole length (one s_and_saveexec; no per-instruction
-// cost).  The wave emulator (tests/emu) supplies its own definition, which parks the inactive fibers.
-#ifndef C2_LANES_ACTIVE_BEGIN
-#define C2_LANES_ACTIVE_BEGIN(cond) if (cond) {
-#define C2_LANES_ACTIVE_END() }
-#endif
-
-// h-state (argmax with the reference's tie rule, pyx:216-228) of a cell on row 0 or column 0,
-// from the closed-form boundary values (pyx:153-176).
-__device__ __forceinline__ int c2_boundary_hstate(int i, int j, int min_score, int ge, int g0) {
-    if (i == 0 && j == 0) return C2_ST_M;                 // M[0,0]=0 beats I=J=min_score
-    if (i == 0) return (ge * j + g0 >= min_score) ? C2_ST_I : C2_ST_J;   // M=J=min_score, I=ge*j+g0
-    return (ge * i + g0 <= min_score) ? C2_ST_I : C2_ST_J;              // M=I=min_score, J=ge*i+g0
-}
-
-// Append the four pointer bits of one cell to `bits` (newest in the low bits):
-//   bit3 = a0 > b0 (I opened), bit2 = a1 > b1 (J opened), bit1 = a2 == b2 (H is I), bit0 = a3 >= b3 (J beats M).
-// On the device: four v_cmp into SGPR pairs, then four v_addc_co_u32 (bits = 2*bits + carry) -- 8 VALU issues, and each
-// compare result is read 3+ issues after it was written (gfx950 needs 2 wait states there, which hipcc cannot see in asm).
-__device__ __forceinline__ void c2_push4(unsigned& bits, int a0, int b0, int a1, int b1, int a2, int b2, int a3, int b3) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long m1, m2, m3;
-    asm("v_cmp_gt_i32 %1, %4, %5\n\t"
-        "v_cmp_gt_i32 %2, %6, %7\n\t"
-        "v_cmp_eq_u32 %3, %8, %9\n\t"
-        "v_cmp_ge_i32 vcc, %10, %11\n\t"
-        "v_addc_co_u32 %0, %1, %0, %0, %1\n\t"
-        "v_addc_co_u32 %0, %2, %0, %0, %2\n\t"
-        "v_addc_co_u32 %0, %3, %0, %0, %3\n\t"
-        "v_addc_co_u32 %0, vcc, %0, %0, vcc"
-        : "+v"(bits), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
-        : "vcc");
-#else
-    bits = (bits << 4) | ((unsigned)(a0 > b0) << 3) | ((unsigned)(a1 > b1) << 2) | ((unsigned)(a2 == b2) << 1) | (unsigned)(a3 >= b3);
-#endif
-}
-
-// Optional per-phase cycle accounting (c2_align_args.phase_cycles != NULL): every workgroup sums the s_memtime delta of
-// each phase of each of its tasks in registers and adds the four sums to the global counters once, when it runs out of
-// work.  Used by tools/phase_profile.py; costs one uniform branch per phase when disabled.
-struct c2_phase_acc { unsigned long long t_last, sum[4]; };
-__device__ __forceinline__ void c2_phase_begin(const unsigned long long* acc, c2_phase_acc& P) { if (acc) P.t_last = (unsigned long long)clock64(); }
-template <int PHASE>
-__device__ __forceinline__ void c2_phase_mark(const unsigned long long* acc, c2_phase_acc& P) {
-    if (acc) {
-        const unsigned long long now = (unsigned long long)clock64();
-        P.sum[PHASE] += now - P.t_last;
-        P.t_last = now;
-    }
-}
-__device__ __forceinline__ void c2_phase_flush(unsigned long long* acc, const c2_phase_acc& P, const int lane) {
-    if (acc && lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(acc + k, P.sum[k]); }
-}
-
-// floor(x / R) for the rows-per-lane values in use (x < 32768)
-template <int R>
-__device__ __forceinline__ int c2_div_rows(int x) {
-    if (R == 1) return x;
-    if (R == 2) return x >> 1;
-    if (R == 4) return x >> 2;
-    return (x * 21846) >> 16;                           // R == 3
-}
-
-// Halfword index of the pointer word of (row-lane `rl`, column j) inside one pass's pointer plane.
-// Full plane: row j-1, slot rl.  BAND: row t-1 (t = j + rl is the step at which that lane computed the column), slot
-// rl - lo(t); *inband tells whether the word was stored.
-// MODE 0: full plane in LDS, 1: banded plane in LDS (BAND), 2: full plane in HBM scratch, row t-1, slot rl.
-template <int R, int MODE>
-__device__ __forceinline__ int c2_ptr_index(const int rl, const int j, const int colStride, const int band_lanes, bool& inband) {
-    if (MODE == 2) { inband = true; return (j + rl - 1) * 64 + rl; }
-    if (MODE == 0) { inband = true; return (j - 1) * colStride + rl; }
-    const int t = j + rl;
-    const int slot = rl - c2_band_lo(R, band_lanes, t);
-    inband = (unsigned)slot < (unsigned)c2_band_slots(R, band_lanes);
-    return (t - 1) * colStride + slot;
-}
-
-// Per-lane DP state of one systolic pass: R consecutive reference rows.
-template <int R>
-struct c2_strip {
-    int a[R], b[R], c[R], delta[R];   // gap constants of the rows (see c2_dp_pass)
-    int sel[R];                       // PACKED: 8 signed score nibbles of the row's base; else: LDS row offset into the score table
-    int Ml[R], Il[R], Hl[R];          // M, I, H=max(M,I,J) of the rows at the column computed last
-    int Mb, Jb, Hb;                   // bottom row at that column: what the lane below receives
-    int upM, upJ, upH;                // hand-off registers: lanes 1..63 receive the lane above (DPP), lane 0 keeps the boundary row
-    int dgsave;                       // H(row above the strip, previous column)
-    int cj;                           // read symbol of the current column (PACKED: 4*code, else code)
-    unsigned bits;                    // pointer nibbles, newest in the low bits
-};
-
-// One column of the strip (the lane is active: 1 <= j <= Lj).  TAIL: the lane may be on the last column, where
-// gap_open is replaced by gap_extend (pyx:234-273) -- delta[] carries ge-go for every row but the last one.
-template <int R, bool PACKED, bool TAIL>
-__device__ __forceinline__ void c2_dp_column(c2_strip<R>& S, const int upM0, const int upJ0, const int ge,
-                                             const bool lastcol, const int16_t* sTbl)
-{
-    int upM = upM0, upJ = upJ0, dg = S.dgsave;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int s;
-        if (PACKED) s = c2_sbfe4(S.sel[r], S.cj);                             // signed nibble number cj/4: one v_bfe_i32
-        else        s = (int)sTbl[S.sel[r] + S.cj];
-        int iFromM = S.Ml[r] + S.a[r];
-        int jFromM = upM + S.c[r];
-        if (TAIL) { const int corr = lastcol ? S.delta[r] : 0; iFromM += corr; jFromM += corr; }
-        const int iExt = S.Il[r] + S.b[r];
-        const int In = c2_imax(iFromM, iExt);             // pyx:191-196: tie -> extend (pointer bit: iFromM > iExt)
-        const int jExt = upJ + ge;
-        const int Jn = c2_imax(jFromM, jExt);             // pyx:199-211: tie -> extend (pointer bit: jFromM > jExt)
-        const int Mn = dg + s;                            // H(i-1,j-1) + matrix[ci,cj], pyx:213-228
-        const int Hn = c2_imax(c2_imax(Mn, Jn), In);      // v_max3_i32
-        // H is I iff In >= max(Mn, Jn) iff In == Hn (I wins all ties); else J iff Jn >= Mn (J beats M on a tie)
-        c2_push4(S.bits, iFromM, iExt, jFromM, jExt, In, Hn, Jn, Mn);
-        dg = S.Hl[r];
-        S.Ml[r] = Mn; S.Il[r] = In; S.Hl[r] = Hn;
-        upM = Mn; upJ = Jn;
-    }
-    S.Mb = upM; S.Jb = upJ; S.Hb = S.Hl[R - 1];
-}
-
-// Symbols of read positions base+l, base+l+64, base+l+128, base+l+192 packed into one register per lane l
-// (PACKED: 4*code, the bit offset of the score nibble).
-template <bool PACKED>
-__device__ __forceinline__ int c2_load_rsym(const unsigned char* sCode, const int base, const int Lj, const int lane) {
-    int w = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int q = base + 64 * b + lane;
-        const int c = q < Lj ? (int)sCode[q] : 0;
-        w |= (PACKED ? (c << 2) : c) << (8 * b);
-    }
-    return w;
-}
-
-// One step of the systolic sweep: hand-off from the lane above (DPP, full EXEC), then this lane's column j = t - lane.
-// PHASE 0: ramp-up (t < 64: lanes with j < 1 wait), 1: steady state (every lane is inside 1..Lj-1: no mask at all),
-// 2: tail (lanes may be on the last column, or past it).
-template <int R, bool PACKED, int PHASE, int MODE>
-__device__ __forceinline__ void c2_dp_step(c2_strip<R>& S, const int t, const int lane, const int Lj, const int ge, const int g0,
-                                           const int min_score, const bool first, const bool feeds_next,
-                                           const int rsym, int& nM, int& nJ, int& nH,
-                                           const unsigned char* sCode, const int16_t* sTbl, int* sBnd,
-                                           uint16_t* planePtr, const int colStride, const int band_lanes)
-{
-    // lane 0's inputs: the row above the pass at column t.  First pass: closed-form row 0 (pyx:153-176): M = J = min_score
-    // (they sit in lane 0 of S.upM / S.upJ since the pass started; the DPP never writes lane 0), H(0,t) = iScore[0,t].
-    if (first) {
-        const int bH = c2_imax(min_score, ge * t + g0);
-        if (lane == 0) S.upH = bH;
-    } else {
-        if (lane == 0) { S.upM = nM; S.upJ = nJ; S.upH = nH; }
-        const int tn = (t + 1 <= Lj) ? t + 1 : Lj;
-        nM = sBnd[3 * tn]; nJ = sBnd[3 * tn + 1]; nH = sBnd[3 * tn + 2];
-    }
-    // read symbol of column t: lane (t-1)&63 of rsym holds the symbols of read positions l, l+64, l+128, l+192 of the
-    // current 256-column chunk (v_readlane + scalar byte extract: no LDS access, nothing to wait for)
-    const int pos = t - 1;
-    const int bC = (__builtin_amdgcn_readlane(rsym, pos & 63) >> ((pos >> 3) & 24)) & 0xff;
-    S.upM = c2_shr1(S.upM, S.Mb);
-    S.upJ = c2_shr1(S.upJ, S.Jb);
-    S.upH = c2_shr1(S.upH, S.Hb);
-    S.cj = c2_shr1(bC, S.cj);
-    const int j = t - lane;
-    bool active = true;
-    if (PHASE == 0) active = (j >= 1);
-    if (PHASE == 2) active = (j >= 1 && j <= Lj);
-    if (active) {
-        c2_dp_column<R, PACKED, PHASE == 2>(S, S.upM, S.upJ, ge, PHASE == 2 && (j == Lj), sTbl);
-        if (MODE == 1) {
-            const int slot = lane - c2_band_lo(R, band_lanes, t);
-            if ((unsigned)slot < (unsigned)c2_band_slots(R, band_lanes)) planePtr[(t - 1) * colStride + slot] = (uint16_t)S.bits;
-        } else if (MODE == 2) {
-            planePtr[(t - 1) * 64 + lane] = (uint16_t)S.bits;             // (HBM: one 128-byte line per step)
-        } else {
-            planePtr[(j - 1) * colStride + lane] = (uint16_t)S.bits;
-        }
-        if (feeds_next && lane == 63) { sBnd[3 * j] = S.Mb; sBnd[3 * j + 1] = S.Jb; sBnd[3 * j + 2] = S.Hb; }
-    }
-    S.dgsave = S.upH;
-}
-
-// One systolic pass over reference rows p*64R+1 .. p*64R+64R.  SINGLE: the reference fits one pass, so the row above
-// lane 0 is the closed-form row 0 and nothing is handed to a next pass.
-template <int R, bool PACKED, bool SINGLE, int MODE>
-__device__ __forceinline__ void c2_dp_pass(const c2_align_args& A, const c2_dev_ref& rf, const unsigned char* sRef,
-                                           const unsigned char* sCode, const int16_t* sTbl, int* sBnd, uint16_t* planePtr,
-                                           const int colStride, const int lane, const int p, const int passes,
-                                           const int Li, const int Lj, const int g0, const int min_score)
-{
-    const int ROWS_PER_PASS = 64 * R;
-    const int ge = A.gap_extend, go = A.gap_open;
-    const int row0 = p * ROWS_PER_PASS + lane * R;      // 0-based row above this lane's strip
-    c2_strip<R> S;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = row0 + r + 1;                      // 1-based reference row
-        const int ic = i <= Li ? i : Li;                 // padding rows below Li compute garbage nobody reads
-        const int gi = rf.gap_incentive[ic], gim1 = rf.gap_incentive[ic - 1];
-        const bool last_row = (i == Li);
-        // last row: gap_open is replaced by gap_extend (pyx:277-317)
-        S.a[r] = (last_row ? ge : go) + gi;              // I opened from M
-        S.b[r] = ge + gi;                                // I extended (incentive on every extension, pyx:197)
-        S.c[r] = (last_row ? ge : go) + gim1;            // J opened from M (incentive only on open, pyx:205-207)
-        S.delta[r] = last_row ? 0 : (ge - go);
-        const int rcode = (int)A.code_of_char[sRef[ic - 1]];
-        S.sel[r] = PACKED ? (int)A.score_pk[rcode] : rcode * A.n_codes;
-        const int J0 = ge * i + g0;                      // jScore[i,0], pyx:170-171
-        S.Ml[r] = min_score; S.Il[r] = min_score;        // mScore[i,0], iScore[i,0]
-        S.Hl[r] = c2_imax(min_score, J0);
-    }
-    S.Mb = min_score; S.Jb = ge * (row0 + R) + g0; S.Hb = S.Hl[R - 1];
-    // diagonal input of the strip's first row at its first column: H(row0, 0)
-    S.dgsave = (row0 == 0) ? 0 : c2_imax(min_score, ge * row0 + g0);
-    S.cj = 0;
-    S.bits = 0;
-    S.upM = min_score; S.upJ = min_score; S.upH = 0;
-    const int nrows = (Li - p * ROWS_PER_PASS) < ROWS_PER_PASS ? (Li - p * ROWS_PER_PASS) : ROWS_PER_PASS;
-    const int nl = (nrows + R - 1) / R;
-    const int steps = Lj + nl - 1;
-    const bool first = SINGLE || (p == 0);
-    const bool feeds_next = !SINGLE && (p + 1 < passes);
-
-    // values entering lane 0 at step t (column t of the row above the pass), fetched one step ahead
-    int rsym = 0;
-    int nM = min_score, nJ = min_score, nH = 0;
-    if (!first) { nM = sBnd[3]; nJ = sBnd[4]; nH = sBnd[5]; }
-    // ramp-up: steps 1 .. min(64, Lj)-1;  steady state: 64 .. Lj-1 (all 64 lanes inside the matrix, not on its last column);
-    // tail: Lj .. steps
-    const int t1 = Lj < 64 ? Lj : 64;
-    const int t2 = Lj < steps + 1 ? Lj : steps + 1;
-    int t = 1;
-    while (t <= steps) {
-        // one 256-column chunk of read symbols per register (c2_load_rsym), then the steps that consume it
-        const int seg_end = (((t - 1) | 255) + 1) < steps ? (((t - 1) | 255) + 1) : steps;
-        rsym = c2_load_rsym<PACKED>(sCode, (t - 1) & ~255, Lj, lane);
-        for (; t <= seg_end && t < t1; ++t)
-            c2_dp_step<R, PACKED, 0, MODE>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
-        for (; t <= seg_end && t < t2; ++t)
-            c2_dp_step<R, PACKED, 1, MODE>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
-        for (; t <= seg_end; ++t)
-            c2_dp_step<R, PACKED, 2, MODE>(S, t, lane, Lj, ge, g0, min_score, first, feeds_next, rsym, nM, nJ, nH, sCode, sTbl, sBnd, planePtr, colStride, A.band_lanes);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Pieces shared by the row-strip kernel (c2_align_classify_kernel) and the diagonal-band kernel (c2_align_diag_kernel)
-// ---------------------------------------------------------------------------------------------------------------
-struct c2_wg {                       // one workgroup's LDS views
-    unsigned char* sRead;            // read characters (reverse-complemented if the task asks for it)
-    unsigned char* sCode;            // their score-table codes
-    unsigned char* sRef;             // reference characters
-    uint16_t* sIncP;                 // window prefix counts of the reference
-    unsigned char* sTmpRead;         // aligned strings, reversed (as the traceback emits them)
-    unsigned char* sTmpRef;
-};
-
-// Pull the next task index from the device counter (chunks of C2_TASK_CHUNK per atomic), so a launch never waits for the
-// slowest statically assigned share and does not depend on how many workgroups are resident.  Returns false when done.
-__device__ __forceinline__ bool c2_next_task(const c2_align_args& A, const int lane, uint64_t& chunk_base, int& chunk_left, uint64_t& task) {
-    const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : A.n_tasks;
-    if (chunk_left == 0) {
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(A.work_counter, (unsigned long long)C2_TASK_CHUNK);
-        chunk_base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
-                     (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
-        chunk_left = C2_TASK_CHUNK;
-    }
-    const uint64_t it = chunk_base;
-    if (it >= n_iter) return false;
-    ++chunk_base; --chunk_left;
-    task = A.task_list ? (uint64_t)A.task_list[it] : it;
-    return true;
-}
-
-// The next task's descriptor and the first 256 bytes of its read, requested from HBM while the current task is still in
-// its DP (nothing waits for these loads until c2_commit_task uses them): one task of software pipelining per workgroup.
-struct c2_prefetch {
-    uint64_t task, off;
-    int valid, Lj, ref_id, rc;
-    unsigned b4;                     // read bytes lane, lane+64, lane+128, lane+192 in bytes 0..3 (already reversed for rc tasks)
-};
-
-__device__ __forceinline__ void c2_prefetch_issue(const c2_align_args& A, const int lane, uint64_t& chunk_base, int& chunk_left,
-                                                  c2_prefetch& pf)
-{
-    // (locals, one unconditional struct assignment at the end: keeps the struct in registers)
-    uint64_t task = 0, off = 0;
-    int Lj = 0, ref_id = 0, rc = 0;
-    unsigned b4 = 0;
-    const bool valid = c2_next_task(A, lane, chunk_base, chunk_left, task);
-    if (valid) {
-        uint64_t read_id;
-        if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
-        else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
-        rc = A.strands ? (int)A.strands[task] : 0;
-        off = A.offsets[read_id];
-        Lj = (int)(A.offsets[read_id + 1] - off);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = 64 * q + lane;
-            const unsigned byte = (k < Lj) ? (unsigned)A.reads[off + (uint64_t)(rc ? Lj - 1 - k : k)] : 0u;
-            b4 |= byte << (8 * q);
-        }
-    }
-    pf.task = task; pf.off = off; pf.valid = valid ? 1 : 0; pf.Lj = Lj; pf.ref_id = ref_id; pf.rc = rc; pf.b4 = b4;
-}
-
-// Stage the prefetched task in LDS: reference (only when the amplicon changes), read characters (reverse complement on
-// request, CRISPRessoShared.py:399-403) and their codes.  Returns the wave-uniform status bits.  max_li / A.max_lj bound
-// what may be written.  sCodeOf: the 256-entry character -> code table, in LDS.
-// Stage a reference in its LDS slot (characters, window prefix counts; `bad`: a character outside the score matrix) -- done
-// only when the amplicon of a slot changes.  sWin (optional): per dword of four reference positions, bit 7 of byte b set iff
-// position 4k + b lies in the quantification window (what c2_emit_gapless4 tests substitutions against).
-__device__ __forceinline__ void c2_stage_ref(const c2_align_args& A, const c2_wg& W, const unsigned char* sCodeOf, const int ref_id, const int lane,
-                                             const int max_li, int& Li, int& g0, int& ref_bad, uint32_t* sWin = nullptr)
-{
-    const c2_dev_ref rf = A.refs[ref_id];
-    Li = rf.len;
-    g0 = rf.gap_incentive[0];
-    const int LiLoad = Li < max_li ? Li : max_li;
-    int bad = 0;                                            // a reference character outside the score matrix: checked when the
-    for (int k = lane; k < LiLoad; k += 64) {               // reference is staged, remembered with it (ref_bad)
-        const unsigned char ch = rf.seq[k];
-        W.sRef[k] = ch;
-        if ((int)sCodeOf[ch] >= A.first_ext_code) bad = 1;      // ord >= matrix dimension (codes >= first_ext_code are read-only symbols)
-    }
-    ref_bad = __ballot(bad) ? 1 : 0;
-    for (int k = lane; k < LiLoad + 2; k += 64) W.sIncP[k] = rf.inc_prefix[k];
-    if (sWin) {
-        for (int k = lane; 4 * k < LiLoad; k += 64) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int c = 4 * k + b;
-                if (c < LiLoad && rf.inc_prefix[c + 1] != rf.inc_prefix[c]) m |= 0x80u << (8 * b);
-            }
-            sWin[k] = m;
-        }
-    }
-}
-
-// code_shift / code_or (packed kernel): the column table holds pair symbols, code A << 5 | code B << 2 -- the first alignment of
-// a lane group writes its codes shifted by 5 (and the zeros around them), the second ORs its codes in shifted by 2.
-template <bool HAVE_B4 = true>
-__device__ __forceinline__ int c2_commit_task(const c2_align_args& A, const c2_wg& W, const unsigned char* sCodeOf, const c2_prefetch& pf,
-                                              const int lane, const int max_li, int& cur_ref, int& Li, int& g0, int& ref_bad, bool& packed,
-                                              unsigned char* sCodes4 = nullptr, uint32_t* sWin = nullptr, const int code_shift = 2, const bool code_or = false,
-                                              const bool stage_ref = true)
-{
-    // sCodes4 (multi-alignment kernel): the zero-padded table of 4 * code per column, written in the same pass -- columns
-    // 1 .. Lj at sCodes4[C2_DIAG_CODE_PAD + 1 ..]; the zeros in front are written once per kernel, the nine behind per task
-    const int Lj = pf.Lj, rc = pf.rc;
-    int status = 0;
-    int read_code_max = 0;
-    const int LjLoad = Lj < A.max_lj ? Lj : A.max_lj;       // never write past the LDS plan
-    if (stage_ref && pf.ref_id != cur_ref) {
-        cur_ref = pf.ref_id;
-        c2_stage_ref(A, W, sCodeOf, pf.ref_id, lane, max_li, Li, g0, ref_bad, sWin);
-    }
-    for (int k = lane; k < LjLoad; k += 64) {
-        unsigned char ch;
-        if (HAVE_B4 && k < 256) ch = (unsigned char)((pf.b4 >> ((k >> 6) * 8)) & 0xffu);
-        else ch = A.reads[pf.off + (uint64_t)(rc ? Lj - 1 - k : k)];
-        if (rc) {
-            unsigned char cc = (unsigned char)c2_fq_complement(ch);     // seq.upper(), then the dictionary; 0: a character outside it
-            if (cc == 0) { status |= C2_STATUS_RC_CHAR; cc = 'N'; }
-            ch = cc;
-        }
-        const unsigned char code = sCodeOf[ch];
-        if (code == C2_INVALID_CODE) status |= C2_STATUS_OOB_CHAR;
-        W.sRead[k] = ch;
-        if (sCodes4) {                                                               // (the multi-alignment kernels read only this table)
-            const unsigned char cv = (unsigned char)((code & 7u) << code_shift);
-            if (code_or) sCodes4[C2_DIAG_CODE_PAD + 1 + k] |= cv; else sCodes4[C2_DIAG_CODE_PAD + 1 + k] = cv;
-        }
-        else W.sCode[k] = code;
-        read_code_max = read_code_max > (int)code ? read_code_max : (int)code;
-    }
-    if (sCodes4 && !code_or && lane < 16) sCodes4[C2_DIAG_CODE_PAD + 1 + LjLoad + lane] = 0;   // (16: the packed kernel's OR pass touches whole dwords)
-    if (ref_bad) status |= C2_STATUS_OOB_CHAR;
-    if (Li <= 0 || Lj <= 0) status |= C2_STATUS_EMPTY;
-    if (Lj > A.max_lj || Li > max_li) status |= C2_STATUS_TOO_LONG;
-    if (__ballot(status != 0))                                  // (rare: one ballot decides for the usual task)
-        status = (__ballot(status & C2_STATUS_EMPTY) ? C2_STATUS_EMPTY : 0) |
-                 (__ballot(status & C2_STATUS_OOB_CHAR) ? C2_STATUS_OOB_CHAR : 0) |
-                 (__ballot(status & C2_STATUS_RC_CHAR) ? C2_STATUS_RC_CHAR : 0) |
-                 (__ballot(status & C2_STATUS_TOO_LONG) ? C2_STATUS_TOO_LONG : 0);
-    // packed = every read symbol has a code < 8 and every score fits a signed nibble: the score row of a reference
-    // base is then one register and a lookup is one v_bfe_i32 (no LDS in the inner loop).
-    packed = (A.score_pk != nullptr) && (__ballot(read_code_max >= 8) == 0ull);
-    if (__ballot(read_code_max >= A.first_ext_code && read_code_max != (int)C2_INVALID_CODE)) {
-        // a read character beyond the matrix dimension: the reference reads the flat element ci * dim + cj (pyx:212, bounds
-        // checking off), which exists iff the LARGEST reference character keeps it inside the buffer (rare path: one more pass)
-        const int lim = A.mat_dim * A.mat_dim - A.refs[pf.ref_id].max_char * A.mat_dim;
-        bool oob = false;
-        for (int k = lane; k < LjLoad; k += 64) if ((int)W.sRead[k] >= lim) oob = true;
-        if (__ballot(oob)) status |= C2_STATUS_OOB_CHAR;
-    }
-    return status;
-}
-
-__device__ __forceinline__ void c2_clear_record(c2_aln_record& rec, const int rc, const int ref_id) {
-    rec.aln_len = 0; rec.matches = 0; rec.insertion_n = 0; rec.deletion_n = 0; rec.substitution_n = 0;
-    rec.all_insertion_events = 0; rec.win_insertion_events = 0; rec.all_deletion_events = 0;
-    rec.win_deletion_events = 0; rec.all_deletion_bases = 0; rec.all_substitutions = 0;
-    rec.irregular_ends = 0; rec.status = 0; rec.strand = (uint8_t)rc; rec.reserved0 = 0; rec.ref_id = (uint16_t)ref_id;
-    rec.reserved2 = 0;
-}
-
-// Pointer plane of the row-strip kernel: nibble of cell (pi, pj), pi, pj >= 1.
-template <int R, int MODE>
-struct c2_row_plane {
-    const uint16_t* sPtr; int pass_halfwords, colStride, band_lanes;
-    __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
-        const int pp = (pi - 1) / (64 * R), rem = (pi - 1) % (64 * R);
-        bool inb;
-        const int pidx = c2_ptr_index<R, MODE>(rem / R, pj, colStride, band_lanes, inb);
-        if (!inb) return false;
-        const unsigned hw = sPtr[(size_t)pp * (size_t)pass_halfwords + pidx];
-        nib = (hw >> (4 * (R - 1 - rem % R))) & 0xF;
-        return true;
-    }
-};
-
-// Traceback (pyx:338-421), wave-parallel: the wave-uniform state (i, j, s) advances one RUN at a time -- lane k probes the
-// k-th cell ahead along the current direction (diagonal for M, row for I, column for J), a ballot gives the length of the
-// run that stays in s, its columns are emitted by the lanes in one shot.  Emits the aligned strings reversed into
-// W.sTmpRead / W.sTmpRef.  need_full: a pointer word that decides the path is not stored in this plane.
-template <class PLANE>
-__device__ __forceinline__ void c2_traceback(const PLANE& P, const c2_wg& W, const int Li, const int Lj, const int min_score,
-                                             const int ge, const int g0, const int lane,
-                                             int& cnt, int& matches, int& status, bool& need_full)
-{
-    int i = Li, j = Lj;
-    int s = C2_ST_M;
-    cnt = 0; matches = 0; need_full = false;
-    {
-        unsigned nib = 0;
-        if (P.fetch(i, j, nib)) s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // start state, pyx:349-358
-        else need_full = true;
-    }
-    while (!need_full && (i > 0 || j > 0)) {
-        if (i == 0 || j == 0) {
-            const int need = (i == 0) ? C2_ST_I : C2_ST_J;           // initialised chains: iPointer[0,1:], jPointer[1:,0]
-            if (s != need) { status |= (s == C2_ST_M) ? C2_STATUS_SENTINEL_PATH : C2_STATUS_UNINIT_PTR; break; }
-            const int len = (i == 0) ? j : i;
-            for (int k = lane; k < len; k += 64) {
-                W.sTmpRead[cnt + k] = (i == 0) ? W.sRead[j - 1 - k] : (unsigned char)'-';
-                W.sTmpRef[cnt + k] = (i == 0) ? (unsigned char)'-' : W.sRef[i - 1 - k];
-            }
-            cnt += len; i = 0; j = 0;
-            break;
-        }
-        const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
-        const int ik = i - lane * di, jk = j - lane * dj;
-        const bool valid = (ik >= 1) && (jk >= 1);
-        int ns = 0;
-        bool oob = false;
-        if (valid) {
-            // cell whose pointer nibble decides the next state
-            const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
-            if (pi == 0 || pj == 0) {
-                ns = c2_boundary_hstate(pi, pj, min_score, ge, g0);   // only reachable for s == M
-            } else {
-                unsigned nib = 0;
-                if (P.fetch(pi, pj, nib)) {
-                    if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
-                    else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
-                    else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
-                } else oob = true;                                    // not stored: ns stays 0 (never == s)
-            }
-        }
-        const unsigned long long vmask = __ballot(valid);
-        const unsigned long long cmask = __ballot(valid && ns == s);
-        const unsigned long long omask = __ballot(oob);
-        const int nv = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
-        const int nc = (~cmask == 0ull) ? 64 : __builtin_ctzll(~cmask);
-        int E, s_next;
-        if (nc < nv) {
-            // lane nc decides the next state; if its pointer word is not stored, another kernel must redo this task
-            if ((omask >> nc) & 1ull) { need_full = true; break; }
-            E = nc + 1; s_next = __builtin_amdgcn_readlane(ns, nc);
-        } else { E = nv; s_next = s; }
-        unsigned char rch = '-', fch = '-';
-        if (lane < E) {
-            if (s != C2_ST_J) rch = W.sRead[jk - 1];
-            if (s != C2_ST_I) fch = W.sRef[ik - 1];
-            W.sTmpRead[cnt + lane] = rch;
-            W.sTmpRef[cnt + lane] = fch;
-        }
-        if (s == C2_ST_M) matches += __popcll(__ballot(lane < E && rch == fch));   // pyx:375-376
-        cnt += E; i -= E * di; j -= E * dj; s = s_next;
-    }
-}
-
-// Aligned strings out (reversed copy, pyx:434) + fused classification (COREResources.pyx:68-187 and the derived counters
-// of CRISPRessoCORE.py:726-760) from the strings still in LDS.  Column c (forward order) = tmp[T-1-c].  The aligner never
-// emits a double-gap column and never puts an insertion column next to a deletion column (I and J only hand over to M),
-// so every gap run is pure and idx advances by one on every non-insertion column.
-__device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int T,
-                                                     const int matches, const int lane, c2_aln_record& rec, const int Li, const int Lj)
-{
-    const unsigned char* sTmpRead = W.sTmpRead; const unsigned char* sTmpRef = W.sTmpRef; const uint16_t* sIncP = W.sIncP;
-    uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
-    uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
-    if (!(A.reserved & 1)) {                                   // (debug knob: C2_DEBUG_SKIP_STRINGS measures the cost of these stores)
-        for (int cidx = lane; cidx < T; cidx += 64) {
-            outR[cidx] = sTmpRead[T - 1 - cidx];
-            outF[cidx] = sTmpRef[T - 1 - cidx];
-        }
-    }
-    int idx_base = 0, last_rf = -1, last_rd = -1;
-    int n_all_sub = 0, n_win_sub = 0, n_all_ins = 0, n_win_ins = 0, n_all_del = 0, n_win_del = 0;
-    int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;   // per-lane partial sums
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (T == Li && T == Lj) {
-        // no gap column in either string (T = Li + insertion columns = Lj + deletion columns): the reference index of a
-        // column is the column, and only substitutions can occur -- most reads of an amplicon run take this path
-        for (int base = 0; base < T; base += 64) {
-            const int cidx = base + lane;
-            const bool in = cidx < T;
-            const unsigned char rd = in ? sTmpRead[T - 1 - cidx] : 0, rfc = in ? sTmpRef[T - 1 - cidx] : 0;
-            const bool sub = in && rd != rfc && rd != 'N';                                  // pyx:113-118
-            const bool sub_win = sub && (sIncP[cidx + 1] != sIncP[cidx]);
-            n_all_sub += __popcll(__ballot(sub));
-            n_win_sub += __popcll(__ballot(sub_win));
-        }
-        last_rd = T - 1;
-    } else
-    for (int base = 0; base < T; base += 64) {
-        const int cidx = base + lane;
-        const bool in = cidx < T;
-        const unsigned char rd = in ? sTmpRead[T - 1 - cidx] : 0, rfc = in ? sTmpRef[T - 1 - cidx] : 0;
-        const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
-        const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
-        {   // 64 columns without a gap, and no gap run open in front of them (most chunks of a traced alignment: its indels sit in one
-            // or two places): only substitutions can occur here, and the reference index of a column is idx_base + lane
-            const unsigned long long m_in = __ballot(in);
-            if (m_rf == m_in && m_rd == m_in && last_rf == base - 1 && last_rd == base - 1) {
-                const int idx0 = idx_base + lane;
-                const bool sub0 = in && rd != rfc && rd != 'N';
-                n_all_sub += __popcll(__ballot(sub0));
-                n_win_sub += __popcll(__ballot(sub0 && (sIncP[idx0 + 1] != sIncP[idx0])));
-                const int cols = __popcll(m_in);
-                idx_base += cols; last_rf = base + cols - 1; last_rd = last_rf;
-                continue;
-            }
-        }
-        const int idx = idx_base + __popcll(m_rf & lt);             // ref bases left of this column
-        const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
-        const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
-        const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
-        // substitution, pyx:113-118
-        const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
-        const bool sub_win = sub && (sIncP[idx + 1] != sIncP[idx]);
-        n_all_sub += __popcll(__ballot(sub));
-        n_win_sub += __popcll(__ballot(sub_win));
-        // insertion closes at this column, pyx:119-128; leading insertions (idx==0) are never opened, pyx:136
-        const bool ins_close = rf_ng && (prev_rf != cidx - 1) && idx > 0;
-        // in the window: both flanks (pyx:121) -- the legacy classifier: either flank (pyx:284)
-        const bool fl = ins_close && (sIncP[idx] != sIncP[idx - 1]), fr = ins_close && (sIncP[idx + 1] != sIncP[idx]);
-        const bool ins_win = A.legacy ? (fl || fr) : (fl && fr);
-        n_all_ins += __popcll(__ballot(ins_close));
-        n_win_ins += __popcll(__ballot(ins_win));
-        if (ins_win) acc_ins_n += cidx - 1 - prev_rf;
-        // deletion closes at this column, pyx:145-153
-        const bool del_close = rd_ng && (prev_rd != cidx - 1);
-        const int dlen = cidx - 1 - prev_rd;
-        // legacy (pyx:253-258): a run that starts in column 0 or 1 is given reference start 0 (`if st-1 > 0`)
-        const int dstart = (A.legacy && prev_rd <= 0) ? 0 : idx - dlen;
-        const bool del_win = del_close && (sIncP[idx] != sIncP[dstart]);       // include set hits range(start,end)
-        n_all_del += __popcll(__ballot(del_close));
-        n_win_del += __popcll(__ballot(del_win));
-        if (del_close) acc_del_bases += idx - dstart;
-        if (del_win) acc_del_n += dlen;
-        idx_base += __popcll(m_rf);
-        if (m_rf) last_rf = base + 63 - __clzll((long long)m_rf);
-        if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
-    }
-    // trailing deletion, pyx:155-162
-    int tr_bases = 0, tr_win = 0;
-    if (last_rd != T - 1) {
-        const int dlen = T - 1 - last_rd;
-        n_all_del += 1;
-        if (!A.legacy) {
-            tr_bases = dlen;
-            if (sIncP[idx_base] != sIncP[idx_base - dlen]) { tr_win = dlen; n_win_del += 1; }
-        } else {
-            // legacy (pyx:259-261): a run that reaches the end of the alignment ends at reference index idx - 1 (exclusive), and
-            // starts at 0 if it begins in column 0 or 1
-            const int dstart = last_rd <= 0 ? 0 : idx_base - dlen, dend = idx_base - 1;
-            tr_bases = dend > dstart ? dend - dstart : 0;
-            if (dend > dstart && sIncP[dend] != sIncP[dstart]) { tr_win = dlen; n_win_del += 1; }
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        acc_ins_n += __shfl_xor(acc_ins_n, m);
-        acc_del_n += __shfl_xor(acc_del_n, m);
-        acc_del_bases += __shfl_xor(acc_del_bases, m);
-    }
-    const unsigned char r0 = sTmpRead[T - 1], f0 = sTmpRef[T - 1], rL = sTmpRead[0], fL = sTmpRef[0];
-    rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
-    rec.aln_len = (uint16_t)T;
-    rec.matches = (uint16_t)matches;
-    rec.insertion_n = (uint16_t)acc_ins_n;
-    rec.deletion_n = (uint16_t)(acc_del_n + tr_win);
-    rec.substitution_n = (uint16_t)n_win_sub;
-    rec.all_insertion_events = (uint16_t)n_all_ins;
-    rec.win_insertion_events = (uint16_t)n_win_ins;
-    rec.all_deletion_events = (uint16_t)n_all_del;
-    rec.win_deletion_events = (uint16_t)n_win_del;
-    rec.all_deletion_bases = (uint16_t)(acc_del_bases + tr_bases);
-    rec.all_substitutions = (uint16_t)n_all_sub;
-}
-
-// Shortcut for the commonest alignment of an amplicon run: equal lengths and no gap at all.  The reference's traceback stays
-// in state M from (L, L) to (0, 0) iff the H-state of every cell (i, i) is M, i.e. the two low pointer bits of all L main-
-// diagonal cells are clear (start-state rule pyx:349-358 for (L, L); Mptr(i+1, i+1) = H-state of (i, i) for the rest; the
-// boundary cell (0, 0) is M).  64 lanes read those nibbles in ceil(L/64) probes and one ballot decides; the aligned
-// strings are then the read and the reference themselves, and only substitutions can occur.  Returns false (nothing
-// written) if the path leaves the diagonal or a nibble is not stored in this plane.
-__device__ __forceinline__ void c2_emit_gapless(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int L, const int lane,
-                                                c2_aln_record& rec);
-template <class PLANE>
-__device__ __forceinline__ bool c2_try_gapless(const PLANE& P, const c2_align_args& A, const c2_wg& W, const uint64_t task, const int L,
-                                               const int lane, c2_aln_record& rec)
-{
-    bool off = false;
-    for (int base = 0; base < L; base += 64) {
-        const int i = base + lane + 1;
-        if (i <= L) { unsigned nib = 0; if (!P.fetch(i, i, nib) || (nib & 3u)) off = true; }
-    }
-    if (__ballot(off)) return false;
-    c2_emit_gapless(A, W, task, L, lane, rec);
-    return true;
-}
-
-// c2_emit_gapless for the multi-alignment kernels, four columns per lane: the read and the reference leave LDS as dwords and
-// go out as dwords (rows are 16-byte aligned: the caller checks the base pointers); mismatching bytes are found with the
-// "has a zero byte" bit trick on read ^ reference, the few lanes that hold one are visited with scalar code.
-// sWin: c2_stage_ref's window masks.  L <= 256 (the caller checks).
-__device__ __forceinline__ void c2_emit_gapless4(const c2_align_args& A, const c2_wg& W, const uint32_t* sWin, const uint64_t task, const int L,
-                                                 const int lane, c2_aln_record& rec)
-{
-    const int p = 4 * lane;
-    const int nb = L - p;                                             // valid bytes of this lane's dword
-    const uint32_t valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
-    const uint32_t rd = ((const uint32_t*)W.sRead)[lane] & valid, rf = ((const uint32_t*)W.sRef)[lane] & valid;
-    if (!(A.reserved & 1) && nb > 0) {
-        ((uint32_t*)(A.aln_read + task * (uint64_t)A.aln_stride))[lane] = rd;      // (a partial last dword is padded with zeros: the row has room, aln_stride is a multiple of 16)
-        ((uint32_t*)(A.aln_ref + task * (uint64_t)A.aln_stride))[lane] = rf;
-    }
-    const uint32_t x = rd ^ rf;
-    const uint32_t mm = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;      // bit 7 of every byte in which read and reference differ
-    int mism = 0, n_all_sub = 0, n_win_sub = 0;
-    unsigned long long todo = __ballot(mm != 0);
-    if (todo) {
-        const uint32_t y = rd ^ 0x4e4e4e4eu;                                         // COREResources.pyx:113-118: a read 'N' is no substitution
-        const uint32_t sub = mm & ((((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u);
-        const uint32_t win = sWin ? (sub & sWin[lane]) : 0u;
-        while (todo) {                                                               // (a read of an amplicon run differs in a lane or two)
-            const int l = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            mism += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)mm, l));
-            const unsigned subl = (unsigned)__builtin_amdgcn_readlane((int)sub, l);
-            n_all_sub += __builtin_popcount(subl);
-            if (sWin) n_win_sub += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)win, l));
-            else if (subl) {                                                         // no mask table (packed kernel): the window prefix counts of the lane's four positions
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if ((subl >> (8 * b + 7)) & 1u) n_win_sub += (W.sIncP[4 * l + b + 1] != W.sIncP[4 * l + b]) ? 1 : 0;
-            }
-        }
-    }
-    const unsigned char r0 = W.sRead[0], f0 = W.sRef[0], rL = W.sRead[L - 1], fL = W.sRef[L - 1];
-    rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
-    rec.aln_len = (uint16_t)L;
-    rec.matches = (uint16_t)(L - mism);                                              // pyx:375-376
-    rec.substitution_n = (uint16_t)n_win_sub;
-    rec.all_substitutions = (uint16_t)n_all_sub;
-}
-
-// A gap-free alignment of two sequences of equal length: the aligned strings are the read and the reference themselves, and
-// only substitutions can occur.  Strings out, counts into `rec`.
-__device__ __forceinline__ void c2_emit_gapless(const c2_align_args& A, const c2_wg& W, const uint64_t task, const int L, const int lane,
-                                                c2_aln_record& rec)
-{
-    uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
-    uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
-    const bool strings = !(A.reserved & 1);
-    int matches = 0, n_all_sub = 0, n_win_sub = 0;
-    for (int base = 0; base < L; base += 64) {
-        const int c = base + lane;
-        const bool in = c < L;
-        const unsigned char rd = in ? W.sRead[c] : 0, rf = in ? W.sRef[c] : 0;
-        if (in && strings) { outR[c] = rd; outF[c] = rf; }
-        matches += __popcll(__ballot(in && rd == rf));                                   // pyx:375-376
-        const bool sub = in && rd != rf && rd != 'N';                                    // COREResources.pyx:113-118 (no '-' here)
-        n_all_sub += __popcll(__ballot(sub));
-        n_win_sub += __popcll(__ballot(sub && (W.sIncP[c + 1] != W.sIncP[c])));
-    }
-    const unsigned char r0 = W.sRead[0], f0 = W.sRef[0], rL = W.sRead[L - 1], fL = W.sRef[L - 1];
-    rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
-    rec.aln_len = (uint16_t)L;
-    rec.matches = (uint16_t)matches;
-    rec.substitution_n = (uint16_t)n_win_sub;
-    rec.all_substitutions = (uint16_t)n_all_sub;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Row-strip kernel.  BAND = false: full pointer plane (any path).  BAND = true: only the lanes within A.band_lanes of the
-// main diagonal keep their pointer words (single-pass references only); a traceback that needs a word outside the band
-// appends the task to A.fb_list, and the host re-runs exactly those tasks with the full-plane kernel (A.task_list mode).
-// The band limits what is STORED, never what is computed, so results do not depend on it.
-// ---------------------------------------------------------------------------------------------------------------
-template <int R, int MODE>
-__global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args A)
-{
-    constexpr bool BAND = MODE == 1;
-    constexpr int MULTI = MODE == 2 ? 2 : 0;                     // plane mode of the multi-pass sweeps (never banded)
-    const int lane = threadIdx.x;
-    const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, BAND ? A.band_lanes : 0, MODE == 2);
-    const int pass_halfwords = MODE == 2 ? (A.max_lj + 64) * 64 : A.max_lj * (int)P.col_stride;
-    uint16_t* sPtr = MODE == 2 ? (uint16_t*)(A.plane + (size_t)blockIdx.x * A.plane_words_per_wg) : (uint16_t*)(c2_smem + P.ptr);
-    int* sBnd = (int*)(c2_smem + P.bnd);
-    int16_t* sTbl = (int16_t*)(c2_smem + P.tbl);
-    c2_wg W;
-    W.sRead = c2_smem + P.read; W.sCode = c2_smem + P.code; W.sRef = c2_smem + P.ref;
-    W.sIncP = (uint16_t*)(c2_smem + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
-    unsigned char* sCodeOf = c2_smem + P.codeof;
-    const int colStride = (int)P.col_stride;
-    const int ROWS_PER_PASS = 64 * R;
-    const int ge = A.gap_extend, go = A.gap_open;
-
-    // score table -> LDS, once per workgroup
-    for (int k = lane; k < A.n_codes * A.n_codes; k += 64) sTbl[k] = A.score_tbl[k];
-
-    for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
-    int cur_ref = -1;
-    int Li = 0, g0 = 0, ref_bad = 0;
-    uint64_t chunk_base = 0;
-    int chunk_left = 0;
-    c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
-    c2_prefetch pf;
-    c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);
-    while (pf.valid) {
-        __syncthreads();   // previous task's LDS readers are done
-        c2_phase_begin(A.phase_cycles, PH);
-        const uint64_t task = pf.task;
-        const int Lj = pf.Lj, ref_id = pf.ref_id, rc = pf.rc;
-        bool packed;
-        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_passes * ROWS_PER_PASS, cur_ref, Li, g0, ref_bad, packed);
-        c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);   // next task's loads fly during this task's DP
-        const c2_dev_ref rf = A.refs[ref_id];
-        const int passes = (Li + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-        if (BAND && passes != 1) status |= C2_STATUS_TOO_LONG;
-        __syncthreads();
-
-        c2_aln_record rec;
-        c2_clear_record(rec, rc, ref_id);
-        if (status == 0) {
-            // pyx:150  int min_score = gap_open * max_j * max_i   (wraps like the reference's C int)
-            const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
-            c2_phase_mark<0>(A.phase_cycles, PH);   // phase 0: task fetch (offsets, read, reference rows)
-            // =========================== DP: systolic sweep, pass by pass ===========================
-            for (int p = 0; p < passes; ++p) {
-                const bool single = (passes == 1);
-                uint16_t* planePtr = sPtr + (size_t)p * (size_t)pass_halfwords;
-                if (packed) {
-                    if (single) c2_dp_pass<R, true, true, MODE>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                    else        c2_dp_pass<R, true, false, MULTI>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                } else {
-                    if (single) c2_dp_pass<R, false, true, MODE>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                    else        c2_dp_pass<R, false, false, MULTI>(A, rf, W.sRef, W.sCode, sTbl, sBnd, planePtr, colStride, lane, p, passes, Li, Lj, g0, min_score);
-                }
-                __syncthreads();
-            }
-            if (MODE == 2) __threadfence_block();                 // the traceback reads other lanes' pointer words back from HBM
-            c2_phase_mark<1>(A.phase_cycles, PH);   // phase 1: DP fill
-            // =========================== traceback ===========================
-            c2_row_plane<R, MODE> plane;
-            plane.sPtr = sPtr; plane.pass_halfwords = pass_halfwords; plane.colStride = colStride; plane.band_lanes = A.band_lanes;
-            if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
-                int cnt, matches;
-                bool need_full;
-                c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, need_full);
-                __syncthreads();
-                c2_phase_mark<2>(A.phase_cycles, PH);   // phase 2: traceback
-                if (need_full) {                                   // only possible with BAND
-                    status |= C2_STATUS_NEED_FULL;
-                    if (lane == 0) { const unsigned k = atomicAdd(A.fb_count, 1u); A.fb_list[k] = (uint32_t)task; }
-                }
-                if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
-            }
-        }
-        rec.status = (uint8_t)status;
-        if (lane == 0) A.records[task] = rec;
-        c2_phase_mark<3>(A.phase_cycles, PH);       // phase 3: strings out, classification, record
-    }
-    c2_phase_flush(A.phase_cycles, PH, lane);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Diagonal-band kernel.  Lanes own DIAGONALS instead of rows: lane l owns d = d0 + 2l ("E") and d0 + 2l + 1 ("O"), 128
-// diagonals around the one that joins (0,0) and (Li,Lj); the sweep runs over anti-diagonals a = i + j, one cell per lane
-// per step (E cells at even a, O cells at odd a), 499 steps x 1 cell instead of 313 steps x 4 cells for 250 x 250.
-// Cells outside the band are never computed (they read as -2^30: the number 0 under C2_DIAG_BIAS), which is exact iff no optimal path leaves the
-// band.  That is PROVEN per alignment after the fill: c2_outside_band_bound gives the most any path that touches a diagonal
-// beyond either band edge can score (its steps down, steps right and diagonal steps priced by the reference's own cost
-// rules).  If the banded score H(Li,Lj) exceeds it, every optimal path -- and every path that ties with one at any cell the
-// reference's traceback visits -- lies inside the band, where banded and full DP values coincide, so the pointers the
-// traceback reads are the full DP's.  Otherwise (and for reads the packed score rows cannot encode) the task goes to the
-// fallback list and the next launch of the chain redoes it.  Neighbour traffic: two DPP reads per step (wave_shr at even
-// steps, wave_shl at odd steps), folded into the adds that consume them; row constants {a_i, b_i, c_i, score row} come from a zero-padded per-reference table in
-// global memory (L2-resident), the column symbols from a zero-padded LDS table, both fetched one group of eight
-// anti-diagonals ahead (c2_diagx_fetch).
-// ---------------------------------------------------------------------------------------------------------------
-#define C2_DPP_WAVE_SHL1 0x130
-// lane n receives `src` of lane n+1; lane 63 keeps `old`
-__device__ __forceinline__ int c2_shl1(int old, int src) {
-    return __builtin_amdgcn_update_dpp(old, src, C2_DPP_WAVE_SHL1, 0xf, 0xf, false);
-}
-// The diagonal kernels keep every DP value with C2_DIAG_BIAS added, so that "outside the band" is the number 0 -- which is
-// what a DPP read with bound_ctrl set returns for a lane without a source (wavefront end, or a source lane switched off in
-// EXEC).  A bound_ctrl move with old = 0 folds into the VALU instruction that consumes it (v_add_u32_dpp): the hand-off
-// between neighbouring diagonals then costs no instruction of its own.  All recurrences add constants to DP values and
-// compare sums of that form, so the bias changes no comparison (values stay within [-2^20, 2^30 + 2^20]).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define C2_KEEP_IN_VGPR(x) asm volatile("" : "+v"(x))
-#else
-#define C2_KEEP_IN_VGPR(x) (void)(x)
-#endif
-__device__ __forceinline__ int c2_shr1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_WAVE_SHR1, 0xf, 0xf, true); }
-__device__ __forceinline__ int c2_shl1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_WAVE_SHL1, 0xf, 0xf, true); }
-// The same hand-off inside a ROW of 16 lanes (row_shr:1 / row_shl:1): the first / last lane of a row has no source and reads 0.
-// A lane group of 16 lanes (eight alignments per wavefront, packed) is exactly a row, so its two ends see "outside the band"
-// without a lane being switched off: all 16 lanes hold diagonals (32 per band instead of 30).
-#define C2_DPP_ROW_SHR1 0x111
-#define C2_DPP_ROW_SHL1 0x101
-__device__ __forceinline__ int c2_rshr1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_ROW_SHR1, 0xf, 0xf, true); }
-__device__ __forceinline__ int c2_rshl1z(int src) { return __builtin_amdgcn_update_dpp(0, src, C2_DPP_ROW_SHL1, 0xf, 0xf, true); }
-
-struct c2_diag_plan { uint32_t plane, codes, codeof, read, code, ref, incp, tmp_read, tmp_ref, total; uint32_t n_words; };
-
-__host__ __device__ inline c2_diag_plan c2_make_diag_plan(int max_li, int max_lj) {
-    c2_diag_plan p;
-    p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // one 32-bit word per lane per 8 anti-diagonals
-    uint32_t off = 0;
-    p.plane = off;    off += p.n_words * (uint32_t)C2_DIAG_STORE_N * 4u;
-    p.codes = off;    off += c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 8u);   // zeros | columns 0 .. Lj+1 | zeros
-    p.codeof = off;   off += 256u;
-    p.read = off;     off += c2_align16((uint32_t)max_lj);
-    p.code = off;     off += c2_align16((uint32_t)max_lj);
-    p.ref = off;      off += c2_align16((uint32_t)max_li);
-    p.incp = off;     off += c2_align16(((uint32_t)max_li + 2u) * 2u);
-    p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
-    p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
-    p.total = off;
-    return p;
-}
-
-// Upper bound of the score of any path from (0,0) to (Li,Lj) that touches a diagonal outside the band [dlo1 + 1, dhi1 - 1]
-// (D = Li - Lj lies inside it).  Such a path takes nv >= dhi1 steps down (or nh >= -dlo1 steps right), nh = nv - D, and
-// exactly Li - nv diagonal steps of at most maxS each.  With gm = max(0, max g) and cb = max(go, ge) + gm:
-//  * a step DOWN never collects the incentive when it extends (jExt = ge + J, pyx:201); opening costs go + g[i-1] -- or
-//    ge + g[i-1] where the reference waives the open: the run down column 0 from (0,0) (pyx:170), a step that lands on the
-//    last row, the run in the last column (pyx:234-317), at most three such places on a path.  If go + gm <= ge, the nv
-//    steps down therefore cost at most ge * nv + 3 gm; otherwise cb each.
-//  * a step RIGHT in row i costs ge + g[i] (extension) or go + g[i] (open; ge + g[i] on the last row or when it lands on the
-//    last column -- one step, once per path); the run along row 0 costs ge per step + g[0] once (pyx:160).  In a row without
-//    incentive every step costs at most ge (go <= ge); a run inside an interior incentive row pays its open, n (ge + gm) +
-//    (go - ge) for n steps.  So nh steps right cost at most max(ge * nh, cb * nh + (go - ge)) + 2 gm -- unless the LAST row
-//    carries an incentive (`last_pos`) or go > ge: then cb each.
-// Every term falls as nv grows, so the bound is taken at the smallest nv.  -> C2_DIAG_NEG if no such path exists.
-__device__ __forceinline__ int c2_outside_band_bound(const int maxS, const int Li, const int Lj, const int D, const int dhi1, const int dlo1,
-                                                     const int cb, const int go, const int ge, const int last_pos)
-{
-    if (maxS < 0) return 0x7fffffff;                            // (the bound grows with nv then: no certificate)
-    const int gm = cb - (go > ge ? go : ge);                    // max(0, max gap incentive)
-    const bool waived = go + gm <= ge;
-    const int down = waived ? ge : cb, extra = waived ? 3 * gm : 0;
-    const bool runs = go <= ge && !last_pos;
-    auto right = [&](const int nh) { return runs ? c2_imax(ge * nh, cb * nh + (go - ge)) + 2 * gm : cb * nh; };
-    int U = C2_DIAG_NEG;
-    if (dhi1 <= Li) U = c2_imax(U, maxS * (Li - dhi1) + down * dhi1 + extra + right(dhi1 - D));
-    if (-dlo1 <= Lj) U = c2_imax(U, maxS * (Lj + dlo1) + down * (D - dlo1) + extra + right(-dlo1));
-    return U;
-}
-
-struct c2_diag_plane {
-    const unsigned* words; int d0;
-    __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
-        const int sl = ((pi - pj - d0) >> 1) - C2_DIAG_STORE_LO;         // stored lane slot of the cell's diagonal
-        if ((unsigned)sl >= (unsigned)C2_DIAG_STORE_N) return false;
-        const int a = pi + pj;
-        nib = (words[(a >> 3) * C2_DIAG_STORE_N + sl] >> (4 * (7 - (a & 7)))) & 0xF;
-        return true;
-    }
-};
-
-struct c2_diag_state {
-    int ME, IE, JE, HE;              // latest cell of the even diagonal
-    int MO, IO, JO, HO;              // latest cell of the odd diagonal
-    unsigned bits;
-};                                   // (all values carry C2_DIAG_BIAS; a neighbour outside the band reads as 0)
-
-// One pair of steps: the E cell on anti-diagonal a = 2k, then the O cell on a + 1.  rowE: constants of the E cell's row,
-// rowO: of the O cell's row (= E row + 1); cj4: 4 * code of their common column.
-// MASK: lanes whose diagonal has not reached its first interior cell yet keep their boundary-cell values.
-// LASTCOL: the column may be the last one, where gap_open is replaced by gap_extend (pyx:234-273): a_i -> b_i, c_i += b_i - a_i.
-template <bool MASK, bool LASTCOL>
-__device__ __forceinline__ void c2_diag_pair(c2_diag_state& S, const int a, const c2_diag_row rowE, const c2_diag_row rowO,
-                                             const int cj4, const int ge, const int startE, const int startO, const bool lastcol)
-{
-    // ---- even step: E cell.  left (i, j-1) is this lane's O cell, up (i-1, j) is the O cell of the lane below (wave_shr).
-    //      `ge` is a VGPR here: a DPP instruction cannot take an SGPR as its second source.
-    const int upM = c2_shr1z(S.MO);
-    const int upJ = c2_shr1z(S.JO);
-    if (!MASK || a >= startE) {
-        const int corr = (LASTCOL && lastcol) ? rowE.b - rowE.a : 0;
-        const int s = c2_sbfe4((int)rowE.prof, cj4);
-        const int iFromM = S.MO + rowE.a + corr;
-        const int iExt = S.IO + rowE.b;
-        const int jFromM = upM + rowE.c + corr;
-        const int jExt = upJ + ge;
-        const int In = c2_imax(iFromM, iExt);
-        const int Jn = c2_imax(jFromM, jExt);
-        const int Mn = S.HE + s;                             // H(i-1, j-1): this diagonal, two steps ago
-        const int Hn = c2_imax(c2_imax(Mn, Jn), In);
-        c2_push4(S.bits, iFromM, iExt, jFromM, jExt, In, Hn, Jn, Mn);
-        S.ME = Mn; S.IE = In; S.JE = Jn; S.HE = Hn;
-    } else {
-        S.bits <<= 4;
-    }
-    // ---- odd step: O cell.  left (i, j-1) is the E cell of the lane above (wave_shl), up (i-1, j) is this lane's E cell
-    const int lfM = c2_shl1z(S.ME);
-    const int lfI = c2_shl1z(S.IE);
-    if (!MASK || a + 1 >= startO) {
-        const int corr = (LASTCOL && lastcol) ? rowO.b - rowO.a : 0;
-        const int s = c2_sbfe4((int)rowO.prof, cj4);
-        const int iFromM = lfM + rowO.a + corr;
-        const int iExt = lfI + rowO.b;
-        const int jFromM = S.ME + rowO.c + corr;
-        const int jExt = S.JE + ge;
-        const int In = c2_imax(iFromM, iExt);
-        const int Jn = c2_imax(jFromM, jExt);
-        const int Mn = S.HO + s;
-        const int Hn = c2_imax(c2_imax(Mn, Jn), In);
-        c2_push4(S.bits, iFromM, iExt, jFromM, jExt, In, Hn, Jn, Mn);
-        S.MO = Mn; S.IO = In; S.JO = Jn; S.HO = Hn;
-    } else {
-        S.bits <<= 4;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Packed fill (c2_align_diagp_kernel): TWO alignments per lane, 16 bits each.  A lane group sweeps two reads of the same
-// length against the same reference; every DP value is an int16 with C2_PK_BIAS added (0 = "outside the band" = what a DPP read
-// with bound_ctrl returns, in both halves), every recurrence one v_pk_*_i16 instruction for both.  The host admits a
-// reference to this kernel only if its DP values provably stay inside int16 around the bias (c2_pk_eligible): the reference's
-// finite sentinel min_score = gap_open * Li * Lj is replaced by -C2_PK_BIAS (the number 0), which changes no comparison a
-// traceback can see: sentinel-derived values keep their order among themselves (same offsets) and stay below every real value.
-// Pointer bits: the signs of four packed differences per cell, gathered by two v_perm_b32 and pushed into four byte-wide shift
-// registers (c2_pk_push4) -- ~24.7 VALU instructions per cell for the two alignments together, against 2 x 17.2 in the 32-bit kernels.
-// ---------------------------------------------------------------------------------------------------------------
-#define C2_PK_BIAS 16384
-#define C2_PK_LUT_CODES 6                     // reference symbols with codes 0..4 (A C G T N), plus an all-zero table (index 5) for the padding rows
-#define C2_PK_PAD_TABLE 5
-#define C2_PK_LUT_LDS_OFFSET 1024u            // = character codes (256) + per-slot table (8 x 24 ints) in c2_make_diagx_plan
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef short c2_s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short c2_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned c2_pk_add(const unsigned a, const unsigned b) { return __builtin_bit_cast(unsigned, (c2_s16x2)(__builtin_bit_cast(c2_s16x2, a) + __builtin_bit_cast(c2_s16x2, b))); }
-__device__ __forceinline__ unsigned c2_pk_sub(const unsigned a, const unsigned b) { return __builtin_bit_cast(unsigned, (c2_s16x2)(__builtin_bit_cast(c2_s16x2, a) - __builtin_bit_cast(c2_s16x2, b))); }
-__device__ __forceinline__ unsigned c2_pk_max(const unsigned a, const unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(c2_s16x2, a), __builtin_bit_cast(c2_s16x2, b))); }
-__device__ __forceinline__ unsigned c2_pk_lshr(const unsigned a, const int n) { return __builtin_bit_cast(unsigned, (c2_u16x2)(__builtin_bit_cast(c2_u16x2, a) >> (c2_u16x2)(unsigned short)n)); }
-#else
-__device__ __forceinline__ unsigned c2_pk_add(const unsigned a, const unsigned b) { return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16); }
-__device__ __forceinline__ unsigned c2_pk_sub(const unsigned a, const unsigned b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
-__device__ __forceinline__ unsigned c2_pk_max(const unsigned a, const unsigned b) {
-    const int al = (int16_t)(a & 0xffffu), bl = (int16_t)(b & 0xffffu), ah = (int16_t)(a >> 16), bh = (int16_t)(b >> 16);
-    return ((unsigned)(al > bl ? al : bl) & 0xffffu) | ((unsigned)(ah > bh ? ah : bh) << 16);
-}
-__device__ __forceinline__ unsigned c2_pk_lshr(const unsigned a, const int n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
-#endif
-__host__ __device__ inline unsigned c2_pk_dup(const int x) { return ((unsigned)x & 0xffffu) | ((unsigned)x << 16); }   // the same int16 in both halves
-
-struct c2_pk_state {
-    unsigned ME, IE, JE, HE;         // latest cell of the even diagonal, two alignments packed
-    unsigned MO, IO, JO, HO;         // latest cell of the odd diagonal
-    unsigned acc;                    // pointer bits of the word in the making: four byte-wide shift registers (see c2_pk_push4), newest cell on top
-    unsigned gf;                     // AND of the finished words (gap-free predicate: "H is not I" and "M beats J" of the E cells all set)
-};
-
-// The four pointer bits of one cell, for both alignments, from the SIGNS of four packed differences (bits 15 and 31 of each).
-// Two v_perm_b32 gather the eight sign-carrying bytes, one shift + one bit-select interleave them, one shift + one bit-select
-// push them into `acc` -- 6 instructions per cell instead of 8 (a 16-bit shift + and-or per bit).  `acc` is four byte-wide
-// shift registers, two bits per cell, newest cell in bits 7..6, four cells per byte:
-//     byte 0: alignment A  { I opened (iFromM > iExt), NOT "H is I" (In < Hn) }      byte 1: A  { J opened, NOT "J beats M" (Jn < Mn) }
-//     byte 2: alignment B  { I opened, NOT "H is I" }                                 byte 3: B  { J opened, NOT "J beats M" }
-#define C2_PK_HI_BYTES 0x03070105u            // v_perm selector: [hi byte of x.lo16, hi byte of y.lo16, hi byte of x.hi16, hi byte of y.hi16] of (x, y)
-__device__ __forceinline__ void c2_pk_push4(unsigned& acc, const unsigned dI, const unsigned dJ, const unsigned dH, const unsigned dM) {
-    const unsigned p_open = __builtin_amdgcn_perm(dI, dJ, C2_PK_HI_BYTES);             // sign of dI / dJ in bit 7 of bytes 0,2 / 1,3
-    const unsigned p_state = __builtin_amdgcn_perm(dH, dM, C2_PK_HI_BYTES);            // sign of dH / dM likewise
-    const unsigned r = (p_open & 0x80808080u) | ((p_state >> 1) & 0x7f7f7f7fu);         // bits 7 and 6 of every byte are the cell's; the rest is noise
-    acc = (r & 0xC0C0C0C0u) | ((acc >> 2) & 0x3F3F3F3Fu);                                // (v_bfi_b32 through inline asm was measured: not faster than what hipcc makes of this)
-}
-// a cell that is not computed: "nothing opened, H is not I, M beats J" (neutral for the gap-free predicate)
-__device__ __forceinline__ void c2_pk_push_none(unsigned& acc) { acc = 0x40404040u | ((acc >> 2) & 0x3F3F3F3Fu); }
-
-// One pair of steps (E cell on anti-diagonal a = 2k, O cell on a + 1) for both alignments of the lane.  rowE / rowO: packed row
-// constants {a, b, c} (both halves equal: the two reads share the reference); sE / sO: the score pairs of the two cells.
-// ROW: the lane group is a DPP row of 16 lanes (row_shr / row_shl hand-off, no lane switched off).
-// ADD32: the sums are plain 32-bit adds (v_add_u32, full rate) instead of v_pk_add_i16 (half rate): every operand half is
-// non-negative and the sums stay below 2^15 (c2_pk_add32_ok), so no carry crosses the halves.  The differences and maxima stay packed.
-template <bool ADD32>
-__device__ __forceinline__ unsigned c2_pk_sum(const unsigned a, const unsigned b) { return ADD32 ? a + b : c2_pk_add(a, b); }
-
-template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
-__device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2_diag_row rowE, const c2_diag_row rowO, const unsigned sE, const unsigned sO,
-                                           const unsigned ge2, const int startE, const int startO, const bool lastcol)
-{
-    const unsigned upM = (unsigned)(ROW ? c2_rshr1z((int)S.MO) : c2_shr1z((int)S.MO));
-    const unsigned upJ = (unsigned)(ROW ? c2_rshr1z((int)S.JO) : c2_shr1z((int)S.JO));
-    if (!MASK || a >= startE) {
-        const unsigned corr = (LASTCOL && lastcol) ? c2_pk_sub((unsigned)rowE.b, (unsigned)rowE.a) : 0u;
-        const unsigned iFromM = c2_pk_sum<ADD32>(c2_pk_sum<ADD32>(S.MO, (unsigned)rowE.a), corr);
-        const unsigned iExt = c2_pk_sum<ADD32>(S.IO, (unsigned)rowE.b);
-        const unsigned jFromM = c2_pk_sum<ADD32>(c2_pk_sum<ADD32>(upM, (unsigned)rowE.c), corr);
-        const unsigned jExt = c2_pk_sum<ADD32>(upJ, ge2);
-        const unsigned In = c2_pk_max(iFromM, iExt);
-        const unsigned Jn = c2_pk_max(jFromM, jExt);
-        const unsigned Mn = c2_pk_sum<ADD32>(S.HE, sE);
-        const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
-        // I opened (iFromM > iExt), J opened (jFromM > jExt), NOT H is I (In < Hn; In <= Hn always), NOT J beats M (Jn < Mn)
-        c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
-        S.ME = Mn; S.IE = In; S.JE = Jn; S.HE = Hn;
-    } else {
-        c2_pk_push_none(S.acc);
-    }
-    const unsigned lfM = (unsigned)(ROW ? c2_rshl1z((int)S.ME) : c2_shl1z((int)S.ME));
-    const unsigned lfI = (unsigned)(ROW ? c2_rshl1z((int)S.IE) : c2_shl1z((int)S.IE));
-    if (!MASK || a + 1 >= startO) {
-        const unsigned corr = (LASTCOL && lastcol) ? c2_pk_sub((unsigned)rowO.b, (unsigned)rowO.a) : 0u;
-        const unsigned iFromM = c2_pk_sum<ADD32>(c2_pk_sum<ADD32>(lfM, (unsigned)rowO.a), corr);
-        const unsigned iExt = c2_pk_sum<ADD32>(lfI, (unsigned)rowO.b);
-        const unsigned jFromM = c2_pk_sum<ADD32>(c2_pk_sum<ADD32>(S.ME, (unsigned)rowO.c), corr);
-        const unsigned jExt = c2_pk_sum<ADD32>(S.JE, ge2);
-        const unsigned In = c2_pk_max(iFromM, iExt);
-        const unsigned Jn = c2_pk_max(jFromM, jExt);
-        const unsigned Mn = c2_pk_sum<ADD32>(S.HO, sO);
-        const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
-        c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
-        S.MO = Mn; S.IO = In; S.JO = Jn; S.HO = Hn;
-    } else {
-        c2_pk_push_none(S.acc);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Multi-alignment diagonal-band kernel: NA (2 or 4) alignments share one wavefront.  One anti-diagonal step costs the
-// same ~19 VALU issues whether 64, 31 or 15 of the lanes hold diagonals that matter, and an amplicon read rarely needs
-// more than a few diagonals either side of the corner-to-corner one -- so the wavefront is cut into NA lane groups of
-// LPA = 64 / NA lanes, each sweeping its own alignment with a band of 2 * (LPA - 1) diagonals, all with the same
-// instruction stream (per-lane table bases and clamps instead of wave-uniform ones).  The last lane of every group is
-// switched off in EXEC for the whole fill: a DPP read (bound_ctrl set) whose source lane is disabled returns 0, so the
-// first lane of the next group (wave_shr) and the last live lane of this group (wave_shl) see "outside the band", exactly
-// what the lanes at the two ends of the wavefront see.  Isolation costs no instruction.
-// A band this narrow fails the optimality certificate more often; those tasks go to the fallback list and the host
-// chains the launches NA = 4 -> NA = 2 -> c2_align_diag_kernel (128 diagonals) -> row-strip kernel (any path), each over
-// the previous list.  The pointer words go to a per-workgroup scratch plane in HBM/L2 instead of LDS (16 KB per group of
-// alignments would halve the resident waves; the words are written once, coalesced, and the traceback reads a handful
-// of them), read back with agent-scope loads that bypass the CU's L1.
-// ---------------------------------------------------------------------------------------------------------------
-struct c2_diagx_plan {
-    uint32_t codeof, table, tmp_read, tmp_ref, stage, slot0, slot_bytes, total, n_words;
-    uint32_t pairlut, pcodes0, pcodes_bytes, group0, group_bytes, gref, gincp;   // packed kernels only
-    uint32_t codes, read, code, ref, incp, win;                     // offsets inside one alignment's slot
-};
-
-__host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, int max_lj, bool pk = false) {
-    c2_diagx_plan p;
-    const uint32_t lpa = 64u / (uint32_t)(pk ? na / 2 : na);        // lanes of one lane group (pk: two alignments share a group, 16 bits each)
-    p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
-    uint32_t off = 0;
-    p.codeof = off;   off += 256u;                                  // character -> code
-    p.table = off;    off += 8u * 24u * 4u;                         // up to 8 slots x C2X_INTS
-    if (pk) off += c2_align16((uint32_t)C2_PK_LUT_CODES * C2_PK_LUT_STRIDE);                // pair-score tables at the FIXED offset C2_PK_LUT_LDS_OFFSET: it folds into the look-ups' immediate offset
-    p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
-    p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
-    p.stage = off;    off += p.n_words * lpa * 4u;                  // pointer words of the alignment being traced
-    p.pairlut = off;  p.pcodes0 = off; p.pcodes_bytes = 0; p.group0 = off; p.group_bytes = 0; p.gref = 0; p.gincp = 0;
-    if (pk) {
-        // LDS is what limits the resident waves of this kernel (8 alignments per wavefront), so its layout is lean: the lane
-        // groups' column tables share the bytes of the two traceback strings (the fill is over when a traceback starts; the
-        // staging rewrites the tables, zeros in front included, every time); reference + window prefix once per lane group (its
-        // two alignments share the reference); per alignment only the read
-        p.pcodes_bytes = c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 16u);   // per lane group: (code A << 5 | code B << 2) per column
-        p.pcodes0 = p.tmp_read;
-        const uint32_t need = (uint32_t)(na / 2) * p.pcodes_bytes, have = 2u * c2_align16((uint32_t)max_li + (uint32_t)max_lj);
-        if (need > have) { off += need - have; }                    // (tmp_read, tmp_ref, stage are consecutive: the tables may run into `stage`, which is rewritten before use too)
-        p.stage = p.tmp_ref + c2_align16((uint32_t)max_li + (uint32_t)max_lj) + (need > have ? need - have : 0u);
-        off = p.stage + p.n_words * lpa * 4u;
-        p.pairlut = C2_PK_LUT_LDS_OFFSET;                           // per reference symbol: the score pair of every (symbol of read A, symbol of read B)
-        p.group0 = off;
-        p.gref = 0; p.gincp = c2_align16((uint32_t)max_li);
-        p.group_bytes = p.gincp + c2_align16(((uint32_t)max_li + 2u) * 2u);
-        off += (uint32_t)(na / 2) * p.group_bytes;
-        p.slot0 = off;
-        p.codes = 0; p.read = 0; p.code = 0; p.ref = 0; p.incp = 0; p.win = 0;
-        p.slot_bytes = c2_align16((uint32_t)max_lj);
-        p.total = p.slot0 + (uint32_t)na * p.slot_bytes;
-        return p;
-    }
-    p.slot0 = off;
-    uint32_t so = 0;
-    p.codes = so;    so += c2_align16((uint32_t)C2_DIAG_CODE_PAD + (uint32_t)max_lj + 2u + 16u);  // zeros | columns 0 .. Lj+1 | zeros (the staging writes them as dwords: up to 15 behind column Lj)
-    p.read = so;     so += c2_align16((uint32_t)max_lj);
-    p.code = so;     so += c2_align16((uint32_t)max_lj);
-    p.ref = so;      so += c2_align16((uint32_t)max_li);
-    p.incp = so;     so += c2_align16(((uint32_t)max_li + 2u) * 2u);
-    p.win = so;      so += c2_align16((uint32_t)max_li + 4u);            // one byte per reference position, read as dwords: 0x80 = inside the quantification window
-    p.slot_bytes = so;
-    p.total = p.slot0 + (uint32_t)na * so;
-    return p;
-}
-
-// pointer words of ONE alignment, staged in LDS: [group of 8 anti-diagonals][lane of the alignment's lane group]
-struct c2_diagx_plane {
-    const unsigned* words; int d0, lpa, nl; bool pk;               // nl: lanes of a group that hold diagonals (lpa - 1, or lpa for a row-DPP group)
-    __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
-        const int sl = (pi - pj - d0) >> 1;                              // lane of the cell's diagonal inside its group
-        if ((unsigned)sl >= (unsigned)nl) return false;
-        const int a = pi + pj;
-        const unsigned w = words[(a >> 3) * lpa + sl];
-        if (!pk) { nib = (w >> (4 * (7 - (a & 7)))) & 0xF; return true; }
-        // packed kernels (c2_pk_push4): the word's low half holds anti-diagonals 8g .. 8g+3, its high half 8g+4 .. 8g+7; in a half,
-        // byte 0 = { I opened, NOT "H is I" } and byte 1 = { J opened, NOT "J beats M" }, cell c in bits 2c+1 .. 2c of both
-        const int c = a & 7;
-        const unsigned h = w >> (16 * (c >> 2));
-        const unsigned ih = (h >> (2 * (c & 3))) & 3u, jm = (h >> (8 + 2 * (c & 3))) & 3u;
-        nib = ((ih >> 1) << 3) | ((jm >> 1) << 2) | (((ih & 1u) ^ 1u) << 1) | ((jm & 1u) ^ 1u);
-        return true;
-    }
-};
-
-// per-lane view of the tables and of the matrix edges.  The row table (global memory) and the column-symbol table (LDS) are
-// padded with zeros, so a lane that is before / past the matrix needs no clamp at the low end and one v_min at the high end
-// per group; the records of a group are consecutive, so one address serves all of its loads (immediate offsets).
-struct c2_diagx_lane {
-    unsigned rowOff, rowMax;         // byte offset from A.diag_base of row (hE + 0) of pair 0's E cell; largest offset a group may start at
-    unsigned colOff, colMax;         // LDS byte address of column (0 - hE); largest address a group may start at
-    int kLast;                       // pair whose cells are on the last column
-    int kCap; bool capOdd;           // pair (and cell of it) that holds H(Li, Lj), if this lane owns that diagonal
-    int startE, startO;              // first interior anti-diagonal of the two diagonals
-};
-
-// rows and column symbols of group g (pairs 4g .. 4g+3): row records 0..4 (the O cell of the last pair needs row + 1) and four symbols.
-// FIRST = false: record 0 is the caller's business -- it is record 4 of group g - 1 (also when the v_min below clamps either
-// group's address: every record from the clamp on is zero padding), so a group costs four 16-byte loads, not five.
-template <bool FIRST>
-__device__ __forceinline__ void c2_diagx_fetch(const int g, const c2_diagx_lane& L, const c2_diag_row* rows, const unsigned char* lds,
-                                               c2_diag_row (&R)[5], int (&C)[4])
-{
-    const unsigned ro = min(L.rowOff + (unsigned)(g * 4 * (int)sizeof(c2_diag_row)), L.rowMax);
-    const c2_diag_row* rp = (const c2_diag_row*)((const unsigned char*)rows + ro);
-#pragma unroll
-    for (int q = FIRST ? 0 : 1; q < 5; ++q) R[q] = rp[q];
-    const unsigned co = min(L.colOff + (unsigned)(g * 4), L.colMax);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) C[q] = (int)lds[co + q];
-}
-
-// One group = four pairs = eight anti-diagonals = one pointer word per lane; the next group's tables are requested first.
-// c2_gapfree: the "is the alignment gap-free" predicate of c2_try_gapless, kept in registers while the pointer bits are made.
-// acc collects the two low pointer bits ("H is I", "J beats M") of every E cell a lane has finished -- for the lane that owns
-// diagonal 0 of a square alignment those are the main-diagonal cells (i, i) -- one v_and_or per group of eight anti-
-// diagonals; cap is acc at the moment the lane passes the cell (Li, Lj) (the cells a lane computes beyond that are zero-
-// padding garbage, like H).  cap == 0 in that lane <=> the traceback never leaves state M: no pointer word has to be read back.
-struct c2_gapfree { unsigned acc, cap; };
-#define C2_GAPFREE_E_LOW2 0x30303030u      // E cells sit in the odd nibbles of a word (anti-diagonals 8g, 8g+2, ...): their bits 1..0
-
-template <bool MASK, bool LASTCOL>
-__device__ __forceinline__ void c2_diagx_group(c2_diag_state& S, const int g, const c2_diagx_lane& L, const int ge, int& Hcap, c2_gapfree& GF,
-                                               const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
-                                               const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride,
-                                               const bool stores = true)
-{
-    RN[0] = R[4];
-    c2_diagx_fetch<false>(g + 1, L, rows, lds, RN, CN);
-    GF.acc |= S.bits & C2_GAPFREE_E_LOW2;                            // the previous group's word (0 before the first group)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = 4 * g + q;
-        c2_diag_pair<MASK, LASTCOL>(S, 2 * k, R[q], R[q + 1], C[q], ge, L.startE, L.startO, LASTCOL && (k == L.kLast));
-        if (LASTCOL && k == L.kCap) {
-            Hcap = (L.capOdd ? S.HO : S.HE) - C2_DIAG_BIAS;
-            // nibbles of this group so far: the low 8 (q + 1) bits of the word in the making (the O cell of this pair lies beyond the matrix)
-            GF.cap = GF.acc | (S.bits & (C2_GAPFREE_E_LOW2 & (q == 3 ? 0xffffffffu : ((1u << (8 * (q + 1))) - 1u))));
-        }
-    }
-    if (stores) myWords[g * wordStride] = S.bits;                    // anti-diagonals 8g .. 8g+7
-}
-
-// Groups g .. g_stop; the tables alternate between two register sets (no copies).  `cur` tells which set holds group g's.
-template <bool MASK, bool LASTCOL>
-__device__ __forceinline__ void c2_diagx_groups(c2_diag_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const int ge,
-                                                int& Hcap, c2_gapfree& GF, c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
-                                                const c2_diag_row* rows, const unsigned char* lds, unsigned* myWords, const int wordStride,
-                                                const bool stores = true)
-{
-    for (; g + 1 <= g_stop; g += 2) {
-        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, GF, RA, CA, RB, CB, rows, lds, myWords, wordStride, stores);
-        c2_diagx_group<MASK, LASTCOL>(S, g + 1, L, ge, Hcap, GF, RB, CB, RA, CA, rows, lds, myWords, wordStride, stores);
-    }
-    if (g <= g_stop) {                                               // odd count: one more group, then move its successor's tables to set A
-        c2_diagx_group<MASK, LASTCOL>(S, g, L, ge, Hcap, GF, RA, CA, RB, CB, rows, lds, myWords, wordStride, stores);
-        ++g;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) RA[q] = RB[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) CA[q] = CB[q];
-    }
-}
-
-__global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
-{
-    const int lane = threadIdx.x;
-    const c2_diag_plan P = c2_make_diag_plan(A.max_li, A.max_lj);
-    unsigned* sWords = (unsigned*)(c2_smem + P.plane);
-    unsigned char* sCodes = c2_smem + P.codes;
-    c2_wg W;
-    W.sRead = c2_smem + P.read; W.sCode = c2_smem + P.code; W.sRef = c2_smem + P.ref;
-    W.sIncP = (uint16_t*)(c2_smem + P.incp); W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
-    const int ge = A.gap_extend, go = A.gap_open;
-    unsigned char* sCodeOf = c2_smem + P.codeof;
-    for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
-
-    int cur_ref = -1;
-    int Li = 0, g0 = 0, ref_bad = 0;
-    uint64_t chunk_base = 0;
-    int chunk_left = 0;
-    c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
-    c2_prefetch pf;
-    c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);
-    while (pf.valid) {
-        __syncthreads();
-        c2_phase_begin(A.phase_cycles, PH);
-        const uint64_t task = pf.task;
-        const int Lj = pf.Lj, ref_id = pf.ref_id, rc = pf.rc;
-        bool packed;
-        int status = c2_commit_task(A, W, sCodeOf, pf, lane, A.max_li, cur_ref, Li, g0, ref_bad, packed);
-        c2_prefetch_issue(A, lane, chunk_base, chunk_left, pf);   // next task's loads fly during this task's DP
-        const c2_dev_ref rf = A.refs[ref_id];
-        __syncthreads();
-        c2_aln_record rec;
-        c2_clear_record(rec, rc, ref_id);
-        bool need_full = false;
-        const int D = Li - Lj;
-        const int d0 = ((D >> 1) - 64) & ~1;                  // even; band = d0 .. d0+127 around the corner-to-corner diagonal
-        int cb = 0;
-        if (status == 0) {
-            cb = (go > ge ? go : ge) + rf.gap_incentive_max;      // the most one gap base can add to a score
-            if (!packed || rf.diag_rows == nullptr || cb >= 0 || d0 > 0 || d0 + 127 < 0 || D < d0 || D > d0 + 127) need_full = true;
-        }
-        if (status == 0 && !need_full) {
-            // ---- tables: row constants (per reference) and 4*code per column (per read), both padded so that the lanes that
-            //      are still before / already past the matrix read zeros instead of running off the arrays
-            // (same zero-padded tables and alternating register sets as the multi-alignment kernel)
-            for (int j = lane; j < C2_DIAG_CODE_PAD + Lj + 2 + 8; j += 64) {
-                const int col = j - C2_DIAG_CODE_PAD;
-                sCodes[j] = (col >= 1 && col <= Lj) ? (unsigned char)(W.sCode[col - 1] << 2) : (unsigned char)0;
-            }
-            __syncthreads();
-            const int min_score = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
-            c2_phase_mark<0>(A.phase_cycles, PH);
-
-            // ---- per-lane diagonals and their boundary cells (pyx:153-176)
-            const int hE = (d0 >> 1) + lane;                  // dE = 2*hE, dO = 2*hE + 1
-            const int dE = 2 * hE, dO = dE + 1;
-            c2_diag_state S;
-            S.bits = 0;
-            // diagonal d >= 1 starts at cell (d, 0): M = I = min_score, J = ge*d + g0;  d <= -1 at (0, -d): M = J = min_score,
-            // I = ge*(-d) + g0;  d == 0 at (0, 0): M = 0, I = J = min_score.  H = max of the three.  (+ C2_DIAG_BIAS)
-            {
-                const int ms = min_score + C2_DIAG_BIAS;
-                const int bE = ((dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + g0) + C2_DIAG_BIAS;
-                S.ME = (dE == 0) ? C2_DIAG_BIAS : ms;
-                S.IE = (dE < 0) ? bE : ms;
-                S.JE = (dE > 0) ? bE : ms;
-                S.HE = c2_imax(c2_imax(S.ME, S.IE), S.JE);
-                const int bO = ge * (dO > 0 ? dO : -dO) + g0 + C2_DIAG_BIAS;   // dO is odd, never 0
-                S.MO = ms;
-                S.IO = (dO < 0) ? bO : ms;
-                S.JO = (dO > 0) ? bO : ms;
-                S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
-            }
-            const int startE = (dE > 0 ? dE : -dE) + 2, startO = (dO > 0 ? dO : -dO) + 2;   // first interior anti-diagonal
-            const int a_end = Li + Lj;
-            const int k_end = a_end >> 1;                      // pair that holds the cell (Li, Lj)
-            const int max_start = (d0 + 127 > -d0 ? d0 + 127 : -d0) + 2;
-            const int gA = ((max_start + 1) >> 1) >> 2;        // groups 0..gA contain lanes that have not started
-            const int gC = ((2 * Lj + d0) >> 1) >> 2;          // first group in which some lane is on the last column
-            const int g_end = k_end >> 2;
-            unsigned* myWords = sWords + (lane - C2_DIAG_STORE_LO);
-            const bool stores = (unsigned)(lane - C2_DIAG_STORE_LO) < (unsigned)C2_DIAG_STORE_N;
-            c2_diagx_lane L;
-            const int vrow = (int)(rf.diag_rows - A.diag_base), vcode = (int)P.codes + C2_DIAG_CODE_PAD;
-            L.rowOff = (unsigned)((vrow + hE) * (int)sizeof(c2_diag_row));
-            L.rowMax = (unsigned)((vrow + Li + 1 + C2_DIAG_ROW_PAD - 5) * (int)sizeof(c2_diag_row));
-            L.colOff = (unsigned)(vcode - hE);
-            L.colMax = (unsigned)(vcode + Lj + 2);
-            L.kLast = Lj + hE;
-            L.kCap = k_end; L.capOdd = (a_end & 1) != 0;
-            L.startE = startE; L.startO = startO;
-            const c2_diag_row* rows = A.diag_base;
-            c2_diag_row RA[5], RB[5];
-            int CA[4], CB[4];
-            c2_diagx_fetch<true>(0, L, rows, c2_smem, RA, CA);
-            int Hcap = C2_DIAG_NEG;
-            c2_gapfree GF; GF.acc = 0; GF.cap = 0xffffffffu;       // (this kernel reads its LDS plane instead: c2_try_gapless)
-            int g = 0;
-            const int gA_stop = gA < g_end ? gA : g_end;
-            int geV = ge;                                          // gap_extend in a VGPR (second source of a DPP add)
-            C2_KEEP_IN_VGPR(geV);
-            if (gC <= gA_stop) {
-                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
-            } else {
-                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
-                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
-            }
-            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, C2_DIAG_STORE_N, stores);
-            __syncthreads();
-            c2_phase_mark<1>(A.phase_cycles, PH);
-
-            // ---- optimality certificate
-            const int lane_end = (D - d0) >> 1;
-            const int Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
-            const int maxS = A.max_score;
-            const int dhi1 = d0 + 128, dlo1 = d0 - 1;         // first diagonals outside the band
-            const int U = c2_outside_band_bound(maxS, Li, Lj, D, dhi1, dlo1, cb, go, ge, rf.gap_incentive_last_pos);
-            if (!(Hend > U)) need_full = true;
-
-            if (!need_full) {
-                c2_diag_plane plane;
-                plane.words = sWords; plane.d0 = d0;
-                if (!(Li == Lj && c2_try_gapless(plane, A, W, task, Li, lane, rec))) {
-                    int cnt, matches;
-                    bool nf2;
-                    c2_traceback(plane, W, Li, Lj, min_score, ge, g0, lane, cnt, matches, status, nf2);
-                    __syncthreads();
-                    c2_phase_mark<2>(A.phase_cycles, PH);
-                    if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                    else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
-                }
-            }
-        }
-        if (need_full) {
-            status |= C2_STATUS_NEED_FULL;
-            if (lane == 0) { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
-        }
-        rec.status = (uint8_t)status;
-        if (lane == 0) A.records[task] = rec;
-        c2_phase_mark<3>(A.phase_cycles, PH);
-    }
-    c2_phase_flush(A.phase_cycles, PH, lane);
-}
-
-
-// per-alignment ("slot") table in LDS: wave-uniform values written by lane 0 and read back through readfirstlane, so the
-// staging / traceback / output code exists once (a loop over the slots) instead of once per slot
-enum { C2X_VALID = 0, C2X_TASK_LO, C2X_TASK_HI, C2X_LJ, C2X_REF, C2X_RC, C2X_STATUS, C2X_PACKED, C2X_CURREF, C2X_LI, C2X_G0,
-       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_UNPAIRED, C2X_INTS = 24 };
-__device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
-// the whole table of one slot with ONE LDS read (lane k gets entry k); C2_TF picks an entry: a v_readlane instead of an
-// LDS round trip per entry
-__device__ __forceinline__ int c2_tab_load(const int* T, const int lane) { return T[lane < C2X_INTS ? lane : 0]; }
-#define C2_TF(v, k) __builtin_amdgcn_readlane((v), (k))
-
-// ---- packed fill: one group = four pairs = eight anti-diagonals = one pointer word per lane AND PER ALIGNMENT.
-// Rows come from the packed row table (A.diagpk_base: {a, b, c} duplicated into both halves, and the LDS offset of the reference
-// symbol's pair-score table), columns from the lane group's pair-symbol table; the eight score pairs of the group are LDS
-// look-ups (row table offset + pair symbol), requested at the top of the group.
-struct c2_pk_cap { unsigned H, gf; };                              // the two alignments' H(Li, Lj) and gap-free words, captured at the cell (Li, Lj)
-
-template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
-__device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
-                                            const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
-                                            const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
-                                            unsigned* wordsA, unsigned* wordsB, const int wordStride)
-{
-    RN[0] = R[4];
-    c2_diagx_fetch<false>(g + 1, L, rows, lds, RN, CN);
-    unsigned sc[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        sc[2 * q] = *(const unsigned*)(lds + C2_PK_LUT_LDS_OFFSET + R[q].prof + (unsigned)C[q]);
-        sc[2 * q + 1] = *(const unsigned*)(lds + C2_PK_LUT_LDS_OFFSET + R[q + 1].prof + (unsigned)C[q]);
-    }
-    unsigned w0 = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = 4 * g + q;
-        c2_pk_pair<MASK, LASTCOL, ROW, ADD32>(S, 2 * k, R[q], R[q + 1], sc[2 * q], sc[2 * q + 1], ge2, L.startE, L.startO, LASTCOL && (k == L.kLast));
-        if (q == 1) { w0 = S.acc; S.gf &= w0; }                    // anti-diagonals 8g .. 8g+3 of both alignments
-        if (q == 3) S.gf &= S.acc;                                  // ... 8g+4 .. 8g+7
-        if (LASTCOL && k == L.kCap) {
-            CAP.H = L.capOdd ? S.HO : S.HE;
-            // q even: the word in the making holds two cells so far, the E cell in bits 5..4 of every byte ("H is not I" / "M beats J" = bit 4)
-            CAP.gf = (q & 1) ? S.gf : (S.gf & (S.acc | 0xEFEFEFEFu));
-        }
-    }
-    // alignment A's word: bytes 0, 1 of the two accumulators, alignment B's: bytes 2, 3 (layout: c2_diagx_plane::fetch)
-    wordsA[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x05040100u);
-    wordsB[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x07060302u);
-}
-
-template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
-__device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
-                                             c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
-                                             const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
-                                             unsigned* wordsA, unsigned* wordsB, const int wordStride)
-{
-    for (; g + 1 <= g_stop; g += 2) {
-        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
-        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g + 1, L, ge2, CAP, RB, CB, RA, CA, rows, lds, lutBase, wordsA, wordsB, wordStride);
-    }
-    if (g <= g_stop) {
-        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
-        ++g;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) RA[q] = RB[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) CA[q] = CB[q];
-    }
-}
-
-template <int NA, bool PK, bool ADD32 = false>
-__device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
-{
-    const int beta = (PK && ADD32) ? (int)A.pk_beta : 0;               // per-anti-diagonal bias of the 32-bit-add variant (else 0)
-    const int PKB = (PK && ADD32) ? (int)A.pk_bias : C2_PK_BIAS;        // the value bias: the smallest one that keeps c2_pk_eligible's margin there
-    // PK (c2_align_diagp_kernel): NA alignments in NA / 2 lane groups, two per group (slots 2g and 2g+1 in the two halves of the lanes' registers)
-    constexpr int NG = PK ? NA / 2 : NA;                             // lane groups
-    // lanes per group, live lanes, diagonals per band.  A packed group of 16 lanes is a DPP row: its hand-off is row_shr / row_shl,
-    // which already reads 0 at the row's ends, so no lane is switched off and all 16 hold diagonals (c2_rshr1z)
-    constexpr int LPA = 64 / NG;
-    constexpr bool ROWDPP = PK && LPA == 16;
-    constexpr int NL = (ROWDPP || NG == 1) ? LPA : LPA - 1, BANDW = 2 * NL;   // (one group = the whole wavefront: its ends read 0 anyway)
-    const int lane = threadIdx.x, grp = lane / LPA, sl = lane - grp * LPA;
-    const int slot = PK ? 2 * grp : grp;                             // (PK: the group's first slot)
-    const c2_diagx_plan P = c2_make_diagx_plan(NA, A.max_li, A.max_lj, PK);
-    unsigned char* sCodeOf = c2_smem + P.codeof;
-    int* sTab = (int*)(c2_smem + P.table);
-    auto wg_of = [&](const int s) {
-        unsigned char* base = c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes;
-        c2_wg W;
-        if (PK) {                                                  // the read per alignment, reference and window prefix per lane group
-            unsigned char* gb = c2_smem + P.group0 + (uint32_t)(s >> 1) * P.group_bytes;
-            W.sRead = base; W.sCode = nullptr; W.sRef = gb + P.gref; W.sIncP = (uint16_t*)(gb + P.gincp);
-        } else {
-            W.sRead = base + P.read; W.sCode = base + P.code; W.sRef = base + P.ref; W.sIncP = (uint16_t*)(base + P.incp);
-        }
-        W.sTmpRead = c2_smem + P.tmp_read; W.sTmpRef = c2_smem + P.tmp_ref;
-        return W;
-    };
-    auto win_of = [&](const int s) { return PK ? (uint32_t*)nullptr : (uint32_t*)(c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.win); };
-    // the column table the fill reads: per alignment (4 * code), or per lane group (PK: the pair symbols)
-    auto coltab_of = [&](const int s) {
-        return PK ? c2_smem + P.pcodes0 + (uint32_t)(s >> 1) * P.pcodes_bytes : c2_smem + P.slot0 + (uint32_t)s * P.slot_bytes + P.codes;
-    };
-    // rows of the output arrays can be written as dwords (c2_emit_gapless4) when their addresses are multiples of 4
-    const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);
-    unsigned* sStage = (unsigned*)(c2_smem + P.stage);
-    unsigned* gWords = A.plane + (size_t)blockIdx.x * A.plane_words_per_wg;   // [slot][group][lane of the slot]
-    const int slotWords = (int)P.n_words * LPA;
-    const int ge = A.gap_extend, go = A.gap_open;
-    for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
-    if (lane < NA) { sTab[lane * C2X_INTS + C2X_CURREF] = -1; sTab[lane * C2X_INTS + C2X_LI] = 0; sTab[lane * C2X_INTS + C2X_G0] = 0; sTab[lane * C2X_INTS + C2X_REFBAD] = 0; }
-    if (!PK)
-        for (int s = 0; s < NA; ++s)                               // zeros in front of column 1 of every slot's symbol table (written once)
-            if (lane <= C2_DIAG_CODE_PAD) c2_smem[P.slot0 + (uint32_t)s * P.slot_bytes + P.codes + lane] = 0;
-
-    if (PK) {
-        // pair-score tables: for reference symbol rc (codes 0..4; table 5 = zeros, for the padding rows) and read symbols (cA, cB) the two
-        // int16 scores side by side, at byte offset rc * C2_PK_LUT_STRIDE + (cA << 5 | cB << 2) -- the column table holds that pair symbol
-        unsigned* lut = (unsigned*)(c2_smem + P.pairlut);
-        for (int e = lane; e < C2_PK_LUT_CODES * 64; e += 64) {
-            const int rc = e >> 6, cA = (e >> 3) & 7, cB = e & 7;
-            unsigned v = 0;
-            if (rc < C2_PK_PAD_TABLE && rc < A.n_codes)
-                v = ((unsigned)(c2_sbfe4((int)A.score_pk[rc], 4 * cA) + 2 * beta) & 0xffffu) | ((unsigned)(c2_sbfe4((int)A.score_pk[rc], 4 * cB) + 2 * beta) << 16);
-            lut[rc * (int)(C2_PK_LUT_STRIDE / 4u) + (e & 63)] = v;
-        }
-    }
-    c2_phase_acc PH; PH.t_last = 0; PH.sum[0] = PH.sum[1] = PH.sum[2] = PH.sum[3] = 0;
-    // Task fetch as a four-stage software pipeline, one stage per group of NA alignments, so that no stage ever waits for
-    // the memory access it depends on (in list mode every one of them misses the caches):
-    //   A0  atomic on the work counter for the group four iterations ahead
-    //   A   lane s < NA: task index of slot s (from the task list, if any)              -- three ahead
-    //   B   lane s < NA: read offsets, reference id and strand of that task             -- two ahead
-    //   C   the first 256 read bytes of every slot, lanes = bytes (c2_prefetch)         -- one ahead
-    //   D   c2_commit_task into LDS, then the fill                                      -- this iteration
-    // Each stage consumes what the previous iteration's earlier stage requested; the barrier at the top of the loop has
-    // waited for all of it.  Task indices fit 32 bits in these launches (the host checks).
-    const bool pair_order = PK && A.pair_order && !A.task_list && A.all_refs;
-    const uint64_t n_reads_po = pair_order ? A.n_tasks / (uint64_t)A.n_refs : 0;
-    const uint64_t n_iter = A.task_list ? (uint64_t)(*A.task_count) : (pair_order ? ((n_reads_po + 1) >> 1) * 2u * (uint64_t)A.n_refs : A.n_tasks);
-    unsigned long long pend = 0;
-    bool pend_valid = false, exhausted = false;
-    unsigned mA_task = 0; int mA_valid = 0;
-    unsigned mB_task = 0; int mB_valid = 0, mB_ref = 0, mB_rc = 0;
-    unsigned long long mB_off = 0, mB_off1 = 0;
-    // stage C keeps its per-slot descriptors in lane s of a few VGPRs too (mC_*: no SGPR is live across the fill); only the
-    // read bytes need a register per slot
-    unsigned mC_task = 0; int mC_valid = 0, mC_lj = 0, mC_ref = 0, mC_rc = 0;
-    unsigned long long mC_off = 0;
-    unsigned b4s[NA];
-#pragma unroll
-    for (int s = 0; s < NA; ++s) b4s[s] = 0;
-    auto lane64 = [&](const unsigned long long v, const int s) {
-        return (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), s) |
-               ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), s) << 32);
-    };
-    for (int iter = 0;; ++iter) {
-        __syncthreads();
-        const bool have_group = __builtin_amdgcn_readlane(mC_valid, 0) != 0;
-        if (iter >= 4 && !have_group) break;
-        c2_phase_begin(A.phase_cycles, PH);
-        // ---- D: stage the NA prefetched tasks in their LDS slots
-        if (have_group) {
-#pragma nounroll                                                     // (one copy of the staging code: the read dwords are picked by a uniform select)
-            for (int s = 0; s < NA; ++s) {
-                int* T = sTab + s * C2X_INTS;
-                const int tvd = c2_tab_load(T, lane);
-                int cref = C2_TF(tvd, C2X_CURREF), li = C2_TF(tvd, C2X_LI), g0 = C2_TF(tvd, C2X_G0), rbad = C2_TF(tvd, C2X_REFBAD);
-                int st = 0;
-                bool packed = false, unpaired = false;
-                c2_prefetch cur;
-                cur.valid = __builtin_amdgcn_readlane(mC_valid, s);
-                cur.task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mC_task, s);
-                cur.off = lane64(mC_off, s);
-                cur.Lj = __builtin_amdgcn_readlane(mC_lj, s); cur.ref_id = __builtin_amdgcn_readlane(mC_ref, s);
-                cur.rc = __builtin_amdgcn_readlane(mC_rc, s); cur.b4 = 0;
-                if (cur.valid) {
-                    unsigned char* sCodes4 = coltab_of(s);
-                    bool done = false;
-                    // PK: the second alignment of a lane group (odd slot) shares the group's reference and column table with the first: it
-                    // joins only if the first one is staged and runs (valid, no status, packed), against the same reference, with a read
-                    // of the same length -- otherwise it is handed to the next launch (packed = false, no status)
-                    bool joins = true;
-                    const bool second = PK && (s & 1);
-                    if (second) {
-                        const int tva = c2_tab_load(T - C2X_INTS, lane);
-                        joins = C2_TF(tva, C2X_VALID) && C2_TF(tva, C2X_STATUS) == 0 && C2_TF(tva, C2X_PACKED) &&
-                                C2_TF(tva, C2X_REF) == cur.ref_id && C2_TF(tva, C2X_LJ) == cur.Lj;
-                        cref = C2_TF(tva, C2X_CURREF); li = C2_TF(tva, C2X_LI); g0 = C2_TF(tva, C2X_G0); rbad = C2_TF(tva, C2X_REFBAD);   // the group's reference
-                    }
-                    if (joins && !cur.rc && cur.Lj >= 4 && cur.Lj <= 256 && cur.Lj <= A.max_lj) {
-                        // the usual read: forward strand, at most 256 bases, nothing but A C G T N.  Four bases per lane: codes through two
-                        // byte permutes ((ch >> 1) & 7 is a perfect hash of the five letters), checked by permuting the letters back.
-                        const c2_wg W = wg_of(s);
-                        if (!second && cur.ref_id != cref) { cref = cur.ref_id; c2_stage_ref(A, W, sCodeOf, cur.ref_id, lane, A.max_li, li, g0, rbad, win_of(s)); }
-                        uint32_t w = b4s[0];
-#pragma unroll
-                        for (int q = 1; q < NA; ++q) if (s == q) w = b4s[q];
-                        const uint32_t idx = (w >> 1) & 0x07070707u;
-                        const uint32_t codes = __builtin_amdgcn_perm(A.lut_code_hi, A.lut_code_lo, idx);
-                        const uint32_t chk = __builtin_amdgcn_perm(A.lut_chr_hi, A.lut_chr_lo, idx);
-                        const int nb = cur.Lj - 4 * lane;
-                        const uint32_t valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
-                        if (__ballot(((chk ^ w) & valid) != 0) == 0ull) {
-                            uint32_t* col = (uint32_t*)(sCodes4 + C2_DIAG_CODE_PAD + 1);
-                            if (nb > 0) {
-                                ((uint32_t*)W.sRead)[lane] = w;
-                                if (!PK) col[lane] = (codes & valid) << 2;                    // 4 * code per column, zeros behind the last one
-                                else if (!second) col[lane] = (codes & valid) << 5;          // pair symbol: code A << 5 ...
-                                else col[lane] |= (codes & valid) << 2;                      // ... | code B << 2
-                            }
-                            if (!second && lane < 3) col[((cur.Lj + 3) >> 2) + lane] = 0u;    // ... nine zeros at least
-                            if (PK && !second && lane < (C2_DIAG_CODE_PAD + 1) / 4) ((uint32_t*)sCodes4)[lane] = 0u;   // (the table shares its bytes with the traceback strings: zeros in front every time)
-                            st = (rbad ? C2_STATUS_OOB_CHAR : 0) | (li <= 0 ? C2_STATUS_EMPTY : 0) | (li > A.max_li ? C2_STATUS_TOO_LONG : 0);
-                            packed = true;
-                            done = true;
-                        }
-                    }
-                    if (!done && joins) {
-                        if (PK && !second && lane < (C2_DIAG_CODE_PAD + 1) / 4) ((uint32_t*)sCodes4)[lane] = 0u;
-                        st = c2_commit_task<false>(A, wg_of(s), sCodeOf, cur, lane, A.max_li, cref, li, g0, rbad, packed, sCodes4, win_of(s),
-                                                   PK && !second ? 5 : 2, second, !second);
-                    }
-                    if (!joins) { st = 0; packed = false; }
-                    unpaired = !joins;
-                }
-                if (lane == 0) {
-                    T[C2X_VALID] = cur.valid; T[C2X_TASK_LO] = (int)(unsigned)(cur.task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(cur.task >> 32);
-                    T[C2X_LJ] = cur.Lj; T[C2X_REF] = cur.ref_id; T[C2X_RC] = cur.rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
-                    T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0; T[C2X_REFBAD] = rbad; T[C2X_UNPAIRED] = unpaired ? 1 : 0;
-                }
-            }
-        }
-        // ---- C: read bytes of the next group
-        mC_valid = mB_valid; mC_task = mB_task; mC_off = mB_off; mC_ref = mB_ref; mC_rc = mB_rc;
-        mC_lj = mB_valid ? (int)(mB_off1 - mB_off) : 0;
-#pragma unroll
-        for (int s = 0; s < NA; ++s) {
-            // one dword per lane: bytes 4l .. 4l+3 of the read (what the fast staging above takes); the dword that holds the read's
-            // last bytes is loaded so that it ENDS at the last byte and shifted down -- nothing behind the read is touched.  Reads
-            // of fewer than 4 or more than 256 bases and reverse-complemented ones are staged by c2_commit_task from memory.
-            const int v = __builtin_amdgcn_readlane(mC_valid, s);
-            unsigned b4 = 0;
-            if (v) {
-                const uint64_t off = lane64(mC_off, s);
-                const int Lj = __builtin_amdgcn_readlane(mC_lj, s);
-                const int p = 4 * lane;
-                if (Lj >= 4 && p < Lj) {
-                    const int q = p < Lj - 4 ? p : Lj - 4;
-                    uint32_t w;
-                    __builtin_memcpy(&w, A.reads + off + (uint64_t)q, 4);
-                    b4 = w >> (8 * (p - q));
-                }
-            }
-            b4s[s] = b4;
-        }
-        // ---- B: descriptors of the group after that
-        mB_valid = mA_valid; mB_task = mA_task; mB_off = 0; mB_off1 = 0; mB_ref = 0; mB_rc = 0;
-        if (lane < NA && mA_valid) {
-            unsigned read_id;
-            if (A.all_refs) { read_id = mA_task / (unsigned)A.n_refs; mB_ref = (int)(mA_task % (unsigned)A.n_refs); }
-            else            { read_id = mA_task; mB_ref = A.ref_ids ? (int)A.ref_ids[mA_task] : 0; }
-            mB_rc = A.strands ? (int)A.strands[mA_task] : 0;
-            mB_off = A.offsets[read_id]; mB_off1 = A.offsets[read_id + 1];
-        }
-        // ---- A: task indices of the group after that;  A0: the work counter for the one after
-        mA_valid = 0; mA_task = 0;
-        if (pend_valid) {
-            const uint64_t base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pend >> 32)) << 32) |
-                                  (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pend & 0xffffffffull));
-            const uint64_t it = base + (uint64_t)lane;
-            if (base >= n_iter) exhausted = true;
-            if (lane < NA && it < n_iter) {
-                if (pair_order) {
-                    // consecutive positions 2m, 2m+1 (the two slots of a lane group): reads 2q, 2q+1 against the same reference
-                    const uint64_t blk = it / (2u * (uint64_t)A.n_refs), i = it - blk * 2u * (uint64_t)A.n_refs;
-                    const uint64_t rd = 2u * blk + (i & 1u);
-                    if (rd < n_reads_po) { mA_valid = 1; mA_task = (unsigned)(rd * (uint64_t)A.n_refs + (i >> 1)); }
-                } else { mA_valid = 1; mA_task = A.task_list ? A.task_list[it] : (unsigned)it; }
-            }
-        }
-        pend = 0; pend_valid = false;
-        if (!exhausted) {
-            if (lane == 0) pend = atomicAdd(A.work_counter, (unsigned long long)NA);
-            pend_valid = true;
-        }
-        __syncthreads();
-        if (!have_group) continue;
-
-        // ---- band of every alignment; the tables its lanes read; the wave-uniform loop limits
-        bool any_ok = false;
-        int gA = 0, gC = 0x7fffffff, g_end = 0;
-#pragma nounroll
-        for (int s = 0; s < NA; ++s) {
-            int* T = sTab + s * C2X_INTS;
-            const int tvb = c2_tab_load(T, lane);
-            const int Li = C2_TF(tvb, C2X_LI), Lj = C2_TF(tvb, C2X_LJ);
-            bool ok = false;
-            int D = 0, d0 = 0, cb = 0, minsc = 0, lastpos = 0, rowBase = C2_DIAG_ROW_PAD;   // (idle slot: row 0 of the buffer's first table)
-            if (C2_TF(tvb, C2X_VALID) && C2_TF(tvb, C2X_STATUS) == 0) {
-                const c2_dev_ref rf = A.refs[C2_TF(tvb, C2X_REF)];
-                D = Li - Lj;
-                d0 = ((D - BANDW + 3) >> 1) & ~1;              // even; band = d0 .. d0 + BANDW - 1, the first diagonals outside it (d0 - 1, d0 + BANDW) as
-                                                               // symmetric about D / 2 as an even d0 allows: the two sides of c2_outside_band_bound are then equal
-                cb = (go > ge ? go : ge) + rf.gap_incentive_max;          // the most one gap base can add to a score
-                lastpos = rf.gap_incentive_last_pos;
-                ok = C2_TF(tvb, C2X_PACKED) && rf.diag_rows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
-                     D >= d0 && D <= d0 + BANDW - 1;
-                if (PK && ok) ok = rf.pk_ok != 0;               // the reference must be admitted to the int16 fill (c2_pk_eligible); pairs were formed by the staging
-                if (ok) {
-                    any_ok = true;
-                    minsc = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
-                    rowBase = (int)(rf.diag_rows - A.diag_base);
-                    const int max_start = (d0 + BANDW - 1 > -d0 ? d0 + BANDW - 1 : -d0) + 2;
-                    const int gA_s = ((max_start + 1) >> 1) >> 2;          // groups 0..gA contain lanes that have not started
-                    const int gC_s = ((2 * Lj + d0) >> 1) >> 2;            // first group in which some lane is on the last column
-                    const int ge_s = ((Li + Lj) >> 1) >> 2;                // group of the cell (Li, Lj)
-                    gA = gA > gA_s ? gA : gA_s; gC = gC < gC_s ? gC : gC_s; g_end = g_end > ge_s ? g_end : ge_s;
-                }
-            }
-            if (lane == 0) {
-                T[C2X_OK] = ok ? 1 : 0; T[C2X_D] = D; T[C2X_D0] = d0; T[C2X_CB] = cb; T[C2X_MINSC] = minsc; T[C2X_ROWBASE] = rowBase; T[C2X_LASTPOS] = lastpos;
-                T[C2X_BAND_LI] = ok ? Li : 0; T[C2X_BAND_LJ] = ok ? Lj : 0;
-            }
-        }
-        __syncthreads();
-        c2_phase_mark<0>(A.phase_cycles, PH);
-
-        int Hcap = C2_DIAG_NEG;
-        c2_gapfree GF; GF.acc = 0; GF.cap = 0xffffffffu;
-        c2_pk_cap CAP; CAP.H = 0u; CAP.gf = 0u;                    // (H = 0 in both halves: below every bound; gf = 0: not gap-free)
-        if (A.reserved & 4) g_end >>= 1;                           // (debug knob C2_DEBUG_HALF_FILL: what half of the fill costs; nothing is certified then)
-        if (PK && any_ok) {
-            const int* T = sTab + slot * C2X_INTS;                 // the lane group's first alignment (the second one, if any, has the same geometry)
-            const int vLi = T[C2X_BAND_LI], vLj = T[C2X_BAND_LJ], vd0 = T[C2X_D0], vg0 = T[C2X_G0];
-            const int vrow = T[C2X_ROWBASE], vcode = (int)(P.pcodes0 + (uint32_t)grp * P.pcodes_bytes) + C2_DIAG_CODE_PAD;
-            C2_LANES_ACTIVE_BEGIN(sl != NL && grp < NG)
-            const int hE = (vd0 >> 1) + sl;
-            const int dE = 2 * hE, dO = dE + 1;
-            c2_pk_state S;
-            S.acc = 0u; S.gf = 0xffffffffu;
-            {
-                // boundary cells (pyx:153-176) with the bias; the sentinel min_score is the number 0 here
-                // (beta: the boundary cell of diagonal d lies on anti-diagonal |d|)
-                const int bE = ((dE == 0) ? 0 : (ge + beta) * (dE > 0 ? dE : -dE) + vg0) + PKB;
-                const int mE = (dE == 0) ? PKB : 0, iE = (dE < 0) ? bE : 0, jE = (dE > 0) ? bE : 0;
-                S.ME = c2_pk_dup(mE); S.IE = c2_pk_dup(iE); S.JE = c2_pk_dup(jE); S.HE = c2_pk_dup(c2_imax(c2_imax(mE, iE), jE));
-                const int bO = (ge + beta) * (dO > 0 ? dO : -dO) + vg0 + PKB;
-                const int iO = (dO < 0) ? bO : 0, jO = (dO > 0) ? bO : 0;
-                S.MO = 0u; S.IO = c2_pk_dup(iO); S.JO = c2_pk_dup(jO); S.HO = c2_pk_dup(c2_imax(iO, jO));
-            }
-            c2_diagx_lane L;
-            L.rowOff = (unsigned)((vrow + hE) * (int)sizeof(c2_diag_row));
-            L.rowMax = (unsigned)((vrow + vLi + 1 + C2_DIAG_ROW_PAD - 5) * (int)sizeof(c2_diag_row));
-            L.colOff = (unsigned)(vcode - hE);
-            L.colMax = (unsigned)(vcode + vLj + 2);
-            L.kLast = vLj + hE;
-            L.kCap = (vLi + vLj) >> 1; L.capOdd = ((vLi + vLj) & 1) != 0;
-            L.startE = (dE > 0 ? dE : -dE) + 2; L.startO = (dO > 0 ? dO : -dO) + 2;
-            const c2_diag_row* rows = A.diagpk_base;
-            c2_diag_row RA[5], RB[5];
-            int CA[4], CB[4];
-            c2_diagx_fetch<true>(0, L, rows, c2_smem, RA, CA);
-            unsigned* wordsA = gWords + slot * slotWords + sl;
-            unsigned* wordsB = wordsA + slotWords;
-            int g = 0;
-            const int gA_stop = gA < g_end ? gA : g_end;
-            unsigned ge2 = c2_pk_dup(ge + beta);
-            const unsigned lutBase = P.pairlut;
-            if (gC <= gA_stop) {
-                c2_pk_groups<true, true, ROWDPP, ADD32>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
-            } else {
-                c2_pk_groups<true, false, ROWDPP, ADD32>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
-                c2_pk_groups<false, false, ROWDPP, ADD32>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
-            }
-            c2_pk_groups<false, true, ROWDPP, ADD32>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
-            C2_LANES_ACTIVE_END()
-        }
-        if (!PK && any_ok) {
-            const int* T = sTab + slot * C2X_INTS;                 // this lane's alignment
-            const int vLi = T[C2X_BAND_LI], vLj = T[C2X_BAND_LJ], vd0 = T[C2X_D0], vg0 = T[C2X_G0], vmin = T[C2X_MINSC];
-            const int vrow = T[C2X_ROWBASE], vcode = (int)(P.slot0 + (uint32_t)slot * P.slot_bytes + P.codes) + C2_DIAG_CODE_PAD;
-            C2_LANES_ACTIVE_BEGIN(sl != NL && grp < NG)            // (grp >= NG: the lanes 64 / NG does not use up, e.g. 60..63 of five groups of 12)
-            // ---- per-lane diagonals and their boundary cells (pyx:153-176), as in c2_align_diag_kernel
-            const int hE = (vd0 >> 1) + sl;                    // dE = 2*hE, dO = 2*hE + 1
-            const int dE = 2 * hE, dO = dE + 1;
-            c2_diag_state S;
-            S.bits = 0;
-            {
-                const int ms = vmin + C2_DIAG_BIAS;
-                const int bE = ((dE == 0) ? 0 : ge * (dE > 0 ? dE : -dE) + vg0) + C2_DIAG_BIAS;
-                S.ME = (dE == 0) ? C2_DIAG_BIAS : ms;
-                S.IE = (dE < 0) ? bE : ms;
-                S.JE = (dE > 0) ? bE : ms;
-                S.HE = c2_imax(c2_imax(S.ME, S.IE), S.JE);
-                const int bO = ge * (dO > 0 ? dO : -dO) + vg0 + C2_DIAG_BIAS;   // dO is odd, never 0
-                S.MO = ms;
-                S.IO = (dO < 0) ? bO : ms;
-                S.JO = (dO > 0) ? bO : ms;
-                S.HO = c2_imax(c2_imax(S.MO, S.IO), S.JO);
-            }
-            c2_diagx_lane L;
-            L.rowOff = (unsigned)((vrow + hE) * (int)sizeof(c2_diag_row));
-            L.rowMax = (unsigned)((vrow + vLi + 1 + C2_DIAG_ROW_PAD - 5) * (int)sizeof(c2_diag_row));
-            L.colOff = (unsigned)(vcode - hE);
-            L.colMax = (unsigned)(vcode + vLj + 2);
-            L.kLast = vLj + hE;
-            L.kCap = (vLi + vLj) >> 1; L.capOdd = ((vLi + vLj) & 1) != 0;
-            L.startE = (dE > 0 ? dE : -dE) + 2; L.startO = (dO > 0 ? dO : -dO) + 2;
-            const c2_diag_row* rows = A.diag_base;
-            c2_diag_row RA[5], RB[5];
-            int CA[4], CB[4];
-            c2_diagx_fetch<true>(0, L, rows, c2_smem, RA, CA);
-            unsigned* myWords = gWords + slot * slotWords + sl;
-            int g = 0;
-            const int gA_stop = gA < g_end ? gA : g_end;
-            int geV = ge;                                          // gap_extend in a VGPR (second source of a DPP add)
-            C2_KEEP_IN_VGPR(geV);
-            if (gC <= gA_stop) {
-                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
-            } else {
-                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
-                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
-            }
-            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
-            C2_LANES_ACTIVE_END()
-        }
-        __syncthreads();                                           // (waits for the plane stores)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // drop this CU's stale L1 lines of the plane before reading it back
-        c2_phase_mark<1>(A.phase_cycles, PH);
-
-        // ---- per alignment: optimality certificate (see c2_align_diag_kernel), then one of three ends:
-        //        gap-free   the main-diagonal lane's c2_gapfree word is 0: the strings are the read and the reference, no pointer
-        //                   word is ever read back (most reads of an amplicon run)
-        //        traced     the alignment's pointer words come back from the scratch plane into LDS, traceback, output
-        //        handed on  no certificate: the task goes to the next launch's list
-        //      First pass: the decision of every slot (wave-uniform bit masks) -- the words of the NEXT traced slot have to be
-        //      requested before the current one is written out (a load issued after those stores would wait for them: one
-        //      vmcnt for loads and stores), so the traced slots must be known before the first one is handled.
-        unsigned m_valid = 0, m_full = 0, m_gapfree = 0, m_trace = 0;
-#pragma nounroll
-        for (int s = 0; s < NA; ++s) {
-            const int tv = c2_tab_load(sTab + s * C2X_INTS, lane);
-            if (!C2_TF(tv, C2X_VALID)) continue;
-            m_valid |= 1u << s;
-            const int status = C2_TF(tv, C2X_STATUS);
-            if (status != 0) continue;
-            if (!C2_TF(tv, C2X_OK)) { m_full |= 1u << s; continue; }
-            const int Li = C2_TF(tv, C2X_LI), Lj = C2_TF(tv, C2X_LJ);
-            const int D = C2_TF(tv, C2X_D), d0 = C2_TF(tv, C2X_D0), cb = C2_TF(tv, C2X_CB);
-            const int lane_end = (PK ? (s >> 1) : s) * LPA + ((D - d0) >> 1);
-            int Hend;
-            bool gapfree;
-            if (PK) {
-                const int half = 16 * (s & 1);
-                Hend = (int)(int16_t)(((unsigned)__builtin_amdgcn_readlane((int)CAP.H, lane_end) >> half) & 0xffffu) - PKB - beta * (Li + Lj);
-                gapfree = (((unsigned)__builtin_amdgcn_readlane((int)CAP.gf, lane_end) >> half) & 0x1111u) == 0x1111u;   // the E cells (cells 0 and 2 of a word): bits 0 and 4 of both bytes
-            } else {
-                Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
-                gapfree = __builtin_amdgcn_readlane((int)GF.cap, lane_end) == 0;
-            }
-            const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
-            const int U = c2_outside_band_bound(A.max_score, Li, Lj, D, dhi1, dlo1, cb, go, ge, C2_TF(tv, C2X_LASTPOS));
-            if (!(Hend > U)) { m_full |= 1u << s; continue; }
-            if (A.reserved & 2) continue;                              // (debug knob C2_DEBUG_SKIP_EPILOGUE: certified, nothing written)
-            if (Li == Lj && gapfree) m_gapfree |= 1u << s;
-            else m_trace |= 1u << s;
-        }
-        constexpr int STG = 16 / NG > 8 ? 8 : 16 / NG;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
-        uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
-        q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = uint4{0u, 0u, 0u, 0u};
-#define C2_STG_LOAD(n) if (STG > n) { const int k = 64 * n + lane; q##n = src[k < n16 ? k : 0]; }
-#define C2_STG_STORE(n) if (STG > n) { const int k = 64 * n + lane; if (k < n16) dst[k] = q##n; }
-        auto request_words = [&](const int s2) {
-            const uint4* src = (const uint4*)(gWords + s2 * slotWords);
-            const int n16 = (g_end + 1) * (LPA / 4);
-            C2_STG_LOAD(0) C2_STG_LOAD(1) C2_STG_LOAD(2) C2_STG_LOAD(3) C2_STG_LOAD(4) C2_STG_LOAD(5) C2_STG_LOAD(6) C2_STG_LOAD(7)
-        };
-        if (m_trace) request_words(__builtin_ctz(m_trace));
-#pragma nounroll
-        for (int s = 0; s < NA; ++s) {
-            if (!((m_valid >> s) & 1u)) continue;
-            const int* T = sTab + s * C2X_INTS;
-            const int tv = c2_tab_load(T, lane);
-            const uint64_t task = (uint64_t)(unsigned)C2_TF(tv, C2X_TASK_LO) | ((uint64_t)(unsigned)C2_TF(tv, C2X_TASK_HI) << 32);
-            const int Li = C2_TF(tv, C2X_LI), Lj = C2_TF(tv, C2X_LJ), g0 = C2_TF(tv, C2X_G0);
-            int status = C2_TF(tv, C2X_STATUS);
-            c2_aln_record rec;
-            c2_clear_record(rec, C2_TF(tv, C2X_RC), C2_TF(tv, C2X_REF));
-            bool need_full = (m_full >> s) & 1u;
-            if ((m_gapfree >> s) & 1u) {
-                if (rows_aligned && Li <= 256) c2_emit_gapless4(A, wg_of(s), win_of(s), task, Li, lane, rec);
-                else c2_emit_gapless(A, wg_of(s), task, Li, lane, rec);
-            } else if ((m_trace >> s) & 1u) {
-                const int d0 = C2_TF(tv, C2X_D0), minsc = C2_TF(tv, C2X_MINSC);
-                const c2_wg W = wg_of(s);
-                // the alignment's pointer words: registers (requested from HBM/L2 before the previous alignment's
-                // output stores were issued) -> LDS; words beyond the first batch (long sequences) are fetched here
-                {
-                    const uint4* src = (const uint4*)(gWords + s * slotWords);
-                    uint4* dst = (uint4*)sStage;
-                    const int n16 = ((((Li + Lj) >> 1) >> 2) + 1) * (LPA / 4);
-                    C2_STG_STORE(0) C2_STG_STORE(1) C2_STG_STORE(2) C2_STG_STORE(3) C2_STG_STORE(4) C2_STG_STORE(5) C2_STG_STORE(6) C2_STG_STORE(7)
-                    for (int k = 64 * STG + lane; k < n16; k += 64) dst[k] = src[k];
-                }
-                __syncthreads();
-                const unsigned later = m_trace & ~((2u << s) - 1u);     // traced slots after this one
-                if (later) request_words(__builtin_ctz(later));
-                c2_diagx_plane plane;
-                plane.words = sStage; plane.d0 = d0; plane.lpa = LPA; plane.nl = NL; plane.pk = PK;
-                int cnt, matches;
-                bool nf2;
-                c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
-                __syncthreads();
-                c2_phase_mark<2>(A.phase_cycles, PH);
-                if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
-            }
-            if (need_full) {
-                status |= C2_STATUS_NEED_FULL;
-                const bool to_unpaired = PK && A.un_list && C2_TF(tv, C2X_UNPAIRED);
-                if (lane == 0) {
-                    if (to_unpaired) { const unsigned q = atomicAdd(A.un_count, 1u); A.un_list[q] = (uint32_t)task; }   // same band, 32-bit kernel
-                    else { const unsigned q = atomicAdd(A.fb_count, 1u); A.fb_list[q] = (uint32_t)task; }
-                }
-            }
-            rec.status = (uint8_t)status;
-            if (lane == 0) A.records[task] = rec;
-            c2_phase_mark<3>(A.phase_cycles, PH);
-        }
-    }
-    c2_phase_flush(A.phase_cycles, PH, lane);
-}
-
-template <int NA>
-__global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A) { c2_diagx_body<NA, false>(A); }
-
-// NA alignments per wavefront, two per lane group, int16 DP values (see "Packed fill")
-template <int NA, bool ADD32 = false>
-__global__ __launch_bounds__(64, 3) void c2_align_diagp_kernel(c2_align_args A) { c2_diagx_body<NA, true, ADD32>(A); }
-
-// =====================================================================================
-// Per-call classifier with full position lists: find_indels_substitutions
-// (CRISPRessoCOREResources.pyx:68-187) and find_indels_substitutions_legacy (pyx:190-315).
-// Accepts ANY pair of equal-length strings, including shapes the aligner never emits
-// (double-gap columns, insertion next to deletion), so it follows the reference's column
-// walk literally.  This is the drop-in for the reference's per-call API (O(10) calls per
-// run); the throughput path is the fused classifier in c2_align_classify_kernel.
-// One lane walks; launch <<<1, 64>>>.
-// =====================================================================================
-struct c2_list_writer {
-    int32_t* base; int32_t cap; int32_t n;
-    __device__ __forceinline__ void push(int32_t v) { if (n < cap) base[n] = v; n++; }
-};
-
-__device__ inline bool c2_inc_has(const int32_t* inc, int n, int x) {
-    int lo = 0, hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (inc[mid] < x) lo = mid + 1; else hi = mid; }
-    return lo < n && inc[lo] == x;
-}
-// include_set.intersection(range(a, b)) non-empty
-__device__ inline bool c2_inc_hits(const int32_t* inc, int n, int a, int b) {
-    int lo = 0, hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (inc[mid] < a) lo = mid + 1; else hi = mid; }
-    return lo < n && inc[lo] < b;
-}
-
-// The column walk of one alignment by one lane; the caller owns the list writers (L[C2_LIST_REF_POSITIONS] must have
-// room for all n entries: the walk reads them back).
-__device__ __forceinline__ void c2_classify_walk(const uint8_t* rd, const uint8_t* rf, const int n, const int32_t* inc, const int ni,
-                                                 const int legacy, c2_list_writer (&L)[C2_LIST_COUNT], int64_t& ins_n, int64_t& del_n)
-{
-    int32_t* rp = L[C2_LIST_REF_POSITIONS].base;
-    ins_n = 0; del_n = 0;
-    int idx = 0;
-    if (!legacy) {
-        int start_deletion = -1, start_insertion = -1, cur_ins = 0;                  // pyx:94,101,109
-        for (int c = 0; c < n; ++c) {                                                 // pyx:110
-            if (rf[c] != '-') {
-                L[C2_LIST_REF_POSITIONS].push(idx);
-                if (rf[c] != rd[c] && rd[c] != '-' && rd[c] != 'N') {                 // pyx:113
-                    L[C2_LIST_ALL_SUBSTITUTION_POSITIONS].push(idx); L[C2_LIST_ALL_SUBSTITUTION_VALUES].push(rd[c]);
-                    if (c2_inc_has(inc, ni, idx)) { L[C2_LIST_SUBSTITUTION_POSITIONS].push(idx); L[C2_LIST_SUBSTITUTION_VALUES].push(rd[c]); }
-                }
-                if (start_insertion != -1) {                                          // pyx:119-128
-                    L[C2_LIST_ALL_INSERTION_LEFT_POSITIONS].push(start_insertion);
-                    L[C2_LIST_ALL_INSERTION_POSITIONS].push(start_insertion); L[C2_LIST_ALL_INSERTION_POSITIONS].push(idx);
-                    if (c2_inc_has(inc, ni, start_insertion) && c2_inc_has(inc, ni, idx)) {
-                        L[C2_LIST_INSERTION_COORDINATES].push(start_insertion); L[C2_LIST_INSERTION_COORDINATES].push(idx);
-                        L[C2_LIST_INSERTION_POSITIONS].push(start_insertion); L[C2_LIST_INSERTION_POSITIONS].push(idx);
-                        L[C2_LIST_INSERTION_SIZES].push(cur_ins); ins_n += cur_ins;
-                    }
-                    start_insertion = -1;
-                }
-                cur_ins = 0; idx++;
-            } else {                                                                  // pyx:131-138
-                L[C2_LIST_REF_POSITIONS].push(idx == 0 ? -1 : -idx);
-                if (idx > 0 && start_insertion == -1) start_insertion = idx - 1;
-                cur_ins++;
-            }
-            if (rd[c] == '-' && start_deletion == -1) {                               // pyx:140-144
-                start_deletion = (c - 1 >= 0) ? rp[c] : 0;
-            } else if (rd[c] != '-' && start_deletion != -1) {                        // pyx:145-153
-                const int end_deletion = rp[c];
-                for (int q = start_deletion; q < end_deletion; ++q) L[C2_LIST_ALL_DELETION_POSITIONS].push(q);
-                L[C2_LIST_ALL_DELETION_COORDINATES].push(start_deletion); L[C2_LIST_ALL_DELETION_COORDINATES].push(end_deletion);
-                if (c2_inc_hits(inc, ni, start_deletion, end_deletion)) {
-                    for (int q = start_deletion; q < end_deletion; ++q) L[C2_LIST_DELETION_POSITIONS].push(q);
-                    L[C2_LIST_DELETION_COORDINATES].push(start_deletion); L[C2_LIST_DELETION_COORDINATES].push(end_deletion);
-                    L[C2_LIST_DELETION_SIZES].push(end_deletion - start_deletion); del_n += end_deletion - start_deletion;
-                }
-                start_deletion = -1;
-            }
-        }
-        if (start_deletion != -1 && n > 0) {                                          // pyx:155-162
-            const int end_deletion = rp[n - 1];
-            for (int q = start_deletion; q < end_deletion + 1; ++q) L[C2_LIST_ALL_DELETION_POSITIONS].push(q);
-            L[C2_LIST_ALL_DELETION_COORDINATES].push(start_deletion); L[C2_LIST_ALL_DELETION_COORDINATES].push(end_deletion + 1);
-            if (c2_inc_hits(inc, ni, start_deletion, end_deletion + 1)) {
-                for (int q = start_deletion; q < end_deletion + 1; ++q) L[C2_LIST_DELETION_POSITIONS].push(q);
-                L[C2_LIST_DELETION_COORDINATES].push(start_deletion); L[C2_LIST_DELETION_COORDINATES].push(end_deletion + 1);
-                L[C2_LIST_DELETION_SIZES].push(end_deletion + 1 - start_deletion); del_n += end_deletion + 1 - start_deletion;
-            }
-        }
-    } else {
-        // legacy, pyx:190-315
-        for (int c = 0; c < n; ++c) {                                                 // pyx:218-233
-            const uint8_t ch = rf[c];
-            if (ch == 'A' || ch == 'T' || ch == 'C' || ch == 'G' || ch == 'N') {
-                L[C2_LIST_REF_POSITIONS].push(idx);
-                if (rf[c] != rd[c] && rd[c] != '-' && rd[c] != 'N') {
-                    L[C2_LIST_ALL_SUBSTITUTION_POSITIONS].push(idx); L[C2_LIST_ALL_SUBSTITUTION_VALUES].push(rd[c]);
-                    if (c2_inc_has(inc, ni, idx)) { L[C2_LIST_SUBSTITUTION_POSITIONS].push(idx); L[C2_LIST_SUBSTITUTION_VALUES].push(rd[c]); }
-                }
-                idx++;
-            } else {
-                L[C2_LIST_REF_POSITIONS].push(idx == 0 ? -1 : -idx);
-            }
-        }
-        // deletions: runs of '-' in the read, pyx:253-267
-        for (int st = 0; st < n;) {
-            if (rd[st] != '-') { ++st; continue; }
-            int en = st; while (en < n && rd[en] == '-') ++en;
-            int ref_st = 0;
-            if (st - 1 > 0) ref_st = rp[st];
-            int ref_en = idx - 1;
-            if (en < n) ref_en = rp[en];
-            for (int q = ref_st; q < ref_en; ++q) L[C2_LIST_ALL_DELETION_POSITIONS].push(q);
-            L[C2_LIST_ALL_DELETION_COORDINATES].push(ref_st); L[C2_LIST_ALL_DELETION_COORDINATES].push(ref_en);
-            if (c2_inc_hits(inc, ni, ref_st, ref_en)) {
-                for (int q = ref_st; q < ref_en; ++q) L[C2_LIST_DELETION_POSITIONS].push(q);
-                L[C2_LIST_DELETION_COORDINATES].push(ref_st); L[C2_LIST_DELETION_COORDINATES].push(ref_en);
-                L[C2_LIST_DELETION_SIZES].push(en - st); del_n += en - st;
-            }
-            st = en;
-        }
-        // insertions: runs of '-' in the reference, pyx:271-288 (either flank in the window counts, pyx:284)
-        for (int st = 0; st < n;) {
-            if (rf[st] != '-') { ++st; continue; }
-            int en = st; while (en < n && rf[en] == '-') ++en;
-            if (st != 0 && en != n) {
-                const int ref_st = rp[st - 1], ref_en = rp[en];
-                L[C2_LIST_ALL_INSERTION_LEFT_POSITIONS].push(ref_st);
-                L[C2_LIST_ALL_INSERTION_POSITIONS].push(ref_st); L[C2_LIST_ALL_INSERTION_POSITIONS].push(ref_en);
-                if (c2_inc_has(inc, ni, ref_st) || c2_inc_has(inc, ni, ref_en)) {
-                    L[C2_LIST_INSERTION_COORDINATES].push(ref_st); L[C2_LIST_INSERTION_COORDINATES].push(ref_en);
-                    L[C2_LIST_INSERTION_POSITIONS].push(ref_st); L[C2_LIST_INSERTION_POSITIONS].push(ref_en);
-                    L[C2_LIST_INSERTION_SIZES].push(en - st); ins_n += en - st;
-                }
-            }
-            st = en;
-        }
-    }
-}
-
-__global__ __launch_bounds__(64) void c2_classify_lists_kernel(c2_classify_args A)
-{
-    if (threadIdx.x != 0) return;
-    c2_list_writer L[C2_LIST_COUNT];
-    for (int k = 0; k < C2_LIST_COUNT; ++k) { L[k].base = A.lists + (size_t)k * A.cap; L[k].cap = A.cap; L[k].n = 0; }
-    int64_t ins_n, del_n;
-    c2_classify_walk(A.read_al, A.ref_al, A.n, A.include_sorted, A.n_include, A.legacy, L, ins_n, del_n);   // cap >= n is guaranteed by the host
-    for (int k = 0; k < C2_LIST_COUNT; ++k) A.list_len[k] = L[k].n;
-    A.counts[0] = ins_n; A.counts[1] = del_n; A.counts[2] = L[C2_LIST_SUBSTITUTION_POSITIONS].n;
-}
-
-// Batched form: one LANE per alignment (the walk is serial in the column index; alignments are independent), two passes
-// over the same walk -- pass 0 counts the 15 list lengths (reference positions go to a scratch row), the host turns the
-// lengths into offsets, pass 1 writes every list at its place in one flat int32 array.  Used by
-// crispresso2_amd.variants.get_new_variant_objects (one launch pair per 32 k alignments instead of one launch each).
-__global__ __launch_bounds__(64) void c2_classify_lists_batch_kernel(c2_classify_batch_args A)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    if (t >= A.n) return;
-    const int set = A.set_ids ? (int)A.set_ids[t] : 0;
-    const int32_t* inc = A.include_sorted + A.include_off[set];
-    const int ni = (int)(A.include_off[set + 1] - A.include_off[set]);
-    const int n = A.lens[t];
-    c2_list_writer L[C2_LIST_COUNT];
-#pragma unroll
-    for (int k = 0; k < C2_LIST_COUNT; ++k) {
-        if (A.pass == 0) { L[k].base = nullptr; L[k].cap = 0; }
-        else { L[k].base = A.values + A.list_off[t * C2_LIST_COUNT + k]; L[k].cap = A.list_len[t * C2_LIST_COUNT + k]; }
-        L[k].n = 0;
-    }
-    if (A.pass == 0) { L[C2_LIST_REF_POSITIONS].base = A.scratch_rp + t * (uint64_t)A.stride; L[C2_LIST_REF_POSITIONS].cap = (int32_t)A.stride; }
-    int64_t ins_n, del_n;
-    c2_classify_walk(A.aln_read + t * (uint64_t)A.stride, A.aln_ref + t * (uint64_t)A.stride, n, inc, ni, A.legacy, L, ins_n, del_n);
-    if (A.pass == 0) {
-#pragma unroll
-        for (int k = 0; k < C2_LIST_COUNT; ++k) A.list_len[t * C2_LIST_COUNT + k] = L[k].n;
-        A.counts[t * 3] = ins_n; A.counts[t * 3 + 1] = del_n; A.counts[t * 3 + 2] = L[C2_LIST_SUBSTITUTION_POSITIONS].n;
-    }
-}
-
-// get_consensus_alignment_from_pairs (CRISPRessoCORE.py:829-984) with get_greater_qual_nuc (:800-826): the two-pointer walk
-// over the alignments of read 1 and read 2 against the same reference, statement for statement -- including that the
-// double-gap column adds no quality character, that a read alone past the other's end copies its gaps, and that the
-// strings are trimmed where the consensus reference starts or ends with '-'.  A quality index past the end of its string
-// is an IndexError in the reference: flag 2, and the host raises.  One lane per pair; every lane walks its own rows, so the
-// six input strings are read a dword at a time (c2_row_bytes: the walk's indices only ever step by one, a dword serves four
-// of them) instead of one byte per load instruction.
-struct c2_row_bytes {
-    const uint32_t* w; uint32_t cur; int at;
-    __device__ __forceinline__ c2_row_bytes(const uint8_t* row) : w((const uint32_t*)row), cur(0), at(-1) {}
-    __device__ __forceinline__ uint8_t operator[](const int i) {
-        const int q = i >> 2;
-        if (q != at) { cur = w[q]; at = q; }
-        return (uint8_t)(cur >> ((i & 3) * 8));
-    }
-};
-
-__global__ __launch_bounds__(64) void c2_consensus_pairs_kernel(c2_consensus_args A)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    if (t >= A.n) return;
-    // (rows start at multiples of 4: the host checks the strides and allocates the arrays)
-    c2_row_bytes s1(A.s1 + t * A.stride), f1(A.f1 + t * A.stride), s2(A.s2 + t * A.stride), f2(A.f2 + t * A.stride);
-    c2_row_bytes q1(A.q1 + t * A.qstride), q2(A.q2 + t * A.qstride);
-    const int n1 = A.n1[t], n2 = A.n2[t], lq1 = A.lq1[t], lq2 = A.lq2[t];
-    const bool best1 = A.best1[t] != 0;
-    uint8_t* oa = A.o_aln + t * A.ostride; uint8_t* orf = A.o_ref + t * A.ostride; uint8_t* oq = A.o_qual + t * A.ostride;
-    int start1 = 0; while (start1 < n1 && s1[start1] == '-') ++start1;            // len(s) - len(s.lstrip('-'))
-    int start2 = 0; while (start2 < n2 && s2[start2] == '-') ++start2;
-    int stop1 = n1 - 1; while (stop1 >= 0 && s1[stop1] == '-') --stop1;            // len(s.rstrip('-')) - 1
-    int stop2 = n2 - 1; while (stop2 >= 0 && s2[stop2] == '-') --stop2;
-    int i1 = 0, i2 = 0, qi1 = 0, qi2 = 0, na = 0, nq = 0;
-    bool caching = true, index_error = false;
-    auto Q1 = [&]() -> uint8_t { if (qi1 >= lq1) { index_error = true; return (uint8_t)'!'; } return q1[qi1]; };
-    auto Q2 = [&]() -> uint8_t { if (qi2 >= lq2) { index_error = true; return (uint8_t)'!'; } return q2[qi2]; };
-    auto greater = [&](uint8_t c1, uint8_t a, uint8_t c2, uint8_t b, uint8_t& nuc, uint8_t& q) {     // :800-826
-        if (c1 == c2) { nuc = c1; q = a >= b ? a : b; return; }
-        caching = false;
-        if (a == b) { nuc = best1 ? c1 : c2; q = b; }
-        else if (a > b) { nuc = c1; q = a; }
-        else { nuc = c2; q = b; }
-    };
-    while ((i1 < n1 || i2 < n2) && !index_error) {
-        const bool in1 = i1 < n1, in2 = i2 < n2;
-        if (in1 && f1[i1] == '-' && in2 && f2[i2] == '-') {
-            uint8_t nuc, q; const uint8_t a = Q1(), b = Q2();
-            greater(s1[i1], a, s2[i2], b, nuc, q);
-            oa[na] = nuc; orf[na] = '-'; ++na; oq[nq++] = q;
-            ++qi1; ++qi2; ++i1; ++i2;
-            continue;
-        } else if (in1 && f1[i1] == '-') {
-            oa[na] = s1[i1]; orf[na] = '-'; ++na; oq[nq++] = Q1();
-            ++qi1; ++i1;
-            continue;
-        } else if (in2 && f2[i2] == '-') {
-            oa[na] = s2[i2]; orf[na] = '-'; ++na; oq[nq++] = Q2();
-            ++qi2; ++i2;
-            continue;
-        }
-        if (in1 && s1[i1] == '-' && in2 && s2[i2] == '-') {
-            oa[na] = ((start1 <= i1 && i1 <= stop1) || (start2 <= i2 && i2 <= stop2)) ? '-' : 'N';
-            orf[na] = f1[i1]; ++na;
-        } else if (in1 && s1[i1] == '-' && in2 && s2[i2] != '-') {
-            oa[na] = s2[i2]; orf[na] = f2[i2]; ++na; oq[nq++] = Q2(); ++qi2;
-        } else if (in1 && s1[i1] != '-' && in2 && s2[i2] == '-') {
-            oa[na] = s1[i1]; orf[na] = f1[i1]; ++na; oq[nq++] = Q1(); ++qi1;
-        } else if (in1 && in2) {
-            uint8_t nuc, q; const uint8_t a = Q1(), b = Q2();
-            greater(s1[i1], a, s2[i2], b, nuc, q);
-            oa[na] = nuc; orf[na] = f1[i1]; ++na; oq[nq++] = q; ++qi1; ++qi2;
-        } else if (in1) {
-            oa[na] = (s1[i1] == '-' && start1 <= i1 && i1 <= stop1) ? (uint8_t)'N' : s1[i1];
-            oq[nq++] = Q1(); orf[na] = f1[i1]; ++na; ++qi1;
-        } else if (in2) {
-            oa[na] = (s2[i2] == '-' && start2 <= i2 && i2 <= stop2) ? (uint8_t)'N' : s2[i2];
-            oq[nq++] = Q2(); orf[na] = f2[i2]; ++na; ++qi2;
-        }
-        ++i1; ++i2;
-    }
-    // trim where the consensus reference starts / ends with '-' (quality string sliced by the same counts, :968-975)
-    int lead = 0; while (lead < na && orf[lead] == '-') ++lead;
-    int trail = 0; while (trail < na - lead && orf[na - 1 - trail] == '-') ++trail;
-    if (lead >= na) index_error = true;                                            // final_ref[0] on an empty string
-    const int len = index_error ? 0 : na - lead - trail;
-    int qlen = nq - (lead < nq ? lead : nq);
-    qlen -= (trail < qlen ? trail : qlen);
-    int hom = 0;
-    for (int k = 0; k < len; ++k) {
-        const uint8_t a = oa[lead + k], r = orf[lead + k];
-        oa[k] = a; orf[k] = r;
-        hom += (a == r);
-    }
-    for (int k = 0; k < qlen; ++k) oq[k] = oq[(lead < nq ? lead : nq) + k];
-    int32_t* info = A.o_info + t * 4;
-    info[0] = len; info[1] = qlen; info[2] = hom; info[3] = (caching ? 1 : 0) | (index_error ? 2 : 0);
-}
-
-// calculate_homology, COREResources.pyx:318-327 (float32 accumulator; result = score / strlen(a))
-__global__ __launch_bounds__(64) void c2_homology_kernel(const uint8_t* a, const uint8_t* b, int n, float* out)
-{
-    if (threadIdx.x != 0) return;
-    float score = 0.0f;
-    for (int k = 0; k < n; ++k) if (a[k] == b[k]) score += 1;
-    *out = score / (float)n;
-}
-
-// Hardware self-test of the cross-lane primitives the DP relies on (wave_shr:1 with `old` kept in lane 0).
-__global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
-{
-    const int lane = threadIdx.x;
-    out[lane] = c2_shr1(-7, lane * 3 + 1);                      // expect lane0=-7, lane n = 3(n-1)+1
-    out[64 + lane] = __builtin_amdgcn_readlane(lane * 5, 17);   // expect 85 everywhere
-    const unsigned long long m = __ballot(lane % 3 == 0);
-    out[128 + lane] = __popcll(m) + (lane == 0 ? __builtin_ctzll(~m) : 0);
-    // a lane that is switched off in EXEC is an invalid DPP source: its neighbour keeps `old` (what isolates the lane
-    // groups of c2_align_diagx_kernel from each other).  expect: lanes 31 -> -99, 32 (shr) / 30 (shl) -> -7
-    int r = -99, l = -99;
-    C2_LANES_ACTIVE_BEGIN(lane != 31)
-        r = c2_shr1(-7, lane * 3 + 1);
-        l = c2_shl1(-7, lane * 3 + 1);
-    C2_LANES_ACTIVE_END()
-    out[192 + lane] = r;
-    out[256 + lane] = l;
-    // the form the diagonal kernels use: bound_ctrl set, folded into an add (v_add_u32_dpp) -- a lane without a source
-    // (wavefront end, or source switched off in EXEC) must read 0.  expect 1000 in lanes 0 and 32 (shr) / 63 and 30 (shl)
-    int rz = -99, lz = -99;
-    int k1000 = 1000;
-    C2_KEEP_IN_VGPR(k1000);
-    C2_LANES_ACTIVE_BEGIN(lane != 31)
-        rz = c2_shr1z(lane * 3 + 1) + k1000;
-        lz = c2_shl1z(lane * 3 + 1) + k1000;
-    C2_LANES_ACTIVE_END()
-    out[320 + lane] = rz;
-    out[384 + lane] = lz;
-}
-
-// ... and of the row forms (c2_rshr1z / c2_rshl1z: the hand-off of the 16-lane groups of c2_align_diagp_kernel<8>), folded into an
-// add like the kernels use them: out[lane] = value of lane - 1 (0 at the start of a row of 16) + 1000, out[64 + lane] = value of
-// lane + 1 (0 at the end of a row) + 1000.
-__global__ __launch_bounds__(64) void c2_selftest_rows_kernel(int* out)
-{
-    const int lane = threadIdx.x;
-    int k1000 = 1000;
-    C2_KEEP_IN_VGPR(k1000);
-    out[lane] = c2_rshr1z(lane * 3 + 1) + k1000;
-    out[64 + lane] = c2_rshl1z(lane * 3 + 1) + k1000;
-}
-
-// =====================================================================================
-// The seed test of get_new_variant_object (CRISPRessoCORE.py:656-687) for a batch of reads that are already on the device:
-// found_fw / found_rc = how many of the reference's first n seeds (forward / reverse complement) occur in the read (Python `in`:
-// the empty seed always does, a seed longer than the read never); plan = 0 forward only (found_fw > seed_min and found_rc == 0),
-// 1 reverse complement only (found_fw == 0 and found_rc > seed_min), else 2 (both strands are aligned).  One wavefront per read:
-// the read goes to LDS, lane p tests the window that starts at p (+64, +128, ...), a ballot says whether any window matched.
-// Same answers as the host's c2_strand_plan (tests/test_select_emulated.py, test_gpu_parity.py).
-// =====================================================================================
-__global__ __launch_bounds__(256) void c2_strand_plan_kernel(c2_strand_args A)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t row = c2_strand_row_bytes(A.max_read_len);
-    unsigned char* sRead = c2_smem + (uint32_t)wave * row;
-    unsigned char* sSeeds = c2_smem + 4u * row;                      // [n_refs][2][max_seeds][C2_SEED_SLOT], zero padded (seed_table)
-    if (A.seed_table) {
-        const int n_slots = A.n_refs * 2 * A.max_seeds;
-        for (int e = threadIdx.x; e < n_slots * (int)(C2_SEED_SLOT / 4u); e += blockDim.x) ((uint32_t*)sSeeds)[e] = 0u;
-        __syncthreads();
-        for (int e = threadIdx.x; e < n_slots * (int)C2_SEED_SLOT; e += blockDim.x) {
-            const int slot = e / (int)C2_SEED_SLOT, k = e % (int)C2_SEED_SLOT;
-            if (k < A.seed_len[slot]) sSeeds[e] = A.seed_blob[A.seed_off[slot] + k];
-        }
-        __syncthreads();
-    }
-    for (uint64_t i = (uint64_t)blockIdx.x * 4u + (uint64_t)wave; i < A.n_reads; i += (uint64_t)gridDim.x * 4u) {
-        const uint64_t o = A.offsets[i];
-        const int Lj = (int)(A.offsets[i + 1] - o);
-        for (int k = lane; k < Lj; k += 64) sRead[k] = A.reads[o + (uint64_t)k];
-        __builtin_amdgcn_wave_barrier();
-        for (int r = 0; r < A.n_refs; ++r) {
-            int found[2] = {0, 0};
-            const int ns = A.n_seeds[r];
-            for (int st = 0; st < 2; ++st)
-                for (int q = 0; q < ns; ++q) {
-                    const int idx = (r * 2 + st) * A.max_seeds + q;
-                    const int len = A.seed_len[idx];
-                    if (len == 0) { ++found[st]; continue; }
-                    if (len > Lj) continue;
-                    bool any = false;
-                    if (A.seed_table) {
-                        // four bytes of the seed against four bytes of the window at a time: the window dword at byte p + 4 j comes out of the two
-                        // aligned LDS dwords around it (v_alignbyte); the seed's dwords are read once (same address in every lane: a broadcast)
-                        const uint32_t* sd = (const uint32_t*)(sSeeds + (uint32_t)idx * C2_SEED_SLOT);
-                        const int nd = (len + 3) >> 2;
-                        const uint32_t last_mask = (len & 3) ? ((1u << (8 * (len & 3))) - 1u) : 0xffffffffu;
-                        const uint32_t* sRead32 = (const uint32_t*)sRead;
-                        for (int base = 0; base + len <= Lj && !any; base += 64) {
-                            const int p = base + lane;
-                            const bool in = p + len <= Lj;
-                            const int pc = in ? p : 0;                 // (a lane without a window reads the first one: inside the row)
-                            uint32_t diff = 0;
-                            for (int j = 0; j < nd; ++j) {
-                                const int b = pc + 4 * j;
-                                const uint32_t lo = sRead32[b >> 2], hi = sRead32[(b >> 2) + 1];
-                                const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(b & 3));
-                                diff |= (w ^ sd[j]) & (j == nd - 1 ? last_mask : 0xffffffffu);
-                            }
-                            any = __ballot(in && diff == 0u) != 0ull;
-                        }
-                    } else {
-                        const uint8_t* seed = A.seed_blob + A.seed_off[idx];
-                        for (int base = 0; base + len <= Lj && !any; base += 64) {
-                            const int p = base + lane;
-                            bool ok = p + len <= Lj;
-                            for (int k = 0; k < len && __ballot(ok) != 0ull; ++k) ok = ok && sRead[ok ? p + k : 0] == seed[k];
-                            any = __ballot(ok) != 0ull;
-                        }
-                    }
-                    if (any) ++found[st];
-                }
-            if (lane == 0)
-                A.plan[i * (uint64_t)A.n_refs + (uint64_t)r] = (found[0] > A.seed_min && found[1] == 0) ? 0 : (found[0] == 0 && found[1] > A.seed_min) ? 1 : 2;
-        }
-        __builtin_amdgcn_wave_barrier();                            // (the next read overwrites the row)
-    }
-}
-
-// =====================================================================================
-// Strand and best-reference choice of get_new_variant_object on the device (CRISPRessoCORE.py:683 strand: strict '>';
-// :697-707 best reference: first strictly better score that also exceeds refs[name]['min_aln_score'], later equal scores
-// join; :710 aligned iff the best score is > 0; :779-785 ambiguous reads), one lane per read over its k records.
-// The reference compares Python floats round(100*matches/float(len), 3); here the same order on integers: c2_mscore is
-// 1000 x that rounded value.  100000*m/T is a multiple of 1/T, so unless it is an exact tie it lies >= 1/(2T) from the
-// rounding boundary -- far more than the double's error -- and an exact tie has the form odd/2000 = x with T a multiple
-// of 64 * 5^j (T < 8000): x is then a dyadic rational, the double is exact and Python rounds half to even.  The host
-// refuses alignments of 8000 columns and more (c2_select_best_device).
-// =====================================================================================
-__host__ __device__ inline uint32_t c2_mscore(const uint32_t matches, const uint32_t T) {
-    if (T == 0) return 0;
-    const uint64_t num = 100000ull * matches;                        // < 2^33
-    // floor(num / T) through one double division (exact operands; the quotient may be off by one): corrected with integers
-    int64_t q = (int64_t)((double)num / (double)T);
-    int64_t r = (int64_t)num - q * (int64_t)T;
-    if (r < 0) { --q; r += T; } else if (r >= (int64_t)T) { ++q; r -= T; }
-    if (2 * r > (int64_t)T) ++q; else if (2 * r == (int64_t)T) q += (q & 1);
-    return (uint32_t)q;
-}
-
-__global__ __launch_bounds__(256) void c2_select_best_kernel(c2_select_args A)
-{
-    const uint64_t read = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    unsigned long long st[C2_SEL_STATS];
-#pragma unroll
-    for (int q = 0; q < C2_SEL_STATS; ++q) st[q] = 0;
-    if (read < A.n_reads) {
-        const int k = A.n_refs;
-        const int W = (k + 63) >> 6;                                         // 64-bit words of a read's masks (bit r of word r / 64: reference r)
-        // the score the choice compares for (read, reference r), and whether it is the reverse-complement batch's (:683)
-        auto score_of = [&](const int r, bool& second, const bool tally) -> long long {
-            const uint64_t t = read * (uint64_t)k + (uint64_t)r;
-            const c2_aln_record* rec = A.records + t;
-            // (what the choice needs of a record -- length, matches, status -- with two loads instead of one per field)
-            const unsigned w0 = ((const unsigned*)rec)[0], w5 = ((const unsigned*)rec)[5];
-            const unsigned rstatus = w5 >> 24;
-            if (tally && rstatus != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rstatus; }
-            long long ms = (long long)c2_mscore(w0 >> 16, w0 & 0xffffu);
-            second = false;
-            if (A.records2 && A.slot2) {
-                const int sl = A.slot2[t];
-                if (sl >= 0) {
-                    const c2_aln_record* rec2 = A.records2 + sl;
-                    if (tally && rec2->status != 0) { st[C2_SEL_N_BAD_STATUS] += 1; st[C2_SEL_FIRST_BAD_STATUS] = rec2->status; }
-                    const long long ms2 = (long long)c2_mscore(rec2->matches, rec2->aln_len);
-                    if (ms2 > ms) { ms = ms2; second = true; }              // :683  if (rvscore > fwscore)
-                }
-            }
-            return ms;
-        };
-        // pass 1: the best score, where it was set, how many references share it, the last of them.  The reference's loop
-        // (:697 `if score > best_match_score and score > min_aln_score: best_match_names = [name]`, :703 `elif score == best_match_score:
-        // append`) makes reference r a best match iff its score equals the final best AND r is not in front of the reference that set
-        // it (one in front with that score did not pass its threshold, or it would have set the best itself).
-        long long best = -1;
-        int first = -1, last = -1, nb = 0; bool last2 = false;
-        for (int r = 0; r < k; ++r) {
-            bool second;
-            const long long ms = score_of(r, second, true);
-            if (ms > best && ms >= (long long)A.min_mscore[r]) { best = ms; first = r; nb = 1; last = r; last2 = second; }   // :697
-            else if (ms == best) { ++nb; last = r; last2 = second; }                                                           // :703
-        }
-        const bool aligned = best > 0;                                       // :710
-        const bool ambiguous = aligned && nb > 1 && A.mode != C2_SEL_MODE_FIRST && A.mode != C2_SEL_MODE_EXPAND;
-        if (A.flags) A.flags[read] = (uint8_t)((aligned ? C2_SEL_FLAG_ALIGNED : 0) | (ambiguous ? C2_SEL_FLAG_AMBIGUOUS : 0));
-        // pass 2: the masks, a word at a time, and the weight of every alignment in the count pass
-        if (A.member || A.use2 || A.weights) {
-            const uint32_t w = A.counts ? A.counts[read] : 1u;
-            unsigned long long member = 0, use2 = 0;
-            for (int r = 0; r < k; ++r) {
-                bool second;
-                const long long ms = score_of(r, second, false);
-                const bool m = aligned && r >= first && ms == best;
-                // counted: every best match (one of them, or --expand_ambiguous_alignments), the first one
-                // (--assign_ambiguous_alignments_to_first_reference), none when the read is ambiguous
-                const bool c = m && (nb == 1 || A.mode == C2_SEL_MODE_EXPAND || (A.mode == C2_SEL_MODE_FIRST && r == first));
-                if (m) member |= 1ull << (r & 63);
-                if (second) use2 |= 1ull << (r & 63);
-                if (A.weights) {
-                    const uint64_t t = read * (uint64_t)k + (uint64_t)r;
-                    A.weights[t] = (c && !second) ? w : 0u;
-                    if (A.weights2 && A.slot2 && A.slot2[t] >= 0) A.weights2[A.slot2[t]] = (c && second) ? w : 0u;
-                }
-                if ((r & 63) == 63 || r == k - 1) {
-                    if (A.member) A.member[read * (uint64_t)W + (uint64_t)(r >> 6)] = member;
-                    if (A.use2) A.use2[read * (uint64_t)W + (uint64_t)(r >> 6)] = use2;
-                    member = 0; use2 = 0;
-                }
-            }
-        }
-        // aln_stats of process_fastq (:1974-1979): payload of the LAST best match, raw multiplicity
-        const unsigned long long raw = A.raw_counts ? (unsigned long long)A.raw_counts[read] : 1ull;
-        if (aligned) {
-            st[C2_SEL_N_COMPUTED_ALN] = 1; st[C2_SEL_N_CACHED_ALN] = raw - 1ull;
-            const c2_aln_record* rec = (last2 ? A.records2 + A.slot2[read * (uint64_t)k + (uint64_t)last] : A.records + read * (uint64_t)k + (uint64_t)last);
-            const unsigned long long sub_all = rec->all_substitutions, sub_win = rec->substitution_n;
-            const unsigned long long total = (unsigned long long)rec->all_insertion_events + rec->all_deletion_bases + sub_all;
-            const unsigned long long in_win = sub_win + rec->deletion_n + rec->insertion_n;
-            st[C2_SEL_N_GLOBAL_SUBS] = sub_all * raw;
-            st[C2_SEL_N_SUBS_OUTSIDE_WINDOW] = (sub_all - sub_win) * raw;
-            st[C2_SEL_N_MODS_IN_WINDOW] = in_win * raw;
-            st[C2_SEL_N_MODS_OUTSIDE_WINDOW] = (total - in_win) * raw;       // (two's complement like the host's int64 sum)
-            st[C2_SEL_N_READS_IRREGULAR_ENDS] = (unsigned long long)rec->irregular_ends * raw;
-        } else {
-            st[C2_SEL_N_COMPUTED_NOTALN] = 1; st[C2_SEL_N_CACHED_NOTALN] = raw - 1ull;
-        }
-    }
-    if (A.stats) {
-        // block sums in LDS (a thread adds only what is non-zero: a handful of LDS atomics), then one global atomic per statistic
-        // per block; FIRST_BAD_STATUS: any non-zero value will do (plain store)
-        unsigned long long* blk = (unsigned long long*)c2_smem;       // (launched with C2_SEL_STATS * 8 bytes of dynamic LDS)
-        if (threadIdx.x < C2_SEL_STATS) blk[threadIdx.x] = 0ull;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < C2_SEL_STATS; ++q) {
-            if (q == C2_SEL_FIRST_BAD_STATUS) { if (st[q] != 0) A.stats[q] = st[q]; continue; }
-            if (st[q] != 0) atomicAdd(&blk[q], st[q]);
-        }
-        __syncthreads();
-        if (threadIdx.x < C2_SEL_STATS && threadIdx.x != C2_SEL_FIRST_BAD_STATUS && blk[threadIdx.x] != 0) atomicAdd(A.stats + threadIdx.x, blk[threadIdx.x]);
-    }
-}
-
-// =====================================================================================
-// Per-amplicon count vectors: the device side of the reference's "Quantifying indels/substitutions"
-// loop (CRISPRessoCORE.py:3964-4115, non-coding case) and of process_fastq's aln_stats (:1974-1979).
-// Input: the aligned strings and records the align kernel left in HBM, plus per-task weights
-// (read multiplicity; 0 = read not assigned to this reference).  One wavefront per alignment;
-// every workgroup accumulates into a private int32 copy of one reference's block in LDS (ds_add),
-// and flushes it to the int64 tensor in HBM with one atomic per non-zero entry.  The tensor is what
-// the multi-GPU path reduces with one RCCL all-reduce.
-// =====================================================================================
-__device__ __forceinline__ int c2_wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
-    return v;
-}
-
-// all_base_count vector of a read / reference character (CRISPRessoCORE.py:4075-4081), or -1.  Without a branch: the compiler turned
-// the chain of comparisons this used to be into a tree of DIVERGENT branches -- ~50 scalar instructions of exec-mask bookkeeping per call,
-// two calls per mismatching column -- and the count kernels are bound by the CU's one scalar unit (244 SALU per alignment,
-// profiles/r03/README.md).  (ch >> 1) & 7 is a perfect hash of A C T G - N (0 1 2 3 6 7); the byte tables are 64-bit constants.
-__device__ __forceinline__ int c2_base_vector(const unsigned char ch) {
-    const unsigned sh = (((unsigned)ch >> 1) & 7u) * 8u;
-    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', '-', 'N') >> sh) & 0xffu;
-    const unsigned v = (unsigned)(C2_BYTE_TABLE(C2_V_BASE_A, C2_V_BASE_C, C2_V_BASE_T, C2_V_BASE_G, C2_V_BASE_GAP, C2_V_BASE_N) >> sh) & 0xffu;
-    return is == (unsigned)ch ? (int)v : -1;
-}
-// substitution_count_vectors of a read base (:4049-4054): A C G T only, else -1
-__device__ __forceinline__ int c2_sub_base_vector(const unsigned char ch) {
-    const unsigned sh = (((unsigned)ch >> 1) & 7u) * 8u;
-    const unsigned is = (unsigned)(C2_BYTE_TABLE('A', 'C', 'T', 'G', 0, 0) >> sh) & 0xffu;
-    const unsigned v = (unsigned)(C2_BYTE_TABLE(C2_V_ALL_SUB_BASE_A, C2_V_ALL_SUB_BASE_C, C2_V_ALL_SUB_BASE_T, C2_V_ALL_SUB_BASE_G, 0, 0) >> sh) & 0xffu;
-    return (ch != 0 && is == (unsigned)ch) ? (int)v : -1;
-}
-
-// Tasks grouped by reference for the count kernel (a chunk of consecutive positions then holds one or two references
-// instead of dozens: with 96 interleaved amplicons the LDS block would be flushed for almost every task).  Counting sort
-// in three tiny launches: histogram of ref_id, exclusive scan (one wavefront), scatter.  The order inside a reference is
-// whatever the atomics give -- the sums do not depend on it.
-// One atomic per distinct reference per wavefront (wave-aggregated): lanes with the same ref_id are found with ballots,
-// their leader adds the group's size, every lane gets base + its rank inside the group.  Returns the lane's slot (or -1).
-__device__ __forceinline__ long long c2_grouped_add(uint32_t* counters, const bool active, const unsigned key, const int lane) {
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    unsigned long long todo = __ballot(active);
-    long long slot = -1;
-    for (int round = 0; round < 4 && todo; ++round) {       // the big groups; what is left after four rounds is scattered
-        const int leader = __builtin_ctzll(todo);
-        const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
-        const unsigned long long grp = __ballot(active && key == k0) & todo;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(counters + k0, (unsigned)__popcll(grp));
-        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-        if ((grp >> lane) & 1ull) slot = (long long)base + __popcll(grp & lt);
-        todo &= ~grp;
-    }
-    if ((todo >> lane) & 1ull) slot = (long long)atomicAdd(counters + key, 1u);
-    return slot;
-}
-
-__global__ __launch_bounds__(256) void c2_ref_histogram_kernel(const c2_aln_record* records, uint64_t n, uint32_t* hist)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const bool active = t < n;
-    const unsigned key = active ? (unsigned)records[t].ref_id : 0u;
-    (void)c2_grouped_add(hist, active, key, (int)(threadIdx.x & 63));
-}
-
-__global__ __launch_bounds__(64) void c2_ref_scan_kernel(uint32_t* hist, int n_refs)     // hist -> exclusive prefix, in place
-{
-    const int lane = threadIdx.x;
-    int carry = 0;
-    for (int base = 0; base < n_refs; base += 64) {
-        const int k = base + lane;
-        const int x = (k < n_refs) ? (int)hist[k] : 0;
-        const int s = c2_wave_incl_scan(x, lane) + carry;
-        if (k < n_refs) hist[k] = (uint32_t)(s - x);
-        carry = __shfl(s, 63);
-    }
-}
-
-__global__ __launch_bounds__(256) void c2_ref_scatter_kernel(const c2_aln_record* records, uint64_t n, uint32_t* cursor, uint32_t* order)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const bool active = t < n;
-    const unsigned key = active ? (unsigned)records[t].ref_id : 0u;
-    const long long slot = c2_grouped_add(cursor, active, key, (int)(threadIdx.x & 63));
-    if (active) order[slot] = (uint32_t)t;
-}
-
-// (launch bounds: 5 workgroups per CU = 5 waves per SIMD = 96 VGPRs.  Left alone the compiler takes 101 -- 99 + 2 that hold 103 spilled
-// SGPRs -- and the kernel runs at 4 waves per SIMD, 8 % slower; with the bound it is 8 % slower than a 96-VGPR build WITHOUT the bound
-// would be (measured with round 1's source, which fits by itself: the occupancy target changes the schedule), but that is not on offer.)
-// HBM: the int32 accumulator block of the workgroup lives in global memory (A.block_scratch) instead of LDS -- amplicons beyond
-// ~1,650 bp, whose block does not fit 160 KB.  Its updates are the same atomics (they execute in L2); what reads the block with plain
-// loads -- the flush -- first drops the CU's L1 lines (agent-scope fence), and the flush takes every entry with an exchange.
-template <bool HBM>
-__device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
-{
-    // C2_CNT_WAVES wavefronts share one LDS block (the block is what limits residency, so sharing it multiplies the
-    // waves per CU); each wavefront walks one alignment at a time.  The workgroup takes C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE
-    // consecutive tasks per atomic; lane k of wave v holds the record of task base + k * C2_CNT_WAVES + v.
-    constexpr int NT = 64 * C2_CNT_WAVES, K = C2_CNT_TASKS_PER_WAVE, CHUNK = C2_CNT_WAVES * K, NONE = 0x7fffffff;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int* acc = HBM ? A.block_scratch + (size_t)blockIdx.x * (size_t)A.block_ints : (int*)c2_smem;
-    const int VL = A.lmax + 1;                                  // vector length incl. the end slot of the difference arrays
-    const int o_sc = C2_CNT_VECTORS * VL, o_h = o_sc + C2_CNT_SCALARS;
-    const int per_ref = o_h + C2_CNT_HISTS * A.hl;
-    auto block_barrier = [&]() {                                // a barrier after which plain loads see the block's latest values
-        __syncthreads();
-        if (HBM) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    };
-    // cov: difference array over the reference positions of "weight of the alignments whose read base EQUALS the reference's here" --
-    // runs of matching columns add +w at their first position and -w behind their last; flush() integrates it and adds every
-    // position's total to the count vector of the reference's own base there (an LDS-only vector, not part of the tensor)
-    int* cov = HBM ? (int*)c2_smem : acc + per_ref;
-    int* ctl = cov + VL;                                        // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
-    uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
-    for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
-    for (int k = tid; k < VL; k += NT) cov[k] = 0;
-    block_barrier();
-    const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
-    const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
-    const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);   // string rows readable as dwords
-    const bool legacy = A.flags & C2_CNT_FLAG_LEGACY;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    int cur_ref = -1;                                           // workgroup-uniform, like everything that guards a barrier
-    unsigned wsum = 0;                                          // load accumulated since the last flush (int32 safety, see C2_CNT_LOAD_BUDGET)
-    int Li = 0, par = 0;
-
-    // flush the LDS block of cur_ref into the int64 tensor (workgroup-wide)
-    auto flush = [&]() {
-        if (cur_ref < 0) return;
-        block_barrier();
-        // deletion vectors were accumulated as difference arrays (start += x, end -= x): integrate them first
-        if (wave < 3) {
-            int* d = wave == 2 ? cov : acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
-            int carry = 0;
-            for (int base = 0; base < VL; base += 64) {
-                const int k = base + lane;
-                const int x = (k < VL) ? d[k] : 0;
-                const int s = c2_wave_incl_scan(x, lane) + carry;
-                if (k < VL) d[k] = s;
-                carry = __shfl(s, 63);
-            }
-        }
-        block_barrier();
-        {   // gap-free reads added only their deviations from the reference (see the column walk): every reference position
-            // gets their total weight on the vector of its own base
-            const int g = acc[o_sc + C2_S_RESERVED0];
-            block_barrier();
-            {   // ... plus, per position, the weight of the alignments with gaps whose read matches the reference there (cov, integrated above)
-                const uint8_t* rs = A.refs[cur_ref].seq;
-                for (int c = tid; c < VL; c += NT) {
-                    const int x = g + cov[c];
-                    cov[c] = 0;
-                    if (c < Li && x != 0) {
-                        const int bv = c2_base_vector(rs[c]);
-                        if (bv >= 0) acc[bv * VL + c] += x;
-                    }
-                }
-                if (tid == 0) acc[o_sc + C2_S_RESERVED0] = 0;
-            }
-        }
-        block_barrier();
-        long long* out = A.counts + (size_t)cur_ref * per_ref;
-        for (int k = tid; k < per_ref; k += NT) {
-            const int x = HBM ? atomicExch(acc + k, 0) : acc[k];
-            if (x != 0) { atomicAdd((unsigned long long*)(out + k), (unsigned long long)(long long)x); if (!HBM) acc[k] = 0; }
-        }
-        wsum = 0;
-        block_barrier();
-    };
-
-    for (;;) {
-        if (tid == 0) {
-            const unsigned long long b = atomicAdd(A.work_counter, (unsigned long long)CHUNK);
-            ctl[0] = (int)(unsigned)(b & 0xffffffffu); ctl[1] = (int)(unsigned)(b >> 32);
-        }
-        __syncthreads();
-        const uint64_t chunk_base = (uint64_t)(unsigned)ctl[0] | ((uint64_t)(unsigned)ctl[1] << 32);
-        if (chunk_base >= A.n_tasks) break;
-        // ---- the records of this wave's K tasks, one per lane; selection test of CRISPRessoCORE.py:697 per lane
-        const uint64_t my_pos = chunk_base + (uint64_t)((lane & (K - 1)) * C2_CNT_WAVES + wave);
-        uint64_t my_task = my_pos;
-        unsigned d0 = 0, d1 = 0, d2 = 0, d4 = 0, d5 = 0, d6 = 0; int v_w = 0;
-        bool sel = false;
-        if (lane < K && my_pos < A.n_tasks) {
-            if (A.order) my_task = (uint64_t)A.order[my_pos];            // tasks grouped by reference: few flushes per chunk
-            else if (A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) {            // all-references batch (task = read * n_refs + reference): the same grouping by arithmetic
-                const uint64_t nr = A.n_tasks / (uint64_t)A.n_refs;
-                const uint64_t r = my_pos / nr;
-                my_task = (my_pos - r * nr) * (uint64_t)A.n_refs + r;
-            }
-            const unsigned wq = A.weights ? A.weights[my_task] : 1u;
-            v_w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
-            if (v_w > 0) {                                               // (an alignment that is not counted is not even read: most of an all-references batch)
-                const unsigned* rp = (const unsigned*)(A.records + my_task);
-                d0 = rp[0]; d1 = rp[1]; d2 = rp[2]; d4 = rp[4]; d5 = rp[5]; d6 = rp[6];
-                if (legacy && (rp[3] >> 16) != 0u) d4 |= 0x80000000u;         // legacy: a deletion event can have NO positions (all_deletion_bases 0): mark "has a deletion column" in the top bit
-                const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16), ref = (int)(d6 >> 16);
-                sel = ((d5 >> 24) == 0) && (T > 0);
-                if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
-            }
-        }
-        unsigned pending = (unsigned)__ballot(sel);
-        // Everything an alignment adds to an int32 entry of the block is its weight times a count of its own columns -- at most
-        // w * aln_len, its LOAD.  The loads since the last flush stay within C2_CNT_LOAD_BUDGET (2^30), so no entry can wrap;
-        // saturating sums decide the flushes before anything is added.
-        // (heavy chunks: v_w is what of the task's weight is still to be added; `counted`: lanes whose alignment has been counted once)
-        unsigned counted = 0;
-        {   // (a task above ~2^26 makes the chunk heavy by itself; the others add up in 32 bits: 32 x 2^26 = 2^31.  The size test is
-            // done in float -- 6.0e7 is safely below 2^26 for its rounding -- so that no 64-bit product has to be formed)
-            const unsigned my_T = (d0 & 0xffffu) ? (d0 & 0xffffu) : 1u;
-            const bool big = sel && (float)v_w * (float)my_T > 6.0e7f;
-            unsigned wv = (sel && !big) ? (unsigned)v_w * my_T : 0u;
-#pragma unroll
-            for (int d = 1; d < K; d <<= 1) wv += (unsigned)__shfl_xor((int)wv, d);
-            if (__ballot(big) != 0ull || wv > C2_CNT_LOAD_BUDGET) wv = C2_CNT_LOAD_BUDGET + 1u;
-            if (lane == 0) ctl[2 + wave] = (int)wv;
-        }
-        __syncthreads();
-        unsigned long long chunk_sum = 0;
-#pragma unroll
-        for (int v = 0; v < C2_CNT_WAVES; ++v) chunk_sum += (unsigned)ctl[2 + v];
-        const unsigned chunk_w = chunk_sum > C2_CNT_LOAD_BUDGET ? C2_CNT_LOAD_BUDGET + 1u : (unsigned)chunk_sum;
-        // a chunk heavier than the budget is processed one task at a time, its weight in pieces whose load fits, with a flush after each
-        const bool heavy = chunk_w > C2_CNT_LOAD_BUDGET;
-        if (!heavy && wsum + chunk_w > C2_CNT_LOAD_BUDGET) flush();
-        wsum += heavy ? 0u : chunk_w;
-        for (;;) {
-            // lowest pending task of the workgroup -> the reference whose tasks are processed in this round
-            const int first = pending ? __builtin_ctz(pending) : -1;
-            int fref = NONE, ftask = NONE;
-            if (first >= 0) { fref = (int)((unsigned)__builtin_amdgcn_readlane((int)d6, first) >> 16); ftask = first * C2_CNT_WAVES + wave; }
-            if (lane == 0) { ctl[16 + par * 2 * C2_CNT_WAVES + wave * 2] = fref; ctl[16 + par * 2 * C2_CNT_WAVES + wave * 2 + 1] = ftask; }
-            __syncthreads();
-            int tref = NONE, ttask = NONE;
-#pragma unroll
-            for (int v = 0; v < C2_CNT_WAVES; ++v) {
-                const int t = ctl[16 + par * 2 * C2_CNT_WAVES + v * 2 + 1];
-                if (t < ttask) { ttask = t; tref = ctl[16 + par * 2 * C2_CNT_WAVES + v * 2]; }
-            }
-            par ^= 1;
-            if (ttask == NONE) break;
-            if (tref != cur_ref) {
-                flush();
-                cur_ref = tref; Li = A.refs[tref].len;
-                const uint16_t* g = A.refs[tref].inc_prefix;
-                for (int k = tid; k < Li + 2; k += NT) incp[k] = g[k];
-                __syncthreads();
-            }
-            unsigned todo = heavy ? ((first >= 0 && ftask == ttask) ? (1u << first) : 0u) : pending;
-            // ---- scalar counters and histograms of ALL tasks of this round at once: lane k holds the record of its own task, so
-            //      every lane adds its task's contributions (LDS atomics; ~20 instructions per round instead of per task).
-            //      aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979), then the tallies of :3996-4072.
-            const bool mine = lane < K && ((todo >> lane) & 1u) && (int)(d6 >> 16) == tref;
-            // the weight this round adds for the lane's task: all of it, or (heavy) a piece whose load fits the budget
-            // heavy chunks: v_w becomes the piece of the weight this round adds, the remainder waits in LDS (no register of the
-            // common path is spent on it: the kernel sits at 96 VGPRs = 5 waves per SIMD)
-            if (heavy && mine) {
-                const unsigned my_T = d0 & 0xffffu;
-                const int piece = (int)(C2_CNT_LOAD_BUDGET / (my_T > 0 ? my_T : 1u));
-                const int rest = v_w > piece ? v_w - piece : 0;
-                ctl[C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1))] = rest;
-                v_w -= rest;
-            }
-            {   // an alignment whose two strings are the reference itself (no gap column, every column a match) adds nothing but
-                // its weight to the "spread over the reference's bases" scalar: done here, its strings are never read
-                const int T_ = (int)(d0 & 0xffffu), matches_ = (int)(d0 >> 16);
-                const bool perfect = mine && T_ == Li && matches_ == T_ && (d4 >> 16) == 0u && d1 == 0u;
-                if (perfect) atomicAdd(acc + o_sc + C2_S_RESERVED0, v_w);
-                const unsigned pm = (unsigned)__ballot(perfect);
-                todo &= ~pm; pending &= ~pm;
-            }
-            if (mine) {
-                const int w = v_w;
-                const int insertion_n = (int)(d1 & 0xffffu), deletion_n = (int)(d1 >> 16), substitution_n = (int)(d2 & 0xffffu);
-                const int all_ins = (int)(d2 >> 16), all_del_bases = (int)((d4 >> 16) & 0x7fffu), all_sub = (int)(d5 & 0xffffu);
-                const bool irregular_ends = (d5 >> 16) & 0xffu;
-                const int total_mods = all_ins + all_del_bases + all_sub;                               // :741
-                const int in_win = substitution_n + deletion_n + insertion_n;                           // :742
-                int* scal = acc + o_sc;
-                atomicAdd(scal + C2_S_N_GLOBAL_SUBS, all_sub * w);
-                atomicAdd(scal + C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - substitution_n) * w);
-                atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
-                atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
-                if (irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
-                if (!((counted >> lane) & 1u)) atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);           // (once per alignment, not per piece of a heavy weight)
-                if (discard && (deletion_n > 0 || insertion_n > 0)) atomicAdd(scal + C2_S_DISCARDED, w);                     // :3996-4000
-                else {
-                    const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
-                    const bool modified = has_del || has_ins || has_sub;
-                    atomicAdd(scal + C2_S_TOTAL, w);
-                    atomicAdd(scal + (modified ? C2_S_MODIFIED : C2_S_UNMODIFIED), w);          // :746-760, :4003-4006
-                    if (has_ins) atomicAdd(scal + C2_S_INSERTION, w);
-                    if (has_del) atomicAdd(scal + C2_S_DELETION, w);
-                    if (has_sub) atomicAdd(scal + C2_S_SUBSTITUTION, w);
-                    int combo = -1;                                                             // :4058-4072
-                    if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
-                                                 : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
-                    else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
-                    else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
-                    if (combo >= 0) atomicAdd(scal + combo, w);
-                    if (!ign_ins) atomicAdd(acc + o_h + C2_H_INSERTED_N * A.hl + insertion_n, w);   // :4020
-                    if (!ign_del) atomicAdd(acc + o_h + C2_H_DELETED_N * A.hl + deletion_n, w);     // :4030
-                    if (!ign_sub) atomicAdd(acc + o_h + C2_H_SUBSTITUTED_N * A.hl + substitution_n, w);   // :4043
-                    const int eff = Li + (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n);   // :4010-4037
-                    atomicAdd(acc + o_h + C2_H_EFFECTIVE_LEN * A.hl + eff, w);
-                }
-            }
-            while (todo) {
-                const int kk = __builtin_ctz(todo);
-                todo &= todo - 1;
-                const unsigned r6 = (unsigned)__builtin_amdgcn_readlane((int)d6, kk);
-                if ((int)(r6 >> 16) != tref) continue;
-                pending &= ~(1u << kk);
-                const uint64_t task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task & 0xffffffffull), kk) |
-                                      ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task >> 32), kk) << 32);
-                const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)d0, kk), r1 = (unsigned)__builtin_amdgcn_readlane((int)d1, kk);
-                const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)d2, kk), r4 = (unsigned)__builtin_amdgcn_readlane((int)d4, kk);
-                const unsigned r5 = (unsigned)__builtin_amdgcn_readlane((int)d5, kk);
-                const int w = __builtin_amdgcn_readlane(v_w, kk);
-                const int T = (int)(r0 & 0xffffu);
-                const int insertion_n = (int)(r1 & 0xffffu), deletion_n = (int)(r1 >> 16), substitution_n = (int)(r2 & 0xffffu);
-                const int all_ins = (int)(r2 >> 16), all_del_bases = (int)((r4 >> 16) & 0x7fffu), all_sub = (int)(r5 & 0xffffu);
-                const bool any_del_column = (r4 >> 16) != 0u;                                      // (positions, or the legacy marker)
-                const bool irregular_ends = (r5 >> 16) & 0xffu;
-                const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride;
-                const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride;
-                if (discard && (deletion_n > 0 || insertion_n > 0)) continue;                      // counted above; no vectors (:3996-4000)
-                if (rows_aligned && T == Li && !any_del_column) {
-                    // No gap column in either string (the usual read).  Four columns per lane: read and reference as dwords, the bytes
-                    // in which they differ by the "has a zero byte" trick on their XOR; only those add anything (the DEVIATIONS from
-                    // "the reference's own base, once per read": see the byte-wise walk below)
-                    for (int base = 0; base < T; base += 256) {
-                        const int p = base + 4 * lane, nb = T - p;
-                        unsigned rdw = 0, rfw = 0;
-                        if (nb > 0) { rdw = ((const unsigned*)R_)[p >> 2]; rfw = ((const unsigned*)F_)[p >> 2]; }
-                        const unsigned valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
-                        const unsigned x = (rdw ^ rfw) & valid;
-                        unsigned mm = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
-                        while (mm) {
-                            const int b = __builtin_ctz(mm) >> 3;
-                            mm &= mm - 1u;
-                            const int c = p + b;
-                            const unsigned char rd = (unsigned char)(rdw >> (8 * b)), rfc = (unsigned char)(rfw >> (8 * b));
-                            const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
-                            if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
-                            if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
-                            if (rd != 'N') {
-                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
-                                if (!ign_sub) {
-                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
-                                    const int sv = c2_sub_base_vector(rd);                      // :4049-4054
-                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
-                                }
-                            }
-                        }
-                    }
-                    if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
-                    continue;
-                }
-                // first 256 columns of both strings: requested now, consumed by the column walk below
-                unsigned rd4 = 0, rf4 = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 64 * q + lane;
-                    if (c < T) { rd4 |= (unsigned)R_[c] << (8 * q); rf4 |= (unsigned)F_[c] << (8 * q); }
-                }
-                const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
-                const bool modified = has_del || has_ins || has_sub;
-                const bool len_block = modified;                                                // :4085 (no coding sequence)
-                // ---- column walk (same scan as the fused classifier), ds_add into the vectors
-                int idx_base = 0, last_rf = -1, last_rd = -1;
-                bool last_rf_close = false, last_rf_wclose = false;
-                if (T == Li && !any_del_column) {
-                    // No gap column in either string: the reference index of a column is the column, only substitutions can
-                    // occur, and the read's base counts differ from "the reference's own base, once per read" only where the
-                    // read differs from the reference.  So the walk adds the DEVIATIONS (+w on the read's base, -w on the
-                    // reference's) and the read's weight goes to one scalar that flush() spreads over the reference's bases.
-                    for (int base = 0; base < T; base += 64) {
-                        const int c = base + lane;
-                        const bool in = c < T;
-                        unsigned char rd, rfc;
-                        if (base < 256) { rd = in ? (unsigned char)((rd4 >> ((base >> 6) * 8)) & 0xffu) : 0; rfc = in ? (unsigned char)((rf4 >> ((base >> 6) * 8)) & 0xffu) : 0; }
-                        else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
-                        if (in && rd != rfc) {
-                            const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
-                            if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
-                            if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
-                            if (rd != 'N') {
-                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
-                                if (!ign_sub) {
-                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
-                                    const int sv = c2_sub_base_vector(rd);                      // :4049-4054
-                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
-                                }
-                            }
-                        }
-                    }
-                    if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
-                    continue;
-                }
-                for (int base = 0; base < T; base += 64) {
-                    const int c = base + lane;
-                    const bool in = c < T;
-                    unsigned char rd, rfc;
-                    if (base < 256) { rd = in ? (unsigned char)((rd4 >> ((base >> 6) * 8)) & 0xffu) : 0; rfc = in ? (unsigned char)((rf4 >> ((base >> 6) * 8)) & 0xffu) : 0; }
-                    else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
-                    const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
-                    const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
-                    const int idx = idx_base + __popcll(m_rf & lt);
-                    const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
-                    const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
-                    const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
-                    // all_base_count, :4075-4081.  Columns where the read's base IS the reference's (nearly all of them) are not added one
-                    // by one: a run of them adds its weight to the difference array `cov` at its two ends (see flush)
-                    const bool same = rf_ng && rd == rfc;
-                    {
-                        const unsigned long long m_same = __ballot(same);
-                        if (same) {
-                            if (lane == 0 || !((m_same >> (lane - 1)) & 1ull)) atomicAdd(cov + idx, w);
-                            if (lane == 63 || !((m_same >> (lane + 1)) & 1ull)) atomicAdd(cov + idx + 1, -w);
-                        }
-                    }
-                    if (rf_ng && !same) {
-                        const int bv = c2_base_vector(rd);
-                        if (bv >= 0) atomicAdd(acc + bv * VL + idx, w);
-                        if (!rd_ng) atomicAdd(acc + C2_V_ALL_DELETION * VL + idx, w);                   // :4028
-                    }
-                    const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';
-                    if (sub) {
-                        atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + idx, w);                           // :4040
-                        if (!ign_sub) {
-                            if (incp[idx + 1] != incp[idx]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + idx, w);   // :4044
-                            const int sv = c2_sub_base_vector(rd);                                      // :4049-4054
-                            if (sv >= 0) atomicAdd(acc + sv * VL + idx, w);
-                        }
-                    }
-                    {   // 64 columns without a gap and no gap run open in front of them (most chunks of an alignment with gaps): no insertion
-                        // or deletion can close here -- the rest of the body would find nothing
-                        const unsigned long long m_in = __ballot(in);
-                        if (m_rf == m_in && m_rd == m_in && last_rf == base - 1 && last_rd == base - 1) {
-                            const int cols = __popcll(m_in);
-                            idx_base += cols; last_rf = base + cols - 1; last_rd = last_rf;
-                            last_rf_close = false; last_rf_wclose = false;
-                            continue;
-                        }
-                    }
-                    // insertions: positions [idx-1, idx] of every event; numpy's fancy += counts a repeated position once (:4016, :4021)
-                    const bool ins_close = rf_ng && (prev_rf != c - 1) && idx > 0;
-                    const bool fl = ins_close && (incp[idx] != incp[idx - 1]), fr = ins_close && (incp[idx + 1] != incp[idx]);
-                    const bool ins_win = legacy ? (fl || fr) : (fl && fr);                              // pyx:121 / legacy pyx:284
-                    const unsigned long long m_ic = __ballot(ins_close), m_iw = __ballot(ins_win);
-                    if (ins_close) {
-                        const bool prev_close = (prev_rf >= base) ? ((m_ic >> (prev_rf - base)) & 1ull) : last_rf_close;
-                        const bool prev_wclose = (prev_rf >= base) ? ((m_iw >> (prev_rf - base)) & 1ull) : last_rf_wclose;
-                        atomicAdd(acc + C2_V_ALL_INSERTION_LEFT * VL + idx - 1, w);                     // :4017
-                        atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx, w);
-                        if (!prev_close) atomicAdd(acc + C2_V_ALL_INSERTION * VL + idx - 1, w);
-                        if (ins_win) {
-                            if (!ign_ins) {
-                                atomicAdd(acc + C2_V_INSERTION * VL + idx, w);
-                                if (!prev_wclose) atomicAdd(acc + C2_V_INSERTION * VL + idx - 1, w);
-                            }
-                            if (len_block) {                                                            // :4104-4106 (scalar index: repeats add twice)
-                                const int sz = (c - 1 - prev_rf) * w;
-                                atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx - 1, sz);
-                                atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + idx, sz);
-                            }
-                        }
-                    }
-                    // deletions that touch the window: range(start, end) as a difference array (integrated in flush)
-                    const bool del_close = rd_ng && (prev_rd != c - 1);
-                    if (del_close) {
-                        const int dlen = c - 1 - prev_rd;
-                        // legacy (pyx:253-258): a run that starts in column 0 or 1 gets reference start 0 -- position 0 joins its
-                        // positions although the read has a base there
-                        const int dstart = (legacy && prev_rd <= 0) ? 0 : idx - dlen;
-                        if (legacy && prev_rd == 0) atomicAdd(acc + C2_V_ALL_DELETION * VL + 0, w);
-                        if (incp[idx] != incp[dstart]) {
-                            if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + dstart, w); atomicAdd(acc + C2_V_DELETION * VL + idx, -w); }   // :4031
-                            if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + idx, -dlen * w); }   // :4114
-                        }
-                    }
-                    idx_base += __popcll(m_rf);
-                    if (m_rf) {
-                        const int hi = 63 - __clzll((long long)m_rf);
-                        last_rf = base + hi;
-                        last_rf_close = (m_ic >> hi) & 1ull;
-                        last_rf_wclose = (m_iw >> hi) & 1ull;
-                    }
-                    if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
-                }
-                if (last_rd != T - 1 && lane == 0) {                                                    // trailing deletion, pyx:155-162
-                    const int dlen = T - 1 - last_rd;
-                    // legacy (pyx:259-261): the run ends at reference index idx - 1, exclusive -- the last base is not among its positions
-                    const int dstart = (legacy && last_rd <= 0) ? 0 : idx_base - dlen, dend = legacy ? idx_base - 1 : idx_base;
-                    if (legacy) {
-                        atomicAdd(acc + C2_V_ALL_DELETION * VL + idx_base - 1, -w);
-                        if (last_rd == 0) atomicAdd(acc + C2_V_ALL_DELETION * VL + 0, w);
-                    }
-                    if (dend > dstart && incp[dend] != incp[dstart]) {
-                        if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + dstart, w); atomicAdd(acc + C2_V_DELETION * VL + dend, -w); }
-                        if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dend, -dlen * w); }
-                    }
-                }
-            }   // tasks of this round
-            if (heavy) {
-                // a task whose weight was added only in part stays pending for another round
-                counted |= (unsigned)__ballot(mine);
-                if (mine) v_w = ctl[C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1))];
-                pending |= (unsigned)__ballot(mine && v_w > 0);
-                flush();
-            }
-        }       // rounds of this chunk
-    }           // chunks
-    flush();
-}
-
-__global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vectors_kernel(c2_count_args A) { c2_count_vectors_body<false>(A); }
-__global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vectors_hbm_kernel(c2_count_args A) { c2_count_vectors_body<true>(A); }
-
-
-// =====================================================================================
-// FASTQ framing and exact de-duplication on the device -- the step in front of the align kernels when the HOST is the bottleneck
-// (the text reaches HBM at the link's rate, 16 host CPUs parse it five times slower).  Semantics: c2_fastq.cpp's, for
-// text without carriage returns -- records are four consecutive '\n'-lines from the top whatever they contain, the sequence line
-// str.strip()ped (ASCII whitespace incl. 0x0b 0x0c 0x1c-0x1f), equal sequences counted, first-seen order.
-// =====================================================================================
-__device__ __forceinline__ bool c2_py_space(const unsigned c) { return (c >= 0x09u && c <= 0x0du) || (c >= 0x1cu && c <= 0x20u); }
-
-// exact per-byte flags (bit 7 of every byte) of "byte == c" in a 32-bit word
-__device__ __forceinline__ unsigned c2_eq_bytes(const unsigned w, const unsigned c4) {
-    const unsigned x = w ^ c4;
-    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
-}
-
-// the 64 bytes of a thread: as 16 words (zero beyond `hi`), and the byte in front of them ('\n' in front of the text)
-__device__ __forceinline__ void c2_fq_load64(const c2_fq_frame_args& A, const uint64_t pos, unsigned (&w)[16], unsigned& prev) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint64_t p = pos + 16u * q;
-        uint4 v = uint4{0u, 0u, 0u, 0u};
-        if (p + 16 <= A.hi) v = *(const uint4*)(A.text + p);
-        else if (p < A.hi) { unsigned char tmp[16]; for (int k = 0; k < 16; ++k) tmp[k] = p + k < A.hi ? A.text[p + k] : 0; __builtin_memcpy(&v, tmp, 16); }
-        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-    }
-    prev = pos == 0 ? 0x0au : (pos <= A.hi ? (unsigned)A.text[pos - 1] : 0u);
-}
-
-__global__ __launch_bounds__(256) void c2_fq_count_kernel(c2_fq_frame_args A)
-{
-    unsigned* const s_acc = (unsigned*)c2_smem;                     // [3] (dynamic LDS: C2_FQ_LDS_BYTES)
-    unsigned& s_nl = s_acc[0]; unsigned& s_em = s_acc[1]; unsigned& s_cr = s_acc[2];
-    if (threadIdx.x == 0) { s_nl = 0; s_em = 0; s_cr = 0; }
-    __syncthreads();
-    const uint64_t pos = A.lo + (uint64_t)blockIdx.x * C2_FQ_TILE + (uint64_t)threadIdx.x * 64u;
-    unsigned nl = 0, em = 0, cr = 0;
-    if (pos < A.hi) {
-        unsigned w[16], prev;
-        c2_fq_load64(A, pos, w, prev);
-        unsigned before = prev == 0x0au ? 0x80u : 0u;                 // "the byte in front is a newline", as bit 7 of a byte
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const unsigned m = c2_eq_bytes(w[q], 0x0a0a0a0au);
-            cr |= c2_eq_bytes(w[q], 0x0d0d0d0du);
-            nl += (unsigned)__builtin_popcount(m);
-            em += (unsigned)__builtin_popcount(m & ((m << 8) | before));      // a newline whose predecessor is a newline
-            before = m >> 24;
-        }
-        // (bytes beyond hi were loaded as 0: neither '\n' nor '\r')
-    }
-    if (nl) atomicAdd(&s_nl, nl);
-    if (em) atomicAdd(&s_em, em);
-    if (cr) atomicOr(&s_cr, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        A.tile_newlines[blockIdx.x] = s_nl; A.tile_empty[blockIdx.x] = s_em;
-        if (s_cr) atomicOr(A.flags, 1u);
-    }
-}
-
-__global__ __launch_bounds__(256) void c2_fq_lines_kernel(c2_fq_frame_args A)
-{
-    unsigned* const s_scan = (unsigned*)c2_smem;                    // [256]
-    const uint64_t pos = A.lo + (uint64_t)blockIdx.x * C2_FQ_TILE + (uint64_t)threadIdx.x * 64u;
-    unsigned w[16], prev, nl = 0;
-    if (pos < A.hi) {
-        c2_fq_load64(A, pos, w, prev);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) nl += (unsigned)__builtin_popcount(c2_eq_bytes(w[q], 0x0a0a0a0au));
-    }
-    // newlines in front of this thread inside the tile (exclusive scan over the 256 threads)
-    s_scan[threadIdx.x] = nl;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const unsigned v = threadIdx.x >= (unsigned)d ? s_scan[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s_scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    if (pos >= A.hi || nl == 0) return;
-    uint64_t g = A.tile_base[blockIdx.x] + (uint64_t)(s_scan[threadIdx.x] - nl);
-    for (int q = 0; q < 16; ++q) {
-        unsigned m = c2_eq_bytes(w[q], 0x0a0a0a0au);
-        while (m) {
-            const int b = __builtin_ctz(m) >> 3;
-            m &= m - 1u;
-            const uint64_t p = pos + 4u * q + (uint64_t)b;
-            const uint64_t r = g >> 2;
-            if (r < A.n_records_cap) {
-                if ((g & 3u) == 0u) A.seq_start[r] = p + 1;            // newline 4r ends the id line: the sequence line starts behind it
-                else if ((g & 3u) == 1u) A.seq_end[r] = p;             // newline 4r + 1 ends the sequence line
-            }
-            ++g;
-        }
-    }
-}
-
-// weight of text position k in a sequence's hash: an odd 64-bit number from a mix of k (splitmix64's finaliser)
-__device__ __forceinline__ unsigned long long c2_fq_weight(unsigned long long k) {
-    k += 0x9e3779b97f4a7c15ull;
-    k = (k ^ (k >> 30)) * 0xbf58476d1ce4e5b9ull;
-    k = (k ^ (k >> 27)) * 0x94d049bb133111ebull;
-    return (k ^ (k >> 31)) | 1ull;
-}
-
-// Same-address atomics serialise in L2 (measured: 80 k of them per launch cost 1 ms -- in real data more than half of the reads are
-// one sequence): the table slot is READ before it is CAS-ed, `first` is read before it is lowered, and the occurrences are added up
-// in a small LDS table per workgroup (C2_FQ_AGG entries: slot -> count; a collision goes to HBM directly) that is flushed at the end.
-#define C2_FQ_AGG 256
-__global__ __launch_bounds__(256) void c2_fq_dedup_kernel(c2_fq_dedup_args A)
-{
-    unsigned* const agg_key = (unsigned*)c2_smem;                   // [C2_FQ_AGG] slot + 1, 0 = free       (dynamic LDS: C2_FQ_DEDUP_LDS_BYTES)
-    unsigned* const agg_cnt = agg_key + C2_FQ_AGG;                  // [C2_FQ_AGG]
-    unsigned* const agg_stats = agg_cnt + C2_FQ_AGG;                // [3] keys created, longest, empty keys
-    const int lane = threadIdx.x & 63;
-    const uint64_t r0 = A.range[0], r1 = A.range[1];
-    if (r1 > A.n_records_cap || r1 >= 0xffffffffull) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(A.flags, 4u); return; }
-    for (unsigned e = threadIdx.x; e < 2u * C2_FQ_AGG + 3u; e += blockDim.x) agg_key[e] = 0u;
-    __syncthreads();
-    for (uint64_t r = r0 + (uint64_t)blockIdx.x * 4u + (uint64_t)(threadIdx.x >> 6); r < r1; r += (uint64_t)gridDim.x * 4u) {
-        uint64_t s = A.seq_start[r], e = A.seq_end[r];
-        if (e < s) e = s;
-        // str.strip(): whitespace at either end goes (one probe at each end decides the usual read)
-        while (s < e && c2_py_space(A.text[s])) ++s;
-        while (e > s && c2_py_space(A.text[e - 1])) --e;
-        const uint64_t len = e - s;
-        if (len >= (1ull << 24) || s >= (1ull << 40)) {
-            if (lane == 0) { atomicOr(A.flags, 2u); A.slot_of[r] = 0xffffffffu; A.rinfo[r] = 0ull; }
-            continue;
-        }
-        const unsigned long long me = ((unsigned long long)s << 24) | (unsigned long long)len;
-        // hash: sum over the bytes of (byte + 1) * weight(position in the sequence), 64-bit wrap-around; lane l takes bytes l, l + 64, ...
-        unsigned long long h = 0;
-        for (uint64_t k = (uint64_t)lane; k < len; k += 64) h += ((unsigned long long)A.text[s + k] + 1ull) * c2_fq_weight(k);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(h & 0xffffffffull), d), hi = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), d);
-            h += ((unsigned long long)hi << 32) | (unsigned long long)lo;
-        }
-        h ^= len * 0xff51afd7ed558ccdull;
-        h ^= h >> 29;
-        if (lane == 0) A.rinfo[r] = me;
-        uint64_t p = h & A.mask;
-        for (;;) {
-            unsigned long long cur = 0;
-            if (lane == 0) {
-                cur = __hip_atomic_load(A.slots + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur == 0ull) cur = atomicCAS(A.slots + p, 0ull, me);          // empty: this record's own bytes become the key's representative
-            }
-            cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur >> 32)) << 32) |
-                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur & 0xffffffffull));
-            const bool created = cur == 0ull;
-            bool same = false;
-            if (!created) {
-                const uint64_t os = cur >> 24, ol = cur & 0xffffffull;
-                if (ol == len) {
-                    bool eq = true;
-                    for (uint64_t k = (uint64_t)lane; k < len; k += 64) eq = eq && A.text[os + k] == A.text[s + k];
-                    same = __ballot(!eq) == 0ull;
-                }
-            }
-            if (created || same) {
-                if (lane == 0) {
-                    A.slot_of[r] = (uint32_t)p;
-                    if (__hip_atomic_load(A.first + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)r) atomicMin(A.first + p, (unsigned)r);
-                    const unsigned a = ((unsigned)p * 0x9e3779b1u) >> 24;         // (C2_FQ_AGG = 2^8)
-                    const unsigned was = atomicCAS(agg_key + a, 0u, (unsigned)p + 1u);
-                    if (was == 0u || was == (unsigned)p + 1u) atomicAdd(agg_cnt + a, 1u);
-                    else atomicAdd(A.count + p, 1u);
-                    if (created) {
-                        atomicAdd(agg_stats, 1u);
-                        atomicMax(agg_stats + 1, (unsigned)len);
-                        if (len == 0) atomicAdd(agg_stats + 2, 1u);
-                    }
-                }
-                break;
-            }
-            p = (p + 1) & A.mask;
-        }
-    }
-    __syncthreads();
-    for (unsigned e = threadIdx.x; e < C2_FQ_AGG; e += blockDim.x) if (agg_key[e]) atomicAdd(A.count + (agg_key[e] - 1u), agg_cnt[e]);
-    if (threadIdx.x == 0 && agg_stats[0]) {
-        atomicAdd(A.stats, agg_stats[0]);
-        atomicMax(A.stats + 1, agg_stats[1]);
-        if (agg_stats[2]) atomicAdd(A.stats + 2, agg_stats[2]);
-    }
-}
-
-__global__ __launch_bounds__(256) void c2_fq_gather_kernel(c2_fq_gather_args A)
-{
-    const int lane = threadIdx.x & 63;
-    for (uint64_t i = (uint64_t)blockIdx.x * 4u + (uint64_t)(threadIdx.x >> 6); i < A.n; i += (uint64_t)gridDim.x * 4u) {
-        const unsigned long long info = A.info[A.records ? (uint64_t)A.records[i] : i];
-        const uint64_t s = info >> 24, len = info & 0xffffffull;
-        uint8_t* o = A.out + A.out_offsets[i];
-        for (uint64_t k = (uint64_t)lane; k < len; k += 64) o[k] = A.text[s + k];
-    }
-}
-
-__global__ __launch_bounds__(256) void c2_fq_rc_partner_kernel(c2_fq_rc_args A)
-{
-    const int lane = threadIdx.x & 63;
-    for (uint64_t i = (uint64_t)blockIdx.x * 4u + (uint64_t)(threadIdx.x >> 6); i < A.n; i += (uint64_t)gridDim.x * 4u) {
-        const unsigned long long info = A.info[A.records[i]];
-        const uint64_t s = info >> 24, len = info & 0xffffffull;
-        // the hash the de-duplication kernel would give the reverse complement: its byte k is the complement of this read's byte len - 1 - k
-        unsigned long long h = 0;
-        bool bad = false;
-        for (uint64_t k = (uint64_t)lane; k < len; k += 64) {
-            const unsigned c = c2_fq_complement(A.text[s + len - 1 - k]);
-            bad = bad || c == 0u;
-            h += ((unsigned long long)c + 1ull) * c2_fq_weight(k);
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(h & 0xffffffffull), d), hi = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), d);
-            h += ((unsigned long long)hi << 32) | (unsigned long long)lo;
-        }
-        h ^= len * 0xff51afd7ed558ccdull;
-        h ^= h >> 29;
-        int found = -1;
-        if (__ballot(bad) == 0ull) {
-            uint64_t p = h & A.mask;
-            for (;;) {
-                const unsigned long long cur = A.slots[p];             // (wave-uniform address)
-                if (cur == 0ull) break;
-                const uint64_t os = cur >> 24, ol = cur & 0xffffffull;
-                if (ol == len) {
-                    bool eq = true;
-                    for (uint64_t k = (uint64_t)lane; k < len; k += 64) eq = eq && (unsigned)A.text[os + k] == c2_fq_complement(A.text[s + len - 1 - k]);
-                    if (__ballot(!eq) == 0ull) { found = (int)p; break; }
-                }
-                p = (p + 1) & A.mask;
-            }
-        }
-        if (lane == 0) A.partner_slot[i] = found;
-    }
-}
+// This file is the umbrella over the kernel units (the wave emulator of tests/emu compiles all of them in one go); the library builds
+// each unit in its own translation unit next to the host code that launches it (c2_api_*.hip, Makefile).
+#include "c2_k_common.h"
+#include "c2_k_align.hip"
+#include "c2_k_classify.hip"
+#include "c2_k_select.hip"
+#include "c2_k_count.hip"
+#include "c2_k_fastq.hip"
+#include "c2_k_alleles.hip"

@@ -54,7 +54,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         { int mc = 0; for (int k = 0; k < lens[r]; ++k) mc = std::max(mc, (int)(unsigned char)seqs[r][k]); refs[r].max_char = mc; }
         max_li = std::max(max_li, lens[r]);
     }
-    // the library's choice (c2_api.hip, update_pk_eligibility): one bias for the batch, the 32-bit-add variant only if every admitted
+    // the library's choice (c2_api_align.hip, update_pk_eligibility): one bias for the batch, the 32-bit-add variant only if every admitted
     // reference stays in range with it (C2_EMU_NO_ADD32: the packed-add variant, as for references beyond that range)
     int pk_beta = 0, pk_bias = 0;
     if (any_pk && !getenv("C2_EMU_NO_ADD32")) {
@@ -130,7 +130,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         std::vector<uint32_t> un_list(A.n_tasks ? A.n_tasks : 1);
         uint32_t un_counts[5] = {0, 0, 0, 0, 0};
         int tier = 0;
-        // the host library's wiring (c2_api.hip, launch_align): a band tier = the packed kernel (if any), then the 32-bit kernel of the
+        // the host library's wiring (c2_api_align.hip, launch_align): a band tier = the packed kernel (if any), then the 32-bit kernel of the
         // same band -- over everything, or over the tasks the packed kernel could not pair
         auto chain = [&](c2_align_args& T, const bool from_unpaired, const bool packed_kernel) {
             if (from_unpaired) { T.task_list = un_list.data(); T.task_count = &un_counts[tier]; }
@@ -404,7 +404,7 @@ int emu_fq_rc_partner(const uint8_t* text, const uint64_t* info, const int64_t* 
 
 // The per-call C ABI on the emulator, argument for argument (the context handle is ignored): what
 // crispresso2_amd.CRISPResso2Align.global_align / CRISPRessoCOREResources.find_indels_substitutions[_legacy] call.
-// Host-side marshalling follows c2_api.hip (c2_global_align, c2_find_indels_substitutions).
+// Host-side marshalling follows c2_api_align.hip / c2_api_classify.hip (c2_global_align, c2_find_indels_substitutions).
 int emu_c2_global_align(void*, const char* read, int32_t Lj, const char* ref, int32_t Li, const int64_t* matrix, int32_t mat_dim,
                         const int64_t* gap_incentive, int32_t n_gap_incentive, int32_t gap_open, int32_t gap_extend,
                         char* out_read_aln, char* out_ref_aln, int32_t* out_len, int32_t* out_matches, int32_t* out_status)

@@ -23,7 +23,9 @@ _lib = None
 
 def build(force=False):
     srcs = [os.path.join(EMU_DIR, f) for f in ("emu_harness.cpp", "emu_runtime.h", "hip/hip_runtime.h")]
-    srcs += [os.path.join(ROOT, "crispresso2_amd/csrc", f) for f in ("c2_kernels.hip", "c2_device.h", "c2_host_prep.h")]
+    srcs += [os.path.join(ROOT, "crispresso2_amd/csrc", f) for f in ("c2_kernels.hip", "c2_k_common.h", "c2_k_align.hip", "c2_k_classify.hip", "c2_k_select.hip",
+                                                                      "c2_k_count.hip", "c2_k_fastq.hip", "c2_k_alleles.hip", "c2_alleles_host.h",
+                                                                      "c2_device.h", "c2_host_prep.h")]
     srcs.append(os.path.join(ROOT, "include/crispresso2_amd.h"))
     def stale():
         return not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs)
