@@ -315,3 +315,63 @@ typedef struct c2_select_args {
     int32_t n_refs;
     int32_t mode;                   // C2_SEL_MODE_*
 } c2_select_args;
+
+// ---- allele frequency table on the device (c2_k_alleles.hip; CRISPRessoCORE.py:3964-4010, :4298-4303, :4498-4530) ----
+// where the two strings of a table row live: batch 1 (row = read * n_refs + reference) or, with bit 31 of `src` set, batch 2
+struct c2_allele_strings {
+    const uint8_t* a1; const uint8_t* f1; const uint8_t* a2; const uint8_t* f2;
+    uint32_t stride1, stride2;
+};
+struct c2_allele_jobs_args {
+    c2_allele_src S;
+    const uint64_t* offsets;          // NULL: pass 1, njobs[read] = rows this read gives; else pass 2: its first row
+    uint32_t* njobs;
+    c2_allele_row* rows;
+};
+// the text of one table line: aligned \t reference \t label \t status \t n_deleted \t n_inserted \t n_mutated \t #Reads \t %Reads [\t dsODN \t fragment] \n
+struct c2_allele_text_args {
+    c2_allele_strings X;
+    const c2_allele_row* rows; const uint32_t* order;      // sorted position q -> row
+    uint64_t m;                       // rows of the table
+    const uint32_t* run_start;        // n_runs ascending positions: rows [run_start[u], run_start[u + 1]) share one #Reads value
+    const uint32_t* pct_off; const uint8_t* pct_len; const uint8_t* pct_blob;   // ... and its %Reads text
+    uint32_t n_runs;
+    const uint32_t* label_off; const uint8_t* label_blob;  // label l = label_blob[label_off[l] .. label_off[l + 1])
+    const uint8_t* probe_bits;        // per sorted position: bit 0 contains dsODN, bit 1 contains the fragment; NULL: no such columns
+    uint32_t* lengths;                // lengths pass: bytes of line q
+    const uint64_t* offsets;          // emit pass: first byte of line q in the whole text
+    uint64_t q0, q1;                  // emit pass: lines [q0, q1) go to out[offsets[q] - offsets[q0]]
+    uint8_t* out;
+};
+struct c2_allele_probe_args {
+    c2_allele_strings X;
+    const c2_allele_row* rows; const uint32_t* order; uint64_t m;
+    const uint8_t* probe_blob; uint32_t probe_off[5];     // four probes back to back
+    uint8_t* probe_bits;
+};
+struct c2_allele_fetch_args {
+    c2_allele_strings X;
+    const c2_allele_row* rows; const uint32_t* order; uint64_t m;
+    c2_allele_row* out_rows; uint8_t* out_a; uint8_t* out_f; uint32_t stride;
+};
+// around-cut windows: key = window of the aligned read (W bytes, zero padded), window of the reference (W), Unedited, n_deleted, n_inserted,
+// n_mutated (big endian) -- byte order of the key = order of the reference's group key; key_bytes a multiple of 8
+struct c2_allele_window_args {
+    c2_allele_strings X;
+    const c2_allele_row* rows; const uint32_t* order; uint64_t m;
+    int32_t label, cut_point, left, right;
+    uint32_t W, key_bytes;
+    const uint64_t* sub_index;        // NULL: flag pass (flag[q] = row q carries the label); else exclusive scan of the flags
+    uint32_t* flag;
+    uint8_t* keys;                    // [subset][key_bytes]
+    uint32_t* sub_reads;              // [subset] #Reads of the row
+    uint32_t* error;                  // set when a row's reference string holds no base cut_point
+};
+struct c2_allele_group_args {
+    const uint8_t* keys; uint32_t key_bytes; uint64_t ms;
+    const uint32_t* perm;             // sorted position j -> subset index
+    uint32_t* head;                   // pass 0: head[j] = key differs from the one before
+    const uint64_t* head_scan;        // pass 1: exclusive scan of head -> group of position j = head_scan[j] + head[j] - 1
+    uint32_t* gid;                    // pass 1: per subset index
+    uint8_t* gkeys;                   // pass 1: [group][key_bytes], in key order
+};

@@ -39,105 +39,92 @@ def strand_plans(arena, offsets, refs, ref_names, args):
 class QuantResult:
     """per_ref[name]: the dict of counts.CountLayout.unpack (vectors named after the reference's variables);
     stats: N_TOT_READS, N_CACHED_ALN, ... (process_fastq's aln_stats) plus N_TOTAL and N_AMBIGUOUS of the aggregation loop;
-    alleles(): the rows of the allele frequency table."""
+    allele_table(): the allele frequency table on the device (alleles.AlleleTable: sorted rows, the text of the files);
+    alleles(): its rows as tuples."""
     def __init__(self, per_ref, stats, layout, tensor, state=None, first_ref_view=None):
         self.per_ref, self.stats, self.layout, self.tensor = per_ref, stats, layout, tensor
-        self._state_src = state                                       # the dict alleles() reads, or a function that brings it to the host when asked
+        # what the allele table is built from: a dict of the device tensors the run left (alleles.AlleleTable's arguments), or None
+        self._state = state
+        self._table = None
         # {name: all_* count vectors of the reads counted for that amplicon, in the coordinates of the FIRST amplicon}
         # (CRISPRessoCORE.py:4195-4270; built for runs with an expected HDR amplicon / prime-editing extension), else None
         self.first_ref_view = first_ref_view
 
     @property
-    def _state(self):
-        if callable(self._state_src):
-            self._state_src = self._state_src()
-        return self._state_src
+    def align_ref_names(self):
+        """the amplicons reads were aligned to (the allele table's labels index them)"""
+        return None if self._state is None else self._state["ref_names"]
+
+    def allele_table(self):
+        """alleles.AlleleTable over this run's alignments: rows built and sorted on the device (c2_allele_table_build) the first time it
+        is asked for; None for a run without reads (an empty shard)."""
+        if self._table is None and self._state is not None:
+            from .alleles import AlleleTable
+            S = self._state
+            self._table = AlleleTable(S["ctx"], S["n"], len(S["ref_names"]), S["mode"], S["flags"], S["a1"], S["f1"], S["r1"], S["stride"],
+                                      S["d_member"], S["d_flags"], S["d_cnt"], a2=S["a2"], f2=S["f2"], r2=S["r2"], stride2=S["stride2"],
+                                      slot2=S["d_slot2"], use2=S["d_use2"], scaffold_hit=S["d_scaffold_hit"], scaffold_ref=S["scaffold_ref"],
+                                      stream=S["stream"], keep=S)
+        return self._table
+
+    def host_view(self):
+        """the selection as numpy arrays, for callers that look at single reads: member / use2 bool [n, k] (best references; those whose
+        reverse-complement alignment won), aligned bool [n], cnt int64 [n] (multiplicities after the reverse-complement transfer),
+        slot2 int64 [n, k] (row in the both-strand batch, -1: none)"""
+        S = self._state
+        n, k = S["n"], len(S["ref_names"])
+        cols = np.arange(k)
+
+        def unpack(t):
+            w = to_host(t).view(np.uint64).reshape(n, -1)
+            return ((w[:, cols >> 6] >> (cols & 63).astype(np.uint64)) & np.uint64(1)).astype(bool)
+        slot2 = np.full((n, k), -1, dtype=np.int64) if S["d_slot2"] is None else to_host(S["d_slot2"]).astype(np.int64).reshape(n, k)
+        return dict(member=unpack(S["d_member"]), use2=unpack(S["d_use2"]) if S["d_use2"] is not None else np.zeros((n, k), dtype=bool),
+                    aligned=(to_host(S["d_flags"]) & 1).astype(bool), cnt=to_host(S["d_cnt"]).view(np.uint32).astype(np.int64), slot2=slot2)
+
+    def allele_rows(self):
+        """alleles.AlleleRows: the sorted table as numpy columns in host memory (aligned strings of every aligned unique read)"""
+        t = self.allele_table()
+        if t is None:
+            return None
+        return t.rows(self._state["ref_names"], self.stats["N_TOTAL"])
 
     def alleles(self, gather=False):
         """Rows (Aligned_Sequence, Reference_Sequence, Reference_Name, Read_Status, n_deleted, n_inserted, n_mutated, #Reads,
         %Reads) of Alleles_frequency_table.txt: one per (read, reference it counts for), 'AMBIGUOUS_<first reference>' rows
         for ambiguous reads, 'DISCARDED_<first reference>' rows under --discard_indel_reads (CRISPRessoCORE.py:3926-4010,
-        :4298-4303), sorted as the reference sorts them (#Reads descending, then the two sequences ascending).  Brings the
-        aligned strings of the aligned unique reads to the host.
+        :4298-4303), sorted as the reference sorts them (#Reads descending, then the two sequences ascending) -- on the device
+        (allele_table); this brings the sorted rows to the host as columns and zips them into tuples.
         gather (sharded run, a collective: every rank calls it): the rows of all ranks' shards, on every rank."""
-        if gather:
-            import torch.distributed as dist
-            mine = self.alleles()
-            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-                return mine
-            parts = [None] * dist.get_world_size()
-            dist.all_gather_object(parts, mine)
-            rows = [r for part in parts for r in part]
-            rows.sort(key=lambda t: (-t[7], t[0], t[1]))
-            return rows
-        import torch
-        S = self._state
-        if S is None:
+        rows = self.allele_rows()
+        if not gather:
+            return [] if rows is None else rows.tuples()
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return [] if rows is None else rows.tuples()
+        from .alleles import AlleleRows
+        mine = None if rows is None else (rows.rows, rows.aligned, rows.reference, rows.labels)
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, mine)
+        parts = [p_ for p_ in parts if p_ is not None and len(p_[0])]
+        if not parts:
             return []
-        args, ref_names = S["args"], S["ref_names"]
-        member, aligned, cnt, use2, slot2 = S["member"], S["aligned"], S["cnt"], S["use2"], S["slot2"]
-        k = len(ref_names)
-        discard = bool(getattr(args, 'discard_indel_reads', False))
-        jobs = []                                                   # (read, reference, row label)
-        hit = S.get("scaffold_hit")
-        for i in np.nonzero(aligned & (cnt > 0))[0]:
-            if hit is not None and hit[i]:                          # aln_ref_names = ['Scaffold-incorporated'], its Prime-edited alignment
-                jobs.append((i, S["scaffold_ref"], 'Scaffold-incorporated', True))
-                continue
-            best = np.nonzero(member[i])[0]
-            names = best
-            if len(best) > 1:
-                if args.assign_ambiguous_alignments_to_first_reference:
-                    names = best[:1]
-                elif not args.expand_ambiguous_alignments:
-                    jobs.append((i, best[0], 'AMBIGUOUS_' + ref_names[best[0]], False))
-                    continue
-            for r in names:
-                jobs.append((i, r, ref_names[r], True))
-        if not jobs:
-            return []
-        ji = np.array([j[0] for j in jobs], dtype=np.int64)
-        jr = np.array([j[1] for j in jobs], dtype=np.int64)
-        in2 = use2[ji, jr]
-        rows1 = torch.from_numpy(ji[~in2] * k + jr[~in2]).to(S["a1"].device)
-        rec = np.empty(len(jobs), dtype=_native.REC_DTYPE)
+        width = max(p_[1].dtype.itemsize for p_ in parts)
+        S = "S%d" % width
+        rec = np.concatenate([p_[0] for p_ in parts])
+        a = np.concatenate([p_[1].astype(S) for p_ in parts])
+        f = np.concatenate([p_[2].astype(S) for p_ in parts])
+        order = np.lexsort((f, a, -rec["reads"].astype(np.int64)))       # (stable: ties keep rank order, then shard order)
+        return AlleleRows(rec[order], a[order], f[order], parts[0][3], self.stats["N_TOTAL"]).tuples()
 
-        def records_of(r_dev, rows):
-            return r_dev.index_select(0, rows).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
-        seqs = [None] * len(jobs)
-        refs_ = [None] * len(jobs)
 
-        def pull(a, f, rows, where, records):
-            ah, fh = a.index_select(0, rows).cpu().numpy(), f.index_select(0, rows).cpu().numpy()
-            for q, j in enumerate(where):
-                T = int(records[q]["aln_len"])
-                seqs[j], refs_[j] = ah[q, :T].tobytes().decode(), fh[q, :T].tobytes().decode()
-                rec[j] = records[q]
-        w1 = np.nonzero(~in2)[0]
-        if len(w1):
-            pull(S["a1"], S["f1"], rows1, w1, records_of(S["r1"], rows1))
-        w2 = np.nonzero(in2)[0]
-        if len(w2):
-            sl = slot2[ji[in2], jr[in2]]
-            rows2 = torch.from_numpy(sl).to(S["a1"].device)
-            pull(S["a2"], S["f2"], rows2, w2, records_of(S["r2"], rows2))
-        n_total = self.stats["N_TOTAL"]
-        out = []
-        for j, (i, r, label, counted) in enumerate(jobs):
-            dn, inn, sn = int(rec[j]["deletion_n"]), int(rec[j]["insertion_n"]), int(rec[j]["substitution_n"])
-            modified = ((not args.ignore_deletions and dn > 0) or (not args.ignore_insertions and inn > 0) or
-                        (not args.ignore_substitutions and sn > 0))
-            if counted and discard and (dn > 0 or inn > 0):
-                if label == 'Scaffold-incorporated':
-                    label = 'DISCARDED_Scaffold-incorporated'
-                else:
-                    first = np.nonzero(member[i])[0]
-                    first = first[:1] if args.assign_ambiguous_alignments_to_first_reference else first
-                    label = 'DISCARDED_' + ref_names[first[0]]
-            reads = int(cnt[i])
-            out.append((seqs[j], refs_[j], label, 'MODIFIED' if modified else 'UNMODIFIED', dn, inn, sn, reads, reads / n_total * 100))
-        out.sort(key=lambda t: (-t[7], t[0], t[1]))
-        return out
+def _pack_masks(b):
+    """bool [n, k] -> int64 [n, ceil(k / 64)] (bit r % 64 of word r / 64: column r), the selection kernel's mask layout"""
+    n, k = b.shape
+    words = (k + 63) // 64
+    padded = np.zeros((n, words * 64), dtype=np.uint8)
+    padded[:, :k] = b
+    return np.packbits(padded, axis=1, bitorder='little').view('<u8').view(np.int64).reshape(n, words)
 
 
 FORCE_HOST_SELECTION = False        # tests: run the host restatement of the selection (_select_on_host) instead of c2_select_best_kernel
@@ -847,11 +834,9 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
                         reduce_stats()
                     torch.cuda.synchronize(dev)
 
-                    def state_on_host():
-                        member_, use2_, aligned_ = masks_to_host()
-                        return dict(args=args, ref_names=list(ref_names), member=member_, aligned=aligned_, cnt=to_host(c1), use2=use2_, slot2=host_slot2(),
-                                    scaffold_hit=np.zeros(n, dtype=bool), scaffold_ref=pe, a1=a1, f1=f1, r1=r1, a2=a2, f2=f2, r2=r2)
-                    return finish(None, None, state_on_host)
+                    return finish(None, None, dict(ctx=ctx, stream=stream, args=args, ref_names=list(ref_names), n=n, mode=mode, flags=flags & 15,
+                                                   a1=a1, f1=f1, r1=r1, stride=stride, a2=a2, f2=f2, r2=r2, stride2=stride2, d_slot2=d_slot2,
+                                                   d_member=d_member, d_use2=d_use2, d_flags=d_flags, d_cnt=d_cnt, d_scaffold_hit=None, scaffold_ref=pe))
         member, use2, aligned = masks_to_host()
     else:
         member, use2, aligned = _select_on_host(r1, r2, n, k, n2, bi if n2 else None, br if n2 else None, host_slot2(), min_scores, raw, stats)
@@ -997,9 +982,17 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
             C.all_reduce(d_scaffold)
         reduce_stats()
     torch.cuda.synchronize(dev)
-    state = dict(args=args, ref_names=list(ref_names), member=member, aligned=aligned, cnt=cnt, use2=use2, slot2=host_slot2(),
-                 scaffold_hit=scaffold_hit, scaffold_ref=pe,
-                 a1=a1, f1=f1, r1=r1, a2=a2, f2=f2, r2=r2)
+    # what the allele table is built from (QuantResult.allele_table): the selection's masks as the kernel left them (or the host
+    # selection's, packed the same way), the merged multiplicities of this rank's reads, the scaffold rule's hits
+    if on_device:
+        t_member, t_use2, t_flags = d_member, d_use2, d_flags
+    else:
+        t_member, t_use2 = to_device(_pack_masks(member), dev), to_device(_pack_masks(use2), dev)
+        t_flags = to_device(aligned.astype(np.uint8), dev)
+    state = dict(ctx=ctx, stream=stream, args=args, ref_names=list(ref_names), n=n, mode=mode, flags=flags & 15,
+                 a1=a1, f1=f1, r1=r1, stride=stride, a2=a2, f2=f2, r2=r2, stride2=stride2, d_slot2=d_slot2,
+                 d_member=t_member, d_use2=t_use2, d_flags=t_flags, d_cnt=to_device(cnt.astype(np.uint32).view(np.int32), dev),
+                 d_scaffold_hit=to_device(scaffold_hit.astype(np.uint8), dev) if scaffold_rule else None, scaffold_ref=pe)
     return finish(d_view, d_scaffold, state)
 
 

@@ -69,7 +69,13 @@ def _write_count_vectors(path, ref_seq, vectors, names):
 def write_alleles_frequency_table(res, path, dsODN=""):
     """Alleles_frequency_table.txt (the reference zips it): CRISPRessoCORE.py:4498-4527, the non-detailed columns.  With
     --dsODN two more columns say whether the aligned read contains the oligo, or the oligo without its first and last three
-    bases, on either strand -- `str.find(...) > 0`, so a match at the very start of the read does not count (:4512-4524)."""
+    bases, on either strand -- `str.find(...) > 0`, so a match at the very start of the read does not count (:4512-4524).
+    A pipeline.QuantResult has the table on the device: its text is formed there and written by native threads
+    (alleles.AlleleTable.write, c2_allele_table_write).  Any other `res` (rows in host memory, res.alleles()) is printed here."""
+    table = res.allele_table() if hasattr(res, "allele_table") else None
+    if table is not None:
+        table.write(path, res.align_ref_names, res.stats["N_TOTAL"], dsODN=dsODN)
+        return
     from .refs import reverse_complement
     head = "Aligned_Sequence\tReference_Sequence\tReference_Name\tRead_Status\tn_deleted\tn_inserted\tn_mutated\t#Reads\t%Reads"
     probes = []
@@ -283,12 +289,19 @@ def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN=""):
         # alleles around each guide's cut (CRISPRessoCORE.py:5250-5273); needs the guides' sequences for the file names
         guides = refs[name].get("sgRNA_orig_sequences") or []
         if guides:
-            if allele_rows is None:
+            table = res.allele_table() if hasattr(res, "allele_table") else None
+            if table is None and allele_rows is None:
                 allele_rows = res.alleles()
             labels = refs[name].get("sgRNA_names") or [""] * len(guides)
             for cut_point, guide, label in zip(refs[name]["sgRNA_cut_points"], guides, labels):
                 fn = prefix + "Alleles_frequency_table_around_" + slugify(label if label != "" else "sgRNA_" + guide) + ".txt"
-                write_alleles_around_cut(alleles_around_cut(allele_rows, name, cut_point, L, plot_window_size), os.path.join(out_dir, fn))
+                if table is not None:
+                    # windows cut and merged on the device, sums and text by native code (c2_allele_table_around_cut_write)
+                    aligned_to = res.align_ref_names
+                    lab = aligned_to.index(name) if name in aligned_to else 3 * len(aligned_to)      # ('Scaffold-incorporated': nothing is aligned to it)
+                    table.write_around_cut(os.path.join(out_dir, fn), lab, cut_point, L, plot_window_size, res.stats["N_TOTAL"])
+                else:
+                    write_alleles_around_cut(alleles_around_cut(allele_rows, name, cut_point, L, plot_window_size), os.path.join(out_dir, fn))
                 written.append(fn)
     if getattr(res, "first_ref_view", None) and any(res.per_ref[nm]["counts_total"] > 0 for nm in ref_names):
         written += write_reads_from_all_amplicons_tables(res, refs, ref_names, out_dir)

@@ -164,6 +164,77 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
                             const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
                             int64_t* d_counts, void* hip_stream);
 
+/* ---- Alleles_frequency_table on the device (second half) ----------------------------------------------------
+ * Replaces the reference's per-variant Python loop that fills alleles_list (CRISPRessoCORE.py:3964-4010: one row per unique read and
+ * reference it counts for; 'AMBIGUOUS_<first best reference>' rows for ambiguous reads, 'DISCARDED_<first best reference>' rows under
+ * --discard_indel_reads), the frame's sort and %Reads (:4298-4303: #Reads descending, then Aligned_Sequence and Reference_Sequence
+ * ascending, stable; %Reads = #Reads / N_TOTAL * 100), the text of Alleles_frequency_table.txt (:4498-4530, the non-detailed
+ * columns, with --dsODN the two "contains dsODN" columns of :4512-4524) and <ref>Alleles_frequency_table_around_<guide>.txt
+ * (CRISPRessoShared.py:1513-1531 get_dataframe_around_cut_asymmetrical, window plots/data_prep.py:285-301, file CRISPRessoCORE.py:5250-5273).
+ * Input: what the count route left in HBM -- the aligned strings and records of the all-references batch (row = read * n_refs +
+ * reference) and of the both-strand batch, c2_select_best_device's masks and flags, the multiplicities after the reverse-complement
+ * transfer.  Nothing but the finished text (or, for c2_allele_table_fetch, the sorted rows) crosses the link. */
+typedef struct c2_allele_src {
+    uint64_t n_reads;                 /* unique reads */
+    int32_t n_refs;
+    int32_t mode;                     /* as c2_select_best_device: 0 ambiguous reads give one AMBIGUOUS_ row, 1 first best reference only, 2 one row per best reference */
+    const uint8_t* d_aln_read1;       /* n_reads * n_refs rows of stride1 bytes */
+    const uint8_t* d_aln_ref1;
+    const c2_aln_record* d_records1;
+    const uint8_t* d_aln_read2;       /* rows of the both-strand batch (stride2), or NULL */
+    const uint8_t* d_aln_ref2;
+    const c2_aln_record* d_records2;
+    const int32_t* d_slot2;           /* n_reads * n_refs: row in batch 2 or -1; NULL without batch 2 */
+    const uint64_t* d_member;         /* ceil(n_refs / 64) words per read: best references */
+    const uint64_t* d_use2;           /* ... whose reverse-complement alignment (batch 2) won */
+    const uint8_t* d_flags;           /* bit 0: aligned */
+    const uint32_t* d_counts;         /* multiplicity per read after the reverse-complement transfer (:3970-3975); 0 = gave its copies away */
+    const uint8_t* d_scaffold_hit;    /* per read: counted for 'Scaffold-incorporated' with its alignment against reference scaffold_ref (:786-796), or NULL */
+    uint32_t stride1, stride2;
+    int32_t scaffold_ref;
+    uint32_t flags;                   /* C2_COUNT_IGNORE_SUBSTITUTIONS / _INSERTIONS / _DELETIONS (Read_Status), C2_COUNT_DISCARD_INDEL_READS */
+} c2_allele_src;
+
+/* One row of the table; `label` indexes the caller's label list: [0, k) reference r; [k, 2k) 'AMBIGUOUS_' + reference r; [2k, 3k)
+ * 'DISCARDED_' + reference r; 3k 'Scaffold-incorporated'; 3k + 1 'DISCARDED_Scaffold-incorporated'  (k = n_refs). */
+typedef struct c2_allele_row {
+    uint32_t src;                     /* row of batch 1, or with bit 31 set of batch 2 */
+    uint32_t reads;                   /* #Reads */
+    uint32_t read;                    /* unique read */
+    uint16_t aln_len, label, n_deleted, n_inserted, n_mutated;
+    uint8_t modified, reserved;
+} c2_allele_row;
+#ifdef __cplusplus
+static_assert(sizeof(c2_allele_row) == 24, "c2_allele_row is ABI: 24 bytes");
+#endif
+#define C2_ALLELE_LABELS(k) (3 * (k) + 2)
+#define C2_ALLELE_MAX_WINDOW 124      /* left + right columns of an around-cut window */
+
+typedef struct c2_allele_table c2_allele_table;
+/* Rows built and sorted on the device (enqueued on hip_stream, complete when it returns).  The table refers to the caller's device
+ * buffers (strings, records): they must outlive it.  n_reads * n_refs and the number of rows must stay below 2^31. */
+int c2_allele_table_build(c2_ctx* ctx, const c2_allele_src* src, c2_allele_table** out, void* hip_stream);
+uint64_t c2_allele_table_rows(const c2_allele_table* t);
+/* Alleles_frequency_table.txt: header + one line per row, text formed on the device chunk by chunk, copied through pinned buffers and
+ * written by `threads` host threads (pwrite).  labels: C2_ALLELE_LABELS(n_refs) strings.  probes: NULL, or 4 strings -- dsODN, its
+ * reverse complement, dsODN[3:-3], its reverse complement -- for the two "contains dsODN" columns (`str.find(..) > 0`: an occurrence at
+ * column 0 hides every later one).  %Reads is printed as Python prints the double #Reads / n_total * 100 (shortest round-trip repr). */
+int c2_allele_table_write(c2_allele_table* t, const char* path, const char* const* labels, int64_t n_total,
+                          const char* const* probes, int32_t threads, uint64_t* bytes_written);
+/* The sorted rows for a caller that wants them in memory: rows[m], and the two strings of every row zero-padded to `stride` bytes
+ * (>= the longest alignment) in aligned[m * stride] / reference[m * stride] (either may be NULL). */
+int c2_allele_table_fetch(c2_allele_table* t, c2_allele_row* rows, uint8_t* aligned, uint8_t* reference, uint32_t stride);
+/* <ref>Alleles_frequency_table_around_<guide>.txt for the rows labelled `label`: every allele cut down to plot_window_size columns either
+ * side of the column that holds reference base `cut_point` (clipped at the amplicon's ends, ref_len), equal windows (same strings,
+ * Unedited, n_deleted, n_inserted, n_mutated) merged -- #Reads summed, %Reads summed in table order with pandas' Kahan compensation --
+ * sorted by #Reads descending, then the merged key ascending.  C2_E_INVALID with "<cut_point> is not in list" when a row's reference
+ * string has no such base.  Grouping on the device; sums, order and text on the host. */
+int c2_allele_table_around_cut_write(c2_allele_table* t, int32_t label, int32_t cut_point, int32_t ref_len, int32_t plot_window_size,
+                                     int64_t n_total, const char* path, int32_t threads, uint64_t* n_groups);
+void c2_allele_table_free(c2_allele_table* t);
+/* repr() of a Python float (David Gay shortest round trip, 'r' format: exponent form below 1e-4 and from 1e16): out >= 32 bytes, returns the length */
+int c2_format_float_repr(double v, char* out);
+
 /* ---- multi-GPU: replaces CRISPRessoMultiProcessing's process pool + the variants_<k>.tsv exchange (CRISPRessoCORE.py:1870-1985) ----
  * One process per GPU, reads sharded by contiguous ranges, no data-path collective; the per-amplicon count tensor of
  * c2_count_vectors_device is the only thing exchanged: one RCCL all-reduce (sum, int64) over xGMI.

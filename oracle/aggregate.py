@@ -202,3 +202,32 @@ def select_best(scores, scores_rc, min_aln_scores, assign_first=False, expand=Fa
         elif not expand:
             counted, ambiguous = [], True
     return best, use_rc, True, counted, ambiguous
+
+
+def allele_table_text(rows, n_total, dsODN=""):
+    """Restatement with pandas of the allele table's frame, sort and file (CRISPRessoCORE.py:4298-4303, :4498-4530): `rows` are the
+    alleles_list entries in the order the reference appends them, as tuples (Aligned_Sequence, Reference_Sequence, Reference_Name,
+    Read_Status, n_deleted, n_inserted, n_mutated, #Reads).  -> the text of Alleles_frequency_table.txt"""
+    import io
+    import pandas as pd
+    cols = ["Aligned_Sequence", "Reference_Sequence", "Reference_Name", "Read_Status", "n_deleted", "n_inserted", "n_mutated", "#Reads"]
+    df = pd.DataFrame(list(rows), columns=cols)
+    df['%Reads'] = df['#Reads'] / n_total * 100
+    df[['n_deleted', 'n_inserted', 'n_mutated']] = df[['n_deleted', 'n_inserted', 'n_mutated']].astype(int)
+    df.sort_values(by=['#Reads', 'Aligned_Sequence', 'Reference_Sequence'], inplace=True, ascending=[False, True, True])
+    out_cols = cols + ['%Reads']
+    if dsODN != "":
+        from .fastq import reverse_complement
+        df["contains dsODN fw"] = df["Aligned_Sequence"].str.find(dsODN) > 0
+        df["contains dsODN rv"] = df["Aligned_Sequence"].str.find(reverse_complement(dsODN)) > 0
+        df["contains dsODN"] = df["contains dsODN fw"] | df["contains dsODN rv"]
+        out_cols.append("contains dsODN")
+        if len(dsODN) > 6:
+            sub = dsODN[3:-3]
+            df["contains dsODN fragment fw"] = df["Aligned_Sequence"].str.find(sub) > 0
+            df["contains dsODN fragment rv"] = df["Aligned_Sequence"].str.find(reverse_complement(sub)) > 0
+            df["contains dsODN fragment"] = df["contains dsODN fragment fw"] | df["contains dsODN fragment rv"]
+        out_cols.append("contains dsODN fragment")
+    buf = io.StringIO()
+    df.loc[:, out_cols].to_csv(buf, sep='\t', header=True, index=None)
+    return buf.getvalue()

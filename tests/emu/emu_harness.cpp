@@ -490,4 +490,69 @@ int emu_select_best(uint64_t n_reads, int n_refs, const c2_aln_record* records, 
 uint32_t emu_mscore(uint32_t matches, uint32_t T) { return c2_mscore(matches, T); }
 
 int emu_selftest(int* out) { emu::launch(1, [&] { c2_selftest_kernel(out); }); return 0; }
+
+}  // extern "C"
+
+// ---- the allele table: c2_alleles_host.h (the product's own orchestration) over an emulator backend -- host memory, the fiber launcher,
+// std::stable_sort with the kernels' comparators.  Same entry points as the C ABI's c2_allele_table_*, without the context.
+#include "../../crispresso2_amd/csrc/c2_alleles_host.h"
+namespace {
+struct EmuBackend {
+    std::string error;
+    void* dalloc(size_t n) { return malloc(n ? n : 1); }
+    void dfree(void* p) { free(p); }
+    void* halloc(size_t n) { return malloc(n ? n : 1); }
+    void hfree(void* p) { free(p); }
+    bool h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return true; }
+    bool d2h(void* h, const void* d, size_t n) { memcpy(h, d, n); return true; }
+    bool zero(void* d, size_t n) { memset(d, 0, n); return true; }
+    bool sync() { return true; }
+    static unsigned blocks(uint64_t n, unsigned per) { return (unsigned)std::max<uint64_t>(1, (n + per - 1) / per); }
+    bool jobs(const c2_allele_jobs_args& A) { emu::launch(blocks(A.S.n_reads, 256), [&] { c2_allele_jobs_kernel(A); }, 256); return true; }
+    bool iota(uint32_t* out, uint64_t n) { for (uint64_t i = 0; i < n; ++i) out[i] = (uint32_t)i; return true; }
+    bool reads(const c2_allele_row* rows, const uint32_t* order, uint64_t m, uint32_t* out) { emu::launch(blocks(m, 256), [&] { c2_allele_reads_kernel(rows, order, m, out); }, 256); return true; }
+    bool probe(const c2_allele_probe_args& A) { emu::launch(blocks(A.m, 4), [&] { c2_allele_probe_kernel(A); }, 256); return true; }
+    bool lengths(const c2_allele_text_args& A) { emu::launch(blocks(A.m, 256), [&] { c2_allele_lengths_kernel(A); }, 256); return true; }
+    bool emit(const c2_allele_text_args& A) { emu::launch(blocks(A.q1 - A.q0, 4), [&] { c2_allele_emit_kernel(A); }, 256); return true; }
+    bool fetch(const c2_allele_fetch_args& A) { emu::launch(blocks(A.m, 4), [&] { c2_allele_fetch_kernel(A); }, 256); return true; }
+    bool window(const c2_allele_window_args& A) { emu::launch(blocks(A.m, A.sub_index ? 4 : 256), [&] { c2_allele_window_kernel(A); }, 256); return true; }
+    bool group(const c2_allele_group_args& A) { emu::launch(blocks(A.ms, 256), [&] { c2_allele_group_kernel(A); }, 256); return true; }
+    bool scan(const uint32_t* in, uint64_t* out, uint64_t n) { uint64_t acc = 0; for (uint64_t i = 0; i < n; ++i) { const uint64_t v = in[i]; out[i] = acc; acc += v; } return true; }
+    template <class Less> bool sort_with(Less less, uint32_t* in, uint32_t* out, uint64_t n) { std::copy(in, in + n, out); std::stable_sort(out, out + n, less); return true; }
+    bool sort_rows(c2_allele_row_less less, uint32_t* in, uint32_t* out, uint64_t n) { return sort_with(less, in, out, n); }
+    bool sort_keys(c2_allele_key_less less, uint32_t* in, uint32_t* out, uint64_t n) { return sort_with(less, in, out, n); }
+};
+std::string g_allele_err;
+}  // namespace
+
+extern "C" {
+const char* emu_allele_last_error() { return g_allele_err.c_str(); }
+int emu_allele_table_build(const c2_allele_src* src, void** out) {
+    c2a_table<EmuBackend>* t = nullptr;
+    const int rc = c2a_build(EmuBackend(), *src, &t, g_allele_err);
+    if (rc == 0) *out = t;
+    return rc;
+}
+uint64_t emu_allele_table_rows(void* t) { return t ? ((c2a_table<EmuBackend>*)t)->m : 0; }
+int emu_allele_table_write(void* t, const char* path, const char* const* labels, int64_t n_total, const char* const* probes, int32_t threads, uint64_t* bytes_written) {
+    auto* T = (c2a_table<EmuBackend>*)t;
+    const int rc = c2a_write(T, path, labels, n_total, probes, threads, bytes_written);
+    if (rc) g_allele_err = T->err;
+    return rc;
+}
+int emu_allele_table_fetch(void* t, c2_allele_row* rows, uint8_t* aligned, uint8_t* reference, uint32_t stride) {
+    auto* T = (c2a_table<EmuBackend>*)t;
+    const int rc = c2a_fetch(T, rows, aligned, reference, stride);
+    if (rc) g_allele_err = T->err;
+    return rc;
+}
+int emu_allele_table_around_cut_write(void* t, int32_t label, int32_t cut_point, int32_t ref_len, int32_t plot_window_size, int64_t n_total, const char* path,
+                                      int32_t threads, uint64_t* n_groups) {
+    auto* T = (c2a_table<EmuBackend>*)t;
+    const int rc = c2a_around_cut_write(T, label, cut_point, ref_len, plot_window_size, n_total, path, threads, n_groups);
+    if (rc) g_allele_err = T->err;
+    return rc;
+}
+void emu_allele_table_free(void* t) { delete (c2a_table<EmuBackend>*)t; }
+int emu_format_float_repr(double v, char* out) { return c2_py_float_repr(v, out); }
 }

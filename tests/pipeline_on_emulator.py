@@ -153,13 +153,58 @@ def _strand_plan(ctx, n_reads, d_reads, d_offsets, max_read_len, refs, ref_names
     assert rc == 0
 
 
+class _EmuAlleleCalls:
+    """alleles.CALLS -> the emulator's allele-table entry points (the product's c2_alleles_host.h over an emulator backend)"""
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            L = E.lib()
+            L.emu_allele_last_error.restype = ctypes.c_char_p
+            raise RuntimeError("%s: %s" % (what, (L.emu_allele_last_error() or b"").decode()))
+
+    @staticmethod
+    def build(ctx, src, stream):
+        h = ctypes.c_void_p()
+        _EmuAlleleCalls._chk(E.lib().emu_allele_table_build(ctypes.byref(src), ctypes.byref(h)), "emu_allele_table_build")
+        return h
+
+    @staticmethod
+    def rows(ctx, h):
+        E.lib().emu_allele_table_rows.restype = ctypes.c_uint64
+        return int(E.lib().emu_allele_table_rows(h))
+
+    @staticmethod
+    def write(ctx, h, path, labels, n_total, probes, threads):
+        nb = ctypes.c_uint64()
+        _EmuAlleleCalls._chk(E.lib().emu_allele_table_write(h, path, labels, ctypes.c_int64(n_total), probes, int(threads), ctypes.byref(nb)), "emu_allele_table_write")
+        return int(nb.value)
+
+    @staticmethod
+    def fetch(ctx, h, rows, aligned, reference, stride):
+        _EmuAlleleCalls._chk(E.lib().emu_allele_table_fetch(h, rows, aligned, reference, ctypes.c_uint32(stride)), "emu_allele_table_fetch")
+
+    @staticmethod
+    def around_cut_write(ctx, h, label, cut_point, ref_len, plot_window_size, n_total, path, threads):
+        ng = ctypes.c_uint64()
+        _EmuAlleleCalls._chk(E.lib().emu_allele_table_around_cut_write(h, int(label), int(cut_point), int(ref_len), int(plot_window_size), ctypes.c_int64(n_total),
+                                                                       path, int(threads), ctypes.byref(ng)), "emu_allele_table_around_cut_write")
+        return int(ng.value)
+
+    @staticmethod
+    def free(ctx, h):
+        E.lib().emu_allele_table_free.restype = None
+        E.lib().emu_allele_table_free(h)
+
+
 @contextlib.contextmanager
 def emulated_device(made=None):
     """Inside the block pipeline.quantify_* run on the emulator; restored afterwards.  made: the caller's list of emulated aligners
     (bench_on_emulator shares its own, so that the count pass always sees the aligner of the batch it counts)."""
     import torch
-    from crispresso2_amd import pipeline, variants, paired, counts as C, _native
+    from crispresso2_amd import pipeline, variants, paired, counts as C, _native, alleles
     made = [] if made is None else made
+    saved_allele_calls = alleles.CALLS
+    alleles.CALLS = _EmuAlleleCalls
 
     def make_aligner(*a, **kw):
         made.append(EmulatedAligner(*a, **kw))
@@ -188,3 +233,4 @@ def emulated_device(made=None):
         variants.BatchAligner, paired.BatchAligner = saved_variants_aligner, saved_paired_aligner
         C.select_best_device = saved_select
         C.strand_plan_device = saved_strand
+        alleles.CALLS = saved_allele_calls

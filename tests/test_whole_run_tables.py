@@ -446,15 +446,15 @@ def test_pipeline_on_the_emulator_both_strand_batch_feeds_counts_view_and_allele
     a["aln_seed_min"] = 1000
     with emulated_device():
         res = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
-        S = res._state
-        assert S["r2"] is not None and S["use2"][:, 0].sum() > 30 and (~S["use2"][:, 0]).sum() > 60
+        S = res.host_view()
+        assert res._state["r2"] is not None and S["use2"][:, 0].sum() > 30 and (~S["use2"][:, 0]).sum() > 60
         # the seed test ran in c2_strand_plan_kernel; the host's c2_strand_plan gives the same run
         pipeline.FORCE_HOST_STRAND_PLAN = True
         try:
             res_h = pipeline.quantify_fastq(str(fq), refs, names, matrices()["EDNAFULL"], _pipeline_args(a))
         finally:
             pipeline.FORCE_HOST_STRAND_PLAN = False
-        assert res_h.stats == res.stats and np.array_equal(res_h._state["use2"], S["use2"])
+        assert res_h.stats == res.stats and np.array_equal(res_h.host_view()["use2"], S["use2"])
         assert all(np.array_equal(res_h.per_ref[nm][kk], vv) if isinstance(vv, np.ndarray) else res_h.per_ref[nm][kk] == vv
                    for nm in names for kk, vv in res.per_ref[nm].items())
         res.stats["N_READS_INPUT"] = 250                              # the file fed here is the already filtered one
@@ -821,7 +821,7 @@ def test_device_ingest_with_both_strand_reads_and_partners(tmp_path, monkeypatch
             monkeypatch.setattr(pipeline, "RC_PARTNERS_ON_DEVICE_MIN", dev_min)
             res = pipeline.quantify_fastq(str(fq), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args())
             assert (getattr(res, "ingest_route", None) == "device") == (route == "device")
-            results.append((res.stats, res.per_ref["Reference"], res.alleles(), res._state["slot2"]))
+            results.append((res.stats, res.per_ref["Reference"], res.alleles(), res.host_view()["slot2"]))
     st0, pr0, al0, slot2 = results[0]
     assert (slot2 >= 0).sum() >= 2                                   # (the second batch ran)
     for st, pr, al, _ in results[1:]:
@@ -962,7 +962,7 @@ def test_count_transfer_on_the_device_equals_the_sequential_loop(tmp_path, monke
             tm = {}
             res = pipeline.quantify_fastq(str(fq), {"Reference": ref, "Palindrome": ref2}, ["Reference", "Palindrome"], matrices()["EDNAFULL"],
                                           _pipeline_args(), timings=tm)
-            out.append((res.stats, res.per_ref, res.alleles(), res._state["cnt"].tolist()))
+            out.append((res.stats, res.per_ref, res.alleles(), res.host_view()["cnt"].tolist()))
     assert out[0][0] == out[1][0] and out[0][2] == out[1][2] and out[0][3] == out[1][3]
     for nm in ("Reference", "Palindrome"):
         for kk, vv in out[0][1][nm].items():
