@@ -442,8 +442,8 @@ def _e2e_prepare(reads, workers):
         except OSError:
             continue
         m = n
-        if free < 1.4 * per * n:
-            m = int(free / (1.4 * per))
+        if free < 1.9 * per * n:                                  # (the FASTQ, its BGZF copy, and the result tables of the with_all_tables leg)
+            m = int(free / (1.9 * per))
             m -= m % 1000
         if m < min(n, 100_000):
             continue
@@ -499,6 +499,39 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
                      "stage_seconds_note": "from one more run with a device synchronisation after every stage (the last of seconds_all_runs); the "
                                            "timed runs have none", "unique_reads": uniq, "ingest_route": route}
     os.environ.pop("C2_FQ_INGEST", None)
+    # ---- a run that ends where the reference's ends: FASTQ -> every result table of tables.write_tables ON DISK (the allele frequency table --
+    # one line per aligned unique read, sorted -- and the alleles around the guide's cut among them: rows, sort, grouping and text on the device)
+    from crispresso2_amd import tables
+    ref_t = dict(ref)
+    ref_t["sgRNA_orig_sequences"] = [amp[L // 2 - 16:L // 2 + 4]]
+    out_dir = os.path.join(files["dir"], "tables")
+    runs = []
+    for rep in range(repeat + 1):
+        shutil.rmtree(out_dir, ignore_errors=True)
+        tt = {}
+        t0 = time.perf_counter()
+        res = pipeline.quantify_fastq(files["plain"], {"Reference": ref_t}, ["Reference"], matrix, args, ctx=ctx)
+        t1 = time.perf_counter()
+        written = tables.write_tables(res, {"Reference": ref_t}, ["Reference"], out_dir, timings=tt)
+        t2 = time.perf_counter()
+        runs.append((t2 - t0, t1 - t0, tt))
+        rows = res.allele_table().n_rows
+        table_bytes = {w: os.path.getsize(os.path.join(out_dir, w)) for w in written}
+        res.allele_table().close()
+        del res
+        time.sleep(0.3)
+    best = min(runs[1:], key=lambda r: r[0])
+    with open(os.path.join(out_dir, "Alleles_frequency_table.txt"), "rb") as fh:
+        head_lines = fh.read(1 << 16).split(b"\n")[:3]
+    out["with_all_tables"] = {"seconds": best[0], "reads_per_s": files["reads"] / best[0], "seconds_all_runs": [r[0] for r in runs],
+                              "quantify_fastq_seconds": best[1], "write_tables_seconds": best[0] - best[1], "write_tables_stage_seconds": best[2],
+                              "files_written": len(table_bytes), "bytes_written": int(sum(table_bytes.values())),
+                              "allele_table_rows": rows, "allele_table_bytes": table_bytes.get("Alleles_frequency_table.txt"),
+                              "alleles_around_cut_bytes": max([v for w, v in table_bytes.items() if "_around_" in w], default=None),
+                              "second_line_of_the_allele_table_starts": head_lines[1][:40].decode("ascii", "replace") if len(head_lines) > 1 else None,
+                              "note": "FASTQ (plain, device ingest) -> count tensors -> every .txt of tables.write_tables on the same file system; best of %d "
+                                      "runs after a warm-up; the reference zips the allele table afterwards (not done here)" % repeat}
+    shutil.rmtree(out_dir, ignore_errors=True)
     out["reads_per_s"] = out["plain"]["reads_per_s"]
     out["stage_seconds"] = out["plain"]["stage_seconds"]
     out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"] == tallies["plain_host_parser"] == tallies["bgzf_host_parser"]
@@ -510,6 +543,36 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
     return out
 
 
+def _compare_with_reference(legs, d_aln_read, d_aln_ref, rec, k, all_refs):
+    """every alignment the reference's compiled code computed for `legs` (oracle/cpu_baseline.py: blake2b digests of the two aligned strings,
+    the classifier's three window counts of the best alignment) against the device's output for the same reads -> (reads compared, identical)"""
+    from oracle import cpu_baseline as cb
+    compared = identical = 0
+    CH = 65536
+    for leg in legs:
+        a0, cnt_r = leg["first_read"], leg["n_reads"]
+        t0_, nt = a0 * (k if all_refs else 1), cnt_r * (k if all_refs else 1)
+        dig = np.zeros(nt, dtype=np.uint64)
+        for c0 in range(0, nt, CH):
+            c1 = min(nt, c0 + CH)
+            ar = d_aln_read[t0_ + c0:t0_ + c1].cpu().numpy()
+            af = d_aln_ref[t0_ + c0:t0_ + c1].cpu().numpy()
+            Ts = rec["aln_len"][t0_ + c0:t0_ + c1]
+            for q in range(c1 - c0):
+                T = int(Ts[q])
+                dig[c0 + q] = cb.digest(ar[q, :T].tobytes(), af[q, :T].tobytes())
+        same = dig == leg["digests"]
+        rr = np.arange(cnt_r)
+        tb = t0_ + (rr * k + leg["best_ref"].astype(np.int64) if all_refs else rr)
+        same_cnt = ((rec["insertion_n"][tb] == leg["counts"][:, 0]) & (rec["deletion_n"][tb] == leg["counts"][:, 1]) &
+                    (rec["substitution_n"][tb] == leg["counts"][:, 2]))
+        if all_refs:
+            same = same.reshape(cnt_r, k).all(axis=1)
+        compared += cnt_r
+        identical += int((same & same_cnt).sum())
+    return compared, identical
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -519,7 +582,10 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (0 = the configuration's size)")
     ap.add_argument("--len", type=int, default=0, dest="L", help="read and amplicon length (0 = the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall seconds of the CPU baseline's sweep over pool sizes")
+    ap.add_argument("--cpu-long-seconds", type=float, default=60.0, help="... then the best pool size once more for this long (0: skip); its rate is cpu_baseline.value")
+    ap.add_argument("--ref-check-reads", type=int, default=100_000,
+                    help="reads of each OTHER configuration (other_configs) aligned by the reference's compiled code before the timed region and compared with the device's output")
     ap.add_argument("--workers", type=int, default=0, help="processes generating the synthetic reads (0 = auto; 1 = no fork, for profiler runs)")
     ap.add_argument("--band", type=int, default=-1, help="pointer-plane band: -1 auto, 0 off, n lanes each side")
     ap.add_argument("--band-wgs", type=int, default=0, help="target workgroups per CU for the automatic band")
@@ -569,8 +635,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline as cb
         cpu_baseline, cpu_legs = cb.run(reads, refs, matrix_path, GO, GE, ref_ids=wl["ref_ids"], all_refs=all_refs, cores=ncpu,
-                                        target_seconds=args.cpu_seconds)
-    other_wl, e2e_files = {}, None
+                                        target_seconds=args.cpu_seconds, long_seconds=args.cpu_long_seconds)
+    other_wl, other_ref, e2e_files = {}, {}, None
     if extras:
         t0 = time.perf_counter()
         for cfg in (2, 4, 5):
@@ -578,6 +644,17 @@ def main():
                 Lc, nc = CONFIG_DEFAULTS[cfg]
                 other_wl[cfg] = (Lc, build_workload(cfg, Lc, min(nc, args.extra_reads) if args.extra_reads else nc, rank, workers))
         t_gen_other = time.perf_counter() - t0
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and args.ref_check_reads > 0 and args.check > 0:
+            # the first reads of every other configuration through the reference's compiled code (a checker, not a timing; before HIP: it forks)
+            from oracle import cpu_baseline as cb
+            procs_ = int((cpu_baseline or {}).get("best_procs") or min(ncpu, 16))
+            for cfg, (Lc, wlc) in sorted(other_wl.items()):
+                m_ = min(len(wlc["reads"]), args.ref_check_reads)
+                try:
+                    other_ref[cfg] = cb.reference_slice(wlc["reads"][:m_], wlc["refs"], matrix_path, GO, GE,
+                                                        ref_ids=None if wlc["ref_ids"] is None else wlc["ref_ids"][:m_], all_refs=wlc["all_refs"], procs=procs_)
+                except Exception as e:
+                    other_ref[cfg] = ({"error": repr(e)}, None)
         if rank == 0 and world == 1 and not all_refs and wl["ref_ids"] is None:
             try:
                 e2e_files = _e2e_prepare(reads[:args.extra_reads] if args.extra_reads else reads, min(64, max(workers, ncpu // 4)))
@@ -612,6 +689,15 @@ def main():
     tm = job.timed(args.warmup, args.steps)
     dt, kernel_ms, first_ms, launches = tm["dt"], tm["kernel_ms"], tm["first_ms"], tm["launches"]
     tiers = ctx.tier_info()
+    packed_share = None                                           # share of the batch's alignments the packed (int16 pair) kernels finished
+    try:
+        left_, unpaired_ = ctx.tier_info_ex()
+        if args.kernel == "auto" and left_ and not os.environ.get("C2_NO_PACKED_FILL"):
+            # what the int16 kernels THEMSELVES finished: a tier's tasks minus those it could not pair (they run its 32-bit twin) minus those it hands on
+            tier_in = [n_tasks] + list(left_[:-1])
+            packed_share = float(sum(tier_in[t] - unpaired_[t] - left_[t] for t in range(len(left_)))) / float(n_tasks)
+    except Exception:
+        packed_share = None
 
     dedup_on = None
     if rank == 0 and world == 1 and not all_refs and wl["ref_ids"] is None and not args.no_dedup_leg:
@@ -664,29 +750,7 @@ def main():
         checks["oracle_sample"] = args.check
         # (2) EVERY alignment the CPU-baseline legs computed with the reference itself (strings by digest, the three window counts)
         if cpu_legs:
-            compared = identical = 0
-            CH = 65536
-            for leg in cpu_legs:
-                a0, cnt_r = leg["first_read"], leg["n_reads"]
-                t0_, nt = a0 * (k if all_refs else 1), cnt_r * (k if all_refs else 1)
-                dig = np.zeros(nt, dtype=np.uint64)
-                for c0 in range(0, nt, CH):
-                    c1 = min(nt, c0 + CH)
-                    ar = d_aln_read[t0_ + c0:t0_ + c1].cpu().numpy()
-                    af = d_aln_ref[t0_ + c0:t0_ + c1].cpu().numpy()
-                    Ts = rec["aln_len"][t0_ + c0:t0_ + c1]
-                    for q in range(c1 - c0):
-                        T = int(Ts[q])
-                        dig[c0 + q] = cb.digest(ar[q, :T].tobytes(), af[q, :T].tobytes())
-                same = dig == leg["digests"]
-                rr = np.arange(cnt_r)
-                tb = t0_ + (rr * k + leg["best_ref"].astype(np.int64) if all_refs else rr)
-                same_cnt = ((rec["insertion_n"][tb] == leg["counts"][:, 0]) & (rec["deletion_n"][tb] == leg["counts"][:, 1]) &
-                            (rec["substitution_n"][tb] == leg["counts"][:, 2]))
-                if all_refs:
-                    same = same.reshape(cnt_r, k).all(axis=1)
-                compared += cnt_r
-                identical += int((same & same_cnt).sum())
+            compared, identical = _compare_with_reference(cpu_legs, d_aln_read, d_aln_ref, rec, k, all_refs)
             checks["reference_compared_n"] = compared
             checks["reference_identical_n"] = identical
             checks["reference_identical"] = bool(compared == identical)
@@ -790,6 +854,17 @@ def main():
                          "alignments_per_s": tc["alignments_per_s"],
                          "step_breakdown_ms": {"align_chain": tc["align_ms"], "select_best": tc["select_ms"], "count_vectors_and_all_reduce": tc["count_ms"]},
                          "tasks_left_after_each_banded_launch": tiers_c, "all_status_ok": bool((rec_c["status"] == 0).all())}
+                if cfg in other_ref:
+                    leg_c, kind_c = other_ref[cfg]
+                    if "error" in leg_c:
+                        entry["reference_check_error"] = leg_c["error"]
+                    else:
+                        cmp_n, same_n = _compare_with_reference([leg_c], jc.outputs[0], jc.outputs[1], rec_c, jc.k, jc.all_refs)
+                        entry["reference_compared_n"], entry["reference_identical_n"] = cmp_n, same_n
+                        entry["reference_identical"] = bool(cmp_n == same_n)
+                        entry["reference_check"] = {"kind": kind_c, "procs": leg_c["procs"], "seconds": leg_c["seconds"],
+                                                    "note": "the first reads of this configuration aligned by the reference's compiled code (oracle/_ref) on the "
+                                                            "host before the timed region; strings by digest + the best alignment's three window counts"}
                 del rec_c
                 if rank == 0 and args.check > 0 and not args.no_full_plane_check:
                     eq, tf = jc.chain_equals_full_plane()
@@ -835,7 +910,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             # the arithmetic type of the dominant kernel's DP cells: int16 pairs in the packed kernels (proven range, c2_pk_eligible), int32 otherwise
-            "dtype": "int16" if dominant.startswith("c2_align_diagp") else "int32",
+            "dtype": ("int16x2 packed, host-proven range; int32 fallback (exact; config.int32_chain_reads_per_s = all-int32 chain)"
+                      if dominant.startswith("c2_align_diagp") else "int32"),
             "packed_fill_sums": ("v_add_u32 under a per-anti-diagonal bias (c2_pk_add32_ok)" if add32 else "v_pk_add_i16") if dominant.startswith("c2_align_diagp") else None,
             "dtype_note": "exact integer DP, not a precision trade: the packed kernels hold two alignments per 32-bit lane as int16 pairs only for "
                           "references whose DP values the host proves to fit (c2_pk_eligible); everything else runs the int32 kernels; the "
@@ -850,7 +926,21 @@ def main():
                        "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
                        "kernel_chain": chain,
                        "tasks_left_after_each_banded_launch": tiers,
-                       "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"]},
+                       "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"],
+                       # (scalars the driver's record keeps: the all-int32 chain on the same batch, how much of the batch the packed kernels finished,
+                       #  the checks against the reference's compiled code, the end-to-end legs)
+                       "int32_chain_reads_per_s": None if not int32_chain else int32_chain["reads_per_s"],
+                       "int32_chain_ms_per_step": None if not int32_chain else int32_chain["ms_per_step"],
+                       "int32_chain_records_equal": None if not int32_chain else int32_chain["records_equal_the_packed_chain"],
+                       "packed_int16_share": packed_share,
+                       "chain_equals_full_plane_n": checks.get("chain_equals_full_plane_n"),
+                       "reference_compared_n": checks.get("reference_compared_n"), "reference_identical_n": checks.get("reference_identical_n"),
+                       "other_configs_reference_identical": None if not other_configs else {
+                           c_: "%s/%s" % (e_.get("reference_identical_n"), e_.get("reference_compared_n")) for c_, e_ in other_configs.items() if isinstance(e_, dict) and "reference_compared_n" in e_},
+                       "other_configs_reads_per_s": None if not other_configs else {c_: e_.get("reads_per_s") for c_, e_ in other_configs.items() if isinstance(e_, dict) and "reads_per_s" in e_},
+                       "e2e_fastq_to_tensors_reads_per_s": None if not e2e or "plain" not in e2e else e2e["plain"]["reads_per_s"],
+                       "e2e_fastq_to_all_tables_seconds": None if not e2e or "with_all_tables" not in e2e else e2e["with_all_tables"]["seconds"],
+                       "e2e_fastq_to_all_tables_reads_per_s": None if not e2e or "with_all_tables" not in e2e else e2e["with_all_tables"]["reads_per_s"]},
             "alignments_per_s": world * n_tasks * args.steps / dt,
             "step_breakdown_ms": {"align_chain": tm["align_ms"], "select_best": tm["select_ms"], "count_vectors_and_all_reduce": tm["count_ms"],
                                   "note": "rank 0, HIP events on the stream of each phase, mean over the timed steps" +

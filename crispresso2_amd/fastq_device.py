@@ -355,6 +355,8 @@ class DeviceIngest:
                    max_len=mx, min_len=mn, batch_bytes=bb, rc_partner=rc_partner, d_counts=d_counts, d_rc_partner=d_rc_partner)
         if last is not None and len(self.batches) == 1:
             out["d_reads"], out["d_off"] = last
+        elif not self.batches:                                                      # (no non-empty sequence line at all: an empty arena, as _device_front makes)
+            out["d_reads"], out["d_off"] = torch.zeros(1, dtype=torch.uint8, device=self.dev), torch.zeros(1, dtype=torch.int64, device=self.dev)
         lap("offsets")
         if trace is not None:
             out["finish_trace_ms"] = {w: round((t - trace[i][1]) * 1e3, 3) for i, (w, t) in enumerate(trace[1:])}
@@ -382,6 +384,27 @@ def estimate_records(source, size):
 
 
 def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
+    """_ingest_file; running out of device memory (the whole text, 40 bytes per record and 16 per table slot are resident) is
+    DeviceIngestUnavailable like the kernels' own "I cannot": the caller takes the host parser, which holds only the unique reads."""
+    import torch
+    try:
+        return _ingest_file(path, ctx, dev, timings, on_batch, min_batch)
+    except torch.OutOfMemoryError as e:
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+        raise DeviceIngestUnavailable("out of device memory (%s)" % str(e).split("\n")[0])
+
+
+def release_pinned():
+    """give the page-locked upload buffers back (3 x the chunk size per device, at most 768 MiB; kept between runs because pinning them costs
+    as much as uploading a GB).  A process that ingests one file and then lives on can call this; hostcopy.release_staging() is its twin."""
+    _pinned.clear()
+
+
+PINNED_CACHE_BYTES = int(os.environ.get("C2_FQ_PINNED_CACHE", 1 << 30))    # the upload buffers are kept between runs up to this size (per device); beyond, freed at once
+
+
+def _ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
     """path: a plain FASTQ file, the text itself as a uint8 array in host memory (what the host inflated / filtered), or a
     _native.BgzfFile (its members are inflated chunk by chunk straight into the pinned upload buffers).
     The whole text -> DeviceIngest.finish()'s dict.  Host threads copy the text into three pinned buffers in turn; every chunk is framed
@@ -473,6 +496,7 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
         copy_stream = torch.cuda.Stream(device=dev)
         q = queue.Queue()
         tail_byte = []
+        stop = threading.Event()                                      # set when the consumer gave up: the producer ends after the chunk in hand
 
         def read_into(args):
             buf, off, n = args
@@ -492,6 +516,8 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
             try:
                 with ThreadPoolExecutor(threads) as pool:
                     for c, (lo, hi, b0, b1) in enumerate(spans):
+                        if stop.is_set():
+                            break
                         k = c % len(pins)
                         if evs[k] is not None:
                             evs[k].synchronize()                      # the upload out of this buffer is done
@@ -524,8 +550,13 @@ def ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000):
                 lo, hi, ev = item
                 compute.wait_event(ev)
                 feed_upto(hi)
+        except BaseException:
+            stop.set()                                                # (a carriage return, more records than estimated, ...: no point in uploading the rest)
+            raise
         finally:
             th.join()
+            if 3 * chunk > PINNED_CACHE_BYTES:
+                _pinned.pop(key, None)
         if timings is not None:
             timings["upload_text"] = time.perf_counter() - t0
         if bgzf is not None:

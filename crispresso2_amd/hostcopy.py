@@ -36,6 +36,12 @@ def to_host(t, dtype=None):
         return a.astype(dtype) if dtype is not None else a.copy()
 
 
+def release_staging():
+    """give the pinned staging buffers back (at least 64 MiB per device, grown to the largest array that went through)"""
+    with _lock:
+        _staging.clear()
+
+
 def to_device(a, dev):
     """numpy array -> tensor on `dev` (same dtype and shape), staged through the pinned buffer: the array's own (pageable, freshly mapped)
     pages are never registered with the driver.  Small arrays and non-GPU devices: torch's own copy."""

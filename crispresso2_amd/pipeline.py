@@ -342,11 +342,13 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
     copy_stream = torch.cuda.Stream(device=dev) if on_gpu else compute
     q = queue.Queue()
 
+    stop = threading.Event()                                          # set when the consumer gave up: the parser ends after the chunk in hand
+
     def producer():
         try:
             done = fq.done
             seen = 0
-            while not done:
+            while not done and not stop.is_set():
                 nu, done = fq.next()
                 if nu - seen >= STREAM_MIN_BATCH or (done and nu > seen):
                     q.put((seen, nu, fq.offsets_slice(seen, nu)))
@@ -407,6 +409,9 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
                 d_off = torch.from_numpy(rel.copy())
             parts.append(_enqueue_first_batch(aligner, ctx, dev, refs, ref_names, args, legacy, m, d_reads, d_off, max_lj, compute.cuda_stream))
             off_parts.append(off)
+    except BaseException:
+        stop.set()
+        raise
     finally:
         th.join()
     t_ingest_done = time.perf_counter()

@@ -222,14 +222,29 @@ def write_reads_from_all_amplicons_tables(res, refs, ref_names, out_dir):
     return written
 
 
-def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN=""):
-    """Writes the tables listed in the module docstring into out_dir; returns the list of file names."""
+def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN="", timings=None):
+    """Writes the tables listed in the module docstring into out_dir; returns the list of file names.
+    timings: optional dict that receives the wall seconds of the allele table's build (rows + sort on the device), its file, the
+    around-cut files, and everything else."""
+    import time
     import numpy as np
     allele_rows = None
+    t_start = time.perf_counter()
+    t_alleles = 0.0
     os.makedirs(out_dir, exist_ok=True)
     written = ["CRISPResso_quantification_of_editing_frequency.txt", "Alleles_frequency_table.txt"]
     write_quantification_of_editing_frequency(res, ref_names, os.path.join(out_dir, written[0]))
+    t0 = time.perf_counter()
+    if hasattr(res, "allele_table"):
+        res.allele_table()
+    t1 = time.perf_counter()
     write_alleles_frequency_table(res, os.path.join(out_dir, written[1]), dsODN=dsODN)
+    t2 = time.perf_counter()
+    t_alleles += t2 - t0
+    t_around = 0.0
+    if timings is not None:
+        timings["allele_table_build"] = t1 - t0
+        timings["allele_table_write"] = t2 - t1
     if all(k in res.stats for k in ("N_TOTAL", "N_COMPUTED_ALN", "N_CACHED_ALN", "N_COMPUTED_NOTALN", "N_CACHED_NOTALN")):
         written.append("CRISPResso_mapping_statistics.txt")
         write_mapping_statistics(res, os.path.join(out_dir, written[-1]))
@@ -293,6 +308,7 @@ def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN=""):
             if table is None and allele_rows is None:
                 allele_rows = res.alleles()
             labels = refs[name].get("sgRNA_names") or [""] * len(guides)
+            t_a0 = time.perf_counter()
             for cut_point, guide, label in zip(refs[name]["sgRNA_cut_points"], guides, labels):
                 fn = prefix + "Alleles_frequency_table_around_" + slugify(label if label != "" else "sgRNA_" + guide) + ".txt"
                 if table is not None:
@@ -303,6 +319,10 @@ def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN=""):
                 else:
                     write_alleles_around_cut(alleles_around_cut(allele_rows, name, cut_point, L, plot_window_size), os.path.join(out_dir, fn))
                 written.append(fn)
+            t_around += time.perf_counter() - t_a0
     if getattr(res, "first_ref_view", None) and any(res.per_ref[nm]["counts_total"] > 0 for nm in ref_names):
         written += write_reads_from_all_amplicons_tables(res, refs, ref_names, out_dir)
+    if timings is not None:
+        timings["around_cut_tables"] = t_around
+        timings["other_tables"] = time.perf_counter() - t_start - t_alleles - t_around
     return written

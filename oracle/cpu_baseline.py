@@ -4,7 +4,8 @@ Times the reference's own Cython hot path (oracle/_ref, kind "reference") -- or,
 (kind "port") -- on this host's cores: process pools over chunks of reads, each worker calling global_align per (read,
 candidate amplicon) and find_indels_substitutions on the best alignment, nothing else in the loop (BASELINE.md plan (A),
 the figure most favourable to the reference).  Measured: ONE process, then a sweep over pool sizes
-(32, 64, 128, 256, ... up to the host's CPUs); the best rate is the baseline and the curve is reported with it.
+(8, 16, 32, ... up to four times the CPUs this process may use: its affinity mask cut down by the cgroup's cpu.max quota), then the best
+pool size once more for a minute; that long leg's rate is the baseline and the curve is reported with it.
 
 Every alignment the legs compute is also kept as a 64-bit digest of its two aligned strings (blake2b; ~1 us next to the
 ~0.8-5 ms the alignment takes in the pool) together with the classifier's three counts, so bench.py can compare ALL of them
@@ -122,41 +123,99 @@ def _leg(ctx, procs, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, sta
     return out, res, kind
 
 
-def run(reads_u8, refs, matrix_path, go, ge, ref_ids=None, all_refs=False, cores=None, target_seconds=20.0, sweep=None):
+def usable_cpus():
+    """(CPUs this process may run on, the cgroup quota in CPUs or None): the affinity mask, and cpu.max of cgroup v2 / cfs_quota of v1"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, p = fh.read().split()[:2]
+            if q != "max":
+                quota = int(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = int(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                p = int(fh.read())
+            if q > 0:
+                quota = q / float(p)
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
+def reference_slice(reads_u8, refs, matrix_path, go, ge, ref_ids=None, all_refs=False, procs=8):
+    """Every alignment of reads_u8 (a slice of a workload) by the reference's compiled code on a pool of `procs` processes -- not a
+    timing, a checker: -> one result dict (first_read 0, n_reads, digests, counts, best_ref) for bench.py's digest comparison, + kind"""
+    import multiprocessing as mp
+    refs = [(s, list(map(int, g)), list(map(int, inc))) for s, g, inc in refs]
+    n, L = reads_u8.shape
+    ctx = mp.get_context("fork")
+    with ctx.Pool(procs, initializer=_init, initargs=(refs, matrix_path, go, ge)) as pool:
+        kind = pool.map(_kind, range(procs))[0]
+        chunk = max(8, n // (procs * 8))
+        jobs = [(reads_u8[a:min(n, a + chunk)].tobytes(), L,
+                 None if ref_ids is None else np.ascontiguousarray(ref_ids[a:min(n, a + chunk)], dtype=np.uint16).tobytes(), all_refs) for a in range(0, n, chunk)]
+        t0 = time.perf_counter()
+        done = pool.map(_work, jobs)
+        dt = time.perf_counter() - t0
+    return {"first_read": 0, "n_reads": int(sum(d[0] for d in done)), "digests": np.concatenate([d[2] for d in done]),
+            "counts": np.concatenate([d[3] for d in done]), "best_ref": np.concatenate([d[4] for d in done]), "seconds": dt, "procs": procs}, kind
+
+
+def run(reads_u8, refs, matrix_path, go, ge, ref_ids=None, all_refs=False, cores=None, target_seconds=20.0, sweep=None, long_seconds=60.0):
     """reads_u8: uint8 [n, L]; refs: list of (sequence, gap_incentive, include_idxs); ref_ids: uint16 [n] or None;
     all_refs: every read against every reference.  Every leg works on its own consecutive slice of the reads, sized for its
-    share of ~target_seconds.  -> (dict for the bench line, list of per-leg results with the digests)"""
+    share of ~target_seconds; then the best pool size runs once more for ~long_seconds (0: no such leg) and gives the reported value.
+    -> (dict for the bench line, list of per-leg results with the digests)"""
     import multiprocessing as mp
-    cores = cores or os.cpu_count() or 1
+    host_cpus = cores or os.cpu_count() or 1
+    affinity, quota = usable_cpus()
+    usable = max(1, int(min(affinity, quota) if quota else affinity))
     refs = [(s, list(map(int, g)), list(map(int, inc))) for s, g, inc in refs]
     if sweep is None:
-        sweep = [p for p in (32, 64, 128, 256, 512) if p <= cores]
-        if cores not in sweep and (not sweep or cores > sweep[-1] * 1.2 or cores < 32):
-            sweep.append(cores)
+        sweep = [p for p in (8, 16, 32, 64, 128, 256, 512) if p <= min(host_cpus, 4 * usable)]
+        if usable not in sweep and usable > 1:
+            sweep.append(usable)
+        sweep.sort()
     legs = [1] + [p for p in sweep if p > 1]
     ctx = mp.get_context("fork")      # bench.py calls this BEFORE it touches HIP, so fork is safe
     share = target_seconds / (len(legs) + 0.5)
     curve, results, start, kind = [], [], 0, None
     n, L = reads_u8.shape
+    reserve = n // 2 if long_seconds > 0 else 0                      # (reads kept for the long leg)
     for q, p in enumerate(legs):
-        if start >= n:
+        if start >= n - reserve:
             break
-        leg, res, kind = _leg(ctx, p, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, share * (0.5 if p == 1 else 1.0),
-                              max(1, (n - start) // (len(legs) - q)))
+        leg, res, kind = _leg(ctx, p, refs, matrix_path, go, ge, reads_u8[:n - reserve], ref_ids, all_refs, start, share * (0.5 if p == 1 else 1.0),
+                              max(1, (n - reserve - start) // (len(legs) - q)))
         curve.append(leg)
         results.append(res)
         start += res["n_reads"]
     multi = [c for c in curve if c["procs"] > 1] or curve
     best = max(multi, key=lambda c: c["reads_per_s"])
+    long_leg = None
+    if long_seconds > 0 and start < n:
+        long_leg, res, kind = _leg(ctx, best["procs"], refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, long_seconds, n - start)
+        results.append(res)
+        start += res["n_reads"]
+    rep = long_leg or best
     one = next((c for c in curve if c["procs"] == 1), None)
     k = len(refs) if all_refs else 1
-    out = {"value": best["reads_per_s"], "unit": "reads/s", "cores": best["procs"], "kind": kind,
-           "best_procs": best["procs"], "host_cpus": cores,
+    out = {"value": rep["reads_per_s"], "unit": "reads/s", "cores": min(best["procs"], usable), "kind": kind,
+           "best_procs": best["procs"], "host_cpus": host_cpus, "cpus_in_affinity_mask": affinity, "cgroup_cpu_quota": quota,
+           "cores_note": "cores = min(pool size, CPUs this process may use: the affinity mask cut down by the cgroup's cpu.max quota)",
            "one_proc_reads_per_s": one["reads_per_s"] if one else None,
            "curve": [{"procs": c["procs"], "reads_per_s": c["reads_per_s"], "reads": c["reads"], "seconds": c["seconds"]} for c in curve],
+           "long_leg": None if long_leg is None else {"procs": long_leg["procs"], "reads": long_leg["reads"], "seconds": long_leg["seconds"],
+                                                      "reads_per_s": long_leg["reads_per_s"]},
            "alignments_per_read": k,
            "sample": "reads %d..%d of the benchmark's reads (%d bp, %d candidate amplicon%s per read), one consecutive slice per "
-                     "pool size; global_align per (read, amplicon) + find_indels_substitutions on the best alignment; best pool "
-                     "size %d: %d reads in %.1f s wall" % (0, start, L, k, "" if k == 1 else "s", best["procs"], best["reads"], best["seconds"]),
-           "modified_in_sample": best["modified_in_sample"]}
+                     "pool size, then the best size (%d) for %.0f s: %d reads; global_align per (read, amplicon) + find_indels_substitutions "
+                     "on the best alignment" % (0, start, L, k, "" if k == 1 else "s", best["procs"], rep["seconds"], rep["reads"]),
+           "modified_in_sample": rep["modified_in_sample"]}
     return out, results

@@ -27,6 +27,7 @@ class _Ctx:
     def timing_enable(self, on): pass
     def timing_read_split(self): return 3.0, 2.0, 1
     def tier_info(self): return [7, 3, 1]
+    def tier_info_ex(self): return [7, 3, 1], [1, 0, 0]
     def launch_info(self, L): return dict(rows_per_lane=4, passes=1, lds_bytes=0, workgroups_per_cu=1, compute_units=1)
     def band_info(self, L): return dict(band_lanes=-1, fallback_tasks_last_launch=0)
 

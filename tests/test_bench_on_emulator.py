@@ -97,10 +97,16 @@ def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fa
     chain = full-plane check, and FASTQ -> tensors (plain and BGZF)."""
     out = BE.run_bench(["--steps", "1", "--warmup", "0", "--reads", "150", "--workers", "1", "--cpu-seconds", "1.0", "--check", "10",
                         "--extras", "on", "--extra-reads", "90", "--extra-steps", "1"])
-    assert out["dtype"] == "int16" and out["int32_chain"]["dtype"] == "int32" and out["int32_chain"]["records_equal_the_packed_chain"]
+    assert out["dtype"].startswith("int16x2 packed") and len(out["dtype"]) < 128 and out["int32_chain"]["dtype"] == "int32" and out["int32_chain"]["records_equal_the_packed_chain"]
+    cfgd = out["config"]                                            # the scalars the driver's record keeps
+    assert cfgd["int32_chain_reads_per_s"] == out["int32_chain"]["reads_per_s"] and cfgd["int32_chain_records_equal"] is True
+    assert 0.0 < cfgd["packed_int16_share"] <= 1.0 and cfgd["e2e_fastq_to_all_tables_seconds"] > 0
     for cfg, k_ in ((2, 1), (4, 3), (5, 1)):
         e = out["other_configs"]["config%d" % cfg]
         assert e["chain_equals_full_plane"] and e["chain_equals_full_plane_n"] == 90 * k_ and e["all_status_ok"] and e["reads_per_s"] > 0
     e2e = out["e2e"]
     assert e2e["reads"] == 90 and e2e["plain_equals_bgzf"] and e2e["plain"]["reads_per_s"] > 0 and e2e["bgzf"]["reads_per_s"] > 0
     assert e2e["tallies"]["N_TOT_READS"] == 90 and set(e2e["stage_seconds"]) >= {"ingest_dedup_streamed", "stream_tail_device", "count_kernels"}
+    wt = e2e["with_all_tables"]                                      # FASTQ -> every result table on disk, the allele table among them
+    assert wt["files_written"] >= 18 and wt["allele_table_rows"] > 0 and wt["allele_table_bytes"] > 500 and wt["alleles_around_cut_bytes"] > 100
+    assert set(wt["write_tables_stage_seconds"]) >= {"allele_table_build", "allele_table_write", "around_cut_tables", "other_tables"}

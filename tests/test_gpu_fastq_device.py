@@ -27,6 +27,23 @@ def _host_unique(path):
     return arena, off, counts, st, n_reads
 
 
+def _oracle_agrees(path, out, d_reads_host):
+    """third party: the restatement of the reference's readline loop (oracle/fastq.py, CRISPRessoCORE.py:1820-1849) -- same unique reads
+    (empty key aside) in first-seen order with the same multiplicities, same number of records"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import fastq as OF
+    cache, num_reads = OF.read_fastq_unique(str(path))
+    assert out["n_reads"] == num_reads
+    keys = [q for q in cache if q != ""]
+    assert out["n_unique"] == len(keys) and out["n_empty_records"] == cache.get("", 0)
+    assert out["counts"].astype(np.int64).tolist() == [cache[q] for q in keys]
+    off = out["offsets"].astype(np.int64)
+    blob = d_reads_host.tobytes()
+    assert blob[:int(off[-1])] == "".join(keys).encode("latin-1")
+    assert np.array_equal(np.diff(off), np.array([len(q) for q in keys], dtype=np.int64))
+
+
 def _write(path, n, L, rng, n_pool, tail=""):
     pool = ["".join(rng.choice("ACGT") for _ in range(rng.randint(L // 2, L))) for _ in range(n_pool)]
     pool[7] = "  " + pool[7] + "\t"                                   # (whitespace the reference strips; equals no other read)
@@ -58,8 +75,10 @@ def test_device_ingest_equals_the_host_parser(tmp_path, monkeypatch, tail):
     assert np.array_equal(out["counts"], counts[keep])
     assert np.array_equal(np.diff(out["offsets"].astype(np.int64)), lens[keep])
     want = np.concatenate([arena[off[i]:off[i + 1]] for i in np.nonzero(keep)[0]]) if keep.any() else np.zeros(0, np.uint8)
-    assert np.array_equal(out["d_reads"][:int(out["offsets"][-1])].cpu().numpy(), want)
+    got_reads = out["d_reads"][:int(out["offsets"][-1])].cpu().numpy()
+    assert np.array_equal(got_reads, want)
     assert int(counts.sum()) == n_reads
+    _oracle_agrees(p, out, got_reads)
     assert np.array_equal(out["rc_partner"], _native.rc_partners(want, out["offsets"]))
 
 
@@ -169,7 +188,9 @@ def test_fuzzed_text_against_the_host_parser(tmp_path, monkeypatch, seed):
     assert int(float(out["nonempty_lines"]) / 4.0) == st["N_READS_AFTER_PREPROCESSING"]
     assert np.array_equal(out["counts"], counts[keep]) and np.array_equal(np.diff(out["offsets"].astype(np.int64)), lens[keep])
     want = np.concatenate([arena[off[i]:off[i + 1]] for i in np.nonzero(keep)[0]]) if keep.any() else np.zeros(0, np.uint8)
-    assert np.array_equal(out["d_reads"][:int(out["offsets"][-1])].cpu().numpy(), want)
+    got_reads = out["d_reads"][:int(out["offsets"][-1])].cpu().numpy()
+    assert np.array_equal(got_reads, want)
+    _oracle_agrees(p, out, got_reads)
 
 
 def _sharded_worker(rank, world, port, path, out_dir, route):

@@ -190,6 +190,18 @@ def test_calculate_homology(ctx):
     import oracle
     for a, b in [(b"ACGTACGT", b"ACGTTCGT"), (b"AAAA", b"TTTT"), (b"ACG", b"ACG"), (b"ACGTACGTAC" * 7, b"ACGAACGTAC" * 7)]:
         assert R.calculate_homology(a, b) == oracle.calculate_homology(a, b)
+    # 200 random byte-string pairs (1 .. 700 bytes, related and unrelated) against the reference's own compiled calculate_homology
+    # (oracle/_ref; the C restatement where that is not built) -- the float32 accumulation included
+    compiled = oracle.ref()
+    want = compiled[1].calculate_homology if compiled is not None else oracle.calculate_homology
+    rng = np.random.default_rng(808)
+    for _ in range(200):
+        n = int(rng.integers(1, 700))
+        a = rng.choice(np.frombuffer(b"ACGTN-", dtype=np.uint8), n)
+        b = a.copy()
+        flip = rng.random(n) < rng.choice([0.0, 0.01, 0.3, 1.0])
+        b[flip] = rng.choice(np.frombuffer(b"ACGTN-", dtype=np.uint8), int(flip.sum()))
+        assert R.calculate_homology(a.tobytes(), b.tobytes()) == want(a.tobytes(), b.tobytes())
 
 
 def test_long_references_multipass_vs_oracle(mats, ctx):
@@ -701,6 +713,26 @@ def test_three_candidate_references_best_reference_selection(mats, ctx):
                 names.append(r)
         best_gpu.append(names)
     assert any(len(x) == 1 and x[0] == 1 for x in best_gpu) and any(len(x) == 1 and x[0] == 2 for x in best_gpu)
+    # ... and c2_select_best_kernel on the records that are on the device: its member masks, aligned / ambiguous flags against the names above
+    import torch
+    from crispresso2_amd import counts as C
+    dev = torch.device("cuda", 0)
+    n_r = len(rd)
+    d_rec = torch.from_numpy(res.records.view(np.uint8).reshape(-1, 32).copy()).to(dev)
+    d_member = torch.zeros((n_r, 1), dtype=torch.int64, device=dev)
+    d_use2 = torch.zeros((n_r, 1), dtype=torch.int64, device=dev)
+    d_flags = torch.zeros(n_r, dtype=torch.uint8, device=dev)
+    d_stats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
+    C.select_best_device(ctx, n_r, 3, d_rec.data_ptr(), C.min_mscore_table([60, 60, 60]), C.SELECT_DROP_AMBIGUOUS, int(res.records["aln_len"].max()),
+                         d_member=d_member.data_ptr(), d_use2=d_use2.data_ptr(), d_flags=d_flags.data_ptr(), d_stats=d_stats.data_ptr())
+    torch.cuda.synchronize()
+    member = d_member.cpu().numpy().reshape(-1)
+    fl = d_flags.cpu().numpy()
+    for k in range(n_r):
+        assert [r for r in range(3) if (int(member[k]) >> r) & 1] == best_gpu[k], (k, member[k], best_gpu[k])
+        assert bool(fl[k] & 1) == (len(best_gpu[k]) > 0) and bool(fl[k] & 2) == (len(best_gpu[k]) > 1), k
+    st = dict(zip(C.SELECT_STATS, d_stats.cpu().numpy().tolist()))
+    assert st["N_COMPUTED_ALN"] == sum(1 for x in best_gpu if x) and st["n_bad_status"] == 0
 
 
 def _default_args(**over):
