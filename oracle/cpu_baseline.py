@@ -90,8 +90,9 @@ def _kind(_):
     return _state["kind"]
 
 
-def _leg(ctx, procs, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, seconds, max_reads):
-    """One pool size on reads [start, start + sample) -> (dict, reads consumed, kind)"""
+def _leg(ctx, procs, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, seconds, max_reads, rate_hint=None):
+    """One pool size on reads [start, start + sample) -> (dict, reads consumed, kind).  The sample is sized from a calibration on a few
+    reads per worker, or from rate_hint (reads/s this pool size was measured at before: the calibration's cold start underestimates)."""
     n, L = reads_u8.shape
     n = min(n, start + max_reads)
     with ctx.Pool(procs, initializer=_init, initargs=(refs, matrix_path, go, ge)) as pool:
@@ -106,7 +107,7 @@ def _leg(ctx, procs, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, sta
         done0 = pool.map(_work, [chunk_of(start + a, min(start + a + per, start + cal)) for a in range(0, cal, per)])
         per_read = (time.perf_counter() - t0) * procs / max(cal, 1)
         a0 = start + cal
-        sample = int(min(n - a0, max(procs * 16, seconds * procs / max(per_read, 1e-6))))
+        sample = int(min(n - a0, max(procs * 16, seconds * rate_hint * 1.05 if rate_hint else seconds * procs / max(per_read, 1e-6))))
         chunk = max(8, sample // (procs * 8))
         bounds = [(a0 + a, min(a0 + a + chunk, a0 + sample)) for a in range(0, sample, chunk)]
         t0 = time.perf_counter()
@@ -200,7 +201,8 @@ def run(reads_u8, refs, matrix_path, go, ge, ref_ids=None, all_refs=False, cores
     best = max(multi, key=lambda c: c["reads_per_s"])
     long_leg = None
     if long_seconds > 0 and start < n:
-        long_leg, res, kind = _leg(ctx, best["procs"], refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, long_seconds, n - start)
+        long_leg, res, kind = _leg(ctx, best["procs"], refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, long_seconds, n - start,
+                                   rate_hint=best["reads_per_s"])
         results.append(res)
         start += res["n_reads"]
     rep = long_leg or best
