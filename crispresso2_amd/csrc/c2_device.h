@@ -248,12 +248,24 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 #define C2_CNT_CTL_BASE_INTS 96     // >= 16 + 4 * C2_CNT_WAVES
 #define C2_CNT_CTL_INTS (C2_CNT_CTL_BASE_INTS + C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE)   // + per task of a chunk: the part of a heavy weight that is still to be added
 #define C2_CNT_LOAD_BUDGET (1u << 30) // sum of weight x alignment length an LDS block may take between two flushes (its entries are int32)
-// LDS of the variant whose accumulator block lives in HBM: the difference array, the control words, the window prefix
-static inline size_t c2_count_lds_bytes_hbm(int lmax) {
-    return (((size_t)lmax + 1) + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
+// Staging: the strings of C2_CNT_STAGE alignments per wavefront are copied to LDS by the memory system itself (global_load_lds: no
+// register holds them) BEFORE the first of them is walked -- so a wavefront has C2_CNT_STAGE alignments' loads in flight instead of one,
+// which is what the kernel waits for (profiles/r03: 65 % of its wave cycles).  A slot holds C2_CNT_STAGE_ROW columns of both strings;
+// longer alignments are walked window by window.
+#ifndef C2_CNT_STAGE
+#define C2_CNT_STAGE 2
+#endif
+#ifndef C2_CNT_STAGE_ROW
+#define C2_CNT_STAGE_ROW 256           // a multiple of 256 (the walk looks at 256 columns at a time)
+#endif
+#define C2_CNT_STAGE_BYTES ((size_t)C2_CNT_WAVES * C2_CNT_STAGE * 2u * C2_CNT_STAGE_ROW)
+// LDS of the variant whose accumulator block lives in HBM: the difference array, the control words, the window prefix, the staging slots
+static inline size_t c2_count_lds_tail_bytes(int lmax) {               // what follows the block: cov, control words, inc_prefix (padded to 16), staging
+    return ((((size_t)lmax + 1) + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4 + 15) / 16 * 16 + C2_CNT_STAGE_BYTES;
 }
-static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {      // block + the LDS-only `cov` vector (lmax + 1) + control words + inc_prefix
-    return (per_ref + ((size_t)lmax + 1) + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4;
+static inline size_t c2_count_lds_bytes_hbm(int lmax) { return c2_count_lds_tail_bytes(lmax); }
+static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {      // block + the LDS-only `cov` vector (lmax + 1) + control words + inc_prefix + staging
+    return per_ref * sizeof(int) + c2_count_lds_tail_bytes(lmax);
 }
 
 // packed (int16) fill: byte stride between the pair-score tables of two reference symbols in LDS.  65 dwords, not 64: lanes that hold the

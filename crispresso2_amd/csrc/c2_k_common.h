@@ -80,3 +80,11 @@ __device__ __forceinline__ unsigned c2_fq_complement(const unsigned c) {
 #define C2_LANES_ACTIVE_BEGIN(cond) if (cond) {
 #define C2_LANES_ACTIVE_END() }
 #endif
+// LDS-DMA (global_load_lds: the memory system writes the loaded bytes to LDS at a wave-uniform base + lane * size; no VGPR holds them).
+// C2_WAIT_LDS_DMA: every copy this wavefront issued has landed; C2_LDS_READS_DONE: every LDS read it issued has returned (a slot may be
+// overwritten).  The wave emulator (tests/emu) copies lane by lane and makes both a rendezvous of the wavefront's lanes.
+#ifndef C2_WAIT_LDS_DMA
+#define C2_WAIT_LDS_DMA() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define C2_LDS_READS_DONE() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+

@@ -117,6 +117,8 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
     int* cov = HBM ? (int*)c2_smem : acc + per_ref;
     int* ctl = cov + VL;                                        // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
     uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
+    // staging slots of the wavefronts (c2_count_lds_tail_bytes: behind cov, the control words and inc_prefix, that part padded to 16 bytes)
+    uint8_t* stage = (uint8_t*)cov + ((((size_t)VL + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)A.lmax + 2 + 1) / 2) * 4 + 15) / 16 * 16);
     for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
     for (int k = tid; k < VL; k += NT) cov[k] = 0;
     block_barrier();
@@ -310,51 +312,103 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                     atomicAdd(acc + o_h + C2_H_EFFECTIVE_LEN * A.hl + eff, w);
                 }
             }
-            while (todo) {
-                const int kk = __builtin_ctz(todo);
-                todo &= todo - 1;
-                const unsigned r6 = (unsigned)__builtin_amdgcn_readlane((int)d6, kk);
-                if ((int)(r6 >> 16) != tref) continue;
-                pending &= ~(1u << kk);
+            // ---- the alignments of this round that are walked: their strings are STAGED in LDS, C2_CNT_STAGE of them at a time, by the
+            //      memory system itself (global_load_lds: no register waits for them), and only then walked one after the other -- a
+            //      wavefront has that many alignments' loads in flight instead of one
+            unsigned walk = (unsigned)__ballot(mine && ((todo >> lane) & 1u) && !(discard && ((d1 & 0xffffu) != 0u || (d1 >> 16) != 0u)));   // (discarded reads: counted above; no vectors, :3996-4000)
+            pending &= ~(unsigned)__ballot(mine && ((todo >> lane) & 1u));
+            uint8_t* const stage_w = stage + (size_t)wave * (C2_CNT_STAGE * 2u * C2_CNT_STAGE_ROW);
+            // columns [col0, col0 + ncols) of both strings of `task` -> slot (ncols <= C2_CNT_STAGE_ROW)
+            auto stage_window = [&](uint8_t* slot, const uint64_t task, const int col0, const int ncols) {
+                const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride + col0;
+                const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride + col0;
+                if (rows_aligned) {
+                    for (int b = 0; b < ncols; b += 256) {                                          // (one round unless the slot is longer than 256 columns)
+                        const int p = b + 4 * lane;
+                        if (p < ncols) {
+                            __builtin_amdgcn_global_load_lds((const void*)(R_ + p), (void*)(slot + b), 4, 0, 0);
+                            __builtin_amdgcn_global_load_lds((const void*)(F_ + p), (void*)(slot + C2_CNT_STAGE_ROW + b), 4, 0, 0);
+                        }
+                    }
+                } else {
+                    for (int b = 0; b < ncols; b += 64) {
+                        const int p = b + lane;
+                        if (p < ncols) {
+                            __builtin_amdgcn_global_load_lds((const void*)(R_ + p), (void*)(slot + b), 1, 0, 0);
+                            __builtin_amdgcn_global_load_lds((const void*)(F_ + p), (void*)(slot + C2_CNT_STAGE_ROW + b), 1, 0, 0);
+                        }
+                    }
+                }
+            };
+#if defined(C2_CNT_ABLATE) && C2_CNT_ABLATE == 2
+            walk &= (unsigned)__ballot(mine && (d0 & 0xffffu) == (unsigned)Li && (d4 >> 16) == 0u);   // (ablation build: alignments with gaps are neither staged nor walked)
+#endif
+#if defined(C2_CNT_ABLATE) && C2_CNT_ABLATE == 3
+            walk = 0;                                                                           // (ablation build: no alignment is staged or walked: records and scalars only)
+#endif
+            while (walk) {
+                unsigned batch = 0;
+                C2_LDS_READS_DONE();                                                                // (the slots are free: every lane has read what it needed of them)
+                for (int sl = 0; sl < C2_CNT_STAGE && walk; ++sl) {
+                    const int kk = __builtin_ctz(walk);
+                    walk &= walk - 1; batch |= 1u << kk;
+                    const uint64_t task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task & 0xffffffffull), kk) |
+                                          ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task >> 32), kk) << 32);
+                    const int T = (int)((unsigned)__builtin_amdgcn_readlane((int)d0, kk) & 0xffffu);
+                    stage_window(stage_w + sl * (2 * C2_CNT_STAGE_ROW), task, 0, T < C2_CNT_STAGE_ROW ? T : C2_CNT_STAGE_ROW);
+                }
+                C2_WAIT_LDS_DMA();
+                for (int sl = 0; batch; ++sl) {
+                const int kk = __builtin_ctz(batch);
+                batch &= batch - 1;
+                uint8_t* const slot = stage_w + sl * (2 * C2_CNT_STAGE_ROW);
+                const uint8_t* SR = slot;                                                           // the staged window of the aligned read ...
+                const uint8_t* SF = slot + C2_CNT_STAGE_ROW;                                        // ... and of the aligned reference
                 const uint64_t task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task & 0xffffffffull), kk) |
                                       ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task >> 32), kk) << 32);
                 const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)d0, kk), r1 = (unsigned)__builtin_amdgcn_readlane((int)d1, kk);
                 const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)d2, kk), r4 = (unsigned)__builtin_amdgcn_readlane((int)d4, kk);
-                const unsigned r5 = (unsigned)__builtin_amdgcn_readlane((int)d5, kk);
                 const int w = __builtin_amdgcn_readlane(v_w, kk);
                 const int T = (int)(r0 & 0xffffu);
                 const int insertion_n = (int)(r1 & 0xffffu), deletion_n = (int)(r1 >> 16), substitution_n = (int)(r2 & 0xffffu);
-                const int all_ins = (int)(r2 >> 16), all_del_bases = (int)((r4 >> 16) & 0x7fffu), all_sub = (int)(r5 & 0xffffu);
                 const bool any_del_column = (r4 >> 16) != 0u;                                      // (positions, or the legacy marker)
-                const bool irregular_ends = (r5 >> 16) & 0xffu;
-                const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride;
-                const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride;
-                if (discard && (deletion_n > 0 || insertion_n > 0)) continue;                      // counted above; no vectors (:3996-4000)
-                if (rows_aligned && T == Li && !any_del_column) {
-                    // No gap column in either string (the usual read).  Four columns per lane: read and reference as dwords, the bytes
-                    // in which they differ by the "has a zero byte" trick on their XOR; only those add anything (the DEVIATIONS from
-                    // "the reference's own base, once per read": see the byte-wise walk below)
-                    for (int base = 0; base < T; base += 256) {
-                        const int p = base + 4 * lane, nb = T - p;
-                        unsigned rdw = 0, rfw = 0;
-                        if (nb > 0) { rdw = ((const unsigned*)R_)[p >> 2]; rfw = ((const unsigned*)F_)[p >> 2]; }
-                        const unsigned valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
-                        const unsigned x = (rdw ^ rfw) & valid;
-                        unsigned mm = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
-                        while (mm) {
-                            const int b = __builtin_ctz(mm) >> 3;
-                            mm &= mm - 1u;
-                            const int c = p + b;
-                            const unsigned char rd = (unsigned char)(rdw >> (8 * b)), rfc = (unsigned char)(rfw >> (8 * b));
-                            const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
-                            if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
-                            if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
-                            if (rd != 'N') {
-                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
-                                if (!ign_sub) {
-                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
-                                    const int sv = c2_sub_base_vector(rd);                      // :4049-4054
-                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
+                // the next window of a long alignment (T > C2_CNT_STAGE_ROW) into this slot
+                auto next_window = [&](const int win0) {
+                    C2_LDS_READS_DONE();
+                    stage_window(slot, task, win0, T - win0 < C2_CNT_STAGE_ROW ? T - win0 : C2_CNT_STAGE_ROW);
+                    C2_WAIT_LDS_DMA();
+                };
+                if (T == Li && !any_del_column) {
+                    // No gap column in either string (the usual read): the reference index of a column is the column, only substitutions can
+                    // occur, and the read's base counts differ from "the reference's own base, once per read" only where the read differs
+                    // from the reference.  So only the DEVIATIONS are added (+w on the read's base, -w on the reference's) and the read's
+                    // weight goes to one scalar that flush() spreads over the reference's bases.  Four columns per lane: read and reference
+                    // as dwords, the bytes in which they differ by the "has a zero byte" trick on their XOR.
+                    for (int win0 = 0; win0 < T; win0 += C2_CNT_STAGE_ROW) {
+                        if (win0) next_window(win0);
+                        const int wl = T - win0 < C2_CNT_STAGE_ROW ? T - win0 : C2_CNT_STAGE_ROW;
+                        for (int b = 0; b < wl; b += 256) {
+                            const int p = b + 4 * lane, nb = wl - p;
+                            unsigned rdw = 0, rfw = 0;
+                            if (nb > 0) { rdw = *(const unsigned*)(SR + p); rfw = *(const unsigned*)(SF + p); }
+                            const unsigned valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
+                            const unsigned x = (rdw ^ rfw) & valid;
+                            unsigned mm = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+                            while (mm) {
+                                const int bb = __builtin_ctz(mm) >> 3;
+                                mm &= mm - 1u;
+                                const int c = win0 + p + bb;
+                                const unsigned char rd = (unsigned char)(rdw >> (8 * bb)), rfc = (unsigned char)(rfw >> (8 * bb));
+                                const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
+                                if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
+                                if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
+                                if (rd != 'N') {
+                                    atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
+                                    if (!ign_sub) {
+                                        if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
+                                        const int sv = c2_sub_base_vector(rd);                      // :4049-4054
+                                        if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
+                                    }
                                 }
                             }
                         }
@@ -362,53 +416,42 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                     if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
                     continue;
                 }
-                // first 256 columns of both strings: requested now, consumed by the column walk below
-                unsigned rd4 = 0, rf4 = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 64 * q + lane;
-                    if (c < T) { rd4 |= (unsigned)R_[c] << (8 * q); rf4 |= (unsigned)F_[c] << (8 * q); }
-                }
+#if defined(C2_CNT_ABLATE) && C2_CNT_ABLATE == 1
+                continue;                                                                       // (ablation build: alignments with gaps are staged, not walked)
+#endif
                 const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
                 const bool modified = has_del || has_ins || has_sub;
                 const bool len_block = modified;                                                // :4085 (no coding sequence)
                 // ---- column walk (same scan as the fused classifier), ds_add into the vectors
                 int idx_base = 0, last_rf = -1, last_rd = -1;
                 bool last_rf_close = false, last_rf_wclose = false;
-                if (T == Li && !any_del_column) {
-                    // No gap column in either string: the reference index of a column is the column, only substitutions can
-                    // occur, and the read's base counts differ from "the reference's own base, once per read" only where the
-                    // read differs from the reference.  So the walk adds the DEVIATIONS (+w on the read's base, -w on the
-                    // reference's) and the read's weight goes to one scalar that flush() spreads over the reference's bases.
-                    for (int base = 0; base < T; base += 64) {
-                        const int c = base + lane;
-                        const bool in = c < T;
-                        unsigned char rd, rfc;
-                        if (base < 256) { rd = in ? (unsigned char)((rd4 >> ((base >> 6) * 8)) & 0xffu) : 0; rfc = in ? (unsigned char)((rf4 >> ((base >> 6) * 8)) & 0xffu) : 0; }
-                        else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
-                        if (in && rd != rfc) {
-                            const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
-                            if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
-                            if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
-                            if (rd != 'N') {
-                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
-                                if (!ign_sub) {
-                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
-                                    const int sv = c2_sub_base_vector(rd);                      // :4049-4054
-                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
-                                }
-                            }
-                        }
-                    }
-                    if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
-                    continue;
-                }
+                unsigned long long dirty = 0;                                                   // of the 256 columns from the last multiple of 256 on: dwords (4 columns) that hold a gap or a mismatch
                 for (int base = 0; base < T; base += 64) {
+                    if (base && (base % C2_CNT_STAGE_ROW) == 0) next_window(base);
+                    if ((base & 255) == 0) {
+                        // ONE look at 256 columns, four per lane: where read and reference differ or either has a gap.  The chunks of 64
+                        // columns in which nothing of the kind happens (most chunks of an alignment with ONE indel) are then passed
+                        // over without a column walk.
+                        const int cq = base + 4 * lane, nbq = T - cq;
+                        unsigned rdw = 0, rfw = 0;
+                        if (nbq > 0) { rdw = *(const unsigned*)(SR + (cq % C2_CNT_STAGE_ROW)); rfw = *(const unsigned*)(SF + (cq % C2_CNT_STAGE_ROW)); }
+                        const unsigned valid = nbq >= 4 ? 0xffffffffu : (nbq > 0 ? ((1u << (8 * nbq)) - 1u) : 0u);
+                        const unsigned yr = rdw ^ 0x2d2d2d2du, yf = rfw ^ 0x2d2d2d2du;
+                        const unsigned dash = (~(((yr & 0x7f7f7f7fu) + 0x7f7f7f7fu) | yr) | ~(((yf & 0x7f7f7f7fu) + 0x7f7f7f7fu) | yf)) & 0x80808080u;
+                        dirty = __ballot((((rdw ^ rfw) | dash) & valid) != 0u);
+                    }
+                    if (((dirty >> (((base & 255) >> 6) * 16)) & 0xffffull) == 0ull && last_rf == base - 1 && last_rd == base - 1) {
+                        // 64 columns (fewer at the end) in which the read IS the reference, no gap run open in front of them: one run of the
+                        // difference array `cov`, the reference index moves on
+                        const int cols = T - base < 64 ? T - base : 64;
+                        if (lane == 0) { atomicAdd(cov + idx_base, w); atomicAdd(cov + idx_base + cols, -w); }
+                        idx_base += cols; last_rf = base + cols - 1; last_rd = last_rf;
+                        last_rf_close = false; last_rf_wclose = false;
+                        continue;
+                    }
                     const int c = base + lane;
                     const bool in = c < T;
-                    unsigned char rd, rfc;
-                    if (base < 256) { rd = in ? (unsigned char)((rd4 >> ((base >> 6) * 8)) & 0xffu) : 0; rfc = in ? (unsigned char)((rf4 >> ((base >> 6) * 8)) & 0xffu) : 0; }
-                    else { rd = in ? R_[c] : 0; rfc = in ? F_[c] : 0; }
+                    const unsigned char rd = in ? SR[c % C2_CNT_STAGE_ROW] : (unsigned char)0, rfc = in ? SF[c % C2_CNT_STAGE_ROW] : (unsigned char)0;
                     const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
                     const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng);
                     const int idx = idx_base + __popcll(m_rf & lt);
@@ -507,7 +550,8 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                         if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dend, -dlen * w); }
                     }
                 }
-            }   // tasks of this round
+                }   // staged alignments of this batch
+            }       // batches of this round
             if (heavy) {
                 // a task whose weight was added only in part stays pending for another round
                 counted |= (unsigned)__ballot(mine);

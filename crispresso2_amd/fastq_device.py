@@ -570,3 +570,277 @@ def _ingest_file(path, ctx, dev, timings=None, on_batch=None, min_batch=200_000)
             _upload_lock.release()
         if fd >= 0:
             os.close(fd)
+
+
+# ---- sharded ingest: every rank uploads, frames and de-duplicates ITS byte range of the text; the ranks then reconcile ----
+SHARD_OVERLAP = int(os.environ.get("C2_FQ_SHARD_OVERLAP", 1 << 20))     # bytes behind a rank's range it also uploads: the line that starts in the range ends in them
+
+
+def _all_gather_i64(values, dev):
+    """list of ints of this rank -> int64 [world, len(values)] on the host"""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu().numpy()
+
+
+def _all_gather_var(t, sizes, dev):
+    """1-D tensors of different lengths (sizes: every rank's length) -> their concatenation in rank order, on every rank"""
+    import torch
+    import torch.distributed as dist
+    mx = int(max(sizes)) if len(sizes) else 0
+    if mx == 0:
+        return torch.zeros(0, dtype=t.dtype, device=dev)
+    pad = torch.zeros(mx, dtype=t.dtype, device=dev)
+    pad[:t.numel()] = t
+    parts = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, pad)
+    return torch.cat([p_[:int(n)] for p_, n in zip(parts, sizes)])
+
+
+def _read_span(source, lo, hi, dst):
+    """bytes [lo, hi) of the text -> dst (a uint8 numpy array of hi - lo bytes): a plain file, the text in host memory, or a BGZF file
+    (only the members that cover the span are inflated)"""
+    n = hi - lo
+    if n <= 0:
+        return
+    if isinstance(source, np.ndarray):
+        dst[:n] = source[lo:hi]
+    elif isinstance(source, _native.BgzfFile):
+        offs = source.text_offsets.astype(np.int64)
+        b0 = int(np.searchsorted(offs, lo, side="right")) - 1
+        b1 = int(np.searchsorted(offs, hi, side="left"))
+        a0, a1 = int(offs[b0]), int(offs[b1])
+        if a0 == lo and a1 == hi:
+            source.inflate(b0, b1, dst.ctypes.data, n, max(2, usable_cpus() - 2))
+        else:
+            tmp = np.empty(a1 - a0, dtype=np.uint8)
+            source.inflate(b0, b1, tmp.ctypes.data, tmp.size, max(2, usable_cpus() - 2))
+            dst[:n] = tmp[lo - a0:hi - a0]
+    else:
+        fd = os.open(source, os.O_RDONLY)
+        try:
+            mv = memoryview(dst)[:n]
+            got_all = 0
+            while got_all < n:
+                got = os.preadv(fd, [mv[got_all:]], lo + got_all)
+                if got <= 0:
+                    raise OSError("short read")
+                got_all += got
+        finally:
+            os.close(fd)
+
+
+def ingest_shard(source, ctx, dev, timings=None):
+    """The sharded form of ingest_file (torch.distributed initialised, one process per GPU, a collective: every rank calls it with the
+    same source).  Rank r takes bytes [r * per, (r + 1) * per) of the text (per: a multiple of the framing tile): it uploads them (plus
+    SHARD_OVERLAP bytes behind them and 16 in front), counts their newlines, learns from an all-gather how many lines lie in front of its
+    range -- records are four lines from the TOP of the file -- frames the records whose id line ends in its range and de-duplicates them
+    on its device.  The ranks then all-gather their unique reads (bytes, multiplicities; in rank order, each rank's in first-seen order:
+    that IS the file's first-seen order with repeats) and every rank de-duplicates the gathered list once more, adding the multiplicities up:
+    the same global list, multiplicities and reverse-complement partners on every rank -- what ingest_file returns for the whole file
+    (DeviceIngest.finish()'s dict; "shard_bytes": what this rank uploaded).  Raises DeviceIngestUnavailable on EVERY rank if any of them
+    meets something the kernels cannot take (a carriage return, a line longer than the overlap, ...)."""
+    import time
+    import torch
+    import torch.distributed as dist
+    t0 = time.perf_counter()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    size = int(source.size) if isinstance(source, np.ndarray) else source.text_bytes if isinstance(source, _native.BgzfFile) else os.path.getsize(source)
+    per = max(TILE, -(-(-(-size // world)) // TILE) * TILE)
+    lo, hi = min(size, rank * per), min(size, (rank + 1) * per)
+    up_lo, up_hi = max(0, lo - 16), min(size, hi + SHARD_OVERLAP)
+    i64, i32 = torch.int64, torch.int32
+    why = None
+    state = {}
+    try:
+        span = np.empty(max(up_hi - up_lo, 1), dtype=np.uint8)
+        _read_span(source, up_lo, up_hi, span)
+        d_span = torch.from_numpy(span).to(dev) if dev.type != "cuda" else _upload(span, dev)
+        text_ptr = d_span.data_ptr() - up_lo                        # the kernels address the text by absolute position
+        s = torch.cuda.current_stream(dev).cuda_stream
+        flags = torch.zeros(1, dtype=i32, device=dev)
+        n_tiles = max(1, (up_hi - lo + TILE - 1) // TILE)
+        own_tiles = (hi - lo + TILE - 1) // TILE
+        tile_nl = torch.zeros(n_tiles, dtype=i32, device=dev)
+        tile_em = torch.zeros(n_tiles, dtype=i32, device=dev)
+        if up_hi > lo:
+            fq_count(ctx, text_ptr, lo, up_hi, tile_nl.data_ptr(), tile_em.data_ptr(), flags.data_ptr(), s)
+        # (the count kernel's tiles run from lo on: the first own_tiles of them are this rank's range; hi - lo is a multiple of the tile
+        #  except at the end of the text, where the overlap is empty)
+        own_nl = int(tile_nl[:own_tiles].sum(dtype=i64).item()) if own_tiles else 0
+        own_em = int(tile_em[:own_tiles].sum(dtype=i64).item()) if own_tiles else 0
+        last_byte = int(span[size - 1 - up_lo]) if (size and up_lo <= size - 1 < up_hi) else -1
+        state.update(d_span=d_span, text_ptr=text_ptr, s=s, flags=flags, tile_nl=tile_nl, own_nl=own_nl, own_em=own_em, last_byte=last_byte)
+        if int(flags.item()) & 1:
+            why = "carriage returns in the text"
+    except Exception as e:                                             # (whatever it is: the vote below must still happen on this rank)
+        why = "%s: %s" % (type(e).__name__, e)
+    # ---- everybody learns everybody's line counts (and whether anybody gave up)
+    g = _all_gather_i64([state.get("own_nl", 0), state.get("own_em", 0), state.get("last_byte", -1), 1 if why else 0], dev)
+    if g[:, 3].any():
+        raise DeviceIngestUnavailable(why or "another rank gave up on the device ingest")
+    nl_before = int(g[:rank, 0].sum())
+    total_nl, total_em = int(g[:, 0].sum()), int(g[:, 1].sum())
+    lasts = [int(x) for x in g[:, 2] if x >= 0]
+    unterminated = bool(size) and (not lasts or lasts[-1] != 0x0a)
+    lines = total_nl + (1 if unterminated else 0)
+    n_records = (lines + 3) // 4                                     # readline() loop: every started group of four lines is a record
+    rec_lo = (nl_before + 3) // 4
+    rec_hi = n_records if rank == world - 1 else min(n_records, (nl_before + state["own_nl"] + 3) // 4)
+    rec_hi = max(rec_hi, rec_lo)
+    n_loc = rec_hi - rec_lo
+    try:
+        if n_loc >= (1 << 31) - 2 or n_records >= 0xffffffff:
+            raise DeviceIngestUnavailable("more than 2^31 records in a shard")
+        text_ptr, s, flags, tile_nl = state["text_ptr"], state["s"], state["flags"], state["tile_nl"]
+        # frame: seq_start / seq_end of the records this rank owns.  The arrays are addressed by ABSOLUTE record number (pointer moved
+        # back by rec_lo entries); one guard entry in front takes the end of the line that was cut by the range's start.
+        seq_start = torch.full((n_loc + 2,), size, dtype=i64, device=dev)
+        seq_end = torch.full((n_loc + 2,), size, dtype=i64, device=dev)
+        nl64 = tile_nl.to(i64)
+        base = (torch.cumsum(nl64, 0) - nl64) + nl_before
+        shift = 8 * (1 - rec_lo)
+        if up_hi > lo and n_loc > 0:
+            fq_lines(ctx, text_ptr, lo, up_hi, base.data_ptr(), seq_start.data_ptr() + shift, seq_end.data_ptr() + shift, rec_hi, s)
+        if up_hi < size and n_loc > 0 and bool((seq_end[1:1 + n_loc] >= up_hi).any().item()):
+            raise DeviceIngestUnavailable("a line longer than the shard overlap (C2_FQ_SHARD_OVERLAP)")
+        # local de-duplication
+        n_slots = 1 << 12
+        while n_slots < 2 * max(n_loc, 1):
+            n_slots <<= 1
+        slots = torch.zeros(n_slots, dtype=i64, device=dev)
+        count = torch.zeros(n_slots, dtype=i32, device=dev)
+        first = torch.full((n_slots,), -1, dtype=i32, device=dev)
+        slot_of = torch.zeros(n_loc + 1, dtype=i32, device=dev)
+        rinfo = torch.zeros(n_loc + 1, dtype=i64, device=dev)
+        stats = torch.zeros(4, dtype=i32, device=dev)
+        rng_t = torch.tensor([rec_lo, rec_hi], dtype=i64, device=dev)
+        if n_loc > 0:
+            fq_dedup(ctx, text_ptr, seq_start.data_ptr() + shift, seq_end.data_ptr() + shift, rng_t.data_ptr(), rec_hi, slots.data_ptr(), n_slots,
+                     count.data_ptr(), first.data_ptr(), slot_of.data_ptr() - 4 * rec_lo, rinfo.data_ptr() - 8 * rec_lo, flags.data_ptr(), stats.data_ptr(), s)
+        fl = int(flags.item())
+        if fl & 1:
+            raise DeviceIngestUnavailable("carriage returns in the text")
+        if fl & ~1:
+            raise DeviceIngestUnavailable("device ingest gave up (flags %d)" % fl)
+        # this rank's unique reads, in first-seen order
+        so = slot_of[:n_loc].to(i64)
+        idx = torch.arange(rec_lo, rec_hi, dtype=i64, device=dev)
+        info = rinfo[:n_loc]
+        is_first = (first[so].to(i64) & 0xffffffff) == idx
+        mask = is_first & ((info & 0xffffff) > 0)
+        rec = torch.nonzero(mask).reshape(-1)                        # (local record numbers)
+        lens = (info[rec] & 0xffffff)
+        m_loc = int(rec.numel())
+        loc_counts = count[so[rec]].contiguous()
+        n_empty = int(count[so[torch.nonzero(is_first & ((info & 0xffffff) == 0)).reshape(-1)]].sum().item())
+        d_off = torch.zeros(m_loc + 1, dtype=i64, device=dev)
+        torch.cumsum(lens, 0, out=d_off[1:])
+        loc_bytes = int(d_off[-1].item())
+        arena = torch.empty(max(loc_bytes, 1), dtype=torch.uint8, device=dev)
+        if m_loc:
+            fq_gather(ctx, text_ptr, rinfo.data_ptr(), rec.data_ptr(), d_off.data_ptr(), arena.data_ptr(), m_loc, s)
+        if lens.numel() and int(lens.max().item()) >= (1 << 24):
+            raise DeviceIngestUnavailable("a sequence line of 2^24 bytes or more")
+    except Exception as e:
+        why = "%s: %s" % (type(e).__name__, e)
+        m_loc = loc_bytes = n_empty = 0
+    t_local = time.perf_counter()
+    # ---- reconcile: all ranks' unique reads in rank order = the file's first-seen order with repeats; de-duplicated again, multiplicities added
+    g2 = _all_gather_i64([m_loc, loc_bytes, n_empty, 1 if why else 0], dev)
+    if g2[:, 3].any():
+        raise DeviceIngestUnavailable(why or "another rank gave up on the device ingest")
+    G, GB = int(g2[:, 0].sum()), int(g2[:, 1].sum())
+    if G >= (1 << 31) - 2:
+        raise DeviceIngestUnavailable("more than 2^31 unique reads over the shards")
+    all_lens = _all_gather_var(lens.to(i32) if m_loc else torch.zeros(0, dtype=i32, device=dev), g2[:, 0], dev).to(i64)
+    all_counts = _all_gather_var(loc_counts if m_loc else torch.zeros(0, dtype=i32, device=dev), g2[:, 0], dev)
+    all_bytes = _all_gather_var(arena[:loc_bytes], g2[:, 1], dev)
+    del arena, d_span
+    state.clear()
+    g_off = torch.zeros(G + 1, dtype=i64, device=dev)
+    torch.cumsum(all_lens, 0, out=g_off[1:])
+    text2 = all_bytes if GB else torch.zeros(1, dtype=torch.uint8, device=dev)
+    n_slots = 1 << 12
+    while n_slots < 2 * max(G, 1):
+        n_slots <<= 1
+    slots = torch.zeros(n_slots, dtype=i64, device=dev)
+    count = torch.zeros(n_slots, dtype=i32, device=dev)
+    first = torch.full((n_slots,), -1, dtype=i32, device=dev)
+    slot_of = torch.zeros(G + 1, dtype=i32, device=dev)
+    rinfo = torch.zeros(G + 1, dtype=i64, device=dev)
+    stats = torch.zeros(4, dtype=i32, device=dev)
+    flags = torch.zeros(1, dtype=i32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    if G:
+        seq_s, seq_e = g_off[:-1].contiguous(), g_off[1:].contiguous()
+        rng_t = torch.tensor([0, G], dtype=i64, device=dev)
+        fq_dedup(ctx, text2.data_ptr(), seq_s.data_ptr(), seq_e.data_ptr(), rng_t.data_ptr(), G, slots.data_ptr(), n_slots, count.data_ptr(), first.data_ptr(),
+                 slot_of.data_ptr(), rinfo.data_ptr(), flags.data_ptr(), stats.data_ptr(), s)
+        if int(flags.item()):
+            raise _native.NativeError("sharded ingest: the second de-duplication raised flags %d" % int(flags.item()))
+    so = slot_of[:G].to(i64)
+    wcount = torch.zeros(n_slots, dtype=i64, device=dev)
+    if G:
+        wcount.index_add_(0, so, all_counts.to(i64))
+    rec = torch.nonzero((first[so].to(i64) & 0xffffffff) == torch.arange(G, dtype=i64, device=dev)).reshape(-1) if G else torch.zeros(0, dtype=i64, device=dev)
+    n = int(rec.numel())
+    lens_u = all_lens[rec] if n else torch.zeros(0, dtype=i64, device=dev)
+    cnt_u = wcount[so[rec]] if n else torch.zeros(0, dtype=i64, device=dev)
+    if n and int(cnt_u.max().item()) > 0x7fffffff:
+        raise OverflowError("a read multiplicity exceeds 2^31 - 1")
+    d_off = torch.zeros(n + 1, dtype=i64, device=dev)
+    torch.cumsum(lens_u, 0, out=d_off[1:])
+    d_reads = torch.empty(max(int(d_off[-1].item()), 1), dtype=torch.uint8, device=dev)
+    rc_partner, d_rc_partner = np.zeros(0, dtype=np.int64), None
+    if n:
+        fq_gather(ctx, text2.data_ptr(), rinfo.data_ptr(), rec.data_ptr(), d_off.data_ptr(), d_reads.data_ptr(), n, s)
+        pslot = torch.empty(n, dtype=i32, device=dev)
+        fq_rc_partner(ctx, text2.data_ptr(), rinfo.data_ptr(), rec.data_ptr(), n, slots.data_ptr(), n_slots, pslot.data_ptr(), s)
+        unique_of_slot = torch.full((n_slots,), -1, dtype=i64, device=dev)
+        unique_of_slot[so[rec]] = torch.arange(n, dtype=i64, device=dev)
+        d_rc_partner = torch.where(pslot >= 0, unique_of_slot[pslot.to(i64).clamp_(min=0)], -1)
+        rc_partner = to_host(d_rc_partner.to(i32), np.int64)
+    d_counts = cnt_u.to(i32).contiguous() if n else None
+    counts = to_host(d_counts, np.int64) if n else np.zeros(0, dtype=np.int64)
+    lens_h = to_host(lens_u.to(i32), np.int64) if n else np.zeros(0, dtype=np.int64)
+    off64 = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens_h, out=off64[1:])
+    if timings is not None:
+        timings["shard_upload_frame_dedup"] = t_local - t0
+        timings["shard_reconcile"] = time.perf_counter() - t_local
+    return dict(offsets=off64.view(np.uint64), counts=counts, n_reads=n_records, n_empty_records=int(g2[:, 2].sum()), nonempty_lines=lines - total_em,
+                n_unique=n, max_len=int(lens_h.max()) if n else 0, min_len=int(lens_h.min()) if n else 0, batch_bytes=[int(off64[-1])] if n else [],
+                rc_partner=rc_partner, d_counts=d_counts, d_rc_partner=d_rc_partner, d_reads=d_reads, d_off=d_off,
+                shard_bytes=up_hi - up_lo, text_bytes=size, shard_records=n_loc, shard_unique=m_loc, gathered_unique=G, gathered_bytes=GB)
+
+
+def _upload(span, dev):
+    """a host byte array -> device tensor through the pinned upload buffers, chunk by chunk (the copies overlap the next chunk's memcpy)"""
+    import torch
+    n = int(span.size)
+    out = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    key = dev.index
+    chunk = chunk_bytes(n)
+    if key not in _pinned or _pinned[key][0].numel() < chunk:
+        _pinned[key] = None
+        _pinned[key] = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
+    pins = _pinned[key]
+    evs = [None] * len(pins)
+    copy_stream = torch.cuda.Stream(device=dev)
+    for c, a in enumerate(range(0, n, chunk)):
+        z = min(n, a + chunk)
+        k = c % len(pins)
+        if evs[k] is not None:
+            evs[k].synchronize()
+        pins[k].numpy()[:z - a] = span[a:z]
+        with torch.cuda.stream(copy_stream):
+            out[a:z].copy_(pins[k][:z - a], non_blocking=True)
+            evs[k] = torch.cuda.Event()
+            evs[k].record(copy_stream)
+    torch.cuda.current_stream(dev).wait_stream(copy_stream)
+    copy_stream.synchronize()
+    return out

@@ -1094,51 +1094,61 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
         if timings is not None:
             timings["host_parser_because"] = why_not
     if sharded and not FORCE_HOST_STRAND_PLAN:
-        # sharded run: every rank frames and de-duplicates the text on ITS device (plain file, BGZF, or what the host inflated / filtered)
-        # and aligns its range of the unique reads; anything the kernels cannot take: the host parser below, on every rank alike --
-        # the ranks agree on the route first (one of them may have found a carriage return the others' estimate missed)
+        # sharded run: every rank uploads, frames and de-duplicates ITS byte range of the text (a plain file: that part of the file; BGZF:
+        # only the members that cover it are inflated; other compressed / filtered input: what the host inflated / filtered, sliced), the
+        # ranks all-gather their unique reads and reconcile them into the run's list (fastq_device.ingest_shard), and each aligns its range
+        # of that list.  Anything the kernels cannot take on ANY rank: the host parser below, on every rank alike (the vote is inside).
         import torch
         from . import fastq_device
         ctx_ = ctx or _native.default_context()
         dev_ = torch.device("cuda", device)
         why_not = fastq_device.applicable(path, flt)
-        ing, holder = None, None
+        source, holder, bg = None, None, None
         try:
-            if why_not is None:
-                ing = fastq_device.ingest_file(path, ctx_, dev_, timings=timings)
-            elif why_not.startswith("in memory:"):
-                bg = None
-                if why_not.startswith("in memory: compressed"):
-                    try:
-                        bg = _native.BgzfFile(path)
-                    except _native.NativeError:
-                        bg = None
-                if bg is not None:
-                    with bg:
+            try:
+                if why_not is None:
+                    source = path
+                elif why_not.startswith("in memory:"):
+                    if why_not.startswith("in memory: compressed"):
+                        try:
+                            bg = _native.BgzfFile(path)
+                        except _native.NativeError:
+                            bg = None
+                    if bg is not None:
                         if fastq_device.size_applicable(bg.text_bytes) is None:
-                            ing = fastq_device.ingest_file(bg, ctx_, dev_, timings=timings)
-                else:
-                    holder = _native.FastqStream(path, *flt)
-                    text = holder.text()
-                    if fastq_device.text_applicable(text) is None:
-                        if holder.filtered:
-                            ingest_stats["N_READS_INPUT"] = int(float(holder.lines_input()) / 4.0)
-                        ing = fastq_device.ingest_file(text, ctx_, dev_, timings=timings)
-        except (fastq_device.DeviceIngestUnavailable, _native.NativeError):
+                            source = bg
+                    else:
+                        holder = _native.FastqStream(path, *flt)
+                        text = holder.text()
+                        if fastq_device.text_applicable(text) is None:
+                            if holder.filtered:
+                                ingest_stats["N_READS_INPUT"] = int(float(holder.lines_input()) / 4.0)
+                            source = text
+            except (_native.NativeError, OSError):
+                source = None
             ing = None
+            # (every rank takes part in the vote, also one that has no source: the others would wait for it otherwise)
+            if C.all_reduce_max(1 if source is None else 0, dev_) == 0:
+                try:
+                    ing = fastq_device.ingest_shard(source, ctx_, dev_, timings=timings)
+                except fastq_device.DeviceIngestUnavailable as e:
+                    if timings is not None:
+                        timings["host_parser_because"] = str(e)
         finally:
             if holder is not None:
                 holder.close()
-        if C.all_reduce_max(1 if ing is None else 0, dev_) == 0:        # (no rank gave up)
+            if bg is not None:
+                bg.close()
+        if ing is not None:
             res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
                                   pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=ing, shard="mine")
             _native._line_stats(ingest_stats, ing["nonempty_lines"])
             res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT']
             res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats['N_READS_AFTER_PREPROCESSING']
-            res.ingest_route = "device, sharded"
+            res.ingest_route = "device, sharded by byte range"
+            res.shard_ingest = {q: ing[q] for q in ("shard_bytes", "text_bytes", "shard_records", "shard_unique", "gathered_unique", "gathered_bytes")}
             return res
         ingest_stats.pop("N_READS_INPUT", None)
-        del ing
     with _native.FastqUnique(path, *flt, stats=ingest_stats) as fq:      # views of the native arena: nothing is copied on the host
         arena, offsets, counts, n_reads = fq.arena, fq.offsets, fq.counts, fq.n_reads
         if timings is not None:

@@ -148,6 +148,12 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
     return (int)(uint32_t)v;
 }
 inline long long clock64() { return 0; }
+// LDS-DMA: lane l's `size` bytes land at dst + off + l * size (dst wave-uniform); the waits are rendezvous of the wavefront's lanes
+inline void __builtin_amdgcn_global_load_lds(const void* src, void* dst, int size, int off, int aux) {
+    (void)aux; memcpy((char*)dst + off + emu::lane_id() * size, src, (size_t)size);
+}
+#define C2_WAIT_LDS_DMA() emu::wave_barrier()
+#define C2_LDS_READS_DONE() emu::wave_barrier()
 inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned shift) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (shift & 3))); }
 inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned shift) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (shift & 31)); }
 // v_perm_b32 for selectors 0..7: byte i of the result = byte sel[i] of the 64-bit {hi, lo}

@@ -202,3 +202,67 @@ def test_count_vectors_with_the_accumulator_block_in_hbm(aligned, flags, monkeyp
         for r in range(2):
             items = [(p, int(c)) for p, c, rid in zip(P, w2, rec2["ref_id"]) if rid == r]
             compare(lay.unpack(counts, r, len(amp)), aggregate.aggregate(items, len(amp)), len(amp))
+
+
+@pytest.mark.parametrize("L,shift", [(300, 0), (560, 0), (700, 0), (300, 1)])
+def test_alignments_longer_than_a_staging_window(L, shift):
+    """The count kernel stages C2_CNT_STAGE_ROW (256) columns of an alignment's strings in LDS at a time: amplicons of 300 / 560 / 700 bp
+    give alignments of 2 and 3 windows -- gap-free reads (dword walk), deletions and insertions that straddle a window's edge (the walk's
+    carried state), a trailing deletion; shift 1: string rows that do not start on a dword (byte-wise copies)."""
+    E.build()
+    mats = matrices()
+    rng = np.random.default_rng(L + shift)
+    amp = "".join(rng.choice(list("ACGT"), L))
+    inc = list(range(L // 2 - 20, L // 2 + 20)) + list(range(250, 262)) + ([510, 511, 512, 513] if L > 520 else [])
+    g = np.zeros(L + 1, dtype=np.int64)
+    g[L // 2 + 1] = 1
+
+    def mut(s, k):
+        s = list(s)
+        for p in rng.integers(0, len(s), k):
+            s[p] = "ACGTN"[rng.integers(0, 5)]
+        return "".join(s)
+    reads = [amp, mut(amp, 3), mut(amp, 9)]
+    for edge in [256] + ([512] if L > 520 else []):
+        reads += [amp[:edge - 5] + amp[edge + 6:], amp[:edge - 1] + amp[edge + 1:], amp[:edge] + "TTGTT" + amp[edge:], amp[:edge - 2] + "GG" + amp[edge - 2:],
+                  mut(amp[:edge - 12] + amp[edge - 3:], 2), amp[:edge + 1] + "ACA" + amp[edge + 1:]]
+    reads += [amp[:-25], amp[20:], mut(amp[:L // 2 - 4] + amp[L // 2 + 9:], 4)]
+    res, rec = E.align_batch(reads, [amp], [g], [inc], mats["EDNAFULL"], -20, -2, stats=(st := {}))
+    o1, o2 = st["raw"]
+    assert int(rec["aln_len"].max()) > 256
+    if shift:                                                          # rows that start one byte into a dword
+        def shifted(o):
+            buf = np.zeros(o.size + 8, dtype=np.uint8)
+            v = buf[shift:shift + o.size].reshape(o.shape)
+            v[:] = o
+            return v
+        o1, o2 = shifted(o1), shifted(o2)
+        assert o1.ctypes.data % 4 == shift
+    w = rng.integers(1, 9, len(reads)).astype(np.uint32)
+    counts, lay = count_vectors_raw(o1, o2, rec, [amp], [inc], max(len(r) for r in reads), w)
+    got = lay.unpack(counts, 0, L)
+    exp = aggregate.aggregate([(p, int(c)) for p, c in zip(payloads(res, inc), w)], L)
+    compare(got, exp, L)
+
+
+def count_vectors_raw(a1, a2, rec, ref_seqs, includes, max_read_len, weights):
+    """E.count_vectors without its np.ascontiguousarray of the string arrays (that would re-align shifted rows)"""
+    import ctypes
+    from crispresso2_amd.counts import CountLayout
+    n, nrefs = len(rec), len(ref_seqs)
+    lens = np.array([len(x) for x in ref_seqs], dtype=np.int32)
+    lay = CountLayout(nrefs, int(lens.max()), max_read_len)
+    counts = np.zeros(lay.shape(), dtype=np.int64)
+    inc = [np.ascontiguousarray(np.asarray(list(x), dtype=np.int64).astype(np.int32)) for x in includes]
+    ip = (ctypes.c_void_p * nrefs)(*[x.ctypes.data for x in inc])
+    ninc = np.array([len(x) for x in inc], dtype=np.int32)
+    seq_ptrs = (ctypes.c_char_p * nrefs)(*[x.encode() for x in ref_seqs])
+    wq = np.ascontiguousarray(weights, dtype=np.uint32)
+    rec = np.ascontiguousarray(rec)
+    assert a1.strides == (a1.shape[1], 1) and a2.strides == (a2.shape[1], 1)
+    rc = E.lib().emu_count_vectors(ctypes.c_uint64(n), ctypes.c_void_p(a1.ctypes.data), ctypes.c_void_p(a2.ctypes.data), ctypes.c_uint32(a1.shape[1]),
+                                   rec.ctypes.data_as(ctypes.c_void_p), wq.ctypes.data_as(ctypes.c_void_p), None, 0, nrefs,
+                                   lens.ctypes.data_as(ctypes.c_void_p), ip, ninc.ctypes.data_as(ctypes.c_void_p), 0, int(lay.hl),
+                                   counts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(2), seq_ptrs)
+    assert rc == 0
+    return counts, lay
