@@ -256,7 +256,7 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 #define C2_CNT_STAGE 2
 #endif
 #ifndef C2_CNT_STAGE_ROW
-#define C2_CNT_STAGE_ROW 256           // a multiple of 256 (the walk looks at 256 columns at a time)
+#define C2_CNT_STAGE_ROW 256           // a multiple of 64
 #endif
 #define C2_CNT_STAGE_BYTES ((size_t)C2_CNT_WAVES * C2_CNT_STAGE * 2u * C2_CNT_STAGE_ROW)
 // LDS of the variant whose accumulator block lives in HBM: the difference array, the control words, the window prefix, the staging slots

@@ -340,12 +340,6 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                     }
                 }
             };
-#if defined(C2_CNT_ABLATE) && C2_CNT_ABLATE == 2
-            walk &= (unsigned)__ballot(mine && (d0 & 0xffffu) == (unsigned)Li && (d4 >> 16) == 0u);   // (ablation build: alignments with gaps are neither staged nor walked)
-#endif
-#if defined(C2_CNT_ABLATE) && C2_CNT_ABLATE == 3
-            walk = 0;                                                                           // (ablation build: no alignment is staged or walked: records and scalars only)
-#endif
             while (walk) {
                 unsigned batch = 0;
                 C2_LDS_READS_DONE();                                                                // (the slots are free: every lane has read what it needed of them)
@@ -416,39 +410,14 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                     if (lane == 0) atomicAdd(acc + o_sc + C2_S_RESERVED0, w);
                     continue;
                 }
-#if defined(C2_CNT_ABLATE) && C2_CNT_ABLATE == 1
-                continue;                                                                       // (ablation build: alignments with gaps are staged, not walked)
-#endif
                 const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
                 const bool modified = has_del || has_ins || has_sub;
                 const bool len_block = modified;                                                // :4085 (no coding sequence)
                 // ---- column walk (same scan as the fused classifier), ds_add into the vectors
                 int idx_base = 0, last_rf = -1, last_rd = -1;
                 bool last_rf_close = false, last_rf_wclose = false;
-                unsigned long long dirty = 0;                                                   // of the 256 columns from the last multiple of 256 on: dwords (4 columns) that hold a gap or a mismatch
                 for (int base = 0; base < T; base += 64) {
                     if (base && (base % C2_CNT_STAGE_ROW) == 0) next_window(base);
-                    if ((base & 255) == 0) {
-                        // ONE look at 256 columns, four per lane: where read and reference differ or either has a gap.  The chunks of 64
-                        // columns in which nothing of the kind happens (most chunks of an alignment with ONE indel) are then passed
-                        // over without a column walk.
-                        const int cq = base + 4 * lane, nbq = T - cq;
-                        unsigned rdw = 0, rfw = 0;
-                        if (nbq > 0) { rdw = *(const unsigned*)(SR + (cq % C2_CNT_STAGE_ROW)); rfw = *(const unsigned*)(SF + (cq % C2_CNT_STAGE_ROW)); }
-                        const unsigned valid = nbq >= 4 ? 0xffffffffu : (nbq > 0 ? ((1u << (8 * nbq)) - 1u) : 0u);
-                        const unsigned yr = rdw ^ 0x2d2d2d2du, yf = rfw ^ 0x2d2d2d2du;
-                        const unsigned dash = (~(((yr & 0x7f7f7f7fu) + 0x7f7f7f7fu) | yr) | ~(((yf & 0x7f7f7f7fu) + 0x7f7f7f7fu) | yf)) & 0x80808080u;
-                        dirty = __ballot((((rdw ^ rfw) | dash) & valid) != 0u);
-                    }
-                    if (((dirty >> (((base & 255) >> 6) * 16)) & 0xffffull) == 0ull && last_rf == base - 1 && last_rd == base - 1) {
-                        // 64 columns (fewer at the end) in which the read IS the reference, no gap run open in front of them: one run of the
-                        // difference array `cov`, the reference index moves on
-                        const int cols = T - base < 64 ? T - base : 64;
-                        if (lane == 0) { atomicAdd(cov + idx_base, w); atomicAdd(cov + idx_base + cols, -w); }
-                        idx_base += cols; last_rf = base + cols - 1; last_rd = last_rf;
-                        last_rf_close = false; last_rf_wclose = false;
-                        continue;
-                    }
                     const int c = base + lane;
                     const bool in = c < T;
                     const unsigned char rd = in ? SR[c % C2_CNT_STAGE_ROW] : (unsigned char)0, rfc = in ? SF[c % C2_CNT_STAGE_ROW] : (unsigned char)0;

@@ -21,8 +21,13 @@ as the per-call path (results never depend on batching: tests/test_gpu_parity.py
 returned; anything else -- other reads, other parameters, quality-filtered or trimmed reads that differ from the registered
 file -- is a miss and takes the per-call path.  No CPU fallback, no oracle.
 
-Environment: C2_PRIME_FASTQ=<path> registers a file at import; C2_PRIME_FROM_ARGV=1 takes the value of -r1 / --fastq_r1 from
-sys.argv (the reference's own command line), so that an unmodified `CRISPResso ...` run is primed without touching its code.
+By default (no environment variable, no code change in the caller) the module watches sys.argv: when the process was started with the
+reference's own command line -- `-r1 / --fastq_r1 <file>` and no `-r2 / --fastq_r2` -- that file is registered, so an unmodified
+`CRISPResso -r1 ...` run gets its hot loop's alignments from one batch per amplicon.  It is a speculation and fails silently: a file
+that cannot be read, reads the run filters or trims before it aligns them, more unique reads than C2_PRIME_MAX_READS -- every call
+that finds no primed answer takes the per-call path, and the results are the same either way.  C2_PRIME_FROM_ARGV=0 switches the
+watching off; C2_PRIME_FASTQ=<path> registers a file at import whatever the command line says; `counters()` (and C2_PRIME_REPORT=1: a
+line on stderr at exit) say how many calls were answered from a batch.
 """
 import os
 import sys
@@ -34,13 +39,30 @@ from .refs import reverse_complement
 
 MAX_READS = int(os.environ.get("C2_PRIME_MAX_READS", 4_000_000))      # unique reads; larger runs belong on pipeline.quantify_fastq
 
-_WATCH_ARGV = bool(os.environ.get("C2_PRIME_FROM_ARGV"))
+_WATCH_ARGV = os.environ.get("C2_PRIME_FROM_ARGV", "1").strip().lower() not in ("", "0", "no", "off", "false")
 _state = {"reads": None, "source": None, "read_set": frozenset()}
 _align_memo = {}                        # key -> _Primed
 _classify_memo = {}                     # (ref sequence, include key, legacy) -> _PrimedLists
 _miss = {}
 stats = {"batches": 0, "classify_batches": 0, "align_hits": 0, "align_misses": 0, "classify_hits": 0, "classify_misses": 0,
-         "per_call_align": 0, "per_call_classify": 0}
+         "per_call_align": 0, "per_call_classify": 0, "not_primed": 0}
+
+
+def counters():
+    """hit / miss counters of the run so far: batches launched, calls answered from them (align_hits, classify_hits), calls that went per
+    call, whether the registered file could not be used (not_primed)"""
+    out = dict(stats)
+    out["registered"] = _state["source"] if isinstance(_state["source"], (str, bytes, os.PathLike)) else (None if _state["source"] is None else "<reads>")
+    return out
+
+
+def _report_at_exit():
+    if os.environ.get("C2_PRIME_REPORT") and (_state["source"] is not None or stats["per_call_align"]):
+        sys.stderr.write("crispresso2_amd.prime: %s\n" % " ".join("%s=%s" % kv for kv in sorted(counters().items())))
+
+
+import atexit
+atexit.register(_report_at_exit)
 
 
 def clear():
@@ -66,7 +88,13 @@ def _reads():
     if _state["reads"] is None and _state["source"] is not None:
         src = _state["source"]
         if isinstance(src, (str, bytes, os.PathLike)):
-            arena, offsets, counts, n_reads = _native.fastq_unique(os.fspath(src))
+            try:
+                arena, offsets, counts, n_reads = _native.fastq_unique(os.fspath(src))
+            except (_native.NativeError, OSError) as e:               # (a speculation: the run itself will say what is wrong with its input)
+                _state["reads"] = []
+                stats["not_primed"] = 1
+                _state["why_not"] = str(e)
+                return _state["reads"]
             if len(counts) > MAX_READS:
                 _state["reads"] = []
                 sys.stderr.write("crispresso2_amd.prime: %d unique reads exceed C2_PRIME_MAX_READS=%d -- not priming (use "
@@ -295,7 +323,7 @@ def _from_environment():
     """C2_PRIME_FASTQ, or (C2_PRIME_FROM_ARGV=1) the -r1 / --fastq_r1 of the command line the process runs -- looked at again
     whenever sys.argv has changed (a host that runs several CRISPResso commands in one interpreter)."""
     path = os.environ.get("C2_PRIME_FASTQ")
-    if not path and os.environ.get("C2_PRIME_FROM_ARGV"):
+    if not path and _WATCH_ARGV:
         argv = list(sys.argv)
         if argv == _argv_seen[0]:
             return
@@ -306,6 +334,9 @@ def _from_environment():
         for a in argv:
             if a.startswith("--fastq_r1="):
                 path = a.split("=", 1)[1]
+        # paired input is merged / aligned pair by pair (process_paired_fastq): the reads of R1 are not what the hot loop aligns
+        if any(a in ("-r2", "--fastq_r2") or a.startswith("--fastq_r2=") for a in argv):
+            path = None
     elif path and _state["source"] is not None:
         return
     if path and os.path.exists(path) and _state["source"] != path:

@@ -266,3 +266,44 @@ def count_vectors_raw(a1, a2, rec, ref_seqs, includes, max_read_len, weights):
                                    counts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(2), seq_ptrs)
     assert rc == 0
     return counts, lay
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_event_walk_at_every_offset_of_an_eight_column_unit(legacy, monkeypatch):
+    """The event walk looks at eight columns per lane and walks only the runs of dirty units: deletions and insertions of 1 .. 17 bases that
+    start at every offset of a unit (a gap that ends exactly where a clean unit begins is closed by that unit's first column), two events a
+    few columns apart, events in the first and the last unit, a trailing deletion -- each against the oracle's aggregation."""
+    E.build()
+    mats = matrices()
+    rng = np.random.default_rng(77)
+    L = 160
+    amp = "".join(rng.choice(list("ACGT"), L))
+    inc = list(range(60, 100))
+    g = np.zeros(L + 1, dtype=np.int64)
+    g[81] = 1
+    reads = []
+    for start in range(40, 56):
+        for ln in (1, 3, 7, 8, 9, 16, 17):
+            reads.append(amp[:start] + amp[start + ln:])                                   # deletion
+            reads.append(amp[:start] + "".join(rng.choice(list("ACGT"), ln)) + amp[start:])   # insertion
+    reads += [amp[:70] + amp[75:90] + "GG" + amp[90:], amp[:66] + "T" + amp[66:72] + amp[74:], amp[3:], amp[:-9], amp[:5] + amp[9:], amp[:L - 12] + amp[L - 8:],
+              amp[:80] + amp[88:96] + amp[104:]]
+    if legacy:
+        monkeypatch.setenv("C2_EMU_LEGACY", "1")
+    res, rec = E.align_batch(reads, [amp], [g], [inc], mats["EDNAFULL"], -20, -2, stats=(st := {}))
+    o1, o2 = st["raw"]
+    w = rng.integers(1, 6, len(reads)).astype(np.uint32)
+    counts, lay = E.count_vectors(o1, o2, rec, [amp], [inc], max(len(r) for r in reads), weights=w, flags=C.FLAG_LEGACY_CLASSIFIER if legacy else 0)
+    got = lay.unpack(counts, 0, L)
+    if legacy:
+        ref = oracle.ref()
+        if ref is None:
+            pytest.skip("the reference's compiled classifier (oracle/_ref) is not built here")
+        items = []
+        for (s1, s2), c in zip(res, w):
+            p = dict(ref[1].find_indels_substitutions_legacy(s1, s2, inc))
+            p["aln_seq"], p["aln_ref"] = s1, s2
+            items.append((p, int(c)))
+    else:
+        items = [(p, int(c)) for p, c in zip(payloads(res, inc), w)]
+    compare(got, aggregate.aggregate(items, L), L)

@@ -65,11 +65,12 @@ print("DROPIN_PRIME", " ".join("%%s=%%d" %% kv for kv in sorted(prime.stats.item
 def test_reference_main_runs_unchanged_over_the_shim(name, tmp_path):
     extra, expected = RUNS[name]
     code = RUNNER % dict(tests=HERE, fastq=os.path.join(REF, "tests", "FANC.Cas9.fastq"), out=str(tmp_path), extra=extra)
-    env = dict(os.environ, C2_DROPIN_DEVICE="emulator")
+    env = dict(os.environ, C2_DROPIN_DEVICE="emulator", C2_PRIME_FROM_ARGV="0")        # (every call per call: the priming is off for this one)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=3000)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     line = [x for x in p.stdout.splitlines() if x.startswith("DROPIN_CALLS")][-1].split()
     assert int(line[1]) > 200 and int(line[2]) > 150, line           # the hot loop really went through the shim
+    assert " batches=0 " in [x for x in p.stdout.splitlines() if x.startswith("DROPIN_PRIME")][-1] + " "
     outdir = os.path.join(str(tmp_path), name)
     for made, kept in expected.items():
         with open(os.path.join(outdir, made)) as fh:
@@ -92,14 +93,17 @@ def test_reference_unit_tests_collected_unchanged_pass_against_the_shim(test_fil
 
 @pytest.mark.parametrize("name", sorted(RUNS))
 def test_reference_main_unchanged_gets_its_alignments_from_one_batch_when_primed(name, tmp_path):
-    """the same unmodified main(), with C2_PRIME_FROM_ARGV=1 in the environment (crispresso2_amd.prime reads the
-    -r1 of the reference's own command line): after the first misses of the hot loop ALL unique reads of the FASTQ are aligned in one
+    """the same unmodified main() with NOTHING in the environment (crispresso2_amd.prime watches the
+    command line by default and reads the -r1 of the reference's own): after the first misses of the hot loop ALL unique reads of the FASTQ are aligned in one
     device batch per amplicon (and classified in one), the rest of the run's >200 calls are look-ups -- the files are the same and
     only a handful of per-call launches remain."""
     extra, expected = RUNS[name]
     code = RUNNER % dict(tests=HERE, fastq=os.path.join(REF, "tests", "FANC.Cas9.fastq"), out=str(tmp_path), extra=extra)
-    env = dict(os.environ, C2_DROPIN_DEVICE="emulator", C2_PRIME_FROM_ARGV="1")
+    env = dict(os.environ, C2_DROPIN_DEVICE="emulator", C2_PRIME_REPORT="1")
+    env.pop("C2_PRIME_FROM_ARGV", None)
+    env.pop("C2_PRIME_FASTQ", None)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=3000)
+    assert "crispresso2_amd.prime: " in p.stderr and "align_hits=" in p.stderr              # (the counters, published at exit)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     line = [x for x in p.stdout.splitlines() if x.startswith("DROPIN_CALLS")][-1].split()
     n_align, n_classify = int(line[1]), int(line[2])

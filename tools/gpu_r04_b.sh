@@ -3,15 +3,15 @@
 # every variant of crispresso2_amd/lib/variants/ on tools/count_kernel_split.py (per kind of alignment) and on bench.py's default step.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/r04d
+OUT=$ROOT/gpurun_out/r04f
 mkdir -p "$OUT"
 cd "$ROOT"
-for v in r03 dm_s2o8 dm_s1o8 dm_s4o6 dm_s3o6; do
+for v in r03 ev_s1o8 ev_s1o6 ev_s2o6 ev_s1o5; do
   LIB=$ROOT/crispresso2_amd/lib/variants/lib_$v.so
   echo "== $v" | tee -a "$OUT/count_split.txt"
   C2_AMD_LIB=$LIB timeout 300 python tools/count_kernel_split.py 4000000 2>&1 | grep -E '"kind"' | tee -a "$OUT/count_split.txt"
 done
-for v in dm_s2o8 dm_s1o8 dm_s4o6; do
+for v in ev_s1o8 ev_s1o6 ev_s2o6 ev_s1o5; do
   LIB=$ROOT/crispresso2_amd/lib/variants/lib_$v.so
   C2_AMD_LIB=$LIB timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --check 300 --no-dedup-leg --no-extras --no-full-plane-check > "$OUT/bench_$v.json" 2> "$OUT/bench_$v.err"
   python - <<PY
