@@ -26,7 +26,7 @@ SYMBOLS = [
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners", "c2_gather_reads",
     "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close",
-    "c2_consensus_pairs_batch", "c2_consensus_pairs_device",
+    "c2_consensus_pairs_batch", "c2_consensus_pairs_device", "c2_classify_records_device",
     "c2_fq_count_device", "c2_fq_lines_device", "c2_fq_dedup_device", "c2_fq_gather_device", "c2_fq_rc_partner_device",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets", "c2_fastq_stream_text",
     "c2_allele_table_build", "c2_allele_table_rows", "c2_allele_table_write", "c2_allele_table_fetch", "c2_allele_table_around_cut_write",
@@ -553,6 +553,18 @@ def _fastq_strings(lib, h, n, data_fn, bytes_fn, offsets_fn):
     return [buf[int(off[k]):int(off[k + 1])].decode('utf-8') for k in range(n)]
 
 
+def _fastq_arrays(lib, h, n):
+    """the arena / offsets and aux / aux offsets of a c2_fastq handle as numpy views"""
+    def view(data_fn, bytes_fn, offsets_fn):
+        nb = int(bytes_fn(h))
+        a = np.ctypeslib.as_array(ctypes.cast(data_fn(h), ctypes.POINTER(ctypes.c_uint8)), (nb,)) if nb else np.zeros(0, dtype=np.uint8)
+        o = np.ctypeslib.as_array(ctypes.cast(offsets_fn(h), ctypes.POINTER(ctypes.c_uint64)), (n + 1,)) if n else np.zeros(1, dtype=np.uint64)
+        return a, o
+    ka, ko = view(lib.c2_fastq_arena, lib.c2_fastq_arena_bytes, lib.c2_fastq_offsets)
+    qa, qo = view(lib.c2_fastq_aux, lib.c2_fastq_aux_bytes, lib.c2_fastq_aux_offsets)
+    return ka, ko, qa, qo
+
+
 class PairedFastq:
     """c2_fastq_unique_paired (host code, needs no GPU): the unique read pairs of two FASTQ files read in lockstep.
     keys[k] = seq1 + '+' + reverse_complement(seq2), counts[k] copies, quals[k] = qual1 + ' ' + qual2[::-1] of the first
@@ -570,17 +582,35 @@ class PairedFastq:
             raise NativeError("c2_fastq_unique_paired: %s" % msg)
         h = self._h
         n = int(lib.c2_fastq_n_unique(h))
-        self.keys = _fastq_strings(lib, h, n, lib.c2_fastq_arena, lib.c2_fastq_arena_bytes, lib.c2_fastq_offsets)
-        self.quals = _fastq_strings(lib, h, n, lib.c2_fastq_aux, lib.c2_fastq_aux_bytes, lib.c2_fastq_aux_offsets)
+        self.n_unique = n
+        self._keys = self._quals = None                               # (Python strings only for a caller that asks for them)
         self.counts = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_counts(h), ctypes.POINTER(ctypes.c_uint32)), (n,)).copy()
                        if n else np.zeros(0, dtype=np.uint32))
         self.n_pairs = int(lib.c2_fastq_n_reads(h))
 
-    def occurrences(self, selected):
-        """selected: bool per key -> (key index per occurrence, quality pair per occurrence), in file order."""
+    @property
+    def keys(self):
+        if self._keys is None:
+            self._keys = _fastq_strings(self._lib, self._h, self.n_unique, self._lib.c2_fastq_arena, self._lib.c2_fastq_arena_bytes, self._lib.c2_fastq_offsets)
+        return self._keys
+
+    @property
+    def quals(self):
+        if self._quals is None:
+            self._quals = _fastq_strings(self._lib, self._h, self.n_unique, self._lib.c2_fastq_aux, self._lib.c2_fastq_aux_bytes, self._lib.c2_fastq_aux_offsets)
+        return self._quals
+
+    def arrays(self):
+        """-> (key bytes uint8, key offsets uint64 [n + 1], quality bytes uint8, quality offsets uint64 [n + 1]): views of the native arenas
+        (valid until close()) -- the keys and quality pairs without a Python string per pair"""
+        return _fastq_arrays(self._lib, self._h, self.n_unique)
+
+    def occurrences(self, selected, as_arrays=False):
+        """selected: bool per key -> (key index per occurrence, quality pair per occurrence), in file order.
+        as_arrays: the quality pairs as (bytes uint8, offsets uint64 [m + 1]) instead of strings."""
         lib = self._lib
         sel = np.ascontiguousarray(selected, dtype=np.uint8)
-        if sel.shape != (len(self.keys),):
+        if sel.shape != (self.n_unique,):
             raise ValueError("one flag per key")
         out = ctypes.c_void_p()
         rc = lib.c2_fastq_paired_occurrences(self._paths[0], self._paths[1], self._h, sel.ctypes.data_as(ctypes.c_void_p), ctypes.byref(out))
@@ -590,7 +620,11 @@ class PairedFastq:
             m = int(lib.c2_fastq_n_unique(out))
             idx = (np.ctypeslib.as_array(ctypes.cast(lib.c2_fastq_counts(out), ctypes.POINTER(ctypes.c_uint32)), (m,)).copy()
                    if m else np.zeros(0, dtype=np.uint32))
-            quals = _fastq_strings(lib, out, m, lib.c2_fastq_aux, lib.c2_fastq_aux_bytes, lib.c2_fastq_aux_offsets)
+            if as_arrays:
+                _, _, qa, qo = _fastq_arrays(lib, out, m)
+                quals = (qa.copy(), qo.copy())
+            else:
+                quals = _fastq_strings(lib, out, m, lib.c2_fastq_aux, lib.c2_fastq_aux_bytes, lib.c2_fastq_aux_offsets)
         finally:
             lib.c2_fastq_free(out)
         return idx, quals

@@ -304,6 +304,22 @@ int c2_consensus_pairs_batch(c2_ctx* ctx, uint64_t n, const uint8_t* s1, const u
     return 0;
 }
 
+int c2_classify_records_device(c2_ctx* ctx, uint64_t n, const uint8_t* d_aln_read, const uint8_t* d_aln_ref, uint32_t stride, const int32_t* d_info,
+                               const uint16_t* d_ref_ids, const uint8_t* d_strands, int32_t legacy, c2_aln_record* d_records, void* hip_stream) {
+    if (!ctx || (n && (!d_aln_read || !d_aln_ref || !d_info || !d_records))) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
+    if (n == 0) return 0;
+    if (ctx->n_refs <= 0) { ctx->err = "references must be set first"; return C2_E_STATE; }
+    if (!d_ref_ids && (n % (uint64_t)ctx->n_refs)) { ctx->err = "all-references layout: n must be a multiple of the number of references"; return C2_E_INVALID; }
+    if (n > 0x7fffffffull * 4ull) { ctx->err = "too many items for one launch"; return C2_E_TOO_LARGE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    c2_records_args A;
+    A.aln_read = d_aln_read; A.aln_ref = d_aln_ref; A.info = d_info; A.ref_ids = d_ref_ids; A.strands = d_strands; A.refs = (const c2_dev_ref*)ctx->d_refdesc.p;
+    A.records = d_records; A.n = n; A.stride = stride; A.n_refs = ctx->n_refs; A.legacy = legacy ? 1 : 0; A.reserved = 0;
+    hipLaunchKernelGGL(c2_classify_records_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, A);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 int c2_calculate_homology(c2_ctx* ctx, const char* a, const char* b, int32_t n, double* out) {
     if (!ctx || !a || !b || !out || n < 0) { if (ctx) ctx->err = "bad argument"; return C2_E_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));

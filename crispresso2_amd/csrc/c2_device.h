@@ -24,6 +24,8 @@
 #endif
 #define C2_TASK_CHUNK 4              // tasks a workgroup takes per atomic
 #define C2_STATUS_NEED_FULL 64     // internal: banded launch could not finish the traceback; the full-plane launch overwrites the record
+#define C2_STATUS_SHAPE 128        // c2_classify_records_kernel: a pair of strings the count route's classifier does not take (a gap in both strings
+                                   // of one column, or an insertion column next to a deletion column: shapes the aligner never emits, a consensus of two reads can)
 
 // Row constants of the diagonal-band kernel: I opened from M (a), I extended (b), J opened from M (c) -- gap_open, gap_extend
 // and the gap incentives of the row folded in, last-row rule included -- and the packed score row of the reference base.
@@ -386,4 +388,20 @@ struct c2_allele_group_args {
     const uint64_t* head_scan;        // pass 1: exclusive scan of head -> group of position j = head_scan[j] + head[j] - 1
     uint32_t* gid;                    // pass 1: per subset index
     uint8_t* gkeys;                   // pass 1: [group][key_bytes], in key order
+};
+
+// ---- records of GIVEN aligned strings (c2_classify_records_kernel): what the fused classifier of the align kernels writes for the
+// alignments it emits, for strings that come from somewhere else -- the consensus alignments of read pairs (c2_consensus_pairs_kernel)
+struct c2_records_args {
+    const uint8_t* aln_read; const uint8_t* aln_ref;   // n x stride
+    const int32_t* info;              // n x 4 (c2_consensus_pairs_kernel's): [0] columns, [2] matching columns, [3] flags
+    const uint16_t* ref_ids;          // per item, or NULL: all-references layout (item = unit * n_refs + reference)
+    const uint8_t* strands;           // per item (copied into the record), or NULL
+    const c2_dev_ref* refs;
+    c2_aln_record* records;
+    uint64_t n;
+    uint32_t stride;
+    int32_t n_refs;
+    int32_t legacy;
+    int32_t reserved;
 };

@@ -273,6 +273,111 @@ __global__ __launch_bounds__(64) void c2_consensus_pairs_kernel(c2_consensus_arg
     info[0] = len; info[1] = qlen; info[2] = hom; info[3] = (caching ? 1 : 0) | (index_error ? 2 : 0);
 }
 
+// The 32-byte record of a GIVEN pair of aligned strings -- the counters the fused classifier of the align kernels derives for the
+// alignments it emits (find_indels_substitutions, COREResources.pyx:68-187, + CRISPRessoCORE.py:726-760), here for strings that come from
+// somewhere else: the consensus alignment of a read pair (get_consensus_alignment_from_pairs, CRISPRessoCORE.py:829-984).  One wavefront per
+// item, 64 columns per step, the same scan as c2_emit_and_classify (forward order, strings in global memory).  That scan relies on what
+// the aligner guarantees -- no column with a gap in both strings, no insertion column next to a deletion column -- and a consensus of two
+// alignments need not keep to it: such an item gets C2_STATUS_SHAPE and the caller takes the list-based classifier for the run.
+__global__ __launch_bounds__(256) void c2_classify_records_kernel(c2_records_args A)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t t = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= A.n) return;                                                          // (wave-uniform)
+    const uint8_t* R = A.aln_read + t * (uint64_t)A.stride;
+    const uint8_t* F = A.aln_ref + t * (uint64_t)A.stride;
+    const int T = A.info[t * 4 + 0], matches = A.info[t * 4 + 2];
+    const int ref_id = A.ref_ids ? (int)A.ref_ids[t] : (int)(t % (uint64_t)A.n_refs);
+    const uint16_t* sIncP = A.refs[ref_id].inc_prefix;
+    c2_aln_record rec;
+    {
+        uint32_t* z = (uint32_t*)&rec;
+        for (int k = 0; k < 8; ++k) z[k] = 0u;
+    }
+    rec.ref_id = (uint16_t)ref_id;
+    rec.strand = A.strands ? A.strands[t] : (uint8_t)0;
+    if (T <= 0 || T > 65535 || (A.info[t * 4 + 3] & 2)) { rec.status = C2_STATUS_EMPTY; if (lane == 0) A.records[t] = rec; return; }
+    int idx_base = 0, last_rf = -1, last_rd = -1;
+    int n_all_sub = 0, n_win_sub = 0, n_all_ins = 0, n_win_ins = 0, n_all_del = 0, n_win_del = 0;
+    int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;
+    bool shape = false;
+    bool prev_ins_col = false, prev_del_col = false;                                // the column in front of this chunk
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = 0; base < T; base += 64) {
+        const int cidx = base + lane;
+        const bool in = cidx < T;
+        const unsigned char rd = in ? R[cidx] : 0, rfc = in ? F[cidx] : 0;
+        const bool rf_ng = in && rfc != '-', rd_ng = in && rd != '-';
+        const unsigned long long m_rf = __ballot(rf_ng), m_rd = __ballot(rd_ng), m_in = __ballot(in);
+        {   // shapes outside the scan's assumptions
+            const unsigned long long ins_col = m_in & ~m_rf, del_col = m_in & ~m_rd;
+            if (ins_col & del_col) shape = true;
+            if ((ins_col & (del_col << 1)) | (del_col & (ins_col << 1))) shape = true;
+            if (((ins_col & 1ull) && prev_del_col) || ((del_col & 1ull) && prev_ins_col)) shape = true;
+            prev_ins_col = (ins_col >> 63) & 1ull; prev_del_col = (del_col >> 63) & 1ull;
+        }
+        const int idx = idx_base + __popcll(m_rf & lt);
+        const unsigned long long below_rf = m_rf & lt, below_rd = m_rd & lt;
+        const int prev_rf = below_rf ? base + 63 - __clzll((long long)below_rf) : last_rf;
+        const int prev_rd = below_rd ? base + 63 - __clzll((long long)below_rd) : last_rd;
+        const bool sub = rf_ng && rd_ng && rd != rfc && rd != 'N';                   // pyx:113-118
+        const bool sub_win = sub && (sIncP[idx + 1] != sIncP[idx]);
+        n_all_sub += __popcll(__ballot(sub));
+        n_win_sub += __popcll(__ballot(sub_win));
+        const bool ins_close = rf_ng && (prev_rf != cidx - 1) && idx > 0;            // pyx:119-128, :136
+        const bool fl = ins_close && (sIncP[idx] != sIncP[idx - 1]), fr = ins_close && (sIncP[idx + 1] != sIncP[idx]);
+        const bool ins_win = A.legacy ? (fl || fr) : (fl && fr);                     // pyx:121 / legacy pyx:284
+        n_all_ins += __popcll(__ballot(ins_close));
+        n_win_ins += __popcll(__ballot(ins_win));
+        if (ins_win) acc_ins_n += cidx - 1 - prev_rf;
+        const bool del_close = rd_ng && (prev_rd != cidx - 1);                       // pyx:145-153
+        const int dlen = cidx - 1 - prev_rd;
+        const int dstart = (A.legacy && prev_rd <= 0) ? 0 : idx - dlen;              // legacy pyx:253-258
+        const bool del_win = del_close && (sIncP[idx] != sIncP[dstart]);
+        n_all_del += __popcll(__ballot(del_close));
+        n_win_del += __popcll(__ballot(del_win));
+        if (del_close) acc_del_bases += idx - dstart;
+        if (del_win) acc_del_n += dlen;
+        idx_base += __popcll(m_rf);
+        if (m_rf) last_rf = base + 63 - __clzll((long long)m_rf);
+        if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
+    }
+    int tr_bases = 0, tr_win = 0;
+    if (last_rd != T - 1) {                                                          // trailing deletion, pyx:155-162
+        const int dlen = T - 1 - last_rd;
+        n_all_del += 1;
+        if (!A.legacy) {
+            tr_bases = dlen;
+            if (idx_base - dlen >= 0 && sIncP[idx_base] != sIncP[idx_base - dlen]) { tr_win = dlen; n_win_del += 1; }
+        } else {
+            const int dstart = last_rd <= 0 ? 0 : idx_base - dlen, dend = idx_base - 1;   // legacy pyx:259-261
+            tr_bases = dend > dstart ? dend - dstart : 0;
+            if (dend > dstart && sIncP[dend] != sIncP[dstart]) { tr_win = dlen; n_win_del += 1; }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        acc_ins_n += __shfl_xor(acc_ins_n, m);
+        acc_del_n += __shfl_xor(acc_del_n, m);
+        acc_del_bases += __shfl_xor(acc_del_bases, m);
+    }
+    const unsigned char r0 = R[0], f0 = F[0], rL = R[T - 1], fL = F[T - 1];
+    rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;   // CRISPRessoCORE.py:1106-1110
+    rec.aln_len = (uint16_t)T;
+    rec.matches = (uint16_t)matches;
+    rec.insertion_n = (uint16_t)acc_ins_n;
+    rec.deletion_n = (uint16_t)(acc_del_n + tr_win);
+    rec.substitution_n = (uint16_t)n_win_sub;
+    rec.all_insertion_events = (uint16_t)n_all_ins;
+    rec.win_insertion_events = (uint16_t)n_win_ins;
+    rec.all_deletion_events = (uint16_t)n_all_del;
+    rec.win_deletion_events = (uint16_t)n_win_del;
+    rec.all_deletion_bases = (uint16_t)(acc_del_bases + tr_bases);
+    rec.all_substitutions = (uint16_t)n_all_sub;
+    rec.status = shape ? C2_STATUS_SHAPE : 0;
+    if (lane == 0) A.records[t] = rec;
+}
+
 // calculate_homology, COREResources.pyx:318-327 (float32 accumulator; result = score / strlen(a))
 __global__ __launch_bounds__(64) void c2_homology_kernel(const uint8_t* a, const uint8_t* b, int n, float* out)
 {

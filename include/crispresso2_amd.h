@@ -377,6 +377,16 @@ int c2_consensus_pairs_device(c2_ctx* ctx, uint64_t n, const uint8_t* d_s1, cons
                               uint32_t qstride, const int32_t* d_lq1, const int32_t* d_lq2, const uint8_t* d_best1,
                               uint8_t* d_out_aln, uint8_t* d_out_ref, uint8_t* d_out_qual, uint32_t ostride, int32_t* d_out_info, void* hip_stream);
 
+/* Records of GIVEN aligned strings on the device: for every item (two rows of `stride` bytes, d_info[4 * item] columns of them, d_info[4 * item + 2]
+ * matching columns -- c2_consensus_pairs_device's d_out_info) the 32-byte c2_aln_record the align kernels' fused classifier would write:
+ * window and whole-amplicon counts of find_indels_substitutions (CRISPRessoCOREResources.pyx:68-187; legacy != 0: pyx:190-315), irregular ends
+ * (CRISPRessoCORE.py:1106-1110).  d_ref_ids NULL: all-references layout (item = unit * n_refs + reference).  An item whose strings have a shape
+ * the aligner never emits (a gap in both strings of a column, an insertion column next to a deletion column) gets status 128: the count route
+ * does not take it, the list-based classifier (c2_classify_lists_batch) does.  A consensus the reference raises IndexError for (info flag 2): status 1.
+ * This is what puts get_new_variant_object_from_paired's consensus alignments (CRISPRessoCORE.py:987-1169) on the count route. */
+int c2_classify_records_device(c2_ctx* ctx, uint64_t n, const uint8_t* d_aln_read, const uint8_t* d_aln_ref, uint32_t stride, const int32_t* d_info,
+                               const uint16_t* d_ref_ids, const uint8_t* d_strands, int32_t legacy, c2_aln_record* d_records, void* hip_stream);
+
 /* ---- FASTQ ingest + exact de-duplication (host code, no GPU): the first pass of process_fastq,
  * CRISPRessoCORE.py:1820-1849 -- every 4-line record's sequence line, str.strip()'ed, counted per distinct sequence in
  * first-seen order; plain or gzip'ed input, universal newlines.  The result owns: the unique sequences back to back

@@ -487,6 +487,24 @@ int emu_select_best(uint64_t n_reads, int n_refs, const c2_aln_record* records, 
     return 0;
 }
 
+int emu_classify_records(uint64_t n, const uint8_t* aln_read, const uint8_t* aln_ref, uint32_t stride, const int32_t* info, const uint16_t* ref_ids,
+                         const uint8_t* strands, int legacy, c2_aln_record* records, int n_refs, const int32_t* lens,
+                         const int32_t* const* include_idx, const int32_t* n_include)
+{
+    std::vector<c2_dev_ref> refs(n_refs);
+    std::vector<std::vector<uint16_t>> incp(n_refs);
+    for (int r = 0; r < n_refs; ++r) {
+        c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
+        memset(&refs[r], 0, sizeof refs[r]);
+        refs[r].inc_prefix = incp[r].data(); refs[r].len = lens[r];
+    }
+    c2_records_args A;
+    A.aln_read = aln_read; A.aln_ref = aln_ref; A.info = info; A.ref_ids = ref_ids; A.strands = strands; A.refs = refs.data(); A.records = records;
+    A.n = n; A.stride = stride; A.n_refs = n_refs; A.legacy = legacy; A.reserved = 0;
+    emu::launch((unsigned)((n + 3) / 4), [&] { c2_classify_records_kernel(A); }, 256);
+    return 0;
+}
+
 uint32_t emu_mscore(uint32_t matches, uint32_t T) { return c2_mscore(matches, T); }
 
 int emu_selftest(int* out) { emu::launch(1, [&] { c2_selftest_kernel(out); }); return 0; }

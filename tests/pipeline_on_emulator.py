@@ -196,13 +196,36 @@ class _EmuAlleleCalls:
         E.lib().emu_allele_table_free(h)
 
 
+def _emu_consensus_device(ctx, n, s1, f1, s2, f2, stride, n1, n2, q1, q2, qstride, lq1, lq2, best1, oa, orf, oq, ostride, info, stream):
+    """paired_device.consensus_device -> c2_consensus_pairs_kernel on the emulator (same arguments; the addresses are host addresses here)"""
+    V = ctypes.c_void_p
+    rc = E.lib().emu_consensus_pairs(ctypes.c_uint64(n), V(s1), V(f1), V(s2), V(f2), ctypes.c_uint32(stride), V(n1), V(n2), V(q1), V(q2), ctypes.c_uint32(qstride),
+                                     V(lq1), V(lq2), V(best1), V(oa), V(orf), V(oq), ctypes.c_uint32(ostride), V(info))
+    assert rc == 0
+
+
+def _emu_classify_records_device(ctx, n, aln_read, aln_ref, stride, info, ref_ids, strands, legacy, records, stream, refs=None, ref_names=None):
+    """paired_device.classify_records_device -> c2_classify_records_kernel on the emulator"""
+    V = ctypes.c_void_p
+    nrefs = len(ref_names)
+    lens = np.array([len(refs[nm]['sequence']) for nm in ref_names], dtype=np.int32)
+    inc = [np.ascontiguousarray(np.asarray(sorted(set(int(x) for x in refs[nm]['include_idxs'])), dtype=np.int64).astype(np.int32)) for nm in ref_names]
+    ip = (ctypes.c_void_p * nrefs)(*[x.ctypes.data for x in inc])
+    ninc = np.array([len(x) for x in inc], dtype=np.int32)
+    rc = E.lib().emu_classify_records(ctypes.c_uint64(n), V(aln_read), V(aln_ref), ctypes.c_uint32(stride), V(info), V(ref_ids or 0), V(strands or 0), int(bool(legacy)),
+                                      V(records), nrefs, lens.ctypes.data_as(V), ip, ninc.ctypes.data_as(V))
+    assert rc == 0
+
+
 @contextlib.contextmanager
 def emulated_device(made=None):
     """Inside the block pipeline.quantify_* run on the emulator; restored afterwards.  made: the caller's list of emulated aligners
     (bench_on_emulator shares its own, so that the count pass always sees the aligner of the batch it counts)."""
     import torch
-    from crispresso2_amd import pipeline, variants, paired, counts as C, _native, alleles
+    from crispresso2_amd import pipeline, variants, paired, counts as C, _native, alleles, paired_device
     made = [] if made is None else made
+    saved_paired_device = (paired_device.consensus_device, paired_device.classify_records_device)
+    paired_device.consensus_device, paired_device.classify_records_device = _emu_consensus_device, _emu_classify_records_device
     saved_allele_calls = alleles.CALLS
     alleles.CALLS = _EmuAlleleCalls
 
@@ -212,6 +235,9 @@ def emulated_device(made=None):
 
     class _Stream:
         cuda_stream = 0
+    import crispresso2_amd.batch as _batch_mod
+    saved_batch_aligner = _batch_mod.BatchAligner
+    _batch_mod.BatchAligner = make_aligner                            # (paired_device imports it from there at call time)
     saved = (torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context)
     saved_select = C.select_best_device
     C.select_best_device = _select
@@ -230,7 +256,9 @@ def emulated_device(made=None):
         yield
     finally:
         torch.device, torch.cuda.current_stream, torch.cuda.synchronize, pipeline.BatchAligner, C.accumulate_device, _native.default_context = saved
+        _batch_mod.BatchAligner = saved_batch_aligner
         variants.BatchAligner, paired.BatchAligner = saved_variants_aligner, saved_paired_aligner
         C.select_best_device = saved_select
         C.strand_plan_device = saved_strand
         alleles.CALLS = saved_allele_calls
+        paired_device.consensus_device, paired_device.classify_records_device = saved_paired_device
