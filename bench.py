@@ -428,7 +428,44 @@ def _dedup_on_leg(job, reads, steps):
     return out
 
 
-def _e2e_prepare(reads, workers):
+def _e2e_sharded_leg(path, n_reads, ctx, L, matrix, dev, repeat=2):
+    """N ranks, one FASTQ file: pipeline.quantify_fastq(shard_across_ranks=True) -- every rank uploads, frames and de-duplicates ITS byte range
+    of the text, the ranks all-gather their unique reads, each aligns its range of the run's list, the count tensors are all-reduced.
+    A collective: every rank calls it.  -> (rank 0) seconds, reads/s, what every rank uploaded."""
+    import torch
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    from crispresso2_amd import pipeline, refs as RF, synth
+    amp, g, inc = synth.amplicon_setup(L)
+    args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=GO, needleman_wunsch_gap_extend=GE,
+                           ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
+                           assign_ambiguous_alignments_to_first_reference=False, expand_ambiguous_alignments=False, discard_indel_reads=False)
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=MIN_ALN_SCORE)
+    runs, last = [], None
+    for rep in range(repeat + 1):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = pipeline.quantify_fastq(path, {"Reference": ref}, ["Reference"], matrix, args, ctx=ctx, shard_across_ranks=True)
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        runs.append(float(t.item()))
+        c = res.per_ref["Reference"]
+        last = (res.stats["N_TOT_READS"], res.stats["N_TOTAL"], c["counts_total"], c["counts_modified"], getattr(res, "ingest_route", "host"), getattr(res, "shard_ingest", None))
+        del res
+    shards = [None] * dist.get_world_size()
+    dist.all_gather_object(shards, last[5])
+    dt = min(runs[1:])
+    return {"reads": n_reads, "seconds": dt, "reads_per_s": n_reads / dt, "seconds_all_runs": runs, "ingest_route": last[4],
+            "tallies": dict(zip(("N_TOT_READS", "N_TOTAL", "counts_total", "modified"), last[:4])),
+            "per_rank": shards,
+            "note": "one FASTQ file, N ranks: each rank uploads + frames + de-duplicates its byte range (shard_bytes of text_bytes), the ranks' unique reads are "
+                    "all-gathered and reconciled, each aligns its range of the run's unique reads, one all-reduce of the count tensor; max over ranks, best of %d "
+                    "runs after a warm-up" % repeat}
+
+
+def _e2e_prepare(reads, workers, bgzf=True):
     """(host, before HIP) the headline's reads as a FASTQ file in /dev/shm -- plain, and BGZF-compressed by a process pool -- sized down if
     the file system is too small.  -> dict(dir, plain, bgzf, reads, bytes_plain, bytes_bgzf, write_s) or {"skipped": reason}"""
     from crispresso2_amd import synth
@@ -451,11 +488,11 @@ def _e2e_prepare(reads, workers):
         try:
             d = tempfile.mkdtemp(prefix="c2bench_", dir=base)
             t0 = time.perf_counter()
-            plain, bgzf = os.path.join(d, "reads.fastq"), os.path.join(d, "reads.bgzf.fastq.gz")
+            plain, bgzf_path = os.path.join(d, "reads.fastq"), os.path.join(d, "reads.bgzf.fastq.gz")
             b1 = synth.write_fastq(reads[:m], plain)
             t1 = time.perf_counter()
-            b2 = synth.write_bgzf(plain, bgzf, workers=workers)
-            return dict(dir=d, plain=plain, bgzf=bgzf, reads=m, bytes_plain=b1, bytes_bgzf=b2, write_plain_s=t1 - t0, write_bgzf_s=time.perf_counter() - t1)
+            b2 = synth.write_bgzf(plain, bgzf_path, workers=workers) if bgzf else 0
+            return dict(dir=d, plain=plain, bgzf=bgzf_path if bgzf else None, reads=m, bytes_plain=b1, bytes_bgzf=b2, write_plain_s=t1 - t0, write_bgzf_s=time.perf_counter() - t1)
         except OSError:
             if d:
                 shutil.rmtree(d, ignore_errors=True)
@@ -655,9 +692,9 @@ def main():
                                                         ref_ids=None if wlc["ref_ids"] is None else wlc["ref_ids"][:m_], all_refs=wlc["all_refs"], procs=procs_)
                 except Exception as e:
                     other_ref[cfg] = ({"error": repr(e)}, None)
-        if rank == 0 and world == 1 and not all_refs and wl["ref_ids"] is None:
-            try:
-                e2e_files = _e2e_prepare(reads[:args.extra_reads] if args.extra_reads else reads, min(64, max(workers, ncpu // 4)))
+        if rank == 0 and not all_refs and wl["ref_ids"] is None:
+            try:                                                     # (N ranks: one plain file, read by all of them -- the sharded FASTQ leg)
+                e2e_files = _e2e_prepare(reads[:args.extra_reads] if args.extra_reads else reads, min(64, max(workers, ncpu // 4)), bgzf=world == 1)
             except Exception as e:                                   # the headline must not die of a side leg
                 e2e_files = {"skipped": "writing the FASTQ files failed: %r" % (e,)}
 
@@ -883,7 +920,23 @@ def main():
                     raise
             other_configs["config%d" % cfg] = entry
         del other_wl
-        if e2e_files is not None:
+        if world > 1:
+            # the sharded FASTQ leg: rank 0 wrote the file (same node: /dev/shm), every rank ingests its byte range of it
+            box = [None if (e2e_files is None or "skipped" in e2e_files) else (e2e_files["plain"], e2e_files["reads"])]
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                try:
+                    e2e = {"sharded": _e2e_sharded_leg(box[0][0], box[0][1], ctx, L, m, dev)}
+                except Exception as e:
+                    e2e = {"sharded": {"error": repr(e)}}
+                    raise
+                finally:
+                    dist.barrier()
+                    if rank == 0:
+                        shutil.rmtree(e2e_files["dir"], ignore_errors=True)
+            elif e2e_files is not None:
+                e2e = e2e_files
+        elif e2e_files is not None:
             if "skipped" in e2e_files:
                 e2e = e2e_files
             else:
@@ -938,7 +991,10 @@ def main():
                        "other_configs_reference_identical": None if not other_configs else {
                            c_: "%s/%s" % (e_.get("reference_identical_n"), e_.get("reference_compared_n")) for c_, e_ in other_configs.items() if isinstance(e_, dict) and "reference_compared_n" in e_},
                        "other_configs_reads_per_s": None if not other_configs else {c_: e_.get("reads_per_s") for c_, e_ in other_configs.items() if isinstance(e_, dict) and "reads_per_s" in e_},
-                       "e2e_fastq_to_tensors_reads_per_s": None if not e2e or "plain" not in e2e else e2e["plain"]["reads_per_s"],
+                       "e2e_fastq_to_tensors_reads_per_s": (None if not e2e else e2e["plain"]["reads_per_s"] if "plain" in e2e else
+                                                            (e2e.get("sharded") or {}).get("reads_per_s")),
+                       "e2e_sharded_shard_bytes_per_rank": None if not e2e or "sharded" not in e2e or not e2e["sharded"].get("per_rank") else
+                                                           [None if sh is None else sh.get("shard_bytes") for sh in e2e["sharded"]["per_rank"]],
                        "e2e_fastq_to_all_tables_seconds": None if not e2e or "with_all_tables" not in e2e else e2e["with_all_tables"]["seconds"],
                        "e2e_fastq_to_all_tables_reads_per_s": None if not e2e or "with_all_tables" not in e2e else e2e["with_all_tables"]["reads_per_s"]},
             "alignments_per_s": world * n_tasks * args.steps / dt,

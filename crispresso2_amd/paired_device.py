@@ -48,33 +48,6 @@ def classify_records_device(ctx, n, aln_read, aln_ref, stride, info, ref_ids, st
                                                  V(strands or 0), int(bool(legacy)), V(records), V(stream or 0)), "c2_classify_records_device")
 
 
-def _gather(arena, starts, lens):
-    """bytes arena[starts[i] : starts[i] + lens[i]] back to back -> (uint8 array, int64 offsets [m + 1])"""
-    lens = np.asarray(lens, dtype=np.int64)
-    off = np.zeros(len(lens) + 1, dtype=np.int64)
-    np.cumsum(lens, out=off[1:])
-    total = int(off[-1])
-    if total == 0:
-        return np.zeros(1, dtype=np.uint8), off
-    src = np.repeat(np.asarray(starts, dtype=np.int64) - off[:-1], lens) + np.arange(total, dtype=np.int64)
-    return np.ascontiguousarray(arena[src]), off
-
-
-def _rows(arena, starts, lens, stride):
-    """the same bytes as rows of `stride` bytes (zero padded)"""
-    lens = np.asarray(lens, dtype=np.int64)
-    m = len(lens)
-    out = np.zeros((m, stride), dtype=np.uint8)
-    total = int(lens.sum())
-    if total:
-        off = np.zeros(m + 1, dtype=np.int64)
-        np.cumsum(lens, out=off[1:])
-        row = np.repeat(np.arange(m, dtype=np.int64), lens)
-        col = np.arange(total, dtype=np.int64) - np.repeat(off[:-1], lens)
-        out[row, col] = arena[np.repeat(np.asarray(starts, dtype=np.int64), lens) + col]
-    return out
-
-
 def _mscore(matches, T):
     """1000 x round(100 * matches / T, 3) as integers (c2_mscore: exact, round half to even), for int64 tensors"""
     num = 100000 * matches
@@ -90,9 +63,31 @@ class _Units:
     pass
 
 
-def _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, ka, k_start, k_plus, k_end, q_arena, q_start, q_space, q_end):
-    """One pass over m pairs: key bytes ka[k_start[i] : k_end[i]] with the '+' at k_plus[i]; quality pair q_arena[q_start[i] : q_end[i]] with the
-    blank at q_space[i]."""
+def _dev_gather(ctx, dev, stream, d_text, starts, lens, row_stride=0):
+    """bytes d_text[starts[i] : starts[i] + lens[i]] (numpy int64 arrays) gathered ON THE DEVICE (c2_fq_gather_kernel): back to back -> (uint8 tensor,
+    int64 offsets tensor [m + 1]); row_stride > 0: as zero-padded rows of that many bytes -> uint8 tensor [m, row_stride]"""
+    import torch
+    from . import fastq_device
+    m = len(starts)
+    lens = np.asarray(lens, dtype=np.int64)
+    info = to_device((np.asarray(starts, dtype=np.int64) << 24) | lens, dev)
+    if row_stride:
+        out_off = torch.arange(m + 1, dtype=torch.int64, device=dev) * row_stride
+        out = torch.zeros((max(m, 1), row_stride), dtype=torch.uint8, device=dev)
+    else:
+        off = np.zeros(m + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        out_off = to_device(off, dev)
+        out = torch.empty(max(int(off[-1]), 1), dtype=torch.uint8, device=dev)
+    if m:
+        fastq_device.fq_gather(ctx, d_text.data_ptr(), info.data_ptr(), None, out_off.data_ptr(), out.data_ptr(), m, stream)
+    return (out[:m] if row_stride else out), out_off
+
+
+def _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, k_start, k_plus, k_end, d_qa, q_start, q_space, q_end):
+    """One pass over m pairs: key bytes d_ka[k_start[i] : k_end[i]] (on the device) with the '+' at k_plus[i]; quality pair
+    d_qa[q_start[i] : q_end[i]] with the blank at q_space[i].  The index arrays are host arrays (8 bytes per pair each); the reads, keys and
+    quality rows are cut out of the two arenas on the device."""
     import torch
     from . import fastq_device
     m, k = len(k_start), len(ref_names)
@@ -101,11 +96,9 @@ def _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, ka, k_start
     l1, l2 = k_plus - k_start, k_end - k_plus - 1
     if m and (int(l1.min()) <= 0 or int(l2.min()) <= 0):
         raise Exception('global_align: undefined alignment (status %d)' % _native.STATUS_EMPTY)     # (an empty read: the reference indexes seq[-1])
-    a_key, o_key = _gather(ka, k_start, k_end - k_start)
-    a_r1, o_r1 = _gather(ka, k_start, l1)
-    a_r2, o_r2 = _gather(ka, k_plus + 1, l2)
-    d_key, d_koff = to_device(a_key, dev), to_device(o_key, dev)
-    d_r1, d_o1, d_r2, d_o2 = to_device(a_r1, dev), to_device(o_r1, dev), to_device(a_r2, dev), to_device(o_r2, dev)
+    d_key, d_koff = _dev_gather(ctx, dev, stream, d_ka, k_start, k_end - k_start)
+    d_r1, d_o1 = _dev_gather(ctx, dev, stream, d_ka, k_start, l1)
+    d_r2, d_o2 = _dev_gather(ctx, dev, stream, d_ka, k_plus + 1, l2)
     max_l = int(max(l1.max(), l2.max())) if m else 1
     max_key = int((k_end - k_start).max()) if m else 1
     # ---- seed test over both reads of the pair (:1024-1036): "seed in read 1 or seed in read 2" = "seed in key" (no seed holds a '+')
@@ -128,8 +121,8 @@ def _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, ka, k_start
     # qualities: one row per read
     ql1, ql2 = q_space - q_start, q_end - q_space - 1
     qstride = max(16, (int(max(ql1.max(), ql2.max())) + 15) // 16 * 16) if m else 16
-    d_q1 = to_device(_rows(q_arena, q_start, ql1, qstride), dev)
-    d_q2 = to_device(_rows(q_arena, q_space + 1, ql2, qstride), dev)
+    d_q1, _ = _dev_gather(ctx, dev, stream, d_qa, q_start, ql1, row_stride=qstride)
+    d_q2, _ = _dev_gather(ctx, dev, stream, d_qa, q_space + 1, ql2, row_stride=qstride)
     d_lq1, d_lq2 = to_device(ql1.astype(np.int32), dev), to_device(ql2.astype(np.int32), dev)
 
     def consensus(n_items, a1, f1, r1, a2, f2, r2, q1, q2, lq1, lq2, ref_ids, strands):
@@ -228,7 +221,9 @@ def quantify_paired_fastq(fastq1, fastq2, refs, ref_names, aln_matrix, args, ctx
         if len(plus) != n or len(blank) != n or (n and (((plus < ko[:-1]) | (plus >= ko[1:])).any() or ((blank < qo[:-1]) | (blank >= qo[1:])).any())):
             raise ValueError("too many values to unpack (expected 2)")             # key.split('+') / quals.split(' ') of the reference (:1225-1226)
         lap("paired_ingest")
-        first = _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, ka, ko[:-1], plus, ko[1:], qa, qo[:-1], blank, qo[1:])
+        d_ka = to_device(ka if ka.size else np.zeros(1, dtype=np.uint8), dev)
+        d_qa = to_device(qa if qa.size else np.zeros(1, dtype=np.uint8), dev)
+        first = _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, ko[:-1], plus, ko[1:], d_qa, qo[:-1], blank, qo[1:])
         lap("first_pass")
         # ---- keys seen more than once whose consensus chose a base by quality: every occurrence again, with its own qualities (:1450-1513)
         again = (raw_all > 1) & ~to_host(first.caching_ok.to(torch.uint8)).astype(bool) if n else np.zeros(0, dtype=bool)
@@ -239,7 +234,9 @@ def quantify_paired_fastq(fastq1, fastq2, refs, ref_names, aln_matrix, args, ctx
             blank2 = np.flatnonzero(qa2 == 32)
             if len(blank2) != len(idx_occ):
                 raise ValueError("too many values to unpack (expected 2)")
-            second = _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, ka, ko[:-1][idx_occ], plus[idx_occ], ko[1:][idx_occ], qa2, qo2[:-1], blank2, qo2[1:])
+            d_qa2 = to_device(qa2 if qa2.size else np.zeros(1, dtype=np.uint8), dev)
+            second = _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, ko[:-1][idx_occ], plus[idx_occ], ko[1:][idx_occ], d_qa2, qo2[:-1], blank2, qo2[1:])
+            del d_qa2
         lap("second_pass")
     finally:
         pf.close()

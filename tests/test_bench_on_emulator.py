@@ -89,7 +89,8 @@ def test_bench_started_bare_with_gpus_2_spawns_its_own_ranks():
     assert out["int32_chain"]["records_equal_the_packed_chain"] and out["int32_chain"]["reads_per_s"] > 0
     c5 = out["other_configs"]["config5"]
     assert c5["n_amplicons"] == 96 and c5["reads_per_gpu_per_step"] == 70 and 70 < c5["reads_aligned_all_gpus"] <= 140
-    assert out["e2e"] is None                                          # (the FASTQ leg is a one-process measurement)
+    sh = out["e2e"]["sharded"]                                         # N ranks: the sharded FASTQ leg (here the file is small: the host parser on every rank)
+    assert sh["reads"] == 70 and sh["tallies"]["N_TOT_READS"] == 70 and sh["reads_per_s"] > 0 and len(sh["per_rank"]) == 2
 
 
 def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fastq_leg():

@@ -239,7 +239,7 @@ def test_two_ranks_each_frame_the_text_on_the_device(tmp_path):
     mp.spawn(_sharded_worker, args=(2, port, str(fq), str(tmp_path), "device"), nprocs=2, join=True)
     for rank in range(2):
         got = pickle.load(open(tmp_path / ("w2_r%d_device.pkl" % rank), "rb"))
-        assert got["route"] == "device, sharded"
+        assert got["route"] == "device, sharded by byte range"
         assert got["stats"] == one["stats"], rank
         for key, v in one["per_ref"]["Reference"].items():
             w = got["per_ref"]["Reference"][key]
