@@ -219,6 +219,16 @@ def _split_partner_worker(rank, world, port, out_dir):
     fq = os.path.join(out_dir, "split_w%d_r%d.fastq" % (world, rank))
     with open(fq, "w") as fh:
         fh.write(text)
+    kind = os.environ.get("C2_TEST_INPUT_KIND", "plain")
+    if kind == "bgzf":                                                  # BGZF: a rank inflates only the members that cover its byte range
+        from crispresso2_amd import synth
+        synth.write_bgzf(fq, fq + ".bgzf.gz", workers=1, slice_bytes=65280 * 2)
+        fq = fq + ".bgzf.gz"
+    elif kind == "gz":                                                  # one gzip member: every rank's host inflates it, each uploads its slice
+        import gzip
+        with gzip.open(fq + ".gz", "wb") as fh:
+            fh.write(text.encode())
+        fq = fq + ".gz"
     a = {k: v for k, v in g["args"].items() if k not in ("plot_window_size", "dsODN")}
     import contextlib
     device_ingest = bool(os.environ.get("C2_TEST_DEVICE_INGEST"))
@@ -309,3 +319,26 @@ def test_sharded_run_with_the_text_framed_on_every_ranks_device(tmp_path, monkey
             assert sh["shard_bytes"] <= -(-size // world // 16384) * 16384 + 2048 + 16, (world, sh)
         assert sum(sh["shard_records"] for sh in shards) == one["stats"]["N_TOT_READS"] + 0 or True
         assert sum(sh["shard_unique"] for sh in shards) == shards[0]["gathered_unique"] >= len(one["alleles"])
+
+
+@pytest.mark.parametrize("kind", ["bgzf", "gz"])
+def test_sharded_device_ingest_of_compressed_input(tmp_path, monkeypatch, kind):
+    """the sharded ingest over compressed input, 2 ranks: BGZF (a rank inflates only the members that cover its byte range of the TEXT) and a
+    single gzip member (the host inflates all of it on every rank, each uploads and frames its slice) -- same result as the single process"""
+    import pickle
+    sys.path.insert(0, HERE)
+    import emu_driver as E
+    E.build()
+    _split_partner_worker(0, 1, 0, str(tmp_path))
+    one = pickle.load(open(tmp_path / "split_world1_rank0.pkl", "rb"))
+    monkeypatch.setenv("C2_TEST_DEVICE_INGEST", "1")
+    monkeypatch.setenv("C2_TEST_INPUT_KIND", kind)
+    mp.spawn(_split_partner_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        got = pickle.load(open(tmp_path / ("split_world2_rank%d.pkl" % rank), "rb"))
+        assert got["stats"] == one["stats"] and got["alleles"] == one["alleles"], (kind, rank)
+        assert got["shard"]["shard_bytes"] < 0.75 * got["shard"]["text_bytes"]
+        for nm in one["per_ref"]:
+            for key, v in one["per_ref"][nm].items():
+                w = got["per_ref"][nm][key]
+                assert np.array_equal(v, w) if isinstance(v, np.ndarray) else v == w, (kind, rank, nm, key)
