@@ -176,6 +176,24 @@ struct c2_fq_frame_args {
     uint64_t* seq_start;              // per record: first byte of its sequence line
     uint64_t* seq_end;                // per record: the newline that ends it
     uint64_t n_records_cap;           // entries of the two arrays
+    uint64_t* qual_start;             // (optional, both or neither) per record: first byte of its quality line ...
+    uint64_t* qual_end;               // ... and the newline that ends it
+};
+// Paired input (process_paired_fastq's reading loop, CRISPRessoCORE.py:1309-1334) over two framed texts: record r of file 1 with record r of file 2.
+// lengths kernel (one thread per record): the four lines str.strip()ped -> s1 / q1 / s2 / q2 [r] = start << 24 | length, key_len[r] = len(seq1) + 1 +
+// len(seq2), qual_len[r] likewise.  write kernel (one wavefront per record): key_out[key_off[r] ..) = seq1 + '+' + reverse_complement(seq2),
+// qual_out[qual_off[r] ..) = qual1 + ' ' + qual2[::-1]; flags bit 0: a line of 2^24 bytes or more / a text of 2^40 or more, bit 1: a character
+// of seq2 outside ACGTN_- (either case; CRISPRessoShared.py:399-403's KeyError).
+struct c2_fq_pair_args {
+    const uint8_t* text1; const uint8_t* text2;
+    const uint64_t* seq_start1; const uint64_t* seq_end1; const uint64_t* qual_start1; const uint64_t* qual_end1;
+    const uint64_t* seq_start2; const uint64_t* seq_end2; const uint64_t* qual_start2; const uint64_t* qual_end2;
+    uint64_t n;
+    unsigned long long* s1; unsigned long long* q1; unsigned long long* s2; unsigned long long* q2;
+    int64_t* key_len; int64_t* qual_len;               // lengths kernel out
+    const int64_t* key_off; const int64_t* qual_off;   // write kernel in (exclusive prefix sums of the lengths)
+    uint8_t* key_out; uint8_t* qual_out;
+    uint32_t* flags;
 };
 // one wavefront per record (grid-stride): strip() the sequence line, look it up in / add it to the table
 struct c2_fq_dedup_args {

@@ -92,9 +92,61 @@ __global__ __launch_bounds__(256) void c2_fq_lines_kernel(c2_fq_frame_args A)
             if (r < A.n_records_cap) {
                 if ((g & 3u) == 0u) A.seq_start[r] = p + 1;            // newline 4r ends the id line: the sequence line starts behind it
                 else if ((g & 3u) == 1u) A.seq_end[r] = p;             // newline 4r + 1 ends the sequence line
+                else if (A.qual_start) {                               // (paired input: the quality line too)
+                    if ((g & 3u) == 2u) A.qual_start[r] = p + 1;
+                    else A.qual_end[r] = p;
+                }
             }
             ++g;
         }
+    }
+}
+
+// ---- paired input: the reading loop of process_paired_fastq (CRISPRessoCORE.py:1309-1334) over two framed texts ----
+__device__ __forceinline__ unsigned long long c2_fq_strip(const uint8_t* text, uint64_t s, uint64_t e, bool& too_long) {
+    if (e < s) e = s;
+    while (s < e && c2_py_space(text[s])) ++s;
+    while (e > s && c2_py_space(text[e - 1])) --e;
+    if (e - s >= (1ull << 24) || s >= (1ull << 40)) { too_long = true; return 0ull; }
+    return ((unsigned long long)s << 24) | (unsigned long long)(e - s);
+}
+
+__global__ __launch_bounds__(256) void c2_fq_pair_lengths_kernel(c2_fq_pair_args A)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= A.n) return;
+    bool bad = false;
+    const unsigned long long s1 = c2_fq_strip(A.text1, A.seq_start1[r], A.seq_end1[r], bad), q1 = c2_fq_strip(A.text1, A.qual_start1[r], A.qual_end1[r], bad);
+    const unsigned long long s2 = c2_fq_strip(A.text2, A.seq_start2[r], A.seq_end2[r], bad), q2 = c2_fq_strip(A.text2, A.qual_start2[r], A.qual_end2[r], bad);
+    A.s1[r] = s1; A.q1[r] = q1; A.s2[r] = s2; A.q2[r] = q2;
+    A.key_len[r] = (int64_t)((s1 & 0xffffffull) + 1ull + (s2 & 0xffffffull));
+    A.qual_len[r] = (int64_t)((q1 & 0xffffffull) + 1ull + (q2 & 0xffffffull));
+    if (bad) atomicOr(A.flags, 1u);
+}
+
+__global__ __launch_bounds__(256) void c2_fq_pair_write_kernel(c2_fq_pair_args A)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4u + (uint64_t)(threadIdx.x >> 6); r < A.n; r += (uint64_t)gridDim.x * 4u) {
+        const unsigned long long s1 = A.s1[r], s2 = A.s2[r], q1 = A.q1[r], q2 = A.q2[r];
+        const uint64_t l1 = s1 & 0xffffffull, l2 = s2 & 0xffffffull, lq1 = q1 & 0xffffffull, lq2 = q2 & 0xffffffull;
+        uint8_t* const ko = A.key_out + A.key_off[r];
+        uint8_t* const qo = A.qual_out + A.qual_off[r];
+        const uint8_t* const p1 = A.text1 + (s1 >> 24);
+        const uint8_t* const p2 = A.text2 + (s2 >> 24);
+        for (uint64_t k = (uint64_t)lane; k < l1; k += 64) ko[k] = p1[k];
+        if (lane == 0) { ko[l1] = (uint8_t)'+'; qo[lq1] = (uint8_t)' '; }
+        bool bad = false;
+        for (uint64_t k = (uint64_t)lane; k < l2; k += 64) {
+            const unsigned c = c2_fq_complement(p2[l2 - 1 - k]);
+            bad = bad || c == 0u;
+            ko[l1 + 1 + k] = (uint8_t)c;
+        }
+        const uint8_t* const g1 = A.text1 + (q1 >> 24);
+        const uint8_t* const g2 = A.text2 + (q2 >> 24);
+        for (uint64_t k = (uint64_t)lane; k < lq1; k += 64) qo[k] = g1[k];
+        for (uint64_t k = (uint64_t)lane; k < lq2; k += 64) qo[lq1 + 1 + k] = g2[lq2 - 1 - k];
+        if (bad) atomicOr(A.flags, 2u);
     }
 }
 

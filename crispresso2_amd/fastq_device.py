@@ -16,6 +16,7 @@ kernel reads its range from there.  The result is exactly c2_fastq_stream's (sam
 line statistics) for text without carriage returns, without quality filters, uncompressed; anything else -- and any of the kernels'
 "I cannot" flags (a line of 16 MB, more records / keys than estimated) -- is DeviceIngestUnavailable, and the caller uses the host
 parser.  The product has no CPU fallback for COMPUTE; this module is an ingest route, and the host parser is the other one."""
+import ctypes
 import os
 
 import numpy as np
@@ -68,6 +69,26 @@ def fq_lines(ctx, d_text, lo, hi, d_tile_base, d_seq_start, d_seq_end, cap, stre
     ctx.check(ctx.lib.c2_fq_lines_device(ctx.handle, ctypes.c_void_p(d_text), ctypes.c_uint64(lo), ctypes.c_uint64(hi), ctypes.c_void_p(d_tile_base),
                                          ctypes.c_void_p(d_seq_start), ctypes.c_void_p(d_seq_end), ctypes.c_uint64(cap), ctypes.c_void_p(stream)),
               "c2_fq_lines_device")
+
+
+def fq_lines4(ctx, d_text, lo, hi, d_tile_base, d_seq_start, d_seq_end, d_qual_start, d_qual_end, cap, stream):
+    V = ctypes.c_void_p
+    ctx.check(ctx.lib.c2_fq_lines4_device(ctx.handle, V(d_text), ctypes.c_uint64(lo), ctypes.c_uint64(hi), V(d_tile_base), V(d_seq_start), V(d_seq_end),
+                                          V(d_qual_start), V(d_qual_end), ctypes.c_uint64(cap), V(stream or 0)), "c2_fq_lines4_device")
+
+
+def fq_pair_lengths(ctx, d_text1, d_text2, lines1, lines2, n, d_s1, d_q1, d_s2, d_q2, d_key_len, d_qual_len, d_flags, stream):
+    """lines1 / lines2: the four device addresses (seq_start, seq_end, qual_start, qual_end) of a text's line arrays"""
+    V = ctypes.c_void_p
+    L1, L2 = (V * 4)(*[V(x) for x in lines1]), (V * 4)(*[V(x) for x in lines2])
+    ctx.check(ctx.lib.c2_fq_pair_lengths_device(ctx.handle, V(d_text1), V(d_text2), L1, L2, ctypes.c_uint64(n), V(d_s1), V(d_q1), V(d_s2), V(d_q2),
+                                                V(d_key_len), V(d_qual_len), V(d_flags), V(stream or 0)), "c2_fq_pair_lengths_device")
+
+
+def fq_pair_write(ctx, d_text1, d_text2, n, d_s1, d_q1, d_s2, d_q2, d_key_off, d_qual_off, d_key_out, d_qual_out, d_flags, stream):
+    V = ctypes.c_void_p
+    ctx.check(ctx.lib.c2_fq_pair_write_device(ctx.handle, V(d_text1), V(d_text2), ctypes.c_uint64(n), V(d_s1), V(d_q1), V(d_s2), V(d_q2), V(d_key_off),
+                                              V(d_qual_off), V(d_key_out), V(d_qual_out), V(d_flags), V(stream or 0)), "c2_fq_pair_write_device")
 
 
 def fq_dedup(ctx, d_text, d_seq_start, d_seq_end, d_range, cap, d_slots, n_slots, d_count, d_first, d_slot_of, d_rinfo, d_flags, d_n_unique, stream):
@@ -844,3 +865,210 @@ def _upload(span, dev):
     torch.cuda.current_stream(dev).wait_stream(copy_stream)
     copy_stream.synchronize()
     return out
+
+
+# ---- paired input: two texts in HBM, record r of one with record r of the other (CRISPRessoCORE.py:1309-1334) ----
+class _Source:
+    """a FASTQ file as something _read_span can read: the path of a plain file, a BgzfFile, or (other gzip input) the text the host inflated;
+    a context manager that closes what it opened.  .source is None when the device route does not apply (the reason in .why_not)."""
+    def __init__(self, path):
+        self.source, self.why_not, self._held = None, None, []
+        why = applicable(path)
+        try:
+            if why is None:
+                self.source = os.fspath(path)
+            elif why.startswith("in memory:"):
+                bg = None
+                if why.startswith("in memory: compressed"):
+                    try:
+                        bg = _native.BgzfFile(path)
+                    except _native.NativeError:
+                        bg = None
+                if bg is not None:
+                    self._held.append(bg)
+                    why = size_applicable(bg.text_bytes)
+                    if why is None:
+                        self.source = bg
+                else:
+                    fq = _native.FastqStream(path, 0, 0, 0)
+                    self._held.append(fq)
+                    text = fq.text()
+                    why = text_applicable(text)
+                    if why is None:
+                        self.source = text
+        except (_native.NativeError, OSError) as e:
+            why = "%s: %s" % (type(e).__name__, e)
+        self.why_not = why
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        for h in self._held:
+            try:
+                h.close()
+            except Exception:
+                pass
+        self._held = []
+        return False
+
+
+def source_size(source):
+    return int(source.size) if isinstance(source, np.ndarray) else source.text_bytes if isinstance(source, _native.BgzfFile) else os.path.getsize(source)
+
+
+def upload_whole(source, dev):
+    """the whole text of a source -> (uint8 device tensor, its size): chunk by chunk through the pinned upload buffers, the host threads reading
+    (a plain file: pread() by all of them; BGZF: members inflated by the native threads) while the previous chunk crosses the link"""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    size = source_size(source)
+    out = torch.empty(max(size, 1), dtype=torch.uint8, device=dev)
+    if dev.type != "cuda":                                            # (tests: the "device" is host memory)
+        _read_span(source, 0, size, out.numpy())
+        return out, size
+    import threading
+    global _upload_lock
+    if _upload_lock is None:
+        _upload_lock = threading.Lock()
+    with _upload_lock:
+        chunk = chunk_bytes(size)
+        key = dev.index
+        if key not in _pinned or _pinned[key][0].numel() < chunk:
+            _pinned[key] = None
+            _pinned[key] = [torch.empty(chunk, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
+        pins = _pinned[key]
+        evs = [None] * len(pins)
+        copy_stream = torch.cuda.Stream(device=dev)
+        threads = copy_threads() if isinstance(source, str) else 1
+        try:
+            with ThreadPoolExecutor(threads) as pool:
+                for c, a in enumerate(range(0, size, chunk)):
+                    z = min(size, a + chunk)
+                    k = c % len(pins)
+                    if evs[k] is not None:
+                        evs[k].synchronize()
+                    view = pins[k].numpy()
+                    if threads > 1:
+                        step = (-(-(z - a) // threads) + 4095) // 4096 * 4096
+                        list(pool.map(lambda p0: _read_span(source, a + p0, min(z, a + p0 + step), view[p0:]), range(0, z - a, step)))
+                    else:
+                        _read_span(source, a, z, view)
+                    with torch.cuda.stream(copy_stream):
+                        out[a:z].copy_(pins[k][:z - a], non_blocking=True)
+                        evs[k] = torch.cuda.Event()
+                        evs[k].record(copy_stream)
+            torch.cuda.current_stream(dev).wait_stream(copy_stream)
+            copy_stream.synchronize()
+        finally:
+            if 3 * chunk > PINNED_CACHE_BYTES:
+                _pinned.pop(key, None)
+    return out, size
+
+
+class PairIngest:
+    """what ingest_pairs leaves in HBM: d_keys / d_quals = the key (seq1 + '+' + reverse_complement(seq2)) and quality pair (qual1 + ' ' + qual2[::-1])
+    of EVERY record, back to back (key_off / qual_off: int64 [n_records + 1]); l1 / lq1 [n_records]: the lengths in front of the '+' / the blank;
+    uniq_rec [n_unique]: the record in which every distinct key first occurs, in file order -- the order of the reference's variantCache;
+    rec_key [n_records]: the index of a record's key in that list; counts [n_unique] int64: copies of every key."""
+    pass
+
+
+def ingest_pairs(source1, source2, ctx, dev, timings=None):
+    """Two sources (see _Source) -> PairIngest.  Raises DeviceIngestUnavailable for what the kernels do not take or where the reference raises an
+    error the host route reproduces (carriage returns; a character of read 2 that reverse_complement() does not know; a '+' inside a read or a
+    blank inside a quality string, which the reference's key.split('+') / quals.split(' ') would trip over)."""
+    import time
+    import torch
+    t0 = time.perf_counter()
+    i64, i32, u8 = torch.int64, torch.int32, torch.uint8
+    s = torch.cuda.current_stream(dev).cuda_stream
+    flags = torch.zeros(1, dtype=i32, device=dev)
+    framed = []
+    for src in (source1, source2):
+        d_t, size = upload_whole(src, dev)
+        tiles = max(1, (size + TILE - 1) // TILE)
+        tile_nl = torch.zeros(tiles, dtype=i32, device=dev)
+        tile_em = torch.zeros(tiles, dtype=i32, device=dev)
+        if size:
+            fq_count(ctx, d_t.data_ptr(), 0, size, tile_nl.data_ptr(), tile_em.data_ptr(), flags.data_ptr(), s)
+        nl = tile_nl.to(i64)
+        upto = torch.cumsum(nl, 0)
+        base = (upto - nl).contiguous()
+        lines = int(upto[-1].item()) + (1 if size and int(d_t[size - 1].item()) != 0x0a else 0)
+        recs = (lines + 3) // 4                                       # readline(): every started group of four lines is a record
+        if recs >= (1 << 31) - 2:
+            raise DeviceIngestUnavailable("more than 2^31 records")
+        arrs = [torch.full((max(recs, 1),), size, dtype=i64, device=dev) for _ in range(4)]   # (a line that never ends: ends with the text; one that never starts: empty)
+        if size:
+            fq_lines4(ctx, d_t.data_ptr(), 0, size, base.data_ptr(), arrs[0].data_ptr(), arrs[1].data_ptr(), arrs[2].data_ptr(), arrs[3].data_ptr(), recs, s)
+        framed.append((d_t, size, recs, arrs))
+    if int(flags.item()) & 1:
+        raise DeviceIngestUnavailable("carriage returns in the text")
+    if timings is not None:
+        torch.cuda.synchronize(dev) if dev.type == "cuda" else None
+        timings["upload_and_frame"] = time.perf_counter() - t0
+    (t1, _, recs1, a1), (t2, _, recs2, a2) = framed
+    n = min(recs1, recs2)                                             # while (fastq1_id and fastq2_id), :1311
+    P = PairIngest()
+    P.n_records, P.different_lengths = n, recs1 != recs2
+    z64 = lambda m: torch.zeros(m, dtype=i64, device=dev)
+    s1, q1, s2, q2, klen, qlen = (z64(max(n, 1)) for _ in range(6))
+    pflags = torch.zeros(1, dtype=i32, device=dev)
+    if n:
+        fq_pair_lengths(ctx, t1.data_ptr(), t2.data_ptr(), [x.data_ptr() for x in a1], [x.data_ptr() for x in a2], n, s1.data_ptr(), q1.data_ptr(),
+                        s2.data_ptr(), q2.data_ptr(), klen.data_ptr(), qlen.data_ptr(), pflags.data_ptr(), s)
+    koff, qoff = z64(n + 1), z64(n + 1)
+    if n:
+        torch.cumsum(klen[:n], 0, out=koff[1:])
+        torch.cumsum(qlen[:n], 0, out=qoff[1:])
+    kb, qb = int(koff[-1].item()), int(qoff[-1].item())
+    if kb >= (1 << 40) or qb >= (1 << 40):
+        raise DeviceIngestUnavailable("more than 2^40 bytes of keys")
+    d_keys = torch.empty(max(kb, 1), dtype=u8, device=dev)
+    d_quals = torch.empty(max(qb, 1), dtype=u8, device=dev)
+    if n:
+        fq_pair_write(ctx, t1.data_ptr(), t2.data_ptr(), n, s1.data_ptr(), q1.data_ptr(), s2.data_ptr(), q2.data_ptr(), koff.data_ptr(), qoff.data_ptr(),
+                      d_keys.data_ptr(), d_quals.data_ptr(), pflags.data_ptr(), s)
+    pf = int(pflags.item())
+    del framed, t1, t2, a1, a2
+    if pf & 1:
+        raise DeviceIngestUnavailable("a line of 2^24 bytes or more")
+    if pf & 2:
+        raise DeviceIngestUnavailable("a character of read 2 outside ACGTN_-")
+    if n and (int((d_keys[:kb] == 43).sum().item()) != n or int((d_quals[:qb] == 32).sum().item()) != n):
+        raise DeviceIngestUnavailable("a '+' inside a read or a blank inside a quality string")
+    # ---- exact de-duplication of the keys: first-seen order, copies (variantCache of :1324-1329)
+    n_slots = 1 << 12
+    while n_slots < 2 * n:
+        n_slots <<= 1
+    if n_slots > (1 << 30):
+        raise DeviceIngestUnavailable("table of more than 2^30 slots")
+    slots = torch.zeros(n_slots, dtype=i64, device=dev)
+    count = torch.zeros(n_slots, dtype=i32, device=dev)
+    first = torch.full((n_slots,), -1, dtype=i32, device=dev)
+    slot_of = torch.zeros(n + 1, dtype=i32, device=dev)
+    rinfo = torch.zeros(n + 1, dtype=i64, device=dev)
+    dstat = torch.zeros(4, dtype=i32, device=dev)
+    dflag = torch.zeros(1, dtype=i32, device=dev)
+    rng = torch.tensor([0, n], dtype=i64, device=dev)
+    if n:
+        fq_dedup(ctx, d_keys.data_ptr(), koff[:-1].data_ptr(), koff[1:].data_ptr(), rng.data_ptr(), n, slots.data_ptr(), n_slots, count.data_ptr(),
+                 first.data_ptr(), slot_of.data_ptr(), rinfo.data_ptr(), dflag.data_ptr(), dstat.data_ptr(), s)
+        if int(dflag.item()):
+            raise DeviceIngestUnavailable("the de-duplication of the pair keys raised flags %d" % int(dflag.item()))
+    so = slot_of[:n].to(i64)
+    is_first = (first.to(i64) & 0xffffffff)[so] == torch.arange(n, dtype=i64, device=dev)
+    P.uniq_rec = torch.nonzero(is_first).reshape(-1)
+    P.n_unique = int(P.uniq_rec.numel())
+    key_of_slot = torch.zeros(n_slots, dtype=i64, device=dev)
+    key_of_slot[so[P.uniq_rec]] = torch.arange(P.n_unique, dtype=i64, device=dev)
+    P.rec_key = key_of_slot[so]
+    P.counts = (count.to(i64) & 0xffffffff)[so[P.uniq_rec]]
+    P.d_keys, P.d_quals, P.key_off, P.qual_off = d_keys, d_quals, koff, qoff
+    P.l1, P.lq1 = (s1[:n] & 0xffffff), (q1[:n] & 0xffffff)
+    P.key_bytes, P.qual_bytes = kb, qb
+    if timings is not None:
+        torch.cuda.synchronize(dev) if dev.type == "cuda" else None
+        timings["pair_keys_and_dedup"] = time.perf_counter() - t0 - timings["upload_and_frame"]
+    return P

@@ -7,13 +7,16 @@ classification of the consensus alignment; keys whose consensus had to choose a 
 again for every occurrence with its own qualities :1450-1513; pair keys are replaced by the consensus read :1439-1448) followed by the
 aggregation loop every run shares (:3964-4115).  paired.process_paired_fastq mirrors it dict by dict; here the same run is a few batches:
 
-    ingest + exact de-duplication of the pair keys      c2_fastq_unique_paired (native host code; arrays, no strings)
+    the two texts -> HBM, framed                        fastq_device.upload_whole, c2_fq_count / c2_fq_lines4 kernels (sequence AND quality line of every record)
+    pair keys and quality pairs of every record         c2_fq_pair_lengths / c2_fq_pair_write kernels (strip(), '+', reverse complement, reversed qualities)
+    exact de-duplication of the keys, first-seen order  c2_fq_dedup_kernel over the key arena
+        (input the kernels do not take -- carriage returns, small files, anything the reference raises an error for: c2_fastq_unique_paired on the host)
     seed test over both reads                           c2_strand_plan_kernel on the KEY (a seed cannot span the '+')
     alignments of read 1 and of read 2                  the align launch chain, all amplicons, + one batch for the both-strand pairs
     consensus of the two alignments                     c2_consensus_pairs_kernel on the rows that are in HBM
     records of the consensus alignments                 c2_classify_records_kernel (what the fused classifier writes for an alignment)
     best amplicon / ambiguity / aln_stats               c2_select_best_kernel
-    second pass for quality-dependent keys              the same batches over their occurrences (native second read of the files)
+    second pass for quality-dependent keys              the same batches over their occurrences: an index selection on the arenas in HBM
     pair key -> consensus read                          the consensus strings de-duplicated in first-seen order (c2_fq_dedup_kernel), copies added up
     reverse-complement merge, weights, count vectors    as pipeline.quantify_unique; the allele table through alleles.AlleleTable
 
@@ -22,12 +25,16 @@ the first-amplicon view of HDR / prime-editing runs, and a consensus whose shape
 strings of a column, an insertion column next to a deletion column).
 """
 import ctypes
+import os
 
 import numpy as np
 
 from . import _native
 from . import counts as C
 from .hostcopy import to_host, to_device
+
+
+FORCE_HOST_PARSER = os.environ.get("C2_PAIRED_HOST_PARSER", "") not in ("", "0")    # the pair keys from c2_fastq_unique_paired instead of the device
 
 
 class PairedDeviceUnavailable(Exception):
@@ -64,21 +71,20 @@ class _Units:
 
 
 def _dev_gather(ctx, dev, stream, d_text, starts, lens, row_stride=0):
-    """bytes d_text[starts[i] : starts[i] + lens[i]] (numpy int64 arrays) gathered ON THE DEVICE (c2_fq_gather_kernel): back to back -> (uint8 tensor,
+    """bytes d_text[starts[i] : starts[i] + lens[i]] (int64 device tensors) gathered ON THE DEVICE (c2_fq_gather_kernel): back to back -> (uint8 tensor,
     int64 offsets tensor [m + 1]); row_stride > 0: as zero-padded rows of that many bytes -> uint8 tensor [m, row_stride]"""
     import torch
     from . import fastq_device
-    m = len(starts)
-    lens = np.asarray(lens, dtype=np.int64)
-    info = to_device((np.asarray(starts, dtype=np.int64) << 24) | lens, dev)
+    m = int(starts.numel())
+    info = ((starts << 24) | lens).contiguous()
     if row_stride:
         out_off = torch.arange(m + 1, dtype=torch.int64, device=dev) * row_stride
         out = torch.zeros((max(m, 1), row_stride), dtype=torch.uint8, device=dev)
     else:
-        off = np.zeros(m + 1, dtype=np.int64)
-        np.cumsum(lens, out=off[1:])
-        out_off = to_device(off, dev)
-        out = torch.empty(max(int(off[-1]), 1), dtype=torch.uint8, device=dev)
+        out_off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+        if m:
+            torch.cumsum(lens, 0, out=out_off[1:])
+        out = torch.empty(max(int(out_off[-1].item()), 1), dtype=torch.uint8, device=dev)
     if m:
         fastq_device.fq_gather(ctx, d_text.data_ptr(), info.data_ptr(), None, out_off.data_ptr(), out.data_ptr(), m, stream)
     return (out[:m] if row_stride else out), out_off
@@ -86,21 +92,23 @@ def _dev_gather(ctx, dev, stream, d_text, starts, lens, row_stride=0):
 
 def _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, k_start, k_plus, k_end, d_qa, q_start, q_space, q_end):
     """One pass over m pairs: key bytes d_ka[k_start[i] : k_end[i]] (on the device) with the '+' at k_plus[i]; quality pair
-    d_qa[q_start[i] : q_end[i]] with the blank at q_space[i].  The index arrays are host arrays (8 bytes per pair each); the reads, keys and
-    quality rows are cut out of the two arenas on the device."""
+    d_qa[q_start[i] : q_end[i]] with the blank at q_space[i].  The index arrays are int64 tensors on the device (numpy arrays are uploaded); the
+    reads, keys and quality rows are cut out of the two arenas there."""
     import torch
     from . import fastq_device
-    m, k = len(k_start), len(ref_names)
+    as_dev = lambda x: x if isinstance(x, torch.Tensor) else to_device(np.ascontiguousarray(x, dtype=np.int64), dev)
+    k_start, k_plus, k_end, q_start, q_space, q_end = (as_dev(x) for x in (k_start, k_plus, k_end, q_start, q_space, q_end))
+    m, k = int(k_start.numel()), len(ref_names)
     U = _Units()
     U.m = m
     l1, l2 = k_plus - k_start, k_end - k_plus - 1
-    if m and (int(l1.min()) <= 0 or int(l2.min()) <= 0):
+    if m and (int(l1.min().item()) <= 0 or int(l2.min().item()) <= 0):
         raise Exception('global_align: undefined alignment (status %d)' % _native.STATUS_EMPTY)     # (an empty read: the reference indexes seq[-1])
     d_key, d_koff = _dev_gather(ctx, dev, stream, d_ka, k_start, k_end - k_start)
     d_r1, d_o1 = _dev_gather(ctx, dev, stream, d_ka, k_start, l1)
     d_r2, d_o2 = _dev_gather(ctx, dev, stream, d_ka, k_plus + 1, l2)
-    max_l = int(max(l1.max(), l2.max())) if m else 1
-    max_key = int((k_end - k_start).max()) if m else 1
+    max_l = int(torch.maximum(l1.max(), l2.max()).item()) if m else 1
+    max_key = int((k_end - k_start).max().item()) if m else 1
     # ---- seed test over both reads of the pair (:1024-1036): "seed in read 1 or seed in read 2" = "seed in key" (no seed holds a '+')
     d_plan = torch.empty(m * k, dtype=torch.uint8, device=dev)
     C.strand_plan_device(ctx, m, d_key.data_ptr(), d_koff.data_ptr(), max_key, refs, ref_names, args.aln_seed_count, args.aln_seed_min, d_plan.data_ptr(), stream=stream)
@@ -120,10 +128,10 @@ def _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, k_sta
     A2, F2, R2 = align(m, d_r2, d_o2, max_l, d_strands=d_str.data_ptr(), all_refs=True)
     # qualities: one row per read
     ql1, ql2 = q_space - q_start, q_end - q_space - 1
-    qstride = max(16, (int(max(ql1.max(), ql2.max())) + 15) // 16 * 16) if m else 16
+    qstride = max(16, (int(torch.maximum(ql1.max(), ql2.max()).item()) + 15) // 16 * 16) if m else 16
     d_q1, _ = _dev_gather(ctx, dev, stream, d_qa, q_start, ql1, row_stride=qstride)
     d_q2, _ = _dev_gather(ctx, dev, stream, d_qa, q_space + 1, ql2, row_stride=qstride)
-    d_lq1, d_lq2 = to_device(ql1.astype(np.int32), dev), to_device(ql2.astype(np.int32), dev)
+    d_lq1, d_lq2 = ql1.to(torch.int32).contiguous(), ql2.to(torch.int32).contiguous()
 
     def consensus(n_items, a1, f1, r1, a2, f2, r2, q1, q2, lq1, lq2, ref_ids, strands):
         """-> consensus strings (two tensors of ostride-byte rows), records, info"""
@@ -211,35 +219,73 @@ def quantify_paired_fastq(fastq1, fastq2, refs, ref_names, aln_matrix, args, ctx
     aligner = BatchAligner([refs[nm]['sequence'] for nm in ref_names], [refs[nm]['gap_incentive'] for nm in ref_names],
                            [refs[nm]['include_idxs'] for nm in ref_names], aln_matrix, args.needleman_wunsch_gap_open, args.needleman_wunsch_gap_extend, ctx=ctx)
     L = [len(refs[nm]['sequence']) for nm in ref_names]
-    pf = _native.PairedFastq(fastq1, fastq2)
-    try:
-        n = pf.n_unique
-        raw_all = pf.counts.astype(np.int64)
-        ka, ko, qa, qo = pf.arrays()
-        ko, qo = ko.astype(np.int64), qo.astype(np.int64)
-        plus, blank = np.flatnonzero(ka == 43), np.flatnonzero(qa == 32)
-        if len(plus) != n or len(blank) != n or (n and (((plus < ko[:-1]) | (plus >= ko[1:])).any() or ((blank < qo[:-1]) | (blank >= qo[1:])).any())):
-            raise ValueError("too many values to unpack (expected 2)")             # key.split('+') / quals.split(' ') of the reference (:1225-1226)
+    front = lambda *idx: _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, *idx)
+    P, why_host = None, None
+    if not FORCE_HOST_PARSER:
+        # the two texts uploaded as they lie in the files (BGZF: as they are inflated), framed, keyed and de-duplicated on the device: the second
+        # pass below is then an index selection on arenas that are already in HBM
+        with fastq_device._Source(fastq1) as S1, fastq_device._Source(fastq2) as S2:
+            if S1.source is None or S2.source is None:
+                why_host = S1.why_not or S2.why_not
+            else:
+                try:
+                    P = fastq_device.ingest_pairs(S1.source, S2.source, ctx, dev, timings=timings)
+                except fastq_device.DeviceIngestUnavailable as e:     # (carriage returns, or something the reference raises an error for: the host parser reproduces it)
+                    why_host = str(e)
+    else:
+        why_host = "C2_PAIRED_HOST_PARSER"
+    if P is not None:
+        n = P.n_unique
+        raw_all = to_host(P.counts).astype(np.int64)
         lap("paired_ingest")
-        d_ka = to_device(ka if ka.size else np.zeros(1, dtype=np.uint8), dev)
-        d_qa = to_device(qa if qa.size else np.zeros(1, dtype=np.uint8), dev)
-        first = _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, ko[:-1], plus, ko[1:], d_qa, qo[:-1], blank, qo[1:])
+        u = P.uniq_rec
+        k_start, q_start = P.key_off[u], P.qual_off[u]
+        k_plus, k_end, q_space, q_end = k_start + P.l1[u], P.key_off[u + 1], q_start + P.lq1[u], P.qual_off[u + 1]
+        first = front(P.d_keys, k_start, k_plus, k_end, P.d_quals, q_start, q_space, q_end)
         lap("first_pass")
-        # ---- keys seen more than once whose consensus chose a base by quality: every occurrence again, with its own qualities (:1450-1513)
-        again = (raw_all > 1) & ~to_host(first.caching_ok.to(torch.uint8)).astype(bool) if n else np.zeros(0, dtype=bool)
+        # ---- keys seen more than once whose consensus chose a base by quality: every occurrence again, with its own qualities (:1450-1513) --
+        # the records whose key is one of them, in file order
+        d_again = (P.counts > 1) & ~first.caching_ok if n else torch.zeros(0, dtype=torch.bool, device=dev)
+        again = to_host(d_again.to(torch.uint8)).astype(bool)
         second = None
         if again.any():
-            idx_occ, (qa2, qo2) = pf.occurrences(again, as_arrays=True)
-            idx_occ, qo2 = idx_occ.astype(np.int64), qo2.astype(np.int64)
-            blank2 = np.flatnonzero(qa2 == 32)
-            if len(blank2) != len(idx_occ):
-                raise ValueError("too many values to unpack (expected 2)")
-            d_qa2 = to_device(qa2 if qa2.size else np.zeros(1, dtype=np.uint8), dev)
-            second = _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, ko[:-1][idx_occ], plus[idx_occ], ko[1:][idx_occ], d_qa2, qo2[:-1], blank2, qo2[1:])
-            del d_qa2
+            occ = torch.nonzero(d_again[P.rec_key]).reshape(-1)
+            ko = P.rec_key[occ]
+            second = front(P.d_keys, k_start[ko], k_plus[ko], k_end[ko], P.d_quals, P.qual_off[occ], P.qual_off[occ] + P.lq1[occ], P.qual_off[occ + 1])
         lap("second_pass")
-    finally:
-        pf.close()
+        ingest_route = "paired, device"
+        P = None
+    else:
+        pf = _native.PairedFastq(fastq1, fastq2)
+        try:
+            n = pf.n_unique
+            raw_all = pf.counts.astype(np.int64)
+            ka, ko, qa, qo = pf.arrays()
+            ko, qo = ko.astype(np.int64), qo.astype(np.int64)
+            plus, blank = np.flatnonzero(ka == 43), np.flatnonzero(qa == 32)
+            if len(plus) != n or len(blank) != n or (n and (((plus < ko[:-1]) | (plus >= ko[1:])).any() or ((blank < qo[:-1]) | (blank >= qo[1:])).any())):
+                raise ValueError("too many values to unpack (expected 2)")             # key.split('+') / quals.split(' ') of the reference (:1225-1226)
+            lap("paired_ingest")
+            d_ka = to_device(ka if ka.size else np.zeros(1, dtype=np.uint8), dev)
+            d_qa = to_device(qa if qa.size else np.zeros(1, dtype=np.uint8), dev)
+            first = front(d_ka, ko[:-1], plus, ko[1:], d_qa, qo[:-1], blank, qo[1:])
+            lap("first_pass")
+            again = (raw_all > 1) & ~to_host(first.caching_ok.to(torch.uint8)).astype(bool) if n else np.zeros(0, dtype=bool)
+            second = None
+            if again.any():
+                idx_occ, (qa2, qo2) = pf.occurrences(again, as_arrays=True)
+                idx_occ, qo2 = idx_occ.astype(np.int64), qo2.astype(np.int64)
+                blank2 = np.flatnonzero(qa2 == 32)
+                if len(blank2) != len(idx_occ):
+                    raise ValueError("too many values to unpack (expected 2)")
+                d_qa2 = to_device(qa2 if qa2.size else np.zeros(1, dtype=np.uint8), dev)
+                second = front(d_ka, ko[:-1][idx_occ], plus[idx_occ], ko[1:][idx_occ], d_qa2, qo2[:-1], blank2, qo2[1:])
+                del d_qa2
+            lap("second_pass")
+            del d_ka, d_qa
+        finally:
+            pf.close()
+        ingest_route = "paired, keys from the host parser (%s)" % why_host
     # ---- the run's entries: the kept keys in key order, then the occurrences in file order (the order of the reference's cache)
     kept = np.flatnonzero(~again)
     d_kept = to_device(kept, dev)
@@ -277,7 +323,7 @@ def quantify_paired_fastq(fastq1, fastq2, refs, ref_names, aln_matrix, args, ctx
         per_ref = {nm: layout.unpack(host, r, L[r]) for r, nm in enumerate(ref_names)}
         res = QuantResult(per_ref, stats, layout, d_counts, state)
         res.stats['N_READS_INPUT'] = res.stats['N_READS_AFTER_PREPROCESSING'] = n_pairs
-        res.ingest_route = "paired, device"
+        res.ingest_route = ingest_route
         return res
     n_pairs = int(raw_all.sum())
     if N == 0:

@@ -513,6 +513,27 @@ int c2_fq_gather_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_in
                         uint8_t* d_out, uint64_t n, void* hip_stream);
 int c2_fq_rc_partner_device(c2_ctx* ctx, const uint8_t* d_text, const uint64_t* d_info, const int64_t* d_records, uint64_t n,
                             const uint64_t* d_slots, uint64_t n_slots, int32_t* d_partner_slot, void* hip_stream);
+/* Paired input on the device: the reading loop of process_paired_fastq (CRISPRessoCORE.py:1309-1334 -- record r of R1 with record r of R2, key =
+ * seq1 + '+' + reverse_complement(seq2), qualities qual1 + ' ' + qual2[::-1], all four lines str.strip()ped) over two texts in HBM.
+ *   c2_fq_lines4_device        c2_fq_lines_device that also records the quality line: qual_start[r] behind newline 4r + 2, qual_end[r] = newline 4r + 3.
+ *                              (A line the text ends in without a newline, or that is not there at all, keeps what the caller put into the arrays:
+ *                              the text's length makes it end there / empty, as readline() at the end of a file.)
+ *   c2_fq_pair_lengths_device  d_lines1 / d_lines2: HOST arrays of the four device pointers {seq_start, seq_end, qual_start, qual_end} of a text; per
+ *                              record r < n the stripped lines -> s1 / q1 / s2 / q2 [r] = start << 24 | length, key_len[r] = len(seq1) + 1 + len(seq2),
+ *                              qual_len[r] likewise.  flags |= 1: a line of 2^24 bytes or more, or a text of 2^40.
+ *   c2_fq_pair_write_device    key_out[key_off[r] ..) = the key, qual_out[qual_off[r] ..) = the quality pair (offsets: the caller's exclusive prefix sums
+ *                              of the lengths).  flags |= 2: a character of seq2 outside ACGTN_- in either case (CRISPRessoShared.py:399-403's KeyError).
+ * The keys are then de-duplicated with c2_fq_dedup_device over the key arena (first-seen order, multiplicities); the second pass of the reference's
+ * route (every occurrence of a key whose consensus depended on its qualities, :1452-1513) is an index selection on what is already in HBM --
+ * crispresso2_amd/paired_device.py. */
+int c2_fq_lines4_device(c2_ctx* ctx, const uint8_t* d_text, uint64_t lo, uint64_t hi, const uint64_t* d_tile_base, uint64_t* d_seq_start,
+                        uint64_t* d_seq_end, uint64_t* d_qual_start, uint64_t* d_qual_end, uint64_t n_records_cap, void* hip_stream);
+int c2_fq_pair_lengths_device(c2_ctx* ctx, const uint8_t* d_text1, const uint8_t* d_text2, const uint64_t* const* d_lines1, const uint64_t* const* d_lines2,
+                              uint64_t n, uint64_t* d_s1, uint64_t* d_q1, uint64_t* d_s2, uint64_t* d_q2, int64_t* d_key_len, int64_t* d_qual_len,
+                              uint32_t* d_flags, void* hip_stream);
+int c2_fq_pair_write_device(c2_ctx* ctx, const uint8_t* d_text1, const uint8_t* d_text2, uint64_t n, const uint64_t* d_s1, const uint64_t* d_q1,
+                            const uint64_t* d_s2, const uint64_t* d_q2, const int64_t* d_key_off, const int64_t* d_qual_off, uint8_t* d_key_out,
+                            uint8_t* d_qual_out, uint32_t* d_flags, void* hip_stream);
 
 /* Hardware self-test of the cross-lane primitives (DPP wave_shr:1 / wave_shl:1 with and without bound_ctrl, also with a
  * lane switched off in EXEC, readlane, ballot) the DP depends on; writes 448 int32 (see c2_selftest_kernel).  Used by the

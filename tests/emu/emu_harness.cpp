@@ -374,6 +374,41 @@ int emu_fq_lines(const uint8_t* text, uint64_t lo, uint64_t hi, const uint64_t* 
     emu::launch((unsigned)((hi - lo + C2_FQ_TILE - 1) / C2_FQ_TILE), [&] { c2_fq_lines_kernel(A); }, 256);
     return 0;
 }
+int emu_fq_lines4(const uint8_t* text, uint64_t lo, uint64_t hi, const uint64_t* tile_base, uint64_t* seq_start, uint64_t* seq_end, uint64_t* qual_start,
+                  uint64_t* qual_end, uint64_t cap)
+{
+    if (hi <= lo) return 0;
+    c2_fq_frame_args A{};
+    A.text = text; A.lo = lo; A.hi = hi; A.tile_base = tile_base; A.seq_start = seq_start; A.seq_end = seq_end; A.n_records_cap = cap;
+    A.qual_start = qual_start; A.qual_end = qual_end;
+    emu::launch((unsigned)((hi - lo + C2_FQ_TILE - 1) / C2_FQ_TILE), [&] { c2_fq_lines_kernel(A); }, 256);
+    return 0;
+}
+// c2_fq_pair_lengths_device / c2_fq_pair_write_device
+int emu_fq_pair_lengths(const uint8_t* text1, const uint8_t* text2, const uint64_t* const* lines1, const uint64_t* const* lines2, uint64_t n, uint64_t* s1,
+                        uint64_t* q1, uint64_t* s2, uint64_t* q2, int64_t* key_len, int64_t* qual_len, uint32_t* flags)
+{
+    if (!n) return 0;
+    c2_fq_pair_args A{};
+    A.text1 = text1; A.text2 = text2;
+    A.seq_start1 = lines1[0]; A.seq_end1 = lines1[1]; A.qual_start1 = lines1[2]; A.qual_end1 = lines1[3];
+    A.seq_start2 = lines2[0]; A.seq_end2 = lines2[1]; A.qual_start2 = lines2[2]; A.qual_end2 = lines2[3];
+    A.n = n; A.s1 = (unsigned long long*)s1; A.q1 = (unsigned long long*)q1; A.s2 = (unsigned long long*)s2; A.q2 = (unsigned long long*)q2;
+    A.key_len = key_len; A.qual_len = qual_len; A.flags = flags;
+    emu::launch((unsigned)((n + 255) / 256), [&] { c2_fq_pair_lengths_kernel(A); }, 256);
+    return 0;
+}
+int emu_fq_pair_write(const uint8_t* text1, const uint8_t* text2, uint64_t n, const uint64_t* s1, const uint64_t* q1, const uint64_t* s2, const uint64_t* q2,
+                      const int64_t* key_off, const int64_t* qual_off, uint8_t* key_out, uint8_t* qual_out, uint32_t* flags)
+{
+    if (!n) return 0;
+    c2_fq_pair_args A{};
+    A.text1 = text1; A.text2 = text2; A.n = n;
+    A.s1 = (unsigned long long*)s1; A.q1 = (unsigned long long*)q1; A.s2 = (unsigned long long*)s2; A.q2 = (unsigned long long*)q2;
+    A.key_off = key_off; A.qual_off = qual_off; A.key_out = key_out; A.qual_out = qual_out; A.flags = flags;
+    emu::launch(3, [&] { c2_fq_pair_write_kernel(A); }, 256);
+    return 0;
+}
 int emu_fq_dedup(const uint8_t* text, const uint64_t* seq_start, const uint64_t* seq_end, const uint64_t* range, uint64_t cap, uint64_t* slots,
                  uint64_t n_slots, uint32_t* count, uint32_t* first, uint32_t* slot_of, uint64_t* rinfo, uint32_t* flags, uint32_t* stats)
 {

@@ -39,7 +39,19 @@ def emulated_fq_kernels(chunk=FD.TILE):
         assert lib.emu_fq_gather(V(d_text), V(info), V(records or 0), V(out_off), V(out), U(n)) == 0
     def rc_partner(ctx, d_text, info, records, n, slots, n_slots, pslot, stream):
         assert lib.emu_fq_rc_partner(V(d_text), V(info), V(records), U(n), V(slots), U(n_slots), V(pslot)) == 0
+
+    def lines4(ctx, d_text, lo, hi, base, s, e, qs, qe, cap, stream):
+        assert lib.emu_fq_lines4(V(d_text), U(lo), U(hi), V(base), V(s), V(e), V(qs), V(qe), U(cap)) == 0
+
+    def pair_lengths(ctx, t1, t2, lines1, lines2, n, s1, q1, s2, q2, klen, qlen, flags, stream):
+        L1, L2 = (V * 4)(*[V(x) for x in lines1]), (V * 4)(*[V(x) for x in lines2])
+        assert lib.emu_fq_pair_lengths(V(t1), V(t2), L1, L2, U(n), V(s1), V(q1), V(s2), V(q2), V(klen), V(qlen), V(flags)) == 0
+
+    def pair_write(ctx, t1, t2, n, s1, q1, s2, q2, koff, qoff, kout, qout, flags, stream):
+        assert lib.emu_fq_pair_write(V(t1), V(t2), U(n), V(s1), V(q1), V(s2), V(q2), V(koff), V(qoff), V(kout), V(qout), V(flags)) == 0
     saved = (FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES, torch.cuda.current_stream, FD.fq_rc_partner)
+    saved_pair = (FD.fq_lines4, FD.fq_pair_lengths, FD.fq_pair_write)
+    FD.fq_lines4, FD.fq_pair_lengths, FD.fq_pair_write = lines4, pair_lengths, pair_write
     FD.fq_rc_partner = rc_partner
 
     class _S:
@@ -50,6 +62,7 @@ def emulated_fq_kernels(chunk=FD.TILE):
         yield
     finally:
         FD.fq_count, FD.fq_lines, FD.fq_dedup, FD.fq_gather, FD.CHUNK_BYTES, torch.cuda.current_stream, FD.fq_rc_partner = saved
+        FD.fq_lines4, FD.fq_pair_lengths, FD.fq_pair_write = saved_pair
 
 
 def device_unique(path, chunk=FD.TILE):
@@ -205,3 +218,89 @@ def test_fuzzed_text_without_any_structure(tmp_path, seed):
     n_empty = want.pop("", 0)
     assert reads == list(want.keys()) and counts == list(want.values())
     assert out["n_reads"] == n_reads and out["n_empty_records"] == n_empty
+
+
+# ---- paired input: fastq_device.ingest_pairs (c2_fq_lines4 / pair_lengths / pair_write / dedup kernels) vs the reference's lock-step loop ----
+def device_pairs(p1, p2):
+    """-> (keys, counts, first qualities, {key: [quality pairs of all its occurrences, in file order]}, n_records) from what the kernels left"""
+    with emulated_fq_kernels(), FD._Source(str(p1)) as S1, FD._Source(str(p2)) as S2:
+        assert S1.source is not None and S2.source is not None, (S1.why_not, S2.why_not)
+        P = FD.ingest_pairs(S1.source, S2.source, None, torch.device("cpu"))
+    ka, qa, ko, qo = P.d_keys.numpy(), P.d_quals.numpy(), P.key_off.numpy(), P.qual_off.numpy()
+    key = lambda r: ka[int(ko[r]):int(ko[r + 1])].tobytes().decode("latin-1")
+    qual = lambda r: qa[int(qo[r]):int(qo[r + 1])].tobytes().decode("latin-1")
+    u = P.uniq_rec.numpy()
+    keys = [key(int(r)) for r in u]
+    for r in range(P.n_records):                                     # the '+' / the blank where l1 / lq1 say, every record's key index
+        assert key(r)[int(P.l1[r])] == '+' and qual(r)[int(P.lq1[r])] == ' '
+        assert keys[int(P.rec_key[r])] == key(r)
+    occ = {}
+    for r in range(P.n_records):
+        occ.setdefault(key(r), []).append(qual(r))
+    return keys, P.counts.tolist(), [qual(int(r)) for r in u], occ, P.n_records
+
+
+def check_pairs_on_device(p1, p2):
+    exp, n = O.read_paired_fastq_unique(str(p1), str(p2))
+    keys, counts, quals, occ, n_rec = device_pairs(p1, p2)
+    assert n_rec == n
+    assert keys == list(exp.keys())
+    assert counts == [v[0] for v in exp.values()]
+    assert quals == [v[1] for v in exp.values()]
+    wanted = {k for k, v in exp.items() if v[0] > 1}
+    again = {}
+    for k, q1, q2 in O.paired_occurrences(str(p1), str(p2), wanted):
+        again.setdefault(k, []).append(q1 + ' ' + q2)
+    assert {k: v for k, v in occ.items() if k in wanted} == again
+    return n
+
+
+def test_pairs_framed_keyed_and_deduplicated_on_the_device(tmp_path, monkeypatch):
+    from test_fastq_ingest import random_pairs, paired_records
+    monkeypatch.setenv("C2_FQ_INGEST", "device")                     # (files below MIN_TEXT_BYTES go to the host parser otherwise)
+    rng = np.random.default_rng(31)
+    pairs = random_pairs(1500, rng, pool=40)
+    t1, t2 = paired_records(pairs)
+    p1, p2 = tmp_path / "a_1.fastq", tmp_path / "a_2.fastq"
+    p1.write_text(t1)
+    p2.write_text(t2)
+    assert check_pairs_on_device(p1, p2) == 1500
+    # gzip'ed (one member: the host inflates, the device frames) and BGZF input, mixed with plain
+    import gzip
+    g1 = tmp_path / "a_1.fastq.gz"
+    with gzip.open(g1, "wt") as fh:
+        fh.write(t1)
+    assert check_pairs_on_device(g1, p2) == 1500
+    # file 2 shorter; cut in the middle of a record without a terminator; whitespace around the lines, blank id lines; an empty file
+    lines2 = t2.splitlines(keepends=True)
+    p2.write_text("".join(lines2[:4 * 150]))
+    assert check_pairs_on_device(p1, p2) == 150
+    p2.write_text("".join(lines2[:4 * 150 + 2]).rstrip("\n"))
+    assert check_pairs_on_device(p1, p2) == 151
+    p2.write_text("".join(lines2[:4 * 150 + 1]))                      # the last record of file 2 is an id line only
+    assert check_pairs_on_device(p1, p2) == 151
+    p1.write_text("@a\n  ACGT \t\n+\n IIII \n\n\x0bGGCC\x0c\n+\nJJJJ\n")
+    p2.write_text("@a\n\tTTGA\n+\nABCD  \n\ncctt \n+\n EFGH\n")
+    assert check_pairs_on_device(p1, p2) == 2
+    keys, counts, quals, _, _ = device_pairs(p1, p2)
+    assert keys == ["ACGT+TCAA", "GGCC+AAGG"] and quals == ["IIII DCBA", "JJJJ HGFE"]
+    p1.write_text("")                                                 # an empty file is the host parser's
+    with FD._Source(str(p1)) as S1:
+        assert S1.source is None and "0 bytes" in S1.why_not
+
+
+def test_pairs_the_device_does_not_take_go_to_the_host_parser(tmp_path, monkeypatch):
+    monkeypatch.setenv("C2_FQ_INGEST", "device")
+    p1, p2 = tmp_path / "k_1.fastq", tmp_path / "k_2.fastq"
+    p1.write_text("@a\nACGT\n+\nIIII\n")
+    for bad2, why in (("@a\nACRT\n+\nIIII\n", "outside ACGTN_-"), ("@a\nAC+T\n+\nIIII\n", "outside ACGTN_-"), ("@a\nACGT\n+\nII I\n", "blank inside"),
+                      ("@a\r\nACGT\r\n+\r\nIIII\r\n", "carriage returns")):
+        p2.write_text(bad2)
+        with emulated_fq_kernels(), FD._Source(str(p1)) as S1, FD._Source(str(p2)) as S2:
+            with pytest.raises(FD.DeviceIngestUnavailable, match=why):
+                FD.ingest_pairs(S1.source, S2.source, None, torch.device("cpu"))
+    p2.write_text("@a\nACGT\n+\nIIII\n")
+    p1.write_text("@a\nAC+T\n+\nIIII\n")
+    with emulated_fq_kernels(), FD._Source(str(p1)) as S1, FD._Source(str(p2)) as S2:
+        with pytest.raises(FD.DeviceIngestUnavailable, match="'\\+' inside a read"):
+            FD.ingest_pairs(S1.source, S2.source, None, torch.device("cpu"))

@@ -90,7 +90,7 @@ def run_cases(tmp_path):
         got_rows = [(a, r, nm, st, dn, inn, sn, c) for a, r, nm, st, dn, inn, sn, c, pct in res.alleles()]
         assert got_rows == rows, case["label"]
         assert "second_pass" in tm and len(case["second_pass"]) > 0
-    return True
+    return res.ingest_route
 
 
 def test_paired_files_to_count_tensors_on_the_emulator(tmp_path, monkeypatch):
@@ -99,9 +99,13 @@ def test_paired_files_to_count_tensors_on_the_emulator(tmp_path, monkeypatch):
     from pipeline_on_emulator import emulated_device
     from test_fastq_device_emulated import emulated_fq_kernels
     with emulated_device(), emulated_fq_kernels():
-        assert run_cases(tmp_path)
+        assert run_cases(tmp_path) == "paired, keys from the host parser (small file)"
+        monkeypatch.setenv("C2_FQ_INGEST", "device")                 # the two texts framed, keyed and de-duplicated by the kernels
+        assert run_cases(tmp_path) == "paired, device"
 
 
 @pytest.mark.gpu
-def test_paired_files_to_count_tensors_on_the_device(tmp_path):
-    assert run_cases(tmp_path)
+def test_paired_files_to_count_tensors_on_the_device(tmp_path, monkeypatch):
+    assert run_cases(tmp_path).startswith("paired, keys from the host parser")
+    monkeypatch.setenv("C2_FQ_INGEST", "device")
+    assert run_cases(tmp_path) == "paired, device"

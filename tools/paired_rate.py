@@ -52,14 +52,15 @@ ref = R.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
 mat = A.read_matrix(os.path.join(ROOT, "crispresso2_amd", "EDNAFULL"))
 ctx = _native.default_context()
 try:
-    for rep in range(3):
-        tm = {} if rep == 2 else None
+    for rep in range(5):
+        tm = {} if rep >= 2 else None
+        paired_device.FORCE_HOST_PARSER = rep >= 3                     # (the last two runs: the pair keys from the host's lock-step parser)
         t0 = time.perf_counter()
         res = paired_device.quantify_paired_fastq(p1, p2, {"Reference": ref}, ["Reference"], mat, args, ctx=ctx, timings=tm)
         dt = time.perf_counter() - t0
         c = res.per_ref["Reference"]
         print(json.dumps({"pairs": n, "seconds": round(dt, 4), "pairs_per_s": round(n / dt), "N_TOTAL": res.stats["N_TOTAL"], "unique_pairs_aligned": res.stats["N_COMPUTED_ALN"],
-                          "modified": c["counts_modified"], "stages": None if tm is None else {k: round(v, 4) for k, v in tm.items()}}), flush=True)
+                          "modified": c["counts_modified"], "route": res.ingest_route, "stages": None if tm is None else {k: round(v, 4) for k, v in tm.items()}}), flush=True)
         del res
 except paired_device.PairedDeviceUnavailable as e:
     print(json.dumps({"unavailable": str(e)}))
