@@ -440,20 +440,21 @@ def _stream_front(fq, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
 
 def quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx=None, device=0, reduce_across_ranks=False,
                     timings=None, pe_scaffold_dna_info=None, shard=None, fastq_stream=None, device_reads=None):
-    """See _quantify_unique.  (This wrapper only makes sure that the host thread the run starts -- it reads `arena`, which may be a
-    view of native memory the caller frees -- has ended before control returns, also when the run raises.)"""
-    threads = []
+    """Unique reads -> QuantResult; see _UniqueRun for the arguments and for the stages.  (This wrapper also makes sure that the host thread the
+    run starts -- it reads `arena`, which may be a view of native memory the caller frees -- has ended before control returns, also when the
+    run raises.)"""
+    run = _UniqueRun(refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks, timings, pe_scaffold_dna_info)
     try:
-        return _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
-                                timings, pe_scaffold_dna_info, threads, shard, fastq_stream, device_reads)
+        return run.run(arena, offsets, read_counts, shard, fastq_stream, device_reads)
     finally:
-        for t in threads:
+        for t in run.threads:
             t.join()
 
 
-def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks,
-                     timings, pe_scaffold_dna_info, _threads, shard=None, fastq_stream=None, device_reads=None):
-    """arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
+class _UniqueRun:
+    """One run of the count route over a list of unique reads, as named stages over explicit state (the attributes below).
+
+    arena / offsets / read_counts: the unique reads (c2_fastq_unique layout) and their multiplicities.
     shard: None -- this process aligns every read it was given.  "mine" (with device_reads): this rank's contiguous range
     (distributed.my_shard) of the unique reads the device ingest finds.  Otherwise arena / offsets / read_counts are the WHOLE run's unique
     reads (every rank holds the same list, as every worker of the reference sees the parent's variantCache keys) and `shard` names
@@ -472,307 +473,387 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
     pe_scaffold_dna_info: (index, dna) of get_pe_scaffold_search for runs with --prime_editing_pegRNA_scaffold_seq: reads whose
     alignment against 'Prime-edited' carries `dna` right after reference base index-1 are counted for 'Scaffold-incorporated'
     (a copy of the Prime-edited amplicon that nothing is aligned to, CRISPRessoCORE.py:786-796, :3759-3764) -- the result then
-    has that extra amplicon."""
-    import time
-    import torch
-    t_last = [time.perf_counter()]
+    has that extra amplicon.
 
-    def lap(name):
-        if timings is not None:
+    Stages, in the order run() calls them:
+        take_input            the reads (host arena / parsed stream / device ingest) and, for a sharded run, this rank's part of them
+        prepare               tensor layout agreed across ranks, count tensor, statistics; an empty shard ends here (empty_shard)
+        reads_to_device       the arena uploaded (unless a front already did)
+        start_partner_search  which read is the reverse complement of which: on the device, or on a host thread under the alignments
+        align_all_references  seed test + batch 1 (every read x every amplicon on the strand the seeds ask for)
+        align_both_strands    batch 2 (the pairs whose seeds were inconclusive, reverse complement)
+        select                best amplicon, strand, ambiguity, aln_stats: c2_select_best_kernel (or the host's comparisons)
+        finish_on_device      the usual run's tail without the host: count transfer over partner pairs, weights, count launches
+        merge_on_host         otherwise: the reference's sequential count transfer (over the WHOLE list when sharded), ambiguity rules
+        scaffold_hits         the prime-editing scaffold rule
+        count                 weights + count launches (+ the 'Scaffold-incorporated' tensor)
+        first_amplicon_view   every amplicon's reads in the first amplicon's coordinates (HDR / prime-editing runs)
+        reduce                all-reduce of the tensors and statistics
+        result                -> QuantResult with the device state the allele table is built from
+    """
+
+    def __init__(self, refs, ref_names, aln_matrix, args, ctx, device, reduce_across_ranks, timings, pe_scaffold_dna_info):
+        import time
+        import torch
+        self.refs, self.ref_names, self.args, self.timings = refs, list(ref_names), args, timings
+        self.reduce_across_ranks, self.pe_scaffold_dna_info = reduce_across_ranks, pe_scaffold_dna_info
+        self.threads = []
+        self._t_last = time.perf_counter()
+        self.legacy = bool(getattr(args, 'use_legacy_insertion_quantification', False))
+        if self.legacy:
+            # find_indels_substitutions_legacy (COREResources.pyx:190-315) on the count route: the fused classifier and the count kernel
+            # follow its rules (an insertion counts when EITHER flank is in the window; its reference coordinates of a deletion that starts
+            # in column 0 / 1 or reaches the end).  Its `nucSet` treats any other reference character as a gap, which the kernels do not.
+            for name in ref_names:
+                if set(refs[name]['sequence']) - set('ACGTN'):
+                    raise NotImplementedError("use_legacy_insertion_quantification with a reference character outside ACGTN: "
+                                              "use variants.process_fastq (per-read route) for this run")
+        self.scaffold_rule = bool(getattr(args, 'prime_editing_pegRNA_scaffold_seq', '')) and 'Prime-edited' in ref_names
+        if self.scaffold_rule and (pe_scaffold_dna_info is None or pe_scaffold_dna_info[1] is None):
+            raise ValueError("prime_editing_pegRNA_scaffold_seq needs pe_scaffold_dna_info = (index, dna) of get_pe_scaffold_search")
+        self.pe = ref_names.index('Prime-edited') if self.scaffold_rule else -1
+        self.ctx = ctx or _native.default_context()
+        self.dev = torch.device("cuda", device)
+        self.aligner = BatchAligner([refs[name]['sequence'] for name in ref_names], [refs[name]['gap_incentive'] for name in ref_names],
+                                    [refs[name]['include_idxs'] for name in ref_names], aln_matrix,
+                                    args.needleman_wunsch_gap_open, args.needleman_wunsch_gap_extend, ctx=self.ctx)
+        self.k = len(ref_names)
+        self.L = [len(refs[name]['sequence']) for name in ref_names]
+        self.want_view = self.k > 1 and bool(getattr(args, 'expected_hdr_amplicon_seq', '') or getattr(args, 'prime_editing_pegRNA_extension_seq', ''))
+        self.flags = ((C.FLAG_IGNORE_SUBSTITUTIONS if args.ignore_substitutions else 0) | (C.FLAG_IGNORE_INSERTIONS if args.ignore_insertions else 0) |
+                      (C.FLAG_IGNORE_DELETIONS if args.ignore_deletions else 0) | (C.FLAG_DISCARD_INDEL_READS if getattr(args, 'discard_indel_reads', False) else 0) |
+                      (C.FLAG_LEGACY_CLASSIFIER if self.legacy else 0))
+        self.front = None                                              # what _stream_front / _device_front already did (seed test, batch 1)
+        self.d_view = self.d_scaffold = None
+        self.scaffold_hit = None
+
+    # ---- helpers ----
+    def lap(self, name):
+        import time
+        import torch
+        if self.timings is not None:
             torch.cuda.synchronize()
             now = time.perf_counter()
-            timings[name] = timings.get(name, 0.0) + now - t_last[0]
-            t_last[0] = now
-    legacy = bool(getattr(args, 'use_legacy_insertion_quantification', False))
-    if legacy:
-        # find_indels_substitutions_legacy (COREResources.pyx:190-315) on the count route: the fused classifier and the count kernel
-        # follow its rules (an insertion counts when EITHER flank is in the window; its reference coordinates of a deletion that starts
-        # in column 0 / 1 or reaches the end).  Its `nucSet` treats any other reference character as a gap, which the kernels do not.
-        for name in ref_names:
-            if set(refs[name]['sequence']) - set('ACGTN'):
-                raise NotImplementedError("use_legacy_insertion_quantification with a reference character outside ACGTN: "
-                                          "use variants.process_fastq (per-read route) for this run")
-    scaffold_rule = bool(getattr(args, 'prime_editing_pegRNA_scaffold_seq', '')) and 'Prime-edited' in ref_names
-    if scaffold_rule and (pe_scaffold_dna_info is None or pe_scaffold_dna_info[1] is None):
-        raise ValueError("prime_editing_pegRNA_scaffold_seq needs pe_scaffold_dna_info = (index, dna) of get_pe_scaffold_search")
-    ctx = ctx or _native.default_context()
-    dev = torch.device("cuda", device)
-    aligner = BatchAligner([refs[name]['sequence'] for name in ref_names], [refs[name]['gap_incentive'] for name in ref_names],
-                           [refs[name]['include_idxs'] for name in ref_names], aln_matrix,
-                           args.needleman_wunsch_gap_open, args.needleman_wunsch_gap_extend, ctx=ctx)
-    front = None
-    if fastq_stream is not None:
-        if shard is not None:
-            raise ValueError("a sharded run cuts the list of ALL unique reads: it cannot start before the file is parsed")
-        front = _stream_front(fastq_stream, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
-        arena, offsets, read_counts = front["arena"], front["offsets"], front["counts"]
-        t_last[0] = time.perf_counter()
-    shard_of_all = isinstance(shard, str) and shard == "mine"          # (the rank's range of a list whose length is not known yet)
-    if isinstance(shard, str) and not (shard_of_all and device_reads is not None):
-        raise ValueError('shard is None, (lo, hi), an index array, or "mine" together with device_reads')
-    if device_reads is not None:
-        if fastq_stream is not None or (shard is not None and not shard_of_all and not isinstance(shard, tuple)):
-            raise ValueError("device_reads takes no fastq_stream and only contiguous shards")
-        if isinstance(device_reads, (str, os.PathLike, np.ndarray, _native.BgzfFile)):
-            source = device_reads if isinstance(device_reads, (np.ndarray, _native.BgzfFile)) else os.fspath(device_reads)
-            if shard is None:
-                # a FASTQ file, or FASTQ text in host memory: framed, de-duplicated AND aligned (batch 1) chunk by chunk under its upload (_device_front)
-                front = _device_front(source, aligner, ctx, dev, refs, ref_names, args, legacy, timings)
-                device_reads = front["device_reads"]
-            else:
-                # sharded: every rank frames and de-duplicates the whole text on ITS device (the parent's variantCache of the reference,
-                # which all workers see) and aligns its range of the unique reads
-                from . import fastq_device
-                device_reads = fastq_device.ingest_file(source, ctx, dev, timings=timings)
-            t_last[0] = time.perf_counter()
-        arena, offsets, read_counts = None, device_reads["offsets"], device_reads["counts"]
-    if shard_of_all:                                                  # (this rank's contiguous range of however many unique reads there are)
-        import torch.distributed as dist
-        from . import distributed as D
-        shard = D.my_shard(len(read_counts), dist.get_rank(), dist.get_world_size())
-    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-    # the whole run's unique reads (what the reverse-complement partner search looks at) and the part this process aligns
-    g_arena, g_offsets, g_raw = arena, offsets, np.asarray(read_counts, dtype=np.int64)
-    n_global = len(g_raw)
-    shard_idx = None
-    if shard is not None:
-        reduce_across_ranks = True
-        if isinstance(shard, tuple):
-            lo, hi = int(shard[0]), int(shard[1])
-            shard_idx = slice(lo, hi)
-            if device_reads is not None:                              # (the reads are on the device: the shard is a view of them)
-                device_reads = dict(device_reads, d_reads=device_reads["d_reads"][int(offsets[lo]):max(int(offsets[hi]), int(offsets[lo]) + 1)],
-                                    d_off=device_reads["d_off"][lo:hi + 1] - device_reads["d_off"][lo],
-                                    d_counts=None if device_reads.get("d_counts") is None else device_reads["d_counts"][lo:hi].contiguous())
-            else:
-                arena = np.asarray(arena)[int(offsets[lo]):int(offsets[hi])]
-            offsets = (offsets[lo:hi + 1] - offsets[lo]).astype(np.uint64)
-        else:
-            shard_idx = np.asarray(shard, dtype=np.int64)
-            ln_ = (offsets[1:] - offsets[:-1]).astype(np.int64)[shard_idx]
-            new_off = np.zeros(len(shard_idx) + 1, dtype=np.uint64)
-            new_off[1:] = np.cumsum(ln_)
-            src = np.repeat(offsets[:-1].astype(np.int64)[shard_idx] - new_off[:-1].astype(np.int64), ln_) + np.arange(int(new_off[-1]), dtype=np.int64)
-            arena = np.asarray(arena)[src] if len(src) else np.zeros(0, dtype=np.uint8)
-            offsets = new_off
-        read_counts = g_raw[shard_idx]
-    n, k = len(read_counts), len(ref_names)
-    L = [len(refs[name]['sequence']) for name in ref_names]
-    lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
-    max_lj = int(lens.max()) if n else 1
-    if reduce_across_ranks:
-        # every rank must build the SAME tensor (the histogram length depends on the longest read): agree on it first
-        max_lj = C.all_reduce_max(max_lj, dev)
-    layout = C.CountLayout(k, max(L), max_lj)
-    d_counts = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
-    flags = ((C.FLAG_IGNORE_SUBSTITUTIONS if args.ignore_substitutions else 0) | (C.FLAG_IGNORE_INSERTIONS if args.ignore_insertions else 0) |
-             (C.FLAG_IGNORE_DELETIONS if args.ignore_deletions else 0) | (C.FLAG_DISCARD_INDEL_READS if getattr(args, 'discard_indel_reads', False) else 0) |
-             (C.FLAG_LEGACY_CLASSIFIER if legacy else 0))
-    stats = dict(N_TOT_READS=int(np.asarray(read_counts, dtype=np.int64).sum()), N_CACHED_ALN=0, N_CACHED_NOTALN=0, N_COMPUTED_ALN=0,
-                 N_COMPUTED_NOTALN=0, N_GLOBAL_SUBS=0, N_SUBS_OUTSIDE_WINDOW=0, N_MODS_IN_WINDOW=0, N_MODS_OUTSIDE_WINDOW=0,
-                 N_READS_IRREGULAR_ENDS=0, N_TOTAL=0, N_AMBIGUOUS=0)
-    want_view = k > 1 and bool(getattr(args, 'expected_hdr_amplicon_seq', '') or getattr(args, 'prime_editing_pegRNA_extension_seq', ''))
-    STAT_KEYS = sorted(stats)
+            self.timings[name] = self.timings.get(name, 0.0) + now - self._t_last
+            self._t_last = now
 
-    def reduce_stats():
-        """the integer statistics summed over the ranks (each rank counted its own shard)"""
-        if reduce_across_ranks:
-            v = C.all_reduce(torch.tensor([stats[q] for q in STAT_KEYS], dtype=torch.int64, device=dev)).cpu().numpy()
-            for q, x in zip(STAT_KEYS, v):
-                stats[q] = int(x)
-    pe = ref_names.index('Prime-edited') if scaffold_rule else -1
+    def _restart_clock(self):
+        import time
+        self._t_last = time.perf_counter()
 
-    def finish(d_view, d_scaffold, state):
-        """the tensors (already all-reduced when sharded) -> QuantResult; the same for a rank whose shard is empty"""
-        host = d_counts.cpu().numpy()
-        lap("count_kernels")
-        per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
-        out_names = list(ref_names)
-        if scaffold_rule:
-            per_ref['Scaffold-incorporated'] = layout.unpack(d_scaffold.cpu().numpy(), pe, L[pe])
-            out_names.append('Scaffold-incorporated')
-        first_ref_view = None
-        if d_view is not None:
-            view_keys = (["all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
-                          "all_substitution_count_vectors"] + ["all_base_count_vectors_" + x for x in "ACGTN-"])
-            host_view = d_view.cpu().numpy()
-            first_ref_view = {ref_names[0]: {kk: per_ref[ref_names[0]][kk] for kk in view_keys}}
-            for r in range(1, len(out_names)):
-                u = layout.unpack(host_view[r], 0, L[0])
-                first_ref_view[out_names[r]] = {kk: u[kk] for kk in view_keys}
-            for v in first_ref_view.values():
-                v["all_indelsub_count_vectors"] = (v["all_insertion_count_vectors"] + v["all_deletion_count_vectors"]
-                                                   + v["all_substitution_count_vectors"])
-        lap("unpack")
-        res = QuantResult(per_ref, stats, layout, d_counts, state, first_ref_view=first_ref_view)
-        if device_reads is not None:
-            res.device_ingest = {q: device_reads[q] for q in ("n_reads", "nonempty_lines", "n_unique", "n_empty_records") if q in device_reads}
-        return res
-
-    def exchange_aligned(aligned_local):
-        """sharded run: which unique reads of the WHOLE list aligned -- every rank contributes its part (one byte per read)"""
-        t = torch.zeros(max(n_global, 1), dtype=torch.uint8, device=dev)
-        if n:
-            idx_t = (torch.arange(shard_idx.start, shard_idx.stop, device=dev) if isinstance(shard_idx, slice)
-                     else torch.from_numpy(shard_idx).to(dev))
-            t[idx_t] = torch.from_numpy(np.ascontiguousarray(aligned_local, dtype=np.uint8)).to(dev)
-        C.all_reduce(t)
-        return t.cpu().numpy()[:n_global] != 0
-    if n == 0:
-        # an empty shard still takes part in every collective of the other ranks (same tensors, zeros, same order) and gets the
-        # same result as they do
-        d_view = d_scaffold = None
-        if reduce_across_ranks:
-            if shard is not None:
-                exchange_aligned(None)
-            C.all_reduce(d_counts)
-            if want_view:
-                d_view = C.all_reduce(torch.zeros((k + (1 if scaffold_rule else 0),) + tuple(layout.shape()), dtype=torch.int64, device=dev))
-            if scaffold_rule:
-                d_scaffold = C.all_reduce(torch.zeros(layout.shape(), dtype=torch.int64, device=dev))
-            reduce_stats()
-        elif scaffold_rule:
-            d_scaffold = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
-            d_view = torch.zeros((k + 1,) + tuple(layout.shape()), dtype=torch.int64, device=dev) if want_view else None
-        elif want_view:
-            d_view = torch.zeros((k,) + tuple(layout.shape()), dtype=torch.int64, device=dev)
-        return finish(d_view, d_scaffold, None)
-    def host_arena():
+    def host_arena(self):
         """the reads' bytes on the host (device_reads: downloaded when a host-side step needs them after all)"""
-        return arena if arena is not None else device_reads["d_reads"][:int(offsets[-1])].cpu().numpy()
-    if device_reads is not None:
-        d_reads, d_off = device_reads["d_reads"], device_reads["d_off"]
-    else:
-        arena = np.ascontiguousarray(arena, dtype=np.uint8)
-    if front is None and device_reads is None:
-        if not arena.flags.writeable:
-            arena = arena.copy()                                      # torch.from_numpy wants a writable array
-        # the reads go to the device now: the copy is in flight while the host tests the seeds
-        d_reads = torch.from_numpy(arena if arena.size else np.zeros(1, dtype=np.uint8)).to(dev, non_blocking=True)
-        d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev, non_blocking=True)
-    lap("setup")
-    # which read is the reverse complement of which (for the count merge of :3970-3975) does not depend on the alignments: a host
-    # thread looks that up while the device aligns
-    import threading
-    partners = {}
+        return self.arena if self.arena is not None else self.device_reads["d_reads"][:int(self.offsets[-1])].cpu().numpy()
 
-    def _find_partners():
-        try:
-            if partners.get('device') is not None:
-                return                                                # (enqueued on the device, below; fetched at the merge)
-            if device_reads is not None and device_reads.get("rc_partner") is not None:
-                partners['index'] = device_reads["rc_partner"]         # (looked up in the device ingest's table, over ALL unique reads)
-            elif front is not None and front.get("rc_partners") is not None:
-                partners['index'] = front["rc_partners"]()            # (from the table the streamed ingest built: no second hash of every read)
-            else:
-                partners['index'] = (_native.rc_partners(host_arena(), offsets) if shard is None else
-                                     _native.rc_partners(np.ascontiguousarray(g_arena, dtype=np.uint8), g_offsets))
-        except BaseException as e:                                   # re-raised by the main thread at the join
-            partners['error'] = e
-    # reads of one length that are already in HBM: the search runs there (milliseconds); anything else on the host thread
-    if (shard is None and n >= RC_PARTNERS_ON_DEVICE_MIN and int(lens.min()) == max_lj
-            and not (device_reads is not None and device_reads.get("rc_partner") is not None)):
-        d_all = front["d_reads_all"] if front is not None else d_reads
-        if d_all is not None and d_all.numel() >= n * max_lj:
-            partners['device'] = rc_partners_device(d_all[:n * max_lj].view(n, max_lj))
-    partner_thread = threading.Thread(target=_find_partners, name="c2-rc-partners")
-    _threads.append(partner_thread)
-    partner_thread.start()
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    n1 = n * k
-    if front is not None:
-        # seed test and batch 1 ran chunk by chunk while the file was parsed
-        plan, stride, a1, f1, r1 = front["plan"], front["stride"], front["a1"], front["f1"], front["r1"]
-    else:
-        # the seed test that picks the strand(s) of every (read, reference) alignment (:656-687): on the device, over the reads that
-        # were just sent there (FORCE_HOST_STRAND_PLAN: the host's threaded c2_strand_plan instead -- the tests compare the two)
-        if FORCE_HOST_STRAND_PLAN:
-            plan = strand_plans(arena, offsets, refs, ref_names, args)
-        else:
-            d_plan = torch.empty(n * k, dtype=torch.uint8, device=dev)
-            C.strand_plan_device(ctx, n, d_reads.data_ptr(), d_off.data_ptr(), max_lj, refs, ref_names, args.aln_seed_count, args.aln_seed_min,
-                                 d_plan.data_ptr(), stream=stream)
-            plan = to_host(d_plan).reshape(n, k)
-        lap("strand_plan")
-        stride = aligner.stride_for(max_lj)
-
-        # ---- batch 1: every read against every reference, on the strand the seeds ask for (forward when they ask for both)
-        d_str1 = to_device((plan == 1).astype(np.uint8).reshape(-1), dev)
-        a1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
-        f1 = torch.empty((n1, stride), dtype=torch.uint8, device=dev)
-        r1 = torch.empty((n1, 32), dtype=torch.uint8, device=dev)
-        aligner.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), a1.data_ptr(), f1.data_ptr(), r1.data_ptr(), stride, max_lj,
-                             d_strands=d_str1.data_ptr(), all_refs=True, stream=stream, legacy=legacy)
-    lap("h2d_align")
-
-    # ---- batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments
-    if front is not None and front.get("both") is not None:
-        bi, br = front["both"][:, 0].copy(), front["both"][:, 1].copy()      # (found on the device, row-major like np.nonzero)
-    else:
-        bi, br = np.nonzero(plan == 2)
-    n2 = len(bi)
-    lap("both_strand_list")
-    r2 = a2 = f2 = None
-    stride2 = stride
-    if n2:
-        # gather the bytes of those reads (a read that is undecided for several references is repeated)
-        max_lj2 = int(lens[bi].max())
-        stride2 = aligner.stride_for(max_lj2)
-        if device_reads is not None:
-            from . import fastq_device
-            d_reads2, d_off2, _ = fastq_device.gather_reads_device(ctx, d_reads, d_off, bi, dev, stream)
-        else:
-            arena2, off2 = _native.gather_reads(arena, offsets, bi)
-            d_reads2 = torch.from_numpy(arena2 if arena2.size else np.zeros(1, dtype=np.uint8)).to(dev)
-            d_off2 = torch.from_numpy(off2.astype(np.int64)).to(dev)
-        d_rid2 = torch.from_numpy(br.astype(np.int16)).to(dev)
-        d_str2 = torch.ones(n2, dtype=torch.uint8, device=dev)
-        a2 = torch.empty((n2, stride2), dtype=torch.uint8, device=dev)
-        f2 = torch.empty((n2, stride2), dtype=torch.uint8, device=dev)
-        r2 = torch.empty((n2, 32), dtype=torch.uint8, device=dev)
-        aligner.align_device(n2, d_reads2.data_ptr(), d_off2.data_ptr(), a2.data_ptr(), f2.data_ptr(), r2.data_ptr(), stride2, max_lj2,
-                             d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=stream, legacy=legacy)
-    lap("both_strand_pairs")
-    # ---- strand and reference choice (:683, :697-707), ambiguity, aln_stats: on the device.  Host selection (the same
-    # comparisons on Python floats) remains for what the kernel's 64-bit masks / exact integer scores do not cover.
-    raw = np.asarray(read_counts, dtype=np.int64)
-    if raw.size and raw.max() > 0x7FFFFFFF:
-        raise OverflowError("a read multiplicity exceeds 2^31 - 1")
-    min_scores = [refs[name]['min_aln_score'] for name in ref_names]
-    class _Slot2:
+    def host_slot2(self):
         """[n, k] -> index of the (read, reference) pair in the both-strand batch, -1: none.  Built on the host only when something there
-        reads it (the host selection, the scaffold rule, alleles()): the kernels take the device copy"""
-        value = None
+        reads it (the host selection, the scaffold rule): the kernels take the device copy"""
+        if self._host_slot2 is None:
+            self._host_slot2 = np.full((self.n, self.k), -1, dtype=np.int64)
+            if self.n2:
+                self._host_slot2[self.bi, self.br] = np.arange(self.n2)
+        return self._host_slot2
 
-        def __call__(self):
-            if self.value is None:
-                self.value = np.full((n, k), -1, dtype=np.int64)
-                if n2:
-                    self.value[bi, br] = np.arange(n2)
-            return self.value
-    host_slot2 = _Slot2()
-    mode = C.select_mode(args)
-    on_device = max(stride, stride2) <= C.SELECT_MAX_ALN_LEN and not FORCE_HOST_SELECTION
-    d_slot2 = None
-    if n2:
-        d_slot2 = torch.full((n * k,), -1, dtype=torch.int32, device=dev)
-        d_slot2[to_device(np.asarray(bi, dtype=np.int64) * k + np.asarray(br, dtype=np.int64), dev)] = torch.arange(n2, dtype=torch.int32, device=dev)
-    if on_device:
+    def reduce_stats(self):
+        """the integer statistics summed over the ranks (each rank counted its own shard)"""
+        import torch
+        if self.reduce_across_ranks:
+            keys = sorted(self.stats)
+            v = C.all_reduce(torch.tensor([self.stats[q] for q in keys], dtype=torch.int64, device=self.dev)).cpu().numpy()
+            for q, x in zip(keys, v):
+                self.stats[q] = int(x)
+
+    def exchange_aligned(self, aligned_local):
+        """sharded run: which unique reads of the WHOLE list aligned -- every rank contributes its part (one byte per read)"""
+        import torch
+        t = torch.zeros(max(self.n_global, 1), dtype=torch.uint8, device=self.dev)
+        if self.n:
+            idx_t = (torch.arange(self.shard_idx.start, self.shard_idx.stop, device=self.dev) if isinstance(self.shard_idx, slice)
+                     else torch.from_numpy(self.shard_idx).to(self.dev))
+            t[idx_t] = torch.from_numpy(np.ascontiguousarray(aligned_local, dtype=np.uint8)).to(self.dev)
+        C.all_reduce(t)
+        return t.cpu().numpy()[:self.n_global] != 0
+
+    def _select_kernel(self, **out):
+        """c2_select_best_kernel over this run's records (first call: masks + statistics from the raw multiplicities; second call: the weights
+        of the count pass from the merged ones)"""
+        n2 = self.n2
+        C.select_best_device(self.ctx, self.n, self.k, self.r1.data_ptr(), self.min_mscore, self.mode, max(self.stride, self.stride2),
+                             d_records2=self.r2.data_ptr() if n2 else None, d_slot2=self.d_slot2.data_ptr() if n2 else None, stream=self.stream, **out)
+
+    def _count_launches(self, d_out, d_w1, d_w2, flags):
+        """the count kernel over batch 1 (all-references layout) and batch 2 with the given weights, into d_out"""
+        C.accumulate_device(self.ctx, self.layout, self.n1, self.a1.data_ptr(), self.f1.data_ptr(), self.stride, self.r1.data_ptr(), d_out.data_ptr(),
+                            d_weights=d_w1.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=self.stream)
+        if self.n2 and d_w2 is not None:
+            C.accumulate_device(self.ctx, self.layout, self.n2, self.a2.data_ptr(), self.f2.data_ptr(), self.stride2, self.r2.data_ptr(), d_out.data_ptr(),
+                                d_weights=d_w2.data_ptr(), flags=flags, stream=self.stream)
+
+    # ---- the run ----
+    def run(self, arena, offsets, read_counts, shard, fastq_stream, device_reads):
+        self.take_input(arena, offsets, read_counts, shard, fastq_stream, device_reads)
+        self.prepare()
+        if self.n == 0:
+            return self.empty_shard()
+        self.reads_to_device()
+        self.start_partner_search()
+        self.align_all_references()
+        self.align_both_strands()
+        self.select()
+        if self.on_device and self.shard is None and not self.scaffold_rule and not self.want_view and not FORCE_HOST_MERGE:
+            res = self.finish_on_device()
+            if res is not None:
+                return res
+        self.merge_on_host()
+        self.scaffold_hits()
+        self.count()
+        self.first_amplicon_view()
+        self.reduce()
+        return self.result(self.device_state())
+
+    def take_input(self, arena, offsets, read_counts, shard, fastq_stream, device_reads):
+        refs, ref_names, args = self.refs, self.ref_names, self.args
+        if fastq_stream is not None:
+            if shard is not None:
+                raise ValueError("a sharded run cuts the list of ALL unique reads: it cannot start before the file is parsed")
+            self.front = _stream_front(fastq_stream, self.aligner, self.ctx, self.dev, refs, ref_names, args, self.legacy, self.timings)
+            arena, offsets, read_counts = self.front["arena"], self.front["offsets"], self.front["counts"]
+            self._restart_clock()
+        shard_of_all = isinstance(shard, str) and shard == "mine"      # (the rank's range of a list whose length is not known yet)
+        if isinstance(shard, str) and not (shard_of_all and device_reads is not None):
+            raise ValueError('shard is None, (lo, hi), an index array, or "mine" together with device_reads')
+        if device_reads is not None:
+            if fastq_stream is not None or (shard is not None and not shard_of_all and not isinstance(shard, tuple)):
+                raise ValueError("device_reads takes no fastq_stream and only contiguous shards")
+            if isinstance(device_reads, (str, os.PathLike, np.ndarray, _native.BgzfFile)):
+                source = device_reads if isinstance(device_reads, (np.ndarray, _native.BgzfFile)) else os.fspath(device_reads)
+                if shard is None:
+                    # a FASTQ file, or FASTQ text in host memory: framed, de-duplicated AND aligned (batch 1) chunk by chunk under its upload (_device_front)
+                    self.front = _device_front(source, self.aligner, self.ctx, self.dev, refs, ref_names, args, self.legacy, self.timings)
+                    device_reads = self.front["device_reads"]
+                else:
+                    # sharded: every rank frames and de-duplicates the whole text on ITS device (the parent's variantCache of the reference,
+                    # which all workers see) and aligns its range of the unique reads
+                    from . import fastq_device
+                    device_reads = fastq_device.ingest_file(source, self.ctx, self.dev, timings=self.timings)
+                self._restart_clock()
+            arena, offsets, read_counts = None, device_reads["offsets"], device_reads["counts"]
+        if shard_of_all:                                              # (this rank's contiguous range of however many unique reads there are)
+            import torch.distributed as dist
+            from . import distributed as D
+            shard = D.my_shard(len(read_counts), dist.get_rank(), dist.get_world_size())
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        # the whole run's unique reads (what the reverse-complement partner search looks at) and the part this process aligns
+        self.g_arena, self.g_offsets, self.g_raw = arena, offsets, np.asarray(read_counts, dtype=np.int64)
+        self.n_global = len(self.g_raw)
+        self.shard_idx = None
+        if shard is not None:
+            self.reduce_across_ranks = True
+            if isinstance(shard, tuple):
+                lo, hi = int(shard[0]), int(shard[1])
+                self.shard_idx = slice(lo, hi)
+                if device_reads is not None:                          # (the reads are on the device: the shard is a view of them)
+                    device_reads = dict(device_reads, d_reads=device_reads["d_reads"][int(offsets[lo]):max(int(offsets[hi]), int(offsets[lo]) + 1)],
+                                        d_off=device_reads["d_off"][lo:hi + 1] - device_reads["d_off"][lo],
+                                        d_counts=None if device_reads.get("d_counts") is None else device_reads["d_counts"][lo:hi].contiguous())
+                else:
+                    arena = np.asarray(arena)[int(offsets[lo]):int(offsets[hi])]
+                offsets = (offsets[lo:hi + 1] - offsets[lo]).astype(np.uint64)
+            else:
+                self.shard_idx = np.asarray(shard, dtype=np.int64)
+                ln_ = (offsets[1:] - offsets[:-1]).astype(np.int64)[self.shard_idx]
+                new_off = np.zeros(len(self.shard_idx) + 1, dtype=np.uint64)
+                new_off[1:] = np.cumsum(ln_)
+                src = np.repeat(offsets[:-1].astype(np.int64)[self.shard_idx] - new_off[:-1].astype(np.int64), ln_) + np.arange(int(new_off[-1]), dtype=np.int64)
+                arena = np.asarray(arena)[src] if len(src) else np.zeros(0, dtype=np.uint8)
+                offsets = new_off
+            read_counts = self.g_raw[self.shard_idx]
+        self.arena, self.offsets, self.read_counts, self.shard, self.device_reads = arena, offsets, read_counts, shard, device_reads
+
+    def prepare(self):
+        import torch
+        self.n = len(self.read_counts)
+        self.n1 = self.n * self.k
+        self.lens = (self.offsets[1:] - self.offsets[:-1]).astype(np.int64)
+        self.max_lj = int(self.lens.max()) if self.n else 1
+        if self.reduce_across_ranks:
+            # every rank must build the SAME tensor (the histogram length depends on the longest read): agree on it first
+            self.max_lj = C.all_reduce_max(self.max_lj, self.dev)
+        self.layout = C.CountLayout(self.k, max(self.L), self.max_lj)
+        self.d_counts = torch.zeros(self.layout.shape(), dtype=torch.int64, device=self.dev)
+        self.stats = dict(N_TOT_READS=int(np.asarray(self.read_counts, dtype=np.int64).sum()), N_CACHED_ALN=0, N_CACHED_NOTALN=0, N_COMPUTED_ALN=0,
+                          N_COMPUTED_NOTALN=0, N_GLOBAL_SUBS=0, N_SUBS_OUTSIDE_WINDOW=0, N_MODS_IN_WINDOW=0, N_MODS_OUTSIDE_WINDOW=0,
+                          N_READS_IRREGULAR_ENDS=0, N_TOTAL=0, N_AMBIGUOUS=0)
+        self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+
+    def empty_shard(self):
+        """an empty shard still takes part in every collective of the other ranks (same tensors, zeros, same order) and gets the same result
+        as they do"""
+        import torch
+        k, dev, shape = self.k, self.dev, tuple(self.layout.shape())
+        if self.reduce_across_ranks:
+            if self.shard is not None:
+                self.exchange_aligned(None)
+            C.all_reduce(self.d_counts)
+            if self.want_view:
+                self.d_view = C.all_reduce(torch.zeros((k + (1 if self.scaffold_rule else 0),) + shape, dtype=torch.int64, device=dev))
+            if self.scaffold_rule:
+                self.d_scaffold = C.all_reduce(torch.zeros(shape, dtype=torch.int64, device=dev))
+            self.reduce_stats()
+        elif self.scaffold_rule:
+            self.d_scaffold = torch.zeros(shape, dtype=torch.int64, device=dev)
+            self.d_view = torch.zeros((k + 1,) + shape, dtype=torch.int64, device=dev) if self.want_view else None
+        elif self.want_view:
+            self.d_view = torch.zeros((k,) + shape, dtype=torch.int64, device=dev)
+        return self.result(None)
+
+    def reads_to_device(self):
+        import torch
+        if self.device_reads is not None:
+            self.d_reads, self.d_off = self.device_reads["d_reads"], self.device_reads["d_off"]
+        else:
+            self.arena = np.ascontiguousarray(self.arena, dtype=np.uint8)
+        if self.front is None and self.device_reads is None:
+            if not self.arena.flags.writeable:
+                self.arena = self.arena.copy()                        # torch.from_numpy wants a writable array
+            # the reads go to the device now: the copy is in flight while the host tests the seeds
+            self.d_reads = torch.from_numpy(self.arena if self.arena.size else np.zeros(1, dtype=np.uint8)).to(self.dev, non_blocking=True)
+            self.d_off = torch.from_numpy(self.offsets.astype(np.int64)).to(self.dev, non_blocking=True)
+        elif self.front is not None and self.device_reads is None:
+            self.d_reads = self.d_off = None                          # (the streamed front sent them chunk by chunk; batch 2 gathers from the host arena)
+        self.lap("setup")
+
+    def start_partner_search(self):
+        """which read is the reverse complement of which (for the count merge of :3970-3975) does not depend on the alignments: reads of one
+        length that are already in HBM are searched there (milliseconds), anything else by a host thread while the device aligns"""
+        import threading
+        self.partners = partners = {}
+        device_reads, front, shard = self.device_reads, self.front, self.shard
+
+        def find():
+            try:
+                if partners.get('device') is not None:
+                    return                                            # (enqueued on the device, below; fetched at the merge)
+                if device_reads is not None and device_reads.get("rc_partner") is not None:
+                    partners['index'] = device_reads["rc_partner"]     # (looked up in the device ingest's table, over ALL unique reads)
+                elif front is not None and front.get("rc_partners") is not None:
+                    partners['index'] = front["rc_partners"]()        # (from the table the streamed ingest built: no second hash of every read)
+                else:
+                    partners['index'] = (_native.rc_partners(self.host_arena(), self.offsets) if shard is None else
+                                         _native.rc_partners(np.ascontiguousarray(self.g_arena, dtype=np.uint8), self.g_offsets))
+            except BaseException as e:                               # re-raised by the main thread at the join
+                partners['error'] = e
+        if (shard is None and self.n >= RC_PARTNERS_ON_DEVICE_MIN and int(self.lens.min()) == self.max_lj
+                and not (device_reads is not None and device_reads.get("rc_partner") is not None)):
+            d_all = front["d_reads_all"] if front is not None else self.d_reads
+            if d_all is not None and d_all.numel() >= self.n * self.max_lj:
+                partners['device'] = rc_partners_device(d_all[:self.n * self.max_lj].view(self.n, self.max_lj))
+        self.partner_thread = threading.Thread(target=find, name="c2-rc-partners")
+        self.threads.append(self.partner_thread)
+        self.partner_thread.start()
+
+    def join_partner_search(self):
+        self.partner_thread.join()
+        if 'error' in self.partners:
+            raise self.partners['error']
+
+    def align_all_references(self):
+        """the seed test that picks the strand(s) of every (read, reference) alignment (:656-687) and batch 1: every read against every
+        reference, on the strand the seeds ask for (forward when they ask for both)"""
+        import torch
+        n, k, dev = self.n, self.k, self.dev
+        if self.front is not None:
+            # seed test and batch 1 ran chunk by chunk while the file was parsed / uploaded
+            f = self.front
+            self.plan, self.stride, self.a1, self.f1, self.r1 = f["plan"], f["stride"], f["a1"], f["f1"], f["r1"]
+        else:
+            # on the device, over the reads that were just sent there (FORCE_HOST_STRAND_PLAN: the host's threaded c2_strand_plan instead --
+            # the tests compare the two)
+            if FORCE_HOST_STRAND_PLAN:
+                self.plan = strand_plans(self.arena, self.offsets, self.refs, self.ref_names, self.args)
+            else:
+                d_plan = torch.empty(n * k, dtype=torch.uint8, device=dev)
+                C.strand_plan_device(self.ctx, n, self.d_reads.data_ptr(), self.d_off.data_ptr(), self.max_lj, self.refs, self.ref_names,
+                                     self.args.aln_seed_count, self.args.aln_seed_min, d_plan.data_ptr(), stream=self.stream)
+                self.plan = to_host(d_plan).reshape(n, k)
+            self.lap("strand_plan")
+            self.stride = self.aligner.stride_for(self.max_lj)
+            d_str1 = to_device((self.plan == 1).astype(np.uint8).reshape(-1), dev)
+            self.a1 = torch.empty((self.n1, self.stride), dtype=torch.uint8, device=dev)
+            self.f1 = torch.empty((self.n1, self.stride), dtype=torch.uint8, device=dev)
+            self.r1 = torch.empty((self.n1, 32), dtype=torch.uint8, device=dev)
+            self.aligner.align_device(n, self.d_reads.data_ptr(), self.d_off.data_ptr(), self.a1.data_ptr(), self.f1.data_ptr(), self.r1.data_ptr(),
+                                      self.stride, self.max_lj, d_strands=d_str1.data_ptr(), all_refs=True, stream=self.stream, legacy=self.legacy)
+        self.lap("h2d_align")
+
+    def align_both_strands(self):
+        """batch 2: the (read, reference) pairs aligned on both strands -- their reverse-complement alignments"""
+        import torch
+        dev = self.dev
+        if self.front is not None and self.front.get("both") is not None:
+            self.bi, self.br = self.front["both"][:, 0].copy(), self.front["both"][:, 1].copy()   # (found on the device, row-major like np.nonzero)
+        else:
+            self.bi, self.br = np.nonzero(self.plan == 2)
+        self.n2 = n2 = len(self.bi)
+        self._host_slot2 = None
+        self.lap("both_strand_list")
+        self.r2 = self.a2 = self.f2 = None
+        self.stride2 = self.stride
+        if n2:
+            # gather the bytes of those reads (a read that is undecided for several references is repeated)
+            max_lj2 = int(self.lens[self.bi].max())
+            self.stride2 = self.aligner.stride_for(max_lj2)
+            if self.device_reads is not None:
+                from . import fastq_device
+                d_reads2, d_off2, _ = fastq_device.gather_reads_device(self.ctx, self.d_reads, self.d_off, self.bi, dev, self.stream)
+            else:
+                arena2, off2 = _native.gather_reads(self.arena, self.offsets, self.bi)
+                d_reads2 = torch.from_numpy(arena2 if arena2.size else np.zeros(1, dtype=np.uint8)).to(dev)
+                d_off2 = torch.from_numpy(off2.astype(np.int64)).to(dev)
+            d_rid2 = torch.from_numpy(self.br.astype(np.int16)).to(dev)
+            d_str2 = torch.ones(n2, dtype=torch.uint8, device=dev)
+            self.a2 = torch.empty((n2, self.stride2), dtype=torch.uint8, device=dev)
+            self.f2 = torch.empty((n2, self.stride2), dtype=torch.uint8, device=dev)
+            self.r2 = torch.empty((n2, 32), dtype=torch.uint8, device=dev)
+            self.aligner.align_device(n2, d_reads2.data_ptr(), d_off2.data_ptr(), self.a2.data_ptr(), self.f2.data_ptr(), self.r2.data_ptr(), self.stride2,
+                                      max_lj2, d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=self.stream, legacy=self.legacy)
+        self.lap("both_strand_pairs")
+        self.d_slot2 = None
+        if n2:
+            self.d_slot2 = torch.full((self.n * self.k,), -1, dtype=torch.int32, device=dev)
+            self.d_slot2[to_device(np.asarray(self.bi, dtype=np.int64) * self.k + np.asarray(self.br, dtype=np.int64), dev)] = \
+                torch.arange(n2, dtype=torch.int32, device=dev)
+
+    def select(self):
+        """strand and reference choice (:683, :697-707), ambiguity, aln_stats: on the device.  Host selection (the same comparisons on Python
+        floats) remains for what the kernel's exact integer scores do not cover (alignments of SELECT_MAX_ALN_LEN columns or more)."""
+        import torch
+        n, k, dev, stats = self.n, self.k, self.dev, self.stats
+        self.raw = np.asarray(self.read_counts, dtype=np.int64)
+        if self.raw.size and self.raw.max() > 0x7FFFFFFF:
+            raise OverflowError("a read multiplicity exceeds 2^31 - 1")
+        self.min_scores = [self.refs[name]['min_aln_score'] for name in self.ref_names]
+        self.mode = C.select_mode(self.args)
+        self.on_device = max(self.stride, self.stride2) <= C.SELECT_MAX_ALN_LEN and not FORCE_HOST_SELECTION
+        self.member = self.use2 = self.aligned = None                  # (host copies of the masks: only when a host-side stage needs them)
+        if not self.on_device:
+            self.member, self.use2, self.aligned = _select_on_host(self.r1, self.r2, n, k, self.n2, self.bi if self.n2 else None, self.br if self.n2 else None,
+                                                                   self.host_slot2(), self.min_scores, self.raw, stats)
+            self.lap("selection_and_stats")
+            return
         words = (k + 63) // 64                                        # 64-bit words of a read's masks (bit r % 64 of word r / 64: reference r)
-        d_member = torch.zeros((n, words), dtype=torch.int64, device=dev)
-        d_use2 = torch.zeros((n, words), dtype=torch.int64, device=dev)
-        d_flags = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.d_member = torch.zeros((n, words), dtype=torch.int64, device=dev)
+        self.d_use2 = torch.zeros((n, words), dtype=torch.int64, device=dev)
+        self.d_flags = torch.zeros(n, dtype=torch.uint8, device=dev)
         d_stats = torch.zeros(len(C.SELECT_STATS), dtype=torch.int64, device=dev)
-        d_raw = (device_reads["d_counts"] if device_reads is not None and device_reads.get("d_counts") is not None
-                 else to_device(raw.astype(np.uint32).view(np.int32), dev))
-        min_mscore = C.min_mscore_table(min_scores)
-        lap("selection_inputs")
-        C.select_best_device(ctx, n, k, r1.data_ptr(), min_mscore, mode, max(stride, stride2),
-                             d_records2=r2.data_ptr() if n2 else None, d_slot2=d_slot2.data_ptr() if n2 else None,
-                             d_raw_counts=d_raw.data_ptr(), d_member=d_member.data_ptr(), d_use2=d_use2.data_ptr(),
-                             d_flags=d_flags.data_ptr(), d_stats=d_stats.data_ptr(), stream=stream)
+        dr = self.device_reads
+        self.d_raw = (dr["d_counts"] if dr is not None and dr.get("d_counts") is not None else to_device(self.raw.astype(np.uint32).view(np.int32), dev))
+        self.min_mscore = C.min_mscore_table(self.min_scores)
+        self.lap("selection_inputs")
+        self._select_kernel(d_raw_counts=self.d_raw.data_ptr(), d_member=self.d_member.data_ptr(), d_use2=self.d_use2.data_ptr(),
+                            d_flags=self.d_flags.data_ptr(), d_stats=d_stats.data_ptr())
         st = dict(zip(C.SELECT_STATS, d_stats.cpu().numpy().tolist()))
-        lap("selection_kernel")
+        self.lap("selection_kernel")
         if st["n_bad_status"]:
             if int(st["a_bad_status"]) & _native.STATUS_RC_CHAR:
                 raise KeyError("reverse_complement: a read has a character outside ACGTN_-")
@@ -780,225 +861,263 @@ def _quantify_unique(arena, offsets, read_counts, refs, ref_names, aln_matrix, a
         for q in ('N_COMPUTED_ALN', 'N_COMPUTED_NOTALN', 'N_CACHED_ALN', 'N_CACHED_NOTALN', 'N_GLOBAL_SUBS', 'N_SUBS_OUTSIDE_WINDOW',
                   'N_MODS_IN_WINDOW', 'N_MODS_OUTSIDE_WINDOW', 'N_READS_IRREGULAR_ENDS'):
             stats[q] = int(st[q])
-        # the kernel's 64-bit masks (bit r: reference r) are taken apart on the device: n x k bytes cross the link, not 16 n
-        ref_ix = torch.arange(k, dtype=torch.int64, device=dev)
+
+    def masks_to_host(self):
+        """the kernel's 64-bit masks (bit r: reference r) taken apart on the device: n x k bytes cross the link, not 16 n"""
+        import torch
+        ref_ix = torch.arange(self.k, dtype=torch.int64, device=self.dev)
         word_of, bit_of = ref_ix >> 6, (ref_ix & 63)[None, :]
+        self.member = to_host(((self.d_member[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool)
+        self.use2 = to_host(((self.d_use2[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool)
+        self.aligned = to_host(self.d_flags & 1).view(bool)
 
-        def masks_to_host():
-            return (to_host(((d_member[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool),
-                    to_host(((d_use2[:, word_of] >> bit_of) & 1).to(torch.uint8)).view(bool), to_host(d_flags & 1).view(bool))
-        if shard is None and not scaffold_rule and not want_view and not FORCE_HOST_MERGE:
-            # ---- the rest of the run without the host in it: the reverse-complement count transfer (:3970-3975), N_TOTAL / N_AMBIGUOUS, the
-            # weights and the count pass on the device; what alleles() reads comes to the host when it is asked for.  The transfer is
-            # sequential in the reference; over partner PAIRS (i <-> j, or i its own partner) it is independent work: when both reads
-            # aligned and have copies the earlier one takes the later one's (a palindrome doubles).  That needs the partner relation to
-            # be symmetric -- lower-case reads break it (their reverse complement is upper case): then the host applies the loop.
-            partner_thread.join()
-            if 'error' in partners:
-                raise partners['error']
-            if partners.get('device') is not None:
-                d_partner = partners['device'].partner_tensor()
-            elif device_reads is not None and device_reads.get("d_rc_partner") is not None:
-                d_partner = device_reads["d_rc_partner"]
-            else:
-                d_partner = to_device(np.ascontiguousarray(partners['index'], dtype=np.int64), dev)
-            if d_partner is not None:
-                ix = torch.arange(n, dtype=torch.int64, device=dev)
-                has = d_partner >= 0
-                pc = d_partner.clamp(min=0)
-                asym = (has & (d_partner[pc] != ix)).sum()
-                c0 = d_raw.to(torch.int64) & 0xffffffff
-                d_al = (d_flags & 1) != 0
-                ok = d_al & (c0 > 0)
-                takes = has & (d_partner > ix) & ok & ok[pc]                  # the earlier read of an aligned pair with copies
-                gives = has & (d_partner < ix) & takes[pc]                    # ... and its partner
-                own = has & (d_partner == ix) & ok
-                c1 = torch.where(gives, torch.zeros_like(c0), c0 + torch.where(takes, c0[pc], torch.zeros_like(c0)) + torch.where(own, c0, torch.zeros_like(c0)))
-                d_amb = (d_flags & 2) != 0
-                sums = to_host(torch.stack([asym, (c1 * d_al).sum(), (c1 * d_amb).sum(), c1.max() if n else asym * 0]))
-                if int(sums[0]) == 0:
-                    if int(sums[3]) > 0x7FFFFFFF:
-                        raise OverflowError("a read multiplicity exceeds 2^31 - 1")
-                    stats['N_TOTAL'] = int(sums[1])
-                    if not args.assign_ambiguous_alignments_to_first_reference and not args.expand_ambiguous_alignments:
-                        stats['N_AMBIGUOUS'] = int(sums[2])
-                    lap("rc_merge_weights")
-                    d_cnt = c1.to(torch.int32)
-                    d_w1 = torch.zeros(n1, dtype=torch.int32, device=dev)
-                    d_w2 = torch.zeros(n2, dtype=torch.int32, device=dev) if n2 else None
-                    C.select_best_device(ctx, n, k, r1.data_ptr(), min_mscore, mode, max(stride, stride2),
-                                         d_records2=r2.data_ptr() if n2 else None, d_slot2=d_slot2.data_ptr() if n2 else None,
-                                         d_counts=d_cnt.data_ptr(), d_weights=d_w1.data_ptr(), d_weights2=d_w2.data_ptr() if n2 else None, stream=stream)
-                    C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_counts.data_ptr(),
-                                        d_weights=d_w1.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=stream)
-                    if n2:
-                        C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_counts.data_ptr(),
-                                            d_weights=d_w2.data_ptr(), flags=flags, stream=stream)
-                    if reduce_across_ranks:
-                        C.all_reduce(d_counts)
-                        reduce_stats()
-                    torch.cuda.synchronize(dev)
-
-                    return finish(None, None, dict(ctx=ctx, stream=stream, args=args, ref_names=list(ref_names), n=n, mode=mode, flags=flags & 15,
-                                                   a1=a1, f1=f1, r1=r1, stride=stride, a2=a2, f2=f2, r2=r2, stride2=stride2, d_slot2=d_slot2,
-                                                   d_member=d_member, d_use2=d_use2, d_flags=d_flags, d_cnt=d_cnt, d_scaffold_hit=None, scaffold_ref=pe))
-        member, use2, aligned = masks_to_host()
-    else:
-        member, use2, aligned = _select_on_host(r1, r2, n, k, n2, bi if n2 else None, br if n2 else None, host_slot2(), min_scores, raw, stats)
-    n_best = member.sum(axis=1)
-    lap("selection_and_stats")
-    # ---- aggregation weights (:3964-4000): rc merge, ambiguous reads, which references a read counts for
-    cnt = np.ascontiguousarray(raw.copy())
-    partner_thread.join()
-    if 'error' in partners:
-        raise partners['error']
-    if partners.get('device') is not None:
-        partners['index'] = partners['device'].result()
-        if partners['index'] is None:                                # (a hash collision among the reads: the host search decides)
-            partners['index'] = _native.rc_partners(host_arena(), offsets)
-    if shard is None:
-        _native.merge_counts_with_partners(aligned, partners['index'], cnt)
-    else:
-        # the reference's sequential transfer over the WHOLE variantCache order, with every rank's `aligned` flags: a read whose
-        # reverse complement was aligned by another rank gives its copies to (or takes them from) that read exactly as in one process
-        g_cnt = np.ascontiguousarray(g_raw.copy())
-        _native.merge_counts_with_partners(exchange_aligned(aligned), partners['index'], g_cnt)
-        cnt = np.ascontiguousarray(g_cnt[shard_idx])
-    # (whole-array arithmetic instead of boolean fancy indexing: these are passes over millions of unique reads)
-    stats['N_TOTAL'] = int(np.dot(cnt, aligned.astype(np.int64)))
-    counted = member.copy()
-    ambiguous = aligned & (n_best > 1)
-    any_ambiguous = bool(ambiguous.any())
-    if args.assign_ambiguous_alignments_to_first_reference:
-        if any_ambiguous:
-            first = np.argmax(member, axis=1)
-            counted[ambiguous, :] = False
-            counted[ambiguous, first[ambiguous]] = True
-    elif not args.expand_ambiguous_alignments:
-        if any_ambiguous:
-            counted &= ~ambiguous[:, None]
-        stats['N_AMBIGUOUS'] = int(np.dot(cnt, ambiguous.astype(np.int64))) if any_ambiguous else 0
-    counted &= aligned[:, None]
-    # ---- prime-editing scaffold rule (:786-796): a read whose best amplicons include 'Prime-edited' and whose alignment against it
-    # shows the scaffold's first bases right after the extension is counted for 'Scaffold-incorporated' ONLY (ambiguous or not),
-    # with that alignment.  The aligned strings of the candidate reads come to the host for the substring test.
-    scaffold_hit = np.zeros(n, dtype=bool)
-    if scaffold_rule:
-        cand = np.nonzero(aligned & member[:, pe])[0]
-        if len(cand):
-            idx0, dna = int(pe_scaffold_dna_info[0]) - 1, pe_scaffold_dna_info[1]
-            in2 = use2[cand, pe]
-            pairs = [None] * len(cand)
-
-            def pull(a, f, rows, where, lens_):
-                ah, fh = a.index_select(0, rows).cpu().numpy(), f.index_select(0, rows).cpu().numpy()
-                for q, j in enumerate(where):
-                    pairs[j] = (ah[q, :int(lens_[q])].tobytes().decode(), fh[q, :int(lens_[q])].tobytes().decode())
-            w_1 = np.nonzero(~in2)[0]
-            if len(w_1):
-                t_ = torch.from_numpy(cand[w_1] * k + pe).to(dev)
-                pull(a1, f1, t_, w_1, r1.index_select(0, t_).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)["aln_len"])
-            w_2 = np.nonzero(in2)[0]
-            if len(w_2):
-                sl = torch.from_numpy(host_slot2()[cand[w_2], pe]).to(dev)
-                pull(a2, f2, sl, w_2, r2.index_select(0, sl).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)["aln_len"])
-            for j, (s_read, s_ref) in enumerate(pairs):
-                seen, col = -1, -1
-                for c_, ch in enumerate(s_ref):                    # ref_positions.index(idx0): the column of reference base idx0
-                    if ch != '-':
-                        seen += 1
-                        if seen == idx0:
-                            col = c_
-                            break
-                if col < 0:
-                    raise ValueError("%d is not in list" % idx0)
-                if s_read[col + 1:col + 1 + len(dna)] == dna:
-                    scaffold_hit[cand[j]] = True
-        counted[scaffold_hit, :] = False
+    def finish_on_device(self):
+        """The rest of the usual run without the host in it: the reverse-complement count transfer (:3970-3975), N_TOTAL / N_AMBIGUOUS, the
+        weights and the count pass on the device; what alleles() reads comes to the host when it is asked for.  The transfer is sequential in
+        the reference; over partner PAIRS (i <-> j, or i its own partner) it is independent work: when both reads aligned and have copies the
+        earlier one takes the later one's (a palindrome doubles).  That needs the partner relation to be symmetric -- lower-case reads break
+        it (their reverse complement is upper case): then (-> None) the host applies the loop."""
+        import torch
+        n, dev, stats, args = self.n, self.dev, self.stats, self.args
+        self.join_partner_search()
+        partners, dr = self.partners, self.device_reads
+        if partners.get('device') is not None:
+            d_partner = partners['device'].partner_tensor()
+        elif dr is not None and dr.get("d_rc_partner") is not None:
+            d_partner = dr["d_rc_partner"]
+        else:
+            d_partner = to_device(np.ascontiguousarray(partners['index'], dtype=np.int64), dev)
+        if d_partner is None:
+            return None
+        ix = torch.arange(n, dtype=torch.int64, device=dev)
+        has = d_partner >= 0
+        pc = d_partner.clamp(min=0)
+        asym = (has & (d_partner[pc] != ix)).sum()
+        c0 = self.d_raw.to(torch.int64) & 0xffffffff
+        d_al = (self.d_flags & 1) != 0
+        ok = d_al & (c0 > 0)
+        takes = has & (d_partner > ix) & ok & ok[pc]                  # the earlier read of an aligned pair with copies
+        gives = has & (d_partner < ix) & takes[pc]                    # ... and its partner
+        own = has & (d_partner == ix) & ok
+        c1 = torch.where(gives, torch.zeros_like(c0), c0 + torch.where(takes, c0[pc], torch.zeros_like(c0)) + torch.where(own, c0, torch.zeros_like(c0)))
+        d_amb = (self.d_flags & 2) != 0
+        sums = to_host(torch.stack([asym, (c1 * d_al).sum(), (c1 * d_amb).sum(), c1.max() if n else asym * 0]))
+        if int(sums[0]) != 0:
+            return None
+        if int(sums[3]) > 0x7FFFFFFF:
+            raise OverflowError("a read multiplicity exceeds 2^31 - 1")
+        stats['N_TOTAL'] = int(sums[1])
         if not args.assign_ambiguous_alignments_to_first_reference and not args.expand_ambiguous_alignments:
-            stats['N_AMBIGUOUS'] = int(cnt[ambiguous & ~scaffold_hit].sum())
-    if cnt.max() > 0x7FFFFFFF:
-        raise OverflowError("a read multiplicity exceeds 2^31 - 1")          # (the count kernel's weights are int32)
-    lap("rc_merge_weights")
-    d_w2 = None
-    if on_device:
-        # the weight of every alignment in the count pass: the kernel again, now with the merged multiplicities (a read the
-        # scaffold rule took away counts for no amplicon here)
-        d_cnt = to_device((np.where(scaffold_hit, 0, cnt) if scaffold_rule else cnt).astype(np.uint32).view(np.int32), dev)
-        d_w1 = torch.zeros(n1, dtype=torch.int32, device=dev)
-        if n2:
-            d_w2 = torch.zeros(n2, dtype=torch.int32, device=dev)
-        C.select_best_device(ctx, n, k, r1.data_ptr(), min_mscore, mode, max(stride, stride2),
-                             d_records2=r2.data_ptr() if n2 else None, d_slot2=d_slot2.data_ptr() if n2 else None,
-                             d_counts=d_cnt.data_ptr(), d_weights=d_w1.data_ptr(), d_weights2=d_w2.data_ptr() if n2 else None, stream=stream)
-    else:
-        w1 = np.where(counted & ~use2, cnt[:, None], 0).astype(np.uint32).reshape(-1)
-        d_w1 = torch.from_numpy(w1.view(np.int32)).to(dev)
-        if n2:
-            w2 = np.where(counted[bi, br] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
-            d_w2 = torch.from_numpy(w2.view(np.int32)).to(dev)
-    C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_counts.data_ptr(),
-                        d_weights=d_w1.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=stream)
-    if n2:
-        C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_counts.data_ptr(),
-                            d_weights=d_w2.data_ptr(), flags=flags, stream=stream)
-    d_scaffold = None
-    if scaffold_rule:
-        d_scaffold = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)       # row `pe` = the 'Scaffold-incorporated' amplicon
-        ws = np.zeros((n, k), dtype=np.uint32)
-        ws[:, pe] = np.where(scaffold_hit & ~use2[:, pe], cnt, 0)
-        d_ws = torch.from_numpy(ws.reshape(-1).view(np.int32)).to(dev)
-        C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_scaffold.data_ptr(),
-                            d_weights=d_ws.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=stream)
-        if n2:
-            ws2 = np.where((br == pe) & scaffold_hit[bi] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
-            d_ws2 = torch.from_numpy(ws2.view(np.int32)).to(dev)
-            C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_scaffold.data_ptr(),
-                                d_weights=d_ws2.data_ptr(), flags=flags, stream=stream)
+            stats['N_AMBIGUOUS'] = int(sums[2])
+        self.lap("rc_merge_weights")
+        d_cnt = c1.to(torch.int32)
+        d_w1 = torch.zeros(self.n1, dtype=torch.int32, device=dev)
+        d_w2 = torch.zeros(self.n2, dtype=torch.int32, device=dev) if self.n2 else None
+        self._select_kernel(d_counts=d_cnt.data_ptr(), d_weights=d_w1.data_ptr(), d_weights2=d_w2.data_ptr() if self.n2 else None)
+        self._count_launches(self.d_counts, d_w1, d_w2, self.flags)
+        if self.reduce_across_ranks:
+            C.all_reduce(self.d_counts)
+            self.reduce_stats()
         torch.cuda.synchronize(dev)
-    # ---- every amplicon's reads in the coordinates of the FIRST amplicon (:4195-4270; runs with an expected HDR amplicon or a
-    # prime-editing extension).  The alignment of every read against the first amplicon is already on the device
-    # (ref_aln_details[0]); the reference classifies it again and adds its all_* positions and bases into arrays of the
-    # amplicon the read is counted for.  Here: one more count launch per other amplicon r over those alignments, weighted
-    # with the multiplicities of the reads counted for r; row 0 of that launch's tensor is amplicon r's view.  No ignore_* /
-    # discard flags: the reference's loop has none.
-    d_view = None
-    if want_view:
-        d_view = torch.zeros((k + (1 if scaffold_rule else 0),) + tuple(layout.shape()), dtype=torch.int64, device=dev)
-        for r in range(1, k + (1 if scaffold_rule else 0)):
-            for_r = counted[:, r] if r < k else scaffold_hit          # row k: the reads counted for 'Scaffold-incorporated'
+        return self.result(self.device_state(d_cnt=d_cnt))
+
+    def merge_on_host(self):
+        """aggregation weights (:3964-4000): the reference's sequential reverse-complement count transfer -- over the WHOLE variantCache order
+        with every rank's `aligned` flags when the run is sharded --, ambiguous reads, which references a read counts for"""
+        args, stats = self.args, self.stats
+        if self.member is None:
+            self.masks_to_host()
+        member, aligned = self.member, self.aligned
+        n_best = member.sum(axis=1)
+        self.lap("selection_and_stats")
+        cnt = np.ascontiguousarray(self.raw.copy())
+        self.join_partner_search()
+        partners = self.partners
+        if partners.get('device') is not None:
+            partners['index'] = partners['device'].result()
+            if partners['index'] is None:                            # (a hash collision among the reads: the host search decides)
+                partners['index'] = _native.rc_partners(self.host_arena(), self.offsets)
+        if self.shard is None:
+            _native.merge_counts_with_partners(aligned, partners['index'], cnt)
+        else:
+            # a read whose reverse complement was aligned by another rank gives its copies to (or takes them from) that read exactly as in one process
+            g_cnt = np.ascontiguousarray(self.g_raw.copy())
+            _native.merge_counts_with_partners(self.exchange_aligned(aligned), partners['index'], g_cnt)
+            cnt = np.ascontiguousarray(g_cnt[self.shard_idx])
+        # (whole-array arithmetic instead of boolean fancy indexing: these are passes over millions of unique reads)
+        stats['N_TOTAL'] = int(np.dot(cnt, aligned.astype(np.int64)))
+        counted = member.copy()
+        ambiguous = aligned & (n_best > 1)
+        any_ambiguous = bool(ambiguous.any())
+        if args.assign_ambiguous_alignments_to_first_reference:
+            if any_ambiguous:
+                first = np.argmax(member, axis=1)
+                counted[ambiguous, :] = False
+                counted[ambiguous, first[ambiguous]] = True
+        elif not args.expand_ambiguous_alignments:
+            if any_ambiguous:
+                counted &= ~ambiguous[:, None]
+            stats['N_AMBIGUOUS'] = int(np.dot(cnt, ambiguous.astype(np.int64))) if any_ambiguous else 0
+        counted &= aligned[:, None]
+        self.cnt, self.counted, self.ambiguous = cnt, counted, ambiguous
+
+    def scaffold_hits(self):
+        """prime-editing scaffold rule (:786-796): a read whose best amplicons include 'Prime-edited' and whose alignment against it shows the
+        scaffold's first bases right after the extension is counted for 'Scaffold-incorporated' ONLY (ambiguous or not), with that alignment.
+        The aligned strings of the candidate reads come to the host for the substring test."""
+        import torch
+        n, k, pe, dev = self.n, self.k, self.pe, self.dev
+        self.scaffold_hit = scaffold_hit = np.zeros(n, dtype=bool)
+        if self.scaffold_rule:
+            cand = np.nonzero(self.aligned & self.member[:, pe])[0]
+            if len(cand):
+                idx0, dna = int(self.pe_scaffold_dna_info[0]) - 1, self.pe_scaffold_dna_info[1]
+                in2 = self.use2[cand, pe]
+                pairs = [None] * len(cand)
+
+                def pull(a, f, rows, where, lens_):
+                    ah, fh = a.index_select(0, rows).cpu().numpy(), f.index_select(0, rows).cpu().numpy()
+                    for q, j in enumerate(where):
+                        pairs[j] = (ah[q, :int(lens_[q])].tobytes().decode(), fh[q, :int(lens_[q])].tobytes().decode())
+                w_1 = np.nonzero(~in2)[0]
+                if len(w_1):
+                    t_ = torch.from_numpy(cand[w_1] * k + pe).to(dev)
+                    pull(self.a1, self.f1, t_, w_1, self.r1.index_select(0, t_).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)["aln_len"])
+                w_2 = np.nonzero(in2)[0]
+                if len(w_2):
+                    sl = torch.from_numpy(self.host_slot2()[cand[w_2], pe]).to(dev)
+                    pull(self.a2, self.f2, sl, w_2, self.r2.index_select(0, sl).cpu().numpy().view(_native.REC_DTYPE).reshape(-1)["aln_len"])
+                for j, (s_read, s_ref) in enumerate(pairs):
+                    seen, col = -1, -1
+                    for c_, ch in enumerate(s_ref):                # ref_positions.index(idx0): the column of reference base idx0
+                        if ch != '-':
+                            seen += 1
+                            if seen == idx0:
+                                col = c_
+                                break
+                    if col < 0:
+                        raise ValueError("%d is not in list" % idx0)
+                    if s_read[col + 1:col + 1 + len(dna)] == dna:
+                        scaffold_hit[cand[j]] = True
+            self.counted[scaffold_hit, :] = False
+            if not self.args.assign_ambiguous_alignments_to_first_reference and not self.args.expand_ambiguous_alignments:
+                self.stats['N_AMBIGUOUS'] = int(self.cnt[self.ambiguous & ~scaffold_hit].sum())
+        if self.cnt.max() > 0x7FFFFFFF:
+            raise OverflowError("a read multiplicity exceeds 2^31 - 1")      # (the count kernel's weights are int32)
+        self.lap("rc_merge_weights")
+
+    def count(self):
+        """the weight of every alignment and the count launches; with the scaffold rule one more pair of launches for 'Scaffold-incorporated'"""
+        import torch
+        n, k, pe, dev, cnt, n2 = self.n, self.k, self.pe, self.dev, self.cnt, self.n2
+        scaffold_hit, use2 = self.scaffold_hit, self.use2
+        d_w2 = None
+        if self.on_device:
+            # the kernel again, now with the merged multiplicities (a read the scaffold rule took away counts for no amplicon here)
+            d_cnt = to_device((np.where(scaffold_hit, 0, cnt) if self.scaffold_rule else cnt).astype(np.uint32).view(np.int32), dev)
+            d_w1 = torch.zeros(self.n1, dtype=torch.int32, device=dev)
+            if n2:
+                d_w2 = torch.zeros(n2, dtype=torch.int32, device=dev)
+            self._select_kernel(d_counts=d_cnt.data_ptr(), d_weights=d_w1.data_ptr(), d_weights2=d_w2.data_ptr() if n2 else None)
+        else:
+            w1 = np.where(self.counted & ~use2, cnt[:, None], 0).astype(np.uint32).reshape(-1)
+            d_w1 = torch.from_numpy(w1.view(np.int32)).to(dev)
+            if n2:
+                w2 = np.where(self.counted[self.bi, self.br] & use2[self.bi, self.br], cnt[self.bi], 0).astype(np.uint32)
+                d_w2 = torch.from_numpy(w2.view(np.int32)).to(dev)
+        self._count_launches(self.d_counts, d_w1, d_w2, self.flags)
+        if self.scaffold_rule:
+            self.d_scaffold = torch.zeros(self.layout.shape(), dtype=torch.int64, device=dev)     # row `pe` = the 'Scaffold-incorporated' amplicon
+            ws = np.zeros((n, k), dtype=np.uint32)
+            ws[:, pe] = np.where(scaffold_hit & ~use2[:, pe], cnt, 0)
+            d_ws = torch.from_numpy(ws.reshape(-1).view(np.int32)).to(dev)
+            d_ws2 = None
+            if n2:
+                ws2 = np.where((self.br == pe) & scaffold_hit[self.bi] & use2[self.bi, self.br], cnt[self.bi], 0).astype(np.uint32)
+                d_ws2 = torch.from_numpy(ws2.view(np.int32)).to(dev)
+            self._count_launches(self.d_scaffold, d_ws, d_ws2, self.flags)
+            torch.cuda.synchronize(dev)
+
+    def first_amplicon_view(self):
+        """Every amplicon's reads in the coordinates of the FIRST amplicon (:4195-4270; runs with an expected HDR amplicon or a prime-editing
+        extension).  The alignment of every read against the first amplicon is already on the device (ref_aln_details[0]); the reference
+        classifies it again and adds its all_* positions and bases into arrays of the amplicon the read is counted for.  Here: one more count
+        launch per other amplicon r over those alignments, weighted with the multiplicities of the reads counted for r; row 0 of that launch's
+        tensor is amplicon r's view.  No ignore_* / discard flags: the reference's loop has none."""
+        import torch
+        if not self.want_view:
+            return
+        n, k, dev, cnt, n2, use2 = self.n, self.k, self.dev, self.cnt, self.n2, self.use2
+        rows = k + (1 if self.scaffold_rule else 0)
+        vflags = C.FLAG_LEGACY_CLASSIFIER if self.legacy else 0
+        self.d_view = torch.zeros((rows,) + tuple(self.layout.shape()), dtype=torch.int64, device=dev)
+        for r in range(1, rows):
+            for_r = self.counted[:, r] if r < k else self.scaffold_hit   # row k: the reads counted for 'Scaffold-incorporated'
             wv = np.zeros((n, k), dtype=np.uint32)
             wv[:, 0] = np.where(for_r & ~use2[:, 0], cnt, 0)
             d_wv = torch.from_numpy(wv.reshape(-1).view(np.int32)).to(dev)
-            C.accumulate_device(ctx, layout, n1, a1.data_ptr(), f1.data_ptr(), stride, r1.data_ptr(), d_view[r].data_ptr(),
-                                d_weights=d_wv.data_ptr(), flags=C.FLAG_ALL_REFS_LAYOUT | (C.FLAG_LEGACY_CLASSIFIER if legacy else 0), stream=stream)
+            d_wv2 = None
             if n2:
-                wv2 = np.where((br == 0) & for_r[bi] & use2[bi, br], cnt[bi], 0).astype(np.uint32)
+                wv2 = np.where((self.br == 0) & for_r[self.bi] & use2[self.bi, self.br], cnt[self.bi], 0).astype(np.uint32)
                 if wv2.any():
                     d_wv2 = torch.from_numpy(wv2.view(np.int32)).to(dev)
-                    C.accumulate_device(ctx, layout, n2, a2.data_ptr(), f2.data_ptr(), stride2, r2.data_ptr(), d_view[r].data_ptr(),
-                                        d_weights=d_wv2.data_ptr(), flags=C.FLAG_LEGACY_CLASSIFIER if legacy else 0, stream=stream)
+            self._count_launches(self.d_view[r], d_wv, d_wv2, vflags)
             torch.cuda.synchronize(dev)                              # the weight tensors of this round are done with
-    if reduce_across_ranks:
-        C.all_reduce(d_counts)
-        if d_view is not None:
-            C.all_reduce(d_view)
-        if d_scaffold is not None:
-            C.all_reduce(d_scaffold)
-        reduce_stats()
-    torch.cuda.synchronize(dev)
-    # what the allele table is built from (QuantResult.allele_table): the selection's masks as the kernel left them (or the host
-    # selection's, packed the same way), the merged multiplicities of this rank's reads, the scaffold rule's hits
-    if on_device:
-        t_member, t_use2, t_flags = d_member, d_use2, d_flags
-    else:
-        t_member, t_use2 = to_device(_pack_masks(member), dev), to_device(_pack_masks(use2), dev)
-        t_flags = to_device(aligned.astype(np.uint8), dev)
-    state = dict(ctx=ctx, stream=stream, args=args, ref_names=list(ref_names), n=n, mode=mode, flags=flags & 15,
-                 a1=a1, f1=f1, r1=r1, stride=stride, a2=a2, f2=f2, r2=r2, stride2=stride2, d_slot2=d_slot2,
-                 d_member=t_member, d_use2=t_use2, d_flags=t_flags, d_cnt=to_device(cnt.astype(np.uint32).view(np.int32), dev),
-                 d_scaffold_hit=to_device(scaffold_hit.astype(np.uint8), dev) if scaffold_rule else None, scaffold_ref=pe)
-    return finish(d_view, d_scaffold, state)
+
+    def reduce(self):
+        import torch
+        if self.reduce_across_ranks:
+            C.all_reduce(self.d_counts)
+            if self.d_view is not None:
+                C.all_reduce(self.d_view)
+            if self.d_scaffold is not None:
+                C.all_reduce(self.d_scaffold)
+            self.reduce_stats()
+        torch.cuda.synchronize(self.dev)
+
+    def device_state(self, d_cnt=None):
+        """what the allele table is built from (QuantResult.allele_table): the selection's masks as the kernel left them (or the host selection's,
+        packed the same way), the merged multiplicities of this rank's reads, the scaffold rule's hits"""
+        dev = self.dev
+        if self.on_device:
+            t_member, t_use2, t_flags = self.d_member, self.d_use2, self.d_flags
+        else:
+            t_member, t_use2 = to_device(_pack_masks(self.member), dev), to_device(_pack_masks(self.use2), dev)
+            t_flags = to_device(self.aligned.astype(np.uint8), dev)
+        if d_cnt is None:
+            d_cnt = to_device(self.cnt.astype(np.uint32).view(np.int32), dev)
+        hit = to_device(self.scaffold_hit.astype(np.uint8), dev) if (self.scaffold_rule and self.scaffold_hit is not None) else None
+        return dict(ctx=self.ctx, stream=self.stream, args=self.args, ref_names=list(self.ref_names), n=self.n, mode=self.mode, flags=self.flags & 15,
+                    a1=self.a1, f1=self.f1, r1=self.r1, stride=self.stride, a2=self.a2, f2=self.f2, r2=self.r2, stride2=self.stride2, d_slot2=self.d_slot2,
+                    d_member=t_member, d_use2=t_use2, d_flags=t_flags, d_cnt=d_cnt, d_scaffold_hit=hit, scaffold_ref=self.pe)
+
+    def result(self, state):
+        """the tensors (already all-reduced when sharded) -> QuantResult; the same for a rank whose shard is empty"""
+        layout, L, ref_names = self.layout, self.L, self.ref_names
+        host = self.d_counts.cpu().numpy()
+        self.lap("count_kernels")
+        per_ref = {name: layout.unpack(host, r, L[r]) for r, name in enumerate(ref_names)}
+        out_names = list(ref_names)
+        if self.scaffold_rule:
+            per_ref['Scaffold-incorporated'] = layout.unpack(self.d_scaffold.cpu().numpy(), self.pe, L[self.pe])
+            out_names.append('Scaffold-incorporated')
+        first_ref_view = None
+        if self.d_view is not None:
+            view_keys = (["all_insertion_count_vectors", "all_insertion_left_count_vectors", "all_deletion_count_vectors",
+                          "all_substitution_count_vectors"] + ["all_base_count_vectors_" + x for x in "ACGTN-"])
+            host_view = self.d_view.cpu().numpy()
+            first_ref_view = {ref_names[0]: {kk: per_ref[ref_names[0]][kk] for kk in view_keys}}
+            for r in range(1, len(out_names)):
+                u = layout.unpack(host_view[r], 0, L[0])
+                first_ref_view[out_names[r]] = {kk: u[kk] for kk in view_keys}
+            for v in first_ref_view.values():
+                v["all_indelsub_count_vectors"] = (v["all_insertion_count_vectors"] + v["all_deletion_count_vectors"]
+                                                   + v["all_substitution_count_vectors"])
+        self.lap("unpack")
+        res = QuantResult(per_ref, self.stats, layout, self.d_counts, state, first_ref_view=first_ref_view)
+        if self.device_reads is not None:
+            res.device_ingest = {q: self.device_reads[q] for q in ("n_reads", "nonempty_lines", "n_unique", "n_empty_records") if q in self.device_reads}
+        return res
 
 
 def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, timings=None, pe_scaffold_dna_info=None,
