@@ -868,12 +868,19 @@ def _upload(span, dev):
 
 
 # ---- paired input: two texts in HBM, record r of one with record r of the other (CRISPRessoCORE.py:1309-1334) ----
-class _Source:
-    """a FASTQ file as something _read_span can read: the path of a plain file, a BgzfFile, or (other gzip input) the text the host inflated;
-    a context manager that closes what it opened.  .source is None when the device route does not apply (the reason in .why_not)."""
-    def __init__(self, path):
-        self.source, self.why_not, self._held = None, None, []
-        why = applicable(path)
+class IngestSource:
+    """A FASTQ file as something the device ingest can read (_read_span): the path of a plain file, a BgzfFile (members inflated range by range
+    straight into the upload buffers), or -- other gzip input, or input the read filter has to see first -- the text the host inflated /
+    filtered into memory.  A context manager that closes what it opened.
+        source     path / BgzfFile / uint8 array, or None when the device route does not apply (why_not says why)
+        route      the name of the route for QuantResult.ingest_route
+        filtered_lines_input   non-empty lines in FRONT of the read filter (the reference's N_READS_INPUT * 4), None without a filter
+        host_stream()          the native chunked parser over the same input (the one that already holds the inflated text, if any): what the
+                               host route parses when the device declines; None when a .gz text exceeds the in-memory budget"""
+    def __init__(self, path, filters=(0, 0, 0)):
+        self.path, self.filters = path, tuple(filters)
+        self.source, self.route, self.filtered_lines_input, self._held, self._stream = None, "device", None, [], None
+        why = applicable(path, filters)
         try:
             if why is None:
                 self.source = os.fspath(path)
@@ -883,33 +890,57 @@ class _Source:
                     try:
                         bg = _native.BgzfFile(path)
                     except _native.NativeError:
-                        bg = None
+                        bg = None                                      # (some other gzip file: inflated as a whole)
                 if bg is not None:
                     self._held.append(bg)
                     why = size_applicable(bg.text_bytes)
                     if why is None:
-                        self.source = bg
+                        self.source, self.route = bg, "device, members inflated into the upload buffers"
                 else:
-                    fq = _native.FastqStream(path, 0, 0, 0)
-                    self._held.append(fq)
-                    text = fq.text()
-                    why = text_applicable(text)
-                    if why is None:
-                        self.source = text
-        except (_native.NativeError, OSError) as e:
+                    try:
+                        fq = _native.FastqStream(path, *self.filters)    # (inflates / filters: its text is in memory now)
+                    except _native.NativeError as e:
+                        if "in-memory budget" not in str(e):
+                            raise
+                        fq, why = None, str(e)                         # (a .gz whose text does not fit in memory streams through zlib on the host)
+                        self._stream = False
+                    if fq is not None:
+                        self._held.append(fq)
+                        self._stream = fq
+                        text = fq.text()
+                        why = text_applicable(text)
+                        if why is None:
+                            self.source, self.route = text, "device, text from host memory"
+                            if fq.filtered:
+                                self.filtered_lines_input = fq.lines_input()
+        except OSError as e:
             why = "%s: %s" % (type(e).__name__, e)
         self.why_not = why
 
-    def __enter__(self):
-        return self
+    def host_stream(self):
+        if self._stream is None:
+            try:
+                self._stream = _native.FastqStream(self.path, *self.filters)
+                self._held.append(self._stream)
+            except _native.NativeError as e:
+                if "in-memory budget" not in str(e):
+                    raise
+                self._stream = False
+        return self._stream or None
 
-    def __exit__(self, *exc):
+    def close(self):
         for h in self._held:
             try:
                 h.close()
             except Exception:
                 pass
         self._held = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
         return False
 
 
@@ -975,7 +1006,7 @@ class PairIngest:
 
 
 def ingest_pairs(source1, source2, ctx, dev, timings=None):
-    """Two sources (see _Source) -> PairIngest.  Raises DeviceIngestUnavailable for what the kernels do not take or where the reference raises an
+    """Two sources (see IngestSource) -> PairIngest.  Raises DeviceIngestUnavailable for what the kernels do not take or where the reference raises an
     error the host route reproduces (carriage returns; a character of read 2 that reverse_complement() does not know; a '+' inside a read or a
     blank inside a quality string, which the reference's key.split('+') / quals.split(' ') would trip over)."""
     import time

@@ -224,14 +224,14 @@ def quantify_paired_fastq(fastq1, fastq2, refs, ref_names, aln_matrix, args, ctx
     if not FORCE_HOST_PARSER:
         # the two texts uploaded as they lie in the files (BGZF: as they are inflated), framed, keyed and de-duplicated on the device: the second
         # pass below is then an index selection on arenas that are already in HBM
-        with fastq_device._Source(fastq1) as S1, fastq_device._Source(fastq2) as S2:
-            if S1.source is None or S2.source is None:
-                why_host = S1.why_not or S2.why_not
-            else:
-                try:
+        try:
+            with fastq_device.IngestSource(fastq1) as S1, fastq_device.IngestSource(fastq2) as S2:
+                if S1.source is None or S2.source is None:
+                    why_host = S1.why_not or S2.why_not
+                else:
                     P = fastq_device.ingest_pairs(S1.source, S2.source, ctx, dev, timings=timings)
-                except fastq_device.DeviceIngestUnavailable as e:     # (carriage returns, or something the reference raises an error for: the host parser reproduces it)
-                    why_host = str(e)
+        except (fastq_device.DeviceIngestUnavailable, _native.NativeError) as e:   # (carriage returns, a damaged gzip stream, something the reference
+            why_host = str(e)                                                      #  raises an error for: the host parser reproduces it)
     else:
         why_host = "C2_PAIRED_HOST_PARSER"
     if P is not None:

@@ -1124,10 +1124,10 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
                    shard_across_ranks=False, stream=True):
     """FASTQ file -> QuantResult.  Empty sequences (blank line / truncated record) are dropped, as in variants.read_fastq_unique
     (the reference's aligner indexes seq[-1] of an empty string: undefined there), and N_TOT_READS counts the records that are left.
-    shard_across_ranks (torch.distributed initialised, one process per GPU): every rank de-duplicates the file -- the parent's
-    variantCache of the reference, which all its workers see -- aligns ITS contiguous range of the unique reads
-    (get_variant_cache_equal_boundaries, CRISPRessoCORE.py:1172-1195) and the count tensors are all-reduced; the result is the
-    single-process one on every rank (quantify_unique, `shard`).
+    shard_across_ranks (torch.distributed initialised, one process per GPU): every rank ingests ITS byte range of the text, the ranks
+    reconcile their unique reads into the run's list -- the parent's variantCache of the reference, which all its workers see --, every
+    rank aligns its contiguous range of that list (get_variant_cache_equal_boundaries, CRISPRessoCORE.py:1172-1195) and the count tensors
+    are all-reduced; the result is the single-process one on every rank (quantify_unique, `shard`).
     stream (default; one process): the file is parsed in chunks on a host thread while the device already aligns the unique reads of
     the chunks before (_stream_front) -- same result as the one-batch flow (stream=False), which sharded runs keep."""
     import time
@@ -1140,134 +1140,79 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
     if shard_across_ranks:
         import torch.distributed as dist
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if stream and not sharded and not FORCE_HOST_STRAND_PLAN:
-        # the text framed and de-duplicated on the device (fastq_device): a plain file as it lies on disk; compressed or quality-filtered
-        # input after the host has inflated / filtered it into memory (the native stream holds that text: it is uploaded from there and
-        # the host parser never runs).  Anything the kernels cannot take (carriage returns, ...): the host parser.
-        from . import fastq_device
+    run = lambda **kw: quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
+                                       pe_scaffold_dna_info=pe_scaffold_dna_info, **kw)
 
-        def on_device(source):
-            res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
-                                  pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=source)
-            _native._line_stats(ingest_stats, res.device_ingest["nonempty_lines"])
-            res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT']
-            res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats['N_READS_AFTER_PREPROCESSING']
-            res.ingest_route = "device"
-            return res
-        why_not = fastq_device.applicable(path, flt)
-        if why_not is None:
-            try:
-                return on_device(path)
-            except fastq_device.DeviceIngestUnavailable as e:
-                why_not = str(e)
-        if why_not.startswith("in memory: compressed"):
-            # BGZF: the members are inflated range by range straight into the pinned upload buffers -- inflate, upload and the device's
-            # framing overlap, and the host never holds the text
-            bg = None
-            try:
-                bg = _native.BgzfFile(path)
-            except _native.NativeError:
-                pass                                                  # (some other gzip file: inflated as a whole below)
-            if bg is not None:
-                with bg:
-                    if fastq_device.size_applicable(bg.text_bytes) is None:
-                        try:
-                            res = on_device(bg)
-                            res.ingest_route = "device, members inflated into the upload buffers"
-                            return res
-                        except fastq_device.DeviceIngestUnavailable as e:
-                            why_not = str(e)                          # (e.g. carriage returns: the host parser takes the file)
-        fq = None
-        try:
-            fq = _native.FastqStream(path, *flt)                     # (inflates / filters a compressed or filtered input: its text is in memory now)
-        except _native.NativeError as e:
-            if "in-memory budget" not in str(e):                     # (a .gz whose text does not fit in memory streams through zlib below)
-                raise
-        if fq is not None:
-            with fq:
-                if why_not.startswith("in memory:"):
-                    text = fq.text()
-                    why_not = fastq_device.text_applicable(text)
-                    if why_not is None:
-                        if fq.filtered:
-                            ingest_stats["N_READS_INPUT"] = int(float(fq.lines_input()) / 4.0)
-                        try:
-                            res = on_device(text)
-                            res.ingest_route = "device, text from host memory"
-                            return res
-                        except fastq_device.DeviceIngestUnavailable as e:
-                            why_not = str(e)
-                            ingest_stats.pop("N_READS_INPUT", None)
-                if timings is not None:
-                    timings["host_parser_because"] = why_not
-                res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
-                                      pe_scaffold_dna_info=pe_scaffold_dna_info, fastq_stream=fq)
-                fq.line_stats(ingest_stats)
-                n_reads = fq.n_reads
-                t_free = time.perf_counter()
-            if timings is not None:
-                timings["free_ingest"] = time.perf_counter() - t_free
-            res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
-            res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats.get('N_READS_AFTER_PREPROCESSING', int(n_reads))
-            return res
+    def reads_as_the_reference_counts_them(res, n_reads=None):
+        # non-empty lines / 4 of the input and of the text that was parsed (get_n_reads_fastq) -- these differ from the number of records
+        # only for files with blank lines or a truncated tail
+        res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT'] if n_reads is None else ingest_stats.get('N_READS_INPUT', int(n_reads))
+        res.stats['N_READS_AFTER_PREPROCESSING'] = (ingest_stats['N_READS_AFTER_PREPROCESSING'] if n_reads is None
+                                                    else ingest_stats.get('N_READS_AFTER_PREPROCESSING', int(n_reads)))
+        return res
+
+    def note(why):
         if timings is not None:
-            timings["host_parser_because"] = why_not
-    if sharded and not FORCE_HOST_STRAND_PLAN:
-        # sharded run: every rank uploads, frames and de-duplicates ITS byte range of the text (a plain file: that part of the file; BGZF:
-        # only the members that cover it are inflated; other compressed / filtered input: what the host inflated / filtered, sliced), the
-        # ranks all-gather their unique reads and reconcile them into the run's list (fastq_device.ingest_shard), and each aligns its range
-        # of that list.  Anything the kernels cannot take on ANY rank: the host parser below, on every rank alike (the vote is inside).
+            timings["host_parser_because"] = why
+    if (stream or sharded) and not FORCE_HOST_STRAND_PLAN:
+        # The text framed and de-duplicated on the device (fastq_device): a plain file as it lies on disk, BGZF members as they are inflated,
+        # other compressed or quality-filtered input after the host has inflated / filtered it into memory (fastq_device.IngestSource says
+        # which).  One process: the whole text under its upload, batch 1 running under it (_device_front).  Sharded: every rank uploads,
+        # frames and de-duplicates ITS byte range, the ranks all-gather their unique reads and reconcile them into the run's list
+        # (fastq_device.ingest_shard), each aligns its range of that list.  Anything the kernels cannot take (carriage returns, small files,
+        # ...; sharded: on ANY rank -- the vote is a collective): the host parser.
         import torch
         from . import fastq_device
-        ctx_ = ctx or _native.default_context()
-        dev_ = torch.device("cuda", device)
-        why_not = fastq_device.applicable(path, flt)
-        source, holder, bg = None, None, None
+        S = None
         try:
-            try:
-                if why_not is None:
-                    source = path
-                elif why_not.startswith("in memory:"):
-                    if why_not.startswith("in memory: compressed"):
-                        try:
-                            bg = _native.BgzfFile(path)
-                        except _native.NativeError:
-                            bg = None
-                    if bg is not None:
-                        if fastq_device.size_applicable(bg.text_bytes) is None:
-                            source = bg
-                    else:
-                        holder = _native.FastqStream(path, *flt)
-                        text = holder.text()
-                        if fastq_device.text_applicable(text) is None:
-                            if holder.filtered:
-                                ingest_stats["N_READS_INPUT"] = int(float(holder.lines_input()) / 4.0)
-                            source = text
-            except (_native.NativeError, OSError):
-                source = None
-            ing = None
-            # (every rank takes part in the vote, also one that has no source: the others would wait for it otherwise)
-            if C.all_reduce_max(1 if source is None else 0, dev_) == 0:
-                try:
-                    ing = fastq_device.ingest_shard(source, ctx_, dev_, timings=timings)
-                except fastq_device.DeviceIngestUnavailable as e:
+            S = fastq_device.IngestSource(path, flt)
+        except _native.NativeError:
+            if not sharded:
+                raise                                                 # (sharded: the vote below must still happen; the host parser raises it again)
+        try:
+            source = S.source if S is not None else None
+            if source is not None and S.filtered_lines_input is not None:
+                ingest_stats["N_READS_INPUT"] = int(float(S.filtered_lines_input) / 4.0)
+            if sharded:
+                dev_ = torch.device("cuda", device)
+                ing = None
+                if C.all_reduce_max(1 if source is None else 0, dev_) == 0:
+                    try:
+                        ing = fastq_device.ingest_shard(source, ctx or _native.default_context(), dev_, timings=timings)
+                    except fastq_device.DeviceIngestUnavailable as e:
+                        note(str(e))
+                if ing is not None:
+                    res = run(device_reads=ing, shard="mine")
+                    _native._line_stats(ingest_stats, ing["nonempty_lines"])
+                    res.ingest_route = "device, sharded by byte range"
+                    res.shard_ingest = {q: ing[q] for q in ("shard_bytes", "text_bytes", "shard_records", "shard_unique", "gathered_unique", "gathered_bytes")}
+                    return reads_as_the_reference_counts_them(res)
+                ingest_stats.pop("N_READS_INPUT", None)               # (sharded runs keep the one-batch host flow below)
+            else:
+                why_not = S.why_not
+                if source is not None:
+                    try:
+                        res = run(device_reads=source)
+                        _native._line_stats(ingest_stats, res.device_ingest["nonempty_lines"])
+                        res.ingest_route = S.route
+                        return reads_as_the_reference_counts_them(res)
+                    except fastq_device.DeviceIngestUnavailable as e:
+                        why_not = str(e)                              # (e.g. carriage returns: the host parser takes the file)
+                        ingest_stats.pop("N_READS_INPUT", None)
+                note(why_not)
+                fq = S.host_stream()                                  # parsed chunk by chunk on a host thread while the device aligns the chunks before
+                if fq is not None:
+                    res = run(fastq_stream=fq)
+                    fq.line_stats(ingest_stats)
+                    n_reads = fq.n_reads
+                    t_free = time.perf_counter()
+                    S.close()
                     if timings is not None:
-                        timings["host_parser_because"] = str(e)
+                        timings["free_ingest"] = time.perf_counter() - t_free
+                    return reads_as_the_reference_counts_them(res, n_reads)
         finally:
-            if holder is not None:
-                holder.close()
-            if bg is not None:
-                bg.close()
-        if ing is not None:
-            res = quantify_unique(None, None, None, refs, ref_names, aln_matrix, args, ctx=ctx, device=device, timings=timings,
-                                  pe_scaffold_dna_info=pe_scaffold_dna_info, device_reads=ing, shard="mine")
-            _native._line_stats(ingest_stats, ing["nonempty_lines"])
-            res.stats['N_READS_INPUT'] = ingest_stats['N_READS_INPUT']
-            res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats['N_READS_AFTER_PREPROCESSING']
-            res.ingest_route = "device, sharded by byte range"
-            res.shard_ingest = {q: ing[q] for q in ("shard_bytes", "text_bytes", "shard_records", "shard_unique", "gathered_unique", "gathered_bytes")}
-            return res
-        ingest_stats.pop("N_READS_INPUT", None)
+            if S is not None:
+                S.close()
     with _native.FastqUnique(path, *flt, stats=ingest_stats) as fq:      # views of the native arena: nothing is copied on the host
         arena, offsets, counts, n_reads = fq.arena, fq.offsets, fq.counts, fq.n_reads
         if timings is not None:
@@ -1292,8 +1237,4 @@ def quantify_fastq(path, refs, ref_names, aln_matrix, args, ctx=None, device=0, 
         t_free = time.perf_counter()
     if timings is not None:
         timings["free_ingest"] = time.perf_counter() - t_free
-    # as the reference counts them: non-empty lines / 4 of the input and of the text that was parsed (get_n_reads_fastq) -- these
-    # differ from the number of records only for files with blank lines or a truncated tail
-    res.stats['N_READS_INPUT'] = ingest_stats.get('N_READS_INPUT', int(n_reads))
-    res.stats['N_READS_AFTER_PREPROCESSING'] = ingest_stats.get('N_READS_AFTER_PREPROCESSING', int(n_reads))
-    return res
+    return reads_as_the_reference_counts_them(res, n_reads)

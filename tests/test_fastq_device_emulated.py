@@ -223,7 +223,7 @@ def test_fuzzed_text_without_any_structure(tmp_path, seed):
 # ---- paired input: fastq_device.ingest_pairs (c2_fq_lines4 / pair_lengths / pair_write / dedup kernels) vs the reference's lock-step loop ----
 def device_pairs(p1, p2):
     """-> (keys, counts, first qualities, {key: [quality pairs of all its occurrences, in file order]}, n_records) from what the kernels left"""
-    with emulated_fq_kernels(), FD._Source(str(p1)) as S1, FD._Source(str(p2)) as S2:
+    with emulated_fq_kernels(), FD.IngestSource(str(p1)) as S1, FD.IngestSource(str(p2)) as S2:
         assert S1.source is not None and S2.source is not None, (S1.why_not, S2.why_not)
         P = FD.ingest_pairs(S1.source, S2.source, None, torch.device("cpu"))
     ka, qa, ko, qo = P.d_keys.numpy(), P.d_quals.numpy(), P.key_off.numpy(), P.qual_off.numpy()
@@ -285,7 +285,7 @@ def test_pairs_framed_keyed_and_deduplicated_on_the_device(tmp_path, monkeypatch
     keys, counts, quals, _, _ = device_pairs(p1, p2)
     assert keys == ["ACGT+TCAA", "GGCC+AAGG"] and quals == ["IIII DCBA", "JJJJ HGFE"]
     p1.write_text("")                                                 # an empty file is the host parser's
-    with FD._Source(str(p1)) as S1:
+    with FD.IngestSource(str(p1)) as S1:
         assert S1.source is None and "0 bytes" in S1.why_not
 
 
@@ -296,11 +296,11 @@ def test_pairs_the_device_does_not_take_go_to_the_host_parser(tmp_path, monkeypa
     for bad2, why in (("@a\nACRT\n+\nIIII\n", "outside ACGTN_-"), ("@a\nAC+T\n+\nIIII\n", "outside ACGTN_-"), ("@a\nACGT\n+\nII I\n", "blank inside"),
                       ("@a\r\nACGT\r\n+\r\nIIII\r\n", "carriage returns")):
         p2.write_text(bad2)
-        with emulated_fq_kernels(), FD._Source(str(p1)) as S1, FD._Source(str(p2)) as S2:
+        with emulated_fq_kernels(), FD.IngestSource(str(p1)) as S1, FD.IngestSource(str(p2)) as S2:
             with pytest.raises(FD.DeviceIngestUnavailable, match=why):
                 FD.ingest_pairs(S1.source, S2.source, None, torch.device("cpu"))
     p2.write_text("@a\nACGT\n+\nIIII\n")
     p1.write_text("@a\nAC+T\n+\nIIII\n")
-    with emulated_fq_kernels(), FD._Source(str(p1)) as S1, FD._Source(str(p2)) as S2:
+    with emulated_fq_kernels(), FD.IngestSource(str(p1)) as S1, FD.IngestSource(str(p2)) as S2:
         with pytest.raises(FD.DeviceIngestUnavailable, match="'\\+' inside a read"):
             FD.ingest_pairs(S1.source, S2.source, None, torch.device("cpu"))
