@@ -62,7 +62,7 @@ VALU_SIMD32_WAVE_INSTR_PER_S = N_SIMD * CLOCK_HZ / 2.0
 VALU_MEASURED_CYCLES_PER_INSTR = 4.15
 VALU_FULL_RATE_CYCLES_PER_INSTR = 2.3
 VALU_MEASURED_SOURCE = "profiles/r03/valu_microbench4.txt (tools/valu_microbench4.hip, cycles from GRBM_GUI_ACTIVE; clock 2.40 GHz)"
-PROFILE_ROUNDS = ["r03", "r02"]                 # the PMC summary of the newest round that has one
+PROFILE_ROUNDS = ["r04", "r03", "r02"]                 # the PMC summary of the newest round that has one
 GO, GE, MIN_ALN_SCORE = -20, -2, 60.0
 
 CONFIG_DEFAULTS = {2: (150, 1_000_000), 3: (250, 10_000_000), 4: (250, 10_000_000), 5: (250, 12_500_000)}
