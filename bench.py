@@ -43,6 +43,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -862,92 +863,10 @@ def main():
 
     # ---------- after the headline: the int32 chain on the same batch, the other BASELINE shapes, FASTQ -> tensors ----------
     int32_chain = other_configs = e2e = None
-    if extras:
-        # the same reads, buffers and step with the 32-bit kernels only (the reference's DP is C int, pyx:142-147): all ranks take part
-        ctx.set_kernel_mode("diag4")
-        job.kernel = "diag4"
-        t32 = job.timed(1, args.extra_steps)
-        rec32_same = bool(torch.equal(job.outputs[2].cpu(), torch.from_numpy(rec.view(np.uint8).reshape(-1, 32))))
-        int32_chain = {"reads_per_s": t32["reads_per_s"], "ms_per_step": 1e3 * t32["dt"] / args.extra_steps, "steps": args.extra_steps,
-                       "kernel_chain": chain_names["diag4"] + [chain[-1]], "dtype": "int32",
-                       "tasks_left_after_each_banded_launch": ctx.tier_info(), "align_chain_ms": t32["align_ms"],
-                       "records_equal_the_packed_chain": rec32_same,
-                       "note": "c2_set_kernel_mode(diag4): the same batch, buffers and step as the headline with every DP cell in int32"}
-        ctx.set_kernel_mode(args.kernel)
-        job.kernel = args.kernel
-    job.free()
-    del job, d_aln_read, d_aln_ref, d_records
-    torch.cuda.empty_cache()
-    if extras:
-        other_configs = {"data_generation_s": t_gen_other}
-        for cfg, (Lc, wlc) in sorted(other_wl.items()):
-            try:
-                jc = Job(ctx, wlc, Lc, m, dev, world, kernel="auto")
-                tc = jc.timed(1, args.extra_steps)
-                tiers_c = ctx.tier_info()
-                rec_c = jc.outputs[2].cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
-                entry = {"workload": wlc["text"], "reads_per_gpu_per_step": jc.n, "alignments_per_gpu_per_step": jc.n_tasks, "n_amplicons": jc.k,
-                         "steps": args.extra_steps, "ms_per_step": 1e3 * tc["dt"] / args.extra_steps, "reads_per_s": tc["reads_per_s"],
-                         "alignments_per_s": tc["alignments_per_s"],
-                         "step_breakdown_ms": {"align_chain": tc["align_ms"], "select_best": tc["select_ms"], "count_vectors_and_all_reduce": tc["count_ms"]},
-                         "tasks_left_after_each_banded_launch": tiers_c, "all_status_ok": bool((rec_c["status"] == 0).all())}
-                if cfg in other_ref:
-                    leg_c, kind_c = other_ref[cfg]
-                    if "error" in leg_c:
-                        entry["reference_check_error"] = leg_c["error"]
-                    else:
-                        cmp_n, same_n = _compare_with_reference([leg_c], jc.outputs[0], jc.outputs[1], rec_c, jc.k, jc.all_refs)
-                        entry["reference_compared_n"], entry["reference_identical_n"] = cmp_n, same_n
-                        entry["reference_identical"] = bool(cmp_n == same_n)
-                        entry["reference_check"] = {"kind": kind_c, "procs": leg_c["procs"], "seconds": leg_c["seconds"],
-                                                    "note": "the first reads of this configuration aligned by the reference's compiled code (oracle/_ref) on the "
-                                                            "host before the timed region; strings by digest + the best alignment's three window counts"}
-                del rec_c
-                if rank == 0 and args.check > 0 and not args.no_full_plane_check:
-                    eq, tf = jc.chain_equals_full_plane()
-                    entry["chain_equals_full_plane_n"] = eq
-                    entry["chain_equals_full_plane"] = bool(eq == jc.n_tasks)
-                tl = jc.tallies()
-                entry["reads_aligned_all_gpus"] = int(sum(t_["counts_total"] for t_ in tl))
-                entry["modified"] = int(sum(t_["counts_modified"] for t_ in tl))
-                if jc.all_refs:
-                    entry["selection"] = dict(zip(C.SELECT_STATS, jc.d_selstats.cpu().numpy().tolist()))
-                jc.free()
-                del jc
-            except Exception as e:                                   # (a side leg reports its failure; collectives inside it would hang the
-                entry = {"error": repr(e)}                           #  other ranks only if one rank alone failed -- then the launcher ends the job)
-                if world > 1:
-                    raise
-            other_configs["config%d" % cfg] = entry
-        del other_wl
-        if world > 1:
-            # the sharded FASTQ leg: rank 0 wrote the file (same node: /dev/shm), every rank ingests its byte range of it
-            box = [None if (e2e_files is None or "skipped" in e2e_files) else (e2e_files["plain"], e2e_files["reads"])]
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is not None:
-                try:
-                    e2e = {"sharded": _e2e_sharded_leg(box[0][0], box[0][1], ctx, L, m, dev)}
-                except Exception as e:
-                    e2e = {"sharded": {"error": repr(e)}}
-                    raise
-                finally:
-                    dist.barrier()
-                    if rank == 0:
-                        shutil.rmtree(e2e_files["dir"], ignore_errors=True)
-            elif e2e_files is not None:
-                e2e = e2e_files
-        elif e2e_files is not None:
-            if "skipped" in e2e_files:
-                e2e = e2e_files
-            else:
-                try:
-                    e2e = _e2e_leg(e2e_files, ctx, L, m)
-                except Exception as e:
-                    e2e = {"error": repr(e)}
-                finally:
-                    shutil.rmtree(e2e_files["dir"], ignore_errors=True)
+    extras_done = threading.Event()
+    extras_note = [None]
 
-    if rank == 0:
+    def emit(file=None):
         total_reads = world * n * args.steps
         out = {
             "metric": "aligned+classified reads/sec (whole node), %d bp reads vs %d bp amplicon" % (L, L),
@@ -1025,8 +944,129 @@ def main():
             out["selection"] = selection
         if cpu_baseline:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_baseline["value"]
-        print(json.dumps(out))
-        sys.stdout.flush()
+        if extras_note[0]:
+            out["side_legs_note"] = extras_note[0]
+        print(json.dumps(out), file=file or sys.stdout)
+        (file or sys.stdout).flush()
+
+    if extras and world > 1:
+        # The side legs below hold collectives.  Whatever happens in them on any rank -- an exception on one rank leaves the others waiting in
+        # a collective -- must not cost the headline that was already measured: every rank runs a watchdog; when the legs have not finished
+        # within C2_BENCH_EXTRAS_TIMEOUT seconds, rank 0 prints the line with what there is and every rank ends with exit code 0.
+        limit = float(os.environ.get("C2_BENCH_EXTRAS_TIMEOUT", "600"))
+
+        def watchdog():
+            if extras_done.wait(limit):
+                return
+            if rank == 0:
+                extras_note[0] = "the side legs did not finish within %.0f s on every rank (%s): the line carries what was there" % (limit, extras_note[0] or "no error on rank 0")
+                try:
+                    emit(sys.__stdout__)
+                finally:
+                    os._exit(0)
+            time.sleep(5.0)                                           # (rank 0 prints first)
+            os._exit(0)
+        threading.Thread(target=watchdog, name="c2-bench-extras-watchdog", daemon=True).start()
+
+    def side_leg_failed(e):
+        """world > 1: this rank cannot go on with the side legs (the others may be waiting for it in a collective): say why and wait for the watchdog"""
+        sys.stderr.write("bench.py rank %d: a side leg failed: %r\n" % (rank, e))
+        sys.stderr.flush()
+        extras_note[0] = repr(e)
+        threading.Event().wait()
+    try:
+        if extras:
+            # the same reads, buffers and step with the 32-bit kernels only (the reference's DP is C int, pyx:142-147): all ranks take part
+            ctx.set_kernel_mode("diag4")
+            job.kernel = "diag4"
+            t32 = job.timed(1, args.extra_steps)
+            rec32_same = bool(torch.equal(job.outputs[2].cpu(), torch.from_numpy(rec.view(np.uint8).reshape(-1, 32))))
+            int32_chain = {"reads_per_s": t32["reads_per_s"], "ms_per_step": 1e3 * t32["dt"] / args.extra_steps, "steps": args.extra_steps,
+                           "kernel_chain": chain_names["diag4"] + [chain[-1]], "dtype": "int32",
+                           "tasks_left_after_each_banded_launch": ctx.tier_info(), "align_chain_ms": t32["align_ms"],
+                           "records_equal_the_packed_chain": rec32_same,
+                           "note": "c2_set_kernel_mode(diag4): the same batch, buffers and step as the headline with every DP cell in int32"}
+            ctx.set_kernel_mode(args.kernel)
+            job.kernel = args.kernel
+        job.free()
+        del job, d_aln_read, d_aln_ref, d_records
+        torch.cuda.empty_cache()
+        if extras:
+            other_configs = {"data_generation_s": t_gen_other}
+            for cfg, (Lc, wlc) in sorted(other_wl.items()):
+                try:
+                    jc = Job(ctx, wlc, Lc, m, dev, world, kernel="auto")
+                    tc = jc.timed(1, args.extra_steps)
+                    tiers_c = ctx.tier_info()
+                    rec_c = jc.outputs[2].cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+                    entry = {"workload": wlc["text"], "reads_per_gpu_per_step": jc.n, "alignments_per_gpu_per_step": jc.n_tasks, "n_amplicons": jc.k,
+                             "steps": args.extra_steps, "ms_per_step": 1e3 * tc["dt"] / args.extra_steps, "reads_per_s": tc["reads_per_s"],
+                             "alignments_per_s": tc["alignments_per_s"],
+                             "step_breakdown_ms": {"align_chain": tc["align_ms"], "select_best": tc["select_ms"], "count_vectors_and_all_reduce": tc["count_ms"]},
+                             "tasks_left_after_each_banded_launch": tiers_c, "all_status_ok": bool((rec_c["status"] == 0).all())}
+                    if cfg in other_ref:
+                        leg_c, kind_c = other_ref[cfg]
+                        if "error" in leg_c:
+                            entry["reference_check_error"] = leg_c["error"]
+                        else:
+                            cmp_n, same_n = _compare_with_reference([leg_c], jc.outputs[0], jc.outputs[1], rec_c, jc.k, jc.all_refs)
+                            entry["reference_compared_n"], entry["reference_identical_n"] = cmp_n, same_n
+                            entry["reference_identical"] = bool(cmp_n == same_n)
+                            entry["reference_check"] = {"kind": kind_c, "procs": leg_c["procs"], "seconds": leg_c["seconds"],
+                                                        "note": "the first reads of this configuration aligned by the reference's compiled code (oracle/_ref) on the "
+                                                                "host before the timed region; strings by digest + the best alignment's three window counts"}
+                    del rec_c
+                    if rank == 0 and args.check > 0 and not args.no_full_plane_check:
+                        eq, tf = jc.chain_equals_full_plane()
+                        entry["chain_equals_full_plane_n"] = eq
+                        entry["chain_equals_full_plane"] = bool(eq == jc.n_tasks)
+                    tl = jc.tallies()
+                    entry["reads_aligned_all_gpus"] = int(sum(t_["counts_total"] for t_ in tl))
+                    entry["modified"] = int(sum(t_["counts_modified"] for t_ in tl))
+                    if jc.all_refs:
+                        entry["selection"] = dict(zip(C.SELECT_STATS, jc.d_selstats.cpu().numpy().tolist()))
+                    jc.free()
+                    del jc
+                except Exception as e:                                   # (a side leg reports its failure; with several ranks the others may be waiting in a
+                    entry = {"error": repr(e)}                           #  collective: this rank waits for the watchdog, which still prints the headline)
+                    if world > 1:
+                        other_configs["config%d" % cfg] = entry
+                        side_leg_failed(e)
+                other_configs["config%d" % cfg] = entry
+            del other_wl
+            if world > 1:
+                # the sharded FASTQ leg: rank 0 wrote the file (same node: /dev/shm), every rank ingests its byte range of it
+                box = [None if (e2e_files is None or "skipped" in e2e_files) else (e2e_files["plain"], e2e_files["reads"])]
+                dist.broadcast_object_list(box, src=0)
+                if box[0] is not None:
+                    try:
+                        e2e = {"sharded": _e2e_sharded_leg(box[0][0], box[0][1], ctx, L, m, dev)}
+                    except Exception as e:
+                        e2e = {"sharded": {"error": repr(e)}}
+                        side_leg_failed(e)
+                    dist.barrier()
+                    if rank == 0:
+                        shutil.rmtree(e2e_files["dir"], ignore_errors=True)
+                elif e2e_files is not None:
+                    e2e = e2e_files
+            elif e2e_files is not None:
+                if "skipped" in e2e_files:
+                    e2e = e2e_files
+                else:
+                    try:
+                        e2e = _e2e_leg(e2e_files, ctx, L, m)
+                    except Exception as e:
+                        e2e = {"error": repr(e)}
+                    finally:
+                        shutil.rmtree(e2e_files["dir"], ignore_errors=True)
+
+    except Exception as e:                                       # (one rank alone in trouble: the others wait in a collective; see the watchdog)
+        if world == 1:
+            raise
+        side_leg_failed(e)
+    extras_done.set()
+    if rank == 0:
+        emit()
     if world > 1:
         dist.destroy_process_group()
 
