@@ -275,13 +275,16 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 #ifndef C2_CNT_STAGE
 #define C2_CNT_STAGE 2
 #endif
+#ifndef C2_CNT_SWAR
+#define C2_CNT_SWAR 1                  // alignments with gaps that fit a slot: eight columns per lane in one pass (0: the 64-column chunk walk for all of them)
+#endif
 #ifndef C2_CNT_STAGE_ROW
-#define C2_CNT_STAGE_ROW 256           // a multiple of 64
+#define C2_CNT_STAGE_ROW 320           // a multiple of 64: a 250-bp read with up to 70 gap columns is walked in one pass (eight columns per lane)
 #endif
 #define C2_CNT_STAGE_BYTES ((size_t)C2_CNT_WAVES * C2_CNT_STAGE * 2u * C2_CNT_STAGE_ROW)
 // LDS of the variant whose accumulator block lives in HBM: the difference array, the control words, the window prefix, the staging slots
-static inline size_t c2_count_lds_tail_bytes(int lmax) {               // what follows the block: cov, control words, inc_prefix (padded to 16), staging
-    return ((((size_t)lmax + 1) + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4 + 15) / 16 * 16 + C2_CNT_STAGE_BYTES;
+static inline size_t c2_count_lds_tail_bytes(int lmax) {               // what follows the block: cov, dcov, control words, inc_prefix (padded to 16), staging
+    return ((2 * ((size_t)lmax + 1) + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)lmax + 2 + 1) / 2) * 4 + 15) / 16 * 16 + C2_CNT_STAGE_BYTES;
 }
 static inline size_t c2_count_lds_bytes_hbm(int lmax) { return c2_count_lds_tail_bytes(lmax); }
 static inline size_t c2_count_lds_bytes(size_t per_ref, int lmax) {      // block + the LDS-only `cov` vector (lmax + 1) + control words + inc_prefix + staging

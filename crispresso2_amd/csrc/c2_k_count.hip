@@ -114,13 +114,16 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
     // cov: difference array over the reference positions of "weight of the alignments whose read base EQUALS the reference's here" --
     // runs of matching columns add +w at their first position and -w behind their last; flush() integrates it and adds every
     // position's total to the count vector of the reference's own base there (an LDS-only vector, not part of the tensor)
+    // dcov: the same for "weight of the alignments that have a DELETION column here" (walk of eight columns per lane): a deletion adds +w at its
+    // first reference position and -w behind its last; flush() adds the integrated totals to all_deletion and to the '-' base counts
     int* cov = HBM ? (int*)c2_smem : acc + per_ref;
-    int* ctl = cov + VL;                                        // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
+    int* dcov = cov + VL;
+    int* ctl = dcov + VL;                                        // [0..1] chunk base, [2..] chunk weight per wave, [16..] two sets of (ref, task) per wave
     uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
     // staging slots of the wavefronts (c2_count_lds_tail_bytes: behind cov, the control words and inc_prefix, that part padded to 16 bytes)
-    uint8_t* stage = (uint8_t*)cov + ((((size_t)VL + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)A.lmax + 2 + 1) / 2) * 4 + 15) / 16 * 16);
+    uint8_t* stage = (uint8_t*)cov + (((2 * (size_t)VL + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)A.lmax + 2 + 1) / 2) * 4 + 15) / 16 * 16);
     for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
-    for (int k = tid; k < VL; k += NT) cov[k] = 0;
+    for (int k = tid; k < 2 * VL; k += NT) cov[k] = 0;                 // (cov and dcov)
     block_barrier();
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
     const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
@@ -136,8 +139,9 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
         if (cur_ref < 0) return;
         block_barrier();
         // deletion vectors were accumulated as difference arrays (start += x, end -= x): integrate them first
-        if (wave < 3) {
-            int* d = wave == 2 ? cov : acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
+        static_assert(C2_CNT_WAVES >= 4, "four difference arrays are integrated by four wavefronts");
+        if (wave < 4) {
+            int* d = wave == 3 ? dcov : wave == 2 ? cov : acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
             int carry = 0;
             for (int base = 0; base < VL; base += 64) {
                 const int k = base + lane;
@@ -155,11 +159,15 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
             {   // ... plus, per position, the weight of the alignments with gaps whose read matches the reference there (cov, integrated above)
                 const uint8_t* rs = A.refs[cur_ref].seq;
                 for (int c = tid; c < VL; c += NT) {
-                    const int x = g + cov[c];
-                    cov[c] = 0;
+                    const int x = g + cov[c], dx = dcov[c];
+                    cov[c] = 0; dcov[c] = 0;
                     if (c < Li && x != 0) {
                         const int bv = c2_base_vector(rs[c]);
                         if (bv >= 0) acc[bv * VL + c] += x;
+                    }
+                    if (c < Li && dx != 0) {                                 // deletion columns: all_deletion (:4028) and the '-' base count (:4075-4081)
+                        acc[C2_V_ALL_DELETION * VL + c] += dx;
+                        acc[C2_V_BASE_GAP * VL + c] += dx;
                     }
                 }
                 if (tid == 0) acc[o_sc + C2_S_RESERVED0] = 0;
@@ -413,6 +421,140 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
                 const bool modified = has_del || has_ins || has_sub;
                 const bool len_block = modified;                                                // :4085 (no coding sequence)
+                if (C2_CNT_SWAR && T <= C2_CNT_STAGE_ROW) {
+                    // ---- An alignment with gaps that lies in its slot as a whole (the usual case): EIGHT columns per lane, classified as the bytes of
+                    //      64-bit words (gap / same / different masks by the zero-byte trick), one pass instead of one 64-column chunk after the other.
+                    //      Columns where nothing happens cost nothing beyond that; runs of matching columns touch `cov` at their two ends, a
+                    //      mismatch adds its base, and everything a gap run adds is added by the lane that holds the column BEHIND the run -- it
+                    //      finds the run's length by walking back over the staged string, so no state travels between lanes except the
+                    //      reference-index prefix and one flag byte of the neighbours.
+                    typedef unsigned long long u64;
+                    const u64 H = 0x8080808080808080ull, L7 = 0x7f7f7f7f7f7f7f7full, DASH = 0x2d2d2d2d2d2d2d2dull;
+                    const int p = 8 * lane, nb = T - p;                                             // this lane: columns p .. p + 7, nb of them inside the alignment
+                    u64 RD = 0, RF = 0;
+                    if (nb > 0) { RD = *(const u64*)(SR + p); RF = *(const u64*)(SF + p); }
+                    const u64 vm = nb >= 8 ? H : (nb > 0 ? (H & ((1ull << (8 * nb)) - 1ull)) : 0ull);
+                    auto nz = [&](const u64 x) { return (((x & L7) + L7) | x) & H; };             // bit 7 of every non-zero byte
+                    const u64 g_rd = ~nz(RD ^ DASH) & vm, g_rf = ~nz(RF ^ DASH) & vm;              // gap columns of the read / of the reference
+                    const u64 ng_rf = vm & ~g_rf;                                                   // columns that have a reference base
+                    const u64 same = ng_rf & ~nz(RD ^ RF);                                          // ... and the read's base is that base
+                    // reference index of the lane's first column: 8 * lane minus the reference's gap columns in the lanes below
+                    int idx_lane = p;
+                    {
+                        const int gcnt = __popcll(g_rf);
+                        if (__ballot(gcnt != 0) != 0ull) {
+                            int below = 0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) below += __popcll(__ballot((gcnt >> q) & 1) & lt) << q;
+                            idx_lane -= below;
+                        }
+                    }
+                    auto idx_of = [&](const int b) { return idx_lane + __popcll(ng_rf & ((1ull << (8 * b)) - 1ull)); };
+                    // the neighbours: the lane below's last column (same / read gap / reference gap), the lane above's first (same)
+                    int prev = __shfl_up((int)((same >> 63) | ((g_rd >> 63) << 1) | ((g_rf >> 63) << 2)), 1);
+                    if (lane == 0) prev = 0;
+                    int next_same = __shfl_down((int)((same >> 7) & 1ull), 1);
+                    if (lane == 63) next_same = 0;
+                    {   // all_base_count of the matching columns (:4075-4081): +w where a run of them starts, -w behind its end (see flush)
+                        u64 starts = same & ~((same << 8) | ((prev & 1) ? 0x80ull : 0ull));
+                        u64 ends = same & ~((same >> 8) | (next_same ? (0x80ull << 56) : 0ull));
+                        while (starts) { const int b = __builtin_ctzll(starts) >> 3; starts &= starts - 1ull; atomicAdd(cov + idx_of(b), w); }
+                        while (ends) { const int b = __builtin_ctzll(ends) >> 3; ends &= ends - 1ull; atomicAdd(cov + idx_of(b) + 1, -w); }
+                    }
+                    {   // columns where read and reference both have a base and differ
+                        u64 mm = ng_rf & ~g_rd & ~same;
+                        while (mm) {
+                            const int b = __builtin_ctzll(mm) >> 3;
+                            mm &= mm - 1ull;
+                            const int ix = idx_of(b);
+                            const unsigned char rd = (unsigned char)(RD >> (8 * b));
+                            const int bv = c2_base_vector(rd);
+                            if (bv >= 0) atomicAdd(acc + bv * VL + ix, w);
+                            if (rd != 'N') {
+                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + ix, w);                // :4040
+                                if (!ign_sub) {
+                                    if (incp[ix + 1] != incp[ix]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + ix, w);   // :4044
+                                    const int sv = c2_sub_base_vector(rd);                          // :4049-4054
+                                    if (sv >= 0) atomicAdd(acc + sv * VL + ix, w);
+                                }
+                            }
+                        }
+                    }
+                    // the column behind a gap run: a reference base behind an insertion, a read base behind a deletion
+                    u64 ic = ng_rf & ((g_rf << 8) | ((prev & 4) ? 0x80ull : 0ull));
+                    u64 dc = (vm & ~g_rd) & ((g_rd << 8) | ((prev & 2) ? 0x80ull : 0ull));
+                    const bool tail = nb >= 1 && nb <= 8 && ((g_rd >> (8 * (nb - 1) + 7)) & 1ull);  // the alignment ends in a deletion: this lane holds its last column
+                    if (__ballot((ic | dc) != 0ull || tail) != 0ull) {
+                        while (ic) {
+                            // insertions: positions [idx-1, idx] of every event; numpy's fancy += counts a repeated position once (:4016, :4021)
+                            const int b = __builtin_ctzll(ic) >> 3;
+                            ic &= ic - 1ull;
+                            const int ix = idx_of(b), c = p + b;
+                            if (ix <= 0) continue;                                                  // (an insertion in front of the first reference base is none)
+                            int k = c - 2;                                                          // (column c - 1 is a gap of the reference)
+                            while (k >= 0 && SF[k] == '-') --k;                                     // the reference base in front of the insertion
+                            // ... was it the end of an insertion itself?  Then position idx - 1 has been counted by that event
+                            const bool prev_close = k >= 1 && SF[k - 1] == '-' && ix - 1 > 0;
+                            const bool fl = incp[ix] != incp[ix - 1], fr = incp[ix + 1] != incp[ix];
+                            const bool ins_win = legacy ? (fl || fr) : (fl && fr);                  // pyx:121 / legacy pyx:284
+                            bool prev_wclose = false;
+                            if (prev_close) {
+                                const bool pl = incp[ix - 1] != incp[ix - 2];                       // (fl of that event; its fr is this one's fl)
+                                prev_wclose = legacy ? (pl || fl) : (pl && fl);
+                            }
+                            atomicAdd(acc + C2_V_ALL_INSERTION_LEFT * VL + ix - 1, w);              // :4017
+                            atomicAdd(acc + C2_V_ALL_INSERTION * VL + ix, w);
+                            if (!prev_close) atomicAdd(acc + C2_V_ALL_INSERTION * VL + ix - 1, w);
+                            if (ins_win) {
+                                if (!ign_ins) {
+                                    atomicAdd(acc + C2_V_INSERTION * VL + ix, w);
+                                    if (!prev_wclose) atomicAdd(acc + C2_V_INSERTION * VL + ix - 1, w);
+                                }
+                                if (len_block) {                                                    // :4104-4106 (scalar index: repeats add twice)
+                                    const int sz = (c - 1 - k) * w;
+                                    atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + ix - 1, sz);
+                                    atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + ix, sz);
+                                }
+                            }
+                        }
+                        while (dc) {
+                            const int b = __builtin_ctzll(dc) >> 3;
+                            dc &= dc - 1ull;
+                            const int ix = idx_of(b), c = p + b;
+                            int k = c - 2;                                                          // (column c - 1 is a gap of the read)
+                            while (k >= 0 && SR[k] == '-') --k;                                     // the read base in front of the deletion
+                            const int dlen = c - 1 - k;
+                            atomicAdd(dcov + ix - dlen, w);                                         // its columns: all_deletion (:4028) and '-' base counts, as a range
+                            atomicAdd(dcov + ix, -w);
+                            // legacy (pyx:253-258): a run that starts in column 0 or 1 gets reference start 0 -- position 0 joins its
+                            // positions although the read has a base there
+                            const int dstart = (legacy && k <= 0) ? 0 : ix - dlen;
+                            if (legacy && k == 0) atomicAdd(acc + C2_V_ALL_DELETION * VL + 0, w);
+                            if (incp[ix] != incp[dstart]) {                                         // deletions that touch the window: range(start, end) as a difference array
+                                if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + dstart, w); atomicAdd(acc + C2_V_DELETION * VL + ix, -w); }   // :4031
+                                if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + ix, -dlen * w); }   // :4114
+                            }
+                        }
+                        if (tail) {                                                                 // trailing deletion, pyx:155-162
+                            int k = T - 2;
+                            while (k >= 0 && SR[k] == '-') --k;
+                            const int dlen = T - 1 - k, idx_end = idx_lane + __popcll(ng_rf);       // (idx_end: the reference bases of the whole alignment)
+                            atomicAdd(dcov + idx_end - dlen, w);
+                            atomicAdd(dcov + idx_end, -w);
+                            // legacy (pyx:259-261): the run ends at reference index idx - 1, exclusive -- the last base is not among its positions
+                            const int dstart = (legacy && k <= 0) ? 0 : idx_end - dlen, dend = legacy ? idx_end - 1 : idx_end;
+                            if (legacy) {
+                                atomicAdd(acc + C2_V_ALL_DELETION * VL + idx_end - 1, -w);
+                                if (k == 0) atomicAdd(acc + C2_V_ALL_DELETION * VL + 0, w);
+                            }
+                            if (dend > dstart && incp[dend] != incp[dstart]) {
+                                if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + dstart, w); atomicAdd(acc + C2_V_DELETION * VL + dend, -w); }
+                                if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dstart, dlen * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + dend, -dlen * w); }
+                            }
+                        }
+                    }
+                    continue;
+                }
                 // ---- column walk (same scan as the fused classifier), ds_add into the vectors
                 int idx_base = 0, last_rf = -1, last_rd = -1;
                 bool last_rf_close = false, last_rf_wclose = false;
