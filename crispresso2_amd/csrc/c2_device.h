@@ -273,10 +273,13 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
 // which is what the kernel waits for (profiles/r03: 65 % of its wave cycles).  A slot holds C2_CNT_STAGE_ROW columns of both strings;
 // longer alignments are walked window by window.
 #ifndef C2_CNT_STAGE
-#define C2_CNT_STAGE 2
+#define C2_CNT_STAGE 1
 #endif
 #ifndef C2_CNT_SWAR
 #define C2_CNT_SWAR 1                  // alignments with gaps that fit a slot: eight columns per lane in one pass (0: the 64-column chunk walk for all of them)
+#endif
+#ifndef C2_CNT_GROUPED
+#define C2_CNT_GROUPED 1               // gap-free alignments of at most 256 columns: eight at a time, eight lanes each (0: one at a time, staged)
 #endif
 #ifndef C2_CNT_STAGE_ROW
 #define C2_CNT_STAGE_ROW 320           // a multiple of 64: a 250-bp read with up to 70 gap columns is walked in one pass (eight columns per lane)

@@ -128,6 +128,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS;
     const bool ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS, discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
     const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);   // string rows readable as dwords
+    const bool rows_aligned16 = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 15u) == 0) && ((A.aln_stride & 15u) == 0);   // ... as 16-byte words
     const bool legacy = A.flags & C2_CNT_FLAG_LEGACY;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int cur_ref = -1;                                           // workgroup-uniform, like everything that guards a barrier
@@ -348,6 +349,73 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                     }
                 }
             };
+            // ---- the gap-free alignments of the round that are no longer than 256 columns (most reads of an amplicon run): EIGHT of them at a
+            //      time, eight lanes each -- a lane loads 32 columns of both strings (two 16-byte loads per string: eight lanes cover a row
+            //      contiguously) and finds the differing columns as the non-zero bytes of four 64-bit XORs.  Nothing is staged, no record field
+            //      travels through a scalar register, and eight alignments' loads are in flight per wavefront.  Like the one-at-a-time walk
+            //      below it adds only the DEVIATIONS from the reference (+w on the read's base, -w on the reference's) and the weight to the
+            //      scalar that flush() spreads over the reference's own bases.
+            if (C2_CNT_GROUPED && rows_aligned16) {
+                const unsigned gfm = (unsigned)__ballot(lane < K && ((walk >> (lane & (K - 1))) & 1u) && (int)(d0 & 0xffffu) == Li && (d4 >> 16) == 0u &&
+                                                        (d0 & 0xffffu) <= 256u);
+                if (gfm) {
+                    typedef unsigned long long u64;
+                    walk &= ~gfm;
+                    const bool gf_mine = lane < K && ((gfm >> (lane & (K - 1))) & 1u);
+                    if (gf_mine) atomicAdd(acc + o_sc + C2_S_RESERVED0, v_w);
+                    // the q-th of them sits in lane tab[q] (the wavefront's staging area is free here)
+                    C2_LDS_READS_DONE();
+                    if (gf_mine) stage_w[__popcll((unsigned long long)(gfm & ((1u << (lane & (K - 1))) - 1u)))] = (uint8_t)lane;
+                    C2_LDS_READS_DONE();
+                    const int ng = __popcll((unsigned long long)gfm), grp = lane >> 3, p0 = 32 * (lane & 7);
+                    const u64 H = 0x8080808080808080ull, L7 = 0x7f7f7f7f7f7f7f7full;
+                    for (int q0 = 0; q0 < ng; q0 += 8) {
+                        const bool on = q0 + grp < ng;
+                        const int src = on ? (int)stage_w[q0 + grp] : 0;
+                        const uint64_t task = (uint64_t)(unsigned)__shfl((int)(unsigned)(my_task & 0xffffffffull), src) |
+                                              ((uint64_t)(unsigned)__shfl((int)(unsigned)(my_task >> 32), src) << 32);
+                        const int w = __shfl(v_w, src);
+                        const int nbytes = on ? Li - p0 : 0;                                        // columns of this lane inside the alignment
+                        u64 RD[4] = {0ull, 0ull, 0ull, 0ull}, RF[4] = {0ull, 0ull, 0ull, 0ull};
+                        if (nbytes > 0) {
+                            const uint8_t* R_ = A.aln_read + task * (uint64_t)A.aln_stride + p0;
+                            const uint8_t* F_ = A.aln_ref + task * (uint64_t)A.aln_stride + p0;
+                            const uint4 a = *(const uint4*)R_, b = *(const uint4*)F_;
+                            RD[0] = (u64)a.x | ((u64)a.y << 32); RD[1] = (u64)a.z | ((u64)a.w << 32);
+                            RF[0] = (u64)b.x | ((u64)b.y << 32); RF[1] = (u64)b.z | ((u64)b.w << 32);
+                            if (nbytes > 16) {
+                                const uint4 c = *(const uint4*)(R_ + 16), d = *(const uint4*)(F_ + 16);
+                                RD[2] = (u64)c.x | ((u64)c.y << 32); RD[3] = (u64)c.z | ((u64)c.w << 32);
+                                RF[2] = (u64)d.x | ((u64)d.y << 32); RF[3] = (u64)d.z | ((u64)d.w << 32);
+                            }
+                        }
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) {
+                            const int nb = nbytes - 8 * k8;
+                            const u64 vm = nb >= 8 ? H : (nb > 0 ? (H & ((1ull << (8 * nb)) - 1ull)) : 0ull);
+                            const u64 x = RD[k8] ^ RF[k8];
+                            u64 mm = (((x & L7) + L7) | x) & vm;
+                            while (mm) {
+                                const int bb = __builtin_ctzll(mm) >> 3;
+                                mm &= mm - 1ull;
+                                const int c = p0 + 8 * k8 + bb;
+                                const unsigned char rd = (unsigned char)(RD[k8] >> (8 * bb)), rfc = (unsigned char)(RF[k8] >> (8 * bb));
+                                const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
+                                if (bvr >= 0) atomicAdd(acc + bvr * VL + c, w);
+                                if (bvf >= 0) atomicAdd(acc + bvf * VL + c, -w);
+                                if (rd != 'N') {
+                                    atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);             // :4040
+                                    if (!ign_sub) {
+                                        if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);   // :4044
+                                        const int sv = c2_sub_base_vector(rd);                      // :4049-4054
+                                        if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
             while (walk) {
                 unsigned batch = 0;
                 C2_LDS_READS_DONE();                                                                // (the slots are free: every lane has read what it needed of them)

@@ -206,8 +206,8 @@ def test_count_vectors_with_the_accumulator_block_in_hbm(aligned, flags, monkeyp
 
 @pytest.mark.parametrize("L,shift", [(300, 0), (560, 0), (700, 0), (300, 1)])
 def test_alignments_longer_than_a_staging_window(L, shift):
-    """The count kernel stages C2_CNT_STAGE_ROW (256) columns of an alignment's strings in LDS at a time: amplicons of 300 / 560 / 700 bp
-    give alignments of 2 and 3 windows -- gap-free reads (dword walk), deletions and insertions that straddle a window's edge (the walk's
+    """The count kernel stages C2_CNT_STAGE_ROW (320) columns of an alignment's strings in LDS at a time: amplicons of 300 / 560 / 700 bp
+    give alignments of one window (the eight-columns-per-lane walk, beyond 256 columns), 2 and 3 windows (the 64-column chunk walk) -- gap-free reads (dword walk), deletions and insertions that straddle a window's edge (the walk's
     carried state), a trailing deletion; shift 1: string rows that do not start on a dword (byte-wise copies)."""
     E.build()
     mats = matrices()
@@ -245,7 +245,7 @@ def test_alignments_longer_than_a_staging_window(L, shift):
     compare(got, exp, L)
 
 
-def count_vectors_raw(a1, a2, rec, ref_seqs, includes, max_read_len, weights):
+def count_vectors_raw(a1, a2, rec, ref_seqs, includes, max_read_len, weights, flags=0):
     """E.count_vectors without its np.ascontiguousarray of the string arrays (that would re-align shifted rows)"""
     import ctypes
     from crispresso2_amd.counts import CountLayout
@@ -262,7 +262,7 @@ def count_vectors_raw(a1, a2, rec, ref_seqs, includes, max_read_len, weights):
     assert a1.strides == (a1.shape[1], 1) and a2.strides == (a2.shape[1], 1)
     rc = E.lib().emu_count_vectors(ctypes.c_uint64(n), ctypes.c_void_p(a1.ctypes.data), ctypes.c_void_p(a2.ctypes.data), ctypes.c_uint32(a1.shape[1]),
                                    rec.ctypes.data_as(ctypes.c_void_p), wq.ctypes.data_as(ctypes.c_void_p), None, 0, nrefs,
-                                   lens.ctypes.data_as(ctypes.c_void_p), ip, ninc.ctypes.data_as(ctypes.c_void_p), 0, int(lay.hl),
+                                   lens.ctypes.data_as(ctypes.c_void_p), ip, ninc.ctypes.data_as(ctypes.c_void_p), int(flags), int(lay.hl),
                                    counts.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(2), seq_ptrs)
     assert rc == 0
     return counts, lay
@@ -270,9 +270,10 @@ def count_vectors_raw(a1, a2, rec, ref_seqs, includes, max_read_len, weights):
 
 @pytest.mark.parametrize("legacy", [False, True])
 def test_event_walk_at_every_offset_of_an_eight_column_unit(legacy, monkeypatch):
-    """The event walk looks at eight columns per lane and walks only the runs of dirty units: deletions and insertions of 1 .. 17 bases that
-    start at every offset of a unit (a gap that ends exactly where a clean unit begins is closed by that unit's first column), two events a
-    few columns apart, events in the first and the last unit, a trailing deletion -- each against the oracle's aggregation."""
+    """An alignment with gaps that fits its staging slot is walked eight columns per lane in one pass: deletions and insertions of 1 .. 17 bases
+    that start at every offset of a lane's eight columns (the run is accounted by the lane that holds the column BEHIND it, which walks back over
+    the staged string), two events a few columns apart, adjacent insertions, events in the first and the last columns, a trailing deletion --
+    each against the oracle's aggregation."""
     E.build()
     mats = matrices()
     rng = np.random.default_rng(77)
@@ -307,3 +308,53 @@ def test_event_walk_at_every_offset_of_an_eight_column_unit(legacy, monkeypatch)
     else:
         items = [(p, int(c)) for p, c in zip(payloads(res, inc), w)]
     compare(got, aggregate.aggregate(items, L), L)
+
+
+@pytest.mark.parametrize("L", [250, 256, 97, 33])
+def test_gap_free_alignments_eight_at_a_time(L):
+    """Gap-free alignments of at most 256 columns are walked eight at a time, eight lanes each, 32 columns per lane as four 64-bit words: a
+    substitution at EVERY column (so every lane, word and byte position, the last partial word included), several per read, N in the read, reads
+    equal to the amplicon in between, more than eight and fewer than eight per round, different weights -- against the oracle's aggregation.
+    (Rows on 16-byte boundaries: what the route needs and what the batch aligner writes.)"""
+    E.build()
+    mats = matrices()
+    rng = np.random.default_rng(L)
+    amp = "".join(rng.choice(list("ACGT"), L))
+    inc = list(range(max(0, L // 2 - 10), min(L, L // 2 + 10)))
+    g = np.zeros(L + 1, dtype=np.int64)
+    g[L // 2 + 1] = 1
+    other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    reads = []
+    for c in range(L):
+        s = list(amp)
+        s[c] = other[s[c]]
+        if c % 7 == 3 and c + 9 < L:
+            s[c + 9] = "N"
+        if c % 5 == 1 and c >= 30:
+            s[c - 30] = other[s[c - 30]]
+        reads.append("".join(s))
+        if c % 11 == 0:
+            reads.append(amp)
+    res, rec = E.align_batch(reads, [amp], [g], [inc], mats["EDNAFULL"], -20, -2, stats=(st := {}))
+    o1, o2 = st["raw"]
+    assert (rec["aln_len"] == L).all()                                  # (all of them gap-free)
+    stride = (o1.shape[1] + 15) // 16 * 16
+
+    def rows16(o):
+        buf = np.zeros(o.shape[0] * stride + 16, dtype=np.uint8)
+        off = (-buf.ctypes.data) % 16
+        v = buf[off:off + o.shape[0] * stride].reshape(o.shape[0], stride)
+        v[:, :o.shape[1]] = o
+        return v
+    a1, a2 = rows16(o1), rows16(o2)
+    assert a1.ctypes.data % 16 == 0 and a2.ctypes.data % 16 == 0 and stride % 16 == 0
+    w = rng.integers(1, 9, len(reads)).astype(np.uint32)
+    counts, lay = count_vectors_raw(a1, a2, rec, [amp], [inc], L, w)
+    compare(lay.unpack(counts, 0, L), aggregate.aggregate([(p, int(c)) for p, c in zip(payloads(res, inc), w)], L), L)
+    # the same rows one byte off a 16-byte boundary take the one-at-a-time walk: same tensor
+    buf = np.zeros(a1.size + 32, dtype=np.uint8)
+    off = (-buf.ctypes.data) % 16 + 4
+    b1 = buf[off:off + a1.size].reshape(a1.shape)
+    b1[:] = a1
+    counts2, _ = count_vectors_raw(b1, a2, rec, [amp], [inc], L, w)
+    assert np.array_equal(counts, counts2)
