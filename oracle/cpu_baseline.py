@@ -92,7 +92,7 @@ def _kind(_):
 
 def _leg(ctx, procs, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, start, seconds, max_reads, rate_hint=None):
     """One pool size on reads [start, start + sample) -> (dict, reads consumed, kind).  The sample is sized from a calibration on a few
-    reads per worker, or from rate_hint (reads/s this pool size was measured at before: the calibration's cold start underestimates)."""
+    reads per worker, or from rate_hint (reads/s this pool size was measured at before: the calibration's cold start underestimates; a quarter more reads than that rate needs, so that the leg lasts at least `seconds` also when the long run is faster than the short one)."""
     n, L = reads_u8.shape
     n = min(n, start + max_reads)
     with ctx.Pool(procs, initializer=_init, initargs=(refs, matrix_path, go, ge)) as pool:
@@ -107,7 +107,7 @@ def _leg(ctx, procs, refs, matrix_path, go, ge, reads_u8, ref_ids, all_refs, sta
         done0 = pool.map(_work, [chunk_of(start + a, min(start + a + per, start + cal)) for a in range(0, cal, per)])
         per_read = (time.perf_counter() - t0) * procs / max(cal, 1)
         a0 = start + cal
-        sample = int(min(n - a0, max(procs * 16, seconds * rate_hint * 1.05 if rate_hint else seconds * procs / max(per_read, 1e-6))))
+        sample = int(min(n - a0, max(procs * 16, seconds * rate_hint * 1.25 if rate_hint else seconds * procs / max(per_read, 1e-6))))
         chunk = max(8, sample // (procs * 8))
         bounds = [(a0 + a, min(a0 + a + chunk, a0 + sample)) for a in range(0, sample, chunk)]
         t0 = time.perf_counter()
