@@ -264,7 +264,9 @@ enum { C2_H_INSERTED_N = 0, C2_H_DELETED_N, C2_H_SUBSTITUTED_N, C2_H_EFFECTIVE_L
                                        // memory round trips, one alignment per wave at a time -- 8 waves at 64 VGPRs (some spilled) beat 5 at 96 by 15 %
                                        // (profiles/r03/ab_count_occupancy.txt)
 #endif
-#define C2_CNT_TASKS_PER_WAVE 32
+#ifndef C2_CNT_TASKS_PER_WAVE
+#define C2_CNT_TASKS_PER_WAVE 32       // records a wavefront holds per chunk, one per lane (32 or 64)
+#endif
 #define C2_CNT_CTL_BASE_INTS 96     // >= 16 + 4 * C2_CNT_WAVES
 #define C2_CNT_CTL_INTS (C2_CNT_CTL_BASE_INTS + C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE)   // + per task of a chunk: the part of a heavy weight that is still to be added
 #define C2_CNT_LOAD_BUDGET (1u << 30) // sum of weight x alignment length an LDS block may take between two flushes (its entries are int32)

@@ -102,6 +102,8 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
     // waves per CU); each wavefront walks one alignment at a time.  The workgroup takes C2_CNT_WAVES * C2_CNT_TASKS_PER_WAVE
     // consecutive tasks per atomic; lane k of wave v holds the record of task base + k * C2_CNT_WAVES + v.
     constexpr int NT = 64 * C2_CNT_WAVES, K = C2_CNT_TASKS_PER_WAVE, CHUNK = C2_CNT_WAVES * K, NONE = 0x7fffffff;
+    static_assert(K == 32 || K == 64, "a wavefront's tasks are one bit each of a 64-bit mask");
+    typedef unsigned long long km_t;                            // one bit per task of the wavefront (lane k holds the record of task k)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* acc = HBM ? A.block_scratch + (size_t)blockIdx.x * (size_t)A.block_ints : (int*)c2_smem;
     const int VL = A.lmax + 1;                                  // vector length incl. the end slot of the difference arrays
@@ -215,12 +217,12 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[(size_t)ref * (A.max_t + 1) + T]);
             }
         }
-        unsigned pending = (unsigned)__ballot(sel);
+        km_t pending = (km_t)__ballot(sel);
         // Everything an alignment adds to an int32 entry of the block is its weight times a count of its own columns -- at most
         // w * aln_len, its LOAD.  The loads since the last flush stay within C2_CNT_LOAD_BUDGET (2^30), so no entry can wrap;
         // saturating sums decide the flushes before anything is added.
         // (heavy chunks: v_w is what of the task's weight is still to be added; `counted`: lanes whose alignment has been counted once)
-        unsigned counted = 0;
+        km_t counted = 0;
         {   // (a task above ~2^26 makes the chunk heavy by itself; the others add up in 32 bits: 32 x 2^26 = 2^31.  The size test is
             // done in float -- 6.0e7 is safely below 2^26 for its rounding -- so that no 64-bit product has to be formed)
             const unsigned my_T = (d0 & 0xffffu) ? (d0 & 0xffffu) : 1u;
@@ -242,7 +244,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
         wsum += heavy ? 0u : chunk_w;
         for (;;) {
             // lowest pending task of the workgroup -> the reference whose tasks are processed in this round
-            const int first = pending ? __builtin_ctz(pending) : -1;
+            const int first = pending ? __builtin_ctzll(pending) : -1;
             int fref = NONE, ftask = NONE;
             if (first >= 0) { fref = (int)((unsigned)__builtin_amdgcn_readlane((int)d6, first) >> 16); ftask = first * C2_CNT_WAVES + wave; }
             if (lane == 0) { ctl[16 + par * 2 * C2_CNT_WAVES + wave * 2] = fref; ctl[16 + par * 2 * C2_CNT_WAVES + wave * 2 + 1] = ftask; }
@@ -262,11 +264,11 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 for (int k = tid; k < Li + 2; k += NT) incp[k] = g[k];
                 __syncthreads();
             }
-            unsigned todo = heavy ? ((first >= 0 && ftask == ttask) ? (1u << first) : 0u) : pending;
+            km_t todo = heavy ? ((first >= 0 && ftask == ttask) ? ((km_t)1 << first) : (km_t)0) : pending;
             // ---- scalar counters and histograms of ALL tasks of this round at once: lane k holds the record of its own task, so
             //      every lane adds its task's contributions (LDS atomics; ~20 instructions per round instead of per task).
             //      aln_stats of process_fastq (CRISPRessoCORE.py:1974-1979), then the tallies of :3996-4072.
-            const bool mine = lane < K && ((todo >> lane) & 1u) && (int)(d6 >> 16) == tref;
+            const bool mine = lane < K && ((todo >> (lane & (K - 1))) & 1ull) && (int)(d6 >> 16) == tref;
             // the weight this round adds for the lane's task: all of it, or (heavy) a piece whose load fits the budget
             // heavy chunks: v_w becomes the piece of the weight this round adds, the remainder waits in LDS (no register of the
             // common path is spent on it: the kernel sits at 96 VGPRs = 5 waves per SIMD)
@@ -282,7 +284,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 const int T_ = (int)(d0 & 0xffffu), matches_ = (int)(d0 >> 16);
                 const bool perfect = mine && T_ == Li && matches_ == T_ && (d4 >> 16) == 0u && d1 == 0u;
                 if (perfect) atomicAdd(acc + o_sc + C2_S_RESERVED0, v_w);
-                const unsigned pm = (unsigned)__ballot(perfect);
+                const km_t pm = (km_t)__ballot(perfect);
                 todo &= ~pm; pending &= ~pm;
             }
             if (mine) {
@@ -298,7 +300,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 atomicAdd(scal + C2_S_N_MODS_IN_WINDOW, in_win * w);
                 atomicAdd(scal + C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * w);
                 if (irregular_ends) atomicAdd(scal + C2_S_N_READS_IRREGULAR_ENDS, w);
-                if (!((counted >> lane) & 1u)) atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);           // (once per alignment, not per piece of a heavy weight)
+                if (!((counted >> (lane & (K - 1))) & 1ull)) atomicAdd(scal + C2_S_ALIGNMENTS_COUNTED, 1);           // (once per alignment, not per piece of a heavy weight)
                 if (discard && (deletion_n > 0 || insertion_n > 0)) atomicAdd(scal + C2_S_DISCARDED, w);                     // :3996-4000
                 else {
                     const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
@@ -324,8 +326,8 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
             // ---- the alignments of this round that are walked: their strings are STAGED in LDS, C2_CNT_STAGE of them at a time, by the
             //      memory system itself (global_load_lds: no register waits for them), and only then walked one after the other -- a
             //      wavefront has that many alignments' loads in flight instead of one
-            unsigned walk = (unsigned)__ballot(mine && ((todo >> lane) & 1u) && !(discard && ((d1 & 0xffffu) != 0u || (d1 >> 16) != 0u)));   // (discarded reads: counted above; no vectors, :3996-4000)
-            pending &= ~(unsigned)__ballot(mine && ((todo >> lane) & 1u));
+            km_t walk = (km_t)__ballot(mine && ((todo >> (lane & (K - 1))) & 1ull) && !(discard && ((d1 & 0xffffu) != 0u || (d1 >> 16) != 0u)));   // (discarded reads: counted above; no vectors, :3996-4000)
+            pending &= ~(km_t)__ballot(mine && ((todo >> (lane & (K - 1))) & 1ull));
             uint8_t* const stage_w = stage + (size_t)wave * (C2_CNT_STAGE * 2u * C2_CNT_STAGE_ROW);
             // columns [col0, col0 + ncols) of both strings of `task` -> slot (ncols <= C2_CNT_STAGE_ROW)
             auto stage_window = [&](uint8_t* slot, const uint64_t task, const int col0, const int ncols) {
@@ -356,18 +358,18 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
             //      below it adds only the DEVIATIONS from the reference (+w on the read's base, -w on the reference's) and the weight to the
             //      scalar that flush() spreads over the reference's own bases.
             if (C2_CNT_GROUPED && rows_aligned16) {
-                const unsigned gfm = (unsigned)__ballot(lane < K && ((walk >> (lane & (K - 1))) & 1u) && (int)(d0 & 0xffffu) == Li && (d4 >> 16) == 0u &&
+                const km_t gfm = (km_t)__ballot(lane < K && ((walk >> (lane & (K - 1))) & 1ull) && (int)(d0 & 0xffffu) == Li && (d4 >> 16) == 0u &&
                                                         (d0 & 0xffffu) <= 256u);
                 if (gfm) {
                     typedef unsigned long long u64;
                     walk &= ~gfm;
-                    const bool gf_mine = lane < K && ((gfm >> (lane & (K - 1))) & 1u);
+                    const bool gf_mine = lane < K && ((gfm >> (lane & (K - 1))) & 1ull);
                     if (gf_mine) atomicAdd(acc + o_sc + C2_S_RESERVED0, v_w);
                     // the q-th of them sits in lane tab[q] (the wavefront's staging area is free here)
                     C2_LDS_READS_DONE();
-                    if (gf_mine) stage_w[__popcll((unsigned long long)(gfm & ((1u << (lane & (K - 1))) - 1u)))] = (uint8_t)lane;
+                    if (gf_mine) stage_w[__popcll(gfm & (((km_t)1 << (lane & (K - 1))) - 1ull))] = (uint8_t)lane;
                     C2_LDS_READS_DONE();
-                    const int ng = __popcll((unsigned long long)gfm), grp = lane >> 3, p0 = 32 * (lane & 7);
+                    const int ng = __popcll(gfm), grp = lane >> 3, p0 = 32 * (lane & 7);
                     const u64 H = 0x8080808080808080ull, L7 = 0x7f7f7f7f7f7f7f7full;
                     for (int q0 = 0; q0 < ng; q0 += 8) {
                         const bool on = q0 + grp < ng;
@@ -417,11 +419,11 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 }
             }
             while (walk) {
-                unsigned batch = 0;
+                km_t batch = 0;
                 C2_LDS_READS_DONE();                                                                // (the slots are free: every lane has read what it needed of them)
                 for (int sl = 0; sl < C2_CNT_STAGE && walk; ++sl) {
-                    const int kk = __builtin_ctz(walk);
-                    walk &= walk - 1; batch |= 1u << kk;
+                    const int kk = __builtin_ctzll(walk);
+                    walk &= walk - 1; batch |= (km_t)1 << kk;
                     const uint64_t task = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task & 0xffffffffull), kk) |
                                           ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_task >> 32), kk) << 32);
                     const int T = (int)((unsigned)__builtin_amdgcn_readlane((int)d0, kk) & 0xffffu);
@@ -429,7 +431,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 }
                 C2_WAIT_LDS_DMA();
                 for (int sl = 0; batch; ++sl) {
-                const int kk = __builtin_ctz(batch);
+                const int kk = __builtin_ctzll(batch);
                 batch &= batch - 1;
                 uint8_t* const slot = stage_w + sl * (2 * C2_CNT_STAGE_ROW);
                 const uint8_t* SR = slot;                                                           // the staged window of the aligned read ...
@@ -733,9 +735,9 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
             }       // batches of this round
             if (heavy) {
                 // a task whose weight was added only in part stays pending for another round
-                counted |= (unsigned)__ballot(mine);
+                counted |= (km_t)__ballot(mine);
                 if (mine) v_w = ctl[C2_CNT_CTL_BASE_INTS + wave * K + (lane & (K - 1))];
-                pending |= (unsigned)__ballot(mine && v_w > 0);
+                pending |= (km_t)__ballot(mine && v_w > 0);
                 flush();
             }
         }       // rounds of this chunk
