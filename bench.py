@@ -934,6 +934,12 @@ def main():
             "e2e": e2e,
             "dedup_on": dedup_on,
             "cpu_baseline": cpu_baseline,
+            # the reference AS SHIPPED (its own main(), dedup, workers, JSON / TSV exchange), log window "Aligning sequences..." ->
+            # "Finished reads;".  The reference's sources are not on the GPU box, so this is a RECORDED measurement from the dev container
+            # (tools/as_shipped_rate.py), not one of this run: context for cpu_baseline, which times the reference's compiled hot path live.
+            "cpu_baseline_as_shipped_recorded": {"reads_per_s": 12730, "procs": 8, "host_cpus": 8, "reads": 200000, "unique_reads": 95704,
+                                                 "where": "dev container, not the GPU box", "source": "profiles/r02/as_shipped_devcontainer.txt",
+                                                 "command": "CRISPResso -r1 reads.fastq -a <250 bp amplicon> -g <guide> -p 8 --suppress_plots --suppress_report"},
             "checks": checks,
             "counts": [{"amplicon": r, "reads_aligned_all_gpus": tl["counts_total"], "modified": tl["counts_modified"],
                         "unmodified": tl["counts_unmodified"], "with_insertion": tl["counts_insertion"],
