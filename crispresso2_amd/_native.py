@@ -56,6 +56,7 @@ class Batch(ctypes.Structure):
         ("aln_read", ctypes.c_void_p), ("aln_ref", ctypes.c_void_p),
         ("aln_stride", ctypes.c_uint32), ("flags", ctypes.c_uint32),
         ("records", ctypes.c_void_p),
+        ("min_read_len", ctypes.c_int32),
     ]
 
 

@@ -150,8 +150,10 @@ class BatchAligner:
         return BatchResult(aln_read, aln_ref, records, n, self.n_refs, all_refs)
 
     def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
-                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False):
-        """All d_* are device addresses (ints).  Enqueues one launch on `stream` and returns immediately."""
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0):
+        """All d_* are device addresses (ints).  Enqueues one launch on `stream` and returns immediately.
+        min_read_len: the shortest read of the batch if the caller knows it (c2_batch.min_read_len: band tiers no read of that length range can use
+        are not launched -- never changes a result)."""
         b = _native.Batch()
         b.n_reads = int(n_reads)
         b.reads = d_reads
@@ -165,4 +167,5 @@ class BatchAligner:
         b.aln_stride = int(aln_stride)
         b.records = d_records
         b.flags = 1 if legacy else 0
+        b.min_read_len = int(min_read_len)
         self.ctx.align_classify_device(b, stream)

@@ -237,8 +237,21 @@ int launch_full(c2_ctx* ctx, c2_align_args& A, const Geometry& g, hipStream_t s)
     return 0;
 }
 
+// Can a band tier of `bandw` diagonals serve ANY task of a batch whose reads are min_lj .. max_lj long?  The kernels' own test (c2_diagx_body:
+// the band d0 .. d0 + bandw - 1 placed symmetrically about D / 2 must hold diagonal 0 and diagonal D = len(ref) - len(read)), over every
+// reference and read length.  min_lj <= 0: not known -> yes.
+bool tier_can_serve(const c2_ctx* ctx, const int bandw, const int min_lj, const int max_lj) {
+    if (min_lj <= 0 || min_lj > max_lj) return true;
+    for (const int li : ctx->ref_len)
+        for (int lj = min_lj; lj <= max_lj; ++lj) {
+            const int D = li - lj, d0 = ((D - bandw + 3) >> 1) & ~1;
+            if (d0 <= 0 && d0 + bandw - 1 >= 0 && D >= d0 && D <= d0 + bandw - 1) return true;
+        }
+    return false;
+}
+
 template <int R>
-int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s) {
+int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s, const int min_lj = 0) {
     TimedLaunch tl{};
     if (ctx->timing) {
         HIPCHK(ctx, hipEventCreate(&tl.a)); HIPCHK(ctx, hipEventCreate(&tl.m)); HIPCHK(ctx, hipEventCreate(&tl.b));
@@ -290,6 +303,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s)
             for (int t = 0; t < 2; ++t) {
                 const bool packed = t == 0 ? g.pk : g.pk2;
                 if (!packed && !g.x[t]) continue;
+                if (!tier_can_serve(ctx, t == 0 ? 32 : 62, min_lj, A.max_lj)) continue;     // (c2_batch.min_read_len: no task could use this band -- the next tier takes them all)
                 if (packed) {
                     const int na = t == 0 ? 8 : 4;
                     const uint64_t resident = cus * (uint64_t)(t == 0 ? g.blocks_pk : g.blocks_pk2);
@@ -429,10 +443,10 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     }
     A.phase_cycles = ctx->phase_prof ? (unsigned long long*)ctx->d_phase.p : nullptr;
     switch (g.R) {
-        case 1: return launch_align<1>(ctx, A, g, s);
-        case 2: return launch_align<2>(ctx, A, g, s);
-        case 3: return launch_align<3>(ctx, A, g, s);
-        default: return launch_align<4>(ctx, A, g, s);
+        case 1: return launch_align<1>(ctx, A, g, s, b->min_read_len);
+        case 2: return launch_align<2>(ctx, A, g, s, b->min_read_len);
+        case 3: return launch_align<3>(ctx, A, g, s, b->min_read_len);
+        default: return launch_align<4>(ctx, A, g, s, b->min_read_len);
     }
 }
 
@@ -726,7 +740,7 @@ namespace {
 //   ctx->stream    launch chain of chunk c (after its input arrived)
 //   stream s_out   outputs of chunk c-1 -> pinned output set
 // Offsets / reference ids / strands are small and go up front.  Two pinned sets each way; events order their reuse.
-int align_host_pipelined(c2_ctx* ctx, const c2_batch* b, int max_lj, uint64_t chunk_reads) {
+int align_host_pipelined(c2_ctx* ctx, const c2_batch* b, int max_lj, uint64_t chunk_reads, int32_t min_lj) {
     const uint64_t n = b->n_reads;
     const uint64_t tpr = (uint64_t)(b->all_refs ? ctx->n_refs : 1);          // tasks per read
     const uint64_t n_tasks = n * tpr;
@@ -799,7 +813,7 @@ int align_host_pipelined(c2_ctx* ctx, const c2_batch* b, int max_lj, uint64_t ch
         // launch chain of chunk c, after its reads arrived
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_in[k], 0));
         c2_batch d = *b;
-        d.n_reads = nr;
+        d.n_reads = nr; d.min_read_len = min_lj;
         d.reads = (const uint8_t*)ctx->d_reads.p; d.offsets = (const uint64_t*)ctx->d_offsets.p + r0;
         d.ref_ids = (b->ref_ids && !b->all_refs) ? (const uint16_t*)ctx->d_refids.p + r0 : nullptr;
         d.strands = b->strands ? (const uint8_t*)ctx->d_strands.p + t0 : nullptr;
@@ -835,10 +849,13 @@ int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
     const uint64_t n = b->n_reads;
     const uint64_t n_tasks = n * (uint64_t)(b->all_refs ? ctx->n_refs : 1);
     int max_lj = 1;
+    uint64_t min_len = ~0ull;                                            // (the host sees the lengths: the hint c2_batch.min_read_len is computed here, whatever the caller put there)
     for (uint64_t k = 0; k < n; ++k) {
         if (b->offsets[k + 1] < b->offsets[k]) { ctx->err = "offsets must be non-decreasing"; return C2_E_INVALID; }
         max_lj = (int)std::max<uint64_t>(max_lj, b->offsets[k + 1] - b->offsets[k]);
+        min_len = std::min<uint64_t>(min_len, b->offsets[k + 1] - b->offsets[k]);
     }
+    const int32_t min_lj = (n && min_len <= 0x7fffffffull) ? (int32_t)min_len : 0;
     if (!b->all_refs && b->ref_ids)
         for (uint64_t k = 0; k < n; ++k) if (b->ref_ids[k] >= ctx->n_refs) { ctx->err = "ref_id out of range"; return C2_E_INVALID; }
     const uint32_t need_stride = (uint32_t)(ctx->max_li + max_lj);
@@ -850,7 +867,7 @@ int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
         if (const char* e = getenv("C2_HOST_PIPE_MIN_TASKS")) pipe_min = strtoull(e, nullptr, 10);
         if (const char* e = getenv("C2_HOST_PIPE_CHUNK_TASKS")) chunk_tasks = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
         const uint64_t tpr = (uint64_t)(b->all_refs ? ctx->n_refs : 1);
-        if (n_tasks >= pipe_min && n >= 2) return align_host_pipelined(ctx, b, max_lj, std::max<uint64_t>(1, chunk_tasks / tpr));
+        if (n_tasks >= pipe_min && n >= 2) return align_host_pipelined(ctx, b, max_lj, std::max<uint64_t>(1, chunk_tasks / tpr), min_lj);
     }
     if ((rc = ensure(ctx, ctx->d_reads, nbytes + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_offsets, (n + 1) * 8))) return rc;
@@ -868,6 +885,7 @@ int c2_align_classify_batch_host(c2_ctx* ctx, const c2_batch* b) {
     if (b->strands) HIPCHK(ctx, hipMemcpyAsync(ctx->d_strands.p, b->strands, n_tasks, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipStreamSynchronize(s));      // `rel` is pageable host memory owned by this call
     c2_batch d = *b;
+    d.min_read_len = min_lj;
     d.reads = (const uint8_t*)ctx->d_reads.p; d.offsets = (const uint64_t*)ctx->d_offsets.p;
     d.ref_ids = (b->ref_ids && !b->all_refs) ? (const uint16_t*)ctx->d_refids.p : nullptr;
     d.strands = b->strands ? (const uint8_t*)ctx->d_strands.p : nullptr;

@@ -108,6 +108,7 @@ def _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, k_sta
     d_r1, d_o1 = _dev_gather(ctx, dev, stream, d_ka, k_start, l1)
     d_r2, d_o2 = _dev_gather(ctx, dev, stream, d_ka, k_plus + 1, l2)
     max_l = int(torch.maximum(l1.max(), l2.max()).item()) if m else 1
+    min_l = int(torch.minimum(l1.min(), l2.min()).item()) if m else 0
     max_key = int((k_end - k_start).max().item()) if m else 1
     # ---- seed test over both reads of the pair (:1024-1036): "seed in read 1 or seed in read 2" = "seed in key" (no seed holds a '+')
     d_plan = torch.empty(m * k, dtype=torch.uint8, device=dev)
@@ -122,7 +123,8 @@ def _front(ctx, aligner, dev, stream, refs, ref_names, args, legacy, d_ka, k_sta
         a = torch.empty((n_items, stride), dtype=u8, device=dev)
         f = torch.empty((n_items, stride), dtype=u8, device=dev)
         r = torch.empty((n_items, 32), dtype=u8, device=dev)
-        aligner.align_device(n_units, d_reads.data_ptr(), d_off.data_ptr(), a.data_ptr(), f.data_ptr(), r.data_ptr(), stride, max_len, stream=stream, legacy=legacy, **kw)
+        aligner.align_device(n_units, d_reads.data_ptr(), d_off.data_ptr(), a.data_ptr(), f.data_ptr(), r.data_ptr(), stride, max_len, stream=stream, legacy=legacy,
+                             min_read_len=min_l, **kw)
         return a, f, r
     A1, F1, R1 = align(m, d_r1, d_o1, max_l, d_strands=d_str.data_ptr(), all_refs=True)
     A2, F2, R2 = align(m, d_r2, d_o2, max_l, d_strands=d_str.data_ptr(), all_refs=True)

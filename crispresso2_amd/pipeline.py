@@ -783,7 +783,8 @@ class _UniqueRun:
             self.f1 = torch.empty((self.n1, self.stride), dtype=torch.uint8, device=dev)
             self.r1 = torch.empty((self.n1, 32), dtype=torch.uint8, device=dev)
             self.aligner.align_device(n, self.d_reads.data_ptr(), self.d_off.data_ptr(), self.a1.data_ptr(), self.f1.data_ptr(), self.r1.data_ptr(),
-                                      self.stride, self.max_lj, d_strands=d_str1.data_ptr(), all_refs=True, stream=self.stream, legacy=self.legacy)
+                                      self.stride, self.max_lj, d_strands=d_str1.data_ptr(), all_refs=True, stream=self.stream, legacy=self.legacy,
+                                      min_read_len=int(self.lens.min()) if n else 0)
         self.lap("h2d_align")
 
     def align_both_strands(self):
@@ -816,7 +817,8 @@ class _UniqueRun:
             self.f2 = torch.empty((n2, self.stride2), dtype=torch.uint8, device=dev)
             self.r2 = torch.empty((n2, 32), dtype=torch.uint8, device=dev)
             self.aligner.align_device(n2, d_reads2.data_ptr(), d_off2.data_ptr(), self.a2.data_ptr(), self.f2.data_ptr(), self.r2.data_ptr(), self.stride2,
-                                      max_lj2, d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=self.stream, legacy=self.legacy)
+                                      max_lj2, d_ref_ids=d_rid2.data_ptr(), d_strands=d_str2.data_ptr(), stream=self.stream, legacy=self.legacy,
+                                      min_read_len=int(self.lens[self.bi].min()))
         self.lap("both_strand_pairs")
         self.d_slot2 = None
         if n2:

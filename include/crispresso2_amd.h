@@ -114,6 +114,9 @@ typedef struct c2_batch {
     uint32_t flags;            /* C2_BATCH_*: bit 0 = the record's window counts follow find_indels_substitutions_legacy
                                   (--use_legacy_insertion_quantification, CRISPRessoCORE.py:721-722) */
     c2_aln_record* records;    /* n_tasks */
+    int32_t min_read_len;      /* shortest read of the batch, or 0 = not known.  A hint that never changes results: a band tier of the launch chain
+                                  that no read of [min_read_len, max_read_len] against any reference can use (|len(ref) - len(read)| outside its band, e.g.
+                                  150-bp mates against a 250-bp amplicon) is not launched instead of being passed through task by task */
 } c2_batch;
 #define C2_BATCH_LEGACY_CLASSIFIER 1u
 

@@ -39,7 +39,7 @@ class _Aligner(EmulatedAligner):
         self.ctx = ctx
 
     def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
-                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False):
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0):
         n, k = int(n_reads), len(self.seqs)
         off = _view(d_offsets, 8 * (n + 1)).view(np.int64)
         arena = _view(d_reads, max(int(off[-1]), 1)).tobytes()

@@ -31,7 +31,7 @@ class EmulatedAligner:
         return (self.max_ref_len + int(max_read_len) + 15) // 16 * 16
 
     def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
-                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False):
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0):
         import os
         if legacy:
             os.environ["C2_EMU_LEGACY"] = "1"

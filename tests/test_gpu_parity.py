@@ -1143,3 +1143,45 @@ def test_count_route_with_the_accumulator_block_in_hbm(mats, ctx, L, force, monk
         else:
             assert got[k_] == v, (k_, got[k_], v)
     assert got["counts_total"] == int(w.sum()) and got["counts_deletion"] > 0 and got["counts_insertion"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("read_len,expect_skipped", [(150, 2), (215, 1), (240, 0)])
+def test_band_tiers_no_read_of_the_batch_can_use_are_not_launched(mats, ctx, read_len, expect_skipped):
+    """c2_batch.min_read_len: mates of 150 bp against a 250-bp amplicon cannot use the 32- and 62-diagonal tiers (diagonal 0 and diagonal
+    len(ref) - len(read) = 100 do not fit one band): with the hint those tiers are not launched -- the same strings and records as without
+    it, and as the oracle's on a sample -- and fewer tiers in c2_tier_info; 215 bp: only the first tier goes; 240 bp: none."""
+    import torch
+    from crispresso2_amd import synth, _native
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    m = mats["EDNAFULL"]
+    L, n = 250, 4000
+    amp, g, _ = synth.amplicon_setup(L)
+    inc = list(range(L // 2 - 10, L // 2 + 10))
+    full = synth.make_reads(L, n)
+    start = (L - read_len) // 2
+    reads = np.ascontiguousarray(full[:, start:start + read_len])
+    al = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    stride = al.stride_for(read_len)
+    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * read_len
+    s = torch.cuda.current_stream().cuda_stream
+    outs, tiers = [], []
+    for hint in (0, read_len):
+        o1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        o2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        rec = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+        al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, read_len, stream=s, min_read_len=hint)
+        torch.cuda.synchronize()
+        outs.append((o1.cpu().numpy(), o2.cpu().numpy(), rec.cpu().numpy()))
+        tiers.append(len(ctx.tier_info()))
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert tiers[0] - tiers[1] == expect_skipped, tiers
+    records = outs[1][2].view(_native.REC_DTYPE).reshape(-1)
+    assert (records["status"] == 0).all()
+    for i in range(0, n, 97):
+        T = int(records["aln_len"][i])
+        s1, s2, _ = oracle.global_align(reads[i].tobytes().decode(), amp, m, g, -20, -2)
+        assert outs[1][0][i, :T].tobytes().decode() == s1 and outs[1][1][i, :T].tobytes().decode() == s2, i
