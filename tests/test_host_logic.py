@@ -53,7 +53,8 @@ def test_record_struct_layout_matches_numpy_dtype():
     from crispresso2_amd import _native
     assert _native.REC_DTYPE.itemsize == 32
     assert _native.REC_DTYPE.fields["status"][1] == 23 and _native.REC_DTYPE.fields["ref_id"][1] == 26
-    assert ctypes.sizeof(_native.Batch) == 80
+    assert ctypes.sizeof(_native.Batch) == 88                         # (struct c2_batch: 80 bytes + min_read_len, padded to 8)
+    assert _native.Batch.min_read_len.offset == 80
 
 
 def test_read_matrix_and_make_matrix():
