@@ -915,6 +915,9 @@ class IngestSource:
                                 self.filtered_lines_input = fq.lines_input()
         except OSError as e:
             why = "%s: %s" % (type(e).__name__, e)
+        except BaseException:
+            self.close()                                              # (what was opened so far; the error goes to the caller)
+            raise
         self.why_not = why
 
     def host_stream(self):
