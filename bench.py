@@ -727,6 +727,7 @@ def main():
     tm = job.timed(args.warmup, args.steps)
     dt, kernel_ms, first_ms, launches = tm["dt"], tm["kernel_ms"], tm["first_ms"], tm["launches"]
     tiers = ctx.tier_info()
+    score_info = ctx.score_stage_info() if hasattr(ctx, "score_stage_info") else (False, 0, 0)     # (of the timed batch: later launches overwrite it)
     packed_share = None                                           # share of the batch's alignments the packed (int16 pair) kernels finished
     try:
         left_, unpaired_ = ctx.tier_info_ex()
@@ -819,9 +820,20 @@ def main():
               ["c2_align_classify_kernel<%d, true>" % info["rows_per_lane"]] if band["band_lanes"] > 0 else [])
              + ["c2_align_classify_kernel<%d, false>" % info["rows_per_lane"]])
     dominant = chain[0]
-    # algorithmic bytes of the dominant kernel's launch: every read and offset in; strings + record out for the tasks it finishes
-    done_first = n_tasks - (tiers[0] if tiers else 0)
-    alg_first = bytes_in + int(bytes_out * (done_first / float(n_tasks)))
+    # the score-only stage in front of the first band tier (c2_align_partition_kernel + c2_align_diags_kernel<8>): the tasks it finished never
+    # reach the dominant kernel
+    score_stage = None
+    if score_info[0]:
+        ran_, took_, fin_ = score_info
+        if ran_:
+            score_stage = {"kernels": ["c2_align_partition_kernel", "c2_align_diags_kernel<8" + pkv], "tasks": took_, "finished": fin_,
+                           "note": "reads as long as the amplicon whose last 32 columns differ from it in at most 6 places go through the packed fill without pointer bits; "
+                                   "it finishes those whose optimal alignment is the main diagonal (gap-free predicate + certificate) and hands the rest, "
+                                   "with all other reads, to the first band tier"}
+    # algorithmic bytes of the dominant kernel's launch: the reads and offsets of its tasks in; strings + record out for the tasks it finishes
+    in_first = n_tasks - (score_stage["finished"] if score_stage else 0)
+    done_first = in_first - (tiers[0] if tiers else 0)
+    alg_first = int(bytes_in * (in_first / float(n_tasks))) + int(bytes_out * (done_first / float(n_tasks)))
     achieved_gbs = alg_first / avg_first_s / 1e9 if avg_first_s > 0 else 0.0
     # HBM bytes and instruction counts per alignment from the committed PMC passes of the newest round's build (separate rocprofv3
     # --pmc runs of this same script over 2 M reads; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming
@@ -896,7 +908,9 @@ def main():
                        "unique_read_fraction": unique_fraction, "unique_read_fraction_sample": n_u,
                        "rows_per_lane": info["rows_per_lane"], "lds_bytes_per_workgroup": info["lds_bytes"],
                        "workgroups_per_cu": info["workgroups_per_cu"], "compute_units": info["compute_units"],
-                       "kernel_chain": chain,
+                       "kernel_chain": (score_stage["kernels"] if score_stage else []) + chain,
+                       "score_only_stage_tasks": None if not score_stage else score_stage["tasks"],
+                       "score_only_stage_finished": None if not score_stage else score_stage["finished"],
                        "tasks_left_after_each_banded_launch": tiers,
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"],
                        # (scalars the driver's record keeps: the all-int32 chain on the same batch, how much of the batch the packed kernels finished,
@@ -929,6 +943,7 @@ def main():
                          "chain_avg_ms": 1e3 * avg_launch_s, "chain_algorithmic_bytes": alg_bytes,
                          "note": "integer DP: VALU-issue-bound by construction, HBM fraction is small (SURVEY 8d); see valu and profiles/*/README.md"},
             "valu": valu,
+            "score_only_stage": score_stage,
             "int32_chain": int32_chain,
             "other_configs": other_configs,
             "e2e": e2e,

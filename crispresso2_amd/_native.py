@@ -25,7 +25,7 @@ SYMBOLS = [
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners", "c2_gather_reads",
-    "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close",
+    "c2_score_stage_info", "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close",
     "c2_consensus_pairs_batch", "c2_consensus_pairs_device", "c2_classify_records_device",
     "c2_fq_count_device", "c2_fq_lines_device", "c2_fq_dedup_device", "c2_fq_gather_device", "c2_fq_rc_partner_device",
     "c2_fq_lines4_device", "c2_fq_pair_lengths_device", "c2_fq_pair_write_device",
@@ -291,7 +291,8 @@ class Context:
         return [int(left[k]) for k in range(n.value)]
 
     CHAIN_KERNELS = ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<4>", "c2_align_diagp_kernel<4>", "c2_align_diagx_kernel<2>",
-                     "c2_align_diagp_kernel<2>", "c2_align_diag_kernel", "banded row-strip", "full plane in HBM scratch", "packed fill with 32-bit adds"]
+                     "c2_align_diagp_kernel<2>", "c2_align_diag_kernel", "banded row-strip", "full plane in HBM scratch", "packed fill with 32-bit adds",
+                     "score-only stage (c2_align_partition_kernel + c2_align_diags_kernel<8>) in front of the first band tier"]
 
     def chain_info(self, max_read_len, n_refs):
         """-> (names of the kernels in the launch chain for reads up to max_read_len, [packed fill admits reference r])"""
@@ -299,6 +300,12 @@ class Context:
         ok = (ctypes.c_uint8 * max(n_refs, 1))()
         self.check(self.lib.c2_chain_info(self.handle, int(max_read_len), ctypes.byref(kern), ok), "c2_chain_info")
         return [nm for b, nm in enumerate(self.CHAIN_KERNELS) if kern.value >> b & 1], [bool(ok[r]) for r in range(n_refs)]
+
+    def score_stage_info(self):
+        """-> (ran, tasks taken, tasks finished) of the score-only stage of the most recent batch (c2_score_stage_info)"""
+        ran, t, f = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self.check(self.lib.c2_score_stage_info(self.handle, ctypes.byref(ran), ctypes.byref(t), ctypes.byref(f)), "c2_score_stage_info")
+        return bool(ran.value), int(t.value), int(f.value)
 
     def tier_info_ex(self):
         """-> (left_over, unpaired) per band tier of the most recent batch (c2_tier_info_ex)."""

@@ -254,11 +254,14 @@ template <int R>
 int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s, const int min_lj = 0) {
     TimedLaunch tl{};
     if (ctx->timing) {
-        HIPCHK(ctx, hipEventCreate(&tl.a)); HIPCHK(ctx, hipEventCreate(&tl.m)); HIPCHK(ctx, hipEventCreate(&tl.b));
+        HIPCHK(ctx, hipEventCreate(&tl.a)); HIPCHK(ctx, hipEventCreate(&tl.m0)); HIPCHK(ctx, hipEventCreate(&tl.m)); HIPCHK(ctx, hipEventCreate(&tl.b));
         HIPCHK(ctx, hipEventRecord(tl.a, s));
     }
-    bool first_marked = false;
-    auto mark_first = [&]() { if (ctx->timing && !first_marked) { (void)hipEventRecord(tl.m, s); first_marked = true; } };
+    ctx->last_score_stage = false; ctx->last_n_tasks = A.n_tasks;
+    bool first_marked = false, first_started = false;
+    // the "first kernel" of the timing split: the kernel of the first band tier (behind the score-only stage, if that runs)
+    auto start_first = [&]() { if (ctx->timing && !first_started) { (void)hipEventRecord(tl.m0, s); first_started = true; } };
+    auto mark_first = [&]() { start_first(); if (ctx->timing && !first_marked) { (void)hipEventRecord(tl.m, s); first_marked = true; } };
     int rc;
     A.band_lanes = 0; A.reserved = (getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0) | (getenv("C2_DEBUG_SKIP_EPILOGUE") ? 2 : 0) | (getenv("C2_DEBUG_HALF_FILL") ? 4 : 0);   // (measurement knobs)
     A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
@@ -269,10 +272,11 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
         // tasks a packed kernel could not pair (run by the 32-bit kernel of the same band), [16 + 2l ..] work counter of launch l --
         // then three task lists: two that alternate between band tiers and one for the unpaired tasks
         const size_t list_words = (size_t)A.n_tasks;
-        if ((rc = ensure(ctx, ctx->d_fb, 256 + 3 * list_words * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, ctx->d_fb, 256 + 4 * list_words * sizeof(uint32_t)))) return rc;
         uint32_t* hdr = (uint32_t*)ctx->d_fb.p;
         uint32_t* lists[2] = {hdr + 64, hdr + 64 + list_words};
         uint32_t* ulist = hdr + 64 + 2 * list_words;
+        uint32_t* elist = hdr + 64 + 3 * list_words;                 // the tasks of the score-only launch (header words 60 / 61: its length, the other list's)
         HIPCHK(ctx, hipMemsetAsync(hdr, 0, 256, s));
         const uint64_t cus = (uint64_t)ctx->prop.multiProcessorCount;
         int tier = 0;                                            // band tiers so far; the next one reads lists[(tier - 1) & 1]
@@ -300,6 +304,37 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
             }
             // band tier t (0: 30 diagonals, 1: 62): the packed kernel if the tier has one, then the 32-bit kernel of the same band --
             // over everything if there is no packed kernel, else over the tasks the packed kernel could not pair
+            // In front of the first band tier, when that tier has its packed kernel: the tasks whose read is as long as its reference and differs
+            // from it in few columns (c2_align_partition_kernel) go through the SCORE-ONLY packed fill (c2_align_diags_kernel: no pointer bits,
+            // no pointer words) -- it finishes the ones whose alignment is the main diagonal, which is most of them, and appends the rest to the
+            // list of the other tasks, which the first tier then runs as before.  (Not for an all-references batch of several references: its
+            // pairs are formed by the order of the tasks.  C2_NO_SCORE_TIER=1 switches the stage off.)
+            bool score_stage = g.pk && !(A.all_refs && A.n_refs > 1) && !getenv("C2_NO_SCORE_TIER") && ctx->kernel_mode == 0 &&
+                               tier_can_serve(ctx, 32, min_lj, A.max_lj);
+            if (score_stage) {
+                c2_partition_args PA;
+                PA.A = A; PA.eq_list = elist; PA.eq_count = hdr + 60; PA.ne_list = lists[1]; PA.ne_count = hdr + 61;
+                PA.max_mismatch = 6;                                     // (of the last 32 columns)
+                if (const char* e = getenv("C2_SCORE_TIER_MAX_MISMATCH")) PA.max_mismatch = atoi(e);
+                const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + C2_PART_CHUNK - 1) / C2_PART_CHUNK, cus * 16));
+                hipLaunchKernelGGL(c2_align_partition_kernel, dim3(pgrid), dim3(256), C2_PART_CHUNK + 64, s, PA);
+                HIPCHK(ctx, hipGetLastError());
+                const uint64_t resident = cus * (uint64_t)g.blocks_pk;
+                const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + 7) / 8, resident));
+                c2_align_args T = A;
+                T.task_list = elist; T.task_count = hdr + 60;
+                T.fb_list = lists[1]; T.fb_count = hdr + 61;             // what it cannot finish joins the other tasks
+                T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
+                T.work_counter = (unsigned long long*)(hdr + 16 + 2 * launch);
+                ++launch;
+                T.plane = nullptr; T.plane_words_per_wg = 0;
+                if (ctx->pk_beta > 0) hipLaunchKernelGGL((c2_align_diags_kernel<8, true>), dim3(grid), dim3(64), g.lds_pk, s, T);
+                else                  hipLaunchKernelGGL((c2_align_diags_kernel<8, false>), dim3(grid), dim3(64), g.lds_pk, s, T);
+                HIPCHK(ctx, hipGetLastError());
+                start_first();                                          // (the timing split's "first kernel" is the one that follows)
+            }
+            else start_first();
+            ctx->last_score_stage = score_stage; ctx->last_n_tasks = A.n_tasks;
             for (int t = 0; t < 2; ++t) {
                 const bool packed = t == 0 ? g.pk : g.pk2;
                 if (!packed && !g.x[t]) continue;
@@ -310,6 +345,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + na - 1) / na, resident));
                     c2_align_args T = A;
                     chain(T, false, true);
+                    if (t == 0 && score_stage) { T.task_list = lists[1]; T.task_count = hdr + 61; }     // (the tasks the score-only stage did not take or could not finish)
                     T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = t == 0 ? g.plane_words_pk : g.plane_words_pk2;
                     const bool a32 = ctx->pk_beta > 0;
                     if (t == 0) { if (a32) hipLaunchKernelGGL((c2_align_diagp_kernel<8, true>), dim3(grid), dim3(64), g.lds_pk, s, T);
@@ -642,6 +678,22 @@ int c2_band_info(c2_ctx* ctx, int32_t max_read_len, int32_t* band_lanes, int32_t
     return 0;
 }
 
+// The score-only stage of the most recent batch: did it run, how many tasks did the partition give it, how many did it finish.
+int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* finished) {
+    if (!ctx || !ran || !tasks || !finished) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *ran = ctx->last_score_stage ? 1 : 0; *tasks = 0; *finished = 0;
+    if (ctx->last_score_stage && ctx->d_fb.p) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        uint32_t c[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpy(c, (const uint32_t*)ctx->d_fb.p + 60, 8, hipMemcpyDeviceToHost));
+        // every task is in one of the two lists; what the stage could not finish was appended to the second one
+        const int64_t handed_on = (int64_t)c[1] - ((int64_t)ctx->last_n_tasks - (int64_t)c[0]);
+        *tasks = (int64_t)c[0]; *finished = (int64_t)c[0] - handed_on;
+    }
+    return 0;
+}
+
 int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4) {
     if (!ctx || !n_tiers || !left_over4) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -664,7 +716,8 @@ int c2_chain_info(c2_ctx* ctx, int32_t max_read_len, uint32_t* kernels, uint8_t*
     int rc = geometry(ctx, max_read_len, g);
     if (rc) return rc;
     *kernels = (g.pk ? 1u : 0u) | (g.x[0] ? 2u : 0u) | (g.pk2 ? 4u : 0u) | (g.x[1] ? 8u : 0u) | (g.pk3 ? 16u : 0u) | (g.diag ? 32u : 0u) |
-               (g.band_lanes > 0 ? 64u : 0u) | (g.full_hbm ? 128u : 0u) | ((g.pk && ctx->pk_beta > 0) ? 256u : 0u);
+               (g.band_lanes > 0 ? 64u : 0u) | (g.full_hbm ? 128u : 0u) | ((g.pk && ctx->pk_beta > 0) ? 256u : 0u) |
+               ((g.pk && ctx->kernel_mode == 0 && !getenv("C2_NO_SCORE_TIER")) ? 512u : 0u);
     if (ref_packed_ok) for (int r = 0; r < ctx->n_refs; ++r) ref_packed_ok[r] = ctx->ref_pk_ok[r];
     return 0;
 }
@@ -696,14 +749,14 @@ int c2_timing_read_split(c2_ctx* ctx, double* total_ms, double* first_kernel_ms,
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, t.a, t.b));
         tot += ms;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, t.a, t.m));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, t.m0, t.m));
         first += ms;
     }
     if (total_ms) *total_ms = tot;
     if (first_kernel_ms) *first_kernel_ms = first;
     if (launches) *launches = (int64_t)ctx->timed.size();
     if (reset) {
-        for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.m); (void)hipEventDestroy(t.b); }
+        for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.m0); (void)hipEventDestroy(t.m); (void)hipEventDestroy(t.b); }
         ctx->timed.clear();
     }
     return 0;

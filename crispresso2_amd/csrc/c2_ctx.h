@@ -26,7 +26,7 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-struct TimedLaunch { hipEvent_t a, m, b; };   // before the chain, after its first kernel, after its last
+struct TimedLaunch { hipEvent_t a, m0, m, b; };   // before the chain, before / after its dominant kernel (the first band tier's), after its last
 
 struct c2_ctx {
     int device = 0;
@@ -80,6 +80,7 @@ struct c2_ctx {
     DevBuf d_lists, d_lists_out;   // batched classifier: staging and flat output
     DevBuf d_order;        // count kernel: histogram + tasks grouped by reference
     int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
+    bool last_score_stage = false; uint64_t last_n_tasks = 0;   // the last run_align: did the score-only stage run, over how many tasks in all
     int occ_lds[5][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
     int occ_blocks[5][3] = {};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table

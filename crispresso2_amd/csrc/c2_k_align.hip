@@ -1037,7 +1037,9 @@ __device__ __forceinline__ void c2_pk_push_none(unsigned& acc) { acc = 0x4040404
 template <bool ADD32>
 __device__ __forceinline__ unsigned c2_pk_sum(const unsigned a, const unsigned b) { return ADD32 ? a + b : c2_pk_add(a, b); }
 
-template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
+// SCORE: no pointer bits are formed -- only the gap-free predicate of the E cells ("H is not I" and "M beats J": the signs of two packed
+// differences, ANDed into S.gf bits 15 / 31).  What such a fill can finish is the alignment that IS the main diagonal (c2_align_diags_kernel).
+template <bool MASK, bool LASTCOL, bool ROW, bool ADD32, bool SCORE = false>
 __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2_diag_row rowE, const c2_diag_row rowO, const unsigned sE, const unsigned sO,
                                            const unsigned ge2, const int startE, const int startO, const bool lastcol)
 {
@@ -1054,9 +1056,10 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
         const unsigned Mn = c2_pk_sum<ADD32>(S.HE, sE);
         const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
         // I opened (iFromM > iExt), J opened (jFromM > jExt), NOT H is I (In < Hn; In <= Hn always), NOT J beats M (Jn < Mn)
-        c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
+        if (SCORE) S.gf &= c2_pk_sub(In, Hn) & c2_pk_sub(Jn, Mn);
+        else c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
         S.ME = Mn; S.IE = In; S.JE = Jn; S.HE = Hn;
-    } else {
+    } else if (!SCORE) {
         c2_pk_push_none(S.acc);
     }
     const unsigned lfM = (unsigned)(ROW ? c2_rshl1z((int)S.ME) : c2_shl1z((int)S.ME));
@@ -1071,9 +1074,9 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
         const unsigned Jn = c2_pk_max(jFromM, jExt);
         const unsigned Mn = c2_pk_sum<ADD32>(S.HO, sO);
         const unsigned Hn = c2_pk_max(c2_pk_max(Mn, Jn), In);
-        c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
+        if (!SCORE) c2_pk_push4(S.acc, c2_pk_sub(iExt, iFromM), c2_pk_sub(jExt, jFromM), c2_pk_sub(In, Hn), c2_pk_sub(Jn, Mn));
         S.MO = Mn; S.IO = In; S.JO = Jn; S.HO = Hn;
-    } else {
+    } else if (!SCORE) {
         c2_pk_push_none(S.acc);
     }
 }
@@ -1404,7 +1407,7 @@ __device__ __forceinline__ int c2_tab_load(const int* T, const int lane) { retur
 // look-ups (row table offset + pair symbol), requested at the top of the group.
 struct c2_pk_cap { unsigned H, gf; };                              // the two alignments' H(Li, Lj) and gap-free words, captured at the cell (Li, Lj)
 
-template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
+template <bool MASK, bool LASTCOL, bool ROW, bool ADD32, bool SCORE = false>
 __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
                                             const c2_diag_row (&R)[5], const int (&C)[4], c2_diag_row (&RN)[5], int (&CN)[4],
                                             const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
@@ -1422,32 +1425,34 @@ __device__ __forceinline__ void c2_pk_group(c2_pk_state& S, const int g, const c
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int k = 4 * g + q;
-        c2_pk_pair<MASK, LASTCOL, ROW, ADD32>(S, 2 * k, R[q], R[q + 1], sc[2 * q], sc[2 * q + 1], ge2, L.startE, L.startO, LASTCOL && (k == L.kLast));
-        if (q == 1) { w0 = S.acc; S.gf &= w0; }                    // anti-diagonals 8g .. 8g+3 of both alignments
-        if (q == 3) S.gf &= S.acc;                                  // ... 8g+4 .. 8g+7
+        c2_pk_pair<MASK, LASTCOL, ROW, ADD32, SCORE>(S, 2 * k, R[q], R[q + 1], sc[2 * q], sc[2 * q + 1], ge2, L.startE, L.startO, LASTCOL && (k == L.kLast));
+        if (!SCORE && q == 1) { w0 = S.acc; S.gf &= w0; }          // anti-diagonals 8g .. 8g+3 of both alignments
+        if (!SCORE && q == 3) S.gf &= S.acc;                        // ... 8g+4 .. 8g+7
         if (LASTCOL && k == L.kCap) {
             CAP.H = L.capOdd ? S.HO : S.HE;
             // q even: the word in the making holds two cells so far, the E cell in bits 5..4 of every byte ("H is not I" / "M beats J" = bit 4)
-            CAP.gf = (q & 1) ? S.gf : (S.gf & (S.acc | 0xEFEFEFEFu));
+            // (SCORE: S.gf is the predicate itself, the cell (Li, Lj) included)
+            CAP.gf = SCORE ? S.gf : ((q & 1) ? S.gf : (S.gf & (S.acc | 0xEFEFEFEFu)));
         }
     }
+    if (SCORE) return;                                              // (no pointer word: nothing is traced from this fill)
     // alignment A's word: bytes 0, 1 of the two accumulators, alignment B's: bytes 2, 3 (layout: c2_diagx_plane::fetch)
     wordsA[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x05040100u);
     wordsB[g * wordStride] = __builtin_amdgcn_perm(S.acc, w0, 0x07060302u);
 }
 
-template <bool MASK, bool LASTCOL, bool ROW, bool ADD32>
+template <bool MASK, bool LASTCOL, bool ROW, bool ADD32, bool SCORE = false>
 __device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g_stop, const c2_diagx_lane& L, const unsigned ge2, c2_pk_cap& CAP,
                                              c2_diag_row (&RA)[5], int (&CA)[4], c2_diag_row (&RB)[5], int (&CB)[4],
                                              const c2_diag_row* rows, const unsigned char* lds, const unsigned lutBase,
                                              unsigned* wordsA, unsigned* wordsB, const int wordStride)
 {
     for (; g + 1 <= g_stop; g += 2) {
-        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
-        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g + 1, L, ge2, CAP, RB, CB, RA, CA, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW, ADD32, SCORE>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW, ADD32, SCORE>(S, g + 1, L, ge2, CAP, RB, CB, RA, CA, rows, lds, lutBase, wordsA, wordsB, wordStride);
     }
     if (g <= g_stop) {
-        c2_pk_group<MASK, LASTCOL, ROW, ADD32>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
+        c2_pk_group<MASK, LASTCOL, ROW, ADD32, SCORE>(S, g, L, ge2, CAP, RA, CA, RB, CB, rows, lds, lutBase, wordsA, wordsB, wordStride);
         ++g;
 #pragma unroll
         for (int q = 0; q < 5; ++q) RA[q] = RB[q];
@@ -1456,7 +1461,7 @@ __device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g
     }
 }
 
-template <int NA, bool PK, bool ADD32 = false>
+template <int NA, bool PK, bool ADD32 = false, bool SCORE = false>
 __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
 {
     const int beta = (PK && ADD32) ? (int)A.pk_beta : 0;               // per-anti-diagonal bias of the 32-bit-add variant (else 0)
@@ -1696,6 +1701,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                 ok = C2_TF(tvb, C2X_PACKED) && rf.diag_rows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
                      D >= d0 && D <= d0 + BANDW - 1;
                 if (PK && ok) ok = rf.pk_ok != 0;               // the reference must be admitted to the int16 fill (c2_pk_eligible); pairs were formed by the staging
+                if (SCORE && ok) ok = Li == Lj;                  // (the score-only fill finishes nothing but the main diagonal)
                 if (ok) {
                     any_ok = true;
                     minsc = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
@@ -1757,12 +1763,12 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             unsigned ge2 = c2_pk_dup(ge + beta);
             const unsigned lutBase = P.pairlut;
             if (gC <= gA_stop) {
-                c2_pk_groups<true, true, ROWDPP, ADD32>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<true, true, ROWDPP, ADD32, SCORE>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             } else {
-                c2_pk_groups<true, false, ROWDPP, ADD32>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
-                c2_pk_groups<false, false, ROWDPP, ADD32>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<true, false, ROWDPP, ADD32, SCORE>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<false, false, ROWDPP, ADD32, SCORE>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             }
-            c2_pk_groups<false, true, ROWDPP, ADD32>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+            c2_pk_groups<false, true, ROWDPP, ADD32, SCORE>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
             C2_LANES_ACTIVE_END()
         }
         if (!PK && any_ok) {
@@ -1843,7 +1849,8 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             if (PK) {
                 const int half = 16 * (s & 1);
                 Hend = (int)(int16_t)(((unsigned)__builtin_amdgcn_readlane((int)CAP.H, lane_end) >> half) & 0xffffu) - PKB - beta * (Li + Lj);
-                gapfree = (((unsigned)__builtin_amdgcn_readlane((int)CAP.gf, lane_end) >> half) & 0x1111u) == 0x1111u;   // the E cells (cells 0 and 2 of a word): bits 0 and 4 of both bytes
+                const unsigned gfw = (unsigned)__builtin_amdgcn_readlane((int)CAP.gf, lane_end) >> half;
+                gapfree = SCORE ? ((gfw & 0x8000u) != 0u) : ((gfw & 0x1111u) == 0x1111u);   // the E cells (cells 0 and 2 of a word): bits 0 and 4 of both bytes; SCORE: the AND of their sign bits
             } else {
                 Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
                 gapfree = __builtin_amdgcn_readlane((int)GF.cap, lane_end) == 0;
@@ -1853,6 +1860,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             if (!(Hend > U)) { m_full |= 1u << s; continue; }
             if (A.reserved & 2) continue;                              // (debug knob C2_DEBUG_SKIP_EPILOGUE: certified, nothing written)
             if (Li == Lj && gapfree) m_gapfree |= 1u << s;
+            else if (SCORE) m_full |= 1u << s;                         // (certified, but not the main diagonal: the launch with the pointer words takes it)
             else m_trace |= 1u << s;
         }
         constexpr int STG = 16 / NG > 8 ? 8 : 16 / NG;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
@@ -1880,7 +1888,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             if ((m_gapfree >> s) & 1u) {
                 if (rows_aligned && Li <= 256) c2_emit_gapless4(A, wg_of(s), win_of(s), task, Li, lane, rec);
                 else c2_emit_gapless(A, wg_of(s), task, Li, lane, rec);
-            } else if ((m_trace >> s) & 1u) {
+            } else if (!SCORE && ((m_trace >> s) & 1u)) {
                 const int d0 = C2_TF(tv, C2X_D0), minsc = C2_TF(tv, C2X_MINSC);
                 const c2_wg W = wg_of(s);
                 // the alignment's pointer words: registers (requested from HBM/L2 before the previous alignment's
@@ -1928,6 +1936,13 @@ __global__ __launch_bounds__(64, 3) void c2_align_diagx_kernel(c2_align_args A) 
 template <int NA, bool ADD32 = false>
 __global__ __launch_bounds__(64, 3) void c2_align_diagp_kernel(c2_align_args A) { c2_diagx_body<NA, true, ADD32>(A); }
 
+// The same packed fill WITHOUT pointer bits (c2_pk_pair<.., SCORE>): per cell pair 4 instructions for the gap-free predicate instead of 21 for eight
+// pointer bits, no pointer word stored.  It can finish exactly one kind of alignment -- read and reference of one length, optimal path = the main
+// diagonal, certificate holds -- which is most reads of an amplicon run; everything else it hands on, untouched, to the launch that keeps pointers.
+// The host puts it in front of the first band tier over the tasks c2_align_partition_kernel expects to be of that kind.
+template <int NA, bool ADD32 = false>
+__global__ __launch_bounds__(64, 3) void c2_align_diags_kernel(c2_align_args A) { c2_diagx_body<NA, true, ADD32, true>(A); }
+
 // Hardware self-test of the cross-lane primitives the DP relies on (wave_shr:1 with `old` kept in lane 0).
 __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
 {
@@ -1956,6 +1971,87 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
     C2_LANES_ACTIVE_END()
     out[320 + lane] = rz;
     out[384 + lane] = lz;
+}
+
+// Which tasks is c2_align_diags_kernel likely to finish?  Read and reference of one length (forward strand, 32 .. 256 bases) whose LAST 32 columns
+// differ in at most `max_mismatch` places: a read with an indel is shifted against the reference behind the indel and differs there in most
+// columns, a read without one in hardly any.  A prediction only -- the score-only fill verifies (gap-free predicate + certificate) and hands on
+// what was predicted wrongly; the other list goes to the launch that keeps pointers right away, so that (almost) no alignment with gaps is filled
+// twice.  One lane per task; both lists in task order inside a chunk of C2_PART_CHUNK tasks, the chunks in the order of their atomics.
+struct c2_partition_args {
+    c2_align_args A;
+    uint32_t* eq_list; uint32_t* eq_count;      // tasks for the score-only launch
+    uint32_t* ne_list; uint32_t* ne_count;      // the others
+    int32_t max_mismatch;
+};
+
+#define C2_PART_CHUNK 4096                         // tasks per workgroup and pair of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
+__global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_args P)
+{
+    const c2_align_args& A = P.A;
+    uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] 1: score-only launch, 0: the other list, 2: no such task
+    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [8] per wavefront: candidates, others; [8..11]: bases of the two lists, totals
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * C2_PART_CHUNK; chunk < A.n_tasks; chunk += (uint64_t)gridDim.x * C2_PART_CHUNK) {
+        // ---- one lane per task: mismatching columns among the LAST 32 of read and reference (an indel anywhere in front of them shifts them
+        //      against each other; one inside them is predicted wrongly and costs that alignment a second fill, no more)
+        for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
+            const int slot = r * 256 + tid;
+            const uint64_t task = chunk + (uint64_t)slot;
+            const bool valid = task < A.n_tasks;
+            int mm = 0x10000;                                       // (not a candidate)
+            if (valid) {
+                uint64_t read_id; int ref_id;
+                if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
+                else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
+                const int rc = A.strands ? (int)A.strands[task] : 0;
+                const uint64_t off = A.offsets[read_id];
+                const int Lj = (int)(A.offsets[read_id + 1] - off);
+                const c2_dev_ref* rf = A.refs + ref_id;
+                if (!rc && Lj == rf->len && Lj >= 32 && Lj <= 256 && rf->pk_ok) {
+                    mm = 0;
+                    const uint8_t* rd = A.reads + off + (Lj - 32);
+                    const uint8_t* f = rf->seq + (Lj - 32);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        uint32_t a, b;
+                        __builtin_memcpy(&a, rd + 4 * q, 4); __builtin_memcpy(&b, f + 4 * q, 4);
+                        const uint32_t x = a ^ b;
+                        mm += __builtin_popcount((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
+                    }
+                }
+            }
+            flag[slot] = valid ? (mm <= P.max_mismatch ? 1 : 0) : 2;
+        }
+        __syncthreads();
+        // ---- thread t owns tasks 16 t .. 16 t + 15 of the chunk: positions by a scan over the workgroup, two atomics per chunk
+        unsigned n_eq = 0, n_ne = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const unsigned f = flag[16 * tid + k]; n_eq += f == 1u; n_ne += f == 0u; }
+        unsigned pack = n_eq | (n_ne << 16), incl = pack;           // (both counts <= 4096: 16 bits each)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) part[wv] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const unsigned x = part[v]; if (v < wv) before += x; total += x; }
+        if (tid == 0) {
+            part[8] = (total & 0xffffu) ? atomicAdd(P.eq_count, total & 0xffffu) : 0u;
+            part[9] = (total >> 16) ? atomicAdd(P.ne_count, total >> 16) : 0u;
+        }
+        __syncthreads();
+        unsigned excl = before + incl - pack;
+        unsigned pe = part[8] + (excl & 0xffffu), pn = part[9] + (excl >> 16);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned f = flag[16 * tid + k];
+            const uint32_t task = (uint32_t)(chunk + (uint64_t)(16 * tid + k));
+            if (f == 1u) P.eq_list[pe++] = task;
+            else if (f == 0u) P.ne_list[pn++] = task;
+        }
+        __syncthreads();                                            // (the flags are overwritten by the next chunk)
+    }
 }
 
 // ... and of the row forms (c2_rshr1z / c2_rshl1z: the hand-off of the 16-lane groups of c2_align_diagp_kernel<8>), folded into an

@@ -140,6 +140,29 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             T.pair_order = packed_kernel && !from_unpaired && tier == 0 && T.all_refs && T.n_refs > 1;
             work_counter = 0;
         };
+        // the score-only stage in front of the first band tier, as the host library wires it (c2_api_align.hip: c2_align_partition_kernel, then
+        // c2_align_diags_kernel over its first list; what that cannot finish joins the second list, which the first tier then runs).
+        // C2_EMU_NO_SCORE_TIER=1 switches it off.
+        bool score_stage = false;
+        std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1);
+        uint32_t e_count = 0, ne_count = 0;
+        if (any_pk && (band_lanes == -87 || band_lanes == -8 || band_lanes == -80) && !(A.all_refs && A.n_refs > 1) && !getenv("C2_EMU_NO_SCORE_TIER")) {
+            const c2_diagx_plan PP = c2_make_diagx_plan(8, A.max_li, A.max_lj, true);
+            if (PP.total > sizeof(c2_smem)) return -5;
+            score_stage = true;
+            c2_partition_args PA;
+            PA.A = A; PA.eq_list = elist.data(); PA.eq_count = &e_count; PA.ne_list = lists[1]; PA.ne_count = &ne_count;
+            PA.max_mismatch = getenv("C2_SCORE_TIER_MAX_MISMATCH") ? atoi(getenv("C2_SCORE_TIER_MAX_MISMATCH")) : 6;
+            emu::launch(2, [&] { c2_align_partition_kernel(PA); }, 256);      // (c2_smem: C2_PART_CHUNK + 64 bytes)
+            c2_align_args T = A;
+            T.task_list = elist.data(); T.task_count = &e_count; T.fb_list = lists[1]; T.fb_count = &ne_count;
+            T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
+            work_counter = 0;
+            T.plane = nullptr; T.plane_words_per_wg = 0;
+            if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch score-only stage over %u tasks (%u others)\n", e_count, ne_count);
+            if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diags_kernel<8, true>(T); });
+            else             emu::launch(grid, [&] { c2_align_diags_kernel<8, false>(T); });
+        }
         // -5: five alignments per wavefront (lane groups of 12, lanes 60..63 idle); -75: the chain 5 -> 2 -> 1 -> full plane
         for (int t = 0; t < 2; ++t) {
             const int pna = t == 0 ? 8 : 4, xna = t == 0 ? ((band_lanes == -5 || band_lanes == -75) ? 5 : 4) : 2;
@@ -152,6 +175,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
                 plane.assign((size_t)grid * PP.n_words * 128u, 0xdeadbeefu);
                 c2_align_args T = A;
                 chain(T, false, true);
+                if (t == 0 && score_stage) { T.task_list = lists[1]; T.task_count = &ne_count; }
                 T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 128u;
                 if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed %d tier %d\n", pna, tier);
                 if (pk_beta > 0) { if (pna == 8) emu::launch(grid, [&] { c2_align_diagp_kernel<8, true>(T); });
