@@ -1185,3 +1185,62 @@ def test_band_tiers_no_read_of_the_batch_can_use_are_not_launched(mats, ctx, rea
         T = int(records["aln_len"][i])
         s1, s2, _ = oracle.global_align(reads[i].tobytes().decode(), amp, m, g, -20, -2)
         assert outs[1][0][i, :T].tobytes().decode() == s1 and outs[1][1][i, :T].tobytes().decode() == s2, i
+
+
+@pytest.mark.gpu
+def test_score_only_stage_changes_no_result(mats, ctx, monkeypatch):
+    """The stage in front of the first band tier (c2_align_partition_kernel + c2_align_diags_kernel<8>: the packed fill without pointer bits over
+    the reads predicted to align along the main diagonal) against the same batch with the stage switched off, and against the oracle: reads equal
+    to the amplicon, with substitutions only, with indels in the middle (predicted right: never in the stage), and the WRONG predictions -- an
+    indel inside the last 32 columns, compensated so that the read keeps the amplicon's length, and a substitution-rich tail on a gap-free read."""
+    import torch
+    from crispresso2_amd import synth, _native
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    m = mats["EDNAFULL"]
+    L = 250
+    amp, g, _ = synth.amplicon_setup(L)
+    inc = list(range(L // 2 - 10, L // 2 + 10))
+    rng = np.random.default_rng(11)
+    other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+
+    def subs(s, ps):
+        s = list(s)
+        for p_ in ps:
+            s[p_] = other[s[p_]]
+        return "".join(s)
+    reads = [amp, subs(amp, [3, 100]), subs(amp, [249]), subs(amp, range(222, 250, 3))]             # gap-free; the last one with a busy tail
+    for cut in (30, 125, 200, 236, 243, 246, 248):
+        for d in (1, 2, 3, 7):
+            reads.append((amp[:cut] + amp[cut + d:] + "ACGTACGTAC"[:d])[:L])                             # deletion, the length kept by bases behind the end
+            reads.append((amp[:cut] + "TGCATGCATG"[:d] + amp[cut:])[:L])                                 # insertion, the end cut off
+    reads += [synth.make_reads(L, 400)[i].tobytes().decode() for i in range(400)]
+    n = len(reads)
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    al = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    stride = al.stride_for(L)
+    d_reads = torch.from_numpy(arena.copy()).to(dev)
+    d_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    s = torch.cuda.current_stream().cuda_stream
+    outs, infos = [], []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("C2_NO_SCORE_TIER", "1")
+        o1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        o2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        rec = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+        al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, L, stream=s)
+        torch.cuda.synchronize()
+        infos.append(ctx.score_stage_info())
+        outs.append((o1.cpu().numpy(), o2.cpu().numpy(), rec.cpu().numpy()))
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+    ran, took, finished = infos[0]
+    assert ran and not infos[1][0]
+    assert 100 < finished < took < n                                   # (it took some it could not finish: the wrong predictions)
+    records = outs[0][2].view(_native.REC_DTYPE).reshape(-1)
+    assert (records["status"] == 0).all()
+    for i in range(n):
+        T = int(records["aln_len"][i])
+        s1, s2, _ = oracle.global_align(reads[i], amp, m, g, -20, -2)
+        assert outs[0][0][i, :T].tobytes().decode() == s1 and outs[0][1][i, :T].tobytes().decode() == s2, (i, reads[i])
