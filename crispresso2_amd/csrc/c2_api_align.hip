@@ -319,7 +319,16 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + C2_PART_CHUNK - 1) / C2_PART_CHUNK, cus * 16));
                 hipLaunchKernelGGL(c2_align_partition_kernel, dim3(pgrid), dim3(256), C2_PART_CHUNK + 64, s, PA);
                 HIPCHK(ctx, hipGetLastError());
-                const uint64_t resident = cus * (uint64_t)g.blocks_pk;
+                // (its own LDS plan -- no staging area for pointer words -- and its own residency)
+                const c2_diagx_plan PS = c2_make_diagx_plan(8, ctx->max_li, g.max_lj, true, true);
+                if (ctx->occ_score_lds != (int)PS.total * (ctx->pk_beta > 0 ? -1 : 1)) {
+                    int nb = 0;
+                    const void* fn = ctx->pk_beta > 0 ? (const void*)c2_align_diags_kernel<8, true> : (const void*)c2_align_diags_kernel<8, false>;
+                    HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, PS.total));
+                    ctx->occ_score_blocks = nb < 1 ? 1 : nb; ctx->occ_score_lds = (int)PS.total * (ctx->pk_beta > 0 ? -1 : 1);
+                }
+                const uint64_t resident = cus * (uint64_t)ctx->occ_score_blocks;
                 const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + 7) / 8, resident));
                 c2_align_args T = A;
                 T.task_list = elist; T.task_count = hdr + 60;
@@ -328,8 +337,8 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 T.work_counter = (unsigned long long*)(hdr + 16 + 2 * launch);
                 ++launch;
                 T.plane = nullptr; T.plane_words_per_wg = 0;
-                if (ctx->pk_beta > 0) hipLaunchKernelGGL((c2_align_diags_kernel<8, true>), dim3(grid), dim3(64), g.lds_pk, s, T);
-                else                  hipLaunchKernelGGL((c2_align_diags_kernel<8, false>), dim3(grid), dim3(64), g.lds_pk, s, T);
+                if (ctx->pk_beta > 0) hipLaunchKernelGGL((c2_align_diags_kernel<8, true>), dim3(grid), dim3(64), PS.total, s, T);
+                else                  hipLaunchKernelGGL((c2_align_diags_kernel<8, false>), dim3(grid), dim3(64), PS.total, s, T);
                 HIPCHK(ctx, hipGetLastError());
                 start_first();                                          // (the timing split's "first kernel" is the one that follows)
             }

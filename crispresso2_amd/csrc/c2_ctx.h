@@ -55,6 +55,7 @@ struct c2_ctx {
     int pk_bias = 0;                    // ... and this value bias (c2_pk_add32_bias_needed)
     int pk_beta = 0;                    // > 0: the admitted references run the packed kernels' 32-bit-add variant with this bias (c2_pk_add32_ok)
     bool pk_dirty = true;
+    int occ_score_lds = -1, occ_score_blocks = 0;            // residency of c2_align_diags_kernel<8> with its LDS plan
     int occ_pk_lds = -1, occ_pk_blocks = 0, occ_pk2_lds = -1, occ_pk2_blocks = 0, occ_pk3_lds = -1, occ_pk3_blocks = 0;
     // staging for the host batch path and the per-call path
     DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;

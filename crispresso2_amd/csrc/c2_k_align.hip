@@ -1102,7 +1102,8 @@ struct c2_diagx_plan {
     uint32_t codes, read, code, ref, incp, win;                     // offsets inside one alignment's slot
 };
 
-__host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, int max_lj, bool pk = false) {
+// score_only (c2_align_diags_kernel): nothing is traced, so the staging area of an alignment's pointer words is not part of the plan
+__host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, int max_lj, bool pk = false, bool score_only = false) {
     c2_diagx_plan p;
     const uint32_t lpa = 64u / (uint32_t)(pk ? na / 2 : na);        // lanes of one lane group (pk: two alignments share a group, 16 bits each)
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
@@ -1124,7 +1125,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
         const uint32_t need = (uint32_t)(na / 2) * p.pcodes_bytes, have = 2u * c2_align16((uint32_t)max_li + (uint32_t)max_lj);
         if (need > have) { off += need - have; }                    // (tmp_read, tmp_ref, stage are consecutive: the tables may run into `stage`, which is rewritten before use too)
         p.stage = p.tmp_ref + c2_align16((uint32_t)max_li + (uint32_t)max_lj) + (need > have ? need - have : 0u);
-        off = p.stage + p.n_words * lpa * 4u;
+        off = p.stage + (score_only ? 0u : p.n_words * lpa * 4u);
         p.pairlut = C2_PK_LUT_LDS_OFFSET;                           // per reference symbol: the score pair of every (symbol of read A, symbol of read B)
         p.group0 = off;
         p.gref = 0; p.gincp = c2_align16((uint32_t)max_li);
@@ -1475,7 +1476,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
     constexpr int NL = (ROWDPP || NG == 1) ? LPA : LPA - 1, BANDW = 2 * NL;   // (one group = the whole wavefront: its ends read 0 anyway)
     const int lane = threadIdx.x, grp = lane / LPA, sl = lane - grp * LPA;
     const int slot = PK ? 2 * grp : grp;                             // (PK: the group's first slot)
-    const c2_diagx_plan P = c2_make_diagx_plan(NA, A.max_li, A.max_lj, PK);
+    const c2_diagx_plan P = c2_make_diagx_plan(NA, A.max_li, A.max_lj, PK, SCORE);
     unsigned char* sCodeOf = c2_smem + P.codeof;
     int* sTab = (int*)(c2_smem + P.table);
     auto wg_of = [&](const int s) {

@@ -147,7 +147,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1);
         uint32_t e_count = 0, ne_count = 0;
         if (any_pk && (band_lanes == -87 || band_lanes == -8 || band_lanes == -80) && !(A.all_refs && A.n_refs > 1) && !getenv("C2_EMU_NO_SCORE_TIER")) {
-            const c2_diagx_plan PP = c2_make_diagx_plan(8, A.max_li, A.max_lj, true);
+            const c2_diagx_plan PP = c2_make_diagx_plan(8, A.max_li, A.max_lj, true, true);
             if (PP.total > sizeof(c2_smem)) return -5;
             score_stage = true;
             c2_partition_args PA;
