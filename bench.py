@@ -826,7 +826,7 @@ def main():
     if score_info[0]:
         ran_, took_, fin_ = score_info
         if ran_:
-            score_stage = {"kernels": ["c2_align_partition_kernel", "c2_align_diags_kernel<8" + pkv], "tasks": took_, "finished": fin_,
+            score_stage = {"kernels": ["c2_align_partition_kernel", "c2_align_diags_kernel<%s" % ("8" if os.environ.get("C2_SCORE_TIER_NA") == "8" else "16") + pkv], "tasks": took_, "finished": fin_,
                            "note": "reads as long as the amplicon whose last 32 columns differ from it in at most 6 places go through the packed fill without pointer bits; "
                                    "it finishes those whose optimal alignment is the main diagonal (gap-free predicate + certificate) and hands the rest, "
                                    "with all other reads, to the first band tier"}

@@ -292,7 +292,7 @@ class Context:
 
     CHAIN_KERNELS = ["c2_align_diagp_kernel<8>", "c2_align_diagx_kernel<4>", "c2_align_diagp_kernel<4>", "c2_align_diagx_kernel<2>",
                      "c2_align_diagp_kernel<2>", "c2_align_diag_kernel", "banded row-strip", "full plane in HBM scratch", "packed fill with 32-bit adds",
-                     "score-only stage (c2_align_partition_kernel + c2_align_diags_kernel<8>) in front of the first band tier"]
+                     "score-only stage (c2_align_partition_kernel + c2_align_diags_kernel<16>) in front of the first band tier"]
 
     def chain_info(self, max_read_len, n_refs):
         """-> (names of the kernels in the launch chain for reads up to max_read_len, [packed fill admits reference r])"""

@@ -319,17 +319,25 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + C2_PART_CHUNK - 1) / C2_PART_CHUNK, cus * 16));
                 hipLaunchKernelGGL(c2_align_partition_kernel, dim3(pgrid), dim3(256), C2_PART_CHUNK + 64, s, PA);
                 HIPCHK(ctx, hipGetLastError());
-                // (its own LDS plan -- no staging area for pointer words -- and its own residency)
-                const c2_diagx_plan PS = c2_make_diagx_plan(8, ctx->max_li, g.max_lj, true, true);
-                if (ctx->occ_score_lds != (int)PS.total * (ctx->pk_beta > 0 ? -1 : 1)) {
+                // (its own LDS plan -- no staging area for pointer words -- and its own residency; SIXTEEN alignments per wavefront: lane groups of
+                //  8 lanes, 14 diagonals -- the alignments it can finish run along the main diagonal, and a band that narrow still certifies them;
+                //  C2_SCORE_TIER_NA=8: eight per wavefront, the first tier's geometry)
+                int sna = 16;
+                if (const char* e = getenv("C2_SCORE_TIER_NA")) sna = atoi(e) == 8 ? 8 : 16;
+                c2_diagx_plan PS = c2_make_diagx_plan(sna, ctx->max_li, g.max_lj, true, true);
+                if (sna == 16 && PS.total > 163840u) { sna = 8; PS = c2_make_diagx_plan(8, ctx->max_li, g.max_lj, true, true); }
+                const bool a32s = ctx->pk_beta > 0;
+                const void* fn = sna == 16 ? (a32s ? (const void*)c2_align_diags_kernel<16, true> : (const void*)c2_align_diags_kernel<16, false>)
+                                           : (a32s ? (const void*)c2_align_diags_kernel<8, true> : (const void*)c2_align_diags_kernel<8, false>);
+                const int key = (int)PS.total * (a32s ? -1 : 1) * (sna == 16 ? 2 : 1);
+                if (ctx->occ_score_lds != key) {
                     int nb = 0;
-                    const void* fn = ctx->pk_beta > 0 ? (const void*)c2_align_diags_kernel<8, true> : (const void*)c2_align_diags_kernel<8, false>;
                     HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
                     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, PS.total));
-                    ctx->occ_score_blocks = nb < 1 ? 1 : nb; ctx->occ_score_lds = (int)PS.total * (ctx->pk_beta > 0 ? -1 : 1);
+                    ctx->occ_score_blocks = nb < 1 ? 1 : nb; ctx->occ_score_lds = key;
                 }
                 const uint64_t resident = cus * (uint64_t)ctx->occ_score_blocks;
-                const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + 7) / 8, resident));
+                const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + sna - 1) / sna, resident));
                 c2_align_args T = A;
                 T.task_list = elist; T.task_count = hdr + 60;
                 T.fb_list = lists[1]; T.fb_count = hdr + 61;             // what it cannot finish joins the other tasks
@@ -337,8 +345,10 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 T.work_counter = (unsigned long long*)(hdr + 16 + 2 * launch);
                 ++launch;
                 T.plane = nullptr; T.plane_words_per_wg = 0;
-                if (ctx->pk_beta > 0) hipLaunchKernelGGL((c2_align_diags_kernel<8, true>), dim3(grid), dim3(64), PS.total, s, T);
-                else                  hipLaunchKernelGGL((c2_align_diags_kernel<8, false>), dim3(grid), dim3(64), PS.total, s, T);
+                if (sna == 16) { if (a32s) hipLaunchKernelGGL((c2_align_diags_kernel<16, true>), dim3(grid), dim3(64), PS.total, s, T);
+                                 else      hipLaunchKernelGGL((c2_align_diags_kernel<16, false>), dim3(grid), dim3(64), PS.total, s, T); }
+                else           { if (a32s) hipLaunchKernelGGL((c2_align_diags_kernel<8, true>), dim3(grid), dim3(64), PS.total, s, T);
+                                 else      hipLaunchKernelGGL((c2_align_diags_kernel<8, false>), dim3(grid), dim3(64), PS.total, s, T); }
                 HIPCHK(ctx, hipGetLastError());
                 start_first();                                          // (the timing split's "first kernel" is the one that follows)
             }

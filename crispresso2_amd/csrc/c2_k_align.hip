@@ -1109,7 +1109,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
     uint32_t off = 0;
     p.codeof = off;   off += 256u;                                  // character -> code
-    p.table = off;    off += 8u * 24u * 4u;                         // up to 8 slots x C2X_INTS
+    p.table = off;    off += 8u * 24u * 4u;                         // up to 8 slots x C2X_INTS (more slots: the table moves behind everything else, below)
     if (pk) off += c2_align16((uint32_t)C2_PK_LUT_CODES * C2_PK_LUT_STRIDE);                // pair-score tables at the FIXED offset C2_PK_LUT_LDS_OFFSET: it folds into the look-ups' immediate offset
     p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
     p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
@@ -1135,6 +1135,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
         p.codes = 0; p.read = 0; p.code = 0; p.ref = 0; p.incp = 0; p.win = 0;
         p.slot_bytes = c2_align16((uint32_t)max_lj);
         p.total = p.slot0 + (uint32_t)na * p.slot_bytes;
+        if (na > 8) { p.table = p.total; p.total += (uint32_t)na * 24u * 4u; }     // (the pair-score tables keep their fixed offset)
         return p;
     }
     p.slot0 = off;

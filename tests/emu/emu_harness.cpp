@@ -147,7 +147,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1);
         uint32_t e_count = 0, ne_count = 0;
         if (any_pk && (band_lanes == -87 || band_lanes == -8 || band_lanes == -80) && !(A.all_refs && A.n_refs > 1) && !getenv("C2_EMU_NO_SCORE_TIER")) {
-            const c2_diagx_plan PP = c2_make_diagx_plan(8, A.max_li, A.max_lj, true, true);
+            const int sna = (getenv("C2_SCORE_TIER_NA") && atoi(getenv("C2_SCORE_TIER_NA")) == 8) ? 8 : 16;
+            const c2_diagx_plan PP = c2_make_diagx_plan(sna, A.max_li, A.max_lj, true, true);
             if (PP.total > sizeof(c2_smem)) return -5;
             score_stage = true;
             c2_partition_args PA;
@@ -160,8 +161,10 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             work_counter = 0;
             T.plane = nullptr; T.plane_words_per_wg = 0;
             if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch score-only stage over %u tasks (%u others)\n", e_count, ne_count);
-            if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diags_kernel<8, true>(T); });
-            else             emu::launch(grid, [&] { c2_align_diags_kernel<8, false>(T); });
+            if (sna == 16) { if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diags_kernel<16, true>(T); });
+                             else             emu::launch(grid, [&] { c2_align_diags_kernel<16, false>(T); }); }
+            else           { if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diags_kernel<8, true>(T); });
+                             else             emu::launch(grid, [&] { c2_align_diags_kernel<8, false>(T); }); }
         }
         // -5: five alignments per wavefront (lane groups of 12, lanes 60..63 idle); -75: the chain 5 -> 2 -> 1 -> full plane
         for (int t = 0; t < 2; ++t) {
