@@ -291,7 +291,7 @@ int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4);
  * in HBM scratch, 8 the packed kernels run their 32-bit-add variant (c2_pk_add32_ok: sums as v_add_u32 under a per-anti-diagonal bias); ref_packed_ok (n_refs bytes, may be NULL): 1 where the packed int16 fill admits the reference (its DP values provably
  * fit, c2_pk_eligible) -- the int32 kernels run everything else (the reference's C ints, CRISPResso2Align.pyx:142-147). */
 int c2_chain_info(c2_ctx* ctx, int32_t max_read_len, uint32_t* kernels, uint8_t* ref_packed_ok);
-/* (*kernels bit 9: the score-only stage is in front of the first band tier -- c2_align_partition_kernel + c2_align_diags_kernel<8>: the tasks whose read is as
+/* (*kernels bit 9: the score-only stage is in front of the first band tier -- c2_align_partition_kernel + c2_align_diags_kernel<16>: the tasks whose read is as
  * long as its reference and agrees with it in its last 32 columns (an indel in front of them would shift them) go through the packed fill WITHOUT pointer bits, which finishes those whose alignment is the
  * main diagonal and hands the rest to the first tier; not for all-references batches of several references.)
  * c2_score_stage_info: did it run for the most recent batch, how many tasks it took, how many it finished. */
