@@ -728,6 +728,7 @@ def main():
     dt, kernel_ms, first_ms, launches = tm["dt"], tm["kernel_ms"], tm["first_ms"], tm["launches"]
     tiers = ctx.tier_info()
     score_info = ctx.score_stage_info() if hasattr(ctx, "score_stage_info") else (False, 0, 0)     # (of the timed batch: later launches overwrite it)
+    part_info = ctx.partition_info() if hasattr(ctx, "partition_info") else None
     packed_share = None                                           # share of the batch's alignments the packed (int16 pair) kernels finished
     try:
         left_, unpaired_ = ctx.tier_info_ex()
@@ -944,6 +945,7 @@ def main():
                          "note": "integer DP: VALU-issue-bound by construction, HBM fraction is small (SURVEY 8d); see valu and profiles/*/README.md"},
             "valu": valu,
             "score_only_stage": score_stage,
+            "partition": part_info,
             "int32_chain": int32_chain,
             "other_configs": other_configs,
             "e2e": e2e,

@@ -78,6 +78,7 @@ void update_pk_eligibility(c2_ctx* ctx) {
 // the packed kernel of a tier: NA alignments per wavefront, with packed (v_pk_add_i16) or plain 32-bit adds
 const void* pk_kernel(int na, bool add32) {
     switch (na) {
+        case 16: return add32 ? (const void*)c2_align_diagp_kernel<16, true> : (const void*)c2_align_diagp_kernel<16, false>;
         case 8: return add32 ? (const void*)c2_align_diagp_kernel<8, true> : (const void*)c2_align_diagp_kernel<8, false>;
         case 4: return add32 ? (const void*)c2_align_diagp_kernel<4, true> : (const void*)c2_align_diagp_kernel<4, false>;
         default: return add32 ? (const void*)c2_align_diagp_kernel<2, true> : (const void*)c2_align_diagp_kernel<2, false>;
@@ -271,12 +272,17 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
         // d_fb: 64 header words -- [0..7] length of the list each BAND tier leaves for the next one, [8..15] length of the list of
         // tasks a packed kernel could not pair (run by the 32-bit kernel of the same band), [16 + 2l ..] work counter of launch l --
         // then three task lists: two that alternate between band tiers and one for the unpaired tasks
+        // (round 4: a list per band tier instead of two that alternate -- c2_align_partition_kernel writes into the lists of LATER tiers;
+        //  header words 48..52: tasks per class of the partition, 56 / 57: length of the first tier's list after the score-only launch and after
+        //  the 14-diagonal launch, 60 / 62 / 61: lengths of the score-only launch's list, the 14-diagonal launch's, the first tier's)
         const size_t list_words = (size_t)A.n_tasks;
-        if ((rc = ensure(ctx, ctx->d_fb, 256 + 4 * list_words * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, ctx->d_fb, 256 + 8 * list_words * sizeof(uint32_t)))) return rc;
         uint32_t* hdr = (uint32_t*)ctx->d_fb.p;
-        uint32_t* lists[2] = {hdr + 64, hdr + 64 + list_words};
-        uint32_t* ulist = hdr + 64 + 2 * list_words;
-        uint32_t* elist = hdr + 64 + 3 * list_words;                 // the tasks of the score-only launch (header words 60 / 61: its length, the other list's)
+        uint32_t* lists[4] = {hdr + 64, hdr + 64 + list_words, hdr + 64 + 2 * list_words, hdr + 64 + 3 * list_words};
+        uint32_t* ulist = hdr + 64 + 4 * list_words;
+        uint32_t* elist = hdr + 64 + 5 * list_words;                 // the tasks of the score-only launch
+        uint32_t* nlist = hdr + 64 + 6 * list_words;                 // the first band tier's, when the partition ran
+        uint32_t* plist = hdr + 64 + 7 * list_words;                 // the 14-diagonal launch's
         HIPCHK(ctx, hipMemsetAsync(hdr, 0, 256, s));
         const uint64_t cus = (uint64_t)ctx->prop.multiProcessorCount;
         int tier = 0;                                            // band tiers so far; the next one reads lists[(tier - 1) & 1]
@@ -285,8 +291,8 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
         // appends what IT cannot finish to the same list as that kernel
         auto chain = [&](c2_align_args& T, const bool from_unpaired, const bool packed_kernel) {
             if (from_unpaired) { T.task_list = ulist; T.task_count = hdr + 8 + tier; }
-            else { T.task_list = tier ? lists[(tier - 1) & 1] : nullptr; T.task_count = tier ? hdr + (tier - 1) : nullptr; }
-            T.fb_list = lists[tier & 1]; T.fb_count = hdr + tier;
+            else { T.task_list = tier ? lists[tier - 1] : nullptr; T.task_count = tier ? hdr + (tier - 1) : nullptr; }
+            T.fb_list = lists[tier]; T.fb_count = hdr + tier;
             T.un_list = packed_kernel ? ulist : nullptr; T.un_count = packed_kernel ? hdr + 8 + tier : nullptr;
             T.pair_order = packed_kernel && !from_unpaired && tier == 0 && T.all_refs && T.n_refs > 1;
             T.work_counter = (unsigned long long*)(hdr + 16 + 2 * launch);
@@ -304,20 +310,40 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
             }
             // band tier t (0: 30 diagonals, 1: 62): the packed kernel if the tier has one, then the 32-bit kernel of the same band --
             // over everything if there is no packed kernel, else over the tasks the packed kernel could not pair
-            // In front of the first band tier, when that tier has its packed kernel: the tasks whose read is as long as its reference and differs
-            // from it in few columns (c2_align_partition_kernel) go through the SCORE-ONLY packed fill (c2_align_diags_kernel: no pointer bits,
-            // no pointer words) -- it finishes the ones whose alignment is the main diagonal, which is most of them, and appends the rest to the
-            // list of the other tasks, which the first tier then runs as before.  (Not for an all-references batch of several references: its
-            // pairs are formed by the order of the tasks.  C2_NO_SCORE_TIER=1 switches the stage off.)
+            // In front of the first band tier, when that tier has its packed kernel: c2_align_partition_kernel looks at every task and says which
+            // launch should see it first --
+            //   the tasks whose read is as long as its reference and differs from it in few columns go through the SCORE-ONLY packed fill
+            //   (c2_align_diags_kernel: no pointer bits, no pointer words), which finishes the ones whose alignment is the main diagonal;
+            //   the tasks whose path needs a few diagonals only through c2_align_diagp_kernel<16> (14 diagonals, sixteen per wavefront);
+            //   the tasks whose path needs more diagonals than the first tier's band has go straight to the list of the tier that has them.
+            // What a launch cannot finish joins the list of the next wider one, as ever.  (Not for an all-references batch of several references:
+            // its pairs are formed by the order of the tasks.  C2_NO_SCORE_TIER=1 switches the whole stage off, C2_NO_P16_TIER=1 the 14-diagonal
+            // launch, C2_NO_ROUTE=1 the routing to later tiers.)
             bool score_stage = g.pk && !(A.all_refs && A.n_refs > 1) && !getenv("C2_NO_SCORE_TIER") && ctx->kernel_mode == 0 &&
                                tier_can_serve(ctx, 32, min_lj, A.max_lj);
+            bool p16_stage = false;
             if (score_stage) {
+                const bool a32s = ctx->pk_beta > 0;
+                const bool tier1_runs = (g.pk2 || g.x[1]) && tier_can_serve(ctx, 62, min_lj, A.max_lj);
+                const bool route = !getenv("C2_NO_ROUTE");
+                c2_diagx_plan PP = c2_make_diagx_plan(16, ctx->max_li, g.max_lj, true, false);
+                p16_stage = !getenv("C2_NO_P16_TIER") && PP.total <= 163840u && tier_can_serve(ctx, 14, min_lj, A.max_lj);
                 c2_partition_args PA;
-                PA.A = A; PA.eq_list = elist; PA.eq_count = hdr + 60; PA.ne_list = lists[1]; PA.ne_count = hdr + 61;
+                PA.A = A;
+                PA.list[0] = elist; PA.count[0] = hdr + 60;
+                PA.list[1] = plist; PA.count[1] = hdr + 62;
+                PA.list[2] = nlist; PA.count[2] = hdr + 61;
+                PA.list[3] = lists[0]; PA.count[3] = hdr + 0;            // (what the first tier leaves: the second tier's list -- or the third's, if there is no second)
+                PA.list[4] = tier1_runs ? lists[1] : lists[0]; PA.count[4] = tier1_runs ? hdr + 1 : hdr + 0;
+                PA.class_count = hdr + 48;
+                PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier1_runs) ? 62 : 0; PA.bandw[3] = route ? 128 : 0;
                 PA.max_mismatch = 6;                                     // (of the last 32 columns)
+                PA.probe_max_mismatch = 4; PA.margin = 3; PA.max_shift = (p16_stage || route) ? 64 : 0;
                 if (const char* e = getenv("C2_SCORE_TIER_MAX_MISMATCH")) PA.max_mismatch = atoi(e);
+                if (const char* e = getenv("C2_ROUTE_PROBE_MISMATCH")) PA.probe_max_mismatch = atoi(e);
+                if (const char* e = getenv("C2_ROUTE_MARGIN")) PA.margin = atoi(e);
                 const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + C2_PART_CHUNK - 1) / C2_PART_CHUNK, cus * 16));
-                hipLaunchKernelGGL(c2_align_partition_kernel, dim3(pgrid), dim3(256), C2_PART_CHUNK + 64, s, PA);
+                hipLaunchKernelGGL(c2_align_partition_kernel, dim3(pgrid), dim3(256), C2_PART_LDS, s, PA);
                 HIPCHK(ctx, hipGetLastError());
                 // (its own LDS plan -- no staging area for pointer words -- and its own residency; SIXTEEN alignments per wavefront: lane groups of
                 //  8 lanes, 14 diagonals -- the alignments it can finish run along the main diagonal, and a band that narrow still certifies them;
@@ -326,7 +352,6 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 if (const char* e = getenv("C2_SCORE_TIER_NA")) sna = atoi(e) == 8 ? 8 : 16;
                 c2_diagx_plan PS = c2_make_diagx_plan(sna, ctx->max_li, g.max_lj, true, true);
                 if (sna == 16 && PS.total > 163840u) { sna = 8; PS = c2_make_diagx_plan(8, ctx->max_li, g.max_lj, true, true); }
-                const bool a32s = ctx->pk_beta > 0;
                 const void* fn = sna == 16 ? (a32s ? (const void*)c2_align_diags_kernel<16, true> : (const void*)c2_align_diags_kernel<16, false>)
                                            : (a32s ? (const void*)c2_align_diags_kernel<8, true> : (const void*)c2_align_diags_kernel<8, false>);
                 const int key = (int)PS.total * (a32s ? -1 : 1) * (sna == 16 ? 2 : 1);
@@ -336,23 +361,54 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, PS.total));
                     ctx->occ_score_blocks = nb < 1 ? 1 : nb; ctx->occ_score_lds = key;
                 }
-                const uint64_t resident = cus * (uint64_t)ctx->occ_score_blocks;
-                const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + sna - 1) / sna, resident));
-                c2_align_args T = A;
-                T.task_list = elist; T.task_count = hdr + 60;
-                T.fb_list = lists[1]; T.fb_count = hdr + 61;             // what it cannot finish joins the other tasks
-                T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
-                T.work_counter = (unsigned long long*)(hdr + 16 + 2 * launch);
-                ++launch;
-                T.plane = nullptr; T.plane_words_per_wg = 0;
-                if (sna == 16) { if (a32s) hipLaunchKernelGGL((c2_align_diags_kernel<16, true>), dim3(grid), dim3(64), PS.total, s, T);
-                                 else      hipLaunchKernelGGL((c2_align_diags_kernel<16, false>), dim3(grid), dim3(64), PS.total, s, T); }
-                else           { if (a32s) hipLaunchKernelGGL((c2_align_diags_kernel<8, true>), dim3(grid), dim3(64), PS.total, s, T);
-                                 else      hipLaunchKernelGGL((c2_align_diags_kernel<8, false>), dim3(grid), dim3(64), PS.total, s, T); }
-                HIPCHK(ctx, hipGetLastError());
+                {
+                    const uint64_t resident = cus * (uint64_t)ctx->occ_score_blocks;
+                    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + sna - 1) / sna, resident));
+                    c2_align_args T = A;
+                    T.task_list = elist; T.task_count = hdr + 60;
+                    T.fb_list = nlist; T.fb_count = hdr + 61;               // what it cannot finish joins the first tier's tasks
+                    T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
+                    T.work_counter = (unsigned long long*)(hdr + 16 + 2 * launch);
+                    ++launch;
+                    T.plane = nullptr; T.plane_words_per_wg = 0;
+                    if (sna == 16) { if (a32s) hipLaunchKernelGGL((c2_align_diags_kernel<16, true>), dim3(grid), dim3(64), PS.total, s, T);
+                                     else      hipLaunchKernelGGL((c2_align_diags_kernel<16, false>), dim3(grid), dim3(64), PS.total, s, T); }
+                    else           { if (a32s) hipLaunchKernelGGL((c2_align_diags_kernel<8, true>), dim3(grid), dim3(64), PS.total, s, T);
+                                     else      hipLaunchKernelGGL((c2_align_diags_kernel<8, false>), dim3(grid), dim3(64), PS.total, s, T); }
+                    HIPCHK(ctx, hipGetLastError());
+                    HIPCHK(ctx, hipMemcpyAsync(hdr + 56, hdr + 61, 4, hipMemcpyDeviceToDevice, s));      // (statistics: the list's length now)
+                }
+                if (p16_stage) {
+                    // the pointer-keeping fill at sixteen per wavefront over the tasks predicted to need a few diagonals only; a task it cannot pair
+                    // or certify joins the first tier's list like the score-only launch's
+                    const void* fp = a32s ? (const void*)c2_align_diagp_kernel<16, true> : (const void*)c2_align_diagp_kernel<16, false>;
+                    const int keyp = (int)PP.total * (a32s ? -1 : 1);
+                    if (ctx->occ_p16_lds != keyp) {
+                        int nb = 0;
+                        HIPCHK(ctx, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                        HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fp, 64, PP.total));
+                        ctx->occ_p16_blocks = nb < 1 ? 1 : nb; ctx->occ_p16_lds = keyp;
+                    }
+                    const uint64_t resident = cus * (uint64_t)ctx->occ_p16_blocks;
+                    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + 15) / 16, resident));
+                    const uint64_t plane_words = (uint64_t)grid * PP.n_words * 128u;                      // 16 slots x 8 lanes
+                    if ((rc = ensure(ctx, ctx->d_plane16, (size_t)plane_words * sizeof(uint32_t)))) return rc;
+                    c2_align_args T = A;
+                    T.task_list = plist; T.task_count = hdr + 62;
+                    T.fb_list = nlist; T.fb_count = hdr + 61;
+                    T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
+                    T.work_counter = (unsigned long long*)(hdr + 16 + 2 * launch);
+                    ++launch;
+                    T.plane = (uint32_t*)ctx->d_plane16.p; T.plane_words_per_wg = PP.n_words * 128u;
+                    if (a32s) hipLaunchKernelGGL((c2_align_diagp_kernel<16, true>), dim3(grid), dim3(64), PP.total, s, T);
+                    else      hipLaunchKernelGGL((c2_align_diagp_kernel<16, false>), dim3(grid), dim3(64), PP.total, s, T);
+                    HIPCHK(ctx, hipGetLastError());
+                }
+                HIPCHK(ctx, hipMemcpyAsync(hdr + 57, hdr + 61, 4, hipMemcpyDeviceToDevice, s));
                 start_first();                                          // (the timing split's "first kernel" is the one that follows)
             }
             else start_first();
+            ctx->last_p16_stage = p16_stage;
             ctx->last_score_stage = score_stage; ctx->last_n_tasks = A.n_tasks;
             for (int t = 0; t < 2; ++t) {
                 const bool packed = t == 0 ? g.pk : g.pk2;
@@ -364,7 +420,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + na - 1) / na, resident));
                     c2_align_args T = A;
                     chain(T, false, true);
-                    if (t == 0 && score_stage) { T.task_list = lists[1]; T.task_count = hdr + 61; }     // (the tasks the score-only stage did not take or could not finish)
+                    if (t == 0 && score_stage) { T.task_list = nlist; T.task_count = hdr + 61; }       // (the tasks the partition gave this tier and those the two launches in front could not finish)
                     T.plane = (uint32_t*)ctx->d_plane.p; T.plane_words_per_wg = t == 0 ? g.plane_words_pk : g.plane_words_pk2;
                     const bool a32 = ctx->pk_beta > 0;
                     if (t == 0) { if (a32) hipLaunchKernelGGL((c2_align_diagp_kernel<8, true>), dim3(grid), dim3(64), g.lds_pk, s, T);
@@ -547,7 +603,7 @@ void c2_destroy(c2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     DevBuf* all[] = {&ctx->d_tbl, &ctx->d_code, &ctx->d_pk, &ctx->d_refblob, &ctx->d_refdesc, &ctx->d_reads, &ctx->d_offsets, &ctx->d_refids,
-                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_diagrows_pk, &ctx->d_plane, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel, &ctx->d_seeds, &ctx->d_cnt_block};
+                     &ctx->d_strands, &ctx->d_aln_read, &ctx->d_aln_ref, &ctx->d_records, &ctx->d_misc, &ctx->d_phase, &ctx->d_fb, &ctx->d_cnt, &ctx->d_diagrows, &ctx->d_diagrows_pk, &ctx->d_plane, &ctx->d_plane16, &ctx->d_lists, &ctx->d_lists_out, &ctx->d_order, &ctx->d_sel, &ctx->d_seeds, &ctx->d_cnt_block};
     for (DevBuf* b : all) release(*b);
     (void)c2_comm_destroy(ctx);
     for (int k = 0; k < 2; ++k) {
@@ -704,11 +760,29 @@ int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* fini
     *ran = ctx->last_score_stage ? 1 : 0; *tasks = 0; *finished = 0;
     if (ctx->last_score_stage && ctx->d_fb.p) {
         HIPCHK(ctx, hipDeviceSynchronize());
-        uint32_t c[2] = {0, 0};
-        HIPCHK(ctx, hipMemcpy(c, (const uint32_t*)ctx->d_fb.p + 60, 8, hipMemcpyDeviceToHost));
-        // every task is in one of the two lists; what the stage could not finish was appended to the second one
-        const int64_t handed_on = (int64_t)c[1] - ((int64_t)ctx->last_n_tasks - (int64_t)c[0]);
-        *tasks = (int64_t)c[0]; *finished = (int64_t)c[0] - handed_on;
+        uint32_t c[64];
+        HIPCHK(ctx, hipMemcpy(c, (const uint32_t*)ctx->d_fb.p, 256, hipMemcpyDeviceToHost));
+        // the first tier's list held the partition's class 2 before the launch; what the launch could not finish was appended to it
+        *tasks = (int64_t)c[60]; *finished = (int64_t)c[60] - ((int64_t)c[56] - (int64_t)c[50]);
+    }
+    return 0;
+}
+
+// The partition of the most recent batch (c2_align_partition_kernel): did it run; tasks per class (0: score-only launch, 1: 14-diagonal launch,
+// 2: first band tier, 3: second, 4: third); how many of their tasks the score-only launch and the 14-diagonal launch finished.
+int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks5, int64_t* finished2) {
+    if (!ctx || !ran || !class_tasks5 || !finished2) return C2_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *ran = ctx->last_score_stage ? (ctx->last_p16_stage ? 3 : 1) : 0;
+    for (int k = 0; k < 5; ++k) class_tasks5[k] = 0;
+    finished2[0] = finished2[1] = 0;
+    if (ctx->last_score_stage && ctx->d_fb.p) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        uint32_t c[64];
+        HIPCHK(ctx, hipMemcpy(c, (const uint32_t*)ctx->d_fb.p, 256, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 5; ++k) class_tasks5[k] = (int64_t)c[48 + k];
+        finished2[0] = (int64_t)c[60] - ((int64_t)c[56] - (int64_t)c[50]);
+        finished2[1] = ctx->last_p16_stage ? (int64_t)c[62] - ((int64_t)c[57] - (int64_t)c[56]) : 0;
     }
     return 0;
 }

@@ -55,7 +55,8 @@ struct c2_ctx {
     int pk_bias = 0;                    // ... and this value bias (c2_pk_add32_bias_needed)
     int pk_beta = 0;                    // > 0: the admitted references run the packed kernels' 32-bit-add variant with this bias (c2_pk_add32_ok)
     bool pk_dirty = true;
-    int occ_score_lds = -1, occ_score_blocks = 0;            // residency of c2_align_diags_kernel<8> with its LDS plan
+    int occ_score_lds = -1, occ_score_blocks = 0;            // residency of c2_align_diags_kernel with its LDS plan
+    int occ_p16_lds = -1, occ_p16_blocks = 0;                // ... of c2_align_diagp_kernel<16>
     int occ_pk_lds = -1, occ_pk_blocks = 0, occ_pk2_lds = -1, occ_pk2_blocks = 0, occ_pk3_lds = -1, occ_pk3_blocks = 0;
     // staging for the host batch path and the per-call path
     DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;
@@ -77,11 +78,12 @@ struct c2_ctx {
     int occ_diag_lds = -1, occ_diag_blocks = 0;
     int occ_x_lds[2] = {-1, -1}, occ_x_blocks[2] = {0, 0};   // [0] 4 alignments per wavefront, [1] 2
     DevBuf d_plane;        // pointer-word scratch of the multi-alignment diagonal kernels
+    DevBuf d_plane16;      // ... of c2_align_diagp_kernel<16> (its residency is its own)
     DevBuf d_cnt_block;            // count route: the workgroups' accumulator blocks when they do not fit LDS
     DevBuf d_lists, d_lists_out;   // batched classifier: staging and flat output
     DevBuf d_order;        // count kernel: histogram + tasks grouped by reference
     int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
-    bool last_score_stage = false; uint64_t last_n_tasks = 0;   // the last run_align: did the score-only stage run, over how many tasks in all
+    bool last_score_stage = false, last_p16_stage = false; uint64_t last_n_tasks = 0;   // the last run_align: did the score-only stage run, over how many tasks in all
     int occ_lds[5][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
     int occ_blocks[5][3] = {};
     DevBuf d_cnt;          // count kernel: work counter + min_matches table

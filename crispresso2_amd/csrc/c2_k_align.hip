@@ -1975,33 +1975,67 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
     out[384 + lane] = lz;
 }
 
-// Which tasks is c2_align_diags_kernel likely to finish?  Read and reference of one length (forward strand, 32 .. 256 bases) whose LAST 32 columns
-// differ in at most `max_mismatch` places: a read with an indel is shifted against the reference behind the indel and differs there in most
-// columns, a read without one in hardly any.  A prediction only -- the score-only fill verifies (gap-free predicate + certificate) and hands on
-// what was predicted wrongly; the other list goes to the launch that keeps pointers right away, so that (almost) no alignment with gaps is filled
-// twice.  One lane per task; both lists in task order inside a chunk of C2_PART_CHUNK tasks, the chunks in the order of their atomics.
+// Which launch of the chain should see a task first?  One lane per task, two cheap looks at the read against its reference (forward strand,
+// reference admitted to the packed fill; everything else goes where it went before: to the first band tier):
+//   class 0  read and reference of one length (32 .. 256 bases) whose LAST 32 columns differ in at most `max_mismatch` places: a read with an
+//            indel is shifted against the reference behind the indel and differs there in most columns, a read without one in hardly any
+//            -> c2_align_diags_kernel (the fill without pointer bits; it can finish a main-diagonal alignment only)
+//   otherwise the DIAGONAL the middle of the read lies on: the 32 bases from column Lj/2 + 16 on, as a 64-bit word of 2-bit codes, against every
+//            window of the reference within `max_shift` of the same place (one shift + one byte per window); the best window with at most
+//            `probe_max_mismatch` differing bases puts the path on diagonal s there, so a band has to hold the diagonals 0 (start), s and
+//            D = Li - Lj (end), with `margin` diagonals to spare on either side (the certificate needs them: a path that leaves the band must
+//            be worse than the one found, and every mismatch of the read brings the two closer):
+//   class 1  ... fit a band of bandw[0] diagonals (14: c2_align_diagp_kernel<16>, sixteen alignments per wavefront)
+//   class 2  ... bandw[1] (32: the first band tier)     -- also: no window found, reverse strand, reference not admitted
+//   class 3  ... bandw[2] (62: the second tier)         class 4  ... bandw[3] (126 / anything wider: the third tier)
+//   (bandw[k] = 0: the chain has no such launch; the next wider one that exists takes the task.)
+// A prediction only: every launch verifies what it finishes (certificate) and hands on what it cannot, so a wrong class costs that alignment a
+// second fill and nothing else -- but a read with a 20-base deletion no longer pays for a fill in a band that cannot hold it.
+// Lists in task order inside a chunk of C2_PART_CHUNK tasks, the chunks in the order of their atomics (one per chunk and class).
 struct c2_partition_args {
     c2_align_args A;
-    uint32_t* eq_list; uint32_t* eq_count;      // tasks for the score-only launch
-    uint32_t* ne_list; uint32_t* ne_count;      // the others
-    int32_t max_mismatch;
+    uint32_t* list[5]; uint32_t* count[5];      // per class: the launch's task list and its length (classes may share a list)
+    uint32_t* class_count;                      // [5] tasks per class (statistics)
+    int32_t bandw[4];                           // diagonals of the launches behind classes 1 .. 4, 0: none
+    int32_t max_mismatch, probe_max_mismatch, margin, max_shift;
 };
 
-#define C2_PART_CHUNK 4096                         // tasks per workgroup and pair of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
+#define C2_PART_CHUNK 4096                         // tasks per workgroup and set of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
+#define C2_PART_LDS (C2_PART_CHUNK + 128)
+
+// 32 bases from p on as 2-bit codes ((c >> 1) & 3: A 0, C 1, T 2, G 3; anything else aliases one of them -- this is a predictor), base k in bits 2k+1 .. 2k
+__device__ __forceinline__ uint64_t c2_code32(const uint8_t* p) {
+    uint64_t code = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint32_t w;
+        __builtin_memcpy(&w, p + 4 * q, 4);
+        const uint32_t t = (w >> 1) & 0x03030303u;
+        code |= (uint64_t)((t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xffu) << (8 * q);
+    }
+    return code;
+}
+
+__device__ __forceinline__ bool c2_band_holds(const int bandw, const int D, const int lo, const int hi, const int margin) {
+    const int d0 = ((D - bandw + 3) >> 1) & ~1;                  // (the kernels' own placement: c2_diagx_body)
+    return bandw > 0 && lo - d0 >= margin && d0 + bandw - 1 - hi >= margin;
+}
+
 __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_args P)
 {
     const c2_align_args& A = P.A;
-    uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] 1: score-only launch, 0: the other list, 2: no such task
-    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [8] per wavefront: candidates, others; [8..11]: bases of the two lists, totals
+    uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] the task's class, 7: no such task
+    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [3 * 4] per wavefront: packed class counts; [16 .. 20]: bases of the five lists
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int widest = 2;                                                 // the class that takes what no band holds
+    if (P.bandw[2] > 0) widest = 3;
+    if (P.bandw[3] > 0) widest = 4;
     for (uint64_t chunk = (uint64_t)blockIdx.x * C2_PART_CHUNK; chunk < A.n_tasks; chunk += (uint64_t)gridDim.x * C2_PART_CHUNK) {
-        // ---- one lane per task: mismatching columns among the LAST 32 of read and reference (an indel anywhere in front of them shifts them
-        //      against each other; one inside them is predicted wrongly and costs that alignment a second fill, no more)
         for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
             const int slot = r * 256 + tid;
             const uint64_t task = chunk + (uint64_t)slot;
             const bool valid = task < A.n_tasks;
-            int mm = 0x10000;                                       // (not a candidate)
+            int cls = 2;
             if (valid) {
                 uint64_t read_id; int ref_id;
                 if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
@@ -2010,47 +2044,93 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                 const uint64_t off = A.offsets[read_id];
                 const int Lj = (int)(A.offsets[read_id + 1] - off);
                 const c2_dev_ref* rf = A.refs + ref_id;
-                if (!rc && Lj == rf->len && Lj >= 32 && Lj <= 256 && rf->pk_ok) {
-                    mm = 0;
-                    const uint8_t* rd = A.reads + off + (Lj - 32);
-                    const uint8_t* f = rf->seq + (Lj - 32);
+                const int Li = rf->len;
+                if (!rc && rf->pk_ok && Lj >= 32) {
+                    const uint8_t* rd = A.reads + off;
+                    const uint8_t* f = rf->seq;
+                    int mm = 0x10000;
+                    if (Lj == Li && Lj <= 256) {
+                        mm = 0;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        uint32_t a, b;
-                        __builtin_memcpy(&a, rd + 4 * q, 4); __builtin_memcpy(&b, f + 4 * q, 4);
-                        const uint32_t x = a ^ b;
-                        mm += __builtin_popcount((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
+                        for (int q = 0; q < 8; ++q) {
+                            uint32_t a, b;
+                            __builtin_memcpy(&a, rd + (Lj - 32) + 4 * q, 4); __builtin_memcpy(&b, f + (Lj - 32) + 4 * q, 4);
+                            const uint32_t x = a ^ b;
+                            mm += __builtin_popcount((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
+                        }
+                    }
+                    if (mm <= P.max_mismatch) cls = 0;
+                    else if (P.max_shift > 0 && Lj >= 96 && Li >= 32) {
+                        const int p = (Lj >> 1) + 16, D = Li - Lj;
+                        const int s_lo = -P.max_shift > -p ? -P.max_shift : -p;
+                        const int s_hi = P.max_shift < Li - 32 - p ? P.max_shift : Li - 32 - p;
+                        if (s_lo <= s_hi) {
+                            const uint64_t rcode = c2_code32(rd + p);
+                            uint64_t fcode = c2_code32(f + p + s_lo);
+                            int best_mm = 64, best_span = 0x10000, best_s = 0;
+                            for (int s = s_lo;; ++s) {
+                                const uint64_t x = fcode ^ rcode;
+                                const int m2 = __popcll((x | (x >> 1)) & 0x5555555555555555ull);
+                                const int lo = s < 0 ? (D < s ? D : s) : (D < 0 ? D : 0), hi = s > 0 ? (D > s ? D : s) : (D > 0 ? D : 0);
+                                const int span = hi - lo;
+                                if (m2 < best_mm || (m2 == best_mm && span < best_span)) { best_mm = m2; best_span = span; best_s = s; }
+                                if (s == s_hi) break;
+                                fcode = (fcode >> 2) | ((uint64_t)((f[p + s + 32] >> 1) & 3u) << 62);
+                            }
+                            if (best_mm <= P.probe_max_mismatch) {
+                                const int s = best_s;
+                                const int lo = s < 0 ? (D < s ? D : s) : (D < 0 ? D : 0), hi = s > 0 ? (D > s ? D : s) : (D > 0 ? D : 0);
+                                cls = widest;
+                                for (int k = 3; k >= 0; --k) if (c2_band_holds(P.bandw[k], D, lo, hi, P.margin)) cls = k + 1;
+                            }
+                        }
                     }
                 }
             }
-            flag[slot] = valid ? (mm <= P.max_mismatch ? 1 : 0) : 2;
+            flag[slot] = valid ? (uint8_t)cls : (uint8_t)7;
         }
         __syncthreads();
-        // ---- thread t owns tasks 16 t .. 16 t + 15 of the chunk: positions by a scan over the workgroup, two atomics per chunk
-        unsigned n_eq = 0, n_ne = 0;
+        // ---- thread t owns tasks 16 t .. 16 t + 15 of the chunk: positions by a scan over the workgroup, one atomic per chunk and class
+        unsigned n[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const unsigned f = flag[16 * tid + k]; n_eq += f == 1u; n_ne += f == 0u; }
-        unsigned pack = n_eq | (n_ne << 16), incl = pack;           // (both counts <= 4096: 16 bits each)
+        for (int k = 0; k < 16; ++k) {
+            const unsigned f = flag[16 * tid + k];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
-        if (lane == 63) part[wv] = incl;
+            for (int c = 0; c < 5; ++c) n[c] += f == (unsigned)c;
+        }
+        unsigned pk[3] = {n[0] | (n[1] << 16), n[2] | (n[3] << 16), n[4]};           // (every count <= 4096: 16 bits each)
+        unsigned incl[3] = {pk[0], pk[1], pk[2]};
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) { const unsigned o = (unsigned)__shfl_up((int)incl[w], d); if (lane >= d) incl[w] += o; }
+        }
+        if (lane == 63) { part[3 * wv] = incl[0]; part[3 * wv + 1] = incl[1]; part[3 * wv + 2] = incl[2]; }
         __syncthreads();
-        unsigned before = 0, total = 0;
+        unsigned before[3] = {0u, 0u, 0u}, total[3] = {0u, 0u, 0u};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { const unsigned x = part[v]; if (v < wv) before += x; total += x; }
-        if (tid == 0) {
-            part[8] = (total & 0xffffu) ? atomicAdd(P.eq_count, total & 0xffffu) : 0u;
-            part[9] = (total >> 16) ? atomicAdd(P.ne_count, total >> 16) : 0u;
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int w = 0; w < 3; ++w) { const unsigned x = part[3 * v + w]; if (v < wv) before[w] += x; total[w] += x; }
+        if (tid < 5) {
+            const unsigned t = tid == 0 ? (total[0] & 0xffffu) : tid == 1 ? (total[0] >> 16) : tid == 2 ? (total[1] & 0xffffu) : tid == 3 ? (total[1] >> 16) : total[2];
+            part[16 + tid] = t ? atomicAdd(P.count[tid], t) : 0u;
+            if (t && P.class_count) atomicAdd(P.class_count + tid, t);
         }
         __syncthreads();
-        unsigned excl = before + incl - pack;
-        unsigned pe = part[8] + (excl & 0xffffu), pn = part[9] + (excl >> 16);
+        unsigned pos[5];
+        {
+            const unsigned e0 = before[0] + incl[0] - pk[0], e1 = before[1] + incl[1] - pk[1], e2 = before[2] + incl[2] - pk[2];
+            pos[0] = part[16] + (e0 & 0xffffu); pos[1] = part[17] + (e0 >> 16);
+            pos[2] = part[18] + (e1 & 0xffffu); pos[3] = part[19] + (e1 >> 16);
+            pos[4] = part[20] + e2;
+        }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const unsigned f = flag[16 * tid + k];
             const uint32_t task = (uint32_t)(chunk + (uint64_t)(16 * tid + k));
-            if (f == 1u) P.eq_list[pe++] = task;
-            else if (f == 0u) P.ne_list[pn++] = task;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) if (f == (unsigned)c) P.list[c][pos[c]++] = task;
         }
         __syncthreads();                                            // (the flags are overwritten by the next chunk)
     }

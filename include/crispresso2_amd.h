@@ -296,6 +296,16 @@ int c2_chain_info(c2_ctx* ctx, int32_t max_read_len, uint32_t* kernels, uint8_t*
  * main diagonal and hands the rest to the first tier; not for all-references batches of several references.)
  * c2_score_stage_info: did it run for the most recent batch, how many tasks it took, how many it finished. */
 int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* finished);
+/* The partition in front of the chain (c2_align_partition_kernel, same conditions as the score-only stage) gives every task a class: 0 the
+ * score-only launch; otherwise, by the diagonal the middle of the read lies on (a 32-base window of the read against the windows of the reference
+ * within 64 bases of the same place) -- 1: the path needs few diagonals, c2_align_diagp_kernel<16> (14 diagonals, sixteen alignments per
+ * wavefront) takes it first; 2: the first band tier (also: nothing found); 3 / 4: the path needs more diagonals than the first / second tier's
+ * band has, the task goes straight to the list of the second / third tier.  Every launch verifies what it finishes and hands on what it cannot:
+ * the class only decides where a task is tried FIRST.  With this, left_over[t] of c2_tier_info is the length of the list the launch behind tier
+ * t reads: what tier t left plus what the partition put there.
+ * c2_partition_info: *ran bit 0 the partition ran for the most recent batch, bit 1 the 14-diagonal launch too; class_tasks5: tasks per class;
+ * finished2: tasks the score-only launch and the 14-diagonal launch finished. */
+int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks5, int64_t* finished2);
 /* The same for up to 8 tiers, plus per tier the number of tasks its packed (int16) kernel could not pair and handed to the 32-bit
  * kernel of the same band: a tier with a packed kernel finished at least tasks_in - unpaired - left_over tasks in int16 arithmetic. */
 int c2_tier_info_ex(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over8, int32_t* unpaired8);

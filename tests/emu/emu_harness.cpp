@@ -18,6 +18,12 @@ static unsigned g_last_unpaired = 0;     // tasks the first packed tier of the l
 extern "C" {
 
 unsigned emu_last_unpaired() { return g_last_unpaired; }
+static const uint32_t* g_last_classes = nullptr;   // tasks per class of the last emu_align_batch's partition (all zero: it did not run)
+static unsigned g_last_p16_finished = 0;           // tasks its 14-diagonal launch finished
+void emu_last_partition(uint32_t* classes5, uint32_t* p16_finished) {
+    for (int k = 0; k < 5; ++k) classes5[k] = g_last_classes ? g_last_classes[k] : 0u;
+    *p16_finished = g_last_p16_finished;
+}
 int emu_last_pk_beta() { return g_last_pk_beta; }
 int emu_last_pk_bias() { return g_last_pk_bias; }
 
@@ -102,7 +108,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     // (references the packed fill does not admit: 2 per wavefront in 32 bits instead)
     const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75 || band_lanes == -8 || band_lanes == -84 || band_lanes == -87 || band_lanes == -82;
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
-    std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1);
+    std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1), fb_list3(A.n_tasks ? A.n_tasks : 1), fb_list4(A.n_tasks ? A.n_tasks : 1);   // (the full-plane launch below reads the last tier's)
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
     std::vector<uint32_t> plane;
     A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)pk_beta; A.pk_bias = (uint32_t)pk_bias; A.reserved4 = 0;
@@ -126,7 +132,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         A.diagpk_base = all_rows_pk.data();
     }
     if (diag) {
-        uint32_t* lists[2] = {fb_list.data(), fb_list2.data()};
+        uint32_t* lists[4] = {fb_list.data(), fb_list2.data(), fb_list3.data(), fb_list4.data()};       // (one per band tier: the partition writes into later tiers' lists)
         std::vector<uint32_t> un_list(A.n_tasks ? A.n_tasks : 1);
         uint32_t un_counts[5] = {0, 0, 0, 0, 0};
         int tier = 0;
@@ -134,37 +140,70 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         // same band -- over everything, or over the tasks the packed kernel could not pair
         auto chain = [&](c2_align_args& T, const bool from_unpaired, const bool packed_kernel) {
             if (from_unpaired) { T.task_list = un_list.data(); T.task_count = &un_counts[tier]; }
-            else { T.task_list = tier ? lists[(tier - 1) & 1] : nullptr; T.task_count = tier ? &fb_counts[tier - 1] : nullptr; }
-            T.fb_list = lists[tier & 1]; T.fb_count = &fb_counts[tier];
+            else { T.task_list = tier ? lists[tier - 1] : nullptr; T.task_count = tier ? &fb_counts[tier - 1] : nullptr; }
+            T.fb_list = lists[tier]; T.fb_count = &fb_counts[tier];
             T.un_list = packed_kernel ? un_list.data() : nullptr; T.un_count = packed_kernel ? &un_counts[tier] : nullptr;
             T.pair_order = packed_kernel && !from_unpaired && tier == 0 && T.all_refs && T.n_refs > 1;
             work_counter = 0;
         };
-        // the score-only stage in front of the first band tier, as the host library wires it (c2_api_align.hip: c2_align_partition_kernel, then
-        // c2_align_diags_kernel over its first list; what that cannot finish joins the second list, which the first tier then runs).
-        // C2_EMU_NO_SCORE_TIER=1 switches it off.
+        // the partition and the two launches in front of the first band tier, as the host library wires them (c2_api_align.hip: c2_align_partition_kernel,
+        // then c2_align_diags_kernel over class 0 and c2_align_diagp_kernel<16> over class 1; what they cannot finish joins the first tier's list
+        // (class 2); classes 3 and 4 go straight to the lists of the second and third tier).  C2_EMU_NO_SCORE_TIER=1 switches all of it off,
+        // C2_NO_P16_TIER=1 the 14-diagonal launch, C2_NO_ROUTE=1 the routing to later tiers.
         bool score_stage = false;
-        std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1);
-        uint32_t e_count = 0, ne_count = 0;
+        std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1), nlist(A.n_tasks ? A.n_tasks : 1), plist(A.n_tasks ? A.n_tasks : 1);
+        uint32_t e_count = 0, ne_count = 0, p_count = 0;
+        static uint32_t class_counts[5];
+        for (int k = 0; k < 5; ++k) class_counts[k] = 0;
+        g_last_classes = class_counts; g_last_p16_finished = 0;
         if (any_pk && (band_lanes == -87 || band_lanes == -8 || band_lanes == -80) && !(A.all_refs && A.n_refs > 1) && !getenv("C2_EMU_NO_SCORE_TIER")) {
             const int sna = (getenv("C2_SCORE_TIER_NA") && atoi(getenv("C2_SCORE_TIER_NA")) == 8) ? 8 : 16;
             const c2_diagx_plan PP = c2_make_diagx_plan(sna, A.max_li, A.max_lj, true, true);
             if (PP.total > sizeof(c2_smem)) return -5;
             score_stage = true;
+            const c2_diagx_plan P16 = c2_make_diagx_plan(16, A.max_li, A.max_lj, true, false);
+            const bool p16_stage = !getenv("C2_NO_P16_TIER") && P16.total <= sizeof(c2_smem);
+            const bool tier1_runs = band_lanes == -87, tier2_runs = band_lanes == -87;       // (-8 / -80: the first tier's kernels alone, then the full plane)
+            const bool route = !getenv("C2_NO_ROUTE");
             c2_partition_args PA;
-            PA.A = A; PA.eq_list = elist.data(); PA.eq_count = &e_count; PA.ne_list = lists[1]; PA.ne_count = &ne_count;
+            PA.A = A;
+            PA.list[0] = elist.data(); PA.count[0] = &e_count;
+            PA.list[1] = plist.data(); PA.count[1] = &p_count;
+            PA.list[2] = nlist.data(); PA.count[2] = &ne_count;
+            PA.list[3] = lists[0]; PA.count[3] = &fb_counts[0];
+            PA.list[4] = tier1_runs ? lists[1] : lists[0]; PA.count[4] = tier1_runs ? &fb_counts[1] : &fb_counts[0];
+            PA.class_count = class_counts;
+            PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier1_runs) ? 62 : 0; PA.bandw[3] = (route && tier2_runs) ? 128 : 0;
             PA.max_mismatch = getenv("C2_SCORE_TIER_MAX_MISMATCH") ? atoi(getenv("C2_SCORE_TIER_MAX_MISMATCH")) : 6;
-            emu::launch(2, [&] { c2_align_partition_kernel(PA); }, 256);      // (c2_smem: C2_PART_CHUNK + 64 bytes)
-            c2_align_args T = A;
-            T.task_list = elist.data(); T.task_count = &e_count; T.fb_list = lists[1]; T.fb_count = &ne_count;
-            T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
-            work_counter = 0;
-            T.plane = nullptr; T.plane_words_per_wg = 0;
-            if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch score-only stage over %u tasks (%u others)\n", e_count, ne_count);
-            if (sna == 16) { if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diags_kernel<16, true>(T); });
-                             else             emu::launch(grid, [&] { c2_align_diags_kernel<16, false>(T); }); }
-            else           { if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diags_kernel<8, true>(T); });
-                             else             emu::launch(grid, [&] { c2_align_diags_kernel<8, false>(T); }); }
+            PA.probe_max_mismatch = getenv("C2_ROUTE_PROBE_MISMATCH") ? atoi(getenv("C2_ROUTE_PROBE_MISMATCH")) : 4;
+            PA.margin = getenv("C2_ROUTE_MARGIN") ? atoi(getenv("C2_ROUTE_MARGIN")) : 3;
+            PA.max_shift = (p16_stage || route) ? 64 : 0;
+            emu::launch(2, [&] { c2_align_partition_kernel(PA); }, 256);      // (c2_smem: C2_PART_LDS bytes)
+            {
+                c2_align_args T = A;
+                T.task_list = elist.data(); T.task_count = &e_count; T.fb_list = nlist.data(); T.fb_count = &ne_count;
+                T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
+                work_counter = 0;
+                T.plane = nullptr; T.plane_words_per_wg = 0;
+                if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch score-only stage over %u tasks (classes %u %u %u %u %u)\n", e_count, class_counts[0], class_counts[1], class_counts[2], class_counts[3], class_counts[4]);
+                if (sna == 16) { if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diags_kernel<16, true>(T); });
+                                 else             emu::launch(grid, [&] { c2_align_diags_kernel<16, false>(T); }); }
+                else           { if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diags_kernel<8, true>(T); });
+                                 else             emu::launch(grid, [&] { c2_align_diags_kernel<8, false>(T); }); }
+            }
+            if (p16_stage) {
+                plane.assign((size_t)grid * P16.n_words * 128u, 0xdeadbeefu);
+                c2_align_args T = A;
+                T.task_list = plist.data(); T.task_count = &p_count; T.fb_list = nlist.data(); T.fb_count = &ne_count;
+                T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
+                work_counter = 0;
+                T.plane = plane.data(); T.plane_words_per_wg = P16.n_words * 128u;
+                const uint32_t before = ne_count;
+                if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diagp_kernel<16, true>(T); });
+                else             emu::launch(grid, [&] { c2_align_diagp_kernel<16, false>(T); });
+                g_last_p16_finished = p_count - (ne_count - before);
+                if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed 16 over %u tasks, %u handed on\n", p_count, ne_count - before);
+            }
         }
         // -5: five alignments per wavefront (lane groups of 12, lanes 60..63 idle); -75: the chain 5 -> 2 -> 1 -> full plane
         for (int t = 0; t < 2; ++t) {
@@ -178,7 +217,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
                 plane.assign((size_t)grid * PP.n_words * 128u, 0xdeadbeefu);
                 c2_align_args T = A;
                 chain(T, false, true);
-                if (t == 0 && score_stage) { T.task_list = lists[1]; T.task_count = &ne_count; }
+                if (t == 0 && score_stage) { T.task_list = nlist.data(); T.task_count = &ne_count; }
                 T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 128u;
                 if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed %d tier %d\n", pna, tier);
                 if (pk_beta > 0) { if (pna == 8) emu::launch(grid, [&] { c2_align_diagp_kernel<8, true>(T); });
@@ -226,7 +265,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         if (tier == 0) {                                           // (no banded tier ran, e.g. -8 without an admitted reference: everything to the full plane)
             A.task_list = nullptr; A.task_count = nullptr; fb_count = 1;
         } else {
-            A.task_list = lists[(tier - 1) & 1]; A.task_count = &fb_counts[tier - 1];
+            A.task_list = lists[tier - 1]; A.task_count = &fb_counts[tier - 1];
             fb_count = fb_counts[tier - 1];
         }
         A.fb_list = nullptr; A.fb_count = nullptr;

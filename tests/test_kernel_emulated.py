@@ -559,3 +559,57 @@ def test_packed_fill_32bit_adds_at_the_limit_of_their_range(mats, go, ge, gval):
             status, s1, s2, mt, ln = oracle.global_align_raw(rd, ref, m, g, go, ge)
             assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k)
             check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+
+
+def _reads_for_the_partition(rng, amp, n):
+    """fixed-length reads like the benchmark's (a deletion at the cut pulls the rest of the amplicon forward and random bases fill the end;
+    an insertion pushes it out) and variable-length ones (the read simply ends where the amplicon does), a few substitutions in each"""
+    L, cut = len(amp), len(amp) // 2
+    reads, kinds = [], []
+    for k in range(n):
+        t = list(amp)
+        for _ in range(int(rng.integers(0, 3))):
+            t[int(rng.integers(0, L))] = str(rng.choice(list("ACGT")))
+        t = "".join(t)
+        kind = k % 8
+        d = [0, 2, 5, 9, 20, 40, 3, 25][kind]
+        if kind < 6:                                   # deletion of d bases, fixed length
+            t = (t[:cut - d // 2] + t[cut - d // 2 + d:] + "".join(rng.choice(list("ACGT"), d)))[:L]
+        elif kind == 6:                                # insertion of d bases, fixed length
+            t = (t[:cut] + "".join(rng.choice(list("ACGT"), d)) + t[cut:])[:L]
+        else:                                          # deletion, the read is shorter
+            t = t[:cut - 10] + t[cut - 10 + d:]
+        reads.append(t); kinds.append(kind)
+    return reads, kinds
+
+
+@pytest.mark.parametrize("L", [250, 150])
+def test_partition_routes_tasks_to_the_launch_whose_band_holds_their_path(mats, L, monkeypatch):
+    """c2_align_partition_kernel's classes and the launches behind them (the host library's wiring, mirrored by the emulator harness): reads without
+    an indel go through the score-only launch, short indels through the 14-diagonal launch (sixteen alignments per wavefront, pointer words kept),
+    long ones straight to the second / third tier -- and whatever the class, every alignment is the oracle's.  The same reads with the
+    routing switched off give the same results."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(4242 + L)
+    amp = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = [L // 2, L // 2 + 1]
+    reads, kinds = _reads_for_the_partition(rng, amp, 96)
+    st = {}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    for k, rd in enumerate(reads):
+        status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, -20, -2)
+        assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k, kinds[k])
+        check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+    cls = st["classes"]
+    assert sum(cls) == len(reads), cls
+    # every kind of launch saw tasks (150 bp: the 40-base deletion leaves the probe's window in the filler -- nothing found, first tier) ...
+    assert cls[0] >= 10 and cls[1] >= 20 and cls[3] >= 10 and (cls[4] >= 8 or L == 150), cls
+    assert st["p16_finished"] >= cls[1] * 3 // 4, st                                     # ... and the 14-diagonal launch finished most of its own
+    for off in ("C2_NO_P16_TIER", "C2_NO_ROUTE"):
+        monkeypatch.setenv(off, "1")
+        st2 = {}
+        res2, rec2 = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st2)
+        monkeypatch.delenv(off)
+        assert res2 == res and np.array_equal(rec2, rec)
+        assert (st2["classes"][1] == 0) if off == "C2_NO_P16_TIER" else (st2["classes"][3] == 0 and st2["classes"][4] == 0), st2
