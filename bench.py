@@ -829,11 +829,21 @@ def main():
         if ran_:
             score_stage = {"kernels": ["c2_align_partition_kernel", "c2_align_diags_kernel<%s" % ("8" if os.environ.get("C2_SCORE_TIER_NA") == "8" else "16") + pkv], "tasks": took_, "finished": fin_,
                            "note": "reads as long as the amplicon whose last 32 columns differ from it in at most 6 places go through the packed fill without pointer bits; "
-                                   "it finishes those whose optimal alignment is the main diagonal (gap-free predicate + certificate) and hands the rest, "
-                                   "with all other reads, to the first band tier"}
+                                   "it finishes those whose optimal alignment is the main diagonal (gap-free predicate + certificate) and hands the rest "
+                                   "to the first band tier; `partition`: tasks per class of c2_align_partition_kernel (score-only launch, 14-diagonal launch "
+                                   "[opt-in], first / second / third band tier: by the diagonal the middle of the read lies on, a task goes straight to the "
+                                   "tier whose band holds its path), so tasks_left_after_each_banded_launch[t] is the length of the list the launch behind "
+                                   "tier t reads: what tier t left plus what the partition put there"}
     # algorithmic bytes of the dominant kernel's launch: the reads and offsets of its tasks in; strings + record out for the tasks it finishes
+    # (with the partition: the first tier sees its own class and what the launches in front could not finish; the list it leaves also holds the
+    #  tasks the partition sent straight to later tiers)
     in_first = n_tasks - (score_stage["finished"] if score_stage else 0)
-    done_first = in_first - (tiers[0] if tiers else 0)
+    left_first = tiers[0] if tiers else 0
+    if part_info and part_info["ran"]:
+        cls_, fin_p = part_info["classes"], part_info["finished"]
+        in_first = cls_[2] + (cls_[0] - fin_p[0]) + (cls_[1] - fin_p[1])
+        left_first = max(0, left_first - cls_[3] - (cls_[4] if len(tiers) < 3 else 0))
+    done_first = in_first - left_first
     alg_first = int(bytes_in * (in_first / float(n_tasks))) + int(bytes_out * (done_first / float(n_tasks)))
     achieved_gbs = alg_first / avg_first_s / 1e9 if avg_first_s > 0 else 0.0
     # HBM bytes and instruction counts per alignment from the committed PMC passes of the newest round's build (separate rocprofv3

@@ -314,11 +314,11 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
             // launch should see it first --
             //   the tasks whose read is as long as its reference and differs from it in few columns go through the SCORE-ONLY packed fill
             //   (c2_align_diags_kernel: no pointer bits, no pointer words), which finishes the ones whose alignment is the main diagonal;
-            //   the tasks whose path needs a few diagonals only through c2_align_diagp_kernel<16> (14 diagonals, sixteen per wavefront);
-            //   the tasks whose path needs more diagonals than the first tier's band has go straight to the list of the tier that has them.
+            //   the tasks whose path needs more diagonals than the first tier's band has go straight to the list of the tier that has them;
+            //   (C2_P16_TIER=1 only: the tasks whose path needs a few diagonals through c2_align_diagp_kernel<16>, 14 diagonals, sixteen per wavefront.)
             // What a launch cannot finish joins the list of the next wider one, as ever.  (Not for an all-references batch of several references:
-            // its pairs are formed by the order of the tasks.  C2_NO_SCORE_TIER=1 switches the whole stage off, C2_NO_P16_TIER=1 the 14-diagonal
-            // launch, C2_NO_ROUTE=1 the routing to later tiers.)
+            // its pairs are formed by the order of the tasks.  C2_NO_SCORE_TIER=1 switches the whole stage off, C2_NO_ROUTE=1 the routing to
+            // later tiers.)
             bool score_stage = g.pk && !(A.all_refs && A.n_refs > 1) && !getenv("C2_NO_SCORE_TIER") && ctx->kernel_mode == 0 &&
                                tier_can_serve(ctx, 32, min_lj, A.max_lj);
             bool p16_stage = false;
@@ -327,7 +327,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 const bool tier1_runs = (g.pk2 || g.x[1]) && tier_can_serve(ctx, 62, min_lj, A.max_lj);
                 const bool route = !getenv("C2_NO_ROUTE");
                 c2_diagx_plan PP = c2_make_diagx_plan(16, ctx->max_li, g.max_lj, true, false);
-                p16_stage = !getenv("C2_NO_P16_TIER") && PP.total <= 163840u && tier_can_serve(ctx, 14, min_lj, A.max_lj);
+                p16_stage = getenv("C2_P16_TIER") && PP.total <= 163840u && tier_can_serve(ctx, 14, min_lj, A.max_lj);   // (measured: slower than leaving its tasks to the first tier -- DESIGN 3.3e; opt-in)
                 c2_partition_args PA;
                 PA.A = A;
                 PA.list[0] = elist; PA.count[0] = hdr + 60;

@@ -149,7 +149,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         // the partition and the two launches in front of the first band tier, as the host library wires them (c2_api_align.hip: c2_align_partition_kernel,
         // then c2_align_diags_kernel over class 0 and c2_align_diagp_kernel<16> over class 1; what they cannot finish joins the first tier's list
         // (class 2); classes 3 and 4 go straight to the lists of the second and third tier).  C2_EMU_NO_SCORE_TIER=1 switches all of it off,
-        // C2_NO_P16_TIER=1 the 14-diagonal launch, C2_NO_ROUTE=1 the routing to later tiers.
+        // C2_NO_ROUTE=1 the routing to later tiers; the 14-diagonal launch runs with C2_P16_TIER=1 only (as in the library).
         bool score_stage = false;
         std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1), nlist(A.n_tasks ? A.n_tasks : 1), plist(A.n_tasks ? A.n_tasks : 1);
         uint32_t e_count = 0, ne_count = 0, p_count = 0;
@@ -162,7 +162,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             if (PP.total > sizeof(c2_smem)) return -5;
             score_stage = true;
             const c2_diagx_plan P16 = c2_make_diagx_plan(16, A.max_li, A.max_lj, true, false);
-            const bool p16_stage = !getenv("C2_NO_P16_TIER") && P16.total <= sizeof(c2_smem);
+            const bool p16_stage = getenv("C2_P16_TIER") && P16.total <= sizeof(c2_smem);
             const bool tier1_runs = band_lanes == -87, tier2_runs = band_lanes == -87;       // (-8 / -80: the first tier's kernels alone, then the full plane)
             const bool route = !getenv("C2_NO_ROUTE");
             c2_partition_args PA;

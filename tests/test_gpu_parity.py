@@ -1244,3 +1244,72 @@ def test_score_only_stage_changes_no_result(mats, ctx, monkeypatch):
         T = int(records["aln_len"][i])
         s1, s2, _ = oracle.global_align(reads[i], amp, m, g, -20, -2)
         assert outs[0][0][i, :T].tobytes().decode() == s1 and outs[0][1][i, :T].tobytes().decode() == s2, (i, reads[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [250, 150])
+def test_partition_routing_changes_no_result(mats, ctx, monkeypatch, L):
+    """c2_align_partition_kernel's classes on the device: the benchmark's kinds of reads (deletions of 2 .. 40 bases whose place in the read is
+    taken by bases behind the amplicon's end, insertions, shorter reads) plus synthetic ones -- with the routing (long indels straight to the tier
+    whose band holds them), without it (C2_NO_ROUTE=1), with the opt-in 14-diagonal launch (C2_P16_TIER=1): the same bytes every time, and the
+    oracle's alignment for every read; c2_partition_info says that every class the setting allows saw tasks."""
+    import torch
+    from crispresso2_amd import synth, _native
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    m = mats["EDNAFULL"]
+    amp, g, _ = synth.amplicon_setup(L)
+    inc = list(range(L // 2 - 10, L // 2 + 10))
+    rng = np.random.default_rng(77 + L)
+    cut = L // 2
+    reads = []
+    for k in range(640):
+        t = list(amp)
+        for _ in range(int(rng.integers(0, 3))):
+            t[int(rng.integers(0, L))] = str(rng.choice(list("ACGT")))
+        t = "".join(t)
+        kind = k % 8
+        d = [0, 2, 5, 9, 20, 40, 3, 25][kind]
+        if kind < 6:
+            t = (t[:cut - d // 2] + t[cut - d // 2 + d:] + "".join(rng.choice(list("ACGT"), d)))[:L]
+        elif kind == 6:
+            t = (t[:cut] + "".join(rng.choice(list("ACGT"), d)) + t[cut:])[:L]
+        else:
+            t = t[:cut - 10] + t[cut - 10 + d:]
+        reads.append(t)
+    reads += [synth.make_reads(L, 384)[i].tobytes().decode() for i in range(384)]
+    n = len(reads)
+    arena = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    al = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    stride = al.stride_for(L)
+    d_reads = torch.from_numpy(arena.copy()).to(dev)
+    d_off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    outs, infos = [], []
+    for env in ({}, {"C2_NO_ROUTE": "1"}, {"C2_P16_TIER": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        o1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        o2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        rec = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+        al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, L, stream=s)
+        torch.cuda.synchronize()
+        infos.append(ctx.partition_info())
+        outs.append((o1.cpu().numpy(), o2.cpu().numpy(), rec.cpu().numpy()))
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    for other in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], other))
+    routed, unrouted, with16 = infos
+    assert routed["ran"] and not routed["p16"] and sum(routed["classes"]) == n
+    assert routed["classes"][0] > 100 and routed["classes"][1] == 0 and routed["classes"][3] >= 60 and (routed["classes"][4] >= 40 or L == 150), routed
+    assert unrouted["classes"][3] == 0 and unrouted["classes"][4] == 0 and unrouted["classes"][2] > routed["classes"][2], unrouted
+    assert with16["p16"] and with16["classes"][1] >= 150 and with16["finished"][1] >= with16["classes"][1] // 2, with16
+    records = outs[0][2].view(_native.REC_DTYPE).reshape(-1)
+    assert (records["status"] == 0).all()
+    for i in range(n):
+        T = int(records["aln_len"][i])
+        s1, s2, _ = oracle.global_align(reads[i], amp, m, g, -20, -2)
+        assert outs[0][0][i, :T].tobytes().decode() == s1 and outs[0][1][i, :T].tobytes().decode() == s2, (i, reads[i])

@@ -222,8 +222,11 @@ def test_soak_packed_int16_fill_at_the_limits_of_its_range_proof(ctx, case):
             # ever sees the unpaired tasks): at least 15 % in the first tier, 40 % over the three packed tiers -- the extreme reads
             # (all mismatched, unrelated, long indels) go down the chain through all of them to the full-plane kernel
             assert len(left) == 3 and max(unpaired) <= 1, (L, left, unpaired)
+            # (left[t] is the length of the list behind tier t: what the tier left plus what the partition sent there directly)
+            pi = ctx.partition_info()
+            direct = [pi["classes"][3], pi["classes"][4], 0] if pi["ran"] else [0, 0, 0]
             tier_in = [n, left[0], left[1]]
-            by_packed = [tier_in[t] - unpaired[t] - left[t] for t in range(3)]
+            by_packed = [tier_in[t] - unpaired[t] - (left[t] - direct[t]) for t in range(3)]
             assert by_packed[0] >= 0.15 * n and sum(by_packed) >= 0.4 * n and left[2] > 0, (case, L, left, unpaired)
 
 

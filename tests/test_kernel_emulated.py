@@ -586,30 +586,38 @@ def _reads_for_the_partition(rng, amp, n):
 @pytest.mark.parametrize("L", [250, 150])
 def test_partition_routes_tasks_to_the_launch_whose_band_holds_their_path(mats, L, monkeypatch):
     """c2_align_partition_kernel's classes and the launches behind them (the host library's wiring, mirrored by the emulator harness): reads without
-    an indel go through the score-only launch, short indels through the 14-diagonal launch (sixteen alignments per wavefront, pointer words kept),
-    long ones straight to the second / third tier -- and whatever the class, every alignment is the oracle's.  The same reads with the
-    routing switched off give the same results."""
+    an indel go through the score-only launch, long indels straight to the second / third tier, and -- with C2_P16_TIER=1, the library's opt-in --
+    short indels through the 14-diagonal launch (sixteen alignments per wavefront, pointer words kept).  Whatever the class, every alignment is
+    the oracle's; the same reads with the routing switched off give the same results."""
     m = mats["EDNAFULL"]
     rng = np.random.default_rng(4242 + L)
     amp = "".join(rng.choice(list("ACGT"), L))
     g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
     inc = [L // 2, L // 2 + 1]
     reads, kinds = _reads_for_the_partition(rng, amp, 96)
-    st = {}
-    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    want = []
     for k, rd in enumerate(reads):
         status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, -20, -2)
-        assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k, kinds[k])
-        check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
-    cls = st["classes"]
-    assert sum(cls) == len(reads), cls
-    # every kind of launch saw tasks (150 bp: the 40-base deletion leaves the probe's window in the filler -- nothing found, first tier) ...
-    assert cls[0] >= 10 and cls[1] >= 20 and cls[3] >= 10 and (cls[4] >= 8 or L == 150), cls
-    assert st["p16_finished"] >= cls[1] * 3 // 4, st                                     # ... and the 14-diagonal launch finished most of its own
-    for off in ("C2_NO_P16_TIER", "C2_NO_ROUTE"):
-        monkeypatch.setenv(off, "1")
-        st2 = {}
-        res2, rec2 = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st2)
-        monkeypatch.delenv(off)
-        assert res2 == res and np.array_equal(rec2, rec)
-        assert (st2["classes"][1] == 0) if off == "C2_NO_P16_TIER" else (st2["classes"][3] == 0 and st2["classes"][4] == 0), st2
+        assert status == 0
+        want.append((s1, s2, mt))
+    for p16 in (False, True):
+        if p16:
+            monkeypatch.setenv("C2_P16_TIER", "1")
+        st = {}
+        res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+        for k, (s1, s2, mt) in enumerate(want):
+            assert rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k, kinds[k], p16)
+            check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+        cls = st["classes"]
+        assert sum(cls) == len(reads), cls
+        # every kind of launch saw tasks (150 bp: the 40-base deletion leaves the probe's window in the filler -- nothing found, first tier) ...
+        assert cls[0] >= 10 and cls[3] >= 10 and (cls[4] >= 8 or L == 150), cls
+        if p16:
+            assert cls[1] >= 20 and st["p16_finished"] >= cls[1] * 3 // 4, st              # ... and the 14-diagonal launch finished most of its own
+        else:
+            assert cls[1] == 0 and cls[2] >= 20, cls
+    monkeypatch.setenv("C2_NO_ROUTE", "1")
+    st2 = {}
+    res2, rec2 = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st2)
+    assert res2 == res and np.array_equal(rec2, rec)
+    assert st2["classes"][3] == 0 and st2["classes"][4] == 0 and st2["classes"][1] > 0, st2
