@@ -1100,6 +1100,7 @@ struct c2_diagx_plan {
     uint32_t codeof, table, tmp_read, tmp_ref, stage, slot0, slot_bytes, total, n_words;
     uint32_t pairlut, pcodes0, pcodes_bytes, group0, group_bytes, gref, gincp;   // packed kernels only
     uint32_t codes, read, code, ref, incp, win;                     // offsets inside one alignment's slot
+    uint32_t slot_read_bytes;                                       // bytes of a slot's read buffer
 };
 
 // score_only (c2_align_diags_kernel): nothing is traced, so the staging area of an alignment's pointer words is not part of the plan
@@ -1107,6 +1108,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     c2_diagx_plan p;
     const uint32_t lpa = 64u / (uint32_t)(pk ? na / 2 : na);        // lanes of one lane group (pk: two alignments share a group, 16 bits each)
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
+    p.slot_read_bytes = c2_align16((uint32_t)max_lj);
     uint32_t off = 0;
     p.codeof = off;   off += 256u;                                  // character -> code
     p.table = off;    off += 8u * 24u * 4u;                         // up to 8 slots x C2X_INTS (more slots: the table moves behind everything else, below)
@@ -1543,9 +1545,15 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
     // read bytes need a register per slot
     unsigned mC_task = 0; int mC_valid = 0, mC_lj = 0, mC_ref = 0, mC_rc = 0;
     unsigned long long mC_off = 0;
-    unsigned b4s[NA];
-#pragma unroll
-    for (int s = 0; s < NA; ++s) b4s[s] = 0;
+    // (sixteen scalars, not an array: as an array they become ONE 16-register tuple, and copies of that tuple were spilled around the fill)
+    unsigned b4_0 = 0, b4_1 = 0, b4_2 = 0, b4_3 = 0, b4_4 = 0, b4_5 = 0, b4_6 = 0, b4_7 = 0, b4_8 = 0, b4_9 = 0, b4_10 = 0, b4_11 = 0, b4_12 = 0, b4_13 = 0, b4_14 = 0, b4_15 = 0;
+    auto b4s = [&](const int s) -> unsigned& {                       // (s is a constant wherever this is called: unrolled loops)
+        switch (s) {
+            case 0: return b4_0; case 1: return b4_1; case 2: return b4_2; case 3: return b4_3; case 4: return b4_4; case 5: return b4_5;
+            case 6: return b4_6; case 7: return b4_7; case 8: return b4_8; case 9: return b4_9; case 10: return b4_10; case 11: return b4_11;
+            case 12: return b4_12; case 13: return b4_13; case 14: return b4_14; default: return b4_15;
+        }
+    };
     auto lane64 = [&](const unsigned long long v, const int s) {
         return (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), s) |
                ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), s) << 32);
@@ -1557,7 +1565,22 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
         c2_phase_begin(A.phase_cycles, PH);
         // ---- D: stage the NA prefetched tasks in their LDS slots
         if (have_group) {
-#pragma nounroll                                                     // (one copy of the staging code: the read dwords are picked by a uniform select)
+            // what needs no decision goes into LDS for all NA slots at once: the prefetched dwords into the slots' read buffers (the staging below
+            // reads its slot's back: one ds_read instead of a select over NA registers), the descriptors lane s holds into the table
+            {
+                if (4 * lane < (int)P.slot_read_bytes) {
+                    uint32_t* rd0 = (uint32_t*)(c2_smem + P.slot0 + P.read) + lane;     // (slot s's read buffer: wg_of(s).sRead)
+                    const uint32_t stride = P.slot_bytes / 4u;
+#pragma unroll
+                    for (int s = 0; s < NA; ++s) rd0[(uint32_t)s * stride] = b4s(s);
+                }
+                if (lane < NA) {
+                    int* T = sTab + lane * C2X_INTS;
+                    T[C2X_VALID] = mC_valid; T[C2X_TASK_LO] = (int)mC_task; T[C2X_TASK_HI] = 0;
+                    T[C2X_LJ] = mC_lj; T[C2X_REF] = mC_ref; T[C2X_RC] = mC_rc;
+                }
+            }
+#pragma nounroll                                                     // (one copy of the staging code)
             for (int s = 0; s < NA; ++s) {
                 int* T = sTab + s * C2X_INTS;
                 const int tvd = c2_tab_load(T, lane);
@@ -1589,9 +1612,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                         // byte permutes ((ch >> 1) & 7 is a perfect hash of the five letters), checked by permuting the letters back.
                         const c2_wg W = wg_of(s);
                         if (!second && cur.ref_id != cref) { cref = cur.ref_id; c2_stage_ref(A, W, sCodeOf, cur.ref_id, lane, A.max_li, li, g0, rbad, win_of(s)); }
-                        uint32_t w = b4s[0];
-#pragma unroll
-                        for (int q = 1; q < NA; ++q) if (s == q) w = b4s[q];
+                        const uint32_t w = ((const uint32_t*)W.sRead)[4 * lane < (int)P.slot_read_bytes ? lane : 0];
                         const uint32_t idx = (w >> 1) & 0x07070707u;
                         const uint32_t codes = __builtin_amdgcn_perm(A.lut_code_hi, A.lut_code_lo, idx);
                         const uint32_t chk = __builtin_amdgcn_perm(A.lut_chr_hi, A.lut_chr_lo, idx);
@@ -1599,8 +1620,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                         const uint32_t valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
                         if (__ballot(((chk ^ w) & valid) != 0) == 0ull) {
                             uint32_t* col = (uint32_t*)(sCodes4 + C2_DIAG_CODE_PAD + 1);
-                            if (nb > 0) {
-                                ((uint32_t*)W.sRead)[lane] = w;
+                            if (nb > 0) {                                                    // (the read itself is in its buffer already)
                                 if (!PK) col[lane] = (codes & valid) << 2;                    // 4 * code per column, zeros behind the last one
                                 else if (!second) col[lane] = (codes & valid) << 5;          // pair symbol: code A << 5 ...
                                 else col[lane] |= (codes & valid) << 2;                      // ... | code B << 2
@@ -1621,8 +1641,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                     unpaired = !joins;
                 }
                 if (lane == 0) {
-                    T[C2X_VALID] = cur.valid; T[C2X_TASK_LO] = (int)(unsigned)(cur.task & 0xffffffffu); T[C2X_TASK_HI] = (int)(unsigned)(cur.task >> 32);
-                    T[C2X_LJ] = cur.Lj; T[C2X_REF] = cur.ref_id; T[C2X_RC] = cur.rc; T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
+                    T[C2X_STATUS] = st; T[C2X_PACKED] = packed ? 1 : 0;
                     T[C2X_CURREF] = cref; T[C2X_LI] = li; T[C2X_G0] = g0; T[C2X_REFBAD] = rbad; T[C2X_UNPAIRED] = unpaired ? 1 : 0;
                 }
             }
@@ -1648,7 +1667,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                     b4 = w >> (8 * (p - q));
                 }
             }
-            b4s[s] = b4;
+            b4s(s) = b4;
         }
         // ---- B: descriptors of the group after that
         mB_valid = mA_valid; mB_task = mA_task; mB_off = 0; mB_off1 = 0; mB_ref = 0; mB_rc = 0;
@@ -1683,42 +1702,49 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
         __syncthreads();
         if (!have_group) continue;
 
-        // ---- band of every alignment; the tables its lanes read; the wave-uniform loop limits
+        // ---- band of every alignment; the tables its lanes read; the wave-uniform loop limits.  Lane s does the arithmetic of slot s (sixteen
+        //      slots one after the other, each on the scalar unit with its own wait for the reference's record, were a sixth of the score-only
+        //      launch's instructions); three reductions over the first NA lanes give the loop limits
         bool any_ok = false;
         int gA = 0, gC = 0x7fffffff, g_end = 0;
-#pragma nounroll
-        for (int s = 0; s < NA; ++s) {
-            int* T = sTab + s * C2X_INTS;
-            const int tvb = c2_tab_load(T, lane);
-            const int Li = C2_TF(tvb, C2X_LI), Lj = C2_TF(tvb, C2X_LJ);
+        {
+            int* T = sTab + (lane < NA ? lane : 0) * C2X_INTS;
+            const int Li = T[C2X_LI], Lj = T[C2X_LJ];
             bool ok = false;
             int D = 0, d0 = 0, cb = 0, minsc = 0, lastpos = 0, rowBase = C2_DIAG_ROW_PAD;   // (idle slot: row 0 of the buffer's first table)
-            if (C2_TF(tvb, C2X_VALID) && C2_TF(tvb, C2X_STATUS) == 0) {
-                const c2_dev_ref rf = A.refs[C2_TF(tvb, C2X_REF)];
+            int gA_s = 0, gC_s = 0x7fffffff, ge_s = 0;
+            if (lane < NA && T[C2X_VALID] && T[C2X_STATUS] == 0) {
+                const c2_dev_ref* rf = A.refs + T[C2X_REF];
+                const c2_diag_row* drows = rf->diag_rows;
                 D = Li - Lj;
                 d0 = ((D - BANDW + 3) >> 1) & ~1;              // even; band = d0 .. d0 + BANDW - 1, the first diagonals outside it (d0 - 1, d0 + BANDW) as
                                                                // symmetric about D / 2 as an even d0 allows: the two sides of c2_outside_band_bound are then equal
-                cb = (go > ge ? go : ge) + rf.gap_incentive_max;          // the most one gap base can add to a score
-                lastpos = rf.gap_incentive_last_pos;
-                ok = C2_TF(tvb, C2X_PACKED) && rf.diag_rows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
+                cb = (go > ge ? go : ge) + rf->gap_incentive_max;         // the most one gap base can add to a score
+                lastpos = rf->gap_incentive_last_pos;
+                ok = T[C2X_PACKED] && drows != nullptr && cb < 0 && d0 <= 0 && d0 + BANDW - 1 >= 0 &&
                      D >= d0 && D <= d0 + BANDW - 1;
-                if (PK && ok) ok = rf.pk_ok != 0;               // the reference must be admitted to the int16 fill (c2_pk_eligible); pairs were formed by the staging
+                if (PK && ok) ok = rf->pk_ok != 0;              // the reference must be admitted to the int16 fill (c2_pk_eligible); pairs were formed by the staging
                 if (SCORE && ok) ok = Li == Lj;                  // (the score-only fill finishes nothing but the main diagonal)
                 if (ok) {
-                    any_ok = true;
                     minsc = (int)(uint32_t)((uint64_t)(int64_t)go * (uint64_t)Lj * (uint64_t)Li);
-                    rowBase = (int)(rf.diag_rows - A.diag_base);
+                    rowBase = (int)(drows - A.diag_base);
                     const int max_start = (d0 + BANDW - 1 > -d0 ? d0 + BANDW - 1 : -d0) + 2;
-                    const int gA_s = ((max_start + 1) >> 1) >> 2;          // groups 0..gA contain lanes that have not started
-                    const int gC_s = ((2 * Lj + d0) >> 1) >> 2;            // first group in which some lane is on the last column
-                    const int ge_s = ((Li + Lj) >> 1) >> 2;                // group of the cell (Li, Lj)
-                    gA = gA > gA_s ? gA : gA_s; gC = gC < gC_s ? gC : gC_s; g_end = g_end > ge_s ? g_end : ge_s;
+                    gA_s = ((max_start + 1) >> 1) >> 2;                    // groups 0..gA contain lanes that have not started
+                    gC_s = ((2 * Lj + d0) >> 1) >> 2;                      // first group in which some lane is on the last column
+                    ge_s = ((Li + Lj) >> 1) >> 2;                          // group of the cell (Li, Lj)
                 }
             }
-            if (lane == 0) {
+            if (lane < NA) {
                 T[C2X_OK] = ok ? 1 : 0; T[C2X_D] = D; T[C2X_D0] = d0; T[C2X_CB] = cb; T[C2X_MINSC] = minsc; T[C2X_ROWBASE] = rowBase; T[C2X_LASTPOS] = lastpos;
                 T[C2X_BAND_LI] = ok ? Li : 0; T[C2X_BAND_LJ] = ok ? Lj : 0;
             }
+            any_ok = __ballot(ok) != 0ull;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {                 // (NA <= 16; the lanes behind hold the neutral values)
+                gA_s = c2_imax(gA_s, __shfl_xor(gA_s, m)); ge_s = c2_imax(ge_s, __shfl_xor(ge_s, m));
+                const int o = __shfl_xor(gC_s, m); gC_s = gC_s < o ? gC_s : o;
+            }
+            gA = __builtin_amdgcn_readfirstlane(gA_s); gC = __builtin_amdgcn_readfirstlane(gC_s); g_end = __builtin_amdgcn_readfirstlane(ge_s);
         }
         __syncthreads();
         c2_phase_mark<0>(A.phase_cycles, PH);
@@ -1834,36 +1860,35 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
         //      First pass: the decision of every slot (wave-uniform bit masks) -- the words of the NEXT traced slot have to be
         //      requested before the current one is written out (a load issued after those stores would wait for them: one
         //      vmcnt for loads and stores), so the traced slots must be known before the first one is handled.
-        unsigned m_valid = 0, m_full = 0, m_gapfree = 0, m_trace = 0;
-#pragma nounroll
-        for (int s = 0; s < NA; ++s) {
-            const int tv = c2_tab_load(sTab + s * C2X_INTS, lane);
-            if (!C2_TF(tv, C2X_VALID)) continue;
-            m_valid |= 1u << s;
-            const int status = C2_TF(tv, C2X_STATUS);
-            if (status != 0) continue;
-            if (!C2_TF(tv, C2X_OK)) { m_full |= 1u << s; continue; }
-            const int Li = C2_TF(tv, C2X_LI), Lj = C2_TF(tv, C2X_LJ);
-            const int D = C2_TF(tv, C2X_D), d0 = C2_TF(tv, C2X_D0), cb = C2_TF(tv, C2X_CB);
-            const int lane_end = (PK ? (s >> 1) : s) * LPA + ((D - d0) >> 1);
+        //      (Lane s decides for slot s; ballots make the masks.)
+        unsigned m_valid, m_full, m_gapfree, m_trace;
+        {
+            const int s = lane < NA ? lane : 0;
+            const int* T = sTab + s * C2X_INTS;
+            const bool valid = lane < NA && T[C2X_VALID] != 0;
+            const bool live = valid && T[C2X_STATUS] == 0;
+            const bool okb = live && T[C2X_OK] != 0;
+            const int Li = T[C2X_LI], Lj = T[C2X_LJ];
+            const int D = T[C2X_D], d0 = T[C2X_D0], cb = T[C2X_CB];
+            const int lane_end = ((PK ? (s >> 1) : s) * LPA + ((D - d0) >> 1)) & 63;
             int Hend;
             bool gapfree;
             if (PK) {
                 const int half = 16 * (s & 1);
-                Hend = (int)(int16_t)(((unsigned)__builtin_amdgcn_readlane((int)CAP.H, lane_end) >> half) & 0xffffu) - PKB - beta * (Li + Lj);
-                const unsigned gfw = (unsigned)__builtin_amdgcn_readlane((int)CAP.gf, lane_end) >> half;
+                Hend = (int)(int16_t)(((unsigned)__shfl((int)CAP.H, lane_end) >> half) & 0xffffu) - PKB - beta * (Li + Lj);
+                const unsigned gfw = (unsigned)__shfl((int)CAP.gf, lane_end) >> half;
                 gapfree = SCORE ? ((gfw & 0x8000u) != 0u) : ((gfw & 0x1111u) == 0x1111u);   // the E cells (cells 0 and 2 of a word): bits 0 and 4 of both bytes; SCORE: the AND of their sign bits
             } else {
-                Hend = __builtin_amdgcn_readlane(Hcap, lane_end);
-                gapfree = __builtin_amdgcn_readlane((int)GF.cap, lane_end) == 0;
+                Hend = __shfl(Hcap, lane_end);
+                gapfree = __shfl((int)GF.cap, lane_end) == 0;
             }
             const int dhi1 = d0 + BANDW, dlo1 = d0 - 1;               // first diagonals outside the band
-            const int U = c2_outside_band_bound(A.max_score, Li, Lj, D, dhi1, dlo1, cb, go, ge, C2_TF(tv, C2X_LASTPOS));
-            if (!(Hend > U)) { m_full |= 1u << s; continue; }
-            if (A.reserved & 2) continue;                              // (debug knob C2_DEBUG_SKIP_EPILOGUE: certified, nothing written)
-            if (Li == Lj && gapfree) m_gapfree |= 1u << s;
-            else if (SCORE) m_full |= 1u << s;                         // (certified, but not the main diagonal: the launch with the pointer words takes it)
-            else m_trace |= 1u << s;
+            const int U = c2_outside_band_bound(A.max_score, Li, Lj, D, dhi1, dlo1, cb, go, ge, T[C2X_LASTPOS]);
+            const bool cert = okb && Hend > U && !(A.reserved & 2);    // (debug knob C2_DEBUG_SKIP_EPILOGUE: certified, nothing written)
+            const bool gf = cert && Li == Lj && gapfree;
+            const bool full = (live && !okb) || (okb && !(Hend > U)) || (SCORE && cert && !gf);   // (SCORE: certified, but not the main diagonal: the launch with the pointer words takes it)
+            m_valid = (unsigned)__ballot(valid); m_full = (unsigned)__ballot(full);
+            m_gapfree = (unsigned)__ballot(gf); m_trace = (unsigned)__ballot(!SCORE && cert && !gf);
         }
         constexpr int STG = 16 / NG > 8 ? 8 : 16 / NG;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
         uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
