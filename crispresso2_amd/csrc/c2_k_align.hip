@@ -1848,8 +1848,10 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
             C2_LANES_ACTIVE_END()
         }
-        __syncthreads();                                           // (waits for the plane stores)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // drop this CU's stale L1 lines of the plane before reading it back
+        if (!SCORE) {
+            __syncthreads();                                       // (waits for the plane stores)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drop this CU's stale L1 lines of the plane before reading it back
+        }                                                          // (the score-only fill stores nothing: its row table stays in L1 from one group of alignments to the next)
         c2_phase_mark<1>(A.phase_cycles, PH);
 
         // ---- per alignment: optimality certificate (see c2_align_diag_kernel), then one of three ends:
