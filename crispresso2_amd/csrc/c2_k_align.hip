@@ -2028,7 +2028,7 @@ struct c2_partition_args {
 };
 
 #define C2_PART_CHUNK 4096                         // tasks per workgroup and set of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
-#define C2_PART_LDS (C2_PART_CHUNK + 128)
+#define C2_PART_LDS (C2_PART_CHUNK + 128 + 2 * C2_PART_CHUNK)
 
 // 32 bases from p on as 2-bit codes ((c >> 1) & 3: A 0, C 1, T 2, G 3; anything else aliases one of them -- this is a predictor), base k in bits 2k+1 .. 2k
 __device__ __forceinline__ uint64_t c2_code32(const uint8_t* p) {
@@ -2048,75 +2048,119 @@ __device__ __forceinline__ bool c2_band_holds(const int bandw, const int D, cons
     return bandw > 0 && lo - d0 >= margin && d0 + bandw - 1 - hi >= margin;
 }
 
+// a task's read and reference as the partition needs them
+struct c2_part_task { const uint8_t* rd; const uint8_t* f; int Li, Lj, rc, pk_ok; };
+__device__ __forceinline__ c2_part_task c2_part_load(const c2_align_args& A, const uint64_t task) {
+    uint64_t read_id; int ref_id;
+    if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
+    else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
+    c2_part_task t;
+    t.rc = A.strands ? (int)A.strands[task] : 0;
+    const uint64_t off = A.offsets[read_id];
+    t.Lj = (int)(A.offsets[read_id + 1] - off);
+    const c2_dev_ref* rf = A.refs + ref_id;
+    t.Li = rf->len; t.pk_ok = rf->pk_ok; t.rd = A.reads + off; t.f = rf->seq;
+    return t;
+}
+__device__ __forceinline__ bool c2_part_probes(const c2_partition_args& P, const c2_part_task& t) {
+    return P.max_shift > 0 && t.Lj >= 96 && t.Li >= 32;
+}
+
+// the class of a task by the diagonal the middle of its read lies on (see above); `widest`: the class that takes what no band holds
+__device__ __forceinline__ int c2_part_probe(const c2_partition_args& P, const c2_part_task& t, const int widest) {
+    const int p = (t.Lj >> 1) + 16, D = t.Li - t.Lj;
+    const int s_lo = -P.max_shift > -p ? -P.max_shift : -p;
+    const int s_hi = P.max_shift < t.Li - 32 - p ? P.max_shift : t.Li - 32 - p;
+    if (s_lo > s_hi) return 2;
+    const uint64_t rcode = c2_code32(t.rd + p);
+    uint64_t fcode = c2_code32(t.f + p + s_lo);
+    int best_mm = 64, best_span = 0x10000, best_s = 0;
+    uint32_t buf = 0;                                               // the next four bases of the reference (one load per four windows)
+    for (int s = s_lo;; ++s) {
+        const uint64_t x = fcode ^ rcode;
+        const int m2 = __popcll((x | (x >> 1)) & 0x5555555555555555ull);
+        const int lo = s < 0 ? (D < s ? D : s) : (D < 0 ? D : 0), hi = s > 0 ? (D > s ? D : s) : (D > 0 ? D : 0);
+        const int span = hi - lo;
+        if (m2 < best_mm || (m2 == best_mm && span < best_span)) { best_mm = m2; best_span = span; best_s = s; }
+        if (s == s_hi) break;
+        const int k = (s - s_lo) & 3, pos = p + s + 32;            // the base that enters the window
+        if (k == 0) {
+            if (pos + 4 <= t.Li) __builtin_memcpy(&buf, t.f + pos, 4);
+            else { buf = 0; for (int b = 0; b < 4; ++b) if (pos + b < t.Li) buf |= (uint32_t)t.f[pos + b] << (8 * b); }
+        }
+        fcode = (fcode >> 2) | ((uint64_t)((buf >> (8 * k + 1)) & 3u) << 62);
+    }
+    if (best_mm > P.probe_max_mismatch) return 2;
+    const int s = best_s;
+    const int lo = s < 0 ? (D < s ? D : s) : (D < 0 ? D : 0), hi = s > 0 ? (D > s ? D : s) : (D > 0 ? D : 0);
+    int cls = widest;
+    for (int k = 3; k >= 0; --k) if (c2_band_holds(P.bandw[k], D, lo, hi, P.margin)) cls = k + 1;
+    return cls;
+}
+
 __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_args P)
 {
     const c2_align_args& A = P.A;
-    uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] the task's class, 7: no such task
-    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [3 * 4] per wavefront: packed class counts; [16 .. 20]: bases of the five lists
+    uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] the task's class, 7: no such task, 8: still to be probed
+    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [3 * 4] per wavefront: packed class counts; [16 .. 20]: bases of the five lists; [24]: tasks to probe
+    uint16_t* const todo = (uint16_t*)(c2_smem + C2_PART_CHUNK + 128);   // [C2_PART_CHUNK] the chunk's tasks that need the probe, densely
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int widest = 2;                                                 // the class that takes what no band holds
     if (P.bandw[2] > 0) widest = 3;
     if (P.bandw[3] > 0) widest = 4;
     for (uint64_t chunk = (uint64_t)blockIdx.x * C2_PART_CHUNK; chunk < A.n_tasks; chunk += (uint64_t)gridDim.x * C2_PART_CHUNK) {
+        // ---- one lane per task: the look at the last 32 columns
         for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
             const int slot = r * 256 + tid;
             const uint64_t task = chunk + (uint64_t)slot;
-            const bool valid = task < A.n_tasks;
-            int cls = 2;
-            if (valid) {
-                uint64_t read_id; int ref_id;
-                if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
-                else            { read_id = task; ref_id = A.ref_ids ? (int)A.ref_ids[task] : 0; }
-                const int rc = A.strands ? (int)A.strands[task] : 0;
-                const uint64_t off = A.offsets[read_id];
-                const int Lj = (int)(A.offsets[read_id + 1] - off);
-                const c2_dev_ref* rf = A.refs + ref_id;
-                const int Li = rf->len;
-                if (!rc && rf->pk_ok && Lj >= 32) {
-                    const uint8_t* rd = A.reads + off;
-                    const uint8_t* f = rf->seq;
+            int cls = 7;
+            if (task < A.n_tasks) {
+                cls = 2;
+                const c2_part_task t = c2_part_load(A, task);
+                if (!t.rc && t.pk_ok && t.Lj >= 32) {
                     int mm = 0x10000;
-                    if (Lj == Li && Lj <= 256) {
+                    if (t.Lj == t.Li && t.Lj <= 256) {
                         mm = 0;
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             uint32_t a, b;
-                            __builtin_memcpy(&a, rd + (Lj - 32) + 4 * q, 4); __builtin_memcpy(&b, f + (Lj - 32) + 4 * q, 4);
+                            __builtin_memcpy(&a, t.rd + (t.Lj - 32) + 4 * q, 4); __builtin_memcpy(&b, t.f + (t.Lj - 32) + 4 * q, 4);
                             const uint32_t x = a ^ b;
                             mm += __builtin_popcount((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
                         }
                     }
                     if (mm <= P.max_mismatch) cls = 0;
-                    else if (P.max_shift > 0 && Lj >= 96 && Li >= 32) {
-                        const int p = (Lj >> 1) + 16, D = Li - Lj;
-                        const int s_lo = -P.max_shift > -p ? -P.max_shift : -p;
-                        const int s_hi = P.max_shift < Li - 32 - p ? P.max_shift : Li - 32 - p;
-                        if (s_lo <= s_hi) {
-                            const uint64_t rcode = c2_code32(rd + p);
-                            uint64_t fcode = c2_code32(f + p + s_lo);
-                            int best_mm = 64, best_span = 0x10000, best_s = 0;
-                            for (int s = s_lo;; ++s) {
-                                const uint64_t x = fcode ^ rcode;
-                                const int m2 = __popcll((x | (x >> 1)) & 0x5555555555555555ull);
-                                const int lo = s < 0 ? (D < s ? D : s) : (D < 0 ? D : 0), hi = s > 0 ? (D > s ? D : s) : (D > 0 ? D : 0);
-                                const int span = hi - lo;
-                                if (m2 < best_mm || (m2 == best_mm && span < best_span)) { best_mm = m2; best_span = span; best_s = s; }
-                                if (s == s_hi) break;
-                                fcode = (fcode >> 2) | ((uint64_t)((f[p + s + 32] >> 1) & 3u) << 62);
-                            }
-                            if (best_mm <= P.probe_max_mismatch) {
-                                const int s = best_s;
-                                const int lo = s < 0 ? (D < s ? D : s) : (D < 0 ? D : 0), hi = s > 0 ? (D > s ? D : s) : (D > 0 ? D : 0);
-                                cls = widest;
-                                for (int k = 3; k >= 0; --k) if (c2_band_holds(P.bandw[k], D, lo, hi, P.margin)) cls = k + 1;
-                            }
-                        }
-                    }
+                    else if (c2_part_probes(P, t)) cls = 8;
                 }
             }
-            flag[slot] = valid ? (uint8_t)cls : (uint8_t)7;
+            flag[slot] = (uint8_t)cls;
         }
         __syncthreads();
+        // ---- the tasks that need the probe, densely (about a third of an amplicon run's reads, scattered: probing them where they stand would
+        //      keep every wavefront in the loop with a third of its lanes), then one lane per such task
+        {
+            unsigned n8 = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) n8 += flag[16 * tid + k] == 8u;
+            unsigned incl = n8;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+            if (lane == 63) part[wv] = incl;
+            __syncthreads();
+            unsigned before = 0, total = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const unsigned x = part[v]; if (v < wv) before += x; total += x; }
+            unsigned pos = before + incl - n8;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (flag[16 * tid + k] == 8u) todo[pos++] = (uint16_t)(16 * tid + k);
+            __syncthreads();
+            for (unsigned k = (unsigned)tid; k < total; k += 256u) {
+                const int slot = (int)todo[k];
+                const c2_part_task t = c2_part_load(A, chunk + (uint64_t)slot);
+                flag[slot] = (uint8_t)c2_part_probe(P, t, widest);
+            }
+            __syncthreads();
+        }
         // ---- thread t owns tasks 16 t .. 16 t + 15 of the chunk: positions by a scan over the workgroup, one atomic per chunk and class
         unsigned n[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
