@@ -430,6 +430,7 @@ __device__ __forceinline__ void c2_clear_record(c2_aln_record& rec, const int rc
 // Pointer plane of the row-strip kernel: nibble of cell (pi, pj), pi, pj >= 1.
 template <int R, int MODE>
 struct c2_row_plane {
+    static constexpr bool kWordRuns = false;
     const uint16_t* sPtr; int pass_halfwords, colStride, band_lanes;
     __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
         const int pp = (pi - 1) / (64 * R), rem = (pi - 1) % (64 * R);
@@ -470,6 +471,53 @@ __device__ __forceinline__ void c2_traceback(const PLANE& P, const c2_wg& W, con
             }
             cnt += len; i = 0; j = 0;
             break;
+        }
+        if constexpr (PLANE::kWordRuns) {
+            // A run of state M in the packed kernels' words, FOUR cells per lane: the cells that decide it, (i-1-k, j-1-k), lie on one diagonal,
+            // every other anti-diagonal -- four of them in each word of the diagonal's lane slot.  "The path stays in M behind the cell" is two
+            // bits of its word (NOT "H is I" and NOT "J beats M", c2_pk_push4), so a lane tests its word's four cells with a mask, and the
+            // lanes together see 250 cells at once where the probe below sees 64.  Interior cells only (k < min(i, j) - 1): the cell on a
+            // matrix edge, and every other state, go through the probe below.
+            const int K = (i < j ? i : j) - 1;
+            const int slw = (i - j - P.d0) >> 1;
+            if (s == C2_ST_M && P.pk && K >= 1 && (unsigned)slw < (unsigned)P.nl) {
+                const int a0 = i + j - 2, par = a0 & 1, ctop = a0 & 7, W0 = a0 >> 3;
+                const int n0 = (ctop >> 1) + 1;                           // path cells in word W0: c = ctop, ctop - 2, ..
+                const int wi = W0 - lane;                                 // this lane's word
+                const int kfirst = lane == 0 ? 0 : n0 + 4 * (lane - 1);   // k of its topmost cell
+                int cells = lane == 0 ? n0 : 4;
+                if (wi < 0 || kfirst >= K) cells = 0; else if (kfirst + cells > K) cells = K - kfirst;
+                unsigned w = 0;
+                if (cells > 0) w = P.words[wi * P.lpa + slw];
+                const unsigned u = ((w & (w >> 8)) >> (2 * par)) & 0x00110011u;      // cell 6+par -> bit 20, 4+par -> 16, 2+par -> 4, par -> 0
+                unsigned m4 = (((u >> 20) & 1u) << 3) | (((u >> 16) & 1u) << 2) | (((u >> 4) & 1u) << 1) | (u & 1u);   // topmost cell first
+                const int ctop_l = lane == 0 ? ctop : 6 + par;            // the lane's topmost cell
+                if (lane == 0) m4 = (m4 << (4 - n0)) & 0xfu;
+                int n_lead = __builtin_clz((((~m4) & 0xfu) << 28) | 0x08000000u);    // cells from the top that keep the path in M (4: all of them)
+                if (n_lead > cells) n_lead = cells;
+                const unsigned long long stop = __ballot(n_lead < cells);
+                const int c_dec = ctop_l - 2 * n_lead;                    // the cell that ends the run, if it is this lane's
+                const int ns_dec = ((w >> (16 * ((c_dec & 7) >> 2) + 2 * (c_dec & 3))) & 1u) ? C2_ST_J : C2_ST_I;     // "H is I" first (pyx:349-358 order)
+                int covered = n0 + 4 * 63; if (covered > K) covered = K;  // cells the 64 words hold
+                int E, s_next;
+                if (stop == 0ull) { E = covered; s_next = C2_ST_M; }
+                else {
+                    const int wl = __builtin_ctzll(stop);
+                    E = (wl == 0 ? 0 : n0 + 4 * (wl - 1)) + __builtin_amdgcn_readlane(n_lead, wl) + 1;
+                    s_next = __builtin_amdgcn_readlane(ns_dec, wl);
+                }
+                for (int base = 0; base < E; base += 64) {
+                    const int k = base + lane;
+                    unsigned char rch = 0, fch = 1;
+                    if (k < E) {
+                        rch = W.sRead[j - 1 - k]; fch = W.sRef[i - 1 - k];
+                        W.sTmpRead[cnt + k] = rch; W.sTmpRef[cnt + k] = fch;
+                    }
+                    matches += __popcll(__ballot(k < E && rch == fch));               // pyx:375-376
+                }
+                cnt += E; i -= E; j -= E; s = s_next;
+                continue;
+            }
         }
         const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
         const int ik = i - lane * di, jk = j - lane * dj;
@@ -909,6 +957,7 @@ __device__ __forceinline__ int c2_outside_band_bound(const int maxS, const int L
 }
 
 struct c2_diag_plane {
+    static constexpr bool kWordRuns = false;
     const unsigned* words; int d0;
     __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
         const int sl = ((pi - pj - d0) >> 1) - C2_DIAG_STORE_LO;         // stored lane slot of the cell's diagonal
@@ -1155,6 +1204,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
 
 // pointer words of ONE alignment, staged in LDS: [group of 8 anti-diagonals][lane of the alignment's lane group]
 struct c2_diagx_plane {
+    static constexpr bool kWordRuns = true;                         // (c2_traceback: runs of state M are read off whole pointer words where pk is set)
     const unsigned* words; int d0, lpa, nl; bool pk;               // nl: lanes of a group that hold diagonals (lpa - 1, or lpa for a row-DPP group)
     __device__ __forceinline__ bool fetch(const int pi, const int pj, unsigned& nib) const {
         const int sl = (pi - pj - d0) >> 1;                              // lane of the cell's diagonal inside its group
