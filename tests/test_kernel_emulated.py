@@ -621,3 +621,36 @@ def test_partition_routes_tasks_to_the_launch_whose_band_holds_their_path(mats, 
     res2, rec2 = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st2)
     assert res2 == res and np.array_equal(rec2, rec)
     assert st2["classes"][3] == 0 and st2["classes"][4] == 0 and st2["classes"][1] > 0, st2
+
+
+@pytest.mark.parametrize("L", [300, 700])
+def test_traceback_runs_of_m_longer_than_one_pass_of_the_word_probe(mats, L):
+    """c2_traceback reads a run of state M off whole pointer words, four cells per lane: 250-odd cells per pass.  References of 300 and 700 bases
+    with reads that differ from them in a substitution or two, one short indel, an indel at either end, or nothing at all: runs of M of up to 700
+    cells (several passes, the last one partial), runs that end in the first word of a pass, at a word's last cell, on the matrix edge."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(9000 + L)
+    ref = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = list(range(L // 2 - 5, L // 2 + 5))
+    other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    reads = [ref, ref[1:], ref[:-1], ref[2:] + "AC", "GT" + ref[:-2]]
+    for cut in (1, 2, 3, 4, 7, 8, 9, 250, 251, 252, 253, 254, 255, 256, 257, L - 9, L - 8, L - 4, L - 3, L - 2, L - 1):
+        reads.append(ref[:cut] + ref[cut + 1:])                                     # one base deleted at every kind of place in a word / a pass
+        reads.append(ref[:cut] + "T" + ref[cut:])                                   # ... inserted
+        reads.append(ref[:cut] + other[ref[cut]] + ref[cut + 1:])                   # ... substituted
+    for _ in range(12):
+        t = list(ref)
+        for _ in range(int(rng.integers(0, 4))):
+            q = int(rng.integers(0, L)); t[q] = other[t[q]]
+        t = "".join(t)
+        a = int(rng.integers(5, L - 40)); d = int(rng.integers(1, 12))
+        reads.append(t[:a] + t[a + d:] if rng.random() < 0.5 else t[:a] + "".join(rng.choice(list("ACGT"), d)) + t[a:])
+    reads.sort(key=len)                                                             # (a packed kernel pairs neighbours of one length: the words read here are its)
+    st = {}
+    res, rec = E.align_batch(reads, [ref], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    assert st["unpaired"] <= 12, st["unpaired"]
+    for k, rd in enumerate(reads):
+        status, s1, s2, mt, ln = oracle.global_align_raw(rd, ref, m, g, -20, -2)
+        assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k, len(rd))
+        check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
