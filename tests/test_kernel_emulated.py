@@ -654,3 +654,53 @@ def test_traceback_runs_of_m_longer_than_one_pass_of_the_word_probe(mats, L):
         status, s1, s2, mt, ln = oracle.global_align_raw(rd, ref, m, g, -20, -2)
         assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k, len(rd))
         check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+
+
+@pytest.mark.parametrize("go,ge", [(-20, -2), (-5, -3)])
+@pytest.mark.parametrize("env", [{}, {"C2_ROUTE_MARGIN": "0"}, {"C2_ROUTE_MARGIN": "12"}, {"C2_ROUTE_PROBE_MISMATCH": "32"}, {"C2_SCORE_TIER_MAX_MISMATCH": "32"},
+                                 {"C2_P16_TIER": "1", "C2_ROUTE_MARGIN": "0"}])
+def test_partition_settings_never_change_a_result(mats, go, ge, env, monkeypatch):
+    """The partition only says which launch sees a task FIRST; every launch verifies what it finishes.  So the most careless settings -- no margin
+    (tasks routed to bands their certificate will refuse), a probe that accepts any window, a tail check that sends every equal-length read to the
+    score-only launch -- must give the oracle's alignments all the same: three references (ref_ids), both strands, reads from 40 to 260 bases (the
+    probe needs 96), Ns, indels of up to 45 bases, two gap scorings."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(515)
+    refs = ["".join(rng.choice(list("ACGT"), L)) for L in (250, 200, 120)]
+    gis = [np.zeros(len(r) + 1, dtype=np.int64) for r in refs]
+    for g in gis:
+        g[len(g) // 2 + 1] = 1
+    incs = [list(range(len(r) // 2 - 5, len(r) // 2 + 5)) for r in refs]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    reads, rids, strands, truth = [], [], [], []
+    for k in range(72):
+        r = k % 3
+        s = list(refs[r])
+        L = len(s)
+        kind = (k // 3) % 6
+        if kind == 1:
+            d = int(rng.integers(1, 46)); a = L // 2 - d // 2
+            s = (s[:a] + s[a + d:] + list(rng.choice(list("ACGT"), d)))[:L]            # deletion, length kept
+        elif kind == 2:
+            d = int(rng.integers(1, 16)); s = (s[:L // 2] + list(rng.choice(list("ACGT"), d)) + s[L // 2:])[:L]
+        elif kind == 3:
+            d = int(rng.integers(1, 46)); a = int(rng.integers(5, L - 50)); s = s[:a] + s[a + d:]   # deletion, the read is shorter
+        elif kind == 4:
+            s = s[int(rng.integers(0, 30)):int(rng.integers(L - 30, L))]                # a fragment
+        elif kind == 5:
+            s = s[:int(rng.integers(40, 96))]                                           # too short for the probe
+        for _ in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, len(s)))] = str(rng.choice(list("ACGTN")))
+        fw = "".join(s)
+        rc = (k // 18) % 2
+        reads.append("".join(comp[c] for c in reversed(fw)) if rc else fw)
+        rids.append(r); strands.append(rc); truth.append(fw)
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    st = {}
+    res, rec = E.align_batch(reads, refs, gis, incs, m, go, ge, ref_ids=rids, strands=strands, band_lanes=-87, stats=st)
+    assert sum(st["classes"]) == len(reads)
+    for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+        exp = oracle.global_align_raw(truth[k], refs[rids[k]], m, gis[rids[k]], go, ge)
+        assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], (k, env)
+        check_record(r, oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
