@@ -271,9 +271,9 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
         if (A.n_tasks > 0xFFFFFFFFull) { ctx->err = "more than 2^32 tasks in one launch"; return C2_E_INVALID; }
         // d_fb: 64 header words -- [0..7] length of the list each BAND tier leaves for the next one, [8..15] length of the list of
         // tasks a packed kernel could not pair (run by the 32-bit kernel of the same band), [16 + 2l ..] work counter of launch l --
-        // then three task lists: two that alternate between band tiers and one for the unpaired tasks
-        // (round 4: a list per band tier instead of two that alternate -- c2_align_partition_kernel writes into the lists of LATER tiers;
-        //  header words 48..52: tasks per class of the partition, 56 / 57: length of the first tier's list after the score-only launch and after
+        // then eight task lists: one per band tier (c2_align_partition_kernel writes into the lists of LATER tiers, so they cannot share
+        // buffers), the unpaired tasks', the score-only launch's, the first tier's when the partition ran, the 14-diagonal launch's
+        // (header words 48..52: tasks per class of the partition, 56 / 57: length of the first tier's list after the score-only launch and after
         //  the 14-diagonal launch, 60 / 62 / 61: lengths of the score-only launch's list, the 14-diagonal launch's, the first tier's)
         const size_t list_words = (size_t)A.n_tasks;
         if ((rc = ensure(ctx, ctx->d_fb, 256 + 8 * list_words * sizeof(uint32_t)))) return rc;
