@@ -83,6 +83,9 @@ def global_align(pystr_seqj, pystr_seqi, matrix, gap_incentive, gap_open=-1, gap
     if hit is not None:
         return hit
     _prime.stats["per_call_align"] += 1
+    if _native.in_forked_child():
+        # a worker the reference fork()ed after the GPU was opened (CRISPRessoCORE.py:1870-1898): the call is served by a spawned helper
+        return _native.forked_child_helper().call("global_align", pystr_seqj, pystr_seqi, m, g, gap_open, gap_extend)
     ctx = _native.default_context()
     cap = len(bi) + len(bj) + 1
     oj = ctypes.create_string_buffer(cap)

@@ -109,6 +109,11 @@ def _classify(read_seq_al, ref_seq_al, _include_indx, legacy):
     return res, counts
 
 
+def _plain_include(_include_indx):
+    """what crosses the pipe to a forked worker's helper: the include indices as a plain list (sets and arrays alike)"""
+    return _include_indx if isinstance(_include_indx, np.ndarray) else list(_include_indx)
+
+
 def _payload(res, counts):
     return ResultsSlotsDict(
         all_insertion_positions=res['all_insertion_positions'],
@@ -141,6 +146,8 @@ def find_indels_substitutions(read_seq_al, ref_seq_al, _include_indx):
     if hit is not None:
         return hit
     _prime.stats["per_call_classify"] += 1
+    if _native.in_forked_child():
+        return _native.forked_child_helper().call("find_indels_substitutions", read_seq_al, ref_seq_al, _plain_include(_include_indx))
     res, counts = _classify(read_seq_al, ref_seq_al, _include_indx, 0)
     return _payload(res, counts)
 
@@ -152,6 +159,8 @@ def find_indels_substitutions_legacy(read_seq_al, ref_seq_al, _include_indx):
     if hit is not None:
         return hit
     _prime.stats["per_call_classify"] += 1
+    if _native.in_forked_child():
+        return _native.forked_child_helper().call("find_indels_substitutions_legacy", read_seq_al, ref_seq_al, _plain_include(_include_indx))
     res, counts = _classify(read_seq_al, ref_seq_al, _include_indx, 1)
     return _payload_legacy(res, counts)
 
@@ -229,6 +238,8 @@ def calculate_homology(a, b):
     if n == 0:
         raise ZeroDivisionError('float division')
     b = bytes(b)[:n].ljust(n, b'\0')
+    if _native.in_forked_child():
+        return _native.forked_child_helper().call("calculate_homology", a, b)
     ctx = _native.default_context()
     out = ctypes.c_double(0)
     ctx.check(ctx.lib.c2_calculate_homology(ctx.handle, a, b, n, ctypes.byref(out)), 'c2_calculate_homology')

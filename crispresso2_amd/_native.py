@@ -44,6 +44,7 @@ assert REC_DTYPE.itemsize == 32
 
 STATUS_EMPTY, STATUS_OOB_CHAR, STATUS_SENTINEL_PATH, STATUS_UNINIT_PTR, STATUS_RC_CHAR, STATUS_TOO_LONG = 1, 2, 4, 8, 16, 32
 E_OVERFLOW = -6
+ABI_VERSION = 2
 LIST_COUNT = 15
 
 
@@ -85,6 +86,9 @@ def load():
             except ImportError:
                 pass
             lib = ctypes.CDLL(LIB_PATH)
+            if lib.c2_abi_version() != ABI_VERSION:                   # (struct layouts below are this version's: include/crispresso2_amd.h)
+                raise NativeError("crispresso2_amd: %s has C ABI version %d, this binding was written for %d -- rebuild the library"
+                                  % (LIB_PATH, lib.c2_abi_version(), ABI_VERSION))
             lib.c2_last_error.restype = ctypes.c_char_p
             lib.c2_last_error.argtypes = [ctypes.c_void_p]
             lib.c2_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
@@ -141,6 +145,10 @@ class Context:
     """One c2_ctx bound to one GPU."""
 
     def __init__(self, device=0):
+        if in_forked_child():
+            raise NativeError("crispresso2_amd: this process was fork()ed from one that had already opened the GPU; the HIP runtime it "
+                              "inherited cannot be used or re-initialised here (the per-call API goes through crispresso2_amd._helper "
+                              "instead; anything else needs a spawned process)")
         self.lib = load()
         self.handle = ctypes.c_void_p()
         rc = self.lib.c2_create(int(device), ctypes.byref(self.handle))
@@ -149,6 +157,8 @@ class Context:
             raise NativeError("crispresso2_amd: cannot create a GPU context on device %d: %s (rc=%d); "
                               "this package has no CPU fallback" % (device, msg.decode() if msg else "?", rc))
         self.device = int(device)
+        self.pid = os.getpid()
+        note_gpu_opened()
 
     def check(self, rc, what):
         if rc != 0:
@@ -157,7 +167,8 @@ class Context:
 
     def close(self):
         if self.handle:
-            self.lib.c2_destroy(self.handle)
+            if getattr(self, "pid", os.getpid()) == os.getpid():   # (a forked child must not tear down the parent's streams and buffers)
+                self.lib.c2_destroy(self.handle)
             self.handle = ctypes.c_void_p()
 
     def __del__(self):
@@ -739,8 +750,90 @@ _default_ctx = None
 
 
 def default_context():
-    """Process-wide context on the current device (LOCAL_RANK, else 0) for the per-call API."""
+    """Process-wide context on the current device (LOCAL_RANK, else 0) for the per-call API.  In a process that was fork()ed
+    after the GPU had been opened (the reference's `-p N` workers, CRISPRessoCORE.py:1870-1898: main() has aligned its guides
+    before it forks) this raises -- the shim modules send their per-call work to `forked_child_helper()` there."""
     global _default_ctx
+    if in_forked_child():
+        raise NativeError("crispresso2_amd: no GPU context in a fork()ed child of a process that had opened the GPU")
     if _default_ctx is None:
         _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
     return _default_ctx
+
+
+# ---- fork(): HIP does not survive it.  The pid that first opened the GPU is remembered; any other pid that finds the mark is a forked
+# child (a spawned process imports this module afresh and has no mark).
+_gpu_pid = [None]
+_helper = [None, None]                                                 # (pid that owns it, _Helper)
+
+
+def note_gpu_opened():
+    if _gpu_pid[0] is None:
+        _gpu_pid[0] = os.getpid()
+
+
+def in_forked_child():
+    return _gpu_pid[0] is not None and _gpu_pid[0] != os.getpid()
+
+
+class _Helper:
+    """A SPAWNED python process with its own HIP runtime that runs the per-call entry points for a forked child
+    (`python -m crispresso2_amd._helper <read fd> <write fd>`; length-prefixed pickles either way)."""
+
+    def __init__(self):
+        import subprocess
+        import sys
+        c2h_r, c2h_w = os.pipe()
+        h2c_r, h2c_w = os.pipe()
+        env = dict(os.environ, C2_PRIME_FROM_ARGV="0")
+        env.pop("C2_PRIME_FASTQ", None)
+        root = os.path.dirname(_HERE)
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        self.proc = subprocess.Popen([sys.executable, "-m", "crispresso2_amd._helper", str(c2h_r), str(h2c_w)], pass_fds=(c2h_r, h2c_w),
+                                     env=env, stdin=subprocess.DEVNULL)
+        os.close(c2h_r)
+        os.close(h2c_w)
+        self.w = os.fdopen(c2h_w, "wb", buffering=0)
+        self.r = os.fdopen(h2c_r, "rb", buffering=0)
+        self.calls = 0
+
+    def call(self, name, *args):
+        import pickle
+        import struct
+        blob = pickle.dumps((name, args), protocol=pickle.HIGHEST_PROTOCOL)
+        self.w.write(struct.pack("<Q", len(blob)) + blob)
+        head = _read_exactly(self.r, 8)
+        if head is None:
+            raise NativeError("crispresso2_amd: the helper process of this forked child ended (exit code %s)" % self.proc.poll())
+        kind, value = pickle.loads(_read_exactly(self.r, struct.unpack("<Q", head)[0]))
+        self.calls += 1
+        if kind == "err":
+            raise value
+        return value
+
+    def close(self):
+        try:
+            self.w.close()
+            self.r.close()
+            self.proc.wait(timeout=30)
+        except Exception:
+            pass
+
+
+def _read_exactly(fh, n):
+    out = b""
+    while len(out) < n:
+        part = fh.read(n - len(out))
+        if not part:
+            return None
+        out += part
+    return out
+
+
+def forked_child_helper():
+    """the helper of THIS process (a grandchild forked from a forked child starts its own)"""
+    if _helper[0] != os.getpid():
+        _helper[0], _helper[1] = os.getpid(), _Helper()
+        import atexit
+        atexit.register(_helper[1].close)
+    return _helper[1]

@@ -24,10 +24,17 @@ def _rows(strings, stride):
     return a
 
 
-def consensus_batch(items, ctx=None):
+def consensus_batch(items, ctx=None, errors="raise"):
     """items: sequence of (aln_seq_r1, aln_ref_r1, score_r1, qual_r1, aln_seq_r2, aln_ref_r2, score_r2, qual_r2).
     -> list of (final_aln, final_qual, final_ref, score, caching_is_ok) as the reference returns them; an item on which the
-    reference raises IndexError (a quality index past the end of its string) raises IndexError here."""
+    reference raises IndexError (a quality index past the end of its string) raises IndexError here -- or, with errors="skip",
+    gives None in its place."""
+    if errors == "skip":
+        good = [k for k, it in enumerate(items) if len(it[0]) >= len(it[1]) and len(it[4]) >= len(it[5])]
+        out = [None] * len(items)
+        for k, c in zip(good, consensus_batch([items[k] for k in good], ctx=ctx, errors="none")):
+            out[k] = c
+        return out
     n = len(items)
     if n == 0:
         return []
@@ -58,6 +65,9 @@ def consensus_batch(items, ctx=None):
     for k in range(n):
         ln, lq, hom, fl = (int(x) for x in info[k])
         if fl & 2:
+            if errors == "none":
+                out.append(None)
+                continue
             raise IndexError('string index out of range')
         out.append((oa[k, :ln].tobytes().decode(), oq[k, :lq].tobytes().decode(), orf[k, :ln].tobytes().decode(),
                     round(float(100 * hom / float(ln)), 3), bool(fl & 1)))

@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define C2_ABI_VERSION 1
+/* 2: struct c2_batch grew by `min_read_len` (round 4).  A caller built against version 1 passes the shorter struct: check c2_abi_version()
+ * against the header you compiled with before the first batch call.  Zero-initialise every struct c2_batch you fill in; fields added later
+ * are hints whose zero means "not known". */
+#define C2_ABI_VERSION 2
 
 /* error codes */
 #define C2_E_INVALID   -1   /* bad argument */

@@ -35,6 +35,11 @@ class _EmuLib:
         self.c2_find_indels_substitutions = lib.emu_c2_find_indels_substitutions
         self.c2_calculate_homology = lib.emu_c2_calculate_homology
 
+    @staticmethod
+    def c2_consensus_pairs_batch(handle, *args):                    # (crispresso2_amd.prime's consensus of the registered pairs)
+        from pipeline_on_emulator import EmulatedContext
+        return EmulatedContext().lib.c2_consensus_pairs_batch(handle, *args)
+
 
 class _EmuContext:
     """stands in for _native.Context for the per-call API: same attributes the shim modules use (plus the batched classifier that
@@ -69,6 +74,21 @@ def use_emulator():
 _done = {}
 
 
+def emulator_context():
+    """the emulator in the place of the GPU context (also what a forked worker's helper process preloads:
+    C2_HELPER_PRELOAD=dropin_inject:emulator_context).  "Opening" it marks the process as one that has opened the GPU, so that
+    a fork()ed child treats it exactly as it must treat a HIP context: not at all."""
+    from crispresso2_amd import _native, batch
+    from pipeline_on_emulator import EmulatedAligner
+    ctx = _EmuContext()
+    _native.default_context = lambda *a, **k: ctx
+    _native.note_gpu_opened()
+    batch.BatchAligner = EmulatedAligner                             # (crispresso2_amd.prime's one-batch-per-amplicon route)
+    os.environ["C2_HELPER_PRELOAD"] = "dropin_inject:emulator_context"
+    os.environ["PYTHONPATH"] = HERE + os.pathsep + os.environ.get("PYTHONPATH", "")
+    return ctx
+
+
 def inject():
     """-> (shim align module, shim resources module); idempotent"""
     if _done:
@@ -76,11 +96,7 @@ def inject():
     import importlib.metadata as md
     from crispresso2_amd import CRISPResso2Align as A, CRISPRessoCOREResources as R, _native
     if use_emulator():
-        ctx = _EmuContext()
-        _native.default_context = lambda *a, **k: ctx
-        from crispresso2_amd import batch
-        from pipeline_on_emulator import EmulatedAligner
-        batch.BatchAligner = EmulatedAligner                         # (crispresso2_amd.prime's one-batch-per-amplicon route)
+        emulator_context()
     pkg = types.ModuleType("CRISPResso2")
     pkg.__path__ = [os.path.join(REF, "CRISPResso2")]
     sys.modules["CRISPResso2"] = pkg

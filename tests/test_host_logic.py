@@ -22,7 +22,7 @@ def test_library_exports_every_symbol_declared_in_the_header():
     for sym in declared:
         assert hasattr(lib, sym), "header declares %s but the library does not export it" % sym
     assert set(_native.SYMBOLS) <= declared
-    assert lib.c2_abi_version() == 1
+    assert lib.c2_abi_version() == 2 == _native.ABI_VERSION
 
 
 def test_no_device_means_loud_failure_not_a_fallback():
