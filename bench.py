@@ -128,6 +128,44 @@ def build_workload(config, L, n, rank, workers):
     raise SystemExit("--config must be 2, 3, 4 or 5")
 
 
+def build_robust_workloads(L, n, rank, workers):
+    """The headline's read budget with inputs that are NOT the synthetic generator's best case: every read of the
+    generator is exactly as long as the amplicon and most are gap-free, which is what the score-only stage and the first band tier are
+    fastest on.  -> {name: workload dict with `reads` padded to a common width with 0 and `lens`}"""
+    from crispresso2_amd import synth
+    blocks = (n + synth.BLOCK - 1) // synth.BLOCK
+    out = {}
+    # (i) reads shaped like the reference's own test data: tests/FANC.Cas9.fastq resampled (crispresso2_amd/fanc_profile.json) -- a 4-base
+    # overhang in front of the 223-bp amplicon, 23+ bases of genomic flank behind it, lengths 248-250 (a few much shorter), deletions at the
+    # cut in a third of the reads, 5 % unrelated reads
+    amp, g, inc = synth.fanc_setup()
+    fr, fl = synth.make_fanc_reads(n, first_block=rank * blocks, workers=workers)
+    out["fanc_shaped"] = dict(refs=[(amp, g, inc)], reads=fr, lens=fl, ref_ids=None, all_refs=False, max_len=int(fl.max()),
+                              text="%s reads resampled from the length / overhang / indel signatures of the reference's tests/FANC.Cas9.fastq "
+                                   "(4-base leading overhang, 23+ bases of flank behind the amplicon, 5 %% unrelated reads) vs the %d bp FANC amplicon"
+                                   % ("{:,}".format(n), len(amp)))
+    # (ii) the generator's reads cut to lengths U[200, L]: the read ends inside the amplicon (a trailing deletion of 0-50 bases)
+    amp2, g2, inc2 = synth.amplicon_setup(L)
+    base = synth.make_reads(L, n, first_block=(rank + 64) * blocks, workers=workers)
+    rng = np.random.default_rng([20240604, rank])
+    W = (L + 15) // 16 * 16
+    vr = np.zeros((n, W), dtype=np.uint8)
+    vr[:, :L] = base
+    vl = rng.integers(min(200, L), L + 1, n).astype(np.int32)
+    vr[np.arange(W, dtype=np.int32)[None, :] >= vl[:, None]] = 0
+    out["lengths_200_to_L"] = dict(refs=[(amp2, g2, inc2)], reads=vr, lens=vl, ref_ids=None, all_refs=False, max_len=L,
+                                   text="%s reads of the synthetic generator cut to lengths U[%d, %d] vs the %d bp amplicon" % ("{:,}".format(n), min(200, L), L, L))
+    # (iii) one read in ten is unrelated to the amplicon (random bases): no band can certify it, it ends in the full-matrix launch
+    ur = np.zeros((n, W), dtype=np.uint8)
+    ur[:, :L] = base
+    del base
+    junk = np.nonzero(rng.random(n) < 0.10)[0]
+    ur[junk, :L] = synth._bases(rng.integers(0, 4, (len(junk), L), dtype=np.uint8))
+    out["unrelated_10_percent"] = dict(refs=[(amp2, g2, inc2)], reads=ur, lens=np.full(n, L, dtype=np.int32), ref_ids=None, all_refs=False, max_len=L,
+                                       text="%s reads of the synthetic generator, 10 %% of them replaced by random sequences, vs the %d bp amplicon" % ("{:,}".format(n), L))
+    return out
+
+
 SPAWN_CMD = [sys.executable, os.path.abspath(__file__)]     # what a rank is (tests/bench_emulated_main.py puts its own script here)
 
 
@@ -185,8 +223,17 @@ class Job:
         self.al = BatchAligner([r[0] for r in refs], [r[1] for r in refs], [r[2] for r in refs], matrix, GO, GE, ctx=ctx)
         self.stride = stride = self.al.stride_for(L)
         self.Lmax = self.al.max_ref_len
-        self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
-        self.d_offsets = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
+        self.min_len = 0
+        if wl.get("lens") is not None:                                # ragged reads: rows padded with 0 + their lengths -> arena + offsets
+            from crispresso2_amd import synth
+            arena, off = synth.pack_ragged(reads, wl["lens"])
+            self.d_reads = torch.from_numpy(arena).to(dev)
+            self.d_offsets = torch.from_numpy(off.view(np.int64)).to(dev)
+            self.min_len = int(wl["lens"].min())
+            del arena
+        else:
+            self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+            self.d_offsets = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
         self.d_rids = None if wl["ref_ids"] is None else torch.from_numpy(wl["ref_ids"].astype(np.int16)).to(dev)
         # output buffers: one set; two with --overlap-count, so that batch k+1 is aligned while batch k is still being counted
         self.n_sets = 2 if overlap_count else 1
@@ -216,7 +263,7 @@ class Job:
     def align_into(self, a_read, a_ref, recs):
         self.al.align_device(self.n, self.d_reads.data_ptr(), self.d_offsets.data_ptr(), a_read.data_ptr(), a_ref.data_ptr(), recs.data_ptr(),
                              self.stride, self.L, d_ref_ids=None if self.d_rids is None else self.d_rids.data_ptr(), all_refs=self.all_refs,
-                             stream=self.stream)
+                             stream=self.stream, min_read_len=self.min_len)
 
     def step(self, e=None):
         """One batch: launch chain on the align stream into buffer set i; reference choice, count pass and all-reduce on the count
@@ -675,6 +722,7 @@ def main():
         cpu_baseline, cpu_legs = cb.run(reads, refs, matrix_path, GO, GE, ref_ids=wl["ref_ids"], all_refs=all_refs, cores=ncpu,
                                         target_seconds=args.cpu_seconds, long_seconds=args.cpu_long_seconds)
     other_wl, other_ref, e2e_files = {}, {}, None
+    robust_wl, robust_ref, t_gen_robust = {}, {}, 0.0
     if extras:
         t0 = time.perf_counter()
         for cfg in (2, 4, 5):
@@ -682,6 +730,10 @@ def main():
                 Lc, nc = CONFIG_DEFAULTS[cfg]
                 other_wl[cfg] = (Lc, build_workload(cfg, Lc, min(nc, args.extra_reads) if args.extra_reads else nc, rank, workers))
         t_gen_other = time.perf_counter() - t0
+        if args.config == 3 and not all_refs:
+            t0 = time.perf_counter()
+            robust_wl = build_robust_workloads(L, min(n, args.extra_reads) if args.extra_reads else n, rank, workers)
+            t_gen_robust = time.perf_counter() - t0
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.ref_check_reads > 0 and args.check > 0:
             # the first reads of every other configuration through the reference's compiled code (a checker, not a timing; before HIP: it forks)
             from oracle import cpu_baseline as cb
@@ -693,6 +745,12 @@ def main():
                                                         ref_ids=None if wlc["ref_ids"] is None else wlc["ref_ids"][:m_], all_refs=wlc["all_refs"], procs=procs_)
                 except Exception as e:
                     other_ref[cfg] = ({"error": repr(e)}, None)
+            for name, wlc in robust_wl.items():
+                m_ = min(len(wlc["reads"]), args.ref_check_reads)
+                try:
+                    robust_ref[name] = cb.reference_slice(wlc["reads"][:m_], wlc["refs"], matrix_path, GO, GE, procs=procs_)
+                except Exception as e:
+                    robust_ref[name] = ({"error": repr(e)}, None)
         if rank == 0 and not all_refs and wl["ref_ids"] is None:
             try:                                                     # (N ranks: one plain file, read by all of them -- the sharded FASTQ leg)
                 e2e_files = _e2e_prepare(reads[:args.extra_reads] if args.extra_reads else reads, min(64, max(workers, ncpu // 4)), bgzf=world == 1)
@@ -885,7 +943,7 @@ def main():
         valu["frac_of_simd32_peak"] = rate / VALU_SIMD32_WAVE_INSTR_PER_S
 
     # ---------- after the headline: the int32 chain on the same batch, the other BASELINE shapes, FASTQ -> tensors ----------
-    int32_chain = other_configs = e2e = None
+    int32_chain = other_configs = e2e = robustness = None
     extras_done = threading.Event()
     extras_note = [None]
 
@@ -934,6 +992,12 @@ def main():
                        "reference_compared_n": checks.get("reference_compared_n"), "reference_identical_n": checks.get("reference_identical_n"),
                        "other_configs_reference_identical": None if not other_configs else {
                            c_: "%s/%s" % (e_.get("reference_identical_n"), e_.get("reference_compared_n")) for c_, e_ in other_configs.items() if isinstance(e_, dict) and "reference_compared_n" in e_},
+                       "robust_fanc_shaped_reads_per_s": None if not robustness else (robustness.get("fanc_shaped") or {}).get("reads_per_s"),
+                       "robust_lengths_200_to_L_reads_per_s": None if not robustness else (robustness.get("lengths_200_to_L") or {}).get("reads_per_s"),
+                       "robust_unrelated_10_percent_reads_per_s": None if not robustness else (robustness.get("unrelated_10_percent") or {}).get("reads_per_s"),
+                       "robust_full_plane_floor_reads_per_s": None if not robustness else (robustness.get("full_plane_floor") or {}).get("reads_per_s"),
+                       "robust_worst_case": None if not robustness or "worst_case" not in robustness else "%s: %.1f M reads/s" % (
+                           robustness["worst_case"]["leg"], robustness["worst_case"]["reads_per_s"] / 1e6),
                        "other_configs_reads_per_s": None if not other_configs else {c_: e_.get("reads_per_s") for c_, e_ in other_configs.items() if isinstance(e_, dict) and "reads_per_s" in e_},
                        "e2e_fastq_to_tensors_reads_per_s": (None if not e2e else e2e["plain"]["reads_per_s"] if "plain" in e2e else
                                                             (e2e.get("sharded") or {}).get("reads_per_s")),
@@ -958,6 +1022,7 @@ def main():
             "partition": part_info,
             "int32_chain": int32_chain,
             "other_configs": other_configs,
+            "robustness": robustness,
             "e2e": e2e,
             "dedup_on": dedup_on,
             "cpu_baseline": cpu_baseline,
@@ -1025,47 +1090,82 @@ def main():
         del job, d_aln_read, d_aln_ref, d_records
         torch.cuda.empty_cache()
         if extras:
+            def run_leg(wlc, Lc, ref_leg):
+                """one more workload through the default chain: 1 warm-up + --extra-steps timed steps, the tier shares, chain = full plane on every
+                task, the reference-compiled slice"""
+                jc = Job(ctx, wlc, Lc, m, dev, world, kernel="auto")
+                tc = jc.timed(1, args.extra_steps)
+                tiers_c = ctx.tier_info()
+                part_c = ctx.partition_info() if hasattr(ctx, "partition_info") else None
+                rec_c = jc.outputs[2].cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+                entry = {"workload": wlc["text"], "reads_per_gpu_per_step": jc.n, "alignments_per_gpu_per_step": jc.n_tasks, "n_amplicons": jc.k,
+                         "steps": args.extra_steps, "ms_per_step": 1e3 * tc["dt"] / args.extra_steps, "reads_per_s": tc["reads_per_s"],
+                         "alignments_per_s": tc["alignments_per_s"],
+                         "step_breakdown_ms": {"align_chain": tc["align_ms"], "select_best": tc["select_ms"], "count_vectors_and_all_reduce": tc["count_ms"]},
+                         "tasks_left_after_each_banded_launch": tiers_c, "all_status_ok": bool((rec_c["status"] == 0).all())}
+                if part_c and part_c.get("ran"):
+                    # which launch sees a task FIRST (c2_align_partition_kernel's classes) and what each tier hands on: the tier shares of this input
+                    cls_ = part_c["classes"]
+                    entry["first_launch_share"] = {"score_only": cls_[0] / float(jc.n_tasks), "tier1_32_diagonals": (cls_[1] + cls_[2]) / float(jc.n_tasks),
+                                                   "tier2_62_diagonals": cls_[3] / float(jc.n_tasks), "tier3_128_diagonals": cls_[4] / float(jc.n_tasks)}
+                    entry["score_only_finished_share"] = part_c["finished"][0] / float(jc.n_tasks)
+                entry["full_plane_launch_share"] = (tiers_c[-1] / float(jc.n_tasks)) if tiers_c else None
+                if ref_leg is not None:
+                    leg_c, kind_c = ref_leg
+                    if "error" in leg_c:
+                        entry["reference_check_error"] = leg_c["error"]
+                    else:
+                        cmp_n, same_n = _compare_with_reference([leg_c], jc.outputs[0], jc.outputs[1], rec_c, jc.k, jc.all_refs)
+                        entry["reference_compared_n"], entry["reference_identical_n"] = cmp_n, same_n
+                        entry["reference_identical"] = bool(cmp_n == same_n)
+                        entry["reference_check"] = {"kind": kind_c, "procs": leg_c["procs"], "seconds": leg_c["seconds"],
+                                                    "note": "the first reads of this workload aligned by the reference's compiled code (oracle/_ref) on the "
+                                                            "host before the timed region; strings by digest + the best alignment's three window counts"}
+                del rec_c
+                if rank == 0 and args.check > 0 and not args.no_full_plane_check:
+                    eq, tf = jc.chain_equals_full_plane()
+                    entry["chain_equals_full_plane_n"] = eq
+                    entry["chain_equals_full_plane"] = bool(eq == jc.n_tasks)
+                    entry["full_plane_pass_s"] = tf
+                tl = jc.tallies()
+                entry["reads_aligned_all_gpus"] = int(sum(t_["counts_total"] for t_ in tl))
+                entry["modified"] = int(sum(t_["counts_modified"] for t_ in tl))
+                if jc.all_refs:
+                    entry["selection"] = dict(zip(C.SELECT_STATS, jc.d_selstats.cpu().numpy().tolist()))
+                jc.free()
+                del jc
+                return entry
+
             other_configs = {"data_generation_s": t_gen_other}
             for cfg, (Lc, wlc) in sorted(other_wl.items()):
                 try:
-                    jc = Job(ctx, wlc, Lc, m, dev, world, kernel="auto")
-                    tc = jc.timed(1, args.extra_steps)
-                    tiers_c = ctx.tier_info()
-                    rec_c = jc.outputs[2].cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
-                    entry = {"workload": wlc["text"], "reads_per_gpu_per_step": jc.n, "alignments_per_gpu_per_step": jc.n_tasks, "n_amplicons": jc.k,
-                             "steps": args.extra_steps, "ms_per_step": 1e3 * tc["dt"] / args.extra_steps, "reads_per_s": tc["reads_per_s"],
-                             "alignments_per_s": tc["alignments_per_s"],
-                             "step_breakdown_ms": {"align_chain": tc["align_ms"], "select_best": tc["select_ms"], "count_vectors_and_all_reduce": tc["count_ms"]},
-                             "tasks_left_after_each_banded_launch": tiers_c, "all_status_ok": bool((rec_c["status"] == 0).all())}
-                    if cfg in other_ref:
-                        leg_c, kind_c = other_ref[cfg]
-                        if "error" in leg_c:
-                            entry["reference_check_error"] = leg_c["error"]
-                        else:
-                            cmp_n, same_n = _compare_with_reference([leg_c], jc.outputs[0], jc.outputs[1], rec_c, jc.k, jc.all_refs)
-                            entry["reference_compared_n"], entry["reference_identical_n"] = cmp_n, same_n
-                            entry["reference_identical"] = bool(cmp_n == same_n)
-                            entry["reference_check"] = {"kind": kind_c, "procs": leg_c["procs"], "seconds": leg_c["seconds"],
-                                                        "note": "the first reads of this configuration aligned by the reference's compiled code (oracle/_ref) on the "
-                                                                "host before the timed region; strings by digest + the best alignment's three window counts"}
-                    del rec_c
-                    if rank == 0 and args.check > 0 and not args.no_full_plane_check:
-                        eq, tf = jc.chain_equals_full_plane()
-                        entry["chain_equals_full_plane_n"] = eq
-                        entry["chain_equals_full_plane"] = bool(eq == jc.n_tasks)
-                    tl = jc.tallies()
-                    entry["reads_aligned_all_gpus"] = int(sum(t_["counts_total"] for t_ in tl))
-                    entry["modified"] = int(sum(t_["counts_modified"] for t_ in tl))
-                    if jc.all_refs:
-                        entry["selection"] = dict(zip(C.SELECT_STATS, jc.d_selstats.cpu().numpy().tolist()))
-                    jc.free()
-                    del jc
+                    entry = run_leg(wlc, Lc, other_ref.get(cfg))
                 except Exception as e:                                   # (a side leg reports its failure; with several ranks the others may be waiting in a
                     entry = {"error": repr(e)}                           #  collective: this rank waits for the watchdog, which still prints the headline)
                     if world > 1:
                         other_configs["config%d" % cfg] = entry
                         side_leg_failed(e)
                 other_configs["config%d" % cfg] = entry
+            # the headline's read budget on inputs that are not the generator's best case
+            robustness = {"data_generation_s": t_gen_robust,
+                          "full_plane_floor": None if "full_plane_pass_s" not in checks else {
+                              "reads_per_s": n_tasks / checks["full_plane_pass_s"], "seconds": checks["full_plane_pass_s"],
+                              "note": "the headline batch through c2_align_classify_kernel alone (--kernel full: every cell of every matrix, no band, no certificate): "
+                                      "what ANY input of this size costs at most per launch chain"}}
+            for name, wlc in robust_wl.items():
+                try:
+                    entry = run_leg(wlc, wlc["max_len"], robust_ref.get(name))
+                except Exception as e:
+                    entry = {"error": repr(e)}
+                    if world > 1:
+                        robustness[name] = entry
+                        side_leg_failed(e)
+                robustness[name] = entry
+            rates = {k_: v_["reads_per_s"] for k_, v_ in robustness.items() if k_ != "full_plane_floor" and isinstance(v_, dict) and "reads_per_s" in v_}
+            if rates:
+                worst = min(rates, key=rates.get)
+                robustness["worst_case"] = {"leg": worst, "reads_per_s": rates[worst]}
+            del robust_wl
             del other_wl
             if world > 1:
                 # the sharded FASTQ leg: rank 0 wrote the file (same node: /dev/shm), every rank ingests its byte range of it

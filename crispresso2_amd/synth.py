@@ -183,3 +183,127 @@ def write_bgzf(src_path, dst_path, workers=1, level=1, slice_bytes=65280 * 256):
                 total += len(part)
         fh.write(_BGZF_EOF)
     return total + len(_BGZF_EOF)
+
+
+# ---- reads shaped like the reference's own test data (bench.py's robustness legs) ------------------------------------------------
+_FANC = {}
+
+
+def fanc_profile():
+    """crispresso2_amd/fanc_profile.json (tools/fanc_profile.py): the 213 distinct reads of the reference's tests/FANC.Cas9.fastq reduced to
+    signatures -- leading overhang, read length, deletions / insertions by reference position, substitution count, or 'junk' -- with their
+    multiplicities, the 223-bp FANC amplicon, its cut point and the genomic flank the reads run into behind the amplicon."""
+    if not _FANC:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fanc_profile.json")) as fh:
+            _FANC.update(json.load(fh))
+    return _FANC
+
+
+def fanc_setup():
+    """-> (amplicon, gap_incentive int64[L+1], include_idxs) of the FANC run as CRISPRessoCORE.py:3205-3207 builds them (-w 1 -wc -3)"""
+    p = fanc_profile()
+    amp, cut = p["amplicon"], int(p["cut_point"])
+    g = np.zeros(len(amp) + 1, dtype=np.int64)
+    g[cut + 1] = 1
+    return amp, g, [cut, cut + 1]
+
+
+def _fanc_bases():
+    """per template: the read it stands for, built from the amplicon (uint8), and where its amplicon part lies"""
+    p = fanc_profile()
+    amp = np.frombuffer(p["amplicon"].encode(), dtype=np.uint8)
+    flank = np.frombuffer(p["trail_flank"].encode(), dtype=np.uint8)
+    out = []
+    for t in p["templates"]:
+        if t["junk"]:
+            out.append((None, 0, t["len"]))
+            continue
+        keep = np.ones(len(amp), dtype=bool)
+        for pos, ln in t["dels"]:
+            keep[pos:pos + ln] = False
+        parts, last = [], 0
+        for pos, ln in sorted(t["ins"]):
+            parts.append(amp[last:pos][keep[last:pos]])
+            parts.append(np.full(ln, ord('A'), dtype=np.uint8))        # (re-drawn per read)
+            last = pos
+        parts.append(amp[last:][keep[last:]])
+        body = np.concatenate(parts)
+        seq = np.concatenate([np.full(t["lead"], ord('A'), dtype=np.uint8), body, flank])
+        if len(seq) < t["len"]:
+            seq = np.concatenate([seq, np.full(t["len"] - len(seq), ord('A'), dtype=np.uint8)])
+        out.append((seq[:t["len"]].copy(), t["lead"], min(t["len"], t["lead"] + len(body))))
+    return out
+
+
+FANC_W = 256                                                          # row width of the padded read matrix (longest FANC read: 250)
+
+
+def _fanc_block(n, block_index):
+    """-> (uint8 [n, FANC_W] reads padded with 0, int32 [n] lengths)"""
+    p = fanc_profile()
+    T = p["templates"]
+    bases = _fanc_bases()
+    rng = np.random.default_rng([20240603, int(block_index)])
+    w = np.array([t["w"] for t in T], dtype=np.float64)
+    which = rng.choice(len(T), n, p=w / w.sum())
+    out = np.zeros((n, FANC_W), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    for ti in np.unique(which):
+        rows = np.nonzero(which == ti)[0]
+        t = T[int(ti)]
+        seq, lead, body_end = bases[int(ti)]
+        ln = t["len"]
+        lens[rows] = ln
+        if seq is None:                                                # junk: an unrelated read of that length
+            out[rows, :ln] = _bases(rng.integers(0, 4, (len(rows), ln), dtype=np.uint8))
+            continue
+        out[rows, :ln] = seq
+        if lead:                                                       # the overhang in front varies from read to read in the data
+            out[rows, :lead] = _bases(rng.integers(0, 4, (len(rows), lead), dtype=np.uint8))
+        col = lead
+        for pos, iln in sorted(t["ins"]):                              # inserted bases: drawn per read
+            c0 = lead + pos - sum(d[1] for d in t["dels"] if d[0] < pos) + sum(i[1] for i in t["ins"] if i[0] < pos)
+            if c0 + iln <= ln:
+                out[rows, c0:c0 + iln] = _bases(rng.integers(0, 4, (len(rows), iln), dtype=np.uint8))
+        if t["subs"] and body_end > lead:
+            pos = rng.integers(lead, body_end, (len(rows), t["subs"]))
+            cur = out[rows[:, None], pos]
+            new = _bases(rng.integers(0, 4, pos.shape, dtype=np.uint8))
+            new = np.where(new == cur, _bases(((rng.integers(0, 4, pos.shape, dtype=np.uint8)) + 1) % 4), new)
+            out[rows[:, None], pos] = new
+    return out, lens
+
+
+def _fanc_block_job(job):
+    return _fanc_block(*job)
+
+
+def make_fanc_reads(n, first_block=0, workers=1):
+    """n reads drawn from the FANC profile -> (uint8 [n, FANC_W] padded with 0, int32 [n] lengths).  workers > 1: a fork()ed pool (before HIP)."""
+    out = np.empty((n, FANC_W), dtype=np.uint8)
+    lens = np.empty(n, dtype=np.int32)
+    jobs = [(min(BLOCK, n - a), first_block + b) for b, a in enumerate(range(0, n, BLOCK))]
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            it = pool.imap(_fanc_block_job, jobs)
+            for b, (blk, ln) in enumerate(it):
+                out[b * BLOCK:b * BLOCK + len(blk)] = blk
+                lens[b * BLOCK:b * BLOCK + len(blk)] = ln
+    else:
+        for b, job in enumerate(jobs):
+            blk, ln = _fanc_block(*job)
+            out[b * BLOCK:b * BLOCK + len(blk)] = blk
+            lens[b * BLOCK:b * BLOCK + len(blk)] = ln
+    return out, lens
+
+
+def pack_ragged(padded, lens):
+    """padded uint8 [n, W] + lengths -> (uint8 arena of the reads back to back, uint64 offsets [n + 1])"""
+    n, W = padded.shape
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:], dtype=np.uint64)
+    mask = np.arange(W, dtype=np.int32)[None, :] < lens[:, None]
+    return np.ascontiguousarray(padded[mask]), off

@@ -52,7 +52,7 @@ def _init(refs, matrix_path, go, ge):
 
 
 def _work(chunk):
-    """chunk: (bytes of concatenated fixed-length reads, read length, ref ids bytes (uint16) or None, all_refs)
+    """chunk: (bytes of concatenated fixed-width rows -- a read, padded with NUL bytes if it is shorter --, row width, ref ids bytes (uint16) or None, all_refs)
     -> (reads done, modified reads, digests uint64 [tasks], counts int32 [reads, 3], best ref per read uint16)"""
     blob, L, rid_bytes, all_refs = chunk
     n = len(blob) // L
@@ -64,7 +64,7 @@ def _work(chunk):
     best_ref = np.zeros(n, dtype=np.uint16)
     mod = 0
     for i in range(n):
-        rd = blob[i * L:(i + 1) * L].decode()
+        rd = blob[i * L:(i + 1) * L].rstrip(b"\0").decode()          # (ragged workloads: rows padded with NUL bytes)
         if all_refs:
             # get_new_variant_object's loop over the candidate amplicons (CRISPRessoCORE.py:653-707), forward strand
             best, bs = None, -1.0

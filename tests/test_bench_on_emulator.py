@@ -134,3 +134,13 @@ def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fa
     wt = e2e["with_all_tables"]                                      # FASTQ -> every result table on disk, the allele table among them
     assert wt["files_written"] >= 18 and wt["allele_table_rows"] > 0 and wt["allele_table_bytes"] > 500 and wt["alleles_around_cut_bytes"] > 100
     assert set(wt["write_tables_stage_seconds"]) >= {"allele_table_build", "allele_table_write", "around_cut_tables", "other_tables"}
+    # the same read budget on inputs that are not the generator's best case -- FANC-shaped reads (ragged, overhangs on both sides),
+    # reads cut to U[200, L], one read in ten unrelated -- each with its tier shares, chain = full plane on every task and a reference-compiled slice
+    rb = out["robustness"]
+    for leg in ("fanc_shaped", "lengths_200_to_L", "unrelated_10_percent"):
+        e = rb[leg]
+        assert e["reads_per_s"] > 0 and e["all_status_ok"] and e["chain_equals_full_plane"] and e["chain_equals_full_plane_n"] == 90, (leg, e)
+        assert e["reference_identical"] and e["reference_compared_n"] == 90, (leg, e)
+        assert e["reads_aligned_all_gpus"] > 60
+    assert rb["full_plane_floor"]["reads_per_s"] > 0 and rb["worst_case"]["leg"] in rb
+    assert cfgd["robust_fanc_shaped_reads_per_s"] == rb["fanc_shaped"]["reads_per_s"] and cfgd["robust_worst_case"].startswith(rb["worst_case"]["leg"])
