@@ -1107,7 +1107,8 @@ def main():
                     # which launch sees a task FIRST (c2_align_partition_kernel's classes) and what each tier hands on: the tier shares of this input
                     cls_ = part_c["classes"]
                     entry["first_launch_share"] = {"score_only": cls_[0] / float(jc.n_tasks), "tier1_32_diagonals": (cls_[1] + cls_[2]) / float(jc.n_tasks),
-                                                   "tier2_62_diagonals": cls_[3] / float(jc.n_tasks), "tier3_128_diagonals": cls_[4] / float(jc.n_tasks)}
+                                                   "tier2_62_diagonals": cls_[3] / float(jc.n_tasks), "tier3_128_diagonals": cls_[4] / float(jc.n_tasks),
+                                                   "full_matrix": (cls_[5] if len(cls_) > 5 else 0) / float(jc.n_tasks)}
                     entry["score_only_finished_share"] = part_c["finished"][0] / float(jc.n_tasks)
                 entry["full_plane_launch_share"] = (tiers_c[-1] / float(jc.n_tasks)) if tiers_c else None
                 if ref_leg is not None:

@@ -273,7 +273,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
         // tasks a packed kernel could not pair (run by the 32-bit kernel of the same band), [16 + 2l ..] work counter of launch l --
         // then eight task lists: one per band tier (c2_align_partition_kernel writes into the lists of LATER tiers, so they cannot share
         // buffers), the unpaired tasks', the score-only launch's, the first tier's when the partition ran, the 14-diagonal launch's
-        // (header words 48..52: tasks per class of the partition, 56 / 57: length of the first tier's list after the score-only launch and after
+        // (header words 48..53: tasks per class of the partition, 56 / 57: length of the first tier's list after the score-only launch and after
         //  the 14-diagonal launch, 60 / 62 / 61: lengths of the score-only launch's list, the 14-diagonal launch's, the first tier's)
         const size_t list_words = (size_t)A.n_tasks;
         if ((rc = ensure(ctx, ctx->d_fb, 256 + 8 * list_words * sizeof(uint32_t)))) return rc;
@@ -319,8 +319,11 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
             // What a launch cannot finish joins the list of the next wider one, as ever.  (Not for an all-references batch of several references:
             // its pairs are formed by the order of the tasks.  C2_NO_SCORE_TIER=1 switches the whole stage off, C2_NO_ROUTE=1 the routing to
             // later tiers.)
-            bool score_stage = g.pk && !(A.all_refs && A.n_refs > 1) && !getenv("C2_NO_SCORE_TIER") && ctx->kernel_mode == 0 &&
-                               tier_can_serve(ctx, 32, min_lj, A.max_lj);
+            // (round 5: also for an all-references batch of several references -- the partition walks its chunks reference-major, so the lists'
+            //  neighbours share a reference and pair; C2_NO_ALLREFS_PARTITION=1 gives such a batch round 4's chain: the first packed launch in pair order)
+            const bool many_refs = A.all_refs && A.n_refs > 1;
+            bool score_stage = g.pk && !(many_refs && (A.n_refs > 64 || getenv("C2_NO_ALLREFS_PARTITION"))) && !getenv("C2_NO_SCORE_TIER") &&
+                               ctx->kernel_mode == 0 && tier_can_serve(ctx, 32, min_lj, A.max_lj);
             bool p16_stage = false;
             if (score_stage) {
                 const bool a32s = ctx->pk_beta > 0;
@@ -335,14 +338,21 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 PA.list[2] = nlist; PA.count[2] = hdr + 61;
                 PA.list[3] = lists[0]; PA.count[3] = hdr + 0;            // (what the first tier leaves: the second tier's list -- or the third's, if there is no second)
                 PA.list[4] = tier1_runs ? lists[1] : lists[0]; PA.count[4] = tier1_runs ? hdr + 1 : hdr + 0;
+                // class 5 (a read that matches its reference nowhere): the list the LAST launch reads -- behind the first tier (this stage runs only if
+                // that tier does), the second if it runs, and the 128-diagonal tier
+                const int last_list = 1 + (tier1_runs ? 1 : 0);
+                PA.list[5] = lists[last_list]; PA.count[5] = hdr + last_list;
                 PA.class_count = hdr + 48;
                 PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier1_runs) ? 62 : 0; PA.bandw[3] = route ? 128 : 0;
                 PA.max_mismatch = 6;                                     // (of the last 32 columns)
                 PA.probe_max_mismatch = 4; PA.margin = 3; PA.max_shift = (p16_stage || route) ? 64 : 0;
+                PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
+                PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
                 if (const char* e = getenv("C2_SCORE_TIER_MAX_MISMATCH")) PA.max_mismatch = atoi(e);
                 if (const char* e = getenv("C2_ROUTE_PROBE_MISMATCH")) PA.probe_max_mismatch = atoi(e);
                 if (const char* e = getenv("C2_ROUTE_MARGIN")) PA.margin = atoi(e);
-                const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + C2_PART_CHUNK - 1) / C2_PART_CHUNK, cus * 16));
+                const uint64_t chunk_tasks = c2_part_chunk_tasks(A.all_refs, A.n_refs);
+                const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + chunk_tasks - 1) / chunk_tasks, cus * 16));
                 hipLaunchKernelGGL(c2_align_partition_kernel, dim3(pgrid), dim3(256), C2_PART_LDS, s, PA);
                 HIPCHK(ctx, hipGetLastError());
                 // (its own LDS plan -- no staging area for pointer words -- and its own residency; SIXTEEN alignments per wavefront: lane groups of
@@ -770,17 +780,17 @@ int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* fini
 
 // The partition of the most recent batch (c2_align_partition_kernel): did it run; tasks per class (0: score-only launch, 1: 14-diagonal launch,
 // 2: first band tier, 3: second, 4: third); how many of their tasks the score-only launch and the 14-diagonal launch finished.
-int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks5, int64_t* finished2) {
-    if (!ctx || !ran || !class_tasks5 || !finished2) return C2_E_INVALID;
+int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks6, int64_t* finished2) {
+    if (!ctx || !ran || !class_tasks6 || !finished2) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     *ran = ctx->last_score_stage ? (ctx->last_p16_stage ? 3 : 1) : 0;
-    for (int k = 0; k < 5; ++k) class_tasks5[k] = 0;
+    for (int k = 0; k < 6; ++k) class_tasks6[k] = 0;
     finished2[0] = finished2[1] = 0;
     if (ctx->last_score_stage && ctx->d_fb.p) {
         HIPCHK(ctx, hipDeviceSynchronize());
         uint32_t c[64];
         HIPCHK(ctx, hipMemcpy(c, (const uint32_t*)ctx->d_fb.p, 256, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 5; ++k) class_tasks5[k] = (int64_t)c[48 + k];
+        for (int k = 0; k < 6; ++k) class_tasks6[k] = (int64_t)c[48 + k];
         finished2[0] = (int64_t)c[60] - ((int64_t)c[56] - (int64_t)c[50]);
         finished2[1] = ctx->last_p16_stage ? (int64_t)c[62] - ((int64_t)c[57] - (int64_t)c[56]) : 0;
     }

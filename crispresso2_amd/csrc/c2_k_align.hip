@@ -2068,17 +2068,28 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
 //   (bandw[k] = 0: the chain has no such launch; the next wider one that exists takes the task.)
 // A prediction only: every launch verifies what it finishes (certificate) and hands on what it cannot, so a wrong class costs that alignment a
 // second fill and nothing else -- but a read with a 20-base deletion no longer pays for a fill in a band that cannot hold it.
-// Lists in task order inside a chunk of C2_PART_CHUNK tasks, the chunks in the order of their atomics (one per chunk and class).
+//   class 5  (round 5, `direct_full`) the read matches the reference NOWHERE: neither the middle window nor the windows a quarter and three quarters
+//            into the read find a place with at most `probe_max_mismatch` differing bases.  No band will certify such a read (an unrelated
+//            sequence, a chimera): it goes straight to the list of the LAST launch, the full matrix, instead of being filled and handed on by
+//            every band tier on its way there (5 + 9 + 19 ns before the 71 ns it cannot avoid).
+// When the middle window finds nothing (a breakpoint inside it), the two other windows place the path: the band then has to hold every diagonal found.
+// Lists in slot order inside a chunk of C2_PART_CHUNK tasks, the chunks in the order of their atomics (one per chunk and class).  Slot order is task
+// order -- unless the chunk's reads differ in LENGTH (round 5): then the chunk's slots are first ordered by read length (a counting sort in LDS),
+// because the packed kernels put two alignments into one lane group only if they share reference AND read length, and neighbours of a ragged input
+// in task order almost never do (reads of lengths U[200, 250]: everything went to the 32-bit kernels, at half the rate).
 struct c2_partition_args {
     c2_align_args A;
-    uint32_t* list[5]; uint32_t* count[5];      // per class: the launch's task list and its length (classes may share a list)
-    uint32_t* class_count;                      // [5] tasks per class (statistics)
+    uint32_t* list[6]; uint32_t* count[6];      // per class: the launch's task list and its length (classes may share a list)
+    uint32_t* class_count;                      // [6] tasks per class (statistics)
     int32_t bandw[4];                           // diagonals of the launches behind classes 1 .. 4, 0: none
     int32_t max_mismatch, probe_max_mismatch, margin, max_shift;
+    int32_t direct_full, sort_by_length;        // class 5 exists; order a ragged chunk's slots by read length
 };
 
 #define C2_PART_CHUNK 4096                         // tasks per workgroup and set of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
-#define C2_PART_LDS (C2_PART_CHUNK + 128 + 2 * C2_PART_CHUNK)
+#define C2_PART_LEN_BINS 512                       // read lengths 0 .. 510 have a bin of their own, longer reads share the last
+// flags | per-wavefront scan words | the slots to probe, later the slots in length order (uint16 each) | the slots' read lengths (uint16) | length histogram
+#define C2_PART_LDS (C2_PART_CHUNK + 128 + 2 * C2_PART_CHUNK + 2 * C2_PART_CHUNK + 4 * C2_PART_LEN_BINS)
 
 // 32 bases from p on as 2-bit codes ((c >> 1) & 3: A 0, C 1, T 2, G 3; anything else aliases one of them -- this is a predictor), base k in bits 2k+1 .. 2k
 __device__ __forceinline__ uint64_t c2_code32(const uint8_t* p) {
@@ -2112,19 +2123,41 @@ __device__ __forceinline__ c2_part_task c2_part_load(const c2_align_args& A, con
     t.Li = rf->len; t.pk_ok = rf->pk_ok; t.rd = A.reads + off; t.f = rf->seq;
     return t;
 }
+// how a chunk's slots map to tasks (see the kernel): reference-major for an all-references batch of several references
+struct c2_part_walk { uint32_t k, rpc, chunk_tasks; };
+__host__ __device__ __forceinline__ uint32_t c2_part_chunk_tasks(const int all_refs, const int n_refs) {
+    return (all_refs && n_refs > 1) ? (uint32_t)(C2_PART_CHUNK / n_refs) * (uint32_t)n_refs : (uint32_t)C2_PART_CHUNK;
+}
+__device__ __forceinline__ c2_part_walk c2_part_walk_of(const c2_align_args& A) {
+    c2_part_walk w;
+    w.k = (A.all_refs && A.n_refs > 1) ? (uint32_t)A.n_refs : 1u;
+    w.rpc = (uint32_t)C2_PART_CHUNK / w.k;
+    w.chunk_tasks = w.rpc * w.k;
+    return w;
+}
+// -> the task in slot `slot` of the chunk that starts at task `chunk`, or ~0 (no task there)
+__device__ __forceinline__ uint64_t c2_part_task_of(const c2_part_walk& w, const c2_align_args& A, const uint64_t chunk, const int slot) {
+    if (w.k == 1u) return chunk + (uint64_t)slot;
+    const uint32_t ref = (uint32_t)slot / w.rpc, rd = (uint32_t)slot - ref * w.rpc;
+    if (ref >= w.k) return ~0ull;
+    const uint64_t task = chunk + (uint64_t)rd * w.k + ref;
+    return task < A.n_tasks ? task : ~0ull;
+}
 __device__ __forceinline__ bool c2_part_probes(const c2_partition_args& P, const c2_part_task& t) {
     return P.max_shift > 0 && t.Lj >= 96 && t.Li >= 32;
 }
 
-// the class of a task by the diagonal the middle of its read lies on (see above); `widest`: the class that takes what no band holds
-__device__ __forceinline__ int c2_part_probe(const c2_partition_args& P, const c2_part_task& t, const int widest) {
-    const int p = (t.Lj >> 1) + 16, D = t.Li - t.Lj;
+// the diagonal the 32 bases of the read from column p on lie on: the window of the reference within max_shift of the same place that differs
+// from them in the fewest bases (ties: the one whose band is narrowest) -> differing bases of that window (64: no window to look at), its shift in s
+__device__ __forceinline__ int c2_part_window(const c2_partition_args& P, const c2_part_task& t, const int p, int& best_s) {
+    const int D = t.Li - t.Lj;
     const int s_lo = -P.max_shift > -p ? -P.max_shift : -p;
     const int s_hi = P.max_shift < t.Li - 32 - p ? P.max_shift : t.Li - 32 - p;
-    if (s_lo > s_hi) return 2;
+    best_s = 0;
+    if (s_lo > s_hi || p < 0 || p + 32 > t.Lj) return 64;
     const uint64_t rcode = c2_code32(t.rd + p);
     uint64_t fcode = c2_code32(t.f + p + s_lo);
-    int best_mm = 64, best_span = 0x10000, best_s = 0;
+    int best_mm = 64, best_span = 0x10000;
     uint32_t buf = 0;                                               // the next four bases of the reference (one load per four windows)
     for (int s = s_lo;; ++s) {
         const uint64_t x = fcode ^ rcode;
@@ -2140,9 +2173,26 @@ __device__ __forceinline__ int c2_part_probe(const c2_partition_args& P, const c
         }
         fcode = (fcode >> 2) | ((uint64_t)((buf >> (8 * k + 1)) & 3u) << 62);
     }
-    if (best_mm > P.probe_max_mismatch) return 2;
-    const int s = best_s;
-    const int lo = s < 0 ? (D < s ? D : s) : (D < 0 ? D : 0), hi = s > 0 ? (D > s ? D : s) : (D > 0 ? D : 0);
+    return best_mm;
+}
+
+// the class of a task by the diagonals its read lies on (see above); `widest`: the class that takes what no band holds
+__device__ __forceinline__ int c2_part_probe(const c2_partition_args& P, const c2_part_task& t, const int widest) {
+    const int D = t.Li - t.Lj;
+    int s = 0;
+    int lo = D < 0 ? D : 0, hi = D > 0 ? D : 0;
+    const int mm = c2_part_window(P, t, (t.Lj >> 1) + 16, s);
+    if (mm <= P.probe_max_mismatch) { lo = s < lo ? s : lo; hi = s > hi ? s : hi; }
+    else {
+        // nothing in the middle (a breakpoint inside the window, a noisy stretch -- or a read that is not this amplicon's at all): a quarter and
+        // three quarters into the read
+        int s1 = 0, s2 = 0;
+        const int m1 = c2_part_window(P, t, t.Lj >> 2, s1), m2 = c2_part_window(P, t, ((3 * t.Lj) >> 2) - 16, s2);
+        const bool ok1 = m1 <= P.probe_max_mismatch, ok2 = m2 <= P.probe_max_mismatch;
+        if (!ok1 && !ok2) return (P.direct_full && mm < 64 && m1 < 64 && m2 < 64) ? 5 : 2;      // (a window that could not be looked at says nothing)
+        if (ok1) { lo = s1 < lo ? s1 : lo; hi = s1 > hi ? s1 : hi; }
+        if (ok2) { lo = s2 < lo ? s2 : lo; hi = s2 > hi ? s2 : hi; }
+    }
     int cls = widest;
     for (int k = 3; k >= 0; --k) if (c2_band_holds(P.bandw[k], D, lo, hi, P.margin)) cls = k + 1;
     return cls;
@@ -2152,21 +2202,31 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
 {
     const c2_align_args& A = P.A;
     uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] the task's class, 7: no such task, 8: still to be probed
-    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [3 * 4] per wavefront: packed class counts; [16 .. 20]: bases of the five lists; [24]: tasks to probe
-    uint16_t* const todo = (uint16_t*)(c2_smem + C2_PART_CHUNK + 128);   // [C2_PART_CHUNK] the chunk's tasks that need the probe, densely
+    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [3 * 4] per wavefront: packed class counts; [16 .. 21]: bases of the six lists; [24]: the chunk's first read length; [25]: ragged
+    uint16_t* const todo = (uint16_t*)(c2_smem + C2_PART_CHUNK + 128);   // [C2_PART_CHUNK] the chunk's tasks that need the probe, densely; afterwards: the slots in length order
+    uint16_t* const len16 = todo + C2_PART_CHUNK;                   // [C2_PART_CHUNK] read length of the slot's task (capped at the last bin)
+    unsigned* const hist = (unsigned*)(len16 + C2_PART_CHUNK);      // [C2_PART_LEN_BINS]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int widest = 2;                                                 // the class that takes what no band holds
     if (P.bandw[2] > 0) widest = 3;
     if (P.bandw[3] > 0) widest = 4;
-    for (uint64_t chunk = (uint64_t)blockIdx.x * C2_PART_CHUNK; chunk < A.n_tasks; chunk += (uint64_t)gridDim.x * C2_PART_CHUNK) {
+    // An all-references batch (task = read * n_refs + reference) is walked REFERENCE-MAJOR inside a chunk: slot s of a chunk of `rpc` reads is read
+    // s % rpc against reference s / rpc.  The lists keep slot order, so their neighbours are two reads against the SAME reference -- what the packed
+    // kernels need to put two alignments into one lane group (a pair shares reference and read length); task order would put (read r, reference 0),
+    // (r, 1), (r, 2) next to each other and nothing would pair.  Every other batch: slot = task.
+    const c2_part_walk WK = c2_part_walk_of(A);
+    const bool may_sort = P.sort_by_length && WK.k == 1u;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * WK.chunk_tasks; chunk < A.n_tasks; chunk += (uint64_t)gridDim.x * WK.chunk_tasks) {
         // ---- one lane per task: the look at the last 32 columns
+        int ragged = 0;
         for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
             const int slot = r * 256 + tid;
-            const uint64_t task = chunk + (uint64_t)slot;
-            int cls = 7;
+            const uint64_t task = c2_part_task_of(WK, A, chunk, slot);
+            int cls = 7, lj = -1;
             if (task < A.n_tasks) {
                 cls = 2;
                 const c2_part_task t = c2_part_load(A, task);
+                lj = t.Lj;
                 if (!t.rc && t.pk_ok && t.Lj >= 32) {
                     int mm = 0x10000;
                     if (t.Lj == t.Li && t.Lj <= 256) {
@@ -2184,8 +2244,21 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                 }
             }
             flag[slot] = (uint8_t)cls;
+            if (may_sort) {
+                len16[slot] = (uint16_t)(lj < 0 ? 0 : (lj < C2_PART_LEN_BINS - 1 ? lj : C2_PART_LEN_BINS - 1));
+                if (slot == 0) { part[24] = (unsigned)lj; part[25] = 0u; }
+            }
         }
         __syncthreads();
+        if (may_sort) {                                             // do the chunk's reads differ in length?
+            const int l0 = (int)part[24];
+            for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
+                const int slot = r * 256 + tid;
+                if (flag[slot] != 7u && (int)len16[slot] != (l0 < C2_PART_LEN_BINS - 1 ? l0 : C2_PART_LEN_BINS - 1)) part[25] = 1u;
+            }
+            __syncthreads();
+            ragged = (int)part[25];
+        }
         // ---- the tasks that need the probe, densely (about a third of an amplicon run's reads, scattered: probing them where they stand would
         //      keep every wavefront in the loop with a third of its lanes), then one lane per such task
         {
@@ -2206,20 +2279,48 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             __syncthreads();
             for (unsigned k = (unsigned)tid; k < total; k += 256u) {
                 const int slot = (int)todo[k];
-                const c2_part_task t = c2_part_load(A, chunk + (uint64_t)slot);
+                const c2_part_task t = c2_part_load(A, c2_part_task_of(WK, A, chunk, slot));
                 flag[slot] = (uint8_t)c2_part_probe(P, t, widest);
             }
             __syncthreads();
         }
-        // ---- thread t owns tasks 16 t .. 16 t + 15 of the chunk: positions by a scan over the workgroup, one atomic per chunk and class
-        unsigned n[5] = {0u, 0u, 0u, 0u, 0u};
+        // ---- a ragged chunk: its slots in the order of their reads' lengths (counting sort; the order among equal lengths is that of the atomics --
+        //      no result depends on the order of a list).  `todo` holds the permutation from here on; a uniform chunk keeps slot order.
+        if (ragged) {
+            for (int b = tid; b < C2_PART_LEN_BINS; b += 256) hist[b] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) atomicAdd(&hist[len16[16 * tid + k]], 1u);
+            __syncthreads();
+            {   // exclusive scan of the bins: thread t owns bins 2t, 2t + 1
+                const unsigned h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+                unsigned incl = h0 + h1;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+                if (lane == 63) part[wv] = incl;
+                __syncthreads();
+                unsigned before = 0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) if (v < wv) before += part[v];
+                const unsigned e = before + incl - (h0 + h1);
+                hist[2 * tid] = e; hist[2 * tid + 1] = e + h0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int slot = 16 * tid + k; todo[atomicAdd(&hist[len16[slot]], 1u)] = (uint16_t)slot; }
+            __syncthreads();
+        }
+        // ---- thread t owns positions 16 t .. 16 t + 15 of the chunk's order: list positions by a scan over the workgroup, one atomic per chunk and class
+        unsigned n[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        unsigned mine[16];                                          // the slots in this thread's positions
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const unsigned f = flag[16 * tid + k];
+            mine[k] = ragged ? (unsigned)todo[16 * tid + k] : (unsigned)(16 * tid + k);
+            const unsigned f = flag[mine[k]];
 #pragma unroll
-            for (int c = 0; c < 5; ++c) n[c] += f == (unsigned)c;
+            for (int c = 0; c < 6; ++c) n[c] += f == (unsigned)c;
         }
-        unsigned pk[3] = {n[0] | (n[1] << 16), n[2] | (n[3] << 16), n[4]};           // (every count <= 4096: 16 bits each)
+        unsigned pk[3] = {n[0] | (n[1] << 16), n[2] | (n[3] << 16), n[4] | (n[5] << 16)};           // (every count <= 4096: 16 bits each, sums <= 4096)
         unsigned incl[3] = {pk[0], pk[1], pk[2]};
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -2233,25 +2334,24 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
         for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int w = 0; w < 3; ++w) { const unsigned x = part[3 * v + w]; if (v < wv) before[w] += x; total[w] += x; }
-        if (tid < 5) {
-            const unsigned t = tid == 0 ? (total[0] & 0xffffu) : tid == 1 ? (total[0] >> 16) : tid == 2 ? (total[1] & 0xffffu) : tid == 3 ? (total[1] >> 16) : total[2];
+        if (tid < 6) {
+            const unsigned t = (tid & 1) ? (total[tid >> 1] >> 16) : (total[tid >> 1] & 0xffffu);
             part[16 + tid] = t ? atomicAdd(P.count[tid], t) : 0u;
             if (t && P.class_count) atomicAdd(P.class_count + tid, t);
         }
         __syncthreads();
-        unsigned pos[5];
-        {
-            const unsigned e0 = before[0] + incl[0] - pk[0], e1 = before[1] + incl[1] - pk[1], e2 = before[2] + incl[2] - pk[2];
-            pos[0] = part[16] + (e0 & 0xffffu); pos[1] = part[17] + (e0 >> 16);
-            pos[2] = part[18] + (e1 & 0xffffu); pos[3] = part[19] + (e1 >> 16);
-            pos[4] = part[20] + e2;
+        unsigned pos[6];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const unsigned e = before[w] + incl[w] - pk[w];
+            pos[2 * w] = part[16 + 2 * w] + (e & 0xffffu); pos[2 * w + 1] = part[17 + 2 * w] + (e >> 16);
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const unsigned f = flag[16 * tid + k];
-            const uint32_t task = (uint32_t)(chunk + (uint64_t)(16 * tid + k));
+            const unsigned f = flag[mine[k]];
+            const uint32_t task = (uint32_t)c2_part_task_of(WK, A, chunk, (int)mine[k]);     // (f < 6 only for a slot that holds a task)
 #pragma unroll
-            for (int c = 0; c < 5; ++c) if (f == (unsigned)c) P.list[c][pos[c]++] = task;
+            for (int c = 0; c < 6; ++c) if (f == (unsigned)c) P.list[c][pos[c]++] = task;
         }
         __syncthreads();                                            // (the flags are overwritten by the next chunk)
     }

@@ -296,7 +296,7 @@ int c2_tier_info(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over4);
 int c2_chain_info(c2_ctx* ctx, int32_t max_read_len, uint32_t* kernels, uint8_t* ref_packed_ok);
 /* (*kernels bit 9: the score-only stage is in front of the first band tier -- c2_align_partition_kernel + c2_align_diags_kernel<16>: the tasks whose read is as
  * long as its reference and agrees with it in its last 32 columns (an indel in front of them would shift them) go through the packed fill WITHOUT pointer bits, which finishes those whose alignment is the
- * main diagonal and hands the rest to the first tier; not for all-references batches of several references.)
+ * main diagonal and hands the rest to the first tier; round 5: all-references batches of up to 64 references too.)
  * c2_score_stage_info: did it run for the most recent batch, how many tasks it took, how many it finished. */
 int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* finished);
 /* The partition in front of the chain (c2_align_partition_kernel, same conditions as the score-only stage) gives every task a class: 0 the
@@ -306,9 +306,13 @@ int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* fini
  * band has, the task goes straight to the list of the second / third tier.  Every launch verifies what it finishes and hands on what it cannot:
  * the class only decides where a task is tried FIRST.  With this, left_over[t] of c2_tier_info is the length of the list the launch behind tier
  * t reads: what tier t left plus what the partition put there.
- * c2_partition_info: *ran bit 0 the partition ran for the most recent batch, bit 1 the 14-diagonal launch too; class_tasks5: tasks per class;
+ * Round 5: class 5 -- the read matches its reference nowhere (three 32-base windows of it find no place within 64 bases of their own with at most
+ * four differing bases): no band will certify it, it goes straight to the list of the last launch (the full matrix).  A batch whose reads differ
+ * in length has the slots of every 4,096-task chunk ordered by read length first, so that the lists' neighbours can share a lane group of the
+ * packed kernels (same reference AND read length); an all-references batch of several references is walked reference-major for the same reason.
+ * c2_partition_info: *ran bit 0 the partition ran for the most recent batch, bit 1 the 14-diagonal launch too; class_tasks6: tasks per class;
  * finished2: tasks the score-only launch and the 14-diagonal launch finished. */
-int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks5, int64_t* finished2);
+int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks6, int64_t* finished2);
 /* The same for up to 8 tiers, plus per tier the number of tasks its packed (int16) kernel could not pair and handed to the 32-bit
  * kernel of the same band: a tier with a packed kernel finished at least tasks_in - unpaired - left_over tasks in int16 arithmetic. */
 int c2_tier_info_ex(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over8, int32_t* unpaired8);

@@ -20,8 +20,8 @@ extern "C" {
 unsigned emu_last_unpaired() { return g_last_unpaired; }
 static const uint32_t* g_last_classes = nullptr;   // tasks per class of the last emu_align_batch's partition (all zero: it did not run)
 static unsigned g_last_p16_finished = 0;           // tasks its 14-diagonal launch finished
-void emu_last_partition(uint32_t* classes5, uint32_t* p16_finished) {
-    for (int k = 0; k < 5; ++k) classes5[k] = g_last_classes ? g_last_classes[k] : 0u;
+void emu_last_partition(uint32_t* classes6, uint32_t* p16_finished) {
+    for (int k = 0; k < 6; ++k) classes6[k] = g_last_classes ? g_last_classes[k] : 0u;
     *p16_finished = g_last_p16_finished;
 }
 int emu_last_pk_beta() { return g_last_pk_beta; }
@@ -153,10 +153,10 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         bool score_stage = false;
         std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1), nlist(A.n_tasks ? A.n_tasks : 1), plist(A.n_tasks ? A.n_tasks : 1);
         uint32_t e_count = 0, ne_count = 0, p_count = 0;
-        static uint32_t class_counts[5];
-        for (int k = 0; k < 5; ++k) class_counts[k] = 0;
+        static uint32_t class_counts[6];
+        for (int k = 0; k < 6; ++k) class_counts[k] = 0;
         g_last_classes = class_counts; g_last_p16_finished = 0;
-        if (any_pk && (band_lanes == -87 || band_lanes == -8 || band_lanes == -80) && !(A.all_refs && A.n_refs > 1) && !getenv("C2_EMU_NO_SCORE_TIER")) {
+        if (any_pk && (band_lanes == -87 || band_lanes == -8 || band_lanes == -80) && !(A.all_refs && A.n_refs > 1 && (A.n_refs > 64 || getenv("C2_NO_ALLREFS_PARTITION"))) && !getenv("C2_EMU_NO_SCORE_TIER")) {
             const int sna = (getenv("C2_SCORE_TIER_NA") && atoi(getenv("C2_SCORE_TIER_NA")) == 8) ? 8 : 16;
             const c2_diagx_plan PP = c2_make_diagx_plan(sna, A.max_li, A.max_lj, true, true);
             if (PP.total > sizeof(c2_smem)) return -5;
@@ -172,6 +172,11 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             PA.list[2] = nlist.data(); PA.count[2] = &ne_count;
             PA.list[3] = lists[0]; PA.count[3] = &fb_counts[0];
             PA.list[4] = tier1_runs ? lists[1] : lists[0]; PA.count[4] = tier1_runs ? &fb_counts[1] : &fb_counts[0];
+            // class 5: the list the last launch (the full plane) reads -- behind the first tier, the second and the third where the chain has them
+            const int last_list = (tier1_runs ? 1 : 0) + (tier2_runs ? 1 : 0);
+            PA.list[5] = lists[last_list]; PA.count[5] = &fb_counts[last_list];
+            PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
+            PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
             PA.class_count = class_counts;
             PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier1_runs) ? 62 : 0; PA.bandw[3] = (route && tier2_runs) ? 128 : 0;
             PA.max_mismatch = getenv("C2_SCORE_TIER_MAX_MISMATCH") ? atoi(getenv("C2_SCORE_TIER_MAX_MISMATCH")) : 6;

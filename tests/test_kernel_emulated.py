@@ -5,6 +5,8 @@ This checks the kernel's logic -- systolic schedule, tie rules, pointer packing,
 traceback, fused classification, multi-pass references -- in the GPU-less container.  It is a test
 harness, not a product path; the `-m gpu` tests are the parity tests proper.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -435,12 +437,22 @@ def test_packed_kernel_pairs_singles_and_mismatched_neighbours(mats):
             check_record(rec[k], oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
         assert 0 < st["fallback"] < st["tasks"], st
         if chain == -8:
-            assert st["unpaired"] > 40, st                                  # neighbours of another reference / length went to the 32-bit kernel of the band
+            # neighbours of another reference / length go to the 32-bit kernel of the band.  Round 5: the partition orders a ragged chunk's slots by
+            # read length first, so fewer are left over than in task order (C2_NO_LENGTH_ORDER=1) -- same alignments either way
+            os.environ["C2_NO_LENGTH_ORDER"] = "1"
+            try:
+                st_t = {}
+                res_t, rec_t = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=rids, band_lanes=chain, grid=3, stats=st_t)
+            finally:
+                del os.environ["C2_NO_LENGTH_ORDER"]
+            assert res_t == res and rec_t.tobytes() == rec.tobytes()
+            assert st_t["unpaired"] > 40 and st["unpaired"] < st_t["unpaired"], (st, st_t)
+            in_task_order = st_t["unpaired"]
     # the same reads in pairs of equal (reference, length): hardly anything is left unpaired
     order = sorted(range(len(reads)), key=lambda k: (rids[k], len(reads[k])))
     st2 = {}
     E.align_batch([reads[k] for k in order], refs, gis, incs, m, -20, -2, ref_ids=[rids[k] for k in order], band_lanes=-8, grid=3, stats=st2)
-    assert st2["unpaired"] < 40 and st2["unpaired"] < st["unpaired"] // 3, (st2, st)
+    assert st2["unpaired"] < 40 and st2["unpaired"] < in_task_order // 3, (st2, in_task_order)
 
 
 # ---- pointer plane in HBM: alignments whose full plane does not fit a CU's LDS --------------------------------------------------
@@ -502,7 +514,9 @@ def test_emulated_kernel_alignments_larger_than_the_lds_plane(mats, li, lj):
             assert (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], (chain, k)
             check_record(r, oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
         if chain and lj == li:
-            assert 0 < st["fallback"] < st["tasks"], st
+            # the long deletion and the unrelated read are beyond the first tier: handed on by it, or (round 5) sent past it by the partition --
+            # the unrelated read straight to the full-matrix launch (class 5)
+            assert 0 < st["fallback"] + sum(st["classes"][3:]) < st["tasks"] and st["classes"][5] == 1, st
 
 
 # ---- the two variants of the packed fill: sums as v_pk_add_i16, or as plain 32-bit adds under a per-anti-diagonal bias ----------------
@@ -704,3 +718,86 @@ def test_partition_settings_never_change_a_result(mats, go, ge, env, monkeypatch
         exp = oracle.global_align_raw(truth[k], refs[rids[k]], m, gis[rids[k]], go, ge)
         assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], (k, env)
         check_record(r, oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
+
+
+def test_all_references_batch_goes_through_the_partition_and_pairs_by_reference(mats):
+    """Round 5 (BASELINE config 4): an all-references batch of several references -- task = read * n_refs + reference --
+    gets the partition and the score-only stage too.  c2_align_partition_kernel walks a chunk reference-major, so the neighbours in every list
+    are two reads against the SAME reference and the packed kernels pair them (in task order nothing would pair).  Three candidate amplicons of
+    config 4's kind (wild type, a 3-base insertion + substitutions, a 12-base replacement), reads derived from each: every alignment and record
+    equals the oracle's; the main-diagonal candidates took the score-only launch; almost nothing was left unpaired; and the chain without the
+    partition for such batches (C2_NO_ALLREFS_PARTITION=1: round 4's pair-order walk) gives the same bytes."""
+    from crispresso2_amd import synth
+    m = mats["EDNAFULL"]
+    L = 160
+    amp, g, inc = synth.amplicon_setup(L)
+    refs = [amp, synth.make_variant(amp, "hdr"), synth.make_variant(amp, "pe")]
+    gis = []
+    for r in refs:
+        x = np.zeros(len(r) + 1, dtype=np.int64)
+        x[L // 2 + 1] = 1
+        gis.append(x)
+    incs = [inc] * 3
+    reads = []
+    for src in range(3):
+        blk = synth.make_reads(L, 70, amplicon_id=100 + src, amplicon=refs[src][:L])
+        reads += [b.tobytes().decode() for b in blk]
+    rng = np.random.default_rng(5)
+    reads = [reads[int(i)] for i in rng.permutation(len(reads))]
+    st = {}
+    res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, all_refs=True, band_lanes=-87, stats=st)
+    assert len(res) == 3 * len(reads)
+    for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+        rd, ri = reads[k // 3], k % 3
+        exp = oracle.global_align_raw(rd, refs[ri], m, gis[ri], -20, -2)
+        assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k
+        check_record(r, oracle.find_indels_substitutions(s1, s2, incs[ri]), s1, s2)
+    assert sum(st["classes"]) == 3 * len(reads), st["classes"]       # the partition ran over every task ...
+    assert st["classes"][0] >= 100, st["classes"]                     # ... reads against the amplicon they derive from (and the same-length one) are main-diagonal candidates
+    assert st["unpaired"] <= 24, st["unpaired"]                       # a pair breaks only where a list passes from one reference to the next
+    os.environ["C2_NO_ALLREFS_PARTITION"] = "1"
+    try:
+        st2 = {}
+        res2, rec2 = E.align_batch(reads, refs, gis, incs, m, -20, -2, all_refs=True, band_lanes=-87, stats=st2)
+    finally:
+        del os.environ["C2_NO_ALLREFS_PARTITION"]
+    assert sum(st2["classes"]) == 0 and res2 == res and rec2.tobytes() == rec.tobytes()
+
+
+def test_ragged_and_unrelated_reads_through_the_partition(mats):
+    """Round 5 (inputs that are not the generator's best case).  Reads cut to lengths U[120, 160], a tenth of them replaced by
+    random sequences, against a 160-bp amplicon through the default chain: the partition orders every chunk's slots by read length (else no two
+    neighbours could share a lane group of the packed kernels) and sends the reads that match the amplicon nowhere straight to the full-matrix
+    launch (class 5).  Every alignment and record equals the oracle's, and the two knobs (C2_NO_LENGTH_ORDER, C2_NO_DIRECT_FULL) change no byte --
+    only how many tasks the int16 kernels could pair and how many launches the unrelated reads passed through."""
+    from crispresso2_amd import synth
+    m = mats["EDNAFULL"]
+    L = 160
+    amp, g, inc = synth.amplicon_setup(L)
+    rng = np.random.default_rng(77)
+    base = synth.make_reads(L, 260)
+    reads = []
+    for k in range(len(base)):
+        s = base[k].tobytes().decode()[:int(rng.integers(120, L + 1))]
+        if k % 10 == 3:
+            s = "".join(rng.choice(list("ACGT"), len(s)))
+        reads.append(s)
+    st = {}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+        exp = oracle.global_align_raw(reads[k], amp, m, g, -20, -2)
+        assert exp[0] == 0 and r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k
+        check_record(r, oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+    assert sum(st["classes"]) == len(reads) and 20 <= st["classes"][5] <= 26, st["classes"]      # the 26 random reads (a few find a window by chance)
+    variants = {}
+    for knob in ("C2_NO_LENGTH_ORDER", "C2_NO_DIRECT_FULL"):
+        os.environ[knob] = "1"
+        try:
+            sv = {}
+            rv, recv = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=sv)
+        finally:
+            del os.environ[knob]
+        assert rv == res and recv.tobytes() == rec.tobytes(), knob
+        variants[knob] = sv
+    assert variants["C2_NO_LENGTH_ORDER"]["unpaired"] > 3 * max(st["unpaired"], 1), (st["unpaired"], variants["C2_NO_LENGTH_ORDER"]["unpaired"])
+    assert variants["C2_NO_DIRECT_FULL"]["classes"][5] == 0
