@@ -52,6 +52,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LINK_PEAK_GBS = 63.0                           # "Host link: PCIe Gen5 x16, 63 GB/s (spec)", MI355X_MICROARCH.md, one direction
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9
 # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
@@ -580,42 +581,87 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
             time.sleep(0.3)                                          # (the run's buffers are unmapped by helper threads: let them finish)
         dt = min(r[0] for r in runs[1:repeat + 1])
         tm = runs[-1][1]
+        # what crosses the host link in this leg: the device-ingest routes upload the TEXT (plain: as it lies in the file; bgzf: as the host inflated
+        # it); the host-parser routes upload the unique reads' arena + offsets + multiplicities.  Results coming back are kilobytes.
+        if kind.endswith("_host_parser"):
+            link_bytes = None
+        else:
+            link_bytes = files["bytes_plain"]
         out[kind] = {"seconds": dt, "reads_per_s": files["reads"] / dt, "seconds_all_runs": [r[0] for r in runs], "stage_seconds": tm,
+                     "link_bytes": link_bytes, "link_gbs": None if link_bytes is None else link_bytes / dt / 1e9,
+                     "frac_of_link_peak": None if link_bytes is None else link_bytes / dt / 1e9 / LINK_PEAK_GBS,
+                     "link_peak_gbs": LINK_PEAK_GBS,
+                     "link_note": "text bytes uploaded / the whole run's seconds / 63 GB/s (PCIe Gen5 x16 spec, MI355X_MICROARCH.md): the run is one upload with the "
+                                  "kernels underneath it, so this fraction is the leg's roofline",
                      "stage_seconds_note": "from one more run with a device synchronisation after every stage (the last of seconds_all_runs); the "
                                            "timed runs have none", "unique_reads": uniq, "ingest_route": route}
     os.environ.pop("C2_FQ_INGEST", None)
     # ---- a run that ends where the reference's ends: FASTQ -> every result table of tables.write_tables ON DISK (the allele frequency table --
-    # one line per aligned unique read, sorted -- and the alleles around the guide's cut among them: rows, sort, grouping and text on the device)
+    # one line per aligned unique read, sorted -- and the alleles around the guide's cut among them: rows, sort, grouping and text on the device).
+    # `with_all_tables`: the allele table as the reference leaves it, Alleles_frequency_table.zip (CRISPRessoCORE.py:4531-4533: deflated, the .txt
+    # removed) -- the chunks that come off the device are deflated on all host threads into ONE stream, only compressed bytes are written;
+    # `with_all_tables_txt`: the same run writing the 2 GB .txt instead (round 4's leg).
     from crispresso2_amd import tables
     ref_t = dict(ref)
     ref_t["sgRNA_orig_sequences"] = [amp[L // 2 - 16:L // 2 + 4]]
     out_dir = os.path.join(files["dir"], "tables")
-    runs = []
-    for rep in range(repeat + 1):
-        shutil.rmtree(out_dir, ignore_errors=True)
-        tt = {}
-        t0 = time.perf_counter()
-        res = pipeline.quantify_fastq(files["plain"], {"Reference": ref_t}, ["Reference"], matrix, args, ctx=ctx)
-        t1 = time.perf_counter()
-        written = tables.write_tables(res, {"Reference": ref_t}, ["Reference"], out_dir, timings=tt)
-        t2 = time.perf_counter()
-        runs.append((t2 - t0, t1 - t0, tt))
-        rows = res.allele_table().n_rows
-        table_bytes = {w: os.path.getsize(os.path.join(out_dir, w)) for w in written}
-        res.allele_table().close()
-        del res
-        time.sleep(0.3)
-    best = min(runs[1:], key=lambda r: r[0])
-    with open(os.path.join(out_dir, "Alleles_frequency_table.txt"), "rb") as fh:
-        head_lines = fh.read(1 << 16).split(b"\n")[:3]
-    out["with_all_tables"] = {"seconds": best[0], "reads_per_s": files["reads"] / best[0], "seconds_all_runs": [r[0] for r in runs],
-                              "quantify_fastq_seconds": best[1], "write_tables_seconds": best[0] - best[1], "write_tables_stage_seconds": best[2],
-                              "files_written": len(table_bytes), "bytes_written": int(sum(table_bytes.values())),
-                              "allele_table_rows": rows, "allele_table_bytes": table_bytes.get("Alleles_frequency_table.txt"),
-                              "alleles_around_cut_bytes": max([v for w, v in table_bytes.items() if "_around_" in w], default=None),
-                              "second_line_of_the_allele_table_starts": head_lines[1][:40].decode("ascii", "replace") if len(head_lines) > 1 else None,
-                              "note": "FASTQ (plain, device ingest) -> count tensors -> every .txt of tables.write_tables on the same file system; best of %d "
-                                      "runs after a warm-up; the reference zips the allele table afterwards (not done here)" % repeat}
+    txt_digest = None
+    for leg, as_zip in (("with_all_tables_txt", False), ("with_all_tables", True)):
+        runs = []
+        for rep in range(repeat + 1):
+            shutil.rmtree(out_dir, ignore_errors=True)
+            tt = {}
+            t0 = time.perf_counter()
+            res = pipeline.quantify_fastq(files["plain"], {"Reference": ref_t}, ["Reference"], matrix, args, ctx=ctx)
+            t1 = time.perf_counter()
+            written = tables.write_tables(res, {"Reference": ref_t}, ["Reference"], out_dir, timings=tt, allele_table_zip=as_zip)
+            t2 = time.perf_counter()
+            runs.append((t2 - t0, t1 - t0, tt))
+            rows = res.allele_table().n_rows
+            table_bytes = {w: os.path.getsize(os.path.join(out_dir, w)) for w in written}
+            res.allele_table().close()
+            del res
+            time.sleep(0.3)
+        best = min(runs[1:], key=lambda r: r[0])
+        entry = {"seconds": best[0], "reads_per_s": files["reads"] / best[0], "seconds_all_runs": [r[0] for r in runs],
+                 "quantify_fastq_seconds": best[1], "write_tables_seconds": best[0] - best[1], "write_tables_stage_seconds": best[2],
+                 "files_written": len(table_bytes), "bytes_written": int(sum(table_bytes.values())), "allele_table_rows": rows,
+                 "alleles_around_cut_bytes": max([v for w, v in table_bytes.items() if "_around_" in w], default=None)}
+        import hashlib
+        import zipfile
+        if not as_zip:
+            with open(os.path.join(out_dir, "Alleles_frequency_table.txt"), "rb") as fh:
+                head_lines = fh.read(1 << 16).split(b"\n")[:3]
+                fh.seek(0)
+                hh, nb_txt = hashlib.blake2b(digest_size=16), 0
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    hh.update(blk)
+                    nb_txt += len(blk)
+            txt_digest = (hh.hexdigest(), nb_txt)
+            aw = best[2].get("allele_table_write") or 0.0
+            entry.update({"allele_table_bytes": table_bytes.get("Alleles_frequency_table.txt"),
+                          "allele_table_write_gbs": (table_bytes.get("Alleles_frequency_table.txt", 0) / aw / 1e9) if aw > 0 else None,
+                          "second_line_of_the_allele_table_starts": head_lines[1][:40].decode("ascii", "replace") if len(head_lines) > 1 else None,
+                          "note": "FASTQ (plain, device ingest) -> count tensors -> every .txt of tables.write_tables on the same file system; best of %d runs after a "
+                                  "warm-up.  allele_table_write_gbs: bytes of the .txt / seconds of its stage (device text -> pinned chunks -> pwrite on all threads): "
+                                  "host memory bandwidth into the page cache, not the link (2 GB at 63 GB/s would be 0.03 s)" % repeat})
+        else:
+            zp = os.path.join(out_dir, "Alleles_frequency_table.zip")
+            with zipfile.ZipFile(zp) as z:                           # the reference's own reader gives the text back: compared with the .txt leg's bytes
+                info = z.getinfo("Alleles_frequency_table.txt")
+                hh, nb_z = hashlib.blake2b(digest_size=16), 0
+                with z.open(info) as fh:
+                    for blk in iter(lambda: fh.read(1 << 24), b""):
+                        hh.update(blk)
+                        nb_z += len(blk)
+            aw = best[2].get("allele_table_write") or 0.0
+            entry.update({"allele_table_zip_bytes": table_bytes.get("Alleles_frequency_table.zip"), "allele_table_text_bytes": info.file_size,
+                          "zip_member_equals_the_txt_legs_file": bool(txt_digest is not None and (hh.hexdigest(), nb_z) == txt_digest),
+                          "allele_table_deflate_gbs": (info.file_size / aw / 1e9) if aw > 0 else None,
+                          "note": "the same run ending as the reference's does: Alleles_frequency_table.zip (one member, deflated by all host threads into one "
+                                  "stream -- zlib level 1, slices ended by sync flushes --, only compressed bytes written) and no .txt; Python's zipfile read the member back "
+                                  "and its bytes equal the .txt leg's file; best of %d runs after a warm-up" % repeat})
+        out[leg] = entry
     shutil.rmtree(out_dir, ignore_errors=True)
     out["reads_per_s"] = out["plain"]["reads_per_s"]
     out["stage_seconds"] = out["plain"]["stage_seconds"]
@@ -626,6 +672,36 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
                    "de-duplication (plain / bgzf: on the device, bgzf after the host inflated it; *_host_parser: the native host parser), seed test, alignments of the unique reads, selection, reverse-complement merge, count kernel; best of %d "
                    "runs after a warm-up; reads/s counts every read of the file" % repeat)
     return out
+
+
+def _host_batch_leg(ctx, reads, L, matrix, n_reads=2_000_000, repeat=2):
+    """The boundary handing over HOST buffers (c2_align_classify_batch_host, the call a C caller without device memory makes): the reads in the caller's
+    pageable arrays, aligned strings + records back into the caller's pageable arrays -- chunks through pinned staging, copies both ways overlapped
+    with the launch chains.  This is the PCIe-inclusive rate; it is never `value`."""
+    from crispresso2_amd import synth
+    from crispresso2_amd.batch import BatchAligner
+    amp, g, inc = synth.amplicon_setup(L)
+    al = BatchAligner([amp], [g], [inc], matrix, GO, GE, ctx=ctx)
+    n = min(n_reads, reads.shape[0])
+    arena = np.ascontiguousarray(reads[:n]).reshape(-1)
+    offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    al.align((arena[:L * 4096], offsets[:4097]))                      # warm-up: staging buffers, row tables
+    runs = []
+    for _ in range(repeat):
+        t0 = time.perf_counter()
+        res = al.align((arena, offsets))
+        runs.append(time.perf_counter() - t0)
+        stride = res.aln_read.shape[1]
+        ok = bool((res.records["status"] == 0).all())
+        del res
+    dt = min(runs)
+    link = n * (L + 8) + n * (2 * stride + 32)
+    return {"reads": n, "seconds": dt, "reads_per_s": n / dt, "seconds_all_runs": runs, "all_status_ok": ok,
+            "link_bytes": link, "link_bytes_per_read": link / n, "link_gbs": link / dt / 1e9, "frac_of_link_peak": link / dt / 1e9 / LINK_PEAK_GBS,
+            "link_peak_gbs": LINK_PEAK_GBS,
+            "note": "c2_align_classify_batch_host: reads from and results into the caller's PAGEABLE numpy arrays (in: read bytes + offsets; out: two aligned "
+                    "strings of `aln_stride` bytes + a 32-byte record per read), including the allocation of the 2 x n x stride output arrays' pages; "
+                    "the PCIe-inclusive rate of the hot path -- bench.py's `value` has the inputs resident in HBM"}
 
 
 def _compare_with_reference(legs, d_aln_read, d_aln_ref, rec, k, all_refs):
@@ -943,7 +1019,7 @@ def main():
         valu["frac_of_simd32_peak"] = rate / VALU_SIMD32_WAVE_INSTR_PER_S
 
     # ---------- after the headline: the int32 chain on the same batch, the other BASELINE shapes, FASTQ -> tensors ----------
-    int32_chain = other_configs = e2e = robustness = None
+    int32_chain = other_configs = e2e = robustness = host_batch = None
     extras_done = threading.Event()
     extras_note = [None]
 
@@ -1003,6 +1079,8 @@ def main():
                                                             (e2e.get("sharded") or {}).get("reads_per_s")),
                        "e2e_sharded_shard_bytes_per_rank": None if not e2e or "sharded" not in e2e or not e2e["sharded"].get("per_rank") else
                                                            [None if sh is None else sh.get("shard_bytes") for sh in e2e["sharded"]["per_rank"]],
+                       "host_batch_pcie_inclusive_reads_per_s": None if not host_batch else host_batch.get("reads_per_s"),
+                       "e2e_frac_of_link_peak": None if not e2e or "plain" not in e2e else e2e["plain"].get("frac_of_link_peak"),
                        "e2e_fastq_to_all_tables_seconds": None if not e2e or "with_all_tables" not in e2e else e2e["with_all_tables"]["seconds"],
                        "e2e_fastq_to_all_tables_reads_per_s": None if not e2e or "with_all_tables" not in e2e else e2e["with_all_tables"]["reads_per_s"]},
             "alignments_per_s": world * n_tasks * args.steps / dt,
@@ -1024,6 +1102,7 @@ def main():
             "other_configs": other_configs,
             "robustness": robustness,
             "e2e": e2e,
+            "host_batch_pcie_inclusive": host_batch,
             "dedup_on": dedup_on,
             "cpu_baseline": cpu_baseline,
             # the reference AS SHIPPED (its own main(), dedup, workers, JSON / TSV exchange), log window "Aligning sequences..." ->
@@ -1193,6 +1272,11 @@ def main():
                         e2e = {"error": repr(e)}
                     finally:
                         shutil.rmtree(e2e_files["dir"], ignore_errors=True)
+            if world == 1 and not all_refs and wl["ref_ids"] is None:
+                try:
+                    host_batch = _host_batch_leg(ctx, reads, L, m, n_reads=min(2_000_000, args.extra_reads or 2_000_000))
+                except Exception as e:
+                    host_batch = {"error": repr(e)}
 
     except Exception as e:                                       # (one rank alone in trouble: the others wait in a collective; see the watchdog)
         if world == 1:

@@ -30,7 +30,7 @@ SYMBOLS = [
     "c2_fq_count_device", "c2_fq_lines_device", "c2_fq_dedup_device", "c2_fq_gather_device", "c2_fq_rc_partner_device",
     "c2_fq_lines4_device", "c2_fq_pair_lengths_device", "c2_fq_pair_write_device",
     "c2_fastq_unique_paired", "c2_fastq_paired_occurrences", "c2_fastq_aux_bytes", "c2_fastq_aux", "c2_fastq_aux_offsets", "c2_fastq_stream_text",
-    "c2_allele_table_build", "c2_allele_table_rows", "c2_allele_table_write", "c2_allele_table_fetch", "c2_allele_table_around_cut_write",
+    "c2_allele_table_build", "c2_allele_table_rows", "c2_allele_table_write", "c2_allele_table_write_zip", "c2_allele_table_fetch", "c2_allele_table_around_cut_write",
     "c2_allele_table_free", "c2_format_float_repr",
 ]
 

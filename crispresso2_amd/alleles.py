@@ -52,6 +52,13 @@ class _NativeCalls:
         return int(nb.value)
 
     @staticmethod
+    def write_zip(ctx, h, zip_path, member, labels, n_total, probes, threads, level):
+        nb, nz = ctypes.c_uint64(), ctypes.c_uint64()
+        ctx.check(ctx.lib.c2_allele_table_write_zip(h, zip_path, member, labels, ctypes.c_int64(n_total), probes, int(threads), int(level),
+                                                    ctypes.byref(nb), ctypes.byref(nz)), "c2_allele_table_write_zip")
+        return int(nb.value), int(nz.value)
+
+    @staticmethod
     def fetch(ctx, h, rows, aligned, reference, stride):
         ctx.check(ctx.lib.c2_allele_table_fetch(h, rows, aligned, reference, ctypes.c_uint32(stride)), "c2_allele_table_fetch")
 
@@ -140,8 +147,9 @@ class AlleleTable:
         except Exception:
             pass
 
-    def write(self, path, ref_names, n_total, dsODN="", threads=None):
-        """Alleles_frequency_table.txt -> bytes written"""
+    def write(self, path, ref_names, n_total, dsODN="", threads=None, zip_member=None, zip_level=1):
+        """Alleles_frequency_table.txt -> bytes written.  zip_member: `path` becomes a zip archive with the table as its one member of that name
+        (what the reference's run leaves behind, CRISPRessoCORE.py:4531-4533) -> (bytes of the text, bytes of the archive)"""
         from .refs import reverse_complement
         labels = labels_for(ref_names)
         lab = (ctypes.c_char_p * len(labels))(*[x.encode() for x in labels])
@@ -151,6 +159,8 @@ class AlleleTable:
                 raise KeyError("contains dsODN fragment")              # the reference selects a column it never made (:4519-4524)
             pr = [dsODN, reverse_complement(dsODN), dsODN[3:-3], reverse_complement(dsODN[3:-3])]
             probes = (ctypes.c_char_p * 4)(*[x.encode() for x in pr])
+        if zip_member:
+            return CALLS.write_zip(self.ctx, self._h, os.fsencode(path), zip_member.encode(), lab, int(n_total), probes, threads or default_threads(), zip_level)
         return CALLS.write(self.ctx, self._h, os.fsencode(path), lab, int(n_total), probes, threads or default_threads())
 
     def write_around_cut(self, path, label, cut_point, ref_len, plot_window_size, n_total, threads=None):

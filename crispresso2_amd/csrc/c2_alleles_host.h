@@ -24,6 +24,8 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <zlib.h>
+#include <time.h>
 #include <mutex>
 #include <condition_variable>
 #include <algorithm>
@@ -100,6 +102,117 @@ inline bool c2_pwrite_parallel(const int fd, const uint8_t* buf, const size_t n,
     work(0, std::min(n, slice));
     for (auto& t : pool) t.join();
     return ok;
+}
+
+// ---- Alleles_frequency_table.zip (CRISPRessoCORE.py:4531: `zipfile.ZipFile(.., 'w', ZIP_DEFLATED, allowZip64=True).write(txt)`, then the .txt is
+// removed): ONE deflate stream made by all threads.  A slice of the text is compressed by its own thread from a fresh window and ended with a sync
+// flush -- an empty stored block, which byte-aligns it -- so the slices' outputs concatenate into one valid stream (the pigz scheme); the stream
+// is closed by an empty final block.  CRC-32 per slice, combined.  The container is written by hand: local header (patched when the sizes
+// are known), the data, central directory, end record -- zip64 records when the text is 4 GiB or more.
+struct c2_zip_out {
+    int fd = -1; uint64_t pos = 0, data_start = 0, usize = 0, csize = 0; uint32_t crc = 0; bool zip64 = false; int level = 1;
+    std::string name; uint16_t dos_time = 0, dos_date = 0;
+};
+inline void c2_le16(std::string& o, const uint32_t v) { o.push_back((char)(v & 0xff)); o.push_back((char)((v >> 8) & 0xff)); }
+inline void c2_le32(std::string& o, const uint32_t v) { c2_le16(o, v & 0xffffu); c2_le16(o, v >> 16); }
+inline void c2_le64(std::string& o, const uint64_t v) { c2_le32(o, (uint32_t)(v & 0xffffffffull)); c2_le32(o, (uint32_t)(v >> 32)); }
+inline std::string c2_zip_local_header(const c2_zip_out& Z) {
+    std::string h;
+    c2_le32(h, 0x04034b50u); c2_le16(h, Z.zip64 ? 45 : 20); c2_le16(h, 0); c2_le16(h, 8); c2_le16(h, Z.dos_time); c2_le16(h, Z.dos_date);
+    c2_le32(h, Z.crc); c2_le32(h, Z.zip64 ? 0xffffffffu : (uint32_t)Z.csize); c2_le32(h, Z.zip64 ? 0xffffffffu : (uint32_t)Z.usize);
+    c2_le16(h, (uint32_t)Z.name.size()); c2_le16(h, Z.zip64 ? 20 : 0);
+    h += Z.name;
+    if (Z.zip64) { c2_le16(h, 1); c2_le16(h, 16); c2_le64(h, Z.usize); c2_le64(h, Z.csize); }
+    return h;
+}
+inline bool c2_zip_begin(c2_zip_out& Z, const int fd, const char* member, const uint64_t text_bytes, const int level, std::string& err) {
+    Z.fd = fd; Z.name = member; Z.level = level < 0 ? 1 : (level > 9 ? 9 : level);
+    Z.zip64 = text_bytes >= 0xffffffffull || getenv("C2_ZIP_FORCE_ZIP64");   // (the compressed size fits if the text's does; the knob: the zip64 records on a small table, for the tests)
+    time_t now = time(nullptr); struct tm tmv; localtime_r(&now, &tmv);
+    const int yr = tmv.tm_year + 1900 < 1980 ? 1980 : tmv.tm_year + 1900;
+    Z.dos_time = (uint16_t)((tmv.tm_hour << 11) | (tmv.tm_min << 5) | (tmv.tm_sec >> 1));
+    Z.dos_date = (uint16_t)(((yr - 1980) << 9) | ((tmv.tm_mon + 1) << 5) | tmv.tm_mday);
+    const std::string h = c2_zip_local_header(Z);                   // (a placeholder of the final size)
+    if (!c2_pwrite_parallel(fd, (const uint8_t*)h.data(), h.size(), 0, 1, err)) return false;
+    Z.pos = Z.data_start = h.size();
+    return true;
+}
+// the text [buf, buf + n) joins the member: `threads` slices compressed side by side, written in order
+inline bool c2_zip_append(c2_zip_out& Z, const uint8_t* buf, const size_t n, int threads, std::string& err) {
+    if (n == 0) return true;
+    if (threads < 1) threads = 1;
+    const size_t slice = std::max<size_t>((n + (size_t)threads - 1) / (size_t)threads, (size_t)1 << 20);
+    const size_t ns = (n + slice - 1) / slice;
+    std::vector<std::vector<uint8_t>> out(ns);
+    std::vector<uint32_t> crcs(ns, 0);
+    std::vector<char> ok(ns, 1);
+    auto work = [&](const size_t k) {
+        const size_t a = k * slice, z = std::min(n, a + slice);
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, Z.level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok[k] = 0; return; }
+        out[k].resize((size_t)deflateBound(&zs, (uLong)(z - a)) + 64);
+        size_t done = 0, produced = 0;
+        while (true) {                                              // (avail_in is 32 bits wide: feed it in pieces)
+            const size_t piece = std::min<size_t>(z - a - done, (size_t)1 << 30);
+            zs.next_in = (Bytef*)(buf + a + done); zs.avail_in = (uInt)piece;
+            const bool last = done + piece == z - a;
+            do {
+                if (produced == out[k].size()) out[k].resize(out[k].size() * 2);
+                zs.next_out = out[k].data() + produced; zs.avail_out = (uInt)std::min<size_t>(out[k].size() - produced, (size_t)1 << 30);
+                const uInt before = zs.avail_out;
+                const int rc = deflate(&zs, last ? Z_SYNC_FLUSH : Z_NO_FLUSH);
+                if (rc != Z_OK && rc != Z_BUF_ERROR) { ok[k] = 0; deflateEnd(&zs); return; }
+                produced += before - zs.avail_out;
+            } while (zs.avail_in > 0 || zs.avail_out == 0);
+            done += piece;
+            if (last) break;
+        }
+        deflateEnd(&zs);
+        out[k].resize(produced);
+        uint32_t c = 0;
+        for (size_t p = a; p < z; p += (size_t)1 << 30) c = (uint32_t)crc32(c, buf + p, (uInt)std::min<size_t>(z - p, (size_t)1 << 30));
+        crcs[k] = c;
+    };
+    { std::vector<std::thread> pool; for (size_t k = 1; k < ns; ++k) pool.emplace_back(work, k); work(0); for (auto& t : pool) t.join(); }
+    for (size_t k = 0; k < ns; ++k) {
+        if (!ok[k]) { err = "deflate failed"; return false; }
+        if (!c2_pwrite_parallel(Z.fd, out[k].data(), out[k].size(), Z.pos, 1, err)) return false;
+        Z.pos += out[k].size(); Z.csize += out[k].size();
+        const size_t a = k * slice, z = std::min(n, a + slice);
+        Z.crc = (uint32_t)crc32_combine(Z.crc, crcs[k], (z_off_t)(z - a));
+        Z.usize += z - a;
+    }
+    return true;
+}
+inline bool c2_zip_end(c2_zip_out& Z, std::string& err, uint64_t* file_bytes) {
+    const uint8_t fin[2] = {0x03, 0x00};                            // an empty final block (fixed Huffman: end-of-block and nothing else) closes the stream
+    if (!c2_pwrite_parallel(Z.fd, fin, 2, Z.pos, 1, err)) return false;
+    Z.pos += 2; Z.csize += 2;
+    const std::string lh = c2_zip_local_header(Z);
+    if (!c2_pwrite_parallel(Z.fd, (const uint8_t*)lh.data(), lh.size(), 0, 1, err)) return false;
+    std::string cd;
+    c2_le32(cd, 0x02014b50u); c2_le16(cd, (3u << 8) | (Z.zip64 ? 45u : 20u)); c2_le16(cd, Z.zip64 ? 45 : 20); c2_le16(cd, 0); c2_le16(cd, 8);
+    c2_le16(cd, Z.dos_time); c2_le16(cd, Z.dos_date); c2_le32(cd, Z.crc);
+    c2_le32(cd, Z.zip64 ? 0xffffffffu : (uint32_t)Z.csize); c2_le32(cd, Z.zip64 ? 0xffffffffu : (uint32_t)Z.usize);
+    c2_le16(cd, (uint32_t)Z.name.size()); c2_le16(cd, Z.zip64 ? 20 : 0); c2_le16(cd, 0); c2_le16(cd, 0); c2_le16(cd, 0);
+    c2_le32(cd, 0x81a40000u);                                      // a regular file, rw-r--r--
+    c2_le32(cd, 0);                                                // the local header's offset
+    cd += Z.name;
+    if (Z.zip64) { c2_le16(cd, 1); c2_le16(cd, 16); c2_le64(cd, Z.usize); c2_le64(cd, Z.csize); }
+    const uint64_t cd_off = Z.pos, cd_size = cd.size();
+    std::string tail = cd;
+    if (Z.zip64 || cd_off >= 0xffffffffull) {
+        c2_le32(tail, 0x06064b50u); c2_le64(tail, 44); c2_le16(tail, 45); c2_le16(tail, 45); c2_le32(tail, 0); c2_le32(tail, 0);
+        c2_le64(tail, 1); c2_le64(tail, 1); c2_le64(tail, cd_size); c2_le64(tail, cd_off);
+        c2_le32(tail, 0x07064b50u); c2_le32(tail, 0); c2_le64(tail, cd_off + cd_size); c2_le32(tail, 1);
+    }
+    c2_le32(tail, 0x06054b50u); c2_le16(tail, 0); c2_le16(tail, 0); c2_le16(tail, 1); c2_le16(tail, 1);
+    c2_le32(tail, (uint32_t)cd_size); c2_le32(tail, cd_off >= 0xffffffffull ? 0xffffffffu : (uint32_t)cd_off); c2_le16(tail, 0);
+    if (!c2_pwrite_parallel(Z.fd, (const uint8_t*)tail.data(), tail.size(), Z.pos, 1, err)) return false;
+    Z.pos += tail.size();
+    if (ftruncate(Z.fd, (off_t)Z.pos) != 0) { /* (nothing behind it anyway) */ }
+    if (file_bytes) *file_bytes = Z.pos;
+    return true;
 }
 
 template <class B>
@@ -180,8 +293,10 @@ inline void c2a_make_runs(const uint32_t* reads, const uint64_t m, const int64_t
 }
 
 template <class B>
-int c2a_write(c2a_table<B>* t, const char* path, const char* const* labels, const int64_t n_total, const char* const* probes, int threads, uint64_t* bytes_written)
+int c2a_write(c2a_table<B>* t, const char* path, const char* const* labels, const int64_t n_total, const char* const* probes, int threads, uint64_t* bytes_written,
+              const char* zip_member = nullptr, const int zip_level = 1, uint64_t* zip_bytes = nullptr)
 {
+    // zip_member: `path` becomes a zip archive whose one member of that name is the table (what the reference leaves behind, CRISPRessoCORE.py:4531)
     B& be = t->be;
     const uint64_t m = t->m;
     std::string head = "Aligned_Sequence\tReference_Sequence\tReference_Name\tRead_Status\tn_deleted\tn_inserted\tn_mutated\t#Reads\t%Reads";
@@ -190,9 +305,14 @@ int c2a_write(c2a_table<B>* t, const char* path, const char* const* labels, cons
     const int fd = open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
     if (fd < 0) { t->err = std::string("open ") + path + ": " + strerror(errno); return C2_E_INVALID; }
     struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
-    if (!c2_pwrite_parallel(fd, (const uint8_t*)head.data(), head.size(), 0, 1, t->err)) return C2_E_INVALID;
+    c2_zip_out Z;
+    if (!zip_member && !c2_pwrite_parallel(fd, (const uint8_t*)head.data(), head.size(), 0, 1, t->err)) return C2_E_INVALID;
     if (bytes_written) *bytes_written = head.size();
-    if (m == 0) return 0;
+    if (m == 0) {
+        if (zip_member && !(c2_zip_begin(Z, fd, zip_member, head.size(), zip_level, t->err) && c2_zip_append(Z, (const uint8_t*)head.data(), head.size(), 1, t->err) &&
+                            c2_zip_end(Z, t->err, zip_bytes))) return C2_E_INVALID;
+        return 0;
+    }
     if (n_total <= 0) { t->err = "n_total must be positive"; return C2_E_INVALID; }
     if (threads < 1) threads = 1;
     c2a_scratch<B> tmp(be);
@@ -242,7 +362,9 @@ int c2a_write(c2a_table<B>* t, const char* path, const char* const* labels, cons
     C2A_TRY(t, be.d2h(off.data(), d_off, m * 8) && be.d2h(&last_len, d_len + (m - 1), 4), "line offsets");
     off[m] = off[m - 1] + last_len;
     const uint64_t total = off[m];
-    if (ftruncate(fd, (off_t)(head.size() + total)) != 0) { /* (a file system without it: pwrite extends the file) */ }
+    if (zip_member) {
+        if (!(c2_zip_begin(Z, fd, zip_member, head.size() + total, zip_level, t->err) && c2_zip_append(Z, (const uint8_t*)head.data(), head.size(), 1, t->err))) return C2_E_INVALID;
+    } else if (ftruncate(fd, (off_t)(head.size() + total)) != 0) { /* (a file system without it: pwrite extends the file) */ }
     // chunks of whole lines, at most `chunk` bytes each (one line always fits: a chunk holds at least one)
     uint64_t chunk = (uint64_t)64 << 20;
     if (const char* e = getenv("C2_ALLELE_CHUNK_BYTES")) { const long long v = atoll(e); if (v > 0) chunk = (uint64_t)v; }
@@ -271,7 +393,8 @@ int c2a_write(c2a_table<B>* t, const char* path, const char* const* labels, cons
             if (!pending[i]) return;
             lk.unlock();
             std::string e;
-            const bool ok = c2_pwrite_parallel(fd, h_buf[i], w_len[i], head.size() + w_off[i], threads, e);
+            const bool ok = zip_member ? c2_zip_append(Z, h_buf[i], w_len[i], threads, e)       // (chunks arrive in order: one writer thread)
+                                       : c2_pwrite_parallel(fd, h_buf[i], w_len[i], head.size() + w_off[i], threads, e);
             lk.lock();
             if (!ok && !failed) { failed = true; werr = e; }
             pending[i] = 0;
@@ -294,6 +417,7 @@ int c2a_write(c2a_table<B>* t, const char* path, const char* const* labels, cons
     writer.join();
     C2A_TRY(t, dev_ok, "c2_allele_emit_kernel");
     if (failed) { t->err = werr; return C2_E_INVALID; }
+    if (zip_member && !c2_zip_end(Z, t->err, zip_bytes)) return C2_E_INVALID;
     if (bytes_written) *bytes_written = head.size() + total;
     return 0;
 }

@@ -104,6 +104,15 @@ int c2_allele_table_write(c2_allele_table* t, const char* path, const char* cons
     return rc;
 }
 
+int c2_allele_table_write_zip(c2_allele_table* t, const char* zip_path, const char* member, const char* const* labels, int64_t n_total,
+                              const char* const* probes, int32_t threads, int32_t level, uint64_t* text_bytes, uint64_t* zip_bytes) {
+    if (!t || !zip_path || !member || !member[0]) return C2_E_INVALID;
+    HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
+    const int rc = c2a_write(t->t, zip_path, labels, n_total, probes, threads, text_bytes, member, level, zip_bytes);
+    if (rc) t->ctx->err = t->t->err;
+    return rc;
+}
+
 int c2_allele_table_fetch(c2_allele_table* t, c2_allele_row* rows, uint8_t* aligned, uint8_t* reference, uint32_t stride) {
     if (!t) return C2_E_INVALID;
     HIPCHK(t->ctx, hipSetDevice(t->ctx->device));

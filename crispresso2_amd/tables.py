@@ -66,7 +66,7 @@ def _write_count_vectors(path, ref_seq, vectors, names):
             fh.write(nm + "\t" + "\t".join(vec) + "\n")
 
 
-def write_alleles_frequency_table(res, path, dsODN=""):
+def write_alleles_frequency_table(res, path, dsODN="", zip_member=None):
     """Alleles_frequency_table.txt (the reference zips it): CRISPRessoCORE.py:4498-4527, the non-detailed columns.  With
     --dsODN two more columns say whether the aligned read contains the oligo, or the oligo without its first and last three
     bases, on either strand -- `str.find(...) > 0`, so a match at the very start of the read does not count (:4512-4524).
@@ -74,7 +74,16 @@ def write_alleles_frequency_table(res, path, dsODN=""):
     (alleles.AlleleTable.write, c2_allele_table_write).  Any other `res` (rows in host memory, res.alleles()) is printed here."""
     table = res.allele_table() if hasattr(res, "allele_table") else None
     if table is not None:
-        table.write(path, res.align_ref_names, res.stats["N_TOTAL"], dsODN=dsODN)
+        table.write(path, res.align_ref_names, res.stats["N_TOTAL"], dsODN=dsODN, zip_member=zip_member)
+        return
+    if zip_member:                                                   # (rows in host memory: the text below, zipped as the reference zips it)
+        import tempfile
+        import zipfile
+        with tempfile.TemporaryDirectory(dir=os.path.dirname(os.path.abspath(path))) as tmp:
+            txt = os.path.join(tmp, zip_member)
+            write_alleles_frequency_table(res, txt, dsODN=dsODN)
+            with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED, allowZip64=True) as z:
+                z.write(txt, zip_member)
         return
     from .refs import reverse_complement
     head = "Aligned_Sequence\tReference_Sequence\tReference_Name\tRead_Status\tn_deleted\tn_inserted\tn_mutated\t#Reads\t%Reads"
@@ -222,8 +231,10 @@ def write_reads_from_all_amplicons_tables(res, refs, ref_names, out_dir):
     return written
 
 
-def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN="", timings=None):
+def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN="", timings=None, allele_table_zip=False):
     """Writes the tables listed in the module docstring into out_dir; returns the list of file names.
+    allele_table_zip: the allele frequency table as Alleles_frequency_table.zip (one member, Alleles_frequency_table.txt) and no .txt -- the state the
+    reference's run ends in (CRISPRessoCORE.py:4531-4533); the device route deflates on all host threads and writes only the compressed bytes.
     timings: optional dict that receives the wall seconds of the allele table's build (rows + sort on the device), its file, the
     around-cut files, and everything else."""
     import time
@@ -232,13 +243,13 @@ def write_tables(res, refs, ref_names, out_dir, plot_window_size=20, dsODN="", t
     t_start = time.perf_counter()
     t_alleles = 0.0
     os.makedirs(out_dir, exist_ok=True)
-    written = ["CRISPResso_quantification_of_editing_frequency.txt", "Alleles_frequency_table.txt"]
+    written = ["CRISPResso_quantification_of_editing_frequency.txt", "Alleles_frequency_table.zip" if allele_table_zip else "Alleles_frequency_table.txt"]
     write_quantification_of_editing_frequency(res, ref_names, os.path.join(out_dir, written[0]))
     t0 = time.perf_counter()
     if hasattr(res, "allele_table"):
         res.allele_table()
     t1 = time.perf_counter()
-    write_alleles_frequency_table(res, os.path.join(out_dir, written[1]), dsODN=dsODN)
+    write_alleles_frequency_table(res, os.path.join(out_dir, written[1]), dsODN=dsODN, zip_member="Alleles_frequency_table.txt" if allele_table_zip else None)
     t2 = time.perf_counter()
     t_alleles += t2 - t0
     t_around = 0.0

@@ -227,6 +227,13 @@ uint64_t c2_allele_table_rows(const c2_allele_table* t);
  * column 0 hides every later one).  %Reads is printed as Python prints the double #Reads / n_total * 100 (shortest round-trip repr). */
 int c2_allele_table_write(c2_allele_table* t, const char* path, const char* const* labels, int64_t n_total,
                           const char* const* probes, int32_t threads, uint64_t* bytes_written);
+/* The same text as the one member `member` of the zip archive `zip_path` -- what the reference's run leaves behind: it zips the table
+ * (ZIP_DEFLATED, allowZip64) and removes the .txt (CRISPRessoCORE.py:4531-4533).  The chunks that come off the device are deflated by
+ * `threads` host threads (zlib `level`, 1 = fastest): every slice from a fresh window, ended with a sync flush, so the slices concatenate into
+ * ONE deflate stream (the pigz scheme); CRC-32 per slice, combined; zip64 records when the text is 4 GiB or more.  Only the compressed
+ * bytes are written.  *text_bytes: the table's size as text, *zip_bytes: the archive's. */
+int c2_allele_table_write_zip(c2_allele_table* t, const char* zip_path, const char* member, const char* const* labels, int64_t n_total,
+                              const char* const* probes, int32_t threads, int32_t level, uint64_t* text_bytes, uint64_t* zip_bytes);
 /* The sorted rows for a caller that wants them in memory: rows[m], and the two strings of every row zero-padded to `stride` bytes
  * (>= the longest alignment) in aligned[m * stride] / reference[m * stride] (either may be NULL). */
 int c2_allele_table_fetch(c2_allele_table* t, c2_allele_row* rows, uint8_t* aligned, uint8_t* reference, uint32_t stride);

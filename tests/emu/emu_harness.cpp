@@ -664,6 +664,13 @@ int emu_allele_table_write(void* t, const char* path, const char* const* labels,
     if (rc) g_allele_err = T->err;
     return rc;
 }
+int emu_allele_table_write_zip(void* t, const char* zip_path, const char* member, const char* const* labels, int64_t n_total, const char* const* probes,
+                               int32_t threads, int32_t level, uint64_t* text_bytes, uint64_t* zip_bytes) {
+    auto* T = (c2a_table<EmuBackend>*)t;
+    const int rc = c2a_write(T, zip_path, labels, n_total, probes, threads, text_bytes, member, level, zip_bytes);
+    if (rc) g_allele_err = T->err;
+    return rc;
+}
 int emu_allele_table_fetch(void* t, c2_allele_row* rows, uint8_t* aligned, uint8_t* reference, uint32_t stride) {
     auto* T = (c2a_table<EmuBackend>*)t;
     const int rc = c2a_fetch(T, rows, aligned, reference, stride);

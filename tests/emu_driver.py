@@ -38,7 +38,7 @@ def build(force=False):
                 tmp = LIB + ".tmp.%d" % os.getpid()
                 subprocess.check_call(["g++", "-O1", "-U_FORTIFY_SOURCE", "-D_FORTIFY_SOURCE=0", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("C2_EMU_CFLAGS", "").split() + ["-I", EMU_DIR,
                                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "crispresso2_amd/csrc"),
-                                       "-x", "c++", os.path.join(EMU_DIR, "emu_harness.cpp"), "-o", tmp])
+                                       "-x", "c++", os.path.join(EMU_DIR, "emu_harness.cpp"), "-o", tmp, "-lz"])
                 os.replace(tmp, LIB)
 
 

@@ -180,6 +180,13 @@ class _EmuAlleleCalls:
         return int(nb.value)
 
     @staticmethod
+    def write_zip(ctx, h, zip_path, member, labels, n_total, probes, threads, level):
+        nb, nz = ctypes.c_uint64(), ctypes.c_uint64()
+        _EmuAlleleCalls._chk(E.lib().emu_allele_table_write_zip(h, zip_path, member, labels, ctypes.c_int64(n_total), probes, int(threads), int(level),
+                                                                ctypes.byref(nb), ctypes.byref(nz)), "emu_allele_table_write_zip")
+        return int(nb.value), int(nz.value)
+
+    @staticmethod
     def fetch(ctx, h, rows, aligned, reference, stride):
         _EmuAlleleCalls._chk(E.lib().emu_allele_table_fetch(h, rows, aligned, reference, ctypes.c_uint32(stride)), "emu_allele_table_fetch")
 

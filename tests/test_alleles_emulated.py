@@ -179,6 +179,26 @@ def test_allele_table_text_equals_the_pandas_restatement(tmp_path, monkeypatch, 
         assert nb == len(got.encode())
         if rows:
             assert got == want
+        # the same table as the reference's run leaves it (CRISPRessoCORE.py:4531-4533): a zip archive with the .txt as its one member.  The
+        # chunks are deflated slice by slice on several threads and concatenated into one stream: Python's zipfile must give the text back
+        import zipfile
+        zp = tmp_path / "Alleles_frequency_table.zip"
+        nb_z, zip_bytes = tab.write(str(zp), names, n_total, dsODN=dsODN, threads=3, zip_member="Alleles_frequency_table.txt")
+        assert nb_z == nb and zip_bytes == zp.stat().st_size
+        with zipfile.ZipFile(str(zp)) as z:
+            assert z.namelist() == ["Alleles_frequency_table.txt"] and z.testzip() is None
+            info = z.getinfo("Alleles_frequency_table.txt")
+            assert info.compress_type == zipfile.ZIP_DEFLATED and info.file_size == nb
+            assert z.read("Alleles_frequency_table.txt").decode() == got
+        if seed == 3:                                                  # the records a table of 4 GiB or more gets (zip64 extra fields, zip64 end record + locator)
+            monkeypatch.setenv("C2_ZIP_FORCE_ZIP64", "1")
+            tab.write(str(zp), names, n_total, dsODN=dsODN, threads=2, zip_member="Alleles_frequency_table.txt")
+            monkeypatch.delenv("C2_ZIP_FORCE_ZIP64")
+            with zipfile.ZipFile(str(zp)) as z:
+                assert z.testzip() is None and z.read("Alleles_frequency_table.txt").decode() == got
+            with open(str(zp), "rb") as fh:
+                blob = fh.read()
+            assert b"PK\x06\x06" in blob and b"PK\x06\x07" in blob
         # the rows in memory: same order, same values
         AR = tab.rows(names, n_total)
         tuples = AR.tuples()
@@ -268,6 +288,10 @@ def test_no_rows_gives_the_header_only(tmp_path):
         p = tmp_path / "t.txt"
         tab.write(str(p), names, 10)
         assert p.read_text() == "Aligned_Sequence\tReference_Sequence\tReference_Name\tRead_Status\tn_deleted\tn_inserted\tn_mutated\t#Reads\t%Reads\n"
+        import zipfile
+        tab.write(str(tmp_path / "t.zip"), names, 10, zip_member="Alleles_frequency_table.txt")
+        with zipfile.ZipFile(str(tmp_path / "t.zip")) as z:
+            assert z.testzip() is None and z.read("Alleles_frequency_table.txt").decode() == p.read_text()
         assert tab.rows(names, 10).tuples() == []
     finally:
         tab.close()

@@ -132,7 +132,12 @@ def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fa
     assert e2e["reads"] == 90 and e2e["plain_equals_bgzf"] and e2e["plain"]["reads_per_s"] > 0 and e2e["bgzf"]["reads_per_s"] > 0
     assert e2e["tallies"]["N_TOT_READS"] == 90 and set(e2e["stage_seconds"]) >= {"ingest_dedup_streamed", "stream_tail_device", "count_kernels"}
     wt = e2e["with_all_tables"]                                      # FASTQ -> every result table on disk, the allele table among them
-    assert wt["files_written"] >= 18 and wt["allele_table_rows"] > 0 and wt["allele_table_bytes"] > 500 and wt["alleles_around_cut_bytes"] > 100
+    assert wt["files_written"] >= 18 and wt["allele_table_rows"] > 0 and wt["allele_table_zip_bytes"] > 100 and wt["alleles_around_cut_bytes"] > 100
+    assert wt["zip_member_equals_the_txt_legs_file"] is True          # (the reference ends with Alleles_frequency_table.zip; Python's zipfile reads our stream back)
+    assert e2e["with_all_tables_txt"]["allele_table_bytes"] == wt["allele_table_text_bytes"] > 500
+    assert e2e["plain"]["link_bytes"] == e2e["file_bytes"] and 0 < e2e["plain"]["frac_of_link_peak"]
+    hb = out["host_batch_pcie_inclusive"]                            # the boundary with host buffers on both sides
+    assert hb["reads"] == 90 and hb["all_status_ok"] and hb["reads_per_s"] > 0 and hb["link_bytes_per_read"] > 700
     assert set(wt["write_tables_stage_seconds"]) >= {"allele_table_build", "allele_table_write", "around_cut_tables", "other_tables"}
     # the same read budget on inputs that are not the generator's best case -- FANC-shaped reads (ragged, overhangs on both sides),
     # reads cut to U[200, L], one read in ten unrelated -- each with its tier shares, chain = full plane on every task and a reference-compiled slice
