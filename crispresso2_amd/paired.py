@@ -97,7 +97,6 @@ def _pair_plan(args, s1, s2, ref):
 def get_new_variant_objects_from_paired(args, pairs, refs, ref_names, aln_matrix, pe_scaffold_dna_info=None, ctx=None):
     """pairs: sequence of (fastq1_seq, fastq2_seq, fastq1_qual, fastq2_qual).  One dict per pair, equal to
     get_new_variant_object_from_paired(args, *pair, refs, ref_names, aln_matrix, pe_scaffold_dna_info)."""
-    from copy import deepcopy
     ctx = ctx or _native.default_context()
     aligner = BatchAligner([refs[n]['sequence'] for n in ref_names], [refs[n]['gap_incentive'] for n in ref_names],
                            [refs[n]['include_idxs'] for n in ref_names], aln_matrix,
@@ -130,102 +129,53 @@ def get_new_variant_objects_from_paired(args, pairs, refs, ref_names, aln_matrix
         item_of[key] = len(items)
         items.append((a1[0], a1[1], float(scores[t]), pairs[i][2], a2[0], a2[1], float(scores[t + 1]), pairs[i][3]))
     cons = consensus_batch(items, ctx=ctx)
-    # ---- per pair: reference choice (:1066-1081) -> classifier jobs
-    chosen, jobs, job_sets = [], [], []
+    # ---- per pair: the winning amplicons (variants._Winners: :1066-1081) -> classifier jobs
+    from .variants import _Winners, _complete_payload, _settle_read
+    picked, jobs, job_sets = [], [], []
+    set_of = {name: r for r, name in enumerate(ref_names)}
     for i in range(npairs):
-        aln_scores, ref_aln_details = [], []
-        best_match_score = -1
-        best_s1s, best_s2s, best_names = [], [], []
-        caching_is_ok = True
+        w = _Winners()
+        cache_ok = True
         for r, ref_name in enumerate(ref_names):
             pl = plans[i][r]
             if pl == 0 or pl == 1:
-                s1, qual, s2, score, caching_is_ok = cons[item_of[(i, r, pl)]]
+                a, qual, f, score, cache_ok = cons[item_of[(i, r, pl)]]
             else:
-                fws1, fwqual, fws2, fwscore, _ = cons[item_of[(i, r, 0)]]
-                rvs1, rvqual, rvs2, rvscore, caching_is_ok = cons[item_of[(i, r, 1)]]      # caching flag of the LAST call, :1049
-                s1, qual, s2, score = fws1, fwqual, fws2, fwscore
-                if rvscore > fwscore:
-                    s1, qual, s2, score = rvs1, rvqual, rvs2, rvscore
-            aln_scores.append(score)
-            ref_aln_details.append((ref_name, s1, s2, score, qual))
-            if score > best_match_score and score > refs[ref_name]['min_aln_score']:
-                best_match_score = score
-                best_s1s, best_s2s, best_names = [s1], [s2], [ref_name]
-            elif score == best_match_score:
-                best_s1s.append(s1)
-                best_s2s.append(s2)
-                best_names.append(ref_name)
-        first_job = len(jobs)
-        if best_match_score > 0:
-            for idx, name in enumerate(best_names):
-                jobs.append((best_s1s[idx], best_s2s[idx]))
-                job_sets.append(ref_names.index(name))
-        chosen.append((aln_scores, ref_aln_details, best_match_score, best_s1s, best_s2s, best_names, caching_is_ok, first_job))
+                a, qual, f, score, _ = cons[item_of[(i, r, 0)]]
+                rv_a, rv_qual, rv_f, rv_score, cache_ok = cons[item_of[(i, r, 1)]]        # caching flag of the LAST consensus call, :1049
+                if rv_score > score:
+                    a, qual, f, score = rv_a, rv_qual, rv_f, rv_score
+            w.offer(ref_name, a, f, score, refs[ref_name]['min_aln_score'], detail=(ref_name, a, f, score, qual))
+        picked.append((w, cache_ok, len(jobs)))
+        if w.aligned:
+            for name, a, f, _ in w.entries:
+                jobs.append((a, f))
+                job_sets.append(set_of[name])
     payloads = CRISPRessoCOREResources.find_indels_substitutions_batch(
         jobs, [refs[name]['include_idxs'] for name in ref_names], set_ids=np.array(job_sets, dtype=np.uint16),
         legacy=bool(args.use_legacy_insertion_quantification), ctx=ctx)
     variants = []
-    for i in range(npairs):
-        aln_scores, ref_aln_details, best_match_score, best_s1s, best_s2s, best_names, caching_is_ok, first_job = chosen[i]
-        new_variant = {'count': 1}
-        if best_match_score <= 0:                                  # :1145-1152
-            new_variant['aln_scores'] = aln_scores
-            new_variant['ref_aln_details'] = ref_aln_details
-            new_variant['best_match_score'] = best_match_score
-            new_variant['caching_is_ok'] = caching_is_ok
-            variants.append(new_variant)
+    for w, cache_ok, first_job in picked:
+        result = {'count': 1}
+        if not w.aligned:                                          # :1145-1152
+            result['aln_scores'] = w.scores
+            result['ref_aln_details'] = w.details
+            result['best_match_score'] = w.top
+            result['caching_is_ok'] = cache_ok
+            variants.append(result)
             continue
-        new_variant['aln_ref_names'] = best_names
-        new_variant['aln_scores'] = aln_scores
-        new_variant['ref_aln_details'] = ref_aln_details
-        new_variant['best_match_score'] = best_match_score
-        new_variant['caching_is_ok'] = caching_is_ok
-        class_names = []
-        for idx, best_match_name in enumerate(best_names):
-            s1, s2 = best_s1s[idx], best_s2s[idx]
-            payload = payloads[first_job + idx]
-            payload['ref_name'] = best_match_name
-            payload['aln_scores'] = aln_scores
-            is_modified = False
-            if not args.ignore_deletions and payload['deletion_n'] > 0:
-                is_modified = True
-            elif not args.ignore_insertions and payload['insertion_n'] > 0:
-                is_modified = True
-            elif not args.ignore_substitutions and payload['substitution_n'] > 0:
-                is_modified = True
-            payload['irregular_ends'] = False                      # :1106-1110
-            if s1[0] == '-' or s2[0] == '-' or s1[0] != s2[0]:
-                payload['irregular_ends'] = True
-            elif s1[-1] == '-' or s2[-1] == '-' or s1[-1] != s2[-1]:
-                payload['irregular_ends'] = True
-            payload['insertions_outside_window'] = (len(payload['all_insertion_positions']) / 2) - (len(payload['insertion_positions']) / 2)
-            payload['deletions_outside_window'] = len(payload['all_deletion_coordinates']) - len(payload['deletion_coordinates'])
-            payload['substitutions_outside_window'] = len(payload['all_substitution_positions']) - len(payload['substitution_positions'])
-            payload['total_mods'] = (len(payload['all_insertion_positions']) / 2) + len(payload['all_deletion_positions']) + len(payload['all_substitution_positions'])
-            payload['mods_in_window'] = payload['substitution_n'] + payload['deletion_n'] + payload['insertion_n']
-            payload['mods_outside_window'] = payload['total_mods'] - payload['mods_in_window']
-            class_names.append(best_match_name + ("_MODIFIED" if is_modified else "_UNMODIFIED"))
-            payload['classification'] = 'MODIFIED' if is_modified else 'UNMODIFIED'
-            payload['aln_seq'] = s1
-            payload['aln_ref'] = s2
-            new_variant['variant_' + best_match_name] = payload
-        new_variant['class_name'] = "&".join(class_names)
-        if len(best_names) > 1:                                    # :1155-1160
-            if args.assign_ambiguous_alignments_to_first_reference:
-                new_variant['class_name'] = class_names[0]
-                new_variant['aln_ref_names'] = [best_names[0]]
-            elif not args.expand_ambiguous_alignments:
-                new_variant['class_name'] = 'AMBIGUOUS'
-        if getattr(args, 'prime_editing_pegRNA_scaffold_seq', '') and 'Prime-edited' in best_names:          # :1164-1172
-            loc = new_variant['variant_Prime-edited']['ref_positions'].index(pe_scaffold_dna_info[0] - 1) + 1
-            if new_variant['variant_Prime-edited']['aln_seq'][loc:(loc + len(pe_scaffold_dna_info[1]))] == pe_scaffold_dna_info[1]:
-                new_variant['aln_ref_names'] = ["Scaffold-incorporated"]
-                new_variant['class_name'] = "Scaffold-incorporated"
-                old_payload = deepcopy(new_variant['variant_Prime-edited'])
-                old_payload['ref_name'] = "Scaffold-incorporated"
-                new_variant['variant_' + "Scaffold-incorporated"] = old_payload
-        variants.append(new_variant)
+        result['aln_ref_names'] = w.names()
+        result['aln_scores'] = w.scores
+        result['ref_aln_details'] = w.details
+        result['best_match_score'] = w.top
+        result['caching_is_ok'] = cache_ok
+        labels = []
+        for q, (name, a, f, _) in enumerate(w.entries):
+            payload = payloads[first_job + q]
+            labels.append(_complete_payload(payload, args, name, a, f, w.scores, paired=True))     # (pairs: no 'aln_strand', float counts, :1093-1131)
+            result['variant_' + name] = payload
+        _settle_read(result, labels, w, args, pe_scaffold_dna_info)
+        variants.append(result)
     return variants
 
 

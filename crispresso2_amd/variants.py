@@ -78,102 +78,125 @@ def align_all(args, fastq_seqs, refs, ref_names, aln_matrix, ctx=None):
     return out
 
 
+class _Winners:
+    """The best-reference rule for one read over its candidate amplicons (CRISPRessoCORE.py:697-707; for pairs :1066-1081): a score that is
+    strictly better than the best so far AND above that amplicon's min_aln_score takes over; an equal score joins it (an ambiguous read)."""
+    __slots__ = ("top", "entries", "scores", "details")
+
+    def __init__(self):
+        self.top = -1
+        self.entries = []                # (reference name, aligned read, aligned reference, strand or None) of the amplicons that share the top score
+        self.scores = []                 # every amplicon's score, in ref_names order        -> 'aln_scores'
+        self.details = []                # every amplicon's (name, strings, score[, qual])   -> 'ref_aln_details'
+
+    def offer(self, ref_name, aligned_read, aligned_ref, score, min_aln_score, strand=None, detail=None):
+        self.scores.append(score)
+        self.details.append(detail if detail is not None else (ref_name, aligned_read, aligned_ref, score))
+        if score > self.top and score > min_aln_score:
+            self.top = score
+            self.entries = [(ref_name, aligned_read, aligned_ref, strand)]
+        elif score == self.top:
+            self.entries.append((ref_name, aligned_read, aligned_ref, strand))
+
+    @property
+    def aligned(self):
+        return self.top > 0
+
+    def names(self):
+        return [e[0] for e in self.entries]
+
+
+def _complete_payload(payload, args, ref_name, aligned_read, aligned_ref, all_scores, paired=False):
+    """the fields the reference derives from the classifier's payload for one winning amplicon (:726-760; pairs :1093-1131, which keep the
+    two halves-of-a-list counts as floats) -> the class label of the read for this amplicon"""
+    payload['ref_name'] = ref_name
+    payload['aln_scores'] = all_scores
+    a, f = aligned_read, aligned_ref
+    payload['irregular_ends'] = bool(a[0] == '-' or f[0] == '-' or a[0] != f[0] or a[-1] == '-' or f[-1] == '-' or a[-1] != f[-1])
+    ins_all, ins_win = len(payload['all_insertion_positions']) / 2, len(payload['insertion_positions']) / 2
+    n_del_pos, n_sub_pos = len(payload['all_deletion_positions']), len(payload['all_substitution_positions'])
+    payload['insertions_outside_window'] = (ins_all - ins_win) if paired else int(ins_all - ins_win)
+    payload['deletions_outside_window'] = len(payload['all_deletion_coordinates']) - len(payload['deletion_coordinates'])
+    payload['substitutions_outside_window'] = n_sub_pos - len(payload['substitution_positions'])
+    payload['total_mods'] = (ins_all + n_del_pos + n_sub_pos) if paired else int(ins_all + n_del_pos + n_sub_pos)
+    payload['mods_in_window'] = payload['substitution_n'] + payload['deletion_n'] + payload['insertion_n']
+    payload['mods_outside_window'] = payload['total_mods'] - payload['mods_in_window']
+    edited = ((not args.ignore_deletions and payload['deletion_n'] > 0) or (not args.ignore_insertions and payload['insertion_n'] > 0) or
+              (not args.ignore_substitutions and payload['substitution_n'] > 0))
+    payload['classification'] = 'MODIFIED' if edited else 'UNMODIFIED'
+    payload['aln_seq'] = aligned_read
+    payload['aln_ref'] = aligned_ref
+    return ref_name + ("_MODIFIED" if edited else "_UNMODIFIED")
+
+
+def _settle_read(result, labels, winners, args, pe_scaffold_dna_info):
+    """what the reference does once every winning amplicon has its payload: the read's class name, the ambiguity flags (:779-785) and the
+    prime-editing scaffold rule (:789-796: a read whose best amplicon is 'Prime-edited' and that carries the scaffold's first bases behind the
+    extension is re-labelled)"""
+    names = winners.names()
+    result['class_name'] = "&".join(labels)
+    if len(names) > 1:
+        if args.assign_ambiguous_alignments_to_first_reference:
+            result['class_name'] = labels[0]
+            result['aln_ref_names'] = [names[0]]
+        elif not args.expand_ambiguous_alignments:
+            result['class_name'] = 'AMBIGUOUS'
+    if getattr(args, 'prime_editing_pegRNA_scaffold_seq', '') and 'Prime-edited' in names:
+        pe = result['variant_Prime-edited']
+        at = pe['ref_positions'].index(pe_scaffold_dna_info[0] - 1) + 1
+        if pe['aln_seq'][at:(at + len(pe_scaffold_dna_info[1]))] == pe_scaffold_dna_info[1]:
+            result['aln_ref_names'] = ["Scaffold-incorporated"]
+            result['class_name'] = "Scaffold-incorporated"
+            twin = deepcopy(pe)
+            twin['ref_name'] = "Scaffold-incorporated"
+            result['variant_' + "Scaffold-incorporated"] = twin
+
+
 def get_new_variant_objects(args, fastq_seqs, refs, ref_names, aln_matrix, pe_scaffold_dna_info=None, ctx=None):
     """One result dict per read, equal to get_new_variant_object(args, seq, refs, ref_names, aln_matrix, pe_info).
-    Alignments: one batch per reference (align_all); classifier payloads of all best alignments: one batched call
-    (c2_classify_lists_batch) instead of one find_indels_substitutions launch per read."""
+    Two passes around two batched device calls: alignments, one batch per reference (align_all); then, with every read's winning
+    amplicons known, the classifier payloads of all of them in one call (c2_classify_lists_batch) instead of one
+    find_indels_substitutions launch per read."""
     ctx = ctx or _native.default_context()
     per_read = align_all(args, fastq_seqs, refs, ref_names, aln_matrix, ctx=ctx)
-    ref_index = {name: r for r, name in enumerate(ref_names)}
-    chosen = []                                                    # per read: scores, details and the best matches (:689-707)
-    jobs, job_sets = [], []                                        # (s1, s2) of every best match, and its reference
+    set_of = {name: r for r, name in enumerate(ref_names)}
+    picked = []                                                    # per read: its _Winners and where its classifier jobs start
+    jobs, job_sets = [], []                                        # (aligned read, aligned reference) of every winning amplicon, and its include set
     for k in range(len(fastq_seqs)):
-        aln_scores = []
-        best_match_score = -1
-        best_match_s1s, best_match_s2s, best_match_names, best_match_strands = [], [], [], []
-        ref_aln_details = []
+        w = _Winners()
         for r, ref_name in enumerate(ref_names):
-            s1, s2, score, strand = per_read[k][r]
-            ref_aln_details.append((ref_name, s1, s2, score))
-            aln_scores.append(score)
-            # best reference: strictly better and above that reference's min_aln_score; equal score -> ambiguous (:697-707)
-            if score > best_match_score and score > refs[ref_name]['min_aln_score']:
-                best_match_score = score
-                best_match_s1s, best_match_s2s = [s1], [s2]
-                best_match_names, best_match_strands = [ref_name], [strand]
-            elif score == best_match_score:
-                best_match_s1s.append(s1)
-                best_match_s2s.append(s2)
-                best_match_names.append(ref_name)
-                best_match_strands.append(strand)
-        first_job = len(jobs)
-        if best_match_score > 0:
-            for idx, name in enumerate(best_match_names):
-                jobs.append((best_match_s1s[idx], best_match_s2s[idx]))
-                job_sets.append(ref_index[name])
-        chosen.append((aln_scores, ref_aln_details, best_match_score, best_match_s1s, best_match_s2s, best_match_names,
-                       best_match_strands, first_job))
+            aligned_read, aligned_ref, score, strand = per_read[k][r]
+            w.offer(ref_name, aligned_read, aligned_ref, score, refs[ref_name]['min_aln_score'], strand=strand)
+        picked.append((w, len(jobs)))
+        if w.aligned:
+            for name, a, f, _ in w.entries:
+                jobs.append((a, f))
+                job_sets.append(set_of[name])
     payloads = CRISPRessoCOREResources.find_indels_substitutions_batch(
         jobs, [refs[name]['include_idxs'] for name in ref_names], set_ids=np.array(job_sets, dtype=np.uint16),
         legacy=bool(args.use_legacy_insertion_quantification), ctx=ctx)
     variants = []
-    for k in range(len(fastq_seqs)):
-        aln_scores, ref_aln_details, best_match_score, best_match_s1s, best_match_s2s, best_match_names, best_match_strands, first_job = chosen[k]
-        new_variant = {'count': 1}
-        if best_match_score <= 0:                                  # not aligned: scores only (:767-773)
-            new_variant['aln_scores'] = aln_scores
-            new_variant['ref_aln_details'] = ref_aln_details
-            new_variant['best_match_score'] = best_match_score
-            variants.append(new_variant)
+    for w, first_job in picked:
+        result = {'count': 1}
+        if not w.aligned:                                          # not aligned: scores only (:767-773)
+            result['aln_scores'] = w.scores
+            result['ref_aln_details'] = w.details
+            result['best_match_score'] = w.top
+            variants.append(result)
             continue
-        new_variant['aln_ref_names'] = best_match_names
-        new_variant['aln_scores'] = aln_scores
-        new_variant['ref_aln_details'] = ref_aln_details
-        new_variant['best_match_score'] = best_match_score
-        class_names = []
-        for idx, best_match_name in enumerate(best_match_names):
-            s1, s2 = best_match_s1s[idx], best_match_s2s[idx]
-            payload = payloads[first_job + idx]                    # find_indels_substitutions[_legacy](s1, s2, include_idxs), :721-724
-            payload['ref_name'] = best_match_name
-            payload['aln_scores'] = aln_scores
-            payload['irregular_ends'] = bool(s1[0] == '-' or s2[0] == '-' or s1[0] != s2[0]
-                                             or s1[-1] == '-' or s2[-1] == '-' or s1[-1] != s2[-1])          # :729-733
-            payload['insertions_outside_window'] = int((len(payload['all_insertion_positions']) / 2) - (len(payload['insertion_positions']) / 2))
-            payload['deletions_outside_window'] = len(payload['all_deletion_coordinates']) - len(payload['deletion_coordinates'])
-            payload['substitutions_outside_window'] = len(payload['all_substitution_positions']) - len(payload['substitution_positions'])
-            payload['total_mods'] = int((len(payload['all_insertion_positions']) / 2) + len(payload['all_deletion_positions']) + len(payload['all_substitution_positions']))
-            payload['mods_in_window'] = payload['substitution_n'] + payload['deletion_n'] + payload['insertion_n']
-            payload['mods_outside_window'] = payload['total_mods'] - payload['mods_in_window']
-            is_modified = False                                    # :746-760 (the elif chain only matters for which test fires first)
-            if not args.ignore_deletions and payload['deletion_n'] > 0:
-                is_modified = True
-            elif not args.ignore_insertions and payload['insertion_n'] > 0:
-                is_modified = True
-            elif not args.ignore_substitutions and payload['substitution_n'] > 0:
-                is_modified = True
-            class_names.append(best_match_name + ("_MODIFIED" if is_modified else "_UNMODIFIED"))
-            payload['classification'] = 'MODIFIED' if is_modified else 'UNMODIFIED'
-            payload['aln_seq'] = s1
-            payload['aln_ref'] = s2
-            payload['aln_strand'] = best_match_strands[idx]
-            new_variant['variant_' + best_match_name] = payload
-            new_variant['best_match_name'] = best_match_name
-        new_variant['class_name'] = "&".join(class_names)
-        if len(best_match_names) > 1:                              # ambiguous alignments (:779-785)
-            if args.assign_ambiguous_alignments_to_first_reference:
-                new_variant['class_name'] = class_names[0]
-                new_variant['aln_ref_names'] = [best_match_names[0]]
-            elif not args.expand_ambiguous_alignments:
-                new_variant['class_name'] = 'AMBIGUOUS'
-        if getattr(args, 'prime_editing_pegRNA_scaffold_seq', '') and 'Prime-edited' in best_match_names:   # :789-796
-            loc = new_variant['variant_Prime-edited']['ref_positions'].index(pe_scaffold_dna_info[0] - 1) + 1
-            if new_variant['variant_Prime-edited']['aln_seq'][loc:(loc + len(pe_scaffold_dna_info[1]))] == pe_scaffold_dna_info[1]:
-                new_variant['aln_ref_names'] = ["Scaffold-incorporated"]
-                new_variant['class_name'] = "Scaffold-incorporated"
-                old_payload = deepcopy(new_variant['variant_Prime-edited'])
-                old_payload['ref_name'] = "Scaffold-incorporated"
-                new_variant['variant_' + "Scaffold-incorporated"] = old_payload
-        variants.append(new_variant)
+        result['aln_ref_names'] = w.names()
+        result['aln_scores'] = w.scores
+        result['ref_aln_details'] = w.details
+        result['best_match_score'] = w.top
+        labels = []
+        for q, (name, a, f, strand) in enumerate(w.entries):
+            payload = payloads[first_job + q]                      # find_indels_substitutions[_legacy](aligned read, aligned reference, include_idxs), :721-724
+            labels.append(_complete_payload(payload, args, name, a, f, w.scores))
+            payload['aln_strand'] = strand
+            result['variant_' + name] = payload
+            result['best_match_name'] = name
+        _settle_read(result, labels, w, args, pe_scaffold_dna_info)
+        variants.append(result)
     return variants
 
 

@@ -434,7 +434,9 @@ def test_banded_pointer_plane_equals_full_plane(mats, ctx):
     # every tier certifies most of what it gets and hands the rest down; the last banded tier is the same in all chains
     assert len(tiers["diag1"]) == 1 and len(tiers["diag2"]) == 2 and len(tiers["auto"]) == 3
     assert n // 2 > tiers["auto"][0] > tiers["auto"][1] >= tiers["auto"][2] > 0
-    assert tiers["auto"][1:] == tiers["diag2"] and tiers["diag2"][1:] == tiers["diag1"]
+    # (round 5: in the default chain the partition sends the reads that match the reference nowhere straight to the LAST list, so the list behind
+    #  its second tier is shorter than the 32-bit chain's; what reaches the full-matrix launch is the same)
+    assert tiers["auto"][2:] == tiers["diag2"][1:] and tiers["auto"][1] <= tiers["diag2"][0] and tiers["diag2"][1:] == tiers["diag1"]
 
 
 def test_count_vectors_device_vs_reference_aggregation(mats, ctx):
