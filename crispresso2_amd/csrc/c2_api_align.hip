@@ -691,7 +691,8 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         desc[r].gap_incentive = (const int32_t*)(base + off_g[r]);
         desc[r].inc_prefix = (const uint16_t*)(base + off_p[r]);
         desc[r].len = lens[r];
-        desc[r].diag_rows = nullptr; desc[r].pk_ok = 0; desc[r].reserved1 = 0;
+        desc[r].diag_rows = nullptr; desc[r].pk_ok = 0; desc[r].first_incentive_pos = -1;
+        for (int i = 0; i <= lens[r]; ++i) if (gap_incentives[r][i] > 0) { desc[r].first_incentive_pos = i; break; }
         int64_t gm = 0;                                          // over the values the kernels add: the reference's C ints
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)(int32_t)gap_incentives[r][k]);
         desc[r].gap_incentive_max = (int32_t)std::min<int64_t>(gm, 1 << 20);

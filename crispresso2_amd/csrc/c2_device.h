@@ -42,7 +42,7 @@ typedef struct c2_dev_ref {
     int32_t gap_incentive_last_pos; // gap_incentive[Li] > 0: insertions along the last row collect an incentive without paying an open
     int32_t max_char;             // largest byte of seq (a read character >= the matrix dimension is defined iff max_char * dim + it < dim * dim)
     int32_t pk_ok;                // admitted to the int16 fill of c2_align_diagp_kernel (c2_pk_eligible); its packed row table sits at the same index in diagpk_base
-    int32_t reserved1;
+    int32_t first_incentive_pos;  // smallest i with gap_incentive[i] > 0 (the cut site the caller marked), -1: none.  A hint for c2_align_partition_kernel only
 } c2_dev_ref;
 
 // Kernel arguments for the fused align + traceback + classify kernel.

@@ -50,7 +50,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = g32[r].data(); refs[r].inc_prefix = incp[r].data();
         c2_build_diag_rows(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows[r]);
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
-        refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 126)) ? 1 : 0; refs[r].reserved1 = 0;
+        refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 126)) ? 1 : 0; refs[r].first_incentive_pos = -1;
+        for (int i = 0; i <= lens[r]; ++i) if (g32[r][i] > 0) { refs[r].first_incentive_pos = i; break; }
         if (refs[r].pk_ok) any_pk = true;
         refs[r].len = lens[r];
         int64_t gm = 0;

@@ -753,7 +753,7 @@ def test_all_references_batch_goes_through_the_partition_and_pairs_by_reference(
         assert r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k
         check_record(r, oracle.find_indels_substitutions(s1, s2, incs[ri]), s1, s2)
     assert sum(st["classes"]) == 3 * len(reads), st["classes"]       # the partition ran over every task ...
-    assert st["classes"][0] >= 100, st["classes"]                     # ... reads against the amplicon they derive from (and the same-length one) are main-diagonal candidates
+    assert st["classes"][0] >= 60, st["classes"]                      # ... reads against the amplicon they derive from are main-diagonal candidates (not those against the 12-base replacement: the look at the cut site)
     assert st["unpaired"] <= 24, st["unpaired"]                       # a pair breaks only where a list passes from one reference to the next
     os.environ["C2_NO_ALLREFS_PARTITION"] = "1"
     try:
