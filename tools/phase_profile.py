@@ -19,12 +19,19 @@ def main():
     ap.add_argument("--band", type=int, default=-1)
     ap.add_argument("--band-wgs", type=int, default=0)
     ap.add_argument("--kernel", default="auto", help="auto | diag2 | diag1 | band | full")
+    ap.add_argument("--only-gapped", action="store_true", help="keep only the reads whose last 32 columns differ from the amplicon's in more than 6 places "
+                                                                  "(an indel in front of them): every task is traced -- the epilogue's share of the band tiers")
     a = ap.parse_args()
     from crispresso2_amd import synth, _native, CRISPResso2Align as A
     from crispresso2_amd.batch import BatchAligner
     import torch
     amp, g, inc = synth.amplicon_setup(a.L)
     reads = synth.make_reads(a.L, a.reads)
+    if a.only_gapped:
+        ampb = np.frombuffer(amp.encode(), dtype=np.uint8)
+        keep = (reads[:, -32:] != ampb[None, -32:]).sum(axis=1) > 6
+        reads = np.ascontiguousarray(reads[keep])
+        a.reads = len(reads)
     ctx = _native.Context(0)
     ctx.set_band(a.band, a.band_wgs)
     ctx.set_kernel_mode(a.kernel)
