@@ -85,7 +85,8 @@ const void* pk_kernel(int na, bool add32) {
     }
 }
 
-int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
+// n_tasks: the batch's size if the caller has one (0: a per-call alignment, or an information request)
+int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
     if (!ctx->have_scoring || ctx->n_refs <= 0) { ctx->err = "scoring and references must be set first"; return C2_E_STATE; }
     g.R = c2_choose_rows_per_lane(ctx->max_li);
     g.passes = (ctx->max_li + 64 * g.R - 1) / (64 * g.R);
@@ -105,7 +106,22 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g) {
             return C2_E_TOO_LARGE;
         }
         if ((rc = occupancy_r<2>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
-    } else if ((rc = occupancy_r<0>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
+    } else {
+        if ((rc = occupancy_r<0>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
+        // Round 5: the plane of a 250 x 250 alignment fits LDS (33 KB) -- but then four workgroups share a CU, one wavefront per SIMD, and the sweep
+        // waits for its own dependent chain: 71 ns per alignment.  With the plane in HBM scratch (one 128-byte line per step) LDS holds the O(Li + Lj)
+        // parts only, the registers allow four wavefronts per SIMD, and the same launch takes 35 ns per alignment (measured: the reads that match their
+        // amplicon nowhere, which every band tier hands on to this launch, are 5 % of a real run).  A batch takes that plan whenever it puts more
+        // workgroups on a CU; a single alignment (the per-call API) keeps the plane in LDS.  C2_FULL_PLANE_IN_LDS=1: as before.
+        if (n_tasks >= 4096 && !getenv("C2_FULL_PLANE_IN_LDS")) {
+            const uint32_t lds_h = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes, 0, true).total;
+            const uint64_t words_h = (c2_hbm_plane_halfwords(g.max_lj, g.passes) + 1) / 2;
+            int blocks_h = 0;
+            if (lds_h <= lds_cu && words_h <= 0xFFFFFFFFull && !(rc = occupancy_r<2>(ctx, g.R, lds_h, blocks_h)) && blocks_h > g.blocks_full) {
+                g.full_hbm = true; g.lds_full = lds_h; g.full_plane_words = words_h; g.blocks_full = blocks_h;
+            }
+        }
+    }
     // Diagonal-band first launch (c2_align_diag_kernel): needs the packed score rows and a negative per-gap-base bound
     g.diag = false; g.lds_diag = 0; g.blocks_diag = 0;
     for (int t = 0; t < 2; ++t) { g.x[t] = false; g.lds_x[t] = 0; g.blocks_x[t] = 0; }
@@ -536,7 +552,7 @@ int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
 
 int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     Geometry g;
-    int rc = geometry(ctx, max_lj, g);
+    int rc = geometry(ctx, max_lj, g, b->n_reads * (uint64_t)(b->all_refs ? std::max(ctx->n_refs, 1) : 1));
     if (rc) return rc;
     if (b->n_reads == 0) return 0;
     if ((rc = refresh_diag_rows(ctx, s))) return rc;

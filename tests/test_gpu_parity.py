@@ -1315,3 +1315,45 @@ def test_partition_routing_changes_no_result(mats, ctx, monkeypatch, L):
         T = int(records["aln_len"][i])
         s1, s2, _ = oracle.global_align(reads[i], amp, m, g, -20, -2)
         assert outs[0][0][i, :T].tobytes().decode() == s1 and outs[0][1][i, :T].tobytes().decode() == s2, (i, reads[i])
+
+
+@pytest.mark.gpu
+def test_ragged_and_unrelated_reads_and_the_full_matrix_launch_with_its_plane_in_hbm(mats, ctx, monkeypatch):
+    """Round 5, inputs that are not the generator's best case: 6,000 reads cut to lengths U[200, 250], every tenth one replaced by a random sequence,
+    against the 250-bp amplicon through the default chain of a BATCH (>= 4,096 tasks: the full-matrix launch keeps its pointer plane in HBM scratch,
+    four wavefronts per SIMD instead of one).  The partition orders the chunks by read length and sends the unrelated reads straight to the last
+    list (class 5).  A sample of every kind against the oracle; and every byte equal to the same batch with the three knobs turned the other way
+    (plane in LDS, task order, no direct route) -- results never depend on them."""
+    import torch
+    from crispresso2_amd import synth
+    from crispresso2_amd.batch import BatchAligner
+    import oracle
+    m = mats["EDNAFULL"]
+    L, n = 250, 6000
+    amp, g, inc = synth.amplicon_setup(L)
+    rng = np.random.default_rng(2025)
+    base = synth.make_reads(L, n)
+    reads = []
+    for k in range(n):
+        s = base[k].tobytes().decode()[:int(rng.integers(200, L + 1))]
+        if k % 10 == 7:
+            s = "".join(rng.choice(list("ACGT"), len(s)))
+        reads.append(s)
+    al = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
+    res = al.align(reads)
+    part = ctx.partition_info()
+    tiers = ctx.tier_info()
+    assert part["ran"] and sum(part["classes"]) == n and 500 <= part["classes"][5] <= 600, part
+    assert tiers[-1] >= part["classes"][5]                             # they sit in the list the full-matrix launch reads
+    assert (res.records["status"] == 0).all()
+    for k in list(range(0, n, 37)) + list(range(7, n, 310)):
+        st, s1, s2, mt, ln = oracle.global_align_raw(reads[k], amp, m, g, -20, -2)
+        assert st == 0 and res.strings(k) == (s1, s2) and int(res.records["matches"][k]) == mt, k
+        p = oracle.find_indels_substitutions(s1, s2, inc)
+        r = res.records[k]
+        assert (r["insertion_n"], r["deletion_n"], r["substitution_n"]) == (p["insertion_n"], p["deletion_n"], p["substitution_n"]), k
+    for knob in ("C2_FULL_PLANE_IN_LDS", "C2_NO_LENGTH_ORDER", "C2_NO_DIRECT_FULL"):
+        monkeypatch.setenv(knob, "1")
+        other = al.align(reads)
+        monkeypatch.delenv(knob)
+        assert np.array_equal(other.records, res.records) and np.array_equal(other.aln_read, res.aln_read) and np.array_equal(other.aln_ref, res.aln_ref), knob
