@@ -94,6 +94,8 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
     const size_t lds_cu = 163840;
     g.lds_full = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes, 0).total;
     g.full_hbm = false; g.full_plane_words = 0;
+    bool hbm_by_choice = false;                                    // (the plane would fit LDS: the banded row-strip launch in front is still possible)
+    int blocks_full_lds = 0;                                       // workgroups per CU of the full launch with its plane in LDS
     int rc;
     if (g.lds_full > lds_cu || getenv("C2_FORCE_HBM_PLANE")) {
         // the full pointer plane does not fit LDS: it goes to per-workgroup scratch in HBM, LDS keeps the O(Li + Lj) parts
@@ -108,6 +110,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
         if ((rc = occupancy_r<2>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
     } else {
         if ((rc = occupancy_r<0>(ctx, g.R, g.lds_full, g.blocks_full))) return rc;
+        blocks_full_lds = g.blocks_full;
         // Round 5: the plane of a 250 x 250 alignment fits LDS (33 KB) -- but then four workgroups share a CU, one wavefront per SIMD, and the sweep
         // waits for its own dependent chain: 71 ns per alignment.  With the plane in HBM scratch (one 128-byte line per step) LDS holds the O(Li + Lj)
         // parts only, the registers allow four wavefronts per SIMD, and the same launch takes 35 ns per alignment (measured: the reads that match their
@@ -119,6 +122,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
             int blocks_h = 0;
             if (lds_h <= lds_cu && words_h <= 0xFFFFFFFFull && !(rc = occupancy_r<2>(ctx, g.R, lds_h, blocks_h)) && blocks_h > g.blocks_full) {
                 g.full_hbm = true; g.lds_full = lds_h; g.full_plane_words = words_h; g.blocks_full = blocks_h;
+                hbm_by_choice = true;
             }
         }
     }
@@ -207,7 +211,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
     // a CU (the DP is latency-bound at one wave per SIMD).  band: -1 auto, 0 off, >0 lanes on each side.
     g.band_lanes = 0; g.lds_band = 0; g.blocks_band = 0;
     int want = ctx->kernel_mode == 2 ? 0 : ctx->band_setting;
-    if (!g.diag && g.passes == 1 && want != 0 && !g.full_hbm) {
+    if (!g.diag && g.passes == 1 && want != 0 && (!g.full_hbm || hbm_by_choice)) {
         if (want < 0) {
             // auto: the widest band whose plan still lets `band_target_wgs` workgroups share a CU's LDS
             want = 0;
@@ -218,7 +222,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
             g.band_lanes = want;
             g.lds_band = c2_make_plan(g.R, g.max_lj, 1, ctx->sc.n_codes, want).total;
             if ((rc = occupancy_r<1>(ctx, g.R, g.lds_band, g.blocks_band))) return rc;
-            if (g.blocks_band <= g.blocks_full) g.band_lanes = 0;      // no occupancy to gain
+            if (g.blocks_band <= (hbm_by_choice ? blocks_full_lds : g.blocks_full)) g.band_lanes = 0;      // no occupancy to gain
         }
     }
     return 0;
