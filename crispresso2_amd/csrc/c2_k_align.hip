@@ -1515,7 +1515,7 @@ __device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g
     }
 }
 
-#define C2X_GRAB 8                                  // groups of NA positions per grab of the work counter
+#define C2X_GRAB 8                                  // groups of NA positions per grab of the work counter, at most
 template <int NA, bool PK, bool ADD32 = false, bool SCORE = false>
 __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
 {
@@ -1593,6 +1593,10 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
     // partition writes a chunk's tasks reference-major, class by class), and a workgroup that walks 8 consecutive groups re-stages the reference
     // of its lane groups once where it did for every group -- with three candidate amplicons the score-only launch spent two thirds of its time
     // there (5.8 ns per task against 1.6 with one amplicon).  One atomic per block instead of one per group.
+    // (a block is C2X_GRAB groups when the launch has work for at least four blocks per workgroup, fewer for a short list: a million-task batch
+    //  over 2,300 workgroups in blocks of 128 tasks left some of them with three blocks and some with two)
+    int grab = (int)(n_iter / ((uint64_t)gridDim.x * (uint64_t)(NA * 4)));
+    grab = grab < 1 ? 1 : (grab > C2X_GRAB ? C2X_GRAB : grab);
     unsigned long long blk_next = 0;                                // next position of the current block (wave-uniform)
     int blk_left = 0;                                               // groups of it not handed out yet
     bool pend_atomic = false;
@@ -1742,7 +1746,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             const uint64_t base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pend >> 32)) << 32) |
                                   (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pend & 0xffffffffull));
             const uint64_t it = base + (uint64_t)lane;
-            if (pend_atomic) { blk_next = base + (uint64_t)NA; blk_left = C2X_GRAB - 1; }
+            if (pend_atomic) { blk_next = base + (uint64_t)NA; blk_left = grab - 1; }
             if (base >= n_iter) { exhausted = true; blk_left = 0; }
             if (lane < NA && it < n_iter) {
                 if (pair_order) {
@@ -1756,7 +1760,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
         pend = 0; pend_valid = false;
         if (!exhausted) {
             if (blk_left > 0) { pend = blk_next; blk_next += (uint64_t)NA; --blk_left; pend_atomic = false; }
-            else { if (lane == 0) pend = atomicAdd(A.work_counter, (unsigned long long)(NA * C2X_GRAB)); pend_atomic = true; }
+            else { if (lane == 0) pend = atomicAdd(A.work_counter, (unsigned long long)(NA * grab)); pend_atomic = true; }
             pend_valid = true;
         }
         __syncthreads();
