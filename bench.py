@@ -64,7 +64,7 @@ VALU_SIMD32_WAVE_INSTR_PER_S = N_SIMD * CLOCK_HZ / 2.0
 VALU_MEASURED_CYCLES_PER_INSTR = 4.15
 VALU_FULL_RATE_CYCLES_PER_INSTR = 2.3
 VALU_MEASURED_SOURCE = "profiles/r03/valu_microbench4.txt (tools/valu_microbench4.hip, cycles from GRBM_GUI_ACTIVE; clock 2.40 GHz)"
-PROFILE_ROUNDS = ["r04", "r03", "r02"]                 # the PMC summary of the newest round that has one
+PROFILE_ROUNDS = ["r05", "r04", "r03", "r02"]                 # the PMC summary of the newest round that has one
 GO, GE, MIN_ALN_SCORE = -20, -2, 60.0
 
 CONFIG_DEFAULTS = {2: (150, 1_000_000), 3: (250, 10_000_000), 4: (250, 10_000_000), 5: (250, 12_500_000)}
@@ -528,8 +528,8 @@ def _e2e_prepare(reads, workers, bgzf=True):
         except OSError:
             continue
         m = n
-        if free < 1.9 * per * n:                                  # (the FASTQ, its BGZF copy, and the result tables of the with_all_tables leg)
-            m = int(free / (1.9 * per))
+        if free < 2.2 * per * n:                                  # (the FASTQ, its BGZF and gzip copies, and the result tables of the with_all_tables legs)
+            m = int(free / (2.2 * per))
             m -= m % 1000
         if m < min(n, 100_000):
             continue
@@ -541,7 +541,12 @@ def _e2e_prepare(reads, workers, bgzf=True):
             b1 = synth.write_fastq(reads[:m], plain)
             t1 = time.perf_counter()
             b2 = synth.write_bgzf(plain, bgzf_path, workers=workers) if bgzf else 0
-            return dict(dir=d, plain=plain, bgzf=bgzf_path if bgzf else None, reads=m, bytes_plain=b1, bytes_bgzf=b2, write_plain_s=t1 - t0, write_bgzf_s=time.perf_counter() - t1)
+            t2 = time.perf_counter()
+            # an ordinary single-member .gz of the same text (what `gzip -6` gives: ONE deflate stream; the reference opens it with gzip.open, CRISPRessoCORE.py:1820-1823)
+            gz_path = os.path.join(d, "reads.fastq.gz")
+            b3 = synth.write_gzip_member(plain, gz_path, workers=workers, level=6) if bgzf else 0
+            return dict(dir=d, plain=plain, bgzf=bgzf_path if bgzf else None, gzip=gz_path if bgzf else None, reads=m, bytes_plain=b1, bytes_bgzf=b2, bytes_gzip=b3,
+                        write_plain_s=t1 - t0, write_bgzf_s=t2 - t1, write_gzip_s=time.perf_counter() - t2)
         except OSError:
             if d:
                 shutil.rmtree(d, ignore_errors=True)
@@ -558,10 +563,14 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
                            ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
                            assign_ambiguous_alignments_to_first_reference=False, expand_ambiguous_alignments=False, discard_indel_reads=False)
     ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=MIN_ALN_SCORE)
-    out = {"reads": files["reads"], "file_bytes": files["bytes_plain"], "file_bytes_bgzf": files["bytes_bgzf"],
-           "file_system": os.path.dirname(files["dir"]), "write_seconds_not_timed": {"plain": files["write_plain_s"], "bgzf": files["write_bgzf_s"]}}
+    out = {"reads": files["reads"], "file_bytes": files["bytes_plain"], "file_bytes_bgzf": files["bytes_bgzf"], "file_bytes_gzip": files.get("bytes_gzip"),
+           "file_system": os.path.dirname(files["dir"]),
+           "write_seconds_not_timed": {"plain": files["write_plain_s"], "bgzf": files["write_bgzf_s"], "gzip": files.get("write_gzip_s")}}
     tallies = {}
-    for kind, path in (("plain", files["plain"]), ("plain_host_parser", files["plain"]), ("bgzf", files["bgzf"]), ("bgzf_host_parser", files["bgzf"])):
+    kinds = [("plain", files["plain"]), ("plain_host_parser", files["plain"]), ("bgzf", files["bgzf"]), ("bgzf_host_parser", files["bgzf"])]
+    if files.get("gzip"):
+        kinds.append(("gzip", files["gzip"]))                        # single member: ONE inflate stream on the host (libdeflate whole-buffer), then the device frames the text
+    for kind, path in kinds:
         # plain: the text is uploaded as it is and framed + de-duplicated by the c2_fq_* kernels (fastq_device); bgzf: the host inflates
         # (all usable threads) and the same kernels frame the text it then holds; *_host_parser: the same files through the native host
         # parser (what text with carriage returns uses), for comparison
@@ -585,6 +594,8 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
         # it); the host-parser routes upload the unique reads' arena + offsets + multiplicities.  Results coming back are kilobytes.
         if kind.endswith("_host_parser"):
             link_bytes = None
+        elif kind == "gzip":
+            link_bytes = files["bytes_plain"]                         # (the host inflates; the text crosses the link)
         else:
             link_bytes = files["bytes_plain"]
         out[kind] = {"seconds": dt, "reads_per_s": files["reads"] / dt, "seconds_all_runs": [r[0] for r in runs], "stage_seconds": tm,
@@ -666,6 +677,11 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
     out["reads_per_s"] = out["plain"]["reads_per_s"]
     out["stage_seconds"] = out["plain"]["stage_seconds"]
     out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"] == tallies["plain_host_parser"] == tallies["bgzf_host_parser"]
+    if "gzip" in tallies:
+        out["plain_equals_gzip"] = tallies["plain"] == tallies["gzip"]
+        out["gzip"]["note"] = ("an ordinary single-member .gz (one deflate stream, level 6): the host inflates it on ONE thread (libdeflate into one buffer; a single "
+                               "stream cannot be split without speculative decoding, which is not built), then the text is uploaded and framed on the device like "
+                               "the plain file's; BGZF input inflates on all threads")
     out["tallies"] = dict(zip(("N_TOT_READS", "N_TOTAL", "counts_total", "modified", "with_insertion", "with_deletion", "with_substitution"),
                               tallies["plain"]))
     out["note"] = ("pipeline.quantify_fastq on the headline's reads as a FASTQ file (qualities 'I'), page cache warm: ingest + exact "
@@ -990,7 +1006,7 @@ def main():
         with open(pmc_path) as fh:
             pj = json.load(fh)
         pmc = pj["kernels"].get(dominant)
-        pmc_reads = float(pj.get("reads", 2.0e6))
+        pmc_reads = float(pj.get("reads", 2.0e6))                    # (files of rounds 2-4 have no "reads" key: their passes ran over 2 M reads)
         pmc_rel = os.path.relpath(pmc_path, ROOT)
         if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / pmc_reads * n      # bytes per launch of n alignments
@@ -1080,6 +1096,7 @@ def main():
                        "e2e_sharded_shard_bytes_per_rank": None if not e2e or "sharded" not in e2e or not e2e["sharded"].get("per_rank") else
                                                            [None if sh is None else sh.get("shard_bytes") for sh in e2e["sharded"]["per_rank"]],
                        "host_batch_pcie_inclusive_reads_per_s": None if not host_batch else host_batch.get("reads_per_s"),
+                       "e2e_gzip_single_member_reads_per_s": None if not e2e or "gzip" not in e2e else e2e["gzip"].get("reads_per_s"),
                        "e2e_frac_of_link_peak": None if not e2e or "plain" not in e2e else e2e["plain"].get("frac_of_link_peak"),
                        "e2e_fastq_to_all_tables_seconds": None if not e2e or "with_all_tables" not in e2e else e2e["with_all_tables"]["seconds"],
                        "e2e_fastq_to_all_tables_reads_per_s": None if not e2e or "with_all_tables" not in e2e else e2e["with_all_tables"]["reads_per_s"]},

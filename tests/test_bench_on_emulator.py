@@ -130,6 +130,7 @@ def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fa
         assert e["chain_equals_full_plane"] and e["chain_equals_full_plane_n"] == 90 * k_ and e["all_status_ok"] and e["reads_per_s"] > 0
     e2e = out["e2e"]
     assert e2e["reads"] == 90 and e2e["plain_equals_bgzf"] and e2e["plain"]["reads_per_s"] > 0 and e2e["bgzf"]["reads_per_s"] > 0
+    assert e2e["plain_equals_gzip"] and e2e["gzip"]["reads_per_s"] > 0 and e2e["file_bytes_gzip"] > 100       # an ordinary single-member .gz of the same reads
     assert e2e["tallies"]["N_TOT_READS"] == 90 and set(e2e["stage_seconds"]) >= {"ingest_dedup_streamed", "stream_tail_device", "count_kernels"}
     wt = e2e["with_all_tables"]                                      # FASTQ -> every result table on disk, the allele table among them
     assert wt["files_written"] >= 18 and wt["allele_table_rows"] > 0 and wt["allele_table_zip_bytes"] > 100 and wt["alleles_around_cut_bytes"] > 100

@@ -46,7 +46,8 @@ def main():
                     e = pmc.setdefault(k, {})
                     e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
     with open(os.path.join(out, "pmc_summary_%s.json" % tag), "w") as fh:
-        json.dump({"note": "counter sums per kernel over ONE bench.py launch of 2,000,000 reads (separate --pmc passes)", "kernels": pmc},
+        reads = int(os.environ.get("C2_PMC_READS", "2000000"))       # (tools/profile_round.sh exports what it passed to bench.py --reads)
+        json.dump({"note": "counter sums per kernel over ONE bench.py launch of %d reads (separate --pmc passes)" % reads, "reads": reads, "kernels": pmc},
                   fh, indent=1, sort_keys=True)
     print(open(os.path.join(out, "kernel_stats_%s.csv" % tag)).read())
     print(json.dumps(pmc, indent=1, sort_keys=True))

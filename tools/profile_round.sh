@@ -11,6 +11,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+PMC_READS=${C2_PMC_READS:-2000000}; export C2_PMC_READS=$PMC_READS
 COMMON="--no-cpu-baseline --check 0 --no-dedup-leg --workers 1 --no-extras"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- \
     python "$ROOT/bench.py" --steps 3 --warmup 1 $COMMON "$@" > "$OUT/trace_bench.log" 2>&1
@@ -20,7 +21,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     timeout 300 rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc_$i" -o pmc -- \
-        python "$ROOT/bench.py" --reads 2000000 --steps 1 --warmup 0 $COMMON "$@" > "$OUT/pmc_$i.log" 2>&1
+        python "$ROOT/bench.py" --reads $PMC_READS --steps 1 --warmup 0 $COMMON "$@" > "$OUT/pmc_$i.log" 2>&1
     i=$((i + 1))
 done
 python "$ROOT/tools/pmc_summary.py" "$OUT" "$TAG"
