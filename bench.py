@@ -965,6 +965,8 @@ def main():
                             "c2_align_diag_kernel" if (os.environ.get("C2_NO_PACKED_TIER2") or os.environ.get("C2_NO_PACKED_TIER3")) else "c2_align_diagp_kernel<2" + pkv],
                    "diag4": ["c2_align_diagx_kernel<4>", "c2_align_diagx_kernel<2>", "c2_align_diag_kernel"],
                    "diag2": ["c2_align_diagx_kernel<2>", "c2_align_diag_kernel"], "diag1": ["c2_align_diag_kernel"]}
+    if len(tiers) == 4 and args.kernel == "auto":                  # (behind the partition: the 40-diagonal tier between the first two)
+        chain_names["auto"].insert(1, "c2_align_diagp_kernel<6" + pkv)
     if os.environ.get("C2_NO_PACKED_FILL"):
         chain_names["auto"] = chain_names["diag4"]
     chain = ((chain_names.get(args.kernel, ["c2_align_diag_kernel"])[-len(tiers):] if band["band_lanes"] < 0 else
@@ -992,7 +994,9 @@ def main():
     if part_info and part_info["ran"]:
         cls_, fin_p = part_info["classes"], part_info["finished"]
         in_first = cls_[2] + (cls_[0] - fin_p[0]) + (cls_[1] - fin_p[1])
-        left_first = max(0, left_first - cls_[3] - (cls_[4] if len(tiers) < 3 else 0))
+        # (the list behind the first tier also holds what the partition sent straight to the launch that reads it: the 40-diagonal tier's class when
+        #  the chain has that tier -- four band tiers --, else the 62-diagonal tier's, else the 128-diagonal one's)
+        left_first = max(0, left_first - cls_[{4: 3, 3: 4, 2: 5}.get(len(tiers), 3)])
     done_first = in_first - left_first
     alg_first = int(bytes_in * (in_first / float(n_tasks))) + int(bytes_out * (done_first / float(n_tasks)))
     achieved_gbs = alg_first / avg_first_s / 1e9 if avg_first_s > 0 else 0.0
@@ -1202,9 +1206,9 @@ def main():
                 if part_c and part_c.get("ran"):
                     # which launch sees a task FIRST (c2_align_partition_kernel's classes) and what each tier hands on: the tier shares of this input
                     cls_ = part_c["classes"]
-                    entry["first_launch_share"] = {"score_only": cls_[0] / float(jc.n_tasks), "tier1_32_diagonals": (cls_[1] + cls_[2]) / float(jc.n_tasks),
-                                                   "tier2_62_diagonals": cls_[3] / float(jc.n_tasks), "tier3_128_diagonals": cls_[4] / float(jc.n_tasks),
-                                                   "full_matrix": (cls_[5] if len(cls_) > 5 else 0) / float(jc.n_tasks)}
+                    entry["first_launch_share"] = {"score_only": cls_[0] / float(jc.n_tasks), "band_32_diagonals": (cls_[1] + cls_[2]) / float(jc.n_tasks),
+                                                   "band_40_diagonals": cls_[3] / float(jc.n_tasks), "band_62_diagonals": cls_[4] / float(jc.n_tasks),
+                                                   "band_128_diagonals": cls_[5] / float(jc.n_tasks), "full_matrix": cls_[6] / float(jc.n_tasks)}
                     entry["score_only_finished_share"] = part_c["finished"][0] / float(jc.n_tasks)
                 entry["full_plane_launch_share"] = (tiers_c[-1] / float(jc.n_tasks)) if tiers_c else None
                 if ref_leg is not None:

@@ -319,10 +319,10 @@ class Context:
         return bool(ran.value), int(t.value), int(f.value)
 
     def partition_info(self):
-        """-> {"ran", "p16", "classes": tasks per class [score-only, 14 diagonals, tier 1, tier 2, tier 3, full matrix], "finished": [score-only, 14 diagonals]}
-        of the most recent batch (c2_partition_info)"""
+        """-> {"ran", "p16", "classes": tasks per class [score-only, 14 diagonals (opt-in), 32 diagonals, 40, 62, 126/128, full matrix],
+        "finished": [score-only, 14 diagonals]} of the most recent batch (c2_partition_info)"""
         ran = ctypes.c_int32(0)
-        cls, fin = (ctypes.c_int64 * 6)(), (ctypes.c_int64 * 2)()
+        cls, fin = (ctypes.c_int64 * 7)(), (ctypes.c_int64 * 2)()
         self.check(self.lib.c2_partition_info(self.handle, ctypes.byref(ran), cls, fin), "c2_partition_info")
         return {"ran": bool(ran.value & 1), "p16": bool(ran.value & 2), "classes": [int(x) for x in cls], "finished": [int(x) for x in fin]}
 

@@ -19,6 +19,7 @@ struct Geometry {
     bool pk; uint32_t lds_pk; int blocks_pk; uint32_t plane_words_pk;      // packed first tier (8 per wavefront, int16) in place of the 4-per-wavefront one
     bool pk2; uint32_t lds_pk2; int blocks_pk2; uint32_t plane_words_pk2;  // packed second tier (4 per wavefront, 62 diagonals) in place of the 2-per-wavefront one
     bool pk3; uint32_t lds_pk3; int blocks_pk3; uint32_t plane_words_pk3;  // packed third tier (2 per wavefront, 128 diagonals) in front of c2_align_diag_kernel
+    bool pk6; uint32_t lds_pk6; int blocks_pk6; uint32_t plane_words_pk6;  // round 5: a packed tier of 40 diagonals (6 per wavefront: three lane groups of 21 lanes) between the first two
 };
 
 template <int R, int BAND>          // (the kernel's MODE: 0 full plane in LDS, 1 banded, 2 full plane in HBM)
@@ -80,6 +81,7 @@ const void* pk_kernel(int na, bool add32) {
     switch (na) {
         case 16: return add32 ? (const void*)c2_align_diagp_kernel<16, true> : (const void*)c2_align_diagp_kernel<16, false>;
         case 8: return add32 ? (const void*)c2_align_diagp_kernel<8, true> : (const void*)c2_align_diagp_kernel<8, false>;
+        case 6: return add32 ? (const void*)c2_align_diagp_kernel<6, true> : (const void*)c2_align_diagp_kernel<6, false>;
         case 4: return add32 ? (const void*)c2_align_diagp_kernel<4, true> : (const void*)c2_align_diagp_kernel<4, false>;
         default: return add32 ? (const void*)c2_align_diagp_kernel<2, true> : (const void*)c2_align_diagp_kernel<2, false>;
     }
@@ -133,6 +135,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
     g.pk = false; g.lds_pk = 0; g.blocks_pk = 0; g.plane_words_pk = 0;
     g.pk2 = false; g.lds_pk2 = 0; g.blocks_pk2 = 0; g.plane_words_pk2 = 0;
     g.pk3 = false; g.lds_pk3 = 0; g.blocks_pk3 = 0; g.plane_words_pk3 = 0;
+    g.pk6 = false; g.lds_pk6 = 0; g.blocks_pk6 = 0; g.plane_words_pk6 = 0;
     const int km = ctx->kernel_mode;
     update_pk_eligibility(ctx);
     if ((km == 0 || km == 3 || km == 4 || km == 5) && !ctx->sc.pk.empty() && std::max(ctx->gap_open, ctx->gap_extend) + ctx->gmax < 0) {
@@ -172,6 +175,20 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
                 }
                 g.pk2 = true; g.lds_pk2 = P2.total; g.blocks_pk2 = ctx->occ_pk2_blocks; g.plane_words_pk2 = P2.n_words * 128u;   // 4 slots x 32 lanes
             }
+            // between the first two (round 5): six per wavefront, three lane groups of 21 lanes, 40 diagonals -- the band of a read that overhangs its
+            // amplicon at both ends (4 bases in front, 23 behind in the reference's own test data: 28 diagonals + margins), which the 32-diagonal tier
+            // cannot certify and the 62-diagonal tier fills at twice the cost.  No 32-bit twin: what it cannot pair goes on to the next tier.
+            // C2_NO_TIER40=1 leaves it out.
+            const c2_diagx_plan P6 = c2_make_diagx_plan(6, ctx->max_li, g.max_lj, true);
+            if (g.pk2 && P6.total <= lds_cu && !getenv("C2_NO_TIER40")) {
+                if (ctx->occ_pk6_lds != (int)P6.total * (ctx->pk_beta > 0 ? -1 : 1)) {
+                    int nb = 0;
+                    HIPCHK(ctx, hipFuncSetAttribute(pk_kernel(6, ctx->pk_beta > 0), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pk_kernel(6, ctx->pk_beta > 0), 64, P6.total));
+                    ctx->occ_pk6_blocks = nb < 1 ? 1 : nb; ctx->occ_pk6_lds = (int)P6.total * (ctx->pk_beta > 0 ? -1 : 1);
+                }
+                g.pk6 = true; g.lds_pk6 = P6.total; g.blocks_pk6 = ctx->occ_pk6_blocks; g.plane_words_pk6 = P6.n_words * 144u;   // 6 slots x 24 words (21 lanes rounded up)
+            }
             // third tier: two per wavefront, one lane group of 64 lanes (126 diagonals) in int16
             const c2_diagx_plan P3 = c2_make_diagx_plan(2, ctx->max_li, g.max_lj, true);
             if (g.pk2 && P3.total <= lds_cu && !getenv("C2_NO_PACKED_TIER3")) {
@@ -206,6 +223,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
         // run by c2_align_diag_kernel, which every diagonal chain has.)
         if (g.pk && !g.x[0]) g.pk = false;
         if (g.pk2 && !g.x[1]) g.pk2 = false;
+        if (!g.pk2) g.pk6 = false;
     }
     // Banded first launch: keep only the pointer words of the lanes near the main diagonal so that more workgroups fit
     // a CU (the DP is latency-bound at one wave per SIMD).  band: -1 auto, 0 off, >0 lanes on each side.
@@ -293,7 +311,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
         // tasks a packed kernel could not pair (run by the 32-bit kernel of the same band), [16 + 2l ..] work counter of launch l --
         // then eight task lists: one per band tier (c2_align_partition_kernel writes into the lists of LATER tiers, so they cannot share
         // buffers), the unpaired tasks', the score-only launch's, the first tier's when the partition ran, the 14-diagonal launch's
-        // (header words 48..53: tasks per class of the partition, 56 / 57: length of the first tier's list after the score-only launch and after
+        // (header words 48..54: tasks per class of the partition, 56 / 57: length of the first tier's list after the score-only launch and after
         //  the 14-diagonal launch, 60 / 62 / 61: lengths of the score-only launch's list, the 14-diagonal launch's, the first tier's)
         const size_t list_words = (size_t)A.n_tasks;
         if ((rc = ensure(ctx, ctx->d_fb, 256 + 8 * list_words * sizeof(uint32_t)))) return rc;
@@ -325,6 +343,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 if (g.pk) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk * g.plane_words_pk);
                 if (g.pk2) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk2 * g.plane_words_pk2);
                 if (g.pk3) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk3 * g.plane_words_pk3);
+                if (g.pk6) most = std::max<uint64_t>(most, cus * (uint64_t)g.blocks_pk6 * g.plane_words_pk6);
                 if (g.full_hbm) most = std::max<uint64_t>(most, hbm_plane_wgs(ctx, g, A.n_tasks) * g.full_plane_words);
                 if (most && (rc = ensure(ctx, ctx->d_plane, (size_t)most * sizeof(uint32_t)))) return rc;
             }
@@ -345,25 +364,29 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
             bool score_stage = g.pk && !(many_refs && (A.n_refs > 64 || getenv("C2_NO_ALLREFS_PARTITION"))) && !getenv("C2_NO_SCORE_TIER") &&
                                ctx->kernel_mode == 0 && tier_can_serve(ctx, 32, min_lj, A.max_lj);
             bool p16_stage = false;
+            bool tier40_runs = false;                                    // (only behind the partition: without its routing every task the first tier leaves would be filled there too)
             if (score_stage) {
                 const bool a32s = ctx->pk_beta > 0;
                 const bool tier1_runs = (g.pk2 || g.x[1]) && tier_can_serve(ctx, 62, min_lj, A.max_lj);
+                tier40_runs = g.pk6 && tier1_runs && tier_can_serve(ctx, 40, min_lj, A.max_lj);
                 const bool route = !getenv("C2_NO_ROUTE");
                 c2_diagx_plan PP = c2_make_diagx_plan(16, ctx->max_li, g.max_lj, true, false);
-                p16_stage = getenv("C2_P16_TIER") && PP.total <= 163840u && tier_can_serve(ctx, 14, min_lj, A.max_lj);   // (measured: slower than leaving its tasks to the first tier -- DESIGN 3.3e; opt-in)
+                p16_stage = getenv("C2_P16_TIER") && PP.total <= 163840u && tier_can_serve(ctx, 14, min_lj, A.max_lj);   // (measured: slower than leaving its tasks to the first tier -- opt-in)
+                // the list every band tier READS is lists[its index - 1]; the tiers in launch order: 32 | 40 (if it runs) | 62 (if it runs) | 128
+                const int i40 = 1, i62 = 1 + (tier40_runs ? 1 : 0), i128 = i62 + (tier1_runs ? 1 : 0), ifull = i128 + 1;
                 c2_partition_args PA;
                 PA.A = A;
                 PA.list[0] = elist; PA.count[0] = hdr + 60;
                 PA.list[1] = plist; PA.count[1] = hdr + 62;
                 PA.list[2] = nlist; PA.count[2] = hdr + 61;
-                PA.list[3] = lists[0]; PA.count[3] = hdr + 0;            // (what the first tier leaves: the second tier's list -- or the third's, if there is no second)
-                PA.list[4] = tier1_runs ? lists[1] : lists[0]; PA.count[4] = tier1_runs ? hdr + 1 : hdr + 0;
-                // class 5 (a read that matches its reference nowhere): the list the LAST launch reads -- behind the first tier (this stage runs only if
-                // that tier does), the second if it runs, and the 128-diagonal tier
-                const int last_list = 1 + (tier1_runs ? 1 : 0);
-                PA.list[5] = lists[last_list]; PA.count[5] = hdr + last_list;
+                PA.list[3] = lists[i40 - 1]; PA.count[3] = hdr + (i40 - 1);      // (class 3 exists only when the 40-diagonal tier runs: bandw[2] below)
+                PA.list[4] = lists[i62 - 1]; PA.count[4] = hdr + (i62 - 1);      // the 62-diagonal tier's list -- or, without that tier, the list the 128-diagonal tier reads
+                PA.list[5] = lists[i128 - 1]; PA.count[5] = hdr + (i128 - 1);
+                // class 6 (a read that matches its reference nowhere): the list the LAST launch reads
+                PA.list[6] = lists[ifull - 1]; PA.count[6] = hdr + (ifull - 1);
                 PA.class_count = hdr + 48;
-                PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier1_runs) ? 62 : 0; PA.bandw[3] = route ? 128 : 0;
+                PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier40_runs) ? 40 : 0;
+                PA.bandw[3] = (route && tier1_runs) ? 62 : 0; PA.bandw[4] = route ? 128 : 0;
                 PA.max_mismatch = 6;                                     // (of the last 32 columns)
                 PA.probe_max_mismatch = 4; PA.margin = 3; PA.max_shift = (p16_stage || route) ? 64 : 0;
                 PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
@@ -473,6 +496,20 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                     mark_first();
                 }
                 ++tier;
+                if (t == 0 && tier40_runs) {
+                    // the 40-diagonal tier: six alignments per wavefront (three lane groups of 21 lanes), over what the first tier left and what the
+                    // partition sent here directly; a task it cannot pair or certify goes on to the 62-diagonal tier's list
+                    const uint64_t resident6 = cus * (uint64_t)g.blocks_pk6;
+                    const unsigned grid6 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((A.n_tasks + 5) / 6, resident6));
+                    c2_align_args T6 = A;
+                    chain(T6, false, true);
+                    T6.un_list = nullptr; T6.un_count = nullptr;             // (no 32-bit twin of this band: unpaired tasks join the next tier's list)
+                    T6.plane = (uint32_t*)ctx->d_plane.p; T6.plane_words_per_wg = g.plane_words_pk6;
+                    if (ctx->pk_beta > 0) hipLaunchKernelGGL((c2_align_diagp_kernel<6, true>), dim3(grid6), dim3(64), g.lds_pk6, s, T6);
+                    else                  hipLaunchKernelGGL((c2_align_diagp_kernel<6, false>), dim3(grid6), dim3(64), g.lds_pk6, s, T6);
+                    HIPCHK(ctx, hipGetLastError());
+                    ++tier;
+                }
             }
             if (g.pk3) {                                               // third band tier, packed: two alignments per wavefront
                 const uint64_t resident3 = cus * (uint64_t)g.blocks_pk3;
@@ -801,17 +838,17 @@ int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* fini
 
 // The partition of the most recent batch (c2_align_partition_kernel): did it run; tasks per class (0: score-only launch, 1: 14-diagonal launch,
 // 2: first band tier, 3: second, 4: third); how many of their tasks the score-only launch and the 14-diagonal launch finished.
-int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks6, int64_t* finished2) {
-    if (!ctx || !ran || !class_tasks6 || !finished2) return C2_E_INVALID;
+int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks7, int64_t* finished2) {
+    if (!ctx || !ran || !class_tasks7 || !finished2) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     *ran = ctx->last_score_stage ? (ctx->last_p16_stage ? 3 : 1) : 0;
-    for (int k = 0; k < 6; ++k) class_tasks6[k] = 0;
+    for (int k = 0; k < 7; ++k) class_tasks7[k] = 0;
     finished2[0] = finished2[1] = 0;
     if (ctx->last_score_stage && ctx->d_fb.p) {
         HIPCHK(ctx, hipDeviceSynchronize());
         uint32_t c[64];
         HIPCHK(ctx, hipMemcpy(c, (const uint32_t*)ctx->d_fb.p, 256, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 6; ++k) class_tasks6[k] = (int64_t)c[48 + k];
+        for (int k = 0; k < 7; ++k) class_tasks7[k] = (int64_t)c[48 + k];
         finished2[0] = (int64_t)c[60] - ((int64_t)c[56] - (int64_t)c[50]);
         finished2[1] = ctx->last_p16_stage ? (int64_t)c[62] - ((int64_t)c[57] - (int64_t)c[56]) : 0;
     }

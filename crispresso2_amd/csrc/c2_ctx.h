@@ -58,6 +58,7 @@ struct c2_ctx {
     int occ_score_lds = -1, occ_score_blocks = 0;            // residency of c2_align_diags_kernel with its LDS plan
     int occ_p16_lds = -1, occ_p16_blocks = 0;                // ... of c2_align_diagp_kernel<16>
     int occ_pk_lds = -1, occ_pk_blocks = 0, occ_pk2_lds = -1, occ_pk2_blocks = 0, occ_pk3_lds = -1, occ_pk3_blocks = 0;
+    int occ_pk6_lds = -1, occ_pk6_blocks = 0;                // ... of c2_align_diagp_kernel<6> (the 40-diagonal tier)
     // staging for the host batch path and the per-call path
     DevBuf d_reads, d_offsets, d_refids, d_strands, d_aln_read, d_aln_ref, d_records, d_misc;
     // timing

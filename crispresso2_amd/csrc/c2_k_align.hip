@@ -1155,7 +1155,8 @@ struct c2_diagx_plan {
 // score_only (c2_align_diags_kernel): nothing is traced, so the staging area of an alignment's pointer words is not part of the plan
 __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, int max_lj, bool pk = false, bool score_only = false) {
     c2_diagx_plan p;
-    const uint32_t lpa = 64u / (uint32_t)(pk ? na / 2 : na);        // lanes of one lane group (pk: two alignments share a group, 16 bits each)
+    const uint32_t lpa = ((64u / (uint32_t)(pk ? na / 2 : na)) + 3u) & ~3u;   // words per group of 8 anti-diagonals in a slot's plane: the lanes of one lane group (pk: two
+                                                                    // alignments share a group, 16 bits each), rounded up to four (three groups of 21 lanes: 24) -- the slice is staged as 16-byte words
     p.n_words = (uint32_t)(max_li + max_lj) / 8u + 1u;              // per lane: one 32-bit word per 8 anti-diagonals
     p.slot_read_bytes = c2_align16((uint32_t)max_lj);
     uint32_t off = 0;
@@ -1526,6 +1527,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
     // lanes per group, live lanes, diagonals per band.  A packed group of 16 lanes is a DPP row: its hand-off is row_shr / row_shl,
     // which already reads 0 at the row's ends, so no lane is switched off and all 16 hold diagonals (c2_rshr1z)
     constexpr int LPA = 64 / NG;
+    constexpr int LPW = (LPA + 3) & ~3;                               // words per group of 8 anti-diagonals in the plane (c2_make_diagx_plan)
     constexpr bool ROWDPP = PK && LPA == 16;
     constexpr int NL = (ROWDPP || NG == 1) ? LPA : LPA - 1, BANDW = 2 * NL;   // (one group = the whole wavefront: its ends read 0 anyway)
     const int lane = threadIdx.x, grp = lane / LPA, sl = lane - grp * LPA;
@@ -1554,7 +1556,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
     const bool rows_aligned = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0) && ((A.aln_stride & 3u) == 0);
     unsigned* sStage = (unsigned*)(c2_smem + P.stage);
     unsigned* gWords = A.plane + (size_t)blockIdx.x * A.plane_words_per_wg;   // [slot][group][lane of the slot]
-    const int slotWords = (int)P.n_words * LPA;
+    const int slotWords = (int)P.n_words * LPW;
     const int ge = A.gap_extend, go = A.gap_open;
     for (int k = lane; k < 256; k += 64) sCodeOf[k] = A.code_of_char[k];
     if (lane < NA) { sTab[lane * C2X_INTS + C2X_CURREF] = -1; sTab[lane * C2X_INTS + C2X_LI] = 0; sTab[lane * C2X_INTS + C2X_G0] = 0; sTab[lane * C2X_INTS + C2X_REFBAD] = 0; }
@@ -1855,12 +1857,12 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             unsigned ge2 = c2_pk_dup(ge + beta);
             const unsigned lutBase = P.pairlut;
             if (gC <= gA_stop) {
-                c2_pk_groups<true, true, ROWDPP, ADD32, SCORE>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<true, true, ROWDPP, ADD32, SCORE>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPW);
             } else {
-                c2_pk_groups<true, false, ROWDPP, ADD32, SCORE>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
-                c2_pk_groups<false, false, ROWDPP, ADD32, SCORE>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+                c2_pk_groups<true, false, ROWDPP, ADD32, SCORE>(S, g, gA_stop, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPW);
+                c2_pk_groups<false, false, ROWDPP, ADD32, SCORE>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPW);
             }
-            c2_pk_groups<false, true, ROWDPP, ADD32, SCORE>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPA);
+            c2_pk_groups<false, true, ROWDPP, ADD32, SCORE>(S, g, g_end, L, ge2, CAP, RA, CA, RB, CB, rows, c2_smem, lutBase, wordsA, wordsB, LPW);
             C2_LANES_ACTIVE_END()
         }
         if (!PK && any_ok) {
@@ -1904,12 +1906,12 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             int geV = ge;                                          // gap_extend in a VGPR (second source of a DPP add)
             C2_KEEP_IN_VGPR(geV);
             if (gC <= gA_stop) {
-                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<true, true>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPW);
             } else {
-                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
-                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+                c2_diagx_groups<true, false>(S, g, gA_stop, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPW);
+                c2_diagx_groups<false, false>(S, g, (gC - 1 < g_end ? gC - 1 : g_end), L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPW);
             }
-            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPA);
+            c2_diagx_groups<false, true>(S, g, g_end, L, geV, Hcap, GF, RA, CA, RB, CB, rows, c2_smem, myWords, LPW);
             C2_LANES_ACTIVE_END()
         }
         if (!SCORE) {
@@ -1956,14 +1958,14 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             m_valid = (unsigned)__ballot(valid); m_full = (unsigned)__ballot(full);
             m_gapfree = (unsigned)__ballot(gf); m_trace = (unsigned)__ballot(!SCORE && cert && !gf);
         }
-        constexpr int STG = 16 / NG > 8 ? 8 : 16 / NG;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
+        constexpr int STG = LPW / 4 > 8 ? 8 : LPW / 4;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
         uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
         q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = uint4{0u, 0u, 0u, 0u};
 #define C2_STG_LOAD(n) if (STG > n) { const int k = 64 * n + lane; q##n = src[k < n16 ? k : 0]; }
 #define C2_STG_STORE(n) if (STG > n) { const int k = 64 * n + lane; if (k < n16) dst[k] = q##n; }
         auto request_words = [&](const int s2) {
             const uint4* src = (const uint4*)(gWords + s2 * slotWords);
-            const int n16 = (g_end + 1) * (LPA / 4);
+            const int n16 = (g_end + 1) * (LPW / 4);
             C2_STG_LOAD(0) C2_STG_LOAD(1) C2_STG_LOAD(2) C2_STG_LOAD(3) C2_STG_LOAD(4) C2_STG_LOAD(5) C2_STG_LOAD(6) C2_STG_LOAD(7)
         };
         if (m_trace) request_words(__builtin_ctz(m_trace));
@@ -1989,7 +1991,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                 {
                     const uint4* src = (const uint4*)(gWords + s * slotWords);
                     uint4* dst = (uint4*)sStage;
-                    const int n16 = ((((Li + Lj) >> 1) >> 2) + 1) * (LPA / 4);
+                    const int n16 = ((((Li + Lj) >> 1) >> 2) + 1) * (LPW / 4);
                     C2_STG_STORE(0) C2_STG_STORE(1) C2_STG_STORE(2) C2_STG_STORE(3) C2_STG_STORE(4) C2_STG_STORE(5) C2_STG_STORE(6) C2_STG_STORE(7)
                     for (int k = 64 * STG + lane; k < n16; k += 64) dst[k] = src[k];
                 }
@@ -1997,7 +1999,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
                 const unsigned later = m_trace & ~((2u << s) - 1u);     // traced slots after this one
                 if (later) request_words(__builtin_ctz(later));
                 c2_diagx_plane plane;
-                plane.words = sStage; plane.d0 = d0; plane.lpa = LPA; plane.nl = NL; plane.pk = PK;
+                plane.words = sStage; plane.d0 = d0; plane.lpa = LPW; plane.nl = NL; plane.pk = PK;
                 int cnt, matches;
                 bool nf2;
                 c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
@@ -2078,11 +2080,12 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
 //            be worse than the one found, and every mismatch of the read brings the two closer):
 //   class 1  ... fit a band of bandw[0] diagonals (14: c2_align_diagp_kernel<16>, sixteen alignments per wavefront)
 //   class 2  ... bandw[1] (32: the first band tier)     -- also: no window found, reverse strand, reference not admitted
-//   class 3  ... bandw[2] (62: the second tier)         class 4  ... bandw[3] (126 / anything wider: the third tier)
+//   class 3  ... bandw[2] (40: round 5's tier between them -- three lane groups of 21 lanes; reads with an overhang at both ends, §DESIGN 3.1)
+//   class 4  ... bandw[3] (62)         class 5  ... bandw[4] (126 / anything wider: the last band tier)
 //   (bandw[k] = 0: the chain has no such launch; the next wider one that exists takes the task.)
 // A prediction only: every launch verifies what it finishes (certificate) and hands on what it cannot, so a wrong class costs that alignment a
 // second fill and nothing else -- but a read with a 20-base deletion no longer pays for a fill in a band that cannot hold it.
-//   class 5  (round 5, `direct_full`) the read matches the reference NOWHERE: neither the middle window nor the windows a quarter and three quarters
+//   class 6  (round 5, `direct_full`) the read matches the reference NOWHERE: neither the middle window nor the windows a quarter and three quarters
 //            into the read find a place with at most `probe_max_mismatch` differing bases.  No band will certify such a read (an unrelated
 //            sequence, a chimera): it goes straight to the list of the LAST launch, the full matrix, instead of being filled and handed on by
 //            every band tier on its way there (5 + 9 + 19 ns before the 71 ns it cannot avoid).
@@ -2091,11 +2094,12 @@ __global__ __launch_bounds__(64) void c2_selftest_kernel(int* out)
 // order -- unless the chunk's reads differ in LENGTH (round 5): then the chunk's slots are first ordered by read length (a counting sort in LDS),
 // because the packed kernels put two alignments into one lane group only if they share reference AND read length, and neighbours of a ragged input
 // in task order almost never do (reads of lengths U[200, 250]: everything went to the 32-bit kernels, at half the rate).
+#define C2_PART_CLASSES 7                          // 0 score-only, 1 .. 5 the band launches by width, 6 the full-matrix launch
 struct c2_partition_args {
     c2_align_args A;
-    uint32_t* list[6]; uint32_t* count[6];      // per class: the launch's task list and its length (classes may share a list)
-    uint32_t* class_count;                      // [6] tasks per class (statistics)
-    int32_t bandw[4];                           // diagonals of the launches behind classes 1 .. 4, 0: none
+    uint32_t* list[C2_PART_CLASSES]; uint32_t* count[C2_PART_CLASSES];      // per class: the launch's task list and its length (classes may share a list)
+    uint32_t* class_count;                      // [C2_PART_CLASSES] tasks per class (statistics)
+    int32_t bandw[5];                           // diagonals of the launches behind classes 1 .. 5 (14, 32, 40, 62, 128), 0: the chain has no such launch
     int32_t max_mismatch, probe_max_mismatch, margin, max_shift;
     int32_t direct_full, sort_by_length;        // class 5 exists; order a ragged chunk's slots by read length
 };
@@ -2203,12 +2207,12 @@ __device__ __forceinline__ int c2_part_probe(const c2_partition_args& P, const c
         int s1 = 0, s2 = 0;
         const int m1 = c2_part_window(P, t, t.Lj >> 2, s1), m2 = c2_part_window(P, t, ((3 * t.Lj) >> 2) - 16, s2);
         const bool ok1 = m1 <= P.probe_max_mismatch, ok2 = m2 <= P.probe_max_mismatch;
-        if (!ok1 && !ok2) return (P.direct_full && mm < 64 && m1 < 64 && m2 < 64) ? 5 : 2;      // (a window that could not be looked at says nothing)
+        if (!ok1 && !ok2) return (P.direct_full && mm < 64 && m1 < 64 && m2 < 64) ? C2_PART_CLASSES - 1 : 2;      // (a window that could not be looked at says nothing)
         if (ok1) { lo = s1 < lo ? s1 : lo; hi = s1 > hi ? s1 : hi; }
         if (ok2) { lo = s2 < lo ? s2 : lo; hi = s2 > hi ? s2 : hi; }
     }
     int cls = widest;
-    for (int k = 3; k >= 0; --k) if (c2_band_holds(P.bandw[k], D, lo, hi, P.margin)) cls = k + 1;
+    for (int k = 4; k >= 0; --k) if (c2_band_holds(P.bandw[k], D, lo, hi, P.margin)) cls = k + 1;
     return cls;
 }
 
@@ -2216,14 +2220,13 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
 {
     const c2_align_args& A = P.A;
     uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] the task's class, 7: no such task, 8: still to be probed
-    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [3 * 4] per wavefront: packed class counts; [16 .. 21]: bases of the six lists; [24]: the chunk's first read length; [25]: ragged
+    unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [4 * 4] per wavefront: packed class counts; [16 .. 22]: bases of the seven lists; [24]: the chunk's first read length; [25]: ragged
     uint16_t* const todo = (uint16_t*)(c2_smem + C2_PART_CHUNK + 128);   // [C2_PART_CHUNK] the chunk's tasks that need the probe, densely; afterwards: the slots in length order
     uint16_t* const len16 = todo + C2_PART_CHUNK;                   // [C2_PART_CHUNK] read length of the slot's task (capped at the last bin)
     unsigned* const hist = (unsigned*)(len16 + C2_PART_CHUNK);      // [C2_PART_LEN_BINS]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int widest = 2;                                                 // the class that takes what no band holds
-    if (P.bandw[2] > 0) widest = 3;
-    if (P.bandw[3] > 0) widest = 4;
+    int widest = 2;                                                 // the class that takes what no band holds: the widest band launch the chain has
+    for (int k = 2; k < 5; ++k) if (P.bandw[k] > 0) widest = k + 1;
     // An all-references batch (task = read * n_refs + reference) is walked REFERENCE-MAJOR inside a chunk: slot s of a chunk of `rpc` reads is read
     // s % rpc against reference s / rpc.  The lists keep slot order, so their neighbours are two reads against the SAME reference -- what the packed
     // kernels need to put two alignments into one lane group (a pair shares reference and read length); task order would put (read r, reference 0),
@@ -2344,47 +2347,57 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             __syncthreads();
         }
         // ---- thread t owns positions 16 t .. 16 t + 15 of the chunk's order: list positions by a scan over the workgroup, one atomic per chunk and class
-        unsigned n[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        constexpr int NC = C2_PART_CLASSES, NW = (C2_PART_CLASSES + 1) / 2;
+        unsigned n[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) n[c] = 0u;
         unsigned mine[16];                                          // the slots in this thread's positions
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             mine[k] = ragged ? (unsigned)todo[16 * tid + k] : (unsigned)(16 * tid + k);
             const unsigned f = flag[mine[k]];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) n[c] += f == (unsigned)c;
+            for (int c = 0; c < NC; ++c) n[c] += f == (unsigned)c;
         }
-        unsigned pk[3] = {n[0] | (n[1] << 16), n[2] | (n[3] << 16), n[4] | (n[5] << 16)};           // (every count <= 4096: 16 bits each, sums <= 4096)
-        unsigned incl[3] = {pk[0], pk[1], pk[2]};
+        unsigned pk[NW], incl[NW];                                  // two 16-bit counters per word (every count <= 4096, every sum <= 4096)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { pk[w] = n[2 * w] | ((2 * w + 1 < NC ? n[2 * w + 1 < NC ? 2 * w + 1 : 0] : 0u) << 16); incl[w] = pk[w]; }
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
 #pragma unroll
-            for (int w = 0; w < 3; ++w) { const unsigned o = (unsigned)__shfl_up((int)incl[w], d); if (lane >= d) incl[w] += o; }
+            for (int w = 0; w < NW; ++w) { const unsigned o = (unsigned)__shfl_up((int)incl[w], d); if (lane >= d) incl[w] += o; }
         }
-        if (lane == 63) { part[3 * wv] = incl[0]; part[3 * wv + 1] = incl[1]; part[3 * wv + 2] = incl[2]; }
+        if (lane == 63) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) part[NW * wv + w] = incl[w];
+        }
         __syncthreads();
-        unsigned before[3] = {0u, 0u, 0u}, total[3] = {0u, 0u, 0u};
+        unsigned before[NW], total[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { before[w] = 0u; total[w] = 0u; }
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int w = 0; w < 3; ++w) { const unsigned x = part[3 * v + w]; if (v < wv) before[w] += x; total[w] += x; }
-        if (tid < 6) {
+            for (int w = 0; w < NW; ++w) { const unsigned x = part[NW * v + w]; if (v < wv) before[w] += x; total[w] += x; }
+        if (tid < NC) {
             const unsigned t = (tid & 1) ? (total[tid >> 1] >> 16) : (total[tid >> 1] & 0xffffu);
             part[16 + tid] = t ? atomicAdd(P.count[tid], t) : 0u;
             if (t && P.class_count) atomicAdd(P.class_count + tid, t);
         }
         __syncthreads();
-        unsigned pos[6];
+        unsigned pos[NC];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const unsigned e = before[w] + incl[w] - pk[w];
-            pos[2 * w] = part[16 + 2 * w] + (e & 0xffffu); pos[2 * w + 1] = part[17 + 2 * w] + (e >> 16);
+            pos[2 * w] = part[16 + 2 * w] + (e & 0xffffu);
+            if (2 * w + 1 < NC) pos[2 * w + 1 < NC ? 2 * w + 1 : 0] = part[16 + 2 * w + 1] + (e >> 16);
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const unsigned f = flag[mine[k]];
-            const uint32_t task = (uint32_t)c2_part_task_of(WK, A, chunk, (int)mine[k]);     // (f < 6 only for a slot that holds a task)
+            const uint32_t task = (uint32_t)c2_part_task_of(WK, A, chunk, (int)mine[k]);     // (f < NC only for a slot that holds a task)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) if (f == (unsigned)c) P.list[c][pos[c]++] = task;
+            for (int c = 0; c < NC; ++c) if (f == (unsigned)c) P.list[c][pos[c]++] = task;
         }
         __syncthreads();                                            // (the flags are overwritten by the next chunk)
     }

@@ -313,13 +313,16 @@ int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* fini
  * band has, the task goes straight to the list of the second / third tier.  Every launch verifies what it finishes and hands on what it cannot:
  * the class only decides where a task is tried FIRST.  With this, left_over[t] of c2_tier_info is the length of the list the launch behind tier
  * t reads: what tier t left plus what the partition put there.
- * Round 5: class 5 -- the read matches its reference nowhere (three 32-base windows of it find no place within 64 bases of their own with at most
+ * Round 5: the last class -- the read matches its reference nowhere (three 32-base windows of it find no place within 64 bases of their own with at most
  * four differing bases): no band will certify it, it goes straight to the list of the last launch (the full matrix).  A batch whose reads differ
  * in length has the slots of every 4,096-task chunk ordered by read length first, so that the lists' neighbours can share a lane group of the
  * packed kernels (same reference AND read length); an all-references batch of several references is walked reference-major for the same reason.
- * c2_partition_info: *ran bit 0 the partition ran for the most recent batch, bit 1 the 14-diagonal launch too; class_tasks6: tasks per class;
+ * Seven classes in all: 0 score-only, 1 the 14-diagonal launch (opt-in), 2 the first band tier (32 diagonals), 3 the 40-diagonal tier (round 5: six
+ * alignments per wavefront, for reads that overhang their amplicon at both ends), 4 the 62-diagonal tier, 5 the 126/128-diagonal tier, 6 the
+ * full-matrix launch.
+ * c2_partition_info: *ran bit 0 the partition ran for the most recent batch, bit 1 the 14-diagonal launch too; class_tasks7: tasks per class;
  * finished2: tasks the score-only launch and the 14-diagonal launch finished. */
-int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks6, int64_t* finished2);
+int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks7, int64_t* finished2);
 /* The same for up to 8 tiers, plus per tier the number of tasks its packed (int16) kernel could not pair and handed to the 32-bit
  * kernel of the same band: a tier with a packed kernel finished at least tasks_in - unpaired - left_over tasks in int16 arithmetic. */
 int c2_tier_info_ex(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over8, int32_t* unpaired8);

@@ -20,8 +20,8 @@ extern "C" {
 unsigned emu_last_unpaired() { return g_last_unpaired; }
 static const uint32_t* g_last_classes = nullptr;   // tasks per class of the last emu_align_batch's partition (all zero: it did not run)
 static unsigned g_last_p16_finished = 0;           // tasks its 14-diagonal launch finished
-void emu_last_partition(uint32_t* classes6, uint32_t* p16_finished) {
-    for (int k = 0; k < 6; ++k) classes6[k] = g_last_classes ? g_last_classes[k] : 0u;
+void emu_last_partition(uint32_t* classes7, uint32_t* p16_finished) {
+    for (int k = 0; k < 7; ++k) classes7[k] = g_last_classes ? g_last_classes[k] : 0u;
     *p16_finished = g_last_p16_finished;
 }
 int emu_last_pk_beta() { return g_last_pk_beta; }
@@ -107,7 +107,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     // chain 4 -> 2 -> 1; every chain ends with the full-plane kernel over what is left (the host library's launch order)
     // -8 / -84: the packed kernels (8 / 4 per wavefront, int16 pairs) alone; -87: the library's default chain 8 (packed) -> 4 (packed) -> 1
     // (references the packed fill does not admit: 2 per wavefront in 32 bits instead)
-    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75 || band_lanes == -8 || band_lanes == -84 || band_lanes == -87 || band_lanes == -82;
+    const bool diag = band_lanes == -1 || band_lanes == -2 || band_lanes == -4 || band_lanes == -5 || band_lanes == -7 || band_lanes == -75 || band_lanes == -8 || band_lanes == -84 || band_lanes == -87 || band_lanes == -82 || band_lanes == -86;
     const bool band = band_lanes > 0 && band_lanes < 32 && A.max_passes == 1;
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1), fb_list3(A.n_tasks ? A.n_tasks : 1), fb_list4(A.n_tasks ? A.n_tasks : 1);   // (the full-plane launch below reads the last tier's)
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
@@ -151,11 +151,11 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         // then c2_align_diags_kernel over class 0 and c2_align_diagp_kernel<16> over class 1; what they cannot finish joins the first tier's list
         // (class 2); classes 3 and 4 go straight to the lists of the second and third tier).  C2_EMU_NO_SCORE_TIER=1 switches all of it off,
         // C2_NO_ROUTE=1 the routing to later tiers; the 14-diagonal launch runs with C2_P16_TIER=1 only (as in the library).
-        bool score_stage = false;
+        bool score_stage = false, tier40_runs = false;
         std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1), nlist(A.n_tasks ? A.n_tasks : 1), plist(A.n_tasks ? A.n_tasks : 1);
         uint32_t e_count = 0, ne_count = 0, p_count = 0;
-        static uint32_t class_counts[6];
-        for (int k = 0; k < 6; ++k) class_counts[k] = 0;
+        static uint32_t class_counts[7];
+        for (int k = 0; k < 7; ++k) class_counts[k] = 0;
         g_last_classes = class_counts; g_last_p16_finished = 0;
         if (any_pk && (band_lanes == -87 || band_lanes == -8 || band_lanes == -80) && !(A.all_refs && A.n_refs > 1 && (A.n_refs > 64 || getenv("C2_NO_ALLREFS_PARTITION"))) && !getenv("C2_EMU_NO_SCORE_TIER")) {
             const int sna = (getenv("C2_SCORE_TIER_NA") && atoi(getenv("C2_SCORE_TIER_NA")) == 8) ? 8 : 16;
@@ -165,21 +165,25 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             const c2_diagx_plan P16 = c2_make_diagx_plan(16, A.max_li, A.max_lj, true, false);
             const bool p16_stage = getenv("C2_P16_TIER") && P16.total <= sizeof(c2_smem);
             const bool tier1_runs = band_lanes == -87, tier2_runs = band_lanes == -87;       // (-8 / -80: the first tier's kernels alone, then the full plane)
+            const c2_diagx_plan P6 = c2_make_diagx_plan(6, A.max_li, A.max_lj, true);
+            tier40_runs = tier1_runs && !getenv("C2_NO_TIER40") && P6.total <= sizeof(c2_smem);
             const bool route = !getenv("C2_NO_ROUTE");
+            // the list a band tier reads is lists[its index - 1]; launch order: 32 | 40 | 62 | 128 (as the host library wires it, c2_api_align.hip)
+            const int i40 = 1, i62 = 1 + (tier40_runs ? 1 : 0), i128 = i62 + (tier1_runs ? 1 : 0), ifull = i128 + (tier2_runs ? 1 : 0);
             c2_partition_args PA;
             PA.A = A;
             PA.list[0] = elist.data(); PA.count[0] = &e_count;
             PA.list[1] = plist.data(); PA.count[1] = &p_count;
             PA.list[2] = nlist.data(); PA.count[2] = &ne_count;
-            PA.list[3] = lists[0]; PA.count[3] = &fb_counts[0];
-            PA.list[4] = tier1_runs ? lists[1] : lists[0]; PA.count[4] = tier1_runs ? &fb_counts[1] : &fb_counts[0];
-            // class 5: the list the last launch (the full plane) reads -- behind the first tier, the second and the third where the chain has them
-            const int last_list = (tier1_runs ? 1 : 0) + (tier2_runs ? 1 : 0);
-            PA.list[5] = lists[last_list]; PA.count[5] = &fb_counts[last_list];
+            PA.list[3] = lists[i40 - 1]; PA.count[3] = &fb_counts[i40 - 1];
+            PA.list[4] = lists[i62 - 1]; PA.count[4] = &fb_counts[i62 - 1];
+            PA.list[5] = lists[i128 - 1]; PA.count[5] = &fb_counts[i128 - 1];
+            PA.list[6] = lists[ifull - 1]; PA.count[6] = &fb_counts[ifull - 1];      // the list the last launch (the full plane) reads
             PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
             PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
             PA.class_count = class_counts;
-            PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier1_runs) ? 62 : 0; PA.bandw[3] = (route && tier2_runs) ? 128 : 0;
+            PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier40_runs) ? 40 : 0;
+            PA.bandw[3] = (route && tier1_runs) ? 62 : 0; PA.bandw[4] = (route && tier2_runs) ? 128 : 0;
             PA.max_mismatch = getenv("C2_SCORE_TIER_MAX_MISMATCH") ? atoi(getenv("C2_SCORE_TIER_MAX_MISMATCH")) : 6;
             PA.probe_max_mismatch = getenv("C2_ROUTE_PROBE_MISMATCH") ? atoi(getenv("C2_ROUTE_PROBE_MISMATCH")) : 4;
             PA.margin = getenv("C2_ROUTE_MARGIN") ? atoi(getenv("C2_ROUTE_MARGIN")) : 3;
@@ -210,6 +214,19 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
                 g_last_p16_finished = p_count - (ne_count - before);
                 if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed 16 over %u tasks, %u handed on\n", p_count, ne_count - before);
             }
+        }
+        if (band_lanes == -86 && any_pk) {
+            // -86: c2_align_diagp_kernel<6> alone over every task (40 diagonals, three lane groups of 21 lanes), then the full plane
+            const c2_diagx_plan PP = c2_make_diagx_plan(6, A.max_li, A.max_lj, true);
+            if (PP.total > sizeof(c2_smem)) return -5;
+            plane.assign((size_t)grid * PP.n_words * 144u, 0xdeadbeefu);
+            c2_align_args T = A;
+            chain(T, false, true);
+            T.un_list = nullptr; T.un_count = nullptr; T.pair_order = 0;
+            T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 144u;
+            if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diagp_kernel<6, true>(T); });
+            else             emu::launch(grid, [&] { c2_align_diagp_kernel<6, false>(T); });
+            ++tier;
         }
         // -5: five alignments per wavefront (lane groups of 12, lanes 60..63 idle); -75: the chain 5 -> 2 -> 1 -> full plane
         for (int t = 0; t < 2; ++t) {
@@ -244,6 +261,21 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
                 else          emu::launch(grid, [&] { c2_align_diagx_kernel<2>(T); });
             }
             ++tier;
+            if (t == 0 && score_stage && tier40_runs) {
+                // the 40-diagonal tier (round 5): six alignments per wavefront, three lane groups of 21 lanes; no 32-bit twin -- what it cannot pair
+                // goes on to the next list
+                const c2_diagx_plan PP = c2_make_diagx_plan(6, A.max_li, A.max_lj, true);
+                if (PP.total > sizeof(c2_smem)) return -5;
+                plane.assign((size_t)grid * PP.n_words * 144u, 0xdeadbeefu);
+                c2_align_args T = A;
+                chain(T, false, true);
+                T.un_list = nullptr; T.un_count = nullptr;
+                T.plane = plane.data(); T.plane_words_per_wg = PP.n_words * 144u;
+                if (getenv("C2_EMU_TRACE")) fprintf(stderr, "launch packed 6 tier %d\n", tier);
+                if (pk_beta > 0) emu::launch(grid, [&] { c2_align_diagp_kernel<6, true>(T); });
+                else             emu::launch(grid, [&] { c2_align_diagp_kernel<6, false>(T); });
+                ++tier;
+            }
         }
         if (band_lanes == -7 || band_lanes == -75 || band_lanes == -1 || band_lanes == -87 || band_lanes == -82) {
             // third band tier (128 diagonals): two alignments per wavefront in int16 halves (c2_align_diagp_kernel<2>, one lane group of

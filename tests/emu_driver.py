@@ -85,9 +85,9 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
     if stats is not None:
         stats['unpaired'] = stats.get('unpaired', 0) + int(lib().emu_last_unpaired())
         stats['pk_beta'], stats['pk_bias'] = int(lib().emu_last_pk_beta()), int(lib().emu_last_pk_bias())
-        cls, p16 = (ctypes.c_uint32 * 6)(), ctypes.c_uint32(0)
+        cls, p16 = (ctypes.c_uint32 * 7)(), ctypes.c_uint32(0)
         lib().emu_last_partition(cls, ctypes.byref(p16))
-        stats['classes'] = [a + int(b) for a, b in zip(stats.get('classes', [0] * 6), cls)]
+        stats['classes'] = [a + int(b) for a, b in zip(stats.get('classes', [0] * 7), cls)]
         stats['p16_finished'] = stats.get('p16_finished', 0) + int(p16.value)
         stats['fallback'] = stats.get('fallback', 0) + max(nfb.value, 0)
         stats['tasks'] = stats.get('tasks', 0) + ntasks

@@ -432,11 +432,11 @@ def test_banded_pointer_plane_equals_full_plane(mats, ctx):
     assert outs[2][1]["fallback_tasks_last_launch"] > outs[6][1]["fallback_tasks_last_launch"] > 0
     assert 0 < outs["diag1"][1]["fallback_tasks_last_launch"] < n // 20
     # every tier certifies most of what it gets and hands the rest down; the last banded tier is the same in all chains
-    assert len(tiers["diag1"]) == 1 and len(tiers["diag2"]) == 2 and len(tiers["auto"]) == 3
-    assert n // 2 > tiers["auto"][0] > tiers["auto"][1] >= tiers["auto"][2] > 0
+    assert len(tiers["diag1"]) == 1 and len(tiers["diag2"]) == 2 and len(tiers["auto"]) == 4      # (32 / 40 / 62 / 128 diagonals)
+    assert n // 2 > tiers["auto"][0] > tiers["auto"][1] >= tiers["auto"][2] >= tiers["auto"][3] > 0
     # (round 5: in the default chain the partition sends the reads that match the reference nowhere straight to the LAST list, so the list behind
     #  its second tier is shorter than the 32-bit chain's; what reaches the full-matrix launch is the same)
-    assert tiers["auto"][2:] == tiers["diag2"][1:] and tiers["auto"][1] <= tiers["diag2"][0] and tiers["diag2"][1:] == tiers["diag1"]
+    assert tiers["auto"][3:] == tiers["diag2"][1:] and tiers["auto"][2] <= tiers["diag2"][0] and tiers["diag2"][1:] == tiers["diag1"]
 
 
 def test_count_vectors_device_vs_reference_aggregation(mats, ctx):
@@ -1306,8 +1306,9 @@ def test_partition_routing_changes_no_result(mats, ctx, monkeypatch, L):
         assert all(np.array_equal(a, b) for a, b in zip(outs[0], other))
     routed, unrouted, with16 = infos
     assert routed["ran"] and not routed["p16"] and sum(routed["classes"]) == n
-    assert routed["classes"][0] > 100 and routed["classes"][1] == 0 and routed["classes"][3] >= 60 and (routed["classes"][4] >= 40 or L == 150), routed
-    assert unrouted["classes"][3] == 0 and unrouted["classes"][4] == 0 and unrouted["classes"][2] > routed["classes"][2], unrouted
+    # (classes: 0 score-only, 1 the 14-diagonal launch, 2 / 3 / 4 / 5 the band tiers of 32 / 40 / 62 / 128 diagonals, 6 the full-matrix launch)
+    assert routed["classes"][0] > 100 and routed["classes"][1] == 0 and routed["classes"][3] + routed["classes"][4] >= 60 and (routed["classes"][5] >= 40 or L == 150), routed
+    assert sum(unrouted["classes"][3:6]) == 0 and unrouted["classes"][2] > routed["classes"][2], unrouted
     assert with16["p16"] and with16["classes"][1] >= 150 and with16["finished"][1] >= with16["classes"][1] // 2, with16
     records = outs[0][2].view(_native.REC_DTYPE).reshape(-1)
     assert (records["status"] == 0).all()
@@ -1322,7 +1323,7 @@ def test_ragged_and_unrelated_reads_and_the_full_matrix_launch_with_its_plane_in
     """Round 5, inputs that are not the generator's best case: 6,000 reads cut to lengths U[200, 250], every tenth one replaced by a random sequence,
     against the 250-bp amplicon through the default chain of a BATCH (>= 4,096 tasks: the full-matrix launch keeps its pointer plane in HBM scratch,
     four wavefronts per SIMD instead of one).  The partition orders the chunks by read length and sends the unrelated reads straight to the last
-    list (class 5).  A sample of every kind against the oracle; and every byte equal to the same batch with the three knobs turned the other way
+    list (class 6).  A sample of every kind against the oracle; and every byte equal to the same batch with the three knobs turned the other way
     (plane in LDS, task order, no direct route) -- results never depend on them."""
     import torch
     from crispresso2_amd import synth
@@ -1343,8 +1344,8 @@ def test_ragged_and_unrelated_reads_and_the_full_matrix_launch_with_its_plane_in
     res = al.align(reads)
     part = ctx.partition_info()
     tiers = ctx.tier_info()
-    assert part["ran"] and sum(part["classes"]) == n and 500 <= part["classes"][5] <= 600, part
-    assert tiers[-1] >= part["classes"][5]                             # they sit in the list the full-matrix launch reads
+    assert part["ran"] and sum(part["classes"]) == n and 500 <= part["classes"][6] <= 600, part
+    assert tiers[-1] >= part["classes"][6]                             # they sit in the list the full-matrix launch reads
     assert (res.records["status"] == 0).all()
     for k in list(range(0, n, 37)) + list(range(7, n, 310)):
         st, s1, s2, mt, ln = oracle.global_align_raw(reads[k], amp, m, g, -20, -2)

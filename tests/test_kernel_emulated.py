@@ -516,7 +516,7 @@ def test_emulated_kernel_alignments_larger_than_the_lds_plane(mats, li, lj):
         if chain and lj == li:
             # the long deletion and the unrelated read are beyond the first tier: handed on by it, or (round 5) sent past it by the partition --
             # the unrelated read straight to the full-matrix launch (class 5)
-            assert 0 < st["fallback"] + sum(st["classes"][3:]) < st["tasks"] and st["classes"][5] == 1, st
+            assert 0 < st["fallback"] + sum(st["classes"][3:]) < st["tasks"] and st["classes"][6] == 1, st
 
 
 # ---- the two variants of the packed fill: sums as v_pk_add_i16, or as plain 32-bit adds under a per-anti-diagonal bias ----------------
@@ -625,7 +625,8 @@ def test_partition_routes_tasks_to_the_launch_whose_band_holds_their_path(mats, 
         cls = st["classes"]
         assert sum(cls) == len(reads), cls
         # every kind of launch saw tasks (150 bp: the 40-base deletion leaves the probe's window in the filler -- nothing found, first tier) ...
-        assert cls[0] >= 10 and cls[3] >= 10 and (cls[4] >= 8 or L == 150), cls
+        # (classes: 0 score-only, 1 the 14-diagonal launch, 2 / 3 / 4 / 5 the band tiers of 32 / 40 / 62 / 128 diagonals, 6 the full-matrix launch)
+        assert cls[0] >= 10 and cls[3] + cls[4] >= 10 and (cls[5] >= 8 or L == 150), cls
         if p16:
             assert cls[1] >= 20 and st["p16_finished"] >= cls[1] * 3 // 4, st              # ... and the 14-diagonal launch finished most of its own
         else:
@@ -634,7 +635,7 @@ def test_partition_routes_tasks_to_the_launch_whose_band_holds_their_path(mats, 
     st2 = {}
     res2, rec2 = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st2)
     assert res2 == res and np.array_equal(rec2, rec)
-    assert st2["classes"][3] == 0 and st2["classes"][4] == 0 and st2["classes"][1] > 0, st2
+    assert st2["classes"][3] == 0 and st2["classes"][4] == 0 and st2["classes"][5] == 0 and st2["classes"][1] > 0, st2
 
 
 @pytest.mark.parametrize("L", [300, 700])
@@ -768,7 +769,7 @@ def test_ragged_and_unrelated_reads_through_the_partition(mats):
     """Round 5 (inputs that are not the generator's best case).  Reads cut to lengths U[120, 160], a tenth of them replaced by
     random sequences, against a 160-bp amplicon through the default chain: the partition orders every chunk's slots by read length (else no two
     neighbours could share a lane group of the packed kernels) and sends the reads that match the amplicon nowhere straight to the full-matrix
-    launch (class 5).  Every alignment and record equals the oracle's, and the two knobs (C2_NO_LENGTH_ORDER, C2_NO_DIRECT_FULL) change no byte --
+    launch (class 6).  Every alignment and record equals the oracle's, and the two knobs (C2_NO_LENGTH_ORDER, C2_NO_DIRECT_FULL) change no byte --
     only how many tasks the int16 kernels could pair and how many launches the unrelated reads passed through."""
     from crispresso2_amd import synth
     m = mats["EDNAFULL"]
@@ -788,7 +789,7 @@ def test_ragged_and_unrelated_reads_through_the_partition(mats):
         exp = oracle.global_align_raw(reads[k], amp, m, g, -20, -2)
         assert exp[0] == 0 and r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], k
         check_record(r, oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
-    assert sum(st["classes"]) == len(reads) and 20 <= st["classes"][5] <= 26, st["classes"]      # the 26 random reads (a few find a window by chance)
+    assert sum(st["classes"]) == len(reads) and 20 <= st["classes"][6] <= 26, st["classes"]      # the 26 random reads (a few find a window by chance)
     variants = {}
     for knob in ("C2_NO_LENGTH_ORDER", "C2_NO_DIRECT_FULL"):
         os.environ[knob] = "1"
@@ -800,4 +801,37 @@ def test_ragged_and_unrelated_reads_through_the_partition(mats):
         assert rv == res and recv.tobytes() == rec.tobytes(), knob
         variants[knob] = sv
     assert variants["C2_NO_LENGTH_ORDER"]["unpaired"] > 3 * max(st["unpaired"], 1), (st["unpaired"], variants["C2_NO_LENGTH_ORDER"]["unpaired"])
-    assert variants["C2_NO_DIRECT_FULL"]["classes"][5] == 0
+    assert variants["C2_NO_DIRECT_FULL"]["classes"][6] == 0
+
+
+def test_forty_diagonal_tier_six_alignments_per_wavefront(mats):
+    """Round 5: c2_align_diagp_kernel<6> -- three lane groups of 21 lanes (20 live: 40 diagonals), two alignments per group, the pointer plane's groups
+    padded to 24 words.  Reads shaped like the reference's own test data (tests/FANC.Cas9.fastq resampled by crispresso2_amd.synth: a 4-base overhang in
+    front of the 223-bp amplicon, 23+ bases of flank behind it -- 28 diagonals the 32-diagonal tier cannot certify --, lengths 248-250, deletions at
+    the cut, some unrelated reads): through the kernel alone (-86: what it cannot finish goes to the full plane) and through the default chain (-87: the
+    partition sends most of them to this tier first).  Every alignment and record equals the oracle's; with the tier left out (C2_NO_TIER40) the bytes
+    are the same."""
+    from crispresso2_amd import synth
+    m = mats["EDNAFULL"]
+    amp, g, inc = synth.fanc_setup()
+    R, lens = synth.make_fanc_reads(420, first_block=3)
+    reads = [R[k, :lens[k]].tobytes().decode() for k in range(len(lens))]
+    want = [oracle.global_align_raw(rd, amp, m, g, -20, -2) for rd in reads]
+    outs = {}
+    for chain in (-86, -87):
+        st = {}
+        res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=chain, grid=3, stats=st)
+        for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+            assert want[k][0] == 0 and r["status"] == 0 and (s1, s2, int(r["matches"]), int(r["aln_len"])) == want[k][1:], (chain, k)
+            check_record(r, oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+        outs[chain] = (res, rec, st)
+    assert outs[-86][2]["fallback"] < 0.5 * len(reads)                # the 40-diagonal kernel alone finishes most of these reads
+    cls = outs[-87][2]["classes"]
+    assert sum(cls) == len(reads) and cls[3] > 0.6 * len(reads) and cls[0] == 0, cls      # class 3 = this tier; no read is as long as the amplicon
+    os.environ["C2_NO_TIER40"] = "1"
+    try:
+        st = {}
+        res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, grid=3, stats=st)
+    finally:
+        del os.environ["C2_NO_TIER40"]
+    assert st["classes"][3] == 0 and res == outs[-87][0] and rec.tobytes() == outs[-87][1].tobytes()
