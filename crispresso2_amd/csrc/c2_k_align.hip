@@ -782,8 +782,11 @@ __device__ __forceinline__ void c2_emit_gapless(const c2_align_args& A, const c2
 // appends the task to A.fb_list, and the host re-runs exactly those tasks with the full-plane kernel (A.task_list mode).
 // The band limits what is STORED, never what is computed, so results do not depend on it.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef C2_FULL_WAVES
+#define C2_FULL_WAVES 4                             // wavefronts per SIMD the full-matrix kernel is compiled for (its registers; measured: see profiles/r05/README.md)
+#endif
 template <int R, int MODE>
-__global__ __launch_bounds__(64, 4) void c2_align_classify_kernel(c2_align_args A)
+__global__ __launch_bounds__(64, C2_FULL_WAVES) void c2_align_classify_kernel(c2_align_args A)
 {
     constexpr bool BAND = MODE == 1;
     constexpr int MULTI = MODE == 2 ? 2 : 0;                     // plane mode of the multi-pass sweeps (never banded)
@@ -2166,30 +2169,41 @@ __device__ __forceinline__ bool c2_part_probes(const c2_partition_args& P, const
 }
 
 // the diagonal the 32 bases of the read from column p on lie on: the window of the reference within max_shift of the same place that differs
-// from them in the fewest bases (ties: the one whose band is narrowest) -> differing bases of that window (64: no window to look at), its shift in s
+// from them in the fewest bases -> differing bases of that window (64: no window to look at), its shift in s.  The windows are visited from
+// shift 0 OUTWARDS (+1, -1, +2, -2, ...: two rolling words, one base shifted in per step each) and the walk ends at the first window that
+// equals the read's bases: a read's shift is a few bases (an indel, an overhang), so it is found after a dozen windows instead of 129
+// (the probe was 2.0 of 37 ms on reads that all need it).  Ties between imperfect windows: the one nearer to shift 0.
 __device__ __forceinline__ int c2_part_window(const c2_partition_args& P, const c2_part_task& t, const int p, int& best_s) {
-    const int D = t.Li - t.Lj;
     const int s_lo = -P.max_shift > -p ? -P.max_shift : -p;
     const int s_hi = P.max_shift < t.Li - 32 - p ? P.max_shift : t.Li - 32 - p;
     best_s = 0;
     if (s_lo > s_hi || p < 0 || p + 32 > t.Lj) return 64;
     const uint64_t rcode = c2_code32(t.rd + p);
-    uint64_t fcode = c2_code32(t.f + p + s_lo);
-    int best_mm = 64, best_span = 0x10000;
-    uint32_t buf = 0;                                               // the next four bases of the reference (one load per four windows)
-    for (int s = s_lo;; ++s) {
-        const uint64_t x = fcode ^ rcode;
-        const int m2 = __popcll((x | (x >> 1)) & 0x5555555555555555ull);
-        const int lo = s < 0 ? (D < s ? D : s) : (D < 0 ? D : 0), hi = s > 0 ? (D > s ? D : s) : (D > 0 ? D : 0);
-        const int span = hi - lo;
-        if (m2 < best_mm || (m2 == best_mm && span < best_span)) { best_mm = m2; best_span = span; best_s = s; }
-        if (s == s_hi) break;
-        const int k = (s - s_lo) & 3, pos = p + s + 32;            // the base that enters the window
-        if (k == 0) {
-            if (pos + 4 <= t.Li) __builtin_memcpy(&buf, t.f + pos, 4);
-            else { buf = 0; for (int b = 0; b < 4; ++b) if (pos + b < t.Li) buf |= (uint32_t)t.f[pos + b] << (8 * b); }
+    const uint64_t m55 = 0x5555555555555555ull;
+    int s0 = 0;                                                     // the shift the walk starts at: 0 where the reference has a window there
+    if (s0 < s_lo) s0 = s_lo;
+    if (s0 > s_hi) s0 = s_hi;
+    uint64_t up = c2_code32(t.f + p + s0), dn = up;                 // the windows at s0 + k and s0 - k
+    int best_mm;
+    {
+        const uint64_t x = up ^ rcode;
+        best_mm = __popcll((x | (x >> 1)) & m55);
+        best_s = s0;
+    }
+    const int reach = (s_hi - s0) > (s0 - s_lo) ? (s_hi - s0) : (s0 - s_lo);
+    for (int k = 1; k <= reach && best_mm > 0; ++k) {
+        if (s0 + k <= s_hi) {                                       // the base that enters at the top: reference position p + s0 + k + 31
+            up = (up >> 2) | ((uint64_t)(((unsigned)t.f[p + s0 + k + 31] >> 1) & 3u) << 62);
+            const uint64_t x = up ^ rcode;
+            const int m2 = __popcll((x | (x >> 1)) & m55);
+            if (m2 < best_mm) { best_mm = m2; best_s = s0 + k; }
         }
-        fcode = (fcode >> 2) | ((uint64_t)((buf >> (8 * k + 1)) & 3u) << 62);
+        if (s0 - k >= s_lo) {                                       // the base that enters at the bottom: reference position p + s0 - k
+            dn = (dn << 2) | (uint64_t)(((unsigned)t.f[p + s0 - k] >> 1) & 3u);
+            const uint64_t x = dn ^ rcode;
+            const int m2 = __popcll((x | (x >> 1)) & m55);
+            if (m2 < best_mm) { best_mm = m2; best_s = s0 - k; }
+        }
     }
     return best_mm;
 }
