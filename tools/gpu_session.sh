@@ -5,7 +5,7 @@
 # FASTQ -> all result tables (tools/e2e_tables.py); paired FASTQ rate; two gloo ranks sharing the GPU with the sharded FASTQ leg; the
 # unchanged caller's call rate.  `quick`: tests + bench only.
 set -u
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 QUICK=${2:-}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/${ROUND}final
@@ -46,4 +46,5 @@ try:
 except Exception as ex:
     print('2-rank parse failed', ex)
 PY
-timeout 600 python tools/shim_call_rate.py > "$OUT/shim_call_rate_20k.json" 2>/dev/null; tail -1 "$OUT/shim_call_rate_20k.json"
+timeout 600 python tools/shim_call_rate.py --procs 16 > "$OUT/shim_call_rate_20k.json" 2>/dev/null; tail -1 "$OUT/shim_call_rate_20k.json" | cut -c1-1500
+( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" ) > "$OUT/smoke.txt" 2>&1; tail -1 "$OUT/smoke.txt"

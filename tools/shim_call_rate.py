@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--len", type=int, default=250, dest="L")
+    ap.add_argument("--procs", type=int, default=0, help="also: the -p N shape -- everything primed in the parent, then N fork()ed workers loop over their slices")
+    ap.add_argument("--fork-reads", type=int, default=200000)
     a = ap.parse_args()
     import numpy as np
     from crispresso2_amd import synth, prime, CRISPResso2Align as A, CRISPRessoCOREResources as R
@@ -58,11 +60,46 @@ def main():
     st = dict(prime.stats)
     prime.clear()
     same = got[:n_pc] == ref
+    forked = None
+    if a.procs > 1:
+        # the reference's -p N (CRISPRessoCORE.py:1870-1898): the parent has used the device, primes what the workers will ask for (crispresso2_amd.prime
+        # does that by itself in a before-fork hook when the caller is the reference's process_fastq; here: the same call, made directly), forks,
+        # and every worker answers its slice from the memory it inherited
+        import multiprocessing as mp
+        from types import SimpleNamespace
+        from crispresso2_amd import refs as RF, _native
+        big = list(dict.fromkeys(r.tobytes().decode() for r in synth.make_reads(a.L, 3 * a.fork_reads)))[:a.fork_reads]
+        args = SimpleNamespace(aln_seed_count=5, aln_seed_min=2, needleman_wunsch_gap_open=-20, needleman_wunsch_gap_extend=-2, use_legacy_insertion_quantification=False)
+        ref_obj = RF.make_ref("Reference", amp, [a.L // 2], inc, min_aln_score=60)
+        ref_obj["gap_incentive"] = g
+        t0 = time.perf_counter()
+        prime.prime_for_caller(args, {"Reference": ref_obj}, ["Reference"], m, reads=big)
+        t_prime = time.perf_counter() - t0
+        b = [len(big) * k // a.procs for k in range(a.procs + 1)]
+
+        def work(lo, hi, q):
+            r = loop(big[lo:hi])
+            q.put((len(r), dict(prime.stats)["align_hits"], _native._helper[1].calls if _native._helper[0] == os.getpid() else 0))
+        ctx_ = mp.get_context("fork")
+        q = ctx_.Queue()
+        t0 = time.perf_counter()
+        ps = [ctx_.Process(target=work, args=(b[k], b[k + 1], q)) for k in range(a.procs)]
+        for p_ in ps:
+            p_.start()
+        res = [q.get() for _ in ps]
+        for p_ in ps:
+            p_.join()
+        t_loop = time.perf_counter() - t0
+        forked = {"procs": a.procs, "reads": len(big), "prime_seconds": t_prime, "loop_seconds": t_loop, "reads_per_s_loop": len(big) / t_loop,
+                  "reads_per_s_with_priming": len(big) / (t_loop + t_prime), "helper_calls": sum(r[2] for r in res), "done": sum(r[0] for r in res),
+                  "note": "the loop body here is two calls and a tuple per read -- lighter than the reference's get_new_variant_object + JSON line per read: the "
+                          "shim's share of a -p N run, not the run"}
+        prime.clear()
     print(json.dumps({"unique_reads": len(reads), "read_len": a.L,
                       "per_call": {"reads": n_pc, "seconds": t_pc, "reads_per_s": n_pc / t_pc, "global_align_call_us": 1e6 * t_align,
                                    "find_indels_substitutions_call_us": 1e6 * t_cls},
                       "primed": {"reads": len(reads), "seconds": t_pr, "reads_per_s": len(reads) / t_pr, "stats": st},
-                      "identical": bool(same),
+                      "identical": bool(same), "forked_workers": forked,
                       "note": "one Python process; the primed loop's time includes the two device batches (alignments, classifier lists) and "
                               "building the reference's Python objects at look-up time"}))
 
