@@ -1142,6 +1142,11 @@ def main():
             out["selection"] = selection
         if cpu_baseline:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu_baseline["value"]
+        # a side leg that failed or did not finish leaves its error in its own entry; this flag is what a script should look at (the exit code
+        # stays 0: the headline was measured, and N ranks must all end the same way -- ADVICE r04)
+        def _has_error(x):
+            return isinstance(x, dict) and ("error" in x or any(_has_error(v) for v in x.values()))
+        out["side_legs_ok"] = bool(extras_note[0] is None and not any(_has_error(leg) for leg in (int32_chain, other_configs, robustness, e2e, host_batch)))
         if extras_note[0]:
             out["side_legs_note"] = extras_note[0]
         print(json.dumps(out), file=file or sys.stdout)

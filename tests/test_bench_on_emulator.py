@@ -113,6 +113,7 @@ def test_side_legs_that_do_not_finish_cannot_cost_the_headline():
     assert len(lines) == 1, p.stdout[-2000:]
     out = lines[0]
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 1 and out["value"] > 0 and "did not finish" in out["side_legs_note"]
+    assert out["side_legs_ok"] is False                               # (what a script looks at: the exit code stays 0)
     assert 66 < out["counts"][0]["reads_aligned_all_gpus"] <= 132
 
 
@@ -137,6 +138,7 @@ def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fa
     assert wt["zip_member_equals_the_txt_legs_file"] is True          # (the reference ends with Alleles_frequency_table.zip; Python's zipfile reads our stream back)
     assert e2e["with_all_tables_txt"]["allele_table_bytes"] == wt["allele_table_text_bytes"] > 500
     assert e2e["plain"]["link_bytes"] == e2e["file_bytes"] and 0 < e2e["plain"]["frac_of_link_peak"]
+    assert out["side_legs_ok"] is True
     hb = out["host_batch_pcie_inclusive"]                            # the boundary with host buffers on both sides
     assert hb["reads"] == 90 and hb["all_status_ok"] and hb["reads_per_s"] > 0 and hb["link_bytes_per_read"] > 700
     assert set(wt["write_tables_stage_seconds"]) >= {"allele_table_build", "allele_table_write", "around_cut_tables", "other_tables"}
