@@ -1148,11 +1148,12 @@ def test_count_route_with_the_accumulator_block_in_hbm(mats, ctx, L, force, monk
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("read_len,expect_skipped", [(150, 2), (215, 1), (240, 0)])
+@pytest.mark.parametrize("read_len,expect_skipped", [(150, 3), (215, 2), (240, 0)])
 def test_band_tiers_no_read_of_the_batch_can_use_are_not_launched(mats, ctx, read_len, expect_skipped):
     """c2_batch.min_read_len: mates of 150 bp against a 250-bp amplicon cannot use the 32- and 62-diagonal tiers (diagonal 0 and diagonal
     len(ref) - len(read) = 100 do not fit one band): with the hint those tiers are not launched -- the same strings and records as without
-    it, and as the oracle's on a sample -- and fewer tiers in c2_tier_info; 215 bp: only the first tier goes; 240 bp: none."""
+    it, and as the oracle's on a sample -- and fewer tiers in c2_tier_info (round 5: the chain behind the partition has four band tiers, 32 / 40 / 62 /
+    128 diagonals: three of them go); 215 bp: the first tier goes, and with it the partition and the 40-diagonal tier that only runs behind it; 240 bp: none."""
     import torch
     from crispresso2_amd import synth, _native
     from crispresso2_amd.batch import BatchAligner
