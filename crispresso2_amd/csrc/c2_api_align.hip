@@ -12,7 +12,8 @@ namespace {
 struct Geometry {
     int R, passes, max_lj;
     uint32_t lds_full; int blocks_full;          // full pointer plane
-    bool full_hbm; uint64_t full_plane_words;    // ... in per-workgroup HBM scratch (it does not fit LDS): 32-bit words per workgroup
+    bool full_hbm; uint64_t full_plane_words;    // ... in per-workgroup HBM scratch (it does not fit LDS, or a batch prefers it): 32-bit words per workgroup
+    bool full_both; uint32_t lds_full_l; int blocks_full_l;    // the plane fits LDS too: a batch's last launch comes in both forms, the list's length decides (list_gate)
     int band_lanes; uint32_t lds_band; int blocks_band;   // banded first launch (band_lanes == 0: not used)
     bool diag; uint32_t lds_diag; int blocks_diag;         // diagonal-band launches
     bool x[2]; uint32_t lds_x[2]; int blocks_x[2]; uint32_t plane_words;   // multi-alignment tiers in front of it: 4, 2 per wavefront
@@ -96,6 +97,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
     const size_t lds_cu = 163840;
     g.lds_full = c2_make_plan(g.R, g.max_lj, g.passes, ctx->sc.n_codes, 0).total;
     g.full_hbm = false; g.full_plane_words = 0;
+    g.full_both = false; g.lds_full_l = 0; g.blocks_full_l = 0;
     bool hbm_by_choice = false;                                    // (the plane would fit LDS: the banded row-strip launch in front is still possible)
     int blocks_full_lds = 0;                                       // workgroups per CU of the full launch with its plane in LDS
     int rc;
@@ -123,6 +125,7 @@ int geometry(c2_ctx* ctx, int max_lj, Geometry& g, const uint64_t n_tasks = 0) {
             const uint64_t words_h = (c2_hbm_plane_halfwords(g.max_lj, g.passes) + 1) / 2;
             int blocks_h = 0;
             if (lds_h <= lds_cu && words_h <= 0xFFFFFFFFull && !(rc = occupancy_r<2>(ctx, g.R, lds_h, blocks_h)) && blocks_h > g.blocks_full) {
+                g.full_both = true; g.lds_full_l = g.lds_full; g.blocks_full_l = g.blocks_full;
                 g.full_hbm = true; g.lds_full = lds_h; g.full_plane_words = words_h; g.blocks_full = blocks_h;
                 hbm_by_choice = true;
             }
@@ -265,10 +268,19 @@ uint64_t hbm_plane_wgs(const c2_ctx* ctx, const Geometry& g, uint64_t work_items
 
 // the last launch of every chain: full pointer plane, in LDS or (if it does not fit) in HBM scratch
 template <int R>
-int launch_full(c2_ctx* ctx, c2_align_args& A, const Geometry& g, hipStream_t s) {
+int launch_full(c2_ctx* ctx, c2_align_args& A, const Geometry& g, hipStream_t s, unsigned long long* second_counter = nullptr) {
     if (!g.full_hbm) return launch_one<R, 0>(ctx, A, g.lds_full, g.blocks_full, A.n_tasks, s);
-    const uint64_t wgs = hbm_plane_wgs(ctx, g, A.n_tasks);
     int rc;
+    constexpr int GATE = 8192;                                     // (0.66 ms = what one alignment takes with the plane in HBM = 9 k alignments with it in LDS)
+    if (g.full_both && A.task_list && second_counter) {
+        // a list of unknown length: the LDS form works if it is short, the HBM form if it is long (the other one returns at once)
+        c2_align_args L = A;
+        L.list_gate = GATE;
+        if ((rc = launch_one<R, 0>(ctx, L, g.lds_full_l, g.blocks_full_l, std::min<uint64_t>(A.n_tasks, (uint64_t)GATE), s))) return rc;
+        A.list_gate = -GATE;
+        A.work_counter = second_counter;
+    }
+    const uint64_t wgs = hbm_plane_wgs(ctx, g, A.n_tasks);
     if ((rc = ensure(ctx, ctx->d_plane, (size_t)(wgs * g.full_plane_words * sizeof(uint32_t))))) return rc;
     A.plane = (uint32_t*)ctx->d_plane.p; A.plane_words_per_wg = (uint32_t)g.full_plane_words;
     hipLaunchKernelGGL((c2_align_classify_kernel<R, 2>), dim3((unsigned)wgs), dim3(64), g.lds_full, s, A);
@@ -391,6 +403,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 PA.probe_max_mismatch = 4; PA.margin = 3; PA.max_shift = (p16_stage || route) ? 64 : 0;
                 PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
                 PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
+                PA.check_cut = many_refs ? 1 : 0;                        // (one amplicon: a read that differs from it around the cut fails the score-only certificate anyway, and the look costs 0.3 ms per 10 M)
                 if (const char* e = getenv("C2_SCORE_TIER_MAX_MISMATCH")) PA.max_mismatch = atoi(e);
                 if (const char* e = getenv("C2_ROUTE_PROBE_MISMATCH")) PA.probe_max_mismatch = atoi(e);
                 if (const char* e = getenv("C2_ROUTE_MARGIN")) PA.margin = atoi(e);
@@ -542,7 +555,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
         chain(A, false, false);
         A.fb_list = nullptr; A.fb_count = nullptr;
         ctx->last_tiers = tier;
-        if ((rc = launch_full<R>(ctx, A, g, s))) return rc;
+        if ((rc = launch_full<R>(ctx, A, g, s, (unsigned long long*)(hdr + 16 + 2 * launch)))) return rc;      // (the second form's own work counter)
     } else {
         ctx->last_tiers = 0;
         if ((rc = ensure(ctx, ctx->d_fb, 32))) return rc;
@@ -610,7 +623,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.max_lj = g.max_lj; A.max_passes = g.passes;
     A.max_li = ctx->max_li;
     A.legacy = (b->flags & C2_BATCH_LEGACY_CLASSIFIER) ? 1 : 0;
-    A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)ctx->pk_beta; A.pk_bias = (uint32_t)ctx->pk_bias; A.reserved4 = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
+    A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)ctx->pk_beta; A.pk_bias = (uint32_t)ctx->pk_bias; A.list_gate = 0; A.diag_base = (const c2_diag_row*)ctx->d_diagrows.p;
     A.diagpk_base = ctx->any_pk_ok ? (const c2_diag_row*)ctx->d_diagrows_pk.p : nullptr;
     A.mat_dim = ctx->sc.mat_dim; A.first_ext_code = ctx->sc.first_ext_code;
     c2_build_base_luts(ctx->sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);

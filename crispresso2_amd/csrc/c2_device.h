@@ -92,7 +92,7 @@ typedef struct c2_align_args {
     const struct c2_diag_row* diag_base;   // start of the buffer every reference's diag_rows points into
     const struct c2_diag_row* diagpk_base; // the packed kernels' row tables, same indexing: {a, b, c} as int16 pairs, prof = LDS offset of the symbol's pair-score table
     uint32_t pk_bias;             // the 32-bit-add variant's value bias (c2_pk_add32_bias_needed); the packed-add variant uses the constant C2_PK_BIAS
-    uint32_t reserved4;
+    int32_t list_gate;            // full-matrix kernel in list mode: > 0: run only if the list holds at most that many tasks; < 0: only if it holds more than -list_gate; 0: always
 } c2_align_args;
 
 // Kernel arguments for the per-call classifier (find_indels_substitutions / _legacy with full lists).

@@ -791,6 +791,13 @@ __global__ __launch_bounds__(64, C2_FULL_WAVES) void c2_align_classify_kernel(c2
     constexpr bool BAND = MODE == 1;
     constexpr int MULTI = MODE == 2 ? 2 : 0;                     // plane mode of the multi-pass sweeps (never banded)
     const int lane = threadIdx.x;
+    // the last launch of a batch's chain comes in two forms -- plane in LDS (a short list is done sooner: one alignment takes 0.3 ms there, 0.6 ms
+    // with the plane in HBM) and plane in HBM scratch (a long list: four wavefronts per SIMD, twice the rate) -- and the host cannot know the
+    // list's length: both are launched, and the list decides which of them works
+    if (A.task_list && A.list_gate) {
+        const uint32_t n = *A.task_count;
+        if (A.list_gate > 0 ? n > (uint32_t)A.list_gate : n <= (uint32_t)(-A.list_gate)) return;
+    }
     const c2_lds_plan P = c2_make_plan(R, A.max_lj, A.max_passes, A.n_codes, BAND ? A.band_lanes : 0, MODE == 2);
     const int pass_halfwords = MODE == 2 ? (A.max_lj + 64) * 64 : A.max_lj * (int)P.col_stride;
     uint16_t* sPtr = MODE == 2 ? (uint16_t*)(A.plane + (size_t)blockIdx.x * A.plane_words_per_wg) : (uint16_t*)(c2_smem + P.ptr);
@@ -2104,7 +2111,8 @@ struct c2_partition_args {
     uint32_t* class_count;                      // [C2_PART_CLASSES] tasks per class (statistics)
     int32_t bandw[5];                           // diagonals of the launches behind classes 1 .. 5 (14, 32, 40, 62, 128), 0: the chain has no such launch
     int32_t max_mismatch, probe_max_mismatch, margin, max_shift;
-    int32_t direct_full, sort_by_length;        // class 5 exists; order a ragged chunk's slots by read length
+    int32_t direct_full, sort_by_length;        // the last class exists; order a ragged chunk's slots by read length
+    int32_t check_cut;                          // class 0 also looks at the 32 columns around the cut site (batches with several candidate amplicons)
 };
 
 #define C2_PART_CHUNK 4096                         // tasks per workgroup and set of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
@@ -2273,7 +2281,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                     // ... and the 32 columns around the cut site (where the edits are, and where a candidate amplicon differs from the others: a read of
                     // the wild type against the prime-edited amplicon of the same length is a dozen mismatches in a row there -- gap-free, but more
                     // than the 14-diagonal certificate of the score-only launch allows: its fill would be for nothing)
-                    if (mm <= P.max_mismatch && t.cut >= 0) {
+                    if (P.check_cut && mm <= P.max_mismatch && t.cut >= 0) {
                         int c0 = t.cut - 16;
                         if (c0 > t.Lj - 64) c0 = t.Lj - 64;                 // (the last 32 columns have been looked at)
                         if (c0 < 0) c0 = 0;

@@ -112,7 +112,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1), fb_list3(A.n_tasks ? A.n_tasks : 1), fb_list4(A.n_tasks ? A.n_tasks : 1);   // (the full-plane launch below reads the last tier's)
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
     std::vector<uint32_t> plane;
-    A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)pk_beta; A.pk_bias = (uint32_t)pk_bias; A.reserved4 = 0;
+    A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)pk_beta; A.pk_bias = (uint32_t)pk_bias; A.list_gate = 0;
     A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0; A.legacy = getenv("C2_EMU_LEGACY") ? 1 : 0;
     A.mat_dim = sc.mat_dim; A.first_ext_code = sc.first_ext_code;
     c2_build_base_luts(sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
@@ -181,6 +181,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             PA.list[6] = lists[ifull - 1]; PA.count[6] = &fb_counts[ifull - 1];      // the list the last launch (the full plane) reads
             PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
             PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
+            PA.check_cut = (A.all_refs && A.n_refs > 1) ? 1 : 0;
             PA.class_count = class_counts;
             PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier40_runs) ? 40 : 0;
             PA.bandw[3] = (route && tier1_runs) ? 62 : 0; PA.bandw[4] = (route && tier2_runs) ? 128 : 0;
