@@ -1526,7 +1526,9 @@ __device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g
     }
 }
 
+#ifndef C2X_GRAB
 #define C2X_GRAB 8                                  // groups of NA positions per grab of the work counter, at most
+#endif
 template <int NA, bool PK, bool ADD32 = false, bool SCORE = false>
 __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
 {
@@ -1607,7 +1609,9 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
     // there (5.8 ns per task against 1.6 with one amplicon).  One atomic per block instead of one per group.
     // (a block is C2X_GRAB groups when the launch has work for at least four blocks per workgroup, fewer for a short list: a million-task batch
     //  over 2,300 workgroups in blocks of 128 tasks left some of them with three blocks and some with two)
-    int grab = (int)(n_iter / ((uint64_t)gridDim.x * (uint64_t)(NA * 4)));
+    //  -- and only for a batch of several references (A.reserved bit 3): with one reference nothing is re-staged, and single groups balance the
+    //  workgroups better (measured on the headline batch: 34.7 ms with single groups, 35.5 with blocks of 8, 36.1 with 16)
+    int grab = (A.reserved & 8) ? (int)(n_iter / ((uint64_t)gridDim.x * (uint64_t)(NA * 4))) : 1;
     grab = grab < 1 ? 1 : (grab > C2X_GRAB ? C2X_GRAB : grab);
     unsigned long long blk_next = 0;                                // next position of the current block (wave-uniform)
     int blk_left = 0;                                               // groups of it not handed out yet
