@@ -2,7 +2,10 @@
 
 Follows CRISPRessoCORE.py:3964-4115 (the "Quantifying indels/substitutions" loop, non-coding case: no exons) and
 process_fastq's aln_stats (:1974-1979), taking per-read classifier payloads (the reference's / the oracle's
-find_indels_substitutions output) and read multiplicities.  Returns plain numpy vectors keyed by the reference's names."""
+find_indels_substitutions output) and read multiplicities.  Returns plain numpy vectors keyed by the reference's names.
+Pinned by runs of the reference itself, not only by reading it: aggregate() by the nucleotide / modification count tables of the eight whole-run goldens
+(tests/test_whole_run_tables.py: the reference's main() wrote those files from its own loop; the tables built from this function's vectors equal them byte
+for byte), allele_table_text() / alleles_around_cut() by the same runs' Alleles_frequency_table.txt and ..._around_sgRNA_... files."""
 from collections import Counter
 
 import numpy as np

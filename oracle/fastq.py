@@ -1,8 +1,12 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the first pass of process_fastq (reference
 CRISPResso2/CRISPRessoCORE.py:1820-1849) and of process_paired_fastq (:1296-1334, :1452-1470): the FASTQ -> {sequence: copies} loop, line for line (text mode, readline,
 strip() on the sequence and '+' lines, every non-empty first line starts a record, '' keys included).
-Parity pinned: it is the reference's own statements with the logging removed; tests/test_fastq_ingest.py compares the
-native c2_fastq_unique with it.  Never imported by the product package."""
+Parity pinned: it is the reference's own statements with the logging removed, and what it feeds is pinned end to end by runs of the reference itself:
+read_fastq_unique by every whole-run golden of tests/test_whole_run_tables.py (tests/golden/fanc_full_run / params_run / both_run / pe_run / ...: the
+reference's main() read the same FASTQ and its result files come out byte for byte), filter_fastq by the filtered FASTQ of the reference's own
+CRISPResso_on_params run (params_run.json.gz: `fastq_after_quality_filter`), the paired loop by tests/golden/paired_fastq.json.gz (the reference's
+process_paired_fastq on the same two files: keys, order, counts).  tests/test_fastq_ingest.py compares the native c2_fastq_unique with it.
+Never imported by the product package."""
 import gzip
 
 
