@@ -579,7 +579,7 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
     }
     int idx_base = 0, last_rf = -1, last_rd = -1;
     int n_all_sub = 0, n_win_sub = 0, n_all_ins = 0, n_win_ins = 0, n_all_del = 0, n_win_del = 0;
-    int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;   // per-lane partial sums
+    int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;   // sums over the events (wave-uniform)
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     if (T == Li && T == Lj) {
         // no gap column in either string (T = Li + insertion columns = Lj + deletion columns): the reference index of a
@@ -629,18 +629,33 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
         const bool fl = ins_close && (sIncP[idx] != sIncP[idx - 1]), fr = ins_close && (sIncP[idx + 1] != sIncP[idx]);
         const bool ins_win = A.legacy ? (fl || fr) : (fl && fr);
         n_all_ins += __popcll(__ballot(ins_close));
-        n_win_ins += __popcll(__ballot(ins_win));
-        if (ins_win) acc_ins_n += cidx - 1 - prev_rf;
+        // (the sums over events are wave-uniform: an alignment has one or two events, so each is fetched from its lane -- no per-lane partial
+        //  sums, and no three six-step reductions at the end for every traced alignment)
+        {
+            unsigned long long ev = __ballot(ins_win);
+            n_win_ins += __popcll(ev);
+            const int isz = cidx - 1 - prev_rf;
+            while (ev) { const int l = __builtin_ctzll(ev); ev &= ev - 1ull; acc_ins_n += __builtin_amdgcn_readlane(isz, l); }
+        }
         // deletion closes at this column, pyx:145-153
         const bool del_close = rd_ng && (prev_rd != cidx - 1);
         const int dlen = cidx - 1 - prev_rd;
         // legacy (pyx:253-258): a run that starts in column 0 or 1 is given reference start 0 (`if st-1 > 0`)
         const int dstart = (A.legacy && prev_rd <= 0) ? 0 : idx - dlen;
         const bool del_win = del_close && (sIncP[idx] != sIncP[dstart]);       // include set hits range(start,end)
-        n_all_del += __popcll(__ballot(del_close));
-        n_win_del += __popcll(__ballot(del_win));
-        if (del_close) acc_del_bases += idx - dstart;
-        if (del_win) acc_del_n += dlen;
+        {
+            unsigned long long ev = __ballot(del_close);
+            const unsigned long long evw = __ballot(del_win);
+            n_all_del += __popcll(ev);
+            n_win_del += __popcll(evw);
+            const int dbases = idx - dstart;
+            while (ev) {
+                const int l = __builtin_ctzll(ev);
+                ev &= ev - 1ull;
+                acc_del_bases += __builtin_amdgcn_readlane(dbases, l);
+                if ((evw >> l) & 1ull) acc_del_n += __builtin_amdgcn_readlane(dlen, l);
+            }
+        }
         idx_base += __popcll(m_rf);
         if (m_rf) last_rf = base + 63 - __clzll((long long)m_rf);
         if (m_rd) last_rd = base + 63 - __clzll((long long)m_rd);
@@ -660,12 +675,6 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
             tr_bases = dend > dstart ? dend - dstart : 0;
             if (dend > dstart && sIncP[dend] != sIncP[dstart]) { tr_win = dlen; n_win_del += 1; }
         }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        acc_ins_n += __shfl_xor(acc_ins_n, m);
-        acc_del_n += __shfl_xor(acc_del_n, m);
-        acc_del_bases += __shfl_xor(acc_del_bases, m);
     }
     const unsigned char r0 = sTmpRead[T - 1], f0 = sTmpRef[T - 1], rL = sTmpRead[0], fL = sTmpRef[0];
     rec.irregular_ends = (r0 == '-' || f0 == '-' || r0 != f0 || rL == '-' || fL == '-' || rL != fL) ? 1 : 0;
