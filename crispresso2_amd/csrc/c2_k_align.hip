@@ -623,27 +623,29 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
         const bool sub_win = sub && (sIncP[idx + 1] != sIncP[idx]);
         n_all_sub += __popcll(__ballot(sub));
         n_win_sub += __popcll(__ballot(sub_win));
-        // insertion closes at this column, pyx:119-128; leading insertions (idx==0) are never opened, pyx:136
-        const bool ins_close = rf_ng && (prev_rf != cidx - 1) && idx > 0;
-        // in the window: both flanks (pyx:121) -- the legacy classifier: either flank (pyx:284)
-        const bool fl = ins_close && (sIncP[idx] != sIncP[idx - 1]), fr = ins_close && (sIncP[idx + 1] != sIncP[idx]);
-        const bool ins_win = A.legacy ? (fl || fr) : (fl && fr);
-        n_all_ins += __popcll(__ballot(ins_close));
-        // (the sums over events are wave-uniform: an alignment has one or two events, so each is fetched from its lane -- no per-lane partial
-        //  sums, and no three six-step reductions at the end for every traced alignment)
-        {
+        // insertion closes at this column, pyx:119-128; leading insertions (idx==0) are never opened, pyx:136.  (Skipped when the chunk has no
+        // gap in the reference string and no such run is open in front of it: no column of it can close one -- a read with one deletion.)
+        const unsigned long long m_in2 = __ballot(in);
+        if (m_rf != m_in2 || last_rf != base - 1) {
+            const bool ins_close = rf_ng && (prev_rf != cidx - 1) && idx > 0;
+            // in the window: both flanks (pyx:121) -- the legacy classifier: either flank (pyx:284)
+            const bool fl = ins_close && (sIncP[idx] != sIncP[idx - 1]), fr = ins_close && (sIncP[idx + 1] != sIncP[idx]);
+            const bool ins_win = A.legacy ? (fl || fr) : (fl && fr);
+            n_all_ins += __popcll(__ballot(ins_close));
+            // (the sums over events are wave-uniform: an alignment has one or two events, so each is fetched from its lane -- no per-lane partial
+            //  sums, and no three six-step reductions at the end for every traced alignment)
             unsigned long long ev = __ballot(ins_win);
             n_win_ins += __popcll(ev);
             const int isz = cidx - 1 - prev_rf;
             while (ev) { const int l = __builtin_ctzll(ev); ev &= ev - 1ull; acc_ins_n += __builtin_amdgcn_readlane(isz, l); }
         }
-        // deletion closes at this column, pyx:145-153
-        const bool del_close = rd_ng && (prev_rd != cidx - 1);
-        const int dlen = cidx - 1 - prev_rd;
-        // legacy (pyx:253-258): a run that starts in column 0 or 1 is given reference start 0 (`if st-1 > 0`)
-        const int dstart = (A.legacy && prev_rd <= 0) ? 0 : idx - dlen;
-        const bool del_win = del_close && (sIncP[idx] != sIncP[dstart]);       // include set hits range(start,end)
-        {
+        // deletion closes at this column, pyx:145-153 (likewise skipped when the read string has no gap here and no run is open)
+        if (m_rd != m_in2 || last_rd != base - 1) {
+            const bool del_close = rd_ng && (prev_rd != cidx - 1);
+            const int dlen = cidx - 1 - prev_rd;
+            // legacy (pyx:253-258): a run that starts in column 0 or 1 is given reference start 0 (`if st-1 > 0`)
+            const int dstart = (A.legacy && prev_rd <= 0) ? 0 : idx - dlen;
+            const bool del_win = del_close && (sIncP[idx] != sIncP[dstart]);       // include set hits range(start,end)
             unsigned long long ev = __ballot(del_close);
             const unsigned long long evw = __ballot(del_win);
             n_all_del += __popcll(ev);
