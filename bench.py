@@ -484,7 +484,8 @@ def _e2e_sharded_leg(path, n_reads, ctx, L, matrix, dev, repeat=2):
     import torch
     import torch.distributed as dist
     from types import SimpleNamespace
-    from crispresso2_amd import pipeline, refs as RF, synth
+    from crispresso2_amd import pipeline, refs as RF, synth, _native
+    gz_inflate = None
     amp, g, inc = synth.amplicon_setup(L)
     args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=GO, needleman_wunsch_gap_extend=GE,
                            ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
@@ -569,7 +570,7 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
     tallies = {}
     kinds = [("plain", files["plain"]), ("plain_host_parser", files["plain"]), ("bgzf", files["bgzf"]), ("bgzf_host_parser", files["bgzf"])]
     if files.get("gzip"):
-        kinds.append(("gzip", files["gzip"]))                        # single member: ONE inflate stream on the host (libdeflate whole-buffer), then the device frames the text
+        kinds.append(("gzip", files["gzip"]))                        # single member: ONE deflate stream, inflated by all host threads (c2_gz_parallel.h), then the device frames the text
     for kind, path in kinds:
         # plain: the text is uploaded as it is and framed + de-duplicated by the c2_fq_* kernels (fastq_device); bgzf: the host inflates
         # (all usable threads) and the same kernels frame the text it then holds; *_host_parser: the same files through the native host
@@ -596,6 +597,7 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
             link_bytes = None
         elif kind == "gzip":
             link_bytes = files["bytes_plain"]                         # (the host inflates; the text crosses the link)
+            gz_inflate = _native.gz_parallel_last()                   # (of the last run: segments, seconds of the search and the two passes)
         else:
             link_bytes = files["bytes_plain"]
         out[kind] = {"seconds": dt, "reads_per_s": files["reads"] / dt, "seconds_all_runs": [r[0] for r in runs], "stage_seconds": tm,
@@ -679,9 +681,10 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
     out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"] == tallies["plain_host_parser"] == tallies["bgzf_host_parser"]
     if "gzip" in tallies:
         out["plain_equals_gzip"] = tallies["plain"] == tallies["gzip"]
-        out["gzip"]["note"] = ("an ordinary single-member .gz (one deflate stream, level 6): the host inflates it on ONE thread (libdeflate into one buffer; a single "
-                               "stream cannot be split without speculative decoding, which is not built), then the text is uploaded and framed on the device like "
-                               "the plain file's; BGZF input inflates on all threads")
+        out["gzip"]["note"] = ("an ordinary single-member .gz (one deflate stream, level 6), inflated by all host threads (c2_gz_parallel.h: block starts found by "
+                               "search, every segment decoded twice -- symbols, then bytes -- CRC-32 and ISIZE checked; whatever it declines goes to libdeflate on "
+                               "one thread), then the text is uploaded and framed on the device like the plain file's")
+        out["gzip"]["inflate"] = gz_inflate
     out["tallies"] = dict(zip(("N_TOT_READS", "N_TOTAL", "counts_total", "modified", "with_insertion", "with_deletion", "with_substitution"),
                               tallies["plain"]))
     out["note"] = ("pipeline.quantify_fastq on the headline's reads as a FASTQ file (qualities 'I'), page cache warm: ingest + exact "

@@ -25,7 +25,7 @@ SYMBOLS = [
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners", "c2_gather_reads",
-    "c2_score_stage_info", "c2_partition_info", "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close",
+    "c2_score_stage_info", "c2_partition_info", "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close", "c2_gz_inflate_parallel", "c2_gz_parallel_last",
     "c2_consensus_pairs_batch", "c2_consensus_pairs_device", "c2_classify_records_device",
     "c2_fq_count_device", "c2_fq_lines_device", "c2_fq_dedup_device", "c2_fq_gather_device", "c2_fq_rc_partner_device",
     "c2_fq_lines4_device", "c2_fq_pair_lengths_device", "c2_fq_pair_write_device",
@@ -127,6 +127,10 @@ def load():
             lib.c2_bgzf_inflate.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32]
             lib.c2_bgzf_close.restype = None
             lib.c2_bgzf_close.argtypes = [ctypes.c_void_p]
+            lib.c2_gz_parallel_last.restype = None
+            lib.c2_gz_parallel_last.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+            lib.c2_gz_inflate_parallel.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                                   ctypes.c_int32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
             lib.c2_fastq_stream_close.restype = None
             lib.c2_fastq_stream_close.argtypes = [ctypes.c_void_p]
             lib.c2_fastq_stream_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
@@ -343,6 +347,14 @@ class Context:
         v = [ctypes.c_int32(0) for _ in range(5)]
         self.check(self.lib.c2_launch_info(self.handle, int(max_read_len), *[ctypes.byref(x) for x in v]), "c2_launch_info")
         return dict(zip(("rows_per_lane", "passes", "lds_bytes", "workgroups_per_cu", "compute_units"), [x.value for x in v]))
+
+
+def gz_parallel_last():
+    """c2_gz_parallel_last: what the one-member-on-all-threads route did for the last .gz file opened on this thread"""
+    st = (ctypes.c_uint64 * 8)()
+    load().c2_gz_parallel_last(st)
+    return dict(segments=int(st[0]), block_starts_found=int(st[1]), text_bytes=int(st[2]), fell_back=bool(st[3]),
+                seconds=dict(search=st[4] / 1e6, first_pass=st[5] / 1e6, windows=st[6] / 1e6, second_pass=st[7] / 1e6))
 
 
 def fastq_unique(path, min_single_bp_quality=0, min_average_read_quality=0, min_bp_quality_or_N=0, stats=None):

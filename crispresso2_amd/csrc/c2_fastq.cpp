@@ -35,6 +35,7 @@
 #include <functional>
 
 #include "crispresso2_amd.h"
+#include "c2_gz_parallel.h"
 
 // Byte arena that never value-initialises what it hands out (a std::vector<uint8_t>::resize to the size of all unique reads is a
 // serial zero-fill of hundreds of megabytes -- and of their page faults -- right before the threads overwrite every byte).
@@ -516,12 +517,14 @@ struct Deflate {
     void* (*alloc)() = nullptr;
     void (*release)(void*) = nullptr;
     int (*gunzip)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;   // libdeflate_gzip_decompress_ex
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;                               // libdeflate_crc32 (carry-less multiply: ~10x zlib 1.2.11's)
     Deflate() {
         lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!lib) return;
         alloc = (void* (*)())dlsym(lib, "libdeflate_alloc_decompressor");
         release = (void (*)(void*))dlsym(lib, "libdeflate_free_decompressor");
         gunzip = (int (*)(void*, const void*, size_t, void*, size_t, size_t*, size_t*))dlsym(lib, "libdeflate_gzip_decompress_ex");
+        crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(lib, "libdeflate_crc32");
     }
     bool ok() const { return alloc && release && gunzip; }
 };
@@ -670,6 +673,28 @@ bool inflate_members(const uint8_t* b, size_t n, TextBuf& text, size_t& n_text) 
     return ok;
 }
 
+// ONE ordinary gzip member (gzip / pigz output, no BGZF index) on all threads: c2_gz_parallel.h.  Only worth it from a few megabytes
+// up; C2_GZ_PARALLEL=0 switches it off, C2_GZ_PARALLEL_MIN / C2_GZ_PARALLEL_CHUNK move its thresholds (tests).  false -> the serial routes.
+thread_local c2gz::Stats g_gz_stats;
+bool inflate_single_parallel(const uint8_t* b, size_t n, TextBuf& text, size_t& n_text, unsigned threads) {
+    if (const char* e = getenv("C2_GZ_PARALLEL")) if (!strcmp(e, "0")) return false;
+    size_t min_bytes = (size_t)4 << 20, chunk = 0;
+    if (const char* e = getenv("C2_GZ_PARALLEL_MIN")) min_bytes = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("C2_GZ_PARALLEL_CHUNK")) chunk = (size_t)strtoull(e, nullptr, 10);
+    if (n < min_bytes || threads < 2) return false;
+    if (!chunk) {                                                  // ~4 segments per thread, 256 KiB .. 8 MiB each
+        chunk = n / ((size_t)threads * 4u);
+        if (chunk < ((size_t)256 << 10)) chunk = (size_t)256 << 10;
+        if (chunk > ((size_t)8 << 20)) chunk = (size_t)8 << 20;
+    }
+    const size_t budget = inflate_budget();
+    auto room = [&](size_t total) -> uint8_t* {
+        if (total > budget || !text.reserve(total ? total : 1)) return nullptr;
+        return (uint8_t*)text.get();
+    };
+    return c2gz::inflate_single_member(b, n, threads, chunk, room, n_text, g_gz_stats, deflate_lib().crc);
+}
+
 // CPUs this process may actually use: the hardware threads, cut to the cgroup's CPU bandwidth quota (cpu.max "<quota> <period>", or
 // cgroup v1's cfs files) and to the affinity mask.  Running more threads than the quota does not add throughput -- the group is
 // throttled for the rest of every period once the quota is spent -- it only adds stalls of up to a period (100 ms).
@@ -732,6 +757,7 @@ int fastq_unique_gz_whole(const uint8_t* m, size_t n, c2_fastq* R) {
     if (hw > 64) hw = 64;
     const char* how = "bgzf";
     bool ok = inflate_bgzf(m, n, use_libdeflate, text, n_text, hw);
+    if (!ok && use_libdeflate) { how = "one member, all threads"; ok = inflate_single_parallel(m, n, text, n_text, hw); }
     if (!ok && use_libdeflate) { how = "libdeflate"; ok = inflate_members(m, n, text, n_text); }
     if (!ok) return 0;
     if (trace) fprintf(stderr, "c2_fastq: gz whole-buffer route (%s), %zu -> %zu bytes in %.3f s\n", how, n, n_text, now_s() - T0);
@@ -825,6 +851,7 @@ struct TextSource {                                             // the whole tex
         if (hw > 64) hw = 64;
         size_t got = 0;
         bool ok = !stream_only && mapped_n >= 18 && inflate_bgzf(b, mapped_n, use_libdeflate, inflated, got, hw);
+        if (!ok && !stream_only && use_libdeflate && mapped_n >= 18) ok = inflate_single_parallel(b, mapped_n, inflated, got, hw);
         if (!ok && !stream_only && use_libdeflate && mapped_n >= 18) ok = inflate_members(b, mapped_n, inflated, got);
         if (!ok) {
             GzMembers gm;
@@ -1294,6 +1321,42 @@ int c2_bgzf_inflate(c2_bgzf* h, uint64_t b0, uint64_t b1, uint8_t* dst, uint64_t
     return 0;
 }
 void c2_bgzf_close(c2_bgzf* h) { delete h; }
+
+static void gz_stats_out(const c2gz::Stats& st, uint64_t* stats8) {
+    stats8[0] = st.segments; stats8[1] = st.blocks_found; stats8[2] = st.bytes_out; stats8[3] = st.fell_back;
+    stats8[4] = (uint64_t)(st.t_find * 1e6); stats8[5] = (uint64_t)(st.t_pass1 * 1e6); stats8[6] = (uint64_t)(st.t_windows * 1e6); stats8[7] = (uint64_t)(st.t_pass2 * 1e6);
+}
+// what the file routes' last attempt on this thread did (all zero: no .gz file opened yet, or the route was not tried)
+void c2_gz_parallel_last(uint64_t* stats8) { if (stats8) gz_stats_out(g_gz_stats, stats8); }
+
+// ---- one ordinary gzip member on all threads (c2_gz_parallel.h), as an entry of its own: tests and tools call it with their own segment size ----
+int c2_gz_inflate_parallel(const uint8_t* gz, uint64_t n, uint8_t* dst, uint64_t cap, uint64_t* n_out, int32_t threads, uint64_t chunk_bytes,
+                           uint64_t* stats8) {
+    if (!gz || !n_out || (!dst && cap)) { g_fastq_error = "c2_gz_inflate_parallel: null argument"; return C2_E_INVALID; }
+    unsigned th = threads > 0 ? (unsigned)threads : usable_cpus();
+    if (th > 256) th = 256;
+    size_t chunk = (size_t)chunk_bytes;
+    if (!chunk) {
+        chunk = (size_t)n / ((size_t)th * 4u);
+        if (chunk < ((size_t)256 << 10)) chunk = (size_t)256 << 10;
+        if (chunk > ((size_t)8 << 20)) chunk = (size_t)8 << 20;
+    }
+    uint64_t needed = 0;
+    bool too_small = false;
+    auto room = [&](size_t total) -> uint8_t* {
+        needed = total;
+        if (total > cap) { too_small = true; return nullptr; }
+        return dst ? dst : (uint8_t*)"";
+    };
+    c2gz::Stats st;
+    size_t got = 0;
+    const bool ok = c2gz::inflate_single_member(gz, (size_t)n, th, chunk, room, got, st, deflate_lib().crc);
+    if (stats8) gz_stats_out(st, stats8);
+    if (too_small) { *n_out = needed; g_fastq_error = "c2_gz_inflate_parallel: destination too small"; return C2_E_OVERFLOW; }
+    if (!ok) { *n_out = 0; g_fastq_error = std::string("c2_gz_inflate_parallel: not applicable (") + st.why + "): inflate the file serially"; return C2_E_INVALID; }
+    *n_out = got;
+    return 0;
+}
 
 // ---- host-side helpers of the read -> reference bookkeeping that sits between ingest and the kernels ----------------
 

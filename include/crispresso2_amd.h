@@ -494,6 +494,22 @@ uint64_t c2_bgzf_n_blocks(const c2_bgzf* h);
 const uint64_t* c2_bgzf_text_offsets(const c2_bgzf* h);
 int c2_bgzf_inflate(c2_bgzf* h, uint64_t b0, uint64_t b1, uint8_t* dst, uint64_t cap, int32_t threads);
 void c2_bgzf_close(c2_bgzf* h);
+
+/* ONE ordinary gzip member (the whole file: `gzip -6 reads.fastq`, pigz) inflated by `threads` host threads (<= 0: the CPUs this process may
+ * use) -- what gzip.open(fastq_filename, 'rt') does on one thread, CRISPResso2/CRISPRessoCORE.py:1820-1823.  The file routes above take this
+ * path by themselves for files of a few megabytes and more (C2_GZ_PARALLEL=0 switches it off); this entry is the same code with the caller's
+ * segment size (`chunk_bytes` of compressed data per segment, 0: the library's choice) and buffer.  Block boundaries are found by search,
+ * every segment is decoded twice (symbols, then bytes), the member's CRC-32 and ISIZE are checked (c2_gz_parallel.h).
+ *   0              the text is in dst, *n_out bytes
+ *   C2_E_OVERFLOW  cap is too small; *n_out = the size of the text
+ *   C2_E_INVALID   not applicable or not certain (several members, trailing bytes, no block boundary found, a damaged stream, too small to
+ *                  cut): nothing is known about dst; inflate the file serially -- that route's text and errors are the result.
+ * stats8 (may be NULL): segments, block starts found, bytes out, fell back (0/1), microseconds of: search, first pass, windows, second pass. */
+int c2_gz_inflate_parallel(const uint8_t* gz, uint64_t n, uint8_t* dst, uint64_t cap, uint64_t* n_out, int32_t threads, uint64_t chunk_bytes,
+                           uint64_t* stats8);
+/* the same eight numbers for the last .gz file one of the file routes (c2_fastq_unique*, c2_fastq_stream_open) opened on the calling thread:
+ * all zero when this route was not tried (BGZF input, a small file, C2_GZ_PARALLEL=0), fell back = 1 when it declined and the serial route ran */
+void c2_gz_parallel_last(uint64_t* stats8);
 /* Host-side bookkeeping between ingest and kernels, over the same arena/offsets layout (errors: c2_fastq_last_error()):
  * the seed test that picks the strand(s) a read is aligned on (CRISPRessoCORE.py:656-687) -> out_plan[n] in {0 forward,
  * 1 reverse complement, 2 both}, and the reverse-complement merge of read counts (CRISPRessoCORE.py:3970-3975), in place. */

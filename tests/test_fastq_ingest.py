@@ -143,14 +143,26 @@ def bgzf_bytes(data, block=0xff00, level=6, eof=True):
     return b"".join(out)
 
 
-GZ_ROUTES = ["auto", "zlib", "stream"]
+GZ_ROUTES = ["auto", "zlib", "stream", "parallel"]
+
+
+def set_gz_route(monkeypatch, route):
+    """C2_FASTQ_GZ picks the route; "parallel" = auto with the one-member-on-all-threads route (c2_gz_parallel.h) forced onto files of any size,
+    segments of 32 KiB of compressed data -- whatever it declines goes to the serial routes, so every expectation is the same"""
+    if route == "parallel":
+        monkeypatch.setenv("C2_FASTQ_GZ", "auto")
+        monkeypatch.setenv("C2_GZ_PARALLEL_MIN", "0")
+        monkeypatch.setenv("C2_GZ_PARALLEL_CHUNK", "32768")
+        monkeypatch.setenv("C2_FASTQ_THREADS", "4")
+    else:
+        monkeypatch.setenv("C2_FASTQ_GZ", route)
 
 
 @pytest.mark.parametrize("route", GZ_ROUTES)
 def test_gzip_routes_bgzf_members_and_single_stream(tmp_path, monkeypatch, route):
     """.gz input takes one of three routes (whole-buffer BGZF on all threads, whole-buffer libdeflate, streaming zlib);
     every route must give the reference's dict for every kind of file, and files a route does not accept fall through."""
-    monkeypatch.setenv("C2_FASTQ_GZ", route)
+    set_gz_route(monkeypatch, route)
     rng = np.random.default_rng(11)
     text = records(random_seqs(6000, rng)).encode()
     crlf = records(random_seqs(900, rng), nl="\r\n").encode()
@@ -203,7 +215,7 @@ def test_gzip_damaged_or_padded_files_behave_like_pythons_gzip_module(tmp_path, 
     which follows gzip.py: zero bytes after a member are skipped (more members may follow), anything else there is
     BadGzipFile, input ending inside a member is EOFError, a wrong checksum is BadGzipFile -- errors on every route."""
     from crispresso2_amd import _native
-    monkeypatch.setenv("C2_FASTQ_GZ", route)
+    set_gz_route(monkeypatch, route)
     rng = np.random.default_rng(12)
     text = records(random_seqs(3000, rng)).encode()
     half = text.index(b"@r1500\n")
@@ -477,7 +489,7 @@ def test_read_filter_reproduces_the_filtered_file_of_the_reference_params_run(tm
 @pytest.mark.parametrize("opts", [(0, 25, 0), (12, 0, 0), (0, 0, 15), (10, 22, 0), (0, 24, 14), (8, 20, 12)])
 @pytest.mark.parametrize("route", ["auto", "stream"])
 def test_read_filter_option_combinations_random_files(tmp_path, monkeypatch, opts, route):
-    monkeypatch.setenv("C2_FASTQ_GZ", route)
+    set_gz_route(monkeypatch, route)
     rng = np.random.default_rng(sum(opts))
     seqs = random_seqs(1500, rng, lo=15, hi=120, pool=40)
     recs = []
