@@ -484,8 +484,7 @@ def _e2e_sharded_leg(path, n_reads, ctx, L, matrix, dev, repeat=2):
     import torch
     import torch.distributed as dist
     from types import SimpleNamespace
-    from crispresso2_amd import pipeline, refs as RF, synth, _native
-    gz_inflate = None
+    from crispresso2_amd import pipeline, refs as RF, synth
     amp, g, inc = synth.amplicon_setup(L)
     args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=GO, needleman_wunsch_gap_extend=GE,
                            ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,
@@ -558,7 +557,8 @@ def _e2e_prepare(reads, workers, bgzf=True):
 def _e2e_leg(files, ctx, L, matrix, repeat=2):
     """FASTQ -> count tensors with the wall time of every stage (pipeline.quantify_fastq), the plain file and the BGZF file."""
     from types import SimpleNamespace
-    from crispresso2_amd import pipeline, refs as RF, synth
+    from crispresso2_amd import pipeline, refs as RF, synth, _native
+    gz_inflate = None
     amp, g, inc = synth.amplicon_setup(L)
     args = SimpleNamespace(aln_seed_count=5, aln_seed_len=10, aln_seed_min=2, needleman_wunsch_gap_open=GO, needleman_wunsch_gap_extend=GE,
                            ignore_deletions=False, ignore_insertions=False, ignore_substitutions=False,

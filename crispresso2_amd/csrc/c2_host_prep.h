@@ -169,6 +169,37 @@ inline bool c2_pk_eligible(const char* seq, int Li, const int32_t* g32, const c2
     return true;
 }
 
+// ---- a read that is a byte-for-byte copy of its reference ------------------------------------------------------------------------
+// Its alignment needs no matrix when the main diagonal provably beats every other path: the aligned strings are then the read and the
+// reference themselves (CRISPResso2Align.pyx:338-421 walks (L, L) -> (0, 0) in state M), matches = L, no event of any kind.
+//   S0 = sum_i s(ref_i, ref_i), the main diagonal's score.
+//   Any other path from (0, 0) to (L, L) has a >= 1 columns with a gap in the reference AND a columns with a gap in the read (both sequences
+//   have L bases), L - a columns that pair two bases.  A paired column adds at most smax (the largest entry of the matrix, >= 0 here); a gap
+//   column adds at most gcol = max(gap_open, gap_extend) + max(0, max_i gap_incentive[i]): an opening pays gap_open (gap_extend on the last row /
+//   column, pyx:234-317) + the incentive of its row, an extension gap_extend (+ the incentive for an insertion), the boundary chains
+//   gap_extend * j + gap_incentive[0] (pyx:153-176).  With gcol < 0 (c2_pk_eligible asks for it) the bound smax (L - a) + 2 a gcol is largest
+//   at a = 1:  every other path scores <= smax (L - 1) + 2 gcol.
+//   S0 > that bound  =>  the main diagonal is the unique best path, and strictly: at every cell (i, i) the M predecessor beats the I and J
+//   predecessors (a better or equal I / J prefix, completed along the diagonal, would be another path with a score >= S0), at (L, L) mScore
+//   beats iScore and jScore (paths that end in a gap), so the pointer walk's strict comparisons (pyx:349-358, :213-228) all say M.
+// Sentinel-derived values stay below real ones (c2_pk_eligible's last condition), as in the fill kernels.
+// EDNAFULL, -20 / -2, incentive 1: S0 = 5 L, bound = 5 L - 7: certified for every reference over A C G T (an N scores -1 against itself... any
+// reference whose diagonal is short of 5 L by 7 or more is not).
+inline bool c2_exact_copy_certified(const char* seq, int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend) {
+    if (Li < 2 || sc.tbl.empty() || sc.n_codes <= 0) return false;
+    int64_t smax = 0, gpos = 0, s0 = 0;
+    for (int16_t v : sc.tbl) smax = std::max<int64_t>(smax, v);
+    for (int i = 0; i <= Li; ++i) gpos = std::max<int64_t>(gpos, g32[i]);
+    const int64_t gcol = std::max<int64_t>(gap_open, gap_extend) + gpos;
+    if (gcol >= 0) return false;
+    for (int i = 0; i < Li; ++i) {
+        const uint8_t c = sc.code_of_char[(unsigned char)seq[i]];
+        if ((int)c >= sc.n_codes) return false;
+        s0 += sc.tbl[(size_t)c * (size_t)sc.n_codes + c];
+    }
+    return s0 > smax * ((int64_t)Li - 1) + 2 * gcol;
+}
+
 // ---- the packed fill with plain 32-bit adds (c2_align_diagp_kernel<NA, true>) --------------------------------------------------
 // On gfx950 v_pk_add_i16 issues at half the rate of v_add_u32 (profiles/r03/valu_microbench4.txt: 4.15 against 2.3 cycles per
 // wave64 instruction), and ten of a cell pair's ~25 instructions are such adds.  A 32-bit add of two int16 pairs is the packed add

@@ -2128,6 +2128,7 @@ struct c2_partition_args {
     int32_t max_mismatch, probe_max_mismatch, margin, max_shift;
     int32_t direct_full, sort_by_length;        // the last class exists; order a ragged chunk's slots by read length
     int32_t check_cut;                          // class 0 also looks at the 32 columns around the cut site (batches with several candidate amplicons)
+    int32_t exact_copies;                       // the output rows can be written as dwords: a class-0 read that EQUALS its reference is finished here (class_count[7])
 };
 
 #define C2_PART_CHUNK 4096                         // tasks per workgroup and set of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
@@ -2154,7 +2155,7 @@ __device__ __forceinline__ bool c2_band_holds(const int bandw, const int D, cons
 }
 
 // a task's read and reference as the partition needs them
-struct c2_part_task { const uint8_t* rd; const uint8_t* f; int Li, Lj, rc, pk_ok, cut; };
+struct c2_part_task { const uint8_t* rd; const uint8_t* f; int Li, Lj, rc, pk_ok, cut, ref_id, exact_ok; };
 __device__ __forceinline__ c2_part_task c2_part_load(const c2_align_args& A, const uint64_t task) {
     uint64_t read_id; int ref_id;
     if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
@@ -2165,6 +2166,7 @@ __device__ __forceinline__ c2_part_task c2_part_load(const c2_align_args& A, con
     t.Lj = (int)(A.offsets[read_id + 1] - off);
     const c2_dev_ref* rf = A.refs + ref_id;
     t.Li = rf->len; t.pk_ok = rf->pk_ok; t.rd = A.reads + off; t.f = rf->seq; t.cut = rf->first_incentive_pos;
+    t.ref_id = ref_id; t.exact_ok = rf->exact_copy_ok;
     return t;
 }
 // how a chunk's slots map to tasks (see the kernel): reference-major for an all-references batch of several references
@@ -2323,6 +2325,42 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             }
         }
         __syncthreads();
+        // ---- class 0, and the read EQUALS its reference (an unedited, error-free read: the commonest read of an amplicon run): the main diagonal
+        //      provably beats every other path (c2_exact_copy_certified, host), so there is nothing to fill -- the aligned strings are the read and
+        //      the reference, every column a match, no event.  One wavefront per such candidate, four columns per lane: compared as dwords, written
+        //      as dwords, the record by lane 0; the slot's flag becomes 9 (in no list).  Each wavefront walks its quarter of the chunk's slots.
+        if (P.exact_copies) {
+            unsigned n_exact = 0;
+            for (int base = wv * (C2_PART_CHUNK / 4); base < (wv + 1) * (C2_PART_CHUNK / 4); base += 64) {
+                unsigned long long cand = __ballot(flag[base + lane] == 0u);
+                while (cand) {
+                    const int slot = base + __builtin_ctzll(cand);
+                    cand &= cand - 1ull;
+                    const uint64_t task = c2_part_task_of(WK, A, chunk, slot);
+                    const c2_part_task t = c2_part_load(A, task);
+                    if (!t.exact_ok) continue;                      // (class 0: forward strand, Li == Lj, 32 .. 256 bases)
+                    const int L = t.Lj, nb = L - 4 * lane;
+                    uint32_t rd = 0, rf = 0;
+                    if (nb >= 4) { __builtin_memcpy(&rd, t.rd + 4 * lane, 4); __builtin_memcpy(&rf, t.f + 4 * lane, 4); }
+                    else for (int b = 0; b < nb; ++b) { rd |= (uint32_t)t.rd[4 * lane + b] << (8 * b); rf |= (uint32_t)t.f[4 * lane + b] << (8 * b); }
+                    if (__ballot(rd != rf)) continue;
+                    if (!(A.reserved & 1) && nb > 0) {              // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
+                        ((uint32_t*)(A.aln_read + task * (uint64_t)A.aln_stride))[lane] = rd;
+                        ((uint32_t*)(A.aln_ref + task * (uint64_t)A.aln_stride))[lane] = rf;
+                    }
+                    if (lane == 0) {
+                        c2_aln_record rec;
+                        c2_clear_record(rec, 0, t.ref_id);
+                        rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)L;
+                        A.records[task] = rec;
+                        flag[slot] = 9u;
+                    }
+                    ++n_exact;
+                }
+            }
+            if (lane == 0 && n_exact && P.class_count) { atomicAdd(P.class_count + 0, n_exact); atomicAdd(P.class_count + 7, n_exact); }
+            __syncthreads();
+        }
         if (may_sort) {                                             // do the chunk's reads differ in length?
             const int l0 = (int)part[24];
             for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {

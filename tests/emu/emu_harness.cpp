@@ -24,6 +24,7 @@ void emu_last_partition(uint32_t* classes7, uint32_t* p16_finished) {
     for (int k = 0; k < 7; ++k) classes7[k] = g_last_classes ? g_last_classes[k] : 0u;
     *p16_finished = g_last_p16_finished;
 }
+unsigned emu_last_exact_copies() { return g_last_classes ? g_last_classes[7] : 0u; }   // class-0 reads equal to their reference, finished by the partition
 int emu_last_pk_beta() { return g_last_pk_beta; }
 int emu_last_pk_bias() { return g_last_pk_bias; }
 
@@ -52,6 +53,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
         refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 126)) ? 1 : 0; refs[r].first_incentive_pos = -1;
         for (int i = 0; i <= lens[r]; ++i) if (g32[r][i] > 0) { refs[r].first_incentive_pos = i; break; }
+        refs[r].exact_copy_ok = (refs[r].pk_ok && !getenv("C2_NO_EXACT_COPIES") && c2_exact_copy_certified(seqs[r], lens[r], g32[r].data(), sc, go, ge)) ? 1 : 0;
+        refs[r].reserved_pad = 0;
         if (refs[r].pk_ok) any_pk = true;
         refs[r].len = lens[r];
         int64_t gm = 0;
@@ -154,8 +157,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         bool score_stage = false, tier40_runs = false;
         std::vector<uint32_t> elist(A.n_tasks ? A.n_tasks : 1), nlist(A.n_tasks ? A.n_tasks : 1), plist(A.n_tasks ? A.n_tasks : 1);
         uint32_t e_count = 0, ne_count = 0, p_count = 0;
-        static uint32_t class_counts[7];
-        for (int k = 0; k < 7; ++k) class_counts[k] = 0;
+        static uint32_t class_counts[8];                                   // [7]: class-0 reads equal to their reference, finished by the partition itself
+        for (int k = 0; k < 8; ++k) class_counts[k] = 0;
         g_last_classes = class_counts; g_last_p16_finished = 0;
         if (any_pk && (band_lanes == -87 || band_lanes == -8 || band_lanes == -80) && !(A.all_refs && A.n_refs > 1 && (A.n_refs > 64 || getenv("C2_NO_ALLREFS_PARTITION"))) && !getenv("C2_EMU_NO_SCORE_TIER")) {
             const int sna = (getenv("C2_SCORE_TIER_NA") && atoi(getenv("C2_SCORE_TIER_NA")) == 8) ? 8 : 16;
@@ -182,6 +185,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
             PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
             PA.check_cut = (A.all_refs && A.n_refs > 1) ? 1 : 0;
+            PA.exact_copies = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0 && (A.aln_stride & 3u) == 0) ? 1 : 0;
             PA.class_count = class_counts;
             PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier40_runs) ? 40 : 0;
             PA.bandw[3] = (route && tier1_runs) ? 62 : 0; PA.bandw[4] = (route && tier2_runs) ? 128 : 0;

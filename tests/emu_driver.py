@@ -89,6 +89,7 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
         lib().emu_last_partition(cls, ctypes.byref(p16))
         stats['classes'] = [a + int(b) for a, b in zip(stats.get('classes', [0] * 7), cls)]
         stats['p16_finished'] = stats.get('p16_finished', 0) + int(p16.value)
+        stats['exact_copies'] = stats.get('exact_copies', 0) + int(lib().emu_last_exact_copies())
         stats['fallback'] = stats.get('fallback', 0) + max(nfb.value, 0)
         stats['tasks'] = stats.get('tasks', 0) + ntasks
     assert rc == 0, rc

@@ -835,3 +835,75 @@ def test_forty_diagonal_tier_six_alignments_per_wavefront(mats):
     finally:
         del os.environ["C2_NO_TIER40"]
     assert st["classes"][3] == 0 and res == outs[-87][0] and rec.tobytes() == outs[-87][1].tobytes()
+
+
+@pytest.mark.parametrize("L", [250, 151, 64, 256])
+def test_reads_equal_to_their_reference_are_finished_by_the_partition(mats, L, monkeypatch):
+    """A class-0 read that EQUALS its reference byte for byte needs no fill when the scoring proves the main diagonal unbeatable
+    (c2_exact_copy_certified: every other path leaves a base of each sequence unpaired).  The partition compares such candidates as dwords and writes
+    the rows and the record itself; everything else -- one substitution anywhere (first byte, last byte, the partial last dword), an N, an indel, a
+    read of another length -- goes through the launches as before.  All results are the oracle's, and identical with the shortcut switched off."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(7100 + L)
+    amp = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = [L // 2, L // 2 + 1]
+    other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    reads = [amp] * 9
+    for q in (0, 1, 3, 4, L // 2, L - 5, L - 4, L - 3, L - 2, L - 1):
+        reads.append(amp[:q] + other[amp[q]] + amp[q + 1:])
+        reads.append(amp[:q] + "N" + amp[q + 1:])
+    reads += [amp[:L // 2] + amp[L // 2 + 3:] + "ACG", amp[:L // 2] + "TT" + amp[L // 2:-2], amp[:-1], amp + "A", amp[1:], amp.lower()[:1] + amp[1:]]
+    reads += [amp] * 3
+    want = []
+    for rd in reads:
+        status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, -20, -2)
+        want.append((status, s1, s2, mt))
+    st = {}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    for k, (status, s1, s2, mt) in enumerate(want):
+        if status != 0:
+            assert rec[k]["status"] != 0, k
+            continue
+        assert rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k)
+        check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+    assert st["exact_copies"] == 12 and sum(st["classes"]) == len(reads), st
+    monkeypatch.setenv("C2_NO_EXACT_COPIES", "1")
+    st2 = {}
+    res2, rec2 = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st2)
+    assert st2["exact_copies"] == 0 and st2["classes"] == st["classes"]
+    assert res2 == res and rec2.tobytes() == rec.tobytes()
+    o1, o2 = st["raw"]
+    p1, p2 = st2["raw"]
+    for k in range(len(reads)):                                    # the rows as the launches leave them, padding of the last dword included
+        n4 = (int(rec[k]["aln_len"]) + 3) // 4 * 4
+        assert o1[k, :n4].tobytes() == p1[k, :n4].tobytes() and o2[k, :n4].tobytes() == p2[k, :n4].tobytes(), k
+
+
+def test_exact_copies_only_where_the_scoring_proves_them(mats, monkeypatch):
+    """the certificate is per reference: an N in the reference (EDNAFULL scores it -1 against itself: the diagonal is short of 5 L) or a matrix
+    whose diagonal is not uniform leave the shortcut off -- and an incentive as large as |gap_extend| leaves even the packed kernels off"""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(7300)
+    L = 120
+    amp = "".join(rng.choice(list("ACGT"), L))
+    with_n = amp[:30] + "N" + amp[31:]
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = [L // 2, L // 2 + 1]
+    for ref, expect in ((amp, 6), (with_n, 0)):
+        reads = [ref] * 6 + [ref[:50] + "A" + ref[50:-1], ref[:10] + ("C" if ref[10] != "C" else "G") + ref[11:]]
+        st = {}
+        res, rec = E.align_batch(reads, [ref], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+        for k, rd in enumerate(reads):
+            status, s1, s2, mt, ln = oracle.global_align_raw(rd, ref, m, g, -20, -2)
+            assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (ref == amp, k)
+        assert st["exact_copies"] == expect, st
+    uneven = m.copy()
+    uneven[ord("C"), ord("C")] = 3                                   # C pairs with C for less than the other bases pair with themselves
+    reads = [amp] * 5 + [amp[:40] + amp[41:] + "T"]
+    st = {}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], uneven, -20, -2, band_lanes=-87, stats=st)
+    for k, rd in enumerate(reads):
+        status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, uneven, g, -20, -2)
+        assert status == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, k
+    assert st["exact_copies"] == 0, st                               # (30 C's at 3 instead of 5: 60 below 5 L, the bound is 7 below)
