@@ -837,7 +837,7 @@ def test_forty_diagonal_tier_six_alignments_per_wavefront(mats):
     assert st["classes"][3] == 0 and res == outs[-87][0] and rec.tobytes() == outs[-87][1].tobytes()
 
 
-@pytest.mark.parametrize("L", [250, 151, 64, 256])
+@pytest.mark.parametrize("L", [250, 151, 203, 256])
 def test_reads_equal_to_their_reference_are_finished_by_the_partition(mats, L, monkeypatch):
     """A class-0 read that EQUALS its reference byte for byte needs no fill when the scoring proves the main diagonal unbeatable
     (c2_exact_copy_certified: every other path leaves a base of each sequence unpaired).  The partition compares such candidates as dwords and writes
@@ -881,16 +881,17 @@ def test_reads_equal_to_their_reference_are_finished_by_the_partition(mats, L, m
 
 
 def test_exact_copies_only_where_the_scoring_proves_them(mats, monkeypatch):
-    """the certificate is per reference: an N in the reference (EDNAFULL scores it -1 against itself: the diagonal is short of 5 L) or a matrix
+    """the certificate is per reference: two N's in the reference (EDNAFULL scores N -1 against itself: the diagonal falls 12 short of 5 L, the bound is 7 short) or a matrix
     whose diagonal is not uniform leave the shortcut off -- and an incentive as large as |gap_extend| leaves even the packed kernels off"""
     m = mats["EDNAFULL"]
     rng = np.random.default_rng(7300)
-    L = 120
+    L = 160
     amp = "".join(rng.choice(list("ACGT"), L))
-    with_n = amp[:30] + "N" + amp[31:]
+    with_n = amp[:30] + "N" + amp[31:]                              # one N: the diagonal is 5 L - 6, the bound 5 L - 7 -- still proven
+    with_nn = with_n[:90] + "N" + with_n[91:]                       # two: 5 L - 12
     g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
     inc = [L // 2, L // 2 + 1]
-    for ref, expect in ((amp, 6), (with_n, 0)):
+    for ref, expect in ((amp, 6), (with_n, 6), (with_nn, 0)):
         reads = [ref] * 6 + [ref[:50] + "A" + ref[50:-1], ref[:10] + ("C" if ref[10] != "C" else "G") + ref[11:]]
         st = {}
         res, rec = E.align_batch(reads, [ref], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
@@ -906,4 +907,4 @@ def test_exact_copies_only_where_the_scoring_proves_them(mats, monkeypatch):
     for k, rd in enumerate(reads):
         status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, uneven, g, -20, -2)
         assert status == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, k
-    assert st["exact_copies"] == 0, st                               # (30 C's at 3 instead of 5: 60 below 5 L, the bound is 7 below)
+    assert st["exact_copies"] == 0, st                               # (some forty C's at 3 instead of 5: the diagonal is 80 below 5 L, the bound 7 below)
