@@ -2275,6 +2275,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
     for (uint64_t chunk = (uint64_t)blockIdx.x * WK.chunk_tasks; chunk < A.n_tasks; chunk += (uint64_t)gridDim.x * WK.chunk_tasks) {
         // ---- one lane per task: the look at the last 32 columns
         int ragged = 0;
+        unsigned n_exact = 0;                                       // (wave-uniform) class-0 tasks this wavefront finished itself
         for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
             const int slot = r * 256 + tid;
             const uint64_t task = c2_part_task_of(WK, A, chunk, slot);
@@ -2316,51 +2317,58 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                     }
                     if (mm <= P.max_mismatch) cls = 0;
                     else if (c2_part_probes(P, t)) cls = 8;
+                    // ---- class 0, and the read EQUALS its reference (the unedited, error-free read: the commonest read of an amplicon run): the main
+                    //      diagonal provably beats every other path (c2_exact_copy_certified, host), so there is nothing to fill -- the aligned strings
+                    //      are the read and the reference, every column a match, no event.  This lane compares the two 16 bytes at a time (the last
+                    //      block overlaps the one before it: nothing is read behind the read), and writes both rows and the record itself: the slot's
+                    //      flag becomes 9, in no list.  (All of a lane's loads are in flight together -- a wavefront per candidate, one after the
+                    //      other, waited for HBM 6 M times over and cost more than the fills it saved.)
+                    if (cls == 0 && P.exact_copies && t.exact_ok) {
+                        const int L = t.Lj, nq = (L + 15) >> 4;             // 32 <= L <= 256: 2 .. 16 blocks
+                        unsigned diff = 0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            if (q < nq) {
+                                const int at = (16 * q + 16 <= L) ? 16 * q : L - 16;
+                                uint4 x, y;
+                                __builtin_memcpy(&x, t.rd + at, 16); __builtin_memcpy(&y, t.f + at, 16);
+                                diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+                            }
+                        }
+                        if (diff == 0) {
+                            uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
+                            uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
+                            if (!(A.reserved & 1)) {
+                                for (int q = 0; q < nq; ++q) {
+                                    const int at = (16 * q + 16 <= L) ? 16 * q : L - 16;
+                                    uint4 x;
+                                    __builtin_memcpy(&x, t.rd + at, 16);
+                                    __builtin_memcpy(outR + at, &x, 16); __builtin_memcpy(outF + at, &x, 16);
+                                }
+                                if (L & 3) {                                // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
+                                    uint32_t w = 0;
+                                    for (int b = 0; b < (L & 3); ++b) w |= (uint32_t)t.rd[(L & ~3) + b] << (8 * b);
+                                    __builtin_memcpy(outR + (L & ~3), &w, 4); __builtin_memcpy(outF + (L & ~3), &w, 4);
+                                }
+                            }
+                            c2_aln_record rec;
+                            c2_clear_record(rec, 0, t.ref_id);
+                            rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)L;
+                            A.records[task] = rec;
+                            cls = 9;
+                        }
+                    }
                 }
             }
+            n_exact += (unsigned)__popcll(__ballot(cls == 9));
             flag[slot] = (uint8_t)cls;
             if (may_sort) {
                 len16[slot] = (uint16_t)(lj < 0 ? 0 : (lj < C2_PART_LEN_BINS - 1 ? lj : C2_PART_LEN_BINS - 1));
                 if (slot == 0) { part[24] = (unsigned)lj; part[25] = 0u; }
             }
         }
+        if (lane == 0 && n_exact && P.class_count) { atomicAdd(P.class_count + 0, n_exact); atomicAdd(P.class_count + 7, n_exact); }
         __syncthreads();
-        // ---- class 0, and the read EQUALS its reference (an unedited, error-free read: the commonest read of an amplicon run): the main diagonal
-        //      provably beats every other path (c2_exact_copy_certified, host), so there is nothing to fill -- the aligned strings are the read and
-        //      the reference, every column a match, no event.  One wavefront per such candidate, four columns per lane: compared as dwords, written
-        //      as dwords, the record by lane 0; the slot's flag becomes 9 (in no list).  Each wavefront walks its quarter of the chunk's slots.
-        if (P.exact_copies) {
-            unsigned n_exact = 0;
-            for (int base = wv * (C2_PART_CHUNK / 4); base < (wv + 1) * (C2_PART_CHUNK / 4); base += 64) {
-                unsigned long long cand = __ballot(flag[base + lane] == 0u);
-                while (cand) {
-                    const int slot = base + __builtin_ctzll(cand);
-                    cand &= cand - 1ull;
-                    const uint64_t task = c2_part_task_of(WK, A, chunk, slot);
-                    const c2_part_task t = c2_part_load(A, task);
-                    if (!t.exact_ok) continue;                      // (class 0: forward strand, Li == Lj, 32 .. 256 bases)
-                    const int L = t.Lj, nb = L - 4 * lane;
-                    uint32_t rd = 0, rf = 0;
-                    if (nb >= 4) { __builtin_memcpy(&rd, t.rd + 4 * lane, 4); __builtin_memcpy(&rf, t.f + 4 * lane, 4); }
-                    else for (int b = 0; b < nb; ++b) { rd |= (uint32_t)t.rd[4 * lane + b] << (8 * b); rf |= (uint32_t)t.f[4 * lane + b] << (8 * b); }
-                    if (__ballot(rd != rf)) continue;
-                    if (!(A.reserved & 1) && nb > 0) {              // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
-                        ((uint32_t*)(A.aln_read + task * (uint64_t)A.aln_stride))[lane] = rd;
-                        ((uint32_t*)(A.aln_ref + task * (uint64_t)A.aln_stride))[lane] = rf;
-                    }
-                    if (lane == 0) {
-                        c2_aln_record rec;
-                        c2_clear_record(rec, 0, t.ref_id);
-                        rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)L;
-                        A.records[task] = rec;
-                        flag[slot] = 9u;
-                    }
-                    ++n_exact;
-                }
-            }
-            if (lane == 0 && n_exact && P.class_count) { atomicAdd(P.class_count + 0, n_exact); atomicAdd(P.class_count + 7, n_exact); }
-            __syncthreads();
-        }
         if (may_sort) {                                             // do the chunk's reads differ in length?
             const int l0 = (int)part[24];
             for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
