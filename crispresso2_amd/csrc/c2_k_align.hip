@@ -2325,11 +2325,14 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                     //      other, waited for HBM 6 M times over and cost more than the fills it saved.)
                     if (cls == 0 && P.exact_copies && t.exact_ok) {
                         const int L = t.Lj, nq = (L + 15) >> 4;             // 32 <= L <= 256: 2 .. 16 blocks
+                        // block q starts at 16 q -- the last one at L - 16 (it overlaps its predecessor); q beyond the last names the last again, so
+                        // that every lane runs the same loads whatever its read's length
+                        auto at_of = [&](int q) { if (q > nq - 1) q = nq - 1; return (16 * q + 16 <= L) ? 16 * q : L - 16; };
                         unsigned diff = 0;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
-                            if (q < nq) {
-                                const int at = (16 * q + 16 <= L) ? 16 * q : L - 16;
+                            if (q < 10 || q < nq) {                         // (reads of 150 bases and more: ten blocks without a branch)
+                                const int at = at_of(q);
                                 uint4 x, y;
                                 __builtin_memcpy(&x, t.rd + at, 16); __builtin_memcpy(&y, t.f + at, 16);
                                 diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
@@ -2339,11 +2342,15 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                             uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
                             uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
                             if (!(A.reserved & 1)) {
-                                for (int q = 0; q < nq; ++q) {
-                                    const int at = (16 * q + 16 <= L) ? 16 * q : L - 16;
-                                    uint4 x;
-                                    __builtin_memcpy(&x, t.rd + at, 16);
-                                    __builtin_memcpy(outR + at, &x, 16); __builtin_memcpy(outF + at, &x, 16);
+                                for (int q0 = 0; q0 < nq; q0 += 4) {         // four blocks in flight (they come from L2 now), then their eight stores
+                                    const int a0 = at_of(q0), a1 = at_of(q0 + 1), a2 = at_of(q0 + 2), a3 = at_of(q0 + 3);
+                                    uint4 x0, x1, x2, x3;
+                                    __builtin_memcpy(&x0, t.rd + a0, 16); __builtin_memcpy(&x1, t.rd + a1, 16);
+                                    __builtin_memcpy(&x2, t.rd + a2, 16); __builtin_memcpy(&x3, t.rd + a3, 16);
+                                    __builtin_memcpy(outR + a0, &x0, 16); __builtin_memcpy(outF + a0, &x0, 16);
+                                    __builtin_memcpy(outR + a1, &x1, 16); __builtin_memcpy(outF + a1, &x1, 16);
+                                    __builtin_memcpy(outR + a2, &x2, 16); __builtin_memcpy(outF + a2, &x2, 16);
+                                    __builtin_memcpy(outR + a3, &x3, 16); __builtin_memcpy(outF + a3, &x3, 16);
                                 }
                                 if (L & 3) {                                // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
                                     uint32_t w = 0;
