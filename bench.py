@@ -997,7 +997,7 @@ def main():
     if part_info and part_info["ran"]:
         cls_, fin_p = part_info["classes"], part_info["finished"]
         # (class 0 counts the reads equal to their reference too: the partition finishes those itself, no launch sees them)
-        in_first = cls_[2] + (cls_[0] - part_info.get("exact_copies", 0) - fin_p[0]) + (cls_[1] - fin_p[1])
+        in_first = cls_[2] + (cls_[0] - part_info.get("finished_by_partition", 0) - fin_p[0]) + (cls_[1] - fin_p[1])
         # (the list behind the first tier also holds what the partition sent straight to the launch that reads it: the 40-diagonal tier's class when
         #  the chain has that tier -- four band tiers --, else the 62-diagonal tier's, else the 128-diagonal one's)
         left_first = max(0, left_first - cls_[{4: 3, 3: 4, 2: 5}.get(len(tiers), 3)])
@@ -1080,9 +1080,9 @@ def main():
                        "kernel_chain": (score_stage["kernels"] if score_stage else []) + chain,
                        "score_only_stage_tasks": None if not score_stage else score_stage["tasks"],
                        "score_only_stage_finished": None if not score_stage else score_stage["finished"],
-                       # (reads that equal their amplicon byte for byte: c2_align_partition_kernel writes their rows and records itself -- the main diagonal is
-                       #  provably the best path, c2_exact_copy_certified -- and no launch fills a matrix for them)
-                       "exact_copies_finished_by_partition": None if not (part_info and part_info.get("ran")) else part_info.get("exact_copies"),
+                       # (reads on their amplicon's main diagonal -- byte-for-byte copies, one or two differing bases: c2_align_partition_kernel writes their rows
+                       #  and records itself where the diagonal is provably the best path, c2_main_diagonal_certificate -- no launch fills a matrix for them)
+                       "finished_by_partition": None if not (part_info and part_info.get("ran")) else part_info.get("finished_by_partition"),
                        "tasks_left_after_each_banded_launch": tiers,
                        "pointer_band_lanes": band["band_lanes"], "full_plane_fallback_tasks": band["fallback_tasks_last_launch"],
                        # (scalars the driver's record keeps: the all-int32 chain on the same batch, how much of the batch the packed kernels finished,
@@ -1222,7 +1222,7 @@ def main():
                                                    "band_40_diagonals": cls_[3] / float(jc.n_tasks), "band_62_diagonals": cls_[4] / float(jc.n_tasks),
                                                    "band_128_diagonals": cls_[5] / float(jc.n_tasks), "full_matrix": cls_[6] / float(jc.n_tasks)}
                     entry["score_only_finished_share"] = part_c["finished"][0] / float(jc.n_tasks)
-                    entry["exact_copy_share"] = part_c.get("exact_copies", 0) / float(jc.n_tasks)      # reads equal to their reference: finished by the partition, no fill
+                    entry["finished_by_partition_share"] = part_c.get("finished_by_partition", 0) / float(jc.n_tasks)      # main-diagonal reads (copies of the reference, one or two differing bases): finished by the partition, no fill
                 entry["full_plane_launch_share"] = (tiers_c[-1] / float(jc.n_tasks)) if tiers_c else None
                 if ref_leg is not None:
                     leg_c, kind_c = ref_leg

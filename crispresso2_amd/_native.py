@@ -25,7 +25,7 @@ SYMBOLS = [
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners", "c2_gather_reads",
-    "c2_score_stage_info", "c2_partition_info", "c2_partition_exact_copies", "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close", "c2_gz_inflate_parallel", "c2_gz_parallel_last",
+    "c2_score_stage_info", "c2_partition_info", "c2_partition_finished", "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close", "c2_gz_inflate_parallel", "c2_gz_parallel_last",
     "c2_consensus_pairs_batch", "c2_consensus_pairs_device", "c2_classify_records_device",
     "c2_fq_count_device", "c2_fq_lines_device", "c2_fq_dedup_device", "c2_fq_gather_device", "c2_fq_rc_partner_device",
     "c2_fq_lines4_device", "c2_fq_pair_lengths_device", "c2_fq_pair_write_device",
@@ -324,15 +324,15 @@ class Context:
 
     def partition_info(self):
         """-> {"ran", "p16", "classes": tasks per class [score-only, 14 diagonals (opt-in), 32 diagonals, 40, 62, 126/128, full matrix],
-        "finished": [score-only, 14 diagonals], "exact_copies": class-0 reads equal to their reference, finished by the partition itself}
-        of the most recent batch (c2_partition_info, c2_partition_exact_copies)"""
+        "finished": [score-only, 14 diagonals], "finished_by_partition": class-0 reads on the main diagonal (a copy of the reference, or one / two differing bases)
+        that the partition finished itself} of the most recent batch (c2_partition_info, c2_partition_finished)"""
         ran = ctypes.c_int32(0)
         cls, fin = (ctypes.c_int64 * 7)(), (ctypes.c_int64 * 2)()
         self.check(self.lib.c2_partition_info(self.handle, ctypes.byref(ran), cls, fin), "c2_partition_info")
         exact = ctypes.c_int64(0)
-        self.check(self.lib.c2_partition_exact_copies(self.handle, ctypes.byref(exact)), "c2_partition_exact_copies")
+        self.check(self.lib.c2_partition_finished(self.handle, ctypes.byref(exact)), "c2_partition_finished")
         return {"ran": bool(ran.value & 1), "p16": bool(ran.value & 2), "classes": [int(x) for x in cls], "finished": [int(x) for x in fin],
-                "exact_copies": int(exact.value)}
+                "finished_by_partition": int(exact.value)}
 
     def tier_info_ex(self):
         """-> (left_over, unpaired) per band tier of the most recent batch (c2_tier_info_ex)."""

@@ -404,7 +404,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 PA.probe_max_mismatch = 4; PA.margin = 3; PA.max_shift = (p16_stage || route) ? 64 : 0;
                 PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
                 PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
-                // a read that equals its reference byte for byte is finished by the partition itself (c2_exact_copy_certified): rows written as dwords
+                // a read on its reference's main diagonal (at most two differing bases) is finished by the partition itself where c2_main_diagonal_certificate allows
                 PA.exact_copies = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0 && (A.aln_stride & 3u) == 0) ? 1 : 0;
                 PA.check_cut = many_refs ? 1 : 0;                        // (one amplicon: a read that differs from it around the cut fails the score-only certificate anyway, and the look costs 0.3 ms per 10 M)
                 if (const char* e = getenv("C2_SCORE_TIER_MAX_MISMATCH")) PA.max_mismatch = atoi(e);
@@ -602,8 +602,14 @@ int refresh_diag_rows(c2_ctx* ctx, hipStream_t s) {
         ctx->ref_desc[r].diag_rows = all.empty() ? nullptr : (const c2_diag_row*)ctx->d_diagrows.p + off[r] + C2_DIAG_ROW_PAD;
         ctx->ref_desc[r].pk_ok = (!allpk.empty() && ctx->ref_pk_ok[r]) ? 1 : 0;
         // (on top of the packed fill's admission: its conditions -- no gap step adds score, the sentinel out of reach -- are part of the proof)
-        ctx->ref_desc[r].exact_copy_ok = (ctx->ref_desc[r].pk_ok && !getenv("C2_NO_EXACT_COPIES") &&
-                                          c2_exact_copy_certified(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend)) ? 1 : 0;
+        c2_diag_cert dc;
+        dc.kmax = -1; dc.mmax[0] = dc.mmax[1] = dc.mmax[2] = dc.mmax[3] = -1;
+        if (ctx->ref_desc[r].pk_ok && !getenv("C2_NO_EXACT_COPIES"))
+            dc = c2_main_diagonal_certificate(ctx->ref_seq[r].data(), ctx->ref_len[r], ctx->ref_g32[r].data(), ctx->sc, ctx->gap_open, ctx->gap_extend);
+        if (const char* e = getenv("C2_DIAG_CERT_KMAX")) dc.kmax = std::min(dc.kmax, atoi(e));       // (0: byte-for-byte copies only)
+        ctx->ref_desc[r].diag_kmax = dc.kmax;
+        for (int k = 0; k < 4; ++k) ctx->ref_desc[r].diag_mmax[k] = dc.mmax[k];
+        ctx->ref_desc[r].reserved_pad = 0;
     }
     HIPCHK(ctx, hipMemcpy(ctx->d_refdesc.p, ctx->ref_desc.data(), sizeof(c2_dev_ref) * (size_t)ctx->n_refs, hipMemcpyHostToDevice));
     ctx->diag_rows_dirty = false;
@@ -767,7 +773,8 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         desc[r].gap_incentive = (const int32_t*)(base + off_g[r]);
         desc[r].inc_prefix = (const uint16_t*)(base + off_p[r]);
         desc[r].len = lens[r];
-        desc[r].diag_rows = nullptr; desc[r].pk_ok = 0; desc[r].first_incentive_pos = -1; desc[r].exact_copy_ok = 0; desc[r].reserved_pad = 0;
+        desc[r].diag_rows = nullptr; desc[r].pk_ok = 0; desc[r].first_incentive_pos = -1; desc[r].diag_kmax = -1; desc[r].reserved_pad = 0;
+        for (int k = 0; k < 4; ++k) desc[r].diag_mmax[k] = -1;
         for (int i = 0; i <= lens[r]; ++i) if (gap_incentives[r][i] > 0) { desc[r].first_incentive_pos = i; break; }
         int64_t gm = 0;                                          // over the values the kernels add: the reference's C ints
         for (int k = 0; k <= lens[r]; ++k) gm = std::max<int64_t>(gm, (int64_t)(int32_t)gap_incentives[r][k]);
@@ -874,8 +881,8 @@ int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks7, int64_t*
     return 0;
 }
 
-// ... and how many class-0 tasks the partition finished itself: reads that equal their reference byte for byte (c2_exact_copy_certified)
-int c2_partition_exact_copies(c2_ctx* ctx, int64_t* n) {
+// ... and how many class-0 tasks the partition finished itself: reads on the main diagonal with at most two differing bases (c2_main_diagonal_certificate)
+int c2_partition_finished(c2_ctx* ctx, int64_t* n) {
     if (!ctx || !n) return C2_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     *n = 0;

@@ -43,7 +43,9 @@ typedef struct c2_dev_ref {
     int32_t max_char;             // largest byte of seq (a read character >= the matrix dimension is defined iff max_char * dim + it < dim * dim)
     int32_t pk_ok;                // admitted to the int16 fill of c2_align_diagp_kernel (c2_pk_eligible); its packed row table sits at the same index in diagpk_base
     int32_t first_incentive_pos;  // smallest i with gap_incentive[i] > 0 (the cut site the caller marked), -1: none.  A hint for c2_align_partition_kernel only
-    int32_t exact_copy_ok;        // a read that EQUALS this reference byte for byte aligns to it without a gap, provably (c2_exact_copy_certified): no fill needed
+    int32_t diag_kmax;            // c2_main_diagonal_certificate: a read of this reference's length with at most this many differing bases (0: a byte-for-byte
+                                  // copy) aligns to it along the main diagonal, provably -- no fill needed; -1: no such proof
+    int32_t diag_mmax[4];         // ... for k = 1, 2 differing bases: [2 (k - 1) + (a - 1)] = the most equal bytes the diagonals +-a may hold
     int32_t reserved_pad;
 } c2_dev_ref;
 

@@ -169,35 +169,84 @@ inline bool c2_pk_eligible(const char* seq, int Li, const int32_t* g32, const c2
     return true;
 }
 
-// ---- a read that is a byte-for-byte copy of its reference ------------------------------------------------------------------------
-// Its alignment needs no matrix when the main diagonal provably beats every other path: the aligned strings are then the read and the
-// reference themselves (CRISPResso2Align.pyx:338-421 walks (L, L) -> (0, 0) in state M), matches = L, no event of any kind.
-//   S0 = sum_i s(ref_i, ref_i), the main diagonal's score.
-//   Any other path from (0, 0) to (L, L) has a >= 1 columns with a gap in the reference AND a columns with a gap in the read (both sequences
-//   have L bases), L - a columns that pair two bases.  A paired column adds at most smax (the largest entry of the matrix, >= 0 here); a gap
-//   column adds at most gcol = max(gap_open, gap_extend) + max(0, max_i gap_incentive[i]): an opening pays gap_open (gap_extend on the last row /
-//   column, pyx:234-317) + the incentive of its row, an extension gap_extend (+ the incentive for an insertion), the boundary chains
-//   gap_extend * j + gap_incentive[0] (pyx:153-176).  With gcol < 0 (c2_pk_eligible asks for it) the bound smax (L - a) + 2 a gcol is largest
-//   at a = 1:  every other path scores <= smax (L - 1) + 2 gcol.
-//   S0 > that bound  =>  the main diagonal is the unique best path, and strictly: at every cell (i, i) the M predecessor beats the I and J
-//   predecessors (a better or equal I / J prefix, completed along the diagonal, would be another path with a score >= S0), at (L, L) mScore
-//   beats iScore and jScore (paths that end in a gap), so the pointer walk's strict comparisons (pyx:349-358, :213-228) all say M.
-// Sentinel-derived values stay below real ones (c2_pk_eligible's last condition), as in the fill kernels.
-// EDNAFULL, -20 / -2, incentive 1: S0 = 5 L, bound = 5 L - 7: certified for every reference over A C G T (an N scores -1 against itself... any
-// reference whose diagonal is short of 5 L by 7 or more is not).
-inline bool c2_exact_copy_certified(const char* seq, int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend) {
-    if (Li < 2 || sc.tbl.empty() || sc.n_codes <= 0) return false;
+// ---- a read that lies on its reference's main diagonal: no matrix where the diagonal provably wins ------------------------------------
+// A read as long as its reference that differs from it in k <= 2 places (k = 0: a byte-for-byte copy -- the unedited, error-free read, the
+// commonest read of an amplicon run) needs no fill when every other path from (0, 0) to (L, L) provably scores LESS than the main diagonal:
+// the pointer walk (CRISPResso2Align.pyx:338-421) then stays in state M from (L, L) to (0, 0) -- at every cell (i, i) the M predecessor
+// strictly beats the I and J predecessors (a better or equal I / J prefix, completed along the diagonal, would be another path with a score
+// >= the diagonal's), at (L, L) mScore strictly beats iScore and jScore -- so the aligned strings are the read and the reference themselves.
+//
+// Scores.  smax = the largest matrix entry (>= 0), soff = the largest entry that pairs a reference base with a DIFFERENT base of A C G T N,
+// delta = the most one differing read base (of A C G T N) costs against the same base, S0 = sum_i s(ref_i, ref_i); the diagonal of a read
+// with k differing bases scores >= S0 - k delta.  A gap column adds at most gcol = max(gap_open, gap_extend) + gpos (gpos = the largest
+// incentive, >= 0): an opening pays gap_open -- gap_extend on row 0 / column 0 (pyx:153-176) and on the last row / column (pyx:234-317) --
+// plus its row's incentive, an extension gap_extend (plus the incentive for an insertion).  gcol < 0 (c2_pk_eligible asks for it).
+//
+// Every other path has a >= 1 columns with a gap in the reference and a with a gap in the read (both sequences have L bases), and is of
+// one of two kinds (a gap run cannot follow a gap run of the other kind without a paired column between them: iScore comes from mScore
+// and iScore only, pyx:187-228):
+//   A  at least one of its gap runs is opened INSIDE the matrix, at gap_open:  score <= smax (L - a) + (gap_open + gpos) + (2a - 1) gcol,
+//      largest at a = 1:  boundA = smax (L - 1) + gap_open + gpos + gcol.
+//   B  its runs are a leading one (row 0 or column 0) and a trailing one (last column or last row) only: the read shifted by a against the
+//      reference, ONE diagonal d = +-a from end to end.  score <= P_d + 2 a gcol with P_d the pair scores along that diagonal,
+//      P_d <= smax m_d + soff (L - a - m_d) for m_d columns of equal bytes on it (<= smax (L - a) in any case).
+// k = 0:  S0 > smax (L - 1) + 2 gcol covers A and B at once (EDNAFULL, -20 / -2, incentive 1: 5 L against 5 L - 7).
+// k = 1, 2:  S0 - k delta > boundA; for a >= 3 kind B is beaten by its smax (L - a) bound; for a = 1, 2 the kernel COUNTS the equal bytes
+// of the four shifted diagonals (an upper bound: whole 16-byte blocks in the middle of the read counted, every other column taken as
+// equal) and compares with mmax[k - 1][a - 1], the largest count the inequality allows -- a homopolymer run or a short tandem repeat
+// shifts onto itself and is refused, an ordinary amplicon has a quarter of its bytes equal there and passes by a wide margin.
+// (EDNAFULL: 5 L - 9 k against boundA = 5 L - 25 -- k <= 2 -- and against 5 m + (L - a - m) - 2 a on the shifted diagonals.)
+// Differing read characters other than A C G T N (IUPAC codes, anything the matrix does not hold) are left to the launches: their status
+// words and scores are theirs.  Sentinel-derived values stay below real ones (c2_pk_eligible's last condition), as in the fill kernels.
+struct c2_diag_cert { int kmax; int mmax[4]; };      // kmax: -1 none, 0 exact copies, 1 / 2 that many differing bases; mmax[2 (k - 1) + (a - 1)]
+inline c2_diag_cert c2_main_diagonal_certificate(const char* seq, int Li, const int32_t* g32, const c2_scoring_tables& sc, int gap_open, int gap_extend) {
+    c2_diag_cert C;
+    C.kmax = -1; C.mmax[0] = C.mmax[1] = C.mmax[2] = C.mmax[3] = -1;
+    if (Li < 2 || sc.tbl.empty() || sc.n_codes <= 0) return C;
+    const int nc = sc.n_codes;
     int64_t smax = 0, gpos = 0, s0 = 0;
     for (int16_t v : sc.tbl) smax = std::max<int64_t>(smax, v);
     for (int i = 0; i <= Li; ++i) gpos = std::max<int64_t>(gpos, g32[i]);
     const int64_t gcol = std::max<int64_t>(gap_open, gap_extend) + gpos;
-    if (gcol >= 0) return false;
+    if (gcol >= 0) return C;
+    bool present[5] = {false, false, false, false, false};
     for (int i = 0; i < Li; ++i) {
         const uint8_t c = sc.code_of_char[(unsigned char)seq[i]];
-        if ((int)c >= sc.n_codes) return false;
-        s0 += sc.tbl[(size_t)c * (size_t)sc.n_codes + c];
+        if ((int)c >= nc || c >= 5) return C;
+        present[c] = true;
+        s0 += sc.tbl[(size_t)c * (size_t)nc + c];
     }
-    return s0 > smax * ((int64_t)Li - 1) + 2 * gcol;
+    const int64_t L = Li;
+    if (!(s0 > smax * (L - 1) + 2 * gcol)) return C;
+    C.kmax = 0;
+    // k >= 1: a differing byte must be a differing CODE (one character per code among the reference's), soff below smax
+    int64_t soff = INT64_MIN, delta = 0;
+    for (int r = 0; r < 5 && r < nc; ++r) {
+        if (!present[r]) continue;
+        int chars = 0;
+        for (int b = 0; b < 256; ++b) if (sc.code_of_char[b] == r) ++chars;
+        if (chars != 1) return C;
+        for (int c = 0; c < 5 && c < nc; ++c) {                    // (every character of a read the kernel lets through is one of the five: its bases
+            if (c == r) continue;                                   //  equal the reference's, or differ from it and are checked)
+            soff = std::max<int64_t>(soff, sc.tbl[(size_t)r * nc + c]);
+            delta = std::max<int64_t>(delta, (int64_t)sc.tbl[(size_t)r * nc + r] - sc.tbl[(size_t)r * nc + c]);
+        }
+    }
+    if (soff == INT64_MIN || smax - soff <= 0 || Li < 8) return C;
+    const int64_t boundA = smax * (L - 1) + gap_open + gpos + gcol;
+    for (int k = 1; k <= 2; ++k) {
+        const int64_t lhs = s0 - k * delta;
+        if (!(lhs > boundA) || !(lhs > smax * (L - 3) + 6 * gcol)) break;
+        bool ok = true;
+        for (int a = 1; a <= 2; ++a) {                              // the largest m with smax m + soff (L - a - m) + 2 a gcol < lhs
+            const int64_t num = lhs - 2 * a * gcol - soff * (L - a) - 1;
+            if (num < 0) { ok = false; break; }
+            C.mmax[2 * (k - 1) + (a - 1)] = (int)std::min<int64_t>(num / (smax - soff), L);
+        }
+        if (!ok) break;
+        C.kmax = k;
+    }
+    return C;
 }
 
 // ---- the packed fill with plain 32-bit adds (c2_align_diagp_kernel<NA, true>) --------------------------------------------------

@@ -2155,7 +2155,7 @@ __device__ __forceinline__ bool c2_band_holds(const int bandw, const int D, cons
 }
 
 // a task's read and reference as the partition needs them
-struct c2_part_task { const uint8_t* rd; const uint8_t* f; int Li, Lj, rc, pk_ok, cut, ref_id, exact_ok; };
+struct c2_part_task { const uint8_t* rd; const uint8_t* f; const c2_dev_ref* ref; int Li, Lj, rc, pk_ok, cut, ref_id, diag_kmax; };
 __device__ __forceinline__ c2_part_task c2_part_load(const c2_align_args& A, const uint64_t task) {
     uint64_t read_id; int ref_id;
     if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
@@ -2166,7 +2166,7 @@ __device__ __forceinline__ c2_part_task c2_part_load(const c2_align_args& A, con
     t.Lj = (int)(A.offsets[read_id + 1] - off);
     const c2_dev_ref* rf = A.refs + ref_id;
     t.Li = rf->len; t.pk_ok = rf->pk_ok; t.rd = A.reads + off; t.f = rf->seq; t.cut = rf->first_incentive_pos;
-    t.ref_id = ref_id; t.exact_ok = rf->exact_copy_ok;
+    t.ref_id = ref_id; t.diag_kmax = rf->diag_kmax; t.ref = rf;
     return t;
 }
 // how a chunk's slots map to tasks (see the kernel): reference-major for an all-references batch of several references
@@ -2317,28 +2317,86 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                     }
                     if (mm <= P.max_mismatch) cls = 0;
                     else if (c2_part_probes(P, t)) cls = 8;
-                    // ---- class 0, and the read EQUALS its reference (the unedited, error-free read: the commonest read of an amplicon run): the main
-                    //      diagonal provably beats every other path (c2_exact_copy_certified, host), so there is nothing to fill -- the aligned strings
-                    //      are the read and the reference, every column a match, no event.  This lane compares the two 16 bytes at a time (the last
-                    //      block overlaps the one before it: nothing is read behind the read), and writes both rows and the record itself: the slot's
-                    //      flag becomes 9, in no list.  (All of a lane's loads are in flight together -- a wavefront per candidate, one after the
-                    //      other, waited for HBM 6 M times over and cost more than the fills it saved.)
-                    if (cls == 0 && P.exact_copies && t.exact_ok) {
+                    // ---- class 0, and the read lies ON its reference's main diagonal: a byte-for-byte copy (the unedited, error-free read: the
+                    //      commonest read of an amplicon run) or one that differs in one or two bases.  Where c2_main_diagonal_certificate (host) proves
+                    //      that the diagonal beats every other path there is nothing to fill: the aligned strings are the read and the reference,
+                    //      the only events substitutions.  This lane compares the two 16 bytes at a time (the last block overlaps the one before it:
+                    //      nothing is read behind the read), for a read with differing bases also against the reference shifted by +-1 and +-2 (the
+                    //      paths that are ONE other diagonal from end to end: their equal bytes must stay under the host's limit), and writes both
+                    //      rows and the record itself: the slot's flag becomes 9, in no list.  (All of a lane's loads are in flight together -- a
+                    //      wavefront per candidate, one after the other, waited for HBM 6 M times over and cost more than the fills it saved.)
+                    if (cls == 0 && P.exact_copies && t.diag_kmax >= 0) {
                         const int L = t.Lj, nq = (L + 15) >> 4;             // 32 <= L <= 256: 2 .. 16 blocks
                         // block q starts at 16 q -- the last one at L - 16 (it overlaps its predecessor); q beyond the last names the last again, so
                         // that every lane runs the same loads whatever its read's length
                         auto at_of = [&](int q) { if (q > nq - 1) q = nq - 1; return (16 * q + 16 <= L) ? 16 * q : L - 16; };
-                        unsigned diff = 0;
+                        auto flags = [](const uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; };     // bit 7 of every non-zero byte
+                        const int ov = 16 * nq - L;                         // bytes at the start of the last block that the block before it holds too
+                        int k = 0, p1 = -1, p2 = -1;                        // differing bases, and where the first two are
+                        int eq_m2 = 0, eq_m1 = 0, eq_p1 = 0, eq_p2 = 0;     // equal bytes of read[j] and reference[j + d] over the blocks 1 .. nq - 3
+                        const bool shifted = t.diag_kmax > 0;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
                             if (q < 10 || q < nq) {                         // (reads of 150 bases and more: ten blocks without a branch)
                                 const int at = at_of(q);
                                 uint4 x, y;
                                 __builtin_memcpy(&x, t.rd + at, 16); __builtin_memcpy(&y, t.f + at, 16);
-                                diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+                                uint32_t f0 = flags(x.x ^ y.x), f1 = flags(x.y ^ y.y), f2 = flags(x.z ^ y.z), f3 = flags(x.w ^ y.w);
+                                if (q >= nq) f0 = f1 = f2 = f3 = 0u;        // (the last block once more)
+                                else if (q == nq - 1 && ov) {               // its first `ov` bytes were counted with the block before
+                                    const uint64_t lo = ov >= 8 ? 0ull : (~0ull << (8 * ov)), hi = ov >= 8 ? (ov >= 16 ? 0ull : (~0ull << (8 * (ov - 8)))) : ~0ull;
+                                    f0 &= (uint32_t)lo; f1 &= (uint32_t)(lo >> 32); f2 &= (uint32_t)hi; f3 &= (uint32_t)(hi >> 32);
+                                }
+                                if (f0 | f1 | f2 | f3) {
+                                    k += __builtin_popcount(f0) + __builtin_popcount(f1) + __builtin_popcount(f2) + __builtin_popcount(f3);
+                                    const uint32_t fw[4] = {f0, f1, f2, f3};
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w) {
+                                        uint32_t f = fw[w];
+                                        while (f) {
+                                            const int pos = at + 4 * w + (__builtin_ctz(f) >> 3);
+                                            f &= f - 1u;
+                                            if (p1 < 0) p1 = pos; else if (p2 < 0) p2 = pos;
+                                        }
+                                    }
+                                }
+                                if (shifted && q >= 1 && q <= nq - 3) {     // whole blocks well inside both sequences: reference[at - 2 .. at + 17] exists
+                                    uint4 s;
+                                    __builtin_memcpy(&s, t.f + at - 2, 16);
+                                    eq_m2 += 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
+                                    __builtin_memcpy(&s, t.f + at - 1, 16);
+                                    eq_m1 += 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
+                                    __builtin_memcpy(&s, t.f + at + 1, 16);
+                                    eq_p1 += 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
+                                    __builtin_memcpy(&s, t.f + at + 2, 16);
+                                    eq_p2 += 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
+                                }
                             }
                         }
-                        if (diff == 0) {
+                        bool done = k <= t.diag_kmax;
+                        int n_all_sub = 0, n_win_sub = 0, irregular = 0;
+                        if (done && k > 0) {
+                            // the shifted diagonals: counted blocks + every other column taken as equal
+                            const int counted = nq >= 4 ? 16 * (nq - 3) : 0;
+                            const int m1 = (eq_m1 > eq_p1 ? eq_m1 : eq_p1) + (L - 1 - counted), m2 = (eq_m2 > eq_p2 ? eq_m2 : eq_p2) + (L - 2 - counted);
+                            const int32_t* mm = t.ref->diag_mmax + 2 * (k - 1);
+                            if (m1 > mm[0] || m2 > mm[1]) done = false;
+                            // the differing bases: A C G T N only (anything else keeps its launch: status words, IUPAC scores); the substitutions among them
+                            const int pp[2] = {p1, k > 1 ? p2 : -1};
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int pos = pp[e];
+                                if (pos < 0 || !done) continue;
+                                const unsigned char rb = t.rd[pos];
+                                if (A.code_of_char[rb] >= 5) { done = false; continue; }
+                                if (rb != 'N') {                            // COREResources.pyx:113-118
+                                    ++n_all_sub;
+                                    if (t.ref->inc_prefix[pos + 1] != t.ref->inc_prefix[pos]) ++n_win_sub;
+                                }
+                                if (pos == 0 || pos == L - 1) irregular = 1;
+                            }
+                        }
+                        if (done) {
                             uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
                             uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
                             if (!(A.reserved & 1)) {
@@ -2347,20 +2405,26 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                                     uint4 x0, x1, x2, x3;
                                     __builtin_memcpy(&x0, t.rd + a0, 16); __builtin_memcpy(&x1, t.rd + a1, 16);
                                     __builtin_memcpy(&x2, t.rd + a2, 16); __builtin_memcpy(&x3, t.rd + a3, 16);
-                                    __builtin_memcpy(outR + a0, &x0, 16); __builtin_memcpy(outF + a0, &x0, 16);
-                                    __builtin_memcpy(outR + a1, &x1, 16); __builtin_memcpy(outF + a1, &x1, 16);
-                                    __builtin_memcpy(outR + a2, &x2, 16); __builtin_memcpy(outF + a2, &x2, 16);
-                                    __builtin_memcpy(outR + a3, &x3, 16); __builtin_memcpy(outF + a3, &x3, 16);
+                                    __builtin_memcpy(outR + a0, &x0, 16); __builtin_memcpy(outR + a1, &x1, 16);
+                                    __builtin_memcpy(outR + a2, &x2, 16); __builtin_memcpy(outR + a3, &x3, 16);
+                                    if (k) {                                // (a copy's reference row is its read row)
+                                        __builtin_memcpy(&x0, t.f + a0, 16); __builtin_memcpy(&x1, t.f + a1, 16);
+                                        __builtin_memcpy(&x2, t.f + a2, 16); __builtin_memcpy(&x3, t.f + a3, 16);
+                                    }
+                                    __builtin_memcpy(outF + a0, &x0, 16); __builtin_memcpy(outF + a1, &x1, 16);
+                                    __builtin_memcpy(outF + a2, &x2, 16); __builtin_memcpy(outF + a3, &x3, 16);
                                 }
                                 if (L & 3) {                                // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
-                                    uint32_t w = 0;
-                                    for (int b = 0; b < (L & 3); ++b) w |= (uint32_t)t.rd[(L & ~3) + b] << (8 * b);
-                                    __builtin_memcpy(outR + (L & ~3), &w, 4); __builtin_memcpy(outF + (L & ~3), &w, 4);
+                                    uint32_t w = 0, v = 0;
+                                    for (int b = 0; b < (L & 3); ++b) { w |= (uint32_t)t.rd[(L & ~3) + b] << (8 * b); v |= (uint32_t)t.f[(L & ~3) + b] << (8 * b); }
+                                    __builtin_memcpy(outR + (L & ~3), &w, 4); __builtin_memcpy(outF + (L & ~3), &v, 4);
                                 }
                             }
                             c2_aln_record rec;
                             c2_clear_record(rec, 0, t.ref_id);
-                            rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)L;
+                            rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)(L - k);                     // pyx:375-376
+                            rec.substitution_n = (uint16_t)n_win_sub; rec.all_substitutions = (uint16_t)n_all_sub;
+                            rec.irregular_ends = (uint8_t)irregular;
                             A.records[task] = rec;
                             cls = 9;
                         }

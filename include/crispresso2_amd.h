@@ -323,13 +323,14 @@ int c2_score_stage_info(c2_ctx* ctx, int32_t* ran, int64_t* tasks, int64_t* fini
  * c2_partition_info: *ran bit 0 the partition ran for the most recent batch, bit 1 the 14-diagonal launch too; class_tasks7: tasks per class;
  * finished2: tasks the score-only launch and the 14-diagonal launch finished. */
 int c2_partition_info(c2_ctx* ctx, int32_t* ran, int64_t* class_tasks7, int64_t* finished2);
-/* Round 5: a class-0 read that EQUALS its reference byte for byte (the unedited, error-free read of an amplicon run) is finished by the partition
- * itself when the scoring proves that the main diagonal beats every other path (every other path leaves at least one base of each sequence
- * unpaired: its score is at most max_score * (L - 1) + 2 * (max(gap_open, gap_extend) + max incentive), and the diagonal's own score is above
- * that -- EDNAFULL with -20 / -2: 5 L against 5 L - 7).  CRISPResso2Align.pyx:338-421 then walks (L, L) -> (0, 0) in state M: the aligned
- * strings are the two sequences, every column a match.  Such tasks count in class_tasks7[0]; *n = how many of them there were
- * (C2_NO_EXACT_COPIES=1: none, every class-0 task goes through the score-only launch). */
-int c2_partition_exact_copies(c2_ctx* ctx, int64_t* n);
+/* Round 5: a class-0 read that lies on its reference's main diagonal -- a byte-for-byte copy (the unedited, error-free read of an amplicon run) or
+ * one that differs from it in one or two bases (A C G T N) -- is finished by the partition itself when the scoring proves that the diagonal beats
+ * every other path (c2_main_diagonal_certificate, csrc/c2_host_prep.h): a path with a gap run opened inside the matrix loses gap_open against at
+ * most two mismatches; a path that is one other diagonal from end to end (a leading and a trailing run only) is bounded by the equal bytes the
+ * kernel counts on the diagonals +-1 and +-2.  CRISPResso2Align.pyx:338-421 then walks (L, L) -> (0, 0) in state M: the aligned strings are the
+ * two sequences, the events their substitutions (COREResources.pyx:113-118).  Such tasks count in class_tasks7[0]; *n = how many of them there
+ * were.  C2_NO_EXACT_COPIES=1: none (every class-0 task goes through the score-only launch); C2_DIAG_CERT_KMAX=0: byte-for-byte copies only. */
+int c2_partition_finished(c2_ctx* ctx, int64_t* n);
 /* The same for up to 8 tiers, plus per tier the number of tasks its packed (int16) kernel could not pair and handed to the 32-bit
  * kernel of the same band: a tier with a packed kernel finished at least tasks_in - unpaired - left_over tasks in int16 arithmetic. */
 int c2_tier_info_ex(c2_ctx* ctx, int32_t* n_tiers, int32_t* left_over8, int32_t* unpaired8);

@@ -53,8 +53,16 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
         refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 126)) ? 1 : 0; refs[r].first_incentive_pos = -1;
         for (int i = 0; i <= lens[r]; ++i) if (g32[r][i] > 0) { refs[r].first_incentive_pos = i; break; }
-        refs[r].exact_copy_ok = (refs[r].pk_ok && !getenv("C2_NO_EXACT_COPIES") && c2_exact_copy_certified(seqs[r], lens[r], g32[r].data(), sc, go, ge)) ? 1 : 0;
-        refs[r].reserved_pad = 0;
+        {
+            c2_diag_cert dc;
+            dc.kmax = -1; dc.mmax[0] = dc.mmax[1] = dc.mmax[2] = dc.mmax[3] = -1;
+            if (refs[r].pk_ok && !getenv("C2_NO_EXACT_COPIES")) dc = c2_main_diagonal_certificate(seqs[r], lens[r], g32[r].data(), sc, go, ge);
+            if (const char* e = getenv("C2_DIAG_CERT_KMAX")) dc.kmax = std::min(dc.kmax, atoi(e));
+            if (getenv("C2_EMU_TRACE")) fprintf(stderr, "ref %d: main-diagonal certificate kmax %d, mmax %d %d %d %d\n", r, dc.kmax, dc.mmax[0], dc.mmax[1], dc.mmax[2], dc.mmax[3]);
+            refs[r].diag_kmax = dc.kmax;
+            for (int k = 0; k < 4; ++k) refs[r].diag_mmax[k] = dc.mmax[k];
+            refs[r].reserved_pad = 0;
+        }
         if (refs[r].pk_ok) any_pk = true;
         refs[r].len = lens[r];
         int64_t gm = 0;

@@ -838,66 +838,80 @@ def test_forty_diagonal_tier_six_alignments_per_wavefront(mats):
 
 
 @pytest.mark.parametrize("L", [250, 151, 203, 256])
-def test_reads_equal_to_their_reference_are_finished_by_the_partition(mats, L, monkeypatch):
-    """A class-0 read that EQUALS its reference byte for byte needs no fill when the scoring proves the main diagonal unbeatable
-    (c2_exact_copy_certified: every other path leaves a base of each sequence unpaired).  The partition compares such candidates as dwords and writes
-    the rows and the record itself; everything else -- one substitution anywhere (first byte, last byte, the partial last dword), an N, an indel, a
-    read of another length -- goes through the launches as before.  All results are the oracle's, and identical with the shortcut switched off."""
+def test_main_diagonal_reads_are_finished_by_the_partition(mats, L, monkeypatch):
+    """A class-0 read on its reference's main diagonal -- a byte-for-byte copy, or one / two differing bases of A C G T N -- needs no fill where the
+    scoring proves the diagonal unbeatable (c2_main_diagonal_certificate).  The partition compares such candidates 16 bytes at a time, counts the
+    equal bytes of the diagonals +-1 / +-2, and writes the rows and the record itself; three differing bases, an IUPAC code or a lower-case base in
+    the read, an indel, another length go through the launches as before.  All results are the oracle's, and identical with the shortcut switched
+    off or restricted to copies (the first byte, the last byte and the partial last dword are among the places that differ)."""
     m = mats["EDNAFULL"]
     rng = np.random.default_rng(7100 + L)
     amp = "".join(rng.choice(list("ACGT"), L))
     g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
-    inc = [L // 2, L // 2 + 1]
+    inc = [L // 2 - 1, L // 2, L // 2 + 1]
     other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    sub = lambda s_, q, c=None: s_[:q] + (c or other[s_[q]]) + s_[q + 1:]
     reads = [amp] * 9
-    for q in (0, 1, 3, 4, L // 2, L - 5, L - 4, L - 3, L - 2, L - 1):
-        reads.append(amp[:q] + other[amp[q]] + amp[q + 1:])
-        reads.append(amp[:q] + "N" + amp[q + 1:])
-    reads += [amp[:L // 2] + amp[L // 2 + 3:] + "ACG", amp[:L // 2] + "TT" + amp[L // 2:-2], amp[:-1], amp + "A", amp[1:], amp.lower()[:1] + amp[1:]]
-    reads += [amp] * 3
+    one = []
+    for q in (0, 1, 3, 4, 15, 16, 17, L // 2 - 1, L // 2, L // 2 + 1, L - 17, L - 16, L - 5, L - 4, L - 3, L - 2, L - 1):
+        one += [sub(amp, q), sub(amp, q, "N")]
+    two = [sub(sub(amp, 0), L - 1), sub(sub(amp, 7), 8), sub(sub(amp, L // 2), L // 2 + 1, "N"), sub(sub(amp, L - 2), L - 1), sub(sub(amp, 30, "N"), 90, "N"),
+           sub(sub(amp, L - 16), L - 15), sub(sub(amp, 15), 16)]
+    more = [sub(sub(sub(amp, 5), 50), 100), sub(amp, 40, "R"), sub(amp, 41, amp[41].lower()), sub(sub(amp, 9), 60, "Y"),
+            amp[:L // 2] + amp[L // 2 + 3:] + "ACG", amp[:L // 2] + "TT" + amp[L // 2:-2], amp[:-1], amp + "A", amp[1:]]
+    reads += one + two + more + [amp] * 3
     want = []
     for rd in reads:
         status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, -20, -2)
         want.append((status, s1, s2, mt))
-    st = {}
-    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
-    for k, (status, s1, s2, mt) in enumerate(want):
-        if status != 0:
-            assert rec[k]["status"] != 0, k
-            continue
-        assert rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k)
-        check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
-    assert st["exact_copies"] == 12 and sum(st["classes"]) == len(reads), st
-    monkeypatch.setenv("C2_NO_EXACT_COPIES", "1")
-    st2 = {}
-    res2, rec2 = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st2)
-    assert st2["exact_copies"] == 0 and st2["classes"] == st["classes"]
-    assert res2 == res and rec2.tobytes() == rec.tobytes()
-    o1, o2 = st["raw"]
-    p1, p2 = st2["raw"]
-    for k in range(len(reads)):                                    # the rows as the launches leave them, padding of the last dword included
-        n4 = (int(rec[k]["aln_len"]) + 3) // 4 * 4
-        assert o1[k, :n4].tobytes() == p1[k, :n4].tobytes() and o2[k, :n4].tobytes() == p2[k, :n4].tobytes(), k
+    outs = {}
+    for name, env in (("on", {}), ("copies", {"C2_DIAG_CERT_KMAX": "0"}), ("off", {"C2_NO_EXACT_COPIES": "1"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        st = {}
+        res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        for k, (status, s1, s2, mt) in enumerate(want):
+            if status != 0:
+                assert rec[k]["status"] != 0, (name, k)
+                continue
+            assert rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (name, L, k)
+            check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+        assert sum(st["classes"]) == len(reads), st
+        outs[name] = (res, rec, st)
+    assert outs["on"][2]["exact_copies"] == 12 + len(one) + len(two), outs["on"][2]
+    assert outs["copies"][2]["exact_copies"] == 12 and outs["off"][2]["exact_copies"] == 0
+    assert outs["on"][2]["classes"] == outs["off"][2]["classes"]
+    for name in ("copies", "off"):
+        assert outs[name][0] == outs["on"][0] and outs[name][1].tobytes() == outs["on"][1].tobytes(), name
+        o1, o2 = outs["on"][2]["raw"]
+        p1, p2 = outs[name][2]["raw"]
+        for k in range(len(reads)):                                # the rows as the launches leave them, padding of the last dword included
+            n4 = (int(outs["on"][1][k]["aln_len"]) + 3) // 4 * 4
+            assert o1[k, :n4].tobytes() == p1[k, :n4].tobytes() and o2[k, :n4].tobytes() == p2[k, :n4].tobytes(), (name, k)
 
 
-def test_exact_copies_only_where_the_scoring_proves_them(mats, monkeypatch):
-    """the certificate is per reference: two N's in the reference (EDNAFULL scores N -1 against itself: the diagonal falls 12 short of 5 L, the bound is 7 short) or a matrix
-    whose diagonal is not uniform leave the shortcut off -- and an incentive as large as |gap_extend| leaves even the packed kernels off"""
+def test_main_diagonal_shortcut_only_where_the_scoring_proves_it(mats, monkeypatch):
+    """the certificate is per reference: two N's in the reference (EDNAFULL scores N -1 against itself: the diagonal falls 12 short of 5 L, the bound
+    is 7 short) or a matrix whose diagonal is not uniform leave the shortcut off; one N still passes (5 L - 6 against 5 L - 7; with two differing
+    bases 5 L - 24 against the 5 L - 25 of a path with a gap opened inside the matrix)"""
     m = mats["EDNAFULL"]
     rng = np.random.default_rng(7300)
     L = 160
     amp = "".join(rng.choice(list("ACGT"), L))
-    with_n = amp[:30] + "N" + amp[31:]                              # one N: the diagonal is 5 L - 6, the bound 5 L - 7 -- still proven
-    with_nn = with_n[:90] + "N" + with_n[91:]                       # two: 5 L - 12
+    with_n = amp[:30] + "N" + amp[31:]
+    with_nn = with_n[:90] + "N" + with_n[91:]
     g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
     inc = [L // 2, L // 2 + 1]
-    for ref, expect in ((amp, 6), (with_n, 6), (with_nn, 0)):
+    for ref, expect in ((amp, 7), (with_n, 7), (with_nn, 0)):
         reads = [ref] * 6 + [ref[:50] + "A" + ref[50:-1], ref[:10] + ("C" if ref[10] != "C" else "G") + ref[11:]]
         st = {}
         res, rec = E.align_batch(reads, [ref], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
         for k, rd in enumerate(reads):
             status, s1, s2, mt, ln = oracle.global_align_raw(rd, ref, m, g, -20, -2)
             assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (ref == amp, k)
+            check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
         assert st["exact_copies"] == expect, st
     uneven = m.copy()
     uneven[ord("C"), ord("C")] = 3                                   # C pairs with C for less than the other bases pair with themselves
@@ -908,3 +922,95 @@ def test_exact_copies_only_where_the_scoring_proves_them(mats, monkeypatch):
         status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, uneven, g, -20, -2)
         assert status == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, k
     assert st["exact_copies"] == 0, st                               # (some forty C's at 3 instead of 5: the diagonal is 80 below 5 L, the bound 7 below)
+
+
+@pytest.mark.parametrize("kind", ["homopolymer", "marker_in_homopolymer", "dinucleotide", "period3", "period5", "half_repeat", "gentle_scoring"])
+def test_main_diagonal_shortcut_refuses_what_shifts_onto_itself(mats, kind):
+    """References that shift onto themselves -- a homopolymer, tandem repeats of period 2 / 3 / 5, a unique half followed by a repeat -- are where a
+    path along ANOTHER diagonal (a leading and a trailing gap run, no opening inside the matrix) comes close to the main diagonal or beats it: reads
+    with one or two differing bases there must keep their fill.  Whatever the partition decides, every alignment is the oracle's (the oracle decides
+    ties and near-ties by the reference's own comparisons).  gentle_scoring: a gap_open of -6, where two mismatches already cost more than a gap."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(hash(kind) % 10000)
+    L = 200
+    go, ge = -20, -2
+    if kind == "homopolymer":
+        amp = "A" * L
+    elif kind == "marker_in_homopolymer":
+        amp = "A" * 100 + "C" + "A" * (L - 101)
+    elif kind == "dinucleotide":
+        amp = "AC" * (L // 2)
+    elif kind == "period3":
+        amp = ("ACG" * L)[:L]
+    elif kind == "period5":
+        amp = ("ACGTT" * L)[:L]
+    elif kind == "half_repeat":
+        amp = "".join(rng.choice(list("ACGT"), L // 2)) + ("GA" * L)[:L - L // 2]
+    else:
+        amp = "".join(rng.choice(list("ACGT"), L))
+        go, ge = -6, -2
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = [L // 2, L // 2 + 1]
+    other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    sub = lambda s_, q, c=None: s_[:q] + (c or other[s_[q]]) + s_[q + 1:]
+    reads = [amp] * 4
+    for q in (0, 1, 2, 50, 99, 100, 101, 150, L - 3, L - 2, L - 1):
+        reads += [sub(amp, q), sub(amp, q, "N"), sub(amp, q, amp[(q + 1) % L]), sub(amp, q, amp[q - 1])]
+    for q, r in ((0, 1), (0, L - 1), (1, 2), (98, 102), (L - 2, L - 1), (3, 7), (60, 61)):
+        reads += [sub(sub(amp, q), r), sub(sub(amp, q, amp[(q + 1) % L]), r, amp[r - 1])]
+    reads += [amp[1:] + amp[0], amp[-1] + amp[:-1], amp[2:] + amp[:2]]                  # the reference rotated: ANOTHER diagonal is the perfect one
+    if kind == "marker_in_homopolymer":
+        # the marker moved by one or two: two differing bases on the main diagonal, none on the diagonal next to it -- the shifted path WINS
+        # (5 (L - 1) - 4 against 5 (L - 2) - 8), and the partition must see that its equal bytes are over the limit
+        for d in (-2, -1, 1, 2):
+            t = list(amp); t[100] = "A"; t[100 + d] = "C"
+            reads.append("".join(t))
+    st = {}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, go, ge, band_lanes=-87, stats=st)
+    for k, rd in enumerate(reads):
+        status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, go, ge)
+        assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (kind, k, rd)
+        check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+    if kind == "marker_in_homopolymer":
+        moved = len(reads) - 4
+        assert all("-" in res[k][0] and "-" in res[k][1] for k in (moved + 1, moved + 2)), "the marker moved by one aligns along the next diagonal, with end gaps"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_main_diagonal_shortcut_on_random_low_complexity_references(mats, seed):
+    """Randomised: references made of a repeat unit of period 1 .. 6 with a few point defects (where another diagonal fits as well as the main one
+    except at the defects), reads = the reference with 0 .. 2 bases changed -- at random places, or so that a defect MOVES by one or two (the read
+    then matches a shifted reference better than the reference itself).  The oracle decides every case, near-ties and ties included."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(991 + seed)
+    for trial in range(12):
+        L = int(rng.integers(160, 257))
+        period = int(rng.integers(1, 7))
+        unit = "".join(rng.choice(list("ACGT"), period))
+        ref = list((unit * L)[:L])
+        defects = sorted(set(int(x) for x in rng.integers(5, L - 5, int(rng.integers(0, 4)))))
+        for q in defects:
+            ref[q] = rng.choice([c for c in "ACGT" if c != ref[q]])
+        amp = "".join(ref)
+        go, ge, cut_incentive = [(-20, -2, 1), (-10, -1, 0), (-6, -2, 1), (-30, -3, 2)][trial % 4]
+        g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = cut_incentive
+        inc = [L // 2, L // 2 + 1]
+        reads = [amp]
+        for _ in range(150):
+            t = list(amp)
+            for _ in range(int(rng.integers(1, 3))):
+                q = int(rng.integers(0, L))
+                t[q] = rng.choice(list("ACGTN"))
+            reads.append("".join(t))
+        for q in defects:                                            # a defect moved: restore the unit's base, put the defect's base next door
+            for d in (-2, -1, 1, 2):
+                t = list(amp)
+                t[q] = (unit * L)[q]
+                t[q + d] = amp[q]
+                reads.append("".join(t))
+        st = {}
+        res, rec = E.align_batch(reads, [amp], [g], [inc], m, go, ge, band_lanes=-87, stats=st)
+        for k, rd in enumerate(reads):
+            status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, go, ge)
+            assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (seed, trial, period, defects, go, ge, k, rd)
+            check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)

@@ -36,7 +36,7 @@ def main():
         tm = job.timed(1, a.steps)
         tiers, part = ctx.tier_info(), ctx.partition_info()
         out = {"leg": name, "reads": job.n, "reads_per_s": tm["reads_per_s"], "align_chain_ms": tm["align_ms"], "count_ms": tm["count_ms"],
-               "classes": part["classes"], "score_only_finished": part["finished"][0], "exact_copies": part.get("exact_copies"), "lists_after_tiers": tiers,
+               "classes": part["classes"], "score_only_finished": part["finished"][0], "finished_by_partition": part.get("finished_by_partition"), "lists_after_tiers": tiers,
                "env": {k: v for k, v in os.environ.items() if k.startswith("C2_")}}
         if not a.no_check:
             eq, tf = job.chain_equals_full_plane()
