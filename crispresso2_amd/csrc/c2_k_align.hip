@@ -2317,129 +2317,159 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                     }
                     if (mm <= P.max_mismatch) cls = 0;
                     else if (c2_part_probes(P, t)) cls = 8;
-                    // ---- class 0, and the read lies ON its reference's main diagonal: a byte-for-byte copy (the unedited, error-free read: the
-                    //      commonest read of an amplicon run) or one that differs in one or two bases.  Where c2_main_diagonal_certificate (host) proves
-                    //      that the diagonal beats every other path there is nothing to fill: the aligned strings are the read and the reference,
-                    //      the only events substitutions.  This lane compares the two 16 bytes at a time (the last block overlaps the one before it:
-                    //      nothing is read behind the read), for a read with differing bases also against the reference shifted by +-1 and +-2 (the
-                    //      paths that are ONE other diagonal from end to end: their equal bytes must stay under the host's limit), and writes both
-                    //      rows and the record itself: the slot's flag becomes 9, in no list.  (All of a lane's loads are in flight together -- a
-                    //      wavefront per candidate, one after the other, waited for HBM 6 M times over and cost more than the fills it saved.)
-                    if (cls == 0 && P.exact_copies && t.diag_kmax >= 0) {
-                        const int L = t.Lj, nq = (L + 15) >> 4;             // 32 <= L <= 256: 2 .. 16 blocks
-                        // block q starts at 16 q -- the last one at L - 16 (it overlaps its predecessor); q beyond the last names the last again, so
-                        // that every lane runs the same loads whatever its read's length
-                        auto at_of = [&](int q) { if (q > nq - 1) q = nq - 1; return (16 * q + 16 <= L) ? 16 * q : L - 16; };
-                        auto flags = [](const uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; };     // bit 7 of every non-zero byte
-                        const int ov = 16 * nq - L;                         // bytes at the start of the last block that the block before it holds too
-                        int k = 0, p1 = -1, p2 = -1;                        // differing bases, and where the first two are
-                        int eq_m2 = 0, eq_m1 = 0, eq_p1 = 0, eq_p2 = 0;     // equal bytes of read[j] and reference[j + d] over the blocks 1 .. nq - 3
-                        const bool shifted = t.diag_kmax > 0;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            if (q < 10 || q < nq) {                         // (reads of 150 bases and more: ten blocks without a branch)
-                                const int at = at_of(q);
-                                uint4 x, y;
-                                __builtin_memcpy(&x, t.rd + at, 16); __builtin_memcpy(&y, t.f + at, 16);
-                                uint32_t f0 = flags(x.x ^ y.x), f1 = flags(x.y ^ y.y), f2 = flags(x.z ^ y.z), f3 = flags(x.w ^ y.w);
-                                if (q >= nq) f0 = f1 = f2 = f3 = 0u;        // (the last block once more)
-                                else if (q == nq - 1 && ov) {               // its first `ov` bytes were counted with the block before
-                                    const uint64_t lo = ov >= 8 ? 0ull : (~0ull << (8 * ov)), hi = ov >= 8 ? (ov >= 16 ? 0ull : (~0ull << (8 * (ov - 8)))) : ~0ull;
-                                    f0 &= (uint32_t)lo; f1 &= (uint32_t)(lo >> 32); f2 &= (uint32_t)hi; f3 &= (uint32_t)(hi >> 32);
-                                }
-                                if (f0 | f1 | f2 | f3) {
-                                    k += __builtin_popcount(f0) + __builtin_popcount(f1) + __builtin_popcount(f2) + __builtin_popcount(f3);
-                                    const uint32_t fw[4] = {f0, f1, f2, f3};
-#pragma unroll
-                                    for (int w = 0; w < 4; ++w) {
-                                        uint32_t f = fw[w];
-                                        while (f) {
-                                            const int pos = at + 4 * w + (__builtin_ctz(f) >> 3);
-                                            f &= f - 1u;
-                                            if (p1 < 0) p1 = pos; else if (p2 < 0) p2 = pos;
-                                        }
-                                    }
-                                }
-                                if (shifted && q >= 1 && q <= nq - 3) {     // whole blocks well inside both sequences: reference[at - 2 .. at + 17] exists
-                                    uint4 s;
-                                    __builtin_memcpy(&s, t.f + at - 2, 16);
-                                    eq_m2 += 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
-                                    __builtin_memcpy(&s, t.f + at - 1, 16);
-                                    eq_m1 += 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
-                                    __builtin_memcpy(&s, t.f + at + 1, 16);
-                                    eq_p1 += 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
-                                    __builtin_memcpy(&s, t.f + at + 2, 16);
-                                    eq_p2 += 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
-                                }
-                            }
-                        }
-                        bool done = k <= t.diag_kmax;
-                        int n_all_sub = 0, n_win_sub = 0, irregular = 0;
-                        if (done && k > 0) {
-                            // the shifted diagonals: counted blocks + every other column taken as equal
-                            const int counted = nq >= 4 ? 16 * (nq - 3) : 0;
-                            const int m1 = (eq_m1 > eq_p1 ? eq_m1 : eq_p1) + (L - 1 - counted), m2 = (eq_m2 > eq_p2 ? eq_m2 : eq_p2) + (L - 2 - counted);
-                            const int32_t* mm = t.ref->diag_mmax + 2 * (k - 1);
-                            if (m1 > mm[0] || m2 > mm[1]) done = false;
-                            // the differing bases: A C G T N only (anything else keeps its launch: status words, IUPAC scores); the substitutions among them
-                            const int pp[2] = {p1, k > 1 ? p2 : -1};
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const int pos = pp[e];
-                                if (pos < 0 || !done) continue;
-                                const unsigned char rb = t.rd[pos];
-                                if (A.code_of_char[rb] >= 5) { done = false; continue; }
-                                if (rb != 'N') {                            // COREResources.pyx:113-118
-                                    ++n_all_sub;
-                                    if (t.ref->inc_prefix[pos + 1] != t.ref->inc_prefix[pos]) ++n_win_sub;
-                                }
-                                if (pos == 0 || pos == L - 1) irregular = 1;
-                            }
-                        }
-                        if (done) {
-                            uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
-                            uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
-                            if (!(A.reserved & 1)) {
-                                for (int q0 = 0; q0 < nq; q0 += 4) {         // four blocks in flight (they come from L2 now), then their eight stores
-                                    const int a0 = at_of(q0), a1 = at_of(q0 + 1), a2 = at_of(q0 + 2), a3 = at_of(q0 + 3);
-                                    uint4 x0, x1, x2, x3;
-                                    __builtin_memcpy(&x0, t.rd + a0, 16); __builtin_memcpy(&x1, t.rd + a1, 16);
-                                    __builtin_memcpy(&x2, t.rd + a2, 16); __builtin_memcpy(&x3, t.rd + a3, 16);
-                                    __builtin_memcpy(outR + a0, &x0, 16); __builtin_memcpy(outR + a1, &x1, 16);
-                                    __builtin_memcpy(outR + a2, &x2, 16); __builtin_memcpy(outR + a3, &x3, 16);
-                                    if (k) {                                // (a copy's reference row is its read row)
-                                        __builtin_memcpy(&x0, t.f + a0, 16); __builtin_memcpy(&x1, t.f + a1, 16);
-                                        __builtin_memcpy(&x2, t.f + a2, 16); __builtin_memcpy(&x3, t.f + a3, 16);
-                                    }
-                                    __builtin_memcpy(outF + a0, &x0, 16); __builtin_memcpy(outF + a1, &x1, 16);
-                                    __builtin_memcpy(outF + a2, &x2, 16); __builtin_memcpy(outF + a3, &x3, 16);
-                                }
-                                if (L & 3) {                                // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
-                                    uint32_t w = 0, v = 0;
-                                    for (int b = 0; b < (L & 3); ++b) { w |= (uint32_t)t.rd[(L & ~3) + b] << (8 * b); v |= (uint32_t)t.f[(L & ~3) + b] << (8 * b); }
-                                    __builtin_memcpy(outR + (L & ~3), &w, 4); __builtin_memcpy(outF + (L & ~3), &v, 4);
-                                }
-                            }
-                            c2_aln_record rec;
-                            c2_clear_record(rec, 0, t.ref_id);
-                            rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)(L - k);                     // pyx:375-376
-                            rec.substitution_n = (uint16_t)n_win_sub; rec.all_substitutions = (uint16_t)n_all_sub;
-                            rec.irregular_ends = (uint8_t)irregular;
-                            A.records[task] = rec;
-                            cls = 9;
-                        }
-                    }
                 }
             }
-            n_exact += (unsigned)__popcll(__ballot(cls == 9));
             flag[slot] = (uint8_t)cls;
             if (may_sort) {
                 len16[slot] = (uint16_t)(lj < 0 ? 0 : (lj < C2_PART_LEN_BINS - 1 ? lj : C2_PART_LEN_BINS - 1));
                 if (slot == 0) { part[24] = (unsigned)lj; part[25] = 0u; }
             }
         }
-        if (lane == 0 && n_exact && P.class_count) { atomicAdd(P.class_count + 0, n_exact); atomicAdd(P.class_count + 7, n_exact); }
         __syncthreads();
+        // ---- class 0, and the read lies ON its reference's main diagonal: a byte-for-byte copy (the unedited, error-free read: the commonest read of
+        //      an amplicon run) or one that differs in one or two bases.  Where c2_main_diagonal_certificate (host) proves that the diagonal beats
+        //      every other path there is nothing to fill: the aligned strings are the read and the reference, the only events substitutions.
+        //      EIGHT lanes per candidate, 32 bytes each (the last lane's block overlaps the one before it: nothing is read behind the read): the
+        //      read against the reference, and -- for the paths that are ONE other diagonal from end to end -- against the reference shifted by
+        //      +-1 and +-2 over the 16-byte halves that lie well inside both (their equal bytes, every other column taken as equal, must stay
+        //      under the host's limit).  The eight lanes write both rows from the registers they compared (256 contiguous bytes per row) and
+        //      their first lane the record; the slot's flag becomes 9, in no list.  The candidates are first gathered densely, as the probe's are.
+        if (P.exact_copies) {
+            unsigned n0 = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) n0 += flag[16 * tid + k] == 0u;
+            unsigned incl = n0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+            if (lane == 63) part[wv] = incl;
+            __syncthreads();
+            unsigned before = 0, total = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const unsigned x = part[v]; if (v < wv) before += x; total += x; }
+            unsigned pos = before + incl - n0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (flag[16 * tid + k] == 0u) todo[pos++] = (uint16_t)(16 * tid + k);
+            __syncthreads();
+            auto flags = [](const uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; };     // bit 7 of every non-zero byte
+            auto eq16 = [&](const uint4& x, const uint8_t* p) {      // equal bytes of a 16-byte half and the 16 bytes at p
+                uint4 s;
+                __builtin_memcpy(&s, p, 16);
+                return 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
+            };
+            const int q = tid & 7, grp = (lane >> 3) << 3;          // this lane's 32-byte block; the first lane of its group of eight
+            for (unsigned i0 = 0; i0 < total; i0 += 32u) {          // 32 candidates per step of the workgroup
+                const unsigned i = i0 + (unsigned)(tid >> 3);
+                const bool act = i < total;
+                const int slot = act ? (int)todo[i] : 0;
+                const uint64_t task = act ? c2_part_task_of(WK, A, chunk, slot) : 0ull;
+                c2_part_task t;
+                t.diag_kmax = -1; t.Lj = 32; t.rd = nullptr; t.f = nullptr; t.ref = nullptr; t.ref_id = 0;
+                if (act) t = c2_part_load(A, task);
+                const bool live = act && t.diag_kmax >= 0;
+                const int L = t.Lj, nq = (L + 31) >> 5;              // 32 <= L <= 256: 1 .. 8 blocks
+                const int at = (32 * q + 32 <= L) ? 32 * q : L - 32; // (the last block starts at L - 32)
+                const int ov = 32 * nq - L;                         // bytes at the start of the last block that the block before it holds too
+                uint4 x0 = {0u, 0u, 0u, 0u}, x1 = x0, y0 = x0, y1 = x0;
+                unsigned kl = 0, eqw = 0, halves = 0;               // this lane's differing bases; equal bytes on the four shifted diagonals (a byte each); halves counted
+                int pa = -1, pb = -1;                               // where its first two differing bases are
+                if (live && q < nq) {
+                    __builtin_memcpy(&x0, t.rd + at, 16); __builtin_memcpy(&x1, t.rd + at + 16, 16);
+                    __builtin_memcpy(&y0, t.f + at, 16); __builtin_memcpy(&y1, t.f + at + 16, 16);
+                    uint32_t f[8] = {flags(x0.x ^ y0.x), flags(x0.y ^ y0.y), flags(x0.z ^ y0.z), flags(x0.w ^ y0.w),
+                                     flags(x1.x ^ y1.x), flags(x1.y ^ y1.y), flags(x1.z ^ y1.z), flags(x1.w ^ y1.w)};
+                    if (q == nq - 1 && ov) {                        // its first `ov` bytes were counted by the lane before
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            const int drop = ov - 4 * w;            // bytes of this dword to forget
+                            if (drop >= 4) f[w] = 0u; else if (drop > 0) f[w] &= ~0u << (8 * drop);
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        uint32_t g = f[w];
+                        kl += (unsigned)__builtin_popcount(g);
+                        while (g) {
+                            const int p_ = at + 4 * w + (__builtin_ctz(g) >> 3);
+                            g &= g - 1u;
+                            if (pa < 0) pa = p_; else if (pb < 0) pb = p_;
+                        }
+                    }
+                    if (t.diag_kmax > 0 && q < nq - 1) {            // (not the last block: it overlaps)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int o = at + 16 * h;
+                            if (o >= 2 && o + 18 <= L) {            // reference[o - 2 .. o + 17] exists
+                                const uint4& xh = h ? x1 : x0;
+                                eqw += (unsigned)eq16(xh, t.f + o - 2) | ((unsigned)eq16(xh, t.f + o - 1) << 8) | ((unsigned)eq16(xh, t.f + o + 1) << 16) | ((unsigned)eq16(xh, t.f + o + 2) << 24);
+                                ++halves;
+                            }
+                        }
+                    }
+                }
+                // the group's sums (every lane of the wavefront takes part: no branch around the exchanges)
+                unsigned ks = kl < 3u ? kl : 3u;
+#pragma unroll
+                for (int d = 1; d < 8; d <<= 1) {
+                    ks += (unsigned)__shfl_xor((int)ks, d); eqw += (unsigned)__shfl_xor((int)eqw, d); halves += (unsigned)__shfl_xor((int)halves, d);
+                }
+                // ... and where its (at most two) differing bases are: the first lane that holds one, then that lane's second or the next lane's first
+                const unsigned gm = (unsigned)(__ballot(kl > 0u) >> grp) & 0xffu;
+                const int l1 = gm ? __builtin_ctz(gm) : 0, l2 = (gm & (gm - 1u)) ? __builtin_ctz(gm & (gm - 1u)) : l1;
+                const int p1 = __shfl(pa, grp + l1), p1b = __shfl(pb, grp + l1), p2n = __shfl(pa, grp + l2);
+                const int k = (int)ks;
+                const int p2 = p1b >= 0 ? p1b : (l2 != l1 ? p2n : -1);
+                bool done = live && k <= t.diag_kmax;
+                int n_all_sub = 0, n_win_sub = 0, irregular = 0;
+                if (done && k > 0) {
+                    const int counted = 16 * (int)halves;
+                    const int e_m2 = (int)(eqw & 0xffu), e_m1 = (int)((eqw >> 8) & 0xffu), e_p1 = (int)((eqw >> 16) & 0xffu), e_p2 = (int)(eqw >> 24);
+                    const int m1 = (e_m1 > e_p1 ? e_m1 : e_p1) + (L - 1 - counted), m2 = (e_m2 > e_p2 ? e_m2 : e_p2) + (L - 2 - counted);
+                    const int32_t* mm = t.ref->diag_mmax + 2 * (k - 1);
+                    if (m1 > mm[0] || m2 > mm[1]) done = false;
+                    // the differing bases: A C G T N only (anything else keeps its launch: status words, IUPAC scores); the substitutions among them
+                    const int pp[2] = {p1, k > 1 ? p2 : -1};
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int pos_ = pp[e];
+                        if (pos_ < 0 || !done) continue;
+                        const unsigned char rb = t.rd[pos_];
+                        if (A.code_of_char[rb] >= 5) { done = false; continue; }
+                        if (rb != 'N') {                            // COREResources.pyx:113-118
+                            ++n_all_sub;
+                            if (t.ref->inc_prefix[pos_ + 1] != t.ref->inc_prefix[pos_]) ++n_win_sub;
+                        }
+                        if (pos_ == 0 || pos_ == L - 1) irregular = 1;
+                    }
+                }
+                if (done) {
+                    uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
+                    uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
+                    if (!(A.reserved & 1)) {
+                        if (q < nq) {
+                            __builtin_memcpy(outR + at, &x0, 16); __builtin_memcpy(outR + at + 16, &x1, 16);
+                            __builtin_memcpy(outF + at, &y0, 16); __builtin_memcpy(outF + at + 16, &y1, 16);
+                        }
+                        if (q == 0 && (L & 3)) {                    // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
+                            uint32_t w = 0, v = 0;
+                            for (int b = 0; b < (L & 3); ++b) { w |= (uint32_t)t.rd[(L & ~3) + b] << (8 * b); v |= (uint32_t)t.f[(L & ~3) + b] << (8 * b); }
+                            __builtin_memcpy(outR + (L & ~3), &w, 4); __builtin_memcpy(outF + (L & ~3), &v, 4);
+                        }
+                    }
+                    if (q == 0) {
+                        c2_aln_record rec;
+                        c2_clear_record(rec, 0, t.ref_id);
+                        rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)(L - k);                             // pyx:375-376
+                        rec.substitution_n = (uint16_t)n_win_sub; rec.all_substitutions = (uint16_t)n_all_sub;
+                        rec.irregular_ends = (uint8_t)irregular;
+                        A.records[task] = rec;
+                        flag[slot] = 9u;
+                    }
+                }
+                n_exact += (unsigned)__popcll(__ballot(done && q == 0));
+            }
+            if (lane == 0 && n_exact && P.class_count) { atomicAdd(P.class_count + 0, n_exact); atomicAdd(P.class_count + 7, n_exact); }
+            __syncthreads();
+        }
         if (may_sort) {                                             // do the chunk's reads differ in length?
             const int l0 = (int)part[24];
             for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
