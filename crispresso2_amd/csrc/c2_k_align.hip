@@ -2357,24 +2357,33 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                 return 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
             };
             const int q = tid & 7, grp = (lane >> 3) << 3;          // this lane's 32-byte block; the first lane of its group of eight
-            for (unsigned i0 = 0; i0 < total; i0 += 32u) {          // 32 candidates per step of the workgroup
-                const unsigned i = i0 + (unsigned)(tid >> 3);
-                const bool act = i < total;
-                const int slot = act ? (int)todo[i] : 0;
-                const uint64_t task = act ? c2_part_task_of(WK, A, chunk, slot) : 0ull;
-                c2_part_task t;
-                t.diag_kmax = -1; t.Lj = 32; t.rd = nullptr; t.f = nullptr; t.ref = nullptr; t.ref_id = 0;
-                if (act) t = c2_part_load(A, task);
-                const bool live = act && t.diag_kmax >= 0;
-                const int L = t.Lj, nq = (L + 31) >> 5;              // 32 <= L <= 256: 1 .. 8 blocks
-                const int at = (32 * q + 32 <= L) ? 32 * q : L - 32; // (the last block starts at L - 32)
-                const int ov = 32 * nq - L;                         // bytes at the start of the last block that the block before it holds too
-                uint4 x0 = {0u, 0u, 0u, 0u}, x1 = x0, y0 = x0, y1 = x0;
+            struct cand_t { bool act, live; int slot, L, nq, at, ov; uint64_t task; c2_part_task t; uint4 x0, x1, y0, y1; };
+            // a candidate's loads (the only ones that come from HBM: two candidates' worth are in flight per lane, see the loop)
+            auto fetch = [&](const unsigned i) {
+                cand_t c;
+                c.act = i < total;
+                c.slot = c.act ? (int)todo[i] : 0;
+                c.task = c.act ? c2_part_task_of(WK, A, chunk, c.slot) : 0ull;
+                c.t.diag_kmax = -1; c.t.Lj = 32; c.t.rd = nullptr; c.t.f = nullptr; c.t.ref = nullptr; c.t.ref_id = 0;
+                if (c.act) c.t = c2_part_load(A, c.task);
+                c.live = c.act && c.t.diag_kmax >= 0;
+                c.L = c.t.Lj; c.nq = (c.L + 31) >> 5;                // 32 <= L <= 256: 1 .. 8 blocks
+                c.at = (32 * q + 32 <= c.L) ? 32 * q : c.L - 32;     // (the last block starts at L - 32)
+                c.ov = 32 * c.nq - c.L;                             // bytes at the start of the last block that the block before it holds too
+                c.x0 = uint4{0u, 0u, 0u, 0u}; c.x1 = c.x0; c.y0 = c.x0; c.y1 = c.x0;
+                if (c.live && q < c.nq) {
+                    __builtin_memcpy(&c.x0, c.t.rd + c.at, 16); __builtin_memcpy(&c.x1, c.t.rd + c.at + 16, 16);
+                    __builtin_memcpy(&c.y0, c.t.f + c.at, 16); __builtin_memcpy(&c.y1, c.t.f + c.at + 16, 16);
+                }
+                return c;
+            };
+            auto finish = [&](const cand_t& c) {
+                const c2_part_task& t = c.t;
+                const int L = c.L, nq = c.nq, at = c.at, ov = c.ov;
+                const uint4 &x0 = c.x0, &x1 = c.x1, &y0 = c.y0, &y1 = c.y1;
                 unsigned kl = 0, eqw = 0, halves = 0;               // this lane's differing bases; equal bytes on the four shifted diagonals (a byte each); halves counted
                 int pa = -1, pb = -1;                               // where its first two differing bases are
-                if (live && q < nq) {
-                    __builtin_memcpy(&x0, t.rd + at, 16); __builtin_memcpy(&x1, t.rd + at + 16, 16);
-                    __builtin_memcpy(&y0, t.f + at, 16); __builtin_memcpy(&y1, t.f + at + 16, 16);
+                if (c.live && q < nq) {
                     uint32_t f[8] = {flags(x0.x ^ y0.x), flags(x0.y ^ y0.y), flags(x0.z ^ y0.z), flags(x0.w ^ y0.w),
                                      flags(x1.x ^ y1.x), flags(x1.y ^ y1.y), flags(x1.z ^ y1.z), flags(x1.w ^ y1.w)};
                     if (q == nq - 1 && ov) {                        // its first `ov` bytes were counted by the lane before
@@ -2418,7 +2427,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                 const int p1 = __shfl(pa, grp + l1), p1b = __shfl(pb, grp + l1), p2n = __shfl(pa, grp + l2);
                 const int k = (int)ks;
                 const int p2 = p1b >= 0 ? p1b : (l2 != l1 ? p2n : -1);
-                bool done = live && k <= t.diag_kmax;
+                bool done = c.live && k <= t.diag_kmax;
                 int n_all_sub = 0, n_win_sub = 0, irregular = 0;
                 if (done && k > 0) {
                     const int counted = 16 * (int)halves;
@@ -2442,8 +2451,8 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                     }
                 }
                 if (done) {
-                    uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
-                    uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
+                    uint8_t* outR = A.aln_read + c.task * (uint64_t)A.aln_stride;
+                    uint8_t* outF = A.aln_ref + c.task * (uint64_t)A.aln_stride;
                     if (!(A.reserved & 1)) {
                         if (q < nq) {
                             __builtin_memcpy(outR + at, &x0, 16); __builtin_memcpy(outR + at + 16, &x1, 16);
@@ -2461,11 +2470,17 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                         rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)(L - k);                             // pyx:375-376
                         rec.substitution_n = (uint16_t)n_win_sub; rec.all_substitutions = (uint16_t)n_all_sub;
                         rec.irregular_ends = (uint8_t)irregular;
-                        A.records[task] = rec;
-                        flag[slot] = 9u;
+                        A.records[c.task] = rec;
+                        flag[c.slot] = 9u;
                     }
                 }
                 n_exact += (unsigned)__popcll(__ballot(done && q == 0));
+            };
+            for (unsigned i0 = 0; i0 < total; i0 += 64u) {          // 64 candidates per step of the workgroup: two per group of eight lanes, both
+                const cand_t ca = fetch(i0 + (unsigned)(tid >> 3)); //  candidates' loads issued before either is looked at
+                const cand_t cb = fetch(i0 + 32u + (unsigned)(tid >> 3));
+                finish(ca);
+                finish(cb);
             }
             if (lane == 0 && n_exact && P.class_count) { atomicAdd(P.class_count + 0, n_exact); atomicAdd(P.class_count + 7, n_exact); }
             __syncthreads();
