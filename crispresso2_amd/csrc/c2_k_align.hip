@@ -726,10 +726,8 @@ __device__ __forceinline__ void c2_emit_gapless4(const c2_align_args& A, const c
     const int nb = L - p;                                             // valid bytes of this lane's dword
     const uint32_t valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
     const uint32_t rd = ((const uint32_t*)W.sRead)[lane] & valid, rf = ((const uint32_t*)W.sRef)[lane] & valid;
-    if (!(A.reserved & 1) && (nb > 0 || 4 * lane < (int)A.aln_stride)) {
-        // (a partial last dword is padded with zeros, and so is the rest of the row -- the row has room, aln_stride is a multiple of 16: a row of 250
-        //  bytes in a stride of 256 is then two whole cache lines instead of one and a half, and half a line written costs HBM a read as well)
-        ((uint32_t*)(A.aln_read + task * (uint64_t)A.aln_stride))[lane] = rd;
+    if (!(A.reserved & 1) && nb > 0) {
+        ((uint32_t*)(A.aln_read + task * (uint64_t)A.aln_stride))[lane] = rd;      // (a partial last dword is padded with zeros: the row has room, aln_stride is a multiple of 16)
         ((uint32_t*)(A.aln_ref + task * (uint64_t)A.aln_stride))[lane] = rf;
     }
     const uint32_t x = rd ^ rf;
@@ -2460,9 +2458,11 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                             __builtin_memcpy(outR + at, &x0, 16); __builtin_memcpy(outR + at + 16, &x1, 16);
                             __builtin_memcpy(outF + at, &y0, 16); __builtin_memcpy(outF + at + 16, &y1, 16);
                         }
-                        // the rest of the row: zeros up to the row's end (c2_emit_gapless4 pads the last dword the same way; the whole row, because a row
-                        // of 250 bytes in a stride of 256 is one and a half cache lines otherwise, and half a line written costs HBM a read as well)
-                        if (q == nq - 1) for (int p_ = L; p_ < (int)A.aln_stride && p_ < L + 16; ++p_) { outR[p_] = 0; outF[p_] = 0; }
+                        if (q == 0 && (L & 3)) {                    // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
+                            uint32_t w = 0, v = 0;
+                            for (int b = 0; b < (L & 3); ++b) { w |= (uint32_t)t.rd[(L & ~3) + b] << (8 * b); v |= (uint32_t)t.f[(L & ~3) + b] << (8 * b); }
+                            __builtin_memcpy(outR + (L & ~3), &w, 4); __builtin_memcpy(outF + (L & ~3), &v, 4);
+                        }
                     }
                     if (q == 0) {
                         c2_aln_record rec;
