@@ -25,7 +25,7 @@ SYMBOLS = [
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
     "c2_fastq_counts", "c2_fastq_free", "c2_fastq_stream_open", "c2_fastq_stream_next", "c2_fastq_stream_arena", "c2_fastq_stream_offsets", "c2_fastq_stream_text_bytes", "c2_fastq_stream_n_reads", "c2_fastq_stream_nonempty_lines", "c2_fastq_stream_nonempty_lines_input", "c2_fastq_stream_counts", "c2_fastq_stream_rc_partners", "c2_fastq_stream_close", "c2_fastq_last_error", "c2_strand_plan", "c2_strand_plan_device", "c2_merge_reverse_complements", "c2_rc_partners", "c2_merge_counts_with_partners", "c2_gather_reads",
-    "c2_score_stage_info", "c2_partition_info", "c2_partition_finished", "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close", "c2_gz_inflate_parallel", "c2_gz_parallel_last",
+    "c2_score_stage_info", "c2_partition_info", "c2_partition_finished", "c2_bgzf_open", "c2_bgzf_n_blocks", "c2_bgzf_text_offsets", "c2_bgzf_inflate", "c2_bgzf_close", "c2_gzseg_open", "c2_gz_inflate_parallel", "c2_gz_parallel_last",
     "c2_consensus_pairs_batch", "c2_consensus_pairs_device", "c2_classify_records_device",
     "c2_fq_count_device", "c2_fq_lines_device", "c2_fq_dedup_device", "c2_fq_gather_device", "c2_fq_rc_partner_device",
     "c2_fq_lines4_device", "c2_fq_pair_lengths_device", "c2_fq_pair_write_device",
@@ -127,6 +127,7 @@ def load():
             lib.c2_bgzf_inflate.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32]
             lib.c2_bgzf_close.restype = None
             lib.c2_bgzf_close.argtypes = [ctypes.c_void_p]
+            lib.c2_gzseg_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
             lib.c2_gz_parallel_last.restype = None
             lib.c2_gz_parallel_last.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
             lib.c2_gz_inflate_parallel.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
@@ -433,6 +434,23 @@ class BgzfFile:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class GzSegFile(BgzfFile):
+    """c2_gzseg_open: ONE ordinary gzip member cut into segments at deflate block starts (c2_gz_parallel.h) -- the same interface as a BGZF
+    file's members (n_blocks, text_offsets, inflate(b0, b1, ...)), so fastq_device inflates it range by range straight into the upload buffers.
+    NativeError "not applicable ..." for anything that is not one clean member of a few megabytes and more."""
+
+    def __init__(self, path, threads=0, chunk_bytes=0):
+        lib = load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        if lib.c2_gzseg_open(os.fsencode(path), int(threads), ctypes.c_uint64(chunk_bytes), ctypes.byref(self._h)) != 0:
+            raise NativeError("c2_gzseg_open: %s" % lib.c2_fastq_last_error().decode())
+        self.n_blocks = int(lib.c2_bgzf_n_blocks(self._h))
+        ptr = lib.c2_bgzf_text_offsets(self._h)
+        self.text_offsets = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint64)), (self.n_blocks + 1,)).copy()
+        self.text_bytes = int(self.text_offsets[-1])
 
 
 class FastqStream:

@@ -1246,6 +1246,13 @@ struct c2_bgzf {
     std::vector<BgzfBlock> blocks;
     std::vector<uint64_t> text_at;                                   // text offset of every block, + the total
     size_t total = 0;
+    // c2_gzseg_open: the "blocks" are the segments of ONE ordinary gzip member (c2_gz_parallel.h's passes A - C are done; c2_bgzf_inflate runs pass D)
+    bool one_member = false;
+    c2gz::Plan plan;
+    std::vector<uint32_t> seg_crc;
+    std::vector<uint8_t> seg_done;
+    std::mutex crc_lock;
+    size_t n_seg_done = 0;
     ~c2_bgzf() { if (mapped) munmap(mapped, mapped_n); }
 };
 extern "C" {
@@ -1269,6 +1276,48 @@ int c2_bgzf_open(const char* path, c2_bgzf** out) {
     *out = H.release();
     return 0;
 }
+// An ordinary one-member .gz as something c2_bgzf_inflate can fill ranges of: the member is cut into segments at deflate block starts found by
+// search, sizes and windows come from a first decode (c2_gz_parallel.h, passes A - C); c2_bgzf_n_blocks / _text_offsets / _inflate / _close then work
+// on the segments as they do on BGZF members.  The member's CRC-32 is checked when the last segment has been inflated (c2_bgzf_inflate fails then,
+// like gzip.py raises at the end of a member).  C2_E_INVALID "not applicable ...": the file routes' serial inflate is the way.
+int c2_gzseg_open(const char* path, int32_t threads, uint64_t chunk_bytes, c2_bgzf** out) {
+    if (!path || !out) { g_fastq_error = "NULL argument"; return C2_E_INVALID; }
+    *out = nullptr;
+    if (const char* e = getenv("C2_GZ_PARALLEL")) if (!strcmp(e, "0")) { g_fastq_error = "c2_gzseg_open: not applicable (C2_GZ_PARALLEL=0)"; return C2_E_INVALID; }
+    std::unique_ptr<c2_bgzf> H(new c2_bgzf);
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); g_fastq_error = std::string("cannot open ") + path; return C2_E_INVALID; }
+    H->mapped_n = (size_t)st.st_size;
+    size_t min_bytes = (size_t)4 << 20;
+    if (const char* e = getenv("C2_GZ_PARALLEL_MIN")) min_bytes = (size_t)strtoull(e, nullptr, 10);
+    if (H->mapped_n < 18 || H->mapped_n < min_bytes) { close(fd); g_fastq_error = "c2_gzseg_open: not applicable (a small file)"; return C2_E_INVALID; }
+    H->mapped = mmap(nullptr, H->mapped_n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (H->mapped == MAP_FAILED) { H->mapped = nullptr; g_fastq_error = std::string("cannot map ") + path; return C2_E_INVALID; }
+    unsigned th = threads > 0 ? (unsigned)threads : usable_cpus();
+    if (th > 64) th = 64;
+    size_t chunk = (size_t)chunk_bytes;
+    if (const char* e = getenv("C2_GZ_PARALLEL_CHUNK")) chunk = (size_t)strtoull(e, nullptr, 10);
+    if (!chunk) {                                                  // segments of a few dozen megabytes of text: several per upload buffer
+        chunk = H->mapped_n / ((size_t)th * 16u);
+        if (chunk < ((size_t)128 << 10)) chunk = (size_t)128 << 10;
+        if (chunk > ((size_t)2 << 20)) chunk = (size_t)2 << 20;
+    }
+    if (!c2gz::plan_single_member((const uint8_t*)H->mapped, H->mapped_n, th, chunk, H->plan, g_gz_stats)) {
+        g_fastq_error = std::string("c2_gzseg_open: not applicable (") + g_gz_stats.why + ")";
+        return C2_E_INVALID;
+    }
+    const size_t S = H->plan.segments();
+    H->one_member = true;
+    H->total = (size_t)H->plan.total();
+    H->blocks.resize(S);
+    for (size_t k = 0; k < S; ++k) H->blocks[k] = BgzfBlock{0, 0, (size_t)H->plan.off[k], 0};
+    H->text_at = H->plan.off;
+    H->seg_crc.assign(S, 0); H->seg_done.assign(S, 0);
+    *out = H.release();
+    return 0;
+}
 uint64_t c2_bgzf_n_blocks(const c2_bgzf* h) { return h ? (uint64_t)h->blocks.size() : 0; }
 const uint64_t* c2_bgzf_text_offsets(const c2_bgzf* h) { return h ? h->text_at.data() : nullptr; }
 
@@ -1281,6 +1330,25 @@ int c2_bgzf_inflate(c2_bgzf* h, uint64_t b0, uint64_t b1, uint8_t* dst, uint64_t
     if (h->text_at[b1] - base > cap) { g_fastq_error = "c2_bgzf_inflate: destination too small"; return C2_E_INVALID; }
     const uint8_t* b = (const uint8_t*)h->mapped;
     const Deflate& L = deflate_lib();
+    if (h->one_member) {                                            // segments of one gzip member: pass D of c2_gz_parallel.h
+        std::atomic<bool> ok(true);
+        unsigned T1 = threads > 0 ? (unsigned)threads : usable_cpus();
+        c2gz::on_threads(T1, (size_t)(b1 - b0), [&](size_t i) {
+            const size_t k = (size_t)b0 + i;
+            uint32_t crc = 0;
+            if (!ok.load(std::memory_order_relaxed)) return;
+            if (!c2gz::inflate_segment(b, h->mapped_n, h->plan, k, dst + (h->text_at[k] - base), crc, L.crc)) { ok = false; return; }
+            std::lock_guard<std::mutex> g(h->crc_lock);
+            h->seg_crc[k] = crc;
+            if (!h->seg_done[k]) { h->seg_done[k] = 1; ++h->n_seg_done; }
+        });
+        if (!ok) { g_fastq_error = "c2_bgzf_inflate: invalid gzip data (the second pass differs from the first)"; return C2_E_INVALID; }
+        if (h->n_seg_done == h->blocks.size() && !c2gz::crc_matches(h->plan, h->seg_crc)) {
+            g_fastq_error = "c2_bgzf_inflate: CRC check failed";   // (gzip.py: BadGzipFile("CRC check failed ...") at the member's end)
+            return C2_E_INVALID;
+        }
+        return 0;
+    }
     const char* route = getenv("C2_FASTQ_GZ");
     const bool fast = L.ok() && !(route && !strcmp(route, "zlib"));
     std::atomic<size_t> next((size_t)b0);

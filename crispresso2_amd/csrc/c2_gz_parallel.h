@@ -505,10 +505,18 @@ inline void on_threads(unsigned threads, size_t items, F&& f) {   // f(item) for
     for (auto& th : pool) th.join();
 }
 
-// One gzip member that is the whole file -> its text.  `room(total)` returns where `total` bytes may be written (or nullptr: no room).
-// false: not applicable / not sure -- nothing may be assumed about the destination; the caller inflates the file its serial way.
-inline bool inflate_single_member(const uint8_t* b, size_t n, unsigned threads, size_t chunk, const std::function<uint8_t*(size_t)>& room,
-                                  size_t& n_text, Stats& st, crc_fn fast_crc = nullptr)
+// What passes A - C leave behind: where every segment starts (bit), where its text goes, and the 32 KiB in front of it.
+struct Plan {
+    std::vector<uint64_t> seg;                                  // S first bits
+    std::vector<uint64_t> off;                                  // S + 1 text offsets (off[S] = the size of the text)
+    std::vector<std::unique_ptr<uint8_t[]>> win;                // per segment (not the first): the 32 KiB of text in front of it
+    uint32_t want_crc = 0;                                      // the member's trailer
+    size_t segments() const { return seg.size(); }
+    uint64_t total() const { return off.empty() ? 0 : off.back(); }
+};
+
+// passes A - C over one gzip member that is the whole file.  false: not applicable / not sure.
+inline bool plan_single_member(const uint8_t* b, size_t n, unsigned threads, size_t chunk, Plan& P, Stats& st)
 {
     st = Stats();
     auto no = [&](const char* why) { st.why = why; st.fell_back = 1; return false; };
@@ -529,7 +537,8 @@ inline bool inflate_single_member(const uint8_t* b, size_t n, unsigned threads, 
         uint64_t f = 0;
         if (find_block(b, n - 8, from, from + scan_bits, *T, f)) start[k] = f;
     });
-    std::vector<uint64_t> seg;
+    std::vector<uint64_t>& seg = P.seg;
+    seg.clear();
     for (size_t k = 0; k < n_cuts; ++k) if (start[k] != ~0ull) seg.push_back(start[k]);
     const size_t S = seg.size();
     st.segments = S; st.blocks_found = S - 1;
@@ -558,11 +567,15 @@ inline bool inflate_single_member(const uint8_t* b, size_t n, unsigned threads, 
     const size_t trailer_at = (size_t)((segs[S - 1].end_bit + 7u) >> 3);
     if (trailer_at + 8 != n) return no("bytes behind the member");
     // C: offsets and windows
-    std::vector<uint64_t> off(S + 1, 0);
+    std::vector<uint64_t>& off = P.off;
+    off.assign(S + 1, 0);
     for (size_t k = 0; k < S; ++k) off[k + 1] = off[k] + segs[k].produced;
     const uint64_t total = off[S];
     if ((uint32_t)total != rd32(b + n - 4)) return no("ISIZE differs");
-    std::vector<std::unique_ptr<uint8_t[]>> win(S);
+    P.want_crc = rd32(b + n - 8);
+    std::vector<std::unique_ptr<uint8_t[]>>& win = P.win;
+    win.clear();
+    win.resize(S);
     for (size_t k = 1; k < S; ++k) {
         win[k].reset(new uint8_t[32768]);
         const uint16_t* t = segs[k - 1].tail.get();
@@ -578,33 +591,61 @@ inline bool inflate_single_member(const uint8_t* b, size_t n, unsigned threads, 
         }
         segs[k - 1].tail.reset();
     }
-    st.t_windows = now() - t0; t0 = now();
-    // D: the text
+    st.t_windows = now() - t0;
+    return true;
+}
+
+// pass D for one segment: its text to dst (off[k + 1] - off[k] bytes), its CRC-32.  false: the second pass differs from the first.
+inline bool inflate_segment(const uint8_t* b, size_t n, const Plan& P, size_t k, uint8_t* dst, uint32_t& crc_out, crc_fn fast_crc = nullptr)
+{
+    const size_t S = P.segments();
+    std::unique_ptr<Tables> T(new Tables);
+    Linear lin;
+    lin.base = lin.out = dst; lin.end = dst + (P.off[k + 1] - P.off[k]);
+    lin.window = P.win[k].get(); lin.have = (size_t)(P.off[k] < 32768u ? P.off[k] : 32768u);
+    lin.crc_upto = lin.base; lin.crc = 0;
+    if (fast_crc) lin.crc_of = fast_crc;
+    Bits br;
+    br.init(b, n - 8, P.seg[k]);
+    const uint64_t stop = k + 1 < S ? P.seg[k + 1] : ~0ull;
+    const int rc = inflate_blocks(br, lin, stop, *T);
+    if (rc != (k + 1 < S ? R_STOP : R_FINAL) || lin.out != lin.end) return false;
+    lin.block_done();
+    crc_out = lin.crc;
+    return true;
+}
+
+// pass E: the segments' CRCs against the member's trailer
+inline bool crc_matches(const Plan& P, const std::vector<uint32_t>& crc)
+{
+    const size_t S = P.segments();
+    uint32_t c = crc[0];
+    for (size_t k = 1; k < S; ++k) c = (uint32_t)crc32_combine(c, crc[k], (z_off_t)(P.off[k + 1] - P.off[k]));
+    return c == P.want_crc;
+}
+
+// One gzip member that is the whole file -> its text.  `room(total)` returns where `total` bytes may be written (or nullptr: no room).
+// false: not applicable / not sure -- nothing may be assumed about the destination; the caller inflates the file its serial way.
+inline bool inflate_single_member(const uint8_t* b, size_t n, unsigned threads, size_t chunk, const std::function<uint8_t*(size_t)>& room,
+                                  size_t& n_text, Stats& st, crc_fn fast_crc = nullptr)
+{
+    Plan P;
+    if (!plan_single_member(b, n, threads, chunk, P, st)) return false;
+    auto no = [&](const char* why) { st.why = why; st.fell_back = 1; return false; };
+    const size_t S = P.segments();
+    const uint64_t total = P.total();
+    double t0 = now();
     uint8_t* text = room((size_t)total);
     if (!text && total) return no("no room for the text");
     std::vector<uint32_t> crc(S, 0);
+    std::atomic<bool> good(true);
     on_threads(threads, S, [&](size_t k) {
         if (!good.load(std::memory_order_relaxed)) return;
-        std::unique_ptr<Tables> T(new Tables);
-        Linear lin;
-        lin.base = lin.out = text + off[k]; lin.end = text + off[k + 1];
-        lin.window = win[k].get(); lin.have = (size_t)(off[k] < 32768u ? off[k] : 32768u);
-        lin.crc_upto = lin.base; lin.crc = 0;
-        if (fast_crc) lin.crc_of = fast_crc;
-        Bits br;
-        br.init(b, n - 8, seg[k]);
-        const uint64_t stop = k + 1 < S ? seg[k + 1] : ~0ull;
-        const int rc = inflate_blocks(br, lin, stop, *T);
-        if (rc != (k + 1 < S ? R_STOP : R_FINAL) || lin.out != lin.end) { good = false; return; }
-        lin.block_done();
-        crc[k] = lin.crc;
+        if (!inflate_segment(b, n, P, k, text + P.off[k], crc[k], fast_crc)) good = false;
     });
     st.t_pass2 = now() - t0;
     if (!good) return no("the second pass differs from the first");
-    // E: the trailer
-    uint32_t c = crc[0];
-    for (size_t k = 1; k < S; ++k) c = (uint32_t)crc32_combine(c, crc[k], (z_off_t)(off[k + 1] - off[k]));
-    if (c != rd32(b + n - 8)) return no("CRC-32 differs");
+    if (!crc_matches(P, crc)) return no("CRC-32 differs");
     n_text = (size_t)total;
     st.bytes_out = total;
     return true;

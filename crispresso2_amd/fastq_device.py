@@ -891,11 +891,18 @@ class IngestSource:
                         bg = _native.BgzfFile(path)
                     except _native.NativeError:
                         bg = None                                      # (some other gzip file: inflated as a whole)
+                gz_route = "device, members inflated into the upload buffers"
+                if bg is None and not any(self.filters):
+                    try:                                               # ONE ordinary gzip member: segments found by search (c2_gz_parallel.h), inflated the same way
+                        bg = _native.GzSegFile(path)
+                        gz_route = "device, one gzip member inflated segment by segment into the upload buffers"
+                    except _native.NativeError:
+                        bg = None                                      # (several members, a small file, ...: inflated as a whole below)
                 if bg is not None:
                     self._held.append(bg)
                     why = size_applicable(bg.text_bytes)
                     if why is None:
-                        self.source, self.route = bg, "device, members inflated into the upload buffers"
+                        self.source, self.route = bg, gz_route
                 else:
                     try:
                         fq = _native.FastqStream(path, *self.filters)    # (inflates / filters: its text is in memory now)

@@ -502,6 +502,13 @@ uint64_t c2_bgzf_n_blocks(const c2_bgzf* h);
 const uint64_t* c2_bgzf_text_offsets(const c2_bgzf* h);
 int c2_bgzf_inflate(c2_bgzf* h, uint64_t b0, uint64_t b1, uint8_t* dst, uint64_t cap, int32_t threads);
 void c2_bgzf_close(c2_bgzf* h);
+/* The same handle over ONE ordinary gzip member (`gzip -6 reads.fastq`: no index): the member is cut into segments at deflate block starts found
+ * by search, a first decode gives every segment's size and the 32 KiB in front of it (c2_gz_parallel.h); c2_bgzf_n_blocks / _text_offsets /
+ * _inflate / _close then treat the segments as they treat BGZF members -- a caller that uploads the text while it is inflated needs no copy of
+ * it in host memory.  The member's CRC-32 is checked when its last segment has been inflated (c2_bgzf_inflate fails then, as gzip.py raises at
+ * the end of a member, CRISPRessoCORE.py:1820-1823).  threads <= 0: the CPUs this process may use; chunk_bytes 0: the library's choice.
+ * C2_E_INVALID "not applicable (...)": several members, trailing bytes, a small file, no block start found -- inflate the file serially. */
+int c2_gzseg_open(const char* path, int32_t threads, uint64_t chunk_bytes, c2_bgzf** out);
 
 /* ONE ordinary gzip member (the whole file: `gzip -6 reads.fastq`, pigz) inflated by `threads` host threads (<= 0: the CPUs this process may
  * use) -- what gzip.open(fastq_filename, 'rt') does on one thread, CRISPResso2/CRISPRessoCORE.py:1820-1823.  The file routes above take this

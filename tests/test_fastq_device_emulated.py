@@ -175,6 +175,56 @@ def test_bgzf_members_inflated_chunk_by_chunk(tmp_path):
         _native.BgzfFile(str(plain))
 
 
+def test_one_gzip_member_inflated_segment_by_segment(tmp_path, monkeypatch):
+    """an ORDINARY one-member .gz as the source (c2_gzseg_open: segments at deflate block starts found by search, sizes and windows from a first
+    decode): inflated range by range into the text buffer through the same c2_bgzf_* entries a BGZF file uses, framed as it arrives.  The
+    member's CRC is checked when its last segment has been inflated; what is not one clean member is declined (the host inflates it as a whole)."""
+    import gzip
+    rng = random.Random(23)
+    text = (records(rng, 12000) + "@cut\nACGTAC").encode()
+    plain = tmp_path / "g.fastq"
+    plain.write_bytes(text)
+    gz = tmp_path / "g.fastq.gz"
+    gz.write_bytes(gzip.compress(text, 6))
+    want, n_reads = O.read_fastq_unique(str(plain))
+    monkeypatch.setenv("C2_GZ_PARALLEL_MIN", "0")
+    monkeypatch.setenv("C2_GZ_PARALLEL_CHUNK", "32768")
+    for chunk in (FD.TILE, 100_000, 1 << 30):
+        with _native.GzSegFile(str(gz), threads=4) as sg, emulated_fq_kernels(chunk):
+            assert sg.text_bytes == len(text) and sg.n_blocks >= 3 and int(sg.text_offsets[0]) == 0
+            whole = np.empty(len(text), dtype=np.uint8)
+            sg.inflate(0, sg.n_blocks, whole.ctypes.data, whole.size, 3)
+            assert whole.tobytes() == text
+            mid = sg.n_blocks // 2                                       # any range, into any place
+            part = np.empty(int(sg.text_offsets[mid + 1] - sg.text_offsets[mid]), dtype=np.uint8)
+            sg.inflate(mid, mid + 1, part.ctypes.data, part.size, 1)
+            assert part.tobytes() == text[int(sg.text_offsets[mid]):int(sg.text_offsets[mid + 1])]
+            out = FD.ingest_file(sg, None, torch.device("cpu"))
+        arena, off = out["d_reads"].numpy(), out["offsets"]
+        reads = [arena[int(off[i]):int(off[i + 1])].tobytes().decode() for i in range(out["n_unique"])]
+        assert reads == list(want.keys()) and out["counts"].tolist() == list(want.values()) and out["n_reads"] == n_reads
+    # IngestSource picks it by itself for a .gz that is no BGZF file
+    with FD.IngestSource(str(gz)) as src:
+        assert isinstance(src.source, _native.GzSegFile) and "one gzip member" in src.route or src.why_not is not None
+    # a wrong CRC shows when the last segment has been inflated
+    bad = bytearray(gz.read_bytes())
+    bad[-8] ^= 1
+    (tmp_path / "bad.fastq.gz").write_bytes(bytes(bad))
+    with _native.GzSegFile(str(tmp_path / "bad.fastq.gz"), threads=4) as sg:
+        buf = np.empty(len(text), dtype=np.uint8)
+        sg.inflate(0, sg.n_blocks - 1, buf.ctypes.data, buf.size, 2)
+        with pytest.raises(_native.NativeError, match="CRC check failed"):
+            sg.inflate(sg.n_blocks - 1, sg.n_blocks, buf.ctypes.data, buf.size, 2)
+    for name, data in (("two.fastq.gz", gzip.compress(text[:9000]) + gzip.compress(text[9000:])), ("plain.fastq", text),
+                       ("padded.fastq.gz", gzip.compress(text) + b"\x00" * 32), ("cut.fastq.gz", gzip.compress(text)[:-20000])):
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(_native.NativeError, match="not applicable|cannot"):
+            _native.GzSegFile(str(tmp_path / name), threads=4)
+    monkeypatch.setenv("C2_GZ_PARALLEL", "0")
+    with pytest.raises(_native.NativeError, match="not applicable"):
+        _native.GzSegFile(str(gz), threads=4)
+
+
 def test_reverse_complement_partners_from_the_table(tmp_path):
     """partner[i] = the unique read that equals reverse_complement(read i): the device's look-up in its own table against the host search
     (c2_rc_partners) -- pairs, palindromes (their own partner), lower case (upper-cased before complementing: the partner is the
