@@ -681,9 +681,10 @@ def _e2e_leg(files, ctx, L, matrix, repeat=2):
     out["plain_equals_bgzf"] = tallies["plain"] == tallies["bgzf"] == tallies["plain_host_parser"] == tallies["bgzf_host_parser"]
     if "gzip" in tallies:
         out["plain_equals_gzip"] = tallies["plain"] == tallies["gzip"]
-        out["gzip"]["note"] = ("an ordinary single-member .gz (one deflate stream, level 6), inflated by all host threads (c2_gz_parallel.h: block starts found by "
-                               "search, every segment decoded twice -- symbols, then bytes -- CRC-32 and ISIZE checked; whatever it declines goes to libdeflate on "
-                               "one thread), then the text is uploaded and framed on the device like the plain file's")
+        out["gzip"]["note"] = ("an ordinary single-member .gz (one deflate stream, level 6): cut into segments at block starts found by search, decoded once for "
+                               "sizes and 32 KiB windows (c2_gz_parallel.h, c2_gzseg_open), then inflated segment by segment by all host threads straight into the "
+                               "pinned upload buffers -- the text never lies in host memory as a whole; CRC-32 and ISIZE checked at the last segment; framed on "
+                               "the device like the plain file's.  Whatever is not one clean member goes to libdeflate on one thread")
         out["gzip"]["inflate"] = gz_inflate
     out["tallies"] = dict(zip(("N_TOT_READS", "N_TOTAL", "counts_total", "modified", "with_insertion", "with_deletion", "with_substitution"),
                               tallies["plain"]))
