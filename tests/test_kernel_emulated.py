@@ -1014,3 +1014,48 @@ def test_main_diagonal_shortcut_on_random_low_complexity_references(mats, seed):
             status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, go, ge)
             assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (seed, trial, period, defects, go, ge, k, rd)
             check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+
+
+@pytest.mark.parametrize("scheme", [(1, -1, -1, -1, -2, -1, 0), (1, -1, 0, 0, -3, -1, 0), (2, -3, -1, -1, -5, -2, 1), (5, -4, -2, -1, -8, -1, 0),
+                                    (3, -2, -2, -1, -4, -4, 2), (7, -8, -3, 0, -8, -3, 2), (1, -2, -1, 1, -2, -2, 1)])
+def test_main_diagonal_shortcut_under_small_scores_where_ties_are_near(scheme):
+    """make_matrix scorings with small numbers (match 1, mismatch -1, gap_open -2 ...): the main diagonal's lead over the next best path is a point
+    or two, ties are common, and the certificate's strict inequalities decide.  Low-complexity references, reads with 0 .. 2 changed bases, moved
+    defects.  Whatever the partition finishes itself or hands on, every alignment is the oracle's."""
+    from crispresso2_amd import CRISPResso2Align as A
+    match, mismatch, n_mis, n_match, go, ge, cut_incentive = scheme
+    m = A.make_matrix(match_score=match, mismatch_score=mismatch, n_mismatch_score=n_mis, n_match_score=n_match)
+    rng = np.random.default_rng(abs(hash(scheme)) % 100000)
+    finished = 0
+    for trial in range(6):
+        L = int(rng.integers(200, 257))
+        period = int(rng.integers(1, 5)) if trial % 2 else 0
+        if period:
+            unit = "".join(rng.choice(list("ACGT"), period))
+            ref = list((unit * L)[:L])
+            for q in rng.integers(5, L - 5, int(rng.integers(0, 3))):
+                ref[int(q)] = rng.choice([c for c in "ACGT" if c != ref[int(q)]])
+        else:
+            ref = list(rng.choice(list("ACGT"), L))
+        amp = "".join(ref)
+        g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = cut_incentive
+        inc = [L // 2, L // 2 + 1]
+        reads = [amp] * 2
+        for _ in range(90):
+            t = list(amp)
+            for _ in range(int(rng.integers(1, 3))):
+                q = int(rng.integers(0, L))
+                t[q] = rng.choice(list("ACGTN"))
+            reads.append("".join(t))
+        for q in range(8, L - 8, 37):                                # a base moved by one or two (two differing bases that a shifted diagonal explains)
+            for d in (-2, -1, 1, 2):
+                t = list(amp); t[q], t[q + d] = amp[q + d], amp[q]
+                reads.append("".join(t))
+        st = {}
+        res, rec = E.align_batch(reads, [amp], [g], [inc], m, go, ge, band_lanes=-87, stats=st)
+        finished += st["exact_copies"]
+        for k, rd in enumerate(reads):
+            status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, go, ge)
+            assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (scheme, trial, period, k, rd)
+            check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+    print("finished by the partition:", finished)
