@@ -99,3 +99,21 @@ def adversarial_case(rng, n, L=120):
             s[q] = "ACGT"[int(rng.integers(0, 4))]
         reads.append("".join(s) if s else "A"); rids.append(k)
     return refs, gis, incs, reads, rids
+
+
+def rc_partner_witness(reads):
+    """partner[i] = the index of the unique read that equals reverse_complement(reads[i]), -1 without one -- written out here, independently of
+    the product's search: the reference's table and order of operations (CRISPRessoShared.py:399-403: `seq.upper()` reversed, every character
+    through nt_complement; a character outside it is a KeyError there: no partner here)"""
+    complement = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "_": "_", "-": "-"}
+    where = {}
+    for i, s in enumerate(reads):
+        where.setdefault(s, i)
+    out = np.full(len(reads), -1, dtype=np.int64)
+    for i, s in enumerate(reads):
+        try:
+            rc = "".join(complement[c] for c in s.upper()[::-1])
+        except KeyError:
+            continue
+        out[i] = where.get(rc, -1)
+    return out

@@ -242,6 +242,8 @@ def test_reverse_complement_partners_from_the_table(tmp_path):
     want = _native.rc_partners(arena, out["offsets"])
     assert np.array_equal(out["rc_partner"], want)
     assert (want >= 0).sum() >= 160 and (want == np.arange(len(want))).sum() >= 3
+    from helpers import rc_partner_witness                             # ... and both against the definition written out in the test helpers
+    assert np.array_equal(np.asarray(out["rc_partner"], dtype=np.int64), rc_partner_witness(reads))
 
 
 def fuzz_text(rng, n_lines, alphabet="ACGTN acgt\t\x0b\x0c\x1c+@I#", max_len=60, blank=0.15):

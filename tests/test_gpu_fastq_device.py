@@ -98,6 +98,10 @@ def test_reverse_complement_partners_from_the_table(tmp_path, monkeypatch):
     want = _native.rc_partners(arena, out["offsets"])
     assert np.array_equal(out["rc_partner"], want)
     assert (want >= 0).sum() >= 24_000
+    from helpers import rc_partner_witness                             # ... and both against the definition written out in the test helpers
+    off = np.asarray(out["offsets"], dtype=np.int64)
+    reads = [arena[off[i]:off[i + 1]].tobytes().decode() for i in range(len(off) - 1)]
+    assert np.array_equal(np.asarray(out["rc_partner"], dtype=np.int64), rc_partner_witness(reads))
 
 
 def test_whole_run_is_the_same_on_either_route(tmp_path, monkeypatch):
