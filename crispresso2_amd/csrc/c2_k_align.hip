@@ -2255,10 +2255,11 @@ __device__ __forceinline__ int c2_part_probe(const c2_partition_args& P, const c
     return cls;
 }
 
-#ifndef C2_PART_WAVES
-#define C2_PART_WAVES 1                            // wavefronts per SIMD the partition is compiled for at least (its register budget)
-#endif
+#ifdef C2_PART_WAVES                               // (A/B builds: at least that many wavefronts per SIMD, i.e. a register budget -- profiles/r05/README.md)
 __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(c2_partition_args P)
+#else
+__global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_args P)
+#endif
 {
     const c2_align_args& A = P.A;
     uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] the task's class, 7: no such task, 8: still to be probed
