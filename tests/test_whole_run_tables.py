@@ -971,3 +971,47 @@ def test_count_transfer_on_the_device_equals_the_sequential_loop(tmp_path, monke
     if not lower_case:
         assert out[0][1]["Palindrome"]["counts_total"] == 6          # the palindrome's three copies, doubled (the reference's own arithmetic)
     assert sum(1 for c_ in out[0][3] if c_ == 0) >= 8                 # the partners that gave their copies away
+
+
+def test_one_gzip_member_through_the_segment_route_gives_the_plain_files_result(tmp_path, monkeypatch):
+    """pipeline.quantify_fastq over an ordinary one-member .gz whose segments are inflated straight into the (emulated) device text
+    (c2_gzseg_open; thresholds lowered so that a file of a few hundred KB is cut into several segments) against the same text as a plain file and
+    against the same .gz with the route switched off (the host inflates the whole member first): statistics and count tensors agree."""
+    import gzip
+    from pipeline_on_emulator import emulated_device
+    from test_fastq_device_emulated import emulated_fq_kernels
+    from crispresso2_amd import pipeline, refs as RF, synth
+    monkeypatch.setenv("C2_FQ_INGEST", "device")
+    monkeypatch.setattr(pipeline, "STREAM_MIN_BATCH", 100)
+    L = 100
+    amp, g_, inc = synth.amplicon_setup(L)
+    uniq = [r.tobytes().decode() for r in synth.make_reads(L, 300)]
+    rng = np.random.default_rng(5)
+    order = rng.integers(0, len(uniq), 16000)
+    text = "".join("@read_%07d_%d\n%s\n+\n%s\n" % (k, int(rng.integers(0, 1 << 30)), uniq[int(i)], "".join(chr(33 + int(q)) for q in rng.integers(20, 41, L)))
+                   for k, i in enumerate(order))
+    plain = tmp_path / "reads.fastq"
+    plain.write_text(text)
+    gz = tmp_path / "reads.fastq.gz"
+    gz.write_bytes(gzip.compress(text.encode(), 6))
+    ref = RF.make_ref("Reference", amp, [L // 2], inc, min_aln_score=60)
+    results = {}
+    with emulated_device(), emulated_fq_kernels():
+        for name, path, env in (("plain", plain, {}), ("segments", gz, {"C2_GZ_PARALLEL_MIN": "0", "C2_GZ_PARALLEL_CHUNK": "32768"}),
+                                ("whole", gz, {"C2_GZ_PARALLEL": "0"})):
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            res = pipeline.quantify_fastq(str(path), {"Reference": ref}, ["Reference"], matrices()["EDNAFULL"], _pipeline_args())
+            for k_ in env:
+                monkeypatch.delenv(k_)
+            results[name] = res
+    assert results["segments"].ingest_route == "device, one gzip member inflated segment by segment into the upload buffers"
+    assert results["whole"].ingest_route == "device, text from host memory"
+    base = results["plain"]
+    for name in ("segments", "whole"):
+        other = results[name]
+        assert other.stats == base.stats, name
+        for kk, vv in base.per_ref["Reference"].items():
+            ww = other.per_ref["Reference"][kk]
+            assert np.array_equal(vv, ww) if isinstance(vv, np.ndarray) else vv == ww, (name, kk)
+    assert base.stats["N_TOT_READS"] == 16000
