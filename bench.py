@@ -889,7 +889,9 @@ def main():
         if args.kernel == "auto" and left_ and not os.environ.get("C2_NO_PACKED_FILL"):
             # what the int16 kernels THEMSELVES finished: a tier's tasks minus those it could not pair (they run its 32-bit twin) minus those it hands on
             tier_in = [n_tasks] + list(left_[:-1])
-            packed_share = float(sum(tier_in[t] - unpaired_[t] - left_[t] for t in range(len(left_)))) / float(n_tasks)
+            # (... minus the main-diagonal reads the partition finished without any fill: config.finished_by_partition)
+            by_part_ = (part_info or {}).get("finished_by_partition", 0) if (part_info and part_info.get("ran")) else 0
+            packed_share = float(sum(tier_in[t] - unpaired_[t] - left_[t] for t in range(len(left_))) - by_part_) / float(n_tasks)
     except Exception:
         packed_share = None
 
