@@ -991,7 +991,9 @@ def main():
                                    "to the first band tier; `partition`: tasks per class of c2_align_partition_kernel (score-only launch, 14-diagonal launch "
                                    "[opt-in], first / second / third band tier: by the diagonal the middle of the read lies on, a task goes straight to the "
                                    "tier whose band holds its path), so tasks_left_after_each_banded_launch[t] is the length of the list the launch behind "
-                                   "tier t reads: what tier t left plus what the partition put there"}
+                                   "tier t reads: what tier t left plus what the partition put there.  Class-0 reads on the amplicon's main diagonal with at most two "
+                                   "differing bases never reach this launch: the partition writes their rows and records itself where the scoring proves the diagonal "
+                                   "(config.finished_by_partition; c2_main_diagonal_certificate)"}
     # algorithmic bytes of the dominant kernel's launch: the reads and offsets of its tasks in; strings + record out for the tasks it finishes
     # (with the partition: the first tier sees its own class and what the launches in front could not finish; the list it leaves also holds the
     #  tasks the partition sent straight to later tiers)
