@@ -3,7 +3,7 @@
 #   tools/gpu_session.sh <round, e.g. r04> [quick]
 # writes gpurun_out/<round>final/: all GPU tests; the driver's bench command; rocprofv3 kernel trace + PMC passes (tools/profile_round.sh);
 # FASTQ -> all result tables (tools/e2e_tables.py); paired FASTQ rate; two gloo ranks sharing the GPU with the sharded FASTQ leg; the
-# unchanged caller's call rate.  `quick`: tests + bench only.
+# unchanged caller's call rate; the end-to-end .gz leg alone.  `quick`: tests + bench only.
 set -u
 ROUND=${1:-r05}
 QUICK=${2:-}
@@ -48,3 +48,4 @@ except Exception as ex:
 PY
 timeout 600 python tools/shim_call_rate.py --procs 16 > "$OUT/shim_call_rate_20k.json" 2>/dev/null; tail -1 "$OUT/shim_call_rate_20k.json" | cut -c1-1500
 ( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" ) > "$OUT/smoke.txt" 2>&1; tail -1 "$OUT/smoke.txt"
+( timeout 300 python tools/gz_leg.py --reads 8000000 ) > "$OUT/gz_leg_8M.json" 2> "$OUT/gz_leg.err"; tail -c 600 "$OUT/gz_leg_8M.json"
