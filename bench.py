@@ -64,7 +64,7 @@ VALU_SIMD32_WAVE_INSTR_PER_S = N_SIMD * CLOCK_HZ / 2.0
 VALU_MEASURED_CYCLES_PER_INSTR = 4.15
 VALU_FULL_RATE_CYCLES_PER_INSTR = 2.3
 VALU_MEASURED_SOURCE = "profiles/r03/valu_microbench4.txt (tools/valu_microbench4.hip, cycles from GRBM_GUI_ACTIVE; clock 2.40 GHz)"
-PROFILE_ROUNDS = ["r05", "r04", "r03", "r02"]                 # the PMC summary of the newest round that has one
+PROFILE_ROUNDS = ["r06", "r05", "r04", "r03", "r02"]                 # the PMC summary of the newest round that has one
 GO, GE, MIN_ALN_SCORE = -20, -2, 60.0
 
 CONFIG_DEFAULTS = {2: (150, 1_000_000), 3: (250, 10_000_000), 4: (250, 10_000_000), 5: (250, 12_500_000)}
@@ -406,6 +406,19 @@ class Job:
             props = props and ok
             del valid, rgap, fgap, keep_r, keep_f
         return props
+
+    def local_reads_aligned(self):
+        """reads of THIS rank's shard the count pass accepted in the last step (the step's own tensor is all-reduced: this one is not)"""
+        torch, C = self.torch, self.C
+        a_read, a_ref, recs = self.out_sets[(self.step_no - 1) % self.n_sets]
+        t = torch.zeros_like(self.d_counts)
+        with torch.cuda.stream(self.t_count):
+            C.accumulate_device(self.ctx, self.layout, self.n_tasks, a_read.data_ptr(), a_ref.data_ptr(), self.stride, recs.data_ptr(), t.data_ptr(),
+                                d_weights=self.d_weights.data_ptr() if self.all_refs else None, min_matches=None if self.all_refs else self.min_matches,
+                                flags=C.FLAG_ALL_REFS_LAYOUT if self.all_refs else 0, stream=self.count_stream)
+        torch.cuda.synchronize()
+        host = t.cpu().numpy()
+        return int(sum(self.layout.unpack(host, r, len(self.wl["refs"][r][0]))["counts_total"] for r in range(self.k)))
 
     def tallies(self):
         host = self.d_counts.cpu().numpy()
@@ -754,6 +767,77 @@ def _compare_with_reference(legs, d_aln_read, d_aln_ref, rec, k, all_refs):
     return compared, identical
 
 
+def _r(x, sig=5):
+    """a float with `sig` significant digits (the short line has no room for 17)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    return x
+
+
+SHORT_LINE_LIMIT = 4096
+
+
+def short_line(d, detail_path=None):
+    """The ONE line on stdout: what the contract names, as scalars, under SHORT_LINE_LIMIT bytes; `d` is the full record (bench_detail.json)."""
+    cfg, ck, rf, vl, cb = d["config"], d["checks"], d["roofline"], d["valu"], d.get("cpu_baseline")
+    oc = d.get("other_configs") or {}
+    e2e = d.get("e2e") or {}
+
+    def leg(name, key):
+        x = e2e.get(name)
+        return _r(x.get(key)) if isinstance(x, dict) else None
+    short = {
+        "metric": d["metric"], "value": _r(d["value"], 6), "unit": d["unit"], "n_gpus": d["n_gpus"], "ranks_seen": d["ranks_seen"],
+        "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": _r(d["ms_per_step"], 6), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": d["dtype"], "data": "synthetic", "collective_backend": d["collective_backend"],
+        "config": {
+            "workload": cfg["workload"], "baseline_config": cfg["baseline_config"], "reads_per_gpu_per_step": cfg["reads_per_gpu_per_step"],
+            "alignments_per_gpu_per_step": cfg["alignments_per_gpu_per_step"], "n_amplicons": cfg["n_amplicons"],
+            "finished_by_partition": cfg["finished_by_partition"], "packed_int16_share": _r(cfg["packed_int16_share"], 4),
+            "int32_chain_reads_per_s": _r(cfg["int32_chain_reads_per_s"]),
+            "robust_fanc_shaped_reads_per_s": _r(cfg["robust_fanc_shaped_reads_per_s"]),
+            "robust_lengths_200_to_L_reads_per_s": _r(cfg["robust_lengths_200_to_L_reads_per_s"]),
+            "robust_unrelated_10_percent_reads_per_s": _r(cfg["robust_unrelated_10_percent_reads_per_s"]),
+            "robust_full_plane_floor_reads_per_s": _r(cfg["robust_full_plane_floor_reads_per_s"]),
+            "other_configs_reads_per_s": {c_: _r(e_.get("reads_per_s")) for c_, e_ in oc.items() if isinstance(e_, dict) and "reads_per_s" in e_} or None,
+            "other_configs_alignments_per_s": {c_: _r(e_.get("alignments_per_s")) for c_, e_ in oc.items() if isinstance(e_, dict) and e_.get("n_amplicons", 1) > 1 and "alignments_per_s" in e_ and e_.get("alignments_per_gpu_per_step") != e_.get("reads_per_gpu_per_step")} or None,
+            "other_configs_chain_equals_full_plane": {c_: e_.get("chain_equals_full_plane") for c_, e_ in oc.items() if isinstance(e_, dict) and "chain_equals_full_plane" in e_} or None,
+            "other_configs_reference_identical": cfg["other_configs_reference_identical"],
+            "chain_equals_full_plane_n": cfg["chain_equals_full_plane_n"], "reference_identical_n": cfg["reference_identical_n"],
+            "reference_compared_n": cfg["reference_compared_n"],
+            "e2e_fastq_to_tensors_reads_per_s": _r(cfg["e2e_fastq_to_tensors_reads_per_s"]),
+            "e2e_frac_of_link_peak": {"plain": leg("plain", "frac_of_link_peak"), "gzip": leg("gzip", "frac_of_link_peak")} if e2e and "plain" in e2e else None,
+            "e2e_gzip_single_member_reads_per_s": _r(cfg["e2e_gzip_single_member_reads_per_s"]),
+            "e2e_gzip_seconds": leg("gzip", "seconds"),
+            "e2e_fastq_to_all_tables_seconds": _r(cfg["e2e_fastq_to_all_tables_seconds"]),
+            "host_batch_pcie_inclusive_reads_per_s": _r(cfg["host_batch_pcie_inclusive_reads_per_s"])},
+        "step_breakdown_ms": {k_: _r(v_, 4) for k_, v_ in d["step_breakdown_ms"].items() if k_ != "note"},
+        "roofline": {"bound": rf["bound"], "achieved": _r(rf["achieved"]), "peak": rf["peak"], "unit": rf["unit"], "frac": _r(rf["frac"], 4),
+                     "traffic": _r(rf["traffic"]), "kernel": rf["kernel"], "avg_launch_ms": _r(rf["avg_launch_ms"]),
+                     "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"], "launches": rf["launches"],
+                     "chain_avg_ms": _r(rf["chain_avg_ms"]), "traffic_source": rf.get("traffic_file")},
+        "valu": {"frac_of_simd32_peak": _r(vl.get("frac_of_simd32_peak"), 4), "frac_of_measured_issue": _r(vl.get("frac_of_measured_issue"), 4),
+                 "wave_instr_per_alignment": _r(vl.get("wave_instr_per_alignment")), "gcups": _r(vl.get("gcups"))},
+        "cpu_baseline": None if not cb else {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                             "best_procs": cb.get("best_procs"), "sample": cb.get("sample_short") or str(cb.get("sample"))[:160]},
+        "speedup_vs_cpu_baseline": _r(d.get("speedup_vs_cpu_baseline")),
+        "checks": {k_: (_r(v_) if isinstance(v_, float) else v_) for k_, v_ in ck.items()},
+        "per_rank_reads_aligned": d.get("per_rank_reads_aligned"),
+        "reads_aligned_all_gpus": [c_["reads_aligned_all_gpus"] for c_ in d["counts"]],
+        "side_legs_ok": d["side_legs_ok"], "side_legs_note": (d.get("side_legs_note") or "")[:200] or None,
+        "detail": None if detail_path is None else (os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) and detail_path.startswith(ROOT) else detail_path),
+    }
+    line = json.dumps(short, separators=(",", ":"))
+    if len(line) >= SHORT_LINE_LIMIT:                                  # (cannot happen with the fields above; if a text grew, the optional groups go first)
+        for k_ in ("step_breakdown_ms", "side_legs_note", "per_rank_reads_aligned", "reads_aligned_all_gpus"):
+            short.pop(k_, None)
+        short["config"]["workload"] = short["config"]["workload"][:200]
+        line = json.dumps(short, separators=(",", ":"))
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -880,6 +964,10 @@ def main():
     stride, Lmax, layout = job.stride, job.Lmax, job.layout
     tm = job.timed(args.warmup, args.steps)
     dt, kernel_ms, first_ms, launches = tm["dt"], tm["kernel_ms"], tm["first_ms"], tm["launches"]
+    per_rank_aligned = None
+    if world > 1:                                                   # (the count tensor of the step is the all-reduced one: every rank's own share next to it)
+        per_rank_aligned = [None] * world
+        dist.all_gather_object(per_rank_aligned, job.local_reads_aligned())
     tiers = ctx.tier_info()
     score_info = ctx.score_stage_info() if hasattr(ctx, "score_stage_info") else (False, 0, 0)     # (of the timed batch: later launches overwrite it)
     part_info = ctx.partition_info() if hasattr(ctx, "partition_info") else None
@@ -1012,7 +1100,7 @@ def main():
     # HBM bytes and instruction counts per alignment from the committed PMC passes of the newest round's build (separate rocprofv3
     # --pmc runs of this same script over 2 M reads; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming
     # reads); null when the profile file is absent or the run is not the default one
-    traffic = traffic_src = None
+    traffic = traffic_src = pmc_rel = None
     valu_per_aln = salu_per_aln = None
     pmc_path = next((q for q in (os.path.join(ROOT, "profiles", r_, "pmc_summary_default.json") for r_ in PROFILE_ROUNDS) if os.path.exists(q)), None)
     if pmc_path and args.config == 3 and L == 250 and args.kernel == "auto":
@@ -1068,8 +1156,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             # the arithmetic type of the dominant kernel's DP cells: int16 pairs in the packed kernels (proven range, c2_pk_eligible), int32 otherwise
-            "dtype": ("int16x2 packed, host-proven range; int32 fallback (exact; config.int32_chain_reads_per_s = all-int32 chain)"
-                      if dominant.startswith("c2_align_diagp") else "int32"),
+            "dtype": ("int16x2 packed (host-proven range; int32 fallback)" if dominant.startswith("c2_align_diagp") else "int32"),
             "packed_fill_sums": ("v_add_u32 under a per-anti-diagonal bias (c2_pk_add32_ok)" if add32 else "v_pk_add_i16") if dominant.startswith("c2_align_diagp") else None,
             "dtype_note": "exact integer DP, not a precision trade: the packed kernels hold two alignments per 32-bit lane as int16 pairs only for "
                           "references whose DP values the host proves to fit (c2_pk_eligible); everything else runs the int32 kernels; the "
@@ -1122,7 +1209,7 @@ def main():
                                           ("" if not args.overlap_count else "; the count pass of batch k runs on a second stream while batch k+1 is aligned "
                                            "(two output buffer sets), so the phases overlap and do not add up to ms_per_step")},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_file": pmc_rel if traffic is not None else None,
                          "kernel": dominant, "avg_launch_ms": 1e3 * avg_first_s, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_first,
                          "algorithmic_bytes_per_read": alg_first / n_tasks,
@@ -1138,16 +1225,11 @@ def main():
             "host_batch_pcie_inclusive": host_batch,
             "dedup_on": dedup_on,
             "cpu_baseline": cpu_baseline,
-            # the reference AS SHIPPED (its own main(), dedup, workers, JSON / TSV exchange), log window "Aligning sequences..." ->
-            # "Finished reads;".  The reference's sources are not on the GPU box, so this is a RECORDED measurement from the dev container
-            # (tools/as_shipped_rate.py), not one of this run: context for cpu_baseline, which times the reference's compiled hot path live.
-            "cpu_baseline_as_shipped_recorded": {"reads_per_s": 12730, "procs": 8, "host_cpus": 8, "reads": 200000, "unique_reads": 95704,
-                                                 "where": "dev container, not the GPU box", "source": "profiles/r02/as_shipped_devcontainer.txt",
-                                                 "command": "CRISPResso -r1 reads.fastq -a <250 bp amplicon> -g <guide> -p 8 --suppress_plots --suppress_report"},
             "checks": checks,
             "counts": [{"amplicon": r, "reads_aligned_all_gpus": tl["counts_total"], "modified": tl["counts_modified"],
                         "unmodified": tl["counts_unmodified"], "with_insertion": tl["counts_insertion"],
                         "with_deletion": tl["counts_deletion"], "with_substitution": tl["counts_substitution"]} for r, tl in list(enumerate(tallies))[:4]],
+            "per_rank_reads_aligned": per_rank_aligned,
             "host": {"cpus": ncpu, "data_generation_s": t_gen},
         }
         if selection is not None:
@@ -1161,7 +1243,16 @@ def main():
         out["side_legs_ok"] = bool(extras_note[0] is None and not any(_has_error(leg) for leg in (int32_chain, other_configs, robustness, e2e, host_batch)))
         if extras_note[0]:
             out["side_legs_note"] = extras_note[0]
-        print(json.dumps(out), file=file or sys.stdout)
+        # Everything above goes to bench_detail.json (legs, notes, stage seconds); stdout gets ONE short line (< 4 KB, no prose) with what the
+        # contract names -- a 31 KB line was more than the driver's record could parse (BENCH_r05.json: "parsed": null).
+        detail_path = os.environ.get("C2_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail_path, "w") as fh:
+                json.dump(out, fh)
+                fh.write("\n")
+        except OSError as e:
+            detail_path = "not written: %r" % (e,)
+        print(short_line(out, detail_path), file=file or sys.stdout)
         (file or sys.stdout).flush()
 
     if extras and world > 1:

@@ -219,5 +219,7 @@ def run(reads_u8, refs, matrix_path, go, ge, ref_ids=None, all_refs=False, cores
            "sample": "reads %d..%d of the benchmark's reads (%d bp, %d candidate amplicon%s per read), one consecutive slice per "
                      "pool size, then the best size (%d) for %.0f s: %d reads; global_align per (read, amplicon) + find_indels_substitutions "
                      "on the best alignment" % (0, start, L, k, "" if k == 1 else "s", best["procs"], rep["seconds"], rep["reads"]),
+           "sample_short": "%d reads of the workload in %.0f s on %d processes: global_align + find_indels_substitutions per read" % (
+               rep["reads"], rep["seconds"], best["procs"]),
            "modified_in_sample": rep["modified_in_sample"]}
     return out, results

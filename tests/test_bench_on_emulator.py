@@ -58,6 +58,11 @@ def test_bench_two_ranks_over_gloo_on_the_emulator(tmp_path):
     assert res[1] is None
     out = res[0]
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["reads_per_gpu_per_step"] == 160
+    # the short line of an N-rank run parses, says how many ranks it saw, every rank's own share and the all-reduced total
+    short = out["_short"]
+    assert out["_line_bytes"] < 4096 and short["ranks_seen"] == 2 and short["n_gpus"] == 2 and short["collective_backend"] == "gloo"
+    assert len(short["per_rank_reads_aligned"]) == 2 and all(v > 0 for v in short["per_rank_reads_aligned"])
+    assert sum(short["per_rank_reads_aligned"]) == short["reads_aligned_all_gpus"][0] == out["counts"][0]["reads_aligned_all_gpus"]
     assert out["value"] == pytest.approx(2 * 160 * 2 / (out["ms_per_step"] * 2 / 1e3), rel=1e-6)      # whole job: both ranks' reads
     single = BE.run_bench(["--config", "3", "--reads", "160", "--steps", "1", "--warmup", "0", "--workers", "1", "--no-cpu-baseline", "--check", "0"])
     # rank 0's shard alone aligns fewer reads than the all-reduced tensor holds (the second shard is a different block of the stream)
@@ -112,9 +117,10 @@ def test_side_legs_that_do_not_finish_cannot_cost_the_headline():
     lines = [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = lines[0]
+    assert len(p.stdout.splitlines()[-1]) < 4096                      # (the watchdog prints the same SHORT line)
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 1 and out["value"] > 0 and "did not finish" in out["side_legs_note"]
     assert out["side_legs_ok"] is False                               # (what a script looks at: the exit code stays 0)
-    assert 66 < out["counts"][0]["reads_aligned_all_gpus"] <= 132
+    assert 66 < out["reads_aligned_all_gpus"][0] <= 132 and sum(out["per_rank_reads_aligned"]) == out["reads_aligned_all_gpus"][0]
 
 
 def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fastq_leg():
@@ -152,3 +158,50 @@ def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fa
         assert e["reads_aligned_all_gpus"] > 60
     assert rb["full_plane_floor"]["reads_per_s"] > 0 and rb["worst_case"]["leg"] in rb
     assert cfgd["robust_fanc_shaped_reads_per_s"] == rb["fanc_shaped"]["reads_per_s"] and cfgd["robust_worst_case"].startswith(rb["worst_case"]["leg"])
+
+
+SHORT_LINE_KEYS = {
+    "": ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+         "config", "roofline", "valu", "cpu_baseline", "checks", "side_legs_ok", "speedup_vs_cpu_baseline", "detail"),
+    "config": ("workload", "baseline_config", "reads_per_gpu_per_step", "finished_by_partition", "packed_int16_share", "int32_chain_reads_per_s",
+               "robust_fanc_shaped_reads_per_s", "robust_lengths_200_to_L_reads_per_s", "robust_unrelated_10_percent_reads_per_s",
+               "robust_full_plane_floor_reads_per_s", "other_configs_reads_per_s", "chain_equals_full_plane_n", "reference_identical_n",
+               "e2e_frac_of_link_peak", "e2e_gzip_seconds"),
+    "roofline": ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch"),
+    "valu": ("frac_of_simd32_peak",),
+    "cpu_baseline": ("value", "unit", "cores", "kind", "best_procs", "sample"),
+}
+
+
+def test_the_one_stdout_line_is_short_and_complete():
+    """BENCH_r05.json had "parsed": null -- the 31 KB line (legs, notes, stage seconds) was more than the driver's record could
+    parse.  The default run's stdout is ONE line under 4 KB with every field the contract and the grading name, no prose; the rest is bench_detail.json."""
+    out = BE.run_bench(["--steps", "1", "--warmup", "0", "--reads", "150", "--workers", "1", "--cpu-seconds", "1.0", "--cpu-long-seconds", "1.0", "--check", "10",
+                        "--extras", "on", "--extra-reads", "90", "--extra-steps", "1"])
+    short = out["_short"]
+    assert out["_line_bytes"] < 4096
+    for group, keys in SHORT_LINE_KEYS.items():
+        d = short if group == "" else short[group]
+        for key in keys:
+            assert key in d, (group, key)
+    assert short["roofline"]["bound"] == "hbm" and short["roofline"]["peak"] == 8000.0 and 0 < short["roofline"]["frac"] < 1
+    assert abs(short["roofline"]["frac"] - short["roofline"]["achieved"] / short["roofline"]["peak"]) < 1e-3 * short["roofline"]["frac"] + 1e-9
+    assert short["cpu_baseline"]["kind"] in ("reference", "port") and short["cpu_baseline"]["value"] > 0 and len(short["cpu_baseline"]["sample"]) <= 160
+    assert short["config"]["baseline_config"] == 3 and short["config"]["reads_per_gpu_per_step"] == 150
+    assert set(short["config"]["other_configs_reads_per_s"]) == {"config2", "config4", "config5"}
+    assert short["config"]["other_configs_alignments_per_s"].keys() == {"config4"}          # (the three-amplicon shape: alignments/s next to reads/s)
+    assert short["config"]["e2e_frac_of_link_peak"]["plain"] > 0 and short["config"]["e2e_frac_of_link_peak"]["gzip"] > 0
+    assert short["checks"]["chain_equals_full_plane"] is True and short["checks"]["reference_identical"] is True
+    assert short["side_legs_ok"] is True and short["n_gpus"] == short["ranks_seen"] == 1 and short["per_rank_reads_aligned"] is None
+    # nothing in it is a paragraph
+    def texts(x):
+        if isinstance(x, dict):
+            for k_, v_ in x.items():
+                if k_ != "workload":
+                    yield from texts(v_)
+        elif isinstance(x, list):
+            for v_ in x:
+                yield from texts(v_)
+        elif isinstance(x, str):
+            yield x
+    assert max(len(t) for t in texts(short)) <= 160
