@@ -55,3 +55,40 @@ def test_paired_read_gpu_tests_on_the_emulator(mats, tmp_path):
     with emulated_device():
         G.test_paired_consensus_and_variants_vs_reference_functions(mats, EmulatedContext())
         G.test_paired_fastq_files_equal_the_reference_run(mats, EmulatedContext(), tmp_path)
+
+
+def test_main_diagonal_gpu_twins_on_the_emulator(mats, monkeypatch):
+    """tests/test_gpu_main_diagonal.py's own plumbing (the stand-in for the emulator's launch, its counters, the soak's generator and comparisons) with the
+    product's launch replaced by the emulator's: what runs on the MI355X at round end ran here first, at a reduced size."""
+    import emu_driver as E
+    import test_gpu_main_diagonal as G
+    real = E.align_batch
+
+    def emulated_batch(ctx, reads, refs, gap_incentives, includes, matrix, gap_open, gap_extend):
+        st = {}
+        res, rec = real(reads, refs, gap_incentives, includes, matrix, gap_open, gap_extend, band_lanes=-87, stats=st)
+        import os
+        return st["raw"][0], st["raw"][1], rec, {"finished_by_partition": st["exact_copies"], "classes": st["classes"]}
+    monkeypatch.setattr(G, "device_batch", emulated_batch)
+    monkeypatch.setattr(G, "SOAK_TRIALS", 8)
+    monkeypatch.setattr(G, "SOAK_READS", 250)
+    G.test_gpu_main_diagonal_soak(mats, None, monkeypatch, 0)
+    seen = {}
+    for kind in ("homopolymer", "marker_in_homopolymer", "dinucleotide", "period3", "period5", "half_repeat", "gentle_scoring"):
+        dev = G.OnDevice(None)
+        monkeypatch.setattr(E, "align_batch", dev)
+        G.test_gpu_main_diagonal_shortcut_refuses_what_shifts_onto_itself(mats, dev, kind)
+        seen[kind] = dev.finished
+    for scheme in [(1, -1, -1, -1, -2, -1, 0), (1, -1, 0, 0, -3, -1, 0), (2, -3, -1, -1, -5, -2, 1), (5, -4, -2, -1, -8, -1, 0),
+                   (3, -2, -2, -1, -4, -4, 2), (7, -8, -3, 0, -8, -3, 2), (1, -2, -1, 1, -2, -2, 1)]:
+        dev = G.OnDevice(None)
+        monkeypatch.setattr(E, "align_batch", dev)
+        G.test_gpu_main_diagonal_shortcut_under_small_scores_where_ties_are_near(dev, scheme)
+        seen[scheme] = dev.finished
+    dev = G.OnDevice(None)
+    monkeypatch.setattr(E, "align_batch", dev)
+    G.test_gpu_main_diagonal_shortcut_only_where_the_scoring_proves_it(mats, dev, monkeypatch)
+    dev = G.OnDevice(None)
+    monkeypatch.setattr(E, "align_batch", dev)
+    G.test_gpu_main_diagonal_differences_at_block_edges(mats, dev, 203)
+    print("finished by the partition per case:", seen)

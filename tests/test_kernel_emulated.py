@@ -1059,3 +1059,29 @@ def test_main_diagonal_shortcut_under_small_scores_where_ties_are_near(scheme):
             assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (scheme, trial, period, k, rd)
             check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
     print("finished by the partition:", finished)
+
+
+@pytest.mark.parametrize("L", [151, 203, 250, 256])
+def test_main_diagonal_differences_at_block_edges(mats, L):
+    """The partition compares a main-diagonal candidate 32 bytes per lane, 16 bytes per load, eight lanes per candidate, with an overlapping last
+    block: one and two differing bases on every byte next to a 16-byte and a 32-byte boundary (both sides), the first and the last byte, pairs that
+    straddle a boundary or sit in different lanes of the group -- every alignment is the oracle's and each of these reads is finished by the partition."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(7700 + L)
+    amp = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = [L // 2 - 1, L // 2, L // 2 + 1]
+    other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    sub = lambda s_, q, c=None: s_[:q] + (c or other[s_[q]]) + s_[q + 1:]
+    edges = sorted(set(q for b in range(0, L + 16, 16) for q in (b - 1, b, b + 1) if 0 <= q < L) | {0, L - 1, L - 2, L - 15, L - 16, L - 17, L - 31, L - 32, L - 33})
+    reads = [amp]
+    reads += [sub(amp, q) for q in edges] + [sub(amp, q, "N") for q in edges[::3]]
+    pairs = [(q, q + 1) for q in edges if q + 1 < L] + [(q, min(L - 1, q + 32)) for q in edges[::2] if q + 32 != q and min(L - 1, q + 32) != q] + [(0, L - 1), (15, L - 16), (31, L - 32)]
+    reads += [sub(sub(amp, a), b) for a, b in pairs if a != b]
+    st = {}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    for k, rd in enumerate(reads):
+        status, s1, s2, mt, ln = oracle.global_align_raw(rd, amp, m, g, -20, -2)
+        assert status == 0 and rec[k]["status"] == 0 and res[k] == (s1, s2) and int(rec[k]["matches"]) == mt, (L, k, rd)
+        check_record(rec[k], oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
+    assert st["exact_copies"] == len(reads), (st["exact_copies"], len(reads))      # a random amplicon: every one of them is certified
