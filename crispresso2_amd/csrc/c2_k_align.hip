@@ -693,6 +693,267 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
     rec.all_substitutions = (uint16_t)n_all_sub;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The traced epilogue of the diagonal-band kernels, round 6: RUNS instead of columns.
+// c2_traceback (above) writes every column of the two aligned strings, reversed, into LDS while it walks, and c2_emit_and_classify reads them
+// back twice (once to copy them out forwards as bytes, once to classify them 64 columns at a time): half the wave cycles of a traced read.
+// But an alignment IS its runs -- an amplicon read has three (M, one indel, M) -- so c2_traceback_runs keeps only one descriptor per run (lane r
+// of three registers holds run r, in trace order), and c2_emit_runs derives everything from the descriptors:
+//   * the indel events (COREResources.pyx:119-162 and the legacy rules pyx:253-261, 284) in closed form, lane r for run r;
+//   * the strings FORWARDS, four columns per lane: per run a lane takes its overlap with the run from the read / reference in LDS as one
+//     unaligned dword (two aligned ds_reads + v_alignbyte) under a byte mask, and the row leaves as dwords;
+//   * substitutions and matches by the zero-byte trick on read ^ reference over the M columns (pyx:113-118, CRISPResso2Align.pyx:375-376).
+// A literal '-' inside the read or the reference (the reference's classifier would see a gap column there) and more than 64 runs hand the task to
+// the next launch; the last launch of every chain (c2_align_classify_kernel) keeps the column-wise epilogue, which takes anything.
+// ---------------------------------------------------------------------------------------------------------------
+struct c2_runs {
+    unsigned a;      // lane r: run r (trace order: run 0 ends in the cell (Li, Lj)) -- columns emitted before it | its length << 16
+    unsigned b;      // lane r: i | j << 16 in front of the run: it covers reference (i - len, i] unless its state is I, read (j - len, j] unless J
+    int s;           // lane r: its state
+    int n, last;     // wave-uniform: runs so far, state of the newest one
+};
+
+template <class PLANE>
+__device__ __forceinline__ void c2_traceback_runs(const PLANE& P, const int Li, const int Lj, const int min_score, const int ge, const int g0,
+                                                  const int lane, c2_runs& R, int& cnt, int& status, bool& need_full)
+{
+    int i = Li, j = Lj;
+    int s = C2_ST_M;
+    cnt = 0; need_full = false;
+    R.a = 0u; R.b = 0u; R.s = 0; R.n = 0; R.last = -1;
+    // E more columns in state st, from (i, j) backwards (a run the probes below see in pieces -- 64 cells, 250 cells -- is one run)
+    auto push = [&](const int st, const int E) {
+        if (st == R.last) { if (lane == R.n - 1) R.a += (unsigned)E << 16; }
+        else {
+            if (lane == R.n) { R.a = (unsigned)cnt | ((unsigned)E << 16); R.b = (unsigned)i | ((unsigned)j << 16); R.s = st; }
+            ++R.n; R.last = st;
+        }
+    };
+    {
+        unsigned nib = 0;
+        if (P.fetch(i, j, nib)) s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // start state, pyx:349-358
+        else need_full = true;
+    }
+    while (!need_full && (i > 0 || j > 0)) {
+        if (i == 0 || j == 0) {
+            const int need = (i == 0) ? C2_ST_I : C2_ST_J;           // initialised chains: iPointer[0,1:], jPointer[1:,0]
+            if (s != need) { status |= (s == C2_ST_M) ? C2_STATUS_SENTINEL_PATH : C2_STATUS_UNINIT_PTR; break; }
+            const int len = (i == 0) ? j : i;
+            push(s, len);
+            cnt += len; i = 0; j = 0;
+            break;
+        }
+        if constexpr (PLANE::kWordRuns) {
+            // a run of state M read off whole pointer words, four cells per lane (see c2_traceback)
+            const int K = (i < j ? i : j) - 1;
+            const int slw = (i - j - P.d0) >> 1;
+            if (s == C2_ST_M && P.pk && K >= 1 && (unsigned)slw < (unsigned)P.nl) {
+                const int a0 = i + j - 2, par = a0 & 1, ctop = a0 & 7, W0 = a0 >> 3;
+                const int n0 = (ctop >> 1) + 1;
+                const int wi = W0 - lane;
+                const int kfirst = lane == 0 ? 0 : n0 + 4 * (lane - 1);
+                int cells = lane == 0 ? n0 : 4;
+                if (wi < 0 || kfirst >= K) cells = 0; else if (kfirst + cells > K) cells = K - kfirst;
+                unsigned w = 0;
+                if (cells > 0) w = P.words[wi * P.lpa + slw];
+                const unsigned u = ((w & (w >> 8)) >> (2 * par)) & 0x00110011u;
+                unsigned m4 = (((u >> 20) & 1u) << 3) | (((u >> 16) & 1u) << 2) | (((u >> 4) & 1u) << 1) | (u & 1u);
+                const int ctop_l = lane == 0 ? ctop : 6 + par;
+                if (lane == 0) m4 = (m4 << (4 - n0)) & 0xfu;
+                int n_lead = __builtin_clz((((~m4) & 0xfu) << 28) | 0x08000000u);
+                if (n_lead > cells) n_lead = cells;
+                const unsigned long long stop = __ballot(n_lead < cells);
+                const int c_dec = ctop_l - 2 * n_lead;
+                const int ns_dec = ((w >> (16 * ((c_dec & 7) >> 2) + 2 * (c_dec & 3))) & 1u) ? C2_ST_J : C2_ST_I;
+                int covered = n0 + 4 * 63; if (covered > K) covered = K;
+                int E, s_next;
+                if (stop == 0ull) { E = covered; s_next = C2_ST_M; }
+                else {
+                    const int wl = __builtin_ctzll(stop);
+                    E = (wl == 0 ? 0 : n0 + 4 * (wl - 1)) + __builtin_amdgcn_readlane(n_lead, wl) + 1;
+                    s_next = __builtin_amdgcn_readlane(ns_dec, wl);
+                }
+                push(C2_ST_M, E);
+                cnt += E; i -= E; j -= E; s = s_next;
+                continue;
+            }
+        }
+        const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
+        const int ik = i - lane * di, jk = j - lane * dj;
+        const bool valid = (ik >= 1) && (jk >= 1);
+        int ns = 0;
+        bool oob = false;
+        if (valid) {
+            const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
+            if (pi == 0 || pj == 0) {
+                ns = c2_boundary_hstate(pi, pj, min_score, ge, g0);   // only reachable for s == M
+            } else {
+                unsigned nib = 0;
+                if (P.fetch(pi, pj, nib)) {
+                    if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
+                    else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
+                    else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
+                } else oob = true;
+            }
+        }
+        const unsigned long long vmask = __ballot(valid);
+        const unsigned long long cmask = __ballot(valid && ns == s);
+        const unsigned long long omask = __ballot(oob);
+        const int nv = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
+        const int nc = (~cmask == 0ull) ? 64 : __builtin_ctzll(~cmask);
+        int E, s_next;
+        if (nc < nv) {
+            if ((omask >> nc) & 1ull) { need_full = true; break; }
+            E = nc + 1; s_next = __builtin_amdgcn_readlane(ns, nc);
+        } else { E = nv; s_next = s; }
+        push(s, E);
+        cnt += E; i -= E * di; j -= E * dj; s = s_next;
+    }
+    if (R.n > 64) need_full = true;                                   // (more runs than lanes: the next launch's business)
+}
+
+// four bytes from LDS at any byte offset `base` of the 4-byte-aligned buffer `buf` (bytes base .. base + 3; `last_word`: the last dword that holds
+// a byte of the buffer -- one dword in front of the buffer and one behind that are read, never used: the LDS plan has them)
+__device__ __forceinline__ unsigned c2_lds_load4(const unsigned char* buf, const int base, const int last_word) {
+    int w4 = base >> 2;
+    w4 = w4 < -1 ? -1 : (w4 > last_word ? last_word : w4);
+    const uint32_t* p = (const uint32_t*)buf + w4;
+    return __builtin_amdgcn_alignbyte(p[1], p[0], (unsigned)base & 3u);
+}
+__device__ __forceinline__ unsigned c2_nonzero_bytes(const unsigned x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }   // bit 7 of every byte of x that is not 0
+
+// sCnt: two LDS ints of the slot (scratch for the wave sums).  Returns false (nothing usable written) when the task must go to the next launch.
+__device__ __forceinline__ bool c2_emit_runs(const c2_align_args& A, const c2_wg& W, const uint64_t task, const c2_runs& R, const int T,
+                                             const int lane, c2_aln_record& rec, const int Li, const int Lj, const bool rows_aligned, int* sCnt)
+{
+    const uint16_t* sIncP = W.sIncP;
+    // ---- the indel events, lane r for run r
+    const int len_r = (int)(R.a >> 16), cs_r = T - (int)(R.a & 0xffffu) - len_r, i_r = (int)(R.b & 0xffffu);
+    const bool mine = lane < R.n;
+    bool all_ins = false, win_ins = false, all_del = false, win_del = false;
+    int del_bases = 0;
+    if (mine && R.s == C2_ST_I) {
+        // a gap in the reference string closes at the next column that has a reference base (pyx:119-128): never for a trailing run (run 0), and a
+        // leading one (no reference base in front) was never opened (pyx:136)
+        const int idx = i_r;
+        if (idx > 0 && lane != 0) {
+            all_ins = true;
+            const bool fl = sIncP[idx] != sIncP[idx - 1], fr = sIncP[idx + 1] != sIncP[idx];
+            win_ins = A.legacy ? (fl || fr) : (fl && fr);              // both flanks in the window (pyx:121); legacy: either (pyx:284)
+        }
+    }
+    if (mine && R.s == C2_ST_J) {
+        all_del = true;
+        if (lane != 0) {                                               // closes at the next read base (pyx:145-153); i_r = reference bases left of that column
+            const int dstart = (A.legacy && cs_r - 1 <= 0) ? 0 : i_r - len_r;      // legacy (pyx:253-258): a run that starts in column 0 or 1 is given start 0
+            win_del = sIncP[i_r] != sIncP[dstart];
+            del_bases = i_r - dstart;
+        } else if (!A.legacy) {                                        // trailing deletion (pyx:155-162)
+            del_bases = len_r;
+            win_del = sIncP[Li] != sIncP[Li - len_r];
+        } else {                                                       // legacy (pyx:259-261): ends at reference index Li - 1 (exclusive)
+            const int dstart = (cs_r - 1 <= 0) ? 0 : Li - len_r, dend = Li - 1;
+            del_bases = dend > dstart ? dend - dstart : 0;
+            win_del = dend > dstart && sIncP[dend] != sIncP[dstart];
+        }
+    }
+    const unsigned long long mI = __ballot(all_ins), mIw = __ballot(win_ins), mD = __ballot(all_del), mDw = __ballot(win_del);
+    int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;
+    for (unsigned long long ev = mIw; ev; ev &= ev - 1ull) acc_ins_n += __builtin_amdgcn_readlane(len_r, __builtin_ctzll(ev));
+    for (unsigned long long ev = mD; ev; ev &= ev - 1ull) {
+        const int l = __builtin_ctzll(ev);
+        acc_del_bases += __builtin_amdgcn_readlane(del_bases, l);
+        if ((mDw >> l) & 1ull) acc_del_n += __builtin_amdgcn_readlane(len_r, l);
+    }
+    // ---- the strings, forwards, four columns per lane and round
+    uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
+    uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
+    const bool strings = !(A.reserved & 1);
+    const int lastR = (Lj - 1) >> 2, lastF = (Li - 1) >> 2;
+    int n_mism = 0, n_sub = 0, n_win = 0;                              // per lane
+    bool dash = false;
+    int ins_before = 0;                                                // (wave-uniform) insertion columns of the runs that end in front of this round
+    int r_hi = R.n - 1;                                                // (wave-uniform) the first run, in forward order, that reaches into this round or a later one
+    for (int c_base = 0; c_base < T; c_base += 256) {
+        const int c0 = c_base + 4 * lane;
+        unsigned accR = 0u, accF = 0u, mM = 0u, mIns = 0u;
+        int ins_left = ins_before;                                     // insertion columns left of column c0
+        for (int r = r_hi; r >= 0; --r) {
+            const unsigned ra = (unsigned)__builtin_amdgcn_readlane((int)R.a, r), rb = (unsigned)__builtin_amdgcn_readlane((int)R.b, r);
+            const int st = __builtin_amdgcn_readlane(R.s, r);
+            const int len = (int)(ra >> 16), cs = T - (int)(ra & 0xffffu) - len, ce = cs + len;
+            if (cs >= c_base + 256) break;                             // this run and the ones behind it: the next round
+            if (ce <= c_base + 256) {                                  // ends inside this round: the next round starts behind it
+                r_hi = r - 1;
+                if (st == C2_ST_I) ins_before += len;
+            }
+            // this lane's bytes [lo, 4) belong to the run -- the runs behind it take their part back
+            const int lo = cs - c0;
+            const unsigned mask = lo >= 4 ? 0u : (0xffffffffu << (8 * (lo < 0 ? 0 : lo)));
+            if (st != C2_ST_J) accR = (accR & ~mask) | (c2_lds_load4(W.sRead, c0 + ((int)(rb >> 16) - len - cs), lastR) & mask);
+            else accR = (accR & ~mask) | (0x2d2d2d2du & mask);
+            if (st != C2_ST_I) accF = (accF & ~mask) | (c2_lds_load4(W.sRef, c0 + ((int)(rb & 0xffffu) - len - cs), lastF) & mask);
+            else accF = (accF & ~mask) | (0x2d2d2d2du & mask);
+            mM = (mM & ~mask) | (st == C2_ST_M ? (0x80808080u & mask) : 0u);
+            mIns = (mIns & ~mask) | (st == C2_ST_I ? (0x80808080u & mask) : 0u);
+            if (st == C2_ST_I) { const int d = c0 - cs; ins_left += d < 0 ? 0 : (d > len ? len : d); }
+        }
+        // bytes behind column T - 1 (the last run took them too): zeros
+        const int nb = T - c0;
+        const unsigned valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
+        accR &= valid; accF &= valid; mM &= valid; mIns &= valid;
+        if (strings && nb > 0) {
+            // (exactly T bytes of a row are written, as by the column-wise epilogue of the other kernels: which kernel finishes a task depends on
+            //  the order of the lists, and the bytes behind column T - 1 must not)
+            if (rows_aligned && nb >= 4) { ((uint32_t*)outR)[c0 >> 2] = accR; ((uint32_t*)outF)[c0 >> 2] = accF; }
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nb) { outR[c0 + q] = (uint8_t)(accR >> (8 * q)); outF[c0 + q] = (uint8_t)(accF >> (8 * q)); }
+            }
+        }
+        const unsigned mm = c2_nonzero_bytes(accR ^ accF) & mM;                          // M columns whose characters differ
+        const unsigned sub = mm & c2_nonzero_bytes(accR ^ 0x4e4e4e4eu);                  // ... and the read's is not 'N' (COREResources.pyx:113-118)
+        // a literal '-' in a column that takes its character from the sequence (the reference's classifier reads the strings: it would see a gap there)
+        const unsigned vb = valid & 0x80808080u;
+        if (((~c2_nonzero_bytes(accR ^ 0x2d2d2d2du) & (mM | mIns)) | (~c2_nonzero_bytes(accF ^ 0x2d2d2d2du) & vb & ~mIns)) != 0u) dash = true;
+        n_mism += __builtin_popcount(mm);
+        if (sub != 0u) {
+            n_sub += __builtin_popcount(sub);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((sub >> (8 * q + 7)) & 1u) {
+                    const int idx = c0 + q - ins_left - __builtin_popcount(mIns & ((1u << (8 * q)) - 1u));     // reference index of the column
+                    n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0;
+                }
+        }
+    }
+    if (__ballot(dash)) return false;
+    // ---- wave sums of the three per-lane counts (an alignment has a handful of differing bases: a few lanes add)
+    if (lane == 0) { sCnt[0] = 0; sCnt[1] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    if (n_mism) atomicAdd(&sCnt[0], n_mism);
+    if (n_sub) atomicAdd(&sCnt[1], n_sub | (n_win << 16));
+    __builtin_amdgcn_wave_barrier();
+    const int mism = __builtin_amdgcn_readfirstlane(sCnt[0]), subs = __builtin_amdgcn_readfirstlane(sCnt[1]);
+    __builtin_amdgcn_wave_barrier();
+    const int st_first = __builtin_amdgcn_readlane(R.s, R.n - 1), st_last = __builtin_amdgcn_readlane(R.s, 0);
+    const unsigned char r0 = W.sRead[0], f0 = W.sRef[0], rL = W.sRead[Lj - 1], fL = W.sRef[Li - 1];
+    rec.irregular_ends = (st_first != C2_ST_M || st_last != C2_ST_M || r0 != f0 || rL != fL) ? 1 : 0;      // (a literal '-' was excluded above)
+    rec.aln_len = (uint16_t)T;
+    rec.matches = (uint16_t)(Li + Lj - T - mism);                      // M columns = Li + Lj - T (pyx:375-376 counts the equal ones)
+    rec.insertion_n = (uint16_t)acc_ins_n;
+    rec.deletion_n = (uint16_t)acc_del_n;
+    rec.substitution_n = (uint16_t)(subs >> 16);
+    rec.all_insertion_events = (uint16_t)__popcll(mI);
+    rec.win_insertion_events = (uint16_t)__popcll(mIw);
+    rec.all_deletion_events = (uint16_t)__popcll(mD);
+    rec.win_deletion_events = (uint16_t)__popcll(mDw);
+    rec.all_deletion_bases = (uint16_t)acc_del_bases;
+    rec.all_substitutions = (uint16_t)(subs & 0xffff);
+    return true;
+}
+
 // Shortcut for the commonest alignment of an amplicon run: equal lengths and no gap at all.  The reference's traceback stays
 // in state M from (L, L) to (0, 0) iff the H-state of every cell (i, i) is M, i.e. the two low pointer bits of all L main-
 // diagonal cells are clear (start-state rule pyx:349-358 for (L, L); Mptr(i+1, i+1) = H-state of (i, i) for the rest; the
@@ -1166,6 +1427,8 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
 // alignments would halve the resident waves; the words are written once, coalesced, and the traceback reads a handful
 // of them), read back with agent-scope loads that bypass the CU's L1.
 // ---------------------------------------------------------------------------------------------------------------
+#define C2_RUNS_MAX 16                              // runs of one alignment the lane-group epilogue keeps (more: the next launch takes the task)
+#define C2_GRP_SLOT_WORDS (C2_RUNS_MAX * 3 + 8)     // LDS words per alignment: run table (3 words per run) + 8 accumulator words
 struct c2_diagx_plan {
     uint32_t codeof, table, tmp_read, tmp_ref, stage, slot0, slot_bytes, total, n_words;
     uint32_t pairlut, pcodes0, pcodes_bytes, group0, group_bytes, gref, gincp;   // packed kernels only
@@ -1186,7 +1449,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
     if (pk) off += c2_align16((uint32_t)C2_PK_LUT_CODES * C2_PK_LUT_STRIDE);                // pair-score tables at the FIXED offset C2_PK_LUT_LDS_OFFSET: it folds into the look-ups' immediate offset
     p.tmp_read = off; off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);   // aligned strings of the alignment being traced
     p.tmp_ref = off;  off += c2_align16((uint32_t)max_li + (uint32_t)max_lj);
-    p.stage = off;    off += p.n_words * lpa * 4u;                  // pointer words of the alignment being traced
+    p.stage = off;    off += (uint32_t)na * C2_GRP_SLOT_WORDS * 4u;  // per alignment: its run table + the epilogue's accumulators (c2_group_epilogue)
     p.pairlut = off;  p.pcodes0 = off; p.pcodes_bytes = 0; p.group0 = off; p.group_bytes = 0; p.gref = 0; p.gincp = 0;
     if (pk) {
         // LDS is what limits the resident waves of this kernel (8 alignments per wavefront), so its layout is lean: the lane
@@ -1198,7 +1461,7 @@ __host__ __device__ inline c2_diagx_plan c2_make_diagx_plan(int na, int max_li, 
         const uint32_t need = (uint32_t)(na / 2) * p.pcodes_bytes, have = 2u * c2_align16((uint32_t)max_li + (uint32_t)max_lj);
         if (need > have) { off += need - have; }                    // (tmp_read, tmp_ref, stage are consecutive: the tables may run into `stage`, which is rewritten before use too)
         p.stage = p.tmp_ref + c2_align16((uint32_t)max_li + (uint32_t)max_lj) + (need > have ? need - have : 0u);
-        off = p.stage + (score_only ? 0u : p.n_words * lpa * 4u);
+        off = p.stage + (score_only ? 0u : (uint32_t)na * C2_GRP_SLOT_WORDS * 4u);
         p.pairlut = C2_PK_LUT_LDS_OFFSET;                           // per reference symbol: the score pair of every (symbol of read A, symbol of read B)
         p.group0 = off;
         p.gref = 0; p.gincp = c2_align16((uint32_t)max_li);
@@ -1470,7 +1733,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
 // per-alignment ("slot") table in LDS: wave-uniform values written by lane 0 and read back through readfirstlane, so the
 // staging / traceback / output code exists once (a loop over the slots) instead of once per slot
 enum { C2X_VALID = 0, C2X_TASK_LO, C2X_TASK_HI, C2X_LJ, C2X_REF, C2X_RC, C2X_STATUS, C2X_PACKED, C2X_CURREF, C2X_LI, C2X_G0,
-       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_UNPAIRED, C2X_INTS = 24 };
+       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_UNPAIRED, C2X_SCRATCH /* two ints: c2_emit_runs' wave sums */, C2X_INTS = 24 };
 __device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
 // the whole table of one slot with ONE LDS read (lane k gets entry k); C2_TF picks an entry: a v_readlane instead of an
 // LDS round trip per entry
@@ -1534,6 +1797,384 @@ __device__ __forceinline__ void c2_pk_groups(c2_pk_state& S, int& g, const int g
         for (int q = 0; q < 5; ++q) RA[q] = RB[q];
 #pragma unroll
         for (int q = 0; q < 4; ++q) CA[q] = CB[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The traced epilogue of the multi-alignment kernels, lane groups in parallel (round 6).
+// Until round 5 the alignments of an iteration were traced and written out ONE AFTER THE OTHER, the whole wavefront on each: wave-uniform state
+// in SGPRs, a few hundred scalar instructions and as many vector ones per alignment whatever its shape (measured on the first band tier:
+// 281 VALU + 478 SALU for the walk, 288 + 274 for the strings and the classification, of ~2,300 + ~960 per task).  Here EL = 8 / 16 / 32 lanes
+// take one alignment each (NA = 8 / 4 / 2 alignments per wavefront), all traced alignments of the iteration at once, state per lane:
+//   * walk (pyx:338-421): a run of state M is read off the pointer words of its diagonal -- 32 / EL words per lane and step, 128 cells per step
+//     (the leaving cell found with the word masks of c2_traceback); a gap run 8 / 16 / 32 cells per step; the words come straight from the scratch
+//     plane (L2), no staging copy.  The walk leaves RUNS -- (state, length, i, j, columns before it) -- in a small LDS table per alignment.
+//   * indel events (COREResources.pyx:119-162; legacy pyx:253-261, 284) in closed form from the runs, a lane per run.
+//   * strings FORWARDS, a dword of four columns per lane and step: a dword inside one run is two unaligned LDS dwords (ds_read2 + v_alignbyte);
+//     the few dwords that straddle a run boundary are put aside and done byte by byte afterwards; substitutions and matches by the zero-byte
+//     trick on read ^ reference over the M columns (pyx:113-118, CRISPResso2Align.pyx:375-376); exactly T bytes of a row are written.
+//   * sums through LDS atomics into the alignment's accumulator words; lane s writes the record of slot s.
+// More than C2_RUNS_MAX runs, a pointer word outside the band, a literal '-' in a column that takes its character from a sequence: the task goes
+// to the next launch (the last launch of every chain, c2_align_classify_kernel, walks column by column and takes anything).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned c2_word_m4(const unsigned w, const int par, const bool pk) {
+    // the four cells of one diagonal in a pointer word (anti-diagonals 6+par, 4+par, 2+par, par of the word's eight; topmost first in bit 3):
+    // bit set = the path stays in state M behind the cell
+    if (pk) {
+        const unsigned u = ((w & (w >> 8)) >> (2 * par)) & 0x00110011u;      // NOT "H is I" and NOT "J beats M" (c2_pk_push4): cell 6+par -> bit 20, 4+par -> 16, 2+par -> 4, par -> 0
+        return (((u >> 20) & 1u) << 3) | (((u >> 16) & 1u) << 2) | (((u >> 4) & 1u) << 1) | (u & 1u);
+    }
+    // 32-bit kernels: nibble of anti-diagonal c at bits 4 * (7 - c); its two low bits ("H is I", "J beats M") clear = stays in M
+    const unsigned z = ~(w | (w >> 1)) & 0x11111111u;                       // bit 4 * (7 - c) set iff both are clear
+    const unsigned zz = z >> (4 * (1 - par));                                // cells 6+par, 4+par, 2+par, par -> bits 0, 8, 16, 24
+    return ((zz & 1u) << 3) | (((zz >> 8) & 1u) << 2) | (((zz >> 16) & 1u) << 1) | ((zz >> 24) & 1u);
+}
+__device__ __forceinline__ unsigned c2_word_nib(const unsigned w, const int a, const bool pk) {
+    // the pointer nibble of anti-diagonal a in its lane's word, as c2_diagx_plane::fetch decodes it
+    if (!pk) return (w >> (4 * (7 - (a & 7)))) & 0xFu;
+    const int c = a & 7;
+    const unsigned h = w >> (16 * (c >> 2));
+    const unsigned ih = (h >> (2 * (c & 3))) & 3u, jm = (h >> (8 + 2 * (c & 3))) & 3u;
+    return ((ih >> 1) << 3) | ((jm >> 1) << 2) | (((ih & 1u) ^ 1u) << 1) | ((jm & 1u) ^ 1u);
+}
+
+template <int NA, bool PK, int LPW, int NL>
+__device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const c2_diagx_plan& P, const int lane, const unsigned m_trace_all, const int sbase,
+                                                  int* sTab, const unsigned* gWords, const int slotWords, const bool rows_aligned)
+{
+    // (sbase: the first slot of this call -- sixteen alignments per wavefront, the opt-in 14-diagonal launch, take two calls of eight)
+    constexpr int NAH = NA > 8 ? 8 : NA;                            // alignments per call
+    constexpr int EL = NAH > 4 ? 8 : (NAH > 2 ? 16 : 32);           // lanes per alignment
+    constexpr int NW = 32 / EL;                                     // pointer words per lane and step of a run of state M
+    const unsigned m_trace = m_trace_all >> sbase;
+    const int e = lane / EL, q = lane - e * EL;
+    const int es = sbase + (e < NAH ? e : 0);
+    const bool act = e < NAH && ((m_trace >> e) & 1u);
+    const unsigned long long gmask = (EL == 32 ? 0xffffffffull : ((1ull << EL) - 1ull));
+    auto sub = [&](const unsigned long long b) { return (unsigned)((b >> (e * EL)) & gmask); };     // this lane group's bits of a ballot
+    const int ge = A.gap_extend;
+    const int* T = sTab + es * C2X_INTS;
+    const int Li = T[C2X_LI], Lj = T[C2X_LJ], d0 = T[C2X_D0], minsc = T[C2X_MINSC], g0 = T[C2X_G0];
+    const unsigned* gW = gWords + es * slotWords;
+    unsigned* runs = (unsigned*)(c2_smem + P.stage) + es * C2_GRP_SLOT_WORDS;
+    int* acc = (int*)(runs + C2_RUNS_MAX * 3);
+    const unsigned char* sRead; const unsigned char* sRef; const uint16_t* sIncP;
+    if (PK) {
+        const unsigned char* gb = c2_smem + P.group0 + (uint32_t)(es >> 1) * P.group_bytes;
+        sRead = c2_smem + P.slot0 + (uint32_t)es * P.slot_bytes; sRef = gb + P.gref; sIncP = (const uint16_t*)(gb + P.gincp);
+    } else {
+        const unsigned char* base = c2_smem + P.slot0 + (uint32_t)es * P.slot_bytes;
+        sRead = base + P.read; sRef = base + P.ref; sIncP = (const uint16_t*)(base + P.incp);
+    }
+    auto nib_at = [&](const int pi, const int pj, unsigned& nib) -> bool {
+        const int sl = (pi - pj - d0) >> 1;
+        if ((unsigned)sl >= (unsigned)NL) return false;
+        const int a = pi + pj;
+        nib = c2_word_nib(gW[(a >> 3) * LPW + sl], a, PK);
+        return true;
+    };
+
+    // ================= the walk =================
+    int i = Li, j = Lj, s = C2_ST_M, cnt = 0, nr = 0, status = 0;
+    int cur_s = 0, cur_len = 0, cur_i = 0, cur_j = 0, cur_cnt = 0;    // the run being collected (a run the steps below see in pieces is one run)
+    bool done = !act, nf = false;
+    auto flush = [&]() {
+        if (cur_s) {
+            if (q == 0 && nr < C2_RUNS_MAX) {
+                runs[3 * nr] = (unsigned)cur_cnt | ((unsigned)cur_len << 16);
+                runs[3 * nr + 1] = (unsigned)cur_i | ((unsigned)cur_j << 16);
+                runs[3 * nr + 2] = (unsigned)cur_s;
+            }
+            ++nr;
+        }
+    };
+    if (act) {
+        unsigned nib = 0;
+        if (nib_at(i, j, nib)) s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // start state, pyx:349-358
+        else { nf = true; done = true; }
+    }
+    while (true) {
+        if (!__ballot(!done)) break;
+        const bool live = !done;
+        const bool bnd = live && (i == 0 || j == 0);
+        const int K = (i < j ? i : j) - 1;
+        const int slw = (i - j - d0) >> 1;
+        const bool wordp = live && !bnd && s == C2_ST_M && K >= 1 && (unsigned)slw < (unsigned)NL;
+        const bool probe = live && !bnd && !wordp;
+        // ---- a run of state M off the words of its diagonal: word n of the run (n = 0: the word of cell (i-1, j-1)) holds its cells
+        //      k = kfirst(n) .. kfirst(n) + 3; lane q takes words q * NW .. q * NW + NW - 1.  Interior cells only (k < K): the cell on a matrix
+        //      edge goes through the probe below
+        const int a0 = i + j - 2, par = a0 & 1, ctop = a0 & 7, W0 = a0 >> 3, n0 = (ctop >> 1) + 1;
+        unsigned wv[NW]; int cl[NW];
+#pragma unroll
+        for (int t = 0; t < NW; ++t) {
+            const int n = q * NW + t, wi = W0 - n;
+            const int kfirst = n == 0 ? 0 : n0 + 4 * (n - 1);
+            int cells = n == 0 ? n0 : 4;
+            if (!wordp || wi < 0 || kfirst >= K) cells = 0; else if (kfirst + cells > K) cells = K - kfirst;
+            cl[t] = cells;
+            wv[t] = cells > 0 ? gW[wi * LPW + slw] : 0u;
+        }
+        int ncont = 0, ns_dec = 0;
+        bool stopped = false;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) {
+            if (!stopped && cl[t] > 0) {
+                const int n = q * NW + t;
+                unsigned m4 = c2_word_m4(wv[t], par, PK);
+                if (n == 0) m4 = (m4 << (4 - n0)) & 0xfu;
+                int n_lead = __builtin_clz((((~m4) & 0xfu) << 28) | 0x08000000u);      // cells from the top that keep the path in M (4: all of them)
+                if (n_lead > cl[t]) n_lead = cl[t];
+                ncont += n_lead;
+                if (n_lead < cl[t]) {
+                    stopped = true;
+                    const int c_dec = (n == 0 ? ctop : 6 + par) - 2 * n_lead;            // the cell that ends the run
+                    const unsigned nb = c2_word_nib(wv[t], c_dec, PK);
+                    ns_dec = (nb & 2u) ? C2_ST_I : C2_ST_J;                              // "H is I" first (pyx:349-358 order); one of the two is set
+                }
+            }
+        }
+        const unsigned stopm = sub(__ballot(stopped));
+        const int wl = stopm ? __builtin_ctz(stopm) : 0;
+        const int ncont_w = __shfl(ncont, e * EL + wl), ns_w = __shfl(ns_dec, e * EL + wl);
+        int covered = n0 + 4 * (EL * NW - 1); if (covered > K) covered = K;
+        // ---- any other state, and the cells on the matrix edges: lane q probes the q-th cell ahead along the current direction
+        const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
+        const int ik = i - q * di, jk = j - q * dj;
+        const bool valid = probe && ik >= 1 && jk >= 1;
+        int ns = 0;
+        bool oob = false;
+        if (valid) {
+            const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
+            if (pi == 0 || pj == 0) ns = c2_boundary_hstate(pi, pj, minsc, ge, g0);      // only reachable for s == M
+            else {
+                unsigned nib = 0;
+                if (nib_at(pi, pj, nib)) {
+                    if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
+                    else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
+                    else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
+                } else oob = true;
+            }
+        }
+        const unsigned vm = sub(__ballot(valid)), cm = sub(__ballot(valid && ns == s)), om = sub(__ballot(oob));
+        const int nv = (~vm & (unsigned)gmask) ? __builtin_ctz(~vm & (unsigned)gmask) : EL;
+        const int nc = (~cm & (unsigned)gmask) ? __builtin_ctz(~cm & (unsigned)gmask) : EL;
+        const int ns_c = __shfl(ns, e * EL + (nc < EL ? nc : EL - 1));
+        // ---- the step
+        if (live) {
+            int E = 0, s_next = s;
+            bool fin = false;
+            if (bnd) {
+                const int need = (i == 0) ? C2_ST_I : C2_ST_J;       // initialised chains: iPointer[0,1:], jPointer[1:,0]
+                if (s != need) status |= (s == C2_ST_M) ? C2_STATUS_SENTINEL_PATH : C2_STATUS_UNINIT_PTR;
+                else E = (i == 0) ? j : i;
+                fin = true;
+            } else if (wordp) {
+                if (stopm == 0u) { E = covered; s_next = C2_ST_M; }
+                else { const int nfirst = wl * NW; E = (nfirst == 0 ? 0 : n0 + 4 * (nfirst - 1)) + ncont_w + 1; s_next = ns_w; }
+            } else {
+                if (nc < nv) {
+                    if ((om >> nc) & 1u) { nf = true; fin = true; }              // the deciding pointer word is not in this plane
+                    else { E = nc + 1; s_next = ns_c; }
+                } else { E = nv; s_next = s; }
+            }
+            if (E > 0) {
+                if (s == cur_s) cur_len += E;
+                else { flush(); cur_s = s; cur_len = E; cur_i = i; cur_j = j; cur_cnt = cnt; }
+                cnt += E;
+                if (bnd) { i = 0; j = 0; } else { i -= E * ((s != C2_ST_I) ? 1 : 0); j -= E * ((s != C2_ST_J) ? 1 : 0); }
+            }
+            s = s_next;
+            if (fin || (i == 0 && j == 0)) done = true;
+        }
+    }
+    flush();
+    if (nr > C2_RUNS_MAX) nf = true;
+    const bool ok = act && !nf && status == 0;
+    const int TT = cnt;                                              // columns of the alignment
+    if (e < NAH && q < 8) acc[q] = 0;
+    __builtin_amdgcn_wave_barrier();                                 // (the run tables and the zeroed accumulators: LDS operations of one wavefront complete in order)
+
+    // ================= indel events, a lane per run =================
+    int ev_counts = 0, ev_ins_n = 0, ev_del_n = 0, ev_del_bases = 0, flags = 0;
+#pragma unroll
+    for (int rb = 0; rb < C2_RUNS_MAX; rb += EL) {
+        const int r = rb + q;
+        if (ok && r < nr) {
+            const unsigned ra = runs[3 * r], rbw = runs[3 * r + 1];
+            const int st = (int)runs[3 * r + 2];
+            const int len_r = (int)(ra >> 16), cs_r = TT - (int)(ra & 0xffffu) - len_r, i_r = (int)(rbw & 0xffffu);
+            if ((r == 0 || r == nr - 1) && st != C2_ST_M) flags |= 2;                     // a gap in the first or the last column (CRISPRessoCORE.py:729-733)
+            if (st == C2_ST_I) {
+                // a gap in the reference string closes at the next column that has a reference base (pyx:119-128): never for a trailing run (run 0),
+                // and a leading one (no reference base in front) was never opened (pyx:136)
+                if (i_r > 0 && r != 0) {
+                    const bool fl = sIncP[i_r] != sIncP[i_r - 1], fr = sIncP[i_r + 1] != sIncP[i_r];
+                    const bool win = A.legacy ? (fl || fr) : (fl && fr);                // both flanks in the window (pyx:121); legacy: either (pyx:284)
+                    ev_counts += 1 + (win ? 0x100 : 0);
+                    if (win) ev_ins_n += len_r;
+                }
+            } else if (st == C2_ST_J) {
+                bool win; int bases;
+                if (r != 0) {                                                           // closes at the next read base (pyx:145-153); i_r = reference bases left of that column
+                    const int dstart = (A.legacy && cs_r - 1 <= 0) ? 0 : i_r - len_r;   // legacy (pyx:253-258): a run that starts in column 0 or 1 is given start 0
+                    win = sIncP[i_r] != sIncP[dstart];
+                    bases = i_r - dstart;
+                } else if (!A.legacy) {                                                 // trailing deletion (pyx:155-162)
+                    bases = len_r;
+                    win = sIncP[Li] != sIncP[Li - len_r];
+                } else {                                                                // legacy (pyx:259-261): ends at reference index Li - 1 (exclusive)
+                    const int dstart = (cs_r - 1 <= 0) ? 0 : Li - len_r, dend = Li - 1;
+                    bases = dend > dstart ? dend - dstart : 0;
+                    win = dend > dstart && sIncP[dend] != sIncP[dstart];
+                }
+                ev_counts += 0x10000 + (win ? 0x1000000 : 0);
+                ev_del_bases += bases;
+                if (win) ev_del_n += len_r;
+            }
+        }
+    }
+
+    // ================= the strings, forwards =================
+    uint8_t* outR = A.aln_read + (uint64_t)(unsigned)T[C2X_TASK_LO] * (uint64_t)A.aln_stride;
+    uint8_t* outF = A.aln_ref + (uint64_t)(unsigned)T[C2X_TASK_LO] * (uint64_t)A.aln_stride;
+    const bool strings = !(A.reserved & 1);
+    const int lastR = (Lj - 1) >> 2, lastF = (Li - 1) >> 2;
+    int n_mism = 0, n_sub = 0, n_win = 0;
+    bool dash = false;
+    struct run_d { int cs, ce, dR, dF, st, len; };                 // a run as the strings need it: columns [cs, ce); read / reference index of its column c: c + dR / c + dF
+    auto load_run = [&](const int r, run_d& d) {
+        const unsigned ra = runs[3 * r], rbw = runs[3 * r + 1];
+        d.st = (int)runs[3 * r + 2];
+        d.len = (int)(ra >> 16); d.cs = TT - (int)(ra & 0xffffu) - d.len; d.ce = d.cs + d.len;
+        d.dR = (int)(rbw >> 16) - d.len - d.cs; d.dF = (int)(rbw & 0xffffu) - d.len - d.cs;
+    };
+    auto store4 = [&](const int c0, const unsigned r4, const unsigned f4, const int nb) {     // nb > 0 bytes of the dword at column c0 are columns
+        if (!strings) return;
+        if (rows_aligned && nb >= 4) { ((uint32_t*)outR)[c0 >> 2] = r4; ((uint32_t*)outF)[c0 >> 2] = f4; }
+        else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (b < nb) { outR[c0 + b] = (uint8_t)(r4 >> (8 * b)); outF[c0 + b] = (uint8_t)(f4 >> (8 * b)); }
+        }
+    };
+    // a dword that straddles run boundaries, byte by byte from the first run on (rare: an alignment has a boundary or two)
+    auto do_bytes = [&](const int c0) {
+        int r2 = nr - 1, il = 0;
+        run_d D;
+        load_run(r2, D);
+        unsigned r4 = 0u, f4 = 0u;
+        int nb = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int c = c0 + b;
+            if (c < TT) {
+                while (c >= D.ce && r2 > 0) { if (D.st == C2_ST_I) il += D.len; --r2; load_run(r2, D); }
+                const int st = D.st;
+                const unsigned char rch = (st != C2_ST_J) ? sRead[c + D.dR] : (unsigned char)'-';
+                const unsigned char fch = (st != C2_ST_I) ? sRef[c + D.dF] : (unsigned char)'-';
+                r4 |= (unsigned)rch << (8 * b); f4 |= (unsigned)fch << (8 * b);
+                nb = b + 1;
+                if (st == C2_ST_M) {
+                    if (rch != fch) {
+                        ++n_mism;
+                        if (rch != 'N') { ++n_sub; const int idx = c - il; n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0; }
+                    }
+                    if (rch == '-' || fch == '-') dash = true;
+                } else if ((st == C2_ST_I && rch == '-') || (st == C2_ST_J && fch == '-')) dash = true;
+            }
+        }
+        store4(c0, r4, f4, nb);
+    };
+    unsigned defer = 0u;
+    int ins_left = 0;                                               // insertion columns of the runs in front of the current one
+    int rp = 0;
+    run_d C; C.cs = 0; C.ce = 0; C.dR = 0; C.dF = 0; C.st = 0; C.len = 0;          // the run this lane's columns are in
+    if (ok) { rp = nr - 1; load_run(rp, C); }
+    for (int t = 0;; ++t) {
+        const int c0 = 4 * (q + EL * t);
+        const bool on = ok && c0 < TT;
+        if (!__ballot(on)) break;
+        if (on) {
+            while (c0 >= C.ce && rp > 0) { if (C.st == C2_ST_I) ins_left += C.len; --rp; load_run(rp, C); }
+            const int st = C.st, dR = C.dR, dF = C.dF;
+            if (c0 + 4 <= C.ce || rp == 0) {
+                // the whole dword lies in the run (or the run is the last one: the bytes behind column T - 1 are cut off)
+                const int nb = TT - c0;
+                const unsigned valid = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+                const unsigned r4 = ((st != C2_ST_J) ? c2_lds_load4(sRead, c0 + dR, lastR) : 0x2d2d2d2du) & valid;
+                const unsigned f4 = ((st != C2_ST_I) ? c2_lds_load4(sRef, c0 + dF, lastF) : 0x2d2d2d2du) & valid;
+                store4(c0, r4, f4, nb);
+                const unsigned vb = valid & 0x80808080u;
+                if (st == C2_ST_M) {
+                    const unsigned mm = c2_nonzero_bytes(r4 ^ f4) & vb;                               // columns whose characters differ
+                    const unsigned sb = mm & c2_nonzero_bytes(r4 ^ 0x4e4e4e4eu);                     // ... and the read's is not 'N' (COREResources.pyx:113-118)
+                    if (((~c2_nonzero_bytes(r4 ^ 0x2d2d2d2du) | ~c2_nonzero_bytes(f4 ^ 0x2d2d2d2du)) & vb) != 0u) dash = true;
+                    if (mm != 0u) {
+                        n_mism += __builtin_popcount(mm);
+                        n_sub += __builtin_popcount(sb);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            if ((sb >> (8 * b + 7)) & 1u) { const int idx = c0 + b - ins_left; n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0; }
+                    }
+                } else {
+                    const unsigned x = (st == C2_ST_I) ? r4 : f4;                                    // a literal '-' in the sequence that fills the gap run
+                    if ((~c2_nonzero_bytes(x ^ 0x2d2d2d2du) & vb) != 0u) dash = true;
+                }
+            } else if (t < 32) defer |= 1u << t;
+            else do_bytes(c0);
+        }
+    }
+    while (true) {
+        if (!__ballot(defer != 0u)) break;
+        if (defer != 0u) { const int t = __builtin_ctz(defer); defer &= defer - 1u; do_bytes(4 * (q + EL * t)); }
+    }
+    // ================= sums, records =================
+    if (ok) {
+        if (q == 0) {
+            const unsigned char r0 = sRead[0], f0 = sRef[0], rL = sRead[Lj - 1], fL = sRef[Li - 1];
+            if (r0 != f0 || rL != fL) flags |= 2;
+        }
+        if (dash) flags |= 1;
+        if (n_mism) atomicAdd(&acc[0], n_mism);
+        if (n_sub) atomicAdd(&acc[1], n_sub | (n_win << 16));
+        if (ev_counts) atomicAdd(&acc[2], ev_counts);
+        if (ev_ins_n | ev_del_n) atomicAdd(&acc[3], ev_ins_n | (ev_del_n << 16));
+        if (ev_del_bases) atomicAdd(&acc[4], ev_del_bases);
+        if (flags) atomicOr(&acc[5], flags);
+    }
+    if (e < NAH && q == 0) { acc[6] = TT; acc[7] = (act ? 1 : 0) | (nf ? 2 : 0) | (status << 8); }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < NAH && ((m_trace >> lane) & 1u)) {
+        const int* Ts = sTab + (sbase + lane) * C2X_INTS;
+        const int* ac = (const int*)((unsigned*)(c2_smem + P.stage) + (sbase + lane) * C2_GRP_SLOT_WORDS + C2_RUNS_MAX * 3);
+        const uint64_t task = (uint64_t)(unsigned)Ts[C2X_TASK_LO] | ((uint64_t)(unsigned)Ts[C2X_TASK_HI] << 32);
+        int st8 = (ac[7] >> 8) & 0xff;
+        const bool need_full = (ac[7] & 2) != 0 || (st8 == 0 && (ac[5] & 1) != 0);
+        c2_aln_record rec;
+        c2_clear_record(rec, Ts[C2X_RC], Ts[C2X_REF]);
+        if (!need_full && st8 == 0) {
+            const int Tn = ac[6], sLi = Ts[C2X_LI], sLj = Ts[C2X_LJ];
+            rec.aln_len = (uint16_t)Tn;
+            rec.matches = (uint16_t)(sLi + sLj - Tn - ac[0]);        // M columns = Li + Lj - T (pyx:375-376 counts the equal ones)
+            rec.insertion_n = (uint16_t)(ac[3] & 0xffff);
+            rec.deletion_n = (uint16_t)((unsigned)ac[3] >> 16);
+            rec.substitution_n = (uint16_t)((unsigned)ac[1] >> 16);
+            rec.all_insertion_events = (uint16_t)(ac[2] & 0xff);
+            rec.win_insertion_events = (uint16_t)((ac[2] >> 8) & 0xff);
+            rec.all_deletion_events = (uint16_t)((ac[2] >> 16) & 0xff);
+            rec.win_deletion_events = (uint16_t)((ac[2] >> 24) & 0xff);
+            rec.all_deletion_bases = (uint16_t)ac[4];
+            rec.all_substitutions = (uint16_t)(ac[1] & 0xffff);
+            rec.irregular_ends = (ac[5] & 2) ? 1 : 0;
+        }
+        if (need_full) {
+            st8 |= C2_STATUS_NEED_FULL;
+            const unsigned k = atomicAdd(A.fb_count, 1u);
+            A.fb_list[k] = (uint32_t)task;
+        }
+        rec.status = (uint8_t)st8;
+        A.records[task] = rec;
     }
 }
 
@@ -1983,20 +2624,10 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             m_valid = (unsigned)__ballot(valid); m_full = (unsigned)__ballot(full);
             m_gapfree = (unsigned)__ballot(gf); m_trace = (unsigned)__ballot(!SCORE && cert && !gf);
         }
-        constexpr int STG = LPW / 4 > 8 ? 8 : LPW / 4;                               // 16-byte words per lane in flight: 64 * STG 16-byte words hold one alignment's pointer bits of 500 anti-diagonals
-        uint4 q0, q1, q2, q3, q4, q5, q6, q7;                       // (named registers: an array here ends up in scratch)
-        q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = uint4{0u, 0u, 0u, 0u};
-#define C2_STG_LOAD(n) if (STG > n) { const int k = 64 * n + lane; q##n = src[k < n16 ? k : 0]; }
-#define C2_STG_STORE(n) if (STG > n) { const int k = 64 * n + lane; if (k < n16) dst[k] = q##n; }
-        auto request_words = [&](const int s2) {
-            const uint4* src = (const uint4*)(gWords + s2 * slotWords);
-            const int n16 = (g_end + 1) * (LPW / 4);
-            C2_STG_LOAD(0) C2_STG_LOAD(1) C2_STG_LOAD(2) C2_STG_LOAD(3) C2_STG_LOAD(4) C2_STG_LOAD(5) C2_STG_LOAD(6) C2_STG_LOAD(7)
-        };
-        if (m_trace) request_words(__builtin_ctz(m_trace));
 #pragma nounroll
         for (int s = 0; s < NA; ++s) {
             if (!((m_valid >> s) & 1u)) continue;
+            if (!SCORE && ((m_trace >> s) & 1u)) continue;           // traced: all of them at once, below (c2_group_epilogue)
             const int* T = sTab + s * C2X_INTS;
             const int tv = c2_tab_load(T, lane);
             const uint64_t task = (uint64_t)(unsigned)C2_TF(tv, C2X_TASK_LO) | ((uint64_t)(unsigned)C2_TF(tv, C2X_TASK_HI) << 32);
@@ -2008,30 +2639,6 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             if ((m_gapfree >> s) & 1u) {
                 if (rows_aligned && Li <= 256) c2_emit_gapless4(A, wg_of(s), win_of(s), task, Li, lane, rec);
                 else c2_emit_gapless(A, wg_of(s), task, Li, lane, rec);
-            } else if (!SCORE && ((m_trace >> s) & 1u)) {
-                const int d0 = C2_TF(tv, C2X_D0), minsc = C2_TF(tv, C2X_MINSC);
-                const c2_wg W = wg_of(s);
-                // the alignment's pointer words: registers (requested from HBM/L2 before the previous alignment's
-                // output stores were issued) -> LDS; words beyond the first batch (long sequences) are fetched here
-                {
-                    const uint4* src = (const uint4*)(gWords + s * slotWords);
-                    uint4* dst = (uint4*)sStage;
-                    const int n16 = ((((Li + Lj) >> 1) >> 2) + 1) * (LPW / 4);
-                    C2_STG_STORE(0) C2_STG_STORE(1) C2_STG_STORE(2) C2_STG_STORE(3) C2_STG_STORE(4) C2_STG_STORE(5) C2_STG_STORE(6) C2_STG_STORE(7)
-                    for (int k = 64 * STG + lane; k < n16; k += 64) dst[k] = src[k];
-                }
-                __syncthreads();
-                const unsigned later = m_trace & ~((2u << s) - 1u);     // traced slots after this one
-                if (later) request_words(__builtin_ctz(later));
-                c2_diagx_plane plane;
-                plane.words = sStage; plane.d0 = d0; plane.lpa = LPW; plane.nl = NL; plane.pk = PK;
-                int cnt, matches;
-                bool nf2;
-                c2_traceback(plane, W, Li, Lj, minsc, ge, g0, lane, cnt, matches, status, nf2);
-                __syncthreads();
-                c2_phase_mark<2>(A.phase_cycles, PH);
-                if (nf2) need_full = true;                     // cannot happen when the certificate holds; kept as a guard
-                else if (status == 0) c2_emit_and_classify(A, W, task, cnt, matches, lane, rec, Li, Lj);
             }
             if (need_full) {
                 status |= C2_STATUS_NEED_FULL;
@@ -2044,6 +2651,14 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             rec.status = (uint8_t)status;
             if (lane == 0) A.records[task] = rec;
             c2_phase_mark<3>(A.phase_cycles, PH);
+        }
+        if constexpr (!SCORE) {
+            if (m_trace) {
+                __syncthreads();
+                c2_group_epilogue<NA, PK, LPW, NL>(A, P, lane, m_trace, 0, sTab, gWords, slotWords, rows_aligned);
+                if constexpr (NA > 8) { if (m_trace >> 8) c2_group_epilogue<NA, PK, LPW, NL>(A, P, lane, m_trace, 8, sTab, gWords, slotWords, rows_aligned); }
+                c2_phase_mark<2>(A.phase_cycles, PH);
+            }
         }
     }
     c2_phase_flush(A.phase_cycles, PH, lane);
