@@ -240,6 +240,10 @@ class Job:
         self.n_sets = 2 if overlap_count else 1
         self.out_sets = [(torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev), torch.empty((n_tasks, stride), dtype=torch.uint8, device=dev),
                           torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)) for _ in range(self.n_sets)]
+        # single amplicon: the hint words c2_align_partition_kernel leaves for the reads it finishes itself (c2_batch.diag_hints); the count pass takes those
+        # tasks from the word alone (c2_count_hinted_kernel).  C2_BENCH_NO_HINTS=1: the step without them (A/B).
+        self.use_hints = (k == 1 and not all_refs and wl["ref_ids"] is None and not os.environ.get("C2_BENCH_NO_HINTS"))
+        self.hint_sets = [torch.zeros(n_tasks, dtype=torch.int32, device=dev) if self.use_hints else None for _ in range(self.n_sets)]
         self.t_align = torch.cuda.current_stream()
         self.t_count = torch.cuda.Stream(device=dev) if overlap_count else self.t_align
         self.stream = self.t_align.cuda_stream
@@ -261,10 +265,10 @@ class Job:
     def outputs(self):
         return self.out_sets[0]
 
-    def align_into(self, a_read, a_ref, recs):
+    def align_into(self, a_read, a_ref, recs, hints=None):
         self.al.align_device(self.n, self.d_reads.data_ptr(), self.d_offsets.data_ptr(), a_read.data_ptr(), a_ref.data_ptr(), recs.data_ptr(),
                              self.stride, self.L, d_ref_ids=None if self.d_rids is None else self.d_rids.data_ptr(), all_refs=self.all_refs,
-                             stream=self.stream, min_read_len=self.min_len)
+                             stream=self.stream, min_read_len=self.min_len, d_hints=None if hints is None else hints.data_ptr())
 
     def step(self, e=None):
         """One batch: launch chain on the align stream into buffer set i; reference choice, count pass and all-reduce on the count
@@ -273,10 +277,11 @@ class Job:
         i = self.step_no % self.n_sets
         self.step_no += 1
         a_read, a_ref, recs = self.out_sets[i]
+        hints = self.hint_sets[i]
         if self.counted_ev[i] is not None:
             self.t_align.wait_event(self.counted_ev[i])
         if e: e[0].record(self.t_align)
-        self.align_into(a_read, a_ref, recs)
+        self.align_into(a_read, a_ref, recs, hints)
         if e: e[1].record(self.t_align)
         self.aligned_ev[i].record(self.t_align)
         self.t_count.wait_event(self.aligned_ev[i])
@@ -292,7 +297,8 @@ class Job:
             C.accumulate_device(self.ctx, self.layout, self.n_tasks, a_read.data_ptr(), a_ref.data_ptr(), self.stride, recs.data_ptr(),
                                 self.d_counts.data_ptr(), d_weights=self.d_weights.data_ptr() if self.all_refs else None,
                                 min_matches=None if self.all_refs else self.min_matches,
-                                flags=C.FLAG_ALL_REFS_LAYOUT if self.all_refs else 0, stream=self.count_stream)
+                                flags=C.FLAG_ALL_REFS_LAYOUT if self.all_refs else 0, stream=self.count_stream,
+                                d_hints=None if hints is None else hints.data_ptr())
             C.all_reduce(self.d_counts)
             if e: e[3].record(self.t_count)
             self.counted_ev[i] = torch.cuda.Event()
@@ -420,12 +426,27 @@ class Job:
         host = t.cpu().numpy()
         return int(sum(self.layout.unpack(host, r, len(self.wl["refs"][r][0]))["counts_total"] for r in range(self.k)))
 
+    def count_tensor_equals_without_hints(self):
+        """the step's count tensor (hinted tasks from their hint word, c2_count_hinted_kernel) against the count pass over the same rows and records
+        WITHOUT the hints (every task's strings read back) -- entry by entry.  None when the step uses no hints."""
+        torch, C = self.torch, self.C
+        if not self.use_hints or self.world > 1:
+            return None
+        a_read, a_ref, recs = self.out_sets[(self.step_no - 1) % self.n_sets]
+        t = torch.zeros_like(self.d_counts)
+        with torch.cuda.stream(self.t_count):
+            C.accumulate_device(self.ctx, self.layout, self.n_tasks, a_read.data_ptr(), a_ref.data_ptr(), self.stride, recs.data_ptr(), t.data_ptr(),
+                                min_matches=self.min_matches, stream=self.count_stream)
+        torch.cuda.synchronize()
+        return bool(torch.equal(t, self.d_counts))
+
     def tallies(self):
         host = self.d_counts.cpu().numpy()
         return [self.layout.unpack(host, r, len(self.wl["refs"][r][0])) for r in range(self.k)]
 
     def free(self):
         self.out_sets = []
+        self.hint_sets = []
         self.d_reads = self.d_offsets = self.d_rids = self.d_weights = self.d_counts = None
         self.torch.cuda.empty_cache()
 
@@ -1041,6 +1062,10 @@ def main():
     # (3) size-independent properties on EVERY alignment of the full-size batch
     if args.check > 0:
         checks["full_batch_properties_hold"] = job.properties_hold()
+        eq_ = job.count_tensor_equals_without_hints()
+        if eq_ is not None:
+            checks["count_tensor_equals_without_hints"] = eq_
+            checks["hinted_tasks"] = int((job.hint_sets[0] < 0).sum().item())       # (bit 31 = valid)
     # (4) the launch chain's certificates, exhaustively: the same batch through the full-plane kernel alone
     if rank == 0 and args.check > 0 and not args.no_full_plane_check and args.kernel == "auto":
         equal_n, tf = job.chain_equals_full_plane()

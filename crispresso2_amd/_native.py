@@ -20,7 +20,7 @@ SYMBOLS = [
     "c2_align_classify_batch_device", "c2_align_classify_batch_host", "c2_synchronize",
     "c2_timing_enable", "c2_timing_read", "c2_launch_info",
     "c2_global_align", "c2_find_indels_substitutions", "c2_calculate_homology",
-    "c2_selftest", "c2_selftest_rows", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_tier_info_ex", "c2_chain_info", "c2_timing_read_split", "c2_count_vectors_device", "c2_select_best_device",
+    "c2_selftest", "c2_selftest_rows", "c2_phase_profile", "c2_set_band", "c2_band_info", "c2_set_kernel_mode", "c2_tier_info", "c2_tier_info_ex", "c2_chain_info", "c2_timing_read_split", "c2_count_vectors_device", "c2_count_vectors_hinted_device", "c2_select_best_device",
     "c2_comm_unique_id", "c2_comm_init", "c2_reduce_counts", "c2_comm_destroy",
     "c2_classify_lists_batch", "c2_lists_total", "c2_lists_index", "c2_lists_values", "c2_lists_counts", "c2_lists_free",
     "c2_fastq_unique", "c2_fastq_unique_filtered", "c2_fastq_n_unique", "c2_fastq_n_reads", "c2_fastq_nonempty_lines", "c2_fastq_arena_bytes", "c2_fastq_arena", "c2_fastq_offsets",
@@ -44,7 +44,7 @@ assert REC_DTYPE.itemsize == 32
 
 STATUS_EMPTY, STATUS_OOB_CHAR, STATUS_SENTINEL_PATH, STATUS_UNINIT_PTR, STATUS_RC_CHAR, STATUS_TOO_LONG = 1, 2, 4, 8, 16, 32
 E_OVERFLOW = -6
-ABI_VERSION = 2
+ABI_VERSION = 3
 LIST_COUNT = 15
 
 
@@ -58,6 +58,7 @@ class Batch(ctypes.Structure):
         ("aln_stride", ctypes.c_uint32), ("flags", ctypes.c_uint32),
         ("records", ctypes.c_void_p),
         ("min_read_len", ctypes.c_int32),
+        ("diag_hints", ctypes.c_void_p),
     ]
 
 

@@ -150,7 +150,7 @@ class BatchAligner:
         return BatchResult(aln_read, aln_ref, records, n, self.n_refs, all_refs)
 
     def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
-                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0):
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0, d_hints=None):
         """All d_* are device addresses (ints).  Enqueues one launch on `stream` and returns immediately.
         min_read_len: the shortest read of the batch if the caller knows it (c2_batch.min_read_len: band tiers no read of that length range can use
         are not launched -- never changes a result)."""
@@ -168,4 +168,5 @@ class BatchAligner:
         b.records = d_records
         b.flags = 1 if legacy else 0
         b.min_read_len = int(min_read_len)
+        b.diag_hints = d_hints                                      # (c2_batch.diag_hints: n_tasks uint32 on the device, or None)
         self.ctx.align_classify_device(b, stream)

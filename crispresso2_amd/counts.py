@@ -82,19 +82,21 @@ def min_matches_table(min_aln_scores, max_t):
 
 
 def accumulate_device(ctx, layout, n_tasks, d_aln_read, d_aln_ref, aln_stride, d_records, d_counts, d_weights=None,
-                      min_matches=None, flags=0, stream=None):
-    """Enqueue c2_count_vectors_kernel.  d_* are device addresses; min_matches is a host uint16 table or None."""
+                      min_matches=None, flags=0, stream=None, d_hints=None):
+    """Enqueue c2_count_vectors_kernel.  d_* are device addresses; min_matches is a host uint16 table or None.
+    d_hints: the hint words the align call of the same batch wrote (BatchAligner.align_device(..., d_hints=)): a task with a valid hint is counted from
+    its hint alone (c2_count_hinted_kernel) -- same tensor, the rows of those tasks are not read back."""
     mm = None
     max_t = 0
     if min_matches is not None:
         mm = np.ascontiguousarray(min_matches, dtype=np.uint16)
         max_t = mm.shape[1] - 1
-    rc = ctx.lib.c2_count_vectors_device(
+    rc = ctx.lib.c2_count_vectors_hinted_device(
         ctx.handle, ctypes.c_uint64(n_tasks), ctypes.c_void_p(d_aln_read), ctypes.c_void_p(d_aln_ref),
-        ctypes.c_uint32(aln_stride), ctypes.c_void_p(d_records), ctypes.c_void_p(d_weights or 0),
+        ctypes.c_uint32(aln_stride), ctypes.c_void_p(d_records), ctypes.c_void_p(d_weights or 0), ctypes.c_void_p(d_hints or 0),
         mm.ctypes.data_as(ctypes.c_void_p) if mm is not None else None, int(max_t), int(flags), int(layout.hl),
         ctypes.c_void_p(d_counts), ctypes.c_void_p(stream or 0))
-    ctx.check(rc, "c2_count_vectors_device")
+    ctx.check(rc, "c2_count_vectors_hinted_device")
 
 
 def all_reduce_max(value, device):

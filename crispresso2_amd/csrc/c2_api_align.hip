@@ -645,6 +645,9 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
         A.max_score = mx;
     }
     A.phase_cycles = ctx->phase_prof ? (unsigned long long*)ctx->d_phase.p : nullptr;
+    // the batch's hint words: zero, then c2_align_partition_kernel (if the chain has it) writes the ones it has something to say about
+    A.diag_hints = b->diag_hints;
+    if (b->diag_hints) HIPCHK(ctx, hipMemsetAsync(b->diag_hints, 0, (size_t)n_tasks * sizeof(uint32_t), s));
     switch (g.R) {
         case 1: return launch_align<1>(ctx, A, g, s, b->min_read_len);
         case 2: return launch_align<2>(ctx, A, g, s, b->min_read_len);
@@ -1067,6 +1070,7 @@ int align_host_pipelined(c2_ctx* ctx, const c2_batch* b, int max_lj, uint64_t ch
         // launch chain of chunk c, after its reads arrived
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_in[k], 0));
         c2_batch d = *b;
+        d.diag_hints = nullptr;                                          // (a device-route output)
         d.n_reads = nr; d.min_read_len = min_lj;
         d.reads = (const uint8_t*)ctx->d_reads.p; d.offsets = (const uint64_t*)ctx->d_offsets.p + r0;
         d.ref_ids = (b->ref_ids && !b->all_refs) ? (const uint16_t*)ctx->d_refids.p + r0 : nullptr;

@@ -11,6 +11,13 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
                             uint32_t aln_stride, const c2_aln_record* d_records, const uint32_t* d_weights,
                             const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
                             int64_t* d_counts, void* hip_stream) {
+    return c2_count_vectors_hinted_device(ctx, n_tasks, d_aln_read, d_aln_ref, aln_stride, d_records, d_weights, nullptr, h_min_matches, max_t, flags, hl, d_counts, hip_stream);
+}
+
+int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_read, const uint8_t* d_aln_ref,
+                                   uint32_t aln_stride, const c2_aln_record* d_records, const uint32_t* d_weights, const uint32_t* d_hints,
+                                   const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
+                                   int64_t* d_counts, void* hip_stream) {
     if (!ctx || !d_aln_read || !d_aln_ref || !d_records || !d_counts) { if (ctx) ctx->err = "NULL argument"; return C2_E_INVALID; }
     if (ctx->n_refs <= 0) { ctx->err = "references must be set first"; return C2_E_STATE; }
     static_assert(C2_CNT_VECTORS == C2_COUNT_VECTORS && C2_CNT_SCALARS == C2_COUNT_SCALARS && C2_CNT_HISTS == C2_COUNT_HISTS, "count layout");
@@ -50,6 +57,15 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
     A.work_counter = (unsigned long long*)ctx->d_cnt.p;
     A.n_tasks = n_tasks; A.aln_stride = aln_stride; A.n_refs = ctx->n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
     A.order = nullptr;
+    // the batch's hint words (c2_batch.diag_hints): one reference only, and its position vectors must fit the hinted kernel's LDS block
+    A.hints = nullptr;
+    if (d_hints && ctx->n_refs == 1 && c2_count_hinted_lds_bytes(lmax) <= 65536 && !getenv("C2_NO_COUNT_HINTS")) {
+        A.hints = d_hints;
+        const size_t hl_lds = c2_count_hinted_lds_bytes(lmax);
+        const unsigned hgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_tasks + 255) / 256, (uint64_t)ctx->prop.multiProcessorCount * 4u));
+        hipLaunchKernelGGL(c2_count_hinted_kernel, dim3(hgrid), dim3(256), hl_lds, s, A);
+        HIPCHK(ctx, hipGetLastError());
+    }
     if ((flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) && (ctx->n_refs <= 1 || n_tasks % (uint64_t)ctx->n_refs != 0)) A.flags = flags & ~C2_CNT_FLAG_ALL_REFS_LAYOUT;
     if (ctx->n_refs > 1 && n_tasks < 0xFFFFFFFFull && !(A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT)) {
         // group the tasks by reference on the device (see c2_ref_histogram_kernel)

@@ -97,6 +97,7 @@ typedef struct c2_align_args {
     const struct c2_diag_row* diagpk_base; // the packed kernels' row tables, same indexing: {a, b, c} as int16 pairs, prof = LDS offset of the symbol's pair-score table
     uint32_t pk_bias;             // the 32-bit-add variant's value bias (c2_pk_add32_bias_needed); the packed-add variant uses the constant C2_PK_BIAS
     int32_t list_gate;            // full-matrix kernel in list mode: > 0: run only if the list holds at most that many tasks; < 0: only if it holds more than -list_gate; 0: always
+    uint32_t* diag_hints;         // c2_batch.diag_hints (or NULL): c2_align_partition_kernel leaves a C2_HINT_VALID word for every task it finishes itself
 } c2_align_args;
 
 // Kernel arguments for the per-call classifier (find_indels_substitutions / _legacy with full lists).
@@ -330,7 +331,13 @@ typedef struct c2_count_args {
     const uint32_t* order;        // optional: tasks grouped by reference (position -> task), else NULL = task order
     int32_t* block_scratch;       // c2_count_vectors_hbm_kernel: one int32 accumulator block per workgroup in HBM (amplicons whose block does not fit LDS)
     uint64_t block_ints;          // ... its size in ints
+    const uint32_t* hints;        // optional (one reference only): c2_batch.diag_hints of the batch -- a task with a valid hint is counted by c2_count_hinted_kernel
+                                  // from the hint word alone, c2_count_vectors_kernel skips it
 } c2_count_args;
+// LDS of c2_count_hinted_kernel: the int32 position vectors, sixteen 64-bit totals, inc_prefix
+static inline size_t c2_count_hinted_lds_bytes(int lmax) {
+    return ((size_t)C2_COUNT_VECTORS * (size_t)(lmax + 1) * sizeof(int32_t) + 15) / 16 * 16 + 16 * sizeof(uint64_t) + (((size_t)lmax + 2) * 2 + 15) / 16 * 16;
+}
 
 // ---- best-reference selection on the device (CRISPRessoCORE.py:683, :697-707, :779-785) ----
 // One lane per read over the k alignments of that read (all-references layout: task = read * n_refs + ref).

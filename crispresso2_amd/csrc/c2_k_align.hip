@@ -1905,38 +1905,50 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
         //      k = kfirst(n) .. kfirst(n) + 3; lane q takes words q * NW .. q * NW + NW - 1.  Interior cells only (k < K): the cell on a matrix
         //      edge goes through the probe below
         const int a0 = i + j - 2, par = a0 & 1, ctop = a0 & 7, W0 = a0 >> 3, n0 = (ctop >> 1) + 1;
-        unsigned wv[NW]; int cl[NW];
+        unsigned stopm = 0u;
+        int wl = 0, ncont_w = 0, ns_w = 0;
+        if (__ballot(wordp)) {                                      // (a step in which every live alignment is inside a gap run skips this)
+            int ncont = 0, ns_dec = 0;
+            bool stopped = false;
+            if (wordp) {
+                // the lane's NW words, all requested at once (a word that holds no cell of the run -- behind word 0 of the plane, or behind cell K - 1 --
+                // is read from a clamped address and not used); a word whose four cells all keep the path in M costs a mask and a compare: only the
+                // first word that does not is decoded
+                unsigned wv[NW];
 #pragma unroll
-        for (int t = 0; t < NW; ++t) {
-            const int n = q * NW + t, wi = W0 - n;
-            const int kfirst = n == 0 ? 0 : n0 + 4 * (n - 1);
-            int cells = n == 0 ? n0 : 4;
-            if (!wordp || wi < 0 || kfirst >= K) cells = 0; else if (kfirst + cells > K) cells = K - kfirst;
-            cl[t] = cells;
-            wv[t] = cells > 0 ? gW[wi * LPW + slw] : 0u;
-        }
-        int ncont = 0, ns_dec = 0;
-        bool stopped = false;
+                for (int t = 0; t < NW; ++t) { const int wi = W0 - (q * NW + t); wv[t] = gW[(wi < 0 ? 0 : wi) * LPW + slw]; }
+                unsigned wbad = 0u, m4bad = 0u; int clbad = 0, nbad = 0;
+                bool open = true;                                    // no word so far ended the lane's look
 #pragma unroll
-        for (int t = 0; t < NW; ++t) {
-            if (!stopped && cl[t] > 0) {
-                const int n = q * NW + t;
-                unsigned m4 = c2_word_m4(wv[t], par, PK);
-                if (n == 0) m4 = (m4 << (4 - n0)) & 0xfu;
-                int n_lead = __builtin_clz((((~m4) & 0xfu) << 28) | 0x08000000u);      // cells from the top that keep the path in M (4: all of them)
-                if (n_lead > cl[t]) n_lead = cl[t];
-                ncont += n_lead;
-                if (n_lead < cl[t]) {
-                    stopped = true;
-                    const int c_dec = (n == 0 ? ctop : 6 + par) - 2 * n_lead;            // the cell that ends the run
-                    const unsigned nb = c2_word_nib(wv[t], c_dec, PK);
-                    ns_dec = (nb & 2u) ? C2_ST_I : C2_ST_J;                              // "H is I" first (pyx:349-358 order); one of the two is set
+                for (int t = 0; t < NW; ++t) {
+                    const int n = q * NW + t;
+                    const int kfirst = n == 0 ? 0 : n0 + 4 * (n - 1);
+                    int cells = n == 0 ? n0 : 4;
+                    if (W0 - n < 0 || kfirst >= K) cells = 0; else if (kfirst + cells > K) cells = K - kfirst;
+                    unsigned m4 = c2_word_m4(wv[t], par, PK);
+                    if (n == 0) m4 = (m4 << (4 - n0)) & 0xfu;                          // (word 0 holds n0 cells of the run: topmost first from bit 3 on)
+                    const bool whole = cells > 0 && (m4 >> (4 - cells)) == ((1u << cells) - 1u);      // every cell of the run in this word keeps the path in M
+                    if (open) {
+                        if (whole) ncont += cells;
+                        else { open = false; wbad = wv[t]; m4bad = m4; clbad = cells; nbad = n; }
+                    }
+                }
+                if (!open && clbad > 0) {
+                    const unsigned m4 = m4bad;
+                    int n_lead = __builtin_clz((((~m4) & 0xfu) << 28) | 0x08000000u);      // cells from the top that keep the path in M (4: all of them)
+                    if (n_lead > clbad) n_lead = clbad;
+                    ncont += n_lead;
+                    if (n_lead < clbad) {
+                        stopped = true;
+                        const int c_dec = (nbad == 0 ? ctop : 6 + par) - 2 * n_lead;        // the cell that ends the run
+                        ns_dec = (c2_word_nib(wbad, c_dec, PK) & 2u) ? C2_ST_I : C2_ST_J;   // "H is I" first (pyx:349-358 order); one of the two is set
+                    }
                 }
             }
+            stopm = sub(__ballot(stopped));
+            wl = stopm ? __builtin_ctz(stopm) : 0;
+            ncont_w = __shfl(ncont, e * EL + wl); ns_w = __shfl(ns_dec, e * EL + wl);
         }
-        const unsigned stopm = sub(__ballot(stopped));
-        const int wl = stopm ? __builtin_ctz(stopm) : 0;
-        const int ncont_w = __shfl(ncont, e * EL + wl), ns_w = __shfl(ns_dec, e * EL + wl);
         int covered = n0 + 4 * (EL * NW - 1); if (covered > K) covered = K;
         // ---- any other state, and the cells on the matrix edges: lane q probes the q-th cell ahead along the current direction
         const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
@@ -1944,6 +1956,7 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
         const bool valid = probe && ik >= 1 && jk >= 1;
         int ns = 0;
         bool oob = false;
+        const bool any_probe = __ballot(probe) != 0ull;
         if (valid) {
             const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
             if (pi == 0 || pj == 0) ns = c2_boundary_hstate(pi, pj, minsc, ge, g0);      // only reachable for s == M
@@ -1956,10 +1969,15 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
                 } else oob = true;
             }
         }
-        const unsigned vm = sub(__ballot(valid)), cm = sub(__ballot(valid && ns == s)), om = sub(__ballot(oob));
-        const int nv = (~vm & (unsigned)gmask) ? __builtin_ctz(~vm & (unsigned)gmask) : EL;
-        const int nc = (~cm & (unsigned)gmask) ? __builtin_ctz(~cm & (unsigned)gmask) : EL;
-        const int ns_c = __shfl(ns, e * EL + (nc < EL ? nc : EL - 1));
+        int nv = 0, nc = 0, ns_c = 0;
+        unsigned om = 0u;
+        if (any_probe) {
+            const unsigned vm = sub(__ballot(valid)), cm = sub(__ballot(valid && ns == s));
+            om = sub(__ballot(oob));
+            nv = (~vm & (unsigned)gmask) ? __builtin_ctz(~vm & (unsigned)gmask) : EL;
+            nc = (~cm & (unsigned)gmask) ? __builtin_ctz(~cm & (unsigned)gmask) : EL;
+            ns_c = __shfl(ns, e * EL + (nc < EL ? nc : EL - 1));
+        }
         // ---- the step
         if (live) {
             int E = 0, s_next = s;
@@ -1990,7 +2008,7 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
     }
     flush();
     if (nr > C2_RUNS_MAX) nf = true;
-    const bool ok = act && !nf && status == 0;
+    const bool ok = act && !nf && status == 0 && !(A.reserved & 16);     // (16: debug knob C2_DEBUG_SKIP_EMIT -- the walk alone)
     const int TT = cnt;                                              // columns of the alignment
     if (e < NAH && q < 8) acc[q] = 0;
     __builtin_amdgcn_wave_barrier();                                 // (the run tables and the zeroed accumulators: LDS operations of one wavefront complete in order)
@@ -2653,7 +2671,7 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
             c2_phase_mark<3>(A.phase_cycles, PH);
         }
         if constexpr (!SCORE) {
-            if (m_trace) {
+            if (m_trace && !(A.reserved & 32)) {                       // (32: debug knob C2_DEBUG_SKIP_TRACE)
                 __syncthreads();
                 c2_group_epilogue<NA, PK, LPW, NL>(A, P, lane, m_trace, 0, sTab, gWords, slotWords, rows_aligned);
                 if constexpr (NA > 8) { if (m_trace >> 8) c2_group_epilogue<NA, PK, LPW, NL>(A, P, lane, m_trace, 8, sTab, gWords, slotWords, rows_aligned); }
@@ -3091,6 +3109,12 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                         rec.irregular_ends = (uint8_t)irregular;
                         A.records[c.task] = rec;
                         flag[c.slot] = 9u;
+                        if (A.diag_hints) {                         // the alignment once more, as one word (c2_batch.diag_hints): the count pass need not read the rows back
+                            unsigned h = C2_HINT_VALID | ((unsigned)k << 24);
+                            if (k > 0) h |= (unsigned)p1 | ((((unsigned)t.rd[p1] >> 1) & 7u) << 9);
+                            if (k > 1) h |= ((unsigned)p2 << 12) | ((((unsigned)t.rd[p2] >> 1) & 7u) << 21);
+                            A.diag_hints[c.task] = h;
+                        }
                     }
                 }
                 n_exact += (unsigned)__popcll(__ballot(done && q == 0));

@@ -206,7 +206,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 const uint64_t r = my_pos / nr;
                 my_task = (my_pos - r * nr) * (uint64_t)A.n_refs + r;
             }
-            const unsigned wq = A.weights ? A.weights[my_task] : 1u;
+            const unsigned wq = (A.hints && (A.hints[my_task] & C2_HINT_VALID)) ? 0u : (A.weights ? A.weights[my_task] : 1u);   // (a hinted task: c2_count_hinted_kernel's)
             v_w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
             if (v_w > 0) {                                               // (an alignment that is not counted is not even read: most of an all-references batch)
                 const unsigned* rp = (const unsigned*)(A.records + my_task);
@@ -747,3 +747,128 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
 
 __global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vectors_kernel(c2_count_args A) { c2_count_vectors_body<false>(A); }
 __global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vectors_hbm_kernel(c2_count_args A) { c2_count_vectors_body<true>(A); }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// c2_count_hinted_kernel (round 6): the tasks whose alignment c2_align_partition_kernel finished itself -- the read on its reference's main diagonal,
+// at most two differing bases: 58 % of the headline batch -- counted from their HINT WORD alone (c2_batch.diag_hints), a lane per task: neither the
+// 2 x 250 bytes of strings nor the record are read back.  One reference (the host checks).  What such an alignment adds (CRISPRessoCORE.py:3996-4115,
+// the same statements c2_count_vectors_body executes for a gap-free alignment): its weight w to the scalars and histogram bins of its class -- kept
+// in 64-bit registers per lane over the lane's ~40 tasks, reduced once per wavefront at the end --, w on the base vector of the reference's own base
+// at every position (the sum over all tasks, spread at the end), and per differing base the deviations (+w on the read's base, -w on the reference's,
+// the substitution vectors) as int32 LDS atomics, flushed before anything can wrap (a weight of 65,536 or more goes to the tensor directly).
+// ---------------------------------------------------------------------------------------------------------------
+#define C2_HCNT_SMALL_W 65536                  // weights below this accumulate in the LDS block ...
+#define C2_HCNT_FLUSH_ROUNDS 64                // ... which is flushed every so many rounds of 256 tasks: 64 x 256 x 2 deviations x 65,535 < 2^31
+__global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
+{
+    typedef unsigned long long u64;
+    const int tid = threadIdx.x;
+    const int VL = A.lmax + 1, NV = C2_CNT_VECTORS * VL;
+    int* acc = (int*)c2_smem;
+    u64* tot = (u64*)(c2_smem + ((size_t)NV * sizeof(int) + 15) / 16 * 16);
+    uint16_t* incp = (uint16_t*)(tot + 16);
+    const c2_dev_ref rf = A.refs[0];
+    const int Li = rf.len;
+    const int o_sc = NV, o_h = o_sc + C2_CNT_SCALARS;
+    for (int k = tid; k < NV; k += 256) acc[k] = 0;
+    if (tid < 16) tot[tid] = 0ull;
+    for (int k = tid; k < Li + 2; k += 256) incp[k] = rf.inc_prefix[k];
+    __syncthreads();
+    const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS, ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS;
+    // the selection test of CRISPRessoCORE.py:697 for an alignment of Li columns with Li - k matches
+    bool gate = Li > 0;
+    int thresh = 0;
+    if (A.min_matches) { if (Li > A.max_t) gate = false; else thresh = (int)A.min_matches[Li]; }
+    long long* out = A.counts;
+    auto flush = [&]() {
+        __syncthreads();
+        for (int k = tid; k < NV; k += 256) { const int x = acc[k]; if (x != 0) { atomicAdd((u64*)(out + k), (u64)(long long)x); acc[k] = 0; } }
+        __syncthreads();
+    };
+    u64 sW = 0, sN = 0, sSubW = 0, sGsub = 0, sOut = 0, sIn = 0, sIrr = 0, sH0 = 0, sH1 = 0, sH2 = 0;
+    const u64 chars = (u64)'A' | ((u64)'C' << 8) | ((u64)'T' << 16) | ((u64)'G' << 24) | ((u64)'N' << 56);      // indexed by (ch >> 1) & 7
+    unsigned rounds = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < A.n_tasks; base += (uint64_t)gridDim.x * 256u) {
+        const uint64_t t = base + (uint64_t)tid;
+        unsigned h = 0;
+        if (t < A.n_tasks) h = A.hints[t];
+        if (h & C2_HINT_VALID) {
+            const unsigned wq = A.weights ? A.weights[t] : 1u;
+            const int w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
+            const int k = (int)((h >> 24) & 3u);
+            if (w > 0 && gate && Li - k >= thresh) {
+                int all_sub = 0, sub_n = 0, irregular = 0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (e >= k) continue;
+                    const int c = (int)((h >> (12 * e)) & 0x1ffu);
+                    const unsigned char rd = (unsigned char)(chars >> (8 * ((h >> (12 * e + 9)) & 7u)));
+                    const unsigned char rfc = rf.seq[c];
+                    const bool big = w >= C2_HCNT_SMALL_W;
+                    auto add = [&](const int idx, const int x) {
+                        if (!big) atomicAdd(acc + idx, x);
+                        else atomicAdd((u64*)(out + idx), (u64)(long long)x);
+                    };
+                    const int bvr = c2_base_vector(rd), bvf = c2_base_vector(rfc);
+                    if (bvr >= 0) add(bvr * VL + c, w);
+                    if (bvf >= 0) add(bvf * VL + c, -w);
+                    if (rd != 'N') {                                                       // COREResources.pyx:113-118
+                        ++all_sub;
+                        add(C2_V_ALL_SUBSTITUTION * VL + c, w);                            // :4040
+                        const bool in_win = incp[c + 1] != incp[c];
+                        if (in_win) ++sub_n;
+                        if (!ign_sub) {
+                            if (in_win) add(C2_V_SUBSTITUTION * VL + c, w);                // :4044
+                            const int sv = c2_sub_base_vector(rd);                         // :4049-4054
+                            if (sv >= 0) add(sv * VL + c, w);
+                        }
+                    }
+                    if (c == 0 || c == Li - 1) irregular = 1;
+                }
+                const u64 W = (u64)(unsigned)w;
+                sW += W; sN += 1ull;
+                if (!ign_sub && sub_n > 0) sSubW += W;
+                sGsub += W * (u64)all_sub; sOut += W * (u64)(all_sub - sub_n); sIn += W * (u64)sub_n;
+                if (irregular) sIrr += W;
+                if (sub_n == 0) sH0 += W; else if (sub_n == 1) sH1 += W; else sH2 += W;
+            }
+        }
+        if ((++rounds % C2_HCNT_FLUSH_ROUNDS) == 0u) flush();
+    }
+    flush();
+    // the lanes' totals -> the wavefront's -> the workgroup's (LDS, 64-bit) -> the tensor
+    u64 v[10] = {sW, sN, sSubW, sGsub, sOut, sIn, sIrr, sH0, sH1, sH2};
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        unsigned lo = (unsigned)v[q], hi = (unsigned)(v[q] >> 32);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned olo = (unsigned)__shfl_xor((int)lo, d), ohi = (unsigned)__shfl_xor((int)hi, d);
+            const u64 sum = ((u64)hi << 32 | lo) + ((u64)ohi << 32 | olo);
+            lo = (unsigned)sum; hi = (unsigned)(sum >> 32);
+        }
+        if ((tid & 63) == 0) atomicAdd(tot + q, ((u64)hi << 32) | lo);
+    }
+    __syncthreads();
+    const u64 W = tot[0];
+    if (W == 0ull && tot[1] == 0ull) return;
+    auto gadd = [&](const int idx, const u64 x) { if (x) atomicAdd((u64*)(out + idx), x); };
+    if (tid == 0) {
+        const u64 subw = tot[2];
+        gadd(o_sc + C2_S_TOTAL, W); gadd(o_sc + C2_S_MODIFIED, subw); gadd(o_sc + C2_S_UNMODIFIED, W - subw);      // :746-760, :4003-4006
+        gadd(o_sc + C2_S_SUBSTITUTION, subw); gadd(o_sc + C2_S_ONLY_SUBSTITUTION, subw);                             // :4058-4072
+        gadd(o_sc + C2_S_N_GLOBAL_SUBS, tot[3]); gadd(o_sc + C2_S_N_SUBS_OUTSIDE_WINDOW, tot[4]);
+        gadd(o_sc + C2_S_N_MODS_IN_WINDOW, tot[5]); gadd(o_sc + C2_S_N_MODS_OUTSIDE_WINDOW, tot[4]);                 // :741-742
+        gadd(o_sc + C2_S_N_READS_IRREGULAR_ENDS, tot[6]); gadd(o_sc + C2_S_ALIGNMENTS_COUNTED, tot[1]);
+        if (!ign_ins) gadd(o_h + C2_H_INSERTED_N * A.hl + 0, W);                                                     // :4020
+        if (!ign_del) gadd(o_h + C2_H_DELETED_N * A.hl + 0, W);                                                      // :4030
+        if (!ign_sub) { gadd(o_h + C2_H_SUBSTITUTED_N * A.hl + 0, tot[7]); gadd(o_h + C2_H_SUBSTITUTED_N * A.hl + 1, tot[8]); gadd(o_h + C2_H_SUBSTITUTED_N * A.hl + 2, tot[9]); }   // :4043
+        gadd(o_h + C2_H_EFFECTIVE_LEN * A.hl + Li, W);                                                               // :4010-4037
+    }
+    // every reference position: the tasks' total weight on the vector of its own base (the deviations above took the differing ones back)
+    for (int c = tid; c < Li; c += 256) {
+        const int bv = c2_base_vector(rf.seq[c]);
+        if (bv >= 0) gadd(bv * VL + c, W);
+    }
+}

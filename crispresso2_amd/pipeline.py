@@ -584,7 +584,8 @@ class _UniqueRun:
     def _count_launches(self, d_out, d_w1, d_w2, flags):
         """the count kernel over batch 1 (all-references layout) and batch 2 with the given weights, into d_out"""
         C.accumulate_device(self.ctx, self.layout, self.n1, self.a1.data_ptr(), self.f1.data_ptr(), self.stride, self.r1.data_ptr(), d_out.data_ptr(),
-                            d_weights=d_w1.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=self.stream)
+                            d_weights=d_w1.data_ptr(), flags=flags | C.FLAG_ALL_REFS_LAYOUT, stream=self.stream,
+                            d_hints=None if getattr(self, "h1", None) is None else self.h1.data_ptr())
         if self.n2 and d_w2 is not None:
             C.accumulate_device(self.ctx, self.layout, self.n2, self.a2.data_ptr(), self.f2.data_ptr(), self.stride2, self.r2.data_ptr(), d_out.data_ptr(),
                                 d_weights=d_w2.data_ptr(), flags=flags, stream=self.stream)
@@ -766,6 +767,7 @@ class _UniqueRun:
             # seed test and batch 1 ran chunk by chunk while the file was parsed / uploaded
             f = self.front
             self.plan, self.stride, self.a1, self.f1, self.r1 = f["plan"], f["stride"], f["a1"], f["f1"], f["r1"]
+            self.h1 = None                                           # (batches enqueued under the upload: no hint words)
         else:
             # on the device, over the reads that were just sent there (FORCE_HOST_STRAND_PLAN: the host's threaded c2_strand_plan instead --
             # the tests compare the two)
@@ -782,9 +784,11 @@ class _UniqueRun:
             self.a1 = torch.empty((self.n1, self.stride), dtype=torch.uint8, device=dev)
             self.f1 = torch.empty((self.n1, self.stride), dtype=torch.uint8, device=dev)
             self.r1 = torch.empty((self.n1, 32), dtype=torch.uint8, device=dev)
+            # one amplicon: the hint words of the reads the partition finishes itself (c2_batch.diag_hints) -- the count pass takes those from the word alone
+            self.h1 = torch.empty(self.n1, dtype=torch.int32, device=dev) if (k == 1 and self.n1) else None
             self.aligner.align_device(n, self.d_reads.data_ptr(), self.d_off.data_ptr(), self.a1.data_ptr(), self.f1.data_ptr(), self.r1.data_ptr(),
                                       self.stride, self.max_lj, d_strands=d_str1.data_ptr(), all_refs=True, stream=self.stream, legacy=self.legacy,
-                                      min_read_len=int(self.lens.min()) if n else 0)
+                                      min_read_len=int(self.lens.min()) if n else 0, d_hints=None if self.h1 is None else self.h1.data_ptr())
         self.lap("h2d_align")
 
     def align_both_strands(self):

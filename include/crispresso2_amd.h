@@ -28,7 +28,9 @@ extern "C" {
 /* 2: struct c2_batch grew by `min_read_len` (round 4).  A caller built against version 1 passes the shorter struct: check c2_abi_version()
  * against the header you compiled with before the first batch call.  Zero-initialise every struct c2_batch you fill in; fields added later
  * are hints whose zero means "not known". */
-#define C2_ABI_VERSION 2
+#define C2_ABI_VERSION 3
+/* 3: struct c2_batch grew by `diag_hints` (round 6), c2_partition_info writes 7 class counts (since round 5; it wrote 5 under ABI 1), new entry
+ * c2_count_vectors_hinted_device. */
 
 /* error codes */
 #define C2_E_INVALID   -1   /* bad argument */
@@ -120,8 +122,15 @@ typedef struct c2_batch {
     int32_t min_read_len;      /* shortest read of the batch, or 0 = not known.  A hint that never changes results: a band tier of the launch chain
                                   that no read of [min_read_len, max_read_len] against any reference can use (|len(ref) - len(read)| outside its band, e.g.
                                   150-bp mates against a 250-bp amplicon) is not launched instead of being passed through task by task */
+    uint32_t* diag_hints;      /* optional output (DEVICE path only; NULL = none), n_tasks words: 0, or C2_HINT_VALID | a summary of an alignment that is its reference's main
+                                  diagonal with at most two differing bases -- what c2_align_partition_kernel finishes without a matrix (round 5).  A hint restates
+                                  the aligned strings and the record of its task (it IS derived from them), so that the count pass need not read them back:
+                                  c2_count_vectors_hinted_device.  Every word is written (0 where there is nothing to say). */
 } c2_batch;
 #define C2_BATCH_LEGACY_CLASSIFIER 1u
+/* a hint word: bit 31 valid | bits 24..25 differing bases k (0, 1, 2) | first: position bits 0..8, read base bits 9..11 | second: position bits 12..20, read base
+ * bits 21..23; read bases as codes 0..4 = A C G T N.  The alignment: aln_len = matches + k = len(reference) = len(read), both strings without a gap. */
+#define C2_HINT_VALID 0x80000000u
 
 /* All pointers in `b` are DEVICE pointers; the launch is enqueued on `hip_stream` (a hipStream_t; NULL is HIP's
  * default stream, exactly as in hipLaunchKernelGGL) and the call returns without waiting. */
@@ -169,6 +178,14 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
                             uint32_t aln_stride, const c2_aln_record* d_records, const uint32_t* d_weights,
                             const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
                             int64_t* d_counts, void* hip_stream);
+/* The same with the hints of the batch (c2_batch.diag_hints of the call that wrote d_records; NULL = c2_count_vectors_device): a task with a valid hint is
+ * counted from its hint word alone -- c2_count_hinted_kernel, a lane per task, neither its record nor its strings are read -- and the kernel above skips it.
+ * The tensor is the same either way (CRISPRessoCORE.py:3996-4115 semantics; tests/test_counts_emulated.py, tests/test_gpu_parity.py).  The hints are used for a
+ * context with ONE reference; with several they are ignored. */
+int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_read, const uint8_t* d_aln_ref,
+                                   uint32_t aln_stride, const c2_aln_record* d_records, const uint32_t* d_weights, const uint32_t* d_hints,
+                                   const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
+                                   int64_t* d_counts, void* hip_stream);
 
 /* ---- Alleles_frequency_table on the device (second half) ----------------------------------------------------
  * Replaces the reference's per-variant Python loop that fills alleles_list (CRISPRessoCORE.py:3964-4010: one row per unique read and

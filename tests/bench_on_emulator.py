@@ -39,16 +39,18 @@ class _Aligner(EmulatedAligner):
         self.ctx = ctx
 
     def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
-                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0):
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0, d_hints=None):
         n, k = int(n_reads), len(self.seqs)
         off = _view(d_offsets, 8 * (n + 1)).view(np.int64)
         arena = _view(d_reads, max(int(off[-1]), 1)).tobytes()
         reads = [arena[int(off[i]):int(off[i + 1])].decode() for i in range(n)]
         ntasks = n * k if all_refs else n
         rids = None if d_ref_ids is None else _view(d_ref_ids, 2 * n).view(np.int16).astype(np.uint16)
-        st = {}
+        st = {"want_hints": bool(d_hints)}
         _, rec = E.align_batch(reads, self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=rids, all_refs=all_refs,
                                band_lanes=-87 if self.ctx.mode == "auto" else 0, stats=st)
+        if d_hints:
+            _view(d_hints, 4 * ntasks).view(np.uint32)[:] = st["hints"]
         o1, o2 = st["raw"]
         w = min(o1.shape[1], aln_stride)
         a = _view(d_aln_read, ntasks * aln_stride).reshape(ntasks, aln_stride)

@@ -28,6 +28,12 @@ unsigned emu_last_exact_copies() { return g_last_classes ? g_last_classes[7] : 0
 int emu_last_pk_beta() { return g_last_pk_beta; }
 int emu_last_pk_bias() { return g_last_pk_bias; }
 
+// c2_batch.diag_hints of the NEXT emu_align_batch (n_tasks words, or NULL); c2_count_args.hints of the NEXT emu_count_vectors
+static uint32_t* g_next_hints_out = nullptr;
+static const uint32_t* g_next_count_hints = nullptr;
+void emu_set_hints_out(uint32_t* p) { g_next_hints_out = p; }
+void emu_set_count_hints(const uint32_t* p) { g_next_count_hints = p; }
+
 int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offsets, const uint16_t* ref_ids,
                     const uint8_t* strands, int all_refs,
                     int n_refs, const char* const* seqs, const int32_t* lens, const int64_t* const* gap_inc,
@@ -92,6 +98,9 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     int max_lj = 1;
     for (uint64_t k = 0; k < n_reads; ++k) max_lj = std::max<int>(max_lj, (int)(offsets[k + 1] - offsets[k]));
     const int R = force_R ? force_R : c2_choose_rows_per_lane(max_li);
+    uint32_t* hints = g_next_hints_out;
+    g_next_hints_out = nullptr;
+    if (hints) memset(hints, 0, (size_t)(n_reads * (uint64_t)(all_refs ? n_refs : 1)) * sizeof(uint32_t));     // (the library's hipMemsetAsync)
     c2_align_args A;
     A.reads = reads; A.offsets = offsets; A.ref_ids = ref_ids; A.strands = strands; A.refs = refs.data();
     A.score_tbl = sc.tbl.data(); A.code_of_char = sc.code_of_char;
@@ -123,7 +132,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     std::vector<uint32_t> fb_list2(A.n_tasks ? A.n_tasks : 1), fb_list3(A.n_tasks ? A.n_tasks : 1), fb_list4(A.n_tasks ? A.n_tasks : 1);   // (the full-plane launch below reads the last tier's)
     uint32_t fb_counts[5] = {0, 0, 0, 0, 0};
     std::vector<uint32_t> plane;
-    A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)pk_beta; A.pk_bias = (uint32_t)pk_bias; A.list_gate = 0;
+    A.plane = nullptr; A.plane_words_per_wg = 0; A.pk_beta = (uint32_t)pk_beta; A.pk_bias = (uint32_t)pk_bias; A.list_gate = 0; A.diag_hints = hints;
     A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0; A.legacy = getenv("C2_EMU_LEGACY") ? 1 : 0;
     A.mat_dim = sc.mat_dim; A.first_ext_code = sc.first_ext_code;
     c2_build_base_luts(sc, A.lut_code_lo, A.lut_code_hi, A.lut_chr_lo, A.lut_chr_hi);
@@ -429,6 +438,12 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     A.aln_read = aln_read; A.aln_ref = aln_ref; A.records = records; A.weights = weights; A.min_matches = min_matches;
     A.refs = refs.data(); A.counts = counts; A.work_counter = &wc; A.n_tasks = n_tasks; A.aln_stride = aln_stride;
     A.n_refs = n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
+    A.hints = nullptr; A.order = nullptr; A.block_scratch = nullptr; A.block_ints = 0;
+    if (g_next_count_hints && n_refs == 1) {                         // (c2_count_vectors_hinted_device: the hinted tasks first, by their own kernel)
+        A.hints = g_next_count_hints;
+        emu::launch(grid ? grid : 2, [&] { c2_count_hinted_kernel(A); }, 256);
+    }
+    g_next_count_hints = nullptr;
     // tasks grouped by reference, as the host library does for more than one reference
     std::vector<uint32_t> hist(n_refs + 1, 0), order(n_tasks ? n_tasks : 1);
     A.order = nullptr;

@@ -73,6 +73,10 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
     rec = np.zeros(ntasks, dtype=REC_DTYPE)
     rid = None if ref_ids is None else np.ascontiguousarray(ref_ids, dtype=np.uint16)
     st = None if strands is None else np.ascontiguousarray(strands, dtype=np.uint8)
+    hints = None
+    if stats is not None and stats.get("want_hints"):                # c2_batch.diag_hints: one word per task
+        hints = np.full(ntasks, 0xdeadbeef, dtype=np.uint32)
+        lib().emu_set_hints_out(hints.ctypes.data_as(ctypes.c_void_p))
     nfb = ctypes.c_int(0)
     rc = lib().emu_align_batch(
         ctypes.c_uint64(n), arena, offs.ctypes.data_as(ctypes.c_void_p),
@@ -99,6 +103,8 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
         out.append((o1[k, :L].tobytes().decode(), o2[k, :L].tobytes().decode()))
     if stats is not None:
         stats["raw"] = (o1, o2)
+        if hints is not None:
+            stats["hints"] = hints
     return out, rec
 
 
@@ -175,7 +181,7 @@ def consensus_pairs(items):
              int(info[k, 2]), bool(info[k, 3] & 1), bool(info[k, 3] & 2)) for k in range(n)]
 
 
-def count_vectors(aln_read, aln_ref, records, ref_seqs, includes, max_read_len, weights=None, min_matches=None, flags=0, grid=2):
+def count_vectors(aln_read, aln_ref, records, ref_seqs, includes, max_read_len, weights=None, min_matches=None, flags=0, grid=2, hints=None):
     """aln_read/aln_ref: uint8 [n, stride]; records: REC_DTYPE [n]; ref_seqs: the reference strings.
     -> (counts int64 [n_refs, per_ref], layout)"""
     ref_lens = [len(x) for x in ref_seqs]
@@ -194,6 +200,10 @@ def count_vectors(aln_read, aln_ref, records, ref_seqs, includes, max_read_len, 
     w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
     mm = None if min_matches is None else np.ascontiguousarray(min_matches, dtype=np.uint16)
     a1 = np.ascontiguousarray(aln_read); a2 = np.ascontiguousarray(aln_ref); rec = np.ascontiguousarray(records)
+    hw = None
+    if hints is not None:                                            # c2_count_vectors_hinted_device
+        hw = np.ascontiguousarray(hints, dtype=np.uint32)
+        lib().emu_set_count_hints(hw.ctypes.data_as(ctypes.c_void_p))
     rc = lib().emu_count_vectors(ctypes.c_uint64(n), a1.ctypes.data_as(ctypes.c_void_p), a2.ctypes.data_as(ctypes.c_void_p),
                                  ctypes.c_uint32(a1.shape[1]), rec.ctypes.data_as(ctypes.c_void_p),
                                  None if w is None else w.ctypes.data_as(ctypes.c_void_p),

@@ -31,7 +31,7 @@ class EmulatedAligner:
         return (self.max_ref_len + int(max_read_len) + 15) // 16 * 16
 
     def align_device(self, n_reads, d_reads, d_offsets, d_aln_read, d_aln_ref, d_records, aln_stride, max_read_len,
-                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0):
+                     d_ref_ids=None, d_strands=None, all_refs=False, stream=None, legacy=False, min_read_len=0, d_hints=None):
         import os
         if legacy:
             os.environ["C2_EMU_LEGACY"] = "1"
@@ -44,9 +44,11 @@ class EmulatedAligner:
         ntasks = n * k if all_refs else n
         strands = None if d_strands is None else _view(d_strands, ntasks).copy()
         rids = None if d_ref_ids is None else _view(d_ref_ids, 2 * n).view(np.int16).astype(np.uint16)
-        st = {}
+        st = {"want_hints": bool(d_hints)}
         _, rec = E.align_batch(reads, self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=rids, strands=strands,
                                all_refs=all_refs, band_lanes=-87, stats=st)
+        if d_hints:
+            _view(d_hints, 4 * ntasks).view(np.uint32)[:] = st["hints"]
         o1, o2 = st["raw"]
         w = min(o1.shape[1], aln_stride)
         assert int(rec["aln_len"].max()) <= w
@@ -117,14 +119,15 @@ class EmulatedContext:
 
 def _accumulate(aligners):
     def accumulate_device(ctx, layout, n_tasks, d_aln_read, d_aln_ref, aln_stride, d_records, d_counts, d_weights=None,
-                          min_matches=None, flags=0, stream=None):
+                          min_matches=None, flags=0, stream=None, d_hints=None):
         al = aligners[-1]
         a = _view(d_aln_read, n_tasks * aln_stride).reshape(n_tasks, aln_stride)
         f = _view(d_aln_ref, n_tasks * aln_stride).reshape(n_tasks, aln_stride)
         rec = _view(d_records, 32 * n_tasks).view(E.REC_DTYPE).reshape(-1)
         w = None if not d_weights else _view(d_weights, 4 * n_tasks).view(np.uint32).copy()
+        hints = None if not d_hints else _view(d_hints, 4 * n_tasks).view(np.uint32).copy()
         counts, lay = E.count_vectors(a, f, rec, al.seqs, al.inc, layout.hl - layout.lmax - 2,
-                                      weights=w, min_matches=min_matches, flags=flags)
+                                      weights=w, min_matches=min_matches, flags=flags, hints=hints)
         assert lay.shape() == layout.shape(), (lay.shape(), layout.shape())
         n64 = int(np.prod(layout.shape()))
         _view(d_counts, 8 * n64).view(np.int64)[:] += counts.reshape(-1)

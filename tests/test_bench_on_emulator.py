@@ -22,6 +22,8 @@ def test_bench_line_on_the_emulator(config, reads, steps, extra):
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["one_proc_reads_per_s"] > 0 and len(cb["curve"]) >= 2
     assert sum(c["reads_aligned_all_gpus"] for c in out["counts"]) > 0
+    if config in (2, 3):                                             # one amplicon: the step counts the partition-finished reads from their hint words
+        assert ck["count_tensor_equals_without_hints"] is True and ck["hinted_tasks"] > 0
     if config in (2, 3):                                             # the dedup-on leg: unique reads + multiplicities give the same count tensor
         d = out["dedup_on"]
         assert d and 0 < d["unique_reads"] <= reads and d["count_tensor_equals_dedup_off"] and d["reads_per_s"] > 0

@@ -358,3 +358,59 @@ def test_gap_free_alignments_eight_at_a_time(L):
     b1[:] = a1
     counts2, _ = count_vectors_raw(b1, a2, rec, [amp], [inc], L, w)
     assert np.array_equal(counts, counts2)
+
+
+@pytest.mark.parametrize("flags", [0, C.FLAG_IGNORE_SUBSTITUTIONS, C.FLAG_IGNORE_INSERTIONS | C.FLAG_IGNORE_DELETIONS, C.FLAG_DISCARD_INDEL_READS])
+@pytest.mark.parametrize("L", [250, 151])
+def test_hinted_tasks_are_counted_from_their_hint_word_alone(L, flags):
+    """Round 6: c2_align_partition_kernel leaves a hint word for every read it finishes itself (main diagonal, at most two
+    differing bases) -- c2_batch.diag_hints --, and c2_count_vectors_hinted_device counts those tasks from the word alone (c2_count_hinted_kernel:
+    neither the rows nor the record are read), the others as ever.  The tensor equals the one without hints entry by entry, and the reference's
+    aggregation loop (oracle/aggregate.py) -- with weights incl. 0, one above the LDS limit (70,000) and one above 2^31 (clamped, as the kernel clamps),
+    differing bases in and outside the window, at both ends, N's, and with the score gate at a value that two differing bases fail."""
+    E.build()
+    m = matrices()["EDNAFULL"]
+    rng = np.random.default_rng(4200 + L)
+    amp = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = list(range(L // 2 - 8, L // 2 + 8))
+    other = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    sub = lambda s_, q, c=None: s_[:q] + (c or other[s_[q]]) + s_[q + 1:]
+    reads = [amp] * 5
+    for q in (0, 1, L // 2 - 9, L // 2 - 8, L // 2, L // 2 + 7, L // 2 + 8, L - 2, L - 1, 33):
+        reads += [sub(amp, q), sub(amp, q, "N")]
+    reads += [sub(sub(amp, 0), L - 1), sub(sub(amp, L // 2), L // 2 + 1), sub(sub(amp, L // 2 - 1, "N"), L // 2 + 2), sub(sub(amp, 10), 200 % L, "N"),
+              sub(sub(amp, L // 2 - 30), L // 2 + 3), sub(sub(sub(amp, 5), 50), 100)]
+    reads += [amp[:L // 2] + amp[L // 2 + 4:] + "ACGT", amp[:L // 2] + "TG" + amp[L // 2:-2], amp[:-3]]      # not on the main diagonal
+    reads += [reads[int(k)] for k in rng.integers(0, len(reads), 300)]
+    st = {"want_hints": True}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    o1, o2 = st["raw"]
+    hints = st["hints"]
+    n_hinted = int((hints >> 31).sum())
+    assert n_hinted == st["exact_copies"] > 200 and (hints[(hints >> 31) == 0] == 0).all()        # every word is written: 0 where there is nothing to say
+    for k in np.nonzero(hints >> 31)[0][:60]:                             # a hint restates its alignment
+        kk = int((hints[k] >> 24) & 3)
+        diff = [c for c in range(L) if reads[k][c] != amp[c]]
+        assert len(reads[k]) == L and kk == len(diff) and int(rec[k]["aln_len"]) == L and int(rec[k]["matches"]) == L - kk
+        for e, c in enumerate(diff):
+            assert int((hints[k] >> (12 * e)) & 0x1ff) == c and "ACTG???N"[int((hints[k] >> (12 * e + 9)) & 7)] == reads[k][c]
+    w = rng.integers(1, 50, len(reads)).astype(np.uint32)
+    w[::11] = 0
+    w[3] = 70000                                                          # (above c2_count_hinted_kernel's LDS limit: straight to the tensor)
+    w[7] = 0x90000000                                                     # (clamped to 2^31 - 1 by both kernels)
+    for mm in (None, C.min_matches_table([99.3], L + L)):                 # 99.3: two differing bases of 250 (99.2) fail, one (99.6) passes
+        plain, lay = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w, min_matches=mm, flags=flags)
+        hinted, _ = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w, min_matches=mm, flags=flags, hints=hints)
+        assert np.array_equal(plain, hinted), np.nonzero(plain != hinted)
+        # ... and with the rows of the hinted tasks wiped: they are not read
+        w1, w2 = o1.copy(), o2.copy()
+        w1[(hints >> 31) == 1] = 0x58; w2[(hints >> 31) == 1] = 0x59
+        wiped, _ = E.count_vectors(w1, w2, rec, [amp], [inc], L, weights=w, min_matches=mm, flags=flags, hints=hints)
+        assert np.array_equal(plain, wiped)
+    got = lay.unpack(hinted, 0, L)
+    thr = 99.3
+    items = [(p, int(min(c, 0x7fffffff))) for p, c, r in zip(payloads(res, inc), w, rec) if c > 0 and round(100 * int(r["matches"]) / float(int(r["aln_len"])), 3) > thr]
+    exp = aggregate.aggregate(items, L, ignore_substitutions=bool(flags & 1), ignore_insertions=bool(flags & 2),
+                              ignore_deletions=bool(flags & 4), discard_indel_reads=bool(flags & 8))
+    compare(got, exp, L)

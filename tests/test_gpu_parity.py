@@ -1361,3 +1361,65 @@ def test_ragged_and_unrelated_reads_and_the_full_matrix_launch_with_its_plane_in
         other = al.align(reads)
         monkeypatch.delenv(knob)
         assert np.array_equal(other.records, res.records) and np.array_equal(other.aln_read, res.aln_read) and np.array_equal(other.aln_ref, res.aln_ref), knob
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [250, 150])
+def test_gpu_hinted_count_equals_the_count_over_the_rows(mats, ctx, L):
+    """Round 6: c2_batch.diag_hints + c2_count_vectors_hinted_device on the hardware.  60,000 synthetic reads (a third of them copies of the amplicon or one /
+    two bases away: finished by the partition, hinted) with weights (0, small, above the hinted kernel's LDS limit, above 2^31): the count tensor with
+    the hints equals the tensor without them entry by entry -- with no gate and with a gate two differing bases fail, with and without
+    --ignore_substitutions --, also after the rows of the hinted tasks were overwritten (they are not read); every hint restates its record."""
+    import torch
+    from crispresso2_amd import synth, _native, counts as C
+    from crispresso2_amd.batch import BatchAligner
+    m = mats["EDNAFULL"]
+    n = 60000
+    amp, g, inc = synth.amplicon_setup(L)
+    reads = synth.make_reads(L, n)
+    al = BatchAligner([amp], [g], [inc], m, -20, -2, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    stride = al.stride_for(L)
+    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    o1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    o2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    rec = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    hints = torch.full((n,), 0x5a5a5a5a, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, L, stream=s, d_hints=hints.data_ptr())
+    torch.cuda.synchronize()
+    h = hints.cpu().numpy().view(np.uint32)
+    records = rec.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+    valid = (h >> 31) == 1
+    assert valid.sum() == ctx.partition_info()["finished_by_partition"] > n // 4 and (h[~valid] == 0).all()
+    kk = ((h >> 24) & 3)[valid]
+    assert (records["aln_len"][valid] == L).all() and (records["matches"][valid].astype(np.int64) + kk == L).all()
+    amp_u8 = np.frombuffer(amp.encode(), dtype=np.uint8)
+    for t in np.nonzero(valid)[0][:2000]:                            # positions and read bases of the differing columns
+        diff = np.nonzero(reads[t] != amp_u8)[0]
+        assert len(diff) == int((h[t] >> 24) & 3)
+        for e, c in enumerate(diff):
+            assert int((h[t] >> (12 * e)) & 0x1ff) == c and ord("ACTG???N"[int((h[t] >> (12 * e + 9)) & 7)]) == reads[t][c]
+    rng = np.random.default_rng(5)
+    w = rng.integers(0, 40, n).astype(np.uint32)
+    first = np.nonzero(valid)[0]
+    w[first[0]] = 70000; w[first[1]] = 0x90000000; w[first[2]] = 65536; w[first[3]] = 65535
+    d_w = torch.from_numpy(w.view(np.int32)).to(dev)
+    layout = C.CountLayout(1, L, L)
+
+    def count(a, f, use_hints, mm, flags):
+        t = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
+        C.accumulate_device(ctx, layout, n, a.data_ptr(), f.data_ptr(), stride, rec.data_ptr(), t.data_ptr(), d_weights=d_w.data_ptr(), min_matches=mm,
+                            flags=flags, stream=s, d_hints=hints.data_ptr() if use_hints else None)
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+    w1, w2 = o1.clone(), o2.clone()
+    vt = torch.from_numpy(valid).to(dev)
+    w1[vt] = 0x58; w2[vt] = 0x59
+    for mm in (None, C.min_matches_table([99.3], L + L)):
+        for flags in (0, C.FLAG_IGNORE_SUBSTITUTIONS, C.FLAG_DISCARD_INDEL_READS):
+            plain = count(o1, o2, False, mm, flags)
+            assert plain.sum() > 0
+            assert np.array_equal(plain, count(o1, o2, True, mm, flags)), (L, mm is None, flags)
+            assert np.array_equal(plain, count(w1, w2, True, mm, flags)), (L, mm is None, flags)
