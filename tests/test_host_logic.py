@@ -22,7 +22,7 @@ def test_library_exports_every_symbol_declared_in_the_header():
     for sym in declared:
         assert hasattr(lib, sym), "header declares %s but the library does not export it" % sym
     assert set(_native.SYMBOLS) <= declared
-    assert lib.c2_abi_version() == 2 == _native.ABI_VERSION
+    assert lib.c2_abi_version() == 3 == _native.ABI_VERSION
 
 
 def test_no_device_means_loud_failure_not_a_fallback():
@@ -53,8 +53,8 @@ def test_record_struct_layout_matches_numpy_dtype():
     from crispresso2_amd import _native
     assert _native.REC_DTYPE.itemsize == 32
     assert _native.REC_DTYPE.fields["status"][1] == 23 and _native.REC_DTYPE.fields["ref_id"][1] == 26
-    assert ctypes.sizeof(_native.Batch) == 88                         # (struct c2_batch: 80 bytes + min_read_len, padded to 8)
-    assert _native.Batch.min_read_len.offset == 80
+    assert ctypes.sizeof(_native.Batch) == 96                         # (struct c2_batch: 80 bytes + min_read_len, padded to 8, + diag_hints: ABI 3)
+    assert _native.Batch.min_read_len.offset == 80 and _native.Batch.diag_hints.offset == 88
 
 
 def test_read_matrix_and_make_matrix():
