@@ -1899,8 +1899,15 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
         const bool bnd = live && (i == 0 || j == 0);
         const int K = (i < j ? i : j) - 1;
         const int slw = (i - j - d0) >> 1;
-        const bool wordp = live && !bnd && s == C2_ST_M && K >= 1 && (unsigned)slw < (unsigned)NL;
-        const bool probe = live && !bnd && !wordp;
+        bool wordp = live && !bnd && s == C2_ST_M && K >= 1 && (unsigned)slw < (unsigned)NL;
+        bool probe = live && !bnd && !wordp;
+        {   // One kind of step per round: the alignments of an iteration have the same shape (M, a gap run, M, ...) but runs of different lengths, so
+            // most rounds would find some of them inside a run of M and some inside a gap run and pay for both kinds of look.  The kind more lanes
+            // ask for is taken; the others wait a round (they ask again, and a round always advances at least half of the live alignments).
+            const int nw = __popcll(__ballot(wordp)), np = __popcll(__ballot(probe));
+            if (nw > 0 && np > 0) { if (nw >= np) probe = false; else wordp = false; }
+        }
+        const bool waits = live && !bnd && !wordp && !probe;
         // ---- a run of state M off the words of its diagonal: word n of the run (n = 0: the word of cell (i-1, j-1)) holds its cells
         //      k = kfirst(n) .. kfirst(n) + 3; lane q takes words q * NW .. q * NW + NW - 1.  Interior cells only (k < K): the cell on a matrix
         //      edge goes through the probe below
@@ -1979,7 +1986,7 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
             ns_c = __shfl(ns, e * EL + (nc < EL ? nc : EL - 1));
         }
         // ---- the step
-        if (live) {
+        if (live && !waits) {
             int E = 0, s_next = s;
             bool fin = false;
             if (bnd) {
