@@ -406,6 +406,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
                 PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
                 // a read on its reference's main diagonal (at most two differing bases) is finished by the partition itself where c2_main_diagonal_certificate allows
                 PA.exact_copies = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0 && (A.aln_stride & 3u) == 0) ? 1 : 0;
+                PA.route_cert = getenv("C2_NO_ROUTE_CERT") ? 0 : 1;
                 PA.check_cut = many_refs ? 1 : 0;                        // (one amplicon: a read that differs from it around the cut fails the score-only certificate anyway, and the look costs 0.3 ms per 10 M)
                 if (const char* e = getenv("C2_SCORE_TIER_MAX_MISMATCH")) PA.max_mismatch = atoi(e);
                 if (const char* e = getenv("C2_ROUTE_PROBE_MISMATCH")) PA.probe_max_mismatch = atoi(e);

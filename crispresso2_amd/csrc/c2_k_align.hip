@@ -2769,6 +2769,7 @@ struct c2_partition_args {
     int32_t direct_full, sort_by_length;        // the last class exists; order a ragged chunk's slots by read length
     int32_t check_cut;                          // class 0 also looks at the 32 columns around the cut site (batches with several candidate amplicons)
     int32_t exact_copies;                       // the output rows can be written as dwords: a class-0 read that EQUALS its reference is finished here (class_count[7])
+    int32_t route_cert;                         // c2_part_probe: a band is chosen only if its launch can be expected to certify the alignment (round 6; 0: the geometric test alone)
 };
 
 #define C2_PART_CHUNK 4096                         // tasks per workgroup and set of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
@@ -2874,24 +2875,80 @@ __device__ __forceinline__ int c2_part_window(const c2_partition_args& P, const 
 }
 
 // the class of a task by the diagonals its read lies on (see above); `widest`: the class that takes what no band holds
+// Which launch should see a probed task first.  Round 6: the band must not only HOLD the path's diagonals (c2_band_holds) -- its launch must be able to
+// CERTIFY the alignment (c2_outside_band_bound, the test the kernels apply after the fill), or the fill is spent for nothing and the task is filled again
+// by the next tier (measured on FANC-shaped reads, round 5: the 40-diagonal tier handed 17 % of its tasks on, the 62-diagonal one 21 %, the 126-diagonal
+// one 24 %).  The path is modelled from two windows -- a quarter into the read and behind its middle --: a leading run to the first window's diagonal
+// s1, one run of s2 - s1 in between, a trailing run to D; end runs cost gap_extend per base (pyx:153-176, 234-317), the one in between gap_open + gap_extend
+// per base; every other column is taken as a match but for an allowance of two mismatches.  A prediction only: every launch verifies what it finishes.
 __device__ __forceinline__ int c2_part_probe(const c2_partition_args& P, const c2_part_task& t, const int widest) {
+    const c2_align_args& A = P.A;
     const int D = t.Li - t.Lj;
     int s = 0;
     int lo = D < 0 ? D : 0, hi = D > 0 ? D : 0;
+    int s1 = 0, s2 = 0;
     const int mm = c2_part_window(P, t, (t.Lj >> 1) + 16, s);
-    if (mm <= P.probe_max_mismatch) { lo = s < lo ? s : lo; hi = s > hi ? s : hi; }
-    else {
-        // nothing in the middle (a breakpoint inside the window, a noisy stretch -- or a read that is not this amplicon's at all): a quarter and
-        // three quarters into the read
-        int s1 = 0, s2 = 0;
-        const int m1 = c2_part_window(P, t, t.Lj >> 2, s1), m2 = c2_part_window(P, t, ((3 * t.Lj) >> 2) - 16, s2);
-        const bool ok1 = m1 <= P.probe_max_mismatch, ok2 = m2 <= P.probe_max_mismatch;
-        if (!ok1 && !ok2) return (P.direct_full && mm < 64 && m1 < 64 && m2 < 64) ? C2_PART_CLASSES - 1 : 2;      // (a window that could not be looked at says nothing)
-        if (ok1) { lo = s1 < lo ? s1 : lo; hi = s1 > hi ? s1 : hi; }
-        if (ok2) { lo = s2 < lo ? s2 : lo; hi = s2 > hi ? s2 : hi; }
+    bool have1 = false, have2 = false;
+    if (mm <= P.probe_max_mismatch) { s2 = s; have2 = true; }
+    int m1 = 64, m2 = 64;
+    bool looked1 = false;
+    if (!have2 || (P.route_cert && D != 0)) {
+        looked1 = true;                        // (a read as long as its reference: the front part is taken to lie on the main diagonal -- the second look cost the headline batch 0.5 ms)
+        m1 = c2_part_window(P, t, t.Lj >> 2, s1);
+        have1 = m1 <= P.probe_max_mismatch;
     }
-    int cls = widest;
-    for (int k = 4; k >= 0; --k) if (c2_band_holds(P.bandw[k], D, lo, hi, P.margin)) cls = k + 1;
+    if (!have2) {
+        // nothing behind the middle (a breakpoint inside the window, a noisy stretch -- or a read that is not this amplicon's at all): three quarters into the read
+        m2 = c2_part_window(P, t, ((3 * t.Lj) >> 2) - 16, s2);
+        have2 = m2 <= P.probe_max_mismatch;
+        if (!have1 && !have2) return (P.direct_full && mm < 64 && m1 < 64 && m2 < 64) ? C2_PART_CLASSES - 1 : 2;      // (a window that could not be looked at says nothing)
+    }
+    if (have1) { lo = s1 < lo ? s1 : lo; hi = s1 > hi ? s1 : hi; }
+    if (have2) { lo = s2 < lo ? s2 : lo; hi = s2 > hi ? s2 : hi; }
+    const int go = A.gap_open, ge = A.gap_extend;
+    const int cb = (go > ge ? go : ge) + t.ref->gap_incentive_max;
+    if (!(P.route_cert && cb < 0 && A.max_score > 0)) {              // the geometric test alone (before round 6; C2_NO_ROUTE_CERT=1)
+        int cls = widest;
+        for (int k = 4; k >= 0; --k) if (c2_band_holds(P.bandw[k], D, lo, hi, P.margin)) cls = k + 1;
+        return cls;
+    }
+    // the model path's score without a mismatch ...
+    const int a1 = have1 ? s1 : ((looked1 && have2) ? s2 : 0), a2 = have2 ? s2 : a1;         // the diagonal in front of / behind the middle (not looked at in front: the main diagonal)
+    const int g_lead = a1, g_mid = a2 - a1, g_trail = D - a2;
+    const int nv = (g_lead > 0 ? g_lead : 0) + (g_mid > 0 ? g_mid : 0) + (g_trail > 0 ? g_trail : 0);
+    const int h0 = t.ref->gap_incentive_max + A.max_score * (t.Li - nv) + ge * ((g_lead < 0 ? -g_lead : g_lead) + (g_trail < 0 ? -g_trail : g_trail)) +
+                   (g_mid != 0 ? go + ge * (g_mid < 0 ? -g_mid : g_mid) : 0);
+    // ... and the launch to start with: the one with the smallest EXPECTED cost, where a launch that cannot certify the alignment hands it to the next
+    // wider one.  A launch certifies iff the read has at most m_k = (h0 - U_k - 1) / (a mismatch's cost) mismatches; their number is taken as Poisson with
+    // mean 1 (0.5 % of 250 bases, a quarter of which put the same base back); the costs are the launches' measured times per task relative to the 32-diagonal one (profiles/r06).
+    const float cdf[6] = {0.368f, 0.736f, 0.920f, 0.981f, 0.996f, 0.999f};
+    const float cost[5] = {0.85f, 1.0f, 1.6f, 2.26f, 4.4f};           // 14 (opt-in), 32, 40, 62, 126 diagonals
+    const int per_mm = A.max_score + 4;                              // (a mismatch instead of a match: EDNAFULL 5 + 4; a guess for other matrices -- this is a prediction)
+    // q[k]: the probability that launch k cannot certify (1: its band does not even hold the path); a task that enters the chain at launch e is filled by
+    // e, and by every later launch k with probability q[k - 1] (the room grows with the band: failing k - 1 implies having failed the ones before)
+    float q[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int W = P.bandw[k];
+        q[k] = 1.0f;
+        if (W > 0 && c2_band_holds(W, D, lo, hi, 1)) {
+            const int d0 = ((D - W + 3) >> 1) & ~1;
+            const int U = c2_outside_band_bound(A.max_score, t.Li, t.Lj, D, d0 + W, d0 - 1, cb, go, ge, t.ref->gap_incentive_last_pos);
+            const int room = h0 - U - 1;
+            if (room >= 0) { const int mk = room / per_mm; q[k] = 1.0f - cdf[mk < 5 ? mk : 5]; }
+        }
+    }
+    // backwards over the launches the chain has: S = what the launches BEHIND launch k cost a task that enters at k (the full-matrix launch: 9)
+    int cls = widest, later = -1;
+    float S = 0.0f, best = 1.0e30f;
+    for (int k = 4; k >= 0; --k) {
+        if (P.bandw[k] <= 0) continue;
+        S = later < 0 ? 9.0f * q[k] : (cost[later] * q[k] + S);
+        const float E_k = cost[k] + S;
+        if (E_k <= best) { best = E_k; cls = k + 1; }
+        later = k;
+    }
+    if (P.direct_full && best > 9.0f + 0.5f) cls = C2_PART_CLASSES - 1;      // no band launch is worth its fill (a read much shorter than its reference, a shift beyond every band): the full-matrix launch at once
     return cls;
 }
 

@@ -98,6 +98,12 @@ def register_reads(source):
     _state["source"] = source
 
 
+def _say_too_many(n, what):
+    """one line on stderr, on every route, when C2_PRIME_MAX_READS stops priming (the calls then take the per-call path: same results, slower)"""
+    sys.stderr.write("crispresso2_amd.prime: %d unique %s exceed C2_PRIME_MAX_READS=%d -- not priming (use pipeline.quantify_fastq / "
+                     "paired_device.quantify_paired_fastq for runs of this size)\n" % (n, what, MAX_READS))
+
+
 def _unique_reads_of_file(path):
     """-> list of the file's unique read strings in first-seen order, or None (and a note in stats) when it cannot be used"""
     try:
@@ -108,8 +114,7 @@ def _unique_reads_of_file(path):
         return None
     if len(counts) > MAX_READS:
         stats["not_primed"] = 1
-        sys.stderr.write("crispresso2_amd.prime: %d unique reads exceed C2_PRIME_MAX_READS=%d -- not priming (use "
-                         "pipeline.quantify_fastq for runs of this size)\n" % (len(counts), MAX_READS))
+        _say_too_many(len(counts), "reads of %s" % (path,))
         return None
     buf = arena.tobytes()
     seqs = []
@@ -324,6 +329,7 @@ def _prime_read_loop(name, loc, before_fork):
             try:
                 if len(pf.counts) > MAX_READS:
                     stats["not_primed"] = 1
+                    _say_too_many(len(pf.counts), "read pairs of %s / %s" % (f1, f2))
                     return False
                 pairs = []
                 for k, q in zip(pf.keys, pf.quals):
@@ -346,6 +352,9 @@ def _prime_read_loop(name, loc, before_fork):
         reads = _unique_reads_of_file(path)
     _discovered.add(mark)
     n = len(pairs) if pairs is not None else len(reads or ())
+    if n > MAX_READS:
+        stats["not_primed"] = 1
+        _say_too_many(n, "reads of the caller's %s" % name)
     if n == 0 or n > MAX_READS:
         return False
     prime_for_caller(args, refs, ref_names, m, reads=reads, pairs=pairs)

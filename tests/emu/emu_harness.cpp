@@ -201,7 +201,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
             PA.list[6] = lists[ifull - 1]; PA.count[6] = &fb_counts[ifull - 1];      // the list the last launch (the full plane) reads
             PA.direct_full = (route && !getenv("C2_NO_DIRECT_FULL")) ? 1 : 0;
             PA.sort_by_length = getenv("C2_NO_LENGTH_ORDER") ? 0 : 1;
-            PA.check_cut = (A.all_refs && A.n_refs > 1) ? 1 : 0;
+            PA.check_cut = (A.all_refs && A.n_refs > 1) ? 1 : 0; PA.route_cert = getenv("C2_NO_ROUTE_CERT") ? 0 : 1;
             PA.exact_copies = ((((uintptr_t)A.aln_read | (uintptr_t)A.aln_ref) & 3u) == 0 && (A.aln_stride & 3u) == 0) ? 1 : 0;
             PA.class_count = class_counts;
             PA.bandw[0] = p16_stage ? 14 : 0; PA.bandw[1] = 32; PA.bandw[2] = (route && tier40_runs) ? 40 : 0;
