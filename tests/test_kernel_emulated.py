@@ -515,8 +515,8 @@ def test_emulated_kernel_alignments_larger_than_the_lds_plane(mats, li, lj):
             check_record(r, oracle.find_indels_substitutions(s1, s2, inc), s1, s2)
         if chain and lj == li:
             # the long deletion and the unrelated read are beyond the first tier: handed on by it, or (round 5) sent past it by the partition --
-            # the unrelated read straight to the full-matrix launch (class 5)
-            assert 0 < st["fallback"] + sum(st["classes"][3:]) < st["tasks"] and st["classes"][6] == 1, st
+            # the unrelated read straight to the full-matrix launch (class 6) -- and (round 6) the 220-base deletion with it: no band launch holds it
+            assert 0 < st["fallback"] + sum(st["classes"][3:]) < st["tasks"] and st["classes"][6] == 2, st
 
 
 # ---- the two variants of the packed fill: sums as v_pk_add_i16, or as plain 32-bit adds under a per-anti-diagonal bias ----------------
