@@ -1312,7 +1312,8 @@ def test_partition_routing_changes_no_result(mats, ctx, monkeypatch, L):
     # (classes: 0 score-only, 1 the 14-diagonal launch, 2 / 3 / 4 / 5 the band tiers of 32 / 40 / 62 / 128 diagonals, 6 the full-matrix launch)
     assert routed["classes"][0] > 100 and routed["classes"][1] == 0 and routed["classes"][3] + routed["classes"][4] >= 60 and (routed["classes"][5] >= 40 or L == 150), routed
     assert sum(unrouted["classes"][3:6]) == 0 and unrouted["classes"][2] > routed["classes"][2], unrouted
-    assert with16["p16"] and with16["classes"][1] >= 150 and with16["finished"][1] >= with16["classes"][1] // 2, with16
+    # (round 6: a band is chosen only if its launch can be expected to CERTIFY the alignment -- fewer tasks take the 14-diagonal launch, nearly all of them finish there)
+    assert with16["p16"] and with16["classes"][1] >= 100 and with16["finished"][1] >= with16["classes"][1] * 3 // 4, with16
     records = outs[0][2].view(_native.REC_DTYPE).reshape(-1)
     assert (records["status"] == 0).all()
     for i in range(n):
