@@ -127,7 +127,10 @@ inline std::string c2_zip_local_header(const c2_zip_out& Z) {
 }
 inline bool c2_zip_begin(c2_zip_out& Z, const int fd, const char* member, const uint64_t text_bytes, const int level, std::string& err) {
     Z.fd = fd; Z.name = member; Z.level = level < 0 ? 1 : (level > 9 ? 9 : level);
-    Z.zip64 = text_bytes >= 0xffffffffull || getenv("C2_ZIP_FORCE_ZIP64");   // (the compressed size fits if the text's does; the knob: the zip64 records on a small table, for the tests)
+    // zip64 records when the text OR what deflate can make of it at worst may reach 4 GiB (stored blocks: 5 bytes per 16 KiB + a sync flush per slice --
+    // a table within 1/3000 of 4 GiB whose text does not compress would otherwise overflow the 32-bit compressed size; c2_zip_end checks again).
+    // The knob: the zip64 records on a small table, for the tests.
+    Z.zip64 = text_bytes + text_bytes / 3000u + (1u << 20) >= 0xffffffffull || getenv("C2_ZIP_FORCE_ZIP64");
     time_t now = time(nullptr); struct tm tmv; localtime_r(&now, &tmv);
     const int yr = tmv.tm_year + 1900 < 1980 ? 1980 : tmv.tm_year + 1900;
     Z.dos_time = (uint16_t)((tmv.tm_hour << 11) | (tmv.tm_min << 5) | (tmv.tm_sec >> 1));
@@ -173,9 +176,19 @@ inline bool c2_zip_append(c2_zip_out& Z, const uint8_t* buf, const size_t n, int
         for (size_t p = a; p < z; p += (size_t)1 << 30) c = (uint32_t)crc32(c, buf + p, (uInt)std::min<size_t>(z - p, (size_t)1 << 30));
         crcs[k] = c;
     };
-    { std::vector<std::thread> pool; for (size_t k = 1; k < ns; ++k) pool.emplace_back(work, k); work(0); for (auto& t : pool) t.join(); }
+    {   // (nothing escapes: a slice whose thread cannot be created is compressed by this thread; std::bad_alloc inside a slice fails the call)
+        auto guarded = [&](const size_t k) { try { work(k); } catch (...) { ok[k] = 0; } };
+        std::vector<std::thread> pool;
+        std::vector<size_t> mine{0};
+        try { pool.reserve(ns); } catch (...) {}
+        for (size_t k = 1; k < ns; ++k) {
+            try { pool.emplace_back(guarded, k); } catch (...) { mine.push_back(k); }
+        }
+        for (const size_t k : mine) guarded(k);
+        for (auto& t : pool) t.join();
+    }
     for (size_t k = 0; k < ns; ++k) {
-        if (!ok[k]) { err = "deflate failed"; return false; }
+        if (!ok[k]) { err = "deflate failed (or out of memory)"; return false; }
         if (!c2_pwrite_parallel(Z.fd, out[k].data(), out[k].size(), Z.pos, 1, err)) return false;
         Z.pos += out[k].size(); Z.csize += out[k].size();
         const size_t a = k * slice, z = std::min(n, a + slice);
@@ -188,6 +201,7 @@ inline bool c2_zip_end(c2_zip_out& Z, std::string& err, uint64_t* file_bytes) {
     const uint8_t fin[2] = {0x03, 0x00};                            // an empty final block (fixed Huffman: end-of-block and nothing else) closes the stream
     if (!c2_pwrite_parallel(Z.fd, fin, 2, Z.pos, 1, err)) return false;
     Z.pos += 2; Z.csize += 2;
+    if (!Z.zip64 && (Z.csize >= 0xffffffffull || Z.usize >= 0xffffffffull)) { err = "the member outgrew the 32-bit zip fields (c2_zip_begin was given a smaller text size)"; return false; }
     const std::string lh = c2_zip_local_header(Z);
     if (!c2_pwrite_parallel(Z.fd, (const uint8_t*)lh.data(), lh.size(), 0, 1, err)) return false;
     std::string cd;

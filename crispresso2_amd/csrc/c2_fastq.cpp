@@ -1333,7 +1333,7 @@ int c2_bgzf_inflate(c2_bgzf* h, uint64_t b0, uint64_t b1, uint8_t* dst, uint64_t
     if (h->one_member) {                                            // segments of one gzip member: pass D of c2_gz_parallel.h
         std::atomic<bool> ok(true);
         unsigned T1 = threads > 0 ? (unsigned)threads : usable_cpus();
-        c2gz::on_threads(T1, (size_t)(b1 - b0), [&](size_t i) {
+        const bool ran = c2gz::on_threads(T1, (size_t)(b1 - b0), [&](size_t i) {
             const size_t k = (size_t)b0 + i;
             uint32_t crc = 0;
             if (!ok.load(std::memory_order_relaxed)) return;
@@ -1342,8 +1342,13 @@ int c2_bgzf_inflate(c2_bgzf* h, uint64_t b0, uint64_t b1, uint8_t* dst, uint64_t
             h->seg_crc[k] = crc;
             if (!h->seg_done[k]) { h->seg_done[k] = 1; ++h->n_seg_done; }
         });
+        if (!ran) { g_fastq_error = "c2_bgzf_inflate: out of memory in a worker"; return C2_E_NOMEM; }
         if (!ok) { g_fastq_error = "c2_bgzf_inflate: invalid gzip data (the second pass differs from the first)"; return C2_E_INVALID; }
-        if (h->n_seg_done == h->blocks.size() && !c2gz::crc_matches(h->plan, h->seg_crc)) {
+        // (the member's CRC-32 can only be checked once EVERY segment has been inflated: a caller that stops early has not verified anything, and on a
+        //  failure here the ranges handed out before are to be discarded -- fastq_device.IngestSource does: it raises, nothing of the file is counted)
+        bool all_done;
+        { std::lock_guard<std::mutex> g(h->crc_lock); all_done = h->n_seg_done == h->blocks.size(); }
+        if (all_done && !c2gz::crc_matches(h->plan, h->seg_crc)) {
             g_fastq_error = "c2_bgzf_inflate: CRC check failed";   // (gzip.py: BadGzipFile("CRC check failed ...") at the member's end)
             return C2_E_INVALID;
         }

@@ -26,6 +26,7 @@
 #include <atomic>
 #include <functional>
 #include <memory>
+#include <new>
 #include <thread>
 #include <vector>
 #include <zlib.h>
@@ -493,16 +494,28 @@ inline double now() {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+// f(item) for every item, items handed out one at a time.  Nothing escapes (these run behind extern "C" entries: ADVICE r05): a thread that cannot
+// be created (a pid / thread limit of the cgroup) is done without -- the threads that did start and the caller share the work --; an exception
+// inside f (std::bad_alloc of a worker's tables under memory pressure) ends the hand-out and makes the call return false: the caller takes the
+// serial route, as for everything else this file declines.
 template <class F>
-inline void on_threads(unsigned threads, size_t items, F&& f) {   // f(item) for every item, items handed out one at a time
+inline bool on_threads(unsigned threads, size_t items, F&& f) {
     std::atomic<size_t> next(0);
-    auto work = [&] { for (;;) { const size_t k = next.fetch_add(1); if (k >= items) break; f(k); } };
+    std::atomic<bool> failed(false);
+    auto work = [&] {
+        try { for (;;) { const size_t k = next.fetch_add(1); if (k >= items) break; f(k); } }
+        catch (...) { failed = true; next.store(items); }
+    };
     if (threads > items) threads = (unsigned)items;
-    if (threads <= 1) { work(); return; }
+    if (threads <= 1) { work(); return !failed; }
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t + 1 < threads; ++t) pool.emplace_back(work);
+    try {
+        pool.reserve(threads);
+        for (unsigned t = 0; t + 1 < threads; ++t) pool.emplace_back(work);
+    } catch (...) {}                                                // (fewer threads than asked for)
     work();
     for (auto& th : pool) th.join();
+    return !failed;
 }
 
 // What passes A - C leave behind: where every segment starts (bit), where its text goes, and the 32 KiB in front of it.
@@ -530,13 +543,13 @@ inline bool plan_single_member(const uint8_t* b, size_t n, unsigned threads, siz
     std::vector<uint64_t> start(n_cuts, ~0ull);
     start[0] = (uint64_t)data_at * 8u;
     const uint64_t scan_bits = (uint64_t)(chunk < ((size_t)1 << 20) ? chunk : ((size_t)1 << 20)) * 8u;
-    on_threads(threads, n_cuts - 1, [&](size_t i) {
+    if (!on_threads(threads, n_cuts - 1, [&](size_t i) {
         const size_t k = i + 1;
         std::unique_ptr<Tables> T(new Tables);
         const uint64_t from = ((uint64_t)data_at + (uint64_t)k * chunk) * 8u;
         uint64_t f = 0;
         if (find_block(b, n - 8, from, from + scan_bits, *T, f)) start[k] = f;
-    });
+    })) return no("no memory for the workers' tables");
     std::vector<uint64_t>& seg = P.seg;
     seg.clear();
     for (size_t k = 0; k < n_cuts; ++k) if (start[k] != ~0ull) seg.push_back(start[k]);
@@ -548,7 +561,7 @@ inline bool plan_single_member(const uint8_t* b, size_t n, unsigned threads, siz
     struct Seg { uint64_t produced = 0, end_bit = 0; int rc = R_ERROR; std::unique_ptr<uint16_t[]> tail; };
     std::vector<Seg> segs(S);
     std::atomic<bool> good(true);
-    on_threads(threads, S, [&](size_t k) {
+    if (!on_threads(threads, S, [&](size_t k) {
         if (!good.load(std::memory_order_relaxed)) return;
         std::unique_ptr<Tables> T(new Tables);
         Ring ring(k == 0);
@@ -560,7 +573,7 @@ inline bool plan_single_member(const uint8_t* b, size_t n, unsigned threads, siz
         if (rc != (k + 1 < S ? R_STOP : R_FINAL)) { good = false; return; }
         segs[k].tail.reset(new uint16_t[32768]);
         ring.tail(segs[k].tail.get());
-    });
+    })) return no("no memory for the workers' tables");
     st.t_pass1 = now() - t0; t0 = now();
     if (!good) return no("a segment did not end on the next segment's block");
     // the trailer follows the final block's last byte, and the file ends behind it
@@ -577,7 +590,8 @@ inline bool plan_single_member(const uint8_t* b, size_t n, unsigned threads, siz
     win.clear();
     win.resize(S);
     for (size_t k = 1; k < S; ++k) {
-        win[k].reset(new uint8_t[32768]);
+        win[k].reset(new (std::nothrow) uint8_t[32768]);
+        if (!win[k]) return no("no memory for the segments' windows");
         const uint16_t* t = segs[k - 1].tail.get();
         const uint8_t* prev = win[k - 1].get();
         const uint64_t have_prev = off[k - 1] < 32768u ? off[k - 1] : 32768u;    // bytes that exist in front of segment k - 1
@@ -639,10 +653,10 @@ inline bool inflate_single_member(const uint8_t* b, size_t n, unsigned threads, 
     if (!text && total) return no("no room for the text");
     std::vector<uint32_t> crc(S, 0);
     std::atomic<bool> good(true);
-    on_threads(threads, S, [&](size_t k) {
+    if (!on_threads(threads, S, [&](size_t k) {
         if (!good.load(std::memory_order_relaxed)) return;
         if (!inflate_segment(b, n, P, k, text + P.off[k], crc[k], fast_crc)) good = false;
-    });
+    })) return no("no memory for the workers' tables");
     st.t_pass2 = now() - t0;
     if (!good) return no("the second pass differs from the first");
     if (!crc_matches(P, crc)) return no("CRC-32 differs");

@@ -580,11 +580,21 @@ def lookup_payload(read_seq_al, ref_seq_al, include_idx, legacy, build):
 
 
 # ---------------------------------------------------------------- fork (module text, 3.)
+_fork_note = [False]
+
+
 def _before_fork():
-    if not _WATCH_FRAMES or _native.in_forked_child():
+    """os.register_at_fork(before=...): what the caller's workers will ask for is computed in the parent, once, before they are forked (a forked child of a
+    HIP process cannot use the GPU).  C2_PRIME_AT_FORK=0 switches the hook off (every miss of a worker then goes through its spawned helper: one more
+    process and GPU context per worker); the first time the hook primes it says so on stderr -- it may read the whole FASTQ file and
+    run GPU batches inside os.fork(), and it opens the GPU in the parent, which is what makes the workers children of a HIP process."""
+    if not _WATCH_FRAMES or _native.in_forked_child() or os.environ.get("C2_PRIME_AT_FORK", "1") == "0":
         return
     try:
-        _discover(sys._getframe(1), before_fork=True)
+        if _discover(sys._getframe(1), before_fork=True) and not _fork_note[0]:
+            _fork_note[0] = True
+            sys.stderr.write("crispresso2_amd.prime: computed the alignments of the caller's reads before its fork() (%d device batches so far; C2_PRIME_AT_FORK=0 "
+                             "switches this off)\n" % stats.get("batches", 0))
     except Exception:                                                 # never in the way of the caller's fork
         pass
 
