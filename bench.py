@@ -243,7 +243,7 @@ class Job:
         # single amplicon: the hint words c2_align_partition_kernel leaves for the reads it finishes itself (c2_batch.diag_hints); the count pass takes those
         # tasks from the word alone (c2_count_hinted_kernel).  C2_BENCH_NO_HINTS=1: the step without them (A/B).
         self.use_hints = (k == 1 and not all_refs and wl["ref_ids"] is None and not os.environ.get("C2_BENCH_NO_HINTS"))
-        self.hint_sets = [torch.zeros(n_tasks, dtype=torch.int32, device=dev) if self.use_hints else None for _ in range(self.n_sets)]
+        self.hint_sets = [torch.zeros(n_tasks * 4, dtype=torch.int32, device=dev) if self.use_hints else None for _ in range(self.n_sets)]      # four words per task
         self.t_align = torch.cuda.current_stream()
         self.t_count = torch.cuda.Stream(device=dev) if overlap_count else self.t_align
         self.stream = self.t_align.cuda_stream
@@ -1065,7 +1065,9 @@ def main():
         eq_ = job.count_tensor_equals_without_hints()
         if eq_ is not None:
             checks["count_tensor_equals_without_hints"] = eq_
-            checks["hinted_tasks"] = int((job.hint_sets[0] < 0).sum().item())       # (bit 31 = valid)
+            h0_ = job.hint_sets[0].view(-1, 4)[:, 0]
+            checks["hinted_tasks"] = int((h0_ < 0).sum().item())                       # (bit 31: a main-diagonal hint, c2_align_partition_kernel)
+            checks["hinted_gapped_tasks"] = int(((h0_ >> 30) == 1).sum().item())        # (bit 30: a gapped hint, c2_group_epilogue)
     # (4) the launch chain's certificates, exhaustively: the same batch through the full-plane kernel alone
     if rank == 0 and args.check > 0 and not args.no_full_plane_check and args.kernel == "auto":
         equal_n, tf = job.chain_equals_full_plane()

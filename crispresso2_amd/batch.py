@@ -168,5 +168,5 @@ class BatchAligner:
         b.records = d_records
         b.flags = 1 if legacy else 0
         b.min_read_len = int(min_read_len)
-        b.diag_hints = d_hints                                      # (c2_batch.diag_hints: n_tasks uint32 on the device, or None)
+        b.diag_hints = d_hints                                      # (c2_batch.diag_hints: n_tasks x 4 uint32 on the device, or None)
         self.ctx.align_classify_device(b, stream)

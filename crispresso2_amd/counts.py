@@ -84,7 +84,7 @@ def min_matches_table(min_aln_scores, max_t):
 def accumulate_device(ctx, layout, n_tasks, d_aln_read, d_aln_ref, aln_stride, d_records, d_counts, d_weights=None,
                       min_matches=None, flags=0, stream=None, d_hints=None):
     """Enqueue c2_count_vectors_kernel.  d_* are device addresses; min_matches is a host uint16 table or None.
-    d_hints: the hint words the align call of the same batch wrote (BatchAligner.align_device(..., d_hints=)): a task with a valid hint is counted from
+    d_hints: the hint words (four per task) the align call of the same batch wrote (BatchAligner.align_device(..., d_hints=)): a task with a valid hint is counted from
     its hint alone (c2_count_hinted_kernel) -- same tensor, the rows of those tasks are not read back."""
     mm = None
     max_t = 0

@@ -648,7 +648,7 @@ int run_align(c2_ctx* ctx, const c2_batch* b, int max_lj, hipStream_t s) {
     A.phase_cycles = ctx->phase_prof ? (unsigned long long*)ctx->d_phase.p : nullptr;
     // the batch's hint words: zero, then c2_align_partition_kernel (if the chain has it) writes the ones it has something to say about
     A.diag_hints = b->diag_hints;
-    if (b->diag_hints) HIPCHK(ctx, hipMemsetAsync(b->diag_hints, 0, (size_t)n_tasks * sizeof(uint32_t), s));
+    if (b->diag_hints) HIPCHK(ctx, hipMemsetAsync(b->diag_hints, 0, (size_t)n_tasks * 4u * sizeof(uint32_t), s));
     switch (g.R) {
         case 1: return launch_align<1>(ctx, A, g, s, b->min_read_len);
         case 2: return launch_align<2>(ctx, A, g, s, b->min_read_len);

@@ -59,9 +59,9 @@ int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t*
     A.order = nullptr;
     // the batch's hint words (c2_batch.diag_hints): one reference only, and its position vectors must fit the hinted kernel's LDS block
     A.hints = nullptr;
-    if (d_hints && ctx->n_refs == 1 && c2_count_hinted_lds_bytes(lmax) <= 65536 && !getenv("C2_NO_COUNT_HINTS")) {
+    if (d_hints && ctx->n_refs == 1 && c2_count_hinted_lds_bytes(lmax, hl) <= 65536 && !getenv("C2_NO_COUNT_HINTS")) {
         A.hints = d_hints;
-        const size_t hl_lds = c2_count_hinted_lds_bytes(lmax);
+        const size_t hl_lds = c2_count_hinted_lds_bytes(lmax, hl);
         const unsigned hgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_tasks + 255) / 256, (uint64_t)ctx->prop.multiProcessorCount * 4u));
         hipLaunchKernelGGL(c2_count_hinted_kernel, dim3(hgrid), dim3(256), hl_lds, s, A);
         HIPCHK(ctx, hipGetLastError());

@@ -334,9 +334,10 @@ typedef struct c2_count_args {
     const uint32_t* hints;        // optional (one reference only): c2_batch.diag_hints of the batch -- a task with a valid hint is counted by c2_count_hinted_kernel
                                   // from the hint word alone, c2_count_vectors_kernel skips it
 } c2_count_args;
-// LDS of c2_count_hinted_kernel: the int32 position vectors, sixteen 64-bit totals, inc_prefix
-static inline size_t c2_count_hinted_lds_bytes(int lmax) {
-    return ((size_t)C2_COUNT_VECTORS * (size_t)(lmax + 1) * sizeof(int32_t) + 15) / 16 * 16 + 16 * sizeof(uint64_t) + (((size_t)lmax + 2) * 2 + 15) / 16 * 16;
+// LDS of c2_count_hinted_kernel: the int32 position vectors, histograms and two difference arrays; 16 + C2_COUNT_SCALARS 64-bit totals; inc_prefix; scan carries
+static inline size_t c2_count_hinted_lds_bytes(int lmax, int hl) {
+    const size_t ints = (size_t)C2_COUNT_VECTORS * (size_t)(lmax + 1) + (size_t)C2_COUNT_HISTS * (size_t)hl + 2u * (size_t)(lmax + 1);
+    return (ints * sizeof(int32_t) + 15) / 16 * 16 + (16 + C2_COUNT_SCALARS) * sizeof(uint64_t) + (size_t)((lmax + 2 + 7) / 8) * 8 * 2 + 64;
 }
 
 // ---- best-reference selection on the device (CRISPRessoCORE.py:683, :697-707, :779-785) ----

@@ -1428,7 +1428,7 @@ __device__ __forceinline__ void c2_pk_pair(c2_pk_state& S, const int a, const c2
 // of them), read back with agent-scope loads that bypass the CU's L1.
 // ---------------------------------------------------------------------------------------------------------------
 #define C2_RUNS_MAX 16                              // runs of one alignment the lane-group epilogue keeps (more: the next launch takes the task)
-#define C2_GRP_SLOT_WORDS (C2_RUNS_MAX * 3 + 8)     // LDS words per alignment: run table (3 words per run) + 8 accumulator words
+#define C2_GRP_SLOT_WORDS (C2_RUNS_MAX * 3 + 12)    // LDS words per alignment: run table (3 words per run) + 8 accumulator words + the differing columns' list (count, 3 entries)
 struct c2_diagx_plan {
     uint32_t codeof, table, tmp_read, tmp_ref, stage, slot0, slot_bytes, total, n_words;
     uint32_t pairlut, pcodes0, pcodes_bytes, group0, group_bytes, gref, gincp;   // packed kernels only
@@ -2017,7 +2017,7 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
     if (nr > C2_RUNS_MAX) nf = true;
     const bool ok = act && !nf && status == 0 && !(A.reserved & 16);     // (16: debug knob C2_DEBUG_SKIP_EMIT -- the walk alone)
     const int TT = cnt;                                              // columns of the alignment
-    if (e < NAH && q < 8) acc[q] = 0;
+    if (e < NAH && q < 8) { acc[q] = 0; if (q < 4) acc[8 + q] = 0; }
     __builtin_amdgcn_wave_barrier();                                 // (the run tables and the zeroed accumulators: LDS operations of one wavefront complete in order)
 
     // ================= indel events, a lane per run =================
@@ -2067,6 +2067,9 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
     const int lastR = (Lj - 1) >> 2, lastF = (Li - 1) >> 2;
     int n_mism = 0, n_sub = 0, n_win = 0;
     bool dash = false;
+    // (c2_batch.diag_hints: an alignment of at most five runs and three differing columns leaves as four words -- its runs, and where and what its differing
+    //  columns are --, which is all the count pass needs of it: c2_count_hinted_kernel.  Not under the legacy classifier, whose positions differ.)
+    const bool want_hint = A.diag_hints != nullptr && !A.legacy && nr <= 5 && Li <= 511 && Lj <= 511;
     struct run_d { int cs, ce, dR, dF, st, len; };                 // a run as the strings need it: columns [cs, ce); read / reference index of its column c: c + dR / c + dF
     auto load_run = [&](const int r, run_d& d) {
         const unsigned ra = runs[3 * r], rbw = runs[3 * r + 1];
@@ -2103,7 +2106,9 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
                 if (st == C2_ST_M) {
                     if (rch != fch) {
                         ++n_mism;
-                        if (rch != 'N') { ++n_sub; const int idx = c - il; n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0; }
+                        const int idx = c - il;
+                        if (rch != 'N') { ++n_sub; n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0; }
+                        if (want_hint) { const int k = atomicAdd(&acc[8], 1); if (k < 3) acc[9 + k] = idx | (int)((((unsigned)rch >> 1) & 7u) << 9); }
                     }
                     if (rch == '-' || fch == '-') dash = true;
                 } else if ((st == C2_ST_I && rch == '-') || (st == C2_ST_J && fch == '-')) dash = true;
@@ -2140,7 +2145,11 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
                         n_sub += __builtin_popcount(sb);
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
-                            if ((sb >> (8 * b + 7)) & 1u) { const int idx = c0 + b - ins_left; n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0; }
+                            if ((mm >> (8 * b + 7)) & 1u) {
+                                const int idx = c0 + b - ins_left;                                      // reference index of the column
+                                if ((sb >> (8 * b + 7)) & 1u) n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0;
+                                if (want_hint) { const int k = atomicAdd(&acc[8], 1); if (k < 3) acc[9 + k] = idx | (int)((((r4 >> (8 * b)) & 0xffu) >> 1) & 7u) << 9; }
+                            }
                     }
                 } else {
                     const unsigned x = (st == C2_ST_I) ? r4 : f4;                                    // a literal '-' in the sequence that fills the gap run
@@ -2168,7 +2177,7 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
         if (ev_del_bases) atomicAdd(&acc[4], ev_del_bases);
         if (flags) atomicOr(&acc[5], flags);
     }
-    if (e < NAH && q == 0) { acc[6] = TT; acc[7] = (act ? 1 : 0) | (nf ? 2 : 0) | (status << 8); }
+    if (e < NAH && q == 0) { acc[6] = TT; acc[7] = (act ? 1 : 0) | (nf ? 2 : 0) | (status << 8) | ((nr < 255 ? nr : 255) << 16); }
     __builtin_amdgcn_wave_barrier();
     if (lane < NAH && ((m_trace >> lane) & 1u)) {
         const int* Ts = sTab + (sbase + lane) * C2X_INTS;
@@ -2192,6 +2201,31 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
             rec.all_deletion_bases = (uint16_t)ac[4];
             rec.all_substitutions = (uint16_t)(ac[1] & 0xffff);
             rec.irregular_ends = (ac[5] & 2) ? 1 : 0;
+            if (A.diag_hints != nullptr && !A.legacy && sLi <= 511 && sLj <= 511 && ac[0] <= 3 && ac[8] == ac[0]) {
+                // the hint (include/crispresso2_amd.h): runs in forward order as state | length << 2, eleven bits each; a run of M of a single column is left to
+                // the count pass's column walk (two insertions one reference base apart share a position: numpy's repeated index, CRISPRessoCORE.py:4016-4021)
+                const unsigned* rt = (const unsigned*)(c2_smem + P.stage) + (sbase + lane) * C2_GRP_SLOT_WORDS;
+                const int nrs = (ac[7] >> 16) & 0xff;
+                unsigned hw[4] = {0u, 0u, 0u, 0u};
+                bool fits = nrs >= 1 && nrs <= 5;
+                for (int f = 0; f < 5 && fits; ++f) {
+                    if (f >= nrs) break;
+                    const int r = nrs - 1 - f;                       // trace order -> forward order
+                    const unsigned len = rt[3 * r] >> 16, stt = rt[3 * r + 2] & 3u;
+                    if (len > 511u || (stt == (unsigned)C2_ST_M && len < 2u && nrs > 1)) { fits = false; break; }
+                    const unsigned fld = stt | (len << 2);
+                    if (f == 0) hw[0] |= fld << 5; else if (f == 1) hw[0] |= fld << 16;
+                    else if (f == 2) hw[1] |= fld; else if (f == 3) hw[1] |= fld << 11; else hw[2] |= fld;
+                }
+                if (fits) {
+                    hw[0] |= C2_HINT_GAPPED | (unsigned)nrs | ((unsigned)ac[0] << 3);
+                    if (ac[0] > 0) hw[2] |= ((unsigned)ac[9] & 0xfffu) << 11;
+                    if (ac[0] > 1) hw[3] |= (unsigned)ac[10] & 0xfffu;
+                    if (ac[0] > 2) hw[3] |= ((unsigned)ac[11] & 0xfffu) << 12;
+                    uint32_t* hp = A.diag_hints + 4u * task;
+                    hp[0] = hw[0]; hp[1] = hw[1]; hp[2] = hw[2]; hp[3] = hw[3];
+                }
+            }
         }
         if (need_full) {
             st8 |= C2_STATUS_NEED_FULL;
@@ -3177,7 +3211,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                             unsigned h = C2_HINT_VALID | ((unsigned)k << 24);
                             if (k > 0) h |= (unsigned)p1 | ((((unsigned)t.rd[p1] >> 1) & 7u) << 9);
                             if (k > 1) h |= ((unsigned)p2 << 12) | ((((unsigned)t.rd[p2] >> 1) & 7u) << 21);
-                            A.diag_hints[c.task] = h;
+                            A.diag_hints[4u * c.task] = h;               // (words 1 .. 3 stay 0)
                         }
                     }
                 }

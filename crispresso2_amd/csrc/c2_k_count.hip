@@ -206,7 +206,11 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
                 const uint64_t r = my_pos / nr;
                 my_task = (my_pos - r * nr) * (uint64_t)A.n_refs + r;
             }
-            const unsigned wq = (A.hints && (A.hints[my_task] & C2_HINT_VALID)) ? 0u : (A.weights ? A.weights[my_task] : 1u);   // (a hinted task: c2_count_hinted_kernel's)
+            unsigned wq = A.weights ? A.weights[my_task] : 1u;
+            if (A.hints) {                                               // (a hinted task is c2_count_hinted_kernel's: every main-diagonal hint, a gapped one below its weight limit)
+                const unsigned h0 = A.hints[4u * my_task];
+                if ((h0 & C2_HINT_VALID) || ((h0 & C2_HINT_GAPPED) && wq < 1024u)) wq = 0u;
+            }
             v_w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
             if (v_w > 0) {                                               // (an alignment that is not counted is not even read: most of an all-references batch)
                 const unsigned* rp = (const unsigned*)(A.records + my_task);
@@ -750,40 +754,73 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vector
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// c2_count_hinted_kernel (round 6): the tasks whose alignment c2_align_partition_kernel finished itself -- the read on its reference's main diagonal,
-// at most two differing bases: 58 % of the headline batch -- counted from their HINT WORD alone (c2_batch.diag_hints), a lane per task: neither the
-// 2 x 250 bytes of strings nor the record are read back.  One reference (the host checks).  What such an alignment adds (CRISPRessoCORE.py:3996-4115,
-// the same statements c2_count_vectors_body executes for a gap-free alignment): its weight w to the scalars and histogram bins of its class -- kept
-// in 64-bit registers per lane over the lane's ~40 tasks, reduced once per wavefront at the end --, w on the base vector of the reference's own base
-// at every position (the sum over all tasks, spread at the end), and per differing base the deviations (+w on the read's base, -w on the reference's,
-// the substitution vectors) as int32 LDS atomics, flushed before anything can wrap (a weight of 65,536 or more goes to the tensor directly).
+// c2_count_hinted_kernel (round 6): the tasks whose alignment left a HINT (c2_batch.diag_hints, four words per task) counted from the hint, a lane per
+// task -- the 2 x 250 bytes of aligned strings are not read back.  One reference (the host checks).
+//   C2_HINT_VALID   (c2_align_partition_kernel: the read on its reference's main diagonal, at most two differing bases -- 58 % of the headline batch):
+//                   from the word alone, not even the record is read.  Its weight w goes to the scalars and histogram bins of its class -- kept in
+//                   64-bit registers per lane, reduced once per wavefront at the end --, w on the base vector of the reference's own base at every
+//                   position (summed, spread at the end), and per differing base the deviations.
+//   C2_HINT_GAPPED  (c2_group_epilogue: at most five runs, at most three differing columns, weight below C2_HCNT_SMALL_W): the record (32 bytes) for the
+//                   scalar counters -- the statements of c2_count_vectors_body's scalar stage --, and from the runs what its column walk adds:
+//                   runs of M as ranges of "the read's base is the reference's" (difference array `cov`), deletions as ranges (`dcov`, C2_V_DELETION,
+//                   C2_V_DELETION_LENGTH), insertions at their two flanks, the differing columns one by one (CRISPRessoCORE.py:4010-4115).
+// The position vectors accumulate in an int32 LDS block, flushed before anything can wrap (every C2_HCNT_FLUSH_ROUNDS rounds of 256 tasks: a task adds
+// at most 512 * w to an entry, w < C2_HCNT_SMALL_W); a main-diagonal task of a larger weight goes to the tensor directly, a gapped one of a larger
+// weight is left to c2_count_vectors_kernel (which skips exactly the tasks this kernel takes: c2_count_task_is_hinted).
 // ---------------------------------------------------------------------------------------------------------------
-#define C2_HCNT_SMALL_W 65536                  // weights below this accumulate in the LDS block ...
-#define C2_HCNT_FLUSH_ROUNDS 64                // ... which is flushed every so many rounds of 256 tasks: 64 x 256 x 2 deviations x 65,535 < 2^31
+#define C2_HCNT_SMALL_W 1024
+#define C2_HCNT_FLUSH_ROUNDS 16                // 16 x 256 tasks x 512 x 1,023 < 2^31
 __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
 {
     typedef unsigned long long u64;
-    const int tid = threadIdx.x;
-    const int VL = A.lmax + 1, NV = C2_CNT_VECTORS * VL;
-    int* acc = (int*)c2_smem;
-    u64* tot = (u64*)(c2_smem + ((size_t)NV * sizeof(int) + 15) / 16 * 16);
-    uint16_t* incp = (uint16_t*)(tot + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int VL = A.lmax + 1, NV = C2_CNT_VECTORS * VL, NH = C2_CNT_HISTS * A.hl;
+    int* acc = (int*)c2_smem;                                       // [NV] position vectors, [NH] histograms, [2 * VL] cov / dcov
+    int* hist = acc + NV;
+    int* cov = hist + NH;
+    int* dcov = cov + VL;
+    u64* tot = (u64*)(c2_smem + (((size_t)(NV + NH + 2 * VL)) * sizeof(int) + 15) / 16 * 16);   // [16] the main-diagonal tasks' totals, [C2_CNT_SCALARS] the gapped tasks' scalars
+    u64* scal = tot + 16;
+    uint16_t* incp = (uint16_t*)(scal + C2_CNT_SCALARS);
+    int* part = (int*)(incp + ((A.lmax + 2 + 7) / 8) * 8);          // [4] carries of the scans
     const c2_dev_ref rf = A.refs[0];
     const int Li = rf.len;
     const int o_sc = NV, o_h = o_sc + C2_CNT_SCALARS;
-    for (int k = tid; k < NV; k += 256) acc[k] = 0;
-    if (tid < 16) tot[tid] = 0ull;
+    for (int k = tid; k < NV + NH + 2 * VL; k += 256) acc[k] = 0;
+    if (tid < 16 + C2_CNT_SCALARS) tot[tid] = 0ull;
     for (int k = tid; k < Li + 2; k += 256) incp[k] = rf.inc_prefix[k];
     __syncthreads();
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS, ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS;
-    // the selection test of CRISPRessoCORE.py:697 for an alignment of Li columns with Li - k matches
+    const bool discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
+    // the selection test of CRISPRessoCORE.py:697 for a main-diagonal alignment: Li columns, Li - k matches
     bool gate = Li > 0;
     int thresh = 0;
     if (A.min_matches) { if (Li > A.max_t) gate = false; else thresh = (int)A.min_matches[Li]; }
     long long* out = A.counts;
+    // the LDS block -> the tensor: the difference arrays integrated first (as c2_count_vectors_body's flush does)
     auto flush = [&]() {
         __syncthreads();
+        {
+            int* d = wave == 3 ? dcov : wave == 2 ? cov : acc + (wave == 0 ? C2_V_DELETION : C2_V_DELETION_LENGTH) * VL;
+            int carry = 0;
+            for (int base = 0; base < VL; base += 64) {
+                const int k = base + lane;
+                const int x = (k < VL) ? d[k] : 0;
+                const int sc_ = c2_wave_incl_scan(x, lane) + carry;
+                if (k < VL) d[k] = sc_;
+                carry = __shfl(sc_, 63);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < VL; c += 256) {
+            const int x = cov[c], dx = dcov[c];
+            cov[c] = 0; dcov[c] = 0;
+            if (c < Li && x != 0) { const int bv = c2_base_vector(rf.seq[c]); if (bv >= 0) acc[bv * VL + c] += x; }
+            if (c < Li && dx != 0) { acc[C2_V_ALL_DELETION * VL + c] += dx; acc[C2_V_BASE_GAP * VL + c] += dx; }     // :4028, :4075-4081
+        }
+        __syncthreads();
         for (int k = tid; k < NV; k += 256) { const int x = acc[k]; if (x != 0) { atomicAdd((u64*)(out + k), (u64)(long long)x); acc[k] = 0; } }
+        for (int k = tid; k < NH; k += 256) { const int x = hist[k]; if (x != 0) { atomicAdd((u64*)(out + o_h + k), (u64)(long long)x); hist[k] = 0; } }
         __syncthreads();
     };
     u64 sW = 0, sN = 0, sSubW = 0, sGsub = 0, sOut = 0, sIn = 0, sIrr = 0, sH0 = 0, sH1 = 0, sH2 = 0;
@@ -792,7 +829,7 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < A.n_tasks; base += (uint64_t)gridDim.x * 256u) {
         const uint64_t t = base + (uint64_t)tid;
         unsigned h = 0;
-        if (t < A.n_tasks) h = A.hints[t];
+        if (t < A.n_tasks) h = A.hints[4u * t];
         if (h & C2_HINT_VALID) {
             const unsigned wq = A.weights ? A.weights[t] : 1u;
             const int w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
@@ -833,11 +870,109 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
                 if (irregular) sIrr += W;
                 if (sub_n == 0) sH0 += W; else if (sub_n == 1) sH1 += W; else sH2 += W;
             }
+        } else if (h & C2_HINT_GAPPED) {
+            const unsigned wq = A.weights ? A.weights[t] : 1u;
+            if (wq > 0u && wq < (unsigned)C2_HCNT_SMALL_W) {
+                const int w = (int)wq;
+                const unsigned* rp = (const unsigned*)(A.records + t);
+                const unsigned d0 = rp[0], d1 = rp[1], d2 = rp[2], d4 = rp[4], d5 = rp[5];
+                const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16);
+                bool sel = ((d5 >> 24) == 0) && (T > 0);
+                if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[T]);
+                if (sel) {
+                    // ---- the scalar counters and histograms, as c2_count_vectors_body adds them from the record (aln_stats of process_fastq,
+                    //      CRISPRessoCORE.py:1974-1979; the tallies of :3996-4072)
+                    const int insertion_n = (int)(d1 & 0xffffu), deletion_n = (int)(d1 >> 16), substitution_n = (int)(d2 & 0xffffu);
+                    const int all_ins = (int)(d2 >> 16), all_del_bases = (int)((d4 >> 16) & 0x7fffu), all_sub = (int)(d5 & 0xffffu);
+                    const bool irregular_ends = (d5 >> 16) & 0xffu;
+                    const int total_mods = all_ins + all_del_bases + all_sub, in_win = substitution_n + deletion_n + insertion_n;      // :741-742
+                    auto sadd = [&](const int k_, const long long x) { if (x) atomicAdd(scal + k_, (u64)x); };
+                    const long long W = w;
+                    sadd(C2_S_N_GLOBAL_SUBS, all_sub * W); sadd(C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - substitution_n) * W);
+                    sadd(C2_S_N_MODS_IN_WINDOW, in_win * W); sadd(C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * W);
+                    if (irregular_ends) sadd(C2_S_N_READS_IRREGULAR_ENDS, W);
+                    sadd(C2_S_ALIGNMENTS_COUNTED, 1);
+                    const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
+                    const bool modified = has_del || has_ins || has_sub;
+                    if (discard && (deletion_n > 0 || insertion_n > 0)) sadd(C2_S_DISCARDED, W);                     // :3996-4000: counted, no vectors
+                    else {
+                        sadd(C2_S_TOTAL, W);
+                        sadd(modified ? C2_S_MODIFIED : C2_S_UNMODIFIED, W);                                        // :746-760, :4003-4006
+                        if (has_ins) sadd(C2_S_INSERTION, W);
+                        if (has_del) sadd(C2_S_DELETION, W);
+                        if (has_sub) sadd(C2_S_SUBSTITUTION, W);
+                        int combo = -1;                                                                             // :4058-4072
+                        if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
+                                                     : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
+                        else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
+                        else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
+                        if (combo >= 0) sadd(combo, W);
+                        if (!ign_ins) atomicAdd(hist + C2_H_INSERTED_N * A.hl + insertion_n, w);                    // :4020
+                        if (!ign_del) atomicAdd(hist + C2_H_DELETED_N * A.hl + deletion_n, w);                      // :4030
+                        if (!ign_sub) atomicAdd(hist + C2_H_SUBSTITUTED_N * A.hl + substitution_n, w);              // :4043
+                        atomicAdd(hist + C2_H_EFFECTIVE_LEN * A.hl + Li + (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n), w);   // :4010-4037
+                        // ---- what the column walk adds, run by run (c2_count_vectors_body, "eight columns per lane")
+                        const bool len_block = modified;                                                            // :4085 (no coding sequence)
+                        const uint4 hw = *(const uint4*)(A.hints + 4u * t);
+                        const int nruns = (int)(hw.x & 7u), nmm = (int)((hw.x >> 3) & 3u);
+                        int ix = 0;                                                                                 // reference bases in front of the run
+#pragma unroll
+                        for (int f = 0; f < 5; ++f) {
+                            if (f >= nruns) continue;
+                            const unsigned fld = (f == 0 ? hw.x >> 5 : f == 1 ? hw.x >> 16 : f == 2 ? hw.y : f == 3 ? hw.y >> 11 : hw.z) & 0x7ffu;
+                            const int st = (int)(fld & 3u), len = (int)(fld >> 2);
+                            if (st == C2_ST_M) {
+                                // the read's base IS the reference's (all_base_count, :4075-4081; the differing columns are taken back below)
+                                atomicAdd(cov + ix, w); atomicAdd(cov + ix + len, -w);
+                                ix += len;
+                            } else if (st == C2_ST_J) {
+                                // a deletion: its columns (all_deletion :4028, the '-' base counts) as a range; the window counts as ranges too
+                                atomicAdd(dcov + ix, w); atomicAdd(dcov + ix + len, -w);
+                                if (incp[ix + len] != incp[ix]) {                                                   // range(start, end) touches the window
+                                    if (!ign_del) { atomicAdd(acc + C2_V_DELETION * VL + ix, w); atomicAdd(acc + C2_V_DELETION * VL + ix + len, -w); }   // :4031
+                                    if (len_block) { atomicAdd(acc + C2_V_DELETION_LENGTH * VL + ix, len * w); atomicAdd(acc + C2_V_DELETION_LENGTH * VL + ix + len, -len * w); }   // :4114
+                                }
+                                ix += len;
+                            } else {
+                                // an insertion closes at the next reference base: positions [ix - 1, ix] (:4016-4021); none in front of the first
+                                // reference base, none behind the last run (pyx:119-136)
+                                if (ix > 0 && f + 1 < nruns) {
+                                    atomicAdd(acc + C2_V_ALL_INSERTION_LEFT * VL + ix - 1, w);                      // :4017
+                                    atomicAdd(acc + C2_V_ALL_INSERTION * VL + ix, w);
+                                    atomicAdd(acc + C2_V_ALL_INSERTION * VL + ix - 1, w);
+                                    if ((incp[ix] != incp[ix - 1]) && (incp[ix + 1] != incp[ix])) {                 // both flanks in the window, pyx:121
+                                        if (!ign_ins) { atomicAdd(acc + C2_V_INSERTION * VL + ix, w); atomicAdd(acc + C2_V_INSERTION * VL + ix - 1, w); }
+                                        if (len_block) { atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + ix - 1, len * w); atomicAdd(acc + C2_V_INSERTION_LENGTH * VL + ix, len * w); }   // :4104-4106
+                                    }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) {
+                            if (e >= nmm) continue;
+                            const unsigned ent = (e == 0 ? hw.z >> 11 : e == 1 ? hw.w : hw.w >> 12) & 0xfffu;
+                            const int c = (int)(ent & 0x1ffu);
+                            const unsigned char rd = (unsigned char)(chars >> (8 * ((ent >> 9) & 7u)));
+                            atomicAdd(cov + c, -w); atomicAdd(cov + c + 1, w);                                      // not "the reference's own base" here ...
+                            const int bv = c2_base_vector(rd);
+                            if (bv >= 0) atomicAdd(acc + bv * VL + c, w);                                           // ... but the read's
+                            if (rd != 'N') {
+                                atomicAdd(acc + C2_V_ALL_SUBSTITUTION * VL + c, w);                                 // :4040
+                                if (!ign_sub) {
+                                    if (incp[c + 1] != incp[c]) atomicAdd(acc + C2_V_SUBSTITUTION * VL + c, w);     // :4044
+                                    const int sv = c2_sub_base_vector(rd);                                          // :4049-4054
+                                    if (sv >= 0) atomicAdd(acc + sv * VL + c, w);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
         }
         if ((++rounds % C2_HCNT_FLUSH_ROUNDS) == 0u) flush();
     }
     flush();
-    // the lanes' totals -> the wavefront's -> the workgroup's (LDS, 64-bit) -> the tensor
+    // the lanes' totals of the main-diagonal tasks -> the wavefront's -> the workgroup's (LDS, 64-bit) -> the tensor
     u64 v[10] = {sW, sN, sSubW, sGsub, sOut, sIn, sIrr, sH0, sH1, sH2};
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
@@ -848,12 +983,13 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
             const u64 sum = ((u64)hi << 32 | lo) + ((u64)ohi << 32 | olo);
             lo = (unsigned)sum; hi = (unsigned)(sum >> 32);
         }
-        if ((tid & 63) == 0) atomicAdd(tot + q, ((u64)hi << 32) | lo);
+        if (lane == 0) atomicAdd(tot + q, ((u64)hi << 32) | lo);
     }
     __syncthreads();
+    auto gadd = [&](const int idx, const u64 x) { if (x) atomicAdd((u64*)(out + idx), x); };
+    if (tid < C2_CNT_SCALARS) gadd(o_sc + tid, scal[tid]);           // the gapped tasks' scalars
     const u64 W = tot[0];
     if (W == 0ull && tot[1] == 0ull) return;
-    auto gadd = [&](const int idx, const u64 x) { if (x) atomicAdd((u64*)(out + idx), x); };
     if (tid == 0) {
         const u64 subw = tot[2];
         gadd(o_sc + C2_S_TOTAL, W); gadd(o_sc + C2_S_MODIFIED, subw); gadd(o_sc + C2_S_UNMODIFIED, W - subw);      // :746-760, :4003-4006
@@ -866,7 +1002,7 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
         if (!ign_sub) { gadd(o_h + C2_H_SUBSTITUTED_N * A.hl + 0, tot[7]); gadd(o_h + C2_H_SUBSTITUTED_N * A.hl + 1, tot[8]); gadd(o_h + C2_H_SUBSTITUTED_N * A.hl + 2, tot[9]); }   // :4043
         gadd(o_h + C2_H_EFFECTIVE_LEN * A.hl + Li, W);                                                               // :4010-4037
     }
-    // every reference position: the tasks' total weight on the vector of its own base (the deviations above took the differing ones back)
+    // every reference position: the main-diagonal tasks' total weight on the vector of its own base (the deviations above took the differing ones back)
     for (int c = tid; c < Li; c += 256) {
         const int bv = c2_base_vector(rf.seq[c]);
         if (bv >= 0) gadd(bv * VL + c, W);

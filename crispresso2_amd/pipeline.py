@@ -785,7 +785,7 @@ class _UniqueRun:
             self.f1 = torch.empty((self.n1, self.stride), dtype=torch.uint8, device=dev)
             self.r1 = torch.empty((self.n1, 32), dtype=torch.uint8, device=dev)
             # one amplicon: the hint words of the reads the partition finishes itself (c2_batch.diag_hints) -- the count pass takes those from the word alone
-            self.h1 = torch.empty(self.n1, dtype=torch.int32, device=dev) if (k == 1 and self.n1) else None
+            self.h1 = torch.empty(self.n1 * 4, dtype=torch.int32, device=dev) if (k == 1 and self.n1) else None
             self.aligner.align_device(n, self.d_reads.data_ptr(), self.d_off.data_ptr(), self.a1.data_ptr(), self.f1.data_ptr(), self.r1.data_ptr(),
                                       self.stride, self.max_lj, d_strands=d_str1.data_ptr(), all_refs=True, stream=self.stream, legacy=self.legacy,
                                       min_read_len=int(self.lens.min()) if n else 0, d_hints=None if self.h1 is None else self.h1.data_ptr())

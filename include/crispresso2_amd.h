@@ -122,15 +122,23 @@ typedef struct c2_batch {
     int32_t min_read_len;      /* shortest read of the batch, or 0 = not known.  A hint that never changes results: a band tier of the launch chain
                                   that no read of [min_read_len, max_read_len] against any reference can use (|len(ref) - len(read)| outside its band, e.g.
                                   150-bp mates against a 250-bp amplicon) is not launched instead of being passed through task by task */
-    uint32_t* diag_hints;      /* optional output (DEVICE path only; NULL = none), n_tasks words: 0, or C2_HINT_VALID | a summary of an alignment that is its reference's main
-                                  diagonal with at most two differing bases -- what c2_align_partition_kernel finishes without a matrix (round 5).  A hint restates
-                                  the aligned strings and the record of its task (it IS derived from them), so that the count pass need not read them back:
-                                  c2_count_vectors_hinted_device.  Every word is written (0 where there is nothing to say). */
+    uint32_t* diag_hints;      /* optional output (DEVICE path only; NULL = none), FOUR words per task (n_tasks x 4): zeros, or a summary of the alignment that the count pass
+                                  can use instead of reading the two aligned strings back (c2_count_vectors_hinted_device):
+                                    C2_HINT_VALID   the read lies on its reference's main diagonal with at most two differing bases -- what c2_align_partition_kernel
+                                                    finishes without a matrix (round 5); word 0 only
+                                    C2_HINT_GAPPED  an alignment of at most five runs (M / insertion / deletion) and at most three differing columns, as the lane-group
+                                                    epilogue of the band kernels leaves it (round 6; not under the legacy classifier)
+                                  A hint restates the aligned strings of its task (it IS derived from them).  Every word is written (0 where there is nothing to say). */
 } c2_batch;
 #define C2_BATCH_LEGACY_CLASSIFIER 1u
 /* a hint word: bit 31 valid | bits 24..25 differing bases k (0, 1, 2) | first: position bits 0..8, read base bits 9..11 | second: position bits 12..20, read base
  * bits 21..23; read bases as codes 0..4 = A C G T N.  The alignment: aln_len = matches + k = len(reference) = len(read), both strings without a gap. */
 #define C2_HINT_VALID 0x80000000u
+/* C2_HINT_GAPPED: word 0 bits 0..2 runs n (1..5), bits 3..4 differing columns m (0..3), run 0 bits 5..15, run 1 bits 16..26; word 1 run 2 bits 0..10, run 3 bits
+ * 11..21; word 2 run 4 bits 0..10, differing column 0 bits 11..22; word 3 differing columns 1 and 2 (bits 0..11, 12..23).  A run, in the order of the strings:
+ * state (1 M, 2 insertion = gap in the reference string, 3 deletion = gap in the read's) | length << 2.  A differing column (both strings have a base there):
+ * reference index | read base code << 9 (codes: (ch >> 1) & 7 -- A 0, C 1, T 2, G 3, N 7). */
+#define C2_HINT_GAPPED 0x40000000u
 
 /* All pointers in `b` are DEVICE pointers; the launch is enqueued on `hip_stream` (a hipStream_t; NULL is HIP's
  * default stream, exactly as in hipLaunchKernelGGL) and the call returns without waiting. */

@@ -50,7 +50,7 @@ class _Aligner(EmulatedAligner):
         _, rec = E.align_batch(reads, self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=rids, all_refs=all_refs,
                                band_lanes=-87 if self.ctx.mode == "auto" else 0, stats=st)
         if d_hints:
-            _view(d_hints, 4 * ntasks).view(np.uint32)[:] = st["hints"]
+            _view(d_hints, 16 * ntasks).view(np.uint32)[:] = st["hints"].reshape(-1)
         o1, o2 = st["raw"]
         w = min(o1.shape[1], aln_stride)
         a = _view(d_aln_read, ntasks * aln_stride).reshape(ntasks, aln_stride)

@@ -100,7 +100,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     const int R = force_R ? force_R : c2_choose_rows_per_lane(max_li);
     uint32_t* hints = g_next_hints_out;
     g_next_hints_out = nullptr;
-    if (hints) memset(hints, 0, (size_t)(n_reads * (uint64_t)(all_refs ? n_refs : 1)) * sizeof(uint32_t));     // (the library's hipMemsetAsync)
+    if (hints) memset(hints, 0, (size_t)(n_reads * (uint64_t)(all_refs ? n_refs : 1)) * 4u * sizeof(uint32_t));     // (the library's hipMemsetAsync)
     c2_align_args A;
     A.reads = reads; A.offsets = offsets; A.ref_ids = ref_ids; A.strands = strands; A.refs = refs.data();
     A.score_tbl = sc.tbl.data(); A.code_of_char = sc.code_of_char;

@@ -75,7 +75,7 @@ def align_batch(reads, refs, gap_incentives, includes, matrix, gap_open, gap_ext
     st = None if strands is None else np.ascontiguousarray(strands, dtype=np.uint8)
     hints = None
     if stats is not None and stats.get("want_hints"):                # c2_batch.diag_hints: one word per task
-        hints = np.full(ntasks, 0xdeadbeef, dtype=np.uint32)
+        hints = np.full((ntasks, 4), 0xdeadbeef, dtype=np.uint32)       # four words per task
         lib().emu_set_hints_out(hints.ctypes.data_as(ctypes.c_void_p))
     nfb = ctypes.c_int(0)
     rc = lib().emu_align_batch(

@@ -48,7 +48,7 @@ class EmulatedAligner:
         _, rec = E.align_batch(reads, self.seqs, self.g, self.inc, self.m, self.go, self.ge, ref_ids=rids, strands=strands,
                                all_refs=all_refs, band_lanes=-87, stats=st)
         if d_hints:
-            _view(d_hints, 4 * ntasks).view(np.uint32)[:] = st["hints"]
+            _view(d_hints, 16 * ntasks).view(np.uint32)[:] = st["hints"].reshape(-1)
         o1, o2 = st["raw"]
         w = min(o1.shape[1], aln_stride)
         assert int(rec["aln_len"].max()) <= w
@@ -125,7 +125,7 @@ def _accumulate(aligners):
         f = _view(d_aln_ref, n_tasks * aln_stride).reshape(n_tasks, aln_stride)
         rec = _view(d_records, 32 * n_tasks).view(E.REC_DTYPE).reshape(-1)
         w = None if not d_weights else _view(d_weights, 4 * n_tasks).view(np.uint32).copy()
-        hints = None if not d_hints else _view(d_hints, 4 * n_tasks).view(np.uint32).copy()
+        hints = None if not d_hints else _view(d_hints, 16 * n_tasks).view(np.uint32).copy().reshape(n_tasks, 4)
         counts, lay = E.count_vectors(a, f, rec, al.seqs, al.inc, layout.hl - layout.lmax - 2,
                                       weights=w, min_matches=min_matches, flags=flags, hints=hints)
         assert lay.shape() == layout.shape(), (lay.shape(), layout.shape())

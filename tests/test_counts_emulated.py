@@ -386,9 +386,10 @@ def test_hinted_tasks_are_counted_from_their_hint_word_alone(L, flags):
     st = {"want_hints": True}
     res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
     o1, o2 = st["raw"]
-    hints = st["hints"]
+    hints4 = st["hints"]
+    hints = hints4[:, 0]
     n_hinted = int((hints >> 31).sum())
-    assert n_hinted == st["exact_copies"] > 200 and (hints[(hints >> 31) == 0] == 0).all()        # every word is written: 0 where there is nothing to say
+    assert n_hinted == st["exact_copies"] > 200 and (hints4[:, 1:][(hints >> 30) == 0] == 0).all() and (hints[(hints >> 30) == 0] == 0).all()   # every word is written: 0 where there is nothing to say
     for k in np.nonzero(hints >> 31)[0][:60]:                             # a hint restates its alignment
         kk = int((hints[k] >> 24) & 3)
         diff = [c for c in range(L) if reads[k][c] != amp[c]]
@@ -401,16 +402,96 @@ def test_hinted_tasks_are_counted_from_their_hint_word_alone(L, flags):
     w[7] = 0x90000000                                                     # (clamped to 2^31 - 1 by both kernels)
     for mm in (None, C.min_matches_table([99.3], L + L)):                 # 99.3: two differing bases of 250 (99.2) fail, one (99.6) passes
         plain, lay = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w, min_matches=mm, flags=flags)
-        hinted, _ = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w, min_matches=mm, flags=flags, hints=hints)
+        hinted, _ = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w, min_matches=mm, flags=flags, hints=hints4)
         assert np.array_equal(plain, hinted), np.nonzero(plain != hinted)
         # ... and with the rows of the hinted tasks wiped: they are not read
         w1, w2 = o1.copy(), o2.copy()
-        w1[(hints >> 31) == 1] = 0x58; w2[(hints >> 31) == 1] = 0x59
-        wiped, _ = E.count_vectors(w1, w2, rec, [amp], [inc], L, weights=w, min_matches=mm, flags=flags, hints=hints)
+        taken = ((hints >> 31) == 1) | (((hints >> 30) & 1) == 1) & (w < 1024)       # (a gapped hint is used below the hinted kernel's weight limit)
+        w1[taken] = 0x58; w2[taken] = 0x59
+        wiped, _ = E.count_vectors(w1, w2, rec, [amp], [inc], L, weights=w, min_matches=mm, flags=flags, hints=hints4)
         assert np.array_equal(plain, wiped)
     got = lay.unpack(hinted, 0, L)
     thr = 99.3
     items = [(p, int(min(c, 0x7fffffff))) for p, c, r in zip(payloads(res, inc), w, rec) if c > 0 and round(100 * int(r["matches"]) / float(int(r["aln_len"])), 3) > thr]
+    exp = aggregate.aggregate(items, L, ignore_substitutions=bool(flags & 1), ignore_insertions=bool(flags & 2),
+                              ignore_deletions=bool(flags & 4), discard_indel_reads=bool(flags & 8))
+    compare(got, exp, L)
+
+
+def _gapped_reads(rng, amp, n):
+    """reads with one or two indels anywhere (also at the window's edges, in front, at the end), 0 .. 4 differing bases (N's among them, next to the gaps too)"""
+    L = len(amp)
+    out = []
+    for k in range(n):
+        t = list(amp)
+        for _ in range(int(rng.integers(0, 5))):
+            t[int(rng.integers(0, L))] = str(rng.choice(list("ACGTN")))
+        for _ in range(int(rng.integers(1, 3))):
+            kind = int(rng.integers(0, 6))
+            p = int(rng.integers(0, len(t)))
+            d = int(rng.integers(1, 25))
+            if kind <= 1: del t[p:p + d]                                           # deletion
+            elif kind <= 3: t[p:p] = list(rng.choice(list("ACGT"), d))             # insertion
+            elif kind == 4: t = t[d:]                                              # the read starts inside the amplicon
+            else: t = t[:len(t) - d] + list(rng.choice(list("ACGT"), int(rng.integers(0, 12))))   # ends early / runs over
+        out.append("".join(t) if len(t) >= 40 else amp)
+    return out
+
+
+@pytest.mark.parametrize("flags", [0, C.FLAG_IGNORE_SUBSTITUTIONS, C.FLAG_IGNORE_INSERTIONS | C.FLAG_IGNORE_DELETIONS, C.FLAG_DISCARD_INDEL_READS])
+@pytest.mark.parametrize("L,seed", [(250, 1), (250, 2), (120, 3)])
+def test_gapped_hints_count_like_the_column_walk(L, seed, flags):
+    """Round 6: the lane-group epilogue leaves a four-word hint for an alignment of at most five runs and three differing columns (C2_HINT_GAPPED: its runs, and
+    where / what its differing columns are); c2_count_hinted_kernel counts it from the hint and its record -- the position vectors run by run, in closed
+    form -- instead of walking the strings.  700 reads with indels of every kind: the tensor with the hints equals the tensor without them entry by entry
+    (also with the hinted tasks' rows wiped), and the reference's aggregation loop; a hint restates its alignment's runs."""
+    E.build()
+    m = matrices()["EDNAFULL"]
+    rng = np.random.default_rng(9000 + seed)
+    amp = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = list(range(L // 2 - 6, L // 2 + 7))
+    reads = _gapped_reads(rng, amp, 700)
+    st = {"want_hints": True}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    assert (rec["status"] == 0).all()
+    o1, o2 = st["raw"]
+    hints4 = st["hints"]
+    h0 = hints4[:, 0]
+    gapped = ((h0 >> 30) & 3) == 1
+    assert gapped.sum() > 300, int(gapped.sum())
+    for k in np.nonzero(gapped)[0][:120]:                                          # the runs of a hint are the runs of its strings
+        s1, s2 = res[k]
+        runs, cur, ln = [], None, 0
+        for a_, b_ in zip(s1, s2):
+            stt = 3 if a_ == "-" else (2 if b_ == "-" else 1)
+            if stt == cur: ln += 1
+            else:
+                if cur is not None: runs.append((cur, ln))
+                cur, ln = stt, 1
+        runs.append((cur, ln))
+        hw = [int(x) for x in hints4[k]]
+        assert (hw[0] & 7) == len(runs) <= 5, (k, runs, hw)
+        flds = [(hw[0] >> 5) & 0x7ff, (hw[0] >> 16) & 0x7ff, hw[1] & 0x7ff, (hw[1] >> 11) & 0x7ff, hw[2] & 0x7ff]
+        assert [(f_ & 3, f_ >> 2) for f_ in flds[:len(runs)]] == runs, (k, runs, flds)
+        diff = [(i, a_) for i, (a_, b_) in enumerate(zip(s1, s2)) if a_ != "-" and b_ != "-" and a_ != b_]
+        assert ((hw[0] >> 3) & 3) == len(diff) <= 3
+    w = rng.integers(1, 30, len(reads)).astype(np.uint32)
+    w[::13] = 0
+    gi = np.nonzero(gapped)[0]
+    w[gi[0]] = 1023; w[gi[1]] = 1024; w[gi[2]] = 70000                             # at / above the hinted kernel's weight limit: the column walk's
+    for mm in (None, C.min_matches_table([90.0], L + max(len(r) for r in reads))):
+        plain, lay = E.count_vectors(o1, o2, rec, [amp], [inc], max(len(r) for r in reads), weights=w, min_matches=mm, flags=flags)
+        hinted, _ = E.count_vectors(o1, o2, rec, [amp], [inc], max(len(r) for r in reads), weights=w, min_matches=mm, flags=flags, hints=hints4)
+        bad = np.nonzero(plain != hinted)
+        assert np.array_equal(plain, hinted), (bad, plain[bad][:8], hinted[bad][:8])
+        taken = ((h0 >> 31) == 1) | (gapped & (w < 1024))
+        w1, w2 = o1.copy(), o2.copy()
+        w1[taken] = 0x58; w2[taken] = 0x59
+        wiped, _ = E.count_vectors(w1, w2, rec, [amp], [inc], max(len(r) for r in reads), weights=w, min_matches=mm, flags=flags, hints=hints4)
+        assert np.array_equal(plain, wiped)
+    got = lay.unpack(hinted, 0, L)
+    items = [(p, int(c)) for p, c, r in zip(payloads(res, inc), w, rec) if c > 0 and round(100 * int(r["matches"]) / float(int(r["aln_len"])), 3) > 90.0]
     exp = aggregate.aggregate(items, L, ignore_substitutions=bool(flags & 1), ignore_insertions=bool(flags & 2),
                               ignore_deletions=bool(flags & 4), discard_indel_reads=bool(flags & 8))
     compare(got, exp, L)

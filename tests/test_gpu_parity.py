@@ -1386,14 +1386,16 @@ def test_gpu_hinted_count_equals_the_count_over_the_rows(mats, ctx, L):
     o1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
     o2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
     rec = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
-    hints = torch.full((n,), 0x5a5a5a5a, dtype=torch.int32, device=dev)
+    hints = torch.full((n * 4,), 0x5a5a5a5a, dtype=torch.int32, device=dev)      # four words per task
     s = torch.cuda.current_stream().cuda_stream
     al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, L, stream=s, d_hints=hints.data_ptr())
     torch.cuda.synchronize()
-    h = hints.cpu().numpy().view(np.uint32)
+    h4 = hints.cpu().numpy().view(np.uint32).reshape(n, 4)
+    h = h4[:, 0]
     records = rec.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
     valid = (h >> 31) == 1
-    assert valid.sum() == ctx.partition_info()["finished_by_partition"] > n // 4 and (h[~valid] == 0).all()
+    gapped = ((h >> 30) & 3) == 1
+    assert valid.sum() == ctx.partition_info()["finished_by_partition"] > n // 4 and (h4[~valid & ~gapped] == 0).all() and gapped.sum() > n // 8
     kk = ((h >> 24) & 3)[valid]
     assert (records["aln_len"][valid] == L).all() and (records["matches"][valid].astype(np.int64) + kk == L).all()
     amp_u8 = np.frombuffer(amp.encode(), dtype=np.uint8)
@@ -1406,6 +1408,8 @@ def test_gpu_hinted_count_equals_the_count_over_the_rows(mats, ctx, L):
     w = rng.integers(0, 40, n).astype(np.uint32)
     first = np.nonzero(valid)[0]
     w[first[0]] = 70000; w[first[1]] = 0x90000000; w[first[2]] = 65536; w[first[3]] = 65535
+    gfirst = np.nonzero(gapped)[0]
+    w[gfirst[0]] = 1024; w[gfirst[1]] = 5000; w[gfirst[2]] = 1023; w[gfirst[3]] = 0x90000000     # (at / above the hinted kernel's weight limit: the column walk's)
     d_w = torch.from_numpy(w.view(np.int32)).to(dev)
     layout = C.CountLayout(1, L, L)
 
@@ -1416,7 +1420,7 @@ def test_gpu_hinted_count_equals_the_count_over_the_rows(mats, ctx, L):
         torch.cuda.synchronize()
         return t.cpu().numpy()
     w1, w2 = o1.clone(), o2.clone()
-    vt = torch.from_numpy(valid).to(dev)
+    vt = torch.from_numpy(valid | (gapped & (w < 1024))).to(dev)          # (a gapped hint is used below the hinted kernel's weight limit)
     w1[vt] = 0x58; w2[vt] = 0x59
     for mm in (None, C.min_matches_table([99.3], L + L)):
         for flags in (0, C.FLAG_IGNORE_SUBSTITUTIONS, C.FLAG_DISCARD_INDEL_READS):
