@@ -995,6 +995,10 @@ __device__ __forceinline__ void c2_emit_gapless4(const c2_align_args& A, const c
     const uint32_t mm = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;      // bit 7 of every byte in which read and reference differ
     int mism = 0, n_all_sub = 0, n_win_sub = 0;
     unsigned long long todo = __ballot(mm != 0);
+    // (c2_batch.diag_hints: a gap-free alignment with at most three differing columns leaves a hint too -- one run of M and the columns; see c2_group_epilogue)
+    const bool want_hint = A.diag_hints != nullptr && L <= 511;
+    unsigned ent[3] = {0u, 0u, 0u};
+    int n_ent = 0;
     if (todo) {
         const uint32_t y = rd ^ 0x4e4e4e4eu;                                         // COREResources.pyx:113-118: a read 'N' is no substitution
         const uint32_t sub = mm & ((((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u);
@@ -1002,6 +1006,17 @@ __device__ __forceinline__ void c2_emit_gapless4(const c2_align_args& A, const c
         while (todo) {                                                               // (a read of an amplicon run differs in a lane or two)
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1ull;
+            if (want_hint) {
+                const unsigned mml = (unsigned)__builtin_amdgcn_readlane((int)mm, l), rdl = (unsigned)__builtin_amdgcn_readlane((int)rd, l);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if ((mml >> (8 * b + 7)) & 1u) {
+                        const unsigned ch = (rdl >> (8 * b)) & 0xffu, code = (ch >> 1) & 7u;
+                        const unsigned long long chars = (unsigned long long)'A' | ((unsigned long long)'C' << 8) | ((unsigned long long)'T' << 16) | ((unsigned long long)'G' << 24) | ((unsigned long long)'N' << 56);
+                        if (((unsigned)(chars >> (8 * code)) & 0xffu) != ch) n_ent = 64;          // (no base: no hint)
+                        else { if (n_ent < 3) ent[n_ent] = (unsigned)(4 * l + b) | (code << 9); ++n_ent; }
+                    }
+            }
             mism += __builtin_popcount((unsigned)__builtin_amdgcn_readlane((int)mm, l));
             const unsigned subl = (unsigned)__builtin_amdgcn_readlane((int)sub, l);
             n_all_sub += __builtin_popcount(subl);
@@ -1019,6 +1034,13 @@ __device__ __forceinline__ void c2_emit_gapless4(const c2_align_args& A, const c
     rec.matches = (uint16_t)(L - mism);                                              // pyx:375-376
     rec.substitution_n = (uint16_t)n_win_sub;
     rec.all_substitutions = (uint16_t)n_all_sub;
+    if (want_hint && n_ent <= 3 && lane == 0) {
+        uint32_t* hp = A.diag_hints + 4u * task;
+        hp[0] = C2_HINT_GAPPED | 1u | ((unsigned)n_ent << 3) | (((unsigned)C2_ST_M | ((unsigned)L << 2)) << 5);
+        hp[1] = 0u;
+        hp[2] = ent[0] << 11;
+        hp[3] = ent[1] | (ent[2] << 12);
+    }
 }
 
 // A gap-free alignment of two sequences of equal length: the aligned strings are the read and the reference themselves, and
@@ -1838,6 +1860,16 @@ __device__ __forceinline__ unsigned c2_word_nib(const unsigned w, const int a, c
     return ((ih >> 1) << 3) | ((jm >> 1) << 2) | (((ih & 1u) ^ 1u) << 1) | ((jm & 1u) ^ 1u);
 }
 
+// a differing column joins the alignment's hint (list[0]: how many so far, list[1 .. 3]: reference index | read base code << 9).  The hint names a read base
+// by (ch >> 1) & 7, which tells A C G T N apart and nothing else: any other character (an IUPAC code) spoils the count, and with it the hint
+__device__ __forceinline__ void c2_hint_note(int* list, const int idx, const unsigned ch) {
+    const unsigned long long chars = (unsigned long long)'A' | ((unsigned long long)'C' << 8) | ((unsigned long long)'T' << 16) | ((unsigned long long)'G' << 24) | ((unsigned long long)'N' << 56);
+    const unsigned code = (ch >> 1) & 7u;
+    if (((unsigned)(chars >> (8 * code)) & 0xffu) != ch) { atomicAdd(list, 64); return; }
+    const int k = atomicAdd(list, 1);
+    if (k < 3) list[1 + k] = idx | (int)(code << 9);
+}
+
 template <int NA, bool PK, int LPW, int NL>
 __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const c2_diagx_plan& P, const int lane, const unsigned m_trace_all, const int sbase,
                                                   int* sTab, const unsigned* gWords, const int slotWords, const bool rows_aligned)
@@ -2108,7 +2140,7 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
                         ++n_mism;
                         const int idx = c - il;
                         if (rch != 'N') { ++n_sub; n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0; }
-                        if (want_hint) { const int k = atomicAdd(&acc[8], 1); if (k < 3) acc[9 + k] = idx | (int)((((unsigned)rch >> 1) & 7u) << 9); }
+                        if (want_hint) c2_hint_note(acc + 8, idx, (unsigned)rch);
                     }
                     if (rch == '-' || fch == '-') dash = true;
                 } else if ((st == C2_ST_I && rch == '-') || (st == C2_ST_J && fch == '-')) dash = true;
@@ -2148,7 +2180,7 @@ __device__ __forceinline__ void c2_group_epilogue(const c2_align_args& A, const 
                             if ((mm >> (8 * b + 7)) & 1u) {
                                 const int idx = c0 + b - ins_left;                                      // reference index of the column
                                 if ((sb >> (8 * b + 7)) & 1u) n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0;
-                                if (want_hint) { const int k = atomicAdd(&acc[8], 1); if (k < 3) acc[9 + k] = idx | (int)((((r4 >> (8 * b)) & 0xffu) >> 1) & 7u) << 9; }
+                                if (want_hint) c2_hint_note(acc + 8, idx, (r4 >> (8 * b)) & 0xffu);
                             }
                     }
                 } else {

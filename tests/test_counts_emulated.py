@@ -495,3 +495,36 @@ def test_gapped_hints_count_like_the_column_walk(L, seed, flags):
     exp = aggregate.aggregate(items, L, ignore_substitutions=bool(flags & 1), ignore_insertions=bool(flags & 2),
                               ignore_deletions=bool(flags & 4), discard_indel_reads=bool(flags & 8))
     compare(got, exp, L)
+
+
+def test_a_differing_column_that_is_no_base_leaves_no_hint():
+    """a hint names a read base by (ch >> 1) & 7 -- A C G T N and nothing else: a read with an IUPAC code in a differing column must not leave one (the
+    count pass then walks its strings, as it did); the tensor with the batch's hints equals the tensor without them"""
+    E.build()
+    m = matrices()["EDNAFULL"]
+    rng = np.random.default_rng(77)
+    L = 200
+    amp = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = list(range(L // 2 - 5, L // 2 + 5))
+    reads = []
+    for k in range(120):
+        t = list(amp)
+        p = int(rng.integers(5, L - 30))
+        t[p] = "RYKMSWBDHV"[k % 10] if k % 3 else str(rng.choice(list("ACGT")))
+        if k % 2: del t[L // 2 - 3:L // 2 + 4]                                          # ... with and without a deletion at the cut
+        reads.append("".join(t))
+    st = {"want_hints": True}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    assert (rec["status"] == 0).all()
+    o1, o2 = st["raw"]
+    h0 = st["hints"][:, 0]
+    for k in range(120):
+        iupac = any(c not in "ACGTN" for c in reads[k])
+        if iupac:
+            assert h0[k] == 0, (k, reads[k], hex(int(h0[k])))
+    assert (h0 != 0).sum() >= 20
+    w = rng.integers(1, 9, len(reads)).astype(np.uint32)
+    plain, _ = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w)
+    hinted, _ = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w, hints=st["hints"])
+    assert np.array_equal(plain, hinted)
