@@ -58,13 +58,20 @@ int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t*
     A.n_tasks = n_tasks; A.aln_stride = aln_stride; A.n_refs = ctx->n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
     A.order = nullptr;
     // the batch's hint words (c2_batch.diag_hints): one reference only, and its position vectors must fit the hinted kernel's LDS block
-    A.hints = nullptr;
+    A.hints = nullptr; A.rest_list = nullptr; A.rest_count = nullptr; A.n_tasks_dev = nullptr;
     if (d_hints && ctx->n_refs == 1 && c2_count_hinted_lds_bytes(lmax, hl) <= 65536 && !getenv("C2_NO_COUNT_HINTS")) {
         A.hints = d_hints;
+        // the tasks the hinted kernel leaves go to a list (in the buffer the grouping by reference uses: one reference here), the column walk runs over it
+        if (n_tasks < 0xFFFFFFFFull && !getenv("C2_NO_COUNT_REST_LIST")) {
+            if ((rc = ensure(ctx, ctx->d_order, 256 + n_tasks * sizeof(uint32_t)))) return rc;
+            A.rest_count = (uint32_t*)ctx->d_cnt.p + 4;              // (bytes 16 .. 19 of the header zeroed above)
+            A.rest_list = (uint32_t*)((uint8_t*)ctx->d_order.p + 256);
+        }
         const size_t hl_lds = c2_count_hinted_lds_bytes(lmax, hl);
         const unsigned hgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_tasks + 255) / 256, (uint64_t)ctx->prop.multiProcessorCount * 4u));
         hipLaunchKernelGGL(c2_count_hinted_kernel, dim3(hgrid), dim3(256), hl_lds, s, A);
         HIPCHK(ctx, hipGetLastError());
+        if (A.rest_list) { A.order = A.rest_list; A.n_tasks_dev = A.rest_count; A.hints = nullptr; }
     }
     if ((flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) && (ctx->n_refs <= 1 || n_tasks % (uint64_t)ctx->n_refs != 0)) A.flags = flags & ~C2_CNT_FLAG_ALL_REFS_LAYOUT;
     if (ctx->n_refs > 1 && n_tasks < 0xFFFFFFFFull && !(A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT)) {

@@ -331,13 +331,16 @@ typedef struct c2_count_args {
     const uint32_t* order;        // optional: tasks grouped by reference (position -> task), else NULL = task order
     int32_t* block_scratch;       // c2_count_vectors_hbm_kernel: one int32 accumulator block per workgroup in HBM (amplicons whose block does not fit LDS)
     uint64_t block_ints;          // ... its size in ints
-    const uint32_t* hints;        // optional (one reference only): c2_batch.diag_hints of the batch -- a task with a valid hint is counted by c2_count_hinted_kernel
-                                  // from the hint word alone, c2_count_vectors_kernel skips it
+    const uint32_t* hints;        // optional (one reference only): c2_batch.diag_hints of the batch -- a task with a usable hint is counted by c2_count_hinted_kernel
+                                  // from the hint words, c2_count_vectors_kernel skips it
+    uint32_t* rest_list;          // c2_count_hinted_kernel: the tasks it does NOT take (and whose weight is not 0), densely -- c2_count_vectors_kernel then runs over
+    uint32_t* rest_count;         // this list (as its `order`) instead of looking at every task; rest_count: its device-resident length
+    const uint32_t* n_tasks_dev;  // c2_count_vectors_kernel: if set, the number of positions to process is read from here (the list above) instead of n_tasks
 } c2_count_args;
 // LDS of c2_count_hinted_kernel: the int32 position vectors, histograms and two difference arrays; 16 + C2_COUNT_SCALARS 64-bit totals; inc_prefix; scan carries
 static inline size_t c2_count_hinted_lds_bytes(int lmax, int hl) {
     const size_t ints = (size_t)C2_COUNT_VECTORS * (size_t)(lmax + 1) + (size_t)C2_COUNT_HISTS * (size_t)hl + 2u * (size_t)(lmax + 1);
-    return (ints * sizeof(int32_t) + 15) / 16 * 16 + (16 + C2_COUNT_SCALARS) * sizeof(uint64_t) + (size_t)((lmax + 2 + 7) / 8) * 8 * 2 + 64;
+    return (ints * sizeof(int32_t) + 15) / 16 * 16 + (16 + C2_COUNT_SCALARS) * sizeof(uint64_t) + (size_t)((lmax + 2 + 7) / 8) * 8 * 2 + 64 + 16 * 256 * sizeof(uint32_t);   // (+ lrest: C2_HCNT_FLUSH_ROUNDS x 256)
 }
 
 // ---- best-reference selection on the device (CRISPRessoCORE.py:683, :697-707, :779-785) ----

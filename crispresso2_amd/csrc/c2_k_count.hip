@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void c2_ref_scatter_kernel(const c2_aln_record
 // HBM: the int32 accumulator block of the workgroup lives in global memory (A.block_scratch) instead of LDS -- amplicons beyond
 // ~1,650 bp, whose block does not fit 160 KB.  Its updates are the same atomics (they execute in L2); what reads the block with plain
 // loads -- the flush -- first drops the CU's L1 lines (agent-scope fence), and the flush takes every entry with an exchange.
+#define C2_HCNT_SMALL_W 1024                   // c2_count_hinted_kernel takes a gapped hint below this weight (its int32 LDS block)
 template <bool HBM>
 __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
 {
@@ -124,6 +125,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
     uint16_t* incp = (uint16_t*)(ctl + C2_CNT_CTL_INTS);        // inc_prefix of the current reference (lmax + 2 entries)
     // staging slots of the wavefronts (c2_count_lds_tail_bytes: behind cov, the control words and inc_prefix, that part padded to 16 bytes)
     uint8_t* stage = (uint8_t*)cov + (((2 * (size_t)VL + C2_CNT_CTL_INTS) * sizeof(int) + (((size_t)A.lmax + 2 + 1) / 2) * 4 + 15) / 16 * 16);
+    const uint64_t n_positions = A.n_tasks_dev ? (uint64_t)(*A.n_tasks_dev) : A.n_tasks;      // (behind c2_count_hinted_kernel: the list of the tasks it left)
     for (int k = tid; k < per_ref; k += NT) acc[k] = 0;
     for (int k = tid; k < 2 * VL; k += NT) cov[k] = 0;                 // (cov and dcov)
     block_barrier();
@@ -193,13 +195,13 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
         }
         __syncthreads();
         const uint64_t chunk_base = (uint64_t)(unsigned)ctl[0] | ((uint64_t)(unsigned)ctl[1] << 32);
-        if (chunk_base >= A.n_tasks) break;
+        if (chunk_base >= n_positions) break;
         // ---- the records of this wave's K tasks, one per lane; selection test of CRISPRessoCORE.py:697 per lane
         const uint64_t my_pos = chunk_base + (uint64_t)((lane & (K - 1)) * C2_CNT_WAVES + wave);
         uint64_t my_task = my_pos;
         unsigned d0 = 0, d1 = 0, d2 = 0, d4 = 0, d5 = 0, d6 = 0; int v_w = 0;
         bool sel = false;
-        if (lane < K && my_pos < A.n_tasks) {
+        if (lane < K && my_pos < n_positions) {
             if (A.order) my_task = (uint64_t)A.order[my_pos];            // tasks grouped by reference: few flushes per chunk
             else if (A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) {            // all-references batch (task = read * n_refs + reference): the same grouping by arithmetic
                 const uint64_t nr = A.n_tasks / (uint64_t)A.n_refs;
@@ -209,7 +211,7 @@ __device__ __forceinline__ void c2_count_vectors_body(const c2_count_args& A)
             unsigned wq = A.weights ? A.weights[my_task] : 1u;
             if (A.hints) {                                               // (a hinted task is c2_count_hinted_kernel's: every main-diagonal hint, a gapped one below its weight limit)
                 const unsigned h0 = A.hints[4u * my_task];
-                if ((h0 & C2_HINT_VALID) || ((h0 & C2_HINT_GAPPED) && wq < 1024u)) wq = 0u;
+                if ((h0 & C2_HINT_VALID) || ((h0 & C2_HINT_GAPPED) && wq < (unsigned)C2_HCNT_SMALL_W)) wq = 0u;
             }
             v_w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);
             if (v_w > 0) {                                               // (an alignment that is not counted is not even read: most of an all-references batch)
@@ -768,7 +770,6 @@ __global__ __launch_bounds__(64 * C2_CNT_WAVES, C2_CNT_OCC) void c2_count_vector
 // at most 512 * w to an entry, w < C2_HCNT_SMALL_W); a main-diagonal task of a larger weight goes to the tensor directly, a gapped one of a larger
 // weight is left to c2_count_vectors_kernel (which skips exactly the tasks this kernel takes: c2_count_task_is_hinted).
 // ---------------------------------------------------------------------------------------------------------------
-#define C2_HCNT_SMALL_W 1024
 #define C2_HCNT_FLUSH_ROUNDS 16                // 16 x 256 tasks x 512 x 1,023 < 2^31
 __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
 {
@@ -782,12 +783,14 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     u64* tot = (u64*)(c2_smem + (((size_t)(NV + NH + 2 * VL)) * sizeof(int) + 15) / 16 * 16);   // [16] the main-diagonal tasks' totals, [C2_CNT_SCALARS] the gapped tasks' scalars
     u64* scal = tot + 16;
     uint16_t* incp = (uint16_t*)(scal + C2_CNT_SCALARS);
-    int* part = (int*)(incp + ((A.lmax + 2 + 7) / 8) * 8);          // [4] carries of the scans
+    int* part = (int*)(incp + ((A.lmax + 2 + 7) / 8) * 8);          // [4] carries of the scans, [4] entries of lrest, [5] their place in the global list
+    uint32_t* lrest = (uint32_t*)(part + 8);                        // [C2_HCNT_FLUSH_ROUNDS * 256] the tasks left to the column walk since the last flush
     const c2_dev_ref rf = A.refs[0];
     const int Li = rf.len;
     const int o_sc = NV, o_h = o_sc + C2_CNT_SCALARS;
     for (int k = tid; k < NV + NH + 2 * VL; k += 256) acc[k] = 0;
     if (tid < 16 + C2_CNT_SCALARS) tot[tid] = 0ull;
+    if (tid < 8) part[tid] = 0;
     for (int k = tid; k < Li + 2; k += 256) incp[k] = rf.inc_prefix[k];
     __syncthreads();
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS, ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS;
@@ -821,6 +824,15 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
         __syncthreads();
         for (int k = tid; k < NV; k += 256) { const int x = acc[k]; if (x != 0) { atomicAdd((u64*)(out + k), (u64)(long long)x); acc[k] = 0; } }
         for (int k = tid; k < NH; k += 256) { const int x = hist[k]; if (x != 0) { atomicAdd((u64*)(out + o_h + k), (u64)(long long)x); hist[k] = 0; } }
+        if (A.rest_list) {
+            const int nrest = part[4];
+            if (tid == 0 && nrest > 0) part[5] = (int)atomicAdd(A.rest_count, (unsigned)nrest);
+            __syncthreads();
+            const unsigned b0 = (unsigned)part[5];
+            for (int k = tid; k < nrest; k += 256) A.rest_list[b0 + (unsigned)k] = lrest[k];
+            __syncthreads();
+            if (tid == 0) part[4] = 0;
+        }
         __syncthreads();
     };
     u64 sW = 0, sN = 0, sSubW = 0, sGsub = 0, sOut = 0, sIn = 0, sIrr = 0, sH0 = 0, sH1 = 0, sH2 = 0;
@@ -830,6 +842,14 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
         const uint64_t t = base + (uint64_t)tid;
         unsigned h = 0;
         if (t < A.n_tasks) h = A.hints[4u * t];
+        if (A.rest_list) {
+            // what this kernel does not take (the rule of c2_count_vectors_body's skip) and what has a weight at all goes to the column walk's list --
+            // through an LDS list of the workgroup, emptied with the block (one global atomic per flush: an atomic per wavefront on one address
+            // serialised in L2 and cost the kernel 1.2 ms)
+            const unsigned wr = (t < A.n_tasks) ? (A.weights ? A.weights[t] : 1u) : 0u;
+            const bool rest = t < A.n_tasks && wr > 0u && !((h & C2_HINT_VALID) || ((h & C2_HINT_GAPPED) && wr < (unsigned)C2_HCNT_SMALL_W));
+            if (rest) lrest[atomicAdd(part + 4, 1)] = (uint32_t)t;
+        }
         if (h & C2_HINT_VALID) {
             const unsigned wq = A.weights ? A.weights[t] : 1u;
             const int w = (int)(wq > 0x7fffffffu ? 0x7fffffffu : wq);

@@ -439,9 +439,15 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     A.refs = refs.data(); A.counts = counts; A.work_counter = &wc; A.n_tasks = n_tasks; A.aln_stride = aln_stride;
     A.n_refs = n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
     A.hints = nullptr; A.order = nullptr; A.block_scratch = nullptr; A.block_ints = 0;
-    if (g_next_count_hints && n_refs == 1) {                         // (c2_count_vectors_hinted_device: the hinted tasks first, by their own kernel)
+    A.rest_list = nullptr; A.rest_count = nullptr; A.n_tasks_dev = nullptr;
+    std::vector<uint32_t> rest(n_tasks ? n_tasks : 1);
+    uint32_t n_rest = 0;
+    bool rest_order = false;
+    if (g_next_count_hints && n_refs == 1) {                         // (c2_count_vectors_hinted_device: the hinted tasks first, by their own kernel; what it leaves as a list)
         A.hints = g_next_count_hints;
+        if (!getenv("C2_NO_COUNT_REST_LIST")) { A.rest_list = rest.data(); A.rest_count = &n_rest; }
         emu::launch(grid ? grid : 2, [&] { c2_count_hinted_kernel(A); }, 256);
+        if (A.rest_list) { rest_order = true; A.n_tasks_dev = &n_rest; A.hints = nullptr; }
     }
     g_next_count_hints = nullptr;
     // tasks grouped by reference, as the host library does for more than one reference
@@ -453,6 +459,7 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
         emu::launch((unsigned)((n_tasks + 255) / 256), [&] { c2_ref_scatter_kernel(records, n_tasks, hist.data(), order.data()); }, 256);
         A.order = order.data();
     }
+    if (rest_order) A.order = rest.data();
     A.block_scratch = nullptr; A.block_ints = 0;
     if (getenv("C2_EMU_COUNT_HBM")) {
         // the variant whose accumulator blocks live in "HBM" (one per workgroup), as the library takes for amplicons beyond the LDS block
