@@ -693,125 +693,6 @@ __device__ __forceinline__ void c2_emit_and_classify(const c2_align_args& A, con
     rec.all_substitutions = (uint16_t)n_all_sub;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The traced epilogue of the diagonal-band kernels, round 6: RUNS instead of columns.
-// c2_traceback (above) writes every column of the two aligned strings, reversed, into LDS while it walks, and c2_emit_and_classify reads them
-// back twice (once to copy them out forwards as bytes, once to classify them 64 columns at a time): half the wave cycles of a traced read.
-// But an alignment IS its runs -- an amplicon read has three (M, one indel, M) -- so c2_traceback_runs keeps only one descriptor per run (lane r
-// of three registers holds run r, in trace order), and c2_emit_runs derives everything from the descriptors:
-//   * the indel events (COREResources.pyx:119-162 and the legacy rules pyx:253-261, 284) in closed form, lane r for run r;
-//   * the strings FORWARDS, four columns per lane: per run a lane takes its overlap with the run from the read / reference in LDS as one
-//     unaligned dword (two aligned ds_reads + v_alignbyte) under a byte mask, and the row leaves as dwords;
-//   * substitutions and matches by the zero-byte trick on read ^ reference over the M columns (pyx:113-118, CRISPResso2Align.pyx:375-376).
-// A literal '-' inside the read or the reference (the reference's classifier would see a gap column there) and more than 64 runs hand the task to
-// the next launch; the last launch of every chain (c2_align_classify_kernel) keeps the column-wise epilogue, which takes anything.
-// ---------------------------------------------------------------------------------------------------------------
-struct c2_runs {
-    unsigned a;      // lane r: run r (trace order: run 0 ends in the cell (Li, Lj)) -- columns emitted before it | its length << 16
-    unsigned b;      // lane r: i | j << 16 in front of the run: it covers reference (i - len, i] unless its state is I, read (j - len, j] unless J
-    int s;           // lane r: its state
-    int n, last;     // wave-uniform: runs so far, state of the newest one
-};
-
-template <class PLANE>
-__device__ __forceinline__ void c2_traceback_runs(const PLANE& P, const int Li, const int Lj, const int min_score, const int ge, const int g0,
-                                                  const int lane, c2_runs& R, int& cnt, int& status, bool& need_full)
-{
-    int i = Li, j = Lj;
-    int s = C2_ST_M;
-    cnt = 0; need_full = false;
-    R.a = 0u; R.b = 0u; R.s = 0; R.n = 0; R.last = -1;
-    // E more columns in state st, from (i, j) backwards (a run the probes below see in pieces -- 64 cells, 250 cells -- is one run)
-    auto push = [&](const int st, const int E) {
-        if (st == R.last) { if (lane == R.n - 1) R.a += (unsigned)E << 16; }
-        else {
-            if (lane == R.n) { R.a = (unsigned)cnt | ((unsigned)E << 16); R.b = (unsigned)i | ((unsigned)j << 16); R.s = st; }
-            ++R.n; R.last = st;
-        }
-    };
-    {
-        unsigned nib = 0;
-        if (P.fetch(i, j, nib)) s = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);   // start state, pyx:349-358
-        else need_full = true;
-    }
-    while (!need_full && (i > 0 || j > 0)) {
-        if (i == 0 || j == 0) {
-            const int need = (i == 0) ? C2_ST_I : C2_ST_J;           // initialised chains: iPointer[0,1:], jPointer[1:,0]
-            if (s != need) { status |= (s == C2_ST_M) ? C2_STATUS_SENTINEL_PATH : C2_STATUS_UNINIT_PTR; break; }
-            const int len = (i == 0) ? j : i;
-            push(s, len);
-            cnt += len; i = 0; j = 0;
-            break;
-        }
-        if constexpr (PLANE::kWordRuns) {
-            // a run of state M read off whole pointer words, four cells per lane (see c2_traceback)
-            const int K = (i < j ? i : j) - 1;
-            const int slw = (i - j - P.d0) >> 1;
-            if (s == C2_ST_M && P.pk && K >= 1 && (unsigned)slw < (unsigned)P.nl) {
-                const int a0 = i + j - 2, par = a0 & 1, ctop = a0 & 7, W0 = a0 >> 3;
-                const int n0 = (ctop >> 1) + 1;
-                const int wi = W0 - lane;
-                const int kfirst = lane == 0 ? 0 : n0 + 4 * (lane - 1);
-                int cells = lane == 0 ? n0 : 4;
-                if (wi < 0 || kfirst >= K) cells = 0; else if (kfirst + cells > K) cells = K - kfirst;
-                unsigned w = 0;
-                if (cells > 0) w = P.words[wi * P.lpa + slw];
-                const unsigned u = ((w & (w >> 8)) >> (2 * par)) & 0x00110011u;
-                unsigned m4 = (((u >> 20) & 1u) << 3) | (((u >> 16) & 1u) << 2) | (((u >> 4) & 1u) << 1) | (u & 1u);
-                const int ctop_l = lane == 0 ? ctop : 6 + par;
-                if (lane == 0) m4 = (m4 << (4 - n0)) & 0xfu;
-                int n_lead = __builtin_clz((((~m4) & 0xfu) << 28) | 0x08000000u);
-                if (n_lead > cells) n_lead = cells;
-                const unsigned long long stop = __ballot(n_lead < cells);
-                const int c_dec = ctop_l - 2 * n_lead;
-                const int ns_dec = ((w >> (16 * ((c_dec & 7) >> 2) + 2 * (c_dec & 3))) & 1u) ? C2_ST_J : C2_ST_I;
-                int covered = n0 + 4 * 63; if (covered > K) covered = K;
-                int E, s_next;
-                if (stop == 0ull) { E = covered; s_next = C2_ST_M; }
-                else {
-                    const int wl = __builtin_ctzll(stop);
-                    E = (wl == 0 ? 0 : n0 + 4 * (wl - 1)) + __builtin_amdgcn_readlane(n_lead, wl) + 1;
-                    s_next = __builtin_amdgcn_readlane(ns_dec, wl);
-                }
-                push(C2_ST_M, E);
-                cnt += E; i -= E; j -= E; s = s_next;
-                continue;
-            }
-        }
-        const int di = (s != C2_ST_I) ? 1 : 0, dj = (s != C2_ST_J) ? 1 : 0;
-        const int ik = i - lane * di, jk = j - lane * dj;
-        const bool valid = (ik >= 1) && (jk >= 1);
-        int ns = 0;
-        bool oob = false;
-        if (valid) {
-            const int pi = (s == C2_ST_M) ? ik - 1 : ik, pj = (s == C2_ST_M) ? jk - 1 : jk;
-            if (pi == 0 || pj == 0) {
-                ns = c2_boundary_hstate(pi, pj, min_score, ge, g0);   // only reachable for s == M
-            } else {
-                unsigned nib = 0;
-                if (P.fetch(pi, pj, nib)) {
-                    if (s == C2_ST_M) ns = (nib & 2) ? C2_ST_I : ((nib & 1) ? C2_ST_J : C2_ST_M);
-                    else if (s == C2_ST_I) ns = (nib & 8) ? C2_ST_M : C2_ST_I;
-                    else ns = (nib & 4) ? C2_ST_M : C2_ST_J;
-                } else oob = true;
-            }
-        }
-        const unsigned long long vmask = __ballot(valid);
-        const unsigned long long cmask = __ballot(valid && ns == s);
-        const unsigned long long omask = __ballot(oob);
-        const int nv = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
-        const int nc = (~cmask == 0ull) ? 64 : __builtin_ctzll(~cmask);
-        int E, s_next;
-        if (nc < nv) {
-            if ((omask >> nc) & 1ull) { need_full = true; break; }
-            E = nc + 1; s_next = __builtin_amdgcn_readlane(ns, nc);
-        } else { E = nv; s_next = s; }
-        push(s, E);
-        cnt += E; i -= E * di; j -= E * dj; s = s_next;
-    }
-    if (R.n > 64) need_full = true;                                   // (more runs than lanes: the next launch's business)
-}
-
 // four bytes from LDS at any byte offset `base` of the 4-byte-aligned buffer `buf` (bytes base .. base + 3; `last_word`: the last dword that holds
 // a byte of the buffer -- one dword in front of the buffer and one behind that are read, never used: the LDS plan has them)
 __device__ __forceinline__ unsigned c2_lds_load4(const unsigned char* buf, const int base, const int last_word) {
@@ -821,138 +702,6 @@ __device__ __forceinline__ unsigned c2_lds_load4(const unsigned char* buf, const
     return __builtin_amdgcn_alignbyte(p[1], p[0], (unsigned)base & 3u);
 }
 __device__ __forceinline__ unsigned c2_nonzero_bytes(const unsigned x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }   // bit 7 of every byte of x that is not 0
-
-// sCnt: two LDS ints of the slot (scratch for the wave sums).  Returns false (nothing usable written) when the task must go to the next launch.
-__device__ __forceinline__ bool c2_emit_runs(const c2_align_args& A, const c2_wg& W, const uint64_t task, const c2_runs& R, const int T,
-                                             const int lane, c2_aln_record& rec, const int Li, const int Lj, const bool rows_aligned, int* sCnt)
-{
-    const uint16_t* sIncP = W.sIncP;
-    // ---- the indel events, lane r for run r
-    const int len_r = (int)(R.a >> 16), cs_r = T - (int)(R.a & 0xffffu) - len_r, i_r = (int)(R.b & 0xffffu);
-    const bool mine = lane < R.n;
-    bool all_ins = false, win_ins = false, all_del = false, win_del = false;
-    int del_bases = 0;
-    if (mine && R.s == C2_ST_I) {
-        // a gap in the reference string closes at the next column that has a reference base (pyx:119-128): never for a trailing run (run 0), and a
-        // leading one (no reference base in front) was never opened (pyx:136)
-        const int idx = i_r;
-        if (idx > 0 && lane != 0) {
-            all_ins = true;
-            const bool fl = sIncP[idx] != sIncP[idx - 1], fr = sIncP[idx + 1] != sIncP[idx];
-            win_ins = A.legacy ? (fl || fr) : (fl && fr);              // both flanks in the window (pyx:121); legacy: either (pyx:284)
-        }
-    }
-    if (mine && R.s == C2_ST_J) {
-        all_del = true;
-        if (lane != 0) {                                               // closes at the next read base (pyx:145-153); i_r = reference bases left of that column
-            const int dstart = (A.legacy && cs_r - 1 <= 0) ? 0 : i_r - len_r;      // legacy (pyx:253-258): a run that starts in column 0 or 1 is given start 0
-            win_del = sIncP[i_r] != sIncP[dstart];
-            del_bases = i_r - dstart;
-        } else if (!A.legacy) {                                        // trailing deletion (pyx:155-162)
-            del_bases = len_r;
-            win_del = sIncP[Li] != sIncP[Li - len_r];
-        } else {                                                       // legacy (pyx:259-261): ends at reference index Li - 1 (exclusive)
-            const int dstart = (cs_r - 1 <= 0) ? 0 : Li - len_r, dend = Li - 1;
-            del_bases = dend > dstart ? dend - dstart : 0;
-            win_del = dend > dstart && sIncP[dend] != sIncP[dstart];
-        }
-    }
-    const unsigned long long mI = __ballot(all_ins), mIw = __ballot(win_ins), mD = __ballot(all_del), mDw = __ballot(win_del);
-    int acc_ins_n = 0, acc_del_n = 0, acc_del_bases = 0;
-    for (unsigned long long ev = mIw; ev; ev &= ev - 1ull) acc_ins_n += __builtin_amdgcn_readlane(len_r, __builtin_ctzll(ev));
-    for (unsigned long long ev = mD; ev; ev &= ev - 1ull) {
-        const int l = __builtin_ctzll(ev);
-        acc_del_bases += __builtin_amdgcn_readlane(del_bases, l);
-        if ((mDw >> l) & 1ull) acc_del_n += __builtin_amdgcn_readlane(len_r, l);
-    }
-    // ---- the strings, forwards, four columns per lane and round
-    uint8_t* outR = A.aln_read + task * (uint64_t)A.aln_stride;
-    uint8_t* outF = A.aln_ref + task * (uint64_t)A.aln_stride;
-    const bool strings = !(A.reserved & 1);
-    const int lastR = (Lj - 1) >> 2, lastF = (Li - 1) >> 2;
-    int n_mism = 0, n_sub = 0, n_win = 0;                              // per lane
-    bool dash = false;
-    int ins_before = 0;                                                // (wave-uniform) insertion columns of the runs that end in front of this round
-    int r_hi = R.n - 1;                                                // (wave-uniform) the first run, in forward order, that reaches into this round or a later one
-    for (int c_base = 0; c_base < T; c_base += 256) {
-        const int c0 = c_base + 4 * lane;
-        unsigned accR = 0u, accF = 0u, mM = 0u, mIns = 0u;
-        int ins_left = ins_before;                                     // insertion columns left of column c0
-        for (int r = r_hi; r >= 0; --r) {
-            const unsigned ra = (unsigned)__builtin_amdgcn_readlane((int)R.a, r), rb = (unsigned)__builtin_amdgcn_readlane((int)R.b, r);
-            const int st = __builtin_amdgcn_readlane(R.s, r);
-            const int len = (int)(ra >> 16), cs = T - (int)(ra & 0xffffu) - len, ce = cs + len;
-            if (cs >= c_base + 256) break;                             // this run and the ones behind it: the next round
-            if (ce <= c_base + 256) {                                  // ends inside this round: the next round starts behind it
-                r_hi = r - 1;
-                if (st == C2_ST_I) ins_before += len;
-            }
-            // this lane's bytes [lo, 4) belong to the run -- the runs behind it take their part back
-            const int lo = cs - c0;
-            const unsigned mask = lo >= 4 ? 0u : (0xffffffffu << (8 * (lo < 0 ? 0 : lo)));
-            if (st != C2_ST_J) accR = (accR & ~mask) | (c2_lds_load4(W.sRead, c0 + ((int)(rb >> 16) - len - cs), lastR) & mask);
-            else accR = (accR & ~mask) | (0x2d2d2d2du & mask);
-            if (st != C2_ST_I) accF = (accF & ~mask) | (c2_lds_load4(W.sRef, c0 + ((int)(rb & 0xffffu) - len - cs), lastF) & mask);
-            else accF = (accF & ~mask) | (0x2d2d2d2du & mask);
-            mM = (mM & ~mask) | (st == C2_ST_M ? (0x80808080u & mask) : 0u);
-            mIns = (mIns & ~mask) | (st == C2_ST_I ? (0x80808080u & mask) : 0u);
-            if (st == C2_ST_I) { const int d = c0 - cs; ins_left += d < 0 ? 0 : (d > len ? len : d); }
-        }
-        // bytes behind column T - 1 (the last run took them too): zeros
-        const int nb = T - c0;
-        const unsigned valid = nb >= 4 ? 0xffffffffu : (nb > 0 ? ((1u << (8 * nb)) - 1u) : 0u);
-        accR &= valid; accF &= valid; mM &= valid; mIns &= valid;
-        if (strings && nb > 0) {
-            // (exactly T bytes of a row are written, as by the column-wise epilogue of the other kernels: which kernel finishes a task depends on
-            //  the order of the lists, and the bytes behind column T - 1 must not)
-            if (rows_aligned && nb >= 4) { ((uint32_t*)outR)[c0 >> 2] = accR; ((uint32_t*)outF)[c0 >> 2] = accF; }
-            else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < nb) { outR[c0 + q] = (uint8_t)(accR >> (8 * q)); outF[c0 + q] = (uint8_t)(accF >> (8 * q)); }
-            }
-        }
-        const unsigned mm = c2_nonzero_bytes(accR ^ accF) & mM;                          // M columns whose characters differ
-        const unsigned sub = mm & c2_nonzero_bytes(accR ^ 0x4e4e4e4eu);                  // ... and the read's is not 'N' (COREResources.pyx:113-118)
-        // a literal '-' in a column that takes its character from the sequence (the reference's classifier reads the strings: it would see a gap there)
-        const unsigned vb = valid & 0x80808080u;
-        if (((~c2_nonzero_bytes(accR ^ 0x2d2d2d2du) & (mM | mIns)) | (~c2_nonzero_bytes(accF ^ 0x2d2d2d2du) & vb & ~mIns)) != 0u) dash = true;
-        n_mism += __builtin_popcount(mm);
-        if (sub != 0u) {
-            n_sub += __builtin_popcount(sub);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if ((sub >> (8 * q + 7)) & 1u) {
-                    const int idx = c0 + q - ins_left - __builtin_popcount(mIns & ((1u << (8 * q)) - 1u));     // reference index of the column
-                    n_win += (sIncP[idx + 1] != sIncP[idx]) ? 1 : 0;
-                }
-        }
-    }
-    if (__ballot(dash)) return false;
-    // ---- wave sums of the three per-lane counts (an alignment has a handful of differing bases: a few lanes add)
-    if (lane == 0) { sCnt[0] = 0; sCnt[1] = 0; }
-    __builtin_amdgcn_wave_barrier();
-    if (n_mism) atomicAdd(&sCnt[0], n_mism);
-    if (n_sub) atomicAdd(&sCnt[1], n_sub | (n_win << 16));
-    __builtin_amdgcn_wave_barrier();
-    const int mism = __builtin_amdgcn_readfirstlane(sCnt[0]), subs = __builtin_amdgcn_readfirstlane(sCnt[1]);
-    __builtin_amdgcn_wave_barrier();
-    const int st_first = __builtin_amdgcn_readlane(R.s, R.n - 1), st_last = __builtin_amdgcn_readlane(R.s, 0);
-    const unsigned char r0 = W.sRead[0], f0 = W.sRef[0], rL = W.sRead[Lj - 1], fL = W.sRef[Li - 1];
-    rec.irregular_ends = (st_first != C2_ST_M || st_last != C2_ST_M || r0 != f0 || rL != fL) ? 1 : 0;      // (a literal '-' was excluded above)
-    rec.aln_len = (uint16_t)T;
-    rec.matches = (uint16_t)(Li + Lj - T - mism);                      // M columns = Li + Lj - T (pyx:375-376 counts the equal ones)
-    rec.insertion_n = (uint16_t)acc_ins_n;
-    rec.deletion_n = (uint16_t)acc_del_n;
-    rec.substitution_n = (uint16_t)(subs >> 16);
-    rec.all_insertion_events = (uint16_t)__popcll(mI);
-    rec.win_insertion_events = (uint16_t)__popcll(mIw);
-    rec.all_deletion_events = (uint16_t)__popcll(mD);
-    rec.win_deletion_events = (uint16_t)__popcll(mDw);
-    rec.all_deletion_bases = (uint16_t)acc_del_bases;
-    rec.all_substitutions = (uint16_t)(subs & 0xffff);
-    return true;
-}
 
 // Shortcut for the commonest alignment of an amplicon run: equal lengths and no gap at all.  The reference's traceback stays
 // in state M from (L, L) to (0, 0) iff the H-state of every cell (i, i) is M, i.e. the two low pointer bits of all L main-
@@ -1755,7 +1504,7 @@ __global__ __launch_bounds__(64, 2) void c2_align_diag_kernel(c2_align_args A)
 // per-alignment ("slot") table in LDS: wave-uniform values written by lane 0 and read back through readfirstlane, so the
 // staging / traceback / output code exists once (a loop over the slots) instead of once per slot
 enum { C2X_VALID = 0, C2X_TASK_LO, C2X_TASK_HI, C2X_LJ, C2X_REF, C2X_RC, C2X_STATUS, C2X_PACKED, C2X_CURREF, C2X_LI, C2X_G0,
-       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_UNPAIRED, C2X_SCRATCH /* two ints: c2_emit_runs' wave sums */, C2X_INTS = 24 };
+       C2X_OK, C2X_D, C2X_D0, C2X_CB, C2X_MINSC, C2X_ROWBASE, C2X_BAND_LI, C2X_BAND_LJ, C2X_LASTPOS, C2X_REFBAD, C2X_UNPAIRED, C2X_INTS = 24 };
 __device__ __forceinline__ int c2_uni(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
 // the whole table of one slot with ONE LDS read (lane k gets entry k); C2_TF picks an entry: a v_readlane instead of an
 // LDS round trip per entry
