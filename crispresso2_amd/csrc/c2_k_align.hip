@@ -2587,7 +2587,9 @@ struct c2_partition_args {
     int32_t route_cert;                         // c2_part_probe: a band is chosen only if its launch can be expected to certify the alignment (round 6; 0: the geometric test alone)
 };
 
+#ifndef C2_PART_CHUNK
 #define C2_PART_CHUNK 4096                         // tasks per workgroup and set of atomics (one per task and list serialises in L2: 28 ms for 10 M tasks)
+#endif
 #define C2_PART_LEN_BINS 512                       // read lengths 0 .. 510 have a bin of their own, longer reads share the last
 // flags | per-wavefront scan words | the slots to probe, later the slots in length order (uint16 each) | the slots' read lengths (uint16) | length histogram
 #define C2_PART_LDS (C2_PART_CHUNK + 128 + 2 * C2_PART_CHUNK + 2 * C2_PART_CHUNK + 4 * C2_PART_LEN_BINS)
@@ -2780,6 +2782,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
     uint16_t* const len16 = todo + C2_PART_CHUNK;                   // [C2_PART_CHUNK] read length of the slot's task (capped at the last bin)
     unsigned* const hist = (unsigned*)(len16 + C2_PART_CHUNK);      // [C2_PART_LEN_BINS]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int PT = C2_PART_CHUNK / 256;                          // tasks per thread of a chunk
     int widest = 2;                                                 // the class that takes what no band holds: the widest band launch the chain has
     for (int k = 2; k < 5; ++k) if (P.bandw[k] > 0) widest = k + 1;
     // An all-references batch (task = read * n_refs + reference) is walked REFERENCE-MAJOR inside a chunk: slot s of a chunk of `rpc` reads is read
@@ -2853,7 +2856,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
         if (P.exact_copies) {
             unsigned n0 = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) n0 += flag[16 * tid + k] == 0u;
+            for (int k = 0; k < PT; ++k) n0 += flag[PT * tid + k] == 0u;
             unsigned incl = n0;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
@@ -2864,7 +2867,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             for (int v = 0; v < 4; ++v) { const unsigned x = part[v]; if (v < wv) before += x; total += x; }
             unsigned pos = before + incl - n0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (flag[16 * tid + k] == 0u) todo[pos++] = (uint16_t)(16 * tid + k);
+            for (int k = 0; k < PT; ++k) if (flag[PT * tid + k] == 0u) todo[pos++] = (uint16_t)(PT * tid + k);
             __syncthreads();
             auto flags = [](const uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; };     // bit 7 of every non-zero byte
             auto eq16 = [&](const uint4& x, const uint8_t* p) {      // equal bytes of a 16-byte half and the 16 bytes at p
@@ -3021,7 +3024,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
         {
             unsigned n8 = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) n8 += flag[16 * tid + k] == 8u;
+            for (int k = 0; k < PT; ++k) n8 += flag[PT * tid + k] == 8u;
             unsigned incl = n8;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
@@ -3032,7 +3035,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             for (int v = 0; v < 4; ++v) { const unsigned x = part[v]; if (v < wv) before += x; total += x; }
             unsigned pos = before + incl - n8;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (flag[16 * tid + k] == 8u) todo[pos++] = (uint16_t)(16 * tid + k);
+            for (int k = 0; k < PT; ++k) if (flag[PT * tid + k] == 8u) todo[pos++] = (uint16_t)(PT * tid + k);
             __syncthreads();
             for (unsigned k = (unsigned)tid; k < total; k += 256u) {
                 const int slot = (int)todo[k];
@@ -3047,7 +3050,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             for (int b = tid; b < C2_PART_LEN_BINS; b += 256) hist[b] = 0u;
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) atomicAdd(&hist[len16[16 * tid + k]], 1u);
+            for (int k = 0; k < PT; ++k) atomicAdd(&hist[len16[PT * tid + k]], 1u);
             __syncthreads();
             {   // exclusive scan of the bins: thread t owns bins 2t, 2t + 1
                 const unsigned h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
@@ -3064,18 +3067,18 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             }
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { const int slot = 16 * tid + k; todo[atomicAdd(&hist[len16[slot]], 1u)] = (uint16_t)slot; }
+            for (int k = 0; k < PT; ++k) { const int slot = PT * tid + k; todo[atomicAdd(&hist[len16[slot]], 1u)] = (uint16_t)slot; }
             __syncthreads();
         }
-        // ---- thread t owns positions 16 t .. 16 t + 15 of the chunk's order: list positions by a scan over the workgroup, one atomic per chunk and class
+        // ---- thread t owns positions PT t .. PT t + PT - 1 of the chunk's order: list positions by a scan over the workgroup, one atomic per chunk and class
         constexpr int NC = C2_PART_CLASSES, NW = (C2_PART_CLASSES + 1) / 2;
         unsigned n[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) n[c] = 0u;
-        unsigned mine[16];                                          // the slots in this thread's positions
+        unsigned mine[PT];                                          // the slots in this thread's positions
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            mine[k] = ragged ? (unsigned)todo[16 * tid + k] : (unsigned)(16 * tid + k);
+        for (int k = 0; k < PT; ++k) {
+            mine[k] = ragged ? (unsigned)todo[PT * tid + k] : (unsigned)(PT * tid + k);
             const unsigned f = flag[mine[k]];
 #pragma unroll
             for (int c = 0; c < NC; ++c) n[c] += f == (unsigned)c;
@@ -3114,7 +3117,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             if (2 * w + 1 < NC) pos[2 * w + 1 < NC ? 2 * w + 1 : 0] = part[16 + 2 * w + 1] + (e >> 16);
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < PT; ++k) {
             const unsigned f = flag[mine[k]];
             const uint32_t task = (uint32_t)c2_part_task_of(WK, A, chunk, (int)mine[k]);     // (f < NC only for a slot that holds a task)
 #pragma unroll
