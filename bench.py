@@ -242,7 +242,7 @@ class Job:
                           torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)) for _ in range(self.n_sets)]
         # single amplicon: the hint words c2_align_partition_kernel leaves for the reads it finishes itself (c2_batch.diag_hints); the count pass takes those
         # tasks from the word alone (c2_count_hinted_kernel).  C2_BENCH_NO_HINTS=1: the step without them (A/B).
-        self.use_hints = (k == 1 and not all_refs and wl["ref_ids"] is None and not os.environ.get("C2_BENCH_NO_HINTS"))
+        self.use_hints = (not (all_refs and k > 1) and not os.environ.get("C2_BENCH_NO_HINTS"))       # (one amplicon, or every read tagged with its own: not an all-references batch, whose weights come from the selection)
         self.hint_sets = [torch.zeros(n_tasks * 4, dtype=torch.int32, device=dev) if self.use_hints else None for _ in range(self.n_sets)]      # four words per task
         self.t_align = torch.cuda.current_stream()
         self.t_count = torch.cuda.Stream(device=dev) if overlap_count else self.t_align
@@ -430,7 +430,7 @@ class Job:
         """the step's count tensor (hinted tasks from their hint word, c2_count_hinted_kernel) against the count pass over the same rows and records
         WITHOUT the hints (every task's strings read back) -- entry by entry.  None when the step uses no hints."""
         torch, C = self.torch, self.C
-        if not self.use_hints or self.world > 1:
+        if not self.use_hints or self.world > 1 or self.all_refs:
             return None
         a_read, a_ref, recs = self.out_sets[(self.step_no - 1) % self.n_sets]
         t = torch.zeros_like(self.d_counts)
@@ -1364,6 +1364,9 @@ def main():
                     entry["chain_equals_full_plane_n"] = eq
                     entry["chain_equals_full_plane"] = bool(eq == jc.n_tasks)
                     entry["full_plane_pass_s"] = tf
+                eqh_ = jc.count_tensor_equals_without_hints() if (rank == 0 and args.check > 0) else None
+                if eqh_ is not None:
+                    entry["count_tensor_equals_without_hints"] = eqh_     # (the step counted its hinted tasks from their hint words: the same tensor over the rows)
                 tl = jc.tallies()
                 entry["reads_aligned_all_gpus"] = int(sum(t_["counts_total"] for t_ in tl))
                 entry["modified"] = int(sum(t_["counts_modified"] for t_ in tl))

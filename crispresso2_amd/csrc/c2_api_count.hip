@@ -58,8 +58,9 @@ int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t*
     A.n_tasks = n_tasks; A.aln_stride = aln_stride; A.n_refs = ctx->n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
     A.order = nullptr;
     // the batch's hint words (c2_batch.diag_hints): one reference only, and its position vectors must fit the hinted kernel's LDS block
-    A.hints = nullptr; A.rest_list = nullptr; A.rest_count = nullptr; A.n_tasks_dev = nullptr;
-    if (d_hints && ctx->n_refs == 1 && c2_count_hinted_lds_bytes(lmax, hl) <= 65536 && !getenv("C2_NO_COUNT_HINTS")) {
+    A.hints = nullptr; A.rest_list = nullptr; A.rest_count = nullptr; A.n_tasks_dev = nullptr; A.ref_ends = nullptr; A.hint_gx = 0;
+    const bool hints_usable = d_hints && c2_count_hinted_lds_bytes(lmax, hl) <= 65536 && !getenv("C2_NO_COUNT_HINTS");
+    if (hints_usable && ctx->n_refs == 1) {
         A.hints = d_hints;
         // the tasks the hinted kernel leaves go to a list (in the buffer the grouping by reference uses: one reference here), the column walk runs over it
         if (n_tasks < 0xFFFFFFFFull && !getenv("C2_NO_COUNT_REST_LIST")) {
@@ -87,6 +88,15 @@ int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t*
         hipLaunchKernelGGL(c2_ref_scatter_kernel, dim3(gb), dim3(256), 0, s, d_records, n_tasks, hist, order);
         HIPCHK(ctx, hipGetLastError());
         A.order = order;
+        if (hints_usable) {
+            // several references, every task against its own (CRISPRessoPooled's shape): the hinted kernel runs per reference over that reference's range
+            // of the grouped order (after the scatter, hist[r] is the position behind reference r's last task); the column walk skips what it took
+            A.hints = d_hints; A.ref_ends = hist;
+            const uint64_t per = n_tasks / (uint64_t)ctx->n_refs + 1;
+            A.hint_gx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((per + 4095) / 4096, 64));
+            hipLaunchKernelGGL(c2_count_hinted_kernel, dim3(A.hint_gx * (unsigned)ctx->n_refs), dim3(256), c2_count_hinted_lds_bytes(lmax, hl), s, A);
+            HIPCHK(ctx, hipGetLastError());
+        }
     }
     const void* fn = hbm_block ? (const void*)c2_count_vectors_hbm_kernel : (const void*)c2_count_vectors_kernel;
     HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));

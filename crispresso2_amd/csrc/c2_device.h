@@ -336,6 +336,8 @@ typedef struct c2_count_args {
     uint32_t* rest_list;          // c2_count_hinted_kernel: the tasks it does NOT take (and whose weight is not 0), densely -- c2_count_vectors_kernel then runs over
     uint32_t* rest_count;         // this list (as its `order`) instead of looking at every task; rest_count: its device-resident length
     const uint32_t* n_tasks_dev;  // c2_count_vectors_kernel: if set, the number of positions to process is read from here (the list above) instead of n_tasks
+    const uint32_t* ref_ends;     // c2_count_hinted_kernel with several references (`order` groups the tasks by reference): position behind the last task of every reference;
+    uint32_t hint_gx;             // ... and the workgroups per reference: workgroup b works on reference b / hint_gx
 } c2_count_args;
 // LDS of c2_count_hinted_kernel: the int32 position vectors, histograms and two difference arrays; 16 + C2_COUNT_SCALARS 64-bit totals; inc_prefix; scan carries
 static inline size_t c2_count_hinted_lds_bytes(int lmax, int hl) {

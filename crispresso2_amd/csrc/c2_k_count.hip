@@ -785,7 +785,13 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     uint16_t* incp = (uint16_t*)(scal + C2_CNT_SCALARS);
     int* part = (int*)(incp + ((A.lmax + 2 + 7) / 8) * 8);          // [4] carries of the scans, [4] entries of lrest, [5] their place in the global list
     uint32_t* lrest = (uint32_t*)(part + 8);                        // [C2_HCNT_FLUSH_ROUNDS * 256] the tasks left to the column walk since the last flush
-    const c2_dev_ref rf = A.refs[0];
+    // one reference per workgroup: the batch's only one, or (tasks grouped by reference in A.order) reference blockIdx.x / hint_gx and its range of positions
+    int ref = 0;
+    unsigned bx = blockIdx.x, gx = gridDim.x;
+    uint64_t p_lo = 0, p_hi = A.n_tasks;
+    if (A.ref_ends) { gx = A.hint_gx; ref = (int)(blockIdx.x / gx); bx = blockIdx.x - (unsigned)ref * gx; p_lo = ref ? A.ref_ends[ref - 1] : 0u; p_hi = A.ref_ends[ref]; }
+    if (p_lo >= p_hi) return;
+    const c2_dev_ref rf = A.refs[ref];
     const int Li = rf.len;
     const int o_sc = NV, o_h = o_sc + C2_CNT_SCALARS;
     for (int k = tid; k < NV + NH + 2 * VL; k += 256) acc[k] = 0;
@@ -798,8 +804,9 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     // the selection test of CRISPRessoCORE.py:697 for a main-diagonal alignment: Li columns, Li - k matches
     bool gate = Li > 0;
     int thresh = 0;
-    if (A.min_matches) { if (Li > A.max_t) gate = false; else thresh = (int)A.min_matches[Li]; }
-    long long* out = A.counts;
+    const uint16_t* mm_row = A.min_matches ? A.min_matches + (size_t)ref * (size_t)(A.max_t + 1) : nullptr;
+    if (mm_row) { if (Li > A.max_t) gate = false; else thresh = (int)mm_row[Li]; }
+    long long* out = A.counts + (size_t)ref * (size_t)(o_h + NH);
     // the LDS block -> the tensor: the difference arrays integrated first (as c2_count_vectors_body's flush does)
     auto flush = [&]() {
         __syncthreads();
@@ -838,16 +845,18 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     u64 sW = 0, sN = 0, sSubW = 0, sGsub = 0, sOut = 0, sIn = 0, sIrr = 0, sH0 = 0, sH1 = 0, sH2 = 0;
     const u64 chars = (u64)'A' | ((u64)'C' << 8) | ((u64)'T' << 16) | ((u64)'G' << 24) | ((u64)'N' << 56);      // indexed by (ch >> 1) & 7
     unsigned rounds = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < A.n_tasks; base += (uint64_t)gridDim.x * 256u) {
-        const uint64_t t = base + (uint64_t)tid;
+    for (uint64_t base = p_lo + (uint64_t)bx * 256u; base < p_hi; base += (uint64_t)gx * 256u) {
+        const uint64_t pos = base + (uint64_t)tid;
+        const bool in_range = pos < p_hi;
+        const uint64_t t = in_range ? (A.ref_ends ? (uint64_t)A.order[pos] : pos) : 0ull;
         unsigned h = 0;
-        if (t < A.n_tasks) h = A.hints[4u * t];
+        if (in_range) h = A.hints[4u * t];
         if (A.rest_list) {
             // what this kernel does not take (the rule of c2_count_vectors_body's skip) and what has a weight at all goes to the column walk's list --
             // through an LDS list of the workgroup, emptied with the block (one global atomic per flush: an atomic per wavefront on one address
             // serialised in L2 and cost the kernel 1.2 ms)
-            const unsigned wr = (t < A.n_tasks) ? (A.weights ? A.weights[t] : 1u) : 0u;
-            const bool rest = t < A.n_tasks && wr > 0u && !((h & C2_HINT_VALID) || ((h & C2_HINT_GAPPED) && wr < (unsigned)C2_HCNT_SMALL_W));
+            const unsigned wr = in_range ? (A.weights ? A.weights[t] : 1u) : 0u;
+            const bool rest = in_range && wr > 0u && !((h & C2_HINT_VALID) || ((h & C2_HINT_GAPPED) && wr < (unsigned)C2_HCNT_SMALL_W));
             if (rest) lrest[atomicAdd(part + 4, 1)] = (uint32_t)t;
         }
         if (h & C2_HINT_VALID) {
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
                 const unsigned d0 = rp[0], d1 = rp[1], d2 = rp[2], d4 = rp[4], d5 = rp[5];
                 const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16);
                 bool sel = ((d5 >> 24) == 0) && (T > 0);
-                if (sel && A.min_matches) sel = (T <= A.max_t) && (matches >= (int)A.min_matches[T]);
+                if (sel && mm_row) sel = (T <= A.max_t) && (matches >= (int)mm_row[T]);
                 if (sel) {
                     // ---- the scalar counters and histograms, as c2_count_vectors_body adds them from the record (aln_stats of process_fastq,
                     //      CRISPRessoCORE.py:1974-1979; the tallies of :3996-4072)

@@ -439,7 +439,8 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     A.refs = refs.data(); A.counts = counts; A.work_counter = &wc; A.n_tasks = n_tasks; A.aln_stride = aln_stride;
     A.n_refs = n_refs; A.lmax = lmax; A.hl = hl; A.max_t = max_t; A.flags = flags;
     A.hints = nullptr; A.order = nullptr; A.block_scratch = nullptr; A.block_ints = 0;
-    A.rest_list = nullptr; A.rest_count = nullptr; A.n_tasks_dev = nullptr;
+    A.rest_list = nullptr; A.rest_count = nullptr; A.n_tasks_dev = nullptr; A.ref_ends = nullptr; A.hint_gx = 0;
+    const uint32_t* hints_multi = (g_next_count_hints && n_refs > 1 && !(flags & C2_CNT_FLAG_ALL_REFS_LAYOUT)) ? g_next_count_hints : nullptr;
     std::vector<uint32_t> rest(n_tasks ? n_tasks : 1);
     uint32_t n_rest = 0;
     bool rest_order = false;
@@ -458,6 +459,10 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
         emu::launch(1, [&] { c2_ref_scan_kernel(hist.data(), n_refs); });
         emu::launch((unsigned)((n_tasks + 255) / 256), [&] { c2_ref_scatter_kernel(records, n_tasks, hist.data(), order.data()); }, 256);
         A.order = order.data();
+        if (hints_multi) {                                           // (c2_count_vectors_hinted_device with several references: per reference over the grouped order)
+            A.hints = hints_multi; A.ref_ends = hist.data(); A.hint_gx = 2;
+            emu::launch(2u * (unsigned)n_refs, [&] { c2_count_hinted_kernel(A); }, 256);
+        }
     }
     if (rest_order) A.order = rest.data();
     A.block_scratch = nullptr; A.block_ints = 0;

@@ -137,6 +137,8 @@ def test_bench_default_line_carries_the_int32_chain_the_other_configs_and_the_fa
     for cfg, k_ in ((2, 1), (4, 3), (5, 1)):
         e = out["other_configs"]["config%d" % cfg]
         assert e["chain_equals_full_plane"] and e["chain_equals_full_plane_n"] == 90 * k_ and e["all_status_ok"] and e["reads_per_s"] > 0
+        if cfg != 4:                                                  # (hint words: one amplicon, or every read tagged with its own -- config 5, the hinted kernel per reference)
+            assert e["count_tensor_equals_without_hints"] is True
     e2e = out["e2e"]
     assert e2e["reads"] == 90 and e2e["plain_equals_bgzf"] and e2e["plain"]["reads_per_s"] > 0 and e2e["bgzf"]["reads_per_s"] > 0
     assert e2e["plain_equals_gzip"] and e2e["gzip"]["reads_per_s"] > 0 and e2e["file_bytes_gzip"] > 100       # an ordinary single-member .gz of the same reads

@@ -528,3 +528,47 @@ def test_a_differing_column_that_is_no_base_leaves_no_hint():
     plain, _ = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w)
     hinted, _ = E.count_vectors(o1, o2, rec, [amp], [inc], L, weights=w, hints=st["hints"])
     assert np.array_equal(plain, hinted)
+
+
+@pytest.mark.parametrize("flags", [0, C.FLAG_IGNORE_SUBSTITUTIONS | C.FLAG_IGNORE_DELETIONS])
+def test_hints_with_several_references_each_task_against_its_own(flags):
+    """CRISPRessoPooled's shape (BASELINE configs[4]): every read tagged with its amplicon.  The hinted kernel runs per reference over that reference's range of
+    the order grouped by reference; the tensor of all three references equals the one without hints, and the reference's aggregation per amplicon."""
+    E.build()
+    m = matrices()["EDNAFULL"]
+    rng = np.random.default_rng(31337)
+    amps = ["".join(rng.choice(list("ACGT"), L)) for L in (200, 250, 180)]
+    gs, incs = [], []
+    for a in amps:
+        g = np.zeros(len(a) + 1, dtype=np.int64); g[len(a) // 2 + 1] = 1
+        gs.append(g); incs.append(list(range(len(a) // 2 - 5, len(a) // 2 + 6)))
+    reads, rids = [], []
+    for k in range(600):
+        r = int(rng.integers(0, 3))
+        rd = _gapped_reads(rng, amps[r], 1)[0] if k % 3 else amps[r]
+        if k % 7 == 0:
+            t = list(amps[r]); t[int(rng.integers(0, len(t)))] = "N"; rd = "".join(t)
+        reads.append(rd); rids.append(r)
+    rids = np.array(rids, dtype=np.uint16)
+    st = {"want_hints": True}
+    res, rec = E.align_batch(reads, amps, gs, incs, m, -20, -2, ref_ids=rids, band_lanes=-87, stats=st)
+    assert (rec["status"] == 0).all() and (rec["ref_id"] == rids).all()
+    o1, o2 = st["raw"]
+    hints4 = st["hints"]
+    assert ((hints4[:, 0] >> 30) != 0).sum() > 300
+    w = rng.integers(0, 20, len(reads)).astype(np.uint32)
+    max_len = max(len(r) for r in reads)
+    plain, lay = E.count_vectors(o1, o2, rec, amps, incs, max_len, weights=w, flags=flags)
+    hinted, _ = E.count_vectors(o1, o2, rec, amps, incs, max_len, weights=w, flags=flags, hints=hints4)
+    assert np.array_equal(plain, hinted), np.nonzero(plain != hinted)
+    pls = payloads(res, [0])                                          # (per-read payloads need the read's own window: below)
+    for r in range(3):
+        items = []
+        for k in range(len(reads)):
+            if rids[k] == r and w[k] > 0:
+                p = oracle.find_indels_substitutions(res[k][0], res[k][1], incs[r])
+                p["aln_seq"], p["aln_ref"] = res[k]
+                items.append((p, int(w[k])))
+        exp = aggregate.aggregate(items, len(amps[r]), ignore_substitutions=bool(flags & 1), ignore_insertions=bool(flags & 2),
+                                  ignore_deletions=bool(flags & 4), discard_indel_reads=bool(flags & 8))
+        compare(lay.unpack(hinted, r, len(amps[r])), exp, len(amps[r]))
