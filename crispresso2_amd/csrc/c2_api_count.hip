@@ -83,9 +83,17 @@ int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t*
         uint32_t* order = (uint32_t*)((uint8_t*)ctx->d_order.p + hist_bytes);
         HIPCHK(ctx, hipMemsetAsync(hist, 0, hist_bytes, s));
         const unsigned gb = (unsigned)((n_tasks + 255) / 256);
+        if (ctx->n_refs <= C2_REF_LDS_MAX && !getenv("C2_NO_REF_LDS_GROUPING")) {
+            const unsigned gc = (unsigned)((n_tasks + C2_REF_CHUNK - 1) / C2_REF_CHUNK);
+            const size_t lb = (size_t)ctx->n_refs * sizeof(uint32_t);
+            hipLaunchKernelGGL(c2_ref_histogram_lds_kernel, dim3(gc), dim3(256), lb, s, d_records, n_tasks, hist, ctx->n_refs);
+            hipLaunchKernelGGL(c2_ref_scan_kernel, dim3(1), dim3(64), 0, s, hist, ctx->n_refs);
+            hipLaunchKernelGGL(c2_ref_scatter_lds_kernel, dim3(gc), dim3(256), lb, s, d_records, n_tasks, hist, order, ctx->n_refs);
+        } else {
         hipLaunchKernelGGL(c2_ref_histogram_kernel, dim3(gb), dim3(256), 0, s, d_records, n_tasks, hist);
         hipLaunchKernelGGL(c2_ref_scan_kernel, dim3(1), dim3(64), 0, s, hist, ctx->n_refs);
         hipLaunchKernelGGL(c2_ref_scatter_kernel, dim3(gb), dim3(256), 0, s, d_records, n_tasks, hist, order);
+        }
         HIPCHK(ctx, hipGetLastError());
         A.order = order;
         if (hints_usable) {

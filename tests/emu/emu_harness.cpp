@@ -455,9 +455,16 @@ int emu_count_vectors(uint64_t n_tasks, const uint8_t* aln_read, const uint8_t* 
     std::vector<uint32_t> hist(n_refs + 1, 0), order(n_tasks ? n_tasks : 1);
     A.order = nullptr;
     if (n_refs > 1) {
+        if (!getenv("C2_NO_REF_LDS_GROUPING")) {                     // (the library's choice up to C2_REF_LDS_MAX references)
+            const unsigned gc = (unsigned)((n_tasks + C2_REF_CHUNK - 1) / C2_REF_CHUNK);
+            emu::launch(gc, [&] { c2_ref_histogram_lds_kernel(records, n_tasks, hist.data(), n_refs); }, 256);
+            emu::launch(1, [&] { c2_ref_scan_kernel(hist.data(), n_refs); });
+            emu::launch(gc, [&] { c2_ref_scatter_lds_kernel(records, n_tasks, hist.data(), order.data(), n_refs); }, 256);
+        } else {
         emu::launch((unsigned)((n_tasks + 255) / 256), [&] { c2_ref_histogram_kernel(records, n_tasks, hist.data()); }, 256);
         emu::launch(1, [&] { c2_ref_scan_kernel(hist.data(), n_refs); });
         emu::launch((unsigned)((n_tasks + 255) / 256), [&] { c2_ref_scatter_kernel(records, n_tasks, hist.data(), order.data()); }, 256);
+        }
         A.order = order.data();
         if (hints_multi) {                                           // (c2_count_vectors_hinted_device with several references: per reference over the grouped order)
             A.hints = hints_multi; A.ref_ends = hist.data(); A.hint_gx = 2;
