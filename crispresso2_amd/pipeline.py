@@ -504,6 +504,8 @@ class _UniqueRun:
             # find_indels_substitutions_legacy (COREResources.pyx:190-315) on the count route: the fused classifier and the count kernel
             # follow its rules (an insertion counts when EITHER flank is in the window; its reference coordinates of a deletion that starts
             # in column 0 / 1 or reaches the end).  Its `nucSet` treats any other reference character as a gap, which the kernels do not.
+            # CRISPRessoCORE never gets here with such an amplicon: it refuses a reference character outside ACGTN before any read is
+            # aligned (CRISPRessoCORE.py:3054-3059, NTException "contains invalid characters"), so only a direct caller of this module can.
             for name in ref_names:
                 if set(refs[name]['sequence']) - set('ACGTN'):
                     raise NotImplementedError("use_legacy_insertion_quantification with a reference character outside ACGTN: "
