@@ -69,8 +69,15 @@ __device__ __forceinline__ void c2_phase_mark(const unsigned long long* acc, c2_
     }
 }
 __device__ __forceinline__ void c2_phase_flush(unsigned long long* acc, const c2_phase_acc& P, const int lane) {
+#ifndef C2_PART_PHASES                              // (A/B build: the four counters belong to c2_align_partition_kernel's phases alone)
     if (acc && lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(acc + k, P.sum[k]); }
+#endif
 }
+#ifdef C2_PART_PHASES
+#define C2_PART_MARK(k) do { if (A.phase_cycles && tid == 0) { const unsigned long long now_ = (unsigned long long)clock64(); atomicAdd(A.phase_cycles + (k), now_ - pt_last); pt_last = now_; } } while (0)
+#else
+#define C2_PART_MARK(k) do { } while (0)
+#endif
 
 // floor(x / R) for the rows-per-lane values in use (x < 32768)
 template <int R>
@@ -2592,7 +2599,8 @@ struct c2_partition_args {
 #endif
 #define C2_PART_LEN_BINS 512                       // read lengths 0 .. 510 have a bin of their own, longer reads share the last
 // flags | per-wavefront scan words | the slots to probe, later the slots in length order (uint16 each) | the slots' read lengths (uint16) | length histogram
-#define C2_PART_LDS (C2_PART_CHUNK + 128 + 2 * C2_PART_CHUNK + 2 * C2_PART_CHUNK + 4 * C2_PART_LEN_BINS)
+// | the reads' byte offsets relative to the chunk's first read (uint32 each)
+#define C2_PART_LDS (C2_PART_CHUNK + 160 + 2 * C2_PART_CHUNK + 2 * C2_PART_CHUNK + 4 * C2_PART_LEN_BINS + 4 * C2_PART_CHUNK)
 
 // 32 bases from p on as 2-bit codes ((c >> 1) & 3: A 0, C 1, T 2, G 3; anything else aliases one of them -- this is a predictor), base k in bits 2k+1 .. 2k
 __device__ __forceinline__ uint64_t c2_code32(const uint8_t* p) {
@@ -2613,7 +2621,7 @@ __device__ __forceinline__ bool c2_band_holds(const int bandw, const int D, cons
 }
 
 // a task's read and reference as the partition needs them
-struct c2_part_task { const uint8_t* rd; const uint8_t* f; const c2_dev_ref* ref; int Li, Lj, rc, pk_ok, cut, ref_id, diag_kmax; };
+struct c2_part_task { const uint8_t* rd; const uint8_t* f; const c2_dev_ref* ref; uint64_t off; int Li, Lj, rc, pk_ok, cut, ref_id, diag_kmax; };
 __device__ __forceinline__ c2_part_task c2_part_load(const c2_align_args& A, const uint64_t task) {
     uint64_t read_id; int ref_id;
     if (A.all_refs) { read_id = task / (uint64_t)A.n_refs; ref_id = (int)(task % (uint64_t)A.n_refs); }
@@ -2622,6 +2630,7 @@ __device__ __forceinline__ c2_part_task c2_part_load(const c2_align_args& A, con
     t.rc = A.strands ? (int)A.strands[task] : 0;
     const uint64_t off = A.offsets[read_id];
     t.Lj = (int)(A.offsets[read_id + 1] - off);
+    t.off = off;
     const c2_dev_ref* rf = A.refs + ref_id;
     t.Li = rf->len; t.pk_ok = rf->pk_ok; t.rd = A.reads + off; t.f = rf->seq; t.cut = rf->first_incentive_pos;
     t.ref_id = ref_id; t.diag_kmax = rf->diag_kmax; t.ref = rf;
@@ -2769,18 +2778,19 @@ __device__ __forceinline__ int c2_part_probe(const c2_partition_args& P, const c
     return cls;
 }
 
-#ifdef C2_PART_WAVES                               // (A/B builds: at least that many wavefronts per SIMD, i.e. a register budget -- profiles/r05/README.md)
-__global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(c2_partition_args P)
-#else
-__global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_args P)
+#ifndef C2_PART_WAVES                              // wavefronts per SIMD the register budget allows: 3 (168 VGPRs, 16 spilled outside the loops; measured, round 6: 2.34 ms per
+#define C2_PART_WAVES 3                            // 10 M headline reads against 2.55 ms with the 203 registers the compiler takes by itself, 2 per SIMD) -- an A/B knob
 #endif
+__global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(c2_partition_args P)
 {
     const c2_align_args& A = P.A;
     uint8_t* const flag = c2_smem;                                  // [C2_PART_CHUNK] the task's class, 7: no such task, 8: still to be probed
     unsigned* const part = (unsigned*)(c2_smem + C2_PART_CHUNK);    // [4 * 4] per wavefront: packed class counts; [16 .. 22]: bases of the seven lists; [24]: the chunk's first read length; [25]: ragged
-    uint16_t* const todo = (uint16_t*)(c2_smem + C2_PART_CHUNK + 128);   // [C2_PART_CHUNK] the chunk's tasks that need the probe, densely; afterwards: the slots in length order
+    unsigned* const okmask = part + 32;                             // [8] a bit per byte value: a base the main-diagonal shortcut may meet in a read (code_of_char < 5)
+    uint16_t* const todo = (uint16_t*)(c2_smem + C2_PART_CHUNK + 160);   // [C2_PART_CHUNK] the chunk's tasks that need the probe, densely; afterwards: the slots in length order
     uint16_t* const len16 = todo + C2_PART_CHUNK;                   // [C2_PART_CHUNK] read length of the slot's task (capped at the last bin)
     unsigned* const hist = (unsigned*)(len16 + C2_PART_CHUNK);      // [C2_PART_LEN_BINS]
+    uint32_t* const roff = (uint32_t*)(hist + C2_PART_LEN_BINS);    // [C2_PART_CHUNK] where the slot's read starts, relative to the chunk's first read
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int PT = C2_PART_CHUNK / 256;                          // tasks per thread of a chunk
     int widest = 2;                                                 // the class that takes what no band holds: the widest band launch the chain has
@@ -2791,8 +2801,16 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
     // (r, 1), (r, 2) next to each other and nothing would pair.  Every other batch: slot = task.
     const c2_part_walk WK = c2_part_walk_of(A);
     const bool may_sort = P.sort_by_length && WK.k == 1u;
+    {   // the bases a read finished on the main diagonal may differ in: A C G T N where the matrix scores them (code_of_char < 5), as a bit per byte value
+        const unsigned long long okb = __ballot(A.code_of_char[tid] < 5);
+        if (lane == 0) { okmask[2 * wv] = (unsigned)okb; okmask[2 * wv + 1] = (unsigned)(okb >> 32); }
+    }
     for (uint64_t chunk = (uint64_t)blockIdx.x * WK.chunk_tasks; chunk < A.n_tasks; chunk += (uint64_t)gridDim.x * WK.chunk_tasks) {
+#ifdef C2_PART_PHASES
+        unsigned long long pt_last = (unsigned long long)clock64();
+#endif
         // ---- one lane per task: the look at the last 32 columns
+        const uint64_t roff_base = A.offsets[A.all_refs ? chunk / (uint64_t)A.n_refs : chunk];
         int ragged = 0;
         unsigned n_exact = 0;                                       // (wave-uniform) class-0 tasks this wavefront finished itself
         for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
@@ -2803,6 +2821,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                 cls = 2;
                 const c2_part_task t = c2_part_load(A, task);
                 lj = t.Lj;
+                roff[slot] = (uint32_t)(t.off - roff_base);
                 if (!t.rc && t.pk_ok && t.Lj >= 32) {
                     int mm = 0x10000;
                     if (t.Lj == t.Li && t.Lj <= 256) {
@@ -2845,6 +2864,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             }
         }
         __syncthreads();
+        C2_PART_MARK(0);
         // ---- class 0, and the read lies ON its reference's main diagonal: a byte-for-byte copy (the unedited, error-free read: the commonest read of
         //      an amplicon run) or one that differs in one or two bases.  Where c2_main_diagonal_certificate (host) proves that the diagonal beats
         //      every other path there is nothing to fill: the aligned strings are the read and the reference, the only events substitutions.
@@ -2870,39 +2890,100 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             for (int k = 0; k < PT; ++k) if (flag[PT * tid + k] == 0u) todo[pos++] = (uint16_t)(PT * tid + k);
             __syncthreads();
             auto flags = [](const uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; };     // bit 7 of every non-zero byte
-            auto eq16 = [&](const uint4& x, const uint8_t* p) {      // equal bytes of a 16-byte half and the 16 bytes at p
-                uint4 s;
-                __builtin_memcpy(&s, p, 16);
-                return 16 - __builtin_popcount(flags(x.x ^ s.x)) - __builtin_popcount(flags(x.y ^ s.y)) - __builtin_popcount(flags(x.z ^ s.z)) - __builtin_popcount(flags(x.w ^ s.w));
-            };
             const int q = tid & 7, grp = (lane >> 3) << 3;          // this lane's 32-byte block; the first lane of its group of eight
-            struct cand_t { bool act, live; int slot, L, nq, at, ov; uint64_t task; c2_part_task t; uint4 x0, x1, y0, y1; };
-            // a candidate's loads (the only ones that come from HBM: two candidates' worth are in flight per lane, see the loop)
-            auto fetch = [&](const unsigned i) {
+            // Round 6: nothing in a candidate's way depends on a load but the read's own 32 bytes per lane.  Where the read lies comes from LDS (roff,
+            // written by the look at the last 32 columns); the differing bases, their window membership and the equal bases of the diagonals +-1 / +-2
+            // come out of the registers that were compared (the shifted diagonals as 2-bit codes of the reference block and four bits of either
+            // neighbour's -- a code aliases N / IUPAC / lower case to one of A C G T, which can only COUNT MORE equal bases: the safe side of the
+            // host's limit); and with ONE reference in the batch its side (ref_t) is made once per workgroup.
+            struct ref_t { uint4 y0, y1; uint64_t w[4]; uint32_t win; int mmax[4]; int L, nq, at, ov, kmax, ref_id; const c2_dev_ref* ref; bool live; };
+            struct cand_t { bool act; int slot; uint64_t task; uint4 x0, x1; };
+            auto regs_code32 = [](const uint4& a, const uint4& b) {  // c2_code32 of 32 bytes held in registers
+                const uint32_t wds[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                uint64_t code = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t t_ = (wds[k] >> 1) & 0x03030303u;
+                    code |= (uint64_t)((t_ | (t_ >> 6) | (t_ >> 12) | (t_ >> 18)) & 0xffu) << (8 * k);
+                }
+                return code;
+            };
+            // the reference's side of a candidate of length L (every lane of the wavefront calls it together: it exchanges codes with its neighbours)
+            auto ref_side = [&](const c2_dev_ref* rf, const int ref_id, const int L, const bool live) {
+                ref_t R;
+                R.ref = rf; R.ref_id = ref_id; R.L = L; R.live = live;
+                R.kmax = live ? rf->diag_kmax : -1;
+                R.nq = (L + 31) >> 5;                               // 32 <= L <= 256: 1 .. 8 blocks
+                R.at = (32 * q + 32 <= L) ? 32 * q : L - 32;        // (the last block starts at L - 32)
+                R.ov = 32 * R.nq - L;                               // bytes at the start of the last block that the block before it holds too
+                R.y0 = uint4{0u, 0u, 0u, 0u}; R.y1 = R.y0; R.win = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) R.mmax[k] = 0;
+                const bool mine = live && q < R.nq;
+                if (mine) {
+                    __builtin_memcpy(&R.y0, rf->seq + R.at, 16); __builtin_memcpy(&R.y1, rf->seq + R.at + 16, 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) R.mmax[k] = rf->diag_mmax[k];
+                    // which of the block's 32 positions are in the quantification window (COREResources.pyx:116)
+                    const uint16_t* ip = rf->inc_prefix + R.at;
+                    unsigned prev = ip[0];
+#pragma unroll 8
+                    for (int k = 0; k < 32; ++k) { const unsigned nx = ip[k + 1]; R.win |= (unsigned)(nx != prev) << k; prev = nx; }
+                }
+                const uint64_t fc = regs_code32(R.y0, R.y1);
+                const uint32_t pv_hi = (uint32_t)__shfl((int)(uint32_t)(fc >> 32), (lane + 63) & 63);      // (only its top four bits are used)
+                const uint64_t pv = (uint64_t)pv_hi << 32;
+                const uint64_t nx = (uint64_t)(uint32_t)__shfl((int)(uint32_t)fc, (lane + 1) & 63) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(fc >> 32), (lane + 1) & 63) << 32);
+                const uint64_t nlo = (q + 1 == R.nq - 1) ? (nx >> (2 * (R.ov & 31))) : nx;          // (the next block is the overlapping last one: its bases from R.ov on)
+                R.w[0] = (fc << 4) | ((pv >> 60) & 0xfull);         // reference bases at - 2 .. at + 29
+                R.w[1] = (fc << 2) | ((pv >> 62) & 0x3ull);         //                 at - 1 .. at + 30
+                R.w[2] = (fc >> 2) | ((nlo & 0x3ull) << 62);        //                 at + 1 .. at + 32
+                R.w[3] = (fc >> 4) | ((nlo & 0xfull) << 60);        //                 at + 2 .. at + 33
+                return R;
+            };
+            const bool one_ref = A.n_refs == 1 || (!A.all_refs && A.ref_ids == nullptr);
+            ref_t R0;
+            {
+                const c2_dev_ref* rf0 = A.refs;
+                const int L0 = rf0->len;
+                R0 = ref_side(rf0, 0, (L0 >= 32 && L0 <= 256) ? L0 : 32, one_ref && L0 >= 32 && L0 <= 256 && rf0->diag_kmax >= 0);
+            }
+            // a candidate's loads: the read's 32 bytes of this lane.  One reference in the batch: where the read lies comes from LDS, and two candidates
+            // are being looked at while the next two are on their way; else the candidate's reference side is made from its own loads first.
+            auto fetch1 = [&](const unsigned i) {
                 cand_t c;
                 c.act = i < total;
                 c.slot = c.act ? (int)todo[i] : 0;
                 c.task = c.act ? c2_part_task_of(WK, A, chunk, c.slot) : 0ull;
-                c.t.diag_kmax = -1; c.t.Lj = 32; c.t.rd = nullptr; c.t.f = nullptr; c.t.ref = nullptr; c.t.ref_id = 0;
-                if (c.act) c.t = c2_part_load(A, c.task);
-                c.live = c.act && c.t.diag_kmax >= 0;
-                c.L = c.t.Lj; c.nq = (c.L + 31) >> 5;                // 32 <= L <= 256: 1 .. 8 blocks
-                c.at = (32 * q + 32 <= c.L) ? 32 * q : c.L - 32;     // (the last block starts at L - 32)
-                c.ov = 32 * c.nq - c.L;                             // bytes at the start of the last block that the block before it holds too
-                c.x0 = uint4{0u, 0u, 0u, 0u}; c.x1 = c.x0; c.y0 = c.x0; c.y1 = c.x0;
-                if (c.live && q < c.nq) {
-                    __builtin_memcpy(&c.x0, c.t.rd + c.at, 16); __builtin_memcpy(&c.x1, c.t.rd + c.at + 16, 16);
-                    __builtin_memcpy(&c.y0, c.t.f + c.at, 16); __builtin_memcpy(&c.y1, c.t.f + c.at + 16, 16);
+                c.x0 = uint4{0u, 0u, 0u, 0u}; c.x1 = c.x0;
+                if (c.act && R0.live && q < R0.nq) {
+                    const uint8_t* rd = A.reads + (roff_base + (uint64_t)roff[c.slot]) + R0.at;
+                    __builtin_memcpy(&c.x0, rd, 16); __builtin_memcpy(&c.x1, rd + 16, 16);
                 }
                 return c;
             };
-            auto finish = [&](const cand_t& c) {
-                const c2_part_task& t = c.t;
-                const int L = c.L, nq = c.nq, at = c.at, ov = c.ov;
-                const uint4 &x0 = c.x0, &x1 = c.x1, &y0 = c.y0, &y1 = c.y1;
-                unsigned kl = 0, eqw = 0, halves = 0;               // this lane's differing bases; equal bytes on the four shifted diagonals (a byte each); halves counted
-                int pa = -1, pb = -1;                               // where its first two differing bases are
-                if (c.live && q < nq) {
+            auto fetchN = [&](const unsigned i, ref_t& R) {
+                cand_t c;
+                c.act = i < total;
+                c.slot = c.act ? (int)todo[i] : 0;
+                c.task = c.act ? c2_part_task_of(WK, A, chunk, c.slot) : 0ull;
+                c.x0 = uint4{0u, 0u, 0u, 0u}; c.x1 = c.x0;
+                c2_part_task t;
+                t.diag_kmax = -1; t.Lj = 32; t.rd = A.reads; t.ref = A.refs; t.ref_id = 0;
+                if (c.act) t = c2_part_load(A, c.task);
+                R = ref_side(t.ref, t.ref_id, t.Lj, c.act && t.diag_kmax >= 0);
+                if (R.live && q < R.nq) { __builtin_memcpy(&c.x0, t.rd + R.at, 16); __builtin_memcpy(&c.x1, t.rd + R.at + 16, 16); }
+                return c;
+            };
+            auto finish = [&](const cand_t& c, const ref_t& R) {
+                const bool live = c.act && R.live;
+                const int L = R.L, nq = R.nq, at = R.at, ov = R.ov;
+                const uint4 &x0 = c.x0, &x1 = c.x1, &y0 = R.y0, &y1 = R.y1;
+                unsigned kl = 0, eqw = 0, halves = 0;               // this lane's differing bases; equal bases on the four shifted diagonals (a byte each); halves counted
+                unsigned wa = 0, wb = 0;                            // its first two differing bases: position | read byte << 9 | in the window << 17 | valid << 18
+                const bool mine = live && q < nq;
+                if (mine) {
+                    const uint32_t xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                     uint32_t f[8] = {flags(x0.x ^ y0.x), flags(x0.y ^ y0.y), flags(x0.z ^ y0.z), flags(x0.w ^ y0.w),
                                      flags(x1.x ^ y1.x), flags(x1.y ^ y1.y), flags(x1.z ^ y1.z), flags(x1.w ^ y1.w)};
                     if (q == nq - 1 && ov) {                        // its first `ov` bytes were counted by the lane before
@@ -2917,20 +2998,22 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                         uint32_t g = f[w];
                         kl += (unsigned)__builtin_popcount(g);
                         while (g) {
-                            const int p_ = at + 4 * w + (__builtin_ctz(g) >> 3);
+                            const int by = __builtin_ctz(g) >> 3, in = 4 * w + by;
                             g &= g - 1u;
-                            if (pa < 0) pa = p_; else if (pb < 0) pb = p_;
+                            const unsigned e = (unsigned)(at + in) | (((xs[w] >> (8 * by)) & 0xffu) << 9) | (((R.win >> in) & 1u) << 17) | (1u << 18);
+                            if (!wa) wa = e; else if (!wb) wb = e;
                         }
                     }
-                    if (t.diag_kmax > 0 && q < nq - 1) {            // (not the last block: it overlaps)
+                    if (R.kmax > 0 && q < nq - 1) {                 // (not the last block: it overlaps)
+                        const uint64_t rc = regs_code32(x0, x1), m55 = 0x5555555555555555ull;
+                        const bool h0 = at >= 2 && at + 18 <= L, h1 = at + 34 <= L;          // reference[o - 2 .. o + 17] exists, o = at, at + 16
+                        halves = (unsigned)h0 + (unsigned)h1;
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int o = at + 16 * h;
-                            if (o >= 2 && o + 18 <= L) {            // reference[o - 2 .. o + 17] exists
-                                const uint4& xh = h ? x1 : x0;
-                                eqw += (unsigned)eq16(xh, t.f + o - 2) | ((unsigned)eq16(xh, t.f + o - 1) << 8) | ((unsigned)eq16(xh, t.f + o + 1) << 16) | ((unsigned)eq16(xh, t.f + o + 2) << 24);
-                                ++halves;
-                            }
+                        for (int sft = 0; sft < 4; ++sft) {
+                            const uint64_t d = rc ^ R.w[sft];
+                            const uint64_t ne = (d | (d >> 1)) & m55;   // a bit per differing base
+                            const unsigned e = (h0 ? 16u - (unsigned)__builtin_popcount((uint32_t)ne) : 0u) + (h1 ? 16u - (unsigned)__builtin_popcount((uint32_t)(ne >> 32)) : 0u);
+                            eqw |= e << (8 * sft);
                         }
                     }
                 }
@@ -2940,31 +3023,31 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                 for (int d = 1; d < 8; d <<= 1) {
                     ks += (unsigned)__shfl_xor((int)ks, d); eqw += (unsigned)__shfl_xor((int)eqw, d); halves += (unsigned)__shfl_xor((int)halves, d);
                 }
-                // ... and where its (at most two) differing bases are: the first lane that holds one, then that lane's second or the next lane's first
+                // ... and its (at most two) differing bases: the first lane that holds one, then that lane's second or the next lane's first
                 const unsigned gm = (unsigned)(__ballot(kl > 0u) >> grp) & 0xffu;
                 const int l1 = gm ? __builtin_ctz(gm) : 0, l2 = (gm & (gm - 1u)) ? __builtin_ctz(gm & (gm - 1u)) : l1;
-                const int p1 = __shfl(pa, grp + l1), p1b = __shfl(pb, grp + l1), p2n = __shfl(pa, grp + l2);
+                const unsigned e1 = (unsigned)__shfl((int)wa, grp + l1), e1b = (unsigned)__shfl((int)wb, grp + l1), e2n = (unsigned)__shfl((int)wa, grp + l2);
                 const int k = (int)ks;
-                const int p2 = p1b >= 0 ? p1b : (l2 != l1 ? p2n : -1);
-                bool done = c.live && k <= t.diag_kmax;
+                const unsigned e2 = e1b ? e1b : (l2 != l1 ? e2n : 0u);
+                const int p1 = e1 ? (int)(e1 & 0x1ffu) : -1, p2 = e2 ? (int)(e2 & 0x1ffu) : -1;
+                bool done = live && k <= R.kmax;
                 int n_all_sub = 0, n_win_sub = 0, irregular = 0;
                 if (done && k > 0) {
                     const int counted = 16 * (int)halves;
                     const int e_m2 = (int)(eqw & 0xffu), e_m1 = (int)((eqw >> 8) & 0xffu), e_p1 = (int)((eqw >> 16) & 0xffu), e_p2 = (int)(eqw >> 24);
                     const int m1 = (e_m1 > e_p1 ? e_m1 : e_p1) + (L - 1 - counted), m2 = (e_m2 > e_p2 ? e_m2 : e_p2) + (L - 2 - counted);
-                    const int32_t* mm = t.ref->diag_mmax + 2 * (k - 1);
-                    if (m1 > mm[0] || m2 > mm[1]) done = false;
+                    if (m1 > (k == 1 ? R.mmax[0] : R.mmax[2]) || m2 > (k == 1 ? R.mmax[1] : R.mmax[3])) done = false;
                     // the differing bases: A C G T N only (anything else keeps its launch: status words, IUPAC scores); the substitutions among them
-                    const int pp[2] = {p1, k > 1 ? p2 : -1};
+                    const unsigned ee[2] = {e1, k > 1 ? e2 : 0u};
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const int pos_ = pp[e];
-                        if (pos_ < 0 || !done) continue;
-                        const unsigned char rb = t.rd[pos_];
-                        if (A.code_of_char[rb] >= 5) { done = false; continue; }
+                        if (!ee[e] || !done) continue;
+                        const int pos_ = (int)(ee[e] & 0x1ffu);
+                        const unsigned rb = (ee[e] >> 9) & 0xffu;
+                        if (!((okmask[rb >> 5] >> (rb & 31u)) & 1u)) { done = false; continue; }
                         if (rb != 'N') {                            // COREResources.pyx:113-118
                             ++n_all_sub;
-                            if (t.ref->inc_prefix[pos_ + 1] != t.ref->inc_prefix[pos_]) ++n_win_sub;
+                            n_win_sub += (int)((ee[e] >> 17) & 1u);
                         }
                         if (pos_ == 0 || pos_ == L - 1) irregular = 1;
                     }
@@ -2977,15 +3060,14 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                             __builtin_memcpy(outR + at, &x0, 16); __builtin_memcpy(outR + at + 16, &x1, 16);
                             __builtin_memcpy(outF + at, &y0, 16); __builtin_memcpy(outF + at + 16, &y1, 16);
                         }
-                        if (q == 0 && (L & 3)) {                    // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it)
-                            uint32_t w = 0, v = 0;
-                            for (int b = 0; b < (L & 3); ++b) { w |= (uint32_t)t.rd[(L & ~3) + b] << (8 * b); v |= (uint32_t)t.f[(L & ~3) + b] << (8 * b); }
+                        if (q == nq - 1 && (L & 3)) {               // (a partial last dword is padded with zeros, as c2_emit_gapless4 pads it: the last block's top bytes)
+                            const uint32_t w = x1.w >> (8 * (4 - (L & 3))), v = y1.w >> (8 * (4 - (L & 3)));
                             __builtin_memcpy(outR + (L & ~3), &w, 4); __builtin_memcpy(outF + (L & ~3), &v, 4);
                         }
                     }
                     if (q == 0) {
                         c2_aln_record rec;
-                        c2_clear_record(rec, 0, t.ref_id);
+                        c2_clear_record(rec, 0, R.ref_id);
                         rec.aln_len = (uint16_t)L; rec.matches = (uint16_t)(L - k);                             // pyx:375-376
                         rec.substitution_n = (uint16_t)n_win_sub; rec.all_substitutions = (uint16_t)n_all_sub;
                         rec.irregular_ends = (uint8_t)irregular;
@@ -2993,23 +3075,37 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
                         flag[c.slot] = 9u;
                         if (A.diag_hints) {                         // the alignment once more, as one word (c2_batch.diag_hints): the count pass need not read the rows back
                             unsigned h = C2_HINT_VALID | ((unsigned)k << 24);
-                            if (k > 0) h |= (unsigned)p1 | ((((unsigned)t.rd[p1] >> 1) & 7u) << 9);
-                            if (k > 1) h |= ((unsigned)p2 << 12) | ((((unsigned)t.rd[p2] >> 1) & 7u) << 21);
+                            if (k > 0) h |= (unsigned)p1 | ((((e1 >> 9) >> 1) & 7u) << 9);
+                            if (k > 1) h |= ((unsigned)p2 << 12) | ((((e2 >> 9) >> 1) & 7u) << 21);
                             A.diag_hints[4u * c.task] = h;               // (words 1 .. 3 stay 0)
                         }
                     }
                 }
                 n_exact += (unsigned)__popcll(__ballot(done && q == 0));
             };
-            for (unsigned i0 = 0; i0 < total; i0 += 64u) {          // 64 candidates per step of the workgroup: two per group of eight lanes, both
-                const cand_t ca = fetch(i0 + (unsigned)(tid >> 3)); //  candidates' loads issued before either is looked at
-                const cand_t cb = fetch(i0 + 32u + (unsigned)(tid >> 3));
-                finish(ca);
-                finish(cb);
+            // 64 candidates per step of the workgroup: two per group of eight lanes; the next step's loads are issued before this step's are looked at
+            if (one_ref) {
+                cand_t ca = fetch1((unsigned)(tid >> 3)), cb = fetch1(32u + (unsigned)(tid >> 3));
+                for (unsigned i0 = 0; i0 < total; i0 += 64u) {
+                    const cand_t na = fetch1(i0 + 64u + (unsigned)(tid >> 3));
+                    const cand_t nb = fetch1(i0 + 96u + (unsigned)(tid >> 3));
+                    finish(ca, R0);
+                    finish(cb, R0);
+                    ca = na; cb = nb;
+                }
+            } else {
+                for (unsigned i0 = 0; i0 < total; i0 += 64u) {
+                    ref_t Ra, Rb;
+                    const cand_t ca = fetchN(i0 + (unsigned)(tid >> 3), Ra);
+                    const cand_t cb = fetchN(i0 + 32u + (unsigned)(tid >> 3), Rb);
+                    finish(ca, Ra);
+                    finish(cb, Rb);
+                }
             }
             if (lane == 0 && n_exact && P.class_count) { atomicAdd(P.class_count + 0, n_exact); atomicAdd(P.class_count + 7, n_exact); }
             __syncthreads();
         }
+        C2_PART_MARK(1);
         if (may_sort) {                                             // do the chunk's reads differ in length?
             const int l0 = (int)part[24];
             for (int r = 0; r < C2_PART_CHUNK / 256; ++r) {
@@ -3044,6 +3140,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             }
             __syncthreads();
         }
+        C2_PART_MARK(2);
         // ---- a ragged chunk: its slots in the order of their reads' lengths (counting sort; the order among equal lengths is that of the atomics --
         //      no result depends on the order of a list).  `todo` holds the permutation from here on; a uniform chunk keeps slot order.
         if (ragged) {
@@ -3124,6 +3221,7 @@ __global__ __launch_bounds__(256) void c2_align_partition_kernel(c2_partition_ar
             for (int c = 0; c < NC; ++c) if (f == (unsigned)c) P.list[c][pos[c]++] = task;
         }
         __syncthreads();                                            // (the flags are overwritten by the next chunk)
+        C2_PART_MARK(3);
     }
 }
 
