@@ -746,9 +746,9 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
                 const int64_t* const* gap_incentives, const int32_t* const* include_idx, const int32_t* n_include) {
     if (!ctx || n_refs <= 0 || n_refs > 65535 || !seqs || !lens || !gap_incentives) { if (ctx) ctx->err = "bad reference arguments"; return C2_E_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // one blob: per ref [seq | pad][gap_incentive int32 x (L+1)][inc_prefix uint16 x (L+2)]
+    // one blob: per ref [seq | pad][gap_incentive int32 x (L+1)][inc_prefix uint16 x (L+2)][seq2: 2-bit codes, 16 per word, padded]
     std::vector<uint8_t> blob;
-    std::vector<size_t> off_seq(n_refs), off_g(n_refs), off_p(n_refs);
+    std::vector<size_t> off_seq(n_refs), off_g(n_refs), off_p(n_refs), off_s2(n_refs);
     int max_li = 0;
     for (int r = 0; r < n_refs; ++r) {
         const int L = lens[r];
@@ -763,6 +763,10 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         c2_build_inc_prefix(include_idx ? include_idx[r] : nullptr, (include_idx && n_include) ? n_include[r] : 0, L, ip);
         align(16); off_p[r] = blob.size();
         blob.insert(blob.end(), (const uint8_t*)ip.data(), (const uint8_t*)(ip.data() + ip.size()));
+        std::vector<uint32_t> s2;
+        c2_build_seq2(seqs[r], L, s2);
+        align(16); off_s2[r] = blob.size();
+        blob.insert(blob.end(), (const uint8_t*)s2.data(), (const uint8_t*)(s2.data() + s2.size()));
     }
     int rc;
     HIPCHK(ctx, hipDeviceSynchronize());      // earlier launches (on whatever stream the caller used) may still read the old tables
@@ -776,6 +780,7 @@ int c2_set_refs(c2_ctx* ctx, int32_t n_refs, const char* const* seqs, const int3
         desc[r].seq = base + off_seq[r];
         desc[r].gap_incentive = (const int32_t*)(base + off_g[r]);
         desc[r].inc_prefix = (const uint16_t*)(base + off_p[r]);
+        desc[r].seq2 = (const uint32_t*)(base + off_s2[r]) + 2;
         desc[r].len = lens[r];
         desc[r].diag_rows = nullptr; desc[r].pk_ok = 0; desc[r].first_incentive_pos = -1; desc[r].diag_kmax = -1; desc[r].reserved_pad = 0;
         for (int k = 0; k < 4; ++k) desc[r].diag_mmax[k] = -1;

@@ -47,6 +47,8 @@ typedef struct c2_dev_ref {
                                   // copy) aligns to it along the main diagonal, provably -- no fill needed; -1: no such proof
     int32_t diag_mmax[4];         // ... for k = 1, 2 differing bases: [2 (k - 1) + (a - 1)] = the most equal bytes the diagonals +-a may hold
     int32_t reserved_pad;
+    const uint32_t* seq2;         // seq as 2-bit codes ((c >> 1) & 3), 16 bases per word, base k of a word in bits 2k+1 .. 2k; two zero words in front of [0] and
+                                  // two behind the last (c2_build_seq2).  What c2_align_partition_kernel's probe walks; NULL: it reads seq byte by byte
 } c2_dev_ref;
 
 // Kernel arguments for the fused align + traceback + classify kernel.

@@ -110,6 +110,12 @@ inline void c2_build_base_luts(const c2_scoring_tables& sc, uint32_t& code_lo, u
     chr_hi = chr[4] | (chr[5] << 8) | (chr[6] << 16) | ((uint32_t)chr[7] << 24);
 }
 
+// c2_dev_ref.seq2: the reference as 2-bit codes, 16 per word, with two zero words on either side (out[2] is word 0)
+inline void c2_build_seq2(const char* seq, int Li, std::vector<uint32_t>& out) {
+    out.assign((size_t)((Li + 15) / 16) + 4, 0u);
+    for (int k = 0; k < Li; ++k) out[2 + (k >> 4)] |= (uint32_t)(((unsigned char)seq[k] >> 1) & 3u) << (2 * (k & 15));
+}
+
 // inc_prefix[x] = number of distinct include idxs < x, x in [0, Li+1]
 inline void c2_build_inc_prefix(const int32_t* inc, int n_inc, int Li, std::vector<uint16_t>& out) {
     std::vector<uint8_t> bit((size_t)Li + 2, 0);

@@ -2675,14 +2675,53 @@ __device__ __forceinline__ int c2_part_window(const c2_partition_args& P, const 
     int s0 = 0;                                                     // the shift the walk starts at: 0 where the reference has a window there
     if (s0 < s_lo) s0 = s_lo;
     if (s0 > s_hi) s0 = s_hi;
-    uint64_t up = c2_code32(t.f + p + s0), dn = up;                 // the windows at s0 + k and s0 - k
+    const int reach = (s_hi - s0) > (s0 - s_lo) ? (s_hi - s0) : (s0 - s_lo);
     int best_mm;
+    if (const uint32_t* s2 = t.ref->seq2) {
+        // Round 6: the reference as 2-bit codes, 16 bases per word (c2_dev_ref.seq2).  A step of the walk takes its base out of a word held in a
+        // register and loads the next word a whole word ahead -- a byte of t.f per step was a load the next step waited for (an L1 hit is some
+        // hundred cycles here, and the wavefront walks as far as its farthest lane: 44 % of the partition's time on the headline batch).
+        const int i0 = p + s0;
+        uint64_t up, dn;
+        {
+            const int d = i0 >> 4, sh = (i0 & 15) * 2;
+            const uint64_t lo = (uint64_t)s2[d] | ((uint64_t)s2[d + 1] << 32);
+            up = sh ? (lo >> sh) | ((uint64_t)s2[d + 2] << (64 - sh)) : lo;
+            dn = up;
+        }
+        {
+            const uint64_t x = up ^ rcode;
+            best_mm = __popcll((x | (x >> 1)) & m55);
+            best_s = s0;
+        }
+        int bu = i0 + 32, bd = i0 - 1;                              // the base that enters at the top / at the bottom next
+        uint32_t wu = s2[bu >> 4], wu_n = s2[(bu >> 4) + 1], wd = s2[bd >> 4], wd_n = s2[(bd >> 4) - 1];
+        for (int k = 1; k <= reach && best_mm > 0; ++k) {
+            if (s0 + k <= s_hi) {
+                up = (up >> 2) | ((uint64_t)((wu >> ((bu & 15) * 2)) & 3u) << 62);
+                ++bu;
+                if (!(bu & 15)) { wu = wu_n; wu_n = s2[(bu >> 4) + 1]; }
+                const uint64_t x = up ^ rcode;
+                const int m2 = __popcll((x | (x >> 1)) & m55);
+                if (m2 < best_mm) { best_mm = m2; best_s = s0 + k; }
+            }
+            if (s0 - k >= s_lo) {
+                dn = (dn << 2) | (uint64_t)((wd >> ((bd & 15) * 2)) & 3u);
+                --bd;
+                if ((bd & 15) == 15) { wd = wd_n; wd_n = s2[(bd >> 4) - 1]; }
+                const uint64_t x = dn ^ rcode;
+                const int m2 = __popcll((x | (x >> 1)) & m55);
+                if (m2 < best_mm) { best_mm = m2; best_s = s0 - k; }
+            }
+        }
+        return best_mm;
+    }
+    uint64_t up = c2_code32(t.f + p + s0), dn = up;                 // the windows at s0 + k and s0 - k
     {
         const uint64_t x = up ^ rcode;
         best_mm = __popcll((x | (x >> 1)) & m55);
         best_s = s0;
     }
-    const int reach = (s_hi - s0) > (s0 - s_lo) ? (s_hi - s0) : (s0 - s_lo);
     for (int k = 1; k <= reach && best_mm > 0; ++k) {
         if (s0 + k <= s_hi) {                                       // the base that enters at the top: reference position p + s0 + k + 31
             up = (up >> 2) | ((uint64_t)(((unsigned)t.f[p + s0 + k + 31] >> 1) & 3u) << 62);

@@ -47,6 +47,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     std::vector<c2_dev_ref> refs(n_refs);
     std::vector<std::vector<int32_t>> g32(n_refs);
     std::vector<std::vector<uint16_t>> incp(n_refs);
+    std::vector<std::vector<uint32_t>> seq2(n_refs);
     std::vector<std::vector<c2_diag_row>> drows(n_refs), drows_pk(n_refs);
     bool any_pk = false;
     int max_li = 1;
@@ -55,6 +56,8 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
         for (int k = 0; k <= lens[r]; ++k) g32[r][k] = (int32_t)gap_inc[r][k];
         c2_build_inc_prefix(include_idx[r], n_include[r], lens[r], incp[r]);
         refs[r].seq = (const uint8_t*)seqs[r]; refs[r].gap_incentive = g32[r].data(); refs[r].inc_prefix = incp[r].data();
+        c2_build_seq2(seqs[r], lens[r], seq2[r]);
+        refs[r].seq2 = getenv("C2_EMU_NO_SEQ2") ? nullptr : seq2[r].data() + 2;
         c2_build_diag_rows(seqs[r], lens[r], g32[r].data(), sc, go, ge, drows[r]);
         refs[r].diag_rows = (drows[r].empty() || no_packed) ? nullptr : drows[r].data() + C2_DIAG_ROW_PAD;
         refs[r].pk_ok = (!no_packed && c2_pk_eligible(seqs[r], lens[r], g32[r].data(), sc, go, ge, 126)) ? 1 : 0; refs[r].first_incentive_pos = -1;

@@ -640,6 +640,47 @@ def test_partition_routes_tasks_to_the_launch_whose_band_holds_their_path(mats, 
     assert st2["classes"][3] == 0 and st2["classes"][4] == 0 and st2["classes"][5] == 0 and st2["classes"][1] > 0, st2
 
 
+@pytest.mark.parametrize("L", [250, 223, 150])
+def test_partition_probe_walks_words_as_it_walked_bytes(mats, L, monkeypatch):
+    """c2_part_window over c2_dev_ref.seq2 (16 two-bit codes per word, a word ahead in a register) finds the windows the byte walk finds: the same
+    classes for the same reads -- shifts to either side, up to the walk's reach, reads shorter and longer than the reference, windows at both ends."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(9100 + L)
+    amp = "".join(rng.choice(list("ACGT"), L))
+    g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+    inc = [L // 2, L // 2 + 1]
+    reads = []
+    for k in range(160):
+        t = list(amp)
+        for _ in range(int(rng.integers(0, 3))):
+            t[int(rng.integers(0, L))] = str(rng.choice(list("ACGTN")))
+        t = "".join(t)
+        cut = int(rng.integers(20, L - 20))
+        d = int(rng.integers(1, 70))
+        kind = k % 5
+        if kind == 0:
+            t = (t[:cut] + t[cut + d:] + "".join(rng.choice(list("ACGT"), d)))[:L]            # deletion, fixed length
+        elif kind == 1:
+            t = (t[:cut] + "".join(rng.choice(list("ACGT"), d)) + t[cut:])[:L]                # insertion, fixed length
+        elif kind == 2:
+            t = t[:cut] + t[cut + d:]                                                          # deletion, shorter read
+        elif kind == 3:
+            t = "".join(rng.choice(list("ACGT"), d % 9)) + t + "".join(rng.choice(list("ACGT"), d % 31))   # overhangs
+        else:
+            t = t[d % 40:]                                                                     # the read starts inside the reference
+        if len(t) >= 40:
+            reads.append(t)
+    st, st2 = {}, {}
+    res, rec = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st)
+    monkeypatch.setenv("C2_EMU_NO_SEQ2", "1")
+    res2, rec2 = E.align_batch(reads, [amp], [g], [inc], m, -20, -2, band_lanes=-87, stats=st2)
+    assert st["classes"] == st2["classes"] and sum(st["classes"][3:]) >= 20, (st["classes"], st2["classes"])
+    assert res2 == res and np.array_equal(rec2, rec)
+    for k in range(0, len(reads), 7):
+        status, s1, s2, mt, ln = oracle.global_align_raw(reads[k], amp, m, g, -20, -2)
+        assert status == 0 and res[k] == (s1, s2), (L, k)
+
+
 @pytest.mark.parametrize("L", [300, 700])
 def test_traceback_runs_of_m_longer_than_one_pass_of_the_word_probe(mats, L):
     """c2_traceback reads a run of state M off whole pointer words, four cells per lane: 250-odd cells per pass.  References of 300 and 700 bases
