@@ -2935,7 +2935,7 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
             // come out of the registers that were compared (the shifted diagonals as 2-bit codes of the reference block and four bits of either
             // neighbour's -- a code aliases N / IUPAC / lower case to one of A C G T, which can only COUNT MORE equal bases: the safe side of the
             // host's limit); and with ONE reference in the batch its side (ref_t) is made once per workgroup.
-            struct ref_t { uint4 y0, y1; uint64_t w[4]; uint32_t win; int mmax[4]; int L, nq, at, ov, kmax, ref_id; const c2_dev_ref* ref; bool live; };
+            struct ref_t { uint4 y0, y1; uint64_t w[4]; uint32_t win; int mmax[4]; int L, nq, at, ov, kmax, ref_id; const c2_dev_ref* ref; bool live, has_win; };
             struct cand_t { bool act; int slot; uint64_t task; uint4 x0, x1; };
             auto regs_code32 = [](const uint4& a, const uint4& b) {  // c2_code32 of 32 bytes held in registers
                 const uint32_t wds[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -2948,9 +2948,9 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
                 return code;
             };
             // the reference's side of a candidate of length L (every lane of the wavefront calls it together: it exchanges codes with its neighbours)
-            auto ref_side = [&](const c2_dev_ref* rf, const int ref_id, const int L, const bool live) {
+            auto ref_side = [&](const c2_dev_ref* rf, const int ref_id, const int L, const bool live, const bool want_win) {
                 ref_t R;
-                R.ref = rf; R.ref_id = ref_id; R.L = L; R.live = live;
+                R.ref = rf; R.ref_id = ref_id; R.L = L; R.live = live; R.has_win = want_win;
                 R.kmax = live ? rf->diag_kmax : -1;
                 R.nq = (L + 31) >> 5;                               // 32 <= L <= 256: 1 .. 8 blocks
                 R.at = (32 * q + 32 <= L) ? 32 * q : L - 32;        // (the last block starts at L - 32)
@@ -2963,11 +2963,12 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
                     __builtin_memcpy(&R.y0, rf->seq + R.at, 16); __builtin_memcpy(&R.y1, rf->seq + R.at + 16, 16);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) R.mmax[k] = rf->diag_mmax[k];
-                    // which of the block's 32 positions are in the quantification window (COREResources.pyx:116)
-                    const uint16_t* ip = rf->inc_prefix + R.at;
-                    unsigned prev = ip[0];
+                    if (want_win) {                                 // which of the block's 32 positions are in the quantification window (COREResources.pyx:116)
+                        const uint16_t* ip = rf->inc_prefix + R.at;
+                        unsigned prev = ip[0];
 #pragma unroll 8
-                    for (int k = 0; k < 32; ++k) { const unsigned nx = ip[k + 1]; R.win |= (unsigned)(nx != prev) << k; prev = nx; }
+                        for (int k = 0; k < 32; ++k) { const unsigned nx = ip[k + 1]; R.win |= (unsigned)(nx != prev) << k; prev = nx; }
+                    }
                 }
                 const uint64_t fc = regs_code32(R.y0, R.y1);
                 const uint32_t pv_hi = (uint32_t)__shfl((int)(uint32_t)(fc >> 32), (lane + 63) & 63);      // (only its top four bits are used)
@@ -2985,7 +2986,7 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
             {
                 const c2_dev_ref* rf0 = A.refs;
                 const int L0 = rf0->len;
-                R0 = ref_side(rf0, 0, (L0 >= 32 && L0 <= 256) ? L0 : 32, one_ref && L0 >= 32 && L0 <= 256 && rf0->diag_kmax >= 0);
+                R0 = ref_side(rf0, 0, (L0 >= 32 && L0 <= 256) ? L0 : 32, one_ref && L0 >= 32 && L0 <= 256 && rf0->diag_kmax >= 0, true);
             }
             // a candidate's loads: the read's 32 bytes of this lane.  One reference in the batch: where the read lies comes from LDS, and two candidates
             // are being looked at while the next two are on their way; else the candidate's reference side is made from its own loads first.
@@ -3010,7 +3011,7 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
                 c2_part_task t;
                 t.diag_kmax = -1; t.Lj = 32; t.rd = A.reads; t.ref = A.refs; t.ref_id = 0;
                 if (c.act) t = c2_part_load(A, c.task);
-                R = ref_side(t.ref, t.ref_id, t.Lj, c.act && t.diag_kmax >= 0);
+                R = ref_side(t.ref, t.ref_id, t.Lj, c.act && t.diag_kmax >= 0, false);      // (the window bits of a differing base: two loads where one is met)
                 if (R.live && q < R.nq) { __builtin_memcpy(&c.x0, t.rd + R.at, 16); __builtin_memcpy(&c.x1, t.rd + R.at + 16, 16); }
                 return c;
             };
@@ -3039,8 +3040,11 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
                         while (g) {
                             const int by = __builtin_ctz(g) >> 3, in = 4 * w + by;
                             g &= g - 1u;
-                            const unsigned e = (unsigned)(at + in) | (((xs[w] >> (8 * by)) & 0xffu) << 9) | (((R.win >> in) & 1u) << 17) | (1u << 18);
-                            if (!wa) wa = e; else if (!wb) wb = e;
+                            if (wa && wb) continue;
+                            unsigned inw = (R.win >> in) & 1u;
+                            if (!R.has_win) { const uint16_t* ip = R.ref->inc_prefix + at + in; inw = ip[1] != ip[0]; }
+                            const unsigned e = (unsigned)(at + in) | (((xs[w] >> (8 * by)) & 0xffu) << 9) | (inw << 17) | (1u << 18);
+                            if (!wa) wa = e; else wb = e;
                         }
                     }
                     if (R.kmax > 0 && q < nq - 1) {                 // (not the last block: it overlaps)
