@@ -344,7 +344,7 @@ typedef struct c2_count_args {
 // LDS of c2_count_hinted_kernel: the int32 position vectors, histograms and two difference arrays; 16 + C2_COUNT_SCALARS 64-bit totals; inc_prefix; scan carries
 static inline size_t c2_count_hinted_lds_bytes(int lmax, int hl) {
     const size_t ints = (size_t)C2_COUNT_VECTORS * (size_t)(lmax + 1) + (size_t)C2_COUNT_HISTS * (size_t)hl + 2u * (size_t)(lmax + 1);
-    return (ints * sizeof(int32_t) + 15) / 16 * 16 + (16 + C2_COUNT_SCALARS) * sizeof(uint64_t) + (size_t)((lmax + 2 + 7) / 8) * 8 * 2 + 64 + 16 * 256 * sizeof(uint32_t);   // (+ lrest: C2_HCNT_FLUSH_ROUNDS x 256)
+    return (ints * sizeof(int32_t) + 15) / 16 * 16 + (16 + C2_COUNT_SCALARS) * sizeof(uint64_t) + (size_t)((lmax + 2 + 7) / 8) * 8 * 2 + 64 + 16 * 256 * sizeof(uint32_t) + (size_t)((lmax + 1 + 15) / 16) * 16;   // (+ lrest: C2_HCNT_FLUSH_ROUNDS x 256; + the reference's bytes)
 }
 
 // ---- best-reference selection on the device (CRISPRessoCORE.py:683, :697-707, :779-785) ----

@@ -826,6 +826,7 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     uint16_t* incp = (uint16_t*)(scal + C2_CNT_SCALARS);
     int* part = (int*)(incp + ((A.lmax + 2 + 7) / 8) * 8);          // [4] carries of the scans, [4] entries of lrest, [5] their place in the global list
     uint32_t* lrest = (uint32_t*)(part + 8);                        // [C2_HCNT_FLUSH_ROUNDS * 256] the tasks left to the column walk since the last flush
+    uint8_t* sseq = (uint8_t*)(lrest + C2_HCNT_FLUSH_ROUNDS * 256);  // [lmax + 1] the reference's bases (a differing base's reference base: no load from HBM behind the hint)
     // one reference per workgroup: the batch's only one, or (tasks grouped by reference in A.order) reference blockIdx.x / hint_gx and its range of positions
     int ref = 0;
     unsigned bx = blockIdx.x, gx = gridDim.x;
@@ -839,6 +840,7 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     if (tid < 16 + C2_CNT_SCALARS) tot[tid] = 0ull;
     if (tid < 8) part[tid] = 0;
     for (int k = tid; k < Li + 2; k += 256) incp[k] = rf.inc_prefix[k];
+    for (int k = tid; k < Li && k <= A.lmax; k += 256) sseq[k] = rf.seq[k];
     __syncthreads();
     const bool ign_sub = A.flags & C2_CNT_FLAG_IGNORE_SUBSTITUTIONS, ign_ins = A.flags & C2_CNT_FLAG_IGNORE_INSERTIONS, ign_del = A.flags & C2_CNT_FLAG_IGNORE_DELETIONS;
     const bool discard = A.flags & C2_CNT_FLAG_DISCARD_INDEL_READS;
@@ -872,17 +874,23 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
         __syncthreads();
         for (int k = tid; k < NV; k += 256) { const int x = acc[k]; if (x != 0) { atomicAdd((u64*)(out + k), (u64)(long long)x); acc[k] = 0; } }
         for (int k = tid; k < NH; k += 256) { const int x = hist[k]; if (x != 0) { atomicAdd((u64*)(out + o_h + k), (u64)(long long)x); hist[k] = 0; } }
-        if (A.rest_list) {
-            const int nrest = part[4];
-            if (tid == 0 && nrest > 0) part[5] = (int)atomicAdd(A.rest_count, (unsigned)nrest);
-            __syncthreads();
-            const unsigned b0 = (unsigned)part[5];
-            for (int k = tid; k < nrest; k += 256) A.rest_list[b0 + (unsigned)k] = lrest[k];
-            __syncthreads();
-            if (tid == 0) part[4] = 0;
-        }
         __syncthreads();
     };
+    // the LDS list of the tasks left to the column walk -> the global list (one atomic per call)
+    auto flush_rest = [&]() {
+        __syncthreads();
+        const int nrest = part[4];
+        if (tid == 0 && nrest > 0) part[5] = (int)atomicAdd(A.rest_count, (unsigned)nrest);
+        __syncthreads();
+        const unsigned b0 = (unsigned)part[5];
+        for (int k = tid; k < nrest; k += 256) A.rest_list[b0 + (unsigned)k] = lrest[k];
+        __syncthreads();
+        if (tid == 0) part[4] = 0;
+        __syncthreads();
+    };
+    // without weights a task adds at most 512 to an entry: the block is emptied once, at the end (or after 2^13 rounds) -- every flush is some thousand
+    // 64-bit atomics on the same addresses from every workgroup of the launch
+    const unsigned acc_rounds = A.weights ? (unsigned)C2_HCNT_FLUSH_ROUNDS : 8192u;
     u64 sW = 0, sN = 0, sSubW = 0, sGsub = 0, sOut = 0, sIn = 0, sIrr = 0, sH0 = 0, sH1 = 0, sH2 = 0;
     const u64 chars = (u64)'A' | ((u64)'C' << 8) | ((u64)'T' << 16) | ((u64)'G' << 24) | ((u64)'N' << 56);      // indexed by (ch >> 1) & 7
     unsigned rounds = 0;
@@ -892,6 +900,15 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
         const uint64_t t = in_range ? (A.ref_ends ? (uint64_t)A.order[pos] : pos) : 0ull;
         unsigned h = 0;
         if (in_range) h = A.hints[4u * t];
+        // a gapped hint's record and other three words: asked for here, looked at behind the main-diagonal tasks' work
+        unsigned d0 = 0, d1 = 0, d2 = 0, d4 = 0, d5 = 0;
+        uint4 hw = uint4{h, 0u, 0u, 0u};
+        if (!(h & C2_HINT_VALID) && (h & C2_HINT_GAPPED)) {
+            const uint4* rq = (const uint4*)(A.records + t);
+            const uint4 ra = rq[0], rb = rq[1];
+            d0 = ra.x; d1 = ra.y; d2 = ra.z; d4 = rb.x; d5 = rb.y;
+            hw = *(const uint4*)(A.hints + 4u * t);
+        }
         if (A.rest_list) {
             // what this kernel does not take (the rule of c2_count_vectors_body's skip) and what has a weight at all goes to the column walk's list --
             // through an LDS list of the workgroup, emptied with the block (one global atomic per flush: an atomic per wavefront on one address
@@ -911,7 +928,7 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
                     if (e >= k) continue;
                     const int c = (int)((h >> (12 * e)) & 0x1ffu);
                     const unsigned char rd = (unsigned char)(chars >> (8 * ((h >> (12 * e + 9)) & 7u)));
-                    const unsigned char rfc = rf.seq[c];
+                    const unsigned char rfc = sseq[c];
                     const bool big = w >= C2_HCNT_SMALL_W;
                     auto add = [&](const int idx, const int x) {
                         if (!big) atomicAdd(acc + idx, x);
@@ -944,8 +961,6 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
             const unsigned wq = A.weights ? A.weights[t] : 1u;
             if (wq > 0u && wq < (unsigned)C2_HCNT_SMALL_W) {
                 const int w = (int)wq;
-                const unsigned* rp = (const unsigned*)(A.records + t);
-                const unsigned d0 = rp[0], d1 = rp[1], d2 = rp[2], d4 = rp[4], d5 = rp[5];
                 const int T = (int)(d0 & 0xffffu), matches = (int)(d0 >> 16);
                 bool sel = ((d5 >> 24) == 0) && (T > 0);
                 if (sel && mm_row) sel = (T <= A.max_t) && (matches >= (int)mm_row[T]);
@@ -983,7 +998,6 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
                         atomicAdd(hist + C2_H_EFFECTIVE_LEN * A.hl + Li + (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n), w);   // :4010-4037
                         // ---- what the column walk adds, run by run (c2_count_vectors_body, "eight columns per lane")
                         const bool len_block = modified;                                                            // :4085 (no coding sequence)
-                        const uint4 hw = *(const uint4*)(A.hints + 4u * t);
                         const int nruns = (int)(hw.x & 7u), nmm = (int)((hw.x >> 3) & 3u);
                         int ix = 0;                                                                                 // reference bases in front of the run
 #pragma unroll
@@ -1039,8 +1053,11 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
                 }
             }
         }
-        if ((++rounds % C2_HCNT_FLUSH_ROUNDS) == 0u) flush();
+        ++rounds;
+        if (A.rest_list && (rounds % C2_HCNT_FLUSH_ROUNDS) == 0u) flush_rest();
+        if ((rounds % acc_rounds) == 0u) flush();
     }
+    if (A.rest_list) flush_rest();
     flush();
     // the lanes' totals of the main-diagonal tasks -> the wavefront's -> the workgroup's (LDS, 64-bit) -> the tensor
     u64 v[10] = {sW, sN, sSubW, sGsub, sOut, sIn, sIrr, sH0, sH1, sH2};
