@@ -892,6 +892,40 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     // 64-bit atomics on the same addresses from every workgroup of the launch
     const unsigned acc_rounds = A.weights ? (unsigned)C2_HCNT_FLUSH_ROUNDS : 8192u;
     u64 sW = 0, sN = 0, sSubW = 0, sGsub = 0, sOut = 0, sIn = 0, sIrr = 0, sH0 = 0, sH1 = 0, sH2 = 0;
+    // The gapped tasks' scalars, the histograms' commonest bins (no insertion / no deletion / no substitution in the window / the reference's own length) and
+    // the two ends of `cov` are what EVERY gapped task of a wavefront adds to: as LDS atomics they are the same address from every lane -- serialised, and the
+    // LDS pipe was busy for half of the kernel's time.  They are kept per lane (int32: drained every C2_HCNT_FLUSH_ROUNDS rounds, 16 x 1,023 x 512 < 2^31)
+    // and reach LDS as one atomic per wavefront.  g_pat[has_del * 4 + has_ins * 2 + has_sub]: what the class counters of :746-760 / :4058-4072 are sums of.
+    int g_gsub = 0, g_out = 0, g_in = 0, g_mout = 0, g_irr = 0, g_n = 0, g_disc = 0;
+    int g_pat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int g_ins0 = 0, g_del0 = 0, g_sub0 = 0, g_eff0 = 0, g_cov0 = 0, g_covL = 0;
+    auto wsum = [&](int x) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) x += __shfl_xor(x, d);
+        return x;
+    };
+    auto drain = [&]() {
+        auto sput = [&](const int k_, int& x) { const int t_ = wsum(x); x = 0; if (lane == 0 && t_) atomicAdd(scal + k_, (u64)(long long)t_); };
+        auto iput = [&](int* dst, int& x) { const int t_ = wsum(x); x = 0; if (lane == 0 && t_) atomicAdd(dst, t_); };
+        sput(C2_S_N_GLOBAL_SUBS, g_gsub); sput(C2_S_N_SUBS_OUTSIDE_WINDOW, g_out); sput(C2_S_N_MODS_IN_WINDOW, g_in); sput(C2_S_N_MODS_OUTSIDE_WINDOW, g_mout);
+        sput(C2_S_N_READS_IRREGULAR_ENDS, g_irr); sput(C2_S_ALIGNMENTS_COUNTED, g_n); sput(C2_S_DISCARDED, g_disc);
+        int pt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { pt[k] = wsum(g_pat[k]); g_pat[k] = 0; }
+        if (lane == 0) {
+            auto sa = [&](const int k_, const long long x) { if (x) atomicAdd(scal + k_, (u64)x); };
+            const long long P0 = pt[0], P1 = pt[1], P2 = pt[2], P3 = pt[3], P4 = pt[4], P5 = pt[5], P6 = pt[6], P7 = pt[7];
+            sa(C2_S_TOTAL, P0 + P1 + P2 + P3 + P4 + P5 + P6 + P7);
+            sa(C2_S_UNMODIFIED, P0); sa(C2_S_MODIFIED, P1 + P2 + P3 + P4 + P5 + P6 + P7);                                   // :746-760, :4003-4006
+            sa(C2_S_INSERTION, P2 + P3 + P6 + P7); sa(C2_S_DELETION, P4 + P5 + P6 + P7); sa(C2_S_SUBSTITUTION, P1 + P3 + P5 + P7);
+            sa(C2_S_ONLY_SUBSTITUTION, P1); sa(C2_S_ONLY_INSERTION, P2); sa(C2_S_INSERTION_AND_SUBSTITUTION, P3);            // :4058-4072
+            sa(C2_S_ONLY_DELETION, P4); sa(C2_S_DELETION_AND_SUBSTITUTION, P5); sa(C2_S_INSERTION_AND_DELETION, P6);
+            sa(C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION, P7);
+        }
+        iput(hist + C2_H_INSERTED_N * A.hl + 0, g_ins0); iput(hist + C2_H_DELETED_N * A.hl + 0, g_del0); iput(hist + C2_H_SUBSTITUTED_N * A.hl + 0, g_sub0);
+        iput(hist + C2_H_EFFECTIVE_LEN * A.hl + Li, g_eff0);
+        iput(cov + 0, g_cov0); iput(cov + Li, g_covL);
+    };
     const u64 chars = (u64)'A' | ((u64)'C' << 8) | ((u64)'T' << 16) | ((u64)'G' << 24) | ((u64)'N' << 56);      // indexed by (ch >> 1) & 7
     unsigned rounds = 0;
     for (uint64_t base = p_lo + (uint64_t)bx * 256u; base < p_hi; base += (uint64_t)gx * 256u) {
@@ -971,31 +1005,24 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
                     const int all_ins = (int)(d2 >> 16), all_del_bases = (int)((d4 >> 16) & 0x7fffu), all_sub = (int)(d5 & 0xffffu);
                     const bool irregular_ends = (d5 >> 16) & 0xffu;
                     const int total_mods = all_ins + all_del_bases + all_sub, in_win = substitution_n + deletion_n + insertion_n;      // :741-742
-                    auto sadd = [&](const int k_, const long long x) { if (x) atomicAdd(scal + k_, (u64)x); };
-                    const long long W = w;
-                    sadd(C2_S_N_GLOBAL_SUBS, all_sub * W); sadd(C2_S_N_SUBS_OUTSIDE_WINDOW, (all_sub - substitution_n) * W);
-                    sadd(C2_S_N_MODS_IN_WINDOW, in_win * W); sadd(C2_S_N_MODS_OUTSIDE_WINDOW, (total_mods - in_win) * W);
-                    if (irregular_ends) sadd(C2_S_N_READS_IRREGULAR_ENDS, W);
-                    sadd(C2_S_ALIGNMENTS_COUNTED, 1);
+                    g_gsub += all_sub * w; g_out += (all_sub - substitution_n) * w;
+                    g_in += in_win * w; g_mout += (total_mods - in_win) * w;
+                    if (irregular_ends) g_irr += w;
+                    g_n += 1;
                     const bool has_ins = !ign_ins && insertion_n > 0, has_del = !ign_del && deletion_n > 0, has_sub = !ign_sub && substitution_n > 0;
                     const bool modified = has_del || has_ins || has_sub;
-                    if (discard && (deletion_n > 0 || insertion_n > 0)) sadd(C2_S_DISCARDED, W);                     // :3996-4000: counted, no vectors
+                    if (discard && (deletion_n > 0 || insertion_n > 0)) g_disc += w;                                 // :3996-4000: counted, no vectors
                     else {
-                        sadd(C2_S_TOTAL, W);
-                        sadd(modified ? C2_S_MODIFIED : C2_S_UNMODIFIED, W);                                        // :746-760, :4003-4006
-                        if (has_ins) sadd(C2_S_INSERTION, W);
-                        if (has_del) sadd(C2_S_DELETION, W);
-                        if (has_sub) sadd(C2_S_SUBSTITUTION, W);
-                        int combo = -1;                                                                             // :4058-4072
-                        if (has_del) combo = has_ins ? (has_sub ? C2_S_INSERTION_AND_DELETION_AND_SUBSTITUTION : C2_S_INSERTION_AND_DELETION)
-                                                     : (has_sub ? C2_S_DELETION_AND_SUBSTITUTION : C2_S_ONLY_DELETION);
-                        else if (has_ins) combo = has_sub ? C2_S_INSERTION_AND_SUBSTITUTION : C2_S_ONLY_INSERTION;
-                        else if (has_sub) combo = C2_S_ONLY_SUBSTITUTION;
-                        if (combo >= 0) sadd(combo, W);
-                        if (!ign_ins) atomicAdd(hist + C2_H_INSERTED_N * A.hl + insertion_n, w);                    // :4020
-                        if (!ign_del) atomicAdd(hist + C2_H_DELETED_N * A.hl + deletion_n, w);                      // :4030
-                        if (!ign_sub) atomicAdd(hist + C2_H_SUBSTITUTED_N * A.hl + substitution_n, w);              // :4043
-                        atomicAdd(hist + C2_H_EFFECTIVE_LEN * A.hl + Li + (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n), w);   // :4010-4037
+                        const int pat = (has_del ? 4 : 0) | (has_ins ? 2 : 0) | (has_sub ? 1 : 0);                   // :746-760, :4003-4006, :4058-4072 (see drain)
+#pragma unroll
+                        for (int k_ = 0; k_ < 8; ++k_) g_pat[k_] += pat == k_ ? w : 0;
+                        if (!ign_ins) { if (insertion_n == 0) g_ins0 += w; else atomicAdd(hist + C2_H_INSERTED_N * A.hl + insertion_n, w); }            // :4020
+                        if (!ign_del) { if (deletion_n == 0) g_del0 += w; else atomicAdd(hist + C2_H_DELETED_N * A.hl + deletion_n, w); }              // :4030
+                        if (!ign_sub) { if (substitution_n == 0) g_sub0 += w; else atomicAdd(hist + C2_H_SUBSTITUTED_N * A.hl + substitution_n, w); }  // :4043
+                        {
+                            const int eff = (ign_ins ? 0 : insertion_n) - (ign_del ? 0 : deletion_n);                                                   // :4010-4037
+                            if (eff == 0) g_eff0 += w; else atomicAdd(hist + C2_H_EFFECTIVE_LEN * A.hl + Li + eff, w);
+                        }
                         // ---- what the column walk adds, run by run (c2_count_vectors_body, "eight columns per lane")
                         const bool len_block = modified;                                                            // :4085 (no coding sequence)
                         const int nruns = (int)(hw.x & 7u), nmm = (int)((hw.x >> 3) & 3u);
@@ -1007,7 +1034,8 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
                             const int st = (int)(fld & 3u), len = (int)(fld >> 2);
                             if (st == C2_ST_M) {
                                 // the read's base IS the reference's (all_base_count, :4075-4081; the differing columns are taken back below)
-                                atomicAdd(cov + ix, w); atomicAdd(cov + ix + len, -w);
+                                if (ix == 0) g_cov0 += w; else atomicAdd(cov + ix, w);
+                                if (ix + len == Li) g_covL -= w; else atomicAdd(cov + ix + len, -w);
                                 ix += len;
                             } else if (st == C2_ST_J) {
                                 // a deletion: its columns (all_deletion :4028, the '-' base counts) as a range; the window counts as ranges too
@@ -1054,9 +1082,10 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
             }
         }
         ++rounds;
-        if (A.rest_list && (rounds % C2_HCNT_FLUSH_ROUNDS) == 0u) flush_rest();
+        if ((rounds % C2_HCNT_FLUSH_ROUNDS) == 0u) { drain(); if (A.rest_list) flush_rest(); }
         if ((rounds % acc_rounds) == 0u) flush();
     }
+    drain();
     if (A.rest_list) flush_rest();
     flush();
     // the lanes' totals of the main-diagonal tasks -> the wavefront's -> the workgroup's (LDS, 64-bit) -> the tensor
