@@ -102,8 +102,24 @@ int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t*
             A.hints = d_hints; A.ref_ends = hist;
             const uint64_t per = n_tasks / (uint64_t)ctx->n_refs + 1;
             A.hint_gx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((per + 4095) / 4096, 64));
+            // ... and walks only what the hinted kernel left: a list per reference (in the reference's own range of a second buffer), closed up into `order`
+            uint32_t* cnt = nullptr; uint32_t* pre = nullptr; uint32_t* total = nullptr; uint32_t* ranged = nullptr;
+            if (!getenv("C2_NO_COUNT_REST_LIST")) {
+                if ((rc = ensure(ctx, ctx->d_order2, 2 * hist_bytes + 256 + n_tasks * sizeof(uint32_t)))) return rc;
+                cnt = (uint32_t*)ctx->d_order2.p; pre = (uint32_t*)((uint8_t*)ctx->d_order2.p + hist_bytes);
+                total = (uint32_t*)((uint8_t*)ctx->d_order2.p + 2 * hist_bytes); ranged = (uint32_t*)((uint8_t*)ctx->d_order2.p + 2 * hist_bytes + 256);
+                HIPCHK(ctx, hipMemsetAsync(cnt, 0, 2 * hist_bytes + 256, s));
+                A.rest_list = ranged; A.rest_count = cnt;
+            }
             hipLaunchKernelGGL(c2_count_hinted_kernel, dim3(A.hint_gx * (unsigned)ctx->n_refs), dim3(256), c2_count_hinted_lds_bytes(lmax, hl), s, A);
             HIPCHK(ctx, hipGetLastError());
+            if (A.rest_list) {
+                hipLaunchKernelGGL(c2_rest_scan_kernel, dim3(1), dim3(64), 0, s, cnt, pre, total, ctx->n_refs);
+                const unsigned cgx = 8;
+                hipLaunchKernelGGL(c2_rest_compact_kernel, dim3(cgx * (unsigned)ctx->n_refs), dim3(256), 0, s, cnt, pre, hist, ranged, order, cgx);
+                HIPCHK(ctx, hipGetLastError());
+                A.n_tasks_dev = total; A.hints = nullptr; A.ref_ends = nullptr;      // (A.order = order: now the tasks left, still grouped by reference)
+            }
         }
     }
     const void* fn = hbm_block ? (const void*)c2_count_vectors_hbm_kernel : (const void*)c2_count_vectors_kernel;

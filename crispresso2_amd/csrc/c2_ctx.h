@@ -83,6 +83,7 @@ struct c2_ctx {
     DevBuf d_cnt_block;            // count route: the workgroups' accumulator blocks when they do not fit LDS
     DevBuf d_lists, d_lists_out;   // batched classifier: staging and flat output
     DevBuf d_order;        // count kernel: histogram + tasks grouped by reference
+    DevBuf d_order2;       // ... several references with hints: per-reference counters and starts + the tasks the hinted kernel left, in every reference's own range
     int last_tiers = 0;    // banded launches in front of the full-plane launch in the last run_align
     bool last_score_stage = false, last_p16_stage = false; uint64_t last_n_tasks = 0;   // the last run_align: did the score-only stage run, over how many tasks in all
     int occ_lds[5][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};

@@ -89,6 +89,29 @@ __global__ __launch_bounds__(256) void c2_ref_scatter_kernel(const c2_aln_record
     if (active) order[slot] = (uint32_t)t;
 }
 
+// Behind c2_count_hinted_kernel with several references: the tasks it left lie in every reference's own range of `ranged` (cnt[r] of them from the range's
+// start, ends[r - 1]); one wavefront turns the counts into starts (pre) and their sum (*total), then the ranges are copied back to back into `dense` --
+// still grouped by reference, which is what keeps c2_count_vectors_kernel's flushes few.
+__global__ __launch_bounds__(64) void c2_rest_scan_kernel(const uint32_t* cnt, uint32_t* pre, uint32_t* total, int n_refs)
+{
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < n_refs; base += 64) {
+        const int k = base + lane;
+        const int x = (k < n_refs) ? (int)cnt[k] : 0;
+        const int s = c2_wave_incl_scan(x, lane) + carry;
+        if (k < n_refs) pre[k] = (uint32_t)(s - x);
+        carry = __shfl(s, 63);
+    }
+    if (lane == 0) *total = (uint32_t)carry;
+}
+__global__ __launch_bounds__(256) void c2_rest_compact_kernel(const uint32_t* cnt, const uint32_t* pre, const uint32_t* ends, const uint32_t* ranged, uint32_t* dense, unsigned gx)
+{
+    const unsigned r = blockIdx.x / gx, j = blockIdx.x - r * gx;
+    const uint32_t n = cnt[r], from = r ? ends[r - 1] : 0u, to = pre[r];
+    for (uint32_t k = j * 256u + threadIdx.x; k < n; k += gx * 256u) dense[to + k] = ranged[from + k];
+}
+
 // The same grouping through LDS (round 6; up to C2_REF_LDS_MAX references): a workgroup counts its 4,096 tasks per reference in LDS and asks the global
 // counters once per reference it holds -- tasks sorted by amplicon in the input (the pooled shape) cost a workgroup one or two atomics instead of one per
 // wavefront and reference (histogram 1.09 -> ms, scatter 1.77 -> ms for 12.5 M tasks of 96 references, profiles/r06).
@@ -880,10 +903,11 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     auto flush_rest = [&]() {
         __syncthreads();
         const int nrest = part[4];
-        if (tid == 0 && nrest > 0) part[5] = (int)atomicAdd(A.rest_count, (unsigned)nrest);
+        // (several references: a counter per reference, the reference's tasks into its own range of the list -- c2_rest_compact_kernel closes the gaps)
+        if (tid == 0 && nrest > 0) part[5] = (int)atomicAdd(A.rest_count + (A.ref_ends ? ref : 0), (unsigned)nrest);
         __syncthreads();
-        const unsigned b0 = (unsigned)part[5];
-        for (int k = tid; k < nrest; k += 256) A.rest_list[b0 + (unsigned)k] = lrest[k];
+        const uint64_t b0 = (A.ref_ends ? p_lo : 0ull) + (uint64_t)(unsigned)part[5];
+        for (int k = tid; k < nrest; k += 256) A.rest_list[b0 + (uint64_t)k] = lrest[k];
         __syncthreads();
         if (tid == 0) part[4] = 0;
         __syncthreads();

@@ -1365,6 +1365,78 @@ def test_ragged_and_unrelated_reads_and_the_full_matrix_launch_with_its_plane_in
 
 
 @pytest.mark.gpu
+def test_gpu_hinted_count_with_several_references(mats, ctx, monkeypatch):
+    """CRISPRessoPooled's shape on the hardware: 7 amplicons of different lengths, 84,000 reads tagged with their amplicon (interleaved, and one amplicon
+    without a read).  The hinted kernel runs per reference over the grouped order and leaves a list per reference that c2_rest_compact_kernel closes up;
+    the count tensor equals the one without hints and the one with the list switched off (C2_NO_COUNT_REST_LIST=1), with and without weights."""
+    import torch
+    from crispresso2_amd import synth, _native, counts as C
+    from crispresso2_amd.batch import BatchAligner
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(777)
+    lens = [250, 200, 223, 250, 180, 240, 250]
+    amps, gs, incs = [], [], []
+    for k, L in enumerate(lens):
+        a = "".join(rng.choice(list("ACGT"), L))
+        g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+        amps.append(a); gs.append(g); incs.append(list(range(L // 2 - 5, L // 2 + 6)))
+    n = 84000
+    rids = rng.integers(0, len(lens), n).astype(np.uint16)
+    rids[rids == 4] = 5                                             # (amplicon 4 has no read)
+    chunks, offs = [], [0]
+    for k in range(n):
+        a = np.frombuffer(amps[rids[k]].encode(), dtype=np.uint8).copy()
+        kind = k % 6
+        if kind in (1, 2):                                          # one / two substitutions
+            for _ in range(kind):
+                a[int(rng.integers(0, len(a)))] = ord("ACGTN"[int(rng.integers(0, 5))])
+        elif kind == 3:                                             # a deletion at the cut, fixed length
+            d = int(rng.integers(1, 20)); c = len(a) // 2
+            a = np.concatenate([a[:c], a[c + d:], rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), d)])
+        elif kind == 4:                                             # an insertion at the cut, fixed length
+            d = int(rng.integers(1, 10)); c = len(a) // 2
+            a = np.concatenate([a[:c], rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), d), a[c:]])[:len(a)]
+        chunks.append(a); offs.append(offs[-1] + len(a))
+    arena = np.concatenate(chunks)
+    al = BatchAligner(amps, gs, incs, m, -20, -2, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    Lmax = max(lens)
+    stride = al.stride_for(Lmax)
+    d_reads = torch.from_numpy(arena).to(dev)
+    d_off = torch.from_numpy(np.array(offs, dtype=np.int64)).to(dev)
+    d_rid = torch.from_numpy(rids.view(np.int16)).to(dev)
+    o1 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    o2 = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    rec = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    hints = torch.zeros((n * 4,), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, Lmax, d_ref_ids=d_rid.data_ptr(),
+                    stream=s, d_hints=hints.data_ptr())
+    torch.cuda.synchronize()
+    records = rec.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+    assert (records["status"] == 0).all() and (records["ref_id"] == rids).all()
+    h0 = hints.cpu().numpy().view(np.uint32).reshape(n, 4)[:, 0]
+    assert ((h0 >> 30) != 0).sum() > n // 2
+    layout = C.CountLayout(len(lens), Lmax, Lmax + 16)
+    w = rng.integers(0, 30, n).astype(np.uint32)
+    w[5] = 70000; w[11] = 1024; w[17] = 0x90000000
+    d_w = torch.from_numpy(w.view(np.int32)).to(dev)
+
+    def count(use_hints, weights):
+        t = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
+        C.accumulate_device(ctx, layout, n, o1.data_ptr(), o2.data_ptr(), stride, rec.data_ptr(), t.data_ptr(), d_weights=d_w.data_ptr() if weights else None,
+                            stream=s, d_hints=hints.data_ptr() if use_hints else None)
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+    for weights in (False, True):
+        plain = count(False, weights)
+        assert plain.sum() > 0
+        assert np.array_equal(plain, count(True, weights)), weights
+        monkeypatch.setenv("C2_NO_COUNT_REST_LIST", "1")
+        assert np.array_equal(plain, count(True, weights)), weights
+        monkeypatch.delenv("C2_NO_COUNT_REST_LIST")
+
+
 @pytest.mark.parametrize("L", [250, 150])
 def test_gpu_hinted_count_equals_the_count_over_the_rows(mats, ctx, L):
     """Round 6: c2_batch.diag_hints + c2_count_vectors_hinted_device on the hardware.  60,000 synthetic reads (a third of them copies of the amplicon or one /
