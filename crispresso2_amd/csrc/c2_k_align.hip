@@ -2600,7 +2600,8 @@ struct c2_partition_args {
 #define C2_PART_LEN_BINS 512                       // read lengths 0 .. 510 have a bin of their own, longer reads share the last
 // flags | per-wavefront scan words | the slots to probe, later the slots in length order (uint16 each) | the slots' read lengths (uint16) | length histogram
 // | the reads' byte offsets relative to the chunk's first read (uint32 each)
-#define C2_PART_LDS (C2_PART_CHUNK + 160 + 2 * C2_PART_CHUNK + 2 * C2_PART_CHUNK + 4 * C2_PART_LEN_BINS + 4 * C2_PART_CHUNK)
+// | the slots' reference ids (uint16; batches whose reads are tagged with their reference)
+#define C2_PART_LDS (C2_PART_CHUNK + 160 + 2 * C2_PART_CHUNK + 2 * C2_PART_CHUNK + 4 * C2_PART_LEN_BINS + 4 * C2_PART_CHUNK + 2 * C2_PART_CHUNK)
 
 // 32 bases from p on as 2-bit codes ((c >> 1) & 3: A 0, C 1, T 2, G 3; anything else aliases one of them -- this is a predictor), base k in bits 2k+1 .. 2k
 __device__ __forceinline__ uint64_t c2_code32(const uint8_t* p) {
@@ -2830,6 +2831,7 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
     uint16_t* const len16 = todo + C2_PART_CHUNK;                   // [C2_PART_CHUNK] read length of the slot's task (capped at the last bin)
     unsigned* const hist = (unsigned*)(len16 + C2_PART_CHUNK);      // [C2_PART_LEN_BINS]
     uint32_t* const roff = (uint32_t*)(hist + C2_PART_LEN_BINS);    // [C2_PART_CHUNK] where the slot's read starts, relative to the chunk's first read
+    uint16_t* const rid16 = (uint16_t*)(roff + C2_PART_CHUNK);       // [C2_PART_CHUNK] the slot's reference
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int PT = C2_PART_CHUNK / 256;                          // tasks per thread of a chunk
     int widest = 2;                                                 // the class that takes what no band holds: the widest band launch the chain has
@@ -2861,6 +2863,7 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
                 const c2_part_task t = c2_part_load(A, task);
                 lj = t.Lj;
                 roff[slot] = (uint32_t)(t.off - roff_base);
+                rid16[slot] = (uint16_t)t.ref_id;
                 if (!t.rc && t.pk_ok && t.Lj >= 32) {
                     int mm = 0x10000;
                     if (t.Lj == t.Li && t.Lj <= 256) {
@@ -2936,7 +2939,7 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
             // neighbour's -- a code aliases N / IUPAC / lower case to one of A C G T, which can only COUNT MORE equal bases: the safe side of the
             // host's limit); and with ONE reference in the batch its side (ref_t) is made once per workgroup.
             struct ref_t { uint4 y0, y1; uint64_t w[4]; uint32_t win; int mmax[4]; int L, nq, at, ov, kmax, ref_id; const c2_dev_ref* ref; bool live, has_win; };
-            struct cand_t { bool act; int slot; uint64_t task; uint4 x0, x1; };
+            struct cand_t { bool act; int slot, ref_id; uint64_t task; uint4 x0, x1; };
             auto regs_code32 = [](const uint4& a, const uint4& b) {  // c2_code32 of 32 bytes held in registers
                 const uint32_t wds[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 uint64_t code = 0;
@@ -2995,6 +2998,7 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
                 c.act = i < total;
                 c.slot = c.act ? (int)todo[i] : 0;
                 c.task = c.act ? c2_part_task_of(WK, A, chunk, c.slot) : 0ull;
+                c.ref_id = 0;
                 c.x0 = uint4{0u, 0u, 0u, 0u}; c.x1 = c.x0;
                 if (c.act && R0.live && q < R0.nq) {
                     const uint8_t* rd = A.reads + (roff_base + (uint64_t)roff[c.slot]) + R0.at;
@@ -3002,18 +3006,40 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
                 }
                 return c;
             };
-            auto fetchN = [&](const unsigned i, ref_t& R) {
+            // several references: the slot's reference from LDS, its length from the reference's record (one load in front of the read's, an L1 hit); the
+            // reference's side is kept per lane group and made again when a group meets another reference (the lists are in slot order: reference-major
+            // chunks of an all-references batch, runs of one amplicon in a pooled one -- a few times per chunk)
+            auto fetchM = [&](const unsigned i) {
                 cand_t c;
                 c.act = i < total;
                 c.slot = c.act ? (int)todo[i] : 0;
                 c.task = c.act ? c2_part_task_of(WK, A, chunk, c.slot) : 0ull;
+                c.ref_id = c.act ? (int)rid16[c.slot] : 0;
                 c.x0 = uint4{0u, 0u, 0u, 0u}; c.x1 = c.x0;
-                c2_part_task t;
-                t.diag_kmax = -1; t.Lj = 32; t.rd = A.reads; t.ref = A.refs; t.ref_id = 0;
-                if (c.act) t = c2_part_load(A, c.task);
-                R = ref_side(t.ref, t.ref_id, t.Lj, c.act && t.diag_kmax >= 0, false);      // (the window bits of a differing base: two loads where one is met)
-                if (R.live && q < R.nq) { __builtin_memcpy(&c.x0, t.rd + R.at, 16); __builtin_memcpy(&c.x1, t.rd + R.at + 16, 16); }
+                if (c.act) {
+                    const int L = A.refs[c.ref_id].len;                 // (a class-0 task: its read is as long as its reference, 32 .. 256)
+                    const int nq = (L + 31) >> 5, at = (32 * q + 32 <= L) ? 32 * q : L - 32;
+                    if (q < nq) {
+                        const uint8_t* rd = A.reads + (roff_base + (uint64_t)roff[c.slot]) + at;
+                        __builtin_memcpy(&c.x0, rd, 16); __builtin_memcpy(&c.x1, rd + 16, 16);
+                    }
+                }
                 return c;
+            };
+            ref_t Rc = R0;                                           // (not live unless the batch has one reference)
+            Rc.ref_id = one_ref ? 0 : -1;
+            auto ensure = [&](const cand_t& c) {                     // every lane of the wavefront together (ref_side exchanges codes between lanes)
+                const bool need = c.act && c.ref_id != Rc.ref_id;
+                if (__ballot(need) != 0ull) {
+                    const int rid = need ? c.ref_id : (Rc.ref_id >= 0 ? Rc.ref_id : 0);
+                    const c2_dev_ref* rf = A.refs + rid;
+                    const int L = rf->len;
+                    const bool ok = (need || Rc.ref_id >= 0) && L >= 32 && L <= 256 && rf->diag_kmax >= 0;
+                    const int keep = (need || Rc.ref_id >= 0) ? rid : -1;
+                    Rc = ref_side(rf, rid, (L >= 32 && L <= 256) ? L : 32, ok, false);   // (the window bits of a differing base: two loads where one is met -- a batch whose neighbours
+                                                                                          //  are of different amplicons comes through here for every candidate)
+                    Rc.ref_id = keep;
+                }
             };
             auto finish = [&](const cand_t& c, const ref_t& R) {
                 const bool live = c.act && R.live;
@@ -3137,12 +3163,15 @@ __global__ __launch_bounds__(256, C2_PART_WAVES) void c2_align_partition_kernel(
                     ca = na; cb = nb;
                 }
             } else {
+                cand_t ca = fetchM((unsigned)(tid >> 3)), cb = fetchM(32u + (unsigned)(tid >> 3));
                 for (unsigned i0 = 0; i0 < total; i0 += 64u) {
-                    ref_t Ra, Rb;
-                    const cand_t ca = fetchN(i0 + (unsigned)(tid >> 3), Ra);
-                    const cand_t cb = fetchN(i0 + 32u + (unsigned)(tid >> 3), Rb);
-                    finish(ca, Ra);
-                    finish(cb, Rb);
+                    const cand_t na = fetchM(i0 + 64u + (unsigned)(tid >> 3));
+                    const cand_t nb = fetchM(i0 + 96u + (unsigned)(tid >> 3));
+                    ensure(ca);
+                    finish(ca, Rc);
+                    ensure(cb);
+                    finish(cb, Rc);
+                    ca = na; cb = nb;
                 }
             }
             if (lane == 0 && n_exact && P.class_count) { atomicAdd(P.class_count + 0, n_exact); atomicAdd(P.class_count + 7, n_exact); }

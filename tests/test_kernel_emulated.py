@@ -764,6 +764,44 @@ def test_partition_settings_never_change_a_result(mats, go, ge, env, monkeypatch
         check_record(r, oracle.find_indels_substitutions(s1, s2, incs[rids[k]]), s1, s2)
 
 
+@pytest.mark.parametrize("layout", ["tagged_sorted", "tagged_interleaved", "all_refs"])
+def test_main_diagonal_reads_of_several_references_are_finished_by_the_partition(mats, layout):
+    """Round 6: with several references the partition keeps the reference's side of the main-diagonal shortcut per lane group and makes it again when a group
+    meets another reference (c2_align_partition_kernel: fetchM / ensure).  Four amplicons of different lengths (one of them a length no block edge likes),
+    reads = copies and one / two / three substitutions, tagged with their amplicon in runs, interleaved, or every read against every amplicon: the
+    partition finishes reads of every amplicon, and every alignment and record is the oracle's."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(606)
+    lens = [250, 203, 160, 97]
+    refs = ["".join(rng.choice(list("ACGT"), L)) for L in lens]
+    gis, incs = [], []
+    for r in refs:
+        g = np.zeros(len(r) + 1, dtype=np.int64); g[len(r) // 2 + 1] = 1
+        gis.append(g); incs.append([len(r) // 2, len(r) // 2 + 1])
+    reads, rids = [], []
+    for k in range(400):
+        r = (k // 100) if layout == "tagged_sorted" else int(rng.integers(0, 4))
+        t = list(refs[r])
+        for _ in range(k % 4):
+            t[int(rng.integers(0, len(t)))] = str(rng.choice(list("ACGTN")))
+        reads.append("".join(t)); rids.append(r)
+    st = {}
+    if layout == "all_refs":
+        reads = reads[:150]
+        res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, all_refs=True, band_lanes=-87, stats=st)
+        pairs = [(reads[k // 4], k % 4) for k in range(4 * len(reads))]
+    else:
+        res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=np.array(rids, dtype=np.uint16), band_lanes=-87, stats=st)
+        pairs = list(zip(reads, rids))
+    finished_of = [0, 0, 0, 0]
+    for k, ((s1, s2), r) in enumerate(zip(res, rec)):
+        rd, ri = pairs[k]
+        exp = oracle.global_align_raw(rd, refs[ri], m, gis[ri], -20, -2)
+        assert r["status"] == 0 and int(r["ref_id"]) == ri and (s1, s2, int(r["matches"]), int(r["aln_len"])) == exp[1:], (layout, k)
+        check_record(r, oracle.find_indels_substitutions(s1, s2, incs[ri]), s1, s2)
+    assert st["exact_copies"] >= (100 if layout != "all_refs" else 60), (layout, st["exact_copies"], st["classes"])
+
+
 def test_all_references_batch_goes_through_the_partition_and_pairs_by_reference(mats):
     """Round 5 (BASELINE config 4): an all-references batch of several references -- task = read * n_refs + reference --
     gets the partition and the score-only stage too.  c2_align_partition_kernel walks a chunk reference-major, so the neighbours in every list
