@@ -314,7 +314,7 @@ int launch_align(c2_ctx* ctx, c2_align_args A, const Geometry& g, hipStream_t s,
     auto start_first = [&]() { if (ctx->timing && !first_started) { (void)hipEventRecord(tl.m0, s); first_started = true; } };
     auto mark_first = [&]() { start_first(); if (ctx->timing && !first_marked) { (void)hipEventRecord(tl.m, s); first_marked = true; } };
     int rc;
-    A.band_lanes = 0; A.reserved = (getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0) | (getenv("C2_DEBUG_SKIP_EPILOGUE") ? 2 : 0) | (getenv("C2_DEBUG_HALF_FILL") ? 4 : 0) | (getenv("C2_DEBUG_SKIP_EMIT") ? 16 : 0) | (getenv("C2_DEBUG_SKIP_TRACE") ? 32 : 0);   // (measurement knobs)
+    A.band_lanes = 0; A.reserved = (getenv("C2_DEBUG_SKIP_STRINGS") ? 1 : 0) | (getenv("C2_DEBUG_SKIP_EPILOGUE") ? 2 : 0) | (getenv("C2_DEBUG_HALF_FILL") ? 4 : 0) | (getenv("C2_DEBUG_SKIP_EMIT") ? 16 : 0) | (getenv("C2_DEBUG_SKIP_TRACE") ? 32 : 0) | (getenv("C2_NO_PAIR_SORT") ? 64 : 0);   // (measurement knobs)
     if (A.n_refs > 1 && !getenv("C2_NO_BLOCK_GRABS")) A.reserved |= 8;      // several references: the work counter hands out blocks of groups (c2_diagx_body)
     A.fb_count = nullptr; A.fb_list = nullptr; A.task_list = nullptr; A.task_count = nullptr;
     A.un_list = nullptr; A.un_count = nullptr; A.pair_order = 0;

@@ -2226,6 +2226,41 @@ __device__ __forceinline__ void c2_diagx_body(const c2_align_args& A)
         // ---- C: read bytes of the next group
         mC_valid = mB_valid; mC_task = mB_task; mC_off = mB_off; mC_ref = mB_ref; mC_rc = mB_rc;
         mC_lj = mB_valid ? (int)(mB_off1 - mB_off) : 0;
+        if (PK && !pair_order && !(A.reserved & 64)) {              // (64: C2_NO_PAIR_SORT, an A/B knob)
+            // Round 6: two alignments share a lane group only if they share reference and read length (the staging's `joins`), and the lists behind the first
+            // launch are in the order of their atomics: neighbours there are whatever failed next to each other (three amplicons, or reads of 248 .. 250
+            // bases: two thirds of a list's tasks went to the 32-bit twin at four times the cost).  The NA tasks a wavefront holds are put in the order
+            // of their keys first -- whole pairs in front, then the tasks left over, then the empty slots.  Nothing depends on a task's slot.
+            const bool v = lane < NA && mB_valid;
+            const unsigned none = 0xffffffffu;
+            const unsigned key = v ? (((unsigned)mB_ref << 12) | (unsigned)(mC_lj < 4095 ? mC_lj : 4095)) : none;
+            const unsigned k0 = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+            if (__ballot(lane < NA && key != k0) != 0ull) {
+                int r = 0, c = 0;                                   // tasks of my key in front of me / in all
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
+                    c += kj == key ? 1 : 0; r += (kj == key && j < lane) ? 1 : 0;
+                }
+                int pb = 0, lb = 0, P2 = 0, nv = 0;                 // pairs / left-over tasks of smaller keys, pairs in all, tasks in all
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
+                    const int cj = __builtin_amdgcn_readlane(c, j), rj = __builtin_amdgcn_readlane(r, j);
+                    if (kj != none) {
+                        ++nv;
+                        if (rj == 0) { P2 += cj >> 1; if (kj < key) { pb += cj >> 1; lb += cj & 1; } }
+                    }
+                }
+                const int slot = key == none ? nv + r : (r < 2 * (c >> 1) ? 2 * pb + r : 2 * P2 + lb);
+                int src = lane;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) if (__builtin_amdgcn_readlane(slot, j) == lane) src = j;
+                mC_valid = __shfl(mB_valid, src); mC_task = (unsigned)__shfl((int)mB_task, src); mC_ref = __shfl(mB_ref, src); mC_rc = __shfl(mB_rc, src);
+                mC_lj = __shfl(mC_lj, src);
+                mC_off = (unsigned long long)(unsigned)__shfl((int)(unsigned)mB_off, src) | ((unsigned long long)(unsigned)__shfl((int)(unsigned)(mB_off >> 32), src) << 32);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NA; ++s) {
             // one dword per lane: bytes 4l .. 4l+3 of the read (what the fast staging above takes); the dword that holds the read's

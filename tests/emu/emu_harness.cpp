@@ -120,7 +120,7 @@ int emu_align_batch(uint64_t n_reads, const uint8_t* reads, const uint64_t* offs
     A.work_counter = &work_counter;
     A.band_lanes = 0; A.reserved = 0; A.fb_count = &fb_count; A.fb_list = fb_list.data(); A.task_list = nullptr; A.task_count = nullptr;
     if (grid == 0) grid = (unsigned)std::min<uint64_t>(A.n_tasks, 3);
-    A.max_li = max_li; A.reserved = (n_refs > 1 && !getenv("C2_NO_BLOCK_GRABS")) ? 8 : 0;      // (several references: blocks of groups from the work counter, as the host library sets it)
+    A.max_li = max_li; A.reserved = ((n_refs > 1 && !getenv("C2_NO_BLOCK_GRABS")) ? 8 : 0) | (getenv("C2_NO_PAIR_SORT") ? 64 : 0);      // (several references: blocks of groups from the work counter, as the host library sets it)
     {
         int mx = 0;
         for (int16_t v : sc.tbl) mx = std::max(mx, (int)v);
