@@ -802,6 +802,41 @@ def test_main_diagonal_reads_of_several_references_are_finished_by_the_partition
     assert st["exact_copies"] >= (100 if layout != "all_refs" else 60), (layout, st["exact_copies"], st["classes"])
 
 
+def test_tasks_of_a_wavefront_are_paired_by_key_before_staging(mats, monkeypatch):
+    """Round 6: the lists behind the first band launch are in the order of their atomics, so neighbours there seldom share reference AND read length -- the
+    condition for two alignments to share a lane group.  c2_align_diagp_kernel puts the tasks a wavefront holds in the order of their keys first (whole
+    pairs in front).  Three amplicons, reads with deletions long enough for the wider tiers and of three lengths: fewer tasks are left unpaired than with
+    C2_NO_PAIR_SORT=1, the routing is the same, and every alignment is the oracle's either way."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(3)
+    L = 160
+    refs = ["".join(rng.choice(list("ACGT"), L)) for _ in range(3)]
+    gis, incs = [], []
+    for r in refs:
+        g = np.zeros(L + 1, dtype=np.int64); g[L // 2 + 1] = 1
+        gis.append(g); incs.append([L // 2, L // 2 + 1])
+    reads, rids = [], []
+    for k in range(600):
+        r = int(rng.integers(0, 3)); t = refs[r]
+        d = int(rng.integers(12, 40)); c = L // 2
+        t = (t[:c] + t[c + d:] + "".join(rng.choice(list("ACGT"), d)))[:L - int(rng.integers(0, 3))]
+        reads.append(t); rids.append(r)
+    rids = np.array(rids, dtype=np.uint16)
+    out = {}
+    for knob in ("", "1"):
+        if knob:
+            monkeypatch.setenv("C2_NO_PAIR_SORT", knob)
+        st = {}
+        res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, ref_ids=rids, band_lanes=-87, stats=st)
+        out[knob] = (res, rec, st)
+    (res, rec, st), (res0, rec0, st0) = out[""], out["1"]
+    assert res == res0 and np.array_equal(rec, rec0) and st["classes"] == st0["classes"]
+    assert st["unpaired"] * 2 <= st0["unpaired"] and st0["unpaired"] >= 30, (st["unpaired"], st0["unpaired"])
+    for k in range(0, len(reads), 3):
+        exp = oracle.global_align_raw(reads[k], refs[rids[k]], m, gis[rids[k]], -20, -2)
+        assert rec[k]["status"] == 0 and (res[k][0], res[k][1], int(rec[k]["matches"]), int(rec[k]["aln_len"])) == exp[1:], k
+
+
 def test_all_references_batch_goes_through_the_partition_and_pairs_by_reference(mats):
     """Round 5 (BASELINE config 4): an all-references batch of several references -- task = read * n_refs + reference --
     gets the partition and the score-only stage too.  c2_align_partition_kernel walks a chunk reference-major, so the neighbours in every list
