@@ -242,7 +242,9 @@ class Job:
                           torch.empty((n_tasks, 32), dtype=torch.uint8, device=dev)) for _ in range(self.n_sets)]
         # single amplicon: the hint words c2_align_partition_kernel leaves for the reads it finishes itself (c2_batch.diag_hints); the count pass takes those
         # tasks from the word alone (c2_count_hinted_kernel).  C2_BENCH_NO_HINTS=1: the step without them (A/B).
-        self.use_hints = (not (all_refs and k > 1) and not os.environ.get("C2_BENCH_NO_HINTS"))       # (one amplicon, or every read tagged with its own: not an all-references batch, whose weights come from the selection)
+        # (an all-references batch can be counted from hints too -- c2_count_vectors_hinted_device takes the selection's weights; measured on config 4: the count
+        #  pass 4.7 -> 1.4 ms, the chain + 3.3 ms for collecting and storing the hints of 30 M alignments of which 20 M are never counted: not used.  C2_BENCH_ALLREFS_HINTS=1: used)
+        self.use_hints = (not (all_refs and k > 1) or bool(os.environ.get("C2_BENCH_ALLREFS_HINTS"))) and not os.environ.get("C2_BENCH_NO_HINTS")
         self.hint_sets = [torch.zeros(n_tasks * 4, dtype=torch.int32, device=dev) if self.use_hints else None for _ in range(self.n_sets)]      # four words per task
         self.t_align = torch.cuda.current_stream()
         self.t_count = torch.cuda.Stream(device=dev) if overlap_count else self.t_align
@@ -430,13 +432,15 @@ class Job:
         """the step's count tensor (hinted tasks from their hint word, c2_count_hinted_kernel) against the count pass over the same rows and records
         WITHOUT the hints (every task's strings read back) -- entry by entry.  None when the step uses no hints."""
         torch, C = self.torch, self.C
-        if not self.use_hints or self.world > 1 or self.all_refs:
+        if not self.use_hints or self.world > 1:
             return None
         a_read, a_ref, recs = self.out_sets[(self.step_no - 1) % self.n_sets]
         t = torch.zeros_like(self.d_counts)
         with torch.cuda.stream(self.t_count):
             C.accumulate_device(self.ctx, self.layout, self.n_tasks, a_read.data_ptr(), a_ref.data_ptr(), self.stride, recs.data_ptr(), t.data_ptr(),
-                                min_matches=self.min_matches, stream=self.count_stream)
+                                d_weights=self.d_weights.data_ptr() if self.all_refs else None,        # (the last step's selection)
+                                min_matches=None if self.all_refs else self.min_matches,
+                                flags=C.FLAG_ALL_REFS_LAYOUT if self.all_refs else 0, stream=self.count_stream)
         torch.cuda.synchronize()
         return bool(torch.equal(t, self.d_counts))
 

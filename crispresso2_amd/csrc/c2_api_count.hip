@@ -116,11 +116,31 @@ int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t*
             if (A.rest_list) {
                 hipLaunchKernelGGL(c2_rest_scan_kernel, dim3(1), dim3(64), 0, s, cnt, pre, total, ctx->n_refs);
                 const unsigned cgx = 8;
-                hipLaunchKernelGGL(c2_rest_compact_kernel, dim3(cgx * (unsigned)ctx->n_refs), dim3(256), 0, s, cnt, pre, hist, ranged, order, cgx);
+                hipLaunchKernelGGL(c2_rest_compact_kernel, dim3(cgx * (unsigned)ctx->n_refs), dim3(256), 0, s, cnt, pre, hist, 0u, ranged, order, cgx);
                 HIPCHK(ctx, hipGetLastError());
                 A.n_tasks_dev = total; A.hints = nullptr; A.ref_ends = nullptr;      // (A.order = order: now the tasks left, still grouped by reference)
             }
         }
+    }
+    if (hints_usable && ctx->n_refs > 1 && (A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) && n_tasks < 0xFFFFFFFFull && !getenv("C2_NO_COUNT_REST_LIST")) {
+        // every read against every reference (task = read * n_refs + reference; the weights are the selection's: most tasks have none): the hinted kernel per
+        // reference over that reference's tasks by arithmetic, what it leaves in a list per reference, closed up into the list the column walk runs over
+        const size_t hist_bytes = ((size_t)ctx->n_refs * 4 + 255) / 256 * 256;
+        if ((rc = ensure(ctx, ctx->d_order, hist_bytes + n_tasks * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, ctx->d_order2, 2 * hist_bytes + 256 + n_tasks * sizeof(uint32_t)))) return rc;
+        uint32_t* order = (uint32_t*)((uint8_t*)ctx->d_order.p + hist_bytes);
+        uint32_t* cnt = (uint32_t*)ctx->d_order2.p; uint32_t* pre = (uint32_t*)((uint8_t*)ctx->d_order2.p + hist_bytes);
+        uint32_t* total = (uint32_t*)((uint8_t*)ctx->d_order2.p + 2 * hist_bytes); uint32_t* ranged = (uint32_t*)((uint8_t*)ctx->d_order2.p + 2 * hist_bytes + 256);
+        HIPCHK(ctx, hipMemsetAsync(cnt, 0, 2 * hist_bytes + 256, s));
+        const uint64_t per = n_tasks / (uint64_t)ctx->n_refs;
+        A.hints = d_hints; A.rest_list = ranged; A.rest_count = cnt;
+        A.hint_gx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((per + 4095) / 4096, (uint64_t)ctx->prop.multiProcessorCount * 4u / (uint64_t)ctx->n_refs + 1));
+        hipLaunchKernelGGL(c2_count_hinted_kernel, dim3(A.hint_gx * (unsigned)ctx->n_refs), dim3(256), c2_count_hinted_lds_bytes(lmax, hl), s, A);
+        hipLaunchKernelGGL(c2_rest_scan_kernel, dim3(1), dim3(64), 0, s, cnt, pre, total, ctx->n_refs);
+        const unsigned cgx = 64;
+        hipLaunchKernelGGL(c2_rest_compact_kernel, dim3(cgx * (unsigned)ctx->n_refs), dim3(256), 0, s, cnt, pre, (const uint32_t*)nullptr, (uint32_t)per, ranged, order, cgx);
+        HIPCHK(ctx, hipGetLastError());
+        A.order = order; A.n_tasks_dev = total; A.hints = nullptr; A.rest_list = nullptr; A.rest_count = nullptr;
     }
     const void* fn = hbm_block ? (const void*)c2_count_vectors_hbm_kernel : (const void*)c2_count_vectors_kernel;
     HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));

@@ -105,10 +105,10 @@ __global__ __launch_bounds__(64) void c2_rest_scan_kernel(const uint32_t* cnt, u
     }
     if (lane == 0) *total = (uint32_t)carry;
 }
-__global__ __launch_bounds__(256) void c2_rest_compact_kernel(const uint32_t* cnt, const uint32_t* pre, const uint32_t* ends, const uint32_t* ranged, uint32_t* dense, unsigned gx)
+__global__ __launch_bounds__(256) void c2_rest_compact_kernel(const uint32_t* cnt, const uint32_t* pre, const uint32_t* ends, uint32_t per_ref, const uint32_t* ranged, uint32_t* dense, unsigned gx)
 {
     const unsigned r = blockIdx.x / gx, j = blockIdx.x - r * gx;
-    const uint32_t n = cnt[r], from = r ? ends[r - 1] : 0u, to = pre[r];
+    const uint32_t n = cnt[r], from = ends ? (r ? ends[r - 1] : 0u) : r * per_ref, to = pre[r];      // (ends == NULL: ranges of per_ref positions each)
     for (uint32_t k = j * 256u + threadIdx.x; k < n; k += gx * 256u) dense[to + k] = ranged[from + k];
 }
 
@@ -854,7 +854,11 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     int ref = 0;
     unsigned bx = blockIdx.x, gx = gridDim.x;
     uint64_t p_lo = 0, p_hi = A.n_tasks;
+    // (an all-references batch, task = read * n_refs + reference: position p of reference r's range is read p - p_lo -- the column walk's own arithmetic)
+    const bool by_layout = !A.ref_ends && (A.flags & C2_CNT_FLAG_ALL_REFS_LAYOUT) && A.n_refs > 1;
+    const bool per_ref = A.ref_ends || by_layout;
     if (A.ref_ends) { gx = A.hint_gx; ref = (int)(blockIdx.x / gx); bx = blockIdx.x - (unsigned)ref * gx; p_lo = ref ? A.ref_ends[ref - 1] : 0u; p_hi = A.ref_ends[ref]; }
+    else if (by_layout) { gx = A.hint_gx; ref = (int)(blockIdx.x / gx); bx = blockIdx.x - (unsigned)ref * gx; const uint64_t nr = A.n_tasks / (uint64_t)A.n_refs; p_lo = (uint64_t)ref * nr; p_hi = p_lo + nr; }
     if (p_lo >= p_hi) return;
     const c2_dev_ref rf = A.refs[ref];
     const int Li = rf.len;
@@ -904,9 +908,9 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
         __syncthreads();
         const int nrest = part[4];
         // (several references: a counter per reference, the reference's tasks into its own range of the list -- c2_rest_compact_kernel closes the gaps)
-        if (tid == 0 && nrest > 0) part[5] = (int)atomicAdd(A.rest_count + (A.ref_ends ? ref : 0), (unsigned)nrest);
+        if (tid == 0 && nrest > 0) part[5] = (int)atomicAdd(A.rest_count + (per_ref ? ref : 0), (unsigned)nrest);
         __syncthreads();
-        const uint64_t b0 = (A.ref_ends ? p_lo : 0ull) + (uint64_t)(unsigned)part[5];
+        const uint64_t b0 = (per_ref ? p_lo : 0ull) + (uint64_t)(unsigned)part[5];
         for (int k = tid; k < nrest; k += 256) A.rest_list[b0 + (uint64_t)k] = lrest[k];
         __syncthreads();
         if (tid == 0) part[4] = 0;
@@ -955,7 +959,7 @@ __global__ __launch_bounds__(256) void c2_count_hinted_kernel(c2_count_args A)
     for (uint64_t base = p_lo + (uint64_t)bx * 256u; base < p_hi; base += (uint64_t)gx * 256u) {
         const uint64_t pos = base + (uint64_t)tid;
         const bool in_range = pos < p_hi;
-        const uint64_t t = in_range ? (A.ref_ends ? (uint64_t)A.order[pos] : pos) : 0ull;
+        const uint64_t t = in_range ? (A.ref_ends ? (uint64_t)A.order[pos] : by_layout ? (pos - p_lo) * (uint64_t)A.n_refs + (uint64_t)ref : pos) : 0ull;
         unsigned h = 0;
         if (in_range) h = A.hints[4u * t];
         // a gapped hint's record and other three words: asked for here, looked at behind the main-diagonal tasks' work

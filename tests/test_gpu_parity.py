@@ -1364,6 +1364,69 @@ def test_ragged_and_unrelated_reads_and_the_full_matrix_launch_with_its_plane_in
         assert np.array_equal(other.records, res.records) and np.array_equal(other.aln_read, res.aln_read) and np.array_equal(other.aln_ref, res.aln_ref), knob
 
 
+def test_gpu_hinted_count_of_an_all_references_batch(mats, ctx, monkeypatch):
+    """Every read against every amplicon (config 4's shape: task = read * n_refs + reference) with weights as the selection leaves them -- none for most
+    tasks, a read's multiplicity for its best amplicon: the count tensor with the hint words equals the one without them and the one with the list of
+    left-over tasks switched off; three amplicons of two lengths."""
+    import torch
+    from crispresso2_amd import synth, _native, counts as C
+    from crispresso2_amd.batch import BatchAligner
+    m = mats["EDNAFULL"]
+    L = 250
+    amp, g, inc = synth.amplicon_setup(L)
+    refs = [amp, synth.make_variant(amp, "hdr"), synth.make_variant(amp, "pe")]
+    gis = []
+    for r in refs:
+        x = np.zeros(len(r) + 1, dtype=np.int64); x[L // 2 + 1] = 1
+        gis.append(x)
+    incs = [inc] * 3
+    n = 40000
+    blocks = [synth.make_reads(L, n // 4 if src else n // 2, amplicon_id=100 + src, amplicon=refs[src][:L]) for src in range(3)]
+    reads = np.concatenate(blocks)
+    rng = np.random.default_rng(12)
+    reads = np.ascontiguousarray(reads[rng.permutation(len(reads))])
+    n = len(reads)
+    k = 3
+    nt = n * k
+    al = BatchAligner(refs, gis, incs, m, -20, -2, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    Lmax = max(len(r) for r in refs)
+    stride = al.stride_for(L)
+    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    o1 = torch.zeros((nt, stride), dtype=torch.uint8, device=dev)
+    o2 = torch.zeros((nt, stride), dtype=torch.uint8, device=dev)
+    rec = torch.zeros((nt, 32), dtype=torch.uint8, device=dev)
+    hints = torch.zeros((nt * 4,), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    al.align_device(n, d_reads.data_ptr(), d_off.data_ptr(), o1.data_ptr(), o2.data_ptr(), rec.data_ptr(), stride, L, all_refs=True, stream=s, d_hints=hints.data_ptr())
+    torch.cuda.synchronize()
+    records = rec.cpu().numpy().view(_native.REC_DTYPE).reshape(-1)
+    assert (records["status"] == 0).all() and (records["ref_id"] == np.tile(np.arange(k), n)).all()
+    h0 = hints.cpu().numpy().view(np.uint32).reshape(nt, 4)[:, 0]
+    assert ((h0 >> 30) != 0).sum() > nt // 4
+    # weights as the selection leaves them: the best amplicon (most matches per column) gets the read's multiplicity, the others nothing
+    score = records["matches"].astype(np.float64) / np.maximum(records["aln_len"], 1)
+    best = score.reshape(n, k).argmax(axis=1)
+    w = np.zeros((n, k), dtype=np.uint32)
+    w[np.arange(n), best] = rng.integers(1, 30, n).astype(np.uint32)
+    w[7, best[7]] = 5000; w[9, best[9]] = 1024
+    d_w = torch.from_numpy(w.reshape(-1).view(np.int32)).to(dev)
+    layout = C.CountLayout(k, Lmax, L + 16)
+
+    def count(use_hints):
+        t = torch.zeros(layout.shape(), dtype=torch.int64, device=dev)
+        C.accumulate_device(ctx, layout, nt, o1.data_ptr(), o2.data_ptr(), stride, rec.data_ptr(), t.data_ptr(), d_weights=d_w.data_ptr(),
+                            flags=C.FLAG_ALL_REFS_LAYOUT, stream=s, d_hints=hints.data_ptr() if use_hints else None)
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+    plain = count(False)
+    assert plain.sum() > 0 and all(plain[r].sum() > 0 for r in range(k))
+    assert np.array_equal(plain, count(True))
+    monkeypatch.setenv("C2_NO_COUNT_REST_LIST", "1")
+    assert np.array_equal(plain, count(True))
+
+
 @pytest.mark.gpu
 def test_gpu_hinted_count_with_several_references(mats, ctx, monkeypatch):
     """CRISPRessoPooled's shape on the hardware: 7 amplicons of different lengths, 84,000 reads tagged with their amplicon (interleaved, and one amplicon
