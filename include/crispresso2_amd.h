@@ -190,7 +190,8 @@ int c2_count_vectors_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_
  * counted from its hint word alone -- c2_count_hinted_kernel, a lane per task, neither its record nor its strings are read -- and the kernel above skips it.
  * The tensor is the same either way (CRISPRessoCORE.py:3996-4115 semantics; tests/test_counts_emulated.py, tests/test_gpu_parity.py).  The hints are used for a
  * context with one reference and for several references with every task against its own (ref_ids; the hinted kernel then runs per reference over the tasks
- * grouped by reference); with the all-references layout (C2_COUNT_FLAG all-references: the weights come from c2_select_best_device) they are ignored. */
+ * grouped by reference), and with the all-references layout (the weights are c2_select_best_device's: a reference's tasks by the layout's arithmetic).  With
+ * several references the tasks the hinted kernel leaves are listed per reference and closed up into one list the column walk runs over. */
 int c2_count_vectors_hinted_device(c2_ctx* ctx, uint64_t n_tasks, const uint8_t* d_aln_read, const uint8_t* d_aln_ref,
                                    uint32_t aln_stride, const c2_aln_record* d_records, const uint32_t* d_weights, const uint32_t* d_hints,
                                    const uint16_t* h_min_matches, int32_t max_t, int32_t flags, int32_t hl,
