@@ -802,6 +802,42 @@ def test_main_diagonal_reads_of_several_references_are_finished_by_the_partition
     assert st["exact_copies"] >= (100 if layout != "all_refs" else 60), (layout, st["exact_copies"], st["classes"])
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_main_diagonal_shortcut_at_every_block_edge_length_one_and_three_references(mats, seed):
+    """References of 100 .. 256 bases -- among them every length at a 32-byte block's edge (128 / 129 / 159 / 160 / 161 / ... / 255 / 256) -- alone and three
+    to a batch (reads tagged), reads with 0 .. 3 changed bases (N among them) and a few 3-base deletions: the partition finishes most of them from the
+    compared registers, and every alignment is the oracle's."""
+    m = mats["EDNAFULL"]
+    rng = np.random.default_rng(9900 + seed)
+    edge = [128, 129, 159, 160, 161, 191, 192, 193, 224, 225, 255, 256]
+    finished = 0
+    for trial in range(12):
+        nrefs = 1 if trial % 2 == 0 else 3
+        lens = [int(rng.integers(100, 257)) for _ in range(nrefs)]
+        lens[0] = edge[(6 * seed + trial // 2) % len(edge)]
+        refs = ["".join(rng.choice(list("ACGT"), L)) for L in lens]
+        gis, incs = [], []
+        for r in refs:
+            g = np.zeros(len(r) + 1, dtype=np.int64); g[len(r) // 2 + 1] = 1
+            gis.append(g); incs.append([len(r) // 2 - 1, len(r) // 2])
+        reads, rids = [], []
+        for k in range(96):
+            r = int(rng.integers(0, nrefs)); t = list(refs[r])
+            for _ in range(k % 4):
+                t[int(rng.integers(0, len(t)))] = str(rng.choice(list("ACGTN")))
+            if k % 11 == 0:
+                t = t[:len(t) // 2] + t[len(t) // 2 + 3:]
+            reads.append("".join(t)); rids.append(r)
+        st = {}
+        kw = dict(ref_ids=np.array(rids, dtype=np.uint16)) if nrefs > 1 else {}
+        res, rec = E.align_batch(reads, refs, gis, incs, m, -20, -2, band_lanes=-87, stats=st, **kw)
+        for k in range(len(reads)):
+            exp = oracle.global_align_raw(reads[k], refs[rids[k]], m, gis[rids[k]], -20, -2)
+            assert rec[k]["status"] == 0 and (res[k][0], res[k][1], int(rec[k]["matches"]), int(rec[k]["aln_len"])) == exp[1:], (seed, trial, k, lens)
+        finished += st.get("exact_copies", 0)
+    assert finished >= 12 * 96 // 2, finished
+
+
 def test_tasks_of_a_wavefront_are_paired_by_key_before_staging(mats, monkeypatch):
     """Round 6: the lists behind the first band launch are in the order of their atomics, so neighbours there seldom share reference AND read length -- the
     condition for two alignments to share a lane group.  c2_align_diagp_kernel puts the tasks a wavefront holds in the order of their keys first (whole
